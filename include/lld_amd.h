@@ -1,0 +1,274 @@
+/*
+ * lld_amd.h — C ABI of the MI355X-native point+line local-BA / pose-optimisation /
+ * descriptor-matching core.
+ *
+ * This is the drop-in boundary for the hot path of alexandervakhitov/lld-slam.  The
+ * reference has no FFI layer: its boundary is a set of C++ static/member functions that
+ * take live SLAM objects (include/Optimizer.h:49-50, include/ORBmatcher.h:41-83,
+ * include/TwoFrameLineMatcher.h:31-42).  Each entry point below names the reference
+ * function it stands in for; the host adapter that gathers KeyFrame/MapPoint/MapLine
+ * state into these flat structs is sketched in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain C, caller-allocated buffers, `int` status return (0 ok, <0 error), no globals;
+ *   - a context is bound to one HIP device and one stream; it is re-entrant per handle
+ *     (one handle per host thread, as Tracking / LocalMapping each would own one);
+ *   - all pointers in the *input* structs are HOST pointers unless the function name ends
+ *     in `_dev`; batch handles keep their inputs resident in HBM between solves;
+ *   - poses are world->camera, stored as 7 doubles (qx,qy,qz,qw,tx,ty,tz) exactly as
+ *     g2o::SE3Quat holds them (Thirdparty/g2o/g2o/types/se3quat.h:47-48);
+ *   - floating point parity target: 1e-5 relative on final chi2 / poses / landmarks,
+ *     identical outlier sets; matcher indices and integer distances bit-exact.
+ *
+ * The same structs are consumed by the CPU oracle (oracle/lld_oracle.cpp, symbols
+ * `lldo_*`), which is test infrastructure only.
+ */
+#ifndef LLD_AMD_H
+#define LLD_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ status codes */
+#define LLD_OK               0
+#define LLD_ERR_INVALID     -1   /* bad argument / inconsistent sizes               */
+#define LLD_ERR_NO_DEVICE   -2   /* no HIP device: the product path never falls back */
+#define LLD_ERR_HIP         -3   /* a HIP runtime call failed                        */
+#define LLD_ERR_ALLOC       -4
+#define LLD_ERR_UNSUPPORTED -5   /* size outside the compiled limits                 */
+
+const char* lld_status_string(int status);
+
+/* ------------------------------------------------------------------ context */
+typedef struct lld_ctx lld_ctx;
+
+/* Binds to HIP device `device`, creates a private stream.  Fails with LLD_ERR_NO_DEVICE
+ * when no GPU is visible (there is no CPU fallback). */
+int  lld_ctx_create(int device, lld_ctx** out);
+void lld_ctx_destroy(lld_ctx* ctx);
+/* Stream the context launches on (hipStream_t as void*), so callers can record events. */
+void* lld_ctx_stream(lld_ctx* ctx);
+int  lld_ctx_synchronize(lld_ctx* ctx);
+
+/* ------------------------------------------------------------------ shared types */
+typedef struct {
+  double fx, fy, cx, cy;   /* pinhole; line edges use fx for both axes (LineOptimizer.cc:66-68) */
+  double bf;               /* baseline * fx (KeyFrame::mbf)                                      */
+} lld_camera;
+
+/* Converter::toSE3Quat (src/Converter.cc:37-47): float 4x4 row-major Tcw -> SE3Quat 7-vector. */
+void lld_se3_from_tcw_f32(const float* tcw16, double* qt7);
+/* Converter::toCvMat(SE3Quat) (src/Converter.cc:49-70): SE3Quat -> float 4x4 row-major. */
+void lld_se3_to_tcw_f32(const double* qt7, float* tcw16);
+/* ORBextractor level table mvInvLevelSigma2 (src/ORBextractor.cc:416-430), float arithmetic. */
+void lld_orb_inv_level_sigma2(float scale_factor, int n_levels, float* out);
+
+/* ================================================================== local bundle adjustment
+ * Stands in for Optimizer::LocalBundleAdjustment (src/Optimizer.cc:936-1388) from the point
+ * where the local window has been collected (:938-1018) to the point where results are
+ * written back (:1334-1386), including LineOptimizer::{AddLineMinimal,DisableOutliers,
+ * GetLineData} (src/LineOptimizer.cc:39-201) and everything g2o does underneath.
+ *
+ * Window layout (the order is the reference's insertion order, so sums run the same way):
+ *   cameras   [0,n_free_cams) are optimised, in ascending KeyFrame::mnId order (g2o orders
+ *             unknowns by vertex id, sparse_optimizer.cpp:166-190); [n_free_cams,n_cams) are
+ *             fixed (lFixedCameras and the mnId==0 keyframe, Optimizer.cc:1037-1063).
+ *   points    each point owns a contiguous run of observations pt_obs_start[p]..[p+1]
+ *             (the loop over MapPoint::GetObservations, Optimizer.cc:1107-1178).
+ *             uR < 0 marks a monocular observation (Optimizer.cc:1119).
+ *   lines     each line owns a run of (line,KF) observations ln_obs_start[l]..[l+1]
+ *             (proj_map, Optimizer.cc:1189-1218); every observation yields a left-image edge
+ *             and, when right xs >= 0, a right-image edge (LineOptimizer.cc:58-65).
+ */
+typedef struct {
+  lld_camera cam;
+  int32_t n_cams;
+  int32_t n_free_cams;
+  const double*  cam_qt;             /* [n_cams][7]                                           */
+
+  int32_t n_points;
+  const double*  pt_xyz;             /* [n_points][3]  (Converter::toVector3d of the f32 pos) */
+  const int32_t* pt_obs_start;       /* [n_points+1]                                          */
+  int32_t n_pt_obs;
+  const int32_t* pt_obs_cam;         /* [n_pt_obs] camera index                               */
+  const double*  pt_obs_uvr;         /* [n_pt_obs][3] u, v, uR (uR<0: mono)                   */
+  const double*  pt_obs_inv_sigma2;  /* [n_pt_obs] mvInvLevelSigma2[octave] widened           */
+
+  int32_t n_lines;
+  const double*  line_x0;            /* [n_lines][3]  MapLine::GetMinimalPos                  */
+  const double*  line_dir;           /* [n_lines][3]                                          */
+  const int32_t* ln_obs_start;       /* [n_lines+1]                                           */
+  int32_t n_ln_obs;
+  const int32_t* ln_obs_cam;         /* [n_ln_obs]                                            */
+  const double*  ln_obs_left;        /* [n_ln_obs][4] xs,ys,xe,ye of the left KeyLine         */
+  const double*  ln_obs_right;       /* [n_ln_obs][4] right KeyLine; xs<0 -> no stereo match  */
+  const int32_t* ln_obs_octave;      /* [n_ln_obs][2] octave of left / right KeyLine          */
+} lld_ba_window;
+
+typedef struct {
+  double  gamma;            /* line weight; LocalMapping passes 1.0 (Optimizer.h:49)           */
+  int32_t its_round1;       /* 5  (Optimizer.cc:1224)                                          */
+  int32_t its_round2;       /* 15 (Optimizer.cc:1273)                                          */
+  int32_t ln_filter;        /* 4  (LineOptimizer.h:90)                                         */
+  int32_t max_trials;       /* 10 (maxTrialsAfterFailure, optimization_algorithm_levenberg.cpp:50) */
+  double  pcg_rel_tol;      /* reduced-system PCG stops at |r|_M / |b|_M <= tol (GPU only)     */
+  int32_t pcg_max_iter;     /* 0 -> 10 * 6 * n_free_cams                                        */
+  int32_t reserved;
+} lld_ba_params;
+
+void lld_ba_params_default(lld_ba_params* p);
+
+typedef struct {
+  double  chi2_round1;      /* LM cost (robust) after optimize(its_round1)                      */
+  double  chi2_final;       /* LM cost after optimize(its_round2) (kernels removed)             */
+  int32_t lm_iterations[2]; /* outer iterations executed per round                              */
+  int32_t lm_trials[2];     /* linear solves (trials) executed per round                        */
+  int32_t pcg_iterations;   /* total PCG iterations (0 for the oracle's direct solve)           */
+  int32_t n_pt_obs_outlier; /* size of vToErase                                                 */
+  int32_t n_ln_edge_outlier;
+  int32_t n_lines_removed;
+  int32_t aborted;          /* 1 when the abort flag cut the protocol short                     */
+  int32_t reserved;
+} lld_ba_stats;
+
+typedef struct {
+  double*  cam_qt;          /* [n_cams][7]    optimised poses (fixed ones copied through)        */
+  double*  pt_xyz;          /* [n_points][3]                                                     */
+  double*  line_x0;         /* [n_lines][3]   LineOptimizer::GetLineData; removed lines keep input */
+  double*  line_dir;        /* [n_lines][3]                                                      */
+  uint8_t* pt_obs_outlier;  /* [n_pt_obs]     1 -> (KF,MapPoint) goes to vToErase (Optimizer.cc:1281-1307) */
+  uint8_t* ln_edge_outlier; /* [n_ln_obs][2]  1 -> kf id pushed by GetLineData for left/right edge */
+  uint8_t* line_removed;    /* [n_lines]      1 -> vertex deleted by DisableOutliers            */
+  lld_ba_stats stats;
+} lld_ba_result;
+
+/* One window, synchronous.  `abort_flag` may be NULL; it is the reference's pbStopFlag
+ * (Optimizer.cc:1030-1031, sparse_optimizer.h:188), polled between LM trials. */
+int lld_local_ba(lld_ctx* ctx, const lld_ba_window* in, const lld_ba_params* params,
+                 volatile const int* abort_flag, lld_ba_result* out);
+
+/* Batched, HBM-resident form: windows are uploaded once, then solved any number of times
+ * (each solve restarts from the uploaded initial state).  This is the throughput path:
+ * independent windows are what shards across GPUs (one batch per rank). */
+typedef struct lld_ba_batch lld_ba_batch;
+int  lld_ba_batch_create(lld_ctx* ctx, int n_windows, const lld_ba_window* windows,
+                         const lld_ba_params* params, lld_ba_batch** out);
+int  lld_ba_batch_solve(lld_ba_batch* batch, volatile const int* abort_flag); /* async on ctx stream until the final sync */
+int  lld_ba_batch_download(lld_ba_batch* batch, int window, lld_ba_result* out);
+int  lld_ba_batch_stats(lld_ba_batch* batch, lld_ba_stats* stats /* [n_windows] */);
+/* Device buffer holding the fixed-stride result records of all windows (for the RCCL
+ * gather): returns base pointer and record stride in bytes. */
+int  lld_ba_batch_result_records(lld_ba_batch* batch, void** dev_ptr, uint64_t* stride_bytes);
+/* Per-phase device time of the last solve in ms: [0] linearise+Schur, [1] PCG,
+ * [2] back-substitution+update+chi2, [3] LM control / classification, [4] total.
+ * Mirrors G2OBatchStatistics (core/batch_stats.h:41-70). */
+int  lld_ba_batch_phase_ms(lld_ba_batch* batch, double* ms5);
+/* Launch counts and HIP-event time of the dominant kernel (linearise+Schur) in the last solve. */
+int  lld_ba_batch_kernel_stats(lld_ba_batch* batch, int64_t* launches, double* total_ms);
+void lld_ba_batch_destroy(lld_ba_batch* batch);
+
+/* ================================================================== pose optimisation
+ * Stands in for Optimizer::PoseOptimization (src/Optimizer.cc:653-932) including
+ * AddLineMinOnlyPose (:562-650): 4 rounds x 10 LM iterations on one SE3 vertex. */
+typedef struct {
+  lld_camera cam;
+  double pose_qt[7];                /* Converter::toSE3Quat(pFrame->mTcw)                       */
+  int32_t n_points;                 /* matched keypoints with a MapPoint                        */
+  const double*  pt_xw;             /* [n_points][3] world position widened from f32            */
+  const double*  pt_uvr;            /* [n_points][3] u,v,uR (uR<0: mono)                        */
+  const double*  pt_inv_sigma2;     /* [n_points]                                               */
+  int32_t n_lines;
+  const double*  ln_x0;             /* [n_lines][3]                                             */
+  const double*  ln_dir;            /* [n_lines][3]                                             */
+  const double*  ln_left;           /* [n_lines][4]                                             */
+  const double*  ln_right;          /* [n_lines][4] xs<0 -> no stereo match                     */
+  const int32_t* ln_octave;         /* [n_lines][2]                                             */
+} lld_pose_problem;
+
+typedef struct {
+  double  gamma;                    /* yaml `gamma` (0.5 for KITTI04-12_LBD.yaml:71)            */
+  int32_t n_rounds;                 /* 4                                                         */
+  int32_t its_per_round;            /* 10                                                        */
+  int32_t max_trials;               /* 10                                                        */
+  int32_t reserved;
+} lld_pose_params;
+
+void lld_pose_params_default(lld_pose_params* p);
+
+typedef struct {
+  double   pose_qt[7];
+  int32_t  n_inliers;               /* return value of PoseOptimization (:931); 0 if <3 points  */
+  int32_t  lm_iterations;           /* summed over rounds                                        */
+  int32_t  lm_trials;
+  int32_t  reserved;
+  double   chi2;                    /* LM cost at the end of the last round                      */
+  uint8_t* pt_outlier;              /* [n_points] pFrame->mvbOutlier                             */
+  uint8_t* ln_outlier;              /* [n_lines]  pFrame->mvbOutlierLines                        */
+} lld_pose_result;
+
+int lld_pose_opt(lld_ctx* ctx, const lld_pose_problem* in, const lld_pose_params* params,
+                 lld_pose_result* out);
+
+typedef struct lld_pose_batch lld_pose_batch;
+int  lld_pose_batch_create(lld_ctx* ctx, int n_frames, const lld_pose_problem* frames,
+                           const lld_pose_params* params, lld_pose_batch** out);
+int  lld_pose_batch_solve(lld_pose_batch* batch);
+int  lld_pose_batch_download(lld_pose_batch* batch, int frame, lld_pose_result* out);
+void lld_pose_batch_destroy(lld_pose_batch* batch);
+
+/* ================================================================== descriptor matching
+ * lld_match_hamming256*: ORBmatcher::DescriptorDistance (src/ORBmatcher.cc:1647-1663) plus
+ * the best / second-best loops of the Search* family (e.g. :76-125, :201-249).  Strict '<'
+ * everywhere, so the FIRST candidate in iteration order wins ties.
+ *   - brute force: candidates are all train rows in index order (mask NULL);
+ *   - mask: byte matrix [nq][nt], non-zero = candidate (index order);
+ *   - csr : explicit candidate lists in the reference's own list order
+ *           (Frame::GetFeaturesInArea / BoW node lists); outputs are train indices.
+ * Unmatched queries (no candidate) return idx -1 and dist 256 (the reference initialises
+ * bestDist=256, ORBmatcher.cc:72).
+ */
+int lld_match_hamming256(lld_ctx* ctx, const uint32_t* q, int nq, const uint32_t* t, int nt,
+                         const uint8_t* mask_or_null,
+                         int32_t* best_idx, int32_t* best_dist,
+                         int32_t* second_idx, int32_t* second_dist);
+int lld_match_hamming256_csr(lld_ctx* ctx, const uint32_t* q, int nq, const uint32_t* t, int nt,
+                             const int32_t* cand_start /*[nq+1]*/, const int32_t* cand_idx,
+                             int32_t* best_idx, int32_t* best_dist,
+                             int32_t* second_idx, int32_t* second_dist);
+/* `batch` independent frame pairs of identical shape, inputs/outputs are DEVICE pointers:
+ * q [batch][nq][8], t [batch][nt][8], outputs [batch][nq]. */
+int lld_match_hamming256_batch_dev(lld_ctx* ctx, int batch, const uint32_t* q_dev, int nq,
+                                   const uint32_t* t_dev, int nt,
+                                   int32_t* best_idx_dev, int32_t* best_dist_dev,
+                                   int32_t* second_idx_dev, int32_t* second_dist_dev);
+
+/* lld_match_l2f32*: LineMatcher::MatchLineDescriptors call sites
+ * (src/TwoFrameLineMatcher.cc:112, src/Tracking.cc:1092,1532).  The function itself lives in
+ * the un-vendored LBDMOD library (parity unpinned); this build defines it as
+ * d = sqrt( sum_i (double)(a_i - b_i)^2 ), the float difference squared and accumulated in
+ * double in ascending i — the arithmetic of cv::norm(a - b) used at src/MapLine.cc:175. */
+int lld_match_l2f32(lld_ctx* ctx, const float* q, int nq, const float* t, int nt, int dim,
+                    const uint8_t* mask_or_null,
+                    int32_t* best_idx, double* best_dist,
+                    int32_t* second_idx, double* second_dist);
+int lld_match_l2f32_batch_dev(lld_ctx* ctx, int batch, const float* q_dev, int nq,
+                              const float* t_dev, int nt, int dim,
+                              int32_t* best_idx_dev, double* best_dist_dev,
+                              int32_t* second_idx_dev, double* second_dist_dev);
+
+/* TwoFrameLineMatcher::MatchLines (src/TwoFrameLineMatcher.cc:26-77): sequential greedy
+ * assignment.  For left line j = 0..nq-1 in order: over right lines oi not yet taken and
+ * with gate[j][oi] != 0 (CheckLinePair's geometric gates, :81-109, computed by the caller),
+ * pick the strict running minimum of the descriptor distance below `tau`; the winner is
+ * masked for all later j.  matches[j] = oi or -1. */
+int lld_line_match_greedy(lld_ctx* ctx, const float* desc_left, int nq, const float* desc_right,
+                          int nt, int dim, const uint8_t* gate /*[nq][nt]*/, double tau,
+                          int32_t* matches /*[nq]*/, double* match_dist /*[nq] or NULL*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LLD_AMD_H */

@@ -1,0 +1,227 @@
+"""ctypes mirror of include/lld_amd.h.
+
+The struct layouts here are the single Python-side definition of the C ABI; the product library
+(`lld_slam_amd/csrc/liblld_amd.so`, symbols ``lld_*``) and the test-only CPU oracle
+(`oracle/liblld_oracle.so`, symbols ``lldo_*``) are both bound through :class:`Lib`.
+
+Nothing in this module touches the oracle; see ``oracle/oracle_py.py`` for that loader (tests only).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+c_double_p = C.POINTER(C.c_double)
+c_float_p = C.POINTER(C.c_float)
+c_int32_p = C.POINTER(C.c_int32)
+c_uint32_p = C.POINTER(C.c_uint32)
+c_uint8_p = C.POINTER(C.c_uint8)
+
+LLD_OK = 0
+LLD_ERR_INVALID = -1
+LLD_ERR_NO_DEVICE = -2
+LLD_ERR_HIP = -3
+LLD_ERR_ALLOC = -4
+LLD_ERR_UNSUPPORTED = -5
+
+
+class Camera(C.Structure):
+    _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double), ("bf", C.c_double)]
+
+
+class BAWindow(C.Structure):
+    _fields_ = [
+        ("cam", Camera),
+        ("n_cams", C.c_int32), ("n_free_cams", C.c_int32),
+        ("cam_qt", c_double_p),
+        ("n_points", C.c_int32),
+        ("pt_xyz", c_double_p),
+        ("pt_obs_start", c_int32_p),
+        ("n_pt_obs", C.c_int32),
+        ("pt_obs_cam", c_int32_p),
+        ("pt_obs_uvr", c_double_p),
+        ("pt_obs_inv_sigma2", c_double_p),
+        ("n_lines", C.c_int32),
+        ("line_x0", c_double_p),
+        ("line_dir", c_double_p),
+        ("ln_obs_start", c_int32_p),
+        ("n_ln_obs", C.c_int32),
+        ("ln_obs_cam", c_int32_p),
+        ("ln_obs_left", c_double_p),
+        ("ln_obs_right", c_double_p),
+        ("ln_obs_octave", c_int32_p),
+    ]
+
+
+class BAParams(C.Structure):
+    _fields_ = [
+        ("gamma", C.c_double),
+        ("its_round1", C.c_int32), ("its_round2", C.c_int32), ("ln_filter", C.c_int32), ("max_trials", C.c_int32),
+        ("pcg_rel_tol", C.c_double),
+        ("pcg_max_iter", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+class BAStats(C.Structure):
+    _fields_ = [
+        ("chi2_round1", C.c_double), ("chi2_final", C.c_double),
+        ("lm_iterations", C.c_int32 * 2), ("lm_trials", C.c_int32 * 2),
+        ("pcg_iterations", C.c_int32), ("n_pt_obs_outlier", C.c_int32),
+        ("n_ln_edge_outlier", C.c_int32), ("n_lines_removed", C.c_int32),
+        ("aborted", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+class BAResult(C.Structure):
+    _fields_ = [
+        ("cam_qt", c_double_p), ("pt_xyz", c_double_p), ("line_x0", c_double_p), ("line_dir", c_double_p),
+        ("pt_obs_outlier", c_uint8_p), ("ln_edge_outlier", c_uint8_p), ("line_removed", c_uint8_p),
+        ("stats", BAStats),
+    ]
+
+
+class PoseProblem(C.Structure):
+    _fields_ = [
+        ("cam", Camera),
+        ("pose_qt", C.c_double * 7),
+        ("n_points", C.c_int32),
+        ("pt_xw", c_double_p), ("pt_uvr", c_double_p), ("pt_inv_sigma2", c_double_p),
+        ("n_lines", C.c_int32),
+        ("ln_x0", c_double_p), ("ln_dir", c_double_p), ("ln_left", c_double_p), ("ln_right", c_double_p),
+        ("ln_octave", c_int32_p),
+    ]
+
+
+class PoseParams(C.Structure):
+    _fields_ = [("gamma", C.c_double), ("n_rounds", C.c_int32), ("its_per_round", C.c_int32),
+                ("max_trials", C.c_int32), ("reserved", C.c_int32)]
+
+
+class PoseResult(C.Structure):
+    _fields_ = [
+        ("pose_qt", C.c_double * 7),
+        ("n_inliers", C.c_int32), ("lm_iterations", C.c_int32), ("lm_trials", C.c_int32), ("reserved", C.c_int32),
+        ("chi2", C.c_double),
+        ("pt_outlier", c_uint8_p), ("ln_outlier", c_uint8_p),
+    ]
+
+
+def _p(arr, ctype):
+    return arr.ctypes.data_as(C.POINTER(ctype))
+
+
+def as_f64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+def as_i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+# Every symbol include/lld_amd.h declares (checked by tests/test_abi.py against the built library).
+PRODUCT_SYMBOLS = [
+    "lld_status_string", "lld_ctx_create", "lld_ctx_destroy", "lld_ctx_stream", "lld_ctx_synchronize",
+    "lld_se3_from_tcw_f32", "lld_se3_to_tcw_f32", "lld_orb_inv_level_sigma2",
+    "lld_ba_params_default", "lld_local_ba",
+    "lld_ba_batch_create", "lld_ba_batch_solve", "lld_ba_batch_download", "lld_ba_batch_stats",
+    "lld_ba_batch_result_records", "lld_ba_batch_phase_ms", "lld_ba_batch_kernel_stats", "lld_ba_batch_destroy",
+    "lld_pose_params_default", "lld_pose_opt",
+    "lld_pose_batch_create", "lld_pose_batch_solve", "lld_pose_batch_download", "lld_pose_batch_destroy",
+    "lld_match_hamming256", "lld_match_hamming256_csr", "lld_match_hamming256_batch_dev",
+    "lld_match_l2f32", "lld_match_l2f32_batch_dev", "lld_line_match_greedy",
+]
+
+
+def product_library_path() -> str:
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "liblld_amd.so")
+
+
+class Lib:
+    """Thin typed view over one shared library exporting the ABI with a given symbol prefix."""
+
+    def __init__(self, path: str, prefix: str):
+        if not os.path.exists(path):
+            raise FileNotFoundError(
+                f"{path} is missing: build it first (python -c 'import __graft_entry__ as g; g.build()'). "
+                "There is no fallback path.")
+        self.path = path
+        self.prefix = prefix
+        self.dll = C.CDLL(path)
+        self._bind()
+
+    def fn(self, name):
+        return getattr(self.dll, self.prefix + name)
+
+    def has(self, name) -> bool:
+        try:
+            self.fn(name)
+            return True
+        except AttributeError:
+            return False
+
+    def _bind(self):
+        vp = C.c_void_p
+        f = self.fn
+        f("se3_from_tcw_f32").argtypes = [c_float_p, c_double_p]; f("se3_from_tcw_f32").restype = None
+        f("se3_to_tcw_f32").argtypes = [c_double_p, c_float_p]; f("se3_to_tcw_f32").restype = None
+        f("orb_inv_level_sigma2").argtypes = [C.c_float, C.c_int, c_float_p]; f("orb_inv_level_sigma2").restype = None
+        f("ba_params_default").argtypes = [C.POINTER(BAParams)]; f("ba_params_default").restype = None
+        f("pose_params_default").argtypes = [C.POINTER(PoseParams)]; f("pose_params_default").restype = None
+        f("local_ba").argtypes = [vp, C.POINTER(BAWindow), C.POINTER(BAParams), C.POINTER(C.c_int), C.POINTER(BAResult)]
+        f("local_ba").restype = C.c_int
+        f("pose_opt").argtypes = [vp, C.POINTER(PoseProblem), C.POINTER(PoseParams), C.POINTER(PoseResult)]
+        f("pose_opt").restype = C.c_int
+        f("match_hamming256").argtypes = [vp, c_uint32_p, C.c_int, c_uint32_p, C.c_int, c_uint8_p,
+                                          c_int32_p, c_int32_p, c_int32_p, c_int32_p]
+        f("match_hamming256").restype = C.c_int
+        f("match_hamming256_csr").argtypes = [vp, c_uint32_p, C.c_int, c_uint32_p, C.c_int, c_int32_p, c_int32_p,
+                                              c_int32_p, c_int32_p, c_int32_p, c_int32_p]
+        f("match_hamming256_csr").restype = C.c_int
+        f("match_l2f32").argtypes = [vp, c_float_p, C.c_int, c_float_p, C.c_int, C.c_int, c_uint8_p,
+                                     c_int32_p, c_double_p, c_int32_p, c_double_p]
+        f("match_l2f32").restype = C.c_int
+        f("line_match_greedy").argtypes = [vp, c_float_p, C.c_int, c_float_p, C.c_int, C.c_int, c_uint8_p, C.c_double,
+                                           c_int32_p, c_double_p]
+        f("line_match_greedy").restype = C.c_int
+        if self.prefix == "lld_":
+            f("status_string").argtypes = [C.c_int]; f("status_string").restype = C.c_char_p
+            f("ctx_create").argtypes = [C.c_int, C.POINTER(vp)]; f("ctx_create").restype = C.c_int
+            f("ctx_destroy").argtypes = [vp]; f("ctx_destroy").restype = None
+            f("ctx_stream").argtypes = [vp]; f("ctx_stream").restype = vp
+            f("ctx_synchronize").argtypes = [vp]; f("ctx_synchronize").restype = C.c_int
+            f("ba_batch_create").argtypes = [vp, C.c_int, C.POINTER(BAWindow), C.POINTER(BAParams), C.POINTER(vp)]
+            f("ba_batch_create").restype = C.c_int
+            f("ba_batch_solve").argtypes = [vp, C.POINTER(C.c_int)]; f("ba_batch_solve").restype = C.c_int
+            f("ba_batch_download").argtypes = [vp, C.c_int, C.POINTER(BAResult)]; f("ba_batch_download").restype = C.c_int
+            f("ba_batch_stats").argtypes = [vp, C.POINTER(BAStats)]; f("ba_batch_stats").restype = C.c_int
+            f("ba_batch_result_records").argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_uint64)]
+            f("ba_batch_result_records").restype = C.c_int
+            f("ba_batch_phase_ms").argtypes = [vp, c_double_p]; f("ba_batch_phase_ms").restype = C.c_int
+            f("ba_batch_kernel_stats").argtypes = [vp, C.POINTER(C.c_int64), c_double_p]
+            f("ba_batch_kernel_stats").restype = C.c_int
+            f("ba_batch_destroy").argtypes = [vp]; f("ba_batch_destroy").restype = None
+            f("pose_batch_create").argtypes = [vp, C.c_int, C.POINTER(PoseProblem), C.POINTER(PoseParams), C.POINTER(vp)]
+            f("pose_batch_create").restype = C.c_int
+            f("pose_batch_solve").argtypes = [vp]; f("pose_batch_solve").restype = C.c_int
+            f("pose_batch_download").argtypes = [vp, C.c_int, C.POINTER(PoseResult)]; f("pose_batch_download").restype = C.c_int
+            f("pose_batch_destroy").argtypes = [vp]; f("pose_batch_destroy").restype = None
+            f("match_hamming256_batch_dev").argtypes = [vp, C.c_int, vp, C.c_int, vp, C.c_int, vp, vp, vp, vp]
+            f("match_hamming256_batch_dev").restype = C.c_int
+            f("match_l2f32_batch_dev").argtypes = [vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, vp, vp, vp, vp]
+            f("match_l2f32_batch_dev").restype = C.c_int
+
+
+_PRODUCT = None
+
+
+def product() -> Lib:
+    """The HIP library.  Raises if it has not been built — the product path never falls back to CPU."""
+    global _PRODUCT
+    if _PRODUCT is None:
+        _PRODUCT = Lib(product_library_path(), "lld_")
+    return _PRODUCT

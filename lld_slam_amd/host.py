@@ -1,0 +1,471 @@
+"""Host-side mirror of the reference interface over the C ABI (Python flavour, used by tests and bench).
+
+Names follow the reference (`Optimizer::LocalBundleAdjustment`, `Optimizer::PoseOptimization`,
+`ORBmatcher`, `TwoFrameLineMatcher`); the arguments are the flat windows of include/lld_amd.h instead
+of live KeyFrame/MapPoint/MapLine objects (INTEGRATION.md shows the gather/scatter adapter).
+
+The marshalling helpers (`ba_call`, `pose_call`, ...) take the library object as an argument so the
+test-only oracle loader can reuse them; the public classes below always use the HIP library and raise
+when it is missing or no GPU is present.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import abi
+from .abi import (BAParams, BAResult, BAStats, BAWindow, Camera, PoseParams, PoseProblem, PoseResult, as_f64,
+                  as_i32, _p)
+
+
+# ------------------------------------------------------------------ flat problem containers
+@dataclass
+class Window:
+    """One local-BA window (see lld_ba_window)."""
+    cam: tuple                      # fx, fy, cx, cy, bf
+    n_free_cams: int
+    cam_qt: np.ndarray              # [n_cams,7]
+    pt_xyz: np.ndarray              # [n_points,3]
+    pt_obs_start: np.ndarray        # [n_points+1]
+    pt_obs_cam: np.ndarray          # [n_pt_obs]
+    pt_obs_uvr: np.ndarray          # [n_pt_obs,3]
+    pt_obs_inv_sigma2: np.ndarray   # [n_pt_obs]
+    line_x0: np.ndarray             # [n_lines,3]
+    line_dir: np.ndarray            # [n_lines,3]
+    ln_obs_start: np.ndarray        # [n_lines+1]
+    ln_obs_cam: np.ndarray          # [n_ln_obs]
+    ln_obs_left: np.ndarray         # [n_ln_obs,4]
+    ln_obs_right: np.ndarray        # [n_ln_obs,4]
+    ln_obs_octave: np.ndarray       # [n_ln_obs,2]
+    meta: dict = field(default_factory=dict)
+
+    def normalise(self):
+        self.cam_qt = as_f64(self.cam_qt, (-1, 7))
+        self.pt_xyz = as_f64(self.pt_xyz, (-1, 3))
+        self.pt_obs_start = as_i32(self.pt_obs_start)
+        self.pt_obs_cam = as_i32(self.pt_obs_cam)
+        self.pt_obs_uvr = as_f64(self.pt_obs_uvr, (-1, 3))
+        self.pt_obs_inv_sigma2 = as_f64(self.pt_obs_inv_sigma2)
+        self.line_x0 = as_f64(self.line_x0, (-1, 3))
+        self.line_dir = as_f64(self.line_dir, (-1, 3))
+        self.ln_obs_start = as_i32(self.ln_obs_start)
+        self.ln_obs_cam = as_i32(self.ln_obs_cam)
+        self.ln_obs_left = as_f64(self.ln_obs_left, (-1, 4))
+        self.ln_obs_right = as_f64(self.ln_obs_right, (-1, 4))
+        self.ln_obs_octave = as_i32(self.ln_obs_octave).reshape(-1, 2)
+        return self
+
+    @property
+    def n_cams(self): return self.cam_qt.shape[0]
+    @property
+    def n_points(self): return self.pt_xyz.shape[0]
+    @property
+    def n_lines(self): return self.line_x0.shape[0]
+    @property
+    def n_pt_obs(self): return self.pt_obs_cam.shape[0]
+    @property
+    def n_ln_obs(self): return self.ln_obs_cam.shape[0]
+
+    def n_edges(self):
+        """g2o edges this window expands to: one per point observation, 1-2 per line observation."""
+        return int(self.n_pt_obs + self.n_ln_obs + np.count_nonzero(self.ln_obs_right[:, 0] >= 0))
+
+    def to_c(self) -> BAWindow:
+        self.normalise()
+        w = BAWindow()
+        w.cam = Camera(*[float(v) for v in self.cam])
+        w.n_cams = self.n_cams; w.n_free_cams = int(self.n_free_cams)
+        w.cam_qt = _p(self.cam_qt, C.c_double)
+        w.n_points = self.n_points
+        w.pt_xyz = _p(self.pt_xyz, C.c_double)
+        w.pt_obs_start = _p(self.pt_obs_start, C.c_int32)
+        w.n_pt_obs = self.n_pt_obs
+        w.pt_obs_cam = _p(self.pt_obs_cam, C.c_int32)
+        w.pt_obs_uvr = _p(self.pt_obs_uvr, C.c_double)
+        w.pt_obs_inv_sigma2 = _p(self.pt_obs_inv_sigma2, C.c_double)
+        w.n_lines = self.n_lines
+        w.line_x0 = _p(self.line_x0, C.c_double)
+        w.line_dir = _p(self.line_dir, C.c_double)
+        w.ln_obs_start = _p(self.ln_obs_start, C.c_int32)
+        w.n_ln_obs = self.n_ln_obs
+        w.ln_obs_cam = _p(self.ln_obs_cam, C.c_int32)
+        w.ln_obs_left = _p(self.ln_obs_left, C.c_double)
+        w.ln_obs_right = _p(self.ln_obs_right, C.c_double)
+        w.ln_obs_octave = _p(self.ln_obs_octave, C.c_int32)
+        return w
+
+
+@dataclass
+class BAOutput:
+    cam_qt: np.ndarray
+    pt_xyz: np.ndarray
+    line_x0: np.ndarray
+    line_dir: np.ndarray
+    pt_obs_outlier: np.ndarray
+    ln_edge_outlier: np.ndarray
+    line_removed: np.ndarray
+    stats: dict
+
+    @staticmethod
+    def alloc(win: Window):
+        return BAOutput(np.zeros((win.n_cams, 7)), np.zeros((win.n_points, 3)), np.zeros((win.n_lines, 3)),
+                        np.zeros((win.n_lines, 3)), np.zeros(win.n_pt_obs, np.uint8),
+                        np.zeros((win.n_ln_obs, 2), np.uint8), np.zeros(win.n_lines, np.uint8), {})
+
+    def to_c(self) -> BAResult:
+        r = BAResult()
+        r.cam_qt = _p(self.cam_qt, C.c_double); r.pt_xyz = _p(self.pt_xyz, C.c_double)
+        r.line_x0 = _p(self.line_x0, C.c_double); r.line_dir = _p(self.line_dir, C.c_double)
+        r.pt_obs_outlier = _p(self.pt_obs_outlier, C.c_uint8)
+        r.ln_edge_outlier = _p(self.ln_edge_outlier, C.c_uint8)
+        r.line_removed = _p(self.line_removed, C.c_uint8)
+        return r
+
+
+def stats_dict(s: BAStats) -> dict:
+    return dict(chi2_round1=s.chi2_round1, chi2_final=s.chi2_final, lm_iterations=list(s.lm_iterations),
+                lm_trials=list(s.lm_trials), pcg_iterations=s.pcg_iterations, n_pt_obs_outlier=s.n_pt_obs_outlier,
+                n_ln_edge_outlier=s.n_ln_edge_outlier, n_lines_removed=s.n_lines_removed, aborted=s.aborted)
+
+
+def ba_params(lib: abi.Lib, gamma=1.0, **kw) -> BAParams:
+    p = BAParams()
+    lib.fn("ba_params_default")(C.byref(p))
+    p.gamma = gamma
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def pose_params(lib: abi.Lib, gamma=0.5, **kw) -> PoseParams:
+    p = PoseParams()
+    lib.fn("pose_params_default")(C.byref(p))
+    p.gamma = gamma
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def check(status: int, what: str):
+    if status != abi.LLD_OK:
+        raise RuntimeError(f"{what} failed with status {status}")
+
+
+def ba_call(lib: abi.Lib, ctx, win: Window, params: BAParams | None = None, abort: bool = False) -> BAOutput:
+    cw = win.to_c()
+    out = BAOutput.alloc(win)
+    cr = out.to_c()
+    if params is None:
+        params = ba_params(lib)
+    flag = C.c_int(1 if abort else 0)
+    check(lib.fn("local_ba")(ctx, C.byref(cw), C.byref(params), C.byref(flag), C.byref(cr)), "local_ba")
+    out.stats = stats_dict(cr.stats)
+    return out
+
+
+@dataclass
+class PoseFrame:
+    """One PoseOptimization problem (see lld_pose_problem)."""
+    cam: tuple
+    pose_qt: np.ndarray
+    pt_xw: np.ndarray
+    pt_uvr: np.ndarray
+    pt_inv_sigma2: np.ndarray
+    ln_x0: np.ndarray
+    ln_dir: np.ndarray
+    ln_left: np.ndarray
+    ln_right: np.ndarray
+    ln_octave: np.ndarray
+    meta: dict = field(default_factory=dict)
+
+    def normalise(self):
+        self.pose_qt = as_f64(self.pose_qt, (7,))
+        self.pt_xw = as_f64(self.pt_xw, (-1, 3)); self.pt_uvr = as_f64(self.pt_uvr, (-1, 3))
+        self.pt_inv_sigma2 = as_f64(self.pt_inv_sigma2)
+        self.ln_x0 = as_f64(self.ln_x0, (-1, 3)); self.ln_dir = as_f64(self.ln_dir, (-1, 3))
+        self.ln_left = as_f64(self.ln_left, (-1, 4)); self.ln_right = as_f64(self.ln_right, (-1, 4))
+        self.ln_octave = as_i32(self.ln_octave).reshape(-1, 2)
+        return self
+
+    @property
+    def n_points(self): return self.pt_xw.shape[0]
+    @property
+    def n_lines(self): return self.ln_x0.shape[0]
+
+    def to_c(self) -> PoseProblem:
+        self.normalise()
+        p = PoseProblem()
+        p.cam = Camera(*[float(v) for v in self.cam])
+        for i in range(7):
+            p.pose_qt[i] = float(self.pose_qt[i])
+        p.n_points = self.n_points
+        p.pt_xw = _p(self.pt_xw, C.c_double); p.pt_uvr = _p(self.pt_uvr, C.c_double)
+        p.pt_inv_sigma2 = _p(self.pt_inv_sigma2, C.c_double)
+        p.n_lines = self.n_lines
+        p.ln_x0 = _p(self.ln_x0, C.c_double); p.ln_dir = _p(self.ln_dir, C.c_double)
+        p.ln_left = _p(self.ln_left, C.c_double); p.ln_right = _p(self.ln_right, C.c_double)
+        p.ln_octave = _p(self.ln_octave, C.c_int32)
+        return p
+
+
+@dataclass
+class PoseOutput:
+    pose_qt: np.ndarray
+    n_inliers: int
+    pt_outlier: np.ndarray
+    ln_outlier: np.ndarray
+    lm_iterations: int
+    lm_trials: int
+    chi2: float
+
+
+def pose_result_alloc(n_points, n_lines):
+    po = np.zeros(n_points, np.uint8); lo = np.zeros(n_lines, np.uint8)
+    r = PoseResult()
+    r.pt_outlier = _p(po, C.c_uint8); r.ln_outlier = _p(lo, C.c_uint8)
+    return r, po, lo
+
+
+def pose_call(lib: abi.Lib, ctx, frame: PoseFrame, params: PoseParams | None = None) -> PoseOutput:
+    cp = frame.to_c()
+    r, po, lo = pose_result_alloc(frame.n_points, frame.n_lines)
+    if params is None:
+        params = pose_params(lib)
+    check(lib.fn("pose_opt")(ctx, C.byref(cp), C.byref(params), C.byref(r)), "pose_opt")
+    return PoseOutput(np.array(list(r.pose_qt)), r.n_inliers, po, lo, r.lm_iterations, r.lm_trials, r.chi2)
+
+
+def hamming_call(lib: abi.Lib, ctx, q: np.ndarray, t: np.ndarray, mask: np.ndarray | None = None):
+    q = np.ascontiguousarray(q, np.uint32).reshape(-1, 8); t = np.ascontiguousarray(t, np.uint32).reshape(-1, 8)
+    nq, nt = q.shape[0], t.shape[0]
+    bi = np.empty(nq, np.int32); bd = np.empty(nq, np.int32); si = np.empty(nq, np.int32); sd = np.empty(nq, np.int32)
+    mp = None
+    if mask is not None:
+        mask = np.ascontiguousarray(mask, np.uint8).reshape(nq, nt)
+        mp = _p(mask, C.c_uint8)
+    check(lib.fn("match_hamming256")(ctx, _p(q, C.c_uint32), nq, _p(t, C.c_uint32), nt, mp, _p(bi, C.c_int32),
+                                     _p(bd, C.c_int32), _p(si, C.c_int32), _p(sd, C.c_int32)), "match_hamming256")
+    return bi, bd, si, sd
+
+
+def hamming_csr_call(lib: abi.Lib, ctx, q, t, cand_start, cand_idx):
+    q = np.ascontiguousarray(q, np.uint32).reshape(-1, 8); t = np.ascontiguousarray(t, np.uint32).reshape(-1, 8)
+    cs = as_i32(cand_start); ci = as_i32(cand_idx)
+    if ci.size == 0:
+        ci = np.zeros(1, np.int32)
+    nq, nt = q.shape[0], t.shape[0]
+    bi = np.empty(nq, np.int32); bd = np.empty(nq, np.int32); si = np.empty(nq, np.int32); sd = np.empty(nq, np.int32)
+    check(lib.fn("match_hamming256_csr")(ctx, _p(q, C.c_uint32), nq, _p(t, C.c_uint32), nt, _p(cs, C.c_int32),
+                                         _p(ci, C.c_int32), _p(bi, C.c_int32), _p(bd, C.c_int32), _p(si, C.c_int32),
+                                         _p(sd, C.c_int32)), "match_hamming256_csr")
+    return bi, bd, si, sd
+
+
+def l2_call(lib: abi.Lib, ctx, q: np.ndarray, t: np.ndarray, mask: np.ndarray | None = None):
+    q = np.ascontiguousarray(q, np.float32); t = np.ascontiguousarray(t, np.float32)
+    nq, dim = q.shape; nt = t.shape[0]
+    bi = np.empty(nq, np.int32); bd = np.empty(nq, np.float64); si = np.empty(nq, np.int32); sd = np.empty(nq, np.float64)
+    mp = None
+    if mask is not None:
+        mask = np.ascontiguousarray(mask, np.uint8).reshape(nq, nt)
+        mp = _p(mask, C.c_uint8)
+    check(lib.fn("match_l2f32")(ctx, _p(q, C.c_float), nq, _p(t, C.c_float), nt, dim, mp, _p(bi, C.c_int32),
+                                _p(bd, C.c_double), _p(si, C.c_int32), _p(sd, C.c_double)), "match_l2f32")
+    return bi, bd, si, sd
+
+
+def greedy_call(lib: abi.Lib, ctx, dl: np.ndarray, dr: np.ndarray, gate: np.ndarray | None, tau: float):
+    dl = np.ascontiguousarray(dl, np.float32); dr = np.ascontiguousarray(dr, np.float32)
+    nq, dim = dl.shape; nt = dr.shape[0]
+    m = np.empty(nq, np.int32); d = np.empty(nq, np.float64)
+    gp = None
+    if gate is not None:
+        gate = np.ascontiguousarray(gate, np.uint8).reshape(nq, nt)
+        gp = _p(gate, C.c_uint8)
+    check(lib.fn("line_match_greedy")(ctx, _p(dl, C.c_float), nq, _p(dr, C.c_float), nt, dim, gp, float(tau),
+                                      _p(m, C.c_int32), _p(d, C.c_double)), "line_match_greedy")
+    return m, d
+
+
+def se3_from_tcw_f32(lib: abi.Lib, tcw: np.ndarray) -> np.ndarray:
+    t = np.ascontiguousarray(tcw, np.float32).reshape(16)
+    out = np.zeros(7)
+    lib.fn("se3_from_tcw_f32")(_p(t, C.c_float), _p(out, C.c_double))
+    return out
+
+
+def se3_to_tcw_f32(lib: abi.Lib, qt: np.ndarray) -> np.ndarray:
+    q = as_f64(qt, (7,))
+    out = np.zeros(16, np.float32)
+    lib.fn("se3_to_tcw_f32")(_p(q, C.c_double), _p(out, C.c_float))
+    return out.reshape(4, 4)
+
+
+def orb_inv_level_sigma2(lib: abi.Lib, scale_factor=1.2, n_levels=8) -> np.ndarray:
+    out = np.zeros(n_levels, np.float32)
+    lib.fn("orb_inv_level_sigma2")(C.c_float(scale_factor), n_levels, _p(out, C.c_float))
+    return out
+
+
+# ------------------------------------------------------------------ product-side API (HIP only)
+class Context:
+    """One lld_ctx: a HIP device + stream.  Raises when no GPU is present (no CPU fallback)."""
+
+    def __init__(self, device: int = 0):
+        self.lib = abi.product()
+        h = C.c_void_p()
+        st = self.lib.fn("ctx_create")(device, C.byref(h))
+        if st != abi.LLD_OK:
+            msg = self.lib.fn("status_string")(st).decode()
+            raise RuntimeError(f"lld_ctx_create(device={device}) failed: {msg} (status {st})")
+        self.handle = h
+        self.device = device
+
+    def stream(self) -> int:
+        return int(self.lib.fn("ctx_stream")(self.handle) or 0)
+
+    def synchronize(self):
+        check(self.lib.fn("ctx_synchronize")(self.handle), "ctx_synchronize")
+
+    def close(self):
+        if self.handle:
+            self.lib.fn("ctx_destroy")(self.handle)
+            self.handle = None
+
+    def __enter__(self): return self
+    def __exit__(self, *a): self.close()
+
+
+class Optimizer:
+    """Mirror of the reference's `Optimizer` static interface (include/Optimizer.h:49-50)."""
+
+    def __init__(self, ctx: Context):
+        self.ctx = ctx
+        self.lib = ctx.lib
+
+    def LocalBundleAdjustment(self, window: Window, pbStopFlag: bool = False, gamma: float = 1.0, **params) -> BAOutput:
+        return ba_call(self.lib, self.ctx.handle, window, ba_params(self.lib, gamma, **params), pbStopFlag)
+
+    def PoseOptimization(self, frame: PoseFrame, gamma: float = 1.0, **params) -> PoseOutput:
+        return pose_call(self.lib, self.ctx.handle, frame, pose_params(self.lib, gamma, **params))
+
+
+class BABatch:
+    """HBM-resident batch of windows (lld_ba_batch_*): upload once, solve many times."""
+
+    def __init__(self, ctx: Context, windows: list[Window], gamma: float = 1.0, **params):
+        self.ctx = ctx; self.lib = ctx.lib; self.windows = windows
+        self._c = (BAWindow * len(windows))(*[w.to_c() for w in windows])
+        self.params = ba_params(self.lib, gamma, **params)
+        h = C.c_void_p()
+        check(self.lib.fn("ba_batch_create")(ctx.handle, len(windows), self._c, C.byref(self.params), C.byref(h)),
+              "ba_batch_create")
+        self.handle = h
+
+    def solve(self, abort: bool = False):
+        flag = C.c_int(1 if abort else 0)
+        check(self.lib.fn("ba_batch_solve")(self.handle, C.byref(flag)), "ba_batch_solve")
+
+    def download(self, i: int) -> BAOutput:
+        out = BAOutput.alloc(self.windows[i]); cr = out.to_c()
+        check(self.lib.fn("ba_batch_download")(self.handle, i, C.byref(cr)), "ba_batch_download")
+        out.stats = stats_dict(cr.stats)
+        return out
+
+    def stats(self) -> list[dict]:
+        arr = (BAStats * len(self.windows))()
+        check(self.lib.fn("ba_batch_stats")(self.handle, arr), "ba_batch_stats")
+        return [stats_dict(s) for s in arr]
+
+    def phase_ms(self) -> np.ndarray:
+        ms = np.zeros(5)
+        check(self.lib.fn("ba_batch_phase_ms")(self.handle, _p(ms, C.c_double)), "ba_batch_phase_ms")
+        return ms
+
+    def kernel_stats(self):
+        n = C.c_int64(0); ms = np.zeros(1)
+        check(self.lib.fn("ba_batch_kernel_stats")(self.handle, C.byref(n), _p(ms, C.c_double)), "ba_batch_kernel_stats")
+        return int(n.value), float(ms[0])
+
+    def result_records(self):
+        p = C.c_void_p(); stride = C.c_uint64(0)
+        check(self.lib.fn("ba_batch_result_records")(self.handle, C.byref(p), C.byref(stride)), "ba_batch_result_records")
+        return int(p.value or 0), int(stride.value)
+
+    def close(self):
+        if self.handle:
+            self.lib.fn("ba_batch_destroy")(self.handle)
+            self.handle = None
+
+    def __enter__(self): return self
+    def __exit__(self, *a): self.close()
+
+
+class PoseBatch:
+    def __init__(self, ctx: Context, frames: list[PoseFrame], gamma: float = 0.5, **params):
+        self.ctx = ctx; self.lib = ctx.lib; self.frames = frames
+        self._c = (PoseProblem * len(frames))(*[f.to_c() for f in frames])
+        self.params = pose_params(self.lib, gamma, **params)
+        h = C.c_void_p()
+        check(self.lib.fn("pose_batch_create")(ctx.handle, len(frames), self._c, C.byref(self.params), C.byref(h)),
+              "pose_batch_create")
+        self.handle = h
+
+    def solve(self):
+        check(self.lib.fn("pose_batch_solve")(self.handle), "pose_batch_solve")
+
+    def download(self, i: int) -> PoseOutput:
+        f = self.frames[i]
+        r, po, lo = pose_result_alloc(f.n_points, f.n_lines)
+        check(self.lib.fn("pose_batch_download")(self.handle, i, C.byref(r)), "pose_batch_download")
+        return PoseOutput(np.array(list(r.pose_qt)), r.n_inliers, po, lo, r.lm_iterations, r.lm_trials, r.chi2)
+
+    def close(self):
+        if self.handle:
+            self.lib.fn("pose_batch_destroy")(self.handle)
+            self.handle = None
+
+    def __enter__(self): return self
+    def __exit__(self, *a): self.close()
+
+
+class ORBmatcher:
+    """Distance + best/second-best core of the reference's ORBmatcher (include/ORBmatcher.h:41-83).
+
+    TH_HIGH / TH_LOW / the ratio test are the reference's accept rules (src/ORBmatcher.cc:37-39, e.g. :118-121,
+    :228-230) applied on the host to the kernel's (best, second) output.
+    """
+    TH_HIGH = 100
+    TH_LOW = 50
+    HISTO_LENGTH = 30
+
+    def __init__(self, ctx: Context, nnratio: float = 0.6, checkOri: bool = True):
+        self.ctx = ctx; self.lib = ctx.lib
+        self.mfNNratio = np.float32(nnratio); self.mbCheckOrientation = checkOri
+
+    def BestTwo(self, q, t, mask=None):
+        return hamming_call(self.lib, self.ctx.handle, q, t, mask)
+
+    def BestTwoCandidates(self, q, t, cand_start, cand_idx):
+        return hamming_csr_call(self.lib, self.ctx.handle, q, t, cand_start, cand_idx)
+
+    def AcceptByRatio(self, best_idx, best_dist, second_dist, th):
+        """`bestDist<=th` and `bestDist < mfNNratio*bestDist2` as in SearchByBoW (src/ORBmatcher.cc:226-230)."""
+        ok = (best_idx >= 0) & (best_dist <= th) & (best_dist.astype(np.float32) < self.mfNNratio * second_dist.astype(np.float32))
+        return np.where(ok, best_idx, -1)
+
+
+class TwoFrameLineMatcher:
+    """Mirror of TwoFrameLineMatcher::MatchLines (include/TwoFrameLineMatcher.h:31-42); the geometric gates of
+    CheckLinePair are supplied by the caller as a byte matrix."""
+
+    def __init__(self, ctx: Context, tau: float):
+        self.ctx = ctx; self.lib = ctx.lib; self.tau = tau
+
+    def MatchLines(self, descsLeft, descsRight, gate=None):
+        return greedy_call(self.lib, self.ctx.handle, descsLeft, descsRight, gate, self.tau)
+
+    def BestTwo(self, q, t, mask=None):
+        return l2_call(self.lib, self.ctx.handle, q, t, mask)

@@ -1,0 +1,344 @@
+"""Deterministic synthetic inputs for the configs of BASELINE.json / SURVEY.md §8(d).
+
+The reference ships no data (KITTI, LBD detections and the ORB vocabulary are absent), so the parity tests and
+the bench run on synthetic keyframe graphs of the named shapes:
+
+  LBA-B  50 free + 10 fixed KFs, 10 000 points x 6 stereo obs, 2 000 lines x 5 KFs x (left+right)   = 80 000 edges
+  LBA-A  20 free +  5 fixed KFs,  5 000 points x 6,            1 000 lines x 5 x 2                   = 40 000 edges
+  PO     1 frame, 1 000 stereo point matches + 200 stereo lines (400 line edges), gamma 0.5
+  MATCH  2 000 x 2 000 ORB (256 bit) + 300 x 300 LBD (72 x f32)
+
+States are stored float32 and widened, mirroring the reference's float32 map (src/Converter.cc).
+Random numbers come from numpy's PCG64 seeded per problem id; generation is pure numpy (no reference code).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import abi
+from .host import PoseFrame, Window
+
+# KITTI04-12_LBD.yaml:8-25, rounded to float32 because KeyFrame::fx/fy/cx/cy/mbf are floats.
+_F32 = lambda v: float(np.float32(v))
+KITTI_CAM = (_F32(707.0912), _F32(707.0912), _F32(601.8873), _F32(183.1104), _F32(379.8145))
+IMG_W, IMG_H = 1241.0, 376.0
+
+SEED_LBA_B = 0xBA5E0000
+SEED_LBA_A = 0xBA5EA000
+SEED_PO = 0x90530000
+SEED_MATCH = 0x0AB00000
+
+
+def inv_level_sigma2(scale=1.2, n=8):
+    """mvInvLevelSigma2 (src/ORBextractor.cc:416-430) in float arithmetic (numpy float32)."""
+    sf = np.ones(n, np.float32); s2 = np.ones(n, np.float32)
+    for i in range(1, n):
+        sf[i] = np.float32(sf[i - 1] * np.float32(scale)); s2[i] = np.float32(sf[i] * sf[i])
+    return (np.float32(1.0) / s2).astype(np.float32)
+
+
+# ------------------------------------------------------------------ small SE3 helpers (generator only)
+def _skew(w):
+    return np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0.0]])
+
+
+def _rodrigues(w):
+    th = np.linalg.norm(w)
+    if th < 1e-12:
+        return np.eye(3) + _skew(w)
+    K = _skew(w / th)
+    return np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K
+
+
+def _tcw_to_qt(T):
+    """Converter::toSE3Quat restated in numpy for the generator (float32 4x4 -> q,t)."""
+    T = np.asarray(T, np.float32).astype(np.float64)
+    R = T[:3, :3]; t = T[:3, 3]
+    tr = R[0, 0] + R[1, 1] + R[2, 2]
+    if tr > 0:
+        s = np.sqrt(tr + 1.0); w = 0.5 * s; s = 0.5 / s
+        q = np.array([(R[2, 1] - R[1, 2]) * s, (R[0, 2] - R[2, 0]) * s, (R[1, 0] - R[0, 1]) * s, w])
+    else:
+        i = 0
+        if R[1, 1] > R[0, 0]: i = 1
+        if R[2, 2] > R[i, i]: i = 2
+        j = (i + 1) % 3; k = (j + 1) % 3
+        s = np.sqrt(R[i, i] - R[j, j] - R[k, k] + 1.0)
+        q = np.zeros(4); q[i] = 0.5 * s; s = 0.5 / s
+        q[3] = (R[k, j] - R[j, k]) * s; q[j] = (R[j, i] + R[i, j]) * s; q[k] = (R[k, i] + R[i, k]) * s
+    if q[3] < 0: q = -q
+    q = q / np.sqrt(np.sum(q * q))
+    return np.concatenate([q, t])
+
+
+def _project(cam, Rcw, tcw, X, bx=0.0):
+    """Pinhole projection of world points X [N,3] into one camera; returns u, v, z."""
+    Xc = X @ Rcw.T + tcw
+    z = Xc[:, 2]
+    u = cam[0] * (Xc[:, 0] + bx) / z + cam[2]
+    v = cam[1] * Xc[:, 1] / z + cam[3]
+    return u, v, z
+
+
+def _trajectory(rng, n, origin):
+    """Forward motion along +z, 1 m steps, yaw random walk sigma 1 deg, lateral jitter 5 cm.  Returns Rcw, tcw lists."""
+    yaw = np.cumsum(rng.normal(0, np.deg2rad(1.0), n))
+    Rs, ts = [], []
+    pos = np.array(origin, float)
+    for i in range(n):
+        Rwc = _rodrigues(np.array([0, yaw[i], 0.0]))
+        p = pos + np.array([rng.normal(0, 0.05), rng.normal(0, 0.05), 0.0])
+        Rs.append(Rwc.T); ts.append(-Rwc.T @ p)
+        pos = pos + Rwc @ np.array([0, 0, 1.0])
+    return np.array(Rs), np.array(ts)
+
+
+def _f32(a):
+    return np.asarray(a, np.float32).astype(np.float64)
+
+
+def make_ba_window(n_free=50, n_fixed=10, n_points=10000, obs_per_point=6, n_lines=2000, obs_per_line=5,
+                   seed=SEED_LBA_B, outlier_frac=0.05, mono_frac=0.0, mono_line_frac=0.0, cam=KITTI_CAM,
+                   pose_sigma=(0.5, 0.05), point_sigma=0.10, line_sigma=(1.0, 0.05), noise=1.0) -> Window:
+    rng = np.random.default_rng(seed)
+    n_cams = n_free + n_fixed
+    fx, fy, cx, cy, bf = cam
+    b = bf / fx
+    # trajectory: the n_fixed poses precede the window; camera index order = free first, then fixed
+    Rt, tt = _trajectory(rng, n_cams, origin=(20.0, -10.0, 5.0))
+    order = list(range(n_fixed, n_cams)) + list(range(0, n_fixed))       # cam index -> trajectory index
+    traj_of_cam = np.array(order)
+    Rcw = Rt[traj_of_cam]; tcw = tt[traj_of_cam]
+    inv_s2 = inv_level_sigma2().astype(np.float64)
+
+    def visible(X, need_right=True):
+        vis = np.zeros((X.shape[0], n_cams), bool)
+        for c in range(n_cams):
+            u, v, z = _project(cam, Rcw[c], tcw[c], X)
+            ok = (z > 1.0) & (u >= 0) & (u < IMG_W) & (v >= 0) & (v < IMG_H)
+            if need_right:
+                ok &= (u - bf / z) >= 0
+            vis[:, c] = ok
+        return vis
+
+    # ---------------- points
+    pts = np.zeros((0, 3)); pts_cams = []
+    while pts.shape[0] < n_points:
+        m = int((n_points - pts.shape[0]) * 1.6) + 64
+        k = rng.integers(0, n_cams, m)
+        u = rng.uniform(0, IMG_W, m); v = rng.uniform(0, IMG_H, m); d = rng.uniform(4.0, 60.0, m)
+        Xc = np.stack([(u - cx) / fx * d, (v - cy) / fy * d, d], 1)
+        X = np.einsum('nij,nj->ni', np.transpose(Rcw[k], (0, 2, 1)), Xc - tcw[k])
+        vis = visible(X)
+        for i in range(m):
+            cams = np.nonzero(vis[i])[0]
+            if cams.size < obs_per_point:
+                continue
+            # nearest in trajectory index to the seeding camera
+            dist = np.abs(traj_of_cam[cams] - traj_of_cam[k[i]])
+            sel = cams[np.argsort(dist, kind='stable')[:obs_per_point]]
+            pts_cams.append(np.sort(sel))
+            pts = np.vstack([pts, X[i:i + 1]])
+            if pts.shape[0] == n_points:
+                break
+    pt_obs_start = np.arange(0, (n_points + 1) * obs_per_point, obs_per_point, dtype=np.int32)
+    pt_obs_cam = np.concatenate(pts_cams).astype(np.int32) if n_points else np.zeros(0, np.int32)
+    n_pt_obs = pt_obs_cam.size
+    pt_of_obs = np.repeat(np.arange(n_points), obs_per_point)
+    Xo = pts[pt_of_obs]
+    Xc = np.einsum('nij,nj->ni', Rcw[pt_obs_cam], Xo) + tcw[pt_obs_cam]
+    octv = rng.integers(0, 8, n_pt_obs)
+    sig = 1.2 ** octv
+    sig = sig * noise
+    u = fx * Xc[:, 0] / Xc[:, 2] + cx + rng.normal(0, 1, n_pt_obs) * sig
+    v = fy * Xc[:, 1] / Xc[:, 2] + cy + rng.normal(0, 1, n_pt_obs) * sig
+    ur = fx * Xc[:, 0] / Xc[:, 2] + cx - bf / Xc[:, 2] + rng.normal(0, 1, n_pt_obs) * sig
+    out = rng.random(n_pt_obs) < outlier_frac
+    u = np.where(out, rng.uniform(0, IMG_W, n_pt_obs), u)
+    v = np.where(out, rng.uniform(0, IMG_H, n_pt_obs), v)
+    ur = np.where(out, u - rng.uniform(0, 80.0, n_pt_obs), ur)
+    ur = np.maximum(ur, 0.0)
+    mono = rng.random(n_pt_obs) < mono_frac
+    ur = np.where(mono, -1.0, ur)
+    pt_obs_uvr = _f32(np.stack([u, v, ur], 1))
+    pt_obs_inv_sigma2 = inv_s2[octv]
+
+    # ---------------- lines
+    lA = np.zeros((0, 3)); lB = np.zeros((0, 3)); ln_cams = []
+    while lA.shape[0] < n_lines:
+        m = int((n_lines - lA.shape[0]) * 2.0) + 64
+        k = rng.integers(0, n_cams, m)
+        u0 = rng.uniform(0, IMG_W, m); v0 = rng.uniform(0, IMG_H, m); d = rng.uniform(4.0, 40.0, m)
+        Xc = np.stack([(u0 - cx) / fx * d, (v0 - cy) / fy * d, d], 1)
+        M = np.einsum('nij,nj->ni', np.transpose(Rcw[k], (0, 2, 1)), Xc - tcw[k])
+        dirv = rng.normal(size=(m, 3)); dirv /= np.linalg.norm(dirv, axis=1, keepdims=True)
+        L = rng.uniform(1.0, 5.0, m)
+        A = M - 0.5 * L[:, None] * dirv; B = M + 0.5 * L[:, None] * dirv
+        vis = visible(A) & visible(B)
+        for i in range(m):
+            cams = np.nonzero(vis[i])[0]
+            if cams.size < obs_per_line:
+                continue
+            dist = np.abs(traj_of_cam[cams] - traj_of_cam[k[i]])
+            sel = cams[np.argsort(dist, kind='stable')[:obs_per_line]]
+            ln_cams.append(np.sort(sel))
+            lA = np.vstack([lA, A[i:i + 1]]); lB = np.vstack([lB, B[i:i + 1]])
+            if lA.shape[0] == n_lines:
+                break
+    ln_obs_start = np.arange(0, (n_lines + 1) * obs_per_line, obs_per_line, dtype=np.int32)
+    ln_obs_cam = np.concatenate(ln_cams).astype(np.int32) if n_lines else np.zeros(0, np.int32)
+    n_ln_obs = ln_obs_cam.size
+    ln_of_obs = np.repeat(np.arange(n_lines), obs_per_line)
+
+    def seg_obs(bx):
+        """Detected segment for every (line,KF): true endpoints slid along the line by +-20 % and jittered 1 px."""
+        A = lA[ln_of_obs]; B = lB[ln_of_obs]
+        s0 = rng.uniform(-0.2, 0.2, n_ln_obs); s1 = rng.uniform(-0.2, 0.2, n_ln_obs)
+        A2 = A + s0[:, None] * (B - A); B2 = B + s1[:, None] * (B - A)
+        segs = []
+        for P in (A2, B2):
+            Xc = np.einsum('nij,nj->ni', Rcw[ln_obs_cam], P) + tcw[ln_obs_cam]
+            uu = fx * (Xc[:, 0] + bx) / Xc[:, 2] + cx + rng.normal(0, 1, n_ln_obs) * noise
+            vv = fy * Xc[:, 1] / Xc[:, 2] + cy + rng.normal(0, 1, n_ln_obs) * noise
+            segs += [uu, vv]
+        return np.stack(segs, 1)
+
+    left = seg_obs(0.0); right = seg_obs(-b)
+    lout = rng.random(n_ln_obs) < outlier_frac
+    for seg in (left, right):
+        rnd = np.stack([rng.uniform(0, IMG_W, n_ln_obs), rng.uniform(0, IMG_H, n_ln_obs),
+                        rng.uniform(0, IMG_W, n_ln_obs), rng.uniform(0, IMG_H, n_ln_obs)], 1)
+        seg[lout] = rnd[lout]
+    right[:, 0] = np.maximum(right[:, 0], 0.0)     # xs >= 0 is the "has stereo match" flag
+    mono_l = rng.random(n_ln_obs) < mono_line_frac
+    right[mono_l] = -1.0
+    loct = rng.integers(0, 3, n_ln_obs)
+    ln_obs_octave = np.stack([loct, loct], 1).astype(np.int32)
+
+    # ---------------- initial state: perturbed, stored float32 (poses, points) / double (lines)
+    cam_qt = np.zeros((n_cams, 7))
+    for c in range(n_cams):
+        T = np.eye(4); T[:3, :3] = Rcw[c]; T[:3, 3] = tcw[c]
+        if c < n_free:
+            w = rng.normal(0, np.deg2rad(pose_sigma[0]), 3); dt = rng.normal(0, pose_sigma[1], 3)
+            dT = np.eye(4); dT[:3, :3] = _rodrigues(w); dT[:3, 3] = dt
+            T = dT @ T
+        cam_qt[c] = _tcw_to_qt(T)
+    pt_xyz = _f32(pts + rng.normal(0, point_sigma, pts.shape))
+    # lines: perturb direction by ~1 deg and position by 5 cm, then re-derive (X0 perpendicular foot, unit dir)
+    dirs = lB - lA
+    dirs = dirs / np.linalg.norm(dirs, axis=1, keepdims=True) if n_lines else dirs
+    dirs_p = dirs + rng.normal(0, np.deg2rad(line_sigma[0]), dirs.shape)
+    dirs_p = dirs_p / np.linalg.norm(dirs_p, axis=1, keepdims=True) if n_lines else dirs_p
+    P0 = lA + rng.normal(0, line_sigma[1], lA.shape)
+    X0 = P0 - np.sum(P0 * dirs_p, 1, keepdims=True) * dirs_p
+
+    w = Window(cam=cam, n_free_cams=n_free, cam_qt=cam_qt, pt_xyz=pt_xyz, pt_obs_start=pt_obs_start,
+               pt_obs_cam=pt_obs_cam, pt_obs_uvr=pt_obs_uvr, pt_obs_inv_sigma2=pt_obs_inv_sigma2,
+               line_x0=X0, line_dir=dirs_p, ln_obs_start=ln_obs_start, ln_obs_cam=ln_obs_cam,
+               ln_obs_left=_f32(left), ln_obs_right=_f32(right), ln_obs_octave=ln_obs_octave,
+               meta=dict(seed=seed, gt_Rcw=Rcw, gt_tcw=tcw, gt_pts=pts, gt_lA=lA, gt_lB=lB))
+    return w.normalise()
+
+
+def make_lba_b(window_id=0, **kw) -> Window:
+    return make_ba_window(50, 10, 10000, 6, 2000, 5, seed=SEED_LBA_B + window_id, **kw)
+
+
+def make_lba_a(window_id=0, **kw) -> Window:
+    return make_ba_window(20, 5, 5000, 6, 1000, 5, seed=SEED_LBA_A + window_id, **kw)
+
+
+def make_lba_small(window_id=0, n_free=6, n_fixed=2, n_points=300, n_lines=60, **kw) -> Window:
+    """Tiny window for fast CPU tests."""
+    return make_ba_window(n_free, n_fixed, n_points, 4, n_lines, 4, seed=0x5A110000 + window_id, **kw)
+
+
+def make_pose_frame(frame_id=0, n_points=1000, n_lines=200, outlier_frac=0.10, mono_frac=0.0, mono_line_frac=0.0,
+                    cam=KITTI_CAM, seed=None) -> PoseFrame:
+    rng = np.random.default_rng(SEED_PO + frame_id if seed is None else seed)
+    fx, fy, cx, cy, bf = cam
+    b = bf / fx
+    Rcw = _rodrigues(rng.normal(0, 0.2, 3)); pos = rng.uniform(-20, 20, 3)
+    tcw = -Rcw @ pos
+    inv_s2 = inv_level_sigma2().astype(np.float64)
+    # points in the frustum
+    u = rng.uniform(0, IMG_W, n_points); v = rng.uniform(0, IMG_H, n_points); d = rng.uniform(4, 60, n_points)
+    d = np.maximum(d, bf / np.maximum(u, 1.0) + 0.5)        # keep uR >= 0
+    Xc = np.stack([(u - cx) / fx * d, (v - cy) / fy * d, d], 1)
+    Xw = _f32((Xc - tcw) @ Rcw)                                # Rcw^T (Xc - t), stored float32
+    Xc = Xw @ Rcw.T + tcw
+    octv = rng.integers(0, 8, n_points); sig = 1.2 ** octv
+    uu = fx * Xc[:, 0] / Xc[:, 2] + cx + rng.normal(0, 1, n_points) * sig
+    vv = fy * Xc[:, 1] / Xc[:, 2] + cy + rng.normal(0, 1, n_points) * sig
+    ur = fx * Xc[:, 0] / Xc[:, 2] + cx - bf / Xc[:, 2] + rng.normal(0, 1, n_points) * sig
+    out = rng.random(n_points) < outlier_frac
+    uu = np.where(out, rng.uniform(0, IMG_W, n_points), uu); vv = np.where(out, rng.uniform(0, IMG_H, n_points), vv)
+    ur = np.where(out, uu - rng.uniform(0, 80, n_points), ur)
+    ur = np.maximum(ur, 0.0)
+    ur = np.where(rng.random(n_points) < mono_frac, -1.0, ur)
+    # lines
+    u0 = rng.uniform(100, IMG_W - 100, n_lines); v0 = rng.uniform(50, IMG_H - 50, n_lines); d = rng.uniform(6, 40, n_lines)
+    Mc = np.stack([(u0 - cx) / fx * d, (v0 - cy) / fy * d, d], 1)
+    dirc = rng.normal(size=(n_lines, 3)); dirc[:, 2] *= 0.3; dirc /= np.linalg.norm(dirc, axis=1, keepdims=True)
+    L = rng.uniform(1, 4, n_lines)
+    Ac = Mc - 0.5 * L[:, None] * dirc; Bc = Mc + 0.5 * L[:, None] * dirc
+    A = (Ac - tcw) @ Rcw; B = (Bc - tcw) @ Rcw
+    dirw = (B - A) / np.linalg.norm(B - A, axis=1, keepdims=True)
+    X0 = A - np.sum(A * dirw, 1, keepdims=True) * dirw
+
+    def seg(bx):
+        s0 = rng.uniform(-0.2, 0.2, n_lines); s1 = rng.uniform(-0.2, 0.2, n_lines)
+        cols = []
+        for P in (Ac + s0[:, None] * (Bc - Ac), Bc + s1[:, None] * (Bc - Ac)):
+            cols += [fx * (P[:, 0] + bx) / P[:, 2] + cx + rng.normal(0, 1, n_lines),
+                     fy * P[:, 1] / P[:, 2] + cy + rng.normal(0, 1, n_lines)]
+        return np.stack(cols, 1)
+
+    left = seg(0.0); right = seg(-b)
+    lout = rng.random(n_lines) < outlier_frac
+    for s in (left, right):
+        rnd = np.stack([rng.uniform(0, IMG_W, n_lines), rng.uniform(0, IMG_H, n_lines),
+                        rng.uniform(0, IMG_W, n_lines), rng.uniform(0, IMG_H, n_lines)], 1)
+        s[lout] = rnd[lout]
+    right[:, 0] = np.maximum(right[:, 0], 0.0)
+    right[rng.random(n_lines) < mono_line_frac] = -1.0
+    loct = rng.integers(0, 3, n_lines)
+    # initial pose = exp(2 deg, 0.3 m) * GT, stored float32
+    w = rng.normal(size=3); w *= np.deg2rad(2.0) / np.linalg.norm(w)
+    dt = rng.normal(size=3); dt *= 0.3 / np.linalg.norm(dt)
+    T = np.eye(4); T[:3, :3] = Rcw; T[:3, 3] = tcw
+    dT = np.eye(4); dT[:3, :3] = _rodrigues(w); dT[:3, 3] = dt
+    pose_qt = _tcw_to_qt(dT @ T)
+    f = PoseFrame(cam=cam, pose_qt=pose_qt, pt_xw=Xw, pt_uvr=_f32(np.stack([uu, vv, ur], 1)),
+                  pt_inv_sigma2=inv_s2[octv], ln_x0=X0, ln_dir=dirw, ln_left=_f32(left), ln_right=_f32(right),
+                  ln_octave=np.stack([loct, loct], 1).astype(np.int32),
+                  meta=dict(gt_Rcw=Rcw, gt_tcw=tcw, gt_qt=_tcw_to_qt(T)))
+    return f.normalise()
+
+
+def make_match_orb(pair_id=0, nq=2000, nt=2000, n_corr=1600, flip_p=0.08, n_dup=16):
+    """ORB descriptors: n_corr train rows are permuted query rows with bits flipped w.p. flip_p, the rest unrelated;
+    n_dup exact duplicates of earlier train rows exercise ties (the lowest index must win)."""
+    rng = np.random.default_rng(SEED_MATCH + pair_id)
+    q = rng.integers(0, 2 ** 32, (nq, 8), dtype=np.uint64).astype(np.uint32)
+    t = rng.integers(0, 2 ** 32, (nt, 8), dtype=np.uint64).astype(np.uint32)
+    n_corr = min(n_corr, nq, nt)
+    src = rng.permutation(nq)[:n_corr]; dst = rng.permutation(nt)[:n_corr]
+    flips = rng.random((n_corr, 256)) < flip_p
+    fl = np.packbits(flips.reshape(n_corr, 8, 32)[:, :, ::-1], axis=2, bitorder='big').view('>u4').reshape(n_corr, 8).astype(np.uint32)
+    t[dst] = q[src] ^ fl
+    if n_dup and nt > 2 * n_dup:
+        a = rng.permutation(nt)[:2 * n_dup]
+        t[a[n_dup:]] = t[a[:n_dup]]
+    return q, t
+
+
+def make_match_lbd(pair_id=0, nq=300, nt=300, dim=72, n_corr=240, noise=0.05):
+    rng = np.random.default_rng(SEED_MATCH + 0x8000 + pair_id)
+    q = rng.normal(size=(nq, dim)); q /= np.linalg.norm(q, axis=1, keepdims=True)
+    t = rng.normal(size=(nt, dim)); t /= np.linalg.norm(t, axis=1, keepdims=True)
+    n_corr = min(n_corr, nq, nt)
+    src = rng.permutation(nq)[:n_corr]; dst = rng.permutation(nt)[:n_corr]
+    t[dst] = q[src] + rng.normal(0, noise, (n_corr, dim))
+    return q.astype(np.float32), t.astype(np.float32)

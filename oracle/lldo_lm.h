@@ -1,0 +1,116 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see lldo_math.h header).  PARITY UNPINNED.
+//
+// lldo_lm.h — Levenberg–Marquardt driver restated from
+//   Thirdparty/g2o/g2o/core/optimization_algorithm_levenberg.cpp:61-189
+//   Thirdparty/g2o/g2o/core/sparse_optimizer.cpp:354-419 (optimize loop, terminate())
+// generic over a "system" that provides the g2o SparseOptimizer / BlockSolver operations.
+#ifndef LLDO_LM_H
+#define LLDO_LM_H
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+
+namespace lldo {
+
+enum LMResult { LM_TERMINATE = 2, LM_OK = 1, LM_FAIL = -1 };
+
+struct LMData {
+  double lambda = -1.;     // _currentLambda
+  double ni = 2.;          // _ni
+  int nBad = 0;            // _nBad
+  double tau = 1e-5;       // _tau
+  double goodUp = 2. / 3.; // _goodStepUpperScale
+  double goodLo = 1. / 3.; // _goodStepLowerScale
+  int maxTrials = 10;      // maxTrialsAfterFailure
+  // bookkeeping (not in the reference)
+  double lastChi = 0.;
+  int trials = 0;
+  int iterations = 0;
+};
+
+// System concept:
+//   bool   buildStructure();                 BlockSolver::buildStructure
+//   void   computeActiveErrors();            SparseOptimizer::computeActiveErrors
+//   double activeRobustChi2();               SparseOptimizer::activeRobustChi2
+//   void   buildSystem();                    BlockSolver::buildSystem
+//   double maxDiagonal();                    max |H_kk| over the index mapping
+//   void   push(); void pop(); void discardTop();
+//   void   setLambda(double); bool solve(); void restoreDiagonal();
+//   void   update();                         SparseOptimizer::update(solver->x())
+//   double computeScale(double lambda);      sum_j x_j*(lambda*x_j + b_j)
+//   bool   terminate();                      forceStopFlag
+//   size_t numUnknownVertices();
+template <class Sys>
+static LMResult lm_solve(Sys& s, LMData& d, int iteration) {
+  if (iteration == 0) {
+    if (!s.buildStructure()) return LM_FAIL;
+  }
+  s.computeActiveErrors();
+  double currentChi = s.activeRobustChi2();
+  double tempChi = currentChi;
+  const double iniChi = currentChi;
+  s.buildSystem();
+  if (iteration == 0) {
+    d.lambda = d.tau * s.maxDiagonal();   // computeLambdaInit (levenberg.cpp:166-180)
+    d.ni = 2;
+    d.nBad = 0;
+  }
+  double rho = 0;
+  int qmax = 0;
+  do {
+    s.push();
+    s.setLambda(d.lambda);
+    const bool ok2 = s.solve();
+    s.update();
+    s.restoreDiagonal();
+    s.computeActiveErrors();
+    tempChi = s.activeRobustChi2();
+    if (!ok2) tempChi = DBL_MAX;
+    rho = (currentChi - tempChi);
+    double scale = s.computeScale(d.lambda);
+    scale += 1e-3;
+    rho /= scale;
+    if (rho > 0 && std::isfinite(tempChi)) {
+      double alpha = 1. - std::pow((2 * rho - 1), 3);
+      alpha = (std::min)(alpha, d.goodUp);
+      const double scaleFactor = (std::max)(d.goodLo, alpha);
+      d.lambda *= scaleFactor;
+      d.ni = 2;
+      currentChi = tempChi;
+      s.discardTop();
+    } else {
+      d.lambda *= d.ni;
+      d.ni *= 2;
+      s.pop();
+    }
+    qmax++;
+    d.trials++;
+  } while (rho < 0 && qmax < d.maxTrials && !s.terminate());
+  d.lastChi = currentChi;
+  if (qmax == d.maxTrials || rho == 0) return LM_TERMINATE;
+  if ((iniChi - currentChi) * 1e3 < iniChi) d.nBad++;
+  else d.nBad = 0;
+  if (d.nBad >= 3) return LM_TERMINATE;
+  return LM_OK;
+}
+
+// SparseOptimizer::optimize (sparse_optimizer.cpp:354-419)
+template <class Sys>
+static int lm_optimize(Sys& s, LMData& d, int iterations) {
+  if (s.numUnknownVertices() == 0) return -1;
+  bool ok = true;
+  int cj = 0;
+  LMResult result = LM_OK;
+  for (int i = 0; i < iterations && !s.terminate() && ok; i++) {
+    result = lm_solve(s, d, i);
+    ok = (result == LM_OK);
+    ++cj;
+    d.iterations++;
+  }
+  if (result == LM_FAIL) return 0;
+  return cj;
+}
+
+}  // namespace lldo
+#endif

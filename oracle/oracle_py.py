@@ -1,0 +1,189 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.
+
+Loader for oracle/liblld_oracle.so (the CPU restatement of the reference algorithm, symbols `lldo_*`).
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; nothing under
+lld_slam_amd/ does.  PARITY UNPINNED (see lld_oracle.cpp).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from lld_slam_amd import abi, host
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force: bool = False) -> str:
+    so = os.path.join(_HERE, "liblld_oracle.so")
+    srcs = [os.path.join(_HERE, f) for f in ("lld_oracle.cpp", "lldo_math.h", "lldo_edges.h", "lldo_lm.h")]
+    srcs.append(os.path.join(_HERE, "..", "include", "lld_amd.h"))
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return so
+
+
+def lib() -> abi.Lib:
+    global _LIB
+    if _LIB is None:
+        _LIB = abi.Lib(build(), "lldo_")
+        d = _LIB.dll
+        dp = abi.c_double_p
+        d.lldo_se3_exp.argtypes = [dp, dp]; d.lldo_se3_mul.argtypes = [dp, dp, dp]; d.lldo_se3_map.argtypes = [dp, dp, dp]
+        d.lldo_se3_oplus.argtypes = [dp, dp, dp]; d.lldo_quat_to_R.argtypes = [dp, dp]; d.lldo_quat_from_R.argtypes = [dp, dp]
+        d.lldo_huber.argtypes = [C.c_double, C.c_double, dp]
+        d.lldo_line_from_x0_dir.argtypes = [dp, dp, dp]; d.lldo_line_oplus.argtypes = [dp, dp, dp]
+        d.lldo_line_to_x0_dir.argtypes = [dp, dp, dp]
+        cp = C.POINTER(abi.Camera)
+        d.lldo_edge_point.argtypes = [cp, dp, dp, dp, C.c_int, dp, dp, dp]
+        d.lldo_edge_point_posonly.argtypes = [cp, dp, dp, dp, C.c_int, dp, dp]
+        d.lldo_edge_line.argtypes = [cp, C.c_double, dp, dp, dp, dp, dp, dp, C.POINTER(C.c_int)]
+        d.lldo_edge_line_posonly.argtypes = [cp, C.c_double, dp, dp, dp, dp, dp, dp]
+        d.lldo_reproject_line_point.argtypes = [dp, dp] + [C.c_double] * 5 + [dp, dp]
+        d.lldo_descriptor_distance.argtypes = [abi.c_uint32_p, abi.c_uint32_p]; d.lldo_descriptor_distance.restype = C.c_int
+        d.lldo_l2f32.argtypes = [abi.c_float_p, abi.c_float_p, C.c_int]; d.lldo_l2f32.restype = C.c_double
+        d.lldo_ba_one_step.argtypes = [C.POINTER(abi.BAWindow), C.POINTER(abi.BAParams), C.c_double, dp, dp,
+                                       C.POINTER(C.c_int), dp, dp]
+        d.lldo_ba_one_step.restype = C.c_int
+        for n in ("lldo_se3_exp", "lldo_se3_mul", "lldo_se3_map", "lldo_se3_oplus", "lldo_quat_to_R", "lldo_quat_from_R",
+                  "lldo_huber", "lldo_line_from_x0_dir", "lldo_line_oplus", "lldo_line_to_x0_dir", "lldo_edge_point",
+                  "lldo_edge_point_posonly", "lldo_edge_line", "lldo_edge_line_posonly", "lldo_reproject_line_point"):
+            getattr(d, n).restype = None
+    return _LIB
+
+
+def _d(a):
+    return np.ascontiguousarray(a, np.float64)
+
+
+def _dp(a):
+    return a.ctypes.data_as(abi.c_double_p)
+
+
+def cam_struct(cam):
+    return abi.Camera(*[float(v) for v in cam])
+
+
+# ---- fine-grained entry points for the known-answer tests
+def se3_exp(u):
+    u = _d(u); o = np.zeros(7); lib().dll.lldo_se3_exp(_dp(u), _dp(o)); return o
+
+
+def se3_mul(a, b):
+    a = _d(a); b = _d(b); o = np.zeros(7); lib().dll.lldo_se3_mul(_dp(a), _dp(b), _dp(o)); return o
+
+
+def se3_map(qt, X):
+    qt = _d(qt); X = _d(X); o = np.zeros(3); lib().dll.lldo_se3_map(_dp(qt), _dp(X), _dp(o)); return o
+
+
+def se3_oplus(qt, u):
+    qt = _d(qt); u = _d(u); o = np.zeros(7); lib().dll.lldo_se3_oplus(_dp(qt), _dp(u), _dp(o)); return o
+
+
+def quat_to_R(q):
+    q = _d(q); o = np.zeros(9); lib().dll.lldo_quat_to_R(_dp(q), _dp(o)); return o.reshape(3, 3)
+
+
+def quat_from_R(R):
+    R = _d(R).reshape(9); o = np.zeros(4); lib().dll.lldo_quat_from_R(_dp(R), _dp(o)); return o
+
+
+def huber(delta, e):
+    o = np.zeros(3); lib().dll.lldo_huber(float(delta), float(e), _dp(o)); return o
+
+
+def line_from_x0_dir(X0, d):
+    X0 = _d(X0); d = _d(d); o = np.zeros(5); lib().dll.lldo_line_from_x0_dir(_dp(X0), _dp(d), _dp(o)); return o
+
+
+def line_oplus(l5, u4):
+    l5 = _d(l5); u4 = _d(u4); o = np.zeros(5); lib().dll.lldo_line_oplus(_dp(l5), _dp(u4), _dp(o)); return o
+
+
+def line_to_x0_dir(l5):
+    l5 = _d(l5); a = np.zeros(3); b = np.zeros(3); lib().dll.lldo_line_to_x0_dir(_dp(l5), _dp(a), _dp(b)); return a, b
+
+
+def edge_point(cam, qt, Xw, obs, stereo, jac=True):
+    c = cam_struct(cam); qt = _d(qt); Xw = _d(Xw); obs = _d(obs)
+    e = np.zeros(3); Jp = np.zeros(9); Jc = np.zeros(18)
+    lib().dll.lldo_edge_point(C.byref(c), _dp(qt), _dp(Xw), _dp(obs), int(stereo), _dp(e), _dp(Jp) if jac else None,
+                              _dp(Jc) if jac else None)
+    D = 3 if stereo else 2
+    return e[:D], Jp.reshape(3, 3)[:D], Jc.reshape(3, 6)[:D]
+
+
+def edge_point_posonly(cam, qt, Xw, obs, stereo):
+    c = cam_struct(cam); qt = _d(qt); Xw = _d(Xw); obs = _d(obs)
+    e = np.zeros(3); Jc = np.zeros(18)
+    lib().dll.lldo_edge_point_posonly(C.byref(c), _dp(qt), _dp(Xw), _dp(obs), int(stereo), _dp(e), _dp(Jc))
+    D = 3 if stereo else 2
+    return e[:D], Jc.reshape(3, 6)[:D]
+
+
+def edge_line(cam, bx, qt, l5, seg):
+    c = cam_struct(cam); qt = _d(qt); l5 = _d(l5); seg = _d(seg)
+    e = np.zeros(2); Jl = np.zeros(8); Jc = np.zeros(12); ok = C.c_int(0)
+    lib().dll.lldo_edge_line(C.byref(c), float(bx), _dp(qt), _dp(l5), _dp(seg), _dp(e), _dp(Jl), _dp(Jc), C.byref(ok))
+    return e, Jl.reshape(2, 4), Jc.reshape(2, 6), bool(ok.value)
+
+
+def edge_line_posonly(cam, bx, qt, X1, X2, seg):
+    c = cam_struct(cam); qt = _d(qt); X1 = _d(X1); X2 = _d(X2); seg = _d(seg)
+    e = np.zeros(2); Jc = np.zeros(12)
+    lib().dll.lldo_edge_line_posonly(C.byref(c), float(bx), _dp(qt), _dp(X1), _dp(X2), _dp(seg), _dp(e), _dp(Jc))
+    return e, Jc.reshape(2, 6)
+
+
+def reproject_line_point(X0, ld, px, py, f, cx, cy):
+    X0 = _d(X0); ld = _d(ld); a = np.zeros(1); b = np.zeros(1)
+    lib().dll.lldo_reproject_line_point(_dp(X0), _dp(ld), px, py, f, cx, cy, _dp(a), _dp(b))
+    return float(a[0]), float(b[0])
+
+
+def descriptor_distance(a, b):
+    a = np.ascontiguousarray(a, np.uint32); b = np.ascontiguousarray(b, np.uint32)
+    return lib().dll.lldo_descriptor_distance(a.ctypes.data_as(abi.c_uint32_p), b.ctypes.data_as(abi.c_uint32_p))
+
+
+def l2f32(a, b):
+    a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(b, np.float32)
+    return lib().dll.lldo_l2f32(a.ctypes.data_as(abi.c_float_p), b.ctypes.data_as(abi.c_float_p), a.size)
+
+
+def ba_one_step(win: host.Window, lam: float, gamma=1.0):
+    cw = win.to_c(); p = host.ba_params(lib(), gamma)
+    n = 6 * win.n_free_cams + 3 * win.n_points + 4 * win.n_lines
+    x = np.zeros(n); b = np.zeros(n); nn = C.c_int(0); chi = np.zeros(1); md = np.zeros(1)
+    st = lib().dll.lldo_ba_one_step(C.byref(cw), C.byref(p), float(lam), _dp(x), _dp(b), C.byref(nn), _dp(chi), _dp(md))
+    return st, x[:nn.value], b[:nn.value], float(chi[0]), float(md[0])
+
+
+# ---- protocol-level entry points (same marshalling as the product)
+def local_ba(win: host.Window, gamma=1.0, abort=False, **params):
+    return host.ba_call(lib(), None, win, host.ba_params(lib(), gamma, **params), abort)
+
+
+def pose_opt(frame: host.PoseFrame, gamma=0.5, **params):
+    return host.pose_call(lib(), None, frame, host.pose_params(lib(), gamma, **params))
+
+
+def match_hamming256(q, t, mask=None):
+    return host.hamming_call(lib(), None, q, t, mask)
+
+
+def match_hamming256_csr(q, t, cs, ci):
+    return host.hamming_csr_call(lib(), None, q, t, cs, ci)
+
+
+def match_l2f32(q, t, mask=None):
+    return host.l2_call(lib(), None, q, t, mask)
+
+
+def line_match_greedy(dl, dr, gate, tau):
+    return host.greedy_call(lib(), None, dl, dr, gate, tau)
