@@ -223,5 +223,12 @@ def product() -> Lib:
     """The HIP library.  Raises if it has not been built — the product path never falls back to CPU."""
     global _PRODUCT
     if _PRODUCT is None:
+        # PyTorch wheels bundle their own libamdhip64.so (soname libamdhip64.so.7).  Two HIP runtimes in one process
+        # cannot both own the GPU, so when torch is importable it is loaded first: liblld_amd.so's DT_NEEDED
+        # libamdhip64.so.7 then resolves to the runtime torch already mapped.  C/C++ hosts simply link /opt/rocm's.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         _PRODUCT = Lib(product_library_path(), "lld_")
     return _PRODUCT

@@ -1,0 +1,61 @@
+// lld_common.h — shared host-side plumbing of liblld_amd.so (gfx950 only, no CUDA shims, no CPU fallback).
+#ifndef LLD_COMMON_H
+#define LLD_COMMON_H
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../include/lld_amd.h"
+
+#define LLD_HIP_TRY(expr)                                                                          \
+  do {                                                                                             \
+    hipError_t _e = (expr);                                                                        \
+    if (_e != hipSuccess) {                                                                        \
+      std::fprintf(stderr, "[lld_amd] %s failed at %s:%d: %s\n", #expr, __FILE__, __LINE__,        \
+                   hipGetErrorString(_e));                                                         \
+      return LLD_ERR_HIP;                                                                          \
+    }                                                                                              \
+  } while (0)
+
+struct lld_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int n_cu = 256;
+  // scratch reused by the single-shot entry points (grown on demand, freed with the context)
+  void* scratch = nullptr;
+  size_t scratch_bytes = 0;
+};
+
+// Grow-only device scratch on the context.
+static inline int lld_ctx_scratch(lld_ctx* ctx, size_t bytes, void** out) {
+  if (bytes > ctx->scratch_bytes) {
+    if (ctx->scratch) LLD_HIP_TRY(hipFree(ctx->scratch));
+    ctx->scratch = nullptr; ctx->scratch_bytes = 0;
+    size_t want = bytes + (bytes >> 2) + 4096;
+    LLD_HIP_TRY(hipMalloc(&ctx->scratch, want));
+    ctx->scratch_bytes = want;
+  }
+  *out = ctx->scratch;
+  return LLD_OK;
+}
+
+// Simple bump allocator over one hipMalloc'd slab (all sub-buffers 256-B aligned).
+struct lld_slab {
+  char* base = nullptr;
+  size_t size = 0, used = 0;
+  template <class T>
+  T* take(size_t count) {
+    size_t bytes = (count * sizeof(T) + 255) & ~size_t(255);
+    T* p = reinterpret_cast<T*>(base + used);
+    used += bytes;
+    return p;
+  }
+  static size_t pad(size_t bytes) { return (bytes + 255) & ~size_t(255); }
+};
+
+#endif

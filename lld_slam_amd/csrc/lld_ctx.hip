@@ -1,0 +1,92 @@
+// lld_ctx.hip — context management and the small host-side conversions of the ABI.
+#include "lld_common.h"
+#include "lld_device_math.h"
+
+extern "C" {
+
+const char* lld_status_string(int status) {
+  switch (status) {
+    case LLD_OK: return "ok";
+    case LLD_ERR_INVALID: return "invalid argument";
+    case LLD_ERR_NO_DEVICE: return "no HIP device (this library has no CPU fallback)";
+    case LLD_ERR_HIP: return "HIP runtime error";
+    case LLD_ERR_ALLOC: return "allocation failed";
+    case LLD_ERR_UNSUPPORTED: return "size outside the supported limits";
+    default: return "unknown status";
+  }
+}
+
+int lld_ctx_create(int device, lld_ctx** out) {
+  if (!out) return LLD_ERR_INVALID;
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0 || device < 0 || device >= n) return LLD_ERR_NO_DEVICE;
+  LLD_HIP_TRY(hipSetDevice(device));
+  lld_ctx* ctx = new lld_ctx();
+  ctx->device = device;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->n_cu = prop.multiProcessorCount;
+  if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return LLD_ERR_HIP; }
+  *out = ctx;
+  return LLD_OK;
+}
+
+void lld_ctx_destroy(lld_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
+  if (ctx->scratch) (void)hipFree(ctx->scratch);
+  delete ctx;
+}
+
+void* lld_ctx_stream(lld_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int lld_ctx_synchronize(lld_ctx* ctx) {
+  if (!ctx) return LLD_ERR_INVALID;
+  LLD_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return LLD_OK;
+}
+
+// Converter::toSE3Quat (src/Converter.cc:37-47): float R,t widened, SE3Quat(R,t) = Quaterniond(R) + normalizeRotation.
+void lld_se3_from_tcw_f32(const float* T, double* qt) {
+  lld::Mat3 R;
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) R.m[i][j] = (double)T[i * 4 + j];
+  lld::Pose p;
+  p.q = lld::quat_from_rotation(R);
+  p.t = lld::vec3((double)T[3], (double)T[7], (double)T[11]);
+  lld::pose_normalize(p);
+  lld::pose_store(p, qt);
+}
+
+// Converter::toCvMat(SE3Quat) (src/Converter.cc:49-70): to_homogeneous_matrix narrowed to float.
+void lld_se3_to_tcw_f32(const double* qt, float* T) {
+  const lld::Pose p = lld::pose_load(qt);
+  const lld::Mat3 R = lld::quat_rotation(p.q);
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) T[i * 4 + j] = (float)R.m[i][j];
+  T[3] = (float)p.t.x; T[7] = (float)p.t.y; T[11] = (float)p.t.z;
+  T[12] = 0.f; T[13] = 0.f; T[14] = 0.f; T[15] = 1.f;
+}
+
+// mvInvLevelSigma2 (src/ORBextractor.cc:416-430): cumulative float products.
+void lld_orb_inv_level_sigma2(float scale_factor, int n_levels, float* out) {
+  float sf = 1.0f;
+  for (int i = 0; i < n_levels; i++) {
+    if (i > 0) sf = sf * scale_factor;
+    const float s2 = (i == 0) ? 1.0f : sf * sf;
+    out[i] = 1.0f / s2;
+  }
+}
+
+void lld_ba_params_default(lld_ba_params* p) {
+  if (!p) return;
+  p->gamma = 1.0; p->its_round1 = 5; p->its_round2 = 15; p->ln_filter = 4; p->max_trials = 10;
+  p->pcg_rel_tol = 1e-12; p->pcg_max_iter = 0; p->reserved = 0;
+}
+
+void lld_pose_params_default(lld_pose_params* p) {
+  if (!p) return;
+  p->gamma = 0.5; p->n_rounds = 4; p->its_per_round = 10; p->max_trials = 10; p->reserved = 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,345 @@
+// lld_match.hip — descriptor matching kernels (gfx950).
+//
+//   hamming256_best2   ORBmatcher::DescriptorDistance (src/ORBmatcher.cc:1647-1663) + the best/second-best loops of
+//                      the Search* family (e.g. :76-114): lane <-> query (two queries per lane), the four waves of a
+//                      workgroup split a train tile that is staged through LDS and read back as wave-uniform
+//                      (broadcast) ds_read_b128; xor + v_bcnt accumulate per word; running (best, second) kept as
+//                      packed (distance, order) keys so that the lexicographic minimum reproduces the reference's
+//                      strict '<' ("first candidate wins ties"); cross-wave merge through LDS.
+//   l2f32_best2        LineMatcher::MatchLineDescriptors argmin loops (src/TwoFrameLineMatcher.cc:112, Tracking.cc:1092,
+//                      1532) with the build-defined float-L2 distance (parity unpinned: LBDMOD is not vendored).
+//   line_greedy        sequential masking of TwoFrameLineMatcher::MatchLines (src/TwoFrameLineMatcher.cc:39-67).
+#include "lld_common.h"
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kMatchThreads = 256;             // 4 waves
+constexpr int kQPerBlock = 128;                // 2 queries per lane, all 4 waves see the same 128 queries
+constexpr int kTileRows = 256;                 // train rows staged per LDS tile (8 KiB)
+constexpr unsigned kIdxBits = 22;              // packed key = dist << 22 | order  (order < 4 Mi)
+constexpr unsigned kKeyEmpty = (256u << kIdxBits) | ((1u << kIdxBits) - 1u);
+
+__device__ __forceinline__ void key_update(unsigned key, unsigned& best, unsigned& second) {
+  // lexicographic top-2: second = min(second, max(best, key)); best = min(best, key)
+  second = min(second, max(best, key));
+  best = min(best, key);
+}
+
+__device__ __forceinline__ unsigned hamming8(const uint4& qa, const uint4& qb, const uint4& ta, const uint4& tb) {
+  unsigned d = __popc(qa.x ^ ta.x);
+  d += __popc(qa.y ^ ta.y); d += __popc(qa.z ^ ta.z); d += __popc(qa.w ^ ta.w);
+  d += __popc(qb.x ^ tb.x); d += __popc(qb.y ^ tb.y); d += __popc(qb.z ^ tb.z); d += __popc(qb.w ^ tb.w);
+  return d;
+}
+
+// grid (ceil(nq / 128), batch); block 256.
+__global__ __launch_bounds__(kMatchThreads) void hamming256_best2_kernel(
+    const uint4* __restrict__ q, int nq, const uint4* __restrict__ t, int nt, const uint8_t* __restrict__ mask,
+    int* __restrict__ best_idx, int* __restrict__ best_dist, int* __restrict__ second_idx, int* __restrict__ second_dist) {
+  __shared__ uint4 tile[kTileRows * 2];                       // 8 KiB train tile
+  __shared__ unsigned merge[4][kQPerBlock][2];                // per-wave (best, second) keys, 4 KiB
+  const int pair = blockIdx.y;
+  q += (size_t)pair * nq * 2; t += (size_t)pair * nt * 2;
+  const size_t out_off = (size_t)pair * nq;
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+  const int q0 = blockIdx.x * kQPerBlock + lane, q1 = q0 + kWave;
+  const bool v0 = q0 < nq, v1 = q1 < nq;
+  uint4 a0 = make_uint4(0, 0, 0, 0), b0 = a0, a1 = a0, b1 = a0;
+  if (v0) { a0 = q[q0 * 2]; b0 = q[q0 * 2 + 1]; }
+  if (v1) { a1 = q[q1 * 2]; b1 = q[q1 * 2 + 1]; }
+  unsigned best0 = kKeyEmpty, sec0 = kKeyEmpty, best1 = kKeyEmpty, sec1 = kKeyEmpty;
+  const uint8_t* m0 = mask ? mask + ((size_t)pair * nq + (v0 ? q0 : 0)) * nt : nullptr;
+  const uint8_t* m1 = mask ? mask + ((size_t)pair * nq + (v1 ? q1 : 0)) * nt : nullptr;
+
+  for (int base = 0; base < nt; base += kTileRows) {
+    const int rows = min(kTileRows, nt - base);
+    __syncthreads();                                           // previous tile fully consumed
+    for (int i = threadIdx.x; i < rows * 2; i += kMatchThreads) tile[i] = t[(size_t)base * 2 + i];   // 16 B / lane, coalesced
+    __syncthreads();
+    // wave w takes rows w, w+4, ... of the tile; LDS reads are wave-uniform (broadcast, conflict-free)
+    for (int r = wave; r < rows; r += 4) {
+      const uint4 ta = tile[r * 2], tb = tile[r * 2 + 1];
+      const unsigned j = (unsigned)(base + r);
+      unsigned k0 = (hamming8(a0, b0, ta, tb) << kIdxBits) | j;
+      unsigned k1 = (hamming8(a1, b1, ta, tb) << kIdxBits) | j;
+      if (mask) {
+        if (!m0[j]) k0 = kKeyEmpty;
+        if (!m1[j]) k1 = kKeyEmpty;
+      }
+      key_update(k0, best0, sec0);
+      key_update(k1, best1, sec1);
+    }
+  }
+  merge[wave][lane][0] = best0; merge[wave][lane][1] = sec0;
+  merge[wave][lane + kWave][0] = best1; merge[wave][lane + kWave][1] = sec1;
+  __syncthreads();
+  if (threadIdx.x < kQPerBlock) {
+    const int qi = blockIdx.x * kQPerBlock + threadIdx.x;
+    if (qi < nq) {
+      unsigned b = kKeyEmpty, s = kKeyEmpty;
+      for (int w = 0; w < 4; w++) { key_update(merge[w][threadIdx.x][0], b, s); key_update(merge[w][threadIdx.x][1], b, s); }
+      const unsigned idx_mask = (1u << kIdxBits) - 1u;
+      best_idx[out_off + qi] = (b == kKeyEmpty) ? -1 : (int)(b & idx_mask);
+      best_dist[out_off + qi] = (int)(b >> kIdxBits);
+      second_idx[out_off + qi] = (s == kKeyEmpty) ? -1 : (int)(s & idx_mask);
+      second_dist[out_off + qi] = (int)(s >> kIdxBits);
+    }
+  }
+}
+
+// Candidate-list form: one lane per query walks its own list (Frame::GetFeaturesInArea / BoW node order); the list
+// position is the tie-break key, the output is the train index.
+__global__ __launch_bounds__(256) void hamming256_csr_kernel(
+    const uint4* __restrict__ q, int nq, const uint4* __restrict__ t, const int* __restrict__ cand_start, const int* __restrict__ cand_idx,
+    int* __restrict__ best_idx, int* __restrict__ best_dist, int* __restrict__ second_idx, int* __restrict__ second_dist) {
+  const int qi = blockIdx.x * blockDim.x + threadIdx.x;
+  if (qi >= nq) return;
+  const uint4 a = q[qi * 2], b = q[qi * 2 + 1];
+  int bd = 256, bi = -1, sd = 256, si = -1;
+  const int s = cand_start[qi], e = cand_start[qi + 1];
+  for (int k = s; k < e; k++) {
+    const int j = cand_idx[k];
+    const int d = (int)hamming8(a, b, t[j * 2], t[j * 2 + 1]);
+    if (d < bd) { sd = bd; si = bi; bd = d; bi = j; }
+    else if (d < sd) { sd = d; si = j; }
+  }
+  best_idx[qi] = bi; best_dist[qi] = bd; second_idx[qi] = si; second_dist[qi] = sd;
+}
+
+// ------------------------------------------------------------------ float L2 (LBD)
+// d = sqrt( sum_i (double)(a_i - b_i)^2 ), float difference, double accumulation in ascending i (the product of two
+// floats is exact in double, so the fused multiply-add below rounds exactly like mul-then-add on the CPU).
+constexpr int kL2Threads = 256;
+constexpr int kL2TileRows = 32;
+
+template <int DIM_MAX>
+__global__ __launch_bounds__(kL2Threads) void l2f32_best2_kernel(
+    const float* __restrict__ q, int nq, const float* __restrict__ t, int nt, int dim, const uint8_t* __restrict__ mask,
+    int* __restrict__ best_idx, double* __restrict__ best_dist, int* __restrict__ second_idx, double* __restrict__ second_dist,
+    double* __restrict__ dist_matrix /* optional [nq][nt] */) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* tile = reinterpret_cast<float*>(smem);                        // [kL2TileRows][dim]
+  const int pair = blockIdx.y;
+  q += (size_t)pair * nq * dim; t += (size_t)pair * nt * dim;
+  const size_t out_off = (size_t)pair * nq;
+  const int qi = blockIdx.x * kL2Threads + threadIdx.x;
+  const bool valid = qi < nq;
+  float qa[DIM_MAX];
+#pragma unroll
+  for (int i = 0; i < DIM_MAX; i++) qa[i] = (valid && i < dim) ? q[(size_t)qi * dim + i] : 0.f;
+  double bd = 1.7976931348623157e308, sd = 1.7976931348623157e308;
+  int bi = -1, si = -1;
+  for (int base = 0; base < nt; base += kL2TileRows) {
+    const int rows = min(kL2TileRows, nt - base);
+    __syncthreads();
+    for (int i = threadIdx.x; i < rows * dim; i += kL2Threads) tile[i] = t[(size_t)base * dim + i];
+    __syncthreads();
+    for (int r = 0; r < rows; r++) {
+      const float* tr = tile + r * dim;
+      double acc = 0.0;
+#pragma unroll
+      for (int i = 0; i < DIM_MAX; i++) {
+        if (i < dim) { const float d = qa[i] - tr[i]; acc = fma((double)d, (double)d, acc); }
+      }
+      const double dist = sqrt(acc);
+      const int j = base + r;
+      if (valid) {
+        if (dist_matrix) dist_matrix[((size_t)pair * nq + qi) * nt + j] = dist;
+        const bool cand = !mask || mask[((size_t)pair * nq + qi) * nt + j];
+        if (cand) {
+          if (dist < bd) { sd = bd; si = bi; bd = dist; bi = j; }
+          else if (dist < sd) { sd = dist; si = j; }
+        }
+      }
+    }
+  }
+  if (valid) {
+    best_idx[out_off + qi] = bi; best_dist[out_off + qi] = bd; second_idx[out_off + qi] = si; second_dist[out_off + qi] = sd;
+  }
+}
+
+// Sequential resolve of TwoFrameLineMatcher::MatchLines on one wavefront: for each left line j in order, the 64 lanes
+// stride over the right lines, keep the lexicographic (distance, index) minimum among untaken, gated candidates below
+// tau, and a wavefront argmin (shuffle butterfly) picks the winner, which is then masked.
+__global__ __launch_bounds__(64) void line_greedy_kernel(const double* __restrict__ dist, int nq, int nt, const uint8_t* __restrict__ gate,
+                                                        double tau, int* __restrict__ matches, double* __restrict__ match_dist,
+                                                        uint8_t* __restrict__ taken) {
+  const int lane = threadIdx.x;
+  for (int i = lane; i < nt; i += 64) taken[i] = 0;
+  __syncthreads();
+  for (int j = 0; j < nq; j++) {
+    double bd = 1.7976931348623157e308; int bi = 0x7fffffff;
+    for (int oi = lane; oi < nt; oi += 64) {
+      if (taken[oi]) continue;
+      if (gate && !gate[(size_t)j * nt + oi]) continue;
+      const double d = dist[(size_t)j * nt + oi];
+      if (d < tau && d < bd) { bd = d; bi = oi; }       // ascending oi per lane: strict '<' keeps the lowest index
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      const double od = __shfl_xor(bd, off); const int oidx = __shfl_xor(bi, off);
+      if (od < bd || (od == bd && oidx < bi)) { bd = od; bi = oidx; }
+    }
+    if (lane == 0) {
+      const bool hit = bi != 0x7fffffff;
+      matches[j] = hit ? bi : -1;
+      if (match_dist) match_dist[j] = hit ? bd : 1.7976931348623157e308;
+      if (hit) taken[bi] = 1;
+    }
+    __syncthreads();
+  }
+}
+
+int launch_hamming(lld_ctx* ctx, int batch, const uint32_t* q, int nq, const uint32_t* t, int nt, const uint8_t* mask,
+                   int* bi, int* bd, int* si, int* sd) {
+  if (nt >= (1 << kIdxBits)) return LLD_ERR_UNSUPPORTED;
+  dim3 grid((nq + kQPerBlock - 1) / kQPerBlock, batch);
+  hipLaunchKernelGGL(hamming256_best2_kernel, grid, dim3(kMatchThreads), 0, ctx->stream, reinterpret_cast<const uint4*>(q), nq,
+                     reinterpret_cast<const uint4*>(t), nt, mask, bi, bd, si, sd);
+  LLD_HIP_TRY(hipGetLastError());
+  return LLD_OK;
+}
+
+int launch_l2(lld_ctx* ctx, int batch, const float* q, int nq, const float* t, int nt, int dim, const uint8_t* mask,
+              int* bi, double* bd, int* si, double* sd, double* dist_matrix) {
+  dim3 grid((nq + kL2Threads - 1) / kL2Threads, batch);
+  const size_t lds = (size_t)kL2TileRows * dim * sizeof(float);
+#define LLD_L2_LAUNCH(N)                                                                                                 \
+  hipLaunchKernelGGL(l2f32_best2_kernel<N>, grid, dim3(kL2Threads), lds, ctx->stream, q, nq, t, nt, dim, mask, bi, bd, si, sd, \
+                     dist_matrix)
+  if (dim <= 32) LLD_L2_LAUNCH(32);
+  else if (dim <= 72) LLD_L2_LAUNCH(72);
+  else if (dim <= 128) LLD_L2_LAUNCH(128);
+  else return LLD_ERR_UNSUPPORTED;
+#undef LLD_L2_LAUNCH
+  LLD_HIP_TRY(hipGetLastError());
+  return LLD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int lld_match_hamming256(lld_ctx* ctx, const uint32_t* q, int nq, const uint32_t* t, int nt, const uint8_t* mask,
+                         int32_t* best_idx, int32_t* best_dist, int32_t* second_idx, int32_t* second_dist) {
+  if (!ctx || !q || !t || nq < 0 || nt < 0 || !best_idx || !best_dist || !second_idx || !second_dist) return LLD_ERR_INVALID;
+  if (nq == 0) return LLD_OK;
+  LLD_HIP_TRY(hipSetDevice(ctx->device));
+  const size_t qb = lld_slab::pad((size_t)nq * 32), tb = lld_slab::pad((size_t)nt * 32 + 32), mb = mask ? lld_slab::pad((size_t)nq * nt) : 0;
+  const size_t ob = lld_slab::pad((size_t)nq * 4);
+  void* base; int st = lld_ctx_scratch(ctx, qb + tb + mb + 4 * ob, &base); if (st) return st;
+  lld_slab s; s.base = (char*)base;
+  uint32_t* dq = s.take<uint32_t>((size_t)nq * 8); uint32_t* dt = s.take<uint32_t>((size_t)nt * 8 + 8);
+  uint8_t* dm = mask ? s.take<uint8_t>((size_t)nq * nt) : nullptr;
+  int *dbi = s.take<int>(nq), *dbd = s.take<int>(nq), *dsi = s.take<int>(nq), *dsd = s.take<int>(nq);
+  LLD_HIP_TRY(hipMemcpyAsync(dq, q, (size_t)nq * 32, hipMemcpyHostToDevice, ctx->stream));
+  if (nt) LLD_HIP_TRY(hipMemcpyAsync(dt, t, (size_t)nt * 32, hipMemcpyHostToDevice, ctx->stream));
+  if (mask) LLD_HIP_TRY(hipMemcpyAsync(dm, mask, (size_t)nq * nt, hipMemcpyHostToDevice, ctx->stream));
+  st = launch_hamming(ctx, 1, dq, nq, dt, nt, dm, dbi, dbd, dsi, dsd); if (st) return st;
+  LLD_HIP_TRY(hipMemcpyAsync(best_idx, dbi, (size_t)nq * 4, hipMemcpyDeviceToHost, ctx->stream));
+  LLD_HIP_TRY(hipMemcpyAsync(best_dist, dbd, (size_t)nq * 4, hipMemcpyDeviceToHost, ctx->stream));
+  LLD_HIP_TRY(hipMemcpyAsync(second_idx, dsi, (size_t)nq * 4, hipMemcpyDeviceToHost, ctx->stream));
+  LLD_HIP_TRY(hipMemcpyAsync(second_dist, dsd, (size_t)nq * 4, hipMemcpyDeviceToHost, ctx->stream));
+  LLD_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return LLD_OK;
+}
+
+int lld_match_hamming256_csr(lld_ctx* ctx, const uint32_t* q, int nq, const uint32_t* t, int nt, const int32_t* cand_start,
+                             const int32_t* cand_idx, int32_t* best_idx, int32_t* best_dist, int32_t* second_idx, int32_t* second_dist) {
+  if (!ctx || !q || !t || !cand_start || !cand_idx || nq < 0 || nt < 0) return LLD_ERR_INVALID;
+  if (nq == 0) return LLD_OK;
+  const int ncand = cand_start[nq];
+  for (int i = 0; i < nq; i++) if (cand_start[i + 1] < cand_start[i]) return LLD_ERR_INVALID;
+  for (int k = 0; k < ncand; k++) if (cand_idx[k] < 0 || cand_idx[k] >= nt) return LLD_ERR_INVALID;
+  LLD_HIP_TRY(hipSetDevice(ctx->device));
+  const size_t need = lld_slab::pad((size_t)nq * 32) + lld_slab::pad((size_t)nt * 32 + 32) + lld_slab::pad((size_t)(nq + 1) * 4) +
+                      lld_slab::pad((size_t)ncand * 4 + 4) + 4 * lld_slab::pad((size_t)nq * 4);
+  void* base; int st = lld_ctx_scratch(ctx, need, &base); if (st) return st;
+  lld_slab s; s.base = (char*)base;
+  uint32_t* dq = s.take<uint32_t>((size_t)nq * 8); uint32_t* dt = s.take<uint32_t>((size_t)nt * 8 + 8);
+  int* dcs = s.take<int>(nq + 1); int* dci = s.take<int>(ncand + 1);
+  int *dbi = s.take<int>(nq), *dbd = s.take<int>(nq), *dsi = s.take<int>(nq), *dsd = s.take<int>(nq);
+  LLD_HIP_TRY(hipMemcpyAsync(dq, q, (size_t)nq * 32, hipMemcpyHostToDevice, ctx->stream));
+  if (nt) LLD_HIP_TRY(hipMemcpyAsync(dt, t, (size_t)nt * 32, hipMemcpyHostToDevice, ctx->stream));
+  LLD_HIP_TRY(hipMemcpyAsync(dcs, cand_start, (size_t)(nq + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+  if (ncand) LLD_HIP_TRY(hipMemcpyAsync(dci, cand_idx, (size_t)ncand * 4, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(hamming256_csr_kernel, dim3((nq + 255) / 256), dim3(256), 0, ctx->stream, reinterpret_cast<const uint4*>(dq), nq,
+                     reinterpret_cast<const uint4*>(dt), dcs, dci, dbi, dbd, dsi, dsd);
+  LLD_HIP_TRY(hipGetLastError());
+  LLD_HIP_TRY(hipMemcpyAsync(best_idx, dbi, (size_t)nq * 4, hipMemcpyDeviceToHost, ctx->stream));
+  LLD_HIP_TRY(hipMemcpyAsync(best_dist, dbd, (size_t)nq * 4, hipMemcpyDeviceToHost, ctx->stream));
+  LLD_HIP_TRY(hipMemcpyAsync(second_idx, dsi, (size_t)nq * 4, hipMemcpyDeviceToHost, ctx->stream));
+  LLD_HIP_TRY(hipMemcpyAsync(second_dist, dsd, (size_t)nq * 4, hipMemcpyDeviceToHost, ctx->stream));
+  LLD_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return LLD_OK;
+}
+
+int lld_match_hamming256_batch_dev(lld_ctx* ctx, int batch, const uint32_t* q_dev, int nq, const uint32_t* t_dev, int nt,
+                                   int32_t* best_idx_dev, int32_t* best_dist_dev, int32_t* second_idx_dev, int32_t* second_dist_dev) {
+  if (!ctx || batch <= 0 || nq <= 0 || nt < 0 || !q_dev || !t_dev) return LLD_ERR_INVALID;
+  LLD_HIP_TRY(hipSetDevice(ctx->device));
+  return launch_hamming(ctx, batch, q_dev, nq, t_dev, nt, nullptr, best_idx_dev, best_dist_dev, second_idx_dev, second_dist_dev);
+}
+
+int lld_match_l2f32(lld_ctx* ctx, const float* q, int nq, const float* t, int nt, int dim, const uint8_t* mask,
+                    int32_t* best_idx, double* best_dist, int32_t* second_idx, double* second_dist) {
+  if (!ctx || !q || !t || nq < 0 || nt < 0 || dim <= 0) return LLD_ERR_INVALID;
+  if (dim > 128) return LLD_ERR_UNSUPPORTED;
+  if (nq == 0) return LLD_OK;
+  LLD_HIP_TRY(hipSetDevice(ctx->device));
+  const size_t need = lld_slab::pad((size_t)nq * dim * 4) + lld_slab::pad((size_t)nt * dim * 4 + 16) + (mask ? lld_slab::pad((size_t)nq * nt) : 0) +
+                      2 * lld_slab::pad((size_t)nq * 4) + 2 * lld_slab::pad((size_t)nq * 8);
+  void* base; int st = lld_ctx_scratch(ctx, need, &base); if (st) return st;
+  lld_slab s; s.base = (char*)base;
+  float* dq = s.take<float>((size_t)nq * dim); float* dt = s.take<float>((size_t)nt * dim + 4);
+  uint8_t* dm = mask ? s.take<uint8_t>((size_t)nq * nt) : nullptr;
+  int *dbi = s.take<int>(nq), *dsi = s.take<int>(nq); double *dbd = s.take<double>(nq), *dsd = s.take<double>(nq);
+  LLD_HIP_TRY(hipMemcpyAsync(dq, q, (size_t)nq * dim * 4, hipMemcpyHostToDevice, ctx->stream));
+  if (nt) LLD_HIP_TRY(hipMemcpyAsync(dt, t, (size_t)nt * dim * 4, hipMemcpyHostToDevice, ctx->stream));
+  if (mask) LLD_HIP_TRY(hipMemcpyAsync(dm, mask, (size_t)nq * nt, hipMemcpyHostToDevice, ctx->stream));
+  st = launch_l2(ctx, 1, dq, nq, dt, nt, dim, dm, dbi, dbd, dsi, dsd, nullptr); if (st) return st;
+  LLD_HIP_TRY(hipMemcpyAsync(best_idx, dbi, (size_t)nq * 4, hipMemcpyDeviceToHost, ctx->stream));
+  LLD_HIP_TRY(hipMemcpyAsync(best_dist, dbd, (size_t)nq * 8, hipMemcpyDeviceToHost, ctx->stream));
+  LLD_HIP_TRY(hipMemcpyAsync(second_idx, dsi, (size_t)nq * 4, hipMemcpyDeviceToHost, ctx->stream));
+  LLD_HIP_TRY(hipMemcpyAsync(second_dist, dsd, (size_t)nq * 8, hipMemcpyDeviceToHost, ctx->stream));
+  LLD_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return LLD_OK;
+}
+
+int lld_match_l2f32_batch_dev(lld_ctx* ctx, int batch, const float* q_dev, int nq, const float* t_dev, int nt, int dim,
+                              int32_t* best_idx_dev, double* best_dist_dev, int32_t* second_idx_dev, double* second_dist_dev) {
+  if (!ctx || batch <= 0 || nq <= 0 || nt < 0 || dim <= 0) return LLD_ERR_INVALID;
+  if (dim > 128) return LLD_ERR_UNSUPPORTED;
+  LLD_HIP_TRY(hipSetDevice(ctx->device));
+  return launch_l2(ctx, batch, q_dev, nq, t_dev, nt, dim, nullptr, best_idx_dev, best_dist_dev, second_idx_dev, second_dist_dev, nullptr);
+}
+
+int lld_line_match_greedy(lld_ctx* ctx, const float* dl, int nq, const float* dr, int nt, int dim, const uint8_t* gate, double tau,
+                          int32_t* matches, double* match_dist) {
+  if (!ctx || !dl || !dr || nq < 0 || nt < 0 || dim <= 0 || !matches) return LLD_ERR_INVALID;
+  if (dim > 128) return LLD_ERR_UNSUPPORTED;
+  if (nq == 0) return LLD_OK;
+  if (nt == 0) { for (int i = 0; i < nq; i++) { matches[i] = -1; if (match_dist) match_dist[i] = 1.7976931348623157e308; } return LLD_OK; }
+  LLD_HIP_TRY(hipSetDevice(ctx->device));
+  const size_t need = lld_slab::pad((size_t)nq * dim * 4) + lld_slab::pad((size_t)nt * dim * 4 + 16) + lld_slab::pad((size_t)nq * nt) +
+                      lld_slab::pad((size_t)nq * nt * 8) + 2 * lld_slab::pad((size_t)nq * 4) + 3 * lld_slab::pad((size_t)nq * 8) + lld_slab::pad(nt);
+  void* base; int st = lld_ctx_scratch(ctx, need, &base); if (st) return st;
+  lld_slab s; s.base = (char*)base;
+  float* dq = s.take<float>((size_t)nq * dim); float* dt = s.take<float>((size_t)nt * dim + 4);
+  uint8_t* dg = s.take<uint8_t>((size_t)nq * nt);
+  double* dmat = s.take<double>((size_t)nq * nt);
+  int *dbi = s.take<int>(nq), *dsi = s.take<int>(nq); double *dbd = s.take<double>(nq), *dsd = s.take<double>(nq), *dmd = s.take<double>(nq);
+  uint8_t* dtaken = s.take<uint8_t>(nt);
+  LLD_HIP_TRY(hipMemcpyAsync(dq, dl, (size_t)nq * dim * 4, hipMemcpyHostToDevice, ctx->stream));
+  LLD_HIP_TRY(hipMemcpyAsync(dt, dr, (size_t)nt * dim * 4, hipMemcpyHostToDevice, ctx->stream));
+  if (gate) LLD_HIP_TRY(hipMemcpyAsync(dg, gate, (size_t)nq * nt, hipMemcpyHostToDevice, ctx->stream));
+  st = launch_l2(ctx, 1, dq, nq, dt, nt, dim, nullptr, dbi, dbd, dsi, dsd, dmat); if (st) return st;
+  hipLaunchKernelGGL(line_greedy_kernel, dim3(1), dim3(64), 0, ctx->stream, dmat, nq, nt, gate ? dg : nullptr, tau, dbi, dmd, dtaken);
+  LLD_HIP_TRY(hipGetLastError());
+  LLD_HIP_TRY(hipMemcpyAsync(matches, dbi, (size_t)nq * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (match_dist) LLD_HIP_TRY(hipMemcpyAsync(match_dist, dmd, (size_t)nq * 8, hipMemcpyDeviceToHost, ctx->stream));
+  LLD_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return LLD_OK;
+}
+
+}  // extern "C"

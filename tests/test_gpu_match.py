@@ -1,0 +1,125 @@
+"""GPU parity: descriptor matching through the C ABI vs the CPU oracle — indices and integer distances bit-exact."""
+import numpy as np
+import pytest
+
+from lld_slam_amd import ORBmatcher, TwoFrameLineMatcher, host, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _same(a, b):
+    for x, y in zip(a, b):
+        np.testing.assert_array_equal(x, y)
+
+
+@pytest.mark.parametrize("nq,nt", [(2000, 2000), (1, 1), (130, 7), (64, 257), (129, 1025)])
+def test_hamming_brute_force_bit_exact(gpu_ctx, oracle, nq, nt):
+    q, t = synth.make_match_orb(1, nq, nt, n_corr=int(0.8 * min(nq, nt)), n_dup=16)
+    _same(ORBmatcher(gpu_ctx).BestTwo(q, t), oracle.match_hamming256(q, t))
+
+
+def test_hamming_ties_pick_the_lowest_index(gpu_ctx, oracle):
+    rng = np.random.default_rng(5)
+    q = rng.integers(0, 2 ** 32, (70, 8), dtype=np.uint64).astype(np.uint32)
+    t = np.repeat(q[:5], 60, axis=0)                       # every query 0..4 has 60 exact duplicates
+    t = t[rng.permutation(t.shape[0])]
+    bi, bd, si, sd = ORBmatcher(gpu_ctx).BestTwo(q, t)
+    _same((bi, bd, si, sd), oracle.match_hamming256(q, t))
+    for i in range(5):
+        dup = np.nonzero((t == q[i]).all(1))[0]
+        assert bi[i] == dup[0] and si[i] == dup[1] and bd[i] == 0 and sd[i] == 0
+
+
+def test_hamming_extremes(gpu_ctx, oracle):
+    z = np.zeros((3, 8), np.uint32); o = np.full((2, 8), 0xFFFFFFFF, np.uint32)
+    bi, bd, si, sd = ORBmatcher(gpu_ctx).BestTwo(z, o)
+    assert bd.tolist() == [256] * 3 and bi.tolist() == [0] * 3 and si.tolist() == [1] * 3
+    # no train rows at all -> unmatched sentinel of the reference (bestDist = 256, no index)
+    bi, bd, si, sd = ORBmatcher(gpu_ctx).BestTwo(z, np.zeros((0, 8), np.uint32))
+    assert bi.tolist() == [-1] * 3 and bd.tolist() == [256] * 3
+
+
+def test_hamming_mask(gpu_ctx, oracle):
+    q, t = synth.make_match_orb(2, 300, 500, n_corr=200)
+    rng = np.random.default_rng(6)
+    mask = (rng.random((300, 500)) < 0.05).astype(np.uint8)
+    mask[7] = 0                                             # a query without candidates
+    res = ORBmatcher(gpu_ctx).BestTwo(q, t, mask)
+    _same(res, oracle.match_hamming256(q, t, mask))
+    assert res[0][7] == -1 and res[1][7] == 256
+
+
+def test_hamming_candidate_lists_first_in_list_wins(gpu_ctx, oracle):
+    q, t = synth.make_match_orb(3, 400, 600, n_corr=300)
+    t[10] = t[500]                                          # duplicate rows: list order decides
+    rng = np.random.default_rng(7)
+    lens = rng.integers(0, 40, 400)
+    cs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    ci = rng.integers(0, 600, cs[-1]).astype(np.int32)
+    ci[cs[3]:cs[3] + 2] = [500, 10] if lens[3] >= 2 else ci[cs[3]:cs[3] + 2]
+    res = ORBmatcher(gpu_ctx).BestTwoCandidates(q, t, cs, ci)
+    _same(res, oracle.match_hamming256_csr(q, t, cs, ci))
+
+
+def test_orb_accept_rule_matches_reference_semantics(gpu_ctx, oracle):
+    q, t = synth.make_match_orb(4, 500, 500, n_corr=400)
+    m = ORBmatcher(gpu_ctx, nnratio=0.7)
+    bi, bd, si, sd = m.BestTwo(q, t)
+    acc = m.AcceptByRatio(bi, bd, sd, ORBmatcher.TH_LOW)
+    obi, obd, osi, osd = oracle.match_hamming256(q, t)
+    exp = np.where((obd <= 50) & (obd.astype(np.float32) < np.float32(0.7) * osd.astype(np.float32)), obi, -1)
+    np.testing.assert_array_equal(acc, exp)
+    assert (acc >= 0).sum() > 300
+
+
+@pytest.mark.parametrize("nq,nt,dim", [(300, 300, 72), (5, 3, 72), (257, 33, 32), (64, 100, 128)])
+def test_l2_best2_bit_exact(gpu_ctx, oracle, nq, nt, dim):
+    q, t = synth.make_match_lbd(1, nq, nt, dim, n_corr=int(0.8 * min(nq, nt)))
+    g = TwoFrameLineMatcher(gpu_ctx, 2.0).BestTwo(q, t)
+    o = oracle.match_l2f32(q, t)
+    np.testing.assert_array_equal(g[0], o[0]); np.testing.assert_array_equal(g[2], o[2])
+    # distances: identical accumulation order; the final sqrt is correctly rounded on both sides
+    np.testing.assert_array_equal(g[1], o[1]); np.testing.assert_array_equal(g[3], o[3])
+
+
+def test_l2_mask(gpu_ctx, oracle):
+    q, t = synth.make_match_lbd(2, 100, 120, 72, n_corr=80)
+    mask = (np.random.default_rng(8).random((100, 120)) < 0.1).astype(np.uint8)
+    g = TwoFrameLineMatcher(gpu_ctx, 2.0).BestTwo(q, t, mask)
+    o = oracle.match_l2f32(q, t, mask)
+    np.testing.assert_array_equal(g[0], o[0]); np.testing.assert_array_equal(g[2], o[2])
+
+
+def test_line_greedy_matches_sequential_reference(gpu_ctx, oracle):
+    q, t = synth.make_match_lbd(3, 300, 300, 72, n_corr=240)
+    t[5] = t[17]                                            # duplicates: order dependence matters (hazard 12)
+    q[40] = q[41]
+    rng = np.random.default_rng(9)
+    gate = (rng.random((300, 300)) < 0.6).astype(np.uint8)
+    for tau in (2.0, 0.5):
+        gm, gd = TwoFrameLineMatcher(gpu_ctx, tau).MatchLines(q, t, gate)
+        om, od = oracle.line_match_greedy(q, t, gate, tau)
+        np.testing.assert_array_equal(gm, om)
+        np.testing.assert_array_equal(gd[gm >= 0], od[om >= 0])
+        used = gm[gm >= 0]
+        assert len(set(used.tolist())) == used.size          # each right line taken at most once
+    gm, _ = TwoFrameLineMatcher(gpu_ctx, 2.0).MatchLines(q, t, None)
+    np.testing.assert_array_equal(gm, oracle.line_match_greedy(q, t, None, 2.0)[0])
+
+
+def test_batched_hamming_device_entry_point(gpu_ctx, oracle):
+    import torch
+    B, nq, nt = 6, 333, 450
+    qs, ts = zip(*[synth.make_match_orb(10 + b, nq, nt, n_corr=300) for b in range(B)])
+    dev = torch.device("cuda", gpu_ctx.device)
+    q = torch.from_numpy(np.stack(qs).view(np.int32)).to(dev); t = torch.from_numpy(np.stack(ts).view(np.int32)).to(dev)
+    outs = [torch.empty((B, nq), dtype=torch.int32, device=dev) for _ in range(4)]
+    torch.cuda.synchronize()
+    st = gpu_ctx.lib.fn("match_hamming256_batch_dev")(gpu_ctx.handle, B, q.data_ptr(), nq, t.data_ptr(), nt,
+                                                      *[o.data_ptr() for o in outs])
+    assert st == 0
+    gpu_ctx.synchronize()
+    for b in range(B):
+        exp = oracle.match_hamming256(qs[b], ts[b])
+        for o, e in zip(outs, exp):
+            np.testing.assert_array_equal(o[b].cpu().numpy(), e)
