@@ -10,9 +10,4 @@ int lld_ba_batch_result_records(lld_ba_batch*, void**, uint64_t*) { return LLD_E
 int lld_ba_batch_phase_ms(lld_ba_batch*, double*) { return LLD_ERR_UNSUPPORTED; }
 int lld_ba_batch_kernel_stats(lld_ba_batch*, int64_t*, double*) { return LLD_ERR_UNSUPPORTED; }
 void lld_ba_batch_destroy(lld_ba_batch*) {}
-int lld_pose_opt(lld_ctx*, const lld_pose_problem*, const lld_pose_params*, lld_pose_result*) { return LLD_ERR_UNSUPPORTED; }
-int lld_pose_batch_create(lld_ctx*, int, const lld_pose_problem*, const lld_pose_params*, lld_pose_batch**) { return LLD_ERR_UNSUPPORTED; }
-int lld_pose_batch_solve(lld_pose_batch*) { return LLD_ERR_UNSUPPORTED; }
-int lld_pose_batch_download(lld_pose_batch*, int, lld_pose_result*) { return LLD_ERR_UNSUPPORTED; }
-void lld_pose_batch_destroy(lld_pose_batch*) {}
 }
