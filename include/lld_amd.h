@@ -162,12 +162,14 @@ int  lld_ba_batch_stats(lld_ba_batch* batch, lld_ba_stats* stats /* [n_windows] 
 /* Device buffer holding the fixed-stride result records of all windows (for the RCCL
  * gather): returns base pointer and record stride in bytes. */
 int  lld_ba_batch_result_records(lld_ba_batch* batch, void** dev_ptr, uint64_t* stride_bytes);
-/* Per-phase device time of the last solve in ms: [0] linearise+Schur, [1] PCG,
- * [2] back-substitution+update+chi2, [3] LM control / classification, [4] total.
+/* Per-phase device time of the last solve in ms (HIP events on the context's stream):
+ * [0] linearise (residuals + Jacobians + Hll/Hpl/Hpp), [1] Schur complement, [2] PCG on the reduced system,
+ * [3] back-substitution + update + chi2, [4] LM control / outlier classification, [5] whole solve.
  * Mirrors G2OBatchStatistics (core/batch_stats.h:41-70). */
-int  lld_ba_batch_phase_ms(lld_ba_batch* batch, double* ms5);
-/* Launch counts and HIP-event time of the dominant kernel (linearise+Schur) in the last solve. */
-int  lld_ba_batch_kernel_stats(lld_ba_batch* batch, int64_t* launches, double* total_ms);
+#define LLD_BA_N_PHASES 6
+int  lld_ba_batch_phase_ms(lld_ba_batch* batch, double* ms6);
+/* Launch count and summed HIP-event time of one kernel family in the last solve; `kernel` uses the phase ids 0..4. */
+int  lld_ba_batch_kernel_stats(lld_ba_batch* batch, int kernel, int64_t* launches, double* total_ms);
 void lld_ba_batch_destroy(lld_ba_batch* batch);
 
 /* ================================================================== pose optimisation

@@ -202,7 +202,7 @@ class Lib:
             f("ba_batch_result_records").argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_uint64)]
             f("ba_batch_result_records").restype = C.c_int
             f("ba_batch_phase_ms").argtypes = [vp, c_double_p]; f("ba_batch_phase_ms").restype = C.c_int
-            f("ba_batch_kernel_stats").argtypes = [vp, C.POINTER(C.c_int64), c_double_p]
+            f("ba_batch_kernel_stats").argtypes = [vp, C.c_int, C.POINTER(C.c_int64), c_double_p]
             f("ba_batch_kernel_stats").restype = C.c_int
             f("ba_batch_destroy").argtypes = [vp]; f("ba_batch_destroy").restype = None
             f("pose_batch_create").argtypes = [vp, C.c_int, C.POINTER(PoseProblem), C.POINTER(PoseParams), C.POINTER(vp)]

@@ -1,0 +1,439 @@
+// lld_ba.hip — host side of the batched local bundle adjustment: HBM layout, upload, the super-step launch loop and
+// read-back.  Kernels live in lld_ba_kernels.h.  Stands in for Optimizer::LocalBundleAdjustment (src/Optimizer.cc:936-1388).
+#include <algorithm>
+#include <cmath>
+
+#include "lld_ba_kernels.h"
+
+using namespace lldba;
+
+namespace {
+constexpr int kNumPhases = 5;
+constexpr int kMaxSuperSteps = 512;      // hard stop: 2 rounds x 15 iterations x 10 trials is the protocol's own bound (300)
+}
+
+struct lld_ba_batch {
+  lld_ctx* ctx = nullptr;
+  int n_windows = 0;
+  lld_ba_params params;
+  std::vector<BAWin> h_wins;
+  std::vector<RowGroup> h_rgs;
+  std::vector<const lld_ba_window*> unused;
+  void* slab = nullptr; size_t slab_bytes = 0;
+  BAArrays A;
+  BAWin* d_wins = nullptr; BAState* d_state = nullptr; RowGroup* d_rgs = nullptr;
+  int* h_counters = nullptr;               // pinned
+  int max_lblocks = 0, max_rg = 0, max_free = 0, max_tile_blocks = 0, max_rows = 0, max_cams = 0;
+  int schur_chunks = 1;
+  size_t S_total = 0, x_total = 0;
+  size_t rec_stride = 0;
+  std::vector<unsigned char> h_records; bool records_valid = false;
+  hipEvent_t ev[kNumPhases + 1] = {};
+  double phase_ms[LLD_BA_N_PHASES] = {};
+  int64_t launches[kNumPhases] = {};
+  int super_steps = 0;
+};
+
+namespace {
+
+template <class T>
+T* upload(lld_slab& sl, const std::vector<T>& h, size_t count, hipStream_t st) {
+  T* d = sl.take<T>(count);
+  if (!h.empty()) (void)hipMemcpyAsync(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, st);
+  return d;
+}
+
+int validate_window(const lld_ba_window& w) {
+  if (w.n_cams <= 0 || w.n_free_cams < 0 || w.n_free_cams > w.n_cams || w.n_points < 0 || w.n_lines < 0 || w.n_pt_obs < 0 || w.n_ln_obs < 0)
+    return LLD_ERR_INVALID;
+  if (!w.cam_qt) return LLD_ERR_INVALID;
+  if (w.n_free_cams > kMaxFreeCams) return LLD_ERR_UNSUPPORTED;
+  if (w.n_points > 0 && (!w.pt_xyz || !w.pt_obs_start)) return LLD_ERR_INVALID;
+  if (w.n_pt_obs > 0 && (!w.pt_obs_cam || !w.pt_obs_uvr || !w.pt_obs_inv_sigma2)) return LLD_ERR_INVALID;
+  if (w.n_lines > 0 && (!w.line_x0 || !w.line_dir || !w.ln_obs_start)) return LLD_ERR_INVALID;
+  if (w.n_ln_obs > 0 && (!w.ln_obs_cam || !w.ln_obs_left || !w.ln_obs_right || !w.ln_obs_octave)) return LLD_ERR_INVALID;
+  if (w.n_points > 0) {
+    if (w.pt_obs_start[0] != 0 || w.pt_obs_start[w.n_points] != w.n_pt_obs) return LLD_ERR_INVALID;
+    for (int p = 0; p < w.n_points; p++) if (w.pt_obs_start[p + 1] < w.pt_obs_start[p]) return LLD_ERR_INVALID;
+  } else if (w.n_pt_obs != 0) return LLD_ERR_INVALID;
+  if (w.n_lines > 0) {
+    if (w.ln_obs_start[0] != 0 || w.ln_obs_start[w.n_lines] != w.n_ln_obs) return LLD_ERR_INVALID;
+    for (int l = 0; l < w.n_lines; l++) if (w.ln_obs_start[l + 1] < w.ln_obs_start[l]) return LLD_ERR_INVALID;
+  } else if (w.n_ln_obs != 0) return LLD_ERR_INVALID;
+  for (int o = 0; o < w.n_pt_obs; o++) if (w.pt_obs_cam[o] < 0 || w.pt_obs_cam[o] >= w.n_cams) return LLD_ERR_INVALID;
+  for (int o = 0; o < w.n_ln_obs; o++) if (w.ln_obs_cam[o] < 0 || w.ln_obs_cam[o] >= w.n_cams) return LLD_ERR_INVALID;
+  return LLD_OK;
+}
+
+size_t record_bytes(const BAWin& W) {
+  size_t b = sizeof(BARecordHeader) + sizeof(double) * (7 * (size_t)W.n_cams + 3 * (size_t)W.n_pt + 6 * (size_t)W.n_ln) + (size_t)W.n_pe + (size_t)W.n_le + (size_t)W.n_ln;
+  return (b + 255) & ~size_t(255);
+}
+
+}  // namespace
+
+extern "C" {
+
+int lld_ba_batch_create(lld_ctx* ctx, int n_windows, const lld_ba_window* wins, const lld_ba_params* params, lld_ba_batch** out) {
+  if (!ctx || n_windows <= 0 || !wins || !out) return LLD_ERR_INVALID;
+  *out = nullptr;
+  for (int w = 0; w < n_windows; w++) { int st = validate_window(wins[w]); if (st) return st; }
+  LLD_HIP_TRY(hipSetDevice(ctx->device));
+  lld_ba_batch* B = new lld_ba_batch();
+  B->ctx = ctx; B->n_windows = n_windows;
+  if (params) B->params = *params; else lld_ba_params_default(&B->params);
+  const lld_ba_params& P = B->params;
+  if (P.its_round1 < 0 || P.its_round2 < 0 || P.max_trials <= 0 || !(P.pcg_rel_tol > 0)) { delete B; return LLD_ERR_INVALID; }
+
+  // ---- layout + host staging
+  std::vector<double> cam_qt0, pt0, ln_x0, ln_dir, pe_u, pe_v, pe_ur, pe_s, le_xs, le_ys, le_xe, le_ye, le_s, le_bx;
+  std::vector<int> pt_obs_start, ln_obs_start, pe_cam, pe_pt, le_cam, le_ln, rg_pe, rg_le;
+  std::vector<uint8_t> le_flags0;
+  B->h_wins.resize(n_windows);
+  const double thMono = (double)(float)std::sqrt(5.991), thStereo = (double)(float)std::sqrt(7.815);   // Optimizer.cc:1088-1089
+  long long NC = 0, NP = 0, NL = 0, NPE = 0, NLO = 0, NF = 0, NPART = 0;
+  size_t S_total = 0, x_total = 0, rec_total = 0;
+  for (int wi = 0; wi < n_windows; wi++) {
+    const lld_ba_window& w = wins[wi];
+    BAWin& W = B->h_wins[wi];
+    std::memset(&W, 0, sizeof W);
+    W.cam = lld::make_camk(w.cam);
+    W.n_cams = w.n_cams; W.n_free = w.n_free_cams;
+    W.cam_off = (int)NC; W.pt_off = (int)NP; W.n_pt = w.n_points; W.ln_off = (int)NL; W.n_ln = w.n_lines;
+    W.pe_off = (int)NPE; W.n_pe = w.n_pt_obs; W.le_off = (int)(2 * NLO); W.n_le = 2 * w.n_ln_obs;
+    W.hpp_off = (int)NF; W.x_off = (int)x_total; W.S_off = (long long)S_total;
+    W.nb_pt = (w.n_points + kLmThreads - 1) / kLmThreads; W.nb_ln = (w.n_lines + kLmThreads - 1) / kLmThreads;
+    W.part_off = (int)NPART;
+    W.its[0] = P.its_round1; W.its[1] = P.its_round2; W.max_trials = P.max_trials; W.ln_filter = P.ln_filter;
+    W.th_mono = thMono; W.th_stereo = thStereo;
+    W.th_ln_mono = thMono * P.gamma; W.th_ln_stereo = thStereo * P.gamma;            // LineOptimizer.cc:33-35
+    cam_qt0.insert(cam_qt0.end(), w.cam_qt, w.cam_qt + 7 * (size_t)w.n_cams);
+    if (w.n_points) pt0.insert(pt0.end(), w.pt_xyz, w.pt_xyz + 3 * (size_t)w.n_points);
+    if (w.n_lines) { ln_x0.insert(ln_x0.end(), w.line_x0, w.line_x0 + 3 * (size_t)w.n_lines); ln_dir.insert(ln_dir.end(), w.line_dir, w.line_dir + 3 * (size_t)w.n_lines); }
+    for (int p = 0; p < w.n_points; p++) {
+      pt_obs_start.push_back((int)NPE + w.pt_obs_start[p]);
+      for (int o = w.pt_obs_start[p]; o < w.pt_obs_start[p + 1]; o++) {
+        pe_cam.push_back(w.pt_obs_cam[o]); pe_pt.push_back(p);
+        pe_u.push_back(w.pt_obs_uvr[3 * o]); pe_v.push_back(w.pt_obs_uvr[3 * o + 1]); pe_ur.push_back(w.pt_obs_uvr[3 * o + 2]);
+        pe_s.push_back(w.pt_obs_inv_sigma2[o]);
+      }
+    }
+    for (int l = 0; l < w.n_lines; l++) {
+      ln_obs_start.push_back((int)NLO + w.ln_obs_start[l]);
+      for (int o = w.ln_obs_start[l]; o < w.ln_obs_start[l + 1]; o++) {
+        const double* Lf = w.ln_obs_left + 4 * (size_t)o; const double* Rt = w.ln_obs_right + 4 * (size_t)o;
+        const bool has_right = !(Rt[0] < 0);                                          // startPointX >= 0 (LineOptimizer.cc:60)
+        for (int si = 0; si < 2; si++) {
+          const double* kl = si == 0 ? Lf : Rt;
+          const bool valid = si == 0 || has_right;
+          le_cam.push_back(w.ln_obs_cam[o]); le_ln.push_back(l);
+          le_xs.push_back(kl[0]); le_ys.push_back(kl[1]); le_xe.push_back(kl[2]); le_ye.push_back(kl[3]);
+          le_s.push_back(valid ? lld::line_info(P.gamma, w.ln_obs_octave[2 * (size_t)o + si]) : 0.0);
+          le_bx.push_back(si == 1 ? W.cam.bx_right : 0.0);
+          le_flags0.push_back((uint8_t)((valid ? EF_VALID : 0) | (has_right ? EF_PAIRSTEREO : 0)));
+        }
+      }
+    }
+    // ---- camera row groups for the Schur tile + edge buckets
+    W.rg_off = (int)B->h_rgs.size();
+    {
+      int r0 = 0;
+      const int nf = w.n_free_cams;
+      while (r0 < nf) {
+        int blocks = 0, r1 = r0;
+        while (r1 < nf && blocks + (nf - r1) <= kTileBlocksMax) { blocks += nf - r1; r1++; }
+        if (r1 == r0) { delete B; return LLD_ERR_UNSUPPORTED; }
+        RowGroup G; std::memset(&G, 0, sizeof G);
+        G.r0 = r0; G.r1 = r1; G.tile_blocks = blocks;
+        G.pe_off = (int)rg_pe.size();
+        for (int o = 0; o < w.n_pt_obs; o++) { const int c = w.pt_obs_cam[o]; if (c >= r0 && c < r1) rg_pe.push_back((int)NPE + o); }
+        G.pe_n = (int)rg_pe.size() - G.pe_off;
+        G.le_off = (int)rg_le.size();
+        for (int o = 0; o < w.n_ln_obs; o++) {
+          const int c = w.ln_obs_cam[o];
+          if (c >= r0 && c < r1) { rg_le.push_back((int)(2 * (NLO + o))); if (!(w.ln_obs_right[4 * (size_t)o] < 0)) rg_le.push_back((int)(2 * (NLO + o) + 1)); }
+        }
+        G.le_n = (int)rg_le.size() - G.le_off;
+        B->h_rgs.push_back(G);
+        B->max_tile_blocks = std::max(B->max_tile_blocks, blocks);
+        B->max_rows = std::max(B->max_rows, r1 - r0);
+        r0 = r1;
+      }
+    }
+    W.n_rg = (int)B->h_rgs.size() - W.rg_off;
+    W.rec_off = (long long)rec_total;
+    NC += w.n_cams; NP += w.n_points; NL += w.n_lines; NPE += w.n_pt_obs; NLO += w.n_ln_obs; NF += w.n_free_cams;
+    NPART += W.nb_pt + W.nb_ln;
+    const size_t n = 6 * (size_t)w.n_free_cams;
+    S_total += n * n; x_total += n;
+    B->max_lblocks = std::max(B->max_lblocks, W.nb_pt + W.nb_ln);
+    B->max_rg = std::max(B->max_rg, W.n_rg);
+    B->max_free = std::max(B->max_free, w.n_free_cams);
+    B->max_cams = std::max(B->max_cams, w.n_cams);
+    B->rec_stride = std::max(B->rec_stride, record_bytes(W));
+  }
+  pt_obs_start.push_back((int)NPE); ln_obs_start.push_back((int)NLO);
+  if (B->max_cams > kPcgThreads) { delete B; return LLD_ERR_UNSUPPORTED; }
+  // fixed-stride result records (what an RCCL gather of the batch moves)
+  for (int wi = 0; wi < n_windows; wi++) B->h_wins[wi].rec_off = (long long)(B->rec_stride * (size_t)wi);
+  rec_total = B->rec_stride * (size_t)n_windows;
+  B->S_total = S_total; B->x_total = x_total;
+  // enough Schur workgroups to fill the chip when the batch is small
+  {
+    const int wg = std::max(1, n_windows * std::max(1, B->max_rg));
+    int c = (2 * ctx->n_cu + wg - 1) / wg;
+    B->schur_chunks = std::max(1, std::min(32, c));
+  }
+
+  // ---- one slab: a dry run of the carve sizes it exactly, the second run assigns pointers and uploads
+  const size_t NLE = 2 * (size_t)NLO;
+  hipStream_t st = ctx->stream;
+  BAArrays& A = B->A;
+  auto carve = [&](lld_slab& sl, bool real) {
+    auto up_d = [&](const std::vector<double>& h, size_t count) { double* d = sl.take<double>(count); if (real && !h.empty()) (void)hipMemcpyAsync(d, h.data(), h.size() * 8, hipMemcpyHostToDevice, st); return (const double*)d; };
+    auto up_i = [&](const std::vector<int>& h, size_t count) { int* d = sl.take<int>(count); if (real && !h.empty()) (void)hipMemcpyAsync(d, h.data(), h.size() * 4, hipMemcpyHostToDevice, st); return (const int*)d; };
+    auto up_b = [&](const std::vector<uint8_t>& h, size_t count) { uint8_t* d = sl.take<uint8_t>(count); if (real && !h.empty()) (void)hipMemcpyAsync(d, h.data(), h.size(), hipMemcpyHostToDevice, st); return (const uint8_t*)d; };
+    B->d_wins = sl.take<BAWin>(n_windows); B->d_state = sl.take<BAState>(n_windows); B->d_rgs = sl.take<RowGroup>(B->h_rgs.size() + 1);
+    std::memset(&A, 0, sizeof A);
+    A.NC = NC; A.NP = NP; A.NL = NL;
+    A.cam_qt = sl.take<double>(2 * NC * 7 + 1);
+    A.ptx = sl.take<double>(2 * NP + 1); A.pty = sl.take<double>(2 * NP + 1); A.ptz = sl.take<double>(2 * NP + 1);
+    A.lqx = sl.take<double>(2 * NL + 1); A.lqy = sl.take<double>(2 * NL + 1); A.lqz = sl.take<double>(2 * NL + 1); A.lqw = sl.take<double>(2 * NL + 1); A.lal = sl.take<double>(2 * NL + 1);
+    A.cam_qt0 = up_d(cam_qt0, NC * 7 + 1); A.pt0 = up_d(pt0, NP * 3 + 1);
+    A.ln_x0 = up_d(ln_x0, NL * 3 + 1); A.ln_dir = up_d(ln_dir, NL * 3 + 1);
+    A.pt_obs_start = up_i(pt_obs_start, NP + 2); A.ln_obs_start = up_i(ln_obs_start, NL + 2);
+    A.pe_cam = up_i(pe_cam, NPE + 1); A.pe_pt = up_i(pe_pt, NPE + 1);
+    A.pe_u = up_d(pe_u, NPE + 1); A.pe_v = up_d(pe_v, NPE + 1); A.pe_ur = up_d(pe_ur, NPE + 1); A.pe_s = up_d(pe_s, NPE + 1);
+    A.le_cam = up_i(le_cam, NLE + 1); A.le_ln = up_i(le_ln, NLE + 1);
+    A.le_xs = up_d(le_xs, NLE + 1); A.le_ys = up_d(le_ys, NLE + 1); A.le_xe = up_d(le_xe, NLE + 1); A.le_ye = up_d(le_ye, NLE + 1);
+    A.le_s = up_d(le_s, NLE + 1); A.le_bx = up_d(le_bx, NLE + 1);
+    A.le_flags0 = up_b(le_flags0, NLE + 1);
+    A.pe_flags = sl.take<uint8_t>(NPE + 1); A.le_flags = sl.take<uint8_t>(NLE + 1);
+    A.pe_chi2 = sl.take<double>(NPE + 1); A.le_chi2 = sl.take<double>(NLE + 1);
+    A.pe_W = sl.take<double>((size_t)NPE * 18 + 1); A.le_W = sl.take<double>(NLE * 24 + 1);
+    A.pt_active = sl.take<uint8_t>(NP + 1); A.ln_active = sl.take<uint8_t>(NL + 1); A.ln_removed = sl.take<uint8_t>(NL + 1);
+    A.pt_V = sl.take<double>((size_t)NP * 9 + 1); A.ln_V = sl.take<double>((size_t)NL * 14 + 1);
+    A.Hpp = sl.take<double>((size_t)NF * 21 + 1); A.bp = sl.take<double>((size_t)NF * 6 + 1);
+    A.S = sl.take<double>(S_total + 1); A.bschur = sl.take<double>(x_total + 1); A.xp = sl.take<double>(x_total + 1);
+    A.chi_part = sl.take<double>(NPART + 1); A.chi_part2 = sl.take<double>(NPART + 1); A.scale_part = sl.take<double>(NPART + 1);
+    A.rg_pe = up_i(rg_pe, rg_pe.size() + 1); A.rg_le = up_i(rg_le, rg_le.size() + 1);
+    A.records = sl.take<unsigned char>(rec_total + 256);
+    A.counters = sl.take<int>(8);
+  };
+  lld_slab dry; dry.base = reinterpret_cast<char*>(256);
+  carve(dry, false);
+  const size_t bytes = dry.used + 4096;
+  if (hipMalloc(&B->slab, bytes) != hipSuccess) { delete B; return LLD_ERR_ALLOC; }
+  B->slab_bytes = bytes;
+  lld_slab sl; sl.base = (char*)B->slab; sl.size = bytes;
+  carve(sl, true);
+  {
+    const size_t schur_lds = ((size_t)B->max_tile_blocks * 36 + (size_t)B->max_rows * 6) * sizeof(double);
+    LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_schur_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)schur_lds));
+    const size_t pcg_lds = ((size_t)B->max_free * 6 * 5 + (size_t)B->max_free * 36 + 32) * sizeof(double);
+    LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_pcg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pcg_lds));
+  }
+  LLD_HIP_TRY(hipMemcpyAsync(B->d_wins, B->h_wins.data(), sizeof(BAWin) * n_windows, hipMemcpyHostToDevice, st));
+  if (!B->h_rgs.empty()) LLD_HIP_TRY(hipMemcpyAsync(B->d_rgs, B->h_rgs.data(), sizeof(RowGroup) * B->h_rgs.size(), hipMemcpyHostToDevice, st));
+  LLD_HIP_TRY(hipHostMalloc((void**)&B->h_counters, 8 * sizeof(int), hipHostMallocDefault));
+  for (auto& e : B->ev) LLD_HIP_TRY(hipEventCreate(&e));
+  LLD_HIP_TRY(hipStreamSynchronize(st));        // staging vectors go out of scope
+  *out = B;
+  return LLD_OK;
+}
+
+int lld_ba_batch_solve(lld_ba_batch* B, volatile const int* abort_flag) {
+  if (!B) return LLD_ERR_INVALID;
+  lld_ctx* ctx = B->ctx;
+  LLD_HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  const int nW = B->n_windows;
+  BAArrays& A = B->A;
+  B->records_valid = false;
+  for (auto& m : B->phase_ms) m = 0.0;
+  for (auto& l : B->launches) l = 0;
+  B->super_steps = 0;
+  hipEvent_t t_begin, t_end;
+  LLD_HIP_TRY(hipEventCreate(&t_begin)); LLD_HIP_TRY(hipEventCreate(&t_end));
+  LLD_HIP_TRY(hipEventRecord(t_begin, st));
+
+  const int init_blocks = std::max(1, std::min(64, B->max_lblocks + 1));
+  hipLaunchKernelGGL(ba_init_kernel, dim3(init_blocks, nW), dim3(kLmThreads), 0, st, A, B->d_wins, B->d_state);
+  LLD_HIP_TRY(hipGetLastError());
+  // Optimizer.cc:1220-1222: a stop request before optimising returns without touching the map -> the read-back kernel copies
+  // the (untouched) working state and every flag stays clear.
+  const bool abort_at_start = abort_flag && *abort_flag;
+  const size_t lin_lds = ((size_t)B->max_free * 27 + 8) * sizeof(double);
+  const size_t schur_lds = ((size_t)B->max_tile_blocks * 36 + (size_t)B->max_rows * 6) * sizeof(double);
+  const size_t pcg_lds = ((size_t)B->max_free * 6 * 5 + (size_t)B->max_free * 36 + 32) * sizeof(double);
+  const dim3 lm_grid(std::max(1, B->max_lblocks), nW);
+  const dim3 fin_grid(B->max_lblocks + 1, nW);
+  const int chunks = B->schur_chunks;
+  const dim3 schur_grid(std::max(1, B->max_rg) * chunks, nW);
+  const int ctl_blocks = (nW + 63) / 64;
+  bool any_left = true;
+  if (abort_at_start) {
+    // every window: phase FINALIZE with aborted = 1, no classification (all chi2 are zero, nothing is flagged)
+    std::vector<BAState> hs(nW);
+    std::memset(hs.data(), 0, sizeof(BAState) * nW);
+    for (auto& s : hs) { s.phase = PH_FINALIZE; s.aborted = 1; }
+    LLD_HIP_TRY(hipMemcpyAsync(B->d_state, hs.data(), sizeof(BAState) * nW, hipMemcpyHostToDevice, st));
+    LLD_HIP_TRY(hipStreamSynchronize(st));
+    // the reference returns before anything is classified: emit untouched states with clear flags
+    hipLaunchKernelGGL(ba_finalize_kernel, fin_grid, dim3(kLmThreads), 0, st, A, B->d_wins, B->d_state);
+    hipLaunchKernelGGL(ba_mark_done_kernel, dim3(ctl_blocks), dim3(64), 0, st, B->d_state, nW);
+    LLD_HIP_TRY(hipGetLastError());
+    any_left = false;
+  }
+  while (any_left) {
+    if (B->super_steps >= kMaxSuperSteps) break;
+    const int abort_now = (abort_flag && *abort_flag) ? 1 : 0;
+    LLD_HIP_TRY(hipMemsetAsync(A.counters, 0, 4 * sizeof(int), st));
+    if (chunks > 1) {
+      LLD_HIP_TRY(hipMemsetAsync(A.S, 0, B->S_total * sizeof(double), st));
+      LLD_HIP_TRY(hipMemsetAsync(A.bschur, 0, B->x_total * sizeof(double), st));
+    }
+    LLD_HIP_TRY(hipEventRecord(B->ev[0], st));
+    hipLaunchKernelGGL(ba_linearize_kernel, lm_grid, dim3(kLmThreads), lin_lds, st, A, B->d_wins, B->d_state);
+    hipLaunchKernelGGL(ba_begin_kernel, dim3(ctl_blocks), dim3(64), 0, st, A, B->d_wins, B->d_state, nW);
+    LLD_HIP_TRY(hipEventRecord(B->ev[1], st));
+    hipLaunchKernelGGL(ba_schur_kernel, schur_grid, dim3(kSchurThreads), schur_lds, st, A, B->d_wins, B->d_state, B->d_rgs, chunks);
+    LLD_HIP_TRY(hipEventRecord(B->ev[2], st));
+    hipLaunchKernelGGL(ba_pcg_kernel, dim3(nW), dim3(kPcgThreads), pcg_lds, st, A, B->d_wins, B->d_state, B->params.pcg_rel_tol, B->params.pcg_max_iter);
+    LLD_HIP_TRY(hipEventRecord(B->ev[3], st));
+    hipLaunchKernelGGL(ba_backsub_kernel, lm_grid, dim3(kLmThreads), 0, st, A, B->d_wins, B->d_state);
+    LLD_HIP_TRY(hipEventRecord(B->ev[4], st));
+    hipLaunchKernelGGL(ba_control_kernel, dim3(nW), dim3(kCtlThreads), 0, st, A, B->d_wins, B->d_state, abort_now);
+    LLD_HIP_TRY(hipGetLastError());
+    LLD_HIP_TRY(hipMemcpyAsync(B->h_counters, A.counters, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
+    LLD_HIP_TRY(hipStreamSynchronize(st));
+    const int n_run = B->h_counters[0], n_trans = B->h_counters[1], n_fin = B->h_counters[2];
+    if (n_trans > 0) {
+      hipLaunchKernelGGL(ba_classify_kernel, lm_grid, dim3(kLmThreads), 0, st, A, B->d_wins, B->d_state);
+      hipLaunchKernelGGL(ba_round2_kernel, dim3(nW), dim3(kCtlThreads), 0, st, A, B->d_wins, B->d_state);
+    }
+    if (n_fin > 0) {
+      hipLaunchKernelGGL(ba_finalize_kernel, fin_grid, dim3(kLmThreads), 0, st, A, B->d_wins, B->d_state);
+      hipLaunchKernelGGL(ba_mark_done_kernel, dim3(ctl_blocks), dim3(64), 0, st, B->d_state, nW);
+    }
+    LLD_HIP_TRY(hipEventRecord(B->ev[5], st));
+    LLD_HIP_TRY(hipGetLastError());
+    LLD_HIP_TRY(hipEventSynchronize(B->ev[5]));
+    for (int k = 0; k < kNumPhases; k++) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, B->ev[k], B->ev[k + 1]) == hipSuccess) B->phase_ms[k] += ms;
+      B->launches[k]++;
+    }
+    B->super_steps++;
+    // a window that classified may have an empty active set and go straight to FINALIZE: it is picked up next step
+    any_left = (n_run + n_trans) > 0;
+    if (!any_left && n_trans == 0) break;
+  }
+  // windows that ba_round2 sent straight to FINALIZE (empty active set) or that hit the hard stop
+  hipLaunchKernelGGL(ba_finalize_kernel, fin_grid, dim3(kLmThreads), 0, st, A, B->d_wins, B->d_state);
+  hipLaunchKernelGGL(ba_mark_done_kernel, dim3(ctl_blocks), dim3(64), 0, st, B->d_state, nW);
+  LLD_HIP_TRY(hipGetLastError());
+  LLD_HIP_TRY(hipEventRecord(t_end, st));
+  LLD_HIP_TRY(hipEventSynchronize(t_end));
+  float tot = 0.f;
+  (void)hipEventElapsedTime(&tot, t_begin, t_end);
+  B->phase_ms[kNumPhases] = tot;
+  (void)hipEventDestroy(t_begin); (void)hipEventDestroy(t_end);
+  return LLD_OK;
+}
+
+static int ba_fetch_records(lld_ba_batch* B) {
+  if (B->records_valid) return LLD_OK;
+  const size_t total = B->rec_stride * (size_t)B->n_windows;
+  B->h_records.resize(total);
+  LLD_HIP_TRY(hipMemcpyAsync(B->h_records.data(), B->A.records, total, hipMemcpyDeviceToHost, B->ctx->stream));
+  LLD_HIP_TRY(hipStreamSynchronize(B->ctx->stream));
+  B->records_valid = true;
+  return LLD_OK;
+}
+
+static void fill_stats(const lld_ba_batch* B, int wi, lld_ba_stats* s) {
+  const BAWin& W = B->h_wins[wi];
+  const unsigned char* rec = B->h_records.data() + W.rec_off;
+  const BARecordHeader* h = reinterpret_cast<const BARecordHeader*>(rec);
+  std::memset(s, 0, sizeof *s);
+  s->chi2_round1 = h->chi2_round1; s->chi2_final = h->chi2_final;
+  s->lm_iterations[0] = h->lm_iterations[0]; s->lm_iterations[1] = h->lm_iterations[1];
+  s->lm_trials[0] = h->lm_trials[0]; s->lm_trials[1] = h->lm_trials[1];
+  s->pcg_iterations = h->pcg_iterations; s->aborted = h->aborted;
+  const unsigned char* flags = rec + sizeof(BARecordHeader) + sizeof(double) * (7 * (size_t)W.n_cams + 3 * (size_t)W.n_pt + 6 * (size_t)W.n_ln);
+  for (int i = 0; i < W.n_pe; i++) s->n_pt_obs_outlier += flags[i];
+  for (int i = 0; i < W.n_le; i++) s->n_ln_edge_outlier += flags[W.n_pe + i];
+  for (int i = 0; i < W.n_ln; i++) s->n_lines_removed += flags[W.n_pe + W.n_le + i];
+}
+
+int lld_ba_batch_download(lld_ba_batch* B, int wi, lld_ba_result* out) {
+  if (!B || !out || wi < 0 || wi >= B->n_windows) return LLD_ERR_INVALID;
+  LLD_HIP_TRY(hipSetDevice(B->ctx->device));
+  int st = ba_fetch_records(B); if (st) return st;
+  const BAWin& W = B->h_wins[wi];
+  const unsigned char* rec = B->h_records.data() + W.rec_off;
+  const double* d = reinterpret_cast<const double*>(rec + sizeof(BARecordHeader));
+  if (out->cam_qt) std::memcpy(out->cam_qt, d, sizeof(double) * 7 * W.n_cams);
+  d += 7 * (size_t)W.n_cams;
+  if (out->pt_xyz && W.n_pt) std::memcpy(out->pt_xyz, d, sizeof(double) * 3 * W.n_pt);
+  d += 3 * (size_t)W.n_pt;
+  if (out->line_x0 && W.n_ln) std::memcpy(out->line_x0, d, sizeof(double) * 3 * W.n_ln);
+  d += 3 * (size_t)W.n_ln;
+  if (out->line_dir && W.n_ln) std::memcpy(out->line_dir, d, sizeof(double) * 3 * W.n_ln);
+  d += 3 * (size_t)W.n_ln;
+  const unsigned char* f = reinterpret_cast<const unsigned char*>(d);
+  if (out->pt_obs_outlier && W.n_pe) std::memcpy(out->pt_obs_outlier, f, W.n_pe);
+  if (out->ln_edge_outlier && W.n_le) std::memcpy(out->ln_edge_outlier, f + W.n_pe, W.n_le);
+  if (out->line_removed && W.n_ln) std::memcpy(out->line_removed, f + W.n_pe + W.n_le, W.n_ln);
+  fill_stats(B, wi, &out->stats);
+  return LLD_OK;
+}
+
+int lld_ba_batch_stats(lld_ba_batch* B, lld_ba_stats* stats) {
+  if (!B || !stats) return LLD_ERR_INVALID;
+  LLD_HIP_TRY(hipSetDevice(B->ctx->device));
+  int st = ba_fetch_records(B); if (st) return st;
+  for (int w = 0; w < B->n_windows; w++) fill_stats(B, w, stats + w);
+  return LLD_OK;
+}
+
+int lld_ba_batch_result_records(lld_ba_batch* B, void** dev_ptr, uint64_t* stride_bytes) {
+  if (!B || !dev_ptr || !stride_bytes) return LLD_ERR_INVALID;
+  *dev_ptr = B->A.records; *stride_bytes = B->rec_stride;
+  return LLD_OK;
+}
+
+int lld_ba_batch_phase_ms(lld_ba_batch* B, double* ms6) {
+  if (!B || !ms6) return LLD_ERR_INVALID;
+  for (int i = 0; i < LLD_BA_N_PHASES; i++) ms6[i] = B->phase_ms[i];
+  return LLD_OK;
+}
+
+int lld_ba_batch_kernel_stats(lld_ba_batch* B, int kernel, int64_t* launches, double* total_ms) {
+  if (!B || kernel < 0 || kernel >= kNumPhases || !launches || !total_ms) return LLD_ERR_INVALID;
+  *launches = B->launches[kernel]; *total_ms = B->phase_ms[kernel];
+  return LLD_OK;
+}
+
+void lld_ba_batch_destroy(lld_ba_batch* B) {
+  if (!B) return;
+  (void)hipSetDevice(B->ctx->device);
+  (void)hipStreamSynchronize(B->ctx->stream);
+  for (auto& e : B->ev) if (e) (void)hipEventDestroy(e);
+  if (B->h_counters) (void)hipHostFree(B->h_counters);
+  if (B->slab) (void)hipFree(B->slab);
+  delete B;
+}
+
+int lld_local_ba(lld_ctx* ctx, const lld_ba_window* in, const lld_ba_params* params, volatile const int* abort_flag, lld_ba_result* out) {
+  if (!ctx || !in || !out) return LLD_ERR_INVALID;
+  lld_ba_batch* B = nullptr;
+  int st = lld_ba_batch_create(ctx, 1, in, params, &B); if (st) return st;
+  st = lld_ba_batch_solve(B, abort_flag);
+  if (!st) st = lld_ba_batch_download(B, 0, out);
+  lld_ba_batch_destroy(B);
+  return st;
+}
+
+}  // extern "C"

@@ -1,0 +1,1021 @@
+// lld_ba_kernels.h — device side of the batched local bundle adjustment (gfx950).
+//
+// One launch of each kernel sweeps ALL windows of a batch (grid.y = window); every window carries its own
+// Levenberg–Marquardt state machine in HBM (BAState) and each kernel starts by reading it, so windows advance
+// independently ("super-steps"): a window that rejected its trial only re-runs Schur/PCG/back-substitution with the
+// new lambda, a window that accepted re-linearises, finished windows fall through.  The host only launches and reads
+// back three counters per super-step.
+//
+// Kernel <-> reference map
+//   ba_linearize   computeActiveErrors + activeRobustChi2 + buildSystem   sparse_optimizer.cpp:61-114, block_solver.hpp:502-560,
+//                  (per-edge residual, Jacobians, Huber weight,           base_binary_edge.hpp:54-120, types_six_dof_expmap.cpp
+//                   Hll/bl in registers, Hpl block per edge, Hpp/bp
+//                   through LDS-staged per-camera 6x6 accumulators)
+//   ba_begin       LM iteration head: chi2, lambda init                    optimization_algorithm_levenberg.cpp:75-99,166-180
+//   ba_schur       setLambda + Schur complement                            block_solver.hpp:373-439,564-589
+//                  (LDS-resident tile of 6x6 S blocks per camera row group)
+//   ba_pcg         reduced camera system solve (block-Jacobi PCG instead   linear_solver_eigen.h:94-124 (exact LDLT there)
+//                  of sparse LDLT) + camera oplus
+//   ba_backsub     landmark back-substitution, oplus, trial chi2           block_solver.hpp:459-483, sparse_optimizer.cpp:422-435
+//   ba_control     accept / reject, lambda update, stop rules              optimization_algorithm_levenberg.cpp:102-164
+//   ba_classify    outlier levels between the two rounds                   Optimizer.cc:1239-1267, LineOptimizer.cc:129-170
+//   ba_finalize    erase lists + read-back                                 Optimizer.cc:1278-1329, LineOptimizer.cc:172-201
+#ifndef LLD_BA_KERNELS_H
+#define LLD_BA_KERNELS_H
+
+#include "lld_common.h"
+#include "lld_device_math.h"
+
+namespace lldba {
+
+using namespace lld;
+
+constexpr int kLmThreads = 256;        // landmark-parallel kernels: one lane per landmark
+constexpr int kSchurThreads = 512;
+constexpr int kPcgThreads = 1024;
+constexpr int kCtlThreads = 64;
+constexpr int kMaxFreeCams = 96;
+constexpr int kTileBlocksMax = 440;    // 6x6 S blocks per LDS tile: 440*36*8 B = 124 KiB
+
+enum Phase : int { PH_RUN = 0, PH_TRANSITION = 2, PH_FINALIZE = 3, PH_DONE = 4 };
+constexpr uint8_t EF_LEVEL1 = 1, EF_ROBUST = 2, EF_VALID = 4, EF_PAIRSTEREO = 8;
+
+struct BAWin {                 // immutable per-window header
+  CamK cam;
+  int n_cams, n_free;
+  int cam_off;                 // cameras
+  int pt_off, n_pt;            // point landmarks
+  int ln_off, n_ln;            // line landmarks
+  int pe_off, n_pe;            // point edges
+  int le_off, n_le;            // line edge slots (2 per observation)
+  int hpp_off;                 // free-camera accumulators
+  int x_off;                   // reduced-system vectors (doubles)
+  long long S_off;             // reduced-system matrix (doubles)
+  int rg_off, n_rg;            // camera row groups of the Schur tile
+  int nb_pt, nb_ln;            // landmark blocks (kLmThreads landmarks each)
+  int part_off;                // per-block partial sums
+  int its[2];                  // LM iterations per round
+  int max_trials, ln_filter;
+  double th_mono, th_stereo;   // Huber deltas of point edges  ((double)(float)sqrt(5.991 / 7.815))
+  double th_ln_mono, th_ln_stereo;   // Huber deltas of line edges (x gamma)
+  long long rec_off;           // result record (bytes)
+};
+
+struct BAState {               // mutable per-window LM state
+  int phase, need_lin, round, it, q, cur, nBad, pcg_ok;
+  double lambda, ni, currentChi, iniChi, scale_cam;
+  unsigned long long maxdiag_bits;
+  double chi2_round1, chi2_final;
+  int lm_iterations[2], lm_trials[2];
+  int pcg_iterations, aborted, n_active_edges, pad;
+};
+
+struct RowGroup { int r0, r1, tile_blocks, pe_off, pe_n, le_off, le_n, pad; };
+
+struct BAArrays {
+  long long NC, NP, NL;        // totals (stride of the double-buffered state arrays)
+  // state, double buffered: [2][N]
+  double* cam_qt;              // [2][NC*7]
+  double *ptx, *pty, *ptz;     // [2][NP]
+  double *lqx, *lqy, *lqz, *lqw, *lal;   // [2][NL]
+  // inputs
+  const double* cam_qt0;       // [NC*7]
+  const double* pt0;           // [NP*3]
+  const double *ln_x0, *ln_dir;          // [NL*3]
+  const int* pt_obs_start;     // [NP+1] global point-edge index
+  const int* ln_obs_start;     // [NL+1] global line-observation index (slots = 2*obs + side)
+  const int* pe_cam; const int* pe_pt;
+  const double *pe_u, *pe_v, *pe_ur, *pe_s;
+  const int* le_cam; const int* le_ln;
+  const double *le_xs, *le_ys, *le_xe, *le_ye, *le_s, *le_bx;
+  const uint8_t* le_flags0;    // initial flags (validity / pair type)
+  // per-edge mutable
+  uint8_t *pe_flags, *le_flags;
+  double *pe_chi2, *le_chi2;
+  double *pe_W;                // [NPE*18]  Hpl block 6x3
+  double *le_W;                // [NLE*24]  Hpl block 6x4
+  // per-landmark mutable
+  uint8_t *pt_active, *ln_active, *ln_removed;
+  double *pt_V;                // [NP*9]   Hll upper (6) + bl (3)
+  double *ln_V;                // [NL*14]  Hll upper (10) + bl (4)
+  // per-window reduced system
+  double *Hpp;                 // [NF*21]
+  double *bp;                  // [NF*6]
+  double *S, *bschur, *xp;
+  double *chi_part, *chi_part2, *scale_part;
+  // row-group edge buckets
+  const int *rg_pe, *rg_le;
+  // results
+  unsigned char* records;
+  int* counters;               // [4]: running, transition, finalize
+};
+
+// ------------------------------------------------------------------ small helpers
+__device__ __forceinline__ double wave_sum(double x) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
+  return x;
+}
+__device__ __forceinline__ double wave_max(double x) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) x = fmax(x, __shfl_xor(x, off));
+  return x;
+}
+// Fixed-tree block sum; result valid in every lane.  `scratch` holds blockDim/64 doubles.
+__device__ __forceinline__ double block_sum(double x, double* scratch) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  x = wave_sum(x);
+  __syncthreads();
+  if (lane == 0) scratch[wave] = x;
+  __syncthreads();
+  double t = 0.0;
+  for (int i = 0; i < nw; i++) t += scratch[i];
+  return t;
+}
+__device__ __forceinline__ double block_max(double x, double* scratch) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  x = wave_max(x);
+  __syncthreads();
+  if (lane == 0) scratch[wave] = x;
+  __syncthreads();
+  double t = 0.0;
+  for (int i = 0; i < nw; i++) t = fmax(t, scratch[i]);
+  return t;
+}
+
+// Inverse of a symmetric positive definite D x D matrix (full row-major in/out) through Cholesky; false if not SPD.
+template <int D>
+__device__ __forceinline__ bool spd_inverse(const double* A, double* Ainv) {
+  double L[D][D];
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < D; j++) {
+    double d = A[j * D + j];
+#pragma unroll
+    for (int k = 0; k < j; k++) d -= L[j][k] * L[j][k];
+    if (!(d > 0.0)) ok = false;
+    const double ljj = sqrt(d);
+    L[j][j] = ljj;
+    const double inv = 1.0 / ljj;
+#pragma unroll
+    for (int i = j + 1; i < D; i++) {
+      double s = A[i * D + j];
+#pragma unroll
+      for (int k = 0; k < j; k++) s -= L[i][k] * L[j][k];
+      L[i][j] = s * inv;
+    }
+  }
+  // Linv (lower)
+  double Li[D][D];
+#pragma unroll
+  for (int j = 0; j < D; j++) {
+    Li[j][j] = 1.0 / L[j][j];
+#pragma unroll
+    for (int i = j + 1; i < D; i++) {
+      double s = 0.0;
+#pragma unroll
+      for (int k = j; k < i; k++) s -= L[i][k] * Li[k][j];
+      Li[i][j] = s / L[i][i];
+    }
+  }
+  // Ainv = Linv^T Linv
+#pragma unroll
+  for (int i = 0; i < D; i++)
+#pragma unroll
+    for (int j = i; j < D; j++) {
+      double s = 0.0;
+#pragma unroll
+      for (int k = j; k < D; k++) s += Li[k][i] * Li[k][j];
+      Ainv[i * D + j] = s; Ainv[j * D + i] = s;
+    }
+  return ok;
+}
+
+// packed upper (row-major) <-> full
+template <int D>
+__device__ __forceinline__ void unpack_sym(const double* U, double lambda, double* F) {
+  int k = 0;
+#pragma unroll
+  for (int i = 0; i < D; i++)
+#pragma unroll
+    for (int j = i; j < D; j++) { F[i * D + j] = U[k]; F[j * D + i] = U[k]; k++; }
+#pragma unroll
+  for (int i = 0; i < D; i++) F[i * D + i] += lambda;
+}
+
+__device__ __forceinline__ Pose load_cam(const BAArrays& A, int buf, int cam_global) {
+  return pose_load(A.cam_qt + ((size_t)buf * A.NC + cam_global) * 7);
+}
+__device__ __forceinline__ Vec3 load_pt(const BAArrays& A, int buf, int g) {
+  const size_t o = (size_t)buf * A.NP + g;
+  return vec3(A.ptx[o], A.pty[o], A.ptz[o]);
+}
+__device__ __forceinline__ void store_pt(const BAArrays& A, int buf, int g, const Vec3& X) {
+  const size_t o = (size_t)buf * A.NP + g;
+  A.ptx[o] = X.x; A.pty[o] = X.y; A.ptz[o] = X.z;
+}
+__device__ __forceinline__ LineQ load_ln(const BAArrays& A, int buf, int g) {
+  const size_t o = (size_t)buf * A.NL + g;
+  LineQ l; l.q.x = A.lqx[o]; l.q.y = A.lqy[o]; l.q.z = A.lqz[o]; l.q.w = A.lqw[o]; l.alpha = A.lal[o];
+  return l;
+}
+__device__ __forceinline__ void store_ln(const BAArrays& A, int buf, int g, const LineQ& l) {
+  const size_t o = (size_t)buf * A.NL + g;
+  A.lqx[o] = l.q.x; A.lqy[o] = l.q.y; A.lqz[o] = l.q.z; A.lqw[o] = l.q.w; A.lal[o] = l.alpha;
+}
+
+__device__ __forceinline__ double chi2_of(const double* e, int D, double s) {
+  double c = e[0] * (s * e[0]) + e[1] * (s * e[1]);
+  if (D == 3) c += e[2] * (s * e[2]);
+  return c;
+}
+
+// ================================================================== init
+// grid (blocks, nW): resets the working state of every window from the uploaded inputs.
+__global__ __launch_bounds__(kLmThreads) void ba_init_kernel(BAArrays A, const BAWin* __restrict__ wins, BAState* __restrict__ st) {
+  const BAWin W = wins[blockIdx.y];
+  const int gid = blockIdx.x * kLmThreads + threadIdx.x, stride = gridDim.x * kLmThreads;
+  for (int c = gid; c < W.n_cams * 7; c += stride) {
+    const double v = A.cam_qt0[(size_t)W.cam_off * 7 + c];
+    A.cam_qt[(size_t)W.cam_off * 7 + c] = v; A.cam_qt[(size_t)(A.NC + W.cam_off) * 7 + c] = v;
+  }
+  for (int p = gid; p < W.n_pt; p += stride) {
+    const int g = W.pt_off + p;
+    const Vec3 X = vec3(A.pt0[(size_t)g * 3], A.pt0[(size_t)g * 3 + 1], A.pt0[(size_t)g * 3 + 2]);
+    store_pt(A, 0, g, X); store_pt(A, 1, g, X);
+    A.pt_active[g] = A.pt_obs_start[g + 1] > A.pt_obs_start[g];
+  }
+  for (int l = gid; l < W.n_ln; l += stride) {
+    const int g = W.ln_off + l;
+    const LineQ L = line_from_x0_dir(vec3(A.ln_x0[(size_t)g * 3], A.ln_x0[(size_t)g * 3 + 1], A.ln_x0[(size_t)g * 3 + 2]),
+                                     vec3(A.ln_dir[(size_t)g * 3], A.ln_dir[(size_t)g * 3 + 1], A.ln_dir[(size_t)g * 3 + 2]));
+    store_ln(A, 0, g, L); store_ln(A, 1, g, L);
+    A.ln_active[g] = A.ln_obs_start[g + 1] > A.ln_obs_start[g];
+    A.ln_removed[g] = 0;
+  }
+  for (int e = gid; e < W.n_pe; e += stride) { A.pe_flags[W.pe_off + e] = EF_VALID | EF_ROBUST; A.pe_chi2[W.pe_off + e] = 0.0; }
+  for (int e = gid; e < W.n_le; e += stride) {
+    const uint8_t f0 = A.le_flags0[W.le_off + e];
+    A.le_flags[W.le_off + e] = (f0 & EF_VALID) ? (uint8_t)(f0 | EF_ROBUST) : (uint8_t)0;
+    A.le_chi2[W.le_off + e] = 0.0;
+  }
+  for (int i = gid; i < W.n_free * 21; i += stride) A.Hpp[(size_t)W.hpp_off * 21 + i] = 0.0;
+  for (int i = gid; i < W.n_free * 6; i += stride) A.bp[(size_t)W.hpp_off * 6 + i] = 0.0;
+  if (gid == 0) {
+    BAState s;
+    memset(&s, 0, sizeof s);
+    const int n_edges = W.n_pe + W.n_le;     // an empty graph skips straight to the read-back
+    s.phase = n_edges > 0 ? PH_RUN : PH_FINALIZE;
+    s.need_lin = 1; s.lambda = -1.0; s.ni = 2.0;
+    st[blockIdx.y] = s;
+  }
+}
+
+// ================================================================== linearise
+// grid (nb_pt + nb_ln, nW); dynamic LDS: n_free_max*27 doubles + 8 scratch.
+__global__ __launch_bounds__(kLmThreads) void ba_linearize_kernel(BAArrays A, const BAWin* __restrict__ wins, BAState* __restrict__ st) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const BAWin W = wins[blockIdx.y];
+  BAState& S = st[blockIdx.y];
+  if (S.phase != PH_RUN || !S.need_lin) return;
+  if ((int)blockIdx.x >= W.nb_pt + W.nb_ln) return;
+  const int nacc = W.n_free * 27;
+  double* acc = lds;                       // per free camera: 21 (Hpp upper) + 6 (bp)
+  double* scratch = lds + nacc;
+  for (int i = threadIdx.x; i < nacc; i += kLmThreads) acc[i] = 0.0;
+  __syncthreads();
+  const int cur = S.cur;
+  const CamK cam = W.cam;
+  double chi = 0.0, maxd = 0.0;
+
+  if ((int)blockIdx.x < W.nb_pt) {
+    const int p = blockIdx.x * kLmThreads + threadIdx.x;
+    const int g = W.pt_off + p;
+    if (p < W.n_pt && A.pt_active[g]) {
+      const Vec3 X = load_pt(A, cur, g);
+      double H[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
+      const int e0 = A.pt_obs_start[g], e1 = A.pt_obs_start[g + 1];
+      for (int e = e0; e < e1; e++) {
+        const uint8_t fl = A.pe_flags[e];
+        if (fl & EF_LEVEL1) continue;
+        const int c = A.pe_cam[e];
+        const Pose T = load_cam(A, cur, W.cam_off + c);
+        const Vec3 Xc = pose_map(T, X);
+        const double urv = A.pe_ur[e];
+        const bool stereo = !(urv < 0);
+        double r[3];
+        point_residual(cam, Xc, A.pe_u[e], A.pe_v[e], urv, stereo, true, r);
+        const double s = A.pe_s[e];
+        const double c2 = chi2_of(r, stereo ? 3 : 2, s);
+        A.pe_chi2[e] = c2;
+        double w = 1.0, rho0 = c2;
+        if (fl & EF_ROBUST) rho0 = huber(c2, stereo ? W.th_stereo : W.th_mono, &w);
+        chi += rho0;
+        const double ws = w * s;
+        const Mat3 R = quat_rotation(T.q);
+        double Jp[9], Jc[18];
+        point_jac_point(cam, Xc, R, stereo, Jp);
+        point_jac_pose(cam, Xc, stereo, Jc);
+        // landmark side: Hll += ws Jp^T Jp, bl -= ws Jp^T r   (rows beyond D are zero for mono)
+        int k = 0;
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+          b[a] -= ws * (Jp[a] * r[0] + Jp[3 + a] * r[1] + Jp[6 + a] * r[2]);
+#pragma unroll
+          for (int d = a; d < 3; d++) H[k++] += ws * (Jp[a] * Jp[d] + Jp[3 + a] * Jp[3 + d] + Jp[6 + a] * Jp[6 + d]);
+        }
+        if (c < W.n_free) {
+          double* Wb = A.pe_W + (size_t)e * 18;
+          double* ac = acc + c * 27;
+          int kk = 0;
+#pragma unroll
+          for (int rr = 0; rr < 6; rr++) {
+#pragma unroll
+            for (int a = 0; a < 3; a++) Wb[rr * 3 + a] = ws * (Jc[rr] * Jp[a] + Jc[6 + rr] * Jp[3 + a] + Jc[12 + rr] * Jp[6 + a]);
+            atomicAdd(&ac[21 + rr], -ws * (Jc[rr] * r[0] + Jc[6 + rr] * r[1] + Jc[12 + rr] * r[2]));
+#pragma unroll
+            for (int cc = rr; cc < 6; cc++) atomicAdd(&ac[kk++], ws * (Jc[rr] * Jc[cc] + Jc[6 + rr] * Jc[6 + cc] + Jc[12 + rr] * Jc[12 + cc]));
+          }
+        }
+      }
+      double* V = A.pt_V + (size_t)g * 9;
+#pragma unroll
+      for (int i = 0; i < 6; i++) V[i] = H[i];
+      V[6] = b[0]; V[7] = b[1]; V[8] = b[2];
+      maxd = fmax(fabs(H[0]), fmax(fabs(H[3]), fabs(H[5])));
+    }
+  } else {
+    const int l = (blockIdx.x - W.nb_pt) * kLmThreads + threadIdx.x;
+    const int g = W.ln_off + l;
+    if (l < W.n_ln && A.ln_active[g]) {
+      const LineQ L = load_ln(A, cur, g);
+      const Mat3 Rl = line_rotation(L);
+      const Vec3 c0 = mat_col(Rl, 0), c1 = mat_col(Rl, 1);
+      const Vec3 X1 = L.alpha * c1, X2 = X1 + c0;
+      double H[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
+      const int e0 = 2 * A.ln_obs_start[g], e1 = 2 * A.ln_obs_start[g + 1];
+      for (int e = e0; e < e1; e++) {
+        const uint8_t fl = A.le_flags[e];
+        if (!(fl & EF_VALID) || (fl & EF_LEVEL1)) continue;
+        const int c = A.le_cam[e];
+        const Pose T = load_cam(A, cur, W.cam_off + c);
+        const Vec3 X1m = pose_map(T, X1), X2m = pose_map(T, X2);
+        double r[2]; LineAdj adj;
+        line_residual(cam, A.le_bx[e], X1m, X2m, A.le_xs[e], A.le_ys[e], A.le_xe[e], A.le_ye[e], r, &adj);
+        const double s = A.le_s[e];
+        const double c2 = chi2_of(r, 2, s);
+        A.le_chi2[e] = c2;
+        double w = 1.0, rho0 = c2;
+        if (fl & EF_ROBUST) rho0 = huber(c2, (fl & EF_PAIRSTEREO) ? W.th_ln_stereo : W.th_ln_mono, &w);
+        chi += rho0;
+        const double ws = w * s;
+        double Jc[12], Jl[8];
+        line_jac_pose(adj, X1m, X2m, Jc);
+        line_jac_line(adj, quat_rotation(T.q), c0, c1, L.alpha, Jl);
+        int k = 0;
+#pragma unroll
+        for (int a = 0; a < 4; a++) {
+          b[a] -= ws * (Jl[a] * r[0] + Jl[4 + a] * r[1]);
+#pragma unroll
+          for (int d = a; d < 4; d++) H[k++] += ws * (Jl[a] * Jl[d] + Jl[4 + a] * Jl[4 + d]);
+        }
+        if (c < W.n_free) {
+          double* Wb = A.le_W + (size_t)e * 24;
+          double* ac = acc + c * 27;
+          int kk = 0;
+#pragma unroll
+          for (int rr = 0; rr < 6; rr++) {
+#pragma unroll
+            for (int a = 0; a < 4; a++) Wb[rr * 4 + a] = ws * (Jc[rr] * Jl[a] + Jc[6 + rr] * Jl[4 + a]);
+            atomicAdd(&ac[21 + rr], -ws * (Jc[rr] * r[0] + Jc[6 + rr] * r[1]));
+#pragma unroll
+            for (int cc = rr; cc < 6; cc++) atomicAdd(&ac[kk++], ws * (Jc[rr] * Jc[cc] + Jc[6 + rr] * Jc[6 + cc]));
+          }
+        }
+      }
+      double* V = A.ln_V + (size_t)g * 14;
+#pragma unroll
+      for (int i = 0; i < 10; i++) V[i] = H[i];
+#pragma unroll
+      for (int i = 0; i < 4; i++) V[10 + i] = b[i];
+      maxd = fmax(fmax(fabs(H[0]), fabs(H[4])), fmax(fabs(H[7]), fabs(H[9])));
+    }
+  }
+  const double chi_t = block_sum(chi, scratch);
+  const double max_t = block_max(maxd, scratch);
+  if (threadIdx.x == 0) {
+    A.chi_part[W.part_off + blockIdx.x] = chi_t;
+    atomicMax(&S.maxdiag_bits, (unsigned long long)__double_as_longlong(max_t));
+  }
+  __syncthreads();
+  double* gH = A.Hpp + (size_t)W.hpp_off * 21;
+  double* gb = A.bp + (size_t)W.hpp_off * 6;
+  for (int i = threadIdx.x; i < nacc; i += kLmThreads) {
+    const double v = acc[i];
+    if (v != 0.0) {
+      const int c = i / 27, k = i - c * 27;
+      if (k < 21) atomicAdd(&gH[c * 21 + k], v); else atomicAdd(&gb[c * 6 + (k - 21)], v);
+    }
+  }
+}
+
+// LM iteration head (one lane per window): chi2 of the current state, lambda initialisation at iteration 0.
+__global__ void ba_begin_kernel(BAArrays A, const BAWin* __restrict__ wins, BAState* __restrict__ st, int n_windows) {
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= n_windows) return;
+  const BAWin& W = wins[w];
+  BAState& S = st[w];
+  if (S.phase != PH_RUN || !S.need_lin) return;
+  double chi = 0.0;
+  const int nb = W.nb_pt + W.nb_ln;
+  for (int i = 0; i < nb; i++) chi += A.chi_part[W.part_off + i];
+  S.currentChi = chi; S.iniChi = chi;
+  if (S.it == 0) {
+    // computeLambdaInit: tau * max |H_kk| over cameras and landmarks (optimization_algorithm_levenberg.cpp:166-180)
+    double md = __longlong_as_double((long long)S.maxdiag_bits);
+    const double* H = A.Hpp + (size_t)W.hpp_off * 21;
+    for (int c = 0; c < W.n_free; c++) {
+      const double* h = H + c * 21;
+      md = fmax(md, fmax(fmax(fabs(h[0]), fabs(h[6])), fmax(fmax(fabs(h[11]), fabs(h[15])), fmax(fabs(h[18]), fabs(h[20])))));
+    }
+    S.lambda = 1e-5 * md; S.ni = 2.0; S.nBad = 0;
+  }
+  S.q = 0; S.need_lin = 0;
+}
+
+// ================================================================== Schur complement
+// grid (n_rg_max * chunks, nW); dynamic LDS: tile_blocks_max*36 + rows_max*6 doubles.
+// Each workgroup owns the rows [r0,r1) of the upper block triangle of S in LDS and walks the bucket of edges whose
+// camera lies in those rows.  Edge a (camera i, landmark l) contributes  -Y_a W_b^T  to block (i, cam(b)) for every
+// active edge b of l with cam(b) >= i, where Y_a = W_a (Hll + lambda I)^-1; the diagonal receives Hpp + lambda I.
+template <int D> struct LmDim;
+template <> struct LmDim<3> { static constexpr int VN = 9, HU = 6, WN = 18; };
+template <> struct LmDim<4> { static constexpr int VN = 14, HU = 10, WN = 24; };
+
+template <int D>
+__device__ __forceinline__ void schur_edge(const double* __restrict__ V, const double* __restrict__ Wall, const int* __restrict__ ecam,
+                                           const uint8_t* __restrict__ eflags, int a, int e0, int e1, int i, int n_free, double lambda,
+                                           const RowGroup& G, double* tile, double* cacc, int row_off) {
+  double F[D * D], Di[D * D];
+  unpack_sym<D>(V, lambda, F);
+  spd_inverse<D>(F, Di);
+  const double* Wa = Wall + (size_t)a * (6 * D);
+  double Y[6 * D];
+#pragma unroll
+  for (int r = 0; r < 6; r++)
+#pragma unroll
+    for (int k = 0; k < D; k++) {
+      double s = 0.0;
+#pragma unroll
+      for (int j = 0; j < D; j++) s += Wa[r * D + j] * Di[j * D + k];
+      Y[r * D + k] = s;
+    }
+  const double* bl = V + LmDim<D>::HU;
+#pragma unroll
+  for (int r = 0; r < 6; r++) {
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < D; k++) s += Y[r * D + k] * bl[k];
+    atomicAdd(&cacc[(i - G.r0) * 6 + r], s);
+  }
+  for (int b = e0; b < e1; b++) {
+    const uint8_t fb = eflags[b];
+    if (!(fb & EF_VALID) || (fb & EF_LEVEL1)) continue;
+    const int j = ecam[b];
+    if (j >= n_free || j < i) continue;
+    const double* Wb = Wall + (size_t)b * (6 * D);
+    double wb[6 * D];
+#pragma unroll
+    for (int t = 0; t < 6 * D; t++) wb[t] = Wb[t];
+    double* blk = tile + (size_t)(row_off + (j - i)) * 36;
+#pragma unroll
+    for (int r = 0; r < 6; r++)
+#pragma unroll
+      for (int c = 0; c < 6; c++) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < D; k++) s += Y[r * D + k] * wb[c * D + k];
+        atomicAdd(&blk[r * 6 + c], -s);
+      }
+  }
+}
+
+__global__ __launch_bounds__(kSchurThreads) void ba_schur_kernel(BAArrays A, const BAWin* __restrict__ wins, const BAState* __restrict__ st,
+                                                                 const RowGroup* __restrict__ rgs, int chunks) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const BAWin W = wins[blockIdx.y];
+  const BAState& S = st[blockIdx.y];
+  if (S.phase != PH_RUN) return;
+  const int gi = blockIdx.x / chunks, ch = blockIdx.x - gi * chunks;
+  if (gi >= W.n_rg) return;
+  const RowGroup G = rgs[W.rg_off + gi];
+  const int nf = W.n_free, n = 6 * nf;
+  double* tile = lds;
+  double* cacc = lds + (size_t)G.tile_blocks * 36;
+  const int rows = G.r1 - G.r0;
+  for (int i = threadIdx.x; i < G.tile_blocks * 36 + rows * 6; i += kSchurThreads) lds[i] = 0.0;
+  __syncthreads();
+  const double lambda = S.lambda;
+  // row_off(i) = sum_{r=r0}^{i-1} (nf - r)
+  auto row_off = [&](int i) { const int k = i - G.r0; return k * nf - (G.r0 * k + k * (k - 1) / 2); };
+  for (int t = ch * kSchurThreads + threadIdx.x; t < G.pe_n; t += chunks * kSchurThreads) {
+    const int a = A.rg_pe[G.pe_off + t];
+    const uint8_t fl = A.pe_flags[a];
+    if (fl & EF_LEVEL1) continue;
+    const int g = W.pt_off + A.pe_pt[a];
+    const int i = A.pe_cam[a];
+    schur_edge<3>(A.pt_V + (size_t)g * 9, A.pe_W, A.pe_cam, A.pe_flags, a, A.pt_obs_start[g], A.pt_obs_start[g + 1], i, nf, lambda, G,
+                  tile, cacc, row_off(i));
+  }
+  for (int t = ch * kSchurThreads + threadIdx.x; t < G.le_n; t += chunks * kSchurThreads) {
+    const int a = A.rg_le[G.le_off + t];
+    const uint8_t fl = A.le_flags[a];
+    if (!(fl & EF_VALID) || (fl & EF_LEVEL1)) continue;
+    const int g = W.ln_off + A.le_ln[a];
+    const int i = A.le_cam[a];
+    schur_edge<4>(A.ln_V + (size_t)g * 14, A.le_W, A.le_cam, A.le_flags, a, 2 * A.ln_obs_start[g], 2 * A.ln_obs_start[g + 1], i, nf, lambda,
+                  G, tile, cacc, row_off(i));
+  }
+  __syncthreads();
+  // flush: S (full symmetric, row-major n x n) and bschur
+  double* Sg = A.S + W.S_off;
+  double* bs = A.bschur + W.x_off;
+  const double* Hp = A.Hpp + (size_t)W.hpp_off * 21;
+  const double* bpv = A.bp + (size_t)W.hpp_off * 6;
+  const bool lead = (ch == 0);
+  for (int i = G.r0; i < G.r1; i++) {
+    const int ro = row_off(i);
+    const int cnt = (nf - i) * 36;
+    for (int t = threadIdx.x; t < cnt; t += kSchurThreads) {
+      const int jb = t / 36, rc = t - jb * 36, r = rc / 6, c = rc - r * 6;
+      const int j = i + jb;
+      double v = tile[(size_t)(ro + jb) * 36 + rc];
+      if (jb == 0 && lead) {
+        const int lo = r < c ? r : c, hi = r < c ? c : r;
+        v += Hp[i * 21 + (lo * 6 - lo * (lo - 1) / 2 + (hi - lo))];
+        if (r == c) v += lambda;
+      }
+      if (chunks == 1) {
+        Sg[(size_t)(i * 6 + r) * n + j * 6 + c] = v;
+        if (jb > 0) Sg[(size_t)(j * 6 + c) * n + i * 6 + r] = v;
+      } else if (v != 0.0) {
+        atomicAdd(&Sg[(size_t)(i * 6 + r) * n + j * 6 + c], v);
+        if (jb > 0) atomicAdd(&Sg[(size_t)(j * 6 + c) * n + i * 6 + r], v);
+      }
+    }
+    for (int r = threadIdx.x; r < 6; r += kSchurThreads) {
+      const double v = (lead ? bpv[i * 6 + r] : 0.0) - cacc[(i - G.r0) * 6 + r];
+      if (chunks == 1) bs[i * 6 + r] = v; else atomicAdd(&bs[i * 6 + r], v);
+    }
+  }
+}
+
+// ================================================================== PCG on the reduced camera system
+// grid (nW); block kPcgThreads; dynamic LDS: 5n + nf*36 + 32 doubles.  Block-Jacobi preconditioner (inverse 6x6 diagonal
+// blocks), fixed reduction trees, stops at |r|_M <= tol |b|_M.  On exit it applies VertexSE3Expmap::oplusImpl to the free
+// cameras (trial buffer) and leaves sum x(lambda x + b) of the camera part for computeScale.
+__global__ __launch_bounds__(kPcgThreads) void ba_pcg_kernel(BAArrays A, const BAWin* __restrict__ wins, BAState* __restrict__ st, double tol,
+                                                            int max_iter_param) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const BAWin W = wins[blockIdx.x];
+  BAState& S = st[blockIdx.x];
+  if (S.phase != PH_RUN) return;
+  const int nf = W.n_free, n = 6 * nf;
+  double* x = lds; double* r = x + n; double* z = r + n; double* p = z + n; double* Ap = p + n;
+  double* Mi = Ap + n;                 // nf * 36
+  double* scratch = Mi + nf * 36;      // 32
+  const double* Sg = A.S + W.S_off;
+  const double* bs = A.bschur + W.x_off;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = kPcgThreads >> 6;
+  double* ok_s = scratch + 31;         // keeps every LDS object inside the (16-B aligned) dynamic region
+  if (tid == 0) *ok_s = 1.0;
+  __syncthreads();
+  if (tid < nf) {
+    double F[36], Fi[36];
+#pragma unroll
+    for (int rr = 0; rr < 6; rr++)
+#pragma unroll
+      for (int c = 0; c < 6; c++) F[rr * 6 + c] = Sg[(size_t)(tid * 6 + rr) * n + tid * 6 + c];
+    if (!spd_inverse<6>(F, Fi)) *ok_s = 0.0;
+#pragma unroll
+    for (int i = 0; i < 36; i++) Mi[tid * 36 + i] = Fi[i];
+  }
+  if (tid < n) { x[tid] = 0.0; r[tid] = bs[tid]; }
+  __syncthreads();
+  auto precond = [&]() {               // z = M^-1 r
+    if (tid < n) {
+      const int b = tid / 6, rr = tid - b * 6;
+      double s = 0.0;
+#pragma unroll
+      for (int c = 0; c < 6; c++) s += Mi[b * 36 + rr * 6 + c] * r[b * 6 + c];
+      z[tid] = s;
+    }
+  };
+  precond();
+  __syncthreads();
+  if (tid < n) p[tid] = z[tid];
+  double rz = block_sum(tid < n ? r[tid] * z[tid] : 0.0, scratch);
+  const double rz0 = rz;
+  const int max_iter = max_iter_param > 0 ? max_iter_param : 10 * n;
+  int iters = 0;
+  bool ok = *ok_s != 0.0 && isfinite(rz0);
+  if (ok && rz0 > 0.0) {
+    const double stop = tol * tol * rz0;
+    for (; iters < max_iter;) {
+      // Ap = S p : one wavefront per row, lanes across columns (coalesced 512-B row segments)
+      for (int row = wave; row < n; row += nwaves) {
+        const double* Sr = Sg + (size_t)row * n;
+        double s = 0.0;
+        for (int c = lane; c < n; c += 64) s += Sr[c] * p[c];
+        s = wave_sum(s);
+        if (lane == 0) Ap[row] = s;
+      }
+      __syncthreads();
+      const double pAp = block_sum(tid < n ? p[tid] * Ap[tid] : 0.0, scratch);
+      if (!(pAp > 0.0) || !isfinite(pAp)) { ok = false; break; }
+      const double alpha = rz / pAp;
+      if (tid < n) { x[tid] += alpha * p[tid]; r[tid] -= alpha * Ap[tid]; }
+      __syncthreads();
+      precond();
+      __syncthreads();
+      const double rz_new = block_sum(tid < n ? r[tid] * z[tid] : 0.0, scratch);
+      iters++;
+      if (!isfinite(rz_new)) { ok = false; break; }
+      if (rz_new <= stop) break;
+      const double beta = rz_new / rz;
+      rz = rz_new;
+      if (tid < n) p[tid] = z[tid] + beta * p[tid];
+      __syncthreads();
+    }
+  }
+  __syncthreads();
+  // solution, camera update into the trial buffer, camera part of computeScale
+  const double lambda = S.lambda;
+  const double* bpv = A.bp + (size_t)W.hpp_off * 6;
+  double sc = 0.0;
+  if (tid < n) { A.xp[W.x_off + tid] = x[tid]; sc = x[tid] * (lambda * x[tid] + bpv[tid]); }
+  const double sc_t = block_sum(sc, scratch);
+  const int cur = S.cur, nxt = cur ^ 1;
+  if (tid < W.n_cams) {
+    const Pose T = load_cam(A, cur, W.cam_off + tid);
+    Pose Tn = T;
+    if (tid < nf) Tn = pose_oplus(T, x + tid * 6);
+    pose_store(Tn, A.cam_qt + ((size_t)nxt * A.NC + W.cam_off + tid) * 7);
+  }
+  if (tid == 0) { S.scale_cam = sc_t; S.pcg_ok = ok ? 1 : 0; S.pcg_iterations += iters; }
+}
+
+// ================================================================== back-substitution + update + trial chi2
+// grid (nb_pt + nb_ln, nW): x_l = (Hll + lambda I)^-1 (b_l - sum_e W_e^T x_cam(e)), landmark oplus into the trial buffer,
+// then computeActiveErrors / activeRobustChi2 of the lane's edges at the trial state.
+__global__ __launch_bounds__(kLmThreads) void ba_backsub_kernel(BAArrays A, const BAWin* __restrict__ wins, const BAState* __restrict__ st) {
+  __shared__ double scratch[8];
+  const BAWin W = wins[blockIdx.y];
+  const BAState& S = st[blockIdx.y];
+  if (S.phase != PH_RUN) return;
+  if ((int)blockIdx.x >= W.nb_pt + W.nb_ln) return;
+  const int cur = S.cur, nxt = cur ^ 1;
+  const double lambda = S.lambda;
+  const CamK cam = W.cam;
+  const double* xp = A.xp + W.x_off;
+  double chi = 0.0, sc = 0.0;
+  if ((int)blockIdx.x < W.nb_pt) {
+    const int p = blockIdx.x * kLmThreads + threadIdx.x;
+    const int g = W.pt_off + p;
+    if (p < W.n_pt) {
+      const Vec3 X = load_pt(A, cur, g);
+      if (!A.pt_active[g]) store_pt(A, nxt, g, X);
+      else {
+        const double* V = A.pt_V + (size_t)g * 9;
+        double F[9], Di[9];
+        unpack_sym<3>(V, lambda, F);
+        spd_inverse<3>(F, Di);
+        double t[3] = {V[6], V[7], V[8]};
+        const int e0 = A.pt_obs_start[g], e1 = A.pt_obs_start[g + 1];
+        for (int e = e0; e < e1; e++) {
+          if (A.pe_flags[e] & EF_LEVEL1) continue;
+          const int c = A.pe_cam[e];
+          if (c >= W.n_free) continue;
+          const double* Wb = A.pe_W + (size_t)e * 18;
+#pragma unroll
+          for (int k = 0; k < 3; k++) {
+            double s = 0.0;
+#pragma unroll
+            for (int r = 0; r < 6; r++) s += Wb[r * 3 + k] * xp[c * 6 + r];
+            t[k] -= s;
+          }
+        }
+        double xl[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) xl[i] = Di[i * 3] * t[0] + Di[i * 3 + 1] * t[1] + Di[i * 3 + 2] * t[2];
+#pragma unroll
+        for (int i = 0; i < 3; i++) sc += xl[i] * (lambda * xl[i] + V[6 + i]);
+        const Vec3 Xn = vec3(X.x + xl[0], X.y + xl[1], X.z + xl[2]);      // VertexSBAPointXYZ::oplusImpl
+        store_pt(A, nxt, g, Xn);
+        for (int e = e0; e < e1; e++) {
+          const uint8_t fl = A.pe_flags[e];
+          if (fl & EF_LEVEL1) continue;
+          const Pose T = load_cam(A, nxt, W.cam_off + A.pe_cam[e]);
+          const Vec3 Xc = pose_map(T, Xn);
+          const double urv = A.pe_ur[e];
+          const bool stereo = !(urv < 0);
+          double r[3];
+          point_residual(cam, Xc, A.pe_u[e], A.pe_v[e], urv, stereo, true, r);
+          const double c2 = chi2_of(r, stereo ? 3 : 2, A.pe_s[e]);
+          A.pe_chi2[e] = c2;
+          double w, rho0 = c2;
+          if (fl & EF_ROBUST) rho0 = huber(c2, stereo ? W.th_stereo : W.th_mono, &w);
+          chi += rho0;
+        }
+      }
+    }
+  } else {
+    const int l = (blockIdx.x - W.nb_pt) * kLmThreads + threadIdx.x;
+    const int g = W.ln_off + l;
+    if (l < W.n_ln) {
+      const LineQ L = load_ln(A, cur, g);
+      if (!A.ln_active[g]) store_ln(A, nxt, g, L);
+      else {
+        const double* V = A.ln_V + (size_t)g * 14;
+        double F[16], Di[16];
+        unpack_sym<4>(V, lambda, F);
+        spd_inverse<4>(F, Di);
+        double t[4] = {V[10], V[11], V[12], V[13]};
+        const int e0 = 2 * A.ln_obs_start[g], e1 = 2 * A.ln_obs_start[g + 1];
+        for (int e = e0; e < e1; e++) {
+          const uint8_t fl = A.le_flags[e];
+          if (!(fl & EF_VALID) || (fl & EF_LEVEL1)) continue;
+          const int c = A.le_cam[e];
+          if (c >= W.n_free) continue;
+          const double* Wb = A.le_W + (size_t)e * 24;
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            double s = 0.0;
+#pragma unroll
+            for (int r = 0; r < 6; r++) s += Wb[r * 4 + k] * xp[c * 6 + r];
+            t[k] -= s;
+          }
+        }
+        double xl[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) xl[i] = Di[i * 4] * t[0] + Di[i * 4 + 1] * t[1] + Di[i * 4 + 2] * t[2] + Di[i * 4 + 3] * t[3];
+#pragma unroll
+        for (int i = 0; i < 4; i++) sc += xl[i] * (lambda * xl[i] + V[10 + i]);
+        const LineQ Ln = line_oplus(L, xl);
+        store_ln(A, nxt, g, Ln);
+        const Mat3 Rl = line_rotation(Ln);
+        const Vec3 c1 = mat_col(Rl, 1);
+        const Vec3 X1 = Ln.alpha * c1, X2 = X1 + mat_col(Rl, 0);
+        for (int e = e0; e < e1; e++) {
+          const uint8_t fl = A.le_flags[e];
+          if (!(fl & EF_VALID) || (fl & EF_LEVEL1)) continue;
+          const Pose T = load_cam(A, nxt, W.cam_off + A.le_cam[e]);
+          double r[2];
+          line_residual(cam, A.le_bx[e], pose_map(T, X1), pose_map(T, X2), A.le_xs[e], A.le_ys[e], A.le_xe[e], A.le_ye[e], r, nullptr);
+          const double c2 = chi2_of(r, 2, A.le_s[e]);
+          A.le_chi2[e] = c2;
+          double w, rho0 = c2;
+          if (fl & EF_ROBUST) rho0 = huber(c2, (fl & EF_PAIRSTEREO) ? W.th_ln_stereo : W.th_ln_mono, &w);
+          chi += rho0;
+        }
+      }
+    }
+  }
+  const double chi_t = block_sum(chi, scratch);
+  const double sc_t = block_sum(sc, scratch);
+  if (threadIdx.x == 0) { A.chi_part2[W.part_off + blockIdx.x] = chi_t; A.scale_part[W.part_off + blockIdx.x] = sc_t; }
+}
+
+// ================================================================== LM control
+// grid (nW), block 64: lane 0 takes the accept / reject decision of the trial that just ran
+// (optimization_algorithm_levenberg.cpp:118-163) and advances the window's state machine; all lanes then clear the
+// camera accumulators when a new linearisation is due.
+__global__ __launch_bounds__(kCtlThreads) void ba_control_kernel(BAArrays A, const BAWin* __restrict__ wins, BAState* __restrict__ st, int abort_flag) {
+  __shared__ int do_clear;
+  const BAWin& W = wins[blockIdx.x];
+  BAState& S = st[blockIdx.x];
+  if (threadIdx.x == 0) do_clear = 0;
+  __syncthreads();
+  if (threadIdx.x == 0 && S.phase == PH_RUN) {
+    const int nb = W.nb_pt + W.nb_ln;
+    double tempChi = 0.0, scale = S.scale_cam;
+    for (int i = 0; i < nb; i++) tempChi += A.chi_part2[W.part_off + i];
+    for (int i = 0; i < nb; i++) scale += A.scale_part[W.part_off + i];
+    if (!S.pcg_ok) tempChi = 1.7976931348623157e308;
+    double rho = (S.currentChi - tempChi);
+    scale += 1e-3;
+    rho /= scale;
+    if (rho > 0 && isfinite(tempChi)) {
+      double alpha = 1. - (2 * rho - 1) * (2 * rho - 1) * (2 * rho - 1);
+      alpha = fmin(alpha, 2. / 3.);
+      S.lambda *= fmax(1. / 3., alpha);
+      S.ni = 2;
+      S.currentChi = tempChi;
+      S.cur ^= 1;                                  // discardTop: the trial buffer becomes the state
+    } else {
+      S.lambda *= S.ni; S.ni *= 2;                 // pop: keep the old buffer
+    }
+    S.q++;
+    const int round = S.round;
+    S.lm_trials[round]++;
+    const bool again = (rho < 0 && S.q < W.max_trials && !abort_flag);
+    if (!again) {
+      bool term = (S.q == W.max_trials || rho == 0);
+      if (!term) {
+        if ((S.iniChi - S.currentChi) * 1e3 < S.iniChi) S.nBad++; else S.nBad = 0;
+        if (S.nBad >= 3) term = true;
+      }
+      S.it++;
+      S.lm_iterations[round]++;
+      if (!term && S.it < W.its[round] && !abort_flag) { S.need_lin = 1; S.maxdiag_bits = 0ull; do_clear = 1; }
+      else if (round == 0) {
+        S.chi2_round1 = S.currentChi; S.chi2_final = S.currentChi;
+        if (abort_flag) { S.aborted = 1; S.phase = PH_FINALIZE; } else S.phase = PH_TRANSITION;
+      } else { S.chi2_final = S.currentChi; S.phase = PH_FINALIZE; }
+    }
+  }
+  __syncthreads();
+  if (do_clear) {
+    for (int i = threadIdx.x; i < W.n_free * 21; i += kCtlThreads) A.Hpp[(size_t)W.hpp_off * 21 + i] = 0.0;
+    for (int i = threadIdx.x; i < W.n_free * 6; i += kCtlThreads) A.bp[(size_t)W.hpp_off * 6 + i] = 0.0;
+  }
+  if (threadIdx.x == 0) {
+    const int ph = S.phase;
+    if (ph == PH_RUN) atomicAdd(&A.counters[0], 1);
+    else if (ph == PH_TRANSITION) atomicAdd(&A.counters[1], 1);
+    else if (ph == PH_FINALIZE) atomicAdd(&A.counters[2], 1);
+  }
+}
+
+// ================================================================== classification between the rounds
+// grid (nb_pt + nb_ln, nW), windows in PH_TRANSITION only.
+__global__ __launch_bounds__(kLmThreads) void ba_classify_kernel(BAArrays A, const BAWin* __restrict__ wins, BAState* __restrict__ st) {
+  __shared__ double scratch[8];
+  const BAWin W = wins[blockIdx.y];
+  BAState& S = st[blockIdx.y];
+  if (S.phase != PH_TRANSITION) return;
+  if ((int)blockIdx.x >= W.nb_pt + W.nb_ln) return;
+  const int cur = S.cur;
+  const CamK cam = W.cam;
+  double n_active = 0.0;
+  if ((int)blockIdx.x < W.nb_pt) {
+    const int p = blockIdx.x * kLmThreads + threadIdx.x;
+    const int g = W.pt_off + p;
+    if (p < W.n_pt) {
+      const Vec3 X = load_pt(A, cur, g);
+      int act = 0;
+      for (int e = A.pt_obs_start[g]; e < A.pt_obs_start[g + 1]; e++) {
+        uint8_t fl = A.pe_flags[e];
+        const Pose T = load_cam(A, cur, W.cam_off + A.pe_cam[e]);
+        const bool depth_pos = pose_map(T, X).z > 0.0;
+        const bool stereo = !(A.pe_ur[e] < 0);
+        if (A.pe_chi2[e] > (stereo ? 7.815 : 5.991) || !depth_pos) fl |= EF_LEVEL1;      // Optimizer.cc:1246,1260
+        fl &= (uint8_t)~EF_ROBUST;                                                       // e->setRobustKernel(0)
+        A.pe_flags[e] = fl;
+        if (!(fl & EF_LEVEL1)) act++;
+      }
+      A.pt_active[g] = act > 0;
+      n_active += act;
+    }
+  } else {
+    const int l = (blockIdx.x - W.nb_pt) * kLmThreads + threadIdx.x;
+    const int g = W.ln_off + l;
+    if (l < W.n_ln) {
+      const LineQ L = load_ln(A, cur, g);
+      const Mat3 Rl = line_rotation(L);
+      const Vec3 c0 = mat_col(Rl, 0), c1 = mat_col(Rl, 1);
+      const int e0 = 2 * A.ln_obs_start[g], e1 = 2 * A.ln_obs_start[g + 1];
+      int cnt = 0, act = 0; bool has_edge = false;
+      for (int e = e0; e < e1; e++) {
+        uint8_t fl = A.le_flags[e];
+        if (!(fl & EF_VALID)) continue;
+        has_edge = true;
+        const double th = (fl & EF_PAIRSTEREO) ? W.th_ln_stereo : W.th_ln_mono;
+        const Pose T = load_cam(A, cur, W.cam_off + A.le_cam[e]);
+        const bool depth_pos = line_depth_positive(cam, A.le_bx[e], T, c0, c1, L.alpha, A.le_xs[e], A.le_ys[e], A.le_xe[e], A.le_ye[e]);
+        if (A.le_chi2[e] > th * th || !depth_pos) fl |= EF_LEVEL1; else { cnt += 2; act++; }      // LineOptimizer.cc:141-153
+        fl &= (uint8_t)~EF_ROBUST;
+        A.le_flags[e] = fl;
+      }
+      const bool removed = has_edge && cnt <= W.ln_filter;                                          // LineOptimizer.cc:156-168
+      if (removed) {
+        for (int e = e0; e < e1; e++) if (A.le_flags[e] & EF_VALID) A.le_flags[e] |= EF_LEVEL1;
+        act = 0;
+      }
+      A.ln_removed[g] = removed;
+      A.ln_active[g] = act > 0;
+      n_active += act;
+    }
+  }
+  const double t = block_sum(n_active, scratch);
+  if (threadIdx.x == 0 && t > 0.0) atomicAdd(&S.n_active_edges, (int)(t + 0.5));
+}
+
+// After classification: start round 2 (initializeOptimization(0); optimize(its[1])).
+__global__ __launch_bounds__(kCtlThreads) void ba_round2_kernel(BAArrays A, const BAWin* __restrict__ wins, BAState* __restrict__ st) {
+  const BAWin& W = wins[blockIdx.x];
+  BAState& S = st[blockIdx.x];
+  if (S.phase != PH_TRANSITION) return;
+  __syncthreads();
+  for (int i = threadIdx.x; i < W.n_free * 21; i += kCtlThreads) A.Hpp[(size_t)W.hpp_off * 21 + i] = 0.0;
+  for (int i = threadIdx.x; i < W.n_free * 6; i += kCtlThreads) A.bp[(size_t)W.hpp_off * 6 + i] = 0.0;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    S.round = 1; S.it = 0; S.q = 0; S.need_lin = 1; S.maxdiag_bits = 0ull;
+    S.phase = S.n_active_edges > 0 ? PH_RUN : PH_FINALIZE;        // optimize() returns -1 on an empty active set
+  }
+}
+
+// ================================================================== final classification + read-back
+struct BARecordHeader {
+  double chi2_round1, chi2_final;
+  int lm_iterations[2], lm_trials[2];
+  int pcg_iterations, aborted, pad0, pad1;
+};
+// record layout (bytes from W.rec_off): header | cam_qt[7*n_cams] | pt[3*n_pt] | x0[3*n_ln] | dir[3*n_ln] |
+//                                       pt_obs_outlier[n_pe] | ln_edge_outlier[n_le] | line_removed[n_ln]
+__device__ __forceinline__ double* rec_cam(unsigned char* r) { return reinterpret_cast<double*>(r + sizeof(BARecordHeader)); }
+
+__global__ __launch_bounds__(kLmThreads) void ba_finalize_kernel(BAArrays A, const BAWin* __restrict__ wins, const BAState* __restrict__ st) {
+  const BAWin W = wins[blockIdx.y];
+  const BAState& S = st[blockIdx.y];
+  if (S.phase != PH_FINALIZE) return;
+  if ((int)blockIdx.x >= W.nb_pt + W.nb_ln + 1) return;
+  const int cur = S.cur;
+  const CamK cam = W.cam;
+  // Optimizer.cc:1220-1222: a stop request before the first optimize() returns without classifying or writing anything
+  const bool untouched = S.aborted && S.lm_trials[0] == 0;
+  unsigned char* rec = A.records + W.rec_off;
+  double* o_cam = rec_cam(rec);
+  double* o_pt = o_cam + 7 * W.n_cams;
+  double* o_x0 = o_pt + 3 * W.n_pt;
+  double* o_dir = o_x0 + 3 * W.n_ln;
+  unsigned char* o_pe = reinterpret_cast<unsigned char*>(o_dir + 3 * W.n_ln);
+  unsigned char* o_le = o_pe + W.n_pe;
+  unsigned char* o_rm = o_le + W.n_le;
+  if ((int)blockIdx.x == W.nb_pt + W.nb_ln) {            // cameras + header
+    for (int i = threadIdx.x; i < W.n_cams * 7; i += kLmThreads) o_cam[i] = A.cam_qt[((size_t)cur * A.NC + W.cam_off) * 7 + i];
+    if (threadIdx.x == 0) {
+      BARecordHeader h;
+      h.chi2_round1 = S.chi2_round1; h.chi2_final = S.chi2_final;
+      h.lm_iterations[0] = S.lm_iterations[0]; h.lm_iterations[1] = S.lm_iterations[1];
+      h.lm_trials[0] = S.lm_trials[0]; h.lm_trials[1] = S.lm_trials[1];
+      h.pcg_iterations = S.pcg_iterations; h.aborted = S.aborted; h.pad0 = 0; h.pad1 = 0;
+      *reinterpret_cast<BARecordHeader*>(rec) = h;
+    }
+    return;
+  }
+  if ((int)blockIdx.x < W.nb_pt) {
+    const int p = blockIdx.x * kLmThreads + threadIdx.x;
+    const int g = W.pt_off + p;
+    if (p < W.n_pt) {
+      const Vec3 X = load_pt(A, cur, g);
+      o_pt[3 * p] = X.x; o_pt[3 * p + 1] = X.y; o_pt[3 * p + 2] = X.z;
+      for (int e = A.pt_obs_start[g]; e < A.pt_obs_start[g + 1]; e++) {
+        const Pose T = load_cam(A, cur, W.cam_off + A.pe_cam[e]);
+        const bool depth_pos = pose_map(T, X).z > 0.0;
+        const bool stereo = !(A.pe_ur[e] < 0);
+        o_pe[e - W.pe_off] = (!untouched && (A.pe_chi2[e] > (stereo ? 7.815 : 5.991) || !depth_pos)) ? 1 : 0;      // Optimizer.cc:1290,1305
+      }
+    }
+  } else {
+    const int l = (blockIdx.x - W.nb_pt) * kLmThreads + threadIdx.x;
+    const int g = W.ln_off + l;
+    if (l < W.n_ln) {
+      const int e0 = 2 * A.ln_obs_start[g], e1 = 2 * A.ln_obs_start[g + 1];
+      const bool removed = A.ln_removed[g] != 0;
+      o_rm[l] = removed;
+      if (removed || untouched) {                                       // GetLineData returns false: nothing updated, nothing erased
+        for (int k = 0; k < 3; k++) { o_x0[3 * l + k] = A.ln_x0[(size_t)g * 3 + k]; o_dir[3 * l + k] = A.ln_dir[(size_t)g * 3 + k]; }
+        for (int e = e0; e < e1; e++) o_le[e - W.le_off] = 0;
+      } else {
+        const LineQ L = load_ln(A, cur, g);
+        const Mat3 Rl = line_rotation(L);
+        const Vec3 c0 = mat_col(Rl, 0), c1 = mat_col(Rl, 1);
+        const Vec3 X1 = L.alpha * c1, X2 = X1 + c0;
+        o_dir[3 * l] = c0.x; o_dir[3 * l + 1] = c0.y; o_dir[3 * l + 2] = c0.z;
+        o_x0[3 * l] = X1.x; o_x0[3 * l + 1] = X1.y; o_x0[3 * l + 2] = X1.z;
+        for (int e = e0; e < e1; e++) {
+          const uint8_t fl = A.le_flags[e];
+          if (!(fl & EF_VALID)) { o_le[e - W.le_off] = 0; continue; }
+          const Pose T = load_cam(A, cur, W.cam_off + A.le_cam[e]);
+          const bool depth_pos = line_depth_positive(cam, A.le_bx[e], T, c0, c1, L.alpha, A.le_xs[e], A.le_ys[e], A.le_xe[e], A.le_ye[e]);
+          double r[2];
+          line_residual(cam, A.le_bx[e], pose_map(T, X1), pose_map(T, X2), A.le_xs[e], A.le_ys[e], A.le_xe[e], A.le_ye[e], r, nullptr);
+          const double c2 = chi2_of(r, 2, A.le_s[e]);
+          A.le_chi2[e] = c2;
+          const double th = (fl & EF_PAIRSTEREO) ? W.th_ln_stereo : W.th_ln_mono;
+          o_le[e - W.le_off] = (c2 > th * th || !depth_pos) ? 1 : 0;                               // LineOptimizer.cc:185-196
+        }
+      }
+    }
+  }
+}
+
+__global__ void ba_mark_done_kernel(BAState* __restrict__ st, int n_windows) {
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w < n_windows && st[w].phase == PH_FINALIZE) st[w].phase = PH_DONE;
+}
+
+}  // namespace lldba
+#endif

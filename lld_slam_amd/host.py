@@ -380,13 +380,14 @@ class BABatch:
         return [stats_dict(s) for s in arr]
 
     def phase_ms(self) -> np.ndarray:
-        ms = np.zeros(5)
+        ms = np.zeros(6)
         check(self.lib.fn("ba_batch_phase_ms")(self.handle, _p(ms, C.c_double)), "ba_batch_phase_ms")
         return ms
 
-    def kernel_stats(self):
+    def kernel_stats(self, kernel: int = 1):
+        """(launches, total ms) of one kernel family of the last solve: 0 linearise, 1 Schur, 2 PCG, 3 backsub, 4 control."""
         n = C.c_int64(0); ms = np.zeros(1)
-        check(self.lib.fn("ba_batch_kernel_stats")(self.handle, C.byref(n), _p(ms, C.c_double)), "ba_batch_kernel_stats")
+        check(self.lib.fn("ba_batch_kernel_stats")(self.handle, kernel, C.byref(n), _p(ms, C.c_double)), "ba_batch_kernel_stats")
         return int(n.value), float(ms[0])
 
     def result_records(self):

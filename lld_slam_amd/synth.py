@@ -112,37 +112,42 @@ def make_ba_window(n_free=50, n_fixed=10, n_points=10000, obs_per_point=6, n_lin
     inv_s2 = inv_level_sigma2().astype(np.float64)
 
     def visible(X, need_right=True):
-        vis = np.zeros((X.shape[0], n_cams), bool)
-        for c in range(n_cams):
-            u, v, z = _project(cam, Rcw[c], tcw[c], X)
+        Xc = np.matmul(Rcw, X.T) + tcw[:, :, None]                           # [cams, 3, n]
+        z = Xc[:, 2, :].T
+        with np.errstate(divide='ignore', invalid='ignore'):
+            u = fx * Xc[:, 0, :].T / z + cx
+            v = fy * Xc[:, 1, :].T / z + cy
             ok = (z > 1.0) & (u >= 0) & (u < IMG_W) & (v >= 0) & (v < IMG_H)
             if need_right:
                 ok &= (u - bf / z) >= 0
-            vis[:, c] = ok
-        return vis
+        return ok
+
+    def pick_nearest(vis, k_seed, n_obs):
+        """For every candidate row: the n_obs visible cameras nearest (in trajectory index) to its seeding camera,
+        ascending camera index; rows with fewer than n_obs visible cameras are dropped.  Returns (row ids, cams)."""
+        ok = vis.sum(1) >= n_obs
+        rows = np.nonzero(ok)[0]
+        if rows.size == 0:
+            return rows, np.zeros((0, n_obs), np.int64)
+        dist = np.abs(traj_of_cam[None, :] - traj_of_cam[k_seed[rows], None]).astype(np.float64)
+        dist = dist + 1e-3 * np.arange(n_cams)[None, :] / n_cams          # stable tie-break: lower camera index first
+        dist[~vis[rows]] = np.inf
+        sel = np.argsort(dist, axis=1, kind='stable')[:, :n_obs]
+        return rows, np.sort(sel, axis=1)
 
     # ---------------- points
-    pts = np.zeros((0, 3)); pts_cams = []
+    pts = np.zeros((0, 3)); pts_cams = np.zeros((0, obs_per_point), np.int64)
     while pts.shape[0] < n_points:
         m = int((n_points - pts.shape[0]) * 1.6) + 64
         k = rng.integers(0, n_cams, m)
         u = rng.uniform(0, IMG_W, m); v = rng.uniform(0, IMG_H, m); d = rng.uniform(4.0, 60.0, m)
         Xc = np.stack([(u - cx) / fx * d, (v - cy) / fy * d, d], 1)
         X = np.einsum('nij,nj->ni', np.transpose(Rcw[k], (0, 2, 1)), Xc - tcw[k])
-        vis = visible(X)
-        for i in range(m):
-            cams = np.nonzero(vis[i])[0]
-            if cams.size < obs_per_point:
-                continue
-            # nearest in trajectory index to the seeding camera
-            dist = np.abs(traj_of_cam[cams] - traj_of_cam[k[i]])
-            sel = cams[np.argsort(dist, kind='stable')[:obs_per_point]]
-            pts_cams.append(np.sort(sel))
-            pts = np.vstack([pts, X[i:i + 1]])
-            if pts.shape[0] == n_points:
-                break
+        rows, sel = pick_nearest(visible(X), k, obs_per_point)
+        take = min(rows.size, n_points - pts.shape[0])
+        pts = np.vstack([pts, X[rows[:take]]]); pts_cams = np.vstack([pts_cams, sel[:take]])
     pt_obs_start = np.arange(0, (n_points + 1) * obs_per_point, obs_per_point, dtype=np.int32)
-    pt_obs_cam = np.concatenate(pts_cams).astype(np.int32) if n_points else np.zeros(0, np.int32)
+    pt_obs_cam = pts_cams.reshape(-1).astype(np.int32)
     n_pt_obs = pt_obs_cam.size
     pt_of_obs = np.repeat(np.arange(n_points), obs_per_point)
     Xo = pts[pt_of_obs]
@@ -164,7 +169,7 @@ def make_ba_window(n_free=50, n_fixed=10, n_points=10000, obs_per_point=6, n_lin
     pt_obs_inv_sigma2 = inv_s2[octv]
 
     # ---------------- lines
-    lA = np.zeros((0, 3)); lB = np.zeros((0, 3)); ln_cams = []
+    lA = np.zeros((0, 3)); lB = np.zeros((0, 3)); ln_cams = np.zeros((0, obs_per_line), np.int64)
     while lA.shape[0] < n_lines:
         m = int((n_lines - lA.shape[0]) * 2.0) + 64
         k = rng.integers(0, n_cams, m)
@@ -174,19 +179,11 @@ def make_ba_window(n_free=50, n_fixed=10, n_points=10000, obs_per_point=6, n_lin
         dirv = rng.normal(size=(m, 3)); dirv /= np.linalg.norm(dirv, axis=1, keepdims=True)
         L = rng.uniform(1.0, 5.0, m)
         A = M - 0.5 * L[:, None] * dirv; B = M + 0.5 * L[:, None] * dirv
-        vis = visible(A) & visible(B)
-        for i in range(m):
-            cams = np.nonzero(vis[i])[0]
-            if cams.size < obs_per_line:
-                continue
-            dist = np.abs(traj_of_cam[cams] - traj_of_cam[k[i]])
-            sel = cams[np.argsort(dist, kind='stable')[:obs_per_line]]
-            ln_cams.append(np.sort(sel))
-            lA = np.vstack([lA, A[i:i + 1]]); lB = np.vstack([lB, B[i:i + 1]])
-            if lA.shape[0] == n_lines:
-                break
+        rows, sel = pick_nearest(visible(A) & visible(B), k, obs_per_line)
+        take = min(rows.size, n_lines - lA.shape[0])
+        lA = np.vstack([lA, A[rows[:take]]]); lB = np.vstack([lB, B[rows[:take]]]); ln_cams = np.vstack([ln_cams, sel[:take]])
     ln_obs_start = np.arange(0, (n_lines + 1) * obs_per_line, obs_per_line, dtype=np.int32)
-    ln_obs_cam = np.concatenate(ln_cams).astype(np.int32) if n_lines else np.zeros(0, np.int32)
+    ln_obs_cam = ln_cams.reshape(-1).astype(np.int32)
     n_ln_obs = ln_obs_cam.size
     ln_of_obs = np.repeat(np.arange(n_lines), obs_per_line)
 
