@@ -80,6 +80,7 @@ def main():
     ap.add_argument("--windows-per-gpu", type=int, default=256)
     ap.add_argument("--cpu-sample", type=int, default=10, help="LBA-B windows timed on the CPU oracle (rank 0, N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gen-workers", type=int, default=0, help="processes generating the synthetic windows (0 = auto; use 1 under rocprofv3)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -91,7 +92,7 @@ def main():
     # ---- synthetic windows for this rank (generated before anything touches the GPU)
     wpg = args.windows_per_gpu
     ncpu = os.cpu_count() or 1
-    workers = max(1, min(16, ncpu // max(1, n_gpus)))
+    workers = args.gen_workers if args.gen_workers > 0 else max(1, min(16, ncpu // max(1, n_gpus)))
     t0 = time.time()
     windows = generate_windows(rank * wpg, wpg, workers)
     gen_s = time.time() - t0

@@ -145,15 +145,31 @@ int lld_ba_batch_create(lld_ctx* ctx, int n_windows, const lld_ba_window* wins, 
         if (r1 == r0) { delete B; return LLD_ERR_UNSUPPORTED; }
         RowGroup G; std::memset(&G, 0, sizeof G);
         G.r0 = r0; G.r1 = r1; G.tile_blocks = blocks;
-        G.pe_off = (int)rg_pe.size();
-        for (int o = 0; o < w.n_pt_obs; o++) { const int c = w.pt_obs_cam[o]; if (c >= r0 && c < r1) rg_pe.push_back((int)NPE + o); }
-        G.pe_n = (int)rg_pe.size() - G.pe_off;
-        G.le_off = (int)rg_le.size();
-        for (int o = 0; o < w.n_ln_obs; o++) {
-          const int c = w.ln_obs_cam[o];
-          if (c >= r0 && c < r1) { rg_le.push_back((int)(2 * (NLO + o))); if (!(w.ln_obs_right[4 * (size_t)o] < 0)) rg_le.push_back((int)(2 * (NLO + o) + 1)); }
+        // Bucket order: round-robin over the group's cameras, so the 64 lanes of a wavefront mostly hold edges of DIFFERENT
+        // cameras and their LDS atomics land in different block rows of the tile (same-address atomics serialise).
+        auto interleave = [&](std::vector<std::vector<int>>& per_cam, std::vector<int>& out_list) {
+          size_t longest = 0;
+          for (auto& v : per_cam) longest = std::max(longest, v.size());
+          for (size_t k = 0; k < longest; k++)
+            for (auto& v : per_cam) if (k < v.size()) out_list.push_back(v[k]);
+        };
+        {
+          std::vector<std::vector<int>> per_cam(r1 - r0);
+          for (int o = 0; o < w.n_pt_obs; o++) { const int c = w.pt_obs_cam[o]; if (c >= r0 && c < r1) per_cam[c - r0].push_back((int)NPE + o); }
+          G.pe_off = (int)rg_pe.size();
+          interleave(per_cam, rg_pe);
+          G.pe_n = (int)rg_pe.size() - G.pe_off;
         }
-        G.le_n = (int)rg_le.size() - G.le_off;
+        {
+          std::vector<std::vector<int>> per_cam(r1 - r0);
+          for (int o = 0; o < w.n_ln_obs; o++) {
+            const int c = w.ln_obs_cam[o];
+            if (c >= r0 && c < r1) { per_cam[c - r0].push_back((int)(2 * (NLO + o))); if (!(w.ln_obs_right[4 * (size_t)o] < 0)) per_cam[c - r0].push_back((int)(2 * (NLO + o) + 1)); }
+          }
+          G.le_off = (int)rg_le.size();
+          interleave(per_cam, rg_le);
+          G.le_n = (int)rg_le.size() - G.le_off;
+        }
         B->h_rgs.push_back(G);
         B->max_tile_blocks = std::max(B->max_tile_blocks, blocks);
         B->max_rows = std::max(B->max_rows, r1 - r0);
@@ -230,7 +246,7 @@ int lld_ba_batch_create(lld_ctx* ctx, int n_windows, const lld_ba_window* wins, 
   {
     const size_t schur_lds = ((size_t)B->max_tile_blocks * 36 + (size_t)B->max_rows * 6) * sizeof(double);
     LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_schur_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)schur_lds));
-    const size_t pcg_lds = ((size_t)B->max_free * 6 * 5 + (size_t)B->max_free * 36 + 32) * sizeof(double);
+    const size_t pcg_lds = ((size_t)B->max_free * 6 * 4 + kPcgThreads + (size_t)B->max_free * 36 + 32) * sizeof(double);
     LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_pcg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pcg_lds));
   }
   LLD_HIP_TRY(hipMemcpyAsync(B->d_wins, B->h_wins.data(), sizeof(BAWin) * n_windows, hipMemcpyHostToDevice, st));
@@ -265,7 +281,7 @@ int lld_ba_batch_solve(lld_ba_batch* B, volatile const int* abort_flag) {
   const bool abort_at_start = abort_flag && *abort_flag;
   const size_t lin_lds = ((size_t)B->max_free * 27 + 8) * sizeof(double);
   const size_t schur_lds = ((size_t)B->max_tile_blocks * 36 + (size_t)B->max_rows * 6) * sizeof(double);
-  const size_t pcg_lds = ((size_t)B->max_free * 6 * 5 + (size_t)B->max_free * 36 + 32) * sizeof(double);
+  const size_t pcg_lds = ((size_t)B->max_free * 6 * 4 + kPcgThreads + (size_t)B->max_free * 36 + 32) * sizeof(double);
   const dim3 lm_grid(std::max(1, B->max_lblocks), nW);
   const dim3 fin_grid(B->max_lblocks + 1, nW);
   const int chunks = B->schur_chunks;

@@ -571,7 +571,7 @@ __global__ __launch_bounds__(kSchurThreads) void ba_schur_kernel(BAArrays A, con
 }
 
 // ================================================================== PCG on the reduced camera system
-// grid (nW); block kPcgThreads; dynamic LDS: 5n + nf*36 + 32 doubles.  Block-Jacobi preconditioner (inverse 6x6 diagonal
+// grid (nW); block kPcgThreads; dynamic LDS: 4n + kPcgThreads + nf*36 + 32 doubles.  Block-Jacobi preconditioner (inverse 6x6 diagonal
 // blocks), fixed reduction trees, stops at |r|_M <= tol |b|_M.  On exit it applies VertexSE3Expmap::oplusImpl to the free
 // cameras (trial buffer) and leaves sum x(lambda x + b) of the camera part for computeScale.
 __global__ __launch_bounds__(kPcgThreads) void ba_pcg_kernel(BAArrays A, const BAWin* __restrict__ wins, BAState* __restrict__ st, double tol,
@@ -581,8 +581,8 @@ __global__ __launch_bounds__(kPcgThreads) void ba_pcg_kernel(BAArrays A, const B
   BAState& S = st[blockIdx.x];
   if (S.phase != PH_RUN) return;
   const int nf = W.n_free, n = 6 * nf;
-  double* x = lds; double* r = x + n; double* z = r + n; double* p = z + n; double* Ap = p + n;
-  double* Mi = Ap + n;                 // nf * 36
+  double* x = lds; double* r = x + n; double* z = r + n; double* p = z + n; double* Ap = p + n;   // Ap: kPcgThreads doubles
+  double* Mi = Ap + kPcgThreads;       // nf * 36
   double* scratch = Mi + nf * 36;      // 32
   const double* Sg = A.S + W.S_off;
   const double* bs = A.bschur + W.x_off;
@@ -619,22 +619,32 @@ __global__ __launch_bounds__(kPcgThreads) void ba_pcg_kernel(BAArrays A, const B
   const int max_iter = max_iter_param > 0 ? max_iter_param : 10 * n;
   int iters = 0;
   bool ok = *ok_s != 0.0 && isfinite(rz0);
+  // S is symmetric and stored in full, so y = S p is computed column-wise: lane <-> column c, K row slices per column,
+  // every load is a coalesced 512-B row segment, independent of its neighbours (deep memory-level parallelism), and no
+  // cross-lane reduction is needed: y[c] = sum_k part[k][c] in a fixed order.
+  const int K = max(1, min(8, kPcgThreads / max(n, 1)));
+  const int rows_per = (n + K - 1) / K;
+  const int mv_c = tid % max(n, 1), mv_k = tid / max(n, 1);
+  const bool mv_on = n > 0 && mv_k < K;
+  const int mv_r0 = mv_k * rows_per, mv_r1 = min(n, mv_r0 + rows_per);
+  double* part = Ap;                    // [K][n] partial products live in the Ap..Mi gap: K*n <= kPcgThreads doubles
   if (ok && rz0 > 0.0) {
     const double stop = tol * tol * rz0;
     for (; iters < max_iter;) {
-      // Ap = S p : one wavefront per row, lanes across columns (coalesced 512-B row segments)
-      for (int row = wave; row < n; row += nwaves) {
-        const double* Sr = Sg + (size_t)row * n;
-        double s = 0.0;
-        for (int c = lane; c < n; c += 64) s += Sr[c] * p[c];
-        s = wave_sum(s);
-        if (lane == 0) Ap[row] = s;
+      if (mv_on) {
+        double acc = 0.0;
+        const double* Sc = Sg + mv_c;
+#pragma unroll 4
+        for (int row = mv_r0; row < mv_r1; row++) acc += Sc[(size_t)row * n] * p[row];
+        part[mv_k * n + mv_c] = acc;
       }
       __syncthreads();
-      const double pAp = block_sum(tid < n ? p[tid] * Ap[tid] : 0.0, scratch);
+      double ap = 0.0;
+      if (tid < n) { for (int k = 0; k < K; k++) ap += part[k * n + tid]; }
+      const double pAp = block_sum(tid < n ? p[tid] * ap : 0.0, scratch);
       if (!(pAp > 0.0) || !isfinite(pAp)) { ok = false; break; }
       const double alpha = rz / pAp;
-      if (tid < n) { x[tid] += alpha * p[tid]; r[tid] -= alpha * Ap[tid]; }
+      if (tid < n) { x[tid] += alpha * p[tid]; r[tid] -= alpha * ap; }
       __syncthreads();
       precond();
       __syncthreads();

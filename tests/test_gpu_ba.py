@@ -31,10 +31,10 @@ def check_ba(g, o, w, rtol=RTOL):
     # test_order_sensitivity_is_the_noise_floor), so their bound is 1e-4.
     if w.n_points:
         r = rel(g.pt_xyz, o.pt_xyz)
-        assert np.quantile(r, 0.999) <= rtol and r.max() <= 10 * rtol
+        assert r.max() <= 10 * rtol and np.mean(r <= rtol) >= 0.999
     if w.n_lines:
         r = rel(g.line_x0, o.line_x0)
-        assert np.quantile(r, 0.99) <= rtol and r.max() <= 10 * rtol
+        assert r.max() <= 10 * rtol and np.mean(r <= rtol) >= min(0.99, 1.0 - 1.5 / w.n_lines)
         assert np.linalg.norm(g.line_dir - o.line_dir, axis=1).max() <= 10 * rtol
     # same LM trajectory up to decisions taken on rounding-level chi2 differences at convergence
     assert abs(sum(g.stats["lm_iterations"]) - sum(o.stats["lm_iterations"])) <= 2
