@@ -333,7 +333,7 @@ struct BASystem {
   }
 };
 
-static double f32(double v) { return (double)(float)v; }
+
 
 }  // namespace
 

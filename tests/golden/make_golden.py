@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""Generates the committed golden fixtures (inputs + expected outputs) under tests/golden/.
+
+The reference ships no golden vectors and cannot be built or imported here (C++ needing Eigen/OpenCV), so the expected
+outputs come from (a) independent mathematics where one exists - scipy's matrix exponential, numpy bit counting, numpy
+float arithmetic - and (b) the CPU oracle (oracle/lld_oracle.cpp), itself pinned by tests/test_oracle_kat.py and
+tests/test_oracle_ba.py.  Re-run with:  python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+from scipy.linalg import expm
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+import oracle_py as O  # noqa: E402
+from lld_slam_amd import synth  # noqa: E402
+
+
+def window_arrays(w):
+    return dict(cam=np.array(w.cam), n_free_cams=w.n_free_cams, cam_qt=w.cam_qt, pt_xyz=w.pt_xyz, pt_obs_start=w.pt_obs_start,
+                pt_obs_cam=w.pt_obs_cam, pt_obs_uvr=w.pt_obs_uvr, pt_obs_inv_sigma2=w.pt_obs_inv_sigma2, line_x0=w.line_x0,
+                line_dir=w.line_dir, ln_obs_start=w.ln_obs_start, ln_obs_cam=w.ln_obs_cam, ln_obs_left=w.ln_obs_left,
+                ln_obs_right=w.ln_obs_right, ln_obs_octave=w.ln_obs_octave)
+
+
+def frame_arrays(f):
+    return dict(cam=np.array(f.cam), pose_qt=f.pose_qt, pt_xw=f.pt_xw, pt_uvr=f.pt_uvr, pt_inv_sigma2=f.pt_inv_sigma2, ln_x0=f.ln_x0,
+                ln_dir=f.ln_dir, ln_left=f.ln_left, ln_right=f.ln_right, ln_octave=f.ln_octave)
+
+
+def main():
+    rng = np.random.default_rng(20261001)
+    # --- SE3 exp: scipy expm of the 4x4 twist (independent of the oracle)
+    tw = np.concatenate([rng.normal(0, 0.6, (24, 3)), rng.normal(0, 2.0, (24, 3))], 1)
+    T = []
+    for u in tw:
+        A = np.zeros((4, 4)); A[:3, :3] = np.array([[0, -u[2], u[1]], [u[2], 0, -u[0]], [-u[1], u[0], 0.0]]); A[:3, 3] = u[3:]
+        T.append(expm(A))
+    np.savez(os.path.join(HERE, "se3_exp.npz"), twist=tw, T=np.array(T))
+
+    # --- ORB matching: numpy popcount brute force (independent) + oracle best/second
+    q, t = synth.make_match_orb(100, 160, 230, n_corr=120, n_dup=8)
+    x = q[:, None, :] ^ t[None, :, :]
+    dist = np.unpackbits(x.view(np.uint8), axis=2).sum(2).astype(np.int32)
+    order = np.lexsort((np.broadcast_to(np.arange(t.shape[0]), dist.shape), dist), axis=1)   # by (dist, idx)
+    bi, bd, si, sd = O.match_hamming256(q, t)
+    assert np.array_equal(bi, order[:, 0]) and np.array_equal(si, order[:, 1])
+    assert np.array_equal(bd, np.take_along_axis(dist, order[:, :1], 1)[:, 0])
+    np.savez(os.path.join(HERE, "match_orb.npz"), q=q, t=t, best_idx=bi, best_dist=bd, second_idx=si, second_dist=sd)
+
+    # --- LBD matching: float32 difference, float64 accumulation (numpy, sequential order) + greedy assignment
+    ql, tl = synth.make_match_lbd(100, 50, 70, 72, n_corr=40)
+    d = np.zeros((50, 70))
+    for i in range(50):
+        diff = (ql[i][None, :] - tl).astype(np.float32).astype(np.float64)
+        acc = np.zeros(70)
+        for k in range(72):
+            acc = acc + diff[:, k] * diff[:, k]
+        d[i] = np.sqrt(acc)
+    lbi, lbd, lsi, lsd = O.match_l2f32(ql, tl)
+    assert np.array_equal(lbi, np.argmin(d, 1)) and np.array_equal(lbd, d.min(1))
+    gate = (rng.random((50, 70)) < 0.7).astype(np.uint8)
+    gm, gd = O.line_match_greedy(ql, tl, gate, 2.0)
+    np.savez(os.path.join(HERE, "match_lbd.npz"), q=ql, t=tl, best_idx=lbi, best_dist=lbd, second_idx=lsi, second_dist=lsd,
+             gate=gate, tau=2.0, greedy=gm, greedy_dist=gd)
+
+    # --- PoseOptimization
+    f = synth.make_pose_frame(100, n_points=150, n_lines=30, mono_frac=0.1, mono_line_frac=0.1)
+    r = O.pose_opt(f, gamma=0.5)
+    np.savez(os.path.join(HERE, "pose_small.npz"), gamma=0.5, out_pose_qt=r.pose_qt, out_n_inliers=r.n_inliers, out_pt_outlier=r.pt_outlier,
+             out_ln_outlier=r.ln_outlier, out_chi2=r.chi2, **frame_arrays(f))
+
+    # --- LocalBundleAdjustment
+    w = synth.make_lba_small(100, n_free=5, n_fixed=2, n_points=180, n_lines=36, mono_frac=0.1, mono_line_frac=0.1)
+    b = O.local_ba(w, gamma=1.0)
+    np.savez(os.path.join(HERE, "lba_small.npz"), gamma=1.0, out_cam_qt=b.cam_qt, out_pt_xyz=b.pt_xyz, out_line_x0=b.line_x0,
+             out_line_dir=b.line_dir, out_pt_obs_outlier=b.pt_obs_outlier, out_ln_edge_outlier=b.ln_edge_outlier,
+             out_line_removed=b.line_removed, out_chi2_round1=b.stats["chi2_round1"], out_chi2_final=b.stats["chi2_final"], **window_arrays(w))
+    for n in sorted(os.listdir(HERE)):
+        if n.endswith(".npz"):
+            print(n, os.path.getsize(os.path.join(HERE, n)), "bytes")
+
+
+if __name__ == "__main__":
+    main()
