@@ -116,7 +116,8 @@ typedef struct {
   int32_t max_trials;       /* 10 (maxTrialsAfterFailure, optimization_algorithm_levenberg.cpp:50) */
   double  pcg_rel_tol;      /* reduced-system PCG stops at |r|_M / |b|_M <= tol (GPU only)     */
   int32_t pcg_max_iter;     /* 0 -> 10 * 6 * n_free_cams                                        */
-  int32_t reserved;
+  int32_t reduced_solver;   /* GPU only: 0 = exact block Cholesky (default; the reference factorises exactly,
+                               linear_solver_eigen.h:94-124), 1 = block-Jacobi PCG                 */
 } lld_ba_params;
 
 void lld_ba_params_default(lld_ba_params* p);

@@ -83,7 +83,7 @@ int lld_ba_batch_create(lld_ctx* ctx, int n_windows, const lld_ba_window* wins, 
   B->ctx = ctx; B->n_windows = n_windows;
   if (params) B->params = *params; else lld_ba_params_default(&B->params);
   const lld_ba_params& P = B->params;
-  if (P.its_round1 < 0 || P.its_round2 < 0 || P.max_trials <= 0 || !(P.pcg_rel_tol > 0)) { delete B; return LLD_ERR_INVALID; }
+  if (P.its_round1 < 0 || P.its_round2 < 0 || P.max_trials <= 0 || !(P.pcg_rel_tol > 0) || P.reduced_solver < 0 || P.reduced_solver > 1) { delete B; return LLD_ERR_INVALID; }
 
   // ---- layout + host staging
   std::vector<double> cam_qt0, pt0, ln_x0, ln_dir, pe_u, pe_v, pe_ur, pe_s, le_xs, le_ys, le_xe, le_ye, le_s, le_bx;
@@ -248,6 +248,8 @@ int lld_ba_batch_create(lld_ctx* ctx, int n_windows, const lld_ba_window* wins, 
     LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_schur_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)schur_lds));
     const size_t pcg_lds = ((size_t)B->max_free * 6 * 4 + kPcgThreads + (size_t)B->max_free * 36 + 32) * sizeof(double);
     LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_pcg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pcg_lds));
+    const size_t chol_lds = ((size_t)B->max_free * 36 * 2 + (size_t)B->max_free * 6 * 2 + 32) * sizeof(double);
+    LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_chol_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)chol_lds));
   }
   LLD_HIP_TRY(hipMemcpyAsync(B->d_wins, B->h_wins.data(), sizeof(BAWin) * n_windows, hipMemcpyHostToDevice, st));
   if (!B->h_rgs.empty()) LLD_HIP_TRY(hipMemcpyAsync(B->d_rgs, B->h_rgs.data(), sizeof(RowGroup) * B->h_rgs.size(), hipMemcpyHostToDevice, st));
@@ -282,6 +284,7 @@ int lld_ba_batch_solve(lld_ba_batch* B, volatile const int* abort_flag) {
   const size_t lin_lds = ((size_t)B->max_free * 27 + 8) * sizeof(double);
   const size_t schur_lds = ((size_t)B->max_tile_blocks * 36 + (size_t)B->max_rows * 6) * sizeof(double);
   const size_t pcg_lds = ((size_t)B->max_free * 6 * 4 + kPcgThreads + (size_t)B->max_free * 36 + 32) * sizeof(double);
+  const size_t chol_lds = ((size_t)B->max_free * 36 * 2 + (size_t)B->max_free * 6 * 2 + 32) * sizeof(double);
   const dim3 lm_grid(std::max(1, B->max_lblocks), nW);
   const dim3 fin_grid(B->max_lblocks + 1, nW);
   const int chunks = B->schur_chunks;
@@ -315,7 +318,10 @@ int lld_ba_batch_solve(lld_ba_batch* B, volatile const int* abort_flag) {
     LLD_HIP_TRY(hipEventRecord(B->ev[1], st));
     hipLaunchKernelGGL(ba_schur_kernel, schur_grid, dim3(kSchurThreads), schur_lds, st, A, B->d_wins, B->d_state, B->d_rgs, chunks);
     LLD_HIP_TRY(hipEventRecord(B->ev[2], st));
-    hipLaunchKernelGGL(ba_pcg_kernel, dim3(nW), dim3(kPcgThreads), pcg_lds, st, A, B->d_wins, B->d_state, B->params.pcg_rel_tol, B->params.pcg_max_iter);
+    if (B->params.reduced_solver == 1)
+      hipLaunchKernelGGL(ba_pcg_kernel, dim3(nW), dim3(kPcgThreads), pcg_lds, st, A, B->d_wins, B->d_state, B->params.pcg_rel_tol, B->params.pcg_max_iter);
+    else
+      hipLaunchKernelGGL(ba_chol_kernel, dim3(nW), dim3(kPcgThreads), chol_lds, st, A, B->d_wins, B->d_state);
     LLD_HIP_TRY(hipEventRecord(B->ev[3], st));
     hipLaunchKernelGGL(ba_backsub_kernel, lm_grid, dim3(kLmThreads), 0, st, A, B->d_wins, B->d_state);
     LLD_HIP_TRY(hipEventRecord(B->ev[4], st));

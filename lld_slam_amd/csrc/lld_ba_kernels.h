@@ -570,6 +570,25 @@ __global__ __launch_bounds__(kSchurThreads) void ba_schur_kernel(BAArrays A, con
   }
 }
 
+// Shared tail of the reduced-system solvers: publish x_p, apply VertexSE3Expmap::oplusImpl to the free cameras (trial
+// buffer), leave sum x (lambda x + b) of the camera part for computeScale (optimization_algorithm_levenberg.cpp:182-189).
+__device__ __forceinline__ void solve_epilogue(const BAArrays& A, const BAWin& W, BAState& S, const double* x, double* scratch, bool ok, int iters) {
+  const int tid = threadIdx.x, nf = W.n_free, n = 6 * nf;
+  const double lambda = S.lambda;
+  const double* bpv = A.bp + (size_t)W.hpp_off * 6;
+  double sc = 0.0;
+  if (tid < n) { A.xp[W.x_off + tid] = x[tid]; sc = x[tid] * (lambda * x[tid] + bpv[tid]); }
+  const double sc_t = block_sum(sc, scratch);
+  const int cur = S.cur, nxt = cur ^ 1;
+  if (tid < W.n_cams) {
+    const Pose T = load_cam(A, cur, W.cam_off + tid);
+    Pose Tn = T;
+    if (tid < nf) Tn = pose_oplus(T, x + tid * 6);
+    pose_store(Tn, A.cam_qt + ((size_t)nxt * A.NC + W.cam_off + tid) * 7);
+  }
+  if (tid == 0) { S.scale_cam = sc_t; S.pcg_ok = ok ? 1 : 0; S.pcg_iterations += iters; }
+}
+
 // ================================================================== PCG on the reduced camera system
 // grid (nW); block kPcgThreads; dynamic LDS: 4n + kPcgThreads + nf*36 + 32 doubles.  Block-Jacobi preconditioner (inverse 6x6 diagonal
 // blocks), fixed reduction trees, stops at |r|_M <= tol |b|_M.  On exit it applies VertexSE3Expmap::oplusImpl to the free
@@ -659,20 +678,140 @@ __global__ __launch_bounds__(kPcgThreads) void ba_pcg_kernel(BAArrays A, const B
     }
   }
   __syncthreads();
-  // solution, camera update into the trial buffer, camera part of computeScale
-  const double lambda = S.lambda;
-  const double* bpv = A.bp + (size_t)W.hpp_off * 6;
-  double sc = 0.0;
-  if (tid < n) { A.xp[W.x_off + tid] = x[tid]; sc = x[tid] * (lambda * x[tid] + bpv[tid]); }
-  const double sc_t = block_sum(sc, scratch);
-  const int cur = S.cur, nxt = cur ^ 1;
-  if (tid < W.n_cams) {
-    const Pose T = load_cam(A, cur, W.cam_off + tid);
-    Pose Tn = T;
-    if (tid < nf) Tn = pose_oplus(T, x + tid * 6);
-    pose_store(Tn, A.cam_qt + ((size_t)nxt * A.NC + W.cam_off + tid) * 7);
+  solve_epilogue(A, W, S, x, scratch, ok, iters);
+}
+
+// ================================================================== exact solve of the reduced camera system
+// grid (nW); block kPcgThreads; dynamic LDS: (2*nf*36 + 2*n + 32) doubles.
+// Right-looking block Cholesky (6x6 camera blocks) in place on the LOWER block triangle of S, the right-hand side carried
+// along as an extra block row (forward substitution for free), then block back-substitution.  This is the counterpart of
+// the reference's exact factorisation (Eigen::SimplicialLDLT, solvers/linear_solver_eigen.h:94-124): S is read once from
+// HBM instead of once per PCG iteration, and the result does not depend on an iteration tolerance.  A non-positive pivot
+// reports failure, which Levenberg–Marquardt turns into a rejected trial (optimization_algorithm_levenberg.cpp:126-127).
+__global__ __launch_bounds__(kPcgThreads) void ba_chol_kernel(BAArrays A, const BAWin* __restrict__ wins, BAState* __restrict__ st) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const BAWin W = wins[blockIdx.x];
+  BAState& S = st[blockIdx.x];
+  if (S.phase != PH_RUN) return;
+  const int nf = W.n_free, n = 6 * nf;
+  double* linv = lds;                    // [nf][36] inverse of the diagonal Cholesky blocks (lower)
+  double* panel = linv + nf * 36;        // [nf][36] current block column of L
+  double* y = panel + nf * 36;           // [n] right-hand side -> forward solution
+  double* x = y + n;                     // [n] solution
+  double* scratch = x + n;               // [32]
+  double* okf = scratch + 31;
+  double* Sg = A.S + W.S_off;
+  const int tid = threadIdx.x;
+  if (tid == 0) *okf = 1.0;
+  if (tid < n) y[tid] = A.bschur[W.x_off + tid];
+  __syncthreads();
+  for (int k = 0; k < nf; k++) {
+    // (1) diagonal block: L_kk = chol(A_kk), Linv_kk, y_k = Linv_kk b_k
+    if (tid == 0) {
+      double a[6][6], L[6][6], Li[6][6];
+      for (int r = 0; r < 6; r++) for (int c = 0; c <= r; c++) a[r][c] = Sg[(size_t)(6 * k + r) * n + 6 * k + c];
+      bool ok = true;
+      for (int j = 0; j < 6; j++) {
+        double d = a[j][j];
+        for (int m = 0; m < j; m++) d -= L[j][m] * L[j][m];
+        if (!(d > 0.0) || !isfinite(d)) ok = false;
+        const double ljj = sqrt(d), inv = 1.0 / ljj;
+        L[j][j] = ljj;
+        for (int i = j + 1; i < 6; i++) {
+          double sacc = a[i][j];
+          for (int m = 0; m < j; m++) sacc -= L[i][m] * L[j][m];
+          L[i][j] = sacc * inv;
+        }
+      }
+      for (int j = 0; j < 6; j++) {
+        Li[j][j] = 1.0 / L[j][j];
+        for (int i = j + 1; i < 6; i++) {
+          double sacc = 0.0;
+          for (int m = j; m < i; m++) sacc -= L[i][m] * Li[m][j];
+          Li[i][j] = sacc / L[i][i];
+        }
+      }
+      for (int r = 0; r < 6; r++) for (int c = 0; c < 6; c++) linv[k * 36 + r * 6 + c] = c <= r ? Li[r][c] : 0.0;
+      for (int r = 0; r < 6; r++) for (int c = 0; c <= r; c++) Sg[(size_t)(6 * k + r) * n + 6 * k + c] = L[r][c];
+      double yk[6];
+      for (int r = 0; r < 6; r++) { double sacc = 0.0; for (int c = 0; c <= r; c++) sacc += Li[r][c] * y[6 * k + c]; yk[r] = sacc; }
+      for (int r = 0; r < 6; r++) y[6 * k + r] = yk[r];
+      if (!ok) *okf = 0.0;
+    }
+    __syncthreads();
+    // (2) panel: L_ik = A_ik Linv_kk^T for i > k (lane <-> one row of one block), b_i -= L_ik y_k
+    const int m_rows = (nf - k - 1) * 6;
+    for (int t = tid; t < m_rows; t += kPcgThreads) {
+      const int i = k + 1 + t / 6, r = t % 6;
+      double* row = Sg + (size_t)(6 * i + r) * n + 6 * k;
+      double arow[6], lrow[6];
+#pragma unroll
+      for (int c = 0; c < 6; c++) arow[c] = row[c];
+      const double* Li = linv + k * 36;
+      double dotv = 0.0;
+#pragma unroll
+      for (int c = 0; c < 6; c++) {
+        double sacc = 0.0;
+#pragma unroll
+        for (int m = 0; m <= c; m++) sacc += arow[m] * Li[c * 6 + m];
+        lrow[c] = sacc;
+        dotv += sacc * y[6 * k + c];
+      }
+#pragma unroll
+      for (int c = 0; c < 6; c++) { row[c] = lrow[c]; panel[i * 36 + r * 6 + c] = lrow[c]; }
+      y[6 * i + r] -= dotv;
+    }
+    __syncthreads();
+    // (3) trailing update: A_ij -= L_ik L_jk^T for k < j <= i (lane <-> block; lower triangle only)
+    const int m = nf - k - 1;
+    const int nblk = m * (m + 1) / 2;
+    for (int t = tid; t < nblk; t += kPcgThreads) {
+      int ii = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+      while ((ii + 1) * (ii + 2) / 2 <= t) ii++;
+      while (ii * (ii + 1) / 2 > t) ii--;
+      const int jj = t - ii * (ii + 1) / 2;
+      const int i = k + 1 + ii, j = k + 1 + jj;
+      const double* Pi = panel + i * 36;
+      const double* Pj = panel + j * 36;
+      double pj[36];
+#pragma unroll
+      for (int q = 0; q < 36; q++) pj[q] = Pj[q];
+#pragma unroll
+      for (int r = 0; r < 6; r++) {
+        double* row = Sg + (size_t)(6 * i + r) * n + 6 * j;
+        double pr[6];
+#pragma unroll
+        for (int q = 0; q < 6; q++) pr[q] = Pi[r * 6 + q];
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+          double sacc = 0.0;
+#pragma unroll
+          for (int q = 0; q < 6; q++) sacc += pr[q] * pj[c * 6 + q];
+          row[c] -= sacc;
+        }
+      }
+    }
+    __syncthreads();
   }
-  if (tid == 0) { S.scale_cam = sc_t; S.pcg_ok = ok ? 1 : 0; S.pcg_iterations += iters; }
+  // back substitution: L^T x = y
+  for (int k = nf - 1; k >= 0; k--) {
+    if (tid < 6) {
+      const double* Li = linv + k * 36;
+      double sacc = 0.0;
+      for (int mm = tid; mm < 6; mm++) sacc += Li[mm * 6 + tid] * y[6 * k + mm];      // x_k = Linv_kk^T y_k
+      x[6 * k + tid] = sacc;
+    }
+    __syncthreads();
+    for (int t = tid; t < 6 * k; t += kPcgThreads) {                                  // y_j -= L_kj^T x_k, j < k (coalesced along the row)
+      double sacc = 0.0;
+#pragma unroll
+      for (int r = 0; r < 6; r++) sacc += Sg[(size_t)(6 * k + r) * n + t] * x[6 * k + r];
+      y[t] -= sacc;
+    }
+    __syncthreads();
+  }
+  const bool ok = *okf != 0.0;
+  solve_epilogue(A, W, S, x, scratch, ok, 0);
 }
 
 // ================================================================== back-substitution + update + trial chi2

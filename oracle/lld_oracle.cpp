@@ -424,7 +424,7 @@ void lldo_reproject_line_point(const double* X0, const double* ldir, double px, 
 
 void lldo_ba_params_default(lld_ba_params* p) {
   p->gamma = 1.0; p->its_round1 = 5; p->its_round2 = 15; p->ln_filter = 4; p->max_trials = 10;
-  p->pcg_rel_tol = 1e-12; p->pcg_max_iter = 0; p->reserved = 0;
+  p->pcg_rel_tol = 1e-12; p->pcg_max_iter = 0; p->reduced_solver = 0;
 }
 void lldo_pose_params_default(lld_pose_params* p) { p->gamma = 0.5; p->n_rounds = 4; p->its_per_round = 10; p->max_trials = 10; p->reserved = 0; }
 

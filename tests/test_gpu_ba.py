@@ -54,6 +54,15 @@ def test_small_windows_match_oracle(gpu_ctx, oracle, wid, kw):
     check_ba(Optimizer(gpu_ctx).LocalBundleAdjustment(w), oracle.local_ba(w), w)
 
 
+@pytest.mark.parametrize("solver", [0, 1])
+def test_both_reduced_solvers(gpu_ctx, oracle, solver):
+    """reduced_solver 0 = exact block Cholesky (default), 1 = block-Jacobi PCG (rel. tol 1e-12)."""
+    w = synth.make_lba_small(9, n_free=12, n_fixed=3, n_points=500, n_lines=80)
+    check_ba(Optimizer(gpu_ctx).LocalBundleAdjustment(w, reduced_solver=solver), oracle.local_ba(w), w)
+    wa = synth.make_lba_a(1)
+    check_ba(Optimizer(gpu_ctx).LocalBundleAdjustment(wa, reduced_solver=solver), oracle.local_ba(wa), wa)
+
+
 def test_gamma_and_iteration_parameters(gpu_ctx, oracle):
     w = synth.make_lba_small(6)
     check_ba(Optimizer(gpu_ctx).LocalBundleAdjustment(w, gamma=0.5, its_round1=3, its_round2=4),
