@@ -17,14 +17,14 @@ struct lld_ba_batch {
   int n_windows = 0;
   lld_ba_params params;
   std::vector<BAWin> h_wins;
-  std::vector<RowGroup> h_rgs;
+  std::vector<SChunk> h_chunks; std::vector<SItem> h_items;
   std::vector<const lld_ba_window*> unused;
   void* slab = nullptr; size_t slab_bytes = 0;
   BAArrays A;
-  BAWin* d_wins = nullptr; BAState* d_state = nullptr; RowGroup* d_rgs = nullptr;
+  BAWin* d_wins = nullptr; BAState* d_state = nullptr;
   int* h_counters = nullptr;               // pinned
-  int max_lblocks = 0, max_rg = 0, max_free = 0, max_tile_blocks = 0, max_rows = 0, max_cams = 0;
-  int schur_chunks = 1;
+  int max_lblocks = 0, max_items = 0, max_free = 0, max_cams = 0;
+  int chunk_landmarks = 32;
   size_t S_total = 0, x_total = 0;
   size_t rec_stride = 0;
   std::vector<unsigned char> h_records; bool records_valid = false;
@@ -87,9 +87,11 @@ int lld_ba_batch_create(lld_ctx* ctx, int n_windows, const lld_ba_window* wins, 
 
   // ---- layout + host staging
   std::vector<double> cam_qt0, pt0, ln_x0, ln_dir, pe_u, pe_v, pe_ur, pe_s, le_xs, le_ys, le_xe, le_ye, le_s, le_bx;
-  std::vector<int> pt_obs_start, ln_obs_start, pe_cam, pe_pt, le_cam, le_ln, rg_pe, rg_le;
+  std::vector<int> pt_obs_start, ln_obs_start, pe_cam, pe_pt, le_cam, le_ln, sg_lm, sg_tab, sg_cams;
   std::vector<uint8_t> le_flags0;
   B->h_wins.resize(n_windows);
+  // landmarks per Schur chunk: long chunks mean fewer atomics into S, short ones more lanes for small batches
+  B->chunk_landmarks = n_windows >= 64 ? 96 : (n_windows >= 8 ? 48 : 24);
   const double thMono = (double)(float)std::sqrt(5.991), thStereo = (double)(float)std::sqrt(7.815);   // Optimizer.cc:1088-1089
   long long NC = 0, NP = 0, NL = 0, NPE = 0, NLO = 0, NF = 0, NPART = 0;
   size_t S_total = 0, x_total = 0, rec_total = 0;
@@ -134,56 +136,57 @@ int lld_ba_batch_create(lld_ctx* ctx, int n_windows, const lld_ba_window* wins, 
         }
       }
     }
-    // ---- camera row groups for the Schur tile + edge buckets
-    W.rg_off = (int)B->h_rgs.size();
-    {
-      int r0 = 0;
-      const int nf = w.n_free_cams;
-      while (r0 < nf) {
-        int blocks = 0, r1 = r0;
-        while (r1 < nf && blocks + (nf - r1) <= kTileBlocksMax) { blocks += nf - r1; r1++; }
-        if (r1 == r0) { delete B; return LLD_ERR_UNSUPPORTED; }
-        RowGroup G; std::memset(&G, 0, sizeof G);
-        G.r0 = r0; G.r1 = r1; G.tile_blocks = blocks;
-        // Bucket order: round-robin over the group's cameras, so the 64 lanes of a wavefront mostly hold edges of DIFFERENT
-        // cameras and their LDS atomics land in different block rows of the tile (same-address atomics serialise).
-        auto interleave = [&](std::vector<std::vector<int>>& per_cam, std::vector<int>& out_list) {
-          size_t longest = 0;
-          for (auto& v : per_cam) longest = std::max(longest, v.size());
-          for (size_t k = 0; k < longest; k++)
-            for (auto& v : per_cam) if (k < v.size()) out_list.push_back(v[k]);
-        };
-        {
-          std::vector<std::vector<int>> per_cam(r1 - r0);
-          for (int o = 0; o < w.n_pt_obs; o++) { const int c = w.pt_obs_cam[o]; if (c >= r0 && c < r1) per_cam[c - r0].push_back((int)NPE + o); }
-          G.pe_off = (int)rg_pe.size();
-          interleave(per_cam, rg_pe);
-          G.pe_n = (int)rg_pe.size() - G.pe_off;
-        }
-        {
-          std::vector<std::vector<int>> per_cam(r1 - r0);
-          for (int o = 0; o < w.n_ln_obs; o++) {
-            const int c = w.ln_obs_cam[o];
-            if (c >= r0 && c < r1) { per_cam[c - r0].push_back((int)(2 * (NLO + o))); if (!(w.ln_obs_right[4 * (size_t)o] < 0)) per_cam[c - r0].push_back((int)(2 * (NLO + o) + 1)); }
-          }
-          G.le_off = (int)rg_le.size();
-          interleave(per_cam, rg_le);
-          G.le_n = (int)rg_le.size() - G.le_off;
-        }
-        B->h_rgs.push_back(G);
-        B->max_tile_blocks = std::max(B->max_tile_blocks, blocks);
-        B->max_rows = std::max(B->max_rows, r1 - r0);
-        r0 = r1;
+    // ---- Schur work items: sort the landmarks by their set of free cameras, cut the runs into chunks, one item per
+    //      (chunk, slot pair).  Structure only: outlier levels are handled through zeroed Hpl blocks at run time.
+    W.lo_off = (int)NLO; W.n_lo = w.n_ln_obs;
+    W.item_off = (int)B->h_items.size();
+    for (int D = 3; D <= 4; D++) {
+      const int n_lm = D == 3 ? w.n_points : w.n_lines;
+      const int32_t* start = D == 3 ? w.pt_obs_start : w.ln_obs_start;
+      const int32_t* ocam = D == 3 ? w.pt_obs_cam : w.ln_obs_cam;
+      const long long id_base = D == 3 ? NPE : NLO, lm_base = D == 3 ? NP : NL;
+      struct Sig { int lm; std::vector<std::pair<int, int>> pairs; };      // (camera, global lc-pair id), free cameras only
+      std::vector<Sig> sigs; sigs.reserve(n_lm);
+      for (int l = 0; l < n_lm; l++) {
+        Sig sg; sg.lm = l;
+        for (int o = start[l]; o < start[l + 1]; o++) if (ocam[o] < w.n_free_cams) sg.pairs.push_back({ocam[o], (int)(id_base + o)});
+        if (sg.pairs.empty()) continue;
+        std::stable_sort(sg.pairs.begin(), sg.pairs.end(), [](const std::pair<int, int>& a, const std::pair<int, int>& b) { return a.first < b.first; });
+        sigs.push_back(std::move(sg));
+      }
+      auto same_cams = [](const Sig& a, const Sig& b) {
+        if (a.pairs.size() != b.pairs.size()) return false;
+        for (size_t i = 0; i < a.pairs.size(); i++) if (a.pairs[i].first != b.pairs[i].first) return false;
+        return true;
+      };
+      std::stable_sort(sigs.begin(), sigs.end(), [](const Sig& a, const Sig& b) {
+        if (a.pairs.size() != b.pairs.size()) return a.pairs.size() < b.pairs.size();
+        for (size_t i = 0; i < a.pairs.size(); i++) if (a.pairs[i].first != b.pairs[i].first) return a.pairs[i].first < b.pairs[i].first;
+        return false;
+      });
+      size_t i0 = 0;
+      while (i0 < sigs.size()) {
+        size_t i1 = i0 + 1;
+        while (i1 < sigs.size() && i1 - i0 < (size_t)B->chunk_landmarks && same_cams(sigs[i0], sigs[i1])) i1++;
+        SChunk C; std::memset(&C, 0, sizeof C);
+        C.k = (int)sigs[i0].pairs.size(); C.D = D; C.n_lm = (int)(i1 - i0);
+        C.lm_off = (int)sg_lm.size(); C.tab_off = (int)sg_tab.size(); C.cams_off = (int)sg_cams.size();
+        for (auto& pr : sigs[i0].pairs) sg_cams.push_back(pr.first);
+        for (size_t i = i0; i < i1; i++) { sg_lm.push_back((int)(lm_base + sigs[i].lm)); for (auto& pr : sigs[i].pairs) sg_tab.push_back(pr.second); }
+        const int ci = (int)B->h_chunks.size();
+        B->h_chunks.push_back(C);
+        for (int sa = 0; sa < C.k; sa++) for (int sb = sa; sb < C.k; sb++) { SItem it; it.chunk = ci; it.sab = sa | (sb << 16); B->h_items.push_back(it); }
+        i0 = i1;
       }
     }
-    W.n_rg = (int)B->h_rgs.size() - W.rg_off;
+    W.n_items = (int)B->h_items.size() - W.item_off;
+    B->max_items = std::max(B->max_items, W.n_items);
     W.rec_off = (long long)rec_total;
     NC += w.n_cams; NP += w.n_points; NL += w.n_lines; NPE += w.n_pt_obs; NLO += w.n_ln_obs; NF += w.n_free_cams;
     NPART += W.nb_pt + W.nb_ln;
     const size_t n = 6 * (size_t)w.n_free_cams;
     S_total += n * n; x_total += n;
     B->max_lblocks = std::max(B->max_lblocks, W.nb_pt + W.nb_ln);
-    B->max_rg = std::max(B->max_rg, W.n_rg);
     B->max_free = std::max(B->max_free, w.n_free_cams);
     B->max_cams = std::max(B->max_cams, w.n_cams);
     B->rec_stride = std::max(B->rec_stride, record_bytes(W));
@@ -194,13 +197,6 @@ int lld_ba_batch_create(lld_ctx* ctx, int n_windows, const lld_ba_window* wins, 
   for (int wi = 0; wi < n_windows; wi++) B->h_wins[wi].rec_off = (long long)(B->rec_stride * (size_t)wi);
   rec_total = B->rec_stride * (size_t)n_windows;
   B->S_total = S_total; B->x_total = x_total;
-  // enough Schur workgroups to fill the chip when the batch is small
-  {
-    const int wg = std::max(1, n_windows * std::max(1, B->max_rg));
-    int c = (2 * ctx->n_cu + wg - 1) / wg;
-    B->schur_chunks = std::max(1, std::min(32, c));
-  }
-
   // ---- one slab: a dry run of the carve sizes it exactly, the second run assigns pointers and uploads
   const size_t NLE = 2 * (size_t)NLO;
   hipStream_t st = ctx->stream;
@@ -209,7 +205,7 @@ int lld_ba_batch_create(lld_ctx* ctx, int n_windows, const lld_ba_window* wins, 
     auto up_d = [&](const std::vector<double>& h, size_t count) { double* d = sl.take<double>(count); if (real && !h.empty()) (void)hipMemcpyAsync(d, h.data(), h.size() * 8, hipMemcpyHostToDevice, st); return (const double*)d; };
     auto up_i = [&](const std::vector<int>& h, size_t count) { int* d = sl.take<int>(count); if (real && !h.empty()) (void)hipMemcpyAsync(d, h.data(), h.size() * 4, hipMemcpyHostToDevice, st); return (const int*)d; };
     auto up_b = [&](const std::vector<uint8_t>& h, size_t count) { uint8_t* d = sl.take<uint8_t>(count); if (real && !h.empty()) (void)hipMemcpyAsync(d, h.data(), h.size(), hipMemcpyHostToDevice, st); return (const uint8_t*)d; };
-    B->d_wins = sl.take<BAWin>(n_windows); B->d_state = sl.take<BAState>(n_windows); B->d_rgs = sl.take<RowGroup>(B->h_rgs.size() + 1);
+    B->d_wins = sl.take<BAWin>(n_windows); B->d_state = sl.take<BAState>(n_windows);
     std::memset(&A, 0, sizeof A);
     A.NC = NC; A.NP = NP; A.NL = NL;
     A.cam_qt = sl.take<double>(2 * NC * 7 + 1);
@@ -226,13 +222,19 @@ int lld_ba_batch_create(lld_ctx* ctx, int n_windows, const lld_ba_window* wins, 
     A.le_flags0 = up_b(le_flags0, NLE + 1);
     A.pe_flags = sl.take<uint8_t>(NPE + 1); A.le_flags = sl.take<uint8_t>(NLE + 1);
     A.pe_chi2 = sl.take<double>(NPE + 1); A.le_chi2 = sl.take<double>(NLE + 1);
-    A.pe_W = sl.take<double>((size_t)NPE * 18 + 1); A.le_W = sl.take<double>(NLE * 24 + 1);
+    A.pe_W = sl.take<double>((size_t)NPE * 18 + 1); A.lo_W = sl.take<double>((size_t)NLO * 24 + 1);
     A.pt_active = sl.take<uint8_t>(NP + 1); A.ln_active = sl.take<uint8_t>(NL + 1); A.ln_removed = sl.take<uint8_t>(NL + 1);
     A.pt_V = sl.take<double>((size_t)NP * 9 + 1); A.ln_V = sl.take<double>((size_t)NL * 14 + 1);
     A.Hpp = sl.take<double>((size_t)NF * 21 + 1); A.bp = sl.take<double>((size_t)NF * 6 + 1);
     A.S = sl.take<double>(S_total + 1); A.bschur = sl.take<double>(x_total + 1); A.xp = sl.take<double>(x_total + 1);
     A.chi_part = sl.take<double>(NPART + 1); A.chi_part2 = sl.take<double>(NPART + 1); A.scale_part = sl.take<double>(NPART + 1);
-    A.rg_pe = up_i(rg_pe, rg_pe.size() + 1); A.rg_le = up_i(rg_le, rg_le.size() + 1);
+    A.sg_lm = up_i(sg_lm, sg_lm.size() + 1); A.sg_tab = up_i(sg_tab, sg_tab.size() + 1); A.sg_cams = up_i(sg_cams, sg_cams.size() + 1);
+    {
+      SChunk* dc = sl.take<SChunk>(B->h_chunks.size() + 1); SItem* di = sl.take<SItem>(B->h_items.size() + 1);
+      if (real && !B->h_chunks.empty()) (void)hipMemcpyAsync(dc, B->h_chunks.data(), B->h_chunks.size() * sizeof(SChunk), hipMemcpyHostToDevice, st);
+      if (real && !B->h_items.empty()) (void)hipMemcpyAsync(di, B->h_items.data(), B->h_items.size() * sizeof(SItem), hipMemcpyHostToDevice, st);
+      A.sg_chunks = dc; A.sg_items = di;
+    }
     A.records = sl.take<unsigned char>(rec_total + 256);
     A.counters = sl.take<int>(8);
   };
@@ -244,15 +246,12 @@ int lld_ba_batch_create(lld_ctx* ctx, int n_windows, const lld_ba_window* wins, 
   lld_slab sl; sl.base = (char*)B->slab; sl.size = bytes;
   carve(sl, true);
   {
-    const size_t schur_lds = ((size_t)B->max_tile_blocks * 36 + (size_t)B->max_rows * 6) * sizeof(double);
-    LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_schur_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)schur_lds));
     const size_t pcg_lds = ((size_t)B->max_free * 6 * 4 + kPcgThreads + (size_t)B->max_free * 36 + 32) * sizeof(double);
     LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_pcg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pcg_lds));
     const size_t chol_lds = ((size_t)B->max_free * 36 * 2 + (size_t)B->max_free * 6 * 2 + 32) * sizeof(double);
     LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_chol_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)chol_lds));
   }
   LLD_HIP_TRY(hipMemcpyAsync(B->d_wins, B->h_wins.data(), sizeof(BAWin) * n_windows, hipMemcpyHostToDevice, st));
-  if (!B->h_rgs.empty()) LLD_HIP_TRY(hipMemcpyAsync(B->d_rgs, B->h_rgs.data(), sizeof(RowGroup) * B->h_rgs.size(), hipMemcpyHostToDevice, st));
   LLD_HIP_TRY(hipHostMalloc((void**)&B->h_counters, 8 * sizeof(int), hipHostMallocDefault));
   for (auto& e : B->ev) LLD_HIP_TRY(hipEventCreate(&e));
   LLD_HIP_TRY(hipStreamSynchronize(st));        // staging vectors go out of scope
@@ -282,13 +281,11 @@ int lld_ba_batch_solve(lld_ba_batch* B, volatile const int* abort_flag) {
   // the (untouched) working state and every flag stays clear.
   const bool abort_at_start = abort_flag && *abort_flag;
   const size_t lin_lds = ((size_t)B->max_free * 27 + 8) * sizeof(double);
-  const size_t schur_lds = ((size_t)B->max_tile_blocks * 36 + (size_t)B->max_rows * 6) * sizeof(double);
   const size_t pcg_lds = ((size_t)B->max_free * 6 * 4 + kPcgThreads + (size_t)B->max_free * 36 + 32) * sizeof(double);
   const size_t chol_lds = ((size_t)B->max_free * 36 * 2 + (size_t)B->max_free * 6 * 2 + 32) * sizeof(double);
   const dim3 lm_grid(std::max(1, B->max_lblocks), nW);
   const dim3 fin_grid(B->max_lblocks + 1, nW);
-  const int chunks = B->schur_chunks;
-  const dim3 schur_grid(std::max(1, B->max_rg) * chunks, nW);
+  const dim3 schur_grid((std::max(1, B->max_items) + kSchurThreads - 1) / kSchurThreads, nW);
   const int ctl_blocks = (nW + 63) / 64;
   bool any_left = true;
   if (abort_at_start) {
@@ -308,15 +305,13 @@ int lld_ba_batch_solve(lld_ba_batch* B, volatile const int* abort_flag) {
     if (B->super_steps >= kMaxSuperSteps) break;
     const int abort_now = (abort_flag && *abort_flag) ? 1 : 0;
     LLD_HIP_TRY(hipMemsetAsync(A.counters, 0, 4 * sizeof(int), st));
-    if (chunks > 1) {
-      LLD_HIP_TRY(hipMemsetAsync(A.S, 0, B->S_total * sizeof(double), st));
-      LLD_HIP_TRY(hipMemsetAsync(A.bschur, 0, B->x_total * sizeof(double), st));
-    }
     LLD_HIP_TRY(hipEventRecord(B->ev[0], st));
     hipLaunchKernelGGL(ba_linearize_kernel, lm_grid, dim3(kLmThreads), lin_lds, st, A, B->d_wins, B->d_state);
     hipLaunchKernelGGL(ba_begin_kernel, dim3(ctl_blocks), dim3(64), 0, st, A, B->d_wins, B->d_state, nW);
     LLD_HIP_TRY(hipEventRecord(B->ev[1], st));
-    hipLaunchKernelGGL(ba_schur_kernel, schur_grid, dim3(kSchurThreads), schur_lds, st, A, B->d_wins, B->d_state, B->d_rgs, chunks);
+    hipLaunchKernelGGL(ba_schur_init_kernel, dim3(16, nW), dim3(256), 0, st, A, B->d_wins, B->d_state);
+    hipLaunchKernelGGL(ba_schur_items_kernel, schur_grid, dim3(kSchurThreads), 0, st, A, B->d_wins, B->d_state);
+    if (B->params.reduced_solver == 1) hipLaunchKernelGGL(ba_symmetrize_kernel, dim3(16, nW), dim3(256), 0, st, A, B->d_wins, B->d_state);
     LLD_HIP_TRY(hipEventRecord(B->ev[2], st));
     if (B->params.reduced_solver == 1)
       hipLaunchKernelGGL(ba_pcg_kernel, dim3(nW), dim3(kPcgThreads), pcg_lds, st, A, B->d_wins, B->d_state, B->params.pcg_rel_tol, B->params.pcg_max_iter);

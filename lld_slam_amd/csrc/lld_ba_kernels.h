@@ -31,11 +31,10 @@ namespace lldba {
 using namespace lld;
 
 constexpr int kLmThreads = 256;        // landmark-parallel kernels: one lane per landmark
-constexpr int kSchurThreads = 512;
+constexpr int kSchurThreads = 128;    // item-parallel Schur kernel: one lane per (landmark chunk, camera-slot pair)
 constexpr int kPcgThreads = 1024;
 constexpr int kCtlThreads = 64;
 constexpr int kMaxFreeCams = 96;
-constexpr int kTileBlocksMax = 440;    // 6x6 S blocks per LDS tile: 440*36*8 B = 124 KiB
 
 enum Phase : int { PH_RUN = 0, PH_TRANSITION = 2, PH_FINALIZE = 3, PH_DONE = 4 };
 constexpr uint8_t EF_LEVEL1 = 1, EF_ROBUST = 2, EF_VALID = 4, EF_PAIRSTEREO = 8;
@@ -51,7 +50,8 @@ struct BAWin {                 // immutable per-window header
   int hpp_off;                 // free-camera accumulators
   int x_off;                   // reduced-system vectors (doubles)
   long long S_off;             // reduced-system matrix (doubles)
-  int rg_off, n_rg;            // camera row groups of the Schur tile
+  int item_off, n_items;       // Schur work items (points first, then lines)
+  int lo_off, n_lo;            // line observations (= le_off / 2)
   int nb_pt, nb_ln;            // landmark blocks (kLmThreads landmarks each)
   int part_off;                // per-block partial sums
   int its[2];                  // LM iterations per round
@@ -70,7 +70,11 @@ struct BAState {               // mutable per-window LM state
   int pcg_iterations, aborted, n_active_edges, pad;
 };
 
-struct RowGroup { int r0, r1, tile_blocks, pe_off, pe_n, le_off, le_n, pad; };
+// Schur work decomposition (built once per window on the host from the camera sets of the landmarks):
+// landmarks that are seen by the SAME set of free cameras are sorted together and cut into chunks; a work item is
+// (chunk, slot pair sa <= sb) and accumulates -Y_a W_b^T over the chunk's landmarks in registers before it touches S.
+struct SChunk { int lm_off, n_lm, tab_off, cams_off, k, D, pad0, pad1; };
+struct SItem { int chunk; int sab; };      // sab = sa | sb << 16
 
 struct BAArrays {
   long long NC, NP, NL;        // totals (stride of the double-buffered state arrays)
@@ -93,7 +97,7 @@ struct BAArrays {
   uint8_t *pe_flags, *le_flags;
   double *pe_chi2, *le_chi2;
   double *pe_W;                // [NPE*18]  Hpl block 6x3
-  double *le_W;                // [NLE*24]  Hpl block 6x4
+  double *lo_W;                // [NLO*24]  Hpl block 6x4 per (line, KF) observation: left + right edge summed
   // per-landmark mutable
   uint8_t *pt_active, *ln_active, *ln_removed;
   double *pt_V;                // [NP*9]   Hll upper (6) + bl (3)
@@ -103,8 +107,9 @@ struct BAArrays {
   double *bp;                  // [NF*6]
   double *S, *bschur, *xp;
   double *chi_part, *chi_part2, *scale_part;
-  // row-group edge buckets
-  const int *rg_pe, *rg_le;
+  // Schur work items
+  const SChunk* sg_chunks; const SItem* sg_items;
+  const int *sg_lm, *sg_tab, *sg_cams;
   // results
   unsigned char* records;
   int* counters;               // [4]: running, transition, finalize
@@ -297,8 +302,11 @@ __global__ __launch_bounds__(kLmThreads) void ba_linearize_kernel(BAArrays A, co
       const int e0 = A.pt_obs_start[g], e1 = A.pt_obs_start[g + 1];
       for (int e = e0; e < e1; e++) {
         const uint8_t fl = A.pe_flags[e];
-        if (fl & EF_LEVEL1) continue;
         const int c = A.pe_cam[e];
+        if (fl & EF_LEVEL1) {                              // level-1 edge: contributes nothing, its Hpl block must read as zero
+          if (c < W.n_free) { double* Wz = A.pe_W + (size_t)e * 18; for (int i = 0; i < 18; i++) Wz[i] = 0.0; }
+          continue;
+        }
         const Pose T = load_cam(A, cur, W.cam_off + c);
         const Vec3 Xc = pose_map(T, X);
         const double urv = A.pe_ur[e];
@@ -353,44 +361,55 @@ __global__ __launch_bounds__(kLmThreads) void ba_linearize_kernel(BAArrays A, co
       const Vec3 c0 = mat_col(Rl, 0), c1 = mat_col(Rl, 1);
       const Vec3 X1 = L.alpha * c1, X2 = X1 + c0;
       double H[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
-      const int e0 = 2 * A.ln_obs_start[g], e1 = 2 * A.ln_obs_start[g + 1];
-      for (int e = e0; e < e1; e++) {
-        const uint8_t fl = A.le_flags[e];
-        if (!(fl & EF_VALID) || (fl & EF_LEVEL1)) continue;
-        const int c = A.le_cam[e];
-        const Pose T = load_cam(A, cur, W.cam_off + c);
-        const Vec3 X1m = pose_map(T, X1), X2m = pose_map(T, X2);
-        double r[2]; LineAdj adj;
-        line_residual(cam, A.le_bx[e], X1m, X2m, A.le_xs[e], A.le_ys[e], A.le_xe[e], A.le_ye[e], r, &adj);
-        const double s = A.le_s[e];
-        const double c2 = chi2_of(r, 2, s);
-        A.le_chi2[e] = c2;
-        double w = 1.0, rho0 = c2;
-        if (fl & EF_ROBUST) rho0 = huber(c2, (fl & EF_PAIRSTEREO) ? W.th_ln_stereo : W.th_ln_mono, &w);
-        chi += rho0;
-        const double ws = w * s;
-        double Jc[12], Jl[8];
-        line_jac_pose(adj, X1m, X2m, Jc);
-        line_jac_line(adj, quat_rotation(T.q), c0, c1, L.alpha, Jl);
-        int k = 0;
+      const int o0 = A.ln_obs_start[g], o1 = A.ln_obs_start[g + 1];
+      for (int o = o0; o < o1; o++) {
+        const int c = A.le_cam[2 * o];
+        const bool free_cam = c < W.n_free;
+        double Wo[24];                                       // Hpl block of the (line, KF) pair: both image edges add into it
 #pragma unroll
-        for (int a = 0; a < 4; a++) {
-          b[a] -= ws * (Jl[a] * r[0] + Jl[4 + a] * r[1]);
+        for (int i = 0; i < 24; i++) Wo[i] = 0.0;
+        bool loaded = false; Pose T; Mat3 Rc; Vec3 X1m, X2m;
+        for (int side = 0; side < 2; side++) {
+          const int e = 2 * o + side;
+          const uint8_t fl = A.le_flags[e];
+          if (!(fl & EF_VALID) || (fl & EF_LEVEL1)) continue;
+          if (!loaded) { T = load_cam(A, cur, W.cam_off + c); Rc = quat_rotation(T.q); X1m = pose_map(T, X1); X2m = pose_map(T, X2); loaded = true; }
+          double r[2]; LineAdj adj;
+          line_residual(cam, A.le_bx[e], X1m, X2m, A.le_xs[e], A.le_ys[e], A.le_xe[e], A.le_ye[e], r, &adj);
+          const double s = A.le_s[e];
+          const double c2 = chi2_of(r, 2, s);
+          A.le_chi2[e] = c2;
+          double w = 1.0, rho0 = c2;
+          if (fl & EF_ROBUST) rho0 = huber(c2, (fl & EF_PAIRSTEREO) ? W.th_ln_stereo : W.th_ln_mono, &w);
+          chi += rho0;
+          const double ws = w * s;
+          double Jc[12], Jl[8];
+          line_jac_pose(adj, X1m, X2m, Jc);
+          line_jac_line(adj, Rc, c0, c1, L.alpha, Jl);
+          int k = 0;
 #pragma unroll
-          for (int d = a; d < 4; d++) H[k++] += ws * (Jl[a] * Jl[d] + Jl[4 + a] * Jl[4 + d]);
-        }
-        if (c < W.n_free) {
-          double* Wb = A.le_W + (size_t)e * 24;
-          double* ac = acc + c * 27;
-          int kk = 0;
+          for (int a = 0; a < 4; a++) {
+            b[a] -= ws * (Jl[a] * r[0] + Jl[4 + a] * r[1]);
 #pragma unroll
-          for (int rr = 0; rr < 6; rr++) {
-#pragma unroll
-            for (int a = 0; a < 4; a++) Wb[rr * 4 + a] = ws * (Jc[rr] * Jl[a] + Jc[6 + rr] * Jl[4 + a]);
-            atomicAdd(&ac[21 + rr], -ws * (Jc[rr] * r[0] + Jc[6 + rr] * r[1]));
-#pragma unroll
-            for (int cc = rr; cc < 6; cc++) atomicAdd(&ac[kk++], ws * (Jc[rr] * Jc[cc] + Jc[6 + rr] * Jc[6 + cc]));
+            for (int d = a; d < 4; d++) H[k++] += ws * (Jl[a] * Jl[d] + Jl[4 + a] * Jl[4 + d]);
           }
+          if (free_cam) {
+            double* ac = acc + c * 27;
+            int kk = 0;
+#pragma unroll
+            for (int rr = 0; rr < 6; rr++) {
+#pragma unroll
+              for (int a = 0; a < 4; a++) Wo[rr * 4 + a] += ws * (Jc[rr] * Jl[a] + Jc[6 + rr] * Jl[4 + a]);
+              atomicAdd(&ac[21 + rr], -ws * (Jc[rr] * r[0] + Jc[6 + rr] * r[1]));
+#pragma unroll
+              for (int cc = rr; cc < 6; cc++) atomicAdd(&ac[kk++], ws * (Jc[rr] * Jc[cc] + Jc[6 + rr] * Jc[6 + cc]));
+            }
+          }
+        }
+        if (free_cam) {
+          double* Wb = A.lo_W + (size_t)o * 24;
+#pragma unroll
+          for (int i = 0; i < 24; i++) Wb[i] = Wo[i];
         }
       }
       double* V = A.ln_V + (size_t)g * 14;
@@ -444,129 +463,152 @@ __global__ void ba_begin_kernel(BAArrays A, const BAWin* __restrict__ wins, BASt
 }
 
 // ================================================================== Schur complement
-// grid (n_rg_max * chunks, nW); dynamic LDS: tile_blocks_max*36 + rows_max*6 doubles.
-// Each workgroup owns the rows [r0,r1) of the upper block triangle of S in LDS and walks the bucket of edges whose
-// camera lies in those rows.  Edge a (camera i, landmark l) contributes  -Y_a W_b^T  to block (i, cam(b)) for every
-// active edge b of l with cam(b) >= i, where Y_a = W_a (Hll + lambda I)^-1; the diagonal receives Hpp + lambda I.
-template <int D> struct LmDim;
-template <> struct LmDim<3> { static constexpr int VN = 9, HU = 6, WN = 18; };
-template <> struct LmDim<4> { static constexpr int VN = 14, HU = 10, WN = 24; };
+// (1) ba_schur_init: S <- blockdiag(Hpp + lambda I) on the lower block triangle, bschur <- b_p.   grid (16, nW)
+// (2) ba_schur_items: one lane per work item (chunk of landmarks with one camera set, slot pair sa <= sb).  For every
+//     landmark of the chunk: Dinv = (Hll + lambda I)^-1 (setLambda + the inverse of block_solver.hpp:391),
+//     Y_a = W_a Dinv, acc -= Y_a W_b^T, and for sa == sb also c_a += Y_a b_l (block_solver.hpp:395-428).  The 6x6
+//     product is accumulated in registers over the whole chunk and only then added to S (36 global atomics per item
+//     instead of 36 per landmark pair).  Only the LOWER block triangle is produced (block (cam_b, cam_a), cam_b >= cam_a).
+__global__ __launch_bounds__(256) void ba_schur_init_kernel(BAArrays A, const BAWin* __restrict__ wins, const BAState* __restrict__ st) {
+  const BAWin W = wins[blockIdx.y];
+  const BAState& S = st[blockIdx.y];
+  if (S.phase != PH_RUN) return;
+  const int nf = W.n_free, n = 6 * nf;
+  double* Sg = A.S + W.S_off;
+  const double* Hp = A.Hpp + (size_t)W.hpp_off * 21;
+  const double lambda = S.lambda;
+  const int total = n * n;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int row = i / n, col = i - row * n;
+    const int bi = row / 6, bj = col / 6;
+    if (bj > bi) continue;
+    double v = 0.0;
+    if (bi == bj) {
+      const int r = row - 6 * bi, c = col - 6 * bj;
+      const int lo = r < c ? r : c, hi = r < c ? c : r;
+      v = Hp[bi * 21 + (lo * 6 - lo * (lo - 1) / 2 + (hi - lo))];
+      if (r == c) v += lambda;
+    }
+    Sg[i] = v;
+  }
+  if (blockIdx.x == 0) {
+    const double* bpv = A.bp + (size_t)W.hpp_off * 6;
+    double* bs = A.bschur + W.x_off;
+    for (int i = threadIdx.x; i < n; i += 256) bs[i] = bpv[i];
+  }
+}
 
 template <int D>
-__device__ __forceinline__ void schur_edge(const double* __restrict__ V, const double* __restrict__ Wall, const int* __restrict__ ecam,
-                                           const uint8_t* __restrict__ eflags, int a, int e0, int e1, int i, int n_free, double lambda,
-                                           const RowGroup& G, double* tile, double* cacc, int row_off) {
-  double F[D * D], Di[D * D];
-  unpack_sym<D>(V, lambda, F);
-  spd_inverse<D>(F, Di);
-  const double* Wa = Wall + (size_t)a * (6 * D);
-  double Y[6 * D];
+__device__ __forceinline__ void schur_item(const BAArrays& A, const SChunk& C, int sa, int sb, double lambda, double* __restrict__ Sg,
+                                           double* __restrict__ bs, int n) {
+  constexpr int VN = (D == 3) ? 9 : 14, HU = (D == 3) ? 6 : 10, WN = 6 * D;
+  const double* __restrict__ Vbase = (D == 3) ? A.pt_V : A.ln_V;
+  const double* __restrict__ Wbase = (D == 3) ? A.pe_W : A.lo_W;
+  const uint8_t* __restrict__ act = (D == 3) ? A.pt_active : A.ln_active;
+  const bool diag = sa == sb;
+  double acc[36], cacc[6];
 #pragma unroll
-  for (int r = 0; r < 6; r++)
+  for (int i = 0; i < 36; i++) acc[i] = 0.0;
 #pragma unroll
-    for (int k = 0; k < D; k++) {
-      double s = 0.0;
+  for (int i = 0; i < 6; i++) cacc[i] = 0.0;
+  const int* __restrict__ lm = A.sg_lm + C.lm_off;
+  const int* __restrict__ tab = A.sg_tab + C.tab_off;
+  const int k = C.k;
+  for (int t = 0; t < C.n_lm; t++) {
+    const int g = lm[t];
+    if (!act[g]) continue;
+    const double* V = Vbase + (size_t)g * VN;
+    double F[D * D], Di[D * D];
+    unpack_sym<D>(V, lambda, F);
+    spd_inverse<D>(F, Di);
+    const double* Wa = Wbase + (size_t)tab[t * k + sa] * WN;
+    const double* Wb = Wbase + (size_t)tab[t * k + sb] * WN;
+    double wb[WN];
 #pragma unroll
-      for (int j = 0; j < D; j++) s += Wa[r * D + j] * Di[j * D + k];
-      Y[r * D + k] = s;
-    }
-  const double* bl = V + LmDim<D>::HU;
+    for (int i = 0; i < WN; i++) wb[i] = Wb[i];
+    double bl[D];
 #pragma unroll
-  for (int r = 0; r < 6; r++) {
-    double s = 0.0;
+    for (int i = 0; i < D; i++) bl[i] = V[HU + i];
 #pragma unroll
-    for (int k = 0; k < D; k++) s += Y[r * D + k] * bl[k];
-    atomicAdd(&cacc[(i - G.r0) * 6 + r], s);
-  }
-  for (int b = e0; b < e1; b++) {
-    const uint8_t fb = eflags[b];
-    if (!(fb & EF_VALID) || (fb & EF_LEVEL1)) continue;
-    const int j = ecam[b];
-    if (j >= n_free || j < i) continue;
-    const double* Wb = Wall + (size_t)b * (6 * D);
-    double wb[6 * D];
+    for (int r = 0; r < 6; r++) {
+      double wa[D], y[D];
 #pragma unroll
-    for (int t = 0; t < 6 * D; t++) wb[t] = Wb[t];
-    double* blk = tile + (size_t)(row_off + (j - i)) * 36;
+      for (int j = 0; j < D; j++) wa[j] = Wa[r * D + j];
 #pragma unroll
-    for (int r = 0; r < 6; r++)
+      for (int q = 0; q < D; q++) {
+        double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < D; j++) s += wa[j] * Di[j * D + q];
+        y[q] = s;
+      }
 #pragma unroll
       for (int c = 0; c < 6; c++) {
         double s = 0.0;
 #pragma unroll
-        for (int k = 0; k < D; k++) s += Y[r * D + k] * wb[c * D + k];
-        atomicAdd(&blk[r * 6 + c], -s);
+        for (int q = 0; q < D; q++) s += y[q] * wb[c * D + q];
+        acc[r * 6 + c] += s;
       }
+      if (diag) {
+        double s = 0.0;
+#pragma unroll
+        for (int q = 0; q < D; q++) s += y[q] * bl[q];
+        cacc[r] += s;
+      }
+    }
+  }
+  const int ca = A.sg_cams[C.cams_off + sa], cb = A.sg_cams[C.cams_off + sb];
+  if (ca == cb) {
+    // diagonal block: Y_a W_a^T is symmetric; two different observations by the same camera contribute P + P^T
+#pragma unroll
+    for (int r = 0; r < 6; r++)
+#pragma unroll
+      for (int c = 0; c < 6; c++) {
+        const double v = diag ? acc[r * 6 + c] : acc[r * 6 + c] + acc[c * 6 + r];
+        if (v != 0.0) atomicAdd(&Sg[(size_t)(6 * ca + r) * n + 6 * ca + c], -v);
+      }
+  } else {
+    // lower block (cb, ca) = (Y_a W_b^T)^T
+#pragma unroll
+    for (int r = 0; r < 6; r++)
+#pragma unroll
+      for (int c = 0; c < 6; c++) {
+        const double v = acc[r * 6 + c];
+        if (v != 0.0) atomicAdd(&Sg[(size_t)(6 * cb + c) * n + 6 * ca + r], -v);
+      }
+  }
+  if (diag) {
+#pragma unroll
+    for (int r = 0; r < 6; r++) if (cacc[r] != 0.0) atomicAdd(&bs[6 * ca + r], -cacc[r]);
   }
 }
 
-__global__ __launch_bounds__(kSchurThreads) void ba_schur_kernel(BAArrays A, const BAWin* __restrict__ wins, const BAState* __restrict__ st,
-                                                                 const RowGroup* __restrict__ rgs, int chunks) {
-  extern __shared__ __attribute__((aligned(16))) double lds[];
+// grid (ceil(max_items / kSchurThreads), nW)
+__global__ __launch_bounds__(kSchurThreads) void ba_schur_items_kernel(BAArrays A, const BAWin* __restrict__ wins, const BAState* __restrict__ st) {
   const BAWin W = wins[blockIdx.y];
   const BAState& S = st[blockIdx.y];
   if (S.phase != PH_RUN) return;
-  const int gi = blockIdx.x / chunks, ch = blockIdx.x - gi * chunks;
-  if (gi >= W.n_rg) return;
-  const RowGroup G = rgs[W.rg_off + gi];
-  const int nf = W.n_free, n = 6 * nf;
-  double* tile = lds;
-  double* cacc = lds + (size_t)G.tile_blocks * 36;
-  const int rows = G.r1 - G.r0;
-  for (int i = threadIdx.x; i < G.tile_blocks * 36 + rows * 6; i += kSchurThreads) lds[i] = 0.0;
-  __syncthreads();
-  const double lambda = S.lambda;
-  // row_off(i) = sum_{r=r0}^{i-1} (nf - r)
-  auto row_off = [&](int i) { const int k = i - G.r0; return k * nf - (G.r0 * k + k * (k - 1) / 2); };
-  for (int t = ch * kSchurThreads + threadIdx.x; t < G.pe_n; t += chunks * kSchurThreads) {
-    const int a = A.rg_pe[G.pe_off + t];
-    const uint8_t fl = A.pe_flags[a];
-    if (fl & EF_LEVEL1) continue;
-    const int g = W.pt_off + A.pe_pt[a];
-    const int i = A.pe_cam[a];
-    schur_edge<3>(A.pt_V + (size_t)g * 9, A.pe_W, A.pe_cam, A.pe_flags, a, A.pt_obs_start[g], A.pt_obs_start[g + 1], i, nf, lambda, G,
-                  tile, cacc, row_off(i));
-  }
-  for (int t = ch * kSchurThreads + threadIdx.x; t < G.le_n; t += chunks * kSchurThreads) {
-    const int a = A.rg_le[G.le_off + t];
-    const uint8_t fl = A.le_flags[a];
-    if (!(fl & EF_VALID) || (fl & EF_LEVEL1)) continue;
-    const int g = W.ln_off + A.le_ln[a];
-    const int i = A.le_cam[a];
-    schur_edge<4>(A.ln_V + (size_t)g * 14, A.le_W, A.le_cam, A.le_flags, a, 2 * A.ln_obs_start[g], 2 * A.ln_obs_start[g + 1], i, nf, lambda,
-                  G, tile, cacc, row_off(i));
-  }
-  __syncthreads();
-  // flush: S (full symmetric, row-major n x n) and bschur
+  const int idx = blockIdx.x * kSchurThreads + threadIdx.x;
+  if (idx >= W.n_items) return;
+  const SItem it = A.sg_items[W.item_off + idx];
+  const SChunk C = A.sg_chunks[it.chunk];
+  const int sa = it.sab & 0xffff, sb = it.sab >> 16;
   double* Sg = A.S + W.S_off;
   double* bs = A.bschur + W.x_off;
-  const double* Hp = A.Hpp + (size_t)W.hpp_off * 21;
-  const double* bpv = A.bp + (size_t)W.hpp_off * 6;
-  const bool lead = (ch == 0);
-  for (int i = G.r0; i < G.r1; i++) {
-    const int ro = row_off(i);
-    const int cnt = (nf - i) * 36;
-    for (int t = threadIdx.x; t < cnt; t += kSchurThreads) {
-      const int jb = t / 36, rc = t - jb * 36, r = rc / 6, c = rc - r * 6;
-      const int j = i + jb;
-      double v = tile[(size_t)(ro + jb) * 36 + rc];
-      if (jb == 0 && lead) {
-        const int lo = r < c ? r : c, hi = r < c ? c : r;
-        v += Hp[i * 21 + (lo * 6 - lo * (lo - 1) / 2 + (hi - lo))];
-        if (r == c) v += lambda;
-      }
-      if (chunks == 1) {
-        Sg[(size_t)(i * 6 + r) * n + j * 6 + c] = v;
-        if (jb > 0) Sg[(size_t)(j * 6 + c) * n + i * 6 + r] = v;
-      } else if (v != 0.0) {
-        atomicAdd(&Sg[(size_t)(i * 6 + r) * n + j * 6 + c], v);
-        if (jb > 0) atomicAdd(&Sg[(size_t)(j * 6 + c) * n + i * 6 + r], v);
-      }
-    }
-    for (int r = threadIdx.x; r < 6; r += kSchurThreads) {
-      const double v = (lead ? bpv[i * 6 + r] : 0.0) - cacc[(i - G.r0) * 6 + r];
-      if (chunks == 1) bs[i * 6 + r] = v; else atomicAdd(&bs[i * 6 + r], v);
-    }
+  const int n = 6 * W.n_free;
+  if (C.D == 3) schur_item<3>(A, C, sa, sb, S.lambda, Sg, bs, n);
+  else schur_item<4>(A, C, sa, sb, S.lambda, Sg, bs, n);
+}
+
+// PCG only: mirror the lower block triangle into the upper one (the column-wise matvec wants the full matrix).  grid (16, nW)
+__global__ __launch_bounds__(256) void ba_symmetrize_kernel(BAArrays A, const BAWin* __restrict__ wins, const BAState* __restrict__ st) {
+  const BAWin W = wins[blockIdx.y];
+  if (st[blockIdx.y].phase != PH_RUN) return;
+  const int n = 6 * W.n_free;
+  double* Sg = A.S + W.S_off;
+  const int total = n * n;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int row = i / n, col = i - row * n;
+    if (col / 6 > row / 6) Sg[i] = Sg[(size_t)col * n + row];
   }
 }
 
@@ -891,12 +933,10 @@ __global__ __launch_bounds__(kLmThreads) void ba_backsub_kernel(BAArrays A, cons
         spd_inverse<4>(F, Di);
         double t[4] = {V[10], V[11], V[12], V[13]};
         const int e0 = 2 * A.ln_obs_start[g], e1 = 2 * A.ln_obs_start[g + 1];
-        for (int e = e0; e < e1; e++) {
-          const uint8_t fl = A.le_flags[e];
-          if (!(fl & EF_VALID) || (fl & EF_LEVEL1)) continue;
-          const int c = A.le_cam[e];
+        for (int o = A.ln_obs_start[g]; o < A.ln_obs_start[g + 1]; o++) {
+          const int c = A.le_cam[2 * o];
           if (c >= W.n_free) continue;
-          const double* Wb = A.le_W + (size_t)e * 24;
+          const double* Wb = A.lo_W + (size_t)o * 24;      // zero when both image edges are inactive
 #pragma unroll
           for (int k = 0; k < 4; k++) {
             double s = 0.0;
