@@ -17,13 +17,14 @@ struct lld_ba_batch {
   int n_windows = 0;
   lld_ba_params params;
   std::vector<BAWin> h_wins;
-  std::vector<SChunk> h_chunks; std::vector<SItem> h_items;
+  std::vector<SChunk> h_chunks;
   std::vector<const lld_ba_window*> unused;
   void* slab = nullptr; size_t slab_bytes = 0;
   BAArrays A;
   BAWin* d_wins = nullptr; BAState* d_state = nullptr;
   int* h_counters = nullptr;               // pinned
-  int max_lblocks = 0, max_items = 0, max_free = 0, max_cams = 0;
+  int max_lblocks = 0, max_items_pt = 0, max_items_ln = 0, max_free = 0, max_cams = 0, max_blk = 0;
+  size_t schur_lds[2] = {0, 0};
   int chunk_landmarks = 32;
   size_t S_total = 0, x_total = 0;
   size_t rec_stride = 0;
@@ -87,11 +88,12 @@ int lld_ba_batch_create(lld_ctx* ctx, int n_windows, const lld_ba_window* wins, 
 
   // ---- layout + host staging
   std::vector<double> cam_qt0, pt0, ln_x0, ln_dir, pe_u, pe_v, pe_ur, pe_s, le_xs, le_ys, le_xe, le_ye, le_s, le_bx;
-  std::vector<int> pt_obs_start, ln_obs_start, pe_cam, pe_pt, le_cam, le_ln, sg_lm, sg_tab, sg_cams;
+  std::vector<int> pt_obs_start, ln_obs_start, pe_cam, pe_pt, le_cam, le_ln, sg_lm, sg_tab, sg_cams, blk_start, blk_src, cam_start, cam_src;
+  size_t n_part = 0, n_cpart = 0; int max_blk = 0;
   std::vector<uint8_t> le_flags0;
   B->h_wins.resize(n_windows);
   // landmarks per Schur chunk: long chunks mean fewer atomics into S, short ones more lanes for small batches
-  B->chunk_landmarks = n_windows >= 64 ? 96 : (n_windows >= 8 ? 48 : 24);
+  B->chunk_landmarks = n_windows >= 64 ? 128 : (n_windows >= 8 ? 64 : 32);
   const double thMono = (double)(float)std::sqrt(5.991), thStereo = (double)(float)std::sqrt(7.815);   // Optimizer.cc:1088-1089
   long long NC = 0, NP = 0, NL = 0, NPE = 0, NLO = 0, NF = 0, NPART = 0;
   size_t S_total = 0, x_total = 0, rec_total = 0;
@@ -139,8 +141,11 @@ int lld_ba_batch_create(lld_ctx* ctx, int n_windows, const lld_ba_window* wins, 
     // ---- Schur work items: sort the landmarks by their set of free cameras, cut the runs into chunks, one item per
     //      (chunk, slot pair).  Structure only: outlier levels are handled through zeroed Hpl blocks at run time.
     W.lo_off = (int)NLO; W.n_lo = w.n_ln_obs;
-    W.item_off = (int)B->h_items.size();
+    W.item_off = (int)B->h_chunks.size();
+    const int nfw = w.n_free_cams, nblkw = nfw * (nfw + 1) / 2;
+    std::vector<std::vector<int>> blk_lists(nblkw), cam_lists(nfw);
     for (int D = 3; D <= 4; D++) {
+      if (D == 4) W.n_items_pt = (int)B->h_chunks.size() - W.item_off;
       const int n_lm = D == 3 ? w.n_points : w.n_lines;
       const int32_t* start = D == 3 ? w.pt_obs_start : w.ln_obs_start;
       const int32_t* ocam = D == 3 ? w.pt_obs_cam : w.ln_obs_cam;
@@ -173,14 +178,40 @@ int lld_ba_batch_create(lld_ctx* ctx, int n_windows, const lld_ba_window* wins, 
         C.lm_off = (int)sg_lm.size(); C.tab_off = (int)sg_tab.size(); C.cams_off = (int)sg_cams.size();
         for (auto& pr : sigs[i0].pairs) sg_cams.push_back(pr.first);
         for (size_t i = i0; i < i1; i++) { sg_lm.push_back((int)(lm_base + sigs[i].lm)); for (auto& pr : sigs[i].pairs) sg_tab.push_back(pr.second); }
-        const int ci = (int)B->h_chunks.size();
+        C.part_off = (int)n_part; C.cpart_off = (int)n_cpart;
+        {
+          int pidx = 0;
+          for (int sa = 0; sa < C.k; sa++) {
+            const int ca = sigs[i0].pairs[sa].first;
+            cam_lists[ca].push_back((int)n_cpart + sa);
+            for (int sb = sa; sb < C.k; sb++, pidx++) {
+              const int cb = sigs[i0].pairs[sb].first;                 // cb >= ca (slots are sorted by camera)
+              const int mode = ca != cb ? 0 : (sa == sb ? 1 : 2);
+              blk_lists[cb * (cb + 1) / 2 + ca].push_back(((int)n_part + pidx) * 4 + mode);
+            }
+          }
+          n_part += (size_t)C.k * (C.k + 1) / 2; n_cpart += C.k;
+        }
+        {   // LDS the wavefront needs: staged sub-batch (W, Y, b_l) or the interleave reduction area, whichever is larger
+          const int WN = 6 * D, np = C.k * (C.k + 1) / 2, per_lm = 2 * C.k * WN + D;
+          int NBc = kSwLdsDoubles / per_lm; if (NBc > 64 / C.k) NBc = 64 / C.k; if (NBc < 1) NBc = 1;
+          const int units = std::min(np, 21) * 3, q = 64 / units;
+          const size_t need = std::max((size_t)NBc * per_lm, (size_t)(q - 1) * units * 14) * sizeof(double);
+          B->schur_lds[D - 3] = std::max(B->schur_lds[D - 3], need);
+        }
         B->h_chunks.push_back(C);
-        for (int sa = 0; sa < C.k; sa++) for (int sb = sa; sb < C.k; sb++) { SItem it; it.chunk = ci; it.sab = sa | (sb << 16); B->h_items.push_back(it); }
         i0 = i1;
       }
     }
-    W.n_items = (int)B->h_items.size() - W.item_off;
-    B->max_items = std::max(B->max_items, W.n_items);
+    W.n_items = (int)B->h_chunks.size() - W.item_off;
+    W.blk_csr_off = (int)blk_start.size(); W.cam_csr_off = (int)cam_start.size();
+    for (auto& l : blk_lists) { blk_start.push_back((int)blk_src.size()); blk_src.insert(blk_src.end(), l.begin(), l.end()); }
+    blk_start.push_back((int)blk_src.size());
+    for (auto& l : cam_lists) { cam_start.push_back((int)cam_src.size()); cam_src.insert(cam_src.end(), l.begin(), l.end()); }
+    cam_start.push_back((int)cam_src.size());
+    max_blk = std::max(max_blk, nblkw);
+    if (n_part * 4 > 0x7fffffffull) { delete B; return LLD_ERR_UNSUPPORTED; }
+    B->max_items_pt = std::max(B->max_items_pt, W.n_items_pt); B->max_items_ln = std::max(B->max_items_ln, W.n_items - W.n_items_pt);
     W.rec_off = (long long)rec_total;
     NC += w.n_cams; NP += w.n_points; NL += w.n_lines; NPE += w.n_pt_obs; NLO += w.n_ln_obs; NF += w.n_free_cams;
     NPART += W.nb_pt + W.nb_ln;
@@ -193,6 +224,7 @@ int lld_ba_batch_create(lld_ctx* ctx, int n_windows, const lld_ba_window* wins, 
   }
   pt_obs_start.push_back((int)NPE); ln_obs_start.push_back((int)NLO);
   if (B->max_cams > kPcgThreads) { delete B; return LLD_ERR_UNSUPPORTED; }
+  B->max_blk = max_blk;
   // fixed-stride result records (what an RCCL gather of the batch moves)
   for (int wi = 0; wi < n_windows; wi++) B->h_wins[wi].rec_off = (long long)(B->rec_stride * (size_t)wi);
   rec_total = B->rec_stride * (size_t)n_windows;
@@ -228,12 +260,14 @@ int lld_ba_batch_create(lld_ctx* ctx, int n_windows, const lld_ba_window* wins, 
     A.Hpp = sl.take<double>((size_t)NF * 21 + 1); A.bp = sl.take<double>((size_t)NF * 6 + 1);
     A.S = sl.take<double>(S_total + 1); A.bschur = sl.take<double>(x_total + 1); A.xp = sl.take<double>(x_total + 1);
     A.chi_part = sl.take<double>(NPART + 1); A.chi_part2 = sl.take<double>(NPART + 1); A.scale_part = sl.take<double>(NPART + 1);
+    A.blk_start = up_i(blk_start, blk_start.size() + 1); A.blk_src = up_i(blk_src, blk_src.size() + 1);
+    A.cam_start = up_i(cam_start, cam_start.size() + 1); A.cam_src = up_i(cam_src, cam_src.size() + 1);
+    A.sp_part = sl.take<double>(n_part * 36 + 2); A.sp_cpart = sl.take<double>(n_cpart * 6 + 2);
     A.sg_lm = up_i(sg_lm, sg_lm.size() + 1); A.sg_tab = up_i(sg_tab, sg_tab.size() + 1); A.sg_cams = up_i(sg_cams, sg_cams.size() + 1);
     {
-      SChunk* dc = sl.take<SChunk>(B->h_chunks.size() + 1); SItem* di = sl.take<SItem>(B->h_items.size() + 1);
+      SChunk* dc = sl.take<SChunk>(B->h_chunks.size() + 1);
       if (real && !B->h_chunks.empty()) (void)hipMemcpyAsync(dc, B->h_chunks.data(), B->h_chunks.size() * sizeof(SChunk), hipMemcpyHostToDevice, st);
-      if (real && !B->h_items.empty()) (void)hipMemcpyAsync(di, B->h_items.data(), B->h_items.size() * sizeof(SItem), hipMemcpyHostToDevice, st);
-      A.sg_chunks = dc; A.sg_items = di;
+      A.sg_chunks = dc;
     }
     A.records = sl.take<unsigned char>(rec_total + 256);
     A.counters = sl.take<int>(8);
@@ -285,7 +319,6 @@ int lld_ba_batch_solve(lld_ba_batch* B, volatile const int* abort_flag) {
   const size_t chol_lds = ((size_t)B->max_free * 36 * 2 + (size_t)B->max_free * 6 * 2 + 32) * sizeof(double);
   const dim3 lm_grid(std::max(1, B->max_lblocks), nW);
   const dim3 fin_grid(B->max_lblocks + 1, nW);
-  const dim3 schur_grid((std::max(1, B->max_items) + kSchurThreads - 1) / kSchurThreads, nW);
   const int ctl_blocks = (nW + 63) / 64;
   bool any_left = true;
   if (abort_at_start) {
@@ -309,8 +342,9 @@ int lld_ba_batch_solve(lld_ba_batch* B, volatile const int* abort_flag) {
     hipLaunchKernelGGL(ba_linearize_kernel, lm_grid, dim3(kLmThreads), lin_lds, st, A, B->d_wins, B->d_state);
     hipLaunchKernelGGL(ba_begin_kernel, dim3(ctl_blocks), dim3(64), 0, st, A, B->d_wins, B->d_state, nW);
     LLD_HIP_TRY(hipEventRecord(B->ev[1], st));
-    hipLaunchKernelGGL(ba_schur_init_kernel, dim3(16, nW), dim3(256), 0, st, A, B->d_wins, B->d_state);
-    hipLaunchKernelGGL(ba_schur_items_kernel, schur_grid, dim3(kSchurThreads), 0, st, A, B->d_wins, B->d_state);
+    if (B->max_items_pt > 0) hipLaunchKernelGGL(ba_schur_items_kernel<3>, dim3(B->max_items_pt, nW), dim3(64), B->schur_lds[0], st, A, B->d_wins, B->d_state);
+    if (B->max_items_ln > 0) hipLaunchKernelGGL(ba_schur_items_kernel<4>, dim3(B->max_items_ln, nW), dim3(64), B->schur_lds[1], st, A, B->d_wins, B->d_state);
+    hipLaunchKernelGGL(ba_schur_reduce_kernel, dim3((std::max(1, B->max_blk) * 36 + 255) / 256, nW), dim3(256), 0, st, A, B->d_wins, B->d_state);
     if (B->params.reduced_solver == 1) hipLaunchKernelGGL(ba_symmetrize_kernel, dim3(16, nW), dim3(256), 0, st, A, B->d_wins, B->d_state);
     LLD_HIP_TRY(hipEventRecord(B->ev[2], st));
     if (B->params.reduced_solver == 1)

@@ -50,8 +50,9 @@ struct BAWin {                 // immutable per-window header
   int hpp_off;                 // free-camera accumulators
   int x_off;                   // reduced-system vectors (doubles)
   long long S_off;             // reduced-system matrix (doubles)
-  int item_off, n_items;       // Schur work items (points first, then lines)
+  int item_off, n_items, n_items_pt;   // Schur chunks of this window (range in sg_chunks): n_items_pt point chunks, then line chunks
   int lo_off, n_lo;            // line observations (= le_off / 2)
+  int blk_csr_off, cam_csr_off; // CSR (per lower S block / per free camera) of the chunk partials that add into it
   int nb_pt, nb_ln;            // landmark blocks (kLmThreads landmarks each)
   int part_off;                // per-block partial sums
   int its[2];                  // LM iterations per round
@@ -71,10 +72,9 @@ struct BAState {               // mutable per-window LM state
 };
 
 // Schur work decomposition (built once per window on the host from the camera sets of the landmarks):
-// landmarks that are seen by the SAME set of free cameras are sorted together and cut into chunks; a work item is
-// (chunk, slot pair sa <= sb) and accumulates -Y_a W_b^T over the chunk's landmarks in registers before it touches S.
-struct SChunk { int lm_off, n_lm, tab_off, cams_off, k, D, pad0, pad1; };
-struct SItem { int chunk; int sab; };      // sab = sa | sb << 16
+// landmarks that are seen by the SAME set of free cameras are sorted together and cut into chunks; one wavefront owns a
+// chunk and accumulates -Y_a W_b^T for every camera-slot pair over the chunk's landmarks in registers before it touches S.
+struct SChunk { int lm_off, n_lm, tab_off, cams_off, k, D, part_off, cpart_off; };   // part_off: 36-double blocks, cpart_off: 6-double vectors
 
 struct BAArrays {
   long long NC, NP, NL;        // totals (stride of the double-buffered state arrays)
@@ -108,7 +108,9 @@ struct BAArrays {
   double *S, *bschur, *xp;
   double *chi_part, *chi_part2, *scale_part;
   // Schur work items
-  const SChunk* sg_chunks; const SItem* sg_items;
+  const SChunk* sg_chunks;
+  double *sp_part, *sp_cpart;  // per (chunk, slot pair) 6x6 partial products / per (chunk, slot) 6-vectors
+  const int *blk_start, *blk_src, *cam_start, *cam_src;
   const int *sg_lm, *sg_tab, *sg_cams;
   // results
   unsigned char* records;
@@ -463,140 +465,216 @@ __global__ void ba_begin_kernel(BAArrays A, const BAWin* __restrict__ wins, BASt
 }
 
 // ================================================================== Schur complement
-// (1) ba_schur_init: S <- blockdiag(Hpp + lambda I) on the lower block triangle, bschur <- b_p.   grid (16, nW)
-// (2) ba_schur_items: one lane per work item (chunk of landmarks with one camera set, slot pair sa <= sb).  For every
-//     landmark of the chunk: Dinv = (Hll + lambda I)^-1 (setLambda + the inverse of block_solver.hpp:391),
-//     Y_a = W_a Dinv, acc -= Y_a W_b^T, and for sa == sb also c_a += Y_a b_l (block_solver.hpp:395-428).  The 6x6
-//     product is accumulated in registers over the whole chunk and only then added to S (36 global atomics per item
-//     instead of 36 per landmark pair).  Only the LOWER block triangle is produced (block (cam_b, cam_a), cam_b >= cam_a).
-__global__ __launch_bounds__(256) void ba_schur_init_kernel(BAArrays A, const BAWin* __restrict__ wins, const BAState* __restrict__ st) {
-  const BAWin W = wins[blockIdx.y];
-  const BAState& S = st[blockIdx.y];
-  if (S.phase != PH_RUN) return;
-  const int nf = W.n_free, n = 6 * nf;
-  double* Sg = A.S + W.S_off;
-  const double* Hp = A.Hpp + (size_t)W.hpp_off * 21;
-  const double lambda = S.lambda;
-  const int total = n * n;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
-    const int row = i / n, col = i - row * n;
-    const int bi = row / 6, bj = col / 6;
-    if (bj > bi) continue;
-    double v = 0.0;
-    if (bi == bj) {
-      const int r = row - 6 * bi, c = col - 6 * bj;
-      const int lo = r < c ? r : c, hi = r < c ? c : r;
-      v = Hp[bi * 21 + (lo * 6 - lo * (lo - 1) / 2 + (hi - lo))];
-      if (r == c) v += lambda;
-    }
-    Sg[i] = v;
-  }
-  if (blockIdx.x == 0) {
-    const double* bpv = A.bp + (size_t)W.hpp_off * 6;
-    double* bs = A.bschur + W.x_off;
-    for (int i = threadIdx.x; i < n; i += 256) bs[i] = bpv[i];
-  }
-}
+// (1) ba_schur_items: one wavefront per chunk of landmarks that share one camera set.  For every landmark:
+//     Dinv = (Hll + lambda I)^-1 (setLambda + the inverse of block_solver.hpp:391), Y_a = W_a Dinv, and for every
+//     camera-slot pair sa <= sb the 6x6 product Y_a W_b^T (block_solver.hpp:395-428) is accumulated in registers over the
+//     whole chunk; for sa == sb also c_a += Y_a b_l.  The chunk's partials are stored once (plain stores).
+// (2) ba_schur_reduce: S = blockdiag(Hpp + lambda I) - sum of partials, bschur = b_p - sum c, through a host-built CSR
+//     (lower block -> contributing partials).  Only the LOWER block triangle is produced.  No atomics, fixed order.
+// One wavefront per chunk.  The chunk is swept in sub-batches of up to 8 landmarks that are staged through LDS:
+//   A  lanes copy the sub-batch's Hpl blocks W (contiguous 144/192-B runs) into LDS, zero for inactive landmarks;
+//   B  lane j inverts Hll_j + lambda I once per landmark;
+//   C  lane (j, slot) forms Y = W Dinv once per (landmark, camera slot);
+//   D  lane (pair p = (sa,sb), row pair h) accumulates two rows of Y_a W_b^T over the landmarks in registers
+//      (21 pairs x 3 row pairs = 63 lanes for a point seen by 6 cameras).
+// After the last sub-batch each lane stores its 12 partial sums once.
+constexpr int kSwLdsDoubles = 2304;        // LDS budget per wavefront for the staged sub-batch (18 KiB)
 
 template <int D>
-__device__ __forceinline__ void schur_item(const BAArrays& A, const SChunk& C, int sa, int sb, double lambda, double* __restrict__ Sg,
-                                           double* __restrict__ bs, int n) {
-  constexpr int VN = (D == 3) ? 9 : 14, HU = (D == 3) ? 6 : 10, WN = 6 * D;
+__device__ __forceinline__ void schur_chunk_wave(const BAArrays& A, const SChunk& C, double lambda, double* lds) {
+  constexpr int VN = (D == 3) ? 9 : 14, HU = (D == 3) ? 6 : 10, WN = 6 * D, DD = D * D;
   const double* __restrict__ Vbase = (D == 3) ? A.pt_V : A.ln_V;
   const double* __restrict__ Wbase = (D == 3) ? A.pe_W : A.lo_W;
   const uint8_t* __restrict__ act = (D == 3) ? A.pt_active : A.ln_active;
-  const bool diag = sa == sb;
-  double acc[36], cacc[6];
-#pragma unroll
-  for (int i = 0; i < 36; i++) acc[i] = 0.0;
-#pragma unroll
-  for (int i = 0; i < 6; i++) cacc[i] = 0.0;
+  const int lane = threadIdx.x;
+  const int k = C.k, np = k * (k + 1) / 2;
+  const int per_lm = 2 * k * WN + D;
+  int NB = kSwLdsDoubles / per_lm;
+  if (NB > 64 / k) NB = 64 / k;          // one lane per (landmark, slot) in the staging phase
+  if (NB < 1) NB = 1;
+  { const int u0 = (np < 21 ? np : 21) * 3, q0 = 64 / u0; if (NB > q0) NB -= NB % q0; }   // every interleave lane gets the same number of landmarks
+  double* Wl = lds;
+  double* Yl = Wl + NB * k * WN;
+  double* bll = Yl + NB * k * WN;
   const int* __restrict__ lm = A.sg_lm + C.lm_off;
   const int* __restrict__ tab = A.sg_tab + C.tab_off;
-  const int k = C.k;
-  for (int t = 0; t < C.n_lm; t++) {
-    const int g = lm[t];
-    if (!act[g]) continue;
-    const double* V = Vbase + (size_t)g * VN;
-    double F[D * D], Di[D * D];
-    unpack_sym<D>(V, lambda, F);
-    spd_inverse<D>(F, Di);
-    const double* Wa = Wbase + (size_t)tab[t * k + sa] * WN;
-    const double* Wb = Wbase + (size_t)tab[t * k + sb] * WN;
-    double wb[WN];
+  // lane <-> (slot pair p, row pair h of the 6x6 product, interleave qq): 21 pairs x 3 row pairs = 63 lanes for a point
+  // seen by 6 cameras; 12 accumulators per lane keep the kernel at ~4 waves per SIMD.
+  for (int pass0 = 0; pass0 < np; pass0 += 21) {
+    const int npp = (np - pass0) < 21 ? (np - pass0) : 21;
+    const int units = npp * 3;
+    const int q = 64 / units;
+    const int u = lane % units, qq = lane / units;
+    const int pl = u / 3, h = u - pl * 3;
+    const bool on = qq < q;
+    int sa = 0, rem = pass0 + pl;
+    while (rem >= k - sa) { rem -= k - sa; sa++; }
+    const int sb = sa + rem;
+    const bool diag = sa == sb;
+    double acc[12], cacc[2];
 #pragma unroll
-    for (int i = 0; i < WN; i++) wb[i] = Wb[i];
-    double bl[D];
+    for (int i = 0; i < 12; i++) acc[i] = 0.0;
+    cacc[0] = 0.0; cacc[1] = 0.0;
+    const int slots = NB * k;                               // <= 64: lane e <-> (landmark e / k, slot e % k)
+    const int ej = lane / k, esl = lane - ej * k;
+    for (int t0 = 0; t0 < C.n_lm; t0 += NB) {
+      const int nb = (C.n_lm - t0) < NB ? (C.n_lm - t0) : NB;
+      __syncthreads();                                      // the previous sub-batch has been consumed
+      // lane (landmark, slot): fetch the Hpl block and Hll/b_l with independent 16-B loads (one memory round trip),
+      // invert Hll + lambda I, leave W and Y = W Dinv in LDS
+      if (lane < slots && ej < nb) {
+        const int g = lm[t0 + ej];
+        const int id = tab[(t0 + ej) * k + esl];
+        const bool a = act[g] != 0;
+        const double* V = Vbase + (size_t)g * VN;
+        const double* Wg = Wbase + (size_t)id * WN;
+        double w[WN], v[VN];
 #pragma unroll
-    for (int i = 0; i < D; i++) bl[i] = V[HU + i];
+        for (int i = 0; i < WN; i += 2) { const double2 t2 = *reinterpret_cast<const double2*>(Wg + i); w[i] = t2.x; w[i + 1] = t2.y; }
 #pragma unroll
-    for (int r = 0; r < 6; r++) {
-      double wa[D], y[D];
+        for (int i = 0; i < VN; i++) v[i] = V[i];
+        double Di[DD];
+        if (a) {
+          double F[DD];
+          unpack_sym<D>(v, lambda, F);
+          spd_inverse<D>(F, Di);
+        } else {
 #pragma unroll
-      for (int j = 0; j < D; j++) wa[j] = Wa[r * D + j];
+          for (int i = 0; i < DD; i++) Di[i] = 0.0;
 #pragma unroll
-      for (int q = 0; q < D; q++) {
-        double s = 0.0;
+          for (int i = 0; i < WN; i++) w[i] = 0.0;
+        }
+        double* wl = Wl + lane * WN;
+        double* yl = Yl + lane * WN;
 #pragma unroll
-        for (int j = 0; j < D; j++) s += wa[j] * Di[j * D + q];
-        y[q] = s;
+        for (int i = 0; i < WN; i++) wl[i] = w[i];
+#pragma unroll
+        for (int r = 0; r < 6; r++)
+#pragma unroll
+          for (int c = 0; c < D; c++) {
+            double sacc = 0.0;
+#pragma unroll
+            for (int m = 0; m < D; m++) sacc += w[r * D + m] * Di[m * D + c];
+            yl[r * D + c] = sacc;
+          }
+        if (esl == 0) {
+#pragma unroll
+          for (int i = 0; i < D; i++) bll[ej * D + i] = a ? v[HU + i] : 0.0;
+        }
       }
+      __syncthreads();
+      // D: block products (two rows of Y_a times W_b^T)
+      if (on) {
+        for (int j = qq; j < nb; j += q) {
+          const double* ya = Yl + (j * k + sa) * WN + 2 * h * D;
+          const double* wbp = Wl + (j * k + sb) * WN;
+          double y0[D], y1[D];
 #pragma unroll
-      for (int c = 0; c < 6; c++) {
-        double s = 0.0;
+          for (int m = 0; m < D; m++) { y0[m] = ya[m]; y1[m] = ya[D + m]; }
 #pragma unroll
-        for (int q = 0; q < D; q++) s += y[q] * wb[c * D + q];
-        acc[r * 6 + c] += s;
+          for (int c = 0; c < 6; c++) {
+            double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+            for (int m = 0; m < D; m++) { const double wv = wbp[c * D + m]; s0 += y0[m] * wv; s1 += y1[m] * wv; }
+            acc[c] += s0; acc[6 + c] += s1;
+          }
+          if (diag) {
+            double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+            for (int m = 0; m < D; m++) { const double bv = bll[j * D + m]; s0 += y0[m] * bv; s1 += y1[m] * bv; }
+            cacc[0] += s0; cacc[1] += s1;
+          }
+        }
       }
+    }
+    // sum the interleave partials through LDS (only when a chunk's pairs leave room for interleaving)
+    if (q > 1) {
+      __syncthreads();
+      if (on && qq > 0) {
+        double* dst = lds + ((qq - 1) * units + u) * 14;
+#pragma unroll
+        for (int i = 0; i < 12; i++) dst[i] = acc[i];
+        dst[12] = cacc[0]; dst[13] = cacc[1];
+      }
+      __syncthreads();
+      if (qq == 0) {
+        for (int o = 1; o < q; o++) {
+          const double* src = lds + ((o - 1) * units + u) * 14;
+#pragma unroll
+          for (int i = 0; i < 12; i++) acc[i] += src[i];
+          cacc[0] += src[12]; cacc[1] += src[13];
+        }
+      }
+    }
+    if (qq == 0) {
+      // plain stores of the chunk's partial products; ba_schur_reduce sums them into S in a fixed order (no atomics)
+      double* dst = A.sp_part + (size_t)(C.part_off + pass0 + pl) * 36 + 12 * h;
+#pragma unroll
+      for (int i = 0; i < 12; i += 2) *reinterpret_cast<double2*>(dst + i) = make_double2(acc[i], acc[i + 1]);
       if (diag) {
-        double s = 0.0;
-#pragma unroll
-        for (int q = 0; q < D; q++) s += y[q] * bl[q];
-        cacc[r] += s;
+        double* cd = A.sp_cpart + (size_t)(C.cpart_off + sa) * 6 + 2 * h;
+        cd[0] = cacc[0]; cd[1] = cacc[1];
       }
     }
   }
-  const int ca = A.sg_cams[C.cams_off + sa], cb = A.sg_cams[C.cams_off + sb];
-  if (ca == cb) {
-    // diagonal block: Y_a W_a^T is symmetric; two different observations by the same camera contribute P + P^T
-#pragma unroll
-    for (int r = 0; r < 6; r++)
-#pragma unroll
-      for (int c = 0; c < 6; c++) {
-        const double v = diag ? acc[r * 6 + c] : acc[r * 6 + c] + acc[c * 6 + r];
-        if (v != 0.0) atomicAdd(&Sg[(size_t)(6 * ca + r) * n + 6 * ca + c], -v);
-      }
-  } else {
-    // lower block (cb, ca) = (Y_a W_b^T)^T
-#pragma unroll
-    for (int r = 0; r < 6; r++)
-#pragma unroll
-      for (int c = 0; c < 6; c++) {
-        const double v = acc[r * 6 + c];
-        if (v != 0.0) atomicAdd(&Sg[(size_t)(6 * cb + c) * n + 6 * ca + r], -v);
-      }
-  }
-  if (diag) {
-#pragma unroll
-    for (int r = 0; r < 6; r++) if (cacc[r] != 0.0) atomicAdd(&bs[6 * ca + r], -cacc[r]);
-  }
 }
 
-// grid (ceil(max_items / kSchurThreads), nW)
-__global__ __launch_bounds__(kSchurThreads) void ba_schur_items_kernel(BAArrays A, const BAWin* __restrict__ wins, const BAState* __restrict__ st) {
+// grid (max chunks of this landmark type, nW), block 64 = one wavefront per chunk; dynamic LDS sized by the host.
+template <int D>
+__global__ __launch_bounds__(64) void ba_schur_items_kernel(BAArrays A, const BAWin* __restrict__ wins, const BAState* __restrict__ st) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
   const BAWin W = wins[blockIdx.y];
   const BAState& S = st[blockIdx.y];
   if (S.phase != PH_RUN) return;
-  const int idx = blockIdx.x * kSchurThreads + threadIdx.x;
-  if (idx >= W.n_items) return;
-  const SItem it = A.sg_items[W.item_off + idx];
-  const SChunk C = A.sg_chunks[it.chunk];
-  const int sa = it.sab & 0xffff, sb = it.sab >> 16;
-  double* Sg = A.S + W.S_off;
-  double* bs = A.bschur + W.x_off;
-  const int n = 6 * W.n_free;
-  if (C.D == 3) schur_item<3>(A, C, sa, sb, S.lambda, Sg, bs, n);
-  else schur_item<4>(A, C, sa, sb, S.lambda, Sg, bs, n);
+  const int first = (D == 3) ? W.item_off : W.item_off + W.n_items_pt;
+  const int count = (D == 3) ? W.n_items_pt : W.n_items - W.n_items_pt;
+  if ((int)blockIdx.x >= count) return;
+  const SChunk C = A.sg_chunks[first + blockIdx.x];
+  schur_chunk_wave<D>(A, C, S.lambda, lds);
+}
+
+// grid (ceil(nblk_max * 36 / 256), nW): lane <-> one entry of one lower 6x6 block of S.  S_ij = [i == j](Hpp_i + lambda I)
+// - sum of the chunk partials listed for the block (fixed order -> deterministic), written once with a plain store.
+// blk_src = part_index * 4 + mode; mode 0: partial is Y_a W_b^T for cameras a < b -> transposed into block (b, a);
+// mode 1: same observation on the diagonal; mode 2: two observations by one camera -> P + P^T.
+__global__ __launch_bounds__(256) void ba_schur_reduce_kernel(BAArrays A, const BAWin* __restrict__ wins, const BAState* __restrict__ st) {
+  const BAWin W = wins[blockIdx.y];
+  const BAState& S = st[blockIdx.y];
+  if (S.phase != PH_RUN) return;
+  const int nf = W.n_free, n = 6 * nf, nblk = nf * (nf + 1) / 2;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx < nblk * 36) {
+    const int blk = idx / 36, e = idx - blk * 36, rr = e / 6, cc = e - rr * 6;
+    int i = (int)((sqrt(8.0 * blk + 1.0) - 1.0) * 0.5);
+    while ((i + 1) * (i + 2) / 2 <= blk) i++;
+    while (i * (i + 1) / 2 > blk) i--;
+    const int j = blk - i * (i + 1) / 2;
+    double v = 0.0;
+    if (i == j) {
+      const int lo = rr < cc ? rr : cc, hi = rr < cc ? cc : rr;
+      v = A.Hpp[((size_t)W.hpp_off + i) * 21 + (lo * 6 - lo * (lo - 1) / 2 + (hi - lo))];
+      if (rr == cc) v += S.lambda;
+    }
+    const int* bst = A.blk_start + W.blk_csr_off;
+    for (int q = bst[blk]; q < bst[blk + 1]; q++) {
+      const int src = A.blk_src[q];
+      const double* P = A.sp_part + (size_t)(src >> 2) * 36;
+      const int mode = src & 3;
+      if (mode == 0) v -= P[cc * 6 + rr];
+      else if (mode == 1) v -= P[rr * 6 + cc];
+      else v -= P[rr * 6 + cc] + P[cc * 6 + rr];
+    }
+    A.S[W.S_off + (size_t)(6 * i + rr) * n + 6 * j + cc] = v;
+  }
+  if (blockIdx.x == 0) {
+    const int* cst = A.cam_start + W.cam_csr_off;
+    for (int t = threadIdx.x; t < n; t += 256) {
+      const int c = t / 6, r = t - c * 6;
+      double v = A.bp[(size_t)W.hpp_off * 6 + t];
+      for (int q = cst[c]; q < cst[c + 1]; q++) v -= A.sp_cpart[(size_t)A.cam_src[q] * 6 + r];
+      A.bschur[W.x_off + t] = v;
+    }
+  }
 }
 
 // PCG only: mirror the lower block triangle into the upper one (the column-wise matvec wants the full matrix).  grid (16, nW)

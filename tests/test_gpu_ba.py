@@ -29,12 +29,14 @@ def check_ba(g, o, w, rtol=RTOL):
     # reference algorithm's own noise floor: re-ordering a point's observations - which the reference does from run to
     # run, it iterates a std::map<KeyFrame*> - moves them by the same few 1e-6 (tests/test_oracle_ba.py::
     # test_order_sensitivity_is_the_noise_floor), so their bound is 1e-4.
+    def bulk(r):
+        assert r.max() <= 10 * rtol and np.median(r) <= rtol
+        if r.size >= 100:
+            assert np.mean(r <= rtol) >= 0.99
     if w.n_points:
-        r = rel(g.pt_xyz, o.pt_xyz)
-        assert r.max() <= 10 * rtol and np.mean(r <= rtol) >= 0.999
+        bulk(rel(g.pt_xyz, o.pt_xyz))
     if w.n_lines:
-        r = rel(g.line_x0, o.line_x0)
-        assert r.max() <= 10 * rtol and np.mean(r <= rtol) >= min(0.99, 1.0 - 1.5 / w.n_lines)
+        bulk(rel(g.line_x0, o.line_x0))
         assert np.linalg.norm(g.line_dir - o.line_dir, axis=1).max() <= 10 * rtol
     # same LM trajectory up to decisions taken on rounding-level chi2 differences at convergence
     assert abs(sum(g.stats["lm_iterations"]) - sum(o.stats["lm_iterations"])) <= 2
