@@ -254,7 +254,7 @@ int lld_ba_batch_create(lld_ctx* ctx, int n_windows, const lld_ba_window* wins, 
     A.le_flags0 = up_b(le_flags0, NLE + 1);
     A.pe_flags = sl.take<uint8_t>(NPE + 1); A.le_flags = sl.take<uint8_t>(NLE + 1);
     A.pe_chi2 = sl.take<double>(NPE + 1); A.le_chi2 = sl.take<double>(NLE + 1);
-    A.pe_W = sl.take<double>((size_t)NPE * 18 + 1); A.lo_W = sl.take<double>((size_t)NLO * 24 + 1);
+    A.pe_ws = sl.take<double>((size_t)NPE + 1); A.lo_W = sl.take<double>((size_t)NLO * 24 + 1);
     A.pt_active = sl.take<uint8_t>(NP + 1); A.ln_active = sl.take<uint8_t>(NL + 1); A.ln_removed = sl.take<uint8_t>(NL + 1);
     A.pt_V = sl.take<double>((size_t)NP * 9 + 1); A.ln_V = sl.take<double>((size_t)NL * 14 + 1);
     A.Hpp = sl.take<double>((size_t)NF * 21 + 1); A.bp = sl.take<double>((size_t)NF * 6 + 1);

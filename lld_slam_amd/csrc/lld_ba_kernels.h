@@ -37,7 +37,7 @@ constexpr int kCtlThreads = 64;
 constexpr int kMaxFreeCams = 96;
 
 enum Phase : int { PH_RUN = 0, PH_TRANSITION = 2, PH_FINALIZE = 3, PH_DONE = 4 };
-constexpr uint8_t EF_LEVEL1 = 1, EF_ROBUST = 2, EF_VALID = 4, EF_PAIRSTEREO = 8;
+constexpr uint8_t EF_LEVEL1 = 1, EF_ROBUST = 2, EF_VALID = 4, EF_PAIRSTEREO = 8, EF_STEREO = 16;
 
 struct BAWin {                 // immutable per-window header
   CamK cam;
@@ -96,7 +96,8 @@ struct BAArrays {
   // per-edge mutable
   uint8_t *pe_flags, *le_flags;
   double *pe_chi2, *le_chi2;
-  double *pe_W;                // [NPE*18]  Hpl block 6x3
+  double *pe_ws;               // [NPE] rho' * invSigma2 of the edge at the linearisation point (0 for level-1 edges): the 6x3 Hpl
+                               //       block of a point edge is recomputed from it (point_hpl) instead of being stored
   double *lo_W;                // [NLO*24]  Hpl block 6x4 per (line, KF) observation: left + right edge summed
   // per-landmark mutable
   uint8_t *pt_active, *ln_active, *ln_removed;
@@ -260,7 +261,10 @@ __global__ __launch_bounds__(kLmThreads) void ba_init_kernel(BAArrays A, const B
     A.ln_active[g] = A.ln_obs_start[g + 1] > A.ln_obs_start[g];
     A.ln_removed[g] = 0;
   }
-  for (int e = gid; e < W.n_pe; e += stride) { A.pe_flags[W.pe_off + e] = EF_VALID | EF_ROBUST; A.pe_chi2[W.pe_off + e] = 0.0; }
+  for (int e = gid; e < W.n_pe; e += stride) {
+    A.pe_flags[W.pe_off + e] = (uint8_t)(EF_VALID | EF_ROBUST | (A.pe_ur[W.pe_off + e] < 0 ? 0 : EF_STEREO));
+    A.pe_chi2[W.pe_off + e] = 0.0; A.pe_ws[W.pe_off + e] = 0.0;
+  }
   for (int e = gid; e < W.n_le; e += stride) {
     const uint8_t f0 = A.le_flags0[W.le_off + e];
     A.le_flags[W.le_off + e] = (f0 & EF_VALID) ? (uint8_t)(f0 | EF_ROBUST) : (uint8_t)0;
@@ -305,10 +309,7 @@ __global__ __launch_bounds__(kLmThreads) void ba_linearize_kernel(BAArrays A, co
       for (int e = e0; e < e1; e++) {
         const uint8_t fl = A.pe_flags[e];
         const int c = A.pe_cam[e];
-        if (fl & EF_LEVEL1) {                              // level-1 edge: contributes nothing, its Hpl block must read as zero
-          if (c < W.n_free) { double* Wz = A.pe_W + (size_t)e * 18; for (int i = 0; i < 18; i++) Wz[i] = 0.0; }
-          continue;
-        }
+        if (fl & EF_LEVEL1) { A.pe_ws[e] = 0.0; continue; }   // level-1 edge: contributes nothing, its Hpl block reads as zero
         const Pose T = load_cam(A, cur, W.cam_off + c);
         const Vec3 Xc = pose_map(T, X);
         const double urv = A.pe_ur[e];
@@ -322,6 +323,7 @@ __global__ __launch_bounds__(kLmThreads) void ba_linearize_kernel(BAArrays A, co
         if (fl & EF_ROBUST) rho0 = huber(c2, stereo ? W.th_stereo : W.th_mono, &w);
         chi += rho0;
         const double ws = w * s;
+        A.pe_ws[e] = ws;
         const Mat3 R = quat_rotation(T.q);
         double Jp[9], Jc[18];
         point_jac_point(cam, Xc, R, stereo, Jp);
@@ -335,13 +337,10 @@ __global__ __launch_bounds__(kLmThreads) void ba_linearize_kernel(BAArrays A, co
           for (int d = a; d < 3; d++) H[k++] += ws * (Jp[a] * Jp[d] + Jp[3 + a] * Jp[3 + d] + Jp[6 + a] * Jp[6 + d]);
         }
         if (c < W.n_free) {
-          double* Wb = A.pe_W + (size_t)e * 18;
           double* ac = acc + c * 27;
           int kk = 0;
 #pragma unroll
           for (int rr = 0; rr < 6; rr++) {
-#pragma unroll
-            for (int a = 0; a < 3; a++) Wb[rr * 3 + a] = ws * (Jc[rr] * Jp[a] + Jc[6 + rr] * Jp[3 + a] + Jc[12 + rr] * Jp[6 + a]);
             atomicAdd(&ac[21 + rr], -ws * (Jc[rr] * r[0] + Jc[6 + rr] * r[1] + Jc[12 + rr] * r[2]));
 #pragma unroll
             for (int cc = rr; cc < 6; cc++) atomicAdd(&ac[kk++], ws * (Jc[rr] * Jc[cc] + Jc[6 + rr] * Jc[6 + cc] + Jc[12 + rr] * Jc[12 + cc]));
@@ -481,10 +480,9 @@ __global__ void ba_begin_kernel(BAArrays A, const BAWin* __restrict__ wins, BASt
 constexpr int kSwLdsDoubles = 2304;        // LDS budget per wavefront for the staged sub-batch (18 KiB)
 
 template <int D>
-__device__ __forceinline__ void schur_chunk_wave(const BAArrays& A, const SChunk& C, double lambda, double* lds) {
+__device__ __forceinline__ void schur_chunk_wave(const BAArrays& A, const BAWin& W, const SChunk& C, double lambda, int cur, double* lds) {
   constexpr int VN = (D == 3) ? 9 : 14, HU = (D == 3) ? 6 : 10, WN = 6 * D, DD = D * D;
   const double* __restrict__ Vbase = (D == 3) ? A.pt_V : A.ln_V;
-  const double* __restrict__ Wbase = (D == 3) ? A.pe_W : A.lo_W;
   const uint8_t* __restrict__ act = (D == 3) ? A.pt_active : A.ln_active;
   const int lane = threadIdx.x;
   const int k = C.k, np = k * (k + 1) / 2;
@@ -527,10 +525,19 @@ __device__ __forceinline__ void schur_chunk_wave(const BAArrays& A, const SChunk
         const int id = tab[(t0 + ej) * k + esl];
         const bool a = act[g] != 0;
         const double* V = Vbase + (size_t)g * VN;
-        const double* Wg = Wbase + (size_t)id * WN;
         double w[WN], v[VN];
+        if constexpr (D == 3) {
+          // point edge: the Hpl block is a function of the linearisation-point pose, point and weight only
+          const double ws = A.pe_ws[id];
+          const bool stereo = (A.pe_flags[id] & EF_STEREO) != 0;
+          const Pose T = load_cam(A, cur, W.cam_off + A.sg_cams[C.cams_off + esl]);
+          const Vec3 X = load_pt(A, cur, g);
+          point_hpl(W.cam, T, X, stereo, ws, w);
+        } else {
+          const double* Wg = A.lo_W + (size_t)id * WN;
 #pragma unroll
-        for (int i = 0; i < WN; i += 2) { const double2 t2 = *reinterpret_cast<const double2*>(Wg + i); w[i] = t2.x; w[i + 1] = t2.y; }
+          for (int i = 0; i < WN; i += 2) { const double2 t2 = *reinterpret_cast<const double2*>(Wg + i); w[i] = t2.x; w[i + 1] = t2.y; }
+        }
 #pragma unroll
         for (int i = 0; i < VN; i++) v[i] = V[i];
         double Di[DD];
@@ -630,7 +637,7 @@ __global__ __launch_bounds__(64) void ba_schur_items_kernel(BAArrays A, const BA
   const int count = (D == 3) ? W.n_items_pt : W.n_items - W.n_items_pt;
   if ((int)blockIdx.x >= count) return;
   const SChunk C = A.sg_chunks[first + blockIdx.x];
-  schur_chunk_wave<D>(A, C, S.lambda, lds);
+  schur_chunk_wave<D>(A, W, C, S.lambda, S.cur, lds);
 }
 
 // grid (ceil(nblk_max * 36 / 256), nW): lane <-> one entry of one lower 6x6 block of S.  S_ij = [i == j](Hpp_i + lambda I)
@@ -965,14 +972,24 @@ __global__ __launch_bounds__(kLmThreads) void ba_backsub_kernel(BAArrays A, cons
           if (A.pe_flags[e] & EF_LEVEL1) continue;
           const int c = A.pe_cam[e];
           if (c >= W.n_free) continue;
-          const double* Wb = A.pe_W + (size_t)e * 18;
+          // W_e^T x_c = ws * Jp^T (Jc x_c) with the Jacobians of the linearisation point (current buffer)
+          const double ws = A.pe_ws[e];
+          const bool stereo = (A.pe_flags[e] & EF_STEREO) != 0;
+          const Pose T = load_cam(A, cur, W.cam_off + c);
+          const Vec3 Xc = pose_map(T, X);
+          double Jp[9], Jc[18];
+          point_jac_point(cam, Xc, quat_rotation(T.q), stereo, Jp);
+          point_jac_pose(cam, Xc, stereo, Jc);
+          double uu[3];
 #pragma unroll
-          for (int k = 0; k < 3; k++) {
+          for (int i = 0; i < 3; i++) {
             double s = 0.0;
 #pragma unroll
-            for (int r = 0; r < 6; r++) s += Wb[r * 3 + k] * xp[c * 6 + r];
-            t[k] -= s;
+            for (int r = 0; r < 6; r++) s += Jc[i * 6 + r] * xp[c * 6 + r];
+            uu[i] = ws * s;
           }
+#pragma unroll
+          for (int k = 0; k < 3; k++) t[k] -= Jp[k] * uu[0] + Jp[3 + k] * uu[1] + Jp[6 + k] * uu[2];
         }
         double xl[3];
 #pragma unroll

@@ -237,6 +237,18 @@ LLD_HD void point_jac_point(const CamK& k, const Vec3& Xc, const Mat3& R, bool s
   }
 }
 
+// Hpl block of a point edge, W (6x3, row-major) = ws * Jc^T Jp, recomputed from the linearisation-point state instead of
+// being stored (BaseBinaryEdge::constructQuadraticForm's `_hessian`, core/base_binary_edge.hpp:84-105, transposed).
+LLD_HD void point_hpl(const CamK& k, const Pose& T, const Vec3& X, bool stereo, double ws, double* W) {
+  const Vec3 Xc = pose_map(T, X);
+  const Mat3 R = quat_rotation(T.q);
+  double Jp[9], Jc[18];
+  point_jac_point(k, Xc, R, stereo, Jp);
+  point_jac_pose(k, Xc, stereo, Jc);
+  for (int r = 0; r < 6; r++)
+    for (int a = 0; a < 3; a++) W[r * 3 + a] = ws * (Jc[r] * Jp[a] + Jc[6 + r] * Jp[3 + a] + Jc[12 + r] * Jp[6 + a]);
+}
+
 // ---------------------------------------------------------------- line edges
 // Residual of EdgeSE3ProjectLine / OnlyPose (types_six_dof_expmap.h:344-375, :403-418) plus, optionally, the adjoint
 // vectors a1,a2 with  d r_k = a1[k] . dX1m + a2[k] . dX2m  (X1m, X2m = endpoints in the camera frame, without b).
