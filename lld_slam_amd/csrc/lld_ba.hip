@@ -22,14 +22,18 @@ struct lld_ba_batch {
   void* slab = nullptr; size_t slab_bytes = 0;
   BAArrays A;
   BAWin* d_wins = nullptr; BAState* d_state = nullptr;
-  int* h_counters = nullptr;               // pinned
+  // window groups solved concurrently, each on its own stream (hides the latency-bound reduced solve, the per-super-step
+  // host poll and kernel tails behind the other groups' work)
+  struct Group { int w0 = 0, nw = 0; hipStream_t st = nullptr; bool own_stream = false; int* d_counters = nullptr; int* h_counters = nullptr;
+                 hipEvent_t ev[kNumPhases + 1] = {}; int steps = 0; bool active = false; int max_lblocks = 0, max_items_pt = 0, max_items_ln = 0, max_blk = 0; };
+  std::vector<Group> groups;
+  int* d_counters = nullptr; int* h_counters = nullptr;               // device / pinned, 4 ints per group
   int max_lblocks = 0, max_items_pt = 0, max_items_ln = 0, max_free = 0, max_cams = 0, max_blk = 0;
   size_t schur_lds[2] = {0, 0};
   int chunk_landmarks = 32;
   size_t S_total = 0, x_total = 0;
   size_t rec_stride = 0;
   std::vector<unsigned char> h_records; bool records_valid = false;
-  hipEvent_t ev[kNumPhases + 1] = {};
   double phase_ms[LLD_BA_N_PHASES] = {};
   int64_t launches[kNumPhases] = {};
   int super_steps = 0;
@@ -270,7 +274,7 @@ int lld_ba_batch_create(lld_ctx* ctx, int n_windows, const lld_ba_window* wins, 
       A.sg_chunks = dc;
     }
     A.records = sl.take<unsigned char>(rec_total + 256);
-    A.counters = sl.take<int>(8);
+    B->d_counters = sl.take<int>(4 * 8);
   };
   lld_slab dry; dry.base = reinterpret_cast<char*>(256);
   carve(dry, false);
@@ -286,8 +290,28 @@ int lld_ba_batch_create(lld_ctx* ctx, int n_windows, const lld_ba_window* wins, 
     LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_chol_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)chol_lds));
   }
   LLD_HIP_TRY(hipMemcpyAsync(B->d_wins, B->h_wins.data(), sizeof(BAWin) * n_windows, hipMemcpyHostToDevice, st));
-  LLD_HIP_TRY(hipHostMalloc((void**)&B->h_counters, 8 * sizeof(int), hipHostMallocDefault));
-  for (auto& e : B->ev) LLD_HIP_TRY(hipEventCreate(&e));
+  LLD_HIP_TRY(hipHostMalloc((void**)&B->h_counters, 4 * 8 * sizeof(int), hipHostMallocDefault));
+  {
+    // 1 group for tiny batches, up to 4 for large ones (LLD_BA_GROUPS overrides, for experiments)
+    int G = n_windows >= 192 ? 4 : (n_windows >= 48 ? 3 : (n_windows >= 8 ? 2 : 1));
+    if (const char* e = std::getenv("LLD_BA_GROUPS")) { const int v = std::atoi(e); if (v >= 1 && v <= 8) G = v; }
+    G = std::min(G, n_windows);
+    B->groups.resize(G);
+    for (int g = 0; g < G; g++) {
+      lld_ba_batch::Group& Gr = B->groups[g];
+      Gr.w0 = (int)((long long)n_windows * g / G); Gr.nw = (int)((long long)n_windows * (g + 1) / G) - Gr.w0;
+      if (g == 0) Gr.st = ctx->stream;
+      else { LLD_HIP_TRY(hipStreamCreateWithFlags(&Gr.st, hipStreamNonBlocking)); Gr.own_stream = true; }
+      Gr.d_counters = B->d_counters + 4 * g; Gr.h_counters = B->h_counters + 4 * g;
+      for (auto& e : Gr.ev) LLD_HIP_TRY(hipEventCreate(&e));
+      for (int wi = Gr.w0; wi < Gr.w0 + Gr.nw; wi++) {
+        const BAWin& W = B->h_wins[wi];
+        Gr.max_lblocks = std::max(Gr.max_lblocks, W.nb_pt + W.nb_ln);
+        Gr.max_items_pt = std::max(Gr.max_items_pt, W.n_items_pt); Gr.max_items_ln = std::max(Gr.max_items_ln, W.n_items - W.n_items_pt);
+        Gr.max_blk = std::max(Gr.max_blk, W.n_free * (W.n_free + 1) / 2);
+      }
+    }
+  }
   LLD_HIP_TRY(hipStreamSynchronize(st));        // staging vectors go out of scope
   *out = B;
   return LLD_OK;
@@ -297,8 +321,6 @@ int lld_ba_batch_solve(lld_ba_batch* B, volatile const int* abort_flag) {
   if (!B) return LLD_ERR_INVALID;
   lld_ctx* ctx = B->ctx;
   LLD_HIP_TRY(hipSetDevice(ctx->device));
-  hipStream_t st = ctx->stream;
-  const int nW = B->n_windows;
   BAArrays& A = B->A;
   B->records_valid = false;
   for (auto& m : B->phase_ms) m = 0.0;
@@ -306,85 +328,101 @@ int lld_ba_batch_solve(lld_ba_batch* B, volatile const int* abort_flag) {
   B->super_steps = 0;
   hipEvent_t t_begin, t_end;
   LLD_HIP_TRY(hipEventCreate(&t_begin)); LLD_HIP_TRY(hipEventCreate(&t_end));
-  LLD_HIP_TRY(hipEventRecord(t_begin, st));
-
-  const int init_blocks = std::max(1, std::min(64, B->max_lblocks + 1));
-  hipLaunchKernelGGL(ba_init_kernel, dim3(init_blocks, nW), dim3(kLmThreads), 0, st, A, B->d_wins, B->d_state);
-  LLD_HIP_TRY(hipGetLastError());
-  // Optimizer.cc:1220-1222: a stop request before optimising returns without touching the map -> the read-back kernel copies
-  // the (untouched) working state and every flag stays clear.
-  const bool abort_at_start = abort_flag && *abort_flag;
+  LLD_HIP_TRY(hipEventRecord(t_begin, ctx->stream));
   const size_t lin_lds = ((size_t)B->max_free * 27 + 8) * sizeof(double);
   const size_t pcg_lds = ((size_t)B->max_free * 6 * 4 + kPcgThreads + (size_t)B->max_free * 36 + 32) * sizeof(double);
   const size_t chol_lds = ((size_t)B->max_free * 36 * 2 + (size_t)B->max_free * 6 * 2 + 32) * sizeof(double);
-  const dim3 lm_grid(std::max(1, B->max_lblocks), nW);
-  const dim3 fin_grid(B->max_lblocks + 1, nW);
-  const int ctl_blocks = (nW + 63) / 64;
-  bool any_left = true;
-  if (abort_at_start) {
-    // every window: phase FINALIZE with aborted = 1, no classification (all chi2 are zero, nothing is flagged)
-    std::vector<BAState> hs(nW);
-    std::memset(hs.data(), 0, sizeof(BAState) * nW);
-    for (auto& s : hs) { s.phase = PH_FINALIZE; s.aborted = 1; }
-    LLD_HIP_TRY(hipMemcpyAsync(B->d_state, hs.data(), sizeof(BAState) * nW, hipMemcpyHostToDevice, st));
-    LLD_HIP_TRY(hipStreamSynchronize(st));
-    // the reference returns before anything is classified: emit untouched states with clear flags
-    hipLaunchKernelGGL(ba_finalize_kernel, fin_grid, dim3(kLmThreads), 0, st, A, B->d_wins, B->d_state);
-    hipLaunchKernelGGL(ba_mark_done_kernel, dim3(ctl_blocks), dim3(64), 0, st, B->d_state, nW);
-    LLD_HIP_TRY(hipGetLastError());
-    any_left = false;
-  }
-  while (any_left) {
-    if (B->super_steps >= kMaxSuperSteps) break;
+  // Optimizer.cc:1220-1222: a stop request before optimising returns without touching the map -> the read-back kernel copies
+  // the (untouched) working state and every flag stays clear.
+  const bool abort_at_start = abort_flag && *abort_flag;
+  using Group = lld_ba_batch::Group;
+
+  auto finalize_group = [&](Group& G) {
+    const BAWin* dw = B->d_wins + G.w0; BAState* ds = B->d_state + G.w0;
+    hipLaunchKernelGGL(ba_finalize_kernel, dim3(G.max_lblocks + 1, G.nw), dim3(kLmThreads), 0, G.st, A, dw, ds);
+    hipLaunchKernelGGL(ba_mark_done_kernel, dim3((G.nw + 63) / 64), dim3(64), 0, G.st, ds, G.nw);
+  };
+  // one super-step of one group: linearise (windows that need it) -> Schur -> reduced solve -> back-substitution + trial chi2
+  // -> LM control; then the three phase counters travel to pinned host memory and ev[5] marks the end.
+  auto launch_superstep = [&](Group& G) -> int {
+    const BAWin* dw = B->d_wins + G.w0; BAState* ds = B->d_state + G.w0;
+    const int nw = G.nw; hipStream_t st = G.st;
     const int abort_now = (abort_flag && *abort_flag) ? 1 : 0;
-    LLD_HIP_TRY(hipMemsetAsync(A.counters, 0, 4 * sizeof(int), st));
-    LLD_HIP_TRY(hipEventRecord(B->ev[0], st));
-    hipLaunchKernelGGL(ba_linearize_kernel, lm_grid, dim3(kLmThreads), lin_lds, st, A, B->d_wins, B->d_state);
-    hipLaunchKernelGGL(ba_begin_kernel, dim3(ctl_blocks), dim3(64), 0, st, A, B->d_wins, B->d_state, nW);
-    LLD_HIP_TRY(hipEventRecord(B->ev[1], st));
-    if (B->max_items_pt > 0) hipLaunchKernelGGL(ba_schur_items_kernel<3>, dim3(B->max_items_pt, nW), dim3(64), B->schur_lds[0], st, A, B->d_wins, B->d_state);
-    if (B->max_items_ln > 0) hipLaunchKernelGGL(ba_schur_items_kernel<4>, dim3(B->max_items_ln, nW), dim3(64), B->schur_lds[1], st, A, B->d_wins, B->d_state);
-    hipLaunchKernelGGL(ba_schur_reduce_kernel, dim3((std::max(1, B->max_blk) * 36 + 255) / 256, nW), dim3(256), 0, st, A, B->d_wins, B->d_state);
-    if (B->params.reduced_solver == 1) hipLaunchKernelGGL(ba_symmetrize_kernel, dim3(16, nW), dim3(256), 0, st, A, B->d_wins, B->d_state);
-    LLD_HIP_TRY(hipEventRecord(B->ev[2], st));
+    const dim3 lm_grid(std::max(1, G.max_lblocks), nw);
+    LLD_HIP_TRY(hipMemsetAsync(G.d_counters, 0, 4 * sizeof(int), st));
+    LLD_HIP_TRY(hipEventRecord(G.ev[0], st));
+    hipLaunchKernelGGL(ba_linearize_kernel, lm_grid, dim3(kLmThreads), lin_lds, st, A, dw, ds);
+    hipLaunchKernelGGL(ba_begin_kernel, dim3((nw + 63) / 64), dim3(64), 0, st, A, dw, ds, nw);
+    LLD_HIP_TRY(hipEventRecord(G.ev[1], st));
+    if (G.max_items_pt > 0) hipLaunchKernelGGL(ba_schur_items_kernel<3>, dim3(G.max_items_pt, nw), dim3(64), B->schur_lds[0], st, A, dw, ds);
+    if (G.max_items_ln > 0) hipLaunchKernelGGL(ba_schur_items_kernel<4>, dim3(G.max_items_ln, nw), dim3(64), B->schur_lds[1], st, A, dw, ds);
+    hipLaunchKernelGGL(ba_schur_reduce_kernel, dim3((std::max(1, G.max_blk) * 36 + 255) / 256, nw), dim3(256), 0, st, A, dw, ds);
+    if (B->params.reduced_solver == 1) hipLaunchKernelGGL(ba_symmetrize_kernel, dim3(16, nw), dim3(256), 0, st, A, dw, ds);
+    LLD_HIP_TRY(hipEventRecord(G.ev[2], st));
     if (B->params.reduced_solver == 1)
-      hipLaunchKernelGGL(ba_pcg_kernel, dim3(nW), dim3(kPcgThreads), pcg_lds, st, A, B->d_wins, B->d_state, B->params.pcg_rel_tol, B->params.pcg_max_iter);
+      hipLaunchKernelGGL(ba_pcg_kernel, dim3(nw), dim3(kPcgThreads), pcg_lds, st, A, dw, ds, B->params.pcg_rel_tol, B->params.pcg_max_iter);
     else
-      hipLaunchKernelGGL(ba_chol_kernel, dim3(nW), dim3(kPcgThreads), chol_lds, st, A, B->d_wins, B->d_state);
-    LLD_HIP_TRY(hipEventRecord(B->ev[3], st));
-    hipLaunchKernelGGL(ba_backsub_kernel, lm_grid, dim3(kLmThreads), 0, st, A, B->d_wins, B->d_state);
-    LLD_HIP_TRY(hipEventRecord(B->ev[4], st));
-    hipLaunchKernelGGL(ba_control_kernel, dim3(nW), dim3(kCtlThreads), 0, st, A, B->d_wins, B->d_state, abort_now);
+      hipLaunchKernelGGL(ba_chol_kernel, dim3(nw), dim3(kPcgThreads), chol_lds, st, A, dw, ds);
+    LLD_HIP_TRY(hipEventRecord(G.ev[3], st));
+    hipLaunchKernelGGL(ba_backsub_kernel, lm_grid, dim3(kLmThreads), 0, st, A, dw, ds);
+    LLD_HIP_TRY(hipEventRecord(G.ev[4], st));
+    hipLaunchKernelGGL(ba_control_kernel, dim3(nw), dim3(kCtlThreads), 0, st, A, dw, ds, abort_now, G.d_counters);
     LLD_HIP_TRY(hipGetLastError());
-    LLD_HIP_TRY(hipMemcpyAsync(B->h_counters, A.counters, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
-    LLD_HIP_TRY(hipStreamSynchronize(st));
-    const int n_run = B->h_counters[0], n_trans = B->h_counters[1], n_fin = B->h_counters[2];
-    if (n_trans > 0) {
-      hipLaunchKernelGGL(ba_classify_kernel, lm_grid, dim3(kLmThreads), 0, st, A, B->d_wins, B->d_state);
-      hipLaunchKernelGGL(ba_round2_kernel, dim3(nW), dim3(kCtlThreads), 0, st, A, B->d_wins, B->d_state);
-    }
-    if (n_fin > 0) {
-      hipLaunchKernelGGL(ba_finalize_kernel, fin_grid, dim3(kLmThreads), 0, st, A, B->d_wins, B->d_state);
-      hipLaunchKernelGGL(ba_mark_done_kernel, dim3(ctl_blocks), dim3(64), 0, st, B->d_state, nW);
-    }
-    LLD_HIP_TRY(hipEventRecord(B->ev[5], st));
+    LLD_HIP_TRY(hipMemcpyAsync(G.h_counters, G.d_counters, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
+    LLD_HIP_TRY(hipEventRecord(G.ev[5], st));
+    return LLD_OK;
+  };
+
+  for (Group& G : B->groups) {
+    const BAWin* dw = B->d_wins + G.w0; BAState* ds = B->d_state + G.w0;
+    if (G.own_stream) LLD_HIP_TRY(hipStreamWaitEvent(G.st, t_begin, 0));
+    G.steps = 0; G.active = !abort_at_start;
+    hipLaunchKernelGGL(ba_init_kernel, dim3(std::max(1, std::min(64, G.max_lblocks + 1)), G.nw), dim3(kLmThreads), 0, G.st, A, dw, ds);
     LLD_HIP_TRY(hipGetLastError());
-    LLD_HIP_TRY(hipEventSynchronize(B->ev[5]));
-    for (int k = 0; k < kNumPhases; k++) {
-      float ms = 0.f;
-      if (hipEventElapsedTime(&ms, B->ev[k], B->ev[k + 1]) == hipSuccess) B->phase_ms[k] += ms;
-      B->launches[k]++;
+    if (abort_at_start) {
+      // every window: phase FINALIZE with aborted = 1; the read-back emits untouched states with clear flags
+      std::vector<BAState> hs(G.nw);
+      std::memset(hs.data(), 0, sizeof(BAState) * G.nw);
+      for (auto& s : hs) { s.phase = PH_FINALIZE; s.aborted = 1; }
+      LLD_HIP_TRY(hipMemcpyAsync(ds, hs.data(), sizeof(BAState) * G.nw, hipMemcpyHostToDevice, G.st));
+      LLD_HIP_TRY(hipStreamSynchronize(G.st));
+      finalize_group(G);
+    } else {
+      int s = launch_superstep(G); if (s) return s;
     }
-    B->super_steps++;
-    // a window that classified may have an empty active set and go straight to FINALIZE: it is picked up next step
-    any_left = (n_run + n_trans) > 0;
-    if (!any_left && n_trans == 0) break;
   }
-  // windows that ba_round2 sent straight to FINALIZE (empty active set) or that hit the hard stop
-  hipLaunchKernelGGL(ba_finalize_kernel, fin_grid, dim3(kLmThreads), 0, st, A, B->d_wins, B->d_state);
-  hipLaunchKernelGGL(ba_mark_done_kernel, dim3(ctl_blocks), dim3(64), 0, st, B->d_state, nW);
-  LLD_HIP_TRY(hipGetLastError());
-  LLD_HIP_TRY(hipEventRecord(t_end, st));
+  // round-robin over the groups: wait for a group's super-step, read its counters, queue its next one; the other groups'
+  // kernels keep the GPU busy meanwhile
+  for (bool any = !abort_at_start; any;) {
+    any = false;
+    for (Group& G : B->groups) {
+      if (!G.active) continue;
+      LLD_HIP_TRY(hipEventSynchronize(G.ev[5]));
+      for (int k = 0; k < kNumPhases; k++) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, G.ev[k], G.ev[k + 1]) == hipSuccess) B->phase_ms[k] += ms;
+        B->launches[k]++;
+      }
+      G.steps++; B->super_steps++;
+      const int n_run = G.h_counters[0], n_trans = G.h_counters[1], n_fin = G.h_counters[2];
+      const BAWin* dw = B->d_wins + G.w0; BAState* ds = B->d_state + G.w0;
+      if (n_trans > 0) {
+        hipLaunchKernelGGL(ba_classify_kernel, dim3(std::max(1, G.max_lblocks), G.nw), dim3(kLmThreads), 0, G.st, A, dw, ds);
+        hipLaunchKernelGGL(ba_round2_kernel, dim3(G.nw), dim3(kCtlThreads), 0, G.st, A, dw, ds);
+      }
+      if (n_fin > 0) finalize_group(G);
+      LLD_HIP_TRY(hipGetLastError());
+      // a window whose classification leaves an empty active set goes straight to FINALIZE: the trailing read-back picks it up
+      if ((n_run + n_trans) > 0 && G.steps < kMaxSuperSteps) { int s = launch_superstep(G); if (s) return s; any = true; }
+      else G.active = false;
+    }
+  }
+  for (Group& G : B->groups) {
+    finalize_group(G);                       // windows sent straight to FINALIZE by ba_round2, or stopped by the hard limit
+    LLD_HIP_TRY(hipGetLastError());
+    if (G.own_stream) { LLD_HIP_TRY(hipEventRecord(G.ev[0], G.st)); LLD_HIP_TRY(hipStreamWaitEvent(ctx->stream, G.ev[0], 0)); }
+  }
+  LLD_HIP_TRY(hipEventRecord(t_end, ctx->stream));
   LLD_HIP_TRY(hipEventSynchronize(t_end));
   float tot = 0.f;
   (void)hipEventElapsedTime(&tot, t_begin, t_end);
@@ -471,7 +509,7 @@ void lld_ba_batch_destroy(lld_ba_batch* B) {
   if (!B) return;
   (void)hipSetDevice(B->ctx->device);
   (void)hipStreamSynchronize(B->ctx->stream);
-  for (auto& e : B->ev) if (e) (void)hipEventDestroy(e);
+  for (auto& G : B->groups) { for (auto& e : G.ev) if (e) (void)hipEventDestroy(e); if (G.own_stream && G.st) { (void)hipStreamSynchronize(G.st); (void)hipStreamDestroy(G.st); } }
   if (B->h_counters) (void)hipHostFree(B->h_counters);
   if (B->slab) (void)hipFree(B->slab);
   delete B;

@@ -115,7 +115,6 @@ struct BAArrays {
   const int *sg_lm, *sg_tab, *sg_cams;
   // results
   unsigned char* records;
-  int* counters;               // [4]: running, transition, finalize
 };
 
 // ------------------------------------------------------------------ small helpers
@@ -1074,7 +1073,8 @@ __global__ __launch_bounds__(kLmThreads) void ba_backsub_kernel(BAArrays A, cons
 // grid (nW), block 64: lane 0 takes the accept / reject decision of the trial that just ran
 // (optimization_algorithm_levenberg.cpp:118-163) and advances the window's state machine; all lanes then clear the
 // camera accumulators when a new linearisation is due.
-__global__ __launch_bounds__(kCtlThreads) void ba_control_kernel(BAArrays A, const BAWin* __restrict__ wins, BAState* __restrict__ st, int abort_flag) {
+__global__ __launch_bounds__(kCtlThreads) void ba_control_kernel(BAArrays A, const BAWin* __restrict__ wins, BAState* __restrict__ st, int abort_flag,
+                                                                 int* __restrict__ counters /* [3]: running, transition, finalize */) {
   __shared__ int do_clear;
   const BAWin& W = wins[blockIdx.x];
   BAState& S = st[blockIdx.x];
@@ -1125,9 +1125,9 @@ __global__ __launch_bounds__(kCtlThreads) void ba_control_kernel(BAArrays A, con
   }
   if (threadIdx.x == 0) {
     const int ph = S.phase;
-    if (ph == PH_RUN) atomicAdd(&A.counters[0], 1);
-    else if (ph == PH_TRANSITION) atomicAdd(&A.counters[1], 1);
-    else if (ph == PH_FINALIZE) atomicAdd(&A.counters[2], 1);
+    if (ph == PH_RUN) atomicAdd(&counters[0], 1);
+    else if (ph == PH_TRANSITION) atomicAdd(&counters[1], 1);
+    else if (ph == PH_FINALIZE) atomicAdd(&counters[2], 1);
   }
 }
 
