@@ -197,7 +197,7 @@ int lld_ba_batch_create(lld_ctx* ctx, int n_windows, const lld_ba_window* wins, 
           n_part += (size_t)C.k * (C.k + 1) / 2; n_cpart += C.k;
         }
         {   // LDS the wavefront needs: staged sub-batch (W, Y, b_l) or the interleave reduction area, whichever is larger
-          const int WN = 6 * D, np = C.k * (C.k + 1) / 2, per_lm = 2 * C.k * WN + D;
+          const int WS = D == 3 ? 18 : 26, np = C.k * (C.k + 1) / 2, per_lm = 2 * C.k * WS + D;
           int NBc = kSwLdsDoubles / per_lm; if (NBc > 64 / C.k) NBc = 64 / C.k; if (NBc < 1) NBc = 1;
           const int units = std::min(np, 21) * 3, q = 64 / units;
           const size_t need = std::max((size_t)NBc * per_lm, (size_t)(q - 1) * units * 14) * sizeof(double);
@@ -356,7 +356,7 @@ int lld_ba_batch_solve(lld_ba_batch* B, volatile const int* abort_flag) {
     LLD_HIP_TRY(hipEventRecord(G.ev[1], st));
     if (G.max_items_pt > 0) hipLaunchKernelGGL(ba_schur_items_kernel<3>, dim3(G.max_items_pt, nw), dim3(64), B->schur_lds[0], st, A, dw, ds);
     if (G.max_items_ln > 0) hipLaunchKernelGGL(ba_schur_items_kernel<4>, dim3(G.max_items_ln, nw), dim3(64), B->schur_lds[1], st, A, dw, ds);
-    hipLaunchKernelGGL(ba_schur_reduce_kernel, dim3((std::max(1, G.max_blk) * 36 + 255) / 256, nw), dim3(256), 0, st, A, dw, ds);
+    hipLaunchKernelGGL(ba_schur_reduce_kernel, dim3((std::max(1, G.max_blk) * 6 + 255) / 256, nw), dim3(256), 0, st, A, dw, ds);
     if (B->params.reduced_solver == 1) hipLaunchKernelGGL(ba_symmetrize_kernel, dim3(16, nw), dim3(256), 0, st, A, dw, ds);
     LLD_HIP_TRY(hipEventRecord(G.ev[2], st));
     if (B->params.reduced_solver == 1)

@@ -481,18 +481,21 @@ constexpr int kSwLdsDoubles = 2304;        // LDS budget per wavefront for the s
 template <int D>
 __device__ __forceinline__ void schur_chunk_wave(const BAArrays& A, const BAWin& W, const SChunk& C, double lambda, int cur, double* lds) {
   constexpr int VN = (D == 3) ? 9 : 14, HU = (D == 3) ? 6 : 10, WN = 6 * D, DD = D * D;
+  // LDS stride of a staged 6xD block: 144 B for points (conflict-free as is); 192 B would put slots 0 and 4 of a line on the
+  // same banks, so line blocks are padded to 208 B (still 16-B aligned)
+  constexpr int WS = (D == 3) ? 18 : 26;
   const double* __restrict__ Vbase = (D == 3) ? A.pt_V : A.ln_V;
   const uint8_t* __restrict__ act = (D == 3) ? A.pt_active : A.ln_active;
   const int lane = threadIdx.x;
   const int k = C.k, np = k * (k + 1) / 2;
-  const int per_lm = 2 * k * WN + D;
+  const int per_lm = 2 * k * WS + D;
   int NB = kSwLdsDoubles / per_lm;
   if (NB > 64 / k) NB = 64 / k;          // one lane per (landmark, slot) in the staging phase
   if (NB < 1) NB = 1;
   { const int u0 = (np < 21 ? np : 21) * 3, q0 = 64 / u0; if (NB > q0) NB -= NB % q0; }   // every interleave lane gets the same number of landmarks
   double* Wl = lds;
-  double* Yl = Wl + NB * k * WN;
-  double* bll = Yl + NB * k * WN;
+  double* Yl = Wl + NB * k * WS;
+  double* bll = Yl + NB * k * WS;
   const int* __restrict__ lm = A.sg_lm + C.lm_off;
   const int* __restrict__ tab = A.sg_tab + C.tab_off;
   // lane <-> (slot pair p, row pair h of the 6x6 product, interleave qq): 21 pairs x 3 row pairs = 63 lanes for a point
@@ -550,8 +553,8 @@ __device__ __forceinline__ void schur_chunk_wave(const BAArrays& A, const BAWin&
 #pragma unroll
           for (int i = 0; i < WN; i++) w[i] = 0.0;
         }
-        double* wl = Wl + lane * WN;
-        double* yl = Yl + lane * WN;
+        double* wl = Wl + lane * WS;
+        double* yl = Yl + lane * WS;
 #pragma unroll
         for (int i = 0; i < WN; i++) wl[i] = w[i];
 #pragma unroll
@@ -572,8 +575,8 @@ __device__ __forceinline__ void schur_chunk_wave(const BAArrays& A, const BAWin&
       // D: block products (two rows of Y_a times W_b^T)
       if (on) {
         for (int j = qq; j < nb; j += q) {
-          const double* ya = Yl + (j * k + sa) * WN + 2 * h * D;
-          const double* wbp = Wl + (j * k + sb) * WN;
+          const double* ya = Yl + (j * k + sa) * WS + 2 * h * D;
+          const double* wbp = Wl + (j * k + sb) * WS;
           double y0[D], y1[D];
 #pragma unroll
           for (int m = 0; m < D; m++) { y0[m] = ya[m]; y1[m] = ya[D + m]; }
@@ -639,7 +642,7 @@ __global__ __launch_bounds__(64) void ba_schur_items_kernel(BAArrays A, const BA
   schur_chunk_wave<D>(A, W, C, S.lambda, S.cur, lds);
 }
 
-// grid (ceil(nblk_max * 36 / 256), nW): lane <-> one entry of one lower 6x6 block of S.  S_ij = [i == j](Hpp_i + lambda I)
+// grid (ceil(nblk_max * 6 / 256), nW): lane <-> one row of one lower 6x6 block of S.  S_ij = [i == j](Hpp_i + lambda I)
 // - sum of the chunk partials listed for the block (fixed order -> deterministic), written once with a plain store.
 // blk_src = part_index * 4 + mode; mode 0: partial is Y_a W_b^T for cameras a < b -> transposed into block (b, a);
 // mode 1: same observation on the diagonal; mode 2: two observations by one camera -> P + P^T.
@@ -648,29 +651,43 @@ __global__ __launch_bounds__(256) void ba_schur_reduce_kernel(BAArrays A, const 
   const BAState& S = st[blockIdx.y];
   if (S.phase != PH_RUN) return;
   const int nf = W.n_free, n = 6 * nf, nblk = nf * (nf + 1) / 2;
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx < nblk * 36) {
-    const int blk = idx / 36, e = idx - blk * 36, rr = e / 6, cc = e - rr * 6;
+  const int idx = blockIdx.x * 256 + threadIdx.x;       // lane <-> one row of one lower 6x6 block
+  if (idx < nblk * 6) {
+    const int blk = idx / 6, rr = idx - blk * 6;
     int i = (int)((sqrt(8.0 * blk + 1.0) - 1.0) * 0.5);
     while ((i + 1) * (i + 2) / 2 <= blk) i++;
     while (i * (i + 1) / 2 > blk) i--;
     const int j = blk - i * (i + 1) / 2;
-    double v = 0.0;
+    double v[6] = {0, 0, 0, 0, 0, 0};
     if (i == j) {
-      const int lo = rr < cc ? rr : cc, hi = rr < cc ? cc : rr;
-      v = A.Hpp[((size_t)W.hpp_off + i) * 21 + (lo * 6 - lo * (lo - 1) / 2 + (hi - lo))];
-      if (rr == cc) v += S.lambda;
+      const double* Hp = A.Hpp + ((size_t)W.hpp_off + i) * 21;
+#pragma unroll
+      for (int cc = 0; cc < 6; cc++) {
+        const int lo = rr < cc ? rr : cc, hi = rr < cc ? cc : rr;
+        v[cc] = Hp[lo * 6 - lo * (lo - 1) / 2 + (hi - lo)];
+      }
+      v[rr] += S.lambda;
     }
     const int* bst = A.blk_start + W.blk_csr_off;
-    for (int q = bst[blk]; q < bst[blk + 1]; q++) {
+    const int q0 = bst[blk], q1 = bst[blk + 1];
+    for (int q = q0; q < q1; q++) {
       const int src = A.blk_src[q];
       const double* P = A.sp_part + (size_t)(src >> 2) * 36;
       const int mode = src & 3;
-      if (mode == 0) v -= P[cc * 6 + rr];
-      else if (mode == 1) v -= P[rr * 6 + cc];
-      else v -= P[rr * 6 + cc] + P[cc * 6 + rr];
+      if (mode == 0) {
+#pragma unroll
+        for (int cc = 0; cc < 6; cc++) v[cc] -= P[cc * 6 + rr];
+      } else if (mode == 1) {
+#pragma unroll
+        for (int cc = 0; cc < 6; cc++) v[cc] -= P[rr * 6 + cc];
+      } else {
+#pragma unroll
+        for (int cc = 0; cc < 6; cc++) v[cc] -= P[rr * 6 + cc] + P[cc * 6 + rr];
+      }
     }
-    A.S[W.S_off + (size_t)(6 * i + rr) * n + 6 * j + cc] = v;
+    double* dst = A.S + W.S_off + (size_t)(6 * i + rr) * n + 6 * j;
+#pragma unroll
+    for (int cc = 0; cc < 6; cc += 2) *reinterpret_cast<double2*>(dst + cc) = make_double2(v[cc], v[cc + 1]);
   }
   if (blockIdx.x == 0) {
     const int* cst = A.cam_start + W.cam_csr_off;
