@@ -17,7 +17,7 @@ struct lld_ba_batch {
   int n_windows = 0;
   lld_ba_params params;
   std::vector<BAWin> h_wins;
-  std::vector<SChunk> h_chunks;
+  std::vector<SChunk> h_chunks; std::vector<PTask> h_ptasks, h_ltasks;
   std::vector<const lld_ba_window*> unused;
   void* slab = nullptr; size_t slab_bytes = 0;
   BAArrays A;
@@ -25,7 +25,7 @@ struct lld_ba_batch {
   // window groups solved concurrently, each on its own stream (hides the latency-bound reduced solve, the per-super-step
   // host poll and kernel tails behind the other groups' work)
   struct Group { int w0 = 0, nw = 0; hipStream_t st = nullptr; bool own_stream = false; int* d_counters = nullptr; int* h_counters = nullptr;
-                 hipEvent_t ev[kNumPhases + 1] = {}; int steps = 0; bool active = false; int max_lblocks = 0, max_items_pt = 0, max_items_ln = 0, max_blk = 0; };
+                 hipEvent_t ev[kNumPhases + 1] = {}; int steps = 0; bool active = false; int max_nt_pt = 0, max_nb_ln = 0, max_lblocks = 0, max_items_pt = 0, max_items_ln = 0, max_blk = 0; };
   std::vector<Group> groups;
   int* d_counters = nullptr; int* h_counters = nullptr;               // device / pinned, 4 ints per group
   int max_lblocks = 0, max_items_pt = 0, max_items_ln = 0, max_free = 0, max_cams = 0, max_blk = 0;
@@ -111,6 +111,31 @@ int lld_ba_batch_create(lld_ctx* ctx, int n_windows, const lld_ba_window* wins, 
     W.pe_off = (int)NPE; W.n_pe = w.n_pt_obs; W.le_off = (int)(2 * NLO); W.n_le = 2 * w.n_ln_obs;
     W.hpp_off = (int)NF; W.x_off = (int)x_total; W.S_off = (long long)S_total;
     W.nb_pt = (w.n_points + kLmThreads - 1) / kLmThreads; W.nb_ln = (w.n_lines + kLmThreads - 1) / kLmThreads;
+    // point tasks for the lane-per-edge kernels: consecutive landmarks while their edges fit into one wavefront
+    W.ptask_off = (int)B->h_ptasks.size();
+    for (int p = 0; p < w.n_points;) {
+      PTask T; T.l0 = p; T.e0 = (int)NPE + w.pt_obs_start[p]; T.nl = 0; T.ne = 0;
+      while (p < w.n_points) {
+        const int ne = w.pt_obs_start[p + 1] - w.pt_obs_start[p];
+        if (T.nl > 0 && (T.ne + ne > 64 || T.nl >= 64)) break;
+        T.nl++; T.ne += ne; p++;
+        if (T.ne > 64) break;                      // a landmark with more than 64 edges is a task of its own
+      }
+      B->h_ptasks.push_back(T);
+    }
+    W.n_ptasks = (int)B->h_ptasks.size() - W.ptask_off; W.nt_pt = (W.n_ptasks + 3) / 4;
+    W.ltask_off = (int)B->h_ltasks.size();
+    for (int l = 0; l < w.n_lines;) {                // line tasks: lane <-> (line, KF) observation
+      PTask T; T.l0 = l; T.e0 = (int)NLO + w.ln_obs_start[l]; T.nl = 0; T.ne = 0;
+      while (l < w.n_lines) {
+        const int no = w.ln_obs_start[l + 1] - w.ln_obs_start[l];
+        if (T.nl > 0 && (T.ne + no > 64 || T.nl >= 64)) break;
+        T.nl++; T.ne += no; l++;
+        if (T.ne > 64) break;
+      }
+      B->h_ltasks.push_back(T);
+    }
+    W.n_ltasks = (int)B->h_ltasks.size() - W.ltask_off; W.nt_ln = (W.n_ltasks + 3) / 4;
     W.part_off = (int)NPART;
     W.its[0] = P.its_round1; W.its[1] = P.its_round2; W.max_trials = P.max_trials; W.ln_filter = P.ln_filter;
     W.th_mono = thMono; W.th_stereo = thStereo;
@@ -218,7 +243,7 @@ int lld_ba_batch_create(lld_ctx* ctx, int n_windows, const lld_ba_window* wins, 
     B->max_items_pt = std::max(B->max_items_pt, W.n_items_pt); B->max_items_ln = std::max(B->max_items_ln, W.n_items - W.n_items_pt);
     W.rec_off = (long long)rec_total;
     NC += w.n_cams; NP += w.n_points; NL += w.n_lines; NPE += w.n_pt_obs; NLO += w.n_ln_obs; NF += w.n_free_cams;
-    NPART += W.nb_pt + W.nb_ln;
+    NPART += W.nt_pt + W.nt_ln;
     const size_t n = 6 * (size_t)w.n_free_cams;
     S_total += n * n; x_total += n;
     B->max_lblocks = std::max(B->max_lblocks, W.nb_pt + W.nb_ln);
@@ -272,6 +297,12 @@ int lld_ba_batch_create(lld_ctx* ctx, int n_windows, const lld_ba_window* wins, 
       SChunk* dc = sl.take<SChunk>(B->h_chunks.size() + 1);
       if (real && !B->h_chunks.empty()) (void)hipMemcpyAsync(dc, B->h_chunks.data(), B->h_chunks.size() * sizeof(SChunk), hipMemcpyHostToDevice, st);
       A.sg_chunks = dc;
+      PTask* dt = sl.take<PTask>(B->h_ptasks.size() + 1);
+      if (real && !B->h_ptasks.empty()) (void)hipMemcpyAsync(dt, B->h_ptasks.data(), B->h_ptasks.size() * sizeof(PTask), hipMemcpyHostToDevice, st);
+      A.ptasks = dt;
+      PTask* dl = sl.take<PTask>(B->h_ltasks.size() + 1);
+      if (real && !B->h_ltasks.empty()) (void)hipMemcpyAsync(dl, B->h_ltasks.data(), B->h_ltasks.size() * sizeof(PTask), hipMemcpyHostToDevice, st);
+      A.ltasks = dl;
     }
     A.records = sl.take<unsigned char>(rec_total + 256);
     B->d_counters = sl.take<int>(4 * 8);
@@ -307,6 +338,7 @@ int lld_ba_batch_create(lld_ctx* ctx, int n_windows, const lld_ba_window* wins, 
       for (int wi = Gr.w0; wi < Gr.w0 + Gr.nw; wi++) {
         const BAWin& W = B->h_wins[wi];
         Gr.max_lblocks = std::max(Gr.max_lblocks, W.nb_pt + W.nb_ln);
+        Gr.max_nt_pt = std::max(Gr.max_nt_pt, W.nt_pt); Gr.max_nb_ln = std::max(Gr.max_nb_ln, W.nt_ln);
         Gr.max_items_pt = std::max(Gr.max_items_pt, W.n_items_pt); Gr.max_items_ln = std::max(Gr.max_items_ln, W.n_items - W.n_items_pt);
         Gr.max_blk = std::max(Gr.max_blk, W.n_free * (W.n_free + 1) / 2);
       }
@@ -348,10 +380,10 @@ int lld_ba_batch_solve(lld_ba_batch* B, volatile const int* abort_flag) {
     const BAWin* dw = B->d_wins + G.w0; BAState* ds = B->d_state + G.w0;
     const int nw = G.nw; hipStream_t st = G.st;
     const int abort_now = (abort_flag && *abort_flag) ? 1 : 0;
-    const dim3 lm_grid(std::max(1, G.max_lblocks), nw);
     LLD_HIP_TRY(hipMemsetAsync(G.d_counters, 0, 4 * sizeof(int), st));
     LLD_HIP_TRY(hipEventRecord(G.ev[0], st));
-    hipLaunchKernelGGL(ba_linearize_kernel, lm_grid, dim3(kLmThreads), lin_lds, st, A, dw, ds);
+    if (G.max_nt_pt > 0) hipLaunchKernelGGL(ba_linearize_pt_kernel, dim3(G.max_nt_pt, nw), dim3(kLmThreads), lin_lds, st, A, dw, ds);
+    if (G.max_nb_ln > 0) hipLaunchKernelGGL(ba_linearize_ln_kernel, dim3(G.max_nb_ln, nw), dim3(kLmThreads), lin_lds, st, A, dw, ds);
     hipLaunchKernelGGL(ba_begin_kernel, dim3((nw + 63) / 64), dim3(64), 0, st, A, dw, ds, nw);
     LLD_HIP_TRY(hipEventRecord(G.ev[1], st));
     if (G.max_items_pt > 0) hipLaunchKernelGGL(ba_schur_items_kernel<3>, dim3(G.max_items_pt, nw), dim3(64), B->schur_lds[0], st, A, dw, ds);
@@ -364,7 +396,8 @@ int lld_ba_batch_solve(lld_ba_batch* B, volatile const int* abort_flag) {
     else
       hipLaunchKernelGGL(ba_chol_kernel, dim3(nw), dim3(kPcgThreads), chol_lds, st, A, dw, ds);
     LLD_HIP_TRY(hipEventRecord(G.ev[3], st));
-    hipLaunchKernelGGL(ba_backsub_kernel, lm_grid, dim3(kLmThreads), 0, st, A, dw, ds);
+    if (G.max_nt_pt > 0) hipLaunchKernelGGL(ba_backsub_pt_kernel, dim3(G.max_nt_pt, nw), dim3(kLmThreads), 0, st, A, dw, ds);
+    if (G.max_nb_ln > 0) hipLaunchKernelGGL(ba_backsub_ln_kernel, dim3(G.max_nb_ln, nw), dim3(kLmThreads), 0, st, A, dw, ds);
     LLD_HIP_TRY(hipEventRecord(G.ev[4], st));
     hipLaunchKernelGGL(ba_control_kernel, dim3(nw), dim3(kCtlThreads), 0, st, A, dw, ds, abort_now, G.d_counters);
     LLD_HIP_TRY(hipGetLastError());

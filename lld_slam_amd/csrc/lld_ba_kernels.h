@@ -54,6 +54,8 @@ struct BAWin {                 // immutable per-window header
   int lo_off, n_lo;            // line observations (= le_off / 2)
   int blk_csr_off, cam_csr_off; // CSR (per lower S block / per free camera) of the chunk partials that add into it
   int nb_pt, nb_ln;            // landmark blocks (kLmThreads landmarks each)
+  int ptask_off, n_ptasks, nt_pt;   // point tasks (4 per workgroup -> nt_pt workgroups)
+  int ltask_off, n_ltasks, nt_ln;   // line tasks; partial-sum slots of a window: nt_pt + nt_ln
   int part_off;                // per-block partial sums
   int its[2];                  // LM iterations per round
   int max_trials, ln_filter;
@@ -74,6 +76,10 @@ struct BAState {               // mutable per-window LM state
 // Schur work decomposition (built once per window on the host from the camera sets of the landmarks):
 // landmarks that are seen by the SAME set of free cameras are sorted together and cut into chunks; one wavefront owns a
 // chunk and accumulates -Y_a W_b^T for every camera-slot pair over the chunk's landmarks in registers before it touches S.
+// Lane-per-edge point kernels: one wavefront per task = a run of consecutive point landmarks whose edges fit in 64 lanes
+// (or a single landmark with any number of edges).
+struct PTask { int l0, nl, e0, ne; };      // local first landmark, landmark count, global first edge, edge count
+
 struct SChunk { int lm_off, n_lm, tab_off, cams_off, k, D, part_off, cpart_off; };   // part_off: 36-double blocks, cpart_off: 6-double vectors
 
 struct BAArrays {
@@ -110,6 +116,7 @@ struct BAArrays {
   double *chi_part, *chi_part2, *scale_part;
   // Schur work items
   const SChunk* sg_chunks;
+  const PTask* ptasks; const PTask* ltasks;
   double *sp_part, *sp_cpart;  // per (chunk, slot pair) 6x6 partial products / per (chunk, slot) 6-vectors
   const int *blk_start, *blk_src, *cam_start, *cam_src;
   const int *sg_lm, *sg_tab, *sg_cams;
@@ -281,143 +288,144 @@ __global__ __launch_bounds__(kLmThreads) void ba_init_kernel(BAArrays A, const B
   }
 }
 
-// ================================================================== linearise
-// grid (nb_pt + nb_ln, nW); dynamic LDS: n_free_max*27 doubles + 8 scratch.
-__global__ __launch_bounds__(kLmThreads) void ba_linearize_kernel(BAArrays A, const BAWin* __restrict__ wins, BAState* __restrict__ st) {
+
+// ================================================================== point landmarks: one lane per EDGE
+// Edge SoA arrays are read fully coalesced (lane i <-> edge e0 + i); what belongs to a landmark (Hll, b_l, the back-substituted
+// update) is combined over the landmark's lanes with a segmented shuffle reduction, the landmark's first lane ("head") does the
+// per-landmark work, and results travel back to the lanes with one shuffle.
+__device__ __forceinline__ bool seg_step(int seg, int lane, int off) {
+  const int so = __shfl_down(seg, off);
+  return (lane + off < 64) && so == seg;
+}
+template <int N>
+__device__ __forceinline__ void seg_sum(double* v, int seg, int lane) {      // valid in the first lane of every segment
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const bool ok = seg_step(seg, lane, off);
+#pragma unroll
+    for (int i = 0; i < N; i++) { const double o = __shfl_down(v[i], off); if (ok) v[i] += o; }
+  }
+}
+template <int N>
+__device__ __forceinline__ void wave_sum_n(double* v) {
+#pragma unroll
+  for (int i = 0; i < N; i++) v[i] = wave_sum(v[i]);
+}
+
+struct PtEdgeLin { double r[3], Jp[9], Jc[18], ws, rho0; bool stereo; };
+
+// residual, chi2 (stored), Huber weight, Jacobians of one active point edge at the linearisation point
+__device__ __forceinline__ void point_edge_linearize(const BAArrays& A, const BAWin& W, int cur, int e, uint8_t fl, int c, const Vec3& X, PtEdgeLin& L) {
+  const Pose T = load_cam(A, cur, W.cam_off + c);
+  const Vec3 Xc = pose_map(T, X);
+  const double urv = A.pe_ur[e];
+  L.stereo = !(urv < 0);
+  point_residual(W.cam, Xc, A.pe_u[e], A.pe_v[e], urv, L.stereo, true, L.r);
+  const double s = A.pe_s[e];
+  const double c2 = chi2_of(L.r, L.stereo ? 3 : 2, s);
+  A.pe_chi2[e] = c2;
+  double w = 1.0;
+  L.rho0 = c2;
+  if (fl & EF_ROBUST) L.rho0 = huber(c2, L.stereo ? W.th_stereo : W.th_mono, &w);
+  L.ws = w * s;
+  A.pe_ws[e] = L.ws;
+  point_jac_point(W.cam, Xc, quat_rotation(T.q), L.stereo, L.Jp);
+  point_jac_pose(W.cam, Xc, L.stereo, L.Jc);
+}
+// landmark side Hll (6 upper) + b_l (3) of one edge
+__device__ __forceinline__ void point_edge_hll(const PtEdgeLin& L, double* hb) {
+  int k = 0;
+#pragma unroll
+  for (int a = 0; a < 3; a++)
+#pragma unroll
+    for (int d = a; d < 3; d++) hb[k++] = L.ws * (L.Jp[a] * L.Jp[d] + L.Jp[3 + a] * L.Jp[3 + d] + L.Jp[6 + a] * L.Jp[6 + d]);
+#pragma unroll
+  for (int a = 0; a < 3; a++) hb[6 + a] = -L.ws * (L.Jp[a] * L.r[0] + L.Jp[3 + a] * L.r[1] + L.Jp[6 + a] * L.r[2]);
+}
+// camera side: Hpp (21 upper) and b_p (6) into the LDS-staged per-camera accumulators
+__device__ __forceinline__ void point_edge_hpp(const PtEdgeLin& L, double* ac) {
+  int kk = 0;
+#pragma unroll
+  for (int rr = 0; rr < 6; rr++) {
+    atomicAdd(&ac[21 + rr], -L.ws * (L.Jc[rr] * L.r[0] + L.Jc[6 + rr] * L.r[1] + L.Jc[12 + rr] * L.r[2]));
+#pragma unroll
+    for (int cc = rr; cc < 6; cc++) atomicAdd(&ac[kk++], L.ws * (L.Jc[rr] * L.Jc[cc] + L.Jc[6 + rr] * L.Jc[6 + cc] + L.Jc[12 + rr] * L.Jc[12 + cc]));
+  }
+}
+
+// grid (nt_pt, nW), block 256 = 4 wavefronts = 4 tasks; dynamic LDS: n_free_max*27 doubles + 8 scratch.
+__global__ __launch_bounds__(kLmThreads) void ba_linearize_pt_kernel(BAArrays A, const BAWin* __restrict__ wins, BAState* __restrict__ st) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const BAWin W = wins[blockIdx.y];
   BAState& S = st[blockIdx.y];
   if (S.phase != PH_RUN || !S.need_lin) return;
-  if ((int)blockIdx.x >= W.nb_pt + W.nb_ln) return;
+  if ((int)blockIdx.x >= W.nt_pt) return;
   const int nacc = W.n_free * 27;
-  double* acc = lds;                       // per free camera: 21 (Hpp upper) + 6 (bp)
+  double* acc = lds;
   double* scratch = lds + nacc;
   for (int i = threadIdx.x; i < nacc; i += kLmThreads) acc[i] = 0.0;
   __syncthreads();
   const int cur = S.cur;
-  const CamK cam = W.cam;
+  const int lane = threadIdx.x & 63, ti = blockIdx.x * 4 + (threadIdx.x >> 6);
   double chi = 0.0, maxd = 0.0;
-
-  if ((int)blockIdx.x < W.nb_pt) {
-    const int p = blockIdx.x * kLmThreads + threadIdx.x;
-    const int g = W.pt_off + p;
-    if (p < W.n_pt && A.pt_active[g]) {
-      const Vec3 X = load_pt(A, cur, g);
-      double H[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
-      const int e0 = A.pt_obs_start[g], e1 = A.pt_obs_start[g + 1];
-      for (int e = e0; e < e1; e++) {
-        const uint8_t fl = A.pe_flags[e];
-        const int c = A.pe_cam[e];
-        if (fl & EF_LEVEL1) { A.pe_ws[e] = 0.0; continue; }   // level-1 edge: contributes nothing, its Hpl block reads as zero
-        const Pose T = load_cam(A, cur, W.cam_off + c);
-        const Vec3 Xc = pose_map(T, X);
-        const double urv = A.pe_ur[e];
-        const bool stereo = !(urv < 0);
-        double r[3];
-        point_residual(cam, Xc, A.pe_u[e], A.pe_v[e], urv, stereo, true, r);
-        const double s = A.pe_s[e];
-        const double c2 = chi2_of(r, stereo ? 3 : 2, s);
-        A.pe_chi2[e] = c2;
-        double w = 1.0, rho0 = c2;
-        if (fl & EF_ROBUST) rho0 = huber(c2, stereo ? W.th_stereo : W.th_mono, &w);
-        chi += rho0;
-        const double ws = w * s;
-        A.pe_ws[e] = ws;
-        const Mat3 R = quat_rotation(T.q);
-        double Jp[9], Jc[18];
-        point_jac_point(cam, Xc, R, stereo, Jp);
-        point_jac_pose(cam, Xc, stereo, Jc);
-        // landmark side: Hll += ws Jp^T Jp, bl -= ws Jp^T r   (rows beyond D are zero for mono)
-        int k = 0;
+  if (ti < W.n_ptasks) {
+    const PTask T = A.ptasks[W.ptask_off + ti];
+    if (T.nl > 1) {
+      const bool has = lane < T.ne;
+      const int e = T.e0 + (has ? lane : 0);
+      const int l = has ? A.pe_pt[e] : -1 - lane;
+      const int g = W.pt_off + (has ? l : T.l0);
+      const uint8_t fl = A.pe_flags[e];
+      const int c = A.pe_cam[e];
+      const bool lm_act = has && A.pt_active[g];
+      double hb[9];
 #pragma unroll
-        for (int a = 0; a < 3; a++) {
-          b[a] -= ws * (Jp[a] * r[0] + Jp[3 + a] * r[1] + Jp[6 + a] * r[2]);
+      for (int i = 0; i < 9; i++) hb[i] = 0.0;
+      if (has && (fl & EF_LEVEL1)) A.pe_ws[e] = 0.0;
+      if (lm_act && !(fl & EF_LEVEL1)) {
+        const Vec3 X = load_pt(A, cur, g);
+        PtEdgeLin L;
+        point_edge_linearize(A, W, cur, e, fl, c, X, L);
+        chi += L.rho0;
+        point_edge_hll(L, hb);
+        if (c < W.n_free) point_edge_hpp(L, acc + c * 27);
+      }
+      seg_sum<9>(hb, l, lane);
+      if (lm_act && e == A.pt_obs_start[g]) {            // head lane of the landmark
+        double* V = A.pt_V + (size_t)g * 9;
 #pragma unroll
-          for (int d = a; d < 3; d++) H[k++] += ws * (Jp[a] * Jp[d] + Jp[3 + a] * Jp[3 + d] + Jp[6 + a] * Jp[6 + d]);
+        for (int i = 0; i < 9; i++) V[i] = hb[i];
+        maxd = fmax(fabs(hb[0]), fmax(fabs(hb[3]), fabs(hb[5])));
+      }
+    } else {                                             // a single landmark, any number of edges
+      const int g = W.pt_off + T.l0;
+      if (A.pt_active[g]) {
+        const Vec3 X = load_pt(A, cur, g);
+        double hb[9];
+#pragma unroll
+        for (int i = 0; i < 9; i++) hb[i] = 0.0;
+        for (int sidx = lane; sidx < T.ne; sidx += 64) {
+          const int e = T.e0 + sidx;
+          const uint8_t fl = A.pe_flags[e];
+          if (fl & EF_LEVEL1) { A.pe_ws[e] = 0.0; continue; }
+          const int c = A.pe_cam[e];
+          PtEdgeLin L;
+          point_edge_linearize(A, W, cur, e, fl, c, X, L);
+          chi += L.rho0;
+          double h1[9];
+          point_edge_hll(L, h1);
+#pragma unroll
+          for (int i = 0; i < 9; i++) hb[i] += h1[i];
+          if (c < W.n_free) point_edge_hpp(L, acc + c * 27);
         }
-        if (c < W.n_free) {
-          double* ac = acc + c * 27;
-          int kk = 0;
+        wave_sum_n<9>(hb);
+        if (lane == 0) {
+          double* V = A.pt_V + (size_t)g * 9;
 #pragma unroll
-          for (int rr = 0; rr < 6; rr++) {
-            atomicAdd(&ac[21 + rr], -ws * (Jc[rr] * r[0] + Jc[6 + rr] * r[1] + Jc[12 + rr] * r[2]));
-#pragma unroll
-            for (int cc = rr; cc < 6; cc++) atomicAdd(&ac[kk++], ws * (Jc[rr] * Jc[cc] + Jc[6 + rr] * Jc[6 + cc] + Jc[12 + rr] * Jc[12 + cc]));
-          }
+          for (int i = 0; i < 9; i++) V[i] = hb[i];
+          maxd = fmax(fabs(hb[0]), fmax(fabs(hb[3]), fabs(hb[5])));
         }
       }
-      double* V = A.pt_V + (size_t)g * 9;
-#pragma unroll
-      for (int i = 0; i < 6; i++) V[i] = H[i];
-      V[6] = b[0]; V[7] = b[1]; V[8] = b[2];
-      maxd = fmax(fabs(H[0]), fmax(fabs(H[3]), fabs(H[5])));
-    }
-  } else {
-    const int l = (blockIdx.x - W.nb_pt) * kLmThreads + threadIdx.x;
-    const int g = W.ln_off + l;
-    if (l < W.n_ln && A.ln_active[g]) {
-      const LineQ L = load_ln(A, cur, g);
-      const Mat3 Rl = line_rotation(L);
-      const Vec3 c0 = mat_col(Rl, 0), c1 = mat_col(Rl, 1);
-      const Vec3 X1 = L.alpha * c1, X2 = X1 + c0;
-      double H[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
-      const int o0 = A.ln_obs_start[g], o1 = A.ln_obs_start[g + 1];
-      for (int o = o0; o < o1; o++) {
-        const int c = A.le_cam[2 * o];
-        const bool free_cam = c < W.n_free;
-        double Wo[24];                                       // Hpl block of the (line, KF) pair: both image edges add into it
-#pragma unroll
-        for (int i = 0; i < 24; i++) Wo[i] = 0.0;
-        bool loaded = false; Pose T; Mat3 Rc; Vec3 X1m, X2m;
-        for (int side = 0; side < 2; side++) {
-          const int e = 2 * o + side;
-          const uint8_t fl = A.le_flags[e];
-          if (!(fl & EF_VALID) || (fl & EF_LEVEL1)) continue;
-          if (!loaded) { T = load_cam(A, cur, W.cam_off + c); Rc = quat_rotation(T.q); X1m = pose_map(T, X1); X2m = pose_map(T, X2); loaded = true; }
-          double r[2]; LineAdj adj;
-          line_residual(cam, A.le_bx[e], X1m, X2m, A.le_xs[e], A.le_ys[e], A.le_xe[e], A.le_ye[e], r, &adj);
-          const double s = A.le_s[e];
-          const double c2 = chi2_of(r, 2, s);
-          A.le_chi2[e] = c2;
-          double w = 1.0, rho0 = c2;
-          if (fl & EF_ROBUST) rho0 = huber(c2, (fl & EF_PAIRSTEREO) ? W.th_ln_stereo : W.th_ln_mono, &w);
-          chi += rho0;
-          const double ws = w * s;
-          double Jc[12], Jl[8];
-          line_jac_pose(adj, X1m, X2m, Jc);
-          line_jac_line(adj, Rc, c0, c1, L.alpha, Jl);
-          int k = 0;
-#pragma unroll
-          for (int a = 0; a < 4; a++) {
-            b[a] -= ws * (Jl[a] * r[0] + Jl[4 + a] * r[1]);
-#pragma unroll
-            for (int d = a; d < 4; d++) H[k++] += ws * (Jl[a] * Jl[d] + Jl[4 + a] * Jl[4 + d]);
-          }
-          if (free_cam) {
-            double* ac = acc + c * 27;
-            int kk = 0;
-#pragma unroll
-            for (int rr = 0; rr < 6; rr++) {
-#pragma unroll
-              for (int a = 0; a < 4; a++) Wo[rr * 4 + a] += ws * (Jc[rr] * Jl[a] + Jc[6 + rr] * Jl[4 + a]);
-              atomicAdd(&ac[21 + rr], -ws * (Jc[rr] * r[0] + Jc[6 + rr] * r[1]));
-#pragma unroll
-              for (int cc = rr; cc < 6; cc++) atomicAdd(&ac[kk++], ws * (Jc[rr] * Jc[cc] + Jc[6 + rr] * Jc[6 + cc]));
-            }
-          }
-        }
-        if (free_cam) {
-          double* Wb = A.lo_W + (size_t)o * 24;
-#pragma unroll
-          for (int i = 0; i < 24; i++) Wb[i] = Wo[i];
-        }
-      }
-      double* V = A.ln_V + (size_t)g * 14;
-#pragma unroll
-      for (int i = 0; i < 10; i++) V[i] = H[i];
-#pragma unroll
-      for (int i = 0; i < 4; i++) V[10 + i] = b[i];
-      maxd = fmax(fmax(fabs(H[0]), fabs(H[4])), fmax(fabs(H[7]), fabs(H[9])));
     }
   }
   const double chi_t = block_sum(chi, scratch);
@@ -438,6 +446,371 @@ __global__ __launch_bounds__(kLmThreads) void ba_linearize_kernel(BAArrays A, co
   }
 }
 
+// W_e^T x_c = ws * Jp^T (Jc x_c) of one point edge with the Jacobians of the linearisation point
+__device__ __forceinline__ void point_edge_wtx(const BAArrays& A, const BAWin& W, int cur, int e, uint8_t fl, int c, const Vec3& X, const double* xp, double* t) {
+  const double ws = A.pe_ws[e];
+  const bool stereo = (fl & EF_STEREO) != 0;
+  const Pose T = load_cam(A, cur, W.cam_off + c);
+  const Vec3 Xc = pose_map(T, X);
+  double Jp[9], Jc[18];
+  point_jac_point(W.cam, Xc, quat_rotation(T.q), stereo, Jp);
+  point_jac_pose(W.cam, Xc, stereo, Jc);
+  double uu[3];
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    double s = 0.0;
+#pragma unroll
+    for (int r = 0; r < 6; r++) s += Jc[i * 6 + r] * xp[c * 6 + r];
+    uu[i] = ws * s;
+  }
+#pragma unroll
+  for (int k = 0; k < 3; k++) t[k] = Jp[k] * uu[0] + Jp[3 + k] * uu[1] + Jp[6 + k] * uu[2];
+}
+// trial-state residual of one active point edge: stores chi2, returns its (robust) cost
+__device__ __forceinline__ double point_edge_trial(const BAArrays& A, const BAWin& W, int nxt, int e, uint8_t fl, int c, const Vec3& Xn) {
+  const Pose T = load_cam(A, nxt, W.cam_off + c);
+  const Vec3 Xc = pose_map(T, Xn);
+  const double urv = A.pe_ur[e];
+  const bool stereo = !(urv < 0);
+  double r[3];
+  point_residual(W.cam, Xc, A.pe_u[e], A.pe_v[e], urv, stereo, true, r);
+  const double c2 = chi2_of(r, stereo ? 3 : 2, A.pe_s[e]);
+  A.pe_chi2[e] = c2;
+  double w, rho0 = c2;
+  if (fl & EF_ROBUST) rho0 = huber(c2, stereo ? W.th_stereo : W.th_mono, &w);
+  return rho0;
+}
+// x_l = (Hll + lambda I)^-1 (b_l - sum W^T x_c), oplus; returns the landmark's part of computeScale
+__device__ __forceinline__ double point_backsub(const double* V, double lambda, const double* wtx, const Vec3& X, Vec3& Xn) {
+  double F[9], Di[9];
+  unpack_sym<3>(V, lambda, F);
+  spd_inverse<3>(F, Di);
+  const double t[3] = {V[6] - wtx[0], V[7] - wtx[1], V[8] - wtx[2]};
+  double xl[3], sc = 0.0;
+#pragma unroll
+  for (int i = 0; i < 3; i++) xl[i] = Di[i * 3] * t[0] + Di[i * 3 + 1] * t[1] + Di[i * 3 + 2] * t[2];
+#pragma unroll
+  for (int i = 0; i < 3; i++) sc += xl[i] * (lambda * xl[i] + V[6 + i]);
+  Xn = vec3(X.x + xl[0], X.y + xl[1], X.z + xl[2]);      // VertexSBAPointXYZ::oplusImpl
+  return sc;
+}
+
+// grid (nt_pt, nW), block 256 = 4 tasks
+__global__ __launch_bounds__(kLmThreads) void ba_backsub_pt_kernel(BAArrays A, const BAWin* __restrict__ wins, const BAState* __restrict__ st) {
+  __shared__ double scratch[8];
+  const BAWin W = wins[blockIdx.y];
+  const BAState& S = st[blockIdx.y];
+  if (S.phase != PH_RUN) return;
+  if ((int)blockIdx.x >= W.nt_pt) return;
+  const int cur = S.cur, nxt = cur ^ 1;
+  const double lambda = S.lambda;
+  const double* xp = A.xp + W.x_off;
+  const int lane = threadIdx.x & 63, ti = blockIdx.x * 4 + (threadIdx.x >> 6);
+  double chi = 0.0, sc = 0.0;
+  if (ti < W.n_ptasks) {
+    const PTask T = A.ptasks[W.ptask_off + ti];
+    if (T.nl > 1) {
+      const bool has = lane < T.ne;
+      const int e = T.e0 + (has ? lane : 0);
+      const int l = has ? A.pe_pt[e] : -1 - lane;
+      const int g = W.pt_off + (has ? l : T.l0);
+      const uint8_t fl = A.pe_flags[e];
+      const int c = A.pe_cam[e];
+      const bool lm_act = has && A.pt_active[g];
+      const bool e_act = lm_act && !(fl & EF_LEVEL1);
+      Vec3 X = vec3(0, 0, 0);
+      if (has) X = load_pt(A, cur, g);
+      double wtx[3] = {0, 0, 0};
+      if (e_act && c < W.n_free) point_edge_wtx(A, W, cur, e, fl, c, X, xp, wtx);
+      seg_sum<3>(wtx, l, lane);
+      const int e_head = has ? A.pt_obs_start[g] : 0;
+      Vec3 Xn = X;
+      if (has && e == e_head) {                          // head lane: the landmark's update
+        if (lm_act) sc += point_backsub(A.pt_V + (size_t)g * 9, lambda, wtx, X, Xn);
+        store_pt(A, nxt, g, Xn);                         // inactive landmarks keep their state in both buffers
+      }
+      const int hl = e_head - T.e0;
+      Xn.x = __shfl(Xn.x, hl); Xn.y = __shfl(Xn.y, hl); Xn.z = __shfl(Xn.z, hl);
+      if (e_act) chi += point_edge_trial(A, W, nxt, e, fl, c, Xn);
+      // landmarks of the task without any edge have no head lane
+      if (lane < T.nl) {
+        const int g2 = W.pt_off + T.l0 + lane;
+        if (A.pt_obs_start[g2 + 1] == A.pt_obs_start[g2]) store_pt(A, nxt, g2, load_pt(A, cur, g2));
+      }
+    } else {
+      const int g = W.pt_off + T.l0;
+      const Vec3 X = load_pt(A, cur, g);
+      if (!A.pt_active[g]) { if (lane == 0) store_pt(A, nxt, g, X); }
+      else {
+        double wtx[3] = {0, 0, 0};
+        for (int sidx = lane; sidx < T.ne; sidx += 64) {
+          const int e = T.e0 + sidx;
+          const uint8_t fl = A.pe_flags[e];
+          const int c = A.pe_cam[e];
+          if ((fl & EF_LEVEL1) || c >= W.n_free) continue;
+          double t1[3];
+          point_edge_wtx(A, W, cur, e, fl, c, X, xp, t1);
+          wtx[0] += t1[0]; wtx[1] += t1[1]; wtx[2] += t1[2];
+        }
+        wave_sum_n<3>(wtx);
+        Vec3 Xn;
+        const double s1 = point_backsub(A.pt_V + (size_t)g * 9, lambda, wtx, X, Xn);      // every lane, same value
+        if (lane == 0) { sc += s1; store_pt(A, nxt, g, Xn); }
+        for (int sidx = lane; sidx < T.ne; sidx += 64) {
+          const int e = T.e0 + sidx;
+          const uint8_t fl = A.pe_flags[e];
+          if (fl & EF_LEVEL1) continue;
+          chi += point_edge_trial(A, W, nxt, e, fl, A.pe_cam[e], Xn);
+        }
+      }
+    }
+  }
+  const double chi_t = block_sum(chi, scratch);
+  const double sc_t = block_sum(sc, scratch);
+  if (threadIdx.x == 0) { A.chi_part2[W.part_off + blockIdx.x] = chi_t; A.scale_part[W.part_off + blockIdx.x] = sc_t; }
+}
+
+// ================================================================== line landmarks: one lane per (line, KF) OBSERVATION
+// Same scheme as the point kernels with the observation as the unit: a lane linearises the left and (if present) right image
+// edge of its observation and keeps their summed Hpl block; Hll/b_l (14 values) are combined over the line's lanes.
+struct LineGeom { Vec3 c0, c1, X1, X2; double alpha; };
+__device__ __forceinline__ LineGeom line_geom(const LineQ& L) {
+  const Mat3 Rl = line_rotation(L);
+  LineGeom G; G.c0 = mat_col(Rl, 0); G.c1 = mat_col(Rl, 1); G.alpha = L.alpha; G.X1 = L.alpha * G.c1; G.X2 = G.X1 + G.c0;
+  return G;
+}
+// linearise one observation: hb (10 + 4) and the summed 6x4 Hpl block; returns the robust cost of its active edges
+__device__ __forceinline__ double line_obs_linearize(const BAArrays& A, const BAWin& W, int cur, int o, int c, const LineGeom& G, double* hb,
+                                                     double* acc_lds) {
+  const bool free_cam = c < W.n_free;
+  double Wo[24];
+#pragma unroll
+  for (int i = 0; i < 24; i++) Wo[i] = 0.0;
+  double chi = 0.0;
+  bool loaded = false; Pose T; Mat3 Rc; Vec3 X1m, X2m;
+  for (int side = 0; side < 2; side++) {
+    const int e = 2 * o + side;
+    const uint8_t fl = A.le_flags[e];
+    if (!(fl & EF_VALID) || (fl & EF_LEVEL1)) continue;
+    if (!loaded) { T = load_cam(A, cur, W.cam_off + c); Rc = quat_rotation(T.q); X1m = pose_map(T, G.X1); X2m = pose_map(T, G.X2); loaded = true; }
+    double r[2]; LineAdj adj;
+    line_residual(W.cam, A.le_bx[e], X1m, X2m, A.le_xs[e], A.le_ys[e], A.le_xe[e], A.le_ye[e], r, &adj);
+    const double s = A.le_s[e];
+    const double c2 = chi2_of(r, 2, s);
+    A.le_chi2[e] = c2;
+    double w = 1.0, rho0 = c2;
+    if (fl & EF_ROBUST) rho0 = huber(c2, (fl & EF_PAIRSTEREO) ? W.th_ln_stereo : W.th_ln_mono, &w);
+    chi += rho0;
+    const double ws = w * s;
+    double Jc[12], Jl[8];
+    line_jac_pose(adj, X1m, X2m, Jc);
+    line_jac_line(adj, Rc, G.c0, G.c1, G.alpha, Jl);
+    int k = 0;
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+      hb[10 + a] -= ws * (Jl[a] * r[0] + Jl[4 + a] * r[1]);
+#pragma unroll
+      for (int d = a; d < 4; d++) hb[k++] += ws * (Jl[a] * Jl[d] + Jl[4 + a] * Jl[4 + d]);
+    }
+    if (free_cam) {
+      double* ac = acc_lds + c * 27;
+      int kk = 0;
+#pragma unroll
+      for (int rr = 0; rr < 6; rr++) {
+#pragma unroll
+        for (int a = 0; a < 4; a++) Wo[rr * 4 + a] += ws * (Jc[rr] * Jl[a] + Jc[6 + rr] * Jl[4 + a]);
+        atomicAdd(&ac[21 + rr], -ws * (Jc[rr] * r[0] + Jc[6 + rr] * r[1]));
+#pragma unroll
+        for (int cc = rr; cc < 6; cc++) atomicAdd(&ac[kk++], ws * (Jc[rr] * Jc[cc] + Jc[6 + rr] * Jc[6 + cc]));
+      }
+    }
+  }
+  if (free_cam) {
+    double* Wb = A.lo_W + (size_t)o * 24;
+#pragma unroll
+    for (int i = 0; i < 24; i += 2) *reinterpret_cast<double2*>(Wb + i) = make_double2(Wo[i], Wo[i + 1]);
+  }
+  return chi;
+}
+
+// grid (nt_ln, nW), block 256 = 4 tasks; dynamic LDS: n_free_max*27 doubles + 8 scratch.
+__global__ __launch_bounds__(kLmThreads) void ba_linearize_ln_kernel(BAArrays A, const BAWin* __restrict__ wins, BAState* __restrict__ st) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const BAWin W = wins[blockIdx.y];
+  BAState& S = st[blockIdx.y];
+  if (S.phase != PH_RUN || !S.need_lin) return;
+  if ((int)blockIdx.x >= W.nt_ln) return;
+  const int nacc = W.n_free * 27;
+  double* acc = lds;
+  double* scratch = lds + nacc;
+  for (int i = threadIdx.x; i < nacc; i += kLmThreads) acc[i] = 0.0;
+  __syncthreads();
+  const int cur = S.cur;
+  const int lane = threadIdx.x & 63, ti = blockIdx.x * 4 + (threadIdx.x >> 6);
+  double chi = 0.0, maxd = 0.0;
+  if (ti < W.n_ltasks) {
+    const PTask T = A.ltasks[W.ltask_off + ti];
+    double hb[14];
+#pragma unroll
+    for (int i = 0; i < 14; i++) hb[i] = 0.0;
+    if (T.nl > 1) {
+      const bool has = lane < T.ne;
+      const int o = T.e0 + (has ? lane : 0);
+      const int l = has ? A.le_ln[2 * o] : -1 - lane;
+      const int g = W.ln_off + (has ? l : T.l0);
+      const bool lm_act = has && A.ln_active[g];
+      if (lm_act) {
+        const LineGeom G = line_geom(load_ln(A, cur, g));
+        chi += line_obs_linearize(A, W, cur, o, A.le_cam[2 * o], G, hb, acc);
+      }
+      seg_sum<14>(hb, l, lane);
+      if (lm_act && o == A.ln_obs_start[g]) {
+        double* V = A.ln_V + (size_t)g * 14;
+#pragma unroll
+        for (int i = 0; i < 14; i++) V[i] = hb[i];
+        maxd = fmax(fmax(fabs(hb[0]), fabs(hb[4])), fmax(fabs(hb[7]), fabs(hb[9])));
+      }
+    } else {
+      const int g = W.ln_off + T.l0;
+      if (A.ln_active[g]) {
+        const LineGeom G = line_geom(load_ln(A, cur, g));
+        for (int sidx = lane; sidx < T.ne; sidx += 64) chi += line_obs_linearize(A, W, cur, T.e0 + sidx, A.le_cam[2 * (T.e0 + sidx)], G, hb, acc);
+        wave_sum_n<14>(hb);
+        if (lane == 0) {
+          double* V = A.ln_V + (size_t)g * 14;
+#pragma unroll
+          for (int i = 0; i < 14; i++) V[i] = hb[i];
+          maxd = fmax(fmax(fabs(hb[0]), fabs(hb[4])), fmax(fabs(hb[7]), fabs(hb[9])));
+        }
+      }
+    }
+  }
+  const double chi_t = block_sum(chi, scratch);
+  const double max_t = block_max(maxd, scratch);
+  if (threadIdx.x == 0) {
+    A.chi_part[W.part_off + W.nt_pt + blockIdx.x] = chi_t;
+    atomicMax(&S.maxdiag_bits, (unsigned long long)__double_as_longlong(max_t));
+  }
+  __syncthreads();
+  double* gH = A.Hpp + (size_t)W.hpp_off * 21;
+  double* gb = A.bp + (size_t)W.hpp_off * 6;
+  for (int i = threadIdx.x; i < nacc; i += kLmThreads) {
+    const double v = acc[i];
+    if (v != 0.0) {
+      const int c = i / 27, k = i - c * 27;
+      if (k < 21) atomicAdd(&gH[c * 21 + k], v); else atomicAdd(&gb[c * 6 + (k - 21)], v);
+    }
+  }
+}
+
+__device__ __forceinline__ void line_obs_wtx(const BAArrays& A, const BAWin& W, int o, int c, const double* xp, double* t) {
+  const double* Wb = A.lo_W + (size_t)o * 24;              // zero when both image edges are inactive
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    double s = 0.0;
+#pragma unroll
+    for (int r = 0; r < 6; r++) s += Wb[r * 4 + k] * xp[c * 6 + r];
+    t[k] = s;
+  }
+}
+__device__ __forceinline__ double line_obs_trial(const BAArrays& A, const BAWin& W, int nxt, int o, int c, const LineGeom& G) {
+  double chi = 0.0;
+  bool loaded = false; Vec3 X1m, X2m;
+  for (int side = 0; side < 2; side++) {
+    const int e = 2 * o + side;
+    const uint8_t fl = A.le_flags[e];
+    if (!(fl & EF_VALID) || (fl & EF_LEVEL1)) continue;
+    if (!loaded) { const Pose T = load_cam(A, nxt, W.cam_off + c); X1m = pose_map(T, G.X1); X2m = pose_map(T, G.X2); loaded = true; }
+    double r[2];
+    line_residual(W.cam, A.le_bx[e], X1m, X2m, A.le_xs[e], A.le_ys[e], A.le_xe[e], A.le_ye[e], r, nullptr);
+    const double c2 = chi2_of(r, 2, A.le_s[e]);
+    A.le_chi2[e] = c2;
+    double w, rho0 = c2;
+    if (fl & EF_ROBUST) rho0 = huber(c2, (fl & EF_PAIRSTEREO) ? W.th_ln_stereo : W.th_ln_mono, &w);
+    chi += rho0;
+  }
+  return chi;
+}
+__device__ __forceinline__ double line_backsub(const double* V, double lambda, const double* wtx, const LineQ& L, LineQ& Ln) {
+  double F[16], Di[16];
+  unpack_sym<4>(V, lambda, F);
+  spd_inverse<4>(F, Di);
+  double t[4], xl[4], sc = 0.0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) t[i] = V[10 + i] - wtx[i];
+#pragma unroll
+  for (int i = 0; i < 4; i++) xl[i] = Di[i * 4] * t[0] + Di[i * 4 + 1] * t[1] + Di[i * 4 + 2] * t[2] + Di[i * 4 + 3] * t[3];
+#pragma unroll
+  for (int i = 0; i < 4; i++) sc += xl[i] * (lambda * xl[i] + V[10 + i]);
+  Ln = line_oplus(L, xl);
+  return sc;
+}
+
+// grid (nt_ln, nW), block 256 = 4 tasks
+__global__ __launch_bounds__(kLmThreads) void ba_backsub_ln_kernel(BAArrays A, const BAWin* __restrict__ wins, const BAState* __restrict__ st) {
+  __shared__ double scratch[8];
+  const BAWin W = wins[blockIdx.y];
+  const BAState& S = st[blockIdx.y];
+  if (S.phase != PH_RUN) return;
+  if ((int)blockIdx.x >= W.nt_ln) return;
+  const int cur = S.cur, nxt = cur ^ 1;
+  const double lambda = S.lambda;
+  const double* xp = A.xp + W.x_off;
+  const int lane = threadIdx.x & 63, ti = blockIdx.x * 4 + (threadIdx.x >> 6);
+  double chi = 0.0, sc = 0.0;
+  if (ti < W.n_ltasks) {
+    const PTask T = A.ltasks[W.ltask_off + ti];
+    if (T.nl > 1) {
+      const bool has = lane < T.ne;
+      const int o = T.e0 + (has ? lane : 0);
+      const int l = has ? A.le_ln[2 * o] : -1 - lane;
+      const int g = W.ln_off + (has ? l : T.l0);
+      const int c = A.le_cam[2 * o];
+      const bool lm_act = has && A.ln_active[g];
+      LineQ L = load_ln(A, cur, g);
+      double wtx[4] = {0, 0, 0, 0};
+      if (lm_act && c < W.n_free) line_obs_wtx(A, W, o, c, xp, wtx);
+      seg_sum<4>(wtx, l, lane);
+      const int o_head = has ? A.ln_obs_start[g] : 0;
+      LineQ Ln = L;
+      if (has && o == o_head) {
+        if (lm_act) sc += line_backsub(A.ln_V + (size_t)g * 14, lambda, wtx, L, Ln);
+        store_ln(A, nxt, g, Ln);
+      }
+      const int hl = o_head - T.e0;
+      Ln.q.x = __shfl(Ln.q.x, hl); Ln.q.y = __shfl(Ln.q.y, hl); Ln.q.z = __shfl(Ln.q.z, hl); Ln.q.w = __shfl(Ln.q.w, hl); Ln.alpha = __shfl(Ln.alpha, hl);
+      if (lm_act) chi += line_obs_trial(A, W, nxt, o, c, line_geom(Ln));
+      if (lane < T.nl) {
+        const int g2 = W.ln_off + T.l0 + lane;
+        if (A.ln_obs_start[g2 + 1] == A.ln_obs_start[g2]) store_ln(A, nxt, g2, load_ln(A, cur, g2));
+      }
+    } else {
+      const int g = W.ln_off + T.l0;
+      const LineQ L = load_ln(A, cur, g);
+      if (!A.ln_active[g]) { if (lane == 0) store_ln(A, nxt, g, L); }
+      else {
+        double wtx[4] = {0, 0, 0, 0};
+        for (int sidx = lane; sidx < T.ne; sidx += 64) {
+          const int o = T.e0 + sidx, c = A.le_cam[2 * o];
+          if (c >= W.n_free) continue;
+          double t1[4];
+          line_obs_wtx(A, W, o, c, xp, t1);
+          wtx[0] += t1[0]; wtx[1] += t1[1]; wtx[2] += t1[2]; wtx[3] += t1[3];
+        }
+        wave_sum_n<4>(wtx);
+        LineQ Ln;
+        const double s1 = line_backsub(A.ln_V + (size_t)g * 14, lambda, wtx, L, Ln);
+        if (lane == 0) { sc += s1; store_ln(A, nxt, g, Ln); }
+        const LineGeom G = line_geom(Ln);
+        for (int sidx = lane; sidx < T.ne; sidx += 64) chi += line_obs_trial(A, W, nxt, T.e0 + sidx, A.le_cam[2 * (T.e0 + sidx)], G);
+      }
+    }
+  }
+  const double chi_t = block_sum(chi, scratch);
+  const double sc_t = block_sum(sc, scratch);
+  if (threadIdx.x == 0) { A.chi_part2[W.part_off + W.nt_pt + blockIdx.x] = chi_t; A.scale_part[W.part_off + W.nt_pt + blockIdx.x] = sc_t; }
+}
+
 // LM iteration head (one lane per window): chi2 of the current state, lambda initialisation at iteration 0.
 __global__ void ba_begin_kernel(BAArrays A, const BAWin* __restrict__ wins, BAState* __restrict__ st, int n_windows) {
   const int w = blockIdx.x * blockDim.x + threadIdx.x;
@@ -446,7 +819,7 @@ __global__ void ba_begin_kernel(BAArrays A, const BAWin* __restrict__ wins, BASt
   BAState& S = st[w];
   if (S.phase != PH_RUN || !S.need_lin) return;
   double chi = 0.0;
-  const int nb = W.nb_pt + W.nb_ln;
+  const int nb = W.nt_pt + W.nt_ln;
   for (int i = 0; i < nb; i++) chi += A.chi_part[W.part_off + i];
   S.currentChi = chi; S.iniChi = chi;
   if (S.it == 0) {
@@ -957,134 +1330,6 @@ __global__ __launch_bounds__(kPcgThreads) void ba_chol_kernel(BAArrays A, const 
   solve_epilogue(A, W, S, x, scratch, ok, 0);
 }
 
-// ================================================================== back-substitution + update + trial chi2
-// grid (nb_pt + nb_ln, nW): x_l = (Hll + lambda I)^-1 (b_l - sum_e W_e^T x_cam(e)), landmark oplus into the trial buffer,
-// then computeActiveErrors / activeRobustChi2 of the lane's edges at the trial state.
-__global__ __launch_bounds__(kLmThreads) void ba_backsub_kernel(BAArrays A, const BAWin* __restrict__ wins, const BAState* __restrict__ st) {
-  __shared__ double scratch[8];
-  const BAWin W = wins[blockIdx.y];
-  const BAState& S = st[blockIdx.y];
-  if (S.phase != PH_RUN) return;
-  if ((int)blockIdx.x >= W.nb_pt + W.nb_ln) return;
-  const int cur = S.cur, nxt = cur ^ 1;
-  const double lambda = S.lambda;
-  const CamK cam = W.cam;
-  const double* xp = A.xp + W.x_off;
-  double chi = 0.0, sc = 0.0;
-  if ((int)blockIdx.x < W.nb_pt) {
-    const int p = blockIdx.x * kLmThreads + threadIdx.x;
-    const int g = W.pt_off + p;
-    if (p < W.n_pt) {
-      const Vec3 X = load_pt(A, cur, g);
-      if (!A.pt_active[g]) store_pt(A, nxt, g, X);
-      else {
-        const double* V = A.pt_V + (size_t)g * 9;
-        double F[9], Di[9];
-        unpack_sym<3>(V, lambda, F);
-        spd_inverse<3>(F, Di);
-        double t[3] = {V[6], V[7], V[8]};
-        const int e0 = A.pt_obs_start[g], e1 = A.pt_obs_start[g + 1];
-        for (int e = e0; e < e1; e++) {
-          if (A.pe_flags[e] & EF_LEVEL1) continue;
-          const int c = A.pe_cam[e];
-          if (c >= W.n_free) continue;
-          // W_e^T x_c = ws * Jp^T (Jc x_c) with the Jacobians of the linearisation point (current buffer)
-          const double ws = A.pe_ws[e];
-          const bool stereo = (A.pe_flags[e] & EF_STEREO) != 0;
-          const Pose T = load_cam(A, cur, W.cam_off + c);
-          const Vec3 Xc = pose_map(T, X);
-          double Jp[9], Jc[18];
-          point_jac_point(cam, Xc, quat_rotation(T.q), stereo, Jp);
-          point_jac_pose(cam, Xc, stereo, Jc);
-          double uu[3];
-#pragma unroll
-          for (int i = 0; i < 3; i++) {
-            double s = 0.0;
-#pragma unroll
-            for (int r = 0; r < 6; r++) s += Jc[i * 6 + r] * xp[c * 6 + r];
-            uu[i] = ws * s;
-          }
-#pragma unroll
-          for (int k = 0; k < 3; k++) t[k] -= Jp[k] * uu[0] + Jp[3 + k] * uu[1] + Jp[6 + k] * uu[2];
-        }
-        double xl[3];
-#pragma unroll
-        for (int i = 0; i < 3; i++) xl[i] = Di[i * 3] * t[0] + Di[i * 3 + 1] * t[1] + Di[i * 3 + 2] * t[2];
-#pragma unroll
-        for (int i = 0; i < 3; i++) sc += xl[i] * (lambda * xl[i] + V[6 + i]);
-        const Vec3 Xn = vec3(X.x + xl[0], X.y + xl[1], X.z + xl[2]);      // VertexSBAPointXYZ::oplusImpl
-        store_pt(A, nxt, g, Xn);
-        for (int e = e0; e < e1; e++) {
-          const uint8_t fl = A.pe_flags[e];
-          if (fl & EF_LEVEL1) continue;
-          const Pose T = load_cam(A, nxt, W.cam_off + A.pe_cam[e]);
-          const Vec3 Xc = pose_map(T, Xn);
-          const double urv = A.pe_ur[e];
-          const bool stereo = !(urv < 0);
-          double r[3];
-          point_residual(cam, Xc, A.pe_u[e], A.pe_v[e], urv, stereo, true, r);
-          const double c2 = chi2_of(r, stereo ? 3 : 2, A.pe_s[e]);
-          A.pe_chi2[e] = c2;
-          double w, rho0 = c2;
-          if (fl & EF_ROBUST) rho0 = huber(c2, stereo ? W.th_stereo : W.th_mono, &w);
-          chi += rho0;
-        }
-      }
-    }
-  } else {
-    const int l = (blockIdx.x - W.nb_pt) * kLmThreads + threadIdx.x;
-    const int g = W.ln_off + l;
-    if (l < W.n_ln) {
-      const LineQ L = load_ln(A, cur, g);
-      if (!A.ln_active[g]) store_ln(A, nxt, g, L);
-      else {
-        const double* V = A.ln_V + (size_t)g * 14;
-        double F[16], Di[16];
-        unpack_sym<4>(V, lambda, F);
-        spd_inverse<4>(F, Di);
-        double t[4] = {V[10], V[11], V[12], V[13]};
-        const int e0 = 2 * A.ln_obs_start[g], e1 = 2 * A.ln_obs_start[g + 1];
-        for (int o = A.ln_obs_start[g]; o < A.ln_obs_start[g + 1]; o++) {
-          const int c = A.le_cam[2 * o];
-          if (c >= W.n_free) continue;
-          const double* Wb = A.lo_W + (size_t)o * 24;      // zero when both image edges are inactive
-#pragma unroll
-          for (int k = 0; k < 4; k++) {
-            double s = 0.0;
-#pragma unroll
-            for (int r = 0; r < 6; r++) s += Wb[r * 4 + k] * xp[c * 6 + r];
-            t[k] -= s;
-          }
-        }
-        double xl[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++) xl[i] = Di[i * 4] * t[0] + Di[i * 4 + 1] * t[1] + Di[i * 4 + 2] * t[2] + Di[i * 4 + 3] * t[3];
-#pragma unroll
-        for (int i = 0; i < 4; i++) sc += xl[i] * (lambda * xl[i] + V[10 + i]);
-        const LineQ Ln = line_oplus(L, xl);
-        store_ln(A, nxt, g, Ln);
-        const Mat3 Rl = line_rotation(Ln);
-        const Vec3 c1 = mat_col(Rl, 1);
-        const Vec3 X1 = Ln.alpha * c1, X2 = X1 + mat_col(Rl, 0);
-        for (int e = e0; e < e1; e++) {
-          const uint8_t fl = A.le_flags[e];
-          if (!(fl & EF_VALID) || (fl & EF_LEVEL1)) continue;
-          const Pose T = load_cam(A, nxt, W.cam_off + A.le_cam[e]);
-          double r[2];
-          line_residual(cam, A.le_bx[e], pose_map(T, X1), pose_map(T, X2), A.le_xs[e], A.le_ys[e], A.le_xe[e], A.le_ye[e], r, nullptr);
-          const double c2 = chi2_of(r, 2, A.le_s[e]);
-          A.le_chi2[e] = c2;
-          double w, rho0 = c2;
-          if (fl & EF_ROBUST) rho0 = huber(c2, (fl & EF_PAIRSTEREO) ? W.th_ln_stereo : W.th_ln_mono, &w);
-          chi += rho0;
-        }
-      }
-    }
-  }
-  const double chi_t = block_sum(chi, scratch);
-  const double sc_t = block_sum(sc, scratch);
-  if (threadIdx.x == 0) { A.chi_part2[W.part_off + blockIdx.x] = chi_t; A.scale_part[W.part_off + blockIdx.x] = sc_t; }
-}
 
 // ================================================================== LM control
 // grid (nW), block 64: lane 0 takes the accept / reject decision of the trial that just ran
@@ -1098,7 +1343,7 @@ __global__ __launch_bounds__(kCtlThreads) void ba_control_kernel(BAArrays A, con
   if (threadIdx.x == 0) do_clear = 0;
   __syncthreads();
   if (threadIdx.x == 0 && S.phase == PH_RUN) {
-    const int nb = W.nb_pt + W.nb_ln;
+    const int nb = W.nt_pt + W.nt_ln;
     double tempChi = 0.0, scale = S.scale_cam;
     for (int i = 0; i < nb; i++) tempChi += A.chi_part2[W.part_off + i];
     for (int i = 0; i < nb; i++) scale += A.scale_part[W.part_off + i];
