@@ -25,7 +25,7 @@ struct lld_ba_batch {
   // window groups solved concurrently, each on its own stream (hides the latency-bound reduced solve, the per-super-step
   // host poll and kernel tails behind the other groups' work)
   struct Group { int w0 = 0, nw = 0; hipStream_t st = nullptr; bool own_stream = false; int* d_counters = nullptr; int* h_counters = nullptr;
-                 hipEvent_t ev[kNumPhases + 1] = {}; int steps = 0; bool active = false; int max_nt_pt = 0, max_nb_ln = 0, max_lblocks = 0, max_items_pt = 0, max_items_ln = 0, max_blk = 0; };
+                 hipEvent_t ev[kNumPhases + 1] = {}; int steps = 0; bool active = false; int max_nt_pt = 0, max_nb_ln = 0, max_nl_pt = 0, max_nl_ln = 0, max_lblocks = 0, max_items_pt = 0, max_items_ln = 0, max_blk = 0; };
   std::vector<Group> groups;
   int* d_counters = nullptr; int* h_counters = nullptr;               // device / pinned, 4 ints per group
   int max_lblocks = 0, max_items_pt = 0, max_items_ln = 0, max_free = 0, max_cams = 0, max_blk = 0;
@@ -93,7 +93,7 @@ int lld_ba_batch_create(lld_ctx* ctx, int n_windows, const lld_ba_window* wins, 
   // ---- layout + host staging
   std::vector<double> cam_qt0, pt0, ln_x0, ln_dir, pe_u, pe_v, pe_ur, pe_s, le_xs, le_ys, le_xe, le_ye, le_s, le_bx;
   std::vector<int> pt_obs_start, ln_obs_start, pe_cam, pe_pt, le_cam, le_ln, sg_lm, sg_tab, sg_cams, blk_start, blk_src, cam_start, cam_src;
-  size_t n_part = 0, n_cpart = 0; int max_blk = 0;
+  size_t n_part = 0, n_cpart = 0, n_hpart = 0; int max_blk = 0;
   std::vector<uint8_t> le_flags0;
   B->h_wins.resize(n_windows);
   // landmarks per Schur chunk: long chunks mean fewer atomics into S, short ones more lanes for small batches
@@ -114,28 +114,29 @@ int lld_ba_batch_create(lld_ctx* ctx, int n_windows, const lld_ba_window* wins, 
     // point tasks for the lane-per-edge kernels: consecutive landmarks while their edges fit into one wavefront
     W.ptask_off = (int)B->h_ptasks.size();
     for (int p = 0; p < w.n_points;) {
-      PTask T; T.l0 = p; T.e0 = (int)NPE + w.pt_obs_start[p]; T.nl = 0; T.ne = 0;
+      PTask T; std::memset(&T, 0, sizeof T); T.l0 = p; T.e0 = (int)NPE + w.pt_obs_start[p];
       while (p < w.n_points) {
         const int ne = w.pt_obs_start[p + 1] - w.pt_obs_start[p];
         if (T.nl > 0 && (T.ne + ne > 64 || T.nl >= 64)) break;
-        T.nl++; T.ne += ne; p++;
+        T.nl++; T.ne += ne; T.ms = std::max(T.ms, ne); p++;
         if (T.ne > 64) break;                      // a landmark with more than 64 edges is a task of its own
       }
       B->h_ptasks.push_back(T);
     }
-    W.n_ptasks = (int)B->h_ptasks.size() - W.ptask_off; W.nt_pt = (W.n_ptasks + 3) / 4;
+    W.n_ptasks = (int)B->h_ptasks.size() - W.ptask_off; W.nt_pt = (W.n_ptasks + 3) / 4; W.nl_pt = (W.n_ptasks + kLinThreads / 64 - 1) / (kLinThreads / 64);
     W.ltask_off = (int)B->h_ltasks.size();
     for (int l = 0; l < w.n_lines;) {                // line tasks: lane <-> (line, KF) observation
-      PTask T; T.l0 = l; T.e0 = (int)NLO + w.ln_obs_start[l]; T.nl = 0; T.ne = 0;
+      PTask T; std::memset(&T, 0, sizeof T); T.l0 = l; T.e0 = (int)NLO + w.ln_obs_start[l];
       while (l < w.n_lines) {
         const int no = w.ln_obs_start[l + 1] - w.ln_obs_start[l];
         if (T.nl > 0 && (T.ne + no > 64 || T.nl >= 64)) break;
-        T.nl++; T.ne += no; l++;
+        T.nl++; T.ne += no; T.ms = std::max(T.ms, no); l++;
         if (T.ne > 64) break;
       }
       B->h_ltasks.push_back(T);
     }
-    W.n_ltasks = (int)B->h_ltasks.size() - W.ltask_off; W.nt_ln = (W.n_ltasks + 3) / 4;
+    W.n_ltasks = (int)B->h_ltasks.size() - W.ltask_off; W.nt_ln = (W.n_ltasks + 3) / 4; W.nl_ln = (W.n_ltasks + kLinThreads / 64 - 1) / (kLinThreads / 64);
+    W.hpart_off = (long long)n_hpart; n_hpart += (size_t)(W.nl_pt + W.nl_ln) * w.n_free_cams * 27;
     W.part_off = (int)NPART;
     W.its[0] = P.its_round1; W.its[1] = P.its_round2; W.max_trials = P.max_trials; W.ln_filter = P.ln_filter;
     W.th_mono = thMono; W.th_stereo = thStereo;
@@ -286,6 +287,7 @@ int lld_ba_batch_create(lld_ctx* ctx, int n_windows, const lld_ba_window* wins, 
     A.pe_ws = sl.take<double>((size_t)NPE + 1); A.lo_W = sl.take<double>((size_t)NLO * 24 + 1);
     A.pt_active = sl.take<uint8_t>(NP + 1); A.ln_active = sl.take<uint8_t>(NL + 1); A.ln_removed = sl.take<uint8_t>(NL + 1);
     A.pt_V = sl.take<double>((size_t)NP * 9 + 1); A.ln_V = sl.take<double>((size_t)NL * 14 + 1);
+    A.hpp_part = sl.take<double>(n_hpart + 2);
     A.Hpp = sl.take<double>((size_t)NF * 21 + 1); A.bp = sl.take<double>((size_t)NF * 6 + 1);
     A.S = sl.take<double>(S_total + 1); A.bschur = sl.take<double>(x_total + 1); A.xp = sl.take<double>(x_total + 1);
     A.chi_part = sl.take<double>(NPART + 1); A.chi_part2 = sl.take<double>(NPART + 1); A.scale_part = sl.take<double>(NPART + 1);
@@ -317,6 +319,9 @@ int lld_ba_batch_create(lld_ctx* ctx, int n_windows, const lld_ba_window* wins, 
   {
     const size_t pcg_lds = ((size_t)B->max_free * 6 * 4 + kPcgThreads + (size_t)B->max_free * 36 + 32) * sizeof(double);
     LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_pcg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pcg_lds));
+    const size_t lin_lds = ((size_t)B->max_free * 27 * kAccCopies + 8) * sizeof(double);
+    LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_linearize_pt_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lin_lds));
+    LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_linearize_ln_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lin_lds));
     const size_t chol_lds = ((size_t)B->max_free * 36 * 2 + (size_t)B->max_free * 6 * 2 + 32) * sizeof(double);
     LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_chol_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)chol_lds));
   }
@@ -339,6 +344,7 @@ int lld_ba_batch_create(lld_ctx* ctx, int n_windows, const lld_ba_window* wins, 
         const BAWin& W = B->h_wins[wi];
         Gr.max_lblocks = std::max(Gr.max_lblocks, W.nb_pt + W.nb_ln);
         Gr.max_nt_pt = std::max(Gr.max_nt_pt, W.nt_pt); Gr.max_nb_ln = std::max(Gr.max_nb_ln, W.nt_ln);
+        Gr.max_nl_pt = std::max(Gr.max_nl_pt, W.nl_pt); Gr.max_nl_ln = std::max(Gr.max_nl_ln, W.nl_ln);
         Gr.max_items_pt = std::max(Gr.max_items_pt, W.n_items_pt); Gr.max_items_ln = std::max(Gr.max_items_ln, W.n_items - W.n_items_pt);
         Gr.max_blk = std::max(Gr.max_blk, W.n_free * (W.n_free + 1) / 2);
       }
@@ -361,7 +367,7 @@ int lld_ba_batch_solve(lld_ba_batch* B, volatile const int* abort_flag) {
   hipEvent_t t_begin, t_end;
   LLD_HIP_TRY(hipEventCreate(&t_begin)); LLD_HIP_TRY(hipEventCreate(&t_end));
   LLD_HIP_TRY(hipEventRecord(t_begin, ctx->stream));
-  const size_t lin_lds = ((size_t)B->max_free * 27 + 8) * sizeof(double);
+  const size_t lin_lds = ((size_t)B->max_free * 27 * kAccCopies + 8) * sizeof(double);
   const size_t pcg_lds = ((size_t)B->max_free * 6 * 4 + kPcgThreads + (size_t)B->max_free * 36 + 32) * sizeof(double);
   const size_t chol_lds = ((size_t)B->max_free * 36 * 2 + (size_t)B->max_free * 6 * 2 + 32) * sizeof(double);
   // Optimizer.cc:1220-1222: a stop request before optimising returns without touching the map -> the read-back kernel copies
@@ -382,8 +388,9 @@ int lld_ba_batch_solve(lld_ba_batch* B, volatile const int* abort_flag) {
     const int abort_now = (abort_flag && *abort_flag) ? 1 : 0;
     LLD_HIP_TRY(hipMemsetAsync(G.d_counters, 0, 4 * sizeof(int), st));
     LLD_HIP_TRY(hipEventRecord(G.ev[0], st));
-    if (G.max_nt_pt > 0) hipLaunchKernelGGL(ba_linearize_pt_kernel, dim3(G.max_nt_pt, nw), dim3(kLmThreads), lin_lds, st, A, dw, ds);
-    if (G.max_nb_ln > 0) hipLaunchKernelGGL(ba_linearize_ln_kernel, dim3(G.max_nb_ln, nw), dim3(kLmThreads), lin_lds, st, A, dw, ds);
+    if (G.max_nl_pt > 0) hipLaunchKernelGGL(ba_linearize_pt_kernel, dim3(G.max_nl_pt, nw), dim3(kLinThreads), lin_lds, st, A, dw, ds);
+    if (G.max_nl_ln > 0) hipLaunchKernelGGL(ba_linearize_ln_kernel, dim3(G.max_nl_ln, nw), dim3(kLinThreads), lin_lds, st, A, dw, ds);
+    hipLaunchKernelGGL(ba_hpp_reduce_kernel, dim3((B->max_free * 27 + 255) / 256, nw), dim3(256), 0, st, A, dw, ds);
     hipLaunchKernelGGL(ba_begin_kernel, dim3((nw + 63) / 64), dim3(64), 0, st, A, dw, ds, nw);
     LLD_HIP_TRY(hipEventRecord(G.ev[1], st));
     if (G.max_items_pt > 0) hipLaunchKernelGGL(ba_schur_items_kernel<3>, dim3(G.max_items_pt, nw), dim3(64), B->schur_lds[0], st, A, dw, ds);

@@ -34,6 +34,9 @@ constexpr int kLmThreads = 256;        // landmark-parallel kernels: one lane pe
 constexpr int kSchurThreads = 128;    // item-parallel Schur kernel: one lane per (landmark chunk, camera-slot pair)
 constexpr int kPcgThreads = 1024;
 constexpr int kCtlThreads = 64;
+constexpr int kLinThreads = 512;        // linearise kernels: 8 tasks per workgroup (fewer per-workgroup Hpp partials to reduce)
+constexpr int kAccCopies = 4;          // LDS copies of the per-camera Hpp/bp accumulators: lanes of one wavefront that hit the
+                                       // same camera are spread over them (same-address LDS atomics serialise)
 constexpr int kMaxFreeCams = 96;
 
 enum Phase : int { PH_RUN = 0, PH_TRANSITION = 2, PH_FINALIZE = 3, PH_DONE = 4 };
@@ -56,6 +59,8 @@ struct BAWin {                 // immutable per-window header
   int nb_pt, nb_ln;            // landmark blocks (kLmThreads landmarks each)
   int ptask_off, n_ptasks, nt_pt;   // point tasks (4 per workgroup -> nt_pt workgroups)
   int ltask_off, n_ltasks, nt_ln;   // line tasks; partial-sum slots of a window: nt_pt + nt_ln
+  int nl_pt, nl_ln;            // workgroups of the linearise kernels (kLinThreads / 64 tasks each)
+  long long hpart_off;         // per-workgroup Hpp/bp partials of the linearise kernels (doubles): [nl_pt + nl_ln][n_free * 27]
   int part_off;                // per-block partial sums
   int its[2];                  // LM iterations per round
   int max_trials, ln_filter;
@@ -78,7 +83,8 @@ struct BAState {               // mutable per-window LM state
 // chunk and accumulates -Y_a W_b^T for every camera-slot pair over the chunk's landmarks in registers before it touches S.
 // Lane-per-edge point kernels: one wavefront per task = a run of consecutive point landmarks whose edges fit in 64 lanes
 // (or a single landmark with any number of edges).
-struct PTask { int l0, nl, e0, ne; };      // local first landmark, landmark count, global first edge, edge count
+struct PTask { int l0, nl, e0, ne, ms, pad0, pad1, pad2; };   // local first landmark, landmark count, global first edge / observation,
+                                                             // edge count, longest run of one landmark (bounds the segmented reductions)
 
 struct SChunk { int lm_off, n_lm, tab_off, cams_off, k, D, part_off, cpart_off; };   // part_off: 36-double blocks, cpart_off: 6-double vectors
 
@@ -110,6 +116,7 @@ struct BAArrays {
   double *pt_V;                // [NP*9]   Hll upper (6) + bl (3)
   double *ln_V;                // [NL*14]  Hll upper (10) + bl (4)
   // per-window reduced system
+  double *hpp_part;            // per linearise workgroup: [n_free][21 + 6]
   double *Hpp;                 // [NF*21]
   double *bp;                  // [NF*6]
   double *S, *bschur, *xp;
@@ -298,9 +305,8 @@ __device__ __forceinline__ bool seg_step(int seg, int lane, int off) {
   return (lane + off < 64) && so == seg;
 }
 template <int N>
-__device__ __forceinline__ void seg_sum(double* v, int seg, int lane) {      // valid in the first lane of every segment
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
+__device__ __forceinline__ void seg_sum(double* v, int seg, int lane, int max_len) {      // valid in the first lane of every segment
+  for (int off = 1; off < max_len; off <<= 1) {
     const bool ok = seg_step(seg, lane, off);
 #pragma unroll
     for (int i = 0; i < N; i++) { const double o = __shfl_down(v[i], off); if (ok) v[i] += o; }
@@ -353,20 +359,21 @@ __device__ __forceinline__ void point_edge_hpp(const PtEdgeLin& L, double* ac) {
   }
 }
 
-// grid (nt_pt, nW), block 256 = 4 wavefronts = 4 tasks; dynamic LDS: n_free_max*27 doubles + 8 scratch.
-__global__ __launch_bounds__(kLmThreads) void ba_linearize_pt_kernel(BAArrays A, const BAWin* __restrict__ wins, BAState* __restrict__ st) {
+// grid (nl_pt, nW), block 512 = 8 wavefronts = 8 tasks; dynamic LDS: kAccCopies*n_free_max*27 doubles + 8 scratch.
+__global__ __launch_bounds__(kLinThreads) void ba_linearize_pt_kernel(BAArrays A, const BAWin* __restrict__ wins, BAState* __restrict__ st) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const BAWin W = wins[blockIdx.y];
   BAState& S = st[blockIdx.y];
   if (S.phase != PH_RUN || !S.need_lin) return;
-  if ((int)blockIdx.x >= W.nt_pt) return;
+  if ((int)blockIdx.x >= W.nl_pt) return;
   const int nacc = W.n_free * 27;
-  double* acc = lds;
-  double* scratch = lds + nacc;
-  for (int i = threadIdx.x; i < nacc; i += kLmThreads) acc[i] = 0.0;
+  double* acc_all = lds;                              // kAccCopies x [n_free][21 Hpp upper + 6 bp]
+  double* scratch = lds + kAccCopies * nacc;
+  for (int i = threadIdx.x; i < kAccCopies * nacc; i += kLinThreads) acc_all[i] = 0.0;
+  double* acc = acc_all + ((threadIdx.x >> 3) & (kAccCopies - 1)) * nacc;
   __syncthreads();
   const int cur = S.cur;
-  const int lane = threadIdx.x & 63, ti = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63, ti = blockIdx.x * (kLinThreads / 64) + (threadIdx.x >> 6);
   double chi = 0.0, maxd = 0.0;
   if (ti < W.n_ptasks) {
     const PTask T = A.ptasks[W.ptask_off + ti];
@@ -390,7 +397,7 @@ __global__ __launch_bounds__(kLmThreads) void ba_linearize_pt_kernel(BAArrays A,
         point_edge_hll(L, hb);
         if (c < W.n_free) point_edge_hpp(L, acc + c * 27);
       }
-      seg_sum<9>(hb, l, lane);
+      seg_sum<9>(hb, l, lane, T.ms);
       if (lm_act && e == A.pt_obs_start[g]) {            // head lane of the landmark
         double* V = A.pt_V + (size_t)g * 9;
 #pragma unroll
@@ -435,14 +442,13 @@ __global__ __launch_bounds__(kLmThreads) void ba_linearize_pt_kernel(BAArrays A,
     atomicMax(&S.maxdiag_bits, (unsigned long long)__double_as_longlong(max_t));
   }
   __syncthreads();
-  double* gH = A.Hpp + (size_t)W.hpp_off * 21;
-  double* gb = A.bp + (size_t)W.hpp_off * 6;
-  for (int i = threadIdx.x; i < nacc; i += kLmThreads) {
-    const double v = acc[i];
-    if (v != 0.0) {
-      const int c = i / 27, k = i - c * 27;
-      if (k < 21) atomicAdd(&gH[c * 21 + k], v); else atomicAdd(&gb[c * 6 + (k - 21)], v);
-    }
+  // plain stores of this workgroup's camera partials; ba_hpp_reduce sums them in a fixed order (no global atomics)
+  double* dst = A.hpp_part + W.hpart_off + (size_t)(blockIdx.x) * nacc;
+  for (int i = threadIdx.x; i < nacc; i += kLinThreads) {
+    double v = 0.0;
+#pragma unroll
+    for (int q = 0; q < kAccCopies; q++) v += acc_all[q * nacc + i];
+    dst[i] = v;
   }
 }
 
@@ -522,7 +528,7 @@ __global__ __launch_bounds__(kLmThreads) void ba_backsub_pt_kernel(BAArrays A, c
       if (has) X = load_pt(A, cur, g);
       double wtx[3] = {0, 0, 0};
       if (e_act && c < W.n_free) point_edge_wtx(A, W, cur, e, fl, c, X, xp, wtx);
-      seg_sum<3>(wtx, l, lane);
+      seg_sum<3>(wtx, l, lane, T.ms);
       const int e_head = has ? A.pt_obs_start[g] : 0;
       Vec3 Xn = X;
       if (has && e == e_head) {                          // head lane: the landmark's update
@@ -633,20 +639,21 @@ __device__ __forceinline__ double line_obs_linearize(const BAArrays& A, const BA
   return chi;
 }
 
-// grid (nt_ln, nW), block 256 = 4 tasks; dynamic LDS: n_free_max*27 doubles + 8 scratch.
-__global__ __launch_bounds__(kLmThreads) void ba_linearize_ln_kernel(BAArrays A, const BAWin* __restrict__ wins, BAState* __restrict__ st) {
+// grid (nl_ln, nW), block 512 = 8 tasks; dynamic LDS: kAccCopies*n_free_max*27 doubles + 8 scratch.
+__global__ __launch_bounds__(kLinThreads) void ba_linearize_ln_kernel(BAArrays A, const BAWin* __restrict__ wins, BAState* __restrict__ st) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const BAWin W = wins[blockIdx.y];
   BAState& S = st[blockIdx.y];
   if (S.phase != PH_RUN || !S.need_lin) return;
-  if ((int)blockIdx.x >= W.nt_ln) return;
+  if ((int)blockIdx.x >= W.nl_ln) return;
   const int nacc = W.n_free * 27;
-  double* acc = lds;
-  double* scratch = lds + nacc;
-  for (int i = threadIdx.x; i < nacc; i += kLmThreads) acc[i] = 0.0;
+  double* acc_all = lds;                              // kAccCopies x [n_free][21 Hpp upper + 6 bp]
+  double* scratch = lds + kAccCopies * nacc;
+  for (int i = threadIdx.x; i < kAccCopies * nacc; i += kLinThreads) acc_all[i] = 0.0;
+  double* acc = acc_all + ((threadIdx.x >> 3) & (kAccCopies - 1)) * nacc;
   __syncthreads();
   const int cur = S.cur;
-  const int lane = threadIdx.x & 63, ti = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63, ti = blockIdx.x * (kLinThreads / 64) + (threadIdx.x >> 6);
   double chi = 0.0, maxd = 0.0;
   if (ti < W.n_ltasks) {
     const PTask T = A.ltasks[W.ltask_off + ti];
@@ -663,7 +670,7 @@ __global__ __launch_bounds__(kLmThreads) void ba_linearize_ln_kernel(BAArrays A,
         const LineGeom G = line_geom(load_ln(A, cur, g));
         chi += line_obs_linearize(A, W, cur, o, A.le_cam[2 * o], G, hb, acc);
       }
-      seg_sum<14>(hb, l, lane);
+      seg_sum<14>(hb, l, lane, T.ms);
       if (lm_act && o == A.ln_obs_start[g]) {
         double* V = A.ln_V + (size_t)g * 14;
 #pragma unroll
@@ -688,18 +695,17 @@ __global__ __launch_bounds__(kLmThreads) void ba_linearize_ln_kernel(BAArrays A,
   const double chi_t = block_sum(chi, scratch);
   const double max_t = block_max(maxd, scratch);
   if (threadIdx.x == 0) {
-    A.chi_part[W.part_off + W.nt_pt + blockIdx.x] = chi_t;
+    A.chi_part[W.part_off + W.nl_pt + blockIdx.x] = chi_t;
     atomicMax(&S.maxdiag_bits, (unsigned long long)__double_as_longlong(max_t));
   }
   __syncthreads();
-  double* gH = A.Hpp + (size_t)W.hpp_off * 21;
-  double* gb = A.bp + (size_t)W.hpp_off * 6;
-  for (int i = threadIdx.x; i < nacc; i += kLmThreads) {
-    const double v = acc[i];
-    if (v != 0.0) {
-      const int c = i / 27, k = i - c * 27;
-      if (k < 21) atomicAdd(&gH[c * 21 + k], v); else atomicAdd(&gb[c * 6 + (k - 21)], v);
-    }
+  // plain stores of this workgroup's camera partials; ba_hpp_reduce sums them in a fixed order (no global atomics)
+  double* dst = A.hpp_part + W.hpart_off + (size_t)(W.nl_pt + blockIdx.x) * nacc;
+  for (int i = threadIdx.x; i < nacc; i += kLinThreads) {
+    double v = 0.0;
+#pragma unroll
+    for (int q = 0; q < kAccCopies; q++) v += acc_all[q * nacc + i];
+    dst[i] = v;
   }
 }
 
@@ -770,7 +776,7 @@ __global__ __launch_bounds__(kLmThreads) void ba_backsub_ln_kernel(BAArrays A, c
       LineQ L = load_ln(A, cur, g);
       double wtx[4] = {0, 0, 0, 0};
       if (lm_act && c < W.n_free) line_obs_wtx(A, W, o, c, xp, wtx);
-      seg_sum<4>(wtx, l, lane);
+      seg_sum<4>(wtx, l, lane, T.ms);
       const int o_head = has ? A.ln_obs_start[g] : 0;
       LineQ Ln = L;
       if (has && o == o_head) {
@@ -811,6 +817,22 @@ __global__ __launch_bounds__(kLmThreads) void ba_backsub_ln_kernel(BAArrays A, c
   if (threadIdx.x == 0) { A.chi_part2[W.part_off + W.nt_pt + blockIdx.x] = chi_t; A.scale_part[W.part_off + W.nt_pt + blockIdx.x] = sc_t; }
 }
 
+// Hpp / b_p = sum over the linearise workgroups' partials, fixed order.  grid (ceil(n_free_max*27 / 256), nW)
+__global__ __launch_bounds__(256) void ba_hpp_reduce_kernel(BAArrays A, const BAWin* __restrict__ wins, const BAState* __restrict__ st) {
+  const BAWin W = wins[blockIdx.y];
+  const BAState& S = st[blockIdx.y];
+  if (S.phase != PH_RUN || !S.need_lin) return;
+  const int nacc = W.n_free * 27;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= nacc) return;
+  const double* src = A.hpp_part + W.hpart_off + i;
+  const int nb = W.nl_pt + W.nl_ln;
+  double v = 0.0;
+  for (int b = 0; b < nb; b++) v += src[(size_t)b * nacc];
+  const int c = i / 27, k = i - c * 27;
+  if (k < 21) A.Hpp[((size_t)W.hpp_off + c) * 21 + k] = v; else A.bp[((size_t)W.hpp_off + c) * 6 + (k - 21)] = v;
+}
+
 // LM iteration head (one lane per window): chi2 of the current state, lambda initialisation at iteration 0.
 __global__ void ba_begin_kernel(BAArrays A, const BAWin* __restrict__ wins, BAState* __restrict__ st, int n_windows) {
   const int w = blockIdx.x * blockDim.x + threadIdx.x;
@@ -819,7 +841,7 @@ __global__ void ba_begin_kernel(BAArrays A, const BAWin* __restrict__ wins, BASt
   BAState& S = st[w];
   if (S.phase != PH_RUN || !S.need_lin) return;
   double chi = 0.0;
-  const int nb = W.nt_pt + W.nt_ln;
+  const int nb = W.nl_pt + W.nl_ln;
   for (int i = 0; i < nb; i++) chi += A.chi_part[W.part_off + i];
   S.currentChi = chi; S.iniChi = chi;
   if (S.it == 0) {
