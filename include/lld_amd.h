@@ -171,6 +171,10 @@ int  lld_ba_batch_result_records(lld_ba_batch* batch, void** dev_ptr, uint64_t* 
 int  lld_ba_batch_phase_ms(lld_ba_batch* batch, double* ms6);
 /* Launch count and summed HIP-event time of one kernel family in the last solve; `kernel` uses the phase ids 0..4. */
 int  lld_ba_batch_kernel_stats(lld_ba_batch* batch, int kernel, int64_t* launches, double* total_ms);
+/* Tuning: number of window groups solved concurrently on separate HIP streams (1..8; 0 restores the default chosen from the
+ * batch size).  One group makes the HIP-event times of lld_ba_batch_phase_ms disjoint, which is what a roofline measurement
+ * wants; several groups hide the latency-bound reduced solve and the per-super-step host poll. */
+int  lld_ba_batch_set_groups(lld_ba_batch* batch, int n_groups);
 void lld_ba_batch_destroy(lld_ba_batch* batch);
 
 /* ================================================================== pose optimisation

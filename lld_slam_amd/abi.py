@@ -129,7 +129,8 @@ PRODUCT_SYMBOLS = [
     "lld_se3_from_tcw_f32", "lld_se3_to_tcw_f32", "lld_orb_inv_level_sigma2",
     "lld_ba_params_default", "lld_local_ba",
     "lld_ba_batch_create", "lld_ba_batch_solve", "lld_ba_batch_download", "lld_ba_batch_stats",
-    "lld_ba_batch_result_records", "lld_ba_batch_phase_ms", "lld_ba_batch_kernel_stats", "lld_ba_batch_destroy",
+    "lld_ba_batch_result_records", "lld_ba_batch_phase_ms", "lld_ba_batch_kernel_stats", "lld_ba_batch_set_groups",
+    "lld_ba_batch_destroy",
     "lld_pose_params_default", "lld_pose_opt",
     "lld_pose_batch_create", "lld_pose_batch_solve", "lld_pose_batch_download", "lld_pose_batch_destroy",
     "lld_match_hamming256", "lld_match_hamming256_csr", "lld_match_hamming256_batch_dev",
@@ -204,6 +205,7 @@ class Lib:
             f("ba_batch_phase_ms").argtypes = [vp, c_double_p]; f("ba_batch_phase_ms").restype = C.c_int
             f("ba_batch_kernel_stats").argtypes = [vp, C.c_int, C.POINTER(C.c_int64), c_double_p]
             f("ba_batch_kernel_stats").restype = C.c_int
+            f("ba_batch_set_groups").argtypes = [vp, C.c_int]; f("ba_batch_set_groups").restype = C.c_int
             f("ba_batch_destroy").argtypes = [vp]; f("ba_batch_destroy").restype = None
             f("pose_batch_create").argtypes = [vp, C.c_int, C.POINTER(PoseProblem), C.POINTER(PoseParams), C.POINTER(vp)]
             f("pose_batch_create").restype = C.c_int

@@ -77,6 +77,46 @@ size_t record_bytes(const BAWin& W) {
 
 }  // namespace
 
+
+static void ba_drop_groups(lld_ba_batch* B) {
+  for (auto& G : B->groups) {
+    for (auto& e : G.ev) if (e) (void)hipEventDestroy(e);
+    if (G.own_stream && G.st) { (void)hipStreamSynchronize(G.st); (void)hipStreamDestroy(G.st); }
+  }
+  B->groups.clear();
+}
+
+// Partition the windows into groups, each with its own stream, counters and events.  n_groups 0 -> default: 1 group for tiny
+// batches, up to 4 for large ones (the environment variable LLD_BA_GROUPS overrides the default, for experiments).
+static int ba_make_groups(lld_ba_batch* B, int n_groups) {
+  const int n_windows = B->n_windows;
+  int G = n_groups;
+  if (G <= 0) {
+    G = n_windows >= 192 ? 4 : (n_windows >= 48 ? 3 : (n_windows >= 8 ? 2 : 1));
+    if (const char* e = std::getenv("LLD_BA_GROUPS")) { const int v = std::atoi(e); if (v >= 1 && v <= 8) G = v; }
+  }
+  G = std::max(1, std::min(std::min(G, 8), n_windows));
+  ba_drop_groups(B);
+  B->groups.resize(G);
+  for (int g = 0; g < G; g++) {
+    lld_ba_batch::Group& Gr = B->groups[g];
+    Gr.w0 = (int)((long long)n_windows * g / G); Gr.nw = (int)((long long)n_windows * (g + 1) / G) - Gr.w0;
+    if (g == 0) Gr.st = B->ctx->stream;
+    else { LLD_HIP_TRY(hipStreamCreateWithFlags(&Gr.st, hipStreamNonBlocking)); Gr.own_stream = true; }
+    Gr.d_counters = B->d_counters + 4 * g; Gr.h_counters = B->h_counters + 4 * g;
+    for (auto& e : Gr.ev) LLD_HIP_TRY(hipEventCreate(&e));
+    for (int wi = Gr.w0; wi < Gr.w0 + Gr.nw; wi++) {
+      const BAWin& W = B->h_wins[wi];
+      Gr.max_lblocks = std::max(Gr.max_lblocks, W.nb_pt + W.nb_ln);
+      Gr.max_nt_pt = std::max(Gr.max_nt_pt, W.nt_pt); Gr.max_nb_ln = std::max(Gr.max_nb_ln, W.nt_ln);
+      Gr.max_nl_pt = std::max(Gr.max_nl_pt, W.nl_pt); Gr.max_nl_ln = std::max(Gr.max_nl_ln, W.nl_ln);
+      Gr.max_items_pt = std::max(Gr.max_items_pt, W.n_items_pt); Gr.max_items_ln = std::max(Gr.max_items_ln, W.n_items - W.n_items_pt);
+      Gr.max_blk = std::max(Gr.max_blk, W.n_free * (W.n_free + 1) / 2);
+    }
+  }
+  return LLD_OK;
+}
+
 extern "C" {
 
 int lld_ba_batch_create(lld_ctx* ctx, int n_windows, const lld_ba_window* wins, const lld_ba_params* params, lld_ba_batch** out) {
@@ -327,29 +367,7 @@ int lld_ba_batch_create(lld_ctx* ctx, int n_windows, const lld_ba_window* wins, 
   }
   LLD_HIP_TRY(hipMemcpyAsync(B->d_wins, B->h_wins.data(), sizeof(BAWin) * n_windows, hipMemcpyHostToDevice, st));
   LLD_HIP_TRY(hipHostMalloc((void**)&B->h_counters, 4 * 8 * sizeof(int), hipHostMallocDefault));
-  {
-    // 1 group for tiny batches, up to 4 for large ones (LLD_BA_GROUPS overrides, for experiments)
-    int G = n_windows >= 192 ? 4 : (n_windows >= 48 ? 3 : (n_windows >= 8 ? 2 : 1));
-    if (const char* e = std::getenv("LLD_BA_GROUPS")) { const int v = std::atoi(e); if (v >= 1 && v <= 8) G = v; }
-    G = std::min(G, n_windows);
-    B->groups.resize(G);
-    for (int g = 0; g < G; g++) {
-      lld_ba_batch::Group& Gr = B->groups[g];
-      Gr.w0 = (int)((long long)n_windows * g / G); Gr.nw = (int)((long long)n_windows * (g + 1) / G) - Gr.w0;
-      if (g == 0) Gr.st = ctx->stream;
-      else { LLD_HIP_TRY(hipStreamCreateWithFlags(&Gr.st, hipStreamNonBlocking)); Gr.own_stream = true; }
-      Gr.d_counters = B->d_counters + 4 * g; Gr.h_counters = B->h_counters + 4 * g;
-      for (auto& e : Gr.ev) LLD_HIP_TRY(hipEventCreate(&e));
-      for (int wi = Gr.w0; wi < Gr.w0 + Gr.nw; wi++) {
-        const BAWin& W = B->h_wins[wi];
-        Gr.max_lblocks = std::max(Gr.max_lblocks, W.nb_pt + W.nb_ln);
-        Gr.max_nt_pt = std::max(Gr.max_nt_pt, W.nt_pt); Gr.max_nb_ln = std::max(Gr.max_nb_ln, W.nt_ln);
-        Gr.max_nl_pt = std::max(Gr.max_nl_pt, W.nl_pt); Gr.max_nl_ln = std::max(Gr.max_nl_ln, W.nl_ln);
-        Gr.max_items_pt = std::max(Gr.max_items_pt, W.n_items_pt); Gr.max_items_ln = std::max(Gr.max_items_ln, W.n_items - W.n_items_pt);
-        Gr.max_blk = std::max(Gr.max_blk, W.n_free * (W.n_free + 1) / 2);
-      }
-    }
-  }
+  { int gs = ba_make_groups(B, 0); if (gs) return gs; }
   LLD_HIP_TRY(hipStreamSynchronize(st));        // staging vectors go out of scope
   *out = B;
   return LLD_OK;
@@ -545,11 +563,18 @@ int lld_ba_batch_kernel_stats(lld_ba_batch* B, int kernel, int64_t* launches, do
   return LLD_OK;
 }
 
+int lld_ba_batch_set_groups(lld_ba_batch* B, int n_groups) {
+  if (!B || n_groups < 0 || n_groups > 8) return LLD_ERR_INVALID;
+  LLD_HIP_TRY(hipSetDevice(B->ctx->device));
+  LLD_HIP_TRY(hipStreamSynchronize(B->ctx->stream));
+  return ba_make_groups(B, n_groups);
+}
+
 void lld_ba_batch_destroy(lld_ba_batch* B) {
   if (!B) return;
   (void)hipSetDevice(B->ctx->device);
   (void)hipStreamSynchronize(B->ctx->stream);
-  for (auto& G : B->groups) { for (auto& e : G.ev) if (e) (void)hipEventDestroy(e); if (G.own_stream && G.st) { (void)hipStreamSynchronize(G.st); (void)hipStreamDestroy(G.st); } }
+  ba_drop_groups(B);
   if (B->h_counters) (void)hipHostFree(B->h_counters);
   if (B->slab) (void)hipFree(B->slab);
   delete B;

@@ -390,6 +390,10 @@ class BABatch:
         check(self.lib.fn("ba_batch_kernel_stats")(self.handle, kernel, C.byref(n), _p(ms, C.c_double)), "ba_batch_kernel_stats")
         return int(n.value), float(ms[0])
 
+    def set_groups(self, n: int):
+        """Window groups solved concurrently on separate streams (0 = default for the batch size)."""
+        check(self.lib.fn("ba_batch_set_groups")(self.handle, int(n)), "ba_batch_set_groups")
+
     def result_records(self):
         p = C.c_void_p(); stride = C.c_uint64(0)
         check(self.lib.fn("ba_batch_result_records")(self.handle, C.byref(p), C.byref(stride)), "ba_batch_result_records")
