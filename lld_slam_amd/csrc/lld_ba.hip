@@ -359,7 +359,7 @@ int lld_ba_batch_create(lld_ctx* ctx, int n_windows, const lld_ba_window* wins, 
   {
     const size_t pcg_lds = ((size_t)B->max_free * 6 * 4 + kPcgThreads + (size_t)B->max_free * 36 + 32) * sizeof(double);
     LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_pcg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pcg_lds));
-    const size_t lin_lds = ((size_t)B->max_free * 27 * kAccCopies + 8) * sizeof(double);
+    const size_t lin_lds = ((size_t)B->max_free * 27 * kAccCopies + 8 + (size_t)B->max_cams * 7) * sizeof(double);
     LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_linearize_pt_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lin_lds));
     LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_linearize_ln_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lin_lds));
     const size_t chol_lds = ((size_t)B->max_free * 36 * 2 + (size_t)B->max_free * 6 * 2 + 32) * sizeof(double);
@@ -385,7 +385,8 @@ int lld_ba_batch_solve(lld_ba_batch* B, volatile const int* abort_flag) {
   hipEvent_t t_begin, t_end;
   LLD_HIP_TRY(hipEventCreate(&t_begin)); LLD_HIP_TRY(hipEventCreate(&t_end));
   LLD_HIP_TRY(hipEventRecord(t_begin, ctx->stream));
-  const size_t lin_lds = ((size_t)B->max_free * 27 * kAccCopies + 8) * sizeof(double);
+  const size_t lin_lds = ((size_t)B->max_free * 27 * kAccCopies + 8 + (size_t)B->max_cams * 7) * sizeof(double);
+  const size_t bs_lds = (8 + (size_t)B->max_cams * 14 + (size_t)B->max_free * 6) * sizeof(double);
   const size_t pcg_lds = ((size_t)B->max_free * 6 * 4 + kPcgThreads + (size_t)B->max_free * 36 + 32) * sizeof(double);
   const size_t chol_lds = ((size_t)B->max_free * 36 * 2 + (size_t)B->max_free * 6 * 2 + 32) * sizeof(double);
   // Optimizer.cc:1220-1222: a stop request before optimising returns without touching the map -> the read-back kernel copies
@@ -421,7 +422,7 @@ int lld_ba_batch_solve(lld_ba_batch* B, volatile const int* abort_flag) {
     else
       hipLaunchKernelGGL(ba_chol_kernel, dim3(nw), dim3(kPcgThreads), chol_lds, st, A, dw, ds);
     LLD_HIP_TRY(hipEventRecord(G.ev[3], st));
-    if (G.max_nt_pt > 0) hipLaunchKernelGGL(ba_backsub_pt_kernel, dim3(G.max_nt_pt, nw), dim3(kLmThreads), 0, st, A, dw, ds);
+    if (G.max_nt_pt > 0) hipLaunchKernelGGL(ba_backsub_pt_kernel, dim3(G.max_nt_pt, nw), dim3(kLmThreads), bs_lds, st, A, dw, ds);
     if (G.max_nb_ln > 0) hipLaunchKernelGGL(ba_backsub_ln_kernel, dim3(G.max_nb_ln, nw), dim3(kLmThreads), 0, st, A, dw, ds);
     LLD_HIP_TRY(hipEventRecord(G.ev[4], st));
     hipLaunchKernelGGL(ba_control_kernel, dim3(nw), dim3(kCtlThreads), 0, st, A, dw, ds, abort_now, G.d_counters);

@@ -338,6 +338,21 @@ __device__ __forceinline__ void point_edge_linearize(const BAArrays& A, const BA
   point_jac_point(W.cam, Xc, quat_rotation(T.q), L.stereo, L.Jp);
   point_jac_pose(W.cam, Xc, L.stereo, L.Jc);
 }
+struct PtObs { double u, v, ur, s; };
+// same with every operand already in registers (pose from the LDS copy, observation loaded up front): no dependent loads
+__device__ __forceinline__ double point_edge_linearize_r(const BAWin& W, const Pose& T, const Vec3& X, const PtObs& ob, uint8_t fl, PtEdgeLin& L) {
+  const Vec3 Xc = pose_map(T, X);
+  L.stereo = !(ob.ur < 0);
+  point_residual(W.cam, Xc, ob.u, ob.v, ob.ur, L.stereo, true, L.r);
+  const double c2 = chi2_of(L.r, L.stereo ? 3 : 2, ob.s);
+  double w = 1.0;
+  L.rho0 = c2;
+  if (fl & EF_ROBUST) L.rho0 = huber(c2, L.stereo ? W.th_stereo : W.th_mono, &w);
+  L.ws = w * ob.s;
+  point_jac_point(W.cam, Xc, quat_rotation(T.q), L.stereo, L.Jp);
+  point_jac_pose(W.cam, Xc, L.stereo, L.Jc);
+  return c2;
+}
 // landmark side Hll (6 upper) + b_l (3) of one edge
 __device__ __forceinline__ void point_edge_hll(const PtEdgeLin& L, double* hb) {
   int k = 0;
@@ -360,7 +375,7 @@ __device__ __forceinline__ void point_edge_hpp(const PtEdgeLin& L, double* ac) {
 }
 
 // grid (nl_pt, nW), block 512 = 8 wavefronts = 8 tasks; dynamic LDS: kAccCopies*n_free_max*27 doubles + 8 scratch.
-__global__ __launch_bounds__(kLinThreads) void ba_linearize_pt_kernel(BAArrays A, const BAWin* __restrict__ wins, BAState* __restrict__ st) {
+__global__ __launch_bounds__(kLinThreads, 4) void ba_linearize_pt_kernel(BAArrays A, const BAWin* __restrict__ wins, BAState* __restrict__ st) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const BAWin W = wins[blockIdx.y];
   BAState& S = st[blockIdx.y];
@@ -369,40 +384,57 @@ __global__ __launch_bounds__(kLinThreads) void ba_linearize_pt_kernel(BAArrays A
   const int nacc = W.n_free * 27;
   double* acc_all = lds;                              // kAccCopies x [n_free][21 Hpp upper + 6 bp]
   double* scratch = lds + kAccCopies * nacc;
+  double* cams = scratch + 8;                         // [n_cams][7] poses of the linearisation point
   for (int i = threadIdx.x; i < kAccCopies * nacc; i += kLinThreads) acc_all[i] = 0.0;
   double* acc = acc_all + ((threadIdx.x >> 3) & (kAccCopies - 1)) * nacc;
-  __syncthreads();
   const int cur = S.cur;
+  for (int i = threadIdx.x; i < W.n_cams * 7; i += kLinThreads) cams[i] = A.cam_qt[((size_t)cur * A.NC + W.cam_off) * 7 + i];
+  __syncthreads();
   const int lane = threadIdx.x & 63, ti = blockIdx.x * (kLinThreads / 64) + (threadIdx.x >> 6);
   double chi = 0.0, maxd = 0.0;
   if (ti < W.n_ptasks) {
     const PTask T = A.ptasks[W.ptask_off + ti];
     if (T.nl > 1) {
+      // two dependent memory levels only: (1) the task, (2) every global operand - edge arrays by edge lane, landmark
+      // state by landmark lane (lane i <-> landmark l0 + i); camera poses come from the workgroup's LDS copy and landmark
+      // data reaches the edge lanes by shuffle.
       const bool has = lane < T.ne;
       const int e = T.e0 + (has ? lane : 0);
       const int l = has ? A.pe_pt[e] : -1 - lane;
-      const int g = W.pt_off + (has ? l : T.l0);
       const uint8_t fl = A.pe_flags[e];
       const int c = A.pe_cam[e];
-      const bool lm_act = has && A.pt_active[g];
+      PtObs ob; ob.u = A.pe_u[e]; ob.v = A.pe_v[e]; ob.ur = A.pe_ur[e]; ob.s = A.pe_s[e];
+      const bool lmk = lane < T.nl;
+      const int g2 = W.pt_off + T.l0 + (lmk ? lane : 0);
+      const Vec3 X2 = load_pt(A, cur, g2);
+      const int act2 = lmk ? (int)A.pt_active[g2] : 0;
+      const int start2 = A.pt_obs_start[g2], end2 = A.pt_obs_start[g2 + 1];
+      const int slot = has ? l - T.l0 : 0;
+      Vec3 X; X.x = __shfl(X2.x, slot); X.y = __shfl(X2.y, slot); X.z = __shfl(X2.z, slot);
+      const bool lm_act = has && __shfl(act2, slot) != 0;
       double hb[9];
 #pragma unroll
       for (int i = 0; i < 9; i++) hb[i] = 0.0;
       if (has && (fl & EF_LEVEL1)) A.pe_ws[e] = 0.0;
       if (lm_act && !(fl & EF_LEVEL1)) {
-        const Vec3 X = load_pt(A, cur, g);
         PtEdgeLin L;
-        point_edge_linearize(A, W, cur, e, fl, c, X, L);
+        A.pe_chi2[e] = point_edge_linearize_r(W, pose_load(cams + c * 7), X, ob, fl, L);
+        A.pe_ws[e] = L.ws;
         chi += L.rho0;
         point_edge_hll(L, hb);
         if (c < W.n_free) point_edge_hpp(L, acc + c * 27);
       }
       seg_sum<9>(hb, l, lane, T.ms);
-      if (lm_act && e == A.pt_obs_start[g]) {            // head lane of the landmark
-        double* V = A.pt_V + (size_t)g * 9;
+      // landmark lane i collects the sum from the first edge lane of its landmark
+      const int first = (lmk && end2 > start2) ? start2 - T.e0 : 0;
+      double vb[9];
 #pragma unroll
-        for (int i = 0; i < 9; i++) V[i] = hb[i];
-        maxd = fmax(fabs(hb[0]), fmax(fabs(hb[3]), fabs(hb[5])));
+      for (int i = 0; i < 9; i++) vb[i] = __shfl(hb[i], first);
+      if (lmk && act2 && end2 > start2) {
+        double* V = A.pt_V + (size_t)g2 * 9;
+#pragma unroll
+        for (int i = 0; i < 9; i++) V[i] = vb[i];
+        maxd = fmax(fabs(vb[0]), fmax(fabs(vb[3]), fabs(vb[5])));
       }
     } else {                                             // a single landmark, any number of edges
       const int g = W.pt_off + T.l0;
@@ -501,9 +533,9 @@ __device__ __forceinline__ double point_backsub(const double* V, double lambda, 
   return sc;
 }
 
-// grid (nt_pt, nW), block 256 = 4 tasks
+// grid (nt_pt, nW), block 256 = 4 tasks; dynamic LDS: 8 + 14 n_cams + 6 n_free doubles
 __global__ __launch_bounds__(kLmThreads) void ba_backsub_pt_kernel(BAArrays A, const BAWin* __restrict__ wins, const BAState* __restrict__ st) {
-  __shared__ double scratch[8];
+  extern __shared__ __attribute__((aligned(16))) double lds[];
   const BAWin W = wins[blockIdx.y];
   const BAState& S = st[blockIdx.y];
   if (S.phase != PH_RUN) return;
@@ -511,6 +543,18 @@ __global__ __launch_bounds__(kLmThreads) void ba_backsub_pt_kernel(BAArrays A, c
   const int cur = S.cur, nxt = cur ^ 1;
   const double lambda = S.lambda;
   const double* xp = A.xp + W.x_off;
+  // workgroup copies of what every edge lane gathers: poses of the linearisation point (camA) and of the trial state (camB),
+  // and the camera part of the solution
+  double* scratch = lds;
+  double* camA = lds + 8;
+  double* camB = camA + W.n_cams * 7;
+  double* xps = camB + W.n_cams * 7;
+  for (int i = threadIdx.x; i < W.n_cams * 7; i += kLmThreads) {
+    camA[i] = A.cam_qt[((size_t)cur * A.NC + W.cam_off) * 7 + i];
+    camB[i] = A.cam_qt[((size_t)nxt * A.NC + W.cam_off) * 7 + i];
+  }
+  for (int i = threadIdx.x; i < 6 * W.n_free; i += kLmThreads) xps[i] = xp[i];
+  __syncthreads();
   const int lane = threadIdx.x & 63, ti = blockIdx.x * 4 + (threadIdx.x >> 6);
   double chi = 0.0, sc = 0.0;
   if (ti < W.n_ptasks) {
@@ -519,29 +563,63 @@ __global__ __launch_bounds__(kLmThreads) void ba_backsub_pt_kernel(BAArrays A, c
       const bool has = lane < T.ne;
       const int e = T.e0 + (has ? lane : 0);
       const int l = has ? A.pe_pt[e] : -1 - lane;
-      const int g = W.pt_off + (has ? l : T.l0);
       const uint8_t fl = A.pe_flags[e];
       const int c = A.pe_cam[e];
-      const bool lm_act = has && A.pt_active[g];
-      const bool e_act = lm_act && !(fl & EF_LEVEL1);
-      Vec3 X = vec3(0, 0, 0);
-      if (has) X = load_pt(A, cur, g);
+      const double ws = A.pe_ws[e];
+      PtObs ob; ob.u = A.pe_u[e]; ob.v = A.pe_v[e]; ob.ur = A.pe_ur[e]; ob.s = A.pe_s[e];
+      const bool lmk = lane < T.nl;
+      const int g2 = W.pt_off + T.l0 + (lmk ? lane : 0);
+      const Vec3 X2 = load_pt(A, cur, g2);
+      const int act2 = lmk ? (int)A.pt_active[g2] : 0;
+      const int start2 = A.pt_obs_start[g2], end2 = A.pt_obs_start[g2 + 1];
+      double V2[9];
+#pragma unroll
+      for (int i = 0; i < 9; i++) V2[i] = A.pt_V[(size_t)g2 * 9 + i];
+      const int slot = has ? l - T.l0 : 0;
+      Vec3 X; X.x = __shfl(X2.x, slot); X.y = __shfl(X2.y, slot); X.z = __shfl(X2.z, slot);
+      const bool e_act = has && __shfl(act2, slot) != 0 && !(fl & EF_LEVEL1);
       double wtx[3] = {0, 0, 0};
-      if (e_act && c < W.n_free) point_edge_wtx(A, W, cur, e, fl, c, X, xp, wtx);
-      seg_sum<3>(wtx, l, lane, T.ms);
-      const int e_head = has ? A.pt_obs_start[g] : 0;
-      Vec3 Xn = X;
-      if (has && e == e_head) {                          // head lane: the landmark's update
-        if (lm_act) sc += point_backsub(A.pt_V + (size_t)g * 9, lambda, wtx, X, Xn);
-        store_pt(A, nxt, g, Xn);                         // inactive landmarks keep their state in both buffers
+      if (e_act && c < W.n_free) {
+        // W_e^T x_c = ws * Jp^T (Jc x_c) with the Jacobians of the linearisation point
+        const Pose Tc = pose_load(camA + c * 7);
+        const Vec3 Xc = pose_map(Tc, X);
+        const bool stereo = (fl & EF_STEREO) != 0;
+        double Jp[9], Jc[18];
+        point_jac_point(W.cam, Xc, quat_rotation(Tc.q), stereo, Jp);
+        point_jac_pose(W.cam, Xc, stereo, Jc);
+        double uu[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+          double sacc = 0.0;
+#pragma unroll
+          for (int r = 0; r < 6; r++) sacc += Jc[i * 6 + r] * xps[c * 6 + r];
+          uu[i] = ws * sacc;
+        }
+#pragma unroll
+        for (int k = 0; k < 3; k++) wtx[k] = Jp[k] * uu[0] + Jp[3 + k] * uu[1] + Jp[6 + k] * uu[2];
       }
-      const int hl = e_head - T.e0;
-      Xn.x = __shfl(Xn.x, hl); Xn.y = __shfl(Xn.y, hl); Xn.z = __shfl(Xn.z, hl);
-      if (e_act) chi += point_edge_trial(A, W, nxt, e, fl, c, Xn);
-      // landmarks of the task without any edge have no head lane
-      if (lane < T.nl) {
-        const int g2 = W.pt_off + T.l0 + lane;
-        if (A.pt_obs_start[g2 + 1] == A.pt_obs_start[g2]) store_pt(A, nxt, g2, load_pt(A, cur, g2));
+      seg_sum<3>(wtx, l, lane, T.ms);
+      // landmark lane: back-substitution and oplus of its landmark (inactive / edge-less landmarks keep their state)
+      const int first = (lmk && end2 > start2) ? start2 - T.e0 : 0;
+      double wl[3];
+#pragma unroll
+      for (int i = 0; i < 3; i++) wl[i] = __shfl(wtx[i], first);
+      Vec3 Xn2 = X2;
+      if (lmk) {
+        if (act2 && end2 > start2) sc += point_backsub(V2, lambda, wl, X2, Xn2);
+        store_pt(A, nxt, g2, Xn2);
+      }
+      Vec3 Xn; Xn.x = __shfl(Xn2.x, slot); Xn.y = __shfl(Xn2.y, slot); Xn.z = __shfl(Xn2.z, slot);
+      if (e_act) {
+        const Vec3 Xc = pose_map(pose_load(camB + c * 7), Xn);
+        const bool stereo = !(ob.ur < 0);
+        double r[3];
+        point_residual(W.cam, Xc, ob.u, ob.v, ob.ur, stereo, true, r);
+        const double c2 = chi2_of(r, stereo ? 3 : 2, ob.s);
+        A.pe_chi2[e] = c2;
+        double w, rho0 = c2;
+        if (fl & EF_ROBUST) rho0 = huber(c2, stereo ? W.th_stereo : W.th_mono, &w);
+        chi += rho0;
       }
     } else {
       const int g = W.pt_off + T.l0;
