@@ -362,8 +362,7 @@ int lld_ba_batch_create(lld_ctx* ctx, int n_windows, const lld_ba_window* wins, 
     const size_t lin_lds = ((size_t)B->max_free * 27 * kAccCopies + 8 + (size_t)B->max_cams * 7) * sizeof(double);
     LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_linearize_pt_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lin_lds));
     LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_linearize_ln_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lin_lds));
-    const size_t chol_lds = ((size_t)B->max_free * 36 * 2 + (size_t)B->max_free * 6 * 2 + 32) * sizeof(double);
-    LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_chol_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)chol_lds));
+    LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_chol_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
   }
   LLD_HIP_TRY(hipMemcpyAsync(B->d_wins, B->h_wins.data(), sizeof(BAWin) * n_windows, hipMemcpyHostToDevice, st));
   LLD_HIP_TRY(hipHostMalloc((void**)&B->h_counters, 4 * 8 * sizeof(int), hipHostMallocDefault));
@@ -388,7 +387,10 @@ int lld_ba_batch_solve(lld_ba_batch* B, volatile const int* abort_flag) {
   const size_t lin_lds = ((size_t)B->max_free * 27 * kAccCopies + 8 + (size_t)B->max_cams * 7) * sizeof(double);
   const size_t bs_lds = (8 + (size_t)B->max_cams * 14 + (size_t)B->max_free * 6) * sizeof(double);
   const size_t pcg_lds = ((size_t)B->max_free * 6 * 4 + kPcgThreads + (size_t)B->max_free * 36 + 32) * sizeof(double);
-  const size_t chol_lds = ((size_t)B->max_free * 36 * 2 + (size_t)B->max_free * 6 * 2 + 32) * sizeof(double);
+  const size_t chol_fixed = ((size_t)B->max_free * 36 * 2 + (size_t)B->max_free * 6 * 2 + 32) * sizeof(double);
+  // whatever LDS is left (a workgroup may own up to 160 KiB) holds the trailing block triangle of S
+  const size_t chol_tri = std::min((size_t)B->max_free * (B->max_free + 1) / 2 * 36 * sizeof(double), (size_t)(156 * 1024) - chol_fixed) / 288 * 288;
+  const size_t chol_lds = chol_fixed + chol_tri;
   // Optimizer.cc:1220-1222: a stop request before optimising returns without touching the map -> the read-back kernel copies
   // the (untouched) working state and every flag stays clear.
   const bool abort_at_start = abort_flag && *abort_flag;
@@ -410,7 +412,7 @@ int lld_ba_batch_solve(lld_ba_batch* B, volatile const int* abort_flag) {
     if (G.max_nl_pt > 0) hipLaunchKernelGGL(ba_linearize_pt_kernel, dim3(G.max_nl_pt, nw), dim3(kLinThreads), lin_lds, st, A, dw, ds);
     if (G.max_nl_ln > 0) hipLaunchKernelGGL(ba_linearize_ln_kernel, dim3(G.max_nl_ln, nw), dim3(kLinThreads), lin_lds, st, A, dw, ds);
     hipLaunchKernelGGL(ba_hpp_reduce_kernel, dim3((B->max_free * 27 + 255) / 256, nw), dim3(256), 0, st, A, dw, ds);
-    hipLaunchKernelGGL(ba_begin_kernel, dim3((nw + 63) / 64), dim3(64), 0, st, A, dw, ds, nw);
+    hipLaunchKernelGGL(ba_begin_kernel, dim3(nw), dim3(kCtlThreads), 0, st, A, dw, ds, nw);
     LLD_HIP_TRY(hipEventRecord(G.ev[1], st));
     if (G.max_items_pt > 0) hipLaunchKernelGGL(ba_schur_items_kernel<3>, dim3(G.max_items_pt, nw), dim3(64), B->schur_lds[0], st, A, dw, ds);
     if (G.max_items_ln > 0) hipLaunchKernelGGL(ba_schur_items_kernel<4>, dim3(G.max_items_ln, nw), dim3(64), B->schur_lds[1], st, A, dw, ds);
@@ -420,7 +422,7 @@ int lld_ba_batch_solve(lld_ba_batch* B, volatile const int* abort_flag) {
     if (B->params.reduced_solver == 1)
       hipLaunchKernelGGL(ba_pcg_kernel, dim3(nw), dim3(kPcgThreads), pcg_lds, st, A, dw, ds, B->params.pcg_rel_tol, B->params.pcg_max_iter);
     else
-      hipLaunchKernelGGL(ba_chol_kernel, dim3(nw), dim3(kPcgThreads), chol_lds, st, A, dw, ds);
+      hipLaunchKernelGGL(ba_chol_kernel, dim3(nw), dim3(kPcgThreads), chol_lds, st, A, dw, ds, (int)(chol_tri / sizeof(double)));
     LLD_HIP_TRY(hipEventRecord(G.ev[3], st));
     if (G.max_nt_pt > 0) hipLaunchKernelGGL(ba_backsub_pt_kernel, dim3(G.max_nt_pt, nw), dim3(kLmThreads), bs_lds, st, A, dw, ds);
     if (G.max_nb_ln > 0) hipLaunchKernelGGL(ba_backsub_ln_kernel, dim3(G.max_nb_ln, nw), dim3(kLmThreads), 0, st, A, dw, ds);

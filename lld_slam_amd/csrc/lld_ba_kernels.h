@@ -912,27 +912,36 @@ __global__ __launch_bounds__(256) void ba_hpp_reduce_kernel(BAArrays A, const BA
 }
 
 // LM iteration head (one lane per window): chi2 of the current state, lambda initialisation at iteration 0.
-__global__ void ba_begin_kernel(BAArrays A, const BAWin* __restrict__ wins, BAState* __restrict__ st, int n_windows) {
-  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(kCtlThreads) void ba_begin_kernel(BAArrays A, const BAWin* __restrict__ wins, BAState* __restrict__ st, int n_windows) {
+  const int w = blockIdx.x;                 // one wavefront per window
   if (w >= n_windows) return;
   const BAWin& W = wins[w];
   BAState& S = st[w];
   if (S.phase != PH_RUN || !S.need_lin) return;
+  const int lane = threadIdx.x;
+  // chi2 of the current state: lanes sum interleaved partials, then a fixed shuffle tree (deterministic)
   double chi = 0.0;
   const int nb = W.nl_pt + W.nl_ln;
-  for (int i = 0; i < nb; i++) chi += A.chi_part[W.part_off + i];
-  S.currentChi = chi; S.iniChi = chi;
+  for (int i = lane; i < nb; i += kCtlThreads) chi += A.chi_part[W.part_off + i];
+  chi = wave_sum(chi);
+  double md = 0.0;
   if (S.it == 0) {
     // computeLambdaInit: tau * max |H_kk| over cameras and landmarks (optimization_algorithm_levenberg.cpp:166-180)
-    double md = __longlong_as_double((long long)S.maxdiag_bits);
     const double* H = A.Hpp + (size_t)W.hpp_off * 21;
-    for (int c = 0; c < W.n_free; c++) {
+    for (int c = lane; c < W.n_free; c += kCtlThreads) {
       const double* h = H + c * 21;
       md = fmax(md, fmax(fmax(fabs(h[0]), fabs(h[6])), fmax(fmax(fabs(h[11]), fabs(h[15])), fmax(fabs(h[18]), fabs(h[20])))));
     }
-    S.lambda = 1e-5 * md; S.ni = 2.0; S.nBad = 0;
+    md = wave_max(md);
   }
-  S.q = 0; S.need_lin = 0;
+  if (lane == 0) {
+    S.currentChi = chi; S.iniChi = chi;
+    if (S.it == 0) {
+      md = fmax(md, __longlong_as_double((long long)S.maxdiag_bits));
+      S.lambda = 1e-5 * md; S.ni = 2.0; S.nBad = 0;
+    }
+    S.q = 0; S.need_lin = 0;
+  }
 }
 
 // ================================================================== Schur complement
@@ -1298,13 +1307,13 @@ __global__ __launch_bounds__(kPcgThreads) void ba_pcg_kernel(BAArrays A, const B
 }
 
 // ================================================================== exact solve of the reduced camera system
-// grid (nW); block kPcgThreads; dynamic LDS: (2*nf*36 + 2*n + 32) doubles.
+// grid (nW); block kPcgThreads; dynamic LDS: (2*nf*36 + 2*n + 32 + lds_tri_doubles) doubles.
 // Right-looking block Cholesky (6x6 camera blocks) in place on the LOWER block triangle of S, the right-hand side carried
 // along as an extra block row (forward substitution for free), then block back-substitution.  This is the counterpart of
 // the reference's exact factorisation (Eigen::SimplicialLDLT, solvers/linear_solver_eigen.h:94-124): S is read once from
 // HBM instead of once per PCG iteration, and the result does not depend on an iteration tolerance.  A non-positive pivot
 // reports failure, which Levenberg–Marquardt turns into a rejected trial (optimization_algorithm_levenberg.cpp:126-127).
-__global__ __launch_bounds__(kPcgThreads) void ba_chol_kernel(BAArrays A, const BAWin* __restrict__ wins, BAState* __restrict__ st) {
+__global__ __launch_bounds__(kPcgThreads) void ba_chol_kernel(BAArrays A, const BAWin* __restrict__ wins, BAState* __restrict__ st, int lds_tri_doubles) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const BAWin W = wins[blockIdx.x];
   BAState& S = st[blockIdx.x];
@@ -1316,16 +1325,36 @@ __global__ __launch_bounds__(kPcgThreads) void ba_chol_kernel(BAArrays A, const 
   double* x = y + n;                     // [n] solution
   double* scratch = x + n;               // [32]
   double* okf = scratch + 31;
+  double* tri = scratch + 32;            // LDS-resident trailing block triangle (cameras >= m0), 36 doubles per block
   double* Sg = A.S + W.S_off;
   const int tid = threadIdx.x;
+  // largest trailing triangle that fits: blocks (i, j), i >= j >= m0, live in LDS for the whole factorisation, so their
+  // read-modify-write updates never wait for HBM/L2; only the first m0 block columns are updated in global memory
+  int mt = 0;
+  while (mt < nf && (mt + 1) * (mt + 2) / 2 * 36 <= lds_tri_doubles) mt++;
+  const int m0 = nf - mt;
+  auto tri_blk = [&](int i, int j) { const int ii = i - m0, jj = j - m0; return tri + (size_t)(ii * (ii + 1) / 2 + jj) * 36; };
   if (tid == 0) *okf = 1.0;
   if (tid < n) y[tid] = A.bschur[W.x_off + tid];
+  for (int t = tid; t < mt * (mt + 1) / 2 * 6; t += kPcgThreads) {        // lane <-> one row of one block
+    const int blk = t / 6, r = t - blk * 6;
+    int ii = (int)((sqrt(8.0 * blk + 1.0) - 1.0) * 0.5);
+    while ((ii + 1) * (ii + 2) / 2 <= blk) ii++;
+    while (ii * (ii + 1) / 2 > blk) ii--;
+    const int jj = blk - ii * (ii + 1) / 2;
+    const double* src = Sg + (size_t)(6 * (m0 + ii) + r) * n + 6 * (m0 + jj);
+    double* dst = tri + (size_t)blk * 36 + r * 6;
+#pragma unroll
+    for (int c = 0; c < 6; c++) dst[c] = src[c];
+  }
   __syncthreads();
   for (int k = 0; k < nf; k++) {
+    const bool k_lds = k >= m0;
     // (1) diagonal block: L_kk = chol(A_kk), Linv_kk, y_k = Linv_kk b_k
     if (tid == 0) {
       double a[6][6], L[6][6], Li[6][6];
-      for (int r = 0; r < 6; r++) for (int c = 0; c <= r; c++) a[r][c] = Sg[(size_t)(6 * k + r) * n + 6 * k + c];
+      if (k_lds) { const double* d = tri_blk(k, k); for (int r = 0; r < 6; r++) for (int c = 0; c <= r; c++) a[r][c] = d[r * 6 + c]; }
+      else for (int r = 0; r < 6; r++) for (int c = 0; c <= r; c++) a[r][c] = Sg[(size_t)(6 * k + r) * n + 6 * k + c];
       bool ok = true;
       for (int j = 0; j < 6; j++) {
         double d = a[j][j];
@@ -1348,21 +1377,26 @@ __global__ __launch_bounds__(kPcgThreads) void ba_chol_kernel(BAArrays A, const 
         }
       }
       for (int r = 0; r < 6; r++) for (int c = 0; c < 6; c++) linv[k * 36 + r * 6 + c] = c <= r ? Li[r][c] : 0.0;
-      for (int r = 0; r < 6; r++) for (int c = 0; c <= r; c++) Sg[(size_t)(6 * k + r) * n + 6 * k + c] = L[r][c];
       double yk[6];
       for (int r = 0; r < 6; r++) { double sacc = 0.0; for (int c = 0; c <= r; c++) sacc += Li[r][c] * y[6 * k + c]; yk[r] = sacc; }
       for (int r = 0; r < 6; r++) y[6 * k + r] = yk[r];
       if (!ok) *okf = 0.0;
     }
     __syncthreads();
-    // (2) panel: L_ik = A_ik Linv_kk^T for i > k (lane <-> one row of one block), b_i -= L_ik y_k
+    // (2) panel: L_ik = A_ik Linv_kk^T for i > k (lane <-> one row of one block), b_i -= L_ik y_k.  The back-substitution
+    //     reads L from global memory, so the panel is stored there as well (plain stores, nothing waits for them).
     const int m_rows = (nf - k - 1) * 6;
     for (int t = tid; t < m_rows; t += kPcgThreads) {
       const int i = k + 1 + t / 6, r = t % 6;
-      double* row = Sg + (size_t)(6 * i + r) * n + 6 * k;
+      double* grow = Sg + (size_t)(6 * i + r) * n + 6 * k;
       double arow[6], lrow[6];
+      if (k_lds) { const double* d = tri_blk(i, k) + r * 6;
 #pragma unroll
-      for (int c = 0; c < 6; c++) arow[c] = row[c];
+        for (int c = 0; c < 6; c++) arow[c] = d[c];
+      } else {
+#pragma unroll
+        for (int c = 0; c < 6; c++) arow[c] = grow[c];
+      }
       const double* Li = linv + k * 36;
       double dotv = 0.0;
 #pragma unroll
@@ -1374,7 +1408,7 @@ __global__ __launch_bounds__(kPcgThreads) void ba_chol_kernel(BAArrays A, const 
         dotv += sacc * y[6 * k + c];
       }
 #pragma unroll
-      for (int c = 0; c < 6; c++) { row[c] = lrow[c]; panel[i * 36 + r * 6 + c] = lrow[c]; }
+      for (int c = 0; c < 6; c++) { grow[c] = lrow[c]; panel[i * 36 + r * 6 + c] = lrow[c]; }
       y[6 * i + r] -= dotv;
     }
     __syncthreads();
@@ -1392,9 +1426,11 @@ __global__ __launch_bounds__(kPcgThreads) void ba_chol_kernel(BAArrays A, const 
       double pj[36];
 #pragma unroll
       for (int q = 0; q < 36; q++) pj[q] = Pj[q];
+      const bool in_lds = j >= m0;
+      double* blk = in_lds ? tri_blk(i, j) : nullptr;
 #pragma unroll
       for (int r = 0; r < 6; r++) {
-        double* row = Sg + (size_t)(6 * i + r) * n + 6 * j;
+        double* row = in_lds ? blk + r * 6 : Sg + (size_t)(6 * i + r) * n + 6 * j;
         double pr[6];
 #pragma unroll
         for (int q = 0; q < 6; q++) pr[q] = Pi[r * 6 + q];
@@ -1442,11 +1478,14 @@ __global__ __launch_bounds__(kCtlThreads) void ba_control_kernel(BAArrays A, con
   BAState& S = st[blockIdx.x];
   if (threadIdx.x == 0) do_clear = 0;
   __syncthreads();
-  if (threadIdx.x == 0 && S.phase == PH_RUN) {
+  double tempChi = 0.0, scale_l = 0.0;
+  if (S.phase == PH_RUN) {                           // interleaved partial sums + fixed shuffle tree (deterministic)
     const int nb = W.nt_pt + W.nt_ln;
-    double tempChi = 0.0, scale = S.scale_cam;
-    for (int i = 0; i < nb; i++) tempChi += A.chi_part2[W.part_off + i];
-    for (int i = 0; i < nb; i++) scale += A.scale_part[W.part_off + i];
+    for (int i = threadIdx.x; i < nb; i += kCtlThreads) { tempChi += A.chi_part2[W.part_off + i]; scale_l += A.scale_part[W.part_off + i]; }
+    tempChi = wave_sum(tempChi); scale_l = wave_sum(scale_l);
+  }
+  if (threadIdx.x == 0 && S.phase == PH_RUN) {
+    double scale = S.scale_cam + scale_l;
     if (!S.pcg_ok) tempChi = 1.7976931348623157e308;
     double rho = (S.currentChi - tempChi);
     scale += 1e-3;
