@@ -1,0 +1,106 @@
+// harness.cpp — a C++ caller of liblld_amd.so through include/lld_amd.hpp, the way a patched reference would call it.
+// It reads one problem from a flat binary file (written by tests/test_cpp_harness.py), runs it on GPU 0 and writes the
+// outputs back, so the tests can compare the C++ route with the golden vectors.
+//
+//   harness ba   <in> <out>     Optimizer::LocalBundleAdjustment
+//   harness pose <in> <out>     Optimizer::PoseOptimization
+//   harness orb  <in> <out>     ORBmatcher::BestTwo (brute force)
+//
+// File layout: int32 header (counts), then the arrays in the order they appear in the structs, native endianness.
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "lld_amd.hpp"
+
+namespace {
+
+struct Reader {
+  FILE* f;
+  explicit Reader(const char* path) : f(std::fopen(path, "rb")) { if (!f) throw std::runtime_error(std::string("cannot open ") + path); }
+  ~Reader() { std::fclose(f); }
+  template <class T> void get(T* p, size_t n) { if (n && std::fread(p, sizeof(T), n, f) != n) throw std::runtime_error("short read"); }
+  template <class T> void get(std::vector<T>& v, size_t n) { v.resize(n); get(v.data(), n); }
+};
+struct Writer {
+  FILE* f;
+  explicit Writer(const char* path) : f(std::fopen(path, "wb")) { if (!f) throw std::runtime_error(std::string("cannot open ") + path); }
+  ~Writer() { std::fclose(f); }
+  template <class T> void put(const T* p, size_t n) { if (n && std::fwrite(p, sizeof(T), n, f) != n) throw std::runtime_error("short write"); }
+  template <class T> void put(const std::vector<T>& v) { put(v.data(), v.size()); }
+};
+
+int run_ba(const char* in, const char* out) {
+  Reader r(in);
+  int32_t h[8]; r.get(h, 8);                   // n_cams n_free n_points n_pt_obs n_lines n_ln_obs stop 0
+  double camg[6]; r.get(camg, 6);              // fx fy cx cy bf gamma
+  lld_amd::BAWindow w;
+  w.cam = lld_camera{camg[0], camg[1], camg[2], camg[3], camg[4]};
+  w.n_free_cams = h[1];
+  r.get(w.cam_qt, 7 * (size_t)h[0]);
+  r.get(w.pt_xyz, 3 * (size_t)h[2]); r.get(w.pt_obs_start, (size_t)h[2] + 1); r.get(w.pt_obs_cam, h[3]);
+  r.get(w.pt_obs_uvr, 3 * (size_t)h[3]); r.get(w.pt_obs_inv_sigma2, h[3]);
+  r.get(w.line_x0, 3 * (size_t)h[4]); r.get(w.line_dir, 3 * (size_t)h[4]); r.get(w.ln_obs_start, (size_t)h[4] + 1);
+  r.get(w.ln_obs_cam, h[5]); r.get(w.ln_obs_left, 4 * (size_t)h[5]); r.get(w.ln_obs_right, 4 * (size_t)h[5]);
+  r.get(w.ln_obs_octave, 2 * (size_t)h[5]);
+  lld_amd::Context ctx(0);
+  bool stop = h[6] != 0;
+  const lld_amd::BAOutput o = lld_amd::Optimizer::LocalBundleAdjustment(ctx, w, &stop, camg[5]);
+  Writer wr(out);
+  wr.put(o.cam_qt); wr.put(o.pt_xyz); wr.put(o.line_x0); wr.put(o.line_dir);
+  wr.put(o.pt_obs_outlier); wr.put(o.ln_edge_outlier); wr.put(o.line_removed);
+  const double chi2[2] = {o.stats.chi2_round1, o.stats.chi2_final};
+  wr.put(chi2, 2);
+  const int32_t st[4] = {o.stats.lm_iterations[0], o.stats.lm_iterations[1], o.stats.aborted, o.stats.n_lines_removed};
+  wr.put(st, 4);
+  std::printf("ba: chi2 %.9g -> %.9g, %d+%d LM iterations, %d point / %d line-edge outliers, %d lines removed\n", chi2[0], chi2[1],
+              st[0], st[1], o.stats.n_pt_obs_outlier, o.stats.n_ln_edge_outlier, o.stats.n_lines_removed);
+  return 0;
+}
+
+int run_pose(const char* in, const char* out) {
+  Reader r(in);
+  int32_t h[2]; r.get(h, 2);                   // n_points n_lines
+  double camg[6]; r.get(camg, 6);
+  lld_amd::PoseFrame f;
+  f.cam = lld_camera{camg[0], camg[1], camg[2], camg[3], camg[4]};
+  r.get(f.pose_qt, 7);
+  r.get(f.pt_xw, 3 * (size_t)h[0]); r.get(f.pt_uvr, 3 * (size_t)h[0]); r.get(f.pt_inv_sigma2, h[0]);
+  r.get(f.ln_x0, 3 * (size_t)h[1]); r.get(f.ln_dir, 3 * (size_t)h[1]); r.get(f.ln_left, 4 * (size_t)h[1]);
+  r.get(f.ln_right, 4 * (size_t)h[1]); r.get(f.ln_octave, 2 * (size_t)h[1]);
+  lld_amd::Context ctx(0);
+  const int32_t n_in = lld_amd::Optimizer::PoseOptimization(ctx, f, camg[5]);
+  Writer wr(out);
+  wr.put(f.pose_qt, 7); wr.put(&n_in, 1); wr.put(f.mvbOutlier); wr.put(f.mvbOutlierLines);
+  std::printf("pose: %d inliers\n", n_in);
+  return 0;
+}
+
+int run_orb(const char* in, const char* out) {
+  Reader r(in);
+  int32_t h[2]; r.get(h, 2);                   // nq nt
+  std::vector<uint32_t> q, t; r.get(q, 8 * (size_t)h[0]); r.get(t, 8 * (size_t)h[1]);
+  lld_amd::Context ctx(0);
+  lld_amd::ORBmatcher m(ctx, 0.6f, true);
+  const lld_amd::ORBmatcher::Best2 b = m.BestTwo(q.data(), h[0], t.data(), h[1]);
+  Writer wr(out);
+  wr.put(b.best_idx); wr.put(b.best_dist); wr.put(b.second_idx); wr.put(b.second_dist);
+  std::printf("orb: %d x %d\n", h[0], h[1]);
+  return 0;
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+  if (argc != 4) { std::fprintf(stderr, "usage: harness ba|pose|orb <in> <out>\n"); return 2; }
+  try {
+    if (!std::strcmp(argv[1], "ba")) return run_ba(argv[2], argv[3]);
+    if (!std::strcmp(argv[1], "pose")) return run_pose(argv[2], argv[3]);
+    if (!std::strcmp(argv[1], "orb")) return run_orb(argv[2], argv[3]);
+    std::fprintf(stderr, "unknown mode %s\n", argv[1]);
+    return 2;
+  } catch (const std::exception& e) {
+    std::fprintf(stderr, "harness: %s\n", e.what());   // e.g. "lld_ctx_create: no HIP device (this library has no CPU fallback)"
+    return 1;
+  }
+}

@@ -1,0 +1,153 @@
+// lld_amd.hpp — header-only C++ host layer over the C ABI (include/lld_amd.h).
+//
+// The reference's hot path is entered through C++ static/member functions on live SLAM objects
+// (include/Optimizer.h:49-50, include/ORBmatcher.h:41-83, include/TwoFrameLineMatcher.h:31-42).  This header mirrors those
+// names and argument meanings on flat, owning containers, so the adapter in INTEGRATION.md shrinks to "fill the vectors,
+// call, scatter".  It needs nothing but the C++11 standard library and liblld_amd.so.
+#ifndef LLD_AMD_HPP
+#define LLD_AMD_HPP
+
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "lld_amd.h"
+
+namespace lld_amd {
+
+inline void check(int status, const char* what) {
+  if (status != LLD_OK) throw std::runtime_error(std::string(what) + ": " + lld_status_string(status));
+}
+
+// One per host thread (Tracking, LocalMapping): a HIP device + stream.  Throws when no GPU is present — there is no CPU fallback.
+class Context {
+ public:
+  explicit Context(int device = 0) { check(lld_ctx_create(device, &h_), "lld_ctx_create"); }
+  ~Context() { lld_ctx_destroy(h_); }
+  Context(const Context&) = delete;
+  Context& operator=(const Context&) = delete;
+  lld_ctx* get() const { return h_; }
+ private:
+  lld_ctx* h_ = nullptr;
+};
+
+// Flat local-BA window (what Optimizer.cc:938-1218 gathers); see lld_ba_window for the meaning of every array.
+struct BAWindow {
+  lld_camera cam{};
+  int n_free_cams = 0;
+  std::vector<double> cam_qt, pt_xyz, pt_obs_uvr, pt_obs_inv_sigma2, line_x0, line_dir, ln_obs_left, ln_obs_right;
+  std::vector<int32_t> pt_obs_start{0}, pt_obs_cam, ln_obs_start{0}, ln_obs_cam, ln_obs_octave;
+  int n_cams() const { return (int)(cam_qt.size() / 7); }
+  int n_points() const { return (int)(pt_xyz.size() / 3); }
+  int n_lines() const { return (int)(line_x0.size() / 3); }
+  lld_ba_window view() const {
+    lld_ba_window w{};
+    w.cam = cam; w.n_cams = n_cams(); w.n_free_cams = n_free_cams; w.cam_qt = cam_qt.data();
+    w.n_points = n_points(); w.pt_xyz = pt_xyz.data(); w.pt_obs_start = pt_obs_start.data();
+    w.n_pt_obs = (int)pt_obs_cam.size(); w.pt_obs_cam = pt_obs_cam.data(); w.pt_obs_uvr = pt_obs_uvr.data();
+    w.pt_obs_inv_sigma2 = pt_obs_inv_sigma2.data();
+    w.n_lines = n_lines(); w.line_x0 = line_x0.data(); w.line_dir = line_dir.data(); w.ln_obs_start = ln_obs_start.data();
+    w.n_ln_obs = (int)ln_obs_cam.size(); w.ln_obs_cam = ln_obs_cam.data(); w.ln_obs_left = ln_obs_left.data();
+    w.ln_obs_right = ln_obs_right.data(); w.ln_obs_octave = ln_obs_octave.data();
+    return w;
+  }
+};
+
+struct BAOutput {
+  std::vector<double> cam_qt, pt_xyz, line_x0, line_dir;
+  std::vector<uint8_t> pt_obs_outlier, ln_edge_outlier, line_removed;   // vToErase / GetLineData outliers / deleted lines
+  lld_ba_stats stats{};
+};
+
+struct PoseFrame {
+  lld_camera cam{};
+  double pose_qt[7] = {0, 0, 0, 1, 0, 0, 0};
+  std::vector<double> pt_xw, pt_uvr, pt_inv_sigma2, ln_x0, ln_dir, ln_left, ln_right;
+  std::vector<int32_t> ln_octave;
+  std::vector<uint8_t> mvbOutlier, mvbOutlierLines;   // filled by PoseOptimization
+};
+
+// Mirror of the reference's `class Optimizer` (include/Optimizer.h:43-61), hot-path members only.
+class Optimizer {
+ public:
+  // void static LocalBundleAdjustment(KeyFrame* pKF, bool* pbStopFlag, Map* pMap, double gamma = 1.0)
+  static BAOutput LocalBundleAdjustment(Context& ctx, const BAWindow& win, const bool* pbStopFlag = nullptr, double gamma = 1.0) {
+    const lld_ba_window w = win.view();
+    lld_ba_params p; lld_ba_params_default(&p); p.gamma = gamma;
+    BAOutput o;
+    o.cam_qt.resize(7 * (size_t)w.n_cams); o.pt_xyz.resize(3 * (size_t)w.n_points);
+    o.line_x0.resize(3 * (size_t)w.n_lines); o.line_dir.resize(3 * (size_t)w.n_lines);
+    o.pt_obs_outlier.resize(w.n_pt_obs); o.ln_edge_outlier.resize(2 * (size_t)w.n_ln_obs); o.line_removed.resize(w.n_lines);
+    lld_ba_result r{};
+    r.cam_qt = o.cam_qt.data(); r.pt_xyz = o.pt_xyz.data(); r.line_x0 = o.line_x0.data(); r.line_dir = o.line_dir.data();
+    r.pt_obs_outlier = o.pt_obs_outlier.data(); r.ln_edge_outlier = o.ln_edge_outlier.data(); r.line_removed = o.line_removed.data();
+    volatile int stop = (pbStopFlag && *pbStopFlag) ? 1 : 0;      // a live caller refreshes this from its bool
+    check(lld_local_ba(ctx.get(), &w, &p, &stop, &r), "lld_local_ba");
+    o.stats = r.stats;
+    return o;
+  }
+  // int static PoseOptimization(Frame* pFrame, double gamma = 1.0): returns the inlier count, writes the pose and the flags
+  static int PoseOptimization(Context& ctx, PoseFrame& f, double gamma = 1.0) {
+    lld_pose_problem q{};
+    q.cam = f.cam;
+    for (int i = 0; i < 7; i++) q.pose_qt[i] = f.pose_qt[i];
+    q.n_points = (int)(f.pt_xw.size() / 3); q.pt_xw = f.pt_xw.data(); q.pt_uvr = f.pt_uvr.data(); q.pt_inv_sigma2 = f.pt_inv_sigma2.data();
+    q.n_lines = (int)(f.ln_x0.size() / 3); q.ln_x0 = f.ln_x0.data(); q.ln_dir = f.ln_dir.data(); q.ln_left = f.ln_left.data();
+    q.ln_right = f.ln_right.data(); q.ln_octave = f.ln_octave.data();
+    lld_pose_params p; lld_pose_params_default(&p); p.gamma = gamma;
+    f.mvbOutlier.assign(q.n_points, 0); f.mvbOutlierLines.assign(q.n_lines, 0);
+    lld_pose_result r{};
+    r.pt_outlier = f.mvbOutlier.data(); r.ln_outlier = f.mvbOutlierLines.data();
+    check(lld_pose_opt(ctx.get(), &q, &p, &r), "lld_pose_opt");
+    for (int i = 0; i < 7; i++) f.pose_qt[i] = r.pose_qt[i];
+    return r.n_inliers;
+  }
+};
+
+// Mirror of `class ORBmatcher` (include/ORBmatcher.h:41-83): the distance + best/second-best core; the accept rules
+// (TH_LOW / TH_HIGH / mfNNratio) stay with the caller as in the reference.
+class ORBmatcher {
+ public:
+  static constexpr int TH_LOW = 50, TH_HIGH = 100, HISTO_LENGTH = 30;     // src/ORBmatcher.cc:37-39
+  ORBmatcher(Context& ctx, float nnratio = 0.6f, bool checkOri = true) : ctx_(ctx), mfNNratio(nnratio), mbCheckOrientation(checkOri) {}
+  struct Best2 { std::vector<int32_t> best_idx, best_dist, second_idx, second_dist; };
+  // descriptors: nq x 8 / nt x 8 uint32 rows (cv::Mat CV_8U 32 bytes per row); mask: nq x nt bytes or empty
+  Best2 BestTwo(const uint32_t* q, int nq, const uint32_t* t, int nt, const std::vector<uint8_t>& mask = {}) const {
+    Best2 b; b.best_idx.resize(nq); b.best_dist.resize(nq); b.second_idx.resize(nq); b.second_dist.resize(nq);
+    check(lld_match_hamming256(ctx_.get(), q, nq, t, nt, mask.empty() ? nullptr : mask.data(), b.best_idx.data(), b.best_dist.data(),
+                               b.second_idx.data(), b.second_dist.data()), "lld_match_hamming256");
+    return b;
+  }
+  // candidate lists in the reference's own order (Frame::GetFeaturesInArea, BoW nodes)
+  Best2 BestTwo(const uint32_t* q, int nq, const uint32_t* t, int nt, const std::vector<int32_t>& cand_start, const std::vector<int32_t>& cand_idx) const {
+    Best2 b; b.best_idx.resize(nq); b.best_dist.resize(nq); b.second_idx.resize(nq); b.second_dist.resize(nq);
+    static const int32_t none = 0;
+    check(lld_match_hamming256_csr(ctx_.get(), q, nq, t, nt, cand_start.data(), cand_idx.empty() ? &none : cand_idx.data(), b.best_idx.data(),
+                                   b.best_dist.data(), b.second_idx.data(), b.second_dist.data()), "lld_match_hamming256_csr");
+    return b;
+  }
+ private:
+  Context& ctx_;
+ public:
+  float mfNNratio; bool mbCheckOrientation;
+};
+
+// Mirror of `class TwoFrameLineMatcher` (include/TwoFrameLineMatcher.h:31-42): the caller supplies CheckLinePair's geometric
+// gates as a byte matrix; the descriptor distance, the running strict minimum under tau and the greedy masking run on the GPU.
+class TwoFrameLineMatcher {
+ public:
+  TwoFrameLineMatcher(Context& ctx, double tau) : ctx_(ctx), tau_(tau) {}
+  void MatchLines(const float* descsLeft, int nLeft, const float* descsRight, int nRight, int dim, const std::vector<uint8_t>& gate,
+                  std::vector<int>* desc_matches) const {
+    desc_matches->assign(nLeft, -1);
+    check(lld_line_match_greedy(ctx_.get(), descsLeft, nLeft, descsRight, nRight, dim, gate.empty() ? nullptr : gate.data(), tau_,
+                                desc_matches->data(), nullptr), "lld_line_match_greedy");
+  }
+ private:
+  Context& ctx_;
+  double tau_;
+};
+
+}  // namespace lld_amd
+#endif

@@ -18,7 +18,6 @@ struct lld_ba_batch {
   lld_ba_params params;
   std::vector<BAWin> h_wins;
   std::vector<SChunk> h_chunks; std::vector<PTask> h_ptasks, h_ltasks;
-  std::vector<const lld_ba_window*> unused;
   void* slab = nullptr; size_t slab_bytes = 0;
   BAArrays A;
   BAWin* d_wins = nullptr; BAState* d_state = nullptr;
@@ -40,13 +39,6 @@ struct lld_ba_batch {
 };
 
 namespace {
-
-template <class T>
-T* upload(lld_slab& sl, const std::vector<T>& h, size_t count, hipStream_t st) {
-  T* d = sl.take<T>(count);
-  if (!h.empty()) (void)hipMemcpyAsync(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, st);
-  return d;
-}
 
 int validate_window(const lld_ba_window& w) {
   if (w.n_cams <= 0 || w.n_free_cams < 0 || w.n_free_cams > w.n_cams || w.n_points < 0 || w.n_lines < 0 || w.n_pt_obs < 0 || w.n_ln_obs < 0)

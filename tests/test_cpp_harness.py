@@ -1,0 +1,125 @@
+"""The C++ route: examples/harness.cpp calls liblld_amd.so through include/lld_amd.hpp (the header a patched reference would
+include, mirroring include/Optimizer.h:49-50 / ORBmatcher.h / TwoFrameLineMatcher.h) and must reproduce the golden vectors."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+HARNESS = os.path.join(ROOT, "examples", "harness")
+
+BA_ARRAYS = (("cam_qt", np.float64), ("pt_xyz", np.float64), ("pt_obs_start", np.int32), ("pt_obs_cam", np.int32),
+             ("pt_obs_uvr", np.float64), ("pt_obs_inv_sigma2", np.float64), ("line_x0", np.float64), ("line_dir", np.float64),
+             ("ln_obs_start", np.int32), ("ln_obs_cam", np.int32), ("ln_obs_left", np.float64), ("ln_obs_right", np.float64),
+             ("ln_obs_octave", np.int32))
+POSE_ARRAYS = (("pose_qt", np.float64), ("pt_xw", np.float64), ("pt_uvr", np.float64), ("pt_inv_sigma2", np.float64),
+               ("ln_x0", np.float64), ("ln_dir", np.float64), ("ln_left", np.float64), ("ln_right", np.float64), ("ln_octave", np.int32))
+
+
+@pytest.fixture(scope="module")
+def harness():
+    if not os.path.exists(os.path.join(ROOT, "lld_slam_amd", "csrc", "liblld_amd.so")):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "lld_slam_amd", "csrc")], check=True, capture_output=True)
+    subprocess.run(["make", "-C", os.path.join(ROOT, "examples")], check=True, capture_output=True)
+    assert os.path.exists(HARNESS)
+    return HARNESS
+
+
+def run(harness, mode, tmp_path):
+    return subprocess.run([harness, mode, str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True, timeout=300)
+
+
+def write_ba(path, d, stop=0):
+    dims = (d["cam_qt"].shape[0], d["pt_xyz"].shape[0], d["pt_obs_cam"].shape[0], d["line_x0"].shape[0], d["ln_obs_cam"].shape[0])
+    with open(path, "wb") as f:
+        np.array([dims[0], int(d["n_free_cams"]), dims[1], dims[2], dims[3], dims[4], stop, 0], np.int32).tofile(f)
+        np.concatenate([d["cam"], [float(d["gamma"])]]).astype(np.float64).tofile(f)
+        for k, t in BA_ARRAYS:
+            np.ascontiguousarray(d[k], t).tofile(f)
+    return dims
+
+
+def read_ba(path, n_cams, n_pts, n_po, n_ln, n_lo):
+    with open(path, "rb") as f:
+        return {"cam_qt": np.fromfile(f, np.float64, 7 * n_cams).reshape(-1, 7), "pt_xyz": np.fromfile(f, np.float64, 3 * n_pts).reshape(-1, 3),
+                "line_x0": np.fromfile(f, np.float64, 3 * n_ln).reshape(-1, 3), "line_dir": np.fromfile(f, np.float64, 3 * n_ln).reshape(-1, 3),
+                "pt_obs_outlier": np.fromfile(f, np.uint8, n_po), "ln_edge_outlier": np.fromfile(f, np.uint8, 2 * n_lo).reshape(-1, 2),
+                "line_removed": np.fromfile(f, np.uint8, n_ln), "chi2": np.fromfile(f, np.float64, 2), "st": np.fromfile(f, np.int32, 4)}
+
+
+def test_harness_builds_and_refuses_without_gpu(harness, tmp_path):
+    """CPU: the C++ layer compiles with plain g++ -std=c++11 and, with no device, fails loudly (no CPU fallback)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    write_ba(tmp_path / "in.bin", np.load(os.path.join(GOLD, "lba_small.npz")))
+    r = run(harness, "ba", tmp_path)
+    assert r.returncode == 1
+    assert "no HIP device" in r.stderr
+
+
+@pytest.mark.gpu
+def test_harness_local_ba_golden(harness, tmp_path):
+    d = np.load(os.path.join(GOLD, "lba_small.npz"))
+    dims = write_ba(tmp_path / "in.bin", d)
+    r = run(harness, "ba", tmp_path)
+    assert r.returncode == 0, r.stderr
+    o = read_ba(tmp_path / "out.bin", *dims)
+    rtol = 1e-5     # north_star tolerance
+    assert abs(o["chi2"][0] - float(d["out_chi2_round1"])) <= rtol * float(d["out_chi2_round1"])
+    assert abs(o["chi2"][1] - float(d["out_chi2_final"])) <= rtol * float(d["out_chi2_final"])
+    assert np.array_equal(o["pt_obs_outlier"], d["out_pt_obs_outlier"])
+    assert np.array_equal(o["ln_edge_outlier"], d["out_ln_edge_outlier"])
+    assert np.array_equal(o["line_removed"], d["out_line_removed"])
+    assert np.max(np.abs(o["cam_qt"] - d["out_cam_qt"])) <= rtol * np.max(np.abs(d["out_cam_qt"]))
+    err = np.linalg.norm(o["pt_xyz"] - d["out_pt_xyz"], axis=1) / np.linalg.norm(d["out_pt_xyz"], axis=1)
+    assert np.median(err) <= rtol and err.max() <= 10 * rtol
+
+
+@pytest.mark.gpu
+def test_harness_abort_at_start_leaves_window_untouched(harness, tmp_path):
+    """pbStopFlag already set: Optimizer.cc:1220-1222 returns before optimize(); nothing moves, nothing is flagged."""
+    d = np.load(os.path.join(GOLD, "lba_small.npz"))
+    dims = write_ba(tmp_path / "in.bin", d, stop=1)
+    r = run(harness, "ba", tmp_path)
+    assert r.returncode == 0, r.stderr
+    o = read_ba(tmp_path / "out.bin", *dims)
+    assert o["st"][2] == 1 and o["st"][0] == 0
+    assert np.array_equal(o["pt_xyz"], d["pt_xyz"])
+    assert not o["pt_obs_outlier"].any() and not o["ln_edge_outlier"].any() and not o["line_removed"].any()
+
+
+@pytest.mark.gpu
+def test_harness_pose_golden(harness, tmp_path):
+    d = np.load(os.path.join(GOLD, "pose_small.npz"))
+    n_pts, n_ln = d["pt_xw"].shape[0], d["ln_x0"].shape[0]
+    with open(tmp_path / "in.bin", "wb") as f:
+        np.array([n_pts, n_ln], np.int32).tofile(f)
+        np.concatenate([d["cam"], [float(d["gamma"])]]).astype(np.float64).tofile(f)
+        for k, t in POSE_ARRAYS:
+            np.ascontiguousarray(d[k], t).tofile(f)
+    r = run(harness, "pose", tmp_path)
+    assert r.returncode == 0, r.stderr
+    with open(tmp_path / "out.bin", "rb") as f:
+        qt = np.fromfile(f, np.float64, 7)
+        n_in = np.fromfile(f, np.int32, 1)[0]
+        po, lo = np.fromfile(f, np.uint8, n_pts), np.fromfile(f, np.uint8, n_ln)
+    assert n_in == int(d["out_n_inliers"])
+    assert np.array_equal(po, d["out_pt_outlier"]) and np.array_equal(lo, d["out_ln_outlier"])
+    assert np.max(np.abs(qt - d["out_pose_qt"])) <= 1e-5 * np.max(np.abs(d["out_pose_qt"]))
+
+
+@pytest.mark.gpu
+def test_harness_orb_golden(harness, tmp_path):
+    d = np.load(os.path.join(GOLD, "match_orb.npz"))
+    with open(tmp_path / "in.bin", "wb") as f:
+        np.array([d["q"].shape[0], d["t"].shape[0]], np.int32).tofile(f)
+        np.ascontiguousarray(d["q"], np.uint32).tofile(f)
+        np.ascontiguousarray(d["t"], np.uint32).tofile(f)
+    r = run(harness, "orb", tmp_path)
+    assert r.returncode == 0, r.stderr
+    out = np.fromfile(tmp_path / "out.bin", np.int32).reshape(4, -1)
+    for got, key in zip(out, ("best_idx", "best_dist", "second_idx", "second_dist")):
+        assert np.array_equal(got, d[key]), key
