@@ -275,6 +275,115 @@ int lld_line_match_greedy(lld_ctx* ctx, const float* desc_left, int nq, const fl
                           int nt, int dim, const uint8_t* gate /*[nq][nt]*/, double tau,
                           int32_t* matches /*[nq]*/, double* match_dist /*[nq] or NULL*/);
 
+/* ================================================================== guided ORB search
+ * lld_orb_search: the complete body of one ORBmatcher::Search* / Fuse / ComputeStereoMatches
+ * routine for one (query set, keypoint set) pair: candidate generation ON THE DEVICE, the
+ * per-candidate skip rules, DescriptorDistance, best / second-best, the accept rules, the
+ * order-dependent "keypoint already taken" rule and the rotation-histogram filter
+ * (SURVEY Appendix B).  The caller (the reference-side adapter) supplies what the reference
+ * computes per query BEFORE its inner loop - projected position, window radius, predicted
+ * level range, predicted right coordinate - and per keypoint the frame's own vectors.
+ *
+ * Candidate sets (lld_orb_search.candidates), always visited in the reference's order, which
+ * decides ties (strict '<': the first candidate in order wins, unless tie_last):
+ *   LLD_ORB_CAND_ALL   every keypoint, index order.
+ *   LLD_ORB_CAND_GRID  Frame::GetFeaturesInArea (src/Frame.cc:391-444) / KeyFrame::
+ *                      GetFeaturesInArea (src/KeyFrame.cc:592-631) over the 64x48 grid built
+ *                      by Frame::AssignFeaturesToGrid + PosInGrid (:294-313, :446-456): cells
+ *                      ix in [nMinCellX,nMaxCellX] outer, iy inner, keypoints of a cell in index
+ *                      order; |dx|<r && |dy|<r; keypoints whose cell falls outside the grid are
+ *                      never candidates.  All in float, as the reference.
+ *   LLD_ORB_CAND_CSR   explicit lists: query q visits cand_idx[cand_range[q][0] .. cand_range[q][1]) in that order;
+ *                      ranges may be shared between queries (all keypoints of one BoW node search the same
+ *                      node list of the other frame: src/ORBmatcher.cc:185-187,561,700).
+ *   LLD_ORB_CAND_ROWS  Frame::ComputeStereoMatches (src/Frame.cc:541-613): right keypoint iR is a
+ *                      candidate of left keypoint iL iff (int)vL lies in [floor(yR-r), ceil(yR+r)],
+ *                      r = 2*scale[octave_R]; index order; uR in [uL-disp_max, uL-disp_min];
+ *                      a query with uL-disp_min < 0 is skipped (:577-578).
+ * Gates (lld_orb_search.gates, OR of LLD_ORB_GATE_*), each skips a candidate:
+ *   LEVEL    octave < q_level_min || (q_level_max >= 0 && octave > q_level_max)
+ *   STEREO   t_uright > 0 && fabs(q_uright - t_uright) > q_stereo_radius   (ORBmatcher.cc:90-95,1400-1406)
+ *   CHI2     Fuse's reprojection gate (ORBmatcher.cc:912-936): stereo keypoints (t_uright>=0)
+ *            e2*invSigma2[octave] > 7.8, others > 5.99, e = (q_uv - t_xy [, q_uright - t_uright])
+ *   EPIPOLAR SearchForTriangulation (ORBmatcher.cc:720-751): only_stereo filter; epipole distance
+ *            when neither side is stereo; CheckDistEpipolarLine (:138-157) with the query's line
+ *   t_occupied[k] != 0 always skips; with `sequential` a keypoint taken by an accepted EARLIER
+ *   query whose q_blocks flag is set is skipped too (the reference writes mvpMapPoints /
+ *   vpMatched / vbMatched2 inside its loop).  The device reaches the sequential answer by
+ *   fixed-point rounds over all queries and reports the number of rounds.
+ * Accept: best <= accept_max, then ratio_mode 0 none | 1 (float)best < nn*(float)second
+ * (:226-228) | 2 reject iff level(best)==level(second) && best > nn*second (:118-121).
+ * check_orientation: 30-bin histogram of q_angle - t_angle, factor 1/30, ComputeThreeMaxima
+ * (:1601-1642); matches outside the three kept bins are flagged `removed`.
+ * Outputs (host arrays): match[nq] accepted keypoint or -1 (before the orientation filter);
+ * removed[nq]; best/second distances (256 = none); owner[nt] = the query that holds keypoint k at
+ * the end of the routine (last accepted writer; -1 if none or if any writer was removed by the
+ * orientation filter - the reference NULLs the slot, :1452-1460); n_matches = the routine's
+ * return value. */
+enum { LLD_ORB_CAND_ALL = 0, LLD_ORB_CAND_GRID = 1, LLD_ORB_CAND_CSR = 2, LLD_ORB_CAND_ROWS = 3 };
+enum { LLD_ORB_GATE_LEVEL = 1, LLD_ORB_GATE_STEREO = 2, LLD_ORB_GATE_CHI2 = 4, LLD_ORB_GATE_EPIPOLAR = 8 };
+#define LLD_ORB_MAX_KEYPOINTS 4096
+#define LLD_ORB_MAX_LEVELS 16
+
+typedef struct {
+  /* keypoints searched (Frame / KeyFrame; the right image for ROWS) */
+  int32_t nt;
+  const uint32_t* t_desc;       /* [nt][8]                                                       */
+  const float*    t_xy;         /* [nt][2] mvKeysUn[k].pt (ROWS: mvKeysRight[k].pt)              */
+  const int32_t*  t_octave;     /* [nt]                                                          */
+  const float*    t_uright;     /* [nt] mvuRight; NULL = all -1                                  */
+  const float*    t_angle;      /* [nt] degrees; needed with check_orientation                   */
+  const uint8_t*  t_occupied;   /* [nt] or NULL                                                  */
+  /* queries, in the order the reference's outer loop visits them */
+  int32_t nq;
+  const uint32_t* q_desc;       /* [nq][8]                                                       */
+  const uint8_t*  q_valid;      /* [nq] or NULL; 0 = the reference `continue`s before the search */
+  const uint8_t*  q_blocks;     /* [nq] or NULL (= all 1); see `sequential`                      */
+  const float*    q_uv;         /* [nq][2] GRID: window centre; ROWS: left keypoint; CHI2: projection */
+  const float*    q_radius;     /* [nq]    GRID                                                  */
+  const int32_t*  q_level_min;  /* [nq]    LEVEL                                                 */
+  const int32_t*  q_level_max;  /* [nq]    LEVEL                                                 */
+  const float*    q_uright;     /* [nq]    STEREO / CHI2                                         */
+  const float*    q_stereo_radius; /* [nq] STEREO                                                */
+  const float*    q_angle;      /* [nq]    check_orientation                                     */
+  const float*    q_epiline;    /* [nq][3] EPIPOLAR: a,b,c of x1'F12 (ORBmatcher.cc:141-143)     */
+  const uint8_t*  q_stereo;     /* [nq]    EPIPOLAR: bStereo1                                    */
+  const int32_t*  cand_range;   /* [nq][2] CSR: begin, end into cand_idx                         */
+  const int32_t*  cand_idx;     /* [n_cand] CSR                                                  */
+  int32_t         n_cand;
+  /* frame constants */
+  float grid_min_x, grid_min_y, grid_width_inv, grid_height_inv;   /* mnMinX, mnMinY, mfGridElement*Inv */
+  int32_t grid_cols, grid_rows;                                    /* 64, 48 (Frame.h:43-44)     */
+  int32_t n_levels;
+  const float* level_scale;       /* [n_levels] mvScaleFactors     (ROWS, EPIPOLAR)              */
+  const float* level_sigma2;      /* [n_levels] mvLevelSigma2      (EPIPOLAR)                    */
+  const float* level_inv_sigma2;  /* [n_levels] mvInvLevelSigma2   (CHI2)                        */
+  float disp_min, disp_max;       /* ROWS: minD, maxD (Frame.cc:558-560)                         */
+  float epipole_x, epipole_y;     /* EPIPOLAR (ORBmatcher.cc:669-671)                            */
+  int32_t only_stereo;            /* EPIPOLAR: bOnlyStereo                                       */
+  /* rules */
+  int32_t candidates;             /* LLD_ORB_CAND_*                                              */
+  int32_t gates;                  /* OR of LLD_ORB_GATE_*                                        */
+  int32_t tie_last;               /* 1: `dist>bestDist -> skip`, later equal distance replaces (ORBmatcher.cc:733) */
+  int32_t accept_max;             /* accept iff best <= accept_max                               */
+  int32_t ratio_mode;
+  float   nnratio;                /* mfNNratio                                                   */
+  int32_t sequential;
+  int32_t check_orientation;
+} lld_orb_search;
+
+typedef struct {
+  int32_t* match;        /* [nq] */
+  int32_t* best_dist;    /* [nq] */
+  int32_t* second_dist;  /* [nq] */
+  uint8_t* removed;      /* [nq] */
+  int32_t* owner;        /* [nt] or NULL */
+  int32_t  n_matches;
+  int32_t  rounds;       /* fixed-point rounds executed (1 without `sequential`) */
+} lld_orb_search_result;
+
+int lld_orb_search_run(lld_ctx* ctx, const lld_orb_search* s, lld_orb_search_result* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,437 @@
+// lld_orb_search.hip — guided ORB search on the device: one kernel runs the whole body of an ORBmatcher::Search* /
+// Fuse / Frame::ComputeStereoMatches routine (reference lines cited at each rule below).
+//
+// One workgroup owns one (query set, keypoint set) problem, one wavefront owns one query at a time:
+//   * the frame's 64x48 keypoint grid (Frame::AssignFeaturesToGrid, src/Frame.cc:294-313) is rebuilt in LDS by a counting
+//     sort, so a window query touches only the grid columns GetFeaturesInArea (src/Frame.cc:391-444) would visit;
+//   * every candidate gets the 64-bit key  dist<<32 | visit-order ; the wavefront keeps the two smallest keys, which is
+//     exactly the reference's strict-'<' best / second-best bookkeeping (first visited wins ties) without visiting in order;
+//   * the order-dependent rule "keypoint already taken by an earlier query" (the reference writes mvpMapPoints / vpMatched
+//     inside its loop) is solved by fixed-point rounds: round r sees the keypoints claimed in round r-1 by queries with a
+//     smaller index; when a round changes no match the result is the sequential one (query i is final after i+1 rounds at
+//     the latest, in practice 2-4 rounds);
+//   * float gates use explicit round-to-nearest intrinsics so no FMA contraction can change a comparison.
+#include "lld_common.h"
+
+namespace {
+
+constexpr int kThreads = 1024;
+constexpr int kWaves = kThreads / 64;
+constexpr int kHisto = 30;                 // HISTO_LENGTH, src/ORBmatcher.cc:39
+constexpr unsigned long long kNone = ~0ull;
+
+struct TKey {        // one keypoint of the searched frame, LDS resident
+  float x, y, ur;
+  int32_t meta;      // octave [0,4) | index [4,16) | cell+1 [16,29) (0 = outside the grid) | occupied bit 29
+};
+__device__ __forceinline__ int tk_oct(int m) { return m & 15; }
+__device__ __forceinline__ int tk_idx(int m) { return (m >> 4) & 4095; }
+__device__ __forceinline__ int tk_cell(int m) { return ((m >> 16) & 8191) - 1; }
+__device__ __forceinline__ bool tk_occ(int m) { return (m >> 29) & 1; }
+
+struct QRec {        // one query, packed on the host
+  float u, v, radius, ur, stereo_radius, angle;
+  float ea, eb, ec;
+  int32_t level_min, level_max;
+  int32_t flags;     // 1 valid | 2 blocks | 4 stereo (bStereo1)
+  int32_t cs, ce;    // CSR range
+  int32_t pad0, pad1;
+};
+
+struct Problem {
+  int nt, nq;
+  const uint32_t* t_desc; const float* t_xy; const int32_t* t_octave; const float* t_uright; const float* t_angle; const uint8_t* t_occupied;
+  const uint32_t* q_desc; const QRec* q; const int32_t* cand_idx;
+  float min_x, min_y, winv, hinv; int cols, rows;
+  int n_levels; float scale[LLD_ORB_MAX_LEVELS], sigma2[LLD_ORB_MAX_LEVELS], inv_sigma2[LLD_ORB_MAX_LEVELS];
+  float disp_min, disp_max, epi_x, epi_y; int only_stereo;
+  int candidates, gates, tie_last, accept_max, ratio_mode; float nnratio; int sequential, check_orientation;
+  int32_t* match; int32_t* best_dist; int32_t* second_dist; uint8_t* removed; int32_t* owner; int32_t* summary;   // summary: n_matches, rounds
+};
+
+__device__ __forceinline__ int hamming256(const uint32_t (&a)[8], const uint32_t* __restrict__ b) {
+  const uint4 b0 = *reinterpret_cast<const uint4*>(b), b1 = *reinterpret_cast<const uint4*>(b + 4);
+  return __popc(a[0] ^ b0.x) + __popc(a[1] ^ b0.y) + __popc(a[2] ^ b0.z) + __popc(a[3] ^ b0.w) +
+         __popc(a[4] ^ b1.x) + __popc(a[5] ^ b1.y) + __popc(a[6] ^ b1.z) + __popc(a[7] ^ b1.w);
+}
+
+__device__ __forceinline__ void top2_insert(unsigned long long c, unsigned long long& b1, unsigned long long& b2) {
+  if (c < b1) { b2 = b1; b1 = c; } else if (c < b2) { b2 = c; }
+}
+
+__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int m) {
+  const int lo = __shfl_xor((int)(v & 0xffffffffu), m), hi = __shfl_xor((int)(v >> 32), m);
+  return ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
+}
+
+// Per-candidate skip rules that do not depend on how the candidate was produced.
+__device__ __forceinline__ bool gates_pass(const Problem& P, const QRec& Q, const TKey& T, int q, const int* blk) {
+  const int m = T.meta;
+  if (tk_occ(m)) return false;
+  if (P.sequential && blk[tk_idx(m)] < q) return false;
+  const int oct = tk_oct(m);
+  if (P.gates & LLD_ORB_GATE_LEVEL) {                                     // Frame.cc:422-430, ORBmatcher.cc:386,907
+    if (oct < Q.level_min) return false;
+    if (Q.level_max >= 0 && oct > Q.level_max) return false;
+  }
+  if (P.gates & LLD_ORB_GATE_STEREO) {                                    // ORBmatcher.cc:90-95, 1400-1406
+    if (T.ur > 0.f && fabsf(__fsub_rn(Q.ur, T.ur)) > Q.stereo_radius) return false;
+  }
+  if (P.gates & LLD_ORB_GATE_CHI2) {                                      // ORBmatcher.cc:912-936
+    const float ex = __fsub_rn(Q.u, T.x), ey = __fsub_rn(Q.v, T.y);
+    float e2 = __fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey));
+    if (T.ur >= 0.f) {
+      const float er = __fsub_rn(Q.ur, T.ur);
+      e2 = __fadd_rn(e2, __fmul_rn(er, er));
+      if ((double)__fmul_rn(e2, P.inv_sigma2[oct]) > 7.8) return false;
+    } else {
+      if ((double)__fmul_rn(e2, P.inv_sigma2[oct]) > 5.99) return false;
+    }
+  }
+  if (P.gates & LLD_ORB_GATE_EPIPOLAR) {                                  // ORBmatcher.cc:720-751, 138-157
+    const bool s1 = (Q.flags & 4) != 0, s2 = T.ur >= 0.f;
+    if (P.only_stereo && !s2) return false;
+    if (!s1 && !s2) {
+      const float dx = __fsub_rn(P.epi_x, T.x), dy = __fsub_rn(P.epi_y, T.y);
+      if (__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)) < __fmul_rn(100.f, P.scale[oct])) return false;
+    }
+    const float num = __fadd_rn(__fadd_rn(__fmul_rn(Q.ea, T.x), __fmul_rn(Q.eb, T.y)), Q.ec);
+    const float den = __fadd_rn(__fmul_rn(Q.ea, Q.ea), __fmul_rn(Q.eb, Q.eb));
+    if (den == 0.f) return false;
+    const float dsqr = __fdiv_rn(__fmul_rn(num, num), den);
+    if (!((double)dsqr < 3.84 * (double)P.sigma2[oct])) return false;
+  }
+  return true;
+}
+
+__global__ __launch_bounds__(kThreads) void orb_search_kernel(const Problem* __restrict__ problems) {
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  const Problem& P = problems[blockIdx.x];
+  const int nt = P.nt, nq = P.nq, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n_cells = P.cols * P.rows;
+  TKey* tk = reinterpret_cast<TKey*>(lds_raw);                                  // [nt]   (grid mode: sorted by cell)
+  int* blk = reinterpret_cast<int*>(tk + nt);                                   // [nt]   first blocking query per keypoint index
+  int* cell_start = blk + nt;                                                   // [n_cells + 1]
+  int* hist = cell_start + n_cells + 1;                                         // [32]
+  int* ctl = hist + 32;                                                         // [8]: 0 changed, 1 accepted, 2 removed, 3..5 kept bins
+  int* scan = ctl + 8;                                                          // [kThreads]
+
+  // ---------------------------------------------------------------- keypoints into LDS (+ grid counting sort)
+  const bool grid = P.candidates == LLD_ORB_CAND_GRID;
+  int* cursor = scan + kThreads;                                                // [n_cells] (grid mode only)
+  auto load_key = [&](int k, int& cell) -> TKey {
+    TKey T; T.x = P.t_xy[2 * k]; T.y = P.t_xy[2 * k + 1]; T.ur = P.t_uright ? P.t_uright[k] : -1.f;
+    cell = -1;
+    if (grid) {                                                                 // Frame::PosInGrid, src/Frame.cc:446-456
+      const int px = (int)roundf(__fmul_rn(__fsub_rn(T.x, P.min_x), P.winv)), py = (int)roundf(__fmul_rn(__fsub_rn(T.y, P.min_y), P.hinv));
+      if (px >= 0 && px < P.cols && py >= 0 && py < P.rows) cell = px * P.rows + py;
+    }
+    T.meta = (P.t_octave[k] & 15) | (k << 4) | ((cell + 1) << 16) | ((P.t_occupied && P.t_occupied[k]) ? (1 << 29) : 0);
+    return T;
+  };
+  for (int c = tid; c <= n_cells; c += kThreads) cell_start[c] = 0;
+  for (int k = tid; k < nt; k += kThreads) blk[k] = 0x7fffffff;
+  if (tid < 32) hist[tid] = 0;
+  if (tid < 8) ctl[tid] = 0;
+  __syncthreads();
+  for (int k = tid; k < nt; k += kThreads) {
+    int cell; const TKey T = load_key(k, cell);
+    if (!grid) tk[k] = T;
+    else if (cell >= 0) atomicAdd(&cell_start[cell], 1);
+  }
+  __syncthreads();
+  if (grid) {
+    // exclusive scan of the cell counts (each thread owns a contiguous run of cells), then an unordered placement:
+    // the position inside a cell is irrelevant because ties are broken by the key, not by the visit position
+    const int per = (n_cells + kThreads - 1) / kThreads, c0 = min(tid * per, n_cells), c1 = min(c0 + per, n_cells);
+    int sum = 0;
+    for (int c = c0; c < c1; c++) sum += cell_start[c];
+    scan[tid] = sum;
+    __syncthreads();
+    for (int off = 1; off < kThreads; off <<= 1) {
+      const int v = (tid >= off) ? scan[tid - off] : 0;
+      __syncthreads();
+      scan[tid] += v;
+      __syncthreads();
+    }
+    int run = scan[tid] - sum;
+    for (int c = c0; c < c1; c++) { const int n = cell_start[c]; cell_start[c] = run; cursor[c] = run; run += n; }
+    if (tid == kThreads - 1) cell_start[n_cells] = scan[kThreads - 1];
+    __syncthreads();
+    for (int k = tid; k < nt; k += kThreads) {
+      int cell; const TKey T = load_key(k, cell);
+      if (cell >= 0) tk[atomicAdd(&cursor[cell], 1)] = T;
+    }
+  }
+  for (int q = tid; q < nq; q += kThreads) P.match[q] = -2;
+  __syncthreads();
+
+  // ---------------------------------------------------------------- fixed-point rounds
+  int rounds = 0;
+  for (;;) {
+    rounds++;
+    for (int q = wave; q < nq; q += kWaves) {
+      const QRec Q = P.q[q];
+      unsigned long long b1 = kNone, b2 = kNone;
+      if (Q.flags & 1) {
+        uint32_t qd[8];
+#pragma unroll
+        for (int w = 0; w < 8; w++) qd[w] = P.q_desc[8 * q + w];
+        if (grid) {
+          // GetFeaturesInArea cell range, src/Frame.cc:396-410 (float arithmetic, floor/ceil, clamps and early returns)
+          const int minCX = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(Q.u, P.min_x), Q.radius), P.winv)));
+          const int maxCX = min(P.cols - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(Q.u, P.min_x), Q.radius), P.winv)));
+          const int minCY = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(Q.v, P.min_y), Q.radius), P.hinv)));
+          const int maxCY = min(P.rows - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(Q.v, P.min_y), Q.radius), P.hinv)));
+          if (minCX < P.cols && maxCX >= 0 && minCY < P.rows && maxCY >= 0) {
+            for (int ix = minCX; ix <= maxCX; ix++) {
+              const int j0 = cell_start[ix * P.rows + minCY], j1 = (maxCY >= minCY) ? cell_start[ix * P.rows + maxCY + 1] : j0;
+              for (int j = j0 + lane; j < j1; j += 64) {
+                const TKey T = tk[j];
+                if (!(fabsf(__fsub_rn(T.x, Q.u)) < Q.radius && fabsf(__fsub_rn(T.y, Q.v)) < Q.radius)) continue;   // Frame.cc:433-437
+                if (!gates_pass(P, Q, T, q, blk)) continue;
+                const int k = tk_idx(T.meta);
+                unsigned key = ((unsigned)tk_cell(T.meta) << 12) | (unsigned)k;
+                if (P.tie_last) key = ~key;
+                top2_insert(((unsigned long long)hamming256(qd, P.t_desc + 8 * k) << 32) | key, b1, b2);
+              }
+            }
+          }
+        } else if (P.candidates == LLD_ORB_CAND_CSR) {
+          for (int p = Q.cs + lane; p < Q.ce; p += 64) {
+            const int k = P.cand_idx[p];
+            const TKey T = tk[k];
+            if (!gates_pass(P, Q, T, q, blk)) continue;
+            unsigned key = (unsigned)(p - Q.cs);
+            if (P.tie_last) key = ~key;
+            top2_insert(((unsigned long long)hamming256(qd, P.t_desc + 8 * k) << 32) | key, b1, b2);
+          }
+        } else {
+          const bool rows = P.candidates == LLD_ORB_CAND_ROWS;
+          const float minU = __fsub_rn(Q.u, P.disp_max), maxU = __fsub_rn(Q.u, P.disp_min);                       // Frame.cc:574-575
+          const long long row = (long long)Q.v;                                                                    // vRowIndices[vL], :569
+          if (!(rows && maxU < 0.f)) {                                                                             // :577-578
+            for (int k = lane; k < nt; k += 64) {
+              const TKey T = tk[k];
+              if (rows) {                                                                                          // :546-556, :594-596
+                const float r = __fmul_rn(2.0f, P.scale[tk_oct(T.meta)]);
+                const long long maxr = (long long)ceilf(__fadd_rn(T.y, r)), minr = (long long)floorf(__fsub_rn(T.y, r));
+                if (row < minr || row > maxr) continue;
+                if (!(T.x >= minU && T.x <= maxU)) continue;
+              }
+              if (!gates_pass(P, Q, T, q, blk)) continue;
+              unsigned key = (unsigned)k;
+              if (P.tie_last) key = ~key;
+              top2_insert(((unsigned long long)hamming256(qd, P.t_desc + 8 * k) << 32) | key, b1, b2);
+            }
+          }
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+          const unsigned long long o1 = shfl_xor_u64(b1, m), o2 = shfl_xor_u64(b2, m);
+          const unsigned long long lo = b1 < o1 ? b1 : o1, hi = b1 < o1 ? o1 : b1, s2 = b2 < o2 ? b2 : o2;
+          b1 = lo; b2 = hi < s2 ? hi : s2;
+        }
+      }
+      if (lane == 0) {
+        auto decode = [&](unsigned long long c) -> int {
+          unsigned key = (unsigned)(c & 0xffffffffu);
+          if (P.tie_last) key = ~key;
+          if (grid) return (int)(key & 4095u);
+          if (P.candidates == LLD_ORB_CAND_CSR) return P.cand_idx[Q.cs + (int)key];
+          return (int)key;
+        };
+        int m = -1, bd = 256, sd = 256;
+        if (b1 != kNone) {
+          bd = (int)(b1 >> 32);
+          const int bi = decode(b1);
+          int lvl1 = P.t_octave[bi], lvl2 = -1;
+          if (b2 != kNone) { sd = (int)(b2 >> 32); lvl2 = P.t_octave[decode(b2)]; }
+          bool ok = bd <= P.accept_max;
+          if (ok && P.ratio_mode == 1) ok = (float)bd < __fmul_rn(P.nnratio, (float)sd);                          // ORBmatcher.cc:226-228
+          if (ok && P.ratio_mode == 2 && lvl1 == lvl2 && (float)bd > __fmul_rn(P.nnratio, (float)sd)) ok = false;   // :118-121
+          if (ok) m = bi;
+        }
+        if (P.match[q] != m) { P.match[q] = m; ctl[0] = 1; }
+        P.best_dist[q] = bd; P.second_dist[q] = sd;
+      }
+    }
+    __syncthreads();
+    const int changed = ctl[0];
+    __syncthreads();
+    if (!P.sequential || !changed) break;
+    if (tid == 0) ctl[0] = 0;
+    for (int k = tid; k < nt; k += kThreads) blk[k] = 0x7fffffff;
+    __syncthreads();
+    for (int q = tid; q < nq; q += kThreads) {
+      const int m = P.match[q];
+      if (m >= 0 && (P.q[q].flags & 2)) atomicMin(&blk[m], q);
+    }
+    __syncthreads();
+  }
+
+  // ---------------------------------------------------------------- rotation histogram, owners, counts
+  int* owner = blk;                                                             // blockers are dead now
+  for (int k = tid; k < nt; k += kThreads) owner[k] = -1;
+  __syncthreads();
+  for (int q = tid; q < nq; q += kThreads) {
+    const int m = P.match[q];
+    int bin = 255;
+    if (m >= 0) {
+      atomicAdd(&ctl[1], 1);
+      atomicMax(&owner[m], q);
+      if (P.check_orientation) {                                                // ORBmatcher.cc:1431-1440
+        float rot = __fsub_rn(P.q[q].angle, P.t_angle[m]);
+        if (rot < 0.f) rot = __fadd_rn(rot, 360.0f);
+        bin = (int)roundf(__fmul_rn(rot, 1.0f / kHisto));
+        if (bin == kHisto) bin = 0;
+        bin = min(max(bin, 0), kHisto - 1);                                     // the reference asserts the range
+        atomicAdd(&hist[bin], 1);
+      }
+    }
+    P.removed[q] = (uint8_t)bin;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    if (P.check_orientation) {                                                  // ComputeThreeMaxima, ORBmatcher.cc:1601-1642
+      int max1 = 0, max2 = 0, max3 = 0;
+      for (int i = 0; i < kHisto; i++) {
+        const int s = hist[i];
+        if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+        else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+        else if (s > max3) { max3 = s; ind3 = i; }
+      }
+      if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+      else if ((float)max3 < 0.1f * (float)max1) { ind3 = -1; }
+    }
+    ctl[3] = ind1; ctl[4] = ind2; ctl[5] = ind3;
+  }
+  __syncthreads();
+  for (int q = tid; q < nq; q += kThreads) {
+    const int bin = P.removed[q];
+    uint8_t rem = 0;
+    if (P.check_orientation && bin != 255 && bin != ctl[3] && bin != ctl[4] && bin != ctl[5]) {
+      rem = 1;
+      atomicAdd(&ctl[2], 1);
+      owner[P.match[q]] = -2;                                                   // slot NULLed, ORBmatcher.cc:1452-1460
+    }
+    P.removed[q] = rem;
+  }
+  __syncthreads();
+  if (P.owner) for (int k = tid; k < nt; k += kThreads) P.owner[k] = owner[k];
+  if (tid == 0) { P.summary[0] = ctl[1] - ctl[2]; P.summary[1] = rounds; }
+}
+
+size_t lds_bytes(int nt, int n_cells, bool grid) {
+  return (size_t)nt * sizeof(TKey) + (size_t)nt * 4 + (size_t)(n_cells + 1) * 4 + 32 * 4 + 8 * 4 + kThreads * 4 + (grid ? (size_t)n_cells * 4 : 0) + 16;
+}
+
+}  // namespace
+
+extern "C" int lld_orb_search_run(lld_ctx* ctx, const lld_orb_search* s, lld_orb_search_result* out) {
+  if (!ctx || !s || !out) return LLD_ERR_INVALID;
+  const int nt = s->nt, nq = s->nq;
+  if (nt < 0 || nq < 0) return LLD_ERR_INVALID;
+  if (nt > LLD_ORB_MAX_KEYPOINTS) return LLD_ERR_UNSUPPORTED;
+  if (!out->match || !out->best_dist || !out->second_dist || !out->removed) return LLD_ERR_INVALID;
+  if (nq > 0 && !s->q_desc) return LLD_ERR_INVALID;
+  if (nt > 0 && (!s->t_desc || !s->t_xy || !s->t_octave)) return LLD_ERR_INVALID;
+  if (s->candidates < LLD_ORB_CAND_ALL || s->candidates > LLD_ORB_CAND_ROWS) return LLD_ERR_INVALID;
+  if (s->ratio_mode < 0 || s->ratio_mode > 2) return LLD_ERR_INVALID;
+  const bool grid = s->candidates == LLD_ORB_CAND_GRID;
+  if (grid && (!s->q_uv || !s->q_radius || s->grid_cols <= 0 || s->grid_rows <= 0 || s->grid_cols * s->grid_rows > 8191)) return LLD_ERR_INVALID;
+  if (s->candidates == LLD_ORB_CAND_CSR && (!s->cand_range || s->n_cand < 0 || (s->n_cand > 0 && !s->cand_idx))) return LLD_ERR_INVALID;
+  if (s->candidates == LLD_ORB_CAND_ROWS && (!s->q_uv || !s->level_scale)) return LLD_ERR_INVALID;
+  if ((s->gates & LLD_ORB_GATE_LEVEL) && (!s->q_level_min || !s->q_level_max)) return LLD_ERR_INVALID;
+  if ((s->gates & LLD_ORB_GATE_STEREO) && (!s->q_uright || !s->q_stereo_radius)) return LLD_ERR_INVALID;
+  if ((s->gates & LLD_ORB_GATE_CHI2) && (!s->q_uv || !s->q_uright || !s->level_inv_sigma2)) return LLD_ERR_INVALID;
+  if ((s->gates & LLD_ORB_GATE_EPIPOLAR) && (!s->q_epiline || !s->q_stereo || !s->level_scale || !s->level_sigma2)) return LLD_ERR_INVALID;
+  if (s->check_orientation && (!s->q_angle || (nt > 0 && !s->t_angle))) return LLD_ERR_INVALID;
+  if (s->n_levels < 0 || s->n_levels > LLD_ORB_MAX_LEVELS) return LLD_ERR_UNSUPPORTED;
+  for (int k = 0; k < nt; k++) if (s->t_octave[k] < 0 || s->t_octave[k] >= LLD_ORB_MAX_LEVELS) return LLD_ERR_INVALID;
+  const int ncand = (s->candidates == LLD_ORB_CAND_CSR) ? s->n_cand : 0;
+  if (s->candidates == LLD_ORB_CAND_CSR) {
+    for (int q = 0; q < nq; q++) if (s->cand_range[2 * q] < 0 || s->cand_range[2 * q + 1] < s->cand_range[2 * q] || s->cand_range[2 * q + 1] > ncand) return LLD_ERR_INVALID;
+    for (int p = 0; p < ncand; p++) if (s->cand_idx[p] < 0 || s->cand_idx[p] >= nt) return LLD_ERR_INVALID;
+  }
+  out->n_matches = 0; out->rounds = 0;
+  if (nq == 0) { if (out->owner) for (int k = 0; k < nt; k++) out->owner[k] = -1; return LLD_OK; }
+  LLD_HIP_TRY(hipSetDevice(ctx->device));
+
+  // ---- pack the queries
+  std::vector<QRec> qr((size_t)nq);
+  for (int q = 0; q < nq; q++) {
+    QRec& Q = qr[q]; std::memset(&Q, 0, sizeof(Q));
+    if (s->q_uv) { Q.u = s->q_uv[2 * q]; Q.v = s->q_uv[2 * q + 1]; }
+    if (s->q_radius) Q.radius = s->q_radius[q];
+    if (s->q_uright) Q.ur = s->q_uright[q];
+    if (s->q_stereo_radius) Q.stereo_radius = s->q_stereo_radius[q];
+    if (s->q_angle) Q.angle = s->q_angle[q];
+    if (s->q_epiline) { Q.ea = s->q_epiline[3 * q]; Q.eb = s->q_epiline[3 * q + 1]; Q.ec = s->q_epiline[3 * q + 2]; }
+    Q.level_min = s->q_level_min ? s->q_level_min[q] : -1;
+    Q.level_max = s->q_level_max ? s->q_level_max[q] : -1;
+    Q.flags = ((!s->q_valid || s->q_valid[q]) ? 1 : 0) | ((!s->q_blocks || s->q_blocks[q]) ? 2 : 0) | ((s->q_stereo && s->q_stereo[q]) ? 4 : 0);
+    if (s->candidates == LLD_ORB_CAND_CSR) { Q.cs = s->cand_range[2 * q]; Q.ce = s->cand_range[2 * q + 1]; }
+  }
+
+  // ---- device buffers out of the context scratch
+  const size_t b_td = lld_slab::pad((size_t)nt * 32 + 32), b_txy = lld_slab::pad((size_t)nt * 8 + 8), b_ti = lld_slab::pad((size_t)nt * 4 + 4), b_tb = lld_slab::pad((size_t)nt + 1);
+  const size_t b_qd = lld_slab::pad((size_t)nq * 32), b_q = lld_slab::pad((size_t)nq * sizeof(QRec)), b_c = lld_slab::pad((size_t)ncand * 4 + 4);
+  const size_t b_oi = lld_slab::pad((size_t)nq * 4), b_ob = lld_slab::pad((size_t)nq);
+  const size_t need = b_td + b_txy + 4 * b_ti + b_tb + b_qd + b_q + b_c + 3 * b_oi + b_ob + lld_slab::pad(sizeof(Problem)) + 256;
+  void* base; int st = lld_ctx_scratch(ctx, need, &base); if (st) return st;
+  lld_slab sl; sl.base = (char*)base;
+  uint32_t* d_td = sl.take<uint32_t>((size_t)nt * 8 + 8); float* d_txy = sl.take<float>((size_t)nt * 2 + 2); int32_t* d_toct = sl.take<int32_t>(nt + 1);
+  float* d_tur = sl.take<float>(nt + 1); float* d_tang = sl.take<float>(nt + 1); int32_t* d_owner = sl.take<int32_t>(nt + 1); uint8_t* d_tocc = sl.take<uint8_t>(nt + 1);
+  uint32_t* d_qd = sl.take<uint32_t>((size_t)nq * 8); QRec* d_q = sl.take<QRec>(nq); int32_t* d_c = sl.take<int32_t>(ncand + 1);
+  int32_t* d_match = sl.take<int32_t>(nq); int32_t* d_bd = sl.take<int32_t>(nq); int32_t* d_sd = sl.take<int32_t>(nq); uint8_t* d_rem = sl.take<uint8_t>(nq);
+  Problem* d_P = sl.take<Problem>(1); int32_t* d_sum = sl.take<int32_t>(2);
+  hipStream_t sm = ctx->stream;
+  if (nt) {
+    LLD_HIP_TRY(hipMemcpyAsync(d_td, s->t_desc, (size_t)nt * 32, hipMemcpyHostToDevice, sm));
+    LLD_HIP_TRY(hipMemcpyAsync(d_txy, s->t_xy, (size_t)nt * 8, hipMemcpyHostToDevice, sm));
+    LLD_HIP_TRY(hipMemcpyAsync(d_toct, s->t_octave, (size_t)nt * 4, hipMemcpyHostToDevice, sm));
+    if (s->t_uright) LLD_HIP_TRY(hipMemcpyAsync(d_tur, s->t_uright, (size_t)nt * 4, hipMemcpyHostToDevice, sm));
+    if (s->t_angle) LLD_HIP_TRY(hipMemcpyAsync(d_tang, s->t_angle, (size_t)nt * 4, hipMemcpyHostToDevice, sm));
+    if (s->t_occupied) LLD_HIP_TRY(hipMemcpyAsync(d_tocc, s->t_occupied, (size_t)nt, hipMemcpyHostToDevice, sm));
+  }
+  LLD_HIP_TRY(hipMemcpyAsync(d_qd, s->q_desc, (size_t)nq * 32, hipMemcpyHostToDevice, sm));
+  LLD_HIP_TRY(hipMemcpyAsync(d_q, qr.data(), (size_t)nq * sizeof(QRec), hipMemcpyHostToDevice, sm));
+  if (ncand) LLD_HIP_TRY(hipMemcpyAsync(d_c, s->cand_idx, (size_t)ncand * 4, hipMemcpyHostToDevice, sm));
+
+  Problem P; std::memset(&P, 0, sizeof(P));
+  P.nt = nt; P.nq = nq;
+  P.t_desc = d_td; P.t_xy = d_txy; P.t_octave = d_toct; P.t_uright = s->t_uright ? d_tur : nullptr; P.t_angle = s->t_angle ? d_tang : nullptr;
+  P.t_occupied = s->t_occupied ? d_tocc : nullptr;
+  P.q_desc = d_qd; P.q = d_q; P.cand_idx = d_c;
+  P.min_x = s->grid_min_x; P.min_y = s->grid_min_y; P.winv = s->grid_width_inv; P.hinv = s->grid_height_inv;
+  P.cols = grid ? s->grid_cols : 1; P.rows = grid ? s->grid_rows : 1;
+  P.n_levels = s->n_levels;
+  for (int i = 0; i < LLD_ORB_MAX_LEVELS; i++) {
+    P.scale[i] = (s->level_scale && i < s->n_levels) ? s->level_scale[i] : 1.f;
+    P.sigma2[i] = (s->level_sigma2 && i < s->n_levels) ? s->level_sigma2[i] : 1.f;
+    P.inv_sigma2[i] = (s->level_inv_sigma2 && i < s->n_levels) ? s->level_inv_sigma2[i] : 1.f;
+  }
+  P.disp_min = s->disp_min; P.disp_max = s->disp_max; P.epi_x = s->epipole_x; P.epi_y = s->epipole_y; P.only_stereo = s->only_stereo;
+  P.candidates = s->candidates; P.gates = s->gates; P.tie_last = s->tie_last; P.accept_max = s->accept_max; P.ratio_mode = s->ratio_mode;
+  P.nnratio = s->nnratio; P.sequential = s->sequential; P.check_orientation = s->check_orientation;
+  P.match = d_match; P.best_dist = d_bd; P.second_dist = d_sd; P.removed = d_rem; P.owner = d_owner; P.summary = d_sum;
+  LLD_HIP_TRY(hipMemcpyAsync(d_P, &P, sizeof(P), hipMemcpyHostToDevice, sm));
+
+  const size_t lds = lds_bytes(nt, P.cols * P.rows, grid);
+  static bool lds_raised = false;
+  if (!lds_raised) { LLD_HIP_TRY(hipFuncSetAttribute((const void*)orb_search_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256)); lds_raised = true; }
+  hipLaunchKernelGGL(orb_search_kernel, dim3(1), dim3(kThreads), lds, sm, d_P);
+  LLD_HIP_TRY(hipGetLastError());
+  int32_t sum[2] = {0, 0};
+  LLD_HIP_TRY(hipMemcpyAsync(out->match, d_match, (size_t)nq * 4, hipMemcpyDeviceToHost, sm));
+  LLD_HIP_TRY(hipMemcpyAsync(out->best_dist, d_bd, (size_t)nq * 4, hipMemcpyDeviceToHost, sm));
+  LLD_HIP_TRY(hipMemcpyAsync(out->second_dist, d_sd, (size_t)nq * 4, hipMemcpyDeviceToHost, sm));
+  LLD_HIP_TRY(hipMemcpyAsync(out->removed, d_rem, (size_t)nq, hipMemcpyDeviceToHost, sm));
+  if (out->owner && nt) LLD_HIP_TRY(hipMemcpyAsync(out->owner, d_owner, (size_t)nt * 4, hipMemcpyDeviceToHost, sm));
+  LLD_HIP_TRY(hipMemcpyAsync(sum, d_sum, 8, hipMemcpyDeviceToHost, sm));
+  LLD_HIP_TRY(hipStreamSynchronize(sm));
+  out->n_matches = sum[0]; out->rounds = sum[1];
+  return LLD_OK;
+}

@@ -456,6 +456,65 @@ class ORBmatcher:
     def BestTwoCandidates(self, q, t, cand_start, cand_idx):
         return hamming_csr_call(self.lib, self.ctx.handle, q, t, cand_start, cand_idx)
 
+    # ---- the reference's search routines, each ONE device call (candidate generation, skip rules, accept rules, the
+    # ---- order-dependent occupancy and the rotation histogram all run in lld_orb_search_run); see orb_search.py
+    def SearchByProjectionMap(self, F, mp_desc, in_view, proj, proj_xr, pred_level, view_cos, mp_obs, f_occupied, th=1.0):
+        """SearchByProjection(Frame&, const vector<MapPoint*>&, th)  (src/ORBmatcher.cc:45-129)."""
+        from . import orb_search as S
+        return S.search_by_projection_map(self.lib, self.ctx.handle, F, mp_desc, in_view, proj, proj_xr, pred_level, view_cos, mp_obs,
+                                          f_occupied, th, float(self.mfNNratio))
+
+    def SearchByProjectionFrame(self, Cur, last_desc, valid, uv, ur, last_octave, last_angle, mp_obs, cur_occupied, direction=0, th=7.0):
+        """SearchByProjection(Frame& Current, const Frame& Last, th, bMono)  (src/ORBmatcher.cc:1328-1470)."""
+        from . import orb_search as S
+        return S.search_by_projection_frame(self.lib, self.ctx.handle, Cur, last_desc, valid, uv, ur, last_octave, last_angle, mp_obs,
+                                            cur_occupied, direction, th, self.mbCheckOrientation)
+
+    def SearchByProjectionReloc(self, Cur, desc, valid, uv, pred_level, kf_angle, cur_occupied, th, ORBdist):
+        """SearchByProjection(Frame&, KeyFrame*, sAlreadyFound, th, ORBdist)  (src/ORBmatcher.cc:1472-1599)."""
+        from . import orb_search as S
+        return S.search_by_projection_reloc(self.lib, self.ctx.handle, Cur, desc, valid, uv, pred_level, kf_angle, cur_occupied, th, ORBdist,
+                                            self.mbCheckOrientation)
+
+    def SearchByProjectionKF(self, KF, desc, valid, uv, pred_level, matched, th):
+        """SearchByProjection(KeyFrame*, Scw, vpPoints, vpMatched, th)  (src/ORBmatcher.cc:290-403)."""
+        from . import orb_search as S
+        return S.search_by_projection_kf(self.lib, self.ctx.handle, KF, desc, valid, uv, pred_level, matched, th)
+
+    def Fuse(self, KF, desc, valid, uv, ur, pred_level, th=3.0):
+        """Inner search of Fuse (src/ORBmatcher.cc:825-1100)."""
+        from . import orb_search as S
+        return S.fuse_search(self.lib, self.ctx.handle, KF, desc, valid, uv, ur, pred_level, th)
+
+    def SearchBySim3(self, KF1, KF2, q1, q2, th=7.5):
+        """SearchBySim3 (src/ORBmatcher.cc:1102-1326)."""
+        from . import orb_search as S
+        return S.search_by_sim3(self.lib, self.ctx.handle, KF1, KF2, q1, q2, th)
+
+    def SearchByBoWFrame(self, KF, F, nodes, kf_valid):
+        """SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches)  (src/ORBmatcher.cc:159-288)."""
+        from . import orb_search as S
+        return S.search_by_bow_frame(self.lib, self.ctx.handle, KF, F, nodes["n_nodes"], nodes["start1"], nodes["idx1"], nodes["start2"],
+                                     nodes["idx2"], kf_valid, float(self.mfNNratio), self.mbCheckOrientation)
+
+    def SearchByBoWKF(self, KF1, KF2, nodes, valid1, valid2):
+        """SearchByBoW(KeyFrame*, KeyFrame*, vpMatches12)  (src/ORBmatcher.cc:522-655)."""
+        from . import orb_search as S
+        return S.search_by_bow_kf(self.lib, self.ctx.handle, KF1, KF2, nodes["n_nodes"], nodes["start1"], nodes["idx1"], nodes["start2"],
+                                  nodes["idx2"], valid1, valid2, float(self.mfNNratio), self.mbCheckOrientation)
+
+    def SearchForTriangulation(self, KF1, KF2, nodes, has_mp1, has_mp2, epilines, epipole, bOnlyStereo=False):
+        """SearchForTriangulation (src/ORBmatcher.cc:657-823)."""
+        from . import orb_search as S
+        return S.search_for_triangulation(self.lib, self.ctx.handle, KF1, KF2, nodes["n_nodes"], nodes["start1"], nodes["idx1"],
+                                          nodes["start2"], nodes["idx2"], has_mp1, has_mp2, epilines, epipole, bOnlyStereo,
+                                          self.mbCheckOrientation)
+
+    def ComputeStereoMatches(self, L, R, min_d, max_d):
+        """Hamming search of Frame::ComputeStereoMatches (src/Frame.cc:530-613)."""
+        from . import orb_search as S
+        return S.stereo_search(self.lib, self.ctx.handle, L, R, min_d, max_d)
+
     def AcceptByRatio(self, best_idx, best_dist, second_dist, th):
         """`bestDist<=th` and `bestDist < mfNNratio*bestDist2` as in SearchByBoW (src/ORBmatcher.cc:226-230)."""
         ok = (best_idx >= 0) & (best_dist <= th) & (best_dist.astype(np.float32) < self.mfNNratio * second_dist.astype(np.float32))

@@ -339,3 +339,121 @@ def make_match_lbd(pair_id=0, nq=300, nt=300, dim=72, n_corr=240, noise=0.05):
     src = rng.permutation(nq)[:n_corr]; dst = rng.permutation(nt)[:n_corr]
     t[dst] = q[src] + rng.normal(0, noise, (n_corr, dim))
     return q.astype(np.float32), t.astype(np.float32)
+
+
+# ====================================================================== guided ORB search scenes
+SEED_SEARCH = 0x5EA2C400
+
+
+def _flip_bits(rng, desc, p, keep_word0_low=0):
+    """XOR each of the 256 bits with probability p; optionally keep the low bits of word 0 (the synthetic 'vocabulary node')."""
+    n = desc.shape[0]
+    flips = rng.random((n, 256)) < p
+    fl = np.packbits(flips.reshape(n, 8, 32)[:, :, ::-1], axis=2, bitorder='big').view('>u4').reshape(n, 8).astype(np.uint32)
+    if keep_word0_low:
+        fl[:, 0] &= np.uint32(~((1 << keep_word0_low) - 1) & 0xFFFFFFFF)
+    return desc ^ fl
+
+
+def make_orb_frame(frame_id=0, n=2000, width=1241.0, height=376.0, stereo_frac=0.75, n_clusters=60):
+    """One frame's keypoints as ORBextractor produces them: integer pixel positions at the keypoint's pyramid level scaled
+    back by mvScaleFactor[octave] (so equal coordinates and exact |dx| == r ties do occur), octaves skewed to the fine
+    levels, angles in [0,360), stereo keypoints with uR = x - disparity, the rest uR = -1.  `n_clusters` tight clusters of
+    near-duplicate descriptors make several queries compete for the same keypoints."""
+    from .orb_search import Frame, orb_levels
+    rng = np.random.default_rng(SEED_SEARCH + frame_id)
+    scale, _, _ = orb_levels()
+    octave = np.minimum(rng.geometric(0.35, n) - 1, 7).astype(np.int32)
+    lx = rng.integers(16, np.floor((width - 16) / scale[octave]).astype(np.int64))
+    ly = rng.integers(16, np.floor((height - 16) / scale[octave]).astype(np.int64))
+    xy = np.stack([lx.astype(np.float32) * scale[octave], ly.astype(np.float32) * scale[octave]], 1).astype(np.float32)
+    desc = rng.integers(0, 2 ** 32, (n, 8), dtype=np.uint64).astype(np.uint32)
+    if n_clusters and n > 8 * n_clusters:
+        centres = rng.permutation(n)[:n_clusters]
+        for c in centres:
+            members = rng.permutation(n)[:3]
+            xy[members] = xy[c] + (rng.integers(-3, 4, (3, 2)) * scale[octave[c]]).astype(np.float32)
+            octave[members] = octave[c]
+            desc[members] = _flip_bits(rng, np.repeat(desc[c:c + 1], 3, 0), 0.01)
+            desc[members[0]] = desc[c]                                             # one exact duplicate: a tie
+        xy[:, 0] = np.clip(xy[:, 0], 0, width - 1); xy[:, 1] = np.clip(xy[:, 1], 0, height - 1)
+    disparity = rng.uniform(2.0, 90.0, n).astype(np.float32)
+    uright = np.where(rng.random(n) < stereo_frac, xy[:, 0] - disparity, np.float32(-1.0)).astype(np.float32)
+    angle = rng.uniform(0.0, 360.0, n).astype(np.float32)
+    return Frame(desc=desc, xy=xy, octave=octave, uright=uright, angle=angle, min_x=0.0, min_y=0.0, max_x=width, max_y=height).normalise()
+
+
+def make_projection_queries(F, scene_id=0, nq=1500, related_frac=0.85, flip_p=0.06, pos_sigma=2.5, rotation=35.0, rot_outliers=0.15,
+                            dup_frac=0.2):
+    """Queries (MapPoints / last-frame keypoints) projected into frame F: most are noisy copies of F's keypoints (position,
+    descriptor, octave +-1, right coordinate, angle = keypoint angle + a common rotation), `dup_frac` of them share their
+    source keypoint with an earlier query (competition -> the order-dependent rule matters), the rest are unrelated."""
+    rng = np.random.default_rng(SEED_SEARCH + 0x1000 + scene_id)
+    n = F.n
+    src = rng.integers(0, n, nq)
+    n_dup = int(dup_frac * nq)
+    if n_dup:
+        a = rng.permutation(nq)[:2 * n_dup]
+        src[a[n_dup:]] = src[a[:n_dup]]
+    related = rng.random(nq) < related_frac
+    desc = _flip_bits(rng, F.desc[src], flip_p)
+    hard = rng.random(nq) < 0.15                                                   # distances around the accept thresholds
+    desc[hard] = _flip_bits(rng, F.desc[src[hard]], 0.2)
+    desc[~related] = rng.integers(0, 2 ** 32, (int((~related).sum()), 8), dtype=np.uint64).astype(np.uint32)
+    uv = (F.xy[src] + rng.normal(0, pos_sigma, (nq, 2))).astype(np.float32)
+    uv[~related] = np.stack([rng.uniform(-30, F.max_x + 30, int((~related).sum())), rng.uniform(-30, F.max_y + 30, int((~related).sum()))], 1)
+    level = np.clip(F.octave[src] + rng.integers(-1, 2, nq), 0, 7).astype(np.int32)
+    ur = np.where(F.uright[src] > 0, F.uright[src] + rng.normal(0, 2.0, nq), uv[:, 0] - rng.uniform(2, 90, nq)).astype(np.float32)
+    far = rng.random(nq) < 0.1
+    ur[far] += rng.uniform(20, 60, int(far.sum())).astype(np.float32)               # stereo gate rejects these
+    ang = F.angle[src] + np.float32(rotation) + rng.normal(0, 6.0, nq)
+    out = rng.random(nq) < rot_outliers
+    ang[out] = rng.uniform(0, 360, int(out.sum()))
+    ang = np.mod(ang, 360.0).astype(np.float32)
+    return dict(desc=desc, uv=uv, ur=ur, level=level, angle=ang, src=src.astype(np.int32),
+                valid=(rng.random(nq) < 0.95).astype(np.uint8), obs=(rng.random(nq) < 0.9).astype(np.uint8),
+                view_cos=rng.uniform(0.99, 1.0, nq).astype(np.float32), occupied=(rng.random(n) < 0.05).astype(np.uint8))
+
+
+def make_bow_pair(pair_id=0, n=2000, n_nodes=400, related_frac=0.7, flip_p=0.06, pos_sigma=(6.0, 6.0)):
+    """Two frames sharing scene content plus their vocabulary-node lists (a stand-in for DBoW2::FeatureVector: the node of a
+    keypoint is the low bits of its first descriptor word, preserved by the noise, so corresponding keypoints share nodes).
+    Returns (F1, F2, nodes) with nodes = dict(n_nodes, start1, idx1, start2, idx2) over the COMMON nodes in ascending id."""
+    from .orb_search import Frame
+    rng = np.random.default_rng(SEED_SEARCH + 0x2000 + pair_id)
+    F1 = make_orb_frame(1000 + 2 * pair_id, n)
+    F2 = make_orb_frame(1001 + 2 * pair_id, n)
+    m = int(related_frac * n)
+    s1 = rng.permutation(n)[:m]; s2 = rng.permutation(n)[:m]
+    bits = max(1, int(np.ceil(np.log2(n_nodes))))
+    F2.desc[s2] = _flip_bits(rng, F1.desc[s1], flip_p, keep_word0_low=bits)
+    F2.xy[s2] = (F1.xy[s1] + rng.normal(0, 1.0, (m, 2)) * np.asarray(pos_sigma)).astype(np.float32)
+    F2.octave[s2] = F1.octave[s1]
+    F2.angle[s2] = np.mod(F1.angle[s1] - 20.0 + rng.normal(0, 5.0, m), 360.0).astype(np.float32)
+    node1 = (F1.desc[:, 0] & np.uint32((1 << bits) - 1)).astype(np.int64) % n_nodes
+    node2 = (F2.desc[:, 0] & np.uint32((1 << bits) - 1)).astype(np.int64) % n_nodes
+    common = np.intersect1d(node1, node2)
+    start1, idx1, start2, idx2 = [0], [], [0], []
+    for nd in common:
+        a = np.nonzero(node1 == nd)[0]; b = np.nonzero(node2 == nd)[0]          # ascending keypoint index inside a node
+        idx1.extend(a.tolist()); start1.append(len(idx1)); idx2.extend(b.tolist()); start2.append(len(idx2))
+    nodes = dict(n_nodes=len(common), start1=np.array(start1, np.int32), idx1=np.array(idx1, np.int32),
+                 start2=np.array(start2, np.int32), idx2=np.array(idx2, np.int32))
+    return F1, F2, nodes
+
+
+def make_stereo_pair(pair_id=0, n=2000, flip_p=0.06):
+    """Left / right keypoints of one stereo frame: right keypoints are the left ones shifted by a disparity (rows within the
+    +-2*scale band), plus unrelated ones."""
+    rng = np.random.default_rng(SEED_SEARCH + 0x3000 + pair_id)
+    L = make_orb_frame(2000 + pair_id, n, n_clusters=40)
+    R = make_orb_frame(2500 + pair_id, n, n_clusters=0)
+    m = int(0.75 * n)
+    sl = rng.permutation(n)[:m]; sr = rng.permutation(n)[:m]
+    disp = rng.uniform(-5.0, 110.0, m).astype(np.float32)                         # some negative / too large: rejected by [minU,maxU]
+    R.xy[sr, 0] = L.xy[sl, 0] - disp
+    R.xy[sr, 1] = L.xy[sl, 1] + rng.normal(0, 1.2, m).astype(np.float32)
+    R.xy[:, 1] = np.clip(R.xy[:, 1], 8.0, 360.0)
+    R.octave[sr] = np.clip(L.octave[sl] + rng.integers(-2, 3, m), 0, 7)
+    R.desc[sr] = _flip_bits(rng, L.desc[sl], flip_p)
+    return L, R

@@ -20,7 +20,7 @@ _LIB = None
 
 def build(force: bool = False) -> str:
     so = os.path.join(_HERE, "liblld_oracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("lld_oracle.cpp", "lldo_math.h", "lldo_edges.h", "lldo_lm.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("lld_oracle.cpp", "lldo_orbsearch.cpp", "lldo_math.h", "lldo_edges.h", "lldo_lm.h")]
     srcs.append(os.path.join(_HERE, "..", "include", "lld_amd.h"))
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"])

@@ -80,6 +80,18 @@ def main():
     np.savez(os.path.join(HERE, "lba_small.npz"), gamma=1.0, out_cam_qt=b.cam_qt, out_pt_xyz=b.pt_xyz, out_line_x0=b.line_x0,
              out_line_dir=b.line_dir, out_pt_obs_outlier=b.pt_obs_outlier, out_ln_edge_outlier=b.ln_edge_outlier,
              out_line_removed=b.line_removed, out_chi2_round1=b.stats["chi2_round1"], out_chi2_final=b.stats["chi2_final"], **window_arrays(w))
+    # --- guided ORB search: local-map projection search and frame-to-frame search on one small frame
+    import oracle_orbsearch as OS
+    F = synth.make_orb_frame(7, 400, n_clusters=25)
+    q = synth.make_projection_queries(F, 7, 360, dup_frac=0.35)
+    q["obs"][::5] = 0
+    n_map, slot_map = OS.search_by_projection_map(F, q["desc"], q["valid"], q["uv"], q["ur"], q["level"], q["view_cos"], q["obs"], q["occupied"], 1.0, 0.8)
+    n_frm, slot_frm = OS.search_by_projection_frame(F, q["desc"], q["valid"], q["uv"], q["ur"], q["level"], q["angle"], q["obs"], q["occupied"], 0, 7.0, True)
+    np.savez(os.path.join(HERE, "orb_search.npz"), f_desc=F.desc, f_xy=F.xy, f_octave=F.octave, f_uright=F.uright, f_angle=F.angle,
+             f_bounds=np.array([F.min_x, F.min_y, F.max_x, F.max_y], np.float32), q_desc=q["desc"], q_valid=q["valid"], q_uv=q["uv"], q_ur=q["ur"],
+             q_level=q["level"], q_view_cos=q["view_cos"], q_angle=q["angle"], q_obs=q["obs"], f_occupied=q["occupied"],
+             map_nnratio=np.float32(0.8), map_th=np.float32(1.0), map_n=n_map, map_slot=slot_map, frame_th=np.float32(7.0), frame_n=n_frm,
+             frame_slot=slot_frm)
     for n in sorted(os.listdir(HERE)):
         if n.endswith(".npz"):
             print(n, os.path.getsize(os.path.join(HERE, n)), "bytes")

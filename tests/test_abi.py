@@ -5,7 +5,7 @@ import re
 
 import pytest
 
-from lld_slam_amd import abi
+from lld_slam_amd import abi, orb_search
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -33,14 +33,19 @@ def test_struct_layouts_match_the_header(tmp_path):
     import subprocess
     names = [("lld_camera", abi.Camera), ("lld_ba_window", abi.BAWindow), ("lld_ba_params", abi.BAParams),
              ("lld_ba_stats", abi.BAStats), ("lld_ba_result", abi.BAResult), ("lld_pose_problem", abi.PoseProblem),
-             ("lld_pose_params", abi.PoseParams), ("lld_pose_result", abi.PoseResult)]
+             ("lld_pose_params", abi.PoseParams), ("lld_pose_result", abi.PoseResult),
+             ("lld_orb_search", orb_search.OrbSearch), ("lld_orb_search_result", orb_search.OrbSearchResult)]
     src = tmp_path / "sz.c"
     body = "".join(f'printf("%zu\\n", sizeof({n}));' for n, _ in names)
-    src.write_text(f'#include <stdio.h>\n#include "{ROOT}/include/lld_amd.h"\nint main(void){{{body}return 0;}}\n')
+    # field offsets of the widest struct too: equal sizes alone would not catch two swapped members
+    probes = ["t_occupied", "q_valid", "q_epiline", "cand_range", "n_cand", "grid_min_x", "n_levels", "disp_min", "only_stereo",
+              "candidates", "nnratio", "check_orientation"]
+    body += "".join(f'printf("%zu\\n", offsetof(lld_orb_search, {f}));' for f in probes)
+    src.write_text(f'#include <stdio.h>\n#include <stddef.h>\n#include "{ROOT}/include/lld_amd.h"\nint main(void){{{body}return 0;}}\n')
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", str(src), "-o", str(exe)])   # the header is plain C
     sizes = [int(x) for x in subprocess.check_output([str(exe)]).split()]
-    assert sizes == [ctypes.sizeof(c) for _, c in names]
+    assert sizes == [ctypes.sizeof(c) for _, c in names] + [getattr(orb_search.OrbSearch, f).offset for f in probes]
 
 
 def test_host_helpers_agree_with_oracle_without_a_gpu(oracle):

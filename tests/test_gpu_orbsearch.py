@@ -1,0 +1,192 @@
+"""GPU parity: the guided ORB searches (one lld_orb_search_run call per reference routine) vs the literal sequential CPU
+restatements in oracle/lldo_orbsearch.cpp.  Everything is integer / index work: bit-exact."""
+import numpy as np
+import pytest
+
+import oracle_orbsearch as OS
+from lld_slam_amd import ORBmatcher, orb_search, synth
+from lld_slam_amd.orb_search import Frame
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+
+
+def expect_slots(out, occupied, token=1 << 20):
+    """Frame slot vector implied by the device's `owner`: untouched slots keep their input, -2 = NULLed by the rotation filter."""
+    slot = np.where(np.asarray(occupied) != 0, token, -1).astype(np.int32)
+    slot = np.where(out.owner >= 0, out.owner, slot)
+    return np.where(out.owner == -2, -1, slot).astype(np.int32)
+
+
+@pytest.mark.parametrize("seed,n,nq,th", [(0, 2000, 1500, 1.0), (1, 2000, 2000, 3.0), (2, 300, 700, 1.0), (3, 4096, 3000, 1.0)])
+def test_search_by_projection_local_map(gpu_ctx, seed, n, nq, th):
+    F = synth.make_orb_frame(seed, n)
+    q = synth.make_projection_queries(F, seed, nq, dup_frac=0.3)
+    out = ORBmatcher(gpu_ctx, 0.8).SearchByProjectionMap(F, q["desc"], q["valid"], q["uv"], q["ur"], q["level"], q["view_cos"], q["obs"], q["occupied"], th)
+    n_exp, slot = OS.search_by_projection_map(F, q["desc"], q["valid"], q["uv"], q["ur"], q["level"], q["view_cos"], q["obs"], q["occupied"], th, 0.8)
+    assert out.n_matches == n_exp and n_exp > nq // 5
+    np.testing.assert_array_equal(expect_slots(out, q["occupied"]), slot)
+    assert out.rounds >= 2                                            # competing queries: the fixed point needed more than one round
+
+
+@pytest.mark.parametrize("seed,direction,check", [(0, 0, True), (1, 1, True), (2, -1, True), (3, 0, False)])
+def test_search_by_projection_last_frame(gpu_ctx, seed, direction, check):
+    F = synth.make_orb_frame(30 + seed, 2000)
+    q = synth.make_projection_queries(F, 30 + seed, 1800, dup_frac=0.3)
+    q["obs"][::4] = 0                                                 # temporal points: they do not block later queries
+    out = ORBmatcher(gpu_ctx, 0.9, check).SearchByProjectionFrame(F, q["desc"], q["valid"], q["uv"], q["ur"], q["level"], q["angle"], q["obs"],
+                                                                    q["occupied"], direction, 7.0)
+    n_exp, slot = OS.search_by_projection_frame(F, q["desc"], q["valid"], q["uv"], q["ur"], q["level"], q["angle"], q["obs"], q["occupied"],
+                                                direction, 7.0, check)
+    assert out.n_matches == n_exp and n_exp > 300
+    np.testing.assert_array_equal(expect_slots(out, q["occupied"]), slot)
+    if check:
+        assert out.removed.sum() > 0                                  # the rotation histogram did drop matches
+
+
+@pytest.mark.parametrize("seed,th,orbdist", [(0, 10.0, 100), (1, 3.0, 64)])
+def test_search_by_projection_relocalisation(gpu_ctx, seed, th, orbdist):
+    F = synth.make_orb_frame(40 + seed, 2000)
+    q = synth.make_projection_queries(F, 40 + seed, 1200, dup_frac=0.3)
+    out = ORBmatcher(gpu_ctx, 0.9, True).SearchByProjectionReloc(F, q["desc"], q["valid"], q["uv"], q["level"], q["angle"], q["occupied"], th, orbdist)
+    n_exp, slot = OS.search_by_projection_reloc(F, q["desc"], q["valid"], q["uv"], q["level"], q["angle"], q["occupied"], th, orbdist, True)
+    assert out.n_matches == n_exp and n_exp > 200
+    np.testing.assert_array_equal(expect_slots(out, q["occupied"]), slot)
+
+
+def test_search_by_projection_keyframe_sim3(gpu_ctx):
+    F = synth.make_orb_frame(50, 2000)
+    q = synth.make_projection_queries(F, 50, 1500, dup_frac=0.3)
+    out = ORBmatcher(gpu_ctx, 0.75).SearchByProjectionKF(F, q["desc"], q["valid"], q["uv"], q["level"], q["occupied"], 10)
+    n_exp, slot = OS.search_by_projection_kf(F, q["desc"], q["valid"], q["uv"], q["level"], q["occupied"], 10)
+    assert out.n_matches == n_exp and n_exp > 200
+    np.testing.assert_array_equal(expect_slots(out, q["occupied"]), slot)
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_fuse_inner_search(gpu_ctx, seed):
+    F = synth.make_orb_frame(60 + seed, 2000)
+    q = synth.make_projection_queries(F, 60 + seed, 1500, pos_sigma=1.2)
+    out = ORBmatcher(gpu_ctx).Fuse(F, q["desc"], q["valid"], q["uv"], q["ur"], q["level"], 3.0)
+    n_exp, best = OS.fuse_search(F, q["desc"], q["valid"], q["uv"], q["ur"], q["level"], 3.0)
+    assert out.n_matches == n_exp and n_exp > 100 and out.rounds == 1
+    np.testing.assert_array_equal(out.match, best)
+
+
+def test_search_by_sim3_mutual_agreement(gpu_ctx):
+    F1, F2, _ = synth.make_bow_pair(3, 1500)
+    q1 = synth.make_projection_queries(F2, 70, F1.n); q2 = synth.make_projection_queries(F1, 71, F2.n)
+    a = dict(desc=q1["desc"], valid=q1["valid"], uv=q1["uv"], pred_level=q1["level"])
+    b = dict(desc=q2["desc"], valid=q2["valid"], uv=q2["uv"], pred_level=q2["level"])
+    # make the two directions agree for a subset: the queries of direction 2 that come from keypoint k of F1 search F1 and
+    # must find k; craft them as exact copies
+    m12, found = ORBmatcher(gpu_ctx).SearchBySim3(F1, F2, a, b, 7.5)
+    m1 = OS.search_sim3_direction(F2, a["desc"], a["valid"], a["uv"], a["pred_level"], 7.5)
+    m2 = OS.search_sim3_direction(F1, b["desc"], b["valid"], b["uv"], b["pred_level"], 7.5)
+    exp = np.array([m1[i] if m1[i] >= 0 and m2[m1[i]] == i else -1 for i in range(F1.n)], np.int32)
+    np.testing.assert_array_equal(m12, exp)
+    assert found == int((exp >= 0).sum())
+
+
+@pytest.mark.parametrize("seed,check", [(0, True), (1, False)])
+def test_search_by_bow_keyframe_to_frame(gpu_ctx, seed, check):
+    F1, F2, nd = synth.make_bow_pair(seed, 2000)
+    valid = (np.random.default_rng(seed).random(F1.n) < 0.85).astype(np.uint8)
+    out = ORBmatcher(gpu_ctx, 0.7, check).SearchByBoWFrame(F1, F2, nd, valid)
+    n_exp, fm = OS.search_by_bow_frame(F1, F2, nd["n_nodes"], nd["start1"], nd["idx1"], nd["start2"], nd["idx2"], valid, 0.7, check)
+    assert out.n_matches == n_exp and n_exp > 400
+    got = np.where(out.owner >= 0, out.query_kp[np.maximum(out.owner, 0)], -1)
+    np.testing.assert_array_equal(got, fm)
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_search_by_bow_keyframe_to_keyframe(gpu_ctx, seed):
+    F1, F2, nd = synth.make_bow_pair(10 + seed, 2000)
+    rng = np.random.default_rng(seed)
+    v1 = (rng.random(F1.n) < 0.85).astype(np.uint8); v2 = (rng.random(F2.n) < 0.85).astype(np.uint8)
+    out = ORBmatcher(gpu_ctx, 0.75, True).SearchByBoWKF(F1, F2, nd, v1, v2)
+    n_exp, m12 = OS.search_by_bow_kf(F1, F2, nd["n_nodes"], nd["start1"], nd["idx1"], nd["start2"], nd["idx2"], v1, v2, 0.75, True)
+    assert out.n_matches == n_exp and n_exp > 300
+    got = -np.ones(F1.n, np.int32); got[out.query_kp] = out.final_match()
+    np.testing.assert_array_equal(got, m12)
+
+
+@pytest.mark.parametrize("seed,only_stereo", [(0, False), (1, True)])
+def test_search_for_triangulation(gpu_ctx, seed, only_stereo):
+    F1, F2, nd = synth.make_bow_pair(20 + seed, 2000, pos_sigma=(25.0, 1.5))
+    rng = np.random.default_rng(seed)
+    # nearly pure x-translation between the two keyframes: epipolar lines are (almost) the image rows
+    F12 = (np.array([[0, 0, 0], [0, 0, -1.0], [0, 1.0, 0.0]]) + rng.normal(0, 2e-6, (3, 3))).astype(f32)
+    has1 = (rng.random(F1.n) < 0.3).astype(np.uint8); has2 = (rng.random(F2.n) < 0.3).astype(np.uint8)
+    if not only_stereo:
+        F1.uright[::2] = -1; F2.uright[::3] = -1                    # mono keypoints: the epipole-distance rule applies
+    epi = OS.epipolar_lines(F12, F1.xy)
+    epipole = (620.0, 180.0)
+    out = ORBmatcher(gpu_ctx, 0.6, True).SearchForTriangulation(F1, F2, nd, has1, has2, epi, epipole, only_stereo)
+    n_exp, m12 = OS.search_for_triangulation(F1, F2, nd["n_nodes"], nd["start1"], nd["idx1"], nd["start2"], nd["idx2"], has1, has2, F12, epipole,
+                                             only_stereo, True)
+    got = -np.ones(F1.n, np.int32); got[out.query_kp] = out.final_match()
+    np.testing.assert_array_equal(got, m12)
+    assert out.n_matches == n_exp and n_exp > 150
+
+
+def test_triangulation_tie_goes_to_the_later_candidate(gpu_ctx):
+    d = np.zeros((1, 8), np.uint32); t = np.zeros((3, 8), np.uint32); t[:, 1] = 1
+    KF1 = Frame(desc=d, xy=np.array([[600, 180]], f32), octave=np.zeros(1, np.int32), uright=np.array([550], f32), angle=np.zeros(1, f32))
+    KF2 = Frame(desc=t, xy=np.array([[500, 180], [520, 180], [540, 180]], f32), octave=np.zeros(3, np.int32), uright=np.array([450, 470, 490], f32),
+                angle=np.zeros(3, f32))
+    F12 = np.array([[0, 0, 0], [0, 0, -1], [0, 1, 0]], f32)
+    nd = dict(n_nodes=1, start1=[0, 1], idx1=[0], start2=[0, 3], idx2=[0, 1, 2])
+    out = ORBmatcher(gpu_ctx, 0.6, False).SearchForTriangulation(KF1, KF2, nd, [0], [0, 0, 0], OS.epipolar_lines(F12, KF1.xy), (1e6, 180.0))
+    assert out.match.tolist() == [2]
+
+
+@pytest.mark.parametrize("seed,n", [(0, 2000), (1, 700)])
+def test_stereo_matches_hamming_search(gpu_ctx, seed, n):
+    L, R = synth.make_stereo_pair(seed, n)
+    out = ORBmatcher(gpu_ctx).ComputeStereoMatches(L, R, 0.0, 100.0)
+    br, bd = OS.stereo_search(L, R, 376, 0.0, 100.0)
+    np.testing.assert_array_equal(out.match, br)
+    m = br >= 0
+    np.testing.assert_array_equal(out.best_dist[m], bd[m])
+    assert m.sum() > n // 5
+
+
+def test_long_dependency_chain_still_reaches_the_sequential_answer(gpu_ctx):
+    """Worst case for the fixed-point rounds: every query wants the same few keypoints, so query i's answer depends on all
+    earlier ones."""
+    F = synth.make_orb_frame(90, 64, n_clusters=0)
+    F.xy[:] = np.array([600.0, 180.0], f32) + np.random.default_rng(0).integers(-3, 4, (64, 2)).astype(f32)
+    F.octave[:] = 0; F.uright[:] = -1
+    base = F.desc[0].copy()
+    for k in range(64):
+        F.desc[k] = base; F.desc[k, 7] ^= np.uint32((1 << (k % 20)) - 1)          # distance k%20 from the base
+    nq = 200
+    q = dict(desc=np.repeat(base[None], nq, 0), valid=np.ones(nq, np.uint8), uv=np.tile(np.array([[600.0, 180.0]], f32), (nq, 1)),
+             ur=np.zeros(nq, f32), level=np.zeros(nq, np.int32), view_cos=np.ones(nq, f32), obs=np.ones(nq, np.uint8), occupied=np.zeros(64, np.uint8))
+    out = ORBmatcher(gpu_ctx, 1.0).SearchByProjectionMap(F, q["desc"], q["valid"], q["uv"], q["ur"], q["level"], q["view_cos"], q["obs"], q["occupied"], 3.0)
+    n_exp, slot = OS.search_by_projection_map(F, q["desc"], q["valid"], q["uv"], q["ur"], q["level"], q["view_cos"], q["obs"], q["occupied"], 3.0, 1.0)
+    assert out.n_matches == n_exp == 64 and out.rounds > 30
+    np.testing.assert_array_equal(expect_slots(out, q["occupied"]), slot)
+
+
+def test_edge_cases(gpu_ctx):
+    F = synth.make_orb_frame(95, 100)
+    q = synth.make_projection_queries(F, 95, 50)
+    m = ORBmatcher(gpu_ctx)
+    # no queries
+    out = m.SearchByProjectionMap(F, np.zeros((0, 8), np.uint32), [], np.zeros((0, 2), f32), [], np.zeros(0, np.int32), [], [], q["occupied"])
+    assert out.n_matches == 0 and out.match.shape == (0,) and (out.owner == -1).all()
+    # no keypoints
+    E = Frame(desc=np.zeros((0, 8), np.uint32), xy=np.zeros((0, 2), f32), octave=np.zeros(0, np.int32), uright=np.zeros(0, f32), angle=np.zeros(0, f32))
+    out = m.SearchByProjectionMap(E, q["desc"], q["valid"], q["uv"], q["ur"], q["level"], q["view_cos"], q["obs"], np.zeros(0, np.uint8))
+    assert out.n_matches == 0 and (out.match == -1).all() and (out.best_dist == 256).all()
+    # everything occupied / nothing valid
+    out = m.SearchByProjectionMap(F, q["desc"], q["valid"], q["uv"], q["ur"], q["level"], q["view_cos"], q["obs"], np.ones(F.n, np.uint8))
+    assert out.n_matches == 0
+    out = m.SearchByProjectionMap(F, q["desc"], np.zeros(50, np.uint8), q["uv"], q["ur"], q["level"], q["view_cos"], q["obs"], q["occupied"])
+    assert out.n_matches == 0
+    # more keypoints than the LDS-resident limit: refused loudly, not truncated
+    big = synth.make_orb_frame(96, orb_search.MAX_KEYPOINTS + 1, n_clusters=0)
+    with pytest.raises(RuntimeError, match="supported limits"):
+        m.SearchByProjectionMap(big, q["desc"], q["valid"], q["uv"], q["ur"], q["level"], q["view_cos"], q["obs"], np.zeros(big.n, np.uint8))

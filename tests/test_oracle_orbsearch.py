@@ -1,0 +1,250 @@
+"""Known-answer tests pinning oracle/lldo_orbsearch.cpp (the CPU restatement of the reference's guided ORB searches):
+each C++ routine is checked against an independent, deliberately naive numpy/Python restatement of the same reference
+lines at small sizes, plus hand-made cases for the tie / ordering / histogram rules.  No GPU."""
+import numpy as np
+import pytest
+
+import oracle_orbsearch as OS
+from lld_slam_amd import synth
+from lld_slam_amd.orb_search import FRAME_GRID_COLS, FRAME_GRID_ROWS, Frame, orb_levels
+
+f32 = np.float32
+
+
+def popcount(a, b):
+    return int(np.unpackbits((a ^ b).view(np.uint8)).sum())
+
+
+def c_round(x):
+    """C round(): half away from zero."""
+    return int(np.floor(abs(float(x)) + 0.5) * (1 if x >= 0 else -1))
+
+
+def py_grid(F):
+    """Frame::AssignFeaturesToGrid + PosInGrid (src/Frame.cc:294-313, 446-456)."""
+    cells = {}
+    for i in range(F.n):
+        px = c_round(f32(f32(F.xy[i, 0] - f32(F.min_x)) * F.width_inv)); py = c_round(f32(f32(F.xy[i, 1] - f32(F.min_y)) * F.height_inv))
+        if px < 0 or px >= FRAME_GRID_COLS or py < 0 or py >= FRAME_GRID_ROWS:
+            continue
+        cells.setdefault((px, py), []).append(i)
+    return cells
+
+
+def py_features_in_area(F, cells, x, y, r, min_level=-1, max_level=-1):
+    """Frame::GetFeaturesInArea (src/Frame.cc:391-444), all arithmetic in float32."""
+    x, y, r = f32(x), f32(y), f32(r)
+    out = []
+    nMinCellX = max(0, int(np.floor(f32(f32(f32(x - f32(F.min_x)) - r) * F.width_inv))))
+    if nMinCellX >= FRAME_GRID_COLS: return out
+    nMaxCellX = min(FRAME_GRID_COLS - 1, int(np.ceil(f32(f32(f32(x - f32(F.min_x)) + r) * F.width_inv))))
+    if nMaxCellX < 0: return out
+    nMinCellY = max(0, int(np.floor(f32(f32(f32(y - f32(F.min_y)) - r) * F.height_inv))))
+    if nMinCellY >= FRAME_GRID_ROWS: return out
+    nMaxCellY = min(FRAME_GRID_ROWS - 1, int(np.ceil(f32(f32(f32(y - f32(F.min_y)) + r) * F.height_inv))))
+    if nMaxCellY < 0: return out
+    check = (min_level > 0) or (max_level >= 0)
+    for ix in range(nMinCellX, nMaxCellX + 1):
+        for iy in range(nMinCellY, nMaxCellY + 1):
+            for k in cells.get((ix, iy), []):
+                if check:
+                    if F.octave[k] < min_level: continue
+                    if max_level >= 0 and F.octave[k] > max_level: continue
+                if abs(f32(F.xy[k, 0] - x)) < r and abs(f32(F.xy[k, 1] - y)) < r:
+                    out.append(k)
+    return out
+
+
+def py_three_maxima(counts):
+    """ORBmatcher::ComputeThreeMaxima (src/ORBmatcher.cc:1601-1642)."""
+    max1 = max2 = max3 = 0; ind1 = ind2 = ind3 = -1
+    for i, s in enumerate(counts):
+        if s > max1: max3, max2, max1, ind3, ind2, ind1 = max2, max1, s, ind2, ind1, i
+        elif s > max2: max3, max2, ind3, ind2 = max2, s, ind2, i
+        elif s > max3: max3, ind3 = s, i
+    if max2 < f32(0.1) * f32(max1): ind2 = ind3 = -1
+    elif max3 < f32(0.1) * f32(max1): ind3 = -1
+    return [ind1, ind2, ind3]
+
+
+def py_rot_bin(a1, a2):
+    rot = f32(f32(a1) - f32(a2))
+    if rot < 0: rot = f32(rot + f32(360.0))
+    b = c_round(f32(rot * f32(f32(1.0) / f32(30))))
+    return 0 if b == 30 else b
+
+
+# --------------------------------------------------------------------------------------------------------------------
+def test_scale_tables_are_cumulative_float_products():
+    s, s2, inv = orb_levels(1.2, 8)
+    assert s.dtype == np.float32 and s[0] == 1.0 and s[1] == f32(1.2) and s[2] == f32(f32(1.2) * f32(1.2))
+    assert np.array_equal(s2, s * s) and np.array_equal(inv, f32(1.0) / s2)
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_features_in_area_matches_the_naive_restatement(seed):
+    F = synth.make_orb_frame(seed, 600)
+    cells = py_grid(F)
+    rng = np.random.default_rng(seed)
+    for _ in range(300):
+        x, y = rng.uniform(-40, F.max_x + 40), rng.uniform(-40, F.max_y + 40)
+        r = float(rng.choice([2.5, 4.0, 7.0, 15.0, 40.0]) * F.scale[rng.integers(0, 8)])
+        lv = int(rng.integers(0, 8)); mode = rng.integers(0, 4)
+        mn, mx = [(-1, -1), (lv - 1, lv), (lv, -1), (0, lv)][mode]
+        got = OS.features_in_area(F, x, y, r, mn, mx).tolist()
+        assert got == py_features_in_area(F, cells, x, y, r, mn, mx)
+
+
+def test_features_in_area_visits_columns_then_rows_then_insertion_order():
+    # five keypoints: two share a cell (index order inside the cell), the others sit in cells visited later / earlier
+    xy = np.array([[100, 100], [100.5, 100.2], [100, 120], [125, 90], [80, 130]], f32)
+    F = Frame(desc=np.zeros((5, 8), np.uint32), xy=xy, octave=np.zeros(5, np.int32), uright=-np.ones(5, f32), angle=np.zeros(5, f32))
+    got = OS.features_in_area(F, 100.0, 105.0, 60.0).tolist()
+    cells = py_grid(F)
+    order = sorted(range(5), key=lambda k: ([c for c, v in cells.items() if k in v][0], k))
+    assert got == order and got.index(0) < got.index(1)
+    # |dx| < r is strict: a keypoint exactly r away is not returned
+    assert 3 not in OS.features_in_area(F, 100.0, 90.0, 25.0).tolist()
+    assert 3 in OS.features_in_area(F, 100.0, 90.0, 25.001).tolist()
+
+
+def test_three_maxima_known_answers():
+    def run(c): return OS.three_maxima(np.array(c + [0] * (30 - len(c)), np.int32)).tolist()
+    assert run([5, 9, 7, 1]) == [1, 2, 0]
+    assert run([10, 10, 10, 10]) == [0, 1, 2]                 # strict '>' keeps the first of equal bins
+    assert run([100, 9, 8]) == [0, -1, -1]                    # max2 < 0.1*max1 drops both
+    assert run([100, 10, 9]) == [0, 1, -1]                    # 10 is not < 10.0; 9 is
+    assert run([0] * 30) == [-1, -1, -1]
+    rng = np.random.default_rng(3)
+    for _ in range(200):
+        c = rng.integers(0, 40, 30).tolist()
+        assert run(c) == py_three_maxima(c)
+
+
+def py_search_map(F, q, th, nn):
+    """ORBmatcher::SearchByProjection(Frame&, vpMapPoints, th) (src/ORBmatcher.cc:45-129), naive."""
+    cells = py_grid(F)
+    slot = np.where(q["occupied"] != 0, 1 << 20, -1).astype(np.int64); slot_obs = q["occupied"].copy()
+    n = 0
+    for i in range(q["desc"].shape[0]):
+        if not q["valid"][i]: continue
+        lvl = int(q["level"][i])
+        r = f32(2.5) if float(q["view_cos"][i]) > 0.998 else f32(4.0)
+        if f32(th) != f32(1.0): r = f32(r * f32(th))
+        rad = f32(r * F.scale[lvl])
+        best = best2 = 256; bl = bl2 = -1; bi = -1
+        for k in py_features_in_area(F, cells, q["uv"][i, 0], q["uv"][i, 1], rad, lvl - 1, lvl):
+            if slot[k] >= 0 and slot_obs[k]: continue
+            if F.uright[k] > 0 and abs(f32(q["ur"][i] - F.uright[k])) > rad: continue
+            d = popcount(q["desc"][i], F.desc[k])
+            if d < best: best2, best, bl2, bl, bi = best, d, bl, int(F.octave[k]), k
+            elif d < best2: bl2, best2 = int(F.octave[k]), d
+        if best <= 100:
+            if bl == bl2 and f32(best) > f32(f32(nn) * f32(best2)): continue
+            slot[bi] = i; slot_obs[bi] = q["obs"][i]; n += 1
+    return n, slot
+
+
+@pytest.mark.parametrize("seed,th", [(0, 1.0), (1, 3.0)])
+def test_search_by_projection_map_matches_the_naive_restatement(seed, th):
+    F = synth.make_orb_frame(10 + seed, 500, n_clusters=30)
+    q = synth.make_projection_queries(F, seed, 400, dup_frac=0.3)
+    n, slot = OS.search_by_projection_map(F, q["desc"], q["valid"], q["uv"], q["ur"], q["level"], q["view_cos"], q["obs"], q["occupied"], th, 0.8)
+    n_py, slot_py = py_search_map(F, q, th, 0.8)
+    assert n == n_py and n > 50
+    np.testing.assert_array_equal(slot, slot_py)
+
+
+def test_search_by_projection_frame_rotation_filter_and_overwrites():
+    """Frame-to-frame search: queries without observations do not block, so a later query can overwrite their keypoint,
+    and the rotation filter NULLs every slot recorded in a dropped bin (src/ORBmatcher.cc:1425-1462)."""
+    F = synth.make_orb_frame(20, 500, n_clusters=30)
+    q = synth.make_projection_queries(F, 5, 450, dup_frac=0.4)
+    q["obs"][::3] = 0
+    n, slot = OS.search_by_projection_frame(F, q["desc"], q["valid"], q["uv"], q["ur"], q["level"], q["angle"], q["obs"], q["occupied"], 0, 7.0, True)
+    n0, slot0 = OS.search_by_projection_frame(F, q["desc"], q["valid"], q["uv"], q["ur"], q["level"], q["angle"], q["obs"], q["occupied"], 0, 7.0, False)
+    # reconstruct the filter from the unfiltered run: bins of every accepted (query -> keypoint) event
+    cells = py_grid(F)
+    events, sl, so = [], np.where(q["occupied"] != 0, 1 << 20, -1), q["occupied"].copy()
+    for i in range(450):
+        if not q["valid"][i]: continue
+        o = int(q["level"][i]); rad = f32(f32(7.0) * F.scale[o]); best, bi = 256, -1
+        for k in py_features_in_area(F, cells, q["uv"][i, 0], q["uv"][i, 1], rad, o - 1, o + 1):
+            if sl[k] >= 0 and so[k]: continue
+            if F.uright[k] > 0 and abs(f32(q["ur"][i] - F.uright[k])) > rad: continue
+            d = popcount(q["desc"][i], F.desc[k])
+            if d < best: best, bi = d, k
+        if best <= 100:
+            sl[bi] = i; so[bi] = q["obs"][i]; events.append((i, bi))
+    assert len(events) == n0 and np.array_equal(sl, slot0)
+    assert len({k for _, k in events}) < len(events)                     # the scene does contain overwrites
+    bins = [py_rot_bin(q["angle"][i], F.angle[k]) for i, k in events]
+    keep = py_three_maxima(np.bincount(bins, minlength=30).tolist())
+    for (i, k), b in zip(events, bins):
+        if b not in keep: sl[k] = -1
+    assert n == len(events) - sum(b not in keep for b in bins)
+    np.testing.assert_array_equal(slot, sl)
+    assert 0 < n < n0
+
+
+def test_bow_frame_search_is_order_dependent_and_ratio_tested():
+    F1, F2, nd = synth.make_bow_pair(0, 600, n_nodes=120)
+    valid = (np.random.default_rng(0).random(F1.n) < 0.9).astype(np.uint8)
+    n, fm = OS.search_by_bow_frame(F1, F2, nd["n_nodes"], nd["start1"], nd["idx1"], nd["start2"], nd["idx2"], valid, 0.7, False)
+    # naive restatement (src/ORBmatcher.cc:183-251)
+    fm_py = -np.ones(F2.n, np.int64); n_py = 0
+    for node in range(nd["n_nodes"]):
+        for a in nd["idx1"][nd["start1"][node]:nd["start1"][node + 1]]:
+            if not valid[a]: continue
+            b1 = b2 = 256; bi = -1
+            for b in nd["idx2"][nd["start2"][node]:nd["start2"][node + 1]]:
+                if fm_py[b] >= 0: continue
+                d = popcount(F1.desc[a], F2.desc[b])
+                if d < b1: b2, b1, bi = b1, d, b
+                elif d < b2: b2 = d
+            if b1 <= 50 and f32(b1) < f32(f32(0.7) * f32(b2)):
+                fm_py[bi] = a; n_py += 1
+    assert n == n_py and n > 100
+    np.testing.assert_array_equal(fm, fm_py)
+    assert len(set(fm[fm >= 0].tolist())) == n                           # a KF keypoint is used once
+
+
+def test_triangulation_prefers_the_last_of_equal_distances():
+    """`dist>bestDist -> continue` (src/ORBmatcher.cc:733): with equal distances the LATER candidate replaces the earlier."""
+    d = np.zeros((1, 8), np.uint32)
+    t = np.zeros((3, 8), np.uint32); t[:, 1] = 1                         # all three at distance 1
+    KF1 = Frame(desc=d, xy=np.array([[600, 180]], f32), octave=np.zeros(1, np.int32), uright=np.array([550], f32), angle=np.zeros(1, f32))
+    KF2 = Frame(desc=t, xy=np.array([[500, 180], [520, 180], [540, 180]], f32), octave=np.zeros(3, np.int32), uright=np.array([450, 470, 490], f32),
+                angle=np.zeros(3, f32))
+    F12 = np.array([[0, 0, 0], [0, 0, -1], [0, 1, 0]], f32)               # pure x-translation: epipolar lines are the rows
+    n, m12 = OS.search_for_triangulation(KF1, KF2, 1, [0, 1], [0], [0, 3], [0, 1, 2], [0], [0, 0, 0], F12, (1e6, 180.0), False, False)
+    assert n == 1 and m12.tolist() == [2]
+    # off the epipolar line by more than sqrt(3.84) px -> rejected
+    KF2.xy[2, 1] = 183.0
+    n, m12 = OS.search_for_triangulation(KF1, KF2, 1, [0, 1], [0], [0, 3], [0, 1, 2], [0], [0, 0, 0], F12, (1e6, 180.0), False, False)
+    assert m12.tolist() == [1]
+
+
+def test_stereo_search_row_band_and_thresholds():
+    L, R = synth.make_stereo_pair(0, 500)
+    br, bd = OS.stereo_search(L, R, 376, 0.0, 100.0)
+    # naive restatement (src/Frame.cc:541-613)
+    rows = [[] for _ in range(376)]
+    for iR in range(R.n):
+        r = f32(f32(2.0) * R.scale[R.octave[iR]])
+        for yi in range(int(np.floor(f32(R.xy[iR, 1] - r))), int(np.ceil(f32(R.xy[iR, 1] + r))) + 1):
+            if 0 <= yi < 376: rows[yi].append(iR)
+    exp = -np.ones(L.n, np.int64)
+    for iL in range(L.n):
+        cand = rows[int(L.xy[iL, 1])]
+        minU, maxU = f32(L.xy[iL, 0] - f32(100.0)), f32(L.xy[iL, 0] - f32(0.0))
+        if not cand or maxU < 0: continue
+        best, bi = 100, 0
+        for iR in cand:
+            if R.octave[iR] < L.octave[iL] - 1 or R.octave[iR] > L.octave[iL] + 1: continue
+            if minU <= R.xy[iR, 0] <= maxU:
+                d = popcount(L.desc[iL], R.desc[iR])
+                if d < best: best, bi = d, iR
+        if best < 75: exp[iL] = bi
+    np.testing.assert_array_equal(br, exp)
+    assert (br >= 0).sum() > 100
