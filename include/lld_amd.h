@@ -383,6 +383,9 @@ typedef struct {
 } lld_orb_search_result;
 
 int lld_orb_search_run(lld_ctx* ctx, const lld_orb_search* s, lld_orb_search_result* out);
+/* `n` independent problems (e.g. one relocalisation / loop candidate keyframe each, or the searches of several frames) in one
+ * launch: one workgroup per problem, all inputs moved in one host-to-device copy and all outputs in one copy back. */
+int lld_orb_search_batch(lld_ctx* ctx, int n, const lld_orb_search* problems, lld_orb_search_result* outs);
 
 #ifdef __cplusplus
 }

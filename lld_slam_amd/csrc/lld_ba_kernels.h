@@ -1230,7 +1230,7 @@ __global__ __launch_bounds__(kPcgThreads) void ba_pcg_kernel(BAArrays A, const B
   double* scratch = Mi + nf * 36;      // 32
   const double* Sg = A.S + W.S_off;
   const double* bs = A.bschur + W.x_off;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = kPcgThreads >> 6;
+  const int tid = threadIdx.x;
   double* ok_s = scratch + 31;         // keeps every LDS object inside the (16-B aligned) dynamic region
   if (tid == 0) *ok_s = 1.0;
   __syncthreads();

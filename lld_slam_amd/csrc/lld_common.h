@@ -29,7 +29,23 @@ struct lld_ctx {
   // scratch reused by the single-shot entry points (grown on demand, freed with the context)
   void* scratch = nullptr;
   size_t scratch_bytes = 0;
+  // pinned host staging for entry points that move many small arrays in one copy
+  void* pinned = nullptr;
+  size_t pinned_bytes = 0;
 };
+
+// Grow-only pinned host staging on the context.
+static inline int lld_ctx_pinned(lld_ctx* ctx, size_t bytes, void** out) {
+  if (bytes > ctx->pinned_bytes) {
+    if (ctx->pinned) LLD_HIP_TRY(hipHostFree(ctx->pinned));
+    ctx->pinned = nullptr; ctx->pinned_bytes = 0;
+    size_t want = bytes + (bytes >> 2) + 4096;
+    LLD_HIP_TRY(hipHostMalloc(&ctx->pinned, want, hipHostMallocDefault));
+    ctx->pinned_bytes = want;
+  }
+  *out = ctx->pinned;
+  return LLD_OK;
+}
 
 // Grow-only device scratch on the context.
 static inline int lld_ctx_scratch(lld_ctx* ctx, size_t bytes, void** out) {

@@ -1,11 +1,13 @@
 // lld_orb_search.hip — guided ORB search on the device: one kernel runs the whole body of an ORBmatcher::Search* /
 // Fuse / Frame::ComputeStereoMatches routine (reference lines cited at each rule below).
 //
-// One workgroup owns one (query set, keypoint set) problem, one wavefront owns one query at a time:
+// One workgroup owns one (query set, keypoint set) problem and one LANE owns one query (a query has only tens of candidates, so
+// the search is latency-bound: 1024 queries in flight per workgroup hide it; a batch puts one problem on each CU):
 //   * the frame's 64x48 keypoint grid (Frame::AssignFeaturesToGrid, src/Frame.cc:294-313) is rebuilt in LDS by a counting
 //     sort, so a window query touches only the grid columns GetFeaturesInArea (src/Frame.cc:391-444) would visit;
-//   * every candidate gets the 64-bit key  dist<<32 | visit-order ; the wavefront keeps the two smallest keys, which is
-//     exactly the reference's strict-'<' best / second-best bookkeeping (first visited wins ties) without visiting in order;
+//   * the keypoint records and (when they fit) the descriptors stay in LDS for all rounds;
+//   * every candidate gets the 64-bit key  dist<<32 | visit-order ; the lane keeps the two smallest keys, which is exactly the
+//     reference's strict-'<' best / second-best bookkeeping (first visited wins ties) without visiting in order;
 //   * the order-dependent rule "keypoint already taken by an earlier query" (the reference writes mvpMapPoints / vpMatched
 //     inside its loop) is solved by fixed-point rounds: round r sees the keypoints claimed in round r-1 by queries with a
 //     smaller index; when a round changes no match the result is the sequential one (query i is final after i+1 rounds at
@@ -16,7 +18,6 @@
 namespace {
 
 constexpr int kThreads = 1024;
-constexpr int kWaves = kThreads / 64;
 constexpr int kHisto = 30;                 // HISTO_LENGTH, src/ORBmatcher.cc:39
 constexpr unsigned long long kNone = ~0ull;
 
@@ -47,9 +48,11 @@ struct Problem {
   float disp_min, disp_max, epi_x, epi_y; int only_stereo;
   int candidates, gates, tie_last, accept_max, ratio_mode; float nnratio; int sequential, check_orientation;
   int32_t* match; int32_t* best_dist; int32_t* second_dist; uint8_t* removed; int32_t* owner; int32_t* summary;   // summary: n_matches, rounds
+  int desc_in_lds, want_owner;
 };
 
-__device__ __forceinline__ int hamming256(const uint32_t (&a)[8], const uint32_t* __restrict__ b) {
+template <class Ptr>
+__device__ __forceinline__ int hamming256(const uint32_t (&a)[8], Ptr b) {
   const uint4 b0 = *reinterpret_cast<const uint4*>(b), b1 = *reinterpret_cast<const uint4*>(b + 4);
   return __popc(a[0] ^ b0.x) + __popc(a[1] ^ b0.y) + __popc(a[2] ^ b0.z) + __popc(a[3] ^ b0.w) +
          __popc(a[4] ^ b1.x) + __popc(a[5] ^ b1.y) + __popc(a[6] ^ b1.z) + __popc(a[7] ^ b1.w);
@@ -107,27 +110,39 @@ __device__ __forceinline__ bool gates_pass(const Problem& P, const QRec& Q, cons
 __global__ __launch_bounds__(kThreads) void orb_search_kernel(const Problem* __restrict__ problems) {
   extern __shared__ __align__(16) unsigned char lds_raw[];
   const Problem& P = problems[blockIdx.x];
-  const int nt = P.nt, nq = P.nq, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nt = P.nt, nq = P.nq, tid = threadIdx.x;
   const int n_cells = P.cols * P.rows;
-  TKey* tk = reinterpret_cast<TKey*>(lds_raw);                                  // [nt]   (grid mode: sorted by cell)
-  int* blk = reinterpret_cast<int*>(tk + nt);                                   // [nt]   first blocking query per keypoint index
+  const bool grid = P.candidates == LLD_ORB_CAND_GRID, rows = P.candidates == LLD_ORB_CAND_ROWS;
+  const bool bucketed = grid || rows;                                           // keypoints sorted by grid cell / by image row
+  TKey* tk = reinterpret_cast<TKey*>(lds_raw);                                  // [nt]   (bucketed: sorted by cell)
+  uint32_t* dsc = reinterpret_cast<uint32_t*>(tk + nt);                         // [nt][8] descriptors in tk order (when they fit)
+  int* blk = reinterpret_cast<int*>(dsc + (P.desc_in_lds ? (size_t)nt * 8 : 0));  // [nt]   first blocking query per keypoint index
   int* cell_start = blk + nt;                                                   // [n_cells + 1]
   int* hist = cell_start + n_cells + 1;                                         // [32]
   int* ctl = hist + 32;                                                         // [8]: 0 changed, 1 accepted, 2 removed, 3..5 kept bins
   int* scan = ctl + 8;                                                          // [kThreads]
+  int* cursor = scan + kThreads;                                                // [n_cells] (bucketed modes only)
 
   // ---------------------------------------------------------------- keypoints into LDS (+ grid counting sort)
-  const bool grid = P.candidates == LLD_ORB_CAND_GRID;
-  int* cursor = scan + kThreads;                                                // [n_cells] (grid mode only)
   auto load_key = [&](int k, int& cell) -> TKey {
     TKey T; T.x = P.t_xy[2 * k]; T.y = P.t_xy[2 * k + 1]; T.ur = P.t_uright ? P.t_uright[k] : -1.f;
     cell = -1;
     if (grid) {                                                                 // Frame::PosInGrid, src/Frame.cc:446-456
       const int px = (int)roundf(__fmul_rn(__fsub_rn(T.x, P.min_x), P.winv)), py = (int)roundf(__fmul_rn(__fsub_rn(T.y, P.min_y), P.hinv));
       if (px >= 0 && px < P.cols && py >= 0 && py < P.rows) cell = px * P.rows + py;
+    } else if (rows) {                                                          // bucket = image row of the keypoint (search aid only)
+      cell = min(max((int)floorf(T.y), 0), n_cells - 1);
     }
     T.meta = (P.t_octave[k] & 15) | (k << 4) | ((cell + 1) << 16) | ((P.t_occupied && P.t_occupied[k]) ? (1 << 29) : 0);
     return T;
+  };
+  auto place = [&](int pos, int k, const TKey& T) {
+    tk[pos] = T;
+    if (P.desc_in_lds) {
+      const uint4* src = reinterpret_cast<const uint4*>(P.t_desc + 8 * (size_t)k);
+      uint4* dst = reinterpret_cast<uint4*>(dsc + 8 * (size_t)pos);
+      dst[0] = src[0]; dst[1] = src[1];
+    }
   };
   for (int c = tid; c <= n_cells; c += kThreads) cell_start[c] = 0;
   for (int k = tid; k < nt; k += kThreads) blk[k] = 0x7fffffff;
@@ -136,11 +151,11 @@ __global__ __launch_bounds__(kThreads) void orb_search_kernel(const Problem* __r
   __syncthreads();
   for (int k = tid; k < nt; k += kThreads) {
     int cell; const TKey T = load_key(k, cell);
-    if (!grid) tk[k] = T;
+    if (!bucketed) place(k, k, T);
     else if (cell >= 0) atomicAdd(&cell_start[cell], 1);
   }
   __syncthreads();
-  if (grid) {
+  if (bucketed) {
     // exclusive scan of the cell counts (each thread owns a contiguous run of cells), then an unordered placement:
     // the position inside a cell is irrelevant because ties are broken by the key, not by the visit position
     const int per = (n_cells + kThreads - 1) / kThreads, c0 = min(tid * per, n_cells), c1 = min(c0 + per, n_cells);
@@ -160,101 +175,97 @@ __global__ __launch_bounds__(kThreads) void orb_search_kernel(const Problem* __r
     __syncthreads();
     for (int k = tid; k < nt; k += kThreads) {
       int cell; const TKey T = load_key(k, cell);
-      if (cell >= 0) tk[atomicAdd(&cursor[cell], 1)] = T;
+      if (cell >= 0) place(atomicAdd(&cursor[cell], 1), k, T);
     }
   }
   for (int q = tid; q < nq; q += kThreads) P.match[q] = -2;
   __syncthreads();
 
-  // ---------------------------------------------------------------- fixed-point rounds
+  // ---------------------------------------------------------------- fixed-point rounds, one lane per query
   int rounds = 0;
   for (;;) {
     rounds++;
-    for (int q = wave; q < nq; q += kWaves) {
+    for (int q = tid; q < nq; q += kThreads) {
       const QRec Q = P.q[q];
       unsigned long long b1 = kNone, b2 = kNone;
       if (Q.flags & 1) {
         uint32_t qd[8];
-#pragma unroll
-        for (int w = 0; w < 8; w++) qd[w] = P.q_desc[8 * q + w];
+        {
+          const uint4 a = *reinterpret_cast<const uint4*>(P.q_desc + 8 * (size_t)q), b = *reinterpret_cast<const uint4*>(P.q_desc + 8 * (size_t)q + 4);
+          qd[0] = a.x; qd[1] = a.y; qd[2] = a.z; qd[3] = a.w; qd[4] = b.x; qd[5] = b.y; qd[6] = b.z; qd[7] = b.w;
+        }
+        auto visit = [&](int pos, const TKey& T, unsigned key) {
+          if (!gates_pass(P, Q, T, q, blk)) return;
+          const int d = P.desc_in_lds ? hamming256(qd, dsc + 8 * (size_t)pos) : hamming256(qd, P.t_desc + 8 * (size_t)tk_idx(T.meta));
+          if (P.tie_last) key = ~key;
+          top2_insert(((unsigned long long)d << 32) | key, b1, b2);
+        };
         if (grid) {
           // GetFeaturesInArea cell range, src/Frame.cc:396-410 (float arithmetic, floor/ceil, clamps and early returns)
           const int minCX = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(Q.u, P.min_x), Q.radius), P.winv)));
           const int maxCX = min(P.cols - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(Q.u, P.min_x), Q.radius), P.winv)));
           const int minCY = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(Q.v, P.min_y), Q.radius), P.hinv)));
           const int maxCY = min(P.rows - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(Q.v, P.min_y), Q.radius), P.hinv)));
-          if (minCX < P.cols && maxCX >= 0 && minCY < P.rows && maxCY >= 0) {
+          if (minCX < P.cols && maxCX >= 0 && minCY < P.rows && maxCY >= 0 && maxCY >= minCY) {
             for (int ix = minCX; ix <= maxCX; ix++) {
-              const int j0 = cell_start[ix * P.rows + minCY], j1 = (maxCY >= minCY) ? cell_start[ix * P.rows + maxCY + 1] : j0;
-              for (int j = j0 + lane; j < j1; j += 64) {
+              const int j0 = cell_start[ix * P.rows + minCY], j1 = cell_start[ix * P.rows + maxCY + 1];   // one column = one contiguous run
+              for (int j = j0; j < j1; j++) {
                 const TKey T = tk[j];
                 if (!(fabsf(__fsub_rn(T.x, Q.u)) < Q.radius && fabsf(__fsub_rn(T.y, Q.v)) < Q.radius)) continue;   // Frame.cc:433-437
-                if (!gates_pass(P, Q, T, q, blk)) continue;
-                const int k = tk_idx(T.meta);
-                unsigned key = ((unsigned)tk_cell(T.meta) << 12) | (unsigned)k;
-                if (P.tie_last) key = ~key;
-                top2_insert(((unsigned long long)hamming256(qd, P.t_desc + 8 * k) << 32) | key, b1, b2);
+                visit(j, T, ((unsigned)tk_cell(T.meta) << 12) | (unsigned)tk_idx(T.meta));
               }
             }
           }
         } else if (P.candidates == LLD_ORB_CAND_CSR) {
-          for (int p = Q.cs + lane; p < Q.ce; p += 64) {
+          for (int p = Q.cs; p < Q.ce; p++) {
             const int k = P.cand_idx[p];
-            const TKey T = tk[k];
-            if (!gates_pass(P, Q, T, q, blk)) continue;
-            unsigned key = (unsigned)(p - Q.cs);
-            if (P.tie_last) key = ~key;
-            top2_insert(((unsigned long long)hamming256(qd, P.t_desc + 8 * k) << 32) | key, b1, b2);
+            visit(k, tk[k], (unsigned)(p - Q.cs));
           }
-        } else {
-          const bool rows = P.candidates == LLD_ORB_CAND_ROWS;
+        } else if (rows) {
+          // Frame::ComputeStereoMatches: vRowIndices[vL] holds right keypoint iR iff floor(yR-r) <= (int)vL <= ceil(yR+r), r = 2*scale[octave]
+          // (src/Frame.cc:546-556).  Only the row buckets that can satisfy this are scanned; the exact test follows.
           const float minU = __fsub_rn(Q.u, P.disp_max), maxU = __fsub_rn(Q.u, P.disp_min);                       // Frame.cc:574-575
           const long long row = (long long)Q.v;                                                                    // vRowIndices[vL], :569
-          if (!(rows && maxU < 0.f)) {                                                                             // :577-578
-            for (int k = lane; k < nt; k += 64) {
-              const TKey T = tk[k];
-              if (rows) {                                                                                          // :546-556, :594-596
-                const float r = __fmul_rn(2.0f, P.scale[tk_oct(T.meta)]);
-                const long long maxr = (long long)ceilf(__fadd_rn(T.y, r)), minr = (long long)floorf(__fsub_rn(T.y, r));
-                if (row < minr || row > maxr) continue;
-                if (!(T.x >= minU && T.x <= maxU)) continue;
-              }
-              if (!gates_pass(P, Q, T, q, blk)) continue;
-              unsigned key = (unsigned)k;
-              if (P.tie_last) key = ~key;
-              top2_insert(((unsigned long long)hamming256(qd, P.t_desc + 8 * k) << 32) | key, b1, b2);
+          if (!(maxU < 0.f)) {                                                                                     // :577-578
+            float rmax = 0.f;
+            for (int l = 0; l < LLD_ORB_MAX_LEVELS; l++) rmax = fmaxf(rmax, __fmul_rn(2.0f, P.scale[l]));
+            const long long margin = (long long)ceilf(rmax) + 2;
+            const int lo = (int)min(max(row - margin, 0ll), (long long)n_cells - 1), hi = (int)min(max(row + margin, 0ll), (long long)n_cells - 1);
+            for (int j = cell_start[lo]; j < cell_start[hi + 1]; j++) {
+              const TKey T = tk[j];
+              const float r = __fmul_rn(2.0f, P.scale[tk_oct(T.meta)]);
+              const long long maxr = (long long)ceilf(__fadd_rn(T.y, r)), minr = (long long)floorf(__fsub_rn(T.y, r));
+              if (row < minr || row > maxr) continue;
+              if (!(T.x >= minU && T.x <= maxU)) continue;                                                         // :594-596
+              visit(j, T, (unsigned)tk_idx(T.meta));
             }
           }
-        }
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) {
-          const unsigned long long o1 = shfl_xor_u64(b1, m), o2 = shfl_xor_u64(b2, m);
-          const unsigned long long lo = b1 < o1 ? b1 : o1, hi = b1 < o1 ? o1 : b1, s2 = b2 < o2 ? b2 : o2;
-          b1 = lo; b2 = hi < s2 ? hi : s2;
+        } else {
+          for (int k = 0; k < nt; k++) visit(k, tk[k], (unsigned)k);
         }
       }
-      if (lane == 0) {
-        auto decode = [&](unsigned long long c) -> int {
-          unsigned key = (unsigned)(c & 0xffffffffu);
-          if (P.tie_last) key = ~key;
-          if (grid) return (int)(key & 4095u);
-          if (P.candidates == LLD_ORB_CAND_CSR) return P.cand_idx[Q.cs + (int)key];
-          return (int)key;
-        };
-        int m = -1, bd = 256, sd = 256;
-        if (b1 != kNone) {
-          bd = (int)(b1 >> 32);
-          const int bi = decode(b1);
-          int lvl1 = P.t_octave[bi], lvl2 = -1;
-          if (b2 != kNone) { sd = (int)(b2 >> 32); lvl2 = P.t_octave[decode(b2)]; }
-          bool ok = bd <= P.accept_max;
-          if (ok && P.ratio_mode == 1) ok = (float)bd < __fmul_rn(P.nnratio, (float)sd);                          // ORBmatcher.cc:226-228
-          if (ok && P.ratio_mode == 2 && lvl1 == lvl2 && (float)bd > __fmul_rn(P.nnratio, (float)sd)) ok = false;   // :118-121
-          if (ok) m = bi;
+      auto decode = [&](unsigned long long c) -> int {
+        unsigned key = (unsigned)(c & 0xffffffffu);
+        if (P.tie_last) key = ~key;
+        if (grid) return (int)(key & 4095u);
+        if (P.candidates == LLD_ORB_CAND_CSR) return P.cand_idx[Q.cs + (int)key];
+        return (int)key;
+      };
+      int m = -1, bd = 256, sd = 256;
+      if (b1 != kNone) {
+        bd = (int)(b1 >> 32);
+        const int bi = decode(b1);
+        bool ok = bd <= P.accept_max;
+        if (b2 != kNone) sd = (int)(b2 >> 32);
+        if (ok && P.ratio_mode == 1) ok = (float)bd < __fmul_rn(P.nnratio, (float)sd);                            // ORBmatcher.cc:226-228
+        if (ok && P.ratio_mode == 2) {                                                                            // :118-121
+          const int lvl1 = P.t_octave[bi], lvl2 = (b2 != kNone) ? P.t_octave[decode(b2)] : -1;
+          if (lvl1 == lvl2 && (float)bd > __fmul_rn(P.nnratio, (float)sd)) ok = false;
         }
-        if (P.match[q] != m) { P.match[q] = m; ctl[0] = 1; }
-        P.best_dist[q] = bd; P.second_dist[q] = sd;
+        if (ok) m = bi;
       }
+      if (P.match[q] != m) { P.match[q] = m; ctl[0] = 1; }
+      P.best_dist[q] = bd; P.second_dist[q] = sd;
     }
     __syncthreads();
     const int changed = ctl[0];
@@ -319,18 +330,20 @@ __global__ __launch_bounds__(kThreads) void orb_search_kernel(const Problem* __r
     P.removed[q] = rem;
   }
   __syncthreads();
-  if (P.owner) for (int k = tid; k < nt; k += kThreads) P.owner[k] = owner[k];
+  if (P.want_owner) for (int k = tid; k < nt; k += kThreads) P.owner[k] = owner[k];
   if (tid == 0) { P.summary[0] = ctl[1] - ctl[2]; P.summary[1] = rounds; }
 }
 
-size_t lds_bytes(int nt, int n_cells, bool grid) {
-  return (size_t)nt * sizeof(TKey) + (size_t)nt * 4 + (size_t)(n_cells + 1) * 4 + 32 * 4 + 8 * 4 + kThreads * 4 + (grid ? (size_t)n_cells * 4 : 0) + 16;
+constexpr size_t kLdsLimit = 160 * 1024 - 512;
+constexpr int kRowBuckets = 1024;          // ROWS mode: one bucket per image row, rows beyond are clamped into the last bucket
+
+size_t lds_bytes(int nt, int n_cells, bool grid, bool desc) {
+  return (size_t)nt * sizeof(TKey) + (desc ? (size_t)nt * 32 : 0) + (size_t)nt * 4 + (size_t)(n_cells + 1) * 4 + 32 * 4 + 8 * 4 + kThreads * 4 +
+         (grid ? (size_t)n_cells * 4 : 0) + 16;
 }
 
-}  // namespace
-
-extern "C" int lld_orb_search_run(lld_ctx* ctx, const lld_orb_search* s, lld_orb_search_result* out) {
-  if (!ctx || !s || !out) return LLD_ERR_INVALID;
+int validate(const lld_orb_search* s, const lld_orb_search_result* out) {
+  if (!s || !out) return LLD_ERR_INVALID;
   const int nt = s->nt, nq = s->nq;
   if (nt < 0 || nq < 0) return LLD_ERR_INVALID;
   if (nt > LLD_ORB_MAX_KEYPOINTS) return LLD_ERR_UNSUPPORTED;
@@ -350,88 +363,141 @@ extern "C" int lld_orb_search_run(lld_ctx* ctx, const lld_orb_search* s, lld_orb
   if (s->check_orientation && (!s->q_angle || (nt > 0 && !s->t_angle))) return LLD_ERR_INVALID;
   if (s->n_levels < 0 || s->n_levels > LLD_ORB_MAX_LEVELS) return LLD_ERR_UNSUPPORTED;
   for (int k = 0; k < nt; k++) if (s->t_octave[k] < 0 || s->t_octave[k] >= LLD_ORB_MAX_LEVELS) return LLD_ERR_INVALID;
-  const int ncand = (s->candidates == LLD_ORB_CAND_CSR) ? s->n_cand : 0;
   if (s->candidates == LLD_ORB_CAND_CSR) {
-    for (int q = 0; q < nq; q++) if (s->cand_range[2 * q] < 0 || s->cand_range[2 * q + 1] < s->cand_range[2 * q] || s->cand_range[2 * q + 1] > ncand) return LLD_ERR_INVALID;
-    for (int p = 0; p < ncand; p++) if (s->cand_idx[p] < 0 || s->cand_idx[p] >= nt) return LLD_ERR_INVALID;
+    for (int q = 0; q < nq; q++)
+      if (s->cand_range[2 * q] < 0 || s->cand_range[2 * q + 1] < s->cand_range[2 * q] || s->cand_range[2 * q + 1] > s->n_cand) return LLD_ERR_INVALID;
+    for (int p = 0; p < s->n_cand; p++) if (s->cand_idx[p] < 0 || s->cand_idx[p] >= nt) return LLD_ERR_INVALID;
   }
-  out->n_matches = 0; out->rounds = 0;
-  if (nq == 0) { if (out->owner) for (int k = 0; k < nt; k++) out->owner[k] = -1; return LLD_OK; }
+  return LLD_OK;
+}
+
+inline size_t al(size_t b) { return (b + 63) & ~size_t(63); }
+
+// Byte layout of one problem inside the packed input / output regions (identical in pinned host memory and in HBM).
+struct Layout {
+  size_t q, q_desc, t_desc, t_xy, t_oct, t_ur, t_ang, t_occ, cand, in_end;      // offsets from the start of the input region
+  size_t match, bd, sd, owner, sum, rem, out_end;                               // offsets from the start of the output region
+};
+
+}  // namespace
+
+extern "C" int lld_orb_search_batch(lld_ctx* ctx, int n, const lld_orb_search* problems, lld_orb_search_result* outs) {
+  if (!ctx || n < 0 || (n > 0 && (!problems || !outs))) return LLD_ERR_INVALID;
+  for (int i = 0; i < n; i++) { const int st = validate(&problems[i], &outs[i]); if (st) return st; }
+  if (n == 0) return LLD_OK;
   LLD_HIP_TRY(hipSetDevice(ctx->device));
 
-  // ---- pack the queries
-  std::vector<QRec> qr((size_t)nq);
-  for (int q = 0; q < nq; q++) {
-    QRec& Q = qr[q]; std::memset(&Q, 0, sizeof(Q));
-    if (s->q_uv) { Q.u = s->q_uv[2 * q]; Q.v = s->q_uv[2 * q + 1]; }
-    if (s->q_radius) Q.radius = s->q_radius[q];
-    if (s->q_uright) Q.ur = s->q_uright[q];
-    if (s->q_stereo_radius) Q.stereo_radius = s->q_stereo_radius[q];
-    if (s->q_angle) Q.angle = s->q_angle[q];
-    if (s->q_epiline) { Q.ea = s->q_epiline[3 * q]; Q.eb = s->q_epiline[3 * q + 1]; Q.ec = s->q_epiline[3 * q + 2]; }
-    Q.level_min = s->q_level_min ? s->q_level_min[q] : -1;
-    Q.level_max = s->q_level_max ? s->q_level_max[q] : -1;
-    Q.flags = ((!s->q_valid || s->q_valid[q]) ? 1 : 0) | ((!s->q_blocks || s->q_blocks[q]) ? 2 : 0) | ((s->q_stereo && s->q_stereo[q]) ? 4 : 0);
-    if (s->candidates == LLD_ORB_CAND_CSR) { Q.cs = s->cand_range[2 * q]; Q.ce = s->cand_range[2 * q + 1]; }
+  // ---- lay the batch out: [Problem x n | per-problem inputs ...] and [per-problem outputs ...]
+  std::vector<Layout> lay((size_t)n);
+  size_t in_off = al(sizeof(Problem) * (size_t)n), out_off = 0, lds_max = 0;
+  for (int i = 0; i < n; i++) {
+    const lld_orb_search& s = problems[i]; Layout& L = lay[i];
+    const size_t nt = s.nt, nq = s.nq, nc = (s.candidates == LLD_ORB_CAND_CSR) ? s.n_cand : 0;
+    L.q = in_off; in_off += al(nq * sizeof(QRec));
+    L.q_desc = in_off; in_off += al(nq * 32);
+    L.t_desc = in_off; in_off += al(nt * 32);
+    L.t_xy = in_off; in_off += al(nt * 8);
+    L.t_oct = in_off; in_off += al(nt * 4);
+    L.t_ur = in_off; in_off += s.t_uright ? al(nt * 4) : 0;
+    L.t_ang = in_off; in_off += s.t_angle ? al(nt * 4) : 0;
+    L.t_occ = in_off; in_off += s.t_occupied ? al(nt) : 0;
+    L.cand = in_off; in_off += al(nc * 4);
+    L.in_end = in_off;
+    L.match = out_off; out_off += al(nq * 4);
+    L.bd = out_off; out_off += al(nq * 4);
+    L.sd = out_off; out_off += al(nq * 4);
+    L.owner = out_off; out_off += al(nt * 4);
+    L.sum = out_off; out_off += al(16);
+    L.rem = out_off; out_off += al(nq);
+    L.out_end = out_off;
+  }
+  const size_t in_bytes = in_off, out_bytes = out_off;
+  void* hbase; int st = lld_ctx_pinned(ctx, in_bytes + out_bytes, &hbase); if (st) return st;
+  void* dbase; st = lld_ctx_scratch(ctx, in_bytes + out_bytes + 256, &dbase); if (st) return st;
+  char* h = (char*)hbase; char* d = (char*)dbase;
+  char* d_out = d + in_bytes; char* h_out = h + in_bytes;
+
+  for (int i = 0; i < n; i++) {
+    const lld_orb_search& s = problems[i]; const Layout& L = lay[i];
+    const int nt = s.nt, nq = s.nq;
+    const bool grid = s.candidates == LLD_ORB_CAND_GRID;
+    QRec* qr = reinterpret_cast<QRec*>(h + L.q);
+    for (int q = 0; q < nq; q++) {
+      QRec& Q = qr[q]; std::memset(&Q, 0, sizeof(Q));
+      if (s.q_uv) { Q.u = s.q_uv[2 * q]; Q.v = s.q_uv[2 * q + 1]; }
+      if (s.q_radius) Q.radius = s.q_radius[q];
+      if (s.q_uright) Q.ur = s.q_uright[q];
+      if (s.q_stereo_radius) Q.stereo_radius = s.q_stereo_radius[q];
+      if (s.q_angle) Q.angle = s.q_angle[q];
+      if (s.q_epiline) { Q.ea = s.q_epiline[3 * q]; Q.eb = s.q_epiline[3 * q + 1]; Q.ec = s.q_epiline[3 * q + 2]; }
+      Q.level_min = s.q_level_min ? s.q_level_min[q] : -1;
+      Q.level_max = s.q_level_max ? s.q_level_max[q] : -1;
+      Q.flags = ((!s.q_valid || s.q_valid[q]) ? 1 : 0) | ((!s.q_blocks || s.q_blocks[q]) ? 2 : 0) | ((s.q_stereo && s.q_stereo[q]) ? 4 : 0);
+      if (s.candidates == LLD_ORB_CAND_CSR) { Q.cs = s.cand_range[2 * q]; Q.ce = s.cand_range[2 * q + 1]; }
+    }
+    if (nq) std::memcpy(h + L.q_desc, s.q_desc, (size_t)nq * 32);
+    if (nt) {
+      std::memcpy(h + L.t_desc, s.t_desc, (size_t)nt * 32);
+      std::memcpy(h + L.t_xy, s.t_xy, (size_t)nt * 8);
+      std::memcpy(h + L.t_oct, s.t_octave, (size_t)nt * 4);
+      if (s.t_uright) std::memcpy(h + L.t_ur, s.t_uright, (size_t)nt * 4);
+      if (s.t_angle) std::memcpy(h + L.t_ang, s.t_angle, (size_t)nt * 4);
+      if (s.t_occupied) std::memcpy(h + L.t_occ, s.t_occupied, (size_t)nt);
+    }
+    if (s.candidates == LLD_ORB_CAND_CSR && s.n_cand) std::memcpy(h + L.cand, s.cand_idx, (size_t)s.n_cand * 4);
+
+    Problem& P = reinterpret_cast<Problem*>(h)[i]; std::memset(&P, 0, sizeof(P));
+    P.nt = nt; P.nq = nq;
+    P.t_desc = reinterpret_cast<const uint32_t*>(d + L.t_desc); P.t_xy = reinterpret_cast<const float*>(d + L.t_xy);
+    P.t_octave = reinterpret_cast<const int32_t*>(d + L.t_oct);
+    P.t_uright = s.t_uright ? reinterpret_cast<const float*>(d + L.t_ur) : nullptr;
+    P.t_angle = s.t_angle ? reinterpret_cast<const float*>(d + L.t_ang) : nullptr;
+    P.t_occupied = s.t_occupied ? reinterpret_cast<const uint8_t*>(d + L.t_occ) : nullptr;
+    P.q_desc = reinterpret_cast<const uint32_t*>(d + L.q_desc); P.q = reinterpret_cast<const QRec*>(d + L.q);
+    P.cand_idx = reinterpret_cast<const int32_t*>(d + L.cand);
+    P.min_x = s.grid_min_x; P.min_y = s.grid_min_y; P.winv = s.grid_width_inv; P.hinv = s.grid_height_inv;
+    P.cols = grid ? s.grid_cols : 1; P.rows = grid ? s.grid_rows : (s.candidates == LLD_ORB_CAND_ROWS ? kRowBuckets : 1);
+    P.n_levels = s.n_levels;
+    for (int l = 0; l < LLD_ORB_MAX_LEVELS; l++) {
+      P.scale[l] = (s.level_scale && l < s.n_levels) ? s.level_scale[l] : 1.f;
+      P.sigma2[l] = (s.level_sigma2 && l < s.n_levels) ? s.level_sigma2[l] : 1.f;
+      P.inv_sigma2[l] = (s.level_inv_sigma2 && l < s.n_levels) ? s.level_inv_sigma2[l] : 1.f;
+    }
+    P.disp_min = s.disp_min; P.disp_max = s.disp_max; P.epi_x = s.epipole_x; P.epi_y = s.epipole_y; P.only_stereo = s.only_stereo;
+    P.candidates = s.candidates; P.gates = s.gates; P.tie_last = s.tie_last; P.accept_max = s.accept_max; P.ratio_mode = s.ratio_mode;
+    P.nnratio = s.nnratio; P.sequential = s.sequential; P.check_orientation = s.check_orientation;
+    P.match = reinterpret_cast<int32_t*>(d_out + L.match); P.best_dist = reinterpret_cast<int32_t*>(d_out + L.bd);
+    P.second_dist = reinterpret_cast<int32_t*>(d_out + L.sd); P.removed = reinterpret_cast<uint8_t*>(d_out + L.rem);
+    P.owner = reinterpret_cast<int32_t*>(d_out + L.owner); P.summary = reinterpret_cast<int32_t*>(d_out + L.sum);
+    P.want_owner = outs[i].owner != nullptr;
+    const bool bucketed = grid || s.candidates == LLD_ORB_CAND_ROWS;
+    P.desc_in_lds = lds_bytes(nt, P.cols * P.rows, bucketed, true) <= kLdsLimit;
+    lds_max = std::max(lds_max, lds_bytes(nt, P.cols * P.rows, bucketed, P.desc_in_lds != 0));
   }
 
-  // ---- device buffers out of the context scratch
-  const size_t b_td = lld_slab::pad((size_t)nt * 32 + 32), b_txy = lld_slab::pad((size_t)nt * 8 + 8), b_ti = lld_slab::pad((size_t)nt * 4 + 4), b_tb = lld_slab::pad((size_t)nt + 1);
-  const size_t b_qd = lld_slab::pad((size_t)nq * 32), b_q = lld_slab::pad((size_t)nq * sizeof(QRec)), b_c = lld_slab::pad((size_t)ncand * 4 + 4);
-  const size_t b_oi = lld_slab::pad((size_t)nq * 4), b_ob = lld_slab::pad((size_t)nq);
-  const size_t need = b_td + b_txy + 4 * b_ti + b_tb + b_qd + b_q + b_c + 3 * b_oi + b_ob + lld_slab::pad(sizeof(Problem)) + 256;
-  void* base; int st = lld_ctx_scratch(ctx, need, &base); if (st) return st;
-  lld_slab sl; sl.base = (char*)base;
-  uint32_t* d_td = sl.take<uint32_t>((size_t)nt * 8 + 8); float* d_txy = sl.take<float>((size_t)nt * 2 + 2); int32_t* d_toct = sl.take<int32_t>(nt + 1);
-  float* d_tur = sl.take<float>(nt + 1); float* d_tang = sl.take<float>(nt + 1); int32_t* d_owner = sl.take<int32_t>(nt + 1); uint8_t* d_tocc = sl.take<uint8_t>(nt + 1);
-  uint32_t* d_qd = sl.take<uint32_t>((size_t)nq * 8); QRec* d_q = sl.take<QRec>(nq); int32_t* d_c = sl.take<int32_t>(ncand + 1);
-  int32_t* d_match = sl.take<int32_t>(nq); int32_t* d_bd = sl.take<int32_t>(nq); int32_t* d_sd = sl.take<int32_t>(nq); uint8_t* d_rem = sl.take<uint8_t>(nq);
-  Problem* d_P = sl.take<Problem>(1); int32_t* d_sum = sl.take<int32_t>(2);
   hipStream_t sm = ctx->stream;
-  if (nt) {
-    LLD_HIP_TRY(hipMemcpyAsync(d_td, s->t_desc, (size_t)nt * 32, hipMemcpyHostToDevice, sm));
-    LLD_HIP_TRY(hipMemcpyAsync(d_txy, s->t_xy, (size_t)nt * 8, hipMemcpyHostToDevice, sm));
-    LLD_HIP_TRY(hipMemcpyAsync(d_toct, s->t_octave, (size_t)nt * 4, hipMemcpyHostToDevice, sm));
-    if (s->t_uright) LLD_HIP_TRY(hipMemcpyAsync(d_tur, s->t_uright, (size_t)nt * 4, hipMemcpyHostToDevice, sm));
-    if (s->t_angle) LLD_HIP_TRY(hipMemcpyAsync(d_tang, s->t_angle, (size_t)nt * 4, hipMemcpyHostToDevice, sm));
-    if (s->t_occupied) LLD_HIP_TRY(hipMemcpyAsync(d_tocc, s->t_occupied, (size_t)nt, hipMemcpyHostToDevice, sm));
-  }
-  LLD_HIP_TRY(hipMemcpyAsync(d_qd, s->q_desc, (size_t)nq * 32, hipMemcpyHostToDevice, sm));
-  LLD_HIP_TRY(hipMemcpyAsync(d_q, qr.data(), (size_t)nq * sizeof(QRec), hipMemcpyHostToDevice, sm));
-  if (ncand) LLD_HIP_TRY(hipMemcpyAsync(d_c, s->cand_idx, (size_t)ncand * 4, hipMemcpyHostToDevice, sm));
-
-  Problem P; std::memset(&P, 0, sizeof(P));
-  P.nt = nt; P.nq = nq;
-  P.t_desc = d_td; P.t_xy = d_txy; P.t_octave = d_toct; P.t_uright = s->t_uright ? d_tur : nullptr; P.t_angle = s->t_angle ? d_tang : nullptr;
-  P.t_occupied = s->t_occupied ? d_tocc : nullptr;
-  P.q_desc = d_qd; P.q = d_q; P.cand_idx = d_c;
-  P.min_x = s->grid_min_x; P.min_y = s->grid_min_y; P.winv = s->grid_width_inv; P.hinv = s->grid_height_inv;
-  P.cols = grid ? s->grid_cols : 1; P.rows = grid ? s->grid_rows : 1;
-  P.n_levels = s->n_levels;
-  for (int i = 0; i < LLD_ORB_MAX_LEVELS; i++) {
-    P.scale[i] = (s->level_scale && i < s->n_levels) ? s->level_scale[i] : 1.f;
-    P.sigma2[i] = (s->level_sigma2 && i < s->n_levels) ? s->level_sigma2[i] : 1.f;
-    P.inv_sigma2[i] = (s->level_inv_sigma2 && i < s->n_levels) ? s->level_inv_sigma2[i] : 1.f;
-  }
-  P.disp_min = s->disp_min; P.disp_max = s->disp_max; P.epi_x = s->epipole_x; P.epi_y = s->epipole_y; P.only_stereo = s->only_stereo;
-  P.candidates = s->candidates; P.gates = s->gates; P.tie_last = s->tie_last; P.accept_max = s->accept_max; P.ratio_mode = s->ratio_mode;
-  P.nnratio = s->nnratio; P.sequential = s->sequential; P.check_orientation = s->check_orientation;
-  P.match = d_match; P.best_dist = d_bd; P.second_dist = d_sd; P.removed = d_rem; P.owner = d_owner; P.summary = d_sum;
-  LLD_HIP_TRY(hipMemcpyAsync(d_P, &P, sizeof(P), hipMemcpyHostToDevice, sm));
-
-  const size_t lds = lds_bytes(nt, P.cols * P.rows, grid);
+  LLD_HIP_TRY(hipMemcpyAsync(d, h, in_bytes, hipMemcpyHostToDevice, sm));
   static bool lds_raised = false;
-  if (!lds_raised) { LLD_HIP_TRY(hipFuncSetAttribute((const void*)orb_search_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256)); lds_raised = true; }
-  hipLaunchKernelGGL(orb_search_kernel, dim3(1), dim3(kThreads), lds, sm, d_P);
+  if (!lds_raised) { LLD_HIP_TRY(hipFuncSetAttribute((const void*)orb_search_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit)); lds_raised = true; }
+  hipLaunchKernelGGL(orb_search_kernel, dim3(n), dim3(kThreads), lds_max, sm, reinterpret_cast<const Problem*>(d));
   LLD_HIP_TRY(hipGetLastError());
-  int32_t sum[2] = {0, 0};
-  LLD_HIP_TRY(hipMemcpyAsync(out->match, d_match, (size_t)nq * 4, hipMemcpyDeviceToHost, sm));
-  LLD_HIP_TRY(hipMemcpyAsync(out->best_dist, d_bd, (size_t)nq * 4, hipMemcpyDeviceToHost, sm));
-  LLD_HIP_TRY(hipMemcpyAsync(out->second_dist, d_sd, (size_t)nq * 4, hipMemcpyDeviceToHost, sm));
-  LLD_HIP_TRY(hipMemcpyAsync(out->removed, d_rem, (size_t)nq, hipMemcpyDeviceToHost, sm));
-  if (out->owner && nt) LLD_HIP_TRY(hipMemcpyAsync(out->owner, d_owner, (size_t)nt * 4, hipMemcpyDeviceToHost, sm));
-  LLD_HIP_TRY(hipMemcpyAsync(sum, d_sum, 8, hipMemcpyDeviceToHost, sm));
+  LLD_HIP_TRY(hipMemcpyAsync(h_out, d_out, out_bytes, hipMemcpyDeviceToHost, sm));
   LLD_HIP_TRY(hipStreamSynchronize(sm));
-  out->n_matches = sum[0]; out->rounds = sum[1];
+
+  for (int i = 0; i < n; i++) {
+    const Layout& L = lay[i]; lld_orb_search_result& o = outs[i];
+    const size_t nt = problems[i].nt, nq = problems[i].nq;
+    if (nq) {
+      std::memcpy(o.match, h_out + L.match, nq * 4); std::memcpy(o.best_dist, h_out + L.bd, nq * 4);
+      std::memcpy(o.second_dist, h_out + L.sd, nq * 4); std::memcpy(o.removed, h_out + L.rem, nq);
+    }
+    if (o.owner && nt) std::memcpy(o.owner, h_out + L.owner, nt * 4);
+    const int32_t* sum = reinterpret_cast<const int32_t*>(h_out + L.sum);
+    o.n_matches = sum[0]; o.rounds = sum[1];
+  }
   return LLD_OK;
+}
+
+extern "C" int lld_orb_search_run(lld_ctx* ctx, const lld_orb_search* s, lld_orb_search_result* out) {
+  return lld_orb_search_batch(ctx, 1, s, out);
 }

@@ -118,11 +118,19 @@ def _i32(a): return None if a is None else np.ascontiguousarray(a, np.int32)
 def _u8(a): return None if a is None else np.ascontiguousarray(a, np.uint8)
 
 
-def run(lib: abi.Lib, ctx, T: Frame, q_desc, *, candidates, gates=0, accept_max, ratio_mode=0, nnratio=0.0, sequential=False,
-        check_orientation=False, tie_last=False, t_occupied=None, q_valid=None, q_blocks=None, q_uv=None, q_radius=None,
-        q_level_min=None, q_level_max=None, q_uright=None, q_stereo_radius=None, q_angle=None, q_epiline=None, q_stereo=None,
-        cand_range=None, cand_idx=None, disp_min=0.0, disp_max=0.0, epipole=(0.0, 0.0), only_stereo=False) -> SearchOutput:
-    """One lld_orb_search_run call; keeps every array alive for the duration of the call."""
+@dataclass
+class Prepared:
+    """One configured problem: the C struct, the arrays it points into and the output holder."""
+    s: OrbSearch
+    r: OrbSearchResult
+    out: SearchOutput
+    keep: tuple
+
+
+def prepare(T: Frame, q_desc, *, candidates, gates=0, accept_max, ratio_mode=0, nnratio=0.0, sequential=False,
+            check_orientation=False, tie_last=False, t_occupied=None, q_valid=None, q_blocks=None, q_uv=None, q_radius=None,
+            q_level_min=None, q_level_max=None, q_uright=None, q_stereo_radius=None, q_angle=None, q_epiline=None, q_stereo=None,
+            cand_range=None, cand_idx=None, disp_min=0.0, disp_max=0.0, epipole=(0.0, 0.0), only_stereo=False) -> Prepared:
     T.normalise()
     q_desc = np.ascontiguousarray(q_desc, np.uint32).reshape(-1, 8)
     nq, nt = q_desc.shape[0], T.n
@@ -158,13 +166,36 @@ def run(lib: abi.Lib, ctx, T: Frame, q_desc, *, candidates, gates=0, accept_max,
     r = OrbSearchResult()
     r.match = _p(out.match, c_int32_p); r.best_dist = _p(out.best_dist, c_int32_p); r.second_dist = _p(out.second_dist, c_int32_p)
     r.removed = _p(out.removed, c_uint8_p); r.owner = _p(out.owner, c_int32_p)
+    return Prepared(s, r, out, (T, q_desc, keep))
+
+
+def run_batch(lib: abi.Lib, ctx, prepared: list) -> list:
+    """lld_orb_search_batch over already configured problems (pass ``lib=None`` to any routine below to get a Prepared
+    instead of running it): one launch, one workgroup per problem."""
+    n = len(prepared)
+    S = (OrbSearch * n)(*[p.s for p in prepared]); R = (OrbSearchResult * n)(*[p.r for p in prepared])
+    fn = lib.fn("orb_search_batch")
+    fn.argtypes = [C.c_void_p, C.c_int, C.POINTER(OrbSearch), C.POINTER(OrbSearchResult)]; fn.restype = C.c_int
+    st = fn(ctx, n, S, R)
+    if st != abi.LLD_OK:
+        raise RuntimeError(f"lld_orb_search_batch failed: {lib.fn('status_string')(st).decode()}")
+    for p, r in zip(prepared, R):
+        p.out.n_matches, p.out.rounds = r.n_matches, r.rounds
+    return [p.out for p in prepared]
+
+
+def run(lib, ctx, T: Frame, q_desc, **kw):
+    """One lld_orb_search_run call (or, with lib None, the configured problem for run_batch)."""
+    p = prepare(T, q_desc, **kw)
+    if lib is None:
+        return p
     fn = lib.fn("orb_search_run")
     fn.argtypes = [C.c_void_p, C.POINTER(OrbSearch), C.POINTER(OrbSearchResult)]; fn.restype = C.c_int
-    st = fn(ctx, C.byref(s), C.byref(r))
+    st = fn(ctx, C.byref(p.s), C.byref(p.r))
     if st != abi.LLD_OK:
         raise RuntimeError(f"lld_orb_search_run failed: {lib.fn('status_string')(st).decode()}")
-    out.n_matches, out.rounds = r.n_matches, r.rounds
-    return out
+    p.out.n_matches, p.out.rounds = p.r.n_matches, p.r.rounds
+    return p.out
 
 
 def bow_queries(start1, idx1, start2, n_nodes):
@@ -282,7 +313,7 @@ def search_by_bow_frame(lib, ctx, KF: Frame, F: Frame, n_nodes, kf_start, kf_idx
     out = run(lib, ctx, F, KF.normalise().desc[order], candidates=CAND_CSR, accept_max=TH_LOW, ratio_mode=1, nnratio=nnratio,
               sequential=True, check_orientation=check_orientation, q_valid=kf_valid[order], q_angle=KF.angle[order], cand_range=cr,
               cand_idx=f_idx)
-    out.query_kp = order
+    (out.out if isinstance(out, Prepared) else out).query_kp = order
     return out
 
 
@@ -294,7 +325,7 @@ def search_by_bow_kf(lib, ctx, KF1: Frame, KF2: Frame, n_nodes, start1, idx1, st
     out = run(lib, ctx, KF2, KF1.normalise().desc[order], candidates=CAND_CSR, accept_max=TH_LOW - 1, ratio_mode=1, nnratio=nnratio,
               sequential=True, check_orientation=check_orientation, t_occupied=1 - np.asarray(valid2, np.uint8),
               q_valid=np.asarray(valid1, np.uint8)[order], q_angle=KF1.angle[order], cand_range=cr, cand_idx=idx2)
-    out.query_kp = order
+    (out.out if isinstance(out, Prepared) else out).query_kp = order
     return out
 
 
@@ -313,7 +344,7 @@ def search_for_triangulation(lib, ctx, KF1: Frame, KF2: Frame, n_nodes, start1, 
               check_orientation=check_orientation, t_occupied=has_mp2, q_valid=valid[order], q_angle=KF1.angle[order],
               q_epiline=np.asarray(epilines, np.float32)[order], q_stereo=stereo1[order], cand_range=cr, cand_idx=idx2,
               epipole=epipole, only_stereo=only_stereo)
-    out.query_kp = order
+    (out.out if isinstance(out, Prepared) else out).query_kp = order
     return out
 
 

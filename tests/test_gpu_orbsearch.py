@@ -152,6 +152,33 @@ def test_stereo_matches_hamming_search(gpu_ctx, seed, n):
     assert m.sum() > n // 5
 
 
+def test_batch_of_mixed_problems_equals_single_calls(gpu_ctx):
+    """lld_orb_search_batch: different routines, sizes and LDS footprints in one launch; every problem equals its own oracle."""
+    S = orb_search
+    prepared, expect = [], []
+    for i in range(6):
+        F = synth.make_orb_frame(100 + i, [2000, 300, 4096, 1200, 2000, 64][i])
+        q = synth.make_projection_queries(F, 100 + i, [1500, 700, 2500, 64, 2000, 300][i], dup_frac=0.3)
+        prepared.append(S.search_by_projection_map(None, None, F, q["desc"], q["valid"], q["uv"], q["ur"], q["level"], q["view_cos"], q["obs"], q["occupied"], 1.0, 0.8))
+        expect.append(("slots", q["occupied"]) + OS.search_by_projection_map(F, q["desc"], q["valid"], q["uv"], q["ur"], q["level"], q["view_cos"], q["obs"], q["occupied"], 1.0, 0.8))
+        prepared.append(S.search_by_projection_frame(None, None, F, q["desc"], q["valid"], q["uv"], q["ur"], q["level"], q["angle"], q["obs"], q["occupied"], 0, 7.0, True))
+        expect.append(("slots", q["occupied"]) + OS.search_by_projection_frame(F, q["desc"], q["valid"], q["uv"], q["ur"], q["level"], q["angle"], q["obs"], q["occupied"], 0, 7.0, True))
+    L, R = synth.make_stereo_pair(5, 1500)
+    prepared.append(S.stereo_search(None, None, L, R, 0.0, 100.0)); expect.append(("stereo",) + OS.stereo_search(L, R, 376, 0.0, 100.0))
+    F1, F2, nd = synth.make_bow_pair(5, 1800); v = np.ones(F1.n, np.uint8)
+    prepared.append(S.search_by_bow_frame(None, None, F1, F2, nd["n_nodes"], nd["start1"], nd["idx1"], nd["start2"], nd["idx2"], v, 0.7, True))
+    expect.append(("bow",) + OS.search_by_bow_frame(F1, F2, nd["n_nodes"], nd["start1"], nd["idx1"], nd["start2"], nd["idx2"], v, 0.7, True))
+    outs = S.run_batch(gpu_ctx.lib, gpu_ctx.handle, prepared)
+    for out, e in zip(outs, expect):
+        if e[0] == "slots":
+            assert out.n_matches == e[2]; np.testing.assert_array_equal(expect_slots(out, e[1]), e[3])
+        elif e[0] == "stereo":
+            np.testing.assert_array_equal(out.match, e[1])
+        else:
+            assert out.n_matches == e[1]
+            np.testing.assert_array_equal(np.where(out.owner >= 0, out.query_kp[np.maximum(out.owner, 0)], -1), e[2])
+
+
 def test_long_dependency_chain_still_reaches_the_sequential_answer(gpu_ctx):
     """Worst case for the fixed-point rounds: every query wants the same few keypoints, so query i's answer depends on all
     earlier ones."""

@@ -52,5 +52,45 @@ t = time.perf_counter(); run2(); dt = time.perf_counter() - t
 t = time.perf_counter(); e2 = O.match_l2f32(ql[0], tl[0]); dtc = time.perf_counter() - t
 out["lbd_l2f32"] = {"pairs": B2, "gpu_pairs_per_s": B2 / dt, "cpu_oracle_pairs_per_s": 1 / dtc,
                     "bit_exact": bool(np.array_equal(bi[0].cpu().numpy(), e2[0]) and np.array_equal(bd[0].cpu().numpy(), e2[1]))}
+# ---- guided ORB searches: one frame (2000 keypoints), whole routine per call, host buffers in and out
+import oracle_orbsearch as OS
+from lld_slam_amd import ORBmatcher
+F = synth.make_orb_frame(0, 2000); qq = synth.make_projection_queries(F, 0, 2000, dup_frac=0.3)
+m = ORBmatcher(ctx, 0.8)
+def timed(f, n=21):
+    f(); ts = []
+    for _ in range(n):
+        t = time.perf_counter(); r = f(); ts.append(time.perf_counter() - t)
+    return float(np.median(ts)), r
+g_map, r_map = timed(lambda: m.SearchByProjectionMap(F, qq["desc"], qq["valid"], qq["uv"], qq["ur"], qq["level"], qq["view_cos"], qq["obs"], qq["occupied"], 1.0))
+c_map, e_map = timed(lambda: OS.search_by_projection_map(F, qq["desc"], qq["valid"], qq["uv"], qq["ur"], qq["level"], qq["view_cos"], qq["obs"], qq["occupied"], 1.0, 0.8))
+g_frm, r_frm = timed(lambda: m.SearchByProjectionFrame(F, qq["desc"], qq["valid"], qq["uv"], qq["ur"], qq["level"], qq["angle"], qq["obs"], qq["occupied"], 0, 15.0))
+c_frm, e_frm = timed(lambda: OS.search_by_projection_frame(F, qq["desc"], qq["valid"], qq["uv"], qq["ur"], qq["level"], qq["angle"], qq["obs"], qq["occupied"], 0, 15.0, True))
+L, R = synth.make_stereo_pair(0, 2000)
+g_st, r_st = timed(lambda: m.ComputeStereoMatches(L, R, 0.0, 100.0))
+c_st, e_st = timed(lambda: OS.stereo_search(L, R, 376, 0.0, 100.0))
+F1, F2, nd = synth.make_bow_pair(0, 2000); v = np.ones(2000, np.uint8)
+g_bow, r_bow = timed(lambda: ORBmatcher(ctx, 0.7).SearchByBoWFrame(F1, F2, nd, v))
+c_bow, e_bow = timed(lambda: OS.search_by_bow_frame(F1, F2, nd["n_nodes"], nd["start1"], nd["idx1"], nd["start2"], nd["idx2"], v, 0.7, True))
+# batch: 512 local-map searches (64 distinct frames) in one launch, one workgroup per problem
+from lld_slam_amd import orb_search as S
+scenes = []
+for i in range(64):
+    Fi = synth.make_orb_frame(200 + i, 2000); qi = synth.make_projection_queries(Fi, 200 + i, 2000, dup_frac=0.3)
+    scenes.append((Fi, qi))
+prep = [S.search_by_projection_map(None, None, Fi, qi["desc"], qi["valid"], qi["uv"], qi["ur"], qi["level"], qi["view_cos"], qi["obs"], qi["occupied"], 1.0, 0.8)
+        for Fi, qi in scenes] * 8
+g_bat, r_bat = timed(lambda: S.run_batch(ctx.lib, ctx.handle, prep), 5)
+t = time.perf_counter()
+e_bat = [OS.search_by_projection_map(Fi, qi["desc"], qi["valid"], qi["uv"], qi["ur"], qi["level"], qi["view_cos"], qi["obs"], qi["occupied"], 1.0, 0.8)[0] for Fi, qi in scenes]
+c_bat = (time.perf_counter() - t) / len(scenes)
+out["orb_guided_search"] = {
+    "map_projection_batch512": {"gpu_searches_per_s": len(prep) / g_bat, "cpu_oracle_searches_per_s": 1.0 / c_bat,
+                                "equal": [o.n_matches for o in r_bat[:64]] == e_bat},
+    "map_projection": {"gpu_ms": g_map * 1e3, "cpu_oracle_ms": c_map * 1e3, "rounds": r_map.rounds, "n_matches": r_map.n_matches, "equal": r_map.n_matches == e_map[0]},
+    "frame_projection": {"gpu_ms": g_frm * 1e3, "cpu_oracle_ms": c_frm * 1e3, "rounds": r_frm.rounds, "n_matches": r_frm.n_matches, "equal": r_frm.n_matches == e_frm[0]},
+    "stereo_rows": {"gpu_ms": g_st * 1e3, "cpu_oracle_ms": c_st * 1e3, "equal": bool(np.array_equal(r_st.match, e_st[0]))},
+    "bow_kf_frame": {"gpu_ms": g_bow * 1e3, "cpu_oracle_ms": c_bow * 1e3, "rounds": r_bow.rounds, "equal": r_bow.n_matches == e_bow[0]},
+}
 ctx.close()
 print(json.dumps(out))
