@@ -275,6 +275,33 @@ int lld_line_match_greedy(lld_ctx* ctx, const float* desc_left, int nq, const fl
                           int nt, int dim, const uint8_t* gate /*[nq][nt]*/, double tau,
                           int32_t* matches /*[nq]*/, double* match_dist /*[nq] or NULL*/);
 
+/* TwoFrameLineMatcher::MatchLines with CheckLinePair's geometric gates computed ON THE DEVICE
+ * (src/TwoFrameLineMatcher.cc:26-124; the only caller is the left/right line association of the
+ * Frame constructor, src/Frame.cc:121-122, so T = identity and T_right = GetTForRight(T, b),
+ * src/LineMatching.cc:228-237).  For every (left j, right oi) pair the gate is
+ *   same octave (:81-84)  &&  both lengths >= min_line_length (:86-91)
+ *   && vgl::TriangulateLine succeeds (src/vgl.cc:78-108: back-projected plane normals
+ *      n = R*GetNormalizedLineEq(kl,K) not closer than |cos| 0.975, direction n1 x n2, X0 from
+ *      the 3x3 system [n1; n2; dir] X0 = [n1.t1; n2.t2; 0])  &&  |X0| >= 0.5 (:100-103)
+ *   && both detected endpoints of the LEFT line, re-projected onto the 3D line by the 3x2 least
+ *      squares of vgl::ReprojectLinePointTo3D (src/vgl.cc:336-346, src/LineMatching.cc:277-292),
+ *      have z >= 0 (:104-109);
+ * then the greedy, order-dependent descriptor assignment of lld_line_match_greedy.
+ * lines: [n][4] float startPointX, startPointY, endPointX, endPointY of the KeyLines.
+ * K: row-major 3x3 (Frame.cc:118-120).  b: mbf / fx.  gate_out: [nq][nt] bytes or NULL. */
+typedef struct {
+  double K[9];
+  double b;
+  double tau;               /* thrDD / mdThr */
+  int32_t min_line_length;  /* minLineLen */
+  int32_t is_stereo;        /* 1: octaves must be equal (:81) */
+} lld_line_stereo_params;
+int lld_line_match_stereo(lld_ctx* ctx, const lld_line_stereo_params* params,
+                          const float* left_lines, const int32_t* left_octave, const float* desc_left, int nq,
+                          const float* right_lines, const int32_t* right_octave, const float* desc_right, int nt,
+                          int dim, int32_t* matches /*[nq]*/, double* match_dist /*[nq] or NULL*/,
+                          uint8_t* gate_out /*[nq][nt] or NULL*/);
+
 /* ================================================================== guided ORB search
  * lld_orb_search: the complete body of one ORBmatcher::Search* / Fuse / ComputeStereoMatches
  * routine for one (query set, keypoint set) pair: candidate generation ON THE DEVICE, the

@@ -55,6 +55,10 @@ class BAWindow(C.Structure):
     ]
 
 
+class LineStereoParams(C.Structure):
+    _fields_ = [("K", C.c_double * 9), ("b", C.c_double), ("tau", C.c_double), ("min_line_length", C.c_int32), ("is_stereo", C.c_int32)]
+
+
 class BAParams(C.Structure):
     _fields_ = [
         ("gamma", C.c_double),
@@ -134,7 +138,7 @@ PRODUCT_SYMBOLS = [
     "lld_pose_params_default", "lld_pose_opt",
     "lld_pose_batch_create", "lld_pose_batch_solve", "lld_pose_batch_download", "lld_pose_batch_destroy",
     "lld_match_hamming256", "lld_match_hamming256_csr", "lld_match_hamming256_batch_dev",
-    "lld_match_l2f32", "lld_match_l2f32_batch_dev", "lld_line_match_greedy",
+    "lld_match_l2f32", "lld_match_l2f32_batch_dev", "lld_line_match_greedy", "lld_line_match_stereo",
     "lld_orb_search_run", "lld_orb_search_batch",
 ]
 
@@ -190,6 +194,9 @@ class Lib:
         f("line_match_greedy").argtypes = [vp, c_float_p, C.c_int, c_float_p, C.c_int, C.c_int, c_uint8_p, C.c_double,
                                            c_int32_p, c_double_p]
         f("line_match_greedy").restype = C.c_int
+        f("line_match_stereo").argtypes = [vp, C.POINTER(LineStereoParams), c_float_p, c_int32_p, c_float_p, C.c_int, c_float_p, c_int32_p,
+                                           c_float_p, C.c_int, C.c_int, c_int32_p, c_double_p, c_uint8_p]
+        f("line_match_stereo").restype = C.c_int
         if self.prefix == "lld_":
             f("status_string").argtypes = [C.c_int]; f("status_string").restype = C.c_char_p
             f("ctx_create").argtypes = [C.c_int, C.POINTER(vp)]; f("ctx_create").restype = C.c_int

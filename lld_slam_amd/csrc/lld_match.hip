@@ -190,6 +190,63 @@ __global__ __launch_bounds__(64) void line_greedy_kernel(const double* __restric
   }
 }
 
+
+// Geometric gates of TwoFrameLineMatcher::CheckLinePair (src/TwoFrameLineMatcher.cc:79-109) for the stereo pair of one frame:
+// one lane per (left j, right oi).  T = identity, T_right = [I | (b,0,0)] (GetTForRight, src/LineMatching.cc:228-237).
+// The 3x3 system of vgl::TriangulateLine (src/vgl.cc:78-108) has rows n1, n2, d = n1 x n2 / |n1 x n2|, so its determinant is
+// |n1 x n2| > 0 once the 0.975 parallelism test passed (rank 3 always) and X0 = (b1 (d x n1)) / det in closed form; the 3x2
+// least squares of vgl::ReprojectLinePointTo3D (src/vgl.cc:336-346) is solved by its normal equations.
+struct LineGateParams { double K[9]; double b; double min_len; int is_stereo; };
+
+__device__ __forceinline__ void normalized_line_eq(const float* kl, const double* K, double* l) {
+  const double sx = kl[0], sy = kl[1], ex = kl[2], ey = kl[3];
+  const double ix = sy - ey, iy = ex - sx, iz = sx * ey - sy * ex;             // (sx,sy,1) x (ex,ey,1)
+  const double a = K[0] * ix + K[3] * iy + K[6] * iz, b = K[1] * ix + K[4] * iy + K[7] * iz, c = K[2] * ix + K[5] * iy + K[8] * iz;
+  const double n = sqrt(a * a + b * b);
+  l[0] = a / n; l[1] = b / n; l[2] = c / n;
+}
+
+__global__ __launch_bounds__(256) void line_pair_gate_kernel(LineGateParams P, const float* __restrict__ left, const int* __restrict__ loct, int nq,
+                                                           const float* __restrict__ right, const int* __restrict__ roct, int nt,
+                                                           uint8_t* __restrict__ gate) {
+  const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= (size_t)nq * nt) return;
+  const int j = (int)(id / nt), oi = (int)(id % nt);
+  const float* k1 = left + 4 * j; const float* k2 = right + 4 * oi;
+  uint8_t ok = 0;
+  do {
+    if (P.is_stereo && loct[j] != roct[oi]) break;
+    const double d1x = (double)k1[0] - (double)k1[2], d1y = (double)k1[1] - (double)k1[3];
+    const double d2x = (double)k2[0] - (double)k2[2], d2y = (double)k2[1] - (double)k2[3];
+    if (sqrt(d1x * d1x + d1y * d1y) < P.min_len || sqrt(d2x * d2x + d2y * d2y) < P.min_len) break;
+    double n1[3], n2[3];
+    normalized_line_eq(k1, P.K, n1); normalized_line_eq(k2, P.K, n2);
+    const double nn1 = sqrt(n1[0] * n1[0] + n1[1] * n1[1] + n1[2] * n1[2]), nn2 = sqrt(n2[0] * n2[0] + n2[1] * n2[1] + n2[2] * n2[2]);
+    if (fabs(n1[0] * n2[0] + n1[1] * n2[1] + n1[2] * n2[2]) / nn1 / nn2 > 0.975) break;
+    double d[3] = {n1[1] * n2[2] - n1[2] * n2[1], n1[2] * n2[0] - n1[0] * n2[2], n1[0] * n2[1] - n1[1] * n2[0]};
+    const double det = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    d[0] /= det; d[1] /= det; d[2] /= det;
+    const double b1 = n2[0] * P.b;                                               // n2 . t2, t2 = (b,0,0); n1 . t1 = 0
+    const double X0[3] = {b1 * (d[1] * n1[2] - d[2] * n1[1]) / det, b1 * (d[2] * n1[0] - d[0] * n1[2]) / det, b1 * (d[0] * n1[1] - d[1] * n1[0]) / det};
+    if (sqrt(X0[0] * X0[0] + X0[1] * X0[1] + X0[2] * X0[2]) < 0.5) break;
+    const double c[3] = {-(P.K[0] * d[0] + P.K[1] * d[1] + P.K[2] * d[2]), -(P.K[3] * d[0] + P.K[4] * d[1] + P.K[5] * d[2]),
+                         -(P.K[6] * d[0] + P.K[7] * d[1] + P.K[8] * d[2])};
+    const double r[3] = {P.K[0] * X0[0] + P.K[1] * X0[1] + P.K[2] * X0[2], P.K[3] * X0[0] + P.K[4] * X0[1] + P.K[5] * X0[2],
+                         P.K[6] * X0[0] + P.K[7] * X0[1] + P.K[8] * X0[2]};
+    const double cc = c[0] * c[0] + c[1] * c[1] + c[2] * c[2], cr = c[0] * r[0] + c[1] * r[1] + c[2] * r[2];
+    bool front = true;
+    for (int e = 0; e < 2; e++) {
+      const double px = k1[2 * e], py = k1[2 * e + 1];
+      const double aa = px * px + py * py + 1.0, ac = px * c[0] + py * c[1] + c[2], ar = px * r[0] + py * r[1] + r[2];
+      const double p = (aa * cr - ac * ar) / (aa * cc - ac * ac);               // line parameter of the re-projected endpoint
+      if (X0[2] + p * d[2] < 0) front = false;
+    }
+    if (!front) break;
+    ok = 1;
+  } while (false);
+  gate[id] = ok;
+}
+
 int launch_hamming(lld_ctx* ctx, int batch, const uint32_t* q, int nq, const uint32_t* t, int nt, const uint8_t* mask,
                    int* bi, int* bd, int* si, int* sd) {
   if (nt >= (1 << kIdxBits)) return LLD_ERR_UNSUPPORTED;
@@ -339,6 +396,51 @@ int lld_line_match_greedy(lld_ctx* ctx, const float* dl, int nq, const float* dr
   LLD_HIP_TRY(hipMemcpyAsync(matches, dbi, (size_t)nq * 4, hipMemcpyDeviceToHost, ctx->stream));
   if (match_dist) LLD_HIP_TRY(hipMemcpyAsync(match_dist, dmd, (size_t)nq * 8, hipMemcpyDeviceToHost, ctx->stream));
   LLD_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return LLD_OK;
+}
+
+int lld_line_match_stereo(lld_ctx* ctx, const lld_line_stereo_params* params, const float* left_lines, const int32_t* left_octave,
+                          const float* dl, int nq, const float* right_lines, const int32_t* right_octave, const float* dr, int nt, int dim,
+                          int32_t* matches, double* match_dist, uint8_t* gate_out) {
+  if (!ctx || !params || nq < 0 || nt < 0 || dim <= 0 || !matches) return LLD_ERR_INVALID;
+  if (nq > 0 && (!left_lines || !left_octave || !dl)) return LLD_ERR_INVALID;
+  if (nt > 0 && (!right_lines || !right_octave || !dr)) return LLD_ERR_INVALID;
+  if (dim > 128) return LLD_ERR_UNSUPPORTED;
+  if (nq == 0) return LLD_OK;
+  if (nt == 0) { for (int i = 0; i < nq; i++) { matches[i] = -1; if (match_dist) match_dist[i] = 1.7976931348623157e308; } return LLD_OK; }
+  LLD_HIP_TRY(hipSetDevice(ctx->device));
+  const size_t need = lld_slab::pad((size_t)nq * dim * 4) + lld_slab::pad((size_t)nt * dim * 4 + 16) + lld_slab::pad((size_t)nq * nt) +
+                      lld_slab::pad((size_t)nq * nt * 8) + 2 * lld_slab::pad((size_t)nq * 4) + 3 * lld_slab::pad((size_t)nq * 8) + lld_slab::pad(nt) +
+                      lld_slab::pad((size_t)nq * 16) + lld_slab::pad((size_t)nt * 16) + lld_slab::pad((size_t)nq * 4) + lld_slab::pad((size_t)nt * 4);
+  void* base; int st = lld_ctx_scratch(ctx, need, &base); if (st) return st;
+  lld_slab s; s.base = (char*)base;
+  float* dq = s.take<float>((size_t)nq * dim); float* dt = s.take<float>((size_t)nt * dim + 4);
+  uint8_t* dg = s.take<uint8_t>((size_t)nq * nt);
+  double* dmat = s.take<double>((size_t)nq * nt);
+  int *dbi = s.take<int>(nq), *dsi = s.take<int>(nq); double *dbd = s.take<double>(nq), *dsd = s.take<double>(nq), *dmd = s.take<double>(nq);
+  uint8_t* dtaken = s.take<uint8_t>(nt);
+  float* dll = s.take<float>((size_t)nq * 4); float* drl = s.take<float>((size_t)nt * 4);
+  int* dlo = s.take<int>(nq); int* dro = s.take<int>(nt);
+  hipStream_t sm = ctx->stream;
+  LLD_HIP_TRY(hipMemcpyAsync(dq, dl, (size_t)nq * dim * 4, hipMemcpyHostToDevice, sm));
+  LLD_HIP_TRY(hipMemcpyAsync(dt, dr, (size_t)nt * dim * 4, hipMemcpyHostToDevice, sm));
+  LLD_HIP_TRY(hipMemcpyAsync(dll, left_lines, (size_t)nq * 16, hipMemcpyHostToDevice, sm));
+  LLD_HIP_TRY(hipMemcpyAsync(drl, right_lines, (size_t)nt * 16, hipMemcpyHostToDevice, sm));
+  LLD_HIP_TRY(hipMemcpyAsync(dlo, left_octave, (size_t)nq * 4, hipMemcpyHostToDevice, sm));
+  LLD_HIP_TRY(hipMemcpyAsync(dro, right_octave, (size_t)nt * 4, hipMemcpyHostToDevice, sm));
+  LineGateParams P;
+  for (int i = 0; i < 9; i++) P.K[i] = params->K[i];
+  P.b = params->b; P.min_len = (double)params->min_line_length; P.is_stereo = params->is_stereo;
+  const size_t pairs = (size_t)nq * nt;
+  hipLaunchKernelGGL(line_pair_gate_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, sm, P, dll, dlo, nq, drl, dro, nt, dg);
+  LLD_HIP_TRY(hipGetLastError());
+  st = launch_l2(ctx, 1, dq, nq, dt, nt, dim, nullptr, dbi, dbd, dsi, dsd, dmat); if (st) return st;
+  hipLaunchKernelGGL(line_greedy_kernel, dim3(1), dim3(64), 0, sm, dmat, nq, nt, dg, params->tau, dbi, dmd, dtaken);
+  LLD_HIP_TRY(hipGetLastError());
+  LLD_HIP_TRY(hipMemcpyAsync(matches, dbi, (size_t)nq * 4, hipMemcpyDeviceToHost, sm));
+  if (match_dist) LLD_HIP_TRY(hipMemcpyAsync(match_dist, dmd, (size_t)nq * 8, hipMemcpyDeviceToHost, sm));
+  if (gate_out) LLD_HIP_TRY(hipMemcpyAsync(gate_out, dg, pairs, hipMemcpyDeviceToHost, sm));
+  LLD_HIP_TRY(hipStreamSynchronize(sm));
   return LLD_OK;
 }
 

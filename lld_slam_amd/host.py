@@ -289,6 +289,26 @@ def greedy_call(lib: abi.Lib, ctx, dl: np.ndarray, dr: np.ndarray, gate: np.ndar
     return m, d
 
 
+def line_stereo_call(lib: abi.Lib, ctx, K, b, tau, min_line_length, left_lines, left_octave, dl, right_lines, right_octave, dr,
+                     is_stereo=True, want_gate=False):
+    """lld_line_match_stereo: CheckLinePair's gates on the device, then the greedy assignment."""
+    dl = np.ascontiguousarray(dl, np.float32); dr = np.ascontiguousarray(dr, np.float32)
+    ll = np.ascontiguousarray(left_lines, np.float32).reshape(-1, 4); rl = np.ascontiguousarray(right_lines, np.float32).reshape(-1, 4)
+    lo = np.ascontiguousarray(left_octave, np.int32); ro = np.ascontiguousarray(right_octave, np.int32)
+    nq, nt = ll.shape[0], rl.shape[0]
+    dim = dl.shape[1] if dl.ndim == 2 else dr.shape[1]
+    P = abi.LineStereoParams()
+    for i, v in enumerate(np.asarray(K, np.float64).reshape(9)):
+        P.K[i] = float(v)
+    P.b = float(b); P.tau = float(tau); P.min_line_length = int(min_line_length); P.is_stereo = int(is_stereo)
+    m = np.empty(nq, np.int32); d = np.empty(nq, np.float64)
+    gate = np.empty((nq, nt), np.uint8) if want_gate else None
+    check(lib.fn("line_match_stereo")(ctx, C.byref(P), _p(ll, C.c_float), _p(lo, C.c_int32), _p(dl, C.c_float), nq, _p(rl, C.c_float),
+                                      _p(ro, C.c_int32), _p(dr, C.c_float), nt, dim, _p(m, C.c_int32), _p(d, C.c_double),
+                                      None if gate is None else _p(gate, C.c_uint8)), "line_match_stereo")
+    return (m, d, gate) if want_gate else (m, d)
+
+
 def se3_from_tcw_f32(lib: abi.Lib, tcw: np.ndarray) -> np.ndarray:
     t = np.ascontiguousarray(tcw, np.float32).reshape(16)
     out = np.zeros(7)
@@ -522,13 +542,22 @@ class ORBmatcher:
 
 
 class TwoFrameLineMatcher:
-    """Mirror of TwoFrameLineMatcher::MatchLines (include/TwoFrameLineMatcher.h:31-42); the geometric gates of
-    CheckLinePair are supplied by the caller as a byte matrix."""
+    """Mirror of TwoFrameLineMatcher (include/TwoFrameLineMatcher.h:31-42).  Constructed like the reference
+    (K, b, tau, minLineLength) it runs the whole MatchLines on the device, CheckLinePair's geometric gates included;
+    constructed with tau only, the caller supplies the gates as a byte matrix."""
 
-    def __init__(self, ctx: Context, tau: float):
+    def __init__(self, ctx: Context, tau: float, K=None, b: float = 0.0, minLineLength: int = 0):
         self.ctx = ctx; self.lib = ctx.lib; self.tau = tau
+        self.K = None if K is None else np.asarray(K, np.float64).reshape(3, 3); self.b = b; self.minLineLength = minLineLength
 
-    def MatchLines(self, descsLeft, descsRight, gate=None):
+    def MatchLines(self, descsLeft, descsRight, gate=None, lines=None, other_lines=None, octaves=None, other_octaves=None, want_gate=False):
+        """MatchLines(lines, other_lines, descsLeft, descsRight, desc_matches): with `lines` [n,4] / `other_lines` [m,4]
+        (startPointX, startPointY, endPointX, endPointY) and their octaves the gates are computed on the device."""
+        if lines is not None:
+            if self.K is None:
+                raise ValueError("TwoFrameLineMatcher was constructed without K / b")
+            return line_stereo_call(self.lib, self.ctx.handle, self.K, self.b, self.tau, self.minLineLength, lines, octaves, descsLeft,
+                                    other_lines, other_octaves, descsRight, True, want_gate)
         return greedy_call(self.lib, self.ctx.handle, descsLeft, descsRight, gate, self.tau)
 
     def BestTwo(self, q, t, mask=None):

@@ -457,3 +457,53 @@ def make_stereo_pair(pair_id=0, n=2000, flip_p=0.06):
     R.octave[sr] = np.clip(L.octave[sl] + rng.integers(-2, 3, m), 0, 7)
     R.desc[sr] = _flip_bits(rng, L.desc[sl], flip_p)
     return L, R
+
+
+# ====================================================================== stereo line association (TwoFrameLineMatcher)
+def make_stereo_lines(frame_id=0, n_left=300, n_right=300, dim=72, related_frac=0.8, pixel_noise=0.4, desc_noise=0.05):
+    """Left / right KeyLines of one stereo frame: random 3D segments (depth 3-40 m, some nearly parallel to the baseline so the
+    triangulation-angle gate rejects them, some partly behind the camera after noise) projected with the KITTI intrinsics
+    and baseline, endpoints slid along the line in the right image, plus unrelated lines, short lines and octave mismatches.
+    Returns dict(K, b, left [n,4] f32, left_octave, right, right_octave, desc_left, desc_right)."""
+    rng = np.random.default_rng(SEED_SEARCH + 0x4000 + frame_id)
+    fx, fy, cx, cy, bf = KITTI_CAM
+    K = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1.0]])
+    b = float(np.float32(np.float32(bf) / np.float32(fx)))               # mbf/mK.at<float>(0,0), src/Frame.cc:121
+    m = int(related_frac * min(n_left, n_right))
+
+    def segs(n):
+        z = rng.uniform(3.0, 40.0, n)
+        c = np.stack([(rng.uniform(60, 1180, n) - cx) * z / fx, (rng.uniform(30, 340, n) - cy) * z / fy, z], 1)
+        d = rng.normal(size=(n, 3)); d[:, 2] *= 0.3
+        flat = rng.random(n) < 0.15
+        d[flat, 1] *= 0.02                                               # nearly parallel to the baseline: epipolar-degenerate
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        half = rng.uniform(0.15, 2.5, n)[:, None] * 0.5
+        return c - half * d, c + half * d
+
+    def proj(X, shift):
+        Xc = X - np.array([shift, 0, 0])
+        zz = np.maximum(Xc[:, 2], 0.3)
+        return np.stack([fx * Xc[:, 0] / zz + cx, fy * Xc[:, 1] / zz + cy], 1)
+    A, B = segs(m)
+    la, lb = proj(A, 0.0), proj(B, 0.0)
+    s = rng.uniform(-0.2, 0.2, (m, 2))                                   # endpoints slide along the 3D line in the right image
+    Ar, Br = A + s[:, :1] * (B - A), B + s[:, 1:] * (B - A)
+    ra, rb = proj(Ar, b), proj(Br, b)
+    left = np.concatenate([la, lb], 1) + rng.normal(0, pixel_noise, (m, 4))
+    right = np.concatenate([ra, rb], 1) + rng.normal(0, pixel_noise, (m, 4))
+    octave = rng.integers(0, 3, m)
+
+    def unrelated(n):
+        p = np.stack([rng.uniform(0, 1241, n), rng.uniform(0, 376, n)], 1)
+        q = p + rng.normal(0, 40, (n, 2))
+        return np.concatenate([p, q], 1)
+    left = np.concatenate([left, unrelated(n_left - m)]); right = np.concatenate([right, unrelated(n_right - m)])
+    lo = np.concatenate([octave, rng.integers(0, 3, n_left - m)]); ro = np.concatenate([octave, rng.integers(0, 3, n_right - m)])
+    mism = rng.random(m) < 0.08; ro[:m][mism] = (ro[:m][mism] + 1) % 3  # octave mismatch -> gate fails
+    dl = rng.normal(size=(n_left, dim)); dl /= np.linalg.norm(dl, axis=1, keepdims=True)
+    dr = rng.normal(size=(n_right, dim)); dr /= np.linalg.norm(dr, axis=1, keepdims=True)
+    dr[:m] = dl[:m] + rng.normal(0, desc_noise, (m, dim))
+    pl, pr = rng.permutation(n_left), rng.permutation(n_right)            # shuffle so correspondences are not index-aligned
+    return dict(K=K, b=b, left=left[pl].astype(np.float32), left_octave=lo[pl].astype(np.int32), right=right[pr].astype(np.float32),
+                right_octave=ro[pr].astype(np.int32), desc_left=dl[pl].astype(np.float32), desc_right=dr[pr].astype(np.float32))

@@ -1,0 +1,216 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY.  Never linked, imported or executed by the product path
+// (lld_slam_amd/); only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it.
+//
+// PARITY UNPINNED: the reference cannot be built here (no Eigen / OpenCV / LBDMOD) and has no tests or golden
+// vectors; this restatement is pinned by the known-answer tests under tests/.
+//
+// lldo_linematch.cpp — literal restatement of the stereo line association:
+//   TwoFrameLineMatcher::{MatchLines, CheckLinePair}      src/TwoFrameLineMatcher.cc:26-124
+//   GetNormalizedLineEq / vgl::NormalizedLineEquation      src/LineMatching.cc:249-254, src/vgl.cc:578-585
+//   LineLength                                             src/LineMatching.cc:50-59
+//   GetTForRight                                           src/LineMatching.cc:228-237
+//   vgl::TriangulateLine                                   src/vgl.cc:78-108
+//   ReprojectKeyLineTo3D / vgl::MapPoint                   src/LineMatching.cc:277-292, src/vgl.cc:587-590
+//   vgl::ReprojectLinePointTo3D                            src/vgl.cc:336-346
+// Eigen is absent, so ColPivHouseholderQR (rank(), solve()) is restated: column pivoting on the largest remaining
+// column norm, Householder reflections, rank = #{ |R_kk| > eps * size * max|R_kk| }, minimum-norm-free solve on the
+// leading rank block (Eigen zeroes the remaining unknowns).
+#include <cfloat>
+#include <cmath>
+#include <cstdint>
+#include <vector>
+
+#include "../include/lld_amd.h"
+#include "lldo_math.h"
+
+using namespace lldo;
+
+extern "C" double lldo_l2f32(const float* a, const float* b, int dim);
+
+namespace {
+
+struct M34 { M3 R; V3 t; };   // T.block<3,4>(0,0) of a 4x4 pose
+
+// Eigen::ColPivHouseholderQR of an m x n matrix (m >= n, m <= 3): solves A x = b in the least-squares sense.
+// Returns the rank; x gets zeros for the dropped unknowns.
+int colpiv_qr_solve(int m, int n, double A[3][3], const double* b_in, double* x) {
+  double b[3]; for (int i = 0; i < m; i++) b[i] = b_in[i];
+  int perm[3] = {0, 1, 2};
+  double maxpivot = 0.0; double diag[3] = {0, 0, 0};
+  for (int k = 0; k < n; k++) {
+    // pivot: largest squared norm of the remaining part of the remaining columns (first maximum wins)
+    int best = k; double best_norm = -1.0;
+    for (int c = k; c < n; c++) {
+      double s = 0.0; for (int r = k; r < m; r++) s += A[r][c] * A[r][c];
+      if (s > best_norm) { best_norm = s; best = c; }
+    }
+    if (best != k) { for (int r = 0; r < m; r++) std::swap(A[r][k], A[r][best]); std::swap(perm[k], perm[best]); }
+    // Householder: makeHouseholderInPlace on A[k..m-1][k]
+    const double c0 = A[k][k];
+    double tail = 0.0; for (int r = k + 1; r < m; r++) tail += A[r][k] * A[r][k];
+    double beta = c0, tau = 0.0; double v[3] = {0, 0, 0};
+    if (tail > DBL_MIN) {
+      beta = std::sqrt(c0 * c0 + tail);
+      if (c0 >= 0) beta = -beta;
+      for (int r = k + 1; r < m; r++) v[r] = A[r][k] / (c0 - beta);
+      tau = (beta - c0) / beta;
+      for (int c = k + 1; c < n; c++) {
+        double w = A[k][c]; for (int r = k + 1; r < m; r++) w += v[r] * A[r][c];
+        A[k][c] -= tau * w; for (int r = k + 1; r < m; r++) A[r][c] -= tau * w * v[r];
+      }
+      double w = b[k]; for (int r = k + 1; r < m; r++) w += v[r] * b[r];
+      b[k] -= tau * w; for (int r = k + 1; r < m; r++) b[r] -= tau * w * v[r];
+    }
+    A[k][k] = beta; for (int r = k + 1; r < m; r++) A[r][k] = 0.0;
+    diag[k] = std::fabs(beta);
+    if (diag[k] > maxpivot) maxpivot = diag[k];
+  }
+  const double threshold = DBL_EPSILON * (double)n;      // NumTraits::epsilon() * diagonalSize()
+  int rank = 0;
+  for (int k = 0; k < n; k++) if (diag[k] > threshold * maxpivot) rank++;
+  double y[3] = {0, 0, 0};
+  for (int k = rank - 1; k >= 0; k--) {
+    double s = b[k]; for (int c = k + 1; c < rank; c++) s -= A[k][c] * y[c];
+    y[k] = s / A[k][k];
+  }
+  for (int k = 0; k < n; k++) x[perm[k]] = (k < rank) ? y[k] : 0.0;
+  return rank;
+}
+
+V3 kt_mul(const double* K, const V3& l) {   // K.transpose() * l
+  return V3{K[0] * l.x + K[3] * l.y + K[6] * l.z, K[1] * l.x + K[4] * l.y + K[7] * l.z, K[2] * l.x + K[5] * l.y + K[8] * l.z};
+}
+V3 k_mul(const double* K, const V3& X) {    // K * X
+  return V3{K[0] * X.x + K[1] * X.y + K[2] * X.z, K[3] * X.x + K[4] * X.y + K[5] * X.z, K[6] * X.x + K[7] * X.y + K[8] * X.z};
+}
+
+// vgl::NormalizedLineEquation
+V3 normalized_line_eq(const float* kl, const double* K) {
+  const V3 Xs{kl[0], kl[1], 1.0}, Xe{kl[2], kl[3], 1.0};
+  const V3 lineImg = cross(Xs, Xe);
+  V3 leq = kt_mul(K, lineImg);
+  const double n = std::sqrt(leq.x * leq.x + leq.y * leq.y);
+  return V3{leq.x / n, leq.y / n, leq.z / n};
+}
+
+double line_length(const float* kl) {
+  const double dx = (double)kl[0] - (double)kl[2], dy = (double)kl[1] - (double)kl[3];
+  return std::sqrt(dx * dx + dy * dy);
+}
+
+// vgl::TriangulateLine
+bool triangulate_line(const M34& T1, const M34& T2, const V3& l1, const V3& l2, V3* X0, V3* line_dir) {
+  const V3 normal_1 = m3_mulv(T1.R, l1), normal_2 = m3_mulv(T2.R, l2);
+  if (std::fabs(dot(normal_1, normal_2)) / norm(normal_1) / norm(normal_2) > 0.975) return false;
+  V3 d = cross(normal_1, normal_2);
+  d = scale(d, 1.0 / norm(d));
+  *line_dir = d;
+  double M[3][3] = {{normal_1.x, normal_1.y, normal_1.z}, {normal_2.x, normal_2.y, normal_2.z}, {d.x, d.y, d.z}};
+  const double b[3] = {dot(normal_1, T1.t), dot(normal_2, T2.t), 0.0};
+  double x[3];
+  if (colpiv_qr_solve(3, 3, M, b, x) < 3) return false;
+  *X0 = V3{x[0], x[1], x[2]};
+  return true;
+}
+
+// vgl::ReprojectLinePointTo3D
+void reproject_line_point_to_3d(const V3& X0, const V3& line_dir, double px, double py, const double* K, double* depth, double* line_param) {
+  const V3 kd = k_mul(K, line_dir);
+  double M[3][3] = {{px, -kd.x, 0}, {py, -kd.y, 0}, {1.0, -kd.z, 0}};
+  const V3 rhs = k_mul(K, X0);
+  const double b[3] = {rhs.x, rhs.y, rhs.z};
+  double sol[3];
+  colpiv_qr_solve(3, 2, M, b, sol);
+  *depth = sol[0]; *line_param = sol[1];
+}
+
+// ReprojectKeyLineTo3D with T = [R|t] camera-to-world as vgl::MapPoint reads it
+void reproject_keyline_to_3d(const float* kl, const M34& T, const double* K, const V3& X0, const V3& lineDir, V3* X1, V3* X2) {
+  const V3 dX = sub(X0, T.t);
+  const V3 X0rot{T.R.m[0][0] * dX.x + T.R.m[1][0] * dX.y + T.R.m[2][0] * dX.z, T.R.m[0][1] * dX.x + T.R.m[1][1] * dX.y + T.R.m[2][1] * dX.z,
+                 T.R.m[0][2] * dX.x + T.R.m[1][2] * dX.y + T.R.m[2][2] * dX.z};
+  const V3 dirRot{T.R.m[0][0] * lineDir.x + T.R.m[1][0] * lineDir.y + T.R.m[2][0] * lineDir.z,
+                  T.R.m[0][1] * lineDir.x + T.R.m[1][1] * lineDir.y + T.R.m[2][1] * lineDir.z,
+                  T.R.m[0][2] * lineDir.x + T.R.m[1][2] * lineDir.y + T.R.m[2][2] * lineDir.z};
+  double d, p;
+  reproject_line_point_to_3d(X0rot, dirRot, kl[0], kl[1], K, &d, &p);
+  *X1 = add(X0, scale(lineDir, p));
+  reproject_line_point_to_3d(X0rot, dirRot, kl[2], kl[3], K, &d, &p);
+  *X2 = add(X0, scale(lineDir, p));
+}
+
+// the geometric part of CheckLinePair (everything before MatchLineDescriptors)
+bool pair_gate(const lld_line_stereo_params& P, const M34& T, const M34& T_right, const float* kl1, int oct1, const float* kl2, int oct2,
+               V3* X0_out) {
+  if (P.is_stereo && oct1 != oct2) return false;
+  const double len_thr = P.min_line_length;
+  if (line_length(kl1) < len_thr || line_length(kl2) < len_thr) return false;
+  V3 X0, line_dir;
+  const V3 leftEq = normalized_line_eq(kl1, P.K), rightEq = normalized_line_eq(kl2, P.K);
+  if (!triangulate_line(T, T_right, leftEq, rightEq, &X0, &line_dir) || norm(X0) < 0.5) return false;
+  V3 p1, p2;
+  reproject_keyline_to_3d(kl1, T, P.K, X0, line_dir, &p1, &p2);
+  if (p1.z < 0 || p2.z < 0) return false;
+  if (X0_out) *X0_out = X0;
+  return true;
+}
+
+void make_poses(const lld_line_stereo_params& P, M34* T, M34* T_right) {
+  T->R = m3_identity(); T->t = V3{0, 0, 0};                       // T.setIdentity()
+  *T_right = *T;                                                  // GetTForRight
+  T_right->t = add(T_right->t, m3_mulv(T_right->R, V3{P.b, 0, 0}));
+}
+
+}  // namespace
+
+extern "C" {
+
+// test hook: vgl::TriangulateLine + the two re-projected endpoints for one pair; out = X0(3) dir(3) p1(3) p2(3); returns the gate
+int lldo_line_pair_geometry(const lld_line_stereo_params* P, const float* kl1, const float* kl2, double* out) {
+  M34 T, Tr; make_poses(*P, &T, &Tr);
+  V3 X0{0, 0, 0}, dir{0, 0, 0}, p1{0, 0, 0}, p2{0, 0, 0};
+  const V3 l1 = normalized_line_eq(kl1, P->K), l2 = normalized_line_eq(kl2, P->K);
+  const bool ok = triangulate_line(T, Tr, l1, l2, &X0, &dir);
+  if (ok) reproject_keyline_to_3d(kl1, T, P->K, X0, dir, &p1, &p2);
+  const double v[12] = {X0.x, X0.y, X0.z, dir.x, dir.y, dir.z, p1.x, p1.y, p1.z, p2.x, p2.y, p2.z};
+  for (int i = 0; i < 12; i++) out[i] = v[i];
+  return ok ? 1 : 0;
+}
+
+// test hook: the restated ColPivHouseholderQR
+int lldo_colpiv_qr_solve(int m, int n, const double* A_rowmajor, const double* b, double* x) {
+  double A[3][3] = {{0}};
+  for (int i = 0; i < m; i++) for (int j = 0; j < n; j++) A[i][j] = A_rowmajor[i * n + j];
+  return colpiv_qr_solve(m, n, A, b, x);
+}
+
+// TwoFrameLineMatcher::MatchLines, whole routine
+int lldo_line_match_stereo(void*, const lld_line_stereo_params* P, const float* left_lines, const int32_t* left_octave, const float* desc_left, int nq,
+                           const float* right_lines, const int32_t* right_octave, const float* desc_right, int nt, int dim,
+                           int32_t* matches, double* match_dist, uint8_t* gate_out) {
+  M34 T, Tr; make_poses(*P, &T, &Tr);
+  std::vector<bool> is_matched(nq, false), is_other_matched(nt, false);
+  if (gate_out)
+    for (int j = 0; j < nq; j++) for (int oi = 0; oi < nt; oi++)
+      gate_out[(size_t)j * nt + oi] = pair_gate(*P, T, Tr, left_lines + 4 * j, left_octave[j], right_lines + 4 * oi, right_octave[oi], nullptr);
+  for (int j = 0; j < nq; j++) {
+    matches[j] = -1; if (match_dist) match_dist[j] = DBL_MAX;
+    if (is_matched[j]) continue;
+    double min_d = DBL_MAX, sec_min_d = DBL_MAX; int min_j = -1;
+    for (int oi = 0; oi < nt; oi++) {
+      if (is_other_matched[oi]) continue;
+      // CheckLinePair
+      if (!pair_gate(*P, T, Tr, left_lines + 4 * j, left_octave[j], right_lines + 4 * oi, right_octave[oi], nullptr)) continue;
+      const double d = lldo_l2f32(desc_left + (size_t)dim * j, desc_right + (size_t)dim * oi, dim);
+      double m = min_d; if (d < m) m = d;
+      if (m < min_d && m < P->tau) { sec_min_d = min_d; min_d = m; min_j = oi; }
+    }
+    (void)sec_min_d;
+    if (min_j >= 0) is_other_matched[min_j] = true;
+    matches[j] = min_j;
+    if (match_dist && min_j >= 0) match_dist[j] = min_d;
+  }
+  return LLD_OK;
+}
+
+}  // extern "C"

@@ -20,7 +20,7 @@ _LIB = None
 
 def build(force: bool = False) -> str:
     so = os.path.join(_HERE, "liblld_oracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("lld_oracle.cpp", "lldo_orbsearch.cpp", "lldo_math.h", "lldo_edges.h", "lldo_lm.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("lld_oracle.cpp", "lldo_orbsearch.cpp", "lldo_linematch.cpp", "lldo_math.h", "lldo_edges.h", "lldo_lm.h")]
     srcs.append(os.path.join(_HERE, "..", "include", "lld_amd.h"))
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
@@ -187,3 +187,31 @@ def match_l2f32(q, t, mask=None):
 
 def line_match_greedy(dl, dr, gate, tau):
     return host.greedy_call(lib(), None, dl, dr, gate, tau)
+
+
+def line_match_stereo(K, b, tau, min_line_length, left_lines, left_octave, dl, right_lines, right_octave, dr, want_gate=False):
+    """TwoFrameLineMatcher::MatchLines, literal (oracle/lldo_linematch.cpp)."""
+    return host.line_stereo_call(lib(), None, K, b, tau, min_line_length, left_lines, left_octave, dl, right_lines, right_octave, dr, True, want_gate)
+
+
+def line_pair_geometry(K, b, kl1, kl2):
+    """vgl::TriangulateLine + ReprojectKeyLineTo3D for one pair: (ok, X0, dir, p1, p2)."""
+    d = lib().dll
+    d.lldo_line_pair_geometry.argtypes = [C.POINTER(abi.LineStereoParams), abi.c_float_p, abi.c_float_p, abi.c_double_p]
+    d.lldo_line_pair_geometry.restype = C.c_int
+    P = abi.LineStereoParams()
+    for i, v in enumerate(np.asarray(K, np.float64).reshape(9)):
+        P.K[i] = float(v)
+    P.b = float(b); P.is_stereo = 1
+    a = np.ascontiguousarray(kl1, np.float32); bb = np.ascontiguousarray(kl2, np.float32); out = np.zeros(12)
+    ok = d.lldo_line_pair_geometry(C.byref(P), a.ctypes.data_as(abi.c_float_p), bb.ctypes.data_as(abi.c_float_p), _dp(out))
+    return bool(ok), out[0:3], out[3:6], out[6:9], out[9:12]
+
+
+def colpiv_qr_solve(A, b):
+    """The restated Eigen::ColPivHouseholderQR: (rank, x)."""
+    d = lib().dll
+    d.lldo_colpiv_qr_solve.argtypes = [C.c_int, C.c_int, abi.c_double_p, abi.c_double_p, abi.c_double_p]; d.lldo_colpiv_qr_solve.restype = C.c_int
+    A = _d(A); b = _d(b); x = np.zeros(A.shape[1])
+    r = d.lldo_colpiv_qr_solve(A.shape[0], A.shape[1], _dp(A), _dp(b), _dp(x))
+    return r, x

@@ -123,3 +123,32 @@ def test_batched_hamming_device_entry_point(gpu_ctx, oracle):
         exp = oracle.match_hamming256(qs[b], ts[b])
         for o, e in zip(outs, exp):
             np.testing.assert_array_equal(o[b].cpu().numpy(), e)
+
+
+@pytest.mark.parametrize("seed,nl,nr", [(0, 300, 300), (1, 257, 130), (2, 64, 400)])
+def test_stereo_line_association_gates_on_device(gpu_ctx, oracle, seed, nl, nr):
+    """TwoFrameLineMatcher::MatchLines incl. CheckLinePair's triangulation / depth gates (src/TwoFrameLineMatcher.cc:26-124): the gate
+    matrix and the greedy assignment equal the literal CPU restatement."""
+    s = synth.make_stereo_lines(seed, nl, nr)
+    tm = TwoFrameLineMatcher(gpu_ctx, 2.0, K=s["K"], b=s["b"], minLineLength=20)
+    m, d, gate = tm.MatchLines(s["desc_left"], s["desc_right"], lines=s["left"], other_lines=s["right"], octaves=s["left_octave"],
+                               other_octaves=s["right_octave"], want_gate=True)
+    me, de, ge = oracle.line_match_stereo(s["K"], s["b"], 2.0, 20, s["left"], s["left_octave"], s["desc_left"], s["right"], s["right_octave"],
+                                          s["desc_right"], want_gate=True)
+    np.testing.assert_array_equal(gate, ge)
+    np.testing.assert_array_equal(m, me)
+    np.testing.assert_array_equal(d[m >= 0], de[me >= 0])
+    assert (m >= 0).sum() > min(nl, nr) // 4
+
+
+def test_stereo_line_association_edge_cases(gpu_ctx, oracle):
+    s = synth.make_stereo_lines(3, 20, 20)
+    tm = TwoFrameLineMatcher(gpu_ctx, 2.0, K=s["K"], b=s["b"], minLineLength=20)
+    m, d = tm.MatchLines(s["desc_left"], np.zeros((0, 72), np.float32), lines=s["left"], other_lines=np.zeros((0, 4), np.float32),
+                         octaves=s["left_octave"], other_octaves=np.zeros(0, np.int32))
+    assert (m == -1).all()
+    # a minimum length nobody reaches: every gate closed
+    tm = TwoFrameLineMatcher(gpu_ctx, 2.0, K=s["K"], b=s["b"], minLineLength=100000)
+    m, d, gate = tm.MatchLines(s["desc_left"], s["desc_right"], lines=s["left"], other_lines=s["right"], octaves=s["left_octave"],
+                               other_octaves=s["right_octave"], want_gate=True)
+    assert (m == -1).all() and not gate.any()
