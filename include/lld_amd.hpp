@@ -127,6 +127,24 @@ class ORBmatcher {
                                    b.best_dist.data(), b.second_idx.data(), b.second_dist.data()), "lld_match_hamming256_csr");
     return b;
   }
+  // One whole Search* / Fuse / ComputeStereoMatches routine on the device: fill an lld_orb_search as INTEGRATION.md §4b shows
+  // (candidate generator, gates, accept rule, `sequential`, `check_orientation`), get the matches and the routine's return value.
+  struct SearchResult {
+    std::vector<int32_t> match, best_dist, second_dist, owner;
+    std::vector<uint8_t> removed;
+    int n_matches = 0, rounds = 0;
+  };
+  SearchResult Search(lld_orb_search s) const {
+    if (s.nnratio == 0.f) s.nnratio = mfNNratio;
+    SearchResult r;
+    r.match.resize(s.nq); r.best_dist.resize(s.nq); r.second_dist.resize(s.nq); r.removed.resize(s.nq); r.owner.resize(s.nt);
+    lld_orb_search_result o{};
+    o.match = r.match.data(); o.best_dist = r.best_dist.data(); o.second_dist = r.second_dist.data(); o.removed = r.removed.data();
+    o.owner = r.owner.data();
+    check(lld_orb_search_run(ctx_.get(), &s, &o), "lld_orb_search_run");
+    r.n_matches = o.n_matches; r.rounds = o.rounds;
+    return r;
+  }
  private:
   Context& ctx_;
  public:
@@ -138,6 +156,19 @@ class ORBmatcher {
 class TwoFrameLineMatcher {
  public:
   TwoFrameLineMatcher(Context& ctx, double tau) : ctx_(ctx), tau_(tau) {}
+  // TwoFrameLineMatcher(K, b, tau, minLineLength, lineMatcher): the whole MatchLines, gates included, on the device
+  TwoFrameLineMatcher(Context& ctx, const double K[9], double b, double tau, int minLineLength) : ctx_(ctx), tau_(tau) {
+    for (int i = 0; i < 9; i++) p_.K[i] = K[i];
+    p_.b = b; p_.tau = tau; p_.min_line_length = minLineLength; p_.is_stereo = 1; has_geometry_ = true;
+  }
+  // lines / other_lines: [n][4] startPointX, startPointY, endPointX, endPointY of the KeyLines
+  void MatchLines(const float* lines, const int32_t* octaves, int nLeft, const float* other_lines, const int32_t* other_octaves, int nRight,
+                  const float* descsLeft, const float* descsRight, int dim, std::vector<int>* desc_matches) const {
+    if (!has_geometry_) throw std::logic_error("TwoFrameLineMatcher constructed without K / b");
+    desc_matches->assign(nLeft, -1);
+    check(lld_line_match_stereo(ctx_.get(), &p_, lines, octaves, descsLeft, nLeft, other_lines, other_octaves, descsRight, nRight, dim,
+                                desc_matches->data(), nullptr, nullptr), "lld_line_match_stereo");
+  }
   void MatchLines(const float* descsLeft, int nLeft, const float* descsRight, int nRight, int dim, const std::vector<uint8_t>& gate,
                   std::vector<int>* desc_matches) const {
     desc_matches->assign(nLeft, -1);
@@ -147,6 +178,8 @@ class TwoFrameLineMatcher {
  private:
   Context& ctx_;
   double tau_;
+  lld_line_stereo_params p_{};
+  bool has_geometry_ = false;
 };
 
 }  // namespace lld_amd
