@@ -116,8 +116,9 @@ typedef struct {
   int32_t max_trials;       /* 10 (maxTrialsAfterFailure, optimization_algorithm_levenberg.cpp:50) */
   double  pcg_rel_tol;      /* reduced-system PCG stops at |r|_M / |b|_M <= tol (GPU only)     */
   int32_t pcg_max_iter;     /* 0 -> 10 * 6 * n_free_cams                                        */
-  int32_t reduced_solver;   /* GPU only: 0 = exact block Cholesky (default; the reference factorises exactly,
-                               linear_solver_eigen.h:94-124), 1 = block-Jacobi PCG                 */
+  int32_t reduced_solver;   /* GPU only: 0 = exact Cholesky (default; the reference factorises exactly,
+                               linear_solver_eigen.h:94-124) on the fp64 matrix cores when 6*n_free <= 304,
+                               1 = block-Jacobi PCG, 2 = exact 6x6-block Cholesky on the vector ALUs     */
 } lld_ba_params;
 
 void lld_ba_params_default(lld_ba_params* p);

@@ -120,7 +120,7 @@ int lld_ba_batch_create(lld_ctx* ctx, int n_windows, const lld_ba_window* wins, 
   B->ctx = ctx; B->n_windows = n_windows;
   if (params) B->params = *params; else lld_ba_params_default(&B->params);
   const lld_ba_params& P = B->params;
-  if (P.its_round1 < 0 || P.its_round2 < 0 || P.max_trials <= 0 || !(P.pcg_rel_tol > 0) || P.reduced_solver < 0 || P.reduced_solver > 1) { delete B; return LLD_ERR_INVALID; }
+  if (P.its_round1 < 0 || P.its_round2 < 0 || P.max_trials <= 0 || !(P.pcg_rel_tol > 0) || P.reduced_solver < 0 || P.reduced_solver > 2) { delete B; return LLD_ERR_INVALID; }
 
   // ---- layout + host staging
   std::vector<double> cam_qt0, pt0, ln_x0, ln_dir, pe_u, pe_v, pe_ur, pe_s, le_xs, le_ys, le_xe, le_ye, le_s, le_bx;
@@ -355,6 +355,8 @@ int lld_ba_batch_create(lld_ctx* ctx, int n_windows, const lld_ba_window* wins, 
     LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_linearize_pt_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lin_lds));
     LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_linearize_ln_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lin_lds));
     LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_chol_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+    LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_chol_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)(kCholMLdsDoubles * sizeof(double))));
   }
   LLD_HIP_TRY(hipMemcpyAsync(B->d_wins, B->h_wins.data(), sizeof(BAWin) * n_windows, hipMemcpyHostToDevice, st));
   LLD_HIP_TRY(hipHostMalloc((void**)&B->h_counters, 4 * 8 * sizeof(int), hipHostMallocDefault));
@@ -413,6 +415,8 @@ int lld_ba_batch_solve(lld_ba_batch* B, volatile const int* abort_flag) {
     LLD_HIP_TRY(hipEventRecord(G.ev[2], st));
     if (B->params.reduced_solver == 1)
       hipLaunchKernelGGL(ba_pcg_kernel, dim3(nw), dim3(kPcgThreads), pcg_lds, st, A, dw, ds, B->params.pcg_rel_tol, B->params.pcg_max_iter);
+    else if (B->params.reduced_solver == 0 && B->max_free * 6 <= kCholMN)      // register-resident tiles on the fp64 matrix cores
+      hipLaunchKernelGGL(ba_chol_mfma_kernel, dim3(nw), dim3(kCholMThreads), kCholMLdsDoubles * sizeof(double), st, A, dw, ds);
     else
       hipLaunchKernelGGL(ba_chol_kernel, dim3(nw), dim3(kPcgThreads), chol_lds, st, A, dw, ds, (int)(chol_tri / sizeof(double)));
     LLD_HIP_TRY(hipEventRecord(G.ev[3], st));
@@ -586,3 +590,7 @@ int lld_local_ba(lld_ctx* ctx, const lld_ba_window* in, const lld_ba_params* par
 }
 
 }  // extern "C"
+
+extern "C" int lld_debug_chol_cycles(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(lldba::g_chol_dbg), 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : -3;
+}

@@ -1466,6 +1466,245 @@ __global__ __launch_bounds__(kPcgThreads) void ba_chol_kernel(BAArrays A, const 
   solve_epilogue(A, W, S, x, scratch, ok, 0);
 }
 
+// ================================================================== exact solve on the fp64 matrix cores
+// grid (nW); block kCholMThreads (8 wavefronts); dynamic LDS kCholMLdsDoubles doubles.  For n = 6*n_free <= 304.
+// Right-looking Cholesky on 16x16 tiles with the WHOLE lower tile triangle held in registers for the entire factorisation
+// (<= 190 tiles, 28 per wavefront, 4 doubles per lane each): S is read from HBM exactly once, L never leaves the chip.
+// Wavefronts 1..7 own the tiles; wavefront 0 owns no tile and does the serial work, so its 16-double row buffers never compete
+// with the accumulator tiles for registers.  Per tile column J:
+//   (a) tile waves publish column J to LDS;
+//   (b) the panel wave factors the 16x16 diagonal tile right-looking with one lane per row — lane 16 carries the right-hand side
+//       and lanes 17..32 the identity as extra rows, which yields y_J and L_JJ^-1 from the same recurrence (v_readlane
+//       broadcasts, no LDS traffic inside the recurrence);
+//   (c) tile waves: L_IJ = A_IJ L_JJ^-T as four v_mfma_f64_16x16x4_f64 per tile, result kept in the registers (it is the L the
+//       back substitution needs) and written to LDS as the operand of (d);
+//   (d) tile waves: every tile (I,K), K > J, takes T -= L_IJ L_KJ^T on the matrix cores — operands are read once per 1024 FMAs
+//       instead of once per 1.5 as in the 6x6 register-blocked kernel above, whose trailing update is LDS-bandwidth bound;
+//       meanwhile the panel wave forward-substitutes the right-hand side below the tile.
+// Tile element layout of v_mfma_f64_16x16x4_f64: C/D lane l, register g -> (row (l>>4) + 4g, col l&15); A[i][k] and B[k][j]
+// come from lane i + 16k resp. j + 16k.
+constexpr int kCholMThreads = 512;
+constexpr int kCholMTileWaves = kCholMThreads / 64 - 1;
+constexpr int kCholMMaxTiles = 19;                                   // 19 * 16 = 304 >= 6 * 50
+constexpr int kCholMSlots = 28;                                      // ceil(190 / 7)
+constexpr int kCholMStride = 17;                                     // padded LDS row of 16 doubles
+constexpr int kCholMN = kCholMMaxTiles * 16;
+constexpr int kCholMLdsDoubles = kCholMN * kCholMStride + kCholMMaxTiles * 16 * kCholMStride + 16 * kCholMStride + 3 * kCholMN + 32;
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
+
+__device__ unsigned long long g_chol_dbg[8];
+__global__ __launch_bounds__(kCholMThreads) void ba_chol_mfma_kernel(BAArrays A, const BAWin* __restrict__ wins, BAState* __restrict__ st) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const BAWin W = wins[blockIdx.x];
+  BAState& S = st[blockIdx.x];
+  if (S.phase != PH_RUN) return;
+  const int nf = W.n_free, n = 6 * nf, NT = (n + 15) >> 4, N = NT << 4;
+  double* Lp = lds;                                        // [N][17]   column J: raw tiles after (a), L after (c)
+  double* Dall = Lp + kCholMN * kCholMStride;              // [NT][16][17] factors of the diagonal tiles
+  double* Li = Dall + kCholMMaxTiles * 16 * kCholMStride;  // [16][17] inverse of the current diagonal factor
+  double* invd = Li + 16 * kCholMStride;                   // [N] 1 / L_cc
+  double* y = invd + kCholMN;                              // [N] right-hand side -> forward solution
+  double* x = y + kCholMN;                                 // [N] solution
+  double* scratch = x + kCholMN;                           // [32]
+  double* colsum = scratch + 8;                            // [16] column sums of the back substitution
+  double* okf = scratch + 31;
+  const double* Sg = A.S + W.S_off;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lrow = lane >> 4, lcol = lane & 15;
+  if (tid < N) y[tid] = (tid < n) ? A.bschur[W.x_off + tid] : 0.0;
+  if (tid == 0) *okf = 1.0;
+  unsigned long long tA = 0, tB = 0, tC = 0, tD = 0, t0 = 0, t1;
+
+  if (wave == 0) {
+    // ================================================================ panel wave
+    __syncthreads();
+    t0 = wall_clock64();
+    for (int J = 0; J < NT; J++) {
+      double* Dg = Dall + J * 16 * kCholMStride;
+      __syncthreads();                                                 // (a) done
+      t1 = wall_clock64(); tA += t1 - t0; t0 = t1;
+      {
+        const int r = lane < 32 ? lane : 32;                           // 0..15 tile rows, 16 rhs, 17..32 identity rows
+        double a[16];
+#pragma unroll
+        for (int c = 0; c < 16; c++) a[c] = (r < 16) ? Dg[r * kCholMStride + c] : (r == 16 ? y[16 * J + c] : (r - 17 == c ? 1.0 : 0.0));
+        bool ok = true;
+#pragma unroll
+        for (int c = 0; c < 16; c++) {
+          const double d = readlane_f64(a[c], c);
+          if (!(d > 0.0) || !isfinite(d)) ok = false;
+          // 1/sqrt(d): v_rsq_f64 seed + two Newton steps (the library sqrt and divide are ~45 dependent instructions,
+          // which is what bounds this serial recurrence; the result is within an ulp or two, L L^T = S to rounding either way)
+          double inv = __builtin_amdgcn_rsq(d);
+          inv = inv * (1.5 - (0.5 * d) * (inv * inv));
+          inv = inv * (1.5 - (0.5 * d) * (inv * inv));
+          const double lc = a[c] * inv;                                        // lane c: sqrt(d); below: L[r][c]; rhs lane: y_c
+          a[c] = lc;
+          if (lane == 0) invd[16 * J + c] = inv;
+#pragma unroll
+          for (int c2 = c + 1; c2 < 16; c2++) a[c2] -= lc * readlane_f64(lc, c2);   // A[r][c2] -= L[r][c] L[c2][c]
+        }
+        if (lane < 16) {
+#pragma unroll
+          for (int c = 0; c < 16; c++) Dg[r * kCholMStride + c] = (c <= r) ? a[c] : 0.0;
+        } else if (lane == 16) {
+#pragma unroll
+          for (int c = 0; c < 16; c++) y[16 * J + c] = a[c];
+        } else if (lane <= 32) {                                                // lane 17+k holds column k of L^-1
+#pragma unroll
+          for (int c = 0; c < 16; c++) Li[c * kCholMStride + (lane - 17)] = a[c];
+        }
+        if (!ok && lane == 0) *okf = 0.0;
+      }
+      __syncthreads();                                                 // (b) done
+      t1 = wall_clock64(); tB += t1 - t0; t0 = t1;
+      __syncthreads();                                                 // (c) done: Lp holds L(:,J)
+      t1 = wall_clock64(); tC += t1 - t0; t0 = t1;
+      for (int row = 16 * (J + 1) + lane; row < N; row += 64) {        // y_i -= l_i . y_J
+        const double* pr = Lp + row * kCholMStride;
+        double dotv = 0.0;
+#pragma unroll
+        for (int c = 0; c < 16; c++) dotv += pr[c] * y[16 * J + c];
+        y[row] -= dotv;
+      }
+      __syncthreads();                                                 // (d) done
+      t1 = wall_clock64(); tD += t1 - t0; t0 = t1;
+    }
+    if (blockIdx.x == 0 && lane == 0) { g_chol_dbg[0] = tA; g_chol_dbg[1] = tB; g_chol_dbg[2] = tC; g_chol_dbg[3] = tD; }
+    t0 = wall_clock64();
+    for (int J = NT - 1; J >= 0; J--) {
+      if (lane < 16) colsum[lane] = 0.0;
+      __syncthreads();
+      __syncthreads();                                                 // column sums complete
+      const double* Dg = Dall + J * 16 * kCholMStride;
+      const int c = lane & 15;
+      double colc[16];                                                 // column c of L_JJ and 1/L_cc: no LDS inside the recurrence
+#pragma unroll
+      for (int m = 0; m < 16; m++) colc[m] = Dg[m * kCholMStride + c];
+      const double ic = invd[16 * J + c];
+      double t = y[16 * J + c] - colsum[c], xc = 0.0;
+#pragma unroll
+      for (int m = 15; m >= 0; m--) {
+        const double xm = readlane_f64(t * ic, m);                     // x_m = (y_m - sum_{m'>m} L[m'][m] x_m') / L[m][m]
+        if (c == m) xc = xm;
+        t -= colc[m] * xm;                                             // only lanes c < m use t again
+      }
+      if (lane < 16) x[16 * J + c] = xc;
+      __syncthreads();
+    }
+    if (blockIdx.x == 0 && lane == 0) g_chol_dbg[5] = wall_clock64() - t0;
+  } else {
+    // ================================================================ tile waves
+    // tile coordinates of this wavefront's slots (wave-uniform): tile t = slot * 7 + (wave - 1), t = I (I + 1) / 2 + K
+    int tI[kCholMSlots], tK[kCholMSlots];
+    const int n_tiles = NT * (NT + 1) / 2;
+#pragma unroll
+    for (int sl = 0; sl < kCholMSlots; sl++) {
+      const int t = sl * kCholMTileWaves + (wave - 1);
+      int I = 0;                                                       // integer-only: stays in scalar registers
+      while ((I + 1) * (I + 2) / 2 <= t) I++;
+      tI[sl] = (t < n_tiles) ? I : -1;
+      tK[sl] = (t < n_tiles) ? t - I * (I + 1) / 2 : -1;
+    }
+    // S -> registers (lower triangle; the padding rows/columns carry an identity so that L is the identity there)
+    v4d acc[kCholMSlots];
+#pragma unroll
+    for (int sl = 0; sl < kCholMSlots; sl++) {
+      v4d v = {0.0, 0.0, 0.0, 0.0};
+      if (tI[sl] >= 0) {
+        const int col = 16 * tK[sl] + lcol;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          const int row = 16 * tI[sl] + lrow + 4 * g;
+          double e = 0.0;
+          if (row < n && col < n) { if (col <= row) e = Sg[(size_t)row * n + col]; }
+          else if (row == col) e = 1.0;
+          v[g] = e;
+        }
+      }
+      acc[sl] = v;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+    for (int J = 0; J < NT; J++) {
+      // Per-lane LDS offsets, made opaque once per iteration: otherwise the per-slot addresses are hoisted out of the J loop as
+      // loop invariants and push the accumulator tiles out of the register file.
+      int off_cd = lrow * kCholMStride + lcol, off_ab = lcol * kCholMStride + lrow;
+      asm volatile("" : "+v"(off_cd), "+v"(off_ab));
+      double* Dg = Dall + J * 16 * kCholMStride;
+      // (a) publish tile column J (raw)
+#pragma unroll
+      for (int sl = 0; sl < kCholMSlots; sl++) {
+        if (tK[sl] == J) {
+          double* dst = ((tI[sl] == J) ? Dg : Lp + 16 * tI[sl] * kCholMStride) + off_cd;
+#pragma unroll
+          for (int g = 0; g < 4; g++) dst[4 * g * kCholMStride] = acc[sl][g];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __syncthreads();                                                 // (a) done
+      __syncthreads();                                                 // (b) done: Li = L_JJ^-1
+      // (c) L_IJ = A_IJ L_JJ^-T on the matrix cores; keep it (back substitution) and publish it (operand of d)
+#pragma unroll
+      for (int sl = 0; sl < kCholMSlots; sl++) {
+        if (tK[sl] == J && tI[sl] > J) {
+          const double* pa = Lp + 16 * tI[sl] * kCholMStride + off_ab;
+          const double* pb = Li + off_ab;
+          v4d c = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int kk = 0; kk < 4; kk++) c = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[4 * kk], pb[4 * kk], c, 0, 0, 0);
+          acc[sl] = c;
+          double* dst = Lp + 16 * tI[sl] * kCholMStride + off_cd;
+#pragma unroll
+          for (int g = 0; g < 4; g++) dst[4 * g * kCholMStride] = c[g];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __syncthreads();                                                 // (c) done
+      // (d) trailing update
+#pragma unroll
+      for (int sl = 0; sl < kCholMSlots; sl++) {
+        if (tK[sl] > J) {
+          const double* pa = Lp + 16 * tI[sl] * kCholMStride + off_ab;
+          const double* pb = Lp + 16 * tK[sl] * kCholMStride + off_ab;
+          v4d c = acc[sl];
+#pragma unroll
+          for (int kk = 0; kk < 4; kk++) c = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[4 * kk], pb[4 * kk], c, 0, 0, 0);
+          acc[sl] = c;
+        }
+        __builtin_amdgcn_sched_barrier(0);                             // keep the operand loads of later tiles from piling up in registers
+      }
+      __syncthreads();                                                 // (d) done
+    }
+    // back substitution L^T x = y: L lives in the register tiles, s_c = sum_{i below tile J} L[i][16J + c] x_i
+    for (int J = NT - 1; J >= 0; J--) {
+      __syncthreads();                                                 // colsum cleared, x of the tiles below is final
+      double part = 0.0; bool any = false;
+#pragma unroll
+      for (int sl = 0; sl < kCholMSlots; sl++) {
+        if (tK[sl] == J && tI[sl] > J) {
+#pragma unroll
+          for (int g = 0; g < 4; g++) part += acc[sl][g] * x[16 * tI[sl] + lrow + 4 * g];
+          any = true;
+        }
+      }
+      if (any) {                                                       // wave-uniform
+        part += __shfl_xor(part, 16); part += __shfl_xor(part, 32);    // sum over the 4 row groups of a column
+        if (lane < 16) atomicAdd(&colsum[lane], part);
+      }
+      __syncthreads();
+      __syncthreads();                                                 // x_J ready
+    }
+  }
+  const bool ok = *okf != 0.0;
+  solve_epilogue(A, W, S, x, scratch, ok, 0);
+}
+
 
 // ================================================================== LM control
 // grid (nW), block 64: lane 0 takes the accept / reject decision of the trial that just ran
