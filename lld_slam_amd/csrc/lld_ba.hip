@@ -590,7 +590,3 @@ int lld_local_ba(lld_ctx* ctx, const lld_ba_window* in, const lld_ba_params* par
 }
 
 }  // extern "C"
-
-extern "C" int lld_debug_chol_cycles(unsigned long long* out) {
-  return hipMemcpyFromSymbol(out, HIP_SYMBOL(lldba::g_chol_dbg), 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : -3;
-}

@@ -1497,7 +1497,6 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
   return __hiloint2double(hi, lo);
 }
 
-__device__ unsigned long long g_chol_dbg[8];
 __global__ __launch_bounds__(kCholMThreads) void ba_chol_mfma_kernel(BAArrays A, const BAWin* __restrict__ wins, BAState* __restrict__ st) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const BAWin W = wins[blockIdx.x];
@@ -1518,16 +1517,13 @@ __global__ __launch_bounds__(kCholMThreads) void ba_chol_mfma_kernel(BAArrays A,
   const int lrow = lane >> 4, lcol = lane & 15;
   if (tid < N) y[tid] = (tid < n) ? A.bschur[W.x_off + tid] : 0.0;
   if (tid == 0) *okf = 1.0;
-  unsigned long long tA = 0, tB = 0, tC = 0, tD = 0, t0 = 0, t1;
 
   if (wave == 0) {
     // ================================================================ panel wave
     __syncthreads();
-    t0 = wall_clock64();
     for (int J = 0; J < NT; J++) {
       double* Dg = Dall + J * 16 * kCholMStride;
       __syncthreads();                                                 // (a) done
-      t1 = wall_clock64(); tA += t1 - t0; t0 = t1;
       {
         const int r = lane < 32 ? lane : 32;                           // 0..15 tile rows, 16 rhs, 17..32 identity rows
         double a[16];
@@ -1562,9 +1558,7 @@ __global__ __launch_bounds__(kCholMThreads) void ba_chol_mfma_kernel(BAArrays A,
         if (!ok && lane == 0) *okf = 0.0;
       }
       __syncthreads();                                                 // (b) done
-      t1 = wall_clock64(); tB += t1 - t0; t0 = t1;
       __syncthreads();                                                 // (c) done: Lp holds L(:,J)
-      t1 = wall_clock64(); tC += t1 - t0; t0 = t1;
       for (int row = 16 * (J + 1) + lane; row < N; row += 64) {        // y_i -= l_i . y_J
         const double* pr = Lp + row * kCholMStride;
         double dotv = 0.0;
@@ -1573,10 +1567,7 @@ __global__ __launch_bounds__(kCholMThreads) void ba_chol_mfma_kernel(BAArrays A,
         y[row] -= dotv;
       }
       __syncthreads();                                                 // (d) done
-      t1 = wall_clock64(); tD += t1 - t0; t0 = t1;
     }
-    if (blockIdx.x == 0 && lane == 0) { g_chol_dbg[0] = tA; g_chol_dbg[1] = tB; g_chol_dbg[2] = tC; g_chol_dbg[3] = tD; }
-    t0 = wall_clock64();
     for (int J = NT - 1; J >= 0; J--) {
       if (lane < 16) colsum[lane] = 0.0;
       __syncthreads();
@@ -1597,7 +1588,6 @@ __global__ __launch_bounds__(kCholMThreads) void ba_chol_mfma_kernel(BAArrays A,
       if (lane < 16) x[16 * J + c] = xc;
       __syncthreads();
     }
-    if (blockIdx.x == 0 && lane == 0) g_chol_dbg[5] = wall_clock64() - t0;
   } else {
     // ================================================================ tile waves
     // tile coordinates of this wavefront's slots (wave-uniform): tile t = slot * 7 + (wave - 1), t = I (I + 1) / 2 + K
@@ -1677,7 +1667,7 @@ __global__ __launch_bounds__(kCholMThreads) void ba_chol_mfma_kernel(BAArrays A,
           for (int kk = 0; kk < 4; kk++) c = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[4 * kk], pb[4 * kk], c, 0, 0, 0);
           acc[sl] = c;
         }
-        __builtin_amdgcn_sched_barrier(0);                             // keep the operand loads of later tiles from piling up in registers
+        if (sl & 1) __builtin_amdgcn_sched_barrier(0);                 // let the loads of one tile overlap the MFMAs of its neighbour, not more
       }
       __syncthreads();                                                 // (d) done
     }

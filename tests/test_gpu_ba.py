@@ -56,13 +56,29 @@ def test_small_windows_match_oracle(gpu_ctx, oracle, wid, kw):
     check_ba(Optimizer(gpu_ctx).LocalBundleAdjustment(w), oracle.local_ba(w), w)
 
 
-@pytest.mark.parametrize("solver", [0, 1])
-def test_both_reduced_solvers(gpu_ctx, oracle, solver):
-    """reduced_solver 0 = exact block Cholesky (default), 1 = block-Jacobi PCG (rel. tol 1e-12)."""
+@pytest.mark.parametrize("solver", [0, 1, 2])
+def test_all_reduced_solvers(gpu_ctx, oracle, solver):
+    """reduced_solver 0 = exact Cholesky on the fp64 matrix cores (default), 1 = block-Jacobi PCG (rel. tol 1e-12),
+    2 = exact 6x6-block Cholesky on the vector ALUs."""
     w = synth.make_lba_small(9, n_free=12, n_fixed=3, n_points=500, n_lines=80)
     check_ba(Optimizer(gpu_ctx).LocalBundleAdjustment(w, reduced_solver=solver), oracle.local_ba(w), w)
     wa = synth.make_lba_a(1)
     check_ba(Optimizer(gpu_ctx).LocalBundleAdjustment(wa, reduced_solver=solver), oracle.local_ba(wa), wa)
+
+
+@pytest.mark.parametrize("n_free", [1, 2, 3, 5, 8, 11, 16, 27, 50])
+def test_matrix_core_cholesky_at_every_tile_padding(gpu_ctx, oracle, n_free):
+    """6*n_free runs through every residue modulo the 16-wide tiles (6, 12, 18, 30, 48, 66, 96, 162, 300): padding rows,
+    partial last tiles and the 1- and 19-tile extremes of the register-resident factorisation."""
+    w = synth.make_lba_small(40 + n_free, n_free=n_free, n_fixed=max(2, 7 - n_free), n_points=60 * n_free + 80, n_lines=8 * n_free + 10)
+    check_ba(Optimizer(gpu_ctx).LocalBundleAdjustment(w), oracle.local_ba(w), w)
+
+
+def test_windows_above_the_matrix_core_limit_use_the_vector_cholesky(gpu_ctx, oracle):
+    """More than 50 free cameras (6*n_free > 304) do not fit the register-resident tile triangle: the batch falls back to the
+    6x6-block kernel, not to an error."""
+    w = synth.make_lba_small(77, n_free=54, n_fixed=3, n_points=1500, n_lines=150)
+    check_ba(Optimizer(gpu_ctx).LocalBundleAdjustment(w), oracle.local_ba(w), w)
 
 
 def test_gamma_and_iteration_parameters(gpu_ctx, oracle):
