@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Builds profiles/roofline_traffic.json from the FETCH_SIZE / WRITE_SIZE summaries of tools/profile_pmc.sh:
+HBM-side bytes per launch of each kernel family = sum over its kernels of the per-dispatch average.
+
+    python tools/make_roofline_traffic.py gpurun_out/pmc_<tag> > profiles/roofline_traffic.json
+"""
+import json, re, sys
+
+FAMILIES = {"ba_linearize": ("ba_linearize_pt", "ba_linearize_ln", "ba_hpp_reduce", "ba_begin"),
+            "ba_schur": ("ba_schur_items_kernel<3>", "ba_schur_items_kernel<4>", "ba_schur_reduce", "ba_symmetrize"),
+            "ba_pcg": ("ba_chol_mfma", "ba_chol_kernel", "ba_pcg"),
+            "ba_backsub": ("ba_backsub_pt", "ba_backsub_ln"),
+            "ba_control": ("ba_control",)}
+
+
+def per_dispatch(path, counter):
+    out = {}
+    for line in open(path):
+        m = re.match(r"^(.*?)\s+" + counter + r"\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s*$", line.rstrip())
+        if m:
+            out[m.group(1).strip()] = float(m.group(4))
+    return out
+
+
+def main(d):
+    fetch = per_dispatch(d + "/tcc_fetch.txt", "FETCH_SIZE"); write = per_dispatch(d + "/tcc_write.txt", "WRITE_SIZE")
+    res = {"_note": "HBM-side bytes per launch of each kernel family (sum of its kernels' per-dispatch averages) from rocprofv3 --pmc "
+                    "FETCH_SIZE / WRITE_SIZE passes, bench.py --windows-per-gpu 256, one stream (LLD_BA_GROUPS=1, what bench.py's roofline "
+                    "pass times). Counters are in KiB; FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950 (it tallies 128-B "
+                    "requests at 64 B); WRITE_SIZE is uncalibrated.", "_raw_KiB": {}}
+    for fam, kernels in FAMILIES.items():
+        f = sum(v for k, v in fetch.items() if any(x in k for x in kernels)); w = sum(v for k, v in write.items() if any(x in k for x in kernels))
+        res["_raw_KiB"][fam] = {"FETCH_SIZE": round(f, 1), "WRITE_SIZE": round(w, 1)}
+        res[fam] = int((2.0 * f + w) * 1024)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])

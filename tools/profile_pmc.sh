@@ -1,8 +1,8 @@
 #!/bin/bash
 # PMC passes for the local-BA kernels (each counter group in its OWN rocprofv3 run, with --kernel-trace only, as the
-# MI355X guide prescribes).  Run on the GPU box:  bash tools/profile_pmc.sh <tag> [windows]
+# MI355X guide prescribes).  Run on the GPU box:  bash tools/profile_pmc.sh <tag> [windows] [groups]
 set -u
-TAG=${1:-r01}; NW=${2:-64}
+TAG=${1:-r01}; NW=${2:-64}; export LLD_BA_GROUPS=${3:-1}   # one stream by default: what bench.py's roofline pass times
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/pmc_$TAG
 mkdir -p $OUT
