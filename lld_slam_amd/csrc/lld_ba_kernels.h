@@ -999,31 +999,56 @@ __device__ __forceinline__ void schur_chunk_wave(const BAArrays& A, const BAWin&
     cacc[0] = 0.0; cacc[1] = 0.0;
     const int slots = NB * k;                               // <= 64: lane e <-> (landmark e / k, slot e % k)
     const int ej = lane / k, esl = lane - ej * k;
+    const bool stager = lane < slots;
+    // The staging lanes run one sub-batch AHEAD of the products: the camera pose of a lane's slot is loop-invariant, the
+    // landmark / edge indices are fetched two sub-batches ahead and the landmark data one ahead, so the two dependent
+    // HBM/L2 round trips (index -> data) of a sub-batch overlap the block products of the previous one instead of
+    // stalling the single wavefront of the workgroup.
+    Pose T;
+    if constexpr (D == 3) { if (stager) T = load_cam(A, cur, W.cam_off + A.sg_cams[C.cams_off + esl]); }
+    int g_n = 0, id_n = 0, g_nn = 0, id_nn = 0;
+    double v_n[VN];
+    double ws_n = 0.0; bool stereo_n = false, a_n = false; Vec3 X_n;
+    auto fetch_idx = [&](int t0, int& g, int& id) {
+      if (stager && t0 + ej < C.n_lm) { g = lm[t0 + ej]; id = tab[(t0 + ej) * k + esl]; }
+    };
+    auto fetch_data = [&](int t0, int g, int id) {
+      if (stager && t0 + ej < C.n_lm) {
+        a_n = act[g] != 0;
+        const double* V = Vbase + (size_t)g * VN;
+#pragma unroll
+        for (int i = 0; i < VN; i++) v_n[i] = V[i];
+        if constexpr (D == 3) { ws_n = A.pe_ws[id]; stereo_n = (A.pe_flags[id] & EF_STEREO) != 0; X_n = load_pt(A, cur, g); }
+      }
+    };
+    fetch_idx(0, g_n, id_n);
+    fetch_idx(NB, g_nn, id_nn);
+    fetch_data(0, g_n, id_n);
     for (int t0 = 0; t0 < C.n_lm; t0 += NB) {
       const int nb = (C.n_lm - t0) < NB ? (C.n_lm - t0) : NB;
+      // this sub-batch's operands (arrived while the previous products ran) -> locals; then put the next loads in flight
+      const bool a = a_n;
+      double w[WN], v[VN];
+#pragma unroll
+      for (int i = 0; i < VN; i++) v[i] = v_n[i];
+      double ws = ws_n; bool stereo = stereo_n; Vec3 X = X_n;
+      const int id_cur = id_n;
+      g_n = g_nn; id_n = id_nn;
+      fetch_data(t0 + NB, g_n, id_n);
+      fetch_idx(t0 + 2 * NB, g_nn, id_nn);
       __syncthreads();                                      // the previous sub-batch has been consumed
-      // lane (landmark, slot): fetch the Hpl block and Hll/b_l with independent 16-B loads (one memory round trip),
-      // invert Hll + lambda I, leave W and Y = W Dinv in LDS
-      if (lane < slots && ej < nb) {
-        const int g = lm[t0 + ej];
-        const int id = tab[(t0 + ej) * k + esl];
-        const bool a = act[g] != 0;
-        const double* V = Vbase + (size_t)g * VN;
-        double w[WN], v[VN];
+      // lane (landmark, slot): build the Hpl block, invert Hll + lambda I, leave W and Y = W Dinv in LDS
+      if (stager && ej < nb) {
         if constexpr (D == 3) {
           // point edge: the Hpl block is a function of the linearisation-point pose, point and weight only
-          const double ws = A.pe_ws[id];
-          const bool stereo = (A.pe_flags[id] & EF_STEREO) != 0;
-          const Pose T = load_cam(A, cur, W.cam_off + A.sg_cams[C.cams_off + esl]);
-          const Vec3 X = load_pt(A, cur, g);
           point_hpl(W.cam, T, X, stereo, ws, w);
         } else {
-          const double* Wg = A.lo_W + (size_t)id * WN;
+          // line observation: the summed 6x4 block was stored by the linearisation (24 doubles; fetched here, not a sub-batch
+          // ahead: holding two of them would halve the occupancy)
+          const double* Wg = A.lo_W + (size_t)id_cur * WN;
 #pragma unroll
           for (int i = 0; i < WN; i += 2) { const double2 t2 = *reinterpret_cast<const double2*>(Wg + i); w[i] = t2.x; w[i + 1] = t2.y; }
         }
-#pragma unroll
-        for (int i = 0; i < VN; i++) v[i] = V[i];
         double Di[DD];
         if (a) {
           double F[DD];
