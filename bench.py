@@ -147,6 +147,22 @@ def main():
     phase += batch.phase_ms()
     launches += np.array([batch.kernel_stats(k)[0] for k in range(5)])
     batch.set_groups(0)
+    # Measured stream ceiling of this GPU (SURVEY.md §8d asks for it next to the nominal 8 TB/s): a device-to-device copy of 2 GiB,
+    # bytes read + bytes written over the HIP-event time, best of 5.
+    stream_gbs = None
+    if rank == 0:
+        try:
+            a = torch.empty(1 << 31, dtype=torch.uint8, device=dev); b = torch.empty_like(a)
+            b.copy_(a); torch.cuda.synchronize()
+            best = 1e30
+            for _ in range(5):
+                e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+                e0.record(); b.copy_(a); e1.record(); torch.cuda.synchronize()
+                best = min(best, e0.elapsed_time(e1))
+            stream_gbs = round(2.0 * a.numel() / (best * 1e-3) / 1e9, 1)
+            del a, b
+        except Exception:
+            stream_gbs = None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -174,7 +190,7 @@ def main():
             except Exception:
                 traffic = None
         roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "measured_copy_ceiling_GBps": stream_gbs,
                     "launches_per_step": dom_launches, "avg_launch_ms": round(dom_ms / max(dom_launches, 1), 4),
                     "algorithmic_bytes_per_launch": int(per[kname] / max(dom_launches, 1)),
                     "phase_ms_single_stream_step": {k: round(phase[i] / prof_steps, 3) for i, k in enumerate(PHASES)},
@@ -189,8 +205,16 @@ def main():
             rel = max(abs(stats[i]["chi2_final"] - ores[i].stats["chi2_final"]) / max(ores[i].stats["chi2_final"], 1e-300) for i in range(ns))
             same = all(np.array_equal(batch.download(i).pt_obs_outlier, ores[i].pt_obs_outlier) and
                        np.array_equal(batch.download(i).line_removed, ores[i].line_removed) for i in range(ns))
+            # the same port with one window per host thread (the reference's g2o is single-threaded per window; ctypes drops the GIL)
+            from concurrent.futures import ThreadPoolExecutor
+            nthr = max(1, min(os.cpu_count() or 1, 32, wpg))
+            tp = time.perf_counter()
+            with ThreadPoolExecutor(nthr) as ex:
+                list(ex.map(lambda i: O.local_ba(windows[i]), range(nthr)))
+            par_s = time.perf_counter() - tp
             cpu = {"value": round(ns / cpu_s, 4), "unit": "windows/s", "cores": 1, "kind": "port",
-                   "sample": f"{ns} LBA-B windows (ids 0..{ns - 1}) through oracle/liblld_oracle.so, 1 thread, exact dense LDLT of the reduced system"}
+                   "sample": f"{ns} LBA-B windows (ids 0..{ns - 1}) through oracle/liblld_oracle.so, 1 thread, exact dense LDLT of the reduced system",
+                   "all_cores": {"value": round(nthr / par_s, 4), "cores": nthr, "sample": f"{nthr} windows, one per thread, concurrently"}}
             parity = {"windows_checked": ns, "max_rel_chi2_final": float(rel), "outlier_sets_identical": bool(same)}
         result = {
             "metric": METRIC, "value": round(value, 3), "unit": "windows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
