@@ -411,6 +411,38 @@ typedef struct {
 } lld_orb_search_result;
 
 int lld_orb_search_run(lld_ctx* ctx, const lld_orb_search* s, lld_orb_search_result* out);
+/* Tracking::SearchLocalPoints (src/Tracking.cc:1613-1664) in one call: Frame::isInFrustum (src/Frame.cc:333-389) for every
+ * local MapPoint ON THE DEVICE - camera transform, projection, image bounds, scale-invariance distance band, viewing angle,
+ * MapPoint::PredictScale (src/MapPoint.cc:402-417), mTrackProjXR - and then ORBmatcher::SearchByProjection(F, vpMapPoints, th)
+ * (src/ORBmatcher.cc:45-129) on the projected points without a trip through the host.
+ * The float / double mixture follows the reference's OpenCV calls as this build restates them (OpenCV is not in the image:
+ * parity unpinned): `mRcw*P+mtcw` is one cv::gemm, i.e. float(sum_k double(R_ik) double(P_k) + double(t_i)); `P-mOw` a float
+ * subtraction; cv::norm and Mat::dot accumulate in double; everything else is float arithmetic in source order; log() of a
+ * float is the float overload.
+ * `frame`: only the keypoint side (nt, t_*), the grid constants and n_levels / level_scale are read.
+ * frustum outputs (any may be NULL): in_view[n] (mbTrackInView), proj_uvr[n][3] (mTrackProjX, mTrackProjY, mTrackProjXR),
+ * level[n] (mnTrackScaleLevel), view_cos[n] (mTrackViewCos); values of points outside the frustum are unspecified. */
+typedef struct {
+  float Rcw[9], tcw[3], Ow[3];          /* Frame::mRcw, mtcw, mOw (UpdatePoseMatrices, src/Frame.cc:325-331) */
+  float fx, fy, cx, cy, bf;             /* mbf = baseline * fx */
+  float min_x, max_x, min_y, max_y;     /* mnMinX ... */
+  float log_scale_factor;               /* mfLogScaleFactor */
+  int32_t n_levels;                     /* mnScaleLevels */
+} lld_frame_view;
+typedef struct {
+  int32_t n;
+  const float*    world_pos;            /* [n][3] MapPoint::GetWorldPos */
+  const float*    normal;               /* [n][3] GetNormal */
+  const float*    max_distance;         /* [n] mfMaxDistance (GetMaxDistanceInvariance = 1.2f * it) */
+  const float*    min_distance;         /* [n] mfMinDistance (0.8f * it) */
+  const uint32_t* desc;                 /* [n][8] GetDescriptor */
+  const uint8_t*  has_obs;              /* [n] Observations()>0, or NULL = all 1 */
+  const uint8_t*  skip;                 /* [n] or NULL: mnLastFrameSeen == frame id || isBad (src/Tracking.cc:1640-1643) */
+} lld_map_points;
+typedef struct { uint8_t* in_view; float* proj_uvr; int32_t* level; float* view_cos; } lld_frustum_result;
+int lld_orb_search_local_points(lld_ctx* ctx, const lld_orb_search* frame, const lld_frame_view* view, const lld_map_points* points,
+                                float viewing_cos_limit, float th, float nnratio,
+                                lld_frustum_result* frustum_or_null, lld_orb_search_result* out);
 /* `n` independent problems (e.g. one relocalisation / loop candidate keyframe each, or the searches of several frames) in one
  * launch: one workgroup per problem, all inputs moved in one host-to-device copy and all outputs in one copy back. */
 int lld_orb_search_batch(lld_ctx* ctx, int n, const lld_orb_search* problems, lld_orb_search_result* outs);

@@ -334,6 +334,71 @@ __global__ __launch_bounds__(kThreads) void orb_search_kernel(const Problem* __r
   if (tid == 0) { P.summary[0] = ctl[1] - ctl[2]; P.summary[1] = rounds; }
 }
 
+// Frame::isInFrustum (src/Frame.cc:333-389) for one MapPoint per lane, written straight into the query record of the search
+// kernel.  Float / double mixture as the reference's OpenCV calls (see include/lld_amd.h); every float operation is an explicit
+// round-to-nearest intrinsic, so nothing is contracted into an FMA.
+struct FrustumArgs {
+  lld_frame_view V;
+  int n;
+  const float* pos; const float* nrm; const float* maxd; const float* mind; const uint8_t* has_obs; const uint8_t* skip;
+  float scale[LLD_ORB_MAX_LEVELS];
+  float cos_limit, th;
+  QRec* q; uint8_t* in_view; float* uvr; int32_t* level; float* view_cos;
+};
+
+__global__ __launch_bounds__(256) void frustum_kernel(FrustumArgs F) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= F.n) return;
+  QRec Q; memset(&Q, 0, sizeof(Q));
+  Q.level_min = -1; Q.level_max = -1;
+  Q.flags = (!F.has_obs || F.has_obs[i]) ? 2 : 0;
+  bool ok = !(F.skip && F.skip[i]);
+  float u = 0.f, v = 0.f, ur = 0.f, vc = 0.f; int lvl = 0;
+  do {
+    if (!ok) break;
+    const float P[3] = {F.pos[3 * i], F.pos[3 * i + 1], F.pos[3 * i + 2]};
+    float Pc[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++)                                                  // cv::gemm: double accumulation, one rounding
+      Pc[r] = (float)__dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn((double)F.V.Rcw[3 * r], (double)P[0]), __dmul_rn((double)F.V.Rcw[3 * r + 1], (double)P[1])),
+                                         __dmul_rn((double)F.V.Rcw[3 * r + 2], (double)P[2])), (double)F.V.tcw[r]);
+    ok = false;
+    if (Pc[2] < 0.0f) break;
+    const float invz = __fdiv_rn(1.0f, Pc[2]);
+    u = __fadd_rn(__fmul_rn(__fmul_rn(F.V.fx, Pc[0]), invz), F.V.cx);
+    v = __fadd_rn(__fmul_rn(__fmul_rn(F.V.fy, Pc[1]), invz), F.V.cy);
+    if (u < F.V.min_x || u > F.V.max_x) break;
+    if (v < F.V.min_y || v > F.V.max_y) break;
+    const float maxDistance = __fmul_rn(1.2f, F.maxd[i]), minDistance = __fmul_rn(0.8f, F.mind[i]);
+    const float PO[3] = {__fsub_rn(P[0], F.V.Ow[0]), __fsub_rn(P[1], F.V.Ow[1]), __fsub_rn(P[2], F.V.Ow[2])};
+    const double n2 = __dadd_rn(__dadd_rn(__dmul_rn((double)PO[0], (double)PO[0]), __dmul_rn((double)PO[1], (double)PO[1])), __dmul_rn((double)PO[2], (double)PO[2]));
+    const float dist = (float)__dsqrt_rn(n2);                                    // cv::norm
+    if (dist < minDistance || dist > maxDistance) break;
+    const double dotv = __dadd_rn(__dadd_rn(__dmul_rn((double)PO[0], (double)F.nrm[3 * i]), __dmul_rn((double)PO[1], (double)F.nrm[3 * i + 1])),
+                                  __dmul_rn((double)PO[2], (double)F.nrm[3 * i + 2]));
+    vc = (float)__ddiv_rn(dotv, (double)dist);                                   // PO.dot(Pn)/dist
+    if (vc < F.cos_limit) break;
+    const float ratio = __fdiv_rn(F.maxd[i], dist);                              // MapPoint::PredictScale
+    lvl = (int)ceilf(__fdiv_rn(logf(ratio), F.V.log_scale_factor));
+    if (lvl < 0) lvl = 0; else if (lvl >= F.V.n_levels) lvl = F.V.n_levels - 1;
+    ur = __fsub_rn(u, __fmul_rn(F.V.bf, invz));
+    ok = true;
+  } while (false);
+  if (ok) {
+    float r = ((double)vc > 0.998) ? 2.5f : 4.0f;                                // RadiusByViewingCos, src/ORBmatcher.cc:131-137
+    if (F.th != 1.0f) r = __fmul_rn(r, F.th);
+    const float radius = __fmul_rn(r, F.scale[lvl]);
+    Q.u = u; Q.v = v; Q.radius = radius; Q.ur = ur; Q.stereo_radius = radius;
+    Q.level_min = lvl - 1; Q.level_max = lvl;
+    Q.flags |= 1;
+  }
+  F.q[i] = Q;
+  if (F.in_view) F.in_view[i] = ok ? 1 : 0;
+  if (F.uvr) { F.uvr[3 * i] = u; F.uvr[3 * i + 1] = v; F.uvr[3 * i + 2] = ur; }
+  if (F.level) F.level[i] = lvl;
+  if (F.view_cos) F.view_cos[i] = vc;
+}
+
 constexpr size_t kLdsLimit = 160 * 1024 - 512;
 constexpr int kRowBuckets = 1024;          // ROWS mode: one bucket per image row, rows beyond are clamped into the last bucket
 
@@ -500,4 +565,122 @@ extern "C" int lld_orb_search_batch(lld_ctx* ctx, int n, const lld_orb_search* p
 
 extern "C" int lld_orb_search_run(lld_ctx* ctx, const lld_orb_search* s, lld_orb_search_result* out) {
   return lld_orb_search_batch(ctx, 1, s, out);
+}
+
+extern "C" int lld_orb_search_local_points(lld_ctx* ctx, const lld_orb_search* frame, const lld_frame_view* view, const lld_map_points* mp,
+                                           float viewing_cos_limit, float th, float nnratio, lld_frustum_result* fr, lld_orb_search_result* out) {
+  if (!ctx || !frame || !view || !mp || !out) return LLD_ERR_INVALID;
+  const int nt = frame->nt, nq = mp->n;
+  if (nt < 0 || nq < 0) return LLD_ERR_INVALID;
+  if (nt > LLD_ORB_MAX_KEYPOINTS) return LLD_ERR_UNSUPPORTED;
+  if (!out->match || !out->best_dist || !out->second_dist || !out->removed) return LLD_ERR_INVALID;
+  if (nt > 0 && (!frame->t_desc || !frame->t_xy || !frame->t_octave)) return LLD_ERR_INVALID;
+  if (nq > 0 && (!mp->world_pos || !mp->normal || !mp->max_distance || !mp->min_distance || !mp->desc)) return LLD_ERR_INVALID;
+  if (!frame->level_scale || frame->n_levels <= 0 || frame->n_levels > LLD_ORB_MAX_LEVELS || view->n_levels != frame->n_levels) return LLD_ERR_INVALID;
+  if (frame->grid_cols <= 0 || frame->grid_rows <= 0 || frame->grid_cols * frame->grid_rows > 8191) return LLD_ERR_INVALID;
+  for (int k = 0; k < nt; k++) if (frame->t_octave[k] < 0 || frame->t_octave[k] >= LLD_ORB_MAX_LEVELS) return LLD_ERR_INVALID;
+  out->n_matches = 0; out->rounds = 0;
+  LLD_HIP_TRY(hipSetDevice(ctx->device));
+
+  // packed input region: Problem | QRec[nq] (device-produced) | q_desc | t_* | map point arrays ; output region: search + frustum outputs
+  size_t in = al(sizeof(Problem));
+  const size_t o_q = in; in += al((size_t)nq * sizeof(QRec));
+  const size_t o_qd = in; in += al((size_t)nq * 32);
+  const size_t o_td = in; in += al((size_t)nt * 32);
+  const size_t o_txy = in; in += al((size_t)nt * 8);
+  const size_t o_toct = in; in += al((size_t)nt * 4);
+  const size_t o_tur = in; in += frame->t_uright ? al((size_t)nt * 4) : 0;
+  const size_t o_tocc = in; in += frame->t_occupied ? al((size_t)nt) : 0;
+  const size_t o_pos = in; in += al((size_t)nq * 12);
+  const size_t o_nrm = in; in += al((size_t)nq * 12);
+  const size_t o_maxd = in; in += al((size_t)nq * 4);
+  const size_t o_mind = in; in += al((size_t)nq * 4);
+  const size_t o_obs = in; in += mp->has_obs ? al((size_t)nq) : 0;
+  const size_t o_skip = in; in += mp->skip ? al((size_t)nq) : 0;
+  const size_t in_bytes = in;
+  size_t o = 0;
+  const size_t r_match = o; o += al((size_t)nq * 4);
+  const size_t r_bd = o; o += al((size_t)nq * 4);
+  const size_t r_sd = o; o += al((size_t)nq * 4);
+  const size_t r_owner = o; o += al((size_t)nt * 4);
+  const size_t r_sum = o; o += al(16);
+  const size_t r_rem = o; o += al((size_t)nq);
+  const size_t r_inv = o; o += al((size_t)nq);
+  const size_t r_uvr = o; o += al((size_t)nq * 12);
+  const size_t r_lvl = o; o += al((size_t)nq * 4);
+  const size_t r_vc = o; o += al((size_t)nq * 4);
+  const size_t out_bytes = o;
+  void* hbase; int st = lld_ctx_pinned(ctx, in_bytes + out_bytes, &hbase); if (st) return st;
+  void* dbase; st = lld_ctx_scratch(ctx, in_bytes + out_bytes + 256, &dbase); if (st) return st;
+  char* h = (char*)hbase; char* d = (char*)dbase; char* h_out = h + in_bytes; char* d_out = d + in_bytes;
+
+  if (nq) {
+    std::memcpy(h + o_qd, mp->desc, (size_t)nq * 32);
+    std::memcpy(h + o_pos, mp->world_pos, (size_t)nq * 12); std::memcpy(h + o_nrm, mp->normal, (size_t)nq * 12);
+    std::memcpy(h + o_maxd, mp->max_distance, (size_t)nq * 4); std::memcpy(h + o_mind, mp->min_distance, (size_t)nq * 4);
+    if (mp->has_obs) std::memcpy(h + o_obs, mp->has_obs, (size_t)nq);
+    if (mp->skip) std::memcpy(h + o_skip, mp->skip, (size_t)nq);
+  }
+  if (nt) {
+    std::memcpy(h + o_td, frame->t_desc, (size_t)nt * 32); std::memcpy(h + o_txy, frame->t_xy, (size_t)nt * 8);
+    std::memcpy(h + o_toct, frame->t_octave, (size_t)nt * 4);
+    if (frame->t_uright) std::memcpy(h + o_tur, frame->t_uright, (size_t)nt * 4);
+    if (frame->t_occupied) std::memcpy(h + o_tocc, frame->t_occupied, (size_t)nt);
+  }
+  Problem& P = *reinterpret_cast<Problem*>(h); std::memset(&P, 0, sizeof(P));
+  P.nt = nt; P.nq = nq;
+  P.t_desc = reinterpret_cast<const uint32_t*>(d + o_td); P.t_xy = reinterpret_cast<const float*>(d + o_txy);
+  P.t_octave = reinterpret_cast<const int32_t*>(d + o_toct);
+  P.t_uright = frame->t_uright ? reinterpret_cast<const float*>(d + o_tur) : nullptr;
+  P.t_occupied = frame->t_occupied ? reinterpret_cast<const uint8_t*>(d + o_tocc) : nullptr;
+  P.q_desc = reinterpret_cast<const uint32_t*>(d + o_qd); P.q = reinterpret_cast<const QRec*>(d + o_q);
+  P.min_x = frame->grid_min_x; P.min_y = frame->grid_min_y; P.winv = frame->grid_width_inv; P.hinv = frame->grid_height_inv;
+  P.cols = frame->grid_cols; P.rows = frame->grid_rows; P.n_levels = frame->n_levels;
+  for (int l = 0; l < LLD_ORB_MAX_LEVELS; l++) { P.scale[l] = l < frame->n_levels ? frame->level_scale[l] : 1.f; P.sigma2[l] = 1.f; P.inv_sigma2[l] = 1.f; }
+  P.candidates = LLD_ORB_CAND_GRID; P.gates = LLD_ORB_GATE_LEVEL | LLD_ORB_GATE_STEREO; P.accept_max = 100;   // TH_HIGH, src/ORBmatcher.cc:37
+  P.ratio_mode = 2; P.nnratio = nnratio; P.sequential = 1;
+  P.match = reinterpret_cast<int32_t*>(d_out + r_match); P.best_dist = reinterpret_cast<int32_t*>(d_out + r_bd);
+  P.second_dist = reinterpret_cast<int32_t*>(d_out + r_sd); P.removed = reinterpret_cast<uint8_t*>(d_out + r_rem);
+  P.owner = reinterpret_cast<int32_t*>(d_out + r_owner); P.summary = reinterpret_cast<int32_t*>(d_out + r_sum);
+  P.want_owner = out->owner != nullptr;
+  P.desc_in_lds = lds_bytes(nt, P.cols * P.rows, true, true) <= kLdsLimit;
+  const size_t lds = lds_bytes(nt, P.cols * P.rows, true, P.desc_in_lds != 0);
+
+  hipStream_t sm = ctx->stream;
+  LLD_HIP_TRY(hipMemcpyAsync(d, h, in_bytes, hipMemcpyHostToDevice, sm));
+  if (nq) {
+    FrustumArgs F; std::memset(&F, 0, sizeof(F));
+    F.V = *view; F.n = nq;
+    F.pos = reinterpret_cast<const float*>(d + o_pos); F.nrm = reinterpret_cast<const float*>(d + o_nrm);
+    F.maxd = reinterpret_cast<const float*>(d + o_maxd); F.mind = reinterpret_cast<const float*>(d + o_mind);
+    F.has_obs = mp->has_obs ? reinterpret_cast<const uint8_t*>(d + o_obs) : nullptr;
+    F.skip = mp->skip ? reinterpret_cast<const uint8_t*>(d + o_skip) : nullptr;
+    for (int l = 0; l < LLD_ORB_MAX_LEVELS; l++) F.scale[l] = P.scale[l];
+    F.cos_limit = viewing_cos_limit; F.th = th;
+    F.q = reinterpret_cast<QRec*>(d + o_q);
+    F.in_view = reinterpret_cast<uint8_t*>(d_out + r_inv); F.uvr = reinterpret_cast<float*>(d_out + r_uvr);
+    F.level = reinterpret_cast<int32_t*>(d_out + r_lvl); F.view_cos = reinterpret_cast<float*>(d_out + r_vc);
+    hipLaunchKernelGGL(frustum_kernel, dim3((nq + 255) / 256), dim3(256), 0, sm, F);
+    LLD_HIP_TRY(hipGetLastError());
+  }
+  static bool lds_raised = false;
+  if (!lds_raised) { LLD_HIP_TRY(hipFuncSetAttribute((const void*)orb_search_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit)); lds_raised = true; }
+  hipLaunchKernelGGL(orb_search_kernel, dim3(1), dim3(kThreads), lds, sm, reinterpret_cast<const Problem*>(d));
+  LLD_HIP_TRY(hipGetLastError());
+  LLD_HIP_TRY(hipMemcpyAsync(h_out, d_out, out_bytes, hipMemcpyDeviceToHost, sm));
+  LLD_HIP_TRY(hipStreamSynchronize(sm));
+  if (nq) {
+    std::memcpy(out->match, h_out + r_match, (size_t)nq * 4); std::memcpy(out->best_dist, h_out + r_bd, (size_t)nq * 4);
+    std::memcpy(out->second_dist, h_out + r_sd, (size_t)nq * 4); std::memcpy(out->removed, h_out + r_rem, (size_t)nq);
+    if (fr) {
+      if (fr->in_view) std::memcpy(fr->in_view, h_out + r_inv, (size_t)nq);
+      if (fr->proj_uvr) std::memcpy(fr->proj_uvr, h_out + r_uvr, (size_t)nq * 12);
+      if (fr->level) std::memcpy(fr->level, h_out + r_lvl, (size_t)nq * 4);
+      if (fr->view_cos) std::memcpy(fr->view_cos, h_out + r_vc, (size_t)nq * 4);
+    }
+  }
+  if (out->owner && nt) std::memcpy(out->owner, h_out + r_owner, (size_t)nt * 4);
+  const int32_t* sum = reinterpret_cast<const int32_t*>(h_out + r_sum);
+  out->n_matches = sum[0]; out->rounds = sum[1];
+  return LLD_OK;
 }

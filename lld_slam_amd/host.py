@@ -484,6 +484,11 @@ class ORBmatcher:
         return S.search_by_projection_map(self.lib, self.ctx.handle, F, mp_desc, in_view, proj, proj_xr, pred_level, view_cos, mp_obs,
                                           f_occupied, th, float(self.mfNNratio))
 
+    def SearchLocalPoints(self, F, view, map_points: dict, f_occupied=None, th=1.0, viewing_cos_limit=0.5):
+        """Tracking::SearchLocalPoints (src/Tracking.cc:1613-1664): Frame::isInFrustum + SearchByProjection, both on the device."""
+        from . import orb_search as S
+        return S.search_local_points(self.lib, self.ctx.handle, F, view, map_points, f_occupied, th, float(self.mfNNratio), viewing_cos_limit)
+
     def SearchByProjectionFrame(self, Cur, last_desc, valid, uv, ur, last_octave, last_angle, mp_obs, cur_occupied, direction=0, th=7.0):
         """SearchByProjection(Frame& Current, const Frame& Last, th, bMono)  (src/ORBmatcher.cc:1328-1470)."""
         from . import orb_search as S

@@ -46,6 +46,21 @@ class OrbSearchResult(C.Structure):
                 ("owner", c_int32_p), ("n_matches", C.c_int32), ("rounds", C.c_int32)]
 
 
+class FrameView(C.Structure):
+    _fields_ = [("Rcw", C.c_float * 9), ("tcw", C.c_float * 3), ("Ow", C.c_float * 3), ("fx", C.c_float), ("fy", C.c_float),
+                ("cx", C.c_float), ("cy", C.c_float), ("bf", C.c_float), ("min_x", C.c_float), ("max_x", C.c_float), ("min_y", C.c_float),
+                ("max_y", C.c_float), ("log_scale_factor", C.c_float), ("n_levels", C.c_int32)]
+
+
+class MapPoints(C.Structure):
+    _fields_ = [("n", C.c_int32), ("world_pos", c_float_p), ("normal", c_float_p), ("max_distance", c_float_p),
+                ("min_distance", c_float_p), ("desc", c_uint32_p), ("has_obs", c_uint8_p), ("skip", c_uint8_p)]
+
+
+class FrustumResult(C.Structure):
+    _fields_ = [("in_view", c_uint8_p), ("proj_uvr", c_float_p), ("level", c_int32_p), ("view_cos", c_float_p)]
+
+
 def orb_levels(scale_factor=1.2, n_levels=8):
     """mvScaleFactor / mvLevelSigma2 / mvInvLevelSigma2 exactly as ORBextractor builds them (src/ORBextractor.cc:416-430):
     cumulative float products."""
@@ -354,3 +369,59 @@ def stereo_search(lib, ctx, L: Frame, R: Frame, min_d, max_d) -> SearchOutput:
     L.normalise()
     return run(lib, ctx, R, L.desc, candidates=CAND_ROWS, gates=GATE_LEVEL, accept_max=(TH_HIGH + TH_LOW) // 2 - 1, q_uv=L.xy,
                q_level_min=L.octave - 1, q_level_max=L.octave + 1, disp_min=min_d, disp_max=max_d)
+
+
+
+# ====================================================================== Tracking::SearchLocalPoints: frustum test + search on the device
+def frame_view(Tcw, cam, F: Frame, scale_factor=1.2) -> FrameView:
+    """Frame::UpdatePoseMatrices (src/Frame.cc:325-331) from a float32 4x4 Tcw: mRcw, mtcw, mOw = -mRcw.t()*mtcw (one cv::gemm:
+    double accumulation, one rounding), plus the intrinsics, image bounds and scale constants the frustum test reads."""
+    T = np.asarray(Tcw, np.float32).reshape(4, 4)
+    R = T[:3, :3]; t = T[:3, 3]
+    Ow = (-(R.T.astype(np.float64) @ t.astype(np.float64))).astype(np.float32)
+    v = FrameView()
+    for i, x in enumerate(R.reshape(9)): v.Rcw[i] = float(x)
+    for i in range(3): v.tcw[i] = float(t[i]); v.Ow[i] = float(Ow[i])
+    v.fx, v.fy, v.cx, v.cy, v.bf = [float(np.float32(c)) for c in cam]
+    v.min_x, v.max_x, v.min_y, v.max_y = float(np.float32(F.min_x)), float(np.float32(F.max_x)), float(np.float32(F.min_y)), float(np.float32(F.max_y))
+    v.log_scale_factor = float(np.log(np.float32(scale_factor)))        # mfLogScaleFactor = log(mfScaleFactor): float log
+    v.n_levels = int(F.scale.shape[0])
+    return v
+
+
+def map_points_struct(mp: dict):
+    keep = dict(world_pos=_f32(mp["world_pos"]).reshape(-1, 3), normal=_f32(mp["normal"]).reshape(-1, 3), max_distance=_f32(mp["max_distance"]),
+                min_distance=_f32(mp["min_distance"]), desc=np.ascontiguousarray(mp["desc"], np.uint32).reshape(-1, 8),
+                has_obs=_u8(mp.get("has_obs")), skip=_u8(mp.get("skip")))
+    m = MapPoints()
+    m.n = keep["world_pos"].shape[0]
+    m.world_pos = _p(keep["world_pos"], c_float_p); m.normal = _p(keep["normal"], c_float_p); m.max_distance = _p(keep["max_distance"], c_float_p)
+    m.min_distance = _p(keep["min_distance"], c_float_p); m.desc = _p(keep["desc"], c_uint32_p)
+    m.has_obs = _p(keep["has_obs"], c_uint8_p); m.skip = _p(keep["skip"], c_uint8_p)
+    return m, keep
+
+
+def search_local_points(lib, ctx, F: Frame, view: FrameView, mp: dict, f_occupied=None, th=1.0, nnratio=0.8, viewing_cos_limit=0.5):
+    """Tracking::SearchLocalPoints (src/Tracking.cc:1613-1664): Frame::isInFrustum for every local MapPoint and
+    ORBmatcher::SearchByProjection(F, vpMapPoints, th), both on the device, one call.  Returns (SearchOutput, frustum dict)."""
+    p = prepare(F, np.zeros((0, 8), np.uint32), candidates=CAND_GRID, accept_max=TH_HIGH, t_occupied=f_occupied)
+    m, keep = map_points_struct(mp)
+    n, nt = m.n, F.n
+    out = SearchOutput(np.empty(n, np.int32), np.empty(n, np.int32), np.empty(n, np.int32), np.empty(n, np.uint8), np.empty(nt, np.int32), 0, 0)
+    r = OrbSearchResult()
+    r.match = _p(out.match, c_int32_p); r.best_dist = _p(out.best_dist, c_int32_p); r.second_dist = _p(out.second_dist, c_int32_p)
+    r.removed = _p(out.removed, c_uint8_p); r.owner = _p(out.owner, c_int32_p)
+    fr = dict(in_view=np.zeros(n, np.uint8), proj_uvr=np.zeros((n, 3), np.float32), level=np.zeros(n, np.int32), view_cos=np.zeros(n, np.float32))
+    fs = FrustumResult()
+    fs.in_view = _p(fr["in_view"], c_uint8_p); fs.proj_uvr = _p(fr["proj_uvr"], c_float_p); fs.level = _p(fr["level"], c_int32_p)
+    fs.view_cos = _p(fr["view_cos"], c_float_p)
+    fn = lib.fn("orb_search_local_points")
+    fn.argtypes = [C.c_void_p, C.POINTER(OrbSearch), C.POINTER(FrameView), C.POINTER(MapPoints), C.c_float, C.c_float, C.c_float,
+                   C.POINTER(FrustumResult), C.POINTER(OrbSearchResult)]
+    fn.restype = C.c_int
+    st = fn(ctx, C.byref(p.s), C.byref(view), C.byref(m), float(np.float32(viewing_cos_limit)), float(np.float32(th)), float(np.float32(nnratio)),
+            C.byref(fs), C.byref(r))
+    if st != abi.LLD_OK:
+        raise RuntimeError(f"lld_orb_search_local_points failed: {lib.fn('status_string')(st).decode()}")
+    out.n_matches, out.rounds = r.n_matches, r.rounds
+    return out, fr

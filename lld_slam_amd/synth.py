@@ -507,3 +507,39 @@ def make_stereo_lines(frame_id=0, n_left=300, n_right=300, dim=72, related_frac=
     pl, pr = rng.permutation(n_left), rng.permutation(n_right)            # shuffle so correspondences are not index-aligned
     return dict(K=K, b=b, left=left[pl].astype(np.float32), left_octave=lo[pl].astype(np.int32), right=right[pr].astype(np.float32),
                 right_octave=ro[pr].astype(np.int32), desc_left=dl[pl].astype(np.float32), desc_right=dr[pr].astype(np.float32))
+
+
+
+def make_local_map(F, scene_id=0, n=2000, related_frac=0.8, flip_p=0.06):
+    """A frame pose and local MapPoints for Tracking::SearchLocalPoints: most points are back-projections of F's keypoints (depth
+    from the stereo disparity or drawn, position perturbed a little), with their observation normals, scale-invariance distances
+    consistent with the keypoint octave, and noisy copies of the descriptors; the rest lie anywhere around the camera (behind it,
+    outside the image, too far / too close, seen from behind).  Returns (Tcw float32 4x4, map-point dict)."""
+    rng = np.random.default_rng(SEED_SEARCH + 0x5000 + scene_id)
+    fx, fy, cx, cy, bf = [np.float64(np.float32(c)) for c in KITTI_CAM]
+    w = _rodrigues(rng.normal(0, 0.2, 3)); t = rng.normal(0, 2.0, 3)
+    T = np.eye(4); T[:3, :3] = w; T[:3, 3] = t
+    T = T.astype(np.float32)
+    R = T[:3, :3].astype(np.float64); tt = T[:3, 3].astype(np.float64); Ow = -R.T @ tt
+    src = rng.integers(0, F.n, n)
+    z = np.where(F.uright[src] > 0, bf / np.maximum(F.xy[src, 0] - F.uright[src], 0.5), rng.uniform(4, 60, n))
+    Xc = np.stack([(F.xy[src, 0] - cx) * z / fx, (F.xy[src, 1] - cy) * z / fy, z], 1) + rng.normal(0, 0.01, (n, 3)) * z[:, None]
+    related = rng.random(n) < related_frac
+    far = ~related
+    Xc[far] = np.stack([rng.uniform(-40, 40, int(far.sum())), rng.uniform(-15, 15, int(far.sum())), rng.uniform(-20, 90, int(far.sum()))], 1)
+    Xw = (R.T @ (Xc - tt).T).T
+    view_dir = Xw - Ow; dist = np.linalg.norm(view_dir, axis=1)
+    normal = view_dir / dist[:, None] + rng.normal(0, 0.25, (n, 3))
+    normal[rng.random(n) < 0.08] *= -1.0                                   # seen from behind: the viewing-angle test rejects
+    normal /= np.linalg.norm(normal, axis=1, keepdims=True)
+    scale = 1.2 ** F.octave[src].astype(np.float64)
+    maxd = dist * scale * rng.uniform(0.9, 1.1, n)                          # mfMaxDistance = dist * scaleFactor^level at creation
+    mind = maxd / 1.2 ** 7
+    off = rng.random(n) < 0.06
+    maxd[off] *= rng.choice([0.3, 4.0], int(off.sum()))                     # outside the scale-invariance band
+    mind[off] = maxd[off] / 1.2 ** 7
+    desc = _flip_bits(rng, F.desc[src], flip_p)
+    desc[far] = rng.integers(0, 2 ** 32, (int(far.sum()), 8), dtype=np.uint64).astype(np.uint32)
+    return T, dict(world_pos=Xw.astype(np.float32), normal=normal.astype(np.float32), max_distance=maxd.astype(np.float32),
+                   min_distance=mind.astype(np.float32), desc=desc, has_obs=(rng.random(n) < 0.9).astype(np.uint8),
+                   skip=(rng.random(n) < 0.1).astype(np.uint8), occupied=(rng.random(F.n) < 0.05).astype(np.uint8))

@@ -19,10 +19,13 @@
 //   ORBmatcher::Fuse / SearchBySim3 inner searches                  src/ORBmatcher.cc:825-1100, 1102-1326
 //   ORBmatcher::ComputeThreeMaxima                                  src/ORBmatcher.cc:1601-1642
 //   Frame::ComputeStereoMatches (Hamming search)                    src/Frame.cc:530-613
+//   Frame::isInFrustum, MapPoint::PredictScale                      src/Frame.cc:333-389, src/MapPoint.cc:402-417
 #include <climits>
 #include <cmath>
 #include <cstdint>
 #include <vector>
+
+#include "../include/lld_amd.h"
 
 extern "C" int lldo_descriptor_distance(const uint32_t* a, const uint32_t* b);
 
@@ -507,6 +510,49 @@ void lldo_stereo_search(const lldo_frame* L, const lldo_frame* R, int n_rows, fl
     best_dist[iL] = bestDist;
     if (bestDist < thOrbDist) best_r[iL] = bestIdxR;
   }
+}
+
+// Frame::isInFrustum for every MapPoint (src/Frame.cc:333-389) with the per-point part of Tracking::SearchLocalPoints
+// (src/Tracking.cc:1637-1649).  OpenCV is absent, so its three calls are restated as this build reads them: `mRcw*P+mtcw` is one
+// cv::gemm = float(sum_k double(R_ik) double(P_k) + double(t_i)); cv::norm and Mat::dot accumulate in double; the rest is float
+// arithmetic in source order (-ffp-contract=off).  Returns nToMatch.
+int lldo_is_in_frustum(const lld_frame_view* V, const lld_map_points* mp, float viewingCosLimit, uint8_t* in_view, float* proj_uvr,
+                       int32_t* level, float* view_cos) {
+  int nToMatch = 0;
+  for (int i = 0; i < mp->n; i++) {
+    in_view[i] = 0;                                                  // pMP->mbTrackInView = false
+    if (mp->skip && mp->skip[i]) continue;
+    const float* P = mp->world_pos + 3 * i;
+    float Pc[3];
+    for (int r = 0; r < 3; r++) {
+      double s0 = 0.0;
+      for (int k = 0; k < 3; k++) s0 += (double)V->Rcw[3 * r + k] * (double)P[k];
+      Pc[r] = (float)(s0 + (double)V->tcw[r]);
+    }
+    const float PcX = Pc[0], PcY = Pc[1], PcZ = Pc[2];
+    if (PcZ < 0.0f) continue;
+    const float invz = 1.0f / PcZ;
+    const float u = V->fx * PcX * invz + V->cx;
+    const float v = V->fy * PcY * invz + V->cy;
+    if (u < V->min_x || u > V->max_x) continue;
+    if (v < V->min_y || v > V->max_y) continue;
+    const float maxDistance = 1.2f * mp->max_distance[i], minDistance = 0.8f * mp->min_distance[i];
+    const float PO[3] = {P[0] - V->Ow[0], P[1] - V->Ow[1], P[2] - V->Ow[2]};
+    double n2 = 0.0; for (int k = 0; k < 3; k++) n2 += (double)PO[k] * (double)PO[k];
+    const float dist = (float)std::sqrt(n2);
+    if (dist < minDistance || dist > maxDistance) continue;
+    double dotv = 0.0; for (int k = 0; k < 3; k++) dotv += (double)PO[k] * (double)mp->normal[3 * i + k];
+    const float viewCos = (float)(dotv / dist);
+    if (viewCos < viewingCosLimit) continue;
+    const float ratio = mp->max_distance[i] / dist;                   // MapPoint::PredictScale
+    int nScale = (int)std::ceil(std::log(ratio) / V->log_scale_factor);
+    if (nScale < 0) nScale = 0; else if (nScale >= V->n_levels) nScale = V->n_levels - 1;
+    in_view[i] = 1;
+    proj_uvr[3 * i] = u; proj_uvr[3 * i + 1] = v; proj_uvr[3 * i + 2] = u - V->bf * invz;
+    level[i] = nScale; view_cos[i] = viewCos;
+    nToMatch++;
+  }
+  return nToMatch;
 }
 
 }  // extern "C"

@@ -179,3 +179,17 @@ def stereo_search(L, R, n_rows, min_d, max_d):
     br = np.empty(L.n, np.int32); bd = np.empty(L.n, np.int32)
     _dll().lldo_stereo_search(C.byref(oframe(L)), C.byref(oframe(R)), n_rows, min_d, max_d, _p(br, c_int32_p), _p(bd, c_int32_p))
     return br, bd
+
+
+def is_in_frustum(view, mp: dict, viewing_cos_limit=0.5):
+    """Frame::isInFrustum over all map points (literal restatement): (nToMatch, in_view, proj_uvr, level, view_cos)."""
+    from lld_slam_amd.orb_search import FrameView, MapPoints, map_points_struct
+    d = _dll()
+    d.lldo_is_in_frustum.argtypes = [C.POINTER(FrameView), C.POINTER(MapPoints), C.c_float, c_uint8_p, c_float_p, c_int32_p, c_float_p]
+    d.lldo_is_in_frustum.restype = C.c_int
+    m, keep = map_points_struct(mp)
+    n = m.n
+    in_view = np.zeros(n, np.uint8); uvr = np.zeros((n, 3), np.float32); level = np.zeros(n, np.int32); vc = np.zeros(n, np.float32)
+    k = d.lldo_is_in_frustum(C.byref(view), C.byref(m), float(np.float32(viewing_cos_limit)), _p(in_view, c_uint8_p), _p(uvr, c_float_p),
+                             _p(level, c_int32_p), _p(vc, c_float_p))
+    return k, in_view, uvr, level, vc

@@ -217,3 +217,35 @@ def test_edge_cases(gpu_ctx):
     big = synth.make_orb_frame(96, orb_search.MAX_KEYPOINTS + 1, n_clusters=0)
     with pytest.raises(RuntimeError, match="supported limits"):
         m.SearchByProjectionMap(big, q["desc"], q["valid"], q["uv"], q["ur"], q["level"], q["view_cos"], q["obs"], np.zeros(big.n, np.uint8))
+
+
+@pytest.mark.parametrize("seed,th", [(0, 1.0), (1, 3.0), (2, 5.0)])
+def test_search_local_points_frustum_and_search_on_device(gpu_ctx, seed, th):
+    """Tracking::SearchLocalPoints: Frame::isInFrustum on the device feeds the projection search without a host round trip; the
+    frustum outputs equal the CPU restatement bit for bit and the matches equal the sequential search on them."""
+    F = synth.make_orb_frame(120 + seed, 2000)
+    T, mp = synth.make_local_map(F, 120 + seed, 2500)
+    view = orb_search.frame_view(T, synth.KITTI_CAM, F)
+    out, fr = orb_search.search_local_points(gpu_ctx.lib, gpu_ctx.handle, F, view, mp, mp["occupied"], th, 0.8)
+    k, inv, uvr, lvl, vc = OS.is_in_frustum(view, mp)
+    np.testing.assert_array_equal(fr["in_view"], inv)
+    m = inv != 0
+    assert 500 < k < 2400 and (~m).sum() > 100
+    np.testing.assert_array_equal(fr["proj_uvr"][m], uvr[m])
+    np.testing.assert_array_equal(fr["view_cos"][m], vc[m])
+    np.testing.assert_array_equal(fr["level"][m], lvl[m])
+    n_exp, slot = OS.search_by_projection_map(F, mp["desc"], inv, uvr[:, :2], uvr[:, 2], lvl, vc, mp["has_obs"], mp["occupied"], th, 0.8)
+    assert out.n_matches == n_exp and n_exp > 150
+    np.testing.assert_array_equal(expect_slots(out, mp["occupied"]), slot)
+
+
+def test_search_local_points_edge_cases(gpu_ctx):
+    F = synth.make_orb_frame(130, 300)
+    T, mp = synth.make_local_map(F, 130, 200)
+    view = orb_search.frame_view(T, synth.KITTI_CAM, F)
+    empty = {k: (v[:0] if k != "occupied" else v) for k, v in mp.items()}
+    out, fr = orb_search.search_local_points(gpu_ctx.lib, gpu_ctx.handle, F, view, empty, mp["occupied"])
+    assert out.n_matches == 0 and out.match.shape == (0,)
+    allskip = dict(mp, skip=np.ones(200, np.uint8))
+    out, fr = orb_search.search_local_points(gpu_ctx.lib, gpu_ctx.handle, F, view, allskip, mp["occupied"])
+    assert out.n_matches == 0 and not fr["in_view"].any()

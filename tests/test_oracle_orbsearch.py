@@ -248,3 +248,40 @@ def test_stereo_search_row_band_and_thresholds():
         if best < 75: exp[iL] = bi
     np.testing.assert_array_equal(br, exp)
     assert (br >= 0).sum() > 100
+
+
+def test_is_in_frustum_matches_a_numpy_restatement():
+    """Frame::isInFrustum (src/Frame.cc:333-389) + MapPoint::PredictScale: the C++ restatement against numpy with the same
+    float32 / float64 mixture, and the rejection reasons all occur in the scene."""
+    from lld_slam_amd import orb_search as S
+    F = synth.make_orb_frame(3, 800)
+    T, mp = synth.make_local_map(F, 3, 1500)
+    view = S.frame_view(T, synth.KITTI_CAM, F)
+    k, inv, uvr, lvl, vc = OS.is_in_frustum(view, mp)
+    R = np.array(view.Rcw, f32).reshape(3, 3); t = np.array(view.tcw, f32); Ow = np.array(view.Ow, f32)
+    reasons = {"skip": 0, "behind": 0, "image": 0, "dist": 0, "angle": 0, "ok": 0}
+    for i in range(1500):
+        P = mp["world_pos"][i]
+        if mp["skip"][i]:
+            reasons["skip"] += 1; assert not inv[i]; continue
+        Pc = (R.astype(np.float64) @ P.astype(np.float64) + t.astype(np.float64)).astype(f32)      # not bit-identical to the k-ordered sum, see below
+        Pc = np.array([f32(np.float64(R[r, 0]) * np.float64(P[0]) + np.float64(R[r, 1]) * np.float64(P[1]) + np.float64(R[r, 2]) * np.float64(P[2])
+                           + np.float64(t[r])) for r in range(3)], f32)
+        if Pc[2] < 0: reasons["behind"] += 1; assert not inv[i]; continue
+        invz = f32(1.0) / Pc[2]
+        u = f32(f32(f32(view.fx) * Pc[0]) * invz) + f32(view.cx); v = f32(f32(f32(view.fy) * Pc[1]) * invz) + f32(view.cy)
+        if u < view.min_x or u > view.max_x or v < view.min_y or v > view.max_y: reasons["image"] += 1; assert not inv[i]; continue
+        PO = (P - Ow).astype(f32)
+        dist = f32(np.sqrt(np.sum(PO.astype(np.float64) ** 2)))
+        if dist < f32(0.8) * mp["min_distance"][i] or dist > f32(1.2) * mp["max_distance"][i]: reasons["dist"] += 1; assert not inv[i]; continue
+        vcos = f32(np.float64(PO[0]) * np.float64(mp["normal"][i, 0]) + np.float64(PO[1]) * np.float64(mp["normal"][i, 1])
+                   + np.float64(PO[2]) * np.float64(mp["normal"][i, 2])) if False else f32((PO.astype(np.float64) @ mp["normal"][i].astype(np.float64)) / np.float64(dist))
+        if vcos < 0.5: reasons["angle"] += 1; assert not inv[i]; continue
+        reasons["ok"] += 1
+        assert inv[i]
+        assert uvr[i, 0] == u and uvr[i, 1] == v and uvr[i, 2] == f32(u - f32(f32(view.bf) * invz))
+        assert abs(float(vc[i]) - float(vcos)) <= 1.2e-7 * abs(float(vcos))          # numpy's dot may associate differently: one float ulp
+        q = np.log(f32(mp["max_distance"][i] / dist)) / f32(view.log_scale_factor)
+        if abs(q - round(float(q))) > 1e-4:
+            assert lvl[i] == min(max(int(np.ceil(q)), 0), 7)
+    assert k == reasons["ok"] and all(c > 20 for c in reasons.values()), reasons
