@@ -443,6 +443,23 @@ typedef struct { uint8_t* in_view; float* proj_uvr; int32_t* level; float* view_
 int lld_orb_search_local_points(lld_ctx* ctx, const lld_orb_search* frame, const lld_frame_view* view, const lld_map_points* points,
                                 float viewing_cos_limit, float th, float nnratio,
                                 lld_frustum_result* frustum_or_null, lld_orb_search_result* out);
+/* ORBmatcher::SearchByProjection(Frame& Current, const Frame& Last, th, bMono) (src/ORBmatcher.cc:1328-1470, the matcher of
+ * Tracking::TrackWithMotionModel) in one call: the projection of the last frame's MapPoints into the current frame (:1358-1377:
+ * cv::gemm transform, invzc = float(1.0 / double(z)), image bounds), the window radius th*scale[octave], the octave range chosen by
+ * `direction` (+1 bForward, -1 bBackward, 0 neither; the caller evaluates :1343-1350 once per frame pair), ur = u - mbf*invzc, then
+ * the search with occupancy and the rotation histogram.  last_valid[i] = LastFrame.mvpMapPoints[i] && !LastFrame.mvbOutlier[i].
+ * proj_uvr (may be NULL): [n][3] u, v, ur of the projected points. */
+typedef struct {
+  int32_t n;
+  const float*    world_pos;    /* [n][3] pMP->GetWorldPos() of LastFrame.mvpMapPoints[i] */
+  const uint8_t*  valid;        /* [n] */
+  const int32_t*  octave;       /* [n] LastFrame.mvKeys[i].octave */
+  const float*    angle;        /* [n] LastFrame.mvKeysUn[i].angle */
+  const uint32_t* desc;         /* [n][8] pMP->GetDescriptor() */
+  const uint8_t*  has_obs;      /* [n] Observations()>0, or NULL = all 1 */
+} lld_last_frame_points;
+int lld_orb_search_last_frame(lld_ctx* ctx, const lld_orb_search* frame, const lld_frame_view* view, const lld_last_frame_points* last,
+                              int direction, float th, int check_orientation, float* proj_uvr_or_null, lld_orb_search_result* out);
 /* `n` independent problems (e.g. one relocalisation / loop candidate keyframe each, or the searches of several frames) in one
  * launch: one workgroup per problem, all inputs moved in one host-to-device copy and all outputs in one copy back. */
 int lld_orb_search_batch(lld_ctx* ctx, int n, const lld_orb_search* problems, lld_orb_search_result* outs);

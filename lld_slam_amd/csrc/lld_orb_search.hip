@@ -399,6 +399,52 @@ __global__ __launch_bounds__(256) void frustum_kernel(FrustumArgs F) {
   if (F.view_cos) F.view_cos[i] = vc;
 }
 
+// Projection loop of ORBmatcher::SearchByProjection(Current, Last, th, bMono) (src/ORBmatcher.cc:1352-1386), one lane per keypoint of
+// the last frame, written straight into the query record of the search kernel.
+struct LastFrameArgs {
+  lld_frame_view V;
+  int n, direction;
+  const float* pos; const uint8_t* valid; const int32_t* octave; const float* angle; const uint8_t* has_obs;
+  float scale[LLD_ORB_MAX_LEVELS];
+  float th;
+  QRec* q; float* uvr;
+};
+
+__global__ __launch_bounds__(256) void project_last_frame_kernel(LastFrameArgs F) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= F.n) return;
+  QRec Q; memset(&Q, 0, sizeof(Q));
+  Q.level_min = -1; Q.level_max = -1;
+  Q.flags = (!F.has_obs || F.has_obs[i]) ? 2 : 0;
+  Q.angle = F.angle ? F.angle[i] : 0.f;
+  float u = 0.f, v = 0.f, ur = 0.f;
+  if (F.valid[i]) {
+    const float P[3] = {F.pos[3 * i], F.pos[3 * i + 1], F.pos[3 * i + 2]};
+    float Pc[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++)                                                  // x3Dc = Rcw*x3Dw+tcw: one cv::gemm
+      Pc[r] = (float)__dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn((double)F.V.Rcw[3 * r], (double)P[0]), __dmul_rn((double)F.V.Rcw[3 * r + 1], (double)P[1])),
+                                         __dmul_rn((double)F.V.Rcw[3 * r + 2], (double)P[2])), (double)F.V.tcw[r]);
+    const float invzc = (float)__ddiv_rn(1.0, (double)Pc[2]);                   // const float invzc = 1.0/x3Dc.at<float>(2);
+    if (!(invzc < 0.f)) {
+      u = __fadd_rn(__fmul_rn(__fmul_rn(F.V.fx, Pc[0]), invzc), F.V.cx);
+      v = __fadd_rn(__fmul_rn(__fmul_rn(F.V.fy, Pc[1]), invzc), F.V.cy);
+      if (!(u < F.V.min_x || u > F.V.max_x) && !(v < F.V.min_y || v > F.V.max_y)) {
+        const int oct = F.octave[i];
+        const float radius = __fmul_rn(F.th, F.scale[oct]);
+        ur = __fsub_rn(u, __fmul_rn(F.V.bf, invzc));                             // :1402
+        Q.u = u; Q.v = v; Q.radius = radius; Q.ur = ur; Q.stereo_radius = radius;
+        if (F.direction > 0) { Q.level_min = oct; Q.level_max = -1; }            // GetFeaturesInArea(u,v,radius,nLastOctave)
+        else if (F.direction < 0) { Q.level_min = 0; Q.level_max = oct; }        // (u,v,radius,0,nLastOctave)
+        else { Q.level_min = oct - 1; Q.level_max = oct + 1; }
+        Q.flags |= 1;
+      }
+    }
+  }
+  F.q[i] = Q;
+  if (F.uvr) { F.uvr[3 * i] = u; F.uvr[3 * i + 1] = v; F.uvr[3 * i + 2] = ur; }
+}
+
 constexpr size_t kLdsLimit = 160 * 1024 - 512;
 constexpr int kRowBuckets = 1024;          // ROWS mode: one bucket per image row, rows beyond are clamped into the last bucket
 
@@ -567,120 +613,185 @@ extern "C" int lld_orb_search_run(lld_ctx* ctx, const lld_orb_search* s, lld_orb
   return lld_orb_search_batch(ctx, 1, s, out);
 }
 
+namespace {
+
+// Shared plumbing of the "project on the device, then search" entry points: one packed input region
+// [Problem | QRec[nq] (written by the projection kernel) | q_desc | frame keypoints | caller inputs] and one output region.
+struct ProjSearch {
+  lld_ctx* ctx; const lld_orb_search* frame; int nt, nq; bool need_angle;
+  size_t in = 0, out = 0;
+  size_t o_q = 0, o_qd = 0, o_td = 0, o_txy = 0, o_toct = 0, o_tur = 0, o_tang = 0, o_tocc = 0;
+  size_t r_match = 0, r_bd = 0, r_sd = 0, r_owner = 0, r_sum = 0, r_rem = 0;
+  char *h = nullptr, *d = nullptr, *h_out = nullptr, *d_out = nullptr;
+  size_t add_in(size_t bytes) { const size_t o = in; in += al(bytes); return o; }
+  size_t add_out(size_t bytes) { const size_t o = out; out += al(bytes); return o; }
+
+  int check(const lld_orb_search_result* res) const {
+    if (nt < 0 || nq < 0) return LLD_ERR_INVALID;
+    if (nt > LLD_ORB_MAX_KEYPOINTS) return LLD_ERR_UNSUPPORTED;
+    if (!res->match || !res->best_dist || !res->second_dist || !res->removed) return LLD_ERR_INVALID;
+    if (nt > 0 && (!frame->t_desc || !frame->t_xy || !frame->t_octave || (need_angle && !frame->t_angle))) return LLD_ERR_INVALID;
+    if (!frame->level_scale || frame->n_levels <= 0 || frame->n_levels > LLD_ORB_MAX_LEVELS) return LLD_ERR_INVALID;
+    if (frame->grid_cols <= 0 || frame->grid_rows <= 0 || frame->grid_cols * frame->grid_rows > 8191) return LLD_ERR_INVALID;
+    for (int k = 0; k < nt; k++) if (frame->t_octave[k] < 0 || frame->t_octave[k] >= LLD_ORB_MAX_LEVELS) return LLD_ERR_INVALID;
+    return LLD_OK;
+  }
+  void layout() {
+    in = al(sizeof(Problem));
+    o_q = add_in((size_t)nq * sizeof(QRec)); o_qd = add_in((size_t)nq * 32);
+    o_td = add_in((size_t)nt * 32); o_txy = add_in((size_t)nt * 8); o_toct = add_in((size_t)nt * 4);
+    o_tur = frame->t_uright ? add_in((size_t)nt * 4) : 0; o_tang = need_angle ? add_in((size_t)nt * 4) : 0;
+    o_tocc = frame->t_occupied ? add_in((size_t)nt) : 0;
+    r_match = add_out((size_t)nq * 4); r_bd = add_out((size_t)nq * 4); r_sd = add_out((size_t)nq * 4); r_owner = add_out((size_t)nt * 4);
+    r_sum = add_out(16); r_rem = add_out((size_t)nq);
+  }
+  int alloc() {
+    void* hb; int st = lld_ctx_pinned(ctx, in + out, &hb); if (st) return st;
+    void* db; st = lld_ctx_scratch(ctx, in + out + 256, &db); if (st) return st;
+    h = (char*)hb; d = (char*)db; h_out = h + in; d_out = d + in;
+    return LLD_OK;
+  }
+  // frame keypoints + query descriptors into the staging buffer, Problem with everything but the matching rules
+  Problem& pack(const uint32_t* q_desc, bool want_owner) {
+    if (nq) std::memcpy(h + o_qd, q_desc, (size_t)nq * 32);
+    if (nt) {
+      std::memcpy(h + o_td, frame->t_desc, (size_t)nt * 32); std::memcpy(h + o_txy, frame->t_xy, (size_t)nt * 8);
+      std::memcpy(h + o_toct, frame->t_octave, (size_t)nt * 4);
+      if (frame->t_uright) std::memcpy(h + o_tur, frame->t_uright, (size_t)nt * 4);
+      if (need_angle) std::memcpy(h + o_tang, frame->t_angle, (size_t)nt * 4);
+      if (frame->t_occupied) std::memcpy(h + o_tocc, frame->t_occupied, (size_t)nt);
+    }
+    Problem& P = *reinterpret_cast<Problem*>(h); std::memset(&P, 0, sizeof(P));
+    P.nt = nt; P.nq = nq;
+    P.t_desc = reinterpret_cast<const uint32_t*>(d + o_td); P.t_xy = reinterpret_cast<const float*>(d + o_txy);
+    P.t_octave = reinterpret_cast<const int32_t*>(d + o_toct);
+    P.t_uright = frame->t_uright ? reinterpret_cast<const float*>(d + o_tur) : nullptr;
+    P.t_angle = need_angle ? reinterpret_cast<const float*>(d + o_tang) : nullptr;
+    P.t_occupied = frame->t_occupied ? reinterpret_cast<const uint8_t*>(d + o_tocc) : nullptr;
+    P.q_desc = reinterpret_cast<const uint32_t*>(d + o_qd); P.q = reinterpret_cast<const QRec*>(d + o_q);
+    P.min_x = frame->grid_min_x; P.min_y = frame->grid_min_y; P.winv = frame->grid_width_inv; P.hinv = frame->grid_height_inv;
+    P.cols = frame->grid_cols; P.rows = frame->grid_rows; P.n_levels = frame->n_levels;
+    for (int l = 0; l < LLD_ORB_MAX_LEVELS; l++) { P.scale[l] = l < frame->n_levels ? frame->level_scale[l] : 1.f; P.sigma2[l] = 1.f; P.inv_sigma2[l] = 1.f; }
+    P.candidates = LLD_ORB_CAND_GRID;
+    P.match = reinterpret_cast<int32_t*>(d_out + r_match); P.best_dist = reinterpret_cast<int32_t*>(d_out + r_bd);
+    P.second_dist = reinterpret_cast<int32_t*>(d_out + r_sd); P.removed = reinterpret_cast<uint8_t*>(d_out + r_rem);
+    P.owner = reinterpret_cast<int32_t*>(d_out + r_owner); P.summary = reinterpret_cast<int32_t*>(d_out + r_sum);
+    P.want_owner = want_owner;
+    P.desc_in_lds = lds_bytes(nt, P.cols * P.rows, true, true) <= kLdsLimit;
+    return P;
+  }
+  int upload() { LLD_HIP_TRY(hipMemcpyAsync(d, h, in, hipMemcpyHostToDevice, ctx->stream)); return LLD_OK; }
+  int search_and_fetch(lld_orb_search_result* res) {
+    const Problem& P = *reinterpret_cast<const Problem*>(h);
+    const size_t lds = lds_bytes(nt, P.cols * P.rows, true, P.desc_in_lds != 0);
+    static bool lds_raised = false;
+    if (!lds_raised) { LLD_HIP_TRY(hipFuncSetAttribute((const void*)orb_search_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit)); lds_raised = true; }
+    hipLaunchKernelGGL(orb_search_kernel, dim3(1), dim3(kThreads), lds, ctx->stream, reinterpret_cast<const Problem*>(d));
+    LLD_HIP_TRY(hipGetLastError());
+    LLD_HIP_TRY(hipMemcpyAsync(h_out, d_out, out, hipMemcpyDeviceToHost, ctx->stream));
+    LLD_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (nq) {
+      std::memcpy(res->match, h_out + r_match, (size_t)nq * 4); std::memcpy(res->best_dist, h_out + r_bd, (size_t)nq * 4);
+      std::memcpy(res->second_dist, h_out + r_sd, (size_t)nq * 4); std::memcpy(res->removed, h_out + r_rem, (size_t)nq);
+    }
+    if (res->owner && nt) std::memcpy(res->owner, h_out + r_owner, (size_t)nt * 4);
+    const int32_t* sum = reinterpret_cast<const int32_t*>(h_out + r_sum);
+    res->n_matches = sum[0]; res->rounds = sum[1];
+    return LLD_OK;
+  }
+};
+
+}  // namespace
+
 extern "C" int lld_orb_search_local_points(lld_ctx* ctx, const lld_orb_search* frame, const lld_frame_view* view, const lld_map_points* mp,
                                            float viewing_cos_limit, float th, float nnratio, lld_frustum_result* fr, lld_orb_search_result* out) {
   if (!ctx || !frame || !view || !mp || !out) return LLD_ERR_INVALID;
-  const int nt = frame->nt, nq = mp->n;
-  if (nt < 0 || nq < 0) return LLD_ERR_INVALID;
-  if (nt > LLD_ORB_MAX_KEYPOINTS) return LLD_ERR_UNSUPPORTED;
-  if (!out->match || !out->best_dist || !out->second_dist || !out->removed) return LLD_ERR_INVALID;
-  if (nt > 0 && (!frame->t_desc || !frame->t_xy || !frame->t_octave)) return LLD_ERR_INVALID;
+  ProjSearch S{ctx, frame, frame->nt, mp->n, false};
+  int st = S.check(out); if (st) return st;
+  const int nq = S.nq;
   if (nq > 0 && (!mp->world_pos || !mp->normal || !mp->max_distance || !mp->min_distance || !mp->desc)) return LLD_ERR_INVALID;
-  if (!frame->level_scale || frame->n_levels <= 0 || frame->n_levels > LLD_ORB_MAX_LEVELS || view->n_levels != frame->n_levels) return LLD_ERR_INVALID;
-  if (frame->grid_cols <= 0 || frame->grid_rows <= 0 || frame->grid_cols * frame->grid_rows > 8191) return LLD_ERR_INVALID;
-  for (int k = 0; k < nt; k++) if (frame->t_octave[k] < 0 || frame->t_octave[k] >= LLD_ORB_MAX_LEVELS) return LLD_ERR_INVALID;
+  if (view->n_levels != frame->n_levels) return LLD_ERR_INVALID;
   out->n_matches = 0; out->rounds = 0;
   LLD_HIP_TRY(hipSetDevice(ctx->device));
-
-  // packed input region: Problem | QRec[nq] (device-produced) | q_desc | t_* | map point arrays ; output region: search + frustum outputs
-  size_t in = al(sizeof(Problem));
-  const size_t o_q = in; in += al((size_t)nq * sizeof(QRec));
-  const size_t o_qd = in; in += al((size_t)nq * 32);
-  const size_t o_td = in; in += al((size_t)nt * 32);
-  const size_t o_txy = in; in += al((size_t)nt * 8);
-  const size_t o_toct = in; in += al((size_t)nt * 4);
-  const size_t o_tur = in; in += frame->t_uright ? al((size_t)nt * 4) : 0;
-  const size_t o_tocc = in; in += frame->t_occupied ? al((size_t)nt) : 0;
-  const size_t o_pos = in; in += al((size_t)nq * 12);
-  const size_t o_nrm = in; in += al((size_t)nq * 12);
-  const size_t o_maxd = in; in += al((size_t)nq * 4);
-  const size_t o_mind = in; in += al((size_t)nq * 4);
-  const size_t o_obs = in; in += mp->has_obs ? al((size_t)nq) : 0;
-  const size_t o_skip = in; in += mp->skip ? al((size_t)nq) : 0;
-  const size_t in_bytes = in;
-  size_t o = 0;
-  const size_t r_match = o; o += al((size_t)nq * 4);
-  const size_t r_bd = o; o += al((size_t)nq * 4);
-  const size_t r_sd = o; o += al((size_t)nq * 4);
-  const size_t r_owner = o; o += al((size_t)nt * 4);
-  const size_t r_sum = o; o += al(16);
-  const size_t r_rem = o; o += al((size_t)nq);
-  const size_t r_inv = o; o += al((size_t)nq);
-  const size_t r_uvr = o; o += al((size_t)nq * 12);
-  const size_t r_lvl = o; o += al((size_t)nq * 4);
-  const size_t r_vc = o; o += al((size_t)nq * 4);
-  const size_t out_bytes = o;
-  void* hbase; int st = lld_ctx_pinned(ctx, in_bytes + out_bytes, &hbase); if (st) return st;
-  void* dbase; st = lld_ctx_scratch(ctx, in_bytes + out_bytes + 256, &dbase); if (st) return st;
-  char* h = (char*)hbase; char* d = (char*)dbase; char* h_out = h + in_bytes; char* d_out = d + in_bytes;
-
+  S.layout();
+  const size_t o_pos = S.add_in((size_t)nq * 12), o_nrm = S.add_in((size_t)nq * 12), o_maxd = S.add_in((size_t)nq * 4), o_mind = S.add_in((size_t)nq * 4);
+  const size_t o_obs = mp->has_obs ? S.add_in((size_t)nq) : 0, o_skip = mp->skip ? S.add_in((size_t)nq) : 0;
+  const size_t r_inv = S.add_out((size_t)nq), r_uvr = S.add_out((size_t)nq * 12), r_lvl = S.add_out((size_t)nq * 4), r_vc = S.add_out((size_t)nq * 4);
+  st = S.alloc(); if (st) return st;
   if (nq) {
-    std::memcpy(h + o_qd, mp->desc, (size_t)nq * 32);
-    std::memcpy(h + o_pos, mp->world_pos, (size_t)nq * 12); std::memcpy(h + o_nrm, mp->normal, (size_t)nq * 12);
-    std::memcpy(h + o_maxd, mp->max_distance, (size_t)nq * 4); std::memcpy(h + o_mind, mp->min_distance, (size_t)nq * 4);
-    if (mp->has_obs) std::memcpy(h + o_obs, mp->has_obs, (size_t)nq);
-    if (mp->skip) std::memcpy(h + o_skip, mp->skip, (size_t)nq);
+    std::memcpy(S.h + o_pos, mp->world_pos, (size_t)nq * 12); std::memcpy(S.h + o_nrm, mp->normal, (size_t)nq * 12);
+    std::memcpy(S.h + o_maxd, mp->max_distance, (size_t)nq * 4); std::memcpy(S.h + o_mind, mp->min_distance, (size_t)nq * 4);
+    if (mp->has_obs) std::memcpy(S.h + o_obs, mp->has_obs, (size_t)nq);
+    if (mp->skip) std::memcpy(S.h + o_skip, mp->skip, (size_t)nq);
   }
-  if (nt) {
-    std::memcpy(h + o_td, frame->t_desc, (size_t)nt * 32); std::memcpy(h + o_txy, frame->t_xy, (size_t)nt * 8);
-    std::memcpy(h + o_toct, frame->t_octave, (size_t)nt * 4);
-    if (frame->t_uright) std::memcpy(h + o_tur, frame->t_uright, (size_t)nt * 4);
-    if (frame->t_occupied) std::memcpy(h + o_tocc, frame->t_occupied, (size_t)nt);
-  }
-  Problem& P = *reinterpret_cast<Problem*>(h); std::memset(&P, 0, sizeof(P));
-  P.nt = nt; P.nq = nq;
-  P.t_desc = reinterpret_cast<const uint32_t*>(d + o_td); P.t_xy = reinterpret_cast<const float*>(d + o_txy);
-  P.t_octave = reinterpret_cast<const int32_t*>(d + o_toct);
-  P.t_uright = frame->t_uright ? reinterpret_cast<const float*>(d + o_tur) : nullptr;
-  P.t_occupied = frame->t_occupied ? reinterpret_cast<const uint8_t*>(d + o_tocc) : nullptr;
-  P.q_desc = reinterpret_cast<const uint32_t*>(d + o_qd); P.q = reinterpret_cast<const QRec*>(d + o_q);
-  P.min_x = frame->grid_min_x; P.min_y = frame->grid_min_y; P.winv = frame->grid_width_inv; P.hinv = frame->grid_height_inv;
-  P.cols = frame->grid_cols; P.rows = frame->grid_rows; P.n_levels = frame->n_levels;
-  for (int l = 0; l < LLD_ORB_MAX_LEVELS; l++) { P.scale[l] = l < frame->n_levels ? frame->level_scale[l] : 1.f; P.sigma2[l] = 1.f; P.inv_sigma2[l] = 1.f; }
-  P.candidates = LLD_ORB_CAND_GRID; P.gates = LLD_ORB_GATE_LEVEL | LLD_ORB_GATE_STEREO; P.accept_max = 100;   // TH_HIGH, src/ORBmatcher.cc:37
+  Problem& P = S.pack(mp->desc, out->owner != nullptr);
+  P.gates = LLD_ORB_GATE_LEVEL | LLD_ORB_GATE_STEREO; P.accept_max = 100;       // TH_HIGH, src/ORBmatcher.cc:37,117
   P.ratio_mode = 2; P.nnratio = nnratio; P.sequential = 1;
-  P.match = reinterpret_cast<int32_t*>(d_out + r_match); P.best_dist = reinterpret_cast<int32_t*>(d_out + r_bd);
-  P.second_dist = reinterpret_cast<int32_t*>(d_out + r_sd); P.removed = reinterpret_cast<uint8_t*>(d_out + r_rem);
-  P.owner = reinterpret_cast<int32_t*>(d_out + r_owner); P.summary = reinterpret_cast<int32_t*>(d_out + r_sum);
-  P.want_owner = out->owner != nullptr;
-  P.desc_in_lds = lds_bytes(nt, P.cols * P.rows, true, true) <= kLdsLimit;
-  const size_t lds = lds_bytes(nt, P.cols * P.rows, true, P.desc_in_lds != 0);
-
-  hipStream_t sm = ctx->stream;
-  LLD_HIP_TRY(hipMemcpyAsync(d, h, in_bytes, hipMemcpyHostToDevice, sm));
+  st = S.upload(); if (st) return st;
   if (nq) {
     FrustumArgs F; std::memset(&F, 0, sizeof(F));
     F.V = *view; F.n = nq;
-    F.pos = reinterpret_cast<const float*>(d + o_pos); F.nrm = reinterpret_cast<const float*>(d + o_nrm);
-    F.maxd = reinterpret_cast<const float*>(d + o_maxd); F.mind = reinterpret_cast<const float*>(d + o_mind);
-    F.has_obs = mp->has_obs ? reinterpret_cast<const uint8_t*>(d + o_obs) : nullptr;
-    F.skip = mp->skip ? reinterpret_cast<const uint8_t*>(d + o_skip) : nullptr;
+    F.pos = reinterpret_cast<const float*>(S.d + o_pos); F.nrm = reinterpret_cast<const float*>(S.d + o_nrm);
+    F.maxd = reinterpret_cast<const float*>(S.d + o_maxd); F.mind = reinterpret_cast<const float*>(S.d + o_mind);
+    F.has_obs = mp->has_obs ? reinterpret_cast<const uint8_t*>(S.d + o_obs) : nullptr;
+    F.skip = mp->skip ? reinterpret_cast<const uint8_t*>(S.d + o_skip) : nullptr;
     for (int l = 0; l < LLD_ORB_MAX_LEVELS; l++) F.scale[l] = P.scale[l];
     F.cos_limit = viewing_cos_limit; F.th = th;
-    F.q = reinterpret_cast<QRec*>(d + o_q);
-    F.in_view = reinterpret_cast<uint8_t*>(d_out + r_inv); F.uvr = reinterpret_cast<float*>(d_out + r_uvr);
-    F.level = reinterpret_cast<int32_t*>(d_out + r_lvl); F.view_cos = reinterpret_cast<float*>(d_out + r_vc);
-    hipLaunchKernelGGL(frustum_kernel, dim3((nq + 255) / 256), dim3(256), 0, sm, F);
+    F.q = reinterpret_cast<QRec*>(S.d + S.o_q);
+    F.in_view = reinterpret_cast<uint8_t*>(S.d_out + r_inv); F.uvr = reinterpret_cast<float*>(S.d_out + r_uvr);
+    F.level = reinterpret_cast<int32_t*>(S.d_out + r_lvl); F.view_cos = reinterpret_cast<float*>(S.d_out + r_vc);
+    hipLaunchKernelGGL(frustum_kernel, dim3((nq + 255) / 256), dim3(256), 0, ctx->stream, F);
     LLD_HIP_TRY(hipGetLastError());
   }
-  static bool lds_raised = false;
-  if (!lds_raised) { LLD_HIP_TRY(hipFuncSetAttribute((const void*)orb_search_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit)); lds_raised = true; }
-  hipLaunchKernelGGL(orb_search_kernel, dim3(1), dim3(kThreads), lds, sm, reinterpret_cast<const Problem*>(d));
-  LLD_HIP_TRY(hipGetLastError());
-  LLD_HIP_TRY(hipMemcpyAsync(h_out, d_out, out_bytes, hipMemcpyDeviceToHost, sm));
-  LLD_HIP_TRY(hipStreamSynchronize(sm));
-  if (nq) {
-    std::memcpy(out->match, h_out + r_match, (size_t)nq * 4); std::memcpy(out->best_dist, h_out + r_bd, (size_t)nq * 4);
-    std::memcpy(out->second_dist, h_out + r_sd, (size_t)nq * 4); std::memcpy(out->removed, h_out + r_rem, (size_t)nq);
-    if (fr) {
-      if (fr->in_view) std::memcpy(fr->in_view, h_out + r_inv, (size_t)nq);
-      if (fr->proj_uvr) std::memcpy(fr->proj_uvr, h_out + r_uvr, (size_t)nq * 12);
-      if (fr->level) std::memcpy(fr->level, h_out + r_lvl, (size_t)nq * 4);
-      if (fr->view_cos) std::memcpy(fr->view_cos, h_out + r_vc, (size_t)nq * 4);
-    }
+  st = S.search_and_fetch(out); if (st) return st;
+  if (nq && fr) {
+    if (fr->in_view) std::memcpy(fr->in_view, S.h_out + r_inv, (size_t)nq);
+    if (fr->proj_uvr) std::memcpy(fr->proj_uvr, S.h_out + r_uvr, (size_t)nq * 12);
+    if (fr->level) std::memcpy(fr->level, S.h_out + r_lvl, (size_t)nq * 4);
+    if (fr->view_cos) std::memcpy(fr->view_cos, S.h_out + r_vc, (size_t)nq * 4);
   }
-  if (out->owner && nt) std::memcpy(out->owner, h_out + r_owner, (size_t)nt * 4);
-  const int32_t* sum = reinterpret_cast<const int32_t*>(h_out + r_sum);
-  out->n_matches = sum[0]; out->rounds = sum[1];
+  return LLD_OK;
+}
+
+extern "C" int lld_orb_search_last_frame(lld_ctx* ctx, const lld_orb_search* frame, const lld_frame_view* view, const lld_last_frame_points* last,
+                                         int direction, float th, int check_orientation, float* proj_uvr, lld_orb_search_result* out) {
+  if (!ctx || !frame || !view || !last || !out) return LLD_ERR_INVALID;
+  ProjSearch S{ctx, frame, frame->nt, last->n, check_orientation != 0};
+  int st = S.check(out); if (st) return st;
+  const int nq = S.nq;
+  if (nq > 0 && (!last->world_pos || !last->valid || !last->octave || !last->desc || (check_orientation && !last->angle))) return LLD_ERR_INVALID;
+  for (int i = 0; i < nq; i++) if (last->octave[i] < 0 || last->octave[i] >= frame->n_levels) return LLD_ERR_INVALID;
+  out->n_matches = 0; out->rounds = 0;
+  LLD_HIP_TRY(hipSetDevice(ctx->device));
+  S.layout();
+  const size_t o_pos = S.add_in((size_t)nq * 12), o_val = S.add_in((size_t)nq), o_oct = S.add_in((size_t)nq * 4);
+  const size_t o_ang = last->angle ? S.add_in((size_t)nq * 4) : 0, o_obs = last->has_obs ? S.add_in((size_t)nq) : 0;
+  const size_t r_uvr = S.add_out((size_t)nq * 12);
+  st = S.alloc(); if (st) return st;
+  if (nq) {
+    std::memcpy(S.h + o_pos, last->world_pos, (size_t)nq * 12); std::memcpy(S.h + o_val, last->valid, (size_t)nq);
+    std::memcpy(S.h + o_oct, last->octave, (size_t)nq * 4);
+    if (last->angle) std::memcpy(S.h + o_ang, last->angle, (size_t)nq * 4);
+    if (last->has_obs) std::memcpy(S.h + o_obs, last->has_obs, (size_t)nq);
+  }
+  Problem& P = S.pack(last->desc, out->owner != nullptr);
+  P.gates = LLD_ORB_GATE_LEVEL | LLD_ORB_GATE_STEREO; P.accept_max = 100;       // TH_HIGH, src/ORBmatcher.cc:1418
+  P.ratio_mode = 0; P.sequential = 1; P.check_orientation = check_orientation != 0;
+  st = S.upload(); if (st) return st;
+  if (nq) {
+    LastFrameArgs F; std::memset(&F, 0, sizeof(F));
+    F.V = *view; F.n = nq; F.direction = direction;
+    F.pos = reinterpret_cast<const float*>(S.d + o_pos); F.valid = reinterpret_cast<const uint8_t*>(S.d + o_val);
+    F.octave = reinterpret_cast<const int32_t*>(S.d + o_oct);
+    F.angle = last->angle ? reinterpret_cast<const float*>(S.d + o_ang) : nullptr;
+    F.has_obs = last->has_obs ? reinterpret_cast<const uint8_t*>(S.d + o_obs) : nullptr;
+    for (int l = 0; l < LLD_ORB_MAX_LEVELS; l++) F.scale[l] = P.scale[l];
+    F.th = th;
+    F.q = reinterpret_cast<QRec*>(S.d + S.o_q); F.uvr = reinterpret_cast<float*>(S.d_out + r_uvr);
+    hipLaunchKernelGGL(project_last_frame_kernel, dim3((nq + 255) / 256), dim3(256), 0, ctx->stream, F);
+    LLD_HIP_TRY(hipGetLastError());
+  }
+  st = S.search_and_fetch(out); if (st) return st;
+  if (nq && proj_uvr) std::memcpy(proj_uvr, S.h_out + r_uvr, (size_t)nq * 12);
   return LLD_OK;
 }

@@ -489,6 +489,11 @@ class ORBmatcher:
         from . import orb_search as S
         return S.search_local_points(self.lib, self.ctx.handle, F, view, map_points, f_occupied, th, float(self.mfNNratio), viewing_cos_limit)
 
+    def SearchLastFrame(self, Cur, view, last: dict, cur_occupied=None, direction=0, th=7.0):
+        """SearchByProjection(Frame& Current, const Frame& Last, th, bMono) with the projection on the device too."""
+        from . import orb_search as S
+        return S.search_last_frame(self.lib, self.ctx.handle, Cur, view, last, cur_occupied, direction, th, self.mbCheckOrientation)
+
     def SearchByProjectionFrame(self, Cur, last_desc, valid, uv, ur, last_octave, last_angle, mp_obs, cur_occupied, direction=0, th=7.0):
         """SearchByProjection(Frame& Current, const Frame& Last, th, bMono)  (src/ORBmatcher.cc:1328-1470)."""
         from . import orb_search as S

@@ -57,6 +57,11 @@ class MapPoints(C.Structure):
                 ("min_distance", c_float_p), ("desc", c_uint32_p), ("has_obs", c_uint8_p), ("skip", c_uint8_p)]
 
 
+class LastFramePoints(C.Structure):
+    _fields_ = [("n", C.c_int32), ("world_pos", c_float_p), ("valid", c_uint8_p), ("octave", c_int32_p), ("angle", c_float_p),
+                ("desc", c_uint32_p), ("has_obs", c_uint8_p)]
+
+
 class FrustumResult(C.Structure):
     _fields_ = [("in_view", c_uint8_p), ("proj_uvr", c_float_p), ("level", c_int32_p), ("view_cos", c_float_p)]
 
@@ -425,3 +430,35 @@ def search_local_points(lib, ctx, F: Frame, view: FrameView, mp: dict, f_occupie
         raise RuntimeError(f"lld_orb_search_local_points failed: {lib.fn('status_string')(st).decode()}")
     out.n_matches, out.rounds = r.n_matches, r.rounds
     return out, fr
+
+
+def last_frame_struct(last: dict):
+    keep = dict(world_pos=_f32(last["world_pos"]).reshape(-1, 3), valid=_u8(last["valid"]), octave=_i32(last["octave"]), angle=_f32(last.get("angle")),
+                desc=np.ascontiguousarray(last["desc"], np.uint32).reshape(-1, 8), has_obs=_u8(last.get("has_obs")))
+    m = LastFramePoints()
+    m.n = keep["world_pos"].shape[0]
+    m.world_pos = _p(keep["world_pos"], c_float_p); m.valid = _p(keep["valid"], c_uint8_p); m.octave = _p(keep["octave"], c_int32_p)
+    m.angle = _p(keep["angle"], c_float_p); m.desc = _p(keep["desc"], c_uint32_p); m.has_obs = _p(keep["has_obs"], c_uint8_p)
+    return m, keep
+
+
+def search_last_frame(lib, ctx, Cur: Frame, view: FrameView, last: dict, cur_occupied=None, direction=0, th=7.0, check_orientation=True):
+    """ORBmatcher::SearchByProjection(Current, Last, th, bMono) (src/ORBmatcher.cc:1328-1470) with the projection of the last
+    frame's MapPoints done on the device.  Returns (SearchOutput, proj_uvr [n,3])."""
+    p = prepare(Cur, np.zeros((0, 8), np.uint32), candidates=CAND_GRID, accept_max=TH_HIGH, t_occupied=cur_occupied)
+    m, keep = last_frame_struct(last)
+    n, nt = m.n, Cur.n
+    out = SearchOutput(np.empty(n, np.int32), np.empty(n, np.int32), np.empty(n, np.int32), np.empty(n, np.uint8), np.empty(nt, np.int32), 0, 0)
+    r = OrbSearchResult()
+    r.match = _p(out.match, c_int32_p); r.best_dist = _p(out.best_dist, c_int32_p); r.second_dist = _p(out.second_dist, c_int32_p)
+    r.removed = _p(out.removed, c_uint8_p); r.owner = _p(out.owner, c_int32_p)
+    uvr = np.zeros((n, 3), np.float32)
+    fn = lib.fn("orb_search_last_frame")
+    fn.argtypes = [C.c_void_p, C.POINTER(OrbSearch), C.POINTER(FrameView), C.POINTER(LastFramePoints), C.c_int, C.c_float, C.c_int, c_float_p,
+                   C.POINTER(OrbSearchResult)]
+    fn.restype = C.c_int
+    st = fn(ctx, C.byref(p.s), C.byref(view), C.byref(m), int(direction), float(np.float32(th)), int(check_orientation), _p(uvr, c_float_p), C.byref(r))
+    if st != abi.LLD_OK:
+        raise RuntimeError(f"lld_orb_search_last_frame failed: {lib.fn('status_string')(st).decode()}")
+    out.n_matches, out.rounds = r.n_matches, r.rounds
+    return out, uvr

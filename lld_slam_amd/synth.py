@@ -542,4 +542,4 @@ def make_local_map(F, scene_id=0, n=2000, related_frac=0.8, flip_p=0.06):
     desc[far] = rng.integers(0, 2 ** 32, (int(far.sum()), 8), dtype=np.uint64).astype(np.uint32)
     return T, dict(world_pos=Xw.astype(np.float32), normal=normal.astype(np.float32), max_distance=maxd.astype(np.float32),
                    min_distance=mind.astype(np.float32), desc=desc, has_obs=(rng.random(n) < 0.9).astype(np.uint8),
-                   skip=(rng.random(n) < 0.1).astype(np.uint8), occupied=(rng.random(F.n) < 0.05).astype(np.uint8))
+                   skip=(rng.random(n) < 0.1).astype(np.uint8), occupied=(rng.random(F.n) < 0.05).astype(np.uint8), src=src.astype(np.int32))

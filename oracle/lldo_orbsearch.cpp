@@ -555,4 +555,28 @@ int lldo_is_in_frustum(const lld_frame_view* V, const lld_map_points* mp, float 
   return nToMatch;
 }
 
+// Projection loop of ORBmatcher::SearchByProjection(Current, Last, th, bMono) (src/ORBmatcher.cc:1352-1377): valid_out[i] = the
+// point survives every `continue` before the window search; uv / ur as the reference computes them (ur = u - mbf*invzc, :1402).
+void lldo_project_last_frame(const lld_frame_view* V, const lld_last_frame_points* L, uint8_t* valid_out, float* uv, float* ur) {
+  for (int i = 0; i < L->n; i++) {
+    valid_out[i] = 0; uv[2 * i] = uv[2 * i + 1] = 0.f; ur[i] = 0.f;
+    if (!L->valid[i]) continue;
+    const float* P = L->world_pos + 3 * i;
+    float x3Dc[3];
+    for (int r = 0; r < 3; r++) {
+      double s0 = 0.0;
+      for (int k = 0; k < 3; k++) s0 += (double)V->Rcw[3 * r + k] * (double)P[k];
+      x3Dc[r] = (float)(s0 + (double)V->tcw[r]);
+    }
+    const float xc = x3Dc[0], yc = x3Dc[1];
+    const float invzc = 1.0 / x3Dc[2];
+    if (invzc < 0) continue;
+    const float u = V->fx * xc * invzc + V->cx;
+    const float v = V->fy * yc * invzc + V->cy;
+    if (u < V->min_x || u > V->max_x) continue;
+    if (v < V->min_y || v > V->max_y) continue;
+    valid_out[i] = 1; uv[2 * i] = u; uv[2 * i + 1] = v; ur[i] = u - V->bf * invzc;
+  }
+}
+
 }  // extern "C"

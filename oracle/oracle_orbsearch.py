@@ -193,3 +193,16 @@ def is_in_frustum(view, mp: dict, viewing_cos_limit=0.5):
     k = d.lldo_is_in_frustum(C.byref(view), C.byref(m), float(np.float32(viewing_cos_limit)), _p(in_view, c_uint8_p), _p(uvr, c_float_p),
                              _p(level, c_int32_p), _p(vc, c_float_p))
     return k, in_view, uvr, level, vc
+
+
+def project_last_frame(view, last: dict):
+    """Projection loop of SearchByProjection(Current, Last): (valid, uv [n,2], ur [n])."""
+    from lld_slam_amd.orb_search import FrameView, LastFramePoints, last_frame_struct
+    d = _dll()
+    d.lldo_project_last_frame.argtypes = [C.POINTER(FrameView), C.POINTER(LastFramePoints), c_uint8_p, c_float_p, c_float_p]
+    d.lldo_project_last_frame.restype = None
+    m, keep = last_frame_struct(last)
+    n = m.n
+    valid = np.zeros(n, np.uint8); uv = np.zeros((n, 2), np.float32); ur = np.zeros(n, np.float32)
+    d.lldo_project_last_frame(C.byref(view), C.byref(m), _p(valid, c_uint8_p), _p(uv, c_float_p), _p(ur, c_float_p))
+    return valid, uv, ur

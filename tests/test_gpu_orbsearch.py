@@ -249,3 +249,26 @@ def test_search_local_points_edge_cases(gpu_ctx):
     allskip = dict(mp, skip=np.ones(200, np.uint8))
     out, fr = orb_search.search_local_points(gpu_ctx.lib, gpu_ctx.handle, F, view, allskip, mp["occupied"])
     assert out.n_matches == 0 and not fr["in_view"].any()
+
+
+@pytest.mark.parametrize("seed,direction,th", [(0, 0, 7.0), (1, 1, 15.0), (2, -1, 7.0)])
+def test_search_last_frame_projection_and_search_on_device(gpu_ctx, seed, direction, th):
+    """Tracking::TrackWithMotionModel's matcher: the last frame's MapPoints are projected on the device (cv::gemm transform,
+    invzc = float(1.0/z), bounds), then searched with occupancy and the rotation histogram."""
+    F = synth.make_orb_frame(140 + seed, 2000)
+    T, mp = synth.make_local_map(F, 140 + seed, 2000)
+    rng = np.random.default_rng(seed)
+    ang = np.mod(F.angle[mp["src"]] + 25.0 + rng.normal(0, 6.0, 2000), 360.0)
+    wild = rng.random(2000) < 0.15; ang[wild] = rng.uniform(0, 360, int(wild.sum()))
+    last = dict(world_pos=mp["world_pos"], valid=(rng.random(2000) < 0.85).astype(np.uint8), octave=F.octave[mp["src"]],
+                angle=ang.astype(np.float32), desc=mp["desc"], has_obs=mp["has_obs"])
+    view = orb_search.frame_view(T, synth.KITTI_CAM, F)
+    out, uvr = orb_search.search_last_frame(gpu_ctx.lib, gpu_ctx.handle, F, view, last, mp["occupied"], direction, th, True)
+    valid, uv, ur = OS.project_last_frame(view, last)
+    m = valid != 0
+    assert 800 < m.sum() < 1900
+    np.testing.assert_array_equal(uvr[m, :2], uv[m]); np.testing.assert_array_equal(uvr[m, 2], ur[m])
+    n_exp, slot = OS.search_by_projection_frame(F, last["desc"], valid, uv, ur, last["octave"], last["angle"], last["has_obs"], mp["occupied"],
+                                                direction, th, True)
+    assert out.n_matches == n_exp and n_exp > 100
+    np.testing.assert_array_equal(expect_slots(out, mp["occupied"]), slot)
