@@ -84,7 +84,26 @@ g_bat, r_bat = timed(lambda: S.run_batch(ctx.lib, ctx.handle, prep), 5)
 t = time.perf_counter()
 e_bat = [OS.search_by_projection_map(Fi, qi["desc"], qi["valid"], qi["uv"], qi["ur"], qi["level"], qi["view_cos"], qi["obs"], qi["occupied"], 1.0, 0.8)[0] for Fi, qi in scenes]
 c_bat = (time.perf_counter() - t) / len(scenes)
+# the two per-frame tracking matchers with the projection on the device as well
+from lld_slam_amd import orb_search as S2
+Tm, mpm = synth.make_local_map(F, 0, 2500)
+view = S2.frame_view(Tm, synth.KITTI_CAM, F)
+g_loc, r_loc = timed(lambda: S2.search_local_points(ctx.lib, ctx.handle, F, view, mpm, mpm["occupied"], 1.0, 0.8))
+def cpu_loc():
+    k, inv, uvr, lvl, vc = OS.is_in_frustum(view, mpm)
+    return OS.search_by_projection_map(F, mpm["desc"], inv, uvr[:, :2], uvr[:, 2], lvl, vc, mpm["has_obs"], mpm["occupied"], 1.0, 0.8)
+c_loc, e_loc = timed(cpu_loc)
+rngl = np.random.default_rng(0)
+lastf = dict(world_pos=mpm["world_pos"], valid=(rngl.random(2500) < 0.85).astype(np.uint8), octave=F.octave[mpm["src"]],
+             angle=np.mod(F.angle[mpm["src"]] + 25.0 + rngl.normal(0, 6.0, 2500), 360.0).astype(np.float32), desc=mpm["desc"], has_obs=mpm["has_obs"])
+g_lf, r_lf = timed(lambda: S2.search_last_frame(ctx.lib, ctx.handle, F, view, lastf, mpm["occupied"], 0, 7.0, True))
+def cpu_lf():
+    valid, uv, ur = OS.project_last_frame(view, lastf)
+    return OS.search_by_projection_frame(F, lastf["desc"], valid, uv, ur, lastf["octave"], lastf["angle"], lastf["has_obs"], mpm["occupied"], 0, 7.0, True)
+c_lf, e_lf = timed(cpu_lf)
 out["orb_guided_search"] = {
+    "search_local_points": {"gpu_ms": g_loc * 1e3, "cpu_oracle_ms": c_loc * 1e3, "n_matches": r_loc[0].n_matches, "equal": r_loc[0].n_matches == e_loc[0]},
+    "search_last_frame": {"gpu_ms": g_lf * 1e3, "cpu_oracle_ms": c_lf * 1e3, "n_matches": r_lf[0].n_matches, "equal": r_lf[0].n_matches == e_lf[0]},
     "map_projection_batch512": {"gpu_searches_per_s": len(prep) / g_bat, "cpu_oracle_searches_per_s": 1.0 / c_bat,
                                 "equal": [o.n_matches for o in r_bat[:64]] == e_bat},
     "map_projection": {"gpu_ms": g_map * 1e3, "cpu_oracle_ms": c_map * 1e3, "rounds": r_map.rounds, "n_matches": r_map.n_matches, "equal": r_map.n_matches == e_map[0]},
