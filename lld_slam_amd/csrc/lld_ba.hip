@@ -405,7 +405,7 @@ int lld_ba_batch_solve(lld_ba_batch* B, volatile const int* abort_flag) {
     LLD_HIP_TRY(hipEventRecord(G.ev[0], st));
     if (G.max_nl_pt > 0) hipLaunchKernelGGL(ba_linearize_pt_kernel, dim3(G.max_nl_pt, nw), dim3(kLinThreads), lin_lds, st, A, dw, ds);
     if (G.max_nl_ln > 0) hipLaunchKernelGGL(ba_linearize_ln_kernel, dim3(G.max_nl_ln, nw), dim3(kLinThreads), lin_lds, st, A, dw, ds);
-    hipLaunchKernelGGL(ba_hpp_reduce_kernel, dim3((B->max_free * 27 + 255) / 256, nw), dim3(256), 0, st, A, dw, ds);
+    hipLaunchKernelGGL(ba_hpp_reduce_kernel, dim3(std::max(1, (B->max_free * 27 + 255) / 256), nw), dim3(256), 0, st, A, dw, ds);
     hipLaunchKernelGGL(ba_begin_kernel, dim3(nw), dim3(kCtlThreads), 0, st, A, dw, ds, nw);
     LLD_HIP_TRY(hipEventRecord(G.ev[1], st));
     if (G.max_items_pt > 0) hipLaunchKernelGGL(ba_schur_items_kernel<3>, dim3(G.max_items_pt, nw), dim3(64), B->schur_lds[0], st, A, dw, ds);

@@ -150,3 +150,32 @@ def test_size_independent_properties_at_full_size(gpu_ctx):
     err0 = np.linalg.norm(w.cam_qt[:50, 4:] - w.meta["gt_tcw"][:50], axis=1).mean()
     err1 = np.linalg.norm(a.cam_qt[:50, 4:] - w.meta["gt_tcw"][:50], axis=1).mean()
     assert err1 < 0.3 * err0
+
+
+def test_window_without_free_cameras_optimises_landmarks_only(gpu_ctx, oracle):
+    """All keyframes fixed (n_free_cams = 0): the reduced camera system is empty, only points and lines move."""
+    w = synth.make_lba_small(5, n_free=0, n_fixed=7, n_points=100, n_lines=20)
+    check_ba(Optimizer(gpu_ctx).LocalBundleAdjustment(w), oracle.local_ba(w), w)
+
+
+def test_degenerate_windows(gpu_ctx, oracle):
+    """No landmarks at all; thinly observed landmarks (2 views per point, 1 keyframe per line: every line falls to the
+    `count <= 4` rule of LineOptimizer::DisableOutliers); half of the observations gross outliers."""
+    empty = synth.make_lba_small(6, n_free=3, n_fixed=2, n_points=0, n_lines=0)
+    g = Optimizer(gpu_ctx).LocalBundleAdjustment(empty)
+    assert g.stats["lm_iterations"] == [0, 0] and g.stats["chi2_final"] == 0.0
+    np.testing.assert_array_equal(g.cam_qt, empty.cam_qt)
+    thin = synth.make_ba_window(4, 3, 120, 2, 20, 1, seed=123)
+    check_ba(Optimizer(gpu_ctx).LocalBundleAdjustment(thin), oracle.local_ba(thin), thin)
+    wild = synth.make_ba_window(4, 3, 150, 3, 30, 2, seed=124, outlier_frac=0.5)
+    check_ba(Optimizer(gpu_ctx).LocalBundleAdjustment(wild), oracle.local_ba(wild), wild)
+
+
+def test_batch_mixing_fixed_only_empty_and_regular_windows(gpu_ctx, oracle):
+    ws = [synth.make_lba_small(5, n_free=0, n_fixed=7, n_points=100, n_lines=20), synth.make_lba_small(6, n_free=3, n_fixed=2, n_points=0, n_lines=0),
+          synth.make_lba_small(0), synth.make_ba_window(4, 3, 120, 2, 20, 1, seed=123)]
+    with BABatch(gpu_ctx, ws) as b:
+        b.solve()
+        for i in (0, 2, 3):
+            check_ba(b.download(i), oracle.local_ba(ws[i]), ws[i])
+        assert b.download(1).stats["lm_iterations"] == [0, 0]
