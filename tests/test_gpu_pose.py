@@ -30,13 +30,17 @@ def _check(g, o, n_points):
     (4, dict(n_points=5, n_lines=2)),                       # fewer than 10 edges: early break before line classification
     (5, dict(n_points=2, n_lines=5)),                       # fewer than 3 points: returns 0
     (6, dict(n_points=400, n_lines=80, outlier_frac=0.3)),
+    (30, dict(n_points=0, n_lines=0)),                      # nothing to optimise
+    (30, dict(n_points=200, n_lines=40, mono_frac=1.0, mono_line_frac=1.0)),   # a monocular frame: 2-D point edges, left line edges only
+    (30, dict(n_points=0, n_lines=50)),                     # lines only: nInitialCorrespondences < 3 -> 0
+    (30, dict(n_points=400, n_lines=80, outlier_frac=0.9)),   # almost everything is rejected in round 1
 ])
 def test_pose_optimization_matches_oracle(gpu_ctx, oracle, fid, kw):
     f = synth.make_pose_frame(fid, **kw)
     g = Optimizer(gpu_ctx).PoseOptimization(f, gamma=0.5)
     o = oracle.pose_opt(f, gamma=0.5)
     _check(g, o, f.n_points)
-    if f.n_points >= 50:
+    if f.n_points >= 50 and kw.get("mono_frac", 0.0) < 1.0 and kw.get("outlier_frac", 0.0) < 0.5:
         gt = f.meta["gt_qt"]
         assert np.linalg.norm(g.pose_qt[4:] - gt[4:]) < 0.05
 
