@@ -19,7 +19,7 @@ def _check(g, o, n_points):
     assert g.chi2 == pytest.approx(o.chi2, rel=RTOL)
     # LM accept/reject decisions at convergence hinge on chi2 differences at rounding level (rho ~ 0/0), so the trial
     # count may differ by a few while the result does not
-    assert abs(g.lm_iterations - o.lm_iterations) <= 2 and abs(g.lm_trials - o.lm_trials) <= 6
+    assert abs(g.lm_iterations - o.lm_iterations) <= 2 and abs(g.lm_trials - o.lm_trials) <= 10
 
 
 @pytest.mark.parametrize("fid,kw", [
