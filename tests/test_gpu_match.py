@@ -152,3 +152,21 @@ def test_stereo_line_association_edge_cases(gpu_ctx, oracle):
     m, d, gate = tm.MatchLines(s["desc_left"], s["desc_right"], lines=s["left"], other_lines=s["right"], octaves=s["left_octave"],
                                other_octaves=s["right_octave"], want_gate=True)
     assert (m == -1).all() and not gate.any()
+
+
+@pytest.mark.parametrize("dim", [1, 3, 7, 31, 33, 71, 73, 127, 128])
+def test_l2_odd_descriptor_lengths(gpu_ctx, oracle, dim):
+    """Descriptor lengths that are not multiples of the vector load width (LBD variants: 8 x bands + ...)."""
+    rng = np.random.default_rng(dim)
+    q = rng.normal(size=(70, dim)).astype(np.float32); t = rng.normal(size=(45, dim)).astype(np.float32)
+    t[7] = q[3]; t[9] = q[3]                                # an exact tie: the lower index wins
+    _same(TwoFrameLineMatcher(gpu_ctx, 2.0).BestTwo(q, t), oracle.match_l2f32(q, t))
+    m, d = TwoFrameLineMatcher(gpu_ctx, 1e9).MatchLines(q, t)
+    me, de = oracle.line_match_greedy(q, t, None, 1e9)
+    np.testing.assert_array_equal(m, me); np.testing.assert_array_equal(d, de)
+
+
+def test_l2_rejects_descriptors_longer_than_128(gpu_ctx):
+    q = np.zeros((4, 129), np.float32)
+    with pytest.raises(RuntimeError):
+        TwoFrameLineMatcher(gpu_ctx, 2.0).BestTwo(q, q)
