@@ -179,3 +179,22 @@ def test_batch_mixing_fixed_only_empty_and_regular_windows(gpu_ctx, oracle):
         for i in (0, 2, 3):
             check_ba(b.download(i), oracle.local_ba(ws[i]), ws[i])
         assert b.download(1).stats["lm_iterations"] == [0, 0]
+
+
+def test_invalid_inputs_are_refused_and_poison_is_contained(gpu_ctx, oracle):
+    """Error behaviour of the boundary: malformed windows are refused at create time with LLD_ERR_INVALID (no partial batch);
+    a non-finite landmark ruins only its own window - LM rejects the trials (levenberg.cpp:126-127) - and neither hangs the
+    batch nor touches its neighbours."""
+    with pytest.raises(RuntimeError):
+        BABatch(gpu_ctx, [])
+    good = synth.make_lba_small(0)
+    bad = synth.make_lba_small(1); bad.pt_obs_cam = bad.pt_obs_cam.copy(); bad.pt_obs_cam[3] = 99          # camera index out of range
+    with pytest.raises(RuntimeError):
+        BABatch(gpu_ctx, [good, bad])
+    bad = synth.make_lba_small(2); bad.pt_obs_start = bad.pt_obs_start.copy(); bad.pt_obs_start[5] = bad.pt_obs_start[4] - 1   # CSR not monotone
+    with pytest.raises(RuntimeError):
+        BABatch(gpu_ctx, [bad])
+    nan = synth.make_lba_small(3); nan.pt_xyz = nan.pt_xyz.copy(); nan.pt_xyz[0, 0] = np.nan
+    with BABatch(gpu_ctx, [nan, good]) as b:
+        b.solve()
+        check_ba(b.download(1), oracle.local_ba(good), good)
