@@ -145,6 +145,35 @@ class ORBmatcher {
     r.n_matches = o.n_matches; r.rounds = o.rounds;
     return r;
   }
+  // Tracking::SearchLocalPoints: Frame::isInFrustum for every local MapPoint + SearchByProjection(F, vpMapPoints, th), one call.
+  // `frame` carries the keypoint side (nt, t_*), the grid constants and the scale table; in_view (may be null) receives mbTrackInView.
+  SearchResult SearchLocalPoints(const lld_orb_search& frame, const lld_frame_view& view, const lld_map_points& points, float th = 1.0f,
+                                 std::vector<uint8_t>* in_view = nullptr, float viewingCosLimit = 0.5f) const {
+    SearchResult r;
+    r.match.resize(points.n); r.best_dist.resize(points.n); r.second_dist.resize(points.n); r.removed.resize(points.n); r.owner.resize(frame.nt);
+    lld_orb_search_result o{};
+    o.match = r.match.data(); o.best_dist = r.best_dist.data(); o.second_dist = r.second_dist.data(); o.removed = r.removed.data();
+    o.owner = r.owner.data();
+    lld_frustum_result fr{};
+    if (in_view) { in_view->assign(points.n, 0); fr.in_view = in_view->data(); }
+    check(lld_orb_search_local_points(ctx_.get(), &frame, &view, &points, viewingCosLimit, th, mfNNratio, &fr, &o), "lld_orb_search_local_points");
+    r.n_matches = o.n_matches; r.rounds = o.rounds;
+    return r;
+  }
+  // SearchByProjection(Frame& Current, const Frame& Last, th, bMono) with the projection of the last frame's points on the device;
+  // direction: +1 bForward, -1 bBackward, 0 neither (src/ORBmatcher.cc:1343-1350)
+  SearchResult SearchByProjection(const lld_orb_search& currentFrame, const lld_frame_view& view, const lld_last_frame_points& last, int direction,
+                                  float th) const {
+    SearchResult r;
+    r.match.resize(last.n); r.best_dist.resize(last.n); r.second_dist.resize(last.n); r.removed.resize(last.n); r.owner.resize(currentFrame.nt);
+    lld_orb_search_result o{};
+    o.match = r.match.data(); o.best_dist = r.best_dist.data(); o.second_dist = r.second_dist.data(); o.removed = r.removed.data();
+    o.owner = r.owner.data();
+    check(lld_orb_search_last_frame(ctx_.get(), &currentFrame, &view, &last, direction, th, mbCheckOrientation ? 1 : 0, nullptr, &o),
+          "lld_orb_search_last_frame");
+    r.n_matches = o.n_matches; r.rounds = o.rounds;
+    return r;
+  }
  private:
   Context& ctx_;
  public:
