@@ -35,6 +35,8 @@ constexpr int kSchurThreads = 128;    // item-parallel Schur kernel: one lane pe
 constexpr int kPcgThreads = 1024;
 constexpr int kCtlThreads = 64;
 constexpr int kLinThreads = 512;        // linearise kernels: 8 tasks per workgroup (fewer per-workgroup Hpp partials to reduce)
+constexpr int kLinRounds = 4;          // tasks per wavefront of a linearise workgroup: amortises zeroing / flushing the LDS accumulators and
+                                       // divides the number of per-workgroup Hpp partials (and ba_hpp_reduce's work) by the same factor
 constexpr int kAccCopies = 4;          // LDS copies of the per-camera Hpp/bp accumulators: lanes of one wavefront that hit the
                                        // same camera are spread over them (same-address LDS atomics serialise)
 constexpr int kMaxFreeCams = 96;
@@ -59,7 +61,7 @@ struct BAWin {                 // immutable per-window header
   int nb_pt, nb_ln;            // landmark blocks (kLmThreads landmarks each)
   int ptask_off, n_ptasks, nt_pt;   // point tasks (4 per workgroup -> nt_pt workgroups)
   int ltask_off, n_ltasks, nt_ln;   // line tasks; partial-sum slots of a window: nt_pt + nt_ln
-  int nl_pt, nl_ln;            // workgroups of the linearise kernels (kLinThreads / 64 tasks each)
+  int nl_pt, nl_ln;            // workgroups of the linearise kernels (kLinRounds * kLinThreads / 64 tasks each)
   long long hpart_off;         // per-workgroup Hpp/bp partials of the linearise kernels (doubles): [nl_pt + nl_ln][n_free * 27]
   int part_off;                // per-block partial sums
   int its[2];                  // LM iterations per round
@@ -374,7 +376,7 @@ __device__ __forceinline__ void point_edge_hpp(const PtEdgeLin& L, double* ac) {
   }
 }
 
-// grid (nl_pt, nW), block 512 = 8 wavefronts = 8 tasks; dynamic LDS: kAccCopies*n_free_max*27 doubles + 8 scratch.
+// grid (nl_pt, nW), block 512 = 8 wavefronts, kLinRounds tasks per wavefront; dynamic LDS: kAccCopies*n_free_max*27 doubles + 8 scratch.
 __global__ __launch_bounds__(kLinThreads, 4) void ba_linearize_pt_kernel(BAArrays A, const BAWin* __restrict__ wins, BAState* __restrict__ st) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const BAWin W = wins[blockIdx.y];
@@ -390,9 +392,11 @@ __global__ __launch_bounds__(kLinThreads, 4) void ba_linearize_pt_kernel(BAArray
   const int cur = S.cur;
   for (int i = threadIdx.x; i < W.n_cams * 7; i += kLinThreads) cams[i] = A.cam_qt[((size_t)cur * A.NC + W.cam_off) * 7 + i];
   __syncthreads();
-  const int lane = threadIdx.x & 63, ti = blockIdx.x * (kLinThreads / 64) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
   double chi = 0.0, maxd = 0.0;
-  if (ti < W.n_ptasks) {
+  for (int rnd = 0; rnd < kLinRounds; rnd++) {
+    const int ti = (blockIdx.x * kLinRounds + rnd) * (kLinThreads / 64) + (threadIdx.x >> 6);
+    if (ti >= W.n_ptasks) break;
     const PTask T = A.ptasks[W.ptask_off + ti];
     if (T.nl > 1) {
       // two dependent memory levels only: (1) the task, (2) every global operand - edge arrays by edge lane, landmark
@@ -434,7 +438,7 @@ __global__ __launch_bounds__(kLinThreads, 4) void ba_linearize_pt_kernel(BAArray
         double* V = A.pt_V + (size_t)g2 * 9;
 #pragma unroll
         for (int i = 0; i < 9; i++) V[i] = vb[i];
-        maxd = fmax(fabs(vb[0]), fmax(fabs(vb[3]), fabs(vb[5])));
+        maxd = fmax(maxd, fmax(fabs(vb[0]), fmax(fabs(vb[3]), fabs(vb[5]))));
       }
     } else {                                             // a single landmark, any number of edges
       const int g = W.pt_off + T.l0;
@@ -462,7 +466,7 @@ __global__ __launch_bounds__(kLinThreads, 4) void ba_linearize_pt_kernel(BAArray
           double* V = A.pt_V + (size_t)g * 9;
 #pragma unroll
           for (int i = 0; i < 9; i++) V[i] = hb[i];
-          maxd = fmax(fabs(hb[0]), fmax(fabs(hb[3]), fabs(hb[5])));
+          maxd = fmax(maxd, fmax(fabs(hb[0]), fmax(fabs(hb[3]), fabs(hb[5]))));
         }
       }
     }
@@ -717,7 +721,7 @@ __device__ __forceinline__ double line_obs_linearize(const BAArrays& A, const BA
   return chi;
 }
 
-// grid (nl_ln, nW), block 512 = 8 tasks; dynamic LDS: kAccCopies*n_free_max*27 doubles + 8 scratch.
+// grid (nl_ln, nW), block 512 = 8 wavefronts, kLinRounds tasks per wavefront; dynamic LDS: kAccCopies*n_free_max*27 doubles + 8 scratch.
 __global__ __launch_bounds__(kLinThreads) void ba_linearize_ln_kernel(BAArrays A, const BAWin* __restrict__ wins, BAState* __restrict__ st) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const BAWin W = wins[blockIdx.y];
@@ -731,9 +735,11 @@ __global__ __launch_bounds__(kLinThreads) void ba_linearize_ln_kernel(BAArrays A
   double* acc = acc_all + ((threadIdx.x >> 3) & (kAccCopies - 1)) * nacc;
   __syncthreads();
   const int cur = S.cur;
-  const int lane = threadIdx.x & 63, ti = blockIdx.x * (kLinThreads / 64) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
   double chi = 0.0, maxd = 0.0;
-  if (ti < W.n_ltasks) {
+  for (int rnd = 0; rnd < kLinRounds; rnd++) {
+    const int ti = (blockIdx.x * kLinRounds + rnd) * (kLinThreads / 64) + (threadIdx.x >> 6);
+    if (ti >= W.n_ltasks) break;
     const PTask T = A.ltasks[W.ltask_off + ti];
     double hb[14];
 #pragma unroll
@@ -753,7 +759,7 @@ __global__ __launch_bounds__(kLinThreads) void ba_linearize_ln_kernel(BAArrays A
         double* V = A.ln_V + (size_t)g * 14;
 #pragma unroll
         for (int i = 0; i < 14; i++) V[i] = hb[i];
-        maxd = fmax(fmax(fabs(hb[0]), fabs(hb[4])), fmax(fabs(hb[7]), fabs(hb[9])));
+        maxd = fmax(maxd, fmax(fmax(fabs(hb[0]), fabs(hb[4])), fmax(fabs(hb[7]), fabs(hb[9]))));
       }
     } else {
       const int g = W.ln_off + T.l0;
@@ -765,7 +771,7 @@ __global__ __launch_bounds__(kLinThreads) void ba_linearize_ln_kernel(BAArrays A
           double* V = A.ln_V + (size_t)g * 14;
 #pragma unroll
           for (int i = 0; i < 14; i++) V[i] = hb[i];
-          maxd = fmax(fmax(fabs(hb[0]), fabs(hb[4])), fmax(fabs(hb[7]), fabs(hb[9])));
+          maxd = fmax(maxd, fmax(fmax(fabs(hb[0]), fabs(hb[4])), fmax(fabs(hb[7]), fabs(hb[9]))));
         }
       }
     }
