@@ -35,7 +35,8 @@ constexpr int kSchurThreads = 128;    // item-parallel Schur kernel: one lane pe
 constexpr int kPcgThreads = 1024;
 constexpr int kCtlThreads = 64;
 constexpr int kLinThreads = 512;        // linearise kernels: 8 tasks per workgroup (fewer per-workgroup Hpp partials to reduce)
-constexpr int kLinRounds = 4;          // tasks per wavefront of a linearise workgroup: amortises zeroing / flushing the LDS accumulators and
+constexpr int kBsRounds = 4;           // same for the back-substitution workgroups (they stage both pose sets and x_p in LDS)
+constexpr int kLinRounds = 8;          // tasks per wavefront of a linearise workgroup: amortises zeroing / flushing the LDS accumulators and
                                        // divides the number of per-workgroup Hpp partials (and ba_hpp_reduce's work) by the same factor
 constexpr int kAccCopies = 4;          // LDS copies of the per-camera Hpp/bp accumulators: lanes of one wavefront that hit the
                                        // same camera are spread over them (same-address LDS atomics serialise)
@@ -59,7 +60,7 @@ struct BAWin {                 // immutable per-window header
   int lo_off, n_lo;            // line observations (= le_off / 2)
   int blk_csr_off, cam_csr_off; // CSR (per lower S block / per free camera) of the chunk partials that add into it
   int nb_pt, nb_ln;            // landmark blocks (kLmThreads landmarks each)
-  int ptask_off, n_ptasks, nt_pt;   // point tasks (4 per workgroup -> nt_pt workgroups)
+  int ptask_off, n_ptasks, nt_pt;   // point tasks (4 * kBsRounds per back-substitution workgroup -> nt_pt workgroups)
   int ltask_off, n_ltasks, nt_ln;   // line tasks; partial-sum slots of a window: nt_pt + nt_ln
   int nl_pt, nl_ln;            // workgroups of the linearise kernels (kLinRounds * kLinThreads / 64 tasks each)
   long long hpart_off;         // per-workgroup Hpp/bp partials of the linearise kernels (doubles): [nl_pt + nl_ln][n_free * 27]
@@ -537,7 +538,7 @@ __device__ __forceinline__ double point_backsub(const double* V, double lambda, 
   return sc;
 }
 
-// grid (nt_pt, nW), block 256 = 4 tasks; dynamic LDS: 8 + 14 n_cams + 6 n_free doubles
+// grid (nt_pt, nW), block 256 = 4 wavefronts, kBsRounds tasks per wavefront; dynamic LDS: 8 + 14 n_cams + 6 n_free doubles
 __global__ __launch_bounds__(kLmThreads) void ba_backsub_pt_kernel(BAArrays A, const BAWin* __restrict__ wins, const BAState* __restrict__ st) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const BAWin W = wins[blockIdx.y];
@@ -559,9 +560,11 @@ __global__ __launch_bounds__(kLmThreads) void ba_backsub_pt_kernel(BAArrays A, c
   }
   for (int i = threadIdx.x; i < 6 * W.n_free; i += kLmThreads) xps[i] = xp[i];
   __syncthreads();
-  const int lane = threadIdx.x & 63, ti = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
   double chi = 0.0, sc = 0.0;
-  if (ti < W.n_ptasks) {
+  for (int rnd = 0; rnd < kBsRounds; rnd++) {
+    const int ti = (blockIdx.x * kBsRounds + rnd) * 4 + (threadIdx.x >> 6);
+    if (ti >= W.n_ptasks) break;
     const PTask T = A.ptasks[W.ptask_off + ti];
     if (T.nl > 1) {
       const bool has = lane < T.ne;
@@ -836,7 +839,7 @@ __device__ __forceinline__ double line_backsub(const double* V, double lambda, c
   return sc;
 }
 
-// grid (nt_ln, nW), block 256 = 4 tasks
+// grid (nt_ln, nW), block 256 = 4 wavefronts, kBsRounds tasks per wavefront
 __global__ __launch_bounds__(kLmThreads) void ba_backsub_ln_kernel(BAArrays A, const BAWin* __restrict__ wins, const BAState* __restrict__ st) {
   __shared__ double scratch[8];
   const BAWin W = wins[blockIdx.y];
@@ -846,9 +849,11 @@ __global__ __launch_bounds__(kLmThreads) void ba_backsub_ln_kernel(BAArrays A, c
   const int cur = S.cur, nxt = cur ^ 1;
   const double lambda = S.lambda;
   const double* xp = A.xp + W.x_off;
-  const int lane = threadIdx.x & 63, ti = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
   double chi = 0.0, sc = 0.0;
-  if (ti < W.n_ltasks) {
+  for (int rnd = 0; rnd < kBsRounds; rnd++) {
+    const int ti = (blockIdx.x * kBsRounds + rnd) * 4 + (threadIdx.x >> 6);
+    if (ti >= W.n_ltasks) break;
     const PTask T = A.ltasks[W.ltask_off + ti];
     if (T.nl > 1) {
       const bool has = lane < T.ne;
