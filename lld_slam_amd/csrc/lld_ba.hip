@@ -167,7 +167,7 @@ int lld_ba_batch_create(lld_ctx* ctx, int n_windows, const lld_ba_window* wins, 
       }
       B->h_ltasks.push_back(T);
     }
-    W.n_ltasks = (int)B->h_ltasks.size() - W.ltask_off; W.nt_ln = (W.n_ltasks + 4 * kBsRounds - 1) / (4 * kBsRounds); W.nl_ln = (W.n_ltasks + kLinRounds * kLinThreads / 64 - 1) / (kLinRounds * kLinThreads / 64);
+    W.n_ltasks = (int)B->h_ltasks.size() - W.ltask_off; W.nt_ln = (W.n_ltasks + 4 * kBsRoundsLn - 1) / (4 * kBsRoundsLn); W.nl_ln = (W.n_ltasks + kLinRoundsLn * kLinThreads / 64 - 1) / (kLinRoundsLn * kLinThreads / 64);
     W.hpart_off = (long long)n_hpart; n_hpart += (size_t)(W.nl_pt + W.nl_ln) * w.n_free_cams * 27;
     W.part_off = (int)NPART;
     W.its[0] = P.its_round1; W.its[1] = P.its_round2; W.max_trials = P.max_trials; W.ln_filter = P.ln_filter;

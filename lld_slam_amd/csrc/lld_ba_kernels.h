@@ -36,6 +36,7 @@ constexpr int kPcgThreads = 1024;
 constexpr int kCtlThreads = 64;
 constexpr int kLinThreads = 512;        // linearise kernels: 8 tasks per workgroup (fewer per-workgroup Hpp partials to reduce)
 constexpr int kBsRounds = 4;           // same for the back-substitution workgroups (they stage both pose sets and x_p in LDS)
+constexpr int kLinRoundsLn = 2, kBsRoundsLn = 1;   // line observations are 6x fewer: more rounds would leave too few workgroups per window
 constexpr int kLinRounds = 8;          // tasks per wavefront of a linearise workgroup: amortises zeroing / flushing the LDS accumulators and
                                        // divides the number of per-workgroup Hpp partials (and ba_hpp_reduce's work) by the same factor
 constexpr int kAccCopies = 4;          // LDS copies of the per-camera Hpp/bp accumulators: lanes of one wavefront that hit the
@@ -740,8 +741,8 @@ __global__ __launch_bounds__(kLinThreads) void ba_linearize_ln_kernel(BAArrays A
   const int cur = S.cur;
   const int lane = threadIdx.x & 63;
   double chi = 0.0, maxd = 0.0;
-  for (int rnd = 0; rnd < kLinRounds; rnd++) {
-    const int ti = (blockIdx.x * kLinRounds + rnd) * (kLinThreads / 64) + (threadIdx.x >> 6);
+  for (int rnd = 0; rnd < kLinRoundsLn; rnd++) {
+    const int ti = (blockIdx.x * kLinRoundsLn + rnd) * (kLinThreads / 64) + (threadIdx.x >> 6);
     if (ti >= W.n_ltasks) break;
     const PTask T = A.ltasks[W.ltask_off + ti];
     double hb[14];
@@ -851,8 +852,8 @@ __global__ __launch_bounds__(kLmThreads) void ba_backsub_ln_kernel(BAArrays A, c
   const double* xp = A.xp + W.x_off;
   const int lane = threadIdx.x & 63;
   double chi = 0.0, sc = 0.0;
-  for (int rnd = 0; rnd < kBsRounds; rnd++) {
-    const int ti = (blockIdx.x * kBsRounds + rnd) * 4 + (threadIdx.x >> 6);
+  for (int rnd = 0; rnd < kBsRoundsLn; rnd++) {
+    const int ti = (blockIdx.x * kBsRoundsLn + rnd) * 4 + (threadIdx.x >> 6);
     if (ti >= W.n_ltasks) break;
     const PTask T = A.ltasks[W.ltask_off + ti];
     if (T.nl > 1) {
