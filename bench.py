@@ -59,6 +59,21 @@ def algorithmic_bytes(w, n_trials, n_iters, pcg_iters):
     }
 
 
+def schur_fmas(w, n_trials):
+    """fp64 FMAs of the Schur family for ONE window over a whole solve (the arithmetic that actually bounds it): per landmark with k
+    free-camera observations, k x (rebuild the 6xD Hpl block ~150 for a point / 0 for a line whose block is stored, Y = W Dinv 6*D*D)
+    + one D x D inverse (~40 / ~90) + k(k+1)/2 block products of 6*6*D."""
+    import numpy as np
+    nf = w.n_free_cams
+    kp = np.add.reduceat((w.pt_obs_cam < nf).astype(np.int64), w.pt_obs_start[:-1]) if w.n_points else np.zeros(0, np.int64)
+    kp = np.where(np.diff(w.pt_obs_start) > 0, kp, 0)
+    kl = np.add.reduceat((w.ln_obs_cam < nf).astype(np.int64), w.ln_obs_start[:-1]) if w.n_lines else np.zeros(0, np.int64)
+    kl = np.where(np.diff(w.ln_obs_start) > 0, kl, 0)
+    pts = np.sum(kp * (150 + 54) + 40 * (kp > 0) + kp * (kp + 1) // 2 * 108)
+    lns = np.sum(kl * 96 + 90 * (kl > 0) + kl * (kl + 1) // 2 * 144)
+    return int(n_trials * (pts + lns))
+
+
 def _make(wid):
     from lld_slam_amd import synth
     return synth.make_lba_b(wid)
@@ -189,12 +204,16 @@ def main():
                 traffic = json.load(open(tpath)).get(kname)
             except Exception:
                 traffic = None
+        fma_total = sum(schur_fmas(w, sum(st_["lm_trials"])) for w, st_ in zip(windows, stats)) if kname == "ba_schur" else None
         roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "measured_copy_ceiling_GBps": stream_gbs,
                     "launches_per_step": dom_launches, "avg_launch_ms": round(dom_ms / max(dom_launches, 1), 4),
                     "algorithmic_bytes_per_launch": int(per[kname] / max(dom_launches, 1)),
                     "phase_ms_single_stream_step": {k: round(phase[i] / prof_steps, 3) for i, k in enumerate(PHASES)},
                     "solve_ms_single_stream_step": round(phase[5] / prof_steps, 3)}
+        if fma_total is not None and dom_ms > 0:      # the arithmetic roofline that actually binds this family (fp64 vector FMA, 39.3 T FMA/s)
+            tf = fma_total / (dom_ms * 1e-3) / 1e12
+            roofline["fp64_fma"] = {"achieved_TFMA_per_s": round(tf, 2), "peak_TFMA_per_s": 39.3, "frac": round(tf / 39.3, 4)}
         # ---- CPU baseline + matched-chi2 check on a bounded sample (N=1 only)
         cpu = None; parity = None
         if world == 1 and not args.no_cpu_baseline and args.cpu_sample > 0:
