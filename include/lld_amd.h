@@ -460,6 +460,14 @@ typedef struct {
 } lld_last_frame_points;
 int lld_orb_search_last_frame(lld_ctx* ctx, const lld_orb_search* frame, const lld_frame_view* view, const lld_last_frame_points* last,
                               int direction, float th, int check_orientation, float* proj_uvr_or_null, lld_orb_search_result* out);
+/* ORBmatcher::Fuse(KeyFrame*, vpMapPoints, th) (src/ORBmatcher.cc:825-958; the loop of LocalMapping::SearchInNeighbors) with the
+ * projection loop (:841-890) on the device: cv::gemm transform, z >= 0, invz = 1/z, u = fx*(x*invz)+cx, KeyFrame::IsInImage
+ * (upper bounds strict, src/KeyFrame.cc:633-636), ur = u - bf*invz, scale-invariance band, PO.dot(Pn) >= 0.5*dist3D, PredictScale;
+ * then the window search with the level and reprojection-chi2 gates and `bestDist <= TH_LOW`.  `points`: as for
+ * lld_orb_search_local_points; skip[i] = !pMP || isBad || IsInKeyFrame(pKF); has_obs is ignored (no occupancy in Fuse).
+ * out->match[i] = bestIdx or -1, out->n_matches = nFused; the replace / add bookkeeping (:936-954) stays with the caller. */
+int lld_orb_fuse_search(lld_ctx* ctx, const lld_orb_search* keyframe, const lld_frame_view* view, const lld_map_points* points,
+                        float th, float* proj_uvr_or_null, lld_orb_search_result* out);
 /* `n` independent problems (e.g. one relocalisation / loop candidate keyframe each, or the searches of several frames) in one
  * launch: one workgroup per problem, all inputs moved in one host-to-device copy and all outputs in one copy back. */
 int lld_orb_search_batch(lld_ctx* ctx, int n, const lld_orb_search* problems, lld_orb_search_result* outs);

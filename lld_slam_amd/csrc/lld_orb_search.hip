@@ -445,6 +445,56 @@ __global__ __launch_bounds__(256) void project_last_frame_kernel(LastFrameArgs F
   if (F.uvr) { F.uvr[3 * i] = u; F.uvr[3 * i + 1] = v; F.uvr[3 * i + 2] = ur; }
 }
 
+// Projection loop of ORBmatcher::Fuse(KeyFrame*, vpMapPoints, th) (src/ORBmatcher.cc:841-890), one lane per MapPoint.
+struct FuseArgs {
+  lld_frame_view V;
+  int n;
+  const float* pos; const float* nrm; const float* maxd; const float* mind; const uint8_t* skip;
+  float scale[LLD_ORB_MAX_LEVELS];
+  float th;
+  QRec* q; float* uvr;
+};
+
+__global__ __launch_bounds__(256) void project_fuse_kernel(FuseArgs F) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= F.n) return;
+  QRec Q; memset(&Q, 0, sizeof(Q));
+  Q.level_min = -1; Q.level_max = -1;
+  float u = 0.f, v = 0.f, ur = 0.f;
+  do {
+    if (F.skip && F.skip[i]) break;
+    const float P[3] = {F.pos[3 * i], F.pos[3 * i + 1], F.pos[3 * i + 2]};
+    float Pc[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+      Pc[r] = (float)__dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn((double)F.V.Rcw[3 * r], (double)P[0]), __dmul_rn((double)F.V.Rcw[3 * r + 1], (double)P[1])),
+                                         __dmul_rn((double)F.V.Rcw[3 * r + 2], (double)P[2])), (double)F.V.tcw[r]);
+    if (Pc[2] < 0.0f) break;
+    const float invz = __fdiv_rn(1.0f, Pc[2]);
+    const float x = __fmul_rn(Pc[0], invz), y = __fmul_rn(Pc[1], invz);
+    u = __fadd_rn(__fmul_rn(F.V.fx, x), F.V.cx);
+    v = __fadd_rn(__fmul_rn(F.V.fy, y), F.V.cy);
+    if (!(u >= F.V.min_x && u < F.V.max_x && v >= F.V.min_y && v < F.V.max_y)) break;      // KeyFrame::IsInImage
+    ur = __fsub_rn(u, __fmul_rn(F.V.bf, invz));
+    const float maxDistance = __fmul_rn(1.2f, F.maxd[i]), minDistance = __fmul_rn(0.8f, F.mind[i]);
+    const float PO[3] = {__fsub_rn(P[0], F.V.Ow[0]), __fsub_rn(P[1], F.V.Ow[1]), __fsub_rn(P[2], F.V.Ow[2])};
+    const double n2 = __dadd_rn(__dadd_rn(__dmul_rn((double)PO[0], (double)PO[0]), __dmul_rn((double)PO[1], (double)PO[1])), __dmul_rn((double)PO[2], (double)PO[2]));
+    const float dist3D = (float)__dsqrt_rn(n2);
+    if (dist3D < minDistance || dist3D > maxDistance) break;
+    const double dotv = __dadd_rn(__dadd_rn(__dmul_rn((double)PO[0], (double)F.nrm[3 * i]), __dmul_rn((double)PO[1], (double)F.nrm[3 * i + 1])),
+                                  __dmul_rn((double)PO[2], (double)F.nrm[3 * i + 2]));
+    if (dotv < __dmul_rn(0.5, (double)dist3D)) break;                                       // PO.dot(Pn)<0.5*dist3D
+    const float ratio = __fdiv_rn(F.maxd[i], dist3D);
+    int lvl = (int)ceilf(__fdiv_rn(logf(ratio), F.V.log_scale_factor));
+    if (lvl < 0) lvl = 0; else if (lvl >= F.V.n_levels) lvl = F.V.n_levels - 1;
+    Q.u = u; Q.v = v; Q.ur = ur; Q.radius = __fmul_rn(F.th, F.scale[lvl]);
+    Q.level_min = lvl - 1; Q.level_max = lvl;
+    Q.flags = 1;
+  } while (false);
+  F.q[i] = Q;
+  if (F.uvr) { F.uvr[3 * i] = u; F.uvr[3 * i + 1] = v; F.uvr[3 * i + 2] = ur; }
+}
+
 constexpr size_t kLdsLimit = 160 * 1024 - 512;
 constexpr int kRowBuckets = 1024;          // ROWS mode: one bucket per image row, rows beyond are clamped into the last bucket
 
@@ -789,6 +839,47 @@ extern "C" int lld_orb_search_last_frame(lld_ctx* ctx, const lld_orb_search* fra
     F.th = th;
     F.q = reinterpret_cast<QRec*>(S.d + S.o_q); F.uvr = reinterpret_cast<float*>(S.d_out + r_uvr);
     hipLaunchKernelGGL(project_last_frame_kernel, dim3((nq + 255) / 256), dim3(256), 0, ctx->stream, F);
+    LLD_HIP_TRY(hipGetLastError());
+  }
+  st = S.search_and_fetch(out); if (st) return st;
+  if (nq && proj_uvr) std::memcpy(proj_uvr, S.h_out + r_uvr, (size_t)nq * 12);
+  return LLD_OK;
+}
+
+extern "C" int lld_orb_fuse_search(lld_ctx* ctx, const lld_orb_search* keyframe, const lld_frame_view* view, const lld_map_points* mp, float th,
+                                   float* proj_uvr, lld_orb_search_result* out) {
+  if (!ctx || !keyframe || !view || !mp || !out) return LLD_ERR_INVALID;
+  ProjSearch S{ctx, keyframe, keyframe->nt, mp->n, false};
+  int st = S.check(out); if (st) return st;
+  const int nq = S.nq;
+  if (nq > 0 && (!mp->world_pos || !mp->normal || !mp->max_distance || !mp->min_distance || !mp->desc)) return LLD_ERR_INVALID;
+  if (view->n_levels != keyframe->n_levels || !keyframe->level_inv_sigma2) return LLD_ERR_INVALID;
+  out->n_matches = 0; out->rounds = 0;
+  LLD_HIP_TRY(hipSetDevice(ctx->device));
+  S.layout();
+  const size_t o_pos = S.add_in((size_t)nq * 12), o_nrm = S.add_in((size_t)nq * 12), o_maxd = S.add_in((size_t)nq * 4), o_mind = S.add_in((size_t)nq * 4);
+  const size_t o_skip = mp->skip ? S.add_in((size_t)nq) : 0;
+  const size_t r_uvr = S.add_out((size_t)nq * 12);
+  st = S.alloc(); if (st) return st;
+  if (nq) {
+    std::memcpy(S.h + o_pos, mp->world_pos, (size_t)nq * 12); std::memcpy(S.h + o_nrm, mp->normal, (size_t)nq * 12);
+    std::memcpy(S.h + o_maxd, mp->max_distance, (size_t)nq * 4); std::memcpy(S.h + o_mind, mp->min_distance, (size_t)nq * 4);
+    if (mp->skip) std::memcpy(S.h + o_skip, mp->skip, (size_t)nq);
+  }
+  Problem& P = S.pack(mp->desc, out->owner != nullptr);
+  for (int l = 0; l < keyframe->n_levels; l++) P.inv_sigma2[l] = keyframe->level_inv_sigma2[l];
+  P.gates = LLD_ORB_GATE_LEVEL | LLD_ORB_GATE_CHI2; P.accept_max = 50;          // TH_LOW, src/ORBmatcher.cc:38,934
+  st = S.upload(); if (st) return st;
+  if (nq) {
+    FuseArgs F; std::memset(&F, 0, sizeof(F));
+    F.V = *view; F.n = nq;
+    F.pos = reinterpret_cast<const float*>(S.d + o_pos); F.nrm = reinterpret_cast<const float*>(S.d + o_nrm);
+    F.maxd = reinterpret_cast<const float*>(S.d + o_maxd); F.mind = reinterpret_cast<const float*>(S.d + o_mind);
+    F.skip = mp->skip ? reinterpret_cast<const uint8_t*>(S.d + o_skip) : nullptr;
+    for (int l = 0; l < LLD_ORB_MAX_LEVELS; l++) F.scale[l] = P.scale[l];
+    F.th = th;
+    F.q = reinterpret_cast<QRec*>(S.d + S.o_q); F.uvr = reinterpret_cast<float*>(S.d_out + r_uvr);
+    hipLaunchKernelGGL(project_fuse_kernel, dim3((nq + 255) / 256), dim3(256), 0, ctx->stream, F);
     LLD_HIP_TRY(hipGetLastError());
   }
   st = S.search_and_fetch(out); if (st) return st;

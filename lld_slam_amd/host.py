@@ -516,6 +516,11 @@ class ORBmatcher:
         from . import orb_search as S
         return S.fuse_search(self.lib, self.ctx.handle, KF, desc, valid, uv, ur, pred_level, th)
 
+    def FusePoints(self, KF, view, map_points: dict, th=3.0):
+        """Fuse(KeyFrame*, vpMapPoints, th) with the projection loop on the device as well (src/ORBmatcher.cc:825-958)."""
+        from . import orb_search as S
+        return S.fuse_search_points(self.lib, self.ctx.handle, KF, view, map_points, th)
+
     def SearchBySim3(self, KF1, KF2, q1, q2, th=7.5):
         """SearchBySim3 (src/ORBmatcher.cc:1102-1326)."""
         from . import orb_search as S

@@ -462,3 +462,24 @@ def search_last_frame(lib, ctx, Cur: Frame, view: FrameView, last: dict, cur_occ
         raise RuntimeError(f"lld_orb_search_last_frame failed: {lib.fn('status_string')(st).decode()}")
     out.n_matches, out.rounds = r.n_matches, r.rounds
     return out, uvr
+
+
+def fuse_search_points(lib, ctx, KF: Frame, view: FrameView, mp: dict, th=3.0):
+    """ORBmatcher::Fuse(KeyFrame*, vpMapPoints, th) (src/ORBmatcher.cc:825-958) with the projection loop on the device too.
+    Returns (SearchOutput, proj_uvr [n,3]); match[i] = bestIdx or -1, n_matches = nFused."""
+    p = prepare(KF, np.zeros((0, 8), np.uint32), candidates=CAND_GRID, accept_max=TH_LOW)
+    m, keep = map_points_struct(mp)
+    n, nt = m.n, KF.n
+    out = SearchOutput(np.empty(n, np.int32), np.empty(n, np.int32), np.empty(n, np.int32), np.empty(n, np.uint8), np.empty(nt, np.int32), 0, 0)
+    r = OrbSearchResult()
+    r.match = _p(out.match, c_int32_p); r.best_dist = _p(out.best_dist, c_int32_p); r.second_dist = _p(out.second_dist, c_int32_p)
+    r.removed = _p(out.removed, c_uint8_p); r.owner = _p(out.owner, c_int32_p)
+    uvr = np.zeros((n, 3), np.float32)
+    fn = lib.fn("orb_fuse_search")
+    fn.argtypes = [C.c_void_p, C.POINTER(OrbSearch), C.POINTER(FrameView), C.POINTER(MapPoints), C.c_float, c_float_p, C.POINTER(OrbSearchResult)]
+    fn.restype = C.c_int
+    st = fn(ctx, C.byref(p.s), C.byref(view), C.byref(m), float(np.float32(th)), _p(uvr, c_float_p), C.byref(r))
+    if st != abi.LLD_OK:
+        raise RuntimeError(f"lld_orb_fuse_search failed: {lib.fn('status_string')(st).decode()}")
+    out.n_matches, out.rounds = r.n_matches, r.rounds
+    return out, uvr

@@ -579,4 +579,38 @@ void lldo_project_last_frame(const lld_frame_view* V, const lld_last_frame_point
   }
 }
 
+// Projection loop of ORBmatcher::Fuse(KeyFrame*, vpMapPoints, th) (src/ORBmatcher.cc:841-890): valid_out, uv, ur, predicted level.
+void lldo_project_fuse(const lld_frame_view* V, const lld_map_points* mp, uint8_t* valid_out, float* uv, float* ur_out, int32_t* level) {
+  for (int i = 0; i < mp->n; i++) {
+    valid_out[i] = 0; uv[2 * i] = uv[2 * i + 1] = 0.f; ur_out[i] = 0.f; level[i] = 0;
+    if (mp->skip && mp->skip[i]) continue;
+    const float* P = mp->world_pos + 3 * i;
+    float p3Dc[3];
+    for (int r = 0; r < 3; r++) {
+      double s0 = 0.0;
+      for (int k = 0; k < 3; k++) s0 += (double)V->Rcw[3 * r + k] * (double)P[k];
+      p3Dc[r] = (float)(s0 + (double)V->tcw[r]);
+    }
+    if (p3Dc[2] < 0.0f) continue;
+    const float invz = 1 / p3Dc[2];
+    const float x = p3Dc[0] * invz;
+    const float y = p3Dc[1] * invz;
+    const float u = V->fx * x + V->cx;
+    const float v = V->fy * y + V->cy;
+    if (!(u >= V->min_x && u < V->max_x && v >= V->min_y && v < V->max_y)) continue;      // KeyFrame::IsInImage
+    const float ur = u - V->bf * invz;
+    const float maxDistance = 1.2f * mp->max_distance[i], minDistance = 0.8f * mp->min_distance[i];
+    const float PO[3] = {P[0] - V->Ow[0], P[1] - V->Ow[1], P[2] - V->Ow[2]};
+    double n2 = 0.0; for (int k = 0; k < 3; k++) n2 += (double)PO[k] * (double)PO[k];
+    const float dist3D = (float)std::sqrt(n2);
+    if (dist3D < minDistance || dist3D > maxDistance) continue;
+    double dotv = 0.0; for (int k = 0; k < 3; k++) dotv += (double)PO[k] * (double)mp->normal[3 * i + k];
+    if (dotv < 0.5 * dist3D) continue;
+    const float ratio = mp->max_distance[i] / dist3D;
+    int nScale = (int)std::ceil(std::log(ratio) / V->log_scale_factor);
+    if (nScale < 0) nScale = 0; else if (nScale >= V->n_levels) nScale = V->n_levels - 1;
+    valid_out[i] = 1; uv[2 * i] = u; uv[2 * i + 1] = v; ur_out[i] = ur; level[i] = nScale;
+  }
+}
+
 }  // extern "C"

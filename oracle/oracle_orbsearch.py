@@ -206,3 +206,16 @@ def project_last_frame(view, last: dict):
     valid = np.zeros(n, np.uint8); uv = np.zeros((n, 2), np.float32); ur = np.zeros(n, np.float32)
     d.lldo_project_last_frame(C.byref(view), C.byref(m), _p(valid, c_uint8_p), _p(uv, c_float_p), _p(ur, c_float_p))
     return valid, uv, ur
+
+
+def project_fuse(view, mp: dict):
+    """Projection loop of Fuse(KeyFrame*, vpMapPoints, th): (valid, uv [n,2], ur [n], level [n])."""
+    from lld_slam_amd.orb_search import FrameView, MapPoints, map_points_struct
+    d = _dll()
+    d.lldo_project_fuse.argtypes = [C.POINTER(FrameView), C.POINTER(MapPoints), c_uint8_p, c_float_p, c_float_p, c_int32_p]
+    d.lldo_project_fuse.restype = None
+    m, keep = map_points_struct(mp)
+    n = m.n
+    valid = np.zeros(n, np.uint8); uv = np.zeros((n, 2), np.float32); ur = np.zeros(n, np.float32); lvl = np.zeros(n, np.int32)
+    d.lldo_project_fuse(C.byref(view), C.byref(m), _p(valid, c_uint8_p), _p(uv, c_float_p), _p(ur, c_float_p), _p(lvl, c_int32_p))
+    return valid, uv, ur, lvl

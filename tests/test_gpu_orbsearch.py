@@ -272,3 +272,20 @@ def test_search_last_frame_projection_and_search_on_device(gpu_ctx, seed, direct
                                                 direction, th, True)
     assert out.n_matches == n_exp and n_exp > 100
     np.testing.assert_array_equal(expect_slots(out, mp["occupied"]), slot)
+
+
+@pytest.mark.parametrize("seed,th", [(0, 3.0), (1, 4.0)])
+def test_fuse_projection_and_search_on_device(gpu_ctx, seed, th):
+    """LocalMapping::SearchInNeighbors' matcher: Fuse's projection loop (IsInImage with strict upper bounds, 60-degree viewing
+    test, PredictScale) on the device, then the window search with the reprojection-chi2 gate."""
+    KF = synth.make_orb_frame(150 + seed, 2000)
+    T, mp = synth.make_local_map(KF, 150 + seed, 2500)
+    view = orb_search.frame_view(T, synth.KITTI_CAM, KF)
+    out, uvr = orb_search.fuse_search_points(gpu_ctx.lib, gpu_ctx.handle, KF, view, mp, th)
+    valid, uv, ur, lvl = OS.project_fuse(view, mp)
+    m = valid != 0
+    assert 800 < m.sum() < 2400
+    np.testing.assert_array_equal(uvr[m, :2], uv[m]); np.testing.assert_array_equal(uvr[m, 2], ur[m])
+    n_exp, best = OS.fuse_search(KF, mp["desc"], valid, uv, ur, lvl, th)
+    assert out.n_matches == n_exp and n_exp > 100
+    np.testing.assert_array_equal(out.match, best)
