@@ -334,6 +334,27 @@ __global__ __launch_bounds__(kThreads) void orb_search_kernel(const Problem* __r
   if (tid == 0) { P.summary[0] = ctl[1] - ctl[2]; P.summary[1] = rounds; }
 }
 
+// ---- the reference's OpenCV calls on float data, as this build restates them (see include/lld_amd.h) --------------------------
+// `R*P + t` is ONE cv::gemm: double accumulation in k order, one rounding to float
+__device__ __forceinline__ void cv_transform(const lld_frame_view& V, const float* P, float* Pc) {
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+    Pc[r] = (float)__dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn((double)V.Rcw[3 * r], (double)P[0]), __dmul_rn((double)V.Rcw[3 * r + 1], (double)P[1])),
+                                       __dmul_rn((double)V.Rcw[3 * r + 2], (double)P[2])), (double)V.tcw[r]);
+}
+// cv::norm(a) and a.dot(b) of CV_32F vectors accumulate in double
+__device__ __forceinline__ double cv_dot3(const float* a, const float* b) {
+  return __dadd_rn(__dadd_rn(__dmul_rn((double)a[0], (double)b[0]), __dmul_rn((double)a[1], (double)b[1])), __dmul_rn((double)a[2], (double)b[2]));
+}
+__device__ __forceinline__ float cv_norm3(const float* a) { return (float)__dsqrt_rn(cv_dot3(a, a)); }
+// MapPoint::PredictScale (src/MapPoint.cc:402-417): float log, float division, ceil, clamp
+__device__ __forceinline__ int predict_scale(float max_distance, float dist, const lld_frame_view& V) {
+  const float ratio = __fdiv_rn(max_distance, dist);
+  int n = (int)ceilf(__fdiv_rn(logf(ratio), V.log_scale_factor));
+  if (n < 0) n = 0; else if (n >= V.n_levels) n = V.n_levels - 1;
+  return n;
+}
+
 // Frame::isInFrustum (src/Frame.cc:333-389) for one MapPoint per lane, written straight into the query record of the search
 // kernel.  Float / double mixture as the reference's OpenCV calls (see include/lld_amd.h); every float operation is an explicit
 // round-to-nearest intrinsic, so nothing is contracted into an FMA.
@@ -357,11 +378,7 @@ __global__ __launch_bounds__(256) void frustum_kernel(FrustumArgs F) {
   do {
     if (!ok) break;
     const float P[3] = {F.pos[3 * i], F.pos[3 * i + 1], F.pos[3 * i + 2]};
-    float Pc[3];
-#pragma unroll
-    for (int r = 0; r < 3; r++)                                                  // cv::gemm: double accumulation, one rounding
-      Pc[r] = (float)__dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn((double)F.V.Rcw[3 * r], (double)P[0]), __dmul_rn((double)F.V.Rcw[3 * r + 1], (double)P[1])),
-                                         __dmul_rn((double)F.V.Rcw[3 * r + 2], (double)P[2])), (double)F.V.tcw[r]);
+    float Pc[3]; cv_transform(F.V, P, Pc);
     ok = false;
     if (Pc[2] < 0.0f) break;
     const float invz = __fdiv_rn(1.0f, Pc[2]);
@@ -371,16 +388,11 @@ __global__ __launch_bounds__(256) void frustum_kernel(FrustumArgs F) {
     if (v < F.V.min_y || v > F.V.max_y) break;
     const float maxDistance = __fmul_rn(1.2f, F.maxd[i]), minDistance = __fmul_rn(0.8f, F.mind[i]);
     const float PO[3] = {__fsub_rn(P[0], F.V.Ow[0]), __fsub_rn(P[1], F.V.Ow[1]), __fsub_rn(P[2], F.V.Ow[2])};
-    const double n2 = __dadd_rn(__dadd_rn(__dmul_rn((double)PO[0], (double)PO[0]), __dmul_rn((double)PO[1], (double)PO[1])), __dmul_rn((double)PO[2], (double)PO[2]));
-    const float dist = (float)__dsqrt_rn(n2);                                    // cv::norm
+    const float dist = cv_norm3(PO);
     if (dist < minDistance || dist > maxDistance) break;
-    const double dotv = __dadd_rn(__dadd_rn(__dmul_rn((double)PO[0], (double)F.nrm[3 * i]), __dmul_rn((double)PO[1], (double)F.nrm[3 * i + 1])),
-                                  __dmul_rn((double)PO[2], (double)F.nrm[3 * i + 2]));
-    vc = (float)__ddiv_rn(dotv, (double)dist);                                   // PO.dot(Pn)/dist
+    vc = (float)__ddiv_rn(cv_dot3(PO, F.nrm + 3 * i), (double)dist);             // PO.dot(Pn)/dist
     if (vc < F.cos_limit) break;
-    const float ratio = __fdiv_rn(F.maxd[i], dist);                              // MapPoint::PredictScale
-    lvl = (int)ceilf(__fdiv_rn(logf(ratio), F.V.log_scale_factor));
-    if (lvl < 0) lvl = 0; else if (lvl >= F.V.n_levels) lvl = F.V.n_levels - 1;
+    lvl = predict_scale(F.maxd[i], dist, F.V);
     ur = __fsub_rn(u, __fmul_rn(F.V.bf, invz));
     ok = true;
   } while (false);
@@ -420,11 +432,7 @@ __global__ __launch_bounds__(256) void project_last_frame_kernel(LastFrameArgs F
   float u = 0.f, v = 0.f, ur = 0.f;
   if (F.valid[i]) {
     const float P[3] = {F.pos[3 * i], F.pos[3 * i + 1], F.pos[3 * i + 2]};
-    float Pc[3];
-#pragma unroll
-    for (int r = 0; r < 3; r++)                                                  // x3Dc = Rcw*x3Dw+tcw: one cv::gemm
-      Pc[r] = (float)__dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn((double)F.V.Rcw[3 * r], (double)P[0]), __dmul_rn((double)F.V.Rcw[3 * r + 1], (double)P[1])),
-                                         __dmul_rn((double)F.V.Rcw[3 * r + 2], (double)P[2])), (double)F.V.tcw[r]);
+    float Pc[3]; cv_transform(F.V, P, Pc);                                       // x3Dc = Rcw*x3Dw+tcw
     const float invzc = (float)__ddiv_rn(1.0, (double)Pc[2]);                   // const float invzc = 1.0/x3Dc.at<float>(2);
     if (!(invzc < 0.f)) {
       u = __fadd_rn(__fmul_rn(__fmul_rn(F.V.fx, Pc[0]), invzc), F.V.cx);
@@ -464,11 +472,7 @@ __global__ __launch_bounds__(256) void project_fuse_kernel(FuseArgs F) {
   do {
     if (F.skip && F.skip[i]) break;
     const float P[3] = {F.pos[3 * i], F.pos[3 * i + 1], F.pos[3 * i + 2]};
-    float Pc[3];
-#pragma unroll
-    for (int r = 0; r < 3; r++)
-      Pc[r] = (float)__dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn((double)F.V.Rcw[3 * r], (double)P[0]), __dmul_rn((double)F.V.Rcw[3 * r + 1], (double)P[1])),
-                                         __dmul_rn((double)F.V.Rcw[3 * r + 2], (double)P[2])), (double)F.V.tcw[r]);
+    float Pc[3]; cv_transform(F.V, P, Pc);
     if (Pc[2] < 0.0f) break;
     const float invz = __fdiv_rn(1.0f, Pc[2]);
     const float x = __fmul_rn(Pc[0], invz), y = __fmul_rn(Pc[1], invz);
@@ -478,15 +482,10 @@ __global__ __launch_bounds__(256) void project_fuse_kernel(FuseArgs F) {
     ur = __fsub_rn(u, __fmul_rn(F.V.bf, invz));
     const float maxDistance = __fmul_rn(1.2f, F.maxd[i]), minDistance = __fmul_rn(0.8f, F.mind[i]);
     const float PO[3] = {__fsub_rn(P[0], F.V.Ow[0]), __fsub_rn(P[1], F.V.Ow[1]), __fsub_rn(P[2], F.V.Ow[2])};
-    const double n2 = __dadd_rn(__dadd_rn(__dmul_rn((double)PO[0], (double)PO[0]), __dmul_rn((double)PO[1], (double)PO[1])), __dmul_rn((double)PO[2], (double)PO[2]));
-    const float dist3D = (float)__dsqrt_rn(n2);
+    const float dist3D = cv_norm3(PO);
     if (dist3D < minDistance || dist3D > maxDistance) break;
-    const double dotv = __dadd_rn(__dadd_rn(__dmul_rn((double)PO[0], (double)F.nrm[3 * i]), __dmul_rn((double)PO[1], (double)F.nrm[3 * i + 1])),
-                                  __dmul_rn((double)PO[2], (double)F.nrm[3 * i + 2]));
-    if (dotv < __dmul_rn(0.5, (double)dist3D)) break;                                       // PO.dot(Pn)<0.5*dist3D
-    const float ratio = __fdiv_rn(F.maxd[i], dist3D);
-    int lvl = (int)ceilf(__fdiv_rn(logf(ratio), F.V.log_scale_factor));
-    if (lvl < 0) lvl = 0; else if (lvl >= F.V.n_levels) lvl = F.V.n_levels - 1;
+    if (cv_dot3(PO, F.nrm + 3 * i) < __dmul_rn(0.5, (double)dist3D)) break;                   // PO.dot(Pn)<0.5*dist3D
+    const int lvl = predict_scale(F.maxd[i], dist3D, F.V);
     Q.u = u; Q.v = v; Q.ur = ur; Q.radius = __fmul_rn(F.th, F.scale[lvl]);
     Q.level_min = lvl - 1; Q.level_max = lvl;
     Q.flags = 1;
