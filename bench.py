@@ -234,7 +234,12 @@ def main():
             cpu = {"value": round(ns / cpu_s, 4), "unit": "windows/s", "cores": 1, "kind": "port",
                    "sample": f"{ns} LBA-B windows (ids 0..{ns - 1}) through oracle/liblld_oracle.so, 1 thread, exact dense LDLT of the reduced system",
                    "all_cores": {"value": round(nthr / par_s, 4), "cores": nthr, "sample": f"{nthr} windows, one per thread, concurrently"}}
-            parity = {"windows_checked": ns, "max_rel_chi2_final": float(rel), "outlier_sets_identical": bool(same)}
+            gres = [batch.download(i) for i in range(ns)]
+            pose_err = max(float(np.max(np.abs(gres[i].cam_qt - ores[i].cam_qt)) / np.max(np.abs(ores[i].cam_qt))) for i in range(ns))
+            pt_err = [np.linalg.norm(gres[i].pt_xyz - ores[i].pt_xyz, axis=1) / np.linalg.norm(ores[i].pt_xyz, axis=1) for i in range(ns)]
+            parity = {"windows_checked": ns, "max_rel_chi2_final": float(rel), "outlier_sets_identical": bool(same),
+                      "max_rel_pose": pose_err, "median_rel_point": float(np.median(np.concatenate(pt_err))),
+                      "points_within_1e-5": float(np.mean(np.concatenate(pt_err) <= 1e-5))}
         result = {
             "metric": METRIC, "value": round(value, 3), "unit": "windows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
