@@ -1189,19 +1189,29 @@ __global__ __launch_bounds__(256) void ba_schur_reduce_kernel(BAArrays A, const 
     }
     const int* bst = A.blk_start + W.blk_csr_off;
     const int q0 = bst[blk], q1 = bst[blk + 1];
-    for (int q = q0; q < q1; q++) {
-      const int src = A.blk_src[q];
-      const double* P = A.sp_part + (size_t)(src >> 2) * 36;
-      const int mode = src & 3;
-      if (mode == 0) {
+    // A diagonal block collects one partial from every chunk that sees its camera (~50), and each list entry is a chain of two
+    // dependent loads (index -> partial): four entries are kept in flight and the three modes are folded into weights (row part
+    // w_r, column part w_c in {0,1}) so that the loads do not sit behind a branch.  0*x + y is exact and mode 2 keeps its
+    // P + P^T order, so the result is bit-identical to the entry-by-entry loop.
+    for (int q = q0; q < q1; q += 4) {
+      int src[4];
 #pragma unroll
-        for (int cc = 0; cc < 6; cc++) v[cc] -= P[cc * 6 + rr];
-      } else if (mode == 1) {
+      for (int uu = 0; uu < 4; uu++) src[uu] = (q + uu < q1) ? A.blk_src[q + uu] : -1;
+      double pr[4][6], pc[4][6];
 #pragma unroll
-        for (int cc = 0; cc < 6; cc++) v[cc] -= P[rr * 6 + cc];
-      } else {
+      for (int uu = 0; uu < 4; uu++) {
+        const double* P = A.sp_part + (size_t)((src[uu] < 0 ? 0 : src[uu]) >> 2) * 36;
 #pragma unroll
-        for (int cc = 0; cc < 6; cc++) v[cc] -= P[rr * 6 + cc] + P[cc * 6 + rr];
+        for (int cc = 0; cc < 6; cc++) { pr[uu][cc] = P[rr * 6 + cc]; pc[uu][cc] = P[cc * 6 + rr]; }
+      }
+#pragma unroll
+      for (int uu = 0; uu < 4; uu++) {
+        if (src[uu] >= 0) {
+          const int mode = src[uu] & 3;
+          const double wr = (mode != 0) ? 1.0 : 0.0, wc = (mode != 1) ? 1.0 : 0.0;
+#pragma unroll
+          for (int cc = 0; cc < 6; cc++) v[cc] -= wr * pr[uu][cc] + wc * pc[uu][cc];
+        }
       }
     }
     double* dst = A.S + W.S_off + (size_t)(6 * i + rr) * n + 6 * j;
@@ -1213,7 +1223,18 @@ __global__ __launch_bounds__(256) void ba_schur_reduce_kernel(BAArrays A, const 
     for (int t = threadIdx.x; t < n; t += 256) {
       const int c = t / 6, r = t - c * 6;
       double v = A.bp[(size_t)W.hpp_off * 6 + t];
-      for (int q = cst[c]; q < cst[c + 1]; q++) v -= A.sp_cpart[(size_t)A.cam_src[q] * 6 + r];
+      // a camera appears in ~50 chunks and every list entry is two dependent loads (index -> partial): eight entries are kept in
+      // flight; they are still subtracted one by one in list order, so the sum is bit-identical to the plain loop
+      const int q0 = cst[c], q1 = cst[c + 1];
+      for (int q = q0; q < q1; q += 8) {
+        int src[8]; double pv[8];
+#pragma unroll
+        for (int uu = 0; uu < 8; uu++) src[uu] = (q + uu < q1) ? A.cam_src[q + uu] : -1;
+#pragma unroll
+        for (int uu = 0; uu < 8; uu++) pv[uu] = (src[uu] >= 0) ? A.sp_cpart[(size_t)src[uu] * 6 + r] : 0.0;
+#pragma unroll
+        for (int uu = 0; uu < 8; uu++) if (src[uu] >= 0) v -= pv[uu];
+      }
       A.bschur[W.x_off + t] = v;
     }
   }
