@@ -1528,17 +1528,17 @@ __global__ __launch_bounds__(kPcgThreads) void ba_chol_kernel(BAArrays A, const 
 // grid (nW); block kCholMThreads (8 wavefronts); dynamic LDS kCholMLdsDoubles doubles.  For n = 6*n_free <= 304.
 // Right-looking Cholesky on 16x16 tiles with the WHOLE lower tile triangle held in registers for the entire factorisation
 // (<= 190 tiles, 28 per wavefront, 4 doubles per lane each): S is read from HBM exactly once, L never leaves the chip.
-// Wavefronts 1..7 own the tiles; wavefront 0 owns no tile and does the serial work, so its 16-double row buffers never compete
-// with the accumulator tiles for registers.  Per tile column J:
-//   (a) tile waves publish column J to LDS;
-//   (b) the panel wave factors the 16x16 diagonal tile right-looking with one lane per row — lane 16 carries the right-hand side
-//       and lanes 17..32 the identity as extra rows, which yields y_J and L_JJ^-1 from the same recurrence (v_readlane
-//       broadcasts, no LDS traffic inside the recurrence);
-//   (c) tile waves: L_IJ = A_IJ L_JJ^-T as four v_mfma_f64_16x16x4_f64 per tile, result kept in the registers (it is the L the
-//       back substitution needs) and written to LDS as the operand of (d);
+// Wavefronts 1..7 own the tiles; wavefront 0 (the panel wave) owns no tile and does the serial work, so its 16-double row
+// buffers never compete with the accumulator tiles for registers.  Per tile column J (two barriers):
+//   (c) tile waves: L_IJ = A_IJ L_JJ^-T as four v_mfma_f64_16x16x4_f64 per tile of column J, result kept in the registers (it is
+//       the L the back substitution needs) and written to the LDS panel buffer as the operand of (d);
 //   (d) tile waves: every tile (I,K), K > J, takes T -= L_IJ L_KJ^T on the matrix cores — operands are read once per 1024 FMAs
 //       instead of once per 1.5 as in the 6x6 register-blocked kernel above, whose trailing update is LDS-bandwidth bound;
-//       meanwhile the panel wave forward-substitutes the right-hand side below the tile.
+//       tiles of column J+1 are then final and go to the other panel buffer, the diagonal tile J+2 to its slot;
+//       LOOKAHEAD, same phase: the panel wave forward-substitutes the right-hand side, applies column J's update to the
+//       diagonal tile J+1 itself (four MFMAs on the published copy) and factors it right-looking with one lane per row — lane 16
+//       carries the right-hand side and lanes 17..32 the identity as extra rows, which yields y_{J+1} and L^-1 from the same
+//       recurrence (v_readlane broadcasts, no LDS traffic inside it).  The serial factorisation is off the critical path.
 // Tile element layout of v_mfma_f64_16x16x4_f64: C/D lane l, register g -> (row (l>>4) + 4g, col l&15); A[i][k] and B[k][j]
 // come from lane i + 16k resp. j + 16k.
 constexpr int kCholMThreads = 512;
@@ -1547,12 +1547,47 @@ constexpr int kCholMMaxTiles = 19;                                   // 19 * 16 
 constexpr int kCholMSlots = 28;                                      // ceil(190 / 7)
 constexpr int kCholMStride = 17;                                     // padded LDS row of 16 doubles
 constexpr int kCholMN = kCholMMaxTiles * 16;
-constexpr int kCholMLdsDoubles = kCholMN * kCholMStride + kCholMMaxTiles * 16 * kCholMStride + 16 * kCholMStride + 3 * kCholMN + 32;
+constexpr int kCholMLdsDoubles = 2 * kCholMN * kCholMStride + kCholMMaxTiles * 16 * kCholMStride + 16 * kCholMStride + 3 * kCholMN + 32;
 typedef double v4d __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ double readlane_f64(double v, int l) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
   return __hiloint2double(hi, lo);
+}
+
+// Panel wave: factor the 16x16 tile in Dg (lower triangle used) in place, L^-1 -> Li, 1/L_cc -> invd, rhs y[0..15] -> L^-1 y.
+__device__ __forceinline__ bool chol_tile_factor(double* Dg, double* Li, double* invd, double* y, int lane) {
+  const int r = lane < 32 ? lane : 32;                               // 0..15 tile rows, 16 rhs, 17..32 identity rows
+  double a[16];
+#pragma unroll
+  for (int c = 0; c < 16; c++) a[c] = (r < 16) ? Dg[r * kCholMStride + c] : (r == 16 ? y[c] : (r - 17 == c ? 1.0 : 0.0));
+  bool ok = true;
+#pragma unroll
+  for (int c = 0; c < 16; c++) {
+    const double d = readlane_f64(a[c], c);
+    if (!(d > 0.0) || !isfinite(d)) ok = false;
+    // 1/sqrt(d): v_rsq_f64 seed + two Newton steps (the library sqrt and divide are ~45 dependent instructions, which is what
+    // bounds this serial recurrence; the result is within an ulp or two, L L^T = S to rounding either way)
+    double inv = __builtin_amdgcn_rsq(d);
+    inv = inv * (1.5 - (0.5 * d) * (inv * inv));
+    inv = inv * (1.5 - (0.5 * d) * (inv * inv));
+    const double lc = a[c] * inv;                                    // lane c: sqrt(d); below: L[r][c]; rhs lane: y_c
+    a[c] = lc;
+    if (lane == 0) invd[c] = inv;
+#pragma unroll
+    for (int c2 = c + 1; c2 < 16; c2++) a[c2] -= lc * readlane_f64(lc, c2);   // A[r][c2] -= L[r][c] L[c2][c]
+  }
+  if (lane < 16) {
+#pragma unroll
+    for (int c = 0; c < 16; c++) Dg[r * kCholMStride + c] = (c <= r) ? a[c] : 0.0;
+  } else if (lane == 16) {
+#pragma unroll
+    for (int c = 0; c < 16; c++) y[c] = a[c];
+  } else if (lane <= 32) {                                           // lane 17+k holds column k of L^-1
+#pragma unroll
+    for (int c = 0; c < 16; c++) Li[c * kCholMStride + (lane - 17)] = a[c];
+  }
+  return ok;
 }
 
 __global__ __launch_bounds__(kCholMThreads) void ba_chol_mfma_kernel(BAArrays A, const BAWin* __restrict__ wins, BAState* __restrict__ st) {
@@ -1561,8 +1596,8 @@ __global__ __launch_bounds__(kCholMThreads) void ba_chol_mfma_kernel(BAArrays A,
   BAState& S = st[blockIdx.x];
   if (S.phase != PH_RUN) return;
   const int nf = W.n_free, n = 6 * nf, NT = (n + 15) >> 4, N = NT << 4;
-  double* Lp = lds;                                        // [N][17]   column J: raw tiles after (a), L after (c)
-  double* Dall = Lp + kCholMN * kCholMStride;              // [NT][16][17] factors of the diagonal tiles
+  double* Lp0 = lds;                                       // [2][N][17] panel buffers: column J in buffer J & 1 (raw, then L)
+  double* Dall = Lp0 + 2 * kCholMN * kCholMStride;         // [NT][16][17] diagonal tiles: raw until factored, then L_JJ
   double* Li = Dall + kCholMMaxTiles * 16 * kCholMStride;  // [16][17] inverse of the current diagonal factor
   double* invd = Li + 16 * kCholMStride;                   // [N] 1 / L_cc
   double* y = invd + kCholMN;                              // [N] right-hand side -> forward solution
@@ -1578,44 +1613,12 @@ __global__ __launch_bounds__(kCholMThreads) void ba_chol_mfma_kernel(BAArrays A,
 
   if (wave == 0) {
     // ================================================================ panel wave
-    __syncthreads();
+    __syncthreads();                                                   // tiles loaded, y staged
+    __syncthreads();                                                   // prologue publish done: column 0, diagonal tiles 0 and 1
+    if (NT > 0) { if (!chol_tile_factor(Dall, Li, invd, y, lane) && lane == 0) *okf = 0.0; }
+    __syncthreads();                                                   // diagonal tile 0 factored
     for (int J = 0; J < NT; J++) {
-      double* Dg = Dall + J * 16 * kCholMStride;
-      __syncthreads();                                                 // (a) done
-      {
-        const int r = lane < 32 ? lane : 32;                           // 0..15 tile rows, 16 rhs, 17..32 identity rows
-        double a[16];
-#pragma unroll
-        for (int c = 0; c < 16; c++) a[c] = (r < 16) ? Dg[r * kCholMStride + c] : (r == 16 ? y[16 * J + c] : (r - 17 == c ? 1.0 : 0.0));
-        bool ok = true;
-#pragma unroll
-        for (int c = 0; c < 16; c++) {
-          const double d = readlane_f64(a[c], c);
-          if (!(d > 0.0) || !isfinite(d)) ok = false;
-          // 1/sqrt(d): v_rsq_f64 seed + two Newton steps (the library sqrt and divide are ~45 dependent instructions,
-          // which is what bounds this serial recurrence; the result is within an ulp or two, L L^T = S to rounding either way)
-          double inv = __builtin_amdgcn_rsq(d);
-          inv = inv * (1.5 - (0.5 * d) * (inv * inv));
-          inv = inv * (1.5 - (0.5 * d) * (inv * inv));
-          const double lc = a[c] * inv;                                        // lane c: sqrt(d); below: L[r][c]; rhs lane: y_c
-          a[c] = lc;
-          if (lane == 0) invd[16 * J + c] = inv;
-#pragma unroll
-          for (int c2 = c + 1; c2 < 16; c2++) a[c2] -= lc * readlane_f64(lc, c2);   // A[r][c2] -= L[r][c] L[c2][c]
-        }
-        if (lane < 16) {
-#pragma unroll
-          for (int c = 0; c < 16; c++) Dg[r * kCholMStride + c] = (c <= r) ? a[c] : 0.0;
-        } else if (lane == 16) {
-#pragma unroll
-          for (int c = 0; c < 16; c++) y[16 * J + c] = a[c];
-        } else if (lane <= 32) {                                                // lane 17+k holds column k of L^-1
-#pragma unroll
-          for (int c = 0; c < 16; c++) Li[c * kCholMStride + (lane - 17)] = a[c];
-        }
-        if (!ok && lane == 0) *okf = 0.0;
-      }
-      __syncthreads();                                                 // (b) done
+      const double* Lp = Lp0 + (J & 1) * kCholMN * kCholMStride;
       __syncthreads();                                                 // (c) done: Lp holds L(:,J)
       for (int row = 16 * (J + 1) + lane; row < N; row += 64) {        // y_i -= l_i . y_J
         const double* pr = Lp + row * kCholMStride;
@@ -1624,7 +1627,20 @@ __global__ __launch_bounds__(kCholMThreads) void ba_chol_mfma_kernel(BAArrays A,
         for (int c = 0; c < 16; c++) dotv += pr[c] * y[16 * J + c];
         y[row] -= dotv;
       }
-      __syncthreads();                                                 // (d) done
+      if (J + 1 < NT) {
+        // lookahead: diagonal tile J+1 (published with the updates of columns < J) takes column J's update here, then is factored
+        double* Dg = Dall + (J + 1) * 16 * kCholMStride;
+        const double* pa = Lp + (16 * (J + 1) + lcol) * kCholMStride + lrow;
+        v4d c;
+#pragma unroll
+        for (int g = 0; g < 4; g++) c[g] = Dg[(lrow + 4 * g) * kCholMStride + lcol];
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) c = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[4 * kk], pa[4 * kk], c, 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < 4; g++) Dg[(lrow + 4 * g) * kCholMStride + lcol] = c[g];
+        if (!chol_tile_factor(Dg, Li, invd + 16 * (J + 1), y + 16 * (J + 1), lane) && lane == 0) *okf = 0.0;
+      }
+      __syncthreads();                                                 // (d) + lookahead done
     }
     for (int J = NT - 1; J >= 0; J--) {
       if (lane < 16) colsum[lane] = 0.0;
@@ -1679,24 +1695,30 @@ __global__ __launch_bounds__(kCholMThreads) void ba_chol_mfma_kernel(BAArrays A,
       __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
-    for (int J = 0; J < NT; J++) {
-      // Per-lane LDS offsets, made opaque once per iteration: otherwise the per-slot addresses are hoisted out of the J loop as
-      // loop invariants and push the accumulator tiles out of the register file.
-      int off_cd = lrow * kCholMStride + lcol, off_ab = lcol * kCholMStride + lrow;
-      asm volatile("" : "+v"(off_cd), "+v"(off_ab));
-      double* Dg = Dall + J * 16 * kCholMStride;
-      // (a) publish tile column J (raw)
+    {
+      // prologue publish: column 0 (raw) -> panel buffer 0, diagonal tiles 0 and 1 (raw) -> their slots
+      int off_cd = lrow * kCholMStride + lcol;
+      asm volatile("" : "+v"(off_cd));
 #pragma unroll
       for (int sl = 0; sl < kCholMSlots; sl++) {
-        if (tK[sl] == J) {
-          double* dst = ((tI[sl] == J) ? Dg : Lp + 16 * tI[sl] * kCholMStride) + off_cd;
+        const bool diag01 = tI[sl] == tK[sl] && (tI[sl] == 0 || tI[sl] == 1);
+        if (diag01 || (tK[sl] == 0 && tI[sl] > 0)) {
+          double* dst = (diag01 ? Dall + tI[sl] * 16 * kCholMStride : Lp0 + 16 * tI[sl] * kCholMStride) + off_cd;
 #pragma unroll
           for (int g = 0; g < 4; g++) dst[4 * g * kCholMStride] = acc[sl][g];
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-      __syncthreads();                                                 // (a) done
-      __syncthreads();                                                 // (b) done: Li = L_JJ^-1
+    }
+    __syncthreads();                                                   // prologue publish done
+    __syncthreads();                                                   // diagonal tile 0 factored: Li = L_00^-1
+    for (int J = 0; J < NT; J++) {
+      // Per-lane LDS offsets, made opaque once per iteration: otherwise the per-slot addresses are hoisted out of the J loop as
+      // loop invariants and push the accumulator tiles out of the register file.
+      int off_cd = lrow * kCholMStride + lcol, off_ab = lcol * kCholMStride + lrow;
+      asm volatile("" : "+v"(off_cd), "+v"(off_ab));
+      double* Lp = Lp0 + (J & 1) * kCholMN * kCholMStride;
+      double* Lnext = Lp0 + ((J + 1) & 1) * kCholMN * kCholMStride;
       // (c) L_IJ = A_IJ L_JJ^-T on the matrix cores; keep it (back substitution) and publish it (operand of d)
 #pragma unroll
       for (int sl = 0; sl < kCholMSlots; sl++) {
@@ -1714,20 +1736,27 @@ __global__ __launch_bounds__(kCholMThreads) void ba_chol_mfma_kernel(BAArrays A,
         __builtin_amdgcn_sched_barrier(0);
       }
       __syncthreads();                                                 // (c) done
-      // (d) trailing update
+      // (d) trailing update; column J+1 and the diagonal tile J+2 are final afterwards and are published for the next steps.
+      //     The diagonal tile J+1 is not touched: the panel wave finishes it from its published copy (lookahead).
 #pragma unroll
       for (int sl = 0; sl < kCholMSlots; sl++) {
-        if (tK[sl] > J) {
+        if (tK[sl] > J && !(tI[sl] == J + 1 && tK[sl] == J + 1)) {
           const double* pa = Lp + 16 * tI[sl] * kCholMStride + off_ab;
           const double* pb = Lp + 16 * tK[sl] * kCholMStride + off_ab;
           v4d c = acc[sl];
 #pragma unroll
           for (int kk = 0; kk < 4; kk++) c = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[4 * kk], pb[4 * kk], c, 0, 0, 0);
           acc[sl] = c;
+          const bool next_col = tK[sl] == J + 1, next_diag = tI[sl] == J + 2 && tK[sl] == J + 2;
+          if (next_col || next_diag) {
+            double* dst = (next_diag ? Dall + (J + 2) * 16 * kCholMStride : Lnext + 16 * tI[sl] * kCholMStride) + off_cd;
+#pragma unroll
+            for (int g = 0; g < 4; g++) dst[4 * g * kCholMStride] = c[g];
+          }
         }
         if (sl & 1) __builtin_amdgcn_sched_barrier(0);                 // let the loads of one tile overlap the MFMAs of its neighbour, not more
       }
-      __syncthreads();                                                 // (d) done
+      __syncthreads();                                                 // (d) + lookahead done
     }
     // back substitution L^T x = y: L lives in the register tiles, s_c = sum_{i below tile J} L[i][16J + c] x_i
     for (int J = NT - 1; J >= 0; J--) {
