@@ -155,7 +155,12 @@ int lld_ba_batch_create(lld_ctx* ctx, int n_windows, const lld_ba_window* wins, 
       }
       B->h_ptasks.push_back(T);
     }
-    W.n_ptasks = (int)B->h_ptasks.size() - W.ptask_off; W.nt_pt = (W.n_ptasks + 4 * kBsRounds - 1) / (4 * kBsRounds); W.nl_pt = (W.n_ptasks + kLinRounds * kLinThreads / 64 - 1) / (kLinRounds * kLinThreads / 64);
+    W.n_ptasks = (int)B->h_ptasks.size() - W.ptask_off;
+    {
+      const int* R = n_windows >= kRoundsThroughputMinWindows ? kRoundsThroughput : kRoundsLatency;
+      for (int i = 0; i < 4; i++) W.rounds[i] = R[i];
+    }
+    W.nt_pt = (W.n_ptasks + 4 * W.rounds[2] - 1) / (4 * W.rounds[2]); W.nl_pt = (W.n_ptasks + W.rounds[0] * kLinThreads / 64 - 1) / (W.rounds[0] * kLinThreads / 64);
     W.ltask_off = (int)B->h_ltasks.size();
     for (int l = 0; l < w.n_lines;) {                // line tasks: lane <-> (line, KF) observation
       PTask T; std::memset(&T, 0, sizeof T); T.l0 = l; T.e0 = (int)NLO + w.ln_obs_start[l];
@@ -167,7 +172,7 @@ int lld_ba_batch_create(lld_ctx* ctx, int n_windows, const lld_ba_window* wins, 
       }
       B->h_ltasks.push_back(T);
     }
-    W.n_ltasks = (int)B->h_ltasks.size() - W.ltask_off; W.nt_ln = (W.n_ltasks + 4 * kBsRoundsLn - 1) / (4 * kBsRoundsLn); W.nl_ln = (W.n_ltasks + kLinRoundsLn * kLinThreads / 64 - 1) / (kLinRoundsLn * kLinThreads / 64);
+    W.n_ltasks = (int)B->h_ltasks.size() - W.ltask_off; W.nt_ln = (W.n_ltasks + 4 * W.rounds[3] - 1) / (4 * W.rounds[3]); W.nl_ln = (W.n_ltasks + W.rounds[1] * kLinThreads / 64 - 1) / (W.rounds[1] * kLinThreads / 64);
     W.hpart_off = (long long)n_hpart; n_hpart += (size_t)(W.nl_pt + W.nl_ln) * w.n_free_cams * 27;
     W.part_off = (int)NPART;
     W.its[0] = P.its_round1; W.its[1] = P.its_round2; W.max_trials = P.max_trials; W.ln_filter = P.ln_filter;

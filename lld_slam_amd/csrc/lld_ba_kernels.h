@@ -35,10 +35,13 @@ constexpr int kSchurThreads = 128;    // item-parallel Schur kernel: one lane pe
 constexpr int kPcgThreads = 1024;
 constexpr int kCtlThreads = 64;
 constexpr int kLinThreads = 512;        // linearise kernels: 8 tasks per workgroup (fewer per-workgroup Hpp partials to reduce)
-constexpr int kBsRounds = 4;           // same for the back-substitution workgroups (they stage both pose sets and x_p in LDS)
-constexpr int kLinRoundsLn = 2, kBsRoundsLn = 1;   // line observations are 6x fewer: more rounds would leave too few workgroups per window
-constexpr int kLinRounds = 8;          // tasks per wavefront of a linearise workgroup: amortises zeroing / flushing the LDS accumulators and
-                                       // divides the number of per-workgroup Hpp partials (and ba_hpp_reduce's work) by the same factor
+// Tasks swept per wavefront of a linearise / back-substitution workgroup (BAWin::rounds, chosen per batch by the host):
+// sweeping several tasks amortises zeroing / flushing the LDS accumulators, the pose copies and x_p, and divides the number of
+// per-workgroup Hpp partials (and ba_hpp_reduce's work) by the same factor - worth it when many windows fill the chip (throughput),
+// not when a handful of windows need every workgroup they can get (latency).  Order: linearise pt, linearise ln, backsub pt, backsub ln.
+constexpr int kRoundsThroughput[4] = {8, 2, 4, 1};
+constexpr int kRoundsLatency[4] = {1, 1, 1, 1};
+constexpr int kRoundsThroughputMinWindows = 32;
 constexpr int kAccCopies = 4;          // LDS copies of the per-camera Hpp/bp accumulators: lanes of one wavefront that hit the
                                        // same camera are spread over them (same-address LDS atomics serialise)
 constexpr int kMaxFreeCams = 96;
@@ -61,9 +64,10 @@ struct BAWin {                 // immutable per-window header
   int lo_off, n_lo;            // line observations (= le_off / 2)
   int blk_csr_off, cam_csr_off; // CSR (per lower S block / per free camera) of the chunk partials that add into it
   int nb_pt, nb_ln;            // landmark blocks (kLmThreads landmarks each)
-  int ptask_off, n_ptasks, nt_pt;   // point tasks (4 * kBsRounds per back-substitution workgroup -> nt_pt workgroups)
+  int ptask_off, n_ptasks, nt_pt;   // point tasks (4 * rounds[2] per back-substitution workgroup -> nt_pt workgroups)
   int ltask_off, n_ltasks, nt_ln;   // line tasks; partial-sum slots of a window: nt_pt + nt_ln
-  int nl_pt, nl_ln;            // workgroups of the linearise kernels (kLinRounds * kLinThreads / 64 tasks each)
+  int nl_pt, nl_ln;            // workgroups of the linearise kernels (rounds[0|1] * kLinThreads / 64 tasks each)
+  int rounds[4];               // tasks per wavefront: linearise pt / ln, backsub pt / ln
   long long hpart_off;         // per-workgroup Hpp/bp partials of the linearise kernels (doubles): [nl_pt + nl_ln][n_free * 27]
   int part_off;                // per-block partial sums
   int its[2];                  // LM iterations per round
@@ -378,7 +382,7 @@ __device__ __forceinline__ void point_edge_hpp(const PtEdgeLin& L, double* ac) {
   }
 }
 
-// grid (nl_pt, nW), block 512 = 8 wavefronts, kLinRounds tasks per wavefront; dynamic LDS: kAccCopies*n_free_max*27 doubles + 8 scratch.
+// grid (nl_pt, nW), block 512 = 8 wavefronts, BAWin::rounds tasks per wavefront; dynamic LDS: kAccCopies*n_free_max*27 doubles + 8 scratch.
 __global__ __launch_bounds__(kLinThreads, 4) void ba_linearize_pt_kernel(BAArrays A, const BAWin* __restrict__ wins, BAState* __restrict__ st) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const BAWin W = wins[blockIdx.y];
@@ -396,8 +400,8 @@ __global__ __launch_bounds__(kLinThreads, 4) void ba_linearize_pt_kernel(BAArray
   __syncthreads();
   const int lane = threadIdx.x & 63;
   double chi = 0.0, maxd = 0.0;
-  for (int rnd = 0; rnd < kLinRounds; rnd++) {
-    const int ti = (blockIdx.x * kLinRounds + rnd) * (kLinThreads / 64) + (threadIdx.x >> 6);
+  for (int rnd = 0; rnd < W.rounds[0]; rnd++) {
+    const int ti = (blockIdx.x * W.rounds[0] + rnd) * (kLinThreads / 64) + (threadIdx.x >> 6);
     if (ti >= W.n_ptasks) break;
     const PTask T = A.ptasks[W.ptask_off + ti];
     if (T.nl > 1) {
@@ -539,7 +543,7 @@ __device__ __forceinline__ double point_backsub(const double* V, double lambda, 
   return sc;
 }
 
-// grid (nt_pt, nW), block 256 = 4 wavefronts, kBsRounds tasks per wavefront; dynamic LDS: 8 + 14 n_cams + 6 n_free doubles
+// grid (nt_pt, nW), block 256 = 4 wavefronts, BAWin::rounds tasks per wavefront; dynamic LDS: 8 + 14 n_cams + 6 n_free doubles
 __global__ __launch_bounds__(kLmThreads) void ba_backsub_pt_kernel(BAArrays A, const BAWin* __restrict__ wins, const BAState* __restrict__ st) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const BAWin W = wins[blockIdx.y];
@@ -563,8 +567,8 @@ __global__ __launch_bounds__(kLmThreads) void ba_backsub_pt_kernel(BAArrays A, c
   __syncthreads();
   const int lane = threadIdx.x & 63;
   double chi = 0.0, sc = 0.0;
-  for (int rnd = 0; rnd < kBsRounds; rnd++) {
-    const int ti = (blockIdx.x * kBsRounds + rnd) * 4 + (threadIdx.x >> 6);
+  for (int rnd = 0; rnd < W.rounds[2]; rnd++) {
+    const int ti = (blockIdx.x * W.rounds[2] + rnd) * 4 + (threadIdx.x >> 6);
     if (ti >= W.n_ptasks) break;
     const PTask T = A.ptasks[W.ptask_off + ti];
     if (T.nl > 1) {
@@ -725,7 +729,7 @@ __device__ __forceinline__ double line_obs_linearize(const BAArrays& A, const BA
   return chi;
 }
 
-// grid (nl_ln, nW), block 512 = 8 wavefronts, kLinRounds tasks per wavefront; dynamic LDS: kAccCopies*n_free_max*27 doubles + 8 scratch.
+// grid (nl_ln, nW), block 512 = 8 wavefronts, BAWin::rounds tasks per wavefront; dynamic LDS: kAccCopies*n_free_max*27 doubles + 8 scratch.
 __global__ __launch_bounds__(kLinThreads) void ba_linearize_ln_kernel(BAArrays A, const BAWin* __restrict__ wins, BAState* __restrict__ st) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const BAWin W = wins[blockIdx.y];
@@ -741,8 +745,8 @@ __global__ __launch_bounds__(kLinThreads) void ba_linearize_ln_kernel(BAArrays A
   const int cur = S.cur;
   const int lane = threadIdx.x & 63;
   double chi = 0.0, maxd = 0.0;
-  for (int rnd = 0; rnd < kLinRoundsLn; rnd++) {
-    const int ti = (blockIdx.x * kLinRoundsLn + rnd) * (kLinThreads / 64) + (threadIdx.x >> 6);
+  for (int rnd = 0; rnd < W.rounds[1]; rnd++) {
+    const int ti = (blockIdx.x * W.rounds[1] + rnd) * (kLinThreads / 64) + (threadIdx.x >> 6);
     if (ti >= W.n_ltasks) break;
     const PTask T = A.ltasks[W.ltask_off + ti];
     double hb[14];
@@ -840,7 +844,7 @@ __device__ __forceinline__ double line_backsub(const double* V, double lambda, c
   return sc;
 }
 
-// grid (nt_ln, nW), block 256 = 4 wavefronts, kBsRounds tasks per wavefront
+// grid (nt_ln, nW), block 256 = 4 wavefronts, BAWin::rounds tasks per wavefront
 __global__ __launch_bounds__(kLmThreads) void ba_backsub_ln_kernel(BAArrays A, const BAWin* __restrict__ wins, const BAState* __restrict__ st) {
   __shared__ double scratch[8];
   const BAWin W = wins[blockIdx.y];
@@ -852,8 +856,8 @@ __global__ __launch_bounds__(kLmThreads) void ba_backsub_ln_kernel(BAArrays A, c
   const double* xp = A.xp + W.x_off;
   const int lane = threadIdx.x & 63;
   double chi = 0.0, sc = 0.0;
-  for (int rnd = 0; rnd < kBsRoundsLn; rnd++) {
-    const int ti = (blockIdx.x * kBsRoundsLn + rnd) * 4 + (threadIdx.x >> 6);
+  for (int rnd = 0; rnd < W.rounds[3]; rnd++) {
+    const int ti = (blockIdx.x * W.rounds[3] + rnd) * 4 + (threadIdx.x >> 6);
     if (ti >= W.n_ltasks) break;
     const PTask T = A.ltasks[W.ltask_off + ti];
     if (T.nl > 1) {
