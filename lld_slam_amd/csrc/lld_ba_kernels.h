@@ -1562,10 +1562,14 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
 // Panel wave: factor the 16x16 tile in Dg (lower triangle used) in place, L^-1 -> Li, 1/L_cc -> invd, rhs y[0..15] -> L^-1 y.
 __device__ __forceinline__ bool chol_tile_factor(double* Dg, double* Li, double* invd, double* y, int lane) {
   const int r = lane < 32 ? lane : 32;                               // 0..15 tile rows, 16 rhs, 17..32 identity rows
+  // one load path for all lanes: tile rows and the right-hand side are read through a per-lane pointer, the identity rows read
+  // the (finite) right-hand side too and are overwritten
+  const double* src = (r < 16) ? Dg + r * kCholMStride : y;
   double a[16];
 #pragma unroll
-  for (int c = 0; c < 16; c++) a[c] = (r < 16) ? Dg[r * kCholMStride + c] : (r == 16 ? y[c] : (r - 17 == c ? 1.0 : 0.0));
+  for (int c = 0; c < 16; c++) { const double v = src[c]; a[c] = (r <= 16) ? v : (r - 17 == c ? 1.0 : 0.0); }
   bool ok = true;
+  double my_inv = 0.0;
 #pragma unroll
   for (int c = 0; c < 16; c++) {
     const double d = readlane_f64(a[c], c);
@@ -1577,11 +1581,12 @@ __device__ __forceinline__ bool chol_tile_factor(double* Dg, double* Li, double*
     inv = inv * (1.5 - (0.5 * d) * (inv * inv));
     const double lc = a[c] * inv;                                    // lane c: sqrt(d); below: L[r][c]; rhs lane: y_c
     a[c] = lc;
-    if (lane == 0) invd[c] = inv;
+    if (lane == c) my_inv = inv;
 #pragma unroll
     for (int c2 = c + 1; c2 < 16; c2++) a[c2] -= lc * readlane_f64(lc, c2);   // A[r][c2] -= L[r][c] L[c2][c]
   }
   if (lane < 16) {
+    invd[lane] = my_inv;
 #pragma unroll
     for (int c = 0; c < 16; c++) Dg[r * kCholMStride + c] = (c <= r) ? a[c] : 0.0;
   } else if (lane == 16) {
