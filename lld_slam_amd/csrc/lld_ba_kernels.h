@@ -1105,16 +1105,16 @@ __device__ __forceinline__ void schur_chunk_wave(const BAArrays& A, const BAWin&
           for (int m = 0; m < D; m++) { y0[m] = ya[m]; y1[m] = ya[D + m]; }
 #pragma unroll
           for (int c = 0; c < 6; c++) {
-            double s0 = 0.0, s1 = 0.0;
+            double s0 = acc[c], s1 = acc[6 + c];             // straight FMA chains into the accumulators (no separate add)
 #pragma unroll
-            for (int m = 0; m < D; m++) { const double wv = wbp[c * D + m]; s0 += y0[m] * wv; s1 += y1[m] * wv; }
-            acc[c] += s0; acc[6 + c] += s1;
+            for (int m = 0; m < D; m++) { const double wv = wbp[c * D + m]; s0 = fma(y0[m], wv, s0); s1 = fma(y1[m], wv, s1); }
+            acc[c] = s0; acc[6 + c] = s1;
           }
           if (diag) {
-            double s0 = 0.0, s1 = 0.0;
+            double s0 = cacc[0], s1 = cacc[1];
 #pragma unroll
-            for (int m = 0; m < D; m++) { const double bv = bll[j * D + m]; s0 += y0[m] * bv; s1 += y1[m] * bv; }
-            cacc[0] += s0; cacc[1] += s1;
+            for (int m = 0; m < D; m++) { const double bv = bll[j * D + m]; s0 = fma(y0[m], bv, s0); s1 = fma(y1[m], bv, s1); }
+            cacc[0] = s0; cacc[1] = s1;
           }
         }
       }
