@@ -137,8 +137,11 @@ LLD_HD Pose pose_oplus(const Pose& T, const double* u) {
   Mat3 R;
   const double W2[3][3] = {{w.x * w.x - ww, w.x * w.y, w.x * w.z}, {w.y * w.x, w.y * w.y - ww, w.y * w.z}, {w.z * w.x, w.z * w.y, w.z * w.z - ww}};
   const double W1[3][3] = {{0, -w.z, w.y}, {w.z, 0, -w.x}, {-w.y, w.x, 0}};
-  for (int i = 0; i < 3; i++)
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+#pragma unroll
     for (int j = 0; j < 3; j++) R.m[i][j] = ((i == j ? 1.0 : 0.0) + a * W1[i][j]) + b * W2[i][j];
+  }
   // V * upsilon = v + bv * (w x v) + c * (w x (w x v))
   const Vec3 wv = cross(w, v);
   const Vec3 wwv = cross(w, wv);

@@ -1,10 +1,13 @@
 // lld_pose.hip — Optimizer::PoseOptimization (src/Optimizer.cc:653-932, AddLineMinOnlyPose :562-650) as ONE kernel:
 // one workgroup per frame runs the whole protocol (4 rounds x 10 Levenberg–Marquardt iterations, outlier
-// classification between rounds) without host round trips.  Per LM iteration the 256 lanes sweep the frame's point and
-// line edges (SoA in HBM, L2-resident), build the 6x6 normal equations in registers (21+6+1 fp64 partials per lane),
-// reduce them with a fixed shuffle tree + LDS, and every lane solves the damped 6x6 system redundantly (LDL^T) so no
-// broadcast is needed.  g2o semantics kept: Huber weights use rho' only, chi2 is float-compared against 5.991f/7.815f,
-// per-edge errors go stale exactly as in the reference (only outliers are re-evaluated before classification).
+// classification between rounds) without host round trips.  The frame's observations are copied ONCE from HBM into LDS
+// (1000 points + 400 line edges = 106 KB of the CU's 160 KB) together with the per-edge working state (chi2, level, robust
+// kernel, outlier flag), so the ~80 sweeps of the protocol never leave the CU.  512 lanes (two wavefronts per SIMD, enough to
+// cover the dependent fp64 latency) sweep the edges, build the 6x6 normal equations in registers (21+6+1 fp64 partials per
+// lane), reduce them with a fixed shuffle tree + LDS; ONE lane solves the damped 6x6 system (LDL^T) and applies the update,
+// the trial pose travels through LDS.  g2o semantics kept: Huber weights use rho' only, chi2 is float-compared against
+// 5.991f/7.815f, per-edge errors go stale exactly as in the reference (only outliers are re-evaluated before classification).
+// Frames too large for LDS run the same code on HBM-resident working arrays (template flag).
 #include "lld_common.h"
 #include "lld_device_math.h"
 
@@ -12,7 +15,11 @@ namespace {
 
 using namespace lld;
 
-constexpr int kPoseThreads = 256;
+constexpr int kPoseThreads = 512;
+constexpr int kPoseWaves = kPoseThreads / 64;
+constexpr size_t kPoseLdsBudget = 150 * 1024;              // dynamic LDS available to the staged frame (160 KB per CU)
+constexpr uint8_t PF_LEVEL = 1, PF_ROBUST = 2, PF_OUTLIER = 4;             // point working flags
+constexpr uint8_t LF_LEVEL = 1, LF_ROBUST = 2, LF_LAST = 4, LF_STEREO = 8; // line-edge flags (LAST / STEREO are inputs)
 
 struct PoseFrameDev {            // per-frame header in HBM
   CamK cam;
@@ -25,24 +32,21 @@ struct PoseFrameDev {            // per-frame header in HBM
   double thr_ln_stereo, thr_ln_mono;        // float*float products, widened
 };
 
-struct PoseSoA {
-  // points
-  const double *px, *py, *pz, *u, *v, *ur, *s;
-  double* pt_chi2; uint8_t* pt_level; uint8_t* pt_robust; uint8_t* pt_outlier;
-  // line edges
-  const double *x1x, *x1y, *x1z, *x2x, *x2y, *x2z, *xs, *ys, *xe, *ye, *ls, *lbx;
-  const int* le_line; const uint8_t* le_last;
-  double* le_chi2; uint8_t* le_level; uint8_t* le_robust;
-  // lines
-  const uint8_t* ln_has_right; uint8_t* ln_outlier;
+struct PoseArrays {
+  const double* pt[7];           // px, py, pz, u, v, ur, s                    [n_pt_total]
+  const double* le[12];          // x1x,x1y,x1z, x2x,x2y,x2z, xs,ys,xe,ye, info, bx   [n_le_total]
+  const int* le_line;            // line of the edge (frame-local)
+  const uint8_t* le_fl0;         // LF_LAST: last edge of its line; LF_STEREO: the line has a right-image edge
+  // working state of the HBM mode (frames that do not fit LDS)
+  double *pt_chi2, *le_chi2; uint8_t *pt_fl, *le_fl;
+  // results
+  uint8_t *pt_outlier, *ln_outlier;
 };
 
 struct PoseOut { double qt[7]; double chi2; int n_inliers, lm_iterations, lm_trials, pad; };
 
-// Fixed-tree block reduction of N doubles per lane; every lane returns with the totals in `v`.
 template <int N>
-__device__ __forceinline__ void block_sum(double* v, double* lds /* [4][N] + [N] */) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+__device__ __forceinline__ void wave_sum_all(double* v) {
 #pragma unroll
   for (int i = 0; i < N; i++) {
     double x = v[i];
@@ -50,102 +54,213 @@ __device__ __forceinline__ void block_sum(double* v, double* lds /* [4][N] + [N]
     for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
     v[i] = x;
   }
+}
+// Fixed-tree block sum of one double per lane; every lane returns the total.
+__device__ __forceinline__ double block_sum1(double x, double* lds /* [kPoseWaves] */) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  wave_sum_all<1>(&x);
   __syncthreads();
-  if (lane == 0) { for (int i = 0; i < N; i++) lds[wave * N + i] = v[i]; }
+  if (lane == 0) lds[wave] = x;
   __syncthreads();
+  double s = lds[0];
 #pragma unroll
-  for (int i = 0; i < N; i++) v[i] = ((lds[i] + lds[N + i]) + lds[2 * N + i]) + lds[3 * N + i];
+  for (int w = 1; w < kPoseWaves; w++) s += lds[w];
+  return s;
 }
 
 // Dense LDL^T of the 6x6 system (LinearSolverDense, solvers/linear_solver_dense.h:65-113): fails unless all pivots > 0.
 __device__ __forceinline__ bool solve6(const double* Hu /*21 upper, row-major packed*/, double lambda, const double* b, double* x) {
   double A[6][6];
-  int k = 0;
-  for (int i = 0; i < 6; i++) for (int j = i; j < 6; j++) { A[i][j] = Hu[k]; A[j][i] = Hu[k]; k++; }
-  for (int i = 0; i < 6; i++) A[i][i] += lambda;
-  double L[6][6], D[6];
-  bool ok = true;
-  for (int j = 0; j < 6; j++) {
-    double d = A[j][j];
-    for (int p = 0; p < j; p++) d -= L[j][p] * L[j][p] * D[p];
-    if (!(d > 0.0) || !isfinite(d)) ok = false;
-    D[j] = d;
-    for (int i = j + 1; i < 6; i++) {
-      double s = A[i][j];
-      for (int p = 0; p < j; p++) s -= L[i][p] * L[j][p] * D[p];
-      L[i][j] = s / d;
+  {
+    int k = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+#pragma unroll
+      for (int j = i; j < 6; j++) { A[j][i] = Hu[k]; k++; }         // lower triangle; becomes L below the diagonal, D on it
     }
   }
+#pragma unroll
+  for (int i = 0; i < 6; i++) A[i][i] += lambda;
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < 6; j++) {
+    double d = A[j][j];
+#pragma unroll
+    for (int p = 0; p < j; p++) d -= A[j][p] * A[j][p] * A[p][p];
+    if (!(d > 0.0) || !isfinite(d)) ok = false;
+#pragma unroll
+    for (int i = j + 1; i < 6; i++) {
+      double s = A[i][j];
+#pragma unroll
+      for (int p = 0; p < j; p++) s -= A[i][p] * A[j][p] * A[p][p];
+      A[i][j] = s / d;
+    }
+    A[j][j] = d;
+  }
   double y[6];
-  for (int i = 0; i < 6; i++) { double s = b[i]; for (int p = 0; p < i; p++) s -= L[i][p] * y[p]; y[i] = s; }
-  for (int i = 0; i < 6; i++) y[i] /= D[i];
-  for (int i = 5; i >= 0; i--) { double s = y[i]; for (int p = i + 1; p < 6; p++) s -= L[p][i] * x[p]; x[i] = s; }
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    double s = b[i];
+#pragma unroll
+    for (int p = 0; p < i; p++) s -= A[i][p] * y[p];
+    y[i] = s;
+  }
+#pragma unroll
+  for (int i = 0; i < 6; i++) y[i] /= A[i][i];
+#pragma unroll
+  for (int i = 5; i >= 0; i--) {
+    double s = y[i];
+#pragma unroll
+    for (int p = i + 1; p < 6; p++) s -= A[p][i] * x[p];
+    x[i] = s;
+  }
   return ok;
 }
 
-__device__ __forceinline__ void accum_unary(const double* J, int D, const double* e, double s, double w, double* H, double* b) {
-  // BaseUnaryEdge::constructQuadraticForm (core/base_unary_edge.hpp:42-72): b -= w A^T (s e), H += A^T (w s) A
+// BaseUnaryEdge::constructQuadraticForm (core/base_unary_edge.hpp:42-72): b -= w A^T (s e), H += A^T (w s) A.  D is a
+// compile-time row count so that J stays in registers (a monocular point passes a zero third row and e[2] = 0).
+template <int D>
+__device__ __forceinline__ void accum_unary(const double* J, const double* e, double s, double w, double* H, double* b) {
   const double ws = w * s;
   int k = 0;
+#pragma unroll
   for (int r = 0; r < 6; r++) {
     double br = 0;
+#pragma unroll
     for (int i = 0; i < D; i++) br += J[i * 6 + r] * e[i];
     b[r] -= ws * br;
+#pragma unroll
     for (int c = r; c < 6; c++) {
       double h = 0;
+#pragma unroll
       for (int i = 0; i < D; i++) h += J[i * 6 + r] * J[i * 6 + c];
       H[k++] += ws * h;
     }
   }
 }
 
-__global__ __launch_bounds__(kPoseThreads) void pose_opt_kernel(const PoseFrameDev* __restrict__ frames, PoseSoA a, PoseOut* __restrict__ out,
+// LDS bytes of one staged frame: 8 point + 13 line-edge double arrays, the edge->line ints, two flag byte arrays.
+__host__ __device__ inline size_t pose_lds_bytes(int n_pt, int n_le) {
+  return (size_t)8 * (8 * (size_t)n_pt + 13 * (size_t)n_le) + 4 * (size_t)n_le + (((size_t)n_pt + 15) & ~(size_t)15) + (((size_t)n_le + 15) & ~(size_t)15) + 32;
+}
+
+template <bool kLds>
+__global__ __launch_bounds__(kPoseThreads) void pose_opt_kernel(const PoseFrameDev* __restrict__ frames, PoseArrays a, PoseOut* __restrict__ out,
                                                                int n_rounds, int its_per_round, int max_trials) {
-  __shared__ double red[5 * 28];
+  extern __shared__ __attribute__((aligned(16))) double dyn[];
+  __shared__ double red[kPoseWaves * 28];       // per-wavefront partials of the normal equations
+  __shared__ double tot[28];                    // H (21 upper), b (6), robust chi2
+  __shared__ double sol[16];                    // trial pose (7), scale, solver ok
+  __shared__ double red1[kPoseWaves];
   const PoseFrameDev& F = frames[blockIdx.x];
   const CamK cam = F.cam;
   const int tid = threadIdx.x;
   const Pose T0 = pose_load(F.T0);
   Pose T = T0;
-  const int n_pt = F.n_pt, n_le = F.n_le;
+  const int n_pt = F.n_pt, n_le = F.n_le, n_ln = F.n_ln;
   const int po = F.pt_off, lo = F.le_off, no = F.ln_off;
+
+  // ---- the frame's view: LDS copies (staged once) or the HBM arrays themselves
+  const double *P[7], *L[12];
+  double *pchi, *lchi; uint8_t *pfl, *lfl; const int* lline;
+  if constexpr (kLds) {
+    double* d = dyn;
+#pragma unroll
+    for (int k = 0; k < 7; k++) { double* dst = d; d += n_pt; for (int i = tid; i < n_pt; i += kPoseThreads) dst[i] = a.pt[k][po + i]; P[k] = dst; }
+    pchi = d; d += n_pt;
+#pragma unroll
+    for (int k = 0; k < 12; k++) { double* dst = d; d += n_le; for (int i = tid; i < n_le; i += kPoseThreads) dst[i] = a.le[k][lo + i]; L[k] = dst; }
+    lchi = d; d += n_le;
+    int* li = reinterpret_cast<int*>(d);
+    for (int i = tid; i < n_le; i += kPoseThreads) li[i] = a.le_line[lo + i];
+    lline = li;
+    pfl = reinterpret_cast<uint8_t*>(li + n_le + (n_le & 1));
+    lfl = pfl + ((n_pt + 15) & ~15);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 7; k++) P[k] = a.pt[k] + po;
+#pragma unroll
+    for (int k = 0; k < 12; k++) L[k] = a.le[k] + lo;
+    pchi = a.pt_chi2 + po; lchi = a.le_chi2 + lo; pfl = a.pt_fl + po; lfl = a.le_fl + lo; lline = a.le_line + lo;
+  }
+  // every solve starts from: level 0, Huber kernels on, nothing flagged
+  for (int i = tid; i < n_pt; i += kPoseThreads) { pfl[i] = PF_ROBUST; pchi[i] = 0.0; }
+  for (int i = tid; i < n_le; i += kPoseThreads) { lfl[i] = a.le_fl0[lo + i] | LF_ROBUST; lchi[i] = 0.0; }
+  for (int i = tid; i < n_ln; i += kPoseThreads) a.ln_outlier[no + i] = 0;
+  __syncthreads();
+
   int lm_iterations = 0, lm_trials = 0;
   double last_chi = 0.0;
   int nBad_pts = 0;
   const bool enough = n_pt >= 3;                     // if(nInitialCorrespondences<3) return 0;  (Optimizer.cc:809-810)
 
-  // error evaluation at pose P for the lane's edges; optionally accumulates the normal equations
-  auto sweep = [&](const Pose& P, bool build, double* acc /*28: H21,b6,chi*/) {
+  // residuals of one edge at pose P (operands are loaded before the level test so the loads of a lane's edges overlap)
+  auto point_eval = [&](const Pose& Pq, int i, Vec3& Xc, double* e, double& s, bool& stereo) {
+    Xc = pose_map(Pq, vec3(P[0][i], P[1][i], P[2][i]));
+    const double urv = P[5][i];
+    stereo = !(urv < 0);
+    point_residual(cam, Xc, P[3][i], P[4][i], urv, stereo, false, e);
+    s = P[6][i];
+    return e[0] * (s * e[0]) + e[1] * (s * e[1]) + (stereo ? e[2] * (s * e[2]) : 0.0);
+  };
+  auto line_eval = [&](const Pose& Pq, int i, Vec3& X1m, Vec3& X2m, double* e, double& s, LineAdj* adj) {
+    X1m = pose_map(Pq, vec3(L[0][i], L[1][i], L[2][i]));
+    X2m = pose_map(Pq, vec3(L[3][i], L[4][i], L[5][i]));
+    line_residual(cam, L[11][i], X1m, X2m, L[6][i], L[7][i], L[8][i], L[9][i], e, adj);
+    s = L[10][i];
+    return e[0] * (s * e[0]) + e[1] * (s * e[1]);
+  };
+  // linearisation sweep: chi2 of every active edge + the lane's share of the normal equations
+  auto sweep_build = [&](const Pose& Pq, double* acc /*28: H21,b6,chi*/) {
+#pragma unroll
     for (int i = 0; i < 28; i++) acc[i] = 0.0;
     for (int i = tid; i < n_pt; i += kPoseThreads) {
-      if (a.pt_level[po + i] != 0) continue;
-      const Vec3 Xc = pose_map(P, vec3(a.px[po + i], a.py[po + i], a.pz[po + i]));
-      const double urv = a.ur[po + i];
-      const bool stereo = !(urv < 0);
-      double e[3];
-      point_residual(cam, Xc, a.u[po + i], a.v[po + i], urv, stereo, false, e);
-      const double s = a.s[po + i];
-      const double chi = e[0] * (s * e[0]) + e[1] * (s * e[1]) + (stereo ? e[2] * (s * e[2]) : 0.0);
-      a.pt_chi2[po + i] = chi;
+      const uint8_t fl = pfl[i];
+      if (fl & PF_LEVEL) continue;
+      Vec3 Xc; double e[3], s; bool stereo;
+      const double chi = point_eval(Pq, i, Xc, e, s, stereo);
+      pchi[i] = chi;
       double w = 1.0, rho0 = chi;
-      if (a.pt_robust[po + i]) rho0 = huber(chi, stereo ? F.delta_stereo : F.delta_mono, &w);
+      if (fl & PF_ROBUST) rho0 = huber(chi, stereo ? F.delta_stereo : F.delta_mono, &w);
       acc[27] += rho0;
-      if (build) { double J[18]; point_jac_pose(cam, Xc, stereo, J); accum_unary(J, stereo ? 3 : 2, e, s, w, acc, acc + 21); }
+      double J[18]; point_jac_pose(cam, Xc, stereo, J); accum_unary<3>(J, e, s, w, acc, acc + 21);
     }
     for (int i = tid; i < n_le; i += kPoseThreads) {
-      if (a.le_level[lo + i] != 0) continue;
-      const Vec3 X1m = pose_map(P, vec3(a.x1x[lo + i], a.x1y[lo + i], a.x1z[lo + i]));
-      const Vec3 X2m = pose_map(P, vec3(a.x2x[lo + i], a.x2y[lo + i], a.x2z[lo + i]));
-      double e[2]; LineAdj adj;
-      line_residual(cam, a.lbx[lo + i], X1m, X2m, a.xs[lo + i], a.ys[lo + i], a.xe[lo + i], a.ye[lo + i], e, build ? &adj : nullptr);
-      const double s = a.ls[lo + i];
-      const double chi = e[0] * (s * e[0]) + e[1] * (s * e[1]);
-      a.le_chi2[lo + i] = chi;
+      const uint8_t fl = lfl[i];
+      if (fl & LF_LEVEL) continue;
+      Vec3 X1m, X2m; double e[2], s; LineAdj adj;
+      const double chi = line_eval(Pq, i, X1m, X2m, e, s, &adj);
+      lchi[i] = chi;
       double w = 1.0, rho0 = chi;
-      if (a.le_robust[lo + i]) rho0 = huber(chi, a.ln_has_right[no + a.le_line[lo + i]] ? F.delta_ln_stereo : F.delta_ln_mono, &w);
+      if (fl & LF_ROBUST) rho0 = huber(chi, (fl & LF_STEREO) ? F.delta_ln_stereo : F.delta_ln_mono, &w);
       acc[27] += rho0;
-      if (build) { double J[12]; line_jac_pose(adj, X1m, X2m, J); accum_unary(J, 2, e, s, w, acc, acc + 21); }
+      double J[12]; line_jac_pose(adj, X1m, X2m, J); accum_unary<2>(J, e, s, w, acc, acc + 21);
     }
+  };
+  // trial sweep: computeActiveErrors + activeRobustChi2 at the trial pose
+  auto sweep_chi = [&](const Pose& Pq) {
+    double c = 0.0;
+    for (int i = tid; i < n_pt; i += kPoseThreads) {
+      const uint8_t fl = pfl[i];
+      if (fl & PF_LEVEL) continue;
+      Vec3 Xc; double e[3], s; bool stereo;
+      const double chi = point_eval(Pq, i, Xc, e, s, stereo);
+      pchi[i] = chi;
+      double w, rho0 = chi;
+      if (fl & PF_ROBUST) rho0 = huber(chi, stereo ? F.delta_stereo : F.delta_mono, &w);
+      c += rho0;
+    }
+    for (int i = tid; i < n_le; i += kPoseThreads) {
+      const uint8_t fl = lfl[i];
+      if (fl & LF_LEVEL) continue;
+      Vec3 X1m, X2m; double e[2], s;
+      const double chi = line_eval(Pq, i, X1m, X2m, e, s, nullptr);
+      lchi[i] = chi;
+      double w, rho0 = chi;
+      if (fl & LF_ROBUST) rho0 = huber(chi, (fl & LF_STEREO) ? F.delta_ln_stereo : F.delta_ln_mono, &w);
+      c += rho0;
+    }
+    return c;
   };
 
   double lambda = -1.0, ni = 2.0;
@@ -154,37 +269,59 @@ __global__ __launch_bounds__(kPoseThreads) void pose_opt_kernel(const PoseFrameD
     for (int round = 0; round < n_rounds; round++) {
       T = T0;                                                        // vSE3->setEstimate(toSE3Quat(pFrame->mTcw))  (:823)
       // initializeOptimization(0): active = level-0 edges.  optimize() returns -1 when nothing is active.
-      double cnt[1] = {0.0};
-      for (int i = tid; i < n_pt; i += kPoseThreads) cnt[0] += a.pt_level[po + i] == 0 ? 1.0 : 0.0;
-      for (int i = tid; i < n_le; i += kPoseThreads) cnt[0] += a.le_level[lo + i] == 0 ? 1.0 : 0.0;
-      block_sum<1>(cnt, red);
-      if (cnt[0] > 0.5) {
+      double cnt = 0.0;
+      for (int i = tid; i < n_pt; i += kPoseThreads) cnt += (pfl[i] & PF_LEVEL) ? 0.0 : 1.0;
+      for (int i = tid; i < n_le; i += kPoseThreads) cnt += (lfl[i] & LF_LEVEL) ? 0.0 : 1.0;
+      cnt = block_sum1(cnt, red1);
+      if (cnt > 0.5) {
         bool ok = true;
         for (int it = 0; it < its_per_round && ok; it++) {
           // ---- OptimizationAlgorithmLevenberg::solve(it)  (optimization_algorithm_levenberg.cpp:61-164)
-          double acc[28];
-          sweep(T, true, acc);
-          block_sum<28>(acc, red);
-          double currentChi = acc[27];
+          {
+            double acc[28];
+            sweep_build(T, acc);
+            wave_sum_all<28>(acc);
+            __syncthreads();                                         // previous readers of red / tot / sol are done
+            if ((tid & 63) == 0) {
+#pragma unroll
+              for (int i = 0; i < 28; i++) red[(tid >> 6) * 28 + i] = acc[i];
+            }
+            __syncthreads();
+            if (tid < 28) {
+              double sv = red[tid];
+#pragma unroll
+              for (int w = 1; w < kPoseWaves; w++) sv += red[w * 28 + tid];
+              tot[tid] = sv;
+            }
+            __syncthreads();
+          }
+          double currentChi = tot[27];
           const double iniChi = currentChi;
           if (it == 0) {
             double md = 0.0; int k = 0;
-            for (int r = 0; r < 6; r++) { md = fmax(fabs(acc[k]), md); k += 6 - r; }
+            for (int r = 0; r < 6; r++) { md = fmax(fabs(tot[k]), md); k += 6 - r; }
             lambda = 1e-5 * md; ni = 2.0; nBadLM = 0;
           }
           double rho = 0.0; int q = 0;
           do {
-            double x[6];
-            const bool ok2 = solve6(acc, lambda, acc + 21, x);
-            const Pose Tn = pose_oplus(T, x);
-            double ev[28];
-            sweep(Tn, false, ev);
-            double tmp[1] = {ev[27]};
-            block_sum<1>(tmp, red);
-            double tempChi = ok2 ? tmp[0] : 1.7976931348623157e308;
-            double scale = 0.0;
-            for (int j = 0; j < 6; j++) scale += x[j] * (lambda * x[j] + acc[21 + j]);
-            scale += 1e-3;
+            if (tid == 0) {                                          // one lane solves; the others wait at the barrier
+              double Hb[27], x[6];
+#pragma unroll
+              for (int i = 0; i < 27; i++) Hb[i] = tot[i];
+              const bool ok2 = solve6(Hb, lambda, Hb + 21, x);
+              const Pose Tn = pose_oplus(T, x);
+              double scale = 0.0;
+              for (int j = 0; j < 6; j++) scale += x[j] * (lambda * x[j] + Hb[21 + j]);
+              scale += 1e-3;
+              pose_store(Tn, sol);
+              sol[7] = scale; sol[8] = ok2 ? 1.0 : 0.0;
+            }
+            __syncthreads();
+            const Pose Tn = pose_load(sol);
+            const double scale = sol[7];
+            const bool ok2 = sol[8] != 0.0;
+            const double tmp = block_sum1(sweep_chi(Tn), red1);     // its barriers also fence `sol` against the next trial
+            const double tempChi = ok2 ? tmp : 1.7976931348623157e308;
             rho = (currentChi - tempChi) / scale;
             if (rho > 0 && isfinite(tempChi)) {
               double alpha = 1. - (2 * rho - 1) * (2 * rho - 1) * (2 * rho - 1);
@@ -205,48 +342,47 @@ __global__ __launch_bounds__(kPoseThreads) void pose_opt_kernel(const PoseFrameD
       }
       // ---- classification (Optimizer.cc:827-913)
       __syncthreads();
-      double nb[1] = {0.0};
+      double nb = 0.0;
       for (int i = tid; i < n_pt; i += kPoseThreads) {
-        const double urv = a.ur[po + i];
-        const bool stereo = !(urv < 0);
-        double chi = a.pt_chi2[po + i];
-        if (a.pt_outlier[po + i]) {                                 // if(pFrame->mvbOutlier[idx]) e->computeError();
-          const Vec3 Xc = pose_map(T, vec3(a.px[po + i], a.py[po + i], a.pz[po + i]));
-          double e[3]; point_residual(cam, Xc, a.u[po + i], a.v[po + i], urv, stereo, false, e);
-          const double s = a.s[po + i];
-          chi = e[0] * (s * e[0]) + e[1] * (s * e[1]) + (stereo ? e[2] * (s * e[2]) : 0.0);
-          a.pt_chi2[po + i] = chi;
+        uint8_t fl = pfl[i];
+        double chi = pchi[i];
+        bool stereo = !(P[5][i] < 0);
+        if (fl & PF_OUTLIER) {                                       // if(pFrame->mvbOutlier[idx]) e->computeError();
+          Vec3 Xc; double e[3], s;
+          chi = point_eval(T, i, Xc, e, s, stereo);
+          pchi[i] = chi;
         }
         const float chif = (float)chi;
         const bool bad = chif > (stereo ? 7.815f : 5.991f);
-        a.pt_outlier[po + i] = bad; a.pt_level[po + i] = bad;
-        nb[0] += bad ? 1.0 : 0.0;
-        if (round == 2) a.pt_robust[po + i] = 0;
+        fl = (uint8_t)((fl & PF_ROBUST) | (bad ? (PF_LEVEL | PF_OUTLIER) : 0));
+        if (round == 2) fl &= (uint8_t)~PF_ROBUST;
+        pfl[i] = fl;
+        nb += bad ? 1.0 : 0.0;
       }
-      block_sum<1>(nb, red);
-      nBad_pts = (int)(nb[0] + 0.5);
+      nb = block_sum1(nb, red1);
+      nBad_pts = (int)(nb + 0.5);
       if (n_pt + n_le < 10) break;                                   // if(optimizer.edges().size()<10) break;
+      // vnStereoLines is filled per EDGE but indexed by the LINE index (Optimizer.cc:643-648 vs :898): the test below reads
+      // other edges' flags, whose LF_STEREO bit never changes, so no barrier is needed between the loops
       for (int i = tid; i < n_le; i += kPoseThreads) {
-        const Vec3 X1m = pose_map(T, vec3(a.x1x[lo + i], a.x1y[lo + i], a.x1z[lo + i]));
-        const Vec3 X2m = pose_map(T, vec3(a.x2x[lo + i], a.x2y[lo + i], a.x2z[lo + i]));
-        double e[2];
-        line_residual(cam, a.lbx[lo + i], X1m, X2m, a.xs[lo + i], a.ys[lo + i], a.xe[lo + i], a.ye[lo + i], e, nullptr);
-        const double s = a.ls[lo + i];
-        const double chi = e[0] * (s * e[0]) + e[1] * (s * e[1]);
-        a.le_chi2[lo + i] = chi;
+        Vec3 X1m, X2m; double e[2], s;
+        const double chi = line_eval(T, i, X1m, X2m, e, s, nullptr);
+        lchi[i] = chi;
         const float chif = (float)chi;
-        const int idx = a.le_line[lo + i];
-        // vnStereoLines is filled per EDGE but indexed by the LINE index (Optimizer.cc:643-648 vs :898)
-        const bool st = idx < n_le ? a.ln_has_right[no + a.le_line[lo + idx]] != 0 : true;
+        const int idx = lline[i];
+        const bool st = idx < n_le ? (a.le_fl0[lo + idx] & LF_STEREO) != 0 : true;
         const double thr = st ? F.thr_ln_stereo : F.thr_ln_mono;
         const bool bad = (double)chif > thr;
-        a.le_level[lo + i] = bad;
-        if (a.le_last[lo + i]) a.ln_outlier[no + idx] = bad;        // the right-image edge overwrites the left one
-        if (round == 2) a.le_robust[lo + i] = 0;
+        uint8_t fl = lfl[i];
+        fl = (uint8_t)((fl & ~LF_LEVEL) | (bad ? LF_LEVEL : 0));
+        if (fl & LF_LAST) a.ln_outlier[no + idx] = bad;              // the right-image edge overwrites the left one
+        if (round == 2) fl &= (uint8_t)~LF_ROBUST;
+        lfl[i] = fl;
       }
       __syncthreads();
     }
   }
+  for (int i = tid; i < n_pt; i += kPoseThreads) a.pt_outlier[po + i] = (pfl[i] & PF_OUTLIER) ? 1 : 0;
   if (tid == 0) {
     PoseOut& o = out[blockIdx.x];
     pose_store(T, o.qt);
@@ -256,20 +392,137 @@ __global__ __launch_bounds__(kPoseThreads) void pose_opt_kernel(const PoseFrameD
 
 }  // namespace
 
+// Byte layout of a batch image: [input region | output region | HBM-mode working arrays], identical on host and device.
+struct PoseLayout {
+  size_t NP = 1, NE = 1, NL = 1;
+  size_t frames = 0, pt = 0, le = 0, le_line = 0, le_fl0 = 0, in_bytes = 0;
+  size_t out = 0, pt_outlier = 0, ln_outlier = 0, out_bytes = 0;           // offsets from the start of the image
+  size_t pt_chi2 = 0, le_chi2 = 0, pt_fl = 0, le_fl = 0, total = 0;
+};
+static PoseLayout pose_layout(int n_frames, size_t np, size_t ne, size_t nl, bool hbm_state) {
+  PoseLayout Y; Y.NP = np + 1; Y.NE = ne + 1; Y.NL = nl + 1;
+  size_t o = 0;
+  auto take = [&](size_t bytes) { const size_t at = o; o += lld_slab::pad(bytes); return at; };
+  Y.frames = take(sizeof(PoseFrameDev) * n_frames);
+  Y.pt = take(7 * Y.NP * 8); Y.le = take(12 * Y.NE * 8); Y.le_line = take(Y.NE * 4); Y.le_fl0 = take(Y.NE);
+  Y.in_bytes = o;
+  Y.out = take(sizeof(PoseOut) * n_frames); Y.pt_outlier = take(Y.NP); Y.ln_outlier = take(Y.NL);
+  Y.out_bytes = o - Y.in_bytes;
+  if (hbm_state) { Y.pt_chi2 = take(Y.NP * 8); Y.le_chi2 = take(Y.NE * 8); Y.pt_fl = take(Y.NP); Y.le_fl = take(Y.NE); }
+  Y.total = o;
+  return Y;
+}
+
+struct PoseCounts { size_t np = 0, ne = 0, nl = 0, max_lds = 0; };
+static int pose_count(int n_frames, const lld_pose_problem* frames, PoseCounts* C) {
+  for (int f = 0; f < n_frames; f++) {
+    const lld_pose_problem& P = frames[f];
+    if (P.n_points < 0 || P.n_lines < 0) return LLD_ERR_INVALID;
+    if ((P.n_points > 0 && (!P.pt_xw || !P.pt_uvr || !P.pt_inv_sigma2)) ||
+        (P.n_lines > 0 && (!P.ln_x0 || !P.ln_dir || !P.ln_left || !P.ln_right || !P.ln_octave))) return LLD_ERR_INVALID;
+    size_t ne = 0;
+    for (int l = 0; l < P.n_lines; l++) ne += (P.ln_right[4 * l] < 0) ? 1 : 2;
+    C->np += P.n_points; C->ne += ne; C->nl += P.n_lines;
+    C->max_lds = std::max(C->max_lds, pose_lds_bytes(P.n_points, (int)ne));
+    if (C->np > 0x3fffffff || C->ne > 0x3fffffff) return LLD_ERR_UNSUPPORTED;
+  }
+  return LLD_OK;
+}
+
+// Host-side expansion (AddLineMinOnlyPose): one left edge per line and a right edge when the line has a stereo match.
+static void pose_pack(int n_frames, const lld_pose_problem* frames, double gamma, const PoseLayout& Y, char* img, PoseFrameDev* hf) {
+  const float dMono = (float)std::sqrt(5.991), dStereo = (float)std::sqrt(7.815);
+  float dLnS = dStereo, dLnM = dMono;
+  dLnS *= gamma; dLnM *= gamma;                                      // float *= double (Optimizer.cc:706-707)
+  double* pt = reinterpret_cast<double*>(img + Y.pt);
+  double* le = reinterpret_cast<double*>(img + Y.le);
+  int* le_line = reinterpret_cast<int*>(img + Y.le_line);
+  uint8_t* le_fl0 = reinterpret_cast<uint8_t*>(img + Y.le_fl0);
+  size_t ip = 0, ie = 0, il = 0;
+  for (int f = 0; f < n_frames; f++) {
+    const lld_pose_problem& P = frames[f];
+    PoseFrameDev& F = hf[f];
+    F.cam = lld::make_camk(P.cam);
+    std::memcpy(F.T0, P.pose_qt, sizeof F.T0);
+    F.pt_off = (int)ip; F.n_pt = P.n_points;
+    F.le_off = (int)ie; F.ln_off = (int)il; F.n_ln = P.n_lines;
+    F.delta_mono = (double)dMono; F.delta_stereo = (double)dStereo;
+    F.delta_ln_stereo = (double)dLnS; F.delta_ln_mono = (double)dLnM;
+    F.thr_ln_stereo = (double)(dLnS * dLnS); F.thr_ln_mono = (double)(dLnM * dLnM);
+    for (int i = 0; i < P.n_points; i++, ip++) {
+      pt[0 * Y.NP + ip] = P.pt_xw[3 * i]; pt[1 * Y.NP + ip] = P.pt_xw[3 * i + 1]; pt[2 * Y.NP + ip] = P.pt_xw[3 * i + 2];
+      pt[3 * Y.NP + ip] = P.pt_uvr[3 * i]; pt[4 * Y.NP + ip] = P.pt_uvr[3 * i + 1]; pt[5 * Y.NP + ip] = P.pt_uvr[3 * i + 2];
+      pt[6 * Y.NP + ip] = P.pt_inv_sigma2[i];
+    }
+    for (int l = 0; l < P.n_lines; l++) {
+      const double* Lk = P.ln_left + 4 * l; const double* Rk = P.ln_right + 4 * l;
+      const bool hr = !(Rk[0] < 0);
+      for (int si = 0; si < 2; si++) {
+        if (si == 1 && !hr) continue;
+        const double* kl = si == 0 ? Lk : Rk;
+        le[0 * Y.NE + ie] = P.ln_x0[3 * l]; le[1 * Y.NE + ie] = P.ln_x0[3 * l + 1]; le[2 * Y.NE + ie] = P.ln_x0[3 * l + 2];
+        le[3 * Y.NE + ie] = P.ln_x0[3 * l] + P.ln_dir[3 * l]; le[4 * Y.NE + ie] = P.ln_x0[3 * l + 1] + P.ln_dir[3 * l + 1];
+        le[5 * Y.NE + ie] = P.ln_x0[3 * l + 2] + P.ln_dir[3 * l + 2];
+        le[6 * Y.NE + ie] = kl[0]; le[7 * Y.NE + ie] = kl[1]; le[8 * Y.NE + ie] = kl[2]; le[9 * Y.NE + ie] = kl[3];
+        le[10 * Y.NE + ie] = lld::line_info(gamma, P.ln_octave[2 * l + si]);
+        le[11 * Y.NE + ie] = si == 1 ? F.cam.bx_right : 0.0;
+        le_line[ie] = l;
+        le_fl0[ie] = (uint8_t)(((si == 1 || !hr) ? LF_LAST : 0) | (hr ? LF_STEREO : 0));
+        ie++;
+      }
+    }
+    F.n_le = (int)ie - F.le_off;
+    il += P.n_lines;
+  }
+  std::memcpy(img + Y.frames, hf, sizeof(PoseFrameDev) * n_frames);
+}
+
+static PoseArrays pose_arrays(char* d, const PoseLayout& Y) {
+  PoseArrays A;
+  for (int k = 0; k < 7; k++) A.pt[k] = reinterpret_cast<const double*>(d + Y.pt) + k * Y.NP;
+  for (int k = 0; k < 12; k++) A.le[k] = reinterpret_cast<const double*>(d + Y.le) + k * Y.NE;
+  A.le_line = reinterpret_cast<const int*>(d + Y.le_line);
+  A.le_fl0 = reinterpret_cast<const uint8_t*>(d + Y.le_fl0);
+  A.pt_chi2 = reinterpret_cast<double*>(d + Y.pt_chi2); A.le_chi2 = reinterpret_cast<double*>(d + Y.le_chi2);
+  A.pt_fl = reinterpret_cast<uint8_t*>(d + Y.pt_fl); A.le_fl = reinterpret_cast<uint8_t*>(d + Y.le_fl);
+  A.pt_outlier = reinterpret_cast<uint8_t*>(d + Y.pt_outlier); A.ln_outlier = reinterpret_cast<uint8_t*>(d + Y.ln_outlier);
+  return A;
+}
+
+static int pose_launch(lld_ctx* ctx, int n_frames, char* d_img, const PoseLayout& Y, size_t lds_bytes, bool use_lds, const lld_pose_params& prm) {
+  hipStream_t st = ctx->stream;
+  const PoseFrameDev* fr = reinterpret_cast<const PoseFrameDev*>(d_img + Y.frames);
+  PoseOut* po = reinterpret_cast<PoseOut*>(d_img + Y.out);
+  const PoseArrays A = pose_arrays(d_img, Y);
+  if (use_lds) {
+    LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&pose_opt_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPoseLdsBudget));
+    hipLaunchKernelGGL(pose_opt_kernel<true>, dim3(n_frames), dim3(kPoseThreads), lds_bytes, st, fr, A, po, prm.n_rounds, prm.its_per_round, prm.max_trials);
+  } else {
+    hipLaunchKernelGGL(pose_opt_kernel<false>, dim3(n_frames), dim3(kPoseThreads), 0, st, fr, A, po, prm.n_rounds, prm.its_per_round, prm.max_trials);
+  }
+  LLD_HIP_TRY(hipGetLastError());
+  return LLD_OK;
+}
+
+static void pose_fill_result(const PoseLayout& Y, const char* h_out /* start of the output region */, const PoseFrameDev& F, int frame, lld_pose_result* out) {
+  const PoseOut& o = reinterpret_cast<const PoseOut*>(h_out + (Y.out - Y.in_bytes))[frame];
+  std::memcpy(out->pose_qt, o.qt, sizeof o.qt);
+  out->n_inliers = o.n_inliers; out->lm_iterations = o.lm_iterations; out->lm_trials = o.lm_trials; out->reserved = 0; out->chi2 = o.chi2;
+  if (out->pt_outlier && F.n_pt) std::memcpy(out->pt_outlier, h_out + (Y.pt_outlier - Y.in_bytes) + F.pt_off, F.n_pt);
+  if (out->ln_outlier && F.n_ln) std::memcpy(out->ln_outlier, h_out + (Y.ln_outlier - Y.in_bytes) + F.ln_off, F.n_ln);
+}
+
 struct lld_pose_batch {
   lld_ctx* ctx = nullptr;
   int n_frames = 0;
   lld_pose_params params;
-  void* slab = nullptr;
-  PoseFrameDev* d_frames = nullptr;
-  PoseSoA soa;
-  PoseOut* d_out = nullptr;
+  char* slab = nullptr;
+  PoseLayout lay;
+  size_t lds_bytes = 0;
+  bool use_lds = true;
   std::vector<PoseFrameDev> h_frames;
-  std::vector<PoseOut> h_out;
-  size_t n_pt_total = 0, n_le_total = 0, n_ln_total = 0;
-  uint8_t *d_pt_level = nullptr, *d_pt_robust = nullptr, *d_pt_outlier = nullptr, *d_le_level = nullptr, *d_le_robust = nullptr, *d_ln_outlier = nullptr;
-  std::vector<uint8_t> h_pt_outlier, h_ln_outlier;
-  bool solved = false;
+  std::vector<char> h_out;
+  bool fetched = false;
 };
 
 extern "C" {
@@ -277,120 +530,39 @@ extern "C" {
 int lld_pose_batch_create(lld_ctx* ctx, int n_frames, const lld_pose_problem* frames, const lld_pose_params* params, lld_pose_batch** out) {
   if (!ctx || n_frames <= 0 || !frames || !out) return LLD_ERR_INVALID;
   LLD_HIP_TRY(hipSetDevice(ctx->device));
+  PoseCounts C;
+  int st = pose_count(n_frames, frames, &C); if (st) return st;
   lld_pose_batch* B = new lld_pose_batch();
   B->ctx = ctx; B->n_frames = n_frames;
   if (params) B->params = *params; else lld_pose_params_default(&B->params);
-  const double gamma = B->params.gamma;
-  // host-side expansion (AddLineMinOnlyPose): one left edge per line and a right edge when the line has a stereo match
-  std::vector<double> px, py, pz, u, v, ur, s, x1x, x1y, x1z, x2x, x2y, x2z, xs, ys, xe, ye, ls, lbx;
-  std::vector<int> le_line; std::vector<uint8_t> le_last, has_right;
+  B->use_lds = C.max_lds <= kPoseLdsBudget; B->lds_bytes = B->use_lds ? C.max_lds : 0;
+  B->lay = pose_layout(n_frames, C.np, C.ne, C.nl, !B->use_lds);
   B->h_frames.resize(n_frames);
-  const float dMono = (float)std::sqrt(5.991), dStereo = (float)std::sqrt(7.815);
-  float dLnS = dStereo, dLnM = dMono;
-  dLnS *= gamma; dLnM *= gamma;                                      // float *= double (Optimizer.cc:706-707)
-  for (int f = 0; f < n_frames; f++) {
-    const lld_pose_problem& P = frames[f];
-    if (P.n_points < 0 || P.n_lines < 0) { delete B; return LLD_ERR_INVALID; }
-    PoseFrameDev& F = B->h_frames[f];
-    F.cam = lld::make_camk(P.cam);
-    std::memcpy(F.T0, P.pose_qt, sizeof F.T0);
-    F.pt_off = (int)px.size(); F.n_pt = P.n_points;
-    F.le_off = (int)ls.size(); F.ln_off = (int)has_right.size(); F.n_ln = P.n_lines;
-    F.delta_mono = (double)dMono; F.delta_stereo = (double)dStereo;
-    F.delta_ln_stereo = (double)dLnS; F.delta_ln_mono = (double)dLnM;
-    F.thr_ln_stereo = (double)(dLnS * dLnS); F.thr_ln_mono = (double)(dLnM * dLnM);
-    for (int i = 0; i < P.n_points; i++) {
-      px.push_back(P.pt_xw[3 * i]); py.push_back(P.pt_xw[3 * i + 1]); pz.push_back(P.pt_xw[3 * i + 2]);
-      u.push_back(P.pt_uvr[3 * i]); v.push_back(P.pt_uvr[3 * i + 1]); ur.push_back(P.pt_uvr[3 * i + 2]);
-      s.push_back(P.pt_inv_sigma2[i]);
-    }
-    for (int l = 0; l < P.n_lines; l++) {
-      const double* L = P.ln_left + 4 * l; const double* R = P.ln_right + 4 * l;
-      const bool hr = !(R[0] < 0);
-      has_right.push_back(hr ? 1 : 0);
-      for (int si = 0; si < 2; si++) {
-        if (si == 1 && !hr) continue;
-        const double* kl = si == 0 ? L : R;
-        x1x.push_back(P.ln_x0[3 * l]); x1y.push_back(P.ln_x0[3 * l + 1]); x1z.push_back(P.ln_x0[3 * l + 2]);
-        x2x.push_back(P.ln_x0[3 * l] + P.ln_dir[3 * l]); x2y.push_back(P.ln_x0[3 * l + 1] + P.ln_dir[3 * l + 1]); x2z.push_back(P.ln_x0[3 * l + 2] + P.ln_dir[3 * l + 2]);
-        xs.push_back(kl[0]); ys.push_back(kl[1]); xe.push_back(kl[2]); ye.push_back(kl[3]);
-        ls.push_back(lld::line_info(gamma, P.ln_octave[2 * l + si]));
-        lbx.push_back(si == 1 ? F.cam.bx_right : 0.0);
-        le_line.push_back(l);
-        le_last.push_back((si == 1 || !hr) ? 1 : 0);
-      }
-    }
-    F.n_le = (int)ls.size() - F.le_off;
-  }
-  B->n_pt_total = px.size(); B->n_le_total = ls.size(); B->n_ln_total = has_right.size();
-  const size_t NP = B->n_pt_total + 1, NE = B->n_le_total + 1, NL = B->n_ln_total + 1;
-  size_t bytes = lld_slab::pad(sizeof(PoseFrameDev) * n_frames) + lld_slab::pad(sizeof(PoseOut) * n_frames) + 8 * lld_slab::pad(NP * 8) + 4 * lld_slab::pad(NP) +
-                 13 * lld_slab::pad(NE * 8) + lld_slab::pad(NE * 4) + 3 * lld_slab::pad(NE) + 2 * lld_slab::pad(NL) + 4096;
-  if (hipMalloc(&B->slab, bytes) != hipSuccess) { delete B; return LLD_ERR_ALLOC; }
-  lld_slab sl; sl.base = (char*)B->slab;
-  B->d_frames = sl.take<PoseFrameDev>(n_frames); B->d_out = sl.take<PoseOut>(n_frames);
-  hipStream_t st = ctx->stream;
-  auto up = [&](const std::vector<double>& h, size_t n) { double* d = sl.take<double>(n); if (!h.empty()) (void)hipMemcpyAsync(d, h.data(), h.size() * 8, hipMemcpyHostToDevice, st); return (const double*)d; };
-  PoseSoA& A = B->soa;
-  A.px = up(px, NP); A.py = up(py, NP); A.pz = up(pz, NP); A.u = up(u, NP); A.v = up(v, NP); A.ur = up(ur, NP); A.s = up(s, NP);
-  A.pt_chi2 = sl.take<double>(NP);
-  B->d_pt_level = sl.take<uint8_t>(NP); B->d_pt_robust = sl.take<uint8_t>(NP); B->d_pt_outlier = sl.take<uint8_t>(NP);
-  A.pt_level = B->d_pt_level; A.pt_robust = B->d_pt_robust; A.pt_outlier = B->d_pt_outlier;
-  (void)sl.take<uint8_t>(NP);
-  A.x1x = up(x1x, NE); A.x1y = up(x1y, NE); A.x1z = up(x1z, NE); A.x2x = up(x2x, NE); A.x2y = up(x2y, NE); A.x2z = up(x2z, NE);
-  A.xs = up(xs, NE); A.ys = up(ys, NE); A.xe = up(xe, NE); A.ye = up(ye, NE); A.ls = up(ls, NE); A.lbx = up(lbx, NE);
-  A.le_chi2 = sl.take<double>(NE);
-  int* dl = sl.take<int>(NE); if (!le_line.empty()) (void)hipMemcpyAsync(dl, le_line.data(), le_line.size() * 4, hipMemcpyHostToDevice, st); A.le_line = dl;
-  uint8_t* dlast = sl.take<uint8_t>(NE); if (!le_last.empty()) (void)hipMemcpyAsync(dlast, le_last.data(), le_last.size(), hipMemcpyHostToDevice, st); A.le_last = dlast;
-  B->d_le_level = sl.take<uint8_t>(NE); B->d_le_robust = sl.take<uint8_t>(NE); A.le_level = B->d_le_level; A.le_robust = B->d_le_robust;
-  uint8_t* dhr = sl.take<uint8_t>(NL); if (!has_right.empty()) (void)hipMemcpyAsync(dhr, has_right.data(), has_right.size(), hipMemcpyHostToDevice, st); A.ln_has_right = dhr;
-  B->d_ln_outlier = sl.take<uint8_t>(NL); A.ln_outlier = B->d_ln_outlier;
-  LLD_HIP_TRY(hipMemcpyAsync(B->d_frames, B->h_frames.data(), sizeof(PoseFrameDev) * n_frames, hipMemcpyHostToDevice, st));
-  LLD_HIP_TRY(hipStreamSynchronize(st));       // the host vectors die with this scope
+  std::vector<char> img(B->lay.in_bytes);
+  pose_pack(n_frames, frames, B->params.gamma, B->lay, img.data(), B->h_frames.data());
+  if (hipMalloc(reinterpret_cast<void**>(&B->slab), B->lay.total) != hipSuccess) { delete B; return LLD_ERR_ALLOC; }
+  if (hipMemcpy(B->slab, img.data(), B->lay.in_bytes, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(B->slab); delete B; return LLD_ERR_HIP; }
   *out = B;
   return LLD_OK;
 }
 
 int lld_pose_batch_solve(lld_pose_batch* B) {
   if (!B) return LLD_ERR_INVALID;
-  lld_ctx* ctx = B->ctx;
-  LLD_HIP_TRY(hipSetDevice(ctx->device));
-  hipStream_t st = ctx->stream;
-  // every solve restarts from the uploaded state: level 0, Huber kernels on, nothing flagged
-  LLD_HIP_TRY(hipMemsetAsync(B->d_pt_level, 0, B->n_pt_total + 1, st));
-  LLD_HIP_TRY(hipMemsetAsync(B->d_pt_robust, 1, B->n_pt_total + 1, st));
-  LLD_HIP_TRY(hipMemsetAsync(B->d_pt_outlier, 0, B->n_pt_total + 1, st));
-  LLD_HIP_TRY(hipMemsetAsync(B->d_le_level, 0, B->n_le_total + 1, st));
-  LLD_HIP_TRY(hipMemsetAsync(B->d_le_robust, 1, B->n_le_total + 1, st));
-  LLD_HIP_TRY(hipMemsetAsync(B->d_ln_outlier, 0, B->n_ln_total + 1, st));
-  hipLaunchKernelGGL(pose_opt_kernel, dim3(B->n_frames), dim3(kPoseThreads), 0, st, B->d_frames, B->soa, B->d_out, B->params.n_rounds,
-                     B->params.its_per_round, B->params.max_trials);
-  LLD_HIP_TRY(hipGetLastError());
-  B->solved = false;
-  return LLD_OK;
-}
-
-static int pose_batch_fetch(lld_pose_batch* B) {
-  if (B->solved) return LLD_OK;
-  hipStream_t st = B->ctx->stream;
-  B->h_out.resize(B->n_frames); B->h_pt_outlier.resize(B->n_pt_total + 1); B->h_ln_outlier.resize(B->n_ln_total + 1);
-  LLD_HIP_TRY(hipMemcpyAsync(B->h_out.data(), B->d_out, sizeof(PoseOut) * B->n_frames, hipMemcpyDeviceToHost, st));
-  LLD_HIP_TRY(hipMemcpyAsync(B->h_pt_outlier.data(), B->d_pt_outlier, B->n_pt_total + 1, hipMemcpyDeviceToHost, st));
-  LLD_HIP_TRY(hipMemcpyAsync(B->h_ln_outlier.data(), B->d_ln_outlier, B->n_ln_total + 1, hipMemcpyDeviceToHost, st));
-  LLD_HIP_TRY(hipStreamSynchronize(st));
-  B->solved = true;
-  return LLD_OK;
+  LLD_HIP_TRY(hipSetDevice(B->ctx->device));
+  B->fetched = false;
+  return pose_launch(B->ctx, B->n_frames, B->slab, B->lay, B->lds_bytes, B->use_lds, B->params);   // the kernel resets its own working state
 }
 
 int lld_pose_batch_download(lld_pose_batch* B, int frame, lld_pose_result* out) {
   if (!B || !out || frame < 0 || frame >= B->n_frames) return LLD_ERR_INVALID;
   LLD_HIP_TRY(hipSetDevice(B->ctx->device));
-  int st = pose_batch_fetch(B); if (st) return st;
-  const PoseOut& o = B->h_out[frame]; const PoseFrameDev& F = B->h_frames[frame];
-  std::memcpy(out->pose_qt, o.qt, sizeof o.qt);
-  out->n_inliers = o.n_inliers; out->lm_iterations = o.lm_iterations; out->lm_trials = o.lm_trials; out->reserved = 0; out->chi2 = o.chi2;
-  if (out->pt_outlier && F.n_pt) std::memcpy(out->pt_outlier, B->h_pt_outlier.data() + F.pt_off, F.n_pt);
-  if (out->ln_outlier && F.n_ln) std::memcpy(out->ln_outlier, B->h_ln_outlier.data() + F.ln_off, F.n_ln);
+  if (!B->fetched) {
+    B->h_out.resize(B->lay.out_bytes);
+    LLD_HIP_TRY(hipMemcpyAsync(B->h_out.data(), B->slab + B->lay.in_bytes, B->lay.out_bytes, hipMemcpyDeviceToHost, B->ctx->stream));
+    LLD_HIP_TRY(hipStreamSynchronize(B->ctx->stream));
+    B->fetched = true;
+  }
+  pose_fill_result(B->lay, B->h_out.data(), B->h_frames[frame], frame, out);
   return LLD_OK;
 }
 
@@ -402,14 +574,29 @@ void lld_pose_batch_destroy(lld_pose_batch* B) {
   delete B;
 }
 
+// One frame, host buffers in and out (what the Tracking thread calls three times per frame): the packed image goes through the
+// context's pinned staging and device scratch, i.e. one H2D copy, one kernel, one D2H copy and no allocation in steady state.
 int lld_pose_opt(lld_ctx* ctx, const lld_pose_problem* in, const lld_pose_params* params, lld_pose_result* out) {
   if (!ctx || !in || !out) return LLD_ERR_INVALID;
-  lld_pose_batch* B = nullptr;
-  int st = lld_pose_batch_create(ctx, 1, in, params, &B); if (st) return st;
-  st = lld_pose_batch_solve(B);
-  if (!st) st = lld_pose_batch_download(B, 0, out);
-  lld_pose_batch_destroy(B);
-  return st;
+  LLD_HIP_TRY(hipSetDevice(ctx->device));
+  lld_pose_params prm;
+  if (params) prm = *params; else lld_pose_params_default(&prm);
+  PoseCounts C;
+  int st = pose_count(1, in, &C); if (st) return st;
+  const bool use_lds = C.max_lds <= kPoseLdsBudget;
+  const PoseLayout Y = pose_layout(1, C.np, C.ne, C.nl, !use_lds);
+  void* hb; st = lld_ctx_pinned(ctx, Y.in_bytes + Y.out_bytes, &hb); if (st) return st;
+  void* db; st = lld_ctx_scratch(ctx, Y.total, &db); if (st) return st;
+  char* h_img = static_cast<char*>(hb); char* d_img = static_cast<char*>(db);
+  PoseFrameDev F;
+  pose_pack(1, in, prm.gamma, Y, h_img, &F);
+  hipStream_t s = ctx->stream;
+  LLD_HIP_TRY(hipMemcpyAsync(d_img, h_img, Y.in_bytes, hipMemcpyHostToDevice, s));
+  st = pose_launch(ctx, 1, d_img, Y, use_lds ? C.max_lds : 0, use_lds, prm); if (st) return st;
+  LLD_HIP_TRY(hipMemcpyAsync(h_img + Y.in_bytes, d_img + Y.in_bytes, Y.out_bytes, hipMemcpyDeviceToHost, s));
+  LLD_HIP_TRY(hipStreamSynchronize(s));
+  pose_fill_result(Y, h_img + Y.in_bytes, F, 0, out);
+  return LLD_OK;
 }
 
 }  // extern "C"

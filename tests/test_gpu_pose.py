@@ -57,3 +57,23 @@ def test_pose_batch_ragged_frames(gpu_ctx, oracle):
             b.solve()
             for i, f in enumerate(frames):
                 _check(b.download(i), oracle.pose_opt(f, gamma=0.5), f.n_points)
+
+
+def test_pose_frame_larger_than_lds(gpu_ctx, oracle):
+    """3000 points + 500 lines do not fit the CU's LDS: the kernel runs on its HBM-resident working arrays instead."""
+    f = synth.make_pose_frame(40, n_points=3000, n_lines=500)
+    _check(Optimizer(gpu_ctx).PoseOptimization(f, gamma=0.5), oracle.pose_opt(f, gamma=0.5), f.n_points)
+    # a batch takes the mode of its largest frame
+    frames = [synth.make_pose_frame(41, n_points=200, n_lines=30), f]
+    with PoseBatch(gpu_ctx, frames, gamma=0.5) as b:
+        b.solve()
+        for i, fr in enumerate(frames):
+            _check(b.download(i), oracle.pose_opt(fr, gamma=0.5), fr.n_points)
+
+
+def test_pose_single_calls_reuse_context_buffers(gpu_ctx, oracle):
+    """lld_pose_opt stages through the context's pinned / device scratch: sizes going up and down must not leak state."""
+    opt = Optimizer(gpu_ctx)
+    for fid, n, m in [(50, 300, 40), (51, 1000, 200), (52, 20, 0), (50, 300, 40)]:
+        f = synth.make_pose_frame(fid, n_points=n, n_lines=m)
+        _check(opt.PoseOptimization(f, gamma=0.5), oracle.pose_opt(f, gamma=0.5), f.n_points)
