@@ -68,6 +68,29 @@ __device__ __forceinline__ double block_sum1(double x, double* lds /* [kPoseWave
   return s;
 }
 
+// Sum of 28 values per lane over the wavefront with a halving butterfly: at every step a lane keeps one half of its values and
+// sends the other half to its partner, so 14 + 7 + 4 + 2 + 1 + 1 = 29 shuffles do the work of 28 x 6.  The totals land in
+// dst[0..27] (LDS).  Fixed tree, hence deterministic.
+__device__ __forceinline__ void wave_sum28(const double* v, double* dst) {
+  const int lane = threadIdx.x & 63;
+  const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8, b2 = lane & 4, b1 = lane & 2;
+  double s[14], t[8], u[4], w[2];
+#pragma unroll
+  for (int i = 0; i < 14; i++) { const double keep = b5 ? v[i + 14] : v[i], send = b5 ? v[i] : v[i + 14]; s[i] = keep + __shfl_xor(send, 32); }
+#pragma unroll
+  for (int i = 0; i < 7; i++) { const double keep = b4 ? s[i + 7] : s[i], send = b4 ? s[i] : s[i + 7]; t[i] = keep + __shfl_xor(send, 16); }
+  t[7] = 0.0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) { const double keep = b3 ? t[i + 4] : t[i], send = b3 ? t[i] : t[i + 4]; u[i] = keep + __shfl_xor(send, 8); }
+#pragma unroll
+  for (int i = 0; i < 2; i++) { const double keep = b2 ? u[i + 2] : u[i], send = b2 ? u[i] : u[i + 2]; w[i] = keep + __shfl_xor(send, 4); }
+  const double keep = b1 ? w[1] : w[0], send = b1 ? w[0] : w[1];
+  double r = keep + __shfl_xor(send, 2);
+  r += __shfl_xor(r, 1);
+  const int sub = (b3 ? 4 : 0) + (b2 ? 2 : 0) + (b1 ? 1 : 0);
+  if (!(lane & 1) && sub < 7) dst[(b5 ? 14 : 0) + (b4 ? 7 : 0) + sub] = r;
+}
+
 // Dense LDL^T of the 6x6 system (LinearSolverDense, solvers/linear_solver_dense.h:65-113): fails unless all pivots > 0.
 __device__ __forceinline__ bool solve6(const double* Hu /*21 upper, row-major packed*/, double lambda, const double* b, double* x) {
   double A[6][6];
@@ -82,18 +105,20 @@ __device__ __forceinline__ bool solve6(const double* Hu /*21 upper, row-major pa
 #pragma unroll
   for (int i = 0; i < 6; i++) A[i][i] += lambda;
   bool ok = true;
+  double inv[6];                                                    // one division per pivot (the columns and y are scaled by it)
 #pragma unroll
   for (int j = 0; j < 6; j++) {
     double d = A[j][j];
 #pragma unroll
     for (int p = 0; p < j; p++) d -= A[j][p] * A[j][p] * A[p][p];
     if (!(d > 0.0) || !isfinite(d)) ok = false;
+    inv[j] = 1.0 / d;
 #pragma unroll
     for (int i = j + 1; i < 6; i++) {
       double s = A[i][j];
 #pragma unroll
       for (int p = 0; p < j; p++) s -= A[i][p] * A[j][p] * A[p][p];
-      A[i][j] = s / d;
+      A[i][j] = s * inv[j];
     }
     A[j][j] = d;
   }
@@ -106,7 +131,7 @@ __device__ __forceinline__ bool solve6(const double* Hu /*21 upper, row-major pa
     y[i] = s;
   }
 #pragma unroll
-  for (int i = 0; i < 6; i++) y[i] /= A[i][i];
+  for (int i = 0; i < 6; i++) y[i] *= inv[i];
 #pragma unroll
   for (int i = 5; i >= 0; i--) {
     double s = y[i];
@@ -280,12 +305,8 @@ __global__ __launch_bounds__(kPoseThreads) void pose_opt_kernel(const PoseFrameD
           {
             double acc[28];
             sweep_build(T, acc);
-            wave_sum_all<28>(acc);
             __syncthreads();                                         // previous readers of red / tot / sol are done
-            if ((tid & 63) == 0) {
-#pragma unroll
-              for (int i = 0; i < 28; i++) red[(tid >> 6) * 28 + i] = acc[i];
-            }
+            wave_sum28(acc, red + (tid >> 6) * 28);
             __syncthreads();
             if (tid < 28) {
               double sv = red[tid];
