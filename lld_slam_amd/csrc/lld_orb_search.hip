@@ -49,6 +49,7 @@ struct Problem {
   int candidates, gates, tie_last, accept_max, ratio_mode; float nnratio; int sequential, check_orientation;
   int32_t* match; int32_t* best_dist; int32_t* second_dist; uint8_t* removed; int32_t* owner; int32_t* summary;   // summary: n_matches, rounds
   int desc_in_lds, want_owner;
+  unsigned long long* cache;   // [nq][4] device scratch of sequential problems: the four smallest candidate keys of round 1
 };
 
 template <class Ptr>
@@ -62,16 +63,26 @@ __device__ __forceinline__ void top2_insert(unsigned long long c, unsigned long 
   if (c < b1) { b2 = b1; b1 = c; } else if (c < b2) { b2 = c; }
 }
 
+// the four smallest keys, ascending
+__device__ __forceinline__ void top4_insert(unsigned long long k, unsigned long long (&c)[4]) {
+  if (k < c[3]) {
+    c[3] = k;
+    if (c[3] < c[2]) { const unsigned long long t = c[2]; c[2] = c[3]; c[3] = t; }
+    if (c[2] < c[1]) { const unsigned long long t = c[1]; c[1] = c[2]; c[2] = t; }
+    if (c[1] < c[0]) { const unsigned long long t = c[0]; c[0] = c[1]; c[1] = t; }
+  }
+}
+
 __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int m) {
   const int lo = __shfl_xor((int)(v & 0xffffffffu), m), hi = __shfl_xor((int)(v >> 32), m);
   return ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
 }
 
 // Per-candidate skip rules that do not depend on how the candidate was produced.
-__device__ __forceinline__ bool gates_pass(const Problem& P, const QRec& Q, const TKey& T, int q, const int* blk) {
+__device__ __forceinline__ bool gates_pass(const Problem& P, const QRec& Q, const TKey& T, int q, const int* blk, bool use_blk, const float* lvl /* LDS: scale[16], sigma2[16], inv_sigma2[16] */) {
   const int m = T.meta;
   if (tk_occ(m)) return false;
-  if (P.sequential && blk[tk_idx(m)] < q) return false;
+  if (use_blk && blk[tk_idx(m)] < q) return false;
   const int oct = tk_oct(m);
   if (P.gates & LLD_ORB_GATE_LEVEL) {                                     // Frame.cc:422-430, ORBmatcher.cc:386,907
     if (oct < Q.level_min) return false;
@@ -86,9 +97,9 @@ __device__ __forceinline__ bool gates_pass(const Problem& P, const QRec& Q, cons
     if (T.ur >= 0.f) {
       const float er = __fsub_rn(Q.ur, T.ur);
       e2 = __fadd_rn(e2, __fmul_rn(er, er));
-      if ((double)__fmul_rn(e2, P.inv_sigma2[oct]) > 7.8) return false;
+      if ((double)__fmul_rn(e2, lvl[32 + oct]) > 7.8) return false;
     } else {
-      if ((double)__fmul_rn(e2, P.inv_sigma2[oct]) > 5.99) return false;
+      if ((double)__fmul_rn(e2, lvl[32 + oct]) > 5.99) return false;
     }
   }
   if (P.gates & LLD_ORB_GATE_EPIPOLAR) {                                  // ORBmatcher.cc:720-751, 138-157
@@ -96,13 +107,13 @@ __device__ __forceinline__ bool gates_pass(const Problem& P, const QRec& Q, cons
     if (P.only_stereo && !s2) return false;
     if (!s1 && !s2) {
       const float dx = __fsub_rn(P.epi_x, T.x), dy = __fsub_rn(P.epi_y, T.y);
-      if (__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)) < __fmul_rn(100.f, P.scale[oct])) return false;
+      if (__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)) < __fmul_rn(100.f, lvl[oct])) return false;
     }
     const float num = __fadd_rn(__fadd_rn(__fmul_rn(Q.ea, T.x), __fmul_rn(Q.eb, T.y)), Q.ec);
     const float den = __fadd_rn(__fmul_rn(Q.ea, Q.ea), __fmul_rn(Q.eb, Q.eb));
     if (den == 0.f) return false;
     const float dsqr = __fdiv_rn(__fmul_rn(num, num), den);
-    if (!((double)dsqr < 3.84 * (double)P.sigma2[oct])) return false;
+    if (!((double)dsqr < 3.84 * (double)lvl[16 + oct])) return false;
   }
   return true;
 }
@@ -122,6 +133,7 @@ __global__ __launch_bounds__(kThreads) void orb_search_kernel(const Problem* __r
   int* ctl = hist + 32;                                                         // [8]: 0 changed, 1 accepted, 2 removed, 3..5 kept bins
   int* scan = ctl + 8;                                                          // [kThreads]
   int* cursor = scan + kThreads;                                                // [n_cells] (bucketed modes only)
+  float* lvl = reinterpret_cast<float*>(cursor + (bucketed ? n_cells : 0));     // [48] level tables: scale, sigma2, 1/sigma2
 
   // ---------------------------------------------------------------- keypoints into LDS (+ grid counting sort)
   auto load_key = [&](int k, int& cell) -> TKey {
@@ -148,6 +160,7 @@ __global__ __launch_bounds__(kThreads) void orb_search_kernel(const Problem* __r
   for (int k = tid; k < nt; k += kThreads) blk[k] = 0x7fffffff;
   if (tid < 32) hist[tid] = 0;
   if (tid < 8) ctl[tid] = 0;
+  if (tid < LLD_ORB_MAX_LEVELS) { lvl[tid] = P.scale[tid]; lvl[16 + tid] = P.sigma2[tid]; lvl[32 + tid] = P.inv_sigma2[tid]; }
   __syncthreads();
   for (int k = tid; k < nt; k += kThreads) {
     int cell; const TKey T = load_key(k, cell);
@@ -188,17 +201,48 @@ __global__ __launch_bounds__(kThreads) void orb_search_kernel(const Problem* __r
     for (int q = tid; q < nq; q += kThreads) {
       const QRec Q = P.q[q];
       unsigned long long b1 = kNone, b2 = kNone;
+      auto decode = [&](unsigned long long c) -> int {
+        unsigned key = (unsigned)(c & 0xffffffffu);
+        if (P.tie_last) key = ~key;
+        if (grid) return (int)(key & 4095u);
+        if (P.candidates == LLD_ORB_CAND_CSR) return P.cand_idx[Q.cs + (int)key];
+        return (int)key;
+      };
       if (Q.flags & 1) {
+        // The candidates of a query, sorted by key, do not depend on the round; only which of them are blocked does.  Round 1
+        // keeps the four smallest keys; later rounds take the first two unblocked ones from that list and rescan only when
+        // the list was full and fewer than two of its entries are still free.
+        unsigned long long c[4] = {kNone, kNone, kNone, kNone};
+        auto pick = [&]() {
+          int found = 0; b1 = kNone; b2 = kNone;
+          auto take = [&](unsigned long long k) {
+            if (k != kNone && !(P.sequential && blk[decode(k)] < q)) {
+              b1 = found == 0 ? k : b1; b2 = found == 1 ? k : b2;          // selects, so that b1 / b2 stay in registers
+              found++;
+            }
+          };
+          take(c[0]); take(c[1]); take(c[2]); take(c[3]);
+          return found;
+        };
+        bool need_scan = rounds == 1;
+        if (rounds > 1) {
+          const ulonglong2 c01 = *reinterpret_cast<const ulonglong2*>(P.cache + 4 * (size_t)q), c23 = *reinterpret_cast<const ulonglong2*>(P.cache + 4 * (size_t)q + 2);
+          c[0] = c01.x; c[1] = c01.y; c[2] = c23.x; c[3] = c23.y;
+          need_scan = pick() < 2 && c[3] != kNone;
+        }
+        if (need_scan) {
+        const bool use_blk = rounds > 1;
+        c[0] = kNone; c[1] = kNone; c[2] = kNone; c[3] = kNone;
         uint32_t qd[8];
         {
           const uint4 a = *reinterpret_cast<const uint4*>(P.q_desc + 8 * (size_t)q), b = *reinterpret_cast<const uint4*>(P.q_desc + 8 * (size_t)q + 4);
           qd[0] = a.x; qd[1] = a.y; qd[2] = a.z; qd[3] = a.w; qd[4] = b.x; qd[5] = b.y; qd[6] = b.z; qd[7] = b.w;
         }
         auto visit = [&](int pos, const TKey& T, unsigned key) {
-          if (!gates_pass(P, Q, T, q, blk)) return;
+          if (!gates_pass(P, Q, T, q, blk, use_blk, lvl)) return;
           const int d = P.desc_in_lds ? hamming256(qd, dsc + 8 * (size_t)pos) : hamming256(qd, P.t_desc + 8 * (size_t)tk_idx(T.meta));
           if (P.tie_last) key = ~key;
-          top2_insert(((unsigned long long)d << 32) | key, b1, b2);
+          top4_insert(((unsigned long long)d << 32) | key, c);
         };
         if (grid) {
           // GetFeaturesInArea cell range, src/Frame.cc:396-410 (float arithmetic, floor/ceil, clamps and early returns)
@@ -228,12 +272,12 @@ __global__ __launch_bounds__(kThreads) void orb_search_kernel(const Problem* __r
           const long long row = (long long)Q.v;                                                                    // vRowIndices[vL], :569
           if (!(maxU < 0.f)) {                                                                                     // :577-578
             float rmax = 0.f;
-            for (int l = 0; l < LLD_ORB_MAX_LEVELS; l++) rmax = fmaxf(rmax, __fmul_rn(2.0f, P.scale[l]));
+            for (int l = 0; l < LLD_ORB_MAX_LEVELS; l++) rmax = fmaxf(rmax, __fmul_rn(2.0f, lvl[l]));
             const long long margin = (long long)ceilf(rmax) + 2;
             const int lo = (int)min(max(row - margin, 0ll), (long long)n_cells - 1), hi = (int)min(max(row + margin, 0ll), (long long)n_cells - 1);
             for (int j = cell_start[lo]; j < cell_start[hi + 1]; j++) {
               const TKey T = tk[j];
-              const float r = __fmul_rn(2.0f, P.scale[tk_oct(T.meta)]);
+              const float r = __fmul_rn(2.0f, lvl[tk_oct(T.meta)]);
               const long long maxr = (long long)ceilf(__fadd_rn(T.y, r)), minr = (long long)floorf(__fsub_rn(T.y, r));
               if (row < minr || row > maxr) continue;
               if (!(T.x >= minU && T.x <= maxU)) continue;                                                         // :594-596
@@ -243,14 +287,13 @@ __global__ __launch_bounds__(kThreads) void orb_search_kernel(const Problem* __r
         } else {
           for (int k = 0; k < nt; k++) visit(k, tk[k], (unsigned)k);
         }
+        if (rounds == 1 && P.sequential) {
+          *reinterpret_cast<ulonglong2*>(P.cache + 4 * (size_t)q) = make_ulonglong2(c[0], c[1]);
+          *reinterpret_cast<ulonglong2*>(P.cache + 4 * (size_t)q + 2) = make_ulonglong2(c[2], c[3]);
+        }
+        pick();
+        }
       }
-      auto decode = [&](unsigned long long c) -> int {
-        unsigned key = (unsigned)(c & 0xffffffffu);
-        if (P.tie_last) key = ~key;
-        if (grid) return (int)(key & 4095u);
-        if (P.candidates == LLD_ORB_CAND_CSR) return P.cand_idx[Q.cs + (int)key];
-        return (int)key;
-      };
       int m = -1, bd = 256, sd = 256;
       if (b1 != kNone) {
         bd = (int)(b1 >> 32);
@@ -499,7 +542,7 @@ constexpr int kRowBuckets = 1024;          // ROWS mode: one bucket per image ro
 
 size_t lds_bytes(int nt, int n_cells, bool grid, bool desc) {
   return (size_t)nt * sizeof(TKey) + (desc ? (size_t)nt * 32 : 0) + (size_t)nt * 4 + (size_t)(n_cells + 1) * 4 + 32 * 4 + 8 * 4 + kThreads * 4 +
-         (grid ? (size_t)n_cells * 4 : 0) + 16;
+         (grid ? (size_t)n_cells * 4 : 0) + 48 * 4 + 16;
 }
 
 int validate(const lld_orb_search* s, const lld_orb_search_result* out) {
@@ -572,10 +615,15 @@ extern "C" int lld_orb_search_batch(lld_ctx* ctx, int n, const lld_orb_search* p
     L.out_end = out_off;
   }
   const size_t in_bytes = in_off, out_bytes = out_off;
+  // device-only scratch behind the output region: the round-1 candidate cache of the sequential problems
+  std::vector<size_t> cache_at((size_t)n);
+  size_t cache_bytes = 0;
+  for (int i = 0; i < n; i++) { cache_at[i] = cache_bytes; if (problems[i].sequential) cache_bytes += al((size_t)problems[i].nq * 32); }
   void* hbase; int st = lld_ctx_pinned(ctx, in_bytes + out_bytes, &hbase); if (st) return st;
-  void* dbase; st = lld_ctx_scratch(ctx, in_bytes + out_bytes + 256, &dbase); if (st) return st;
+  void* dbase; st = lld_ctx_scratch(ctx, in_bytes + out_bytes + cache_bytes + 256, &dbase); if (st) return st;
   char* h = (char*)hbase; char* d = (char*)dbase;
   char* d_out = d + in_bytes; char* h_out = h + in_bytes;
+  char* d_cache = d_out + out_bytes;
 
   for (int i = 0; i < n; i++) {
     const lld_orb_search& s = problems[i]; const Layout& L = lay[i];
@@ -630,6 +678,7 @@ extern "C" int lld_orb_search_batch(lld_ctx* ctx, int n, const lld_orb_search* p
     P.second_dist = reinterpret_cast<int32_t*>(d_out + L.sd); P.removed = reinterpret_cast<uint8_t*>(d_out + L.rem);
     P.owner = reinterpret_cast<int32_t*>(d_out + L.owner); P.summary = reinterpret_cast<int32_t*>(d_out + L.sum);
     P.want_owner = outs[i].owner != nullptr;
+    P.cache = reinterpret_cast<unsigned long long*>(d_cache + cache_at[i]);
     const bool bucketed = grid || s.candidates == LLD_ORB_CAND_ROWS;
     P.desc_in_lds = lds_bytes(nt, P.cols * P.rows, bucketed, true) <= kLdsLimit;
     lds_max = std::max(lds_max, lds_bytes(nt, P.cols * P.rows, bucketed, P.desc_in_lds != 0));
@@ -696,7 +745,7 @@ struct ProjSearch {
   }
   int alloc() {
     void* hb; int st = lld_ctx_pinned(ctx, in + out, &hb); if (st) return st;
-    void* db; st = lld_ctx_scratch(ctx, in + out + 256, &db); if (st) return st;
+    void* db; st = lld_ctx_scratch(ctx, in + out + al((size_t)nq * 32) + 256, &db); if (st) return st;   // + the round-1 candidate cache
     h = (char*)hb; d = (char*)db; h_out = h + in; d_out = d + in;
     return LLD_OK;
   }
@@ -726,6 +775,7 @@ struct ProjSearch {
     P.second_dist = reinterpret_cast<int32_t*>(d_out + r_sd); P.removed = reinterpret_cast<uint8_t*>(d_out + r_rem);
     P.owner = reinterpret_cast<int32_t*>(d_out + r_owner); P.summary = reinterpret_cast<int32_t*>(d_out + r_sum);
     P.want_owner = want_owner;
+    P.cache = reinterpret_cast<unsigned long long*>(d_out + out);
     P.desc_in_lds = lds_bytes(nt, P.cols * P.rows, true, true) <= kLdsLimit;
     return P;
   }
