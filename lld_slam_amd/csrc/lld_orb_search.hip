@@ -49,7 +49,7 @@ struct Problem {
   int candidates, gates, tie_last, accept_max, ratio_mode; float nnratio; int sequential, check_orientation;
   int32_t* match; int32_t* best_dist; int32_t* second_dist; uint8_t* removed; int32_t* owner; int32_t* summary;   // summary: n_matches, rounds
   int desc_in_lds, want_owner;
-  unsigned long long* cache;   // [nq][4] device scratch of sequential problems: the four smallest candidate keys of round 1
+  unsigned long long* cache;   // [nq][kTopK] device scratch of sequential problems: the smallest candidate keys of round 1
 };
 
 template <class Ptr>
@@ -63,13 +63,16 @@ __device__ __forceinline__ void top2_insert(unsigned long long c, unsigned long 
   if (c < b1) { b2 = b1; b1 = c; } else if (c < b2) { b2 = c; }
 }
 
-// the four smallest keys, ascending
-__device__ __forceinline__ void top4_insert(unsigned long long k, unsigned long long (&c)[4]) {
-  if (k < c[3]) {
-    c[3] = k;
-    if (c[3] < c[2]) { const unsigned long long t = c[2]; c[2] = c[3]; c[3] = t; }
-    if (c[2] < c[1]) { const unsigned long long t = c[1]; c[1] = c[2]; c[2] = t; }
-    if (c[1] < c[0]) { const unsigned long long t = c[0]; c[0] = c[1]; c[1] = t; }
+// the kTopK smallest keys, ascending
+constexpr int kTopK = 8;
+__device__ __forceinline__ void topk_insert(unsigned long long k, unsigned long long (&c)[kTopK]) {
+  if (k < c[kTopK - 1]) {
+    c[kTopK - 1] = k;
+#pragma unroll
+    for (int i = kTopK - 1; i > 0; i--) {
+      const unsigned long long lo = c[i] < c[i - 1] ? c[i] : c[i - 1], hi = c[i] < c[i - 1] ? c[i - 1] : c[i];
+      c[i - 1] = lo; c[i] = hi;
+    }
   }
 }
 
@@ -132,8 +135,7 @@ __global__ __launch_bounds__(kThreads) void orb_search_kernel(const Problem* __r
   int* hist = cell_start + n_cells + 1;                                         // [32]
   int* ctl = hist + 32;                                                         // [8]: 0 changed, 1 accepted, 2 removed, 3..5 kept bins
   int* scan = ctl + 8;                                                          // [kThreads]
-  int* cursor = scan + kThreads;                                                // [n_cells] (bucketed modes only)
-  float* lvl = reinterpret_cast<float*>(cursor + (bucketed ? n_cells : 0));     // [48] level tables: scale, sigma2, 1/sigma2
+  float* lvl = reinterpret_cast<float*>(scan + kThreads);                       // [48] level tables: scale, sigma2, 1/sigma2
 
   // ---------------------------------------------------------------- keypoints into LDS (+ grid counting sort)
   auto load_key = [&](int k, int& cell) -> TKey {
@@ -142,8 +144,8 @@ __global__ __launch_bounds__(kThreads) void orb_search_kernel(const Problem* __r
     if (grid) {                                                                 // Frame::PosInGrid, src/Frame.cc:446-456
       const int px = (int)roundf(__fmul_rn(__fsub_rn(T.x, P.min_x), P.winv)), py = (int)roundf(__fmul_rn(__fsub_rn(T.y, P.min_y), P.hinv));
       if (px >= 0 && px < P.cols && py >= 0 && py < P.rows) cell = px * P.rows + py;
-    } else if (rows) {                                                          // bucket = image row of the keypoint (search aid only)
-      cell = min(max((int)floorf(T.y), 0), n_cells - 1);
+    } else if (rows) {                                                          // bucket = (octave, image row) of the keypoint (search aid only)
+      cell = min(P.t_octave[k], P.cols - 1) * P.rows + min(max((int)floorf(T.y), 0), P.rows - 1);
     }
     T.meta = (P.t_octave[k] & 15) | (k << 4) | ((cell + 1) << 16) | ((P.t_occupied && P.t_occupied[k]) ? (1 << 29) : 0);
     return T;
@@ -169,26 +171,26 @@ __global__ __launch_bounds__(kThreads) void orb_search_kernel(const Problem* __r
   }
   __syncthreads();
   if (bucketed) {
-    // exclusive scan of the cell counts (each thread owns a contiguous run of cells), then an unordered placement:
-    // the position inside a cell is irrelevant because ties are broken by the key, not by the visit position
+    // scan of the cell counts (each thread owns a contiguous run of cells) into cell ENDS, then an unordered placement that
+    // counts every cell's end down to its start - one array serves as counter, cursor and final cell_start (end of cell c =
+    // start of cell c + 1).  The position inside a cell is irrelevant: ties are broken by the key, not by the visit position.
     const int per = (n_cells + kThreads - 1) / kThreads, c0 = min(tid * per, n_cells), c1 = min(c0 + per, n_cells);
     int sum = 0;
     for (int c = c0; c < c1; c++) sum += cell_start[c];
-    scan[tid] = sum;
+    // block-wide exclusive prefix of the per-thread sums: shuffle scan inside the wavefront + the 16 wavefront totals
+    int incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off); if ((tid & 63) >= off) incl += t; }
+    if ((tid & 63) == 63) scan[tid >> 6] = incl;
     __syncthreads();
-    for (int off = 1; off < kThreads; off <<= 1) {
-      const int v = (tid >= off) ? scan[tid - off] : 0;
-      __syncthreads();
-      scan[tid] += v;
-      __syncthreads();
-    }
-    int run = scan[tid] - sum;
-    for (int c = c0; c < c1; c++) { const int n = cell_start[c]; cell_start[c] = run; cursor[c] = run; run += n; }
-    if (tid == kThreads - 1) cell_start[n_cells] = scan[kThreads - 1];
+    int run = incl - sum, total = 0;
+    for (int w = 0; w < kThreads / 64; w++) { const int t = scan[w]; if (w < (tid >> 6)) run += t; total += t; }
+    for (int c = c0; c < c1; c++) { run += cell_start[c]; cell_start[c] = run; }
+    if (tid == kThreads - 1) cell_start[n_cells] = total;
     __syncthreads();
     for (int k = tid; k < nt; k += kThreads) {
       int cell; const TKey T = load_key(k, cell);
-      if (cell >= 0) place(atomicAdd(&cursor[cell], 1), k, T);
+      if (cell >= 0) place(atomicSub(&cell_start[cell], 1) - 1, k, T);
     }
   }
   for (int q = tid; q < nq; q += kThreads) P.match[q] = -2;
@@ -210,9 +212,11 @@ __global__ __launch_bounds__(kThreads) void orb_search_kernel(const Problem* __r
       };
       if (Q.flags & 1) {
         // The candidates of a query, sorted by key, do not depend on the round; only which of them are blocked does.  Round 1
-        // keeps the four smallest keys; later rounds take the first two unblocked ones from that list and rescan only when
+        // keeps the kTopK smallest keys; later rounds take the first two unblocked ones from that list and rescan only when
         // the list was full and fewer than two of its entries are still free.
-        unsigned long long c[4] = {kNone, kNone, kNone, kNone};
+        unsigned long long c[kTopK];
+#pragma unroll
+        for (int i = 0; i < kTopK; i++) c[i] = kNone;
         auto pick = [&]() {
           int found = 0; b1 = kNone; b2 = kNone;
           auto take = [&](unsigned long long k) {
@@ -221,18 +225,23 @@ __global__ __launch_bounds__(kThreads) void orb_search_kernel(const Problem* __r
               found++;
             }
           };
-          take(c[0]); take(c[1]); take(c[2]); take(c[3]);
+#pragma unroll
+          for (int i = 0; i < kTopK; i++) take(c[i]);
           return found;
         };
         bool need_scan = rounds == 1;
         if (rounds > 1) {
-          const ulonglong2 c01 = *reinterpret_cast<const ulonglong2*>(P.cache + 4 * (size_t)q), c23 = *reinterpret_cast<const ulonglong2*>(P.cache + 4 * (size_t)q + 2);
-          c[0] = c01.x; c[1] = c01.y; c[2] = c23.x; c[3] = c23.y;
-          need_scan = pick() < 2 && c[3] != kNone;
+#pragma unroll
+          for (int i = 0; i < kTopK; i += 2) {
+            const ulonglong2 t2 = *reinterpret_cast<const ulonglong2*>(P.cache + kTopK * (size_t)q + i);
+            c[i] = t2.x; c[i + 1] = t2.y;
+          }
+          need_scan = pick() < 2 && c[kTopK - 1] != kNone;
         }
         if (need_scan) {
         const bool use_blk = rounds > 1;
-        c[0] = kNone; c[1] = kNone; c[2] = kNone; c[3] = kNone;
+#pragma unroll
+        for (int i = 0; i < kTopK; i++) c[i] = kNone;
         uint32_t qd[8];
         {
           const uint4 a = *reinterpret_cast<const uint4*>(P.q_desc + 8 * (size_t)q), b = *reinterpret_cast<const uint4*>(P.q_desc + 8 * (size_t)q + 4);
@@ -242,7 +251,7 @@ __global__ __launch_bounds__(kThreads) void orb_search_kernel(const Problem* __r
           if (!gates_pass(P, Q, T, q, blk, use_blk, lvl)) return;
           const int d = P.desc_in_lds ? hamming256(qd, dsc + 8 * (size_t)pos) : hamming256(qd, P.t_desc + 8 * (size_t)tk_idx(T.meta));
           if (P.tie_last) key = ~key;
-          top4_insert(((unsigned long long)d << 32) | key, c);
+          topk_insert(((unsigned long long)d << 32) | key, c);
         };
         if (grid) {
           // GetFeaturesInArea cell range, src/Frame.cc:396-410 (float arithmetic, floor/ceil, clamps and early returns)
@@ -271,25 +280,30 @@ __global__ __launch_bounds__(kThreads) void orb_search_kernel(const Problem* __r
           const float minU = __fsub_rn(Q.u, P.disp_max), maxU = __fsub_rn(Q.u, P.disp_min);                       // Frame.cc:574-575
           const long long row = (long long)Q.v;                                                                    // vRowIndices[vL], :569
           if (!(maxU < 0.f)) {                                                                                     // :577-578
-            float rmax = 0.f;
-            for (int l = 0; l < LLD_ORB_MAX_LEVELS; l++) rmax = fmaxf(rmax, __fmul_rn(2.0f, lvl[l]));
-            const long long margin = (long long)ceilf(rmax) + 2;
-            const int lo = (int)min(max(row - margin, 0ll), (long long)n_cells - 1), hi = (int)min(max(row + margin, 0ll), (long long)n_cells - 1);
-            for (int j = cell_start[lo]; j < cell_start[hi + 1]; j++) {
-              const TKey T = tk[j];
-              const float r = __fmul_rn(2.0f, lvl[tk_oct(T.meta)]);
-              const long long maxr = (long long)ceilf(__fadd_rn(T.y, r)), minr = (long long)floorf(__fsub_rn(T.y, r));
-              if (row < minr || row > maxr) continue;
-              if (!(T.x >= minU && T.x <= maxU)) continue;                                                         // :594-596
-              visit(j, T, (unsigned)tk_idx(T.meta));
+            // buckets are (octave, row): only the octaves the level gate admits are scanned, each with its own row margin
+            int o_lo = 0, o_hi = P.cols - 1;
+            if (P.gates & LLD_ORB_GATE_LEVEL) { o_lo = min(max(Q.level_min, 0), P.cols - 1); if (Q.level_max >= 0) o_hi = min(Q.level_max, P.cols - 1); }
+            for (int o = o_lo; o <= o_hi; o++) {
+              float rmax = __fmul_rn(2.0f, lvl[o]);
+              if (o == P.cols - 1) for (int l = o + 1; l < LLD_ORB_MAX_LEVELS; l++) rmax = fmaxf(rmax, __fmul_rn(2.0f, lvl[l]));   // clamped octaves
+              const long long margin = (long long)ceilf(rmax) + 2;
+              const int lo = (int)min(max(row - margin, 0ll), (long long)P.rows - 1), hi = (int)min(max(row + margin, 0ll), (long long)P.rows - 1);
+              for (int j = cell_start[o * P.rows + lo]; j < cell_start[o * P.rows + hi + 1]; j++) {
+                const TKey T = tk[j];
+                const float r = __fmul_rn(2.0f, lvl[tk_oct(T.meta)]);
+                const long long maxr = (long long)ceilf(__fadd_rn(T.y, r)), minr = (long long)floorf(__fsub_rn(T.y, r));
+                if (row < minr || row > maxr) continue;
+                if (!(T.x >= minU && T.x <= maxU)) continue;                                                       // :594-596
+                visit(j, T, (unsigned)tk_idx(T.meta));
+              }
             }
           }
         } else {
           for (int k = 0; k < nt; k++) visit(k, tk[k], (unsigned)k);
         }
         if (rounds == 1 && P.sequential) {
-          *reinterpret_cast<ulonglong2*>(P.cache + 4 * (size_t)q) = make_ulonglong2(c[0], c[1]);
-          *reinterpret_cast<ulonglong2*>(P.cache + 4 * (size_t)q + 2) = make_ulonglong2(c[2], c[3]);
+#pragma unroll
+          for (int i = 0; i < kTopK; i += 2) *reinterpret_cast<ulonglong2*>(P.cache + kTopK * (size_t)q + i) = make_ulonglong2(c[i], c[i + 1]);
         }
         pick();
         }
@@ -538,11 +552,11 @@ __global__ __launch_bounds__(256) void project_fuse_kernel(FuseArgs F) {
 }
 
 constexpr size_t kLdsLimit = 160 * 1024 - 512;
-constexpr int kRowBuckets = 1024;          // ROWS mode: one bucket per image row, rows beyond are clamped into the last bucket
+constexpr int kRowBuckets = 512;           // ROWS mode: one bucket per (octave, image row); rows beyond are clamped into the last bucket of the octave
 
 size_t lds_bytes(int nt, int n_cells, bool grid, bool desc) {
   return (size_t)nt * sizeof(TKey) + (desc ? (size_t)nt * 32 : 0) + (size_t)nt * 4 + (size_t)(n_cells + 1) * 4 + 32 * 4 + 8 * 4 + kThreads * 4 +
-         (grid ? (size_t)n_cells * 4 : 0) + 48 * 4 + 16;
+         48 * 4 + 16;
 }
 
 int validate(const lld_orb_search* s, const lld_orb_search_result* out) {
@@ -618,7 +632,7 @@ extern "C" int lld_orb_search_batch(lld_ctx* ctx, int n, const lld_orb_search* p
   // device-only scratch behind the output region: the round-1 candidate cache of the sequential problems
   std::vector<size_t> cache_at((size_t)n);
   size_t cache_bytes = 0;
-  for (int i = 0; i < n; i++) { cache_at[i] = cache_bytes; if (problems[i].sequential) cache_bytes += al((size_t)problems[i].nq * 32); }
+  for (int i = 0; i < n; i++) { cache_at[i] = cache_bytes; if (problems[i].sequential) cache_bytes += al((size_t)problems[i].nq * 8 * kTopK); }
   void* hbase; int st = lld_ctx_pinned(ctx, in_bytes + out_bytes, &hbase); if (st) return st;
   void* dbase; st = lld_ctx_scratch(ctx, in_bytes + out_bytes + cache_bytes + 256, &dbase); if (st) return st;
   char* h = (char*)hbase; char* d = (char*)dbase;
@@ -664,7 +678,9 @@ extern "C" int lld_orb_search_batch(lld_ctx* ctx, int n, const lld_orb_search* p
     P.q_desc = reinterpret_cast<const uint32_t*>(d + L.q_desc); P.q = reinterpret_cast<const QRec*>(d + L.q);
     P.cand_idx = reinterpret_cast<const int32_t*>(d + L.cand);
     P.min_x = s.grid_min_x; P.min_y = s.grid_min_y; P.winv = s.grid_width_inv; P.hinv = s.grid_height_inv;
-    P.cols = grid ? s.grid_cols : 1; P.rows = grid ? s.grid_rows : (s.candidates == LLD_ORB_CAND_ROWS ? kRowBuckets : 1);
+    const int n_lv = std::max(1, s.n_levels);
+    P.cols = grid ? s.grid_cols : (s.candidates == LLD_ORB_CAND_ROWS ? n_lv : 1);
+    P.rows = grid ? s.grid_rows : (s.candidates == LLD_ORB_CAND_ROWS ? std::min(kRowBuckets, 8190 / n_lv) : 1);
     P.n_levels = s.n_levels;
     for (int l = 0; l < LLD_ORB_MAX_LEVELS; l++) {
       P.scale[l] = (s.level_scale && l < s.n_levels) ? s.level_scale[l] : 1.f;
@@ -745,7 +761,7 @@ struct ProjSearch {
   }
   int alloc() {
     void* hb; int st = lld_ctx_pinned(ctx, in + out, &hb); if (st) return st;
-    void* db; st = lld_ctx_scratch(ctx, in + out + al((size_t)nq * 32) + 256, &db); if (st) return st;   // + the round-1 candidate cache
+    void* db; st = lld_ctx_scratch(ctx, in + out + al((size_t)nq * 8 * kTopK) + 256, &db); if (st) return st;   // + the round-1 candidate cache
     h = (char*)hb; d = (char*)db; h_out = h + in; d_out = d + in;
     return LLD_OK;
   }
