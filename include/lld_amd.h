@@ -468,6 +468,45 @@ int lld_orb_search_last_frame(lld_ctx* ctx, const lld_orb_search* frame, const l
  * out->match[i] = bestIdx or -1, out->n_matches = nFused; the replace / add bookkeeping (:936-954) stays with the caller. */
 int lld_orb_fuse_search(lld_ctx* ctx, const lld_orb_search* keyframe, const lld_frame_view* view, const lld_map_points* points,
                         float th, float* proj_uvr_or_null, lld_orb_search_result* out);
+/* ------------------------------------------------------------------ Frame::ComputeStereoMatches, whole routine
+ * src/Frame.cc:530-704: (1) the row-band Hamming search (:536-613, the ROWS problem of lld_orb_search_run with the level gate
+ * octave +-1, disparity range [0, mbf/mb] and bestDist < (TH_HIGH+TH_LOW)/2), (2) the sub-pixel refinement (:615-688): 11x11
+ * patch of the left pyramid level around the rounded scaled keypoint, centre pixel subtracted, L1 distance to the right patch slid
+ * over incR = -5..5, first minimum (int bestDist, strict <), parabola through the three distances around it, |deltaR| <= 1,
+ * bestuR = scale * (scaleduR0 + bestincR + deltaR), 0 <= disparity < mbf/mb (disparity <= 0 -> 0.01), (3) the outlier cut
+ * (:690-703): median of the SAD distances, entries with dist >= 1.5f*1.4f*median are cleared.
+ * All of it is integer / single-rounding float work: results are bit-exact against the CPU restatement.
+ * Deviation: the reference slices cv::Mat ranges unchecked (OpenCV aborts when a patch leaves the image; ORB keeps keypoints
+ * 19 px inside); here such a keypoint simply gets no stereo match. */
+typedef struct {
+  int32_t n;
+  const float*    xy;           /* [n][2] mvKeys / mvKeysRight .pt */
+  const int32_t*  octave;       /* [n]                              */
+  const uint32_t* desc;         /* [n][8]                           */
+} lld_keypoints;
+typedef struct {
+  int32_t n_levels;
+  const uint8_t* const* left;   /* [n_levels] mpORBextractorLeft->mvImagePyramid[l].data (CV_8U)  */
+  const uint8_t* const* right;  /* [n_levels] mpORBextractorRight->mvImagePyramid[l].data         */
+  const int32_t* cols;          /* [n_levels]                                                       */
+  const int32_t* rows;          /* [n_levels]                                                       */
+  const int32_t* left_step;     /* [n_levels] bytes per image row (cv::Mat::step)                   */
+  const int32_t* right_step;
+  const float*   scale_factors;     /* [n_levels] mvScaleFactors    */
+  const float*   inv_scale_factors; /* [n_levels] mvInvScaleFactors */
+  int32_t on_device;            /* 1: the image pointers are HBM pointers (e.g. of a device ORB extractor), nothing is uploaded */
+  int32_t reserved;
+} lld_stereo_pyramids;
+typedef struct {
+  float*   u_right;             /* [n_left] mvuRight (-1 = none)                                   */
+  float*   depth;               /* [n_left] mvDepth  (-1 = none)                                   */
+  int32_t* best_r;              /* [n_left] or NULL: bestIdxR of the Hamming stage, -1 = none      */
+  int32_t* sad;                 /* [n_left] or NULL: bestDist of the refinement as pushed into vDistIdx, -1 = not pushed */
+  int32_t  n_matches;           /* entries of vDistIdx that survive the median cut                 */
+  int32_t  reserved;
+} lld_stereo_result;
+int lld_compute_stereo_matches(lld_ctx* ctx, const lld_keypoints* left, const lld_keypoints* right, const lld_stereo_pyramids* pyr,
+                               float mb, float mbf, lld_stereo_result* out);
 /* `n` independent problems (e.g. one relocalisation / loop candidate keyframe each, or the searches of several frames) in one
  * launch: one workgroup per problem, all inputs moved in one host-to-device copy and all outputs in one copy back. */
 int lld_orb_search_batch(lld_ctx* ctx, int n, const lld_orb_search* problems, lld_orb_search_result* outs);

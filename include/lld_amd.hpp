@@ -174,6 +174,16 @@ class ORBmatcher {
     r.n_matches = o.n_matches; r.rounds = o.rounds;
     return r;
   }
+  // Frame::ComputeStereoMatches as a whole (src/Frame.cc:530-704): row-band Hamming search, 11x11 SAD refinement on the image
+  // pyramids, median cut.  Fills mvuRight / mvDepth; returns the number of stereo keypoints kept.
+  int ComputeStereoMatches(const lld_keypoints& left, const lld_keypoints& right, const lld_stereo_pyramids& pyramids, float mb, float mbf,
+                           std::vector<float>& mvuRight, std::vector<float>& mvDepth) const {
+    mvuRight.assign(left.n, -1.0f); mvDepth.assign(left.n, -1.0f);
+    lld_stereo_result o{};
+    o.u_right = mvuRight.data(); o.depth = mvDepth.data();
+    check(lld_compute_stereo_matches(ctx_.get(), &left, &right, &pyramids, mb, mbf, &o), "lld_compute_stereo_matches");
+    return o.n_matches;
+  }
  private:
   Context& ctx_;
  public:

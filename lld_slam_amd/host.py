@@ -550,6 +550,11 @@ class ORBmatcher:
         from . import orb_search as S
         return S.stereo_search(self.lib, self.ctx.handle, L, R, min_d, max_d)
 
+    def ComputeStereoMatchesFull(self, L, R, left_levels, right_levels, inv_scale, mb, mbf):
+        """Frame::ComputeStereoMatches incl. the SAD sub-pixel refinement and the median cut (src/Frame.cc:530-704)."""
+        from . import orb_search as S
+        return S.compute_stereo_matches(self.lib, self.ctx.handle, L, R, left_levels, right_levels, inv_scale, mb, mbf)
+
     def AcceptByRatio(self, best_idx, best_dist, second_dist, th):
         """`bestDist<=th` and `bestDist < mfNNratio*bestDist2` as in SearchByBoW (src/ORBmatcher.cc:226-230)."""
         ok = (best_idx >= 0) & (best_dist <= th) & (best_dist.astype(np.float32) < self.mfNNratio * second_dist.astype(np.float32))

@@ -66,6 +66,21 @@ class FrustumResult(C.Structure):
     _fields_ = [("in_view", c_uint8_p), ("proj_uvr", c_float_p), ("level", c_int32_p), ("view_cos", c_float_p)]
 
 
+class Keypoints(C.Structure):
+    _fields_ = [("n", C.c_int32), ("xy", c_float_p), ("octave", c_int32_p), ("desc", c_uint32_p)]
+
+
+class StereoPyramids(C.Structure):
+    _fields_ = [("n_levels", C.c_int32), ("left", C.POINTER(c_uint8_p)), ("right", C.POINTER(c_uint8_p)), ("cols", c_int32_p), ("rows", c_int32_p),
+                ("left_step", c_int32_p), ("right_step", c_int32_p), ("scale_factors", c_float_p), ("inv_scale_factors", c_float_p),
+                ("on_device", C.c_int32), ("reserved", C.c_int32)]
+
+
+class StereoResult(C.Structure):
+    _fields_ = [("u_right", c_float_p), ("depth", c_float_p), ("best_r", c_int32_p), ("sad", c_int32_p), ("n_matches", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
 def orb_levels(scale_factor=1.2, n_levels=8):
     """mvScaleFactor / mvLevelSigma2 / mvInvLevelSigma2 exactly as ORBextractor builds them (src/ORBextractor.cc:416-430):
     cumulative float products."""
@@ -375,6 +390,59 @@ def stereo_search(lib, ctx, L: Frame, R: Frame, min_d, max_d) -> SearchOutput:
     return run(lib, ctx, R, L.desc, candidates=CAND_ROWS, gates=GATE_LEVEL, accept_max=(TH_HIGH + TH_LOW) // 2 - 1, q_uv=L.xy,
                q_level_min=L.octave - 1, q_level_max=L.octave + 1, disp_min=min_d, disp_max=max_d)
 
+
+
+@dataclass
+class StereoMatches:
+    u_right: np.ndarray      # mvuRight
+    depth: np.ndarray        # mvDepth
+    best_r: np.ndarray       # bestIdxR of the Hamming stage
+    sad: np.ndarray          # SAD bestDist of the entries pushed into vDistIdx
+    n_matches: int
+
+
+def keypoints_struct(F: Frame):
+    F.normalise()
+    k = Keypoints(); k.n = F.n
+    k.xy = _p(F.xy, c_float_p); k.octave = _p(F.octave, c_int32_p); k.desc = _p(F.desc, c_uint32_p)
+    return k
+
+
+def pyramids_struct(left_levels, right_levels, scale, inv_scale):
+    """left_levels / right_levels: lists of 2-D uint8 arrays (mvImagePyramid); rows may be strided (cv::Mat::step)."""
+    n = len(left_levels)
+    keep = dict(left=[np.asarray(a, np.uint8) for a in left_levels], right=[np.asarray(a, np.uint8) for a in right_levels])
+    for side in ("left", "right"):
+        keep[side] = [a if a.strides[1] == 1 else np.ascontiguousarray(a) for a in keep[side]]
+    keep["cols"] = np.array([a.shape[1] for a in keep["left"]], np.int32); keep["rows"] = np.array([a.shape[0] for a in keep["left"]], np.int32)
+    keep["lstep"] = np.array([a.strides[0] for a in keep["left"]], np.int32); keep["rstep"] = np.array([a.strides[0] for a in keep["right"]], np.int32)
+    keep["scale"] = _f32(scale); keep["inv"] = _f32(inv_scale)
+    keep["lp"] = (c_uint8_p * n)(*[a.ctypes.data_as(c_uint8_p) for a in keep["left"]])
+    keep["rp"] = (c_uint8_p * n)(*[a.ctypes.data_as(c_uint8_p) for a in keep["right"]])
+    P = StereoPyramids(); P.n_levels = n
+    P.left = C.cast(keep["lp"], C.POINTER(c_uint8_p)); P.right = C.cast(keep["rp"], C.POINTER(c_uint8_p))
+    P.cols = _p(keep["cols"], c_int32_p); P.rows = _p(keep["rows"], c_int32_p)
+    P.left_step = _p(keep["lstep"], c_int32_p); P.right_step = _p(keep["rstep"], c_int32_p)
+    P.scale_factors = _p(keep["scale"], c_float_p); P.inv_scale_factors = _p(keep["inv"], c_float_p)
+    P.on_device = 0
+    return P, keep
+
+
+def compute_stereo_matches(lib, ctx, L: Frame, R: Frame, left_levels, right_levels, inv_scale, mb, mbf) -> StereoMatches:
+    """Frame::ComputeStereoMatches, whole routine (src/Frame.cc:530-704): lld_compute_stereo_matches."""
+    kl, kr = keypoints_struct(L), keypoints_struct(R)
+    P, keep = pyramids_struct(left_levels, right_levels, L.scale, inv_scale)
+    out = StereoMatches(np.empty(L.n, np.float32), np.empty(L.n, np.float32), np.empty(L.n, np.int32), np.empty(L.n, np.int32), 0)
+    r = StereoResult(); r.u_right = _p(out.u_right, c_float_p); r.depth = _p(out.depth, c_float_p)
+    r.best_r = _p(out.best_r, c_int32_p); r.sad = _p(out.sad, c_int32_p)
+    fn = lib.fn("compute_stereo_matches")
+    fn.argtypes = [C.c_void_p, C.POINTER(Keypoints), C.POINTER(Keypoints), C.POINTER(StereoPyramids), C.c_float, C.c_float, C.POINTER(StereoResult)]
+    fn.restype = C.c_int
+    st = fn(ctx, C.byref(kl), C.byref(kr), C.byref(P), float(np.float32(mb)), float(np.float32(mbf)), C.byref(r))
+    if st != abi.LLD_OK:
+        raise RuntimeError(f"lld_compute_stereo_matches failed: {lib.fn('status_string')(st).decode()}")
+    out.n_matches = r.n_matches
+    return out
 
 
 # ====================================================================== Tracking::SearchLocalPoints: frustum test + search on the device

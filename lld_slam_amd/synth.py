@@ -459,6 +459,62 @@ def make_stereo_pair(pair_id=0, n=2000, flip_p=0.06):
     return L, R
 
 
+def make_stereo_scene(pair_id=0, n=2000, width=1241, height=376, flip_p=0.05, edge=19):
+    """A rectified stereo frame WITH images, for Frame::ComputeStereoMatches as a whole: a smooth random texture as the left image,
+    the right image = the left one warped by a smooth disparity field d(x,y) in [4, 70] px, both as 8-level pyramids (level sizes
+    cvRound(size * invScale) like ORBextractor, bilinear resampling); left keypoints on integer pixels of their level at least
+    `edge` px inside it, right keypoints at x - d (+ sub-pixel jitter), a few rows off, octave +-1, descriptors with flipped bits,
+    plus unrelated right keypoints and some pairs with a wrong disparity (caught by the SAD stage or the median cut).
+    Returns dict(L, R, left, right, inv_scale, mb, mbf)."""
+    from scipy import ndimage
+    from .orb_search import Frame, orb_levels
+    rng = np.random.default_rng(SEED_SEARCH + 0x5000 + pair_id)
+    scale, _, _ = orb_levels()
+    inv_scale = (np.float32(1.0) / scale).astype(np.float32)
+    tex = ndimage.gaussian_filter(rng.normal(size=(height, width + 96)), 1.6) + 0.6 * ndimage.gaussian_filter(rng.normal(size=(height, width + 96)), 5.0)
+    tex = (tex - tex.min()) / (tex.max() - tex.min())
+    big = np.clip(255.0 * tex, 0, 255)
+    yy, xx = np.mgrid[0:height, 0:width].astype(np.float64)
+    disp = 4.0 + 60.0 * (yy / height) + 6.0 * np.sin(xx / 170.0)                                  # nearer towards the bottom of the image
+    left0 = ndimage.map_coordinates(big, [yy, xx + 8.0], order=1)
+    right0 = ndimage.map_coordinates(big, [yy, xx + 8.0 + disp], order=1, mode="nearest")       # R(x) = L(x + d)
+    def pyramid(img0):
+        out = []
+        for l in range(scale.shape[0]):
+            w, h = int(np.round(width * inv_scale[l])), int(np.round(height * inv_scale[l]))
+            y, x = np.mgrid[0:h, 0:w].astype(np.float64)
+            out.append(np.clip(np.round(ndimage.map_coordinates(img0, [y * float(scale[l]), x * float(scale[l])], order=1, mode="nearest")), 0, 255).astype(np.uint8))
+        return out
+    left, right = pyramid(left0), pyramid(right0)
+    octave = np.minimum(rng.geometric(0.35, n) - 1, 7).astype(np.int32)
+    lw = np.array([left[o].shape[1] for o in octave]); lh = np.array([left[o].shape[0] for o in octave])
+    lx = rng.integers(edge, lw - edge); ly = rng.integers(edge, lh - edge)
+    xy = np.stack([lx.astype(np.float32) * scale[octave], ly.astype(np.float32) * scale[octave]], 1).astype(np.float32)
+    desc = rng.integers(0, 2 ** 32, (n, 8), dtype=np.uint64).astype(np.uint32)
+    L = Frame(desc=desc, xy=xy, octave=octave, uright=np.full(n, -1, np.float32), angle=np.zeros(n, np.float32), min_x=0.0, min_y=0.0,
+              max_x=float(width), max_y=float(height)).normalise()
+    m = int(0.8 * n)
+    src = rng.permutation(n)[:m]
+    d_true = ndimage.map_coordinates(disp, [xy[src, 1].astype(np.float64), xy[src, 0].astype(np.float64)], order=1, mode="nearest")
+    wrong = rng.random(m) < 0.06
+    d_used = np.where(wrong, d_true + rng.uniform(-25, 25, m), d_true) + rng.normal(0, 0.4, m)
+    r_oct = np.clip(octave[src] + rng.integers(-1, 2, m), 0, 7).astype(np.int32)
+    rxy = np.stack([xy[src, 0] - d_used, xy[src, 1] + rng.normal(0, 0.8, m)], 1).astype(np.float32)
+    # unrelated right keypoints
+    k = n - m
+    uo = np.minimum(rng.geometric(0.35, k) - 1, 7).astype(np.int32)
+    uxy = np.stack([rng.uniform(20, width - 20, k), rng.uniform(20, height - 20, k)], 1).astype(np.float32)
+    R = Frame(desc=np.concatenate([_flip_bits(rng, desc[src], flip_p), rng.integers(0, 2 ** 32, (k, 8), dtype=np.uint64).astype(np.uint32)]),
+              xy=np.concatenate([rxy, uxy]), octave=np.concatenate([r_oct, uo]), uright=np.full(n, -1, np.float32), angle=np.zeros(n, np.float32),
+              min_x=0.0, min_y=0.0, max_x=float(width), max_y=float(height)).normalise()
+    R.xy[:, 0] = np.clip(R.xy[:, 0], 0.0, width - 1.0); R.xy[:, 1] = np.clip(R.xy[:, 1], 0.0, height - 1.0)
+    perm = rng.permutation(n)                                                                    # right keypoints in no particular order
+    R.desc, R.xy, R.octave = np.ascontiguousarray(R.desc[perm]), np.ascontiguousarray(R.xy[perm]), np.ascontiguousarray(R.octave[perm])
+    fx, _, _, _, bf = KITTI_CAM
+    mbf = np.float32(bf); mb = np.float32(mbf / np.float32(fx))                                   # mb = mbf / fx (src/Frame.cc:100)
+    return dict(L=L, R=R, left=left, right=right, inv_scale=inv_scale, mb=float(mb), mbf=float(mbf), src=src, perm=perm, d_true=d_true, wrong=wrong)
+
+
 # ====================================================================== stereo line association (TwoFrameLineMatcher, SURVEY §8 a23 / f3)
 def make_stereo_lines(frame_id=0, n_left=300, n_right=300, dim=72, related_frac=0.8, pixel_noise=0.4, desc_noise=0.05):
     """Left / right KeyLines of one stereo frame: random 3D segments (depth 3-40 m, some nearly parallel to the baseline so the

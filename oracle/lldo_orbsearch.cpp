@@ -20,6 +20,7 @@
 //   ORBmatcher::ComputeThreeMaxima                                  src/ORBmatcher.cc:1601-1642
 //   Frame::ComputeStereoMatches (Hamming search)                    src/Frame.cc:530-613
 //   Frame::isInFrustum, MapPoint::PredictScale                      src/Frame.cc:333-389, src/MapPoint.cc:402-417
+#include <algorithm>
 #include <climits>
 #include <cmath>
 #include <cstdint>
@@ -510,6 +511,117 @@ void lldo_stereo_search(const lldo_frame* L, const lldo_frame* R, int n_rows, fl
     best_dist[iL] = bestDist;
     if (bestDist < thOrbDist) best_r[iL] = bestIdxR;
   }
+}
+
+// Frame::ComputeStereoMatches, whole routine (src/Frame.cc:530-704), through the structs of include/lld_amd.h.  cv::Mat slicing and
+// cv::norm(IL,IR,NORM_L1) on CV_32F patches of 8-bit pixels are exact integer arithmetic; patches that would leave the image (where
+// OpenCV aborts) get no match, as in the product.  Returns the number of entries of vDistIdx that survive the median cut.
+int lldo_compute_stereo_matches(const lld_keypoints* left, const lld_keypoints* right, const lld_stereo_pyramids* pyr, float mb, float mbf,
+                                float* mvuRight, float* mvDepth, int32_t* best_r, int32_t* sad) {
+  const int N = left->n, Nr = right->n;
+  for (int i = 0; i < N; i++) { mvuRight[i] = -1.0f; mvDepth[i] = -1.0f; if (best_r) best_r[i] = -1; if (sad) sad[i] = -1; }
+  const int thOrbDist = (TH_HIGH + TH_LOW) / 2;
+  const int nRows = pyr->rows[0];
+  std::vector<std::vector<size_t>> vRowIndices(nRows);
+  for (int iR = 0; iR < Nr; iR++) {
+    const float kpY = right->xy[2 * iR + 1];
+    const float r = 2.0f * pyr->scale_factors[right->octave[iR]];
+    const int maxr = (int)std::ceil(kpY + r);
+    const int minr = (int)std::floor(kpY - r);
+    for (int yi = minr; yi <= maxr; yi++) if (yi >= 0 && yi < nRows) vRowIndices[yi].push_back(iR);   // the reference indexes unchecked
+  }
+  const float minZ = mb;
+  const float minD = 0;
+  const float maxD = mbf / minZ;
+  std::vector<std::pair<int, int>> vDistIdx;
+  vDistIdx.reserve(N);
+  for (int iL = 0; iL < N; iL++) {
+    const int levelL = left->octave[iL];
+    const float vL = left->xy[2 * iL + 1];
+    const float uL = left->xy[2 * iL];
+    if (!((long long)vL >= 0 && (long long)vL < nRows)) continue;                                       // unchecked in the reference
+    const std::vector<size_t>& vCandidates = vRowIndices[(size_t)vL];
+    if (vCandidates.empty()) continue;
+    const float minU = uL - maxD;
+    const float maxU = uL - minD;
+    if (maxU < 0) continue;
+    int bestDist = TH_HIGH;
+    size_t bestIdxR = 0;
+    for (size_t iC = 0; iC < vCandidates.size(); iC++) {
+      const size_t iR = vCandidates[iC];
+      if (right->octave[iR] < levelL - 1 || right->octave[iR] > levelL + 1) continue;
+      const float uR = right->xy[2 * iR];
+      if (uR >= minU && uR <= maxU) {
+        const int dist = lldo_descriptor_distance(left->desc + 8 * iL, right->desc + 8 * iR);
+        if (dist < bestDist) { bestDist = dist; bestIdxR = iR; }
+      }
+    }
+    if (bestDist < thOrbDist) {
+      if (best_r) best_r[iL] = (int32_t)bestIdxR;
+      const float uR0 = right->xy[2 * bestIdxR];
+      const float scaleFactor = pyr->inv_scale_factors[levelL];
+      const float scaleduL = std::round(uL * scaleFactor);
+      const float scaledvL = std::round(vL * scaleFactor);
+      const float scaleduR0 = std::round(uR0 * scaleFactor);
+      const int w = 5;
+      const int cols = pyr->cols[levelL], rows = pyr->rows[levelL];
+      const uint8_t* imL = pyr->left[levelL]; const uint8_t* imR = pyr->right[levelL];
+      const int sL = pyr->left_step[levelL], sR = pyr->right_step[levelL];
+      const int x0 = (int)scaleduL, y0 = (int)scaledvL, xr = (int)scaleduR0;
+      int bestDist = INT_MAX;
+      int bestincR = 0;
+      const int L = 5;
+      std::vector<float> vDists;
+      vDists.resize(2 * L + 1);
+      const float iniu = scaleduR0 + L - w;
+      const float endu = scaleduR0 + L + w + 1;
+      if (iniu < 0 || endu >= cols) continue;
+      // rowRange / colRange outside the image: cv::Mat would abort; no match here
+      if (x0 - w < 0 || x0 + w >= cols || y0 - w < 0 || y0 + w >= rows || xr - L - w < 0 || xr + L + w >= cols) continue;
+      float IL[11][11];
+      const float cL = (float)imL[(size_t)y0 * sL + x0];
+      for (int r = 0; r < 2 * w + 1; r++) for (int c = 0; c < 2 * w + 1; c++) IL[r][c] = (float)imL[(size_t)(y0 - w + r) * sL + (x0 - w + c)] - cL;
+      for (int incR = -L; incR <= +L; incR++) {
+        const float cR = (float)imR[(size_t)y0 * sR + (xr + incR)];
+        double acc = 0.0;                                                                               // cv::norm accumulates in double
+        for (int r = 0; r < 2 * w + 1; r++)
+          for (int c = 0; c < 2 * w + 1; c++) {
+            const float ir = (float)imR[(size_t)(y0 - w + r) * sR + (xr + incR - w + c)] - cR;
+            acc += (double)std::fabs(IL[r][c] - ir);
+          }
+        float dist = (float)acc;
+        if (dist < bestDist) { bestDist = dist; bestincR = incR; }
+        vDists[L + incR] = dist;
+      }
+      if (bestincR == -L || bestincR == L) continue;
+      const float dist1 = vDists[L + bestincR - 1];
+      const float dist2 = vDists[L + bestincR];
+      const float dist3 = vDists[L + bestincR + 1];
+      const float deltaR = (dist1 - dist3) / (2.0f * (dist1 + dist3 - 2.0f * dist2));
+      if (deltaR < -1 || deltaR > 1) continue;
+      float bestuR = pyr->scale_factors[levelL] * ((float)scaleduR0 + (float)bestincR + deltaR);
+      float disparity = (uL - bestuR);
+      if (disparity >= minD && disparity < maxD) {
+        if (disparity <= 0) { disparity = 0.01; bestuR = uL - 0.01; }
+        mvDepth[iL] = mbf / disparity;
+        mvuRight[iL] = bestuR;
+        vDistIdx.push_back(std::pair<int, int>(bestDist, iL));
+        if (sad) sad[iL] = bestDist;
+      }
+    }
+  }
+  if (vDistIdx.empty()) return 0;                                                                       // the reference reads vDistIdx[0] regardless
+  std::sort(vDistIdx.begin(), vDistIdx.end());
+  const float median = vDistIdx[vDistIdx.size() / 2].first;
+  const float thDist = 1.5f * 1.4f * median;
+  int kept = (int)vDistIdx.size();
+  for (int i = (int)vDistIdx.size() - 1; i >= 0; i--) {
+    if (vDistIdx[i].first < thDist) break;
+    mvuRight[vDistIdx[i].second] = -1;
+    mvDepth[vDistIdx[i].second] = -1;
+    kept--;
+  }
+  return kept;
 }
 
 // Frame::isInFrustum for every MapPoint (src/Frame.cc:333-389) with the per-point part of Tracking::SearchLocalPoints

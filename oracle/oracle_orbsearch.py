@@ -181,6 +181,21 @@ def stereo_search(L, R, n_rows, min_d, max_d):
     return br, bd
 
 
+def compute_stereo_matches(L, R, left_levels, right_levels, inv_scale, mb, mbf):
+    """Frame::ComputeStereoMatches, whole routine (literal restatement): (n_kept, mvuRight, mvDepth, best_r, sad)."""
+    from lld_slam_amd.orb_search import Keypoints, StereoPyramids, keypoints_struct, pyramids_struct
+    d = _dll()
+    d.lldo_compute_stereo_matches.argtypes = [C.POINTER(Keypoints), C.POINTER(Keypoints), C.POINTER(StereoPyramids), C.c_float, C.c_float,
+                                              c_float_p, c_float_p, c_int32_p, c_int32_p]
+    d.lldo_compute_stereo_matches.restype = C.c_int
+    kl, kr = keypoints_struct(L), keypoints_struct(R)
+    P, keep = pyramids_struct(left_levels, right_levels, L.scale, inv_scale)
+    ur = np.empty(L.n, np.float32); dep = np.empty(L.n, np.float32); br = np.empty(L.n, np.int32); sad = np.empty(L.n, np.int32)
+    n = d.lldo_compute_stereo_matches(C.byref(kl), C.byref(kr), C.byref(P), float(np.float32(mb)), float(np.float32(mbf)),
+                                      _p(ur, c_float_p), _p(dep, c_float_p), _p(br, c_int32_p), _p(sad, c_int32_p))
+    return n, ur, dep, br, sad
+
+
 def is_in_frustum(view, mp: dict, viewing_cos_limit=0.5):
     """Frame::isInFrustum over all map points (literal restatement): (nToMatch, in_view, proj_uvr, level, view_cos)."""
     from lld_slam_amd.orb_search import FrameView, MapPoints, map_points_struct

@@ -289,3 +289,72 @@ def test_fuse_projection_and_search_on_device(gpu_ctx, seed, th):
     n_exp, best = OS.fuse_search(KF, mp["desc"], valid, uv, ur, lvl, th)
     assert out.n_matches == n_exp and n_exp > 100
     np.testing.assert_array_equal(out.match, best)
+
+
+# ---------------------------------------------------------------------- Frame::ComputeStereoMatches, whole routine (with images)
+def _check_stereo(g, ref):
+    n, ur, dep, br, sad = ref
+    np.testing.assert_array_equal(g.best_r, br)
+    np.testing.assert_array_equal(g.sad, sad)
+    np.testing.assert_array_equal(g.u_right.view(np.uint32), ur.view(np.uint32))     # float results bit for bit
+    np.testing.assert_array_equal(g.depth.view(np.uint32), dep.view(np.uint32))
+    assert g.n_matches == n
+
+
+@pytest.mark.parametrize("seed,n", [(0, 2000), (1, 700), (2, 4096)])
+def test_compute_stereo_matches_whole_routine(gpu_ctx, seed, n):
+    sc = synth.make_stereo_scene(seed, n)
+    g = ORBmatcher(gpu_ctx).ComputeStereoMatchesFull(sc["L"], sc["R"], sc["left"], sc["right"], sc["inv_scale"], sc["mb"], sc["mbf"])
+    ref = OS.compute_stereo_matches(sc["L"], sc["R"], sc["left"], sc["right"], sc["inv_scale"], sc["mb"], sc["mbf"])
+    _check_stereo(g, ref)
+    assert g.n_matches > n // 3
+
+
+def test_compute_stereo_matches_strided_images_and_borders(gpu_ctx):
+    sc = synth.make_stereo_scene(3, 600)
+    L, R = sc["L"], sc["R"]
+    L.xy[:50, 0] = 2.0; R.xy[:50, 0] = 1.0                           # patches leave the image: no match, no fault
+    L.xy[50:80, 1] = 374.0
+    pad = lambda a: np.pad(a, ((0, 0), (0, 13)))[:, :a.shape[1]]     # views with a row step larger than the width (cv::Mat::step)
+    left, right = [pad(a) for a in sc["left"]], [pad(a) for a in sc["right"]]
+    assert left[0].strides[0] > left[0].shape[1]
+    g = ORBmatcher(gpu_ctx).ComputeStereoMatchesFull(L, R, left, right, sc["inv_scale"], sc["mb"], sc["mbf"])
+    _check_stereo(g, OS.compute_stereo_matches(L, R, left, right, sc["inv_scale"], sc["mb"], sc["mbf"]))
+    assert (g.u_right[:50] < 0).all()
+
+
+def test_compute_stereo_matches_empty_sides(gpu_ctx):
+    sc = synth.make_stereo_scene(4, 300)
+    E = Frame(desc=np.zeros((0, 8), np.uint32), xy=np.zeros((0, 2), np.float32), octave=np.zeros(0, np.int32), uright=np.zeros(0, np.float32),
+              angle=np.zeros(0, np.float32))
+    m = ORBmatcher(gpu_ctx)
+    g = m.ComputeStereoMatchesFull(sc["L"], E, sc["left"], sc["right"], sc["inv_scale"], sc["mb"], sc["mbf"])
+    assert g.n_matches == 0 and (g.u_right < 0).all() and (g.depth < 0).all()
+    g = m.ComputeStereoMatchesFull(E, sc["R"], sc["left"], sc["right"], sc["inv_scale"], sc["mb"], sc["mbf"])
+    assert g.n_matches == 0 and g.u_right.shape == (0,)
+
+
+def test_compute_stereo_matches_device_resident_pyramids(gpu_ctx):
+    """on_device = 1: the image pointers are HBM pointers (here torch tensors), only keypoints travel."""
+    import ctypes as C
+    import torch
+    from lld_slam_amd import orb_search as S
+    from lld_slam_amd.abi import c_uint8_p
+    sc = synth.make_stereo_scene(5, 1500)
+    ref = OS.compute_stereo_matches(sc["L"], sc["R"], sc["left"], sc["right"], sc["inv_scale"], sc["mb"], sc["mbf"])
+    dl = [torch.from_numpy(a).cuda() for a in sc["left"]]; dr = [torch.from_numpy(a).cuda() for a in sc["right"]]
+    torch.cuda.synchronize()
+    kl, kr = S.keypoints_struct(sc["L"]), S.keypoints_struct(sc["R"])
+    P, keep = S.pyramids_struct(sc["left"], sc["right"], sc["L"].scale, sc["inv_scale"])
+    lp = (c_uint8_p * len(dl))(*[C.cast(t.data_ptr(), c_uint8_p) for t in dl]); rp = (c_uint8_p * len(dr))(*[C.cast(t.data_ptr(), c_uint8_p) for t in dr])
+    P.left = C.cast(lp, C.POINTER(c_uint8_p)); P.right = C.cast(rp, C.POINTER(c_uint8_p)); P.on_device = 1
+    n = sc["L"].n
+    g = S.StereoMatches(np.empty(n, np.float32), np.empty(n, np.float32), np.empty(n, np.int32), np.empty(n, np.int32), 0)
+    r = S.StereoResult(); r.u_right = g.u_right.ctypes.data_as(S.c_float_p); r.depth = g.depth.ctypes.data_as(S.c_float_p)
+    r.best_r = g.best_r.ctypes.data_as(S.c_int32_p); r.sad = g.sad.ctypes.data_as(S.c_int32_p)
+    fn = gpu_ctx.lib.fn("compute_stereo_matches")
+    fn.argtypes = [C.c_void_p, C.POINTER(S.Keypoints), C.POINTER(S.Keypoints), C.POINTER(S.StereoPyramids), C.c_float, C.c_float, C.POINTER(S.StereoResult)]
+    fn.restype = C.c_int
+    assert fn(gpu_ctx.handle, C.byref(kl), C.byref(kr), C.byref(P), sc["mb"], sc["mbf"], C.byref(r)) == 0
+    g.n_matches = r.n_matches
+    _check_stereo(g, ref)

@@ -114,7 +114,13 @@ def cpu_lf():
     valid, uv, ur = OS.project_last_frame(view, lastf)
     return OS.search_by_projection_frame(F, lastf["desc"], valid, uv, ur, lastf["octave"], lastf["angle"], lastf["has_obs"], mpm["occupied"], 0, 7.0, True)
 c_lf, e_lf = timed(cpu_lf)
+# Frame::ComputeStereoMatches as a whole: Hamming rows + SAD refinement on the pyramids + median cut (3 MB of images per call)
+sc = synth.make_stereo_scene(0, 2000)
+g_sf, r_sf = timed(lambda: m.ComputeStereoMatchesFull(sc["L"], sc["R"], sc["left"], sc["right"], sc["inv_scale"], sc["mb"], sc["mbf"]))
+c_sf, e_sf = timed(lambda: OS.compute_stereo_matches(sc["L"], sc["R"], sc["left"], sc["right"], sc["inv_scale"], sc["mb"], sc["mbf"]))
 out["orb_guided_search"] = {
+    "compute_stereo_matches_full": {"gpu_ms": g_sf * 1e3, "cpu_oracle_ms": c_sf * 1e3, "n_matches": r_sf.n_matches,
+                                    "equal": bool(r_sf.n_matches == e_sf[0] and np.array_equal(r_sf.u_right.view(np.uint32), e_sf[1].view(np.uint32)))},
     "search_local_points": {"gpu_ms": g_loc * 1e3, "cpu_oracle_ms": c_loc * 1e3, "n_matches": r_loc[0].n_matches, "equal": r_loc[0].n_matches == e_loc[0]},
     "search_last_frame": {"gpu_ms": g_lf * 1e3, "cpu_oracle_ms": c_lf * 1e3, "n_matches": r_lf[0].n_matches, "equal": r_lf[0].n_matches == e_lf[0]},
     "map_projection_batch512": {"gpu_searches_per_s": len(prep) / g_bat, "cpu_oracle_searches_per_s": 1.0 / c_bat,
