@@ -18,7 +18,7 @@ def main(path):
     print(f"# {path}")
     print(f"{'kernel':70s} {'calls':>7s} {'total_ms':>10s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s} {'pct':>6s}")
     for n, c, t, a, mn, mx in rows:
-        short = n.split("(")[0][-70:]
+        short = n.replace("(anonymous namespace)::", "").split("(")[0][-70:]
         print(f"{short:70s} {c:7d} {t / 1e6:10.3f} {a / 1e3:10.2f} {mn / 1e3:10.2f} {mx / 1e3:10.2f} {100.0 * t / total:6.2f}")
     try:
         pm = cur.execute("select name from sqlite_master where name='counters_collection'").fetchall()
@@ -31,7 +31,7 @@ def main(path):
             if rows:
                 print("\n# PMC counters: kernel, counter, dispatches, sum, per-dispatch")
                 for k, c, n, v in rows:
-                    print(f"{k.split('(')[0][-60:]:60s} {c:28s} {n:7d} {v:18.1f} {v / max(n, 1):16.1f}")
+                    print(f"{k.replace('(anonymous namespace)::', '').split('(')[0][-60:]:60s} {c:28s} {n:7d} {v:18.1f} {v / max(n, 1):16.1f}")
     except sqlite3.Error as e:
         print("# no counters:", e)
 
