@@ -119,6 +119,13 @@ typedef struct {
   int32_t reduced_solver;   /* GPU only: 0 = exact Cholesky (default; the reference factorises exactly,
                                linear_solver_eigen.h:94-124) on the fp64 matrix cores when 6*n_free <= 304,
                                1 = block-Jacobi PCG, 2 = exact 6x6-block Cholesky on the vector ALUs     */
+  int32_t protocol;         /* 0 = Optimizer::LocalBundleAdjustment: optimize(its_round1), outlier protocol, optimize(its_round2).
+                               1 = Optimizer::BundleAdjustment / GlobalBundleAdjustment (src/Optimizer.cc:312-559) on the same
+                                   kernels: ONE optimize(its_round1) call and nothing else - no classification, no line removal, all
+                                   result flags 0; line edges carry identity information and the Huber delta thHuber3D/2
+                                   (AddLineMinimalGlobal, :149-240), `gamma` and `ln_filter` are ignored.  The window holds the whole
+                                   map: every keyframe but mnId==0 free (n_free_cams <= 170 in this build)                       */
+  int32_t robust_points;    /* protocol 1 only: bRobust (Huber kernels on the point edges, default 1); lines are always robust */
 } lld_ba_params;
 
 void lld_ba_params_default(lld_ba_params* p);

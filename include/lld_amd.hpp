@@ -73,8 +73,17 @@ class Optimizer {
  public:
   // void static LocalBundleAdjustment(KeyFrame* pKF, bool* pbStopFlag, Map* pMap, double gamma = 1.0)
   static BAOutput LocalBundleAdjustment(Context& ctx, const BAWindow& win, const bool* pbStopFlag = nullptr, double gamma = 1.0) {
-    const lld_ba_window w = win.view();
     lld_ba_params p; lld_ba_params_default(&p); p.gamma = gamma;
+    return Solve(ctx, win, p, pbStopFlag);
+  }
+  // void static GlobalBundleAdjustment(Map* pMap, int nIterations=5, bool* pbStopFlag=NULL, const unsigned long nLoopKF=0, const bool bRobust = true)
+  // `win` holds the whole map (every keyframe but mnId==0 free); one optimize(nIterations), nothing is erased (src/Optimizer.cc:312-559)
+  static BAOutput GlobalBundleAdjustment(Context& ctx, const BAWindow& win, int nIterations = 5, const bool* pbStopFlag = nullptr, bool bRobust = true) {
+    lld_ba_params p; lld_ba_params_default(&p); p.protocol = 1; p.its_round1 = nIterations; p.robust_points = bRobust ? 1 : 0;
+    return Solve(ctx, win, p, pbStopFlag);
+  }
+  static BAOutput Solve(Context& ctx, const BAWindow& win, const lld_ba_params& p, const bool* pbStopFlag = nullptr) {
+    const lld_ba_window w = win.view();
     BAOutput o;
     o.cam_qt.resize(7 * (size_t)w.n_cams); o.pt_xyz.resize(3 * (size_t)w.n_points);
     o.line_x0.resize(3 * (size_t)w.n_lines); o.line_dir.resize(3 * (size_t)w.n_lines);

@@ -27,7 +27,7 @@ struct lld_ba_batch {
                  hipEvent_t ev[kNumPhases + 1] = {}; int steps = 0; bool active = false; int max_nt_pt = 0, max_nb_ln = 0, max_nl_pt = 0, max_nl_ln = 0, max_lblocks = 0, max_items_pt = 0, max_items_ln = 0, max_blk = 0; };
   std::vector<Group> groups;
   int* d_counters = nullptr; int* h_counters = nullptr;               // device / pinned, 4 ints per group
-  int max_lblocks = 0, max_items_pt = 0, max_items_ln = 0, max_free = 0, max_cams = 0, max_blk = 0;
+  int max_lblocks = 0, max_items_pt = 0, max_items_ln = 0, max_free = 0, max_cams = 0, max_blk = 0, acc_copies = 4;
   size_t schur_lds[2] = {0, 0};
   int chunk_landmarks = 32;
   size_t S_total = 0, x_total = 0;
@@ -120,7 +120,7 @@ int lld_ba_batch_create(lld_ctx* ctx, int n_windows, const lld_ba_window* wins, 
   B->ctx = ctx; B->n_windows = n_windows;
   if (params) B->params = *params; else lld_ba_params_default(&B->params);
   const lld_ba_params& P = B->params;
-  if (P.its_round1 < 0 || P.its_round2 < 0 || P.max_trials <= 0 || !(P.pcg_rel_tol > 0) || P.reduced_solver < 0 || P.reduced_solver > 2) { delete B; return LLD_ERR_INVALID; }
+  if (P.its_round1 < 0 || P.its_round2 < 0 || P.max_trials <= 0 || !(P.pcg_rel_tol > 0) || P.reduced_solver < 0 || P.reduced_solver > 2 || P.protocol < 0 || P.protocol > 1) { delete B; return LLD_ERR_INVALID; }
 
   // ---- layout + host staging
   std::vector<double> cam_qt0, pt0, ln_x0, ln_dir, pe_u, pe_v, pe_ur, pe_s, le_xs, le_ys, le_xe, le_ye, le_s, le_bx;
@@ -178,6 +178,8 @@ int lld_ba_batch_create(lld_ctx* ctx, int n_windows, const lld_ba_window* wins, 
     W.its[0] = P.its_round1; W.its[1] = P.its_round2; W.max_trials = P.max_trials; W.ln_filter = P.ln_filter;
     W.th_mono = thMono; W.th_stereo = thStereo;
     W.th_ln_mono = thMono * P.gamma; W.th_ln_stereo = thStereo * P.gamma;            // LineOptimizer.cc:33-35
+    W.protocol = P.protocol; W.robust_pts = P.protocol == 1 ? (P.robust_points != 0) : 1;
+    if (P.protocol == 1) { W.its[1] = 0; W.th_ln_mono = W.th_ln_stereo = thStereo / 2.0; }   // double thHuberLines = thHuber3D/2.0  (Optimizer.cc:358)
     cam_qt0.insert(cam_qt0.end(), w.cam_qt, w.cam_qt + 7 * (size_t)w.n_cams);
     if (w.n_points) pt0.insert(pt0.end(), w.pt_xyz, w.pt_xyz + 3 * (size_t)w.n_points);
     if (w.n_lines) { ln_x0.insert(ln_x0.end(), w.line_x0, w.line_x0 + 3 * (size_t)w.n_lines); ln_dir.insert(ln_dir.end(), w.line_dir, w.line_dir + 3 * (size_t)w.n_lines); }
@@ -199,7 +201,7 @@ int lld_ba_batch_create(lld_ctx* ctx, int n_windows, const lld_ba_window* wins, 
           const bool valid = si == 0 || has_right;
           le_cam.push_back(w.ln_obs_cam[o]); le_ln.push_back(l);
           le_xs.push_back(kl[0]); le_ys.push_back(kl[1]); le_xe.push_back(kl[2]); le_ye.push_back(kl[3]);
-          le_s.push_back(valid ? lld::line_info(P.gamma, w.ln_obs_octave[2 * (size_t)o + si]) : 0.0);
+          le_s.push_back(valid ? (P.protocol == 1 ? 1.0 : lld::line_info(P.gamma, w.ln_obs_octave[2 * (size_t)o + si])) : 0.0);   // AddLineMinimalGlobal: identity
           le_bx.push_back(si == 1 ? W.cam.bx_right : 0.0);
           le_flags0.push_back((uint8_t)((valid ? EF_VALID : 0) | (has_right ? EF_PAIRSTEREO : 0)));
         }
@@ -291,6 +293,11 @@ int lld_ba_batch_create(lld_ctx* ctx, int n_windows, const lld_ba_window* wins, 
   }
   pt_obs_start.push_back((int)NPE); ln_obs_start.push_back((int)NLO);
   if (B->max_cams > kPcgThreads) { delete B; return LLD_ERR_UNSUPPORTED; }
+  // LDS copies of the per-camera accumulators in the linearise kernels: as many as fit (4 for local windows)
+  B->acc_copies = kAccCopies;
+  while (B->acc_copies > 1 && ((size_t)B->max_free * 27 * B->acc_copies + 8 + (size_t)B->max_cams * 7) * sizeof(double) > 150 * 1024) B->acc_copies >>= 1;
+  if (((size_t)B->max_free * 27 * B->acc_copies + 8 + (size_t)B->max_cams * 7) * sizeof(double) > 158 * 1024) { delete B; return LLD_ERR_UNSUPPORTED; }
+  for (int wi = 0; wi < n_windows; wi++) B->h_wins[wi].acc_copies = B->acc_copies;
   B->max_blk = max_blk;
   // fixed-stride result records (what an RCCL gather of the batch moves)
   for (int wi = 0; wi < n_windows; wi++) B->h_wins[wi].rec_off = (long long)(B->rec_stride * (size_t)wi);
@@ -356,7 +363,7 @@ int lld_ba_batch_create(lld_ctx* ctx, int n_windows, const lld_ba_window* wins, 
   {
     const size_t pcg_lds = ((size_t)B->max_free * 6 * 4 + kPcgThreads + (size_t)B->max_free * 36 + 32) * sizeof(double);
     LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_pcg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pcg_lds));
-    const size_t lin_lds = ((size_t)B->max_free * 27 * kAccCopies + 8 + (size_t)B->max_cams * 7) * sizeof(double);
+    const size_t lin_lds = ((size_t)B->max_free * 27 * B->acc_copies + 8 + (size_t)B->max_cams * 7) * sizeof(double);
     LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_linearize_pt_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lin_lds));
     LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_linearize_ln_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lin_lds));
     LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_chol_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
@@ -383,7 +390,7 @@ int lld_ba_batch_solve(lld_ba_batch* B, volatile const int* abort_flag) {
   hipEvent_t t_begin, t_end;
   LLD_HIP_TRY(hipEventCreate(&t_begin)); LLD_HIP_TRY(hipEventCreate(&t_end));
   LLD_HIP_TRY(hipEventRecord(t_begin, ctx->stream));
-  const size_t lin_lds = ((size_t)B->max_free * 27 * kAccCopies + 8 + (size_t)B->max_cams * 7) * sizeof(double);
+  const size_t lin_lds = ((size_t)B->max_free * 27 * B->acc_copies + 8 + (size_t)B->max_cams * 7) * sizeof(double);
   const size_t bs_lds = (8 + (size_t)B->max_cams * 14 + (size_t)B->max_free * 6) * sizeof(double);
   const size_t pcg_lds = ((size_t)B->max_free * 6 * 4 + kPcgThreads + (size_t)B->max_free * 36 + 32) * sizeof(double);
   const size_t chol_fixed = ((size_t)B->max_free * 36 * 2 + (size_t)B->max_free * 6 * 2 + 32) * sizeof(double);

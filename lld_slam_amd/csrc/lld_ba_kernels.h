@@ -42,9 +42,10 @@ constexpr int kLinThreads = 512;        // linearise kernels: 8 tasks per workgr
 constexpr int kRoundsThroughput[4] = {8, 2, 4, 1};
 constexpr int kRoundsLatency[4] = {1, 1, 1, 1};
 constexpr int kRoundsThroughputMinWindows = 32;
-constexpr int kAccCopies = 4;          // LDS copies of the per-camera Hpp/bp accumulators: lanes of one wavefront that hit the
+constexpr int kAccCopies = 4;          // (default; BAWin::acc_copies drops to 2 or 1 when a window's cameras would not fit LDS otherwise)
+constexpr int kAccCopiesDoc = 4;          // LDS copies of the per-camera Hpp/bp accumulators: lanes of one wavefront that hit the
                                        // same camera are spread over them (same-address LDS atomics serialise)
-constexpr int kMaxFreeCams = 96;
+constexpr int kMaxFreeCams = 170;        // the reduced solvers map one lane to one unknown: 6 * 170 <= 1024 lanes
 
 enum Phase : int { PH_RUN = 0, PH_TRANSITION = 2, PH_FINALIZE = 3, PH_DONE = 4 };
 constexpr uint8_t EF_LEVEL1 = 1, EF_ROBUST = 2, EF_VALID = 4, EF_PAIRSTEREO = 8, EF_STEREO = 16;
@@ -72,6 +73,8 @@ struct BAWin {                 // immutable per-window header
   int part_off;                // per-block partial sums
   int its[2];                  // LM iterations per round
   int max_trials, ln_filter;
+  int protocol, robust_pts, acc_copies;   // acc_copies: LDS copies of the per-camera accumulators in the linearise kernels (4, 2 or 1)
+  int pad_w;    // lld_ba_params::protocol / robust_points (1 = global BA: one round, no classification)
   double th_mono, th_stereo;   // Huber deltas of point edges  ((double)(float)sqrt(5.991 / 7.815))
   double th_ln_mono, th_ln_stereo;   // Huber deltas of line edges (x gamma)
   long long rec_off;           // result record (bytes)
@@ -283,7 +286,7 @@ __global__ __launch_bounds__(kLmThreads) void ba_init_kernel(BAArrays A, const B
     A.ln_removed[g] = 0;
   }
   for (int e = gid; e < W.n_pe; e += stride) {
-    A.pe_flags[W.pe_off + e] = (uint8_t)(EF_VALID | EF_ROBUST | (A.pe_ur[W.pe_off + e] < 0 ? 0 : EF_STEREO));
+    A.pe_flags[W.pe_off + e] = (uint8_t)(EF_VALID | (W.robust_pts ? EF_ROBUST : 0) | (A.pe_ur[W.pe_off + e] < 0 ? 0 : EF_STEREO));
     A.pe_chi2[W.pe_off + e] = 0.0; A.pe_ws[W.pe_off + e] = 0.0;
   }
   for (int e = gid; e < W.n_le; e += stride) {
@@ -391,10 +394,10 @@ __global__ __launch_bounds__(kLinThreads, 4) void ba_linearize_pt_kernel(BAArray
   if ((int)blockIdx.x >= W.nl_pt) return;
   const int nacc = W.n_free * 27;
   double* acc_all = lds;                              // kAccCopies x [n_free][21 Hpp upper + 6 bp]
-  double* scratch = lds + kAccCopies * nacc;
+  double* scratch = lds + W.acc_copies * nacc;
   double* cams = scratch + 8;                         // [n_cams][7] poses of the linearisation point
-  for (int i = threadIdx.x; i < kAccCopies * nacc; i += kLinThreads) acc_all[i] = 0.0;
-  double* acc = acc_all + ((threadIdx.x >> 3) & (kAccCopies - 1)) * nacc;
+  for (int i = threadIdx.x; i < W.acc_copies * nacc; i += kLinThreads) acc_all[i] = 0.0;
+  double* acc = acc_all + ((threadIdx.x >> 3) & (W.acc_copies - 1)) * nacc;
   const int cur = S.cur;
   for (int i = threadIdx.x; i < W.n_cams * 7; i += kLinThreads) cams[i] = A.cam_qt[((size_t)cur * A.NC + W.cam_off) * 7 + i];
   __syncthreads();
@@ -488,8 +491,7 @@ __global__ __launch_bounds__(kLinThreads, 4) void ba_linearize_pt_kernel(BAArray
   double* dst = A.hpp_part + W.hpart_off + (size_t)(blockIdx.x) * nacc;
   for (int i = threadIdx.x; i < nacc; i += kLinThreads) {
     double v = 0.0;
-#pragma unroll
-    for (int q = 0; q < kAccCopies; q++) v += acc_all[q * nacc + i];
+    for (int q = 0; q < W.acc_copies; q++) v += acc_all[q * nacc + i];
     dst[i] = v;
   }
 }
@@ -738,9 +740,9 @@ __global__ __launch_bounds__(kLinThreads) void ba_linearize_ln_kernel(BAArrays A
   if ((int)blockIdx.x >= W.nl_ln) return;
   const int nacc = W.n_free * 27;
   double* acc_all = lds;                              // kAccCopies x [n_free][21 Hpp upper + 6 bp]
-  double* scratch = lds + kAccCopies * nacc;
-  for (int i = threadIdx.x; i < kAccCopies * nacc; i += kLinThreads) acc_all[i] = 0.0;
-  double* acc = acc_all + ((threadIdx.x >> 3) & (kAccCopies - 1)) * nacc;
+  double* scratch = lds + W.acc_copies * nacc;
+  for (int i = threadIdx.x; i < W.acc_copies * nacc; i += kLinThreads) acc_all[i] = 0.0;
+  double* acc = acc_all + ((threadIdx.x >> 3) & (W.acc_copies - 1)) * nacc;
   __syncthreads();
   const int cur = S.cur;
   const int lane = threadIdx.x & 63;
@@ -795,8 +797,7 @@ __global__ __launch_bounds__(kLinThreads) void ba_linearize_ln_kernel(BAArrays A
   double* dst = A.hpp_part + W.hpart_off + (size_t)(W.nl_pt + blockIdx.x) * nacc;
   for (int i = threadIdx.x; i < nacc; i += kLinThreads) {
     double v = 0.0;
-#pragma unroll
-    for (int q = 0; q < kAccCopies; q++) v += acc_all[q * nacc + i];
+    for (int q = 0; q < W.acc_copies; q++) v += acc_all[q * nacc + i];
     dst[i] = v;
   }
 }
@@ -1840,7 +1841,9 @@ __global__ __launch_bounds__(kCtlThreads) void ba_control_kernel(BAArrays A, con
       if (!term && S.it < W.its[round] && !abort_flag) { S.need_lin = 1; S.maxdiag_bits = 0ull; do_clear = 1; }
       else if (round == 0) {
         S.chi2_round1 = S.currentChi; S.chi2_final = S.currentChi;
-        if (abort_flag) { S.aborted = 1; S.phase = PH_FINALIZE; } else S.phase = PH_TRANSITION;
+        if (abort_flag) { S.aborted = 1; S.phase = PH_FINALIZE; }
+        else if (W.protocol == 1) S.phase = PH_FINALIZE;              // global BA: optimize(nIterations) and nothing else
+        else S.phase = PH_TRANSITION;
       } else { S.chi2_final = S.currentChi; S.phase = PH_FINALIZE; }
     }
   }
@@ -1954,6 +1957,7 @@ __global__ __launch_bounds__(kLmThreads) void ba_finalize_kernel(BAArrays A, con
   const int cur = S.cur;
   const CamK cam = W.cam;
   // Optimizer.cc:1220-1222: a stop request before the first optimize() returns without classifying or writing anything
+  const bool global = W.protocol == 1;                     // Optimizer::BundleAdjustment erases nothing: all flags stay 0
   const bool untouched = S.aborted && S.lm_trials[0] == 0;
   unsigned char* rec = A.records + W.rec_off;
   double* o_cam = rec_cam(rec);
@@ -1985,7 +1989,7 @@ __global__ __launch_bounds__(kLmThreads) void ba_finalize_kernel(BAArrays A, con
         const Pose T = load_cam(A, cur, W.cam_off + A.pe_cam[e]);
         const bool depth_pos = pose_map(T, X).z > 0.0;
         const bool stereo = !(A.pe_ur[e] < 0);
-        o_pe[e - W.pe_off] = (!untouched && (A.pe_chi2[e] > (stereo ? 7.815 : 5.991) || !depth_pos)) ? 1 : 0;      // Optimizer.cc:1290,1305
+        o_pe[e - W.pe_off] = (!untouched && !global && (A.pe_chi2[e] > (stereo ? 7.815 : 5.991) || !depth_pos)) ? 1 : 0;      // Optimizer.cc:1290,1305
       }
     }
   } else {
@@ -2015,7 +2019,7 @@ __global__ __launch_bounds__(kLmThreads) void ba_finalize_kernel(BAArrays A, con
           const double c2 = chi2_of(r, 2, A.le_s[e]);
           A.le_chi2[e] = c2;
           const double th = (fl & EF_PAIRSTEREO) ? W.th_ln_stereo : W.th_ln_mono;
-          o_le[e - W.le_off] = (c2 > th * th || !depth_pos) ? 1 : 0;                               // LineOptimizer.cc:185-196
+          o_le[e - W.le_off] = (!global && (c2 > th * th || !depth_pos)) ? 1 : 0;                    // LineOptimizer.cc:185-196
         }
       }
     }

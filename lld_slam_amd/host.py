@@ -368,6 +368,12 @@ class Optimizer:
     def LocalBundleAdjustment(self, window: Window, pbStopFlag: bool = False, gamma: float = 1.0, **params) -> BAOutput:
         return ba_call(self.lib, self.ctx.handle, window, ba_params(self.lib, gamma, **params), pbStopFlag)
 
+    def GlobalBundleAdjustment(self, window: Window, nIterations: int = 5, pbStopFlag: bool = False, bRobust: bool = True, **params) -> BAOutput:
+        """Optimizer::GlobalBundleAdjustment / BundleAdjustment (src/Optimizer.cc:312-559): the window is the whole map (every
+        keyframe but mnId==0 free), ONE optimize(nIterations), no outlier handling, identity line information."""
+        return ba_call(self.lib, self.ctx.handle, window,
+                       ba_params(self.lib, 1.0, protocol=1, its_round1=nIterations, robust_points=1 if bRobust else 0, **params), pbStopFlag)
+
     def PoseOptimization(self, frame: PoseFrame, gamma: float = 1.0, **params) -> PoseOutput:
         return pose_call(self.lib, self.ctx.handle, frame, pose_params(self.lib, gamma, **params))
 

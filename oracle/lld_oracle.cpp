@@ -424,7 +424,7 @@ void lldo_reproject_line_point(const double* X0, const double* ldir, double px, 
 
 void lldo_ba_params_default(lld_ba_params* p) {
   p->gamma = 1.0; p->its_round1 = 5; p->its_round2 = 15; p->ln_filter = 4; p->max_trials = 10;
-  p->pcg_rel_tol = 1e-12; p->pcg_max_iter = 0; p->reduced_solver = 0;
+  p->pcg_rel_tol = 1e-12; p->pcg_max_iter = 0; p->reduced_solver = 0; p->protocol = 0; p->robust_points = 1;
 }
 void lldo_pose_params_default(lld_pose_params* p) { p->gamma = 0.5; p->n_rounds = 4; p->its_per_round = 10; p->max_trials = 10; p->reserved = 0; }
 
@@ -453,7 +453,8 @@ static void ba_setup(BASystem& S, const lld_ba_window* in, const lld_ba_params* 
       e.obs[0] = in->pt_obs_uvr[3 * o]; e.obs[1] = in->pt_obs_uvr[3 * o + 1]; e.obs[2] = in->pt_obs_uvr[3 * o + 2];
       e.stereo = !(e.obs[2] < 0);           // if(pKFi->mvuRight[...]<0) -> mono (Optimizer.cc:1119)
       e.s = in->pt_obs_inv_sigma2[o];
-      e.level = 0; e.robust = true; e.hub = huber_make(e.stereo ? thHuberStereo : thHuberMono);
+      e.level = 0; e.robust = prm->protocol == 1 ? prm->robust_points != 0 : true;      // if(bRobust)  (Optimizer.cc:405,437)
+      e.hub = huber_make(e.stereo ? thHuberStereo : thHuberMono);
       e.err[0] = e.err[1] = e.err[2] = 0;
       S.pe.push_back(e);
     }
@@ -478,6 +479,10 @@ static void ba_setup(BASystem& S, const lld_ba_window* in, const lld_ba_params* 
         const double thr = reproj_thr_pyramid(1.0, in->ln_obs_octave[2 * o + si]);
         double info = infoLines; info /= thr * thr;
         e.s = info;
+        if (prm->protocol == 1) {            // AddLineMinimalGlobal (Optimizer.cc:149-240): identity information, delta = thHuber3D/2.0
+          e.s = 1.0;
+          e.hub = huber_make((double)(float)std::sqrt(7.815) / 2.0);
+        }
         e.level = 0; e.robust = true; e.removed = false;
         S.le.push_back(e);
         S.ln_edge_error(S.le.back());   // e->computeError() before addEdge (LineOptimizer.cc:114)
@@ -515,6 +520,8 @@ extern "C" int lldo_local_ba(void* /*ctx*/, const lld_ba_window* in, const lld_b
   out->stats.lm_iterations[0] = lm.iterations; out->stats.lm_trials[0] = lm.trials;
   bool bDoMore = true;
   if (abort_flag && *abort_flag) { bDoMore = false; out->stats.aborted = 1; }
+  const bool global = prm.protocol == 1;     // Optimizer::BundleAdjustment: optimize(nIterations), then "Recover optimized data" (:493-558)
+  if (global) bDoMore = false;
   const double thLinesStereo = (double)(float)std::sqrt(7.815) * prm.gamma, thLinesMono = (double)(float)std::sqrt(5.991) * prm.gamma;
   if (bDoMore) {
     for (auto& e : S.pe) {
@@ -542,7 +549,7 @@ extern "C" int lldo_local_ba(void* /*ctx*/, const lld_ba_window* in, const lld_b
     out->stats.lm_iterations[1] = lm2.iterations; out->stats.lm_trials[1] = lm2.trials;
   }
   // final classification (Optimizer.cc:1278-1329)
-  {
+  if (!global) {
     int o = 0;
     for (auto& e : S.pe) {
       const bool depth_pos = se3_map(S.cams[e.cam], S.pts[e.pt]).z > 0.0;
@@ -551,6 +558,7 @@ extern "C" int lldo_local_ba(void* /*ctx*/, const lld_ba_window* in, const lld_b
     }
   }
   for (auto& e : S.le) {
+    if (global) break;
     if (S.line_removed[e.line]) continue;      // GetLineData returns false: vertex deleted
     const bool depth_pos = line_depth_positive(S.lf, S.lcx, S.lcy, e.bx, S.cams[e.cam], S.lines[e.line], e.x1, e.x2);
     S.ln_edge_error(e);

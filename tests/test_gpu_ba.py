@@ -198,3 +198,39 @@ def test_invalid_inputs_are_refused_and_poison_is_contained(gpu_ctx, oracle):
     with BABatch(gpu_ctx, [nan, good]) as b:
         b.solve()
         check_ba(b.download(1), oracle.local_ba(good), good)
+
+
+@pytest.mark.parametrize("wid,kw,its,robust", [
+    (40, dict(n_free=7, n_fixed=1, n_points=250, n_lines=40, outlier_frac=0.1), 5, True),
+    (41, dict(n_free=12, n_fixed=1, n_points=500, n_lines=80, mono_frac=0.2, mono_line_frac=0.2), 10, True),
+    (42, dict(n_free=6, n_fixed=1, n_points=200, n_lines=30, outlier_frac=0.0), 20, False),       # bRobust = false
+    (43, dict(n_free=60, n_fixed=1, n_points=1500, n_lines=150), 5, True),                          # above the matrix-core tile limit
+    (44, dict(n_free=170, n_fixed=1, n_points=4000, n_lines=400), 5, True),                         # 170 keyframes (the limit): 2 LDS accumulator copies, streamed Cholesky
+])
+def test_global_bundle_adjustment_protocol(gpu_ctx, oracle, wid, kw, its, robust):
+    """Optimizer::GlobalBundleAdjustment on the same kernels: one optimize(n), no classification, identity line information."""
+    w = synth.make_lba_small(wid, **kw)
+    g = Optimizer(gpu_ctx).GlobalBundleAdjustment(w, its, bRobust=robust)
+    o = oracle.local_ba(w, protocol=1, its_round1=its, robust_points=1 if robust else 0)
+    check_ba(g, o, w)
+    assert g.stats["lm_iterations"][1] == 0 and not g.pt_obs_outlier.any() and not g.ln_edge_outlier.any() and not g.line_removed.any()
+    assert g.stats["chi2_final"] == g.stats["chi2_round1"]
+
+
+def test_large_window_limits(gpu_ctx, oracle):
+    """Up to 170 free cameras per window; the local protocol works there too, beyond that the library refuses."""
+    w = synth.make_lba_small(45, n_free=130, n_fixed=2, n_points=2500, n_lines=200)
+    check_ba(Optimizer(gpu_ctx).LocalBundleAdjustment(w), oracle.local_ba(w), w)
+    check_ba(Optimizer(gpu_ctx).LocalBundleAdjustment(w, reduced_solver=1), oracle.local_ba(w), w)      # PCG on an 780 x 780 system
+    big = synth.make_lba_small(46, n_free=171, n_fixed=1, n_points=1200, n_lines=0)
+    with pytest.raises(RuntimeError):
+        Optimizer(gpu_ctx).GlobalBundleAdjustment(big)
+
+
+def test_global_and_local_protocols_share_a_batch_engine(gpu_ctx, oracle):
+    """A resident batch solved with protocol 1 (e.g. one GBA problem per loop candidate)."""
+    ws = [synth.make_lba_small(50 + i, n_free=5 + i, n_fixed=1, n_points=150 + 40 * i, n_lines=20 + 5 * i) for i in range(4)]
+    with BABatch(gpu_ctx, ws, protocol=1, its_round1=8) as b:
+        b.solve()
+        for i, w in enumerate(ws):
+            check_ba(b.download(i), oracle.local_ba(w, protocol=1, its_round1=8), w)

@@ -159,3 +159,27 @@ def test_order_sensitivity_is_the_noise_floor(oracle):
     np.testing.assert_allclose(a.cam_qt, b.cam_qt, rtol=0, atol=1e-6)
     rel = np.linalg.norm(a.pt_xyz - b.pt_xyz, axis=1) / np.linalg.norm(a.pt_xyz, axis=1)
     assert rel.max() < 1e-4
+
+
+def test_global_ba_protocol_rules(oracle):
+    """Optimizer::BundleAdjustment (src/Optimizer.cc:321-559): one optimize(n) call, nothing classified or erased, line edges with
+    identity information and delta thHuber3D/2, point kernels only when bRobust."""
+    w = synth.make_lba_small(30, n_free=7, n_fixed=1, n_points=250, n_lines=40, outlier_frac=0.1)
+    g = oracle.local_ba(w, protocol=1, its_round1=6)
+    assert g.stats["lm_iterations"][1] == 0 and g.stats["lm_trials"][1] == 0 and 1 <= g.stats["lm_iterations"][0] <= 6
+    assert g.stats["chi2_final"] == g.stats["chi2_round1"]
+    assert not g.pt_obs_outlier.any() and not g.ln_edge_outlier.any() and not g.line_removed.any()
+    assert g.stats["n_pt_obs_outlier"] == 0 and g.stats["n_lines_removed"] == 0
+    np.testing.assert_array_equal(g.cam_qt[w.n_free_cams:], w.cam_qt[w.n_free_cams:])
+    # gamma and ln_filter play no role
+    g2 = oracle.local_ba(w, gamma=0.3, protocol=1, its_round1=6, ln_filter=99)
+    np.testing.assert_array_equal(g.cam_qt, g2.cam_qt); np.testing.assert_array_equal(g.line_x0, g2.line_x0)
+    # bRobust = false is a different (plain least squares) problem: gross outliers pull harder
+    g3 = oracle.local_ba(w, protocol=1, its_round1=6, robust_points=0)
+    assert g3.stats["chi2_final"] > g.stats["chi2_final"] and not np.allclose(g3.cam_qt, g.cam_qt)
+    # more iterations never raise the cost (LM accepts only decreasing steps)
+    g10 = oracle.local_ba(w, protocol=1, its_round1=12)
+    assert g10.stats["chi2_final"] <= g.stats["chi2_final"] * (1 + 1e-12)
+    # and it is not the local protocol
+    loc = oracle.local_ba(w)
+    assert loc.stats["lm_iterations"][1] > 0

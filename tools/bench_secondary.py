@@ -34,6 +34,16 @@ if nla > 0:
     t = time.perf_counter(); oa = O.local_ba(wa[0]); dtc = time.perf_counter() - t
     out["local_ba_lba_a"] = {"windows": nla, "gpu_windows_per_s": nla / dt, "cpu_oracle_windows_per_s": 1 / dtc,
                              "chi2_rel": abs(ga.stats["chi2_final"] - oa.stats["chi2_final"]) / oa.stats["chi2_final"]}
+# ---- GlobalBundleAdjustment protocol (src/Optimizer.cc:312-559) on one map: 170 keyframes, 12k points x 4 obs, 1.2k lines, 10 iterations
+from lld_slam_amd import Optimizer
+wg = synth.make_ba_window(170, 1, 12000, 4, 1200, 4, seed=0x6BA00000)
+opt = Optimizer(ctx)
+opt.GlobalBundleAdjustment(wg, 10)
+t = time.perf_counter(); gg = opt.GlobalBundleAdjustment(wg, 10); dt = time.perf_counter() - t
+t = time.perf_counter(); og = O.local_ba(wg, protocol=1, its_round1=10); dtc = time.perf_counter() - t
+out["global_ba_170kf"] = {"gpu_ms": dt * 1e3, "cpu_oracle_ms": dtc * 1e3, "edges": int(wg.n_pt_obs + 2 * wg.n_ln_obs),
+                          "chi2_rel": abs(gg.stats["chi2_final"] - og.stats["chi2_final"]) / og.stats["chi2_final"],
+                          "lm_iterations": gg.stats["lm_iterations"][0]}
 # ---- ORB 2000 x 2000 Hamming best/second, batched in HBM
 B, nq, nt = 256, 2000, 2000
 dev = torch.device("cuda", 0)
