@@ -55,16 +55,19 @@ __device__ __forceinline__ void wave_sum_all(double* v) {
     v[i] = x;
   }
 }
-// Fixed-tree block sum of one double per lane; every lane returns the total.
-__device__ __forceinline__ double block_sum1(double x, double* lds /* [kPoseWaves] */) {
+// Fixed-tree block sum of one double per lane; every lane returns the total.  Consecutive calls alternate between two LDS
+// buffers (`flip`), so ONE barrier per call is enough: a buffer is rewritten only after every lane has passed the barrier of the
+// call in between, i.e. after it has read the previous contents.
+__device__ __forceinline__ double block_sum1(double x, double* lds /* [2][kPoseWaves] */, int& flip) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   wave_sum_all<1>(&x);
+  double* buf = lds + flip * kPoseWaves;
+  flip ^= 1;
+  if (lane == 0) buf[wave] = x;
   __syncthreads();
-  if (lane == 0) lds[wave] = x;
-  __syncthreads();
-  double s = lds[0];
+  double s = buf[0];
 #pragma unroll
-  for (int w = 1; w < kPoseWaves; w++) s += lds[w];
+  for (int w = 1; w < kPoseWaves; w++) s += buf[w];
   return s;
 }
 
@@ -89,6 +92,46 @@ __device__ __forceinline__ void wave_sum28(const double* v, double* dst) {
   r += __shfl_xor(r, 1);
   const int sub = (b3 ? 4 : 0) + (b2 ? 2 : 0) + (b1 ? 1 : 0);
   if (!(lane & 1) && sub < 7) dst[(b5 ? 14 : 0) + (b4 ? 7 : 0) + sub] = r;
+}
+
+// pose_oplus of lld_device_math.h with the two quaternion normalisations done by one reciprocal each instead of four divisions:
+// the solve runs on ONE lane while the workgroup waits, and fp64 divisions (~30 dependent instructions each) were most of it.
+// Differs from the division form by at most one rounding per component, far inside the 1e-5 parity band.
+__device__ __forceinline__ void pose_normalize_rcp(Pose& p) {
+  if (p.q.w < 0) { p.q.x = -p.q.x; p.q.y = -p.q.y; p.q.z = -p.q.z; p.q.w = -p.q.w; }
+  const double inv = 1.0 / sqrt(p.q.x * p.q.x + p.q.y * p.q.y + p.q.z * p.q.z + p.q.w * p.q.w);
+  p.q.x *= inv; p.q.y *= inv; p.q.z *= inv; p.q.w *= inv;
+}
+__device__ __forceinline__ Pose pose_oplus_rcp(const Pose& T, const double* u) {
+  const Vec3 w = vec3(u[0], u[1], u[2]), v = vec3(u[3], u[4], u[5]);
+  const double ww = dot(w, w);
+  const double theta = sqrt(ww);
+  double a, b, c;
+  if (theta < 0.00001) { a = 1.0; b = 1.0; c = 1.0; }
+  else {
+    double s, co; sincos(theta, &s, &co);
+    const double it = 1.0 / theta, it2 = it * it;
+    a = s * it; b = (1 - co) * it2; c = (theta - s) * it2 * it;
+  }
+  Mat3 R;
+  const double W2[3][3] = {{w.x * w.x - ww, w.x * w.y, w.x * w.z}, {w.y * w.x, w.y * w.y - ww, w.y * w.z}, {w.z * w.x, w.z * w.y, w.z * w.z - ww}};
+  const double W1[3][3] = {{0, -w.z, w.y}, {w.z, 0, -w.x}, {-w.y, w.x, 0}};
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+#pragma unroll
+    for (int j = 0; j < 3; j++) R.m[i][j] = ((i == j ? 1.0 : 0.0) + a * W1[i][j]) + b * W2[i][j];
+  }
+  const Vec3 wv = cross(w, v);
+  const Vec3 wwv = cross(w, wv);
+  Pose E;
+  E.q = quat_from_rotation(R);
+  E.t = v + b * wv + c * wwv;
+  pose_normalize_rcp(E);
+  Pose r;
+  r.t = E.t + quat_rotate(E.q, T.t);
+  r.q = quat_mul(E.q, T.q);
+  pose_normalize_rcp(r);
+  return r;
 }
 
 // Dense LDL^T of the 6x6 system (LinearSolverDense, solvers/linear_solver_dense.h:65-113): fails unless all pivots > 0.
@@ -176,7 +219,8 @@ __global__ __launch_bounds__(kPoseThreads) void pose_opt_kernel(const PoseFrameD
   __shared__ double red[kPoseWaves * 28];       // per-wavefront partials of the normal equations
   __shared__ double tot[28];                    // H (21 upper), b (6), robust chi2
   __shared__ double sol[16];                    // trial pose (7), scale, solver ok
-  __shared__ double red1[kPoseWaves];
+  __shared__ double red1[2 * kPoseWaves];
+  int flip = 0;
   const PoseFrameDev& F = frames[blockIdx.x];
   const CamK cam = F.cam;
   const int tid = threadIdx.x;
@@ -297,7 +341,7 @@ __global__ __launch_bounds__(kPoseThreads) void pose_opt_kernel(const PoseFrameD
       double cnt = 0.0;
       for (int i = tid; i < n_pt; i += kPoseThreads) cnt += (pfl[i] & PF_LEVEL) ? 0.0 : 1.0;
       for (int i = tid; i < n_le; i += kPoseThreads) cnt += (lfl[i] & LF_LEVEL) ? 0.0 : 1.0;
-      cnt = block_sum1(cnt, red1);
+      cnt = block_sum1(cnt, red1, flip);
       if (cnt > 0.5) {
         bool ok = true;
         for (int it = 0; it < its_per_round && ok; it++) {
@@ -305,8 +349,7 @@ __global__ __launch_bounds__(kPoseThreads) void pose_opt_kernel(const PoseFrameD
           {
             double acc[28];
             sweep_build(T, acc);
-            __syncthreads();                                         // previous readers of red / tot / sol are done
-            wave_sum28(acc, red + (tid >> 6) * 28);
+            wave_sum28(acc, red + (tid >> 6) * 28);               // red / tot were last read before the previous trial's barrier
             __syncthreads();
             if (tid < 28) {
               double sv = red[tid];
@@ -314,34 +357,43 @@ __global__ __launch_bounds__(kPoseThreads) void pose_opt_kernel(const PoseFrameD
               for (int w = 1; w < kPoseWaves; w++) sv += red[w * 28 + tid];
               tot[tid] = sv;
             }
-            __syncthreads();
           }
-          double currentChi = tot[27];
-          const double iniChi = currentChi;
-          if (it == 0) {
-            double md = 0.0; int k = 0;
-            for (int r = 0; r < 6; r++) { md = fmax(fabs(tot[k]), md); k += 6 - r; }
-            lambda = 1e-5 * md; ni = 2.0; nBadLM = 0;
-          }
+          // lanes 0..27 belong to wavefront 0, which runs in lockstep: its lane 0 may read `tot` without a workgroup barrier; the
+          // other wavefronts read tot[27] only after the barrier that follows the first solve
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          __builtin_amdgcn_wave_barrier();
+          bool first_trial = true;
+          double currentChi = 0.0, iniChi = 0.0;
           double rho = 0.0; int q = 0;
           do {
             if (tid == 0) {                                          // one lane solves; the others wait at the barrier
               double Hb[27], x[6];
 #pragma unroll
               for (int i = 0; i < 27; i++) Hb[i] = tot[i];
+              if (first_trial && it == 0) {                          // computeLambdaInit: 1e-5 * max diagonal, iteration 0 of every optimize()
+                double md = 0.0; int k = 0;
+#pragma unroll
+                for (int r = 0; r < 6; r++) { md = fmax(fabs(Hb[k]), md); k += 6 - r; }
+                lambda = 1e-5 * md;
+              }
               const bool ok2 = solve6(Hb, lambda, Hb + 21, x);
-              const Pose Tn = pose_oplus(T, x);
+              const Pose Tn = pose_oplus_rcp(T, x);
               double scale = 0.0;
               for (int j = 0; j < 6; j++) scale += x[j] * (lambda * x[j] + Hb[21 + j]);
               scale += 1e-3;
               pose_store(Tn, sol);
-              sol[7] = scale; sol[8] = ok2 ? 1.0 : 0.0;
+              sol[7] = scale; sol[8] = ok2 ? 1.0 : 0.0; sol[9] = lambda;
             }
             __syncthreads();
             const Pose Tn = pose_load(sol);
             const double scale = sol[7];
             const bool ok2 = sol[8] != 0.0;
-            const double tmp = block_sum1(sweep_chi(Tn), red1);     // its barriers also fence `sol` against the next trial
+            if (first_trial) {
+              currentChi = tot[27]; iniChi = currentChi;
+              if (it == 0) { lambda = sol[9]; ni = 2.0; nBadLM = 0; }
+              first_trial = false;
+            }
+            const double tmp = block_sum1(sweep_chi(Tn), red1, flip);   // its barrier also fences `sol` and `tot` against the next trial
             const double tempChi = ok2 ? tmp : 1.7976931348623157e308;
             rho = (currentChi - tempChi) / scale;
             if (rho > 0 && isfinite(tempChi)) {
@@ -380,7 +432,7 @@ __global__ __launch_bounds__(kPoseThreads) void pose_opt_kernel(const PoseFrameD
         pfl[i] = fl;
         nb += bad ? 1.0 : 0.0;
       }
-      nb = block_sum1(nb, red1);
+      nb = block_sum1(nb, red1, flip);
       nBad_pts = (int)(nb + 0.5);
       if (n_pt + n_le < 10) break;                                   // if(optimizer.edges().size()<10) break;
       // vnStereoLines is filled per EDGE but indexed by the LINE index (Optimizer.cc:643-648 vs :898): the test below reads
