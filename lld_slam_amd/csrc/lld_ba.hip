@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cmath>
 
+#include <chrono>
 #include "lld_ba_kernels.h"
 
 using namespace lldba;
@@ -18,7 +19,7 @@ struct lld_ba_batch {
   lld_ba_params params;
   std::vector<BAWin> h_wins;
   std::vector<SChunk> h_chunks; std::vector<PTask> h_ptasks, h_ltasks;
-  void* slab = nullptr; size_t slab_bytes = 0;
+  void* slab = nullptr; bool borrowed = false; size_t slab_bytes = 0;
   BAArrays A;
   BAWin* d_wins = nullptr; BAState* d_state = nullptr;
   // window groups solved concurrently, each on its own stream (hides the latency-bound reduced solve, the per-super-step
@@ -111,11 +112,16 @@ static int ba_make_groups(lld_ba_batch* B, int n_groups) {
 
 extern "C" {
 
-int lld_ba_batch_create(lld_ctx* ctx, int n_windows, const lld_ba_window* wins, const lld_ba_params* params, lld_ba_batch** out) {
+// `borrow`: the slab and the pinned poll counters come from the context (grow-only, reused by the next call) instead of a fresh
+// allocation - what lld_local_ba uses, one window at a time on one host thread.
+static int ba_batch_create_impl(lld_ctx* ctx, int n_windows, const lld_ba_window* wins, const lld_ba_params* params, lld_ba_batch** out, bool borrow) {
   if (!ctx || n_windows <= 0 || !wins || !out) return LLD_ERR_INVALID;
   *out = nullptr;
   for (int w = 0; w < n_windows; w++) { int st = validate_window(wins[w]); if (st) return st; }
   LLD_HIP_TRY(hipSetDevice(ctx->device));
+  static const bool timing = std::getenv("LLD_BA_TIMING") != nullptr;
+  const auto tc0 = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) { if (timing) std::fprintf(stderr, "[ba_create] %s at %.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc0).count()); };
   lld_ba_batch* B = new lld_ba_batch();
   B->ctx = ctx; B->n_windows = n_windows;
   if (params) B->params = *params; else lld_ba_params_default(&B->params);
@@ -133,6 +139,18 @@ int lld_ba_batch_create(lld_ctx* ctx, int n_windows, const lld_ba_window* wins, 
   const double thMono = (double)(float)std::sqrt(5.991), thStereo = (double)(float)std::sqrt(7.815);   // Optimizer.cc:1088-1089
   long long NC = 0, NP = 0, NL = 0, NPE = 0, NLO = 0, NF = 0, NPART = 0;
   size_t S_total = 0, x_total = 0, rec_total = 0;
+  {   // exact sizes are known up front: no reallocation while the windows are flattened
+    size_t tc = 0, tp = 0, tl = 0, tpe = 0, tlo = 0;
+    for (int wi = 0; wi < n_windows; wi++) { tc += wins[wi].n_cams; tp += wins[wi].n_points; tl += wins[wi].n_lines; tpe += wins[wi].n_pt_obs; tlo += wins[wi].n_ln_obs; }
+    cam_qt0.reserve(7 * tc); pt0.reserve(3 * tp); ln_x0.reserve(3 * tl); ln_dir.reserve(3 * tl);
+    pt_obs_start.reserve(tp + 2); ln_obs_start.reserve(tl + 2);
+    for (auto* v : {&pe_u, &pe_v, &pe_ur, &pe_s}) v->reserve(tpe);
+    for (auto* v : {&pe_cam, &pe_pt}) v->reserve(tpe);
+    for (auto* v : {&le_xs, &le_ys, &le_xe, &le_ye, &le_s, &le_bx}) v->reserve(2 * tlo);
+    for (auto* v : {&le_cam, &le_ln}) v->reserve(2 * tlo);
+    le_flags0.reserve(2 * tlo);
+    sg_lm.reserve(tp + tl); sg_tab.reserve(tpe + tlo);
+  }
   for (int wi = 0; wi < n_windows; wi++) {
     const lld_ba_window& w = wins[wi];
     BAWin& W = B->h_wins[wi];
@@ -219,23 +237,31 @@ int lld_ba_batch_create(lld_ctx* ctx, int n_windows, const lld_ba_window* wins, 
       const int32_t* start = D == 3 ? w.pt_obs_start : w.ln_obs_start;
       const int32_t* ocam = D == 3 ? w.pt_obs_cam : w.ln_obs_cam;
       const long long id_base = D == 3 ? NPE : NLO, lm_base = D == 3 ? NP : NL;
-      struct Sig { int lm; std::vector<std::pair<int, int>> pairs; };      // (camera, global lc-pair id), free cameras only
-      std::vector<Sig> sigs; sigs.reserve(n_lm);
+      // a landmark's signature = its free cameras in ascending order (ties keep the observation order) with the ids of the
+      // matching observations; flat arrays, no per-landmark allocation
+      std::vector<int> soff(1, 0), scam, sid, sigs;                    // sigs: landmarks that touch a free camera
+      soff.reserve(n_lm + 1); scam.reserve(start[n_lm] - start[0]); sid.reserve(start[n_lm] - start[0]); sigs.reserve(n_lm);
       for (int l = 0; l < n_lm; l++) {
-        Sig sg; sg.lm = l;
-        for (int o = start[l]; o < start[l + 1]; o++) if (ocam[o] < w.n_free_cams) sg.pairs.push_back({ocam[o], (int)(id_base + o)});
-        if (sg.pairs.empty()) continue;
-        std::stable_sort(sg.pairs.begin(), sg.pairs.end(), [](const std::pair<int, int>& a, const std::pair<int, int>& b) { return a.first < b.first; });
-        sigs.push_back(std::move(sg));
+        const int b0 = (int)scam.size();
+        for (int o = start[l]; o < start[l + 1]; o++) {
+          if (ocam[o] >= w.n_free_cams) continue;
+          int at = (int)scam.size();
+          scam.push_back(ocam[o]); sid.push_back((int)(id_base + o));
+          while (at > b0 && scam[at - 1] > scam[at]) { std::swap(scam[at - 1], scam[at]); std::swap(sid[at - 1], sid[at]); at--; }   // stable insertion
+        }
+        soff.push_back((int)scam.size());
+        if ((int)scam.size() > b0) sigs.push_back(l);
       }
-      auto same_cams = [](const Sig& a, const Sig& b) {
-        if (a.pairs.size() != b.pairs.size()) return false;
-        for (size_t i = 0; i < a.pairs.size(); i++) if (a.pairs[i].first != b.pairs[i].first) return false;
-        return true;
+      auto sig_k = [&](int l) { return soff[l + 1] - soff[l]; };
+      auto same_cams = [&](int a, int b) {
+        if (sig_k(a) != sig_k(b)) return false;
+        return std::equal(scam.begin() + soff[a], scam.begin() + soff[a + 1], scam.begin() + soff[b]);
       };
-      std::stable_sort(sigs.begin(), sigs.end(), [](const Sig& a, const Sig& b) {
-        if (a.pairs.size() != b.pairs.size()) return a.pairs.size() < b.pairs.size();
-        for (size_t i = 0; i < a.pairs.size(); i++) if (a.pairs[i].first != b.pairs[i].first) return a.pairs[i].first < b.pairs[i].first;
+      std::stable_sort(sigs.begin(), sigs.end(), [&](int a, int b) {
+        const int ka = sig_k(a), kb = sig_k(b);
+        if (ka != kb) return ka < kb;
+        const int* pa = scam.data() + soff[a]; const int* pb = scam.data() + soff[b];
+        for (int i = 0; i < ka; i++) if (pa[i] != pb[i]) return pa[i] < pb[i];
         return false;
       });
       size_t i0 = 0;
@@ -243,18 +269,19 @@ int lld_ba_batch_create(lld_ctx* ctx, int n_windows, const lld_ba_window* wins, 
         size_t i1 = i0 + 1;
         while (i1 < sigs.size() && i1 - i0 < (size_t)B->chunk_landmarks && same_cams(sigs[i0], sigs[i1])) i1++;
         SChunk C; std::memset(&C, 0, sizeof C);
-        C.k = (int)sigs[i0].pairs.size(); C.D = D; C.n_lm = (int)(i1 - i0);
+        const int* c0cams = scam.data() + soff[sigs[i0]];
+        C.k = sig_k(sigs[i0]); C.D = D; C.n_lm = (int)(i1 - i0);
         C.lm_off = (int)sg_lm.size(); C.tab_off = (int)sg_tab.size(); C.cams_off = (int)sg_cams.size();
-        for (auto& pr : sigs[i0].pairs) sg_cams.push_back(pr.first);
-        for (size_t i = i0; i < i1; i++) { sg_lm.push_back((int)(lm_base + sigs[i].lm)); for (auto& pr : sigs[i].pairs) sg_tab.push_back(pr.second); }
+        sg_cams.insert(sg_cams.end(), c0cams, c0cams + C.k);
+        for (size_t i = i0; i < i1; i++) { sg_lm.push_back((int)(lm_base + sigs[i])); sg_tab.insert(sg_tab.end(), sid.begin() + soff[sigs[i]], sid.begin() + soff[sigs[i] + 1]); }
         C.part_off = (int)n_part; C.cpart_off = (int)n_cpart;
         {
           int pidx = 0;
           for (int sa = 0; sa < C.k; sa++) {
-            const int ca = sigs[i0].pairs[sa].first;
+            const int ca = c0cams[sa];
             cam_lists[ca].push_back((int)n_cpart + sa);
             for (int sb = sa; sb < C.k; sb++, pidx++) {
-              const int cb = sigs[i0].pairs[sb].first;                 // cb >= ca (slots are sorted by camera)
+              const int cb = c0cams[sb];                               // cb >= ca (slots are sorted by camera)
               const int mode = ca != cb ? 0 : (sa == sb ? 1 : 2);
               blk_lists[cb * (cb + 1) / 2 + ca].push_back(((int)n_part + pidx) * 4 + mode);
             }
@@ -353,13 +380,17 @@ int lld_ba_batch_create(lld_ctx* ctx, int n_windows, const lld_ba_window* wins, 
     A.records = sl.take<unsigned char>(rec_total + 256);
     B->d_counters = sl.take<int>(4 * 8);
   };
+  lap("host staging done");
   lld_slab dry; dry.base = reinterpret_cast<char*>(256);
   carve(dry, false);
   const size_t bytes = dry.used + 4096;
-  if (hipMalloc(&B->slab, bytes) != hipSuccess) { delete B; return LLD_ERR_ALLOC; }
+  if (borrow) { const int gs = lld_ctx_scratch(ctx, bytes, &B->slab); if (gs) { delete B; return gs; } B->borrowed = true; }
+  else if (hipMalloc(&B->slab, bytes) != hipSuccess) { delete B; return LLD_ERR_ALLOC; }
   B->slab_bytes = bytes;
+  lap("hipMalloc done");
   lld_slab sl; sl.base = (char*)B->slab; sl.size = bytes;
   carve(sl, true);
+  lap("uploads queued");
   {
     const size_t pcg_lds = ((size_t)B->max_free * 6 * 4 + kPcgThreads + (size_t)B->max_free * 36 + 32) * sizeof(double);
     LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_pcg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pcg_lds));
@@ -371,11 +402,22 @@ int lld_ba_batch_create(lld_ctx* ctx, int n_windows, const lld_ba_window* wins, 
                                     (int)(kCholMLdsDoubles * sizeof(double))));
   }
   LLD_HIP_TRY(hipMemcpyAsync(B->d_wins, B->h_wins.data(), sizeof(BAWin) * n_windows, hipMemcpyHostToDevice, st));
-  LLD_HIP_TRY(hipHostMalloc((void**)&B->h_counters, 4 * 8 * sizeof(int), hipHostMallocDefault));
+  lap("attributes set");
+  if (borrow) {
+    if (!ctx->poll) LLD_HIP_TRY(hipHostMalloc(&ctx->poll, 256, hipHostMallocDefault));
+    B->h_counters = static_cast<int*>(ctx->poll);
+  } else LLD_HIP_TRY(hipHostMalloc((void**)&B->h_counters, 4 * 8 * sizeof(int), hipHostMallocDefault));
+  lap("pinned counters");
   { int gs = ba_make_groups(B, 0); if (gs) return gs; }
+  lap("groups made");
   LLD_HIP_TRY(hipStreamSynchronize(st));        // staging vectors go out of scope
+  lap("synchronised");
   *out = B;
   return LLD_OK;
+}
+
+int lld_ba_batch_create(lld_ctx* ctx, int n_windows, const lld_ba_window* wins, const lld_ba_params* params, lld_ba_batch** out) {
+  return ba_batch_create_impl(ctx, n_windows, wins, params, out, false);
 }
 
 int lld_ba_batch_solve(lld_ba_batch* B, volatile const int* abort_flag) {
@@ -422,7 +464,7 @@ int lld_ba_batch_solve(lld_ba_batch* B, volatile const int* abort_flag) {
     LLD_HIP_TRY(hipEventRecord(G.ev[1], st));
     if (G.max_items_pt > 0) hipLaunchKernelGGL(ba_schur_items_kernel<3>, dim3(G.max_items_pt, nw), dim3(64), B->schur_lds[0], st, A, dw, ds);
     if (G.max_items_ln > 0) hipLaunchKernelGGL(ba_schur_items_kernel<4>, dim3(G.max_items_ln, nw), dim3(64), B->schur_lds[1], st, A, dw, ds);
-    hipLaunchKernelGGL(ba_schur_reduce_kernel, dim3((std::max(1, G.max_blk) * 6 + 255) / 256, nw), dim3(256), 0, st, A, dw, ds);
+    hipLaunchKernelGGL(ba_schur_reduce_kernel, dim3((std::max(1, G.max_blk) * 6 + 255) / 256 + 1, nw), dim3(256), 0, st, A, dw, ds);
     if (B->params.reduced_solver == 1) hipLaunchKernelGGL(ba_symmetrize_kernel, dim3(16, nw), dim3(256), 0, st, A, dw, ds);
     LLD_HIP_TRY(hipEventRecord(G.ev[2], st));
     if (B->params.reduced_solver == 1)
@@ -586,18 +628,28 @@ void lld_ba_batch_destroy(lld_ba_batch* B) {
   (void)hipSetDevice(B->ctx->device);
   (void)hipStreamSynchronize(B->ctx->stream);
   ba_drop_groups(B);
-  if (B->h_counters) (void)hipHostFree(B->h_counters);
-  if (B->slab) (void)hipFree(B->slab);
+  if (!B->borrowed) {
+    if (B->h_counters) (void)hipHostFree(B->h_counters);
+    if (B->slab) (void)hipFree(B->slab);
+  }
   delete B;
 }
 
 int lld_local_ba(lld_ctx* ctx, const lld_ba_window* in, const lld_ba_params* params, volatile const int* abort_flag, lld_ba_result* out) {
   if (!ctx || !in || !out) return LLD_ERR_INVALID;
   lld_ba_batch* B = nullptr;
-  int st = lld_ba_batch_create(ctx, 1, in, params, &B); if (st) return st;
+  static const bool timing = std::getenv("LLD_BA_TIMING") != nullptr;      // prints where a single call spends its time
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+  const auto t0 = now();
+  int st = ba_batch_create_impl(ctx, 1, in, params, &B, true); if (st) return st;
+  const auto t1 = now();
   st = lld_ba_batch_solve(B, abort_flag);
+  const auto t2 = now();
   if (!st) st = lld_ba_batch_download(B, 0, out);
+  const auto t3 = now();
   lld_ba_batch_destroy(B);
+  if (timing) std::fprintf(stderr, "[lld_local_ba] create %.3f ms, solve %.3f ms, download %.3f ms, destroy %.3f ms\n", ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, now()));
   return st;
 }
 

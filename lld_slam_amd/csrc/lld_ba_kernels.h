@@ -922,8 +922,18 @@ __global__ __launch_bounds__(256) void ba_hpp_reduce_kernel(BAArrays A, const BA
   if (i >= nacc) return;
   const double* src = A.hpp_part + W.hpart_off + i;
   const int nb = W.nl_pt + W.nl_ln;
+  // a small batch has ~140 partial rows per window and every row sits in another XCD's L2: eight independent loads in flight,
+  // summed in row order (bit-identical to the plain loop)
   double v = 0.0;
-  for (int b = 0; b < nb; b++) v += src[(size_t)b * nacc];
+  int b = 0;
+  for (; b + 8 <= nb; b += 8) {
+    double t[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) t[u] = src[(size_t)(b + u) * nacc];
+#pragma unroll
+    for (int u = 0; u < 8; u++) v += t[u];
+  }
+  for (; b < nb; b++) v += src[(size_t)b * nacc];
   const int c = i / 27, k = i - c * 27;
   if (k < 21) A.Hpp[((size_t)W.hpp_off + c) * 21 + k] = v; else A.bp[((size_t)W.hpp_off + c) * 6 + (k - 21)] = v;
 }
@@ -1175,8 +1185,11 @@ __global__ __launch_bounds__(256) void ba_schur_reduce_kernel(BAArrays A, const 
   const BAState& S = st[blockIdx.y];
   if (S.phase != PH_RUN) return;
   const int nf = W.n_free, n = 6 * nf, nblk = nf * (nf + 1) / 2;
+  // the LAST workgroup of a window does the right-hand side, the others the blocks: for a single window both are chains of
+  // dependent cross-XCD loads and must not queue behind one another
+  const bool rhs_block = blockIdx.x == gridDim.x - 1;
   const int idx = blockIdx.x * 256 + threadIdx.x;       // lane <-> one row of one lower 6x6 block
-  if (idx < nblk * 6) {
+  if (!rhs_block && idx < nblk * 6) {
     const int blk = idx / 6, rr = idx - blk * 6;
     int i = (int)((sqrt(8.0 * blk + 1.0) - 1.0) * 0.5);
     while ((i + 1) * (i + 2) / 2 <= blk) i++;
@@ -1198,10 +1211,15 @@ __global__ __launch_bounds__(256) void ba_schur_reduce_kernel(BAArrays A, const 
     // dependent loads (index -> partial): four entries are kept in flight and the three modes are folded into weights (row part
     // w_r, column part w_c in {0,1}) so that the loads do not sit behind a branch.  0*x + y is exact and mode 2 keeps its
     // P + P^T order, so the result is bit-identical to the entry-by-entry loop.
+    // the indices of the next four entries are fetched while the partials of the current four are in flight (two dependent
+    // round trips per group otherwise; for a single window every one of them leaves the XCD)
+    int nxt[4];
+#pragma unroll
+    for (int uu = 0; uu < 4; uu++) nxt[uu] = (q0 + uu < q1) ? A.blk_src[q0 + uu] : -1;
     for (int q = q0; q < q1; q += 4) {
       int src[4];
 #pragma unroll
-      for (int uu = 0; uu < 4; uu++) src[uu] = (q + uu < q1) ? A.blk_src[q + uu] : -1;
+      for (int uu = 0; uu < 4; uu++) src[uu] = nxt[uu];
       double pr[4][6], pc[4][6];
 #pragma unroll
       for (int uu = 0; uu < 4; uu++) {
@@ -1209,6 +1227,8 @@ __global__ __launch_bounds__(256) void ba_schur_reduce_kernel(BAArrays A, const 
 #pragma unroll
         for (int cc = 0; cc < 6; cc++) { pr[uu][cc] = P[rr * 6 + cc]; pc[uu][cc] = P[cc * 6 + rr]; }
       }
+#pragma unroll
+      for (int uu = 0; uu < 4; uu++) nxt[uu] = (q + 4 + uu < q1) ? A.blk_src[q + 4 + uu] : -1;
 #pragma unroll
       for (int uu = 0; uu < 4; uu++) {
         if (src[uu] >= 0) {
@@ -1223,22 +1243,22 @@ __global__ __launch_bounds__(256) void ba_schur_reduce_kernel(BAArrays A, const 
 #pragma unroll
     for (int cc = 0; cc < 6; cc += 2) *reinterpret_cast<double2*>(dst + cc) = make_double2(v[cc], v[cc + 1]);
   }
-  if (blockIdx.x == 0) {
+  if (rhs_block) {
     const int* cst = A.cam_start + W.cam_csr_off;
     for (int t = threadIdx.x; t < n; t += 256) {
       const int c = t / 6, r = t - c * 6;
       double v = A.bp[(size_t)W.hpp_off * 6 + t];
-      // a camera appears in ~50 chunks and every list entry is two dependent loads (index -> partial): eight entries are kept in
+      // a camera appears in ~50 chunks and every list entry is two dependent loads (index -> partial): sixteen entries are kept in
       // flight; they are still subtracted one by one in list order, so the sum is bit-identical to the plain loop
       const int q0 = cst[c], q1 = cst[c + 1];
-      for (int q = q0; q < q1; q += 8) {
-        int src[8]; double pv[8];
+      for (int q = q0; q < q1; q += 16) {
+        int src[16]; double pv[16];
 #pragma unroll
-        for (int uu = 0; uu < 8; uu++) src[uu] = (q + uu < q1) ? A.cam_src[q + uu] : -1;
+        for (int uu = 0; uu < 16; uu++) src[uu] = (q + uu < q1) ? A.cam_src[q + uu] : -1;
 #pragma unroll
-        for (int uu = 0; uu < 8; uu++) pv[uu] = (src[uu] >= 0) ? A.sp_cpart[(size_t)src[uu] * 6 + r] : 0.0;
+        for (int uu = 0; uu < 16; uu++) pv[uu] = (src[uu] >= 0) ? A.sp_cpart[(size_t)src[uu] * 6 + r] : 0.0;
 #pragma unroll
-        for (int uu = 0; uu < 8; uu++) if (src[uu] >= 0) v -= pv[uu];
+        for (int uu = 0; uu < 16; uu++) if (src[uu] >= 0) v -= pv[uu];
       }
       A.bschur[W.x_off + t] = v;
     }

@@ -32,6 +32,8 @@ struct lld_ctx {
   // pinned host staging for entry points that move many small arrays in one copy
   void* pinned = nullptr;
   size_t pinned_bytes = 0;
+  // small pinned block the single-window BA polls its progress counters through
+  void* poll = nullptr;
 };
 
 // Grow-only pinned host staging on the context.

@@ -38,6 +38,7 @@ void lld_ctx_destroy(lld_ctx* ctx) {
   if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+  if (ctx->poll) (void)hipHostFree(ctx->poll);
   delete ctx;
 }
 
