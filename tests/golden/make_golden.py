@@ -92,6 +92,20 @@ def main():
              q_level=q["level"], q_view_cos=q["view_cos"], q_angle=q["angle"], q_obs=q["obs"], f_occupied=q["occupied"],
              map_nnratio=np.float32(0.8), map_th=np.float32(1.0), map_n=n_map, map_slot=slot_map, frame_th=np.float32(7.0), frame_n=n_frm,
              frame_slot=slot_frm)
+    # --- GlobalBundleAdjustment protocol on a small map (same window generator, one fixed keyframe)
+    wg = synth.make_lba_small(101, n_free=6, n_fixed=1, n_points=160, n_lines=30, mono_frac=0.1, mono_line_frac=0.1)
+    g = O.local_ba(wg, protocol=1, its_round1=10)
+    np.savez(os.path.join(HERE, "gba_small.npz"), iterations=10, out_cam_qt=g.cam_qt, out_pt_xyz=g.pt_xyz, out_line_x0=g.line_x0,
+             out_line_dir=g.line_dir, out_chi2_final=g.stats["chi2_final"], out_lm_iterations=g.stats["lm_iterations"][0], **window_arrays(wg))
+    # --- Frame::ComputeStereoMatches as a whole on a small image pair (stage 2 is pinned by the numpy statement in
+    #     tests/test_oracle_orbsearch.py::test_compute_stereo_matches_whole_routine)
+    sc = synth.make_stereo_scene(9, 180, width=320, height=150)
+    n_st, ur, dep, br, sad = OS.compute_stereo_matches(sc["L"], sc["R"], sc["left"], sc["right"], sc["inv_scale"], sc["mb"], sc["mbf"])
+    assert n_st > 40
+    lv = {f"left{l}": a for l, a in enumerate(sc["left"])}; lv.update({f"right{l}": a for l, a in enumerate(sc["right"])})
+    np.savez_compressed(os.path.join(HERE, "stereo_small.npz"), l_desc=sc["L"].desc, l_xy=sc["L"].xy, l_octave=sc["L"].octave, r_desc=sc["R"].desc,
+                        r_xy=sc["R"].xy, r_octave=sc["R"].octave, inv_scale=sc["inv_scale"], mb=np.float32(sc["mb"]), mbf=np.float32(sc["mbf"]),
+                        n_levels=len(sc["left"]), out_n=n_st, out_u_right=ur, out_depth=dep, out_best_r=br, out_sad=sad, **lv)
     for n in sorted(os.listdir(HERE)):
         if n.endswith(".npz"):
             print(n, os.path.getsize(os.path.join(HERE, n)), "bytes")
