@@ -159,40 +159,19 @@ __global__ __launch_bounds__(kL2Threads) void l2f32_best2_kernel(
   }
 }
 
-// Sequential resolve of TwoFrameLineMatcher::MatchLines on one wavefront: for each left line j in order, the 64 lanes
-// stride over the right lines, keep the lexicographic (distance, index) minimum among untaken, gated candidates below
-// tau, and a wavefront argmin (shuffle butterfly) picks the winner, which is then masked.
-__global__ __launch_bounds__(64) void line_greedy_kernel(const double* __restrict__ dist, int nq, int nt, const uint8_t* __restrict__ gate,
-                                                        double tau, int* __restrict__ matches, double* __restrict__ match_dist,
-                                                        uint8_t* __restrict__ taken) {
-  const int lane = threadIdx.x;
-  for (int i = lane; i < nt; i += 64) taken[i] = 0;
-  __syncthreads();
-  for (int j = 0; j < nq; j++) {
-    double bd = 1.7976931348623157e308; int bi = 0x7fffffff;
-    for (int oi = lane; oi < nt; oi += 64) {
-      if (taken[oi]) continue;
-      if (gate && !gate[(size_t)j * nt + oi]) continue;
-      const double d = dist[(size_t)j * nt + oi];
-      if (d < tau && d < bd) { bd = d; bi = oi; }       // ascending oi per lane: strict '<' keeps the lowest index
-    }
-    for (int off = 32; off > 0; off >>= 1) {
-      const double od = __shfl_xor(bd, off); const int oidx = __shfl_xor(bi, off);
-      if (od < bd || (od == bd && oidx < bi)) { bd = od; bi = oidx; }
-    }
-    if (lane == 0) {
-      const bool hit = bi != 0x7fffffff;
-      matches[j] = hit ? bi : -1;
-      if (match_dist) match_dist[j] = hit ? bd : 1.7976931348623157e308;
-      if (hit) taken[bi] = 1;
-    }
-    __syncthreads();
-  }
-}
+// ------------------------------------------------------------------ TwoFrameLineMatcher::MatchLines (src/TwoFrameLineMatcher.cc:26-77)
+// The reference walks the left lines in order; each takes the untaken, gated right line with the smallest distance below tau
+// (strict '<' while scanning in index order = lexicographic (distance, index) minimum).  Only `taken` is order dependent, so:
+//   line_candidates_kernel  one wavefront per LEFT line: gates + float-L2 distances of its row, then the row's kLineTopK smallest
+//                           (distance, index) candidates by repeated wavefront argmin - all left lines in parallel;
+//   line_resolve_kernel     one wavefront walks the left lines in order and takes the first untaken entry of each short list
+//                           (LDS only); a list that is full and completely taken falls back to a scan of the stored row.
+constexpr int kLineTopK = 8;
+struct LineCand { double d[kLineTopK]; int idx[kLineTopK]; int n, pad; };
+constexpr double kInfD = 1.7976931348623157e308;
 
-
-// Geometric gates of TwoFrameLineMatcher::CheckLinePair (src/TwoFrameLineMatcher.cc:79-109) for the stereo pair of one frame:
-// one lane per (left j, right oi).  T = identity, T_right = [I | (b,0,0)] (GetTForRight, src/LineMatching.cc:228-237).
+// Geometric gates of TwoFrameLineMatcher::CheckLinePair (src/TwoFrameLineMatcher.cc:79-109) for the stereo pair of one frame.
+// T = identity, T_right = [I | (b,0,0)] (GetTForRight, src/LineMatching.cc:228-237).
 // The 3x3 system of vgl::TriangulateLine (src/vgl.cc:78-108) has rows n1, n2, d = n1 x n2 / |n1 x n2|, so its determinant is
 // |n1 x n2| > 0 once the 0.975 parallelism test passed (rank 3 always) and X0 = (b1 (d x n1)) / det in closed form; the 3x2
 // least squares of vgl::ReprojectLinePointTo3D (src/vgl.cc:336-346) is solved by its normal equations.
@@ -206,45 +185,138 @@ __device__ __forceinline__ void normalized_line_eq(const float* kl, const double
   l[0] = a / n; l[1] = b / n; l[2] = c / n;
 }
 
-__global__ __launch_bounds__(256) void line_pair_gate_kernel(LineGateParams P, const float* __restrict__ left, const int* __restrict__ loct, int nq,
-                                                           const float* __restrict__ right, const int* __restrict__ roct, int nt,
-                                                           uint8_t* __restrict__ gate) {
-  const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (id >= (size_t)nq * nt) return;
-  const int j = (int)(id / nt), oi = (int)(id % nt);
-  const float* k1 = left + 4 * j; const float* k2 = right + 4 * oi;
-  uint8_t ok = 0;
-  do {
-    if (P.is_stereo && loct[j] != roct[oi]) break;
-    const double d1x = (double)k1[0] - (double)k1[2], d1y = (double)k1[1] - (double)k1[3];
-    const double d2x = (double)k2[0] - (double)k2[2], d2y = (double)k2[1] - (double)k2[3];
-    if (sqrt(d1x * d1x + d1y * d1y) < P.min_len || sqrt(d2x * d2x + d2y * d2y) < P.min_len) break;
-    double n1[3], n2[3];
-    normalized_line_eq(k1, P.K, n1); normalized_line_eq(k2, P.K, n2);
-    const double nn1 = sqrt(n1[0] * n1[0] + n1[1] * n1[1] + n1[2] * n1[2]), nn2 = sqrt(n2[0] * n2[0] + n2[1] * n2[1] + n2[2] * n2[2]);
-    if (fabs(n1[0] * n2[0] + n1[1] * n2[1] + n1[2] * n2[2]) / nn1 / nn2 > 0.975) break;
-    double d[3] = {n1[1] * n2[2] - n1[2] * n2[1], n1[2] * n2[0] - n1[0] * n2[2], n1[0] * n2[1] - n1[1] * n2[0]};
-    const double det = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
-    d[0] /= det; d[1] /= det; d[2] /= det;
-    const double b1 = n2[0] * P.b;                                               // n2 . t2, t2 = (b,0,0); n1 . t1 = 0
-    const double X0[3] = {b1 * (d[1] * n1[2] - d[2] * n1[1]) / det, b1 * (d[2] * n1[0] - d[0] * n1[2]) / det, b1 * (d[0] * n1[1] - d[1] * n1[0]) / det};
-    if (sqrt(X0[0] * X0[0] + X0[1] * X0[1] + X0[2] * X0[2]) < 0.5) break;
-    const double c[3] = {-(P.K[0] * d[0] + P.K[1] * d[1] + P.K[2] * d[2]), -(P.K[3] * d[0] + P.K[4] * d[1] + P.K[5] * d[2]),
-                         -(P.K[6] * d[0] + P.K[7] * d[1] + P.K[8] * d[2])};
-    const double r[3] = {P.K[0] * X0[0] + P.K[1] * X0[1] + P.K[2] * X0[2], P.K[3] * X0[0] + P.K[4] * X0[1] + P.K[5] * X0[2],
-                         P.K[6] * X0[0] + P.K[7] * X0[1] + P.K[8] * X0[2]};
-    const double cc = c[0] * c[0] + c[1] * c[1] + c[2] * c[2], cr = c[0] * r[0] + c[1] * r[1] + c[2] * r[2];
-    bool front = true;
-    for (int e = 0; e < 2; e++) {
-      const double px = k1[2 * e], py = k1[2 * e + 1];
-      const double aa = px * px + py * py + 1.0, ac = px * c[0] + py * c[1] + c[2], ar = px * r[0] + py * r[1] + r[2];
-      const double p = (aa * cr - ac * ar) / (aa * cc - ac * ac);               // line parameter of the re-projected endpoint
-      if (X0[2] + p * d[2] < 0) front = false;
+__device__ __forceinline__ bool line_pair_gate(const LineGateParams& P, const float* k1, int o1, const float* k2, int o2) {
+  if (P.is_stereo && o1 != o2) return false;
+  const double d1x = (double)k1[0] - (double)k1[2], d1y = (double)k1[1] - (double)k1[3];
+  const double d2x = (double)k2[0] - (double)k2[2], d2y = (double)k2[1] - (double)k2[3];
+  if (sqrt(d1x * d1x + d1y * d1y) < P.min_len || sqrt(d2x * d2x + d2y * d2y) < P.min_len) return false;
+  double n1[3], n2[3];
+  normalized_line_eq(k1, P.K, n1); normalized_line_eq(k2, P.K, n2);
+  const double nn1 = sqrt(n1[0] * n1[0] + n1[1] * n1[1] + n1[2] * n1[2]), nn2 = sqrt(n2[0] * n2[0] + n2[1] * n2[1] + n2[2] * n2[2]);
+  if (fabs(n1[0] * n2[0] + n1[1] * n2[1] + n1[2] * n2[2]) / nn1 / nn2 > 0.975) return false;
+  double d[3] = {n1[1] * n2[2] - n1[2] * n2[1], n1[2] * n2[0] - n1[0] * n2[2], n1[0] * n2[1] - n1[1] * n2[0]};
+  const double det = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+  d[0] /= det; d[1] /= det; d[2] /= det;
+  const double b1 = n2[0] * P.b;                                               // n2 . t2, t2 = (b,0,0); n1 . t1 = 0
+  const double X0[3] = {b1 * (d[1] * n1[2] - d[2] * n1[1]) / det, b1 * (d[2] * n1[0] - d[0] * n1[2]) / det, b1 * (d[0] * n1[1] - d[1] * n1[0]) / det};
+  if (sqrt(X0[0] * X0[0] + X0[1] * X0[1] + X0[2] * X0[2]) < 0.5) return false;
+  const double c[3] = {-(P.K[0] * d[0] + P.K[1] * d[1] + P.K[2] * d[2]), -(P.K[3] * d[0] + P.K[4] * d[1] + P.K[5] * d[2]),
+                       -(P.K[6] * d[0] + P.K[7] * d[1] + P.K[8] * d[2])};
+  const double r[3] = {P.K[0] * X0[0] + P.K[1] * X0[1] + P.K[2] * X0[2], P.K[3] * X0[0] + P.K[4] * X0[1] + P.K[5] * X0[2],
+                       P.K[6] * X0[0] + P.K[7] * X0[1] + P.K[8] * X0[2]};
+  const double cc = c[0] * c[0] + c[1] * c[1] + c[2] * c[2], cr = c[0] * r[0] + c[1] * r[1] + c[2] * r[2];
+  bool front = true;
+  for (int e = 0; e < 2; e++) {
+    const double px = k1[2 * e], py = k1[2 * e + 1];
+    const double aa = px * px + py * py + 1.0, ac = px * c[0] + py * c[1] + c[2], ar = px * r[0] + py * r[1] + r[2];
+    const double p = (aa * cr - ac * ar) / (aa * cc - ac * ac);               // line parameter of the re-projected endpoint
+    if (X0[2] + p * d[2] < 0) front = false;
+  }
+  return front;
+}
+
+// grid nq, block 64; dynamic LDS: nt doubles (the row's admissible distances) + dim floats (the left descriptor).
+// kGeom: the gate is CheckLinePair's geometry (written to gate_mat); otherwise gate_in is the caller's matrix (or NULL = all pass).
+template <bool kGeom>
+__global__ __launch_bounds__(64) void line_candidates_kernel(LineGateParams P, const float* __restrict__ left, const int* __restrict__ loct,
+                                                            const float* __restrict__ right, const int* __restrict__ roct,
+                                                            const float* __restrict__ q, const float* __restrict__ t, int dim, int nt,
+                                                            const uint8_t* __restrict__ gate_in, double tau, uint8_t* __restrict__ gate_mat,
+                                                            double* __restrict__ dmat, LineCand* __restrict__ cand) {
+  extern __shared__ __attribute__((aligned(16))) double lds_row[];
+  double* drow = lds_row;
+  float* qrow = reinterpret_cast<float*>(drow + nt);
+  const int j = blockIdx.x, lane = threadIdx.x;
+  for (int i = lane; i < dim; i += 64) qrow[i] = q[(size_t)j * dim + i];
+  __syncthreads();
+  float k1[4] = {0.f, 0.f, 0.f, 0.f}; int o1 = 0;
+  if (kGeom) { for (int e = 0; e < 4; e++) k1[e] = left[4 * j + e]; o1 = loct[j]; }
+  for (int oi = lane; oi < nt; oi += 64) {
+    bool g;
+    if (kGeom) { float k2[4]; for (int e = 0; e < 4; e++) k2[e] = right[4 * oi + e]; g = line_pair_gate(P, k1, o1, k2, roct[oi]); gate_mat[(size_t)j * nt + oi] = g ? 1 : 0; }
+    else g = !gate_in || gate_in[(size_t)j * nt + oi] != 0;
+    double dist = kInfD;
+    if (g) {                                                           // LineMatcher::MatchLineDescriptors: float difference, double accumulation
+      const float* tr = t + (size_t)oi * dim;
+      double acc = 0.0;
+      for (int i = 0; i < dim; i++) { const float df = qrow[i] - tr[i]; acc = fma((double)df, (double)df, acc); }
+      dist = sqrt(acc);
     }
-    if (!front) break;
-    ok = 1;
-  } while (false);
-  gate[id] = ok;
+    dmat[(size_t)j * nt + oi] = dist;
+    drow[oi] = (g && dist < tau) ? dist : kInfD;
+  }
+  __syncthreads();
+  // the kLineTopK smallest (distance, index) pairs of the row, in order: every round takes the smallest pair greater than the last
+  double pd = -1.0; int pi = -1, n = 0;
+  double my_d = kInfD; int my_i = -1;
+  for (int r = 0; r < kLineTopK; r++) {
+    double bd = kInfD; int bi = 0x7fffffff;
+    for (int oi = lane; oi < nt; oi += 64) {
+      const double d = drow[oi];
+      if (d < tau && (d > pd || (d == pd && oi > pi)) && d < bd) { bd = d; bi = oi; }    // ascending oi per lane: lowest index on ties
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      const double od = __shfl_xor(bd, off); const int oidx = __shfl_xor(bi, off);
+      if (od < bd || (od == bd && oidx < bi)) { bd = od; bi = oidx; }
+    }
+    if (bi == 0x7fffffff) break;
+    if (lane == r) { my_d = bd; my_i = bi; }
+    pd = bd; pi = bi; n++;
+  }
+  if (lane < kLineTopK) { cand[j].d[lane] = my_d; cand[j].idx[lane] = my_i; }
+  if (lane == 0) { cand[j].n = n; cand[j].pad = 0; }
+}
+
+// one wavefront; LDS: taken[nt] bytes (dynamic) + a chunk of candidate lists (static)
+constexpr int kResolveChunk = 256;
+__global__ __launch_bounds__(64) void line_resolve_kernel(const LineCand* __restrict__ cand, const double* __restrict__ dmat, const uint8_t* __restrict__ gate,
+                                                         int nq, int nt, double tau, int* __restrict__ matches, double* __restrict__ match_dist) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char taken[];
+  __shared__ LineCand chunk[kResolveChunk];
+  const int lane = threadIdx.x;
+  for (int i = lane; i < nt; i += 64) taken[i] = 0;
+  for (int j0 = 0; j0 < nq; j0 += kResolveChunk) {
+    const int nj = min(kResolveChunk, nq - j0);
+    __syncthreads();
+    {
+      const int words = nj * (int)(sizeof(LineCand) / 4);
+      const int* src = reinterpret_cast<const int*>(cand + j0); int* dst = reinterpret_cast<int*>(chunk);
+      for (int i = lane; i < words; i += 64) dst[i] = src[i];
+    }
+    __syncthreads();
+    for (int jj = 0; jj < nj; jj++) {
+      const int j = j0 + jj;
+      const LineCand& C = chunk[jj];
+      const int my_i = lane < kLineTopK ? C.idx[lane] : -1;
+      const bool free_ = lane < C.n && !taken[my_i];
+      const unsigned long long mask = __ballot(free_);
+      int bi = -1; double bd = kInfD;
+      if (mask) {
+        const int w = __ffsll((long long)mask) - 1;
+        bi = C.idx[w]; bd = C.d[w];
+      } else if (C.n == kLineTopK) {
+        // every listed candidate is taken and the list was cut: scan the stored row like the reference does
+        double sd = kInfD; int si = 0x7fffffff;
+        for (int oi = lane; oi < nt; oi += 64) {
+          if (taken[oi]) continue;
+          if (gate && !gate[(size_t)j * nt + oi]) continue;
+          const double d = dmat[(size_t)j * nt + oi];
+          if (d < tau && d < sd) { sd = d; si = oi; }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+          const double od = __shfl_xor(sd, off); const int oidx = __shfl_xor(si, off);
+          if (od < sd || (od == sd && oidx < si)) { sd = od; si = oidx; }
+        }
+        if (si != 0x7fffffff) { bi = si; bd = sd; }
+      }
+      if (lane == 0) {
+        matches[j] = bi;
+        if (match_dist) match_dist[j] = bi >= 0 ? bd : kInfD;
+        if (bi >= 0) taken[bi] = 1;
+      }
+      __syncthreads();                                               // one wavefront: orders the LDS write before the next reads
+    }
+  }
 }
 
 int launch_hamming(lld_ctx* ctx, int batch, const uint32_t* q, int nq, const uint32_t* t, int nt, const uint8_t* mask,
@@ -371,32 +443,77 @@ int lld_match_l2f32_batch_dev(lld_ctx* ctx, int batch, const float* q_dev, int n
   return launch_l2(ctx, batch, q_dev, nq, t_dev, nt, dim, nullptr, best_idx_dev, best_dist_dev, second_idx_dev, second_dist_dev, nullptr);
 }
 
-int lld_line_match_greedy(lld_ctx* ctx, const float* dl, int nq, const float* dr, int nt, int dim, const uint8_t* gate, double tau,
-                          int32_t* matches, double* match_dist) {
-  if (!ctx || !dl || !dr || nq < 0 || nt < 0 || dim <= 0 || !matches) return LLD_ERR_INVALID;
+// Shared body of the two line matchers: one pinned-staged H2D copy of every input, candidate lists for all left lines in parallel,
+// the in-order resolve on one wavefront, one D2H copy.
+static int line_match_core(lld_ctx* ctx, const lld_line_stereo_params* geom, const float* left_lines, const int32_t* left_octave,
+                           const float* dl, int nq, const float* right_lines, const int32_t* right_octave, const float* dr, int nt, int dim,
+                           const uint8_t* gate_in, double tau, int32_t* matches, double* match_dist, uint8_t* gate_out) {
   if (dim > 128) return LLD_ERR_UNSUPPORTED;
   if (nq == 0) return LLD_OK;
   if (nt == 0) { for (int i = 0; i < nq; i++) { matches[i] = -1; if (match_dist) match_dist[i] = 1.7976931348623157e308; } return LLD_OK; }
+  if ((size_t)nt * 8 + (size_t)dim * 4 > 60 * 1024) return LLD_ERR_UNSUPPORTED;          // one row of distances lives in LDS
   LLD_HIP_TRY(hipSetDevice(ctx->device));
-  const size_t need = lld_slab::pad((size_t)nq * dim * 4) + lld_slab::pad((size_t)nt * dim * 4 + 16) + lld_slab::pad((size_t)nq * nt) +
-                      lld_slab::pad((size_t)nq * nt * 8) + 2 * lld_slab::pad((size_t)nq * 4) + 3 * lld_slab::pad((size_t)nq * 8) + lld_slab::pad(nt);
-  void* base; int st = lld_ctx_scratch(ctx, need, &base); if (st) return st;
-  lld_slab s; s.base = (char*)base;
-  float* dq = s.take<float>((size_t)nq * dim); float* dt = s.take<float>((size_t)nt * dim + 4);
-  uint8_t* dg = s.take<uint8_t>((size_t)nq * nt);
-  double* dmat = s.take<double>((size_t)nq * nt);
-  int *dbi = s.take<int>(nq), *dsi = s.take<int>(nq); double *dbd = s.take<double>(nq), *dsd = s.take<double>(nq), *dmd = s.take<double>(nq);
-  uint8_t* dtaken = s.take<uint8_t>(nt);
-  LLD_HIP_TRY(hipMemcpyAsync(dq, dl, (size_t)nq * dim * 4, hipMemcpyHostToDevice, ctx->stream));
-  LLD_HIP_TRY(hipMemcpyAsync(dt, dr, (size_t)nt * dim * 4, hipMemcpyHostToDevice, ctx->stream));
-  if (gate) LLD_HIP_TRY(hipMemcpyAsync(dg, gate, (size_t)nq * nt, hipMemcpyHostToDevice, ctx->stream));
-  st = launch_l2(ctx, 1, dq, nq, dt, nt, dim, nullptr, dbi, dbd, dsi, dsd, dmat); if (st) return st;
-  hipLaunchKernelGGL(line_greedy_kernel, dim3(1), dim3(64), 0, ctx->stream, dmat, nq, nt, gate ? dg : nullptr, tau, dbi, dmd, dtaken);
+  const size_t pairs = (size_t)nq * nt;
+  auto pad = [](size_t b) { return (b + 255) & ~size_t(255); };
+  // input region
+  size_t in = 0;
+  const size_t o_q = in; in += pad((size_t)nq * dim * 4);
+  const size_t o_t = in; in += pad((size_t)nt * dim * 4);
+  size_t o_ll = 0, o_rl = 0, o_lo = 0, o_ro = 0, o_g = 0;
+  if (geom) { o_ll = in; in += pad((size_t)nq * 16); o_rl = in; in += pad((size_t)nt * 16); o_lo = in; in += pad((size_t)nq * 4); o_ro = in; in += pad((size_t)nt * 4); }
+  else if (gate_in) { o_g = in; in += pad(pairs); }
+  // output region (copied back), then device-only scratch
+  size_t out = 0;
+  const size_t r_m = out; out += pad((size_t)nq * 4);
+  const size_t r_d = out; out += pad((size_t)nq * 8);
+  const size_t r_g = out; if (geom && gate_out) out += pad(pairs);
+  size_t dev = 0;
+  const size_t s_g = dev; if (geom && !gate_out) dev += pad(pairs);
+  const size_t s_mat = dev; dev += pad(pairs * 8);
+  const size_t s_c = dev; dev += pad((size_t)nq * sizeof(LineCand));
+  void* hb; int st = lld_ctx_pinned(ctx, in + out, &hb); if (st) return st;
+  void* db; st = lld_ctx_scratch(ctx, in + out + dev + 256, &db); if (st) return st;
+  char* h = (char*)hb; char* d = (char*)db; char* h_out = h + in; char* d_out = d + in; char* d_dev = d_out + out;
+  std::memcpy(h + o_q, dl, (size_t)nq * dim * 4); std::memcpy(h + o_t, dr, (size_t)nt * dim * 4);
+  if (geom) {
+    std::memcpy(h + o_ll, left_lines, (size_t)nq * 16); std::memcpy(h + o_rl, right_lines, (size_t)nt * 16);
+    std::memcpy(h + o_lo, left_octave, (size_t)nq * 4); std::memcpy(h + o_ro, right_octave, (size_t)nt * 4);
+  } else if (gate_in) std::memcpy(h + o_g, gate_in, pairs);
+  hipStream_t sm = ctx->stream;
+  LLD_HIP_TRY(hipMemcpyAsync(d, h, in, hipMemcpyHostToDevice, sm));
+  LineGateParams P; std::memset(&P, 0, sizeof P);
+  uint8_t* dgate = nullptr;
+  const uint8_t* dgate_in = nullptr;
+  if (geom) {
+    for (int i = 0; i < 9; i++) P.K[i] = geom->K[i];
+    P.b = geom->b; P.min_len = (double)geom->min_line_length; P.is_stereo = geom->is_stereo;
+    dgate = reinterpret_cast<uint8_t*>(gate_out ? d_out + r_g : d_dev + s_g);
+  } else if (gate_in) dgate_in = reinterpret_cast<const uint8_t*>(d + o_g);
+  double* dmat = reinterpret_cast<double*>(d_dev + s_mat);
+  LineCand* dc = reinterpret_cast<LineCand*>(d_dev + s_c);
+  const size_t lds = (size_t)nt * 8 + (size_t)dim * 4 + 16;
+  if (geom)
+    hipLaunchKernelGGL(line_candidates_kernel<true>, dim3(nq), dim3(64), lds, sm, P, reinterpret_cast<const float*>(d + o_ll), reinterpret_cast<const int*>(d + o_lo),
+                       reinterpret_cast<const float*>(d + o_rl), reinterpret_cast<const int*>(d + o_ro), reinterpret_cast<const float*>(d + o_q),
+                       reinterpret_cast<const float*>(d + o_t), dim, nt, nullptr, tau, dgate, dmat, dc);
+  else
+    hipLaunchKernelGGL(line_candidates_kernel<false>, dim3(nq), dim3(64), lds, sm, P, nullptr, nullptr, nullptr, nullptr, reinterpret_cast<const float*>(d + o_q),
+                       reinterpret_cast<const float*>(d + o_t), dim, nt, dgate_in, tau, nullptr, dmat, dc);
+  hipLaunchKernelGGL(line_resolve_kernel, dim3(1), dim3(64), (size_t)nt + 16, sm, dc, dmat, geom ? dgate : dgate_in, nq, nt, tau,
+                     reinterpret_cast<int*>(d_out + r_m), reinterpret_cast<double*>(d_out + r_d));
   LLD_HIP_TRY(hipGetLastError());
-  LLD_HIP_TRY(hipMemcpyAsync(matches, dbi, (size_t)nq * 4, hipMemcpyDeviceToHost, ctx->stream));
-  if (match_dist) LLD_HIP_TRY(hipMemcpyAsync(match_dist, dmd, (size_t)nq * 8, hipMemcpyDeviceToHost, ctx->stream));
-  LLD_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  LLD_HIP_TRY(hipMemcpyAsync(h_out, d_out, out, hipMemcpyDeviceToHost, sm));
+  LLD_HIP_TRY(hipStreamSynchronize(sm));
+  std::memcpy(matches, h_out + r_m, (size_t)nq * 4);
+  if (match_dist) std::memcpy(match_dist, h_out + r_d, (size_t)nq * 8);
+  if (geom && gate_out) std::memcpy(gate_out, h_out + r_g, pairs);
   return LLD_OK;
+}
+
+int lld_line_match_greedy(lld_ctx* ctx, const float* dl, int nq, const float* dr, int nt, int dim, const uint8_t* gate, double tau,
+                          int32_t* matches, double* match_dist) {
+  if (!ctx || !dl || !dr || nq < 0 || nt < 0 || dim <= 0 || !matches) return LLD_ERR_INVALID;
+  return line_match_core(ctx, nullptr, nullptr, nullptr, dl, nq, nullptr, nullptr, dr, nt, dim, gate, tau, matches, match_dist, nullptr);
 }
 
 int lld_line_match_stereo(lld_ctx* ctx, const lld_line_stereo_params* params, const float* left_lines, const int32_t* left_octave,
@@ -405,43 +522,7 @@ int lld_line_match_stereo(lld_ctx* ctx, const lld_line_stereo_params* params, co
   if (!ctx || !params || nq < 0 || nt < 0 || dim <= 0 || !matches) return LLD_ERR_INVALID;
   if (nq > 0 && (!left_lines || !left_octave || !dl)) return LLD_ERR_INVALID;
   if (nt > 0 && (!right_lines || !right_octave || !dr)) return LLD_ERR_INVALID;
-  if (dim > 128) return LLD_ERR_UNSUPPORTED;
-  if (nq == 0) return LLD_OK;
-  if (nt == 0) { for (int i = 0; i < nq; i++) { matches[i] = -1; if (match_dist) match_dist[i] = 1.7976931348623157e308; } return LLD_OK; }
-  LLD_HIP_TRY(hipSetDevice(ctx->device));
-  const size_t need = lld_slab::pad((size_t)nq * dim * 4) + lld_slab::pad((size_t)nt * dim * 4 + 16) + lld_slab::pad((size_t)nq * nt) +
-                      lld_slab::pad((size_t)nq * nt * 8) + 2 * lld_slab::pad((size_t)nq * 4) + 3 * lld_slab::pad((size_t)nq * 8) + lld_slab::pad(nt) +
-                      lld_slab::pad((size_t)nq * 16) + lld_slab::pad((size_t)nt * 16) + lld_slab::pad((size_t)nq * 4) + lld_slab::pad((size_t)nt * 4);
-  void* base; int st = lld_ctx_scratch(ctx, need, &base); if (st) return st;
-  lld_slab s; s.base = (char*)base;
-  float* dq = s.take<float>((size_t)nq * dim); float* dt = s.take<float>((size_t)nt * dim + 4);
-  uint8_t* dg = s.take<uint8_t>((size_t)nq * nt);
-  double* dmat = s.take<double>((size_t)nq * nt);
-  int *dbi = s.take<int>(nq), *dsi = s.take<int>(nq); double *dbd = s.take<double>(nq), *dsd = s.take<double>(nq), *dmd = s.take<double>(nq);
-  uint8_t* dtaken = s.take<uint8_t>(nt);
-  float* dll = s.take<float>((size_t)nq * 4); float* drl = s.take<float>((size_t)nt * 4);
-  int* dlo = s.take<int>(nq); int* dro = s.take<int>(nt);
-  hipStream_t sm = ctx->stream;
-  LLD_HIP_TRY(hipMemcpyAsync(dq, dl, (size_t)nq * dim * 4, hipMemcpyHostToDevice, sm));
-  LLD_HIP_TRY(hipMemcpyAsync(dt, dr, (size_t)nt * dim * 4, hipMemcpyHostToDevice, sm));
-  LLD_HIP_TRY(hipMemcpyAsync(dll, left_lines, (size_t)nq * 16, hipMemcpyHostToDevice, sm));
-  LLD_HIP_TRY(hipMemcpyAsync(drl, right_lines, (size_t)nt * 16, hipMemcpyHostToDevice, sm));
-  LLD_HIP_TRY(hipMemcpyAsync(dlo, left_octave, (size_t)nq * 4, hipMemcpyHostToDevice, sm));
-  LLD_HIP_TRY(hipMemcpyAsync(dro, right_octave, (size_t)nt * 4, hipMemcpyHostToDevice, sm));
-  LineGateParams P;
-  for (int i = 0; i < 9; i++) P.K[i] = params->K[i];
-  P.b = params->b; P.min_len = (double)params->min_line_length; P.is_stereo = params->is_stereo;
-  const size_t pairs = (size_t)nq * nt;
-  hipLaunchKernelGGL(line_pair_gate_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, sm, P, dll, dlo, nq, drl, dro, nt, dg);
-  LLD_HIP_TRY(hipGetLastError());
-  st = launch_l2(ctx, 1, dq, nq, dt, nt, dim, nullptr, dbi, dbd, dsi, dsd, dmat); if (st) return st;
-  hipLaunchKernelGGL(line_greedy_kernel, dim3(1), dim3(64), 0, sm, dmat, nq, nt, dg, params->tau, dbi, dmd, dtaken);
-  LLD_HIP_TRY(hipGetLastError());
-  LLD_HIP_TRY(hipMemcpyAsync(matches, dbi, (size_t)nq * 4, hipMemcpyDeviceToHost, sm));
-  if (match_dist) LLD_HIP_TRY(hipMemcpyAsync(match_dist, dmd, (size_t)nq * 8, hipMemcpyDeviceToHost, sm));
-  if (gate_out) LLD_HIP_TRY(hipMemcpyAsync(gate_out, dg, pairs, hipMemcpyDeviceToHost, sm));
-  LLD_HIP_TRY(hipStreamSynchronize(sm));
-  return LLD_OK;
+  return line_match_core(ctx, params, left_lines, left_octave, dl, nq, right_lines, right_octave, dr, nt, dim, nullptr, params->tau, matches, match_dist, gate_out);
 }
 
 }  // extern "C"

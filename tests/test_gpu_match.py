@@ -107,6 +107,21 @@ def test_line_greedy_matches_sequential_reference(gpu_ctx, oracle):
     np.testing.assert_array_equal(gm, oracle.line_match_greedy(q, t, None, 2.0)[0])
 
 
+def test_line_greedy_exhausted_candidate_lists_fall_back_to_the_row_scan(gpu_ctx, oracle):
+    """The device keeps the 8 best candidates per left line; 20 identical left lines compete for the same right lines, so from the
+    9th on every listed candidate is taken and the stored row is scanned like the reference does."""
+    q, t = synth.make_match_lbd(4, 120, 150, 72, n_corr=100)
+    q[10:30] = q[10]
+    q[60:75] = q[61]
+    gate = np.ones((120, 150), np.uint8); gate[12, :] = 0; gate[:, 7] = 0
+    for tau in (1e9, 1.6):
+        gm, gd = TwoFrameLineMatcher(gpu_ctx, tau).MatchLines(q, t, gate)
+        om, od = oracle.line_match_greedy(q, t, gate, tau)
+        np.testing.assert_array_equal(gm, om)
+        np.testing.assert_array_equal(gd[gm >= 0], od[om >= 0])
+    assert (gm[10:30] >= 0).sum() >= 18
+
+
 def test_batched_hamming_device_entry_point(gpu_ctx, oracle):
     import torch
     B, nq, nt = 6, 333, 450

@@ -75,6 +75,22 @@ t = time.perf_counter(); run2(); dt = time.perf_counter() - t
 t = time.perf_counter(); e2 = O.match_l2f32(ql[0], tl[0]); dtc = time.perf_counter() - t
 out["lbd_l2f32"] = {"pairs": B2, "gpu_pairs_per_s": B2 / dt, "cpu_oracle_pairs_per_s": 1 / dtc,
                     "bit_exact": bool(np.array_equal(bi[0].cpu().numpy(), e2[0]) and np.array_equal(bd[0].cpu().numpy(), e2[1]))}
+# ---- TwoFrameLineMatcher::MatchLines with CheckLinePair's gates on the device: 300 x 300 stereo lines per frame, one call
+from lld_slam_amd import TwoFrameLineMatcher
+sl = synth.make_stereo_lines(0, 300, 300)
+tm = TwoFrameLineMatcher(ctx, 2.0, sl["K"], sl["b"], 20)
+def _tm():
+    return tm.MatchLines(sl["desc_left"], sl["desc_right"], lines=sl["left"], other_lines=sl["right"], octaves=sl["left_octave"], other_octaves=sl["right_octave"])
+_tm(); ts = []
+for _ in range(21):
+    t = time.perf_counter(); gm = _tm(); ts.append(time.perf_counter() - t)
+def _om():
+    return O.line_match_stereo(sl["K"], sl["b"], 2.0, 20, sl["left"], sl["left_octave"], sl["desc_left"], sl["right"], sl["right_octave"], sl["desc_right"])
+_om(); tc = []
+for _ in range(5):
+    t = time.perf_counter(); om = _om(); tc.append(time.perf_counter() - t)
+out["line_match_stereo_300x300"] = {"gpu_ms": 1e3 * float(np.median(ts)), "cpu_oracle_ms": 1e3 * float(np.median(tc)),
+                                    "equal": bool(np.array_equal(gm[0], om[0]))}
 # ---- guided ORB searches: one frame (2000 keypoints), whole routine per call, host buffers in and out
 import oracle_orbsearch as OS
 from lld_slam_amd import ORBmatcher
