@@ -159,6 +159,44 @@ __global__ __launch_bounds__(kL2Threads) void l2f32_best2_kernel(
   }
 }
 
+// Latency form of the same search for small problems (one frame pair): one wavefront per QUERY row, lanes stride over the train
+// rows, so a 300 x 300 x 72 problem is 300 short wavefronts instead of two workgroups walking 21 600 dependent FMAs per lane.
+// Same arithmetic per pair and the same lexicographic (distance, index) order, hence identical outputs.
+__global__ __launch_bounds__(64) void l2f32_best2_row_kernel(const float* __restrict__ q, const float* __restrict__ t, int nt, int dim,
+                                                            const uint8_t* __restrict__ mask, int* __restrict__ best_idx, double* __restrict__ best_dist,
+                                                            int* __restrict__ second_idx, double* __restrict__ second_dist, double* __restrict__ dist_matrix) {
+  extern __shared__ __attribute__((aligned(16))) float qrow_l2[];
+  const int qi = blockIdx.x, lane = threadIdx.x;
+  for (int i = lane; i < dim; i += 64) qrow_l2[i] = q[(size_t)qi * dim + i];
+  __syncthreads();
+  double bd = 1.7976931348623157e308, sd = 1.7976931348623157e308;
+  int bi = 0x7fffffff, si = 0x7fffffff;
+  for (int j = lane; j < nt; j += 64) {
+    const float* tr = t + (size_t)j * dim;
+    double acc = 0.0;
+    for (int i = 0; i < dim; i++) { const float d = qrow_l2[i] - tr[i]; acc = fma((double)d, (double)d, acc); }
+    const double dist = sqrt(acc);
+    if (dist_matrix) dist_matrix[(size_t)qi * nt + j] = dist;
+    if (mask && !mask[(size_t)qi * nt + j]) continue;
+    if (dist < bd) { sd = bd; si = bi; bd = dist; bi = j; }            // ascending j per lane: strict '<' keeps the lower index
+    else if (dist < sd) { sd = dist; si = j; }
+  }
+  auto less = [](double da, int ia, double db, int ib) { return da < db || (da == db && ia < ib); };
+  for (int off = 32; off > 0; off >>= 1) {
+    const double obd = __shfl_xor(bd, off), osd = __shfl_xor(sd, off);
+    const int obi = __shfl_xor(bi, off), osi = __shfl_xor(si, off);
+    // merge two sorted pairs (b, s) and (ob, os): the two smallest of the four in (distance, index) order
+    if (less(obd, obi, bd, bi)) {
+      if (less(bd, bi, osd, osi)) { sd = bd; si = bi; } else { sd = osd; si = osi; }
+      bd = obd; bi = obi;
+    } else if (less(obd, obi, sd, si)) { sd = obd; si = obi; }
+  }
+  if (lane == 0) {
+    best_idx[qi] = bi == 0x7fffffff ? -1 : bi; best_dist[qi] = bd;
+    second_idx[qi] = si == 0x7fffffff ? -1 : si; second_dist[qi] = sd;
+  }
+}
+
 // ------------------------------------------------------------------ TwoFrameLineMatcher::MatchLines (src/TwoFrameLineMatcher.cc:26-77)
 // The reference walks the left lines in order; each takes the untaken, gated right line with the smallest distance below tau
 // (strict '<' while scanning in index order = lexicographic (distance, index) minimum).  Only `taken` is order dependent, so:
@@ -331,6 +369,11 @@ int launch_hamming(lld_ctx* ctx, int batch, const uint32_t* q, int nq, const uin
 
 int launch_l2(lld_ctx* ctx, int batch, const float* q, int nq, const float* t, int nt, int dim, const uint8_t* mask,
               int* bi, double* bd, int* si, double* sd, double* dist_matrix) {
+  if (batch == 1 && nq <= 8192 && dim <= 128) {                       // one frame pair: the wavefront-per-row form
+    hipLaunchKernelGGL(l2f32_best2_row_kernel, dim3(nq), dim3(64), (size_t)dim * sizeof(float), ctx->stream, q, t, nt, dim, mask, bi, bd, si, sd, dist_matrix);
+    LLD_HIP_TRY(hipGetLastError());
+    return LLD_OK;
+  }
   dim3 grid((nq + kL2Threads - 1) / kL2Threads, batch);
   const size_t lds = (size_t)kL2TileRows * dim * sizeof(float);
 #define LLD_L2_LAUNCH(N)                                                                                                 \
