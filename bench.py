@@ -121,7 +121,12 @@ def main():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # LLD_BENCH_FORCE_DIST=1 takes the RCCL path even with one rank (checks the collective plumbing on a 1-GPU box)
+    use_dist = world > 1 or os.environ.get("LLD_BENCH_FORCE_DIST") == "1"
+    saved_stdout = None
+    if use_dist:
+        # RCCL prints a version banner on stdout when its first communicator comes up: keep stdout for the one JSON line
+        sys.stdout.flush(); saved_stdout = os.dup(1); os.dup2(2, 1)
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)          # RCCL
 
@@ -133,16 +138,16 @@ def main():
     class _Dev:                                                   # zero-copy torch view of the library's record buffer
         __cuda_array_interface__ = {"shape": (rec_bytes,), "typestr": "|u1", "data": (rec_ptr, False), "version": 2}
     records = torch.as_tensor(_Dev(), device=dev)
-    gathered = [torch.empty(rec_bytes, dtype=torch.uint8, device=dev) for _ in range(world)] if (world > 1 and rank == 0) else None
+    gathered = [torch.empty(rec_bytes, dtype=torch.uint8, device=dev) for _ in range(world)] if (use_dist and rank == 0) else None
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
     def step():
         batch.solve()                     # synchronous on the library's stream (it polls the LM state every super-step)
-        if world > 1:
+        if use_dist:
             dist.gather(records, gathered, dst=0)                 # the final gather over xGMI: the only collective
 
     for _ in range(args.warmup):
@@ -178,7 +183,7 @@ def main():
             del a, b
         except Exception:
             stream_gbs = None
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -253,9 +258,11 @@ def main():
                    "mean_pcg_iterations_per_trial": float(np.sum([s["pcg_iterations"] for s in stats]) / max(1, np.sum([sum(s["lm_trials"]) for s in stats])))},
         }
     batch.close(); ctx.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if saved_stdout is not None:
+        sys.stdout.flush(); os.dup2(saved_stdout, 1); os.close(saved_stdout)
     if rank == 0:
         print(json.dumps(result))
 
