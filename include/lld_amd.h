@@ -124,7 +124,9 @@ typedef struct {
                                    kernels: ONE optimize(its_round1) call and nothing else - no classification, no line removal, all
                                    result flags 0; line edges carry identity information and the Huber delta thHuber3D/2
                                    (AddLineMinimalGlobal, :149-240), `gamma` and `ln_filter` are ignored.  The window holds the whole
-                                   map: every keyframe but mnId==0 free (n_free_cams <= 170 in this build)                       */
+                                   map: every keyframe but mnId==0 free.  Limits of this build: n_free_cams <= 170 per window in general,
+                                   <= 590 when the batch has at most 8 windows (then the reduced system is solved by the
+                                   multi-workgroup PCG whatever `reduced_solver` says, except 2)                       */
   int32_t robust_points;    /* protocol 1 only: bRobust (Huber kernels on the point edges, default 1); lines are always robust */
 } lld_ba_params;
 

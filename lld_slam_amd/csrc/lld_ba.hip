@@ -29,6 +29,7 @@ struct lld_ba_batch {
   std::vector<Group> groups;
   int* d_counters = nullptr; int* h_counters = nullptr;               // device / pinned, 4 ints per group
   int max_lblocks = 0, max_items_pt = 0, max_items_ln = 0, max_free = 0, max_cams = 0, max_blk = 0, acc_copies = 4;
+  bool pcg_multi = false;
   size_t schur_lds[2] = {0, 0};
   int chunk_landmarks = 32;
   size_t S_total = 0, x_total = 0;
@@ -320,6 +321,9 @@ static int ba_batch_create_impl(lld_ctx* ctx, int n_windows, const lld_ba_window
   }
   pt_obs_start.push_back((int)NPE); ln_obs_start.push_back((int)NLO);
   if (B->max_cams > kPcgThreads) { delete B; return LLD_ERR_UNSUPPORTED; }
+  // few windows whose reduced system is beyond the matrix-core Cholesky: the PCG runs across the whole GPU (see ba_pcgm_*)
+  B->pcg_multi = n_windows <= 8 && B->max_free * 6 > kCholMN && P.reduced_solver != 2;
+  if (B->max_free > kMaxFreeCamsOneWg && !B->pcg_multi) { delete B; return LLD_ERR_UNSUPPORTED; }   // batches of huge windows: not in this build
   // LDS copies of the per-camera accumulators in the linearise kernels: as many as fit (4 for local windows)
   B->acc_copies = kAccCopies;
   while (B->acc_copies > 1 && ((size_t)B->max_free * 27 * B->acc_copies + 8 + (size_t)B->max_cams * 7) * sizeof(double) > 150 * 1024) B->acc_copies >>= 1;
@@ -361,6 +365,8 @@ static int ba_batch_create_impl(lld_ctx* ctx, int n_windows, const lld_ba_window
     A.hpp_part = sl.take<double>(n_hpart + 2);
     A.Hpp = sl.take<double>((size_t)NF * 21 + 1); A.bp = sl.take<double>((size_t)NF * 6 + 1);
     A.S = sl.take<double>(S_total + 1); A.bschur = sl.take<double>(x_total + 1); A.xp = sl.take<double>(x_total + 1);
+    A.x_total = (long long)x_total;
+    if (B->pcg_multi) { A.pcg_vec = sl.take<double>(4 * x_total + 4); A.pcg_mi = sl.take<double>((size_t)NF * 36 + 1); A.pcg_sc = sl.take<double>(8 * (size_t)n_windows + 8); }
     A.chi_part = sl.take<double>(NPART + 1); A.chi_part2 = sl.take<double>(NPART + 1); A.scale_part = sl.take<double>(NPART + 1);
     A.blk_start = up_i(blk_start, blk_start.size() + 1); A.blk_src = up_i(blk_src, blk_src.size() + 1);
     A.cam_start = up_i(cam_start, cam_start.size() + 1); A.cam_src = up_i(cam_src, cam_src.size() + 1);
@@ -393,7 +399,9 @@ static int ba_batch_create_impl(lld_ctx* ctx, int n_windows, const lld_ba_window
   lap("uploads queued");
   {
     const size_t pcg_lds = ((size_t)B->max_free * 6 * 4 + kPcgThreads + (size_t)B->max_free * 36 + 32) * sizeof(double);
-    LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_pcg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pcg_lds));
+    if (!B->pcg_multi) LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_pcg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pcg_lds));
+    const size_t bs_lds0 = (8 + (size_t)B->max_cams * 14 + (size_t)B->max_free * 6) * sizeof(double);
+    if (bs_lds0 > 48 * 1024) LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_backsub_pt_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bs_lds0));
     const size_t lin_lds = ((size_t)B->max_free * 27 * B->acc_copies + 8 + (size_t)B->max_cams * 7) * sizeof(double);
     LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_linearize_pt_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lin_lds));
     LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_linearize_ln_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lin_lds));
@@ -465,9 +473,26 @@ int lld_ba_batch_solve(lld_ba_batch* B, volatile const int* abort_flag) {
     if (G.max_items_pt > 0) hipLaunchKernelGGL(ba_schur_items_kernel<3>, dim3(G.max_items_pt, nw), dim3(64), B->schur_lds[0], st, A, dw, ds);
     if (G.max_items_ln > 0) hipLaunchKernelGGL(ba_schur_items_kernel<4>, dim3(G.max_items_ln, nw), dim3(64), B->schur_lds[1], st, A, dw, ds);
     hipLaunchKernelGGL(ba_schur_reduce_kernel, dim3((std::max(1, G.max_blk) * 6 + 255) / 256 + 1, nw), dim3(256), 0, st, A, dw, ds);
-    if (B->params.reduced_solver == 1) hipLaunchKernelGGL(ba_symmetrize_kernel, dim3(16, nw), dim3(256), 0, st, A, dw, ds);
+    if (B->params.reduced_solver == 1 || B->pcg_multi) hipLaunchKernelGGL(ba_symmetrize_kernel, dim3(B->pcg_multi ? 256 : 16, nw), dim3(256), 0, st, A, dw, ds);
     LLD_HIP_TRY(hipEventRecord(G.ev[2], st));
-    if (B->params.reduced_solver == 1)
+    if (B->pcg_multi) {
+      // block-Jacobi PCG with the matrix-vector product spread over the GPU; the host looks at the `done` scalars every 16 iterations
+      hipLaunchKernelGGL(ba_pcgm_init_kernel, dim3(nw), dim3(kPcgThreads), 0, st, A, dw, ds, B->params.pcg_rel_tol);
+      const int n_max = B->max_free * 6, limit = B->params.pcg_max_iter > 0 ? B->params.pcg_max_iter : 10 * n_max;
+      std::vector<double> hsc(8 * (size_t)nw);
+      for (int it = 0; it < limit;) {
+        for (int k = 0; k < 16 && it < limit; k++, it++) {
+          hipLaunchKernelGGL(ba_pcgm_matvec_kernel, dim3((n_max + 3) / 4, nw), dim3(256), 0, st, A, dw);
+          hipLaunchKernelGGL(ba_pcgm_update_kernel, dim3(nw), dim3(kPcgThreads), 0, st, A, dw, B->params.pcg_max_iter);
+        }
+        LLD_HIP_TRY(hipMemcpyAsync(hsc.data(), A.pcg_sc + 8 * (size_t)G.w0, hsc.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+        LLD_HIP_TRY(hipStreamSynchronize(st));
+        bool all_done = true;
+        for (int wI = 0; wI < nw; wI++) all_done = all_done && hsc[8 * (size_t)wI + 3] != 0.0;
+        if (all_done) break;
+      }
+      hipLaunchKernelGGL(ba_pcgm_final_kernel, dim3(nw), dim3(kPcgThreads), 0, st, A, dw, ds);
+    } else if (B->params.reduced_solver == 1)
       hipLaunchKernelGGL(ba_pcg_kernel, dim3(nw), dim3(kPcgThreads), pcg_lds, st, A, dw, ds, B->params.pcg_rel_tol, B->params.pcg_max_iter);
     else if (B->params.reduced_solver == 0 && B->max_free * 6 <= kCholMN)      // register-resident tiles on the fp64 matrix cores
       hipLaunchKernelGGL(ba_chol_mfma_kernel, dim3(nw), dim3(kCholMThreads), kCholMLdsDoubles * sizeof(double), st, A, dw, ds);

@@ -45,7 +45,8 @@ constexpr int kRoundsThroughputMinWindows = 32;
 constexpr int kAccCopies = 4;          // (default; BAWin::acc_copies drops to 2 or 1 when a window's cameras would not fit LDS otherwise)
 constexpr int kAccCopiesDoc = 4;          // LDS copies of the per-camera Hpp/bp accumulators: lanes of one wavefront that hit the
                                        // same camera are spread over them (same-address LDS atomics serialise)
-constexpr int kMaxFreeCams = 170;        // the reduced solvers map one lane to one unknown: 6 * 170 <= 1024 lanes
+constexpr int kMaxFreeCams = 590;        // LDS of the linearise accumulators (216 B + 56 B per camera); the one-workgroup reduced solvers
+constexpr int kMaxFreeCamsOneWg = 170;   // map one lane to one unknown (6 * 170 <= 1024), larger windows need the multi-workgroup PCG
 
 enum Phase : int { PH_RUN = 0, PH_TRANSITION = 2, PH_FINALIZE = 3, PH_DONE = 4 };
 constexpr uint8_t EF_LEVEL1 = 1, EF_ROBUST = 2, EF_VALID = 4, EF_PAIRSTEREO = 8, EF_STEREO = 16;
@@ -131,6 +132,10 @@ struct BAArrays {
   double *Hpp;                 // [NF*21]
   double *bp;                  // [NF*6]
   double *S, *bschur, *xp;
+  double *pcg_vec;             // multi-workgroup PCG: r, z, p, Sp of every window ([4][x_total])
+  double *pcg_mi;              // its block-Jacobi preconditioner ([NF][36])
+  double *pcg_sc;              // its scalars per window: rz, stop, iterations, done, ok, 3 spare
+  long long x_total;
   double *chi_part, *chi_part2, *scale_part;
   // Schur work items
   const SChunk* sg_chunks;
@@ -1301,6 +1306,132 @@ __device__ __forceinline__ void solve_epilogue(const BAArrays& A, const BAWin& W
 // grid (nW); block kPcgThreads; dynamic LDS: 4n + kPcgThreads + nf*36 + 32 doubles.  Block-Jacobi preconditioner (inverse 6x6 diagonal
 // blocks), fixed reduction trees, stops at |r|_M <= tol |b|_M.  On exit it applies VertexSE3Expmap::oplusImpl to the free
 // cameras (trial buffer) and leaves sum x(lambda x + b) of the camera part for computeScale.
+// ------------------------------------------------------------------ PCG across the whole GPU (few, larger windows)
+// The same block-Jacobi PCG as ba_pcg_kernel, cut into kernels so that the matrix-vector product of ONE window runs on every CU:
+//   init    (1 workgroup per window)  Minv, x = 0, r = b, z = Minv r, p = z, rz
+//   matvec  (wavefront per row)       Sp = S p                                   -- S symmetric, stored in full
+//   update  (1 workgroup per window)  alpha, x, r, z, rz, stop test, beta, p
+//   final   (1 workgroup per window)  the common epilogue (x -> xp, scale, trial cameras)
+// The host launches matvec/update pairs in chunks and looks at the `done` scalars between chunks; finished windows return at once.
+__global__ __launch_bounds__(kPcgThreads) void ba_pcgm_init_kernel(BAArrays A, const BAWin* __restrict__ wins, const BAState* __restrict__ st, double tol) {
+  __shared__ double scratch[32];
+  const BAWin W = wins[blockIdx.x];
+  const BAState& S = st[blockIdx.x];
+  double* sc = A.pcg_sc + 8 * (size_t)blockIdx.x;
+  if (S.phase != PH_RUN) { if (threadIdx.x == 0) sc[3] = 1.0; return; }
+  const int nf = W.n_free, n = 6 * nf, tid = threadIdx.x;
+  const double* Sg = A.S + W.S_off;
+  double* Mi = A.pcg_mi + (size_t)W.hpp_off * 36;
+  double* x = A.xp + W.x_off;
+  double* r = A.pcg_vec + W.x_off; double* z = r + A.x_total; double* p = z + A.x_total;
+  double* ok_s = scratch + 31;
+  if (tid == 0) *ok_s = 1.0;
+  __syncthreads();
+  for (int cb = tid; cb < nf; cb += kPcgThreads) {
+    double F[36], Fi[36];
+#pragma unroll
+    for (int rr = 0; rr < 6; rr++)
+#pragma unroll
+      for (int c = 0; c < 6; c++) F[rr * 6 + c] = Sg[(size_t)(cb * 6 + rr) * n + cb * 6 + c];
+    if (!spd_inverse<6>(F, Fi)) *ok_s = 0.0;
+#pragma unroll
+    for (int i = 0; i < 36; i++) Mi[cb * 36 + i] = Fi[i];
+  }
+  for (int i = tid; i < n; i += kPcgThreads) { x[i] = 0.0; r[i] = A.bschur[W.x_off + i]; }
+  __syncthreads();                                       // Mi and r of this workgroup are visible to it
+  double part = 0.0;
+  for (int i = tid; i < n; i += kPcgThreads) {
+    const int b = i / 6, rr = i - b * 6;
+    double zv = 0.0;
+#pragma unroll
+    for (int c = 0; c < 6; c++) zv += Mi[b * 36 + rr * 6 + c] * r[b * 6 + c];
+    z[i] = zv; p[i] = zv;
+    part += r[i] * zv;
+  }
+  const double rz0 = block_sum(part, scratch);
+  if (tid == 0) {
+    const bool ok = *ok_s != 0.0 && isfinite(rz0);
+    sc[0] = rz0; sc[1] = tol * tol * rz0; sc[2] = 0.0; sc[3] = (ok && rz0 > 0.0) ? 0.0 : 1.0; sc[4] = ok ? 1.0 : 0.0;
+  }
+}
+
+// grid (ceil(n_max / 4), nW), block 256: one wavefront per row of S
+__global__ __launch_bounds__(256) void ba_pcgm_matvec_kernel(BAArrays A, const BAWin* __restrict__ wins) {
+  const double* sc = A.pcg_sc + 8 * (size_t)blockIdx.y;
+  if (sc[3] != 0.0) return;
+  const BAWin W = wins[blockIdx.y];
+  const int n = 6 * W.n_free, lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const double* Sr = A.S + W.S_off + (size_t)row * n;
+  const double* p = A.pcg_vec + 2 * A.x_total + W.x_off;
+  double acc = 0.0;
+  for (int c = lane; c < n; c += 64) acc = fma(Sr[c], p[c], acc);
+  acc = wave_sum(acc);
+  if (lane == 0) A.pcg_vec[3 * A.x_total + W.x_off + row] = acc;
+}
+
+__global__ __launch_bounds__(kPcgThreads) void ba_pcgm_update_kernel(BAArrays A, const BAWin* __restrict__ wins, int max_iter_param) {
+  __shared__ double scratch[32];
+  double* sc = A.pcg_sc + 8 * (size_t)blockIdx.x;
+  if (sc[3] != 0.0) return;
+  const BAWin W = wins[blockIdx.x];
+  const int nf = W.n_free, n = 6 * nf, tid = threadIdx.x;
+  const double* Mi = A.pcg_mi + (size_t)W.hpp_off * 36;
+  double* x = A.xp + W.x_off;
+  double* r = A.pcg_vec + W.x_off; double* z = r + A.x_total; double* p = z + A.x_total; const double* ap = p + A.x_total;
+  const double rz = sc[0], stop = sc[1];
+  const int max_iter = max_iter_param > 0 ? max_iter_param : 10 * n;
+  double part = 0.0;
+  for (int i = tid; i < n; i += kPcgThreads) part += p[i] * ap[i];
+  const double pAp = block_sum(part, scratch);
+  if (!(pAp > 0.0) || !isfinite(pAp)) { if (tid == 0) { sc[3] = 1.0; sc[4] = 0.0; } return; }
+  const double alpha = rz / pAp;
+  for (int i = tid; i < n; i += kPcgThreads) { x[i] += alpha * p[i]; r[i] -= alpha * ap[i]; }
+  __syncthreads();
+  part = 0.0;
+  for (int i = tid; i < n; i += kPcgThreads) {
+    const int b = i / 6, rr = i - b * 6;
+    double zv = 0.0;
+#pragma unroll
+    for (int c = 0; c < 6; c++) zv += Mi[b * 36 + rr * 6 + c] * r[b * 6 + c];
+    z[i] = zv;
+    part += r[i] * zv;
+  }
+  const double rz_new = block_sum(part, scratch);
+  const double iters = sc[2] + 1.0;
+  bool done = false, ok = true;
+  if (!isfinite(rz_new)) { done = true; ok = false; }
+  else if (rz_new <= stop || iters >= (double)max_iter) done = true;
+  if (!done) { const double beta = rz_new / rz; for (int i = tid; i < n; i += kPcgThreads) p[i] = z[i] + beta * p[i]; }
+  __syncthreads();                                        // every lane has read sc[] before lane 0 rewrites it
+  if (tid == 0) { sc[0] = rz_new; sc[2] = iters; if (done) sc[3] = 1.0; if (!ok) sc[4] = 0.0; }
+}
+
+// the epilogue of solve_epilogue for any number of unknowns: scale of the step, trial cameras
+__global__ __launch_bounds__(kPcgThreads) void ba_pcgm_final_kernel(BAArrays A, const BAWin* __restrict__ wins, BAState* __restrict__ st) {
+  __shared__ double scratch[32];
+  const BAWin W = wins[blockIdx.x];
+  BAState& S = st[blockIdx.x];
+  if (S.phase != PH_RUN) return;
+  const double* sc = A.pcg_sc + 8 * (size_t)blockIdx.x;
+  const int tid = threadIdx.x, nf = W.n_free, n = 6 * nf;
+  const double lambda = S.lambda;
+  const double* x = A.xp + W.x_off;
+  const double* bpv = A.bp + (size_t)W.hpp_off * 6;
+  double part = 0.0;
+  for (int i = tid; i < n; i += kPcgThreads) part += x[i] * (lambda * x[i] + bpv[i]);
+  const double sc_t = block_sum(part, scratch);
+  const int cur = S.cur, nxt = cur ^ 1;
+  for (int c = tid; c < W.n_cams; c += kPcgThreads) {
+    const Pose T = load_cam(A, cur, W.cam_off + c);
+    Pose Tn = T;
+    if (c < nf) Tn = pose_oplus(T, x + c * 6);
+    pose_store(Tn, A.cam_qt + ((size_t)nxt * A.NC + W.cam_off + c) * 7);
+  }
+  if (tid == 0) { S.scale_cam = sc_t; S.pcg_ok = sc[4] != 0.0 ? 1 : 0; S.pcg_iterations += (int)sc[2]; }
+}
+
 __global__ __launch_bounds__(kPcgThreads) void ba_pcg_kernel(BAArrays A, const BAWin* __restrict__ wins, BAState* __restrict__ st, double tol,
                                                             int max_iter_param) {
   extern __shared__ __attribute__((aligned(16))) double lds[];

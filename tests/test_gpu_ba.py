@@ -217,14 +217,26 @@ def test_global_bundle_adjustment_protocol(gpu_ctx, oracle, wid, kw, its, robust
     assert g.stats["chi2_final"] == g.stats["chi2_round1"]
 
 
+def test_map_sized_window_uses_the_multi_workgroup_pcg(gpu_ctx, oracle):
+    """300 free keyframes (1800 unknowns in the reduced system): beyond one lane per unknown, so the block-Jacobi PCG runs with its
+    matrix-vector product spread over the GPU; 590 is the limit for up to 8 windows, 170 for larger batches."""
+    w = synth.make_ba_window(300, 1, 8000, 4, 800, 4, seed=0x6BA00001)
+    check_ba(Optimizer(gpu_ctx).GlobalBundleAdjustment(w, 4), oracle.local_ba(w, protocol=1, its_round1=4), w)
+    with pytest.raises(RuntimeError):
+        BABatch(gpu_ctx, [synth.make_lba_small(47, n_free=171, n_fixed=1, n_points=900, n_lines=0)] * 9)   # a batch of 9 such windows
+    with pytest.raises(RuntimeError):
+        Optimizer(gpu_ctx).GlobalBundleAdjustment(synth.make_lba_small(48, n_free=591, n_fixed=1, n_points=2500, n_lines=0))
+
+
 def test_large_window_limits(gpu_ctx, oracle):
-    """Up to 170 free cameras per window; the local protocol works there too, beyond that the library refuses."""
+    """Windows of 130 / 171 free cameras, local protocol, all three reduced solvers where they apply."""
     w = synth.make_lba_small(45, n_free=130, n_fixed=2, n_points=2500, n_lines=200)
     check_ba(Optimizer(gpu_ctx).LocalBundleAdjustment(w), oracle.local_ba(w), w)
     check_ba(Optimizer(gpu_ctx).LocalBundleAdjustment(w, reduced_solver=1), oracle.local_ba(w), w)      # PCG on an 780 x 780 system
     big = synth.make_lba_small(46, n_free=171, n_fixed=1, n_points=1200, n_lines=0)
+    check_ba(Optimizer(gpu_ctx).GlobalBundleAdjustment(big, 3), oracle.local_ba(big, protocol=1, its_round1=3), big)
     with pytest.raises(RuntimeError):
-        Optimizer(gpu_ctx).GlobalBundleAdjustment(big)
+        Optimizer(gpu_ctx).GlobalBundleAdjustment(big, 3, reduced_solver=2)          # the vector Cholesky stops at 170
 
 
 def test_global_and_local_protocols_share_a_batch_engine(gpu_ctx, oracle):

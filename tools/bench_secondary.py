@@ -44,6 +44,15 @@ t = time.perf_counter(); og = O.local_ba(wg, protocol=1, its_round1=10); dtc = t
 out["global_ba_170kf"] = {"gpu_ms": dt * 1e3, "cpu_oracle_ms": dtc * 1e3, "edges": int(wg.n_pt_obs + 2 * wg.n_ln_obs),
                           "chi2_rel": abs(gg.stats["chi2_final"] - og.stats["chi2_final"]) / og.stats["chi2_final"],
                           "lm_iterations": gg.stats["lm_iterations"][0]}
+# a map-sized problem: 590 keyframes (the limit), 30k points x 4 obs, 3k lines; the oracle (dense LDL^T of 3540^2) is timed on 2 iterations
+wb = synth.make_ba_window(590, 1, 30000, 4, 3000, 4, seed=0x6BA00002)
+opt.GlobalBundleAdjustment(wb, 10)
+t = time.perf_counter(); gb = opt.GlobalBundleAdjustment(wb, 10); dtb = time.perf_counter() - t
+g2 = opt.GlobalBundleAdjustment(wb, 2)
+t = time.perf_counter(); ob = O.local_ba(wb, protocol=1, its_round1=2); dtcb = time.perf_counter() - t
+out["global_ba_590kf"] = {"gpu_ms_10_iterations": dtb * 1e3, "gpu_pcg_iterations": gb.stats["pcg_iterations"], "cpu_oracle_ms_2_iterations": dtcb * 1e3,
+                          "edges": int(wb.n_pt_obs + 2 * wb.n_ln_obs),
+                          "chi2_rel_after_2": abs(g2.stats["chi2_final"] - ob.stats["chi2_final"]) / ob.stats["chi2_final"]}
 # ---- ORB 2000 x 2000 Hamming best/second, batched in HBM
 B, nq, nt = 256, 2000, 2000
 dev = torch.device("cuda", 0)
