@@ -236,6 +236,53 @@ int  lld_pose_batch_solve(lld_pose_batch* batch);
 int  lld_pose_batch_download(lld_pose_batch* batch, int frame, lld_pose_result* out);
 void lld_pose_batch_destroy(lld_pose_batch* batch);
 
+/* ================================================================== Optimizer::OptimizeSim3 (src/Optimizer.cc:1656-1851)
+ * One Sim3 vertex (S12, 7 dof, `_fix_scale` zeroes the scale update), the matched MapPoints of the two keyframes as FIXED points
+ * in their own camera frames, two edges per correspondence (EdgeSim3ProjectXYZ: x1 = K1 proj(S12 X2); EdgeInverseSim3ProjectXYZ:
+ * x2 = K2 proj(S12^-1 X1)) with Huber delta sqrt(th2), LM on the dense 7x7 system.  g2o differentiates these edges NUMERICALLY
+ * (central differences, delta 1e-9, core/base_binary_edge.hpp:131-197): so do the oracle and the device.  Protocol: optimize(5);
+ * a correspondence whose e12 or e21 chi2 exceeds th2 is dropped (both edges; vpMatches1[idx] = NULL); nMoreIterations = 10 if any
+ * was dropped else 5; fewer than 10 correspondences left -> return 0 WITHOUT updating S12; optimize(nMoreIterations); count the
+ * correspondences still within th2 (the others are NULLed too); S12 <- estimate.  `n`, the arrays and their order are the loop
+ * :1704-1786 restricted to the correspondences that pass its tests (pMP1 && pMP2, neither bad, i2 >= 0). */
+typedef struct {
+  double fx1, fy1, cx1, cy1;        /* pKF1->mK (floats widened)                                   */
+  double fx2, fy2, cx2, cy2;        /* pKF2->mK                                                    */
+  double s12_q[4];                  /* g2oS12.rotation().coeffs(): x, y, z, w                      */
+  double s12_t[3];
+  double s12_s;
+  int32_t n;
+  int32_t reserved;
+  const double* p1c;                /* [n][3] P3D1c = R1w*P3D1w + t1w (Converter::toVector3d)      */
+  const double* p2c;                /* [n][3] P3D2c                                                */
+  const double* obs1;               /* [n][2] pKF1->mvKeysUn[i].pt                                 */
+  const double* obs2;               /* [n][2] pKF2->mvKeysUn[i2].pt                                */
+  const double* inv_sigma2_1;       /* [n] pKF1->mvInvLevelSigma2[kpUn1.octave]                    */
+  const double* inv_sigma2_2;       /* [n]                                                         */
+} lld_sim3_problem;
+typedef struct {
+  double  th2;                      /* float th2 of the caller, widened (LoopClosing passes 10)    */
+  int32_t fix_scale;                /* bFixScale (true for stereo / RGB-D)                         */
+  int32_t its_first;                /* 5                                                           */
+  int32_t its_more_bad;             /* 10 (when the first round dropped something)                 */
+  int32_t its_more_clean;           /* 5                                                           */
+  int32_t min_inliers;              /* 10                                                          */
+  int32_t max_trials;               /* 10                                                          */
+} lld_sim3_params;
+void lld_sim3_params_default(lld_sim3_params* p);
+typedef struct {
+  double   s12_q[4], s12_t[3], s12_s;  /* g2oS12 on return (unchanged when the function returns 0 early) */
+  uint8_t* dropped;                 /* [n] 1 -> vpMatches1[idx] = NULL                             */
+  int32_t  n_inliers;               /* the return value (nIn, or 0)                                */
+  int32_t  n_bad_first;             /* nBad of the first check                                     */
+  int32_t  lm_iterations[2];
+  int32_t  lm_trials[2];
+  double   chi2;                    /* LM cost at the end of the last optimize()                   */
+} lld_sim3_result;
+int lld_optimize_sim3(lld_ctx* ctx, const lld_sim3_problem* in, const lld_sim3_params* params, lld_sim3_result* out);
+/* several loop / relocalisation candidates in one launch (one workgroup each) */
+int lld_optimize_sim3_batch(lld_ctx* ctx, int n, const lld_sim3_problem* problems, const lld_sim3_params* params, lld_sim3_result* outs);
+
 /* ================================================================== descriptor matching
  * lld_match_hamming256*: ORBmatcher::DescriptorDistance (src/ORBmatcher.cc:1647-1663) plus
  * the best / second-best loops of the Search* family (e.g. :76-125, :201-249).  Strict '<'

@@ -82,6 +82,20 @@ class Optimizer {
     lld_ba_params p; lld_ba_params_default(&p); p.protocol = 1; p.its_round1 = nIterations; p.robust_points = bRobust ? 1 : 0;
     return Solve(ctx, win, p, pbStopFlag);
   }
+  // int static OptimizeSim3(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches1, g2o::Sim3& g2oS12, const float th2, const bool bFixScale)
+  // `pair` holds the correspondences that pass the loop's tests (src/Optimizer.cc:1704-1786); S12 is updated in place, dropped[i] = 1
+  // means vpMatches1[idx] = NULL; returns nIn
+  static int OptimizeSim3(Context& ctx, lld_sim3_problem& pair, std::vector<uint8_t>& dropped, float th2, bool bFixScale) {
+    lld_sim3_params p; lld_sim3_params_default(&p); p.th2 = th2; p.fix_scale = bFixScale ? 1 : 0;
+    dropped.assign(pair.n > 0 ? pair.n : 1, 0);
+    lld_sim3_result r{}; r.dropped = dropped.data();
+    check(lld_optimize_sim3(ctx.get(), &pair, &p, &r), "lld_optimize_sim3");
+    dropped.resize(pair.n);
+    for (int k = 0; k < 4; k++) pair.s12_q[k] = r.s12_q[k];
+    for (int k = 0; k < 3; k++) pair.s12_t[k] = r.s12_t[k];
+    pair.s12_s = r.s12_s;
+    return r.n_inliers;
+  }
   static BAOutput Solve(Context& ctx, const BAWindow& win, const lld_ba_params& p, const bool* pbStopFlag = nullptr) {
     const lld_ba_window w = win.view();
     BAOutput o;

@@ -128,6 +128,24 @@ def as_i32(a):
 
 
 # Every symbol include/lld_amd.h declares (checked by tests/test_abi.py against the built library).
+class Sim3Problem(C.Structure):
+    _fields_ = [("fx1", C.c_double), ("fy1", C.c_double), ("cx1", C.c_double), ("cy1", C.c_double),
+                ("fx2", C.c_double), ("fy2", C.c_double), ("cx2", C.c_double), ("cy2", C.c_double),
+                ("s12_q", C.c_double * 4), ("s12_t", C.c_double * 3), ("s12_s", C.c_double), ("n", C.c_int32), ("reserved", C.c_int32),
+                ("p1c", c_double_p), ("p2c", c_double_p), ("obs1", c_double_p), ("obs2", c_double_p), ("inv_sigma2_1", c_double_p),
+                ("inv_sigma2_2", c_double_p)]
+
+
+class Sim3Params(C.Structure):
+    _fields_ = [("th2", C.c_double), ("fix_scale", C.c_int32), ("its_first", C.c_int32), ("its_more_bad", C.c_int32),
+                ("its_more_clean", C.c_int32), ("min_inliers", C.c_int32), ("max_trials", C.c_int32)]
+
+
+class Sim3Result(C.Structure):
+    _fields_ = [("s12_q", C.c_double * 4), ("s12_t", C.c_double * 3), ("s12_s", C.c_double), ("dropped", c_uint8_p), ("n_inliers", C.c_int32),
+                ("n_bad_first", C.c_int32), ("lm_iterations", C.c_int32 * 2), ("lm_trials", C.c_int32 * 2), ("chi2", C.c_double)]
+
+
 PRODUCT_SYMBOLS = [
     "lld_status_string", "lld_ctx_create", "lld_ctx_destroy", "lld_ctx_stream", "lld_ctx_synchronize",
     "lld_se3_from_tcw_f32", "lld_se3_to_tcw_f32", "lld_orb_inv_level_sigma2",
@@ -141,6 +159,7 @@ PRODUCT_SYMBOLS = [
     "lld_match_l2f32", "lld_match_l2f32_batch_dev", "lld_line_match_greedy", "lld_line_match_stereo",
     "lld_orb_search_run", "lld_orb_search_batch", "lld_orb_search_local_points", "lld_orb_search_last_frame", "lld_orb_fuse_search",
     "lld_compute_stereo_matches",
+    "lld_sim3_params_default", "lld_optimize_sim3", "lld_optimize_sim3_batch",
 ]
 
 

@@ -139,6 +139,76 @@ def ba_params(lib: abi.Lib, gamma=1.0, **kw) -> BAParams:
     return p
 
 
+@dataclass
+class Sim3Pair:
+    """Inputs of Optimizer::OptimizeSim3 for one (KF1, KF2) candidate: the correspondences that pass the loop's tests, in order."""
+    K1: tuple                    # fx, fy, cx, cy of pKF1->mK
+    K2: tuple
+    s12_q: np.ndarray            # g2oS12 rotation (x, y, z, w)
+    s12_t: np.ndarray
+    s12_s: float
+    p1c: np.ndarray              # [n,3] MapPoints of KF1 in KF1's camera frame
+    p2c: np.ndarray              # [n,3] MapPoints of KF2 in KF2's camera frame
+    obs1: np.ndarray             # [n,2]
+    obs2: np.ndarray             # [n,2]
+    inv_sigma2_1: np.ndarray     # [n]
+    inv_sigma2_2: np.ndarray
+    meta: dict = field(default_factory=dict)
+
+    @property
+    def n(self): return int(np.asarray(self.p1c).shape[0])
+
+    def to_c(self):
+        keep = [np.ascontiguousarray(a, np.float64) for a in (self.p1c, self.p2c, self.obs1, self.obs2, self.inv_sigma2_1, self.inv_sigma2_2)]
+        P = abi.Sim3Problem()
+        P.fx1, P.fy1, P.cx1, P.cy1 = [float(v) for v in self.K1]; P.fx2, P.fy2, P.cx2, P.cy2 = [float(v) for v in self.K2]
+        for i in range(4): P.s12_q[i] = float(self.s12_q[i])
+        for i in range(3): P.s12_t[i] = float(self.s12_t[i])
+        P.s12_s = float(self.s12_s); P.n = self.n
+        P.p1c, P.p2c, P.obs1, P.obs2, P.inv_sigma2_1, P.inv_sigma2_2 = [a.ctypes.data_as(abi.c_double_p) for a in keep]
+        P._keep = keep
+        return P
+
+
+@dataclass
+class Sim3Output:
+    s12_q: np.ndarray
+    s12_t: np.ndarray
+    s12_s: float
+    dropped: np.ndarray
+    n_inliers: int
+    n_bad_first: int
+    lm_iterations: list
+    lm_trials: list
+    chi2: float
+
+
+def sim3_params(lib: abi.Lib, th2=10.0, bFixScale=True, **kw) -> abi.Sim3Params:
+    p = abi.Sim3Params()
+    lib.fn("sim3_params_default")(C.byref(p))
+    p.th2 = float(np.float32(th2)); p.fix_scale = 1 if bFixScale else 0
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def sim3_call(lib: abi.Lib, ctx, pairs: list, params: abi.Sim3Params) -> list:
+    """lld_optimize_sim3_batch (or the oracle's lldo_optimize_sim3, one by one, when ctx is None)."""
+    cs = [p.to_c() for p in pairs]
+    drops = [np.zeros(max(1, p.n), np.uint8) for p in pairs]
+    res = (abi.Sim3Result * len(pairs))()
+    for r, d in zip(res, drops): r.dropped = d.ctypes.data_as(abi.c_uint8_p)
+    if ctx is None:
+        fn = lib.fn("optimize_sim3"); fn.argtypes = [C.c_void_p, C.POINTER(abi.Sim3Problem), C.POINTER(abi.Sim3Params), C.POINTER(abi.Sim3Result)]; fn.restype = C.c_int
+        for c, r in zip(cs, res): check(fn(None, C.byref(c), C.byref(params), C.byref(r)), "optimize_sim3")
+    else:
+        arr = (abi.Sim3Problem * len(pairs))(*cs)
+        fn = lib.fn("optimize_sim3_batch"); fn.argtypes = [C.c_void_p, C.c_int, C.POINTER(abi.Sim3Problem), C.POINTER(abi.Sim3Params), C.POINTER(abi.Sim3Result)]; fn.restype = C.c_int
+        check(fn(ctx, len(pairs), arr, C.byref(params), res), "optimize_sim3_batch")
+    return [Sim3Output(np.array(r.s12_q[:]), np.array(r.s12_t[:]), float(r.s12_s), d[:p.n].copy(), int(r.n_inliers), int(r.n_bad_first),
+                       list(r.lm_iterations), list(r.lm_trials), float(r.chi2)) for r, d, p in zip(res, drops, pairs)]
+
+
 def pose_params(lib: abi.Lib, gamma=0.5, **kw) -> PoseParams:
     p = PoseParams()
     lib.fn("pose_params_default")(C.byref(p))
@@ -373,6 +443,12 @@ class Optimizer:
         keyframe but mnId==0 free), ONE optimize(nIterations), no outlier handling, identity line information."""
         return ba_call(self.lib, self.ctx.handle, window,
                        ba_params(self.lib, 1.0, protocol=1, its_round1=nIterations, robust_points=1 if bRobust else 0, **params), pbStopFlag)
+
+    def OptimizeSim3(self, pair, th2: float = 10.0, bFixScale: bool = True, **params):
+        """Optimizer::OptimizeSim3 (src/Optimizer.cc:1656-1851); a list of pairs goes through one launch (one workgroup per candidate)."""
+        many = isinstance(pair, (list, tuple))
+        outs = sim3_call(self.lib, self.ctx.handle, list(pair) if many else [pair], sim3_params(self.lib, th2, bFixScale, **params))
+        return outs if many else outs[0]
 
     def PoseOptimization(self, frame: PoseFrame, gamma: float = 1.0, **params) -> PoseOutput:
         return pose_call(self.lib, self.ctx.handle, frame, pose_params(self.lib, gamma, **params))

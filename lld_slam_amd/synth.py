@@ -251,6 +251,36 @@ def make_lba_small(window_id=0, n_free=6, n_fixed=2, n_points=300, n_lines=60, *
     return make_ba_window(n_free, n_fixed, n_points, 4, n_lines, 4, seed=0x5A110000 + window_id, **kw)
 
 
+def make_sim3_pair(pair_id=0, n=300, outlier_frac=0.15, scale=1.0, noise=1.0, cam=KITTI_CAM):
+    """One loop-closure candidate for Optimizer::OptimizeSim3: n MapPoints seen by both keyframes, each known in its own camera
+    frame (X1 = S12 X2 up to 3-D noise), keypoints with per-octave pixel noise, a fraction of wrong correspondences, and a start
+    value of S12 a few degrees / decimetres / percent off."""
+    from .host import Sim3Pair
+    rng = np.random.default_rng(0x51300000 + pair_id)
+    fx, fy, cx, cy, _ = cam
+    R12 = _rodrigues(rng.normal(0, 0.25, 3)); t12 = rng.normal(0, 1.5, 3); s12 = float(scale)
+    X2 = np.stack([rng.uniform(-12, 12, n), rng.uniform(-3, 3, n), rng.uniform(5, 45, n)], 1)
+    X1 = s12 * (X2 @ R12.T) + t12
+    keep = X1[:, 2] > 2.0
+    X1, X2 = X1[keep], X2[keep]; n = X1.shape[0]
+    octv = np.minimum(rng.geometric(0.35, n) - 1, 7)
+    inv_s2 = inv_level_sigma2().astype(np.float64)
+    sig = 1.2 ** octv
+    def proj(X): return np.stack([fx * X[:, 0] / X[:, 2] + cx, fy * X[:, 1] / X[:, 2] + cy], 1)
+    obs1 = proj(X1) + noise * sig[:, None] * rng.normal(size=(n, 2))
+    obs2 = proj(X2) + noise * sig[:, None] * rng.normal(size=(n, 2))
+    bad = rng.random(n) < outlier_frac
+    obs2[bad] += rng.uniform(-60, 60, (int(bad.sum()), 2))
+    p1c = _f32(X1 + rng.normal(0, 0.02, X1.shape)).astype(np.float64); p2c = _f32(X2 + rng.normal(0, 0.02, X2.shape)).astype(np.float64)
+    R0 = _rodrigues(rng.normal(0, 0.03, 3)) @ R12
+    from scipy.spatial.transform import Rotation
+    q0 = Rotation.from_matrix(R0).as_quat()                       # x, y, z, w
+    return Sim3Pair(K1=(np.float32(fx), np.float32(fy), np.float32(cx), np.float32(cy)), K2=(np.float32(fx), np.float32(fy), np.float32(cx), np.float32(cy)),
+                    s12_q=q0, s12_t=t12 + rng.normal(0, 0.15, 3), s12_s=s12 * (1.0 + (0.0 if scale == 1.0 else rng.normal(0, 0.03))),
+                    p1c=p1c, p2c=p2c, obs1=_f32(obs1).astype(np.float64), obs2=_f32(obs2).astype(np.float64),
+                    inv_sigma2_1=inv_s2[octv], inv_sigma2_2=inv_s2[octv], meta=dict(R12=R12, t12=t12, s12=s12, bad=bad))
+
+
 def make_pose_frame(frame_id=0, n_points=1000, n_lines=200, outlier_frac=0.10, mono_frac=0.0, mono_line_frac=0.0,
                     cam=KITTI_CAM, seed=None) -> PoseFrame:
     rng = np.random.default_rng(SEED_PO + frame_id if seed is None else seed)

@@ -821,3 +821,183 @@ int lldo_line_match_greedy(void*, const float* dl, int nq, const float* dr, int 
 }
 
 }  // extern "C"
+
+// ================================================================== Optimizer::OptimizeSim3 (src/Optimizer.cc:1656-1851)
+// g2o::Sim3 (types/sim3.h), VertexSim3Expmap / EdgeSim3ProjectXYZ / EdgeInverseSim3ProjectXYZ (types/types_seven_dof_expmap.h:48-171),
+// numeric Jacobians of BaseBinaryEdge (core/base_binary_edge.hpp:131-197; the MapPoint vertices are fixed), dense 7x7 LM.
+namespace {
+
+struct Sim3T { Quat r; V3 t; double s; };
+
+// Sim3(const Vector7d& update)  (sim3.h:64-131): update = (omega, upsilon, sigma)
+Sim3T sim3_exp(const double* u) {
+  const V3 omega{u[0], u[1], u[2]}, upsilon{u[3], u[4], u[5]};
+  const double sigma = u[6];
+  const double theta = norm(omega);
+  const M3 Omega = skew(omega);
+  const double s = std::exp(sigma);
+  const M3 Omega2 = m3_mul(Omega, Omega);
+  const M3 I = m3_identity();
+  M3 R;
+  const double eps = 0.00001;
+  double A, B, C;
+  auto small_R = [&]() { const M3 OO = m3_mul(Omega, Omega); for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) R.m[i][j] = (I.m[i][j] + Omega.m[i][j]) + OO.m[i][j]; };
+  auto big_R = [&]() {
+    const double a = std::sin(theta) / theta, b = (1 - std::cos(theta)) / (theta * theta);
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) R.m[i][j] = (I.m[i][j] + a * Omega.m[i][j]) + b * Omega2.m[i][j];
+  };
+  if (std::fabs(sigma) < eps) {
+    C = 1;
+    if (theta < eps) { A = 1. / 2.; B = 1. / 6.; small_R(); }
+    else {
+      const double theta2 = theta * theta;
+      A = (1 - std::cos(theta)) / (theta2);
+      B = (theta - std::sin(theta)) / (theta2 * theta);
+      big_R();
+    }
+  } else {
+    C = (s - 1) / sigma;
+    if (theta < eps) {
+      const double sigma2 = sigma * sigma;
+      A = ((sigma - 1) * s + 1) / sigma2;
+      B = ((0.5 * sigma2 - sigma + 1) * s) / (sigma2 * sigma);
+      small_R();
+    } else {
+      big_R();
+      const double a = s * std::sin(theta), b = s * std::cos(theta);
+      const double theta2 = theta * theta, sigma2 = sigma * sigma;
+      const double c = theta2 + sigma2;
+      A = (a * sigma + (1 - b) * theta) / (theta * c);
+      B = (C - ((b - 1) * sigma + a * theta) / (c)) * 1. / (theta2);
+    }
+  }
+  Sim3T r; r.r = quat_from_R(R); r.s = s;
+  M3 W;
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) W.m[i][j] = (A * Omega.m[i][j] + B * Omega2.m[i][j]) + C * I.m[i][j];
+  r.t = m3_mulv(W, upsilon);
+  return r;
+}
+V3 sim3_map(const Sim3T& S, const V3& x) { return add(scale(quat_rot(S.r, x), S.s), S.t); }                       // s*(r*xyz) + t
+Sim3T sim3_mul(const Sim3T& a, const Sim3T& b) { Sim3T r; r.r = quat_mul(a.r, b.r); r.t = add(scale(quat_rot(a.r, b.t), a.s), a.t); r.s = a.s * b.s; return r; }
+Sim3T sim3_inverse(const Sim3T& a) {
+  const Quat c{-a.r.x, -a.r.y, -a.r.z, a.r.w};
+  Sim3T r; r.r = c; r.t = quat_rot(c, scale(a.t, -1. / a.s)); r.s = 1. / a.s;
+  return r;
+}
+
+struct Sim3System {
+  double f1[2], pp1[2], f2[2], pp2[2];
+  bool fix_scale;
+  Sim3T S, bk;
+  struct Edge { V3 X; double obs[2]; double s; bool inverse; bool alive; Huber hub; double err[2]; };
+  std::vector<Edge> e;              // e12_0, e21_0, e12_1, e21_1, ...
+  std::vector<int> act;
+  double H[49], b[7], x[7], diagBackup[7];
+  bool terminate() { return false; }
+  size_t numUnknownVertices() { return act.empty() ? 0 : 1; }
+  void initializeOptimization() { act.clear(); for (size_t i = 0; i < e.size(); i++) if (e[i].alive) act.push_back((int)i); }
+  bool buildStructure() { return true; }
+  void edge_error(const Sim3T& T, const Edge& ed, double* err) const {
+    const V3 m = ed.inverse ? sim3_map(sim3_inverse(T), ed.X) : sim3_map(T, ed.X);
+    const double px = m.x / m.z, py = m.y / m.z;                                                                 // project()
+    const double* f = ed.inverse ? f2 : f1; const double* pp = ed.inverse ? pp2 : pp1;
+    err[0] = ed.obs[0] - (px * f[0] + pp[0]); err[1] = ed.obs[1] - (py * f[1] + pp[1]);
+  }
+  void computeActiveErrors() { for (int i : act) edge_error(S, e[i], e[i].err); }
+  double activeRobustChi2() {
+    double chi = 0, rho[3];
+    for (int i : act) { huber_robustify(e[i].hub, chi2_iso(e[i].err, 2, e[i].s), rho); chi += rho[0]; }
+    return chi;
+  }
+  Sim3T oplus(const double* upd) const { double u[7]; std::memcpy(u, upd, sizeof u); if (fix_scale) u[6] = 0; return sim3_mul(sim3_exp(u), S); }
+  void buildSystem() {
+    std::memset(H, 0, sizeof H); std::memset(b, 0, sizeof b);
+    const double delta = 1e-9, scalar = 1.0 / (2 * delta);
+    Sim3T plus[7], minus[7];
+    for (int d = 0; d < 7; d++) { double add_v[7] = {0, 0, 0, 0, 0, 0, 0}; add_v[d] = delta; plus[d] = oplus(add_v); add_v[d] = -delta; minus[d] = oplus(add_v); }
+    for (int i : act) {
+      const Edge& ed = e[i];
+      double J[2][7];
+      for (int d = 0; d < 7; d++) {
+        double ep[2], em[2];
+        edge_error(plus[d], ed, ep); edge_error(minus[d], ed, em);
+        J[0][d] = scalar * (ep[0] - em[0]); J[1][d] = scalar * (ep[1] - em[1]);
+      }
+      double rho[3]; huber_robustify(ed.hub, chi2_iso(ed.err, 2, ed.s), rho);
+      const double w = rho[1];
+      for (int r = 0; r < 7; r++) {
+        double acc = 0; for (int k = 0; k < 2; k++) acc += J[k][r] * (ed.s * ed.err[k]);
+        b[r] -= w * acc;
+        for (int c = 0; c < 7; c++) { double h = 0; for (int k = 0; k < 2; k++) h += J[k][r] * (w * ed.s) * J[k][c]; H[r * 7 + c] += h; }
+      }
+    }
+  }
+  double maxDiagonal() { double m = 0; for (int j = 0; j < 7; j++) m = std::max(std::fabs(H[j * 7 + j]), m); return m; }
+  void push() { bk = S; } void pop() { S = bk; } void discardTop() {}
+  void setLambda(double l) { for (int j = 0; j < 7; j++) { diagBackup[j] = H[j * 7 + j]; H[j * 7 + j] += l; } }
+  void restoreDiagonal() { for (int j = 0; j < 7; j++) H[j * 7 + j] = diagBackup[j]; }
+  bool solve() { std::vector<double> A(H, H + 49); return ldlt_solve(A, 7, b, x, true); }
+  void update() { if (fix_scale) x[6] = 0; S = oplus(x); }   // oplusImpl zeroes update[6] in place, i.e. in the solver's x (types_seven_dof_expmap.h:62-65)
+  double computeScale(double lambda) { double sc = 0; for (int j = 0; j < 7; j++) sc += x[j] * (lambda * x[j] + b[j]); return sc; }
+};
+
+}  // namespace
+
+extern "C" void lldo_sim3_params_default(lld_sim3_params* p) {
+  p->th2 = 10.0; p->fix_scale = 1; p->its_first = 5; p->its_more_bad = 10; p->its_more_clean = 5; p->min_inliers = 10; p->max_trials = 10;
+}
+extern "C" void lldo_sim3_exp(const double* u7, double* qts8) {
+  const Sim3T s = sim3_exp(u7);
+  qts8[0] = s.r.x; qts8[1] = s.r.y; qts8[2] = s.r.z; qts8[3] = s.r.w; qts8[4] = s.t.x; qts8[5] = s.t.y; qts8[6] = s.t.z; qts8[7] = s.s;
+}
+
+extern "C" int lldo_optimize_sim3(void* /*ctx*/, const lld_sim3_problem* in, const lld_sim3_params* prm_in, lld_sim3_result* out) {
+  lld_sim3_params prm; if (prm_in) prm = *prm_in; else lldo_sim3_params_default(&prm);
+  Sim3System Y;
+  Y.f1[0] = in->fx1; Y.f1[1] = in->fy1; Y.pp1[0] = in->cx1; Y.pp1[1] = in->cy1;
+  Y.f2[0] = in->fx2; Y.f2[1] = in->fy2; Y.pp2[0] = in->cx2; Y.pp2[1] = in->cy2;
+  Y.fix_scale = prm.fix_scale != 0;
+  Y.S.r = Quat{in->s12_q[0], in->s12_q[1], in->s12_q[2], in->s12_q[3]}; Y.S.t = V3{in->s12_t[0], in->s12_t[1], in->s12_t[2]}; Y.S.s = in->s12_s;
+  const Sim3T S0 = Y.S;
+  const double deltaHuber = (double)(float)std::sqrt(prm.th2);                     // const float deltaHuber = sqrt(th2)
+  const int n = in->n;
+  for (int i = 0; i < n; i++) {
+    Sim3System::Edge a; a.X = V3{in->p2c[3 * i], in->p2c[3 * i + 1], in->p2c[3 * i + 2]}; a.obs[0] = in->obs1[2 * i]; a.obs[1] = in->obs1[2 * i + 1];
+    a.s = in->inv_sigma2_1[i]; a.inverse = false; a.alive = true; a.hub = huber_make(deltaHuber); a.err[0] = a.err[1] = 0;
+    Sim3System::Edge c; c.X = V3{in->p1c[3 * i], in->p1c[3 * i + 1], in->p1c[3 * i + 2]}; c.obs[0] = in->obs2[2 * i]; c.obs[1] = in->obs2[2 * i + 1];
+    c.s = in->inv_sigma2_2[i]; c.inverse = true; c.alive = true; c.hub = huber_make(deltaHuber); c.err[0] = c.err[1] = 0;
+    Y.e.push_back(a); Y.e.push_back(c);
+  }
+  auto store = [&](const Sim3T& S) {
+    out->s12_q[0] = S.r.x; out->s12_q[1] = S.r.y; out->s12_q[2] = S.r.z; out->s12_q[3] = S.r.w;
+    out->s12_t[0] = S.t.x; out->s12_t[1] = S.t.y; out->s12_t[2] = S.t.z; out->s12_s = S.s;
+  };
+  for (int i = 0; i < n; i++) out->dropped[i] = 0;
+  out->n_inliers = 0; out->n_bad_first = 0; out->lm_iterations[0] = out->lm_iterations[1] = 0; out->lm_trials[0] = out->lm_trials[1] = 0; out->chi2 = 0;
+  store(S0);
+  LMData lm; lm.maxTrials = prm.max_trials;
+  Y.initializeOptimization();
+  lm_optimize(Y, lm, prm.its_first);
+  out->lm_iterations[0] = lm.iterations; out->lm_trials[0] = lm.trials; out->chi2 = lm.lastChi;
+  int nBad = 0;
+  for (int i = 0; i < n; i++) {
+    Sim3System::Edge& e12 = Y.e[2 * i]; Sim3System::Edge& e21 = Y.e[2 * i + 1];
+    if (chi2_iso(e12.err, 2, e12.s) > prm.th2 || chi2_iso(e21.err, 2, e21.s) > prm.th2) { out->dropped[i] = 1; e12.alive = false; e21.alive = false; nBad++; }
+  }
+  out->n_bad_first = nBad;
+  const int nMoreIterations = nBad > 0 ? prm.its_more_bad : prm.its_more_clean;
+  if (n - nBad < prm.min_inliers) return LLD_OK;                                     // return 0; g2oS12 untouched
+  LMData lm2; lm2.maxTrials = prm.max_trials; lm2.lambda = lm.lambda; lm2.ni = lm.ni; lm2.nBad = lm.nBad;
+  Y.initializeOptimization();
+  lm_optimize(Y, lm2, nMoreIterations);
+  out->lm_iterations[1] = lm2.iterations; out->lm_trials[1] = lm2.trials; if (lm2.iterations > 0) out->chi2 = lm2.lastChi;
+  int nIn = 0;
+  for (int i = 0; i < n; i++) {
+    if (out->dropped[i]) continue;
+    const Sim3System::Edge& e12 = Y.e[2 * i]; const Sim3System::Edge& e21 = Y.e[2 * i + 1];
+    if (chi2_iso(e12.err, 2, e12.s) > prm.th2 || chi2_iso(e21.err, 2, e21.s) > prm.th2) out->dropped[i] = 1; else nIn++;
+  }
+  store(Y.S);
+  out->n_inliers = nIn;
+  return LLD_OK;
+}

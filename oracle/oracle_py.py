@@ -169,6 +169,21 @@ def local_ba(win: host.Window, gamma=1.0, abort=False, **params):
     return host.ba_call(lib(), None, win, host.ba_params(lib(), gamma, **params), abort)
 
 
+def optimize_sim3(pair, th2=10.0, bFixScale=True, **params):
+    """Optimizer::OptimizeSim3, literal restatement (numeric Jacobians as g2o)."""
+    many = isinstance(pair, (list, tuple))
+    outs = host.sim3_call(lib(), None, list(pair) if many else [pair], host.sim3_params(lib(), th2, bFixScale, **params))
+    return outs if many else outs[0]
+
+
+def sim3_exp(u7):
+    d = lib().dll
+    d.lldo_sim3_exp.argtypes = [abi.c_double_p, abi.c_double_p]; d.lldo_sim3_exp.restype = None
+    u = _d(u7); o = np.zeros(8)
+    d.lldo_sim3_exp(_dp(u), _dp(o))
+    return o
+
+
 def pose_opt(frame: host.PoseFrame, gamma=0.5, **params):
     return host.pose_call(lib(), None, frame, host.pose_params(lib(), gamma, **params))
 

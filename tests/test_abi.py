@@ -37,7 +37,8 @@ def test_struct_layouts_match_the_header(tmp_path):
              ("lld_line_stereo_params", abi.LineStereoParams), ("lld_orb_search", orb_search.OrbSearch), ("lld_orb_search_result", orb_search.OrbSearchResult),
              ("lld_frame_view", orb_search.FrameView), ("lld_map_points", orb_search.MapPoints), ("lld_frustum_result", orb_search.FrustumResult),
              ("lld_last_frame_points", orb_search.LastFramePoints), ("lld_keypoints", orb_search.Keypoints),
-             ("lld_stereo_pyramids", orb_search.StereoPyramids), ("lld_stereo_result", orb_search.StereoResult)]
+             ("lld_stereo_pyramids", orb_search.StereoPyramids), ("lld_stereo_result", orb_search.StereoResult),
+             ("lld_sim3_problem", abi.Sim3Problem), ("lld_sim3_params", abi.Sim3Params), ("lld_sim3_result", abi.Sim3Result)]
     src = tmp_path / "sz.c"
     body = "".join(f'printf("%zu\\n", sizeof({n}));' for n, _ in names)
     # field offsets of the widest struct too: equal sizes alone would not catch two swapped members

@@ -53,6 +53,20 @@ t = time.perf_counter(); ob = O.local_ba(wb, protocol=1, its_round1=2); dtcb = t
 out["global_ba_590kf"] = {"gpu_ms_10_iterations": dtb * 1e3, "gpu_pcg_iterations": gb.stats["pcg_iterations"], "cpu_oracle_ms_2_iterations": dtcb * 1e3,
                           "edges": int(wb.n_pt_obs + 2 * wb.n_ln_obs),
                           "chi2_rel_after_2": abs(g2.stats["chi2_final"] - ob.stats["chi2_final"]) / ob.stats["chi2_final"]}
+# ---- Optimizer::OptimizeSim3 (loop-closure candidates): one call, and 16 candidates in one launch
+sp = synth.make_sim3_pair(0, 300)
+opt.OptimizeSim3(sp); ts = []
+for _ in range(21):
+    t = time.perf_counter(); gs = opt.OptimizeSim3(sp); ts.append(time.perf_counter() - t)
+tc = []
+for _ in range(5):
+    t = time.perf_counter(); os_ = O.optimize_sim3(sp); tc.append(time.perf_counter() - t)
+sps = [synth.make_sim3_pair(20 + i, 300) for i in range(16)]
+opt.OptimizeSim3(sps); tb = []
+for _ in range(7):
+    t = time.perf_counter(); opt.OptimizeSim3(sps); tb.append(time.perf_counter() - t)
+out["optimize_sim3_300"] = {"gpu_ms": 1e3 * float(np.median(ts)), "cpu_oracle_ms": 1e3 * float(np.median(tc)), "gpu_ms_16_candidates": 1e3 * float(np.median(tb)),
+                            "equal": bool(np.array_equal(gs.dropped, os_.dropped) and gs.n_inliers == os_.n_inliers)}
 # ---- ORB 2000 x 2000 Hamming best/second, batched in HBM
 B, nq, nt = 256, 2000, 2000
 dev = torch.device("cuda", 0)
