@@ -283,6 +283,39 @@ int lld_optimize_sim3(lld_ctx* ctx, const lld_sim3_problem* in, const lld_sim3_p
 /* several loop / relocalisation candidates in one launch (one workgroup each) */
 int lld_optimize_sim3_batch(lld_ctx* ctx, int n, const lld_sim3_problem* problems, const lld_sim3_params* params, lld_sim3_result* outs);
 
+/* ================================================================== Optimizer::OptimizeEssentialGraph (src/Optimizer.cc:1391-1654)
+ * The pose graph itself: one Sim3 vertex per keyframe (Siw; `fixed[k]` for pLoopKF), one EdgeSim3 per loop / spanning-tree / old
+ * loop / covisibility (>= 100) connection in the reference's insertion order, error = log(Sji * Siw * Sjw^-1)
+ * (types_seven_dof_expmap.h:99-127), identity information, no robust kernel, NUMERIC Jacobians for both vertices like g2o
+ * (core/base_binary_edge.hpp:131-197), Levenberg-Marquardt with setUserLambdaInit(1e-16), optimize(15).  Nothing is marginalised:
+ * H is the 7N x 7N system, solved by the block-Jacobi PCG spread over the GPU (g2o: sparse Cholesky).
+ * Building the edge list from the map (:1447-1585) and the write-back (:1593-1653: SE3 recovery [R t/s], MapPoint correction through
+ * the reference keyframe) stay with the adapter. */
+typedef struct {
+  int32_t n_vertices;
+  int32_t n_edges;
+  const double*  sim3;          /* [n_vertices][8] Siw: rotation x, y, z, w, translation, scale      */
+  const uint8_t* fixed;         /* [n_vertices] 1 = setFixed(true)                                    */
+  const int32_t* edge_i;        /* [n_edges] vertex 0 of the edge (nIDi)                              */
+  const int32_t* edge_j;        /* [n_edges] vertex 1 of the edge (nIDj)                              */
+  const double*  edge_sji;      /* [n_edges][8] measurement Sji                                       */
+} lld_pose_graph;
+typedef struct {
+  int32_t iterations;           /* 15                                                                 */
+  int32_t fix_scale;            /* bFixScale                                                          */
+  double  lambda_init;          /* 1e-16 (solver->setUserLambdaInit)                                  */
+  int32_t max_trials;           /* 10                                                                 */
+  int32_t pcg_max_iter;         /* 0 -> 10 * 7 * n_vertices                                           */
+  double  pcg_rel_tol;          /* |r|_M / |b|_M of the PCG                                           */
+} lld_pose_graph_params;
+void lld_pose_graph_params_default(lld_pose_graph_params* p);
+typedef struct {
+  double* sim3;                 /* [n_vertices][8] CorrectedSiw                                       */
+  double  chi2;                 /* active chi2 after the last accepted step                           */
+  int32_t lm_iterations, lm_trials, pcg_iterations, reserved;
+} lld_pose_graph_result;
+int lld_optimize_essential_graph(lld_ctx* ctx, const lld_pose_graph* graph, const lld_pose_graph_params* params, lld_pose_graph_result* out);
+
 /* ================================================================== descriptor matching
  * lld_match_hamming256*: ORBmatcher::DescriptorDistance (src/ORBmatcher.cc:1647-1663) plus
  * the best / second-best loops of the Search* family (e.g. :76-125, :201-249).  Strict '<'

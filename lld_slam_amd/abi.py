@@ -146,6 +146,21 @@ class Sim3Result(C.Structure):
                 ("n_bad_first", C.c_int32), ("lm_iterations", C.c_int32 * 2), ("lm_trials", C.c_int32 * 2), ("chi2", C.c_double)]
 
 
+class PoseGraph(C.Structure):
+    _fields_ = [("n_vertices", C.c_int32), ("n_edges", C.c_int32), ("sim3", c_double_p), ("fixed", c_uint8_p), ("edge_i", c_int32_p),
+                ("edge_j", c_int32_p), ("edge_sji", c_double_p)]
+
+
+class PoseGraphParams(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("fix_scale", C.c_int32), ("lambda_init", C.c_double), ("max_trials", C.c_int32),
+                ("pcg_max_iter", C.c_int32), ("pcg_rel_tol", C.c_double)]
+
+
+class PoseGraphResult(C.Structure):
+    _fields_ = [("sim3", c_double_p), ("chi2", C.c_double), ("lm_iterations", C.c_int32), ("lm_trials", C.c_int32), ("pcg_iterations", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
 PRODUCT_SYMBOLS = [
     "lld_status_string", "lld_ctx_create", "lld_ctx_destroy", "lld_ctx_stream", "lld_ctx_synchronize",
     "lld_se3_from_tcw_f32", "lld_se3_to_tcw_f32", "lld_orb_inv_level_sigma2",
@@ -160,6 +175,7 @@ PRODUCT_SYMBOLS = [
     "lld_orb_search_run", "lld_orb_search_batch", "lld_orb_search_local_points", "lld_orb_search_last_frame", "lld_orb_fuse_search",
     "lld_compute_stereo_matches",
     "lld_sim3_params_default", "lld_optimize_sim3", "lld_optimize_sim3_batch",
+    "lld_pose_graph_params_default", "lld_optimize_essential_graph",
 ]
 
 

@@ -1,0 +1,370 @@
+// lld_posegraph.hip — Optimizer::OptimizeEssentialGraph (src/Optimizer.cc:1391-1654), the optimisation proper: Sim3 vertices, EdgeSim3
+// edges (error = log(Sji * Siw * Sjw^-1), identity information, numeric Jacobians for both vertices as g2o computes them),
+// Levenberg-Marquardt with a user lambda (1e-16) on the 7N x 7N system.
+//   pg_errors     lane <-> edge: the 7-vector errors at the current estimate, chi2
+//   pg_linearize  lane <-> (edge, vertex, dof): central differences on the vertex's oplus (delta 1e-9) -> J[e][v] (7x7)
+//   pg_diag       lane group <-> unknown vertex: b_v = -sum J^T e and H_vv = sum J^T J over its incident edges (vertex CSR, fixed order)
+// H itself is never formed: the system is applied edge by edge (H p = sum_e J_e^T (J_e p)) through the same CSR,
+// so memory is O(edges) and every sum has a fixed order (deterministic):
+//   pg_pcg_init / pg_matvec / pg_pcg_update   block-Jacobi PCG ((H_vv + lambda I)^-1 per vertex) with the host polling `done`
+//   pg_update     V <- exp(x_v) V (the scale update zeroed in place when fix_scale), scale = sum x (lambda x + b)
+// The LM control (push / pop, rho, lambda schedule, stop rules of optimization_algorithm_levenberg.cpp:61-164) runs on the host:
+// a loop closure happens once in a while, latency of a few polls is irrelevant.
+#include "lld_common.h"
+#include "lld_device_math.h"
+#include "lld_sim3_math.h"
+
+namespace {
+
+constexpr int kPgThreads = 256;
+
+struct PgArrays {
+  int N, E, nu;
+  double* V;                 // [N][8] current estimate
+  const int* hidx;           // [N] unknown index or -1
+  const int* ei; const int* ej;
+  const double* C;           // [E][8]
+  double* err;               // [E][7]
+  double* J;                 // [E][2][49] row-major 7x7 (error row, dof)
+  const int* vstart;         // [nu+1] CSR: incident (edge, role) of every unknown vertex, in edge order
+  const int* vinc;           // entry = edge * 2 + role (0: the vertex is edge_i, 1: edge_j)
+  const int* uvert;          // [nu] vertex id of an unknown
+  double* Hd;                // [nu][49]  H_vv
+  double* Mi;                // [nu][49]  (H_vv + lambda I)^-1
+  double* b; double* x; double* r; double* z; double* p; double* ap;   // [7 nu]
+  double* sc;                // scalars: 0 rz, 1 stop, 2 iterations, 3 done, 4 ok, 5 chi2, 6 scale
+  int fix_scale;
+};
+
+__device__ __forceinline__ void edge_error(const Sim3& C, const Sim3& v1, const Sim3& v2, double* e) {
+  sim3_log(sim3_mul(sim3_mul(C, v1), sim3_inverse(v2)), e);            // Sim3 error_ = C * v1 * v2.inverse(); _error = error_.log()
+}
+__device__ __forceinline__ Sim3 oplus(const Sim3& S, const double* upd, int fix_scale) {
+  double u[7];
+#pragma unroll
+  for (int i = 0; i < 7; i++) u[i] = upd[i];
+  if (fix_scale) u[6] = 0;
+  return sim3_mul(sim3_exp(u), S);
+}
+
+// one workgroup: errors of all edges, chi2 = sum e^T e in a fixed order
+__global__ __launch_bounds__(1024) void pg_errors_kernel(PgArrays A) {
+  __shared__ double scratch[32];
+  const int tid = threadIdx.x;
+  double part = 0.0;
+  for (int e = tid; e < A.E; e += 1024) {
+    double er[7];
+    edge_error(sim3_load(A.C + 8 * (size_t)e), sim3_load(A.V + 8 * (size_t)A.ei[e]), sim3_load(A.V + 8 * (size_t)A.ej[e]), er);
+    double c = 0.0;
+#pragma unroll
+    for (int k = 0; k < 7; k++) { A.err[7 * (size_t)e + k] = er[k]; c += er[k] * er[k]; }
+    part += c;
+  }
+  for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+  __syncthreads();
+  if ((tid & 63) == 0) scratch[tid >> 6] = part;
+  __syncthreads();
+  if (tid == 0) { double s = 0.0; for (int w = 0; w < 16; w++) s += scratch[w]; A.sc[5] = s; }
+}
+
+// lane <-> (edge, vertex role, dof)
+__global__ __launch_bounds__(kPgThreads) void pg_linearize_kernel(PgArrays A) {
+  const long long id = (long long)blockIdx.x * kPgThreads + threadIdx.x;
+  if (id >= (long long)A.E * 14) return;
+  const int e = (int)(id / 14), pq = (int)(id % 14), role = pq / 7, d = pq % 7;
+  const int vi = A.ei[e], vj = A.ej[e];
+  const int vid = role == 0 ? vi : vj;
+  if (A.hidx[vid] < 0) return;
+  const Sim3 C = sim3_load(A.C + 8 * (size_t)e);
+  const Sim3 S1 = sim3_load(A.V + 8 * (size_t)vi), S2 = sim3_load(A.V + 8 * (size_t)vj);
+  double add_v[7] = {0, 0, 0, 0, 0, 0, 0}, ep[7], em[7];
+  add_v[d] = 1e-9;
+  const Sim3 Pp = oplus(role == 0 ? S1 : S2, add_v, A.fix_scale);
+  add_v[d] = -1e-9;
+  const Sim3 Pm = oplus(role == 0 ? S1 : S2, add_v, A.fix_scale);
+  if (role == 0) { edge_error(C, Pp, S2, ep); edge_error(C, Pm, S2, em); }
+  else { edge_error(C, S1, Pp, ep); edge_error(C, S1, Pm, em); }
+  const double scalar = 1.0 / (2 * 1e-9);
+  double* Jd = A.J + ((size_t)e * 2 + role) * 49;
+#pragma unroll
+  for (int r = 0; r < 7; r++) Jd[r * 7 + d] = scalar * (ep[r] - em[r]);
+}
+
+// lane <-> (unknown vertex, entry of H_vv or of b_v): 56 lanes of a wavefront per vertex
+__global__ __launch_bounds__(64) void pg_diag_kernel(PgArrays A) {
+  const int u = blockIdx.x, t = threadIdx.x;
+  if (u >= A.nu || t >= 56) return;
+  double acc = 0.0;
+  for (int q = A.vstart[u]; q < A.vstart[u + 1]; q++) {
+    const int e = A.vinc[q] >> 1, role = A.vinc[q] & 1;
+    const double* Jd = A.J + ((size_t)e * 2 + role) * 49;
+    if (t < 49) {
+      const int r = t / 7, c = t % 7;
+#pragma unroll
+      for (int k = 0; k < 7; k++) acc += Jd[k * 7 + r] * Jd[k * 7 + c];
+    } else {
+      const int r = t - 49;
+      double s = 0.0;
+#pragma unroll
+      for (int k = 0; k < 7; k++) s += Jd[k * 7 + r] * A.err[7 * (size_t)e + k];
+      acc -= s;
+    }
+  }
+  if (t < 49) A.Hd[(size_t)u * 49 + t] = acc; else A.b[(size_t)u * 7 + (t - 49)] = acc;
+}
+
+// (H_vv + lambda I)^-1 by LDL^T; ok = 0 when a pivot is not positive.  lane <-> vertex
+__device__ bool inv7(const double* Hm, double lambda, double* out) {
+  double L[7][7], D[7];
+  for (int j = 0; j < 7; j++) {
+    double d = Hm[j * 7 + j] + lambda;
+    for (int p = 0; p < j; p++) d -= L[j][p] * L[j][p] * D[p];
+    if (!(d > 0.0) || !isfinite(d)) return false;
+    D[j] = d;
+    for (int i = j + 1; i < 7; i++) {
+      double s = Hm[i * 7 + j];
+      for (int p = 0; p < j; p++) s -= L[i][p] * L[j][p] * D[p];
+      L[i][j] = s / d;
+    }
+  }
+  for (int c = 0; c < 7; c++) {                       // solve for the unit vectors
+    double y[7];
+    for (int i = 0; i < 7; i++) { double s = i == c ? 1.0 : 0.0; for (int p = 0; p < i; p++) s -= L[i][p] * y[p]; y[i] = s; }
+    for (int i = 0; i < 7; i++) y[i] /= D[i];
+    double xs[7];
+    for (int i = 6; i >= 0; i--) { double s = y[i]; for (int p = i + 1; p < 7; p++) s -= L[p][i] * xs[p]; xs[i] = s; }
+    for (int i = 0; i < 7; i++) out[i * 7 + c] = xs[i];
+  }
+  return true;
+}
+
+__global__ __launch_bounds__(1024) void pg_pcg_init_kernel(PgArrays A, double lambda, double tol) {
+  __shared__ double scratch[32];
+  __shared__ int ok_s;
+  const int tid = threadIdx.x, n = 7 * A.nu;
+  if (tid == 0) ok_s = 1;
+  __syncthreads();
+  for (int u = tid; u < A.nu; u += 1024) if (!inv7(A.Hd + (size_t)u * 49, lambda, A.Mi + (size_t)u * 49)) ok_s = 0;
+  for (int i = tid; i < n; i += 1024) { A.x[i] = 0.0; A.r[i] = A.b[i]; }
+  __syncthreads();
+  double part = 0.0;
+  for (int i = tid; i < n; i += 1024) {
+    const int u = i / 7, rr = i - u * 7;
+    double zv = 0.0;
+#pragma unroll
+    for (int c = 0; c < 7; c++) zv += A.Mi[(size_t)u * 49 + rr * 7 + c] * A.r[u * 7 + c];
+    A.z[i] = zv; A.p[i] = zv;
+    part += A.r[i] * zv;
+  }
+  for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+  __syncthreads();
+  if ((tid & 63) == 0) scratch[tid >> 6] = part;
+  __syncthreads();
+  if (tid == 0) {
+    double rz0 = 0.0; for (int w = 0; w < 16; w++) rz0 += scratch[w];
+    const bool ok = ok_s != 0 && isfinite(rz0);
+    A.sc[0] = rz0; A.sc[1] = tol * tol * rz0; A.sc[2] = 0.0; A.sc[3] = (ok && rz0 > 0.0) ? 0.0 : 1.0; A.sc[4] = ok ? 1.0 : 0.0;
+  }
+}
+
+// ap_v = lambda p_v + sum_{e incident to v} J_{e,v}^T (J_{e,i} p_i + J_{e,j} p_j): 8 lanes per unknown vertex (7 used)
+__global__ __launch_bounds__(kPgThreads) void pg_matvec_kernel(PgArrays A, double lambda) {
+  if (A.sc[3] != 0.0) return;
+  const int g = (blockIdx.x * kPgThreads + threadIdx.x) >> 3, l = threadIdx.x & 7;
+  if (g >= A.nu) return;
+  double acc = l < 7 ? lambda * A.p[(size_t)g * 7 + l] : 0.0;
+  for (int q = A.vstart[g]; q < A.vstart[g + 1]; q++) {
+    const int e = A.vinc[q] >> 1, role = A.vinc[q] & 1;
+    const int hi = A.hidx[A.ei[e]], hj = A.hidx[A.ej[e]];
+    const double* Ji = A.J + ((size_t)e * 2) * 49; const double* Jj = Ji + 49;
+    double w = 0.0;                                      // lane l: component l of J_i p_i + J_j p_j
+    if (l < 7) {
+      if (hi >= 0) for (int d = 0; d < 7; d++) w += Ji[l * 7 + d] * A.p[(size_t)hi * 7 + d];
+      if (hj >= 0) for (int d = 0; d < 7; d++) w += Jj[l * 7 + d] * A.p[(size_t)hj * 7 + d];
+    }
+    const double* Jv = role == 0 ? Ji : Jj;
+#pragma unroll
+    for (int k = 0; k < 7; k++) {
+      const double wk = __shfl(w, k, 8);
+      if (l < 7) acc += Jv[k * 7 + l] * wk;
+    }
+  }
+  if (l < 7) A.ap[(size_t)g * 7 + l] = acc;
+}
+
+__global__ __launch_bounds__(1024) void pg_pcg_update_kernel(PgArrays A, int max_iter) {
+  __shared__ double scratch[32];
+  if (A.sc[3] != 0.0) return;
+  const int tid = threadIdx.x, n = 7 * A.nu;
+  const double rz = A.sc[0], stop = A.sc[1];
+  auto bsum = [&](double part) {
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+    __syncthreads();
+    if ((tid & 63) == 0) scratch[tid >> 6] = part;
+    __syncthreads();
+    double s = 0.0; for (int w = 0; w < 16; w++) s += scratch[w];
+    return s;
+  };
+  double part = 0.0;
+  for (int i = tid; i < n; i += 1024) part += A.p[i] * A.ap[i];
+  const double pAp = bsum(part);
+  if (!(pAp > 0.0) || !isfinite(pAp)) { if (tid == 0) { A.sc[3] = 1.0; A.sc[4] = 0.0; } return; }
+  const double alpha = rz / pAp;
+  for (int i = tid; i < n; i += 1024) { A.x[i] += alpha * A.p[i]; A.r[i] -= alpha * A.ap[i]; }
+  __syncthreads();
+  part = 0.0;
+  for (int i = tid; i < n; i += 1024) {
+    const int u = i / 7, rr = i - u * 7;
+    double zv = 0.0;
+#pragma unroll
+    for (int c = 0; c < 7; c++) zv += A.Mi[(size_t)u * 49 + rr * 7 + c] * A.r[u * 7 + c];
+    A.z[i] = zv;
+    part += A.r[i] * zv;
+  }
+  const double rz_new = bsum(part);
+  const double iters = A.sc[2] + 1.0;
+  bool done = false, ok = true;
+  if (!isfinite(rz_new)) { done = true; ok = false; }
+  else if (rz_new <= stop || iters >= (double)max_iter) done = true;
+  if (!done) { const double beta = rz_new / rz; for (int i = tid; i < n; i += 1024) A.p[i] = A.z[i] + beta * A.p[i]; }
+  __syncthreads();
+  if (tid == 0) { A.sc[0] = rz_new; A.sc[2] = iters; if (done) A.sc[3] = 1.0; if (!ok) A.sc[4] = 0.0; }
+}
+
+// V <- exp(x_v) V for the unknown vertices; scale = sum_j x_j (lambda x_j + b_j) with the zeroed scale components
+__global__ __launch_bounds__(1024) void pg_update_kernel(PgArrays A, double lambda) {
+  __shared__ double scratch[32];
+  const int tid = threadIdx.x;
+  double part = 0.0;
+  for (int u = tid; u < A.nu; u += 1024) {
+    double* xu = A.x + (size_t)u * 7;
+    if (A.fix_scale) xu[6] = 0;                               // oplusImpl zeroes update[6] in the solver's x
+    const int v = A.uvert[u];
+    sim3_store(oplus(sim3_load(A.V + 8 * (size_t)v), xu, A.fix_scale), A.V + 8 * (size_t)v);
+#pragma unroll
+    for (int k = 0; k < 7; k++) part += xu[k] * (lambda * xu[k] + A.b[(size_t)u * 7 + k]);
+  }
+  for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+  __syncthreads();
+  if ((tid & 63) == 0) scratch[tid >> 6] = part;
+  __syncthreads();
+  if (tid == 0) { double s = 0.0; for (int w = 0; w < 16; w++) s += scratch[w]; A.sc[6] = s; }
+}
+
+inline size_t pad256(size_t b) { return (b + 255) & ~size_t(255); }
+
+}  // namespace
+
+extern "C" void lld_pose_graph_params_default(lld_pose_graph_params* p) {
+  if (!p) return;
+  p->iterations = 15; p->fix_scale = 1; p->lambda_init = 1e-16; p->max_trials = 10; p->pcg_max_iter = 0; p->pcg_rel_tol = 1e-12;
+}
+
+extern "C" int lld_optimize_essential_graph(lld_ctx* ctx, const lld_pose_graph* g, const lld_pose_graph_params* params, lld_pose_graph_result* out) {
+  if (!ctx || !g || !out || !out->sim3) return LLD_ERR_INVALID;
+  lld_pose_graph_params prm; if (params) prm = *params; else lld_pose_graph_params_default(&prm);
+  const int N = g->n_vertices, E = g->n_edges;
+  if (N < 0 || E < 0 || (N > 0 && !g->sim3) || (E > 0 && (!g->edge_i || !g->edge_j || !g->edge_sji))) return LLD_ERR_INVALID;
+  if (prm.iterations < 0 || prm.max_trials <= 0 || !(prm.pcg_rel_tol > 0)) return LLD_ERR_INVALID;
+  for (int e = 0; e < E; e++) if (g->edge_i[e] < 0 || g->edge_i[e] >= N || g->edge_j[e] < 0 || g->edge_j[e] >= N) return LLD_ERR_INVALID;
+  out->chi2 = 0; out->lm_iterations = 0; out->lm_trials = 0; out->pcg_iterations = 0; out->reserved = 0;
+  if (N) std::memcpy(out->sim3, g->sim3, sizeof(double) * 8 * (size_t)N);
+  // unknowns in vertex order (g2o: buildIndexMapping over the vertices sorted by id), vertex CSR in edge order
+  std::vector<int> hidx(N, -1), uvert;
+  for (int v = 0; v < N; v++) if (!(g->fixed && g->fixed[v])) { hidx[v] = (int)uvert.size(); uvert.push_back(v); }
+  const int nu = (int)uvert.size();
+  if (E == 0 || nu == 0) return LLD_OK;                      // optimize() has nothing to do
+  std::vector<int> vstart(nu + 1, 0), vinc;
+  for (int e = 0; e < E; e++) { if (hidx[g->edge_i[e]] >= 0) vstart[hidx[g->edge_i[e]] + 1]++; if (hidx[g->edge_j[e]] >= 0) vstart[hidx[g->edge_j[e]] + 1]++; }
+  for (int u = 0; u < nu; u++) vstart[u + 1] += vstart[u];
+  vinc.resize(vstart[nu]);
+  { std::vector<int> cur(vstart.begin(), vstart.end() - 1);
+    for (int e = 0; e < E; e++) { const int a = hidx[g->edge_i[e]], b = hidx[g->edge_j[e]]; if (a >= 0) vinc[cur[a]++] = e * 2; if (b >= 0) vinc[cur[b]++] = e * 2 + 1; } }
+  LLD_HIP_TRY(hipSetDevice(ctx->device));
+  const size_t n = 7 * (size_t)nu;
+  // one scratch slab
+  size_t off = 0; auto take = [&](size_t bytes) { const size_t o = off; off += pad256(bytes); return o; };
+  const size_t o_V = take((size_t)N * 64), o_Vbk = take((size_t)N * 64), o_h = take((size_t)N * 4), o_ei = take((size_t)E * 4), o_ej = take((size_t)E * 4), o_C = take((size_t)E * 64),
+               o_err = take((size_t)E * 56), o_J = take((size_t)E * 2 * 49 * 8), o_vs = take((size_t)(nu + 1) * 4), o_vi = take(vinc.size() * 4 + 4), o_uv = take((size_t)nu * 4),
+               o_Hd = take((size_t)nu * 49 * 8), o_Mi = take((size_t)nu * 49 * 8), o_vec = take(6 * n * 8), o_sc = take(64);
+  void* db; int st = lld_ctx_scratch(ctx, off + 256, &db); if (st) return st;
+  char* d = (char*)db;
+  hipStream_t sm = ctx->stream;
+  LLD_HIP_TRY(hipMemcpyAsync(d + o_V, g->sim3, (size_t)N * 64, hipMemcpyHostToDevice, sm));
+  LLD_HIP_TRY(hipMemcpyAsync(d + o_h, hidx.data(), (size_t)N * 4, hipMemcpyHostToDevice, sm));
+  LLD_HIP_TRY(hipMemcpyAsync(d + o_ei, g->edge_i, (size_t)E * 4, hipMemcpyHostToDevice, sm));
+  LLD_HIP_TRY(hipMemcpyAsync(d + o_ej, g->edge_j, (size_t)E * 4, hipMemcpyHostToDevice, sm));
+  LLD_HIP_TRY(hipMemcpyAsync(d + o_C, g->edge_sji, (size_t)E * 64, hipMemcpyHostToDevice, sm));
+  LLD_HIP_TRY(hipMemcpyAsync(d + o_vs, vstart.data(), (size_t)(nu + 1) * 4, hipMemcpyHostToDevice, sm));
+  LLD_HIP_TRY(hipMemcpyAsync(d + o_vi, vinc.data(), vinc.size() * 4, hipMemcpyHostToDevice, sm));
+  LLD_HIP_TRY(hipMemcpyAsync(d + o_uv, uvert.data(), (size_t)nu * 4, hipMemcpyHostToDevice, sm));
+  LLD_HIP_TRY(hipMemsetAsync(d + o_J, 0, (size_t)E * 2 * 49 * 8, sm));
+  PgArrays A; std::memset(&A, 0, sizeof A);
+  A.N = N; A.E = E; A.nu = nu; A.V = reinterpret_cast<double*>(d + o_V); A.hidx = reinterpret_cast<const int*>(d + o_h);
+  A.ei = reinterpret_cast<const int*>(d + o_ei); A.ej = reinterpret_cast<const int*>(d + o_ej); A.C = reinterpret_cast<const double*>(d + o_C);
+  A.err = reinterpret_cast<double*>(d + o_err); A.J = reinterpret_cast<double*>(d + o_J);
+  A.vstart = reinterpret_cast<const int*>(d + o_vs); A.vinc = reinterpret_cast<const int*>(d + o_vi); A.uvert = reinterpret_cast<const int*>(d + o_uv);
+  A.Hd = reinterpret_cast<double*>(d + o_Hd); A.Mi = reinterpret_cast<double*>(d + o_Mi);
+  double* vec = reinterpret_cast<double*>(d + o_vec);
+  A.b = vec; A.x = vec + n; A.r = vec + 2 * n; A.z = vec + 3 * n; A.p = vec + 4 * n; A.ap = vec + 5 * n;
+  A.sc = reinterpret_cast<double*>(d + o_sc); A.fix_scale = prm.fix_scale;
+  double* dVbk = reinterpret_cast<double*>(d + o_Vbk);
+  double hsc[8];
+  auto read_sc = [&]() -> int { LLD_HIP_TRY(hipMemcpyAsync(hsc, A.sc, sizeof hsc, hipMemcpyDeviceToHost, sm)); LLD_HIP_TRY(hipStreamSynchronize(sm)); return LLD_OK; };
+  auto errors = [&](double* chi) -> int { hipLaunchKernelGGL(pg_errors_kernel, dim3(1), dim3(1024), 0, sm, A); int s = read_sc(); if (s) return s; *chi = hsc[5]; return LLD_OK; };
+  const int pcg_limit = prm.pcg_max_iter > 0 ? prm.pcg_max_iter : 10 * (int)n;
+
+  // ---- SparseOptimizer::optimize(iterations) with OptimizationAlgorithmLevenberg::solve (lambda from setUserLambdaInit)
+  double lambda = -1.0, ni = 2.0; int nBad = 0;
+  bool ok = true;
+  for (int it = 0; it < prm.iterations && ok; it++) {
+    double currentChi; st = errors(&currentChi); if (st) return st;
+    const double iniChi = currentChi;
+    hipLaunchKernelGGL(pg_linearize_kernel, dim3((unsigned)(((long long)E * 14 + kPgThreads - 1) / kPgThreads)), dim3(kPgThreads), 0, sm, A);
+    hipLaunchKernelGGL(pg_diag_kernel, dim3(nu), dim3(64), 0, sm, A);
+    if (it == 0) { lambda = prm.lambda_init > 0 ? prm.lambda_init : 1e-5; ni = 2.0; nBad = 0; }   // computeLambdaInit with a user lambda
+    double rho = 0.0; int q = 0;
+    do {
+      LLD_HIP_TRY(hipMemcpyAsync(dVbk, A.V, (size_t)N * 64, hipMemcpyDeviceToDevice, sm));          // push
+      hipLaunchKernelGGL(pg_pcg_init_kernel, dim3(1), dim3(1024), 0, sm, A, lambda, prm.pcg_rel_tol);
+      for (int k = 0; k < pcg_limit;) {
+        for (int c = 0; c < 16 && k < pcg_limit; c++, k++) {
+          hipLaunchKernelGGL(pg_matvec_kernel, dim3((nu * 8 + kPgThreads - 1) / kPgThreads), dim3(kPgThreads), 0, sm, A, lambda);
+          hipLaunchKernelGGL(pg_pcg_update_kernel, dim3(1), dim3(1024), 0, sm, A, pcg_limit);
+        }
+        st = read_sc(); if (st) return st;
+        if (hsc[3] != 0.0) break;
+      }
+      st = read_sc(); if (st) return st;
+      const bool ok2 = hsc[4] != 0.0;
+      out->pcg_iterations += (int)hsc[2];
+      hipLaunchKernelGGL(pg_update_kernel, dim3(1), dim3(1024), 0, sm, A, lambda);
+      double tempChi; st = errors(&tempChi); if (st) return st;                                      // also brings sc[6] = scale
+      double scale = hsc[6];
+      if (!ok2) tempChi = 1.7976931348623157e308;
+      rho = (currentChi - tempChi);
+      scale += 1e-3;
+      rho /= scale;
+      if (rho > 0 && std::isfinite(tempChi)) {
+        double alpha = 1. - std::pow((2 * rho - 1), 3);
+        alpha = std::min(alpha, 2. / 3.);
+        lambda *= std::max(1. / 3., alpha);
+        ni = 2; currentChi = tempChi;                                                                // discardTop
+      } else {
+        lambda *= ni; ni *= 2;
+        LLD_HIP_TRY(hipMemcpyAsync(A.V, dVbk, (size_t)N * 64, hipMemcpyDeviceToDevice, sm));        // pop
+      }
+      q++; out->lm_trials++;
+    } while (rho < 0 && q < prm.max_trials);
+    out->chi2 = currentChi;
+    out->lm_iterations++;
+    if (q == prm.max_trials || rho == 0) ok = false;
+    else {
+      if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;
+      if (nBad >= 3) ok = false;
+    }
+  }
+  LLD_HIP_TRY(hipMemcpyAsync(out->sim3, A.V, (size_t)N * 64, hipMemcpyDeviceToHost, sm));
+  LLD_HIP_TRY(hipStreamSynchronize(sm));
+  return LLD_OK;
+}

@@ -6,6 +6,7 @@
 // lane then evaluates its edges against them.  Dense 7x7 LDL^T on one lane; LM rules as in lld_pose.hip.
 #include "lld_common.h"
 #include "lld_device_math.h"
+#include "lld_sim3_math.h"
 
 namespace {
 
@@ -13,91 +14,6 @@ using namespace lld;
 
 constexpr int kSimThreads = 256;
 constexpr int kSimWaves = kSimThreads / 64;
-
-struct Sim3 { Quat r; Vec3 t; double s; };
-
-__device__ __forceinline__ Mat3 skew3(const Vec3& v) {
-  Mat3 r;
-  r.m[0][0] = 0; r.m[0][1] = -v.z; r.m[0][2] = v.y;
-  r.m[1][0] = v.z; r.m[1][1] = 0; r.m[1][2] = -v.x;
-  r.m[2][0] = -v.y; r.m[2][1] = v.x; r.m[2][2] = 0;
-  return r;
-}
-__device__ __forceinline__ Mat3 mat_mat(const Mat3& a, const Mat3& b) {
-  Mat3 r;
-#pragma unroll
-  for (int i = 0; i < 3; i++)
-#pragma unroll
-    for (int j = 0; j < 3; j++) r.m[i][j] = a.m[i][0] * b.m[0][j] + a.m[i][1] * b.m[1][j] + a.m[i][2] * b.m[2][j];
-  return r;
-}
-
-// Sim3(const Vector7d& update)  (types/sim3.h:64-131): update = (omega, upsilon, sigma)
-__device__ Sim3 sim3_exp(const double* u) {
-  const Vec3 omega = vec3(u[0], u[1], u[2]), upsilon = vec3(u[3], u[4], u[5]);
-  const double sigma = u[6];
-  const double theta = sqrt(dot(omega, omega));
-  const Mat3 Omega = skew3(omega);
-  const double s = exp(sigma);
-  const Mat3 Omega2 = mat_mat(Omega, Omega);
-  Mat3 R;
-  const double eps = 0.00001;
-  double A, B, C;
-  const bool small = theta < eps;
-  if (small) {
-#pragma unroll
-    for (int i = 0; i < 3; i++)
-#pragma unroll
-      for (int j = 0; j < 3; j++) R.m[i][j] = ((i == j ? 1.0 : 0.0) + Omega.m[i][j]) + Omega2.m[i][j];
-  } else {
-    const double a = sin(theta) / theta, b = (1 - cos(theta)) / (theta * theta);
-#pragma unroll
-    for (int i = 0; i < 3; i++)
-#pragma unroll
-      for (int j = 0; j < 3; j++) R.m[i][j] = ((i == j ? 1.0 : 0.0) + a * Omega.m[i][j]) + b * Omega2.m[i][j];
-  }
-  if (fabs(sigma) < eps) {
-    C = 1;
-    if (small) { A = 1. / 2.; B = 1. / 6.; }
-    else {
-      const double theta2 = theta * theta;
-      A = (1 - cos(theta)) / (theta2);
-      B = (theta - sin(theta)) / (theta2 * theta);
-    }
-  } else {
-    C = (s - 1) / sigma;
-    if (small) {
-      const double sigma2 = sigma * sigma;
-      A = ((sigma - 1) * s + 1) / sigma2;
-      B = ((0.5 * sigma2 - sigma + 1) * s) / (sigma2 * sigma);
-    } else {
-      const double a = s * sin(theta), b = s * cos(theta);
-      const double theta2 = theta * theta, sigma2 = sigma * sigma;
-      const double c = theta2 + sigma2;
-      A = (a * sigma + (1 - b) * theta) / (theta * c);
-      B = (C - ((b - 1) * sigma + a * theta) / (c)) * 1. / (theta2);
-    }
-  }
-  Sim3 r; r.r = quat_from_rotation(R); r.s = s;
-  Mat3 W;
-#pragma unroll
-  for (int i = 0; i < 3; i++)
-#pragma unroll
-    for (int j = 0; j < 3; j++) W.m[i][j] = (A * Omega.m[i][j] + B * Omega2.m[i][j]) + C * (i == j ? 1.0 : 0.0);
-  r.t = mat_mul(W, upsilon);
-  return r;
-}
-__device__ __forceinline__ Vec3 sim3_map(const Sim3& S, const Vec3& x) { return S.s * quat_rotate(S.r, x) + S.t; }       // s*(r*xyz) + t
-__device__ __forceinline__ Sim3 sim3_mul(const Sim3& a, const Sim3& b) {
-  Sim3 r; r.r = quat_mul(a.r, b.r); r.t = a.s * quat_rotate(a.r, b.t) + a.t; r.s = a.s * b.s; return r;
-}
-__device__ __forceinline__ Sim3 sim3_inverse(const Sim3& a) {
-  Quat c; c.x = -a.r.x; c.y = -a.r.y; c.z = -a.r.z; c.w = a.r.w;
-  Sim3 r; r.r = c; r.t = quat_rotate(c, (-1. / a.s) * a.t); r.s = 1. / a.s;
-  return r;
-}
-__device__ __forceinline__ void sim3_store(const Sim3& S, double* d) { d[0] = S.r.x; d[1] = S.r.y; d[2] = S.r.z; d[3] = S.r.w; d[4] = S.t.x; d[5] = S.t.y; d[6] = S.t.z; d[7] = S.s; }
-__device__ __forceinline__ Sim3 sim3_load(const double* d) { Sim3 S; S.r.x = d[0]; S.r.y = d[1]; S.r.z = d[2]; S.r.w = d[3]; S.t = vec3(d[4], d[5], d[6]); S.s = d[7]; return S; }
 
 struct SimProblemDev {
   double f1[2], pp1[2], f2[2], pp2[2];

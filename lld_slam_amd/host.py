@@ -209,6 +209,40 @@ def sim3_call(lib: abi.Lib, ctx, pairs: list, params: abi.Sim3Params) -> list:
                        list(r.lm_iterations), list(r.lm_trials), float(r.chi2)) for r, d, p in zip(res, drops, pairs)]
 
 
+@dataclass
+class EssentialGraph:
+    """The pose graph of Optimizer::OptimizeEssentialGraph: Sim3 vertices (Siw as x, y, z, w, tx, ty, tz, s), EdgeSim3 list."""
+    sim3: np.ndarray             # [n,8]
+    fixed: np.ndarray            # [n] uint8
+    edge_i: np.ndarray           # [e] int32
+    edge_j: np.ndarray
+    edge_sji: np.ndarray         # [e,8]
+    meta: dict = field(default_factory=dict)
+
+
+@dataclass
+class EssentialGraphOutput:
+    sim3: np.ndarray
+    chi2: float
+    lm_iterations: int
+    lm_trials: int
+    pcg_iterations: int
+
+
+def essential_graph_call(lib: abi.Lib, ctx, g: EssentialGraph, bFixScale=True, **kw) -> EssentialGraphOutput:
+    keep = [np.ascontiguousarray(g.sim3, np.float64).reshape(-1, 8), np.ascontiguousarray(g.fixed, np.uint8), np.ascontiguousarray(g.edge_i, np.int32),
+            np.ascontiguousarray(g.edge_j, np.int32), np.ascontiguousarray(g.edge_sji, np.float64).reshape(-1, 8)]
+    G = abi.PoseGraph(); G.n_vertices = keep[0].shape[0]; G.n_edges = keep[2].shape[0]
+    G.sim3 = keep[0].ctypes.data_as(abi.c_double_p); G.fixed = keep[1].ctypes.data_as(abi.c_uint8_p)
+    G.edge_i = keep[2].ctypes.data_as(abi.c_int32_p); G.edge_j = keep[3].ctypes.data_as(abi.c_int32_p); G.edge_sji = keep[4].ctypes.data_as(abi.c_double_p)
+    P = abi.PoseGraphParams(); lib.fn("pose_graph_params_default")(C.byref(P)); P.fix_scale = 1 if bFixScale else 0
+    for k, v in kw.items(): setattr(P, k, v)
+    o = np.zeros_like(keep[0]); R = abi.PoseGraphResult(); R.sim3 = o.ctypes.data_as(abi.c_double_p)
+    fn = lib.fn("optimize_essential_graph"); fn.argtypes = [C.c_void_p, C.POINTER(abi.PoseGraph), C.POINTER(abi.PoseGraphParams), C.POINTER(abi.PoseGraphResult)]; fn.restype = C.c_int
+    check(fn(ctx, C.byref(G), C.byref(P), C.byref(R)), "optimize_essential_graph")
+    return EssentialGraphOutput(o, float(R.chi2), int(R.lm_iterations), int(R.lm_trials), int(R.pcg_iterations))
+
+
 def pose_params(lib: abi.Lib, gamma=0.5, **kw) -> PoseParams:
     p = PoseParams()
     lib.fn("pose_params_default")(C.byref(p))
@@ -443,6 +477,10 @@ class Optimizer:
         keyframe but mnId==0 free), ONE optimize(nIterations), no outlier handling, identity line information."""
         return ba_call(self.lib, self.ctx.handle, window,
                        ba_params(self.lib, 1.0, protocol=1, its_round1=nIterations, robust_points=1 if bRobust else 0, **params), pbStopFlag)
+
+    def OptimizeEssentialGraph(self, graph, bFixScale: bool = True, **params):
+        """Optimizer::OptimizeEssentialGraph (src/Optimizer.cc:1391-1654), the optimisation proper: 15 LM iterations on the Sim3 pose graph."""
+        return essential_graph_call(self.lib, self.ctx.handle, graph, bFixScale, **params)
 
     def OptimizeSim3(self, pair, th2: float = 10.0, bFixScale: bool = True, **params):
         """Optimizer::OptimizeSim3 (src/Optimizer.cc:1656-1851); a list of pairs goes through one launch (one workgroup per candidate)."""

@@ -281,6 +281,51 @@ def make_sim3_pair(pair_id=0, n=300, outlier_frac=0.15, scale=1.0, noise=1.0, ca
                     inv_sigma2_1=inv_s2[octv], inv_sigma2_2=inv_s2[octv], meta=dict(R12=R12, t12=t12, s12=s12, bad=bad))
 
 
+def make_essential_graph(graph_id=0, n_kf=120, drift=(0.002, 0.03), covis=3, n_corrected=6):
+    """A loop for Optimizer::OptimizeEssentialGraph: keyframes on a closed path, odometry that drifts (rotation / translation noise
+    per step), so the last keyframes do not meet the first ones.  Vertices = the drifted Siw, except the last `n_corrected`
+    keyframes, which carry their loop-corrected Sim3 (CorrectedSim3); edges: spanning tree (i -> i-1), covisibility (i -> i-2 ..
+    i-covis) - both measured on the NON-corrected poses - and the loop edge last -> first measured on the corrected ones; keyframe
+    0 (the loop keyframe) is fixed.  Returns EssentialGraph with meta = ground-truth poses."""
+    from scipy.spatial.transform import Rotation
+    from .host import EssentialGraph
+    rng = np.random.default_rng(0xE5500000 + graph_id)
+    ang = np.linspace(0, 2 * np.pi, n_kf, endpoint=False)
+    Rw = [Rotation.from_euler("y", -a).as_matrix() for a in ang]                  # camera-to-world rotation: heading along the circle
+    tw = np.stack([40 * np.cos(ang), 0.3 * np.sin(3 * ang), 40 * np.sin(ang)], 1)
+    Tgt = [np.block([[Rw[k].T, (-Rw[k].T @ tw[k])[:, None]], [np.zeros((1, 3)), np.ones((1, 1))]]) for k in range(n_kf)]   # Tiw
+    # drifted odometry: T_k = (noisy relative) * T_{k-1}
+    Td = [Tgt[0]]
+    for k in range(1, n_kf):
+        rel = Tgt[k] @ np.linalg.inv(Tgt[k - 1])
+        N = np.eye(4); N[:3, :3] = _rodrigues(rng.normal(0, drift[0], 3)); N[:3, 3] = rng.normal(0, drift[1], 3)
+        Td.append(N @ rel @ Td[k - 1])
+    def to_sim3(T, s=1.0):
+        q = Rotation.from_matrix(T[:3, :3]).as_quat()
+        return np.concatenate([q, T[:3, 3], [s]])
+    def mat(S): M = np.eye(4); M[:3, :3] = S[7] * Rotation.from_quat(S[:4]).as_matrix(); M[:3, 3] = S[4:7]; return M
+    def from_mat(M):
+        s = np.cbrt(np.linalg.det(M[:3, :3])); return np.concatenate([Rotation.from_matrix(M[:3, :3] / s).as_quat(), M[:3, 3], [s]])
+    non_corr = np.stack([to_sim3(T) for T in Td])
+    verts = non_corr.copy()
+    # loop correction of the tail: the corrected pose of the last keyframe is its ground truth (what ComputeSim3 found), the
+    # keyframes before it get the same correction transform (CorrectLoop propagates g2oCorrectedSiw = Sic * Scw)
+    corr = mat(to_sim3(Tgt[-1])) @ np.linalg.inv(mat(non_corr[-1]))              # Scw_corrected * Swc_old ... applied on the world side
+    for k in range(n_kf - n_corrected, n_kf):
+        verts[k] = from_mat(mat(non_corr[k]) @ np.linalg.inv(mat(non_corr[-1])) @ mat(to_sim3(Tgt[-1])))
+    ei, ej, meas = [], [], []
+    def add(i, j, Si, Sj):                                                        # Sji = Sjw * Swi
+        ei.append(i); ej.append(j); meas.append(from_mat(mat(Sj) @ np.linalg.inv(mat(Si))))
+    add(n_kf - 1, 0, verts[n_kf - 1], verts[0])                                   # loop edge, corrected poses (LoopConnections)
+    for i in range(1, n_kf):
+        add(i, i - 1, non_corr[i], non_corr[i - 1])                               # spanning tree
+        for d in range(2, covis + 1):
+            if i - d >= 0: add(i, i - d, non_corr[i], non_corr[i - d])            # covisibility >= 100
+    fixed = np.zeros(n_kf, np.uint8); fixed[0] = 1
+    return EssentialGraph(sim3=verts, fixed=fixed, edge_i=np.array(ei, np.int32), edge_j=np.array(ej, np.int32), edge_sji=np.stack(meas),
+                          meta=dict(gt=np.stack([to_sim3(T) for T in Tgt]), drifted=non_corr))
+
+
 def make_pose_frame(frame_id=0, n_points=1000, n_lines=200, outlier_frac=0.10, mono_frac=0.0, mono_line_frac=0.0,
                     cam=KITTI_CAM, seed=None) -> PoseFrame:
     rng = np.random.default_rng(SEED_PO + frame_id if seed is None else seed)

@@ -1001,3 +1001,161 @@ extern "C" int lldo_optimize_sim3(void* /*ctx*/, const lld_sim3_problem* in, con
   out->n_inliers = nIn;
   return LLD_OK;
 }
+
+// ================================================================== Optimizer::OptimizeEssentialGraph (src/Optimizer.cc:1391-1654)
+// EdgeSim3 (types_seven_dof_expmap.h:99-127): error = log(C * v1 * v2^-1), numeric Jacobians for both vertices, identity information;
+// Sim3::log (sim3.h:137-212) incl. the 3x3 partial-pivoting LU of W.lu().solve(t); dense LDL^T of the 7N x 7N system.
+namespace {
+
+V3 solve3_lu(const M3& Win, const V3& rhs) {          // Eigen::PartialPivLU<Matrix3d>::solve
+  double A[3][4];
+  for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) A[i][j] = Win.m[i][j]; A[i][3] = at(rhs, i); }
+  for (int k = 0; k < 3; k++) {
+    int piv = k; double best = std::fabs(A[k][k]);
+    for (int i = k + 1; i < 3; i++) if (std::fabs(A[i][k]) > best) { best = std::fabs(A[i][k]); piv = i; }
+    if (piv != k) for (int j = 0; j < 4; j++) std::swap(A[k][j], A[piv][j]);
+    for (int i = k + 1; i < 3; i++) { const double f = A[i][k] / A[k][k]; for (int j = k; j < 4; j++) A[i][j] -= f * A[k][j]; }
+  }
+  double x[3];
+  for (int i = 2; i >= 0; i--) { double s0 = A[i][3]; for (int j = i + 1; j < 3; j++) s0 -= A[i][j] * x[j]; x[i] = s0 / A[i][i]; }
+  return V3{x[0], x[1], x[2]};
+}
+
+void sim3_log(const Sim3T& S, double* res) {
+  const double sigma = std::log(S.s);
+  const M3 R = quat_to_R(S.r);
+  const double d = 0.5 * (R.m[0][0] + R.m[1][1] + R.m[2][2] - 1);
+  const V3 dR{R.m[2][1] - R.m[1][2], R.m[0][2] - R.m[2][0], R.m[1][0] - R.m[0][1]};
+  const double eps = 0.00001;
+  V3 omega; double A, B, C;
+  if (std::fabs(sigma) < eps) {
+    C = 1;
+    if (d > 1 - eps) { omega = scale(dR, 0.5); A = 1. / 2.; B = 1. / 6.; }
+    else {
+      const double theta = std::acos(d), theta2 = theta * theta;
+      omega = scale(dR, theta / (2 * std::sqrt(1 - d * d)));
+      A = (1 - std::cos(theta)) / (theta2);
+      B = (theta - std::sin(theta)) / (theta2 * theta);
+    }
+  } else {
+    C = (S.s - 1) / sigma;
+    if (d > 1 - eps) {
+      const double sigma2 = sigma * sigma;
+      omega = scale(dR, 0.5);
+      A = ((sigma - 1) * S.s + 1) / (sigma2);
+      B = ((0.5 * sigma2 - sigma + 1) * S.s) / (sigma2 * sigma);
+    } else {
+      const double theta = std::acos(d);
+      omega = scale(dR, theta / (2 * std::sqrt(1 - d * d)));
+      const double theta2 = theta * theta;
+      const double a = S.s * std::sin(theta), b = S.s * std::cos(theta);
+      const double c = theta2 + sigma * sigma;
+      A = (a * sigma + (1 - b) * theta) / (theta * c);
+      B = (C - ((b - 1) * sigma + a * theta) / (c)) * 1. / (theta2);
+    }
+  }
+  const M3 Omega = skew(omega), OO = m3_mul(Omega, Omega), I = m3_identity();
+  M3 W;
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) W.m[i][j] = (A * Omega.m[i][j] + B * OO.m[i][j]) + C * I.m[i][j];
+  const V3 upsilon = solve3_lu(W, S.t);
+  res[0] = omega.x; res[1] = omega.y; res[2] = omega.z; res[3] = upsilon.x; res[4] = upsilon.y; res[5] = upsilon.z; res[6] = sigma;
+}
+
+struct PoseGraphSystem {
+  bool fix_scale = true;
+  std::vector<Sim3T> V, bk;
+  std::vector<int> hidx;                                  // hessian index of a vertex, -1 = fixed
+  struct Edge { int i, j; Sim3T C; double err[7]; };
+  std::vector<Edge> E;
+  int nu = 0;                                             // unknown vertices
+  std::vector<double> H, b, x, diagBackup;
+  bool terminate() { return false; }
+  size_t numUnknownVertices() { return (size_t)nu; }
+  bool buildStructure() { return true; }
+  void edge_error(const Sim3T& v1, const Sim3T& v2, const Sim3T& C, double* err) const { sim3_log(sim3_mul(sim3_mul(C, v1), sim3_inverse(v2)), err); }
+  void computeActiveErrors() { for (auto& e : E) edge_error(V[e.i], V[e.j], e.C, e.err); }
+  double activeRobustChi2() { double chi = 0; for (auto& e : E) { double c = 0; for (int k = 0; k < 7; k++) c += e.err[k] * e.err[k]; chi += c; } return chi; }
+  Sim3T oplus(const Sim3T& S, const double* upd) const { double u[7]; std::memcpy(u, upd, sizeof u); if (fix_scale) u[6] = 0; return sim3_mul(sim3_exp(u), S); }
+  void buildSystem() {
+    const int n = 7 * nu;
+    std::fill(H.begin(), H.end(), 0.0); std::fill(b.begin(), b.end(), 0.0);
+    const double delta = 1e-9, scalar = 1.0 / (2 * delta);
+    for (auto& e : E) {
+      double J[2][7][7];                                  // [vertex][error row][dof]
+      for (int v = 0; v < 2; v++) {
+        const int vid = v == 0 ? e.i : e.j;
+        if (hidx[vid] < 0) continue;
+        for (int d = 0; d < 7; d++) {
+          double add_v[7] = {0, 0, 0, 0, 0, 0, 0}, ep[7], em[7];
+          add_v[d] = delta; const Sim3T P = oplus(V[vid], add_v);
+          add_v[d] = -delta; const Sim3T M = oplus(V[vid], add_v);
+          if (v == 0) { edge_error(P, V[e.j], e.C, ep); edge_error(M, V[e.j], e.C, em); }
+          else { edge_error(V[e.i], P, e.C, ep); edge_error(V[e.i], M, e.C, em); }
+          for (int r = 0; r < 7; r++) J[v][r][d] = scalar * (ep[r] - em[r]);
+        }
+      }
+      // BaseBinaryEdge::constructQuadraticForm without a robust kernel, Omega = I (core/base_binary_edge.hpp:54-120)
+      for (int v = 0; v < 2; v++) {
+        const int hv = hidx[v == 0 ? e.i : e.j];
+        if (hv < 0) continue;
+        for (int r = 0; r < 7; r++) {
+          double acc = 0; for (int k = 0; k < 7; k++) acc += J[v][k][r] * e.err[k];
+          b[7 * hv + r] -= acc;
+          for (int c = 0; c < 7; c++) { double h = 0; for (int k = 0; k < 7; k++) h += J[v][k][r] * J[v][k][c]; H[(size_t)(7 * hv + r) * n + 7 * hv + c] += h; }
+        }
+      }
+      const int hi = hidx[e.i], hj = hidx[e.j];
+      if (hi >= 0 && hj >= 0)
+        for (int r = 0; r < 7; r++)
+          for (int c = 0; c < 7; c++) {
+            double h = 0; for (int k = 0; k < 7; k++) h += J[0][k][r] * J[1][k][c];
+            H[(size_t)(7 * hi + r) * n + 7 * hj + c] += h; H[(size_t)(7 * hj + c) * n + 7 * hi + r] += h;
+          }
+    }
+  }
+  double maxDiagonal() { double m = 0; const int n = 7 * nu; for (int j = 0; j < n; j++) m = std::max(std::fabs(H[(size_t)j * n + j]), m); return m; }
+  void push() { bk = V; } void pop() { V = bk; } void discardTop() {}
+  void setLambda(double l) { const int n = 7 * nu; for (int j = 0; j < n; j++) { diagBackup[j] = H[(size_t)j * n + j]; H[(size_t)j * n + j] += l; } }
+  void restoreDiagonal() { const int n = 7 * nu; for (int j = 0; j < n; j++) H[(size_t)j * n + j] = diagBackup[j]; }
+  bool solve() { std::vector<double> A(H); return ldlt_solve(A, 7 * nu, b.data(), x.data(), true); }
+  void update() { for (size_t v = 0; v < V.size(); v++) if (hidx[v] >= 0) { double* u = &x[7 * hidx[v]]; if (fix_scale) u[6] = 0; V[v] = oplus(V[v], u); } }
+  double computeScale(double lambda) { double sc = 0; for (int j = 0; j < 7 * nu; j++) sc += x[j] * (lambda * x[j] + b[j]); return sc; }
+};
+
+}  // namespace
+
+extern "C" void lldo_pose_graph_params_default(lld_pose_graph_params* p) {
+  p->iterations = 15; p->fix_scale = 1; p->lambda_init = 1e-16; p->max_trials = 10; p->pcg_max_iter = 0; p->pcg_rel_tol = 1e-12;
+}
+extern "C" void lldo_sim3_log(const double* qts8, double* u7) {
+  Sim3T s; s.r = Quat{qts8[0], qts8[1], qts8[2], qts8[3]}; s.t = V3{qts8[4], qts8[5], qts8[6]}; s.s = qts8[7];
+  sim3_log(s, u7);
+}
+extern "C" int lldo_optimize_essential_graph(void* /*ctx*/, const lld_pose_graph* g, const lld_pose_graph_params* prm_in, lld_pose_graph_result* out) {
+  lld_pose_graph_params prm; if (prm_in) prm = *prm_in; else lldo_pose_graph_params_default(&prm);
+  PoseGraphSystem Y; Y.fix_scale = prm.fix_scale != 0;
+  const int N = g->n_vertices;
+  Y.V.resize(N); Y.hidx.assign(N, -1);
+  for (int v = 0; v < N; v++) {
+    const double* s = g->sim3 + 8 * v;
+    Y.V[v].r = Quat{s[0], s[1], s[2], s[3]}; Y.V[v].t = V3{s[4], s[5], s[6]}; Y.V[v].s = s[7];
+    if (!(g->fixed && g->fixed[v])) Y.hidx[v] = Y.nu++;
+  }
+  for (int e = 0; e < g->n_edges; e++) {
+    PoseGraphSystem::Edge ed; ed.i = g->edge_i[e]; ed.j = g->edge_j[e];
+    const double* s = g->edge_sji + 8 * e;
+    ed.C.r = Quat{s[0], s[1], s[2], s[3]}; ed.C.t = V3{s[4], s[5], s[6]}; ed.C.s = s[7];
+    std::memset(ed.err, 0, sizeof ed.err);
+    Y.E.push_back(ed);
+  }
+  const size_t n = 7 * (size_t)Y.nu;
+  Y.H.assign(n * n, 0.0); Y.b.assign(n, 0.0); Y.x.assign(n, 0.0); Y.diagBackup.assign(n, 0.0);
+  LMData lm; lm.maxTrials = prm.max_trials; lm.userLambdaInit = prm.lambda_init;
+  if (!Y.E.empty()) lm_optimize(Y, lm, prm.iterations);
+  for (int v = 0; v < N; v++) {
+    double* s = out->sim3 + 8 * v;
+    s[0] = Y.V[v].r.x; s[1] = Y.V[v].r.y; s[2] = Y.V[v].r.z; s[3] = Y.V[v].r.w; s[4] = Y.V[v].t.x; s[5] = Y.V[v].t.y; s[6] = Y.V[v].t.z; s[7] = Y.V[v].s;
+  }
+  out->chi2 = lm.lastChi; out->lm_iterations = lm.iterations; out->lm_trials = lm.trials; out->pcg_iterations = 0; out->reserved = 0;
+  return LLD_OK;
+}

@@ -20,6 +20,7 @@ struct LMData {
   double ni = 2.;          // _ni
   int nBad = 0;            // _nBad
   double tau = 1e-5;       // _tau
+  double userLambdaInit = 0.;   // _userLambdaInit (setUserLambdaInit); > 0 replaces tau * max diagonal (levenberg.cpp:166-169)
   double goodUp = 2. / 3.; // _goodStepUpperScale
   double goodLo = 1. / 3.; // _goodStepLowerScale
   int maxTrials = 10;      // maxTrialsAfterFailure
@@ -52,7 +53,7 @@ static LMResult lm_solve(Sys& s, LMData& d, int iteration) {
   const double iniChi = currentChi;
   s.buildSystem();
   if (iteration == 0) {
-    d.lambda = d.tau * s.maxDiagonal();   // computeLambdaInit (levenberg.cpp:166-180)
+    d.lambda = d.userLambdaInit > 0 ? d.userLambdaInit : d.tau * s.maxDiagonal();   // computeLambdaInit (levenberg.cpp:166-180)
     d.ni = 2;
     d.nBad = 0;
   }

@@ -176,6 +176,18 @@ def optimize_sim3(pair, th2=10.0, bFixScale=True, **params):
     return outs if many else outs[0]
 
 
+def optimize_essential_graph(graph, bFixScale=True, **params):
+    return host.essential_graph_call(lib(), None, graph, bFixScale, **params)
+
+
+def sim3_log(qts8):
+    d = lib().dll
+    d.lldo_sim3_log.argtypes = [abi.c_double_p, abi.c_double_p]; d.lldo_sim3_log.restype = None
+    q = _d(qts8); o = np.zeros(7)
+    d.lldo_sim3_log(_dp(q), _dp(o))
+    return o
+
+
 def sim3_exp(u7):
     d = lib().dll
     d.lldo_sim3_exp.argtypes = [abi.c_double_p, abi.c_double_p]; d.lldo_sim3_exp.restype = None

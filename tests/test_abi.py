@@ -38,7 +38,8 @@ def test_struct_layouts_match_the_header(tmp_path):
              ("lld_frame_view", orb_search.FrameView), ("lld_map_points", orb_search.MapPoints), ("lld_frustum_result", orb_search.FrustumResult),
              ("lld_last_frame_points", orb_search.LastFramePoints), ("lld_keypoints", orb_search.Keypoints),
              ("lld_stereo_pyramids", orb_search.StereoPyramids), ("lld_stereo_result", orb_search.StereoResult),
-             ("lld_sim3_problem", abi.Sim3Problem), ("lld_sim3_params", abi.Sim3Params), ("lld_sim3_result", abi.Sim3Result)]
+             ("lld_sim3_problem", abi.Sim3Problem), ("lld_sim3_params", abi.Sim3Params), ("lld_sim3_result", abi.Sim3Result),
+             ("lld_pose_graph", abi.PoseGraph), ("lld_pose_graph_params", abi.PoseGraphParams), ("lld_pose_graph_result", abi.PoseGraphResult)]
     src = tmp_path / "sz.c"
     body = "".join(f'printf("%zu\\n", sizeof({n}));' for n, _ in names)
     # field offsets of the widest struct too: equal sizes alone would not catch two swapped members

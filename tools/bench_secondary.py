@@ -67,6 +67,13 @@ for _ in range(7):
     t = time.perf_counter(); opt.OptimizeSim3(sps); tb.append(time.perf_counter() - t)
 out["optimize_sim3_300"] = {"gpu_ms": 1e3 * float(np.median(ts)), "cpu_oracle_ms": 1e3 * float(np.median(tc)), "gpu_ms_16_candidates": 1e3 * float(np.median(tb)),
                             "equal": bool(np.array_equal(gs.dropped, os_.dropped) and gs.n_inliers == os_.n_inliers)}
+# ---- Optimizer::OptimizeEssentialGraph: 300 keyframes, ~890 Sim3 edges (the oracle solves the 2093^2 system densely)
+eg = synth.make_essential_graph(0, 300)
+opt.OptimizeEssentialGraph(eg)
+t = time.perf_counter(); ge = opt.OptimizeEssentialGraph(eg); dte = time.perf_counter() - t
+t = time.perf_counter(); oe = O.optimize_essential_graph(eg); dtce = time.perf_counter() - t
+out["essential_graph_300kf"] = {"gpu_ms": dte * 1e3, "cpu_oracle_ms_dense": dtce * 1e3, "edges": int(eg.edge_i.shape[0]), "lm_iterations": ge.lm_iterations,
+                                "pcg_iterations": ge.pcg_iterations, "chi2_rel": abs(ge.chi2 - oe.chi2) / max(oe.chi2, 1e-300)}
 # ---- ORB 2000 x 2000 Hamming best/second, batched in HBM
 B, nq, nt = 256, 2000, 2000
 dev = torch.device("cuda", 0)
