@@ -199,6 +199,7 @@ static int ba_batch_create_impl(lld_ctx* ctx, int n_windows, const lld_ba_window
     W.th_ln_mono = thMono * P.gamma; W.th_ln_stereo = thStereo * P.gamma;            // LineOptimizer.cc:33-35
     W.protocol = P.protocol; W.robust_pts = P.protocol == 1 ? (P.robust_points != 0) : 1;
     if (P.protocol == 1) { W.its[1] = 0; W.th_ln_mono = W.th_ln_stereo = thStereo / 2.0; }   // double thHuberLines = thHuber3D/2.0  (Optimizer.cc:358)
+    if (n_windows == 1) lap("tasks built");
     cam_qt0.insert(cam_qt0.end(), w.cam_qt, w.cam_qt + 7 * (size_t)w.n_cams);
     if (w.n_points) pt0.insert(pt0.end(), w.pt_xyz, w.pt_xyz + 3 * (size_t)w.n_points);
     if (w.n_lines) { ln_x0.insert(ln_x0.end(), w.line_x0, w.line_x0 + 3 * (size_t)w.n_lines); ln_dir.insert(ln_dir.end(), w.line_dir, w.line_dir + 3 * (size_t)w.n_lines); }
@@ -226,6 +227,7 @@ static int ba_batch_create_impl(lld_ctx* ctx, int n_windows, const lld_ba_window
         }
       }
     }
+    if (n_windows == 1) lap("edges flattened");
     // ---- Schur work items: sort the landmarks by their set of free cameras, cut the runs into chunks, one item per
     //      (chunk, slot pair).  Structure only: outlier levels are handled through zeroed Hpl blocks at run time.
     W.lo_off = (int)NLO; W.n_lo = w.n_ln_obs;
@@ -300,6 +302,7 @@ static int ba_batch_create_impl(lld_ctx* ctx, int n_windows, const lld_ba_window
         i0 = i1;
       }
     }
+    if (n_windows == 1) lap("chunks built");
     W.n_items = (int)B->h_chunks.size() - W.item_off;
     W.blk_csr_off = (int)blk_start.size(); W.cam_csr_off = (int)cam_start.size();
     for (auto& l : blk_lists) { blk_start.push_back((int)blk_src.size()); blk_src.insert(blk_src.end(), l.begin(), l.end()); }
@@ -328,7 +331,7 @@ static int ba_batch_create_impl(lld_ctx* ctx, int n_windows, const lld_ba_window
   B->acc_copies = kAccCopies;
   while (B->acc_copies > 1 && ((size_t)B->max_free * 27 * B->acc_copies + 8 + (size_t)B->max_cams * 7) * sizeof(double) > 150 * 1024) B->acc_copies >>= 1;
   if (((size_t)B->max_free * 27 * B->acc_copies + 8 + (size_t)B->max_cams * 7) * sizeof(double) > 158 * 1024) { delete B; return LLD_ERR_UNSUPPORTED; }
-  for (int wi = 0; wi < n_windows; wi++) B->h_wins[wi].acc_copies = B->acc_copies;
+  for (int wi = 0; wi < n_windows; wi++) { B->h_wins[wi].acc_copies = B->acc_copies; B->h_wins[wi].win_index = wi; }
   B->max_blk = max_blk;
   // fixed-stride result records (what an RCCL gather of the batch moves)
   for (int wi = 0; wi < n_windows; wi++) B->h_wins[wi].rec_off = (long long)(B->rec_stride * (size_t)wi);

@@ -75,7 +75,7 @@ struct BAWin {                 // immutable per-window header
   int its[2];                  // LM iterations per round
   int max_trials, ln_filter;
   int protocol, robust_pts, acc_copies;   // acc_copies: LDS copies of the per-camera accumulators in the linearise kernels (4, 2 or 1)
-  int pad_w;    // lld_ba_params::protocol / robust_points (1 = global BA: one round, no classification)
+  int win_index;               // index of the window in its batch (slot of the multi-workgroup PCG scalars)    // lld_ba_params::protocol / robust_points (1 = global BA: one round, no classification)
   double th_mono, th_stereo;   // Huber deltas of point edges  ((double)(float)sqrt(5.991 / 7.815))
   double th_ln_mono, th_ln_stereo;   // Huber deltas of line edges (x gamma)
   long long rec_off;           // result record (bytes)
@@ -1317,7 +1317,7 @@ __global__ __launch_bounds__(kPcgThreads) void ba_pcgm_init_kernel(BAArrays A, c
   __shared__ double scratch[32];
   const BAWin W = wins[blockIdx.x];
   const BAState& S = st[blockIdx.x];
-  double* sc = A.pcg_sc + 8 * (size_t)blockIdx.x;
+  double* sc = A.pcg_sc + 8 * (size_t)W.win_index;
   if (S.phase != PH_RUN) { if (threadIdx.x == 0) sc[3] = 1.0; return; }
   const int nf = W.n_free, n = 6 * nf, tid = threadIdx.x;
   const double* Sg = A.S + W.S_off;
@@ -1357,9 +1357,9 @@ __global__ __launch_bounds__(kPcgThreads) void ba_pcgm_init_kernel(BAArrays A, c
 
 // grid (ceil(n_max / 4), nW), block 256: one wavefront per row of S
 __global__ __launch_bounds__(256) void ba_pcgm_matvec_kernel(BAArrays A, const BAWin* __restrict__ wins) {
-  const double* sc = A.pcg_sc + 8 * (size_t)blockIdx.y;
-  if (sc[3] != 0.0) return;
   const BAWin W = wins[blockIdx.y];
+  const double* sc = A.pcg_sc + 8 * (size_t)W.win_index;
+  if (sc[3] != 0.0) return;
   const int n = 6 * W.n_free, lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= n) return;
@@ -1373,9 +1373,9 @@ __global__ __launch_bounds__(256) void ba_pcgm_matvec_kernel(BAArrays A, const B
 
 __global__ __launch_bounds__(kPcgThreads) void ba_pcgm_update_kernel(BAArrays A, const BAWin* __restrict__ wins, int max_iter_param) {
   __shared__ double scratch[32];
-  double* sc = A.pcg_sc + 8 * (size_t)blockIdx.x;
-  if (sc[3] != 0.0) return;
   const BAWin W = wins[blockIdx.x];
+  double* sc = A.pcg_sc + 8 * (size_t)W.win_index;
+  if (sc[3] != 0.0) return;
   const int nf = W.n_free, n = 6 * nf, tid = threadIdx.x;
   const double* Mi = A.pcg_mi + (size_t)W.hpp_off * 36;
   double* x = A.xp + W.x_off;
@@ -1414,7 +1414,7 @@ __global__ __launch_bounds__(kPcgThreads) void ba_pcgm_final_kernel(BAArrays A, 
   const BAWin W = wins[blockIdx.x];
   BAState& S = st[blockIdx.x];
   if (S.phase != PH_RUN) return;
-  const double* sc = A.pcg_sc + 8 * (size_t)blockIdx.x;
+  const double* sc = A.pcg_sc + 8 * (size_t)W.win_index;
   const int tid = threadIdx.x, nf = W.n_free, n = 6 * nf;
   const double lambda = S.lambda;
   const double* x = A.xp + W.x_off;

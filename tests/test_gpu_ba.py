@@ -228,6 +228,15 @@ def test_map_sized_window_uses_the_multi_workgroup_pcg(gpu_ctx, oracle):
         Optimizer(gpu_ctx).GlobalBundleAdjustment(synth.make_lba_small(48, n_free=591, n_fixed=1, n_points=2500, n_lines=0))
 
 
+def test_batch_of_eight_mid_size_windows_runs_the_pcg_in_two_groups(gpu_ctx, oracle):
+    """8 windows of 55..62 free cameras: two stream groups, each driving its own multi-workgroup PCG (separate scalar slots)."""
+    ws = [synth.make_lba_small(60 + i, n_free=55 + i, n_fixed=2, n_points=600, n_lines=60) for i in range(8)]
+    with BABatch(gpu_ctx, ws) as b:
+        b.solve()
+        for i, w in enumerate(ws):
+            check_ba(b.download(i), oracle.local_ba(w), w)
+
+
 def test_large_window_limits(gpu_ctx, oracle):
     """Windows of 130 / 171 free cameras, local protocol, all three reduced solvers where they apply."""
     w = synth.make_lba_small(45, n_free=130, n_fixed=2, n_points=2500, n_lines=200)
