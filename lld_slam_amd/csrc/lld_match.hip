@@ -494,7 +494,7 @@ static int line_match_core(lld_ctx* ctx, const lld_line_stereo_params* geom, con
   if (dim > 128) return LLD_ERR_UNSUPPORTED;
   if (nq == 0) return LLD_OK;
   if (nt == 0) { for (int i = 0; i < nq; i++) { matches[i] = -1; if (match_dist) match_dist[i] = 1.7976931348623157e308; } return LLD_OK; }
-  if ((size_t)nt * 8 + (size_t)dim * 4 > 60 * 1024) return LLD_ERR_UNSUPPORTED;          // one row of distances lives in LDS
+  if ((size_t)nt * 8 + (size_t)dim * 4 > 150 * 1024) return LLD_ERR_UNSUPPORTED;         // one row of distances lives in LDS (nt <= ~19 000)
   LLD_HIP_TRY(hipSetDevice(ctx->device));
   const size_t pairs = (size_t)nq * nt;
   auto pad = [](size_t b) { return (b + 255) & ~size_t(255); };
@@ -535,6 +535,11 @@ static int line_match_core(lld_ctx* ctx, const lld_line_stereo_params* geom, con
   double* dmat = reinterpret_cast<double*>(d_dev + s_mat);
   LineCand* dc = reinterpret_cast<LineCand*>(d_dev + s_c);
   const size_t lds = (size_t)nt * 8 + (size_t)dim * 4 + 16;
+  if (lds > 48 * 1024) {
+    LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&line_candidates_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&line_candidates_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  }
+  if ((size_t)nt + 16 > 48 * 1024) LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&line_resolve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)nt + 16));
   if (geom)
     hipLaunchKernelGGL(line_candidates_kernel<true>, dim3(nq), dim3(64), lds, sm, P, reinterpret_cast<const float*>(d + o_ll), reinterpret_cast<const int*>(d + o_lo),
                        reinterpret_cast<const float*>(d + o_rl), reinterpret_cast<const int*>(d + o_ro), reinterpret_cast<const float*>(d + o_q),

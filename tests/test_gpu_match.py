@@ -122,6 +122,15 @@ def test_line_greedy_exhausted_candidate_lists_fall_back_to_the_row_scan(gpu_ctx
     assert (gm[10:30] >= 0).sum() >= 18
 
 
+def test_line_greedy_many_right_lines(gpu_ctx, oracle):
+    """9000 right lines: the row of distances (72 KB) needs more than the default dynamic LDS."""
+    q, t = synth.make_match_lbd(5, 40, 9000, 32, n_corr=30)
+    gm, gd = TwoFrameLineMatcher(gpu_ctx, 2.0).MatchLines(q, t, None)
+    om, od = oracle.line_match_greedy(q, t, None, 2.0)
+    np.testing.assert_array_equal(gm, om)
+    np.testing.assert_array_equal(gd[gm >= 0], od[om >= 0])
+
+
 def test_batched_hamming_device_entry_point(gpu_ctx, oracle):
     import torch
     B, nq, nt = 6, 333, 450
