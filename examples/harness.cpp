@@ -3,6 +3,8 @@
 // outputs back, so the tests can compare the C++ route with the golden vectors.
 //
 //   harness ba   <in> <out>     Optimizer::LocalBundleAdjustment
+//   harness gba  <in> <out>     Optimizer::GlobalBundleAdjustment (same file layout, header[7] = nIterations)
+//   harness sim3 <in> <out>     Optimizer::OptimizeSim3
 //   harness pose <in> <out>     Optimizer::PoseOptimization
 //   harness orb  <in> <out>     ORBmatcher::BestTwo (brute force)
 //
@@ -30,7 +32,7 @@ struct Writer {
   template <class T> void put(const std::vector<T>& v) { put(v.data(), v.size()); }
 };
 
-int run_ba(const char* in, const char* out) {
+int run_ba(const char* in, const char* out, bool global) {
   Reader r(in);
   int32_t h[8]; r.get(h, 8);                   // n_cams n_free n_points n_pt_obs n_lines n_ln_obs stop 0
   double camg[6]; r.get(camg, 6);              // fx fy cx cy bf gamma
@@ -45,7 +47,8 @@ int run_ba(const char* in, const char* out) {
   r.get(w.ln_obs_octave, 2 * (size_t)h[5]);
   lld_amd::Context ctx(0);
   bool stop = h[6] != 0;
-  const lld_amd::BAOutput o = lld_amd::Optimizer::LocalBundleAdjustment(ctx, w, &stop, camg[5]);
+  const lld_amd::BAOutput o = global ? lld_amd::Optimizer::GlobalBundleAdjustment(ctx, w, h[7], &stop, true)
+                                     : lld_amd::Optimizer::LocalBundleAdjustment(ctx, w, &stop, camg[5]);
   Writer wr(out);
   wr.put(o.cam_qt); wr.put(o.pt_xyz); wr.put(o.line_x0); wr.put(o.line_dir);
   wr.put(o.pt_obs_outlier); wr.put(o.ln_edge_outlier); wr.put(o.line_removed);
@@ -89,12 +92,36 @@ int run_orb(const char* in, const char* out) {
   return 0;
 }
 
+int run_sim3(const char* in, const char* out) {
+  Reader r(in);
+  int32_t h[2]; r.get(h, 2);                   // n, bFixScale
+  double k[17]; r.get(k, 17);                  // K1 (4), K2 (4), S12 q (4) t (3) s (1), th2
+  std::vector<double> p1c, p2c, obs1, obs2, s1, s2;
+  r.get(p1c, 3 * (size_t)h[0]); r.get(p2c, 3 * (size_t)h[0]); r.get(obs1, 2 * (size_t)h[0]); r.get(obs2, 2 * (size_t)h[0]); r.get(s1, h[0]); r.get(s2, h[0]);
+  lld_sim3_problem P{};
+  P.fx1 = k[0]; P.fy1 = k[1]; P.cx1 = k[2]; P.cy1 = k[3]; P.fx2 = k[4]; P.fy2 = k[5]; P.cx2 = k[6]; P.cy2 = k[7];
+  for (int i = 0; i < 4; i++) P.s12_q[i] = k[8 + i];
+  for (int i = 0; i < 3; i++) P.s12_t[i] = k[12 + i];
+  P.s12_s = k[15]; P.n = h[0];
+  P.p1c = p1c.data(); P.p2c = p2c.data(); P.obs1 = obs1.data(); P.obs2 = obs2.data(); P.inv_sigma2_1 = s1.data(); P.inv_sigma2_2 = s2.data();
+  lld_amd::Context ctx(0);
+  std::vector<uint8_t> dropped;
+  const int32_t nIn = lld_amd::Optimizer::OptimizeSim3(ctx, P, dropped, (float)k[16], h[1] != 0);
+  Writer wr(out);
+  const double S[8] = {P.s12_q[0], P.s12_q[1], P.s12_q[2], P.s12_q[3], P.s12_t[0], P.s12_t[1], P.s12_t[2], P.s12_s};
+  wr.put(S, 8); wr.put(&nIn, 1); wr.put(dropped);
+  std::printf("sim3: %d inliers of %d\n", nIn, h[0]);
+  return 0;
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
-  if (argc != 4) { std::fprintf(stderr, "usage: harness ba|pose|orb <in> <out>\n"); return 2; }
+  if (argc != 4) { std::fprintf(stderr, "usage: harness ba|gba|pose|orb|sim3 <in> <out>\n"); return 2; }
   try {
-    if (!std::strcmp(argv[1], "ba")) return run_ba(argv[2], argv[3]);
+    if (!std::strcmp(argv[1], "ba")) return run_ba(argv[2], argv[3], false);
+    if (!std::strcmp(argv[1], "gba")) return run_ba(argv[2], argv[3], true);
+    if (!std::strcmp(argv[1], "sim3")) return run_sim3(argv[2], argv[3]);
     if (!std::strcmp(argv[1], "pose")) return run_pose(argv[2], argv[3]);
     if (!std::strcmp(argv[1], "orb")) return run_orb(argv[2], argv[3]);
     std::fprintf(stderr, "unknown mode %s\n", argv[1]);

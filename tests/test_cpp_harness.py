@@ -31,11 +31,11 @@ def run(harness, mode, tmp_path):
     return subprocess.run([harness, mode, str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True, timeout=300)
 
 
-def write_ba(path, d, stop=0):
+def write_ba(path, d, stop=0, iterations=0):
     dims = (d["cam_qt"].shape[0], d["pt_xyz"].shape[0], d["pt_obs_cam"].shape[0], d["line_x0"].shape[0], d["ln_obs_cam"].shape[0])
     with open(path, "wb") as f:
-        np.array([dims[0], int(d["n_free_cams"]), dims[1], dims[2], dims[3], dims[4], stop, 0], np.int32).tofile(f)
-        np.concatenate([d["cam"], [float(d["gamma"])]]).astype(np.float64).tofile(f)
+        np.array([dims[0], int(d["n_free_cams"]), dims[1], dims[2], dims[3], dims[4], stop, iterations], np.int32).tofile(f)
+        np.concatenate([d["cam"], [float(d["gamma"]) if "gamma" in d else 1.0]]).astype(np.float64).tofile(f)
         for k, t in BA_ARRAYS:
             np.ascontiguousarray(d[k], t).tofile(f)
     return dims
@@ -97,7 +97,7 @@ def test_harness_pose_golden(harness, tmp_path):
     n_pts, n_ln = d["pt_xw"].shape[0], d["ln_x0"].shape[0]
     with open(tmp_path / "in.bin", "wb") as f:
         np.array([n_pts, n_ln], np.int32).tofile(f)
-        np.concatenate([d["cam"], [float(d["gamma"])]]).astype(np.float64).tofile(f)
+        np.concatenate([d["cam"], [float(d["gamma"]) if "gamma" in d else 1.0]]).astype(np.float64).tofile(f)
         for k, t in POSE_ARRAYS:
             np.ascontiguousarray(d[k], t).tofile(f)
     r = run(harness, "pose", tmp_path)
@@ -123,3 +123,34 @@ def test_harness_orb_golden(harness, tmp_path):
     out = np.fromfile(tmp_path / "out.bin", np.int32).reshape(4, -1)
     for got, key in zip(out, ("best_idx", "best_dist", "second_idx", "second_dist")):
         assert np.array_equal(got, d[key]), key
+
+
+@pytest.mark.gpu
+def test_harness_global_ba_golden(harness, tmp_path):
+    d = np.load(os.path.join(GOLD, "gba_small.npz"))
+    dims = write_ba(tmp_path / "in.bin", d, iterations=int(d["iterations"]))
+    r = run(harness, "gba", tmp_path)
+    assert r.returncode == 0, r.stderr
+    o = read_ba(tmp_path / "out.bin", *dims)
+    rtol = 1e-5
+    assert abs(o["chi2"][1] - float(d["out_chi2_final"])) <= rtol * float(d["out_chi2_final"])
+    assert o["st"][1] == 0 and not o["pt_obs_outlier"].any() and not o["line_removed"].any()
+    assert np.max(np.abs(o["cam_qt"] - d["out_cam_qt"])) <= rtol * np.max(np.abs(d["out_cam_qt"]))
+
+
+@pytest.mark.gpu
+def test_harness_optimize_sim3(harness, tmp_path, oracle):
+    from lld_slam_amd import synth
+    p = synth.make_sim3_pair(30, 200)
+    with open(tmp_path / "in.bin", "wb") as f:
+        np.array([p.n, 1], np.int32).tofile(f)
+        np.concatenate([np.asarray(p.K1, np.float64), np.asarray(p.K2, np.float64), p.s12_q, p.s12_t, [p.s12_s], [10.0]]).astype(np.float64).tofile(f)
+        for a in (p.p1c, p.p2c, p.obs1, p.obs2, p.inv_sigma2_1, p.inv_sigma2_2):
+            np.ascontiguousarray(a, np.float64).tofile(f)
+    r = run(harness, "sim3", tmp_path)
+    assert r.returncode == 0, r.stderr
+    with open(tmp_path / "out.bin", "rb") as f:
+        S = np.fromfile(f, np.float64, 8); n_in = int(np.fromfile(f, np.int32, 1)[0]); dropped = np.fromfile(f, np.uint8, p.n)
+    o = oracle.optimize_sim3(p)
+    assert n_in == o.n_inliers and np.array_equal(dropped, o.dropped)
+    np.testing.assert_allclose(S[:4], o.s12_q, rtol=1e-5, atol=1e-7); np.testing.assert_allclose(S[4:7], o.s12_t, rtol=1e-5, atol=1e-6)
