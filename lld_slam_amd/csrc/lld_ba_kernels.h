@@ -1037,7 +1037,8 @@ __device__ __forceinline__ void schur_chunk_wave(const BAArrays& A, const BAWin&
     // HBM/L2 round trips (index -> data) of a sub-batch overlap the block products of the previous one instead of
     // stalling the single wavefront of the workgroup.
     Pose T;
-    if constexpr (D == 3) { if (stager) T = load_cam(A, cur, W.cam_off + A.sg_cams[C.cams_off + esl]); }
+    Mat3 Rt;                                                // rotation of the lane's camera: loop-invariant like T
+    if constexpr (D == 3) { if (stager) { T = load_cam(A, cur, W.cam_off + A.sg_cams[C.cams_off + esl]); Rt = quat_rotation(T.q); } }
     int g_n = 0, id_n = 0, g_nn = 0, id_nn = 0;
     double v_n[VN];
     double ws_n = 0.0; bool stereo_n = false, a_n = false; Vec3 X_n;
@@ -1073,7 +1074,7 @@ __device__ __forceinline__ void schur_chunk_wave(const BAArrays& A, const BAWin&
       if (stager && ej < nb) {
         if constexpr (D == 3) {
           // point edge: the Hpl block is a function of the linearisation-point pose, point and weight only
-          point_hpl(W.cam, T, X, stereo, ws, w);
+          point_hpl_closed(W.cam, T, Rt, X, stereo, ws, w);
         } else {
           // line observation: the summed 6x4 block was stored by the linearisation (24 doubles; fetched here, not a sub-batch
           // ahead: holding two of them would halve the occupancy)

@@ -240,16 +240,31 @@ LLD_HD void point_jac_point(const CamK& k, const Vec3& Xc, const Mat3& R, bool s
   }
 }
 
-// Hpl block of a point edge, W (6x3, row-major) = ws * Jc^T Jp, recomputed from the linearisation-point state instead of
-// being stored (BaseBinaryEdge::constructQuadraticForm's `_hessian`, core/base_binary_edge.hpp:84-105, transposed).
-LLD_HD void point_hpl(const CamK& k, const Pose& T, const Vec3& X, bool stereo, double ws, double* W) {
-  const Vec3 Xc = pose_map(T, X);
-  const Mat3 R = quat_rotation(T.q);
-  double Jp[9], Jc[18];
-  point_jac_point(k, Xc, R, stereo, Jp);
-  point_jac_pose(k, Xc, stereo, Jc);
-  for (int r = 0; r < 6; r++)
-    for (int a = 0; a < 3; a++) W[r * 3 + a] = ws * (Jc[r] * Jp[a] + Jc[6 + r] * Jp[3 + a] + Jc[12 + r] * Jp[6 + a]);
+// Hpl block of a point edge, W (6x3, row-major) = ws * Jc^T Jp, recomputed from the linearisation-point state instead of being stored
+// (BaseBinaryEdge::constructQuadraticForm's `_hessian`, core/base_binary_edge.hpp:84-105, transposed), in closed form:
+// with A = d(u, v, uR)/dXc (3x3, third row only for stereo) the two Jacobians are Jp = -A R and
+// Jc = [A [Xc]x | -A], hence W = ws Jc^T Jp = [ [Xc]x G ; G ] with G = ws (A^T A) R: one symmetric 3x3 (with a structural zero),
+// one 3x3 product and three cross products instead of two full Jacobians and a 6x3x3 contraction.  R = quat_rotation(T.q) is passed in because the callers keep it per lane.
+LLD_HD void point_hpl_closed(const CamK& k, const Pose& T, const Mat3& R, const Vec3& X, bool stereo, double ws, double* W) {
+  const Vec3 Xc = mat_mul(R, X) + T.t;
+  const double iz = 1.0 / Xc.z, iz2 = iz * iz;
+  const double a = k.fx * iz, b = k.fy * iz;
+  const double c0 = -k.fx * Xc.x * iz2, c1 = -k.fy * Xc.y * iz2, c2 = c0 + k.bf * iz2;
+  // ws * A^T A
+  const double m00 = ws * (stereo ? 2.0 * a * a : a * a);
+  const double m02 = ws * (stereo ? a * (c0 + c2) : a * c0);
+  const double m11 = ws * (b * b), m12 = ws * (b * c1);
+  const double m22 = ws * (stereo ? c0 * c0 + c1 * c1 + c2 * c2 : c0 * c0 + c1 * c1);
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    const double g0 = m00 * R.m[0][j] + m02 * R.m[2][j];
+    const double g1 = m11 * R.m[1][j] + m12 * R.m[2][j];
+    const double g2 = m02 * R.m[0][j] + m12 * R.m[1][j] + m22 * R.m[2][j];
+    W[0 * 3 + j] = Xc.y * g2 - Xc.z * g1;               // Xc x g
+    W[1 * 3 + j] = Xc.z * g0 - Xc.x * g2;
+    W[2 * 3 + j] = Xc.x * g1 - Xc.y * g0;
+    W[3 * 3 + j] = g0; W[4 * 3 + j] = g1; W[5 * 3 + j] = g2;
+  }
 }
 
 // ---------------------------------------------------------------- line edges
