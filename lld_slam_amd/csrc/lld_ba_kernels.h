@@ -390,6 +390,66 @@ __device__ __forceinline__ void point_edge_hpp(const PtEdgeLin& L, double* ac) {
   }
 }
 
+// Everything one active point edge adds to the normal equations, in closed form (same algebra as point_hpl_closed): with
+// A = d(u,v,uR)/dXc, M = ws A^T A, g = A^T (ws r), P = [Xc]x M:
+//   Hll = R^T M R, b_l = R^T g;  Hpp = [[ Xc x P_i (rows) , P ], [ . , M ]], b_p = [ Xc x g ; g ]
+// instead of forming Jp (3x3) and Jc (3x6) and contracting them.  hb: 6 upper of Hll + b_l; hp: 21 upper of Hpp + b_p (row-major
+// packed like point_edge_hpp).  Returns chi2 of the edge; ws and rho0 through the references.
+__device__ __forceinline__ double point_edge_blocks_closed(const BAWin& W, const Pose& T, const Vec3& X, const PtObs& ob, uint8_t fl, double& ws_out,
+                                                           double& rho0_out, double* hb, double* hp) {
+  const CamK& k = W.cam;
+  const Vec3 Xc = pose_map(T, X);
+  const bool stereo = !(ob.ur < 0);
+  double r[3];
+  point_residual(k, Xc, ob.u, ob.v, ob.ur, stereo, true, r);
+  const double c2e = chi2_of(r, stereo ? 3 : 2, ob.s);
+  double w = 1.0, rho0 = c2e;
+  if (fl & EF_ROBUST) rho0 = huber(c2e, stereo ? W.th_stereo : W.th_mono, &w);
+  const double ws = w * ob.s;
+  ws_out = ws; rho0_out = rho0;
+  const Mat3 R = quat_rotation(T.q);
+  const double iz = 1.0 / Xc.z, iz2 = iz * iz;
+  const double a = k.fx * iz, b = k.fy * iz;
+  const double c0 = -k.fx * Xc.x * iz2, c1 = -k.fy * Xc.y * iz2, c2 = c0 + k.bf * iz2;
+  const double m00 = ws * (stereo ? 2.0 * a * a : a * a);
+  const double m02 = ws * (stereo ? a * (c0 + c2) : a * c0);
+  const double m11 = ws * (b * b), m12 = ws * (b * c1);
+  const double m22 = ws * (stereo ? c0 * c0 + c1 * c1 + c2 * c2 : c0 * c0 + c1 * c1);
+  const double wr0 = ws * r[0], wr1 = ws * r[1], wr2 = stereo ? ws * r[2] : 0.0;
+  const double g0 = a * (wr0 + wr2), g1 = b * wr1, g2 = c0 * wr0 + c1 * wr1 + c2 * wr2;
+  // landmark side
+  double G[3][3];
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    G[0][j] = m00 * R.m[0][j] + m02 * R.m[2][j];
+    G[1][j] = m11 * R.m[1][j] + m12 * R.m[2][j];
+    G[2][j] = m02 * R.m[0][j] + m12 * R.m[1][j] + m22 * R.m[2][j];
+  }
+  int kk = 0;
+#pragma unroll
+  for (int p = 0; p < 3; p++)
+#pragma unroll
+    for (int d = p; d < 3; d++) hb[kk++] = R.m[0][p] * G[0][d] + R.m[1][p] * G[1][d] + R.m[2][p] * G[2][d];
+#pragma unroll
+  for (int p = 0; p < 3; p++) hb[6 + p] = R.m[0][p] * g0 + R.m[1][p] * g1 + R.m[2][p] * g2;
+  // camera side: P = [Xc]x M (column j = Xc x M[:,j]); M is symmetric with m01 = 0
+  const double x = Xc.x, y = Xc.y, z = Xc.z;
+  const double P[3][3] = {{y * m02 - z * 0.0, y * m12 - z * m11, y * m22 - z * m12},
+                          {z * m00 - x * m02, z * 0.0 - x * m12, z * m02 - x * m22},
+                          {x * 0.0 - y * m00, x * m11 - y * 0.0, x * m12 - y * m02}};
+  // rotation-rotation block: row i = Xc x P[i,:]
+  const double Q[3][3] = {{y * P[0][2] - z * P[0][1], z * P[0][0] - x * P[0][2], x * P[0][1] - y * P[0][0]},
+                          {y * P[1][2] - z * P[1][1], z * P[1][0] - x * P[1][2], x * P[1][1] - y * P[1][0]},
+                          {y * P[2][2] - z * P[2][1], z * P[2][0] - x * P[2][2], x * P[2][1] - y * P[2][0]}};
+  // packed upper triangle, rows 0..5: (0,0..5) (1,1..5) (2,2..5) (3,3..5) (4,4..5) (5,5)
+  hp[0] = Q[0][0]; hp[1] = Q[0][1]; hp[2] = Q[0][2]; hp[3] = P[0][0]; hp[4] = P[0][1]; hp[5] = P[0][2];
+  hp[6] = Q[1][1]; hp[7] = Q[1][2]; hp[8] = P[1][0]; hp[9] = P[1][1]; hp[10] = P[1][2];
+  hp[11] = Q[2][2]; hp[12] = P[2][0]; hp[13] = P[2][1]; hp[14] = P[2][2];
+  hp[15] = m00; hp[16] = 0.0; hp[17] = m02; hp[18] = m11; hp[19] = m12; hp[20] = m22;
+  hp[21] = y * g2 - z * g1; hp[22] = z * g0 - x * g2; hp[23] = x * g1 - y * g0; hp[24] = g0; hp[25] = g1; hp[26] = g2;
+  return c2e;
+}
+
 // grid (nl_pt, nW), block 512 = 8 wavefronts, BAWin::rounds tasks per wavefront; dynamic LDS: kAccCopies*n_free_max*27 doubles + 8 scratch.
 __global__ __launch_bounds__(kLinThreads, 4) void ba_linearize_pt_kernel(BAArrays A, const BAWin* __restrict__ wins, BAState* __restrict__ st) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -435,12 +495,15 @@ __global__ __launch_bounds__(kLinThreads, 4) void ba_linearize_pt_kernel(BAArray
       for (int i = 0; i < 9; i++) hb[i] = 0.0;
       if (has && (fl & EF_LEVEL1)) A.pe_ws[e] = 0.0;
       if (lm_act && !(fl & EF_LEVEL1)) {
-        PtEdgeLin L;
-        A.pe_chi2[e] = point_edge_linearize_r(W, pose_load(cams + c * 7), X, ob, fl, L);
-        A.pe_ws[e] = L.ws;
-        chi += L.rho0;
-        point_edge_hll(L, hb);
-        if (c < W.n_free) point_edge_hpp(L, acc + c * 27);
+        double hp[27], ws_e, rho0_e;
+        A.pe_chi2[e] = point_edge_blocks_closed(W, pose_load(cams + c * 7), X, ob, fl, ws_e, rho0_e, hb, hp);
+        A.pe_ws[e] = ws_e;
+        chi += rho0_e;
+        if (c < W.n_free) {
+          double* ac = acc + c * 27;
+#pragma unroll
+          for (int i = 0; i < 27; i++) if (i != 16) atomicAdd(&ac[i], hp[i]);          // entry 16 is the structural zero of M
+        }
       }
       seg_sum<9>(hb, l, lane, T.ms);
       // landmark lane i collects the sum from the first edge lane of its landmark
