@@ -663,22 +663,20 @@ __global__ __launch_bounds__(kLmThreads) void ba_backsub_pt_kernel(BAArrays A, c
       double wtx[3] = {0, 0, 0};
       if (e_act && c < W.n_free) {
         // W_e^T x_c = ws * Jp^T (Jc x_c) with the Jacobians of the linearisation point
+        // closed form (see point_hpl_closed): Jc x = A (Xc x x_w - x_t), Jp^T u = -R^T A^T u
         const Pose Tc = pose_load(camA + c * 7);
         const Vec3 Xc = pose_map(Tc, X);
         const bool stereo = (fl & EF_STEREO) != 0;
-        double Jp[9], Jc[18];
-        point_jac_point(W.cam, Xc, quat_rotation(Tc.q), stereo, Jp);
-        point_jac_pose(W.cam, Xc, stereo, Jc);
-        double uu[3];
+        const Mat3 R = quat_rotation(Tc.q);
+        const double* xc = xps + c * 6;
+        const Vec3 v = cross(Xc, vec3(xc[0], xc[1], xc[2])) - vec3(xc[3], xc[4], xc[5]);
+        const double iz = 1.0 / Xc.z, iz2 = iz * iz;
+        const double a = W.cam.fx * iz, b = W.cam.fy * iz;
+        const double c0 = -W.cam.fx * Xc.x * iz2, c1 = -W.cam.fy * Xc.y * iz2, c2 = c0 + W.cam.bf * iz2;
+        const double u0 = ws * (a * v.x + c0 * v.z), u1 = ws * (b * v.y + c1 * v.z), u2 = stereo ? ws * (a * v.x + c2 * v.z) : 0.0;
+        const double h0 = a * (u0 + u2), h1 = b * u1, h2 = c0 * u0 + c1 * u1 + c2 * u2;
 #pragma unroll
-        for (int i = 0; i < 3; i++) {
-          double sacc = 0.0;
-#pragma unroll
-          for (int r = 0; r < 6; r++) sacc += Jc[i * 6 + r] * xps[c * 6 + r];
-          uu[i] = ws * sacc;
-        }
-#pragma unroll
-        for (int k = 0; k < 3; k++) wtx[k] = Jp[k] * uu[0] + Jp[3 + k] * uu[1] + Jp[6 + k] * uu[2];
+        for (int k = 0; k < 3; k++) wtx[k] = -(R.m[0][k] * h0 + R.m[1][k] * h1 + R.m[2][k] * h2);
       }
       seg_sum<3>(wtx, l, lane, T.ms);
       // landmark lane: back-substitution and oplus of its landmark (inactive / edge-less landmarks keep their state)
