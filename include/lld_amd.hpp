@@ -96,6 +96,17 @@ class Optimizer {
     pair.s12_s = r.s12_s;
     return r.n_inliers;
   }
+  // void static OptimizeEssentialGraph(Map*, KeyFrame* pLoopKF, KeyFrame* pCurKF, NonCorrectedSim3, CorrectedSim3, LoopConnections, bFixScale)
+  // `graph` is what the reference hands to g2o (src/Optimizer.cc:1413-1585: vertices vScw, fixed[pLoopKF] = 1, edges (nIDi, nIDj, Sji));
+  // returns CorrectedSiw per vertex (8 doubles each), from which the caller recovers the SE3 poses and corrects the MapPoints (:1593-1653)
+  static std::vector<double> OptimizeEssentialGraph(Context& ctx, const lld_pose_graph& graph, bool bFixScale) {
+    lld_pose_graph_params p; lld_pose_graph_params_default(&p); p.fix_scale = bFixScale ? 1 : 0;
+    std::vector<double> corrected(8 * (size_t)(graph.n_vertices > 0 ? graph.n_vertices : 1));
+    lld_pose_graph_result r{}; r.sim3 = corrected.data();
+    check(lld_optimize_essential_graph(ctx.get(), &graph, &p, &r), "lld_optimize_essential_graph");
+    corrected.resize(8 * (size_t)graph.n_vertices);
+    return corrected;
+  }
   static BAOutput Solve(Context& ctx, const BAWindow& win, const lld_ba_params& p, const bool* pbStopFlag = nullptr) {
     const lld_ba_window w = win.view();
     BAOutput o;
