@@ -1,9 +1,13 @@
 // lld_ba.hip — host side of the batched local bundle adjustment: HBM layout, upload, the super-step launch loop and
 // read-back.  Kernels live in lld_ba_kernels.h.  Stands in for Optimizer::LocalBundleAdjustment (src/Optimizer.cc:936-1388).
 #include <algorithm>
-#include <cmath>
-
+#include <atomic>
 #include <chrono>
+#include <cmath>
+#include <memory>
+#include <new>
+#include <thread>
+
 #include "lld_ba_kernels.h"
 
 using namespace lldba;
@@ -42,7 +46,8 @@ struct lld_ba_batch {
 
 namespace {
 
-int validate_window(const lld_ba_window& w) {
+// deep = false: the O(1) part only (counts and pointers), what the layout needs before the windows are walked
+int validate_window(const lld_ba_window& w, bool deep = true) {
   if (w.n_cams <= 0 || w.n_free_cams < 0 || w.n_free_cams > w.n_cams || w.n_points < 0 || w.n_lines < 0 || w.n_pt_obs < 0 || w.n_ln_obs < 0)
     return LLD_ERR_INVALID;
   if (!w.cam_qt) return LLD_ERR_INVALID;
@@ -51,6 +56,7 @@ int validate_window(const lld_ba_window& w) {
   if (w.n_pt_obs > 0 && (!w.pt_obs_cam || !w.pt_obs_uvr || !w.pt_obs_inv_sigma2)) return LLD_ERR_INVALID;
   if (w.n_lines > 0 && (!w.line_x0 || !w.line_dir || !w.ln_obs_start)) return LLD_ERR_INVALID;
   if (w.n_ln_obs > 0 && (!w.ln_obs_cam || !w.ln_obs_left || !w.ln_obs_right || !w.ln_obs_octave)) return LLD_ERR_INVALID;
+  if (!deep) return LLD_OK;
   if (w.n_points > 0) {
     if (w.pt_obs_start[0] != 0 || w.pt_obs_start[w.n_points] != w.n_pt_obs) return LLD_ERR_INVALID;
     for (int p = 0; p < w.n_points; p++) if (w.pt_obs_start[p + 1] < w.pt_obs_start[p]) return LLD_ERR_INVALID;
@@ -67,6 +73,216 @@ int validate_window(const lld_ba_window& w) {
 size_t record_bytes(const BAWin& W) {
   size_t b = sizeof(BARecordHeader) + sizeof(double) * (7 * (size_t)W.n_cams + 3 * (size_t)W.n_pt + 6 * (size_t)W.n_ln) + (size_t)W.n_pe + (size_t)W.n_le + (size_t)W.n_ln;
   return (b + 255) & ~size_t(255);
+}
+
+
+// ---- host staging (see ba_batch_create_impl) ------------------------------------------------------------------------------------
+// Uninitialised host array: the staging threads write every element, so neither a zero fill nor push_back bookkeeping.
+template <class T> struct HostBuf {
+  std::unique_ptr<T[]> p; size_t n = 0;
+  bool alloc(size_t count) { p.reset(new (std::nothrow) T[count ? count : 1]); n = count; return p != nullptr; }
+  const T* data() const { return p.get(); }
+  size_t size() const { return n; }
+  bool empty() const { return n == 0; }
+};
+
+struct HostArrays {      // the flattened inputs, batch-global indexing (BAArrays' input section)
+  HostBuf<double> cam_qt0, pt0, ln_x0, ln_dir, pe_u, pe_v, pe_ur, pe_s, le_xs, le_ys, le_xe, le_ye, le_s, le_bx;
+  HostBuf<int> pt_obs_start, ln_obs_start, pe_cam, pe_pt, le_cam, le_ln;
+  HostBuf<uint8_t> le_flags0;
+};
+
+struct WinBases { long long NC, NP, NL, NPE, NLO, NF; size_t S_total, x_total; };   // totals of the windows before this one
+
+// Schur chunks of one window and one landmark kind, offsets local to this stage
+struct ChunkStage {
+  std::vector<SChunk> chunks;
+  std::vector<int> sg_lm, sg_tab, sg_cams;
+  std::vector<int> blk_key, blk_val, cam_key, cam_val;     // (block | camera, partial index [*4 + mode]) in generation order
+  size_t n_part = 0, n_cpart = 0, lds_need = 0;
+};
+
+struct WinStage {
+  std::vector<PTask> ptasks, ltasks;
+  ChunkStage cs[2];                                        // points, lines
+  std::vector<int> blk_start, blk_src, cam_start, cam_src; // window-local CSRs over both kinds (stage_csr)
+};
+
+// wavefront tasks of the lane-per-edge kernels + everything in BAWin that follows from the window sizes
+void stage_tasks(const lld_ba_window& w, const lld_ba_params& P, const WinBases& b, int n_windows, BAWin& W, WinStage& S) {
+  std::memset(&W, 0, sizeof W);
+  W.cam = lld::make_camk(w.cam);
+  W.n_cams = w.n_cams; W.n_free = w.n_free_cams;
+  W.cam_off = (int)b.NC; W.pt_off = (int)b.NP; W.n_pt = w.n_points; W.ln_off = (int)b.NL; W.n_ln = w.n_lines;
+  W.pe_off = (int)b.NPE; W.n_pe = w.n_pt_obs; W.le_off = (int)(2 * b.NLO); W.n_le = 2 * w.n_ln_obs;
+  W.lo_off = (int)b.NLO; W.n_lo = w.n_ln_obs;
+  W.hpp_off = (int)b.NF; W.x_off = (int)b.x_total; W.S_off = (long long)b.S_total;
+  W.nb_pt = (w.n_points + kLmThreads - 1) / kLmThreads; W.nb_ln = (w.n_lines + kLmThreads - 1) / kLmThreads;
+  // a task = consecutive landmarks while their edges fit into one wavefront; a landmark with more than 64 edges is a task of its own
+  auto build = [](int n_lm, const int32_t* start, long long e_base, std::vector<PTask>& out) {
+    out.reserve((size_t)(start ? start[n_lm] : 0) / 48 + 8);
+    for (int l = 0; l < n_lm;) {
+      PTask T; std::memset(&T, 0, sizeof T); T.l0 = l; T.e0 = (int)e_base + start[l];
+      while (l < n_lm) {
+        const int ne = start[l + 1] - start[l];
+        if (T.nl > 0 && (T.ne + ne > 64 || T.nl >= 64)) break;
+        T.nl++; T.ne += ne; T.ms = std::max(T.ms, ne); l++;
+        if (T.ne > 64) break;
+      }
+      out.push_back(T);
+    }
+  };
+  build(w.n_points, w.pt_obs_start, b.NPE, S.ptasks);      // lane <-> point edge
+  build(w.n_lines, w.ln_obs_start, b.NLO, S.ltasks);       // lane <-> (line, KF) observation
+  W.n_ptasks = (int)S.ptasks.size(); W.n_ltasks = (int)S.ltasks.size();
+  const int* R = n_windows >= kRoundsThroughputMinWindows ? kRoundsThroughput : kRoundsLatency;
+  for (int i = 0; i < 4; i++) W.rounds[i] = R[i];
+  W.nt_pt = (W.n_ptasks + 4 * W.rounds[2] - 1) / (4 * W.rounds[2]); W.nl_pt = (W.n_ptasks + W.rounds[0] * kLinThreads / 64 - 1) / (W.rounds[0] * kLinThreads / 64);
+  W.nt_ln = (W.n_ltasks + 4 * W.rounds[3] - 1) / (4 * W.rounds[3]); W.nl_ln = (W.n_ltasks + W.rounds[1] * kLinThreads / 64 - 1) / (W.rounds[1] * kLinThreads / 64);
+  const double thMono = (double)(float)std::sqrt(5.991), thStereo = (double)(float)std::sqrt(7.815);   // Optimizer.cc:1088-1089
+  W.its[0] = P.its_round1; W.its[1] = P.its_round2; W.max_trials = P.max_trials; W.ln_filter = P.ln_filter;
+  W.th_mono = thMono; W.th_stereo = thStereo;
+  W.th_ln_mono = thMono * P.gamma; W.th_ln_stereo = thStereo * P.gamma;            // LineOptimizer.cc:33-35
+  W.protocol = P.protocol; W.robust_pts = P.protocol == 1 ? (P.robust_points != 0) : 1;
+  if (P.protocol == 1) { W.its[1] = 0; W.th_ln_mono = W.th_ln_stereo = thStereo / 2.0; }   // double thHuberLines = thHuber3D/2.0  (Optimizer.cc:358)
+}
+
+// the window's vertices and edges into their slots of the batch-global arrays
+void stage_edges(const lld_ba_window& w, const lld_ba_params& P, const WinBases& b, const BAWin& W, HostArrays& H) {
+  std::copy(w.cam_qt, w.cam_qt + 7 * (size_t)w.n_cams, H.cam_qt0.p.get() + 7 * (size_t)b.NC);
+  if (w.n_points) std::copy(w.pt_xyz, w.pt_xyz + 3 * (size_t)w.n_points, H.pt0.p.get() + 3 * (size_t)b.NP);
+  if (w.n_lines) {
+    std::copy(w.line_x0, w.line_x0 + 3 * (size_t)w.n_lines, H.ln_x0.p.get() + 3 * (size_t)b.NL);
+    std::copy(w.line_dir, w.line_dir + 3 * (size_t)w.n_lines, H.ln_dir.p.get() + 3 * (size_t)b.NL);
+  }
+  {
+    int* os = H.pt_obs_start.p.get() + b.NP; int* cam = H.pe_cam.p.get() + b.NPE; int* pt = H.pe_pt.p.get() + b.NPE;
+    double* u = H.pe_u.p.get() + b.NPE; double* v = H.pe_v.p.get() + b.NPE; double* ur = H.pe_ur.p.get() + b.NPE; double* s = H.pe_s.p.get() + b.NPE;
+    for (int p = 0; p < w.n_points; p++) {
+      os[p] = (int)b.NPE + w.pt_obs_start[p];
+      for (int o = w.pt_obs_start[p]; o < w.pt_obs_start[p + 1]; o++) {
+        cam[o] = w.pt_obs_cam[o]; pt[o] = p;
+        u[o] = w.pt_obs_uvr[3 * (size_t)o]; v[o] = w.pt_obs_uvr[3 * (size_t)o + 1]; ur[o] = w.pt_obs_uvr[3 * (size_t)o + 2];
+        s[o] = w.pt_obs_inv_sigma2[o];
+      }
+    }
+  }
+  {
+    const size_t e0 = 2 * (size_t)b.NLO;
+    int* os = H.ln_obs_start.p.get() + b.NL; int* cam = H.le_cam.p.get() + e0; int* ln = H.le_ln.p.get() + e0;
+    double* xs = H.le_xs.p.get() + e0; double* ys = H.le_ys.p.get() + e0; double* xe = H.le_xe.p.get() + e0; double* ye = H.le_ye.p.get() + e0;
+    double* s = H.le_s.p.get() + e0; double* bx = H.le_bx.p.get() + e0; uint8_t* fl = H.le_flags0.p.get() + e0;
+    for (int l = 0; l < w.n_lines; l++) {
+      os[l] = (int)b.NLO + w.ln_obs_start[l];
+      for (int o = w.ln_obs_start[l]; o < w.ln_obs_start[l + 1]; o++) {
+        const double* Lf = w.ln_obs_left + 4 * (size_t)o; const double* Rt = w.ln_obs_right + 4 * (size_t)o;
+        const bool has_right = !(Rt[0] < 0);                                          // startPointX >= 0 (LineOptimizer.cc:60)
+        for (int si = 0; si < 2; si++) {
+          const double* kl = si == 0 ? Lf : Rt;
+          const bool valid = si == 0 || has_right;
+          const size_t e = 2 * (size_t)o + si;
+          cam[e] = w.ln_obs_cam[o]; ln[e] = l;
+          xs[e] = kl[0]; ys[e] = kl[1]; xe[e] = kl[2]; ye[e] = kl[3];
+          s[e] = valid ? (P.protocol == 1 ? 1.0 : lld::line_info(P.gamma, w.ln_obs_octave[2 * (size_t)o + si])) : 0.0;   // AddLineMinimalGlobal: identity
+          bx[e] = si == 1 ? W.cam.bx_right : 0.0;
+          fl[e] = (uint8_t)((valid ? EF_VALID : 0) | (has_right ? EF_PAIRSTEREO : 0));
+        }
+      }
+    }
+  }
+}
+
+// Schur work items of one landmark kind: sort the landmarks by their set of free cameras, cut the runs into chunks, one item per
+// (chunk, slot pair).  Structure only: outlier levels are handled through zeroed Hpl blocks at run time.
+void stage_chunks(const lld_ba_window& w, int D, const WinBases& b, int chunk_landmarks, ChunkStage& out) {
+  const int n_lm = D == 3 ? w.n_points : w.n_lines;
+  if (n_lm == 0) return;
+  const int32_t* start = D == 3 ? w.pt_obs_start : w.ln_obs_start;
+  const int32_t* ocam = D == 3 ? w.pt_obs_cam : w.ln_obs_cam;
+  const long long id_base = D == 3 ? b.NPE : b.NLO, lm_base = D == 3 ? b.NP : b.NL;
+  // a landmark's signature = its free cameras in ascending order (ties keep the observation order) with the ids of the
+  // matching observations; flat arrays, no per-landmark allocation
+  std::vector<int> soff(1, 0), scam, sid, sigs;                    // sigs: landmarks that touch a free camera
+  soff.reserve(n_lm + 1); scam.reserve(start[n_lm] - start[0]); sid.reserve(start[n_lm] - start[0]); sigs.reserve(n_lm);
+  for (int l = 0; l < n_lm; l++) {
+    const int b0 = (int)scam.size();
+    for (int o = start[l]; o < start[l + 1]; o++) {
+      if (ocam[o] >= w.n_free_cams) continue;
+      int at = (int)scam.size();
+      scam.push_back(ocam[o]); sid.push_back((int)(id_base + o));
+      while (at > b0 && scam[at - 1] > scam[at]) { std::swap(scam[at - 1], scam[at]); std::swap(sid[at - 1], sid[at]); at--; }   // stable insertion
+    }
+    soff.push_back((int)scam.size());
+    if ((int)scam.size() > b0) sigs.push_back(l);
+  }
+  auto sig_k = [&](int l) { return soff[l + 1] - soff[l]; };
+  auto same_cams = [&](int a, int c) {
+    if (sig_k(a) != sig_k(c)) return false;
+    return std::equal(scam.begin() + soff[a], scam.begin() + soff[a + 1], scam.begin() + soff[c]);
+  };
+  std::stable_sort(sigs.begin(), sigs.end(), [&](int a, int c) {
+    const int ka = sig_k(a), kc = sig_k(c);
+    if (ka != kc) return ka < kc;
+    const int* pa = scam.data() + soff[a]; const int* pc = scam.data() + soff[c];
+    for (int i = 0; i < ka; i++) if (pa[i] != pc[i]) return pa[i] < pc[i];
+    return false;
+  });
+  out.sg_lm.reserve(sigs.size()); out.sg_tab.reserve(scam.size());
+  size_t i0 = 0;
+  while (i0 < sigs.size()) {
+    size_t i1 = i0 + 1;
+    while (i1 < sigs.size() && i1 - i0 < (size_t)chunk_landmarks && same_cams(sigs[i0], sigs[i1])) i1++;
+    SChunk C; std::memset(&C, 0, sizeof C);
+    const int* c0cams = scam.data() + soff[sigs[i0]];
+    C.k = sig_k(sigs[i0]); C.D = D; C.n_lm = (int)(i1 - i0);
+    C.lm_off = (int)out.sg_lm.size(); C.tab_off = (int)out.sg_tab.size(); C.cams_off = (int)out.sg_cams.size();
+    out.sg_cams.insert(out.sg_cams.end(), c0cams, c0cams + C.k);
+    for (size_t i = i0; i < i1; i++) { out.sg_lm.push_back((int)(lm_base + sigs[i])); out.sg_tab.insert(out.sg_tab.end(), sid.begin() + soff[sigs[i]], sid.begin() + soff[sigs[i] + 1]); }
+    C.part_off = (int)out.n_part; C.cpart_off = (int)out.n_cpart;
+    int pidx = 0;
+    for (int sa = 0; sa < C.k; sa++) {
+      const int ca = c0cams[sa];
+      out.cam_key.push_back(ca); out.cam_val.push_back((int)out.n_cpart + sa);
+      for (int sb = sa; sb < C.k; sb++, pidx++) {
+        const int cb = c0cams[sb];                               // cb >= ca (slots are sorted by camera)
+        const int mode = ca != cb ? 0 : (sa == sb ? 1 : 2);
+        out.blk_key.push_back(cb * (cb + 1) / 2 + ca); out.blk_val.push_back(((int)out.n_part + pidx) * 4 + mode);
+      }
+    }
+    out.n_part += (size_t)C.k * (C.k + 1) / 2; out.n_cpart += C.k;
+    {   // LDS the wavefront needs: staged sub-batch (W, Y, b_l) or the interleave reduction area, whichever is larger
+      const int WS = D == 3 ? 18 : 26, np = C.k * (C.k + 1) / 2, per_lm = 2 * C.k * WS + D;
+      int NBc = kSwLdsDoubles / per_lm; if (NBc > 64 / C.k) NBc = 64 / C.k; if (NBc < 1) NBc = 1;
+      const int units = std::min(np, 21) * 3, q = 64 / units;
+      const size_t need = std::max((size_t)NBc * per_lm, (size_t)(q - 1) * units * 14) * sizeof(double);
+      out.lds_need = std::max(out.lds_need, need);
+    }
+    out.chunks.push_back(C);
+    i0 = i1;
+  }
+}
+
+// Per reduced-system block / per camera: which partials to sum, in generation order (points before lines).  Counting sort of
+// the (key, value) pairs both kinds left; the line chunks' partials are numbered after the point chunks'.
+void stage_csr(int n_free, WinStage& S) {
+  const int nblk = n_free * (n_free + 1) / 2;
+  const size_t part3 = S.cs[0].n_part, cpart3 = S.cs[0].n_cpart;
+  for (SChunk& c : S.cs[1].chunks) { c.part_off += (int)part3; c.cpart_off += (int)cpart3; }
+  auto csr = [&](int n_keys, std::vector<int> ChunkStage::*key, std::vector<int> ChunkStage::*val, size_t off1, std::vector<int>& start, std::vector<int>& src) {
+    start.assign((size_t)n_keys, 0);
+    std::vector<int> fill((size_t)n_keys + 1, 0);
+    for (int d = 0; d < 2; d++) for (int k : S.cs[d].*key) fill[(size_t)k + 1]++;
+    for (int k = 0; k < n_keys; k++) { fill[k + 1] += fill[k]; start[k] = fill[k]; }
+    src.resize((size_t)fill[n_keys]);
+    for (int d = 0; d < 2; d++) {
+      const std::vector<int>& K = S.cs[d].*key; const std::vector<int>& V = S.cs[d].*val;
+      const int add = d == 0 ? 0 : (int)off1;
+      for (size_t i = 0; i < K.size(); i++) src[(size_t)fill[K[i]]++] = V[i] + add;
+    }
+    for (int d = 0; d < 2; d++) { std::vector<int>().swap(S.cs[d].*key); std::vector<int>().swap(S.cs[d].*val); }
+  };
+  csr(nblk, &ChunkStage::blk_key, &ChunkStage::blk_val, part3 * 4, S.blk_start, S.blk_src);
+  csr(n_free, &ChunkStage::cam_key, &ChunkStage::cam_val, cpart3, S.cam_start, S.cam_src);
 }
 
 }  // namespace
@@ -118,7 +334,7 @@ extern "C" {
 static int ba_batch_create_impl(lld_ctx* ctx, int n_windows, const lld_ba_window* wins, const lld_ba_params* params, lld_ba_batch** out, bool borrow) {
   if (!ctx || n_windows <= 0 || !wins || !out) return LLD_ERR_INVALID;
   *out = nullptr;
-  for (int w = 0; w < n_windows; w++) { int st = validate_window(wins[w]); if (st) return st; }
+  for (int w = 0; w < n_windows; w++) { int st = validate_window(wins[w], false); if (st) return st; }
   LLD_HIP_TRY(hipSetDevice(ctx->device));
   static const bool timing = std::getenv("LLD_BA_TIMING") != nullptr;
   const auto tc0 = std::chrono::steady_clock::now();
@@ -129,200 +345,152 @@ static int ba_batch_create_impl(lld_ctx* ctx, int n_windows, const lld_ba_window
   const lld_ba_params& P = B->params;
   if (P.its_round1 < 0 || P.its_round2 < 0 || P.max_trials <= 0 || !(P.pcg_rel_tol > 0) || P.reduced_solver < 0 || P.reduced_solver > 2 || P.protocol < 0 || P.protocol > 1) { delete B; return LLD_ERR_INVALID; }
 
-  // ---- layout + host staging
-  std::vector<double> cam_qt0, pt0, ln_x0, ln_dir, pe_u, pe_v, pe_ur, pe_s, le_xs, le_ys, le_xe, le_ye, le_s, le_bx;
-  std::vector<int> pt_obs_start, ln_obs_start, pe_cam, pe_pt, le_cam, le_ln, sg_lm, sg_tab, sg_cams, blk_start, blk_src, cam_start, cam_src;
-  size_t n_part = 0, n_cpart = 0, n_hpart = 0; int max_blk = 0;
-  std::vector<uint8_t> le_flags0;
+  // ---- layout + host staging: the windows are flattened by a few host threads straight into their final positions
+  //      (every offset that depends only on the window sizes is known up front), the variable-length Schur structures are
+  //      staged per window and placed by a second parallel pass once their sizes are known
   B->h_wins.resize(n_windows);
   // landmarks per Schur chunk: long chunks mean fewer atomics into S, short ones more lanes for small batches
   B->chunk_landmarks = n_windows >= 64 ? 128 : (n_windows >= 8 ? 64 : 32);
-  const double thMono = (double)(float)std::sqrt(5.991), thStereo = (double)(float)std::sqrt(7.815);   // Optimizer.cc:1088-1089
-  long long NC = 0, NP = 0, NL = 0, NPE = 0, NLO = 0, NF = 0, NPART = 0;
-  size_t S_total = 0, x_total = 0, rec_total = 0;
-  {   // exact sizes are known up front: no reallocation while the windows are flattened
-    size_t tc = 0, tp = 0, tl = 0, tpe = 0, tlo = 0;
-    for (int wi = 0; wi < n_windows; wi++) { tc += wins[wi].n_cams; tp += wins[wi].n_points; tl += wins[wi].n_lines; tpe += wins[wi].n_pt_obs; tlo += wins[wi].n_ln_obs; }
-    cam_qt0.reserve(7 * tc); pt0.reserve(3 * tp); ln_x0.reserve(3 * tl); ln_dir.reserve(3 * tl);
-    pt_obs_start.reserve(tp + 2); ln_obs_start.reserve(tl + 2);
-    for (auto* v : {&pe_u, &pe_v, &pe_ur, &pe_s}) v->reserve(tpe);
-    for (auto* v : {&pe_cam, &pe_pt}) v->reserve(tpe);
-    for (auto* v : {&le_xs, &le_ys, &le_xe, &le_ye, &le_s, &le_bx}) v->reserve(2 * tlo);
-    for (auto* v : {&le_cam, &le_ln}) v->reserve(2 * tlo);
-    le_flags0.reserve(2 * tlo);
-    sg_lm.reserve(tp + tl); sg_tab.reserve(tpe + tlo);
+  std::vector<WinBases> bases(n_windows + 1);
+  {
+    WinBases b{};
+    for (int wi = 0; wi < n_windows; wi++) {
+      bases[wi] = b;
+      const lld_ba_window& w = wins[wi];
+      b.NC += w.n_cams; b.NP += w.n_points; b.NL += w.n_lines; b.NPE += w.n_pt_obs; b.NLO += w.n_ln_obs; b.NF += w.n_free_cams;
+      const size_t n = 6 * (size_t)w.n_free_cams;
+      b.S_total += n * n; b.x_total += n;
+    }
+    bases[n_windows] = b;
   }
-  for (int wi = 0; wi < n_windows; wi++) {
-    const lld_ba_window& w = wins[wi];
+  const long long NC = bases[n_windows].NC, NP = bases[n_windows].NP, NL = bases[n_windows].NL, NPE = bases[n_windows].NPE, NLO = bases[n_windows].NLO, NF = bases[n_windows].NF;
+  if (NPE > 0x3fffffffll || NLO > 0x1fffffffll || NC * 7 > 0x7fffffffll) { delete B; return LLD_ERR_UNSUPPORTED; }   // 32-bit edge indices
+  const size_t S_total = bases[n_windows].S_total, x_total = bases[n_windows].x_total;
+  const size_t NLE = 2 * (size_t)NLO;
+  HostArrays H;
+  bool mem_ok = true;
+  mem_ok &= H.cam_qt0.alloc(7 * (size_t)NC); mem_ok &= H.pt0.alloc(3 * (size_t)NP); mem_ok &= H.ln_x0.alloc(3 * (size_t)NL); mem_ok &= H.ln_dir.alloc(3 * (size_t)NL);
+  mem_ok &= H.pt_obs_start.alloc((size_t)NP + 1); mem_ok &= H.ln_obs_start.alloc((size_t)NL + 1);
+  mem_ok &= H.pe_cam.alloc(NPE); mem_ok &= H.pe_pt.alloc(NPE); mem_ok &= H.pe_u.alloc(NPE); mem_ok &= H.pe_v.alloc(NPE); mem_ok &= H.pe_ur.alloc(NPE); mem_ok &= H.pe_s.alloc(NPE);
+  mem_ok &= H.le_cam.alloc(NLE); mem_ok &= H.le_ln.alloc(NLE); mem_ok &= H.le_xs.alloc(NLE); mem_ok &= H.le_ys.alloc(NLE); mem_ok &= H.le_xe.alloc(NLE); mem_ok &= H.le_ye.alloc(NLE); mem_ok &= H.le_s.alloc(NLE); mem_ok &= H.le_bx.alloc(NLE);
+  mem_ok &= H.le_flags0.alloc(NLE);
+  if (!mem_ok) { delete B; return LLD_ERR_ALLOC; }
+  H.pt_obs_start.p[NP] = (int)NPE; H.ln_obs_start.p[NL] = (int)NLO;
+  std::vector<WinStage> stages(n_windows);
+  int n_threads = 1;
+  if (n_windows >= 4) {
+    n_threads = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
+    if (const char* e = std::getenv("LLD_HOST_THREADS")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) n_threads = v; }
+    n_threads = std::min(n_threads, n_windows);
+  }
+  std::atomic<int> first_error{LLD_OK};
+  // run body(wi) for every window on n_threads host threads (the calling thread is one of them)
+  auto for_windows = [&](auto&& body) {
+    std::atomic<int> next{0};
+    auto worker = [&]() {
+      for (;;) {
+        const int wi = next.fetch_add(1);
+        if (wi >= n_windows || first_error.load() != LLD_OK) break;
+        try { body(wi); } catch (...) { int ok = LLD_OK; first_error.compare_exchange_strong(ok, LLD_ERR_ALLOC); }
+      }
+    };
+    std::vector<std::thread> pool;
+    try { for (int t = 1; t < n_threads; t++) pool.emplace_back(worker); } catch (...) {}      // fewer threads is fine
+    worker();
+    for (auto& t : pool) t.join();
+  };
+  const auto lap1 = [&](const char* what) { if (n_windows == 1) lap(what); };
+  for_windows([&](int wi) {
+    const int st = validate_window(wins[wi]);
+    if (st) { int ok = LLD_OK; first_error.compare_exchange_strong(ok, st); return; }
     BAWin& W = B->h_wins[wi];
-    std::memset(&W, 0, sizeof W);
-    W.cam = lld::make_camk(w.cam);
-    W.n_cams = w.n_cams; W.n_free = w.n_free_cams;
-    W.cam_off = (int)NC; W.pt_off = (int)NP; W.n_pt = w.n_points; W.ln_off = (int)NL; W.n_ln = w.n_lines;
-    W.pe_off = (int)NPE; W.n_pe = w.n_pt_obs; W.le_off = (int)(2 * NLO); W.n_le = 2 * w.n_ln_obs;
-    W.hpp_off = (int)NF; W.x_off = (int)x_total; W.S_off = (long long)S_total;
-    W.nb_pt = (w.n_points + kLmThreads - 1) / kLmThreads; W.nb_ln = (w.n_lines + kLmThreads - 1) / kLmThreads;
-    // point tasks for the lane-per-edge kernels: consecutive landmarks while their edges fit into one wavefront
-    W.ptask_off = (int)B->h_ptasks.size();
-    for (int p = 0; p < w.n_points;) {
-      PTask T; std::memset(&T, 0, sizeof T); T.l0 = p; T.e0 = (int)NPE + w.pt_obs_start[p];
-      while (p < w.n_points) {
-        const int ne = w.pt_obs_start[p + 1] - w.pt_obs_start[p];
-        if (T.nl > 0 && (T.ne + ne > 64 || T.nl >= 64)) break;
-        T.nl++; T.ne += ne; T.ms = std::max(T.ms, ne); p++;
-        if (T.ne > 64) break;                      // a landmark with more than 64 edges is a task of its own
-      }
-      B->h_ptasks.push_back(T);
+    WinStage& S = stages[wi];
+    stage_tasks(wins[wi], P, bases[wi], n_windows, W, S);
+    lap1("tasks built");
+    if (n_windows == 1 && wins[wi].n_pt_obs + wins[wi].n_ln_obs > 20000) {
+      // a single large window: the point chunks on a helper thread, edges and line chunks here
+      std::thread helper;
+      bool helped = false;
+      try { helper = std::thread([&]() { try { stage_chunks(wins[wi], 3, bases[wi], B->chunk_landmarks, S.cs[0]); } catch (...) { int ok = LLD_OK; first_error.compare_exchange_strong(ok, LLD_ERR_ALLOC); } }); helped = true; } catch (...) {}
+      stage_edges(wins[wi], P, bases[wi], W, H);
+      lap1("edges flattened");
+      stage_chunks(wins[wi], 4, bases[wi], B->chunk_landmarks, S.cs[1]);
+      if (helped) helper.join(); else stage_chunks(wins[wi], 3, bases[wi], B->chunk_landmarks, S.cs[0]);
+    } else {
+      stage_edges(wins[wi], P, bases[wi], W, H);
+      lap1("edges flattened");
+      stage_chunks(wins[wi], 3, bases[wi], B->chunk_landmarks, S.cs[0]);
+      stage_chunks(wins[wi], 4, bases[wi], B->chunk_landmarks, S.cs[1]);
     }
-    W.n_ptasks = (int)B->h_ptasks.size() - W.ptask_off;
-    {
-      const int* R = n_windows >= kRoundsThroughputMinWindows ? kRoundsThroughput : kRoundsLatency;
-      for (int i = 0; i < 4; i++) W.rounds[i] = R[i];
+    stage_csr(wins[wi].n_free_cams, S);
+    lap1("chunks built");
+  });
+  if (first_error.load() != LLD_OK) { const int st = first_error.load(); delete B; return st; }
+  // ---- where each window's variable-length pieces go
+  struct Place { size_t ptask, ltask, chunk, lm, tab, cams, blk_start, blk_src, cam_start, cam_src, part, cpart; };
+  std::vector<Place> place(n_windows + 1);
+  size_t n_hpart = 0; long long NPART = 0; int max_blk = 0;
+  {
+    Place q{};
+    for (int wi = 0; wi < n_windows; wi++) {
+      place[wi] = q;
+      const WinStage& S = stages[wi];
+      BAWin& W = B->h_wins[wi];
+      W.ptask_off = (int)q.ptask; W.ltask_off = (int)q.ltask; W.item_off = (int)q.chunk;
+      W.n_items_pt = (int)S.cs[0].chunks.size(); W.n_items = W.n_items_pt + (int)S.cs[1].chunks.size();
+      W.blk_csr_off = (int)q.blk_start; W.cam_csr_off = (int)q.cam_start;
+      W.hpart_off = (long long)n_hpart; n_hpart += (size_t)(W.nl_pt + W.nl_ln) * W.n_free * 27;
+      W.part_off = (int)NPART; NPART += W.nt_pt + W.nt_ln;
+      q.ptask += S.ptasks.size(); q.ltask += S.ltasks.size(); q.chunk += (size_t)W.n_items;
+      q.lm += S.cs[0].sg_lm.size() + S.cs[1].sg_lm.size(); q.tab += S.cs[0].sg_tab.size() + S.cs[1].sg_tab.size(); q.cams += S.cs[0].sg_cams.size() + S.cs[1].sg_cams.size();
+      q.blk_start += S.blk_start.size(); q.blk_src += S.blk_src.size(); q.cam_start += S.cam_start.size(); q.cam_src += S.cam_src.size();
+      q.part += S.cs[0].n_part + S.cs[1].n_part; q.cpart += S.cs[0].n_cpart + S.cs[1].n_cpart;
+      if (q.part * 4 > 0x7fffffffull || q.tab > 0x7fffffffull) { delete B; return LLD_ERR_UNSUPPORTED; }
+      for (int d = 0; d < 2; d++) B->schur_lds[d] = std::max(B->schur_lds[d], S.cs[d].lds_need);
+      max_blk = std::max(max_blk, W.n_free * (W.n_free + 1) / 2);
+      B->max_items_pt = std::max(B->max_items_pt, W.n_items_pt); B->max_items_ln = std::max(B->max_items_ln, W.n_items - W.n_items_pt);
+      B->max_lblocks = std::max(B->max_lblocks, W.nb_pt + W.nb_ln);
+      B->max_free = std::max(B->max_free, W.n_free);
+      B->max_cams = std::max(B->max_cams, W.n_cams);
+      B->rec_stride = std::max(B->rec_stride, record_bytes(W));
     }
-    W.nt_pt = (W.n_ptasks + 4 * W.rounds[2] - 1) / (4 * W.rounds[2]); W.nl_pt = (W.n_ptasks + W.rounds[0] * kLinThreads / 64 - 1) / (W.rounds[0] * kLinThreads / 64);
-    W.ltask_off = (int)B->h_ltasks.size();
-    for (int l = 0; l < w.n_lines;) {                // line tasks: lane <-> (line, KF) observation
-      PTask T; std::memset(&T, 0, sizeof T); T.l0 = l; T.e0 = (int)NLO + w.ln_obs_start[l];
-      while (l < w.n_lines) {
-        const int no = w.ln_obs_start[l + 1] - w.ln_obs_start[l];
-        if (T.nl > 0 && (T.ne + no > 64 || T.nl >= 64)) break;
-        T.nl++; T.ne += no; T.ms = std::max(T.ms, no); l++;
-        if (T.ne > 64) break;
-      }
-      B->h_ltasks.push_back(T);
-    }
-    W.n_ltasks = (int)B->h_ltasks.size() - W.ltask_off; W.nt_ln = (W.n_ltasks + 4 * W.rounds[3] - 1) / (4 * W.rounds[3]); W.nl_ln = (W.n_ltasks + W.rounds[1] * kLinThreads / 64 - 1) / (W.rounds[1] * kLinThreads / 64);
-    W.hpart_off = (long long)n_hpart; n_hpart += (size_t)(W.nl_pt + W.nl_ln) * w.n_free_cams * 27;
-    W.part_off = (int)NPART;
-    W.its[0] = P.its_round1; W.its[1] = P.its_round2; W.max_trials = P.max_trials; W.ln_filter = P.ln_filter;
-    W.th_mono = thMono; W.th_stereo = thStereo;
-    W.th_ln_mono = thMono * P.gamma; W.th_ln_stereo = thStereo * P.gamma;            // LineOptimizer.cc:33-35
-    W.protocol = P.protocol; W.robust_pts = P.protocol == 1 ? (P.robust_points != 0) : 1;
-    if (P.protocol == 1) { W.its[1] = 0; W.th_ln_mono = W.th_ln_stereo = thStereo / 2.0; }   // double thHuberLines = thHuber3D/2.0  (Optimizer.cc:358)
-    if (n_windows == 1) lap("tasks built");
-    cam_qt0.insert(cam_qt0.end(), w.cam_qt, w.cam_qt + 7 * (size_t)w.n_cams);
-    if (w.n_points) pt0.insert(pt0.end(), w.pt_xyz, w.pt_xyz + 3 * (size_t)w.n_points);
-    if (w.n_lines) { ln_x0.insert(ln_x0.end(), w.line_x0, w.line_x0 + 3 * (size_t)w.n_lines); ln_dir.insert(ln_dir.end(), w.line_dir, w.line_dir + 3 * (size_t)w.n_lines); }
-    for (int p = 0; p < w.n_points; p++) {
-      pt_obs_start.push_back((int)NPE + w.pt_obs_start[p]);
-      for (int o = w.pt_obs_start[p]; o < w.pt_obs_start[p + 1]; o++) {
-        pe_cam.push_back(w.pt_obs_cam[o]); pe_pt.push_back(p);
-        pe_u.push_back(w.pt_obs_uvr[3 * o]); pe_v.push_back(w.pt_obs_uvr[3 * o + 1]); pe_ur.push_back(w.pt_obs_uvr[3 * o + 2]);
-        pe_s.push_back(w.pt_obs_inv_sigma2[o]);
-      }
-    }
-    for (int l = 0; l < w.n_lines; l++) {
-      ln_obs_start.push_back((int)NLO + w.ln_obs_start[l]);
-      for (int o = w.ln_obs_start[l]; o < w.ln_obs_start[l + 1]; o++) {
-        const double* Lf = w.ln_obs_left + 4 * (size_t)o; const double* Rt = w.ln_obs_right + 4 * (size_t)o;
-        const bool has_right = !(Rt[0] < 0);                                          // startPointX >= 0 (LineOptimizer.cc:60)
-        for (int si = 0; si < 2; si++) {
-          const double* kl = si == 0 ? Lf : Rt;
-          const bool valid = si == 0 || has_right;
-          le_cam.push_back(w.ln_obs_cam[o]); le_ln.push_back(l);
-          le_xs.push_back(kl[0]); le_ys.push_back(kl[1]); le_xe.push_back(kl[2]); le_ye.push_back(kl[3]);
-          le_s.push_back(valid ? (P.protocol == 1 ? 1.0 : lld::line_info(P.gamma, w.ln_obs_octave[2 * (size_t)o + si])) : 0.0);   // AddLineMinimalGlobal: identity
-          le_bx.push_back(si == 1 ? W.cam.bx_right : 0.0);
-          le_flags0.push_back((uint8_t)((valid ? EF_VALID : 0) | (has_right ? EF_PAIRSTEREO : 0)));
-        }
-      }
-    }
-    if (n_windows == 1) lap("edges flattened");
-    // ---- Schur work items: sort the landmarks by their set of free cameras, cut the runs into chunks, one item per
-    //      (chunk, slot pair).  Structure only: outlier levels are handled through zeroed Hpl blocks at run time.
-    W.lo_off = (int)NLO; W.n_lo = w.n_ln_obs;
-    W.item_off = (int)B->h_chunks.size();
-    const int nfw = w.n_free_cams, nblkw = nfw * (nfw + 1) / 2;
-    std::vector<std::vector<int>> blk_lists(nblkw), cam_lists(nfw);
-    for (int D = 3; D <= 4; D++) {
-      if (D == 4) W.n_items_pt = (int)B->h_chunks.size() - W.item_off;
-      const int n_lm = D == 3 ? w.n_points : w.n_lines;
-      const int32_t* start = D == 3 ? w.pt_obs_start : w.ln_obs_start;
-      const int32_t* ocam = D == 3 ? w.pt_obs_cam : w.ln_obs_cam;
-      const long long id_base = D == 3 ? NPE : NLO, lm_base = D == 3 ? NP : NL;
-      // a landmark's signature = its free cameras in ascending order (ties keep the observation order) with the ids of the
-      // matching observations; flat arrays, no per-landmark allocation
-      std::vector<int> soff(1, 0), scam, sid, sigs;                    // sigs: landmarks that touch a free camera
-      soff.reserve(n_lm + 1); scam.reserve(start[n_lm] - start[0]); sid.reserve(start[n_lm] - start[0]); sigs.reserve(n_lm);
-      for (int l = 0; l < n_lm; l++) {
-        const int b0 = (int)scam.size();
-        for (int o = start[l]; o < start[l + 1]; o++) {
-          if (ocam[o] >= w.n_free_cams) continue;
-          int at = (int)scam.size();
-          scam.push_back(ocam[o]); sid.push_back((int)(id_base + o));
-          while (at > b0 && scam[at - 1] > scam[at]) { std::swap(scam[at - 1], scam[at]); std::swap(sid[at - 1], sid[at]); at--; }   // stable insertion
-        }
-        soff.push_back((int)scam.size());
-        if ((int)scam.size() > b0) sigs.push_back(l);
-      }
-      auto sig_k = [&](int l) { return soff[l + 1] - soff[l]; };
-      auto same_cams = [&](int a, int b) {
-        if (sig_k(a) != sig_k(b)) return false;
-        return std::equal(scam.begin() + soff[a], scam.begin() + soff[a + 1], scam.begin() + soff[b]);
-      };
-      std::stable_sort(sigs.begin(), sigs.end(), [&](int a, int b) {
-        const int ka = sig_k(a), kb = sig_k(b);
-        if (ka != kb) return ka < kb;
-        const int* pa = scam.data() + soff[a]; const int* pb = scam.data() + soff[b];
-        for (int i = 0; i < ka; i++) if (pa[i] != pb[i]) return pa[i] < pb[i];
-        return false;
-      });
-      size_t i0 = 0;
-      while (i0 < sigs.size()) {
-        size_t i1 = i0 + 1;
-        while (i1 < sigs.size() && i1 - i0 < (size_t)B->chunk_landmarks && same_cams(sigs[i0], sigs[i1])) i1++;
-        SChunk C; std::memset(&C, 0, sizeof C);
-        const int* c0cams = scam.data() + soff[sigs[i0]];
-        C.k = sig_k(sigs[i0]); C.D = D; C.n_lm = (int)(i1 - i0);
-        C.lm_off = (int)sg_lm.size(); C.tab_off = (int)sg_tab.size(); C.cams_off = (int)sg_cams.size();
-        sg_cams.insert(sg_cams.end(), c0cams, c0cams + C.k);
-        for (size_t i = i0; i < i1; i++) { sg_lm.push_back((int)(lm_base + sigs[i])); sg_tab.insert(sg_tab.end(), sid.begin() + soff[sigs[i]], sid.begin() + soff[sigs[i] + 1]); }
-        C.part_off = (int)n_part; C.cpart_off = (int)n_cpart;
-        {
-          int pidx = 0;
-          for (int sa = 0; sa < C.k; sa++) {
-            const int ca = c0cams[sa];
-            cam_lists[ca].push_back((int)n_cpart + sa);
-            for (int sb = sa; sb < C.k; sb++, pidx++) {
-              const int cb = c0cams[sb];                               // cb >= ca (slots are sorted by camera)
-              const int mode = ca != cb ? 0 : (sa == sb ? 1 : 2);
-              blk_lists[cb * (cb + 1) / 2 + ca].push_back(((int)n_part + pidx) * 4 + mode);
-            }
-          }
-          n_part += (size_t)C.k * (C.k + 1) / 2; n_cpart += C.k;
-        }
-        {   // LDS the wavefront needs: staged sub-batch (W, Y, b_l) or the interleave reduction area, whichever is larger
-          const int WS = D == 3 ? 18 : 26, np = C.k * (C.k + 1) / 2, per_lm = 2 * C.k * WS + D;
-          int NBc = kSwLdsDoubles / per_lm; if (NBc > 64 / C.k) NBc = 64 / C.k; if (NBc < 1) NBc = 1;
-          const int units = std::min(np, 21) * 3, q = 64 / units;
-          const size_t need = std::max((size_t)NBc * per_lm, (size_t)(q - 1) * units * 14) * sizeof(double);
-          B->schur_lds[D - 3] = std::max(B->schur_lds[D - 3], need);
-        }
-        B->h_chunks.push_back(C);
-        i0 = i1;
-      }
-    }
-    if (n_windows == 1) lap("chunks built");
-    W.n_items = (int)B->h_chunks.size() - W.item_off;
-    W.blk_csr_off = (int)blk_start.size(); W.cam_csr_off = (int)cam_start.size();
-    for (auto& l : blk_lists) { blk_start.push_back((int)blk_src.size()); blk_src.insert(blk_src.end(), l.begin(), l.end()); }
-    blk_start.push_back((int)blk_src.size());
-    for (auto& l : cam_lists) { cam_start.push_back((int)cam_src.size()); cam_src.insert(cam_src.end(), l.begin(), l.end()); }
-    cam_start.push_back((int)cam_src.size());
-    max_blk = std::max(max_blk, nblkw);
-    if (n_part * 4 > 0x7fffffffull) { delete B; return LLD_ERR_UNSUPPORTED; }
-    B->max_items_pt = std::max(B->max_items_pt, W.n_items_pt); B->max_items_ln = std::max(B->max_items_ln, W.n_items - W.n_items_pt);
-    W.rec_off = (long long)rec_total;
-    NC += w.n_cams; NP += w.n_points; NL += w.n_lines; NPE += w.n_pt_obs; NLO += w.n_ln_obs; NF += w.n_free_cams;
-    NPART += W.nt_pt + W.nt_ln;
-    const size_t n = 6 * (size_t)w.n_free_cams;
-    S_total += n * n; x_total += n;
-    B->max_lblocks = std::max(B->max_lblocks, W.nb_pt + W.nb_ln);
-    B->max_free = std::max(B->max_free, w.n_free_cams);
-    B->max_cams = std::max(B->max_cams, w.n_cams);
-    B->rec_stride = std::max(B->rec_stride, record_bytes(W));
+    place[n_windows] = q;
   }
-  pt_obs_start.push_back((int)NPE); ln_obs_start.push_back((int)NLO);
+  const Place& tot = place[n_windows];
+  const size_t n_part = tot.part, n_cpart = tot.cpart;
+  size_t rec_total = 0;
+  B->h_ptasks.resize(tot.ptask); B->h_ltasks.resize(tot.ltask); B->h_chunks.resize(tot.chunk);
+  HostBuf<int> sg_lm, sg_tab, sg_cams, blk_start, blk_src, cam_start, cam_src;
+  mem_ok &= sg_lm.alloc(tot.lm); mem_ok &= sg_tab.alloc(tot.tab); mem_ok &= sg_cams.alloc(tot.cams);
+  mem_ok &= blk_start.alloc(tot.blk_start + 1); mem_ok &= blk_src.alloc(tot.blk_src); mem_ok &= cam_start.alloc(tot.cam_start + 1); mem_ok &= cam_src.alloc(tot.cam_src);
+  if (!mem_ok) { delete B; return LLD_ERR_ALLOC; }
+  blk_start.p[tot.blk_start] = (int)tot.blk_src; cam_start.p[tot.cam_start] = (int)tot.cam_src;
+  for_windows([&](int wi) {
+    const Place& q = place[wi];
+    WinStage& S = stages[wi];
+    std::copy(S.ptasks.begin(), S.ptasks.end(), B->h_ptasks.begin() + q.ptask);
+    std::copy(S.ltasks.begin(), S.ltasks.end(), B->h_ltasks.begin() + q.ltask);
+    size_t at_chunk = q.chunk, at_lm = q.lm, at_tab = q.tab, at_cams = q.cams;
+    for (int d = 0; d < 2; d++) {
+      const ChunkStage& C = S.cs[d];
+      for (SChunk c : C.chunks) {
+        c.lm_off += (int)at_lm; c.tab_off += (int)at_tab; c.cams_off += (int)at_cams; c.part_off += (int)q.part; c.cpart_off += (int)q.cpart;      // stage_csr numbered both kinds within the window
+        B->h_chunks[at_chunk++] = c;
+      }
+      std::copy(C.sg_lm.begin(), C.sg_lm.end(), sg_lm.p.get() + at_lm); at_lm += C.sg_lm.size();
+      std::copy(C.sg_tab.begin(), C.sg_tab.end(), sg_tab.p.get() + at_tab); at_tab += C.sg_tab.size();
+      std::copy(C.sg_cams.begin(), C.sg_cams.end(), sg_cams.p.get() + at_cams); at_cams += C.sg_cams.size();
+    }
+    // the window-local CSRs number their partials from the window's first one
+    const int part4 = (int)(q.part * 4), cpart0 = (int)q.cpart, bsrc0 = (int)q.blk_src, csrc0 = (int)q.cam_src;
+    for (size_t i = 0; i < S.blk_start.size(); i++) blk_start.p[q.blk_start + i] = S.blk_start[i] + bsrc0;
+    for (size_t i = 0; i < S.blk_src.size(); i++) blk_src.p[q.blk_src + i] = S.blk_src[i] + part4;
+    for (size_t i = 0; i < S.cam_start.size(); i++) cam_start.p[q.cam_start + i] = S.cam_start[i] + csrc0;
+    for (size_t i = 0; i < S.cam_src.size(); i++) cam_src.p[q.cam_src + i] = S.cam_src[i] + cpart0;
+    S = WinStage();
+  });
+  if (first_error.load() != LLD_OK) { const int st = first_error.load(); delete B; return st; }
+  stages.clear();
   if (B->max_cams > kPcgThreads) { delete B; return LLD_ERR_UNSUPPORTED; }
   // few windows whose reduced system is beyond the matrix-core Cholesky: the PCG runs across the whole GPU (see ba_pcgm_*)
   B->pcg_multi = n_windows <= 8 && B->max_free * 6 > kCholMN && P.reduced_solver != 2;
@@ -338,28 +506,27 @@ static int ba_batch_create_impl(lld_ctx* ctx, int n_windows, const lld_ba_window
   rec_total = B->rec_stride * (size_t)n_windows;
   B->S_total = S_total; B->x_total = x_total;
   // ---- one slab: a dry run of the carve sizes it exactly, the second run assigns pointers and uploads
-  const size_t NLE = 2 * (size_t)NLO;
   hipStream_t st = ctx->stream;
   BAArrays& A = B->A;
   auto carve = [&](lld_slab& sl, bool real) {
-    auto up_d = [&](const std::vector<double>& h, size_t count) { double* d = sl.take<double>(count); if (real && !h.empty()) (void)hipMemcpyAsync(d, h.data(), h.size() * 8, hipMemcpyHostToDevice, st); return (const double*)d; };
-    auto up_i = [&](const std::vector<int>& h, size_t count) { int* d = sl.take<int>(count); if (real && !h.empty()) (void)hipMemcpyAsync(d, h.data(), h.size() * 4, hipMemcpyHostToDevice, st); return (const int*)d; };
-    auto up_b = [&](const std::vector<uint8_t>& h, size_t count) { uint8_t* d = sl.take<uint8_t>(count); if (real && !h.empty()) (void)hipMemcpyAsync(d, h.data(), h.size(), hipMemcpyHostToDevice, st); return (const uint8_t*)d; };
+    auto up_d = [&](const HostBuf<double>& h, size_t count) { double* d = sl.take<double>(count); if (real && !h.empty()) (void)hipMemcpyAsync(d, h.data(), h.size() * 8, hipMemcpyHostToDevice, st); return (const double*)d; };
+    auto up_i = [&](const HostBuf<int>& h, size_t count) { int* d = sl.take<int>(count); if (real && !h.empty()) (void)hipMemcpyAsync(d, h.data(), h.size() * 4, hipMemcpyHostToDevice, st); return (const int*)d; };
+    auto up_b = [&](const HostBuf<uint8_t>& h, size_t count) { uint8_t* d = sl.take<uint8_t>(count); if (real && !h.empty()) (void)hipMemcpyAsync(d, h.data(), h.size(), hipMemcpyHostToDevice, st); return (const uint8_t*)d; };
     B->d_wins = sl.take<BAWin>(n_windows); B->d_state = sl.take<BAState>(n_windows);
     std::memset(&A, 0, sizeof A);
     A.NC = NC; A.NP = NP; A.NL = NL;
     A.cam_qt = sl.take<double>(2 * NC * 7 + 1);
     A.ptx = sl.take<double>(2 * NP + 1); A.pty = sl.take<double>(2 * NP + 1); A.ptz = sl.take<double>(2 * NP + 1);
     A.lqx = sl.take<double>(2 * NL + 1); A.lqy = sl.take<double>(2 * NL + 1); A.lqz = sl.take<double>(2 * NL + 1); A.lqw = sl.take<double>(2 * NL + 1); A.lal = sl.take<double>(2 * NL + 1);
-    A.cam_qt0 = up_d(cam_qt0, NC * 7 + 1); A.pt0 = up_d(pt0, NP * 3 + 1);
-    A.ln_x0 = up_d(ln_x0, NL * 3 + 1); A.ln_dir = up_d(ln_dir, NL * 3 + 1);
-    A.pt_obs_start = up_i(pt_obs_start, NP + 2); A.ln_obs_start = up_i(ln_obs_start, NL + 2);
-    A.pe_cam = up_i(pe_cam, NPE + 1); A.pe_pt = up_i(pe_pt, NPE + 1);
-    A.pe_u = up_d(pe_u, NPE + 1); A.pe_v = up_d(pe_v, NPE + 1); A.pe_ur = up_d(pe_ur, NPE + 1); A.pe_s = up_d(pe_s, NPE + 1);
-    A.le_cam = up_i(le_cam, NLE + 1); A.le_ln = up_i(le_ln, NLE + 1);
-    A.le_xs = up_d(le_xs, NLE + 1); A.le_ys = up_d(le_ys, NLE + 1); A.le_xe = up_d(le_xe, NLE + 1); A.le_ye = up_d(le_ye, NLE + 1);
-    A.le_s = up_d(le_s, NLE + 1); A.le_bx = up_d(le_bx, NLE + 1);
-    A.le_flags0 = up_b(le_flags0, NLE + 1);
+    A.cam_qt0 = up_d(H.cam_qt0, NC * 7 + 1); A.pt0 = up_d(H.pt0, NP * 3 + 1);
+    A.ln_x0 = up_d(H.ln_x0, NL * 3 + 1); A.ln_dir = up_d(H.ln_dir, NL * 3 + 1);
+    A.pt_obs_start = up_i(H.pt_obs_start, NP + 2); A.ln_obs_start = up_i(H.ln_obs_start, NL + 2);
+    A.pe_cam = up_i(H.pe_cam, NPE + 1); A.pe_pt = up_i(H.pe_pt, NPE + 1);
+    A.pe_u = up_d(H.pe_u, NPE + 1); A.pe_v = up_d(H.pe_v, NPE + 1); A.pe_ur = up_d(H.pe_ur, NPE + 1); A.pe_s = up_d(H.pe_s, NPE + 1);
+    A.le_cam = up_i(H.le_cam, NLE + 1); A.le_ln = up_i(H.le_ln, NLE + 1);
+    A.le_xs = up_d(H.le_xs, NLE + 1); A.le_ys = up_d(H.le_ys, NLE + 1); A.le_xe = up_d(H.le_xe, NLE + 1); A.le_ye = up_d(H.le_ye, NLE + 1);
+    A.le_s = up_d(H.le_s, NLE + 1); A.le_bx = up_d(H.le_bx, NLE + 1);
+    A.le_flags0 = up_b(H.le_flags0, NLE + 1);
     A.pe_flags = sl.take<uint8_t>(NPE + 1); A.le_flags = sl.take<uint8_t>(NLE + 1);
     A.pe_chi2 = sl.take<double>(NPE + 1); A.le_chi2 = sl.take<double>(NLE + 1);
     A.pe_ws = sl.take<double>((size_t)NPE + 1); A.lo_W = sl.take<double>((size_t)NLO * 24 + 1);
