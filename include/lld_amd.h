@@ -307,12 +307,14 @@ typedef struct {
   int32_t max_trials;           /* 10                                                                 */
   int32_t pcg_max_iter;         /* 0 -> 10 * 7 * n_vertices                                           */
   double  pcg_rel_tol;          /* |r|_M / |b|_M of the PCG                                           */
+  int32_t solver;               /* 0 auto (dense Cholesky up to 7*unknowns <= 32768, else PCG), 1 dense Cholesky, 2 PCG */
+  int32_t reserved;
 } lld_pose_graph_params;
 void lld_pose_graph_params_default(lld_pose_graph_params* p);
 typedef struct {
   double* sim3;                 /* [n_vertices][8] CorrectedSiw                                       */
   double  chi2;                 /* active chi2 after the last accepted step                           */
-  int32_t lm_iterations, lm_trials, pcg_iterations, reserved;
+  int32_t lm_iterations, lm_trials, pcg_iterations, solver_used;   /* solver_used: 1 dense Cholesky, 2 PCG, 0 nothing to solve */
 } lld_pose_graph_result;
 int lld_optimize_essential_graph(lld_ctx* ctx, const lld_pose_graph* graph, const lld_pose_graph_params* params, lld_pose_graph_result* out);
 

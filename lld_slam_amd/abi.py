@@ -153,12 +153,12 @@ class PoseGraph(C.Structure):
 
 class PoseGraphParams(C.Structure):
     _fields_ = [("iterations", C.c_int32), ("fix_scale", C.c_int32), ("lambda_init", C.c_double), ("max_trials", C.c_int32),
-                ("pcg_max_iter", C.c_int32), ("pcg_rel_tol", C.c_double)]
+                ("pcg_max_iter", C.c_int32), ("pcg_rel_tol", C.c_double), ("solver", C.c_int32), ("reserved", C.c_int32)]
 
 
 class PoseGraphResult(C.Structure):
     _fields_ = [("sim3", c_double_p), ("chi2", C.c_double), ("lm_iterations", C.c_int32), ("lm_trials", C.c_int32), ("pcg_iterations", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("solver_used", C.c_int32)]
 
 
 PRODUCT_SYMBOLS = [

@@ -4,8 +4,17 @@
 //   pg_errors     lane <-> edge: the 7-vector errors at the current estimate, chi2
 //   pg_linearize  lane <-> (edge, vertex, dof): central differences on the vertex's oplus (delta 1e-9) -> J[e][v] (7x7)
 //   pg_diag       lane group <-> unknown vertex: b_v = -sum J^T e and H_vv = sum J^T J over its incident edges (vertex CSR, fixed order)
-// H itself is never formed: the system is applied edge by edge (H p = sum_e J_e^T (J_e p)) through the same CSR,
-// so memory is O(edges) and every sum has a fixed order (deterministic):
+// Linear solve, default: the 7nu x 7nu system is formed DENSE in HBM (a 4000-keyframe map is 6 GB of 288) and factored on the
+// fp64 matrix cores - a pose graph is a chain with a few loops, the worst case for a block-Jacobi PCG (thousands of iterations),
+// while n^3/3 flops are nothing for this chip:
+//   pg_dense_fill   lower triangle of H + lambda I from the edge Jacobians, the right-hand side as one more matrix row
+//   pg_chol_col     left-looking Cholesky on 16x16 tiles, one launch per tile column: workgroup <-> row tile I >= J computes
+//                   A_IJ - sum_K L_IK L_JK^T with v_mfma_f64_16x16x4_f64 and multiplies by L_JJ^-T (every workgroup factors the
+//                   diagonal tile itself, so a column needs no grid-wide synchronisation); the right-hand side row comes out as
+//                   y = L^-1 b
+//   pg_chol_back    L^T x = y, one launch per tile column from the last: x_J = L_JJ^-T y_J, y_I -= L_JI^T x_J for I < J
+// Beyond 2048 tiles (n > 32768) or on request the system is instead applied edge by edge (H p = sum_e J_e^T (J_e p)) through
+// the vertex CSR, memory O(edges), every sum in a fixed order:
 //   pg_pcg_init / pg_matvec / pg_pcg_update   block-Jacobi PCG ((H_vv + lambda I)^-1 per vertex) with the host polling `done`
 //   pg_update     V <- exp(x_v) V (the scale update zeroed in place when fix_scale), scale = sum x (lambda x + b)
 // The LM control (push / pop, rho, lambda schedule, stop rules of optimization_algorithm_levenberg.cpp:61-164) runs on the host:
@@ -251,13 +260,176 @@ __global__ __launch_bounds__(1024) void pg_update_kernel(PgArrays A, double lamb
   if (tid == 0) { double s = 0.0; for (int w = 0; w < 16; w++) s += scratch[w]; A.sc[6] = s; }
 }
 
+
+// ---------------------------------------------------------------- dense Cholesky of H + lambda I on the matrix cores
+constexpr int kPgTS = 17;                                  // padded LDS row of a 16x16 tile
+constexpr int kPgMaxTiles = 2048;
+typedef double pg_v4d __attribute__((ext_vector_type(4)));
+
+struct PgDense {
+  double* M;                 // [(NT+1)*16][ld] row-major, lower triangle: H + lambda I, then L below the diagonal tiles (those stay
+                             // as assembled); row 16*NT: b, then y = L^-1 b
+  double* Linv;              // [NT][16][16] inverses of the diagonal tiles of L
+  int NT, n;                 // tile columns, unknowns (<= 16*NT; the padding rows are identity)
+  size_t ld;                 // 16*NT
+};
+
+__device__ __forceinline__ double pg_readlane(double v, int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
+
+// One wavefront: factor the tile T (LDS, lower triangle used) in place, L^-1 -> Li.  Lane r < 16 holds row r; lanes 16..31 carry
+// the identity as extra rows, which the same right-looking recurrence turns into the columns of L^-1 (readlane broadcasts only).
+__device__ __forceinline__ bool pg_tile_factor(double* T, double* Li, int lane) {
+  const int r = lane & 31;
+  double a[16];
+#pragma unroll
+  for (int c = 0; c < 16; c++) { const double v = T[(r & 15) * kPgTS + c]; a[c] = r < 16 ? v : (r - 16 == c ? 1.0 : 0.0); }
+  bool ok = true;
+#pragma unroll
+  for (int c = 0; c < 16; c++) {
+    const double d = pg_readlane(a[c], c);
+    if (!(d > 0.0) || !isfinite(d)) ok = false;
+    double inv = __builtin_amdgcn_rsq(d);                           // 1/sqrt(d): seed + two Newton steps
+    inv = inv * (1.5 - (0.5 * d) * (inv * inv));
+    inv = inv * (1.5 - (0.5 * d) * (inv * inv));
+    const double lc = a[c] * inv;
+    a[c] = lc;
+#pragma unroll
+    for (int c2 = c + 1; c2 < 16; c2++) a[c2] -= lc * pg_readlane(lc, c2);
+  }
+  if (lane < 16) {
+#pragma unroll
+    for (int c = 0; c < 16; c++) T[r * kPgTS + c] = (c <= r) ? a[c] : 0.0;
+  } else if (lane < 32) {                                           // lane 16+k holds column k of L^-1
+#pragma unroll
+    for (int c = 0; c < 16; c++) Li[c * kPgTS + (lane - 16)] = a[c];
+  }
+  return ok;
+}
+
+// lane <-> entry of an off-diagonal 7x7 block (per edge), of a diagonal block (per unknown), of the right-hand side / the padding
+__global__ __launch_bounds__(kPgThreads) void pg_dense_fill_kernel(PgArrays A, PgDense D, double lambda) {
+  const long long id = (long long)blockIdx.x * kPgThreads + threadIdx.x;
+  const long long n_off = (long long)A.E * 49, n_diag = (long long)A.nu * 49, N = 16ll * D.NT;
+  if (id == 0) { A.sc[4] = 1.0; A.sc[2] = 0.0; }
+  if (id < n_off) {
+    const int e = (int)(id / 49), t = (int)(id % 49), r = t / 7, c = t % 7;
+    const int hi = A.hidx[A.ei[e]], hj = A.hidx[A.ej[e]];
+    if (hi < 0 || hj < 0 || hi == hj) return;
+    const double* Ji = A.J + ((size_t)e * 2) * 49; const double* Jj = Ji + 49;
+    const double* Jr = hi > hj ? Ji : Jj; const double* Jc = hi > hj ? Jj : Ji;       // block (max, min) = J_max^T J_min
+    const int ur = hi > hj ? hi : hj, uc = hi > hj ? hj : hi;
+    double v = 0.0;
+#pragma unroll
+    for (int k = 0; k < 7; k++) v += Jr[k * 7 + r] * Jc[k * 7 + c];
+    atomicAdd(D.M + (size_t)(7 * ur + r) * D.ld + 7 * uc + c, v);
+  } else if (id < n_off + n_diag) {
+    const long long q = id - n_off;
+    const int u = (int)(q / 49), t = (int)(q % 49), r = t / 7, c = t % 7;
+    D.M[(size_t)(7 * u + r) * D.ld + 7 * u + c] = A.Hd[(size_t)u * 49 + t] + (r == c ? lambda : 0.0);
+  } else if (id < n_off + n_diag + N) {
+    const long long i = id - n_off - n_diag;
+    if (i < D.n) D.M[(size_t)N * D.ld + i] = A.b[i];
+    else D.M[(size_t)i * D.ld + i] = 1.0;
+  }
+}
+
+// grid (NT + 1 - J) x 256 lanes: workgroup <-> row tile I = J + blockIdx (I = NT is the right-hand side).  The K loop of both
+// sums (diagonal tile and own tile) is split over the four wavefronts, four tile columns in flight per wavefront: the loop is a
+// chain of L2 round trips, not of matrix-core work.
+__global__ __launch_bounds__(256) void pg_chol_col_kernel(PgDense D, int J, double* sc) {
+  __shared__ __attribute__((aligned(16))) double Dg[16 * kPgTS], Li[16 * kPgTS], T[16 * kPgTS], red_d[4][256], red_t[4][256];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lrow = lane >> 4, lcol = lane & 15;
+  const int I = J + (int)blockIdx.x;
+  const bool own = I != J;
+  const double* rowJ = D.M + (size_t)(16 * J + lcol) * D.ld + 4 * lrow;      // MFMA operand: row lcol of tile row J, k = 4 lrow + kk
+  const double* rowI = D.M + (size_t)(16 * I + lcol) * D.ld + 4 * lrow;
+  pg_v4d cd = {0.0, 0.0, 0.0, 0.0}, ct = {0.0, 0.0, 0.0, 0.0};
+  const pg_v4d zero = {0.0, 0.0, 0.0, 0.0};
+  for (int K0 = wave; K0 < J; K0 += 16) {
+    pg_v4d a[4], b[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int K = K0 + 4 * q;
+      const bool valid = K < J;
+      b[q] = valid ? *reinterpret_cast<const pg_v4d*>(rowJ + 16 * (valid ? K : 0)) : zero;
+      a[q] = (valid && own) ? *reinterpret_cast<const pg_v4d*>(rowI + 16 * (valid ? K : 0)) : zero;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+#pragma unroll
+      for (int kk = 0; kk < 4; kk++) {
+        cd = __builtin_amdgcn_mfma_f64_16x16x4f64(b[q][kk], b[q][kk], cd, 0, 0, 0);
+        ct = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q][kk], b[q][kk], ct, 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < 4; g++) { red_d[wave][g * 64 + lane] = cd[g]; red_t[wave][g * 64 + lane] = ct[g]; }
+  __syncthreads();
+  if (wave == 0) {                                                   // diagonal tile A_JJ - sum_K L_JK L_JK^T
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      const double sum = red_d[0][g * 64 + lane] + red_d[1][g * 64 + lane] + red_d[2][g * 64 + lane] + red_d[3][g * 64 + lane];
+      Dg[(lrow + 4 * g) * kPgTS + lcol] = D.M[(size_t)(16 * J + lrow + 4 * g) * D.ld + 16 * J + lcol] - sum;
+    }
+  } else if (wave == 1 && own) {                                     // own tile A_IJ - sum_K L_IK L_JK^T
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      const double sum = red_t[0][g * 64 + lane] + red_t[1][g * 64 + lane] + red_t[2][g * 64 + lane] + red_t[3][g * 64 + lane];
+      T[(lrow + 4 * g) * kPgTS + lcol] = D.M[(size_t)(16 * I + lrow + 4 * g) * D.ld + 16 * J + lcol] - sum;
+    }
+  }
+  __syncthreads();
+  bool ok = true;
+  if (wave == 0) ok = pg_tile_factor(Dg, Li, lane);
+  __syncthreads();
+  if (wave != 0) return;
+  if (!own) {
+    // publish the inverse of L_JJ (all the back substitution needs); the tile itself stays as assembled: the other workgroups
+    // of this launch are still reading it for their own copy of the factorisation
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      D.Linv[(size_t)J * 256 + (lrow + 4 * g) * 16 + lcol] = (lcol <= lrow + 4 * g) ? Li[(lrow + 4 * g) * kPgTS + lcol] : 0.0;
+    }
+    if (!ok && lane == 0) sc[4] = 0.0;
+    return;
+  }
+  // L_IJ = T L_JJ^-T; T is read back from LDS in the operand layout
+  pg_v4d o = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int kk = 0; kk < 4; kk++) o = __builtin_amdgcn_mfma_f64_16x16x4f64(T[lcol * kPgTS + 4 * lrow + kk], Li[lcol * kPgTS + 4 * lrow + kk], o, 0, 0, 0);
+#pragma unroll
+  for (int g = 0; g < 4; g++) D.M[(size_t)(16 * I + lrow + 4 * g) * D.ld + 16 * J + lcol] = o[g];
+}
+
+// grid ceil((J + 1) / 4) x 256 lanes: wavefront <-> tile I <= J.  x_J = L_JJ^-T y_J (every wavefront), y_I -= L_JI^T x_J
+__global__ __launch_bounds__(256) void pg_chol_back_kernel(PgDense D, int J, double* x) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, part = lane >> 4, c = lane & 15;
+  const int I = 4 * (int)blockIdx.x + wave;
+  if (I > J) return;
+  double* y = D.M + (size_t)(16 * D.NT) * D.ld;
+  double s = 0.0;
+#pragma unroll
+  for (int q = 0; q < 4; q++) s += D.Linv[(size_t)J * 256 + (4 * part + q) * 16 + c] * y[16 * J + 4 * part + q];
+  s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);                     // x_J[c] on every lane with this c
+  if (I == J) { if (lane < 16 && 16 * J + c < D.n) x[16 * J + c] = s; return; }
+  double t = 0.0;
+#pragma unroll
+  for (int q = 0; q < 4; q++) t += D.M[(size_t)(16 * J + 4 * part + q) * D.ld + 16 * I + c] * __shfl(s, 4 * part + q);
+  t += __shfl_xor(t, 16); t += __shfl_xor(t, 32);
+  if (lane < 16) y[16 * I + c] -= t;
+}
+
 inline size_t pad256(size_t b) { return (b + 255) & ~size_t(255); }
 
 }  // namespace
 
 extern "C" void lld_pose_graph_params_default(lld_pose_graph_params* p) {
   if (!p) return;
-  p->iterations = 15; p->fix_scale = 1; p->lambda_init = 1e-16; p->max_trials = 10; p->pcg_max_iter = 0; p->pcg_rel_tol = 1e-12;
+  p->iterations = 15; p->fix_scale = 1; p->lambda_init = 1e-16; p->max_trials = 10; p->pcg_max_iter = 0; p->pcg_rel_tol = 1e-12; p->solver = 0; p->reserved = 0;
 }
 
 extern "C" int lld_optimize_essential_graph(lld_ctx* ctx, const lld_pose_graph* g, const lld_pose_graph_params* params, lld_pose_graph_result* out) {
@@ -265,9 +437,9 @@ extern "C" int lld_optimize_essential_graph(lld_ctx* ctx, const lld_pose_graph* 
   lld_pose_graph_params prm; if (params) prm = *params; else lld_pose_graph_params_default(&prm);
   const int N = g->n_vertices, E = g->n_edges;
   if (N < 0 || E < 0 || (N > 0 && !g->sim3) || (E > 0 && (!g->edge_i || !g->edge_j || !g->edge_sji))) return LLD_ERR_INVALID;
-  if (prm.iterations < 0 || prm.max_trials <= 0 || !(prm.pcg_rel_tol > 0)) return LLD_ERR_INVALID;
+  if (prm.iterations < 0 || prm.max_trials <= 0 || !(prm.pcg_rel_tol > 0) || prm.solver < 0 || prm.solver > 2) return LLD_ERR_INVALID;
   for (int e = 0; e < E; e++) if (g->edge_i[e] < 0 || g->edge_i[e] >= N || g->edge_j[e] < 0 || g->edge_j[e] >= N) return LLD_ERR_INVALID;
-  out->chi2 = 0; out->lm_iterations = 0; out->lm_trials = 0; out->pcg_iterations = 0; out->reserved = 0;
+  out->chi2 = 0; out->lm_iterations = 0; out->lm_trials = 0; out->pcg_iterations = 0; out->solver_used = 0;
   if (N) std::memcpy(out->sim3, g->sim3, sizeof(double) * 8 * (size_t)N);
   // unknowns in vertex order (g2o: buildIndexMapping over the vertices sorted by id), vertex CSR in edge order
   std::vector<int> hidx(N, -1), uvert;
@@ -286,7 +458,14 @@ extern "C" int lld_optimize_essential_graph(lld_ctx* ctx, const lld_pose_graph* 
   size_t off = 0; auto take = [&](size_t bytes) { const size_t o = off; off += pad256(bytes); return o; };
   const size_t o_V = take((size_t)N * 64), o_Vbk = take((size_t)N * 64), o_h = take((size_t)N * 4), o_ei = take((size_t)E * 4), o_ej = take((size_t)E * 4), o_C = take((size_t)E * 64),
                o_err = take((size_t)E * 56), o_J = take((size_t)E * 2 * 49 * 8), o_vs = take((size_t)(nu + 1) * 4), o_vi = take(vinc.size() * 4 + 4), o_uv = take((size_t)nu * 4),
-               o_Hd = take((size_t)nu * 49 * 8), o_Mi = take((size_t)nu * 49 * 8), o_vec = take(6 * n * 8), o_sc = take(64);
+               o_Hd = take((size_t)nu * 49 * 8), o_Mi = take((size_t)nu * 49 * 8), o_vec = take(6 * n * 8 + 256), o_sc = take(64);
+  // dense Cholesky unless the system is beyond kPgMaxTiles tile columns (or the caller asks for the PCG)
+  const int NT = (int)((n + 15) / 16);
+  if (prm.solver == 1 && NT > kPgMaxTiles) return LLD_ERR_UNSUPPORTED;
+  const bool dense = prm.solver == 1 || (prm.solver == 0 && NT <= kPgMaxTiles);
+  const size_t dense_bytes = dense ? (size_t)(NT + 1) * 16 * ((size_t)NT * 16) * 8 : 0;
+  const size_t o_M = take(dense_bytes), o_Li = take(dense ? (size_t)NT * 256 * 8 : 0);
+  out->solver_used = dense ? 1 : 2;
   void* db; int st = lld_ctx_scratch(ctx, off + 256, &db); if (st) return st;
   char* d = (char*)db;
   hipStream_t sm = ctx->stream;
@@ -309,6 +488,7 @@ extern "C" int lld_optimize_essential_graph(lld_ctx* ctx, const lld_pose_graph* 
   A.b = vec; A.x = vec + n; A.r = vec + 2 * n; A.z = vec + 3 * n; A.p = vec + 4 * n; A.ap = vec + 5 * n;
   A.sc = reinterpret_cast<double*>(d + o_sc); A.fix_scale = prm.fix_scale;
   double* dVbk = reinterpret_cast<double*>(d + o_Vbk);
+  PgDense D; D.M = reinterpret_cast<double*>(d + o_M); D.Linv = reinterpret_cast<double*>(d + o_Li); D.NT = NT; D.n = (int)n; D.ld = (size_t)NT * 16;
   double hsc[8];
   auto read_sc = [&]() -> int { LLD_HIP_TRY(hipMemcpyAsync(hsc, A.sc, sizeof hsc, hipMemcpyDeviceToHost, sm)); LLD_HIP_TRY(hipStreamSynchronize(sm)); return LLD_OK; };
   auto errors = [&](double* chi) -> int { hipLaunchKernelGGL(pg_errors_kernel, dim3(1), dim3(1024), 0, sm, A); int s = read_sc(); if (s) return s; *chi = hsc[5]; return LLD_OK; };
@@ -326,14 +506,22 @@ extern "C" int lld_optimize_essential_graph(lld_ctx* ctx, const lld_pose_graph* 
     double rho = 0.0; int q = 0;
     do {
       LLD_HIP_TRY(hipMemcpyAsync(dVbk, A.V, (size_t)N * 64, hipMemcpyDeviceToDevice, sm));          // push
-      hipLaunchKernelGGL(pg_pcg_init_kernel, dim3(1), dim3(1024), 0, sm, A, lambda, prm.pcg_rel_tol);
-      for (int k = 0; k < pcg_limit;) {
-        for (int c = 0; c < 16 && k < pcg_limit; c++, k++) {
-          hipLaunchKernelGGL(pg_matvec_kernel, dim3((nu * 8 + kPgThreads - 1) / kPgThreads), dim3(kPgThreads), 0, sm, A, lambda);
-          hipLaunchKernelGGL(pg_pcg_update_kernel, dim3(1), dim3(1024), 0, sm, A, pcg_limit);
+      if (dense) {
+        LLD_HIP_TRY(hipMemsetAsync(D.M, 0, dense_bytes, sm));
+        const long long fill = (long long)E * 49 + (long long)nu * 49 + 16ll * NT;
+        hipLaunchKernelGGL(pg_dense_fill_kernel, dim3((unsigned)((fill + kPgThreads - 1) / kPgThreads)), dim3(kPgThreads), 0, sm, A, D, lambda);
+        for (int J = 0; J < NT; J++) hipLaunchKernelGGL(pg_chol_col_kernel, dim3(NT + 1 - J), dim3(256), 0, sm, D, J, A.sc);
+        for (int J = NT - 1; J >= 0; J--) hipLaunchKernelGGL(pg_chol_back_kernel, dim3((J + 1 + 3) / 4), dim3(256), 0, sm, D, J, A.x);
+      } else {
+        hipLaunchKernelGGL(pg_pcg_init_kernel, dim3(1), dim3(1024), 0, sm, A, lambda, prm.pcg_rel_tol);
+        for (int k = 0; k < pcg_limit;) {
+          for (int c = 0; c < 16 && k < pcg_limit; c++, k++) {
+            hipLaunchKernelGGL(pg_matvec_kernel, dim3((nu * 8 + kPgThreads - 1) / kPgThreads), dim3(kPgThreads), 0, sm, A, lambda);
+            hipLaunchKernelGGL(pg_pcg_update_kernel, dim3(1), dim3(1024), 0, sm, A, pcg_limit);
+          }
+          st = read_sc(); if (st) return st;
+          if (hsc[3] != 0.0) break;
         }
-        st = read_sc(); if (st) return st;
-        if (hsc[3] != 0.0) break;
       }
       st = read_sc(); if (st) return st;
       const bool ok2 = hsc[4] != 0.0;

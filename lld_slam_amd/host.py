@@ -227,6 +227,7 @@ class EssentialGraphOutput:
     lm_iterations: int
     lm_trials: int
     pcg_iterations: int
+    solver_used: int = 0          # 1 dense Cholesky on the matrix cores, 2 matrix-free PCG
 
 
 def essential_graph_call(lib: abi.Lib, ctx, g: EssentialGraph, bFixScale=True, **kw) -> EssentialGraphOutput:
@@ -240,7 +241,7 @@ def essential_graph_call(lib: abi.Lib, ctx, g: EssentialGraph, bFixScale=True, *
     o = np.zeros_like(keep[0]); R = abi.PoseGraphResult(); R.sim3 = o.ctypes.data_as(abi.c_double_p)
     fn = lib.fn("optimize_essential_graph"); fn.argtypes = [C.c_void_p, C.POINTER(abi.PoseGraph), C.POINTER(abi.PoseGraphParams), C.POINTER(abi.PoseGraphResult)]; fn.restype = C.c_int
     check(fn(ctx, C.byref(G), C.byref(P), C.byref(R)), "optimize_essential_graph")
-    return EssentialGraphOutput(o, float(R.chi2), int(R.lm_iterations), int(R.lm_trials), int(R.pcg_iterations))
+    return EssentialGraphOutput(o, float(R.chi2), int(R.lm_iterations), int(R.lm_trials), int(R.pcg_iterations), int(R.solver_used))
 
 
 def pose_params(lib: abi.Lib, gamma=0.5, **kw) -> PoseParams:

@@ -1156,6 +1156,6 @@ extern "C" int lldo_optimize_essential_graph(void* /*ctx*/, const lld_pose_graph
     double* s = out->sim3 + 8 * v;
     s[0] = Y.V[v].r.x; s[1] = Y.V[v].r.y; s[2] = Y.V[v].r.z; s[3] = Y.V[v].r.w; s[4] = Y.V[v].t.x; s[5] = Y.V[v].t.y; s[6] = Y.V[v].t.z; s[7] = Y.V[v].s;
   }
-  out->chi2 = lm.lastChi; out->lm_iterations = lm.iterations; out->lm_trials = lm.trials; out->pcg_iterations = 0; out->reserved = 0;
+  out->chi2 = lm.lastChi; out->lm_iterations = lm.iterations; out->lm_trials = lm.trials; out->pcg_iterations = 0; out->solver_used = 0;
   return LLD_OK;
 }

@@ -73,7 +73,7 @@ opt.OptimizeEssentialGraph(eg)
 t = time.perf_counter(); ge = opt.OptimizeEssentialGraph(eg); dte = time.perf_counter() - t
 t = time.perf_counter(); oe = O.optimize_essential_graph(eg); dtce = time.perf_counter() - t
 out["essential_graph_300kf"] = {"gpu_ms": dte * 1e3, "cpu_oracle_ms_dense": dtce * 1e3, "edges": int(eg.edge_i.shape[0]), "lm_iterations": ge.lm_iterations,
-                                "pcg_iterations": ge.pcg_iterations, "chi2_rel": abs(ge.chi2 - oe.chi2) / max(oe.chi2, 1e-300)}
+                                "pcg_iterations": ge.pcg_iterations, "solver_used": ge.solver_used, "chi2_rel": abs(ge.chi2 - oe.chi2) / max(oe.chi2, 1e-300)}
 # ---- ORB 2000 x 2000 Hamming best/second, batched in HBM
 B, nq, nt = 256, 2000, 2000
 dev = torch.device("cuda", 0)
