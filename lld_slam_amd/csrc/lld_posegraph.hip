@@ -19,6 +19,8 @@
 //   pg_update     V <- exp(x_v) V (the scale update zeroed in place when fix_scale), scale = sum x (lambda x + b)
 // The LM control (push / pop, rho, lambda schedule, stop rules of optimization_algorithm_levenberg.cpp:61-164) runs on the host:
 // a loop closure happens once in a while, latency of a few polls is irrelevant.
+#include <algorithm>
+#include <vector>
 #include "lld_common.h"
 #include "lld_device_math.h"
 #include "lld_sim3_math.h"
@@ -272,6 +274,10 @@ struct PgDense {
   double* Linv;              // [NT][16][16] inverses of the diagonal tiles of L
   int NT, n;                 // tile columns, unknowns (<= 16*NT; the padding rows are identity)
   size_t ld;                 // 16*NT
+  // tile pattern of L from the host's symbolic factorisation (a pose graph in keyframe order is a band plus the fill of a few
+  // loop edges): the kernels only visit non-zero tiles, the zero ones stay as the memset left them
+  const int* col_start; const int* col_rows;     // per tile column J: the rows I > J with L_IJ != 0, ascending
+  const int* row_start; const int* row_cols;     // per tile row J: the columns K < J with L_JK != 0, ascending
 };
 
 __device__ __forceinline__ double pg_readlane(double v, int l) {
@@ -336,26 +342,29 @@ __global__ __launch_bounds__(kPgThreads) void pg_dense_fill_kernel(PgArrays A, P
   }
 }
 
-// grid (NT + 1 - J) x 256 lanes: workgroup <-> row tile I = J + blockIdx (I = NT is the right-hand side).  The K loop of both
+// grid (2 + #rows of column J) x 256 lanes: workgroup <-> row tile I = J, NT (the right-hand side) or a non-zero row of the
+// column.  K runs over the non-zero tiles of row J (a zero L_JK contributes nothing whatever L_IK is).  The K loop of both
 // sums (diagonal tile and own tile) is split over the four wavefronts, four tile columns in flight per wavefront: the loop is a
 // chain of L2 round trips, not of matrix-core work.
 __global__ __launch_bounds__(256) void pg_chol_col_kernel(PgDense D, int J, double* sc) {
   __shared__ __attribute__((aligned(16))) double Dg[16 * kPgTS], Li[16 * kPgTS], T[16 * kPgTS], red_d[4][256], red_t[4][256];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lrow = lane >> 4, lcol = lane & 15;
-  const int I = J + (int)blockIdx.x;
+  const int I = blockIdx.x == 0 ? J : (blockIdx.x == 1 ? D.NT : D.col_rows[D.col_start[J] + (int)blockIdx.x - 2]);
   const bool own = I != J;
+  const int* Ks = D.row_cols + D.row_start[J];
+  const int nK = D.row_start[J + 1] - D.row_start[J];
   const double* rowJ = D.M + (size_t)(16 * J + lcol) * D.ld + 4 * lrow;      // MFMA operand: row lcol of tile row J, k = 4 lrow + kk
   const double* rowI = D.M + (size_t)(16 * I + lcol) * D.ld + 4 * lrow;
   pg_v4d cd = {0.0, 0.0, 0.0, 0.0}, ct = {0.0, 0.0, 0.0, 0.0};
   const pg_v4d zero = {0.0, 0.0, 0.0, 0.0};
-  for (int K0 = wave; K0 < J; K0 += 16) {
+  for (int k0 = wave; k0 < nK; k0 += 16) {
     pg_v4d a[4], b[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-      const int K = K0 + 4 * q;
-      const bool valid = K < J;
-      b[q] = valid ? *reinterpret_cast<const pg_v4d*>(rowJ + 16 * (valid ? K : 0)) : zero;
-      a[q] = (valid && own) ? *reinterpret_cast<const pg_v4d*>(rowI + 16 * (valid ? K : 0)) : zero;
+      const bool valid = k0 + 4 * q < nK;
+      const int K = valid ? Ks[k0 + 4 * q] : 0;
+      b[q] = valid ? *reinterpret_cast<const pg_v4d*>(rowJ + 16 * K) : zero;
+      a[q] = (valid && own) ? *reinterpret_cast<const pg_v4d*>(rowI + 16 * K) : zero;
     }
 #pragma unroll
     for (int q = 0; q < 4; q++) {
@@ -405,11 +414,13 @@ __global__ __launch_bounds__(256) void pg_chol_col_kernel(PgDense D, int J, doub
   for (int g = 0; g < 4; g++) D.M[(size_t)(16 * I + lrow + 4 * g) * D.ld + 16 * J + lcol] = o[g];
 }
 
-// grid ceil((J + 1) / 4) x 256 lanes: wavefront <-> tile I <= J.  x_J = L_JJ^-T y_J (every wavefront), y_I -= L_JI^T x_J
+// grid ceil((1 + #non-zero tiles of row J) / 4) x 256 lanes: wavefront <-> tile I = J or a non-zero column of row J.
+// x_J = L_JJ^-T y_J (every wavefront), y_I -= L_JI^T x_J
 __global__ __launch_bounds__(256) void pg_chol_back_kernel(PgDense D, int J, double* x) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, part = lane >> 4, c = lane & 15;
-  const int I = 4 * (int)blockIdx.x + wave;
-  if (I > J) return;
+  const int slot = 4 * (int)blockIdx.x + wave, nK = D.row_start[J + 1] - D.row_start[J];
+  if (slot > nK) return;
+  const int I = slot == 0 ? J : D.row_cols[D.row_start[J] + slot - 1];
   double* y = D.M + (size_t)(16 * D.NT) * D.ld;
   double s = 0.0;
 #pragma unroll
@@ -464,7 +475,27 @@ extern "C" int lld_optimize_essential_graph(lld_ctx* ctx, const lld_pose_graph* 
   if (prm.solver == 1 && NT > kPgMaxTiles) return LLD_ERR_UNSUPPORTED;
   const bool dense = prm.solver == 1 || (prm.solver == 0 && NT <= kPgMaxTiles);
   const size_t dense_bytes = dense ? (size_t)(NT + 1) * 16 * ((size_t)NT * 16) * 8 : 0;
+  // symbolic factorisation on 16x16 tiles: the pattern of column J is merged into the column of its first sub-diagonal row
+  std::vector<int> col_start, col_rows, row_start, row_cols;
+  if (dense) {
+    std::vector<std::vector<int>> col(NT), row(NT);
+    auto mark = [&](int ur, int uc) {                                 // unknowns ur >= uc: every tile their 7x7 block touches
+      for (int tr = (7 * ur) / 16; tr <= (7 * ur + 6) / 16; tr++) for (int tc = (7 * uc) / 16; tc <= (7 * uc + 6) / 16; tc++) if (tr > tc) col[tc].push_back(tr);
+    };
+    for (int u = 0; u < nu; u++) mark(u, u);
+    for (int e = 0; e < E; e++) { const int a = hidx[g->edge_i[e]], b = hidx[g->edge_j[e]]; if (a >= 0 && b >= 0 && a != b) mark(std::max(a, b), std::min(a, b)); }
+    for (int J = 0; J < NT; J++) {
+      std::vector<int>& c = col[J];
+      std::sort(c.begin(), c.end()); c.erase(std::unique(c.begin(), c.end()), c.end());
+      if (c.size() > 1) col[c[0]].insert(col[c[0]].end(), c.begin() + 1, c.end());
+      for (int I : c) row[I].push_back(J);
+    }
+    col_start.assign(1, 0); row_start.assign(1, 0);
+    for (int J = 0; J < NT; J++) { col_rows.insert(col_rows.end(), col[J].begin(), col[J].end()); col_start.push_back((int)col_rows.size()); }
+    for (int J = 0; J < NT; J++) { row_cols.insert(row_cols.end(), row[J].begin(), row[J].end()); row_start.push_back((int)row_cols.size()); }
+  }
   const size_t o_M = take(dense_bytes), o_Li = take(dense ? (size_t)NT * 256 * 8 : 0);
+  const size_t o_cs = take(col_start.size() * 4), o_cr = take(col_rows.size() * 4 + 4), o_rs = take(row_start.size() * 4), o_rc = take(row_cols.size() * 4 + 4);
   out->solver_used = dense ? 1 : 2;
   void* db; int st = lld_ctx_scratch(ctx, off + 256, &db); if (st) return st;
   char* d = (char*)db;
@@ -488,7 +519,15 @@ extern "C" int lld_optimize_essential_graph(lld_ctx* ctx, const lld_pose_graph* 
   A.b = vec; A.x = vec + n; A.r = vec + 2 * n; A.z = vec + 3 * n; A.p = vec + 4 * n; A.ap = vec + 5 * n;
   A.sc = reinterpret_cast<double*>(d + o_sc); A.fix_scale = prm.fix_scale;
   double* dVbk = reinterpret_cast<double*>(d + o_Vbk);
-  PgDense D; D.M = reinterpret_cast<double*>(d + o_M); D.Linv = reinterpret_cast<double*>(d + o_Li); D.NT = NT; D.n = (int)n; D.ld = (size_t)NT * 16;
+  if (dense) {
+    LLD_HIP_TRY(hipMemcpyAsync(d + o_cs, col_start.data(), col_start.size() * 4, hipMemcpyHostToDevice, sm));
+    if (!col_rows.empty()) LLD_HIP_TRY(hipMemcpyAsync(d + o_cr, col_rows.data(), col_rows.size() * 4, hipMemcpyHostToDevice, sm));
+    LLD_HIP_TRY(hipMemcpyAsync(d + o_rs, row_start.data(), row_start.size() * 4, hipMemcpyHostToDevice, sm));
+    if (!row_cols.empty()) LLD_HIP_TRY(hipMemcpyAsync(d + o_rc, row_cols.data(), row_cols.size() * 4, hipMemcpyHostToDevice, sm));
+  }
+  PgDense D; D.col_start = reinterpret_cast<const int*>(d + o_cs); D.col_rows = reinterpret_cast<const int*>(d + o_cr);
+  D.row_start = reinterpret_cast<const int*>(d + o_rs); D.row_cols = reinterpret_cast<const int*>(d + o_rc);
+  D.M = reinterpret_cast<double*>(d + o_M); D.Linv = reinterpret_cast<double*>(d + o_Li); D.NT = NT; D.n = (int)n; D.ld = (size_t)NT * 16;
   double hsc[8];
   auto read_sc = [&]() -> int { LLD_HIP_TRY(hipMemcpyAsync(hsc, A.sc, sizeof hsc, hipMemcpyDeviceToHost, sm)); LLD_HIP_TRY(hipStreamSynchronize(sm)); return LLD_OK; };
   auto errors = [&](double* chi) -> int { hipLaunchKernelGGL(pg_errors_kernel, dim3(1), dim3(1024), 0, sm, A); int s = read_sc(); if (s) return s; *chi = hsc[5]; return LLD_OK; };
@@ -510,8 +549,8 @@ extern "C" int lld_optimize_essential_graph(lld_ctx* ctx, const lld_pose_graph* 
         LLD_HIP_TRY(hipMemsetAsync(D.M, 0, dense_bytes, sm));
         const long long fill = (long long)E * 49 + (long long)nu * 49 + 16ll * NT;
         hipLaunchKernelGGL(pg_dense_fill_kernel, dim3((unsigned)((fill + kPgThreads - 1) / kPgThreads)), dim3(kPgThreads), 0, sm, A, D, lambda);
-        for (int J = 0; J < NT; J++) hipLaunchKernelGGL(pg_chol_col_kernel, dim3(NT + 1 - J), dim3(256), 0, sm, D, J, A.sc);
-        for (int J = NT - 1; J >= 0; J--) hipLaunchKernelGGL(pg_chol_back_kernel, dim3((J + 1 + 3) / 4), dim3(256), 0, sm, D, J, A.x);
+        for (int J = 0; J < NT; J++) hipLaunchKernelGGL(pg_chol_col_kernel, dim3(2 + col_start[J + 1] - col_start[J]), dim3(256), 0, sm, D, J, A.sc);
+        for (int J = NT - 1; J >= 0; J--) hipLaunchKernelGGL(pg_chol_back_kernel, dim3((1 + row_start[J + 1] - row_start[J] + 3) / 4), dim3(256), 0, sm, D, J, A.x);
       } else {
         hipLaunchKernelGGL(pg_pcg_init_kernel, dim3(1), dim3(1024), 0, sm, A, lambda, prm.pcg_rel_tol);
         for (int k = 0; k < pcg_limit;) {
