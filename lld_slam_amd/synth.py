@@ -137,6 +137,8 @@ def make_ba_window(n_free=50, n_fixed=10, n_points=10000, obs_per_point=6, n_lin
 
     # ---------------- points
     pts = np.zeros((0, 3)); pts_cams = np.zeros((0, obs_per_point), np.int64)
+    if n_points > 0 and obs_per_point > n_cams:
+        raise ValueError(f"{obs_per_point} observations per point need at least as many cameras (have {n_cams})")
     while pts.shape[0] < n_points:
         m = int((n_points - pts.shape[0]) * 1.6) + 64
         k = rng.integers(0, n_cams, m)
@@ -170,6 +172,8 @@ def make_ba_window(n_free=50, n_fixed=10, n_points=10000, obs_per_point=6, n_lin
 
     # ---------------- lines
     lA = np.zeros((0, 3)); lB = np.zeros((0, 3)); ln_cams = np.zeros((0, obs_per_line), np.int64)
+    if n_lines > 0 and obs_per_line > n_cams:
+        raise ValueError(f"{obs_per_line} observations per line need at least as many cameras (have {n_cams})")
     while lA.shape[0] < n_lines:
         m = int((n_lines - lA.shape[0]) * 2.0) + 64
         k = rng.integers(0, n_cams, m)
