@@ -1773,8 +1773,9 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
   return __hiloint2double(hi, lo);
 }
 
-// Panel wave: factor the 16x16 tile in Dg (lower triangle used) in place, L^-1 -> Li, 1/L_cc -> invd, rhs y[0..15] -> L^-1 y.
-__device__ __forceinline__ bool chol_tile_factor(double* Dg, double* Li, double* invd, double* y, int lane) {
+// Panel wave: factor the 16x16 tile in Dg (lower triangle used); L^-1 -> Li (operand of the column's L_IJ = A_IJ L_JJ^-T) and -> Dg
+// (kept for the back substitution, which only needs the inverse); rhs y[0..15] -> L^-1 y.
+__device__ __forceinline__ bool chol_tile_factor(double* Dg, double* Li, double* y, int lane) {
   const int r = lane < 32 ? lane : 32;                               // 0..15 tile rows, 16 rhs, 17..32 identity rows
   // one load path for all lanes: tile rows and the right-hand side are read through a per-lane pointer, the identity rows read
   // the (finite) right-hand side too and are overwritten
@@ -1783,7 +1784,6 @@ __device__ __forceinline__ bool chol_tile_factor(double* Dg, double* Li, double*
 #pragma unroll
   for (int c = 0; c < 16; c++) { const double v = src[c]; a[c] = (r <= 16) ? v : (r - 17 == c ? 1.0 : 0.0); }
   bool ok = true;
-  double my_inv = 0.0;
 #pragma unroll
   for (int c = 0; c < 16; c++) {
     const double d = readlane_f64(a[c], c);
@@ -1795,20 +1795,15 @@ __device__ __forceinline__ bool chol_tile_factor(double* Dg, double* Li, double*
     inv = inv * (1.5 - (0.5 * d) * (inv * inv));
     const double lc = a[c] * inv;                                    // lane c: sqrt(d); below: L[r][c]; rhs lane: y_c
     a[c] = lc;
-    if (lane == c) my_inv = inv;
 #pragma unroll
     for (int c2 = c + 1; c2 < 16; c2++) a[c2] -= lc * readlane_f64(lc, c2);   // A[r][c2] -= L[r][c] L[c2][c]
   }
-  if (lane < 16) {
-    invd[lane] = my_inv;
-#pragma unroll
-    for (int c = 0; c < 16; c++) Dg[r * kCholMStride + c] = (c <= r) ? a[c] : 0.0;
-  } else if (lane == 16) {
+  if (lane == 16) {
 #pragma unroll
     for (int c = 0; c < 16; c++) y[c] = a[c];
-  } else if (lane <= 32) {                                           // lane 17+k holds column k of L^-1
+  } else if (lane > 16 && lane <= 32) {                              // lane 17+k holds column k of L^-1
 #pragma unroll
-    for (int c = 0; c < 16; c++) Li[c * kCholMStride + (lane - 17)] = a[c];
+    for (int c = 0; c < 16; c++) { Li[c * kCholMStride + (lane - 17)] = a[c]; Dg[c * kCholMStride + (lane - 17)] = a[c]; }
   }
   return ok;
 }
@@ -1822,11 +1817,10 @@ __global__ __launch_bounds__(kCholMThreads) void ba_chol_mfma_kernel(BAArrays A,
   double* Lp0 = lds;                                       // [2][N][17] panel buffers: column J in buffer J & 1 (raw, then L)
   double* Dall = Lp0 + 2 * kCholMN * kCholMStride;         // [NT][16][17] diagonal tiles: raw until factored, then L_JJ
   double* Li = Dall + kCholMMaxTiles * 16 * kCholMStride;  // [16][17] inverse of the current diagonal factor
-  double* invd = Li + 16 * kCholMStride;                   // [N] 1 / L_cc
-  double* y = invd + kCholMN;                              // [N] right-hand side -> forward solution
+  double* colsum = Li + 16 * kCholMStride;                 // [7][16] per tile wave: column sums of the back substitution (room for N)
+  double* y = colsum + kCholMN;                            // [N] right-hand side -> forward solution
   double* x = y + kCholMN;                                 // [N] solution
   double* scratch = x + kCholMN;                           // [32]
-  double* colsum = scratch + 8;                            // [16] column sums of the back substitution
   double* okf = scratch + 31;
   const double* Sg = A.S + W.S_off;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1838,7 +1832,7 @@ __global__ __launch_bounds__(kCholMThreads) void ba_chol_mfma_kernel(BAArrays A,
     // ================================================================ panel wave
     __syncthreads();                                                   // tiles loaded, y staged
     __syncthreads();                                                   // prologue publish done: column 0, diagonal tiles 0 and 1
-    if (NT > 0) { if (!chol_tile_factor(Dall, Li, invd, y, lane) && lane == 0) *okf = 0.0; }
+    if (NT > 0) { if (!chol_tile_factor(Dall, Li, y, lane) && lane == 0) *okf = 0.0; }
     __syncthreads();                                                   // diagonal tile 0 factored
     for (int J = 0; J < NT; J++) {
       const double* Lp = Lp0 + (J & 1) * kCholMN * kCholMStride;
@@ -1861,60 +1855,90 @@ __global__ __launch_bounds__(kCholMThreads) void ba_chol_mfma_kernel(BAArrays A,
         for (int kk = 0; kk < 4; kk++) c = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[4 * kk], pa[4 * kk], c, 0, 0, 0);
 #pragma unroll
         for (int g = 0; g < 4; g++) Dg[(lrow + 4 * g) * kCholMStride + lcol] = c[g];
-        if (!chol_tile_factor(Dg, Li, invd + 16 * (J + 1), y + 16 * (J + 1), lane) && lane == 0) *okf = 0.0;
+        if (!chol_tile_factor(Dg, Li, y + 16 * (J + 1), lane) && lane == 0) *okf = 0.0;
       }
       __syncthreads();                                                 // (d) + lookahead done
     }
+    // back substitution L^T x = y: x_J = L_JJ^-T (y_J - s_J), s_J = the tile waves' column sums of L_IJ^T x_I (I > J); two barriers per tile
     for (int J = NT - 1; J >= 0; J--) {
-      if (lane < 16) colsum[lane] = 0.0;
-      __syncthreads();
-      __syncthreads();                                                 // column sums complete
-      const double* Dg = Dall + J * 16 * kCholMStride;
-      const int c = lane & 15;
-      double colc[16];                                                 // column c of L_JJ and 1/L_cc: no LDS inside the recurrence
+      __syncthreads();                                                 // column sums of J complete
+      const double* Di = Dall + J * 16 * kCholMStride;                 // L_JJ^-1
+      const int c = lane & 15, part = lane >> 4;
+      double xc = 0.0;
 #pragma unroll
-      for (int m = 0; m < 16; m++) colc[m] = Dg[m * kCholMStride + c];
-      const double ic = invd[16 * J + c];
-      double t = y[16 * J + c] - colsum[c], xc = 0.0;
+      for (int q = 0; q < 4; q++) {
+        const int r = 4 * part + q;
+        double sum = 0.0;
 #pragma unroll
-      for (int m = 15; m >= 0; m--) {
-        const double xm = readlane_f64(t * ic, m);                     // x_m = (y_m - sum_{m'>m} L[m'][m] x_m') / L[m][m]
-        if (c == m) xc = xm;
-        t -= colc[m] * xm;                                             // only lanes c < m use t again
+        for (int w = 0; w < kCholMTileWaves; w++) sum += colsum[w * 16 + r];
+        xc += Di[r * kCholMStride + c] * (y[16 * J + r] - sum);
       }
+      xc += __shfl_xor(xc, 16); xc += __shfl_xor(xc, 32);
       if (lane < 16) x[16 * J + c] = xc;
-      __syncthreads();
+      __syncthreads();                                                 // x_J ready
     }
   } else {
     // ================================================================ tile waves
-    // tile coordinates of this wavefront's slots (wave-uniform): tile t = slot * 7 + (wave - 1), t = I (I + 1) / 2 + K
+    // tile coordinates of this wavefront's slots (wave-uniform, integer-only: scalar registers).  Tile (I, K) belongs to tile wave
+    // (I + 2K) mod 7: the tiles of one COLUMN (I consecutive) and of one row spread evenly over the seven waves, so the
+    // L_IJ = A_IJ L_JJ^-T phase of a column is at most ceil(rows / 7) tiles deep (a round-robin over the packed index
+    // I (I + 1) / 2 + K puts a column on four of the seven waves only); <= 28 tiles per wave for 19 tile rows.
     int tI[kCholMSlots], tK[kCholMSlots];
-    const int n_tiles = NT * (NT + 1) / 2;
+    {
+      const int w0 = wave - 1;
+      int I = 0, K = (4 * w0) % 7;                                     // in row I: K = 4 (w0 - I) mod 7 (4 = 2^-1 mod 7), then every 7th column
 #pragma unroll
-    for (int sl = 0; sl < kCholMSlots; sl++) {
-      const int t = sl * kCholMTileWaves + (wave - 1);
-      int I = 0;                                                       // integer-only: stays in scalar registers
-      while ((I + 1) * (I + 2) / 2 <= t) I++;
-      tI[sl] = (t < n_tiles) ? I : -1;
-      tK[sl] = (t < n_tiles) ? t - I * (I + 1) / 2 : -1;
+      for (int sl = 0; sl < kCholMSlots; sl++) {
+        while (I < NT && K > I) { I++; K = (4 * (((w0 - I) % 7) + 7)) % 7; }
+        const bool valid = I < NT;
+        tI[sl] = valid ? I : -1;
+        tK[sl] = valid ? K : -1;
+        K += 7;
+      }
     }
-    // S -> registers (lower triangle; the padding rows/columns carry an identity so that L is the identity there)
+    // S -> registers (lower triangle; the padding rows/columns carry an identity so that L is the identity there).  Fourteen tiles
+    // (56 loads per lane) go out before the first value is touched: one slot at a time, the 28 slots were 28 dependent round
+    // trips to another XCD's L2 (18 us of a 160 us kernel).  Tile base in scalar registers, four per-lane offsets shared by all slots.
     v4d acc[kCholMSlots];
+    int offg[4];
 #pragma unroll
-    for (int sl = 0; sl < kCholMSlots; sl++) {
-      v4d v = {0.0, 0.0, 0.0, 0.0};
-      if (tI[sl] >= 0) {
-        const int col = 16 * tK[sl] + lcol;
+    for (int g = 0; g < 4; g++) offg[g] = (lrow + 4 * g) * n + lcol;
+    constexpr int kLoadGroup = 14;
 #pragma unroll
-        for (int g = 0; g < 4; g++) {
-          const int row = 16 * tI[sl] + lrow + 4 * g;
-          double e = 0.0;
-          if (row < n && col < n) { if (col <= row) e = Sg[(size_t)row * n + col]; }
-          else if (row == col) e = 1.0;
-          v[g] = e;
+    for (int s0 = 0; s0 < kCholMSlots; s0 += kLoadGroup) {
+#pragma unroll
+      for (int sl = s0; sl < s0 + kLoadGroup; sl++) {
+        v4d v = {0.0, 0.0, 0.0, 0.0};
+        if (tI[sl] >= 0) {
+          const double* base = Sg + (16 * tI[sl]) * n + 16 * tK[sl];
+          if (tK[sl] < tI[sl] && 16 * tI[sl] + 16 <= n) {               // interior tile (wave-uniform): scalar base + the shared lane offsets
+#pragma unroll
+            for (int g = 0; g < 4; g++) v[g] = base[offg[g]];
+          } else {
+            const int col = 16 * tK[sl] + lcol;
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+              const int row = 16 * tI[sl] + lrow + 4 * g;
+              const bool lower = row < n && col < n && col <= row;
+              v[g] = base[lower ? offg[g] : 0];
+            }
+          }
+        }
+        acc[sl] = v;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int sl = s0; sl < s0 + kLoadGroup; sl++) {
+        if (tI[sl] >= 0 && !(tK[sl] < tI[sl] && 16 * tI[sl] + 16 <= n)) {
+          const int col = 16 * tK[sl] + lcol;
+#pragma unroll
+          for (int g = 0; g < 4; g++) {
+            const int row = 16 * tI[sl] + lrow + 4 * g;
+            const bool inside = row < n && col < n, lower = inside && col <= row;
+            acc[sl][g] = lower ? acc[sl][g] : ((!inside && row == col) ? 1.0 : 0.0);
+          }
         }
       }
-      acc[sl] = v;
       __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
@@ -1983,7 +2007,6 @@ __global__ __launch_bounds__(kCholMThreads) void ba_chol_mfma_kernel(BAArrays A,
     }
     // back substitution L^T x = y: L lives in the register tiles, s_c = sum_{i below tile J} L[i][16J + c] x_i
     for (int J = NT - 1; J >= 0; J--) {
-      __syncthreads();                                                 // colsum cleared, x of the tiles below is final
       double part = 0.0; bool any = false;
 #pragma unroll
       for (int sl = 0; sl < kCholMSlots; sl++) {
@@ -1993,11 +2016,9 @@ __global__ __launch_bounds__(kCholMThreads) void ba_chol_mfma_kernel(BAArrays A,
           any = true;
         }
       }
-      if (any) {                                                       // wave-uniform
-        part += __shfl_xor(part, 16); part += __shfl_xor(part, 32);    // sum over the 4 row groups of a column
-        if (lane < 16) atomicAdd(&colsum[lane], part);
-      }
-      __syncthreads();
+      if (any) { part += __shfl_xor(part, 16); part += __shfl_xor(part, 32); }   // wave-uniform; sum over the 4 row groups of a column
+      if (lane < 16) colsum[(wave - 1) * 16 + lane] = part;            // one row of partial sums per tile wave: no atomics
+      __syncthreads();                                                 // column sums of J complete
       __syncthreads();                                                 // x_J ready
     }
   }
