@@ -55,6 +55,17 @@ for i in range(4):
     try: check_ba(opt.GlobalBundleAdjustment(w, 7), O.local_ba(w, protocol=1, its_round1=7), w)
     except AssertionError as e: bad += 1; print("gba mismatch", i, str(e)[:200])
 print("gba checked 4 mismatches", bad)
+# essential graphs, dense tile Cholesky and PCG vs the oracle's dense LDL^T (fixed scale: the two sides stop together)
+from test_gpu_posegraph import _check as check_pg
+bad = 0; n_pg = 0
+for i in range(8):
+    g = synth.make_essential_graph(700 + i, int(rng.integers(12, 260)))
+    o = O.optimize_essential_graph(g, bFixScale=True)
+    for solver in (1, 2):
+        n_pg += 1
+        try: check_pg(opt.OptimizeEssentialGraph(g, bFixScale=True, solver=solver), o, 2e-5)
+        except AssertionError as e: bad += 1; print("essential graph mismatch", i, g.sim3.shape[0], solver, str(e)[:200])
+print("essential graphs checked", n_pg, "mismatches", bad)
 bad = 0
 m = ORBmatcher(ctx, 0.8)
 for seed in range(100, 125):
