@@ -451,12 +451,12 @@ __device__ __forceinline__ double point_edge_blocks_closed(const BAWin& W, const
 }
 
 // grid (nl_pt, nW), block 512 = 8 wavefronts, BAWin::rounds tasks per wavefront; dynamic LDS: kAccCopies*n_free_max*27 doubles + 8 scratch.
-__global__ __launch_bounds__(kLinThreads, 4) void ba_linearize_pt_kernel(BAArrays A, const BAWin* __restrict__ wins, BAState* __restrict__ st) {
+__device__ __forceinline__ void ba_linearize_pt_body(const BAArrays& A, const BAWin* __restrict__ wins, BAState* __restrict__ st, const int bx) {   // bx: the workgroup's index along x
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const BAWin W = wins[blockIdx.y];
   BAState& S = st[blockIdx.y];
   if (S.phase != PH_RUN || !S.need_lin) return;
-  if ((int)blockIdx.x >= W.nl_pt) return;
+  if ((int)bx >= W.nl_pt) return;
   const int nacc = W.n_free * 27;
   double* acc_all = lds;                              // kAccCopies x [n_free][21 Hpp upper + 6 bp]
   double* scratch = lds + W.acc_copies * nacc;
@@ -469,7 +469,7 @@ __global__ __launch_bounds__(kLinThreads, 4) void ba_linearize_pt_kernel(BAArray
   const int lane = threadIdx.x & 63;
   double chi = 0.0, maxd = 0.0;
   for (int rnd = 0; rnd < W.rounds[0]; rnd++) {
-    const int ti = (blockIdx.x * W.rounds[0] + rnd) * (kLinThreads / 64) + (threadIdx.x >> 6);
+    const int ti = (bx * W.rounds[0] + rnd) * (kLinThreads / 64) + (threadIdx.x >> 6);
     if (ti >= W.n_ptasks) break;
     const PTask T = A.ptasks[W.ptask_off + ti];
     if (T.nl > 1) {
@@ -551,18 +551,19 @@ __global__ __launch_bounds__(kLinThreads, 4) void ba_linearize_pt_kernel(BAArray
   const double chi_t = block_sum(chi, scratch);
   const double max_t = block_max(maxd, scratch);
   if (threadIdx.x == 0) {
-    A.chi_part[W.part_off + blockIdx.x] = chi_t;
+    A.chi_part[W.part_off + bx] = chi_t;
     atomicMax(&S.maxdiag_bits, (unsigned long long)__double_as_longlong(max_t));
   }
   __syncthreads();
   // plain stores of this workgroup's camera partials; ba_hpp_reduce sums them in a fixed order (no global atomics)
-  double* dst = A.hpp_part + W.hpart_off + (size_t)(blockIdx.x) * nacc;
+  double* dst = A.hpp_part + W.hpart_off + (size_t)(bx) * nacc;
   for (int i = threadIdx.x; i < nacc; i += kLinThreads) {
     double v = 0.0;
     for (int q = 0; q < W.acc_copies; q++) v += acc_all[q * nacc + i];
     dst[i] = v;
   }
 }
+__global__ __launch_bounds__(kLinThreads, 4) void ba_linearize_pt_kernel(BAArrays A, const BAWin* __restrict__ wins, BAState* __restrict__ st) { ba_linearize_pt_body(A, wins, st, (int)blockIdx.x); }
 
 // W_e^T x_c = ws * Jp^T (Jc x_c) of one point edge with the Jacobians of the linearisation point
 __device__ __forceinline__ void point_edge_wtx(const BAArrays& A, const BAWin& W, int cur, int e, uint8_t fl, int c, const Vec3& X, const double* xp, double* t) {
@@ -614,12 +615,12 @@ __device__ __forceinline__ double point_backsub(const double* V, double lambda, 
 }
 
 // grid (nt_pt, nW), block 256 = 4 wavefronts, BAWin::rounds tasks per wavefront; dynamic LDS: 8 + 14 n_cams + 6 n_free doubles
-__global__ __launch_bounds__(kLmThreads) void ba_backsub_pt_kernel(BAArrays A, const BAWin* __restrict__ wins, const BAState* __restrict__ st) {
+__device__ __forceinline__ void ba_backsub_pt_body(const BAArrays& A, const BAWin* __restrict__ wins, const BAState* __restrict__ st, const int bx) {   // bx: the workgroup's index along x
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const BAWin W = wins[blockIdx.y];
   const BAState& S = st[blockIdx.y];
   if (S.phase != PH_RUN) return;
-  if ((int)blockIdx.x >= W.nt_pt) return;
+  if ((int)bx >= W.nt_pt) return;
   const int cur = S.cur, nxt = cur ^ 1;
   const double lambda = S.lambda;
   const double* xp = A.xp + W.x_off;
@@ -638,7 +639,7 @@ __global__ __launch_bounds__(kLmThreads) void ba_backsub_pt_kernel(BAArrays A, c
   const int lane = threadIdx.x & 63;
   double chi = 0.0, sc = 0.0;
   for (int rnd = 0; rnd < W.rounds[2]; rnd++) {
-    const int ti = (blockIdx.x * W.rounds[2] + rnd) * 4 + (threadIdx.x >> 6);
+    const int ti = (bx * W.rounds[2] + rnd) * 4 + (threadIdx.x >> 6);
     if (ti >= W.n_ptasks) break;
     const PTask T = A.ptasks[W.ptask_off + ti];
     if (T.nl > 1) {
@@ -731,8 +732,9 @@ __global__ __launch_bounds__(kLmThreads) void ba_backsub_pt_kernel(BAArrays A, c
   }
   const double chi_t = block_sum(chi, scratch);
   const double sc_t = block_sum(sc, scratch);
-  if (threadIdx.x == 0) { A.chi_part2[W.part_off + blockIdx.x] = chi_t; A.scale_part[W.part_off + blockIdx.x] = sc_t; }
+  if (threadIdx.x == 0) { A.chi_part2[W.part_off + bx] = chi_t; A.scale_part[W.part_off + bx] = sc_t; }
 }
+__global__ __launch_bounds__(kLmThreads) void ba_backsub_pt_kernel(BAArrays A, const BAWin* __restrict__ wins, const BAState* __restrict__ st) { ba_backsub_pt_body(A, wins, st, (int)blockIdx.x); }
 
 // ================================================================== line landmarks: one lane per (line, KF) OBSERVATION
 // Same scheme as the point kernels with the observation as the unit: a lane linearises the left and (if present) right image
@@ -798,12 +800,12 @@ __device__ __forceinline__ double line_obs_linearize(const BAArrays& A, const BA
 }
 
 // grid (nl_ln, nW), block 512 = 8 wavefronts, BAWin::rounds tasks per wavefront; dynamic LDS: kAccCopies*n_free_max*27 doubles + 8 scratch.
-__global__ __launch_bounds__(kLinThreads) void ba_linearize_ln_kernel(BAArrays A, const BAWin* __restrict__ wins, BAState* __restrict__ st) {
+__device__ __forceinline__ void ba_linearize_ln_body(const BAArrays& A, const BAWin* __restrict__ wins, BAState* __restrict__ st, const int bx) {   // bx: the workgroup's index along x
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const BAWin W = wins[blockIdx.y];
   BAState& S = st[blockIdx.y];
   if (S.phase != PH_RUN || !S.need_lin) return;
-  if ((int)blockIdx.x >= W.nl_ln) return;
+  if ((int)bx >= W.nl_ln) return;
   const int nacc = W.n_free * 27;
   double* acc_all = lds;                              // kAccCopies x [n_free][21 Hpp upper + 6 bp]
   double* scratch = lds + W.acc_copies * nacc;
@@ -814,7 +816,7 @@ __global__ __launch_bounds__(kLinThreads) void ba_linearize_ln_kernel(BAArrays A
   const int lane = threadIdx.x & 63;
   double chi = 0.0, maxd = 0.0;
   for (int rnd = 0; rnd < W.rounds[1]; rnd++) {
-    const int ti = (blockIdx.x * W.rounds[1] + rnd) * (kLinThreads / 64) + (threadIdx.x >> 6);
+    const int ti = (bx * W.rounds[1] + rnd) * (kLinThreads / 64) + (threadIdx.x >> 6);
     if (ti >= W.n_ltasks) break;
     const PTask T = A.ltasks[W.ltask_off + ti];
     double hb[14];
@@ -855,18 +857,19 @@ __global__ __launch_bounds__(kLinThreads) void ba_linearize_ln_kernel(BAArrays A
   const double chi_t = block_sum(chi, scratch);
   const double max_t = block_max(maxd, scratch);
   if (threadIdx.x == 0) {
-    A.chi_part[W.part_off + W.nl_pt + blockIdx.x] = chi_t;
+    A.chi_part[W.part_off + W.nl_pt + bx] = chi_t;
     atomicMax(&S.maxdiag_bits, (unsigned long long)__double_as_longlong(max_t));
   }
   __syncthreads();
   // plain stores of this workgroup's camera partials; ba_hpp_reduce sums them in a fixed order (no global atomics)
-  double* dst = A.hpp_part + W.hpart_off + (size_t)(W.nl_pt + blockIdx.x) * nacc;
+  double* dst = A.hpp_part + W.hpart_off + (size_t)(W.nl_pt + bx) * nacc;
   for (int i = threadIdx.x; i < nacc; i += kLinThreads) {
     double v = 0.0;
     for (int q = 0; q < W.acc_copies; q++) v += acc_all[q * nacc + i];
     dst[i] = v;
   }
 }
+__global__ __launch_bounds__(kLinThreads) void ba_linearize_ln_kernel(BAArrays A, const BAWin* __restrict__ wins, BAState* __restrict__ st) { ba_linearize_ln_body(A, wins, st, (int)blockIdx.x); }
 
 __device__ __forceinline__ void line_obs_wtx(const BAArrays& A, const BAWin& W, int o, int c, const double* xp, double* t) {
   const double* Wb = A.lo_W + (size_t)o * 24;              // zero when both image edges are inactive
@@ -912,19 +915,19 @@ __device__ __forceinline__ double line_backsub(const double* V, double lambda, c
 }
 
 // grid (nt_ln, nW), block 256 = 4 wavefronts, BAWin::rounds tasks per wavefront
-__global__ __launch_bounds__(kLmThreads) void ba_backsub_ln_kernel(BAArrays A, const BAWin* __restrict__ wins, const BAState* __restrict__ st) {
+__device__ __forceinline__ void ba_backsub_ln_body(const BAArrays& A, const BAWin* __restrict__ wins, const BAState* __restrict__ st, const int bx) {   // bx: the workgroup's index along x
   __shared__ double scratch[8];
   const BAWin W = wins[blockIdx.y];
   const BAState& S = st[blockIdx.y];
   if (S.phase != PH_RUN) return;
-  if ((int)blockIdx.x >= W.nt_ln) return;
+  if ((int)bx >= W.nt_ln) return;
   const int cur = S.cur, nxt = cur ^ 1;
   const double lambda = S.lambda;
   const double* xp = A.xp + W.x_off;
   const int lane = threadIdx.x & 63;
   double chi = 0.0, sc = 0.0;
   for (int rnd = 0; rnd < W.rounds[3]; rnd++) {
-    const int ti = (blockIdx.x * W.rounds[3] + rnd) * 4 + (threadIdx.x >> 6);
+    const int ti = (bx * W.rounds[3] + rnd) * 4 + (threadIdx.x >> 6);
     if (ti >= W.n_ltasks) break;
     const PTask T = A.ltasks[W.ltask_off + ti];
     if (T.nl > 1) {
@@ -975,7 +978,20 @@ __global__ __launch_bounds__(kLmThreads) void ba_backsub_ln_kernel(BAArrays A, c
   }
   const double chi_t = block_sum(chi, scratch);
   const double sc_t = block_sum(sc, scratch);
-  if (threadIdx.x == 0) { A.chi_part2[W.part_off + W.nt_pt + blockIdx.x] = chi_t; A.scale_part[W.part_off + W.nt_pt + blockIdx.x] = sc_t; }
+  if (threadIdx.x == 0) { A.chi_part2[W.part_off + W.nt_pt + bx] = chi_t; A.scale_part[W.part_off + W.nt_pt + bx] = sc_t; }
+}
+__global__ __launch_bounds__(kLmThreads) void ba_backsub_ln_kernel(BAArrays A, const BAWin* __restrict__ wins, const BAState* __restrict__ st) { ba_backsub_ln_body(A, wins, st, (int)blockIdx.x); }
+
+// Point and line landmarks in one launch, for batches too small to fill the GPU (a single window above all): there the two
+// kernels of a pair are dependent launches of 8-16 us each on idle hardware.  Not for large batches: the fused kernel gets the
+// register budget of the line body (223 VGPRs), which would halve the occupancy of the point body.
+__global__ __launch_bounds__(kLinThreads) void ba_linearize_both_kernel(BAArrays A, const BAWin* __restrict__ wins, BAState* __restrict__ st, int n_pt_blocks) {
+  if ((int)blockIdx.x < n_pt_blocks) ba_linearize_pt_body(A, wins, st, (int)blockIdx.x);
+  else ba_linearize_ln_body(A, wins, st, (int)blockIdx.x - n_pt_blocks);
+}
+__global__ __launch_bounds__(kLmThreads) void ba_backsub_both_kernel(BAArrays A, const BAWin* __restrict__ wins, const BAState* __restrict__ st, int n_pt_blocks) {
+  if ((int)blockIdx.x < n_pt_blocks) ba_backsub_pt_body(A, wins, st, (int)blockIdx.x);
+  else ba_backsub_ln_body(A, wins, st, (int)blockIdx.x - n_pt_blocks);
 }
 
 // Hpp / b_p = sum over the linearise workgroups' partials, fixed order.  grid (ceil(n_free_max*27 / 256), nW)
@@ -1241,6 +1257,26 @@ __global__ __launch_bounds__(64) void ba_schur_items_kernel(BAArrays A, const BA
   if ((int)blockIdx.x >= count) return;
   const SChunk C = A.sg_chunks[first + blockIdx.x];
   schur_chunk_wave<D>(A, W, C, S.lambda, S.cur, lds);
+}
+
+// Point and line chunks in ONE launch: grid (n_pt_blocks + max line chunks, nW).  Same register budget (196 / 182 VGPRs, two
+// waves per SIMD either way), and the line chunks fill the tail of the point chunks instead of waiting for it - for a single
+// window the two kernels were two dependent 17 us launches on an otherwise idle GPU.
+__global__ __launch_bounds__(64) void ba_schur_items_both_kernel(BAArrays A, const BAWin* __restrict__ wins, const BAState* __restrict__ st, int n_pt_blocks) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const BAWin W = wins[blockIdx.y];
+  const BAState& S = st[blockIdx.y];
+  if (S.phase != PH_RUN) return;
+  if ((int)blockIdx.x < n_pt_blocks) {
+    if ((int)blockIdx.x >= W.n_items_pt) return;
+    const SChunk C = A.sg_chunks[W.item_off + blockIdx.x];
+    schur_chunk_wave<3>(A, W, C, S.lambda, S.cur, lds);
+  } else {
+    const int i = (int)blockIdx.x - n_pt_blocks;
+    if (i >= W.n_items - W.n_items_pt) return;
+    const SChunk C = A.sg_chunks[W.item_off + W.n_items_pt + i];
+    schur_chunk_wave<4>(A, W, C, S.lambda, S.cur, lds);
+  }
 }
 
 // grid (ceil(nblk_max * 6 / 256), nW): lane <-> one row of one lower 6x6 block of S.  S_ij = [i == j](Hpp_i + lambda I)
