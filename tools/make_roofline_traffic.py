@@ -6,10 +6,10 @@ HBM-side bytes per launch of each kernel family = sum over its kernels of the pe
 """
 import json, re, sys
 
-FAMILIES = {"ba_linearize": ("ba_linearize_pt", "ba_linearize_ln", "ba_hpp_reduce", "ba_begin"),
-            "ba_schur": ("ba_schur_items_kernel<3>", "ba_schur_items_kernel<4>", "ba_schur_reduce", "ba_symmetrize"),
+FAMILIES = {"ba_linearize": ("ba_linearize_", "ba_hpp_reduce", "ba_begin"),
+            "ba_schur": ("ba_schur_items", "ba_schur_reduce", "ba_symmetrize"),
             "ba_pcg": ("ba_chol_mfma", "ba_chol_kernel", "ba_pcg"),
-            "ba_backsub": ("ba_backsub_pt", "ba_backsub_ln"),
+            "ba_backsub": ("ba_backsub_",),
             "ba_control": ("ba_control",)}
 
 
