@@ -1932,14 +1932,14 @@ __global__ __launch_bounds__(kCholMThreads) void ba_chol_mfma_kernel(BAArrays A,
         K += 7;
       }
     }
-    // S -> registers (lower triangle; the padding rows/columns carry an identity so that L is the identity there).  Fourteen tiles
-    // (56 loads per lane) go out before the first value is touched: one slot at a time, the 28 slots were 28 dependent round
+    // S -> registers (lower triangle; the padding rows/columns carry an identity so that L is the identity there).  All 28 tiles
+    // (112 loads per lane, the hardware queues what it cannot keep in flight) go out before the first value is touched: one slot at a time, the 28 slots were 28 dependent round
     // trips to another XCD's L2 (18 us of a 160 us kernel).  Tile base in scalar registers, four per-lane offsets shared by all slots.
     v4d acc[kCholMSlots];
     int offg[4];
 #pragma unroll
     for (int g = 0; g < 4; g++) offg[g] = (lrow + 4 * g) * n + lcol;
-    constexpr int kLoadGroup = 14;
+    constexpr int kLoadGroup = 28;
 #pragma unroll
     for (int s0 = 0; s0 < kCholMSlots; s0 += kLoadGroup) {
 #pragma unroll
