@@ -185,6 +185,8 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 
 def product_library_path() -> str:
+    if os.environ.get("LLD_AMD_LIB"):          # kernel experiments: an alternative build of the same ABI
+        return os.environ["LLD_AMD_LIB"]
     return os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "liblld_amd.so")
 
 

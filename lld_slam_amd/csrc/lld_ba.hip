@@ -35,7 +35,7 @@ struct lld_ba_batch {
   int* d_counters = nullptr; int* h_counters = nullptr;               // device / pinned, 4 ints per group
   int max_lblocks = 0, max_items_pt = 0, max_items_ln = 0, max_free = 0, max_cams = 0, max_blk = 0, acc_copies = 4;
   bool pcg_multi = false;
-  size_t schur_lds[2] = {0, 0};
+  size_t schur_lds[2] = {0, 0}; size_t schur_wide_lds = 0;
   int chunk_landmarks = 32;
   size_t S_total = 0, x_total = 0;
   size_t rec_stride = 0;
@@ -100,7 +100,7 @@ struct ChunkStage {
   std::vector<SChunk> chunks;
   std::vector<int> sg_lm, sg_tab, sg_cams;
   std::vector<int> blk_key, blk_val, cam_key, cam_val;     // (block | camera, partial index [*4 + mode]) in generation order
-  size_t n_part = 0, n_cpart = 0, lds_need = 0;
+  size_t n_part = 0, n_cpart = 0, lds_need = 0, wide_lds_need = 0;
 };
 
 struct WinStage {
@@ -251,13 +251,8 @@ void stage_chunks(const lld_ba_window& w, int D, const WinBases& b, int chunk_la
       }
     }
     out.n_part += (size_t)C.k * (C.k + 1) / 2; out.n_cpart += C.k;
-    {   // LDS the wavefront needs: staged sub-batch (W, Y, b_l) or the interleave reduction area, whichever is larger
-      const int WS = D == 3 ? 18 : 26, np = C.k * (C.k + 1) / 2, per_lm = 2 * C.k * WS + D;
-      int NBc = kSwLdsDoubles / per_lm; if (NBc > 64 / C.k) NBc = 64 / C.k; if (NBc < 1) NBc = 1;
-      const int units = std::min(np, 21) * 3, q = 64 / units;
-      const size_t need = std::max((size_t)NBc * per_lm, (size_t)(q - 1) * units * 14) * sizeof(double);
-      out.lds_need = std::max(out.lds_need, need);
-    }
+    if (C.k > kSchurWideK) out.wide_lds_need = std::max(out.wide_lds_need, (size_t)schur_lds_doubles(C.k, D) * sizeof(double));
+    else out.lds_need = std::max(out.lds_need, (size_t)schur_lds_doubles(C.k, D) * sizeof(double));   // two staged sub-batches
     out.chunks.push_back(C);
     i0 = i1;
   }
@@ -352,6 +347,7 @@ static int ba_batch_create_impl(lld_ctx* ctx, int n_windows, const lld_ba_window
   B->h_wins.resize(n_windows);
   // landmarks per Schur chunk: long chunks mean fewer atomics into S, short ones more lanes for small batches
   B->chunk_landmarks = n_windows >= 64 ? 128 : (n_windows >= 8 ? 64 : 32);
+  if (const char* e = std::getenv("LLD_BA_CHUNK")) { const int v = std::atoi(e); if (v >= 1 && v <= 4096) B->chunk_landmarks = v; }   // experiments
   std::vector<WinBases> bases(n_windows + 1);
   {
     WinBases b{};
@@ -448,6 +444,8 @@ static int ba_batch_create_impl(lld_ctx* ctx, int n_windows, const lld_ba_window
       q.part += S.cs[0].n_part + S.cs[1].n_part; q.cpart += S.cs[0].n_cpart + S.cs[1].n_cpart;
       if (q.part * 4 > 0x7fffffffull || q.tab > 0x7fffffffull) { delete B; return LLD_ERR_UNSUPPORTED; }
       for (int d = 0; d < 2; d++) B->schur_lds[d] = std::max(B->schur_lds[d], S.cs[d].lds_need);
+      for (int d = 0; d < 2; d++) B->schur_wide_lds = std::max(B->schur_wide_lds, S.cs[d].wide_lds_need);
+      if (B->schur_wide_lds > 64 * 1024) { delete B; return LLD_ERR_UNSUPPORTED; }       // a landmark with > ~450 free observations
       max_blk = std::max(max_blk, W.n_free * (W.n_free + 1) / 2);
       B->max_items_pt = std::max(B->max_items_pt, W.n_items_pt); B->max_items_ln = std::max(B->max_items_ln, W.n_items - W.n_items_pt);
       B->max_lblocks = std::max(B->max_lblocks, W.nb_pt + W.nb_ln);
@@ -651,11 +649,12 @@ int lld_ba_batch_solve(lld_ba_batch* B, volatile const int* abort_flag) {
     LLD_HIP_TRY(hipEventRecord(G.ev[1], st));
     static const bool split_schur = std::getenv("LLD_BA_SPLIT_SCHUR") != nullptr;             // experiments: the two launches of before
     if (split_schur) {
-      if (G.max_items_pt > 0) hipLaunchKernelGGL(ba_schur_items_kernel<3>, dim3(G.max_items_pt, nw), dim3(64), B->schur_lds[0], st, A, dw, ds);
-      if (G.max_items_ln > 0) hipLaunchKernelGGL(ba_schur_items_kernel<4>, dim3(G.max_items_ln, nw), dim3(64), B->schur_lds[1], st, A, dw, ds);
+      if (G.max_items_pt > 0) hipLaunchKernelGGL(ba_schur_items_kernel<3>, dim3(G.max_items_pt, nw), dim3(kSchurThreads), B->schur_lds[0], st, A, dw, ds);
+      if (G.max_items_ln > 0) hipLaunchKernelGGL(ba_schur_items_kernel<4>, dim3(G.max_items_ln, nw), dim3(kSchurThreads), B->schur_lds[1], st, A, dw, ds);
     } else if (G.max_items_pt + G.max_items_ln > 0) {
-      hipLaunchKernelGGL(ba_schur_items_both_kernel, dim3(G.max_items_pt + G.max_items_ln, nw), dim3(64), std::max(B->schur_lds[0], B->schur_lds[1]), st, A, dw, ds, G.max_items_pt);
+      hipLaunchKernelGGL(ba_schur_items_both_kernel, dim3(G.max_items_pt + G.max_items_ln, nw), dim3(kSchurThreads), std::max(B->schur_lds[0], B->schur_lds[1]), st, A, dw, ds, G.max_items_pt);
     }
+    if (B->schur_wide_lds > 0) hipLaunchKernelGGL(ba_schur_wide_kernel, dim3(G.max_items_pt + G.max_items_ln, nw), dim3(kSchurWideThreads), B->schur_wide_lds, st, A, dw, ds);
     hipLaunchKernelGGL(ba_schur_reduce_kernel, dim3((std::max(1, G.max_blk) * 6 + 255) / 256 + 1, nw), dim3(256), 0, st, A, dw, ds);
     if (B->params.reduced_solver == 1 || B->pcg_multi) hipLaunchKernelGGL(ba_symmetrize_kernel, dim3(B->pcg_multi ? 256 : 16, nw), dim3(256), 0, st, A, dw, ds);
     LLD_HIP_TRY(hipEventRecord(G.ev[2], st));

@@ -31,7 +31,8 @@ namespace lldba {
 using namespace lld;
 
 constexpr int kLmThreads = 256;        // landmark-parallel kernels: one lane per landmark
-constexpr int kSchurThreads = 128;    // item-parallel Schur kernel: one lane per (landmark chunk, camera-slot pair)
+constexpr int kSchurThreads = 64;     // Schur kernel: one wavefront per landmark chunk
+constexpr int kSchurWideThreads = 256; // ... and its variant for landmarks with more than 64 free observations
 constexpr int kPcgThreads = 1024;
 constexpr int kCtlThreads = 64;
 constexpr int kLinThreads = 512;        // linearise kernels: 8 tasks per workgroup (fewer per-workgroup Hpp partials to reduce)
@@ -1054,24 +1055,167 @@ __global__ __launch_bounds__(kCtlThreads) void ba_begin_kernel(BAArrays A, const
 }
 
 // ================================================================== Schur complement
-// (1) ba_schur_items: one wavefront per chunk of landmarks that share one camera set.  For every landmark:
-//     Dinv = (Hll + lambda I)^-1 (setLambda + the inverse of block_solver.hpp:391), Y_a = W_a Dinv, and for every
-//     camera-slot pair sa <= sb the 6x6 product Y_a W_b^T (block_solver.hpp:395-428) is accumulated in registers over the
-//     whole chunk; for sa == sb also c_a += Y_a b_l.  The chunk's partials are stored once (plain stores).
+// (1) ba_schur_items: one wavefront per chunk of landmarks that share one set of free cameras.  With
+//     Hll + lambda I = L L^T (setLambda + the inverse of block_solver.hpp:391 folded into a Cholesky factor) and Z_a = W_a L^-T,
+//     the reference's  Y_a W_b^T = W_a (Hll + lambda I)^-1 W_b^T  (block_solver.hpp:395-428) is Z_a Z_b^T and
+//     Y_a b_l = Z_a (L^-1 b_l).  The chunk is swept in sub-batches of up to 64/k landmarks that are staged through LDS:
+//       stage    lane (landmark, slot) rebuilds its 6xD Hpl block (points: closed form from pose, point and weight; lines: the
+//                stored block), factors Hll + lambda I, and leaves Z (and t = L^-1 b_l, once per landmark) in LDS.  Its global
+//                loads run ahead: indices two sub-batches ahead, landmark data one.
+//       product  lane (slot pair (a,b), interleave) keeps the WHOLE 6x6 product Z_a Z_b^T of its pair in 36 registers over the
+//                chunk: 36 LDS doubles (16-byte reads) per 36*D FMAs.  (An fp64 FMA of a wavefront takes 4 cycles on one of the four
+//                SIMDs, the CU's single LDS pipe moves 32 doubles per cycle with ds_read_b128 and 16 with ds_read2_b64: the 2-row
+//                blocks this replaces read 24 doubles per 12*D FMAs through ds_read2_b64 and ran at the speed of the LDS pipe.)
+//     The chunk's partials are stored once (plain stores).
 // (2) ba_schur_reduce: S = blockdiag(Hpp + lambda I) - sum of partials, bschur = b_p - sum c, through a host-built CSR
 //     (lower block -> contributing partials).  Only the LOWER block triangle is produced.  No atomics, fixed order.
-// One wavefront per chunk.  The chunk is swept in sub-batches of up to 8 landmarks that are staged through LDS:
-//   A  lanes copy the sub-batch's Hpl blocks W (contiguous 144/192-B runs) into LDS, zero for inactive landmarks;
-//   B  lane j inverts Hll_j + lambda I once per landmark;
-//   C  lane (j, slot) forms Y = W Dinv once per (landmark, camera slot);
-//   D  lane (pair p = (sa,sb), row pair h) accumulates two rows of Y_a W_b^T over the landmarks in registers
-//      (21 pairs x 3 row pairs = 63 lanes for a point seen by 6 cameras).
-// After the last sub-batch each lane stores its 12 partial sums once.
-constexpr int kSwLdsDoubles = 2304;        // LDS budget per wavefront for the staged sub-batch (18 KiB)
+constexpr int kSchurWideK = 64;            // more free observations of one landmark than this: schur_chunk_wide
+
+// sub-batch geometry shared by host (LDS size) and device: landmarks per sub-batch, LDS doubles
+__host__ __device__ inline int schur_nb(int k) {
+  int NB = 64 / k; if (NB < 1) NB = 1;
+  const int np = k * (k + 1) / 2, units = np < 64 ? np : 64, q = 64 / units;
+  if (NB >= q) NB -= NB % q;               // every interleave lane gets the same number of landmarks
+  return NB;
+}
+__host__ __device__ inline int schur_lds_doubles(int k, int D) {
+  const int WS = (D == 3) ? 18 : 26;
+  return k > kSchurWideK ? k * WS + D + 1 : ((schur_nb(k) * (k * WS + D) + 1) & ~1);
+}
+
+// 1 / sqrt(d): v_rsq_f64 seed + two Newton steps (the library sqrt and divide are ~45 dependent instructions; the result is within an
+// ulp or two and L L^T = Hll + lambda I to rounding either way)
+__device__ __forceinline__ double rsqrt_nr(double d) {
+  double y = __builtin_amdgcn_rsq(d);
+  y = y * (1.5 - (0.5 * d) * (y * y));
+  y = y * (1.5 - (0.5 * d) * (y * y));
+  return y;
+}
+// lower Cholesky factor of (packed upper U) + lambda I, D x D: L packed row-major lower (L[i][j] at i(i+1)/2 + j, diagonal entries
+// unused), idiag[i] = 1 / L[i][i]
+template <int D>
+__device__ __forceinline__ void chol_packed(const double* U, double lambda, double* L, double* idiag) {
+  double F[D][D];
+  int kk = 0;
+#pragma unroll
+  for (int i = 0; i < D; i++)
+#pragma unroll
+    for (int j = i; j < D; j++) { F[j][i] = U[kk++]; }
+#pragma unroll
+  for (int i = 0; i < D; i++) F[i][i] += lambda;
+#pragma unroll
+  for (int j = 0; j < D; j++) {
+    double d = F[j][j];
+#pragma unroll
+    for (int m = 0; m < j; m++) d -= L[j * (j + 1) / 2 + m] * L[j * (j + 1) / 2 + m];
+    const double inv = rsqrt_nr(d);
+    idiag[j] = inv;
+#pragma unroll
+    for (int i = j + 1; i < D; i++) {
+      double sacc = F[i][j];
+#pragma unroll
+      for (int m = 0; m < j; m++) sacc -= L[i * (i + 1) / 2 + m] * L[j * (j + 1) / 2 + m];
+      L[i * (i + 1) / 2 + j] = sacc * inv;
+    }
+  }
+}
+// factor + stage one (landmark, slot): Z = W L^-T into zl (6 x D), t = L^-1 b_l into tl
+template <int D>
+__device__ __forceinline__ void schur_stage_one(bool a, const double* v, double lambda, const double* w, double* zl, double* tl, bool write_t) {
+  constexpr int HU = (D == 3) ? 6 : 10;
+  double L[D * (D + 1) / 2], idg[D];
+  if (a) chol_packed<D>(v, lambda, L, idg);
+  else {                                                    // inactive landmark: contributes nothing
+#pragma unroll
+    for (int i = 0; i < D * (D + 1) / 2; i++) L[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < D; i++) idg[i] = 0.0;
+  }
+  double z[6 * D];
+#pragma unroll
+  for (int r = 0; r < 6; r++)
+#pragma unroll
+    for (int c = 0; c < D; c++) {
+      double sacc = w[r * D + c];
+#pragma unroll
+      for (int m = 0; m < c; m++) sacc -= z[r * D + m] * L[c * (c + 1) / 2 + m];
+      z[r * D + c] = sacc * idg[c];
+    }
+#pragma unroll
+  for (int i = 0; i < 6 * D; i += 2) *reinterpret_cast<double2*>(zl + i) = make_double2(z[i], z[i + 1]);
+  if (write_t) {
+    double t[D];
+#pragma unroll
+    for (int c = 0; c < D; c++) {
+      double sacc = v[HU + c];
+#pragma unroll
+      for (int m = 0; m < c; m++) sacc -= t[m] * L[c * (c + 1) / 2 + m];
+      t[c] = sacc * idg[c];
+    }
+#pragma unroll
+    for (int c = 0; c < D; c++) tl[c] = t[c];
+  }
+}
+
+// A landmark with more than kSchurWideK free observations (global BA of a long track): no pipelining and no register accumulators -
+// the whole workgroup stages the landmark's k blocks, then thread t adds the products of the pairs t, t + 256, ... into the chunk's
+// partials in HBM (one writer per pair, landmarks in order: deterministic).  Such chunks hold a handful of landmarks.
+template <int D>
+__device__ __forceinline__ void schur_chunk_wide(const BAArrays& A, const BAWin& W, const SChunk& C, double lambda, int cur, double* lds) {
+  constexpr int VN = (D == 3) ? 9 : 14, WN = 6 * D, WS = (D == 3) ? 18 : 26;
+  const double* __restrict__ Vbase = (D == 3) ? A.pt_V : A.ln_V;
+  const uint8_t* __restrict__ act = (D == 3) ? A.pt_active : A.ln_active;
+  const int k = C.k, np = k * (k + 1) / 2;
+  double* Zl = lds; double* tl = lds + ((k * WS + 1) & ~1);
+  for (int t0 = 0; t0 < C.n_lm; t0++) {
+    const int g = A.sg_lm[C.lm_off + t0];
+    const bool a = act[g] != 0;
+    double v[VN];
+#pragma unroll
+    for (int i = 0; i < VN; i++) v[i] = Vbase[(size_t)g * VN + i];
+    __syncthreads();
+    for (int sl = threadIdx.x; sl < k; sl += kSchurWideThreads) {
+      const int id = A.sg_tab[C.tab_off + (size_t)t0 * k + sl];
+      double w[WN];
+      if constexpr (D == 3) {
+        const Pose Ts = load_cam(A, cur, W.cam_off + A.sg_cams[C.cams_off + sl]);
+        point_hpl_closed(W.cam, Ts, quat_rotation(Ts.q), load_pt(A, cur, g), (A.pe_flags[id] & EF_STEREO) != 0, A.pe_ws[id], w);
+      } else {
+#pragma unroll
+        for (int i = 0; i < WN; i++) w[i] = A.lo_W[(size_t)id * WN + i];
+      }
+      schur_stage_one<D>(a, v, lambda, w, Zl + sl * WS, tl, sl == 0);
+    }
+    __syncthreads();
+    for (int pr = threadIdx.x; pr < np; pr += kSchurWideThreads) {
+      int sa = 0, rem = pr;
+      while (rem >= k - sa) { rem -= k - sa; sa++; }
+      const int sb = sa + rem;
+      const double* za = Zl + sa * WS; const double* zb = Zl + sb * WS;
+      double* dst = A.sp_part + (size_t)(C.part_off + pr) * 36;
+      for (int r = 0; r < 6; r++)
+        for (int c = 0; c < 6; c++) {
+          double sacc = t0 == 0 ? 0.0 : dst[r * 6 + c];
+#pragma unroll
+          for (int m = 0; m < D; m++) sacc = fma(za[r * D + m], zb[c * D + m], sacc);
+          dst[r * 6 + c] = sacc;
+        }
+      if (sa == sb) {
+        double* cd = A.sp_cpart + (size_t)(C.cpart_off + sa) * 6;
+        for (int r = 0; r < 6; r++) {
+          double sacc = t0 == 0 ? 0.0 : cd[r];
+#pragma unroll
+          for (int m = 0; m < D; m++) sacc = fma(za[r * D + m], tl[m], sacc);
+          cd[r] = sacc;
+        }
+      }
+    }
+  }
+}
 
 template <int D>
 __device__ __forceinline__ void schur_chunk_wave(const BAArrays& A, const BAWin& W, const SChunk& C, double lambda, int cur, double* lds) {
-  constexpr int VN = (D == 3) ? 9 : 14, HU = (D == 3) ? 6 : 10, WN = 6 * D, DD = D * D;
+  constexpr int VN = (D == 3) ? 9 : 14, WN = 6 * D;
   // LDS stride of a staged 6xD block: 144 B for points (conflict-free as is); 192 B would put slots 0 and 4 of a line on the
   // same banks, so line blocks are padded to 208 B (still 16-B aligned)
   constexpr int WS = (D == 3) ? 18 : 26;
@@ -1079,56 +1223,47 @@ __device__ __forceinline__ void schur_chunk_wave(const BAArrays& A, const BAWin&
   const uint8_t* __restrict__ act = (D == 3) ? A.pt_active : A.ln_active;
   const int lane = threadIdx.x;
   const int k = C.k, np = k * (k + 1) / 2;
-  const int per_lm = 2 * k * WS + D;
-  int NB = kSwLdsDoubles / per_lm;
-  if (NB > 64 / k) NB = 64 / k;          // one lane per (landmark, slot) in the staging phase
-  if (NB < 1) NB = 1;
-  { const int u0 = (np < 21 ? np : 21) * 3, q0 = 64 / u0; if (NB > q0) NB -= NB % q0; }   // every interleave lane gets the same number of landmarks
-  double* Wl = lds;
-  double* Yl = Wl + NB * k * WS;
-  double* bll = Yl + NB * k * WS;
+  const int NB = schur_nb(k);
+  double* Zl = lds;
+  double* tl = lds + NB * k * WS;
   const int* __restrict__ lm = A.sg_lm + C.lm_off;
   const int* __restrict__ tab = A.sg_tab + C.tab_off;
-  // lane <-> (slot pair p, row pair h of the 6x6 product, interleave qq): 21 pairs x 3 row pairs = 63 lanes for a point
-  // seen by 6 cameras; 12 accumulators per lane keep the kernel at ~4 waves per SIMD.
-  for (int pass0 = 0; pass0 < np; pass0 += 21) {
-    const int npp = (np - pass0) < 21 ? (np - pass0) : 21;
-    const int units = npp * 3;
-    const int q = 64 / units;
-    const int u = lane % units, qq = lane / units;
-    const int pl = u / 3, h = u - pl * 3;
+  // stage lane <-> (landmark ej, slot esl) of a sub-batch
+  const int ej = lane / k, esl = lane - ej * k;
+  const bool stager = lane < NB * k;
+  for (int pass0 = 0; pass0 < np; pass0 += 64) {
+    const int units = (np - pass0) < 64 ? (np - pass0) : 64;        // slot pairs of this pass
+    const int q = 64 / units;                                       // landmarks worked on at a time
+    const int pl = lane % units, qq = lane / units;
     const bool on = qq < q;
     int sa = 0, rem = pass0 + pl;
     while (rem >= k - sa) { rem -= k - sa; sa++; }
     const int sb = sa + rem;
     const bool diag = sa == sb;
-    double acc[12], cacc[2];
+    double acc[36], cacc[6];
 #pragma unroll
-    for (int i = 0; i < 12; i++) acc[i] = 0.0;
-    cacc[0] = 0.0; cacc[1] = 0.0;
-    const int slots = NB * k;                               // <= 64: lane e <-> (landmark e / k, slot e % k)
-    const int ej = lane / k, esl = lane - ej * k;
-    const bool stager = lane < slots;
-    // The staging lanes run one sub-batch AHEAD of the products: the camera pose of a lane's slot is loop-invariant, the
-    // landmark / edge indices are fetched two sub-batches ahead and the landmark data one ahead, so the two dependent
-    // HBM/L2 round trips (index -> data) of a sub-batch overlap the block products of the previous one instead of
-    // stalling the single wavefront of the workgroup.
-    Pose T;
-    Mat3 Rt;                                                // rotation of the lane's camera: loop-invariant like T
+    for (int i = 0; i < 36; i++) acc[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) cacc[i] = 0.0;
+    // The staging runs one sub-batch AHEAD of its loads' latency: the camera pose of a lane's slot is loop-invariant, the landmark /
+    // edge indices are fetched two sub-batches ahead and the landmark data one ahead, so the two dependent HBM/L2 round trips
+    // (index -> data) of a sub-batch overlap the block products of the previous one.  Bytes stay as loaded (a_n, fl_n): turning
+    // them into flags where they are fetched would wait for the loads right there.
+    Pose T; Mat3 Rt;
     if constexpr (D == 3) { if (stager) { T = load_cam(A, cur, W.cam_off + A.sg_cams[C.cams_off + esl]); Rt = quat_rotation(T.q); } }
-    int g_n = 0, id_n = 0, g_nn = 0, id_nn = 0;
+    int g_n = 0, id_n = 0, g_nn = 0, id_nn = 0, a_n = 0, fl_n = 0;
     double v_n[VN];
-    double ws_n = 0.0; bool stereo_n = false, a_n = false; Vec3 X_n;
+    double ws_n = 0.0; Vec3 X_n = vec3(0, 0, 1);
     auto fetch_idx = [&](int t0, int& g, int& id) {
-      if (stager && t0 + ej < C.n_lm) { g = lm[t0 + ej]; id = tab[(t0 + ej) * k + esl]; }
+      if (stager && t0 + ej < C.n_lm) { g = lm[t0 + ej]; id = tab[(size_t)(t0 + ej) * k + esl]; }
     };
     auto fetch_data = [&](int t0, int g, int id) {
       if (stager && t0 + ej < C.n_lm) {
-        a_n = act[g] != 0;
+        a_n = act[g];
         const double* V = Vbase + (size_t)g * VN;
 #pragma unroll
         for (int i = 0; i < VN; i++) v_n[i] = V[i];
-        if constexpr (D == 3) { ws_n = A.pe_ws[id]; stereo_n = (A.pe_flags[id] & EF_STEREO) != 0; X_n = load_pt(A, cur, g); }
+        if constexpr (D == 3) { ws_n = A.pe_ws[id]; fl_n = A.pe_flags[id]; X_n = load_pt(A, cur, g); }
       }
     };
     fetch_idx(0, g_n, id_n);
@@ -1137,109 +1272,80 @@ __device__ __forceinline__ void schur_chunk_wave(const BAArrays& A, const BAWin&
     for (int t0 = 0; t0 < C.n_lm; t0 += NB) {
       const int nb = (C.n_lm - t0) < NB ? (C.n_lm - t0) : NB;
       // this sub-batch's operands (arrived while the previous products ran) -> locals; then put the next loads in flight
-      const bool a = a_n;
       double w[WN], v[VN];
 #pragma unroll
       for (int i = 0; i < VN; i++) v[i] = v_n[i];
-      double ws = ws_n; bool stereo = stereo_n; Vec3 X = X_n;
+      const double ws = ws_n; const Vec3 X = X_n; const int a_raw = a_n, fl_raw = fl_n;
       const int id_cur = id_n;
       g_n = g_nn; id_n = id_nn;
       fetch_data(t0 + NB, g_n, id_n);
       fetch_idx(t0 + 2 * NB, g_nn, id_nn);
       __syncthreads();                                      // the previous sub-batch has been consumed
-      // lane (landmark, slot): build the Hpl block, invert Hll + lambda I, leave W and Y = W Dinv in LDS
       if (stager && ej < nb) {
         if constexpr (D == 3) {
-          // point edge: the Hpl block is a function of the linearisation-point pose, point and weight only
-          point_hpl_closed(W.cam, T, Rt, X, stereo, ws, w);
+          // point edge: the Hpl block is a function of the linearisation-point pose, point and one weight
+          point_hpl_closed(W.cam, T, Rt, X, (fl_raw & EF_STEREO) != 0, ws, w);
         } else {
-          // line observation: the summed 6x4 block was stored by the linearisation (24 doubles; fetched here, not a sub-batch
-          // ahead: holding two of them would halve the occupancy)
+          // line observation: the summed 6x4 block was stored by the linearisation (fetched here, not a sub-batch ahead: holding
+          // two of them would halve the occupancy)
           const double* Wg = A.lo_W + (size_t)id_cur * WN;
 #pragma unroll
           for (int i = 0; i < WN; i += 2) { const double2 t2 = *reinterpret_cast<const double2*>(Wg + i); w[i] = t2.x; w[i + 1] = t2.y; }
         }
-        double Di[DD];
-        if (a) {
-          double F[DD];
-          unpack_sym<D>(v, lambda, F);
-          spd_inverse<D>(F, Di);
-        } else {
-#pragma unroll
-          for (int i = 0; i < DD; i++) Di[i] = 0.0;
-#pragma unroll
-          for (int i = 0; i < WN; i++) w[i] = 0.0;
-        }
-        double* wl = Wl + lane * WS;
-        double* yl = Yl + lane * WS;
-#pragma unroll
-        for (int i = 0; i < WN; i++) wl[i] = w[i];
-#pragma unroll
-        for (int r = 0; r < 6; r++)
-#pragma unroll
-          for (int c = 0; c < D; c++) {
-            double sacc = 0.0;
-#pragma unroll
-            for (int m = 0; m < D; m++) sacc += w[r * D + m] * Di[m * D + c];
-            yl[r * D + c] = sacc;
-          }
-        if (esl == 0) {
-#pragma unroll
-          for (int i = 0; i < D; i++) bll[ej * D + i] = a ? v[HU + i] : 0.0;
-        }
+        schur_stage_one<D>(a_raw != 0, v, lambda, w, Zl + lane * WS, tl + ej * D, esl == 0);
       }
       __syncthreads();
-      // D: block products (two rows of Y_a times W_b^T)
       if (on) {
         for (int j = qq; j < nb; j += q) {
-          const double* ya = Yl + (j * k + sa) * WS + 2 * h * D;
-          const double* wbp = Wl + (j * k + sb) * WS;
-          double y0[D], y1[D];
+          const double* za = Zl + (j * k + sa) * WS;
+          const double* zb = Zl + (j * k + sb) * WS;
+          double b[WN];
 #pragma unroll
-          for (int m = 0; m < D; m++) { y0[m] = ya[m]; y1[m] = ya[D + m]; }
+          for (int i = 0; i < WN; i += 2) { const double2 t2 = *reinterpret_cast<const double2*>(zb + i); b[i] = t2.x; b[i + 1] = t2.y; }
+          double tv[D];
 #pragma unroll
-          for (int c = 0; c < 6; c++) {
-            double s0 = acc[c], s1 = acc[6 + c];             // straight FMA chains into the accumulators (no separate add)
+          for (int m = 0; m < D; m++) tv[m] = diag ? tl[j * D + m] : 0.0;
 #pragma unroll
-            for (int m = 0; m < D; m++) { const double wv = wbp[c * D + m]; s0 = fma(y0[m], wv, s0); s1 = fma(y1[m], wv, s1); }
-            acc[c] = s0; acc[6 + c] = s1;
-          }
-          if (diag) {
-            double s0 = cacc[0], s1 = cacc[1];
+          for (int rp = 0; rp < 3; rp++) {                   // two rows of Z_a at a time: 16-byte LDS reads
+            double a2[2 * D];
 #pragma unroll
-            for (int m = 0; m < D; m++) { const double bv = bll[j * D + m]; s0 = fma(y0[m], bv, s0); s1 = fma(y1[m], bv, s1); }
-            cacc[0] = s0; cacc[1] = s1;
+            for (int i = 0; i < 2 * D; i += 2) { const double2 t2 = *reinterpret_cast<const double2*>(za + rp * 2 * D + i); a2[i] = t2.x; a2[i + 1] = t2.y; }
+#pragma unroll
+            for (int rr = 0; rr < 2; rr++) {
+              const int r = 2 * rp + rr;
+#pragma unroll
+              for (int cc = 0; cc < 6; cc++) {
+                double s0 = acc[r * 6 + cc];
+#pragma unroll
+                for (int m = 0; m < D; m++) s0 = fma(a2[rr * D + m], b[cc * D + m], s0);
+                acc[r * 6 + cc] = s0;
+              }
+              double s1 = cacc[r];
+#pragma unroll
+              for (int m = 0; m < D; m++) s1 = fma(a2[rr * D + m], tv[m], s1);
+              cacc[r] = s1;
+            }
           }
         }
       }
     }
-    // sum the interleave partials through LDS (only when a chunk's pairs leave room for interleaving)
-    if (q > 1) {
-      __syncthreads();
-      if (on && qq > 0) {
-        double* dst = lds + ((qq - 1) * units + u) * 14;
+    // sum over the interleave (lanes qq * units + pl): a fixed shuffle tree, result in the lanes qq == 0
+    for (int sft = 1; sft < q; sft <<= 1) {
+      const bool take = (qq % (2 * sft)) == 0 && qq + sft < q;
 #pragma unroll
-        for (int i = 0; i < 12; i++) dst[i] = acc[i];
-        dst[12] = cacc[0]; dst[13] = cacc[1];
-      }
-      __syncthreads();
-      if (qq == 0) {
-        for (int o = 1; o < q; o++) {
-          const double* src = lds + ((o - 1) * units + u) * 14;
+      for (int i = 0; i < 36; i++) { const double o = __shfl_down(acc[i], sft * units); if (take) acc[i] += o; }
 #pragma unroll
-          for (int i = 0; i < 12; i++) acc[i] += src[i];
-          cacc[0] += src[12]; cacc[1] += src[13];
-        }
-      }
+      for (int i = 0; i < 6; i++) { const double o = __shfl_down(cacc[i], sft * units); if (take) cacc[i] += o; }
     }
-    if (qq == 0) {
+    if (on && qq == 0) {
       // plain stores of the chunk's partial products; ba_schur_reduce sums them into S in a fixed order (no atomics)
-      double* dst = A.sp_part + (size_t)(C.part_off + pass0 + pl) * 36 + 12 * h;
+      double* dst = A.sp_part + (size_t)(C.part_off + pass0 + pl) * 36;
 #pragma unroll
-      for (int i = 0; i < 12; i += 2) *reinterpret_cast<double2*>(dst + i) = make_double2(acc[i], acc[i + 1]);
+      for (int i = 0; i < 36; i += 2) *reinterpret_cast<double2*>(dst + i) = make_double2(acc[i], acc[i + 1]);
       if (diag) {
-        double* cd = A.sp_cpart + (size_t)(C.cpart_off + sa) * 6 + 2 * h;
-        cd[0] = cacc[0]; cd[1] = cacc[1];
+        double* cd = A.sp_cpart + (size_t)(C.cpart_off + sa) * 6;
+#pragma unroll
+        for (int i = 0; i < 6; i += 2) *reinterpret_cast<double2*>(cd + i) = make_double2(cacc[i], cacc[i + 1]);
       }
     }
   }
@@ -1247,7 +1353,7 @@ __device__ __forceinline__ void schur_chunk_wave(const BAArrays& A, const BAWin&
 
 // grid (max chunks of this landmark type, nW), block 64 = one wavefront per chunk; dynamic LDS sized by the host.
 template <int D>
-__global__ __launch_bounds__(64) void ba_schur_items_kernel(BAArrays A, const BAWin* __restrict__ wins, const BAState* __restrict__ st) {
+__global__ __launch_bounds__(kSchurThreads) void ba_schur_items_kernel(BAArrays A, const BAWin* __restrict__ wins, const BAState* __restrict__ st) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const BAWin W = wins[blockIdx.y];
   const BAState& S = st[blockIdx.y];
@@ -1256,13 +1362,12 @@ __global__ __launch_bounds__(64) void ba_schur_items_kernel(BAArrays A, const BA
   const int count = (D == 3) ? W.n_items_pt : W.n_items - W.n_items_pt;
   if ((int)blockIdx.x >= count) return;
   const SChunk C = A.sg_chunks[first + blockIdx.x];
-  schur_chunk_wave<D>(A, W, C, S.lambda, S.cur, lds);
+  if (C.k <= kSchurWideK) schur_chunk_wave<D>(A, W, C, S.lambda, S.cur, lds);   // (wider chunks: ba_schur_wide_kernel)
 }
 
-// Point and line chunks in ONE launch: grid (n_pt_blocks + max line chunks, nW).  Same register budget (196 / 182 VGPRs, two
-// waves per SIMD either way), and the line chunks fill the tail of the point chunks instead of waiting for it - for a single
-// window the two kernels were two dependent 17 us launches on an otherwise idle GPU.
-__global__ __launch_bounds__(64) void ba_schur_items_both_kernel(BAArrays A, const BAWin* __restrict__ wins, const BAState* __restrict__ st, int n_pt_blocks) {
+// Point and line chunks in ONE launch: grid (n_pt_blocks + max line chunks, nW).  The line chunks fill the tail of the point
+// chunks instead of waiting for it - for a single window the two kernels were two dependent 17 us launches on an otherwise idle GPU.
+__global__ __launch_bounds__(kSchurThreads) void ba_schur_items_both_kernel(BAArrays A, const BAWin* __restrict__ wins, const BAState* __restrict__ st, int n_pt_blocks) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const BAWin W = wins[blockIdx.y];
   const BAState& S = st[blockIdx.y];
@@ -1270,13 +1375,26 @@ __global__ __launch_bounds__(64) void ba_schur_items_both_kernel(BAArrays A, con
   if ((int)blockIdx.x < n_pt_blocks) {
     if ((int)blockIdx.x >= W.n_items_pt) return;
     const SChunk C = A.sg_chunks[W.item_off + blockIdx.x];
-    schur_chunk_wave<3>(A, W, C, S.lambda, S.cur, lds);
+    if (C.k <= kSchurWideK) schur_chunk_wave<3>(A, W, C, S.lambda, S.cur, lds);
   } else {
     const int i = (int)blockIdx.x - n_pt_blocks;
     if (i >= W.n_items - W.n_items_pt) return;
     const SChunk C = A.sg_chunks[W.item_off + W.n_items_pt + i];
-    schur_chunk_wave<4>(A, W, C, S.lambda, S.cur, lds);
+    if (C.k <= kSchurWideK) schur_chunk_wave<4>(A, W, C, S.lambda, S.cur, lds);
   }
+}
+
+// The chunks the kernels above skip (a landmark with more than kSchurWideK free observations); launched only for batches that
+// have one.  grid (max chunks, nW) over all chunks of a window, block kSchurThreads.
+__global__ __launch_bounds__(kSchurWideThreads) void ba_schur_wide_kernel(BAArrays A, const BAWin* __restrict__ wins, const BAState* __restrict__ st) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const BAWin W = wins[blockIdx.y];
+  const BAState& S = st[blockIdx.y];
+  if (S.phase != PH_RUN || (int)blockIdx.x >= W.n_items) return;
+  const SChunk C = A.sg_chunks[W.item_off + blockIdx.x];
+  if (C.k <= kSchurWideK) return;
+  if (C.D == 3) schur_chunk_wide<3>(A, W, C, S.lambda, S.cur, lds);
+  else schur_chunk_wide<4>(A, W, C, S.lambda, S.cur, lds);
 }
 
 // grid (ceil(nblk_max * 6 / 256), nW): lane <-> one row of one lower 6x6 block of S.  S_ij = [i == j](Hpp_i + lambda I)
