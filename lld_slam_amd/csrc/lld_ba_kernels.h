@@ -63,7 +63,8 @@ struct BAWin {                 // immutable per-window header
   int hpp_off;                 // free-camera accumulators
   int x_off;                   // reduced-system vectors (doubles)
   long long S_off;             // reduced-system matrix (doubles)
-  int item_off, n_items, n_items_pt;   // Schur chunks of this window (range in sg_chunks): n_items_pt point chunks, then line chunks
+  int item_off, n_items, n_items_pt;   // chunks of this window (range in sg_chunks): n_items_pt point chunks, then line chunks
+  int n_k0_pt, n_k0_ln;                // ... of which the first n_k0 of a kind have no free camera (nothing for the Schur complement)
   int lo_off, n_lo;            // line observations (= le_off / 2)
   int blk_csr_off, cam_csr_off; // CSR (per lower S block / per free camera) of the chunk partials that add into it
   int nb_pt, nb_ln;            // landmark blocks (kLmThreads landmarks each)
@@ -99,7 +100,9 @@ struct BAState {               // mutable per-window LM state
 struct PTask { int l0, nl, e0, ne, ms, pad0, pad1, pad2; };   // local first landmark, landmark count, global first edge / observation,
                                                              // edge count, longest run of one landmark (bounds the segmented reductions)
 
-struct SChunk { int lm_off, n_lm, tab_off, cams_off, k, D, part_off, cpart_off; };   // part_off: 36-double blocks, cpart_off: 6-double vectors
+// A chunk = a run of storage landmarks with one camera tuple (k free cameras ascending, then k_all - k fixed ones): landmark l0 + j,
+// observation e0 + j * k_all + s (point edge / line observation) and camera sg_cams[cams_off + s] for 0 <= j < n_lm, 0 <= s < k_all.
+struct SChunk { int l0, n_lm, e0, k, k_all, cams_off, part_off, cpart_off; };   // part_off: 36-double blocks, cpart_off: 6-double vectors
 
 struct BAArrays {
   long long NC, NP, NL;        // totals (stride of the double-buffered state arrays)
@@ -143,7 +146,8 @@ struct BAArrays {
   const PTask* ptasks; const PTask* ltasks;
   double *sp_part, *sp_cpart;  // per (chunk, slot pair) 6x6 partial products / per (chunk, slot) 6-vectors
   const int *blk_start, *blk_src, *cam_start, *cam_src;
-  const int *sg_lm, *sg_tab, *sg_cams;
+  const int *sg_cams;
+  const int *pt_perm, *pe_perm, *ln_perm, *lo_perm;   // storage position -> the caller's window-local landmark / observation index
   // results
   unsigned char* records;
 };
@@ -1168,14 +1172,14 @@ __device__ __forceinline__ void schur_chunk_wide(const BAArrays& A, const BAWin&
   const int k = C.k, np = k * (k + 1) / 2;
   double* Zl = lds; double* tl = lds + ((k * WS + 1) & ~1);
   for (int t0 = 0; t0 < C.n_lm; t0++) {
-    const int g = A.sg_lm[C.lm_off + t0];
+    const int g = C.l0 + t0;
     const bool a = act[g] != 0;
     double v[VN];
 #pragma unroll
     for (int i = 0; i < VN; i++) v[i] = Vbase[(size_t)g * VN + i];
     __syncthreads();
     for (int sl = threadIdx.x; sl < k; sl += kSchurWideThreads) {
-      const int id = A.sg_tab[C.tab_off + (size_t)t0 * k + sl];
+      const int id = C.e0 + t0 * C.k_all + sl;
       double w[WN];
       if constexpr (D == 3) {
         const Pose Ts = load_cam(A, cur, W.cam_off + A.sg_cams[C.cams_off + sl]);
@@ -1226,8 +1230,6 @@ __device__ __forceinline__ void schur_chunk_wave(const BAArrays& A, const BAWin&
   const int NB = schur_nb(k);
   double* Zl = lds;
   double* tl = lds + NB * k * WS;
-  const int* __restrict__ lm = A.sg_lm + C.lm_off;
-  const int* __restrict__ tab = A.sg_tab + C.tab_off;
   // stage lane <-> (landmark ej, slot esl) of a sub-batch
   const int ej = lane / k, esl = lane - ej * k;
   const bool stager = lane < NB * k;
@@ -1251,14 +1253,12 @@ __device__ __forceinline__ void schur_chunk_wave(const BAArrays& A, const BAWin&
     // them into flags where they are fetched would wait for the loads right there.
     Pose T; Mat3 Rt;
     if constexpr (D == 3) { if (stager) { T = load_cam(A, cur, W.cam_off + A.sg_cams[C.cams_off + esl]); Rt = quat_rotation(T.q); } }
-    int g_n = 0, id_n = 0, g_nn = 0, id_nn = 0, a_n = 0, fl_n = 0;
+    int a_n = 0, fl_n = 0;
     double v_n[VN];
     double ws_n = 0.0; Vec3 X_n = vec3(0, 0, 1);
-    auto fetch_idx = [&](int t0, int& g, int& id) {
-      if (stager && t0 + ej < C.n_lm) { g = lm[t0 + ej]; id = tab[(size_t)(t0 + ej) * k + esl]; }
-    };
-    auto fetch_data = [&](int t0, int g, int id) {
+    auto fetch_data = [&](int t0) {
       if (stager && t0 + ej < C.n_lm) {
+        const int g = C.l0 + t0 + ej, id = C.e0 + (t0 + ej) * C.k_all + esl;
         a_n = act[g];
         const double* V = Vbase + (size_t)g * VN;
 #pragma unroll
@@ -1266,9 +1266,7 @@ __device__ __forceinline__ void schur_chunk_wave(const BAArrays& A, const BAWin&
         if constexpr (D == 3) { ws_n = A.pe_ws[id]; fl_n = A.pe_flags[id]; X_n = load_pt(A, cur, g); }
       }
     };
-    fetch_idx(0, g_n, id_n);
-    fetch_idx(NB, g_nn, id_nn);
-    fetch_data(0, g_n, id_n);
+    fetch_data(0);
     for (int t0 = 0; t0 < C.n_lm; t0 += NB) {
       const int nb = (C.n_lm - t0) < NB ? (C.n_lm - t0) : NB;
       // this sub-batch's operands (arrived while the previous products ran) -> locals; then put the next loads in flight
@@ -1276,10 +1274,7 @@ __device__ __forceinline__ void schur_chunk_wave(const BAArrays& A, const BAWin&
 #pragma unroll
       for (int i = 0; i < VN; i++) v[i] = v_n[i];
       const double ws = ws_n; const Vec3 X = X_n; const int a_raw = a_n, fl_raw = fl_n;
-      const int id_cur = id_n;
-      g_n = g_nn; id_n = id_nn;
-      fetch_data(t0 + NB, g_n, id_n);
-      fetch_idx(t0 + 2 * NB, g_nn, id_nn);
+      fetch_data(t0 + NB);
       __syncthreads();                                      // the previous sub-batch has been consumed
       if (stager && ej < nb) {
         if constexpr (D == 3) {
@@ -1288,7 +1283,7 @@ __device__ __forceinline__ void schur_chunk_wave(const BAArrays& A, const BAWin&
         } else {
           // line observation: the summed 6x4 block was stored by the linearisation (fetched here, not a sub-batch ahead: holding
           // two of them would halve the occupancy)
-          const double* Wg = A.lo_W + (size_t)id_cur * WN;
+          const double* Wg = A.lo_W + (size_t)(C.e0 + (t0 + ej) * C.k_all + esl) * WN;
 #pragma unroll
           for (int i = 0; i < WN; i += 2) { const double2 t2 = *reinterpret_cast<const double2*>(Wg + i); w[i] = t2.x; w[i + 1] = t2.y; }
         }
@@ -1358,8 +1353,8 @@ __global__ __launch_bounds__(kSchurThreads) void ba_schur_items_kernel(BAArrays 
   const BAWin W = wins[blockIdx.y];
   const BAState& S = st[blockIdx.y];
   if (S.phase != PH_RUN) return;
-  const int first = (D == 3) ? W.item_off : W.item_off + W.n_items_pt;
-  const int count = (D == 3) ? W.n_items_pt : W.n_items - W.n_items_pt;
+  const int first = (D == 3) ? W.item_off + W.n_k0_pt : W.item_off + W.n_items_pt + W.n_k0_ln;
+  const int count = (D == 3) ? W.n_items_pt - W.n_k0_pt : W.n_items - W.n_items_pt - W.n_k0_ln;
   if ((int)blockIdx.x >= count) return;
   const SChunk C = A.sg_chunks[first + blockIdx.x];
   if (C.k <= kSchurWideK) schur_chunk_wave<D>(A, W, C, S.lambda, S.cur, lds);   // (wider chunks: ba_schur_wide_kernel)
@@ -1373,13 +1368,13 @@ __global__ __launch_bounds__(kSchurThreads) void ba_schur_items_both_kernel(BAAr
   const BAState& S = st[blockIdx.y];
   if (S.phase != PH_RUN) return;
   if ((int)blockIdx.x < n_pt_blocks) {
-    if ((int)blockIdx.x >= W.n_items_pt) return;
-    const SChunk C = A.sg_chunks[W.item_off + blockIdx.x];
+    if ((int)blockIdx.x >= W.n_items_pt - W.n_k0_pt) return;
+    const SChunk C = A.sg_chunks[W.item_off + W.n_k0_pt + blockIdx.x];
     if (C.k <= kSchurWideK) schur_chunk_wave<3>(A, W, C, S.lambda, S.cur, lds);
   } else {
     const int i = (int)blockIdx.x - n_pt_blocks;
-    if (i >= W.n_items - W.n_items_pt) return;
-    const SChunk C = A.sg_chunks[W.item_off + W.n_items_pt + i];
+    if (i >= W.n_items - W.n_items_pt - W.n_k0_ln) return;
+    const SChunk C = A.sg_chunks[W.item_off + W.n_items_pt + W.n_k0_ln + i];
     if (C.k <= kSchurWideK) schur_chunk_wave<4>(A, W, C, S.lambda, S.cur, lds);
   }
 }
@@ -1393,7 +1388,7 @@ __global__ __launch_bounds__(kSchurWideThreads) void ba_schur_wide_kernel(BAArra
   if (S.phase != PH_RUN || (int)blockIdx.x >= W.n_items) return;
   const SChunk C = A.sg_chunks[W.item_off + blockIdx.x];
   if (C.k <= kSchurWideK) return;
-  if (C.D == 3) schur_chunk_wide<3>(A, W, C, S.lambda, S.cur, lds);
+  if ((int)blockIdx.x < W.n_items_pt) schur_chunk_wide<3>(A, W, C, S.lambda, S.cur, lds);
   else schur_chunk_wide<4>(A, W, C, S.lambda, S.cur, lds);
 }
 
@@ -2372,12 +2367,13 @@ __global__ __launch_bounds__(kLmThreads) void ba_finalize_kernel(BAArrays A, con
     const int g = W.pt_off + p;
     if (p < W.n_pt) {
       const Vec3 X = load_pt(A, cur, g);
-      o_pt[3 * p] = X.x; o_pt[3 * p + 1] = X.y; o_pt[3 * p + 2] = X.z;
+      const int po = A.pt_perm[g];                                        // the caller's index of this storage position
+      o_pt[3 * po] = X.x; o_pt[3 * po + 1] = X.y; o_pt[3 * po + 2] = X.z;
       for (int e = A.pt_obs_start[g]; e < A.pt_obs_start[g + 1]; e++) {
         const Pose T = load_cam(A, cur, W.cam_off + A.pe_cam[e]);
         const bool depth_pos = pose_map(T, X).z > 0.0;
         const bool stereo = !(A.pe_ur[e] < 0);
-        o_pe[e - W.pe_off] = (!untouched && !global && (A.pe_chi2[e] > (stereo ? 7.815 : 5.991) || !depth_pos)) ? 1 : 0;      // Optimizer.cc:1290,1305
+        o_pe[A.pe_perm[e]] = (!untouched && !global && (A.pe_chi2[e] > (stereo ? 7.815 : 5.991) || !depth_pos)) ? 1 : 0;      // Optimizer.cc:1290,1305
       }
     }
   } else {
@@ -2386,20 +2382,22 @@ __global__ __launch_bounds__(kLmThreads) void ba_finalize_kernel(BAArrays A, con
     if (l < W.n_ln) {
       const int e0 = 2 * A.ln_obs_start[g], e1 = 2 * A.ln_obs_start[g + 1];
       const bool removed = A.ln_removed[g] != 0;
-      o_rm[l] = removed;
+      const int lo = A.ln_perm[g];                                        // the caller's index of this storage position
+      auto out_slot = [&](int e) { return 2 * A.lo_perm[e >> 1] + (e & 1); };    // ... and of an edge slot
+      o_rm[lo] = removed;
       if (removed || untouched) {                                       // GetLineData returns false: nothing updated, nothing erased
-        for (int k = 0; k < 3; k++) { o_x0[3 * l + k] = A.ln_x0[(size_t)g * 3 + k]; o_dir[3 * l + k] = A.ln_dir[(size_t)g * 3 + k]; }
-        for (int e = e0; e < e1; e++) o_le[e - W.le_off] = 0;
+        for (int k = 0; k < 3; k++) { o_x0[3 * lo + k] = A.ln_x0[(size_t)g * 3 + k]; o_dir[3 * lo + k] = A.ln_dir[(size_t)g * 3 + k]; }
+        for (int e = e0; e < e1; e++) o_le[out_slot(e)] = 0;
       } else {
         const LineQ L = load_ln(A, cur, g);
         const Mat3 Rl = line_rotation(L);
         const Vec3 c0 = mat_col(Rl, 0), c1 = mat_col(Rl, 1);
         const Vec3 X1 = L.alpha * c1, X2 = X1 + c0;
-        o_dir[3 * l] = c0.x; o_dir[3 * l + 1] = c0.y; o_dir[3 * l + 2] = c0.z;
-        o_x0[3 * l] = X1.x; o_x0[3 * l + 1] = X1.y; o_x0[3 * l + 2] = X1.z;
+        o_dir[3 * lo] = c0.x; o_dir[3 * lo + 1] = c0.y; o_dir[3 * lo + 2] = c0.z;
+        o_x0[3 * lo] = X1.x; o_x0[3 * lo + 1] = X1.y; o_x0[3 * lo + 2] = X1.z;
         for (int e = e0; e < e1; e++) {
           const uint8_t fl = A.le_flags[e];
-          if (!(fl & EF_VALID)) { o_le[e - W.le_off] = 0; continue; }
+          if (!(fl & EF_VALID)) { o_le[out_slot(e)] = 0; continue; }
           const Pose T = load_cam(A, cur, W.cam_off + A.le_cam[e]);
           const bool depth_pos = line_depth_positive(cam, A.le_bx[e], T, c0, c1, L.alpha, A.le_xs[e], A.le_ys[e], A.le_xe[e], A.le_ye[e]);
           double r[2];
@@ -2407,7 +2405,7 @@ __global__ __launch_bounds__(kLmThreads) void ba_finalize_kernel(BAArrays A, con
           const double c2 = chi2_of(r, 2, A.le_s[e]);
           A.le_chi2[e] = c2;
           const double th = (fl & EF_PAIRSTEREO) ? W.th_ln_stereo : W.th_ln_mono;
-          o_le[e - W.le_off] = (!global && (c2 > th * th || !depth_pos)) ? 1 : 0;                    // LineOptimizer.cc:185-196
+          o_le[out_slot(e)] = (!global && (c2 > th * th || !depth_pos)) ? 1 : 0;                    // LineOptimizer.cc:185-196
         }
       }
     }
