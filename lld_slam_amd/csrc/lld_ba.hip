@@ -14,7 +14,6 @@ using namespace lldba;
 
 namespace {
 constexpr int kNumPhases = 5;
-constexpr int kFusePairsBelowWindows = 8;  // fewer windows than this: point + line kernels of a pair share one launch
 constexpr int kMaxSuperSteps = 512;      // hard stop: 2 rounds x 15 iterations x 10 trials is the protocol's own bound (300)
 }
 
@@ -23,17 +22,19 @@ struct lld_ba_batch {
   int n_windows = 0;
   lld_ba_params params;
   std::vector<BAWin> h_wins;
-  std::vector<SChunk> h_chunks; std::vector<PTask> h_ptasks, h_ltasks;
+  std::vector<SChunk> h_chunks;
   void* slab = nullptr; bool borrowed = false; size_t slab_bytes = 0;
   BAArrays A;
   BAWin* d_wins = nullptr; BAState* d_state = nullptr;
   // window groups solved concurrently, each on its own stream (hides the latency-bound reduced solve, the per-super-step
   // host poll and kernel tails behind the other groups' work)
   struct Group { int w0 = 0, nw = 0; hipStream_t st = nullptr; bool own_stream = false; int* d_counters = nullptr; int* h_counters = nullptr;
-                 hipEvent_t ev[kNumPhases + 1] = {}; int steps = 0; bool active = false; int max_nt_pt = 0, max_nb_ln = 0, max_nl_pt = 0, max_nl_ln = 0, max_lblocks = 0, max_items_pt = 0, max_items_ln = 0, max_items_all = 0, max_blk = 0; };
+                 hipEvent_t ev[kNumPhases + 1] = {}; int steps = 0; bool active = false; int max_lblocks = 0, max_items_pt = 0, max_items_ln = 0, max_chunks_pt = 0, max_chunks_ln = 0, max_items_all = 0, max_blk = 0; };
   std::vector<Group> groups;
   int* d_counters = nullptr; int* h_counters = nullptr;               // device / pinned, 4 ints per group
-  int max_lblocks = 0, max_items_pt = 0, max_items_ln = 0, max_free = 0, max_cams = 0, max_blk = 0, acc_copies = 4;
+  int max_lblocks = 0, max_items_pt = 0, max_items_ln = 0, max_free = 0, max_cams = 0, max_blk = 0;
+  bool has_wide_obs = false;                              // some landmark has more than 64 observations (ba_update_wide_kernel)
+  int max_k = 1;                                          // most free cameras of a chunk the update kernels handle (LDS accumulators)
   bool pcg_multi = false;
   size_t schur_lds[2] = {0, 0}; size_t schur_wide_lds = 0;
   int chunk_landmarks = 32;
@@ -158,18 +159,17 @@ struct ChunkStage {
   std::vector<int> blk_key, blk_val, cam_key, cam_val;     // (block | camera, partial index [*4 + mode]) in generation order
   size_t n_part = 0, n_cpart = 0, lds_need = 0, wide_lds_need = 0;
   int n_k0 = 0;                                            // leading chunks without a free camera
+  bool has_wide_obs = false; int max_k = 1;
 };
 
 struct WinStage {
   LmOrder ord[2];                                          // points, lines
-  std::vector<PTask> ptasks, ltasks;
   ChunkStage cs[2];                                        // points, lines
   std::vector<int> blk_start, blk_src, cam_start, cam_src; // window-local CSRs over both kinds (stage_csr)
 };
 
-// wavefront tasks of the lane-per-edge kernels + everything in BAWin that follows from the window sizes
-void stage_tasks(const lld_ba_window& w, const lld_ba_params& P, const WinBases& b, int n_windows, BAWin& W, WinStage& S) {
-  const std::vector<int>& pstart = S.ord[0].start; const std::vector<int>& lstart = S.ord[1].start;
+// everything in BAWin that follows from the window sizes
+void stage_header(const lld_ba_window& w, const lld_ba_params& P, const WinBases& b, BAWin& W) {
   std::memset(&W, 0, sizeof W);
   W.cam = lld::make_camk(w.cam);
   W.n_cams = w.n_cams; W.n_free = w.n_free_cams;
@@ -178,27 +178,6 @@ void stage_tasks(const lld_ba_window& w, const lld_ba_params& P, const WinBases&
   W.lo_off = (int)b.NLO; W.n_lo = w.n_ln_obs;
   W.hpp_off = (int)b.NF; W.x_off = (int)b.x_total; W.S_off = (long long)b.S_total;
   W.nb_pt = (w.n_points + kLmThreads - 1) / kLmThreads; W.nb_ln = (w.n_lines + kLmThreads - 1) / kLmThreads;
-  // a task = consecutive landmarks while their edges fit into one wavefront; a landmark with more than 64 edges is a task of its own
-  auto build = [](int n_lm, const int* start, long long e_base, std::vector<PTask>& out) {
-    out.reserve((size_t)(n_lm ? start[n_lm] : 0) / 48 + 8);
-    for (int l = 0; l < n_lm;) {
-      PTask T; std::memset(&T, 0, sizeof T); T.l0 = l; T.e0 = (int)e_base + start[l];
-      while (l < n_lm) {
-        const int ne = start[l + 1] - start[l];
-        if (T.nl > 0 && (T.ne + ne > 64 || T.nl >= 64)) break;
-        T.nl++; T.ne += ne; T.ms = std::max(T.ms, ne); l++;
-        if (T.ne > 64) break;
-      }
-      out.push_back(T);
-    }
-  };
-  build(w.n_points, pstart.data(), b.NPE, S.ptasks);       // lane <-> point edge
-  build(w.n_lines, lstart.data(), b.NLO, S.ltasks);        // lane <-> (line, KF) observation
-  W.n_ptasks = (int)S.ptasks.size(); W.n_ltasks = (int)S.ltasks.size();
-  const int* R = n_windows >= kRoundsThroughputMinWindows ? kRoundsThroughput : kRoundsLatency;
-  for (int i = 0; i < 4; i++) W.rounds[i] = R[i];
-  W.nt_pt = (W.n_ptasks + 4 * W.rounds[2] - 1) / (4 * W.rounds[2]); W.nl_pt = (W.n_ptasks + W.rounds[0] * kLinThreads / 64 - 1) / (W.rounds[0] * kLinThreads / 64);
-  W.nt_ln = (W.n_ltasks + 4 * W.rounds[3] - 1) / (4 * W.rounds[3]); W.nl_ln = (W.n_ltasks + W.rounds[1] * kLinThreads / 64 - 1) / (W.rounds[1] * kLinThreads / 64);
   const double thMono = (double)(float)std::sqrt(5.991), thStereo = (double)(float)std::sqrt(7.815);   // Optimizer.cc:1088-1089
   W.its[0] = P.its_round1; W.its[1] = P.its_round2; W.max_trials = P.max_trials; W.ln_filter = P.ln_filter;
   W.th_mono = thMono; W.th_stereo = thStereo;
@@ -281,6 +260,7 @@ void stage_chunks(const lld_ba_window& w, int D, const WinBases& b, int chunk_la
     out.sg_cams.insert(out.sg_cams.end(), c0cams, c0cams + C.k_all);
     C.part_off = (int)out.n_part; C.cpart_off = (int)out.n_cpart;
     if (C.k == 0) out.n_k0++;
+    if (C.k_all > 64) out.has_wide_obs = true; else out.max_k = std::max(out.max_k, C.k);
     int pidx = 0;
     for (int sa = 0; sa < C.k; sa++) {
       const int ca = c0cams[sa];
@@ -297,6 +277,16 @@ void stage_chunks(const lld_ba_window& w, int D, const WinBases& b, int chunk_la
     out.chunks.push_back(C);
     i0 = i1;
   }
+}
+
+// The update kernels put four consecutive chunks of a window into one workgroup, which lives as long as its longest wavefront: order
+// the chunks by the work in them (those without a free camera stay in front: the Schur kernels skip that prefix).  Chunk order
+// carries no meaning - partial slots and CSR entries go by the numbers assigned above.
+void order_chunks(ChunkStage& cs) {
+  std::stable_sort(cs.chunks.begin(), cs.chunks.end(), [](const SChunk& a, const SChunk& b) {
+    if ((a.k == 0) != (b.k == 0)) return a.k == 0;
+    return (long long)a.n_lm * a.k_all > (long long)b.n_lm * b.k_all;
+  });
 }
 
 // Per reduced-system block / per camera: which partials to sum, in generation order (points before lines).  Counting sort of
@@ -355,8 +345,7 @@ static int ba_make_groups(lld_ba_batch* B, int n_groups) {
     for (int wi = Gr.w0; wi < Gr.w0 + Gr.nw; wi++) {
       const BAWin& W = B->h_wins[wi];
       Gr.max_lblocks = std::max(Gr.max_lblocks, W.nb_pt + W.nb_ln);
-      Gr.max_nt_pt = std::max(Gr.max_nt_pt, W.nt_pt); Gr.max_nb_ln = std::max(Gr.max_nb_ln, W.nt_ln);
-      Gr.max_nl_pt = std::max(Gr.max_nl_pt, W.nl_pt); Gr.max_nl_ln = std::max(Gr.max_nl_ln, W.nl_ln);
+      Gr.max_chunks_pt = std::max(Gr.max_chunks_pt, W.n_items_pt); Gr.max_chunks_ln = std::max(Gr.max_chunks_ln, W.n_items - W.n_items_pt);
       Gr.max_items_pt = std::max(Gr.max_items_pt, W.n_items_pt - W.n_k0_pt); Gr.max_items_ln = std::max(Gr.max_items_ln, W.n_items - W.n_items_pt - W.n_k0_ln);
       Gr.max_items_all = std::max(Gr.max_items_all, W.n_items);
       Gr.max_blk = std::max(Gr.max_blk, W.n_free * (W.n_free + 1) / 2);
@@ -448,33 +437,34 @@ static int ba_batch_create_impl(lld_ctx* ctx, int n_windows, const lld_ba_window
     order_landmarks(wins[wi], 3, S.ord[0]);
     order_landmarks(wins[wi], 4, S.ord[1]);
     lap1("landmarks ordered");
-    stage_tasks(wins[wi], P, bases[wi], n_windows, W, S);
-    lap1("tasks built");
+    stage_header(wins[wi], P, bases[wi], W);
     stage_edges(wins[wi], P, bases[wi], W, S, H);
     lap1("edges flattened");
     stage_chunks(wins[wi], 3, bases[wi], B->chunk_landmarks, S.ord[0], S.cs[0]);
     stage_chunks(wins[wi], 4, bases[wi], B->chunk_landmarks, S.ord[1], S.cs[1]);
+    order_chunks(S.cs[0]); order_chunks(S.cs[1]);
     stage_csr(wins[wi].n_free_cams, S);
     lap1("chunks built");
   });
   if (first_error.load() != LLD_OK) { const int st = first_error.load(); delete B; return st; }
   // ---- where each window's variable-length pieces go
-  struct Place { size_t ptask, ltask, chunk, cams, blk_start, blk_src, cam_start, cam_src, part, cpart; };
+  struct Place { size_t chunk, cams, blk_start, blk_src, cam_start, cam_src, part, cpart; };
   std::vector<Place> place(n_windows + 1);
-  size_t n_hpart = 0; long long NPART = 0; int max_blk = 0;
+  long long NPART = 0; int max_blk = 0;
   {
     Place q{};
     for (int wi = 0; wi < n_windows; wi++) {
       place[wi] = q;
       const WinStage& S = stages[wi];
       BAWin& W = B->h_wins[wi];
-      W.ptask_off = (int)q.ptask; W.ltask_off = (int)q.ltask; W.item_off = (int)q.chunk;
+      W.item_off = (int)q.chunk;
       W.n_items_pt = (int)S.cs[0].chunks.size(); W.n_items = W.n_items_pt + (int)S.cs[1].chunks.size();
       W.n_k0_pt = S.cs[0].n_k0; W.n_k0_ln = S.cs[1].n_k0;
       W.blk_csr_off = (int)q.blk_start; W.cam_csr_off = (int)q.cam_start;
-      W.hpart_off = (long long)n_hpart; n_hpart += (size_t)(W.nl_pt + W.nl_ln) * W.n_free * 27;
-      W.part_off = (int)NPART; NPART += W.nt_pt + W.nt_ln;
-      q.ptask += S.ptasks.size(); q.ltask += S.ltasks.size(); q.chunk += (size_t)W.n_items;
+      W.part_off = (int)NPART; NPART += W.n_items;
+      B->has_wide_obs = B->has_wide_obs || S.cs[0].has_wide_obs || S.cs[1].has_wide_obs;
+      B->max_k = std::max(B->max_k, std::max(S.cs[0].max_k, S.cs[1].max_k));
+      q.chunk += (size_t)W.n_items;
       q.cams += S.cs[0].sg_cams.size() + S.cs[1].sg_cams.size();
       q.blk_start += S.blk_start.size(); q.blk_src += S.blk_src.size(); q.cam_start += S.cam_start.size(); q.cam_src += S.cam_src.size();
       q.part += S.cs[0].n_part + S.cs[1].n_part; q.cpart += S.cs[0].n_cpart + S.cs[1].n_cpart;
@@ -494,7 +484,7 @@ static int ba_batch_create_impl(lld_ctx* ctx, int n_windows, const lld_ba_window
   const Place& tot = place[n_windows];
   const size_t n_part = tot.part, n_cpart = tot.cpart;
   size_t rec_total = 0;
-  B->h_ptasks.resize(tot.ptask); B->h_ltasks.resize(tot.ltask); B->h_chunks.resize(tot.chunk);
+  B->h_chunks.resize(tot.chunk);
   HostBuf<int> sg_cams, blk_start, blk_src, cam_start, cam_src;
   mem_ok &= sg_cams.alloc(tot.cams);
   mem_ok &= blk_start.alloc(tot.blk_start + 1); mem_ok &= blk_src.alloc(tot.blk_src); mem_ok &= cam_start.alloc(tot.cam_start + 1); mem_ok &= cam_src.alloc(tot.cam_src);
@@ -503,8 +493,6 @@ static int ba_batch_create_impl(lld_ctx* ctx, int n_windows, const lld_ba_window
   for_windows([&](int wi) {
     const Place& q = place[wi];
     WinStage& S = stages[wi];
-    std::copy(S.ptasks.begin(), S.ptasks.end(), B->h_ptasks.begin() + q.ptask);
-    std::copy(S.ltasks.begin(), S.ltasks.end(), B->h_ltasks.begin() + q.ltask);
     size_t at_chunk = q.chunk, at_cams = q.cams;
     for (int d = 0; d < 2; d++) {
       const ChunkStage& C = S.cs[d];
@@ -528,11 +516,7 @@ static int ba_batch_create_impl(lld_ctx* ctx, int n_windows, const lld_ba_window
   // few windows whose reduced system is beyond the matrix-core Cholesky: the PCG runs across the whole GPU (see ba_pcgm_*)
   B->pcg_multi = n_windows <= 8 && B->max_free * 6 > kCholMN && P.reduced_solver != 2;
   if (B->max_free > kMaxFreeCamsOneWg && !B->pcg_multi) { delete B; return LLD_ERR_UNSUPPORTED; }   // batches of huge windows: not in this build
-  // LDS copies of the per-camera accumulators in the linearise kernels: as many as fit (4 for local windows)
-  B->acc_copies = kAccCopies;
-  while (B->acc_copies > 1 && ((size_t)B->max_free * 27 * B->acc_copies + 8 + (size_t)B->max_cams * 7) * sizeof(double) > 150 * 1024) B->acc_copies >>= 1;
-  if (((size_t)B->max_free * 27 * B->acc_copies + 8 + (size_t)B->max_cams * 7) * sizeof(double) > 158 * 1024) { delete B; return LLD_ERR_UNSUPPORTED; }
-  for (int wi = 0; wi < n_windows; wi++) { B->h_wins[wi].acc_copies = B->acc_copies; B->h_wins[wi].win_index = wi; }
+  for (int wi = 0; wi < n_windows; wi++) B->h_wins[wi].win_index = wi;
   B->max_blk = max_blk;
   // fixed-stride result records (what an RCCL gather of the batch moves)
   for (int wi = 0; wi < n_windows; wi++) B->h_wins[wi].rec_off = (long long)(B->rec_stride * (size_t)wi);
@@ -547,7 +531,7 @@ static int ba_batch_create_impl(lld_ctx* ctx, int n_windows, const lld_ba_window
     auto up_b = [&](const HostBuf<uint8_t>& h, size_t count) { uint8_t* d = sl.take<uint8_t>(count); if (real && !h.empty()) (void)hipMemcpyAsync(d, h.data(), h.size(), hipMemcpyHostToDevice, st); return (const uint8_t*)d; };
     B->d_wins = sl.take<BAWin>(n_windows); B->d_state = sl.take<BAState>(n_windows);
     std::memset(&A, 0, sizeof A);
-    A.NC = NC; A.NP = NP; A.NL = NL;
+    A.NC = NC; A.NP = NP; A.NL = NL; A.NPE = NPE; A.NLO = NLO; A.n_cpart = (long long)n_cpart;
     A.cam_qt = sl.take<double>(2 * NC * 7 + 1);
     A.ptx = sl.take<double>(2 * NP + 1); A.pty = sl.take<double>(2 * NP + 1); A.ptz = sl.take<double>(2 * NP + 1);
     A.lqx = sl.take<double>(2 * NL + 1); A.lqy = sl.take<double>(2 * NL + 1); A.lqz = sl.take<double>(2 * NL + 1); A.lqw = sl.take<double>(2 * NL + 1); A.lal = sl.take<double>(2 * NL + 1);
@@ -563,10 +547,10 @@ static int ba_batch_create_impl(lld_ctx* ctx, int n_windows, const lld_ba_window
     A.le_flags0 = up_b(H.le_flags0, NLE + 1);
     A.pe_flags = sl.take<uint8_t>(NPE + 1); A.le_flags = sl.take<uint8_t>(NLE + 1);
     A.pe_chi2 = sl.take<double>(NPE + 1); A.le_chi2 = sl.take<double>(NLE + 1);
-    A.pe_ws = sl.take<double>((size_t)NPE + 1); A.lo_W = sl.take<double>((size_t)NLO * 24 + 1);
+    A.pe_ws = sl.take<double>(2 * (size_t)NPE + 1); A.lo_W = sl.take<double>(2 * (size_t)NLO * 24 + 1);
     A.pt_active = sl.take<uint8_t>(NP + 1); A.ln_active = sl.take<uint8_t>(NL + 1); A.ln_removed = sl.take<uint8_t>(NL + 1);
-    A.pt_V = sl.take<double>((size_t)NP * 9 + 1); A.ln_V = sl.take<double>((size_t)NL * 14 + 1);
-    A.hpp_part = sl.take<double>(n_hpart + 2);
+    A.pt_V = sl.take<double>(2 * (size_t)NP * 9 + 1); A.ln_V = sl.take<double>(2 * (size_t)NL * 14 + 1);
+    A.hp_part = sl.take<double>(2 * n_cpart * 27 + 2);
     A.Hpp = sl.take<double>((size_t)NF * 21 + 1); A.bp = sl.take<double>((size_t)NF * 6 + 1);
     A.S = sl.take<double>(S_total + 1); A.bschur = sl.take<double>(x_total + 1); A.xp = sl.take<double>(x_total + 1);
     A.x_total = (long long)x_total;
@@ -580,13 +564,8 @@ static int ba_batch_create_impl(lld_ctx* ctx, int n_windows, const lld_ba_window
       SChunk* dc = sl.take<SChunk>(B->h_chunks.size() + 1);
       if (real && !B->h_chunks.empty()) (void)hipMemcpyAsync(dc, B->h_chunks.data(), B->h_chunks.size() * sizeof(SChunk), hipMemcpyHostToDevice, st);
       A.sg_chunks = dc;
-      PTask* dt = sl.take<PTask>(B->h_ptasks.size() + 1);
-      if (real && !B->h_ptasks.empty()) (void)hipMemcpyAsync(dt, B->h_ptasks.data(), B->h_ptasks.size() * sizeof(PTask), hipMemcpyHostToDevice, st);
-      A.ptasks = dt;
-      PTask* dl = sl.take<PTask>(B->h_ltasks.size() + 1);
-      if (real && !B->h_ltasks.empty()) (void)hipMemcpyAsync(dl, B->h_ltasks.data(), B->h_ltasks.size() * sizeof(PTask), hipMemcpyHostToDevice, st);
-      A.ltasks = dl;
     }
+    A.sink = sl.take<double>((size_t)kSinkSlots * 64);
     A.records = sl.take<unsigned char>(rec_total + 256);
     B->d_counters = sl.take<int>(4 * 8);
   };
@@ -604,15 +583,12 @@ static int ba_batch_create_impl(lld_ctx* ctx, int n_windows, const lld_ba_window
   {
     const size_t pcg_lds = ((size_t)B->max_free * 6 * 4 + kPcgThreads + (size_t)B->max_free * 36 + 32) * sizeof(double);
     if (!B->pcg_multi) LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_pcg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pcg_lds));
-    const size_t bs_lds0 = (8 + (size_t)B->max_cams * 14 + (size_t)B->max_free * 6) * sizeof(double);
-    if (bs_lds0 > 48 * 1024) {
-      LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_backsub_pt_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bs_lds0));
-      LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_backsub_both_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bs_lds0));
+    const size_t upd_lds0 = (8 + (size_t)B->max_cams * 14 + (size_t)B->max_free * 6 + (size_t)kUpdChunks * upd_wave_lds_doubles(B->max_k)) * sizeof(double);
+    if (upd_lds0 > 160 * 1024) { delete B; return LLD_ERR_UNSUPPORTED; }
+    if (upd_lds0 > 48 * 1024) {
+      LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_update_pt_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)upd_lds0));
+      LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_update_ln_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)upd_lds0));
     }
-    const size_t lin_lds = ((size_t)B->max_free * 27 * B->acc_copies + 8 + (size_t)B->max_cams * 7) * sizeof(double);
-    LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_linearize_pt_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lin_lds));
-    LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_linearize_ln_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lin_lds));
-    LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_linearize_both_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lin_lds));
     LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_chol_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
     LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_chol_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)(kCholMLdsDoubles * sizeof(double))));
@@ -648,8 +624,7 @@ int lld_ba_batch_solve(lld_ba_batch* B, volatile const int* abort_flag) {
   hipEvent_t t_begin, t_end;
   LLD_HIP_TRY(hipEventCreate(&t_begin)); LLD_HIP_TRY(hipEventCreate(&t_end));
   LLD_HIP_TRY(hipEventRecord(t_begin, ctx->stream));
-  const size_t lin_lds = ((size_t)B->max_free * 27 * B->acc_copies + 8 + (size_t)B->max_cams * 7) * sizeof(double);
-  const size_t bs_lds = (8 + (size_t)B->max_cams * 14 + (size_t)B->max_free * 6) * sizeof(double);
+  const size_t upd_lds = (8 + (size_t)B->max_cams * 14 + (size_t)B->max_free * 6 + (size_t)kUpdChunks * upd_wave_lds_doubles(B->max_k)) * sizeof(double);
   const size_t pcg_lds = ((size_t)B->max_free * 6 * 4 + kPcgThreads + (size_t)B->max_free * 36 + 32) * sizeof(double);
   const size_t chol_fixed = ((size_t)B->max_free * 36 * 2 + (size_t)B->max_free * 6 * 2 + 32) * sizeof(double);
   // whatever LDS is left (a workgroup may own up to 160 KiB) holds the trailing block triangle of S
@@ -673,12 +648,13 @@ int lld_ba_batch_solve(lld_ba_batch* B, volatile const int* abort_flag) {
     const int abort_now = (abort_flag && *abort_flag) ? 1 : 0;
     LLD_HIP_TRY(hipMemsetAsync(G.d_counters, 0, 4 * sizeof(int), st));
     LLD_HIP_TRY(hipEventRecord(G.ev[0], st));
-    const bool fuse_pairs = B->n_windows < kFusePairsBelowWindows;                           // see ba_linearize_both_kernel
-    if (fuse_pairs && G.max_nl_pt > 0 && G.max_nl_ln > 0) hipLaunchKernelGGL(ba_linearize_both_kernel, dim3(G.max_nl_pt + G.max_nl_ln, nw), dim3(kLinThreads), lin_lds, st, A, dw, ds, G.max_nl_pt);
-    else {
-      if (G.max_nl_pt > 0) hipLaunchKernelGGL(ba_linearize_pt_kernel, dim3(G.max_nl_pt, nw), dim3(kLinThreads), lin_lds, st, A, dw, ds);
-      if (G.max_nl_ln > 0) hipLaunchKernelGGL(ba_linearize_ln_kernel, dim3(G.max_nl_ln, nw), dim3(kLinThreads), lin_lds, st, A, dw, ds);
-    }
+    // landmark update kernels: sel 0 = the linearisation a round starts with (windows with need_lin), sel 1 = the LM trial
+    auto launch_update = [&](int sel) {
+      if (G.max_chunks_pt > 0) hipLaunchKernelGGL(ba_update_pt_kernel, dim3((G.max_chunks_pt + kUpdChunks - 1) / kUpdChunks, nw), dim3(kUpdThreads), upd_lds, st, A, dw, ds, sel, B->max_k);
+      if (G.max_chunks_ln > 0) hipLaunchKernelGGL(ba_update_ln_kernel, dim3((G.max_chunks_ln + kUpdChunks - 1) / kUpdChunks, nw), dim3(kUpdThreads), upd_lds, st, A, dw, ds, sel);
+      if (B->has_wide_obs) hipLaunchKernelGGL(ba_update_wide_kernel, dim3(G.max_items_all, nw), dim3(64), 0, st, A, dw, ds, sel);
+    };
+    launch_update(0);
     hipLaunchKernelGGL(ba_hpp_reduce_kernel, dim3(std::max(1, (B->max_free * 27 + 255) / 256), nw), dim3(256), 0, st, A, dw, ds);
     hipLaunchKernelGGL(ba_begin_kernel, dim3(nw), dim3(kCtlThreads), 0, st, A, dw, ds, nw);
     LLD_HIP_TRY(hipEventRecord(G.ev[1], st));
@@ -717,13 +693,9 @@ int lld_ba_batch_solve(lld_ba_batch* B, volatile const int* abort_flag) {
     else
       hipLaunchKernelGGL(ba_chol_kernel, dim3(nw), dim3(kPcgThreads), chol_lds, st, A, dw, ds, (int)(chol_tri / sizeof(double)));
     LLD_HIP_TRY(hipEventRecord(G.ev[3], st));
-    if (fuse_pairs && G.max_nt_pt > 0 && G.max_nb_ln > 0) hipLaunchKernelGGL(ba_backsub_both_kernel, dim3(G.max_nt_pt + G.max_nb_ln, nw), dim3(kLmThreads), bs_lds, st, A, dw, ds, G.max_nt_pt);
-    else {
-      if (G.max_nt_pt > 0) hipLaunchKernelGGL(ba_backsub_pt_kernel, dim3(G.max_nt_pt, nw), dim3(kLmThreads), bs_lds, st, A, dw, ds);
-      if (G.max_nb_ln > 0) hipLaunchKernelGGL(ba_backsub_ln_kernel, dim3(G.max_nb_ln, nw), dim3(kLmThreads), 0, st, A, dw, ds);
-    }
+    launch_update(1);
     LLD_HIP_TRY(hipEventRecord(G.ev[4], st));
-    hipLaunchKernelGGL(ba_control_kernel, dim3(nw), dim3(kCtlThreads), 0, st, A, dw, ds, abort_now, G.d_counters);
+    hipLaunchKernelGGL(ba_control_kernel, dim3(nw), dim3(kCtlThreads), 0, st, A, dw, ds, abort_now, G.d_counters, std::getenv("LLD_BA_NO_SPEC") ? 1 : 0);
     LLD_HIP_TRY(hipGetLastError());
     LLD_HIP_TRY(hipMemcpyAsync(G.h_counters, G.d_counters, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
     LLD_HIP_TRY(hipEventRecord(G.ev[5], st));
