@@ -14,6 +14,7 @@ using namespace lldba;
 
 namespace {
 constexpr int kNumPhases = 5;
+constexpr int kFusePairsBelowWindows = 8;  // fewer windows than this: point + line kernels of a pair share one launch
 constexpr int kMaxSuperSteps = 512;      // hard stop: 2 rounds x 15 iterations x 10 trials is the protocol's own bound (300)
 }
 
@@ -22,19 +23,17 @@ struct lld_ba_batch {
   int n_windows = 0;
   lld_ba_params params;
   std::vector<BAWin> h_wins;
-  std::vector<SChunk> h_chunks;
+  std::vector<SChunk> h_chunks; std::vector<PTask> h_ptasks, h_ltasks;
   void* slab = nullptr; bool borrowed = false; size_t slab_bytes = 0;
   BAArrays A;
   BAWin* d_wins = nullptr; BAState* d_state = nullptr;
   // window groups solved concurrently, each on its own stream (hides the latency-bound reduced solve, the per-super-step
   // host poll and kernel tails behind the other groups' work)
   struct Group { int w0 = 0, nw = 0; hipStream_t st = nullptr; bool own_stream = false; int* d_counters = nullptr; int* h_counters = nullptr;
-                 hipEvent_t ev[kNumPhases + 1] = {}; int steps = 0; bool active = false; int max_lblocks = 0, max_items_pt = 0, max_items_ln = 0, max_chunks_pt = 0, max_chunks_ln = 0, max_items_all = 0, max_blk = 0; };
+                 hipEvent_t ev[kNumPhases + 1] = {}; int steps = 0; bool active = false; int max_nt_pt = 0, max_nb_ln = 0, max_nl_pt = 0, max_nl_ln = 0, max_lblocks = 0, max_items_pt = 0, max_items_ln = 0, max_blk = 0; };
   std::vector<Group> groups;
   int* d_counters = nullptr; int* h_counters = nullptr;               // device / pinned, 4 ints per group
-  int max_lblocks = 0, max_items_pt = 0, max_items_ln = 0, max_free = 0, max_cams = 0, max_blk = 0;
-  bool has_wide_obs = false;                              // some landmark has more than 64 observations (ba_update_wide_kernel)
-  int max_k = 1;                                          // most free cameras of a chunk the update kernels handle (LDS accumulators)
+  int max_lblocks = 0, max_items_pt = 0, max_items_ln = 0, max_free = 0, max_cams = 0, max_blk = 0, acc_copies = 4;
   bool pcg_multi = false;
   size_t schur_lds[2] = {0, 0}; size_t schur_wide_lds = 0;
   int chunk_landmarks = 32;
@@ -91,85 +90,27 @@ template <class T> struct HostBuf {
 struct HostArrays {      // the flattened inputs, batch-global indexing (BAArrays' input section)
   HostBuf<double> cam_qt0, pt0, ln_x0, ln_dir, pe_u, pe_v, pe_ur, pe_s, le_xs, le_ys, le_xe, le_ye, le_s, le_bx;
   HostBuf<int> pt_obs_start, ln_obs_start, pe_cam, pe_pt, le_cam, le_ln;
-  HostBuf<int> pt_perm, pe_perm, ln_perm, lo_perm;     // storage position -> the caller's (window-local) landmark / observation index
   HostBuf<uint8_t> le_flags0;
 };
-
-// Storage order of one landmark kind of one window.  Landmarks are stored sorted by their camera tuple - free cameras ascending,
-// then fixed cameras ascending - and every landmark's observations in that same order, so that a run of landmarks with one tuple
-// (a chunk) is a dense (landmark, slot) array: observation e0 + j * k_all + s belongs to landmark l0 + j and camera cams[s].
-struct LmOrder {
-  std::vector<int> lm;        // storage position -> caller's landmark index
-  std::vector<int> obs;       // storage position of an observation -> caller's observation index
-  std::vector<int> cam;       // ... and its camera
-  std::vector<int> start;     // CSR over the storage landmarks into obs / cam (n + 1 entries)
-  std::vector<int> kfree;     // free observations of a storage landmark (they come first)
-  bool same_tuple(int a, int c) const {
-    const int na = start[a + 1] - start[a];
-    return kfree[a] == kfree[c] && na == start[c + 1] - start[c] && std::equal(cam.begin() + start[a], cam.begin() + start[a + 1], cam.begin() + start[c]);
-  }
-};
-
-void order_landmarks(const lld_ba_window& w, int D, LmOrder& out) {
-  const int n_lm = D == 3 ? w.n_points : w.n_lines;
-  const int32_t* start = D == 3 ? w.pt_obs_start : w.ln_obs_start;
-  const int32_t* ocam = D == 3 ? w.pt_obs_cam : w.ln_obs_cam;
-  const int n_obs = n_lm ? start[n_lm] : 0, nf = w.n_free_cams;
-  // per landmark: observations sorted by (fixed?, camera), stable
-  std::vector<int> scam(n_obs), sid(n_obs), kf(n_lm);
-  for (int l = 0; l < n_lm; l++) {
-    const int b0 = start[l];
-    int kfl = 0;
-    for (int o = start[l]; o < start[l + 1]; o++) {
-      const int c = ocam[o], key = (c >= nf ? (1 << 24) : 0) + c;
-      int at = b0 + (o - start[l]);
-      scam[at] = key; sid[at] = o;
-      while (at > b0 && scam[at - 1] > scam[at]) { std::swap(scam[at - 1], scam[at]); std::swap(sid[at - 1], sid[at]); at--; }   // stable insertion
-      kfl += c < nf;
-    }
-    kf[l] = kfl;
-  }
-  std::vector<int> idx(n_lm);
-  for (int l = 0; l < n_lm; l++) idx[l] = l;
-  std::stable_sort(idx.begin(), idx.end(), [&](int a, int c) {
-    if (kf[a] != kf[c]) return kf[a] < kf[c];
-    const int na = start[a + 1] - start[a], nc = start[c + 1] - start[c];
-    const int* pa = scam.data() + start[a]; const int* pc = scam.data() + start[c];
-    for (int i = 0; i < kf[a]; i++) if (pa[i] != pc[i]) return pa[i] < pc[i];
-    if (na != nc) return na < nc;
-    for (int i = kf[a]; i < na; i++) if (pa[i] != pc[i]) return pa[i] < pc[i];
-    return false;
-  });
-  out.lm = idx; out.obs.resize(n_obs); out.cam.resize(n_obs); out.start.resize(n_lm + 1); out.kfree.resize(n_lm);
-  int at = 0;
-  for (int i = 0; i < n_lm; i++) {
-    const int l = idx[i];
-    out.start[i] = at; out.kfree[i] = kf[l];
-    for (int o = start[l]; o < start[l + 1]; o++, at++) { out.obs[at] = sid[o]; out.cam[at] = scam[o] & ((1 << 24) - 1); }
-  }
-  out.start[n_lm] = at;
-}
 
 struct WinBases { long long NC, NP, NL, NPE, NLO, NF; size_t S_total, x_total; };   // totals of the windows before this one
 
 // Schur chunks of one window and one landmark kind, offsets local to this stage
 struct ChunkStage {
   std::vector<SChunk> chunks;
-  std::vector<int> sg_cams;
+  std::vector<int> sg_lm, sg_tab, sg_cams;
   std::vector<int> blk_key, blk_val, cam_key, cam_val;     // (block | camera, partial index [*4 + mode]) in generation order
   size_t n_part = 0, n_cpart = 0, lds_need = 0, wide_lds_need = 0;
-  int n_k0 = 0;                                            // leading chunks without a free camera
-  bool has_wide_obs = false; int max_k = 1;
 };
 
 struct WinStage {
-  LmOrder ord[2];                                          // points, lines
+  std::vector<PTask> ptasks, ltasks;
   ChunkStage cs[2];                                        // points, lines
   std::vector<int> blk_start, blk_src, cam_start, cam_src; // window-local CSRs over both kinds (stage_csr)
 };
 
-// everything in BAWin that follows from the window sizes
-void stage_header(const lld_ba_window& w, const lld_ba_params& P, const WinBases& b, BAWin& W) {
+// wavefront tasks of the lane-per-edge kernels + everything in BAWin that follows from the window sizes
+void stage_tasks(const lld_ba_window& w, const lld_ba_params& P, const WinBases& b, int n_windows, BAWin& W, WinStage& S) {
   std::memset(&W, 0, sizeof W);
   W.cam = lld::make_camk(w.cam);
   W.n_cams = w.n_cams; W.n_free = w.n_free_cams;
@@ -178,6 +119,27 @@ void stage_header(const lld_ba_window& w, const lld_ba_params& P, const WinBases
   W.lo_off = (int)b.NLO; W.n_lo = w.n_ln_obs;
   W.hpp_off = (int)b.NF; W.x_off = (int)b.x_total; W.S_off = (long long)b.S_total;
   W.nb_pt = (w.n_points + kLmThreads - 1) / kLmThreads; W.nb_ln = (w.n_lines + kLmThreads - 1) / kLmThreads;
+  // a task = consecutive landmarks while their edges fit into one wavefront; a landmark with more than 64 edges is a task of its own
+  auto build = [](int n_lm, const int32_t* start, long long e_base, std::vector<PTask>& out) {
+    out.reserve((size_t)(start ? start[n_lm] : 0) / 48 + 8);
+    for (int l = 0; l < n_lm;) {
+      PTask T; std::memset(&T, 0, sizeof T); T.l0 = l; T.e0 = (int)e_base + start[l];
+      while (l < n_lm) {
+        const int ne = start[l + 1] - start[l];
+        if (T.nl > 0 && (T.ne + ne > 64 || T.nl >= 64)) break;
+        T.nl++; T.ne += ne; T.ms = std::max(T.ms, ne); l++;
+        if (T.ne > 64) break;
+      }
+      out.push_back(T);
+    }
+  };
+  build(w.n_points, w.pt_obs_start, b.NPE, S.ptasks);      // lane <-> point edge
+  build(w.n_lines, w.ln_obs_start, b.NLO, S.ltasks);       // lane <-> (line, KF) observation
+  W.n_ptasks = (int)S.ptasks.size(); W.n_ltasks = (int)S.ltasks.size();
+  const int* R = n_windows >= kRoundsThroughputMinWindows ? kRoundsThroughput : kRoundsLatency;
+  for (int i = 0; i < 4; i++) W.rounds[i] = R[i];
+  W.nt_pt = (W.n_ptasks + 4 * W.rounds[2] - 1) / (4 * W.rounds[2]); W.nl_pt = (W.n_ptasks + W.rounds[0] * kLinThreads / 64 - 1) / (W.rounds[0] * kLinThreads / 64);
+  W.nt_ln = (W.n_ltasks + 4 * W.rounds[3] - 1) / (4 * W.rounds[3]); W.nl_ln = (W.n_ltasks + W.rounds[1] * kLinThreads / 64 - 1) / (W.rounds[1] * kLinThreads / 64);
   const double thMono = (double)(float)std::sqrt(5.991), thStereo = (double)(float)std::sqrt(7.815);   // Optimizer.cc:1088-1089
   W.its[0] = P.its_round1; W.its[1] = P.its_round2; W.max_trials = P.max_trials; W.ln_filter = P.ln_filter;
   W.th_mono = thMono; W.th_stereo = thStereo;
@@ -186,50 +148,40 @@ void stage_header(const lld_ba_window& w, const lld_ba_params& P, const WinBases
   if (P.protocol == 1) { W.its[1] = 0; W.th_ln_mono = W.th_ln_stereo = thStereo / 2.0; }   // double thHuberLines = thHuber3D/2.0  (Optimizer.cc:358)
 }
 
-// the window's vertices and edges into their slots of the batch-global arrays, in storage order (LmOrder)
-void stage_edges(const lld_ba_window& w, const lld_ba_params& P, const WinBases& b, const BAWin& W, const WinStage& S, HostArrays& H) {
+// the window's vertices and edges into their slots of the batch-global arrays
+void stage_edges(const lld_ba_window& w, const lld_ba_params& P, const WinBases& b, const BAWin& W, HostArrays& H) {
   std::copy(w.cam_qt, w.cam_qt + 7 * (size_t)w.n_cams, H.cam_qt0.p.get() + 7 * (size_t)b.NC);
+  if (w.n_points) std::copy(w.pt_xyz, w.pt_xyz + 3 * (size_t)w.n_points, H.pt0.p.get() + 3 * (size_t)b.NP);
+  if (w.n_lines) {
+    std::copy(w.line_x0, w.line_x0 + 3 * (size_t)w.n_lines, H.ln_x0.p.get() + 3 * (size_t)b.NL);
+    std::copy(w.line_dir, w.line_dir + 3 * (size_t)w.n_lines, H.ln_dir.p.get() + 3 * (size_t)b.NL);
+  }
   {
-    const LmOrder& O = S.ord[0];
-    double* x = H.pt0.p.get() + 3 * (size_t)b.NP; int* perm = H.pt_perm.p.get() + b.NP; int* eperm = H.pe_perm.p.get() + b.NPE;
     int* os = H.pt_obs_start.p.get() + b.NP; int* cam = H.pe_cam.p.get() + b.NPE; int* pt = H.pe_pt.p.get() + b.NPE;
     double* u = H.pe_u.p.get() + b.NPE; double* v = H.pe_v.p.get() + b.NPE; double* ur = H.pe_ur.p.get() + b.NPE; double* s = H.pe_s.p.get() + b.NPE;
     for (int p = 0; p < w.n_points; p++) {
-      const int po = O.lm[p];
-      perm[p] = po;
-      x[3 * (size_t)p] = w.pt_xyz[3 * (size_t)po]; x[3 * (size_t)p + 1] = w.pt_xyz[3 * (size_t)po + 1]; x[3 * (size_t)p + 2] = w.pt_xyz[3 * (size_t)po + 2];
-      os[p] = (int)b.NPE + O.start[p];
-      for (int e = O.start[p]; e < O.start[p + 1]; e++) {
-        const int o = O.obs[e];
-        eperm[e] = o;
-        cam[e] = w.pt_obs_cam[o]; pt[e] = p;
-        u[e] = w.pt_obs_uvr[3 * (size_t)o]; v[e] = w.pt_obs_uvr[3 * (size_t)o + 1]; ur[e] = w.pt_obs_uvr[3 * (size_t)o + 2];
-        s[e] = w.pt_obs_inv_sigma2[o];
+      os[p] = (int)b.NPE + w.pt_obs_start[p];
+      for (int o = w.pt_obs_start[p]; o < w.pt_obs_start[p + 1]; o++) {
+        cam[o] = w.pt_obs_cam[o]; pt[o] = p;
+        u[o] = w.pt_obs_uvr[3 * (size_t)o]; v[o] = w.pt_obs_uvr[3 * (size_t)o + 1]; ur[o] = w.pt_obs_uvr[3 * (size_t)o + 2];
+        s[o] = w.pt_obs_inv_sigma2[o];
       }
     }
   }
   {
-    const LmOrder& O = S.ord[1];
     const size_t e0 = 2 * (size_t)b.NLO;
-    double* x0 = H.ln_x0.p.get() + 3 * (size_t)b.NL; double* dir = H.ln_dir.p.get() + 3 * (size_t)b.NL;
-    int* perm = H.ln_perm.p.get() + b.NL; int* operm = H.lo_perm.p.get() + b.NLO;
     int* os = H.ln_obs_start.p.get() + b.NL; int* cam = H.le_cam.p.get() + e0; int* ln = H.le_ln.p.get() + e0;
     double* xs = H.le_xs.p.get() + e0; double* ys = H.le_ys.p.get() + e0; double* xe = H.le_xe.p.get() + e0; double* ye = H.le_ye.p.get() + e0;
     double* s = H.le_s.p.get() + e0; double* bx = H.le_bx.p.get() + e0; uint8_t* fl = H.le_flags0.p.get() + e0;
     for (int l = 0; l < w.n_lines; l++) {
-      const int lo = O.lm[l];
-      perm[l] = lo;
-      for (int i = 0; i < 3; i++) { x0[3 * (size_t)l + i] = w.line_x0[3 * (size_t)lo + i]; dir[3 * (size_t)l + i] = w.line_dir[3 * (size_t)lo + i]; }
-      os[l] = (int)b.NLO + O.start[l];
-      for (int q = O.start[l]; q < O.start[l + 1]; q++) {
-        const int o = O.obs[q];
-        operm[q] = o;
+      os[l] = (int)b.NLO + w.ln_obs_start[l];
+      for (int o = w.ln_obs_start[l]; o < w.ln_obs_start[l + 1]; o++) {
         const double* Lf = w.ln_obs_left + 4 * (size_t)o; const double* Rt = w.ln_obs_right + 4 * (size_t)o;
         const bool has_right = !(Rt[0] < 0);                                          // startPointX >= 0 (LineOptimizer.cc:60)
         for (int si = 0; si < 2; si++) {
           const double* kl = si == 0 ? Lf : Rt;
           const bool valid = si == 0 || has_right;
-          const size_t e = 2 * (size_t)q + si;
+          const size_t e = 2 * (size_t)o + si;
           cam[e] = w.ln_obs_cam[o]; ln[e] = l;
           xs[e] = kl[0]; ys[e] = kl[1]; xe[e] = kl[2]; ye[e] = kl[3];
           s[e] = valid ? (P.protocol == 1 ? 1.0 : lld::line_info(P.gamma, w.ln_obs_octave[2 * (size_t)o + si])) : 0.0;   // AddLineMinimalGlobal: identity
@@ -241,26 +193,53 @@ void stage_edges(const lld_ba_window& w, const lld_ba_params& P, const WinBases&
   }
 }
 
-// Chunks of one landmark kind: runs of storage landmarks with one camera tuple, cut at chunk_landmarks.  The chunks whose landmarks
-// see a free camera are the Schur work items: one partial per slot pair of the free slots.  Structure only: outlier levels are
-// handled through zeroed Hpl blocks at run time.  Chunks come out sorted by the number of free cameras, so those without one
-// (landmarks seen by fixed cameras only, or by none) lead the list.
-void stage_chunks(const lld_ba_window& w, int D, const WinBases& b, int chunk_landmarks, const LmOrder& O, ChunkStage& out) {
+// Schur work items of one landmark kind: sort the landmarks by their set of free cameras, cut the runs into chunks, one item per
+// (chunk, slot pair).  Structure only: outlier levels are handled through zeroed Hpl blocks at run time.
+void stage_chunks(const lld_ba_window& w, int D, const WinBases& b, int chunk_landmarks, ChunkStage& out) {
   const int n_lm = D == 3 ? w.n_points : w.n_lines;
   if (n_lm == 0) return;
+  const int32_t* start = D == 3 ? w.pt_obs_start : w.ln_obs_start;
+  const int32_t* ocam = D == 3 ? w.pt_obs_cam : w.ln_obs_cam;
   const long long id_base = D == 3 ? b.NPE : b.NLO, lm_base = D == 3 ? b.NP : b.NL;
-  int i0 = 0;
-  while (i0 < n_lm) {
-    int i1 = i0 + 1;
-    while (i1 < n_lm && i1 - i0 < chunk_landmarks && O.same_tuple(i0, i1)) i1++;
+  // a landmark's signature = its free cameras in ascending order (ties keep the observation order) with the ids of the
+  // matching observations; flat arrays, no per-landmark allocation
+  std::vector<int> soff(1, 0), scam, sid, sigs;                    // sigs: landmarks that touch a free camera
+  soff.reserve(n_lm + 1); scam.reserve(start[n_lm] - start[0]); sid.reserve(start[n_lm] - start[0]); sigs.reserve(n_lm);
+  for (int l = 0; l < n_lm; l++) {
+    const int b0 = (int)scam.size();
+    for (int o = start[l]; o < start[l + 1]; o++) {
+      if (ocam[o] >= w.n_free_cams) continue;
+      int at = (int)scam.size();
+      scam.push_back(ocam[o]); sid.push_back((int)(id_base + o));
+      while (at > b0 && scam[at - 1] > scam[at]) { std::swap(scam[at - 1], scam[at]); std::swap(sid[at - 1], sid[at]); at--; }   // stable insertion
+    }
+    soff.push_back((int)scam.size());
+    if ((int)scam.size() > b0) sigs.push_back(l);
+  }
+  auto sig_k = [&](int l) { return soff[l + 1] - soff[l]; };
+  auto same_cams = [&](int a, int c) {
+    if (sig_k(a) != sig_k(c)) return false;
+    return std::equal(scam.begin() + soff[a], scam.begin() + soff[a + 1], scam.begin() + soff[c]);
+  };
+  std::stable_sort(sigs.begin(), sigs.end(), [&](int a, int c) {
+    const int ka = sig_k(a), kc = sig_k(c);
+    if (ka != kc) return ka < kc;
+    const int* pa = scam.data() + soff[a]; const int* pc = scam.data() + soff[c];
+    for (int i = 0; i < ka; i++) if (pa[i] != pc[i]) return pa[i] < pc[i];
+    return false;
+  });
+  out.sg_lm.reserve(sigs.size()); out.sg_tab.reserve(scam.size());
+  size_t i0 = 0;
+  while (i0 < sigs.size()) {
+    size_t i1 = i0 + 1;
+    while (i1 < sigs.size() && i1 - i0 < (size_t)chunk_landmarks && same_cams(sigs[i0], sigs[i1])) i1++;
     SChunk C; std::memset(&C, 0, sizeof C);
-    const int* c0cams = O.cam.data() + O.start[i0];
-    C.k = O.kfree[i0]; C.k_all = O.start[i0 + 1] - O.start[i0]; C.n_lm = i1 - i0;
-    C.l0 = (int)(lm_base + i0); C.e0 = (int)(id_base + O.start[i0]); C.cams_off = (int)out.sg_cams.size();
-    out.sg_cams.insert(out.sg_cams.end(), c0cams, c0cams + C.k_all);
+    const int* c0cams = scam.data() + soff[sigs[i0]];
+    C.k = sig_k(sigs[i0]); C.D = D; C.n_lm = (int)(i1 - i0);
+    C.lm_off = (int)out.sg_lm.size(); C.tab_off = (int)out.sg_tab.size(); C.cams_off = (int)out.sg_cams.size();
+    out.sg_cams.insert(out.sg_cams.end(), c0cams, c0cams + C.k);
+    for (size_t i = i0; i < i1; i++) { out.sg_lm.push_back((int)(lm_base + sigs[i])); out.sg_tab.insert(out.sg_tab.end(), sid.begin() + soff[sigs[i]], sid.begin() + soff[sigs[i] + 1]); }
     C.part_off = (int)out.n_part; C.cpart_off = (int)out.n_cpart;
-    if (C.k == 0) out.n_k0++;
-    if (C.k_all > 64) out.has_wide_obs = true; else out.max_k = std::max(out.max_k, C.k);
     int pidx = 0;
     for (int sa = 0; sa < C.k; sa++) {
       const int ca = c0cams[sa];
@@ -273,20 +252,10 @@ void stage_chunks(const lld_ba_window& w, int D, const WinBases& b, int chunk_la
     }
     out.n_part += (size_t)C.k * (C.k + 1) / 2; out.n_cpart += C.k;
     if (C.k > kSchurWideK) out.wide_lds_need = std::max(out.wide_lds_need, (size_t)schur_lds_doubles(C.k, D) * sizeof(double));
-    else if (C.k > 0) out.lds_need = std::max(out.lds_need, (size_t)schur_lds_doubles(C.k, D) * sizeof(double));   // one staged sub-batch
+    else out.lds_need = std::max(out.lds_need, (size_t)schur_lds_doubles(C.k, D) * sizeof(double));   // two staged sub-batches
     out.chunks.push_back(C);
     i0 = i1;
   }
-}
-
-// The update kernels put four consecutive chunks of a window into one workgroup, which lives as long as its longest wavefront: order
-// the chunks by the work in them (those without a free camera stay in front: the Schur kernels skip that prefix).  Chunk order
-// carries no meaning - partial slots and CSR entries go by the numbers assigned above.
-void order_chunks(ChunkStage& cs) {
-  std::stable_sort(cs.chunks.begin(), cs.chunks.end(), [](const SChunk& a, const SChunk& b) {
-    if ((a.k == 0) != (b.k == 0)) return a.k == 0;
-    return (long long)a.n_lm * a.k_all > (long long)b.n_lm * b.k_all;
-  });
 }
 
 // Per reduced-system block / per camera: which partials to sum, in generation order (points before lines).  Counting sort of
@@ -345,9 +314,9 @@ static int ba_make_groups(lld_ba_batch* B, int n_groups) {
     for (int wi = Gr.w0; wi < Gr.w0 + Gr.nw; wi++) {
       const BAWin& W = B->h_wins[wi];
       Gr.max_lblocks = std::max(Gr.max_lblocks, W.nb_pt + W.nb_ln);
-      Gr.max_chunks_pt = std::max(Gr.max_chunks_pt, W.n_items_pt); Gr.max_chunks_ln = std::max(Gr.max_chunks_ln, W.n_items - W.n_items_pt);
-      Gr.max_items_pt = std::max(Gr.max_items_pt, W.n_items_pt - W.n_k0_pt); Gr.max_items_ln = std::max(Gr.max_items_ln, W.n_items - W.n_items_pt - W.n_k0_ln);
-      Gr.max_items_all = std::max(Gr.max_items_all, W.n_items);
+      Gr.max_nt_pt = std::max(Gr.max_nt_pt, W.nt_pt); Gr.max_nb_ln = std::max(Gr.max_nb_ln, W.nt_ln);
+      Gr.max_nl_pt = std::max(Gr.max_nl_pt, W.nl_pt); Gr.max_nl_ln = std::max(Gr.max_nl_ln, W.nl_ln);
+      Gr.max_items_pt = std::max(Gr.max_items_pt, W.n_items_pt); Gr.max_items_ln = std::max(Gr.max_items_ln, W.n_items - W.n_items_pt);
       Gr.max_blk = std::max(Gr.max_blk, W.n_free * (W.n_free + 1) / 2);
     }
   }
@@ -376,8 +345,10 @@ static int ba_batch_create_impl(lld_ctx* ctx, int n_windows, const lld_ba_window
   //      (every offset that depends only on the window sizes is known up front), the variable-length Schur structures are
   //      staged per window and placed by a second parallel pass once their sizes are known
   B->h_wins.resize(n_windows);
-  // landmarks per Schur chunk: long chunks mean fewer atomics into S, short ones more lanes for small batches
-  B->chunk_landmarks = n_windows >= 64 ? 128 : (n_windows >= 8 ? 64 : 32);
+  // landmarks per Schur chunk: long chunks mean fewer partials to reduce (256: 566 us per Schur launch of 256 windows, 128 and 512: 607),
+  // short ones more wavefronts for small batches
+  B->chunk_landmarks = n_windows >= 64 ? 256 : (n_windows >= 8 ? 64 : 32);
+  if (const char* e = std::getenv("LLD_BA_CHUNK")) { const int v = std::atoi(e); if (v >= 1 && v <= 4096) B->chunk_landmarks = v; }   // experiments
   if (const char* e = std::getenv("LLD_BA_CHUNK")) { const int v = std::atoi(e); if (v >= 1 && v <= 4096) B->chunk_landmarks = v; }   // experiments
   std::vector<WinBases> bases(n_windows + 1);
   {
@@ -399,7 +370,6 @@ static int ba_batch_create_impl(lld_ctx* ctx, int n_windows, const lld_ba_window
   bool mem_ok = true;
   mem_ok &= H.cam_qt0.alloc(7 * (size_t)NC); mem_ok &= H.pt0.alloc(3 * (size_t)NP); mem_ok &= H.ln_x0.alloc(3 * (size_t)NL); mem_ok &= H.ln_dir.alloc(3 * (size_t)NL);
   mem_ok &= H.pt_obs_start.alloc((size_t)NP + 1); mem_ok &= H.ln_obs_start.alloc((size_t)NL + 1);
-  mem_ok &= H.pt_perm.alloc((size_t)NP); mem_ok &= H.pe_perm.alloc((size_t)NPE); mem_ok &= H.ln_perm.alloc((size_t)NL); mem_ok &= H.lo_perm.alloc((size_t)NLO);
   mem_ok &= H.pe_cam.alloc(NPE); mem_ok &= H.pe_pt.alloc(NPE); mem_ok &= H.pe_u.alloc(NPE); mem_ok &= H.pe_v.alloc(NPE); mem_ok &= H.pe_ur.alloc(NPE); mem_ok &= H.pe_s.alloc(NPE);
   mem_ok &= H.le_cam.alloc(NLE); mem_ok &= H.le_ln.alloc(NLE); mem_ok &= H.le_xs.alloc(NLE); mem_ok &= H.le_ys.alloc(NLE); mem_ok &= H.le_xe.alloc(NLE); mem_ok &= H.le_ye.alloc(NLE); mem_ok &= H.le_s.alloc(NLE); mem_ok &= H.le_bx.alloc(NLE);
   mem_ok &= H.le_flags0.alloc(NLE);
@@ -434,46 +404,52 @@ static int ba_batch_create_impl(lld_ctx* ctx, int n_windows, const lld_ba_window
     if (st) { int ok = LLD_OK; first_error.compare_exchange_strong(ok, st); return; }
     BAWin& W = B->h_wins[wi];
     WinStage& S = stages[wi];
-    order_landmarks(wins[wi], 3, S.ord[0]);
-    order_landmarks(wins[wi], 4, S.ord[1]);
-    lap1("landmarks ordered");
-    stage_header(wins[wi], P, bases[wi], W);
-    stage_edges(wins[wi], P, bases[wi], W, S, H);
-    lap1("edges flattened");
-    stage_chunks(wins[wi], 3, bases[wi], B->chunk_landmarks, S.ord[0], S.cs[0]);
-    stage_chunks(wins[wi], 4, bases[wi], B->chunk_landmarks, S.ord[1], S.cs[1]);
-    order_chunks(S.cs[0]); order_chunks(S.cs[1]);
+    stage_tasks(wins[wi], P, bases[wi], n_windows, W, S);
+    lap1("tasks built");
+    if (n_windows == 1 && wins[wi].n_pt_obs + wins[wi].n_ln_obs > 20000) {
+      // a single large window: the point chunks on a helper thread, edges and line chunks here
+      std::thread helper;
+      bool helped = false;
+      try { helper = std::thread([&]() { try { stage_chunks(wins[wi], 3, bases[wi], B->chunk_landmarks, S.cs[0]); } catch (...) { int ok = LLD_OK; first_error.compare_exchange_strong(ok, LLD_ERR_ALLOC); } }); helped = true; } catch (...) {}
+      stage_edges(wins[wi], P, bases[wi], W, H);
+      lap1("edges flattened");
+      stage_chunks(wins[wi], 4, bases[wi], B->chunk_landmarks, S.cs[1]);
+      if (helped) helper.join(); else stage_chunks(wins[wi], 3, bases[wi], B->chunk_landmarks, S.cs[0]);
+    } else {
+      stage_edges(wins[wi], P, bases[wi], W, H);
+      lap1("edges flattened");
+      stage_chunks(wins[wi], 3, bases[wi], B->chunk_landmarks, S.cs[0]);
+      stage_chunks(wins[wi], 4, bases[wi], B->chunk_landmarks, S.cs[1]);
+    }
     stage_csr(wins[wi].n_free_cams, S);
     lap1("chunks built");
   });
   if (first_error.load() != LLD_OK) { const int st = first_error.load(); delete B; return st; }
   // ---- where each window's variable-length pieces go
-  struct Place { size_t chunk, cams, blk_start, blk_src, cam_start, cam_src, part, cpart; };
+  struct Place { size_t ptask, ltask, chunk, lm, tab, cams, blk_start, blk_src, cam_start, cam_src, part, cpart; };
   std::vector<Place> place(n_windows + 1);
-  long long NPART = 0; int max_blk = 0;
+  size_t n_hpart = 0; long long NPART = 0; int max_blk = 0;
   {
     Place q{};
     for (int wi = 0; wi < n_windows; wi++) {
       place[wi] = q;
       const WinStage& S = stages[wi];
       BAWin& W = B->h_wins[wi];
-      W.item_off = (int)q.chunk;
+      W.ptask_off = (int)q.ptask; W.ltask_off = (int)q.ltask; W.item_off = (int)q.chunk;
       W.n_items_pt = (int)S.cs[0].chunks.size(); W.n_items = W.n_items_pt + (int)S.cs[1].chunks.size();
-      W.n_k0_pt = S.cs[0].n_k0; W.n_k0_ln = S.cs[1].n_k0;
       W.blk_csr_off = (int)q.blk_start; W.cam_csr_off = (int)q.cam_start;
-      W.part_off = (int)NPART; NPART += W.n_items;
-      B->has_wide_obs = B->has_wide_obs || S.cs[0].has_wide_obs || S.cs[1].has_wide_obs;
-      B->max_k = std::max(B->max_k, std::max(S.cs[0].max_k, S.cs[1].max_k));
-      q.chunk += (size_t)W.n_items;
-      q.cams += S.cs[0].sg_cams.size() + S.cs[1].sg_cams.size();
+      W.hpart_off = (long long)n_hpart; n_hpart += (size_t)(W.nl_pt + W.nl_ln) * W.n_free * 27;
+      W.part_off = (int)NPART; NPART += W.nt_pt + W.nt_ln;
+      q.ptask += S.ptasks.size(); q.ltask += S.ltasks.size(); q.chunk += (size_t)W.n_items;
+      q.lm += S.cs[0].sg_lm.size() + S.cs[1].sg_lm.size(); q.tab += S.cs[0].sg_tab.size() + S.cs[1].sg_tab.size(); q.cams += S.cs[0].sg_cams.size() + S.cs[1].sg_cams.size();
       q.blk_start += S.blk_start.size(); q.blk_src += S.blk_src.size(); q.cam_start += S.cam_start.size(); q.cam_src += S.cam_src.size();
       q.part += S.cs[0].n_part + S.cs[1].n_part; q.cpart += S.cs[0].n_cpart + S.cs[1].n_cpart;
-      if (q.part * 4 > 0x7fffffffull) { delete B; return LLD_ERR_UNSUPPORTED; }
+      if (q.part * 4 > 0x7fffffffull || q.tab > 0x7fffffffull) { delete B; return LLD_ERR_UNSUPPORTED; }
       for (int d = 0; d < 2; d++) B->schur_lds[d] = std::max(B->schur_lds[d], S.cs[d].lds_need);
       for (int d = 0; d < 2; d++) B->schur_wide_lds = std::max(B->schur_wide_lds, S.cs[d].wide_lds_need);
       if (B->schur_wide_lds > 64 * 1024) { delete B; return LLD_ERR_UNSUPPORTED; }       // a landmark with > ~450 free observations
       max_blk = std::max(max_blk, W.n_free * (W.n_free + 1) / 2);
-      B->max_items_pt = std::max(B->max_items_pt, W.n_items_pt - W.n_k0_pt); B->max_items_ln = std::max(B->max_items_ln, W.n_items - W.n_items_pt - W.n_k0_ln);
+      B->max_items_pt = std::max(B->max_items_pt, W.n_items_pt); B->max_items_ln = std::max(B->max_items_ln, W.n_items - W.n_items_pt);
       B->max_lblocks = std::max(B->max_lblocks, W.nb_pt + W.nb_ln);
       B->max_free = std::max(B->max_free, W.n_free);
       B->max_cams = std::max(B->max_cams, W.n_cams);
@@ -484,22 +460,26 @@ static int ba_batch_create_impl(lld_ctx* ctx, int n_windows, const lld_ba_window
   const Place& tot = place[n_windows];
   const size_t n_part = tot.part, n_cpart = tot.cpart;
   size_t rec_total = 0;
-  B->h_chunks.resize(tot.chunk);
-  HostBuf<int> sg_cams, blk_start, blk_src, cam_start, cam_src;
-  mem_ok &= sg_cams.alloc(tot.cams);
+  B->h_ptasks.resize(tot.ptask); B->h_ltasks.resize(tot.ltask); B->h_chunks.resize(tot.chunk);
+  HostBuf<int> sg_lm, sg_tab, sg_cams, blk_start, blk_src, cam_start, cam_src;
+  mem_ok &= sg_lm.alloc(tot.lm); mem_ok &= sg_tab.alloc(tot.tab); mem_ok &= sg_cams.alloc(tot.cams);
   mem_ok &= blk_start.alloc(tot.blk_start + 1); mem_ok &= blk_src.alloc(tot.blk_src); mem_ok &= cam_start.alloc(tot.cam_start + 1); mem_ok &= cam_src.alloc(tot.cam_src);
   if (!mem_ok) { delete B; return LLD_ERR_ALLOC; }
   blk_start.p[tot.blk_start] = (int)tot.blk_src; cam_start.p[tot.cam_start] = (int)tot.cam_src;
   for_windows([&](int wi) {
     const Place& q = place[wi];
     WinStage& S = stages[wi];
-    size_t at_chunk = q.chunk, at_cams = q.cams;
+    std::copy(S.ptasks.begin(), S.ptasks.end(), B->h_ptasks.begin() + q.ptask);
+    std::copy(S.ltasks.begin(), S.ltasks.end(), B->h_ltasks.begin() + q.ltask);
+    size_t at_chunk = q.chunk, at_lm = q.lm, at_tab = q.tab, at_cams = q.cams;
     for (int d = 0; d < 2; d++) {
       const ChunkStage& C = S.cs[d];
       for (SChunk c : C.chunks) {
-        c.cams_off += (int)at_cams; c.part_off += (int)q.part; c.cpart_off += (int)q.cpart;      // stage_csr numbered both kinds within the window
+        c.lm_off += (int)at_lm; c.tab_off += (int)at_tab; c.cams_off += (int)at_cams; c.part_off += (int)q.part; c.cpart_off += (int)q.cpart;      // stage_csr numbered both kinds within the window
         B->h_chunks[at_chunk++] = c;
       }
+      std::copy(C.sg_lm.begin(), C.sg_lm.end(), sg_lm.p.get() + at_lm); at_lm += C.sg_lm.size();
+      std::copy(C.sg_tab.begin(), C.sg_tab.end(), sg_tab.p.get() + at_tab); at_tab += C.sg_tab.size();
       std::copy(C.sg_cams.begin(), C.sg_cams.end(), sg_cams.p.get() + at_cams); at_cams += C.sg_cams.size();
     }
     // the window-local CSRs number their partials from the window's first one
@@ -516,7 +496,11 @@ static int ba_batch_create_impl(lld_ctx* ctx, int n_windows, const lld_ba_window
   // few windows whose reduced system is beyond the matrix-core Cholesky: the PCG runs across the whole GPU (see ba_pcgm_*)
   B->pcg_multi = n_windows <= 8 && B->max_free * 6 > kCholMN && P.reduced_solver != 2;
   if (B->max_free > kMaxFreeCamsOneWg && !B->pcg_multi) { delete B; return LLD_ERR_UNSUPPORTED; }   // batches of huge windows: not in this build
-  for (int wi = 0; wi < n_windows; wi++) B->h_wins[wi].win_index = wi;
+  // LDS copies of the per-camera accumulators in the linearise kernels: as many as fit (4 for local windows)
+  B->acc_copies = kAccCopies;
+  while (B->acc_copies > 1 && ((size_t)B->max_free * 27 * B->acc_copies + 8 + (size_t)B->max_cams * 7) * sizeof(double) > 150 * 1024) B->acc_copies >>= 1;
+  if (((size_t)B->max_free * 27 * B->acc_copies + 8 + (size_t)B->max_cams * 7) * sizeof(double) > 158 * 1024) { delete B; return LLD_ERR_UNSUPPORTED; }
+  for (int wi = 0; wi < n_windows; wi++) { B->h_wins[wi].acc_copies = B->acc_copies; B->h_wins[wi].win_index = wi; }
   B->max_blk = max_blk;
   // fixed-stride result records (what an RCCL gather of the batch moves)
   for (int wi = 0; wi < n_windows; wi++) B->h_wins[wi].rec_off = (long long)(B->rec_stride * (size_t)wi);
@@ -531,14 +515,13 @@ static int ba_batch_create_impl(lld_ctx* ctx, int n_windows, const lld_ba_window
     auto up_b = [&](const HostBuf<uint8_t>& h, size_t count) { uint8_t* d = sl.take<uint8_t>(count); if (real && !h.empty()) (void)hipMemcpyAsync(d, h.data(), h.size(), hipMemcpyHostToDevice, st); return (const uint8_t*)d; };
     B->d_wins = sl.take<BAWin>(n_windows); B->d_state = sl.take<BAState>(n_windows);
     std::memset(&A, 0, sizeof A);
-    A.NC = NC; A.NP = NP; A.NL = NL; A.NPE = NPE; A.NLO = NLO; A.n_cpart = (long long)n_cpart;
+    A.NC = NC; A.NP = NP; A.NL = NL;
     A.cam_qt = sl.take<double>(2 * NC * 7 + 1);
     A.ptx = sl.take<double>(2 * NP + 1); A.pty = sl.take<double>(2 * NP + 1); A.ptz = sl.take<double>(2 * NP + 1);
     A.lqx = sl.take<double>(2 * NL + 1); A.lqy = sl.take<double>(2 * NL + 1); A.lqz = sl.take<double>(2 * NL + 1); A.lqw = sl.take<double>(2 * NL + 1); A.lal = sl.take<double>(2 * NL + 1);
     A.cam_qt0 = up_d(H.cam_qt0, NC * 7 + 1); A.pt0 = up_d(H.pt0, NP * 3 + 1);
     A.ln_x0 = up_d(H.ln_x0, NL * 3 + 1); A.ln_dir = up_d(H.ln_dir, NL * 3 + 1);
     A.pt_obs_start = up_i(H.pt_obs_start, NP + 2); A.ln_obs_start = up_i(H.ln_obs_start, NL + 2);
-    A.pt_perm = up_i(H.pt_perm, NP + 1); A.pe_perm = up_i(H.pe_perm, NPE + 1); A.ln_perm = up_i(H.ln_perm, NL + 1); A.lo_perm = up_i(H.lo_perm, NLO + 1);
     A.pe_cam = up_i(H.pe_cam, NPE + 1); A.pe_pt = up_i(H.pe_pt, NPE + 1);
     A.pe_u = up_d(H.pe_u, NPE + 1); A.pe_v = up_d(H.pe_v, NPE + 1); A.pe_ur = up_d(H.pe_ur, NPE + 1); A.pe_s = up_d(H.pe_s, NPE + 1);
     A.le_cam = up_i(H.le_cam, NLE + 1); A.le_ln = up_i(H.le_ln, NLE + 1);
@@ -547,10 +530,10 @@ static int ba_batch_create_impl(lld_ctx* ctx, int n_windows, const lld_ba_window
     A.le_flags0 = up_b(H.le_flags0, NLE + 1);
     A.pe_flags = sl.take<uint8_t>(NPE + 1); A.le_flags = sl.take<uint8_t>(NLE + 1);
     A.pe_chi2 = sl.take<double>(NPE + 1); A.le_chi2 = sl.take<double>(NLE + 1);
-    A.pe_ws = sl.take<double>(2 * (size_t)NPE + 1); A.lo_W = sl.take<double>(2 * (size_t)NLO * 24 + 1);
+    A.pe_ws = sl.take<double>((size_t)NPE + 1); A.lo_W = sl.take<double>((size_t)NLO * 24 + 1);
     A.pt_active = sl.take<uint8_t>(NP + 1); A.ln_active = sl.take<uint8_t>(NL + 1); A.ln_removed = sl.take<uint8_t>(NL + 1);
-    A.pt_V = sl.take<double>(2 * (size_t)NP * 9 + 1); A.ln_V = sl.take<double>(2 * (size_t)NL * 14 + 1);
-    A.hp_part = sl.take<double>(2 * n_cpart * 27 + 2);
+    A.pt_V = sl.take<double>((size_t)NP * 9 + 1); A.ln_V = sl.take<double>((size_t)NL * 14 + 1);
+    A.hpp_part = sl.take<double>(n_hpart + 2);
     A.Hpp = sl.take<double>((size_t)NF * 21 + 1); A.bp = sl.take<double>((size_t)NF * 6 + 1);
     A.S = sl.take<double>(S_total + 1); A.bschur = sl.take<double>(x_total + 1); A.xp = sl.take<double>(x_total + 1);
     A.x_total = (long long)x_total;
@@ -559,13 +542,18 @@ static int ba_batch_create_impl(lld_ctx* ctx, int n_windows, const lld_ba_window
     A.blk_start = up_i(blk_start, blk_start.size() + 1); A.blk_src = up_i(blk_src, blk_src.size() + 1);
     A.cam_start = up_i(cam_start, cam_start.size() + 1); A.cam_src = up_i(cam_src, cam_src.size() + 1);
     A.sp_part = sl.take<double>(n_part * 36 + 2); A.sp_cpart = sl.take<double>(n_cpart * 6 + 2);
-    A.sg_cams = up_i(sg_cams, sg_cams.size() + 1);
+    A.sg_lm = up_i(sg_lm, sg_lm.size() + 1); A.sg_tab = up_i(sg_tab, sg_tab.size() + 1); A.sg_cams = up_i(sg_cams, sg_cams.size() + 1);
     {
       SChunk* dc = sl.take<SChunk>(B->h_chunks.size() + 1);
       if (real && !B->h_chunks.empty()) (void)hipMemcpyAsync(dc, B->h_chunks.data(), B->h_chunks.size() * sizeof(SChunk), hipMemcpyHostToDevice, st);
       A.sg_chunks = dc;
+      PTask* dt = sl.take<PTask>(B->h_ptasks.size() + 1);
+      if (real && !B->h_ptasks.empty()) (void)hipMemcpyAsync(dt, B->h_ptasks.data(), B->h_ptasks.size() * sizeof(PTask), hipMemcpyHostToDevice, st);
+      A.ptasks = dt;
+      PTask* dl = sl.take<PTask>(B->h_ltasks.size() + 1);
+      if (real && !B->h_ltasks.empty()) (void)hipMemcpyAsync(dl, B->h_ltasks.data(), B->h_ltasks.size() * sizeof(PTask), hipMemcpyHostToDevice, st);
+      A.ltasks = dl;
     }
-    A.sink = sl.take<double>((size_t)kSinkSlots * 64);
     A.records = sl.take<unsigned char>(rec_total + 256);
     B->d_counters = sl.take<int>(4 * 8);
   };
@@ -583,12 +571,15 @@ static int ba_batch_create_impl(lld_ctx* ctx, int n_windows, const lld_ba_window
   {
     const size_t pcg_lds = ((size_t)B->max_free * 6 * 4 + kPcgThreads + (size_t)B->max_free * 36 + 32) * sizeof(double);
     if (!B->pcg_multi) LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_pcg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pcg_lds));
-    const size_t upd_lds0 = (8 + (size_t)B->max_cams * 14 + (size_t)B->max_free * 6 + (size_t)kUpdChunks * upd_wave_lds_doubles(B->max_k)) * sizeof(double);
-    if (upd_lds0 > 160 * 1024) { delete B; return LLD_ERR_UNSUPPORTED; }
-    if (upd_lds0 > 48 * 1024) {
-      LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_update_pt_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)upd_lds0));
-      LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_update_ln_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)upd_lds0));
+    const size_t bs_lds0 = (8 + (size_t)B->max_cams * 14 + (size_t)B->max_free * 6) * sizeof(double);
+    if (bs_lds0 > 48 * 1024) {
+      LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_backsub_pt_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bs_lds0));
+      LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_backsub_both_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bs_lds0));
     }
+    const size_t lin_lds = ((size_t)B->max_free * 27 * B->acc_copies + 8 + (size_t)B->max_cams * 7) * sizeof(double);
+    LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_linearize_pt_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lin_lds));
+    LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_linearize_ln_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lin_lds));
+    LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_linearize_both_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lin_lds));
     LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_chol_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
     LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_chol_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)(kCholMLdsDoubles * sizeof(double))));
@@ -624,7 +615,8 @@ int lld_ba_batch_solve(lld_ba_batch* B, volatile const int* abort_flag) {
   hipEvent_t t_begin, t_end;
   LLD_HIP_TRY(hipEventCreate(&t_begin)); LLD_HIP_TRY(hipEventCreate(&t_end));
   LLD_HIP_TRY(hipEventRecord(t_begin, ctx->stream));
-  const size_t upd_lds = (8 + (size_t)B->max_cams * 14 + (size_t)B->max_free * 6 + (size_t)kUpdChunks * upd_wave_lds_doubles(B->max_k)) * sizeof(double);
+  const size_t lin_lds = ((size_t)B->max_free * 27 * B->acc_copies + 8 + (size_t)B->max_cams * 7) * sizeof(double);
+  const size_t bs_lds = (8 + (size_t)B->max_cams * 14 + (size_t)B->max_free * 6) * sizeof(double);
   const size_t pcg_lds = ((size_t)B->max_free * 6 * 4 + kPcgThreads + (size_t)B->max_free * 36 + 32) * sizeof(double);
   const size_t chol_fixed = ((size_t)B->max_free * 36 * 2 + (size_t)B->max_free * 6 * 2 + 32) * sizeof(double);
   // whatever LDS is left (a workgroup may own up to 160 KiB) holds the trailing block triangle of S
@@ -648,13 +640,12 @@ int lld_ba_batch_solve(lld_ba_batch* B, volatile const int* abort_flag) {
     const int abort_now = (abort_flag && *abort_flag) ? 1 : 0;
     LLD_HIP_TRY(hipMemsetAsync(G.d_counters, 0, 4 * sizeof(int), st));
     LLD_HIP_TRY(hipEventRecord(G.ev[0], st));
-    // landmark update kernels: sel 0 = the linearisation a round starts with (windows with need_lin), sel 1 = the LM trial
-    auto launch_update = [&](int sel) {
-      if (G.max_chunks_pt > 0) hipLaunchKernelGGL(ba_update_pt_kernel, dim3((G.max_chunks_pt + kUpdChunks - 1) / kUpdChunks, nw), dim3(kUpdThreads), upd_lds, st, A, dw, ds, sel, B->max_k);
-      if (G.max_chunks_ln > 0) hipLaunchKernelGGL(ba_update_ln_kernel, dim3((G.max_chunks_ln + kUpdChunks - 1) / kUpdChunks, nw), dim3(kUpdThreads), upd_lds, st, A, dw, ds, sel);
-      if (B->has_wide_obs) hipLaunchKernelGGL(ba_update_wide_kernel, dim3(G.max_items_all, nw), dim3(64), 0, st, A, dw, ds, sel);
-    };
-    launch_update(0);
+    const bool fuse_pairs = B->n_windows < kFusePairsBelowWindows;                           // see ba_linearize_both_kernel
+    if (fuse_pairs && G.max_nl_pt > 0 && G.max_nl_ln > 0) hipLaunchKernelGGL(ba_linearize_both_kernel, dim3(G.max_nl_pt + G.max_nl_ln, nw), dim3(kLinThreads), lin_lds, st, A, dw, ds, G.max_nl_pt);
+    else {
+      if (G.max_nl_pt > 0) hipLaunchKernelGGL(ba_linearize_pt_kernel, dim3(G.max_nl_pt, nw), dim3(kLinThreads), lin_lds, st, A, dw, ds);
+      if (G.max_nl_ln > 0) hipLaunchKernelGGL(ba_linearize_ln_kernel, dim3(G.max_nl_ln, nw), dim3(kLinThreads), lin_lds, st, A, dw, ds);
+    }
     hipLaunchKernelGGL(ba_hpp_reduce_kernel, dim3(std::max(1, (B->max_free * 27 + 255) / 256), nw), dim3(256), 0, st, A, dw, ds);
     hipLaunchKernelGGL(ba_begin_kernel, dim3(nw), dim3(kCtlThreads), 0, st, A, dw, ds, nw);
     LLD_HIP_TRY(hipEventRecord(G.ev[1], st));
@@ -665,7 +656,7 @@ int lld_ba_batch_solve(lld_ba_batch* B, volatile const int* abort_flag) {
     } else if (G.max_items_pt + G.max_items_ln > 0) {
       hipLaunchKernelGGL(ba_schur_items_both_kernel, dim3(G.max_items_pt + G.max_items_ln, nw), dim3(kSchurThreads), std::max(B->schur_lds[0], B->schur_lds[1]), st, A, dw, ds, G.max_items_pt);
     }
-    if (B->schur_wide_lds > 0) hipLaunchKernelGGL(ba_schur_wide_kernel, dim3(G.max_items_all, nw), dim3(kSchurWideThreads), B->schur_wide_lds, st, A, dw, ds);
+    if (B->schur_wide_lds > 0) hipLaunchKernelGGL(ba_schur_wide_kernel, dim3(G.max_items_pt + G.max_items_ln, nw), dim3(kSchurWideThreads), B->schur_wide_lds, st, A, dw, ds);
     hipLaunchKernelGGL(ba_schur_reduce_kernel, dim3((std::max(1, G.max_blk) * 6 + 255) / 256 + 1, nw), dim3(256), 0, st, A, dw, ds);
     if (B->params.reduced_solver == 1 || B->pcg_multi) hipLaunchKernelGGL(ba_symmetrize_kernel, dim3(B->pcg_multi ? 256 : 16, nw), dim3(256), 0, st, A, dw, ds);
     LLD_HIP_TRY(hipEventRecord(G.ev[2], st));
@@ -693,9 +684,13 @@ int lld_ba_batch_solve(lld_ba_batch* B, volatile const int* abort_flag) {
     else
       hipLaunchKernelGGL(ba_chol_kernel, dim3(nw), dim3(kPcgThreads), chol_lds, st, A, dw, ds, (int)(chol_tri / sizeof(double)));
     LLD_HIP_TRY(hipEventRecord(G.ev[3], st));
-    launch_update(1);
+    if (fuse_pairs && G.max_nt_pt > 0 && G.max_nb_ln > 0) hipLaunchKernelGGL(ba_backsub_both_kernel, dim3(G.max_nt_pt + G.max_nb_ln, nw), dim3(kLmThreads), bs_lds, st, A, dw, ds, G.max_nt_pt);
+    else {
+      if (G.max_nt_pt > 0) hipLaunchKernelGGL(ba_backsub_pt_kernel, dim3(G.max_nt_pt, nw), dim3(kLmThreads), bs_lds, st, A, dw, ds);
+      if (G.max_nb_ln > 0) hipLaunchKernelGGL(ba_backsub_ln_kernel, dim3(G.max_nb_ln, nw), dim3(kLmThreads), 0, st, A, dw, ds);
+    }
     LLD_HIP_TRY(hipEventRecord(G.ev[4], st));
-    hipLaunchKernelGGL(ba_control_kernel, dim3(nw), dim3(kCtlThreads), 0, st, A, dw, ds, abort_now, G.d_counters, std::getenv("LLD_BA_NO_SPEC") ? 1 : 0);
+    hipLaunchKernelGGL(ba_control_kernel, dim3(nw), dim3(kCtlThreads), 0, st, A, dw, ds, abort_now, G.d_counters);
     LLD_HIP_TRY(hipGetLastError());
     LLD_HIP_TRY(hipMemcpyAsync(G.h_counters, G.d_counters, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
     LLD_HIP_TRY(hipEventRecord(G.ev[5], st));

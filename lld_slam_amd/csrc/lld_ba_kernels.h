@@ -7,16 +7,16 @@
 // back three counters per super-step.
 //
 // Kernel <-> reference map
-//   ba_update      sel 0: computeActiveErrors + activeRobustChi2 +       sparse_optimizer.cpp:61-114, block_solver.hpp:502-560,
-//                  buildSystem (per-edge residual, Huber weight, Hll/bl,  base_binary_edge.hpp:54-120, types_six_dof_expmap.cpp
-//                  Hpl, Hpp/bp per (chunk, slot) in registers);
-//                  sel 1: landmark back-substitution, oplus, trial chi2  block_solver.hpp:459-483, sparse_optimizer.cpp:422-435
-//                  + the same buildSystem at the trial state
+//   ba_linearize   computeActiveErrors + activeRobustChi2 + buildSystem   sparse_optimizer.cpp:61-114, block_solver.hpp:502-560,
+//                  (per-edge residual, Jacobians, Huber weight,           base_binary_edge.hpp:54-120, types_six_dof_expmap.cpp
+//                   Hll/bl in registers, Hpl block per edge, Hpp/bp
+//                   through LDS-staged per-camera 6x6 accumulators)
 //   ba_begin       LM iteration head: chi2, lambda init                    optimization_algorithm_levenberg.cpp:75-99,166-180
 //   ba_schur       setLambda + Schur complement                            block_solver.hpp:373-439,564-589
 //                  (LDS-resident tile of 6x6 S blocks per camera row group)
 //   ba_pcg         reduced camera system solve (block-Jacobi PCG instead   linear_solver_eigen.h:94-124 (exact LDLT there)
 //                  of sparse LDLT) + camera oplus
+//   ba_backsub     landmark back-substitution, oplus, trial chi2           block_solver.hpp:459-483, sparse_optimizer.cpp:422-435
 //   ba_control     accept / reject, lambda update, stop rules              optimization_algorithm_levenberg.cpp:102-164
 //   ba_classify    outlier levels between the two rounds                   Optimizer.cc:1239-1267, LineOptimizer.cc:129-170
 //   ba_finalize    erase lists + read-back                                 Optimizer.cc:1278-1329, LineOptimizer.cc:172-201
@@ -35,7 +35,18 @@ constexpr int kSchurThreads = 64;     // Schur kernel: one wavefront per landmar
 constexpr int kSchurWideThreads = 256; // ... and its variant for landmarks with more than 64 free observations
 constexpr int kPcgThreads = 1024;
 constexpr int kCtlThreads = 64;
-constexpr int kMaxFreeCams = 590;        // (S is dense and every kernel keeps the poses in LDS); the one-workgroup reduced solvers
+constexpr int kLinThreads = 512;        // linearise kernels: 8 tasks per workgroup (fewer per-workgroup Hpp partials to reduce)
+// Tasks swept per wavefront of a linearise / back-substitution workgroup (BAWin::rounds, chosen per batch by the host):
+// sweeping several tasks amortises zeroing / flushing the LDS accumulators, the pose copies and x_p, and divides the number of
+// per-workgroup Hpp partials (and ba_hpp_reduce's work) by the same factor - worth it when many windows fill the chip (throughput),
+// not when a handful of windows need every workgroup they can get (latency).  Order: linearise pt, linearise ln, backsub pt, backsub ln.
+constexpr int kRoundsThroughput[4] = {8, 2, 4, 1};
+constexpr int kRoundsLatency[4] = {1, 1, 1, 1};
+constexpr int kRoundsThroughputMinWindows = 32;
+constexpr int kAccCopies = 4;          // (default; BAWin::acc_copies drops to 2 or 1 when a window's cameras would not fit LDS otherwise)
+constexpr int kAccCopiesDoc = 4;          // LDS copies of the per-camera Hpp/bp accumulators: lanes of one wavefront that hit the
+                                       // same camera are spread over them (same-address LDS atomics serialise)
+constexpr int kMaxFreeCams = 590;        // LDS of the linearise accumulators (216 B + 56 B per camera); the one-workgroup reduced solvers
 constexpr int kMaxFreeCamsOneWg = 170;   // map one lane to one unknown (6 * 170 <= 1024), larger windows need the multi-workgroup PCG
 
 enum Phase : int { PH_RUN = 0, PH_TRANSITION = 2, PH_FINALIZE = 3, PH_DONE = 4 };
@@ -52,15 +63,19 @@ struct BAWin {                 // immutable per-window header
   int hpp_off;                 // free-camera accumulators
   int x_off;                   // reduced-system vectors (doubles)
   long long S_off;             // reduced-system matrix (doubles)
-  int item_off, n_items, n_items_pt;   // chunks of this window (range in sg_chunks): n_items_pt point chunks, then line chunks
-  int n_k0_pt, n_k0_ln;                // ... of which the first n_k0 of a kind have no free camera (nothing for the Schur complement)
+  int item_off, n_items, n_items_pt;   // Schur chunks of this window (range in sg_chunks): n_items_pt point chunks, then line chunks
   int lo_off, n_lo;            // line observations (= le_off / 2)
   int blk_csr_off, cam_csr_off; // CSR (per lower S block / per free camera) of the chunk partials that add into it
   int nb_pt, nb_ln;            // landmark blocks (kLmThreads landmarks each)
-  int part_off;                // per-chunk partial sums (chi2, computeScale): n_items slots
+  int ptask_off, n_ptasks, nt_pt;   // point tasks (4 * rounds[2] per back-substitution workgroup -> nt_pt workgroups)
+  int ltask_off, n_ltasks, nt_ln;   // line tasks; partial-sum slots of a window: nt_pt + nt_ln
+  int nl_pt, nl_ln;            // workgroups of the linearise kernels (rounds[0|1] * kLinThreads / 64 tasks each)
+  int rounds[4];               // tasks per wavefront: linearise pt / ln, backsub pt / ln
+  long long hpart_off;         // per-workgroup Hpp/bp partials of the linearise kernels (doubles): [nl_pt + nl_ln][n_free * 27]
+  int part_off;                // per-block partial sums
   int its[2];                  // LM iterations per round
   int max_trials, ln_filter;
-  int protocol, robust_pts;
+  int protocol, robust_pts, acc_copies;   // acc_copies: LDS copies of the per-camera accumulators in the linearise kernels (4, 2 or 1)
   int win_index;               // index of the window in its batch (slot of the multi-workgroup PCG scalars)    // lld_ba_params::protocol / robust_points (1 = global BA: one round, no classification)
   double th_mono, th_stereo;   // Huber deltas of point edges  ((double)(float)sqrt(5.991 / 7.815))
   double th_ln_mono, th_ln_stereo;   // Huber deltas of line edges (x gamma)
@@ -73,19 +88,21 @@ struct BAState {               // mutable per-window LM state
   unsigned long long maxdiag_bits;
   double chi2_round1, chi2_final;
   int lm_iterations[2], lm_trials[2];
-  int pcg_iterations, aborted, n_active_edges, need_hpp;   // need_hpp: an accepted trial left its linearisation in buffer `cur`, Hpp / b_p are still to be summed
+  int pcg_iterations, aborted, n_active_edges, pad;
 };
 
 // Schur work decomposition (built once per window on the host from the camera sets of the landmarks):
 // landmarks that are seen by the SAME set of free cameras are sorted together and cut into chunks; one wavefront owns a
 // chunk and accumulates -Y_a W_b^T for every camera-slot pair over the chunk's landmarks in registers before it touches S.
-// A chunk = a run of storage landmarks with one camera tuple (k free cameras ascending, then k_all - k fixed ones): landmark l0 + j,
-// observation e0 + j * k_all + s (point edge / line observation) and camera sg_cams[cams_off + s] for 0 <= j < n_lm, 0 <= s < k_all.
-struct SChunk { int l0, n_lm, e0, k, k_all, cams_off, part_off, cpart_off; };   // part_off: 36-double blocks, cpart_off: 6-double vectors
+// Lane-per-edge point kernels: one wavefront per task = a run of consecutive point landmarks whose edges fit in 64 lanes
+// (or a single landmark with any number of edges).
+struct PTask { int l0, nl, e0, ne, ms, pad0, pad1, pad2; };   // local first landmark, landmark count, global first edge / observation,
+                                                             // edge count, longest run of one landmark (bounds the segmented reductions)
+
+struct SChunk { int lm_off, n_lm, tab_off, cams_off, k, D, part_off, cpart_off; };   // part_off: 36-double blocks, cpart_off: 6-double vectors
 
 struct BAArrays {
   long long NC, NP, NL;        // totals (stride of the double-buffered state arrays)
-  long long NPE, NLO, n_cpart; // point edges, line observations, (chunk, free slot) pairs (stride of the double-buffered linearisation)
   // state, double buffered: [2][N]
   double* cam_qt;              // [2][NC*7]
   double *ptx, *pty, *ptz;     // [2][NP]
@@ -104,17 +121,15 @@ struct BAArrays {
   // per-edge mutable
   uint8_t *pe_flags, *le_flags;
   double *pe_chi2, *le_chi2;
-  // the linearisation, double buffered like the state ([2][N]): buffer `cur` belongs to the current state, a trial leaves the
-  // linearisation of ITS state in the other one
-  double *pe_ws;               // [2][NPE] rho' * invSigma2 of the edge at the linearisation point (0 for level-1 edges): the 6x3 Hpl
+  double *pe_ws;               // [NPE] rho' * invSigma2 of the edge at the linearisation point (0 for level-1 edges): the 6x3 Hpl
                                //       block of a point edge is recomputed from it (point_hpl) instead of being stored
-  double *lo_W;                // [2][NLO*24]  Hpl block 6x4 per (line, KF) observation: left + right edge summed
+  double *lo_W;                // [NLO*24]  Hpl block 6x4 per (line, KF) observation: left + right edge summed
   // per-landmark mutable
   uint8_t *pt_active, *ln_active, *ln_removed;
-  double *pt_V;                // [2][NP*9]   Hll upper (6) + bl (3)
-  double *ln_V;                // [2][NL*14]  Hll upper (10) + bl (4)
+  double *pt_V;                // [NP*9]   Hll upper (6) + bl (3)
+  double *ln_V;                // [NL*14]  Hll upper (10) + bl (4)
   // per-window reduced system
-  double *hp_part;             // [2][n_cpart][21 + 6]  Hpp upper + b_p summed over a chunk, per free slot
+  double *hpp_part;            // per linearise workgroup: [n_free][21 + 6]
   double *Hpp;                 // [NF*21]
   double *bp;                  // [NF*6]
   double *S, *bschur, *xp;
@@ -125,11 +140,10 @@ struct BAArrays {
   double *chi_part, *chi_part2, *scale_part;
   // Schur work items
   const SChunk* sg_chunks;
+  const PTask* ptasks; const PTask* ltasks;
   double *sp_part, *sp_cpart;  // per (chunk, slot pair) 6x6 partial products / per (chunk, slot) 6-vectors
   const int *blk_start, *blk_src, *cam_start, *cam_src;
-  const int *sg_cams;
-  const int *pt_perm, *pe_perm, *ln_perm, *lo_perm;   // storage position -> the caller's window-local landmark / observation index
-  double* sink;                // [kSinkSlots][64]: see ba_update_pt_kernel
+  const int *sg_lm, *sg_tab, *sg_cams;
   // results
   unsigned char* records;
 };
@@ -215,70 +229,6 @@ __device__ __forceinline__ bool spd_inverse(const double* A, double* Ainv) {
   return ok;
 }
 
-// 1 / sqrt(d): v_rsq_f64 seed + two Newton steps (the library sqrt and divide are ~45 dependent instructions; the result is within an
-// ulp or two and L L^T = Hll + lambda I to rounding either way)
-// 1 / z: v_rcp_f64 seed + two Newton steps (Jacobians only; residuals keep the reference's divisions)
-__device__ __forceinline__ double rcp_nr(double z) {
-  double r = __builtin_amdgcn_rcp(z);
-  r = r * (2.0 - z * r);
-  r = r * (2.0 - z * r);
-  return r;
-}
-__device__ __forceinline__ double rsqrt_nr(double d) {
-  double y = __builtin_amdgcn_rsq(d);
-  y = y * (1.5 - (0.5 * d) * (y * y));
-  y = y * (1.5 - (0.5 * d) * (y * y));
-  return y;
-}
-// lower Cholesky factor of (packed upper U) + lambda I, D x D: L packed row-major lower (L[i][j] at i(i+1)/2 + j, diagonal entries
-// unused), idiag[i] = 1 / L[i][i]
-template <int D>
-__device__ __forceinline__ void chol_packed(const double* U, double lambda, double* L, double* idiag) {
-  double F[D][D];
-  int kk = 0;
-#pragma unroll
-  for (int i = 0; i < D; i++)
-#pragma unroll
-    for (int j = i; j < D; j++) { F[j][i] = U[kk++]; }
-#pragma unroll
-  for (int i = 0; i < D; i++) F[i][i] += lambda;
-#pragma unroll
-  for (int j = 0; j < D; j++) {
-    double d = F[j][j];
-#pragma unroll
-    for (int m = 0; m < j; m++) d -= L[j * (j + 1) / 2 + m] * L[j * (j + 1) / 2 + m];
-    const double inv = rsqrt_nr(d);
-    idiag[j] = inv;
-#pragma unroll
-    for (int i = j + 1; i < D; i++) {
-      double sacc = F[i][j];
-#pragma unroll
-      for (int m = 0; m < j; m++) sacc -= L[i * (i + 1) / 2 + m] * L[j * (j + 1) / 2 + m];
-      L[i * (i + 1) / 2 + j] = sacc * inv;
-    }
-  }
-}
-// x = (U + lambda I)^-1 t through that factor (forward, then backward substitution)
-template <int D>
-__device__ __forceinline__ void chol_solve(const double* U, double lambda, const double* t, double* x) {
-  double L[D * (D + 1) / 2], idg[D], y[D];
-  chol_packed<D>(U, lambda, L, idg);
-#pragma unroll
-  for (int c = 0; c < D; c++) {
-    double sacc = t[c];
-#pragma unroll
-    for (int m = 0; m < c; m++) sacc -= y[m] * L[c * (c + 1) / 2 + m];
-    y[c] = sacc * idg[c];
-  }
-#pragma unroll
-  for (int c = D - 1; c >= 0; c--) {
-    double sacc = y[c];
-#pragma unroll
-    for (int m = c + 1; m < D; m++) sacc -= x[m] * L[m * (m + 1) / 2 + c];
-    x[c] = sacc * idg[c];
-  }
-}
-
 // packed upper (row-major) <-> full
 template <int D>
 __device__ __forceinline__ void unpack_sym(const double* U, double lambda, double* F) {
@@ -343,7 +293,7 @@ __global__ __launch_bounds__(kLmThreads) void ba_init_kernel(BAArrays A, const B
   }
   for (int e = gid; e < W.n_pe; e += stride) {
     A.pe_flags[W.pe_off + e] = (uint8_t)(EF_VALID | (W.robust_pts ? EF_ROBUST : 0) | (A.pe_ur[W.pe_off + e] < 0 ? 0 : EF_STEREO));
-    A.pe_chi2[W.pe_off + e] = 0.0; A.pe_ws[W.pe_off + e] = 0.0; A.pe_ws[A.NPE + W.pe_off + e] = 0.0;
+    A.pe_chi2[W.pe_off + e] = 0.0; A.pe_ws[W.pe_off + e] = 0.0;
   }
   for (int e = gid; e < W.n_le; e += stride) {
     const uint8_t f0 = A.le_flags0[W.le_off + e];
@@ -363,21 +313,91 @@ __global__ __launch_bounds__(kLmThreads) void ba_init_kernel(BAArrays A, const B
 }
 
 
-// ================================================================== per-edge / per-landmark building blocks
+// ================================================================== point landmarks: one lane per EDGE
+// Edge SoA arrays are read fully coalesced (lane i <-> edge e0 + i); what belongs to a landmark (Hll, b_l, the back-substituted
+// update) is combined over the landmark's lanes with a segmented shuffle reduction, the landmark's first lane ("head") does the
+// per-landmark work, and results travel back to the lanes with one shuffle.
+__device__ __forceinline__ bool seg_step(int seg, int lane, int off) {
+  const int so = __shfl_down(seg, off);
+  return (lane + off < 64) && so == seg;
+}
+template <int N>
+__device__ __forceinline__ void seg_sum(double* v, int seg, int lane, int max_len) {      // valid in the first lane of every segment
+  for (int off = 1; off < max_len; off <<= 1) {
+    const bool ok = seg_step(seg, lane, off);
+#pragma unroll
+    for (int i = 0; i < N; i++) { const double o = __shfl_down(v[i], off); if (ok) v[i] += o; }
+  }
+}
 template <int N>
 __device__ __forceinline__ void wave_sum_n(double* v) {
 #pragma unroll
   for (int i = 0; i < N; i++) v[i] = wave_sum(v[i]);
 }
 
+struct PtEdgeLin { double r[3], Jp[9], Jc[18], ws, rho0; bool stereo; };
+
+// residual, chi2 (stored), Huber weight, Jacobians of one active point edge at the linearisation point
+__device__ __forceinline__ void point_edge_linearize(const BAArrays& A, const BAWin& W, int cur, int e, uint8_t fl, int c, const Vec3& X, PtEdgeLin& L) {
+  const Pose T = load_cam(A, cur, W.cam_off + c);
+  const Vec3 Xc = pose_map(T, X);
+  const double urv = A.pe_ur[e];
+  L.stereo = !(urv < 0);
+  point_residual(W.cam, Xc, A.pe_u[e], A.pe_v[e], urv, L.stereo, true, L.r);
+  const double s = A.pe_s[e];
+  const double c2 = chi2_of(L.r, L.stereo ? 3 : 2, s);
+  A.pe_chi2[e] = c2;
+  double w = 1.0;
+  L.rho0 = c2;
+  if (fl & EF_ROBUST) L.rho0 = huber(c2, L.stereo ? W.th_stereo : W.th_mono, &w);
+  L.ws = w * s;
+  A.pe_ws[e] = L.ws;
+  point_jac_point(W.cam, Xc, quat_rotation(T.q), L.stereo, L.Jp);
+  point_jac_pose(W.cam, Xc, L.stereo, L.Jc);
+}
 struct PtObs { double u, v, ur, s; };
+// same with every operand already in registers (pose from the LDS copy, observation loaded up front): no dependent loads
+__device__ __forceinline__ double point_edge_linearize_r(const BAWin& W, const Pose& T, const Vec3& X, const PtObs& ob, uint8_t fl, PtEdgeLin& L) {
+  const Vec3 Xc = pose_map(T, X);
+  L.stereo = !(ob.ur < 0);
+  point_residual(W.cam, Xc, ob.u, ob.v, ob.ur, L.stereo, true, L.r);
+  const double c2 = chi2_of(L.r, L.stereo ? 3 : 2, ob.s);
+  double w = 1.0;
+  L.rho0 = c2;
+  if (fl & EF_ROBUST) L.rho0 = huber(c2, L.stereo ? W.th_stereo : W.th_mono, &w);
+  L.ws = w * ob.s;
+  point_jac_point(W.cam, Xc, quat_rotation(T.q), L.stereo, L.Jp);
+  point_jac_pose(W.cam, Xc, L.stereo, L.Jc);
+  return c2;
+}
+// landmark side Hll (6 upper) + b_l (3) of one edge
+__device__ __forceinline__ void point_edge_hll(const PtEdgeLin& L, double* hb) {
+  int k = 0;
+#pragma unroll
+  for (int a = 0; a < 3; a++)
+#pragma unroll
+    for (int d = a; d < 3; d++) hb[k++] = L.ws * (L.Jp[a] * L.Jp[d] + L.Jp[3 + a] * L.Jp[3 + d] + L.Jp[6 + a] * L.Jp[6 + d]);
+#pragma unroll
+  for (int a = 0; a < 3; a++) hb[6 + a] = -L.ws * (L.Jp[a] * L.r[0] + L.Jp[3 + a] * L.r[1] + L.Jp[6 + a] * L.r[2]);
+}
+// camera side: Hpp (21 upper) and b_p (6) into the LDS-staged per-camera accumulators
+__device__ __forceinline__ void point_edge_hpp(const PtEdgeLin& L, double* ac) {
+  int kk = 0;
+#pragma unroll
+  for (int rr = 0; rr < 6; rr++) {
+    atomicAdd(&ac[21 + rr], -L.ws * (L.Jc[rr] * L.r[0] + L.Jc[6 + rr] * L.r[1] + L.Jc[12 + rr] * L.r[2]));
+#pragma unroll
+    for (int cc = rr; cc < 6; cc++) atomicAdd(&ac[kk++], L.ws * (L.Jc[rr] * L.Jc[cc] + L.Jc[6 + rr] * L.Jc[6 + cc] + L.Jc[12 + rr] * L.Jc[12 + cc]));
+  }
+}
+
 // Everything one active point edge adds to the normal equations, in closed form (same algebra as point_hpl_closed): with
 // A = d(u,v,uR)/dXc, M = ws A^T A, g = A^T (ws r), P = [Xc]x M:
 //   Hll = R^T M R, b_l = R^T g;  Hpp = [[ Xc x P_i (rows) , P ], [ . , M ]], b_p = [ Xc x g ; g ]
-// instead of forming Jp (3x3) and Jc (3x6) and contracting them.  hb: 6 upper of Hll + b_l (assigned); hp: 21 upper of Hpp + b_p,
-// packed row-major (ADDED to hp when `cam_side`, untouched otherwise).  Returns chi2 of the edge; ws and rho0 through the references.
+// instead of forming Jp (3x3) and Jc (3x6) and contracting them.  hb: 6 upper of Hll + b_l; hp: 21 upper of Hpp + b_p (row-major
+// packed like point_edge_hpp).  Returns chi2 of the edge; ws and rho0 through the references.
 __device__ __forceinline__ double point_edge_blocks_closed(const BAWin& W, const Pose& T, const Vec3& X, const PtObs& ob, uint8_t fl, double& ws_out,
-                                                           double& rho0_out, double* hb, double* hp, bool cam_side) {
+                                                           double& rho0_out, double* hb, double* hp) {
   const CamK& k = W.cam;
   const Vec3 Xc = pose_map(T, X);
   const bool stereo = !(ob.ur < 0);
@@ -389,7 +409,7 @@ __device__ __forceinline__ double point_edge_blocks_closed(const BAWin& W, const
   const double ws = w * ob.s;
   ws_out = ws; rho0_out = rho0;
   const Mat3 R = quat_rotation(T.q);
-  const double iz = rcp_nr(Xc.z), iz2 = iz * iz;
+  const double iz = 1.0 / Xc.z, iz2 = iz * iz;
   const double a = k.fx * iz, b = k.fy * iz;
   const double c0 = -k.fx * Xc.x * iz2, c1 = -k.fy * Xc.y * iz2, c2 = c0 + k.bf * iz2;
   const double m00 = ws * (stereo ? 2.0 * a * a : a * a);
@@ -422,297 +442,331 @@ __device__ __forceinline__ double point_edge_blocks_closed(const BAWin& W, const
   const double Q[3][3] = {{y * P[0][2] - z * P[0][1], z * P[0][0] - x * P[0][2], x * P[0][1] - y * P[0][0]},
                           {y * P[1][2] - z * P[1][1], z * P[1][0] - x * P[1][2], x * P[1][1] - y * P[1][0]},
                           {y * P[2][2] - z * P[2][1], z * P[2][0] - x * P[2][2], x * P[2][1] - y * P[2][0]}};
-  // packed upper triangle, rows 0..5: (0,0..5) (1,1..5) (2,2..5) (3,3..5) (4,4..5) (5,5); entry 16 is the structural zero of M
-  if (cam_side) {
-    hp[0] += Q[0][0]; hp[1] += Q[0][1]; hp[2] += Q[0][2]; hp[3] += P[0][0]; hp[4] += P[0][1]; hp[5] += P[0][2];
-    hp[6] += Q[1][1]; hp[7] += Q[1][2]; hp[8] += P[1][0]; hp[9] += P[1][1]; hp[10] += P[1][2];
-    hp[11] += Q[2][2]; hp[12] += P[2][0]; hp[13] += P[2][1]; hp[14] += P[2][2];
-    hp[15] += m00; hp[17] += m02; hp[18] += m11; hp[19] += m12; hp[20] += m22;
-    hp[21] += y * g2 - z * g1; hp[22] += z * g0 - x * g2; hp[23] += x * g1 - y * g0; hp[24] += g0; hp[25] += g1; hp[26] += g2;
-  }
+  // packed upper triangle, rows 0..5: (0,0..5) (1,1..5) (2,2..5) (3,3..5) (4,4..5) (5,5)
+  hp[0] = Q[0][0]; hp[1] = Q[0][1]; hp[2] = Q[0][2]; hp[3] = P[0][0]; hp[4] = P[0][1]; hp[5] = P[0][2];
+  hp[6] = Q[1][1]; hp[7] = Q[1][2]; hp[8] = P[1][0]; hp[9] = P[1][1]; hp[10] = P[1][2];
+  hp[11] = Q[2][2]; hp[12] = P[2][0]; hp[13] = P[2][1]; hp[14] = P[2][2];
+  hp[15] = m00; hp[16] = 0.0; hp[17] = m02; hp[18] = m11; hp[19] = m12; hp[20] = m22;
+  hp[21] = y * g2 - z * g1; hp[22] = z * g0 - x * g2; hp[23] = x * g1 - y * g0; hp[24] = g0; hp[25] = g1; hp[26] = g2;
   return c2e;
 }
 
+// grid (nl_pt, nW), block 512 = 8 wavefronts, BAWin::rounds tasks per wavefront; dynamic LDS: kAccCopies*n_free_max*27 doubles + 8 scratch.
+__device__ __forceinline__ void ba_linearize_pt_body(const BAArrays& A, const BAWin* __restrict__ wins, BAState* __restrict__ st, const int bx) {   // bx: the workgroup's index along x
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const BAWin W = wins[blockIdx.y];
+  BAState& S = st[blockIdx.y];
+  if (S.phase != PH_RUN || !S.need_lin) return;
+  if ((int)bx >= W.nl_pt) return;
+  const int nacc = W.n_free * 27;
+  double* acc_all = lds;                              // kAccCopies x [n_free][21 Hpp upper + 6 bp]
+  double* scratch = lds + W.acc_copies * nacc;
+  double* cams = scratch + 8;                         // [n_cams][7] poses of the linearisation point
+  for (int i = threadIdx.x; i < W.acc_copies * nacc; i += kLinThreads) acc_all[i] = 0.0;
+  double* acc = acc_all + ((threadIdx.x >> 3) & (W.acc_copies - 1)) * nacc;
+  const int cur = S.cur;
+  for (int i = threadIdx.x; i < W.n_cams * 7; i += kLinThreads) cams[i] = A.cam_qt[((size_t)cur * A.NC + W.cam_off) * 7 + i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  double chi = 0.0, maxd = 0.0;
+  for (int rnd = 0; rnd < W.rounds[0]; rnd++) {
+    const int ti = (bx * W.rounds[0] + rnd) * (kLinThreads / 64) + (threadIdx.x >> 6);
+    if (ti >= W.n_ptasks) break;
+    const PTask T = A.ptasks[W.ptask_off + ti];
+    if (T.nl > 1) {
+      // two dependent memory levels only: (1) the task, (2) every global operand - edge arrays by edge lane, landmark
+      // state by landmark lane (lane i <-> landmark l0 + i); camera poses come from the workgroup's LDS copy and landmark
+      // data reaches the edge lanes by shuffle.
+      const bool has = lane < T.ne;
+      const int e = T.e0 + (has ? lane : 0);
+      const int l = has ? A.pe_pt[e] : -1 - lane;
+      const uint8_t fl = A.pe_flags[e];
+      const int c = A.pe_cam[e];
+      PtObs ob; ob.u = A.pe_u[e]; ob.v = A.pe_v[e]; ob.ur = A.pe_ur[e]; ob.s = A.pe_s[e];
+      const bool lmk = lane < T.nl;
+      const int g2 = W.pt_off + T.l0 + (lmk ? lane : 0);
+      const Vec3 X2 = load_pt(A, cur, g2);
+      const int act2 = lmk ? (int)A.pt_active[g2] : 0;
+      const int start2 = A.pt_obs_start[g2], end2 = A.pt_obs_start[g2 + 1];
+      const int slot = has ? l - T.l0 : 0;
+      Vec3 X; X.x = __shfl(X2.x, slot); X.y = __shfl(X2.y, slot); X.z = __shfl(X2.z, slot);
+      const bool lm_act = has && __shfl(act2, slot) != 0;
+      double hb[9];
+#pragma unroll
+      for (int i = 0; i < 9; i++) hb[i] = 0.0;
+      if (has && (fl & EF_LEVEL1)) A.pe_ws[e] = 0.0;
+      if (lm_act && !(fl & EF_LEVEL1)) {
+        double hp[27], ws_e, rho0_e;
+        A.pe_chi2[e] = point_edge_blocks_closed(W, pose_load(cams + c * 7), X, ob, fl, ws_e, rho0_e, hb, hp);
+        A.pe_ws[e] = ws_e;
+        chi += rho0_e;
+        if (c < W.n_free) {
+          double* ac = acc + c * 27;
+#pragma unroll
+          for (int i = 0; i < 27; i++) if (i != 16) atomicAdd(&ac[i], hp[i]);          // entry 16 is the structural zero of M
+        }
+      }
+      seg_sum<9>(hb, l, lane, T.ms);
+      // landmark lane i collects the sum from the first edge lane of its landmark
+      const int first = (lmk && end2 > start2) ? start2 - T.e0 : 0;
+      double vb[9];
+#pragma unroll
+      for (int i = 0; i < 9; i++) vb[i] = __shfl(hb[i], first);
+      if (lmk && act2 && end2 > start2) {
+        double* V = A.pt_V + (size_t)g2 * 9;
+#pragma unroll
+        for (int i = 0; i < 9; i++) V[i] = vb[i];
+        maxd = fmax(maxd, fmax(fabs(vb[0]), fmax(fabs(vb[3]), fabs(vb[5]))));
+      }
+    } else {                                             // a single landmark, any number of edges
+      const int g = W.pt_off + T.l0;
+      if (A.pt_active[g]) {
+        const Vec3 X = load_pt(A, cur, g);
+        double hb[9];
+#pragma unroll
+        for (int i = 0; i < 9; i++) hb[i] = 0.0;
+        for (int sidx = lane; sidx < T.ne; sidx += 64) {
+          const int e = T.e0 + sidx;
+          const uint8_t fl = A.pe_flags[e];
+          if (fl & EF_LEVEL1) { A.pe_ws[e] = 0.0; continue; }
+          const int c = A.pe_cam[e];
+          PtEdgeLin L;
+          point_edge_linearize(A, W, cur, e, fl, c, X, L);
+          chi += L.rho0;
+          double h1[9];
+          point_edge_hll(L, h1);
+#pragma unroll
+          for (int i = 0; i < 9; i++) hb[i] += h1[i];
+          if (c < W.n_free) point_edge_hpp(L, acc + c * 27);
+        }
+        wave_sum_n<9>(hb);
+        if (lane == 0) {
+          double* V = A.pt_V + (size_t)g * 9;
+#pragma unroll
+          for (int i = 0; i < 9; i++) V[i] = hb[i];
+          maxd = fmax(maxd, fmax(fabs(hb[0]), fmax(fabs(hb[3]), fabs(hb[5]))));
+        }
+      }
+    }
+  }
+  const double chi_t = block_sum(chi, scratch);
+  const double max_t = block_max(maxd, scratch);
+  if (threadIdx.x == 0) {
+    A.chi_part[W.part_off + bx] = chi_t;
+    atomicMax(&S.maxdiag_bits, (unsigned long long)__double_as_longlong(max_t));
+  }
+  __syncthreads();
+  // plain stores of this workgroup's camera partials; ba_hpp_reduce sums them in a fixed order (no global atomics)
+  double* dst = A.hpp_part + W.hpart_off + (size_t)(bx) * nacc;
+  for (int i = threadIdx.x; i < nacc; i += kLinThreads) {
+    double v = 0.0;
+    for (int q = 0; q < W.acc_copies; q++) v += acc_all[q * nacc + i];
+    dst[i] = v;
+  }
+}
+__global__ __launch_bounds__(kLinThreads, 4) void ba_linearize_pt_kernel(BAArrays A, const BAWin* __restrict__ wins, BAState* __restrict__ st) { ba_linearize_pt_body(A, wins, st, (int)blockIdx.x); }
+
+// W_e^T x_c = ws * Jp^T (Jc x_c) of one point edge with the Jacobians of the linearisation point
+__device__ __forceinline__ void point_edge_wtx(const BAArrays& A, const BAWin& W, int cur, int e, uint8_t fl, int c, const Vec3& X, const double* xp, double* t) {
+  const double ws = A.pe_ws[e];
+  const bool stereo = (fl & EF_STEREO) != 0;
+  const Pose T = load_cam(A, cur, W.cam_off + c);
+  const Vec3 Xc = pose_map(T, X);
+  double Jp[9], Jc[18];
+  point_jac_point(W.cam, Xc, quat_rotation(T.q), stereo, Jp);
+  point_jac_pose(W.cam, Xc, stereo, Jc);
+  double uu[3];
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    double s = 0.0;
+#pragma unroll
+    for (int r = 0; r < 6; r++) s += Jc[i * 6 + r] * xp[c * 6 + r];
+    uu[i] = ws * s;
+  }
+#pragma unroll
+  for (int k = 0; k < 3; k++) t[k] = Jp[k] * uu[0] + Jp[3 + k] * uu[1] + Jp[6 + k] * uu[2];
+}
+// trial-state residual of one active point edge: stores chi2, returns its (robust) cost
+__device__ __forceinline__ double point_edge_trial(const BAArrays& A, const BAWin& W, int nxt, int e, uint8_t fl, int c, const Vec3& Xn) {
+  const Pose T = load_cam(A, nxt, W.cam_off + c);
+  const Vec3 Xc = pose_map(T, Xn);
+  const double urv = A.pe_ur[e];
+  const bool stereo = !(urv < 0);
+  double r[3];
+  point_residual(W.cam, Xc, A.pe_u[e], A.pe_v[e], urv, stereo, true, r);
+  const double c2 = chi2_of(r, stereo ? 3 : 2, A.pe_s[e]);
+  A.pe_chi2[e] = c2;
+  double w, rho0 = c2;
+  if (fl & EF_ROBUST) rho0 = huber(c2, stereo ? W.th_stereo : W.th_mono, &w);
+  return rho0;
+}
 // x_l = (Hll + lambda I)^-1 (b_l - sum W^T x_c), oplus; returns the landmark's part of computeScale
 __device__ __forceinline__ double point_backsub(const double* V, double lambda, const double* wtx, const Vec3& X, Vec3& Xn) {
+  double F[9], Di[9];
+  unpack_sym<3>(V, lambda, F);
+  spd_inverse<3>(F, Di);
   const double t[3] = {V[6] - wtx[0], V[7] - wtx[1], V[8] - wtx[2]};
   double xl[3], sc = 0.0;
-  chol_solve<3>(V, lambda, t, xl);
+#pragma unroll
+  for (int i = 0; i < 3; i++) xl[i] = Di[i * 3] * t[0] + Di[i * 3 + 1] * t[1] + Di[i * 3 + 2] * t[2];
 #pragma unroll
   for (int i = 0; i < 3; i++) sc += xl[i] * (lambda * xl[i] + V[6 + i]);
   Xn = vec3(X.x + xl[0], X.y + xl[1], X.z + xl[2]);      // VertexSBAPointXYZ::oplusImpl
   return sc;
 }
 
+// grid (nt_pt, nW), block 256 = 4 wavefronts, BAWin::rounds tasks per wavefront; dynamic LDS: 8 + 14 n_cams + 6 n_free doubles
+__device__ __forceinline__ void ba_backsub_pt_body(const BAArrays& A, const BAWin* __restrict__ wins, const BAState* __restrict__ st, const int bx) {   // bx: the workgroup's index along x
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const BAWin W = wins[blockIdx.y];
+  const BAState& S = st[blockIdx.y];
+  if (S.phase != PH_RUN) return;
+  if ((int)bx >= W.nt_pt) return;
+  const int cur = S.cur, nxt = cur ^ 1;
+  const double lambda = S.lambda;
+  const double* xp = A.xp + W.x_off;
+  // workgroup copies of what every edge lane gathers: poses of the linearisation point (camA) and of the trial state (camB),
+  // and the camera part of the solution
+  double* scratch = lds;
+  double* camA = lds + 8;
+  double* camB = camA + W.n_cams * 7;
+  double* xps = camB + W.n_cams * 7;
+  for (int i = threadIdx.x; i < W.n_cams * 7; i += kLmThreads) {
+    camA[i] = A.cam_qt[((size_t)cur * A.NC + W.cam_off) * 7 + i];
+    camB[i] = A.cam_qt[((size_t)nxt * A.NC + W.cam_off) * 7 + i];
+  }
+  for (int i = threadIdx.x; i < 6 * W.n_free; i += kLmThreads) xps[i] = xp[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  double chi = 0.0, sc = 0.0;
+  for (int rnd = 0; rnd < W.rounds[2]; rnd++) {
+    const int ti = (bx * W.rounds[2] + rnd) * 4 + (threadIdx.x >> 6);
+    if (ti >= W.n_ptasks) break;
+    const PTask T = A.ptasks[W.ptask_off + ti];
+    if (T.nl > 1) {
+      const bool has = lane < T.ne;
+      const int e = T.e0 + (has ? lane : 0);
+      const int l = has ? A.pe_pt[e] : -1 - lane;
+      const uint8_t fl = A.pe_flags[e];
+      const int c = A.pe_cam[e];
+      const double ws = A.pe_ws[e];
+      PtObs ob; ob.u = A.pe_u[e]; ob.v = A.pe_v[e]; ob.ur = A.pe_ur[e]; ob.s = A.pe_s[e];
+      const bool lmk = lane < T.nl;
+      const int g2 = W.pt_off + T.l0 + (lmk ? lane : 0);
+      const Vec3 X2 = load_pt(A, cur, g2);
+      const int act2 = lmk ? (int)A.pt_active[g2] : 0;
+      const int start2 = A.pt_obs_start[g2], end2 = A.pt_obs_start[g2 + 1];
+      double V2[9];
+#pragma unroll
+      for (int i = 0; i < 9; i++) V2[i] = A.pt_V[(size_t)g2 * 9 + i];
+      const int slot = has ? l - T.l0 : 0;
+      Vec3 X; X.x = __shfl(X2.x, slot); X.y = __shfl(X2.y, slot); X.z = __shfl(X2.z, slot);
+      const bool e_act = has && __shfl(act2, slot) != 0 && !(fl & EF_LEVEL1);
+      double wtx[3] = {0, 0, 0};
+      if (e_act && c < W.n_free) {
+        // W_e^T x_c = ws * Jp^T (Jc x_c) with the Jacobians of the linearisation point
+        // closed form (see point_hpl_closed): Jc x = A (Xc x x_w - x_t), Jp^T u = -R^T A^T u
+        const Pose Tc = pose_load(camA + c * 7);
+        const Vec3 Xc = pose_map(Tc, X);
+        const bool stereo = (fl & EF_STEREO) != 0;
+        const Mat3 R = quat_rotation(Tc.q);
+        const double* xc = xps + c * 6;
+        const Vec3 v = cross(Xc, vec3(xc[0], xc[1], xc[2])) - vec3(xc[3], xc[4], xc[5]);
+        const double iz = 1.0 / Xc.z, iz2 = iz * iz;
+        const double a = W.cam.fx * iz, b = W.cam.fy * iz;
+        const double c0 = -W.cam.fx * Xc.x * iz2, c1 = -W.cam.fy * Xc.y * iz2, c2 = c0 + W.cam.bf * iz2;
+        const double u0 = ws * (a * v.x + c0 * v.z), u1 = ws * (b * v.y + c1 * v.z), u2 = stereo ? ws * (a * v.x + c2 * v.z) : 0.0;
+        const double h0 = a * (u0 + u2), h1 = b * u1, h2 = c0 * u0 + c1 * u1 + c2 * u2;
+#pragma unroll
+        for (int k = 0; k < 3; k++) wtx[k] = -(R.m[0][k] * h0 + R.m[1][k] * h1 + R.m[2][k] * h2);
+      }
+      seg_sum<3>(wtx, l, lane, T.ms);
+      // landmark lane: back-substitution and oplus of its landmark (inactive / edge-less landmarks keep their state)
+      const int first = (lmk && end2 > start2) ? start2 - T.e0 : 0;
+      double wl[3];
+#pragma unroll
+      for (int i = 0; i < 3; i++) wl[i] = __shfl(wtx[i], first);
+      Vec3 Xn2 = X2;
+      if (lmk) {
+        if (act2 && end2 > start2) sc += point_backsub(V2, lambda, wl, X2, Xn2);
+        store_pt(A, nxt, g2, Xn2);
+      }
+      Vec3 Xn; Xn.x = __shfl(Xn2.x, slot); Xn.y = __shfl(Xn2.y, slot); Xn.z = __shfl(Xn2.z, slot);
+      if (e_act) {
+        const Vec3 Xc = pose_map(pose_load(camB + c * 7), Xn);
+        const bool stereo = !(ob.ur < 0);
+        double r[3];
+        point_residual(W.cam, Xc, ob.u, ob.v, ob.ur, stereo, true, r);
+        const double c2 = chi2_of(r, stereo ? 3 : 2, ob.s);
+        A.pe_chi2[e] = c2;
+        double w, rho0 = c2;
+        if (fl & EF_ROBUST) rho0 = huber(c2, stereo ? W.th_stereo : W.th_mono, &w);
+        chi += rho0;
+      }
+    } else {
+      const int g = W.pt_off + T.l0;
+      const Vec3 X = load_pt(A, cur, g);
+      if (!A.pt_active[g]) { if (lane == 0) store_pt(A, nxt, g, X); }
+      else {
+        double wtx[3] = {0, 0, 0};
+        for (int sidx = lane; sidx < T.ne; sidx += 64) {
+          const int e = T.e0 + sidx;
+          const uint8_t fl = A.pe_flags[e];
+          const int c = A.pe_cam[e];
+          if ((fl & EF_LEVEL1) || c >= W.n_free) continue;
+          double t1[3];
+          point_edge_wtx(A, W, cur, e, fl, c, X, xp, t1);
+          wtx[0] += t1[0]; wtx[1] += t1[1]; wtx[2] += t1[2];
+        }
+        wave_sum_n<3>(wtx);
+        Vec3 Xn;
+        const double s1 = point_backsub(A.pt_V + (size_t)g * 9, lambda, wtx, X, Xn);      // every lane, same value
+        if (lane == 0) { sc += s1; store_pt(A, nxt, g, Xn); }
+        for (int sidx = lane; sidx < T.ne; sidx += 64) {
+          const int e = T.e0 + sidx;
+          const uint8_t fl = A.pe_flags[e];
+          if (fl & EF_LEVEL1) continue;
+          chi += point_edge_trial(A, W, nxt, e, fl, A.pe_cam[e], Xn);
+        }
+      }
+    }
+  }
+  const double chi_t = block_sum(chi, scratch);
+  const double sc_t = block_sum(sc, scratch);
+  if (threadIdx.x == 0) { A.chi_part2[W.part_off + bx] = chi_t; A.scale_part[W.part_off + bx] = sc_t; }
+}
+__global__ __launch_bounds__(kLmThreads) void ba_backsub_pt_kernel(BAArrays A, const BAWin* __restrict__ wins, const BAState* __restrict__ st) { ba_backsub_pt_body(A, wins, st, (int)blockIdx.x); }
+
+// ================================================================== line landmarks: one lane per (line, KF) OBSERVATION
+// Same scheme as the point kernels with the observation as the unit: a lane linearises the left and (if present) right image
+// edge of its observation and keeps their summed Hpl block; Hll/b_l (14 values) are combined over the line's lanes.
 struct LineGeom { Vec3 c0, c1, X1, X2; double alpha; };
 __device__ __forceinline__ LineGeom line_geom(const LineQ& L) {
   const Mat3 Rl = line_rotation(L);
   LineGeom G; G.c0 = mat_col(Rl, 0); G.c1 = mat_col(Rl, 1); G.alpha = L.alpha; G.X1 = L.alpha * G.c1; G.X2 = G.X1 + G.c0;
   return G;
 }
-__device__ __forceinline__ double line_backsub(const double* V, double lambda, const double* wtx, const LineQ& L, LineQ& Ln) {
-  double t[4], xl[4], sc = 0.0;
-#pragma unroll
-  for (int i = 0; i < 4; i++) t[i] = V[10 + i] - wtx[i];
-  chol_solve<4>(V, lambda, t, xl);
-#pragma unroll
-  for (int i = 0; i < 4; i++) sc += xl[i] * (lambda * xl[i] + V[10 + i]);
-  Ln = line_oplus(L, xl);
-  return sc;
-}
-
-
-// ================================================================== chunk-structured landmark update + linearisation
-// One wavefront per chunk (SChunk), lane <-> (landmark j, slot s) of a sub-batch of 64 / k_all landmarks: every per-edge array is read
-// with lane-consecutive addresses, the lane's camera never changes, what belongs to a landmark is combined over its k_all
-// neighbouring lanes by shuffles, and what belongs to a camera (Hpp, b_p) is summed in the lane's registers over the whole chunk and
-// stored once per (chunk, free slot) - no atomics anywhere, every sum has a fixed order.
-//
-// The kernel is BOTH halves of an LM trial and the linearisation of the state it produces:
-//   sel = 0  (windows with need_lin: the first iteration of an optimize() round)   computeActiveErrors + buildSystem at the current
-//            state: chi2, V = (Hll, b_l), the edge weights / line Hpl blocks and the Hpp partials of buffer `cur`;
-//   sel = 1  (every trial)   W^T x_c, back-substitution, oplus into buffer `nxt`, computeActiveErrors of the trial state
-//            (block_solver.hpp:459-483, sparse_optimizer.cpp:422-435) - and, speculatively, buildSystem at that trial state into the
-//            `nxt` copies of V / weights / Hpp partials.  An accepted trial flips `cur` and the next iteration starts from a
-//            ready linearisation (g2o recomputes the same numbers at the top of its next solve()); a rejected one costs nothing more
-//            than the arithmetic, its buffers are simply overwritten by the next trial.
-constexpr int kUpdThreads = 256;          // four chunks per workgroup (they share the LDS copies of the poses and of x_c; the host orders a
-                                          // window's chunks by length, so the four are about equally long)
-constexpr int kUpdChunks = kUpdThreads / 64;
-constexpr int kSinkSlots = 1024;         // 64-double slots of BAArrays::sink: where lanes without work put their (unconditional) stores
-
-// sum of v over the k_all neighbouring lanes of a landmark; valid in the landmark's first lane (s == 0)
-template <int N>
-__device__ __forceinline__ void group_sum(double* v, int s, int k_all) {
-  for (int off = 1; off < k_all; off <<= 1) {
-    const bool ok = s + off < k_all;
-#pragma unroll
-    for (int i = 0; i < N; i++) { const double o = __shfl_down(v[i], off); if (ok) v[i] += o; }
-  }
-}
-// sum of v over the lanes of one slot (stride k_all, NB of them) by a fixed binary tree; valid in the lanes j == 0
-template <int N>
-__device__ __forceinline__ void slot_sum(double* v, int j, int k_all, int NB) {
-  for (int off = 1; off < NB; off <<= 1) {
-    const bool ok = (j % (2 * off)) == 0 && j + off < NB;
-#pragma unroll
-    for (int i = 0; i < N; i++) { const double o = __shfl_down(v[i], off * k_all); if (ok) v[i] += o; }
-  }
-}
-
-// ---- camera-side accumulation without atomics and without per-lane accumulators
-// Hpp / b_p of a chunk = sum over its landmarks, per free slot: 27 numbers per (chunk, slot).  Lane (j, s) of a sub-batch holds the
-// 27 numbers of ONE edge; summing them over j in registers (one private accumulator set per lane) costs 54 VGPRs for the whole
-// kernel, summing them with LDS atomics makes ten lanes fight for one address - and an unordered sum.  Instead the wavefront
-// TRANSPOSES through LDS: every lane writes its numbers as a row (RC at a time, odd row stride), then lane p owns the (slot, number)
-// pair p and adds the NB rows of its column in order - consecutive lanes read consecutive doubles - into its accumulator, which also
-// lives in LDS (owner-exclusive: a plain read-modify-write).  One wavefront's LDS operations execute in order, so no barrier.
-template <int D> struct HpMap;
-template <> struct HpMap<3> { static constexpr int rounds = 2, rc = 13;       // 26 numbers: entry 16 of the packed Hpp is a structural zero
-  __device__ static constexpr int comp(int h, int i) { return h == 0 ? i : (i < 3 ? 13 + i : 14 + i); } };
-template <> struct HpMap<4> { static constexpr int rounds = 3, rc = 9;
-  __device__ static constexpr int comp(int h, int i) { return 9 * h + i; } };
-__host__ __device__ inline int upd_wave_lds_doubles(int kmax) { return 64 * 13 + kmax * 27; }   // rows + accumulators of one wavefront
-
-template <int D>
-__device__ __forceinline__ void slot_accumulate(const double* hp, double* rows, double* accl, int lane, int ka, int k, int NB) {
-  using M = HpMap<D>;
-#pragma unroll
-  for (int h = 0; h < M::rounds; h++) {
-#pragma unroll
-    for (int i = 0; i < M::rc; i++) rows[lane * M::rc + i] = hp[M::comp(h, i)];
-    for (int p = lane; p < k * M::rc; p += 64) {
-      double sacc = accl[h * k * M::rc + p];
-      for (int jx = 0; jx < NB; jx++) sacc += rows[jx * ka * M::rc + p];
-      accl[h * k * M::rc + p] = sacc;
-    }
-  }
-}
-template <int D>
-__device__ __forceinline__ void slot_store(const double* accl, double* hp_out /* [k][27] */, int lane, int k) {
-  using M = HpMap<D>;
-#pragma unroll
-  for (int h = 0; h < M::rounds; h++)
-    for (int p = lane; p < k * M::rc; p += 64) {
-      const int sp = p / M::rc, cp = p - sp * M::rc;
-      int comp = 0;
-#pragma unroll
-      for (int i = 0; i < M::rc; i++) if (i == cp) comp = M::comp(h, i);
-      hp_out[sp * 27 + comp] = accl[h * k * M::rc + p];
-    }
-  if (D == 3) for (int sp = lane; sp < k; sp += 64) hp_out[sp * 27 + 16] = 0.0;
-}
-
-// W_e^T x_c of one point edge in closed form (Jc x = A (Xc x x_w - x_t), Jp^T u = -R^T A^T u) at the linearisation point
-__device__ __forceinline__ void point_wtx_closed(const CamK& cam, const Pose& Tc, const Vec3& X, bool stereo, double ws, const double* xc, double* wtx) {
-  const Vec3 Xc = pose_map(Tc, X);
-  const Mat3 R = quat_rotation(Tc.q);
-  const Vec3 v = cross(Xc, vec3(xc[0], xc[1], xc[2])) - vec3(xc[3], xc[4], xc[5]);
-  const double iz = rcp_nr(Xc.z), iz2 = iz * iz;
-  const double a = cam.fx * iz, b = cam.fy * iz;
-  const double c0 = -cam.fx * Xc.x * iz2, c1 = -cam.fy * Xc.y * iz2, c2 = c0 + cam.bf * iz2;
-  const double u0 = ws * (a * v.x + c0 * v.z), u1 = ws * (b * v.y + c1 * v.z), u2 = stereo ? ws * (a * v.x + c2 * v.z) : 0.0;
-  const double h0 = a * (u0 + u2), h1 = b * u1, h2 = c0 * u0 + c1 * u1 + c2 * u2;
-#pragma unroll
-  for (int k = 0; k < 3; k++) wtx[k] = -(R.m[0][k] * h0 + R.m[1][k] * h1 + R.m[2][k] * h2);
-}
-
-// LDS of the update kernels: 8 scratch + poses of the source and destination buffers + x_c
-__device__ __forceinline__ void update_stage_cams(const BAArrays& A, const BAWin& W, int src, int dst, bool trial, double* camA, double* camB, double* xps) {
-  for (int i = threadIdx.x; i < W.n_cams * 7; i += kUpdThreads) {
-    camA[i] = A.cam_qt[((size_t)src * A.NC + W.cam_off) * 7 + i];
-    camB[i] = A.cam_qt[((size_t)dst * A.NC + W.cam_off) * 7 + i];
-  }
-  if (trial) for (int i = threadIdx.x; i < 6 * W.n_free; i += kUpdThreads) xps[i] = A.xp[W.x_off + i];
-  __syncthreads();
-}
-
-// grid (ceil(max point chunks / kUpdChunks), nW), block kUpdThreads; dynamic LDS 8 + 14 n_cams + 6 n_free doubles
-__global__ __launch_bounds__(kUpdThreads) __attribute__((amdgpu_waves_per_eu(3, 4))) void ba_update_pt_kernel(BAArrays A, const BAWin* __restrict__ wins, BAState* __restrict__ st, int sel, int kmax) {
-  extern __shared__ __attribute__((aligned(16))) double lds[];
-  const BAWin W = wins[blockIdx.y];
-  BAState& S = st[blockIdx.y];
-  if (S.phase != PH_RUN) return;
-  const bool trial = sel != 0;
-  if (trial == (S.need_lin != 0)) return;                 // sel 0: windows that need a linearisation; sel 1: everybody (ba_begin has cleared need_lin)
-  if (trial && !S.pcg_ok) return;                         // failed solve: g2o evaluates nothing (levenberg.cpp:126-127), the errors stay stale
-  if ((int)blockIdx.x * kUpdChunks >= W.n_items_pt) return;
-  const int cur = S.cur, src = cur, dst = trial ? cur ^ 1 : cur;
-  const double lambda = S.lambda;
-  double* camA = lds + 8; double* camB = camA + W.n_cams * 7; double* xps = camB + W.n_cams * 7;
-  double* rows = xps + 6 * W.n_free + (size_t)(threadIdx.x >> 6) * upd_wave_lds_doubles(kmax); double* accl = rows + 64 * 13;
-  update_stage_cams(A, W, src, dst, trial, camA, camB, xps);
-  const int lane = threadIdx.x & 63, ci = blockIdx.x * kUpdChunks + (threadIdx.x >> 6);
-  if (ci >= W.n_items_pt) return;
-  const SChunk C = A.sg_chunks[W.item_off + ci];
-  const int ka = C.k_all;
-  if (ka > 64) return;                                    // ba_update_wide_kernel
-  double chi = 0.0, sc = 0.0, maxd = 0.0;
-  if (ka == 0) {
-    // landmarks without observations: g2o never sees them, the state passes through
-    if (trial) for (int i = lane; i < C.n_lm; i += 64) store_pt(A, dst, C.l0 + i, load_pt(A, src, C.l0 + i));
-  } else {
-    const int NB = 64 / ka;
-    const int j = lane / ka, s = lane - j * ka;
-    const bool lane_on = lane < NB * ka;
-    const int c = A.sg_cams[C.cams_off + (lane_on ? s : 0)];
-    const bool free_cam = lane_on && s < C.k;
-    for (int i = lane; i < C.k * 26; i += 64) accl[i] = 0.0;
-    double* Vsrc = A.pt_V + (size_t)src * A.NP * 9; double* Vdst = A.pt_V + (size_t)dst * A.NP * 9;
-    const double* ws_src = A.pe_ws + (size_t)src * A.NPE; double* ws_dst = A.pe_ws + (size_t)dst * A.NPE;
-    // Memory discipline of the loop below: EVERY load and store is issued by every lane on every pass - lanes without work read a
-    // clamped (valid) address and write to a per-workgroup sink - and the operands of a sub-batch are requested one sub-batch ahead.
-    // Nothing touches memory under a divergent branch, so the compiler can count the outstanding operations exactly: it waits for
-    // the prefetched operands only, never for the stores it has just issued (gfx950 has one counter for loads and stores, and
-    // an operation under a skip branch forces a full drain at the next use).
-    double* sink = A.sink + ((size_t)((blockIdx.y * gridDim.x + blockIdx.x) & (kSinkSlots - 1)) * 64 + lane);
-    uint8_t fl_n, act_n; PtObs ob_n; double ws_n; Vec3 X_n;
-    auto fetch = [&](int t0) {
-      const int jj = (lane_on && t0 + j < C.n_lm) ? t0 + j : 0;
-      const int g = C.l0 + jj, e = C.e0 + jj * ka + (lane_on ? s : 0);
-      fl_n = A.pe_flags[e]; act_n = A.pt_active[g];
-      ob_n.u = A.pe_u[e]; ob_n.v = A.pe_v[e]; ob_n.ur = A.pe_ur[e]; ob_n.s = A.pe_s[e];
-      ws_n = ws_src[e];
-      X_n = load_pt(A, src, g);
-    };
-    fetch(0);
-    // the current sub-batch's operands; they are taken over from the prefetch registers at the BOTTOM of the loop body, inside the
-    // iteration that issued the loads (a use at the top of the next iteration sits behind the loop header's merge with the
-    // prologue, where the compiler must assume that nothing was issued after them and drains the counter)
-    int fl = fl_n; bool act = act_n != 0; PtObs ob = ob_n; double ws_old = ws_n; Vec3 X0 = X_n;
-    for (int t0 = 0; t0 < C.n_lm; t0 += NB) {
-      const bool has = lane_on && t0 + j < C.n_lm;
-      const int jj = has ? t0 + j : 0;
-      const int g = C.l0 + jj, e = C.e0 + jj * ka + (lane_on ? s : 0);
-      double V0[9];                                          // requested BEFORE the prefetch: waiting for it must not wait for that
-      if (trial) {
-#pragma unroll
-        for (int i = 0; i < 9; i++) V0[i] = Vsrc[(size_t)g * 9 + i];
-      }
-      fetch(t0 + NB);
-      const bool e_act = has && act && !(fl & EF_LEVEL1);
-      const bool head = has && s == 0;
-      Vec3 X = X0;
-      if (trial) {
-        double wtx[3] = {0.0, 0.0, 0.0};
-        if (e_act && free_cam) {
-          double xc[6];
-#pragma unroll
-          for (int i = 0; i < 6; i++) xc[i] = xps[c * 6 + i];
-          point_wtx_closed(W.cam, pose_load(camA + c * 7), X0, (fl & EF_STEREO) != 0, ws_old, xc, wtx);
-        }
-        group_sum<3>(wtx, s, ka);
-        Vec3 Xn = X0;
-        if (head && act) sc += point_backsub(V0, lambda, wtx, X0, Xn);
-        { double* px = head ? A.ptx + (size_t)dst * A.NP + g : sink; double* py = head ? A.pty + (size_t)dst * A.NP + g : sink; double* pz = head ? A.ptz + (size_t)dst * A.NP + g : sink;
-          *px = Xn.x; *py = Xn.y; *pz = Xn.z; }
-        const int hl = lane - s;
-        X.x = __shfl(Xn.x, hl); X.y = __shfl(Xn.y, hl); X.z = __shfl(Xn.z, hl);
-      }
-      double hb[9];
-#pragma unroll
-      for (int i = 0; i < 9; i++) hb[i] = 0.0;
-      double ws_e = 0.0, c2_e = 0.0;
-      double hp[27];
-#pragma unroll
-      for (int i = 0; i < 27; i++) hp[i] = 0.0;
-      if (e_act) {
-        double rho0_e;
-        c2_e = point_edge_blocks_closed(W, pose_load(camB + c * 7), X, ob, (uint8_t)fl, ws_e, rho0_e, hb, hp, free_cam);
-        chi += rho0_e;
-      }
-      if (C.k > 0) slot_accumulate<3>(hp, rows, accl, lane, ka, C.k, NB);
-      *(e_act ? A.pe_chi2 + e : sink) = c2_e;                 // the edge's chi2 (stale for inactive edges, as in the reference)
-      *((e_act || (has && (fl & EF_LEVEL1))) ? ws_dst + e : sink) = ws_e;   // 0 for level-1 edges: their Hpl block vanishes
-      group_sum<9>(hb, s, ka);
-      const bool wr = head && act;
-      if (wr) maxd = fmax(maxd, fmax(fabs(hb[0]), fmax(fabs(hb[3]), fabs(hb[5]))));
-      double* vd = wr ? Vdst + (size_t)g * 9 : sink;
-#pragma unroll
-      for (int i = 0; i < 9; i++) vd[wr ? i : 0] = hb[i];
-      fl = fl_n; act = act_n != 0; ob = ob_n; ws_old = ws_n; X0 = X_n;
-    }
-    if (C.k > 0) slot_store<3>(accl, A.hp_part + ((size_t)dst * A.n_cpart + C.cpart_off) * 27, lane, C.k);
-  }
-  chi = wave_sum(chi); sc = wave_sum(sc); maxd = wave_max(maxd);
-  if (lane == 0) {
-    if (trial) { A.chi_part2[W.part_off + ci] = chi; A.scale_part[W.part_off + ci] = sc; }
-    else { A.chi_part[W.part_off + ci] = chi; atomicMax(&S.maxdiag_bits, (unsigned long long)__double_as_longlong(maxd)); }
-  }
-}
-
-// the two image edges of one (line, KF) observation as loaded: flags and (xs, ys, xe, ye, info) of the left and right slot
-struct LnObsIn { uint8_t fl[2]; double xs[2], ys[2], xe[2], ye[2], s[2]; };
-__device__ __forceinline__ void line_obs_load(const BAArrays& A, int o, LnObsIn& I) {
-#pragma unroll
-  for (int side = 0; side < 2; side++) {
-    const int e = 2 * o + side;
-    I.fl[side] = A.le_flags[e];
-    I.xs[side] = A.le_xs[e]; I.ys[side] = A.le_ys[e]; I.xe[side] = A.le_xe[e]; I.ye[side] = A.le_ye[e]; I.s[side] = A.le_s[e];
-  }
-}
-// one (line, KF) observation at the state (T, G): residuals of its left / right edge, chi2 (returned in c2[], stored by the caller),
-// Huber weights; adds the edges' parts of Hll / b_l to hb (10 + 4), of Hpp / b_p to hp (21 + 6) and returns the summed 6x4 Hpl block in
-// Wo.  Returns the robust cost.  `on[side]`: the edge is evaluated (valid, level 0, active line).
-__device__ __forceinline__ double line_obs_blocks(const BAWin& W, const Pose& T, const LnObsIn& I, const bool* on, const LineGeom& G, bool free_cam,
-                                                  double* hb, double* hp, double* Wo, double* c2) {
+// linearise one observation: hb (10 + 4) and the summed 6x4 Hpl block; returns the robust cost of its active edges
+__device__ __forceinline__ double line_obs_linearize(const BAArrays& A, const BAWin& W, int cur, int o, int c, const LineGeom& G, double* hb,
+                                                     double* acc_lds) {
+  const bool free_cam = c < W.n_free;
+  double Wo[24];
 #pragma unroll
   for (int i = 0; i < 24; i++) Wo[i] = 0.0;
   double chi = 0.0;
-  const Mat3 Rc = quat_rotation(T.q);
-  const Vec3 X1m = pose_map(T, G.X1), X2m = pose_map(T, G.X2);
-#pragma unroll 1
+  bool loaded = false; Pose T; Mat3 Rc; Vec3 X1m, X2m;
   for (int side = 0; side < 2; side++) {
-    c2[side] = 0.0;
-    if (!on[side]) continue;
-    const uint8_t fl = I.fl[side];
+    const int e = 2 * o + side;
+    const uint8_t fl = A.le_flags[e];
+    if (!(fl & EF_VALID) || (fl & EF_LEVEL1)) continue;
+    if (!loaded) { T = load_cam(A, cur, W.cam_off + c); Rc = quat_rotation(T.q); X1m = pose_map(T, G.X1); X2m = pose_map(T, G.X2); loaded = true; }
     double r[2]; LineAdj adj;
-    line_residual(W.cam, side == 1 ? W.cam.bx_right : 0.0, X1m, X2m, I.xs[side], I.ys[side], I.xe[side], I.ye[side], r, &adj);
-    const double s = I.s[side];
-    const double c2e = chi2_of(r, 2, s);
-    c2[side] = c2e;
-    double w = 1.0, rho0 = c2e;
-    if (fl & EF_ROBUST) rho0 = huber(c2e, (fl & EF_PAIRSTEREO) ? W.th_ln_stereo : W.th_ln_mono, &w);
+    line_residual(W.cam, A.le_bx[e], X1m, X2m, A.le_xs[e], A.le_ys[e], A.le_xe[e], A.le_ye[e], r, &adj);
+    const double s = A.le_s[e];
+    const double c2 = chi2_of(r, 2, s);
+    A.le_chi2[e] = c2;
+    double w = 1.0, rho0 = c2;
+    if (fl & EF_ROBUST) rho0 = huber(c2, (fl & EF_PAIRSTEREO) ? W.th_ln_stereo : W.th_ln_mono, &w);
     chi += rho0;
     const double ws = w * s;
     double Jc[12], Jl[8];
@@ -726,308 +780,260 @@ __device__ __forceinline__ double line_obs_blocks(const BAWin& W, const Pose& T,
       for (int d = a; d < 4; d++) hb[k++] += ws * (Jl[a] * Jl[d] + Jl[4 + a] * Jl[4 + d]);
     }
     if (free_cam) {
+      double* ac = acc_lds + c * 27;
       int kk = 0;
 #pragma unroll
       for (int rr = 0; rr < 6; rr++) {
 #pragma unroll
         for (int a = 0; a < 4; a++) Wo[rr * 4 + a] += ws * (Jc[rr] * Jl[a] + Jc[6 + rr] * Jl[4 + a]);
-        hp[21 + rr] -= ws * (Jc[rr] * r[0] + Jc[6 + rr] * r[1]);
+        atomicAdd(&ac[21 + rr], -ws * (Jc[rr] * r[0] + Jc[6 + rr] * r[1]));
 #pragma unroll
-        for (int cc = rr; cc < 6; cc++) hp[kk++] += ws * (Jc[rr] * Jc[cc] + Jc[6 + rr] * Jc[6 + cc]);
+        for (int cc = rr; cc < 6; cc++) atomicAdd(&ac[kk++], ws * (Jc[rr] * Jc[cc] + Jc[6 + rr] * Jc[6 + cc]));
       }
     }
+  }
+  if (free_cam) {
+    double* Wb = A.lo_W + (size_t)o * 24;
+#pragma unroll
+    for (int i = 0; i < 24; i += 2) *reinterpret_cast<double2*>(Wb + i) = make_double2(Wo[i], Wo[i + 1]);
   }
   return chi;
 }
 
-// grid (ceil(max line chunks / kUpdChunks), nW), block kUpdThreads; same LDS.  lane <-> (line j, observation slot s): left + right image edge.
-__global__ __launch_bounds__(kUpdThreads) __attribute__((amdgpu_waves_per_eu(2, 4))) void ba_update_ln_kernel(BAArrays A, const BAWin* __restrict__ wins, BAState* __restrict__ st, int sel) {
+// grid (nl_ln, nW), block 512 = 8 wavefronts, BAWin::rounds tasks per wavefront; dynamic LDS: kAccCopies*n_free_max*27 doubles + 8 scratch.
+__device__ __forceinline__ void ba_linearize_ln_body(const BAArrays& A, const BAWin* __restrict__ wins, BAState* __restrict__ st, const int bx) {   // bx: the workgroup's index along x
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const BAWin W = wins[blockIdx.y];
   BAState& S = st[blockIdx.y];
-  if (S.phase != PH_RUN) return;
-  const bool trial = sel != 0;
-  if (trial == (S.need_lin != 0)) return;
-  if (trial && !S.pcg_ok) return;
-  const int n_items_ln = W.n_items - W.n_items_pt;
-  if ((int)blockIdx.x * kUpdChunks >= n_items_ln) return;
-  const int cur = S.cur, src = cur, dst = trial ? cur ^ 1 : cur;
-  const double lambda = S.lambda;
-  double* camA = lds + 8; double* camB = camA + W.n_cams * 7; double* xps = camB + W.n_cams * 7;
-  update_stage_cams(A, W, src, dst, trial, camA, camB, xps);
-  const int lane = threadIdx.x & 63, ci = blockIdx.x * kUpdChunks + (threadIdx.x >> 6);
-  if (ci >= n_items_ln) return;
-  const SChunk C = A.sg_chunks[W.item_off + W.n_items_pt + ci];
-  const int ka = C.k_all;
-  if (ka > 64) return;                                    // ba_update_wide_kernel
-  double chi = 0.0, sc = 0.0, maxd = 0.0;
-  if (ka == 0) {
-    if (trial) for (int i = lane; i < C.n_lm; i += 64) store_ln(A, dst, C.l0 + i, load_ln(A, src, C.l0 + i));
-  } else {
-    const int NB = 64 / ka;
-    const int j = lane / ka, s = lane - j * ka;
-    const bool lane_on = lane < NB * ka;
-    const int c = A.sg_cams[C.cams_off + (lane_on ? s : 0)];
-    const bool free_cam = lane_on && s < C.k;
-    double acc[27];
+  if (S.phase != PH_RUN || !S.need_lin) return;
+  if ((int)bx >= W.nl_ln) return;
+  const int nacc = W.n_free * 27;
+  double* acc_all = lds;                              // kAccCopies x [n_free][21 Hpp upper + 6 bp]
+  double* scratch = lds + W.acc_copies * nacc;
+  for (int i = threadIdx.x; i < W.acc_copies * nacc; i += kLinThreads) acc_all[i] = 0.0;
+  double* acc = acc_all + ((threadIdx.x >> 3) & (W.acc_copies - 1)) * nacc;
+  __syncthreads();
+  const int cur = S.cur;
+  const int lane = threadIdx.x & 63;
+  double chi = 0.0, maxd = 0.0;
+  for (int rnd = 0; rnd < W.rounds[1]; rnd++) {
+    const int ti = (bx * W.rounds[1] + rnd) * (kLinThreads / 64) + (threadIdx.x >> 6);
+    if (ti >= W.n_ltasks) break;
+    const PTask T = A.ltasks[W.ltask_off + ti];
+    double hb[14];
 #pragma unroll
-    for (int i = 0; i < 27; i++) acc[i] = 0.0;
-    double* Vsrc = A.ln_V + (size_t)src * A.NL * 14; double* Vdst = A.ln_V + (size_t)dst * A.NL * 14;
-    const double* W_src = A.lo_W + (size_t)src * A.NLO * 24; double* W_dst = A.lo_W + (size_t)dst * A.NLO * 24;
-    // memory discipline as in ba_update_pt_kernel: every load and store is issued by every lane (clamped addresses / the sink),
-    // nothing touches memory under a divergent branch; the loads of a pass are all requested at its top
-    double* sink = A.sink + ((size_t)((blockIdx.y * gridDim.x + blockIdx.x) & (kSinkSlots - 1)) * 64 + lane);
-    for (int t0 = 0; t0 < C.n_lm; t0 += NB) {
-      const bool has = lane_on && t0 + j < C.n_lm;
-      const int jj = has ? t0 + j : 0;
-      const int g = C.l0 + jj, o = C.e0 + jj * ka + (lane_on ? s : 0);
-      const LineQ L0 = load_ln(A, src, g);
-      const uint8_t act_raw = A.ln_active[g];
-      LnObsIn I;
-      line_obs_load(A, o, I);
-      double wtx[4] = {0.0, 0.0, 0.0, 0.0};
-      double V0[14];
-      if (trial) {
-        double Wb[24];
-#pragma unroll
-        for (int i = 0; i < 24; i += 2) { const double2 t2 = *reinterpret_cast<const double2*>(W_src + (size_t)o * 24 + i); Wb[i] = t2.x; Wb[i + 1] = t2.y; }
-#pragma unroll
-        for (int i = 0; i < 14; i++) V0[i] = Vsrc[(size_t)g * 14 + i];
-        const bool use = has && act_raw != 0 && free_cam;    // (the stored block is zero when both image edges are inactive)
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-          double sacc = 0.0;
-#pragma unroll
-          for (int r = 0; r < 6; r++) sacc += Wb[r * 4 + k] * xps[(free_cam ? c : 0) * 6 + r];
-          wtx[k] = use ? sacc : 0.0;
-        }
+    for (int i = 0; i < 14; i++) hb[i] = 0.0;
+    if (T.nl > 1) {
+      const bool has = lane < T.ne;
+      const int o = T.e0 + (has ? lane : 0);
+      const int l = has ? A.le_ln[2 * o] : -1 - lane;
+      const int g = W.ln_off + (has ? l : T.l0);
+      const bool lm_act = has && A.ln_active[g];
+      if (lm_act) {
+        const LineGeom G = line_geom(load_ln(A, cur, g));
+        chi += line_obs_linearize(A, W, cur, o, A.le_cam[2 * o], G, hb, acc);
       }
-      const bool act = act_raw != 0;
-      const bool head = has && s == 0;
-      LineQ L = L0;
-      if (trial) {
-        group_sum<4>(wtx, s, ka);
-        LineQ Ln = L0;
-        if (head && act) sc += line_backsub(V0, lambda, wtx, L0, Ln);
-        { const size_t od = (size_t)dst * A.NL + g;
-          *(head ? A.lqx + od : sink) = Ln.q.x; *(head ? A.lqy + od : sink) = Ln.q.y; *(head ? A.lqz + od : sink) = Ln.q.z;
-          *(head ? A.lqw + od : sink) = Ln.q.w; *(head ? A.lal + od : sink) = Ln.alpha; }
-        const int hl = lane - s;
-        L.q.x = __shfl(Ln.q.x, hl); L.q.y = __shfl(Ln.q.y, hl); L.q.z = __shfl(Ln.q.z, hl); L.q.w = __shfl(Ln.q.w, hl); L.alpha = __shfl(Ln.alpha, hl);
-      }
-      double hb[14];
-#pragma unroll
-      for (int i = 0; i < 14; i++) hb[i] = 0.0;
-      const bool o_act = has && act;
-      bool on[2];
-#pragma unroll
-      for (int side = 0; side < 2; side++) on[side] = o_act && (I.fl[side] & EF_VALID) && !(I.fl[side] & EF_LEVEL1);
-      double Wo[24], c2[2] = {0.0, 0.0};
-#pragma unroll
-      for (int i = 0; i < 24; i++) Wo[i] = 0.0;
-      if (on[0] || on[1]) chi += line_obs_blocks(W, pose_load(camB + c * 7), I, on, line_geom(L), free_cam, hb, acc, Wo, c2);
-      *(on[0] ? A.le_chi2 + 2 * o : sink) = c2[0];
-      *(on[1] ? A.le_chi2 + 2 * o + 1 : sink) = c2[1];
-      {
-        const bool wr = o_act && free_cam;                    // (an active line's observation without an active edge stores zeros)
-        double* Wd = wr ? W_dst + (size_t)o * 24 : sink;
-#pragma unroll
-        for (int i = 0; i < 24; i += 2) *reinterpret_cast<double2*>(wr ? Wd + i : Wd) = make_double2(Wo[i], Wo[i + 1]);
-      }
-      group_sum<14>(hb, s, ka);
-      const bool wrv = head && act;
-      if (wrv) maxd = fmax(maxd, fmax(fmax(fabs(hb[0]), fabs(hb[4])), fmax(fabs(hb[7]), fabs(hb[9]))));
-      double* vd = wrv ? Vdst + (size_t)g * 14 : sink;
-#pragma unroll
-      for (int i = 0; i < 14; i++) vd[wrv ? i : 0] = hb[i];
-    }
-    slot_sum<27>(acc, j, ka, NB);
-    if (free_cam && j == 0) {
-      double* hp = A.hp_part + ((size_t)dst * A.n_cpart + C.cpart_off + s) * 27;
-#pragma unroll
-      for (int i = 0; i < 27; i++) hp[i] = acc[i];
-    }
-  }
-  chi = wave_sum(chi); sc = wave_sum(sc); maxd = wave_max(maxd);
-  if (lane == 0) {
-    const int slot = W.part_off + W.n_items_pt + ci;
-    if (trial) { A.chi_part2[slot] = chi; A.scale_part[slot] = sc; }
-    else { A.chi_part[slot] = chi; atomicMax(&S.maxdiag_bits, (unsigned long long)__double_as_longlong(maxd)); }
-  }
-}
-
-// Chunks whose landmarks have more than 64 observations (global BA of a long track): one wavefront per chunk, one landmark at a
-// time, the lanes stride over its observations; the camera partials of a slot are accumulated in HBM by its single writer
-// (landmarks in order: deterministic).  grid (max chunks, nW) over all chunks of a window, block 64; launched only for batches that
-// have such a chunk.
-__global__ __launch_bounds__(64) void ba_update_wide_kernel(BAArrays A, const BAWin* __restrict__ wins, BAState* __restrict__ st, int sel) {
-  const BAWin W = wins[blockIdx.y];
-  BAState& S = st[blockIdx.y];
-  if (S.phase != PH_RUN) return;
-  const bool trial = sel != 0;
-  if (trial == (S.need_lin != 0)) return;
-  if (trial && !S.pcg_ok) return;
-  const int ci = blockIdx.x;
-  if (ci >= W.n_items) return;
-  const SChunk C = A.sg_chunks[W.item_off + ci];
-  const int ka = C.k_all;
-  if (ka <= 64) return;
-  const bool is_pt = ci < W.n_items_pt;
-  const int cur = S.cur, src = cur, dst = trial ? cur ^ 1 : cur;
-  const double lambda = S.lambda;
-  const int lane = threadIdx.x;
-  const double* xp = A.xp + W.x_off;
-  double chi = 0.0, sc = 0.0, maxd = 0.0;
-  for (int jj = 0; jj < C.n_lm; jj++) {
-    const int g = C.l0 + jj;
-    if (is_pt) {
-      const Vec3 X0 = load_pt(A, src, g);
-      const bool act = A.pt_active[g] != 0;
-      Vec3 X = X0;
-      if (trial) {
-        double wtx[3] = {0.0, 0.0, 0.0};
-        for (int s = lane; s < C.k; s += 64) {
-          const int e = C.e0 + jj * ka + s, c = A.sg_cams[C.cams_off + s];
-          const uint8_t fl = A.pe_flags[e];
-          if (!act || (fl & EF_LEVEL1)) continue;
-          double t1[3];
-          point_wtx_closed(W.cam, load_cam(A, src, W.cam_off + c), X0, (fl & EF_STEREO) != 0, A.pe_ws[(size_t)src * A.NPE + e], xp + c * 6, t1);
-          wtx[0] += t1[0]; wtx[1] += t1[1]; wtx[2] += t1[2];
-        }
-        wave_sum_n<3>(wtx);
-        if (act) { const double s1 = point_backsub(A.pt_V + ((size_t)src * A.NP + g) * 9, lambda, wtx, X0, X); if (lane == 0) sc += s1; }   // every lane, same value
-        if (lane == 0) store_pt(A, dst, g, X);
-      }
-      double hb[9];
-#pragma unroll
-      for (int i = 0; i < 9; i++) hb[i] = 0.0;
-      for (int s = lane; s < ka; s += 64) {
-        const int e = C.e0 + jj * ka + s, c = A.sg_cams[C.cams_off + s];
-        const uint8_t fl = A.pe_flags[e];
-        double* ws_dst = A.pe_ws + (size_t)dst * A.NPE;
-        if (fl & EF_LEVEL1) { ws_dst[e] = 0.0; continue; }
-        if (!act) continue;
-        PtObs ob; ob.u = A.pe_u[e]; ob.v = A.pe_v[e]; ob.ur = A.pe_ur[e]; ob.s = A.pe_s[e];
-        double h1[9], hp[27], ws_e, rho0_e;
-        for (int i = 0; i < 27; i++) hp[i] = 0.0;
-        A.pe_chi2[e] = point_edge_blocks_closed(W, load_cam(A, dst, W.cam_off + c), X, ob, fl, ws_e, rho0_e, h1, hp, s < C.k);
-        ws_dst[e] = ws_e; chi += rho0_e;
-#pragma unroll
-        for (int i = 0; i < 9; i++) hb[i] += h1[i];
-        if (s < C.k) {
-          double* hq = A.hp_part + ((size_t)dst * A.n_cpart + C.cpart_off + s) * 27;
-          for (int i = 0; i < 27; i++) hq[i] = (jj == 0 ? 0.0 : hq[i]) + hp[i];
-        }
-      }
-      if (jj == 0) for (int s = lane; s < C.k; s += 64) {          // slots whose first edge was skipped start from zero as well
-        const uint8_t fl = A.pe_flags[C.e0 + s];
-        if (!act || (fl & EF_LEVEL1)) { double* hq = A.hp_part + ((size_t)dst * A.n_cpart + C.cpart_off + s) * 27; for (int i = 0; i < 27; i++) hq[i] = 0.0; }
-      }
-      wave_sum_n<9>(hb);
-      if (lane == 0 && act) {
-        double* V = A.pt_V + ((size_t)dst * A.NP + g) * 9;
-#pragma unroll
-        for (int i = 0; i < 9; i++) V[i] = hb[i];
-        maxd = fmax(maxd, fmax(fabs(hb[0]), fmax(fabs(hb[3]), fabs(hb[5]))));
-      }
-    } else {
-      const LineQ L0 = load_ln(A, src, g);
-      const bool act = A.ln_active[g] != 0;
-      LineQ L = L0;
-      if (trial) {
-        double wtx[4] = {0.0, 0.0, 0.0, 0.0};
-        for (int s = lane; s < C.k; s += 64) {
-          if (!act) continue;
-          const int o = C.e0 + jj * ka + s, c = A.sg_cams[C.cams_off + s];
-          const double* Wb = A.lo_W + ((size_t)src * A.NLO + o) * 24;
-          for (int k = 0; k < 4; k++) { double sacc = 0.0; for (int r = 0; r < 6; r++) sacc += Wb[r * 4 + k] * xp[c * 6 + r]; wtx[k] += sacc; }
-        }
-        wave_sum_n<4>(wtx);
-        if (act) { const double s1 = line_backsub(A.ln_V + ((size_t)src * A.NL + g) * 14, lambda, wtx, L0, L); if (lane == 0) sc += s1; }
-        if (lane == 0) store_ln(A, dst, g, L);
-      }
-      double hb[14];
-#pragma unroll
-      for (int i = 0; i < 14; i++) hb[i] = 0.0;
-      const LineGeom G = line_geom(L);
-      for (int s = lane; s < ka; s += 64) {
-        const int o = C.e0 + jj * ka + s, c = A.sg_cams[C.cams_off + s];
-        double hp[27], Wo[24];
-        for (int i = 0; i < 27; i++) hp[i] = 0.0;
-        for (int i = 0; i < 24; i++) Wo[i] = 0.0;
-        if (act) {
-          LnObsIn I; line_obs_load(A, o, I);
-          bool on[2]; double c2[2];
-          for (int side = 0; side < 2; side++) on[side] = (I.fl[side] & EF_VALID) && !(I.fl[side] & EF_LEVEL1);
-          chi += line_obs_blocks(W, load_cam(A, dst, W.cam_off + c), I, on, G, s < C.k, hb, hp, Wo, c2);
-          for (int side = 0; side < 2; side++) if (on[side]) A.le_chi2[2 * o + side] = c2[side];
-        }
-        if (s < C.k) {
-          double* Wb = A.lo_W + ((size_t)dst * A.NLO + o) * 24;
-          if (act) for (int i = 0; i < 24; i++) Wb[i] = Wo[i];
-          double* hq = A.hp_part + ((size_t)dst * A.n_cpart + C.cpart_off + s) * 27;
-          for (int i = 0; i < 27; i++) hq[i] = (jj == 0 ? 0.0 : hq[i]) + hp[i];
-        }
-      }
-      wave_sum_n<14>(hb);
-      if (lane == 0 && act) {
-        double* V = A.ln_V + ((size_t)dst * A.NL + g) * 14;
+      seg_sum<14>(hb, l, lane, T.ms);
+      if (lm_act && o == A.ln_obs_start[g]) {
+        double* V = A.ln_V + (size_t)g * 14;
 #pragma unroll
         for (int i = 0; i < 14; i++) V[i] = hb[i];
         maxd = fmax(maxd, fmax(fmax(fabs(hb[0]), fabs(hb[4])), fmax(fabs(hb[7]), fabs(hb[9]))));
       }
+    } else {
+      const int g = W.ln_off + T.l0;
+      if (A.ln_active[g]) {
+        const LineGeom G = line_geom(load_ln(A, cur, g));
+        for (int sidx = lane; sidx < T.ne; sidx += 64) chi += line_obs_linearize(A, W, cur, T.e0 + sidx, A.le_cam[2 * (T.e0 + sidx)], G, hb, acc);
+        wave_sum_n<14>(hb);
+        if (lane == 0) {
+          double* V = A.ln_V + (size_t)g * 14;
+#pragma unroll
+          for (int i = 0; i < 14; i++) V[i] = hb[i];
+          maxd = fmax(maxd, fmax(fmax(fabs(hb[0]), fabs(hb[4])), fmax(fabs(hb[7]), fabs(hb[9]))));
+        }
+      }
     }
   }
-  chi = wave_sum(chi); sc = wave_sum(sc); maxd = wave_max(maxd);
-  if (lane == 0) {
-    if (trial) { A.chi_part2[W.part_off + ci] = chi; A.scale_part[W.part_off + ci] = sc; }
-    else { A.chi_part[W.part_off + ci] = chi; atomicMax(&S.maxdiag_bits, (unsigned long long)__double_as_longlong(maxd)); }
+  const double chi_t = block_sum(chi, scratch);
+  const double max_t = block_max(maxd, scratch);
+  if (threadIdx.x == 0) {
+    A.chi_part[W.part_off + W.nl_pt + bx] = chi_t;
+    atomicMax(&S.maxdiag_bits, (unsigned long long)__double_as_longlong(max_t));
+  }
+  __syncthreads();
+  // plain stores of this workgroup's camera partials; ba_hpp_reduce sums them in a fixed order (no global atomics)
+  double* dst = A.hpp_part + W.hpart_off + (size_t)(W.nl_pt + bx) * nacc;
+  for (int i = threadIdx.x; i < nacc; i += kLinThreads) {
+    double v = 0.0;
+    for (int q = 0; q < W.acc_copies; q++) v += acc_all[q * nacc + i];
+    dst[i] = v;
   }
 }
+__global__ __launch_bounds__(kLinThreads) void ba_linearize_ln_kernel(BAArrays A, const BAWin* __restrict__ wins, BAState* __restrict__ st) { ba_linearize_ln_body(A, wins, st, (int)blockIdx.x); }
 
-// Hpp / b_p of the free cameras = sum of the (chunk, slot) partials of buffer `cur`, in the order of the camera's list (host-built
-// CSR, the one ba_schur_reduce uses for the right-hand side): fixed order, plain stores.  grid (ceil(n_free_max * 27 / 256), nW)
+__device__ __forceinline__ void line_obs_wtx(const BAArrays& A, const BAWin& W, int o, int c, const double* xp, double* t) {
+  const double* Wb = A.lo_W + (size_t)o * 24;              // zero when both image edges are inactive
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    double s = 0.0;
+#pragma unroll
+    for (int r = 0; r < 6; r++) s += Wb[r * 4 + k] * xp[c * 6 + r];
+    t[k] = s;
+  }
+}
+__device__ __forceinline__ double line_obs_trial(const BAArrays& A, const BAWin& W, int nxt, int o, int c, const LineGeom& G) {
+  double chi = 0.0;
+  bool loaded = false; Vec3 X1m, X2m;
+  for (int side = 0; side < 2; side++) {
+    const int e = 2 * o + side;
+    const uint8_t fl = A.le_flags[e];
+    if (!(fl & EF_VALID) || (fl & EF_LEVEL1)) continue;
+    if (!loaded) { const Pose T = load_cam(A, nxt, W.cam_off + c); X1m = pose_map(T, G.X1); X2m = pose_map(T, G.X2); loaded = true; }
+    double r[2];
+    line_residual(W.cam, A.le_bx[e], X1m, X2m, A.le_xs[e], A.le_ys[e], A.le_xe[e], A.le_ye[e], r, nullptr);
+    const double c2 = chi2_of(r, 2, A.le_s[e]);
+    A.le_chi2[e] = c2;
+    double w, rho0 = c2;
+    if (fl & EF_ROBUST) rho0 = huber(c2, (fl & EF_PAIRSTEREO) ? W.th_ln_stereo : W.th_ln_mono, &w);
+    chi += rho0;
+  }
+  return chi;
+}
+__device__ __forceinline__ double line_backsub(const double* V, double lambda, const double* wtx, const LineQ& L, LineQ& Ln) {
+  double F[16], Di[16];
+  unpack_sym<4>(V, lambda, F);
+  spd_inverse<4>(F, Di);
+  double t[4], xl[4], sc = 0.0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) t[i] = V[10 + i] - wtx[i];
+#pragma unroll
+  for (int i = 0; i < 4; i++) xl[i] = Di[i * 4] * t[0] + Di[i * 4 + 1] * t[1] + Di[i * 4 + 2] * t[2] + Di[i * 4 + 3] * t[3];
+#pragma unroll
+  for (int i = 0; i < 4; i++) sc += xl[i] * (lambda * xl[i] + V[10 + i]);
+  Ln = line_oplus(L, xl);
+  return sc;
+}
+
+// grid (nt_ln, nW), block 256 = 4 wavefronts, BAWin::rounds tasks per wavefront
+__device__ __forceinline__ void ba_backsub_ln_body(const BAArrays& A, const BAWin* __restrict__ wins, const BAState* __restrict__ st, const int bx) {   // bx: the workgroup's index along x
+  __shared__ double scratch[8];
+  const BAWin W = wins[blockIdx.y];
+  const BAState& S = st[blockIdx.y];
+  if (S.phase != PH_RUN) return;
+  if ((int)bx >= W.nt_ln) return;
+  const int cur = S.cur, nxt = cur ^ 1;
+  const double lambda = S.lambda;
+  const double* xp = A.xp + W.x_off;
+  const int lane = threadIdx.x & 63;
+  double chi = 0.0, sc = 0.0;
+  for (int rnd = 0; rnd < W.rounds[3]; rnd++) {
+    const int ti = (bx * W.rounds[3] + rnd) * 4 + (threadIdx.x >> 6);
+    if (ti >= W.n_ltasks) break;
+    const PTask T = A.ltasks[W.ltask_off + ti];
+    if (T.nl > 1) {
+      const bool has = lane < T.ne;
+      const int o = T.e0 + (has ? lane : 0);
+      const int l = has ? A.le_ln[2 * o] : -1 - lane;
+      const int g = W.ln_off + (has ? l : T.l0);
+      const int c = A.le_cam[2 * o];
+      const bool lm_act = has && A.ln_active[g];
+      LineQ L = load_ln(A, cur, g);
+      double wtx[4] = {0, 0, 0, 0};
+      if (lm_act && c < W.n_free) line_obs_wtx(A, W, o, c, xp, wtx);
+      seg_sum<4>(wtx, l, lane, T.ms);
+      const int o_head = has ? A.ln_obs_start[g] : 0;
+      LineQ Ln = L;
+      if (has && o == o_head) {
+        if (lm_act) sc += line_backsub(A.ln_V + (size_t)g * 14, lambda, wtx, L, Ln);
+        store_ln(A, nxt, g, Ln);
+      }
+      const int hl = o_head - T.e0;
+      Ln.q.x = __shfl(Ln.q.x, hl); Ln.q.y = __shfl(Ln.q.y, hl); Ln.q.z = __shfl(Ln.q.z, hl); Ln.q.w = __shfl(Ln.q.w, hl); Ln.alpha = __shfl(Ln.alpha, hl);
+      if (lm_act) chi += line_obs_trial(A, W, nxt, o, c, line_geom(Ln));
+      if (lane < T.nl) {
+        const int g2 = W.ln_off + T.l0 + lane;
+        if (A.ln_obs_start[g2 + 1] == A.ln_obs_start[g2]) store_ln(A, nxt, g2, load_ln(A, cur, g2));
+      }
+    } else {
+      const int g = W.ln_off + T.l0;
+      const LineQ L = load_ln(A, cur, g);
+      if (!A.ln_active[g]) { if (lane == 0) store_ln(A, nxt, g, L); }
+      else {
+        double wtx[4] = {0, 0, 0, 0};
+        for (int sidx = lane; sidx < T.ne; sidx += 64) {
+          const int o = T.e0 + sidx, c = A.le_cam[2 * o];
+          if (c >= W.n_free) continue;
+          double t1[4];
+          line_obs_wtx(A, W, o, c, xp, t1);
+          wtx[0] += t1[0]; wtx[1] += t1[1]; wtx[2] += t1[2]; wtx[3] += t1[3];
+        }
+        wave_sum_n<4>(wtx);
+        LineQ Ln;
+        const double s1 = line_backsub(A.ln_V + (size_t)g * 14, lambda, wtx, L, Ln);
+        if (lane == 0) { sc += s1; store_ln(A, nxt, g, Ln); }
+        const LineGeom G = line_geom(Ln);
+        for (int sidx = lane; sidx < T.ne; sidx += 64) chi += line_obs_trial(A, W, nxt, T.e0 + sidx, A.le_cam[2 * (T.e0 + sidx)], G);
+      }
+    }
+  }
+  const double chi_t = block_sum(chi, scratch);
+  const double sc_t = block_sum(sc, scratch);
+  if (threadIdx.x == 0) { A.chi_part2[W.part_off + W.nt_pt + bx] = chi_t; A.scale_part[W.part_off + W.nt_pt + bx] = sc_t; }
+}
+__global__ __launch_bounds__(kLmThreads) void ba_backsub_ln_kernel(BAArrays A, const BAWin* __restrict__ wins, const BAState* __restrict__ st) { ba_backsub_ln_body(A, wins, st, (int)blockIdx.x); }
+
+// Point and line landmarks in one launch, for batches too small to fill the GPU (a single window above all): there the two
+// kernels of a pair are dependent launches of 8-16 us each on idle hardware.  Not for large batches: the fused kernel gets the
+// register budget of the line body (223 VGPRs), which would halve the occupancy of the point body.
+__global__ __launch_bounds__(kLinThreads) void ba_linearize_both_kernel(BAArrays A, const BAWin* __restrict__ wins, BAState* __restrict__ st, int n_pt_blocks) {
+  if ((int)blockIdx.x < n_pt_blocks) ba_linearize_pt_body(A, wins, st, (int)blockIdx.x);
+  else ba_linearize_ln_body(A, wins, st, (int)blockIdx.x - n_pt_blocks);
+}
+__global__ __launch_bounds__(kLmThreads) void ba_backsub_both_kernel(BAArrays A, const BAWin* __restrict__ wins, const BAState* __restrict__ st, int n_pt_blocks) {
+  if ((int)blockIdx.x < n_pt_blocks) ba_backsub_pt_body(A, wins, st, (int)blockIdx.x);
+  else ba_backsub_ln_body(A, wins, st, (int)blockIdx.x - n_pt_blocks);
+}
+
+// Hpp / b_p = sum over the linearise workgroups' partials, fixed order.  grid (ceil(n_free_max*27 / 256), nW)
 __global__ __launch_bounds__(256) void ba_hpp_reduce_kernel(BAArrays A, const BAWin* __restrict__ wins, const BAState* __restrict__ st) {
   const BAWin W = wins[blockIdx.y];
   const BAState& S = st[blockIdx.y];
-  if (S.phase != PH_RUN || !(S.need_lin || S.need_hpp)) return;
+  if (S.phase != PH_RUN || !S.need_lin) return;
+  const int nacc = W.n_free * 27;
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= W.n_free * 27) return;
-  const int c = i / 27, k = i - c * 27;
-  const int* cst = A.cam_start + W.cam_csr_off;
-  const double* hp = A.hp_part + (size_t)S.cur * A.n_cpart * 27 + k;
-  const int q0 = cst[c], q1 = cst[c + 1];
-  // a camera is seen by a few dozen chunks and every entry is two dependent loads (index -> partial): eight are kept in flight,
-  // summed in list order
+  if (i >= nacc) return;
+  const double* src = A.hpp_part + W.hpart_off + i;
+  const int nb = W.nl_pt + W.nl_ln;
+  // a small batch has ~140 partial rows per window and every row sits in another XCD's L2: eight independent loads in flight,
+  // summed in row order (bit-identical to the plain loop)
   double v = 0.0;
-  for (int q = q0; q < q1; q += 8) {
-    int src[8]; double t[8];
+  int b = 0;
+  for (; b + 8 <= nb; b += 8) {
+    double t[8];
 #pragma unroll
-    for (int u = 0; u < 8; u++) src[u] = (q + u < q1) ? A.cam_src[q + u] : -1;
+    for (int u = 0; u < 8; u++) t[u] = src[(size_t)(b + u) * nacc];
 #pragma unroll
-    for (int u = 0; u < 8; u++) t[u] = (src[u] >= 0) ? hp[(size_t)src[u] * 27] : 0.0;
-#pragma unroll
-    for (int u = 0; u < 8; u++) if (src[u] >= 0) v += t[u];
+    for (int u = 0; u < 8; u++) v += t[u];
   }
+  for (; b < nb; b++) v += src[(size_t)b * nacc];
+  const int c = i / 27, k = i - c * 27;
   if (k < 21) A.Hpp[((size_t)W.hpp_off + c) * 21 + k] = v; else A.bp[((size_t)W.hpp_off + c) * 6 + (k - 21)] = v;
 }
 
-// LM iteration head (one wavefront per window): chi2 of the current state, lambda initialisation at iteration 0.
+// LM iteration head (one lane per window): chi2 of the current state, lambda initialisation at iteration 0.
 __global__ __launch_bounds__(kCtlThreads) void ba_begin_kernel(BAArrays A, const BAWin* __restrict__ wins, BAState* __restrict__ st, int n_windows) {
-  const int w = blockIdx.x;
+  const int w = blockIdx.x;                 // one wavefront per window
   if (w >= n_windows) return;
   const BAWin& W = wins[w];
   BAState& S = st[w];
-  if (S.phase != PH_RUN || !(S.need_lin || S.need_hpp)) return;
+  if (S.phase != PH_RUN || !S.need_lin) return;
   const int lane = threadIdx.x;
-  // after a linearisation pass: chi2 of the current state from the chunks' partials - lanes sum interleaved partials, then a fixed
-  // shuffle tree (deterministic).  After an accepted trial currentChi already holds the trial's chi2, the same number
-  // (levenberg.cpp:132; the reference recomputes it at the top of the next solve()).
+  // chi2 of the current state: lanes sum interleaved partials, then a fixed shuffle tree (deterministic)
   double chi = 0.0;
-  if (S.need_lin) {
-    for (int i = lane; i < W.n_items; i += kCtlThreads) chi += A.chi_part[W.part_off + i];
-    chi = wave_sum(chi);
-  }
+  const int nb = W.nl_pt + W.nl_ln;
+  for (int i = lane; i < nb; i += kCtlThreads) chi += A.chi_part[W.part_off + i];
+  chi = wave_sum(chi);
   double md = 0.0;
   if (S.it == 0) {
     // computeLambdaInit: tau * max |H_kk| over cameras and landmarks (optimization_algorithm_levenberg.cpp:166-180)
@@ -1039,13 +1045,12 @@ __global__ __launch_bounds__(kCtlThreads) void ba_begin_kernel(BAArrays A, const
     md = wave_max(md);
   }
   if (lane == 0) {
-    if (S.need_lin) S.currentChi = chi;
-    S.iniChi = S.currentChi;
+    S.currentChi = chi; S.iniChi = chi;
     if (S.it == 0) {
       md = fmax(md, __longlong_as_double((long long)S.maxdiag_bits));
       S.lambda = 1e-5 * md; S.ni = 2.0; S.nBad = 0;
     }
-    S.q = 0; S.need_lin = 0; S.need_hpp = 0;
+    S.q = 0; S.need_lin = 0;
   }
 }
 
@@ -1078,6 +1083,42 @@ __host__ __device__ inline int schur_lds_doubles(int k, int D) {
   return k > kSchurWideK ? k * WS + D + 1 : ((schur_nb(k) * (k * WS + D) + 1) & ~1);
 }
 
+// 1 / sqrt(d): v_rsq_f64 seed + two Newton steps (the library sqrt and divide are ~45 dependent instructions; the result is within an
+// ulp or two and L L^T = Hll + lambda I to rounding either way)
+__device__ __forceinline__ double rsqrt_nr(double d) {
+  double y = __builtin_amdgcn_rsq(d);
+  y = y * (1.5 - (0.5 * d) * (y * y));
+  y = y * (1.5 - (0.5 * d) * (y * y));
+  return y;
+}
+// lower Cholesky factor of (packed upper U) + lambda I, D x D: L packed row-major lower (L[i][j] at i(i+1)/2 + j, diagonal entries
+// unused), idiag[i] = 1 / L[i][i]
+template <int D>
+__device__ __forceinline__ void chol_packed(const double* U, double lambda, double* L, double* idiag) {
+  double F[D][D];
+  int kk = 0;
+#pragma unroll
+  for (int i = 0; i < D; i++)
+#pragma unroll
+    for (int j = i; j < D; j++) { F[j][i] = U[kk++]; }
+#pragma unroll
+  for (int i = 0; i < D; i++) F[i][i] += lambda;
+#pragma unroll
+  for (int j = 0; j < D; j++) {
+    double d = F[j][j];
+#pragma unroll
+    for (int m = 0; m < j; m++) d -= L[j * (j + 1) / 2 + m] * L[j * (j + 1) / 2 + m];
+    const double inv = rsqrt_nr(d);
+    idiag[j] = inv;
+#pragma unroll
+    for (int i = j + 1; i < D; i++) {
+      double sacc = F[i][j];
+#pragma unroll
+      for (int m = 0; m < j; m++) sacc -= L[i * (i + 1) / 2 + m] * L[j * (j + 1) / 2 + m];
+      L[i * (i + 1) / 2 + j] = sacc * inv;
+    }
+  }
+}
 // factor + stage one (landmark, slot): Z = W L^-T into zl (6 x D), t = L^-1 b_l into tl
 template <int D>
 __device__ __forceinline__ void schur_stage_one(bool a, const double* v, double lambda, const double* w, double* zl, double* tl, bool write_t) {
@@ -1098,7 +1139,7 @@ __device__ __forceinline__ void schur_stage_one(bool a, const double* v, double 
       double sacc = w[r * D + c];
 #pragma unroll
       for (int m = 0; m < c; m++) sacc -= z[r * D + m] * L[c * (c + 1) / 2 + m];
-      z[r * D + c] = a ? sacc * idg[c] : 0.0;               // (never 0 * stale block: that could be a NaN)
+      z[r * D + c] = sacc * idg[c];
     }
 #pragma unroll
   for (int i = 0; i < 6 * D; i += 2) *reinterpret_cast<double2*>(zl + i) = make_double2(z[i], z[i + 1]);
@@ -1109,7 +1150,7 @@ __device__ __forceinline__ void schur_stage_one(bool a, const double* v, double 
       double sacc = v[HU + c];
 #pragma unroll
       for (int m = 0; m < c; m++) sacc -= t[m] * L[c * (c + 1) / 2 + m];
-      t[c] = a ? sacc * idg[c] : 0.0;
+      t[c] = sacc * idg[c];
     }
 #pragma unroll
     for (int c = 0; c < D; c++) tl[c] = t[c];
@@ -1122,26 +1163,26 @@ __device__ __forceinline__ void schur_stage_one(bool a, const double* v, double 
 template <int D>
 __device__ __forceinline__ void schur_chunk_wide(const BAArrays& A, const BAWin& W, const SChunk& C, double lambda, int cur, double* lds) {
   constexpr int VN = (D == 3) ? 9 : 14, WN = 6 * D, WS = (D == 3) ? 18 : 26;
-  const double* __restrict__ Vbase = (D == 3) ? A.pt_V + (size_t)cur * A.NP * 9 : A.ln_V + (size_t)cur * A.NL * 14;
+  const double* __restrict__ Vbase = (D == 3) ? A.pt_V : A.ln_V;
   const uint8_t* __restrict__ act = (D == 3) ? A.pt_active : A.ln_active;
   const int k = C.k, np = k * (k + 1) / 2;
   double* Zl = lds; double* tl = lds + ((k * WS + 1) & ~1);
   for (int t0 = 0; t0 < C.n_lm; t0++) {
-    const int g = C.l0 + t0;
+    const int g = A.sg_lm[C.lm_off + t0];
     const bool a = act[g] != 0;
     double v[VN];
 #pragma unroll
     for (int i = 0; i < VN; i++) v[i] = Vbase[(size_t)g * VN + i];
     __syncthreads();
     for (int sl = threadIdx.x; sl < k; sl += kSchurWideThreads) {
-      const int id = C.e0 + t0 * C.k_all + sl;
+      const int id = A.sg_tab[C.tab_off + (size_t)t0 * k + sl];
       double w[WN];
       if constexpr (D == 3) {
         const Pose Ts = load_cam(A, cur, W.cam_off + A.sg_cams[C.cams_off + sl]);
-        point_hpl_closed(W.cam, Ts, quat_rotation(Ts.q), load_pt(A, cur, g), (A.pe_flags[id] & EF_STEREO) != 0, A.pe_ws[(size_t)cur * A.NPE + id], w);
+        point_hpl_closed(W.cam, Ts, quat_rotation(Ts.q), load_pt(A, cur, g), (A.pe_flags[id] & EF_STEREO) != 0, A.pe_ws[id], w);
       } else {
 #pragma unroll
-        for (int i = 0; i < WN; i++) w[i] = A.lo_W[((size_t)cur * A.NLO + id) * WN + i];
+        for (int i = 0; i < WN; i++) w[i] = A.lo_W[(size_t)id * WN + i];
       }
       schur_stage_one<D>(a, v, lambda, w, Zl + sl * WS, tl, sl == 0);
     }
@@ -1178,15 +1219,15 @@ __device__ __forceinline__ void schur_chunk_wave(const BAArrays& A, const BAWin&
   // LDS stride of a staged 6xD block: 144 B for points (conflict-free as is); 192 B would put slots 0 and 4 of a line on the
   // same banks, so line blocks are padded to 208 B (still 16-B aligned)
   constexpr int WS = (D == 3) ? 18 : 26;
-  const double* __restrict__ Vbase = (D == 3) ? A.pt_V + (size_t)cur * A.NP * 9 : A.ln_V + (size_t)cur * A.NL * 14;   // the linearisation of buffer `cur`
-  const double* __restrict__ ws_cur = A.pe_ws + (size_t)cur * A.NPE;
-  const double* __restrict__ W_cur = A.lo_W + (size_t)cur * A.NLO * 24;
+  const double* __restrict__ Vbase = (D == 3) ? A.pt_V : A.ln_V;
   const uint8_t* __restrict__ act = (D == 3) ? A.pt_active : A.ln_active;
   const int lane = threadIdx.x;
   const int k = C.k, np = k * (k + 1) / 2;
   const int NB = schur_nb(k);
   double* Zl = lds;
   double* tl = lds + NB * k * WS;
+  const int* __restrict__ lm = A.sg_lm + C.lm_off;
+  const int* __restrict__ tab = A.sg_tab + C.tab_off;
   // stage lane <-> (landmark ej, slot esl) of a sub-batch
   const int ej = lane / k, esl = lane - ej * k;
   const bool stager = lane < NB * k;
@@ -1210,20 +1251,24 @@ __device__ __forceinline__ void schur_chunk_wave(const BAArrays& A, const BAWin&
     // them into flags where they are fetched would wait for the loads right there.
     Pose T; Mat3 Rt;
     if constexpr (D == 3) { if (stager) { T = load_cam(A, cur, W.cam_off + A.sg_cams[C.cams_off + esl]); Rt = quat_rotation(T.q); } }
-    int a_n = 0, fl_n = 0;
+    int g_n = 0, id_n = 0, g_nn = 0, id_nn = 0, a_n = 0, fl_n = 0;
     double v_n[VN];
     double ws_n = 0.0; Vec3 X_n = vec3(0, 0, 1);
-    auto fetch_data = [&](int t0) {
+    auto fetch_idx = [&](int t0, int& g, int& id) {
+      if (stager && t0 + ej < C.n_lm) { g = lm[t0 + ej]; id = tab[(size_t)(t0 + ej) * k + esl]; }
+    };
+    auto fetch_data = [&](int t0, int g, int id) {
       if (stager && t0 + ej < C.n_lm) {
-        const int g = C.l0 + t0 + ej, id = C.e0 + (t0 + ej) * C.k_all + esl;
         a_n = act[g];
         const double* V = Vbase + (size_t)g * VN;
 #pragma unroll
         for (int i = 0; i < VN; i++) v_n[i] = V[i];
-        if constexpr (D == 3) { ws_n = ws_cur[id]; fl_n = A.pe_flags[id]; X_n = load_pt(A, cur, g); }
+        if constexpr (D == 3) { ws_n = A.pe_ws[id]; fl_n = A.pe_flags[id]; X_n = load_pt(A, cur, g); }
       }
     };
-    fetch_data(0);
+    fetch_idx(0, g_n, id_n);
+    fetch_idx(NB, g_nn, id_nn);
+    fetch_data(0, g_n, id_n);
     for (int t0 = 0; t0 < C.n_lm; t0 += NB) {
       const int nb = (C.n_lm - t0) < NB ? (C.n_lm - t0) : NB;
       // this sub-batch's operands (arrived while the previous products ran) -> locals; then put the next loads in flight
@@ -1231,7 +1276,10 @@ __device__ __forceinline__ void schur_chunk_wave(const BAArrays& A, const BAWin&
 #pragma unroll
       for (int i = 0; i < VN; i++) v[i] = v_n[i];
       const double ws = ws_n; const Vec3 X = X_n; const int a_raw = a_n, fl_raw = fl_n;
-      fetch_data(t0 + NB);
+      const int id_cur = id_n;
+      g_n = g_nn; id_n = id_nn;
+      fetch_data(t0 + NB, g_n, id_n);
+      fetch_idx(t0 + 2 * NB, g_nn, id_nn);
       __syncthreads();                                      // the previous sub-batch has been consumed
       if (stager && ej < nb) {
         if constexpr (D == 3) {
@@ -1240,7 +1288,7 @@ __device__ __forceinline__ void schur_chunk_wave(const BAArrays& A, const BAWin&
         } else {
           // line observation: the summed 6x4 block was stored by the linearisation (fetched here, not a sub-batch ahead: holding
           // two of them would halve the occupancy)
-          const double* Wg = W_cur + (size_t)(C.e0 + (t0 + ej) * C.k_all + esl) * WN;
+          const double* Wg = A.lo_W + (size_t)id_cur * WN;
 #pragma unroll
           for (int i = 0; i < WN; i += 2) { const double2 t2 = *reinterpret_cast<const double2*>(Wg + i); w[i] = t2.x; w[i + 1] = t2.y; }
         }
@@ -1310,8 +1358,8 @@ __global__ __launch_bounds__(kSchurThreads) void ba_schur_items_kernel(BAArrays 
   const BAWin W = wins[blockIdx.y];
   const BAState& S = st[blockIdx.y];
   if (S.phase != PH_RUN) return;
-  const int first = (D == 3) ? W.item_off + W.n_k0_pt : W.item_off + W.n_items_pt + W.n_k0_ln;
-  const int count = (D == 3) ? W.n_items_pt - W.n_k0_pt : W.n_items - W.n_items_pt - W.n_k0_ln;
+  const int first = (D == 3) ? W.item_off : W.item_off + W.n_items_pt;
+  const int count = (D == 3) ? W.n_items_pt : W.n_items - W.n_items_pt;
   if ((int)blockIdx.x >= count) return;
   const SChunk C = A.sg_chunks[first + blockIdx.x];
   if (C.k <= kSchurWideK) schur_chunk_wave<D>(A, W, C, S.lambda, S.cur, lds);   // (wider chunks: ba_schur_wide_kernel)
@@ -1325,13 +1373,13 @@ __global__ __launch_bounds__(kSchurThreads) void ba_schur_items_both_kernel(BAAr
   const BAState& S = st[blockIdx.y];
   if (S.phase != PH_RUN) return;
   if ((int)blockIdx.x < n_pt_blocks) {
-    if ((int)blockIdx.x >= W.n_items_pt - W.n_k0_pt) return;
-    const SChunk C = A.sg_chunks[W.item_off + W.n_k0_pt + blockIdx.x];
+    if ((int)blockIdx.x >= W.n_items_pt) return;
+    const SChunk C = A.sg_chunks[W.item_off + blockIdx.x];
     if (C.k <= kSchurWideK) schur_chunk_wave<3>(A, W, C, S.lambda, S.cur, lds);
   } else {
     const int i = (int)blockIdx.x - n_pt_blocks;
-    if (i >= W.n_items - W.n_items_pt - W.n_k0_ln) return;
-    const SChunk C = A.sg_chunks[W.item_off + W.n_items_pt + W.n_k0_ln + i];
+    if (i >= W.n_items - W.n_items_pt) return;
+    const SChunk C = A.sg_chunks[W.item_off + W.n_items_pt + i];
     if (C.k <= kSchurWideK) schur_chunk_wave<4>(A, W, C, S.lambda, S.cur, lds);
   }
 }
@@ -1345,7 +1393,7 @@ __global__ __launch_bounds__(kSchurWideThreads) void ba_schur_wide_kernel(BAArra
   if (S.phase != PH_RUN || (int)blockIdx.x >= W.n_items) return;
   const SChunk C = A.sg_chunks[W.item_off + blockIdx.x];
   if (C.k <= kSchurWideK) return;
-  if ((int)blockIdx.x < W.n_items_pt) schur_chunk_wide<3>(A, W, C, S.lambda, S.cur, lds);
+  if (C.D == 3) schur_chunk_wide<3>(A, W, C, S.lambda, S.cur, lds);
   else schur_chunk_wide<4>(A, W, C, S.lambda, S.cur, lds);
 }
 
@@ -2135,14 +2183,19 @@ __global__ __launch_bounds__(kCholMThreads) void ba_chol_mfma_kernel(BAArrays A,
 
 // ================================================================== LM control
 // grid (nW), block 64: lane 0 takes the accept / reject decision of the trial that just ran
-// (optimization_algorithm_levenberg.cpp:118-163) and advances the window's state machine.
+// (optimization_algorithm_levenberg.cpp:118-163) and advances the window's state machine; all lanes then clear the
+// camera accumulators when a new linearisation is due.
 __global__ __launch_bounds__(kCtlThreads) void ba_control_kernel(BAArrays A, const BAWin* __restrict__ wins, BAState* __restrict__ st, int abort_flag,
-                                                                 int* __restrict__ counters /* [3]: running, transition, finalize */, int abort_flag_dbg) {
+                                                                 int* __restrict__ counters /* [3]: running, transition, finalize */) {
+  __shared__ int do_clear;
   const BAWin& W = wins[blockIdx.x];
   BAState& S = st[blockIdx.x];
+  if (threadIdx.x == 0) do_clear = 0;
+  __syncthreads();
   double tempChi = 0.0, scale_l = 0.0;
   if (S.phase == PH_RUN) {                           // interleaved partial sums + fixed shuffle tree (deterministic)
-    if (S.pcg_ok) for (int i = threadIdx.x; i < W.n_items; i += kCtlThreads) { tempChi += A.chi_part2[W.part_off + i]; scale_l += A.scale_part[W.part_off + i]; }
+    const int nb = W.nt_pt + W.nt_ln;
+    for (int i = threadIdx.x; i < nb; i += kCtlThreads) { tempChi += A.chi_part2[W.part_off + i]; scale_l += A.scale_part[W.part_off + i]; }
     tempChi = wave_sum(tempChi); scale_l = wave_sum(scale_l);
   }
   if (threadIdx.x == 0 && S.phase == PH_RUN) {
@@ -2173,7 +2226,7 @@ __global__ __launch_bounds__(kCtlThreads) void ba_control_kernel(BAArrays A, con
       }
       S.it++;
       S.lm_iterations[round]++;
-      if (!term && S.it < W.its[round] && !abort_flag) { if (abort_flag_dbg) S.need_lin = 1; else S.need_hpp = 1; }     // (not terminated implies the trial was accepted: its linearisation is in `cur`)
+      if (!term && S.it < W.its[round] && !abort_flag) { S.need_lin = 1; S.maxdiag_bits = 0ull; do_clear = 1; }
       else if (round == 0) {
         S.chi2_round1 = S.currentChi; S.chi2_final = S.currentChi;
         if (abort_flag) { S.aborted = 1; S.phase = PH_FINALIZE; }
@@ -2181,6 +2234,11 @@ __global__ __launch_bounds__(kCtlThreads) void ba_control_kernel(BAArrays A, con
         else S.phase = PH_TRANSITION;
       } else { S.chi2_final = S.currentChi; S.phase = PH_FINALIZE; }
     }
+  }
+  __syncthreads();
+  if (do_clear) {
+    for (int i = threadIdx.x; i < W.n_free * 21; i += kCtlThreads) A.Hpp[(size_t)W.hpp_off * 21 + i] = 0.0;
+    for (int i = threadIdx.x; i < W.n_free * 6; i += kCtlThreads) A.bp[(size_t)W.hpp_off * 6 + i] = 0.0;
   }
   if (threadIdx.x == 0) {
     const int ph = S.phase;
@@ -2256,10 +2314,15 @@ __global__ __launch_bounds__(kLmThreads) void ba_classify_kernel(BAArrays A, con
 
 // After classification: start round 2 (initializeOptimization(0); optimize(its[1])).
 __global__ __launch_bounds__(kCtlThreads) void ba_round2_kernel(BAArrays A, const BAWin* __restrict__ wins, BAState* __restrict__ st) {
+  const BAWin& W = wins[blockIdx.x];
   BAState& S = st[blockIdx.x];
   if (S.phase != PH_TRANSITION) return;
+  __syncthreads();
+  for (int i = threadIdx.x; i < W.n_free * 21; i += kCtlThreads) A.Hpp[(size_t)W.hpp_off * 21 + i] = 0.0;
+  for (int i = threadIdx.x; i < W.n_free * 6; i += kCtlThreads) A.bp[(size_t)W.hpp_off * 6 + i] = 0.0;
+  __syncthreads();
   if (threadIdx.x == 0) {
-    S.round = 1; S.it = 0; S.q = 0; S.need_lin = 1; S.need_hpp = 0; S.maxdiag_bits = 0ull;
+    S.round = 1; S.it = 0; S.q = 0; S.need_lin = 1; S.maxdiag_bits = 0ull;
     S.phase = S.n_active_edges > 0 ? PH_RUN : PH_FINALIZE;        // optimize() returns -1 on an empty active set
   }
 }
@@ -2309,13 +2372,12 @@ __global__ __launch_bounds__(kLmThreads) void ba_finalize_kernel(BAArrays A, con
     const int g = W.pt_off + p;
     if (p < W.n_pt) {
       const Vec3 X = load_pt(A, cur, g);
-      const int po = A.pt_perm[g];                                        // the caller's index of this storage position
-      o_pt[3 * po] = X.x; o_pt[3 * po + 1] = X.y; o_pt[3 * po + 2] = X.z;
+      o_pt[3 * p] = X.x; o_pt[3 * p + 1] = X.y; o_pt[3 * p + 2] = X.z;
       for (int e = A.pt_obs_start[g]; e < A.pt_obs_start[g + 1]; e++) {
         const Pose T = load_cam(A, cur, W.cam_off + A.pe_cam[e]);
         const bool depth_pos = pose_map(T, X).z > 0.0;
         const bool stereo = !(A.pe_ur[e] < 0);
-        o_pe[A.pe_perm[e]] = (!untouched && !global && (A.pe_chi2[e] > (stereo ? 7.815 : 5.991) || !depth_pos)) ? 1 : 0;      // Optimizer.cc:1290,1305
+        o_pe[e - W.pe_off] = (!untouched && !global && (A.pe_chi2[e] > (stereo ? 7.815 : 5.991) || !depth_pos)) ? 1 : 0;      // Optimizer.cc:1290,1305
       }
     }
   } else {
@@ -2324,22 +2386,20 @@ __global__ __launch_bounds__(kLmThreads) void ba_finalize_kernel(BAArrays A, con
     if (l < W.n_ln) {
       const int e0 = 2 * A.ln_obs_start[g], e1 = 2 * A.ln_obs_start[g + 1];
       const bool removed = A.ln_removed[g] != 0;
-      const int lo = A.ln_perm[g];                                        // the caller's index of this storage position
-      auto out_slot = [&](int e) { return 2 * A.lo_perm[e >> 1] + (e & 1); };    // ... and of an edge slot
-      o_rm[lo] = removed;
+      o_rm[l] = removed;
       if (removed || untouched) {                                       // GetLineData returns false: nothing updated, nothing erased
-        for (int k = 0; k < 3; k++) { o_x0[3 * lo + k] = A.ln_x0[(size_t)g * 3 + k]; o_dir[3 * lo + k] = A.ln_dir[(size_t)g * 3 + k]; }
-        for (int e = e0; e < e1; e++) o_le[out_slot(e)] = 0;
+        for (int k = 0; k < 3; k++) { o_x0[3 * l + k] = A.ln_x0[(size_t)g * 3 + k]; o_dir[3 * l + k] = A.ln_dir[(size_t)g * 3 + k]; }
+        for (int e = e0; e < e1; e++) o_le[e - W.le_off] = 0;
       } else {
         const LineQ L = load_ln(A, cur, g);
         const Mat3 Rl = line_rotation(L);
         const Vec3 c0 = mat_col(Rl, 0), c1 = mat_col(Rl, 1);
         const Vec3 X1 = L.alpha * c1, X2 = X1 + c0;
-        o_dir[3 * lo] = c0.x; o_dir[3 * lo + 1] = c0.y; o_dir[3 * lo + 2] = c0.z;
-        o_x0[3 * lo] = X1.x; o_x0[3 * lo + 1] = X1.y; o_x0[3 * lo + 2] = X1.z;
+        o_dir[3 * l] = c0.x; o_dir[3 * l + 1] = c0.y; o_dir[3 * l + 2] = c0.z;
+        o_x0[3 * l] = X1.x; o_x0[3 * l + 1] = X1.y; o_x0[3 * l + 2] = X1.z;
         for (int e = e0; e < e1; e++) {
           const uint8_t fl = A.le_flags[e];
-          if (!(fl & EF_VALID)) { o_le[out_slot(e)] = 0; continue; }
+          if (!(fl & EF_VALID)) { o_le[e - W.le_off] = 0; continue; }
           const Pose T = load_cam(A, cur, W.cam_off + A.le_cam[e]);
           const bool depth_pos = line_depth_positive(cam, A.le_bx[e], T, c0, c1, L.alpha, A.le_xs[e], A.le_ys[e], A.le_xe[e], A.le_ye[e]);
           double r[2];
@@ -2347,7 +2407,7 @@ __global__ __launch_bounds__(kLmThreads) void ba_finalize_kernel(BAArrays A, con
           const double c2 = chi2_of(r, 2, A.le_s[e]);
           A.le_chi2[e] = c2;
           const double th = (fl & EF_PAIRSTEREO) ? W.th_ln_stereo : W.th_ln_mono;
-          o_le[out_slot(e)] = (!global && (c2 > th * th || !depth_pos)) ? 1 : 0;                    // LineOptimizer.cc:185-196
+          o_le[e - W.le_off] = (!global && (c2 > th * th || !depth_pos)) ? 1 : 0;                    // LineOptimizer.cc:185-196
         }
       }
     }
