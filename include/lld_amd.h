@@ -110,8 +110,8 @@ typedef struct {
 
 typedef struct {
   double  gamma;            /* line weight; LocalMapping passes 1.0 (Optimizer.h:49)           */
-  int32_t its_round1;       /* 5  (Optimizer.cc:1224)                                          */
-  int32_t its_round2;       /* 15 (Optimizer.cc:1273)                                          */
+  int32_t its_round1;       /* 5  (Optimizer.cc:1224); >= 1: optimize(0) evaluates no error, the classification that follows would read g2o's uninitialised _error (undefined in the reference) -> LLD_ERR_INVALID */
+  int32_t its_round2;       /* 15 (Optimizer.cc:1273); >= 1 for protocol 0 */
   int32_t ln_filter;        /* 4  (LineOptimizer.h:90)                                         */
   int32_t max_trials;       /* 10 (maxTrialsAfterFailure, optimization_algorithm_levenberg.cpp:50) */
   double  pcg_rel_tol;      /* reduced-system PCG stops at |r|_M / |b|_M <= tol (GPU only)     */

@@ -339,7 +339,8 @@ static int ba_batch_create_impl(lld_ctx* ctx, int n_windows, const lld_ba_window
   B->ctx = ctx; B->n_windows = n_windows;
   if (params) B->params = *params; else lld_ba_params_default(&B->params);
   const lld_ba_params& P = B->params;
-  if (P.its_round1 < 0 || P.its_round2 < 0 || P.max_trials <= 0 || !(P.pcg_rel_tol > 0) || P.reduced_solver < 0 || P.reduced_solver > 2 || P.protocol < 0 || P.protocol > 1) { delete B; return LLD_ERR_INVALID; }
+  // (optimize(0) would evaluate no error at all: the classification that follows would read g2o's uninitialised _error vectors)
+  if (P.its_round1 < 1 || (P.protocol == 0 && P.its_round2 < 1) || P.its_round2 < 0 || P.max_trials <= 0 || !(P.pcg_rel_tol > 0) || P.reduced_solver < 0 || P.reduced_solver > 2 || P.protocol < 0 || P.protocol > 1) { delete B; return LLD_ERR_INVALID; }
 
   // ---- layout + host staging: the windows are flattened by a few host threads straight into their final positions
   //      (every offset that depends only on the window sizes is known up front), the variable-length Schur structures are

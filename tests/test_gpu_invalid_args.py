@@ -38,3 +38,14 @@ def test_null_and_malformed_arguments_return_a_status(gpu_ctx):
     # the context is still usable afterwards
     from lld_slam_amd import Optimizer
     assert Optimizer(gpu_ctx).OptimizeSim3(synth.make_sim3_pair(1, 60)).n_inliers > 10
+
+
+def test_zero_iteration_rounds_are_refused(gpu_ctx):
+    """optimize(0) would evaluate no error at all, and the outlier classification that follows would read g2o's uninitialised _error
+    vectors (undefined behaviour in the reference): the parameter set is refused instead of being given a meaning of our own."""
+    from lld_slam_amd import Optimizer
+    w = synth.make_lba_small(12, n_free=4, n_fixed=2, n_points=60, n_lines=10)
+    for kw in (dict(its_round1=0), dict(its_round2=0), dict(its_round1=0, its_round2=0)):
+        with pytest.raises(RuntimeError):
+            Optimizer(gpu_ctx).LocalBundleAdjustment(w, **kw)
+    assert Optimizer(gpu_ctx).LocalBundleAdjustment(w, its_round1=1, its_round2=1).stats["lm_iterations"] == [1, 1]
