@@ -394,6 +394,49 @@ int lld_line_match_stereo(lld_ctx* ctx, const lld_line_stereo_params* params,
                           int dim, int32_t* matches /*[nq]*/, double* match_dist /*[nq] or NULL*/,
                           uint8_t* gate_out /*[nq][nt] or NULL*/);
 
+/* Tracking::AddLinesFrom (src/Tracking.cc:996-1124): the per-frame association of map lines (lines of the last frame /
+ * of the local map) with the lines of the current frame, candidate selection and geometric gates ON THE DEVICE.
+ * For map line i = 0..n_map-1 in order (skip[i] != 0: NULL, already tracked in this frame or bad, :1023-1034):
+ *   candidates = SubselectWithGrid (src/LineMatching.cc:154-180): the projected line's Hough cell neighbourhood
+ *     (GetHoughCoordinates, :63-152, 3 cells to each side in distance and angle) looked up in the frame's 50 x 50
+ *     line grid, in ascending line index (the reference collects them in a std::set);
+ *   a candidate si is dropped if it already holds a map line (:1054), has no stereo partner (:1059-1063, unless
+ *     monocular), if one of the map line's main points X1, X2 lies behind the camera (:1066-1074), or if the L1
+ *     reprojection error of its left / right detected endpoints against the projected 3D line
+ *     (GetReprojErrPixelsL1 = vgl::LineReprojErrorL1, src/vgl.cc:548-559) exceeds thr_reproj_base * 1.44^octave
+ *     (GetReprojThrPyramid, src/LineMatching.cc:239-247) in EITHER image (:1085);
+ *   the strict running minimum of MatchLineDescriptors (float L2, see lld_match_l2f32) wins if it is <= md_thr
+ *     (:1099) and then occupies its line for all later i (:1117).
+ * The reference allocates the line grid (Frame.cc:746-755) but never fills it (SURVEY hazard 10), so its loop never
+ * sees a candidate; this build DEFINES the fill it lacks: a frame line sits in the cell (dist_ind, ang_ind) that
+ * GetHoughCoordinates computes for the image line through its left KeyLine's endpoints (GetLineEq, :255-268).
+ * use_grid = 0 makes every line of the frame a candidate (brute force under the same gates).
+ * T_curr: camera-to-world 4x4, row-major (the callers pass mTcw.inv()); the right camera is GetTForRight(T_curr, b).
+ * map_x0 / map_dir: MapLine::GetMinimalPos; map_x1 / map_x2: GetMainPoints3D.  lines: [n][4] float startPointX,
+ * startPointY, endPointX, endPointY.  line_matches[si]: index of the right line matched to left line si or -1.
+ * matches[i] = frame line or -1; gate_out [n_map][n_cur] (optional): 1 where a pair passed every test but the
+ * descriptor threshold. */
+typedef struct {
+  double K[9];
+  double T_curr[16];
+  double b;
+  double thr_reproj_base;   /* thrReprojLineBase */
+  double md_thr;            /* mdThr (KITTI04-12_LBD.yaml:70) */
+  double sx, sy;            /* 1 / mnMaxX, 1 / mnMaxY */
+  int32_t monocular;
+  int32_t use_grid;
+} lld_line_track_params;
+int lld_line_track_match(lld_ctx* ctx, const lld_line_track_params* params,
+                         int n_map, const double* map_x0, const double* map_dir, const double* map_x1, const double* map_x2,
+                         const uint8_t* map_skip /*[n_map] or NULL*/, const float* map_desc,
+                         int n_cur, const float* left_lines, const int32_t* left_octave,
+                         int n_right, const float* right_lines, const int32_t* line_matches /*[n_cur]*/,
+                         const uint8_t* occupied /*[n_cur] or NULL*/, const float* cur_desc, int dim,
+                         int32_t* matches /*[n_map]*/, double* match_dist /*[n_map] or NULL*/,
+                         uint8_t* gate_out /*[n_map][n_cur] or NULL*/);
+/* The grid cell of that fill: cell[si] = dist_ind * 50 + ang_ind (host helper, no device work). */
+int lld_line_hough_cells(const float* lines, int n, double sx, double sy, int32_t* cell);
+
 /* ================================================================== guided ORB search
  * lld_orb_search: the complete body of one ORBmatcher::Search* / Fuse / ComputeStereoMatches
  * routine for one (query set, keypoint set) pair: candidate generation ON THE DEVICE, the

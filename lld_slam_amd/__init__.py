@@ -6,8 +6,8 @@ problem generators (synth.py).  There is no CPU fallback: everything that comput
 csrc/liblld_amd.so and fails loudly when the library or the GPU is missing.
 """
 from . import abi  # noqa: F401
-from .host import (BABatch, Context, Optimizer, ORBmatcher, PoseBatch, PoseFrame, TwoFrameLineMatcher,  # noqa: F401
+from .host import (BABatch, Context, Optimizer, ORBmatcher, PoseBatch, PoseFrame, Tracking, TwoFrameLineMatcher,  # noqa: F401
                    Window)
 
-__all__ = ["abi", "Context", "Optimizer", "ORBmatcher", "TwoFrameLineMatcher", "BABatch", "PoseBatch", "Window",
+__all__ = ["abi", "Context", "Optimizer", "ORBmatcher", "TwoFrameLineMatcher", "Tracking", "BABatch", "PoseBatch", "Window",
            "PoseFrame"]

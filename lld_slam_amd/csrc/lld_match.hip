@@ -9,6 +9,9 @@
 //   l2f32_best2        LineMatcher::MatchLineDescriptors argmin loops (src/TwoFrameLineMatcher.cc:112, Tracking.cc:1092,
 //                      1532) with the build-defined float-L2 distance (parity unpinned: LBDMOD is not vendored).
 //   line_greedy        sequential masking of TwoFrameLineMatcher::MatchLines (src/TwoFrameLineMatcher.cc:39-67).
+#include <algorithm>
+#include <cmath>
+
 #include "lld_common.h"
 
 namespace {
@@ -357,6 +360,108 @@ __global__ __launch_bounds__(64) void line_resolve_kernel(const LineCand* __rest
   }
 }
 
+// ------------------------------------------------------------------ Tracking::AddLinesFrom (src/Tracking.cc:996-1124)
+// Gate matrix of the map-line -> frame-line association: row = map line, column = line of the current frame.  Everything that depends
+// on the map line only is computed once per row (projected image lines in the left / right camera for vgl::LineReprojErrorL1, the Hough
+// cell neighbourhood of SubselectWithGrid, the depth test of the main points); a column contributes its cell, its occupancy, its stereo
+// partner and four dot products.  The greedy, order-dependent part is line_resolve_kernel's, as for TwoFrameLineMatcher.
+constexpr int kHoughDist = 50, kHoughAng = 50;           // FRAME_DIST_CELLS, FRAME_ANG_CELLS (include/Frame.h:45-46)
+#define LLD_HOUGH_PI 3.14159265                          /* the literal of src/LineMatching.cc:61 */
+struct HoughCell { int dist_ind, ang_ind, shift_dist, shift_ang; };
+// centre cell + shifts of GetHoughCoordinates (src/LineMatching.cc:63-110) for the homogeneous image line leq (pixels)
+__host__ __device__ inline HoughCell hough_cell(double lx, double ly, double lz, double sx, double sy) {
+  lx /= sx; ly /= sy;
+  const double n = sqrt(lx * lx + ly * ly);
+  lx /= n; ly /= n; lz /= n;
+  if (ly < 0) { lx = -lx; ly = -ly; lz = -lz; }
+  HoughCell c;
+  const double dist_level = fabs(lz / (sqrt(2.0))) * kHoughDist;
+  int di = (int)floor(dist_level + 0.5);
+  di = di < kHoughDist - 1 ? di : kHoughDist - 1; di = di > 0 ? di : 0;
+  c.dist_ind = di; c.shift_dist = (dist_level - di < 0) ? 1 : -1;
+  const double ang = atan2(ly, lx);
+  const double ang_level = ang / LLD_HOUGH_PI * kHoughAng;
+  int ai = (int)floor(ang_level + 0.5);
+  ai = ai < kHoughAng - 1 ? ai : kHoughAng - 1; ai = ai > 0 ? ai : 0;
+  c.ang_ind = ai; c.shift_ang = (ang_level - ai < 0) ? 1 : -1;
+  return c;
+}
+struct LineTrackParams { double K[9]; double R[9]; double t[3]; double tr[3]; double thr_base, sx, sy; int monocular, use_grid; };
+
+// one thread per frame line: its grid cell (the fill the reference lacks: the centre cell of the line through the left KeyLine)
+__global__ void line_cells_kernel(const float* __restrict__ lines, int n, double sx, double sy, int* __restrict__ cell) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double xs = lines[4 * i], ys = lines[4 * i + 1], xe = lines[4 * i + 2], ye = lines[4 * i + 3];
+  const HoughCell c = hough_cell(ys - ye, xe - xs, xs * ye - ys * xe, sx, sy);          // GetLineEq: (xs,ys,1) x (xe,ye,1)
+  cell[i] = c.dist_ind * kHoughAng + c.ang_ind;
+}
+
+__device__ __forceinline__ void track_map_point(const LineTrackParams& P, const double* t, const double* X, double* o) {   // vgl::MapPoint: R^T (X - t)
+  const double d0 = X[0] - t[0], d1 = X[1] - t[1], d2 = X[2] - t[2];
+  for (int c = 0; c < 3; c++) o[c] = P.R[0 * 3 + c] * d0 + P.R[1 * 3 + c] * d1 + P.R[2 * 3 + c] * d2;
+}
+__device__ __forceinline__ void track_k_mul(const double* K, const double* X, double* o) {
+  for (int r = 0; r < 3; r++) o[r] = K[3 * r] * X[0] + K[3 * r + 1] * X[1] + K[3 * r + 2] * X[2];
+}
+// image line of the 3D line (X0, dir) in the camera with centre t: K MapPoint(X0) x K MapPoint(X0 + dir), first two components normalised
+__device__ __forceinline__ void track_image_line(const LineTrackParams& P, const double* t, const double* X0, const double* dir, double* l) {
+  double a[3], b[3], Xa[3], Xb[3];
+  const double X0d[3] = {X0[0] + dir[0], X0[1] + dir[1], X0[2] + dir[2]};
+  track_map_point(P, t, X0, a); track_map_point(P, t, X0d, b);
+  track_k_mul(P.K, a, Xa); track_k_mul(P.K, b, Xb);
+  l[0] = Xa[1] * Xb[2] - Xa[2] * Xb[1]; l[1] = Xa[2] * Xb[0] - Xa[0] * Xb[2]; l[2] = Xa[0] * Xb[1] - Xa[1] * Xb[0];
+  const double n = sqrt(l[0] * l[0] + l[1] * l[1]);
+  l[0] /= n; l[1] /= n; l[2] /= n;
+}
+
+// grid n_map, block 64
+__global__ __launch_bounds__(64) void line_track_gate_kernel(LineTrackParams P, const double* __restrict__ x0, const double* __restrict__ dir,
+                                                            const double* __restrict__ x1, const double* __restrict__ x2, const uint8_t* __restrict__ skip,
+                                                            int n_cur, const float* __restrict__ left, const int* __restrict__ loct,
+                                                            const float* __restrict__ right, const int* __restrict__ lmatch,
+                                                            const uint8_t* __restrict__ occupied, const int* __restrict__ cell, uint8_t* __restrict__ gate) {
+  const int i = blockIdx.x, lane = threadIdx.x;
+  uint8_t* grow = gate + (size_t)i * n_cur;
+  bool row_ok = !(skip && skip[i]);
+  double X1c[3], X2c[3];
+  track_map_point(P, P.t, x1 + 3 * i, X1c); track_map_point(P, P.t, x2 + 3 * i, X2c);
+  if (X1c[2] < 0 || X2c[2] < 0) row_ok = false;                               // Tracking.cc:1066-1074
+  double ll[3], lr[3];
+  track_image_line(P, P.t, x0 + 3 * i, dir + 3 * i, ll);
+  track_image_line(P, P.tr, x0 + 3 * i, dir + 3 * i, lr);
+  // SubselectWithGrid: the cell neighbourhood of the projected line (GetHoughCoordinates with step 3: six consecutive angle cells
+  // around the centre, modulo the grid, and up to six distance cells, the last distance row excluded as in the reference)
+  const HoughCell hc = hough_cell(ll[0], ll[1], ll[2], P.sx, P.sy);
+  const int ang_min = hc.ang_ind < hc.ang_ind + hc.shift_ang ? hc.ang_ind : hc.ang_ind + hc.shift_ang;
+  const int dist_min = hc.dist_ind < hc.dist_ind + hc.shift_dist ? hc.dist_ind : hc.dist_ind + hc.shift_dist;
+  for (int si = lane; si < n_cur; si += 64) {
+    bool g = row_ok && !(occupied && occupied[si]);
+    const int ri = lmatch[si];
+    if (ri < 0 && !P.monocular) g = false;
+    if (g && P.use_grid) {
+      const int cd = cell[si] / kHoughAng, ca = cell[si] - cd * kHoughAng;
+      int da = ca - (ang_min - 2); da %= kHoughAng; if (da < 0) da += kHoughAng;
+      const bool in_ang = da < 6;
+      const bool in_dist = cd >= dist_min - 2 && cd <= dist_min + 3 && cd >= 0 && cd < kHoughDist - 1;
+      g = in_ang && in_dist;
+    }
+    if (g) {
+      double thr = P.thr_base;                                                // GetReprojThrPyramid
+      for (int o = 0; o < loct[si]; o++) thr *= 1.44;
+      const float* kl = left + 4 * si;
+      const double se = fabs((double)kl[0] * ll[0] + (double)kl[1] * ll[1] + ll[2]) + fabs((double)kl[2] * ll[0] + (double)kl[3] * ll[1] + ll[2]);
+      double se2 = 0.0;
+      if (!P.monocular) {
+        const float* kr = right + 4 * ri;
+        se2 = fabs((double)kr[0] * lr[0] + (double)kr[1] * lr[1] + lr[2]) + fabs((double)kr[2] * lr[0] + (double)kr[3] * lr[1] + lr[2]);
+      }
+      if (se > thr || se2 > thr) g = false;                                   // Tracking.cc:1085
+    }
+    grow[si] = g ? 1 : 0;
+  }
+}
+
 int launch_hamming(lld_ctx* ctx, int batch, const uint32_t* q, int nq, const uint32_t* t, int nt, const uint8_t* mask,
                    int* bi, int* bd, int* si, int* sd) {
   if (nt >= (1 << kIdxBits)) return LLD_ERR_UNSUPPORTED;
@@ -571,6 +676,99 @@ int lld_line_match_stereo(lld_ctx* ctx, const lld_line_stereo_params* params, co
   if (nq > 0 && (!left_lines || !left_octave || !dl)) return LLD_ERR_INVALID;
   if (nt > 0 && (!right_lines || !right_octave || !dr)) return LLD_ERR_INVALID;
   return line_match_core(ctx, params, left_lines, left_octave, dl, nq, right_lines, right_octave, dr, nt, dim, nullptr, params->tau, matches, match_dist, gate_out);
+}
+
+int lld_line_hough_cells(const float* lines, int n, double sx, double sy, int32_t* cell) {
+  if (n < 0 || (n > 0 && (!lines || !cell)) || !(sx > 0) || !(sy > 0)) return LLD_ERR_INVALID;
+  for (int i = 0; i < n; i++) {
+    const double xs = lines[4 * i], ys = lines[4 * i + 1], xe = lines[4 * i + 2], ye = lines[4 * i + 3];
+    const HoughCell c = hough_cell(ys - ye, xe - xs, xs * ye - ys * xe, sx, sy);
+    cell[i] = c.dist_ind * kHoughAng + c.ang_ind;
+  }
+  return LLD_OK;
+}
+
+int lld_line_track_match(lld_ctx* ctx, const lld_line_track_params* prm, int n_map, const double* map_x0, const double* map_dir, const double* map_x1,
+                         const double* map_x2, const uint8_t* map_skip, const float* map_desc, int n_cur, const float* left_lines,
+                         const int32_t* left_octave, int n_right, const float* right_lines, const int32_t* line_matches, const uint8_t* occupied,
+                         const float* cur_desc, int dim, int32_t* matches, double* match_dist, uint8_t* gate_out) {
+  if (!ctx || !prm || n_map < 0 || n_cur < 0 || n_right < 0 || dim <= 0 || !matches) return LLD_ERR_INVALID;
+  if (n_map > 0 && (!map_x0 || !map_dir || !map_x1 || !map_x2 || !map_desc)) return LLD_ERR_INVALID;
+  if (n_cur > 0 && (!left_lines || !left_octave || !line_matches || !cur_desc)) return LLD_ERR_INVALID;
+  if (!prm->monocular && n_right > 0 && !right_lines) return LLD_ERR_INVALID;
+  if (!(prm->sx > 0) || !(prm->sy > 0)) return LLD_ERR_INVALID;
+  for (int si = 0; si < n_cur; si++) {
+    if (left_octave[si] < 0 || left_octave[si] > 64) return LLD_ERR_INVALID;
+    if (line_matches[si] >= n_right) return LLD_ERR_INVALID;
+  }
+  if (dim > 128) return LLD_ERR_UNSUPPORTED;
+  if (n_map == 0) return LLD_OK;
+  if (n_cur == 0) { for (int i = 0; i < n_map; i++) { matches[i] = -1; if (match_dist) match_dist[i] = 1.7976931348623157e308; } return LLD_OK; }
+  if ((size_t)n_cur * 8 + (size_t)dim * 4 > 150 * 1024) return LLD_ERR_UNSUPPORTED;
+  LLD_HIP_TRY(hipSetDevice(ctx->device));
+  const size_t pairs = (size_t)n_map * n_cur;
+  auto pad = [](size_t b) { return (b + 255) & ~size_t(255); };
+  size_t in = 0;
+  const size_t o_q = in; in += pad((size_t)n_map * dim * 4);
+  const size_t o_t = in; in += pad((size_t)n_cur * dim * 4);
+  const size_t o_x0 = in; in += pad((size_t)n_map * 24); const size_t o_dr = in; in += pad((size_t)n_map * 24);
+  const size_t o_x1 = in; in += pad((size_t)n_map * 24); const size_t o_x2 = in; in += pad((size_t)n_map * 24);
+  const size_t o_sk = in; in += pad((size_t)n_map);
+  const size_t o_ll = in; in += pad((size_t)n_cur * 16); const size_t o_lo = in; in += pad((size_t)n_cur * 4);
+  const size_t o_rl = in; in += pad((size_t)std::max(n_right, 1) * 16);
+  const size_t o_lm = in; in += pad((size_t)n_cur * 4); const size_t o_oc = in; in += pad((size_t)n_cur);
+  size_t out = 0;
+  const size_t r_m = out; out += pad((size_t)n_map * 4);
+  const size_t r_d = out; out += pad((size_t)n_map * 8);
+  const size_t r_g = out; out += pad(pairs);
+  size_t dev = 0;
+  const size_t s_cell = dev; dev += pad((size_t)n_cur * 4);
+  const size_t s_mat = dev; dev += pad(pairs * 8);
+  const size_t s_c = dev; dev += pad((size_t)n_map * sizeof(LineCand));
+  void* hb; int st = lld_ctx_pinned(ctx, in + out, &hb); if (st) return st;
+  void* db; st = lld_ctx_scratch(ctx, in + out + dev + 256, &db); if (st) return st;
+  char* h = (char*)hb; char* d = (char*)db; char* h_out = h + in; char* d_out = d + in; char* d_dev = d_out + out;
+  std::memcpy(h + o_q, map_desc, (size_t)n_map * dim * 4); std::memcpy(h + o_t, cur_desc, (size_t)n_cur * dim * 4);
+  std::memcpy(h + o_x0, map_x0, (size_t)n_map * 24); std::memcpy(h + o_dr, map_dir, (size_t)n_map * 24);
+  std::memcpy(h + o_x1, map_x1, (size_t)n_map * 24); std::memcpy(h + o_x2, map_x2, (size_t)n_map * 24);
+  if (map_skip) std::memcpy(h + o_sk, map_skip, (size_t)n_map); else std::memset(h + o_sk, 0, (size_t)n_map);
+  std::memcpy(h + o_ll, left_lines, (size_t)n_cur * 16); std::memcpy(h + o_lo, left_octave, (size_t)n_cur * 4);
+  if (n_right > 0 && right_lines) std::memcpy(h + o_rl, right_lines, (size_t)n_right * 16);
+  std::memcpy(h + o_lm, line_matches, (size_t)n_cur * 4);
+  if (occupied) std::memcpy(h + o_oc, occupied, (size_t)n_cur); else std::memset(h + o_oc, 0, (size_t)n_cur);
+  hipStream_t sm = ctx->stream;
+  LLD_HIP_TRY(hipMemcpyAsync(d, h, in, hipMemcpyHostToDevice, sm));
+  LineTrackParams P; std::memset(&P, 0, sizeof P);
+  for (int i = 0; i < 9; i++) P.K[i] = prm->K[i];
+  for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) P.R[3 * r + c] = prm->T_curr[4 * r + c]; P.t[r] = prm->T_curr[4 * r + 3]; }
+  for (int r = 0; r < 3; r++) P.tr[r] = P.t[r] + P.R[3 * r] * prm->b;            // GetTForRight: t + R (b, 0, 0)
+  P.thr_base = prm->thr_reproj_base; P.sx = prm->sx; P.sy = prm->sy; P.monocular = prm->monocular; P.use_grid = prm->use_grid;
+  int* dcell = reinterpret_cast<int*>(d_dev + s_cell);
+  uint8_t* dgate = reinterpret_cast<uint8_t*>(d_out + r_g);
+  double* dmat = reinterpret_cast<double*>(d_dev + s_mat);
+  LineCand* dc = reinterpret_cast<LineCand*>(d_dev + s_c);
+  hipLaunchKernelGGL(line_cells_kernel, dim3((n_cur + 255) / 256), dim3(256), 0, sm, reinterpret_cast<const float*>(d + o_ll), n_cur, P.sx, P.sy, dcell);
+  hipLaunchKernelGGL(line_track_gate_kernel, dim3(n_map), dim3(64), 0, sm, P, reinterpret_cast<const double*>(d + o_x0), reinterpret_cast<const double*>(d + o_dr),
+                     reinterpret_cast<const double*>(d + o_x1), reinterpret_cast<const double*>(d + o_x2), reinterpret_cast<const uint8_t*>(d + o_sk), n_cur,
+                     reinterpret_cast<const float*>(d + o_ll), reinterpret_cast<const int*>(d + o_lo), reinterpret_cast<const float*>(d + o_rl),
+                     reinterpret_cast<const int*>(d + o_lm), reinterpret_cast<const uint8_t*>(d + o_oc), dcell, dgate);
+  // `md > mdThr` rejects (Tracking.cc:1099): distances up to and including md_thr pass, where the stereo matcher's tau is strict
+  const double tau = std::nextafter(prm->md_thr, 1.7976931348623157e308);
+  const size_t lds = (size_t)n_cur * 8 + (size_t)dim * 4 + 16;
+  if (lds > 48 * 1024) LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&line_candidates_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  if ((size_t)n_cur + 16 > 48 * 1024) LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&line_resolve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)n_cur + 16));
+  LineGateParams G0; std::memset(&G0, 0, sizeof G0);
+  hipLaunchKernelGGL(line_candidates_kernel<false>, dim3(n_map), dim3(64), lds, sm, G0, nullptr, nullptr, nullptr, nullptr, reinterpret_cast<const float*>(d + o_q),
+                     reinterpret_cast<const float*>(d + o_t), dim, n_cur, dgate, tau, nullptr, dmat, dc);
+  hipLaunchKernelGGL(line_resolve_kernel, dim3(1), dim3(64), (size_t)n_cur + 16, sm, dc, dmat, dgate, n_map, n_cur, tau,
+                     reinterpret_cast<int*>(d_out + r_m), reinterpret_cast<double*>(d_out + r_d));
+  LLD_HIP_TRY(hipGetLastError());
+  LLD_HIP_TRY(hipMemcpyAsync(h_out, d_out, gate_out ? out : r_g, hipMemcpyDeviceToHost, sm));
+  LLD_HIP_TRY(hipStreamSynchronize(sm));
+  std::memcpy(matches, h_out + r_m, (size_t)n_map * 4);
+  if (match_dist) std::memcpy(match_dist, h_out + r_d, (size_t)n_map * 8);
+  if (gate_out) std::memcpy(gate_out, h_out + r_g, pairs);
+  return LLD_OK;
 }
 
 }  // extern "C"

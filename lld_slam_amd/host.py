@@ -414,6 +414,35 @@ def line_stereo_call(lib: abi.Lib, ctx, K, b, tau, min_line_length, left_lines, 
     return (m, d, gate) if want_gate else (m, d)
 
 
+def line_track_call(lib: abi.Lib, ctx, K, T_curr, b, thr_reproj_base, md_thr, sx, sy, map_x0, map_dir, map_x1, map_x2, map_skip, map_desc,
+                    left_lines, left_octave, right_lines, line_matches, occupied, cur_desc, monocular=False, use_grid=True, want_gate=False):
+    """lld_line_track_match: Tracking::AddLinesFrom with the Hough-cell candidates and the reprojection gates on the device."""
+    P = abi.LineTrackParams()
+    for i, v in enumerate(np.asarray(K, np.float64).reshape(9)):
+        P.K[i] = float(v)
+    for i, v in enumerate(np.asarray(T_curr, np.float64).reshape(16)):
+        P.T_curr[i] = float(v)
+    P.b = float(b); P.thr_reproj_base = float(thr_reproj_base); P.md_thr = float(md_thr); P.sx = float(sx); P.sy = float(sy)
+    P.monocular = int(monocular); P.use_grid = int(use_grid)
+    x0 = np.ascontiguousarray(map_x0, np.float64).reshape(-1, 3); dr = np.ascontiguousarray(map_dir, np.float64).reshape(-1, 3)
+    x1 = np.ascontiguousarray(map_x1, np.float64).reshape(-1, 3); x2 = np.ascontiguousarray(map_x2, np.float64).reshape(-1, 3)
+    n_map = x0.shape[0]
+    sk = None if map_skip is None else np.ascontiguousarray(map_skip, np.uint8)
+    md = np.ascontiguousarray(map_desc, np.float32); cd = np.ascontiguousarray(cur_desc, np.float32)
+    ll = np.ascontiguousarray(left_lines, np.float32).reshape(-1, 4); lo = np.ascontiguousarray(left_octave, np.int32)
+    rl = np.ascontiguousarray(right_lines, np.float32).reshape(-1, 4); lm = np.ascontiguousarray(line_matches, np.int32)
+    oc = None if occupied is None else np.ascontiguousarray(occupied, np.uint8)
+    n_cur, n_right = ll.shape[0], rl.shape[0]
+    dim = md.shape[1] if md.ndim == 2 else cd.shape[1]
+    m = np.empty(n_map, np.int32); d = np.empty(n_map, np.float64)
+    gate = np.empty((n_map, n_cur), np.uint8) if want_gate else None
+    check(lib.fn("line_track_match")(ctx, C.byref(P), n_map, _p(x0, C.c_double), _p(dr, C.c_double), _p(x1, C.c_double), _p(x2, C.c_double),
+                                     None if sk is None else _p(sk, C.c_uint8), _p(md, C.c_float), n_cur, _p(ll, C.c_float), _p(lo, C.c_int32), n_right,
+                                     _p(rl, C.c_float), _p(lm, C.c_int32), None if oc is None else _p(oc, C.c_uint8), _p(cd, C.c_float), dim,
+                                     _p(m, C.c_int32), _p(d, C.c_double), None if gate is None else _p(gate, C.c_uint8)), "line_track_match")
+    return (m, d, gate) if want_gate else (m, d)
+
+
 def se3_from_tcw_f32(lib: abi.Lib, tcw: np.ndarray) -> np.ndarray:
     t = np.ascontiguousarray(tcw, np.float32).reshape(16)
     out = np.zeros(7)
@@ -680,6 +709,31 @@ class ORBmatcher:
         """`bestDist<=th` and `bestDist < mfNNratio*bestDist2` as in SearchByBoW (src/ORBmatcher.cc:226-230)."""
         ok = (best_idx >= 0) & (best_dist <= th) & (best_dist.astype(np.float32) < self.mfNNratio * second_dist.astype(np.float32))
         return np.where(ok, best_idx, -1)
+
+
+class Tracking:
+    """The line half of the Tracking thread that runs on the device: Tracking::AddLinesFrom (src/Tracking.cc:996-1124), the per-frame
+    association of map lines with the lines of the current frame.  K, b (= mbf / fx), the image size and mdThr are the members the
+    reference's Tracking object holds."""
+
+    def __init__(self, ctx: "Context", K, b: float, mnMaxX: float, mnMaxY: float, mdThr: float = 2.0, monocular: bool = False):
+        self.ctx = ctx; self.lib = ctx.lib
+        self.K = np.asarray(K, np.float64).reshape(3, 3); self.b = b; self.sx = 1.0 / mnMaxX; self.sy = 1.0 / mnMaxY
+        self.mdThr = mdThr; self.monocular = monocular
+
+    def AddLinesFrom(self, lines_last: dict, T_curr, thrReprojLineBase: float, frame: dict, use_grid: bool = True, want_gate: bool = False):
+        """lines_last: X0, dir (GetMinimalPos), X1, X2 (GetMainPoints3D), desc, skip; frame: left_lines, left_octave, right_lines,
+        line_matches, occupied (mvpMapLines != NULL), desc.  Returns (matches, distances[, gates])."""
+        return line_track_call(self.lib, self.ctx.handle, self.K, T_curr, self.b, thrReprojLineBase, self.mdThr, self.sx, self.sy,
+                               lines_last["X0"], lines_last["dir"], lines_last["X1"], lines_last["X2"], lines_last.get("skip"), lines_last["desc"],
+                               frame["left_lines"], frame["left_octave"], frame["right_lines"], frame["line_matches"], frame.get("occupied"),
+                               frame["desc"], self.monocular, use_grid, want_gate)
+
+    def HoughCells(self, lines):
+        """The frame's line grid as this build fills it: cell index dist_ind * 50 + ang_ind per line (lld_line_hough_cells)."""
+        ll = np.ascontiguousarray(lines, np.float32).reshape(-1, 4); cell = np.empty(ll.shape[0], np.int32)
+        check(self.lib.fn("line_hough_cells")(_p(ll, C.c_float), ll.shape[0], self.sx, self.sy, _p(cell, C.c_int32)), "line_hough_cells")
+        return cell
 
 
 class TwoFrameLineMatcher:

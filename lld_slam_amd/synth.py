@@ -645,6 +645,63 @@ def make_stereo_lines(frame_id=0, n_left=300, n_right=300, dim=72, related_frac=
 
 
 
+# ====================================================================== map-line tracking (Tracking::AddLinesFrom)
+def make_line_track_scene(scene_id=0, n_map=250, n_cur=300, dim=72, related_frac=0.75, pixel_noise=0.5, desc_noise=0.05, behind_frac=0.05,
+                          occupied_frac=0.05, no_partner_frac=0.1, skip_frac=0.08):
+    """Map lines and the lines of the current stereo frame for Tracking::AddLinesFrom.  A camera pose T_curr (camera-to-world), 3D
+    segments in front of it (a few behind), their noisy left / right projections among unrelated frame lines, left -> right
+    partner indices (some missing), pre-occupied frame lines, skipped map lines, near-duplicate descriptors so that several map lines
+    compete for one frame line.  Returns (params dict, lines_last dict, frame dict)."""
+    rng = np.random.default_rng(SEED_SEARCH + 0x7000 + scene_id)
+    fx, fy, cx, cy, bf = KITTI_CAM
+    K = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1.0]])
+    b = float(np.float32(np.float32(bf) / np.float32(fx)))
+    R = _rodrigues(rng.normal(0, 0.3, 3)); t = rng.normal(0, 3.0, 3)
+    T = np.eye(4); T[:3, :3] = R; T[:3, 3] = t                               # camera-to-world: X_cam = R^T (X - t)
+    z = rng.uniform(3.0, 40.0, n_map)
+    c = np.stack([(rng.uniform(60, 1180, n_map) - cx) * z / fx, (rng.uniform(30, 340, n_map) - cy) * z / fy, z], 1)
+    behind = rng.random(n_map) < behind_frac
+    c[behind, 2] = -rng.uniform(1.0, 10.0, int(behind.sum()))
+    d = rng.normal(size=(n_map, 3)); d[:, 2] *= 0.3; d /= np.linalg.norm(d, axis=1, keepdims=True)
+    half = rng.uniform(0.3, 2.5, n_map)[:, None] * 0.5
+    A, B = c - half * d, c + half * d                                        # camera frame
+
+    def proj(X, shift):
+        Xc = X - np.array([shift, 0, 0]); zz = np.maximum(Xc[:, 2], 0.3)
+        return np.stack([fx * Xc[:, 0] / zz + cx, fy * Xc[:, 1] / zz + cy], 1)
+    m = int(related_frac * min(n_map, n_cur))
+    left = np.concatenate([proj(A[:m], 0.0), proj(B[:m], 0.0)], 1) + rng.normal(0, pixel_noise, (m, 4))
+    s = rng.uniform(-0.2, 0.2, (m, 2))
+    Ar, Br = A[:m] + s[:, :1] * (B[:m] - A[:m]), B[:m] + s[:, 1:] * (B[:m] - A[:m])
+    right = np.concatenate([proj(Ar, b), proj(Br, b)], 1) + rng.normal(0, pixel_noise, (m, 4))
+    far = rng.random(m) < 0.1                                                # wrong geometry: the reprojection gate must reject
+    left[far] += rng.normal(0, 25.0, (int(far.sum()), 4))
+
+    def unrelated(n):
+        p = np.stack([rng.uniform(0, 1241, n), rng.uniform(0, 376, n)], 1)
+        return np.concatenate([p, p + rng.normal(0, 40, (n, 2))], 1)
+    left = np.concatenate([left, unrelated(n_cur - m)]); right = np.concatenate([right, unrelated(n_cur - m)])
+    lo = rng.integers(0, 3, n_cur)
+    to_w = lambda X: (R @ X.T).T + t
+    Aw, Bw = to_w(A), to_w(B)
+    dirw = (Bw - Aw) / np.linalg.norm(Bw - Aw, axis=1, keepdims=True)
+    X0 = Aw - np.sum(Aw * dirw, axis=1, keepdims=True) * dirw                 # minimal position: the point of the line closest to the origin
+    dm = rng.normal(size=(n_map, dim)); dm /= np.linalg.norm(dm, axis=1, keepdims=True)
+    dup = rng.integers(0, m, max(1, n_map // 12)); tgt = rng.integers(0, m, dup.size)
+    dm[dup] = dm[tgt] + rng.normal(0, 0.01, (dup.size, dim))               # rivals for the same frame line
+    dc = rng.normal(size=(n_cur, dim)); dc /= np.linalg.norm(dc, axis=1, keepdims=True)
+    dc[:m] = dm[:m] + rng.normal(0, desc_noise, (m, dim))
+    perm = rng.permutation(n_cur); rperm = rng.permutation(n_cur)          # right lines stored in another order
+    inv_r = np.empty(n_cur, np.int64); inv_r[rperm] = np.arange(n_cur)
+    line_matches = inv_r[perm].astype(np.int32)                             # left line (after perm) -> index of its right partner
+    line_matches[rng.random(n_cur) < no_partner_frac] = -1
+    params = dict(K=K, T_curr=T, b=b, thr_reproj_base=2.0, md_thr=0.9, sx=1.0 / 1241.0, sy=1.0 / 376.0)
+    lines_last = dict(X0=X0, dir=dirw, X1=Aw, X2=Bw, desc=dm.astype(np.float32), skip=(rng.random(n_map) < skip_frac).astype(np.uint8))
+    frame = dict(left_lines=left[perm].astype(np.float32), left_octave=lo[perm].astype(np.int32), right_lines=right[rperm].astype(np.float32),
+                 line_matches=line_matches, occupied=(rng.random(n_cur) < occupied_frac).astype(np.uint8), desc=dc[perm].astype(np.float32))
+    return params, lines_last, frame
+
+
 def make_local_map(F, scene_id=0, n=2000, related_frac=0.8, flip_p=0.06):
     """A frame pose and local MapPoints for Tracking::SearchLocalPoints: most points are back-projections of F's keypoints (depth
     from the stereo disparity or drawn, position perturbed a little), with their observation normals, scale-invariance distances

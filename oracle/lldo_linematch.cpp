@@ -12,6 +12,9 @@
 //   vgl::TriangulateLine                                   src/vgl.cc:78-108
 //   ReprojectKeyLineTo3D / vgl::MapPoint                   src/LineMatching.cc:277-292, src/vgl.cc:587-590
 //   vgl::ReprojectLinePointTo3D                            src/vgl.cc:336-346
+//   Tracking::AddLinesFrom                                src/Tracking.cc:996-1124
+//   SubselectWithGrid / GetHoughCoordinates               src/LineMatching.cc:63-180
+//   GetReprojThrPyramid, GetLineEq, GetReprojErrPixelsL1  src/LineMatching.cc:239-275;  vgl::LineReprojErrorL1  src/vgl.cc:548-559
 // Eigen is absent, so ColPivHouseholderQR (rank(), solve()) is restated: column pivoting on the largest remaining
 // column norm, Householder reflections, rank = #{ |R_kk| > eps * size * max|R_kk| }, minimum-norm-free solve on the
 // leading rank block (Eigen zeroes the remaining unknowns).
@@ -210,6 +213,139 @@ int lldo_line_match_stereo(void*, const lld_line_stereo_params* P, const float* 
     matches[j] = min_j;
     if (match_dist && min_j >= 0) match_dist[j] = min_d;
   }
+  return LLD_OK;
+}
+
+
+// ---------------------------------------------------------------- Tracking::AddLinesFrom
+namespace {
+constexpr int kDistCells = 50, kAngCells = 50;          // FRAME_DIST_CELLS, FRAME_ANG_CELLS (include/Frame.h:45-46)
+#define LLDO_PI 3.14159265                               /* the literal of src/LineMatching.cc:61 */
+
+// GetHoughCoordinates (src/LineMatching.cc:63-152), literal; also returns the centre cell
+void hough_coordinates(V3 leq, double sx, double sy, std::vector<int>* dist_inds, std::vector<int>* ang_inds, int step_dist, int step_ang,
+                       int* dist_c, int* ang_c) {
+  dist_inds->clear(); ang_inds->clear();
+  leq.x /= sx; leq.y /= sy;
+  { const double n = std::sqrt(leq.x * leq.x + leq.y * leq.y); leq.x /= n; leq.y /= n; leq.z /= n; }
+  if (leq.y < 0) { leq.x = -leq.x; leq.y = -leq.y; leq.z = -leq.z; }
+  const int dist_cell_num = kDistCells, ang_cell_num = kAngCells;
+  const double dist_level = std::fabs(leq.z / (std::sqrt(2.0))) * dist_cell_num;
+  int dist_ind = (int)std::floor(dist_level + 0.5);
+  dist_ind = std::min(dist_ind, dist_cell_num - 1); dist_ind = std::max(dist_ind, 0);
+  int shift_dist = -1;
+  if (dist_level - dist_ind < 0) shift_dist = 1;
+  const double ang = std::atan2(leq.y, leq.x);
+  const double ang_level = ang / LLDO_PI * ang_cell_num;
+  int ang_ind = (int)std::floor(ang_level + 0.5);
+  ang_ind = std::min(ang_ind, ang_cell_num - 1); ang_ind = std::max(ang_ind, 0);
+  int shift_ang = -1;
+  if (ang_level - ang_ind < 0) shift_ang = 1;
+  if (dist_c) *dist_c = dist_ind;
+  if (ang_c) *ang_c = ang_ind;
+  const int ang_max = std::max(ang_ind, ang_ind + shift_ang);
+  for (int i = ang_max; i < ang_max + step_ang; i++) { int a = i; if (i < 0) a += ang_cell_num; a = a % ang_cell_num; ang_inds->push_back(a); }
+  const int ang_min = std::min(ang_ind, ang_ind + shift_ang);
+  for (int i = ang_min; i > ang_min - step_ang; i--) { int a = i; if (i < 0) a += ang_cell_num; a = a % ang_cell_num; ang_inds->push_back(a); }
+  const int dist_max = std::max(dist_ind, dist_ind + shift_dist);
+  for (int i = dist_max; i < dist_max + step_dist; i++) if (i >= 0 && i < dist_cell_num - 1) dist_inds->push_back(i);
+  const int dist_min = std::min(dist_ind, dist_ind + shift_dist);
+  for (int i = dist_min; i > dist_min - step_dist; i--) if (i >= 0 && i < dist_cell_num - 1) dist_inds->push_back(i);
+}
+V3 line_eq_px(const float* kl) { return cross(V3{kl[0], kl[1], 1.0}, V3{kl[2], kl[3], 1.0}); }   // GetLineEq
+struct M44 { M3 R; V3 t; };
+M44 pose44(const double* T) { M44 P; for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) P.R.m[r][c] = T[4 * r + c]; P.t = V3{T[3], T[7], T[11]}; return P; }
+V3 m3t_mulv(const M3& a, const V3& v) {                    // R^T v
+  return V3{a.m[0][0] * v.x + a.m[1][0] * v.y + a.m[2][0] * v.z, a.m[0][1] * v.x + a.m[1][1] * v.y + a.m[2][1] * v.z, a.m[0][2] * v.x + a.m[1][2] * v.y + a.m[2][2] * v.z};
+}
+V3 map_point(const M44& T, const V3& X) { return m3t_mulv(T.R, sub(X, T.t)); }                    // vgl::MapPoint: R^T (X - t)
+// vgl::LineReprojErrorL1
+double line_reproj_err_l1(double xs, double ys, double xe, double ye, const M44& T, const V3& X0, const V3& dir, const double* K) {
+  const V3 Xc1 = k_mul(K, map_point(T, X0)), Xc2 = k_mul(K, map_point(T, add(X0, dir)));
+  V3 l = cross(Xc1, Xc2);
+  const double n = std::sqrt(l.x * l.x + l.y * l.y);
+  l.x /= n; l.y /= n; l.z /= n;
+  return std::fabs(xs * l.x + ys * l.y + l.z) + std::fabs(xe * l.x + ye * l.y + l.z);
+}
+}  // namespace
+
+int lld_line_hough_cells_oracle(const float* lines, int n, double sx, double sy, int32_t* cell) {
+  std::vector<int> d, a;
+  for (int i = 0; i < n; i++) { int dc, ac; hough_coordinates(line_eq_px(lines + 4 * i), sx, sy, &d, &a, 0, 0, &dc, &ac); cell[i] = dc * kAngCells + ac; }
+  return LLD_OK;
+}
+int lldo_line_hough_cells(const float* lines, int n, double sx, double sy, int32_t* cell) { return lld_line_hough_cells_oracle(lines, n, sx, sy, cell); }
+// the two index lists of GetHoughCoordinates for a homogeneous image line (known-answer tests)
+int lldo_hough_coordinates(const double* leq, double sx, double sy, int step_dist, int step_ang, int32_t* dist_inds, int32_t* n_dist, int32_t* ang_inds, int32_t* n_ang) {
+  std::vector<int> d, a;
+  hough_coordinates(V3{leq[0], leq[1], leq[2]}, sx, sy, &d, &a, step_dist, step_ang, nullptr, nullptr);
+  *n_dist = (int)d.size(); *n_ang = (int)a.size();
+  for (size_t i = 0; i < d.size(); i++) dist_inds[i] = d[i];
+  for (size_t i = 0; i < a.size(); i++) ang_inds[i] = a[i];
+  return LLD_OK;
+}
+
+int lldo_line_track_match(void*, const lld_line_track_params* P, int n_map, const double* map_x0, const double* map_dir, const double* map_x1,
+                          const double* map_x2, const uint8_t* map_skip, const float* map_desc, int n_cur, const float* left_lines,
+                          const int32_t* left_octave, int n_right, const float* right_lines, const int32_t* line_matches, const uint8_t* occupied0,
+                          const float* cur_desc, int dim, int32_t* matches, double* match_dist, uint8_t* gate_out) {
+  const M44 T_curr = pose44(P->T_curr);
+  M44 T_right = T_curr;                                   // GetTForRight
+  T_right.t = add(T_curr.t, m3_mulv(T_curr.R, V3{P->b, 0.0, 0.0}));
+  // the line grid of the frame (the fill the reference lacks: every line in its centre cell)
+  std::vector<std::vector<std::vector<int>>> lines_grid(kDistCells, std::vector<std::vector<int>>(kAngCells));
+  {
+    std::vector<int32_t> cell(n_cur);
+    lld_line_hough_cells_oracle(left_lines, n_cur, P->sx, P->sy, cell.data());
+    for (int si = 0; si < n_cur; si++) lines_grid[cell[si] / kAngCells][cell[si] % kAngCells].push_back(si);
+  }
+  std::vector<char> occupied(n_cur, 0);
+  if (occupied0) for (int si = 0; si < n_cur; si++) occupied[si] = occupied0[si] != 0;
+  if (gate_out) std::fill(gate_out, gate_out + (size_t)n_map * n_cur, (uint8_t)0);
+  for (int i = 0; i < n_map; i++) {
+    matches[i] = -1; if (match_dist) match_dist[i] = DBL_MAX;
+    if (map_skip && map_skip[i]) continue;
+    const V3 X0m{map_x0[3 * i], map_x0[3 * i + 1], map_x0[3 * i + 2]}, dirm{map_dir[3 * i], map_dir[3 * i + 1], map_dir[3 * i + 2]};
+    std::vector<int> sub_inds;
+    if (P->use_grid) {
+      // SubselectWithGrid
+      const V3 Xl1 = k_mul(P->K, m3t_mulv(T_curr.R, sub(X0m, T_curr.t))), Xl2 = k_mul(P->K, m3t_mulv(T_curr.R, sub(add(X0m, dirm), T_curr.t)));
+      V3 leq = cross(Xl1, Xl2);
+      { const double n = std::sqrt(leq.x * leq.x + leq.y * leq.y); leq.x /= n; leq.y /= n; leq.z /= n; }
+      std::vector<int> dis, ais;
+      hough_coordinates(leq, P->sx, P->sy, &dis, &ais, 3, 3, nullptr, nullptr);
+      std::vector<char> in(n_cur, 0);                    // std::set<int>: unique, ascending
+      for (int ai : ais) for (int di : dis) for (int oi : lines_grid[di][ai]) in[oi] = 1;
+      for (int oi = 0; oi < n_cur; oi++) if (in[oi]) sub_inds.push_back(oi);
+    } else for (int oi = 0; oi < n_cur; oi++) sub_inds.push_back(oi);
+    int match_id = -1; double md = 1e10;
+    const float* ml_desc = map_desc + (size_t)dim * i;
+    for (int si : sub_inds) {
+      if (occupied[si]) continue;
+      const int ri = line_matches[si];
+      if (ri < 0 && !P->monocular) continue;
+      const V3 X1{map_x1[3 * i], map_x1[3 * i + 1], map_x1[3 * i + 2]}, X2{map_x2[3 * i], map_x2[3 * i + 1], map_x2[3 * i + 2]};
+      const V3 X1c = map_point(T_curr, X1), X2c = map_point(T_curr, X2);
+      if (X1c.z < 0 || X2c.z < 0) continue;
+      double thr = P->thr_reproj_base;                  // GetReprojThrPyramid
+      for (int oi = 0; oi < left_octave[si]; oi++) thr *= 1.44;
+      const float* kl1 = left_lines + 4 * si;
+      const double se = line_reproj_err_l1(kl1[0], kl1[1], kl1[2], kl1[3], T_curr, X0m, dirm, P->K);
+      double se2 = 0;
+      if (!P->monocular) { const float* kr = right_lines + 4 * ri; se2 = line_reproj_err_l1(kr[0], kr[1], kr[2], kr[3], T_right, X0m, dirm, P->K); }
+      if (se > thr || se2 > thr) continue;
+      if (gate_out) gate_out[(size_t)i * n_cur + si] = 1;
+      const double cd = lldo_l2f32(ml_desc, cur_desc + (size_t)dim * si, dim);
+      if (cd < md) { md = cd; match_id = si; }
+    }
+    if (md > P->md_thr) continue;
+    if (match_id >= 0) {
+      if (occupied[match_id]) continue;
+      occupied[match_id] = 1;
+      matches[i] = match_id; if (match_dist) match_dist[i] = md;
+    }
+  }
+  (void)n_right;
   return LLD_OK;
 }
 

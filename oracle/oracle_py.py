@@ -221,6 +221,31 @@ def line_match_stereo(K, b, tau, min_line_length, left_lines, left_octave, dl, r
     return host.line_stereo_call(lib(), None, K, b, tau, min_line_length, left_lines, left_octave, dl, right_lines, right_octave, dr, True, want_gate)
 
 
+def line_track_match(K, T_curr, b, thr_reproj_base, md_thr, sx, sy, lines_last, frame, monocular=False, use_grid=True, want_gate=False):
+    """Tracking::AddLinesFrom, literal (oracle/lldo_linematch.cpp)."""
+    return host.line_track_call(lib(), None, K, T_curr, b, thr_reproj_base, md_thr, sx, sy, lines_last["X0"], lines_last["dir"], lines_last["X1"],
+                                lines_last["X2"], lines_last.get("skip"), lines_last["desc"], frame["left_lines"], frame["left_octave"],
+                                frame["right_lines"], frame["line_matches"], frame.get("occupied"), frame["desc"], monocular, use_grid, want_gate)
+
+
+def hough_coordinates(leq, sx, sy, step_dist=3, step_ang=3):
+    """GetHoughCoordinates, literal: (dist_inds, ang_inds) in the order the reference pushes them."""
+    d = lib().dll
+    d.lldo_hough_coordinates.argtypes = [abi.c_double_p, C.c_double, C.c_double, C.c_int, C.c_int, abi.c_int32_p, abi.c_int32_p, abi.c_int32_p, abi.c_int32_p]
+    d.lldo_hough_coordinates.restype = C.c_int
+    l = _d(leq); di = np.zeros(64, np.int32); ai = np.zeros(64, np.int32); nd = np.zeros(1, np.int32); na = np.zeros(1, np.int32)
+    d.lldo_hough_coordinates(_dp(l), sx, sy, step_dist, step_ang, di.ctypes.data_as(abi.c_int32_p), nd.ctypes.data_as(abi.c_int32_p),
+                             ai.ctypes.data_as(abi.c_int32_p), na.ctypes.data_as(abi.c_int32_p))
+    return di[:nd[0]].copy(), ai[:na[0]].copy()
+
+
+def line_hough_cells(lines, sx, sy):
+    d = lib().dll
+    ll = np.ascontiguousarray(lines, np.float32).reshape(-1, 4); cell = np.empty(ll.shape[0], np.int32)
+    d.lldo_line_hough_cells(ll.ctypes.data_as(abi.c_float_p), ll.shape[0], sx, sy, cell.ctypes.data_as(abi.c_int32_p))
+    return cell
+
+
 def line_pair_geometry(K, b, kl1, kl2):
     """vgl::TriangulateLine + ReprojectKeyLineTo3D for one pair: (ok, X0, dir, p1, p2)."""
     d = lib().dll

@@ -1,0 +1,63 @@
+"""GPU parity: Tracking::AddLinesFrom through the C ABI (lld_line_track_match) vs the CPU oracle - matches and gates bit for bit."""
+import numpy as np
+import pytest
+
+from lld_slam_amd import Tracking, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def run_both(gpu_ctx, oracle, P, L, F, **kw):
+    trk = Tracking(gpu_ctx, P["K"], P["b"], 1.0 / P["sx"], 1.0 / P["sy"], mdThr=P["md_thr"], monocular=kw.get("monocular", False))
+    g = trk.AddLinesFrom(L, P["T_curr"], P["thr_reproj_base"], F, use_grid=kw.get("use_grid", True), want_gate=True)
+    o = oracle.line_track_match(P["K"], P["T_curr"], P["b"], P["thr_reproj_base"], P["md_thr"], P["sx"], P["sy"], L, F, want_gate=True, **kw)
+    return g, o
+
+
+@pytest.mark.parametrize("scene,kw", [(0, {}), (1, dict(monocular=True)), (2, dict(use_grid=False)), (3, dict(use_grid=False, monocular=True)),
+                                      (5, {}), (6, dict(use_grid=False))])
+def test_add_lines_from_matches_oracle(gpu_ctx, oracle, scene, kw):
+    P, L, F = synth.make_line_track_scene(scene)
+    (gm, gd, gg), (om, od, og) = run_both(gpu_ctx, oracle, P, L, F, **kw)
+    np.testing.assert_array_equal(gm, om)
+    np.testing.assert_array_equal(gd[gm >= 0], od[om >= 0])                 # float difference, double accumulation in index order: identical
+    # the oracle records a gate only for pairs its sequential loop reaches (a frame line taken earlier is skipped before the gates);
+    # the device gate matrix is the order-independent part: it must contain every recorded pair and nothing on rows / columns that are excluded
+    assert np.all(gg[og.astype(bool)] == 1)
+    assert not np.any(gg[L["skip"].astype(bool)])
+    assert not np.any(gg[:, F["occupied"].astype(bool)])
+    assert (gm >= 0).sum() > 10
+
+
+def test_hough_cells_equal_the_oracle_fill(gpu_ctx, oracle):
+    P, L, F = synth.make_line_track_scene(7, n_cur=500)
+    trk = Tracking(gpu_ctx, P["K"], P["b"], 1.0 / P["sx"], 1.0 / P["sy"])
+    np.testing.assert_array_equal(trk.HoughCells(F["left_lines"]), oracle.line_hough_cells(F["left_lines"], P["sx"], P["sy"]))
+
+
+def test_rivals_chain_and_edge_cases(gpu_ctx, oracle):
+    """Many map lines with one descriptor: the frame line goes to the first, the others fall back to their next candidate (the
+    cut candidate lists must be refilled from the stored row); empty inputs; every frame line occupied."""
+    P, L, F = synth.make_line_track_scene(8, n_map=300, n_cur=120)
+    L["desc"][:] = L["desc"][0]; F["desc"][:] = L["desc"][0]               # all distances zero: pure order dependence
+    (gm, _, _), (om, _, _) = run_both(gpu_ctx, oracle, P, L, F, use_grid=False)
+    np.testing.assert_array_equal(gm, om)
+    F2 = dict(F); F2["occupied"] = np.ones_like(F["occupied"])
+    (gm, _, _), (om, _, _) = run_both(gpu_ctx, oracle, P, L, F2)
+    assert np.all(gm == -1) and np.all(om == -1)
+    empty = dict(left_lines=np.zeros((0, 4), np.float32), left_octave=np.zeros(0, np.int32), right_lines=np.zeros((0, 4), np.float32),
+                 line_matches=np.zeros(0, np.int32), occupied=np.zeros(0, np.uint8), desc=np.zeros((0, 72), np.float32))
+    trk = Tracking(gpu_ctx, P["K"], P["b"], 1.0 / P["sx"], 1.0 / P["sy"], mdThr=P["md_thr"])
+    m, d = trk.AddLinesFrom(L, P["T_curr"], 2.0, empty)
+    assert np.all(m == -1)
+
+
+def test_malformed_arguments_are_refused(gpu_ctx):
+    P, L, F = synth.make_line_track_scene(9, n_map=20, n_cur=30)
+    trk = Tracking(gpu_ctx, P["K"], P["b"], 1.0 / P["sx"], 1.0 / P["sy"], mdThr=P["md_thr"])
+    bad = dict(F); bad["line_matches"] = F["line_matches"].copy(); bad["line_matches"][0] = 10 ** 6          # partner index out of range
+    with pytest.raises(RuntimeError):
+        trk.AddLinesFrom(L, P["T_curr"], 2.0, bad)
+    bad = dict(F); bad["left_octave"] = F["left_octave"].copy(); bad["left_octave"][0] = -1
+    with pytest.raises(RuntimeError):
+        trk.AddLinesFrom(L, P["T_curr"], 2.0, bad)
