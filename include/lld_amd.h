@@ -434,6 +434,39 @@ int lld_line_track_match(lld_ctx* ctx, const lld_line_track_params* params,
                          const uint8_t* occupied /*[n_cur] or NULL*/, const float* cur_desc, int dim,
                          int32_t* matches /*[n_map]*/, double* match_dist /*[n_map] or NULL*/,
                          uint8_t* gate_out /*[n_map][n_cur] or NULL*/);
+/* Tracking::MatchLinesLastKF (src/Tracking.cc:1449-1611): new map lines from the lines the current and the last
+ * stereo frame share.  For every line i of the current frame that holds no map line and has a stereo partner
+ * (:1477-1487): vgl::TriangulateLine of its left / right KeyLine (src/vgl.cc:78-108) in the current pose; the Hough
+ * cell neighbourhood of that 3D line projected into the LAST frame (SubselectWithGrid, :1504) gives the candidates
+ * li; li is dropped without stereo partner (:1511-1515), if last_skip[li] (its map line was tracked in this frame,
+ * :1517-1520) or if the L1 reprojection error exceeds 6 px * 1.44^octave in BOTH images of the last frame (:1526 -
+ * `&&`, where AddLinesFrom has `||`); strict running minimum of MatchLineDescriptors, accepted if <= md_thr
+ * (:1558); then vgl::MultiTriangulateLine over the four views (src/vgl.cc:28-76: unit plane normals, |cos| <= 0.975
+ * against the first one, direction = right singular vector of the smallest singular value of the normal matrix,
+ * X0 = least-squares point of the four planes minus its component along the direction), ReprojectKeyLineTo3D of
+ * the current left KeyLine (src/LineMatching.cc:277-292) and the depth test of both end points in all four views
+ * (:1580-1592).  No step depends on another line: rows run in parallel.
+ * match_last[i]: the accepted line of the last frame or -1; created[i]: 1 if the reference would construct the
+ * MapLine (x0 / dir [n_cur][3] valid).  The sign of dir is the build's (largest component positive): Eigen's JacobiSVD
+ * is not restated and a 3D line has no orientation.  T_curr, T_last: camera-to-world, row-major 4x4. */
+typedef struct {
+  double K[9];
+  double T_curr[16], T_last[16];
+  double b;
+  double thr_reproj_base;   /* 6 px (Tracking.cc:1451) */
+  double md_thr;
+  double sx, sy;
+  int32_t use_grid;
+  int32_t pad;
+} lld_line_lastkf_params;
+int lld_line_match_last_frame(lld_ctx* ctx, const lld_line_lastkf_params* params,
+                              int n_cur, const float* cur_left, int n_cur_right, const float* cur_right,
+                              const int32_t* cur_line_matches, const uint8_t* cur_occupied /*or NULL*/, const float* cur_desc,
+                              int n_last, const float* last_left, const int32_t* last_left_octave, int n_last_right,
+                              const float* last_right, const int32_t* last_line_matches, const uint8_t* last_skip /*or NULL*/,
+                              const float* last_desc, int dim,
+                              int32_t* match_last /*[n_cur]*/, uint8_t* created /*[n_cur]*/, double* x0 /*[n_cur][3]*/,
+                              double* dir /*[n_cur][3]*/);
 /* The grid cell of that fill: cell[si] = dist_ind * 50 + ang_ind (host helper, no device work). */
 int lld_line_hough_cells(const float* lines, int n, double sx, double sy, int32_t* cell);
 

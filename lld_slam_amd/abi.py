@@ -64,6 +64,11 @@ class LineTrackParams(C.Structure):
                 ("sx", C.c_double), ("sy", C.c_double), ("monocular", C.c_int32), ("use_grid", C.c_int32)]
 
 
+class LineLastKfParams(C.Structure):
+    _fields_ = [("K", C.c_double * 9), ("T_curr", C.c_double * 16), ("T_last", C.c_double * 16), ("b", C.c_double), ("thr_reproj_base", C.c_double),
+                ("md_thr", C.c_double), ("sx", C.c_double), ("sy", C.c_double), ("use_grid", C.c_int32), ("pad", C.c_int32)]
+
+
 class BAParams(C.Structure):
     _fields_ = [
         ("gamma", C.c_double),
@@ -177,7 +182,7 @@ PRODUCT_SYMBOLS = [
     "lld_pose_batch_create", "lld_pose_batch_solve", "lld_pose_batch_download", "lld_pose_batch_destroy",
     "lld_match_hamming256", "lld_match_hamming256_csr", "lld_match_hamming256_batch_dev",
     "lld_match_l2f32", "lld_match_l2f32_batch_dev", "lld_line_match_greedy", "lld_line_match_stereo",
-    "lld_line_track_match", "lld_line_hough_cells",
+    "lld_line_track_match", "lld_line_hough_cells", "lld_line_match_last_frame",
     "lld_orb_search_run", "lld_orb_search_batch", "lld_orb_search_local_points", "lld_orb_search_last_frame", "lld_orb_fuse_search",
     "lld_compute_stereo_matches",
     "lld_sim3_params_default", "lld_optimize_sim3", "lld_optimize_sim3_batch",
@@ -252,6 +257,10 @@ class Lib:
         f("line_track_match").restype = C.c_int
         f("line_hough_cells").argtypes = [c_float_p, C.c_int, C.c_double, C.c_double, c_int32_p]
         f("line_hough_cells").restype = C.c_int
+        f("line_match_last_frame").argtypes = [vp, C.POINTER(LineLastKfParams), C.c_int, c_float_p, C.c_int, c_float_p, c_int32_p, c_uint8_p, c_float_p,
+                                               C.c_int, c_float_p, c_int32_p, C.c_int, c_float_p, c_int32_p, c_uint8_p, c_float_p, C.c_int,
+                                               c_int32_p, c_uint8_p, c_double_p, c_double_p]
+        f("line_match_last_frame").restype = C.c_int
         if self.prefix == "lld_":
             f("status_string").argtypes = [C.c_int]; f("status_string").restype = C.c_char_p
             f("ctx_create").argtypes = [C.c_int, C.POINTER(vp)]; f("ctx_create").restype = C.c_int

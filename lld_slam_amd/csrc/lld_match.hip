@@ -462,6 +462,171 @@ __global__ __launch_bounds__(64) void line_track_gate_kernel(LineTrackParams P, 
   }
 }
 
+// ------------------------------------------------------------------ Tracking::MatchLinesLastKF (src/Tracking.cc:1449-1611)
+struct LastKfParams { double K[9]; double R[9], t[3], tr[3]; double Rl[9], tl[3], tlr[3]; double thr_base, md_thr, sx, sy; int use_grid; };
+__device__ __forceinline__ void d3_cross(const double* a, const double* b, double* o) { o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0]; }
+__device__ __forceinline__ double d3_dot(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+__device__ __forceinline__ void d3_rmul(const double* R, const double* v, double* o) { for (int r = 0; r < 3; r++) o[r] = R[3 * r] * v[0] + R[3 * r + 1] * v[1] + R[3 * r + 2] * v[2]; }
+__device__ __forceinline__ void d3_rtmul(const double* R, const double* v, double* o) { for (int c = 0; c < 3; c++) o[c] = R[c] * v[0] + R[3 + c] * v[1] + R[6 + c] * v[2]; }
+// vgl::TriangulateLine (src/vgl.cc:78-108) for two cameras with one rotation R (camera-to-world) and centres t1, t2.  The 3x3 system with
+// rows n1, n2, d = n1 x n2 / |n1 x n2| has determinant |n1 x n2| > 0 once the parallelism test passed, so Eigen's rank() < 3 cannot fire
+// and the solution is Cramer's rule with b = (n1.t1, n2.t2, 0).
+__device__ __forceinline__ bool tri_line(const double* R, const double* t1, const double* t2, const double* l1, const double* l2, double* X0, double* dir) {
+  double n1[3], n2[3];
+  d3_rmul(R, l1, n1); d3_rmul(R, l2, n2);
+  if (fabs(d3_dot(n1, n2)) / sqrt(d3_dot(n1, n1)) / sqrt(d3_dot(n2, n2)) > 0.975) return false;
+  d3_cross(n1, n2, dir);
+  const double dn = sqrt(d3_dot(dir, dir));
+  dir[0] /= dn; dir[1] /= dn; dir[2] /= dn;
+  double c23[3], c31[3];
+  d3_cross(n2, dir, c23); d3_cross(dir, n1, c31);
+  const double det = d3_dot(n1, c23), b1 = d3_dot(n1, t1), b2 = d3_dot(n2, t2);
+  for (int k = 0; k < 3; k++) X0[k] = (b1 * c23[k] + b2 * c31[k]) / det;
+  return true;
+}
+// symmetric 3x3 eigen-decomposition (cyclic Jacobi): A -> eigenvalues w[3], eigenvectors as the columns of V
+__device__ __forceinline__ void sym3_eig(double A[3][3], double V[3][3], double* w) {
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) V[i][j] = i == j ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 12; sweep++) {
+    for (int p = 0; p < 2; p++) for (int q = p + 1; q < 3; q++) {
+      if (A[p][q] == 0.0) continue;
+      const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+      const double tt = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+      const double c = 1.0 / sqrt(tt * tt + 1.0), sn = tt * c;
+      for (int k = 0; k < 3; k++) { const double akp = A[k][p], akq = A[k][q]; A[k][p] = c * akp - sn * akq; A[k][q] = sn * akp + c * akq; }
+      for (int k = 0; k < 3; k++) { const double apk = A[p][k], aqk = A[q][k]; A[p][k] = c * apk - sn * aqk; A[q][k] = sn * apk + c * aqk; }
+      for (int k = 0; k < 3; k++) { const double vkp = V[k][p], vkq = V[k][q]; V[k][p] = c * vkp - sn * vkq; V[k][q] = sn * vkp + c * vkq; }
+    }
+  }
+  for (int i = 0; i < 3; i++) w[i] = A[i][i];
+}
+// vgl::MultiTriangulateLine (src/vgl.cc:28-76) for four views.  The direction is the eigenvector of the smallest eigenvalue of M^T M (the
+// right singular vector of the smallest singular value of the normal matrix M), its largest component positive.  The reference solves
+// M X0 = b by a pivoted QR and then removes X0's component along that direction: with M^T M = sum lambda_k v_k v_k^T this is
+// X0 = sum over the two LARGER eigenpairs of v_k (v_k . M^T b) / lambda_k - the ill-conditioned third term never formed.
+__device__ __forceinline__ bool multi_tri_line(const double* const* Rs, const double* const* ts, const double (*leqs)[3], double* X0, double* dir) {
+  double nrm[4][3];
+  for (int i = 0; i < 4; i++) {
+    const double ln = sqrt(d3_dot(leqs[i], leqs[i]));
+    const double u[3] = {leqs[i][0] / ln, leqs[i][1] / ln, leqs[i][2] / ln};
+    d3_rmul(Rs[i], u, nrm[i]);
+  }
+  for (int i = 1; i < 4; i++) if (fabs(d3_dot(nrm[0], nrm[i])) / sqrt(d3_dot(nrm[0], nrm[0])) / sqrt(d3_dot(nrm[i], nrm[i])) > 0.975) return false;
+  double A[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, Mtb[3] = {0, 0, 0};
+  for (int i = 0; i < 4; i++) {
+    const double bi = d3_dot(nrm[i], ts[i]);
+    for (int r = 0; r < 3; r++) { Mtb[r] += nrm[i][r] * bi; for (int c = 0; c < 3; c++) A[r][c] += nrm[i][r] * nrm[i][c]; }
+  }
+  double V[3][3], w[3];
+  sym3_eig(A, V, w);
+  int m = 0; for (int i = 1; i < 3; i++) if (w[i] < w[m]) m = i;
+  double d[3] = {V[0][m], V[1][m], V[2][m]};
+  const double dn = sqrt(d3_dot(d, d));
+  int big = 0; if (fabs(d[1]) > fabs(d[big])) big = 1; if (fabs(d[2]) > fabs(d[big])) big = 2;
+  const double sg = d[big] < 0 ? -1.0 / dn : 1.0 / dn;
+  for (int k = 0; k < 3; k++) { dir[k] = d[k] * sg; X0[k] = 0.0; }
+  for (int e = 0; e < 3; e++) {
+    if (e == m) continue;
+    const double v[3] = {V[0][e], V[1][e], V[2][e]};
+    const double cf = d3_dot(v, Mtb) / w[e];
+    for (int k = 0; k < 3; k++) X0[k] += cf * v[k];
+  }
+  return true;
+}
+// the line parameter of vgl::ReprojectLinePointTo3D (src/vgl.cc:336-346) through the normal equations of its 3x2 least squares
+__device__ __forceinline__ double reproject_param(const double* K, const double* X0rot, const double* dirRot, double px, double py) {
+  double c[3], r[3];
+  for (int q = 0; q < 3; q++) { c[q] = -(K[3 * q] * dirRot[0] + K[3 * q + 1] * dirRot[1] + K[3 * q + 2] * dirRot[2]); r[q] = K[3 * q] * X0rot[0] + K[3 * q + 1] * X0rot[1] + K[3 * q + 2] * X0rot[2]; }
+  const double aa = px * px + py * py + 1.0, ac = px * c[0] + py * c[1] + c[2], ar = px * r[0] + py * r[1] + r[2];
+  const double cc = d3_dot(c, c), cr = d3_dot(c, r);
+  return (aa * cr - ac * ar) / (aa * cc - ac * ac);
+}
+__device__ __forceinline__ void image_line_of(const double* K, const double* R, const double* t, const double* X0, const double* dir, double* l) {
+  double a[3], b[3], Xa[3], Xb[3];
+  const double d0[3] = {X0[0] - t[0], X0[1] - t[1], X0[2] - t[2]}, d1[3] = {X0[0] + dir[0] - t[0], X0[1] + dir[1] - t[1], X0[2] + dir[2] - t[2]};
+  d3_rtmul(R, d0, a); d3_rtmul(R, d1, b);
+  for (int r = 0; r < 3; r++) { Xa[r] = K[3 * r] * a[0] + K[3 * r + 1] * a[1] + K[3 * r + 2] * a[2]; Xb[r] = K[3 * r] * b[0] + K[3 * r + 1] * b[1] + K[3 * r + 2] * b[2]; }
+  d3_cross(Xa, Xb, l);
+  const double n = sqrt(l[0] * l[0] + l[1] * l[1]);
+  l[0] /= n; l[1] /= n; l[2] /= n;
+}
+
+// grid n_cur, block 64; dynamic LDS: dim floats (the current line's descriptor)
+__global__ __launch_bounds__(64) void line_lastkf_kernel(LastKfParams P, int n_cur, const float* __restrict__ cur_left, const float* __restrict__ cur_right,
+                                                        const int* __restrict__ cur_lm, const uint8_t* __restrict__ cur_occ, const float* __restrict__ cur_desc,
+                                                        int n_last, const float* __restrict__ last_left, const int* __restrict__ last_oct,
+                                                        const float* __restrict__ last_right, const int* __restrict__ last_lm,
+                                                        const uint8_t* __restrict__ last_skip, const float* __restrict__ last_desc, const int* __restrict__ last_cell,
+                                                        int dim, int* __restrict__ match_last, uint8_t* __restrict__ created, double* __restrict__ x0_out,
+                                                        double* __restrict__ dir_out) {
+  extern __shared__ __attribute__((aligned(16))) float qrow[];
+  const int i = blockIdx.x, lane = threadIdx.x;
+  if (lane == 0) { match_last[i] = -1; created[i] = 0; for (int k = 0; k < 3; k++) { x0_out[3 * i + k] = 0.0; dir_out[3 * i + k] = 0.0; } }
+  if (cur_occ && cur_occ[i]) return;
+  const int ri = cur_lm[i];
+  if (ri < 0) return;
+  for (int k = lane; k < dim; k += 64) qrow[k] = cur_desc[(size_t)i * dim + k];
+  __syncthreads();
+  double l1[3], l2[3], X0[3], ld[3];
+  normalized_line_eq(cur_left + 4 * i, P.K, l1); normalized_line_eq(cur_right + 4 * ri, P.K, l2);
+  if (!tri_line(P.R, P.t, P.tr, l1, l2, X0, ld)) return;
+  double ll[3], lr[3];
+  image_line_of(P.K, P.Rl, P.tl, X0, ld, ll);
+  image_line_of(P.K, P.Rl, P.tlr, X0, ld, lr);
+  const HoughCell hc = hough_cell(ll[0], ll[1], ll[2], P.sx, P.sy);
+  const int ang_min = hc.ang_ind < hc.ang_ind + hc.shift_ang ? hc.ang_ind : hc.ang_ind + hc.shift_ang;
+  const int dist_min = hc.dist_ind < hc.dist_ind + hc.shift_dist ? hc.dist_ind : hc.dist_ind + hc.shift_dist;
+  double bd = kInfD; int bi = 0x7fffffff;
+  for (int li = lane; li < n_last; li += 64) {
+    const int pri = last_lm[li];
+    if (pri < 0) continue;
+    if (last_skip && last_skip[li]) continue;
+    if (P.use_grid) {
+      const int cd = last_cell[li] / kHoughAng, ca = last_cell[li] - cd * kHoughAng;
+      int da = ca - (ang_min - 2); da %= kHoughAng; if (da < 0) da += kHoughAng;
+      if (!(da < 6 && cd >= dist_min - 2 && cd <= dist_min + 3 && cd >= 0 && cd < kHoughDist - 1)) continue;
+    }
+    double thr = P.thr_base;
+    for (int o = 0; o < last_oct[li]; o++) thr *= 1.44;
+    const float* kl = last_left + 4 * li; const float* kr = last_right + 4 * pri;
+    const double se = fabs((double)kl[0] * ll[0] + (double)kl[1] * ll[1] + ll[2]) + fabs((double)kl[2] * ll[0] + (double)kl[3] * ll[1] + ll[2]);
+    const double se2 = fabs((double)kr[0] * lr[0] + (double)kr[1] * lr[1] + lr[2]) + fabs((double)kr[2] * lr[0] + (double)kr[3] * lr[1] + lr[2]);
+    if (se > thr && se2 > thr) continue;                                    // Tracking.cc:1526
+    const float* tr = last_desc + (size_t)li * dim;
+    double acc = 0.0;
+    for (int k = 0; k < dim; k++) { const float df = tr[k] - qrow[k]; acc = fma((double)df, (double)df, acc); }
+    const double dist = sqrt(acc);
+    if (dist < bd) { bd = dist; bi = li; }                                  // ascending li per lane: the lowest index wins ties
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    const double od = __shfl_xor(bd, off); const int oidx = __shfl_xor(bi, off);
+    if (od < bd || (od == bd && oidx < bi)) { bd = od; bi = oidx; }
+  }
+  if (lane != 0 || bi == 0x7fffffff || bd > P.md_thr) return;
+  match_last[i] = bi;
+  const int pri = last_lm[bi];
+  double leqs[4][3];
+  for (int k = 0; k < 3; k++) { leqs[0][k] = l1[k]; leqs[1][k] = l2[k]; }
+  normalized_line_eq(last_left + 4 * bi, P.K, leqs[2]); normalized_line_eq(last_right + 4 * pri, P.K, leqs[3]);
+  const double* Rs[4] = {P.R, P.R, P.Rl, P.Rl}; const double* ts[4] = {P.t, P.tr, P.tl, P.tlr};
+  if (!multi_tri_line(Rs, ts, leqs, X0, ld)) return;
+  // ReprojectKeyLineTo3D of the current left KeyLine in the current pose
+  double X0rot[3], dirRot[3];
+  { const double dd[3] = {X0[0] - P.t[0], X0[1] - P.t[1], X0[2] - P.t[2]}; d3_rtmul(P.R, dd, X0rot); d3_rtmul(P.R, ld, dirRot); }
+  const float* kc = cur_left + 4 * i;
+  const double p_s = reproject_param(P.K, X0rot, dirRot, kc[0], kc[1]), p_e = reproject_param(P.K, X0rot, dirRot, kc[2], kc[3]);
+  const double p1[3] = {X0[0] + p_s * ld[0], X0[1] + p_s * ld[1], X0[2] + p_s * ld[2]}, p2[3] = {X0[0] + p_e * ld[0], X0[1] + p_e * ld[1], X0[2] + p_e * ld[2]};
+  bool behind = false;
+  for (int v = 0; v < 4; v++) {
+    const double a1[3] = {p1[0] - ts[v][0], p1[1] - ts[v][1], p1[2] - ts[v][2]}, a2[3] = {p2[0] - ts[v][0], p2[1] - ts[v][1], p2[2] - ts[v][2]};
+    const double z1 = Rs[v][2] * a1[0] + Rs[v][5] * a1[1] + Rs[v][8] * a1[2], z2 = Rs[v][2] * a2[0] + Rs[v][5] * a2[1] + Rs[v][8] * a2[2];
+    if (z1 < 0 || z2 < 0) behind = true;
+  }
+  if (behind) return;
+  created[i] = 1;
+  for (int k = 0; k < 3; k++) { x0_out[3 * i + k] = X0[k]; dir_out[3 * i + k] = ld[k]; }
+}
+
 int launch_hamming(lld_ctx* ctx, int batch, const uint32_t* q, int nq, const uint32_t* t, int nt, const uint8_t* mask,
                    int* bi, int* bd, int* si, int* sd) {
   if (nt >= (1 << kIdxBits)) return LLD_ERR_UNSUPPORTED;
@@ -768,6 +933,69 @@ int lld_line_track_match(lld_ctx* ctx, const lld_line_track_params* prm, int n_m
   std::memcpy(matches, h_out + r_m, (size_t)n_map * 4);
   if (match_dist) std::memcpy(match_dist, h_out + r_d, (size_t)n_map * 8);
   if (gate_out) std::memcpy(gate_out, h_out + r_g, pairs);
+  return LLD_OK;
+}
+
+int lld_line_match_last_frame(lld_ctx* ctx, const lld_line_lastkf_params* prm, int n_cur, const float* cur_left, int n_cur_right, const float* cur_right,
+                              const int32_t* cur_line_matches, const uint8_t* cur_occupied, const float* cur_desc, int n_last, const float* last_left,
+                              const int32_t* last_left_octave, int n_last_right, const float* last_right, const int32_t* last_line_matches,
+                              const uint8_t* last_skip, const float* last_desc, int dim, int32_t* match_last, uint8_t* created, double* x0, double* dir) {
+  if (!ctx || !prm || n_cur < 0 || n_last < 0 || n_cur_right < 0 || n_last_right < 0 || dim <= 0 || !match_last || !created || !x0 || !dir) return LLD_ERR_INVALID;
+  if (n_cur > 0 && (!cur_left || !cur_line_matches || !cur_desc)) return LLD_ERR_INVALID;
+  if (n_last > 0 && (!last_left || !last_left_octave || !last_line_matches || !last_desc)) return LLD_ERR_INVALID;
+  if ((n_cur_right > 0 && !cur_right) || (n_last_right > 0 && !last_right)) return LLD_ERR_INVALID;
+  if (!(prm->sx > 0) || !(prm->sy > 0)) return LLD_ERR_INVALID;
+  for (int i = 0; i < n_cur; i++) if (cur_line_matches[i] >= n_cur_right) return LLD_ERR_INVALID;
+  for (int i = 0; i < n_last; i++) if (last_line_matches[i] >= n_last_right || last_left_octave[i] < 0 || last_left_octave[i] > 64) return LLD_ERR_INVALID;
+  if (dim > 4096) return LLD_ERR_UNSUPPORTED;
+  if (n_cur == 0) return LLD_OK;
+  LLD_HIP_TRY(hipSetDevice(ctx->device));
+  auto pad = [](size_t b) { return (b + 255) & ~size_t(255); };
+  size_t in = 0;
+  const size_t o_cl = in; in += pad((size_t)n_cur * 16); const size_t o_cr = in; in += pad((size_t)std::max(n_cur_right, 1) * 16);
+  const size_t o_clm = in; in += pad((size_t)n_cur * 4); const size_t o_co = in; in += pad((size_t)n_cur);
+  const size_t o_cd = in; in += pad((size_t)n_cur * dim * 4);
+  const size_t o_ll = in; in += pad((size_t)std::max(n_last, 1) * 16); const size_t o_lo = in; in += pad((size_t)std::max(n_last, 1) * 4);
+  const size_t o_lr = in; in += pad((size_t)std::max(n_last_right, 1) * 16); const size_t o_llm = in; in += pad((size_t)std::max(n_last, 1) * 4);
+  const size_t o_ls = in; in += pad((size_t)std::max(n_last, 1)); const size_t o_ld = in; in += pad((size_t)std::max(n_last, 1) * dim * 4);
+  size_t out = 0;
+  const size_t r_m = out; out += pad((size_t)n_cur * 4); const size_t r_c = out; out += pad((size_t)n_cur);
+  const size_t r_x = out; out += pad((size_t)n_cur * 24); const size_t r_d = out; out += pad((size_t)n_cur * 24);
+  const size_t s_cell = pad((size_t)std::max(n_last, 1) * 4);
+  void* hb; int st = lld_ctx_pinned(ctx, in + out, &hb); if (st) return st;
+  void* db; st = lld_ctx_scratch(ctx, in + out + s_cell + 256, &db); if (st) return st;
+  char* h = (char*)hb; char* d = (char*)db; char* h_out = h + in; char* d_out = d + in; char* d_dev = d_out + out;
+  std::memcpy(h + o_cl, cur_left, (size_t)n_cur * 16); if (n_cur_right) std::memcpy(h + o_cr, cur_right, (size_t)n_cur_right * 16);
+  std::memcpy(h + o_clm, cur_line_matches, (size_t)n_cur * 4);
+  if (cur_occupied) std::memcpy(h + o_co, cur_occupied, (size_t)n_cur); else std::memset(h + o_co, 0, (size_t)n_cur);
+  std::memcpy(h + o_cd, cur_desc, (size_t)n_cur * dim * 4);
+  if (n_last) {
+    std::memcpy(h + o_ll, last_left, (size_t)n_last * 16); std::memcpy(h + o_lo, last_left_octave, (size_t)n_last * 4);
+    if (n_last_right) std::memcpy(h + o_lr, last_right, (size_t)n_last_right * 16);
+    std::memcpy(h + o_llm, last_line_matches, (size_t)n_last * 4);
+    if (last_skip) std::memcpy(h + o_ls, last_skip, (size_t)n_last); else std::memset(h + o_ls, 0, (size_t)n_last);
+    std::memcpy(h + o_ld, last_desc, (size_t)n_last * dim * 4);
+  }
+  hipStream_t sm = ctx->stream;
+  LLD_HIP_TRY(hipMemcpyAsync(d, h, in, hipMemcpyHostToDevice, sm));
+  LastKfParams P; std::memset(&P, 0, sizeof P);
+  for (int i = 0; i < 9; i++) P.K[i] = prm->K[i];
+  for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) { P.R[3 * r + c] = prm->T_curr[4 * r + c]; P.Rl[3 * r + c] = prm->T_last[4 * r + c]; } P.t[r] = prm->T_curr[4 * r + 3]; P.tl[r] = prm->T_last[4 * r + 3]; }
+  for (int r = 0; r < 3; r++) { P.tr[r] = P.t[r] + P.R[3 * r] * prm->b; P.tlr[r] = P.tl[r] + P.Rl[3 * r] * prm->b; }      // GetTForRight
+  P.thr_base = prm->thr_reproj_base; P.md_thr = prm->md_thr; P.sx = prm->sx; P.sy = prm->sy; P.use_grid = prm->use_grid;
+  int* dcell = reinterpret_cast<int*>(d_dev);
+  if (n_last > 0) hipLaunchKernelGGL(line_cells_kernel, dim3((n_last + 255) / 256), dim3(256), 0, sm, reinterpret_cast<const float*>(d + o_ll), n_last, P.sx, P.sy, dcell);
+  hipLaunchKernelGGL(line_lastkf_kernel, dim3(n_cur), dim3(64), (size_t)dim * 4 + 16, sm, P, n_cur, reinterpret_cast<const float*>(d + o_cl),
+                     reinterpret_cast<const float*>(d + o_cr), reinterpret_cast<const int*>(d + o_clm), reinterpret_cast<const uint8_t*>(d + o_co),
+                     reinterpret_cast<const float*>(d + o_cd), n_last, reinterpret_cast<const float*>(d + o_ll), reinterpret_cast<const int*>(d + o_lo),
+                     reinterpret_cast<const float*>(d + o_lr), reinterpret_cast<const int*>(d + o_llm), reinterpret_cast<const uint8_t*>(d + o_ls),
+                     reinterpret_cast<const float*>(d + o_ld), dcell, dim, reinterpret_cast<int*>(d_out + r_m), reinterpret_cast<uint8_t*>(d_out + r_c),
+                     reinterpret_cast<double*>(d_out + r_x), reinterpret_cast<double*>(d_out + r_d));
+  LLD_HIP_TRY(hipGetLastError());
+  LLD_HIP_TRY(hipMemcpyAsync(h_out, d_out, out, hipMemcpyDeviceToHost, sm));
+  LLD_HIP_TRY(hipStreamSynchronize(sm));
+  std::memcpy(match_last, h_out + r_m, (size_t)n_cur * 4); std::memcpy(created, h_out + r_c, (size_t)n_cur);
+  std::memcpy(x0, h_out + r_x, (size_t)n_cur * 24); std::memcpy(dir, h_out + r_d, (size_t)n_cur * 24);
   return LLD_OK;
 }
 

@@ -443,6 +443,32 @@ def line_track_call(lib: abi.Lib, ctx, K, T_curr, b, thr_reproj_base, md_thr, sx
     return (m, d, gate) if want_gate else (m, d)
 
 
+def line_lastkf_call(lib: abi.Lib, ctx, K, T_curr, T_last, b, thr_reproj_base, md_thr, sx, sy, cur: dict, last: dict, use_grid=True):
+    """lld_line_match_last_frame: Tracking::MatchLinesLastKF.  cur / last: left_lines, right_lines, line_matches, desc, plus occupied (cur)
+    and left_octave, skip (last).  Returns (match_last, created, X0, dir)."""
+    P = abi.LineLastKfParams()
+    for i, v in enumerate(np.asarray(K, np.float64).reshape(9)):
+        P.K[i] = float(v)
+    for i, v in enumerate(np.asarray(T_curr, np.float64).reshape(16)):
+        P.T_curr[i] = float(v)
+    for i, v in enumerate(np.asarray(T_last, np.float64).reshape(16)):
+        P.T_last[i] = float(v)
+    P.b = float(b); P.thr_reproj_base = float(thr_reproj_base); P.md_thr = float(md_thr); P.sx = float(sx); P.sy = float(sy); P.use_grid = int(use_grid)
+    cl = np.ascontiguousarray(cur["left_lines"], np.float32).reshape(-1, 4); cr = np.ascontiguousarray(cur["right_lines"], np.float32).reshape(-1, 4)
+    clm = np.ascontiguousarray(cur["line_matches"], np.int32); cd = np.ascontiguousarray(cur["desc"], np.float32)
+    co = None if cur.get("occupied") is None else np.ascontiguousarray(cur["occupied"], np.uint8)
+    ll = np.ascontiguousarray(last["left_lines"], np.float32).reshape(-1, 4); lr = np.ascontiguousarray(last["right_lines"], np.float32).reshape(-1, 4)
+    lo = np.ascontiguousarray(last["left_octave"], np.int32); llm = np.ascontiguousarray(last["line_matches"], np.int32)
+    ls = None if last.get("skip") is None else np.ascontiguousarray(last["skip"], np.uint8); ld = np.ascontiguousarray(last["desc"], np.float32)
+    n_cur = cl.shape[0]; dim = cd.shape[1] if cd.ndim == 2 else ld.shape[1]
+    m = np.empty(n_cur, np.int32); cre = np.empty(n_cur, np.uint8); x0 = np.zeros((n_cur, 3)); dr = np.zeros((n_cur, 3))
+    check(lib.fn("line_match_last_frame")(ctx, C.byref(P), n_cur, _p(cl, C.c_float), cr.shape[0], _p(cr, C.c_float), _p(clm, C.c_int32),
+                                          None if co is None else _p(co, C.c_uint8), _p(cd, C.c_float), ll.shape[0], _p(ll, C.c_float), _p(lo, C.c_int32),
+                                          lr.shape[0], _p(lr, C.c_float), _p(llm, C.c_int32), None if ls is None else _p(ls, C.c_uint8), _p(ld, C.c_float), dim,
+                                          _p(m, C.c_int32), _p(cre, C.c_uint8), _p(x0, C.c_double), _p(dr, C.c_double)), "line_match_last_frame")
+    return m, cre, x0, dr
+
+
 def se3_from_tcw_f32(lib: abi.Lib, tcw: np.ndarray) -> np.ndarray:
     t = np.ascontiguousarray(tcw, np.float32).reshape(16)
     out = np.zeros(7)
@@ -728,6 +754,13 @@ class Tracking:
                                lines_last["X0"], lines_last["dir"], lines_last["X1"], lines_last["X2"], lines_last.get("skip"), lines_last["desc"],
                                frame["left_lines"], frame["left_octave"], frame["right_lines"], frame["line_matches"], frame.get("occupied"),
                                frame["desc"], self.monocular, use_grid, want_gate)
+
+    def MatchLinesLastKF(self, T_curr, T_last, current: dict, last: dict, thrReprojLineBase: float = 6.0, use_grid: bool = True):
+        """Tracking::MatchLinesLastKF (src/Tracking.cc:1449-1611): per unmatched stereo line of the current frame the best line of the
+        last frame under the Hough-cell / reprojection gates, then vgl::MultiTriangulateLine over the four views.  Returns
+        (match_last, created, X0, line_dir); the reference constructs a MapLine(X0, line_dir) where created is set."""
+        return line_lastkf_call(self.lib, self.ctx.handle, self.K, T_curr, T_last, self.b, thrReprojLineBase, self.mdThr, self.sx, self.sy,
+                                current, last, use_grid)
 
     def HoughCells(self, lines):
         """The frame's line grid as this build fills it: cell index dist_ind * 50 + ang_ind per line (lld_line_hough_cells)."""

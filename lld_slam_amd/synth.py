@@ -702,6 +702,66 @@ def make_line_track_scene(scene_id=0, n_map=250, n_cur=300, dim=72, related_frac
     return params, lines_last, frame
 
 
+def make_two_frame_lines(scene_id=0, n_lines=260, dim=72, shared_frac=0.7, pixel_noise=0.4, desc_noise=0.05, baseline=2.0):
+    """Two consecutive stereo frames that see a set of 3D segments (Tracking::MatchLinesLastKF): poses T_last, T_curr
+    (camera-to-world, about one metre apart), left / right KeyLines of both frames with noise, stereo partner indices, unrelated and
+    occupied lines, a few lines of the last frame already tracked.  vgl::TriangulateLine refuses two views whose back-projected
+    planes meet under less than acos(0.975) = 12.8 degrees, i.e. lines further away than ~4.4 baselines: the rig here has a wide baseline
+    and near lines so that true stereo pairs pass (with KITTI's 0.54 m only lines within 2.4 m would).
+    Returns (params, current dict, last dict, truth)."""
+    rng = np.random.default_rng(SEED_SEARCH + 0x8000 + scene_id)
+    fx, fy, cx, cy, bf = KITTI_CAM
+    K = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1.0]])
+    b = float(baseline)
+
+    def pose(w, t):
+        T = np.eye(4); T[:3, :3] = _rodrigues(w); T[:3, 3] = t; return T
+    T_last = pose(rng.normal(0, 0.05, 3), rng.normal(0, 0.5, 3))
+    # (vgl::MultiTriangulateLine wants every other view's plane more than 12.8 degrees away from the first one: a sideways / vertical move)
+    T_curr = pose(rng.normal(0, 0.05, 3), T_last[:3, 3] + T_last[:3, :3] @ np.array([rng.normal(-0.9, 0.1), rng.normal(1.6, 0.1), rng.normal(0.3, 0.1)]))
+    m = int(shared_frac * n_lines)
+    z = rng.uniform(2.5, 9.0, m)                                            # (beyond ~4.4 baselines the triangulation-angle gate refuses)
+    c = np.stack([(rng.uniform(350, 1000, m) - cx) * z / fx, (rng.uniform(80, 290, m) - cy) * z / fy, z], 1)
+    d = rng.normal(size=(m, 3)); d[:, 2] *= 0.3
+    d[rng.random(m) < 0.12, 1] *= 0.02                                      # nearly parallel to the baseline: the stereo triangulation refuses
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    half = rng.uniform(0.3, 1.2, m)[:, None] * 0.5
+    Aw = (T_last[:3, :3] @ (c - half * d).T).T + T_last[:3, 3]; Bw = (T_last[:3, :3] @ (c + half * d).T).T + T_last[:3, 3]
+
+    def frame(T, seed_shift):
+        R, t = T[:3, :3], T[:3, 3]
+
+        def proj(X, shift):
+            Xc = (R.T @ (X - t).T).T - np.array([shift, 0, 0]); zz = np.maximum(Xc[:, 2], 0.3)
+            return np.stack([fx * Xc[:, 0] / zz + cx, fy * Xc[:, 1] / zz + cy], 1)
+        left = np.concatenate([proj(Aw, 0.0), proj(Bw, 0.0)], 1) + rng.normal(0, pixel_noise, (m, 4))
+        s = rng.uniform(-0.15, 0.15, (m, 2))
+        right = np.concatenate([proj(Aw + s[:, :1] * (Bw - Aw), b), proj(Bw + s[:, 1:] * (Bw - Aw), b)], 1) + rng.normal(0, pixel_noise, (m, 4))
+        p = np.stack([rng.uniform(0, 1241, n_lines - m), rng.uniform(0, 376, n_lines - m)], 1)
+        un = np.concatenate([p, p + rng.normal(0, 40, (n_lines - m, 2))], 1)
+        p2 = np.stack([rng.uniform(0, 1241, n_lines - m), rng.uniform(0, 376, n_lines - m)], 1)
+        un2 = np.concatenate([p2, p2 + rng.normal(0, 40, (n_lines - m, 2))], 1)
+        return np.concatenate([left, un]), np.concatenate([right, un2])
+    cl, cr = frame(T_curr, 0); ll, lr = frame(T_last, 1)
+    base = rng.normal(size=(n_lines, dim)); base /= np.linalg.norm(base, axis=1, keepdims=True)
+    dc = base + rng.normal(0, desc_noise, base.shape); dl = base + rng.normal(0, desc_noise, base.shape)
+    dl[m:] = rng.normal(size=(n_lines - m, dim)) / np.sqrt(dim)
+
+    def shuffle(left, right, desc):
+        pl, pr = rng.permutation(n_lines), rng.permutation(n_lines)
+        inv = np.empty(n_lines, np.int64); inv[pr] = np.arange(n_lines)
+        lm = inv[pl].astype(np.int32); lm[rng.random(n_lines) < 0.08] = -1
+        return left[pl].astype(np.float32), right[pr].astype(np.float32), lm, desc[pl].astype(np.float32), pl
+    cl, cr, clm, dc, pc = shuffle(cl, cr, dc); ll, lr, llm, dl, pl_ = shuffle(ll, lr, dl)
+    params = dict(K=K, T_curr=T_curr, T_last=T_last, b=b, thr_reproj_base=6.0, md_thr=0.9, sx=1.0 / 1241.0, sy=1.0 / 376.0)
+    cur = dict(left_lines=cl, right_lines=cr, line_matches=clm, desc=dc, occupied=(rng.random(n_lines) < 0.06).astype(np.uint8))
+    last = dict(left_lines=ll, right_lines=lr, line_matches=llm, desc=dl, left_octave=rng.integers(0, 3, n_lines).astype(np.int32),
+                skip=(rng.random(n_lines) < 0.06).astype(np.uint8))
+    inv_last = np.empty(n_lines, np.int64); inv_last[pl_] = np.arange(n_lines)
+    truth = dict(last_of_cur=np.where(pc < m, inv_last[pc], -1), Aw=Aw, Bw=Bw, src=pc)
+    return params, cur, last, truth
+
+
 def make_local_map(F, scene_id=0, n=2000, related_frac=0.8, flip_p=0.06):
     """A frame pose and local MapPoints for Tracking::SearchLocalPoints: most points are back-projections of F's keypoints (depth
     from the stereo disparity or drawn, position perturbed a little), with their observation normals, scale-invariance distances

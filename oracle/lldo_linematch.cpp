@@ -13,6 +13,10 @@
 //   ReprojectKeyLineTo3D / vgl::MapPoint                   src/LineMatching.cc:277-292, src/vgl.cc:587-590
 //   vgl::ReprojectLinePointTo3D                            src/vgl.cc:336-346
 //   Tracking::AddLinesFrom                                src/Tracking.cc:996-1124
+//   Tracking::MatchLinesLastKF                            src/Tracking.cc:1449-1611
+//   vgl::MultiTriangulateLine                             src/vgl.cc:28-76  (JacobiSVD is NOT restated: the right singular vector of the
+//                                                         smallest singular value comes from a Jacobi eigen-decomposition of M^T M, sign fixed
+//                                                         so that its largest component is positive; the rest is literal)
 //   SubselectWithGrid / GetHoughCoordinates               src/LineMatching.cc:63-180
 //   GetReprojThrPyramid, GetLineEq, GetReprojErrPixelsL1  src/LineMatching.cc:239-275;  vgl::LineReprojErrorL1  src/vgl.cc:548-559
 // Eigen is absent, so ColPivHouseholderQR (rank(), solve()) is restated: column pivoting on the largest remaining
@@ -34,10 +38,10 @@ namespace {
 
 struct M34 { M3 R; V3 t; };   // T.block<3,4>(0,0) of a 4x4 pose
 
-// Eigen::ColPivHouseholderQR of an m x n matrix (m >= n, m <= 3): solves A x = b in the least-squares sense.
+// Eigen::ColPivHouseholderQR of an m x n matrix (m >= n, m <= 4, n <= 3): solves A x = b in the least-squares sense.
 // Returns the rank; x gets zeros for the dropped unknowns.
-int colpiv_qr_solve(int m, int n, double A[3][3], const double* b_in, double* x) {
-  double b[3]; for (int i = 0; i < m; i++) b[i] = b_in[i];
+int colpiv_qr_solve(int m, int n, double A[4][3], const double* b_in, double* x) {
+  double b[4]; for (int i = 0; i < m; i++) b[i] = b_in[i];
   int perm[3] = {0, 1, 2};
   double maxpivot = 0.0; double diag[3] = {0, 0, 0};
   for (int k = 0; k < n; k++) {
@@ -51,7 +55,7 @@ int colpiv_qr_solve(int m, int n, double A[3][3], const double* b_in, double* x)
     // Householder: makeHouseholderInPlace on A[k..m-1][k]
     const double c0 = A[k][k];
     double tail = 0.0; for (int r = k + 1; r < m; r++) tail += A[r][k] * A[r][k];
-    double beta = c0, tau = 0.0; double v[3] = {0, 0, 0};
+    double beta = c0, tau = 0.0; double v[4] = {0, 0, 0, 0};
     if (tail > DBL_MIN) {
       beta = std::sqrt(c0 * c0 + tail);
       if (c0 >= 0) beta = -beta;
@@ -108,7 +112,7 @@ bool triangulate_line(const M34& T1, const M34& T2, const V3& l1, const V3& l2, 
   V3 d = cross(normal_1, normal_2);
   d = scale(d, 1.0 / norm(d));
   *line_dir = d;
-  double M[3][3] = {{normal_1.x, normal_1.y, normal_1.z}, {normal_2.x, normal_2.y, normal_2.z}, {d.x, d.y, d.z}};
+  double M[4][3] = {{normal_1.x, normal_1.y, normal_1.z}, {normal_2.x, normal_2.y, normal_2.z}, {d.x, d.y, d.z}, {0, 0, 0}};
   const double b[3] = {dot(normal_1, T1.t), dot(normal_2, T2.t), 0.0};
   double x[3];
   if (colpiv_qr_solve(3, 3, M, b, x) < 3) return false;
@@ -119,7 +123,7 @@ bool triangulate_line(const M34& T1, const M34& T2, const V3& l1, const V3& l2, 
 // vgl::ReprojectLinePointTo3D
 void reproject_line_point_to_3d(const V3& X0, const V3& line_dir, double px, double py, const double* K, double* depth, double* line_param) {
   const V3 kd = k_mul(K, line_dir);
-  double M[3][3] = {{px, -kd.x, 0}, {py, -kd.y, 0}, {1.0, -kd.z, 0}};
+  double M[4][3] = {{px, -kd.x, 0}, {py, -kd.y, 0}, {1.0, -kd.z, 0}, {0, 0, 0}};
   const V3 rhs = k_mul(K, X0);
   const double b[3] = {rhs.x, rhs.y, rhs.z};
   double sol[3];
@@ -182,7 +186,8 @@ int lldo_line_pair_geometry(const lld_line_stereo_params* P, const float* kl1, c
 
 // test hook: the restated ColPivHouseholderQR
 int lldo_colpiv_qr_solve(int m, int n, const double* A_rowmajor, const double* b, double* x) {
-  double A[3][3] = {{0}};
+  if (m < 1 || m > 4 || n < 1 || n > 3 || m < n) return -1;
+  double A[4][3] = {{0}};
   for (int i = 0; i < m; i++) for (int j = 0; j < n; j++) A[i][j] = A_rowmajor[i * n + j];
   return colpiv_qr_solve(m, n, A, b, x);
 }
@@ -346,6 +351,132 @@ int lldo_line_track_match(void*, const lld_line_track_params* P, int n_map, cons
     }
   }
   (void)n_right;
+  return LLD_OK;
+}
+
+// ---------------------------------------------------------------- Tracking::MatchLinesLastKF
+namespace {
+// eigenvector of the smallest eigenvalue of the symmetric 3x3 A (cyclic Jacobi in long double), largest component positive
+V3 smallest_eigvec(const double A_in[3][3]) {
+  long double A[3][3], V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) A[i][j] = A_in[i][j];
+  for (int sweep = 0; sweep < 60; sweep++) {
+    long double off = fabsl(A[0][1]) + fabsl(A[0][2]) + fabsl(A[1][2]);
+    if (off == 0.0L) break;
+    for (int p = 0; p < 2; p++) for (int q = p + 1; q < 3; q++) {
+      if (A[p][q] == 0.0L) continue;
+      const long double theta = (A[q][q] - A[p][p]) / (2.0L * A[p][q]);
+      const long double t = (theta >= 0 ? 1.0L : -1.0L) / (fabsl(theta) + sqrtl(theta * theta + 1.0L));
+      const long double c = 1.0L / sqrtl(t * t + 1.0L), sn = t * c;
+      for (int k = 0; k < 3; k++) { const long double akp = A[k][p], akq = A[k][q]; A[k][p] = c * akp - sn * akq; A[k][q] = sn * akp + c * akq; }
+      for (int k = 0; k < 3; k++) { const long double apk = A[p][k], aqk = A[q][k]; A[p][k] = c * apk - sn * aqk; A[q][k] = sn * apk + c * aqk; }
+      for (int k = 0; k < 3; k++) { const long double vkp = V[k][p], vkq = V[k][q]; V[k][p] = c * vkp - sn * vkq; V[k][q] = sn * vkp + c * vkq; }
+    }
+  }
+  int m = 0; for (int i = 1; i < 3; i++) if (A[i][i] < A[m][m]) m = i;
+  V3 v{(double)V[0][m], (double)V[1][m], (double)V[2][m]};
+  const double n = norm(v); v = scale(v, 1.0 / n);
+  int big = 0; if (std::fabs(v.y) > std::fabs(at(v, big))) big = 1; if (std::fabs(v.z) > std::fabs(at(v, big))) big = 2;
+  if (at(v, big) < 0) v = scale(v, -1.0);
+  return v;
+}
+// vgl::MultiTriangulateLine (src/vgl.cc:28-76)
+bool multi_triangulate_line(int n, const M44* Ts, const V3* lines, V3* X0_p, V3* line_dir_p) {
+  if (n < 3) return false;
+  if (n > 4) return false;                                          // (the reference takes any count; its only call site passes four views)
+  V3 normals[4];
+  for (int i = 0; i < n; i++) { const V3 leq = scale(lines[i], 1.0 / norm(lines[i])); normals[i] = m3_mulv(Ts[i].R, leq); }
+  for (int i = 1; i < n; i++) if (std::fabs(dot(normals[0], normals[i])) / norm(normals[0]) / norm(normals[i]) > 0.975) return false;
+  double MtM[3][3] = {{0}};
+  for (int i = 0; i < n; i++) for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) MtM[r][c] += at(normals[i], r) * at(normals[i], c);
+  const V3 line_dir = smallest_eigvec(MtM);                         // Vm.col(2) of M2.jacobiSvd(...)
+  double M1[4][3], b1[4], x[3];
+  for (int i = 0; i < n; i++) { M1[i][0] = normals[i].x; M1[i][1] = normals[i].y; M1[i][2] = normals[i].z; b1[i] = dot(normals[i], Ts[i].t); }
+  colpiv_qr_solve(n, 3, M1, b1, x);                                 // M1.colPivHouseholderQr().solve(b1)
+  V3 X0{x[0], x[1], x[2]};
+  X0 = sub(X0, scale(line_dir, dot(X0, line_dir)));
+  *line_dir_p = line_dir; *X0_p = X0;
+  return true;
+}
+M34 m34_of(const M44& T) { M34 r; r.R = T.R; r.t = T.t; return r; }
+}  // namespace
+
+int lldo_multi_triangulate_line(int n, const double* Ts /*[n][16]*/, const double* lines /*[n][3]*/, double* x0, double* dir) {
+  M44 T[4]; V3 l[4];
+  if (n > 4) return 0;
+  for (int i = 0; i < n; i++) { T[i] = pose44(Ts + 16 * i); l[i] = V3{lines[3 * i], lines[3 * i + 1], lines[3 * i + 2]}; }
+  V3 X0, d;
+  if (!multi_triangulate_line(n, T, l, &X0, &d)) return 0;
+  x0[0] = X0.x; x0[1] = X0.y; x0[2] = X0.z; dir[0] = d.x; dir[1] = d.y; dir[2] = d.z;
+  return 1;
+}
+
+int lldo_line_match_last_frame(void*, const lld_line_lastkf_params* P, int n_cur, const float* cur_left, int n_cur_right, const float* cur_right,
+                               const int32_t* cur_line_matches, const uint8_t* cur_occupied, const float* cur_desc, int n_last, const float* last_left,
+                               const int32_t* last_left_octave, int n_last_right, const float* last_right, const int32_t* last_line_matches,
+                               const uint8_t* last_skip, const float* last_desc, int dim, int32_t* match_last, uint8_t* created, double* x0_out, double* dir_out) {
+  const M44 T = pose44(P->T_curr), T_last = pose44(P->T_last);
+  M44 T_right = T, T_last_right = T_last;                                 // GetTForRight
+  T_right.t = add(T.t, m3_mulv(T.R, V3{P->b, 0.0, 0.0}));
+  T_last_right.t = add(T_last.t, m3_mulv(T_last.R, V3{P->b, 0.0, 0.0}));
+  std::vector<std::vector<std::vector<int>>> grid(kDistCells, std::vector<std::vector<int>>(kAngCells));
+  {
+    std::vector<int32_t> cell(n_last);
+    lld_line_hough_cells_oracle(last_left, n_last, P->sx, P->sy, cell.data());
+    for (int li = 0; li < n_last; li++) grid[cell[li] / kAngCells][cell[li] % kAngCells].push_back(li);
+  }
+  for (int i = 0; i < n_cur; i++) {
+    match_last[i] = -1; created[i] = 0;
+    for (int k = 0; k < 3; k++) { x0_out[3 * i + k] = 0.0; dir_out[3 * i + k] = 0.0; }
+    if (cur_occupied && cur_occupied[i]) continue;
+    const int ri = cur_line_matches[i];
+    if (ri < 0) continue;                                               // (the stereo system; the reference would index mvLinesRight[-1] otherwise)
+    const V3 l1 = normalized_line_eq(cur_left + 4 * i, P->K), l2 = normalized_line_eq(cur_right + 4 * ri, P->K);
+    V3 X0, line_dir;
+    if (!triangulate_line(m34_of(T), m34_of(T_right), l1, l2, &X0, &line_dir)) continue;
+    std::vector<int> lines_inds;
+    if (P->use_grid) {
+      const V3 Xl1 = k_mul(P->K, m3t_mulv(T_last.R, sub(X0, T_last.t))), Xl2 = k_mul(P->K, m3t_mulv(T_last.R, sub(add(X0, line_dir), T_last.t)));
+      V3 leq = cross(Xl1, Xl2);
+      { const double n = std::sqrt(leq.x * leq.x + leq.y * leq.y); leq.x /= n; leq.y /= n; leq.z /= n; }
+      std::vector<int> dis, ais;
+      hough_coordinates(leq, P->sx, P->sy, &dis, &ais, 3, 3, nullptr, nullptr);
+      std::vector<char> in(n_last, 0);
+      for (int ai : ais) for (int di : dis) for (int oi : grid[di][ai]) in[oi] = 1;
+      for (int oi = 0; oi < n_last; oi++) if (in[oi]) lines_inds.push_back(oi);
+    } else for (int oi = 0; oi < n_last; oi++) lines_inds.push_back(oi);
+    int match_id = -1; double md = 1e10;
+    for (int li : lines_inds) {
+      const int pri = last_line_matches[li];
+      if (pri < 0) continue;
+      if (last_skip && last_skip[li]) continue;
+      double thr = P->thr_reproj_base;
+      for (int oi = 0; oi < last_left_octave[li]; oi++) thr *= 1.44;
+      const float* kl = last_left + 4 * li; const float* kr = last_right + 4 * pri;
+      const double se = line_reproj_err_l1(kl[0], kl[1], kl[2], kl[3], T_last, X0, line_dir, P->K);
+      const double se2 = line_reproj_err_l1(kr[0], kr[1], kr[2], kr[3], T_last_right, X0, line_dir, P->K);
+      if (se > thr && se2 > thr) continue;
+      const double cd = lldo_l2f32(last_desc + (size_t)dim * li, cur_desc + (size_t)dim * i, dim);
+      if (cd < md) { md = cd; match_id = li; }
+    }
+    if (match_id < 0) continue;
+    const int pi = match_id;
+    if (md > P->md_thr) continue;
+    match_last[i] = pi;
+    const M44 Ts[4] = {T, T_right, T_last, T_last_right};
+    const int pri = last_line_matches[pi];
+    const V3 leqs[4] = {l1, l2, normalized_line_eq(last_left + 4 * pi, P->K), normalized_line_eq(last_right + 4 * pri, P->K)};
+    if (!multi_triangulate_line(4, Ts, leqs, &X0, &line_dir)) continue;
+    V3 p1, p2;
+    reproject_keyline_to_3d(cur_left + 4 * i, m34_of(T), P->K, X0, line_dir, &p1, &p2);
+    bool is_behind = false;
+    for (const M44& Ti : Ts) { const V3 p1c = map_point(Ti, p1), p2c = map_point(Ti, p2); if (p1c.z < 0 || p2c.z < 0) is_behind = true; }
+    if (is_behind) continue;
+    created[i] = 1;
+    x0_out[3 * i] = X0.x; x0_out[3 * i + 1] = X0.y; x0_out[3 * i + 2] = X0.z;
+    dir_out[3 * i] = line_dir.x; dir_out[3 * i + 1] = line_dir.y; dir_out[3 * i + 2] = line_dir.z;
+  }
+  (void)n_cur_right; (void)n_last_right;
   return LLD_OK;
 }
 

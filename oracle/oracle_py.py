@@ -228,6 +228,20 @@ def line_track_match(K, T_curr, b, thr_reproj_base, md_thr, sx, sy, lines_last, 
                                 frame["right_lines"], frame["line_matches"], frame.get("occupied"), frame["desc"], monocular, use_grid, want_gate)
 
 
+def line_match_last_frame(K, T_curr, T_last, b, thr_reproj_base, md_thr, sx, sy, cur, last, use_grid=True):
+    """Tracking::MatchLinesLastKF, literal (oracle/lldo_linematch.cpp)."""
+    return host.line_lastkf_call(lib(), None, K, T_curr, T_last, b, thr_reproj_base, md_thr, sx, sy, cur, last, use_grid)
+
+
+def multi_triangulate_line(Ts, lines):
+    """vgl::MultiTriangulateLine: (ok, X0, dir) for n <= 4 views (Ts [n,4,4] camera-to-world, lines [n,3] normalised image lines)."""
+    d = lib().dll
+    d.lldo_multi_triangulate_line.argtypes = [C.c_int, abi.c_double_p, abi.c_double_p, abi.c_double_p, abi.c_double_p]; d.lldo_multi_triangulate_line.restype = C.c_int
+    T = _d(np.asarray(Ts, np.float64).reshape(-1, 16)); l = _d(np.asarray(lines, np.float64).reshape(-1, 3)); x0 = np.zeros(3); dr = np.zeros(3)
+    ok = d.lldo_multi_triangulate_line(T.shape[0], _dp(T), _dp(l), _dp(x0), _dp(dr))
+    return bool(ok), x0, dr
+
+
 def hough_coordinates(leq, sx, sy, step_dist=3, step_ang=3):
     """GetHoughCoordinates, literal: (dist_inds, ang_inds) in the order the reference pushes them."""
     d = lib().dll

@@ -61,3 +61,35 @@ def test_malformed_arguments_are_refused(gpu_ctx):
     bad = dict(F); bad["left_octave"] = F["left_octave"].copy(); bad["left_octave"][0] = -1
     with pytest.raises(RuntimeError):
         trk.AddLinesFrom(L, P["T_curr"], 2.0, bad)
+
+
+@pytest.mark.parametrize("scene,use_grid", [(0, True), (1, False), (2, True), (3, False)])
+def test_match_lines_last_kf_matches_oracle(gpu_ctx, oracle, scene, use_grid):
+    """Matches and the created flags bit for bit; X0 / direction to 1e-6 (the device takes the two well-conditioned eigen-directions of
+    the normal matrix where the oracle, like the reference, solves the rank-deficient least squares by pivoted QR and projects)."""
+    P, cur, last, _ = synth.make_two_frame_lines(scene)
+    trk = Tracking(gpu_ctx, P["K"], P["b"], 1.0 / P["sx"], 1.0 / P["sy"], mdThr=P["md_thr"])
+    gm, gc, gx, gd = trk.MatchLinesLastKF(P["T_curr"], P["T_last"], cur, last, P["thr_reproj_base"], use_grid)
+    om, oc, ox, od = oracle.line_match_last_frame(P["K"], P["T_curr"], P["T_last"], P["b"], P["thr_reproj_base"], P["md_thr"], P["sx"], P["sy"], cur, last, use_grid)
+    np.testing.assert_array_equal(gm, om)
+    np.testing.assert_array_equal(gc, oc)
+    ok = oc.astype(bool)
+    assert ok.sum() > 20
+    np.testing.assert_allclose(gd[ok], od[ok], atol=1e-7)
+    np.testing.assert_allclose(gx[ok], ox[ok], rtol=1e-6, atol=1e-6)
+    assert np.all(gx[~ok] == 0) and np.all(gd[~ok] == 0)
+
+
+def test_match_lines_last_kf_edge_cases(gpu_ctx, oracle):
+    P, cur, last, _ = synth.make_two_frame_lines(4, n_lines=60)
+    trk = Tracking(gpu_ctx, P["K"], P["b"], 1.0 / P["sx"], 1.0 / P["sy"], mdThr=P["md_thr"])
+    none = dict(last); none["line_matches"] = -np.ones_like(last["line_matches"])            # no line of the last frame has a stereo partner
+    m, c, _, _ = trk.MatchLinesLastKF(P["T_curr"], P["T_last"], cur, none)
+    assert np.all(m == -1) and not c.any()
+    empty = dict(left_lines=np.zeros((0, 4), np.float32), right_lines=np.zeros((0, 4), np.float32), line_matches=np.zeros(0, np.int32),
+                 desc=np.zeros((0, 72), np.float32), left_octave=np.zeros(0, np.int32), skip=np.zeros(0, np.uint8))
+    m, c, _, _ = trk.MatchLinesLastKF(P["T_curr"], P["T_last"], cur, empty)
+    assert np.all(m == -1) and not c.any()
+    bad = dict(cur); bad["line_matches"] = cur["line_matches"].copy(); bad["line_matches"][0] = 10 ** 6
+    with pytest.raises(RuntimeError):
+        trk.MatchLinesLastKF(P["T_curr"], P["T_last"], bad, last)

@@ -128,3 +128,51 @@ def test_grid_cells_and_rivals(oracle):
     # a map line that projects next to its frame line shares (or neighbours) its Hough cell: the grid loses few of the brute-force matches
     both = (m_all >= 0)
     assert both.sum() > 60 and np.mean(m_grid[both] == m_all[both]) > 0.6
+
+
+# ---------------------------------------------------------------- Tracking::MatchLinesLastKF / vgl::MultiTriangulateLine
+def test_multi_triangulate_line_against_numpy(oracle):
+    """Direction = right singular vector of the smallest singular value (numpy SVD, sign made canonical), X0 = least-squares point of
+    the planes (numpy lstsq) minus its component along the direction; degenerate inputs refused like the reference."""
+    rng = np.random.default_rng(11)
+    for trial in range(40):
+        X0t = rng.normal(0, 3, 3) + np.array([0, 0, 12.0]); dt = rng.normal(size=3); dt /= np.linalg.norm(dt)
+        Ts, ls = [], []
+        for v in range(4):
+            T = np.eye(4); T[:3, :3] = synth._rodrigues(rng.normal(0, 0.08, 3)); T[:3, 3] = rng.normal(0, 0.8, 3)
+            a = T[:3, :3].T @ (X0t - T[:3, 3]); bb = T[:3, :3].T @ (X0t + dt - T[:3, 3])
+            l = np.cross(a, bb) + rng.normal(0, 1e-3, 3); l /= np.hypot(l[0], l[1])
+            Ts.append(T); ls.append(l)
+        ok, x0, dr = oracle.multi_triangulate_line(Ts, ls)
+        N = np.stack([T[:3, :3] @ (l / np.linalg.norm(l)) for T, l in zip(Ts, ls)])
+        par = any(abs(N[0] @ N[i]) / np.linalg.norm(N[0]) / np.linalg.norm(N[i]) > 0.975 for i in range(1, 4))
+        assert ok == (not par)
+        if not ok:
+            continue
+        v = np.linalg.svd(N)[2][2]; v = v * np.sign(v[np.argmax(np.abs(v))])
+        bvec = np.array([N[i] @ Ts[i][:3, 3] for i in range(4)])
+        xl = np.linalg.lstsq(N, bvec, rcond=None)[0]; xl = xl - (xl @ v) * v
+        np.testing.assert_allclose(dr, v, atol=1e-9)
+        np.testing.assert_allclose(x0, xl, rtol=1e-6, atol=1e-6)
+        assert abs(abs(dr @ dt) - 1) < 1e-2                                   # and it is the line that was projected
+    assert oracle.multi_triangulate_line(Ts[:2], ls[:2])[0] is False            # fewer than three views (src/vgl.cc:32-35)
+
+
+def test_match_lines_last_kf_recovers_the_shared_lines(oracle):
+    P, cur, last, truth = synth.make_two_frame_lines(0)
+    for use_grid in (True, False):
+        m, cre, x0, dr = oracle.line_match_last_frame(P["K"], P["T_curr"], P["T_last"], P["b"], P["thr_reproj_base"], P["md_thr"], P["sx"], P["sy"],
+                                                      cur, last, use_grid)
+        hit = m >= 0
+        assert hit.sum() > 50 and np.mean(m[hit] == truth["last_of_cur"][hit]) > 0.97
+        assert not np.any(hit & cur["occupied"].astype(bool)) and not np.any(hit & (cur["line_matches"] < 0))
+        assert not np.any(last["skip"][m[hit]].astype(bool)) and np.all(last["line_matches"][m[hit]] >= 0)
+        assert cre.sum() > 20 and np.all(cre[~hit] == 0)
+        ok = cre.astype(bool)
+        # the created lines are the 3D segments that were projected: direction parallel, X0 on the line
+        src = truth["src"][ok]; A, B = truth["Aw"][src], truth["Bw"][src]
+        dt = (B - A) / np.linalg.norm(B - A, axis=1, keepdims=True)
+        assert np.median(np.abs(np.abs(np.sum(dr[ok] * dt, axis=1)) - 1)) < 1e-3
+        off = x0[ok] - A; off -= np.sum(off * dt, axis=1, keepdims=True) * dt
+        assert np.median(np.linalg.norm(off, axis=1)) < 0.2
+        np.testing.assert_allclose(np.sum(x0[ok] * dr[ok], axis=1), 0, atol=1e-6)         # X0 is the point closest to the origin
