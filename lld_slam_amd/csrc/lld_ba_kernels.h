@@ -229,6 +229,70 @@ __device__ __forceinline__ bool spd_inverse(const double* A, double* Ainv) {
   return ok;
 }
 
+// 1 / sqrt(d): v_rsq_f64 seed + two Newton steps (the library sqrt and divide are ~45 dependent instructions; the result is within an
+// ulp or two and L L^T = Hll + lambda I to rounding either way)
+// 1 / z: v_rcp_f64 seed + two Newton steps (Jacobians only; residuals keep the reference's divisions)
+__device__ __forceinline__ double rcp_nr(double z) {
+  double r = __builtin_amdgcn_rcp(z);
+  r = r * (2.0 - z * r);
+  r = r * (2.0 - z * r);
+  return r;
+}
+__device__ __forceinline__ double rsqrt_nr(double d) {
+  double y = __builtin_amdgcn_rsq(d);
+  y = y * (1.5 - (0.5 * d) * (y * y));
+  y = y * (1.5 - (0.5 * d) * (y * y));
+  return y;
+}
+// lower Cholesky factor of (packed upper U) + lambda I, D x D: L packed row-major lower (L[i][j] at i(i+1)/2 + j, diagonal entries
+// unused), idiag[i] = 1 / L[i][i]
+template <int D>
+__device__ __forceinline__ void chol_packed(const double* U, double lambda, double* L, double* idiag) {
+  double F[D][D];
+  int kk = 0;
+#pragma unroll
+  for (int i = 0; i < D; i++)
+#pragma unroll
+    for (int j = i; j < D; j++) { F[j][i] = U[kk++]; }
+#pragma unroll
+  for (int i = 0; i < D; i++) F[i][i] += lambda;
+#pragma unroll
+  for (int j = 0; j < D; j++) {
+    double d = F[j][j];
+#pragma unroll
+    for (int m = 0; m < j; m++) d -= L[j * (j + 1) / 2 + m] * L[j * (j + 1) / 2 + m];
+    const double inv = rsqrt_nr(d);
+    idiag[j] = inv;
+#pragma unroll
+    for (int i = j + 1; i < D; i++) {
+      double sacc = F[i][j];
+#pragma unroll
+      for (int m = 0; m < j; m++) sacc -= L[i * (i + 1) / 2 + m] * L[j * (j + 1) / 2 + m];
+      L[i * (i + 1) / 2 + j] = sacc * inv;
+    }
+  }
+}
+// x = (U + lambda I)^-1 t through that factor (forward, then backward substitution)
+template <int D>
+__device__ __forceinline__ void chol_solve(const double* U, double lambda, const double* t, double* x) {
+  double L[D * (D + 1) / 2], idg[D], y[D];
+  chol_packed<D>(U, lambda, L, idg);
+#pragma unroll
+  for (int c = 0; c < D; c++) {
+    double sacc = t[c];
+#pragma unroll
+    for (int m = 0; m < c; m++) sacc -= y[m] * L[c * (c + 1) / 2 + m];
+    y[c] = sacc * idg[c];
+  }
+#pragma unroll
+  for (int c = D - 1; c >= 0; c--) {
+    double sacc = y[c];
+#pragma unroll
+    for (int m = c + 1; m < D; m++) sacc -= x[m] * L[m * (m + 1) / 2 + c];
+    x[c] = sacc * idg[c];
+  }
+}
+
 // packed upper (row-major) <-> full
 template <int D>
 __device__ __forceinline__ void unpack_sym(const double* U, double lambda, double* F) {
@@ -409,7 +473,7 @@ __device__ __forceinline__ double point_edge_blocks_closed(const BAWin& W, const
   const double ws = w * ob.s;
   ws_out = ws; rho0_out = rho0;
   const Mat3 R = quat_rotation(T.q);
-  const double iz = 1.0 / Xc.z, iz2 = iz * iz;
+  const double iz = rcp_nr(Xc.z), iz2 = iz * iz;
   const double a = k.fx * iz, b = k.fy * iz;
   const double c0 = -k.fx * Xc.x * iz2, c1 = -k.fy * Xc.y * iz2, c2 = c0 + k.bf * iz2;
   const double m00 = ws * (stereo ? 2.0 * a * a : a * a);
@@ -602,13 +666,9 @@ __device__ __forceinline__ double point_edge_trial(const BAArrays& A, const BAWi
 }
 // x_l = (Hll + lambda I)^-1 (b_l - sum W^T x_c), oplus; returns the landmark's part of computeScale
 __device__ __forceinline__ double point_backsub(const double* V, double lambda, const double* wtx, const Vec3& X, Vec3& Xn) {
-  double F[9], Di[9];
-  unpack_sym<3>(V, lambda, F);
-  spd_inverse<3>(F, Di);
   const double t[3] = {V[6] - wtx[0], V[7] - wtx[1], V[8] - wtx[2]};
   double xl[3], sc = 0.0;
-#pragma unroll
-  for (int i = 0; i < 3; i++) xl[i] = Di[i * 3] * t[0] + Di[i * 3 + 1] * t[1] + Di[i * 3 + 2] * t[2];
+  chol_solve<3>(V, lambda, t, xl);
 #pragma unroll
   for (int i = 0; i < 3; i++) sc += xl[i] * (lambda * xl[i] + V[6 + i]);
   Xn = vec3(X.x + xl[0], X.y + xl[1], X.z + xl[2]);      // VertexSBAPointXYZ::oplusImpl
@@ -672,7 +732,7 @@ __device__ __forceinline__ void ba_backsub_pt_body(const BAArrays& A, const BAWi
         const Mat3 R = quat_rotation(Tc.q);
         const double* xc = xps + c * 6;
         const Vec3 v = cross(Xc, vec3(xc[0], xc[1], xc[2])) - vec3(xc[3], xc[4], xc[5]);
-        const double iz = 1.0 / Xc.z, iz2 = iz * iz;
+        const double iz = rcp_nr(Xc.z), iz2 = iz * iz;
         const double a = W.cam.fx * iz, b = W.cam.fy * iz;
         const double c0 = -W.cam.fx * Xc.x * iz2, c1 = -W.cam.fy * Xc.y * iz2, c2 = c0 + W.cam.bf * iz2;
         const double u0 = ws * (a * v.x + c0 * v.z), u1 = ws * (b * v.y + c1 * v.z), u2 = stereo ? ws * (a * v.x + c2 * v.z) : 0.0;
@@ -901,14 +961,10 @@ __device__ __forceinline__ double line_obs_trial(const BAArrays& A, const BAWin&
   return chi;
 }
 __device__ __forceinline__ double line_backsub(const double* V, double lambda, const double* wtx, const LineQ& L, LineQ& Ln) {
-  double F[16], Di[16];
-  unpack_sym<4>(V, lambda, F);
-  spd_inverse<4>(F, Di);
   double t[4], xl[4], sc = 0.0;
 #pragma unroll
   for (int i = 0; i < 4; i++) t[i] = V[10 + i] - wtx[i];
-#pragma unroll
-  for (int i = 0; i < 4; i++) xl[i] = Di[i * 4] * t[0] + Di[i * 4 + 1] * t[1] + Di[i * 4 + 2] * t[2] + Di[i * 4 + 3] * t[3];
+  chol_solve<4>(V, lambda, t, xl);
 #pragma unroll
   for (int i = 0; i < 4; i++) sc += xl[i] * (lambda * xl[i] + V[10 + i]);
   Ln = line_oplus(L, xl);
@@ -1083,42 +1139,6 @@ __host__ __device__ inline int schur_lds_doubles(int k, int D) {
   return k > kSchurWideK ? k * WS + D + 1 : ((schur_nb(k) * (k * WS + D) + 1) & ~1);
 }
 
-// 1 / sqrt(d): v_rsq_f64 seed + two Newton steps (the library sqrt and divide are ~45 dependent instructions; the result is within an
-// ulp or two and L L^T = Hll + lambda I to rounding either way)
-__device__ __forceinline__ double rsqrt_nr(double d) {
-  double y = __builtin_amdgcn_rsq(d);
-  y = y * (1.5 - (0.5 * d) * (y * y));
-  y = y * (1.5 - (0.5 * d) * (y * y));
-  return y;
-}
-// lower Cholesky factor of (packed upper U) + lambda I, D x D: L packed row-major lower (L[i][j] at i(i+1)/2 + j, diagonal entries
-// unused), idiag[i] = 1 / L[i][i]
-template <int D>
-__device__ __forceinline__ void chol_packed(const double* U, double lambda, double* L, double* idiag) {
-  double F[D][D];
-  int kk = 0;
-#pragma unroll
-  for (int i = 0; i < D; i++)
-#pragma unroll
-    for (int j = i; j < D; j++) { F[j][i] = U[kk++]; }
-#pragma unroll
-  for (int i = 0; i < D; i++) F[i][i] += lambda;
-#pragma unroll
-  for (int j = 0; j < D; j++) {
-    double d = F[j][j];
-#pragma unroll
-    for (int m = 0; m < j; m++) d -= L[j * (j + 1) / 2 + m] * L[j * (j + 1) / 2 + m];
-    const double inv = rsqrt_nr(d);
-    idiag[j] = inv;
-#pragma unroll
-    for (int i = j + 1; i < D; i++) {
-      double sacc = F[i][j];
-#pragma unroll
-      for (int m = 0; m < j; m++) sacc -= L[i * (i + 1) / 2 + m] * L[j * (j + 1) / 2 + m];
-      L[i * (i + 1) / 2 + j] = sacc * inv;
-    }
-  }
-}
 // factor + stage one (landmark, slot): Z = W L^-T into zl (6 x D), t = L^-1 b_l into tl
 template <int D>
 __device__ __forceinline__ void schur_stage_one(bool a, const double* v, double lambda, const double* w, double* zl, double* tl, bool write_t) {
