@@ -66,16 +66,16 @@ def algorithmic_bytes(w, n_trials, n_iters, pcg_iters):
 
 def schur_fmas(w, n_trials):
     """fp64 FMAs of the Schur family for ONE window over a whole solve (the arithmetic that actually bounds it): per landmark with k
-    free-camera observations, k x (rebuild the 6xD Hpl block in closed form ~70 for a point / 0 for a line whose block is stored, Y = W Dinv 6*D*D)
-    + one D x D inverse (~40 / ~90) + k(k+1)/2 block products of 6*6*D."""
+    free-camera observations, k x (rebuild the 6xD Hpl block in closed form ~70 for a point / 0 for a line whose block is stored,
+    Z = W L^-T 6*D*(D+1)/2, Z (L^-1 b) 6*D) + one D x D Cholesky (~10 / ~20) + k(k+1)/2 block products Z_a Z_b^T of 6*6*D."""
     import numpy as np
     nf = w.n_free_cams
     kp = np.add.reduceat((w.pt_obs_cam < nf).astype(np.int64), w.pt_obs_start[:-1]) if w.n_points else np.zeros(0, np.int64)
     kp = np.where(np.diff(w.pt_obs_start) > 0, kp, 0)
     kl = np.add.reduceat((w.ln_obs_cam < nf).astype(np.int64), w.ln_obs_start[:-1]) if w.n_lines else np.zeros(0, np.int64)
     kl = np.where(np.diff(w.ln_obs_start) > 0, kl, 0)
-    pts = np.sum(kp * (70 + 54) + 40 * (kp > 0) + kp * (kp + 1) // 2 * 108)
-    lns = np.sum(kl * 96 + 90 * (kl > 0) + kl * (kl + 1) // 2 * 144)
+    pts = np.sum(kp * (70 + 36 + 18) + 10 * (kp > 0) + kp * (kp + 1) // 2 * 108)
+    lns = np.sum(kl * (60 + 24) + 20 * (kl > 0) + kl * (kl + 1) // 2 * 144)
     return int(n_trials * (pts + lns))
 
 

@@ -186,5 +186,23 @@ out["orb_guided_search"] = {
     "stereo_rows": {"gpu_ms": g_st * 1e3, "cpu_oracle_ms": c_st * 1e3, "equal": bool(np.array_equal(r_st.match, e_st[0]))},
     "bow_kf_frame": {"gpu_ms": g_bow * 1e3, "cpu_oracle_ms": c_bow * 1e3, "rounds": r_bow.rounds, "equal": r_bow.n_matches == e_bow[0]},
 }
+# ---- the line half of the Tracking thread: AddLinesFrom (250 map lines x 300 frame lines) and MatchLinesLastKF (260 x 260), host buffers in and out
+from lld_slam_amd import Tracking
+Pt, Lt, Ft = synth.make_line_track_scene(0)
+trk = Tracking(ctx, Pt["K"], Pt["b"], 1.0 / Pt["sx"], 1.0 / Pt["sy"], mdThr=Pt["md_thr"])
+g_al, r_al = timed(lambda: trk.AddLinesFrom(Lt, Pt["T_curr"], Pt["thr_reproj_base"], Ft))
+c_al, e_al = timed(lambda: O.line_track_match(Pt["K"], Pt["T_curr"], Pt["b"], Pt["thr_reproj_base"], Pt["md_thr"], Pt["sx"], Pt["sy"], Lt, Ft))
+g_ab, r_ab = timed(lambda: trk.AddLinesFrom(Lt, Pt["T_curr"], Pt["thr_reproj_base"], Ft, use_grid=False))
+c_ab, e_ab = timed(lambda: O.line_track_match(Pt["K"], Pt["T_curr"], Pt["b"], Pt["thr_reproj_base"], Pt["md_thr"], Pt["sx"], Pt["sy"], Lt, Ft, use_grid=False))
+P2, cur2, last2, _ = synth.make_two_frame_lines(0)
+trk2 = Tracking(ctx, P2["K"], P2["b"], 1.0 / P2["sx"], 1.0 / P2["sy"], mdThr=P2["md_thr"])
+g_lk, r_lk = timed(lambda: trk2.MatchLinesLastKF(P2["T_curr"], P2["T_last"], cur2, last2, P2["thr_reproj_base"]))
+c_lk, e_lk = timed(lambda: O.line_match_last_frame(P2["K"], P2["T_curr"], P2["T_last"], P2["b"], P2["thr_reproj_base"], P2["md_thr"], P2["sx"], P2["sy"], cur2, last2))
+out["line_tracking"] = {
+    "add_lines_from_grid": {"gpu_ms": g_al * 1e3, "cpu_oracle_ms": c_al * 1e3, "n_matches": int((r_al[0] >= 0).sum()), "equal": bool(np.array_equal(r_al[0], e_al[0]))},
+    "add_lines_from_brute_force": {"gpu_ms": g_ab * 1e3, "cpu_oracle_ms": c_ab * 1e3, "n_matches": int((r_ab[0] >= 0).sum()), "equal": bool(np.array_equal(r_ab[0], e_ab[0]))},
+    "match_lines_last_kf": {"gpu_ms": g_lk * 1e3, "cpu_oracle_ms": c_lk * 1e3, "n_created": int(r_lk[1].sum()),
+                            "equal": bool(np.array_equal(r_lk[0], e_lk[0]) and np.array_equal(r_lk[1], e_lk[1]))},
+}
 ctx.close()
 print(json.dumps(out))
