@@ -255,5 +255,60 @@ class TwoFrameLineMatcher {
   bool has_geometry_ = false;
 };
 
+// The line half of `class Tracking` (include/Tracking.h) that runs on the device: the two temporal line matchers.
+struct MapLineSet {            // what AddLinesFrom reads off its MapLine* list (GetMinimalPos, GetMainPoints3D, descriptor row, skip rule :1023-1034)
+  std::vector<double> X0, dir, X1, X2;      // [n][3] each
+  std::vector<uint8_t> skip;                 // [n] or empty
+  std::vector<float> desc;                   // [n][dim]
+  int size() const { return (int)(X0.size() / 3); }
+};
+struct FrameLines {            // the line members of a stereo Frame
+  std::vector<float> left, right;            // [n][4] / [n_right][4] startPointX, startPointY, endPointX, endPointY (mvLinesLeft / mvLinesRight)
+  std::vector<int32_t> left_octave, line_matches;   // [n]
+  std::vector<uint8_t> occupied;             // [n] mvpMapLines[i] != NULL (AddLinesFrom) / tracked-in-this-frame (last frame of MatchLinesLastKF), or empty
+  std::vector<float> desc;                   // [n][dim] mDescriptorsLines
+  int size() const { return (int)(left.size() / 4); }
+};
+class Tracking {
+ public:
+  Tracking(Context& ctx, const double K[9], double b, double mnMaxX, double mnMaxY, double mdThr, bool monocular = false)
+      : ctx_(ctx), b_(b), sx_(1.0 / mnMaxX), sy_(1.0 / mnMaxY), mdThr_(mdThr), mono_(monocular) { for (int i = 0; i < 9; i++) K_[i] = K[i]; }
+  // Tracking::AddLinesFrom (src/Tracking.cc:996-1124): matches[i] = line of `frame` given to map line i, or -1 (the caller sets
+  // frame->mvpMapLines[matches[i]] and tracked_last_id).  T_curr: camera-to-world, row-major 4x4.
+  void AddLinesFrom(const MapLineSet& lines_last, const double T_curr[16], double thrReprojLineBase, const FrameLines& frame, int dim,
+                    std::vector<int>* matches, bool use_grid = true) const {
+    lld_line_track_params p{};
+    for (int i = 0; i < 9; i++) p.K[i] = K_[i];
+    for (int i = 0; i < 16; i++) p.T_curr[i] = T_curr[i];
+    p.b = b_; p.thr_reproj_base = thrReprojLineBase; p.md_thr = mdThr_; p.sx = sx_; p.sy = sy_; p.monocular = mono_; p.use_grid = use_grid;
+    matches->assign(lines_last.size(), -1);
+    check(lld_line_track_match(ctx_.get(), &p, lines_last.size(), lines_last.X0.data(), lines_last.dir.data(), lines_last.X1.data(), lines_last.X2.data(),
+                               lines_last.skip.empty() ? nullptr : lines_last.skip.data(), lines_last.desc.data(), frame.size(), frame.left.data(),
+                               frame.left_octave.data(), (int)(frame.right.size() / 4), frame.right.data(), frame.line_matches.data(),
+                               frame.occupied.empty() ? nullptr : frame.occupied.data(), frame.desc.data(), dim, matches->data(), nullptr, nullptr),
+          "lld_line_track_match");
+  }
+  // Tracking::MatchLinesLastKF (src/Tracking.cc:1449-1611): created[i] != 0 -> the reference constructs MapLine(X0[i], dir[i]) for line i
+  // of the current frame; match_last[i] is the line of the last frame it was matched with.  last.occupied plays last_skip (:1517-1520).
+  void MatchLinesLastKF(const double T_curr[16], const double T_last[16], const FrameLines& current, const FrameLines& last, int dim,
+                        std::vector<int>* match_last, std::vector<uint8_t>* created, std::vector<double>* X0, std::vector<double>* dir,
+                        double thrReprojLineBase = 6.0, bool use_grid = true) const {
+    lld_line_lastkf_params p{};
+    for (int i = 0; i < 9; i++) p.K[i] = K_[i];
+    for (int i = 0; i < 16; i++) { p.T_curr[i] = T_curr[i]; p.T_last[i] = T_last[i]; }
+    p.b = b_; p.thr_reproj_base = thrReprojLineBase; p.md_thr = mdThr_; p.sx = sx_; p.sy = sy_; p.use_grid = use_grid;
+    const int n = current.size();
+    match_last->assign(n, -1); created->assign(n, 0); X0->assign(3 * (size_t)n, 0.0); dir->assign(3 * (size_t)n, 0.0);
+    check(lld_line_match_last_frame(ctx_.get(), &p, n, current.left.data(), (int)(current.right.size() / 4), current.right.data(), current.line_matches.data(),
+                                    current.occupied.empty() ? nullptr : current.occupied.data(), current.desc.data(), last.size(), last.left.data(),
+                                    last.left_octave.data(), (int)(last.right.size() / 4), last.right.data(), last.line_matches.data(),
+                                    last.occupied.empty() ? nullptr : last.occupied.data(), last.desc.data(), dim, match_last->data(), created->data(),
+                                    X0->data(), dir->data()), "lld_line_match_last_frame");
+  }
+ private:
+  Context& ctx_;
+  double K_[9]; double b_, sx_, sy_, mdThr_; bool mono_;
+};
+
 }  // namespace lld_amd
 #endif
