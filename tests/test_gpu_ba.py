@@ -87,6 +87,39 @@ def test_gamma_and_iteration_parameters(gpu_ctx, oracle):
              oracle.local_ba(w, gamma=0.5, its_round1=3, its_round2=4), w)
 
 
+def _with_long_tracks(w, n_long=5, seed=3):
+    """Gives the first `n_long` points an observation in EVERY camera that has them in front (a long track of global BA)."""
+    import oracle_py as O
+    rng = np.random.default_rng(seed)
+    fx, fy, cx, cy, bf = w.cam
+    start, cam, uvr, s2 = [0], [], [], []
+    for p in range(w.n_points):
+        o0, o1 = w.pt_obs_start[p], w.pt_obs_start[p + 1]
+        if p < n_long:
+            for c in range(w.n_cams):
+                Xc = O.se3_map(w.cam_qt[c], w.pt_xyz[p])
+                if Xc[2] < 2.0:
+                    continue
+                u, v = fx * Xc[0] / Xc[2] + cx, fy * Xc[1] / Xc[2] + cy
+                cam.append(c); uvr.append([u + rng.normal(0, 1), v + rng.normal(0, 1), u - bf / Xc[2] + rng.normal(0, 1)]); s2.append(1.0)
+        else:
+            cam.extend(w.pt_obs_cam[o0:o1]); uvr.extend(w.pt_obs_uvr[o0:o1]); s2.extend(w.pt_obs_inv_sigma2[o0:o1])
+        start.append(len(cam))
+    w.pt_obs_start = np.array(start, np.int32); w.pt_obs_cam = np.array(cam, np.int32)
+    w.pt_obs_uvr = np.array(uvr, np.float64).reshape(-1, 3); w.pt_obs_inv_sigma2 = np.array(s2, np.float64)
+    return w.normalise()
+
+
+def test_landmarks_with_more_than_64_free_observations(gpu_ctx, oracle):
+    """A landmark seen by more than 64 free cameras does not fit the lane-per-(landmark, slot) staging of the Schur kernel nor one
+    wavefront of the lane-per-edge kernels: ba_schur_wide_kernel and the single-landmark task path (round 1 produced a wrong reduced
+    system for such tracks without saying so)."""
+    w = _with_long_tracks(synth.make_ba_window(90, 2, 600, 5, 40, 4, seed=0x6BA00077))
+    k = np.diff(w.pt_obs_start)
+    assert k[:5].max() > 64 and np.add.reduceat((w.pt_obs_cam < w.n_free_cams).astype(int), w.pt_obs_start[:-1])[:5].max() > 64
+    check_ba(Optimizer(gpu_ctx).GlobalBundleAdjustment(w, 4), oracle.local_ba(w, protocol=1, its_round1=4), w)
+
+
 def test_noise_free_window_recovers_ground_truth(gpu_ctx):
     w = synth.make_lba_small(7, n_free=5, n_fixed=2, n_points=200, n_lines=40, outlier_frac=0.0, noise=0.0)
     g = Optimizer(gpu_ctx).LocalBundleAdjustment(w)
