@@ -8,14 +8,17 @@
 //
 // Kernel <-> reference map
 //   ba_linearize   computeActiveErrors + activeRobustChi2 + buildSystem   sparse_optimizer.cpp:61-114, block_solver.hpp:502-560,
-//                  (per-edge residual, Jacobians, Huber weight,           base_binary_edge.hpp:54-120, types_six_dof_expmap.cpp
-//                   Hll/bl in registers, Hpl block per edge, Hpp/bp
-//                   through LDS-staged per-camera 6x6 accumulators)
+//                  (per-edge residual, Huber weight, closed-form blocks:  base_binary_edge.hpp:54-120, types_six_dof_expmap.cpp
+//                   Hll/bl by a segmented shuffle sum, the weight of a
+//                   point edge / the Hpl block of a line observation,
+//                   Hpp/bp through LDS-staged per-camera accumulators)
 //   ba_begin       LM iteration head: chi2, lambda init                    optimization_algorithm_levenberg.cpp:75-99,166-180
-//   ba_schur       setLambda + Schur complement                            block_solver.hpp:373-439,564-589
-//                  (LDS-resident tile of 6x6 S blocks per camera row group)
-//   ba_pcg         reduced camera system solve (block-Jacobi PCG instead   linear_solver_eigen.h:94-124 (exact LDLT there)
-//                  of sparse LDLT) + camera oplus
+//   ba_schur       setLambda + Schur complement: Z = W L^-T per (landmark,    block_solver.hpp:373-439,564-589
+//                  slot) through LDS, whole 6x6 products Z_a Z_b^T in
+//                  registers per chunk, fixed-order reduction into S
+//   ba_chol_mfma   reduced camera system solve (exact Cholesky on the      linear_solver_eigen.h:94-124 (sparse LDLT there)
+//   ba_chol/ba_pcg fp64 matrix cores; vector-ALU Cholesky and block-
+//                  Jacobi PCG as alternatives) + camera oplus
 //   ba_backsub     landmark back-substitution, oplus, trial chi2           block_solver.hpp:459-483, sparse_optimizer.cpp:422-435
 //   ba_control     accept / reject, lambda update, stop rules              optimization_algorithm_levenberg.cpp:102-164
 //   ba_classify    outlier levels between the two rounds                   Optimizer.cc:1239-1267, LineOptimizer.cc:129-170
@@ -293,18 +296,6 @@ __device__ __forceinline__ void chol_solve(const double* U, double lambda, const
   }
 }
 
-// packed upper (row-major) <-> full
-template <int D>
-__device__ __forceinline__ void unpack_sym(const double* U, double lambda, double* F) {
-  int k = 0;
-#pragma unroll
-  for (int i = 0; i < D; i++)
-#pragma unroll
-    for (int j = i; j < D; j++) { F[i * D + j] = U[k]; F[j * D + i] = U[k]; k++; }
-#pragma unroll
-  for (int i = 0; i < D; i++) F[i * D + i] += lambda;
-}
-
 __device__ __forceinline__ Pose load_cam(const BAArrays& A, int buf, int cam_global) {
   return pose_load(A.cam_qt + ((size_t)buf * A.NC + cam_global) * 7);
 }
@@ -420,20 +411,6 @@ __device__ __forceinline__ void point_edge_linearize(const BAArrays& A, const BA
   point_jac_pose(W.cam, Xc, L.stereo, L.Jc);
 }
 struct PtObs { double u, v, ur, s; };
-// same with every operand already in registers (pose from the LDS copy, observation loaded up front): no dependent loads
-__device__ __forceinline__ double point_edge_linearize_r(const BAWin& W, const Pose& T, const Vec3& X, const PtObs& ob, uint8_t fl, PtEdgeLin& L) {
-  const Vec3 Xc = pose_map(T, X);
-  L.stereo = !(ob.ur < 0);
-  point_residual(W.cam, Xc, ob.u, ob.v, ob.ur, L.stereo, true, L.r);
-  const double c2 = chi2_of(L.r, L.stereo ? 3 : 2, ob.s);
-  double w = 1.0;
-  L.rho0 = c2;
-  if (fl & EF_ROBUST) L.rho0 = huber(c2, L.stereo ? W.th_stereo : W.th_mono, &w);
-  L.ws = w * ob.s;
-  point_jac_point(W.cam, Xc, quat_rotation(T.q), L.stereo, L.Jp);
-  point_jac_pose(W.cam, Xc, L.stereo, L.Jc);
-  return c2;
-}
 // landmark side Hll (6 upper) + b_l (3) of one edge
 __device__ __forceinline__ void point_edge_hll(const PtEdgeLin& L, double* hb) {
   int k = 0;
