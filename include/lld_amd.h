@@ -125,8 +125,10 @@ typedef struct {
                                    result flags 0; line edges carry identity information and the Huber delta thHuber3D/2
                                    (AddLineMinimalGlobal, :149-240), `gamma` and `ln_filter` are ignored.  The window holds the whole
                                    map: every keyframe but mnId==0 free.  Limits of this build: n_free_cams <= 170 per window in general,
-                                   <= 590 when the batch has at most 8 windows (then the reduced system is solved by the
-                                   multi-workgroup PCG whatever `reduced_solver` says, except 2)                       */
+                                   <= 8192 when the batch has at most 8 windows (then the reduced system - dense, 6 n_free squared
+                                   doubles of HBM - is solved by the multi-workgroup PCG whatever `reduced_solver` says, except 2;
+                                   beyond 590 cameras the camera accumulators and pose copies of the landmark kernels live in HBM
+                                   instead of LDS)                                                                     */
   int32_t robust_points;    /* protocol 1 only: bRobust (Huber kernels on the point edges, default 1); lines are always robust */
 } lld_ba_params;
 

@@ -35,6 +35,7 @@ struct lld_ba_batch {
   int* d_counters = nullptr; int* h_counters = nullptr;               // device / pinned, 4 ints per group
   int max_lblocks = 0, max_items_pt = 0, max_items_ln = 0, max_free = 0, max_cams = 0, max_blk = 0, acc_copies = 4;
   bool pcg_multi = false;
+  bool big = false;                                       // a map beyond kMaxFreeCamsLds cameras: accumulators and poses of the linearise / back-substitution kernels in HBM
   size_t schur_lds[2] = {0, 0}; size_t schur_wide_lds = 0;
   int chunk_landmarks = 32;
   size_t S_total = 0, x_total = 0;
@@ -427,6 +428,13 @@ static int ba_batch_create_impl(lld_ctx* ctx, int n_windows, const lld_ba_window
   });
   if (first_error.load() != LLD_OK) { const int st = first_error.load(); delete B; return st; }
   // ---- where each window's variable-length pieces go
+  // more cameras than the LDS holds accumulators and pose copies for (a global BA of a long sequence): those live in HBM (BAWin::big)
+  bool big_map = false;
+  for (int wi = 0; wi < n_windows; wi++) {
+    const size_t nf = (size_t)wins[wi].n_free_cams, nc = (size_t)wins[wi].n_cams;
+    if (nf > (size_t)kMaxFreeCamsLds || (nf * 27 + 8 + nc * 7) * sizeof(double) > 158 * 1024 || (8 + nc * 14 + nf * 6) * sizeof(double) > 158 * 1024) big_map = true;
+  }
+  if (std::getenv("LLD_BA_FORCE_BIG")) big_map = true;            // tests: the HBM path on windows of any size
   struct Place { size_t ptask, ltask, chunk, lm, tab, cams, blk_start, blk_src, cam_start, cam_src, part, cpart; };
   std::vector<Place> place(n_windows + 1);
   size_t n_hpart = 0; long long NPART = 0; int max_blk = 0;
@@ -439,7 +447,7 @@ static int ba_batch_create_impl(lld_ctx* ctx, int n_windows, const lld_ba_window
       W.ptask_off = (int)q.ptask; W.ltask_off = (int)q.ltask; W.item_off = (int)q.chunk;
       W.n_items_pt = (int)S.cs[0].chunks.size(); W.n_items = W.n_items_pt + (int)S.cs[1].chunks.size();
       W.blk_csr_off = (int)q.blk_start; W.cam_csr_off = (int)q.cam_start;
-      W.hpart_off = (long long)n_hpart; n_hpart += (size_t)(W.nl_pt + W.nl_ln) * W.n_free * 27;
+      W.hpart_off = (long long)n_hpart; n_hpart += (size_t)(big_map ? 1 : W.nl_pt + W.nl_ln) * W.n_free * 27;
       W.part_off = (int)NPART; NPART += W.nt_pt + W.nt_ln;
       q.ptask += S.ptasks.size(); q.ltask += S.ltasks.size(); q.chunk += (size_t)W.n_items;
       q.lm += S.cs[0].sg_lm.size() + S.cs[1].sg_lm.size(); q.tab += S.cs[0].sg_tab.size() + S.cs[1].sg_tab.size(); q.cams += S.cs[0].sg_cams.size() + S.cs[1].sg_cams.size();
@@ -493,15 +501,16 @@ static int ba_batch_create_impl(lld_ctx* ctx, int n_windows, const lld_ba_window
   });
   if (first_error.load() != LLD_OK) { const int st = first_error.load(); delete B; return st; }
   stages.clear();
-  if (B->max_cams > kPcgThreads) { delete B; return LLD_ERR_UNSUPPORTED; }
   // few windows whose reduced system is beyond the matrix-core Cholesky: the PCG runs across the whole GPU (see ba_pcgm_*)
   B->pcg_multi = n_windows <= 8 && B->max_free * 6 > kCholMN && P.reduced_solver != 2;
   if (B->max_free > kMaxFreeCamsOneWg && !B->pcg_multi) { delete B; return LLD_ERR_UNSUPPORTED; }   // batches of huge windows: not in this build
+  if (B->max_cams > kPcgThreads && !B->pcg_multi) { delete B; return LLD_ERR_UNSUPPORTED; }           // (the one-workgroup solvers move one camera per lane)
+  B->big = big_map;
   // LDS copies of the per-camera accumulators in the linearise kernels: as many as fit (4 for local windows)
-  B->acc_copies = kAccCopies;
-  while (B->acc_copies > 1 && ((size_t)B->max_free * 27 * B->acc_copies + 8 + (size_t)B->max_cams * 7) * sizeof(double) > 150 * 1024) B->acc_copies >>= 1;
-  if (((size_t)B->max_free * 27 * B->acc_copies + 8 + (size_t)B->max_cams * 7) * sizeof(double) > 158 * 1024) { delete B; return LLD_ERR_UNSUPPORTED; }
-  for (int wi = 0; wi < n_windows; wi++) { B->h_wins[wi].acc_copies = B->acc_copies; B->h_wins[wi].win_index = wi; }
+  B->acc_copies = B->big ? 1 : kAccCopies;
+  while (!B->big && B->acc_copies > 1 && ((size_t)B->max_free * 27 * B->acc_copies + 8 + (size_t)B->max_cams * 7) * sizeof(double) > 150 * 1024) B->acc_copies >>= 1;
+  if (!B->big && ((size_t)B->max_free * 27 * B->acc_copies + 8 + (size_t)B->max_cams * 7) * sizeof(double) > 158 * 1024) { delete B; return LLD_ERR_UNSUPPORTED; }
+  for (int wi = 0; wi < n_windows; wi++) { B->h_wins[wi].acc_copies = B->acc_copies; B->h_wins[wi].win_index = wi; B->h_wins[wi].big = B->big ? 1 : 0; }
   B->max_blk = max_blk;
   // fixed-stride result records (what an RCCL gather of the batch moves)
   for (int wi = 0; wi < n_windows; wi++) B->h_wins[wi].rec_off = (long long)(B->rec_stride * (size_t)wi);
@@ -572,12 +581,12 @@ static int ba_batch_create_impl(lld_ctx* ctx, int n_windows, const lld_ba_window
   {
     const size_t pcg_lds = ((size_t)B->max_free * 6 * 4 + kPcgThreads + (size_t)B->max_free * 36 + 32) * sizeof(double);
     if (!B->pcg_multi) LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_pcg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pcg_lds));
-    const size_t bs_lds0 = (8 + (size_t)B->max_cams * 14 + (size_t)B->max_free * 6) * sizeof(double);
+    const size_t bs_lds0 = B->big ? 64 : (8 + (size_t)B->max_cams * 14 + (size_t)B->max_free * 6) * sizeof(double);
     if (bs_lds0 > 48 * 1024) {
       LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_backsub_pt_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bs_lds0));
       LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_backsub_both_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bs_lds0));
     }
-    const size_t lin_lds = ((size_t)B->max_free * 27 * B->acc_copies + 8 + (size_t)B->max_cams * 7) * sizeof(double);
+    const size_t lin_lds = B->big ? 64 : ((size_t)B->max_free * 27 * B->acc_copies + 8 + (size_t)B->max_cams * 7) * sizeof(double);
     LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_linearize_pt_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lin_lds));
     LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_linearize_ln_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lin_lds));
     LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_linearize_both_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lin_lds));
@@ -616,8 +625,8 @@ int lld_ba_batch_solve(lld_ba_batch* B, volatile const int* abort_flag) {
   hipEvent_t t_begin, t_end;
   LLD_HIP_TRY(hipEventCreate(&t_begin)); LLD_HIP_TRY(hipEventCreate(&t_end));
   LLD_HIP_TRY(hipEventRecord(t_begin, ctx->stream));
-  const size_t lin_lds = ((size_t)B->max_free * 27 * B->acc_copies + 8 + (size_t)B->max_cams * 7) * sizeof(double);
-  const size_t bs_lds = (8 + (size_t)B->max_cams * 14 + (size_t)B->max_free * 6) * sizeof(double);
+  const size_t lin_lds = B->big ? 64 : ((size_t)B->max_free * 27 * B->acc_copies + 8 + (size_t)B->max_cams * 7) * sizeof(double);
+  const size_t bs_lds = B->big ? 64 : (8 + (size_t)B->max_cams * 14 + (size_t)B->max_free * 6) * sizeof(double);
   const size_t pcg_lds = ((size_t)B->max_free * 6 * 4 + kPcgThreads + (size_t)B->max_free * 36 + 32) * sizeof(double);
   const size_t chol_fixed = ((size_t)B->max_free * 36 * 2 + (size_t)B->max_free * 6 * 2 + 32) * sizeof(double);
   // whatever LDS is left (a workgroup may own up to 160 KiB) holds the trailing block triangle of S
@@ -641,8 +650,11 @@ int lld_ba_batch_solve(lld_ba_batch* B, volatile const int* abort_flag) {
     const int abort_now = (abort_flag && *abort_flag) ? 1 : 0;
     LLD_HIP_TRY(hipMemsetAsync(G.d_counters, 0, 4 * sizeof(int), st));
     LLD_HIP_TRY(hipEventRecord(G.ev[0], st));
-    const bool fuse_pairs = B->n_windows < kFusePairsBelowWindows;                           // see ba_linearize_both_kernel
-    if (fuse_pairs && G.max_nl_pt > 0 && G.max_nl_ln > 0) hipLaunchKernelGGL(ba_linearize_both_kernel, dim3(G.max_nl_pt + G.max_nl_ln, nw), dim3(kLinThreads), lin_lds, st, A, dw, ds, G.max_nl_pt);
+    const bool fuse_pairs = B->n_windows < kFusePairsBelowWindows && !B->big;                // see ba_linearize_both_kernel
+    if (B->big) {
+      if (G.max_nl_pt > 0) hipLaunchKernelGGL(ba_linearize_pt_big_kernel, dim3(G.max_nl_pt, nw), dim3(kLinThreads), lin_lds, st, A, dw, ds);
+      if (G.max_nl_ln > 0) hipLaunchKernelGGL(ba_linearize_ln_big_kernel, dim3(G.max_nl_ln, nw), dim3(kLinThreads), lin_lds, st, A, dw, ds);
+    } else if (fuse_pairs && G.max_nl_pt > 0 && G.max_nl_ln > 0) hipLaunchKernelGGL(ba_linearize_both_kernel, dim3(G.max_nl_pt + G.max_nl_ln, nw), dim3(kLinThreads), lin_lds, st, A, dw, ds, G.max_nl_pt);
     else {
       if (G.max_nl_pt > 0) hipLaunchKernelGGL(ba_linearize_pt_kernel, dim3(G.max_nl_pt, nw), dim3(kLinThreads), lin_lds, st, A, dw, ds);
       if (G.max_nl_ln > 0) hipLaunchKernelGGL(ba_linearize_ln_kernel, dim3(G.max_nl_ln, nw), dim3(kLinThreads), lin_lds, st, A, dw, ds);
@@ -685,7 +697,10 @@ int lld_ba_batch_solve(lld_ba_batch* B, volatile const int* abort_flag) {
     else
       hipLaunchKernelGGL(ba_chol_kernel, dim3(nw), dim3(kPcgThreads), chol_lds, st, A, dw, ds, (int)(chol_tri / sizeof(double)));
     LLD_HIP_TRY(hipEventRecord(G.ev[3], st));
-    if (fuse_pairs && G.max_nt_pt > 0 && G.max_nb_ln > 0) hipLaunchKernelGGL(ba_backsub_both_kernel, dim3(G.max_nt_pt + G.max_nb_ln, nw), dim3(kLmThreads), bs_lds, st, A, dw, ds, G.max_nt_pt);
+    if (B->big) {
+      if (G.max_nt_pt > 0) hipLaunchKernelGGL(ba_backsub_pt_big_kernel, dim3(G.max_nt_pt, nw), dim3(kLmThreads), bs_lds, st, A, dw, ds);
+      if (G.max_nb_ln > 0) hipLaunchKernelGGL(ba_backsub_ln_kernel, dim3(G.max_nb_ln, nw), dim3(kLmThreads), 0, st, A, dw, ds);
+    } else if (fuse_pairs && G.max_nt_pt > 0 && G.max_nb_ln > 0) hipLaunchKernelGGL(ba_backsub_both_kernel, dim3(G.max_nt_pt + G.max_nb_ln, nw), dim3(kLmThreads), bs_lds, st, A, dw, ds, G.max_nt_pt);
     else {
       if (G.max_nt_pt > 0) hipLaunchKernelGGL(ba_backsub_pt_kernel, dim3(G.max_nt_pt, nw), dim3(kLmThreads), bs_lds, st, A, dw, ds);
       if (G.max_nb_ln > 0) hipLaunchKernelGGL(ba_backsub_ln_kernel, dim3(G.max_nb_ln, nw), dim3(kLmThreads), 0, st, A, dw, ds);

@@ -49,7 +49,8 @@ constexpr int kRoundsThroughputMinWindows = 32;
 constexpr int kAccCopies = 4;          // (default; BAWin::acc_copies drops to 2 or 1 when a window's cameras would not fit LDS otherwise)
 constexpr int kAccCopiesDoc = 4;          // LDS copies of the per-camera Hpp/bp accumulators: lanes of one wavefront that hit the
                                        // same camera are spread over them (same-address LDS atomics serialise)
-constexpr int kMaxFreeCams = 590;        // LDS of the linearise accumulators (216 B + 56 B per camera); the one-workgroup reduced solvers
+constexpr int kMaxFreeCams = 8192;       // (S is dense: 6 n_free squared doubles); up to 590 the linearise accumulators (216 B + 56 B per camera) live in LDS,
+constexpr int kMaxFreeCamsLds = 590;     // beyond that in HBM (BAWin::big); the one-workgroup reduced solvers
 constexpr int kMaxFreeCamsOneWg = 170;   // map one lane to one unknown (6 * 170 <= 1024), larger windows need the multi-workgroup PCG
 
 enum Phase : int { PH_RUN = 0, PH_TRANSITION = 2, PH_FINALIZE = 3, PH_DONE = 4 };
@@ -78,6 +79,7 @@ struct BAWin {                 // immutable per-window header
   int part_off;                // per-block partial sums
   int its[2];                  // LM iterations per round
   int max_trials, ln_filter;
+  int big;                     // more cameras than the LDS of the linearise / back-substitution kernels holds: accumulators and poses in HBM
   int protocol, robust_pts, acc_copies;   // acc_copies: LDS copies of the per-camera accumulators in the linearise kernels (4, 2 or 1)
   int win_index;               // index of the window in its batch (slot of the multi-workgroup PCG scalars)    // lld_ba_params::protocol / robust_points (1 = global BA: one round, no classification)
   double th_mono, th_stereo;   // Huber deltas of point edges  ((double)(float)sqrt(5.991 / 7.815))
@@ -357,6 +359,7 @@ __global__ __launch_bounds__(kLmThreads) void ba_init_kernel(BAArrays A, const B
   }
   for (int i = gid; i < W.n_free * 21; i += stride) A.Hpp[(size_t)W.hpp_off * 21 + i] = 0.0;
   for (int i = gid; i < W.n_free * 6; i += stride) A.bp[(size_t)W.hpp_off * 6 + i] = 0.0;
+  if (W.big) for (int i = gid; i < W.n_free * 27; i += stride) A.hpp_part[W.hpart_off + i] = 0.0;
   if (gid == 0) {
     BAState s;
     memset(&s, 0, sizeof s);
@@ -493,6 +496,9 @@ __device__ __forceinline__ double point_edge_blocks_closed(const BAWin& W, const
 }
 
 // grid (nl_pt, nW), block 512 = 8 wavefronts, BAWin::rounds tasks per wavefront; dynamic LDS: kAccCopies*n_free_max*27 doubles + 8 scratch.
+// kBig (a map with more cameras than the LDS holds accumulators and poses for, BAWin::big): the camera accumulators are ONE row in HBM
+// (zeroed by ba_init / ba_control / ba_round2, added to with global fp64 atomics) and the poses are read from HBM.
+template <bool kBig>
 __device__ __forceinline__ void ba_linearize_pt_body(const BAArrays& A, const BAWin* __restrict__ wins, BAState* __restrict__ st, const int bx) {   // bx: the workgroup's index along x
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const BAWin W = wins[blockIdx.y];
@@ -500,13 +506,17 @@ __device__ __forceinline__ void ba_linearize_pt_body(const BAArrays& A, const BA
   if (S.phase != PH_RUN || !S.need_lin) return;
   if ((int)bx >= W.nl_pt) return;
   const int nacc = W.n_free * 27;
-  double* acc_all = lds;                              // kAccCopies x [n_free][21 Hpp upper + 6 bp]
-  double* scratch = lds + W.acc_copies * nacc;
-  double* cams = scratch + 8;                         // [n_cams][7] poses of the linearisation point
-  for (int i = threadIdx.x; i < W.acc_copies * nacc; i += kLinThreads) acc_all[i] = 0.0;
-  double* acc = acc_all + ((threadIdx.x >> 3) & (W.acc_copies - 1)) * nacc;
   const int cur = S.cur;
-  for (int i = threadIdx.x; i < W.n_cams * 7; i += kLinThreads) cams[i] = A.cam_qt[((size_t)cur * A.NC + W.cam_off) * 7 + i];
+  double* acc_all = kBig ? A.hpp_part + W.hpart_off : lds;   // kAccCopies x [n_free][21 Hpp upper + 6 bp]
+  double* scratch = kBig ? lds : lds + W.acc_copies * nacc;
+  double* cams_l = scratch + 8;                              // [n_cams][7] poses of the linearisation point
+  const double* cams = kBig ? A.cam_qt + ((size_t)cur * A.NC + W.cam_off) * 7 : cams_l;
+  double* acc = acc_all;
+  if (!kBig) {
+    for (int i = threadIdx.x; i < W.acc_copies * nacc; i += kLinThreads) acc_all[i] = 0.0;
+    acc = acc_all + ((threadIdx.x >> 3) & (W.acc_copies - 1)) * nacc;
+    for (int i = threadIdx.x; i < W.n_cams * 7; i += kLinThreads) cams_l[i] = A.cam_qt[((size_t)cur * A.NC + W.cam_off) * 7 + i];
+  }
   __syncthreads();
   const int lane = threadIdx.x & 63;
   double chi = 0.0, maxd = 0.0;
@@ -597,6 +607,7 @@ __device__ __forceinline__ void ba_linearize_pt_body(const BAArrays& A, const BA
     atomicMax(&S.maxdiag_bits, (unsigned long long)__double_as_longlong(max_t));
   }
   __syncthreads();
+  if (kBig) return;
   // plain stores of this workgroup's camera partials; ba_hpp_reduce sums them in a fixed order (no global atomics)
   double* dst = A.hpp_part + W.hpart_off + (size_t)(bx) * nacc;
   for (int i = threadIdx.x; i < nacc; i += kLinThreads) {
@@ -605,7 +616,8 @@ __device__ __forceinline__ void ba_linearize_pt_body(const BAArrays& A, const BA
     dst[i] = v;
   }
 }
-__global__ __launch_bounds__(kLinThreads, 4) void ba_linearize_pt_kernel(BAArrays A, const BAWin* __restrict__ wins, BAState* __restrict__ st) { ba_linearize_pt_body(A, wins, st, (int)blockIdx.x); }
+__global__ __launch_bounds__(kLinThreads, 4) void ba_linearize_pt_kernel(BAArrays A, const BAWin* __restrict__ wins, BAState* __restrict__ st) { ba_linearize_pt_body<false>(A, wins, st, (int)blockIdx.x); }
+__global__ __launch_bounds__(kLinThreads, 4) void ba_linearize_pt_big_kernel(BAArrays A, const BAWin* __restrict__ wins, BAState* __restrict__ st) { ba_linearize_pt_body<true>(A, wins, st, (int)blockIdx.x); }
 
 // W_e^T x_c = ws * Jp^T (Jc x_c) of one point edge with the Jacobians of the linearisation point
 __device__ __forceinline__ void point_edge_wtx(const BAArrays& A, const BAWin& W, int cur, int e, uint8_t fl, int c, const Vec3& X, const double* xp, double* t) {
@@ -653,6 +665,7 @@ __device__ __forceinline__ double point_backsub(const double* V, double lambda, 
 }
 
 // grid (nt_pt, nW), block 256 = 4 wavefronts, BAWin::rounds tasks per wavefront; dynamic LDS: 8 + 14 n_cams + 6 n_free doubles
+template <bool kBig>
 __device__ __forceinline__ void ba_backsub_pt_body(const BAArrays& A, const BAWin* __restrict__ wins, const BAState* __restrict__ st, const int bx) {   // bx: the workgroup's index along x
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const BAWin W = wins[blockIdx.y];
@@ -665,14 +678,20 @@ __device__ __forceinline__ void ba_backsub_pt_body(const BAArrays& A, const BAWi
   // workgroup copies of what every edge lane gathers: poses of the linearisation point (camA) and of the trial state (camB),
   // and the camera part of the solution
   double* scratch = lds;
-  double* camA = lds + 8;
-  double* camB = camA + W.n_cams * 7;
-  double* xps = camB + W.n_cams * 7;
-  for (int i = threadIdx.x; i < W.n_cams * 7; i += kLmThreads) {
-    camA[i] = A.cam_qt[((size_t)cur * A.NC + W.cam_off) * 7 + i];
-    camB[i] = A.cam_qt[((size_t)nxt * A.NC + W.cam_off) * 7 + i];
+  double* camA_l = lds + 8;
+  double* camB_l = camA_l + W.n_cams * 7;
+  double* xps_l = camB_l + W.n_cams * 7;
+  // kBig: no LDS copies, the poses and x_c are read from HBM (see ba_linearize_pt_body)
+  const double* camA = kBig ? A.cam_qt + ((size_t)cur * A.NC + W.cam_off) * 7 : camA_l;
+  const double* camB = kBig ? A.cam_qt + ((size_t)nxt * A.NC + W.cam_off) * 7 : camB_l;
+  const double* xps = kBig ? xp : xps_l;
+  if (!kBig) {
+    for (int i = threadIdx.x; i < W.n_cams * 7; i += kLmThreads) {
+      camA_l[i] = A.cam_qt[((size_t)cur * A.NC + W.cam_off) * 7 + i];
+      camB_l[i] = A.cam_qt[((size_t)nxt * A.NC + W.cam_off) * 7 + i];
+    }
+    for (int i = threadIdx.x; i < 6 * W.n_free; i += kLmThreads) xps_l[i] = xp[i];
   }
-  for (int i = threadIdx.x; i < 6 * W.n_free; i += kLmThreads) xps[i] = xp[i];
   __syncthreads();
   const int lane = threadIdx.x & 63;
   double chi = 0.0, sc = 0.0;
@@ -772,7 +791,8 @@ __device__ __forceinline__ void ba_backsub_pt_body(const BAArrays& A, const BAWi
   const double sc_t = block_sum(sc, scratch);
   if (threadIdx.x == 0) { A.chi_part2[W.part_off + bx] = chi_t; A.scale_part[W.part_off + bx] = sc_t; }
 }
-__global__ __launch_bounds__(kLmThreads) void ba_backsub_pt_kernel(BAArrays A, const BAWin* __restrict__ wins, const BAState* __restrict__ st) { ba_backsub_pt_body(A, wins, st, (int)blockIdx.x); }
+__global__ __launch_bounds__(kLmThreads) void ba_backsub_pt_kernel(BAArrays A, const BAWin* __restrict__ wins, const BAState* __restrict__ st) { ba_backsub_pt_body<false>(A, wins, st, (int)blockIdx.x); }
+__global__ __launch_bounds__(kLmThreads) void ba_backsub_pt_big_kernel(BAArrays A, const BAWin* __restrict__ wins, const BAState* __restrict__ st) { ba_backsub_pt_body<true>(A, wins, st, (int)blockIdx.x); }
 
 // ================================================================== line landmarks: one lane per (line, KF) OBSERVATION
 // Same scheme as the point kernels with the observation as the unit: a lane linearises the left and (if present) right image
@@ -838,6 +858,7 @@ __device__ __forceinline__ double line_obs_linearize(const BAArrays& A, const BA
 }
 
 // grid (nl_ln, nW), block 512 = 8 wavefronts, BAWin::rounds tasks per wavefront; dynamic LDS: kAccCopies*n_free_max*27 doubles + 8 scratch.
+template <bool kBig>
 __device__ __forceinline__ void ba_linearize_ln_body(const BAArrays& A, const BAWin* __restrict__ wins, BAState* __restrict__ st, const int bx) {   // bx: the workgroup's index along x
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const BAWin W = wins[blockIdx.y];
@@ -845,10 +866,13 @@ __device__ __forceinline__ void ba_linearize_ln_body(const BAArrays& A, const BA
   if (S.phase != PH_RUN || !S.need_lin) return;
   if ((int)bx >= W.nl_ln) return;
   const int nacc = W.n_free * 27;
-  double* acc_all = lds;                              // kAccCopies x [n_free][21 Hpp upper + 6 bp]
-  double* scratch = lds + W.acc_copies * nacc;
-  for (int i = threadIdx.x; i < W.acc_copies * nacc; i += kLinThreads) acc_all[i] = 0.0;
-  double* acc = acc_all + ((threadIdx.x >> 3) & (W.acc_copies - 1)) * nacc;
+  double* acc_all = kBig ? A.hpp_part + W.hpart_off : lds;   // kAccCopies x [n_free][21 Hpp upper + 6 bp]; kBig: see ba_linearize_pt_body
+  double* scratch = kBig ? lds : lds + W.acc_copies * nacc;
+  double* acc = acc_all;
+  if (!kBig) {
+    for (int i = threadIdx.x; i < W.acc_copies * nacc; i += kLinThreads) acc_all[i] = 0.0;
+    acc = acc_all + ((threadIdx.x >> 3) & (W.acc_copies - 1)) * nacc;
+  }
   __syncthreads();
   const int cur = S.cur;
   const int lane = threadIdx.x & 63;
@@ -899,6 +923,7 @@ __device__ __forceinline__ void ba_linearize_ln_body(const BAArrays& A, const BA
     atomicMax(&S.maxdiag_bits, (unsigned long long)__double_as_longlong(max_t));
   }
   __syncthreads();
+  if (kBig) return;
   // plain stores of this workgroup's camera partials; ba_hpp_reduce sums them in a fixed order (no global atomics)
   double* dst = A.hpp_part + W.hpart_off + (size_t)(W.nl_pt + bx) * nacc;
   for (int i = threadIdx.x; i < nacc; i += kLinThreads) {
@@ -907,7 +932,8 @@ __device__ __forceinline__ void ba_linearize_ln_body(const BAArrays& A, const BA
     dst[i] = v;
   }
 }
-__global__ __launch_bounds__(kLinThreads) void ba_linearize_ln_kernel(BAArrays A, const BAWin* __restrict__ wins, BAState* __restrict__ st) { ba_linearize_ln_body(A, wins, st, (int)blockIdx.x); }
+__global__ __launch_bounds__(kLinThreads) void ba_linearize_ln_kernel(BAArrays A, const BAWin* __restrict__ wins, BAState* __restrict__ st) { ba_linearize_ln_body<false>(A, wins, st, (int)blockIdx.x); }
+__global__ __launch_bounds__(kLinThreads) void ba_linearize_ln_big_kernel(BAArrays A, const BAWin* __restrict__ wins, BAState* __restrict__ st) { ba_linearize_ln_body<true>(A, wins, st, (int)blockIdx.x); }
 
 __device__ __forceinline__ void line_obs_wtx(const BAArrays& A, const BAWin& W, int o, int c, const double* xp, double* t) {
   const double* Wb = A.lo_W + (size_t)o * 24;              // zero when both image edges are inactive
@@ -1020,11 +1046,11 @@ __global__ __launch_bounds__(kLmThreads) void ba_backsub_ln_kernel(BAArrays A, c
 // kernels of a pair are dependent launches of 8-16 us each on idle hardware.  Not for large batches: the fused kernel gets the
 // register budget of the line body (223 VGPRs), which would halve the occupancy of the point body.
 __global__ __launch_bounds__(kLinThreads) void ba_linearize_both_kernel(BAArrays A, const BAWin* __restrict__ wins, BAState* __restrict__ st, int n_pt_blocks) {
-  if ((int)blockIdx.x < n_pt_blocks) ba_linearize_pt_body(A, wins, st, (int)blockIdx.x);
-  else ba_linearize_ln_body(A, wins, st, (int)blockIdx.x - n_pt_blocks);
+  if ((int)blockIdx.x < n_pt_blocks) ba_linearize_pt_body<false>(A, wins, st, (int)blockIdx.x);
+  else ba_linearize_ln_body<false>(A, wins, st, (int)blockIdx.x - n_pt_blocks);
 }
 __global__ __launch_bounds__(kLmThreads) void ba_backsub_both_kernel(BAArrays A, const BAWin* __restrict__ wins, const BAState* __restrict__ st, int n_pt_blocks) {
-  if ((int)blockIdx.x < n_pt_blocks) ba_backsub_pt_body(A, wins, st, (int)blockIdx.x);
+  if ((int)blockIdx.x < n_pt_blocks) ba_backsub_pt_body<false>(A, wins, st, (int)blockIdx.x);
   else ba_backsub_ln_body(A, wins, st, (int)blockIdx.x - n_pt_blocks);
 }
 
@@ -1037,7 +1063,7 @@ __global__ __launch_bounds__(256) void ba_hpp_reduce_kernel(BAArrays A, const BA
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= nacc) return;
   const double* src = A.hpp_part + W.hpart_off + i;
-  const int nb = W.nl_pt + W.nl_ln;
+  const int nb = W.big ? 1 : W.nl_pt + W.nl_ln;          // big: the linearise kernels added into one row directly
   // a small batch has ~140 partial rows per window and every row sits in another XCD's L2: eight independent loads in flight,
   // summed in row order (bit-identical to the plain loop)
   double v = 0.0;
@@ -2236,6 +2262,7 @@ __global__ __launch_bounds__(kCtlThreads) void ba_control_kernel(BAArrays A, con
   if (do_clear) {
     for (int i = threadIdx.x; i < W.n_free * 21; i += kCtlThreads) A.Hpp[(size_t)W.hpp_off * 21 + i] = 0.0;
     for (int i = threadIdx.x; i < W.n_free * 6; i += kCtlThreads) A.bp[(size_t)W.hpp_off * 6 + i] = 0.0;
+    if (W.big) for (int i = threadIdx.x; i < W.n_free * 27; i += kCtlThreads) A.hpp_part[W.hpart_off + i] = 0.0;
   }
   if (threadIdx.x == 0) {
     const int ph = S.phase;
@@ -2317,6 +2344,7 @@ __global__ __launch_bounds__(kCtlThreads) void ba_round2_kernel(BAArrays A, cons
   __syncthreads();
   for (int i = threadIdx.x; i < W.n_free * 21; i += kCtlThreads) A.Hpp[(size_t)W.hpp_off * 21 + i] = 0.0;
   for (int i = threadIdx.x; i < W.n_free * 6; i += kCtlThreads) A.bp[(size_t)W.hpp_off * 6 + i] = 0.0;
+  if (W.big) for (int i = threadIdx.x; i < W.n_free * 27; i += kCtlThreads) A.hpp_part[W.hpart_off + i] = 0.0;
   __syncthreads();
   if (threadIdx.x == 0) {
     S.round = 1; S.it = 0; S.q = 0; S.need_lin = 1; S.maxdiag_bits = 0ull;

@@ -281,6 +281,29 @@ def test_large_window_limits(gpu_ctx, oracle):
         Optimizer(gpu_ctx).GlobalBundleAdjustment(big, 3, reduced_solver=2)          # the vector Cholesky stops at 170
 
 
+def test_global_ba_beyond_the_lds_limit(gpu_ctx, oracle):
+    """More than 590 free cameras: the camera accumulators of the linearisation and the pose copies of the landmark kernels no longer fit
+    the LDS and live in HBM (BAWin::big); the reduced system (3 960 unknowns) is solved by the multi-workgroup PCG."""
+    w = synth.make_ba_window(600, 2, 3000, 4, 200, 4, seed=0x6BA00660)
+    g = Optimizer(gpu_ctx).GlobalBundleAdjustment(w, 1)
+    check_ba(g, oracle.local_ba(w, protocol=1, its_round1=1), w)
+
+
+def test_hbm_accumulator_path_on_small_windows(gpu_ctx, oracle, monkeypatch):
+    """The same path (LLD_BA_FORCE_BIG) on windows the oracle solves quickly: both protocols, single windows and a batch."""
+    monkeypatch.setenv("LLD_BA_FORCE_BIG", "1")
+    for wid, kw in ((0, dict()), (4, dict(n_free=10, n_fixed=3, n_points=700, n_lines=120, outlier_frac=0.15))):
+        w = synth.make_lba_small(wid, **kw)
+        check_ba(Optimizer(gpu_ctx).LocalBundleAdjustment(w), oracle.local_ba(w), w)
+    w = synth.make_lba_small(46, n_free=171, n_fixed=1, n_points=1200, n_lines=40)
+    check_ba(Optimizer(gpu_ctx).GlobalBundleAdjustment(w, 3), oracle.local_ba(w, protocol=1, its_round1=3), w)
+    ws = [synth.make_lba_small(60 + i, n_free=4 + i, n_fixed=1, n_points=120 + 30 * i, n_lines=15 + 5 * i) for i in range(5)]
+    with BABatch(gpu_ctx, ws) as b:
+        b.solve()
+        for i, wi in enumerate(ws):
+            check_ba(b.download(i), oracle.local_ba(wi), wi)
+
+
 def test_global_and_local_protocols_share_a_batch_engine(gpu_ctx, oracle):
     """A resident batch solved with protocol 1 (e.g. one GBA problem per loop candidate)."""
     ws = [synth.make_lba_small(50 + i, n_free=5 + i, n_fixed=1, n_points=150 + 40 * i, n_lines=20 + 5 * i) for i in range(4)]
