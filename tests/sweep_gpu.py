@@ -1,5 +1,5 @@
 """Randomised GPU-vs-oracle sweep over every optimiser / matcher entry point (more seeds and sizes than the pytest cases; run by hand on the
-GPU box: python tests/sweep_gpu.py).  Prints the number of mismatches per family; round 1: 0 everywhere."""
+GPU box: python tests/sweep_gpu.py).  Prints the number of mismatches per family; rounds 1 and 2: 0 everywhere."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -78,3 +78,21 @@ for seed in range(100, 125):
     n_exp, slot = OS.search_by_projection_frame(F, q["desc"], q["valid"], q["uv"], q["ur"], q["level"], q["angle"], q["obs"], q["occupied"], 0, 15.0, True)
     if out.n_matches != n_exp or not np.array_equal(expect_slots(out, q["occupied"]), slot): bad += 1; print("frame mismatch", seed)
 print("orb searches checked 50 mismatches", bad)
+bad = 0
+from lld_slam_amd import Tracking
+for seed in range(200, 240):
+    P, L, F = synth.make_line_track_scene(seed, n_map=int(rng.integers(1, 400)), n_cur=int(rng.integers(1, 500)), related_frac=float(rng.uniform(0.2, 0.9)),
+                                          occupied_frac=float(rng.uniform(0, 0.3)), no_partner_frac=float(rng.uniform(0, 0.4)))
+    mono, grid = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+    trk = Tracking(ctx, P["K"], P["b"], 1.0 / P["sx"], 1.0 / P["sy"], mdThr=P["md_thr"], monocular=mono)
+    g = trk.AddLinesFrom(L, P["T_curr"], P["thr_reproj_base"], F, use_grid=grid)
+    o = O.line_track_match(P["K"], P["T_curr"], P["b"], P["thr_reproj_base"], P["md_thr"], P["sx"], P["sy"], L, F, monocular=mono, use_grid=grid)
+    if not (np.array_equal(g[0], o[0]) and np.array_equal(g[1][g[0] >= 0], o[1][o[0] >= 0])): bad += 1; print("AddLinesFrom mismatch", seed)
+    P2, cur, last, _ = synth.make_two_frame_lines(seed, n_lines=int(rng.integers(8, 400)), shared_frac=float(rng.uniform(0.2, 0.9)), baseline=float(rng.uniform(0.5, 3.0)))
+    trk2 = Tracking(ctx, P2["K"], P2["b"], 1.0 / P2["sx"], 1.0 / P2["sy"], mdThr=P2["md_thr"])
+    gm, gc, gx, gd = trk2.MatchLinesLastKF(P2["T_curr"], P2["T_last"], cur, last, P2["thr_reproj_base"], grid)
+    om, oc, ox, od = O.line_match_last_frame(P2["K"], P2["T_curr"], P2["T_last"], P2["b"], P2["thr_reproj_base"], P2["md_thr"], P2["sx"], P2["sy"], cur, last, grid)
+    okc = oc.astype(bool)
+    if not (np.array_equal(gm, om) and np.array_equal(gc, oc) and np.allclose(gx[okc], ox[okc], rtol=1e-6, atol=1e-6) and np.allclose(gd[okc], od[okc], atol=1e-7)):
+        bad += 1; print("MatchLinesLastKF mismatch", seed)
+print("line tracking scenes checked 80 mismatches", bad)
