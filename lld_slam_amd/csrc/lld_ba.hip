@@ -584,6 +584,7 @@ static int ba_batch_create_impl(lld_ctx* ctx, int n_windows, const lld_ba_window
     const size_t bs_lds0 = B->big ? 64 : (8 + (size_t)B->max_cams * 14 + (size_t)B->max_free * 6) * sizeof(double);
     if (bs_lds0 > 48 * 1024) {
       LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_backsub_pt_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bs_lds0));
+      LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_backsub_ln_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bs_lds0));
       LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_backsub_both_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bs_lds0));
     }
     const size_t lin_lds = B->big ? 64 : ((size_t)B->max_free * 27 * B->acc_copies + 8 + (size_t)B->max_cams * 7) * sizeof(double);
@@ -699,11 +700,11 @@ int lld_ba_batch_solve(lld_ba_batch* B, volatile const int* abort_flag) {
     LLD_HIP_TRY(hipEventRecord(G.ev[3], st));
     if (B->big) {
       if (G.max_nt_pt > 0) hipLaunchKernelGGL(ba_backsub_pt_big_kernel, dim3(G.max_nt_pt, nw), dim3(kLmThreads), bs_lds, st, A, dw, ds);
-      if (G.max_nb_ln > 0) hipLaunchKernelGGL(ba_backsub_ln_kernel, dim3(G.max_nb_ln, nw), dim3(kLmThreads), 0, st, A, dw, ds);
+      if (G.max_nb_ln > 0) hipLaunchKernelGGL(ba_backsub_ln_big_kernel, dim3(G.max_nb_ln, nw), dim3(kLmThreads), bs_lds, st, A, dw, ds);
     } else if (fuse_pairs && G.max_nt_pt > 0 && G.max_nb_ln > 0) hipLaunchKernelGGL(ba_backsub_both_kernel, dim3(G.max_nt_pt + G.max_nb_ln, nw), dim3(kLmThreads), bs_lds, st, A, dw, ds, G.max_nt_pt);
     else {
       if (G.max_nt_pt > 0) hipLaunchKernelGGL(ba_backsub_pt_kernel, dim3(G.max_nt_pt, nw), dim3(kLmThreads), bs_lds, st, A, dw, ds);
-      if (G.max_nb_ln > 0) hipLaunchKernelGGL(ba_backsub_ln_kernel, dim3(G.max_nb_ln, nw), dim3(kLmThreads), 0, st, A, dw, ds);
+      if (G.max_nb_ln > 0) hipLaunchKernelGGL(ba_backsub_ln_kernel, dim3(G.max_nb_ln, nw), dim3(kLmThreads), bs_lds, st, A, dw, ds);
     }
     LLD_HIP_TRY(hipEventRecord(G.ev[4], st));
     hipLaunchKernelGGL(ba_control_kernel, dim3(nw), dim3(kCtlThreads), 0, st, A, dw, ds, abort_now, G.d_counters);

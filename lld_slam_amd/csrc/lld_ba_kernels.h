@@ -803,23 +803,36 @@ __device__ __forceinline__ LineGeom line_geom(const LineQ& L) {
   LineGeom G; G.c0 = mat_col(Rl, 0); G.c1 = mat_col(Rl, 1); G.alpha = L.alpha; G.X1 = L.alpha * G.c1; G.X2 = G.X1 + G.c0;
   return G;
 }
+// The two image edges of one (line, KF) observation as loaded: flags and (xs, ys, xe, ye, info) of the left and right slot.  Loaded for
+// both slots at once and before anything is decided on them: one memory round trip per observation instead of one per slot behind a
+// branch on the slot's flags (b_x needs no load: it is 0 for the left and CamK::bx_right for the right slot).
+struct LnObsIn { uint8_t fl[2]; double xs[2], ys[2], xe[2], ye[2], s[2]; };
+__device__ __forceinline__ void line_obs_load(const BAArrays& A, int o, LnObsIn& I) {
+#pragma unroll
+  for (int side = 0; side < 2; side++) {
+    const int e = 2 * o + side;
+    I.fl[side] = A.le_flags[e];
+    I.xs[side] = A.le_xs[e]; I.ys[side] = A.le_ys[e]; I.xe[side] = A.le_xe[e]; I.ye[side] = A.le_ye[e]; I.s[side] = A.le_s[e];
+  }
+}
 // linearise one observation: hb (10 + 4) and the summed 6x4 Hpl block; returns the robust cost of its active edges
-__device__ __forceinline__ double line_obs_linearize(const BAArrays& A, const BAWin& W, int cur, int o, int c, const LineGeom& G, double* hb,
-                                                     double* acc_lds) {
+__device__ __forceinline__ double line_obs_linearize(const BAArrays& A, const BAWin& W, const Pose& T, int o, int c, const LineGeom& G, const LnObsIn& I,
+                                                     double* hb, double* acc_lds) {
   const bool free_cam = c < W.n_free;
   double Wo[24];
 #pragma unroll
   for (int i = 0; i < 24; i++) Wo[i] = 0.0;
   double chi = 0.0;
-  bool loaded = false; Pose T; Mat3 Rc; Vec3 X1m, X2m;
+  const Mat3 Rc = quat_rotation(T.q);
+  const Vec3 X1m = pose_map(T, G.X1), X2m = pose_map(T, G.X2);
+#pragma unroll
   for (int side = 0; side < 2; side++) {
     const int e = 2 * o + side;
-    const uint8_t fl = A.le_flags[e];
+    const uint8_t fl = I.fl[side];
     if (!(fl & EF_VALID) || (fl & EF_LEVEL1)) continue;
-    if (!loaded) { T = load_cam(A, cur, W.cam_off + c); Rc = quat_rotation(T.q); X1m = pose_map(T, G.X1); X2m = pose_map(T, G.X2); loaded = true; }
     double r[2]; LineAdj adj;
-    line_residual(W.cam, A.le_bx[e], X1m, X2m, A.le_xs[e], A.le_ys[e], A.le_xe[e], A.le_ye[e], r, &adj);
-    const double s = A.le_s[e];
+    line_residual(W.cam, side == 1 ? W.cam.bx_right : 0.0, X1m, X2m, I.xs[side], I.ys[side], I.xe[side], I.ye[side], r, &adj);
+    const double s = I.s[side];
     const double c2 = chi2_of(r, 2, s);
     A.le_chi2[e] = c2;
     double w = 1.0, rho0 = c2;
@@ -869,12 +882,15 @@ __device__ __forceinline__ void ba_linearize_ln_body(const BAArrays& A, const BA
   double* acc_all = kBig ? A.hpp_part + W.hpart_off : lds;   // kAccCopies x [n_free][21 Hpp upper + 6 bp]; kBig: see ba_linearize_pt_body
   double* scratch = kBig ? lds : lds + W.acc_copies * nacc;
   double* acc = acc_all;
+  const int cur = S.cur;
+  double* cams_l = scratch + 8;                              // [n_cams][7] poses of the linearisation point
+  const double* cams = kBig ? A.cam_qt + ((size_t)cur * A.NC + W.cam_off) * 7 : cams_l;
   if (!kBig) {
     for (int i = threadIdx.x; i < W.acc_copies * nacc; i += kLinThreads) acc_all[i] = 0.0;
     acc = acc_all + ((threadIdx.x >> 3) & (W.acc_copies - 1)) * nacc;
+    for (int i = threadIdx.x; i < W.n_cams * 7; i += kLinThreads) cams_l[i] = A.cam_qt[((size_t)cur * A.NC + W.cam_off) * 7 + i];
   }
   __syncthreads();
-  const int cur = S.cur;
   const int lane = threadIdx.x & 63;
   double chi = 0.0, maxd = 0.0;
   for (int rnd = 0; rnd < W.rounds[1]; rnd++) {
@@ -885,15 +901,18 @@ __device__ __forceinline__ void ba_linearize_ln_body(const BAArrays& A, const BA
 #pragma unroll
     for (int i = 0; i < 14; i++) hb[i] = 0.0;
     if (T.nl > 1) {
+      // two dependent memory levels only: (1) everything addressed by the observation - line index, camera, both edge slots -
+      // (2) the line's state; the camera pose comes from the workgroup's LDS copy
       const bool has = lane < T.ne;
       const int o = T.e0 + (has ? lane : 0);
-      const int l = has ? A.le_ln[2 * o] : -1 - lane;
+      const int l_raw = A.le_ln[2 * o], c = A.le_cam[2 * o];
+      LnObsIn I;
+      line_obs_load(A, o, I);
+      const int l = has ? l_raw : -1 - lane;
       const int g = W.ln_off + (has ? l : T.l0);
+      const LineQ Lq = load_ln(A, cur, g);
       const bool lm_act = has && A.ln_active[g];
-      if (lm_act) {
-        const LineGeom G = line_geom(load_ln(A, cur, g));
-        chi += line_obs_linearize(A, W, cur, o, A.le_cam[2 * o], G, hb, acc);
-      }
+      if (lm_act) chi += line_obs_linearize(A, W, pose_load(cams + c * 7), o, c, line_geom(Lq), I, hb, acc);
       seg_sum<14>(hb, l, lane, T.ms);
       if (lm_act && o == A.ln_obs_start[g]) {
         double* V = A.ln_V + (size_t)g * 14;
@@ -905,7 +924,12 @@ __device__ __forceinline__ void ba_linearize_ln_body(const BAArrays& A, const BA
       const int g = W.ln_off + T.l0;
       if (A.ln_active[g]) {
         const LineGeom G = line_geom(load_ln(A, cur, g));
-        for (int sidx = lane; sidx < T.ne; sidx += 64) chi += line_obs_linearize(A, W, cur, T.e0 + sidx, A.le_cam[2 * (T.e0 + sidx)], G, hb, acc);
+        for (int sidx = lane; sidx < T.ne; sidx += 64) {
+          const int o = T.e0 + sidx, c = A.le_cam[2 * o];
+          LnObsIn I;
+          line_obs_load(A, o, I);
+          chi += line_obs_linearize(A, W, pose_load(cams + c * 7), o, c, G, I, hb, acc);
+        }
         wave_sum_n<14>(hb);
         if (lane == 0) {
           double* V = A.ln_V + (size_t)g * 14;
@@ -945,17 +969,17 @@ __device__ __forceinline__ void line_obs_wtx(const BAArrays& A, const BAWin& W, 
     t[k] = s;
   }
 }
-__device__ __forceinline__ double line_obs_trial(const BAArrays& A, const BAWin& W, int nxt, int o, int c, const LineGeom& G) {
+__device__ __forceinline__ double line_obs_trial(const BAArrays& A, const BAWin& W, const Pose& T, int o, const LineGeom& G, const LnObsIn& I) {
   double chi = 0.0;
-  bool loaded = false; Vec3 X1m, X2m;
+  const Vec3 X1m = pose_map(T, G.X1), X2m = pose_map(T, G.X2);
+#pragma unroll
   for (int side = 0; side < 2; side++) {
     const int e = 2 * o + side;
-    const uint8_t fl = A.le_flags[e];
+    const uint8_t fl = I.fl[side];
     if (!(fl & EF_VALID) || (fl & EF_LEVEL1)) continue;
-    if (!loaded) { const Pose T = load_cam(A, nxt, W.cam_off + c); X1m = pose_map(T, G.X1); X2m = pose_map(T, G.X2); loaded = true; }
     double r[2];
-    line_residual(W.cam, A.le_bx[e], X1m, X2m, A.le_xs[e], A.le_ys[e], A.le_xe[e], A.le_ye[e], r, nullptr);
-    const double c2 = chi2_of(r, 2, A.le_s[e]);
+    line_residual(W.cam, side == 1 ? W.cam.bx_right : 0.0, X1m, X2m, I.xs[side], I.ys[side], I.xe[side], I.ye[side], r, nullptr);
+    const double c2 = chi2_of(r, 2, I.s[side]);
     A.le_chi2[e] = c2;
     double w, rho0 = c2;
     if (fl & EF_ROBUST) rho0 = huber(c2, (fl & EF_PAIRSTEREO) ? W.th_ln_stereo : W.th_ln_mono, &w);
@@ -975,15 +999,25 @@ __device__ __forceinline__ double line_backsub(const double* V, double lambda, c
 }
 
 // grid (nt_ln, nW), block 256 = 4 wavefronts, BAWin::rounds tasks per wavefront
+// dynamic LDS: 8 + 7 n_cams + 6 n_free doubles (poses of the trial state, x_c); kBig: read from HBM instead (see ba_linearize_pt_body)
+template <bool kBig>
 __device__ __forceinline__ void ba_backsub_ln_body(const BAArrays& A, const BAWin* __restrict__ wins, const BAState* __restrict__ st, const int bx) {   // bx: the workgroup's index along x
-  __shared__ double scratch[8];
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double* scratch = lds;
   const BAWin W = wins[blockIdx.y];
   const BAState& S = st[blockIdx.y];
   if (S.phase != PH_RUN) return;
   if ((int)bx >= W.nt_ln) return;
   const int cur = S.cur, nxt = cur ^ 1;
   const double lambda = S.lambda;
-  const double* xp = A.xp + W.x_off;
+  double* camB_l = lds + 8; double* xps_l = camB_l + W.n_cams * 7;
+  const double* camB = kBig ? A.cam_qt + ((size_t)nxt * A.NC + W.cam_off) * 7 : camB_l;
+  const double* xp = kBig ? A.xp + W.x_off : xps_l;
+  if (!kBig) {
+    for (int i = threadIdx.x; i < W.n_cams * 7; i += kLmThreads) camB_l[i] = A.cam_qt[((size_t)nxt * A.NC + W.cam_off) * 7 + i];
+    for (int i = threadIdx.x; i < 6 * W.n_free; i += kLmThreads) xps_l[i] = A.xp[W.x_off + i];
+  }
+  __syncthreads();
   const int lane = threadIdx.x & 63;
   double chi = 0.0, sc = 0.0;
   for (int rnd = 0; rnd < W.rounds[3]; rnd++) {
@@ -993,9 +1027,11 @@ __device__ __forceinline__ void ba_backsub_ln_body(const BAArrays& A, const BAWi
     if (T.nl > 1) {
       const bool has = lane < T.ne;
       const int o = T.e0 + (has ? lane : 0);
-      const int l = has ? A.le_ln[2 * o] : -1 - lane;
+      const int l_raw = A.le_ln[2 * o], c = A.le_cam[2 * o];
+      LnObsIn I;
+      line_obs_load(A, o, I);                              // (used after the back-substitution: in flight meanwhile)
+      const int l = has ? l_raw : -1 - lane;
       const int g = W.ln_off + (has ? l : T.l0);
-      const int c = A.le_cam[2 * o];
       const bool lm_act = has && A.ln_active[g];
       LineQ L = load_ln(A, cur, g);
       double wtx[4] = {0, 0, 0, 0};
@@ -1009,7 +1045,7 @@ __device__ __forceinline__ void ba_backsub_ln_body(const BAArrays& A, const BAWi
       }
       const int hl = o_head - T.e0;
       Ln.q.x = __shfl(Ln.q.x, hl); Ln.q.y = __shfl(Ln.q.y, hl); Ln.q.z = __shfl(Ln.q.z, hl); Ln.q.w = __shfl(Ln.q.w, hl); Ln.alpha = __shfl(Ln.alpha, hl);
-      if (lm_act) chi += line_obs_trial(A, W, nxt, o, c, line_geom(Ln));
+      if (lm_act) chi += line_obs_trial(A, W, pose_load(camB + c * 7), o, line_geom(Ln), I);
       if (lane < T.nl) {
         const int g2 = W.ln_off + T.l0 + lane;
         if (A.ln_obs_start[g2 + 1] == A.ln_obs_start[g2]) store_ln(A, nxt, g2, load_ln(A, cur, g2));
@@ -1032,7 +1068,12 @@ __device__ __forceinline__ void ba_backsub_ln_body(const BAArrays& A, const BAWi
         const double s1 = line_backsub(A.ln_V + (size_t)g * 14, lambda, wtx, L, Ln);
         if (lane == 0) { sc += s1; store_ln(A, nxt, g, Ln); }
         const LineGeom G = line_geom(Ln);
-        for (int sidx = lane; sidx < T.ne; sidx += 64) chi += line_obs_trial(A, W, nxt, T.e0 + sidx, A.le_cam[2 * (T.e0 + sidx)], G);
+        for (int sidx = lane; sidx < T.ne; sidx += 64) {
+          const int o = T.e0 + sidx;
+          LnObsIn I;
+          line_obs_load(A, o, I);
+          chi += line_obs_trial(A, W, pose_load(camB + A.le_cam[2 * o] * 7), o, G, I);
+        }
       }
     }
   }
@@ -1040,7 +1081,8 @@ __device__ __forceinline__ void ba_backsub_ln_body(const BAArrays& A, const BAWi
   const double sc_t = block_sum(sc, scratch);
   if (threadIdx.x == 0) { A.chi_part2[W.part_off + W.nt_pt + bx] = chi_t; A.scale_part[W.part_off + W.nt_pt + bx] = sc_t; }
 }
-__global__ __launch_bounds__(kLmThreads) void ba_backsub_ln_kernel(BAArrays A, const BAWin* __restrict__ wins, const BAState* __restrict__ st) { ba_backsub_ln_body(A, wins, st, (int)blockIdx.x); }
+__global__ __launch_bounds__(kLmThreads, 4) void ba_backsub_ln_kernel(BAArrays A, const BAWin* __restrict__ wins, const BAState* __restrict__ st) { ba_backsub_ln_body<false>(A, wins, st, (int)blockIdx.x); }
+__global__ __launch_bounds__(kLmThreads) void ba_backsub_ln_big_kernel(BAArrays A, const BAWin* __restrict__ wins, const BAState* __restrict__ st) { ba_backsub_ln_body<true>(A, wins, st, (int)blockIdx.x); }
 
 // Point and line landmarks in one launch, for batches too small to fill the GPU (a single window above all): there the two
 // kernels of a pair are dependent launches of 8-16 us each on idle hardware.  Not for large batches: the fused kernel gets the
@@ -1051,7 +1093,7 @@ __global__ __launch_bounds__(kLinThreads) void ba_linearize_both_kernel(BAArrays
 }
 __global__ __launch_bounds__(kLmThreads) void ba_backsub_both_kernel(BAArrays A, const BAWin* __restrict__ wins, const BAState* __restrict__ st, int n_pt_blocks) {
   if ((int)blockIdx.x < n_pt_blocks) ba_backsub_pt_body<false>(A, wins, st, (int)blockIdx.x);
-  else ba_backsub_ln_body(A, wins, st, (int)blockIdx.x - n_pt_blocks);
+  else ba_backsub_ln_body<false>(A, wins, st, (int)blockIdx.x - n_pt_blocks);
 }
 
 // Hpp / b_p = sum over the linearise workgroups' partials, fixed order.  grid (ceil(n_free_max*27 / 256), nW)

@@ -252,13 +252,11 @@ def test_global_bundle_adjustment_protocol(gpu_ctx, oracle, wid, kw, its, robust
 
 def test_map_sized_window_uses_the_multi_workgroup_pcg(gpu_ctx, oracle):
     """300 free keyframes (1800 unknowns in the reduced system): beyond one lane per unknown, so the block-Jacobi PCG runs with its
-    matrix-vector product spread over the GPU; 590 is the limit for up to 8 windows, 170 for larger batches."""
+    matrix-vector product spread over the GPU (up to 8 windows per batch; 170 free cameras is the limit for larger batches)."""
     w = synth.make_ba_window(300, 1, 8000, 4, 800, 4, seed=0x6BA00001)
     check_ba(Optimizer(gpu_ctx).GlobalBundleAdjustment(w, 4), oracle.local_ba(w, protocol=1, its_round1=4), w)
     with pytest.raises(RuntimeError):
         BABatch(gpu_ctx, [synth.make_lba_small(47, n_free=171, n_fixed=1, n_points=900, n_lines=0)] * 9)   # a batch of 9 such windows
-    with pytest.raises(RuntimeError):
-        Optimizer(gpu_ctx).GlobalBundleAdjustment(synth.make_lba_small(48, n_free=591, n_fixed=1, n_points=2500, n_lines=0))
 
 
 def test_batch_of_eight_mid_size_windows_runs_the_pcg_in_two_groups(gpu_ctx, oracle):
