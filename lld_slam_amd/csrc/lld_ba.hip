@@ -575,6 +575,9 @@ static int ba_batch_create_impl(lld_ctx* ctx, int n_windows, const lld_ba_window
   else if (hipMalloc(&B->slab, bytes) != hipSuccess) { delete B; return LLD_ERR_ALLOC; }
   B->slab_bytes = bytes;
   lap("hipMalloc done");
+  // debugging aid: every byte of the slab starts as 0xFF (NaN doubles, -1 indices), so a kernel that reads what nothing wrote shows up in the results
+  static const bool poison = std::getenv("LLD_BA_POISON") != nullptr;
+  if (poison) LLD_HIP_TRY(hipMemsetAsync(B->slab, 0xFF, bytes, st));
   lld_slab sl; sl.base = (char*)B->slab; sl.size = bytes;
   carve(sl, true);
   lap("uploads queued");

@@ -375,6 +375,8 @@ __host__ __device__ inline HoughCell hough_cell(double lx, double ly, double lz,
   lx /= n; ly /= n; lz /= n;
   if (ly < 0) { lx = -lx; ly = -ly; lz = -lz; }
   HoughCell c;
+  // a degenerate line (coincident end points): the reference would index its grid with the integer cast of a NaN; the build treats it as the line y = 0
+  if (!(lx - lx == 0.0) || !(ly - ly == 0.0) || !(lz - lz == 0.0)) { lx = 0.0; ly = 1.0; lz = 0.0; }      // x - x == 0 only for a finite x
   const double dist_level = fabs(lz / (sqrt(2.0))) * kHoughDist;
   int di = (int)floor(dist_level + 0.5);
   di = di < kHoughDist - 1 ? di : kHoughDist - 1; di = di > 0 ? di : 0;
@@ -410,7 +412,12 @@ __device__ __forceinline__ void track_image_line(const LineTrackParams& P, const
   const double X0d[3] = {X0[0] + dir[0], X0[1] + dir[1], X0[2] + dir[2]};
   track_map_point(P, t, X0, a); track_map_point(P, t, X0d, b);
   track_k_mul(P.K, a, Xa); track_k_mul(P.K, b, Xb);
-  l[0] = Xa[1] * Xb[2] - Xa[2] * Xb[1]; l[1] = Xa[2] * Xb[0] - Xa[0] * Xb[2]; l[2] = Xa[0] * Xb[1] - Xa[1] * Xb[0];
+  {
+    // no fused multiply-add here: a map line with a zero direction has Xa == Xb and the reference's cross product is exactly zero (the line
+    // becomes NaN and, `NaN > thr` being false, passes the reprojection gate); a contracted a*b - c*d would leave a rounding residue instead
+#pragma clang fp contract(off)
+    l[0] = Xa[1] * Xb[2] - Xa[2] * Xb[1]; l[1] = Xa[2] * Xb[0] - Xa[0] * Xb[2]; l[2] = Xa[0] * Xb[1] - Xa[1] * Xb[0];
+  }
   const double n = sqrt(l[0] * l[0] + l[1] * l[1]);
   l[0] /= n; l[1] /= n; l[2] /= n;
 }

@@ -234,6 +234,11 @@ void hough_coordinates(V3 leq, double sx, double sy, std::vector<int>* dist_inds
   leq.x /= sx; leq.y /= sy;
   { const double n = std::sqrt(leq.x * leq.x + leq.y * leq.y); leq.x /= n; leq.y /= n; leq.z /= n; }
   if (leq.y < 0) { leq.x = -leq.x; leq.y = -leq.y; leq.z = -leq.z; }
+  if (!std::isfinite(leq.x) || !std::isfinite(leq.y) || !std::isfinite(leq.z)) {
+    // a degenerate line (coincident end points): the reference would cast a NaN to int and index its grid with it; the build treats it as
+    // the line y = 0 - same rule as the device code
+    leq = V3{0.0, 1.0, 0.0};
+  }
   const int dist_cell_num = kDistCells, ang_cell_num = kAngCells;
   const double dist_level = std::fabs(leq.z / (std::sqrt(2.0))) * dist_cell_num;
   int dist_ind = (int)std::floor(dist_level + 0.5);

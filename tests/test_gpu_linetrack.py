@@ -93,3 +93,19 @@ def test_match_lines_last_kf_edge_cases(gpu_ctx, oracle):
     bad = dict(cur); bad["line_matches"] = cur["line_matches"].copy(); bad["line_matches"][0] = 10 ** 6
     with pytest.raises(RuntimeError):
         trk.MatchLinesLastKF(P["T_curr"], P["T_last"], bad, last)
+
+
+def test_degenerate_lines_take_the_documented_cell(gpu_ctx, oracle):
+    """A KeyLine with coincident end points and a map line with a zero direction have no line equation (0/0): both sides treat them as the
+    line y = 0 instead of indexing the grid with a NaN cast, and still agree on every match."""
+    P, L, F = synth.make_line_track_scene(11, n_map=150, n_cur=200)
+    F["left_lines"][::17, 2:] = F["left_lines"][::17, :2]
+    L["dir"][::13] = 0.0
+    trk = Tracking(gpu_ctx, P["K"], P["b"], 1.0 / P["sx"], 1.0 / P["sy"])
+    cells = trk.HoughCells(F["left_lines"])
+    np.testing.assert_array_equal(cells, oracle.line_hough_cells(F["left_lines"], P["sx"], P["sy"]))
+    assert np.all(cells[::17] == 25)                                       # distance row 0, angle column 25 (pi/2)
+    for kw in ({}, dict(use_grid=False)):
+        (gm, gd, _), (om, od, _) = run_both(gpu_ctx, oracle, P, L, F, **kw)
+        np.testing.assert_array_equal(gm, om)
+        np.testing.assert_array_equal(gd[gm >= 0], od[om >= 0])

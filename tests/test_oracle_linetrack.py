@@ -176,3 +176,14 @@ def test_match_lines_last_kf_recovers_the_shared_lines(oracle):
         off = x0[ok] - A; off -= np.sum(off * dt, axis=1, keepdims=True) * dt
         assert np.median(np.linalg.norm(off, axis=1)) < 0.2
         np.testing.assert_allclose(np.sum(x0[ok] * dr[ok], axis=1), 0, atol=1e-6)         # X0 is the point closest to the origin
+
+
+def test_degenerate_keyline_does_not_index_outside_the_grid(oracle):
+    """Coincident end points: no line equation. The oracle (and the device) file it as the line y = 0: cell 25."""
+    P, L, F = synth.make_line_track_scene(11, n_map=60, n_cur=80)
+    F["left_lines"][::7, 2:] = F["left_lines"][::7, :2]
+    L["dir"][::5] = 0.0
+    cells = oracle.line_hough_cells(F["left_lines"], P["sx"], P["sy"])
+    assert np.all(cells[::7] == 25) and cells.min() >= 0 and cells.max() < 2500
+    m, d = oracle.line_track_match(P["K"], P["T_curr"], P["b"], P["thr_reproj_base"], P["md_thr"], P["sx"], P["sy"], L, F)
+    assert m.shape == (60,)
