@@ -31,8 +31,10 @@ def check_ba(g, o, w, rtol=RTOL):
     # test_order_sensitivity_is_the_noise_floor), so their bound is 1e-4.
     def bulk(r):
         assert r.max() <= 10 * rtol and np.median(r) <= rtol
+        # at most 1 % beyond rtol, and never fewer than four allowed: the weak landmarks move together when one rounding-level event flips
+        # (tools/exp_flake.py: 6000 runs of one 138-line window, up to 3 lines at 1.8e-5 in the same run, in under 1 % of the runs)
         if r.size >= 100:
-            assert np.mean(r <= rtol) >= 0.99
+            assert (r > rtol).sum() <= max(4, int(0.01 * r.size))
     if w.n_points:
         bulk(rel(g.pt_xyz, o.pt_xyz))
     if w.n_lines:

@@ -16,9 +16,9 @@ for i in range(runs):
     g = Optimizer(ctx).LocalBundleAdjustment(w)
     rp = rel(g.pt_xyz, o.pt_xyz); rl = rel(g.line_x0, o.line_x0)
     rows.append((rp.max(), rl.max(), np.linalg.norm(g.line_dir - o.line_dir, axis=1).max(), abs(g.stats["chi2_final"] / o.stats["chi2_final"] - 1), sum(g.stats["lm_trials"]),
-                 np.abs(g.cam_qt - o.cam_qt).max()))
+                 np.abs(g.cam_qt - o.cam_qt).max(), (rp > 1e-5).sum(), (rl > 1e-5).sum()))
     if rows[-1][0] > 1e-4 or rows[-1][1] > 1e-4 or rows[-1][2] > 1e-4:
         print("run", i, rows[-1], "stats", g.stats, "worst pt", int(rp.argmax()), "worst ln", int(rl.argmax()))
 rows = np.array(rows)
-for k, name in enumerate(["pt", "ln_x0", "ln_dir", "chi2", "trials", "cam"]):
+for k, name in enumerate(["pt", "ln_x0", "ln_dir", "chi2", "trials", "cam", "n_pt_above_1e-5", "n_ln_above_1e-5"]):
     print(name, "max", rows[:, k].max(), "p99", np.quantile(rows[:, k], 0.99), "median", np.median(rows[:, k]), "min", rows[:, k].min())
