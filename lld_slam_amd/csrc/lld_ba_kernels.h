@@ -375,13 +375,37 @@ __global__ __launch_bounds__(kLmThreads) void ba_init_kernel(BAArrays A, const B
 // Edge SoA arrays are read fully coalesced (lane i <-> edge e0 + i); what belongs to a landmark (Hll, b_l, the back-substituted
 // update) is combined over the landmark's lanes with a segmented shuffle reduction, the landmark's first lane ("head") does the
 // per-landmark work, and results travel back to the lanes with one shuffle.
+// Shifts by one lane over the whole wavefront go through the VALU (v_mov_b32_dpp wave_shl:1 / wave_shr:1), not through the LDS pipe:
+// tools/microbench/lds_ops.hip measures 6.3 CU clocks per ds_bpermute_b32 against 1.3 for a DPP move, and the LDS pipe is what bounds
+// the linearise kernels (it also carries their fp64 atomics).  Shifts by 2 and 4 are chains of single shifts.
+__device__ __forceinline__ int dpp_down1(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x130, 0xf, 0xf, false); }   // lane i <- lane i + 1; lane 63 <- fill
+__device__ __forceinline__ int dpp_up1(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false); }     // lane i <- lane i - 1; lane 0 <- fill
+template <int OFF>
+__device__ __forceinline__ int dpp_down(int v, int fill) {
+#pragma unroll
+  for (int h = 0; h < OFF; h++) v = dpp_down1(v, fill);
+  return v;
+}
+template <int OFF>
+__device__ __forceinline__ double dpp_down(double v) {
+  return __hiloint2double(dpp_down<OFF>(__double2hiint(v), 0), dpp_down<OFF>(__double2loint(v), 0));
+}
 __device__ __forceinline__ bool seg_step(int seg, int lane, int off) {
   const int so = __shfl_down(seg, off);
   return (lane + off < 64) && so == seg;
 }
+template <int N, int OFF>
+__device__ __forceinline__ void seg_sum_step(double* v, int seg) {
+  const bool ok = dpp_down<OFF>(seg, (int)0x80000000) == seg;       // the fill value is no segment id: the last OFF lanes add nothing
+#pragma unroll
+  for (int i = 0; i < N; i++) { const double o = dpp_down<OFF>(v[i]); if (ok) v[i] += o; }
+}
 template <int N>
 __device__ __forceinline__ void seg_sum(double* v, int seg, int lane, int max_len) {      // valid in the first lane of every segment
-  for (int off = 1; off < max_len; off <<= 1) {
+  if (max_len > 1) seg_sum_step<N, 1>(v, seg);
+  if (max_len > 2) seg_sum_step<N, 2>(v, seg);
+  if (max_len > 4) seg_sum_step<N, 4>(v, seg);
+  for (int off = 8; off < max_len; off <<= 1) {
     const bool ok = seg_step(seg, lane, off);
 #pragma unroll
     for (int i = 0; i < N; i++) { const double o = __shfl_down(v[i], off); if (ok) v[i] += o; }
@@ -538,10 +562,10 @@ __device__ __forceinline__ void ba_linearize_pt_body(const BAArrays& A, const BA
       const int g2 = W.pt_off + T.l0 + (lmk ? lane : 0);
       const Vec3 X2 = load_pt(A, cur, g2);
       const int act2 = lmk ? (int)A.pt_active[g2] : 0;
-      const int start2 = A.pt_obs_start[g2], end2 = A.pt_obs_start[g2 + 1];
       const int slot = has ? l - T.l0 : 0;
       Vec3 X; X.x = __shfl(X2.x, slot); X.y = __shfl(X2.y, slot); X.z = __shfl(X2.z, slot);
       const bool lm_act = has && __shfl(act2, slot) != 0;
+      const bool head = lm_act && dpp_up1(l, (int)0x80000000) != l;      // the first edge lane of an active landmark
       double hb[9];
 #pragma unroll
       for (int i = 0; i < 9; i++) hb[i] = 0.0;
@@ -558,16 +582,12 @@ __device__ __forceinline__ void ba_linearize_pt_body(const BAArrays& A, const BA
         }
       }
       seg_sum<9>(hb, l, lane, T.ms);
-      // landmark lane i collects the sum from the first edge lane of its landmark
-      const int first = (lmk && end2 > start2) ? start2 - T.e0 : 0;
-      double vb[9];
+      // the head lane of a landmark holds the sums: it writes Hll / b_l itself (no trip back to the landmark lane)
+      if (head) {
+        double* V = A.pt_V + (size_t)(W.pt_off + l) * 9;
 #pragma unroll
-      for (int i = 0; i < 9; i++) vb[i] = __shfl(hb[i], first);
-      if (lmk && act2 && end2 > start2) {
-        double* V = A.pt_V + (size_t)g2 * 9;
-#pragma unroll
-        for (int i = 0; i < 9; i++) V[i] = vb[i];
-        maxd = fmax(maxd, fmax(fabs(vb[0]), fmax(fabs(vb[3]), fabs(vb[5]))));
+        for (int i = 0; i < 9; i++) V[i] = hb[i];
+        maxd = fmax(maxd, fmax(fabs(hb[0]), fmax(fabs(hb[3]), fabs(hb[5]))));
       }
     } else {                                             // a single landmark, any number of edges
       const int g = W.pt_off + T.l0;
@@ -819,9 +839,11 @@ __device__ __forceinline__ void line_obs_load(const BAArrays& A, int o, LnObsIn&
 __device__ __forceinline__ double line_obs_linearize(const BAArrays& A, const BAWin& W, const Pose& T, int o, int c, const LineGeom& G, const LnObsIn& I,
                                                      double* hb, double* acc_lds) {
   const bool free_cam = c < W.n_free;
-  double Wo[24];
+  double Wo[24], Jc0[12], r0[2] = {0.0, 0.0}, ws0 = 0.0;
 #pragma unroll
   for (int i = 0; i < 24; i++) Wo[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < 12; i++) Jc0[i] = 0.0;
   double chi = 0.0;
   const Mat3 Rc = quat_rotation(T.q);
   const Vec3 X1m = pose_map(T, G.X1), X2m = pose_map(T, G.X2);
@@ -850,15 +872,27 @@ __device__ __forceinline__ double line_obs_linearize(const BAArrays& A, const BA
       for (int d = a; d < 4; d++) hb[k++] += ws * (Jl[a] * Jl[d] + Jl[4 + a] * Jl[4 + d]);
     }
     if (free_cam) {
-      double* ac = acc_lds + c * 27;
-      int kk = 0;
 #pragma unroll
-      for (int rr = 0; rr < 6; rr++) {
+      for (int rr = 0; rr < 6; rr++)
 #pragma unroll
         for (int a = 0; a < 4; a++) Wo[rr * 4 + a] += ws * (Jc[rr] * Jl[a] + Jc[6 + rr] * Jl[4 + a]);
-        atomicAdd(&ac[21 + rr], -ws * (Jc[rr] * r[0] + Jc[6 + rr] * r[1]));
+      // the camera block of BOTH image edges goes to the accumulators in one pass of LDS atomics (8 ... 24 CU clocks each,
+      // tools/microbench/lds_ops.hip): the left edge only keeps its Jacobian, the right edge adds the sum
+      if (side == 0) {
 #pragma unroll
-        for (int cc = rr; cc < 6; cc++) atomicAdd(&ac[kk++], ws * (Jc[rr] * Jc[cc] + Jc[6 + rr] * Jc[6 + cc]));
+        for (int i = 0; i < 12; i++) Jc0[i] = Jc[i];
+        r0[0] = r[0]; r0[1] = r[1]; ws0 = ws;
+      } else {
+        double* ac = acc_lds + c * 27;
+        int kk = 0;
+#pragma unroll
+        for (int rr = 0; rr < 6; rr++) {
+          atomicAdd(&ac[21 + rr], -(ws0 * (Jc0[rr] * r0[0] + Jc0[6 + rr] * r0[1]) + ws * (Jc[rr] * r[0] + Jc[6 + rr] * r[1])));
+#pragma unroll
+          for (int cc = rr; cc < 6; cc++)
+            atomicAdd(&ac[kk++], ws0 * (Jc0[rr] * Jc0[cc] + Jc0[6 + rr] * Jc0[6 + cc]) + ws * (Jc[rr] * Jc[cc] + Jc[6 + rr] * Jc[6 + cc]));
+        }
+        ws0 = 0.0;                                           // added
       }
     }
   }
@@ -866,6 +900,16 @@ __device__ __forceinline__ double line_obs_linearize(const BAArrays& A, const BA
     double* Wb = A.lo_W + (size_t)o * 24;
 #pragma unroll
     for (int i = 0; i < 24; i += 2) *reinterpret_cast<double2*>(Wb + i) = make_double2(Wo[i], Wo[i + 1]);
+    if (ws0 != 0.0) {                                        // a left edge without an active right edge
+      double* ac = acc_lds + c * 27;
+      int kk = 0;
+#pragma unroll
+      for (int rr = 0; rr < 6; rr++) {
+        atomicAdd(&ac[21 + rr], -ws0 * (Jc0[rr] * r0[0] + Jc0[6 + rr] * r0[1]));
+#pragma unroll
+        for (int cc = rr; cc < 6; cc++) atomicAdd(&ac[kk++], ws0 * (Jc0[rr] * Jc0[cc] + Jc0[6 + rr] * Jc0[6 + cc]));
+      }
+    }
   }
   return chi;
 }
