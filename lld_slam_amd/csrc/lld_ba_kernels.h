@@ -378,33 +378,38 @@ __global__ __launch_bounds__(kLmThreads) void ba_init_kernel(BAArrays A, const B
 // Shifts by one lane over the whole wavefront go through the VALU (v_mov_b32_dpp wave_shl:1 / wave_shr:1), not through the LDS pipe:
 // tools/microbench/lds_ops.hip measures 6.3 CU clocks per ds_bpermute_b32 against 1.3 for a DPP move, and the LDS pipe is what bounds
 // the linearise kernels (it also carries their fp64 atomics).  Shifts by 2 and 4 are chains of single shifts.
-__device__ __forceinline__ int dpp_down1(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x130, 0xf, 0xf, false); }   // lane i <- lane i + 1; lane 63 <- fill
-__device__ __forceinline__ int dpp_up1(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false); }     // lane i <- lane i - 1; lane 0 <- fill
+// dpp_down1: lane i <- lane i + 1, dpp_up1: lane i <- lane i - 1; the lane without a source receives 0 (bound_ctrl), so no register has
+// to be preset with a fill value
+__device__ __forceinline__ int dpp_down1(int v) { return __builtin_amdgcn_mov_dpp(v, 0x130, 0xf, 0xf, true); }
+__device__ __forceinline__ int dpp_up1(int v) { return __builtin_amdgcn_mov_dpp(v, 0x138, 0xf, 0xf, true); }
 template <int OFF>
-__device__ __forceinline__ int dpp_down(int v, int fill) {
+__device__ __forceinline__ int dpp_down(int v) {
 #pragma unroll
-  for (int h = 0; h < OFF; h++) v = dpp_down1(v, fill);
+  for (int h = 0; h < OFF; h++) v = dpp_down1(v);
   return v;
 }
 template <int OFF>
 __device__ __forceinline__ double dpp_down(double v) {
-  return __hiloint2double(dpp_down<OFF>(__double2hiint(v), 0), dpp_down<OFF>(__double2loint(v), 0));
+  return __hiloint2double(dpp_down<OFF>(__double2hiint(v)), dpp_down<OFF>(__double2loint(v)));
 }
 __device__ __forceinline__ bool seg_step(int seg, int lane, int off) {
   const int so = __shfl_down(seg, off);
   return (lane + off < 64) && so == seg;
 }
+// one step of the segmented sum: v += (value OFF lanes up, if that lane is in the same segment).  seg1 = segment id + 1 is never 0 in a
+// lane that can receive the zero fill (ids are >= 0, or -1 - lane in idle lanes, and lane 0 receives no fill).  The condition enters as
+// a factor 0.0 / 1.0 of one fused multiply-add per value (the partial sums are finite: idle lanes hold zeros).
 template <int N, int OFF>
-__device__ __forceinline__ void seg_sum_step(double* v, int seg) {
-  const bool ok = dpp_down<OFF>(seg, (int)0x80000000) == seg;       // the fill value is no segment id: the last OFF lanes add nothing
+__device__ __forceinline__ void seg_sum_step(double* v, int seg1) {
+  const double okf = dpp_down<OFF>(seg1) == seg1 ? 1.0 : 0.0;
 #pragma unroll
-  for (int i = 0; i < N; i++) { const double o = dpp_down<OFF>(v[i]); if (ok) v[i] += o; }
+  for (int i = 0; i < N; i++) v[i] = fma(okf, dpp_down<OFF>(v[i]), v[i]);
 }
 template <int N>
 __device__ __forceinline__ void seg_sum(double* v, int seg, int lane, int max_len) {      // valid in the first lane of every segment
-  if (max_len > 1) seg_sum_step<N, 1>(v, seg);
-  if (max_len > 2) seg_sum_step<N, 2>(v, seg);
-  if (max_len > 4) seg_sum_step<N, 4>(v, seg);
+  if (max_len > 1) seg_sum_step<N, 1>(v, seg + 1);
+  if (max_len > 2) seg_sum_step<N, 2>(v, seg + 1);
+  if (max_len > 4) seg_sum_step<N, 4>(v, seg + 1);
   for (int off = 8; off < max_len; off <<= 1) {
     const bool ok = seg_step(seg, lane, off);
 #pragma unroll
@@ -545,7 +550,7 @@ __device__ __forceinline__ void ba_linearize_pt_body(const BAArrays& A, const BA
   const int lane = threadIdx.x & 63;
   double chi = 0.0, maxd = 0.0;
   for (int rnd = 0; rnd < W.rounds[0]; rnd++) {
-    const int ti = (bx * W.rounds[0] + rnd) * (kLinThreads / 64) + (threadIdx.x >> 6);
+    const int ti = (bx * W.rounds[0] + rnd) * (kLinThreads / 64) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // the wavefront index as a scalar: the task and every address built on it stay in SGPRs
     if (ti >= W.n_ptasks) break;
     const PTask T = A.ptasks[W.ptask_off + ti];
     if (T.nl > 1) {
@@ -565,7 +570,7 @@ __device__ __forceinline__ void ba_linearize_pt_body(const BAArrays& A, const BA
       const int slot = has ? l - T.l0 : 0;
       Vec3 X; X.x = __shfl(X2.x, slot); X.y = __shfl(X2.y, slot); X.z = __shfl(X2.z, slot);
       const bool lm_act = has && __shfl(act2, slot) != 0;
-      const bool head = lm_act && dpp_up1(l, (int)0x80000000) != l;      // the first edge lane of an active landmark
+      const bool head = lm_act && dpp_up1(l + 1) != l + 1;               // the first edge lane of an active landmark (lane 0 receives 0)
       double hb[9];
 #pragma unroll
       for (int i = 0; i < 9; i++) hb[i] = 0.0;
@@ -716,7 +721,7 @@ __device__ __forceinline__ void ba_backsub_pt_body(const BAArrays& A, const BAWi
   const int lane = threadIdx.x & 63;
   double chi = 0.0, sc = 0.0;
   for (int rnd = 0; rnd < W.rounds[2]; rnd++) {
-    const int ti = (bx * W.rounds[2] + rnd) * 4 + (threadIdx.x >> 6);
+    const int ti = (bx * W.rounds[2] + rnd) * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // the wavefront index as a scalar: the task and every address built on it stay in SGPRs
     if (ti >= W.n_ptasks) break;
     const PTask T = A.ptasks[W.ptask_off + ti];
     if (T.nl > 1) {
@@ -938,7 +943,7 @@ __device__ __forceinline__ void ba_linearize_ln_body(const BAArrays& A, const BA
   const int lane = threadIdx.x & 63;
   double chi = 0.0, maxd = 0.0;
   for (int rnd = 0; rnd < W.rounds[1]; rnd++) {
-    const int ti = (bx * W.rounds[1] + rnd) * (kLinThreads / 64) + (threadIdx.x >> 6);
+    const int ti = (bx * W.rounds[1] + rnd) * (kLinThreads / 64) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // the wavefront index as a scalar: the task and every address built on it stay in SGPRs
     if (ti >= W.n_ltasks) break;
     const PTask T = A.ltasks[W.ltask_off + ti];
     double hb[14];
@@ -1065,7 +1070,7 @@ __device__ __forceinline__ void ba_backsub_ln_body(const BAArrays& A, const BAWi
   const int lane = threadIdx.x & 63;
   double chi = 0.0, sc = 0.0;
   for (int rnd = 0; rnd < W.rounds[3]; rnd++) {
-    const int ti = (bx * W.rounds[3] + rnd) * 4 + (threadIdx.x >> 6);
+    const int ti = (bx * W.rounds[3] + rnd) * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // the wavefront index as a scalar: the task and every address built on it stay in SGPRs
     if (ti >= W.n_ltasks) break;
     const PTask T = A.ltasks[W.ltask_off + ti];
     if (T.nl > 1) {
@@ -1686,7 +1691,7 @@ __global__ __launch_bounds__(256) void ba_pcgm_matvec_kernel(BAArrays A, const B
   const double* sc = A.pcg_sc + 8 * (size_t)W.win_index;
   if (sc[3] != 0.0) return;
   const int n = 6 * W.n_free, lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int row = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // the wavefront index as a scalar: the task and every address built on it stay in SGPRs
   if (row >= n) return;
   const double* Sr = A.S + W.S_off + (size_t)row * n;
   const double* p = A.pcg_vec + 2 * A.x_total + W.x_off;

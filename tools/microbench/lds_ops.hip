@@ -52,6 +52,35 @@ __global__ __launch_bounds__(1024) void bench(double* out, int cams, int copies_
   out[blockIdx.x * blockDim.x + threadIdx.x] = acc + iv;
 }
 
+// 8 x ds_add_f64 at a per-lane address given by the host (doubles), the same for every repetition: the bank-conflict model
+__global__ __launch_bounds__(1024) void bench_table(double* out, const int* __restrict__ addr) {
+  extern __shared__ double lds[];
+  for (int i = threadIdx.x; i < 16384; i += blockDim.x) lds[i] = 0.0;
+  __syncthreads();
+  double* a = lds + addr[threadIdx.x & 63];
+  const double acc = threadIdx.x;
+  for (int r = 0; r < kReps; r++) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) atomicAdd(&a[k], acc);
+  }
+  out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+}
+int run_table(const char* name, const std::vector<int>& addr, double clock_ghz, double* d) {
+  int* da; CHECK(hipMalloc(&da, 64 * sizeof(int)));
+  CHECK(hipMemcpy(da, addr.data(), 64 * sizeof(int), hipMemcpyHostToDevice));
+  hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
+  CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(bench_table), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+  bench_table<<<256, 1024, 131072>>>(d, da);
+  CHECK(hipDeviceSynchronize());
+  CHECK(hipEventRecord(a));
+  bench_table<<<256, 1024, 131072>>>(d, da);
+  CHECK(hipEventRecord(b)); CHECK(hipEventSynchronize(b));
+  float ms; CHECK(hipEventElapsedTime(&ms, a, b));
+  printf("%-58s %8.3f ms  %7.2f CU-clk per wavefront instruction\n", name, ms, ms * 1e-3 * clock_ghz * 1e9 / (16.0 * kReps * 8));
+  CHECK(hipFree(da));
+  return 0;
+}
+
 template <int kMode>
 int run(const char* name, int per_iter, int cams, int copies_shift, double clock_ghz, double* d) {
   hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
@@ -80,5 +109,17 @@ int main() {
   if (run<1>("ds_add_f64, 50 cameras x 1 copy", 8, 50, 0, ghz, d)) return 1;
   if (run<1>("ds_add_f64, 50 cameras x 8 copies", 8, 50, 3, ghz, d)) return 1;
   if (run<3>("ds_read_b64 x7, pose of a random camera", 7, 60, 2, ghz, d)) return 1;
+  {
+    std::vector<int> t(64);
+    for (int j = 0; j < 64; j++) t[j] = j * 9;                      if (run_table("table: 64 addresses, 2 lanes per 8-byte bank (stride 9)", t, ghz, d)) return 1;
+    for (int j = 0; j < 64; j++) t[j] = (j % 16) * 9 + 32 * 9 * (j / 16);   if (run_table("table: 4 lanes per bank, all addresses distinct", t, ghz, d)) return 1;
+    for (int j = 0; j < 64; j++) t[j] = (j % 8) * 9 + 32 * 9 * (j / 8);     if (run_table("table: 8 lanes per bank, all addresses distinct", t, ghz, d)) return 1;
+    for (int j = 0; j < 64; j++) t[j] = 32 * 9 * j % 16000;          if (run_table("table: 64 lanes in one bank, all addresses distinct", t, ghz, d)) return 1;
+    for (int j = 0; j < 64; j++) t[j] = 0;                          if (run_table("table: one address for all lanes", t, ghz, d)) return 1;
+    for (int j = 0; j < 64; j++) t[j] = (j / 2) * 9;                 if (run_table("table: pairs of lanes share an address, 32 banks", t, ghz, d)) return 1;
+    for (int j = 0; j < 64; j++) t[j] = (j / 4) * 9;                 if (run_table("table: 4 lanes share an address, 16 banks used", t, ghz, d)) return 1;
+    for (int j = 0; j < 64; j++) t[j] = (j % 32) * 9;                if (run_table("table: lanes j and j+32 share an address", t, ghz, d)) return 1;
+    for (int j = 0; j < 64; j++) t[j] = j * 9 + (j / 32) * 16 * 9;   if (run_table("table: 64 addresses in 64 4-byte-bank pairs?", t, ghz, d)) return 1;
+  }
   return 0;
 }
