@@ -4,6 +4,9 @@
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <memory>
 #include <new>
 #include <thread>
@@ -139,6 +142,10 @@ void stage_tasks(const lld_ba_window& w, const lld_ba_params& P, const WinBases&
   W.n_ptasks = (int)S.ptasks.size(); W.n_ltasks = (int)S.ltasks.size();
   const int* R = n_windows >= kRoundsThroughputMinWindows ? kRoundsThroughput : kRoundsLatency;
   for (int i = 0; i < 4; i++) W.rounds[i] = R[i];
+  if (const char* e = std::getenv("LLD_BA_ROUNDS")) {        // experiments: "lin_pt,lin_ln,backsub_pt,backsub_ln" tasks per wavefront
+    int r[4];
+    if (std::sscanf(e, "%d,%d,%d,%d", &r[0], &r[1], &r[2], &r[3]) == 4) for (int i = 0; i < 4; i++) if (r[i] >= 1 && r[i] <= 64) W.rounds[i] = r[i];
+  }
   W.nt_pt = (W.n_ptasks + 4 * W.rounds[2] - 1) / (4 * W.rounds[2]); W.nl_pt = (W.n_ptasks + W.rounds[0] * kLinThreads / 64 - 1) / (W.rounds[0] * kLinThreads / 64);
   W.nt_ln = (W.n_ltasks + 4 * W.rounds[3] - 1) / (4 * W.rounds[3]); W.nl_ln = (W.n_ltasks + W.rounds[1] * kLinThreads / 64 - 1) / (W.rounds[1] * kLinThreads / 64);
   const double thMono = (double)(float)std::sqrt(5.991), thStereo = (double)(float)std::sqrt(7.815);   // Optimizer.cc:1088-1089
