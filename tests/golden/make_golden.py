@@ -32,7 +32,34 @@ def frame_arrays(f):
                 ln_dir=f.ln_dir, ln_left=f.ln_left, ln_right=f.ln_right, ln_octave=f.ln_octave)
 
 
+def make_line_track():
+    """Tracking::AddLinesFrom and Tracking::MatchLinesLastKF on small scenes; the Hough cells additionally from plain numpy
+    (GetHoughCoordinates with the reference's PI literal) - independent of the oracle."""
+    P, L, F = synth.make_line_track_scene(21, n_map=90, n_cur=120)
+    m_grid, d_grid = O.line_track_match(P["K"], P["T_curr"], P["b"], P["thr_reproj_base"], P["md_thr"], P["sx"], P["sy"], L, F)
+    m_all, d_all = O.line_track_match(P["K"], P["T_curr"], P["b"], P["thr_reproj_base"], P["md_thr"], P["sx"], P["sy"], L, F, use_grid=False)
+    assert (m_grid >= 0).sum() > 20 and (m_all >= 0).sum() >= (m_grid >= 0).sum()
+    ll = F["left_lines"].astype(np.float64)
+    leq = np.stack([ll[:, 1] - ll[:, 3], ll[:, 2] - ll[:, 0], ll[:, 0] * ll[:, 3] - ll[:, 1] * ll[:, 2]], 1)      # (xs,ys,1) x (xe,ye,1)
+    leq[:, 0] /= P["sx"]; leq[:, 1] /= P["sy"]
+    leq /= np.hypot(leq[:, 0], leq[:, 1])[:, None]
+    leq[leq[:, 1] < 0] *= -1
+    di = np.clip(np.floor(np.abs(leq[:, 2] / np.sqrt(2.0)) * 50 + 0.5).astype(int), 0, 49)
+    ai = np.clip(np.floor(np.arctan2(leq[:, 1], leq[:, 0]) / 3.14159265 * 50 + 0.5).astype(int), 0, 49)
+    cells = (di * 50 + ai).astype(np.int32)
+    np.testing.assert_array_equal(cells, O.line_hough_cells(F["left_lines"], P["sx"], P["sy"]))
+    P2, cur, last, _ = synth.make_two_frame_lines(23, n_lines=110)
+    km, kc, kx, kd = O.line_match_last_frame(P2["K"], P2["T_curr"], P2["T_last"], P2["b"], P2["thr_reproj_base"], P2["md_thr"], P2["sx"], P2["sy"], cur, last, True)
+    assert kc.sum() > 10
+    pk = {f"p_{k}": np.asarray(v) for k, v in P.items()}; pk.update({f"l_{k}": v for k, v in L.items()}); pk.update({f"f_{k}": v for k, v in F.items()})
+    pk.update({f"p2_{k}": np.asarray(v) for k, v in P2.items()}); pk.update({f"c_{k}": v for k, v in cur.items()}); pk.update({f"k_{k}": v for k, v in last.items()})
+    np.savez_compressed(os.path.join(HERE, "line_track.npz"), out_cells=cells, out_m_grid=m_grid, out_d_grid=d_grid, out_m_all=m_all, out_d_all=d_all,
+                        out_k_match=km, out_k_created=kc, out_k_x0=kx, out_k_dir=kd, **pk)
+
+
 def main():
+    if sys.argv[1:] == ["line_track"]:
+        make_line_track(); return
     rng = np.random.default_rng(20261001)
     # --- SE3 exp: scipy expm of the 4x4 twist (independent of the oracle)
     tw = np.concatenate([rng.normal(0, 0.6, (24, 3)), rng.normal(0, 2.0, (24, 3))], 1)
@@ -106,6 +133,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "stereo_small.npz"), l_desc=sc["L"].desc, l_xy=sc["L"].xy, l_octave=sc["L"].octave, r_desc=sc["R"].desc,
                         r_xy=sc["R"].xy, r_octave=sc["R"].octave, inv_scale=sc["inv_scale"], mb=np.float32(sc["mb"]), mbf=np.float32(sc["mbf"]),
                         n_levels=len(sc["left"]), out_n=n_st, out_u_right=ur, out_depth=dep, out_best_r=br, out_sad=sad, **lv)
+    make_line_track()
     for n in sorted(os.listdir(HERE)):
         if n.endswith(".npz"):
             print(n, os.path.getsize(os.path.join(HERE, n)), "bytes")
