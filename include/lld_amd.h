@@ -508,6 +508,12 @@ int lld_line_hough_cells(const float* lines, int n, double sx, double sy, int32_
  *   query whose q_blocks flag is set is skipped too (the reference writes mvpMapPoints /
  *   vpMatched / vbMatched2 inside its loop).  The device reaches the sequential answer by
  *   fixed-point rounds over all queries and reports the number of rounds.
+ *   sequential = 2 is the rule of ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:405-520), the one routine whose order
+ *   dependence is not an occupancy: a candidate is skipped when an EARLIER query holds it with a distance <= this one
+ *   (`vMatchedDistance[i2]<=dist`, :443), an accepted query takes the keypoint away from its holder, whose match is cleared
+ *   (:458-465), and the rotation histogram counts every acceptance, also those taken away later (:466-476).  match[] is
+ *   vnMatches12 before the orientation filter, owner[] vnMatches21, `rounds` 1 + the number of queries whose cached candidate
+ *   list ran dry; GRID or ALL candidates, ratio_mode 0 or 1, no tie_last.
  * Accept: best <= accept_max, then ratio_mode 0 none | 1 (float)best < nn*(float)second
  * (:226-228) | 2 reject iff level(best)==level(second) && best > nn*second (:118-121).
  * check_orientation: 30-bin histogram of q_angle - t_angle, factor 1/30, ComputeThreeMaxima
@@ -565,7 +571,7 @@ typedef struct {
   int32_t accept_max;             /* accept iff best <= accept_max                               */
   int32_t ratio_mode;
   float   nnratio;                /* mfNNratio                                                   */
-  int32_t sequential;
+  int32_t sequential;             /* 0 | 1 occupancy by earlier queries | 2 SearchForInitialization's take-over rule        */
   int32_t check_orientation;
 } lld_orb_search;
 

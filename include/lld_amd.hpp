@@ -208,6 +208,26 @@ class ORBmatcher {
     r.n_matches = o.n_matches; r.rounds = o.rounds;
     return r;
   }
+  // SearchForInitialization(Frame& F1, Frame& F2, vbPrevMatched, vnMatches12, windowSize) (src/ORBmatcher.cc:405-520).  `f2` carries
+  // the keypoints of F2 (nt, t_desc, t_xy, t_octave, t_angle) and the grid constants; the arrays of F1 have n1 rows.  vbPrevMatched
+  // ([n1][2], in / out) and vnMatches12 are updated as the reference does; returns nmatches.
+  int SearchForInitialization(lld_orb_search f2, int n1, const uint32_t* desc1, const int32_t* octave1, const float* angle1,
+                              std::vector<float>& vbPrevMatched, std::vector<int32_t>& vnMatches12, int windowSize = 10) const {
+    std::vector<uint8_t> valid(n1); std::vector<float> radius(n1, (float)windowSize); std::vector<int32_t> level(n1, 0);
+    for (int i = 0; i < n1; i++) valid[i] = octave1[i] <= 0;                    // `if(level1>0) continue;` (:423-425)
+    f2.nq = n1; f2.q_desc = desc1; f2.q_valid = valid.data(); f2.q_uv = vbPrevMatched.data(); f2.q_radius = radius.data();
+    f2.q_level_min = level.data(); f2.q_level_max = level.data(); f2.q_angle = angle1;
+    f2.candidates = LLD_ORB_CAND_GRID; f2.gates = LLD_ORB_GATE_LEVEL; f2.accept_max = TH_LOW; f2.ratio_mode = 1; f2.nnratio = mfNNratio;
+    f2.sequential = 2; f2.check_orientation = mbCheckOrientation ? 1 : 0; f2.tie_last = 0;
+    const SearchResult r = Search(f2);
+    vnMatches12.assign(n1, -1);
+    for (int i = 0; i < n1; i++)
+      if (r.match[i] >= 0 && !r.removed[i]) {
+        vnMatches12[i] = r.match[i];
+        vbPrevMatched[2 * i] = f2.t_xy[2 * r.match[i]]; vbPrevMatched[2 * i + 1] = f2.t_xy[2 * r.match[i] + 1];   // :513-516
+      }
+    return r.n_matches;
+  }
   // Frame::ComputeStereoMatches as a whole (src/Frame.cc:530-704): row-band Hamming search, 11x11 SAD refinement on the image
   // pyramids, median cut.  Fills mvuRight / mvDepth; returns the number of stereo keypoints kept.
   int ComputeStereoMatches(const lld_keypoints& left, const lld_keypoints& right, const lld_stereo_pyramids& pyramids, float mb, float mbf,

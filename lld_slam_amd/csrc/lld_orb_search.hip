@@ -136,6 +136,8 @@ __global__ __launch_bounds__(kThreads) void orb_search_kernel(const Problem* __r
   int* ctl = hist + 32;                                                         // [8]: 0 changed, 1 accepted, 2 removed, 3..5 kept bins
   int* scan = ctl + 8;                                                          // [kThreads]
   float* lvl = reinterpret_cast<float*>(scan + kThreads);                       // [48] level tables: scale, sigma2, 1/sigma2
+  int* holder = reinterpret_cast<int*>(lvl + 48);                               // [nt]   sequential == 2: the query that holds keypoint k (vnMatches21)
+  unsigned long long* lkeys = reinterpret_cast<unsigned long long*>((reinterpret_cast<uintptr_t>(holder + nt) + 15) & ~uintptr_t(15));   // [64][kTopK], 16-byte aligned
 
   // ---------------------------------------------------------------- keypoints into LDS (+ grid counting sort)
   auto load_key = [&](int k, int& cell) -> TKey {
@@ -196,50 +198,9 @@ __global__ __launch_bounds__(kThreads) void orb_search_kernel(const Problem* __r
   for (int q = tid; q < nq; q += kThreads) P.match[q] = -2;
   __syncthreads();
 
-  // ---------------------------------------------------------------- fixed-point rounds, one lane per query
-  int rounds = 0;
-  for (;;) {
-    rounds++;
-    for (int q = tid; q < nq; q += kThreads) {
-      const QRec Q = P.q[q];
-      unsigned long long b1 = kNone, b2 = kNone;
-      auto decode = [&](unsigned long long c) -> int {
-        unsigned key = (unsigned)(c & 0xffffffffu);
-        if (P.tie_last) key = ~key;
-        if (grid) return (int)(key & 4095u);
-        if (P.candidates == LLD_ORB_CAND_CSR) return P.cand_idx[Q.cs + (int)key];
-        return (int)key;
-      };
-      if (Q.flags & 1) {
-        // The candidates of a query, sorted by key, do not depend on the round; only which of them are blocked does.  Round 1
-        // keeps the kTopK smallest keys; later rounds take the first two unblocked ones from that list and rescan only when
-        // the list was full and fewer than two of its entries are still free.
-        unsigned long long c[kTopK];
-#pragma unroll
-        for (int i = 0; i < kTopK; i++) c[i] = kNone;
-        auto pick = [&]() {
-          int found = 0; b1 = kNone; b2 = kNone;
-          auto take = [&](unsigned long long k) {
-            if (k != kNone && !(P.sequential && blk[decode(k)] < q)) {
-              b1 = found == 0 ? k : b1; b2 = found == 1 ? k : b2;          // selects, so that b1 / b2 stay in registers
-              found++;
-            }
-          };
-#pragma unroll
-          for (int i = 0; i < kTopK; i++) take(c[i]);
-          return found;
-        };
-        bool need_scan = rounds == 1;
-        if (rounds > 1) {
-#pragma unroll
-          for (int i = 0; i < kTopK; i += 2) {
-            const ulonglong2 t2 = *reinterpret_cast<const ulonglong2*>(P.cache + kTopK * (size_t)q + i);
-            c[i] = t2.x; c[i + 1] = t2.y;
-          }
-          need_scan = pick() < 2 && c[kTopK - 1] != kNone;
-        }
-        if (need_scan) {
-        const bool use_blk = rounds > 1;
+  // every candidate of query q that passes the gates, its kTopK smallest keys (distance, then visit order) into c.  `steal`: the
+  // SearchForInitialization rule - a keypoint held by an earlier query with a distance <= this one is no candidate (blk = vMatchedDistance)
+  auto scan_candidates = [&](int q, const QRec& Q, unsigned long long (&c)[kTopK], bool use_blk, bool steal) {
 #pragma unroll
         for (int i = 0; i < kTopK; i++) c[i] = kNone;
         uint32_t qd[8];
@@ -250,6 +211,7 @@ __global__ __launch_bounds__(kThreads) void orb_search_kernel(const Problem* __r
         auto visit = [&](int pos, const TKey& T, unsigned key) {
           if (!gates_pass(P, Q, T, q, blk, use_blk, lvl)) return;
           const int d = P.desc_in_lds ? hamming256(qd, dsc + 8 * (size_t)pos) : hamming256(qd, P.t_desc + 8 * (size_t)tk_idx(T.meta));
+          if (steal && blk[tk_idx(T.meta)] <= d) return;                                                           // ORBmatcher.cc:443-444
           if (P.tie_last) key = ~key;
           topk_insert(((unsigned long long)d << 32) | key, c);
         };
@@ -301,6 +263,52 @@ __global__ __launch_bounds__(kThreads) void orb_search_kernel(const Problem* __r
         } else {
           for (int k = 0; k < nt; k++) visit(k, tk[k], (unsigned)k);
         }
+  };
+
+  // ---------------------------------------------------------------- fixed-point rounds, one lane per query
+  int rounds = 0;
+  for (;;) {
+    rounds++;
+    for (int q = tid; q < nq; q += kThreads) {
+      const QRec Q = P.q[q];
+      unsigned long long b1 = kNone, b2 = kNone;
+      auto decode = [&](unsigned long long c) -> int {
+        unsigned key = (unsigned)(c & 0xffffffffu);
+        if (P.tie_last) key = ~key;
+        if (grid) return (int)(key & 4095u);
+        if (P.candidates == LLD_ORB_CAND_CSR) return P.cand_idx[Q.cs + (int)key];
+        return (int)key;
+      };
+      if (Q.flags & 1) {
+        // The candidates of a query, sorted by key, do not depend on the round; only which of them are blocked does.  Round 1
+        // keeps the kTopK smallest keys; later rounds take the first two unblocked ones from that list and rescan only when
+        // the list was full and fewer than two of its entries are still free.
+        unsigned long long c[kTopK];
+#pragma unroll
+        for (int i = 0; i < kTopK; i++) c[i] = kNone;
+        auto pick = [&]() {
+          int found = 0; b1 = kNone; b2 = kNone;
+          auto take = [&](unsigned long long k) {
+            if (k != kNone && !(P.sequential && blk[decode(k)] < q)) {
+              b1 = found == 0 ? k : b1; b2 = found == 1 ? k : b2;          // selects, so that b1 / b2 stay in registers
+              found++;
+            }
+          };
+#pragma unroll
+          for (int i = 0; i < kTopK; i++) take(c[i]);
+          return found;
+        };
+        bool need_scan = rounds == 1;
+        if (rounds > 1) {
+#pragma unroll
+          for (int i = 0; i < kTopK; i += 2) {
+            const ulonglong2 t2 = *reinterpret_cast<const ulonglong2*>(P.cache + kTopK * (size_t)q + i);
+            c[i] = t2.x; c[i + 1] = t2.y;
+          }
+          need_scan = pick() < 2 && c[kTopK - 1] != kNone;
+        }
+        if (need_scan) {
+          scan_candidates(q, Q, c, rounds > 1, false);
         if (rounds == 1 && P.sequential) {
 #pragma unroll
           for (int i = 0; i < kTopK; i += 2) *reinterpret_cast<ulonglong2*>(P.cache + kTopK * (size_t)q + i) = make_ulonglong2(c[i], c[i + 1]);
@@ -327,6 +335,148 @@ __global__ __launch_bounds__(kThreads) void orb_search_kernel(const Problem* __r
     __syncthreads();
     const int changed = ctl[0];
     __syncthreads();
+    if (P.sequential == 2) {
+      // ---- ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:417-476): the one order-dependent rule that is not an occupancy.  A
+      // candidate is skipped when an EARLIER query holds it with a distance <= this one (vMatchedDistance[i2] <= dist, :443), and an
+      // accepted query takes the keypoint away from its holder (:458-465).  Round 1 above left every query's kTopK smallest candidates
+      // (distance, then visit order) in P.cache; wavefront 0 walks the queries in order with lane i on list entry i: the first two
+      // entries still free are bestDist / bestDist2.  Only when fewer than two of a FULL list are free is the window scanned again (by
+      // one lane, with the rule applied).  blk = vMatchedDistance (INT_MAX so far), holder = vnMatches21; the rotation histogram
+      // counts every acceptance, also those stolen later (rotHist is never cleaned, :466-476).
+      for (int k = tid; k < nt; k += kThreads) holder[k] = -1;
+      __syncthreads();
+      if (tid < 64) {
+        // No global load sits on the query-to-query chain: a chunk of 64 queries is loaded lane-wise (lane l: flags and list of query
+        // q0 + l), the walk takes query i's values out of lane i's registers with v_readlane, results stay in lane registers until the
+        // chunk is done, and the rotation bins (which need both angles) are counted afterwards by all lanes from the recorded acceptances.
+        auto dec = [&](unsigned long long c) -> int { const unsigned kk = (unsigned)(c & 0xffffffffu); return grid ? (int)(kk & 4095u) : (int)kk; };
+        auto rl64 = [&](unsigned long long v, int lane) -> unsigned long long {
+          const int lo = __builtin_amdgcn_readlane((int)(v & 0xffffffffu), lane), hi = __builtin_amdgcn_readlane((int)(v >> 32), lane);
+          return ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
+        };
+        // the window of query q once more, with the take-over rule, by the whole wavefront: lanes stride over the candidates of a grid
+        // column (or over all keypoints), keep their two smallest keys, and a butterfly merges the 64 pairs
+        auto wave_rescan = [&](int q, unsigned long long& r1, unsigned long long& r2) {
+          const QRec Q = P.q[q];
+          uint32_t qd[8];
+          {
+            const uint4 a = *reinterpret_cast<const uint4*>(P.q_desc + 8 * (size_t)q), b = *reinterpret_cast<const uint4*>(P.q_desc + 8 * (size_t)q + 4);
+            qd[0] = a.x; qd[1] = a.y; qd[2] = a.z; qd[3] = a.w; qd[4] = b.x; qd[5] = b.y; qd[6] = b.z; qd[7] = b.w;
+          }
+          unsigned long long t1 = kNone, t2 = kNone;
+          auto visit = [&](int pos, const TKey& T, unsigned key) {
+            if (!gates_pass(P, Q, T, q, blk, false, lvl)) return;
+            const int d = P.desc_in_lds ? hamming256(qd, dsc + 8 * (size_t)pos) : hamming256(qd, P.t_desc + 8 * (size_t)tk_idx(T.meta));
+            if (blk[tk_idx(T.meta)] <= d) return;                                                                  // ORBmatcher.cc:443-444
+            top2_insert(((unsigned long long)d << 32) | key, t1, t2);
+          };
+          if (grid) {
+            const int minCX = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(Q.u, P.min_x), Q.radius), P.winv)));
+            const int maxCX = min(P.cols - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(Q.u, P.min_x), Q.radius), P.winv)));
+            const int minCY = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(Q.v, P.min_y), Q.radius), P.hinv)));
+            const int maxCY = min(P.rows - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(Q.v, P.min_y), Q.radius), P.hinv)));
+            if (minCX < P.cols && maxCX >= 0 && minCY < P.rows && maxCY >= 0 && maxCY >= minCY) {
+              for (int ix = minCX; ix <= maxCX; ix++) {
+                const int j0 = cell_start[ix * P.rows + minCY], j1 = cell_start[ix * P.rows + maxCY + 1];
+                for (int j = j0 + tid; j < j1; j += 64) {
+                  const TKey T = tk[j];
+                  if (!(fabsf(__fsub_rn(T.x, Q.u)) < Q.radius && fabsf(__fsub_rn(T.y, Q.v)) < Q.radius)) continue;
+                  visit(j, T, ((unsigned)tk_cell(T.meta) << 12) | (unsigned)tk_idx(T.meta));
+                }
+              }
+            }
+          } else {
+            for (int k = tid; k < nt; k += 64) visit(k, tk[k], (unsigned)k);
+          }
+#pragma unroll
+          for (int off = 32; off > 0; off >>= 1) {
+            const unsigned long long o1 = shfl_xor_u64(t1, off), o2 = shfl_xor_u64(t2, off);
+            const unsigned long long lo = t1 < o1 ? t1 : o1, hi = t1 < o1 ? o1 : t1, s2 = t2 < o2 ? t2 : o2;
+            t1 = lo; t2 = hi < s2 ? hi : s2;
+          }
+          r1 = t1; r2 = t2;
+        };
+        for (int q0 = 0; q0 < nq; q0 += 64) {
+          const int ql = q0 + tid;
+          int fl = 0;
+          {
+            unsigned long long kk[kTopK];
+#pragma unroll
+            for (int t = 0; t < kTopK; t++) kk[t] = kNone;
+            if (ql < nq) {
+              fl = P.q[ql].flags;
+#pragma unroll
+              for (int t = 0; t < kTopK; t += 2) {
+                const ulonglong2 t2 = *reinterpret_cast<const ulonglong2*>(P.cache + kTopK * (size_t)ql + t);
+                kk[t] = t2.x; kk[t + 1] = t2.y;
+              }
+            }
+#pragma unroll
+            for (int t = 0; t < kTopK; t += 2) *reinterpret_cast<ulonglong2*>(lkeys + kTopK * tid + t) = make_ulonglong2(kk[t], kk[t + 1]);
+          }
+          int m_l = -1, bd_l = 256, sd_l = 256, acc_l = -1;                      // this lane's query: match, distances, keypoint accepted at its turn
+          const int cnt = min(64, nq - q0);
+          const int tl = tid < kTopK ? tid : 0;
+          unsigned long long key_n = lkeys[tl];                                 // query 0 of the chunk; the next one is always in flight
+          for (int i = 0; i < cnt; i++) {
+            unsigned long long key = tid < kTopK ? key_n : kNone;
+            const bool full = __builtin_amdgcn_readlane((int)(key_n >> 32), kTopK - 1) != -1 || __builtin_amdgcn_readlane((int)key_n, kTopK - 1) != -1;
+            key_n = lkeys[kTopK * min(i + 1, 63) + tl];
+            const int flags = __builtin_amdgcn_readlane(fl, i);
+            if (!(flags & 1)) continue;
+            const int q = q0 + i;
+            const int kp = key != kNone ? dec(key) : 0;
+            const int vmd = blk[kp], hold = holder[kp];                         // vMatchedDistance and vnMatches21 of this lane's candidate
+            const bool free_ = key != kNone && vmd > (int)(key >> 32);
+            const unsigned long long fm = __ballot(free_) & ((1ull << kTopK) - 1);
+            unsigned long long b1 = kNone, b2 = kNone;
+            int prev = -1;
+            if (__popcll(fm) < 2 && full) {
+              rounds++;                                                         // reported: 1 + the number of rescans
+              wave_rescan(q, b1, b2);
+              if (b1 != kNone) prev = holder[dec(b1)];
+            } else {
+              const unsigned long long fm2 = fm & (fm - 1);
+              if (fm) { const int l1 = __ffsll((long long)fm) - 1; b1 = rl64(key, l1); prev = __builtin_amdgcn_readlane(hold, l1); }
+              if (fm2) b2 = rl64(key, __ffsll((long long)fm2) - 1);
+            }
+            int m = -1, bd = 256, sd = 256;
+            if (b1 != kNone) {
+              bd = (int)(b1 >> 32);
+              const int bi = dec(b1);
+              bool ok = bd <= P.accept_max;
+              if (b2 != kNone) sd = (int)(b2 >> 32);
+              if (ok && P.ratio_mode == 1) ok = (float)bd < __fmul_rn(P.nnratio, (float)sd);                      // ORBmatcher.cc:456
+              if (ok) m = bi;
+            }
+            if (m >= 0) {                                                       // uniform: every lane holds the same m
+              if (prev >= q0) { if (tid == prev - q0) m_l = -1; }               // :460-461, the holder is in this chunk
+              else if (prev >= 0 && tid == 0) P.match[prev] = -1;
+              if (tid == 0) { holder[m] = q; blk[m] = bd; }
+            }
+            if (tid == i) { m_l = m; bd_l = bd; sd_l = sd; acc_l = m; }
+          }
+          if (ql < nq) {
+            P.match[ql] = m_l; P.best_dist[ql] = bd_l; P.second_dist[ql] = sd_l;
+            P.cache[kTopK * (size_t)ql] = (unsigned long long)(long long)acc_l;   // the list is spent: its first word records the acceptance
+          }
+        }
+      }
+      __syncthreads();
+      if (P.check_orientation) {                                                // rotHist of every acceptance (:468-476)
+        for (int q = tid; q < nq; q += kThreads) {
+          const int acc = (int)(long long)P.cache[kTopK * (size_t)q];
+          if (acc < 0 || !(P.q[q].flags & 1)) continue;
+          float rot = __fsub_rn(P.q[q].angle, P.t_angle[acc]);
+          if (rot < 0.f) rot = __fadd_rn(rot, 360.0f);
+          int bin = (int)roundf(__fmul_rn(rot, 1.0f / kHisto));
+          if (bin == kHisto) bin = 0;
+          atomicAdd(&hist[min(max(bin, 0), kHisto - 1)], 1);
+        }
+      }
+      __syncthreads();
+      break;
+    }
     if (!P.sequential || !changed) break;
     if (tid == 0) ctl[0] = 0;
     for (int k = tid; k < nt; k += kThreads) blk[k] = 0x7fffffff;
@@ -354,7 +504,7 @@ __global__ __launch_bounds__(kThreads) void orb_search_kernel(const Problem* __r
         bin = (int)roundf(__fmul_rn(rot, 1.0f / kHisto));
         if (bin == kHisto) bin = 0;
         bin = min(max(bin, 0), kHisto - 1);                                     // the reference asserts the range
-        atomicAdd(&hist[bin], 1);
+        if (P.sequential != 2) atomicAdd(&hist[bin], 1);                        // (steal mode counted every acceptance in its pass)
       }
     }
     P.removed[q] = (uint8_t)bin;
@@ -556,7 +706,7 @@ constexpr int kRowBuckets = 512;           // ROWS mode: one bucket per (octave,
 
 size_t lds_bytes(int nt, int n_cells, bool grid, bool desc) {
   return (size_t)nt * sizeof(TKey) + (desc ? (size_t)nt * 32 : 0) + (size_t)nt * 4 + (size_t)(n_cells + 1) * 4 + 32 * 4 + 8 * 4 + kThreads * 4 +
-         48 * 4 + 16;
+         48 * 4 + (size_t)nt * 4 + 64 * 8 * 8 + 32;
 }
 
 int validate(const lld_orb_search* s, const lld_orb_search_result* out) {
@@ -569,6 +719,8 @@ int validate(const lld_orb_search* s, const lld_orb_search_result* out) {
   if (nt > 0 && (!s->t_desc || !s->t_xy || !s->t_octave)) return LLD_ERR_INVALID;
   if (s->candidates < LLD_ORB_CAND_ALL || s->candidates > LLD_ORB_CAND_ROWS) return LLD_ERR_INVALID;
   if (s->ratio_mode < 0 || s->ratio_mode > 2) return LLD_ERR_INVALID;
+  if (s->sequential < 0 || s->sequential > 2) return LLD_ERR_INVALID;
+  if (s->sequential == 2 && (s->tie_last || s->ratio_mode == 2 || (s->candidates != LLD_ORB_CAND_GRID && s->candidates != LLD_ORB_CAND_ALL))) return LLD_ERR_INVALID;
   const bool grid = s->candidates == LLD_ORB_CAND_GRID;
   if (grid && (!s->q_uv || !s->q_radius || s->grid_cols <= 0 || s->grid_rows <= 0 || s->grid_cols * s->grid_rows > 8191)) return LLD_ERR_INVALID;
   if (s->candidates == LLD_ORB_CAND_CSR && (!s->cand_range || s->n_cand < 0 || (s->n_cand > 0 && !s->cand_idx))) return LLD_ERR_INVALID;

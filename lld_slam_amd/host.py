@@ -687,6 +687,12 @@ class ORBmatcher:
         from . import orb_search as S
         return S.search_by_projection_kf(self.lib, self.ctx.handle, KF, desc, valid, uv, pred_level, matched, th)
 
+    def SearchForInitialization(self, F1, F2, vbPrevMatched, windowSize=10):
+        """SearchForInitialization(Frame&, Frame&, vbPrevMatched, vnMatches12, windowSize)  (src/ORBmatcher.cc:405-520):
+        returns (nmatches, vnMatches12, the updated vbPrevMatched)."""
+        from . import orb_search as S
+        return S.search_for_initialization(self.lib, self.ctx.handle, F1, F2, vbPrevMatched, windowSize, float(self.mfNNratio), self.mbCheckOrientation)
+
     def Fuse(self, KF, desc, valid, uv, ur, pred_level, th=3.0):
         """Inner search of Fuse (src/ORBmatcher.cc:825-1100)."""
         from . import orb_search as S

@@ -306,6 +306,23 @@ def search_by_projection_kf(lib, ctx, KF: Frame, desc, valid, uv, pred_level, ma
                q_valid=valid, q_uv=uv, q_radius=radius, q_level_min=lvl - 1, q_level_max=lvl)
 
 
+def search_for_initialization(lib, ctx, F1: Frame, F2: Frame, prev_matched, window_size=10, nnratio=0.9, check_orientation=True, info=None):
+    """ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:405-520): octave-0 keypoints of F1 against the octave-0 keypoints of F2
+    inside a square window around vbPrevMatched; a keypoint of F2 goes to the query with the smallest distance so far (`sequential = 2`:
+    an earlier holder with a distance <= this one blocks, a better one steals).  Returns (nmatches, vnMatches12, updated vbPrevMatched)."""
+    F1.normalise(); F2.normalise()
+    pm = np.array(prev_matched, np.float32, copy=True).reshape(-1, 2)
+    lvl = np.zeros(F1.n, np.int32)
+    out = run(lib, ctx, F2, F1.desc, candidates=CAND_GRID, gates=GATE_LEVEL, accept_max=TH_LOW, ratio_mode=1, nnratio=nnratio, sequential=2,
+              check_orientation=check_orientation, q_valid=(F1.octave <= 0).astype(np.uint8), q_uv=pm, q_radius=np.full(F1.n, np.float32(int(window_size))),
+              q_level_min=lvl, q_level_max=lvl, q_angle=F1.angle)
+    if info is not None: info["rescans"] = out.rounds - 1                     # queries whose cached candidate list ran dry
+    m12 = np.where(out.removed != 0, -1, out.match).astype(np.int32)
+    ok = m12 >= 0
+    pm[ok] = F2.xy[m12[ok]]
+    return out.n_matches, m12, pm
+
+
 def fuse_search(lib, ctx, KF: Frame, desc, valid, uv, ur, pred_level, th=3.0) -> SearchOutput:
     """Inner search of ORBmatcher::Fuse (src/ORBmatcher.cc:825-958; the Scw overload :960-1100 has the same loop):
     match[i] = bestIdx when bestDist<=TH_LOW; n_matches = nFused.  The replace / add bookkeeping stays with the caller."""

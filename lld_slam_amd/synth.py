@@ -521,6 +521,35 @@ def make_bow_pair(pair_id=0, n=2000, n_nodes=400, related_frac=0.7, flip_p=0.06,
     return F1, F2, nodes
 
 
+def make_init_pair(pair_id=0, n=2000, related_frac=0.8, flip_p=0.05, flow_sigma=12.0, rival_frac=0.15):
+    """Two consecutive monocular frames for ORBmatcher::SearchForInitialization: F2 shows `related_frac` of F1's keypoints again, moved
+    by an optical flow of a few pixels, with descriptor noise and a common rotation; a share of F1's keypoints are near-duplicates
+    of an earlier one (same place, descriptor a few bits off), so that several queries want the same keypoint of F2 and the later,
+    better one takes it away from its holder.  vbPrevMatched starts as F1's own positions (Tracking::MonocularInitialization).
+    Returns (F1, F2, prev_matched)."""
+    rng = np.random.default_rng(SEED_SEARCH + 0x9000 + pair_id)
+    F1 = make_orb_frame(3000 + 2 * pair_id, n, n_clusters=0)
+    F2 = make_orb_frame(3001 + 2 * pair_id, n, n_clusters=0)
+    F1.octave[:] = np.where(rng.random(n) < 0.6, 0, F1.octave); F2.octave[:] = np.where(rng.random(n) < 0.6, 0, F2.octave)   # mostly the finest level
+    n_riv = int(rival_frac * n)
+    src = rng.integers(0, n, n_riv); dst = rng.permutation(n)[:n_riv]
+    keep = dst > src                                                             # the rival comes later in the loop than its original
+    src, dst = src[keep], dst[keep]
+    F1.xy[dst] = F1.xy[src] + rng.integers(-2, 3, (src.size, 2)).astype(np.float32)
+    F1.octave[dst] = F1.octave[src]
+    F1.desc[dst] = _flip_bits(rng, F1.desc[src], 0.01)
+    m = int(related_frac * n)
+    s1 = rng.permutation(n)[:m]; s2 = rng.permutation(n)[:m]
+    F2.desc[s2] = _flip_bits(rng, F1.desc[s1], flip_p)
+    F2.xy[s2] = (F1.xy[s1] + rng.normal(0, flow_sigma, (m, 2))).astype(np.float32)
+    F2.xy[:, 0] = np.clip(F2.xy[:, 0], 0, 1240); F2.xy[:, 1] = np.clip(F2.xy[:, 1], 0, 375)
+    F2.octave[s2] = F1.octave[s1]
+    F2.angle[s2] = np.mod(F1.angle[s1] - 15.0 + rng.normal(0, 4.0, m), 360.0).astype(np.float32)
+    wrong = rng.random(m) < 0.1                                                  # some with an unrelated orientation: the histogram removes them
+    F2.angle[s2[wrong]] = rng.uniform(0, 360, int(wrong.sum())).astype(np.float32)
+    return F1.normalise(), F2.normalise(), F1.xy.copy()
+
+
 def make_stereo_pair(pair_id=0, n=2000, flip_p=0.06):
     """Left / right keypoints of one stereo frame: right keypoints are the left ones shifted by a disparity (rows within the
     +-2*scale band), plus unrelated ones."""

@@ -290,6 +290,54 @@ int lldo_search_by_projection_kf(const lldo_frame* KF, int n, const uint32_t* de
   return nmatches;
 }
 
+// ORBmatcher::SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize)   ORBmatcher.cc:405-520
+//   prev_matched [n1][2] = vbPrevMatched (in: where each F1 keypoint was last matched; out: updated with the F2 position of every match)
+//   matches12 [n1] = vnMatches12.  INT_MAX of the reference is 256 here (no distance exceeds it).
+int lldo_search_for_initialization(const lldo_frame* F1, const lldo_frame* F2, float* prev_matched, int windowSize, float nnratio,
+                                   int check_orientation, int32_t* matches12) {
+  const Grid g = build_grid(*F2);
+  int nmatches = 0;
+  for (int i = 0; i < F1->n; i++) matches12[i] = -1;
+  std::vector<int> rotHist[HISTO_LENGTH];
+  std::vector<int> vMatchedDistance((size_t)F2->n, 0x7fffffff), vnMatches21((size_t)F2->n, -1);
+  for (int i1 = 0; i1 < F1->n; i1++) {
+    const int level1 = F1->octave[i1];
+    if (level1 > 0) continue;
+    const std::vector<int> vIndices2 = features_in_area(*F2, g, prev_matched[2 * i1], prev_matched[2 * i1 + 1], (float)windowSize, level1, level1);
+    if (vIndices2.empty()) continue;
+    int bestDist = 0x7fffffff, bestDist2 = 0x7fffffff, bestIdx2 = -1;
+    for (size_t c = 0; c < vIndices2.size(); c++) {
+      const int i2 = vIndices2[c];
+      const int dist = lldo_descriptor_distance(F1->desc + 8 * i1, F2->desc + 8 * i2);
+      if (vMatchedDistance[i2] <= dist) continue;
+      if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx2 = i2; }
+      else if (dist < bestDist2) bestDist2 = dist;
+    }
+    if (bestDist <= TH_LOW) {
+      if (bestDist < (float)bestDist2 * nnratio) {
+        if (vnMatches21[bestIdx2] >= 0) { matches12[vnMatches21[bestIdx2]] = -1; nmatches--; }
+        matches12[i1] = bestIdx2; vnMatches21[bestIdx2] = i1; vMatchedDistance[bestIdx2] = bestDist;
+        nmatches++;
+        if (check_orientation) rotHist[rot_bin(F1->angle[i1], F2->angle[bestIdx2])].push_back(i1);
+      }
+    }
+  }
+  if (check_orientation) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (size_t j = 0; j < rotHist[i].size(); j++) {
+        const int idx1 = rotHist[i][j];
+        if (matches12[idx1] >= 0) { matches12[idx1] = -1; nmatches--; }
+      }
+    }
+  }
+  for (int i1 = 0; i1 < F1->n; i1++)
+    if (matches12[i1] >= 0) { prev_matched[2 * i1] = F2->xy[2 * matches12[i1]]; prev_matched[2 * i1 + 1] = F2->xy[2 * matches12[i1] + 1]; }
+  return nmatches;
+}
+
 // Inner search of ORBmatcher::Fuse(KeyFrame*, vpMapPoints, th)   ORBmatcher.cc:825-958 (the Scw variant :960-1100 has the
 // same loop without the stereo branch inputs).  best_idx[i] = bestIdx when bestDist<=TH_LOW else -1; the replace/add
 // bookkeeping on the map (:936-954) is the caller's.  Returns nFused.

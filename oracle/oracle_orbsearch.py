@@ -47,6 +47,8 @@ def _dll():
                                                       C.c_int, c_int32_p]
         d.lldo_search_by_projection_kf.argtypes = [fp, C.c_int, c_uint32_p, c_uint8_p, c_float_p, c_int32_p, C.c_int, c_int32_p]
         d.lldo_fuse_search.argtypes = [fp, C.c_int, c_uint32_p, c_uint8_p, c_float_p, c_float_p, c_int32_p, C.c_float, c_int32_p]
+        d.lldo_search_for_initialization.argtypes = [fp, fp, c_float_p, C.c_int, C.c_float, C.c_int, c_int32_p]
+        d.lldo_search_for_initialization.restype = C.c_int
         d.lldo_search_sim3_direction.argtypes = [fp, C.c_int, c_uint32_p, c_uint8_p, c_float_p, c_int32_p, C.c_float, c_int32_p]
         d.lldo_search_sim3_direction.restype = None
         d.lldo_search_by_bow_frame.argtypes = [fp, fp, C.c_int, c_int32_p, c_int32_p, c_int32_p, c_int32_p, c_uint8_p, C.c_float, C.c_int, c_int32_p]
@@ -121,6 +123,15 @@ def search_by_projection_kf(KF, desc, valid, uv, pred_level, matched, th):
     n = _dll().lldo_search_by_projection_kf(C.byref(oframe(KF)), a[0].shape[0], _p(a[0], c_uint32_p), _p(a[1], c_uint8_p), _p(a[2], c_float_p),
                                             _p(a[3], c_int32_p), int(th), _p(slot, c_int32_p))
     return n, slot
+
+
+def search_for_initialization(F1, F2, prev_matched, window_size=10, nnratio=0.9, check_orientation=True):
+    """ORBmatcher::SearchForInitialization: (nmatches, vnMatches12, updated vbPrevMatched)."""
+    pm = np.array(prev_matched, np.float32, copy=True).reshape(-1, 2)
+    m = np.empty(F1.n, np.int32)
+    n = _dll().lldo_search_for_initialization(C.byref(oframe(F1)), C.byref(oframe(F2)), _p(pm, c_float_p), int(window_size), np.float32(nnratio),
+                                              int(check_orientation), _p(m, c_int32_p))
+    return n, m, pm
 
 
 def fuse_search(KF, desc, valid, uv, ur, pred_level, th=3.0):

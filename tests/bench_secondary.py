@@ -174,7 +174,12 @@ c_lf, e_lf = timed(cpu_lf)
 sc = synth.make_stereo_scene(0, 2000)
 g_sf, r_sf = timed(lambda: m.ComputeStereoMatchesFull(sc["L"], sc["R"], sc["left"], sc["right"], sc["inv_scale"], sc["mb"], sc["mbf"]))
 c_sf, e_sf = timed(lambda: OS.compute_stereo_matches(sc["L"], sc["R"], sc["left"], sc["right"], sc["inv_scale"], sc["mb"], sc["mbf"]))
+Fi1, Fi2, prev_i = synth.make_init_pair(0)
+g_ini, r_ini = timed(lambda: ORBmatcher(ctx, 0.9, True).SearchForInitialization(Fi1, Fi2, prev_i, 100))
+c_ini, e_ini = timed(lambda: OS.search_for_initialization(Fi1, Fi2, prev_i, 100, 0.9, True))
 out["orb_guided_search"] = {
+    "search_for_initialization": {"gpu_ms": g_ini * 1e3, "cpu_oracle_ms": c_ini * 1e3, "n_matches": int(r_ini[0]),
+                                  "equal": bool(r_ini[0] == e_ini[0] and np.array_equal(r_ini[1], e_ini[1]))},
     "compute_stereo_matches_full": {"gpu_ms": g_sf * 1e3, "cpu_oracle_ms": c_sf * 1e3, "n_matches": r_sf.n_matches,
                                     "equal": bool(r_sf.n_matches == e_sf[0] and np.array_equal(r_sf.u_right.view(np.uint32), e_sf[1].view(np.uint32)))},
     "search_local_points": {"gpu_ms": g_loc * 1e3, "cpu_oracle_ms": c_loc * 1e3, "n_matches": r_loc[0].n_matches, "equal": r_loc[0].n_matches == e_loc[0]},

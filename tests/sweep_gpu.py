@@ -79,6 +79,14 @@ for seed in range(100, 125):
     if out.n_matches != n_exp or not np.array_equal(expect_slots(out, q["occupied"]), slot): bad += 1; print("frame mismatch", seed)
 print("orb searches checked 50 mismatches", bad)
 bad = 0
+for pid in range(40, 60):
+    F1, F2, prev = synth.make_init_pair(pid, n=int(rng.integers(200, 3500)), rival_frac=float(rng.uniform(0, 0.4)))
+    win, nn, ori = int(rng.integers(5, 160)), float(rng.uniform(0.6, 0.95)), bool(rng.integers(0, 2))
+    on, om, opm = OS.search_for_initialization(F1, F2, prev, win, nn, ori)
+    gn, gm, gpm = ORBmatcher(ctx, nn, ori).SearchForInitialization(F1, F2, prev, win)
+    if gn != on or not np.array_equal(gm, om) or not np.array_equal(gpm, opm): bad += 1; print("initialisation search mismatch", pid, win, nn, ori)
+print("initialisation searches checked 20 mismatches", bad)
+bad = 0
 from lld_slam_amd import Tracking
 for seed in range(200, 240):
     P, L, F = synth.make_line_track_scene(seed, n_map=int(rng.integers(1, 400)), n_cur=int(rng.integers(1, 500)), related_frac=float(rng.uniform(0.2, 0.9)),

@@ -358,3 +358,51 @@ def test_compute_stereo_matches_device_resident_pyramids(gpu_ctx):
     assert fn(gpu_ctx.handle, C.byref(kl), C.byref(kr), C.byref(P), sc["mb"], sc["mbf"], C.byref(r)) == 0
     g.n_matches = r.n_matches
     _check_stereo(g, ref)
+
+
+# ------------------------------------------------------------------ ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:405-520)
+@pytest.mark.parametrize("pid,n,window,nn,check", [(0, 2000, 100, 0.9, True), (1, 2000, 30, 0.9, True), (2, 1200, 60, 0.7, False), (3, 3000, 150, 0.9, True),
+                                                   (4, 300, 10, 0.9, True)])
+def test_search_for_initialization(gpu_ctx, pid, n, window, nn, check):
+    """The one matcher whose order dependence is not an occupancy: a keypoint of F2 goes to the query with the smallest distance so far
+    (an earlier holder with a distance <= this one blocks, a better query takes it over).  vnMatches12, nmatches and the updated
+    vbPrevMatched equal the sequential oracle."""
+    F1, F2, prev = synth.make_init_pair(pid, n=n)
+    on, om, opm = OS.search_for_initialization(F1, F2, prev, window, nn, check)
+    gn, gm, gpm = ORBmatcher(gpu_ctx, nn, check).SearchForInitialization(F1, F2, prev, window)
+    assert gn == on and (on > 20 or n < 500)
+    np.testing.assert_array_equal(gm, om); np.testing.assert_array_equal(gpm, opm)
+
+
+def test_search_for_initialization_with_crowded_windows(gpu_ctx):
+    """Every level-0 keypoint of F1 is a near-duplicate of one of 40 prototypes sitting in one spot: hundreds of queries compete for
+    the same few keypoints of F2 and most cached candidate lists run dry (fewer than two free entries of a full list), which sends
+    the query through the rescan with the take-over rule."""
+    F1, F2, prev = synth.make_init_pair(7, n=1500, rival_frac=0.0)
+    rng = np.random.default_rng(5)
+    proto = rng.integers(0, 1500, 40)
+    for i in range(1500):
+        if i in proto: continue
+        p = proto[i % 40]
+        F1.desc[i] = synth._flip_bits(rng, F1.desc[p:p + 1], 0.004)[0]; F1.xy[i] = F1.xy[p] + rng.integers(-3, 4, 2).astype(np.float32); F1.octave[i] = 0
+    F2.xy[:400] = F1.xy[proto[np.arange(400) % 40]] + rng.integers(-6, 7, (400, 2)).astype(np.float32); F2.octave[:400] = 0
+    F2.desc[:400] = synth._flip_bits(rng, F1.desc[proto[np.arange(400) % 40]], 0.02)
+    F1.normalise(); F2.normalise()
+    prev = F1.xy.copy()
+    on, om, opm = OS.search_for_initialization(F1, F2, prev, 40, 0.95, True)
+    info = {}
+    gn, gm, gpm = orb_search.search_for_initialization(gpu_ctx.lib, gpu_ctx.handle, F1, F2, prev, 40, 0.95, True, info=info)
+    assert gn == on and info["rescans"] > 20
+    np.testing.assert_array_equal(gm, om); np.testing.assert_array_equal(gpm, opm)
+
+
+def test_search_for_initialization_edge_cases(gpu_ctx):
+    F1, F2, prev = synth.make_init_pair(9, n=200)
+    F1.octave[:] = 1; F1.normalise()                                          # no level-0 keypoint: nothing is searched
+    n, m, pm = ORBmatcher(gpu_ctx, 0.9, True).SearchForInitialization(F1, F2, prev, 100)
+    assert n == 0 and np.all(m == -1) and np.array_equal(pm, prev)
+    F1, F2, prev = synth.make_init_pair(9, n=200)
+    far = prev + np.float32(5000.0)                                           # windows outside the image
+    n, m, pm = ORBmatcher(gpu_ctx, 0.9, True).SearchForInitialization(F1, F2, far, 100)
+    on, om, _ = OS.search_for_initialization(F1, F2, far, 100, 0.9, True)
+    assert n == on == 0 and np.all(m == -1)

@@ -359,3 +359,62 @@ def test_compute_stereo_matches_degenerate_inputs():
               angle=np.zeros(0, np.float32))
     n, ur, dep, br, sad = OS.compute_stereo_matches(L, E, sc["left"], sc["right"], sc["inv_scale"], sc["mb"], sc["mbf"])
     assert n == 0 and (ur < 0).all() and (br < 0).all()
+
+
+def py_search_for_initialization(F1, F2, prev, window, nn, check_ori):
+    """ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:405-520) line by line; also counts the matches taken away from a holder."""
+    cells = py_grid(F2)
+    m12 = [-1] * F1.n; m21 = [-1] * F2.n; md = [2 ** 31 - 1] * F2.n
+    hist = [[] for _ in range(30)]; n = 0; steals = 0
+    for i1 in range(F1.n):
+        if F1.octave[i1] > 0: continue
+        cand = py_features_in_area(F2, cells, prev[i1, 0], prev[i1, 1], window, 0, 0)
+        if not cand: continue
+        best = best2 = 2 ** 31 - 1; bi = -1
+        for i2 in cand:
+            d = popcount(F1.desc[i1], F2.desc[i2])
+            if md[i2] <= d: continue
+            if d < best: best2 = best; best = d; bi = i2
+            elif d < best2: best2 = d
+        if best <= 50 and f32(best) < f32(f32(best2) * f32(nn)):
+            if m21[bi] >= 0: m12[m21[bi]] = -1; n -= 1; steals += 1
+            m12[i1] = bi; m21[bi] = i1; md[bi] = best; n += 1
+            if check_ori: hist[py_rot_bin(F1.angle[i1], F2.angle[bi])].append(i1)
+    if check_ori:
+        keep = py_three_maxima([len(h) for h in hist])
+        for b in range(30):
+            if b in keep: continue
+            for i1 in hist[b]:
+                if m12[i1] >= 0: m12[i1] = -1; n -= 1
+    prev = prev.copy()
+    for i1 in range(F1.n):
+        if m12[i1] >= 0: prev[i1] = F2.xy[m12[i1]]
+    return n, np.array(m12, np.int32), prev, steals
+
+
+@pytest.mark.parametrize("pid,window,nn,ori", [(0, 30, 0.9, True), (1, 100, 0.9, True), (2, 60, 0.7, False)])
+def test_search_for_initialization_matches_the_naive_restatement(pid, window, nn, ori):
+    F1, F2, prev = synth.make_init_pair(pid, n=500)
+    n, m, pm = OS.search_for_initialization(F1, F2, prev, window, nn, ori)
+    pn, pm12, pprev, steals = py_search_for_initialization(F1, F2, prev, window, nn, ori)
+    assert n == pn and n > 80
+    np.testing.assert_array_equal(m, pm12); np.testing.assert_array_equal(pm, pprev)
+    assert steals > 0                                                        # the scene does exercise the take-over rule
+
+
+def test_search_for_initialization_takes_a_keypoint_from_a_worse_holder():
+    """Three level-0 queries on one keypoint of F2: distances 6, 3 (takes over), 3 (an equal distance does not), a level-1 query is
+    skipped, the stale histogram entry of the displaced query still counts."""
+    scale, sigma2, inv = orb_levels()
+    d0 = np.zeros(8, np.uint32)
+    def desc(bits):
+        d = d0.copy(); d[0] = (1 << bits) - 1; return d
+    F2 = Frame(desc=np.stack([d0, np.full(8, 0xffffffff, np.uint32)]), xy=np.array([[100, 100], [400, 200]], f32), octave=np.zeros(2, np.int32), uright=-np.ones(2, f32),
+               angle=np.array([10, 10], f32), min_x=0.0, min_y=0.0, max_x=1241.0, max_y=376.0).normalise()
+    F1 = Frame(desc=np.stack([desc(6), desc(3), desc(3) ^ np.array([0, 1, 0, 0, 0, 0, 0, 0], np.uint32) ^ np.array([1, 0, 0, 0, 0, 0, 0, 0], np.uint32), desc(1)]),
+               xy=np.array([[101, 100], [99, 101], [100, 99], [100, 100]], f32), octave=np.array([0, 0, 0, 1], np.int32), uright=-np.ones(4, f32),
+               angle=np.array([200, 12, 12, 12], f32), min_x=0.0, min_y=0.0, max_x=1241.0, max_y=376.0).normalise()
+    n, m, pm = OS.search_for_initialization(F1, F2, F1.xy.copy(), 10, 0.9, True)
+    assert popcount(F1.desc[2], F2.desc[0]) == 3
+    assert n == 1 and m.tolist() == [-1, 0, -1, -1]
+    np.testing.assert_array_equal(pm[1], F2.xy[0]); np.testing.assert_array_equal(pm[0], F1.xy[0])
