@@ -1368,17 +1368,20 @@ __device__ __forceinline__ void schur_chunk_wave(const BAArrays& A, const BAWin&
     int g_n = 0, id_n = 0, g_nn = 0, id_nn = 0, a_n = 0, fl_n = 0;
     double v_n[VN];
     double ws_n = 0.0; Vec3 X_n = vec3(0, 0, 1);
+    // Every lane issues every load, with the landmark index clamped into the chunk (a lane past the end or outside the staging range
+    // re-reads the last landmark and never uses it): loads under a divergent `if` cannot be counted and the compiler waits for
+    // vmcnt(0) at the first use of any loaded value (14 such waits in this kernel before, 7 now; the loads are a whole sub-batch of
+    // arithmetic ahead either way, so the launch time did not move).
     auto fetch_idx = [&](int t0, int& g, int& id) {
-      if (stager && t0 + ej < C.n_lm) { g = lm[t0 + ej]; id = tab[(size_t)(t0 + ej) * k + esl]; }
+      const int tj = min(t0 + ej, C.n_lm - 1);
+      g = lm[tj]; id = tab[(size_t)tj * k + esl];
     };
     auto fetch_data = [&](int t0, int g, int id) {
-      if (stager && t0 + ej < C.n_lm) {
-        a_n = act[g];
-        const double* V = Vbase + (size_t)g * VN;
+      a_n = act[g];
+      const double* V = Vbase + (size_t)g * VN;
 #pragma unroll
-        for (int i = 0; i < VN; i++) v_n[i] = V[i];
-        if constexpr (D == 3) { ws_n = A.pe_ws[id]; fl_n = A.pe_flags[id]; X_n = load_pt(A, cur, g); }
-      }
+      for (int i = 0; i < VN; i++) v_n[i] = V[i];
+      if constexpr (D == 3) { ws_n = A.pe_ws[id]; fl_n = A.pe_flags[id]; X_n = load_pt(A, cur, g); }
     };
     fetch_idx(0, g_n, id_n);
     fetch_idx(NB, g_nn, id_nn);
@@ -1394,18 +1397,17 @@ __device__ __forceinline__ void schur_chunk_wave(const BAArrays& A, const BAWin&
       g_n = g_nn; id_n = id_nn;
       fetch_data(t0 + NB, g_n, id_n);
       fetch_idx(t0 + 2 * NB, g_nn, id_nn);
+      if constexpr (D == 4) {
+        // line observation: the summed 6x4 block was stored by the linearisation (fetched here, not a sub-batch ahead: holding two
+        // of them would halve the occupancy); by every lane, like the prefetch (id_cur is a valid observation in all of them)
+        const double* Wg = A.lo_W + (size_t)id_cur * WN;
+#pragma unroll
+        for (int i = 0; i < WN; i += 2) { const double2 t2 = *reinterpret_cast<const double2*>(Wg + i); w[i] = t2.x; w[i + 1] = t2.y; }
+      }
       __syncthreads();                                      // the previous sub-batch has been consumed
       if (stager && ej < nb) {
-        if constexpr (D == 3) {
-          // point edge: the Hpl block is a function of the linearisation-point pose, point and one weight
-          point_hpl_closed(W.cam, T, Rt, X, (fl_raw & EF_STEREO) != 0, ws, w);
-        } else {
-          // line observation: the summed 6x4 block was stored by the linearisation (fetched here, not a sub-batch ahead: holding
-          // two of them would halve the occupancy)
-          const double* Wg = A.lo_W + (size_t)id_cur * WN;
-#pragma unroll
-          for (int i = 0; i < WN; i += 2) { const double2 t2 = *reinterpret_cast<const double2*>(Wg + i); w[i] = t2.x; w[i + 1] = t2.y; }
-        }
+        // point edge: the Hpl block is a function of the linearisation-point pose, point and one weight
+        if constexpr (D == 3) point_hpl_closed(W.cam, T, Rt, X, (fl_raw & EF_STEREO) != 0, ws, w);
         schur_stage_one<D>(a_raw != 0, v, lambda, w, Zl + lane * WS, tl + ej * D, esl == 0);
       }
       __syncthreads();
