@@ -1,0 +1,91 @@
+"""Random local-BA / global-BA windows, GPU vs oracle at the parity bar of tests/test_gpu_ba.py (check_ba).  Window shape, observation
+counts, outlier and monocular fractions, noise levels, gamma, iteration counts and the solver are drawn at random.
+   python tools/fuzz_ba.py [n=200] [seed=0]"""
+import sys, traceback, numpy as np
+sys.path.insert(0, "."); sys.path.insert(0, "tests"); sys.path.insert(0, "oracle")
+from lld_slam_amd import Context, Optimizer, BABatch, synth
+import oracle_py as O
+from test_gpu_ba import check_ba
+ctx = Context(0); O.lib()
+
+
+def rel(a, b): return np.linalg.norm(a - b, axis=1) / np.maximum(np.linalg.norm(b, axis=1), 1e-3)
+
+
+def deviation(a, o, w):
+    return dict(cam=float(np.abs(a.cam_qt - o.cam_qt).max()) if w.n_cams else 0.0, pt=float(rel(a.pt_xyz, o.pt_xyz).max()) if w.n_points else 0.0,
+                ln=float(rel(a.line_x0, o.line_x0).max()) if w.n_lines else 0.0,
+                chi=abs(a.stats["chi2_final"] - o.stats["chi2_final"]) / max(o.stats["chi2_round1"], 1e-30))
+
+
+def permuted(w, rng):
+    """the same window with the landmarks in another order and every landmark's observations in another order - what the reference
+    does from run to run (its lists and std::map<KeyFrame*, size_t> are in address order).  Returns (window, point order, line order):
+    landmark i of the new window is landmark order[i] of the old one."""
+    from lld_slam_amd import host
+    def reorder(start, n_lm):
+        order = rng.permutation(n_lm)
+        new_start = [0]; idx = []
+        for l_ in order:
+            s_, e_ = start[l_], start[l_ + 1]
+            idx.extend((s_ + rng.permutation(e_ - s_)).tolist()); new_start.append(len(idx))
+        return order, np.array(new_start, np.int32), np.array(idx, np.int64)
+    po, ps, pi = reorder(w.pt_obs_start, w.n_points)
+    lo, ls, li = reorder(w.ln_obs_start, w.n_lines)
+    w2 = host.Window(cam=w.cam, n_free_cams=w.n_free_cams, cam_qt=w.cam_qt.copy(), pt_xyz=w.pt_xyz[po], pt_obs_start=ps, pt_obs_cam=w.pt_obs_cam[pi],
+                     pt_obs_uvr=w.pt_obs_uvr.reshape(-1, 3)[pi], pt_obs_inv_sigma2=w.pt_obs_inv_sigma2[pi], line_x0=w.line_x0[lo], line_dir=w.line_dir[lo],
+                     ln_obs_start=ls, ln_obs_cam=w.ln_obs_cam[li], ln_obs_left=w.ln_obs_left.reshape(-1, 4)[li], ln_obs_right=w.ln_obs_right.reshape(-1, 4)[li],
+                     ln_obs_octave=w.ln_obs_octave.reshape(-1, 2)[li])
+    return w2.normalise(), po, lo
+
+
+def deviation_permuted(b, po, lo, o, w):
+    """b: result on the permuted window; back to the original landmark order"""
+    import copy
+    b2 = copy.copy(b)
+    pt = np.empty_like(o.pt_xyz); pt[po] = b.pt_xyz; b2.pt_xyz = pt
+    x0 = np.empty_like(o.line_x0); x0[lo] = b.line_x0; b2.line_x0 = x0
+    return deviation(b2, o, w)
+
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+bad = 0; done = 0; soft = 0
+batch = []
+for it in range(n):
+    n_free = int(rng.integers(0, 40)); n_fixed = int(rng.integers(1 if n_free == 0 else 0, 6))
+    if n_free + n_fixed < 2: n_fixed += 2
+    kw = dict(n_free=n_free, n_fixed=n_fixed, n_points=int(rng.integers(0, 900)), obs_per_point=int(rng.integers(2, min(7, n_free + n_fixed) + 1)),
+              n_lines=int(rng.integers(0, 150)), obs_per_line=int(rng.integers(1, min(6, n_free + n_fixed) + 1)), seed=int(rng.integers(1, 2 ** 31)),
+              outlier_frac=float(rng.choice([0.0, 0.05, 0.2, 0.5])), mono_frac=float(rng.choice([0.0, 0.0, 0.3, 1.0])),
+              mono_line_frac=float(rng.choice([0.0, 0.0, 0.4, 1.0])), noise=float(rng.choice([0.0, 0.5, 1.0, 3.0])),
+              pose_sigma=(float(rng.uniform(0, 1.5)), float(rng.uniform(0, 0.15))), point_sigma=float(rng.uniform(0, 0.3)))
+    par = dict(gamma=float(rng.choice([1.0, 1.0, 0.5, 0.1])), its_round1=int(rng.integers(1, 8)), its_round2=int(rng.integers(1, 18)))
+    try:
+        w = synth.make_ba_window(**kw)
+    except Exception as e:
+        continue
+    if w.n_edges() == 0 and rng.random() < 0.8: continue
+    try:
+        o = O.local_ba(w, **par)
+        g = Optimizer(ctx).LocalBundleAdjustment(w, reduced_solver=int(rng.choice([0, 0, 1, 2])) if n_free <= 50 else 0, **par)
+        check_ba(g, o, w)
+        done += 1
+    except AssertionError as e:
+        # beyond the bar: is it the reference's own order sensitivity on this window (an ill-conditioned one), or something else?
+        same = (np.array_equal(g.pt_obs_outlier, o.pt_obs_outlier) and np.array_equal(g.ln_edge_outlier, o.ln_edge_outlier) and np.array_equal(g.line_removed, o.line_removed)
+                and g.stats["lm_trials"] == o.stats["lm_trials"])
+        dg = deviation(g, o, w)
+        floor = dict(cam=0.0, pt=0.0, ln=0.0, chi=0.0)
+        for r_ in range(6):
+            w2, po, lo = permuted(w, rng)
+            d2 = deviation_permuted(O.local_ba(w2, **par), po, lo, o, w)
+            floor = {k_: max(floor[k_], d2[k_]) for k_ in floor}
+        within = all(dg[k_] <= 10 * floor[k_] + 1e-12 for k_ in dg)
+        if within: soft += 1
+        else: bad += 1
+        print("FLOOR   " if within else "MISMATCH", it, "sets / trials equal", same, "gpu-oracle", {k_: "%.1e" % v_ for k_, v_ in dg.items()},
+              "oracle-reordered oracle", {k_: "%.1e" % v_ for k_, v_ in floor.items()}, kw if not within else "", par if not within else "", flush=True)
+    except Exception as e:
+        bad += 1; print("ERROR", it, kw, par, repr(e)[:300], flush=True)
+print("fuzzed", done + soft + bad, "windows:", done, "within the parity bar,", soft, "beyond it but within 10x the oracle's own order sensitivity,", bad, "mismatches / errors")
