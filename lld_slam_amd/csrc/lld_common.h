@@ -34,6 +34,8 @@ struct lld_ctx {
   size_t pinned_bytes = 0;
   // small pinned block the single-window BA polls its progress counters through
   void* poll = nullptr;
+  // kernel attributes are per device: remembered per context, not in a process-wide static (a process may hold contexts on several GPUs)
+  bool orb_lds_raised = false;
 };
 
 // Grow-only pinned host staging on the context.

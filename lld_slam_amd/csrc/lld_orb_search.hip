@@ -854,8 +854,7 @@ extern "C" int lld_orb_search_batch(lld_ctx* ctx, int n, const lld_orb_search* p
 
   hipStream_t sm = ctx->stream;
   LLD_HIP_TRY(hipMemcpyAsync(d, h, in_bytes, hipMemcpyHostToDevice, sm));
-  static bool lds_raised = false;
-  if (!lds_raised) { LLD_HIP_TRY(hipFuncSetAttribute((const void*)orb_search_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit)); lds_raised = true; }
+  if (!ctx->orb_lds_raised) { LLD_HIP_TRY(hipFuncSetAttribute((const void*)orb_search_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit)); ctx->orb_lds_raised = true; }
   hipLaunchKernelGGL(orb_search_kernel, dim3(n), dim3(kThreads), lds_max, sm, reinterpret_cast<const Problem*>(d));
   LLD_HIP_TRY(hipGetLastError());
   LLD_HIP_TRY(hipMemcpyAsync(h_out, d_out, out_bytes, hipMemcpyDeviceToHost, sm));
@@ -951,8 +950,7 @@ struct ProjSearch {
   int search_and_fetch(lld_orb_search_result* res) {
     const Problem& P = *reinterpret_cast<const Problem*>(h);
     const size_t lds = lds_bytes(nt, P.cols * P.rows, true, P.desc_in_lds != 0);
-    static bool lds_raised = false;
-    if (!lds_raised) { LLD_HIP_TRY(hipFuncSetAttribute((const void*)orb_search_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit)); lds_raised = true; }
+    if (!ctx->orb_lds_raised) { LLD_HIP_TRY(hipFuncSetAttribute((const void*)orb_search_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit)); ctx->orb_lds_raised = true; }
     hipLaunchKernelGGL(orb_search_kernel, dim3(1), dim3(kThreads), lds, ctx->stream, reinterpret_cast<const Problem*>(d));
     LLD_HIP_TRY(hipGetLastError());
     LLD_HIP_TRY(hipMemcpyAsync(h_out, d_out, out, hipMemcpyDeviceToHost, ctx->stream));
