@@ -61,6 +61,7 @@ for it in range(n):
               mono_line_frac=float(rng.choice([0.0, 0.0, 0.4, 1.0])), noise=float(rng.choice([0.0, 0.5, 1.0, 3.0])),
               pose_sigma=(float(rng.uniform(0, 1.5)), float(rng.uniform(0, 0.15))), point_sigma=float(rng.uniform(0, 0.3)))
     par = dict(gamma=float(rng.choice([1.0, 1.0, 0.5, 0.1])), its_round1=int(rng.integers(1, 8)), its_round2=int(rng.integers(1, 18)))
+    if rng.random() < 0.25: par = dict(protocol=1, its_round1=int(rng.integers(1, 12)), robust_points=int(rng.integers(0, 2)))   # Optimizer::BundleAdjustment
     try:
         w = synth.make_ba_window(**kw)
     except Exception as e:
