@@ -7,6 +7,8 @@
 //   harness sim3 <in> <out>     Optimizer::OptimizeSim3
 //   harness pose <in> <out>     Optimizer::PoseOptimization
 //   harness orb  <in> <out>     ORBmatcher::BestTwo (brute force)
+//   harness lines <in> <out>    Tracking::AddLinesFrom + Tracking::MatchLinesLastKF
+//   harness init <in> <out>     ORBmatcher::SearchForInitialization
 //
 // File layout: int32 header (counts), then the arrays in the order they appear in the structs, native endianness.
 #include <cstdio>
@@ -92,6 +94,55 @@ int run_orb(const char* in, const char* out) {
   return 0;
 }
 
+// one stereo frame's lines: n, n_right, then left[4n] right[4 n_right] left_octave[n] line_matches[n] occupied[n] desc[n dim]
+void read_frame_lines(Reader& r, int dim, lld_amd::FrameLines& F) {
+  int32_t h[2]; r.get(h, 2);
+  r.get(F.left, 4 * (size_t)h[0]); r.get(F.right, 4 * (size_t)h[1]); r.get(F.left_octave, h[0]); r.get(F.line_matches, h[0]);
+  r.get(F.occupied, h[0]); r.get(F.desc, (size_t)h[0] * dim);
+}
+
+int run_lines(const char* in, const char* out) {
+  Reader r(in);
+  int32_t h[3]; r.get(h, 3);                   // dim, n_map, use_grid
+  double k[9 + 16 + 16 + 5]; r.get(k, 46);     // K, T_curr, T_last (unused here), b, mnMaxX, mnMaxY, mdThr, thrReprojLineBase
+  const int dim = h[0], n_map = h[1];
+  lld_amd::MapLineSet L;
+  r.get(L.X0, 3 * (size_t)n_map); r.get(L.dir, 3 * (size_t)n_map); r.get(L.X1, 3 * (size_t)n_map); r.get(L.X2, 3 * (size_t)n_map);
+  r.get(L.skip, n_map); r.get(L.desc, (size_t)n_map * dim);
+  lld_amd::FrameLines F, cur, last;
+  read_frame_lines(r, dim, F);
+  double k2[9 + 16 + 16 + 5]; r.get(k2, 46);   // the second scene: K, T_curr, T_last, b, mnMaxX, mnMaxY, mdThr, thr
+  read_frame_lines(r, dim, cur); read_frame_lines(r, dim, last);
+  lld_amd::Context ctx(0);
+  std::vector<int> m;
+  lld_amd::Tracking(ctx, k, k[41], k[42], k[43], k[44]).AddLinesFrom(L, k + 9, k[45], F, dim, &m, h[2] != 0);
+  std::vector<int> ml; std::vector<uint8_t> created; std::vector<double> X0, dir;
+  lld_amd::Tracking(ctx, k2, k2[41], k2[42], k2[43], k2[44]).MatchLinesLastKF(k2 + 9, k2 + 25, cur, last, dim, &ml, &created, &X0, &dir, k2[45], h[2] != 0);
+  Writer wr(out);
+  wr.put(m); wr.put(ml); wr.put(created); wr.put(X0); wr.put(dir);
+  std::printf("lines: %d map lines x %d frame lines, %d x %d\n", n_map, F.size(), cur.size(), last.size());
+  return 0;
+}
+
+int run_init(const char* in, const char* out) {
+  Reader r(in);
+  int32_t h[4]; r.get(h, 4);                   // n1, n2, windowSize, checkOrientation
+  float g[5]; r.get(g, 5);                     // mnMinX, mnMinY, mfGridElementWidthInv, mfGridElementHeightInv, mfNNratio
+  std::vector<uint32_t> d1, d2; std::vector<int32_t> o1, o2; std::vector<float> a1, a2, xy2, prev;
+  r.get(d1, 8 * (size_t)h[0]); r.get(o1, h[0]); r.get(a1, h[0]); r.get(prev, 2 * (size_t)h[0]);
+  r.get(d2, 8 * (size_t)h[1]); r.get(o2, h[1]); r.get(a2, h[1]); r.get(xy2, 2 * (size_t)h[1]);
+  lld_orb_search f2{};
+  f2.nt = h[1]; f2.t_desc = d2.data(); f2.t_xy = xy2.data(); f2.t_octave = o2.data(); f2.t_angle = a2.data();
+  f2.grid_min_x = g[0]; f2.grid_min_y = g[1]; f2.grid_width_inv = g[2]; f2.grid_height_inv = g[3]; f2.grid_cols = 64; f2.grid_rows = 48;
+  lld_amd::Context ctx(0);
+  std::vector<int32_t> m12;
+  const int n = lld_amd::ORBmatcher(ctx, g[4], h[3] != 0).SearchForInitialization(f2, h[0], d1.data(), o1.data(), a1.data(), prev, m12, h[2]);
+  Writer wr(out);
+  const int32_t n32 = n; wr.put(&n32, 1); wr.put(m12); wr.put(prev);
+  std::printf("init: %d matches of %d\n", n, h[0]);
+  return 0;
+}
+
 int run_sim3(const char* in, const char* out) {
   Reader r(in);
   int32_t h[2]; r.get(h, 2);                   // n, bFixScale
@@ -117,13 +168,15 @@ int run_sim3(const char* in, const char* out) {
 }  // namespace
 
 int main(int argc, char** argv) {
-  if (argc != 4) { std::fprintf(stderr, "usage: harness ba|gba|pose|orb|sim3 <in> <out>\n"); return 2; }
+  if (argc != 4) { std::fprintf(stderr, "usage: harness ba|gba|pose|orb|sim3|lines|init <in> <out>\n"); return 2; }
   try {
     if (!std::strcmp(argv[1], "ba")) return run_ba(argv[2], argv[3], false);
     if (!std::strcmp(argv[1], "gba")) return run_ba(argv[2], argv[3], true);
     if (!std::strcmp(argv[1], "sim3")) return run_sim3(argv[2], argv[3]);
     if (!std::strcmp(argv[1], "pose")) return run_pose(argv[2], argv[3]);
     if (!std::strcmp(argv[1], "orb")) return run_orb(argv[2], argv[3]);
+    if (!std::strcmp(argv[1], "lines")) return run_lines(argv[2], argv[3]);
+    if (!std::strcmp(argv[1], "init")) return run_init(argv[2], argv[3]);
     std::fprintf(stderr, "unknown mode %s\n", argv[1]);
     return 2;
   } catch (const std::exception& e) {

@@ -154,3 +154,61 @@ def test_harness_optimize_sim3(harness, tmp_path, oracle):
     o = oracle.optimize_sim3(p)
     assert n_in == o.n_inliers and np.array_equal(dropped, o.dropped)
     np.testing.assert_allclose(S[:4], o.s12_q, rtol=1e-5, atol=1e-7); np.testing.assert_allclose(S[4:7], o.s12_t, rtol=1e-5, atol=1e-6)
+
+
+def _write_frame_lines(f, left, right, octave, matches, occupied, desc):
+    np.array([left.shape[0], right.shape[0]], np.int32).tofile(f)
+    np.ascontiguousarray(left, np.float32).tofile(f); np.ascontiguousarray(right, np.float32).tofile(f)
+    np.ascontiguousarray(octave, np.int32).tofile(f); np.ascontiguousarray(matches, np.int32).tofile(f)
+    np.ascontiguousarray(occupied, np.uint8).tofile(f); np.ascontiguousarray(desc, np.float32).tofile(f)
+
+
+@pytest.mark.gpu
+def test_harness_tracking_line_matchers_golden(harness, tmp_path):
+    """lld_amd::Tracking::AddLinesFrom / MatchLinesLastKF (include/lld_amd.hpp) on tests/golden/line_track.npz."""
+    d = np.load(os.path.join(GOLD, "line_track.npz"))
+    dim = d["l_desc"].shape[1]; n_map = d["l_X0"].shape[0]
+    def params(pre, T_last=None):
+        return np.concatenate([d[pre + "K"].reshape(-1), d[pre + "T_curr"].reshape(-1), (np.zeros(16) if T_last is None else T_last.reshape(-1)),
+                               [float(d[pre + "b"]), 1.0 / float(d[pre + "sx"]), 1.0 / float(d[pre + "sy"]), float(d[pre + "md_thr"]), float(d[pre + "thr_reproj_base"])]]).astype(np.float64)
+    with open(tmp_path / "in.bin", "wb") as f:
+        np.array([dim, n_map, 1], np.int32).tofile(f)
+        params("p_").tofile(f)
+        for k in ("l_X0", "l_dir", "l_X1", "l_X2"): np.ascontiguousarray(d[k], np.float64).tofile(f)
+        np.ascontiguousarray(d["l_skip"], np.uint8).tofile(f); np.ascontiguousarray(d["l_desc"], np.float32).tofile(f)
+        _write_frame_lines(f, d["f_left_lines"], d["f_right_lines"], d["f_left_octave"], d["f_line_matches"], d["f_occupied"], d["f_desc"])
+        params("p2_", d["p2_T_last"]).tofile(f)
+        nc = d["c_left_lines"].shape[0]
+        _write_frame_lines(f, d["c_left_lines"], d["c_right_lines"], np.zeros(nc, np.int32), d["c_line_matches"], d["c_occupied"], d["c_desc"])
+        _write_frame_lines(f, d["k_left_lines"], d["k_right_lines"], d["k_left_octave"], d["k_line_matches"], d["k_skip"], d["k_desc"])
+    r = run(harness, "lines", tmp_path)
+    assert r.returncode == 0, r.stderr
+    with open(tmp_path / "out.bin", "rb") as f:
+        m = np.fromfile(f, np.int32, n_map); ml = np.fromfile(f, np.int32, nc); created = np.fromfile(f, np.uint8, nc)
+        x0 = np.fromfile(f, np.float64, 3 * nc).reshape(-1, 3); dr = np.fromfile(f, np.float64, 3 * nc).reshape(-1, 3)
+    np.testing.assert_array_equal(m, d["out_m_grid"])
+    np.testing.assert_array_equal(ml, d["out_k_match"]); np.testing.assert_array_equal(created, d["out_k_created"])
+    ok = created.astype(bool)
+    np.testing.assert_allclose(x0[ok], d["out_k_x0"][ok], rtol=1e-6, atol=1e-6); np.testing.assert_allclose(dr[ok], d["out_k_dir"][ok], atol=1e-7)
+
+
+@pytest.mark.gpu
+def test_harness_search_for_initialization(harness, tmp_path):
+    """lld_amd::ORBmatcher::SearchForInitialization (include/lld_amd.hpp) against the oracle."""
+    import oracle_orbsearch as OS
+    from lld_slam_amd import synth
+    F1, F2, prev = synth.make_init_pair(12, n=900)
+    on, om, opm = OS.search_for_initialization(F1, F2, prev, 60, 0.9, True)
+    with open(tmp_path / "in.bin", "wb") as f:
+        np.array([F1.n, F2.n, 60, 1], np.int32).tofile(f)
+        np.array([F2.min_x, F2.min_y, F2.width_inv, F2.height_inv, 0.9], np.float32).tofile(f)
+        np.ascontiguousarray(F1.desc, np.uint32).tofile(f); np.ascontiguousarray(F1.octave, np.int32).tofile(f); np.ascontiguousarray(F1.angle, np.float32).tofile(f)
+        np.ascontiguousarray(prev, np.float32).tofile(f)
+        np.ascontiguousarray(F2.desc, np.uint32).tofile(f); np.ascontiguousarray(F2.octave, np.int32).tofile(f); np.ascontiguousarray(F2.angle, np.float32).tofile(f)
+        np.ascontiguousarray(F2.xy, np.float32).tofile(f)
+    r = run(harness, "init", tmp_path)
+    assert r.returncode == 0, r.stderr
+    with open(tmp_path / "out.bin", "rb") as f:
+        n = int(np.fromfile(f, np.int32, 1)[0]); m = np.fromfile(f, np.int32, F1.n); pm = np.fromfile(f, np.float32, 2 * F1.n).reshape(-1, 2)
+    assert n == on and on > 100
+    np.testing.assert_array_equal(m, om); np.testing.assert_array_equal(pm, opm)
