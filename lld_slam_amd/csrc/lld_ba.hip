@@ -229,6 +229,31 @@ void stage_chunks(const lld_ba_window& w, int D, const WinBases& b, int chunk_la
     if (sig_k(a) != sig_k(c)) return false;
     return std::equal(scam.begin() + soff[a], scam.begin() + soff[a + 1], scam.begin() + soff[c]);
   };
+  // Landmarks with equal camera sets must end up adjacent, in landmark order; which set comes first is immaterial.  With at most 64 free
+  // cameras and no camera twice in a landmark (every local-BA window) the set is a 64-bit mask and up to eight stable 8-bit radix passes
+  // sort the landmarks by it (a comparison sort on the camera lists was half of this function's time); otherwise by the lists.
+  bool by_mask = w.n_free_cams <= 64;
+  std::vector<unsigned long long> mask;
+  if (by_mask) {
+    mask.resize(sigs.size());
+    for (size_t i = 0; i < sigs.size() && by_mask; i++) {
+      unsigned long long m = 0;
+      for (int j = soff[sigs[i]]; j < soff[sigs[i] + 1]; j++) { const unsigned long long bit = 1ull << scam[j]; by_mask &= !(m & bit); m |= bit; }
+      mask[i] = m;
+    }
+  }
+  if (by_mask) {
+    std::vector<int> tmp(sigs.size()); std::vector<unsigned long long> tmask(sigs.size());
+    for (int pass = 0; pass < 8; pass++) {
+      size_t cnt[257] = {0};
+      const int sh = 8 * pass;
+      for (size_t i = 0; i < sigs.size(); i++) cnt[((mask[i] >> sh) & 0xff) + 1]++;
+      if (cnt[1] == sigs.size()) continue;                       // this digit is zero everywhere (fewer than 8 * pass cameras)
+      for (int d = 0; d < 256; d++) cnt[d + 1] += cnt[d];
+      for (size_t i = 0; i < sigs.size(); i++) { const size_t at = cnt[(mask[i] >> sh) & 0xff]++; tmp[at] = sigs[i]; tmask[at] = mask[i]; }
+      sigs.swap(tmp); mask.swap(tmask);
+    }
+  } else
   std::stable_sort(sigs.begin(), sigs.end(), [&](int a, int c) {
     const int ka = sig_k(a), kc = sig_k(c);
     if (ka != kc) return ka < kc;
