@@ -32,6 +32,11 @@
 extern "C" {
 #endif
 
+/* liblld_amd.so is built with -fvisibility=hidden: only the declarations of this header are exported. */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
+
 /* ------------------------------------------------------------------ status codes */
 #define LLD_OK               0
 #define LLD_ERR_INVALID     -1   /* bad argument / inconsistent sizes               */
@@ -128,8 +133,13 @@ typedef struct {
                                    <= 8192 when the batch has at most 8 windows (then the reduced system - dense, 6 n_free squared
                                    doubles of HBM - is solved by the multi-workgroup PCG whatever `reduced_solver` says, except 2;
                                    beyond 590 cameras the camera accumulators and pose copies of the landmark kernels live in HBM
-                                   instead of LDS)                                                                     */
+                                   instead of LDS and are summed with global fp64 atomics: results of such maps are reproducible
+                                   to rounding, not bit for bit, from run to run; parity-tested to 600 free cameras, timed to 4000) */
   int32_t robust_points;    /* protocol 1 only: bRobust (Huber kernels on the point edges, default 1); lines are always robust */
+  int32_t abort_after_trials; /* TEST HOOK, 0 = off: behave as if *abort_flag had been raised right after the k-th LM trial of the
+                               window (trials counted over both rounds) and stayed up - a deterministic stand-in for the asynchronous
+                               pbStopFlag, honoured identically by the library and by the CPU oracle (tests/test_gpu_ba.py)          */
+  int32_t reserved;
 } lld_ba_params;
 
 void lld_ba_params_default(lld_ba_params* p);
@@ -143,7 +153,11 @@ typedef struct {
   int32_t n_pt_obs_outlier; /* size of vToErase                                                 */
   int32_t n_ln_edge_outlier;
   int32_t n_lines_removed;
-  int32_t aborted;          /* 1 when the abort flag cut the protocol short                     */
+  int32_t aborted;          /* 1 iff the stop flag was up at the protocol's LAST poll: the check before optimising (Optimizer.cc:1220,
+                               nothing is touched then), the check after optimize(its_round1) (:1230, round 2 is skipped, the final
+                               classification still runs on the round-1 state), or - when round 2 ran - the last terminate() of
+                               optimize(its_round2) (sparse_optimizer.cpp:376, levenberg.cpp:149).  The reference returns void; the
+                               adapter needs only "aborted && lm_iterations[0]==0 -> leave the map alone"                          */
   int32_t reserved;
 } lld_ba_stats;
 
@@ -685,6 +699,10 @@ int lld_compute_stereo_matches(lld_ctx* ctx, const lld_keypoints* left, const ll
 /* `n` independent problems (e.g. one relocalisation / loop candidate keyframe each, or the searches of several frames) in one
  * launch: one workgroup per problem, all inputs moved in one host-to-device copy and all outputs in one copy back. */
 int lld_orb_search_batch(lld_ctx* ctx, int n, const lld_orb_search* problems, lld_orb_search_result* outs);
+
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 
 #ifdef __cplusplus
 }

@@ -75,6 +75,7 @@ class BAParams(C.Structure):
         ("its_round1", C.c_int32), ("its_round2", C.c_int32), ("ln_filter", C.c_int32), ("max_trials", C.c_int32),
         ("pcg_rel_tol", C.c_double),
         ("pcg_max_iter", C.c_int32), ("reduced_solver", C.c_int32), ("protocol", C.c_int32), ("robust_points", C.c_int32),
+        ("abort_after_trials", C.c_int32), ("reserved", C.c_int32),
     ]
 
 

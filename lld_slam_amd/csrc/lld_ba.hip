@@ -142,14 +142,14 @@ void stage_tasks(const lld_ba_window& w, const lld_ba_params& P, const WinBases&
   W.n_ptasks = (int)S.ptasks.size(); W.n_ltasks = (int)S.ltasks.size();
   const int* R = n_windows >= kRoundsThroughputMinWindows ? kRoundsThroughput : kRoundsLatency;
   for (int i = 0; i < 4; i++) W.rounds[i] = R[i];
-  if (const char* e = std::getenv("LLD_BA_ROUNDS")) {        // experiments: "lin_pt,lin_ln,backsub_pt,backsub_ln" tasks per wavefront
-    int r[4];
-    if (std::sscanf(e, "%d,%d,%d,%d", &r[0], &r[1], &r[2], &r[3]) == 4) for (int i = 0; i < 4; i++) if (r[i] >= 1 && r[i] <= 64) W.rounds[i] = r[i];
-  }
+  // experiments: LLD_BA_ROUNDS="lin_pt,lin_ln,backsub_pt,backsub_ln" tasks per wavefront (parsed once per process)
+  static const struct RoundsEnv { int r[4]; bool set; RoundsEnv() : r{0, 0, 0, 0}, set(false) {
+    if (const char* e = std::getenv("LLD_BA_ROUNDS")) set = std::sscanf(e, "%d,%d,%d,%d", &r[0], &r[1], &r[2], &r[3]) == 4; } } rounds_env;
+  if (rounds_env.set) for (int i = 0; i < 4; i++) if (rounds_env.r[i] >= 1 && rounds_env.r[i] <= 64) W.rounds[i] = rounds_env.r[i];
   W.nt_pt = (W.n_ptasks + 4 * W.rounds[2] - 1) / (4 * W.rounds[2]); W.nl_pt = (W.n_ptasks + W.rounds[0] * kLinThreads / 64 - 1) / (W.rounds[0] * kLinThreads / 64);
   W.nt_ln = (W.n_ltasks + 4 * W.rounds[3] - 1) / (4 * W.rounds[3]); W.nl_ln = (W.n_ltasks + W.rounds[1] * kLinThreads / 64 - 1) / (W.rounds[1] * kLinThreads / 64);
   const double thMono = (double)(float)std::sqrt(5.991), thStereo = (double)(float)std::sqrt(7.815);   // Optimizer.cc:1088-1089
-  W.its[0] = P.its_round1; W.its[1] = P.its_round2; W.max_trials = P.max_trials; W.ln_filter = P.ln_filter;
+  W.its[0] = P.its_round1; W.its[1] = P.its_round2; W.max_trials = P.max_trials; W.ln_filter = P.ln_filter; W.abort_after = P.abort_after_trials;
   W.th_mono = thMono; W.th_stereo = thStereo;
   W.th_ln_mono = thMono * P.gamma; W.th_ln_stereo = thStereo * P.gamma;            // LineOptimizer.cc:33-35
   W.protocol = P.protocol; W.robust_pts = P.protocol == 1 ? (P.robust_points != 0) : 1;
@@ -373,7 +373,7 @@ static int ba_batch_create_impl(lld_ctx* ctx, int n_windows, const lld_ba_window
   if (params) B->params = *params; else lld_ba_params_default(&B->params);
   const lld_ba_params& P = B->params;
   // (optimize(0) would evaluate no error at all: the classification that follows would read g2o's uninitialised _error vectors)
-  if (P.its_round1 < 1 || (P.protocol == 0 && P.its_round2 < 1) || P.its_round2 < 0 || P.max_trials <= 0 || !(P.pcg_rel_tol > 0) || P.reduced_solver < 0 || P.reduced_solver > 2 || P.protocol < 0 || P.protocol > 1) { delete B; return LLD_ERR_INVALID; }
+  if (P.its_round1 < 1 || (P.protocol == 0 && P.its_round2 < 1) || P.its_round2 < 0 || P.max_trials <= 0 || !(P.pcg_rel_tol > 0) || P.reduced_solver < 0 || P.reduced_solver > 2 || P.protocol < 0 || P.protocol > 1 || P.abort_after_trials < 0) { delete B; return LLD_ERR_INVALID; }
 
   // ---- layout + host staging: the windows are flattened by a few host threads straight into their final positions
   //      (every offset that depends only on the window sizes is known up front), the variable-length Schur structures are
@@ -382,7 +382,6 @@ static int ba_batch_create_impl(lld_ctx* ctx, int n_windows, const lld_ba_window
   // landmarks per Schur chunk: long chunks mean fewer partials to reduce (256: 566 us per Schur launch of 256 windows, 128 and 512: 607),
   // short ones more wavefronts for small batches
   B->chunk_landmarks = n_windows >= 64 ? 256 : (n_windows >= 8 ? 64 : 32);
-  if (const char* e = std::getenv("LLD_BA_CHUNK")) { const int v = std::atoi(e); if (v >= 1 && v <= 4096) B->chunk_landmarks = v; }   // experiments
   if (const char* e = std::getenv("LLD_BA_CHUNK")) { const int v = std::atoi(e); if (v >= 1 && v <= 4096) B->chunk_landmarks = v; }   // experiments
   std::vector<WinBases> bases(n_windows + 1);
   {

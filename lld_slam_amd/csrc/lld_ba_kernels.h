@@ -79,6 +79,7 @@ struct BAWin {                 // immutable per-window header
   int part_off;                // per-block partial sums
   int its[2];                  // LM iterations per round
   int max_trials, ln_filter;
+  int abort_after;             // lld_ba_params::abort_after_trials (test hook: the stop flag counts as raised once this many LM trials are done; 0 = off)
   int big;                     // more cameras than the LDS of the linearise / back-substitution kernels holds: accumulators and poses in HBM
   int protocol, robust_pts, acc_copies;   // acc_copies: LDS copies of the per-camera accumulators in the linearise kernels (4, 2 or 1)
   int win_index;               // index of the window in its batch (slot of the multi-workgroup PCG scalars)    // lld_ba_params::protocol / robust_points (1 = global BA: one round, no classification)
@@ -401,9 +402,16 @@ __device__ __forceinline__ bool seg_step(int seg, int lane, int off) {
 // a factor 0.0 / 1.0 of one fused multiply-add per value (the partial sums are finite: idle lanes hold zeros).
 template <int N, int OFF>
 __device__ __forceinline__ void seg_sum_step(double* v, int seg1) {
-  const double okf = dpp_down<OFF>(seg1) == seg1 ? 1.0 : 0.0;
+  const bool ok = dpp_down<OFF>(seg1) == seg1;
+  double o[N];
 #pragma unroll
-  for (int i = 0; i < N; i++) v[i] = fma(okf, dpp_down<OFF>(v[i]), v[i]);
+  for (int i = 0; i < N; i++) o[i] = dpp_down<OFF>(v[i]);
+  // one predicated block of adds (EXEC = the lanes that continue their segment): a non-finite partial of a NEIGHBOURING landmark
+  // cannot leak in, which a 0.0 / 1.0 factor in an FMA would let it do (0 * NaN)
+  if (ok) {
+#pragma unroll
+    for (int i = 0; i < N; i++) v[i] += o[i];
+  }
 }
 template <int N>
 __device__ __forceinline__ void seg_sum(double* v, int seg, int lane, int max_len) {      // valid in the first lane of every segment
@@ -1238,13 +1246,16 @@ template <int D>
 __device__ __forceinline__ void schur_stage_one(bool a, const double* v, double lambda, const double* w, double* zl, double* tl, bool write_t) {
   constexpr int HU = (D == 3) ? 6 : 10;
   double L[D * (D + 1) / 2], idg[D];
-  if (a) chol_packed<D>(v, lambda, L, idg);
-  else {                                                    // inactive landmark: contributes nothing
+  if (!a) {                                                 // inactive landmark (rare): contributes nothing - explicit zeros, so that a
+#pragma unroll                                              // non-finite stale block cannot turn into 0 * NaN
+    for (int i = 0; i < 6 * D; i += 2) *reinterpret_cast<double2*>(zl + i) = make_double2(0.0, 0.0);
+    if (write_t) {
 #pragma unroll
-    for (int i = 0; i < D * (D + 1) / 2; i++) L[i] = 0.0;
-#pragma unroll
-    for (int i = 0; i < D; i++) idg[i] = 0.0;
+      for (int c = 0; c < D; c++) tl[c] = 0.0;
+    }
+    return;
   }
+  chol_packed<D>(v, lambda, L, idg);
   double z[6 * D];
 #pragma unroll
   for (int r = 0; r < 6; r++)
@@ -1608,9 +1619,10 @@ __global__ __launch_bounds__(256) void ba_symmetrize_kernel(BAArrays A, const BA
   if (st[blockIdx.y].phase != PH_RUN) return;
   const int n = 6 * W.n_free;
   double* Sg = A.S + W.S_off;
-  const int total = n * n;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
-    const int row = i / n, col = i - row * n;
+  // 64-bit element index: n * n passes 2^31 from 7724 free cameras on (n = 46344), and the limit is 8192
+  const long long total = (long long)n * n, stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+    const int row = (int)(i / n), col = (int)(i - (long long)row * n);
     if (col / 6 > row / 6) Sg[i] = Sg[(size_t)col * n + row];
   }
 }
@@ -2333,7 +2345,9 @@ __global__ __launch_bounds__(kCtlThreads) void ba_control_kernel(BAArrays A, con
     S.q++;
     const int round = S.round;
     S.lm_trials[round]++;
-    const bool again = (rho < 0 && S.q < W.max_trials && !abort_flag);
+    // terminate(): the host's sample of *abort_flag at the launch of this super-step, or the deterministic test hook
+    const bool stop = abort_flag || (W.abort_after > 0 && S.lm_trials[0] + S.lm_trials[1] >= W.abort_after);
+    const bool again = (rho < 0 && S.q < W.max_trials && !stop);
     if (!again) {
       bool term = (S.q == W.max_trials || rho == 0);
       if (!term) {
@@ -2342,13 +2356,13 @@ __global__ __launch_bounds__(kCtlThreads) void ba_control_kernel(BAArrays A, con
       }
       S.it++;
       S.lm_iterations[round]++;
-      if (!term && S.it < W.its[round] && !abort_flag) { S.need_lin = 1; S.maxdiag_bits = 0ull; do_clear = 1; }
+      if (!term && S.it < W.its[round] && !stop) { S.need_lin = 1; S.maxdiag_bits = 0ull; do_clear = 1; }
       else if (round == 0) {
         S.chi2_round1 = S.currentChi; S.chi2_final = S.currentChi;
-        if (abort_flag) { S.aborted = 1; S.phase = PH_FINALIZE; }
+        if (stop) { S.aborted = 1; S.phase = PH_FINALIZE; }           // Optimizer.cc:1230-1232: bDoMore = false, the final classification still runs
         else if (W.protocol == 1) S.phase = PH_FINALIZE;              // global BA: optimize(nIterations) and nothing else
         else S.phase = PH_TRANSITION;
-      } else { S.chi2_final = S.currentChi; S.phase = PH_FINALIZE; }
+      } else { S.chi2_final = S.currentChi; S.aborted = stop ? 1 : 0; S.phase = PH_FINALIZE; }   // lld_ba_stats::aborted = the flag at the last poll
     }
   }
   __syncthreads();

@@ -192,21 +192,27 @@ def sim3_params(lib: abi.Lib, th2=10.0, bFixScale=True, **kw) -> abi.Sim3Params:
     return p
 
 
-def sim3_call(lib: abi.Lib, ctx, pairs: list, params: abi.Sim3Params) -> list:
-    """lld_optimize_sim3_batch (or the oracle's lldo_optimize_sim3, one by one, when ctx is None)."""
+def sim3_pack(pairs: list):
+    """C structs + result buffers of a list of Sim3Pair (shared with the test-only oracle loader, which calls one pair at a time)."""
     cs = [p.to_c() for p in pairs]
     drops = [np.zeros(max(1, p.n), np.uint8) for p in pairs]
     res = (abi.Sim3Result * len(pairs))()
     for r, d in zip(res, drops): r.dropped = d.ctypes.data_as(abi.c_uint8_p)
-    if ctx is None:
-        fn = lib.fn("optimize_sim3"); fn.argtypes = [C.c_void_p, C.POINTER(abi.Sim3Problem), C.POINTER(abi.Sim3Params), C.POINTER(abi.Sim3Result)]; fn.restype = C.c_int
-        for c, r in zip(cs, res): check(fn(None, C.byref(c), C.byref(params), C.byref(r)), "optimize_sim3")
-    else:
-        arr = (abi.Sim3Problem * len(pairs))(*cs)
-        fn = lib.fn("optimize_sim3_batch"); fn.argtypes = [C.c_void_p, C.c_int, C.POINTER(abi.Sim3Problem), C.POINTER(abi.Sim3Params), C.POINTER(abi.Sim3Result)]; fn.restype = C.c_int
-        check(fn(ctx, len(pairs), arr, C.byref(params), res), "optimize_sim3_batch")
+    return cs, drops, res
+
+
+def sim3_unpack(pairs, drops, res) -> list:
     return [Sim3Output(np.array(r.s12_q[:]), np.array(r.s12_t[:]), float(r.s12_s), d[:p.n].copy(), int(r.n_inliers), int(r.n_bad_first),
                        list(r.lm_iterations), list(r.lm_trials), float(r.chi2)) for r, d, p in zip(res, drops, pairs)]
+
+
+def sim3_call(lib: abi.Lib, ctx, pairs: list, params: abi.Sim3Params) -> list:
+    """lld_optimize_sim3_batch: all candidates in one launch."""
+    cs, drops, res = sim3_pack(pairs)
+    arr = (abi.Sim3Problem * len(pairs))(*cs)
+    fn = lib.fn("optimize_sim3_batch"); fn.argtypes = [C.c_void_p, C.c_int, C.POINTER(abi.Sim3Problem), C.POINTER(abi.Sim3Params), C.POINTER(abi.Sim3Result)]; fn.restype = C.c_int
+    check(fn(ctx, len(pairs), arr, C.byref(params), res), "optimize_sim3_batch")
+    return sim3_unpack(pairs, drops, res)
 
 
 @dataclass
@@ -562,6 +568,10 @@ class BABatch:
 
     def solve(self, abort: bool = False):
         flag = C.c_int(1 if abort else 0)
+        check(self.lib.fn("ba_batch_solve")(self.handle, C.byref(flag)), "ba_batch_solve")
+
+    def solve_with_flag(self, flag: "C.c_int"):
+        """`flag` is the live pbStopFlag: another host thread may raise it while this call runs (ctypes releases the GIL)."""
         check(self.lib.fn("ba_batch_solve")(self.handle, C.byref(flag)), "ba_batch_solve")
 
     def download(self, i: int) -> BAOutput:

@@ -250,6 +250,19 @@ def make_lba_a(window_id=0, **kw) -> Window:
     return make_ba_window(20, 5, 5000, 6, 1000, 5, seed=SEED_LBA_A + window_id, **kw)
 
 
+def generate_windows(first_id: int, count: int, workers: int = 0, maker=make_lba_b) -> list:
+    """`count` synthetic windows maker(first_id + i), generated on `workers` processes (0: min(cores, 16)).  Spawned, never forked:
+    the caller may already have touched the GPU."""
+    import os
+    if workers <= 0:
+        workers = max(1, min(16, os.cpu_count() or 1))
+    if workers <= 1 or count < 4:
+        return [maker(first_id + i) for i in range(count)]
+    import multiprocessing as mp
+    with mp.get_context("spawn").Pool(min(workers, count)) as pool:
+        return pool.map(maker, range(first_id, first_id + count), chunksize=max(1, count // (4 * workers)))
+
+
 def make_lba_small(window_id=0, n_free=6, n_fixed=2, n_points=300, n_lines=60, **kw) -> Window:
     """Tiny window for fast CPU tests."""
     return make_ba_window(n_free, n_fixed, n_points, 4, n_lines, 4, seed=0x5A110000 + window_id, **kw)

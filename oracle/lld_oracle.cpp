@@ -112,7 +112,12 @@ struct BASystem {
   // estimate backup stack (depth 1 is enough for LM)
   std::vector<SE3> bk_cams; std::vector<V3> bk_pts; std::vector<Line> bk_lines;
 
-  bool terminate() { return abort_flag && *abort_flag; }
+  // lld_ba_params::abort_after_trials (test hook): the flag counts as raised once that many LM trials are done, over both rounds
+  int abort_after = 0; const int* trials_a = nullptr; const int* trials_b = nullptr;
+  bool terminate() {
+    if (abort_flag && *abort_flag) return true;
+    return abort_after > 0 && (trials_a ? *trials_a : 0) + (trials_b ? *trials_b : 0) >= abort_after;
+  }
   size_t numUnknownVertices() { return acams.size() + apts.size() + alns.size(); }
 
   bool cam_fixed(int c) const { return c >= n_free; }
@@ -424,7 +429,7 @@ void lldo_reproject_line_point(const double* X0, const double* ldir, double px, 
 
 void lldo_ba_params_default(lld_ba_params* p) {
   p->gamma = 1.0; p->its_round1 = 5; p->its_round2 = 15; p->ln_filter = 4; p->max_trials = 10;
-  p->pcg_rel_tol = 1e-12; p->pcg_max_iter = 0; p->reduced_solver = 0; p->protocol = 0; p->robust_points = 1;
+  p->pcg_rel_tol = 1e-12; p->pcg_max_iter = 0; p->reduced_solver = 0; p->protocol = 0; p->robust_points = 1; p->abort_after_trials = 0; p->reserved = 0;
 }
 void lldo_pose_params_default(lld_pose_params* p) { p->gamma = 0.5; p->n_rounds = 4; p->its_per_round = 10; p->max_trials = 10; p->reserved = 0; }
 
@@ -514,12 +519,13 @@ extern "C" int lldo_local_ba(void* /*ctx*/, const lld_ba_window* in, const lld_b
     return LLD_OK;
   }
   LMData lm; lm.maxTrials = prm.max_trials;
+  S.abort_after = prm.abort_after_trials; S.trials_a = &lm.trials;
   S.initializeOptimization(0);
   lm_optimize(S, lm, prm.its_round1);
   out->stats.chi2_round1 = lm.lastChi; out->stats.chi2_final = lm.lastChi;
   out->stats.lm_iterations[0] = lm.iterations; out->stats.lm_trials[0] = lm.trials;
   bool bDoMore = true;
-  if (abort_flag && *abort_flag) { bDoMore = false; out->stats.aborted = 1; }
+  if (S.terminate()) { bDoMore = false; out->stats.aborted = 1; }        // if(pbStopFlag) if(*pbStopFlag) bDoMore = false;  (Optimizer.cc:1230-1232)
   const bool global = prm.protocol == 1;     // Optimizer::BundleAdjustment: optimize(nIterations), then "Recover optimized data" (:493-558)
   if (global) bDoMore = false;
   const double thLinesStereo = (double)(float)std::sqrt(7.815) * prm.gamma, thLinesMono = (double)(float)std::sqrt(5.991) * prm.gamma;
@@ -543,10 +549,16 @@ extern "C" int lldo_local_ba(void* /*ctx*/, const lld_ba_window* in, const lld_b
     for (auto& e : S.le) if (S.line_removed[e.line]) e.removed = true;
     LMData lm2; lm2.maxTrials = prm.max_trials;
     lm2.lambda = lm.lambda; lm2.ni = lm.ni; lm2.nBad = lm.nBad;   // same algorithm object; all reset at iteration 0
+    S.trials_b = &lm2.trials;
     S.initializeOptimization(0);
     const int r = lm_optimize(S, lm2, prm.its_round2);
     if (r >= 0) out->stats.chi2_final = lm2.lastChi;
     out->stats.lm_iterations[1] = lm2.iterations; out->stats.lm_trials[1] = lm2.trials;
+    // lld_ba_stats::aborted is the stop flag at the protocol's last poll (include/lld_amd.h); the reference itself returns void.
+    // An empty active set makes optimize() return before it polls (sparse_optimizer.cpp:356-359).
+    if (r >= 0 && S.terminate()) out->stats.aborted = 1;
+    S.trials_b = nullptr; S.trials_a = nullptr;       // (lm2 goes out of scope)
+    S.abort_after = 0;
   }
   // final classification (Optimizer.cc:1278-1329)
   if (!global) {

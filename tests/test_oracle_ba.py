@@ -183,3 +183,39 @@ def test_global_ba_protocol_rules(oracle):
     # and it is not the local protocol
     loc = oracle.local_ba(w)
     assert loc.stats["lm_iterations"][1] > 0
+
+
+def test_abort_after_k_trials_hook(oracle):
+    """lld_ba_params.abort_after_trials: the stop flag counts as raised right after the k-th LM trial (both rounds counted) and stays up.
+    Reference semantics: terminate() ends the trial loop (levenberg.cpp:149) and the iteration loop (sparse_optimizer.cpp:376);
+    a flag up after optimize(5) skips classification + round 2 (Optimizer.cc:1230-1232) but NOT the final classification / write-back
+    (:1278-1386).  `aborted` = the flag at the protocol's last poll."""
+    w = synth.make_lba_small(12)
+    full = oracle.local_ba(w)
+    t1, t2 = full.stats["lm_trials"]
+    assert full.stats["aborted"] == 0 and t1 >= 5 and t2 >= 2
+    # k = 1: one trial of one iteration, then everything stops; the erase lists come from the round-1 state with kernels on
+    r = oracle.local_ba(w, abort_after_trials=1)
+    assert r.stats["lm_trials"] == [1, 0] and r.stats["lm_iterations"] == [1, 0] and r.stats["aborted"] == 1
+    assert r.stats["n_lines_removed"] == 0 and r.line_removed.sum() == 0            # DisableOutliers never ran
+    assert r.stats["chi2_final"] == r.stats["chi2_round1"]
+    assert not np.array_equal(r.cam_qt[:w.n_free_cams], w.cam_qt[:w.n_free_cams])   # the map IS updated (unlike the abort before the start)
+    assert r.pt_obs_outlier.sum() > 0
+    # k in the middle of round 1
+    r = oracle.local_ba(w, abort_after_trials=3)
+    assert r.stats["lm_trials"] == [3, 0] and r.stats["aborted"] == 1 and r.stats["lm_iterations"][0] <= 3
+    # k = the last trial of round 1: optimize(5) ends on its own, the check after it sees the flag
+    r = oracle.local_ba(w, abort_after_trials=t1)
+    assert r.stats["lm_trials"] == [t1, 0] and r.stats["lm_iterations"] == [full.stats["lm_iterations"][0], 0] and r.stats["aborted"] == 1
+    assert r.stats["chi2_round1"] == full.stats["chi2_round1"]
+    # k = first trial of round 2: classification and line removal happened, round 2 is one iteration of one trial
+    r = oracle.local_ba(w, abort_after_trials=t1 + 1)
+    assert r.stats["lm_trials"] == [t1, 1] and r.stats["lm_iterations"] == [full.stats["lm_iterations"][0], 1] and r.stats["aborted"] == 1
+    np.testing.assert_array_equal(r.line_removed, full.line_removed)
+    # k = the very last trial: nothing is cut short, but the flag is up at the last poll
+    r = oracle.local_ba(w, abort_after_trials=t1 + t2)
+    assert r.stats["lm_trials"] == [t1, t2] and r.stats["aborted"] == 1
+    np.testing.assert_array_equal(r.cam_qt, full.cam_qt)
+    # k beyond the end: never raised
+    r = oracle.local_ba(w, abort_after_trials=t1 + t2 + 1)
+    assert r.stats == full.stats
