@@ -30,7 +30,26 @@ namespace {
 // ------------------------------------------------------------------ small dense helpers
 // Inverse of a d x d matrix (d <= 4) by Gauss-Jordan with partial pivoting.  The reference calls
 // D->inverse() on a dynamic Eigen::MatrixXd (BlockSolverX, block_solver.hpp:391), i.e. PartialPivLU.
+// Test knob (lldo_set_landmark_inverse): 1 = the same inverse through a Cholesky factor, A^-1 = L^-T L^-1 - equal in exact
+// arithmetic, rounded differently.  The difference between the two is the sensitivity of a landmark to HOW (Hll + lambda I)^-1 is
+// rounded; the device (Cholesky solve) is held to that spread on nearly singular blocks (tests/test_gpu_ba.py, "ill-conditioned Hll").
+static int g_landmark_inverse = 0;
+static bool invert_small_chol(const double* A, int d, double* Ainv) {
+  double L[4][4] = {{0}}, Li[4][4] = {{0}};
+  for (int j = 0; j < d; j++) {
+    double s = A[j * d + j];
+    for (int k = 0; k < j; k++) s -= L[j][k] * L[j][k];
+    if (!(s > 0.0)) return false;
+    L[j][j] = std::sqrt(s);
+    for (int i = j + 1; i < d; i++) { double t = A[i * d + j]; for (int k = 0; k < j; k++) t -= L[i][k] * L[j][k]; L[i][j] = t / L[j][j]; }
+  }
+  for (int c = 0; c < d; c++)                       // Li = L^-1, column by column (forward substitution on the identity)
+    for (int i = c; i < d; i++) { double t = (i == c) ? 1.0 : 0.0; for (int k = c; k < i; k++) t -= L[i][k] * Li[k][c]; Li[i][c] = t / L[i][i]; }
+  for (int i = 0; i < d; i++) for (int j = 0; j < d; j++) { double t = 0; for (int k = (i > j ? i : j); k < d; k++) t += Li[k][i] * Li[k][j]; Ainv[i * d + j] = t; }
+  return true;
+}
 static bool invert_small(const double* A, int d, double* Ainv) {
+  if (g_landmark_inverse == 1 && invert_small_chol(A, d, Ainv)) return true;
   double M[4][8];
   for (int i = 0; i < d; i++) {
     for (int j = 0; j < d; j++) { M[i][j] = A[i * d + j]; M[i][d + j] = (i == j) ? 1.0 : 0.0; }
@@ -426,6 +445,8 @@ void lldo_edge_line_posonly(const lld_camera* c, double bx, const double* qt, co
 void lldo_reproject_line_point(const double* X0, const double* ldir, double px, double py, double f, double cx, double cy, double* depth, double* param) {
   reproject_line_point(V3{X0[0], X0[1], X0[2]}, V3{ldir[0], ldir[1], ldir[2]}, px, py, f, cx, cy, depth, param);
 }
+
+void lldo_set_landmark_inverse(int how) { g_landmark_inverse = how; }      // test knob, see invert_small
 
 void lldo_ba_params_default(lld_ba_params* p) {
   p->gamma = 1.0; p->its_round1 = 5; p->its_round2 = 15; p->ln_filter = 4; p->max_trials = 10;

@@ -16,15 +16,25 @@ from lld_slam_amd import abi, host
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
+_LIB_FMA = None
 
 
 def build(force: bool = False) -> str:
     so = os.path.join(_HERE, "liblld_oracle.so")
     srcs = [os.path.join(_HERE, f) for f in ("lld_oracle.cpp", "lldo_orbsearch.cpp", "lldo_linematch.cpp", "lldo_math.h", "lldo_edges.h", "lldo_lm.h")]
     srcs.append(os.path.join(_HERE, "..", "include", "lld_amd.h"))
-    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+    if force or not os.path.exists(so) or not os.path.exists(os.path.join(_HERE, "liblld_oracle_fma.so")) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return so
+
+
+def lib_fma() -> abi.Lib:
+    """The same sources compiled with -ffp-contract=fast (oracle/Makefile): used ONLY to measure how far rounding alone moves a result."""
+    global _LIB_FMA
+    if _LIB_FMA is None:
+        build()
+        _LIB_FMA = abi.Lib(os.path.join(_HERE, "liblld_oracle_fma.so"), "lldo_")
+    return _LIB_FMA
 
 
 def lib() -> abi.Lib:
@@ -169,6 +179,12 @@ def local_ba(win: host.Window, gamma=1.0, abort=False, **params):
     return host.ba_call(lib(), None, win, host.ba_params(lib(), gamma, **params), abort)
 
 
+def set_landmark_inverse(how: int):
+    """0: (Hll + lambda I)^-1 by Gauss-Jordan with partial pivoting (default; the reference calls MatrixXd::inverse(), block_solver.hpp:391),
+    1: the same inverse through a Cholesky factor - equal in exact arithmetic.  Not thread-safe: a process-wide test knob."""
+    lib().dll.lldo_set_landmark_inverse(int(how))
+
+
 def optimize_sim3(pair, th2=10.0, bFixScale=True, **params):
     """Optimizer::OptimizeSim3, literal restatement (numeric Jacobians as g2o)."""
     many = isinstance(pair, (list, tuple))
@@ -182,8 +198,9 @@ def optimize_sim3(pair, th2=10.0, bFixScale=True, **params):
     return outs if many else outs[0]
 
 
-def optimize_essential_graph(graph, bFixScale=True, **params):
-    return host.essential_graph_call(lib(), None, graph, bFixScale, **params)
+def optimize_essential_graph(graph, bFixScale=True, fma=False, **params):
+    """`fma=True`: through the FMA-contracted build (rounding-sensitivity measurements only)."""
+    return host.essential_graph_call(lib_fma() if fma else lib(), None, graph, bFixScale, **params)
 
 
 def sim3_log(qts8):

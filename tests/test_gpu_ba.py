@@ -14,7 +14,16 @@ pytestmark = pytest.mark.gpu
 RTOL = 1e-5
 
 
-def check_ba(g, o, w, rtol=RTOL):
+def landmark_rel(a, b):
+    """deviation relative to the landmark's own magnitude (a coordinate that happens to be ~0 has no relative scale)"""
+    return np.linalg.norm(a - b, axis=1) / np.maximum(np.linalg.norm(b, axis=1), 1e-3)
+
+
+def check_ba(g, o, w, rtol=RTOL, pt_floor=None):
+    """`pt_floor`: the NAMED allowance "ill-conditioned Hll" - per point, how far the oracle itself moves when (Hll + lambda I)^-1 is
+    rounded another way (oracle_py.set_landmark_inverse); a point may then deviate by 10x that instead of rtol.  Only
+    test_nearly_singular_landmark_blocks passes it: the device solves with the landmark blocks by Cholesky where the reference forms
+    MatrixXd::inverse() (block_solver.hpp:391) - a device choice, not noise - and the bar everywhere else does not rely on it."""
     assert g.stats["chi2_final"] == pytest.approx(o.stats["chi2_final"], rel=rtol, abs=1e-9)
     assert g.stats["chi2_round1"] == pytest.approx(o.stats["chi2_round1"], rel=rtol, abs=1e-9)
     np.testing.assert_array_equal(g.pt_obs_outlier, o.pt_obs_outlier)
@@ -24,8 +33,7 @@ def check_ba(g, o, w, rtol=RTOL):
         assert g.stats[k] == o.stats[k]
     np.testing.assert_allclose(g.cam_qt, o.cam_qt, rtol=rtol, atol=1e-7)
     # landmarks: relative to the landmark's own magnitude (a coordinate that happens to be ~0 has no relative scale)
-    def rel(a, b):
-        return np.linalg.norm(a - b, axis=1) / np.maximum(np.linalg.norm(b, axis=1), 1e-3)
+    rel = landmark_rel
     # 1e-5 holds for the bulk; the few weakest landmarks of a window (far lines seen under tiny parallax) sit at the
     # reference algorithm's own noise floor: re-ordering a point's observations - which the reference does from run to
     # run, it iterates a std::map<KeyFrame*> - moves them by the same few 1e-6 (tests/test_oracle_ba.py::
@@ -36,7 +44,10 @@ def check_ba(g, o, w, rtol=RTOL):
         # (tools/exp_flake.py: 6000 runs of one 138-line window, up to 3 lines at 1.8e-5 in the same run, in under 1 % of the runs)
         if r.size >= 100:
             assert (r > rtol).sum() <= max(4, int(0.01 * r.size))
-    if w.n_points:
+    if w.n_points and pt_floor is not None:
+        r = rel(g.pt_xyz, o.pt_xyz)
+        assert np.all(r <= np.maximum(rtol, 10 * pt_floor)), (r.max(), int(np.argmax(r)), pt_floor[int(np.argmax(r))])
+    elif w.n_points:
         bulk(rel(g.pt_xyz, o.pt_xyz))
     if w.n_lines:
         bulk(rel(g.line_x0, o.line_x0))
@@ -430,3 +441,24 @@ def test_batch_config_256_lba_b_windows(gpu_ctx, oracle):
             loose += not (c.stats["chi2_final"] == pytest.approx(first[i].stats["chi2_final"], rel=1e-5))
             np.testing.assert_allclose(c.cam_qt, first[i].cam_qt, rtol=1e-5, atol=1e-7)
         assert loose <= 2
+
+
+# ---------------------------------------------------------------------------------------------------------------- ill-conditioned Hll
+@pytest.mark.parametrize("seed", [48, 26, 16, 2])
+def test_nearly_singular_landmark_blocks(gpu_ctx, oracle, seed):
+    """No free camera, two-view points, a third of them monocular: every point is its own 3x3 problem with a nearly singular Hll, and
+    the answer depends on how (Hll + lambda I)^-1 is ROUNDED - the oracle moves by up to 1e-3 between two inverses that are equal in
+    exact arithmetic (tests/test_oracle_ba.py::test_landmark_inverse_rounding_moves_nearly_singular_points).  The reference forms
+    MatrixXd::inverse() (block_solver.hpp:391), the device solves by Cholesky: a point is held to 10x the oracle's own spread, every
+    well-conditioned point, chi2 and the erase lists to the usual bar (fuzz: the three such windows of profiles/r02_fuzz_ba_5000.txt)."""
+    w = synth.make_ba_window(n_free=0, n_fixed=3, n_points=400, obs_per_point=2, n_lines=5, obs_per_line=1, seed=seed, outlier_frac=0.5, mono_frac=0.3, noise=1.0)
+    o = oracle.local_ba(w)
+    try:
+        oracle.set_landmark_inverse(1)
+        o1 = oracle.local_ba(w)
+    finally:
+        oracle.set_landmark_inverse(0)
+    np.testing.assert_array_equal(o.pt_obs_outlier, o1.pt_obs_outlier)
+    floor = landmark_rel(o1.pt_xyz, o.pt_xyz)
+    assert floor.max() > 1e-5                                   # the window does exercise the allowance
+    check_ba(Optimizer(gpu_ctx).LocalBundleAdjustment(w), o, w, pt_floor=floor)

@@ -7,31 +7,56 @@ from lld_slam_amd import Optimizer, synth
 pytestmark = pytest.mark.gpu
 
 
-def _check(g, o, tol=1e-5):
-    assert g.chi2 == pytest.approx(o.chi2, rel=100 * tol, abs=1e-18)
-    # 1e-5 relative to the size of the quantity (unit quaternion, translation vector): g2o's central differences with delta 1e-9
-    # carry ~1e-7 of rounding noise into every Jacobian, on the CPU as on the GPU, so single small components agree to ~1e-6 only
-    assert np.abs(g.sim3[:, :4] - o.sim3[:, :4]).max() <= tol
-    dt = np.linalg.norm(g.sim3[:, 4:7] - o.sim3[:, 4:7], axis=1)
-    assert (dt <= tol * np.maximum(1.0, np.linalg.norm(o.sim3[:, 4:7], axis=1))).all()
-    np.testing.assert_allclose(g.sim3[:, 7], o.sim3[:, 7], rtol=tol)
+def deviation(a, b):
+    """(rotation, translation, scale, chi2) of a against b: quaternion components absolute, translation relative to max(1, |t|), scale
+    and chi2 relative."""
+    dq = float(np.abs(a.sim3[:, :4] - b.sim3[:, :4]).max())
+    dt = float((np.linalg.norm(a.sim3[:, 4:7] - b.sim3[:, 4:7], axis=1) / np.maximum(1.0, np.linalg.norm(b.sim3[:, 4:7], axis=1))).max())
+    ds = float(np.abs(a.sim3[:, 7] / b.sim3[:, 7] - 1).max())
+    return np.array([dq, dt, ds, abs(a.chi2 - b.chi2) / max(abs(b.chi2), 1e-300)])
+
+
+def _check(g, o, floor=None, tol=1e-5):
+    """1e-5 on rotation / translation / scale / chi2 - or, where the ALGORITHM is more sensitive to rounding than that, ten times the
+    distance between the oracle and the same oracle compiled with fused multiply-adds (`floor`, oracle_py.optimize_essential_graph(fma=True)).
+    g2o differentiates EdgeSim3 numerically with delta 1e-9 (core/base_binary_edge.hpp:131-197): every Jacobian entry carries ~1e-7 of
+    rounding noise, on the CPU as on the GPU; tests/test_oracle_posegraph.py::test_numeric_jacobians_make_the_result_rounding_sensitive
+    shows what that does to the CPU result alone (chi2 of a free-scale graph moves by 3e-4, the poses of a 7-keyframe loop by 2e-5)."""
+    d = deviation(g, o)
+    lim = np.full(4, tol) if floor is None else np.maximum(tol, 10 * np.asarray(floor))
+    assert (d <= lim).all(), (d, lim)
     # at convergence LM's accept / reject decisions hinge on chi2 differences at rounding level (rho ~ 0/0): the last iteration may
     # burn its 10 trials on one side and not on the other; the result is the same
     assert abs(g.lm_iterations - o.lm_iterations) <= 2 and abs(g.lm_trials - o.lm_trials) <= 12
 
 
+GRAPHS = [(0, 120, True), (2, 60, False), (3, 300, True), (6, 7, True), (7, 16, True), (8, 17, False)]
+
+
 @pytest.mark.parametrize("solver", [1, 2])
-@pytest.mark.parametrize("gid,n,fix", [(0, 120, True), (2, 60, False), (3, 300, True), (6, 7, True), (7, 16, True), (8, 17, False)])
+@pytest.mark.parametrize("gid,n,fix", GRAPHS)
 def test_essential_graph_matches_oracle(gpu_ctx, oracle, gid, n, fix, solver):
     gr = synth.make_essential_graph(gid, n)
     g = Optimizer(gpu_ctx).OptimizeEssentialGraph(gr, bFixScale=fix, solver=solver)
     assert g.solver_used == solver and (g.pcg_iterations > 0) == (solver == 2)
-    # LM stops as soon as three iterations in a row improve chi2 by less than 0.1 %: with the scale free the valley is flat enough for
-    # the two sides to stop one iteration apart, which is worth ~1e-4 of chi2 and ~1e-5..1e-4 of the poses; with the scale fixed they
-    # stop together
-    # (7 keyframes: a loop of 7 with 10 % drift per edge moves every pose by ~0.5, the 1e-7 Jacobian noise then shows at 1e-5)
-    _check(g, oracle.optimize_essential_graph(gr, bFixScale=fix), (1e-4 if n < 10 else 1e-5) if fix else 2e-4)
+    o = oracle.optimize_essential_graph(gr, bFixScale=fix)
+    _check(g, o, deviation(oracle.optimize_essential_graph(gr, bFixScale=fix, fma=True), o))
     np.testing.assert_array_equal(g.sim3[0], gr.sim3[0])
+
+
+@pytest.mark.parametrize("gid,n,fix", GRAPHS)
+@pytest.mark.parametrize("k", [2, 3])
+def test_essential_graph_at_equal_iteration_counts(gpu_ctx, oracle, gid, n, fix, k):
+    """optimize(k) for k small enough that no stop rule can fire on one side only: both sides run the same k iterations (or terminate
+    together in the flat valley of a free-scale graph), so what is left is the Jacobian noise alone."""
+    gr = synth.make_essential_graph(gid, n)
+    g = Optimizer(gpu_ctx).OptimizeEssentialGraph(gr, bFixScale=fix, iterations=k)
+    o = oracle.optimize_essential_graph(gr, bFixScale=fix, iterations=k)
+    assert g.lm_iterations == o.lm_iterations
+    _check(g, o, deviation(oracle.optimize_essential_graph(gr, bFixScale=fix, iterations=k, fma=True), o))
+    # the well-conditioned graphs hold the plain 1e-5 bar on every pose
+    if n >= 16:
+        assert (deviation(g, o)[:3] <= 1e-5).all()
 
 
 def test_essential_graph_degenerate_inputs(gpu_ctx, oracle):
@@ -47,7 +72,8 @@ def test_essential_graph_degenerate_inputs(gpu_ctx, oracle):
     with pytest.raises(RuntimeError):
         Optimizer(gpu_ctx).OptimizeEssentialGraph(bad)
     consistent = synth.make_essential_graph(5, 40, drift=(0.0, 0.0))
-    _check(Optimizer(gpu_ctx).OptimizeEssentialGraph(consistent), oracle.optimize_essential_graph(consistent))
+    g, o = Optimizer(gpu_ctx).OptimizeEssentialGraph(consistent), oracle.optimize_essential_graph(consistent)
+    assert g.chi2 < 1e-16 and o.chi2 < 1e-16 and (deviation(g, o)[:3] <= 1e-7).all()         # a fixed point: nothing moves
 
 
 def test_essential_graph_default_solver_is_dense_and_agrees_with_pcg(gpu_ctx):
@@ -56,6 +82,6 @@ def test_essential_graph_default_solver_is_dense_and_agrees_with_pcg(gpu_ctx):
     d = opt.OptimizeEssentialGraph(gr)
     p = opt.OptimizeEssentialGraph(gr, solver=2)
     assert d.solver_used == 1 and p.solver_used == 2
-    _check(d, p)
+    assert (deviation(d, p) <= [1e-5, 1e-5, 1e-5, 1e-4]).all()       # two solvers of the same device code (the chi2 of the last accepted step: see _check)
     with pytest.raises(RuntimeError):
         opt.OptimizeEssentialGraph(gr, solver=3)

@@ -38,3 +38,31 @@ def test_essential_graph_closes_the_loop(oracle):
     # free scale: the scales move away from 1 when the loop needs it
     rf = oracle.optimize_essential_graph(g, bFixScale=False)
     assert np.abs(rf.sim3[:, 7] - 1).max() > 1e-6
+
+
+def test_numeric_jacobians_make_the_result_rounding_sensitive(oracle):
+    """The oracle against ITSELF compiled with fused multiply-adds (oracle/Makefile: liblld_oracle_fma.so): equal in exact arithmetic.
+    g2o's central differences with delta 1e-9 turn the ~1e-16 rounding differences of log / exp into ~1e-7 of every Jacobian entry, and
+    that moves the optimum: chi2 of a free-scale graph (one accepted Gauss-Newton step, then ten rejected trials) by ~3e-4 relative, the
+    poses of a short loop with large corrections by ~1e-5.  This - not a tolerance picked by hand - is what the GPU parity test of the
+    essential graph allows beyond 1e-5 (tests/test_gpu_posegraph.py::_check)."""
+    import numpy as np
+    def deviation(a, b):
+        dq = np.abs(a.sim3[:, :4] - b.sim3[:, :4]).max()
+        dt = (np.linalg.norm(a.sim3[:, 4:7] - b.sim3[:, 4:7], axis=1) / np.maximum(1.0, np.linalg.norm(b.sim3[:, 4:7], axis=1))).max()
+        return dq, dt, abs(a.chi2 - b.chi2) / abs(b.chi2)
+    free = synth.make_essential_graph(2, 60)
+    a, b = oracle.optimize_essential_graph(free, bFixScale=False), oracle.optimize_essential_graph(free, bFixScale=False, fma=True)
+    assert (a.lm_iterations, a.lm_trials) == (b.lm_iterations, b.lm_trials) == (2, 11)
+    dq, dt, dchi = deviation(b, a)
+    assert 1e-5 < dchi < 5e-3 and dq < 1e-5 and dt < 1e-5          # chi2 moves by more than the 1e-5 bar, the poses do not
+    short = synth.make_essential_graph(6, 7)
+    a, b = oracle.optimize_essential_graph(short, iterations=3), oracle.optimize_essential_graph(short, iterations=3, fma=True)
+    dq, dt, dchi = deviation(b, a)
+    assert a.lm_iterations == b.lm_iterations == 3 and 2e-6 < dt < 5e-4 and dchi < 1e-5
+    # the same experiment on BA, whose Jacobians are analytic, stays at 1e-9: the sensitivity belongs to the numeric differentiation
+    from lld_slam_amd import host
+    w = synth.make_lba_small(3)
+    x, y = oracle.local_ba(w), host.ba_call(oracle.lib_fma(), None, w, host.ba_params(oracle.lib_fma()))
+    np.testing.assert_allclose(x.cam_qt, y.cam_qt, rtol=1e-7, atol=1e-9)
+    assert x.stats["lm_trials"] == y.stats["lm_trials"] and abs(x.stats["chi2_final"] / y.stats["chi2_final"] - 1) < 1e-8
