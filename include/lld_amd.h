@@ -185,6 +185,9 @@ int  lld_ba_batch_create(lld_ctx* ctx, int n_windows, const lld_ba_window* windo
                          const lld_ba_params* params, lld_ba_batch** out);
 int  lld_ba_batch_solve(lld_ba_batch* batch, volatile const int* abort_flag); /* async on ctx stream until the final sync */
 int  lld_ba_batch_download(lld_ba_batch* batch, int window, lld_ba_result* out);
+/* Windows [first, first + count) into out[0..count): the same as `count` calls of lld_ba_batch_download, unpacked by several host
+ * threads (a caller that wants every result of a 256-window batch moves 100 MB out of the landing buffer). */
+int  lld_ba_batch_download_range(lld_ba_batch* batch, int first, int count, lld_ba_result* out /* [count] */);
 int  lld_ba_batch_stats(lld_ba_batch* batch, lld_ba_stats* stats /* [n_windows] */);
 /* Device buffer holding the fixed-stride result records of all windows (for the RCCL
  * gather): returns base pointer and record stride in bytes. */

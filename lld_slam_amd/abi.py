@@ -176,7 +176,7 @@ PRODUCT_SYMBOLS = [
     "lld_status_string", "lld_ctx_create", "lld_ctx_destroy", "lld_ctx_stream", "lld_ctx_synchronize",
     "lld_se3_from_tcw_f32", "lld_se3_to_tcw_f32", "lld_orb_inv_level_sigma2",
     "lld_ba_params_default", "lld_local_ba",
-    "lld_ba_batch_create", "lld_ba_batch_solve", "lld_ba_batch_download", "lld_ba_batch_stats",
+    "lld_ba_batch_create", "lld_ba_batch_solve", "lld_ba_batch_download", "lld_ba_batch_download_range", "lld_ba_batch_stats",
     "lld_ba_batch_result_records", "lld_ba_batch_phase_ms", "lld_ba_batch_kernel_stats", "lld_ba_batch_set_groups",
     "lld_ba_batch_destroy",
     "lld_pose_params_default", "lld_pose_opt",
@@ -272,6 +272,7 @@ class Lib:
             f("ba_batch_create").restype = C.c_int
             f("ba_batch_solve").argtypes = [vp, C.POINTER(C.c_int)]; f("ba_batch_solve").restype = C.c_int
             f("ba_batch_download").argtypes = [vp, C.c_int, C.POINTER(BAResult)]; f("ba_batch_download").restype = C.c_int
+            f("ba_batch_download_range").argtypes = [vp, C.c_int, C.c_int, C.POINTER(BAResult)]; f("ba_batch_download_range").restype = C.c_int
             f("ba_batch_stats").argtypes = [vp, C.POINTER(BAStats)]; f("ba_batch_stats").restype = C.c_int
             f("ba_batch_result_records").argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_uint64)]
             f("ba_batch_result_records").restype = C.c_int

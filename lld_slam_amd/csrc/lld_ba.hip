@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <new>
 #include <thread>
 
@@ -19,6 +20,13 @@ namespace {
 constexpr int kNumPhases = 5;
 constexpr int kFusePairsBelowWindows = 8;  // fewer windows than this: point + line kernels of a pair share one launch
 constexpr int kMaxSuperSteps = 512;      // hard stop: 2 rounds x 15 iterations x 10 trials is the protocol's own bound (300)
+// A batch of this many windows fills the GPU on its own (four stream groups in flight).  Two such solves interleaved from two
+// contexts ran 20 - 30 % slower in aggregate than one after the other (2 lanes: 2930 windows/s host buffers in and out, 3910 with the
+// solves taking turns; tools/exp_e2e_lanes.py), so solves of large batches take turns per device; everything else of a pipelined
+// caller - the next batch's flattening and upload, the previous batch's download - overlaps the solve in flight.  Small batches and
+// single windows (lld_local_ba on the LocalMapping thread next to lld_pose_opt on the Tracking thread) never wait.
+constexpr int kSerialiseSolvesFromWindows = 64;
+std::mutex g_big_solve[64];               // per HIP device
 }
 
 struct lld_ba_batch {
@@ -26,8 +34,7 @@ struct lld_ba_batch {
   int n_windows = 0;
   lld_ba_params params;
   std::vector<BAWin> h_wins;
-  std::vector<SChunk> h_chunks; std::vector<PTask> h_ptasks, h_ltasks;
-  void* slab = nullptr; bool borrowed = false; size_t slab_bytes = 0;
+  void* slab = nullptr; bool borrowed = false; size_t slab_bytes = 0;      // borrowed: slab, streams, events and poll block are the context's cached set
   BAArrays A;
   BAWin* d_wins = nullptr; BAState* d_state = nullptr;
   // window groups solved concurrently, each on its own stream (hides the latency-bound reduced solve, the per-super-step
@@ -43,7 +50,7 @@ struct lld_ba_batch {
   int chunk_landmarks = 32;
   size_t S_total = 0, x_total = 0;
   size_t rec_stride = 0;
-  std::vector<unsigned char> h_records; bool records_valid = false;
+  unsigned char* h_records = nullptr; bool records_pinned_own = false; std::vector<unsigned char> h_records_pageable; bool records_valid = false;
   double phase_ms[LLD_BA_N_PHASES] = {};
   int64_t launches[kNumPhases] = {};
   int super_steps = 0;
@@ -82,11 +89,11 @@ size_t record_bytes(const BAWin& W) {
 
 
 // ---- host staging (see ba_batch_create_impl) ------------------------------------------------------------------------------------
-// Uninitialised host array: the staging threads write every element, so neither a zero fill nor push_back bookkeeping.
+// A host staging array: a view into the pinned upload arena (the staging threads write every element).
 template <class T> struct HostBuf {
-  std::unique_ptr<T[]> p; size_t n = 0;
-  bool alloc(size_t count) { p.reset(new (std::nothrow) T[count ? count : 1]); n = count; return p != nullptr; }
-  const T* data() const { return p.get(); }
+  T* p = nullptr; size_t n = 0;
+  void view(T* at, size_t count) { p = at; n = count; }
+  const T* data() const { return p; }
   size_t size() const { return n; }
   bool empty() const { return n == 0; }
 };
@@ -112,6 +119,48 @@ struct WinStage {
   ChunkStage cs[2];                                        // points, lines
   std::vector<int> blk_start, blk_src, cam_start, cam_src; // window-local CSRs over both kinds (stage_csr)
 };
+
+// The slab starts with two sections that come from the host: A = the flattened inputs, B = the Schur / task structures and the
+// window headers.  The pinned upload arenas are carved by the SAME sequence of takes, so host and device offsets agree and each
+// section travels in ONE host-to-device copy (section A while the host still places section B).
+struct SecA {
+  double *cam_qt0, *pt0, *ln_x0, *ln_dir; int *pt_obs_start, *ln_obs_start, *pe_cam, *pe_pt; double *pe_u, *pe_v, *pe_ur, *pe_s;
+  int *le_cam, *le_ln; double *le_xs, *le_ys, *le_xe, *le_ye, *le_s, *le_bx; uint8_t* le_flags0;
+};
+void carve_a(lld_slab& sl, long long NC, long long NP, long long NL, long long NPE, size_t NLE, SecA& a) {
+  a.cam_qt0 = sl.take<double>(NC * 7 + 1); a.pt0 = sl.take<double>(NP * 3 + 1); a.ln_x0 = sl.take<double>(NL * 3 + 1); a.ln_dir = sl.take<double>(NL * 3 + 1);
+  a.pt_obs_start = sl.take<int>(NP + 2); a.ln_obs_start = sl.take<int>(NL + 2);
+  a.pe_cam = sl.take<int>(NPE + 1); a.pe_pt = sl.take<int>(NPE + 1);
+  a.pe_u = sl.take<double>(NPE + 1); a.pe_v = sl.take<double>(NPE + 1); a.pe_ur = sl.take<double>(NPE + 1); a.pe_s = sl.take<double>(NPE + 1);
+  a.le_cam = sl.take<int>(NLE + 1); a.le_ln = sl.take<int>(NLE + 1);
+  a.le_xs = sl.take<double>(NLE + 1); a.le_ys = sl.take<double>(NLE + 1); a.le_xe = sl.take<double>(NLE + 1); a.le_ye = sl.take<double>(NLE + 1);
+  a.le_s = sl.take<double>(NLE + 1); a.le_bx = sl.take<double>(NLE + 1);
+  a.le_flags0 = sl.take<uint8_t>(NLE + 1);
+}
+struct SecBSizes { size_t blk_start, blk_src, cam_start, cam_src, lm, tab, cams, chunk, ptask, ltask; int n_windows; };
+struct SecB { int *blk_start, *blk_src, *cam_start, *cam_src, *sg_lm, *sg_tab, *sg_cams; SChunk* chunks; PTask *ptasks, *ltasks; BAWin* wins; };
+void carve_b(lld_slab& sl, const SecBSizes& z, SecB& b) {
+  b.blk_start = sl.take<int>(z.blk_start + 2); b.blk_src = sl.take<int>(z.blk_src + 1); b.cam_start = sl.take<int>(z.cam_start + 2); b.cam_src = sl.take<int>(z.cam_src + 1);
+  b.sg_lm = sl.take<int>(z.lm + 1); b.sg_tab = sl.take<int>(z.tab + 1); b.sg_cams = sl.take<int>(z.cams + 1);
+  b.chunks = sl.take<SChunk>(z.chunk + 1); b.ptasks = sl.take<PTask>(z.ptask + 1); b.ltasks = sl.take<PTask>(z.ltask + 1);
+  b.wins = sl.take<BAWin>((size_t)z.n_windows);
+}
+
+// Grow-only pinned arena `which` of the context's cache (or, for a batch that does not own the cache, a private one the caller frees).
+int stage_arena(lld_ctx* ctx, bool cached, int which, size_t bytes, void** out) {
+  if (!cached) { LLD_HIP_TRY(hipHostMalloc(out, bytes, hipHostMallocDefault)); return LLD_OK; }
+  lld_ctx::BACache& c = ctx->ba;
+  if (c.stage_pending) { LLD_HIP_TRY(hipEventSynchronize(c.stage_free)); c.stage_pending = false; }     // the previous batch's uploads have left
+  if (bytes > c.stage_bytes[which]) {
+    if (c.stage[which]) LLD_HIP_TRY(hipHostFree(c.stage[which]));
+    c.stage[which] = nullptr; c.stage_bytes[which] = 0;
+    const size_t want = bytes + (bytes >> 3) + 4096;
+    LLD_HIP_TRY(hipHostMalloc(&c.stage[which], want, hipHostMallocDefault));
+    c.stage_bytes[which] = want;
+  }
+  *out = c.stage[which];
+  return LLD_OK;
+}
 
 // wavefront tasks of the lane-per-edge kernels + everything in BAWin that follows from the window sizes
 void stage_tasks(const lld_ba_window& w, const lld_ba_params& P, const WinBases& b, int n_windows, BAWin& W, WinStage& S) {
@@ -158,15 +207,15 @@ void stage_tasks(const lld_ba_window& w, const lld_ba_params& P, const WinBases&
 
 // the window's vertices and edges into their slots of the batch-global arrays
 void stage_edges(const lld_ba_window& w, const lld_ba_params& P, const WinBases& b, const BAWin& W, HostArrays& H) {
-  std::copy(w.cam_qt, w.cam_qt + 7 * (size_t)w.n_cams, H.cam_qt0.p.get() + 7 * (size_t)b.NC);
-  if (w.n_points) std::copy(w.pt_xyz, w.pt_xyz + 3 * (size_t)w.n_points, H.pt0.p.get() + 3 * (size_t)b.NP);
+  std::copy(w.cam_qt, w.cam_qt + 7 * (size_t)w.n_cams, H.cam_qt0.p + 7 * (size_t)b.NC);
+  if (w.n_points) std::copy(w.pt_xyz, w.pt_xyz + 3 * (size_t)w.n_points, H.pt0.p + 3 * (size_t)b.NP);
   if (w.n_lines) {
-    std::copy(w.line_x0, w.line_x0 + 3 * (size_t)w.n_lines, H.ln_x0.p.get() + 3 * (size_t)b.NL);
-    std::copy(w.line_dir, w.line_dir + 3 * (size_t)w.n_lines, H.ln_dir.p.get() + 3 * (size_t)b.NL);
+    std::copy(w.line_x0, w.line_x0 + 3 * (size_t)w.n_lines, H.ln_x0.p + 3 * (size_t)b.NL);
+    std::copy(w.line_dir, w.line_dir + 3 * (size_t)w.n_lines, H.ln_dir.p + 3 * (size_t)b.NL);
   }
   {
-    int* os = H.pt_obs_start.p.get() + b.NP; int* cam = H.pe_cam.p.get() + b.NPE; int* pt = H.pe_pt.p.get() + b.NPE;
-    double* u = H.pe_u.p.get() + b.NPE; double* v = H.pe_v.p.get() + b.NPE; double* ur = H.pe_ur.p.get() + b.NPE; double* s = H.pe_s.p.get() + b.NPE;
+    int* os = H.pt_obs_start.p + b.NP; int* cam = H.pe_cam.p + b.NPE; int* pt = H.pe_pt.p + b.NPE;
+    double* u = H.pe_u.p + b.NPE; double* v = H.pe_v.p + b.NPE; double* ur = H.pe_ur.p + b.NPE; double* s = H.pe_s.p + b.NPE;
     for (int p = 0; p < w.n_points; p++) {
       os[p] = (int)b.NPE + w.pt_obs_start[p];
       for (int o = w.pt_obs_start[p]; o < w.pt_obs_start[p + 1]; o++) {
@@ -178,9 +227,9 @@ void stage_edges(const lld_ba_window& w, const lld_ba_params& P, const WinBases&
   }
   {
     const size_t e0 = 2 * (size_t)b.NLO;
-    int* os = H.ln_obs_start.p.get() + b.NL; int* cam = H.le_cam.p.get() + e0; int* ln = H.le_ln.p.get() + e0;
-    double* xs = H.le_xs.p.get() + e0; double* ys = H.le_ys.p.get() + e0; double* xe = H.le_xe.p.get() + e0; double* ye = H.le_ye.p.get() + e0;
-    double* s = H.le_s.p.get() + e0; double* bx = H.le_bx.p.get() + e0; uint8_t* fl = H.le_flags0.p.get() + e0;
+    int* os = H.ln_obs_start.p + b.NL; int* cam = H.le_cam.p + e0; int* ln = H.le_ln.p + e0;
+    double* xs = H.le_xs.p + e0; double* ys = H.le_ys.p + e0; double* xe = H.le_xe.p + e0; double* ye = H.le_ye.p + e0;
+    double* s = H.le_s.p + e0; double* bx = H.le_bx.p + e0; uint8_t* fl = H.le_flags0.p + e0;
     for (int l = 0; l < w.n_lines; l++) {
       os[l] = (int)b.NLO + w.ln_obs_start[l];
       for (int o = w.ln_obs_start[l]; o < w.ln_obs_start[l + 1]; o++) {
@@ -319,8 +368,10 @@ void stage_csr(int n_free, WinStage& S) {
 
 static void ba_drop_groups(lld_ba_batch* B) {
   for (auto& G : B->groups) {
+    if (G.own_stream && G.st) (void)hipStreamSynchronize(G.st);
+    if (B->borrowed) continue;                         // streams and events belong to the context's cache
     for (auto& e : G.ev) if (e) (void)hipEventDestroy(e);
-    if (G.own_stream && G.st) { (void)hipStreamSynchronize(G.st); (void)hipStreamDestroy(G.st); }
+    if (G.own_stream && G.st) (void)hipStreamDestroy(G.st);
   }
   B->groups.clear();
 }
@@ -340,10 +391,17 @@ static int ba_make_groups(lld_ba_batch* B, int n_groups) {
   for (int g = 0; g < G; g++) {
     lld_ba_batch::Group& Gr = B->groups[g];
     Gr.w0 = (int)((long long)n_windows * g / G); Gr.nw = (int)((long long)n_windows * (g + 1) / G) - Gr.w0;
+    lld_ctx::BACache& cache = B->ctx->ba;
     if (g == 0) Gr.st = B->ctx->stream;
-    else { LLD_HIP_TRY(hipStreamCreateWithFlags(&Gr.st, hipStreamNonBlocking)); Gr.own_stream = true; }
+    else if (B->borrowed) {                            // created once per context (stream / event creation was 18 ms of every batch create)
+      if (!cache.streams[g - 1]) LLD_HIP_TRY(hipStreamCreateWithFlags(&cache.streams[g - 1], hipStreamNonBlocking));
+      Gr.st = cache.streams[g - 1]; Gr.own_stream = true;
+    } else { LLD_HIP_TRY(hipStreamCreateWithFlags(&Gr.st, hipStreamNonBlocking)); Gr.own_stream = true; }
     Gr.d_counters = B->d_counters + 4 * g; Gr.h_counters = B->h_counters + 4 * g;
-    for (auto& e : Gr.ev) LLD_HIP_TRY(hipEventCreate(&e));
+    for (int k = 0; k < kNumPhases + 1; k++) {
+      if (B->borrowed) { if (!cache.events[g][k]) LLD_HIP_TRY(hipEventCreate(&cache.events[g][k])); Gr.ev[k] = cache.events[g][k]; }
+      else LLD_HIP_TRY(hipEventCreate(&Gr.ev[k]));
+    }
     for (int wi = Gr.w0; wi < Gr.w0 + Gr.nw; wi++) {
       const BAWin& W = B->h_wins[wi];
       Gr.max_lblocks = std::max(Gr.max_lblocks, W.nb_pt + W.nb_ln);
@@ -358,9 +416,9 @@ static int ba_make_groups(lld_ba_batch* B, int n_groups) {
 
 extern "C" {
 
-// `borrow`: the slab and the pinned poll counters come from the context (grow-only, reused by the next call) instead of a fresh
-// allocation - what lld_local_ba uses, one window at a time on one host thread.
-static int ba_batch_create_impl(lld_ctx* ctx, int n_windows, const lld_ba_window* wins, const lld_ba_params* params, lld_ba_batch** out, bool borrow) {
+// The slab, the pinned upload arenas, the group streams / events and the pinned poll block come from the context's cache (grow-only,
+// reused by the next batch on this context) unless a live batch already holds them - see lld_ctx::BACache.
+static int ba_batch_create_impl(lld_ctx* ctx, int n_windows, const lld_ba_window* wins, const lld_ba_params* params, lld_ba_batch** out) {
   if (!ctx || n_windows <= 0 || !wins || !out) return LLD_ERR_INVALID;
   *out = nullptr;
   for (int w = 0; w < n_windows; w++) { int st = validate_window(wins[w], false); if (st) return st; }
@@ -399,14 +457,30 @@ static int ba_batch_create_impl(lld_ctx* ctx, int n_windows, const lld_ba_window
   if (NPE > 0x3fffffffll || NLO > 0x1fffffffll || NC * 7 > 0x7fffffffll) { delete B; return LLD_ERR_UNSUPPORTED; }   // 32-bit edge indices
   const size_t S_total = bases[n_windows].S_total, x_total = bases[n_windows].x_total;
   const size_t NLE = 2 * (size_t)NLO;
+  // ---- resources: the context's cached set if no live batch holds it, private ones otherwise
+  lld_ctx::BACache& cache = ctx->ba;
+  const bool cached = !cache.busy;
+  void* priv_stage[2] = {nullptr, nullptr};
+  auto fail = [&](int st) {
+    for (void* q : priv_stage) if (q) (void)hipHostFree(q);
+    if (B->borrowed) cache.busy = false; else if (B->slab) (void)hipFree(B->slab);
+    delete B; return st;
+  };
+  if (cached) { cache.busy = true; B->borrowed = true; }
+  // ---- section A (flattened inputs) in the pinned arena
+  SecA hA{}, dA{};
+  lld_slab dryA; dryA.base = reinterpret_cast<char*>(256);
+  carve_a(dryA, NC, NP, NL, NPE, NLE, hA);
+  const size_t bytesA = dryA.used;
+  void* arenaA = nullptr;
+  { const int gs = stage_arena(ctx, cached, 0, bytesA, &arenaA); if (gs) return fail(gs); if (!cached) priv_stage[0] = arenaA; }
+  { lld_slab sl; sl.base = static_cast<char*>(arenaA); sl.size = bytesA; carve_a(sl, NC, NP, NL, NPE, NLE, hA); }
   HostArrays H;
-  bool mem_ok = true;
-  mem_ok &= H.cam_qt0.alloc(7 * (size_t)NC); mem_ok &= H.pt0.alloc(3 * (size_t)NP); mem_ok &= H.ln_x0.alloc(3 * (size_t)NL); mem_ok &= H.ln_dir.alloc(3 * (size_t)NL);
-  mem_ok &= H.pt_obs_start.alloc((size_t)NP + 1); mem_ok &= H.ln_obs_start.alloc((size_t)NL + 1);
-  mem_ok &= H.pe_cam.alloc(NPE); mem_ok &= H.pe_pt.alloc(NPE); mem_ok &= H.pe_u.alloc(NPE); mem_ok &= H.pe_v.alloc(NPE); mem_ok &= H.pe_ur.alloc(NPE); mem_ok &= H.pe_s.alloc(NPE);
-  mem_ok &= H.le_cam.alloc(NLE); mem_ok &= H.le_ln.alloc(NLE); mem_ok &= H.le_xs.alloc(NLE); mem_ok &= H.le_ys.alloc(NLE); mem_ok &= H.le_xe.alloc(NLE); mem_ok &= H.le_ye.alloc(NLE); mem_ok &= H.le_s.alloc(NLE); mem_ok &= H.le_bx.alloc(NLE);
-  mem_ok &= H.le_flags0.alloc(NLE);
-  if (!mem_ok) { delete B; return LLD_ERR_ALLOC; }
+  H.cam_qt0.view(hA.cam_qt0, 7 * (size_t)NC); H.pt0.view(hA.pt0, 3 * (size_t)NP); H.ln_x0.view(hA.ln_x0, 3 * (size_t)NL); H.ln_dir.view(hA.ln_dir, 3 * (size_t)NL);
+  H.pt_obs_start.view(hA.pt_obs_start, (size_t)NP + 1); H.ln_obs_start.view(hA.ln_obs_start, (size_t)NL + 1);
+  H.pe_cam.view(hA.pe_cam, NPE); H.pe_pt.view(hA.pe_pt, NPE); H.pe_u.view(hA.pe_u, NPE); H.pe_v.view(hA.pe_v, NPE); H.pe_ur.view(hA.pe_ur, NPE); H.pe_s.view(hA.pe_s, NPE);
+  H.le_cam.view(hA.le_cam, NLE); H.le_ln.view(hA.le_ln, NLE); H.le_xs.view(hA.le_xs, NLE); H.le_ys.view(hA.le_ys, NLE); H.le_xe.view(hA.le_xe, NLE); H.le_ye.view(hA.le_ye, NLE);
+  H.le_s.view(hA.le_s, NLE); H.le_bx.view(hA.le_bx, NLE); H.le_flags0.view(hA.le_flags0, NLE);
   H.pt_obs_start.p[NP] = (int)NPE; H.ln_obs_start.p[NL] = (int)NLO;
   std::vector<WinStage> stages(n_windows);
   int n_threads = 1;
@@ -457,7 +531,7 @@ static int ba_batch_create_impl(lld_ctx* ctx, int n_windows, const lld_ba_window
     stage_csr(wins[wi].n_free_cams, S);
     lap1("chunks built");
   });
-  if (first_error.load() != LLD_OK) { const int st = first_error.load(); delete B; return st; }
+  if (first_error.load() != LLD_OK) return fail(first_error.load());
   // ---- where each window's variable-length pieces go
   // more cameras than the LDS holds accumulators and pose copies for (a global BA of a long sequence): those live in HBM (BAWin::big)
   bool big_map = false;
@@ -465,7 +539,8 @@ static int ba_batch_create_impl(lld_ctx* ctx, int n_windows, const lld_ba_window
     const size_t nf = (size_t)wins[wi].n_free_cams, nc = (size_t)wins[wi].n_cams;
     if (nf > (size_t)kMaxFreeCamsLds || (nf * 27 + 8 + nc * 7) * sizeof(double) > 158 * 1024 || (8 + nc * 14 + nf * 6) * sizeof(double) > 158 * 1024) big_map = true;
   }
-  if (std::getenv("LLD_BA_FORCE_BIG")) big_map = true;            // tests: the HBM path on windows of any size
+  static const bool force_big = std::getenv("LLD_BA_FORCE_BIG") != nullptr;            // tests: the HBM path on windows of any size
+  if (force_big) big_map = true;
   struct Place { size_t ptask, ltask, chunk, lm, tab, cams, blk_start, blk_src, cam_start, cam_src, part, cpart; };
   std::vector<Place> place(n_windows + 1);
   size_t n_hpart = 0; long long NPART = 0; int max_blk = 0;
@@ -484,10 +559,10 @@ static int ba_batch_create_impl(lld_ctx* ctx, int n_windows, const lld_ba_window
       q.lm += S.cs[0].sg_lm.size() + S.cs[1].sg_lm.size(); q.tab += S.cs[0].sg_tab.size() + S.cs[1].sg_tab.size(); q.cams += S.cs[0].sg_cams.size() + S.cs[1].sg_cams.size();
       q.blk_start += S.blk_start.size(); q.blk_src += S.blk_src.size(); q.cam_start += S.cam_start.size(); q.cam_src += S.cam_src.size();
       q.part += S.cs[0].n_part + S.cs[1].n_part; q.cpart += S.cs[0].n_cpart + S.cs[1].n_cpart;
-      if (q.part * 4 > 0x7fffffffull || q.tab > 0x7fffffffull) { delete B; return LLD_ERR_UNSUPPORTED; }
+      if (q.part * 4 > 0x7fffffffull || q.tab > 0x7fffffffull) return fail(LLD_ERR_UNSUPPORTED);
       for (int d = 0; d < 2; d++) B->schur_lds[d] = std::max(B->schur_lds[d], S.cs[d].lds_need);
       for (int d = 0; d < 2; d++) B->schur_wide_lds = std::max(B->schur_wide_lds, S.cs[d].wide_lds_need);
-      if (B->schur_wide_lds > 64 * 1024) { delete B; return LLD_ERR_UNSUPPORTED; }       // a landmark with > ~450 free observations
+      if (B->schur_wide_lds > 64 * 1024) return fail(LLD_ERR_UNSUPPORTED);       // a landmark with > ~450 free observations
       max_blk = std::max(max_blk, W.n_free * (W.n_free + 1) / 2);
       B->max_items_pt = std::max(B->max_items_pt, W.n_items_pt); B->max_items_ln = std::max(B->max_items_ln, W.n_items - W.n_items_pt);
       B->max_lblocks = std::max(B->max_lblocks, W.nb_pt + W.nb_ln);
@@ -499,76 +574,43 @@ static int ba_batch_create_impl(lld_ctx* ctx, int n_windows, const lld_ba_window
   }
   const Place& tot = place[n_windows];
   const size_t n_part = tot.part, n_cpart = tot.cpart;
-  size_t rec_total = 0;
-  B->h_ptasks.resize(tot.ptask); B->h_ltasks.resize(tot.ltask); B->h_chunks.resize(tot.chunk);
-  HostBuf<int> sg_lm, sg_tab, sg_cams, blk_start, blk_src, cam_start, cam_src;
-  mem_ok &= sg_lm.alloc(tot.lm); mem_ok &= sg_tab.alloc(tot.tab); mem_ok &= sg_cams.alloc(tot.cams);
-  mem_ok &= blk_start.alloc(tot.blk_start + 1); mem_ok &= blk_src.alloc(tot.blk_src); mem_ok &= cam_start.alloc(tot.cam_start + 1); mem_ok &= cam_src.alloc(tot.cam_src);
-  if (!mem_ok) { delete B; return LLD_ERR_ALLOC; }
-  blk_start.p[tot.blk_start] = (int)tot.blk_src; cam_start.p[tot.cam_start] = (int)tot.cam_src;
-  for_windows([&](int wi) {
-    const Place& q = place[wi];
-    WinStage& S = stages[wi];
-    std::copy(S.ptasks.begin(), S.ptasks.end(), B->h_ptasks.begin() + q.ptask);
-    std::copy(S.ltasks.begin(), S.ltasks.end(), B->h_ltasks.begin() + q.ltask);
-    size_t at_chunk = q.chunk, at_lm = q.lm, at_tab = q.tab, at_cams = q.cams;
-    for (int d = 0; d < 2; d++) {
-      const ChunkStage& C = S.cs[d];
-      for (SChunk c : C.chunks) {
-        c.lm_off += (int)at_lm; c.tab_off += (int)at_tab; c.cams_off += (int)at_cams; c.part_off += (int)q.part; c.cpart_off += (int)q.cpart;      // stage_csr numbered both kinds within the window
-        B->h_chunks[at_chunk++] = c;
-      }
-      std::copy(C.sg_lm.begin(), C.sg_lm.end(), sg_lm.p.get() + at_lm); at_lm += C.sg_lm.size();
-      std::copy(C.sg_tab.begin(), C.sg_tab.end(), sg_tab.p.get() + at_tab); at_tab += C.sg_tab.size();
-      std::copy(C.sg_cams.begin(), C.sg_cams.end(), sg_cams.p.get() + at_cams); at_cams += C.sg_cams.size();
-    }
-    // the window-local CSRs number their partials from the window's first one
-    const int part4 = (int)(q.part * 4), cpart0 = (int)q.cpart, bsrc0 = (int)q.blk_src, csrc0 = (int)q.cam_src;
-    for (size_t i = 0; i < S.blk_start.size(); i++) blk_start.p[q.blk_start + i] = S.blk_start[i] + bsrc0;
-    for (size_t i = 0; i < S.blk_src.size(); i++) blk_src.p[q.blk_src + i] = S.blk_src[i] + part4;
-    for (size_t i = 0; i < S.cam_start.size(); i++) cam_start.p[q.cam_start + i] = S.cam_start[i] + csrc0;
-    for (size_t i = 0; i < S.cam_src.size(); i++) cam_src.p[q.cam_src + i] = S.cam_src[i] + cpart0;
-    S = WinStage();
-  });
-  if (first_error.load() != LLD_OK) { const int st = first_error.load(); delete B; return st; }
-  stages.clear();
   // few windows whose reduced system is beyond the matrix-core Cholesky: the PCG runs across the whole GPU (see ba_pcgm_*)
   B->pcg_multi = n_windows <= 8 && B->max_free * 6 > kCholMN && P.reduced_solver != 2;
-  if (B->max_free > kMaxFreeCamsOneWg && !B->pcg_multi) { delete B; return LLD_ERR_UNSUPPORTED; }   // batches of huge windows: not in this build
-  if (B->max_cams > kPcgThreads && !B->pcg_multi) { delete B; return LLD_ERR_UNSUPPORTED; }           // (the one-workgroup solvers move one camera per lane)
+  if (B->max_free > kMaxFreeCamsOneWg && !B->pcg_multi) return fail(LLD_ERR_UNSUPPORTED);   // batches of huge windows: not in this build
+  if (B->max_cams > kPcgThreads && !B->pcg_multi) return fail(LLD_ERR_UNSUPPORTED);           // (the one-workgroup solvers move one camera per lane)
   B->big = big_map;
   // LDS copies of the per-camera accumulators in the linearise kernels: as many as fit (4 for local windows)
   B->acc_copies = B->big ? 1 : kAccCopies;
   while (!B->big && B->acc_copies > 1 && ((size_t)B->max_free * 27 * B->acc_copies + 8 + (size_t)B->max_cams * 7) * sizeof(double) > 150 * 1024) B->acc_copies >>= 1;
-  if (!B->big && ((size_t)B->max_free * 27 * B->acc_copies + 8 + (size_t)B->max_cams * 7) * sizeof(double) > 158 * 1024) { delete B; return LLD_ERR_UNSUPPORTED; }
+  if (!B->big && ((size_t)B->max_free * 27 * B->acc_copies + 8 + (size_t)B->max_cams * 7) * sizeof(double) > 158 * 1024) return fail(LLD_ERR_UNSUPPORTED);
   for (int wi = 0; wi < n_windows; wi++) { B->h_wins[wi].acc_copies = B->acc_copies; B->h_wins[wi].win_index = wi; B->h_wins[wi].big = B->big ? 1 : 0; }
   B->max_blk = max_blk;
   // fixed-stride result records (what an RCCL gather of the batch moves)
   for (int wi = 0; wi < n_windows; wi++) B->h_wins[wi].rec_off = (long long)(B->rec_stride * (size_t)wi);
-  rec_total = B->rec_stride * (size_t)n_windows;
+  const size_t rec_total = B->rec_stride * (size_t)n_windows;
   B->S_total = S_total; B->x_total = x_total;
-  // ---- one slab: a dry run of the carve sizes it exactly, the second run assigns pointers and uploads
+  const SecBSizes zB{tot.blk_start, tot.blk_src, tot.cam_start, tot.cam_src, tot.lm, tot.tab, tot.cams, tot.chunk, tot.ptask, tot.ltask, n_windows};
+  // ---- one slab: a dry run of the carve sizes it exactly, the second run assigns the pointers
   hipStream_t st = ctx->stream;
   BAArrays& A = B->A;
-  auto carve = [&](lld_slab& sl, bool real) {
-    auto up_d = [&](const HostBuf<double>& h, size_t count) { double* d = sl.take<double>(count); if (real && !h.empty()) (void)hipMemcpyAsync(d, h.data(), h.size() * 8, hipMemcpyHostToDevice, st); return (const double*)d; };
-    auto up_i = [&](const HostBuf<int>& h, size_t count) { int* d = sl.take<int>(count); if (real && !h.empty()) (void)hipMemcpyAsync(d, h.data(), h.size() * 4, hipMemcpyHostToDevice, st); return (const int*)d; };
-    auto up_b = [&](const HostBuf<uint8_t>& h, size_t count) { uint8_t* d = sl.take<uint8_t>(count); if (real && !h.empty()) (void)hipMemcpyAsync(d, h.data(), h.size(), hipMemcpyHostToDevice, st); return (const uint8_t*)d; };
-    B->d_wins = sl.take<BAWin>(n_windows); B->d_state = sl.take<BAState>(n_windows);
+  SecB dB{};
+  size_t offA = 0, offB = 0, bytesB = 0;
+  auto carve = [&](lld_slab& sl) {
     std::memset(&A, 0, sizeof A);
+    offA = sl.used; carve_a(sl, NC, NP, NL, NPE, NLE, dA);
+    offB = sl.used; carve_b(sl, zB, dB); bytesB = sl.used - offB;
+    A.cam_qt0 = dA.cam_qt0; A.pt0 = dA.pt0; A.ln_x0 = dA.ln_x0; A.ln_dir = dA.ln_dir; A.pt_obs_start = dA.pt_obs_start; A.ln_obs_start = dA.ln_obs_start;
+    A.pe_cam = dA.pe_cam; A.pe_pt = dA.pe_pt; A.pe_u = dA.pe_u; A.pe_v = dA.pe_v; A.pe_ur = dA.pe_ur; A.pe_s = dA.pe_s;
+    A.le_cam = dA.le_cam; A.le_ln = dA.le_ln; A.le_xs = dA.le_xs; A.le_ys = dA.le_ys; A.le_xe = dA.le_xe; A.le_ye = dA.le_ye; A.le_s = dA.le_s; A.le_bx = dA.le_bx;
+    A.le_flags0 = dA.le_flags0;
+    A.blk_start = dB.blk_start; A.blk_src = dB.blk_src; A.cam_start = dB.cam_start; A.cam_src = dB.cam_src;
+    A.sg_lm = dB.sg_lm; A.sg_tab = dB.sg_tab; A.sg_cams = dB.sg_cams; A.sg_chunks = dB.chunks; A.ptasks = dB.ptasks; A.ltasks = dB.ltasks;
+    B->d_wins = dB.wins;
+    B->d_state = sl.take<BAState>(n_windows);
     A.NC = NC; A.NP = NP; A.NL = NL;
     A.cam_qt = sl.take<double>(2 * NC * 7 + 1);
     A.ptx = sl.take<double>(2 * NP + 1); A.pty = sl.take<double>(2 * NP + 1); A.ptz = sl.take<double>(2 * NP + 1);
     A.lqx = sl.take<double>(2 * NL + 1); A.lqy = sl.take<double>(2 * NL + 1); A.lqz = sl.take<double>(2 * NL + 1); A.lqw = sl.take<double>(2 * NL + 1); A.lal = sl.take<double>(2 * NL + 1);
-    A.cam_qt0 = up_d(H.cam_qt0, NC * 7 + 1); A.pt0 = up_d(H.pt0, NP * 3 + 1);
-    A.ln_x0 = up_d(H.ln_x0, NL * 3 + 1); A.ln_dir = up_d(H.ln_dir, NL * 3 + 1);
-    A.pt_obs_start = up_i(H.pt_obs_start, NP + 2); A.ln_obs_start = up_i(H.ln_obs_start, NL + 2);
-    A.pe_cam = up_i(H.pe_cam, NPE + 1); A.pe_pt = up_i(H.pe_pt, NPE + 1);
-    A.pe_u = up_d(H.pe_u, NPE + 1); A.pe_v = up_d(H.pe_v, NPE + 1); A.pe_ur = up_d(H.pe_ur, NPE + 1); A.pe_s = up_d(H.pe_s, NPE + 1);
-    A.le_cam = up_i(H.le_cam, NLE + 1); A.le_ln = up_i(H.le_ln, NLE + 1);
-    A.le_xs = up_d(H.le_xs, NLE + 1); A.le_ys = up_d(H.le_ys, NLE + 1); A.le_xe = up_d(H.le_xe, NLE + 1); A.le_ye = up_d(H.le_ye, NLE + 1);
-    A.le_s = up_d(H.le_s, NLE + 1); A.le_bx = up_d(H.le_bx, NLE + 1);
-    A.le_flags0 = up_b(H.le_flags0, NLE + 1);
     A.pe_flags = sl.take<uint8_t>(NPE + 1); A.le_flags = sl.take<uint8_t>(NLE + 1);
     A.pe_chi2 = sl.take<double>(NPE + 1); A.le_chi2 = sl.take<double>(NLE + 1);
     A.pe_ws = sl.take<double>((size_t)NPE + 1); A.lo_W = sl.take<double>((size_t)NLO * 24 + 1);
@@ -580,78 +622,111 @@ static int ba_batch_create_impl(lld_ctx* ctx, int n_windows, const lld_ba_window
     A.x_total = (long long)x_total;
     if (B->pcg_multi) { A.pcg_vec = sl.take<double>(4 * x_total + 4); A.pcg_mi = sl.take<double>((size_t)NF * 36 + 1); A.pcg_sc = sl.take<double>(8 * (size_t)n_windows + 8); }
     A.chi_part = sl.take<double>(NPART + 1); A.chi_part2 = sl.take<double>(NPART + 1); A.scale_part = sl.take<double>(NPART + 1);
-    A.blk_start = up_i(blk_start, blk_start.size() + 1); A.blk_src = up_i(blk_src, blk_src.size() + 1);
-    A.cam_start = up_i(cam_start, cam_start.size() + 1); A.cam_src = up_i(cam_src, cam_src.size() + 1);
     A.sp_part = sl.take<double>(n_part * 36 + 2); A.sp_cpart = sl.take<double>(n_cpart * 6 + 2);
-    A.sg_lm = up_i(sg_lm, sg_lm.size() + 1); A.sg_tab = up_i(sg_tab, sg_tab.size() + 1); A.sg_cams = up_i(sg_cams, sg_cams.size() + 1);
-    {
-      SChunk* dc = sl.take<SChunk>(B->h_chunks.size() + 1);
-      if (real && !B->h_chunks.empty()) (void)hipMemcpyAsync(dc, B->h_chunks.data(), B->h_chunks.size() * sizeof(SChunk), hipMemcpyHostToDevice, st);
-      A.sg_chunks = dc;
-      PTask* dt = sl.take<PTask>(B->h_ptasks.size() + 1);
-      if (real && !B->h_ptasks.empty()) (void)hipMemcpyAsync(dt, B->h_ptasks.data(), B->h_ptasks.size() * sizeof(PTask), hipMemcpyHostToDevice, st);
-      A.ptasks = dt;
-      PTask* dl = sl.take<PTask>(B->h_ltasks.size() + 1);
-      if (real && !B->h_ltasks.empty()) (void)hipMemcpyAsync(dl, B->h_ltasks.data(), B->h_ltasks.size() * sizeof(PTask), hipMemcpyHostToDevice, st);
-      A.ltasks = dl;
-    }
     A.records = sl.take<unsigned char>(rec_total + 256);
     B->d_counters = sl.take<int>(4 * 8);
   };
   lap("host staging done");
   lld_slab dry; dry.base = reinterpret_cast<char*>(256);
-  carve(dry, false);
+  carve(dry);
   const size_t bytes = dry.used + 4096;
-  if (borrow) { const int gs = lld_ctx_scratch(ctx, bytes, &B->slab); if (gs) { delete B; return gs; } B->borrowed = true; }
-  else if (hipMalloc(&B->slab, bytes) != hipSuccess) { delete B; return LLD_ERR_ALLOC; }
+  if (cached) {
+    if (bytes > cache.slab_bytes) {                   // grow-only (hipFree synchronises the device: it happens only while a context warms up)
+      if (cache.slab) { if (hipFree(cache.slab) != hipSuccess) return fail(LLD_ERR_HIP); }
+      cache.slab = nullptr; cache.slab_bytes = 0;
+      const size_t want = bytes + (bytes >> 4);
+      if (hipMalloc(&cache.slab, want) != hipSuccess) return fail(LLD_ERR_ALLOC);
+      cache.slab_bytes = want;
+    }
+    B->slab = cache.slab;
+  } else if (hipMalloc(&B->slab, bytes) != hipSuccess) return fail(LLD_ERR_ALLOC);
   B->slab_bytes = bytes;
-  lap("hipMalloc done");
+  lap("slab ready");
   // debugging aid: every byte of the slab starts as 0xFF (NaN doubles, -1 indices), so a kernel that reads what nothing wrote shows up in the results
   static const bool poison = std::getenv("LLD_BA_POISON") != nullptr;
-  if (poison) LLD_HIP_TRY(hipMemsetAsync(B->slab, 0xFF, bytes, st));
+  if (poison && hipMemsetAsync(B->slab, 0xFF, bytes, st) != hipSuccess) return fail(LLD_ERR_HIP);
   lld_slab sl; sl.base = (char*)B->slab; sl.size = bytes;
-  carve(sl, true);
-  lap("uploads queued");
-  {
-    const size_t pcg_lds = ((size_t)B->max_free * 6 * 4 + kPcgThreads + (size_t)B->max_free * 36 + 32) * sizeof(double);
-    if (!B->pcg_multi) LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_pcg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pcg_lds));
-    const size_t bs_lds0 = B->big ? 64 : (8 + (size_t)B->max_cams * 14 + (size_t)B->max_free * 6) * sizeof(double);
-    if (bs_lds0 > 48 * 1024) {
-      LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_backsub_pt_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bs_lds0));
-      LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_backsub_ln_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bs_lds0));
-      LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_backsub_both_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bs_lds0));
+  carve(sl);
+  // section A leaves now and travels while the host places section B
+  if (hipMemcpyAsync((char*)B->slab + offA, arenaA, bytesA, hipMemcpyHostToDevice, st) != hipSuccess) return fail(LLD_ERR_HIP);
+  lap("inputs queued");
+  // ---- section B in its pinned arena: every window writes its pieces straight into their final places
+  void* arenaB = nullptr;
+  { const int gs = stage_arena(ctx, cached, 1, bytesB, &arenaB); if (gs) return fail(gs); if (!cached) priv_stage[1] = arenaB; }
+  SecB hB{};
+  { lld_slab slb; slb.base = static_cast<char*>(arenaB); slb.size = bytesB; carve_b(slb, zB, hB); }
+  hB.blk_start[tot.blk_start] = (int)tot.blk_src; hB.cam_start[tot.cam_start] = (int)tot.cam_src;
+  for_windows([&](int wi) {
+    const Place& q = place[wi];
+    WinStage& S = stages[wi];
+    std::copy(S.ptasks.begin(), S.ptasks.end(), hB.ptasks + q.ptask);
+    std::copy(S.ltasks.begin(), S.ltasks.end(), hB.ltasks + q.ltask);
+    size_t at_chunk = q.chunk, at_lm = q.lm, at_tab = q.tab, at_cams = q.cams;
+    for (int d = 0; d < 2; d++) {
+      const ChunkStage& C = S.cs[d];
+      for (SChunk c : C.chunks) {
+        c.lm_off += (int)at_lm; c.tab_off += (int)at_tab; c.cams_off += (int)at_cams; c.part_off += (int)q.part; c.cpart_off += (int)q.cpart;      // stage_csr numbered both kinds within the window
+        hB.chunks[at_chunk++] = c;
+      }
+      std::copy(C.sg_lm.begin(), C.sg_lm.end(), hB.sg_lm + at_lm); at_lm += C.sg_lm.size();
+      std::copy(C.sg_tab.begin(), C.sg_tab.end(), hB.sg_tab + at_tab); at_tab += C.sg_tab.size();
+      std::copy(C.sg_cams.begin(), C.sg_cams.end(), hB.sg_cams + at_cams); at_cams += C.sg_cams.size();
     }
-    const size_t lin_lds = B->big ? 64 : ((size_t)B->max_free * 27 * B->acc_copies + 8 + (size_t)B->max_cams * 7) * sizeof(double);
-    LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_linearize_pt_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lin_lds));
-    LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_linearize_ln_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lin_lds));
-    LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_linearize_both_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lin_lds));
-    LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_chol_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
-    LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_chol_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)(kCholMLdsDoubles * sizeof(double))));
+    // the window-local CSRs number their partials from the window's first one
+    const int part4 = (int)(q.part * 4), cpart0 = (int)q.cpart, bsrc0 = (int)q.blk_src, csrc0 = (int)q.cam_src;
+    for (size_t i = 0; i < S.blk_start.size(); i++) hB.blk_start[q.blk_start + i] = S.blk_start[i] + bsrc0;
+    for (size_t i = 0; i < S.blk_src.size(); i++) hB.blk_src[q.blk_src + i] = S.blk_src[i] + part4;
+    for (size_t i = 0; i < S.cam_start.size(); i++) hB.cam_start[q.cam_start + i] = S.cam_start[i] + csrc0;
+    for (size_t i = 0; i < S.cam_src.size(); i++) hB.cam_src[q.cam_src + i] = S.cam_src[i] + cpart0;
+    hB.wins[wi] = B->h_wins[wi];
+    S = WinStage();
+  });
+  if (first_error.load() != LLD_OK) return fail(first_error.load());
+  stages.clear();
+  if (hipMemcpyAsync((char*)B->slab + offB, arenaB, bytesB, hipMemcpyHostToDevice, st) != hipSuccess) return fail(LLD_ERR_HIP);
+  lap("structures queued");
+  if (!cache.attrs_set || !cached) {
+    // dynamic LDS ceilings of the kernels that may ask for more than the 64 KiB default: raised once per context to what a workgroup
+    // can own on gfx950 (a launch still states the bytes it needs)
+    const int lds_max = 159 * 1024;
+    const void* fns[] = {reinterpret_cast<const void*>(ba_pcg_kernel), reinterpret_cast<const void*>(ba_backsub_pt_kernel), reinterpret_cast<const void*>(ba_backsub_ln_kernel),
+                         reinterpret_cast<const void*>(ba_backsub_both_kernel), reinterpret_cast<const void*>(ba_linearize_pt_kernel), reinterpret_cast<const void*>(ba_linearize_ln_kernel),
+                         reinterpret_cast<const void*>(ba_linearize_both_kernel), reinterpret_cast<const void*>(ba_chol_kernel), reinterpret_cast<const void*>(ba_chol_mfma_kernel)};
+    for (const void* f : fns) if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max) != hipSuccess) return fail(LLD_ERR_HIP);
+    if (cached) cache.attrs_set = true;
   }
-  LLD_HIP_TRY(hipMemcpyAsync(B->d_wins, B->h_wins.data(), sizeof(BAWin) * n_windows, hipMemcpyHostToDevice, st));
   lap("attributes set");
-  if (borrow) {
-    if (!ctx->poll) LLD_HIP_TRY(hipHostMalloc(&ctx->poll, 256, hipHostMallocDefault));
+  if (B->borrowed) {
+    if (!ctx->poll && hipHostMalloc(&ctx->poll, 256, hipHostMallocDefault) != hipSuccess) return fail(LLD_ERR_HIP);
     B->h_counters = static_cast<int*>(ctx->poll);
-  } else LLD_HIP_TRY(hipHostMalloc((void**)&B->h_counters, 4 * 8 * sizeof(int), hipHostMallocDefault));
+  } else if (hipHostMalloc((void**)&B->h_counters, 4 * 8 * sizeof(int), hipHostMallocDefault) != hipSuccess) return fail(LLD_ERR_HIP);
   lap("pinned counters");
-  { int gs = ba_make_groups(B, 0); if (gs) return gs; }
+  { int gs = ba_make_groups(B, 0); if (gs) return fail(gs); }
   lap("groups made");
-  LLD_HIP_TRY(hipStreamSynchronize(st));        // staging vectors go out of scope
-  lap("synchronised");
+  if (cached) {
+    // the arenas are free again once both copies have left; the next create on this context waits for that, not this one
+    if (!cache.stage_free && hipEventCreateWithFlags(&cache.stage_free, hipEventDisableTiming) != hipSuccess) return fail(LLD_ERR_HIP);
+    if (hipEventRecord(cache.stage_free, st) != hipSuccess) return fail(LLD_ERR_HIP);
+    cache.stage_pending = true;
+  } else {
+    if (hipStreamSynchronize(st) != hipSuccess) return fail(LLD_ERR_HIP);
+    for (void*& q : priv_stage) if (q) { (void)hipHostFree(q); q = nullptr; }
+  }
+  lap("done");
   *out = B;
   return LLD_OK;
 }
 
 int lld_ba_batch_create(lld_ctx* ctx, int n_windows, const lld_ba_window* wins, const lld_ba_params* params, lld_ba_batch** out) {
-  return ba_batch_create_impl(ctx, n_windows, wins, params, out, false);
+  return ba_batch_create_impl(ctx, n_windows, wins, params, out);
 }
 
 int lld_ba_batch_solve(lld_ba_batch* B, volatile const int* abort_flag) {
   if (!B) return LLD_ERR_INVALID;
   lld_ctx* ctx = B->ctx;
   LLD_HIP_TRY(hipSetDevice(ctx->device));
+  std::unique_lock<std::mutex> turn(g_big_solve[ctx->device & 63], std::defer_lock);
+  if (B->n_windows >= kSerialiseSolvesFromWindows) turn.lock();
   BAArrays& A = B->A;
   B->records_valid = false;
   for (auto& m : B->phase_ms) m = 0.0;
@@ -683,7 +758,6 @@ int lld_ba_batch_solve(lld_ba_batch* B, volatile const int* abort_flag) {
     const BAWin* dw = B->d_wins + G.w0; BAState* ds = B->d_state + G.w0;
     const int nw = G.nw; hipStream_t st = G.st;
     const int abort_now = (abort_flag && *abort_flag) ? 1 : 0;
-    LLD_HIP_TRY(hipMemsetAsync(G.d_counters, 0, 4 * sizeof(int), st));
     LLD_HIP_TRY(hipEventRecord(G.ev[0], st));
     const bool fuse_pairs = B->n_windows < kFusePairsBelowWindows && !B->big;                // see ba_linearize_both_kernel
     if (B->big) {
@@ -741,9 +815,8 @@ int lld_ba_batch_solve(lld_ba_batch* B, volatile const int* abort_flag) {
       if (G.max_nb_ln > 0) hipLaunchKernelGGL(ba_backsub_ln_kernel, dim3(G.max_nb_ln, nw), dim3(kLmThreads), bs_lds, st, A, dw, ds);
     }
     LLD_HIP_TRY(hipEventRecord(G.ev[4], st));
-    hipLaunchKernelGGL(ba_control_kernel, dim3(nw), dim3(kCtlThreads), 0, st, A, dw, ds, abort_now, G.d_counters);
+    hipLaunchKernelGGL(ba_control_kernel, dim3(nw), dim3(kCtlThreads), 0, st, A, dw, ds, abort_now, G.d_counters, G.h_counters);   // totals land in pinned host memory
     LLD_HIP_TRY(hipGetLastError());
-    LLD_HIP_TRY(hipMemcpyAsync(G.h_counters, G.d_counters, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
     LLD_HIP_TRY(hipEventRecord(G.ev[5], st));
     return LLD_OK;
   };
@@ -752,6 +825,7 @@ int lld_ba_batch_solve(lld_ba_batch* B, volatile const int* abort_flag) {
     const BAWin* dw = B->d_wins + G.w0; BAState* ds = B->d_state + G.w0;
     if (G.own_stream) LLD_HIP_TRY(hipStreamWaitEvent(G.st, t_begin, 0));
     G.steps = 0; G.active = !abort_at_start;
+    LLD_HIP_TRY(hipMemsetAsync(G.d_counters, 0, 4 * sizeof(int), G.st));     // the control kernel leaves them at zero after every super-step
     hipLaunchKernelGGL(ba_init_kernel, dim3(std::max(1, std::min(64, G.max_lblocks + 1)), G.nw), dim3(kLmThreads), 0, G.st, A, dw, ds);
     LLD_HIP_TRY(hipGetLastError());
     if (abort_at_start) {
@@ -809,8 +883,18 @@ int lld_ba_batch_solve(lld_ba_batch* B, volatile const int* abort_flag) {
 static int ba_fetch_records(lld_ba_batch* B) {
   if (B->records_valid) return LLD_OK;
   const size_t total = B->rec_stride * (size_t)B->n_windows;
-  B->h_records.resize(total);
-  LLD_HIP_TRY(hipMemcpyAsync(B->h_records.data(), B->A.records, total, hipMemcpyDeviceToHost, B->ctx->stream));
+  if (B->borrowed) {                                  // pinned landing buffer kept by the context (grow-only): one DMA at link speed
+    lld_ctx::BACache& c = B->ctx->ba;
+    if (total > c.rec_bytes) {
+      if (c.rec) LLD_HIP_TRY(hipHostFree(c.rec));
+      c.rec = nullptr; c.rec_bytes = 0;
+      const size_t want = total + (total >> 3) + 4096;
+      LLD_HIP_TRY(hipHostMalloc(&c.rec, want, hipHostMallocDefault));
+      c.rec_bytes = want;
+    }
+    B->h_records = static_cast<unsigned char*>(c.rec);
+  } else { B->h_records_pageable.resize(total); B->h_records = B->h_records_pageable.data(); }
+  LLD_HIP_TRY(hipMemcpyAsync(B->h_records, B->A.records, total, hipMemcpyDeviceToHost, B->ctx->stream));
   LLD_HIP_TRY(hipStreamSynchronize(B->ctx->stream));
   B->records_valid = true;
   return LLD_OK;
@@ -818,7 +902,7 @@ static int ba_fetch_records(lld_ba_batch* B) {
 
 static void fill_stats(const lld_ba_batch* B, int wi, lld_ba_stats* s) {
   const BAWin& W = B->h_wins[wi];
-  const unsigned char* rec = B->h_records.data() + W.rec_off;
+  const unsigned char* rec = B->h_records + W.rec_off;
   const BARecordHeader* h = reinterpret_cast<const BARecordHeader*>(rec);
   std::memset(s, 0, sizeof *s);
   s->chi2_round1 = h->chi2_round1; s->chi2_final = h->chi2_final;
@@ -831,12 +915,35 @@ static void fill_stats(const lld_ba_batch* B, int wi, lld_ba_stats* s) {
   for (int i = 0; i < W.n_ln; i++) s->n_lines_removed += flags[W.n_pe + W.n_le + i];
 }
 
+static void ba_unpack_record(const lld_ba_batch* B, int wi, lld_ba_result* out);
+
 int lld_ba_batch_download(lld_ba_batch* B, int wi, lld_ba_result* out) {
   if (!B || !out || wi < 0 || wi >= B->n_windows) return LLD_ERR_INVALID;
   LLD_HIP_TRY(hipSetDevice(B->ctx->device));
   int st = ba_fetch_records(B); if (st) return st;
+  ba_unpack_record(B, wi, out);
+  return LLD_OK;
+}
+
+int lld_ba_batch_download_range(lld_ba_batch* B, int first, int count, lld_ba_result* out) {
+  if (!B || !out || first < 0 || count < 0 || first + count > B->n_windows) return LLD_ERR_INVALID;
+  LLD_HIP_TRY(hipSetDevice(B->ctx->device));
+  int st = ba_fetch_records(B); if (st) return st;
+  int n_threads = count >= 8 ? (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u) : 1;
+  if (const char* e = std::getenv("LLD_HOST_THREADS")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) n_threads = std::min(n_threads, v); }
+  n_threads = std::max(1, std::min(n_threads, count / 4));
+  std::atomic<int> next{0};
+  auto worker = [&]() { for (;;) { const int i = next.fetch_add(1); if (i >= count) break; ba_unpack_record(B, first + i, out + i); } };
+  std::vector<std::thread> pool;
+  try { for (int t = 1; t < n_threads; t++) pool.emplace_back(worker); } catch (...) {}
+  worker();
+  for (auto& t : pool) t.join();
+  return LLD_OK;
+}
+
+static void ba_unpack_record(const lld_ba_batch* B, int wi, lld_ba_result* out) {
   const BAWin& W = B->h_wins[wi];
-  const unsigned char* rec = B->h_records.data() + W.rec_off;
+  const unsigned char* rec = B->h_records + W.rec_off;
   const double* d = reinterpret_cast<const double*>(rec + sizeof(BARecordHeader));
   if (out->cam_qt) std::memcpy(out->cam_qt, d, sizeof(double) * 7 * W.n_cams);
   d += 7 * (size_t)W.n_cams;
@@ -851,7 +958,6 @@ int lld_ba_batch_download(lld_ba_batch* B, int wi, lld_ba_result* out) {
   if (out->ln_edge_outlier && W.n_le) std::memcpy(out->ln_edge_outlier, f + W.n_pe, W.n_le);
   if (out->line_removed && W.n_ln) std::memcpy(out->line_removed, f + W.n_pe + W.n_le, W.n_ln);
   fill_stats(B, wi, &out->stats);
-  return LLD_OK;
 }
 
 int lld_ba_batch_stats(lld_ba_batch* B, lld_ba_stats* stats) {
@@ -892,7 +998,8 @@ void lld_ba_batch_destroy(lld_ba_batch* B) {
   (void)hipSetDevice(B->ctx->device);
   (void)hipStreamSynchronize(B->ctx->stream);
   ba_drop_groups(B);
-  if (!B->borrowed) {
+  if (B->borrowed) B->ctx->ba.busy = false;          // slab, arenas, streams, events and poll block stay with the context for the next batch
+  else {
     if (B->h_counters) (void)hipHostFree(B->h_counters);
     if (B->slab) (void)hipFree(B->slab);
   }
@@ -906,7 +1013,7 @@ int lld_local_ba(lld_ctx* ctx, const lld_ba_window* in, const lld_ba_params* par
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
   const auto t0 = now();
-  int st = ba_batch_create_impl(ctx, 1, in, params, &B, true); if (st) return st;
+  int st = ba_batch_create_impl(ctx, 1, in, params, &B); if (st) return st;
   const auto t1 = now();
   st = lld_ba_batch_solve(B, abort_flag);
   const auto t2 = now();

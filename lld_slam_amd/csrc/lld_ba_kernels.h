@@ -2314,7 +2314,8 @@ __global__ __launch_bounds__(kCholMThreads) void ba_chol_mfma_kernel(BAArrays A,
 // (optimization_algorithm_levenberg.cpp:118-163) and advances the window's state machine; all lanes then clear the
 // camera accumulators when a new linearisation is due.
 __global__ __launch_bounds__(kCtlThreads) void ba_control_kernel(BAArrays A, const BAWin* __restrict__ wins, BAState* __restrict__ st, int abort_flag,
-                                                                 int* __restrict__ counters /* [3]: running, transition, finalize */) {
+                                                                 int* __restrict__ counters /* [4]: running, transition, finalize, ticket (all zero on entry) */,
+                                                                 int* __restrict__ host_counters /* pinned host memory: the group's totals */) {
   __shared__ int do_clear;
   const BAWin& W = wins[blockIdx.x];
   BAState& S = st[blockIdx.x];
@@ -2376,6 +2377,21 @@ __global__ __launch_bounds__(kCtlThreads) void ba_control_kernel(BAArrays A, con
     if (ph == PH_RUN) atomicAdd(&counters[0], 1);
     else if (ph == PH_TRANSITION) atomicAdd(&counters[1], 1);
     else if (ph == PH_FINALIZE) atomicAdd(&counters[2], 1);
+    // The last window's block publishes the totals straight into pinned host memory and leaves the device counters at zero for the
+    // next super-step: no 16-byte device-to-host copy (a blit kernel of its own, 30 - 40 us on the dependent chain of every
+    // super-step, 110 us while another context's upload holds the link) and no memset.  The host reads after the event that
+    // follows this kernel.
+    __threadfence();
+    if (atomicAdd(&counters[3], 1) == (int)gridDim.x - 1) {
+      __threadfence();
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        const int v = atomicExch(&counters[i], 0);
+        __hip_atomic_store(&host_counters[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      counters[3] = 0;
+      __threadfence_system();
+    }
   }
 }
 

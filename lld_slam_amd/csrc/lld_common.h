@@ -36,6 +36,20 @@ struct lld_ctx {
   void* poll = nullptr;
   // kernel attributes are per device: remembered per context, not in a process-wide static (a process may hold contexts on several GPUs)
   bool orb_lds_raised = false;
+  // Resources of the batched local BA that outlive a batch.  A pipelined caller creates one batch after another on the same
+  // context (one context per host thread): allocating a multi-gigabyte slab per batch and, worse, freeing it (hipFree synchronises
+  // the device, stalling every other context's solve) was most of the host-buffer rate, and so were pageable uploads.  At most one
+  // live batch per context owns the cached set (a second concurrent batch on the same context allocates its own).
+  struct BACache {
+    bool busy = false;                       // a live batch holds slab / streams / events / poll block
+    void* slab = nullptr; size_t slab_bytes = 0;
+    void* stage[2] = {nullptr, nullptr}; size_t stage_bytes[2] = {0, 0};   // pinned upload arenas: [0] flattened inputs, [1] Schur / task structures
+    hipEvent_t stage_free = nullptr; bool stage_pending = false;            // the arenas may be rewritten once this event has completed
+    void* rec = nullptr; size_t rec_bytes = 0;                              // pinned landing buffer of the result records
+    hipStream_t streams[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // group streams 1..7 (group 0 runs on ctx->stream)
+    hipEvent_t events[8][6] = {};
+    bool attrs_set = false;                  // hipFuncSetAttribute(max dynamic LDS) done for this device
+  } ba;
 };
 
 // Grow-only pinned host staging on the context.

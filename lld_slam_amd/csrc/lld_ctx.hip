@@ -39,6 +39,12 @@ void lld_ctx_destroy(lld_ctx* ctx) {
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   if (ctx->poll) (void)hipHostFree(ctx->poll);
+  if (ctx->ba.stage_free) { (void)hipEventSynchronize(ctx->ba.stage_free); (void)hipEventDestroy(ctx->ba.stage_free); }
+  if (ctx->ba.slab) (void)hipFree(ctx->ba.slab);
+  for (void* p : ctx->ba.stage) if (p) (void)hipHostFree(p);
+  if (ctx->ba.rec) (void)hipHostFree(ctx->ba.rec);
+  for (hipStream_t s : ctx->ba.streams) if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
+  for (auto& row : ctx->ba.events) for (hipEvent_t e : row) if (e) (void)hipEventDestroy(e);
   delete ctx;
 }
 

@@ -580,6 +580,15 @@ class BABatch:
         out.stats = stats_dict(cr.stats)
         return out
 
+    def download_all(self) -> list[BAOutput]:
+        """Every window's result through one lld_ba_batch_download_range call (unpacked by several host threads)."""
+        outs = [BAOutput.alloc(w) for w in self.windows]
+        arr = (BAResult * len(outs))(*[o.to_c() for o in outs])
+        check(self.lib.fn("ba_batch_download_range")(self.handle, 0, len(outs), arr), "ba_batch_download_range")
+        for o, r in zip(outs, arr):
+            o.stats = stats_dict(r.stats)
+        return outs
+
     def stats(self) -> list[dict]:
         arr = (BAStats * len(self.windows))()
         check(self.lib.fn("ba_batch_stats")(self.handle, arr), "ba_batch_stats")

@@ -1,12 +1,15 @@
 """N>1 path on CPU: window sharding and the final gather of fixed-stride result records, world_size 2 over gloo.
 
-The GPU bench shards `--windows-per-gpu` windows to every rank and gathers each rank's record buffer on rank 0
-(bench.py); here the same plumbing runs with host tensors, the records being produced by the CPU oracle instead of the
-HIP library (there is no GPU in this container)."""
+The workers import `lld_slam_amd.dist` - the module bench.py runs (shard, record layout, the staged asynchronous gather, the MAX over
+ranks of the elapsed time) - and drive it with host tensors; the records are packed from CPU-oracle results in the library's record
+layout (there is no GPU in this container).  tests/test_gpu_ba.py checks the same layout against the HIP library's buffer."""
 import os
 import subprocess
 import sys
 import textwrap
+
+import numpy as np
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -15,37 +18,79 @@ WORKER = textwrap.dedent('''
     sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "oracle"))
     import numpy as np, torch, torch.distributed as dist
     import oracle_py as O
-    from lld_slam_amd import synth
+    from lld_slam_amd import synth, dist as D
+    strong = %(strong)r; n = %(n)d
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
-    wpg = 3                                            # windows per rank (weak scaling: every rank gets wpg windows)
-    ids = [rank * wpg + i for i in range(wpg)]
-    wins = [synth.make_lba_small(i, n_free=3, n_fixed=1, n_points=40, n_lines=6) for i in ids]
-    res = [O.local_ba(w) for w in wins]
-    stride = 7 * 4 + 1                                 # fixed-stride record: 4 camera poses + chi2
-    rec = torch.zeros(wpg * stride, dtype=torch.float64)
-    for k, r in enumerate(res):
-        rec[k * stride:k * stride + 28] = torch.from_numpy(r.cam_qt.reshape(-1)); rec[k * stride + 28] = r.stats["chi2_final"]
-    gathered = [torch.zeros_like(rec) for _ in range(world)] if rank == 0 else None
-    dist.gather(rec, gathered, dst=0)
-    t = torch.tensor([0.5 + rank], dtype=torch.float64)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)           # the bench takes the MAX elapsed time over ranks
-    assert float(t) == 0.5 + (world - 1)
+    first, count = D.shard(n, world, rank, strong)
+    make = lambda i: synth.make_lba_small(i, n_free=3, n_fixed=1 + i %% 2, n_points=40 + 7 * i, n_lines=6 + i)      # ragged: the stride is the largest record
+    total = n if strong else n * world
+    everyone = [make(i) for i in range(total)]
+    stride = D.record_stride(everyone)                  # (a batch's stride comes from ITS windows; ranks agree on the common size below)
+    mine = everyone[first:first + count]
+    res = [O.local_ba(w) for w in mine]
+    records = torch.from_numpy(np.concatenate([D.pack_record(r, w, stride) for r, w in zip(res, mine)])) if count else torch.zeros(0, dtype=torch.uint8)
+    counts = D.gather_counts(count, torch.device("cpu"), True, world)
+    assert sum(counts) == total and counts[rank] == count
+    g = D.RecordGather(records, world, rank, n_bytes=max(counts) * stride)
+    for step in range(2):                               # two steps: the second waits for the first gather in flight, as in bench.py
+        g.step()
+    g.drain()
+    D.barrier(True, False)
+    assert D.max_over_ranks(0.5 + rank, torch.device("cpu"), True) == 0.5 + (world - 1)
     if rank == 0:
-        allrec = torch.cat(gathered).numpy().reshape(world * wpg, stride)
-        for wid in range(world * wpg):                 # every window of every rank arrived, in window-id order
-            ref = O.local_ba(synth.make_lba_small(wid, n_free=3, n_fixed=1, n_points=40, n_lines=6))
-            assert np.array_equal(allrec[wid, :28], ref.cam_qt.reshape(-1)) and allrec[wid, 28] == ref.stats["chi2_final"]
-        print("GATHER_OK", world * wpg)
+        wid = 0
+        for r in range(world):
+            buf = g.rank_records(r)
+            for k in range(counts[r]):
+                w = everyone[wid]
+                out = D.unpack_record(buf[k * stride:(k + 1) * stride], w)
+                ref = O.local_ba(w)
+                assert np.array_equal(out.cam_qt, ref.cam_qt) and np.array_equal(out.pt_xyz, ref.pt_xyz) and np.array_equal(out.line_x0, ref.line_x0)
+                assert np.array_equal(out.pt_obs_outlier, ref.pt_obs_outlier) and np.array_equal(out.ln_edge_outlier, ref.ln_edge_outlier)
+                assert np.array_equal(out.line_removed, ref.line_removed)
+                for key in ("chi2_final", "chi2_round1", "lm_iterations", "lm_trials", "aborted", "n_pt_obs_outlier", "n_lines_removed"):
+                    assert out.stats[key] == ref.stats[key], key
+                wid += 1
+        assert wid == total
+        print("GATHER_OK", total, counts)
     dist.destroy_process_group()
 ''')
 
 
-def test_two_rank_shard_and_gather(tmp_path):
+@pytest.mark.parametrize("strong,n,port,expect", [(False, 3, 29533, "GATHER_OK 6 [3, 3]"), (True, 5, 29534, "GATHER_OK 5 [2, 3]")])
+def test_two_rank_shard_and_gather(tmp_path, strong, n, port, expect):
+    """weak: 3 windows on each of 2 ranks; strong: 5 windows split 2 + 3 (uneven shards pad to the common gather size)."""
     script = tmp_path / "worker.py"
-    script.write_text(WORKER % {"root": ROOT})
+    script.write_text(WORKER % {"root": ROOT, "strong": strong, "n": n})
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-                          "--master-port", "29533", str(script)], capture_output=True, text=True, timeout=300, env=env)
+                          "--master-port", str(port), str(script)], capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
-    assert "GATHER_OK 6" in out.stdout
+    assert expect in out.stdout
+
+
+def test_shard_and_thread_budget():
+    from lld_slam_amd import dist as D
+    assert [D.shard(256, 8, r, False) for r in (0, 7)] == [(0, 256), (1792, 256)]
+    blocks = [D.shard(256, 8, r, True) for r in range(8)]
+    assert blocks == [(32 * r, 32) for r in range(8)]
+    odd = [D.shard(10, 4, r, True) for r in range(4)]
+    assert sum(c for _, c in odd) == 10 and [f for f, _ in odd] == [0, 2, 5, 7] and all(odd[i][0] + odd[i][1] == odd[i + 1][0] for i in range(3))
+    with pytest.raises(ValueError):
+        D.shard(4, 2, 2, True)
+    cores = os.cpu_count() or 1
+    assert D.host_thread_budget(1) == max(1, min(16, cores - 1)) and D.host_thread_budget(10 ** 6) == 1
+    assert D.host_thread_budget(8) * 8 <= max(8, cores)
+
+
+def test_record_pack_unpack_round_trip(oracle):
+    from lld_slam_amd import synth, dist as D
+    w = synth.make_lba_small(3)
+    r = oracle.local_ba(w)
+    stride = D.record_stride([w, synth.make_lba_small(4, n_points=500)])
+    assert stride % 256 == 0 and stride >= D.record_bytes(w)
+    back = D.unpack_record(D.pack_record(r, w, stride), w)
+    for a, b in ((back.cam_qt, r.cam_qt), (back.pt_xyz, r.pt_xyz), (back.line_dir, r.line_dir), (back.ln_edge_outlier, r.ln_edge_outlier), (back.line_removed, r.line_removed)):
+        np.testing.assert_array_equal(a, b)
+    assert back.stats["chi2_final"] == r.stats["chi2_final"] and back.stats["lm_trials"] == r.stats["lm_trials"]

@@ -462,3 +462,31 @@ def test_nearly_singular_landmark_blocks(gpu_ctx, oracle, seed):
     floor = landmark_rel(o1.pt_xyz, o.pt_xyz)
     assert floor.max() > 1e-5                                   # the window does exercise the allowance
     check_ba(Optimizer(gpu_ctx).LocalBundleAdjustment(w), o, w, pt_floor=floor)
+
+
+def test_record_layout_of_dist_py_is_the_library_s(gpu_ctx):
+    """lld_slam_amd/dist.py (what bench.py and the gloo test use for the RCCL gather) restates the fixed-stride record layout: its stride
+    equals lld_ba_batch_result_records', and unpacking the device buffer gives exactly what lld_ba_batch_download fills."""
+    import ctypes
+    from lld_slam_amd import dist as D
+    ws = [synth.make_lba_small(20 + i, n_free=3 + i, n_fixed=1 + i % 3, n_points=100 + 90 * i, n_lines=15 * i) for i in range(5)]
+    with BABatch(gpu_ctx, ws) as b:
+        b.solve()
+        ptr, stride = b.result_records()
+        assert stride == D.record_stride(ws)
+        outs = b.download_all()
+        for i, w in enumerate(ws):
+            one = b.download(i)
+            for f in ("cam_qt", "pt_xyz", "line_x0", "line_dir", "pt_obs_outlier", "ln_edge_outlier", "line_removed"):
+                np.testing.assert_array_equal(getattr(outs[i], f), getattr(one, f))
+            assert outs[i].stats == one.stats
+        import torch
+        class _Dev:
+            __cuda_array_interface__ = {"shape": (stride * len(ws),), "typestr": "|u1", "data": (ptr, False), "version": 2}
+        host_bytes = torch.as_tensor(_Dev(), device="cuda:0").cpu().numpy()
+        for i, w in enumerate(ws):
+            u = D.unpack_record(host_bytes[i * stride:(i + 1) * stride], w)
+            for f in ("cam_qt", "pt_xyz", "line_x0", "line_dir", "pt_obs_outlier", "ln_edge_outlier", "line_removed"):
+                np.testing.assert_array_equal(getattr(u, f), getattr(outs[i], f))
+            for k in ("chi2_final", "chi2_round1", "lm_iterations", "lm_trials", "aborted", "n_pt_obs_outlier", "n_ln_edge_outlier", "n_lines_removed"):
+                assert u.stats[k] == outs[i].stats[k], k
