@@ -255,7 +255,7 @@ def generate_windows(first_id: int, count: int, workers: int = 0, maker=make_lba
     the caller may already have touched the GPU."""
     import os
     if workers <= 0:
-        workers = max(1, min(16, os.cpu_count() or 1))
+        workers = int(os.environ.get("LLD_GEN_WORKERS", "0")) or max(1, min(16, os.cpu_count() or 1))     # LLD_GEN_WORKERS=1 under rocprofv3: no child processes
     if workers <= 1 or count < 4:
         return [maker(first_id + i) for i in range(count)]
     import multiprocessing as mp

@@ -8,7 +8,7 @@ import json, re, sys
 
 FAMILIES = {"ba_linearize": ("ba_linearize_", "ba_hpp_reduce", "ba_begin"),
             "ba_schur": ("ba_schur_items", "ba_schur_reduce", "ba_symmetrize"),
-            "ba_pcg": ("ba_chol_mfma", "ba_chol_kernel", "ba_pcg"),
+            "ba_solve": ("ba_chol_mfma", "ba_chol_kernel", "ba_pcg"),
             "ba_backsub": ("ba_backsub_",),
             "ba_control": ("ba_control",)}
 
