@@ -1,0 +1,296 @@
+// adapter_harness.cpp — builds a live object graph (KeyFrame / MapPoint / MapLine / Frame, adapters/lld_slam_objects.h) from a flat
+// problem file, runs the COMPILED host adapters (adapters/lld_optimizer_adapter.cc) on it the way LocalMapping::Run / Tracking would,
+// and dumps (1) the flat problem the adapter gathered, (2) what the library returned, (3) the state of the objects after the
+// write-back, with the bookkeeping the test needs to map gathered indices to the input's (tests/test_cpp_adapter.py).
+//
+//   adapter_harness ba   <in> <out> [seed]    Optimizer::LocalBundleAdjustment(pKF, &mbAbortBA, pMap, gamma)
+//   adapter_harness pose <in> <out> [seed]    Optimizer::PoseOptimization(&mCurrentFrame, gamma)
+//
+// The object graph is deliberately awkward: keyframes are allocated in shuffled order (std::map<KeyFrame*, ...> iterates by ADDRESS),
+// their mnIds are a permutation of the input's camera order, one covisible keyframe has mnId 0 (fixed although local), and there are
+// objects the reference skips (a bad MapPoint, a MapLine with two observations, a bad observing KeyFrame, keypoints / lines without
+// a landmark).  Input files are the ones examples/harness.cpp reads (`ba` / `pose` modes).
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <random>
+#include <string>
+
+#include "../adapters/lld_optimizer_adapter.h"
+
+std::mutex lld_slam::MapPoint::mGlobalMutex;        // the doubles' static member (the real class defines its own, MapPoint.cc:30)
+
+using namespace lld_slam;
+
+namespace {
+
+struct Reader {
+  FILE* f;
+  explicit Reader(const char* path) : f(std::fopen(path, "rb")) { if (!f) throw std::runtime_error(std::string("cannot open ") + path); }
+  ~Reader() { std::fclose(f); }
+  template <class T> void get(T* p, size_t n) { if (n && std::fread(p, sizeof(T), n, f) != n) throw std::runtime_error("short read"); }
+  template <class T> void get(std::vector<T>& v, size_t n) { v.resize(n); get(v.data(), n); }
+};
+struct Writer {
+  FILE* f;
+  explicit Writer(const char* path) : f(std::fopen(path, "wb")) { if (!f) throw std::runtime_error(std::string("cannot open ") + path); }
+  ~Writer() { std::fclose(f); }
+  template <class T> void put(const T* p, size_t n) { if (n && std::fwrite(p, sizeof(T), n, f) != n) throw std::runtime_error("short write"); }
+  template <class T> void put(const std::vector<T>& v) { put(v.data(), v.size()); }
+};
+
+std::vector<float> level_table() { std::vector<float> t(8); lld_orb_inv_level_sigma2(1.2f, 8, t.data()); return t; }
+int octave_of(const std::vector<float>& table, double inv_sigma2) {
+  int best = 0; double d = 1e300;
+  for (int o = 0; o < (int)table.size(); o++) { const double e = std::abs((double)table[o] - inv_sigma2); if (e < d) { d = e; best = o; } }
+  return best;
+}
+Mat pose_mat(const double* qt7) { float T[16]; lld_se3_to_tcw_f32(qt7, T); return Mat(4, 4, T); }
+Mat k_mat(float fx, float fy, float cx, float cy) { Mat K(3, 3); K.at<float>(0, 0) = fx; K.at<float>(1, 1) = fy; K.at<float>(0, 2) = cx; K.at<float>(1, 2) = cy; K.at<float>(2, 2) = 1.f; return K; }
+KeyLine key_line(const double* seg, int octave) { KeyLine k; k.startPointX = (float)seg[0]; k.startPointY = (float)seg[1]; k.endPointX = (float)seg[2]; k.endPointY = (float)seg[3]; k.octave = octave; return k; }
+
+int run_ba(const char* in, const char* out, unsigned seed) {
+  Reader r(in);
+  int32_t h[8]; r.get(h, 8);                   // n_cams n_free n_points n_pt_obs n_lines n_ln_obs stop 0
+  double camg[6]; r.get(camg, 6);              // fx fy cx cy bf gamma
+  lld_amd::BAWindow w;
+  w.n_free_cams = h[1];
+  r.get(w.cam_qt, 7 * (size_t)h[0]);
+  r.get(w.pt_xyz, 3 * (size_t)h[2]); r.get(w.pt_obs_start, (size_t)h[2] + 1); r.get(w.pt_obs_cam, h[3]);
+  r.get(w.pt_obs_uvr, 3 * (size_t)h[3]); r.get(w.pt_obs_inv_sigma2, h[3]);
+  r.get(w.line_x0, 3 * (size_t)h[4]); r.get(w.line_dir, 3 * (size_t)h[4]); r.get(w.ln_obs_start, (size_t)h[4] + 1);
+  r.get(w.ln_obs_cam, h[5]); r.get(w.ln_obs_left, 4 * (size_t)h[5]); r.get(w.ln_obs_right, 4 * (size_t)h[5]);
+  r.get(w.ln_obs_octave, 2 * (size_t)h[5]);
+  const int n_cams = h[0], n_free = h[1], n_pts = h[2], n_lns = h[4];
+  if (n_free < 1) throw std::runtime_error("adapter-ba needs a free camera (pKF)");
+  std::mt19937 rng(seed);
+  const std::vector<float> table = level_table();
+
+  // ---- keyframes: allocated in shuffled order, mnIds a permutation of the input order; the first fixed camera becomes mnId 0 and local
+  std::vector<int> alloc_order(n_cams + 1);
+  for (int i = 0; i <= n_cams; i++) alloc_order[i] = i;
+  std::shuffle(alloc_order.begin(), alloc_order.end(), rng);
+  std::vector<std::unique_ptr<KeyFrame> > kf_store(n_cams + 1);
+  for (int i : alloc_order) kf_store[i].reset(new KeyFrame());
+  std::vector<KeyFrame*> kf(n_cams);
+  for (int c = 0; c < n_cams; c++) kf[c] = kf_store[c].get();
+  KeyFrame* bad_kf = kf_store[n_cams].get();                                   // an observer the reference skips
+  std::vector<int> perm(n_free);
+  for (int i = 0; i < n_free; i++) perm[i] = i;
+  std::shuffle(perm.begin(), perm.end(), rng);
+  std::map<const KeyFrame*, int> kf_orig;
+  for (int c = 0; c < n_cams; c++) {
+    KeyFrame& K = *kf[c];
+    K.mnId = c < n_free ? (unsigned long)(5 + 2 * perm[c]) : (c == n_free ? 0ul : (unsigned long)(1000 + c));
+    K.fx = (float)camg[0]; K.fy = (float)camg[1]; K.cx = (float)camg[2]; K.cy = (float)camg[3]; K.mbf = (float)camg[4];
+    K.mK = k_mat(K.fx, K.fy, K.cx, K.cy);
+    K.mvInvLevelSigma2 = table;
+    K.Tcw = pose_mat(&w.cam_qt[7 * (size_t)c]);
+    kf_orig[&K] = c;
+  }
+  bad_kf->mnId = 777; bad_kf->mbBad = true; bad_kf->mvInvLevelSigma2 = table; bad_kf->Tcw = pose_mat(&w.cam_qt[0]);
+  bad_kf->fx = (float)camg[0]; bad_kf->mK = k_mat((float)camg[0], (float)camg[1], (float)camg[2], (float)camg[3]);
+  // pKF = the free camera with the largest mnId; every other free camera and the mnId-0 one are covisible (in shuffled order)
+  KeyFrame* pKF = kf[0];
+  for (int c = 1; c < n_free; c++) if (kf[c]->mnId > pKF->mnId) pKF = kf[c];
+  for (int c = 0; c < n_cams; c++) if (kf[c] != pKF && (c < n_free || c == n_free)) pKF->mvpOrderedConnectedKeyFrames.push_back(kf[c]);
+  std::shuffle(pKF->mvpOrderedConnectedKeyFrames.begin(), pKF->mvpOrderedConnectedKeyFrames.end(), rng);
+  pKF->mvpOrderedConnectedKeyFrames.push_back(bad_kf);                         // a bad covisible keyframe: marked local, never a camera
+
+  // ---- map points and their observations
+  std::vector<std::unique_ptr<MapPoint> > mp_store(n_pts + 1);
+  std::map<const MapPoint*, int> mp_orig;
+  std::map<std::pair<const KeyFrame*, const MapPoint*>, int> ptobs_orig;
+  for (int p = 0; p < n_pts; p++) {
+    mp_store[p].reset(new MapPoint());
+    MapPoint& M = *mp_store[p];
+    M.mnId = (unsigned long)(3 * p + 1);
+    M.mWorldPos = Mat(3, 1);
+    for (int k = 0; k < 3; k++) M.mWorldPos.at<float>(k) = (float)w.pt_xyz[3 * (size_t)p + k];
+    mp_orig[&M] = p;
+    for (int o = w.pt_obs_start[p]; o < w.pt_obs_start[p + 1]; o++) {
+      KeyFrame& K = *kf[w.pt_obs_cam[o]];
+      KeyPoint kp; kp.pt.x = (float)w.pt_obs_uvr[3 * (size_t)o]; kp.pt.y = (float)w.pt_obs_uvr[3 * (size_t)o + 1]; kp.octave = octave_of(table, w.pt_obs_inv_sigma2[o]);
+      if (K.mvKeysUn.size() % 5 == 2) { K.mvKeysUn.push_back(kp); K.mvuRight.push_back(-1.f); K.mvpMapPoints.push_back(nullptr); }   // a keypoint without a MapPoint in between
+      M.mObservations[&K] = K.mvKeysUn.size();
+      K.mvKeysUn.push_back(kp); K.mvuRight.push_back((float)w.pt_obs_uvr[3 * (size_t)o + 2]); K.mvpMapPoints.push_back(&M);
+      ptobs_orig[std::make_pair((const KeyFrame*)&K, (const MapPoint*)&M)] = o;
+    }
+    if (p % 7 == 3) {                                                           // the bad keyframe also observes this point: skipped by the reference
+      KeyPoint kp; kp.pt.x = 10.f; kp.pt.y = 10.f; kp.octave = 0;
+      M.mObservations[bad_kf] = bad_kf->mvKeysUn.size();
+      bad_kf->mvKeysUn.push_back(kp); bad_kf->mvuRight.push_back(5.f); bad_kf->mvpMapPoints.push_back(&M);
+    }
+  }
+  mp_store[n_pts].reset(new MapPoint());                                         // a bad MapPoint among pKF's matches: never enters the window
+  MapPoint& bad_mp = *mp_store[n_pts];
+  bad_mp.mnId = 999999; bad_mp.mbBad = true; bad_mp.mWorldPos = Mat(3, 1);
+  { KeyPoint kp; kp.pt.x = 1.f; kp.pt.y = 2.f; kp.octave = 0; bad_mp.mObservations[pKF] = pKF->mvKeysUn.size(); pKF->mvKeysUn.push_back(kp); pKF->mvuRight.push_back(1.f); pKF->mvpMapPoints.push_back(&bad_mp); }
+
+  // ---- map lines
+  std::vector<std::unique_ptr<MapLine> > ml_store(n_lns + 1);
+  std::map<const MapLine*, int> ml_orig;
+  std::map<std::pair<const KeyFrame*, const MapLine*>, int> lnobs_orig;
+  for (int l = 0; l < n_lns; l++) {
+    ml_store[l].reset(new MapLine());
+    MapLine& L = *ml_store[l];
+    L.mnId = (unsigned long)(2 * l + 7);
+    L.mX0 = Vector3d(w.line_x0[3 * (size_t)l], w.line_x0[3 * (size_t)l + 1], w.line_x0[3 * (size_t)l + 2]);
+    L.mDir = Vector3d(w.line_dir[3 * (size_t)l], w.line_dir[3 * (size_t)l + 1], w.line_dir[3 * (size_t)l + 2]);
+    ml_orig[&L] = l;
+    for (int o = w.ln_obs_start[l]; o < w.ln_obs_start[l + 1]; o++) {
+      KeyFrame& K = *kf[w.ln_obs_cam[o]];
+      const bool has_right = !(w.ln_obs_right[4 * (size_t)o] < 0);
+      L.mObservations[&K] = K.mvLinesLeft.size();
+      K.mvLinesLeft.push_back(key_line(&w.ln_obs_left[4 * (size_t)o], w.ln_obs_octave[2 * (size_t)o]));
+      if (has_right) { K.line_matches.push_back((int)K.mvLinesRight.size()); K.mvLinesRight.push_back(key_line(&w.ln_obs_right[4 * (size_t)o], w.ln_obs_octave[2 * (size_t)o + 1])); }
+      else K.line_matches.push_back(-1);
+      K.mvpMapLines.push_back(&L);
+      lnobs_orig[std::make_pair((const KeyFrame*)&K, (const MapLine*)&L)] = o;
+    }
+  }
+  ml_store[n_lns].reset(new MapLine());                                          // a MapLine with two observations: below the `Observations() < 4` bar (:972)
+  MapLine& short_ml = *ml_store[n_lns];
+  short_ml.mnId = 888888; short_ml.mX0 = Vector3d(1, 2, 3); short_ml.mDir = Vector3d(1, 0, 0);
+  for (int c = 0; c < std::min(2, n_free); c++) {
+    KeyFrame& K = *kf[c];
+    short_ml.mObservations[&K] = K.mvLinesLeft.size();
+    const double seg[4] = {10, 10, 50, 50};
+    K.mvLinesLeft.push_back(key_line(seg, 0)); K.line_matches.push_back(-1); K.mvpMapLines.push_back(&short_ml);
+  }
+
+  // ---- the call, as LocalMapping::Run makes it (LocalMapping.cc:76-82)
+  Map map;
+  bool mbAbortBA = h[6] != 0;
+  lld_amd::Context ctx(0);
+  lld_adapter::LbaTrace tr;
+  lld_adapter::LocalBundleAdjustment(ctx.get(), pKF, &mbAbortBA, &map, camg[5], &tr);
+
+  // ---- dump: gathered window (same layout as the input), raw output, object state
+  const lld_amd::BAWindow& g = tr.window;
+  const lld_amd::BAOutput& o = tr.output;
+  Writer wr(out);
+  const int32_t gh[8] = {g.n_cams(), g.n_free_cams, g.n_points(), (int32_t)g.pt_obs_cam.size(), g.n_lines(), (int32_t)g.ln_obs_cam.size(), tr.returned_before_optimising ? 1 : 0,
+                         (int32_t)pKF->mnId};
+  wr.put(gh, 8);
+  const double gcam[6] = {g.cam.fx, g.cam.fy, g.cam.cx, g.cam.cy, g.cam.bf, camg[5]};
+  wr.put(gcam, 6);
+  wr.put(g.cam_qt); wr.put(g.pt_xyz); wr.put(g.pt_obs_start); wr.put(g.pt_obs_cam); wr.put(g.pt_obs_uvr); wr.put(g.pt_obs_inv_sigma2);
+  wr.put(g.line_x0); wr.put(g.line_dir); wr.put(g.ln_obs_start); wr.put(g.ln_obs_cam); wr.put(g.ln_obs_left); wr.put(g.ln_obs_right); wr.put(g.ln_obs_octave);
+  wr.put(o.cam_qt); wr.put(o.pt_xyz); wr.put(o.line_x0); wr.put(o.line_dir); wr.put(o.pt_obs_outlier); wr.put(o.ln_edge_outlier); wr.put(o.line_removed);
+  const double chi2[2] = {o.stats.chi2_round1, o.stats.chi2_final};
+  wr.put(chi2, 2);
+  const int32_t st[4] = {o.stats.lm_iterations[0], o.stats.lm_iterations[1], o.stats.aborted, o.stats.n_lines_removed};
+  wr.put(st, 4);
+  // cameras
+  for (KeyFrame* K : tr.cams) { const int32_t v[3] = {kf_orig.count(K) ? kf_orig[K] : -1, (int32_t)K->mnId, K->n_set_pose}; wr.put(v, 3); wr.put(K->Tcw.ptr<float>(), 16); }
+  // points
+  for (MapPoint* M : tr.points) { const int32_t v[3] = {mp_orig.count(M) ? mp_orig[M] : -1, M->n_set_pos, M->n_update_normal}; wr.put(v, 3); wr.put(M->mWorldPos.ptr<float>(), 3); }
+  for (size_t k = 0; k < tr.pt_obs_owner.size(); k++) {
+    KeyFrame* K = tr.pt_obs_owner[k].first; MapPoint* M = tr.pt_obs_owner[k].second;
+    const auto it = ptobs_orig.find(std::make_pair((const KeyFrame*)K, (const MapPoint*)M));
+    bool in_kf = false; for (MapPoint* q : K->mvpMapPoints) in_kf = in_kf || q == M;
+    const int32_t v[3] = {it == ptobs_orig.end() ? -1 : it->second, M->mObservations.count(K) ? 1 : 0, in_kf ? 1 : 0};
+    wr.put(v, 3);
+  }
+  // lines
+  for (MapLine* L : tr.lines) { const int32_t v[2] = {ml_orig.count(L) ? ml_orig[L] : -1, L->n_set_pos}; wr.put(v, 2); wr.put(L->mX0.v, 3); wr.put(L->mDir.v, 3); }
+  for (size_t k = 0; k < tr.ln_obs_owner.size(); k++) {
+    KeyFrame* K = tr.ln_obs_owner[k].first; MapLine* L = tr.ln_obs_owner[k].second;
+    const auto it = lnobs_orig.find(std::make_pair((const KeyFrame*)K, (const MapLine*)L));
+    bool in_kf = false; for (MapLine* q : K->mvpMapLines) in_kf = in_kf || q == L;
+    const int32_t v[3] = {it == lnobs_orig.end() ? -1 : it->second, L->mObservations.count(K) ? 1 : 0, in_kf ? 1 : 0};
+    wr.put(v, 3);
+  }
+  // the objects the reference skips must be untouched; std::map<KeyFrame*> order must really differ from the mnId order for the test to mean something
+  int addr_inversions = 0;
+  for (size_t i = 1; i < tr.cams.size(); i++) if ((tr.cams[i] < tr.cams[i - 1]) != (tr.cams[i]->mnId < tr.cams[i - 1]->mnId)) addr_inversions++;
+  const int32_t extra[8] = {bad_mp.n_set_pos + bad_mp.n_update_normal, short_ml.n_set_pos, bad_kf->n_set_pose, (int32_t)tr.vToErase.size(), (int32_t)tr.vToEraseLines.size(),
+                            addr_inversions, (int32_t)short_ml.mObservations.size(), (int32_t)bad_mp.mObservations.size()};
+  wr.put(extra, 8);
+  std::printf("adapter-ba: pKF %lu, %d cameras (%d free), %d points, %d lines gathered; chi2 %.9g -> %.9g; %zu + %zu erased\n", pKF->mnId, g.n_cams(), g.n_free_cams, g.n_points(),
+              g.n_lines(), chi2[0], chi2[1], tr.vToErase.size(), tr.vToEraseLines.size());
+  return 0;
+}
+
+int run_pose(const char* in, const char* out, unsigned seed) {
+  Reader r(in);
+  int32_t h[2]; r.get(h, 2);                   // n_points n_lines
+  double camg[6]; r.get(camg, 6);
+  lld_amd::PoseFrame f;
+  r.get(f.pose_qt, 7);
+  r.get(f.pt_xw, 3 * (size_t)h[0]); r.get(f.pt_uvr, 3 * (size_t)h[0]); r.get(f.pt_inv_sigma2, h[0]);
+  r.get(f.ln_x0, 3 * (size_t)h[1]); r.get(f.ln_dir, 3 * (size_t)h[1]); r.get(f.ln_left, 4 * (size_t)h[1]);
+  r.get(f.ln_right, 4 * (size_t)h[1]); r.get(f.ln_octave, 2 * (size_t)h[1]);
+  std::mt19937 rng(seed);
+  const std::vector<float> table = level_table();
+  Frame F;
+  F.fx = (float)camg[0]; F.fy = (float)camg[1]; F.cx = (float)camg[2]; F.cy = (float)camg[3]; F.mbf = (float)camg[4];
+  F.mK = k_mat(F.fx, F.fy, F.cx, F.cy);
+  F.mvInvLevelSigma2 = table;
+  F.mTcw = pose_mat(f.pose_qt);
+  std::vector<std::unique_ptr<MapPoint> > mps; std::vector<std::unique_ptr<MapLine> > mls;
+  for (int p = 0; p < h[0]; p++) {
+    if (rng() % 3 == 0) { KeyPoint kp; kp.pt.x = 5.f; kp.pt.y = 6.f; kp.octave = 1; F.mvKeysUn.push_back(kp); F.mvuRight.push_back(-1.f); F.mvpMapPoints.push_back(nullptr); }   // keypoint without a MapPoint
+    mps.emplace_back(new MapPoint());
+    mps.back()->mWorldPos = Mat(3, 1);
+    for (int k = 0; k < 3; k++) mps.back()->mWorldPos.at<float>(k) = (float)f.pt_xw[3 * (size_t)p + k];
+    KeyPoint kp; kp.pt.x = (float)f.pt_uvr[3 * (size_t)p]; kp.pt.y = (float)f.pt_uvr[3 * (size_t)p + 1]; kp.octave = octave_of(table, f.pt_inv_sigma2[p]);
+    F.mvKeysUn.push_back(kp); F.mvuRight.push_back((float)f.pt_uvr[3 * (size_t)p + 2]); F.mvpMapPoints.push_back(mps.back().get());
+  }
+  F.N = (int)F.mvKeysUn.size();
+  F.mvbOutlier.assign(F.N, true);                                                  // stale flags: the call must reset the ones it uses and leave the rest
+  for (int l = 0; l < h[1]; l++) {
+    if (rng() % 2 == 0) { const double seg[4] = {1, 1, 9, 9}; F.mvLinesLeft.push_back(key_line(seg, 0)); F.line_matches.push_back(-1); F.mvpMapLines.push_back(nullptr); }      // a line without a MapLine
+    mls.emplace_back(new MapLine());
+    mls.back()->mX0 = Vector3d(f.ln_x0[3 * (size_t)l], f.ln_x0[3 * (size_t)l + 1], f.ln_x0[3 * (size_t)l + 2]);
+    mls.back()->mDir = Vector3d(f.ln_dir[3 * (size_t)l], f.ln_dir[3 * (size_t)l + 1], f.ln_dir[3 * (size_t)l + 2]);
+    const bool has_right = !(f.ln_right[4 * (size_t)l] < 0);
+    F.mvLinesLeft.push_back(key_line(&f.ln_left[4 * (size_t)l], f.ln_octave[2 * (size_t)l]));
+    if (has_right) { F.line_matches.push_back((int)F.mvLinesRight.size()); F.mvLinesRight.push_back(key_line(&f.ln_right[4 * (size_t)l], f.ln_octave[2 * (size_t)l + 1])); }
+    else F.line_matches.push_back(-1);
+    F.mvpMapLines.push_back(mls.back().get());
+  }
+  F.mvbOutlierLines.assign(F.mvLinesLeft.size(), true);
+  lld_amd::Context ctx(0);
+  lld_adapter::PoseTrace tr;
+  const int32_t n_in = lld_adapter::PoseOptimization(ctx.get(), &F, camg[5], &tr);
+  const lld_amd::PoseFrame& g = tr.frame;
+  Writer wr(out);
+  const int32_t gh[4] = {(int32_t)tr.vnIndexEdge.size(), (int32_t)tr.vnIndexLines.size(), F.N, (int32_t)F.mvLinesLeft.size()};
+  wr.put(gh, 4);
+  // gathered problem (the pose_qt field of the trace has been overwritten with the result: the INPUT pose is the frame's old mTcw, rebuilt by the test)
+  wr.put(g.pt_xw); wr.put(g.pt_uvr); wr.put(g.pt_inv_sigma2); wr.put(g.ln_x0); wr.put(g.ln_dir); wr.put(g.ln_left); wr.put(g.ln_right); wr.put(g.ln_octave); wr.put(g.ln_frame_index);
+  wr.put(g.pose_qt, 7); wr.put(&n_in, 1); wr.put(g.mvbOutlier); wr.put(g.mvbOutlierLines);
+  std::vector<int32_t> ie(tr.vnIndexEdge.begin(), tr.vnIndexEdge.end()), il(tr.vnIndexLines.begin(), tr.vnIndexLines.end());
+  wr.put(ie); wr.put(il);
+  wr.put(F.mTcw.ptr<float>(), 16);
+  const int32_t nset = F.n_set_pose; wr.put(&nset, 1);
+  std::vector<uint8_t> fo(F.N), fl(F.mvbOutlierLines.size());
+  for (int i = 0; i < F.N; i++) fo[i] = F.mvbOutlier[i] ? 1 : 0;
+  for (size_t i = 0; i < fl.size(); i++) fl[i] = F.mvbOutlierLines[i] ? 1 : 0;
+  wr.put(fo); wr.put(fl);
+  std::printf("adapter-pose: %d of %d keypoints and %d of %zu lines carry a landmark; %d inliers\n", gh[0], F.N, gh[1], F.mvLinesLeft.size(), n_in);
+  return 0;
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+  if (argc < 4) { std::fprintf(stderr, "usage: adapter_harness ba|pose <in> <out> [seed]\n"); return 2; }
+  const unsigned seed = argc > 4 ? (unsigned)std::atoi(argv[4]) : 1u;
+  try {
+    const std::string mode = argv[1];
+    if (mode == "ba") return run_ba(argv[2], argv[3], seed);
+    if (mode == "pose") return run_pose(argv[2], argv[3], seed);
+    std::fprintf(stderr, "unknown mode %s\n", argv[1]);
+    return 2;
+  } catch (const std::exception& e) {
+    std::fprintf(stderr, "adapter_harness: %s\n", e.what());
+    return 1;
+  }
+}

@@ -177,6 +177,11 @@ typedef struct {
 int lld_local_ba(lld_ctx* ctx, const lld_ba_window* in, const lld_ba_params* params,
                  volatile const int* abort_flag, lld_ba_result* out);
 
+/* The same call with the stop flag as a BYTE: the reference's pbStopFlag is a `bool*` (LocalMapping::mbAbortBA, Optimizer.h:49); an
+ * adapter passes it as `(volatile const unsigned char*)pbStopFlag` - character types may alias any object, an `int*` may not. */
+int lld_local_ba_stopflag(lld_ctx* ctx, const lld_ba_window* in, const lld_ba_params* params,
+                          volatile const unsigned char* stop_flag, lld_ba_result* out);
+
 /* Batched, HBM-resident form: windows are uploaded once, then solved any number of times
  * (each solve restarts from the uploaded initial state).  This is the throughput path:
  * independent windows are what shards across GPUs (one batch per rank). */
@@ -222,6 +227,12 @@ typedef struct {
   const double*  ln_left;           /* [n_lines][4]                                             */
   const double*  ln_right;          /* [n_lines][4] xs<0 -> no stereo match                     */
   const int32_t* ln_octave;         /* [n_lines][2]                                             */
+  const int32_t* ln_frame_index;    /* [n_lines] index i of the line in pFrame->mvLinesLeft (what AddLineMinOnlyPose pushes to
+                                       vnIndexLines, Optimizer.cc:640); NULL = 0..n_lines-1 (every frame line has a MapLine).
+                                       The reference classifies the edges of line i against the stereo or the mono threshold by
+                                       vnStereoLines[i] (:898) although vnStereoLines is filled per EDGE (:643-648): the entry read
+                                       is the stereo flag of the i-th edge added, whichever line that edge belongs to.  Reproduced
+                                       as is; an index beyond the edge count (undefined behaviour there) counts as stereo.      */
 } lld_pose_problem;
 
 typedef struct {

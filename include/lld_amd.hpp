@@ -65,6 +65,7 @@ struct PoseFrame {
   double pose_qt[7] = {0, 0, 0, 1, 0, 0, 0};
   std::vector<double> pt_xw, pt_uvr, pt_inv_sigma2, ln_x0, ln_dir, ln_left, ln_right;
   std::vector<int32_t> ln_octave;
+  std::vector<int32_t> ln_frame_index;                // index of each line in the frame's mvLinesLeft (empty: 0..n-1), see lld_pose_problem
   std::vector<uint8_t> mvbOutlier, mvbOutlierLines;   // filled by PoseOptimization
 };
 
@@ -129,6 +130,7 @@ class Optimizer {
     q.n_points = (int)(f.pt_xw.size() / 3); q.pt_xw = f.pt_xw.data(); q.pt_uvr = f.pt_uvr.data(); q.pt_inv_sigma2 = f.pt_inv_sigma2.data();
     q.n_lines = (int)(f.ln_x0.size() / 3); q.ln_x0 = f.ln_x0.data(); q.ln_dir = f.ln_dir.data(); q.ln_left = f.ln_left.data();
     q.ln_right = f.ln_right.data(); q.ln_octave = f.ln_octave.data();
+    q.ln_frame_index = f.ln_frame_index.empty() ? nullptr : f.ln_frame_index.data();
     lld_pose_params p; lld_pose_params_default(&p); p.gamma = gamma;
     f.mvbOutlier.assign(q.n_points, 0); f.mvbOutlierLines.assign(q.n_lines, 0);
     lld_pose_result r{};

@@ -106,6 +106,7 @@ class PoseProblem(C.Structure):
         ("n_lines", C.c_int32),
         ("ln_x0", c_double_p), ("ln_dir", c_double_p), ("ln_left", c_double_p), ("ln_right", c_double_p),
         ("ln_octave", c_int32_p),
+        ("ln_frame_index", c_int32_p),
     ]
 
 
@@ -176,7 +177,7 @@ PRODUCT_SYMBOLS = [
     "lld_status_string", "lld_ctx_create", "lld_ctx_destroy", "lld_ctx_stream", "lld_ctx_synchronize",
     "lld_se3_from_tcw_f32", "lld_se3_to_tcw_f32", "lld_orb_inv_level_sigma2",
     "lld_ba_params_default", "lld_local_ba",
-    "lld_ba_batch_create", "lld_ba_batch_solve", "lld_ba_batch_download", "lld_ba_batch_download_range", "lld_ba_batch_stats",
+    "lld_local_ba_stopflag", "lld_ba_batch_create", "lld_ba_batch_solve", "lld_ba_batch_download", "lld_ba_batch_download_range", "lld_ba_batch_stats",
     "lld_ba_batch_result_records", "lld_ba_batch_phase_ms", "lld_ba_batch_kernel_stats", "lld_ba_batch_set_groups",
     "lld_ba_batch_destroy",
     "lld_pose_params_default", "lld_pose_opt",

@@ -721,7 +721,14 @@ int lld_ba_batch_create(lld_ctx* ctx, int n_windows, const lld_ba_window* wins, 
   return ba_batch_create_impl(ctx, n_windows, wins, params, out);
 }
 
-int lld_ba_batch_solve(lld_ba_batch* B, volatile const int* abort_flag) {
+// The reference's pbStopFlag is a plain `bool*` (LocalMapping::mbAbortBA, written by the Tracking thread): the byte form of the
+// flag lets an adapter pass that pointer as it is (character types may alias any object).
+struct StopFlag {
+  volatile const int* i32; volatile const unsigned char* u8;
+  bool up() const { return (i32 && *i32) || (u8 && *u8); }
+};
+
+static int ba_batch_solve_impl(lld_ba_batch* B, StopFlag abort_flag) {
   if (!B) return LLD_ERR_INVALID;
   lld_ctx* ctx = B->ctx;
   LLD_HIP_TRY(hipSetDevice(ctx->device));
@@ -744,7 +751,7 @@ int lld_ba_batch_solve(lld_ba_batch* B, volatile const int* abort_flag) {
   const size_t chol_lds = chol_fixed + chol_tri;
   // Optimizer.cc:1220-1222: a stop request before optimising returns without touching the map -> the read-back kernel copies
   // the (untouched) working state and every flag stays clear.
-  const bool abort_at_start = abort_flag && *abort_flag;
+  const bool abort_at_start = abort_flag.up();
   using Group = lld_ba_batch::Group;
 
   auto finalize_group = [&](Group& G) {
@@ -757,7 +764,7 @@ int lld_ba_batch_solve(lld_ba_batch* B, volatile const int* abort_flag) {
   auto launch_superstep = [&](Group& G) -> int {
     const BAWin* dw = B->d_wins + G.w0; BAState* ds = B->d_state + G.w0;
     const int nw = G.nw; hipStream_t st = G.st;
-    const int abort_now = (abort_flag && *abort_flag) ? 1 : 0;
+    const int abort_now = abort_flag.up() ? 1 : 0;
     LLD_HIP_TRY(hipEventRecord(G.ev[0], st));
     const bool fuse_pairs = B->n_windows < kFusePairsBelowWindows && !B->big;                // see ba_linearize_both_kernel
     if (B->big) {
@@ -879,6 +886,8 @@ int lld_ba_batch_solve(lld_ba_batch* B, volatile const int* abort_flag) {
   (void)hipEventDestroy(t_begin); (void)hipEventDestroy(t_end);
   return LLD_OK;
 }
+
+int lld_ba_batch_solve(lld_ba_batch* B, volatile const int* abort_flag) { return ba_batch_solve_impl(B, StopFlag{abort_flag, nullptr}); }
 
 static int ba_fetch_records(lld_ba_batch* B) {
   if (B->records_valid) return LLD_OK;
@@ -1006,7 +1015,7 @@ void lld_ba_batch_destroy(lld_ba_batch* B) {
   delete B;
 }
 
-int lld_local_ba(lld_ctx* ctx, const lld_ba_window* in, const lld_ba_params* params, volatile const int* abort_flag, lld_ba_result* out) {
+static int local_ba_impl(lld_ctx* ctx, const lld_ba_window* in, const lld_ba_params* params, StopFlag abort_flag, lld_ba_result* out) {
   if (!ctx || !in || !out) return LLD_ERR_INVALID;
   lld_ba_batch* B = nullptr;
   static const bool timing = std::getenv("LLD_BA_TIMING") != nullptr;      // prints where a single call spends its time
@@ -1015,13 +1024,21 @@ int lld_local_ba(lld_ctx* ctx, const lld_ba_window* in, const lld_ba_params* par
   const auto t0 = now();
   int st = ba_batch_create_impl(ctx, 1, in, params, &B); if (st) return st;
   const auto t1 = now();
-  st = lld_ba_batch_solve(B, abort_flag);
+  st = ba_batch_solve_impl(B, abort_flag);
   const auto t2 = now();
   if (!st) st = lld_ba_batch_download(B, 0, out);
   const auto t3 = now();
   lld_ba_batch_destroy(B);
   if (timing) std::fprintf(stderr, "[lld_local_ba] create %.3f ms, solve %.3f ms, download %.3f ms, destroy %.3f ms\n", ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, now()));
   return st;
+}
+
+int lld_local_ba(lld_ctx* ctx, const lld_ba_window* in, const lld_ba_params* params, volatile const int* abort_flag, lld_ba_result* out) {
+  return local_ba_impl(ctx, in, params, StopFlag{abort_flag, nullptr}, out);
+}
+
+int lld_local_ba_stopflag(lld_ctx* ctx, const lld_ba_window* in, const lld_ba_params* params, volatile const unsigned char* stop_flag, lld_ba_result* out) {
+  return local_ba_impl(ctx, in, params, StopFlag{nullptr, stop_flag}, out);
 }
 
 }  // extern "C"

@@ -19,7 +19,7 @@ constexpr int kPoseThreads = 512;
 constexpr int kPoseWaves = kPoseThreads / 64;
 constexpr size_t kPoseLdsBudget = 150 * 1024;              // dynamic LDS available to the staged frame (160 KB per CU)
 constexpr uint8_t PF_LEVEL = 1, PF_ROBUST = 2, PF_OUTLIER = 4;             // point working flags
-constexpr uint8_t LF_LEVEL = 1, LF_ROBUST = 2, LF_LAST = 4, LF_STEREO = 8; // line-edge flags (LAST / STEREO are inputs)
+constexpr uint8_t LF_LEVEL = 1, LF_ROBUST = 2, LF_LAST = 4, LF_STEREO = 8, LF_THR_STEREO = 16; // line-edge flags (LAST / STEREO / THR_STEREO are inputs)
 
 struct PoseFrameDev {            // per-frame header in HBM
   CamK cam;
@@ -36,7 +36,8 @@ struct PoseArrays {
   const double* pt[7];           // px, py, pz, u, v, ur, s                    [n_pt_total]
   const double* le[12];          // x1x,x1y,x1z, x2x,x2y,x2z, xs,ys,xe,ye, info, bx   [n_le_total]
   const int* le_line;            // line of the edge (frame-local)
-  const uint8_t* le_fl0;         // LF_LAST: last edge of its line; LF_STEREO: the line has a right-image edge
+  const uint8_t* le_fl0;         // LF_LAST: last edge of its line; LF_STEREO: the line has a right-image edge; LF_THR_STEREO: the
+                                 // classification threshold the reference applies to this edge is the stereo one (see pose_pack)
   // working state of the HBM mode (frames that do not fit LDS)
   double *pt_chi2, *le_chi2; uint8_t *pt_fl, *le_fl;
   // results
@@ -435,15 +436,15 @@ __global__ __launch_bounds__(kPoseThreads) void pose_opt_kernel(const PoseFrameD
       nb = block_sum1(nb, red1, flip);
       nBad_pts = (int)(nb + 0.5);
       if (n_pt + n_le < 10) break;                                   // if(optimizer.edges().size()<10) break;
-      // vnStereoLines is filled per EDGE but indexed by the LINE index (Optimizer.cc:643-648 vs :898): the test below reads
-      // other edges' flags, whose LF_STEREO bit never changes, so no barrier is needed between the loops
+      // vnStereoLines is filled per EDGE but indexed by the LINE's index in the frame (Optimizer.cc:643-648 vs :898): which entry
+      // that is was resolved on the host (LF_THR_STEREO, pose_pack)
       for (int i = tid; i < n_le; i += kPoseThreads) {
         Vec3 X1m, X2m; double e[2], s;
         const double chi = line_eval(T, i, X1m, X2m, e, s, nullptr);
         lchi[i] = chi;
         const float chif = (float)chi;
         const int idx = lline[i];
-        const bool st = idx < n_le ? (a.le_fl0[lo + idx] & LF_STEREO) != 0 : true;
+        const bool st = (a.le_fl0[lo + i] & LF_THR_STEREO) != 0;
         const double thr = st ? F.thr_ln_stereo : F.thr_ln_mono;
         const bool bad = (double)chif > thr;
         uint8_t fl = lfl[i];
@@ -527,9 +528,15 @@ static void pose_pack(int n_frames, const lld_pose_problem* frames, double gamma
       pt[3 * Y.NP + ip] = P.pt_uvr[3 * i]; pt[4 * Y.NP + ip] = P.pt_uvr[3 * i + 1]; pt[5 * Y.NP + ip] = P.pt_uvr[3 * i + 2];
       pt[6 * Y.NP + ip] = P.pt_inv_sigma2[i];
     }
+    // vnStereoLines of this frame: one entry per edge, in the order AddLineMinOnlyPose adds them (Optimizer.cc:643-648)
+    std::vector<uint8_t> vnStereoLines;
+    for (int l = 0; l < P.n_lines; l++) { const bool hr = !(P.ln_right[4 * l] < 0); vnStereoLines.push_back(hr); if (hr) vnStereoLines.push_back(1); }
     for (int l = 0; l < P.n_lines; l++) {
       const double* Lk = P.ln_left + 4 * l; const double* Rk = P.ln_right + 4 * l;
       const bool hr = !(Rk[0] < 0);
+      // ... and the entry the classification reads for this line: vnStereoLines[idx], idx = vnIndexLines[.] = the line's index in the frame (:893-898)
+      const long long fi = P.ln_frame_index ? (long long)P.ln_frame_index[l] : (long long)l;
+      const bool thr_stereo = (fi >= 0 && fi < (long long)vnStereoLines.size()) ? vnStereoLines[(size_t)fi] != 0 : true;
       for (int si = 0; si < 2; si++) {
         if (si == 1 && !hr) continue;
         const double* kl = si == 0 ? Lk : Rk;
@@ -540,7 +547,7 @@ static void pose_pack(int n_frames, const lld_pose_problem* frames, double gamma
         le[10 * Y.NE + ie] = lld::line_info(gamma, P.ln_octave[2 * l + si]);
         le[11 * Y.NE + ie] = si == 1 ? F.cam.bx_right : 0.0;
         le_line[ie] = l;
-        le_fl0[ie] = (uint8_t)(((si == 1 || !hr) ? LF_LAST : 0) | (hr ? LF_STEREO : 0));
+        le_fl0[ie] = (uint8_t)(((si == 1 || !hr) ? LF_LAST : 0) | (hr ? LF_STEREO : 0) | (thr_stereo ? LF_THR_STEREO : 0));
         ie++;
       }
     }

@@ -289,6 +289,7 @@ class PoseFrame:
     ln_left: np.ndarray
     ln_right: np.ndarray
     ln_octave: np.ndarray
+    ln_frame_index: np.ndarray | None = None     # [n_lines] index of each line in the frame's mvLinesLeft; None = 0..n_lines-1
     meta: dict = field(default_factory=dict)
 
     def normalise(self):
@@ -298,6 +299,8 @@ class PoseFrame:
         self.ln_x0 = as_f64(self.ln_x0, (-1, 3)); self.ln_dir = as_f64(self.ln_dir, (-1, 3))
         self.ln_left = as_f64(self.ln_left, (-1, 4)); self.ln_right = as_f64(self.ln_right, (-1, 4))
         self.ln_octave = as_i32(self.ln_octave).reshape(-1, 2)
+        if self.ln_frame_index is not None:
+            self.ln_frame_index = as_i32(self.ln_frame_index)
         return self
 
     @property
@@ -318,6 +321,7 @@ class PoseFrame:
         p.ln_x0 = _p(self.ln_x0, C.c_double); p.ln_dir = _p(self.ln_dir, C.c_double)
         p.ln_left = _p(self.ln_left, C.c_double); p.ln_right = _p(self.ln_right, C.c_double)
         p.ln_octave = _p(self.ln_octave, C.c_int32)
+        p.ln_frame_index = None if self.ln_frame_index is None else _p(self.ln_frame_index, C.c_int32)
         return p
 
 

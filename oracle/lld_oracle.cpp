@@ -758,7 +758,9 @@ extern "C" int lldo_pose_opt(void* /*ctx*/, const lld_pose_problem* in, const ll
       S.le_error(e);
       const float chi2 = (float)S.le_chi2(e);
       double thr = deltaLinesStereo * deltaLinesStereo;       // float * float
-      const bool st = (size_t)idx < vnStereoLines.size() ? vnStereoLines[idx] != 0 : true;   // out of range = UB in the reference
+      // int idx = vnIndexLines[i]: the line's index in the FRAME (Optimizer.cc:893), used for mvbOutlierLines and for vnStereoLines alike
+      const long long fi = in->ln_frame_index ? (long long)in->ln_frame_index[idx] : (long long)idx;
+      const bool st = (fi >= 0 && (size_t)fi < vnStereoLines.size()) ? vnStereoLines[(size_t)fi] != 0 : true;   // out of range = UB in the reference
       if (!st) thr = deltaLinesMono * deltaLinesMono;
       if (chi2 > thr) { out->ln_outlier[idx] = 1; e.level = 1; } else { out->ln_outlier[idx] = 0; e.level = 0; }
       if (it == 2) e.robust = false;

@@ -77,3 +77,19 @@ def test_pose_single_calls_reuse_context_buffers(gpu_ctx, oracle):
     for fid, n, m in [(50, 300, 40), (51, 1000, 200), (52, 20, 0), (50, 300, 40)]:
         f = synth.make_pose_frame(fid, n_points=n, n_lines=m)
         _check(opt.PoseOptimization(f, gamma=0.5), oracle.pose_opt(f, gamma=0.5), f.n_points)
+
+
+@pytest.mark.parametrize("fid,kw", [(40, dict(n_points=300, n_lines=80, mono_line_frac=0.4)), (41, dict(n_points=200, n_lines=50, mono_frac=0.3, mono_line_frac=0.6, outlier_frac=0.2))])
+def test_frame_line_indices_select_the_threshold(gpu_ctx, oracle, fid, kw):
+    """lld_pose_problem::ln_frame_index (vnIndexLines): the reference reads vnStereoLines - one entry per EDGE - with the line's index in
+    the frame (Optimizer.cc:893-898).  Random increasing frame indices (lines without a MapLine in between), device vs oracle, and the
+    known-answer frame of tests/test_oracle_kat.py."""
+    import dataclasses
+    rng = np.random.default_rng(fid)
+    f = synth.make_pose_frame(fid, **kw)
+    f = dataclasses.replace(f, ln_frame_index=np.cumsum(rng.integers(1, 4, f.n_lines)).astype(np.int32) - 1)
+    _check(Optimizer(gpu_ctx).PoseOptimization(f, gamma=0.5), oracle.pose_opt(f, gamma=0.5), f.n_points)
+    with PoseBatch(gpu_ctx, [f, dataclasses.replace(f, ln_frame_index=None)], gamma=0.5) as b:
+        b.solve()
+        _check(b.download(0), oracle.pose_opt(f, gamma=0.5), f.n_points)
+        _check(b.download(1), oracle.pose_opt(dataclasses.replace(f, ln_frame_index=None), gamma=0.5), f.n_points)

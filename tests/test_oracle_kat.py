@@ -261,3 +261,49 @@ def test_line_depth_test_flags_lines_behind_camera(oracle):
     # mirror the camera: rotate by pi about its x axis so the line is behind it
     flip = oracle.se3_mul(np.array([1.0, 0, 0, 0, 0, 0, 0]), qt)
     assert not oracle.edge_line(CAM, 0.0, flip, l5, seg)[3]
+
+
+def test_line_threshold_is_looked_up_by_the_frame_index_of_the_line(oracle):
+    """Optimizer.cc:893-898: `int idx = vnIndexLines[i]` is the line's index in the FRAME; the classification threshold comes from
+    vnStereoLines[idx] although vnStereoLines holds one entry per EDGE (:643-648).  Known answer: a mono line (one edge) whose two
+    detected end points sit 1.85 px off the projected 3D line has chi2 = gamma^2 * 2 * 1.85^2 = gamma^2 * 6.845, between the mono
+    (5.991 gamma^2) and the stereo (7.815 gamma^2) threshold.  Which one it is compared with depends only on the stereo flag of the
+    edge that happens to sit at position `frame index` of the edge list."""
+    from lld_slam_amd import host, synth
+    f = synth.make_pose_frame(11, n_points=600, n_lines=6, outlier_frac=0.0)
+    gt = f.meta["gt_qt"]; Rcw, tcw = f.meta["gt_Rcw"], f.meta["gt_tcw"]
+    fx, fy, cx, cy, bf = f.cam
+    # noise-free point observations at the ground-truth pose: the optimum is the ground truth, the line edges barely matter
+    Xc = f.pt_xw @ Rcw.T + tcw
+    uvr = np.stack([fx * Xc[:, 0] / Xc[:, 2] + cx, fy * Xc[:, 1] / Xc[:, 2] + cy, fx * Xc[:, 0] / Xc[:, 2] + cx - bf / Xc[:, 2]], 1)
+    # line 0: mono, both end points 1.85 px off its projection; lines 1..5: stereo, exact
+    def project(P, bx=0.0):
+        Pc = P @ Rcw.T + tcw
+        return np.stack([fx * (Pc[:, 0] + bx) / Pc[:, 2] + cx, fx * Pc[:, 1] / Pc[:, 2] + cy], 1)       # line edges use fx on both axes
+    A, B = f.ln_x0, f.ln_x0 + f.ln_dir
+    a, b = project(A), project(B)
+    left = np.concatenate([a, b], 1); ar, br = project(A, -bf / fx), project(B, -bf / fx); right = np.concatenate([ar, br], 1)
+    n = np.stack([-(b - a)[:, 1], (b - a)[:, 0]], 1); n /= np.linalg.norm(n, axis=1, keepdims=True)
+    left[0, :2] += 1.85 * n[0]; left[0, 2:] += 1.85 * n[0]
+    right[0] = -1.0
+    base = dict(cam=f.cam, pose_qt=gt, pt_xw=f.pt_xw, pt_uvr=uvr, pt_inv_sigma2=np.ones(f.n_points), ln_x0=f.ln_x0, ln_dir=f.ln_dir, ln_left=left, ln_right=right,
+                ln_octave=np.zeros((6, 2), np.int32))
+    # edge list: [L0 left (mono), L1 left, L1 right, L2 left, L2 right, ...] -> vnStereoLines = [0, 1, 1, 1, 1, ...]
+    r = oracle.pose_opt(host.PoseFrame(**base), gamma=0.5)                               # frame index 0 -> entry 0 = mono -> 6.845 > 5.991: outlier
+    assert r.ln_outlier.tolist() == [1, 0, 0, 0, 0, 0]
+    r = oracle.pose_opt(host.PoseFrame(ln_frame_index=np.array([0, 1, 2, 3, 4, 5], np.int32), **base), gamma=0.5)
+    assert r.ln_outlier.tolist() == [1, 0, 0, 0, 0, 0]                                    # NULL and the identity are the same thing
+    r = oracle.pose_opt(host.PoseFrame(ln_frame_index=np.array([1, 2, 3, 4, 5, 6], np.int32), **base), gamma=0.5)
+    assert r.ln_outlier.tolist() == [0, 0, 0, 0, 0, 0]                                    # frame index 1 -> entry 1 = L1's left edge = stereo -> 6.845 < 7.815: inlier
+    r = oracle.pose_opt(host.PoseFrame(ln_frame_index=np.array([40, 41, 42, 43, 44, 45], np.int32), **base), gamma=0.5)
+    assert r.ln_outlier.tolist() == [0, 0, 0, 0, 0, 0]                                    # beyond the edge list (undefined in the reference): stereo
+    # and a stereo line read through the mono line's entry: line 1 gets the 1.85 px on its RIGHT edge (mvbOutlierLines[idx] keeps what the
+    # line's last edge says, :899-907), and the frame indices put it on entry 0
+    left2 = np.concatenate([a, b], 1); right2 = right.copy()
+    nr = np.stack([-(br - ar)[:, 1], (br - ar)[:, 0]], 1); nr /= np.linalg.norm(nr, axis=1, keepdims=True)
+    right2[1, :2] += 1.85 * nr[1]; right2[1, 2:] += 1.85 * nr[1]
+    base2 = dict(base, ln_left=left2, ln_right=right2)
+    r = oracle.pose_opt(host.PoseFrame(ln_frame_index=np.array([3, 0, 4, 5, 6, 7], np.int32), **base2), gamma=0.5)
+    assert r.ln_outlier.tolist() == [0, 1, 0, 0, 0, 0]                                    # L1 (stereo) classified with the MONO threshold
+    r = oracle.pose_opt(host.PoseFrame(**base2), gamma=0.5)
+    assert r.ln_outlier.tolist() == [0, 0, 0, 0, 0, 0]
