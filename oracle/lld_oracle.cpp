@@ -448,6 +448,17 @@ void lldo_reproject_line_point(const double* X0, const double* ldir, double px, 
 
 void lldo_set_landmark_inverse(int how) { g_landmark_inverse = how; }      // test knob, see invert_small
 
+// test hook: record the LM trajectory of the calls that follow into buf[3 * cap] (lambda used, trial chi2, accepted); returns the
+// number of trials recorded so far; buf == nullptr switches it off
+static lldo::LMTrace g_trace_store{nullptr, 0, 0};
+int lldo_lm_trace(double* buf, int cap) {
+  const int n = g_trace_store.n;
+  if (!buf) { lldo::g_lm_trace = nullptr; return n; }
+  g_trace_store = lldo::LMTrace{buf, cap, 0};
+  lldo::g_lm_trace = &g_trace_store;
+  return n;
+}
+
 void lldo_ba_params_default(lld_ba_params* p) {
   p->gamma = 1.0; p->its_round1 = 5; p->its_round2 = 15; p->ln_filter = 4; p->max_trials = 10;
   p->pcg_rel_tol = 1e-12; p->pcg_max_iter = 0; p->reduced_solver = 0; p->protocol = 0; p->robust_points = 1; p->abort_after_trials = 0; p->reserved = 0;

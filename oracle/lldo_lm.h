@@ -30,6 +30,11 @@ struct LMData {
   int iterations = 0;
 };
 
+// Test hook: when set, every LM trial appends (lambda used, chi2 of the trial, accepted) - the trajectory the independent numpy
+// reference (tests/golden/reference_numpy.py) is compared with.  One thread at a time.
+struct LMTrace { double* buf; int cap; int n; };
+static LMTrace* g_lm_trace = nullptr;
+
 // System concept:
 //   bool   buildStructure();                 BlockSolver::buildStructure
 //   void   computeActiveErrors();            SparseOptimizer::computeActiveErrors
@@ -61,6 +66,7 @@ static LMResult lm_solve(Sys& s, LMData& d, int iteration) {
   int qmax = 0;
   do {
     s.push();
+    const double lambda_used = d.lambda;
     s.setLambda(d.lambda);
     const bool ok2 = s.solve();
     s.update();
@@ -84,6 +90,10 @@ static LMResult lm_solve(Sys& s, LMData& d, int iteration) {
       d.lambda *= d.ni;
       d.ni *= 2;
       s.pop();
+    }
+    if (g_lm_trace && g_lm_trace->n < g_lm_trace->cap) {
+      double* t = g_lm_trace->buf + 3 * g_lm_trace->n++;
+      t[0] = lambda_used; t[1] = tempChi; t[2] = (rho > 0 && std::isfinite(tempChi)) ? 1.0 : 0.0;
     }
     qmax++;
     d.trials++;

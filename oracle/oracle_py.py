@@ -179,6 +179,19 @@ def local_ba(win: host.Window, gamma=1.0, abort=False, **params):
     return host.ba_call(lib(), None, win, host.ba_params(lib(), gamma, **params), abort)
 
 
+def local_ba_traced(win: host.Window, gamma=1.0, **params):
+    """local_ba plus the LM trajectory: [n_trials, 3] = (lambda used, robust chi2 of the trial, accepted)."""
+    buf = np.zeros(3 * 512)
+    d = lib().dll
+    d.lldo_lm_trace.argtypes = [abi.c_double_p, C.c_int]; d.lldo_lm_trace.restype = C.c_int
+    d.lldo_lm_trace(_dp(buf), 512)
+    try:
+        r = local_ba(win, gamma, **params)
+    finally:
+        n = d.lldo_lm_trace(None, 0)
+    return r, buf[:3 * n].reshape(-1, 3).copy()
+
+
 def set_landmark_inverse(how: int):
     """0: (Hll + lambda I)^-1 by Gauss-Jordan with partial pivoting (default; the reference calls MatrixXd::inverse(), block_solver.hpp:391),
     1: the same inverse through a Cholesky factor - equal in exact arithmetic.  Not thread-safe: a process-wide test knob."""
