@@ -18,8 +18,16 @@ using namespace lldba;
 
 namespace {
 constexpr int kNumPhases = 5;
-constexpr int kFusePairsBelowWindows = 8;  // fewer windows than this: point + line kernels of a pair share one launch
+constexpr int kFusePairsBelowWindows = 64; // a GROUP of fewer windows than this: the point + line kernels of a pair share one launch (a dependent
+                                           // launch less per pair on a chain that is latency-bound anyway: 32 windows 2520 -> 2610 windows/s, 64: 3680 -> 3780)
 constexpr int kMaxSuperSteps = 512;      // hard stop: 2 rounds x 15 iterations x 10 trials is the protocol's own bound (300)
+// Super-steps queued per host poll.  A group of few windows is a chain of dependent, latency-bound kernels (a 32-window batch: 390 us per
+// super-step, of which ~30 us are the host's wait-read-launch round trip and more are launch gaps): such groups queue kChunkSmall
+// super-steps at once - every kernel looks at its window's state first, so a super-step queued for a window that is already done
+// falls through - with the round transition (ba_classify + ba_round2) inside every queued super-step.  Groups of >= kChunkFromWindows
+// windows keep one poll per super-step: their polls hide behind the other groups' kernels, and two more launches per super-step
+// over 64+ windows would cost more than they save.
+constexpr int kChunkSmall = 4, kChunkFromWindows = 64;
 // A batch of this many windows fills the GPU on its own (four stream groups in flight).  Two such solves interleaved from two
 // contexts ran 20 - 30 % slower in aggregate than one after the other (2 lanes: 2930 windows/s host buffers in and out, 3910 with the
 // solves taking turns; tools/exp_e2e_lanes.py), so solves of large batches take turns per device; everything else of a pipelined
@@ -40,7 +48,7 @@ struct lld_ba_batch {
   // window groups solved concurrently, each on its own stream (hides the latency-bound reduced solve, the per-super-step
   // host poll and kernel tails behind the other groups' work)
   struct Group { int w0 = 0, nw = 0; hipStream_t st = nullptr; bool own_stream = false; int* d_counters = nullptr; int* h_counters = nullptr;
-                 hipEvent_t ev[kNumPhases + 1] = {}; int steps = 0; bool active = false; int max_nt_pt = 0, max_nb_ln = 0, max_nl_pt = 0, max_nl_ln = 0, max_lblocks = 0, max_items_pt = 0, max_items_ln = 0, max_blk = 0; };
+                 hipEvent_t ev[kChunkSmall][kNumPhases + 1] = {}; int chunk = 1; int steps = 0; bool active = false; int max_nt_pt = 0, max_nb_ln = 0, max_nl_pt = 0, max_nl_ln = 0, max_lblocks = 0, max_items_pt = 0, max_items_ln = 0, max_blk = 0; };
   std::vector<Group> groups;
   int* d_counters = nullptr; int* h_counters = nullptr;               // device / pinned, 4 ints per group
   int max_lblocks = 0, max_items_pt = 0, max_items_ln = 0, max_free = 0, max_cams = 0, max_blk = 0, acc_copies = 4;
@@ -370,7 +378,7 @@ static void ba_drop_groups(lld_ba_batch* B) {
   for (auto& G : B->groups) {
     if (G.own_stream && G.st) (void)hipStreamSynchronize(G.st);
     if (B->borrowed) continue;                         // streams and events belong to the context's cache
-    for (auto& e : G.ev) if (e) (void)hipEventDestroy(e);
+    for (auto& row : G.ev) for (auto& e : row) if (e) (void)hipEventDestroy(e);
     if (G.own_stream && G.st) (void)hipStreamDestroy(G.st);
   }
   B->groups.clear();
@@ -398,10 +406,12 @@ static int ba_make_groups(lld_ba_batch* B, int n_groups) {
       Gr.st = cache.streams[g - 1]; Gr.own_stream = true;
     } else { LLD_HIP_TRY(hipStreamCreateWithFlags(&Gr.st, hipStreamNonBlocking)); Gr.own_stream = true; }
     Gr.d_counters = B->d_counters + 4 * g; Gr.h_counters = B->h_counters + 4 * g;
-    for (int k = 0; k < kNumPhases + 1; k++) {
-      if (B->borrowed) { if (!cache.events[g][k]) LLD_HIP_TRY(hipEventCreate(&cache.events[g][k])); Gr.ev[k] = cache.events[g][k]; }
-      else LLD_HIP_TRY(hipEventCreate(&Gr.ev[k]));
-    }
+    Gr.chunk = (B->pcg_multi || Gr.nw >= kChunkFromWindows) ? 1 : kChunkSmall;
+    for (int q = 0; q < Gr.chunk; q++)
+      for (int k = 0; k < kNumPhases + 1; k++) {
+        if (B->borrowed) { if (!cache.events[g][q][k]) LLD_HIP_TRY(hipEventCreate(&cache.events[g][q][k])); Gr.ev[q][k] = cache.events[g][q][k]; }
+        else LLD_HIP_TRY(hipEventCreate(&Gr.ev[q][k]));
+      }
     for (int wi = Gr.w0; wi < Gr.w0 + Gr.nw; wi++) {
       const BAWin& W = B->h_wins[wi];
       Gr.max_lblocks = std::max(Gr.max_lblocks, W.nb_pt + W.nb_ln);
@@ -761,12 +771,13 @@ static int ba_batch_solve_impl(lld_ba_batch* B, StopFlag abort_flag) {
   };
   // one super-step of one group: linearise (windows that need it) -> Schur -> reduced solve -> back-substitution + trial chi2
   // -> LM control; then the three phase counters travel to pinned host memory and ev[5] marks the end.
-  auto launch_superstep = [&](Group& G) -> int {
+  auto launch_superstep = [&](Group& G, int q) -> int {
     const BAWin* dw = B->d_wins + G.w0; BAState* ds = B->d_state + G.w0;
     const int nw = G.nw; hipStream_t st = G.st;
     const int abort_now = abort_flag.up() ? 1 : 0;
-    LLD_HIP_TRY(hipEventRecord(G.ev[0], st));
-    const bool fuse_pairs = B->n_windows < kFusePairsBelowWindows && !B->big;                // see ba_linearize_both_kernel
+    hipEvent_t* ev = G.ev[q];
+    LLD_HIP_TRY(hipEventRecord(ev[0], st));
+    const bool fuse_pairs = nw < kFusePairsBelowWindows && !B->big;                // see ba_linearize_both_kernel
     if (B->big) {
       if (G.max_nl_pt > 0) hipLaunchKernelGGL(ba_linearize_pt_big_kernel, dim3(G.max_nl_pt, nw), dim3(kLinThreads), lin_lds, st, A, dw, ds);
       if (G.max_nl_ln > 0) hipLaunchKernelGGL(ba_linearize_ln_big_kernel, dim3(G.max_nl_ln, nw), dim3(kLinThreads), lin_lds, st, A, dw, ds);
@@ -777,7 +788,7 @@ static int ba_batch_solve_impl(lld_ba_batch* B, StopFlag abort_flag) {
     }
     hipLaunchKernelGGL(ba_hpp_reduce_kernel, dim3(std::max(1, (B->max_free * 27 + 255) / 256), nw), dim3(256), 0, st, A, dw, ds);
     hipLaunchKernelGGL(ba_begin_kernel, dim3(nw), dim3(kCtlThreads), 0, st, A, dw, ds, nw);
-    LLD_HIP_TRY(hipEventRecord(G.ev[1], st));
+    LLD_HIP_TRY(hipEventRecord(ev[1], st));
     static const bool split_schur = std::getenv("LLD_BA_SPLIT_SCHUR") != nullptr;             // experiments: the two launches of before
     if (split_schur) {
       if (G.max_items_pt > 0) hipLaunchKernelGGL(ba_schur_items_kernel<3>, dim3(G.max_items_pt, nw), dim3(kSchurThreads), B->schur_lds[0], st, A, dw, ds);
@@ -788,7 +799,7 @@ static int ba_batch_solve_impl(lld_ba_batch* B, StopFlag abort_flag) {
     if (B->schur_wide_lds > 0) hipLaunchKernelGGL(ba_schur_wide_kernel, dim3(G.max_items_pt + G.max_items_ln, nw), dim3(kSchurWideThreads), B->schur_wide_lds, st, A, dw, ds);
     hipLaunchKernelGGL(ba_schur_reduce_kernel, dim3((std::max(1, G.max_blk) * 6 + 255) / 256 + 1, nw), dim3(256), 0, st, A, dw, ds);
     if (B->params.reduced_solver == 1 || B->pcg_multi) hipLaunchKernelGGL(ba_symmetrize_kernel, dim3(B->pcg_multi ? 256 : 16, nw), dim3(256), 0, st, A, dw, ds);
-    LLD_HIP_TRY(hipEventRecord(G.ev[2], st));
+    LLD_HIP_TRY(hipEventRecord(ev[2], st));
     if (B->pcg_multi) {
       // block-Jacobi PCG with the matrix-vector product spread over the GPU; the host looks at the `done` scalars every 16 iterations
       hipLaunchKernelGGL(ba_pcgm_init_kernel, dim3(nw), dim3(kPcgThreads), 0, st, A, dw, ds, B->params.pcg_rel_tol);
@@ -812,7 +823,7 @@ static int ba_batch_solve_impl(lld_ba_batch* B, StopFlag abort_flag) {
       hipLaunchKernelGGL(ba_chol_mfma_kernel, dim3(nw), dim3(kCholMThreads), kCholMLdsDoubles * sizeof(double), st, A, dw, ds);
     else
       hipLaunchKernelGGL(ba_chol_kernel, dim3(nw), dim3(kPcgThreads), chol_lds, st, A, dw, ds, (int)(chol_tri / sizeof(double)));
-    LLD_HIP_TRY(hipEventRecord(G.ev[3], st));
+    LLD_HIP_TRY(hipEventRecord(ev[3], st));
     if (B->big) {
       if (G.max_nt_pt > 0) hipLaunchKernelGGL(ba_backsub_pt_big_kernel, dim3(G.max_nt_pt, nw), dim3(kLmThreads), bs_lds, st, A, dw, ds);
       if (G.max_nb_ln > 0) hipLaunchKernelGGL(ba_backsub_ln_big_kernel, dim3(G.max_nb_ln, nw), dim3(kLmThreads), bs_lds, st, A, dw, ds);
@@ -821,10 +832,18 @@ static int ba_batch_solve_impl(lld_ba_batch* B, StopFlag abort_flag) {
       if (G.max_nt_pt > 0) hipLaunchKernelGGL(ba_backsub_pt_kernel, dim3(G.max_nt_pt, nw), dim3(kLmThreads), bs_lds, st, A, dw, ds);
       if (G.max_nb_ln > 0) hipLaunchKernelGGL(ba_backsub_ln_kernel, dim3(G.max_nb_ln, nw), dim3(kLmThreads), bs_lds, st, A, dw, ds);
     }
-    LLD_HIP_TRY(hipEventRecord(G.ev[4], st));
+    LLD_HIP_TRY(hipEventRecord(ev[4], st));
     hipLaunchKernelGGL(ba_control_kernel, dim3(nw), dim3(kCtlThreads), 0, st, A, dw, ds, abort_now, G.d_counters, G.h_counters);   // totals land in pinned host memory
+    if (G.chunk > 1) {                                    // the round transition rides along (windows in PH_TRANSITION only)
+      hipLaunchKernelGGL(ba_classify_kernel, dim3(std::max(1, G.max_lblocks), nw), dim3(kLmThreads), 0, st, A, dw, ds);
+      hipLaunchKernelGGL(ba_round2_kernel, dim3(nw), dim3(kCtlThreads), 0, st, A, dw, ds);
+    }
     LLD_HIP_TRY(hipGetLastError());
-    LLD_HIP_TRY(hipEventRecord(G.ev[5], st));
+    LLD_HIP_TRY(hipEventRecord(ev[5], st));
+    return LLD_OK;
+  };
+  auto launch_chunk = [&](Group& G) -> int {
+    for (int q = 0; q < G.chunk; q++) { const int s_ = launch_superstep(G, q); if (s_) return s_; }
     return LLD_OK;
   };
 
@@ -844,7 +863,7 @@ static int ba_batch_solve_impl(lld_ba_batch* B, StopFlag abort_flag) {
       LLD_HIP_TRY(hipStreamSynchronize(G.st));
       finalize_group(G);
     } else {
-      int s = launch_superstep(G); if (s) return s;
+      int s = launch_chunk(G); if (s) return s;
     }
   }
   // round-robin over the groups: wait for a group's super-step, read its counters, queue its next one; the other groups'
@@ -853,30 +872,31 @@ static int ba_batch_solve_impl(lld_ba_batch* B, StopFlag abort_flag) {
     any = false;
     for (Group& G : B->groups) {
       if (!G.active) continue;
-      LLD_HIP_TRY(hipEventSynchronize(G.ev[5]));
-      for (int k = 0; k < kNumPhases; k++) {
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, G.ev[k], G.ev[k + 1]) == hipSuccess) B->phase_ms[k] += ms;
-        B->launches[k]++;
-      }
-      G.steps++; B->super_steps++;
+      LLD_HIP_TRY(hipEventSynchronize(G.ev[G.chunk - 1][5]));
+      for (int q = 0; q < G.chunk; q++)
+        for (int k = 0; k < kNumPhases; k++) {
+          float ms = 0.f;
+          if (hipEventElapsedTime(&ms, G.ev[q][k], G.ev[q][k + 1]) == hipSuccess) B->phase_ms[k] += ms;
+          B->launches[k]++;
+        }
+      G.steps += G.chunk; B->super_steps += G.chunk;
       const int n_run = G.h_counters[0], n_trans = G.h_counters[1], n_fin = G.h_counters[2];
       const BAWin* dw = B->d_wins + G.w0; BAState* ds = B->d_state + G.w0;
-      if (n_trans > 0) {
+      if (n_trans > 0 && G.chunk == 1) {
         hipLaunchKernelGGL(ba_classify_kernel, dim3(std::max(1, G.max_lblocks), G.nw), dim3(kLmThreads), 0, G.st, A, dw, ds);
         hipLaunchKernelGGL(ba_round2_kernel, dim3(G.nw), dim3(kCtlThreads), 0, G.st, A, dw, ds);
       }
       if (n_fin > 0) finalize_group(G);
       LLD_HIP_TRY(hipGetLastError());
       // a window whose classification leaves an empty active set goes straight to FINALIZE: the trailing read-back picks it up
-      if ((n_run + n_trans) > 0 && G.steps < kMaxSuperSteps) { int s = launch_superstep(G); if (s) return s; any = true; }
+      if ((n_run + n_trans) > 0 && G.steps < kMaxSuperSteps) { int s = launch_chunk(G); if (s) return s; any = true; }
       else G.active = false;
     }
   }
   for (Group& G : B->groups) {
     finalize_group(G);                       // windows sent straight to FINALIZE by ba_round2, or stopped by the hard limit
     LLD_HIP_TRY(hipGetLastError());
-    if (G.own_stream) { LLD_HIP_TRY(hipEventRecord(G.ev[0], G.st)); LLD_HIP_TRY(hipStreamWaitEvent(ctx->stream, G.ev[0], 0)); }
+    if (G.own_stream) { LLD_HIP_TRY(hipEventRecord(G.ev[0][0], G.st)); LLD_HIP_TRY(hipStreamWaitEvent(ctx->stream, G.ev[0][0], 0)); }
   }
   LLD_HIP_TRY(hipEventRecord(t_end, ctx->stream));
   LLD_HIP_TRY(hipEventSynchronize(t_end));

@@ -47,7 +47,7 @@ struct lld_ctx {
     hipEvent_t stage_free = nullptr; bool stage_pending = false;            // the arenas may be rewritten once this event has completed
     void* rec = nullptr; size_t rec_bytes = 0;                              // pinned landing buffer of the result records
     hipStream_t streams[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // group streams 1..7 (group 0 runs on ctx->stream)
-    hipEvent_t events[8][6] = {};
+    hipEvent_t events[8][4][6] = {};           // [group][super-step of a queued chunk][phase boundary]
     bool attrs_set = false;                  // hipFuncSetAttribute(max dynamic LDS) done for this device
   } ba;
 };

@@ -44,7 +44,7 @@ void lld_ctx_destroy(lld_ctx* ctx) {
   for (void* p : ctx->ba.stage) if (p) (void)hipHostFree(p);
   if (ctx->ba.rec) (void)hipHostFree(ctx->ba.rec);
   for (hipStream_t s : ctx->ba.streams) if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
-  for (auto& row : ctx->ba.events) for (hipEvent_t e : row) if (e) (void)hipEventDestroy(e);
+  for (auto& grp : ctx->ba.events) for (auto& row : grp) for (hipEvent_t e : row) if (e) (void)hipEventDestroy(e);
   delete ctx;
 }
 

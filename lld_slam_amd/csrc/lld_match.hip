@@ -18,7 +18,8 @@ namespace {
 
 constexpr int kWave = 64;
 constexpr int kMatchThreads = 256;             // 4 waves
-constexpr int kQPerBlock = 128;                // 2 queries per lane, all 4 waves see the same 128 queries
+constexpr int kQPerLane = 4;                   // queries per lane: one pair of broadcast LDS reads feeds kQPerLane distance computations
+constexpr int kQPerBlock = kQPerLane * 64;     // all 4 waves see the same 256 queries and split the train rows
 constexpr int kTileRows = 256;                 // train rows staged per LDS tile (8 KiB)
 constexpr unsigned kIdxBits = 22;              // packed key = dist << 22 | order  (order < 4 Mi)
 constexpr unsigned kKeyEmpty = (256u << kIdxBits) | ((1u << kIdxBits) - 1u);
@@ -36,25 +37,27 @@ __device__ __forceinline__ unsigned hamming8(const uint4& qa, const uint4& qb, c
   return d;
 }
 
-// grid (ceil(nq / 128), batch); block 256.
+// grid (ceil(nq / kQPerBlock), batch); block 256.
 __global__ __launch_bounds__(kMatchThreads) void hamming256_best2_kernel(
     const uint4* __restrict__ q, int nq, const uint4* __restrict__ t, int nt, const uint8_t* __restrict__ mask,
     int* __restrict__ best_idx, int* __restrict__ best_dist, int* __restrict__ second_idx, int* __restrict__ second_dist) {
   __shared__ uint4 tile[kTileRows * 2];                       // 8 KiB train tile
-  __shared__ unsigned merge[4][kQPerBlock][2];                // per-wave (best, second) keys, 4 KiB
+  __shared__ unsigned merge[4][kQPerBlock][2];                // per-wave (best, second) keys
   const int pair = blockIdx.y;
   q += (size_t)pair * nq * 2; t += (size_t)pair * nt * 2;
   const size_t out_off = (size_t)pair * nq;
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
-  const int q0 = blockIdx.x * kQPerBlock + lane, q1 = q0 + kWave;
-  const bool v0 = q0 < nq, v1 = q1 < nq;
-  uint4 a0 = make_uint4(0, 0, 0, 0), b0 = a0, a1 = a0, b1 = a0;
-  if (v0) { a0 = q[q0 * 2]; b0 = q[q0 * 2 + 1]; }
-  if (v1) { a1 = q[q1 * 2]; b1 = q[q1 * 2 + 1]; }
-  unsigned best0 = kKeyEmpty, sec0 = kKeyEmpty, best1 = kKeyEmpty, sec1 = kKeyEmpty;
-  const uint8_t* m0 = mask ? mask + ((size_t)pair * nq + (v0 ? q0 : 0)) * nt : nullptr;
-  const uint8_t* m1 = mask ? mask + ((size_t)pair * nq + (v1 ? q1 : 0)) * nt : nullptr;
-
+  uint4 qa[kQPerLane], qb[kQPerLane];
+  unsigned best[kQPerLane], sec[kQPerLane];
+  const uint8_t* mrow[kQPerLane];
+#pragma unroll
+  for (int k = 0; k < kQPerLane; k++) {
+    const int qk = blockIdx.x * kQPerBlock + k * kWave + lane;
+    const bool v = qk < nq;
+    qa[k] = v ? q[qk * 2] : make_uint4(0, 0, 0, 0); qb[k] = v ? q[qk * 2 + 1] : make_uint4(0, 0, 0, 0);
+    best[k] = kKeyEmpty; sec[k] = kKeyEmpty;
+    mrow[k] = mask ? mask + ((size_t)pair * nq + (v ? qk : 0)) * nt : nullptr;
+  }
   for (int base = 0; base < nt; base += kTileRows) {
     const int rows = min(kTileRows, nt - base);
     __syncthreads();                                           // previous tile fully consumed
@@ -64,24 +67,22 @@ __global__ __launch_bounds__(kMatchThreads) void hamming256_best2_kernel(
     for (int r = wave; r < rows; r += 4) {
       const uint4 ta = tile[r * 2], tb = tile[r * 2 + 1];
       const unsigned j = (unsigned)(base + r);
-      unsigned k0 = (hamming8(a0, b0, ta, tb) << kIdxBits) | j;
-      unsigned k1 = (hamming8(a1, b1, ta, tb) << kIdxBits) | j;
-      if (mask) {
-        if (!m0[j]) k0 = kKeyEmpty;
-        if (!m1[j]) k1 = kKeyEmpty;
+#pragma unroll
+      for (int k = 0; k < kQPerLane; k++) {
+        unsigned key = (hamming8(qa[k], qb[k], ta, tb) << kIdxBits) | j;
+        if (mask && !mrow[k][j]) key = kKeyEmpty;
+        key_update(key, best[k], sec[k]);
       }
-      key_update(k0, best0, sec0);
-      key_update(k1, best1, sec1);
     }
   }
-  merge[wave][lane][0] = best0; merge[wave][lane][1] = sec0;
-  merge[wave][lane + kWave][0] = best1; merge[wave][lane + kWave][1] = sec1;
+#pragma unroll
+  for (int k = 0; k < kQPerLane; k++) { merge[wave][k * kWave + lane][0] = best[k]; merge[wave][k * kWave + lane][1] = sec[k]; }
   __syncthreads();
-  if (threadIdx.x < kQPerBlock) {
-    const int qi = blockIdx.x * kQPerBlock + threadIdx.x;
+  for (int qo = threadIdx.x; qo < kQPerBlock; qo += kMatchThreads) {
+    const int qi = blockIdx.x * kQPerBlock + qo;
     if (qi < nq) {
       unsigned b = kKeyEmpty, s = kKeyEmpty;
-      for (int w = 0; w < 4; w++) { key_update(merge[w][threadIdx.x][0], b, s); key_update(merge[w][threadIdx.x][1], b, s); }
+      for (int w = 0; w < 4; w++) { key_update(merge[w][qo][0], b, s); key_update(merge[w][qo][1], b, s); }
       const unsigned idx_mask = (1u << kIdxBits) - 1u;
       best_idx[out_off + qi] = (b == kKeyEmpty) ? -1 : (int)(b & idx_mask);
       best_dist[out_off + qi] = (int)(b >> kIdxBits);
@@ -133,30 +134,52 @@ __global__ __launch_bounds__(kL2Threads) void l2f32_best2_kernel(
   for (int i = 0; i < DIM_MAX; i++) qa[i] = (valid && i < dim) ? q[(size_t)qi * dim + i] : 0.f;
   double bd = 1.7976931348623157e308, sd = 1.7976931348623157e308;
   int bi = -1, si = -1;
+  // a wavefront without a single query (300 queries in blocks of 256: three of the second block's four) only helps to stage the tiles
+  const bool wave_has_queries = blockIdx.x * kL2Threads + (threadIdx.x & ~63) < nq;
+#define LLD_L2_TAKE(DIST, J)                                                                              \
+  do {                                                                                                    \
+    const double dist_ = (DIST); const int j_ = (J);                                                      \
+    if (valid) {                                                                                          \
+      if (dist_matrix) dist_matrix[((size_t)pair * nq + qi) * nt + j_] = dist_;                           \
+      const bool cand_ = !mask || mask[((size_t)pair * nq + qi) * nt + j_];                               \
+      if (cand_) {                                                                                        \
+        if (dist_ < bd) { sd = bd; si = bi; bd = dist_; bi = j_; }                                        \
+        else if (dist_ < sd) { sd = dist_; si = j_; }                                                     \
+      }                                                                                                   \
+    }                                                                                                     \
+  } while (0)
   for (int base = 0; base < nt; base += kL2TileRows) {
     const int rows = min(kL2TileRows, nt - base);
     __syncthreads();
     for (int i = threadIdx.x; i < rows * dim; i += kL2Threads) tile[i] = t[(size_t)base * dim + i];
     __syncthreads();
-    for (int r = 0; r < rows; r++) {
+    if (!wave_has_queries) continue;
+    int r = 0;
+    // two train rows at a time: two independent accumulation chains (each row's sum keeps its own index order, so the result is
+    // bit-identical to the one-row loop and to the oracle)
+    for (; r + 1 < rows; r += 2) {
+      const float* tr0 = tile + r * dim; const float* tr1 = tr0 + dim;
+      double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+      for (int i = 0; i < DIM_MAX; i++) {
+        if (i < dim) {
+          const float d0 = qa[i] - tr0[i], d1 = qa[i] - tr1[i];
+          acc0 = fma((double)d0, (double)d0, acc0); acc1 = fma((double)d1, (double)d1, acc1);
+        }
+      }
+      LLD_L2_TAKE(sqrt(acc0), base + r); LLD_L2_TAKE(sqrt(acc1), base + r + 1);
+    }
+    for (; r < rows; r++) {
       const float* tr = tile + r * dim;
       double acc = 0.0;
 #pragma unroll
       for (int i = 0; i < DIM_MAX; i++) {
         if (i < dim) { const float d = qa[i] - tr[i]; acc = fma((double)d, (double)d, acc); }
       }
-      const double dist = sqrt(acc);
-      const int j = base + r;
-      if (valid) {
-        if (dist_matrix) dist_matrix[((size_t)pair * nq + qi) * nt + j] = dist;
-        const bool cand = !mask || mask[((size_t)pair * nq + qi) * nt + j];
-        if (cand) {
-          if (dist < bd) { sd = bd; si = bi; bd = dist; bi = j; }
-          else if (dist < sd) { sd = dist; si = j; }
-        }
-      }
+      LLD_L2_TAKE(sqrt(acc), base + r);
     }
   }
+#undef LLD_L2_TAKE
   if (valid) {
     best_idx[out_off + qi] = bi; best_dist[out_off + qi] = bd; second_idx[out_off + qi] = si; second_dist[out_off + qi] = sd;
   }
