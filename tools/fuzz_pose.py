@@ -14,6 +14,9 @@ for it in range(n):
               mono_frac=float(rng.choice([0.0, 0.0, 0.3, 1.0])), mono_line_frac=float(rng.choice([0.0, 0.0, 0.3, 1.0])))
     gamma = float(rng.choice([0.5, 0.5, 1.0, 0.1]))
     f = synth.make_pose_frame(5000 + it, seed=int(rng.integers(1, 2 ** 31)), **kw)
+    if f.n_lines and rng.random() < 0.5:                     # round 3: lines without a MapLine in between (lld_pose_problem::ln_frame_index)
+        import dataclasses
+        f = dataclasses.replace(f, ln_frame_index=(np.cumsum(rng.integers(1, 4, f.n_lines)) - 1).astype(np.int32))
     try:
         o = O.pose_opt(f, gamma=gamma)
         g = Optimizer(ctx).PoseOptimization(f, gamma=gamma)
