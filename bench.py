@@ -363,6 +363,9 @@ def main():
         # RCCL prints a version banner on stdout when its first communicator comes up: keep stdout for the one JSON line
         sys.stdout.flush(); saved_stdout = os.dup(1); os.dup2(2, 1)
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if world == 1:                                          # LLD_BENCH_FORCE_DIST without a launcher: a one-rank group of our own
+            for k_, v_ in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29577")):
+                os.environ.setdefault(k_, v_)
         dist.init_process_group("nccl", device_id=dev)          # RCCL
 
     ctx = Context(local_rank)
