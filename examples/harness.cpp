@@ -9,6 +9,7 @@
 //   harness orb  <in> <out>     ORBmatcher::BestTwo (brute force)
 //   harness lines <in> <out>    Tracking::AddLinesFrom + Tracking::MatchLinesLastKF
 //   harness init <in> <out>     ORBmatcher::SearchForInitialization
+//   harness loop <in> <out>     the relocalisation / Scw / SearchBySim3 matchers with their projection loops
 //
 // File layout: int32 header (counts), then the arrays in the order they appear in the structs, native endianness.
 #include <cstdio>
@@ -143,6 +144,59 @@ int run_init(const char* in, const char* out) {
   return 0;
 }
 
+// One keyframe / frame side of a projected search: keypoints, grid constants, scale table, occupancy
+struct OrbSide {
+  std::vector<uint32_t> desc; std::vector<float> xy, angle, scale; std::vector<int32_t> octave; std::vector<uint8_t> occupied;
+  lld_frame_view view; lld_orb_search s;
+  void read(Reader& r) {
+    int32_t h[2]; r.get(h, 2);                 // n keypoints, n levels
+    float g[4]; r.get(g, 4);                   // mnMinX, mnMinY, mfGridElementWidthInv, mfGridElementHeightInv
+    r.get(&view, 1);
+    r.get(desc, 8 * (size_t)h[0]); r.get(xy, 2 * (size_t)h[0]); r.get(octave, h[0]); r.get(angle, h[0]); r.get(occupied, h[0]); r.get(scale, h[1]);
+    s = lld_orb_search{};
+    s.nt = h[0]; s.t_desc = desc.data(); s.t_xy = xy.data(); s.t_octave = octave.data(); s.t_angle = angle.data();
+    s.grid_min_x = g[0]; s.grid_min_y = g[1]; s.grid_width_inv = g[2]; s.grid_height_inv = g[3]; s.grid_cols = 64; s.grid_rows = 48;
+    s.n_levels = h[1]; s.level_scale = scale.data();
+  }
+};
+struct OrbPoints {
+  std::vector<float> pos, nrm, maxd, mind, angle; std::vector<uint32_t> desc; std::vector<uint8_t> skip;
+  lld_map_points m;
+  void read(Reader& r) {
+    int32_t n; r.get(&n, 1);
+    r.get(pos, 3 * (size_t)n); r.get(nrm, 3 * (size_t)n); r.get(maxd, n); r.get(mind, n); r.get(desc, 8 * (size_t)n); r.get(skip, n); r.get(angle, n);
+    m = lld_map_points{};
+    m.n = n; m.world_pos = pos.data(); m.normal = nrm.data(); m.max_distance = maxd.data(); m.min_distance = mind.data(); m.desc = desc.data();
+    m.skip = skip.data();
+  }
+};
+
+// The relocalisation / loop-closing matchers through lld_amd::ORBmatcher: SearchByProjection(Frame&, KeyFrame*, ...),
+// SearchByProjection(KeyFrame*, Scw, ...), Fuse(KeyFrame*, Scw, ...) on one keyframe and SearchBySim3 on a pair.
+int run_loop(const char* in, const char* out) {
+  Reader r(in);
+  float p[4]; r.get(p, 4);                     // th (reloc), ORBdist, th (KF / Scw), th (Fuse)
+  OrbSide kf; kf.read(r);
+  OrbPoints pts; pts.read(r);
+  OrbSide k1, k2; OrbPoints p1, p2;
+  k1.read(r); p1.read(r); k2.read(r); p2.read(r);
+  float sim[25]; r.get(sim, 25);               // sR12 (9) t12 (3) sR21 (9) t21 (3) th
+  lld_amd::Context ctx(0);
+  lld_amd::ORBmatcher m(ctx, 0.9f, true);
+  lld_orb_search occupied = kf.s; occupied.t_occupied = kf.occupied.data();
+  const lld_amd::ORBmatcher::SearchResult reloc = m.SearchByProjection(occupied, kf.view, pts.m, pts.angle.data(), p[0], (int)p[1]);
+  const lld_amd::ORBmatcher::SearchResult scw = m.SearchByProjection(occupied, kf.view, pts.m, (int)p[2]);
+  const lld_amd::ORBmatcher::SearchResult fuse = m.Fuse(kf.s, kf.view, pts.m, p[3]);
+  std::vector<int32_t> m12;
+  const int found = m.SearchBySim3(k1.s, k1.view, p1.m, k2.s, k2.view, p2.m, sim, sim + 9, sim + 12, sim + 21, sim[24], m12);
+  Writer wr(out);
+  const int32_t counts[4] = {reloc.n_matches, scw.n_matches, fuse.n_matches, found};
+  wr.put(counts, 4);
+  wr.put(reloc.match); wr.put(reloc.removed); wr.put(scw.match); wr.put(fuse.match); wr.put(m12);
+  std::printf("loop: reloc %d, Scw projection %d, Scw fuse %d, SearchBySim3 %d\n", counts[0], counts[1], counts[2], counts[3]);
+  return 0;
+}
+
 int run_sim3(const char* in, const char* out) {
   Reader r(in);
   int32_t h[2]; r.get(h, 2);                   // n, bFixScale
@@ -168,7 +222,7 @@ int run_sim3(const char* in, const char* out) {
 }  // namespace
 
 int main(int argc, char** argv) {
-  if (argc != 4) { std::fprintf(stderr, "usage: harness ba|gba|pose|orb|sim3|lines|init <in> <out>\n"); return 2; }
+  if (argc != 4) { std::fprintf(stderr, "usage: harness ba|gba|pose|orb|sim3|lines|init|loop <in> <out>\n"); return 2; }
   try {
     if (!std::strcmp(argv[1], "ba")) return run_ba(argv[2], argv[3], false);
     if (!std::strcmp(argv[1], "gba")) return run_ba(argv[2], argv[3], true);
@@ -177,6 +231,7 @@ int main(int argc, char** argv) {
     if (!std::strcmp(argv[1], "orb")) return run_orb(argv[2], argv[3]);
     if (!std::strcmp(argv[1], "lines")) return run_lines(argv[2], argv[3]);
     if (!std::strcmp(argv[1], "init")) return run_init(argv[2], argv[3]);
+    if (!std::strcmp(argv[1], "loop")) return run_loop(argv[2], argv[3]);
     std::fprintf(stderr, "unknown mode %s\n", argv[1]);
     return 2;
   } catch (const std::exception& e) {

@@ -671,6 +671,51 @@ int lld_orb_search_last_frame(lld_ctx* ctx, const lld_orb_search* frame, const l
  * out->match[i] = bestIdx or -1, out->n_matches = nFused; the replace / add bookkeeping (:936-954) stays with the caller. */
 int lld_orb_fuse_search(lld_ctx* ctx, const lld_orb_search* keyframe, const lld_frame_view* view, const lld_map_points* points,
                         float th, float* proj_uvr_or_null, lld_orb_search_result* out);
+/* The matchers of relocalisation and loop closing WITH their projection loops on the device (round 3; before, the searches were
+ * mirrored and the per-query projections stayed with the adapter).  One entry point, four routines:
+ *   LLD_ORB_PROJ_KF_SIM3    ORBmatcher::SearchByProjection(KeyFrame*, Scw, vpPoints, vpMatched, th)      src/ORBmatcher.cc:290-403
+ *                           (LoopClosing::ComputeSim3): z >= 0, invz = 1/z, u = fx*(x*invz)+cx, KeyFrame::IsInImage, distance band,
+ *                           PO.dot(Pn) >= 0.5*dist, PredictScale, radius = th*scale[level], levels [l-1, l], keypoints with
+ *                           vpMatched[idx] skipped (frame->t_occupied) and taken ones blocking later points, bestDist <= TH_LOW.
+ *   LLD_ORB_PROJ_RELOC      ORBmatcher::SearchByProjection(Frame&, KeyFrame*, sAlreadyFound, th, ORBdist)  :1472-1599
+ *                           (Tracking::Relocalization): NO depth test, invzc = float(1.0/z), u = fx*xc*invzc+cx, frame bounds
+ *                           (u<min || u>max), distance band, PredictScale, radius = th*scale, levels [l-1, l+1], occupied keypoints
+ *                           (CurrentFrame.mvpMapPoints[i2], frame->t_occupied) skipped and blocking, bestDist <= accept_max (ORBdist),
+ *                           rotation histogram over `angle` (pKF->mvKeysUn[i].angle) when check_orientation.
+ *   LLD_ORB_PROJ_FUSE_SIM3  ORBmatcher::Fuse(KeyFrame*, Scw, vpPoints, th, vpReplacePoint)                :977-1100
+ *                           (LoopClosing::SearchAndFuse): projection as KF_SIM3, levels [l-1, l], no occupancy, bestDist <= TH_LOW;
+ *                           match[i] = bestIdx, the replace / add bookkeeping (:1078-1093) stays with the caller.
+ *   LLD_ORB_PROJ_SIM3_DIR   one direction of ORBmatcher::SearchBySim3                                     :1147-1224 / :1227-1304
+ *                           p3Dc1 = R1w*p3Dw+t1w (view), p3Dc2 = sR*p3Dc1+t (second cv::gemm, `sR`, `t` below), z >= 0, IsInImage,
+ *                           dist3D = cv::norm(p3Dc2), band, PredictScale, levels [l-1, l], bestDist <= TH_HIGH.  view->fx.. are pKF1's in
+ *                           both directions (:1105-1108), the bounds and the scale pyramid those of the keyframe searched in.
+ * `view` carries the DECOMPOSED transform (Rcw = sRcw/scw, tcw = Scw.col(3)/scw, Ow = -Rcw.t()*tcw, :298-303 - three OpenCV calls
+ * that stay with the adapter) and the intrinsics / image bounds of the keyframe or frame searched in; `points`: as for
+ * lld_orb_search_local_points (normal may be NULL for RELOC and SIM3_DIR; skip[i] = isBad / already found / vbAlreadyMatched;
+ * has_obs is ignored).  proj_uv [n][2] and level [n] (either may be NULL) return u, v and nPredictedLevel of the points that reach
+ * the window search.  Same OpenCV restatement as above (parity unpinned), bit-identical between device and oracle. */
+#define LLD_ORB_PROJ_KF_SIM3   0
+#define LLD_ORB_PROJ_RELOC     1
+#define LLD_ORB_PROJ_FUSE_SIM3 2
+#define LLD_ORB_PROJ_SIM3_DIR  3
+typedef struct {
+  int32_t routine;
+  float   th;
+  int32_t accept_max;         /* RELOC: ORBdist; ignored by the other routines (TH_LOW / TH_HIGH as listed) */
+  int32_t check_orientation;  /* RELOC only */
+  float   sR[9], t[3];        /* SIM3_DIR: sR21, t21 (KF1 -> KF2) or sR12, t12 (KF2 -> KF1), row-major */
+} lld_orb_projection;
+int lld_orb_search_projected(lld_ctx* ctx, const lld_orb_search* frame, const lld_frame_view* view, const lld_map_points* points,
+                             const float* angle_or_null, const lld_orb_projection* proj, float* proj_uv_or_null, int32_t* level_or_null,
+                             lld_orb_search_result* out);
+/* ORBmatcher::SearchBySim3 (src/ORBmatcher.cc:1102-1326) as a whole: both directions (two LLD_ORB_PROJ_SIM3_DIR searches) and the
+ * agreement check (:1306-1322).  kf1 / view1 / points1: KF1's keypoints, its pose (R1w, t1w) and its MapPoints per keypoint
+ * (skip[i] = !pMP || vbAlreadyMatched1[i] || isBad), likewise KF2; sR12, t12, sR21, t21 as the reference forms them (:1121-1124).
+ * match12[i1] = index of the KF2 keypoint whose MapPoint becomes vpMatches12[i1], or -1; returns nFound in *n_found. */
+int lld_orb_search_by_sim3(lld_ctx* ctx, const lld_orb_search* kf1, const lld_frame_view* view1, const lld_map_points* points1,
+                           const lld_orb_search* kf2, const lld_frame_view* view2, const lld_map_points* points2,
+                           const float* sR12, const float* t12, const float* sR21, const float* t21, float th,
+                           int32_t* match12 /* [points1->n] */, int32_t* n_found);
 /* ------------------------------------------------------------------ Frame::ComputeStereoMatches, whole routine
  * src/Frame.cc:530-704: (1) the row-band Hamming search (:536-613, the ROWS problem of lld_orb_search_run with the level gate
  * octave +-1, disparity range [0, mbf/mb] and bestDist < (TH_HIGH+TH_LOW)/2), (2) the sub-pixel refinement (:615-688): 11x11

@@ -210,6 +210,34 @@ class ORBmatcher {
     r.n_matches = o.n_matches; r.rounds = o.rounds;
     return r;
   }
+  // The relocalisation / loop-closing matchers with their projection loops on the device (include/lld_amd.h, LLD_ORB_PROJ_*):
+  //   SearchByProjection(Frame&, KeyFrame*, sAlreadyFound, th, ORBdist)   src/ORBmatcher.cc:1472-1599   (kfAngle = pKF->mvKeysUn[i].angle)
+  SearchResult SearchByProjection(const lld_orb_search& currentFrame, const lld_frame_view& view, const lld_map_points& kfPoints,
+                                  const float* kfAngle, float th, int ORBdist) const {
+    lld_orb_projection pr{}; pr.routine = LLD_ORB_PROJ_RELOC; pr.th = th; pr.accept_max = ORBdist; pr.check_orientation = mbCheckOrientation ? 1 : 0;
+    return Projected(currentFrame, view, kfPoints, kfAngle, pr);
+  }
+  //   SearchByProjection(KeyFrame*, Scw, vpPoints, vpMatched, th)         :290-403   (view = the decomposed Scw, frame.t_occupied = vpMatched[idx] != NULL)
+  SearchResult SearchByProjection(const lld_orb_search& keyFrame, const lld_frame_view& scwView, const lld_map_points& points, int th) const {
+    lld_orb_projection pr{}; pr.routine = LLD_ORB_PROJ_KF_SIM3; pr.th = (float)th;
+    return Projected(keyFrame, scwView, points, nullptr, pr);
+  }
+  //   Fuse(KeyFrame*, Scw, vpPoints, th, vpReplacePoint)                  :977-1100  (match[i] = bestIdx; the bookkeeping of :1078-1093 stays here)
+  SearchResult Fuse(const lld_orb_search& keyFrame, const lld_frame_view& scwView, const lld_map_points& points, float th) const {
+    lld_orb_projection pr{}; pr.routine = LLD_ORB_PROJ_FUSE_SIM3; pr.th = th;
+    return Projected(keyFrame, scwView, points, nullptr, pr);
+  }
+  //   SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th)            :1102-1326 (sR12 = s12*R12, sR21 = (1.0/s12)*R12.t(), t21 = -sR21*t12
+  //   formed by the caller, :1121-1124); vnMatch12[i1] = KF2 keypoint index or -1; returns nFound
+  int SearchBySim3(const lld_orb_search& kf1, const lld_frame_view& view1, const lld_map_points& points1, const lld_orb_search& kf2,
+                   const lld_frame_view& view2, const lld_map_points& points2, const float sR12[9], const float t12[3], const float sR21[9],
+                   const float t21[3], float th, std::vector<int32_t>& vnMatch12) const {
+    vnMatch12.assign(points1.n, -1);
+    int32_t found = 0, none = -1;
+    check(lld_orb_search_by_sim3(ctx_.get(), &kf1, &view1, &points1, &kf2, &view2, &points2, sR12, t12, sR21, t21, th,
+                                 points1.n ? vnMatch12.data() : &none, &found), "lld_orb_search_by_sim3");
+    return found;
+  }
   // SearchForInitialization(Frame& F1, Frame& F2, vbPrevMatched, vnMatches12, windowSize) (src/ORBmatcher.cc:405-520).  `f2` carries
   // the keypoints of F2 (nt, t_desc, t_xy, t_octave, t_angle) and the grid constants; the arrays of F1 have n1 rows.  vbPrevMatched
   // ([n1][2], in / out) and vnMatches12 are updated as the reference does; returns nmatches.
@@ -241,6 +269,17 @@ class ORBmatcher {
     return o.n_matches;
   }
  private:
+  SearchResult Projected(const lld_orb_search& frame, const lld_frame_view& view, const lld_map_points& points, const float* angle,
+                         const lld_orb_projection& pr) const {
+    SearchResult r;
+    r.match.resize(points.n); r.best_dist.resize(points.n); r.second_dist.resize(points.n); r.removed.resize(points.n); r.owner.resize(frame.nt);
+    lld_orb_search_result o{};
+    o.match = r.match.data(); o.best_dist = r.best_dist.data(); o.second_dist = r.second_dist.data(); o.removed = r.removed.data();
+    o.owner = r.owner.data();
+    check(lld_orb_search_projected(ctx_.get(), &frame, &view, &points, angle, &pr, nullptr, nullptr, &o), "lld_orb_search_projected");
+    r.n_matches = o.n_matches; r.rounds = o.rounds;
+    return r;
+  }
   Context& ctx_;
  public:
   float mfNNratio; bool mbCheckOrientation;

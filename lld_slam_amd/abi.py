@@ -185,7 +185,7 @@ PRODUCT_SYMBOLS = [
     "lld_match_hamming256", "lld_match_hamming256_csr", "lld_match_hamming256_batch_dev",
     "lld_match_l2f32", "lld_match_l2f32_batch_dev", "lld_line_match_greedy", "lld_line_match_stereo",
     "lld_line_track_match", "lld_line_hough_cells", "lld_line_match_last_frame",
-    "lld_orb_search_run", "lld_orb_search_batch", "lld_orb_search_local_points", "lld_orb_search_last_frame", "lld_orb_fuse_search",
+    "lld_orb_search_run", "lld_orb_search_batch", "lld_orb_search_local_points", "lld_orb_search_last_frame", "lld_orb_fuse_search", "lld_orb_search_projected", "lld_orb_search_by_sim3",
     "lld_compute_stereo_matches",
     "lld_sim3_params_default", "lld_optimize_sim3", "lld_optimize_sim3_batch",
     "lld_pose_graph_params_default", "lld_optimize_essential_graph",

@@ -701,6 +701,72 @@ __global__ __launch_bounds__(256) void project_fuse_kernel(FuseArgs F) {
   if (F.uvr) { F.uvr[3 * i] = u; F.uvr[3 * i + 1] = v; F.uvr[3 * i + 2] = ur; }
 }
 
+// Projection loops of the relocalisation / loop-closing matchers (lld_orb_search_projected), one lane per MapPoint; `routine` selects
+// the reference's sequence of tests and its float arithmetic (see include/lld_amd.h).
+struct ProjGenArgs {
+  lld_frame_view V;
+  int n, routine;
+  float sR[9], t2[3];
+  const float* pos; const float* nrm; const float* maxd; const float* mind; const uint8_t* skip; const float* angle;
+  float scale[LLD_ORB_MAX_LEVELS];
+  float th;
+  QRec* q; float* uv; int32_t* level;
+};
+
+__global__ __launch_bounds__(256) void project_general_kernel(ProjGenArgs F) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= F.n) return;
+  QRec Q; memset(&Q, 0, sizeof(Q));
+  Q.level_min = -1; Q.level_max = -1;
+  Q.angle = F.angle ? F.angle[i] : 0.f;
+  float u = 0.f, v = 0.f; int lvl = 0;
+  do {
+    if (F.skip && F.skip[i]) break;
+    const float P[3] = {F.pos[3 * i], F.pos[3 * i + 1], F.pos[3 * i + 2]};
+    float Pc[3]; cv_transform(F.V, P, Pc);                                       // Rcw*p3Dw+tcw: one cv::gemm
+    if (F.routine == LLD_ORB_PROJ_SIM3_DIR) {                                    // p3Dc2 = sR21*p3Dc1 + t21: a second cv::gemm
+      float P2[3];
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+        P2[r] = (float)__dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn((double)F.sR[3 * r], (double)Pc[0]), __dmul_rn((double)F.sR[3 * r + 1], (double)Pc[1])),
+                                           __dmul_rn((double)F.sR[3 * r + 2], (double)Pc[2])), (double)F.t2[r]);
+      Pc[0] = P2[0]; Pc[1] = P2[1]; Pc[2] = P2[2];
+    }
+    float dist;
+    if (F.routine == LLD_ORB_PROJ_RELOC) {
+      const float invzc = (float)__ddiv_rn(1.0, (double)Pc[2]);                 // const float invzc = 1.0/x3Dc.at<float>(2);  (no depth test, :1499-1503)
+      u = __fadd_rn(__fmul_rn(__fmul_rn(F.V.fx, Pc[0]), invzc), F.V.cx);
+      v = __fadd_rn(__fmul_rn(__fmul_rn(F.V.fy, Pc[1]), invzc), F.V.cy);
+      if (u < F.V.min_x || u > F.V.max_x) break;
+      if (v < F.V.min_y || v > F.V.max_y) break;
+    } else {
+      if (Pc[2] < 0.0f) break;
+      // `1/z` is a float division in :328, `1.0/z` a double one rounded to float in :1019, :1168, :1246
+      const float invz = F.routine == LLD_ORB_PROJ_KF_SIM3 ? __fdiv_rn(1.0f, Pc[2]) : (float)__ddiv_rn(1.0, (double)Pc[2]);
+      const float x = __fmul_rn(Pc[0], invz), y = __fmul_rn(Pc[1], invz);
+      u = __fadd_rn(__fmul_rn(F.V.fx, x), F.V.cx);
+      v = __fadd_rn(__fmul_rn(F.V.fy, y), F.V.cy);
+      if (!(u >= F.V.min_x && u < F.V.max_x && v >= F.V.min_y && v < F.V.max_y)) break;      // KeyFrame::IsInImage
+    }
+    const float maxDistance = __fmul_rn(1.2f, F.maxd[i]), minDistance = __fmul_rn(0.8f, F.mind[i]);
+    if (F.routine == LLD_ORB_PROJ_SIM3_DIR) dist = cv_norm3(Pc);                  // cv::norm(p3Dc2)
+    else {
+      const float PO[3] = {__fsub_rn(P[0], F.V.Ow[0]), __fsub_rn(P[1], F.V.Ow[1]), __fsub_rn(P[2], F.V.Ow[2])};
+      dist = cv_norm3(PO);
+      if (dist < minDistance || dist > maxDistance) break;
+      if (F.routine != LLD_ORB_PROJ_RELOC && cv_dot3(PO, F.nrm + 3 * i) < __dmul_rn(0.5, (double)dist)) break;   // PO.dot(Pn)<0.5*dist
+    }
+    if (dist < minDistance || dist > maxDistance) break;
+    lvl = predict_scale(F.maxd[i], dist, F.V);
+    Q.u = u; Q.v = v; Q.radius = __fmul_rn(F.th, F.scale[lvl]);
+    Q.level_min = lvl - 1; Q.level_max = F.routine == LLD_ORB_PROJ_RELOC ? lvl + 1 : lvl;
+    Q.flags = 1 | 2;                                                              // valid; a match blocks the keypoint for later points (routines with occupancy)
+  } while (false);
+  F.q[i] = Q;
+  if (F.uv) { F.uv[2 * i] = u; F.uv[2 * i + 1] = v; }
+  if (F.level) F.level[i] = lvl;
+}
+
 constexpr size_t kLdsLimit = 160 * 1024 - 512;
 constexpr int kRowBuckets = 512;           // ROWS mode: one bucket per (octave, image row); rows beyond are clamped into the last bucket of the octave
 
@@ -1099,5 +1165,99 @@ extern "C" int lld_orb_fuse_search(lld_ctx* ctx, const lld_orb_search* keyframe,
   }
   st = S.search_and_fetch(out); if (st) return st;
   if (nq && proj_uvr) std::memcpy(proj_uvr, S.h_out + r_uvr, (size_t)nq * 12);
+  return LLD_OK;
+}
+
+extern "C" int lld_orb_search_projected(lld_ctx* ctx, const lld_orb_search* frame, const lld_frame_view* view, const lld_map_points* mp,
+                                        const float* angle, const lld_orb_projection* proj, float* proj_uv, int32_t* level, lld_orb_search_result* out) {
+  if (!ctx || !frame || !view || !mp || !proj || !out) return LLD_ERR_INVALID;
+  const int routine = proj->routine;
+  if (routine < LLD_ORB_PROJ_KF_SIM3 || routine > LLD_ORB_PROJ_SIM3_DIR) return LLD_ERR_INVALID;
+  const bool reloc = routine == LLD_ORB_PROJ_RELOC, orient = reloc && proj->check_orientation != 0;
+  const bool need_normal = routine == LLD_ORB_PROJ_KF_SIM3 || routine == LLD_ORB_PROJ_FUSE_SIM3;
+  ProjSearch S{ctx, frame, frame->nt, mp->n, orient};
+  int st = S.check(out); if (st) return st;
+  const int nq = S.nq;
+  if (nq > 0 && (!mp->world_pos || !mp->max_distance || !mp->min_distance || !mp->desc || (need_normal && !mp->normal) || (orient && !angle))) return LLD_ERR_INVALID;
+  if (view->n_levels != frame->n_levels) return LLD_ERR_INVALID;
+  out->n_matches = 0; out->rounds = 0;
+  LLD_HIP_TRY(hipSetDevice(ctx->device));
+  S.layout();
+  const size_t o_pos = S.add_in((size_t)nq * 12), o_nrm = need_normal ? S.add_in((size_t)nq * 12) : 0, o_maxd = S.add_in((size_t)nq * 4), o_mind = S.add_in((size_t)nq * 4);
+  const size_t o_skip = mp->skip ? S.add_in((size_t)nq) : 0, o_ang = angle ? S.add_in((size_t)nq * 4) : 0;
+  const size_t r_uv = S.add_out((size_t)nq * 8), r_lvl = S.add_out((size_t)nq * 4);
+  st = S.alloc(); if (st) return st;
+  if (nq) {
+    std::memcpy(S.h + o_pos, mp->world_pos, (size_t)nq * 12);
+    if (need_normal) std::memcpy(S.h + o_nrm, mp->normal, (size_t)nq * 12);
+    std::memcpy(S.h + o_maxd, mp->max_distance, (size_t)nq * 4); std::memcpy(S.h + o_mind, mp->min_distance, (size_t)nq * 4);
+    if (mp->skip) std::memcpy(S.h + o_skip, mp->skip, (size_t)nq);
+    if (angle) std::memcpy(S.h + o_ang, angle, (size_t)nq * 4);
+  }
+  Problem& P = S.pack(mp->desc, out->owner != nullptr);
+  P.gates = LLD_ORB_GATE_LEVEL;
+  switch (routine) {
+    case LLD_ORB_PROJ_KF_SIM3: P.accept_max = 50; P.sequential = 1; break;                                   // TH_LOW (:394); vpMatched[bestIdx]=pMP inside the loop
+    case LLD_ORB_PROJ_RELOC: P.accept_max = proj->accept_max; P.sequential = 1; P.check_orientation = orient; break;   // ORBdist (:1555)
+    case LLD_ORB_PROJ_FUSE_SIM3: P.accept_max = 50; break;                                                   // TH_LOW (:1078)
+    default: P.accept_max = 100; break;                                                                      // TH_HIGH (:1220, :1300)
+  }
+  st = S.upload(); if (st) return st;
+  if (nq) {
+    ProjGenArgs F; std::memset(&F, 0, sizeof(F));
+    F.V = *view; F.n = nq; F.routine = routine;
+    for (int k = 0; k < 9; k++) F.sR[k] = proj->sR[k];
+    for (int k = 0; k < 3; k++) F.t2[k] = proj->t[k];
+    F.pos = reinterpret_cast<const float*>(S.d + o_pos); F.nrm = need_normal ? reinterpret_cast<const float*>(S.d + o_nrm) : nullptr;
+    F.maxd = reinterpret_cast<const float*>(S.d + o_maxd); F.mind = reinterpret_cast<const float*>(S.d + o_mind);
+    F.skip = mp->skip ? reinterpret_cast<const uint8_t*>(S.d + o_skip) : nullptr;
+    F.angle = angle ? reinterpret_cast<const float*>(S.d + o_ang) : nullptr;
+    for (int l = 0; l < LLD_ORB_MAX_LEVELS; l++) F.scale[l] = P.scale[l];
+    F.th = proj->th;
+    F.q = reinterpret_cast<QRec*>(S.d + S.o_q); F.uv = reinterpret_cast<float*>(S.d_out + r_uv); F.level = reinterpret_cast<int32_t*>(S.d_out + r_lvl);
+    hipLaunchKernelGGL(project_general_kernel, dim3((nq + 255) / 256), dim3(256), 0, ctx->stream, F);
+    LLD_HIP_TRY(hipGetLastError());
+  }
+  st = S.search_and_fetch(out); if (st) return st;
+  if (nq && proj_uv) std::memcpy(proj_uv, S.h_out + r_uv, (size_t)nq * 8);
+  if (nq && level) std::memcpy(level, S.h_out + r_lvl, (size_t)nq * 4);
+  return LLD_OK;
+}
+
+extern "C" int lld_orb_search_by_sim3(lld_ctx* ctx, const lld_orb_search* kf1, const lld_frame_view* view1, const lld_map_points* points1,
+                                      const lld_orb_search* kf2, const lld_frame_view* view2, const lld_map_points* points2,
+                                      const float* sR12, const float* t12, const float* sR21, const float* t21, float th, int32_t* match12, int32_t* n_found) {
+  if (!ctx || !kf1 || !kf2 || !view1 || !view2 || !points1 || !points2 || !sR12 || !t12 || !sR21 || !t21 || !match12 || !n_found) return LLD_ERR_INVALID;
+  const int n1 = points1->n, n2 = points2->n;
+  if (n1 != kf1->nt || n2 != kf2->nt) return LLD_ERR_INVALID;                   // vpMapPoints1 / 2 are per keypoint of their keyframe
+  std::vector<int32_t> m1((size_t)std::max(n1, 1)), m2((size_t)std::max(n2, 1)), bd((size_t)std::max(std::max(n1, n2), 1)), sd(bd.size());
+  std::vector<uint8_t> rem(bd.size());
+  lld_orb_projection pr; std::memset(&pr, 0, sizeof pr);
+  pr.routine = LLD_ORB_PROJ_SIM3_DIR; pr.th = th;
+  // KF1's MapPoints into KF2 (:1147-1224): camera 1 from world, then sR21 / t21; searched among KF2's keypoints
+  for (int k = 0; k < 9; k++) pr.sR[k] = sR21[k];
+  for (int k = 0; k < 3; k++) pr.t[k] = t21[k];
+  // pose R1w, t1w; fx, fy, cx, cy are pKF1's in BOTH directions (:1105-1108); IsInImage and PredictScale are pKF2's (:1176, :1188)
+  lld_frame_view v = *view1;
+  v.min_x = view2->min_x; v.max_x = view2->max_x; v.min_y = view2->min_y; v.max_y = view2->max_y;
+  v.log_scale_factor = view2->log_scale_factor; v.n_levels = view2->n_levels;
+  lld_orb_search_result r1{m1.data(), bd.data(), sd.data(), rem.data(), nullptr, 0, 0};
+  int st = lld_orb_search_projected(ctx, kf2, &v, points1, nullptr, &pr, nullptr, nullptr, &r1); if (st) return st;
+  // KF2's MapPoints into KF1 (:1227-1304)
+  for (int k = 0; k < 9; k++) pr.sR[k] = sR12[k];
+  for (int k = 0; k < 3; k++) pr.t[k] = t12[k];
+  v = *view2;                                                                   // pose R2w, t2w; pKF1's intrinsics, bounds and scale pyramid (:1256, :1268)
+  v.fx = view1->fx; v.fy = view1->fy; v.cx = view1->cx; v.cy = view1->cy; v.min_x = view1->min_x; v.max_x = view1->max_x; v.min_y = view1->min_y; v.max_y = view1->max_y;
+  v.log_scale_factor = view1->log_scale_factor; v.n_levels = view1->n_levels;
+  lld_orb_search_result r2{m2.data(), bd.data(), sd.data(), rem.data(), nullptr, 0, 0};
+  st = lld_orb_search_projected(ctx, kf1, &v, points2, nullptr, &pr, nullptr, nullptr, &r2); if (st) return st;
+  // agreement (:1306-1322)
+  int found = 0;
+  for (int i1 = 0; i1 < n1; i1++) {
+    const int idx2 = m1[i1];
+    match12[i1] = -1;
+    if (idx2 >= 0 && idx2 < n2 && m2[idx2] == i1) { match12[i1] = idx2; found++; }
+  }
+  *n_found = found;
   return LLD_OK;
 }

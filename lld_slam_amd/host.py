@@ -726,6 +726,30 @@ class ORBmatcher:
         from . import orb_search as S
         return S.fuse_search_points(self.lib, self.ctx.handle, KF, view, map_points, th)
 
+    def SearchByProjectionRelocPoints(self, Cur, view, map_points: dict, kf_angle, cur_occupied, th, ORBdist):
+        """SearchByProjection(Frame&, KeyFrame*, sAlreadyFound, th, ORBdist) with its projection loop on the device
+        (src/ORBmatcher.cc:1472-1599).  Returns (SearchOutput, uv, level)."""
+        from . import orb_search as S
+        return S.search_projected(self.lib, self.ctx.handle, Cur, view, map_points, S.PROJ_RELOC, th, accept_max=ORBdist,
+                                  check_orientation=self.mbCheckOrientation, angle=kf_angle, occupied=cur_occupied)
+
+    def SearchByProjectionKFPoints(self, KF, view, map_points: dict, matched, th):
+        """SearchByProjection(KeyFrame*, Scw, vpPoints, vpMatched, th) with its projection loop on the device
+        (src/ORBmatcher.cc:290-403); `view` = orb_search.sim3_view(Scw, ...)."""
+        from . import orb_search as S
+        return S.search_projected(self.lib, self.ctx.handle, KF, view, map_points, S.PROJ_KF_SIM3, int(th), occupied=matched)
+
+    def FuseSim3Points(self, KF, view, map_points: dict, th=4.0):
+        """Fuse(KeyFrame*, Scw, vpPoints, th, vpReplacePoint) with its projection loop on the device (src/ORBmatcher.cc:977-1100)."""
+        from . import orb_search as S
+        return S.search_projected(self.lib, self.ctx.handle, KF, view, map_points, S.PROJ_FUSE_SIM3, th)
+
+    def SearchBySim3Points(self, KF1, view1, points1, KF2, view2, points2, s12, R12, t12, th=7.5):
+        """SearchBySim3 (src/ORBmatcher.cc:1102-1326), projections and both searches on the device: (match12, nFound)."""
+        from . import orb_search as S
+        sR12, t12, sR21, t21 = S.sim3_transforms(s12, R12, t12)
+        return S.search_by_sim3_points(self.lib, self.ctx.handle, KF1, view1, points1, KF2, view2, points2, sR12, t12, sR21, t21, th)
+
     def SearchBySim3(self, KF1, KF2, q1, q2, th=7.5):
         """SearchBySim3 (src/ORBmatcher.cc:1102-1326)."""
         from . import orb_search as S

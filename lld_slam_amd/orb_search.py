@@ -480,7 +480,8 @@ def frame_view(Tcw, cam, F: Frame, scale_factor=1.2) -> FrameView:
 
 
 def map_points_struct(mp: dict):
-    keep = dict(world_pos=_f32(mp["world_pos"]).reshape(-1, 3), normal=_f32(mp["normal"]).reshape(-1, 3), max_distance=_f32(mp["max_distance"]),
+    nrm = _f32(mp.get("normal"))
+    keep = dict(world_pos=_f32(mp["world_pos"]).reshape(-1, 3), normal=None if nrm is None else nrm.reshape(-1, 3), max_distance=_f32(mp["max_distance"]),
                 min_distance=_f32(mp["min_distance"]), desc=np.ascontiguousarray(mp["desc"], np.uint32).reshape(-1, 8),
                 has_obs=_u8(mp.get("has_obs")), skip=_u8(mp.get("skip")))
     m = MapPoints()
@@ -568,3 +569,87 @@ def fuse_search_points(lib, ctx, KF: Frame, view: FrameView, mp: dict, th=3.0):
         raise RuntimeError(f"lld_orb_fuse_search failed: {lib.fn('status_string')(st).decode()}")
     out.n_matches, out.rounds = r.n_matches, r.rounds
     return out, uvr
+
+
+# ---------------------------------------------------------------------- relocalisation / loop closing with the projection on the device
+PROJ_KF_SIM3, PROJ_RELOC, PROJ_FUSE_SIM3, PROJ_SIM3_DIR = 0, 1, 2, 3
+
+
+class OrbProjection(C.Structure):
+    _fields_ = [("routine", C.c_int32), ("th", C.c_float), ("accept_max", C.c_int32), ("check_orientation", C.c_int32),
+                ("sR", C.c_float * 9), ("t", C.c_float * 3)]
+
+
+def sim3_view(Scw, cam, F: Frame, scale_factor=1.2) -> FrameView:
+    """The decomposition at the head of SearchByProjection(KeyFrame*, Scw, ...) and Fuse(KeyFrame*, Scw, ...)
+    (src/ORBmatcher.cc:298-303, :984-989) from a float32 4x4 Scw: scw = sqrt(sRcw.row(0).dot(sRcw.row(0))) (dot in double, sqrt of
+    the double, rounded to float), Rcw = sRcw/scw and tcw = Scw.col(3)/scw (cv::divide by a double scalar, rounded to float),
+    Ow = -Rcw.t()*tcw (one gemm).  These are the adapter's OpenCV calls; what the device needs is their result."""
+    S = np.asarray(Scw, np.float32).reshape(4, 4)
+    sR = S[:3, :3]
+    scw = np.float32(np.sqrt(np.dot(sR[0].astype(np.float64), sR[0].astype(np.float64))))
+    T = np.eye(4, dtype=np.float32)
+    T[:3, :3] = (sR.astype(np.float64) / np.float64(scw)).astype(np.float32)
+    T[:3, 3] = (S[:3, 3].astype(np.float64) / np.float64(scw)).astype(np.float32)
+    return frame_view(T, cam, F, scale_factor)
+
+
+def search_projected(lib, ctx, F: Frame, view: FrameView, mp: dict, routine: int, th, accept_max=0, check_orientation=False, angle=None,
+                     occupied=None, sR=None, t=None):
+    """lld_orb_search_projected: the matchers of relocalisation and loop closing (src/ORBmatcher.cc:290-403, :977-1100, :1147-1304,
+    :1472-1599) with their projection loops on the device.  Returns (SearchOutput, uv [n,2], level [n])."""
+    p = prepare(F, np.zeros((0, 8), np.uint32), candidates=CAND_GRID, accept_max=TH_HIGH, t_occupied=occupied,
+                check_orientation=bool(check_orientation) and routine == PROJ_RELOC)
+    m, keep = map_points_struct(mp)
+    n, nt = m.n, F.n
+    out = SearchOutput(np.empty(n, np.int32), np.empty(n, np.int32), np.empty(n, np.int32), np.empty(n, np.uint8), np.empty(nt, np.int32), 0, 0)
+    r = OrbSearchResult()
+    r.match = _p(out.match, c_int32_p); r.best_dist = _p(out.best_dist, c_int32_p); r.second_dist = _p(out.second_dist, c_int32_p)
+    r.removed = _p(out.removed, c_uint8_p); r.owner = _p(out.owner, c_int32_p)
+    pr = OrbProjection()
+    pr.routine, pr.th, pr.accept_max, pr.check_orientation = int(routine), float(np.float32(th)), int(accept_max), int(bool(check_orientation))
+    if sR is not None:
+        for i, x in enumerate(np.asarray(sR, np.float32).reshape(9)): pr.sR[i] = float(x)
+        for i, x in enumerate(np.asarray(t, np.float32).reshape(3)): pr.t[i] = float(x)
+    ang = _f32(angle)
+    uv = np.zeros((n, 2), np.float32); lvl = np.zeros(n, np.int32)
+    fn = lib.fn("orb_search_projected")
+    fn.argtypes = [C.c_void_p, C.POINTER(OrbSearch), C.POINTER(FrameView), C.POINTER(MapPoints), c_float_p, C.POINTER(OrbProjection), c_float_p,
+                   c_int32_p, C.POINTER(OrbSearchResult)]
+    fn.restype = C.c_int
+    st = fn(ctx, C.byref(p.s), C.byref(view), C.byref(m), _p(ang, c_float_p), C.byref(pr), _p(uv, c_float_p), _p(lvl, c_int32_p), C.byref(r))
+    if st != abi.LLD_OK:
+        raise RuntimeError(f"lld_orb_search_projected failed: {lib.fn('status_string')(st).decode()}")
+    out.n_matches, out.rounds = r.n_matches, r.rounds
+    return out, uv, lvl
+
+
+def sim3_transforms(s12, R12, t12):
+    """sR12 = s12*R12, sR21 = (1.0/s12)*R12.t(), t21 = -sR21*t12 (src/ORBmatcher.cc:1121-1124) as OpenCV evaluates them on CV_32F
+    matrices: scalar factors are doubles applied element-wise with one rounding, the product is one gemm."""
+    R12 = np.asarray(R12, np.float32).reshape(3, 3); t12 = np.asarray(t12, np.float32).reshape(3)
+    s12 = np.float32(s12)
+    sR12 = (np.float64(s12) * R12.astype(np.float64)).astype(np.float32)
+    sR21 = ((1.0 / np.float64(s12)) * R12.T.astype(np.float64)).astype(np.float32)
+    t21 = (-(sR21.astype(np.float64) @ t12.astype(np.float64))).astype(np.float32)
+    return sR12, t12, sR21, t21
+
+
+def search_by_sim3_points(lib, ctx, KF1: Frame, view1: FrameView, mp1: dict, KF2: Frame, view2: FrameView, mp2: dict, sR12, t12, sR21, t21, th=7.5):
+    """lld_orb_search_by_sim3: ORBmatcher::SearchBySim3 (src/ORBmatcher.cc:1102-1326) in one call.  Returns (match12 [N1], nFound)."""
+    p1 = prepare(KF1, np.zeros((0, 8), np.uint32), candidates=CAND_GRID, accept_max=TH_HIGH)
+    p2 = prepare(KF2, np.zeros((0, 8), np.uint32), candidates=CAND_GRID, accept_max=TH_HIGH)
+    m1, keep1 = map_points_struct(mp1)
+    m2, keep2 = map_points_struct(mp2)
+    arr = [np.ascontiguousarray(a, np.float32).reshape(-1) for a in (sR12, t12, sR21, t21)]
+    match12 = np.full(m1.n, -1, np.int32); nf = C.c_int32(0)
+    fn = lib.fn("orb_search_by_sim3")
+    fn.argtypes = [C.c_void_p, C.POINTER(OrbSearch), C.POINTER(FrameView), C.POINTER(MapPoints), C.POINTER(OrbSearch), C.POINTER(FrameView),
+                   C.POINTER(MapPoints), c_float_p, c_float_p, c_float_p, c_float_p, C.c_float, c_int32_p, C.POINTER(C.c_int32)]
+    fn.restype = C.c_int
+    st = fn(ctx, C.byref(p1.s), C.byref(view1), C.byref(m1), C.byref(p2.s), C.byref(view2), C.byref(m2), _p(arr[0], c_float_p), _p(arr[1], c_float_p),
+            _p(arr[2], c_float_p), _p(arr[3], c_float_p), float(np.float32(th)), _p(match12, c_int32_p), C.byref(nf))
+    if st != abi.LLD_OK:
+        raise RuntimeError(f"lld_orb_search_by_sim3 failed: {lib.fn('status_string')(st).decode()}")
+    return match12, int(nf.value)
+

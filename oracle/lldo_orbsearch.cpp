@@ -399,6 +399,32 @@ void lldo_search_sim3_direction(const lldo_frame* KF2, int n, const uint32_t* de
   }
 }
 
+// Inner search of ORBmatcher::Fuse(KeyFrame*, Scw, vpPoints, th, vpReplacePoint) (ORBmatcher.cc:1050-1093): no chi2 gate, no
+// occupancy; best[i] = bestIdx when bestDist<=TH_LOW, else -1; returns nFused
+int lldo_fuse_search_sim3(const lldo_frame* KF, int n, const uint32_t* desc, const uint8_t* valid, const float* uv,
+                          const int32_t* pred_level, float th, int32_t* best) {
+  const Grid g = build_grid(*KF);
+  int nFused = 0;
+  for (int iMP = 0; iMP < n; iMP++) {
+    best[iMP] = -1;
+    if (!valid[iMP]) continue;
+    const int nPredictedLevel = pred_level[iMP];
+    const float radius = th * KF->scale[nPredictedLevel];
+    const std::vector<int> vIndices = features_in_area(*KF, g, uv[2 * iMP], uv[2 * iMP + 1], radius);
+    if (vIndices.empty()) continue;
+    int bestDist = INT_MAX, bestIdx = -1;
+    for (size_t c = 0; c < vIndices.size(); c++) {
+      const int idx = vIndices[c];
+      const int kpLevel = KF->octave[idx];
+      if (kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel) continue;
+      const int dist = lldo_descriptor_distance(desc + 8 * iMP, KF->desc + 8 * idx);
+      if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+    }
+    if (bestDist <= TH_LOW) { best[iMP] = bestIdx; nFused++; }
+  }
+  return nFused;
+}
+
 // ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches)   ORBmatcher.cc:159-288
 //   the two FeatureVectors arrive as the list of COMMON nodes in ascending node id (what the merge loop :183-251 visits):
 //   node n holds KF indices kf_idx[kf_start[n]..kf_start[n+1]) and F indices f_idx[f_start[n]..).  kf_valid[k] = pMP && !isBad.
@@ -770,6 +796,73 @@ void lldo_project_fuse(const lld_frame_view* V, const lld_map_points* mp, uint8_
     int nScale = (int)std::ceil(std::log(ratio) / V->log_scale_factor);
     if (nScale < 0) nScale = 0; else if (nScale >= V->n_levels) nScale = V->n_levels - 1;
     valid_out[i] = 1; uv[2 * i] = u; uv[2 * i + 1] = v; ur_out[i] = ur; level[i] = nScale;
+  }
+}
+
+// Projection loops of the relocalisation / loop-closing matchers, `routine` as LLD_ORB_PROJ_* (include/lld_amd.h):
+//   0 SearchByProjection(KeyFrame*, Scw, ...) src/ORBmatcher.cc:311-358      2 Fuse(KeyFrame*, Scw, ...) :1000-1048
+//   1 SearchByProjection(Frame&, KeyFrame*, ...) :1487-1531                   3 one direction of SearchBySim3 :1152-1191 / :1232-1271
+// valid_out, uv, predicted level of the points that reach GetFeaturesInArea.  sR / t: second transform of routine 3 only.
+void lldo_project_general(const lld_frame_view* V, const lld_map_points* mp, int routine, const float* sR, const float* t,
+                          uint8_t* valid_out, float* uv, int32_t* level) {
+  for (int i = 0; i < mp->n; i++) {
+    valid_out[i] = 0; uv[2 * i] = uv[2 * i + 1] = 0.f; level[i] = 0;
+    if (mp->skip && mp->skip[i]) continue;
+    const float* P = mp->world_pos + 3 * i;
+    float p3Dc[3];
+    for (int r = 0; r < 3; r++) {                                              // Rcw*p3Dw+tcw
+      double s0 = 0.0;
+      for (int k = 0; k < 3; k++) s0 += (double)V->Rcw[3 * r + k] * (double)P[k];
+      p3Dc[r] = (float)(s0 + (double)V->tcw[r]);
+    }
+    if (routine == 3) {                                                        // p3Dc2 = sR21*p3Dc1 + t21
+      float q[3];
+      for (int r = 0; r < 3; r++) {
+        double s0 = 0.0;
+        for (int k = 0; k < 3; k++) s0 += (double)sR[3 * r + k] * (double)p3Dc[k];
+        q[r] = (float)(s0 + (double)t[r]);
+      }
+      p3Dc[0] = q[0]; p3Dc[1] = q[1]; p3Dc[2] = q[2];
+    }
+    float u, v;
+    if (routine == 1) {
+      const float xc = p3Dc[0];
+      const float yc = p3Dc[1];
+      const float invzc = 1.0 / p3Dc[2];
+      u = V->fx * xc * invzc + V->cx;
+      v = V->fy * yc * invzc + V->cy;
+      if (u < V->min_x || u > V->max_x) continue;
+      if (v < V->min_y || v > V->max_y) continue;
+    } else {
+      if (p3Dc[2] < 0.0) continue;
+      float invz;
+      if (routine == 0) invz = 1 / p3Dc[2]; else invz = 1.0 / p3Dc[2];
+      const float x = p3Dc[0] * invz;
+      const float y = p3Dc[1] * invz;
+      u = V->fx * x + V->cx;
+      v = V->fy * y + V->cy;
+      if (!(u >= V->min_x && u < V->max_x && v >= V->min_y && v < V->max_y)) continue;      // KeyFrame::IsInImage
+    }
+    const float maxDistance = 1.2f * mp->max_distance[i], minDistance = 0.8f * mp->min_distance[i];
+    float dist;
+    if (routine == 3) {
+      double n2 = 0.0; for (int k = 0; k < 3; k++) n2 += (double)p3Dc[k] * (double)p3Dc[k];
+      dist = (float)std::sqrt(n2);
+      if (dist < minDistance || dist > maxDistance) continue;
+    } else {
+      const float PO[3] = {P[0] - V->Ow[0], P[1] - V->Ow[1], P[2] - V->Ow[2]};
+      double n2 = 0.0; for (int k = 0; k < 3; k++) n2 += (double)PO[k] * (double)PO[k];
+      dist = (float)std::sqrt(n2);
+      if (dist < minDistance || dist > maxDistance) continue;
+      if (routine != 1) {
+        double dotv = 0.0; for (int k = 0; k < 3; k++) dotv += (double)PO[k] * (double)mp->normal[3 * i + k];
+        if (dotv < 0.5 * dist) continue;
+      }
+    }
+    const float ratio = mp->max_distance[i] / dist;
+    int nScale = (int)std::ceil(std::log(ratio) / V->log_scale_factor);
+    if (nScale < 0) nScale = 0; else if (nScale >= V->n_levels) nScale = V->n_levels - 1;
+    valid_out[i] = 1; uv[2 * i] = u; uv[2 * i + 1] = v; level[i] = nScale;
   }
 }
 

@@ -142,6 +142,18 @@ def fuse_search(KF, desc, valid, uv, ur, pred_level, th=3.0):
     return n, best
 
 
+def fuse_search_sim3(KF, desc, valid, uv, pred_level, th=4.0):
+    """Inner search of Fuse(KeyFrame*, Scw, ...): (nFused, bestIdx or -1 per point)."""
+    a = [_u32(desc), _u8(valid), _f32(uv), _i32(pred_level)]
+    best = np.empty(a[0].shape[0], np.int32)
+    d = _dll()
+    d.lldo_fuse_search_sim3.argtypes = [C.POINTER(OFrame), C.c_int, c_uint32_p, c_uint8_p, c_float_p, c_int32_p, C.c_float, c_int32_p]
+    d.lldo_fuse_search_sim3.restype = C.c_int
+    n = d.lldo_fuse_search_sim3(C.byref(oframe(KF)), a[0].shape[0], _p(a[0], c_uint32_p), _p(a[1], c_uint8_p), _p(a[2], c_float_p), _p(a[3], c_int32_p),
+                                th, _p(best, c_int32_p))
+    return n, best
+
+
 def search_sim3_direction(KF2, desc, valid, uv, pred_level, th=7.5):
     a = [_u32(desc), _u8(valid), _f32(uv), _i32(pred_level)]
     m = np.empty(a[0].shape[0], np.int32)
@@ -245,3 +257,20 @@ def project_fuse(view, mp: dict):
     valid = np.zeros(n, np.uint8); uv = np.zeros((n, 2), np.float32); ur = np.zeros(n, np.float32); lvl = np.zeros(n, np.int32)
     d.lldo_project_fuse(C.byref(view), C.byref(m), _p(valid, c_uint8_p), _p(uv, c_float_p), _p(ur, c_float_p), _p(lvl, c_int32_p))
     return valid, uv, ur, lvl
+
+
+def project_general(view, mp: dict, routine: int, sR=None, t=None):
+    """Projection loops of SearchByProjection(KeyFrame*, Scw) / SearchByProjection(Frame&, KeyFrame*) / Fuse(KeyFrame*, Scw) /
+    one direction of SearchBySim3 (routine 0..3): (valid, uv [n,2], level [n])."""
+    from lld_slam_amd.orb_search import FrameView, MapPoints, map_points_struct
+    d = _dll()
+    d.lldo_project_general.argtypes = [C.POINTER(FrameView), C.POINTER(MapPoints), C.c_int, c_float_p, c_float_p, c_uint8_p, c_float_p, c_int32_p]
+    d.lldo_project_general.restype = None
+    m, keep = map_points_struct(mp)
+    n = m.n
+    sR = np.ascontiguousarray(np.zeros(9) if sR is None else sR, np.float32).reshape(9)
+    t = np.ascontiguousarray(np.zeros(3) if t is None else t, np.float32).reshape(3)
+    valid = np.zeros(n, np.uint8); uv = np.zeros((n, 2), np.float32); lvl = np.zeros(n, np.int32)
+    d.lldo_project_general(C.byref(view), C.byref(m), int(routine), _p(sR, c_float_p), _p(t, c_float_p), _p(valid, c_uint8_p), _p(uv, c_float_p),
+                           _p(lvl, c_int32_p))
+    return valid, uv, lvl

@@ -212,3 +212,81 @@ def test_harness_search_for_initialization(harness, tmp_path):
         n = int(np.fromfile(f, np.int32, 1)[0]); m = np.fromfile(f, np.int32, F1.n); pm = np.fromfile(f, np.float32, 2 * F1.n).reshape(-1, 2)
     assert n == on and on > 100
     np.testing.assert_array_equal(m, om); np.testing.assert_array_equal(pm, opm)
+
+
+def _write_side(f, F, view, occupied):
+    import ctypes
+    np.array([F.n, F.scale.shape[0]], np.int32).tofile(f)
+    np.array([F.min_x, F.min_y, F.width_inv, F.height_inv], np.float32).tofile(f)
+    f.write(bytes(memoryview(ctypes.string_at(ctypes.addressof(view), ctypes.sizeof(view)))))
+    np.ascontiguousarray(F.desc, np.uint32).tofile(f); np.ascontiguousarray(F.xy, np.float32).tofile(f); np.ascontiguousarray(F.octave, np.int32).tofile(f)
+    np.ascontiguousarray(F.angle, np.float32).tofile(f); np.ascontiguousarray(occupied, np.uint8).tofile(f); np.ascontiguousarray(F.scale, np.float32).tofile(f)
+
+
+def _write_points(f, mp, angle):
+    n = mp["world_pos"].shape[0]
+    np.array([n], np.int32).tofile(f)
+    for k, t in (("world_pos", np.float32), ("normal", np.float32), ("max_distance", np.float32), ("min_distance", np.float32), ("desc", np.uint32),
+                 ("skip", np.uint8)):
+        np.ascontiguousarray(mp[k], t).tofile(f)
+    np.ascontiguousarray(angle, np.float32).tofile(f)
+
+
+@pytest.mark.gpu
+def test_harness_relocalisation_and_loop_closing_matchers(harness, tmp_path):
+    """lld_amd::ORBmatcher's SearchByProjection(Frame&, KeyFrame*) / SearchByProjection(KeyFrame*, Scw) / Fuse(KeyFrame*, Scw) /
+    SearchBySim3 (include/lld_amd.hpp) with the projection loops on the device, against the oracle."""
+    import oracle_orbsearch as OS
+    from lld_slam_amd import orb_search, synth
+    KF = synth.make_orb_frame(300, 1500).normalise()
+    T, mp = synth.make_local_map(KF, 300, 1800)
+    view = orb_search.frame_view(T, synth.KITTI_CAM, KF)
+    ang = np.mod(KF.angle[mp["src"]] + 30.0, 360.0).astype(np.float32)
+    K1 = synth.make_orb_frame(301, 1200).normalise(); K2 = synth.make_orb_frame(302, 1100).normalise()
+    T2, mp1 = synth.make_local_map(K2, 301, K1.n); T1, mp2 = synth.make_local_map(K1, 302, K2.n)
+    v1 = orb_search.frame_view(T1, synth.KITTI_CAM, K1); v2 = orb_search.frame_view(T2, synth.KITTI_CAM, K2)
+    R1, t1, R2, t2 = T1[:3, :3].astype(np.float64), T1[:3, 3].astype(np.float64), T2[:3, :3].astype(np.float64), T2[:3, 3].astype(np.float64)
+    R12 = R1 @ R2.T; t12 = t1 - R12 @ t2
+    sR12, t12f, sR21, t21 = orb_search.sim3_transforms(1.0, R12, t12)
+    with open(tmp_path / "in.bin", "wb") as f:
+        np.array([10.0, 100.0, 10.0, 4.0], np.float32).tofile(f)
+        _write_side(f, KF, view, mp["occupied"]); _write_points(f, mp, ang)
+        _write_side(f, K1, v1, np.zeros(K1.n, np.uint8)); _write_points(f, mp1, np.zeros(K1.n, np.float32))
+        _write_side(f, K2, v2, np.zeros(K2.n, np.uint8)); _write_points(f, mp2, np.zeros(K2.n, np.float32))
+        np.concatenate([sR12.reshape(9), t12f, sR21.reshape(9), t21, [7.5]]).astype(np.float32).tofile(f)
+    r = run(harness, "loop", tmp_path)
+    assert r.returncode == 0, r.stderr
+    n = mp["world_pos"].shape[0]
+    with open(tmp_path / "out.bin", "rb") as f:
+        counts = np.fromfile(f, np.int32, 4); reloc = np.fromfile(f, np.int32, n); removed = np.fromfile(f, np.uint8, n)
+        scw = np.fromfile(f, np.int32, n); fuse = np.fromfile(f, np.int32, n); m12 = np.fromfile(f, np.int32, K1.n)
+
+    def slots(match, rem):
+        s = OS.slots_from_occupied(mp["occupied"])
+        ok = (match >= 0) & (rem == 0)
+        s[match[ok]] = np.nonzero(ok)[0]
+        return s
+    va, uva, la = OS.project_general(view, mp, orb_search.PROJ_RELOC)
+    n_exp, slot = OS.search_by_projection_reloc(KF, mp["desc"], va, uva, la, ang, mp["occupied"], 10.0, 100, True)
+    assert counts[0] == n_exp and n_exp > 100
+    np.testing.assert_array_equal(slots(reloc, removed), slot)
+    vb, uvb, lb = OS.project_general(view, mp, orb_search.PROJ_KF_SIM3)
+    n_exp, slot = OS.search_by_projection_kf(KF, mp["desc"], vb, uvb, lb, mp["occupied"], 10)
+    assert counts[1] == n_exp and n_exp > 100
+    np.testing.assert_array_equal(slots(scw, np.zeros(n, np.uint8)), slot)
+    vc, uvc, lc = OS.project_general(view, mp, orb_search.PROJ_FUSE_SIM3)
+    n_exp, best = OS.fuse_search_sim3(KF, mp["desc"], vc, uvc, lc, 4.0)
+    assert counts[2] == n_exp and n_exp > 100
+    np.testing.assert_array_equal(fuse, best)
+    mix = orb_search.FrameView.from_buffer_copy(v1)
+    mix.min_x, mix.max_x, mix.min_y, mix.max_y, mix.log_scale_factor, mix.n_levels = v2.min_x, v2.max_x, v2.min_y, v2.max_y, v2.log_scale_factor, v2.n_levels
+    vd, uvd, ld = OS.project_general(mix, mp1, orb_search.PROJ_SIM3_DIR, sR21, t21)
+    mix2 = orb_search.FrameView.from_buffer_copy(v2)
+    mix2.fx, mix2.fy, mix2.cx, mix2.cy = v1.fx, v1.fy, v1.cx, v1.cy
+    mix2.min_x, mix2.max_x, mix2.min_y, mix2.max_y, mix2.log_scale_factor, mix2.n_levels = v1.min_x, v1.max_x, v1.min_y, v1.max_y, v1.log_scale_factor, v1.n_levels
+    ve, uve, le = OS.project_general(mix2, mp2, orb_search.PROJ_SIM3_DIR, sR12, t12f)
+    a = OS.search_sim3_direction(K2, mp1["desc"], vd, uvd, ld, 7.5); b = OS.search_sim3_direction(K1, mp2["desc"], ve, uve, le, 7.5)
+    exp = np.array([a[i] if a[i] >= 0 and b[a[i]] == i else -1 for i in range(K1.n)], np.int32)
+    np.testing.assert_array_equal(m12, exp)
+    assert counts[3] == int((exp >= 0).sum())
+

@@ -291,6 +291,153 @@ def test_fuse_projection_and_search_on_device(gpu_ctx, seed, th):
     np.testing.assert_array_equal(out.match, best)
 
 
+# ---------------------------------------------------------------------- relocalisation / loop-closing matchers, projection on the device
+def _sim3_of(T, s):
+    """Scw whose decomposition (src/ORBmatcher.cc:298-303) gives back T's rotation and translation up to float rounding."""
+    S = np.array(T, np.float32, copy=True)
+    S[:3, :] = (np.float64(s) * T[:3, :].astype(np.float64)).astype(np.float32)
+    return S
+
+
+@pytest.mark.parametrize("seed,th,orbdist", [(0, 10.0, 100), (1, 3.0, 64)])
+def test_relocalisation_projection_and_search_on_device(gpu_ctx, seed, th, orbdist):
+    """Tracking::Relocalization's matcher: no depth test, invzc = float(1.0/z), inclusive frame bounds, three octaves, occupancy
+    by CurrentFrame.mvpMapPoints and the rotation histogram over the keyframe's keypoint angles."""
+    F = synth.make_orb_frame(160 + seed, 2000)
+    T, mp = synth.make_local_map(F, 160 + seed, 2200)
+    rng = np.random.default_rng(160 + seed)
+    ang = np.mod(F.angle[mp["src"]] + 40.0 + rng.normal(0, 6.0, 2200), 360.0)
+    wild = rng.random(2200) < 0.15; ang[wild] = rng.uniform(0, 360, int(wild.sum()))
+    ang = ang.astype(np.float32)
+    view = orb_search.frame_view(T, synth.KITTI_CAM, F)
+    m = ORBmatcher(gpu_ctx, 0.9, True)
+    out, uv, lvl = m.SearchByProjectionRelocPoints(F, view, mp, ang, mp["occupied"], th, orbdist)
+    valid, uv_o, lvl_o = OS.project_general(view, mp, orb_search.PROJ_RELOC)
+    k = valid != 0
+    assert 800 < k.sum() < 2100
+    np.testing.assert_array_equal(uv[k], uv_o[k]); np.testing.assert_array_equal(lvl[k], lvl_o[k])
+    n_exp, slot = OS.search_by_projection_reloc(F, mp["desc"], valid, uv_o, lvl_o, ang, mp["occupied"], th, orbdist, True)
+    assert out.n_matches == n_exp and n_exp > 150 and out.removed.sum() > 0
+    np.testing.assert_array_equal(expect_slots(out, mp["occupied"]), slot)
+    # without the normals (the routine never reads them) and without the orientation check
+    bare = {k2: v for k2, v in mp.items() if k2 != "normal"}
+    out2, _, _ = ORBmatcher(gpu_ctx, 0.9, False).SearchByProjectionRelocPoints(F, view, bare, None, mp["occupied"], th, orbdist)
+    n2, slot2 = OS.search_by_projection_reloc(F, mp["desc"], valid, uv_o, lvl_o, ang, mp["occupied"], th, orbdist, False)
+    assert out2.n_matches == n2
+    np.testing.assert_array_equal(expect_slots(out2, mp["occupied"]), slot2)
+
+
+@pytest.mark.parametrize("seed,scale,th", [(0, 1.0, 10), (1, 1.37, 10), (2, 0.61, 6)])
+def test_keyframe_sim3_projection_and_search_on_device(gpu_ctx, seed, scale, th):
+    """LoopClosing::ComputeSim3's matcher: SearchByProjection(KeyFrame*, Scw, vpPoints, vpMatched, th)."""
+    KF = synth.make_orb_frame(170 + seed, 2000)
+    T, mp = synth.make_local_map(KF, 170 + seed, 2500)
+    view = orb_search.sim3_view(_sim3_of(T, scale), synth.KITTI_CAM, KF)
+    out, uv, lvl = ORBmatcher(gpu_ctx, 0.75).SearchByProjectionKFPoints(KF, view, mp, mp["occupied"], th)
+    valid, uv_o, lvl_o = OS.project_general(view, mp, orb_search.PROJ_KF_SIM3)
+    k = valid != 0
+    assert 800 < k.sum() < 2400
+    np.testing.assert_array_equal(uv[k], uv_o[k]); np.testing.assert_array_equal(lvl[k], lvl_o[k])
+    n_exp, slot = OS.search_by_projection_kf(KF, mp["desc"], valid, uv_o, lvl_o, mp["occupied"], th)
+    assert out.n_matches == n_exp and n_exp > 150
+    np.testing.assert_array_equal(expect_slots(out, mp["occupied"]), slot)
+
+
+@pytest.mark.parametrize("seed,scale,th", [(0, 1.0, 4.0), (1, 0.83, 3.0)])
+def test_fuse_sim3_projection_and_search_on_device(gpu_ctx, seed, scale, th):
+    """LoopClosing::SearchAndFuse's matcher: Fuse(KeyFrame*, Scw, vpPoints, th, vpReplacePoint) - no chi2 gate, no occupancy."""
+    KF = synth.make_orb_frame(180 + seed, 2000)
+    T, mp = synth.make_local_map(KF, 180 + seed, 2500)
+    view = orb_search.sim3_view(_sim3_of(T, scale), synth.KITTI_CAM, KF)
+    out, uv, lvl = ORBmatcher(gpu_ctx).FuseSim3Points(KF, view, mp, th)
+    valid, uv_o, lvl_o = OS.project_general(view, mp, orb_search.PROJ_FUSE_SIM3)
+    k = valid != 0
+    np.testing.assert_array_equal(uv[k], uv_o[k]); np.testing.assert_array_equal(lvl[k], lvl_o[k])
+    n_exp, best = OS.fuse_search_sim3(KF, mp["desc"], valid, uv_o, lvl_o, th)
+    assert out.n_matches == n_exp and n_exp > 100 and out.rounds == 1
+    np.testing.assert_array_equal(out.match, best)
+
+
+def _sim3_pair(seed, s12):
+    """Two keyframes with MapPoints per keypoint: KF1's points project onto KF2's keypoints through S21 and vice versa; the entries
+    are ordered so that a good share of the two directions agrees (src/ORBmatcher.cc:1306-1322)."""
+    KF1 = synth.make_orb_frame(190 + seed, 1800); KF2 = synth.make_orb_frame(195 + seed, 1700)
+    T2, mp1 = synth.make_local_map(KF2, 190 + seed, KF1.n)                  # KF1's MapPoints, seen by KF2 at its keypoints src
+    T1, mp2 = synth.make_local_map(KF1, 195 + seed, KF2.n)                  # KF2's MapPoints, seen by KF1
+    want = mp2["src"][mp1["src"]]                                             # KF1 keypoint that the partner of entry e was drawn from
+    order = np.full(KF1.n, -1, np.int64); used = np.zeros(KF1.n, bool)
+    for e in range(KF1.n):
+        if order[want[e]] < 0: order[want[e]] = e; used[e] = True
+    order[order < 0] = np.nonzero(~used)[0]
+    mp1 = {k: (v[order] if k != "occupied" else v) for k, v in mp1.items()}
+    R1, t1 = T1[:3, :3].astype(np.float64), T1[:3, 3].astype(np.float64)
+    R2, t2 = T2[:3, :3].astype(np.float64), T2[:3, 3].astype(np.float64)
+    R12 = R1 @ R2.T                                                           # cam1 = s12*R12*cam2 + t12
+    t12 = t1 - s12 * R12 @ t2
+    return KF1, T1, mp1, KF2, T2, mp2, R12.astype(np.float32), t12.astype(np.float32)
+
+
+@pytest.mark.parametrize("seed,s12,th", [(0, 1.0, 7.5), (1, 1.04, 7.5)])
+def test_search_by_sim3_whole_routine_on_device(gpu_ctx, seed, s12, th):
+    """LoopClosing::ComputeSim3's guided matcher: both projection loops (two gemms each), both searches and the agreement check."""
+    KF1, T1, mp1, KF2, T2, mp2, R12, t12 = _sim3_pair(seed, s12)
+    v1 = orb_search.frame_view(T1, synth.KITTI_CAM, KF1); v2 = orb_search.frame_view(T2, synth.KITTI_CAM, KF2)
+    m12, found = ORBmatcher(gpu_ctx).SearchBySim3Points(KF1, v1, mp1, KF2, v2, mp2, s12, R12, t12, th)
+    sR12, t12f, sR21, t21 = orb_search.sim3_transforms(s12, R12, t12)
+    va, uva, la = OS.project_general(_mixed_view(v1, v1, v2), mp1, orb_search.PROJ_SIM3_DIR, sR21, t21)
+    vb, uvb, lb = OS.project_general(_mixed_view(v2, v1, v1), mp2, orb_search.PROJ_SIM3_DIR, sR12, t12f)
+    assert va.sum() > 600 and vb.sum() > 600
+    m1 = OS.search_sim3_direction(KF2, mp1["desc"], va, uva, la, th)
+    m2 = OS.search_sim3_direction(KF1, mp2["desc"], vb, uvb, lb, th)
+    exp = np.array([m1[i] if m1[i] >= 0 and m2[m1[i]] == i else -1 for i in range(KF1.n)], np.int32)
+    np.testing.assert_array_equal(m12, exp)
+    assert found == int((exp >= 0).sum()) and found > 100
+    # one direction alone, with its projections returned
+    out, uv, lvl = orb_search.search_projected(gpu_ctx.lib, gpu_ctx.handle, KF2, _mixed_view(v1, v1, v2), mp1, orb_search.PROJ_SIM3_DIR, th,
+                                               sR=sR21, t=t21)
+    k = va != 0
+    np.testing.assert_array_equal(uv[k], uva[k]); np.testing.assert_array_equal(lvl[k], la[k])
+    np.testing.assert_array_equal(out.match, m1)
+
+
+def _mixed_view(pose, intr, searched):
+    """SearchBySim3 projects with pKF1's fx..cy in both directions and tests IsInImage / PredictScale on the keyframe searched in."""
+    v = orb_search.FrameView.from_buffer_copy(pose)
+    v.fx, v.fy, v.cx, v.cy = intr.fx, intr.fy, intr.cx, intr.cy
+    v.min_x, v.max_x, v.min_y, v.max_y = searched.min_x, searched.max_x, searched.min_y, searched.max_y
+    v.log_scale_factor, v.n_levels = searched.log_scale_factor, searched.n_levels
+    return v
+
+
+def test_projected_search_edge_cases(gpu_ctx):
+    KF = synth.make_orb_frame(199, 300)
+    T, mp = synth.make_local_map(KF, 199, 200)
+    view = orb_search.frame_view(T, synth.KITTI_CAM, KF)
+    lib, h = gpu_ctx.lib, gpu_ctx.handle
+    empty = {k: (v[:0] if k != "occupied" else v) for k, v in mp.items()}
+    for routine in range(4):
+        out, uv, lvl = orb_search.search_projected(lib, h, KF, view, empty, routine, 5.0, accept_max=100, sR=np.eye(3), t=np.zeros(3))
+        assert out.n_matches == 0 and out.match.shape == (0,)
+        allskip = dict(mp, skip=np.ones(200, np.uint8))
+        out, uv, lvl = orb_search.search_projected(lib, h, KF, view, allskip, routine, 5.0, accept_max=100, sR=np.eye(3), t=np.zeros(3))
+        assert out.n_matches == 0 and (out.match == -1).all()
+    with pytest.raises(RuntimeError, match="invalid"):
+        orb_search.search_projected(lib, h, KF, view, mp, 7, 5.0)
+    bare = {k: v for k, v in mp.items() if k != "normal"}
+    with pytest.raises(RuntimeError, match="invalid"):                    # the viewing-angle test of :350 needs the normals
+        orb_search.search_projected(lib, h, KF, view, bare, orb_search.PROJ_KF_SIM3, 5.0)
+    with pytest.raises(RuntimeError, match="invalid"):                    # orientation check without the keyframe's angles
+        orb_search.search_projected(lib, h, KF, view, mp, orb_search.PROJ_RELOC, 5.0, accept_max=100, check_orientation=True)
+    # a point exactly behind the camera plane: z = 0 passes `z<0.0`, 1/z = inf, u = nan fails IsInImage; RELOC rejects it on the bounds
+    P0 = (T[:3, :3].astype(np.float64).T @ (np.array([0.3, 0.2, 0.0]) - T[:3, 3].astype(np.float64))).astype(np.float32)
+    one = {k: (v[:1].copy() if k != "occupied" else v) for k, v in mp.items()}
+    one["world_pos"][0] = P0; one["skip"][0] = 0
+    for routine in range(3):
+        out, _, _ = orb_search.search_projected(lib, h, KF, view, one, routine, 5.0, accept_max=100)
+        valid, _, _ = OS.project_general(view, one, routine)
+        assert out.n_matches == 0 and valid[0] == 0
+
+
 # ---------------------------------------------------------------------- Frame::ComputeStereoMatches, whole routine (with images)
 def _check_stereo(g, ref):
     n, ur, dep, br, sad = ref

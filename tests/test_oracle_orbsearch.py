@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 import oracle_orbsearch as OS
-from lld_slam_amd import synth
+from lld_slam_amd import orb_search, synth
 from lld_slam_amd.orb_search import FRAME_GRID_COLS, FRAME_GRID_ROWS, Frame, orb_levels
 
 f32 = np.float32
@@ -418,3 +418,66 @@ def test_search_for_initialization_takes_a_keypoint_from_a_worse_holder():
     assert popcount(F1.desc[2], F2.desc[0]) == 3
     assert n == 1 and m.tolist() == [-1, 0, -1, -1]
     np.testing.assert_array_equal(pm[1], F2.xy[0]); np.testing.assert_array_equal(pm[0], F1.xy[0])
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_projection_loops_of_the_sim3_and_relocalisation_matchers(seed):
+    """lldo_project_general against the restatements it overlaps with and a numpy restatement of what differs:
+    routine 0 / 2 (SearchByProjection(KF, Scw) :311-358, Fuse(KF, Scw) :1000-1048) are Fuse(KF, vpMapPoints)'s loop (:841-890) without
+    the stereo coordinate - `1/z` in float and float(1.0/z) are the same number (double rounding of a quotient is innocuous at
+    53 >= 2*24+2 bits); routine 3 with the identity as second transform drops the viewing-angle test and takes the distance
+    from the camera-frame point; routine 1 has no depth test, inclusive bounds and `fx*xc*invzc+cx`."""
+    F = synth.make_orb_frame(500 + seed, 1500)
+    T, mp = synth.make_local_map(F, 500 + seed, 2000)
+    view = orb_search.frame_view(T, synth.KITTI_CAM, F)
+    vf, uvf, urf, lf = OS.project_fuse(view, mp)
+    for routine in (0, 2):
+        v, uv, lvl = OS.project_general(view, mp, routine)
+        np.testing.assert_array_equal(v, vf)
+        np.testing.assert_array_equal(uv[v != 0], uvf[v != 0]); np.testing.assert_array_equal(lvl[v != 0], lf[v != 0])
+    # numpy restatement of the shared head
+    R = np.array(view.Rcw, np.float32).reshape(3, 3).astype(np.float64); t = np.array(view.tcw, np.float32).astype(np.float64)
+    Ow = np.array(view.Ow, np.float32)
+    P = mp["world_pos"].astype(np.float32)
+    Pc = (P.astype(np.float64) @ R.T + t).astype(np.float32)
+    f32 = np.float32
+    fx, fy, cx, cy = f32(view.fx), f32(view.fy), f32(view.cx), f32(view.cy)
+    skip = mp["skip"] != 0
+    maxD = f32(1.2) * mp["max_distance"]; minD = f32(0.8) * mp["min_distance"]
+    with np.errstate(all="ignore"):
+        # routine 1
+        invz = (1.0 / Pc[:, 2].astype(np.float64)).astype(np.float32)
+        u = fx * Pc[:, 0] * invz + cx; v_ = fy * Pc[:, 1] * invz + cy
+        inb = ~((u < f32(view.min_x)) | (u > f32(view.max_x)) | (v_ < f32(view.min_y)) | (v_ > f32(view.max_y)))
+        PO = P - Ow
+        dist = np.sqrt((PO.astype(np.float64) ** 2).sum(1)).astype(np.float32)
+        band = ~((dist < minD) | (dist > maxD))
+        exp1 = ~skip & inb & band
+        v1, uv1, l1 = OS.project_general(view, mp, 1)
+        np.testing.assert_array_equal(v1 != 0, exp1)
+        np.testing.assert_array_equal(uv1[exp1], np.stack([u, v_], 1)[exp1])
+        ratio = mp["max_distance"] / dist
+        lv = np.clip(np.ceil(np.log(ratio) / f32(view.log_scale_factor)), 0, view.n_levels - 1).astype(np.int32)
+        np.testing.assert_array_equal(l1[exp1], lv[exp1])
+        assert (exp1 & (Pc[:, 2] < 0)).sum() >= 0 and 500 < exp1.sum() < 1900
+        # routine 3, identity second transform
+        x = Pc[:, 0] * invz; y = Pc[:, 1] * invz
+        u3 = fx * x + cx; v3 = fy * y + cy
+        inimg = (u3 >= f32(view.min_x)) & (u3 < f32(view.max_x)) & (v3 >= f32(view.min_y)) & (v3 < f32(view.max_y))
+        d3 = np.sqrt((Pc.astype(np.float64) ** 2).sum(1)).astype(np.float32)
+        exp3 = ~skip & ~(Pc[:, 2] < 0) & inimg & ~((d3 < minD) | (d3 > maxD))
+        v3o, uv3, l3 = OS.project_general(view, mp, 3, np.eye(3), np.zeros(3))
+        np.testing.assert_array_equal(v3o != 0, exp3)
+        np.testing.assert_array_equal(uv3[exp3], np.stack([u3, v3], 1)[exp3])
+        assert (exp3 & (vf == 0)).sum() > 20                                 # points the 60-degree test of Fuse rejects
+    # routine 3 with a real second transform: the composition equals one transform by the product up to float rounding
+    sR = (0.9 * synth._rodrigues(np.array([0.02, -0.01, 0.03]))).astype(np.float32); t2 = np.array([0.1, -0.05, 0.2], np.float32)
+    v3b, uv3b, _ = OS.project_general(view, mp, 3, sR, t2)
+    Pc2 = (Pc.astype(np.float64) @ sR.astype(np.float64).T + t2.astype(np.float64)).astype(np.float32)
+    with np.errstate(all="ignore"):
+        iz = (1.0 / Pc2[:, 2].astype(np.float64)).astype(np.float32)
+        ub = fx * (Pc2[:, 0] * iz) + cx
+    k = v3b != 0
+    assert k.sum() > 300
+    np.testing.assert_array_equal(uv3b[k, 0], ub[k])
+
