@@ -1,0 +1,244 @@
+// lld_matcher_adapter.cc — see lld_matcher_adapter.h.  Each routine keeps the reference's statements around its per-point loop
+// (which points are skipped, what is written back to Frame::mvpMapPoints / MapPoint / KeyFrame, in which order) and hands the loop
+// itself - projection, window search, gates, accept rule, occupancy, rotation histogram - to ONE call of the C ABI.
+#include "lld_matcher_adapter.h"
+
+#include <cstring>
+#include <stdexcept>
+#include <string>
+
+namespace lld_adapter {
+
+namespace {
+
+void check(int status, const char* what) {
+  if (status != LLD_OK) throw std::runtime_error(std::string(what) + ": " + lld_status_string(status));
+}
+
+// The keypoint side of a Frame or KeyFrame as the C ABI reads it: flat copies of mvKeysUn (pt, octave, angle), pointers into
+// mDescriptors / mvuRight / the scale tables, the grid constants (Frame.h:43-44: 64 x 48 cells).
+struct KeypointSide {
+  std::vector<float> xy, angle;
+  std::vector<int32_t> octave;
+  std::vector<uint8_t> occupied;
+  lld_orb_search s;
+  template <class F>
+  void fill(const F& f, int n) {
+    xy.resize(2 * (size_t)n); angle.resize(n); octave.resize(n); occupied.assign(n, 0);
+    for (int k = 0; k < n; k++) {
+      xy[2 * k] = f.mvKeysUn[k].pt.x; xy[2 * k + 1] = f.mvKeysUn[k].pt.y;
+      octave[k] = f.mvKeysUn[k].octave; angle[k] = f.mvKeysUn[k].angle;
+    }
+    std::memset(&s, 0, sizeof s);
+    s.nt = n; s.t_desc = f.mDescriptors.template ptr<uint32_t>(); s.t_xy = xy.data(); s.t_octave = octave.data();
+    s.t_uright = f.mvuRight.data(); s.t_angle = angle.data(); s.t_occupied = occupied.data();
+    s.grid_min_x = (float)f.mnMinX; s.grid_min_y = (float)f.mnMinY;
+    s.grid_width_inv = f.mfGridElementWidthInv; s.grid_height_inv = f.mfGridElementHeightInv;
+    s.grid_cols = 64; s.grid_rows = 48;
+    s.n_levels = f.mnScaleLevels; s.level_scale = f.mvScaleFactors.data(); s.level_sigma2 = f.mvLevelSigma2.data();
+    s.level_inv_sigma2 = f.mvInvLevelSigma2.data();
+  }
+};
+
+struct Result {
+  std::vector<int32_t> match, best, second, owner;
+  std::vector<uint8_t> removed;
+  lld_orb_search_result r;
+  Result(int nq, int nt) : match(nq + 1, -1), best(nq + 1, 256), second(nq + 1, 256), owner(nt + 1, -1), removed(nq + 1, 0) {
+    r.match = match.data(); r.best_dist = best.data(); r.second_dist = second.data(); r.removed = removed.data(); r.owner = owner.data();
+    r.n_matches = 0; r.rounds = 0;
+  }
+  void to(MatchTrace* t, int nq) const {
+    if (!t) return;
+    t->match.assign(match.begin(), match.begin() + nq); t->best_dist.assign(best.begin(), best.begin() + nq);
+    t->removed.assign(removed.begin(), removed.begin() + nq);
+  }
+};
+
+// MapPoints as the C ABI reads them
+struct PointSide {
+  std::vector<float> pos, nrm, maxd, mind;
+  std::vector<uint32_t> desc;
+  std::vector<uint8_t> has_obs, skip;
+  lld_map_points m;
+  explicit PointSide(int n) : pos(3 * (size_t)n + 3), nrm(3 * (size_t)n + 3), maxd(n + 1), mind(n + 1), desc(8 * (size_t)n + 8), has_obs(n + 1, 0), skip(n + 1, 1) {
+    m.n = n; m.world_pos = pos.data(); m.normal = nrm.data(); m.max_distance = maxd.data(); m.min_distance = mind.data();
+    m.desc = desc.data(); m.has_obs = has_obs.data(); m.skip = skip.data();
+  }
+  void set(int i, MapPoint* pMP) {
+    const lld_slam::Mat P = pMP->GetWorldPos(), Pn = pMP->GetNormal();
+    for (int k = 0; k < 3; k++) { pos[3 * i + k] = P.at<float>(k); nrm[3 * i + k] = Pn.at<float>(k); }
+    maxd[i] = pMP->GetMaxDistance(); mind[i] = pMP->GetMinDistance();
+    const lld_slam::MatU8 d = pMP->GetDescriptor();
+    std::memcpy(&desc[8 * (size_t)i], d.ptr<unsigned char>(), 32);
+    has_obs[i] = pMP->Observations() > 0;
+  }
+};
+
+template <class M>
+void view_pose(lld_frame_view& v, const M& Rcw, const M& tcw, const M& Ow) {
+  for (int r = 0; r < 3; r++) {
+    for (int c = 0; c < 3; c++) v.Rcw[3 * r + c] = Rcw.template at<float>(r, c);
+    v.tcw[r] = tcw.template at<float>(r); v.Ow[r] = Ow.template at<float>(r);
+  }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ Tracking::SearchLocalPoints   src/Tracking.cc:1613-1664
+int SearchLocalPoints(lld_ctx* ctx, Frame& mCurrentFrame, const std::vector<MapPoint*>& mvpLocalMapPoints, int th, MatchTrace* trace) {
+  // Do not search map points already matched (:1616-1633)
+  for (std::vector<MapPoint*>::iterator vit = mCurrentFrame.mvpMapPoints.begin(), vend = mCurrentFrame.mvpMapPoints.end(); vit != vend; vit++) {
+    MapPoint* pMP = *vit;
+    if (pMP) {
+      if (pMP->isBad()) *vit = static_cast<MapPoint*>(NULL);
+      else { pMP->IncreaseVisible(); pMP->mnLastFrameSeen = mCurrentFrame.mnId; pMP->mbTrackInView = false; }
+    }
+  }
+  // Project points in frame and check its visibility (:1637-1650) + matcher.SearchByProjection(mCurrentFrame, mvpLocalMapPoints, th)
+  // (:1652-1662; ORBmatcher.cc:45-129): one device call
+  Frame& F = mCurrentFrame;
+  const int n = (int)mvpLocalMapPoints.size();
+  PointSide pts(n);
+  for (int i = 0; i < n; i++) {
+    MapPoint* pMP = mvpLocalMapPoints[i];
+    pts.skip[i] = (pMP->mnLastFrameSeen == F.mnId) || pMP->isBad();           // the two `continue`s of :1640-1643
+    if (!pts.skip[i]) pts.set(i, pMP);
+  }
+  KeypointSide ks; ks.fill(F, F.N);
+  for (int k = 0; k < F.N; k++)                                               // ORBmatcher.cc:86-88: a MapPoint with observations blocks its keypoint
+    ks.occupied[k] = F.mvpMapPoints[k] && F.mvpMapPoints[k]->Observations() > 0;
+  lld_frame_view view; std::memset(&view, 0, sizeof view);
+  view_pose(view, F.mRcw, F.mtcw, F.mOw);
+  view.fx = F.fx; view.fy = F.fy; view.cx = F.cx; view.cy = F.cy; view.bf = F.mbf;
+  view.min_x = F.mnMinX; view.max_x = F.mnMaxX; view.min_y = F.mnMinY; view.max_y = F.mnMaxY;
+  view.log_scale_factor = F.mfLogScaleFactor; view.n_levels = F.mnScaleLevels;
+  std::vector<uint8_t> in_view(n + 1, 0); std::vector<float> uvr(3 * (size_t)n + 3), vcos(n + 1); std::vector<int32_t> level(n + 1);
+  lld_frustum_result fr; fr.in_view = in_view.data(); fr.proj_uvr = uvr.data(); fr.level = level.data(); fr.view_cos = vcos.data();
+  Result res(n, F.N);
+  check(lld_orb_search_local_points(ctx, &ks.s, &view, &pts.m, 0.5f, (float)th, 0.8f, &fr, &res.r), "lld_orb_search_local_points");
+  // what Frame::isInFrustum leaves in the MapPoint (Frame.cc:335, 379-386) and :1646-1647
+  int nToMatch = 0;
+  for (int i = 0; i < n; i++) {
+    if (pts.skip[i]) continue;
+    MapPoint* pMP = mvpLocalMapPoints[i];
+    pMP->mbTrackInView = in_view[i] != 0;
+    if (!in_view[i]) continue;
+    pMP->mTrackProjX = uvr[3 * i]; pMP->mTrackProjY = uvr[3 * i + 1]; pMP->mTrackProjXR = uvr[3 * i + 2];
+    pMP->mnTrackScaleLevel = level[i]; pMP->mTrackViewCos = vcos[i];
+    pMP->IncreaseVisible();
+    nToMatch++;
+  }
+  res.to(trace, n);
+  if (trace) { trace->in_view.assign(in_view.begin(), in_view.begin() + n); trace->nToMatch = nToMatch; }
+  if (nToMatch == 0) return 0;
+  // F.mvpMapPoints[bestIdx]=pMP (ORBmatcher.cc:122): the keypoint's final holder (a MapPoint without observations does not block
+  // and may be overwritten by a later one - owner[] is the last writer)
+  for (int k = 0; k < F.N; k++)
+    if (res.owner[k] >= 0) F.mvpMapPoints[k] = mvpLocalMapPoints[res.owner[k]];
+  return res.r.n_matches;
+}
+
+// ------------------------------------------------------------------ ORBmatcher::SearchByProjection(Current, Last)   src/ORBmatcher.cc:1328-1470
+int ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, const float th, const bool bMono, MatchTrace* trace) {
+  // :1338-1350: tlc = Rlw*twc+tlw with twc = -Rcw.t()*tcw, each product one gemm (double accumulation, one rounding)
+  float twc[3];
+  for (int r = 0; r < 3; r++) {
+    double acc = 0.0;
+    for (int k = 0; k < 3; k++) acc += (double)CurrentFrame.mTcw.at<float>(k, r) * (double)CurrentFrame.mTcw.at<float>(k, 3);
+    twc[r] = (float)(-acc);
+  }
+  double accz = 0.0;
+  for (int k = 0; k < 3; k++) accz += (double)LastFrame.mTcw.at<float>(2, k) * (double)twc[k];
+  const float tlc2 = (float)(accz + (double)LastFrame.mTcw.at<float>(2, 3));
+  const bool bForward = tlc2 > CurrentFrame.mb && !bMono;
+  const bool bBackward = -tlc2 > CurrentFrame.mb && !bMono;
+  const int direction = bForward ? 1 : (bBackward ? -1 : 0);
+
+  const int n = LastFrame.N;
+  std::vector<float> pos(3 * (size_t)n + 3, 0.f), angle(n + 1, 0.f);
+  std::vector<uint8_t> valid(n + 1, 0), has_obs(n + 1, 0);
+  std::vector<int32_t> octave(n + 1, 0);
+  std::vector<uint32_t> desc(8 * (size_t)n + 8, 0u);
+  for (int i = 0; i < n; i++) {
+    MapPoint* pMP = LastFrame.mvpMapPoints[i];
+    if (!pMP || LastFrame.mvbOutlier[i]) continue;                            // :1354-1358
+    valid[i] = 1;
+    const lld_slam::Mat x3Dw = pMP->GetWorldPos();
+    for (int k = 0; k < 3; k++) pos[3 * i + k] = x3Dw.at<float>(k);
+    octave[i] = LastFrame.mvKeys[i].octave;                                   // :1381
+    angle[i] = LastFrame.mvKeysUn[i].angle;                                   // :1435
+    const lld_slam::MatU8 d = pMP->GetDescriptor();
+    std::memcpy(&desc[8 * (size_t)i], d.ptr<unsigned char>(), 32);
+    has_obs[i] = pMP->Observations() > 0;
+  }
+  lld_last_frame_points last; std::memset(&last, 0, sizeof last);
+  last.n = n; last.world_pos = pos.data(); last.valid = valid.data(); last.octave = octave.data(); last.angle = angle.data();
+  last.desc = desc.data(); last.has_obs = has_obs.data();
+  KeypointSide ks; ks.fill(CurrentFrame, CurrentFrame.N);
+  for (int k = 0; k < CurrentFrame.N; k++)                                    // :1404-1406
+    ks.occupied[k] = CurrentFrame.mvpMapPoints[k] && CurrentFrame.mvpMapPoints[k]->Observations() > 0;
+  lld_frame_view view; std::memset(&view, 0, sizeof view);
+  for (int r = 0; r < 3; r++) {
+    for (int c = 0; c < 3; c++) view.Rcw[3 * r + c] = CurrentFrame.mTcw.at<float>(r, c);
+    view.tcw[r] = CurrentFrame.mTcw.at<float>(r, 3); view.Ow[r] = twc[r];
+  }
+  view.fx = CurrentFrame.fx; view.fy = CurrentFrame.fy; view.cx = CurrentFrame.cx; view.cy = CurrentFrame.cy; view.bf = CurrentFrame.mbf;
+  view.min_x = CurrentFrame.mnMinX; view.max_x = CurrentFrame.mnMaxX; view.min_y = CurrentFrame.mnMinY; view.max_y = CurrentFrame.mnMaxY;
+  view.log_scale_factor = CurrentFrame.mfLogScaleFactor; view.n_levels = CurrentFrame.mnScaleLevels;
+  Result res(n, CurrentFrame.N);
+  check(lld_orb_search_last_frame(ctx_, &ks.s, &view, &last, direction, th, mbCheckOrientation ? 1 : 0, NULL, &res.r), "lld_orb_search_last_frame");
+  // CurrentFrame.mvpMapPoints[bestIdx2]=pMP in loop order (:1429), then the slots of the bins outside the three maxima are nulled (:1452-1460)
+  for (int i = 0; i < n; i++) if (res.match[i] >= 0) CurrentFrame.mvpMapPoints[res.match[i]] = LastFrame.mvpMapPoints[i];
+  for (int i = 0; i < n; i++) if (res.match[i] >= 0 && res.removed[i]) CurrentFrame.mvpMapPoints[res.match[i]] = static_cast<MapPoint*>(NULL);
+  res.to(trace, n);
+  if (trace) trace->direction = direction;
+  return res.r.n_matches;
+}
+
+// ------------------------------------------------------------------ ORBmatcher::Fuse(KeyFrame*, vpMapPoints, th)   src/ORBmatcher.cc:825-958
+int ORBmatcher::Fuse(KeyFrame* pKF, const std::vector<MapPoint*>& vpMapPoints, const float th, MatchTrace* trace) {
+  const lld_slam::Mat Rcw = pKF->GetRotation(), tcw = pKF->GetTranslation(), Ow = pKF->GetCameraCenter();
+  const int nMPs = (int)vpMapPoints.size();
+  PointSide pts(nMPs);
+  for (int i = 0; i < nMPs; i++) {
+    MapPoint* pMP = vpMapPoints[i];
+    pts.skip[i] = !pMP || pMP->isBad() || pMP->IsInKeyFrame(pKF);            // :845-849
+    if (!pts.skip[i]) pts.set(i, pMP);
+  }
+  const int N = (int)pKF->mvKeysUn.size();
+  KeypointSide ks; ks.fill(*pKF, N);
+  ks.s.t_occupied = NULL;                                                     // Fuse has no occupancy
+  lld_frame_view view; std::memset(&view, 0, sizeof view);
+  view_pose(view, Rcw, tcw, Ow);
+  view.fx = pKF->fx; view.fy = pKF->fy; view.cx = pKF->cx; view.cy = pKF->cy; view.bf = pKF->mbf;
+  view.min_x = (float)pKF->mnMinX; view.max_x = (float)pKF->mnMaxX; view.min_y = (float)pKF->mnMinY; view.max_y = (float)pKF->mnMaxY;
+  view.log_scale_factor = pKF->mfLogScaleFactor; view.n_levels = pKF->mnScaleLevels;
+  Result res(nMPs, N);
+  check(lld_orb_fuse_search(ctx_, &ks.s, &view, &pts.m, th, NULL, &res.r), "lld_orb_fuse_search");
+  res.to(trace, nMPs);
+  // If there is already a MapPoint replace otherwise add new measurement (:934-954), in loop order.  The search of a point does not
+  // read what this loop changes, its skip test does: a point that an earlier iteration replaced (now bad) or attached to pKF would
+  // have been skipped at :848 - test again before acting.
+  int nFused = 0;
+  for (int i = 0; i < nMPs; i++) {
+    const int bestIdx = res.match[i];
+    if (bestIdx < 0) continue;
+    MapPoint* pMP = vpMapPoints[i];
+    if (pMP->isBad() || pMP->IsInKeyFrame(pKF)) continue;
+    MapPoint* pMPinKF = pKF->GetMapPoint(bestIdx);
+    if (pMPinKF) {
+      if (!pMPinKF->isBad()) {
+        if (pMPinKF->Observations() > pMP->Observations()) pMP->Replace(pMPinKF);
+        else pMPinKF->Replace(pMP);
+      }
+    } else {
+      pMP->AddObservation(pKF, bestIdx);
+      pKF->AddMapPoint(pMP, bestIdx);
+    }
+    nFused++;
+  }
+  return nFused;
+}
+
+}  // namespace lld_adapter

@@ -1,5 +1,5 @@
-// lld_slam_objects.h — a minimal object model for COMPILING and RUNNING the host adapters (adapters/lld_optimizer_adapter.cc)
-// without the reference's dependencies.
+// lld_slam_objects.h — a minimal object model for COMPILING and RUNNING the host adapters (adapters/lld_optimizer_adapter.cc,
+// adapters/lld_matcher_adapter.cc) without the reference's dependencies.
 //
 // These are this repository's own test doubles, not reference headers: each class carries only the members the adapter touches,
 // under the names the reference uses (include/KeyFrame.h, MapPoint.h, MapLine.h, Frame.h, Map.h), so that the adapter source reads
@@ -50,8 +50,23 @@ struct Vector3d {
   double operator()(int i) const { return v[i]; }
 };
 
+// ---- cv::Mat (CV_8U) stand-in for ORB descriptors: one 32-byte row per keypoint (Frame::mDescriptors, MapPoint::GetDescriptor)
+class MatU8 {
+ public:
+  MatU8() : rows(0), cols(0) {}
+  MatU8(int r, int c) : rows(r), cols(c), d_(((size_t)r * c + 3) / 4, 0u) {}
+  int rows, cols;
+  bool empty() const { return rows == 0; }
+  MatU8 clone() const { return *this; }
+  MatU8 row(int r) const { MatU8 m(1, cols); std::memcpy(m.d_.data(), ptr<unsigned char>(r), (size_t)cols); return m; }
+  template <class T> T* ptr(int r = 0) { return reinterpret_cast<T*>(reinterpret_cast<unsigned char*>(d_.data()) + (size_t)r * cols); }
+  template <class T> const T* ptr(int r = 0) const { return reinterpret_cast<const T*>(reinterpret_cast<const unsigned char*>(d_.data()) + (size_t)r * cols); }
+ private:
+  std::vector<unsigned int> d_;                                    // 4-byte aligned like cv::Mat's rows of 32
+};
+
 struct Point2f { float x, y; };
-struct KeyPoint { Point2f pt; int octave; };                       // cv::KeyPoint: the adapter reads pt and octave
+struct KeyPoint { Point2f pt; int octave; float angle; KeyPoint() : pt{0.f, 0.f}, octave(0), angle(0.f) {} };   // cv::KeyPoint: pt, octave, angle
 struct KeyLine {                                                   // cv::line_descriptor::KeyLine (LineMatching.h:27): end points and octave
   float startPointX, startPointY, endPointX, endPointY; int octave;
   KeyLine() : startPointX(0), startPointY(0), endPointX(0), endPointY(0), octave(0) {}
@@ -79,7 +94,24 @@ class KeyFrame {
   std::vector<MapPoint*> GetMapPointMatches() const { return mvpMapPoints; }
   std::vector<MapLine*> GetMapLineMatches() const { return mvpMapLines; }
   void EraseMapPointMatch(MapPoint* p) { for (auto& q : mvpMapPoints) if (q == p) q = nullptr; }
+  void EraseMapPointMatch(const size_t& idx) { mvpMapPoints[idx] = nullptr; }
   void EraseMapLineMatch(MapLine* l) { for (auto& q : mvpMapLines) if (q == l) q = nullptr; }
+  // what the matchers read (include/KeyFrame.h): keypoint descriptors, the image bounds and grid constants, the scale pyramid, the
+  // pose pieces; and what ORBmatcher::Fuse writes
+  MatU8 mDescriptors;
+  int mnMinX = 0, mnMinY = 0, mnMaxX = 0, mnMaxY = 0;               // KeyFrame.h:196-199 (const int there)
+  float mfGridElementWidthInv = 0, mfGridElementHeightInv = 0;
+  int mnScaleLevels = 0;
+  float mfScaleFactor = 0, mfLogScaleFactor = 0;
+  std::vector<float> mvScaleFactors, mvLevelSigma2;
+  Mat GetRotation() const { Mat R(3, 3); for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) R.at<float>(r, c) = Tcw.at<float>(r, c); return R; }
+  Mat GetTranslation() const { Mat t(3, 1); for (int r = 0; r < 3; r++) t.at<float>(r) = Tcw.at<float>(r, 3); return t; }
+  Mat GetCameraCenter() const { return Ow.clone(); }
+  bool IsInImage(const float& x, const float& y) const { return (x >= mnMinX && x < mnMaxX && y >= mnMinY && y < mnMaxY); }   // KeyFrame.cc:633-636
+  void AddMapPoint(MapPoint* pMP, const size_t& idx) { mvpMapPoints[idx] = pMP; }
+  MapPoint* GetMapPoint(const size_t& idx) const { return mvpMapPoints[idx]; }
+  void ReplaceMapPointMatch(const size_t& idx, MapPoint* pMP) { mvpMapPoints[idx] = pMP; }
+  Mat Ow;                                                          // 3x1, set with the pose by the reference (KeyFrame::SetPose)
 
   // (test access)
   Mat Tcw;
@@ -101,6 +133,43 @@ class MapPoint {
   void EraseObservation(KeyFrame* kf) { mObservations.erase(kf); }
   bool isBad() const { return mbBad; }
   void UpdateNormalAndDepth() { n_update_normal++; }
+  // what the matchers read and write (include/MapPoint.h)
+  Mat GetNormal() const { return mNormalVector.clone(); }
+  MatU8 GetDescriptor() const { return mDescriptor.clone(); }
+  float GetMinDistanceInvariance() const { return 0.8f * mfMinDistance; }
+  float GetMaxDistanceInvariance() const { return 1.2f * mfMaxDistance; }
+  int Observations() const { return nObs; }
+  bool IsInKeyFrame(KeyFrame* pKF) const { return mObservations.count(pKF) != 0; }
+  void IncreaseVisible(int n = 1) { mnVisible += n; }
+  void IncreaseFound(int n = 1) { mnFound += n; }
+  void AddObservation(KeyFrame* pKF, size_t idx) {                  // MapPoint.cc:67-78
+    if (mObservations.count(pKF)) return;
+    mObservations[pKF] = idx;
+    if (pKF->mvuRight[idx] >= 0) nObs += 2; else nObs++;
+  }
+  void Replace(MapPoint* pMP) {                                     // MapPoint.cc:176-220 (without the map / descriptor upkeep)
+    if (pMP->mnId == this->mnId) return;
+    const std::map<KeyFrame*, size_t> obs = mObservations;
+    mObservations.clear(); mbBad = true; mpReplaced = pMP;
+    for (std::map<KeyFrame*, size_t>::const_iterator mit = obs.begin(); mit != obs.end(); ++mit) {
+      KeyFrame* pKF = mit->first;
+      if (!pMP->IsInKeyFrame(pKF)) { pKF->ReplaceMapPointMatch(mit->second, pMP); pMP->AddObservation(pKF, mit->second); }
+      else pKF->EraseMapPointMatch(mit->second);
+    }
+    pMP->IncreaseFound(mnFound); pMP->IncreaseVisible(mnVisible);
+  }
+  Mat mNormalVector;                                               // 3x1 CV_32F
+  MatU8 mDescriptor;                                               // 1x32
+  float mfMinDistance = 0, mfMaxDistance = 0;                      // protected in the reference: the patch adds the two getters below
+  float GetMinDistance() const { return mfMinDistance; }
+  float GetMaxDistance() const { return mfMaxDistance; }
+  int nObs = 0, mnVisible = 1, mnFound = 1;
+  MapPoint* mpReplaced = nullptr;
+  // variables used by the tracking (MapPoint.h:88-96)
+  float mTrackProjX = 0, mTrackProjY = 0, mTrackProjXR = 0, mTrackViewCos = 0;
+  bool mbTrackInView = false;
+  int mnTrackScaleLevel = 0;
+  unsigned long mnLastFrameSeen = 0;
 
   Mat mWorldPos;                                                   // 3x1 CV_32F
   std::map<KeyFrame*, size_t> mObservations;                       // pointer-ordered, as in the reference
@@ -139,8 +208,30 @@ class Frame {                                                      // what PoseO
   std::vector<int> line_matches;
   std::vector<MapLine*> mvpMapLines;
   std::vector<bool> mvbOutlierLines;
-  void SetPose(const Mat& T) { mTcw = T.clone(); n_set_pose++; }
+  void SetPose(const Mat& T) { mTcw = T.clone(); n_set_pose++; UpdatePoseMatrices(); }
   int n_set_pose = 0;
+  // what the matchers read (include/Frame.h).  The image bounds and grid constants are static members of the reference's Frame;
+  // the adapter reaches them through an object (F.mnMinX), which compiles for both
+  unsigned long mnId = 0;
+  float mb = 0;
+  std::vector<KeyPoint> mvKeys;
+  std::vector<float> mvDepth;
+  MatU8 mDescriptors;
+  float mnMinX = 0, mnMaxX = 0, mnMinY = 0, mnMaxY = 0, mfGridElementWidthInv = 0, mfGridElementHeightInv = 0;
+  int mnScaleLevels = 0;
+  float mfScaleFactor = 0, mfLogScaleFactor = 0;
+  std::vector<float> mvScaleFactors, mvLevelSigma2;
+  Mat mRcw, mtcw, mOw;
+  void UpdatePoseMatrices() {                                       // Frame.cc:325-331: mOw = -mRcw.t()*mtcw is one gemm (double accumulation)
+    if (mTcw.empty()) return;
+    mRcw = Mat(3, 3); mtcw = Mat(3, 1); mOw = Mat(3, 1);
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) mRcw.at<float>(r, c) = mTcw.at<float>(r, c); mtcw.at<float>(r) = mTcw.at<float>(r, 3); }
+    for (int r = 0; r < 3; r++) {
+      double acc = 0.0;
+      for (int k = 0; k < 3; k++) acc += (double)mRcw.at<float>(k, r) * (double)mtcw.at<float>(k);
+      mOw.at<float>(r) = (float)(-acc);
+    }
+  }
 };
 
 class Map {

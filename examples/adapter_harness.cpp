@@ -21,6 +21,7 @@
 #include <string>
 
 #include "../adapters/lld_optimizer_adapter.h"
+#include "../adapters/lld_matcher_adapter.h"
 
 std::mutex lld_slam::MapPoint::mGlobalMutex;        // the doubles' static member (the real class defines its own, MapPoint.cc:30)
 
@@ -280,13 +281,144 @@ int run_pose(const char* in, const char* out, unsigned seed) {
 
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------------------------- matchers
+// The keypoint side shared by the frames and the keyframe of the matcher scene (as Frame::Frame / KeyFrame::KeyFrame fill it)
+struct KeypointData {
+  int N, nl;
+  float cam[6], bounds[6], logsf;
+  std::vector<float> scale, sigma2, inv_sigma2, xy, angle, uright;
+  std::vector<int32_t> octave;
+  std::vector<uint32_t> desc;
+  void read(Reader& r, int n, int levels) {
+    N = n; nl = levels;
+    r.get(cam, 6); r.get(bounds, 6);           // fx fy cx cy bf mb | mnMinX mnMaxX mnMinY mnMaxY mfGridElementWidthInv mfGridElementHeightInv
+    r.get(scale, nl); r.get(sigma2, nl); r.get(inv_sigma2, nl); r.get(&logsf, 1);
+    r.get(xy, 2 * (size_t)N); r.get(octave, N); r.get(angle, N); r.get(uright, N); r.get(desc, 8 * (size_t)N);
+  }
+  template <class F> void keys(F& f) const {
+    f.fx = cam[0]; f.fy = cam[1]; f.cx = cam[2]; f.cy = cam[3]; f.mbf = cam[4];
+    f.mvKeysUn.resize(N);
+    for (int k = 0; k < N; k++) { f.mvKeysUn[k].pt.x = xy[2 * k]; f.mvKeysUn[k].pt.y = xy[2 * k + 1]; f.mvKeysUn[k].octave = octave[k]; f.mvKeysUn[k].angle = angle[k]; }
+    f.mvuRight = uright;
+    f.mDescriptors = MatU8(N, 32); std::memcpy(f.mDescriptors.template ptr<unsigned char>(), desc.data(), 32 * (size_t)N);
+    f.mnMinX = bounds[0]; f.mnMaxX = bounds[1]; f.mnMinY = bounds[2]; f.mnMaxY = bounds[3];
+    f.mfGridElementWidthInv = bounds[4]; f.mfGridElementHeightInv = bounds[5];
+    f.mnScaleLevels = nl; f.mfScaleFactor = scale[1]; f.mfLogScaleFactor = logsf;
+    f.mvScaleFactors = scale; f.mvLevelSigma2 = sigma2; f.mvInvLevelSigma2 = inv_sigma2;
+  }
+  void frame(Frame& F, const float* Tcw, unsigned long id) const {
+    keys(F); F.N = N; F.mnId = id; F.mb = cam[5]; F.mvKeys = F.mvKeysUn;
+    F.mvpMapPoints.assign(N, nullptr); F.mvbOutlier.assign(N, false);
+    F.SetPose(Mat(4, 4, Tcw));
+  }
+};
+struct PointData {
+  int n;
+  std::vector<float> pos, nrm, maxd, mind;
+  std::vector<uint32_t> desc;
+  std::vector<int32_t> nobs;
+  std::vector<uint8_t> bad;
+  void read(Reader& r, int count) {
+    n = count;
+    r.get(pos, 3 * (size_t)n); r.get(nrm, 3 * (size_t)n); r.get(maxd, n); r.get(mind, n); r.get(desc, 8 * (size_t)n); r.get(nobs, n); r.get(bad, n);
+  }
+  void make(std::vector<std::unique_ptr<MapPoint> >& own, std::vector<MapPoint*>& out, unsigned long id0) const {
+    for (int i = 0; i < n; i++) {
+      own.emplace_back(new MapPoint()); MapPoint* p = own.back().get();
+      p->mnId = id0 + i; p->mWorldPos = Mat(3, 1, &pos[3 * i]); p->mNormalVector = Mat(3, 1, &nrm[3 * i]);
+      p->mfMaxDistance = maxd[i]; p->mfMinDistance = mind[i];
+      p->mDescriptor = MatU8(1, 32); std::memcpy(p->mDescriptor.ptr<unsigned char>(), &desc[8 * (size_t)i], 32);
+      p->nObs = nobs[i]; p->mbBad = bad[i] != 0;
+      out.push_back(p);
+    }
+  }
+};
+
+// The three per-frame / per-keyframe matchers through adapters/lld_matcher_adapter.cc on an object graph built from a scene file
+int run_match(const char* in, const char* out) {
+  Reader r(in);
+  int32_t h[8]; r.get(h, 8);                   // N, levels, n_local, n_fuse, th_local, bMono, checkOrientation, 0
+  KeypointData K; K.read(r, h[0], h[1]);
+  float T[16], Tlast[16], th[2]; r.get(T, 16); r.get(Tlast, 16); r.get(th, 2);   // current pose, last pose, th (last frame), th (fuse)
+  std::vector<uint8_t> occupied, last_valid, last_outlier, kf_has; std::vector<int32_t> kf_nobs;
+  r.get(occupied, K.N);                        // keypoints of the current frame that already hold a MapPoint with observations
+  PointData local; local.read(r, h[2]);
+  PointData last; last.read(r, K.N); r.get(last_valid, K.N); r.get(last_outlier, K.N);
+  std::vector<int32_t> last_octave; std::vector<float> last_angle;
+  r.get(last_octave, K.N); r.get(last_angle, K.N);   // LastFrame.mvKeys[i].octave, LastFrame.mvKeysUn[i].angle
+  PointData fuse; fuse.read(r, h[3]); r.get(kf_has, K.N); r.get(kf_nobs, K.N);
+  lld_amd::Context ctx(0);
+  std::vector<std::unique_ptr<MapPoint> > own;
+  Writer wr(out);
+  auto holder = [](const std::vector<MapPoint*>& slots, unsigned long id0, int n, std::vector<int32_t>& idx) {
+    idx.assign(slots.size(), -1);
+    for (size_t k = 0; k < slots.size(); k++)
+      if (slots[k]) idx[k] = (slots[k]->mnId >= id0 && slots[k]->mnId < id0 + (unsigned long)n) ? (int32_t)(slots[k]->mnId - id0) : -2;
+  };
+  {  // ---- Tracking::SearchLocalPoints
+    Frame F; K.frame(F, T, 7);
+    std::vector<MapPoint*> occ, pts;
+    for (int k = 0; k < K.N; k++)
+      if (occupied[k]) { own.emplace_back(new MapPoint()); own.back()->mnId = 900000 + k; own.back()->nObs = 2; F.mvpMapPoints[k] = own.back().get(); }
+    local.make(own, pts, 1000);
+    lld_adapter::MatchTrace tr;
+    const int nm = lld_adapter::SearchLocalPoints(ctx.get(), F, pts, h[4], &tr);
+    std::vector<int32_t> idx; holder(F.mvpMapPoints, 1000, local.n, idx);
+    std::vector<int32_t> lvl(local.n), vis(local.n); std::vector<float> uvr(3 * (size_t)local.n), vc(local.n); std::vector<uint8_t> inview(local.n);
+    for (int i = 0; i < local.n; i++) {
+      inview[i] = pts[i]->mbTrackInView; lvl[i] = pts[i]->mnTrackScaleLevel; vis[i] = pts[i]->mnVisible; vc[i] = pts[i]->mTrackViewCos;
+      uvr[3 * i] = pts[i]->mTrackProjX; uvr[3 * i + 1] = pts[i]->mTrackProjY; uvr[3 * i + 2] = pts[i]->mTrackProjXR;
+    }
+    const int32_t c[2] = {nm, tr.nToMatch};
+    wr.put(c, 2); wr.put(idx); wr.put(inview); wr.put(lvl); wr.put(vis); wr.put(uvr); wr.put(vc);
+    int seen = 0; for (int k = 0; k < K.N; k++) if (occupied[k] && F.mvpMapPoints[k] && F.mvpMapPoints[k]->mnLastFrameSeen == 7) seen++;
+    std::printf("SearchLocalPoints: %d matches of %d in view (%d local points, %d occupied keypoints marked seen)\n", nm, tr.nToMatch, local.n, seen);
+  }
+  {  // ---- ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono)
+    Frame Cur, Last; K.frame(Cur, T, 8); K.frame(Last, Tlast, 7);
+    for (int k = 0; k < K.N; k++)
+      if (occupied[k]) { own.emplace_back(new MapPoint()); own.back()->mnId = 910000 + k; own.back()->nObs = 2; Cur.mvpMapPoints[k] = own.back().get(); }
+    std::vector<MapPoint*> pts; last.make(own, pts, 200000);
+    for (int i = 0; i < K.N; i++) {
+      Last.mvpMapPoints[i] = last_valid[i] ? pts[i] : nullptr; Last.mvbOutlier[i] = last_outlier[i] != 0;
+      Last.mvKeys[i].octave = last_octave[i]; Last.mvKeysUn[i].angle = last_angle[i];
+    }
+    lld_adapter::MatchTrace tr;
+    const int nm = lld_adapter::ORBmatcher(ctx.get(), 0.9f, h[6] != 0).SearchByProjection(Cur, Last, th[0], h[5] != 0, &tr);
+    std::vector<int32_t> idx; holder(Cur.mvpMapPoints, 200000, K.N, idx);
+    const int32_t c[2] = {nm, tr.direction};
+    wr.put(c, 2); wr.put(idx); wr.put(tr.removed);
+    std::printf("SearchByProjection(Current, Last): %d matches, direction %d\n", nm, tr.direction);
+  }
+  {  // ---- ORBmatcher::Fuse(pKF, vpMapPoints, th)
+    KeyFrame KF; K.keys(KF); KF.mnId = 3; KF.Tcw = Mat(4, 4, T);
+    { Frame tmp; tmp.SetPose(Mat(4, 4, T)); KF.Ow = tmp.mOw; }                // KeyFrame::SetPose computes Ow the same way (KeyFrame.cc:74-88)
+    KF.mvpMapPoints.assign(K.N, nullptr);
+    std::vector<MapPoint*> inkf(K.N, nullptr);
+    for (int k = 0; k < K.N; k++)
+      if (kf_has[k]) { own.emplace_back(new MapPoint()); MapPoint* p = own.back().get(); p->mnId = 920000 + k; p->nObs = kf_nobs[k]; p->mObservations[&KF] = k; KF.mvpMapPoints[k] = p; inkf[k] = p; }
+    std::vector<MapPoint*> pts; fuse.make(own, pts, 300000);
+    lld_adapter::MatchTrace tr;
+    const int nf = lld_adapter::ORBmatcher(ctx.get()).Fuse(&KF, pts, th[1], &tr);
+    std::vector<int32_t> idx; holder(KF.mvpMapPoints, 300000, fuse.n, idx);
+    std::vector<uint8_t> pbad(fuse.n), kbad(K.N, 0); std::vector<int32_t> pobs(fuse.n);
+    for (int i = 0; i < fuse.n; i++) { pbad[i] = pts[i]->isBad(); pobs[i] = pts[i]->Observations(); }
+    for (int k = 0; k < K.N; k++) if (inkf[k]) kbad[k] = inkf[k]->isBad();
+    const int32_t c[1] = {nf};
+    wr.put(c, 1); wr.put(tr.match); wr.put(idx); wr.put(pbad); wr.put(pobs); wr.put(kbad);
+    std::printf("Fuse: %d fused of %d points\n", nf, fuse.n);
+  }
+  return 0;
+}
+
 int main(int argc, char** argv) {
-  if (argc < 4) { std::fprintf(stderr, "usage: adapter_harness ba|pose <in> <out> [seed]\n"); return 2; }
+  if (argc < 4) { std::fprintf(stderr, "usage: adapter_harness ba|pose|match <in> <out> [seed]\n"); return 2; }
   const unsigned seed = argc > 4 ? (unsigned)std::atoi(argv[4]) : 1u;
   try {
     const std::string mode = argv[1];
     if (mode == "ba") return run_ba(argv[2], argv[3], seed);
     if (mode == "pose") return run_pose(argv[2], argv[3], seed);
+    if (mode == "match") return run_match(argv[2], argv[3]);
     std::fprintf(stderr, "unknown mode %s\n", argv[1]);
     return 2;
   } catch (const std::exception& e) {

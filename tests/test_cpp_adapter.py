@@ -14,6 +14,8 @@ reference skips - runs the adapter and dumps what it gathered, what came back an
   scatter  poses / points / lines of the objects are the library's output through Converter::toCvMat - EXACTLY - every local keyframe
            written once (the fixed mnId-0 one too), UpdateNormalAndDepth on every point, removed lines and skipped objects untouched,
            and an observation is erased from BOTH sides iff its outlier flag is set.
+
+adapters/lld_matcher_adapter.cc (the per-frame / per-keyframe ORB matchers on live objects) is checked at the end of this file.
 """
 import os
 import subprocess
@@ -275,3 +277,123 @@ def test_pose_optimization_through_the_compiled_adapter(harness, gpu_ctx, oracle
     expect_l = np.ones(len(obj["mvbOutlierLines"]), np.uint8); expect_l[obj["vnIndexLines"]] = res["ln_outlier"]
     np.testing.assert_array_equal(obj["mvbOutlierLines"], expect_l)
     assert res["n_in"] == len(obj["vnIndexEdge"]) - int(res["pt_outlier"].sum())
+
+
+# ---------------------------------------------------------------------------------------------------------------- matcher adapters
+def _write_points(f, mp, n, nobs, bad):
+    for k, t in (("world_pos", np.float32), ("normal", np.float32), ("max_distance", np.float32), ("min_distance", np.float32), ("desc", np.uint32)):
+        np.ascontiguousarray(mp[k][:n], t).tofile(f)
+    np.ascontiguousarray(nobs, np.int32).tofile(f); np.ascontiguousarray(bad, np.uint8).tofile(f)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,th_local,back", [(0, 1, False), (1, 5, True)])
+def test_matcher_adapters_on_live_objects(harness, tmp_path, seed, th_local, back):
+    """adapters/lld_matcher_adapter.cc on an object graph of test doubles: Tracking::SearchLocalPoints (src/Tracking.cc:1613-1664),
+    ORBmatcher::SearchByProjection(Current, Last) (src/ORBmatcher.cc:1328-1470) and ORBmatcher::Fuse (:825-958), each one device
+    call plus the reference's bookkeeping, against the oracle's literal restatements: Frame::mvpMapPoints / KeyFrame slots,
+    mbTrackInView and the mTrack* fields, IncreaseVisible counts, the forward / backward decision, Replace / AddObservation."""
+    import oracle_orbsearch as OS
+    from lld_slam_amd import orb_search
+    F = synth.make_orb_frame(700 + seed, 1800).normalise()
+    N = F.n
+    T, mp = synth.make_local_map(F, 700 + seed, 2300)
+    rng = np.random.default_rng(700 + seed)
+    cam = np.array(list(synth.KITTI_CAM) + [synth.KITTI_CAM[4] / synth.KITTI_CAM[0]], np.float32)            # fx fy cx cy bf mb
+    view = orb_search.frame_view(T, synth.KITTI_CAM, F)
+    # the last frame: one MapPoint per keypoint where the local map has one drawn from that keypoint; its pose one step behind / ahead
+    Tl, mpl = synth.make_local_map(F, 700 + seed, 4 * N)                      # the same scene id draws the same pose, another n other points
+    assert np.array_equal(Tl, T)
+    first = np.full(N, -1, np.int64)
+    for e in range(4 * N - 1, -1, -1): first[mpl["src"][e]] = e
+    last_valid = (first >= 0) & (rng.random(N) < 0.9)
+    sel = np.where(first >= 0, first, 0)
+    last = {k: mpl[k][sel] for k in ("world_pos", "normal", "max_distance", "min_distance", "desc")}
+    last_outlier = (rng.random(N) < 0.08).astype(np.uint8)
+    last_nobs = (rng.random(N) < 0.9).astype(np.int32) * 2
+    last_angle = np.mod(F.angle + 25.0 + rng.normal(0, 6.0, N), 360.0)
+    wild = rng.random(N) < 0.15; last_angle[wild] = rng.uniform(0, 360, int(wild.sum())); last_angle = last_angle.astype(np.float32)
+    Tlast = T.copy(); Tlast[2, 3] += np.float32(-1.1 if back else 1.1)                                      # tlc.z = +-1.1 m against mb = 0.54 m
+    # fuse candidates and the keyframe's own MapPoints
+    Tf, mpf = synth.make_local_map(F, 700 + seed, 2000)
+    assert np.array_equal(Tf, T)
+    kf_has = (rng.random(N) < 0.4).astype(np.uint8); kf_nobs = rng.integers(1, 6, N).astype(np.int32)
+    f_nobs = rng.integers(0, 6, 2000).astype(np.int32); f_bad = mpf["skip"].astype(np.uint8)
+    l_nobs = mp["has_obs"].astype(np.int32) * 2; l_bad = mp["skip"].astype(np.uint8)
+    with open(tmp_path / "in.bin", "wb") as f:
+        np.array([N, F.scale.shape[0], 2300, 2000, th_local, 0, 1, 0], np.int32).tofile(f)
+        cam.tofile(f)
+        np.array([F.min_x, F.max_x, F.min_y, F.max_y, F.width_inv, F.height_inv], np.float32).tofile(f)
+        F.scale.astype(np.float32).tofile(f); F.sigma2.astype(np.float32).tofile(f); F.inv_sigma2.astype(np.float32).tofile(f)
+        np.array([view.log_scale_factor], np.float32).tofile(f)
+        F.xy.astype(np.float32).tofile(f); F.octave.astype(np.int32).tofile(f); F.angle.astype(np.float32).tofile(f); F.uright.astype(np.float32).tofile(f)
+        np.ascontiguousarray(F.desc, np.uint32).tofile(f)
+        T.astype(np.float32).tofile(f); Tlast.astype(np.float32).tofile(f); np.array([7.0, 3.0], np.float32).tofile(f)
+        mp["occupied"].astype(np.uint8).tofile(f)
+        _write_points(f, mp, 2300, l_nobs, l_bad)
+        _write_points(f, last, N, last_nobs, np.zeros(N, np.uint8)); last_valid.astype(np.uint8).tofile(f); last_outlier.tofile(f)
+        F.octave.astype(np.int32).tofile(f); last_angle.tofile(f)
+        _write_points(f, mpf, 2000, f_nobs, f_bad); kf_has.tofile(f); kf_nobs.tofile(f)
+    r = subprocess.run([harness, "match", str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    with open(tmp_path / "out.bin", "rb") as f:
+        c1 = np.fromfile(f, np.int32, 2); idx1 = np.fromfile(f, np.int32, N); inview = np.fromfile(f, np.uint8, 2300); lvl = np.fromfile(f, np.int32, 2300)
+        vis = np.fromfile(f, np.int32, 2300); uvr = np.fromfile(f, np.float32, 3 * 2300).reshape(-1, 3); vc = np.fromfile(f, np.float32, 2300)
+        c2 = np.fromfile(f, np.int32, 2); idx2 = np.fromfile(f, np.int32, N); removed2 = np.fromfile(f, np.uint8, N)
+        c3 = np.fromfile(f, np.int32, 1); match3 = np.fromfile(f, np.int32, 2000); idx3 = np.fromfile(f, np.int32, N)
+        pbad = np.fromfile(f, np.uint8, 2000); pobs = np.fromfile(f, np.int32, 2000); kbad = np.fromfile(f, np.uint8, N)
+    token = 1 << 20
+
+    def as_slot(idx):
+        return np.where(idx == -2, token, idx).astype(np.int32)
+    # ---- SearchLocalPoints
+    k, inv, uvr_o, lvl_o, vc_o = OS.is_in_frustum(view, mp)
+    n_exp, slot = OS.search_by_projection_map(F, mp["desc"], inv, uvr_o[:, :2], uvr_o[:, 2], lvl_o, vc_o, mp["has_obs"], mp["occupied"], float(th_local), 0.8)
+    assert c1[1] == k and c1[0] == n_exp and n_exp > 150
+    np.testing.assert_array_equal(as_slot(idx1), slot)
+    np.testing.assert_array_equal(inview != 0, inv != 0)
+    m = inv != 0
+    np.testing.assert_array_equal(uvr[m], uvr_o[m]); np.testing.assert_array_equal(lvl[m], lvl_o[m]); np.testing.assert_array_equal(vc[m], vc_o[m])
+    np.testing.assert_array_equal(vis, 1 + m.astype(np.int32))                      # IncreaseVisible once per point in the frustum
+    # ---- SearchByProjection(Current, Last)
+    lastd = dict(world_pos=last["world_pos"], valid=(last_valid & (last_outlier == 0)).astype(np.uint8), octave=F.octave, angle=last_angle,
+                 desc=last["desc"], has_obs=(last_nobs > 0).astype(np.uint8))
+    valid, uv, ur = OS.project_last_frame(view, lastd)
+    direction = -1 if back else 1
+    n2, slot2 = OS.search_by_projection_frame(F, lastd["desc"], valid, uv, ur, lastd["octave"], lastd["angle"], lastd["has_obs"], mp["occupied"],
+                                              direction, 7.0, True)
+    assert c2[1] == direction and c2[0] == n2 and n2 > 100 and removed2.sum() > 0
+    np.testing.assert_array_equal(as_slot(idx2), slot2)
+    # ---- Fuse: the search, then the reference's bookkeeping replayed on plain arrays
+    mpf_s = dict(mpf, skip=f_bad)
+    vf, uvf, urf, lf = OS.project_fuse(view, mpf_s)
+    n_search, best = OS.fuse_search(F, mpf["desc"], vf, uvf, urf, lf, 3.0)
+    np.testing.assert_array_equal(match3, best)
+    holder = np.where(kf_has != 0, -2, -1).astype(np.int64)                         # per keypoint: -2 the keyframe's own MapPoint, -1 none, else a fused point
+    hold_obs = kf_nobs.astype(np.int64).copy(); own_bad = np.zeros(N, bool)
+    p_bad = f_bad.astype(bool).copy(); p_obs = f_nobs.astype(np.int64).copy(); p_in_kf = np.zeros(2000, bool)
+    fused = 0
+    for i in range(2000):
+        b = best[i]
+        if b < 0 or p_bad[i] or p_in_kf[i]: continue
+        if holder[b] != -1:
+            if holder[b] == -2:
+                if not own_bad[b]:
+                    if hold_obs[b] > p_obs[i]: p_bad[i] = True                       # pMP->Replace(pMPinKF): pMP has no observations to move
+                    else:                                                           # pMPinKF->Replace(pMP): its observation in pKF moves to pMP
+                        own_bad[b] = True; holder[b] = i; p_in_kf[i] = True; p_obs[i] += 2 if F.uright[b] >= 0 else 1
+            else:
+                j = holder[b]                                                       # a point fused earlier in this loop holds the keypoint
+                if not p_bad[j]:
+                    if p_obs[j] > p_obs[i]: p_bad[i] = True
+                    else:
+                        p_bad[j] = True; p_in_kf[j] = False; holder[b] = i; p_in_kf[i] = True; p_obs[i] += 2 if F.uright[b] >= 0 else 1
+        else:
+            holder[b] = i; p_in_kf[i] = True; p_obs[i] += 2 if F.uright[b] >= 0 else 1
+        fused += 1
+    assert c3[0] == fused and 100 < fused <= n_search
+    np.testing.assert_array_equal(idx3, holder)
+    np.testing.assert_array_equal(pbad != 0, p_bad); np.testing.assert_array_equal(kbad != 0, own_bad)
+    live = ~p_bad
+    np.testing.assert_array_equal(pobs[live], p_obs[live])
+
