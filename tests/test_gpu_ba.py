@@ -432,15 +432,21 @@ def test_batch_config_256_lba_b_windows(gpu_ctx, oracle):
             assert np.linalg.norm(a.cam_qt[:50, 4:] - gt, axis=1).mean() < 0.3 * np.linalg.norm(w.cam_qt[:50, 4:] - gt, axis=1).mean(), i
         b.solve()                                          # restart from the uploaded state: the same answer (to the run-to-run noise of the LDS atomics)
         # (the per-camera sums go through LDS atomics whose order varies; 20 LM iterations amplify that to ~1e-6 on chi2, DESIGN.md "Determinism")
-        loose = 0
+        # An observation whose final chi2 lands within that noise of the classification threshold is bistable: window 232 holds one
+        # point observation that comes out on either side of 7.815 from run to run (tools/exp_restart_noise.py: one flag of that
+        # window differs from the first solve in 40 % of 56 repeats, no other window ever, chi2 within 5e-6, poses within 6e-7) - so
+        # the sets are compared with a budget of two flags in at most three windows, not bit for bit.
+        loose = 0; flipped = 0
         for i in range(256):
             c = b.download(i)
-            np.testing.assert_array_equal(c.pt_obs_outlier, first[i].pt_obs_outlier); np.testing.assert_array_equal(c.line_removed, first[i].line_removed)
-            np.testing.assert_array_equal(c.ln_edge_outlier, first[i].ln_edge_outlier)
+            flips = int((c.pt_obs_outlier != first[i].pt_obs_outlier).sum() + (c.ln_edge_outlier != first[i].ln_edge_outlier).sum()
+                        + (c.line_removed != first[i].line_removed).sum())
+            assert flips <= 2, i
+            flipped += flips > 0
             assert c.stats["chi2_final"] == pytest.approx(first[i].stats["chi2_final"], rel=1e-4)
             loose += not (c.stats["chi2_final"] == pytest.approx(first[i].stats["chi2_final"], rel=1e-5))
             np.testing.assert_allclose(c.cam_qt, first[i].cam_qt, rtol=1e-5, atol=1e-7)
-        assert loose <= 2
+        assert loose <= 2 and flipped <= 3
 
 
 # ---------------------------------------------------------------------------------------------------------------- ill-conditioned Hll
