@@ -93,3 +93,23 @@ def test_frame_line_indices_select_the_threshold(gpu_ctx, oracle, fid, kw):
         b.solve()
         _check(b.download(0), oracle.pose_opt(f, gamma=0.5), f.n_points)
         _check(b.download(1), oracle.pose_opt(dataclasses.replace(f, ln_frame_index=None), gamma=0.5), f.n_points)
+
+
+@pytest.mark.parametrize("what", ["nan_keypoint", "inf_map_point", "nan_pose"])
+def test_non_finite_frame_terminates_and_leaves_the_context_clean(gpu_ctx, oracle, what):
+    """A NaN / Inf in one frame: the call returns (4 rounds of at most 10 iterations x 10 trials), the other frames of a batch are the
+    oracle's answers, and so is the next call on the same context."""
+    import copy
+    clean = synth.make_pose_frame(8, n_points=300, n_lines=60)
+    bad = copy.deepcopy(clean)
+    if what == "nan_keypoint": bad.pt_uvr = bad.pt_uvr.copy(); bad.pt_uvr[11, 1] = np.nan
+    elif what == "inf_map_point": bad.pt_xw = bad.pt_xw.copy(); bad.pt_xw[3, 0] = np.inf
+    else: bad.pose_qt = bad.pose_qt.copy(); bad.pose_qt[5] = np.nan
+    g = Optimizer(gpu_ctx).PoseOptimization(bad, gamma=0.5)
+    assert g.lm_iterations <= 40 and g.lm_trials <= 400
+    ref = oracle.pose_opt(clean, gamma=0.5)
+    with PoseBatch(gpu_ctx, [clean, bad, clean], gamma=0.5) as b:
+        b.solve()
+        _check(b.download(0), ref, clean.n_points); _check(b.download(2), ref, clean.n_points)
+    _check(Optimizer(gpu_ctx).PoseOptimization(clean, gamma=0.5), ref, clean.n_points)
+
