@@ -26,14 +26,23 @@ constexpr unsigned kKeyEmpty = (256u << kIdxBits) | ((1u << kIdxBits) - 1u);
 
 __device__ __forceinline__ void key_update(unsigned key, unsigned& best, unsigned& second) {
   // lexicographic top-2: second = min(second, max(best, key)); best = min(best, key)
-  second = min(second, max(best, key));
+  // with best <= second the new second is the median of the three (one v_med3_u32 instead of a max and a min)
+  asm("v_med3_u32 %0, %1, %2, %3" : "=v"(second) : "v"(best), "v"(second), "v"(key));
   best = min(best, key);
 }
 
+// v_bcnt_u32_b32 D = popcount(S0) + S1: the eight words of a descriptor pair are counted in one accumulating chain.  Written as asm
+// because the compiler prefers eight independent counts and three v_add3_u32 (shorter chains, 3 more instructions per pair); the brute-
+// force kernel has four independent queries per lane to fill the chain's latency and is bound by VALU issue.
+__device__ __forceinline__ unsigned bcnt_acc(unsigned x, unsigned acc) {
+  unsigned d;
+  asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(acc));
+  return d;
+}
 __device__ __forceinline__ unsigned hamming8(const uint4& qa, const uint4& qb, const uint4& ta, const uint4& tb) {
   unsigned d = __popc(qa.x ^ ta.x);
-  d += __popc(qa.y ^ ta.y); d += __popc(qa.z ^ ta.z); d += __popc(qa.w ^ ta.w);
-  d += __popc(qb.x ^ tb.x); d += __popc(qb.y ^ tb.y); d += __popc(qb.z ^ tb.z); d += __popc(qb.w ^ tb.w);
+  d = bcnt_acc(qa.y ^ ta.y, d); d = bcnt_acc(qa.z ^ ta.z, d); d = bcnt_acc(qa.w ^ ta.w, d);
+  d = bcnt_acc(qb.x ^ tb.x, d); d = bcnt_acc(qb.y ^ tb.y, d); d = bcnt_acc(qb.z ^ tb.z, d); d = bcnt_acc(qb.w ^ tb.w, d);
   return d;
 }
 
