@@ -126,13 +126,17 @@ __global__ __launch_bounds__(256) void hamming256_csr_kernel(
 constexpr int kL2Threads = 256;
 constexpr int kL2TileRows = 32;
 
-template <int DIM_MAX>
+// kExact: dim == DIM_MAX, known at compile time.  With a run-time dim every component of the unrolled sums sits behind its own `i < dim`
+// branch: one ds_read_b32 per component, scalar registers spilled into lanes, 3158 instructions of which 225 are the FMAs.  The
+// descriptor lengths in use (72: LBD, 32) therefore get the exact form, other lengths the guarded one.
+template <int DIM_MAX, bool kExact>
 __global__ __launch_bounds__(kL2Threads) void l2f32_best2_kernel(
-    const float* __restrict__ q, int nq, const float* __restrict__ t, int nt, int dim, const uint8_t* __restrict__ mask,
+    const float* __restrict__ q, int nq, const float* __restrict__ t, int nt, int dim_arg, const uint8_t* __restrict__ mask,
     int* __restrict__ best_idx, double* __restrict__ best_dist, int* __restrict__ second_idx, double* __restrict__ second_dist,
     double* __restrict__ dist_matrix /* optional [nq][nt] */) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* tile = reinterpret_cast<float*>(smem);                        // [kL2TileRows][dim]
+  const int dim = kExact ? DIM_MAX : dim_arg;
   const int pair = blockIdx.y;
   q += (size_t)pair * nq * dim; t += (size_t)pair * nt * dim;
   const size_t out_off = (size_t)pair * nq;
@@ -140,7 +144,7 @@ __global__ __launch_bounds__(kL2Threads) void l2f32_best2_kernel(
   const bool valid = qi < nq;
   float qa[DIM_MAX];
 #pragma unroll
-  for (int i = 0; i < DIM_MAX; i++) qa[i] = (valid && i < dim) ? q[(size_t)qi * dim + i] : 0.f;
+  for (int i = 0; i < DIM_MAX; i++) qa[i] = (valid && (kExact || i < dim)) ? q[(size_t)qi * dim + i] : 0.f;
   double bd = 1.7976931348623157e308, sd = 1.7976931348623157e308;
   int bi = -1, si = -1;
   // a wavefront without a single query (300 queries in blocks of 256: three of the second block's four) only helps to stage the tiles
@@ -163,15 +167,16 @@ __global__ __launch_bounds__(kL2Threads) void l2f32_best2_kernel(
     for (int i = threadIdx.x; i < rows * dim; i += kL2Threads) tile[i] = t[(size_t)base * dim + i];
     __syncthreads();
     if (!wave_has_queries) continue;
+    const float* tile_rows = tile;
     int r = 0;
     // two train rows at a time: two independent accumulation chains (each row's sum keeps its own index order, so the result is
     // bit-identical to the one-row loop and to the oracle)
     for (; r + 1 < rows; r += 2) {
-      const float* tr0 = tile + r * dim; const float* tr1 = tr0 + dim;
+      const float* tr0 = tile_rows + r * dim; const float* tr1 = tr0 + dim;
       double acc0 = 0.0, acc1 = 0.0;
 #pragma unroll
       for (int i = 0; i < DIM_MAX; i++) {
-        if (i < dim) {
+        if (kExact || i < dim) {
           const float d0 = qa[i] - tr0[i], d1 = qa[i] - tr1[i];
           acc0 = fma((double)d0, (double)d0, acc0); acc1 = fma((double)d1, (double)d1, acc1);
         }
@@ -179,11 +184,11 @@ __global__ __launch_bounds__(kL2Threads) void l2f32_best2_kernel(
       LLD_L2_TAKE(sqrt(acc0), base + r); LLD_L2_TAKE(sqrt(acc1), base + r + 1);
     }
     for (; r < rows; r++) {
-      const float* tr = tile + r * dim;
+      const float* tr = tile_rows + r * dim;
       double acc = 0.0;
 #pragma unroll
       for (int i = 0; i < DIM_MAX; i++) {
-        if (i < dim) { const float d = qa[i] - tr[i]; acc = fma((double)d, (double)d, acc); }
+        if (kExact || i < dim) { const float d = qa[i] - tr[i]; acc = fma((double)d, (double)d, acc); }
       }
       LLD_L2_TAKE(sqrt(acc), base + r);
     }
@@ -685,12 +690,14 @@ int launch_l2(lld_ctx* ctx, int batch, const float* q, int nq, const float* t, i
   }
   dim3 grid((nq + kL2Threads - 1) / kL2Threads, batch);
   const size_t lds = (size_t)kL2TileRows * dim * sizeof(float);
-#define LLD_L2_LAUNCH(N)                                                                                                 \
-  hipLaunchKernelGGL(l2f32_best2_kernel<N>, grid, dim3(kL2Threads), lds, ctx->stream, q, nq, t, nt, dim, mask, bi, bd, si, sd, \
+#define LLD_L2_LAUNCH(N, EXACT)                                                                                                 \
+  hipLaunchKernelGGL((l2f32_best2_kernel<N, EXACT>), grid, dim3(kL2Threads), lds, ctx->stream, q, nq, t, nt, dim, mask, bi, bd, si, sd, \
                      dist_matrix)
-  if (dim <= 32) LLD_L2_LAUNCH(32);
-  else if (dim <= 72) LLD_L2_LAUNCH(72);
-  else if (dim <= 128) LLD_L2_LAUNCH(128);
+  if (dim == 32) LLD_L2_LAUNCH(32, true);
+  else if (dim == 72) LLD_L2_LAUNCH(72, true);
+  else if (dim <= 32) LLD_L2_LAUNCH(32, false);
+  else if (dim <= 72) LLD_L2_LAUNCH(72, false);
+  else if (dim <= 128) LLD_L2_LAUNCH(128, false);
   else return LLD_ERR_UNSUPPORTED;
 #undef LLD_L2_LAUNCH
   LLD_HIP_TRY(hipGetLastError());
