@@ -44,7 +44,10 @@ METRIC = "local-BA windows/sec (50 KF, 10k pts, 2k lines) at matched chi2; 1/2/4
 HBM_PEAK_GBS = 8000.0               # nominal HBM3E (MI355X_MICROARCH.md)
 HBM_ACHIEVABLE_GBS = 6300.0         # what a streaming kernel reaches on this part (same guide)
 FP64_FMA_PEAK_T = 39.3              # 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz (vector fp64 FMA/s; the fp64 matrix rate is the same)
-VALU32_PEAK_T = 78.6                # 256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz (32-bit VALU lane-ops/s: v_xor_b32, v_fma_f32)
+# 32-bit VALU lane-ops/s for the Hamming kernel's mix of 8 v_xor_b32 + 8 v_bcnt_u32_b32 per descriptor pair, MEASURED on the part
+# (tools/microbench/valu_rate.hip: v_xor_b32 55.3 T, v_bcnt_u32_b32 35.0 T, v_fma_f32 44.3 T lane-ops/s with 8 waves per SIMD):
+# 16 / (8 / 55.3 + 8 / 35.0).  The 78.6 T of the data sheet (32 lanes/clk/SIMD) is the packed-fp32 rate; no integer instruction reaches it.
+VALU32_PEAK_T = 42.9
 PHASES = ["ba_linearize", "ba_schur", "ba_solve", "ba_backsub", "ba_control"]
 
 
