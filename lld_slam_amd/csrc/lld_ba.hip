@@ -886,7 +886,7 @@ static int ba_batch_solve_impl(lld_ba_batch* B, StopFlag abort_flag) {
         hipLaunchKernelGGL(ba_classify_kernel, dim3(std::max(1, G.max_lblocks), G.nw), dim3(kLmThreads), 0, G.st, A, dw, ds);
         hipLaunchKernelGGL(ba_round2_kernel, dim3(G.nw), dim3(kCtlThreads), 0, G.st, A, dw, ds);
       }
-      if (n_fin > 0) finalize_group(G);
+      (void)n_fin;                             // finished windows wait for the group's trailing read-back (one launch instead of one per super-step that finished a window)
       LLD_HIP_TRY(hipGetLastError());
       // a window whose classification leaves an empty active set goes straight to FINALIZE: the trailing read-back picks it up
       if ((n_run + n_trans) > 0 && G.steps < kMaxSuperSteps) { int s = launch_chunk(G); if (s) return s; any = true; }
