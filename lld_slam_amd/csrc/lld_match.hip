@@ -123,8 +123,12 @@ __global__ __launch_bounds__(256) void hamming256_csr_kernel(
 // ------------------------------------------------------------------ float L2 (LBD)
 // d = sqrt( sum_i (double)(a_i - b_i)^2 ), float difference, double accumulation in ascending i (the product of two
 // floats is exact in double, so the fused multiply-add below rounds exactly like mul-then-add on the CPU).
-constexpr int kL2Threads = 256;
-constexpr int kL2TileRows = 32;
+// One wavefront per workgroup: the exact kernel holds a 72-float query and two rows' sums in 192 VGPRs (two wavefronts per SIMD), and the
+// 300 queries of a frame pair are 4.7 wavefronts - in workgroups of 256 lanes the second one kept three idle wavefronts resident beside its
+// single working one (5 working wavefronts in 8 slots).  Each wavefront now stages the train tile for itself (86 KB per pair and
+// wavefront out of L2): 826 k -> 1.2 M frame pairs/s.
+constexpr int kL2Threads = 64;
+constexpr int kL2TileRows = 64;
 
 // kExact: dim == DIM_MAX, known at compile time.  With a run-time dim every component of the unrolled sums sits behind its own `i < dim`
 // branch: one ds_read_b32 per component, scalar registers spilled into lanes, 3158 instructions of which 225 are the FMAs.  The
@@ -147,7 +151,7 @@ __global__ __launch_bounds__(kL2Threads) void l2f32_best2_kernel(
   for (int i = 0; i < DIM_MAX; i++) qa[i] = (valid && (kExact || i < dim)) ? q[(size_t)qi * dim + i] : 0.f;
   double bd = 1.7976931348623157e308, sd = 1.7976931348623157e308;
   int bi = -1, si = -1;
-  // a wavefront without a single query (300 queries in blocks of 256: three of the second block's four) only helps to stage the tiles
+  // (with workgroups of more than one wavefront: a wavefront without a single query only helps to stage the tiles)
   const bool wave_has_queries = blockIdx.x * kL2Threads + (threadIdx.x & ~63) < nq;
 #define LLD_L2_TAKE(DIST, J)                                                                              \
   do {                                                                                                    \
