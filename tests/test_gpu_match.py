@@ -149,6 +149,34 @@ def test_batched_hamming_device_entry_point(gpu_ctx, oracle):
             np.testing.assert_array_equal(o[b].cpu().numpy(), e)
 
 
+@pytest.mark.parametrize("B,nq,nt,dim", [(5, 300, 300, 72), (3, 65, 131, 72), (4, 257, 33, 32), (2, 70, 45, 40), (2, 64, 100, 128), (3, 10, 7, 7),
+                                         (2, 1, 300, 72), (2, 129, 1, 72)])
+def test_batched_l2_device_entry_point(gpu_ctx, oracle, B, nq, nt, dim):
+    """lld_match_l2f32_batch_dev (the MATCH / LBD config's kernel): descriptor lengths with a compile-time form (72, 32) and without,
+    query counts around the 64-lane workgroup, train counts around the 64-row tile - every pair bit-exact against the oracle, all four
+    outputs."""
+    import torch
+    dev = torch.device("cuda", gpu_ctx.device)
+    rng = np.random.default_rng(1000 * B + nq + dim)
+    if dim == 72 and nq >= 65:
+        qs, ts = zip(*[synth.make_match_lbd(20 + b, nq, nt, dim, n_corr=int(0.5 * min(nq, nt))) for b in range(B)])
+    else:
+        qs = [rng.normal(size=(nq, dim)).astype(np.float32) for _ in range(B)]; ts = [rng.normal(size=(nt, dim)).astype(np.float32) for _ in range(B)]
+        ts[0][nt // 2] = ts[0][0]                                                       # a tie: the lower index must win
+    q = torch.from_numpy(np.stack(qs)).to(dev); t = torch.from_numpy(np.stack(ts)).to(dev)
+    bi = torch.empty((B, nq), dtype=torch.int32, device=dev); si = torch.empty_like(bi)
+    bd = torch.empty((B, nq), dtype=torch.float64, device=dev); sd = torch.empty_like(bd)
+    torch.cuda.synchronize()
+    assert gpu_ctx.lib.fn("match_l2f32_batch_dev")(gpu_ctx.handle, B, q.data_ptr(), nq, t.data_ptr(), nt, dim, bi.data_ptr(), bd.data_ptr(),
+                                                   si.data_ptr(), sd.data_ptr()) == 0
+    gpu_ctx.synchronize()
+    for b in range(B):
+        ebi, ebd, esi, esd = oracle.match_l2f32(qs[b], ts[b])
+        np.testing.assert_array_equal(bi[b].cpu().numpy(), ebi); np.testing.assert_array_equal(bd[b].cpu().numpy(), ebd)
+        if nt > 1:
+            np.testing.assert_array_equal(si[b].cpu().numpy(), esi); np.testing.assert_array_equal(sd[b].cpu().numpy(), esd)
+
+
 @pytest.mark.parametrize("seed,nl,nr", [(0, 300, 300), (1, 257, 130), (2, 64, 400)])
 def test_stereo_line_association_gates_on_device(gpu_ctx, oracle, seed, nl, nr):
     """TwoFrameLineMatcher::MatchLines incl. CheckLinePair's triangulation / depth gates (src/TwoFrameLineMatcher.cc:26-124): the gate
