@@ -3,6 +3,7 @@
 // itself - projection, window search, gates, accept rule, occupancy, rotation histogram - to ONE call of the C ABI.
 #include "lld_matcher_adapter.h"
 
+#include <cmath>
 #include <cstring>
 #include <stdexcept>
 #include <string>
@@ -239,6 +240,166 @@ int ORBmatcher::Fuse(KeyFrame* pKF, const std::vector<MapPoint*>& vpMapPoints, c
     nFused++;
   }
   return nFused;
+}
+
+// ================================================================== relocalisation / loop closing
+namespace {
+
+// The decomposition at the head of SearchByProjection(KeyFrame*, Scw, ...) and Fuse(KeyFrame*, Scw, ...) (ORBmatcher.cc:298-303, :984-989):
+// scw = sqrt(sRcw.row(0).dot(sRcw.row(0))), Rcw = sRcw/scw, tcw = Scw.col(3)/scw, Ow = -Rcw.t()*tcw.  With the real classes these are the
+// four OpenCV expressions themselves; the doubles have no matrix algebra, so they are spelled out (dot and gemm accumulate in double).
+void scw_view(const lld_slam::Mat& Scw, lld_frame_view& v) {
+  double n2 = 0.0;
+  for (int c = 0; c < 3; c++) n2 += (double)Scw.at<float>(0, c) * (double)Scw.at<float>(0, c);
+  const float scw = (float)std::sqrt(n2);
+  for (int r = 0; r < 3; r++) {
+    for (int c = 0; c < 3; c++) v.Rcw[3 * r + c] = (float)((double)Scw.at<float>(r, c) / (double)scw);
+    v.tcw[r] = (float)((double)Scw.at<float>(r, 3) / (double)scw);
+  }
+  for (int r = 0; r < 3; r++) {
+    double acc = 0.0;
+    for (int k = 0; k < 3; k++) acc += (double)v.Rcw[3 * k + r] * (double)v.tcw[k];
+    v.Ow[r] = (float)(-acc);
+  }
+}
+template <class KF>
+void view_camera(lld_frame_view& v, const KF& f) {
+  v.fx = f.fx; v.fy = f.fy; v.cx = f.cx; v.cy = f.cy; v.bf = f.mbf;
+  v.min_x = (float)f.mnMinX; v.max_x = (float)f.mnMaxX; v.min_y = (float)f.mnMinY; v.max_y = (float)f.mnMaxY;
+  v.log_scale_factor = f.mfLogScaleFactor; v.n_levels = f.mnScaleLevels;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ SearchByProjection(Frame&, KeyFrame*, sAlreadyFound, th, ORBdist)   :1472-1599
+int ORBmatcher::SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const std::set<MapPoint*>& sAlreadyFound, const float th, const int ORBdist, MatchTrace* trace) {
+  const std::vector<MapPoint*> vpMPs = pKF->GetMapPointMatches();
+  const int n = (int)vpMPs.size();
+  PointSide pts(n);
+  std::vector<float> angle(n + 1, 0.f);
+  for (int i = 0; i < n; i++) {
+    MapPoint* pMP = vpMPs[i];
+    pts.skip[i] = !pMP || pMP->isBad() || sAlreadyFound.count(pMP);           // :1491-1494
+    if (!pts.skip[i]) pts.set(i, pMP);
+    angle[i] = pKF->mvKeysUn[i].angle;                                        // :1563
+  }
+  KeypointSide ks; ks.fill(CurrentFrame, CurrentFrame.N);
+  for (int k = 0; k < CurrentFrame.N; k++) ks.occupied[k] = CurrentFrame.mvpMapPoints[k] != NULL;   // :1542-1543: any MapPoint blocks
+  lld_frame_view view; std::memset(&view, 0, sizeof view);
+  // Rcw, tcw of CurrentFrame.mTcw and Ow = -Rcw.t()*tcw (:1476-1478): the frame keeps exactly these (Frame::UpdatePoseMatrices)
+  view_pose(view, CurrentFrame.mRcw, CurrentFrame.mtcw, CurrentFrame.mOw);
+  view_camera(view, CurrentFrame);
+  lld_orb_projection pr; std::memset(&pr, 0, sizeof pr);
+  pr.routine = LLD_ORB_PROJ_RELOC; pr.th = th; pr.accept_max = ORBdist; pr.check_orientation = mbCheckOrientation ? 1 : 0;
+  Result res(n, CurrentFrame.N);
+  check(lld_orb_search_projected(ctx_, &ks.s, &view, &pts.m, angle.data(), &pr, NULL, NULL, &res.r), "lld_orb_search_projected");
+  for (int i = 0; i < n; i++) if (res.match[i] >= 0) CurrentFrame.mvpMapPoints[res.match[i]] = vpMPs[i];                       // :1557
+  for (int i = 0; i < n; i++) if (res.match[i] >= 0 && res.removed[i]) CurrentFrame.mvpMapPoints[res.match[i]] = NULL;         // :1590
+  res.to(trace, n);
+  return res.r.n_matches;
+}
+
+// ------------------------------------------------------------------ SearchByProjection(KeyFrame*, Scw, vpPoints, vpMatched, th)   :290-403
+int ORBmatcher::SearchByProjection(KeyFrame* pKF, const lld_slam::Mat& Scw, const std::vector<MapPoint*>& vpPoints, std::vector<MapPoint*>& vpMatched, int th, MatchTrace* trace) {
+  std::set<MapPoint*> spAlreadyFound(vpMatched.begin(), vpMatched.end());    // :306-307
+  spAlreadyFound.erase(static_cast<MapPoint*>(NULL));
+  const int n = (int)vpPoints.size(), N = (int)pKF->mvKeysUn.size();
+  PointSide pts(n);
+  for (int i = 0; i < n; i++) {
+    MapPoint* pMP = vpPoints[i];
+    pts.skip[i] = pMP->isBad() || spAlreadyFound.count(pMP);                  // :317-318
+    if (!pts.skip[i]) pts.set(i, pMP);
+  }
+  KeypointSide ks; ks.fill(*pKF, N);
+  for (int k = 0; k < N; k++) ks.occupied[k] = vpMatched[k] != NULL;          // :375-376
+  lld_frame_view view; std::memset(&view, 0, sizeof view);
+  scw_view(Scw, view); view_camera(view, *pKF);
+  lld_orb_projection pr; std::memset(&pr, 0, sizeof pr);
+  pr.routine = LLD_ORB_PROJ_KF_SIM3; pr.th = (float)th;
+  Result res(n, N);
+  check(lld_orb_search_projected(ctx_, &ks.s, &view, &pts.m, NULL, &pr, NULL, NULL, &res.r), "lld_orb_search_projected");
+  for (int i = 0; i < n; i++) if (res.match[i] >= 0) vpMatched[res.match[i]] = vpPoints[i];   // :396
+  res.to(trace, n);
+  return res.r.n_matches;
+}
+
+// ------------------------------------------------------------------ Fuse(KeyFrame*, Scw, vpPoints, th, vpReplacePoint)   :977-1100
+int ORBmatcher::Fuse(KeyFrame* pKF, const lld_slam::Mat& Scw, const std::vector<MapPoint*>& vpPoints, float th, std::vector<MapPoint*>& vpReplacePoint, MatchTrace* trace) {
+  const std::set<MapPoint*> spAlreadyFound = pKF->GetMapPoints();             // :992
+  const int nPoints = (int)vpPoints.size(), N = (int)pKF->mvKeysUn.size();
+  PointSide pts(nPoints);
+  for (int i = 0; i < nPoints; i++) {
+    MapPoint* pMP = vpPoints[i];
+    pts.skip[i] = pMP->isBad() || spAlreadyFound.count(pMP);                  // :1004-1005
+    if (!pts.skip[i]) pts.set(i, pMP);
+  }
+  KeypointSide ks; ks.fill(*pKF, N);
+  ks.s.t_occupied = NULL;
+  lld_frame_view view; std::memset(&view, 0, sizeof view);
+  scw_view(Scw, view); view_camera(view, *pKF);
+  lld_orb_projection pr; std::memset(&pr, 0, sizeof pr);
+  pr.routine = LLD_ORB_PROJ_FUSE_SIM3; pr.th = th;
+  Result res(nPoints, N);
+  check(lld_orb_search_projected(ctx_, &ks.s, &view, &pts.m, NULL, &pr, NULL, NULL, &res.r), "lld_orb_search_projected");
+  res.to(trace, nPoints);
+  // :1078-1093 in loop order (the set of :992 is a copy taken before the loop, so the skip test does not change while it runs)
+  int nFused = 0;
+  for (int iMP = 0; iMP < nPoints; iMP++) {
+    const int bestIdx = res.match[iMP];
+    if (bestIdx < 0) continue;
+    MapPoint* pMP = vpPoints[iMP];
+    MapPoint* pMPinKF = pKF->GetMapPoint(bestIdx);
+    if (pMPinKF) {
+      if (!pMPinKF->isBad()) vpReplacePoint[iMP] = pMPinKF;
+    } else {
+      pMP->AddObservation(pKF, bestIdx);
+      pKF->AddMapPoint(pMP, bestIdx);
+    }
+    nFused++;
+  }
+  return nFused;
+}
+
+// ------------------------------------------------------------------ SearchBySim3   :1102-1326
+int ORBmatcher::SearchBySim3(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches12, const float& s12, const lld_slam::Mat& R12, const lld_slam::Mat& t12,
+                             const float th, MatchTrace* trace) {
+  // sR12 = s12*R12, sR21 = (1.0/s12)*R12.t(), t21 = -sR21*t12 (:1121-1124): scalar factors applied in double with one rounding, the product one gemm
+  float sR12[9], sR21[9], t12f[3], t21[3];
+  for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) {
+    sR12[3 * r + c] = (float)((double)s12 * (double)R12.at<float>(r, c));
+    sR21[3 * r + c] = (float)((1.0 / (double)s12) * (double)R12.at<float>(c, r));
+  }
+  for (int r = 0; r < 3; r++) t12f[r] = t12.at<float>(r);
+  for (int r = 0; r < 3; r++) {
+    double acc = 0.0;
+    for (int k = 0; k < 3; k++) acc += (double)sR21[3 * r + k] * (double)t12f[k];
+    t21[r] = (float)(-acc);
+  }
+  const std::vector<MapPoint*> vpMapPoints1 = pKF1->GetMapPointMatches(), vpMapPoints2 = pKF2->GetMapPointMatches();
+  const int N1 = (int)vpMapPoints1.size(), N2 = (int)vpMapPoints2.size();
+  std::vector<bool> vbAlreadyMatched1(N1, false), vbAlreadyMatched2(N2, false);
+  for (int i = 0; i < N1; i++) {                                              // :1133-1144
+    MapPoint* pMP = vpMatches12[i];
+    if (pMP) {
+      vbAlreadyMatched1[i] = true;
+      const int idx2 = pMP->GetIndexInKeyFrame(pKF2);
+      if (idx2 >= 0 && idx2 < N2) vbAlreadyMatched2[idx2] = true;
+    }
+  }
+  PointSide p1(N1), p2(N2);
+  for (int i = 0; i < N1; i++) { MapPoint* pMP = vpMapPoints1[i]; p1.skip[i] = !pMP || vbAlreadyMatched1[i] || pMP->isBad(); if (!p1.skip[i]) p1.set(i, pMP); }   // :1152-1157
+  for (int i = 0; i < N2; i++) { MapPoint* pMP = vpMapPoints2[i]; p2.skip[i] = !pMP || vbAlreadyMatched2[i] || pMP->isBad(); if (!p2.skip[i]) p2.set(i, pMP); }   // :1232-1237
+  KeypointSide k1, k2; k1.fill(*pKF1, N1); k2.fill(*pKF2, N2);
+  k1.s.t_occupied = NULL; k2.s.t_occupied = NULL;
+  lld_frame_view v1, v2; std::memset(&v1, 0, sizeof v1); std::memset(&v2, 0, sizeof v2);
+  view_pose(v1, pKF1->GetRotation(), pKF1->GetTranslation(), pKF1->GetCameraCenter()); view_camera(v1, *pKF1);
+  view_pose(v2, pKF2->GetRotation(), pKF2->GetTranslation(), pKF2->GetCameraCenter()); view_camera(v2, *pKF2);
+  std::vector<int32_t> match12(N1 + 1, -1);
+  int32_t nFound = 0;
+  check(lld_orb_search_by_sim3(ctx_, &k1.s, &v1, &p1.m, &k2.s, &v2, &p2.m, sR12, t12f, sR21, t21, th, match12.data(), &nFound), "lld_orb_search_by_sim3");
+  for (int i1 = 0; i1 < N1; i1++) if (match12[i1] >= 0) vpMatches12[i1] = vpMapPoints2[match12[i1]];   // :1317
+  if (trace) trace->match.assign(match12.begin(), match12.begin() + N1);
+  return nFound;
 }
 
 }  // namespace lld_adapter

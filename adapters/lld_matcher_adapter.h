@@ -1,7 +1,9 @@
-// lld_matcher_adapter.h — host adapters for the three ORB matchers that run every frame / keyframe, on live SLAM objects:
+// lld_matcher_adapter.h — host adapters for the ORB matchers that project MapPoints, on live SLAM objects.  Every frame / keyframe:
 //   Tracking::SearchLocalPoints                     src/Tracking.cc:1613-1664  (Frame::isInFrustum + ORBmatcher::SearchByProjection(F, points, th))
 //   ORBmatcher::SearchByProjection(Current, Last)   src/ORBmatcher.cc:1328-1470 (the matcher of Tracking::TrackWithMotionModel)
 //   ORBmatcher::Fuse(KeyFrame*, vpMapPoints, th)    src/ORBmatcher.cc:825-958   (the matcher of LocalMapping::SearchInNeighbors)
+// and, at relocalisation / loop closing, SearchByProjection(Frame&, KeyFrame*, ...) :1472-1599, SearchByProjection(KeyFrame*, Scw, ...)
+// :290-403, Fuse(KeyFrame*, Scw, ...) :977-1100 and SearchBySim3 :1102-1326.
 // Each is gather -> ONE call of liblld_amd.so (projection loop and search on the device) -> the reference's bookkeeping on the
 // objects.  Same object model switch as lld_optimizer_adapter.h (LLD_ADAPTER_OBJECTS_HEADER).  Against the real classes the patch
 // adds two trivial getters to MapPoint (GetMinDistance / GetMaxDistance: mfMinDistance and mfMaxDistance are protected and
@@ -9,6 +11,7 @@
 #ifndef LLD_MATCHER_ADAPTER_H
 #define LLD_MATCHER_ADAPTER_H
 
+#include <set>
 #include <vector>
 
 #include "../include/lld_amd.h"
@@ -45,6 +48,16 @@ class ORBmatcher {
   int SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, const float th, const bool bMono, MatchTrace* trace = nullptr);
   // int ORBmatcher::Fuse(KeyFrame *pKF, const vector<MapPoint *> &vpMapPoints, const float th)
   int Fuse(KeyFrame* pKF, const std::vector<MapPoint*>& vpMapPoints, const float th = 3.0f, MatchTrace* trace = nullptr);
+  // The relocalisation / loop-closing matchers (projection loops on the device through lld_orb_search_projected / _by_sim3):
+  // int ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const set<MapPoint*> &sAlreadyFound, const float th, const int ORBdist)   :1472-1599
+  int SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const std::set<MapPoint*>& sAlreadyFound, const float th, const int ORBdist, MatchTrace* trace = nullptr);
+  // int ORBmatcher::SearchByProjection(KeyFrame* pKF, cv::Mat Scw, const vector<MapPoint*> &vpPoints, vector<MapPoint*> &vpMatched, int th)            :290-403
+  int SearchByProjection(KeyFrame* pKF, const lld_slam::Mat& Scw, const std::vector<MapPoint*>& vpPoints, std::vector<MapPoint*>& vpMatched, int th, MatchTrace* trace = nullptr);
+  // int ORBmatcher::Fuse(KeyFrame *pKF, cv::Mat Scw, const vector<MapPoint *> &vpPoints, float th, vector<MapPoint *> &vpReplacePoint)                 :977-1100
+  int Fuse(KeyFrame* pKF, const lld_slam::Mat& Scw, const std::vector<MapPoint*>& vpPoints, float th, std::vector<MapPoint*>& vpReplacePoint, MatchTrace* trace = nullptr);
+  // int ORBmatcher::SearchBySim3(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint*> &vpMatches12, const float &s12, const cv::Mat &R12, const cv::Mat &t12, const float th)   :1102-1326
+  int SearchBySim3(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches12, const float& s12, const lld_slam::Mat& R12, const lld_slam::Mat& t12, const float th,
+                   MatchTrace* trace = nullptr);
 
  private:
   lld_ctx* ctx_;

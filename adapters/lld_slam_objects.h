@@ -18,6 +18,7 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <set>
 #include <vector>
 
 namespace lld_slam {
@@ -110,6 +111,7 @@ class KeyFrame {
   bool IsInImage(const float& x, const float& y) const { return (x >= mnMinX && x < mnMaxX && y >= mnMinY && y < mnMaxY); }   // KeyFrame.cc:633-636
   void AddMapPoint(MapPoint* pMP, const size_t& idx) { mvpMapPoints[idx] = pMP; }
   MapPoint* GetMapPoint(const size_t& idx) const { return mvpMapPoints[idx]; }
+  std::set<MapPoint*> GetMapPoints() const { std::set<MapPoint*> s; for (size_t i = 0; i < mvpMapPoints.size(); i++) if (mvpMapPoints[i]) s.insert(mvpMapPoints[i]); return s; }   // KeyFrame.cc:277-291 (bad points are filtered there; the doubles of the tests hold none)
   void ReplaceMapPointMatch(const size_t& idx, MapPoint* pMP) { mvpMapPoints[idx] = pMP; }
   Mat Ow;                                                          // 3x1, set with the pose by the reference (KeyFrame::SetPose)
 
@@ -140,6 +142,7 @@ class MapPoint {
   float GetMaxDistanceInvariance() const { return 1.2f * mfMaxDistance; }
   int Observations() const { return nObs; }
   bool IsInKeyFrame(KeyFrame* pKF) const { return mObservations.count(pKF) != 0; }
+  int GetIndexInKeyFrame(KeyFrame* pKF) const { std::map<KeyFrame*, size_t>::const_iterator it = mObservations.find(pKF); return it == mObservations.end() ? -1 : (int)it->second; }
   void IncreaseVisible(int n = 1) { mnVisible += n; }
   void IncreaseFound(int n = 1) { mnFound += n; }
   void AddObservation(KeyFrame* pKF, size_t idx) {                  // MapPoint.cc:67-78

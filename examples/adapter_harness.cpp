@@ -18,6 +18,7 @@
 #include <map>
 #include <memory>
 #include <random>
+#include <set>
 #include <string>
 
 #include "../adapters/lld_optimizer_adapter.h"
@@ -411,14 +412,93 @@ int run_match(const char* in, const char* out) {
   return 0;
 }
 
+// The relocalisation / loop-closing matchers through adapters/lld_matcher_adapter.cc: SearchByProjection(Frame&, KeyFrame*, ...),
+// SearchByProjection(KeyFrame*, Scw, ...), Fuse(KeyFrame*, Scw, ...) on one keyframe whose keypoint i holds MapPoint i, and SearchBySim3 on a pair.
+int run_loopmatch(const char* in, const char* out) {
+  Reader r(in);
+  int32_t h[8]; r.get(h, 8);                   // N1, levels, N2, ORBdist, checkOrientation, 0, 0, 0
+  KeypointData K1, K2; K1.read(r, h[0], h[1]);
+  float T[16], Scw[16], th[4]; r.get(T, 16); r.get(Scw, 16); r.get(th, 4);   // th: relocalisation, KF / Scw, Fuse / Scw, SearchBySim3
+  PointData pts; pts.read(r, K1.N);
+  std::vector<float> kf_angle; std::vector<uint8_t> cur_occupied, kf_matched, kf_has, found;
+  r.get(kf_angle, K1.N); r.get(cur_occupied, K1.N); r.get(kf_matched, K1.N); r.get(kf_has, K1.N); r.get(found, K1.N);
+  K2.read(r, h[2], h[1]);
+  float T1[16], T2[16], sim[13]; r.get(T1, 16); r.get(T2, 16); r.get(sim, 13);   // s12, R12 (9), t12 (3)
+  PointData p1, p2; p1.read(r, K1.N); p2.read(r, K2.N);
+  std::vector<uint8_t> has1, has2; std::vector<int32_t> pre12; r.get(has1, K1.N); r.get(has2, K2.N); r.get(pre12, K1.N);
+  lld_amd::Context ctx(0);
+  std::vector<std::unique_ptr<MapPoint> > own;
+  Writer wr(out);
+  auto index_of = [](const std::vector<MapPoint*>& slots, unsigned long id0, int n, std::vector<int32_t>& idx) {
+    idx.assign(slots.size(), -1);
+    for (size_t k = 0; k < slots.size(); k++)
+      if (slots[k]) idx[k] = (slots[k]->mnId >= id0 && slots[k]->mnId < id0 + (unsigned long)n) ? (int32_t)(slots[k]->mnId - id0) : -2;
+  };
+  auto keyframe = [](KeyFrame& KF, const KeypointData& K, const float* Tcw, unsigned long id) {
+    K.keys(KF); KF.mnId = id; KF.Tcw = Mat(4, 4, Tcw);
+    Frame tmp; tmp.SetPose(Mat(4, 4, Tcw)); KF.Ow = tmp.mOw;
+    KF.mvpMapPoints.assign(K.N, nullptr);
+  };
+  {  // ---- relocalisation: the keyframe's MapPoints into the current frame
+    Frame Cur; K1.frame(Cur, T, 20);
+    KeyFrame KF; keyframe(KF, K1, T, 5);
+    for (int k = 0; k < K1.N; k++) KF.mvKeysUn[k].angle = kf_angle[k];
+    std::vector<MapPoint*> mps; pts.make(own, mps, 400000);
+    std::set<MapPoint*> sFound;
+    for (int k = 0; k < K1.N; k++) { KF.mvpMapPoints[k] = mps[k]; if (found[k]) sFound.insert(mps[k]); }
+    for (int k = 0; k < K1.N; k++) if (cur_occupied[k]) { own.emplace_back(new MapPoint()); own.back()->mnId = 930000 + k; Cur.mvpMapPoints[k] = own.back().get(); }
+    lld_adapter::MatchTrace tr;
+    const int n = lld_adapter::ORBmatcher(ctx.get(), 0.9f, h[4] != 0).SearchByProjection(Cur, &KF, sFound, th[0], h[3], &tr);
+    std::vector<int32_t> idx; index_of(Cur.mvpMapPoints, 400000, K1.N, idx);
+    const int32_t c = n; wr.put(&c, 1); wr.put(idx); wr.put(tr.removed);
+    std::printf("SearchByProjection(Frame, KeyFrame): %d matches\n", n);
+  }
+  {  // ---- SearchByProjection(KeyFrame, Scw)
+    KeyFrame KF; keyframe(KF, K1, T, 6);
+    std::vector<MapPoint*> mps; pts.make(own, mps, 500000);
+    std::vector<MapPoint*> vpMatched(K1.N, nullptr);
+    for (int k = 0; k < K1.N; k++) if (kf_matched[k]) { own.emplace_back(new MapPoint()); own.back()->mnId = 940000 + k; vpMatched[k] = own.back().get(); }
+    const int n = lld_adapter::ORBmatcher(ctx.get(), 0.75f).SearchByProjection(&KF, Mat(4, 4, Scw), mps, vpMatched, (int)th[1]);
+    std::vector<int32_t> idx; index_of(vpMatched, 500000, K1.N, idx);
+    const int32_t c = n; wr.put(&c, 1); wr.put(idx);
+    std::printf("SearchByProjection(KeyFrame, Scw): %d matches\n", n);
+  }
+  {  // ---- Fuse(KeyFrame, Scw)
+    KeyFrame KF; keyframe(KF, K1, T, 7);
+    std::vector<MapPoint*> mps; pts.make(own, mps, 600000);
+    for (int k = 0; k < K1.N; k++) if (kf_has[k]) { own.emplace_back(new MapPoint()); own.back()->mnId = 950000 + k; KF.mvpMapPoints[k] = own.back().get(); }
+    std::vector<MapPoint*> vpReplace(K1.N, nullptr);
+    lld_adapter::MatchTrace tr;
+    const int n = lld_adapter::ORBmatcher(ctx.get()).Fuse(&KF, Mat(4, 4, Scw), mps, th[2], vpReplace, &tr);
+    std::vector<int32_t> slots, rep; index_of(KF.mvpMapPoints, 600000, K1.N, slots); index_of(vpReplace, 600000, K1.N, rep);
+    std::vector<int32_t> pobs(K1.N); for (int i = 0; i < K1.N; i++) pobs[i] = mps[i]->Observations();
+    const int32_t c = n; wr.put(&c, 1); wr.put(tr.match); wr.put(slots); wr.put(rep); wr.put(pobs);
+    std::printf("Fuse(KeyFrame, Scw): %d fused\n", n);
+  }
+  {  // ---- SearchBySim3
+    KeyFrame KFa, KFb; keyframe(KFa, K1, T1, 8); keyframe(KFb, K2, T2, 9);
+    std::vector<MapPoint*> m1, m2; p1.make(own, m1, 700000); p2.make(own, m2, 800000);
+    for (int k = 0; k < K1.N; k++) KFa.mvpMapPoints[k] = has1[k] ? m1[k] : nullptr;
+    for (int k = 0; k < K2.N; k++) { KFb.mvpMapPoints[k] = has2[k] ? m2[k] : nullptr; m2[k]->mObservations[&KFb] = k; }
+    std::vector<MapPoint*> vpMatches12(K1.N, nullptr);
+    for (int k = 0; k < K1.N; k++) if (pre12[k] >= 0) vpMatches12[k] = m2[pre12[k]];
+    const int n = lld_adapter::ORBmatcher(ctx.get()).SearchBySim3(&KFa, &KFb, vpMatches12, sim[0], Mat(3, 3, sim + 1), Mat(3, 1, sim + 10), th[3]);
+    std::vector<int32_t> idx; index_of(vpMatches12, 800000, K2.N, idx);
+    const int32_t c = n; wr.put(&c, 1); wr.put(idx);
+    std::printf("SearchBySim3: %d found\n", n);
+  }
+  return 0;
+}
+
 int main(int argc, char** argv) {
-  if (argc < 4) { std::fprintf(stderr, "usage: adapter_harness ba|pose|match <in> <out> [seed]\n"); return 2; }
+  if (argc < 4) { std::fprintf(stderr, "usage: adapter_harness ba|pose|match|loopmatch <in> <out> [seed]\n"); return 2; }
   const unsigned seed = argc > 4 ? (unsigned)std::atoi(argv[4]) : 1u;
   try {
     const std::string mode = argv[1];
     if (mode == "ba") return run_ba(argv[2], argv[3], seed);
     if (mode == "pose") return run_pose(argv[2], argv[3], seed);
     if (mode == "match") return run_match(argv[2], argv[3]);
+    if (mode == "loopmatch") return run_loopmatch(argv[2], argv[3]);
     std::fprintf(stderr, "unknown mode %s\n", argv[1]);
     return 2;
   } catch (const std::exception& e) {

@@ -397,3 +397,102 @@ def test_matcher_adapters_on_live_objects(harness, tmp_path, seed, th_local, bac
     live = ~p_bad
     np.testing.assert_array_equal(pobs[live], p_obs[live])
 
+
+def _write_keys(f, F, cam, log_scale_factor):
+    cam.tofile(f)
+    np.array([F.min_x, F.max_x, F.min_y, F.max_y, F.width_inv, F.height_inv], np.float32).tofile(f)
+    F.scale.astype(np.float32).tofile(f); F.sigma2.astype(np.float32).tofile(f); F.inv_sigma2.astype(np.float32).tofile(f)
+    np.array([log_scale_factor], np.float32).tofile(f)
+    F.xy.astype(np.float32).tofile(f); F.octave.astype(np.int32).tofile(f); F.angle.astype(np.float32).tofile(f); F.uright.astype(np.float32).tofile(f)
+    np.ascontiguousarray(F.desc, np.uint32).tofile(f)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,scale,s12", [(0, 1.0, 1.0), (1, 1.37, 1.04)])
+def test_relocalisation_and_loop_closing_adapters_on_live_objects(harness, tmp_path, seed, scale, s12):
+    """adapters/lld_matcher_adapter.cc, second half: SearchByProjection(Frame&, KeyFrame*, sAlreadyFound, th, ORBdist) (src/ORBmatcher.cc:1472-1599),
+    SearchByProjection(KeyFrame*, Scw, vpPoints, vpMatched, th) (:290-403), Fuse(KeyFrame*, Scw, vpPoints, th, vpReplacePoint) (:977-1100) and
+    SearchBySim3 (:1102-1326) on test doubles - the Scw decomposition, sAlreadyFound / vpMatched / vbAlreadyMatched handling and the
+    write-back on the adapter's side, projection + search on the device - against the oracle's restatements."""
+    import oracle_orbsearch as OS
+    from lld_slam_amd import orb_search
+    from test_gpu_orbsearch import _sim3_pair
+    rng = np.random.default_rng(900 + seed)
+    F1, T1, mp1, K2, T2, mp2, R12, t12 = _sim3_pair(seed, s12)                 # the two keyframes of SearchBySim3; F1 also serves the other three
+    F1.normalise(); K2.normalise(); N1 = F1.n; N2 = K2.n
+    T, mp = synth.make_local_map(F1, 800 + seed, N1)
+    cam = np.array(list(synth.KITTI_CAM) + [synth.KITTI_CAM[4] / synth.KITTI_CAM[0]], np.float32)
+    view = orb_search.frame_view(T, synth.KITTI_CAM, F1)
+    Scw = np.array(T, np.float32, copy=True); Scw[:3, :] = (np.float64(scale) * T[:3, :].astype(np.float64)).astype(np.float32)
+    sview = orb_search.sim3_view(Scw, synth.KITTI_CAM, F1)
+    bad = mp["skip"].astype(np.uint8); nobs = rng.integers(0, 5, N1).astype(np.int32)
+    kf_angle = np.mod(F1.angle[mp["src"]] + 40.0 + rng.normal(0, 6.0, N1), 360.0)
+    wild = rng.random(N1) < 0.15; kf_angle[wild] = rng.uniform(0, 360, int(wild.sum())); kf_angle = kf_angle.astype(np.float32)
+    cur_occ = mp["occupied"].astype(np.uint8); kf_matched = (rng.random(N1) < 0.05).astype(np.uint8)
+    kf_has = (rng.random(N1) < 0.4).astype(np.uint8); found = (rng.random(N1) < 0.1).astype(np.uint8)
+    # the Sim3 pair
+    v1 = orb_search.frame_view(T1, synth.KITTI_CAM, F1); v2 = orb_search.frame_view(T2, synth.KITTI_CAM, K2)
+    has1 = (rng.random(N1) < 0.9).astype(np.uint8); has2 = (rng.random(N2) < 0.9).astype(np.uint8)
+    pre12 = np.where(rng.random(N1) < 0.03, rng.integers(0, N2, N1), -1).astype(np.int32)
+    with open(tmp_path / "in.bin", "wb") as f:
+        np.array([N1, F1.scale.shape[0], N2, 100, 1, 0, 0, 0], np.int32).tofile(f)
+        _write_keys(f, F1, cam, view.log_scale_factor)
+        T.astype(np.float32).tofile(f); Scw.tofile(f); np.array([10.0, 10.0, 4.0, 7.5], np.float32).tofile(f)
+        _write_points(f, mp, N1, nobs, bad)
+        kf_angle.tofile(f); cur_occ.tofile(f); kf_matched.tofile(f); kf_has.tofile(f); found.tofile(f)
+        _write_keys(f, K2, cam, v2.log_scale_factor)
+        T1.astype(np.float32).tofile(f); T2.astype(np.float32).tofile(f)
+        np.concatenate([[s12], R12.reshape(9), t12]).astype(np.float32).tofile(f)
+        _write_points(f, mp1, N1, np.ones(N1, np.int32), mp1["skip"].astype(np.uint8))
+        _write_points(f, mp2, N2, np.ones(N2, np.int32), mp2["skip"].astype(np.uint8))
+        has1.tofile(f); has2.tofile(f); pre12.tofile(f)
+    r = subprocess.run([harness, "loopmatch", str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    with open(tmp_path / "out.bin", "rb") as f:
+        c1 = int(np.fromfile(f, np.int32, 1)[0]); idx1 = np.fromfile(f, np.int32, N1); removed1 = np.fromfile(f, np.uint8, N1)
+        c2 = int(np.fromfile(f, np.int32, 1)[0]); idx2 = np.fromfile(f, np.int32, N1)
+        c3 = int(np.fromfile(f, np.int32, 1)[0]); match3 = np.fromfile(f, np.int32, N1); slots3 = np.fromfile(f, np.int32, N1)
+        rep3 = np.fromfile(f, np.int32, N1); pobs3 = np.fromfile(f, np.int32, N1)
+        c4 = int(np.fromfile(f, np.int32, 1)[0]); idx4 = np.fromfile(f, np.int32, N1)
+    token = 1 << 20
+    as_slot = lambda idx: np.where(idx == -2, token, idx).astype(np.int32)
+    # ---- relocalisation
+    va, uva, la = OS.project_general(view, dict(mp, skip=(bad | found)), orb_search.PROJ_RELOC)
+    n_exp, slot = OS.search_by_projection_reloc(F1, mp["desc"], va, uva, la, kf_angle, cur_occ, 10.0, 100, True)
+    assert c1 == n_exp and n_exp > 100 and removed1.sum() > 0
+    np.testing.assert_array_equal(as_slot(idx1), slot)
+    # ---- SearchByProjection(KeyFrame, Scw)
+    vb, uvb, lb = OS.project_general(sview, dict(mp, skip=bad), orb_search.PROJ_KF_SIM3)
+    n_exp, slot = OS.search_by_projection_kf(F1, mp["desc"], vb, uvb, lb, kf_matched, 10)
+    assert c2 == n_exp and n_exp > 100
+    np.testing.assert_array_equal(as_slot(idx2), slot)
+    # ---- Fuse(KeyFrame, Scw): the search, then :1078-1093 replayed
+    vc, uvc, lc = OS.project_general(sview, dict(mp, skip=bad), orb_search.PROJ_FUSE_SIM3)
+    n_search, best = OS.fuse_search_sim3(F1, mp["desc"], vc, uvc, lc, 4.0)
+    np.testing.assert_array_equal(match3, best)
+    holder = np.where(kf_has != 0, -2, -1).astype(np.int64); rep = np.full(N1, -1, np.int64); obs = nobs.astype(np.int64).copy()
+    for i in range(N1):
+        b = best[i]
+        if b < 0: continue
+        if holder[b] != -1: rep[i] = holder[b]
+        else: holder[b] = i; obs[i] += 2 if F1.uright[b] >= 0 else 1
+    assert c3 == n_search and n_search > 100
+    np.testing.assert_array_equal(slots3, holder); np.testing.assert_array_equal(rep3, rep); np.testing.assert_array_equal(pobs3, obs)
+    # ---- SearchBySim3
+    sR12, t12f, sR21, t21 = orb_search.sim3_transforms(s12, R12, t12)
+    already2 = np.zeros(N2, bool); already2[pre12[pre12 >= 0]] = True
+    skip1 = ((has1 == 0) | (pre12 >= 0) | (mp1["skip"] != 0)).astype(np.uint8); skip2 = ((has2 == 0) | already2 | (mp2["skip"] != 0)).astype(np.uint8)
+    mix1 = orb_search.FrameView.from_buffer_copy(v1)
+    mix1.min_x, mix1.max_x, mix1.min_y, mix1.max_y, mix1.log_scale_factor, mix1.n_levels = v2.min_x, v2.max_x, v2.min_y, v2.max_y, v2.log_scale_factor, v2.n_levels
+    mix2 = orb_search.FrameView.from_buffer_copy(v2)
+    mix2.fx, mix2.fy, mix2.cx, mix2.cy = v1.fx, v1.fy, v1.cx, v1.cy
+    mix2.min_x, mix2.max_x, mix2.min_y, mix2.max_y, mix2.log_scale_factor, mix2.n_levels = v1.min_x, v1.max_x, v1.min_y, v1.max_y, v1.log_scale_factor, v1.n_levels
+    vd, uvd, ld = OS.project_general(mix1, dict(mp1, skip=skip1), orb_search.PROJ_SIM3_DIR, sR21, t21)
+    ve, uve, le = OS.project_general(mix2, dict(mp2, skip=skip2), orb_search.PROJ_SIM3_DIR, sR12, t12f)
+    a = OS.search_sim3_direction(K2, mp1["desc"], vd, uvd, ld, 7.5); b2 = OS.search_sim3_direction(F1, mp2["desc"], ve, uve, le, 7.5)
+    exp = pre12.copy(); found_n = 0
+    for i in range(N1):
+        if a[i] >= 0 and b2[a[i]] == i: exp[i] = a[i]; found_n += 1
+    assert c4 == found_n and found_n > 20
+    np.testing.assert_array_equal(idx4, exp)
+
