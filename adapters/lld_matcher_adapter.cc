@@ -402,4 +402,139 @@ int ORBmatcher::SearchBySim3(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoin
   return nFound;
 }
 
+// ================================================================== vocabulary-guided matchers
+namespace {
+
+// The merge loop over two FeatureVectors (ORBmatcher.cc:183-251 / :546-629): common nodes in ascending id; the queries are the first
+// side's keypoints node by node (`order`), the candidates of a query the second side's keypoints of the same node.
+struct BowLists {
+  std::vector<int32_t> order, cand_range, cand_idx;
+  BowLists(const DBoW2::FeatureVector& v1, const DBoW2::FeatureVector& v2) {
+    DBoW2::FeatureVector::const_iterator f1it = v1.begin(), f2it = v2.begin(), f1end = v1.end(), f2end = v2.end();
+    while (f1it != f1end && f2it != f2end) {
+      if (f1it->first == f2it->first) {
+        const int c0 = (int)cand_idx.size();
+        for (size_t i2 = 0; i2 < f2it->second.size(); i2++) cand_idx.push_back((int32_t)f2it->second[i2]);
+        const int c1 = (int)cand_idx.size();
+        for (size_t i1 = 0; i1 < f1it->second.size(); i1++) { order.push_back((int32_t)f1it->second[i1]); cand_range.push_back(c0); cand_range.push_back(c1); }
+        f1it++; f2it++;
+      } else if (f1it->first < f2it->first) f1it = v1.lower_bound(f2it->first);
+      else f2it = v2.lower_bound(f1it->first);
+    }
+    if (cand_idx.empty()) cand_idx.push_back(0);
+  }
+};
+
+struct BowQueries {
+  std::vector<uint32_t> desc; std::vector<uint8_t> valid; std::vector<float> angle;
+  template <class KF>
+  BowQueries(const KF& kf, const std::vector<MapPoint*>& mps, const std::vector<int32_t>& order)
+      : desc(8 * order.size() + 8), valid(order.size() + 1, 0), angle(order.size() + 1, 0.f) {
+    for (size_t i = 0; i < order.size(); i++) {
+      const int idx = order[i];
+      MapPoint* pMP = mps[idx];
+      valid[i] = pMP && !pMP->isBad();                                        // :198-202 / :561-565
+      std::memcpy(&desc[8 * i], kf.mDescriptors.template ptr<unsigned char>(idx), 32);
+      angle[i] = kf.mvKeysUn[idx].angle;
+    }
+  }
+};
+
+}  // namespace
+
+// ------------------------------------------------------------------ SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches)   :159-288
+int ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame& F, std::vector<MapPoint*>& vpMapPointMatches, MatchTrace* trace) {
+  const std::vector<MapPoint*> vpMapPointsKF = pKF->GetMapPointMatches();
+  vpMapPointMatches = std::vector<MapPoint*>(F.N, static_cast<MapPoint*>(NULL));
+  const BowLists L(pKF->mFeatVec, F.mFeatVec);
+  const int nq = (int)L.order.size();
+  const BowQueries Q(*pKF, vpMapPointsKF, L.order);
+  KeypointSide ks; ks.fill(F, F.N);
+  for (int k = 0; k < F.N; k++) ks.angle[k] = F.mvKeys[k].angle;              // :241 reads F.mvKeys, not mvKeysUn
+  ks.s.t_occupied = NULL;
+  ks.s.nq = nq; ks.s.q_desc = Q.desc.data(); ks.s.q_valid = Q.valid.data(); ks.s.q_angle = Q.angle.data();
+  ks.s.cand_range = L.cand_range.data(); ks.s.cand_idx = L.cand_idx.data(); ks.s.n_cand = (int)L.cand_idx.size();
+  ks.s.candidates = LLD_ORB_CAND_CSR; ks.s.accept_max = TH_LOW; ks.s.ratio_mode = 1; ks.s.nnratio = mfNNratio;
+  ks.s.sequential = 1; ks.s.check_orientation = mbCheckOrientation ? 1 : 0;
+  Result res(nq, F.N);
+  check(lld_orb_search_run(ctx_, &ks.s, &res.r), "lld_orb_search_run");
+  // vpMapPointMatches[bestIdxF]=pMP (:237) minus the bins the rotation histogram drops (:272-281): owner[] is that final state
+  for (int k = 0; k < F.N; k++) if (res.owner[k] >= 0) vpMapPointMatches[k] = vpMapPointsKF[L.order[res.owner[k]]];
+  res.to(trace, nq);
+  return res.r.n_matches;
+}
+
+// ------------------------------------------------------------------ SearchByBoW(KeyFrame*, KeyFrame*, vpMatches12)   :522-655
+int ORBmatcher::SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches12, MatchTrace* trace) {
+  const std::vector<MapPoint*> vpMapPoints1 = pKF1->GetMapPointMatches(), vpMapPoints2 = pKF2->GetMapPointMatches();
+  vpMatches12 = std::vector<MapPoint*>(vpMapPoints1.size(), static_cast<MapPoint*>(NULL));
+  const BowLists L(pKF1->mFeatVec, pKF2->mFeatVec);
+  const int nq = (int)L.order.size(), N2 = (int)vpMapPoints2.size();
+  const BowQueries Q(*pKF1, vpMapPoints1, L.order);
+  KeypointSide ks; ks.fill(*pKF2, N2);
+  for (int k = 0; k < N2; k++) ks.occupied[k] = !vpMapPoints2[k] || vpMapPoints2[k]->isBad();   // :571-575: never a candidate; vbMatched2 adds to it
+  ks.s.nq = nq; ks.s.q_desc = Q.desc.data(); ks.s.q_valid = Q.valid.data(); ks.s.q_angle = Q.angle.data();
+  ks.s.cand_range = L.cand_range.data(); ks.s.cand_idx = L.cand_idx.data(); ks.s.n_cand = (int)L.cand_idx.size();
+  ks.s.candidates = LLD_ORB_CAND_CSR; ks.s.accept_max = TH_LOW - 1;           // `bestDist1<TH_LOW` is strict here (:586)
+  ks.s.ratio_mode = 1; ks.s.nnratio = mfNNratio; ks.s.sequential = 1; ks.s.check_orientation = mbCheckOrientation ? 1 : 0;
+  Result res(nq, N2);
+  check(lld_orb_search_run(ctx_, &ks.s, &res.r), "lld_orb_search_run");
+  for (int i = 0; i < nq; i++)                                                // :590 and :642-646
+    if (res.match[i] >= 0 && !res.removed[i]) vpMatches12[L.order[i]] = vpMapPoints2[res.match[i]];
+  res.to(trace, nq);
+  return res.r.n_matches;
+}
+
+// ------------------------------------------------------------------ SearchForTriangulation   :657-823
+int ORBmatcher::SearchForTriangulation(KeyFrame* pKF1, KeyFrame* pKF2, const lld_slam::Mat& F12, std::vector<std::pair<size_t, size_t> >& vMatchedPairs,
+                                       const bool bOnlyStereo, MatchTrace* trace) {
+  // Compute epipole in second image (:663-670): C2 = R2w*Cw+t2w is one gemm, the projection float arithmetic in source order
+  const lld_slam::Mat Cw = pKF1->GetCameraCenter(), R2w = pKF2->GetRotation(), t2w = pKF2->GetTranslation();
+  float C2[3];
+  for (int r = 0; r < 3; r++) {
+    double acc = 0.0;
+    for (int k = 0; k < 3; k++) acc += (double)R2w.at<float>(r, k) * (double)Cw.at<float>(k);
+    C2[r] = (float)(acc + (double)t2w.at<float>(r));
+  }
+  const float invz = 1.0f / C2[2];
+  const float ex = pKF2->fx * C2[0] * invz + pKF2->cx;
+  const float ey = pKF2->fy * C2[1] * invz + pKF2->cy;
+  const int N1 = (int)pKF1->mvKeysUn.size(), N2 = (int)pKF2->mvKeysUn.size();
+  const BowLists L(pKF1->mFeatVec, pKF2->mFeatVec);
+  const int nq = (int)L.order.size();
+  std::vector<uint32_t> desc(8 * (size_t)nq + 8); std::vector<uint8_t> valid(nq + 1, 0), stereo1(nq + 1, 0); std::vector<float> angle(nq + 1, 0.f), epi(3 * (size_t)nq + 3);
+  for (int i = 0; i < nq; i++) {
+    const int idx1 = L.order[i];
+    const bool bStereo1 = pKF1->mvuRight[idx1] >= 0;
+    valid[i] = !pKF1->GetMapPoint(idx1) && (!bOnlyStereo || bStereo1);        // :699-708
+    stereo1[i] = bStereo1;
+    std::memcpy(&desc[8 * (size_t)i], pKF1->mDescriptors.ptr<unsigned char>(idx1), 32);
+    const lld_slam::KeyPoint& kp1 = pKF1->mvKeysUn[idx1];
+    angle[i] = kp1.angle;
+    // CheckDistEpipolarLine (:141-143): l = x1'F12 = [a b c]
+    epi[3 * i] = kp1.pt.x * F12.at<float>(0, 0) + kp1.pt.y * F12.at<float>(1, 0) + F12.at<float>(2, 0);
+    epi[3 * i + 1] = kp1.pt.x * F12.at<float>(0, 1) + kp1.pt.y * F12.at<float>(1, 1) + F12.at<float>(2, 1);
+    epi[3 * i + 2] = kp1.pt.x * F12.at<float>(0, 2) + kp1.pt.y * F12.at<float>(1, 2) + F12.at<float>(2, 2);
+  }
+  KeypointSide ks; ks.fill(*pKF2, N2);
+  for (int k = 0; k < N2; k++) ks.occupied[k] = pKF2->GetMapPoint(k) != NULL;  // :724-726 (vbMatched2 is never set by the reference)
+  ks.s.nq = nq; ks.s.q_desc = desc.data(); ks.s.q_valid = valid.data(); ks.s.q_angle = angle.data(); ks.s.q_epiline = epi.data(); ks.s.q_stereo = stereo1.data();
+  ks.s.cand_range = L.cand_range.data(); ks.s.cand_idx = L.cand_idx.data(); ks.s.n_cand = (int)L.cand_idx.size();
+  ks.s.candidates = LLD_ORB_CAND_CSR; ks.s.gates = LLD_ORB_GATE_EPIPOLAR; ks.s.accept_max = TH_LOW;
+  ks.s.tie_last = 1;                                                           // `dist>bestDist -> continue`: a later equal distance replaces (:733)
+  ks.s.check_orientation = mbCheckOrientation ? 1 : 0; ks.s.epipole_x = ex; ks.s.epipole_y = ey; ks.s.only_stereo = bOnlyStereo ? 1 : 0;
+  Result res(nq, N2);
+  check(lld_orb_search_run(ctx_, &ks.s, &res.r), "lld_orb_search_run");
+  std::vector<int> vMatches12(N1, -1);
+  for (int i = 0; i < nq; i++) if (res.match[i] >= 0 && !res.removed[i]) vMatches12[L.order[i]] = res.match[i];   // :752 and :800
+  vMatchedPairs.clear();
+  vMatchedPairs.reserve(res.r.n_matches > 0 ? res.r.n_matches : 0);
+  for (size_t i = 0, iend = vMatches12.size(); i < iend; i++) {                // :810-815
+    if (vMatches12[i] < 0) continue;
+    vMatchedPairs.push_back(std::make_pair(i, (size_t)vMatches12[i]));
+  }
+  res.to(trace, nq);
+  return res.r.n_matches;
+}
+
 }  // namespace lld_adapter

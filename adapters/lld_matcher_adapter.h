@@ -12,6 +12,7 @@
 #define LLD_MATCHER_ADAPTER_H
 
 #include <set>
+#include <utility>
 #include <vector>
 
 #include "../include/lld_amd.h"
@@ -58,6 +59,14 @@ class ORBmatcher {
   // int ORBmatcher::SearchBySim3(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint*> &vpMatches12, const float &s12, const cv::Mat &R12, const cv::Mat &t12, const float th)   :1102-1326
   int SearchBySim3(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches12, const float& s12, const lld_slam::Mat& R12, const lld_slam::Mat& t12, const float th,
                    MatchTrace* trace = nullptr);
+  // The vocabulary-guided matchers (the merge loop over the two FeatureVectors becomes CSR candidate lists, node-major):
+  // int ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame &F, vector<MapPoint*> &vpMapPointMatches)                    :159-288
+  int SearchByBoW(KeyFrame* pKF, Frame& F, std::vector<MapPoint*>& vpMapPointMatches, MatchTrace* trace = nullptr);
+  // int ORBmatcher::SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint *> &vpMatches12)                   :522-655
+  int SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches12, MatchTrace* trace = nullptr);
+  // int ORBmatcher::SearchForTriangulation(KeyFrame *pKF1, KeyFrame *pKF2, cv::Mat F12, vector<pair<size_t, size_t> > &vMatchedPairs, const bool bOnlyStereo)   :657-823
+  int SearchForTriangulation(KeyFrame* pKF1, KeyFrame* pKF2, const lld_slam::Mat& F12, std::vector<std::pair<size_t, size_t> >& vMatchedPairs, const bool bOnlyStereo,
+                             MatchTrace* trace = nullptr);
 
  private:
   lld_ctx* ctx_;

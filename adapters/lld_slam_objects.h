@@ -21,6 +21,11 @@
 #include <set>
 #include <vector>
 
+// ---- DBoW2::FeatureVector stand-in (Thirdparty/DBoW2/DBoW2/FeatureVector.h: a std::map<NodeId, std::vector<unsigned int>>)
+namespace DBoW2 {
+class FeatureVector : public std::map<unsigned int, std::vector<unsigned int> > {};
+}
+
 namespace lld_slam {
 
 // ---- cv::Mat (CV_32F) stand-in: row-major floats with shared-nothing value semantics (the reference clones on every Get/Set)
@@ -100,6 +105,7 @@ class KeyFrame {
   // what the matchers read (include/KeyFrame.h): keypoint descriptors, the image bounds and grid constants, the scale pyramid, the
   // pose pieces; and what ORBmatcher::Fuse writes
   MatU8 mDescriptors;
+  DBoW2::FeatureVector mFeatVec;                                   // vocabulary node -> keypoint indices (KeyFrame::ComputeBoW)
   int mnMinX = 0, mnMinY = 0, mnMaxX = 0, mnMaxY = 0;               // KeyFrame.h:196-199 (const int there)
   float mfGridElementWidthInv = 0, mfGridElementHeightInv = 0;
   int mnScaleLevels = 0;
@@ -220,6 +226,7 @@ class Frame {                                                      // what PoseO
   std::vector<KeyPoint> mvKeys;
   std::vector<float> mvDepth;
   MatU8 mDescriptors;
+  DBoW2::FeatureVector mFeatVec;
   float mnMinX = 0, mnMaxX = 0, mnMinY = 0, mnMaxY = 0, mfGridElementWidthInv = 0, mfGridElementHeightInv = 0;
   int mnScaleLevels = 0;
   float mfScaleFactor = 0, mfLogScaleFactor = 0;

@@ -490,8 +490,67 @@ int run_loopmatch(const char* in, const char* out) {
   return 0;
 }
 
+// The vocabulary-guided matchers through adapters/lld_matcher_adapter.cc: SearchByBoW(KeyFrame*, Frame&, ...) and SearchByBoW(KeyFrame*, KeyFrame*, ...)
+// with FeatureVectors that also hold nodes only one side has (the lower_bound branches of the merge loop).
+int run_bow(const char* in, const char* out) {
+  Reader r(in);
+  int32_t h[4]; r.get(h, 4);                   // N1, N2, levels, checkOrientation
+  float nn[2]; r.get(nn, 2);                   // mfNNratio of the two calls
+  KeypointData K1, K2; K1.read(r, h[0], h[2]); K2.read(r, h[1], h[2]);
+  auto read_featvec = [&](DBoW2::FeatureVector& fv) {
+    int32_t n; r.get(&n, 1);
+    std::vector<int32_t> ids, start, idx; r.get(ids, n); r.get(start, (size_t)n + 1); r.get(idx, (size_t)start[n]);
+    for (int k = 0; k < n; k++) { std::vector<unsigned int>& v = fv[(unsigned)ids[k]]; for (int j = start[k]; j < start[k + 1]; j++) v.push_back((unsigned)idx[j]); }
+  };
+  DBoW2::FeatureVector fv1, fv2; read_featvec(fv1); read_featvec(fv2);
+  std::vector<uint8_t> has1, bad1, has2, bad2; r.get(has1, K1.N); r.get(bad1, K1.N); r.get(has2, K2.N); r.get(bad2, K2.N);
+  float T[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  lld_amd::Context ctx(0);
+  std::vector<std::unique_ptr<MapPoint> > own;
+  auto points = [&](KeyFrame& KF, const std::vector<uint8_t>& has, const std::vector<uint8_t>& bad, unsigned long id0) {
+    KF.mvpMapPoints.assign(has.size(), nullptr);
+    for (size_t k = 0; k < has.size(); k++) if (has[k]) { own.emplace_back(new MapPoint()); own.back()->mnId = id0 + k; own.back()->mbBad = bad[k] != 0; KF.mvpMapPoints[k] = own.back().get(); }
+  };
+  Writer wr(out);
+  {
+    KeyFrame KF; K1.keys(KF); KF.mFeatVec = fv1; points(KF, has1, bad1, 100000);
+    Frame F; K2.frame(F, T, 1); F.mFeatVec = fv2;
+    std::vector<MapPoint*> vpMapPointMatches;
+    const int n = lld_adapter::ORBmatcher(ctx.get(), nn[0], h[3] != 0).SearchByBoW(&KF, F, vpMapPointMatches);
+    std::vector<int32_t> idx(K2.N, -1);
+    for (int k = 0; k < K2.N; k++) if (vpMapPointMatches[k]) idx[k] = (int32_t)(vpMapPointMatches[k]->mnId - 100000);
+    const int32_t c = n; wr.put(&c, 1); wr.put(idx);
+    std::printf("SearchByBoW(KeyFrame, Frame): %d matches\n", n);
+  }
+  {
+    KeyFrame KFa, KFb; K1.keys(KFa); K2.keys(KFb); KFa.mFeatVec = fv1; KFb.mFeatVec = fv2;
+    points(KFa, has1, bad1, 100000); points(KFb, has2, bad2, 200000);
+    std::vector<MapPoint*> vpMatches12;
+    const int n = lld_adapter::ORBmatcher(ctx.get(), nn[1], h[3] != 0).SearchByBoW(&KFa, &KFb, vpMatches12);
+    std::vector<int32_t> idx(K1.N, -1);
+    for (int k = 0; k < K1.N; k++) if (vpMatches12[k]) idx[k] = (int32_t)(vpMatches12[k]->mnId - 200000);
+    const int32_t c = n; wr.put(&c, 1); wr.put(idx);
+    std::printf("SearchByBoW(KeyFrame, KeyFrame): %d matches\n", n);
+  }
+  {  // ---- SearchForTriangulation: the keypoints WITHOUT a MapPoint, epipolar gate from F12, epipole from the two poses
+    float T1[16], T2[16], F12[9]; int32_t only; r.get(T1, 16); r.get(T2, 16); r.get(F12, 9); r.get(&only, 1);
+    KeyFrame KFa, KFb; K1.keys(KFa); K2.keys(KFb); KFa.mFeatVec = fv1; KFb.mFeatVec = fv2;
+    KFa.Tcw = Mat(4, 4, T1); KFb.Tcw = Mat(4, 4, T2);
+    { Frame tmp; tmp.SetPose(Mat(4, 4, T1)); KFa.Ow = tmp.mOw; }
+    std::vector<uint8_t> nobad1(K1.N, 0), nobad2(K2.N, 0);
+    points(KFa, has1, nobad1, 100000); points(KFb, has2, nobad2, 200000);
+    std::vector<std::pair<size_t, size_t> > pairs;
+    const int n = lld_adapter::ORBmatcher(ctx.get(), 0.6f, h[3] != 0).SearchForTriangulation(&KFa, &KFb, Mat(3, 3, F12), pairs, only != 0);
+    std::vector<int32_t> m12(K1.N, -1);
+    for (size_t i = 0; i < pairs.size(); i++) m12[pairs[i].first] = (int32_t)pairs[i].second;
+    const int32_t c[2] = {n, (int32_t)pairs.size()}; wr.put(c, 2); wr.put(m12);
+    std::printf("SearchForTriangulation: %d matches\n", n);
+  }
+  return 0;
+}
+
 int main(int argc, char** argv) {
-  if (argc < 4) { std::fprintf(stderr, "usage: adapter_harness ba|pose|match|loopmatch <in> <out> [seed]\n"); return 2; }
+  if (argc < 4) { std::fprintf(stderr, "usage: adapter_harness ba|pose|match|loopmatch|bow <in> <out> [seed]\n"); return 2; }
   const unsigned seed = argc > 4 ? (unsigned)std::atoi(argv[4]) : 1u;
   try {
     const std::string mode = argv[1];
@@ -499,6 +558,7 @@ int main(int argc, char** argv) {
     if (mode == "pose") return run_pose(argv[2], argv[3], seed);
     if (mode == "match") return run_match(argv[2], argv[3]);
     if (mode == "loopmatch") return run_loopmatch(argv[2], argv[3]);
+    if (mode == "bow") return run_bow(argv[2], argv[3]);
     std::fprintf(stderr, "unknown mode %s\n", argv[1]);
     return 2;
   } catch (const std::exception& e) {

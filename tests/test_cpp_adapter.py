@@ -496,3 +496,69 @@ def test_relocalisation_and_loop_closing_adapters_on_live_objects(harness, tmp_p
     assert c4 == found_n and found_n > 20
     np.testing.assert_array_equal(idx4, exp)
 
+
+def _featvec(f, ids, start, idx):
+    np.array([len(ids)], np.int32).tofile(f); np.asarray(ids, np.int32).tofile(f); np.asarray(start, np.int32).tofile(f); np.asarray(idx, np.int32).tofile(f)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,check", [(0, True), (1, False)])
+def test_bow_matcher_adapters_on_live_objects(harness, tmp_path, seed, check):
+    """adapters/lld_matcher_adapter.cc, third part: SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches) (src/ORBmatcher.cc:159-288) and
+    SearchByBoW(KeyFrame*, KeyFrame*, vpMatches12) (:522-655).  The FeatureVectors of the doubles also hold nodes that only one side
+    has, so the adapter's merge loop takes its lower_bound branches; the matches equal the oracle's sequential restatement."""
+    import oracle_orbsearch as OS
+    F1, F2, nodes = synth.make_bow_pair(40 + seed, 1600, pos_sigma=(25.0, 1.5))    # corresponding keypoints lie on (almost) the same image row
+    F1.normalise(); F2.normalise()
+    if seed == 0: F1.uright[::2] = -1; F2.uright[::3] = -1                        # mono keypoints: the epipole-distance rule applies
+    rng = np.random.default_rng(40 + seed)
+    cam = np.array(list(synth.KITTI_CAM) + [synth.KITTI_CAM[4] / synth.KITTI_CAM[0]], np.float32)
+    n = nodes["n_nodes"]
+    # common nodes get the even ids; odd ids are nodes of one side only, filled with keypoints outside every common node
+    def side(start, idx, N, offset):
+        used = np.zeros(N, bool); used[idx] = True
+        rest = np.nonzero(~used)[0]
+        ids, st, ix = [], [0], []
+        extra = np.array_split(rest, max(1, n // 3))
+        for k in range(n):
+            ids.append(2 * k); ix.extend(idx[start[k]:start[k + 1]].tolist()); st.append(len(ix))
+            if k % 3 == offset and k // 3 < len(extra) and len(extra[k // 3]):
+                ids.append(2 * k + 1); ix.extend(extra[k // 3].tolist()); st.append(len(ix))
+        return ids, st, ix
+    fv1 = side(nodes["start1"], nodes["idx1"], F1.n, 0); fv2 = side(nodes["start2"], nodes["idx2"], F2.n, 1)
+    has1 = (rng.random(F1.n) < 0.55).astype(np.uint8); bad1 = (rng.random(F1.n) < 0.05).astype(np.uint8)    # half with a MapPoint (SearchByBoW), half without (triangulation)
+    has2 = (rng.random(F2.n) < 0.55).astype(np.uint8); bad2 = (rng.random(F2.n) < 0.05).astype(np.uint8)
+    with open(tmp_path / "in.bin", "wb") as f:
+        np.array([F1.n, F2.n, F1.scale.shape[0], int(check)], np.int32).tofile(f)
+        np.array([0.7, 0.75], np.float32).tofile(f)
+        _write_keys(f, F1, cam, float(np.log(np.float32(1.2)))); _write_keys(f, F2, cam, float(np.log(np.float32(1.2))))
+        _featvec(f, *fv1); _featvec(f, *fv2)
+        has1.tofile(f); bad1.tofile(f); has2.tofile(f); bad2.tofile(f)
+        # SearchForTriangulation: two poses one baseline apart along x (the epipole the adapter derives from them lies far outside the
+        # image), the same synthetic F12 as tests/test_gpu_orbsearch.py
+        T1 = np.eye(4, dtype=np.float32); T2 = np.eye(4, dtype=np.float32); T2[0, 3] = np.float32(-0.54); T2[2, 3] = np.float32(0.002)
+        F12 = (np.array([[0, 0, 0], [0, 0, -1.0], [0, 1.0, 0.0]]) + rng.normal(0, 2e-6, (3, 3))).astype(np.float32)
+        T1.tofile(f); T2.tofile(f); F12.tofile(f); np.array([int(seed == 1)], np.int32).tofile(f)
+    r = subprocess.run([harness, "bow", str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    with open(tmp_path / "out.bin", "rb") as f:
+        ca = int(np.fromfile(f, np.int32, 1)[0]); fm = np.fromfile(f, np.int32, F2.n)
+        cb = int(np.fromfile(f, np.int32, 1)[0]); m12 = np.fromfile(f, np.int32, F1.n)
+        cc = np.fromfile(f, np.int32, 2); t12 = np.fromfile(f, np.int32, F1.n)
+    valid1 = (has1 != 0) & (bad1 == 0); valid2 = (has2 != 0) & (bad2 == 0)
+    na, fma = OS.search_by_bow_frame(F1, F2, n, nodes["start1"], nodes["idx1"], nodes["start2"], nodes["idx2"], valid1.astype(np.uint8), np.float32(0.7), check)
+    assert ca == na and na > 100
+    np.testing.assert_array_equal(fm, fma)
+    nb, m12o = OS.search_by_bow_kf(F1, F2, n, nodes["start1"], nodes["idx1"], nodes["start2"], nodes["idx2"], valid1.astype(np.uint8), valid2.astype(np.uint8),
+                                   np.float32(0.75), check)
+    assert cb == nb and nb > 60
+    np.testing.assert_array_equal(m12, m12o)
+    # SearchForTriangulation: C2 = R2w*Cw+t2w with Cw = 0 -> t2w; invz = 1.0f/z; ex = fx*x*invz+cx in float, as the adapter forms it
+    f32 = np.float32
+    invz = f32(1.0) / T2[2, 3]
+    epipole = (float(f32(cam[0]) * T2[0, 3] * invz + f32(cam[2])), float(f32(cam[1]) * T2[1, 3] * invz + f32(cam[3])))
+    only = bool(seed == 1)
+    nt, m12t = OS.search_for_triangulation(F1, F2, n, nodes["start1"], nodes["idx1"], nodes["start2"], nodes["idx2"], has1, has2, F12, epipole, only, check)
+    assert cc[0] == nt and cc[1] == int((m12t >= 0).sum()) and nt > 40
+    np.testing.assert_array_equal(t12, m12t)
+
