@@ -1,0 +1,61 @@
+// lld_line_adapter.cc — see lld_line_adapter.h
+#include "lld_line_adapter.h"
+
+namespace lld_adapter {
+
+namespace {
+void key_lines(const std::vector<KeyLine>& kl, std::vector<float>& seg, std::vector<int32_t>& octave) {
+  seg.resize(4 * kl.size()); octave.resize(kl.size());
+  for (size_t i = 0; i < kl.size(); i++) {
+    seg[4 * i] = kl[i].startPointX; seg[4 * i + 1] = kl[i].startPointY; seg[4 * i + 2] = kl[i].endPointX; seg[4 * i + 3] = kl[i].endPointY;
+    octave[i] = kl[i].octave;
+  }
+}
+}  // namespace
+
+void TwoFrameLineMatcher::MatchLines(const std::vector<KeyLine>& lines, const std::vector<KeyLine>& other_lines, const lld_slam::Mat& descsLeft,
+                                     const lld_slam::Mat& descsRight, std::vector<int>* desc_matches) const {
+  std::vector<float> l, r; std::vector<int32_t> lo, ro;
+  key_lines(lines, l, lo); key_lines(other_lines, r, ro);
+  // every statement of MatchLines / CheckLinePair runs on the device; desc_matches comes back as the reference leaves it (:39-67)
+  m_.MatchLines(l.data(), lo.data(), (int)lines.size(), r.data(), ro.data(), (int)other_lines.size(), descsLeft.ptr<float>(), descsRight.ptr<float>(), descsLeft.cols,
+                desc_matches);
+}
+
+void AddLinesFrom(lld_amd::Context& ctx, const TrackingLines& tr, const std::vector<MapLine*>& lines_last, const double T_curr[16],
+                  const std::vector<lld_slam::Mat>& descs, const lld_slam::Mat& last_descs, double thrReprojLineBase, Frame* frame, std::vector<int>* matches_trace) {
+  const int n = (int)lines_last.size(), dim = frame->mDescriptorsLines.cols;
+  lld_amd::MapLineSet L;
+  L.X0.assign(3 * (size_t)n, 0.0); L.dir.assign(3 * (size_t)n, 0.0); L.X1.assign(3 * (size_t)n, 0.0); L.X2.assign(3 * (size_t)n, 0.0);
+  L.skip.assign(n, 1); L.desc.assign((size_t)n * dim, 0.f);
+  for (int i = 0; i < n; i++) {
+    MapLine* pML = lines_last[i];
+    if (!pML) continue;                                                       // :1015-1018
+    if ((unsigned int)pML->tracked_last_id == frame->mnId) continue;          // :1019-1022
+    if (pML->isBad()) continue;                                               // :1023-1026
+    L.skip[i] = 0;
+    lld_slam::Vector3d X0, d, X1, X2;
+    pML->GetMinimalPos(&X0, &d); pML->GetMainPoints3D(&X1, &X2);
+    for (int k = 0; k < 3; k++) { L.X0[3 * i + k] = X0(k); L.dir[3 * i + k] = d(k); L.X1[3 * i + k] = X1(k); L.X2[3 * i + k] = X2(k); }
+    const float* row = descs.size() > 0 ? descs[i].ptr<float>() : last_descs.ptr<float>(i);   // :1043-1048
+    for (int k = 0; k < dim; k++) L.desc[(size_t)i * dim + k] = row[k];
+  }
+  lld_amd::FrameLines F;
+  std::vector<int32_t> right_octave;
+  key_lines(frame->mvLinesLeft, F.left, F.left_octave); key_lines(frame->mvLinesRight, F.right, right_octave);
+  const int nl = (int)frame->mvLinesLeft.size();
+  F.line_matches.assign(frame->line_matches.begin(), frame->line_matches.end());
+  F.occupied.assign(nl, 0);
+  for (int i = 0; i < nl; i++) F.occupied[i] = frame->mvpMapLines[i] != NULL;  // :1053-1056 (and :1109-1112: the device keeps the in-order occupancy of this loop)
+  F.desc.assign(frame->mDescriptorsLines.ptr<float>(), frame->mDescriptorsLines.ptr<float>() + (size_t)nl * dim);
+  std::vector<int> matches;
+  lld_amd::Tracking(ctx, tr.K, tr.mb, tr.mnMaxX, tr.mnMaxY, tr.mdThr, tr.monocular).AddLinesFrom(L, T_curr, thrReprojLineBase, F, dim, &matches, true);
+  for (int i = 0; i < n; i++) {                                               // :1114-1118
+    if (matches[i] < 0) continue;
+    frame->mvpMapLines[matches[i]] = lines_last[i];
+    lines_last[i]->tracked_last_id = (long)frame->mnId;
+  }
+  if (matches_trace) *matches_trace = matches;
+}
+
+}  // namespace lld_adapter

@@ -1,0 +1,50 @@
+// lld_line_adapter.h — host adapters for the line matchers on live objects (same object-model switch as lld_optimizer_adapter.h):
+//   TwoFrameLineMatcher::MatchLines(lines, other_lines, descsLeft, descsRight, desc_matches)   src/TwoFrameLineMatcher.cc:26-77 (+ CheckLinePair :81-124)
+//   Tracking::AddLinesFrom(lines_last, T_curr, descs, thrReprojLineBase, frame)                src/Tracking.cc:996-1124
+// Gather -> include/lld_amd.hpp (one device call: gates, descriptor distances, the greedy / in-order assignment) -> the reference's
+// write-back.  Tracking's members that AddLinesFrom reads (mK, mCurrentFrame.mb, mnMaxX / mnMaxY, mdThr, mSensor) arrive through
+// TrackingLines.
+#ifndef LLD_LINE_ADAPTER_H
+#define LLD_LINE_ADAPTER_H
+
+#include <vector>
+
+#include "../include/lld_amd.hpp"
+
+#ifndef LLD_ADAPTER_OBJECTS_HEADER
+#define LLD_ADAPTER_OBJECTS_HEADER "lld_slam_objects.h"
+#endif
+#include LLD_ADAPTER_OBJECTS_HEADER
+
+namespace lld_adapter {
+
+using lld_slam::Frame;
+using lld_slam::KeyLine;
+using lld_slam::MapLine;
+
+class TwoFrameLineMatcher {
+ public:
+  // TwoFrameLineMatcher(const Eigen::Matrix3d& K, double b, double tau, int minLineLength, LineMatcher* lineMatcher)   include/TwoFrameLineMatcher.h:31-38
+  TwoFrameLineMatcher(lld_amd::Context& ctx, const double K[9], double b, double tau, int minLineLength) : m_(ctx, K, b, tau, minLineLength) {}
+  // void MatchLines(const std::vector<KeyLine>& lines, const std::vector<KeyLine>& other_lines, const cv::Mat& descsLeft, const cv::Mat& descsRight, std::vector<int>* desc_matches)
+  void MatchLines(const std::vector<KeyLine>& lines, const std::vector<KeyLine>& other_lines, const lld_slam::Mat& descsLeft, const lld_slam::Mat& descsRight,
+                  std::vector<int>* desc_matches) const;
+ private:
+  lld_amd::TwoFrameLineMatcher m_;
+};
+
+struct TrackingLines {          // what Tracking::AddLinesFrom reads off `this`
+  double K[9];                  // mK (cv2eigen, :1003-1004)
+  double mb;                    // mCurrentFrame.mb
+  double mnMaxX, mnMaxY;        // mCurrentFrame.mnMaxX / mnMaxY
+  double mdThr;
+  bool monocular;               // mSensor == System::MONOCULAR
+};
+// void Tracking::AddLinesFrom(const std::vector<MapLine*>& lines_last, const Eigen::Matrix4d& T_curr, const std::vector<cv::Mat>& descs,
+//                             double thrReprojLineBase, Frame* frame);   T_curr row-major.  `last_descs`: mLastFrame.mDescriptorsLines, read when `descs` is empty (:1043-1048).
+void AddLinesFrom(lld_amd::Context& ctx, const TrackingLines& tracking, const std::vector<MapLine*>& lines_last, const double T_curr[16],
+                  const std::vector<lld_slam::Mat>& descs, const lld_slam::Mat& last_descs, double thrReprojLineBase, Frame* frame,
+                  std::vector<int>* matches_trace = nullptr);
+
+}  // namespace lld_adapter
+#endif

@@ -191,6 +191,9 @@ class MapLine {
   unsigned long mnId = 0;
   unsigned long mnBALocalForKF = 0;
   void GetMinimalPos(Vector3d* X0, Vector3d* dir) const { *X0 = mX0; *dir = mDir; }
+  void GetMainPoints3D(Vector3d* X1, Vector3d* X2) const { *X1 = mX1; *X2 = mX2; }   // the 3D end points the depth test of Tracking::AddLinesFrom maps (:1064-1072)
+  Vector3d mX1, mX2;
+  long tracked_last_id = -1;                                       // MapLine.h: the frame that last took this line (Tracking.cc:1019, :1118)
   void SetMinimalPos(const Vector3d& X0, const Vector3d& dir) { mX0 = X0; mDir = dir; n_set_pos++; }
   std::map<KeyFrame*, size_t> GetObservations() const { return mObservations; }
   int Observations() const { return (int)mObservations.size(); }
@@ -217,6 +220,7 @@ class Frame {                                                      // what PoseO
   std::vector<int> line_matches;
   std::vector<MapLine*> mvpMapLines;
   std::vector<bool> mvbOutlierLines;
+  Mat mDescriptorsLines;                                           // one LBD descriptor (CV_32F row) per left line
   void SetPose(const Mat& T) { mTcw = T.clone(); n_set_pose++; UpdatePoseMatrices(); }
   int n_set_pose = 0;
   // what the matchers read (include/Frame.h).  The image bounds and grid constants are static members of the reference's Frame;

@@ -23,6 +23,7 @@
 
 #include "../adapters/lld_optimizer_adapter.h"
 #include "../adapters/lld_matcher_adapter.h"
+#include "../adapters/lld_line_adapter.h"
 
 std::mutex lld_slam::MapPoint::mGlobalMutex;        // the doubles' static member (the real class defines its own, MapPoint.cc:30)
 
@@ -549,8 +550,70 @@ int run_bow(const char* in, const char* out) {
   return 0;
 }
 
+// The line matchers through adapters/lld_line_adapter.cc: Tracking::AddLinesFrom on MapLine / Frame objects built from the first scene of
+// the `harness lines` input (same file format), then TwoFrameLineMatcher::MatchLines on the KeyLines / descriptors of a second block.
+int run_lines(const char* in, const char* out) {
+  Reader r(in);
+  int32_t h[3]; r.get(h, 3);                   // dim, n_map, use_grid
+  double k[9 + 16 + 16 + 5]; r.get(k, 46);     // K, T_curr, T_last (unused), b, mnMaxX, mnMaxY, mdThr, thrReprojLineBase
+  const int dim = h[0], n_map = h[1];
+  std::vector<double> X0, dir, X1, X2; std::vector<uint8_t> skip; std::vector<float> ldesc;
+  r.get(X0, 3 * (size_t)n_map); r.get(dir, 3 * (size_t)n_map); r.get(X1, 3 * (size_t)n_map); r.get(X2, 3 * (size_t)n_map);
+  r.get(skip, n_map); r.get(ldesc, (size_t)n_map * dim);
+  int32_t nf[2]; r.get(nf, 2);
+  std::vector<float> left, right, fdesc; std::vector<int32_t> octave, lm; std::vector<uint8_t> occ;
+  r.get(left, 4 * (size_t)nf[0]); r.get(right, 4 * (size_t)nf[1]); r.get(octave, nf[0]); r.get(lm, nf[0]); r.get(occ, nf[0]); r.get(fdesc, (size_t)nf[0] * dim);
+  lld_amd::Context ctx(0);
+  Frame F; F.mnId = 42;
+  auto kl = [](const float* s4, int oct) { KeyLine q; q.startPointX = s4[0]; q.startPointY = s4[1]; q.endPointX = s4[2]; q.endPointY = s4[3]; q.octave = oct; return q; };
+  for (int i = 0; i < nf[0]; i++) F.mvLinesLeft.push_back(kl(&left[4 * i], octave[i]));
+  for (int i = 0; i < nf[1]; i++) F.mvLinesRight.push_back(kl(&right[4 * i], 0));
+  F.line_matches.assign(lm.begin(), lm.end());
+  F.mDescriptorsLines = Mat(nf[0], dim, fdesc.data());
+  std::vector<std::unique_ptr<MapLine> > own;
+  F.mvpMapLines.assign(nf[0], nullptr);
+  for (int i = 0; i < nf[0]; i++) if (occ[i]) { own.emplace_back(new MapLine()); own.back()->mnId = 990000 + i; F.mvpMapLines[i] = own.back().get(); }
+  // the skipped map lines take the three forms the reference tests for (:1015-1026) in turn
+  std::vector<MapLine*> lines_last(n_map, nullptr); std::vector<Mat> descs;
+  int kind = 0;
+  for (int i = 0; i < n_map; i++) {
+    descs.push_back(Mat(1, dim, &ldesc[(size_t)i * dim]));
+    if (skip[i] && (kind++ % 3) == 0) continue;                              // NULL
+    own.emplace_back(new MapLine()); MapLine* p = own.back().get(); p->mnId = i;
+    p->mX0 = Vector3d(X0[3 * i], X0[3 * i + 1], X0[3 * i + 2]); p->mDir = Vector3d(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]);
+    p->mX1 = Vector3d(X1[3 * i], X1[3 * i + 1], X1[3 * i + 2]); p->mX2 = Vector3d(X2[3 * i], X2[3 * i + 1], X2[3 * i + 2]);
+    if (skip[i]) { if ((kind % 3) == 1) p->tracked_last_id = 42; else p->mbBad = true; }
+    lines_last[i] = p;
+  }
+  lld_adapter::TrackingLines T;
+  for (int i = 0; i < 9; i++) T.K[i] = k[i];
+  T.mb = k[41]; T.mnMaxX = k[42]; T.mnMaxY = k[43]; T.mdThr = k[44]; T.monocular = false;
+  lld_adapter::AddLinesFrom(ctx, T, lines_last, k + 9, descs, Mat(), k[45], &F);
+  std::vector<int32_t> m(n_map, -1), tracked(n_map, 0);
+  for (int i = 0; i < nf[0]; i++) if (F.mvpMapLines[i] && F.mvpMapLines[i]->mnId < 990000) m[F.mvpMapLines[i]->mnId] = i;
+  for (int i = 0; i < n_map; i++) tracked[i] = lines_last[i] && !skip[i] && lines_last[i]->tracked_last_id == 42;
+  Writer wr(out);
+  wr.put(m); wr.put(tracked);
+  int na = 0; for (int i = 0; i < n_map; i++) na += m[i] >= 0;
+  std::printf("AddLinesFrom: %d of %d map lines placed in the frame\n", na, n_map);
+  // TwoFrameLineMatcher::MatchLines on a stereo pair of line sets
+  double K[9], bt[3]; int32_t n2[3]; r.get(K, 9); r.get(bt, 3); r.get(n2, 3);   // K; b, tau, minLineLength; nl, nr, dim
+  std::vector<float> sl, sr, dl, dr; std::vector<int32_t> ol, orr;
+  r.get(sl, 4 * (size_t)n2[0]); r.get(ol, n2[0]); r.get(dl, (size_t)n2[0] * n2[2]); r.get(sr, 4 * (size_t)n2[1]); r.get(orr, n2[1]); r.get(dr, (size_t)n2[1] * n2[2]);
+  std::vector<KeyLine> kl1, kl2;
+  for (int i = 0; i < n2[0]; i++) kl1.push_back(kl(&sl[4 * i], ol[i]));
+  for (int i = 0; i < n2[1]; i++) kl2.push_back(kl(&sr[4 * i], orr[i]));
+  std::vector<int> dm;
+  lld_adapter::TwoFrameLineMatcher(ctx, K, bt[0], bt[1], (int)bt[2]).MatchLines(kl1, kl2, Mat(n2[0], n2[2], dl.data()), Mat(n2[1], n2[2], dr.data()), &dm);
+  std::vector<int32_t> dm32(dm.begin(), dm.end());
+  wr.put(dm32);
+  int ns = 0; for (size_t i = 0; i < dm.size(); i++) ns += dm[i] >= 0;
+  std::printf("TwoFrameLineMatcher::MatchLines: %d of %d left lines matched\n", ns, n2[0]);
+  return 0;
+}
+
 int main(int argc, char** argv) {
-  if (argc < 4) { std::fprintf(stderr, "usage: adapter_harness ba|pose|match|loopmatch|bow <in> <out> [seed]\n"); return 2; }
+  if (argc < 4) { std::fprintf(stderr, "usage: adapter_harness ba|pose|match|loopmatch|bow|lines <in> <out> [seed]\n"); return 2; }
   const unsigned seed = argc > 4 ? (unsigned)std::atoi(argv[4]) : 1u;
   try {
     const std::string mode = argv[1];
@@ -559,6 +622,7 @@ int main(int argc, char** argv) {
     if (mode == "match") return run_match(argv[2], argv[3]);
     if (mode == "loopmatch") return run_loopmatch(argv[2], argv[3]);
     if (mode == "bow") return run_bow(argv[2], argv[3]);
+    if (mode == "lines") return run_lines(argv[2], argv[3]);
     std::fprintf(stderr, "unknown mode %s\n", argv[1]);
     return 2;
   } catch (const std::exception& e) {

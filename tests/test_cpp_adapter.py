@@ -562,3 +562,37 @@ def test_bow_matcher_adapters_on_live_objects(harness, tmp_path, seed, check):
     assert cc[0] == nt and cc[1] == int((m12t >= 0).sum()) and nt > 40
     np.testing.assert_array_equal(t12, m12t)
 
+
+@pytest.mark.gpu
+def test_line_adapters_on_live_objects(harness, tmp_path, oracle):
+    """adapters/lld_line_adapter.cc: Tracking::AddLinesFrom (src/Tracking.cc:996-1124) on MapLine / Frame doubles - the three skip forms
+    (NULL, tracked in this frame, bad), occupied frame lines, mvpMapLines / tracked_last_id written back - against the golden fixture of
+    the flat path (tests/golden/line_track.npz), and TwoFrameLineMatcher::MatchLines (src/TwoFrameLineMatcher.cc:26-124) on KeyLine
+    vectors against the oracle."""
+    from test_cpp_harness import GOLD, _write_frame_lines
+    d = np.load(os.path.join(GOLD, "line_track.npz"))
+    dim = d["l_desc"].shape[1]; n_map = d["l_X0"].shape[0]
+    s2 = synth.make_stereo_lines(5, 280, 300)
+    with open(tmp_path / "in.bin", "wb") as f:
+        np.array([dim, n_map, 1], np.int32).tofile(f)
+        np.concatenate([d["p_K"].reshape(-1), d["p_T_curr"].reshape(-1), np.zeros(16),
+                        [float(d["p_b"]), 1.0 / float(d["p_sx"]), 1.0 / float(d["p_sy"]), float(d["p_md_thr"]), float(d["p_thr_reproj_base"])]]).astype(np.float64).tofile(f)
+        for k in ("l_X0", "l_dir", "l_X1", "l_X2"): np.ascontiguousarray(d[k], np.float64).tofile(f)
+        np.ascontiguousarray(d["l_skip"], np.uint8).tofile(f); np.ascontiguousarray(d["l_desc"], np.float32).tofile(f)
+        _write_frame_lines(f, d["f_left_lines"], d["f_right_lines"], d["f_left_octave"], d["f_line_matches"], d["f_occupied"], d["f_desc"])
+        np.asarray(s2["K"], np.float64).reshape(9).tofile(f); np.array([s2["b"], 2.0, 20.0], np.float64).tofile(f)
+        np.array([s2["left"].shape[0], s2["right"].shape[0], s2["desc_left"].shape[1]], np.int32).tofile(f)
+        np.ascontiguousarray(s2["left"], np.float32).tofile(f); np.ascontiguousarray(s2["left_octave"], np.int32).tofile(f); np.ascontiguousarray(s2["desc_left"], np.float32).tofile(f)
+        np.ascontiguousarray(s2["right"], np.float32).tofile(f); np.ascontiguousarray(s2["right_octave"], np.int32).tofile(f); np.ascontiguousarray(s2["desc_right"], np.float32).tofile(f)
+    r = subprocess.run([harness, "lines", str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    nl = s2["left"].shape[0]
+    with open(tmp_path / "out.bin", "rb") as f:
+        m = np.fromfile(f, np.int32, n_map); tracked = np.fromfile(f, np.int32, n_map); dm = np.fromfile(f, np.int32, nl)
+    np.testing.assert_array_equal(m, d["out_m_grid"])
+    np.testing.assert_array_equal(tracked != 0, d["out_m_grid"] >= 0)            # tracked_last_id is set exactly where a line was placed
+    assert (m >= 0).sum() > 20 and (d["l_skip"] != 0).sum() >= 3
+    me, de = oracle.line_match_stereo(s2["K"], s2["b"], 2.0, 20, s2["left"], s2["left_octave"], s2["desc_left"], s2["right"], s2["right_octave"], s2["desc_right"])[:2]
+    np.testing.assert_array_equal(dm, me)
+    assert (dm >= 0).sum() > 60
+
