@@ -33,7 +33,9 @@ import time
 # The solve keeps up to four window groups in flight on separate HIP streams.  ROCm maps the streams of a process onto
 # GPU_MAX_HW_QUEUES hardware queues (default 4); once RCCL has created its own streams, several of ours share a queue and
 # serialise (measured: 4240 -> 3580 windows/s on one GPU with an initialised process group).  Must be set before HIP initialises.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# 16, not 8: the `e2e` leg runs two more contexts (five streams each) next to the resident one; with 8 queues their uploads shared a
+# queue with another lane's group streams and a solve's turn took 70 ms instead of 55 (e2e 3550 -> 4150 windows/s, `value` unchanged).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for _p in (ROOT, os.path.join(ROOT, "oracle")):
@@ -262,7 +264,7 @@ def secondary_block(ctx, dev, repeats=5):
 
 
 # ================================================================================================== host buffers in -> results out
-def e2e_block(windows, device, lanes=2, batches_per_lane=5):
+def e2e_block(windows, device, lanes=2, batches_per_lane=8):
     """Steady-state rate at the C ABI with HOST buffers on both sides: `lanes` host threads, each with its own context, loop
     lld_ba_batch_create -> lld_ba_batch_solve -> lld_ba_batch_download_range -> lld_ba_batch_destroy on the same 256 host windows.
     Flattening + upload of one lane's next batch and the download of its previous one overlap the other lane's solve (solves of large

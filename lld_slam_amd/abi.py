@@ -194,7 +194,7 @@ PRODUCT_SYMBOLS = [
 
 # see bench.py: more hardware queues than the default 4, so that the library's group streams do not share a queue with the caller's
 # other streams (effective only if HIP has not been initialised yet)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 
 def product_library_path() -> str:

@@ -198,13 +198,14 @@ def set_landmark_inverse(how: int):
     lib().dll.lldo_set_landmark_inverse(int(how))
 
 
-def optimize_sim3(pair, th2=10.0, bFixScale=True, **params):
-    """Optimizer::OptimizeSim3, literal restatement (numeric Jacobians as g2o)."""
+def optimize_sim3(pair, th2=10.0, bFixScale=True, fma=False, **params):
+    """Optimizer::OptimizeSim3, literal restatement (numeric Jacobians as g2o).  `fma=True`: the FMA-contracted build (sensitivity only)."""
     many = isinstance(pair, (list, tuple))
     pairs = list(pair) if many else [pair]
-    prm = host.sim3_params(lib(), th2, bFixScale, **params)
+    L = lib_fma() if fma else lib()
+    prm = host.sim3_params(L, th2, bFixScale, **params)
     cs, drops, res = host.sim3_pack(pairs)
-    fn = lib().fn("optimize_sim3"); fn.argtypes = [C.c_void_p, C.POINTER(abi.Sim3Problem), C.POINTER(abi.Sim3Params), C.POINTER(abi.Sim3Result)]; fn.restype = C.c_int
+    fn = L.fn("optimize_sim3"); fn.argtypes = [C.c_void_p, C.POINTER(abi.Sim3Problem), C.POINTER(abi.Sim3Params), C.POINTER(abi.Sim3Result)]; fn.restype = C.c_int
     for c, r in zip(cs, res):                                      # the oracle has no batch entry point: one candidate at a time
         host.check(fn(None, C.byref(c), C.byref(prm), C.byref(r)), "lldo_optimize_sim3")
     outs = host.sim3_unpack(pairs, drops, res)
