@@ -88,6 +88,43 @@ def test_matrix_core_cholesky_at_every_tile_padding(gpu_ctx, oracle, n_free):
     check_ba(Optimizer(gpu_ctx).LocalBundleAdjustment(w), oracle.local_ba(w), w)
 
 
+@pytest.mark.parametrize("wid,kw", [
+    (0, dict(obs_per_point=2, obs_per_line=2)),                      # block-tridiagonal S: nearly every tile of the factor is a zero tile
+    (1, dict(obs_per_point=3, obs_per_line=6, n_free=37)),           # a band of six cameras on a last tile that is only partly filled
+    (2, dict(obs_per_point=25, obs_per_line=12)),                    # every camera pair shares a landmark: dense S, nothing to skip
+    (3, dict(obs_per_point=2, obs_per_line=1, n_lines=40)),          # single-observation lines add diagonal blocks only
+])
+def test_reduced_systems_from_block_tridiagonal_to_dense(gpu_ctx, oracle, wid, kw):
+    """The covisibility structure of the reduced camera system at its extremes (LBA-B windows are about a quarter dense at block level):
+    exact zero tiles through all 19 tile columns of the matrix-core Cholesky, partly filled last tiles, a fully dense S."""
+    args = dict(n_free=50, n_fixed=4, n_points=1500, n_lines=200); args.update(kw)
+    w = synth.make_ba_window(seed=0x5A120000 + wid, **args)
+    check_ba(Optimizer(gpu_ctx).LocalBundleAdjustment(w), oracle.local_ba(w), w)
+
+
+def test_window_of_two_unconnected_camera_groups(gpu_ctx, oracle):
+    """Two halves of the window that share no landmark (cameras 0..24 see the first half of the landmarks, 25..49 the second): S is
+    block diagonal and the solution is that of the two halves side by side."""
+    import dataclasses
+    a = synth.make_lba_small(310, n_free=25, n_fixed=2, n_points=700, n_lines=90)
+    b = synth.make_lba_small(311, n_free=25, n_fixed=2, n_points=700, n_lines=90)
+    # camera order of a window: free first, then fixed -> a's free, b's free, a's fixed, b's fixed
+    def remap(cam, nf_self, off_free, off_fixed): return np.where(cam < nf_self, cam + off_free, cam - nf_self + off_fixed).astype(np.int32)
+    w = dataclasses.replace(
+        a, n_free_cams=50, cam_qt=np.concatenate([a.cam_qt[:25], b.cam_qt[:25], a.cam_qt[25:], b.cam_qt[25:]]),
+        pt_xyz=np.concatenate([a.pt_xyz, b.pt_xyz]),
+        pt_obs_start=np.concatenate([a.pt_obs_start, b.pt_obs_start[1:] + a.pt_obs_start[-1]]).astype(np.int32),
+        pt_obs_cam=np.concatenate([remap(a.pt_obs_cam, 25, 0, 50), remap(b.pt_obs_cam, 25, 25, 52)]),
+        pt_obs_uvr=np.concatenate([a.pt_obs_uvr, b.pt_obs_uvr]), pt_obs_inv_sigma2=np.concatenate([a.pt_obs_inv_sigma2, b.pt_obs_inv_sigma2]),
+        line_x0=np.concatenate([a.line_x0, b.line_x0]), line_dir=np.concatenate([a.line_dir, b.line_dir]),
+        ln_obs_start=np.concatenate([a.ln_obs_start, b.ln_obs_start[1:] + a.ln_obs_start[-1]]).astype(np.int32),
+        ln_obs_cam=np.concatenate([remap(a.ln_obs_cam, 25, 0, 50), remap(b.ln_obs_cam, 25, 25, 52)]),
+        ln_obs_left=np.concatenate([a.ln_obs_left, b.ln_obs_left]), ln_obs_right=np.concatenate([a.ln_obs_right, b.ln_obs_right]),
+        ln_obs_octave=np.concatenate([a.ln_obs_octave, b.ln_obs_octave]))
+    g, o = Optimizer(gpu_ctx).LocalBundleAdjustment(w), oracle.local_ba(w)
+    check_ba(g, o, w)
+
+
 def test_windows_above_the_matrix_core_limit_use_the_vector_cholesky(gpu_ctx, oracle):
     """More than 50 free cameras (6*n_free > 304) do not fit the register-resident tile triangle: the batch falls back to the
     6x6-block kernel, not to an error."""
