@@ -534,7 +534,13 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if saved_stdout is not None:
-        sys.stdout.flush(); os.dup2(saved_stdout, 1); os.close(saved_stdout)
+        sys.stdout.flush()
+        try:                                  # what native libraries (RCCL: "Librccl path : ...") left in the C stdio buffer goes where fd 1 points NOW
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        os.dup2(saved_stdout, 1); os.close(saved_stdout)
     if rank == 0:
         print(json.dumps(result))
 
