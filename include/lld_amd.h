@@ -621,7 +621,8 @@ int lld_orb_search_run(lld_ctx* ctx, const lld_orb_search* s, lld_orb_search_res
  * The float / double mixture follows the reference's OpenCV calls as this build restates them (OpenCV is not in the image:
  * parity unpinned): `mRcw*P+mtcw` is one cv::gemm, i.e. float(sum_k double(R_ik) double(P_k) + double(t_i)); `P-mOw` a float
  * subtraction; cv::norm and Mat::dot accumulate in double; everything else is float arithmetic in source order; log() of a
- * float is the float overload.
+ * float is the float overload - computed the way glibc (>= 2.27) computes logf, so that PredictScale's ceil() flips at the same
+ * float as on the reference's host (lld_orb_search.hip glibc_logf; a libm with another logf moves one level in ~1e8).
  * `frame`: only the keypoint side (nt, t_*), the grid constants and n_levels / level_scale are read.
  * frustum outputs (any may be NULL): in_view[n] (mbTrackInView), proj_uvr[n][3] (mTrackProjX, mTrackProjY, mTrackProjXR),
  * level[n] (mnTrackScaleLevel), view_cos[n] (mTrackViewCos); values of points outside the frustum are unspecified. */

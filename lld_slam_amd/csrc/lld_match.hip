@@ -255,9 +255,61 @@ constexpr double kInfD = 1.7976931348623157e308;
 // Geometric gates of TwoFrameLineMatcher::CheckLinePair (src/TwoFrameLineMatcher.cc:79-109) for the stereo pair of one frame.
 // T = identity, T_right = [I | (b,0,0)] (GetTForRight, src/LineMatching.cc:228-237).
 // The 3x3 system of vgl::TriangulateLine (src/vgl.cc:78-108) has rows n1, n2, d = n1 x n2 / |n1 x n2|, so its determinant is
-// |n1 x n2| > 0 once the 0.975 parallelism test passed (rank 3 always) and X0 = (b1 (d x n1)) / det in closed form; the 3x2
-// least squares of vgl::ReprojectLinePointTo3D (src/vgl.cc:336-346) is solved by its normal equations.
+// |n1 x n2| > 0 once the 0.975 parallelism test passed (rank 3 always) and X0 = (b1 (d x n1)) / det in closed form.  The 3x2
+// least squares of vgl::ReprojectLinePointTo3D (src/vgl.cc:336-346) is solved the way the reference solves it, by a column-pivoted
+// Householder QR (reproject_param_qr): its normal equations square the condition number, and when the viewing ray of an end point is
+// parallel to the triangulated line to ~1e-8 (two unrelated segments: one pair in ~1e8) they return a line parameter of the wrong
+// sign, and the depth test `p.z < 0` with it (found by tools/fuzz_matchers.py, FUZZ_BIG=1, seed 9, scene 13712).
 struct LineGateParams { double K[9]; double b; double min_len; int is_stereo; };
+
+// Eigen::ColPivHouseholderQR::solve of the 3x2 system [a | c] (depth, param)^T = r, restated as oracle/lldo_linematch.cpp restates it
+// (pivot on the larger column norm, makeHouseholderInPlace, rank by |R_kk| > 2 eps max|R_kk|, dropped unknowns = 0); returns the
+// line parameter.  No contraction: the same operations as the host code, one rounding each.
+__device__ __forceinline__ double reproject_param_qr(const double a[3], const double c[3], const double r[3]) {
+#pragma clang fp contract(off)
+  double A[3][2] = {{a[0], c[0]}, {a[1], c[1]}, {a[2], c[2]}};
+  double b[3] = {r[0], r[1], r[2]};
+  int perm[2] = {0, 1};
+  double diag[2] = {0.0, 0.0}, maxpivot = 0.0;
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    int best = k; double best_norm = -1.0;
+    for (int cc = k; cc < 2; cc++) {
+      double sn = 0.0; for (int rr = k; rr < 3; rr++) sn += A[rr][cc] * A[rr][cc];
+      if (sn > best_norm) { best_norm = sn; best = cc; }
+    }
+    if (best != k) { for (int rr = 0; rr < 3; rr++) { const double t = A[rr][k]; A[rr][k] = A[rr][best]; A[rr][best] = t; } const int t = perm[k]; perm[k] = perm[best]; perm[best] = t; }
+    const double c0 = A[k][k];
+    double tail = 0.0; for (int rr = k + 1; rr < 3; rr++) tail += A[rr][k] * A[rr][k];
+    double beta = c0, tau = 0.0; double v[3] = {0.0, 0.0, 0.0};
+    if (tail > 2.2250738585072014e-308) {
+      beta = sqrt(c0 * c0 + tail);
+      if (c0 >= 0) beta = -beta;
+      for (int rr = k + 1; rr < 3; rr++) v[rr] = A[rr][k] / (c0 - beta);
+      tau = (beta - c0) / beta;
+      for (int cc = k + 1; cc < 2; cc++) {
+        double w = A[k][cc]; for (int rr = k + 1; rr < 3; rr++) w += v[rr] * A[rr][cc];
+        A[k][cc] -= tau * w; for (int rr = k + 1; rr < 3; rr++) A[rr][cc] -= tau * w * v[rr];
+      }
+      double w = b[k]; for (int rr = k + 1; rr < 3; rr++) w += v[rr] * b[rr];
+      b[k] -= tau * w; for (int rr = k + 1; rr < 3; rr++) b[rr] -= tau * w * v[rr];
+    }
+    A[k][k] = beta; for (int rr = k + 1; rr < 3; rr++) A[rr][k] = 0.0;
+    diag[k] = fabs(beta);
+    if (diag[k] > maxpivot) maxpivot = diag[k];
+  }
+  const double threshold = 2.220446049250313e-16 * 2.0;                         // NumTraits::epsilon() * diagonalSize()
+  int rank = 0;
+  for (int k = 0; k < 2; k++) if (diag[k] > threshold * maxpivot) rank++;
+  double y[2] = {0.0, 0.0};
+  for (int k = rank - 1; k >= 0; k--) {
+    double sacc = b[k]; for (int cc = k + 1; cc < rank; cc++) sacc -= A[k][cc] * y[cc];
+    y[k] = sacc / A[k][k];
+  }
+  double x[2] = {0.0, 0.0};
+  for (int k = 0; k < 2; k++) x[perm[k]] = (k < rank) ? y[k] : 0.0;
+  return x[1];
+}
 
 __device__ __forceinline__ void normalized_line_eq(const float* kl, const double* K, double* l) {
   const double sx = kl[0], sy = kl[1], ex = kl[2], ey = kl[3];
@@ -286,12 +338,10 @@ __device__ __forceinline__ bool line_pair_gate(const LineGateParams& P, const fl
                        -(P.K[6] * d[0] + P.K[7] * d[1] + P.K[8] * d[2])};
   const double r[3] = {P.K[0] * X0[0] + P.K[1] * X0[1] + P.K[2] * X0[2], P.K[3] * X0[0] + P.K[4] * X0[1] + P.K[5] * X0[2],
                        P.K[6] * X0[0] + P.K[7] * X0[1] + P.K[8] * X0[2]};
-  const double cc = c[0] * c[0] + c[1] * c[1] + c[2] * c[2], cr = c[0] * r[0] + c[1] * r[1] + c[2] * r[2];
   bool front = true;
   for (int e = 0; e < 2; e++) {
-    const double px = k1[2 * e], py = k1[2 * e + 1];
-    const double aa = px * px + py * py + 1.0, ac = px * c[0] + py * c[1] + c[2], ar = px * r[0] + py * r[1] + r[2];
-    const double p = (aa * cr - ac * ar) / (aa * cc - ac * ac);               // line parameter of the re-projected endpoint
+    const double a[3] = {(double)k1[2 * e], (double)k1[2 * e + 1], 1.0};
+    const double p = reproject_param_qr(a, c, r);                               // line parameter of the re-projected endpoint
     if (X0[2] + p * d[2] < 0) front = false;
   }
   return front;

@@ -554,10 +554,40 @@ __device__ __forceinline__ double cv_dot3(const float* a, const float* b) {
   return __dadd_rn(__dadd_rn(__dmul_rn((double)a[0], (double)b[0]), __dmul_rn((double)a[1], (double)b[1])), __dmul_rn((double)a[2], (double)b[2]));
 }
 __device__ __forceinline__ float cv_norm3(const float* a) { return (float)__dsqrt_rn(cv_dot3(a, a)); }
+// log(float) as the reference's libm computes it.  MapPoint::PredictScale takes ceil(log(ratio) / mfLogScaleFactor): where the quotient
+// lands on an integer, a logarithm that is one unit in the last place off moves the predicted level by one, and the device library's
+// logf and glibc's are both "within an ulp" without being the same function (found by tools/fuzz_matchers.py with FUZZ_BIG=1: one
+// level in 6128 in-view points of one scene in 100 000).  This is glibc's algorithm (sysdeps/ieee754/flt-32/e_logf.c and
+// logf_data.c, glibc >= 2.27, taken from ARM's optimized routines; constants checked against the libm.so.6 of this image, glibc 2.35):
+// x = 2^k z with z in [0x1.66p-1, 0x1.66p0), sixteen sub-intervals with 1/c and log(c) tabulated, log1p(z/c - 1) by a cubic, all in
+// double, rounded to float once.  tests/test_oracle_kat.py holds the same restatement (oracle/) against std::log(float) on this host;
+// contraction of its multiply-adds does not change the float result (0 differences in 2e8 random arguments either way).
+__device__ __forceinline__ float glibc_logf(float x) {
+  const double T[16][2] = {
+      {0x1.661ec79f8f3bep+0, -0x1.57bf7808caadep-2}, {0x1.571ed4aaf883dp+0, -0x1.2bef0a7c06ddbp-2}, {0x1.49539f0f010bp+0, -0x1.01eae7f513a67p-2},
+      {0x1.3c995b0b80385p+0, -0x1.b31d8a68224e9p-3}, {0x1.30d190c8864a5p+0, -0x1.6574f0ac07758p-3}, {0x1.25e227b0b8eap+0, -0x1.1aa2bc79c81p-3},
+      {0x1.1bb4a4a1a343fp+0, -0x1.a4e76ce8c0e5ep-4}, {0x1.12358f08ae5bap+0, -0x1.1973c5a611cccp-4}, {0x1.0953f419900a7p+0, -0x1.252f438e10c1ep-5},
+      {0x1p+0, 0x0p+0},                              {0x1.e608cfd9a47acp-1, 0x1.aa5aa5df25984p-5},  {0x1.ca4b31f026aap-1, 0x1.c5e53aa362eb4p-4},
+      {0x1.b2036576afce6p-1, 0x1.526e57720db08p-3},  {0x1.9c2d163a1aa2dp-1, 0x1.bc2860d22477p-3},   {0x1.886e6037841edp-1, 0x1.1058bc8a07ee1p-2},
+      {0x1.767dcf5534862p-1, 0x1.4043057b6ee09p-2}};
+  const double Ln2 = 0x1.62e42fefa39efp-1, A0 = -0x1.00ea348b88334p-2, A1 = 0x1.5575b0be00b6ap-2, A2 = -0x1.ffffef20a4123p-2;
+  const uint32_t ix = __float_as_uint(x);
+  if (ix == 0x3f800000u) return 0.0f;
+  if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u) return logf(x);            // zero, subnormal, negative, inf, nan: not a distance ratio
+  const uint32_t tmp = ix - 0x3f330000u;
+  const int i = (int)((tmp >> 19) & 15u), k = (int)tmp >> 23;                   // arithmetic shift
+  const double z = (double)__uint_as_float(ix - (tmp & 0xff800000u));
+  const double r = __dsub_rn(__dmul_rn(z, T[i][0]), 1.0), y0 = __dadd_rn(T[i][1], __dmul_rn((double)k, Ln2)), r2 = __dmul_rn(r, r);
+  double y = __dadd_rn(__dmul_rn(A1, r), A2);
+  y = __dadd_rn(__dmul_rn(A0, r2), y);
+  y = __dadd_rn(__dmul_rn(y, r2), __dadd_rn(y0, r));
+  return (float)y;
+}
+
 // MapPoint::PredictScale (src/MapPoint.cc:402-417): float log, float division, ceil, clamp
 __device__ __forceinline__ int predict_scale(float max_distance, float dist, const lld_frame_view& V) {
   const float ratio = __fdiv_rn(max_distance, dist);
-  int n = (int)ceilf(__fdiv_rn(logf(ratio), V.log_scale_factor));
+  int n = (int)ceilf(__fdiv_rn(glibc_logf(ratio), V.log_scale_factor));
   if (n < 0) n = 0; else if (n >= V.n_levels) n = V.n_levels - 1;
   return n;
 }

@@ -24,6 +24,7 @@
 #include <climits>
 #include <cmath>
 #include <cstdint>
+#include <cstring>
 #include <vector>
 
 #include "../include/lld_amd.h"
@@ -864,6 +865,63 @@ void lldo_project_general(const lld_frame_view* V, const lld_map_points* mp, int
     if (nScale < 0) nScale = 0; else if (nScale >= V->n_levels) nScale = V->n_levels - 1;
     valid_out[i] = 1; uv[2 * i] = u; uv[2 * i + 1] = v; level[i] = nScale;
   }
+}
+
+// The libm under MapPoint::PredictScale's log(ratio), restated: glibc's logf (sysdeps/ieee754/flt-32/e_logf.c + logf_data.c, glibc >= 2.27;
+// constants read back from this image's libm.so.6, glibc 2.35).  The routines above keep calling std::log - the reference's behaviour on
+// this platform; the DEVICE cannot call it and carries this algorithm (lld_orb_search.hip, glibc_logf).  lldo_glibc_logf_differences pins
+// the restatement to std::log(float) of the host the tests run on: if that libm ever computes logf another way, the test says so.
+float lldo_glibc_logf(float x) {
+  static const double T[16][2] = {
+      {0x1.661ec79f8f3bep+0, -0x1.57bf7808caadep-2}, {0x1.571ed4aaf883dp+0, -0x1.2bef0a7c06ddbp-2}, {0x1.49539f0f010bp+0, -0x1.01eae7f513a67p-2},
+      {0x1.3c995b0b80385p+0, -0x1.b31d8a68224e9p-3}, {0x1.30d190c8864a5p+0, -0x1.6574f0ac07758p-3}, {0x1.25e227b0b8eap+0, -0x1.1aa2bc79c81p-3},
+      {0x1.1bb4a4a1a343fp+0, -0x1.a4e76ce8c0e5ep-4}, {0x1.12358f08ae5bap+0, -0x1.1973c5a611cccp-4}, {0x1.0953f419900a7p+0, -0x1.252f438e10c1ep-5},
+      {0x1p+0, 0x0p+0},                              {0x1.e608cfd9a47acp-1, 0x1.aa5aa5df25984p-5},  {0x1.ca4b31f026aap-1, 0x1.c5e53aa362eb4p-4},
+      {0x1.b2036576afce6p-1, 0x1.526e57720db08p-3},  {0x1.9c2d163a1aa2dp-1, 0x1.bc2860d22477p-3},   {0x1.886e6037841edp-1, 0x1.1058bc8a07ee1p-2},
+      {0x1.767dcf5534862p-1, 0x1.4043057b6ee09p-2}};
+  static const double Ln2 = 0x1.62e42fefa39efp-1, A0 = -0x1.00ea348b88334p-2, A1 = 0x1.5575b0be00b6ap-2, A2 = -0x1.ffffef20a4123p-2;
+  uint32_t ix; std::memcpy(&ix, &x, 4);
+  if (ix == 0x3f800000u) return 0.0f;
+  if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u) return std::log(x);       // zero, subnormal, negative, inf, nan: not a distance ratio
+  const uint32_t tmp = ix - 0x3f330000u;
+  const int i = (int)((tmp >> 19) & 15u), k = (int)((int32_t)tmp >> 23);
+  const uint32_t iz = ix - (tmp & 0xff800000u);
+  float zf; std::memcpy(&zf, &iz, 4);
+  const double z = zf;
+  volatile double zi = z * T[i][0];                                             // volatile: no contraction, whatever the flags (liblld_oracle_fma.so)
+  const double r = zi - 1.0;
+  volatile double kl = (double)k * Ln2, r2 = r * r, a1r = A1 * r;
+  const double y0 = T[i][1] + kl;
+  double y = a1r + A2;
+  volatile double a0r2 = A0 * r2;
+  y = a0r2 + y;
+  volatile double yr2 = y * r2;
+  y = yr2 + (y0 + r);
+  return (float)y;
+}
+
+// how many of n pseudo-random positive normal floats (+ the neighbourhoods of 1.2^k, PredictScale's boundaries) give another bit pattern
+// than std::log(float); *first_bad = the first such argument
+long lldo_glibc_logf_differences(long n, unsigned long long seed, float* first_bad) {
+  long bad = 0;
+  unsigned long long s = seed * 6364136223846793005ull + 1442695040888963407ull;
+  auto check = [&](float x) {
+    volatile float xv = x;
+    const float ref = std::log(xv), got = lldo_glibc_logf(x);
+    if (std::memcmp(&ref, &got, 4) != 0) { if (!bad && first_bad) *first_bad = x; bad++; }
+  };
+  for (long t = 0; t < n; t++) {
+    s = s * 6364136223846793005ull + 1442695040888963407ull;
+    uint32_t b = (uint32_t)(s >> 33) & 0x7fffffffu;
+    if ((b >> 23) == 0 || (b >> 23) == 255) continue;
+    float x; std::memcpy(&x, &b, 4);
+    check(x);
+  }
+  for (int k = -8; k <= 16; k++) {
+    float c = (float)std::pow(1.2, k); uint32_t cb; std::memcpy(&cb, &c, 4);
+    for (int d = -4096; d <= 4096; d++) { const uint32_t b = cb + (uint32_t)d; float x; std::memcpy(&x, &b, 4); check(x); }
+  }
+  return bad;
 }
 
 }  // extern "C"

@@ -274,3 +274,12 @@ def project_general(view, mp: dict, routine: int, sR=None, t=None):
     d.lldo_project_general(C.byref(view), C.byref(m), int(routine), _p(sR, c_float_p), _p(t, c_float_p), _p(valid, c_uint8_p), _p(uv, c_float_p),
                            _p(lvl, c_int32_p))
     return valid, uv, lvl
+
+
+def glibc_logf_differences(n: int, seed: int = 1):
+    """(count, first argument) where the restated glibc logf (what the device carries for MapPoint::PredictScale) differs from this host's
+    std::log(float), over n pseudo-random positive floats plus 8193 neighbours of every 1.2^k, k = -8..16."""
+    d = _dll()
+    d.lldo_glibc_logf_differences.argtypes = [C.c_long, C.c_ulonglong, c_float_p]; d.lldo_glibc_logf_differences.restype = C.c_long
+    first = np.zeros(1, np.float32)
+    return int(d.lldo_glibc_logf_differences(int(n), int(seed), _p(first, c_float_p))), float(first[0])

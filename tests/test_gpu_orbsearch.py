@@ -239,6 +239,38 @@ def test_search_local_points_frustum_and_search_on_device(gpu_ctx, seed, th):
     np.testing.assert_array_equal(expect_slots(out, mp["occupied"]), slot)
 
 
+def test_predict_scale_at_its_ceil_boundaries(gpu_ctx):
+    """MapPoint::PredictScale = ceil(log(maxDistance / dist) / logScaleFactor): 400 float neighbours on either side of every 1.2^k, k = 1..7,
+    as distance ratios.  The level flips where the quotient crosses an integer, and it flips at the same float on the device and on the
+    host only if both compute the same logf: the device carries glibc's algorithm (lld_orb_search.hip glibc_logf; the device library's
+    own logf differs from it by an ulp often enough to move one level in ~1e8 - tools/fuzz_matchers.py, FUZZ_BIG=1, seed 9)."""
+    F = synth.make_orb_frame(160, 600)
+    T, mp = synth.make_local_map(F, 160, 9000, related_frac=1.0)
+    view = orb_search.frame_view(T, synth.KITTI_CAM, F)
+    _, inv0, _, _, _ = OS.is_in_frustum(view, mp)
+    idx = np.nonzero(inv0)[0]
+    PO = mp["world_pos"][idx] - np.array(view.Ow[:], f32)                       # float subtraction, double norm, float: as Frame::isInFrustum
+    dist = np.sqrt((PO.astype(np.float64) ** 2).sum(1)).astype(f32)
+    lsf = np.float64(f32(view.log_scale_factor))
+    ratios = []
+    for k in range(1, 8):
+        c = f32(np.exp(k * lsf))
+        ratios.append((np.array([c]).view(np.uint32)[0] + np.arange(-400, 401)).astype(np.uint32).view(f32))
+    ratios = np.concatenate(ratios)
+    assert idx.size >= ratios.size
+    idx = idx[:ratios.size]; dist = dist[:ratios.size]
+    mp["max_distance"][idx] = ratios * dist                                        # float product: the ratio the routine forms is within an ulp of the target
+    mp["min_distance"][idx] = mp["max_distance"][idx] / f32(8.0)
+    out, fr = orb_search.search_local_points(gpu_ctx.lib, gpu_ctx.handle, F, view, mp, mp["occupied"], 1.0, 0.8)
+    _, inv, uvr, lvl, vc = OS.is_in_frustum(view, mp)
+    np.testing.assert_array_equal(fr["in_view"], inv)
+    m = inv != 0
+    assert m[idx].sum() > 0.9 * idx.size
+    np.testing.assert_array_equal(fr["level"][m], lvl[m])
+    got = np.unique(lvl[idx][m[idx]])
+    assert got.min() <= 1 and got.max() >= 7                                       # both sides of every boundary were reached
+
+
 def test_search_local_points_edge_cases(gpu_ctx):
     F = synth.make_orb_frame(130, 300)
     T, mp = synth.make_local_map(F, 130, 200)

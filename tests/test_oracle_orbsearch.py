@@ -481,3 +481,10 @@ def test_projection_loops_of_the_sim3_and_relocalisation_matchers(seed):
     assert k.sum() > 300
     np.testing.assert_array_equal(uv3b[k, 0], ub[k])
 
+
+def test_device_logf_restatement_equals_the_platform_libm():
+    """The device cannot call the host's libm, and MapPoint::PredictScale's ceil(log(ratio) / logScaleFactor) moves by a level when logf is an
+    ulp off at a boundary: the device carries glibc's logf algorithm (lld_orb_search.hip glibc_logf).  oracle/lldo_orbsearch.cpp holds the
+    same restatement; here it must equal std::log(float) of THIS host bit for bit - 20 M random floats and 8193 neighbours of every 1.2^k."""
+    bad, first = OS.glibc_logf_differences(20_000_000, 7)
+    assert bad == 0, first

@@ -25,8 +25,13 @@ def expect_slots(out, occupied, token=1 << 20):
     return np.where(out.owner == -2, -1, slot).astype(np.int32)
 
 
+BIG = os.environ.get("FUZZ_BIG") == "1"       # FUZZ_BIG=1: most sizes in the top tenth of their range, three times as many queries / MapPoints
+
+
 def size(rng, hi, lo=1):
     """Mostly uniform, sometimes right at a power of two or one off it."""
+    if BIG and rng.random() < 0.7:
+        return int(rng.integers(max(lo, int(0.9 * hi)), hi + 1))
     if rng.random() < 0.25:
         p = 1 << int(rng.integers(0, max(1, int(np.log2(hi))) + 1))
         return int(np.clip(p + int(rng.integers(-1, 2)), lo, hi))
@@ -112,7 +117,7 @@ def r_line_lastkf(ctx, rng, sid):
 def _frame_and_queries(rng, sid):
     n = size(rng, S.MAX_KEYPOINTS, 1)
     F = synth.make_orb_frame(sid, n, n_clusters=int(rng.choice([0, 10, 60])))
-    q = synth.make_projection_queries(F, sid, size(rng, 3500), dup_frac=float(rng.choice([0.0, 0.3, 0.5])), pos_sigma=float(rng.choice([1.2, 2.5, 6.0])))
+    q = synth.make_projection_queries(F, sid, size(rng, 10500 if BIG else 3500), dup_frac=float(rng.choice([0.0, 0.3, 0.5])), pos_sigma=float(rng.choice([1.2, 2.5, 6.0])))
     return F, q
 
 
@@ -143,7 +148,7 @@ def r_fuse_inner(ctx, rng, sid):
 
 def _map_scene(rng, sid):
     F = synth.make_orb_frame(sid, size(rng, S.MAX_KEYPOINTS, 1))
-    nm = size(rng, 3500)
+    nm = size(rng, 10500 if BIG else 3500)
     T, mp = synth.make_local_map(F, sid, nm, related_frac=float(rng.uniform(0.2, 0.95)))
     return F, T, mp, nm
 
