@@ -7,6 +7,8 @@ from lld_slam_amd import Context, Optimizer, BABatch, synth
 import oracle_py as O
 from test_gpu_ba import check_ba
 ctx = Context(0); O.lib()
+import os
+BIG = os.environ.get("FUZZ_BIG") == "1"
 
 
 def rel(a, b): return np.linalg.norm(a - b, axis=1) / np.maximum(np.linalg.norm(b, axis=1), 1e-3)
@@ -54,9 +56,10 @@ bad = 0; done = 0; soft = 0
 batch = []
 for it in range(n):
     n_free = int(rng.integers(0, 40)); n_fixed = int(rng.integers(1 if n_free == 0 else 0, 6))
+    if BIG: n_free = int(rng.integers(20, 58)); n_fixed = int(rng.integers(0, 13))      # FUZZ_BIG=1: windows of the LBA-B class and beyond the 50-camera matrix-core limit
     if n_free + n_fixed < 2: n_fixed += 2
-    kw = dict(n_free=n_free, n_fixed=n_fixed, n_points=int(rng.integers(0, 900)), obs_per_point=int(rng.integers(2, min(7, n_free + n_fixed) + 1)),
-              n_lines=int(rng.integers(0, 150)), obs_per_line=int(rng.integers(1, min(6, n_free + n_fixed) + 1)), seed=int(rng.integers(1, 2 ** 31)),
+    kw = dict(n_free=n_free, n_fixed=n_fixed, n_points=int(rng.integers(0, 12000 if BIG else 900)), obs_per_point=int(rng.integers(2, min(12 if BIG else 7, n_free + n_fixed) + 1)),
+              n_lines=int(rng.integers(0, 2500 if BIG else 150)), obs_per_line=int(rng.integers(1, min(8 if BIG else 6, n_free + n_fixed) + 1)), seed=int(rng.integers(1, 2 ** 31)),
               outlier_frac=float(rng.choice([0.0, 0.05, 0.2, 0.5])), mono_frac=float(rng.choice([0.0, 0.0, 0.3, 1.0])),
               mono_line_frac=float(rng.choice([0.0, 0.0, 0.4, 1.0])), noise=float(rng.choice([0.0, 0.5, 1.0, 3.0])),
               pose_sigma=(float(rng.uniform(0, 1.5)), float(rng.uniform(0, 0.15))), point_sigma=float(rng.uniform(0, 0.3)))

@@ -6,11 +6,13 @@ from lld_slam_amd import Context, Optimizer, PoseBatch, synth
 import oracle_py as O
 from test_gpu_pose import _check
 ctx = Context(0); O.lib()
+import os
+BIG = os.environ.get("FUZZ_BIG") == "1"        # frames around and beyond what the kernel keeps in LDS (1000 points + 400 line edges = 106 KB)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 500
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 bad = 0; soft = 0; done = 0
 for it in range(n):
-    kw = dict(n_points=int(rng.choice([0, 2, 5, 30, 200, 1000, 1500])), n_lines=int(rng.choice([0, 2, 20, 200, 400])), outlier_frac=float(rng.choice([0.0, 0.1, 0.3, 0.6, 0.9])),
+    kw = dict(n_points=int(rng.choice([1000, 1500, 2100, 3000, 6000] if BIG else [0, 2, 5, 30, 200, 1000, 1500])), n_lines=int(rng.choice([200, 400, 800, 1500] if BIG else [0, 2, 20, 200, 400])), outlier_frac=float(rng.choice([0.0, 0.1, 0.3, 0.6, 0.9])),
               mono_frac=float(rng.choice([0.0, 0.0, 0.3, 1.0])), mono_line_frac=float(rng.choice([0.0, 0.0, 0.3, 1.0])))
     gamma = float(rng.choice([0.5, 0.5, 1.0, 0.1]))
     f = synth.make_pose_frame(5000 + it, seed=int(rng.integers(1, 2 ** 31)), **kw)

@@ -30,13 +30,16 @@ def oracle_spread(p, o, th2, fix, rng):
     return spread, same_sets
 
 
+BIG = __import__("os").environ.get("FUZZ_BIG") == "1"        # thousands of correspondences per candidate
+
+
 def main():
     ctx = Context(0); O.lib()
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 500
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
     bad = soft = done = floor = 0
     for it in range(n):
-        kw = dict(n=int(rng.choice([10, 14, 20, 40, 120, 300, 900, 1500])), outlier_frac=float(rng.choice([0.0, 0.05, 0.15, 0.3, 0.6])),
+        kw = dict(n=int(rng.choice([1500, 3000, 6000, 12000] if BIG else [10, 14, 20, 40, 120, 300, 900, 1500])), outlier_frac=float(rng.choice([0.0, 0.05, 0.15, 0.3, 0.6])),
                   scale=float(rng.choice([1.0, 1.0, 1.08, 0.9, 1.5])), noise=float(rng.choice([0.2, 1.0, 1.0, 2.5])))
         fix = bool(rng.integers(0, 2)); th2 = float(rng.choice([10.0, 10.0, 4.0, 25.0]))
         p = synth.make_sim3_pair(int(rng.integers(0, 1 << 30)), **kw)
