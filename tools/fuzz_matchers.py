@@ -25,6 +25,20 @@ def expect_slots(out, occupied, token=1 << 20):
     return np.where(out.owner == -2, -1, slot).astype(np.int32)
 
 
+QUANT = os.environ.get("FUZZ_QUANT") == "1"   # FUZZ_QUANT=1: keypoint and projection coordinates on a half-pixel lattice, so that |dx| == r, ceil / floor of an
+                                              # integer and round(x.5) - the strict / non-strict comparisons and rounding modes of the reference - actually occur
+
+
+def quant(a):
+    return (np.round(np.asarray(a, np.float64) * 2.0) / 2.0).astype(np.float32)
+
+
+def quant_frame(F):
+    if QUANT:
+        F.xy = quant(F.xy); F.uright = np.where(F.uright > 0, quant(F.uright), F.uright).astype(np.float32)
+    return F
+
+
 BIG = os.environ.get("FUZZ_BIG") == "1"       # FUZZ_BIG=1: most sizes in the top tenth of their range, three times as many queries / MapPoints
 
 
@@ -118,6 +132,8 @@ def _frame_and_queries(rng, sid):
     n = size(rng, S.MAX_KEYPOINTS, 1)
     F = synth.make_orb_frame(sid, n, n_clusters=int(rng.choice([0, 10, 60])))
     q = synth.make_projection_queries(F, sid, size(rng, 10500 if BIG else 3500), dup_frac=float(rng.choice([0.0, 0.3, 0.5])), pos_sigma=float(rng.choice([1.2, 2.5, 6.0])))
+    if QUANT:
+        quant_frame(F); q["uv"] = quant(q["uv"]); q["ur"] = quant(q["ur"])
     return F, q
 
 
@@ -219,6 +235,7 @@ def r_bow_kf(ctx, rng, sid):
 
 def r_triangulation(ctx, rng, sid):
     F1, F2, nd = _bow(rng, sid, pos_sigma=(25.0, 1.5))
+    if QUANT: quant_frame(F1); quant_frame(F2)
     F12 = (np.array([[0, 0, 0], [0, 0, -1.0], [0, 1.0, 0.0]]) + rng.normal(0, 2e-6, (3, 3))).astype(f32)
     has1 = (rng.random(F1.n) < rng.choice([0.3, 0.6])).astype(np.uint8); has2 = (rng.random(F2.n) < 0.3).astype(np.uint8)
     only = bool(rng.integers(0, 2)); chk = bool(rng.integers(0, 2))
@@ -233,6 +250,7 @@ def r_triangulation(ctx, rng, sid):
 def r_init(ctx, rng, sid):
     n = size(rng, S.MAX_KEYPOINTS, 2)
     F1, F2, prev = synth.make_init_pair(sid, n=n, rival_frac=float(rng.choice([0.0, 0.15, 0.5])), flow_sigma=float(rng.choice([4.0, 12.0, 40.0])))
+    if QUANT: quant_frame(F1); quant_frame(F2); prev = quant(prev)
     w, nn, chk = int(rng.choice([10, 30, 60, 100, 150])), float(rng.choice([0.7, 0.9, 0.95])), bool(rng.integers(0, 2))
     on, om, opm = OS.search_for_initialization(F1, F2, prev, w, nn, chk)
     gn, gm, gpm = ORBmatcher(ctx, nn, chk).SearchForInitialization(F1, F2, prev, w)
@@ -241,6 +259,7 @@ def r_init(ctx, rng, sid):
 
 def r_stereo(ctx, rng, sid):
     sc = synth.make_stereo_scene(sid, size(rng, S.MAX_KEYPOINTS, 1))
+    if QUANT: quant_frame(sc["L"]); quant_frame(sc["R"])
     g = ORBmatcher(ctx).ComputeStereoMatchesFull(sc["L"], sc["R"], sc["left"], sc["right"], sc["inv_scale"], sc["mb"], sc["mbf"])
     n, ur, dep, br, sad = OS.compute_stereo_matches(sc["L"], sc["R"], sc["left"], sc["right"], sc["inv_scale"], sc["mb"], sc["mbf"])
     return g.n_matches == n and eq((g.best_r, br), (g.sad, sad), (g.u_right.view(np.uint32), ur.view(np.uint32)), (g.depth.view(np.uint32), dep.view(np.uint32))), n
