@@ -265,7 +265,38 @@ def r_stereo(ctx, rng, sid):
     return g.n_matches == n and eq((g.best_r, br), (g.sad, sad), (g.u_right.view(np.uint32), ur.view(np.uint32)), (g.depth.view(np.uint32), dep.view(np.uint32))), n
 
 
-ROUTINES = dict(hamming=r_hamming, l2=r_l2, line_greedy=r_line_greedy, line_stereo=r_line_stereo, line_track=r_line_track, line_lastkf=r_line_lastkf,
+def r_batch(ctx, rng, sid):
+    """lld_orb_search_batch: 2..10 problems of mixed routines and sizes in ONE launch; every problem against its own oracle."""
+    prepared, expect = [], []
+    for k in range(int(rng.integers(2, 11))):
+        kind = int(rng.integers(0, 4)); sub = int(rng.integers(0, 1 << 30))
+        if kind == 0:
+            F, q = _frame_and_queries(rng, sub); th, nn = float(rng.choice([1.0, 3.0])), float(rng.choice([0.6, 0.8]))
+            prepared.append(S.search_by_projection_map(None, None, F, q["desc"], q["valid"], q["uv"], q["ur"], q["level"], q["view_cos"], q["obs"], q["occupied"], th, nn))
+            expect.append(("slots", q["occupied"]) + OS.search_by_projection_map(F, q["desc"], q["valid"], q["uv"], q["ur"], q["level"], q["view_cos"], q["obs"], q["occupied"], th, nn))
+        elif kind == 1:
+            F, q = _frame_and_queries(rng, sub); d, th, chk = int(rng.integers(-1, 2)), float(rng.choice([7.0, 15.0])), bool(rng.integers(0, 2))
+            prepared.append(S.search_by_projection_frame(None, None, F, q["desc"], q["valid"], q["uv"], q["ur"], q["level"], q["angle"], q["obs"], q["occupied"], d, th, chk))
+            expect.append(("slots", q["occupied"]) + OS.search_by_projection_frame(F, q["desc"], q["valid"], q["uv"], q["ur"], q["level"], q["angle"], q["obs"], q["occupied"], d, th, chk))
+        elif kind == 2:
+            L, R = synth.make_stereo_pair(sub, size(rng, S.MAX_KEYPOINTS, 1))
+            prepared.append(S.stereo_search(None, None, L, R, 0.0, 100.0)); expect.append(("stereo",) + OS.stereo_search(L, R, 376, 0.0, 100.0))
+        else:
+            F1, F2, nd = _bow(rng, sub); v = (rng.random(F1.n) < 0.85).astype(np.uint8); nn, chk = float(rng.choice([0.7, 0.9])), bool(rng.integers(0, 2))
+            prepared.append(S.search_by_bow_frame(None, None, F1, F2, nd["n_nodes"], nd["start1"], nd["idx1"], nd["start2"], nd["idx2"], v, nn, chk))
+            expect.append(("bow",) + OS.search_by_bow_frame(F1, F2, nd["n_nodes"], nd["start1"], nd["idx1"], nd["start2"], nd["idx2"], v, nn, chk))
+    outs = S.run_batch(ctx.lib, ctx.handle, prepared)
+    ok = True; nm = 0
+    for out, e in zip(outs, expect):
+        if e[0] == "slots": ok = ok and out.n_matches == e[2] and eq((expect_slots(out, e[1]), e[3])); nm += int(e[2])
+        elif e[0] == "stereo": ok = ok and eq((out.match, e[1])); nm += int((e[1] >= 0).sum())
+        else:
+            got = np.where(out.owner >= 0, out.query_kp[np.maximum(out.owner, 0)], -1) if out.query_kp.size else -np.ones_like(e[2])
+            ok = ok and out.n_matches == e[1] and eq((got, e[2])); nm += int(e[1])
+    return ok, nm
+
+
+ROUTINES = dict(batch=r_batch, hamming=r_hamming, l2=r_l2, line_greedy=r_line_greedy, line_stereo=r_line_stereo, line_track=r_line_track, line_lastkf=r_line_lastkf,
                 proj_map=r_proj_map, proj_frame=r_proj_frame, fuse_inner=r_fuse_inner, local_points=r_local_points, last_frame=r_last_frame, fuse=r_fuse,
                 bow_frame=r_bow_frame, bow_kf=r_bow_kf, triangulation=r_triangulation, init=r_init, stereo=r_stereo)
 
