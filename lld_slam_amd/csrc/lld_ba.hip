@@ -390,7 +390,10 @@ static int ba_make_groups(lld_ba_batch* B, int n_groups) {
   const int n_windows = B->n_windows;
   int G = n_groups;
   if (G <= 0) {
-    G = n_windows >= 192 ? 4 : (n_windows >= 48 ? 3 : (n_windows >= 8 ? 2 : 1));
+    // >= 128 windows: groups of at least 64, which run one super-step per host poll with separate point / line kernels (kChunkFromWindows,
+    // kFusePairsBelowWindows) - four groups of 48 ran a 192-window batch at 4850 windows/s where two or three groups run it at 5150,
+    // 160 windows: 4720 -> 4950, 128: 4560 -> 4690.  Smaller batches: the chains of small groups, as measured by tools/exp_small_groups.sh.
+    G = n_windows >= 128 ? std::min(4, n_windows / 64) : (n_windows >= 48 ? 3 : (n_windows >= 8 ? 2 : 1));
     if (const char* e = std::getenv("LLD_BA_GROUPS")) { const int v = std::atoi(e); if (v >= 1 && v <= 8) G = v; }
   }
   G = std::max(1, std::min(std::min(G, 8), n_windows));
