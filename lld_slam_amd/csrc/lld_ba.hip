@@ -18,16 +18,20 @@ using namespace lldba;
 
 namespace {
 constexpr int kNumPhases = 5;
-constexpr int kFusePairsBelowWindows = 64; // a GROUP of fewer windows than this: the point + line kernels of a pair share one launch (a dependent
-                                           // launch less per pair on a chain that is latency-bound anyway: 32 windows 2520 -> 2610 windows/s, 64: 3680 -> 3780)
+constexpr int kFusePairsBelowWindows = 24; // a GROUP of fewer windows than this: the point + line kernels of a pair share one launch (a dependent
+                                           // launch less per pair on a chain that is latency-bound anyway: 32 windows = two groups of 16: 2520 -> 2610
+                                           // windows/s).  It was 64 until the end of round 3; swept then (LLD_BA_FUSE_BELOW / LLD_BA_CHUNK_FROM): groups of
+                                           // 16 - 21 windows do not care, groups of 27 - 48 lose 2.5 - 6 % to the fused kernels and the queued super-steps
+                                           // (96 windows = 3 x 32: 4220 -> 4410 windows/s without them, 112: 4400 -> 4560, 192 = 4 x 48: 4850 -> 5120)
 constexpr int kMaxSuperSteps = 512;      // hard stop: 2 rounds x 15 iterations x 10 trials is the protocol's own bound (300)
 // Super-steps queued per host poll.  A group of few windows is a chain of dependent, latency-bound kernels (a 32-window batch: 390 us per
 // super-step, of which ~30 us are the host's wait-read-launch round trip and more are launch gaps): such groups queue kChunkSmall
 // super-steps at once - every kernel looks at its window's state first, so a super-step queued for a window that is already done
 // falls through - with the round transition (ba_classify + ba_round2) inside every queued super-step.  Groups of >= kChunkFromWindows
 // windows keep one poll per super-step: their polls hide behind the other groups' kernels, and two more launches per super-step
-// over 64+ windows would cost more than they save.
-constexpr int kChunkSmall = 4, kChunkFromWindows = 64;
+// over that many windows cost more than they save (same sweep as kFusePairsBelowWindows).
+constexpr int kChunkSmall = 4, kChunkFromWindows = 24;
+static int exp_threshold(const char* name, int dflt) { const char* e = std::getenv(name); return e ? std::atoi(e) : dflt; }   // experiments
 // A batch of this many windows fills the GPU on its own (four stream groups in flight).  Two such solves interleaved from two
 // contexts ran 20 - 30 % slower in aggregate than one after the other (2 lanes: 2930 windows/s host buffers in and out, 3910 with the
 // solves taking turns; tools/exp_e2e_lanes.py), so solves of large batches take turns per device; everything else of a pipelined
@@ -390,9 +394,8 @@ static int ba_make_groups(lld_ba_batch* B, int n_groups) {
   const int n_windows = B->n_windows;
   int G = n_groups;
   if (G <= 0) {
-    // >= 128 windows: groups of at least 64, which run one super-step per host poll with separate point / line kernels (kChunkFromWindows,
-    // kFusePairsBelowWindows) - four groups of 48 ran a 192-window batch at 4850 windows/s where two or three groups run it at 5150,
-    // 160 windows: 4720 -> 4950, 128: 4560 -> 4690.  Smaller batches: the chains of small groups, as measured by tools/exp_small_groups.sh.
+    // >= 128 windows: groups of at least 64 (with groups of >= kChunkFromWindows windows the count hardly matters: 128 - 224 windows run within
+    // 1 % of each other with 2, 3 or 4 groups).  Smaller batches: the chains of small groups, as measured by tools/exp_small_groups.sh.
     G = n_windows >= 128 ? std::min(4, n_windows / 64) : (n_windows >= 48 ? 3 : (n_windows >= 8 ? 2 : 1));
     if (const char* e = std::getenv("LLD_BA_GROUPS")) { const int v = std::atoi(e); if (v >= 1 && v <= 8) G = v; }
   }
@@ -409,7 +412,7 @@ static int ba_make_groups(lld_ba_batch* B, int n_groups) {
       Gr.st = cache.streams[g - 1]; Gr.own_stream = true;
     } else { LLD_HIP_TRY(hipStreamCreateWithFlags(&Gr.st, hipStreamNonBlocking)); Gr.own_stream = true; }
     Gr.d_counters = B->d_counters + 4 * g; Gr.h_counters = B->h_counters + 4 * g;
-    Gr.chunk = (B->pcg_multi || Gr.nw >= kChunkFromWindows) ? 1 : kChunkSmall;
+    Gr.chunk = (B->pcg_multi || Gr.nw >= exp_threshold("LLD_BA_CHUNK_FROM", kChunkFromWindows)) ? 1 : kChunkSmall;
     for (int q = 0; q < Gr.chunk; q++)
       for (int k = 0; k < kNumPhases + 1; k++) {
         if (B->borrowed) { if (!cache.events[g][q][k]) LLD_HIP_TRY(hipEventCreate(&cache.events[g][q][k])); Gr.ev[q][k] = cache.events[g][q][k]; }
@@ -780,7 +783,7 @@ static int ba_batch_solve_impl(lld_ba_batch* B, StopFlag abort_flag) {
     const int abort_now = abort_flag.up() ? 1 : 0;
     hipEvent_t* ev = G.ev[q];
     LLD_HIP_TRY(hipEventRecord(ev[0], st));
-    const bool fuse_pairs = nw < kFusePairsBelowWindows && !B->big;                // see ba_linearize_both_kernel
+    const bool fuse_pairs = nw < exp_threshold("LLD_BA_FUSE_BELOW", kFusePairsBelowWindows) && !B->big;                // see ba_linearize_both_kernel
     if (B->big) {
       if (G.max_nl_pt > 0) hipLaunchKernelGGL(ba_linearize_pt_big_kernel, dim3(G.max_nl_pt, nw), dim3(kLinThreads), lin_lds, st, A, dw, ds);
       if (G.max_nl_ln > 0) hipLaunchKernelGGL(ba_linearize_ln_big_kernel, dim3(G.max_nl_ln, nw), dim3(kLinThreads), lin_lds, st, A, dw, ds);
