@@ -201,7 +201,7 @@ void stage_tasks(const lld_ba_window& w, const lld_ba_params& P, const WinBases&
   build(w.n_points, w.pt_obs_start, b.NPE, S.ptasks);      // lane <-> point edge
   build(w.n_lines, w.ln_obs_start, b.NLO, S.ltasks);       // lane <-> (line, KF) observation
   W.n_ptasks = (int)S.ptasks.size(); W.n_ltasks = (int)S.ltasks.size();
-  const int* R = n_windows >= kRoundsThroughputMinWindows ? kRoundsThroughput : kRoundsLatency;
+  const int* R = n_windows >= kRoundsBigMinWindows ? kRoundsThroughputBig : (n_windows >= kRoundsThroughputMinWindows ? kRoundsThroughput : kRoundsLatency);
   for (int i = 0; i < 4; i++) W.rounds[i] = R[i];
   // experiments: LLD_BA_ROUNDS="lin_pt,lin_ln,backsub_pt,backsub_ln" tasks per wavefront (parsed once per process)
   static const struct RoundsEnv { int r[4]; bool set; RoundsEnv() : r{0, 0, 0, 0}, set(false) {

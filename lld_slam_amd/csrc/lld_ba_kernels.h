@@ -46,6 +46,11 @@ constexpr int kLinThreads = 512;        // linearise kernels: 8 tasks per workgr
 constexpr int kRoundsThroughput[4] = {8, 2, 4, 1};
 constexpr int kRoundsLatency[4] = {1, 1, 1, 1};
 constexpr int kRoundsThroughputMinWindows = 32;
+// batches that fill the GPU many times over: twice / four times the tasks per workgroup (fewer, longer workgroups, fewer per-workgroup partials to
+// reduce).  Swept at the end of round 3 (LLD_BA_ROUNDS): 256 LBA-B windows 5320 -> 5430 windows/s; 128 windows and fewer, and the smaller LBA-A
+// windows, are 1 - 5 % faster with the setting above.
+constexpr int kRoundsThroughputBig[4] = {16, 4, 16, 1};
+constexpr int kRoundsBigMinWindows = 192;
 constexpr int kAccCopies = 4;          // (default; BAWin::acc_copies drops to 2 or 1 when a window's cameras would not fit LDS otherwise)
 constexpr int kAccCopiesDoc = 4;          // LDS copies of the per-camera Hpp/bp accumulators: lanes of one wavefront that hit the
                                        // same camera are spread over them (same-address LDS atomics serialise)
