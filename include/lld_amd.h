@@ -136,8 +136,12 @@ typedef struct {
   double  pcg_rel_tol;      /* reduced-system PCG stops at |r|_M / |b|_M <= tol (GPU only)     */
   int32_t pcg_max_iter;     /* 0 -> 10 * 6 * n_free_cams                                        */
   int32_t reduced_solver;   /* GPU only: 0 = exact Cholesky (default; the reference factorises exactly,
-                               linear_solver_eigen.h:94-124) on the fp64 matrix cores when 6*n_free <= 304,
-                               1 = block-Jacobi PCG, 2 = exact 6x6-block Cholesky on the vector ALUs     */
+                               linear_solver_eigen.h:94-124) on the fp64 matrix cores when 6*n_free <= 304 - along the
+                               block structure of S in an elimination order chosen per window, as the reference's sparse
+                               LDL^T does after computeSymbolicDecomposition (linear_solver_eigen.h:147-232), wherever the
+                               symbolic factor fits the kernel (lld_ba_chol_plan), dense otherwise,
+                               1 = block-Jacobi PCG, 2 = exact 6x6-block Cholesky on the vector ALUs,
+                               3 = the matrix-core Cholesky over all tiles in the caller's camera order (round 4's default) */
   int32_t protocol;         /* 0 = Optimizer::LocalBundleAdjustment: optimize(its_round1), outlier protocol, optimize(its_round2).
                                1 = Optimizer::BundleAdjustment / GlobalBundleAdjustment (src/Optimizer.cc:312-559) on the same
                                    kernels: ONE optimize(its_round1) call and nothing else - no classification, no line removal, all
@@ -235,6 +239,14 @@ int  lld_ba_batch_kernel_stats(lld_ba_batch* batch, int kernel, int64_t* launche
  * wants; several groups hide the latency-bound reduced solve and the per-super-step host poll. */
 int  lld_ba_batch_set_groups(lld_ba_batch* batch, int n_groups);
 void lld_ba_batch_destroy(lld_ba_batch* batch);
+
+/* Diagnostic, host only (no device needed): the symbolic factorisation `reduced_solver = 0` runs per window - the stand-in for
+ * LinearSolverEigen::computeSymbolicDecomposition (linear_solver_eigen.h:147-232).  block_nz[a * n_free_cams + b] != 0: free cameras a and
+ * b share a landmark (symmetric; the diagonal is implied).  force: 0 = the plan a batch would use, 1 = the caller's camera order as one
+ * chain of tile columns, 2 = the best two-chain (separator) plan only.  Writes the kernel's schedule (struct CholPlan of
+ * lld_slam_amd/csrc/lld_ba_chol_plan.h, *plan_size bytes; its first byte is 1 when the structure-following kernel takes the window, 0
+ * when it goes to the dense kernel) to plan_out if plan_bytes suffices.  tests/test_chol_plan.py executes such plans in numpy. */
+int lld_ba_chol_plan(int32_t n_free_cams, const uint8_t* block_nz, int32_t force, void* plan_out, uint64_t plan_bytes, uint64_t* plan_size);
 
 /* ================================================================== pose optimisation
  * Stands in for Optimizer::PoseOptimization (src/Optimizer.cc:653-932) including

@@ -71,7 +71,7 @@ struct lld_ba_batch {
   // window groups solved concurrently, each on its own stream (hides the latency-bound reduced solve, the per-super-step
   // host poll and kernel tails behind the other groups' work)
   struct Group { int w0 = 0, nw = 0; hipStream_t st = nullptr; bool own_stream = false; int* d_counters = nullptr; int* h_counters = nullptr;
-                 hipEvent_t ev[kChunkSmall][kNumPhases + 1] = {}; int chunk = 1, chunk0 = 1, chunk_from = 0; int steps = 0; bool active = false; int rows = 0; int max_nt_pt = 0, max_nb_ln = 0, max_nl_pt = 0, max_nl_ln = 0, max_lblocks = 0, max_items_pt = 0, max_items_ln = 0, max_blk = 0; };
+                 hipEvent_t ev[kChunkSmall][kNumPhases + 1] = {}; int chunk = 1, chunk0 = 1, chunk_from = 0; int steps = 0; bool active = false; int rows = 0; int max_nt_pt = 0, max_nb_ln = 0, max_nl_pt = 0, max_nl_ln = 0, max_lblocks = 0, max_items_pt = 0, max_items_ln = 0, max_blk = 0; bool any_sparse = false, any_dense = false; };
   std::vector<Group> groups;
   int* d_counters = nullptr; int* h_counters = nullptr;               // device / pinned, 4 ints per group
   int* d_slot_map = nullptr; int* d_active_pub = nullptr;            // per window: grid row -> window map of its group, published "still at work" bits (BAArrays::slot_map)
@@ -87,6 +87,7 @@ struct lld_ba_batch {
   double phase_ms[LLD_BA_N_PHASES] = {};
   int64_t launches[kNumPhases] = {};
   int super_steps = 0;
+  std::vector<uint8_t> plan_mode;                         // per window: CholPlan::mode (1: ba_chol_sparse_kernel, 0: ba_chol_mfma_kernel)
 };
 
 namespace {
@@ -159,6 +160,7 @@ struct WinStage {
   std::vector<uint8_t> pt_slot, ln_slot;                   // per landmark: its position in its task (landmark - PTask::l0; 0 for a task of one)
   ChunkStage cs[2];                                        // points, lines
   std::vector<int> blk_start, blk_src, cam_start, cam_src; // window-local CSRs over both kinds (stage_csr)
+  CholPlan plan;                                           // schedule of the structure-following reduced solve (stage_chol_plan; mode 0: dense kernel)
 };
 
 // The slab starts with two sections that come from the host: A = the flattened inputs, B = the Schur / task structures and the
@@ -189,12 +191,13 @@ void carve_a(lld_slab& sl, bool packed, long long NC, long long NP, long long NL
   a.le_s = sl.take<double>(NLE + 1);
 }
 struct SecBSizes { size_t blk_start, blk_src, cam_start, cam_src, lm, tab, cams, chunk, ptask, ltask; int n_windows; };
-struct SecB { int *blk_start, *blk_src, *cam_start, *cam_src, *sg_lm, *sg_tab, *sg_cams; SChunk* chunks; PTask *ptasks, *ltasks; BAWin* wins; };
+struct SecB { int *blk_start, *blk_src, *cam_start, *cam_src, *sg_lm, *sg_tab, *sg_cams; SChunk* chunks; PTask *ptasks, *ltasks; BAWin* wins; CholPlan* plans; };
 void carve_b(lld_slab& sl, const SecBSizes& z, SecB& b) {
   b.blk_start = sl.take<int>(z.blk_start + 2); b.blk_src = sl.take<int>(z.blk_src + 1); b.cam_start = sl.take<int>(z.cam_start + 2); b.cam_src = sl.take<int>(z.cam_src + 1);
   b.sg_lm = sl.take<int>(z.lm + 1); b.sg_tab = sl.take<int>(z.tab + 1); b.sg_cams = sl.take<int>(z.cams + 1);
   b.chunks = sl.take<SChunk>(z.chunk + 1); b.ptasks = sl.take<PTask>(z.ptask + 1); b.ltasks = sl.take<PTask>(z.ltask + 1);
   b.wins = sl.take<BAWin>((size_t)z.n_windows);
+  b.plans = sl.take<CholPlan>((size_t)z.n_windows);
 }
 
 // Grow-only pinned arena `which` of the context's cache (or, for a batch that does not own the cache, a private one the caller frees).
@@ -461,6 +464,23 @@ void stage_csr(int n_free, WinStage& S) {
   csr(n_free, &ChunkStage::cam_key, &ChunkStage::cam_val, cpart3, S.cam_start, S.cam_src);
 }
 
+// The symbolic factorisation of the window's reduced camera system (lld_ba_chol_plan.h): block (a, b) of S is structurally non-zero iff some
+// landmark is seen by both free cameras, i.e. iff the Schur reduce has a partial to sum into it.  `force`: 0 = the best plan, 1 = natural
+// order / one chain, 2 = two chains only, 3 = none (the dense kernel); experiments and tests.
+void stage_chol_plan(int n_free, int force, WinStage& S) {
+  std::memset(&S.plan, 0, sizeof S.plan);
+  if (force == 3 || n_free < 1 || 6 * n_free > kCholMN || n_free > 64) return;
+  uint64_t adj[64] = {0};
+  const int nblk = n_free * (n_free + 1) / 2;
+  for (int b = 0; b < n_free; b++)
+    for (int a = 0; a <= b; a++) {
+      const int k = b * (b + 1) / 2 + a;
+      const int cnt = (k + 1 < nblk ? S.blk_start[k + 1] : (int)S.blk_src.size()) - S.blk_start[k];
+      if (cnt > 0 || a == b) { adj[a] |= 1ull << b; adj[b] |= 1ull << a; }
+    }
+  if (!cholplan::build(n_free, adj, force, S.plan)) std::memset(&S.plan, 0, sizeof S.plan);
+}
+
 }  // namespace
 
 
@@ -517,6 +537,8 @@ static int ba_make_groups(lld_ba_batch* B, int n_groups) {
       Gr.max_nl_pt = std::max(Gr.max_nl_pt, W.nl_pt); Gr.max_nl_ln = std::max(Gr.max_nl_ln, W.nl_ln);
       Gr.max_items_pt = std::max(Gr.max_items_pt, W.n_items_pt); Gr.max_items_ln = std::max(Gr.max_items_ln, W.n_items - W.n_items_pt);
       Gr.max_blk = std::max(Gr.max_blk, W.n_free * (W.n_free + 1) / 2);
+      const bool sp = (size_t)wi < B->plan_mode.size() && B->plan_mode[wi] == 1;
+      Gr.any_sparse = Gr.any_sparse || sp; Gr.any_dense = Gr.any_dense || !sp;
     }
   }
   return LLD_OK;
@@ -542,7 +564,7 @@ static int ba_batch_create_impl(lld_ctx* ctx, int n_windows, const lld_ba_window
   if (params) B->params = *params; else lld_ba_params_default(&B->params);
   const lld_ba_params& P = B->params;
   // (optimize(0) would evaluate no error at all: the classification that follows would read g2o's uninitialised _error vectors)
-  if (P.its_round1 < 1 || (P.protocol == 0 && P.its_round2 < 1) || P.its_round2 < 0 || P.max_trials <= 0 || !(P.pcg_rel_tol > 0) || P.reduced_solver < 0 || P.reduced_solver > 2 || P.protocol < 0 || P.protocol > 1 || P.abort_after_trials < 0) { delete B; return LLD_ERR_INVALID; }
+  if (P.its_round1 < 1 || (P.protocol == 0 && P.its_round2 < 1) || P.its_round2 < 0 || P.max_trials <= 0 || !(P.pcg_rel_tol > 0) || P.reduced_solver < 0 || P.reduced_solver > 3 || P.protocol < 0 || P.protocol > 1 || P.abort_after_trials < 0) { delete B; return LLD_ERR_INVALID; }
 
   // ---- layout + host staging: the windows are flattened by a few host threads straight into their final positions
   //      (every offset that depends only on the window sizes is known up front), the variable-length Schur structures are
@@ -694,6 +716,10 @@ static int ba_batch_create_impl(lld_ctx* ctx, int n_windows, const lld_ba_window
       stage_chunks(wins[wi], 4, bases[wi], B->chunk_landmarks, S.cs[1]);
     }
     stage_csr(wins[wi].n_free_cams, S);
+    {
+      static const int plan_force = exp_int("LLD_BA_CHOL_FORCE", 0);          // experiments: 1 natural order / one chain, 2 two chains only, 3 dense kernel
+      stage_chol_plan(wins[wi].n_free_cams, P.reduced_solver == 0 ? plan_force : 3, S);
+    }
     lap1("chunks built");
   });
   if (first_error.load() != LLD_OK) return fail(first_error.load());
@@ -758,7 +784,7 @@ static int ba_batch_create_impl(lld_ctx* ctx, int n_windows, const lld_ba_window
     A.le_cam = dA.le_cam; A.le_ln = dA.le_ln; A.le_xs = dA.le_xs; A.le_ys = dA.le_ys; A.le_xe = dA.le_xe; A.le_ye = dA.le_ye; A.le_s = dA.le_s;
     A.blk_start = dB.blk_start; A.blk_src = dB.blk_src; A.cam_start = dB.cam_start; A.cam_src = dB.cam_src;
     A.sg_lm = dB.sg_lm; A.sg_tab = dB.sg_tab; A.sg_cams = dB.sg_cams; A.sg_chunks = dB.chunks; A.ptasks = dB.ptasks; A.ltasks = dB.ltasks;
-    B->d_wins = dB.wins;
+    B->d_wins = dB.wins; A.chol_plan = dB.plans;
     B->d_state = sl.take<BAState>(n_windows);
     A.NC = NC; A.NP = NP; A.NL = NL;
     A.cam_qt = sl.take<double>(2 * NC * 7 + 1);
@@ -816,6 +842,7 @@ static int ba_batch_create_impl(lld_ctx* ctx, int n_windows, const lld_ba_window
   void* arenaB = nullptr;
   { const int gs = stage_arena(ctx, cached, 1, bytesB, &arenaB); if (gs) return fail(gs); if (!cached) priv_stage[1] = arenaB; }
   SecB hB{};
+  B->plan_mode.assign((size_t)n_windows, 0);
   { lld_slab slb; slb.base = static_cast<char*>(arenaB); slb.size = bytesB; carve_b(slb, zB, hB); }
   hB.blk_start[tot.blk_start] = (int)tot.blk_src; hB.cam_start[tot.cam_start] = (int)tot.cam_src;
   for_windows([&](int wi) {
@@ -841,6 +868,7 @@ static int ba_batch_create_impl(lld_ctx* ctx, int n_windows, const lld_ba_window
     for (size_t i = 0; i < S.cam_start.size(); i++) hB.cam_start[q.cam_start + i] = S.cam_start[i] + csrc0;
     for (size_t i = 0; i < S.cam_src.size(); i++) hB.cam_src[q.cam_src + i] = S.cam_src[i] + cpart0;
     hB.wins[wi] = B->h_wins[wi];
+    hB.plans[wi] = S.plan; B->plan_mode[wi] = S.plan.mode;
     S = WinStage();
   });
   if (first_error.load() != LLD_OK) return fail(first_error.load());
@@ -854,7 +882,7 @@ static int ba_batch_create_impl(lld_ctx* ctx, int n_windows, const lld_ba_window
     const void* fns[] = {reinterpret_cast<const void*>(ba_pcg_kernel), reinterpret_cast<const void*>(ba_backsub_pt_kernel), reinterpret_cast<const void*>(ba_backsub_ln_kernel),
                          reinterpret_cast<const void*>(ba_backsub_ctl_kernel), reinterpret_cast<const void*>(ba_linearize_pt_kernel), reinterpret_cast<const void*>(ba_linearize_ln_kernel),
                          reinterpret_cast<const void*>(ba_linearize_both_kernel), reinterpret_cast<const void*>(ba_backsub_pt_f64_kernel), reinterpret_cast<const void*>(ba_backsub_ln_f64_kernel),
-                         reinterpret_cast<const void*>(ba_linearize_pt_f64_kernel), reinterpret_cast<const void*>(ba_linearize_ln_f64_kernel), reinterpret_cast<const void*>(ba_chol_kernel), reinterpret_cast<const void*>(ba_chol_mfma_kernel),
+                         reinterpret_cast<const void*>(ba_linearize_pt_f64_kernel), reinterpret_cast<const void*>(ba_linearize_ln_f64_kernel), reinterpret_cast<const void*>(ba_chol_kernel), reinterpret_cast<const void*>(ba_chol_mfma_kernel), reinterpret_cast<const void*>(ba_chol_sparse_kernel),
 #ifdef LLD_EXPERIMENTS
                          reinterpret_cast<const void*>(ba_chol_mfma2_kernel<false>), reinterpret_cast<const void*>(ba_chol_mfma2_kernel<true>),
 #endif
@@ -1001,7 +1029,11 @@ static int ba_batch_solve_impl(lld_ba_batch* B, StopFlag abort_flag) {
       hipLaunchKernelGGL(ba_pcgm_final_kernel, dim3(nw), dim3(kPcgThreads), 0, st, A, dw, ds);
     } else if (B->params.reduced_solver == 1)
       hipLaunchKernelGGL(ba_pcg_kernel, dim3(nw), dim3(kPcgThreads), pcg_lds, st, A, dw, ds, B->params.pcg_rel_tol, B->params.pcg_max_iter);
-    else if (B->params.reduced_solver == 0 && B->max_free * 6 <= kCholMN) {    // register-resident tiles on the fp64 matrix cores
+    else if ((B->params.reduced_solver == 0 || B->params.reduced_solver == 3) && B->max_free * 6 <= kCholMN) {    // register-resident tiles on the fp64 matrix cores
+      // windows with a plan (lld_ba_chol_plan.h) factor along the structure of S; a group that holds both kinds launches both kernels and each
+      // leaves the other's windows alone
+      if (G.any_sparse) hipLaunchKernelGGL(ba_chol_sparse_kernel, dim3(nw), dim3(kSpThreads), kSpLdsBytes, st, A, dw, ds);
+      if (G.any_dense) {
 #ifdef LLD_EXPERIMENTS
       // LLD_BA_CHOL_V2 selects round 4's restructured kernel (lld_ba_chol_exp.h), LLD_BA_CHOL_BLK its four-pivots-per-update tile factor
       static const bool chol_v2 = exp_flag("LLD_BA_CHOL_V2"), blk = exp_flag("LLD_BA_CHOL_BLK");
@@ -1010,6 +1042,7 @@ static int ba_batch_solve_impl(lld_ba_batch* B, StopFlag abort_flag) {
       else
 #endif
       hipLaunchKernelGGL(ba_chol_mfma_kernel, dim3(nw), dim3(kCholMThreads), kCholMLdsDoubles * sizeof(double), st, A, dw, ds);
+      }
     }
     else
       hipLaunchKernelGGL(ba_chol_kernel, dim3(nw), dim3(kPcgThreads), chol_lds, st, A, dw, ds, (int)(chol_tri / sizeof(double)));
@@ -1251,6 +1284,20 @@ __attribute__((visibility("default"))) int lld_exp_chol_stamps(lld_ba_batch* B, 
   return LLD_OK;
 }
 #endif
+
+int lld_ba_chol_plan(int32_t n_free_cams, const uint8_t* block_nz, int32_t force, void* plan_out, uint64_t plan_bytes, uint64_t* plan_size) {
+  if (plan_size) *plan_size = sizeof(CholPlan);
+  if (n_free_cams < 1 || n_free_cams > 64 || !block_nz || force < 0 || force > 2) return LLD_ERR_INVALID;
+  uint64_t adj[64] = {0};
+  for (int a = 0; a < n_free_cams; a++)
+    for (int b = 0; b < n_free_cams; b++)
+      if (a == b || block_nz[a * n_free_cams + b] || block_nz[b * n_free_cams + a]) adj[a] |= 1ull << b;
+  CholPlan P;
+  if (6 * n_free_cams > kCholMN || !cholplan::build(n_free_cams, adj, force, P)) std::memset(&P, 0, sizeof P);
+  if (plan_out && plan_bytes >= sizeof(CholPlan)) std::memcpy(plan_out, &P, sizeof P);
+  else if (plan_out) return LLD_ERR_INVALID;
+  return LLD_OK;
+}
 
 void lld_ba_batch_destroy(lld_ba_batch* B) {
   if (!B) return;

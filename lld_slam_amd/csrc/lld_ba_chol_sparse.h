@@ -1,0 +1,345 @@
+// lld_ba_chol_sparse.h — the reduced camera system solved along its structure (round 5): right-looking Cholesky on 16x16 tiles of the fp64
+// matrix cores like ba_chol_mfma_kernel, but only over the tiles of the host's symbolic factorisation (lld_ba_chol_plan.h), in the host's
+// elimination order, and with TWO panel wavefronts where the plan splits the cameras into two chains that meet in a separator.
+// Stands in for LinearSolverEigen::solve with its symbolic decomposition (Thirdparty/g2o/g2o/solvers/linear_solver_eigen.h:94-124, :147-232).
+//
+// Included by lld_ba_kernels.h after the dense kernel (chol tile layout, readlane_f64, v4d, solve_epilogue are defined there).
+//
+// One workgroup of 512 lanes per window.  Wavefront 0 / 1: panel wavefront of chain 0 / 1 (the second one idles in a one-chain plan);
+// wavefronts 2..7: tile wavefronts, each with up to 24 tiles of the factor resident in registers (lane l of a tile wavefront also keeps the
+// coordinates of slot l in three registers: v_readlane hands them to the scalar unit when a slot is touched - no tables in scalar registers).
+// A step eliminates one tile column per chain:
+//   (c)  tile wavefronts: L_IJ = A_IJ L_JJ^-T for the column's non-zero tiles (raw tile in the step's panel buffer -> L in place + registers)
+//   ---- barrier
+//   (d)  tile wavefronts: T_IK -= L_IJ L_KJ^T for the tiles the plan lists, then publish the next step's columns (raw) into the other panel buffer
+//        and the diagonal tiles of the step after into Dall; forward substitution of the right-hand side below the panel's rows;
+//        panel wavefronts (lookahead): the next column's diagonal tile takes this step's update(s) from the panel buffer, its right-hand side
+//        rows likewise, then the serial 16x16 factor (one lane per row, right-hand side and identity as extra rows: y_J and L_JJ^-1)
+//   ---- barrier
+// then the back substitution in reverse step order (tile wavefronts: column sums of L_IJ^T x_I per chain; panel wavefronts: x_J = L_JJ^-T (y_J - sum)).
+// The permutation lives in the plan's row map only: S is gathered through it, x is scattered back through it.
+#ifndef LLD_BA_CHOL_SPARSE_H
+#define LLD_BA_CHOL_SPARSE_H
+
+constexpr int kSpTile = 16 * kCholMStride;                          // doubles of one padded LDS tile
+constexpr int kSpN = kSpMaxT * 16;
+constexpr int kSpLdsDoubles = 2 * kSpPos * kSpTile + kSpMaxT * kSpTile + 2 * kSpTileWaves * 16 + 3 * kSpN + 32;
+constexpr size_t kSpLdsBytes = kSpLdsDoubles * sizeof(double) + sizeof(CholPlan);
+
+// Panel wavefront: factor the 16x16 tile in Dg (lower triangle used) in place into L^-1 (all the column's L_IJ = A_IJ L_JJ^-T and the back
+// substitution need); rhs y[0..15] -> L^-1 y.  Same recurrence as chol_tile_factor.
+__device__ __forceinline__ bool chol_tile_factor_inplace(double* Dg, double* y, int lane) {
+  const int r = lane < 32 ? lane : 32;                               // 0..15 tile rows, 16 rhs, 17..32 identity rows
+  const double* src = (r < 16) ? Dg + r * kCholMStride : y;
+  double a[16];
+#pragma unroll
+  for (int c = 0; c < 16; c++) { const double v = src[c]; a[c] = (r <= 16) ? v : (r - 17 == c ? 1.0 : 0.0); }
+  bool ok = true;
+#pragma unroll
+  for (int c = 0; c < 16; c++) {
+    const double d = readlane_f64(a[c], c);
+    if (!(d > 0.0) || !isfinite(d)) ok = false;
+    double inv = __builtin_amdgcn_rsq(d);
+    inv = inv * (1.5 - (0.5 * d) * (inv * inv));
+    inv = inv * (1.5 - (0.5 * d) * (inv * inv));
+    const double lc = a[c] * inv;
+    a[c] = lc;
+#pragma unroll
+    for (int c2 = c + 1; c2 < 16; c2++) a[c2] -= lc * readlane_f64(lc, c2);
+  }
+  if (lane == 16) {
+#pragma unroll
+    for (int c = 0; c < 16; c++) y[c] = a[c];
+  } else if (lane > 16 && lane <= 32) {                              // lane 17+k holds column k of L^-1
+#pragma unroll
+    for (int c = 0; c < 16; c++) Dg[c * kCholMStride + (lane - 17)] = a[c];
+  }
+  return ok;
+}
+
+__global__ __launch_bounds__(kSpThreads) void ba_chol_sparse_kernel(BAArrays A, const BAWin* __restrict__ wins, BAState* __restrict__ st) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int wrow = LLD_ROW_WINDOW(A, st, blockIdx.x);
+  if (wrow < 0) return;
+  const BAWin W = wins[wrow];
+  BAState& S = st[wrow];
+  if (S.phase != PH_RUN) return;
+  const CholPlan* __restrict__ Pg = A.chol_plan + W.win_index;
+  if (Pg->mode != 1) return;                                         // this window is the dense kernel's
+  double* Lp0 = lds;                                                 // [2][kSpPos] panel buffers: the tiles of step s's columns in buffer s & 1 (raw, then L)
+  double* Dall = Lp0 + 2 * kSpPos * kSpTile;                         // [NT] diagonal tiles: raw until factored, then L_JJ^-1
+  double* colsum = Dall + kSpMaxT * kSpTile;                         // [2 chains][6 tile wavefronts][16] column sums of the back substitution
+  double* y = colsum + 2 * kSpTileWaves * 16;                        // [N] right-hand side -> forward solution (permuted order)
+  double* x = y + kSpN;                                              // [N] solution (permuted order)
+  double* xo = x + kSpN;                                             // [n] solution in S's order
+  double* scratch = xo + kSpN;                                       // [32]
+  double* okf = scratch + 31;
+  CholPlan* P = reinterpret_cast<CholPlan*>(scratch + 32);
+  const double* Sg = A.S + W.S_off;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lrow = lane >> 4, lcol = lane & 15;
+  const int n = 6 * W.n_free;
+  {
+    const int4* src = reinterpret_cast<const int4*>(Pg); int4* dst = reinterpret_cast<int4*>(P);
+    for (int i = tid; i < (int)(sizeof(CholPlan) / 16); i += kSpThreads) dst[i] = src[i];
+  }
+  if (tid == 0) *okf = 1.0;
+  __syncthreads();                                                   // B0: the plan is in LDS
+  const int NT = P->NT, T = P->T, N = NT << 4;
+
+  if (wave < 2) {
+    // ================================================================ panel wavefront of chain `wave`
+    const int ch = wave;
+    const int J0 = P->cols[0][ch];
+    if (J0 != kSpNone) {                                             // step 0's diagonal tile: fetched and factored here while the tile wavefronts load
+      double* Dg = Dall + J0 * kSpTile;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int idx = lane + 64 * q, row = idx >> 4, col = idx & 15;
+        const int R = P->rowmap[16 * J0 + row], C = P->rowmap[16 * J0 + col];
+        const bool inside = R >= 0 && C >= 0;
+        const int hi = R > C ? R : C, lo = R > C ? C : R;
+        const double v = Sg[inside ? hi * n + lo : 0];
+        Dg[row * kCholMStride + col] = inside ? v : (row == col ? 1.0 : 0.0);
+      }
+      if (lane < 16) { const int R = P->rowmap[16 * J0 + lane]; y[16 * J0 + lane] = R >= 0 ? A.bschur[W.x_off + R] : 0.0; }
+      if (!chol_tile_factor_inplace(Dg, y + 16 * J0, lane) && lane == 0) *okf = 0.0;
+    }
+    __syncthreads();                                                 // B1: tiles loaded, y staged
+    __syncthreads();                                                 // B2: prologue publish done
+    for (int s = 0; s < T; s++) {
+      const double* Lp = Lp0 + (s & 1) * kSpPos * kSpTile;
+      __syncthreads();                                               // (c) done: Lp holds L of step s's columns
+      const int Jn = P->cols[s + 1][ch];
+      if (Jn != kSpNone) {
+        // lookahead: diagonal tile Jn (published with the updates of the steps before s) takes step s's update(s) here, then is factored
+        double* Dg = Dall + Jn * kSpTile;
+        v4d c;
+#pragma unroll
+        for (int g = 0; g < 4; g++) c[g] = Dg[(lrow + 4 * g) * kCholMStride + lcol];
+        double dotv = 0.0;
+#pragma unroll
+        for (int c2 = 0; c2 < 2; c2++) {
+          const int J = P->cols[s][c2];
+          if (J == kSpNone) continue;
+          const int p = P->pos[J][Jn];
+          if (p == kSpNone) continue;
+          const double* Lt = Lp + p * kSpTile;
+          if (lane < 16) {                                           // y_Jn -= L_(Jn)J y_J
+            const double* pr = Lt + lane * kCholMStride;
+#pragma unroll
+            for (int cc = 0; cc < 16; cc++) dotv += pr[cc] * y[16 * J + cc];
+          }
+          const double* pa = Lt + lcol * kCholMStride + lrow;
+#pragma unroll
+          for (int kk = 0; kk < 4; kk++) c = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[4 * kk], pa[4 * kk], c, 0, 0, 0);
+        }
+        if (lane < 16) y[16 * Jn + lane] -= dotv;
+#pragma unroll
+        for (int g = 0; g < 4; g++) Dg[(lrow + 4 * g) * kCholMStride + lcol] = c[g];
+        if (!chol_tile_factor_inplace(Dg, y + 16 * Jn, lane) && lane == 0) *okf = 0.0;
+      }
+      __syncthreads();                                               // (d) + lookahead done
+    }
+    // back substitution L^T x = y in reverse step order: x_J = L_JJ^-T (y_J - s_J), s_J = the tile wavefronts' column sums of L_IJ^T x_I
+    for (int s = T - 1; s >= 0; s--) {
+      __syncthreads();                                               // column sums of step s complete
+      const int J = P->cols[s][ch];
+      if (J != kSpNone) {
+        const double* Di = Dall + J * kSpTile;                       // L_JJ^-1
+        const double* cs = colsum + ch * kSpTileWaves * 16;
+        const int c = lane & 15, part = lane >> 4;
+        double xc = 0.0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int r = 4 * part + q;
+          double sum = 0.0;
+#pragma unroll
+          for (int w = 0; w < kSpTileWaves; w++) sum += cs[w * 16 + r];
+          xc += Di[r * kCholMStride + c] * (y[16 * J + r] - sum);
+        }
+        xc += __shfl_xor(xc, 16); xc += __shfl_xor(xc, 32);
+        if (lane < 16) x[16 * J + c] = xc;
+      }
+      __syncthreads();                                               // x of step s ready
+    }
+  } else {
+    // ================================================================ tile wavefronts
+    const int w = wave - 2;
+    // lane l <-> slot l: tile row / column and the tile's position in its own column's panel buffer (0x80 | row for a diagonal tile)
+    int myI = kSpNone, myK = kSpNone, selfpos = kSpNone;
+    if (lane < kSpSlots) {
+      myI = P->slotI[w][lane]; myK = P->slotK[w][lane];
+      if (myI != kSpNone) selfpos = myI == myK ? (0x80 | myI) : P->pos[myK][myI];
+    }
+    // right-hand side in permuted order (the rows of step 0's columns are the panel wavefronts' own)
+    {
+      const int t = tid - 128;
+      if (t < N && (t >> 4) != P->cols[0][0] && (t >> 4) != P->cols[0][1]) { const int R = P->rowmap[t]; y[t] = R >= 0 ? A.bschur[W.x_off + R] : 0.0; }
+    }
+    // S -> registers through the row map; every load goes out before the first value is touched
+    v4d acc[kSpSlots];
+#pragma unroll
+    for (int sl = 0; sl < kSpSlots; sl++) {
+      v4d v = {0.0, 0.0, 0.0, 0.0};
+      const int I = __builtin_amdgcn_readlane(myI, sl);
+      if (I != kSpNone) {
+        const int K = __builtin_amdgcn_readlane(myK, sl);
+        const int C = P->rowmap[16 * K + lcol];
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          const int R = P->rowmap[16 * I + lrow + 4 * g];
+          const bool inside = R >= 0 && C >= 0;
+          const int hi = R > C ? R : C, lo = R > C ? C : R;
+          v[g] = Sg[inside ? hi * n + lo : 0];
+        }
+      }
+      acc[sl] = v;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      const unsigned pm = __builtin_amdgcn_readfirstlane(P->padmask[w]);
+#pragma unroll
+      for (int sl = 0; sl < kSpSlots; sl++) {
+        if (pm & (1u << sl)) {
+          const int I = __builtin_amdgcn_readlane(myI, sl), K = __builtin_amdgcn_readlane(myK, sl);
+          const int C = P->rowmap[16 * K + lcol];
+#pragma unroll
+          for (int g = 0; g < 4; g++) {
+            const int R = P->rowmap[16 * I + lrow + 4 * g];
+            const bool inside = R >= 0 && C >= 0;
+            acc[sl][g] = inside ? acc[sl][g] : ((16 * I + lrow + 4 * g == 16 * K + lcol) ? 1.0 : 0.0);
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();                                                 // B1
+    int off_cd0 = lrow * kCholMStride + lcol;
+    asm volatile("" : "+v"(off_cd0));
+    // publish the slots of `mask`: an off-diagonal tile into its column's panel buffer `Lto`, a diagonal tile into Dall
+#define LLD_SP_PUBLISH(mask_, Lto_, off_cd_)                                                                         \
+    do {                                                                                                             \
+      const unsigned pmask_ = (mask_);                                                                               \
+      _Pragma("unroll") for (int sl = 0; sl < kSpSlots; sl++) {                                                      \
+        if (pmask_ & (1u << sl)) {                                                                                   \
+          const int sp = __builtin_amdgcn_readlane(selfpos, sl);                                                     \
+          double* dst = ((sp & 0x80) ? Dall + (sp & 0x7f) * kSpTile : (Lto_) + sp * kSpTile) + (off_cd_);            \
+          _Pragma("unroll") for (int g = 0; g < 4; g++) dst[4 * g * kCholMStride] = acc[sl][g];                      \
+        }                                                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+      }                                                                                                              \
+    } while (0)
+    LLD_SP_PUBLISH(__builtin_amdgcn_readfirstlane(P->pub0[w]), Lp0, off_cd0);
+    __syncthreads();                                                 // B2: prologue publish done
+    for (int s = 0; s < T; s++) {
+      int off_cd = lrow * kCholMStride + lcol, off_ab = lcol * kCholMStride + lrow;
+      asm volatile("" : "+v"(off_cd), "+v"(off_ab));
+      double* Lp = Lp0 + (s & 1) * kSpPos * kSpTile;
+      double* Lnext = Lp0 + ((s + 1) & 1) * kSpPos * kSpTile;
+      const int JA = P->cols[s][0], JB = P->cols[s][1];
+      // (c) L_IJ = A_IJ L_JJ^-T on the matrix cores; keep it (back substitution) and leave it in the panel buffer (operand of d)
+      {
+        const unsigned mA = __builtin_amdgcn_readfirstlane(P->cA[w][s]), mB = __builtin_amdgcn_readfirstlane(P->cB[w][s]);
+#pragma unroll
+        for (int sl = 0; sl < kSpSlots; sl++) {
+          if ((mA | mB) & (1u << sl)) {
+            const int sp = __builtin_amdgcn_readlane(selfpos, sl);
+            const double* pa = Lp + sp * kSpTile + off_ab;
+            const double* pb = Dall + ((mA & (1u << sl)) ? JA : JB) * kSpTile + off_ab;
+            v4d c = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) c = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[4 * kk], pb[4 * kk], c, 0, 0, 0);
+            acc[sl] = c;
+            double* dst = Lp + sp * kSpTile + off_cd;
+#pragma unroll
+            for (int g = 0; g < 4; g++) dst[4 * g * kCholMStride] = c[g];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      __syncthreads();                                               // (c) done
+      // (d) trailing updates of this step's column(s), then the publishes
+      {
+        const unsigned mA = __builtin_amdgcn_readfirstlane(P->dA[w][s]), mB = __builtin_amdgcn_readfirstlane(P->dB[w][s]);
+        // lane l: the panel-buffer positions of L(I, JA), L(K, JA), L(I, JB), L(K, JB) for slot l's tile (I, K)
+        unsigned opnd = 0;
+        if (lane < kSpSlots && myI != kSpNone) {
+          if (JA != kSpNone) opnd |= (unsigned)P->pos[JA][myI] | ((unsigned)P->pos[JA][myK] << 8);
+          if (JB != kSpNone) opnd |= ((unsigned)P->pos[JB][myI] << 16) | ((unsigned)P->pos[JB][myK] << 24);
+        }
+#pragma unroll
+        for (int sl = 0; sl < kSpSlots; sl++) {
+          if ((mA | mB) & (1u << sl)) {
+            const unsigned o = __builtin_amdgcn_readlane(opnd, sl);
+            v4d c = acc[sl];
+            if (mA & (1u << sl)) {
+              const double* pa = Lp + (o & 0xff) * kSpTile + off_ab;
+              const double* pb = Lp + ((o >> 8) & 0xff) * kSpTile + off_ab;
+#pragma unroll
+              for (int kk = 0; kk < 4; kk++) c = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[4 * kk], pb[4 * kk], c, 0, 0, 0);
+            }
+            if (mB & (1u << sl)) {
+              const double* pa = Lp + ((o >> 16) & 0xff) * kSpTile + off_ab;
+              const double* pb = Lp + (o >> 24) * kSpTile + off_ab;
+#pragma unroll
+              for (int kk = 0; kk < 4; kk++) c = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[4 * kk], pb[4 * kk], c, 0, 0, 0);
+            }
+            acc[sl] = c;
+          }
+          if (sl & 1) __builtin_amdgcn_sched_barrier(0);
+        }
+        LLD_SP_PUBLISH(__builtin_amdgcn_readfirstlane(P->pub[w][s]), Lnext, off_cd);
+      }
+      // forward substitution of the right-hand side below the panel wavefronts' rows: y_I -= L_IJ y_J, tile rows I = w, w + 6, ...
+      {
+        const unsigned yA = __builtin_amdgcn_readfirstlane(P->yrows[s][0]), yB = __builtin_amdgcn_readfirstlane(P->yrows[s][1]);
+        for (int I = w; I < NT; I += kSpTileWaves) {
+          if (!(((yA | yB) >> I) & 1)) continue;
+          double dotv = 0.0;
+          if ((yA >> I) & 1) {
+            const double* pr = Lp + P->pos[JA][I] * kSpTile + lcol * kCholMStride + 4 * lrow;
+            const double* yj = y + 16 * JA + 4 * lrow;
+            dotv += pr[0] * yj[0] + pr[1] * yj[1] + pr[2] * yj[2] + pr[3] * yj[3];
+          }
+          if ((yB >> I) & 1) {
+            const double* pr = Lp + P->pos[JB][I] * kSpTile + lcol * kCholMStride + 4 * lrow;
+            const double* yj = y + 16 * JB + 4 * lrow;
+            dotv += pr[0] * yj[0] + pr[1] * yj[1] + pr[2] * yj[2] + pr[3] * yj[3];
+          }
+          dotv += __shfl_xor(dotv, 16); dotv += __shfl_xor(dotv, 32);
+          if (lane < 16) y[16 * I + lane] -= dotv;
+        }
+      }
+      __syncthreads();                                               // (d) + lookahead done
+    }
+    // back substitution: L lives in the register tiles, s_c = sum over the column's tiles of L[i][c] x_i
+    for (int s = T - 1; s >= 0; s--) {
+      const unsigned mA = __builtin_amdgcn_readfirstlane(P->cA[w][s]), mB = __builtin_amdgcn_readfirstlane(P->cB[w][s]);
+      double partA = 0.0, partB = 0.0;
+#pragma unroll
+      for (int sl = 0; sl < kSpSlots; sl++) {
+        if ((mA | mB) & (1u << sl)) {
+          const int I = __builtin_amdgcn_readlane(myI, sl);
+          double t = 0.0;
+#pragma unroll
+          for (int g = 0; g < 4; g++) t += acc[sl][g] * x[16 * I + lrow + 4 * g];
+          if (mA & (1u << sl)) partA += t; else partB += t;
+        }
+      }
+      if (mA) { partA += __shfl_xor(partA, 16); partA += __shfl_xor(partA, 32); }
+      if (mB) { partB += __shfl_xor(partB, 16); partB += __shfl_xor(partB, 32); }
+      if (lane < 16) { colsum[w * 16 + lane] = partA; colsum[kSpTileWaves * 16 + w * 16 + lane] = partB; }
+      __syncthreads();                                               // column sums of step s complete
+      __syncthreads();                                               // x of step s ready
+    }
+  }
+  // back to S's row order, then the common epilogue
+  if (tid < N) { const int R = P->rowmap[tid]; if (R >= 0) xo[R] = x[tid]; }
+  __syncthreads();
+  const bool ok = *okf != 0.0;
+  solve_epilogue(A, W, S, xo, scratch, ok, 0);
+}
+#undef LLD_SP_PUBLISH
+
+#endif

@@ -29,6 +29,7 @@
 
 #include "lld_common.h"
 #include "lld_device_math.h"
+#include "lld_ba_chol_plan.h"
 
 namespace lldba {
 
@@ -189,6 +190,7 @@ struct BAArrays {
   double *sp_part, *sp_cpart;  // per (chunk, slot pair) 6x6 partial products / per (chunk, slot) 6-vectors
   const int *blk_start, *blk_src, *cam_start, *cam_src;
   const int *sg_lm, *sg_tab, *sg_cams;
+  const CholPlan* chol_plan;   // [windows of the batch] schedule of the structure-following reduced solve (mode 0: the dense kernel's window); null: none
   // results
   unsigned char* records;
 #ifdef LLD_EXPERIMENTS
@@ -2288,6 +2290,7 @@ __global__ __launch_bounds__(kCholMThreads) void ba_chol_mfma_kernel(BAArrays A,
   const BAWin W = wins[wrow];
   BAState& S = st[wrow];
   if (S.phase != PH_RUN) return;
+  if (A.chol_plan && A.chol_plan[W.win_index].mode == 1) return;      // this window is ba_chol_sparse_kernel's (launched next to this one when a group holds both kinds)
   const int nf = W.n_free, n = 6 * nf, NT = (n + 15) >> 4, N = NT << 4;
   double* Lp0 = lds;                                       // [2][N][17] panel buffers: column J in buffer J & 1 (raw, then L)
   double* Dall = Lp0 + 2 * kCholMN * kCholMStride;         // [NT][16][17] diagonal tiles: raw until factored, then L_JJ
@@ -2562,6 +2565,8 @@ __global__ __launch_bounds__(kCholMThreads) void ba_chol_mfma_kernel(BAArrays A,
   LLD_CHOL_STAMP(6);
 }
 
+
+#include "lld_ba_chol_sparse.h"   // round 5: the same factorisation along the structure of S, two panel wavefronts where the plan has two chains
 
 #ifdef LLD_EXPERIMENTS
 #include "lld_ba_chol_exp.h"      // round 4's restructured factorisation (measured slower than the kernel above: experiments build only)
