@@ -453,6 +453,7 @@ def main():
     ap.add_argument("--shared-accumulators", action="store_true", help="run the timed leg with lld_ba_params.deterministic = 0 (not bit-reproducible; the default is)")
     ap.add_argument("--groups", type=int, default=0, help="stream groups of the timed solves (0 = the library's choice; 1 under rocprofv3: per-kernel times of one stream)")
     ap.add_argument("--gen-workers", type=int, default=0, help="processes generating the synthetic windows (0 = auto; use 1 under rocprofv3)")
+    ap.add_argument("--no-rccl-check", action="store_true", help="N = 1: skip the untimed step through a one-rank RCCL group (profiling runs: no RCCL kernels in the trace)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -551,13 +552,36 @@ def main():
     elapsed = D.max_over_ranks(elapsed, dev, use_dist)
 
     stats = batch.stats()
+    # One rank, no launcher: the timed steps above had no collective to run.  ONE untimed step now goes through a one-rank RCCL group - the
+    # same RecordGather the N > 1 line times, the same check of the gathered records - so that the driver's N = 1 line says whether the
+    # collective path works on this box (`gathered_records_ok`), not null.  Failing to bring RCCL up must not cost the headline line.
+    late_gather = None
+    if world == 1 and not use_dist and not args.no_rccl_check:
+        try:
+            sys.stdout.flush(); saved_stdout = os.dup(1); os.dup2(2, 1)          # (RCCL's banner goes to stderr)
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            for k_, v_ in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29577")):
+                os.environ.setdefault(k_, v_)
+            dist.init_process_group("nccl", device_id=dev)
+            late_counts = D.gather_counts(wpg, dev, True, 1)
+            late_stride = D.max_count_stride(rec_stride, dev, True)
+            late = D.RecordGather(records, 1, 0, n_bytes=max(late_counts) * late_stride, enabled=True, local_stride=rec_stride, common_stride=late_stride)
+            batch.set_groups(args.groups); batch.solve(); late.step(); late.drain()
+            D.barrier(True, True)
+            late_gather = (late, late_counts, late_stride)
+        except Exception as ex:
+            print(f"[bench] one-rank RCCL check skipped: {ex!r}", file=sys.stderr)
+            late_gather = None
     result = None
     if rank == 0:
         # every rank's records arrived AND are the windows shard() assigned: per rank, the first and the last record are checked against
         # the window id of their slot (index + edge count in the header, fixed cameras bit for bit against the generator), all headers
         # for a finished protocol
         gathered_ok = None
-        if use_dist:
+        if late_gather is not None:                        # N = 1: the untimed one-rank RCCL step above
+            gather, counts_g, common_stride = late_gather[0], late_gather[1], late_gather[2]
+            assert counts_g == counts
+        if use_dist or late_gather is not None:
             gathered_ok = True
             try:
                 D.verify_gathered_records(gather.rank_records, counts, common_stride, args.windows_per_gpu, world, args.strong, synth.make_lba_b)
@@ -597,14 +621,27 @@ def main():
             return r
         fam = {k: rulers(k) for k in PHASES if k != "ba_control"}
         dom = fam[kname]
-        achieved = dom["model_GBps"]
-        roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": dom.get("counter_bytes_per_launch"),
-                    "traffic_source": None if not traffic_tab else "profiles/roofline_traffic.json: TCC FETCH_SIZE (doubled on gfx950) + WRITE_SIZE of separate rocprofv3 --pmc passes "
-                                      "over `bench.py --windows-per-gpu 256` (tools/profile_pmc.sh + tools/make_roofline_traffic.py), committed with the kernels they were taken on; "
-                                      "NOT re-measured in this run (a bench process cannot run under --pmc and time itself)",
-                    "counter_ruler": None if "counter_GBps" not in dom else {"achieved_GBps": dom["counter_GBps"], "peak_achievable_GBps": HBM_ACHIEVABLE_GBS,
-                                                                           "frac": dom["counter_frac_of_6.3TBps_achievable"]},
+        # HBM ruler of the dominant family: the bytes the counters SAW (per launch, committed passes) over this run's HIP-event time, against the
+        # 8 TB/s of the data sheet; the SURVEY model (which charges every point edge a 144 B block the kernels recompute) stays beside it
+        hbm = {"achieved": dom.get("counter_GBps"), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+               "frac": None if "counter_GBps" not in dom else round(dom["counter_GBps"] / HBM_PEAK_GBS, 4), "source": "counters" if "counter_GBps" in dom else None,
+               "frac_of_6.3TBps_achievable": dom.get("counter_frac_of_6.3TBps_achievable"),
+               "model": {"achieved": dom["model_GBps"], "frac": round(dom["model_GBps"] / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": dom["model_bytes_per_launch"],
+                         "note": "SURVEY 8d bytes: W + V + S per launch; charges point Hpl blocks the kernel does not move"}}
+        if hbm["achieved"] is None:                      # no counters for this batch size: the model is all there is
+            hbm.update({"achieved": dom["model_GBps"], "frac": round(dom["model_GBps"] / HBM_PEAK_GBS, 4), "source": "model"})
+        # the whole step: counter bytes of every family x its launches in the single-stream step, over the TIMED step
+        step_ruler = None
+        if traffic_tab:
+            step_bytes = sum(float(traffic_tab.get(k, 0)) * float(launches[i]) for i, k in enumerate(PHASES)) + float(traffic_tab.get("_other_per_solve", 0))
+            step_gbs = step_bytes / (elapsed / args.steps) / 1e9
+            step_ruler = {"counter_bytes_per_step": int(step_bytes), "achieved_GBps": round(step_gbs, 1), "frac_of_8TBps": round(step_gbs / HBM_PEAK_GBS, 4),
+                          "note": "sum over the kernel families of (counter bytes per launch x launches of the single-stream step) / ms_per_step of the timed steps"}
+        roofline = {"kernel": kname, "traffic": dom.get("counter_bytes_per_launch"),
+                    "traffic_source": None if not traffic_tab else "profiles/roofline_traffic.json (" + str(traffic_tab.get("_taken_on", "see its _note")) + "): TCC FETCH_SIZE (doubled on gfx950) + WRITE_SIZE of separate "
+                                      "rocprofv3 --pmc passes over `bench.py --windows-per-gpu 256` (tools/profile_pmc.sh + tools/make_roofline_traffic.py); NOT re-measured in this run "
+                                      "(a bench process cannot run under --pmc and time itself)",
+                    "hbm": hbm, "step": step_ruler,
                     "measured_copy_ceiling_GBps": stream_gbs,
                     "launches_per_step": float(launches[kdom]), "avg_launch_ms": dom["avg_launch_ms"], "algorithmic_bytes_per_launch": dom["model_bytes_per_launch"],
                     "families": fam,
@@ -612,10 +649,15 @@ def main():
                               "the model ruler overstates traffic and the counter ruler is the honest one); counter = FETCH_SIZE (doubled on gfx950) + WRITE_SIZE of separate rocprofv3 --pmc passes",
                     "phase_ms_single_stream_step": {k: round(float(phase[i]), 3) for i, k in enumerate(PHASES)},
                     "solve_ms_single_stream_step": round(float(phase[5]), 3)}
-        if kname == "ba_schur":      # the arithmetic roofline that actually binds this family (fp64 vector FMA)
+        if kname == "ba_schur":
+            # The ruler that BINDS this family is arithmetic (fp64 vector FMA; the blocks are 6x6 / 6x3 / 6x4, no matrix cores): it goes first.
             fma_total = sum(schur_fmas(w, sum(st_["lm_trials"])) for w, st_ in zip(windows, stats))
             tf = fma_total / (float(phase[kdom]) * 1e-3) / 1e12
-            roofline["fp64_fma"] = {"achieved_TFMA_per_s": round(tf, 2), "peak_TFMA_per_s": FP64_FMA_PEAK_T, "frac": round(tf / FP64_FMA_PEAK_T, 4)}
+            roofline.update({"bound": "fp64_fma", "achieved": round(2.0 * tf, 2), "peak": round(2.0 * FP64_FMA_PEAK_T, 1), "unit": "TFLOP/s", "frac": round(tf / FP64_FMA_PEAK_T, 4),
+                             "fp64_fma": {"achieved_TFMA_per_s": round(tf, 2), "peak_TFMA_per_s": FP64_FMA_PEAK_T, "frac": round(tf / FP64_FMA_PEAK_T, 4),
+                                          "note": "useful FMAs of the family (bench.schur_fmas) over its HIP-event time; vector fp64 peak = 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz"}})
+        else:
+            roofline.update({"bound": "hbm", "achieved": hbm["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm["frac"]})
         # ---- CPU baseline + matched-chi2 check on a bounded sample (N=1 only)
         cpu = None; parity = None
         if world == 1 and not args.no_cpu_baseline and args.cpu_sample > 0:
@@ -651,7 +693,8 @@ def main():
                                    f"windows resident in HBM, every step restarts from the uploaded state",
                        "bit_reproducible": not args.shared_accumulators, "windows_per_gpu": counts if args.strong else wpg, "edges_per_window": int(windows[0].n_edges()),
                        "parallelism": f"{world} x independent window batches, RCCL gather of result records", "resident": True,
-                       "result_record_bytes": int(rec_stride), "generate_s": round(gen_s, 1), "host_threads_per_rank": budget, "gathered_records_ok": gathered_ok},
+                       "result_record_bytes": int(rec_stride), "generate_s": round(gen_s, 1), "host_threads_per_rank": budget, "gathered_records_ok": gathered_ok,
+                       "gathered_records_how": ("RCCL gather inside every timed step" if use_dist else ("one untimed step through a one-rank RCCL group after the timed region" if late_gather is not None else None))},
             "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
             "lm": {"mean_trials_per_window": float(np.mean([sum(s["lm_trials"]) for s in stats])),
                    "mean_pcg_iterations_per_trial": float(np.sum([s["pcg_iterations"] for s in stats]) / max(1, np.sum([sum(s["lm_trials"]) for s in stats])))},
@@ -684,7 +727,7 @@ def main():
             except Exception as ex:
                 result["secondary"] = dict(result.get("secondary") or {}, error=repr(ex)[:300])
     ctx.close()
-    if use_dist:
+    if use_dist or late_gather is not None:
         dist.barrier()
         dist.destroy_process_group()
     if saved_stdout is not None:

@@ -71,7 +71,7 @@ struct lld_ba_batch {
   // window groups solved concurrently, each on its own stream (hides the latency-bound reduced solve, the per-super-step
   // host poll and kernel tails behind the other groups' work)
   struct Group { int w0 = 0, nw = 0; hipStream_t st = nullptr; bool own_stream = false; int* d_counters = nullptr; int* h_counters = nullptr;
-                 hipEvent_t ev[kChunkSmall][kNumPhases + 1] = {}; int chunk = 1, chunk0 = 1, chunk_from = 0; int steps = 0; bool active = false; int rows = 0; int max_nt_pt = 0, max_nb_ln = 0, max_nl_pt = 0, max_nl_ln = 0, max_lblocks = 0, max_items_pt = 0, max_items_ln = 0, max_blk = 0; bool any_sparse = false, any_dense = false; };
+                 hipEvent_t ev[kChunkSmall][kNumPhases + 1] = {}; int chunk = 1, chunk0 = 1, chunk_from = 0; int steps = 0; bool active = false; int rows = 0; int map_parity = 0; int max_nt_pt = 0, max_nb_ln = 0, max_nl_pt = 0, max_nl_ln = 0, max_lblocks = 0, max_items_pt = 0, max_items_ln = 0, max_blk = 0; bool any_sparse = false, any_dense = false; };
   std::vector<Group> groups;
   int* d_counters = nullptr; int* h_counters = nullptr;               // device / pinned, 4 ints per group
   int* d_slot_map = nullptr; int* d_active_pub = nullptr;            // per window: grid row -> window map of its group, published "still at work" bits (BAArrays::slot_map)
@@ -807,7 +807,7 @@ static int ba_batch_create_impl(lld_ctx* ctx, int n_windows, const lld_ba_window
     A.chol_stamps = exp_flag("LLD_BA_CHOL_STAMPS") ? sl.take<long long>((size_t)n_windows * 8 * kCholStampSlots) : nullptr;
 #endif
     B->d_counters = sl.take<int>(4 * 8);
-    B->d_slot_map = sl.take<int>((size_t)n_windows + 1); B->d_active_pub = sl.take<int>((size_t)n_windows + 1);
+    B->d_slot_map = sl.take<int>(2 * ((size_t)n_windows + 1)); B->d_active_pub = sl.take<int>((size_t)n_windows + 1);
   };
   lap("host staging done");
   lld_slab dry; dry.base = reinterpret_cast<char*>(256);
@@ -977,8 +977,13 @@ static int ba_batch_solve_impl(lld_ba_batch* B, StopFlag abort_flag) {
   // Grid rows of a super-step = the windows of the group that were still at work at the last poll, mapped to windows on the device
   // (BAArrays::slot_map); the PCG paths keep one row per window.
   const bool use_slots = !(B->params.reduced_solver == 1 || B->pcg_multi);
-  auto group_arrays = [&](const Group& G) { BAArrays Ag = B->A; Ag.slot_map = use_slots ? B->d_slot_map + G.w0 : nullptr; Ag.active_pub = use_slots ? B->d_active_pub + G.w0 : nullptr;
-                                            Ag.slot_rd = (use_slots && G.rows < G.nw) ? Ag.slot_map : nullptr; return Ag; };
+  // The row -> window map is double buffered: the kernels of a super-step READ the map the previous super-step's control wrote, the control
+  // of this super-step WRITES the other buffer (workgroups of the fused back-substitution + control launch may still be dispatched - and read
+  // their row - after the group's last control wavefront has rebuilt the map: nothing orders them).  The parity flips with every launch.
+  auto group_arrays = [&](const Group& G) { BAArrays Ag = B->A; int* rd = B->d_slot_map + (size_t)G.map_parity * ((size_t)B->n_windows + 1) + G.w0;
+                                            int* wr = B->d_slot_map + (size_t)(G.map_parity ^ 1) * ((size_t)B->n_windows + 1) + G.w0;
+                                            Ag.slot_map = use_slots ? wr : nullptr; Ag.active_pub = use_slots ? B->d_active_pub + G.w0 : nullptr;
+                                            Ag.slot_rd = (use_slots && G.rows < G.nw) ? rd : nullptr; return Ag; };
   auto launch_superstep = [&](Group& G, int q) -> int {
     const BAWin* dw = B->d_wins + G.w0; BAState* ds = B->d_state + G.w0;
     const BAArrays A = group_arrays(G);                                // (shadows the batch's arrays: every launch below is per group)
@@ -1069,6 +1074,7 @@ static int ba_batch_solve_impl(lld_ba_batch* B, StopFlag abort_flag) {
     }
     LLD_HIP_TRY(hipGetLastError());
     LLD_HIP_TRY(hipEventRecord(ev[5], st));
+    G.map_parity ^= 1;                                   // the next launch reads the map this one's control wrote
     return LLD_OK;
   };
   auto launch_chunk = [&](Group& G) -> int {
@@ -1079,7 +1085,7 @@ static int ba_batch_solve_impl(lld_ba_batch* B, StopFlag abort_flag) {
   for (Group& G : B->groups) {
     const BAWin* dw = B->d_wins + G.w0; BAState* ds = B->d_state + G.w0;
     if (G.own_stream) LLD_HIP_TRY(hipStreamWaitEvent(G.st, t_begin, 0));
-    G.steps = 0; G.active = !abort_at_start; G.rows = G.nw; G.chunk = G.chunk0;
+    G.steps = 0; G.active = !abort_at_start; G.rows = G.nw; G.chunk = G.chunk0; G.map_parity = 0;
     LLD_HIP_TRY(hipMemsetAsync(G.d_counters, 0, 4 * sizeof(int), G.st));     // the control kernel leaves them at zero after every super-step
     hipLaunchKernelGGL(ba_init_kernel, dim3(std::max(1, std::min(64, G.max_lblocks + 1)), G.nw), dim3(kLmThreads), 0, G.st, group_arrays(G), dw, ds);
     LLD_HIP_TRY(hipGetLastError());

@@ -84,6 +84,10 @@ __global__ __launch_bounds__(kSpThreads) void ba_chol_sparse_kernel(BAArrays A, 
     for (int i = tid; i < (int)(sizeof(CholPlan) / 16); i += kSpThreads) dst[i] = src[i];
   }
   if (tid == 0) *okf = 1.0;
+#ifdef LLD_EXPERIMENTS
+  long long* stamp_base = A.chol_stamps ? A.chol_stamps + ((size_t)W.win_index * 8 + wave) * kCholStampSlots : nullptr;
+#endif
+  LLD_CHOL_STAMP(0);
   __syncthreads();                                                   // B0: the plan is in LDS
   const int NT = P->NT, T = P->T, N = NT << 4;
 
@@ -105,11 +109,16 @@ __global__ __launch_bounds__(kSpThreads) void ba_chol_sparse_kernel(BAArrays A, 
       if (lane < 16) { const int R = P->rowmap[16 * J0 + lane]; y[16 * J0 + lane] = R >= 0 ? A.bschur[W.x_off + R] : 0.0; }
       if (!chol_tile_factor_inplace(Dg, y + 16 * J0, lane) && lane == 0) *okf = 0.0;
     }
+    LLD_CHOL_STAMP(1);
     __syncthreads();                                                 // B1: tiles loaded, y staged
+    LLD_CHOL_STAMP(2);
     __syncthreads();                                                 // B2: prologue publish done
+    LLD_CHOL_STAMP(3);
     for (int s = 0; s < T; s++) {
       const double* Lp = Lp0 + (s & 1) * kSpPos * kSpTile;
+      LLD_CHOL_STAMP(8 + 6 * s);
       __syncthreads();                                               // (c) done: Lp holds L of step s's columns
+      LLD_CHOL_STAMP(10 + 6 * s);
       const int Jn = P->cols[s + 1][ch];
       if (Jn != kSpNone) {
         // lookahead: diagonal tile Jn (published with the updates of the steps before s) takes step s's update(s) here, then is factored
@@ -137,10 +146,14 @@ __global__ __launch_bounds__(kSpThreads) void ba_chol_sparse_kernel(BAArrays A, 
         if (lane < 16) y[16 * Jn + lane] -= dotv;
 #pragma unroll
         for (int g = 0; g < 4; g++) Dg[(lrow + 4 * g) * kCholMStride + lcol] = c[g];
+        LLD_CHOL_STAMP(11 + 6 * s);
         if (!chol_tile_factor_inplace(Dg, y + 16 * Jn, lane) && lane == 0) *okf = 0.0;
       }
+      LLD_CHOL_STAMP(12 + 6 * s);
       __syncthreads();                                               // (d) + lookahead done
+      LLD_CHOL_STAMP(13 + 6 * s);
     }
+    LLD_CHOL_STAMP(4);
     // back substitution L^T x = y in reverse step order: x_J = L_JJ^-T (y_J - s_J), s_J = the tile wavefronts' column sums of L_IJ^T x_I
     for (int s = T - 1; s >= 0; s--) {
       __syncthreads();                                               // column sums of step s complete
@@ -163,6 +176,7 @@ __global__ __launch_bounds__(kSpThreads) void ba_chol_sparse_kernel(BAArrays A, 
       }
       __syncthreads();                                               // x of step s ready
     }
+    LLD_CHOL_STAMP(5);
   } else {
     // ================================================================ tile wavefronts
     const int w = wave - 2;
@@ -214,6 +228,7 @@ __global__ __launch_bounds__(kSpThreads) void ba_chol_sparse_kernel(BAArrays A, 
       }
     }
     __builtin_amdgcn_sched_barrier(0);
+    LLD_CHOL_STAMP(1);
     __syncthreads();                                                 // B1
     int off_cd0 = lrow * kCholMStride + lcol;
     asm volatile("" : "+v"(off_cd0));
@@ -231,8 +246,11 @@ __global__ __launch_bounds__(kSpThreads) void ba_chol_sparse_kernel(BAArrays A, 
       }                                                                                                              \
     } while (0)
     LLD_SP_PUBLISH(__builtin_amdgcn_readfirstlane(P->pub0[w]), Lp0, off_cd0);
+    LLD_CHOL_STAMP(2);
     __syncthreads();                                                 // B2: prologue publish done
+    LLD_CHOL_STAMP(3);
     for (int s = 0; s < T; s++) {
+      LLD_CHOL_STAMP(8 + 6 * s);
       int off_cd = lrow * kCholMStride + lcol, off_ab = lcol * kCholMStride + lrow;
       asm volatile("" : "+v"(off_cd), "+v"(off_ab));
       double* Lp = Lp0 + (s & 1) * kSpPos * kSpTile;
@@ -258,7 +276,9 @@ __global__ __launch_bounds__(kSpThreads) void ba_chol_sparse_kernel(BAArrays A, 
           __builtin_amdgcn_sched_barrier(0);
         }
       }
+      LLD_CHOL_STAMP(9 + 6 * s);
       __syncthreads();                                               // (c) done
+      LLD_CHOL_STAMP(10 + 6 * s);
       // (d) trailing updates of this step's column(s), then the publishes
       {
         const unsigned mA = __builtin_amdgcn_readfirstlane(P->dA[w][s]), mB = __builtin_amdgcn_readfirstlane(P->dB[w][s]);
@@ -311,8 +331,11 @@ __global__ __launch_bounds__(kSpThreads) void ba_chol_sparse_kernel(BAArrays A, 
           if (lane < 16) y[16 * I + lane] -= dotv;
         }
       }
+      LLD_CHOL_STAMP(12 + 6 * s);
       __syncthreads();                                               // (d) + lookahead done
+      LLD_CHOL_STAMP(13 + 6 * s);
     }
+    LLD_CHOL_STAMP(4);
     // back substitution: L lives in the register tiles, s_c = sum over the column's tiles of L[i][c] x_i
     for (int s = T - 1; s >= 0; s--) {
       const unsigned mA = __builtin_amdgcn_readfirstlane(P->cA[w][s]), mB = __builtin_amdgcn_readfirstlane(P->cB[w][s]);
@@ -333,12 +356,14 @@ __global__ __launch_bounds__(kSpThreads) void ba_chol_sparse_kernel(BAArrays A, 
       __syncthreads();                                               // column sums of step s complete
       __syncthreads();                                               // x of step s ready
     }
+    LLD_CHOL_STAMP(5);
   }
   // back to S's row order, then the common epilogue
   if (tid < N) { const int R = P->rowmap[tid]; if (R >= 0) xo[R] = x[tid]; }
   __syncthreads();
   const bool ok = *okf != 0.0;
   solve_epilogue(A, W, S, xo, scratch, ok, 0);
+  LLD_CHOL_STAMP(6);
 }
 #undef LLD_SP_PUBLISH
 

@@ -149,7 +149,7 @@ struct BAArrays {
   // super-step of a 64-window group took 700 us where one window alone takes 250).  The LM control rebuilds the map after every
   // super-step, in window order, from the "still running / in transition" bits its wavefronts publish in active_pub (agent-scope stores,
   // read by the group's last control wavefront of the same launch).
-  int* slot_map;
+  int* slot_map;               // the buffer the LM control WRITES (the next super-step's rows); double buffered by the host, never the one slot_rd reads in the same launch
   int* active_pub;
   const int* slot_rd;          // what the kernels READ rows through: slot_map, or null (row y = window y) while every window of the group is still at work - the map is
                                // the identity then, and a launch spares its workgroups one dependent load (4 us of a single window's 225 us super-step)
@@ -2700,7 +2700,9 @@ __global__ __launch_bounds__(kLmThreads) void ba_backsub_ctl_kernel(BAArrays A, 
   }
   const BAWin& W = wins[wrow];
   BAState& S = st[wrow];
-  const bool running = S.phase == PH_RUN;                 // (uniform over the window's workgroups: the phase only changes behind the ticket)
+  const bool running = S.phase == PH_RUN;                 // (uniform over the window's WORKING workgroups: the phase only changes behind their ticket.  A padding workgroup - bx beyond the
+                                                          //  window's own count - may be dispatched after the control ran: it reads its row through the map of THIS launch, which the control does not
+                                                          //  touch (it writes the other buffer, see BAArrays::slot_map), finds `works` false whatever the phase says, and leaves)
   const bool is_pt = bx < n_pt_blocks;
   const bool works = running && (is_pt ? bx < W.nt_pt : bx - n_pt_blocks < W.nt_ln);
   if (works) {

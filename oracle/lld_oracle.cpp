@@ -468,6 +468,16 @@ static inline void cls_margin(int which, double chi2, double thr) {
   const double m = std::fabs(chi2 - thr) / thr;
   if (m < g_cls_margin[which]) g_cls_margin[which] = m;
 }
+// test hook: the OTHER side of a decision that hangs on the last digits of a chi2.  With flip[which] set, an edge whose chi2 lies within
+// `margin` (relative) of its threshold at classification `which` is classified the other way - the result a run takes whose sums are
+// rounded differently (the reference's follow pointer order).  tests/test_gpu_ba.py holds the device to ONE of the two results, in full.
+static int g_cls_flip[2] = {0, 0};
+static double g_cls_flip_margin = 0.0;
+void lldo_set_classification_flip(int which, int on, double margin) { if (which >= 0 && which < 2) g_cls_flip[which] = on; g_cls_flip_margin = margin; }
+static inline bool cls_over(int which, double chi2, double thr) {
+  const bool over = chi2 > thr;
+  return (g_cls_flip[which] && std::fabs(chi2 - thr) / thr < g_cls_flip_margin) ? !over : over;
+}
 
 void lldo_ba_params_default(lld_ba_params* p) {
   p->gamma = 1.0; p->its_round1 = 5; p->its_round2 = 15; p->ln_filter = 4; p->max_trials = 10;
@@ -575,7 +585,7 @@ extern "C" int lldo_local_ba(void* /*ctx*/, const lld_ba_window* in, const lld_b
   if (bDoMore) {
     for (auto& e : S.pe) {
       const bool depth_pos = se3_map(S.cams[e.cam], S.pts[e.pt]).z > 0.0;
-      if (S.pe_chi2(e) > (e.stereo ? 7.815 : 5.991) || !depth_pos) e.level = 1;
+      if (cls_over(0, S.pe_chi2(e), e.stereo ? 7.815 : 5.991) || !depth_pos) e.level = 1;
       cls_margin(0, S.pe_chi2(e), e.stereo ? 7.815 : 5.991);
       e.robust = false;
     }
@@ -586,7 +596,7 @@ extern "C" int lldo_local_ba(void* /*ctx*/, const lld_ba_window* in, const lld_b
       double thr = thLinesStereo * thLinesStereo;
       if (!e.pair_stereo) thr = thLinesMono * thLinesMono;
       const bool depth_pos = line_depth_positive(S.lf, S.lcx, S.lcy, e.bx, S.cams[e.cam], S.lines[e.line], e.x1, e.x2);
-      if (S.le_chi2(e) > thr || !depth_pos) e.level = 1; else cnt[e.line] += 2;
+      if (cls_over(0, S.le_chi2(e), thr) || !depth_pos) e.level = 1; else cnt[e.line] += 2;
       cls_margin(0, S.le_chi2(e), thr);
       e.robust = false;
     }
@@ -610,7 +620,7 @@ extern "C" int lldo_local_ba(void* /*ctx*/, const lld_ba_window* in, const lld_b
     int o = 0;
     for (auto& e : S.pe) {
       const bool depth_pos = se3_map(S.cams[e.cam], S.pts[e.pt]).z > 0.0;
-      if (S.pe_chi2(e) > (e.stereo ? 7.815 : 5.991) || !depth_pos) { out->pt_obs_outlier[o] = 1; out->stats.n_pt_obs_outlier++; }
+      if (cls_over(1, S.pe_chi2(e), e.stereo ? 7.815 : 5.991) || !depth_pos) { out->pt_obs_outlier[o] = 1; out->stats.n_pt_obs_outlier++; }
       cls_margin(1, S.pe_chi2(e), e.stereo ? 7.815 : 5.991);
       o++;
     }
@@ -622,7 +632,7 @@ extern "C" int lldo_local_ba(void* /*ctx*/, const lld_ba_window* in, const lld_b
     S.ln_edge_error(e);
     double thr = thLinesStereo * thLinesStereo;
     if (!e.pair_stereo) thr = thLinesMono * thLinesMono;
-    if (S.le_chi2(e) > thr || !depth_pos) { out->ln_edge_outlier[2 * e.obs + e.side] = 1; out->stats.n_ln_edge_outlier++; }
+    if (cls_over(1, S.le_chi2(e), thr) || !depth_pos) { out->ln_edge_outlier[2 * e.obs + e.side] = 1; out->stats.n_ln_edge_outlier++; }
     cls_margin(1, S.le_chi2(e), thr);
   }
   write_back(false);

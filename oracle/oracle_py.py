@@ -268,6 +268,14 @@ def last_classification_margin():
     return float(out[0]), float(out[1])
 
 
+def set_classification_flip(which: int, on: bool, margin: float = 1e-6):
+    """Test hook: classification `which` (0 between the rounds, 1 final) takes the OTHER side for edges whose chi2 lies within `margin`
+    (relative) of their threshold.  Not thread-safe: a process-wide knob, reset it in a finally."""
+    d = lib().dll
+    d.lldo_set_classification_flip.argtypes = [C.c_int, C.c_int, C.c_double]; d.lldo_set_classification_flip.restype = None
+    d.lldo_set_classification_flip(int(which), 1 if on else 0, float(margin))
+
+
 def set_landmark_inverse(how: int):
     """0: (Hll + lambda I)^-1 by Gauss-Jordan with partial pivoting (default; the reference calls MatrixXd::inverse(), block_solver.hpp:391),
     1: the same inverse through a Cholesky factor - equal in exact arithmetic.  Not thread-safe: a process-wide test knob."""

@@ -13,6 +13,28 @@ from lld_slam_amd import BABatch, Optimizer, synth
 
 pytestmark = pytest.mark.gpu
 RTOL = 1e-5
+# Landmarks of ONE check_ba call that may sit beyond 1e-5 with the measured excuse of `twins` (each within 10x the oracle's own twin
+# spread).  Round 4 allowed max(4, 5 %) of the population; round 5 logs the count of every call (profiles/r05_parity_margins.txt, written
+# through gpurun_out/ by the fixture below) and holds it to the largest count observed + 1.
+MAX_EXCUSED_LANDMARKS = 6
+_MARGIN_LOG = []
+
+
+def _log_margin(kind, n_beyond, n, worst):
+    import os
+    _MARGIN_LOG.append(f"{os.environ.get('PYTEST_CURRENT_TEST', '?').split(' ')[0]:110s} {kind:8s} beyond_1e-5 {n_beyond:4d} of {n:6d}   worst {worst:.3e}")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _write_margin_log():
+    yield
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = os.path.join(root, "gpurun_out")
+    if _MARGIN_LOG and os.path.isdir(d):
+        with open(os.path.join(d, "parity_margins_test_gpu_ba.txt"), "w") as f:
+            f.write("# per check_ba call of tests/test_gpu_ba.py: landmarks beyond 1e-5 relative of the oracle (each within 10x the oracle's twin spread, or the test fails)\n")
+            f.write("\n".join(_MARGIN_LOG) + "\n")
 
 
 def landmark_rel(a, b):
@@ -53,6 +75,7 @@ def check_ba(g, o, w, rtol=RTOL, pt_floor=None, tail=None, twins=None):
     rel = landmark_rel
     twin_cache = []
     def bulk(r, field="pt_xyz"):
+        _log_margin(field, int((r > rtol).sum()), int(r.size), float(r.max()))
         if not noisy:
             if r.max() > rtol and twins is not None:
                 if not twin_cache: twin_cache.extend(twins())
@@ -62,7 +85,7 @@ def check_ba(g, o, w, rtol=RTOL, pt_floor=None, tail=None, twins=None):
                 # the landmarks on which the ORACLE'S twins disagree by more than 1e-6; which of those end beyond 1e-5 on the device moves
                 # with the summation order of its accumulators (test_window_of_two_unconnected_camera_groups, 180 weak lines: 2 with one
                 # task per wavefront, 4 - 5 at 1.1e-5 .. 3.1e-5 with round 4's four tasks; the twins themselves are 2.1e-5 apart there)
-                assert (r > rtol).sum() <= max(4, int(0.05 * r.size)), int((r > rtol).sum())
+                assert (r > rtol).sum() <= MAX_EXCUSED_LANDMARKS, int((r > rtol).sum())
                 return
             assert r.max() <= rtol, (float(r.max()), int(np.argmax(r)))
             return
@@ -77,10 +100,11 @@ def check_ba(g, o, w, rtol=RTOL, pt_floor=None, tail=None, twins=None):
     if w.n_lines:
         bulk(rel(g.line_x0, o.line_x0), "line_x0")
         dn = np.linalg.norm(g.line_dir - o.line_dir, axis=1)
+        _log_margin("line_dir", int((dn > rtol).sum()), int(dn.size), float(dn.max()))
         if dn.max() > rtol and not noisy and twins is not None:
             if not twin_cache: twin_cache.extend(twins())
             floor = np.max([np.linalg.norm(t.line_dir - o.line_dir, axis=1) for t in twin_cache], axis=0)
-            assert np.all(dn <= np.maximum(rtol, 10 * floor)) and (dn > rtol).sum() <= max(4, int(0.05 * dn.size)), (float(dn.max()), int(np.argmax(dn)), float(floor[int(np.argmax(dn))]))
+            assert np.all(dn <= np.maximum(rtol, 10 * floor)) and (dn > rtol).sum() <= MAX_EXCUSED_LANDMARKS, (float(dn.max()), int(np.argmax(dn)), float(floor[int(np.argmax(dn))]))
         else:
             assert dn.max() <= (10 * rtol if noisy else rtol)
     # same LM trajectory up to decisions taken on rounding-level chi2 differences at convergence
@@ -305,7 +329,8 @@ def test_size_independent_properties_at_full_size(gpu_ctx):
     w = synth.make_lba_b(1)
     opt = Optimizer(gpu_ctx)
     a = opt.LocalBundleAdjustment(w); b = opt.LocalBundleAdjustment(w)
-    np.testing.assert_allclose(a.cam_qt, b.cam_qt, rtol=1e-5, atol=1e-6)         # run-to-run: LDS atomics reorder the sums
+    np.testing.assert_array_equal(a.cam_qt, b.cam_qt)                             # the default mode is bit-reproducible (lld_ba_params::deterministic = 2)
+    np.testing.assert_array_equal(a.pt_xyz, b.pt_xyz); np.testing.assert_array_equal(a.line_x0, b.line_x0)
     assert a.stats["chi2_final"] < a.stats["chi2_round1"]
     assert 0.03 * w.n_pt_obs < a.stats["n_pt_obs_outlier"] < 0.25 * w.n_pt_obs
     keep = ~a.line_removed.astype(bool)
@@ -692,31 +717,47 @@ def test_non_finite_input_terminates_and_leaves_the_context_clean(gpu_ctx, oracl
 # ---------------------------------------------------------------------------------------------------------------- the BATCH config
 def test_batch_config_256_lba_b_windows(gpu_ctx, oracle):
     """BASELINE.json config 5 on one GPU: ONE batch of 256 LBA-B windows (ids 0..255, four stream groups of 64), solved in the
-    bit-reproducible mode (lld_ba_params.deterministic).  Oracle parity - exact erase lists, no allowance - on twelve windows of all four
-    groups whose classification decisions do not hang on the last digits of a chi2 (the margin is asserted), size-independent properties
+    bit-reproducible mode (lld_ba_params.deterministic).  Oracle parity - exact erase lists - on twelve fixed windows of all four groups
+    (a window whose decisions hang on the last digits of a chi2 must equal one of the two sides of that decision in full), size-independent properties
     on all 256, and a second solve that restarts from the uploaded state and must reproduce every output BIT FOR BIT."""
     ws = synth.generate_windows(0, 256)
     assert all(w.n_edges() == 80000 and w.n_free_cams == 50 for w in ws)
-    # three windows of every stream group, first and last of each among them.  A window whose oracle run comes within 1e-6 (relative) of
-    # a classification threshold is replaced by its neighbour: there "identical outlier sets" is a statement about the last bits of a sum,
-    # in the reference as much as here (its sums follow pointer order).
+    # Three windows of every stream group, first and last of each among them - the ids as listed, none replaced.  A window whose oracle run
+    # comes within 1e-6 (relative) of a classification threshold is checked too: there "identical outlier sets" is a statement about the last
+    # bits of one sum (in the reference as much as here: its sums follow pointer order), so the device must equal, IN FULL, either the
+    # oracle's result or the oracle's result with that one decision taken the other way (oracle_py.set_classification_flip).  How many of
+    # the twelve are such windows is logged and bounded.
     MARGIN = 1e-6
     wanted = [0, 37, 63, 64, 101, 127, 128, 170, 191, 192, 230, 255]
-    checked = {}
+    checked, near = {}, []
     for i in wanted:
-        step = 1 if i % 64 < 32 else -1
-        for j in range(i, i + 8 * step, step):
-            o = oracle.local_ba(ws[j])
-            if min(oracle.last_classification_margin()) > MARGIN:
-                checked[j] = o; break
-        else:
-            raise AssertionError(f"no window with a classification margin above {MARGIN} near id {i}")
-    assert len(checked) == 12 and {min(c // 64 for c in checked), max(c // 64 for c in checked)} == {0, 3}
+        o = oracle.local_ba(ws[i])
+        m = oracle.last_classification_margin()
+        variants = [o]
+        for which in (0, 1):
+            if m[which] <= MARGIN:
+                try:
+                    oracle.set_classification_flip(which, True, MARGIN)
+                    variants.append(oracle.local_ba(ws[i]))
+                finally:
+                    oracle.set_classification_flip(which, False, MARGIN)
+        if len(variants) > 1:
+            near.append((i, m))
+        checked[i] = variants
+    _MARGIN_LOG.append(f"test_batch_config_256_lba_b_windows: {len(near)} of {len(wanted)} oracle-checked windows within {MARGIN} of a classification threshold: {near}")
+    assert len(near) <= 3, near
     with BABatch(gpu_ctx, ws, deterministic=1) as b:
         b.solve()
         first = b.download_all()
-        for i, o in checked.items():
-            check_ba(first[i], o, ws[i], twins=oracle_twins(oracle, ws[i]))
+        for i, variants in checked.items():
+            errors = []
+            for o in variants:
+                try:
+                    check_ba(first[i], o, ws[i], twins=oracle_twins(oracle, ws[i])); break
+                except AssertionError as ex:
+                    errors.append(ex)
+            else:
+                raise errors[0]
         for i, (w, a) in enumerate(zip(ws, first)):
             s = a.stats
             assert s["aborted"] == 0 and 1 <= s["lm_iterations"][0] <= 5 and 1 <= s["lm_iterations"][1] <= 15, i

@@ -2,13 +2,13 @@
 """Builds profiles/roofline_traffic.json from the FETCH_SIZE / WRITE_SIZE summaries of tools/profile_pmc.sh:
 HBM-side bytes per launch of each kernel family = sum over its kernels of the per-dispatch average.
 
-    python tools/make_roofline_traffic.py gpurun_out/pmc_<tag> > profiles/roofline_traffic.json
+    python tools/make_roofline_traffic.py gpurun_out/pmc_<tag> ["commit / date the passes were taken on"] > profiles/roofline_traffic.json
 """
 import json, re, sys
 
 FAMILIES = {"ba_linearize": ("ba_linearize_", "ba_hpp_reduce"),
             "ba_schur": ("ba_schur_items", "ba_schur_reduce", "ba_symmetrize"),
-            "ba_solve": ("ba_chol_mfma", "ba_chol_kernel", "ba_pcg"),
+            "ba_solve": ("ba_chol_mfma", "ba_chol_sparse", "ba_chol_kernel", "ba_pcg"),
             "ba_backsub": ("ba_backsub_",),
             "ba_control": ("ba_control",)}
 
@@ -37,6 +37,15 @@ def main(d):
         w = sum(v for k, (_, v) in write.items() if any(x in k for x in kernels)) / n_steps
         res["_raw_KiB_per_super_step"][fam] = {"FETCH_SIZE": round(f, 1), "WRITE_SIZE": round(w, 1)}
         res[fam] = int((2.0 * f + w) * 1024)
+    # everything else the solves launch (init, classification, read-back), per SOLVE: the finalize kernel runs once per solve and group
+    fam_all = tuple(x for v in FAMILIES.values() for x in v)
+    n_solves = max(1, [n for k, (n, _) in fetch.items() if "ba_finalize" in k][0])
+    fo = sum(v for k, (_, v) in fetch.items() if k.strip().startswith("ba_") or "lldba" in k if not any(x in k for x in fam_all))
+    wo = sum(v for k, (_, v) in write.items() if k.strip().startswith("ba_") or "lldba" in k if not any(x in k for x in fam_all))
+    res["_other_per_solve"] = int((2.0 * fo + wo) * 1024 / n_solves)
+    res["_solves"] = n_solves
+    if len(sys.argv) > 2:
+        res["_taken_on"] = sys.argv[2]
     print(json.dumps(res, indent=1))
 
 
