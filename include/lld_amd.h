@@ -240,6 +240,28 @@ int  lld_ba_batch_kernel_stats(lld_ba_batch* batch, int kernel, int64_t* launche
 int  lld_ba_batch_set_groups(lld_ba_batch* batch, int n_groups);
 void lld_ba_batch_destroy(lld_ba_batch* batch);
 
+/* ------------------------------------------------------------------ the batch over several GPUs of one node
+ * SURVEY.md 7 step 7 / 8e, north_star: independent windows shard across the GPUs of one node, the only exchange is the final gather of the
+ * fixed-stride result records.  For a C++ host (LocalMapping / a relocalisation service keeps its threads): ONE process, one host thread
+ * and one context per shard, created and driven by the library.  devices[] lists the HIP device of every shard; a device may appear
+ * more than once (two shards share it).  Shard d owns the windows lld_ba_multi_shard(n_windows, n_devices, d) - the block partition of
+ * lld_slam_amd/dist.py's shard(strong=True).  lld_ba_multi_solve runs every shard's lld_ba_batch_solve concurrently and, as each shard
+ * finishes, copies its records into one buffer on devices[0] (hipMemcpyPeerAsync: peer-to-peer over xGMI, what an RCCL send / recv pair
+ * of that size does; the torchrun path of bench.py uses RCCL itself): record k of the whole batch at k * stride.
+ * lld_ba_multi_verify_gathered is the receiver's check that every record IS the window the partition put there (win_index and edge count
+ * in the header) with a finished protocol.  Results per window are those of lld_ba_batch_* on that shard's batch, bit for bit. */
+int  lld_device_count(void);                                          /* visible HIP devices; 0 without a GPU */
+void lld_ba_multi_shard(int32_t n_windows, int32_t n_parts, int32_t part, int32_t* first, int32_t* count);   /* host only */
+typedef struct lld_ba_multi lld_ba_multi;
+int  lld_ba_multi_create(int32_t n_devices, const int32_t* devices, int32_t n_windows, const lld_ba_window* windows,
+                         const lld_ba_params* params, lld_ba_multi** out);   /* n_windows >= n_devices */
+int  lld_ba_multi_solve(lld_ba_multi* m, volatile const int* abort_flag);
+int  lld_ba_multi_result_records(lld_ba_multi* m, void** dev_ptr, uint64_t* stride_bytes, int32_t* device);   /* the gathered buffer, on `device` = devices[0] */
+int  lld_ba_multi_verify_gathered(lld_ba_multi* m, int32_t* n_checked);
+int  lld_ba_multi_download(lld_ba_multi* m, int32_t window, lld_ba_result* out);   /* window of the whole batch, from the shard that solved it */
+int  lld_ba_multi_times_ms(lld_ba_multi* m, double* slowest_solve_ms, double* slowest_gather_ms);   /* host clocks of the last lld_ba_multi_solve */
+void lld_ba_multi_destroy(lld_ba_multi* m);
+
 /* Diagnostic, host only (no device needed): the symbolic factorisation `reduced_solver = 0` runs per window - the stand-in for
  * LinearSolverEigen::computeSymbolicDecomposition (linear_solver_eigen.h:147-232).  block_nz[a * n_free_cams + b] != 0: free cameras a and
  * b share a landmark (symmetric; the diagonal is implied).  force: 0 = the plan a batch would use, 1 = the caller's camera order as one

@@ -180,6 +180,8 @@ PRODUCT_SYMBOLS = [
     "lld_local_ba_stopflag", "lld_ba_batch_create", "lld_ba_batch_solve", "lld_ba_batch_download", "lld_ba_batch_download_range", "lld_ba_batch_stats",
     "lld_ba_batch_result_records", "lld_ba_batch_phase_ms", "lld_ba_batch_kernel_stats", "lld_ba_batch_set_groups",
     "lld_ba_batch_destroy", "lld_ba_chol_plan",
+    "lld_device_count", "lld_ba_multi_shard", "lld_ba_multi_create", "lld_ba_multi_solve", "lld_ba_multi_result_records", "lld_ba_multi_verify_gathered",
+    "lld_ba_multi_download", "lld_ba_multi_times_ms", "lld_ba_multi_destroy",
     "lld_pose_params_default", "lld_pose_opt",
     "lld_pose_batch_create", "lld_pose_batch_solve", "lld_pose_batch_download", "lld_pose_batch_destroy",
     "lld_match_hamming256", "lld_match_hamming256_csr", "lld_match_hamming256_batch_dev",

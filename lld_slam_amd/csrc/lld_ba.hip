@@ -1289,6 +1289,37 @@ __attribute__((visibility("default"))) int lld_exp_chol_stamps(lld_ba_batch* B, 
   LLD_HIP_TRY(hipMemcpy(out, B->A.chol_stamps, sizeof(long long) * (size_t)B->n_windows * 8 * kCholStampSlots, hipMemcpyDeviceToHost));
   return LLD_OK;
 }
+// experiments build only, no device needed: host time of every staging stage of ONE window, as lld_ba_batch_create runs them for a batch of
+// `n_windows_hint` windows (chunk size, tasks per wavefront); ms per call, the minimum over `reps` (tools/time_host_staging.py)
+__attribute__((visibility("default"))) int lld_exp_stage_timing(const lld_ba_window* w, int n_windows_hint, int reps, double* ms6) {
+  if (!w || !ms6 || validate_window(*w)) return LLD_ERR_INVALID;
+  lld_ba_params P; lld_ba_params_default(&P);
+  WinBases b{};
+  const int lin_waves[2] = {4, 4};
+  const int chunk_landmarks = n_windows_hint >= 64 ? 256 : (n_windows_hint >= 8 ? 64 : 32);
+  const size_t NPE = (size_t)w->n_pt_obs, NLO = (size_t)w->n_ln_obs;
+  std::vector<double> d7((size_t)w->n_cams * 7 + 1), d3p((size_t)w->n_points * 3 + 1), d3l((size_t)w->n_lines * 3 + 1), d3l2((size_t)w->n_lines * 3 + 1);
+  std::vector<int> ps((size_t)w->n_points + 2), ls((size_t)w->n_lines + 2), pept(NPE + 1), pecs(NPE + 1), locs(NLO + 1), loln(NLO + 1);
+  std::vector<float4> peobs(NPE + 1), loseg(2 * NLO + 2);
+  std::vector<unsigned short> looct(NLO + 1);
+  HostArrays H; H.packed = true;
+  H.cam_qt0.view(d7.data(), d7.size()); H.pt0.view(d3p.data(), d3p.size()); H.ln_x0.view(d3l.data(), d3l.size()); H.ln_dir.view(d3l2.data(), d3l2.size());
+  H.pt_obs_start.view(ps.data(), ps.size()); H.ln_obs_start.view(ls.data(), ls.size()); H.pe_pt.view(pept.data(), NPE);
+  H.pe_obs.view(peobs.data(), NPE); H.pe_cs.view(pecs.data(), NPE); H.lo_seg.view(loseg.data(), 2 * NLO); H.lo_cs.view(locs.data(), NLO); H.lo_ln.view(loln.data(), NLO); H.lo_oct.view(looct.data(), NLO);
+  for (int k = 0; k < 6; k++) ms6[k] = 1e30;
+  for (int r = 0; r < std::max(1, reps); r++) {
+    BAWin W; WinStage S;
+    auto t0 = std::chrono::steady_clock::now();
+    auto lapms = [&](int k) { const auto t1 = std::chrono::steady_clock::now(); ms6[k] = std::min(ms6[k], std::chrono::duration<double, std::milli>(t1 - t0).count()); t0 = t1; };
+    stage_tasks(*w, P, b, n_windows_hint, lin_waves, true, W, S); lapms(0);
+    (void)stage_edges(*w, P, b, W, S, H); lapms(1);
+    stage_chunks(*w, 3, b, chunk_landmarks, S.cs[0]); lapms(2);
+    stage_chunks(*w, 4, b, chunk_landmarks, S.cs[1]); lapms(3);
+    stage_csr(w->n_free_cams, S); lapms(4);
+    stage_chol_plan(w->n_free_cams, 0, S); lapms(5);
+  }
+  return LLD_OK;
+}
 #endif
 
 int lld_ba_chol_plan(int32_t n_free_cams, const uint8_t* block_nz, int32_t force, void* plan_out, uint64_t plan_bytes, uint64_t* plan_size) {
