@@ -788,7 +788,7 @@ static int ba_batch_create_impl(lld_ctx* ctx, int n_windows, const lld_ba_window
     B->d_state = sl.take<BAState>(n_windows);
     A.NC = NC; A.NP = NP; A.NL = NL;
     A.cam_qt = sl.take<double>(2 * NC * 7 + 1);
-    A.ptx = sl.take<double>(2 * NP + 1); A.pty = sl.take<double>(2 * NP + 1); A.ptz = sl.take<double>(2 * NP + 1);
+    A.pt4 = sl.take<double>(8 * NP + 4);
     A.lqx = sl.take<double>(2 * NL + 1); A.lqy = sl.take<double>(2 * NL + 1); A.lqz = sl.take<double>(2 * NL + 1); A.lqw = sl.take<double>(2 * NL + 1); A.lal = sl.take<double>(2 * NL + 1);
     A.pe_flags = sl.take<uint8_t>(NPE + 1); A.le_flags = sl.take<uint8_t>(NLE + 1);
     A.pe_chi2 = sl.take<double>(NPE + 1); A.le_chi2 = sl.take<double>(NLE + 1);
@@ -883,9 +883,6 @@ static int ba_batch_create_impl(lld_ctx* ctx, int n_windows, const lld_ba_window
                          reinterpret_cast<const void*>(ba_backsub_ctl_kernel), reinterpret_cast<const void*>(ba_linearize_pt_kernel), reinterpret_cast<const void*>(ba_linearize_ln_kernel),
                          reinterpret_cast<const void*>(ba_linearize_both_kernel), reinterpret_cast<const void*>(ba_backsub_pt_f64_kernel), reinterpret_cast<const void*>(ba_backsub_ln_f64_kernel),
                          reinterpret_cast<const void*>(ba_linearize_pt_f64_kernel), reinterpret_cast<const void*>(ba_linearize_ln_f64_kernel), reinterpret_cast<const void*>(ba_chol_kernel), reinterpret_cast<const void*>(ba_chol_mfma_kernel), reinterpret_cast<const void*>(ba_chol_sparse_kernel),
-#ifdef LLD_EXPERIMENTS
-                         reinterpret_cast<const void*>(ba_chol_mfma2_kernel<false>), reinterpret_cast<const void*>(ba_chol_mfma2_kernel<true>),
-#endif
     };
     for (const void* f : fns) if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max) != hipSuccess) return fail(LLD_ERR_HIP);
     if (cached) cache.attrs_set = true;
@@ -1038,16 +1035,7 @@ static int ba_batch_solve_impl(lld_ba_batch* B, StopFlag abort_flag) {
       // windows with a plan (lld_ba_chol_plan.h) factor along the structure of S; a group that holds both kinds launches both kernels and each
       // leaves the other's windows alone
       if (G.any_sparse) hipLaunchKernelGGL(ba_chol_sparse_kernel, dim3(nw), dim3(kSpThreads), kSpLdsBytes, st, A, dw, ds);
-      if (G.any_dense) {
-#ifdef LLD_EXPERIMENTS
-      // LLD_BA_CHOL_V2 selects round 4's restructured kernel (lld_ba_chol_exp.h), LLD_BA_CHOL_BLK its four-pivots-per-update tile factor
-      static const bool chol_v2 = exp_flag("LLD_BA_CHOL_V2"), blk = exp_flag("LLD_BA_CHOL_BLK");
-      if (chol_v2 && blk) hipLaunchKernelGGL(ba_chol_mfma2_kernel<true>, dim3(nw), dim3(kCholMThreads), kChol2LdsDoubles * sizeof(double), st, A, dw, ds);
-      else if (chol_v2) hipLaunchKernelGGL(ba_chol_mfma2_kernel<false>, dim3(nw), dim3(kCholMThreads), kChol2LdsDoubles * sizeof(double), st, A, dw, ds);
-      else
-#endif
-      hipLaunchKernelGGL(ba_chol_mfma_kernel, dim3(nw), dim3(kCholMThreads), kCholMLdsDoubles * sizeof(double), st, A, dw, ds);
-      }
+      if (G.any_dense) hipLaunchKernelGGL(ba_chol_mfma_kernel, dim3(nw), dim3(kCholMThreads), kCholMLdsDoubles * sizeof(double), st, A, dw, ds);
     }
     else
       hipLaunchKernelGGL(ba_chol_kernel, dim3(nw), dim3(kPcgThreads), chol_lds, st, A, dw, ds, (int)(chol_tri / sizeof(double)));

@@ -46,9 +46,11 @@ struct CholPlan {
   uint32_t dA[kSpTileWaves][kSpStride];           // per step: slots that take the trailing update of the chain-0 column
   uint32_t dB[kSpTileWaves][kSpStride];
   uint32_t pub[kSpTileWaves][kSpStride];          // per step: slots published after the update (next step's columns -> panel buffer, the diagonal tiles of the step after -> Dall)
+  uint32_t own[kSpTileWaves][kSpStride];          // per step: the subset of cA | cB whose L_IJ the next column's PANEL wavefront forms (tile (Jn, J), Jn a column of the next
+                                                  // step): the panel's chain does not wait for the tile wavefronts; the slot's wavefront fetches L from the panel buffer afterwards
   uint32_t pub0[kSpTileWaves];                    // ... in the prologue (step 0's columns, step 1's diagonal tiles)
   uint32_t padmask[kSpTileWaves];                 // slots whose tile touches padding rows (identity there)
-  uint32_t yrows[kSpStride][2];                   // per step and chain: tile rows I with L(I, J) != 0 whose right-hand side the tile wavefronts forward-substitute (the panel wavefronts take the next columns' rows)
+  uint32_t yrows[kSpStride][2];                   // per step and chain: tile rows I with L(I, J) != 0: y_I -= L_IJ y_J on the tile wavefronts (the right-hand side is not on the panel's chain)
   int16_t rowmap[kSpMaxT * 16];                   // permuted scalar row -> row of S (-1: padding)
   int32_t n_tiles, n_updates, n_cams, est_ns;     // non-zero tiles incl. fill, tile updates, cameras, estimated time (diagnostics)
   int32_t pad_[3];
@@ -125,24 +127,52 @@ inline bool build_from_segments(int nf, const uint64_t* adj, const std::vector<i
       for (int I = J + 1; I < NT; I++) if (nz(I, J)) { if (p >= kSpPos) return false; P.pos[J][I] = (uint8_t)p++; }
     }
   }
-  // register slots: column-major round robin over the tile wavefronts (the tiles of one column land on different wavefronts); the
-  // diagonal tiles of step 0's columns belong to the panel wavefronts alone
-  int used[kSpTileWaves] = {0}, rr = 0, n_tiles = 0;
-  int8_t wave_of[kSpMaxT][kSpMaxT], slot_of[kSpMaxT][kSpMaxT];
-  std::memset(wave_of, -1, sizeof wave_of); std::memset(slot_of, -1, sizeof slot_of);
+  // Register slots.  What a tile costs its wavefront and when: one L_IJ product in its column's step, one trailing update in the step of
+  // every earlier column J with L(I, J), L(K, J) != 0, one publish.  The tile wavefronts run a step in lock-step (two barriers), so the step
+  // is as slow as its most loaded wavefront: tiles go, busiest first, to the wavefront whose load in THEIR steps is smallest (ties: fewest
+  // tiles).  The diagonal tiles of step 0's columns belong to the panel wavefronts alone.
+  auto in_step = [&](int K, int s) { return s >= 0 && s < T && (P.cols[s][0] == K || P.cols[s][1] == K); };
+  struct TileJob { int I, K, n_ev; uint8_t ev_step[kSpMaxT + 2], ev_cost[kSpMaxT + 2]; };
+  std::vector<TileJob> jobs;
+  int n_tiles = 0;
   for (int K = 0; K < NT; K++)
     for (int I = K; I < NT; I++) {
       if (!nz(I, K)) continue;
       n_tiles++;
       if (I == K && step_of[K] == 0) continue;
-      int tries = 0;
-      while (used[rr] >= kSpSlots && tries < kSpTileWaves) { rr = (rr + 1) % kSpTileWaves; tries++; }
-      if (used[rr] >= kSpSlots) return false;
-      P.slotI[rr][used[rr]] = (uint8_t)I; P.slotK[rr][used[rr]] = (uint8_t)K;
-      wave_of[I][K] = (int8_t)rr; slot_of[I][K] = (int8_t)used[rr];
-      used[rr]++; rr = (rr + 1) % kSpTileWaves;
+      TileJob j; j.I = I; j.K = K; j.n_ev = 0;
+      for (int J = 0; J < K; J++) {
+        if (!nz(I, J) || !nz(K, J)) continue;
+        if (I == K && in_step(K, step_of[J] + 1)) continue;
+        int at = -1;
+        for (int q = 0; q < j.n_ev; q++) if (j.ev_step[q] == step_of[J]) at = q;
+        if (at < 0) { at = j.n_ev++; j.ev_step[at] = (uint8_t)step_of[J]; j.ev_cost[at] = 0; }
+        j.ev_cost[at] += 4;                                   // four matrix-core instructions + their operand reads
+      }
+      if (I > K) { j.ev_step[j.n_ev] = (uint8_t)step_of[K]; j.ev_cost[j.n_ev++] = 5; }      // L_IJ: product + write-back
+      jobs.push_back(j);
     }
-  auto in_step = [&](int K, int s) { return s >= 0 && s < T && (P.cols[s][0] == K || P.cols[s][1] == K); };
+  std::stable_sort(jobs.begin(), jobs.end(), [](const TileJob& a, const TileJob& b) { return a.n_ev > b.n_ev; });
+  int used[kSpTileWaves] = {0};
+  int load[kSpTileWaves][kSpMaxT + 2];
+  std::memset(load, 0, sizeof load);
+  int8_t wave_of[kSpMaxT][kSpMaxT], slot_of[kSpMaxT][kSpMaxT];
+  std::memset(wave_of, -1, sizeof wave_of); std::memset(slot_of, -1, sizeof slot_of);
+  for (const TileJob& j : jobs) {
+    int best = -1; long best_cost = 0;
+    for (int w = 0; w < kSpTileWaves; w++) {
+      if (used[w] >= kSpSlots) continue;
+      long c = 0;
+      for (int q = 0; q < j.n_ev; q++) { const long l = load[w][j.ev_step[q]] + j.ev_cost[q]; c += l * l; }
+      c = c * 64 + used[w];
+      if (best < 0 || c < best_cost) { best = w; best_cost = c; }
+    }
+    if (best < 0) return false;
+    for (int q = 0; q < j.n_ev; q++) load[best][j.ev_step[q]] += j.ev_cost[q];
+    P.slotI[best][used[best]] = (uint8_t)j.I; P.slotK[best][used[best]] = (uint8_t)j.K;
+    wave_of[j.I][j.K] = (int8_t)best; slot_of[j.I][j.K] = (int8_t)used[best];
+    used[best]++;
+  }
   for (int K = 0; K < NT; K++)
     for (int I = K; I < NT; I++) {
       const int w = wave_of[I][K];
@@ -154,6 +184,7 @@ inline bool build_from_segments(int nf, const uint64_t* adj, const std::vector<i
       const int sK = step_of[K];
       if (I > K) {
         (P.cols[sK][0] == K ? P.cA : P.cB)[w][sK] |= bit;
+        if (in_step(I, sK + 1)) P.own[w][sK] |= bit;          // L(Jn, J) of the NEXT step's column: formed by that column's panel wavefront, fetched here after the barrier
         if (sK == 0) P.pub0[w] |= bit; else P.pub[w][sK - 1] |= bit;
       } else {
         if (sK == 1) P.pub0[w] |= bit; else if (sK >= 2) P.pub[w][sK - 2] |= bit;
@@ -171,7 +202,7 @@ inline bool build_from_segments(int nf, const uint64_t* adj, const std::vector<i
     for (int ch = 0; ch < 2; ch++) {
       const int J = P.cols[s][ch];
       if (J == kSpNone) continue;
-      for (int I = J + 1; I < NT; I++) if (nz(I, J) && !in_step(I, s + 1)) P.yrows[s][ch] |= 1u << I;
+      for (int I = J + 1; I < NT; I++) if (nz(I, J)) P.yrows[s][ch] |= 1u << I;
     }
   P.mode = 1; P.NT = (uint8_t)NT; P.T = (uint8_t)T; P.chains = two ? 2 : 1;
   P.n_tiles = n_tiles; P.n_updates = n_updates; P.n_cams = nf;

@@ -26,14 +26,14 @@ constexpr int kSpN = kSpMaxT * 16;
 constexpr int kSpLdsDoubles = 2 * kSpPos * kSpTile + kSpMaxT * kSpTile + 2 * kSpTileWaves * 16 + 3 * kSpN + 32;
 constexpr size_t kSpLdsBytes = kSpLdsDoubles * sizeof(double) + sizeof(CholPlan);
 
-// Panel wavefront: factor the 16x16 tile in Dg (lower triangle used) in place into L^-1 (all the column's L_IJ = A_IJ L_JJ^-T and the back
-// substitution need); rhs y[0..15] -> L^-1 y.  Same recurrence as chol_tile_factor.
-__device__ __forceinline__ bool chol_tile_factor_inplace(double* Dg, double* y, int lane) {
-  const int r = lane < 32 ? lane : 32;                               // 0..15 tile rows, 16 rhs, 17..32 identity rows
-  const double* src = (r < 16) ? Dg + r * kCholMStride : y;
+// Panel wavefront: factor the 16x16 tile in Dg (lower triangle used) in place into L^-1 - all the column's L_IJ = A_IJ L_JJ^-T, the forward
+// substitution y_J = L_JJ^-1 (...) and the back substitution need.  Same recurrence as chol_tile_factor (one lane per row, the identity as
+// sixteen extra rows), without the right-hand side: that is the tile wavefronts' business here, off the chain of the factors.
+__device__ __forceinline__ bool chol_tile_factor_inplace(double* Dg, int lane) {
+  const int r = lane < 32 ? lane : 31;                               // 0..15 tile rows, 16..31 identity rows
   double a[16];
 #pragma unroll
-  for (int c = 0; c < 16; c++) { const double v = src[c]; a[c] = (r <= 16) ? v : (r - 17 == c ? 1.0 : 0.0); }
+  for (int c = 0; c < 16; c++) { const double v = Dg[(r & 15) * kCholMStride + c]; a[c] = (r < 16) ? v : (r - 16 == c ? 1.0 : 0.0); }
   bool ok = true;
 #pragma unroll
   for (int c = 0; c < 16; c++) {
@@ -47,12 +47,9 @@ __device__ __forceinline__ bool chol_tile_factor_inplace(double* Dg, double* y, 
 #pragma unroll
     for (int c2 = c + 1; c2 < 16; c2++) a[c2] -= lc * readlane_f64(lc, c2);
   }
-  if (lane == 16) {
+  if (lane >= 16 && lane < 32) {                                     // lane 16+k holds column k of L^-1
 #pragma unroll
-    for (int c = 0; c < 16; c++) y[c] = a[c];
-  } else if (lane > 16 && lane <= 32) {                              // lane 17+k holds column k of L^-1
-#pragma unroll
-    for (int c = 0; c < 16; c++) Dg[c * kCholMStride + (lane - 17)] = a[c];
+    for (int c = 0; c < 16; c++) Dg[c * kCholMStride + (lane - 16)] = a[c];
   }
   return ok;
 }
@@ -106,8 +103,7 @@ __global__ __launch_bounds__(kSpThreads) void ba_chol_sparse_kernel(BAArrays A, 
         const double v = Sg[inside ? hi * n + lo : 0];
         Dg[row * kCholMStride + col] = inside ? v : (row == col ? 1.0 : 0.0);
       }
-      if (lane < 16) { const int R = P->rowmap[16 * J0 + lane]; y[16 * J0 + lane] = R >= 0 ? A.bschur[W.x_off + R] : 0.0; }
-      if (!chol_tile_factor_inplace(Dg, y + 16 * J0, lane) && lane == 0) *okf = 0.0;
+      if (!chol_tile_factor_inplace(Dg, lane) && lane == 0) *okf = 0.0;
     }
     LLD_CHOL_STAMP(1);
     __syncthreads();                                                 // B1: tiles loaded, y staged
@@ -115,40 +111,44 @@ __global__ __launch_bounds__(kSpThreads) void ba_chol_sparse_kernel(BAArrays A, 
     __syncthreads();                                                 // B2: prologue publish done
     LLD_CHOL_STAMP(3);
     for (int s = 0; s < T; s++) {
-      const double* Lp = Lp0 + (s & 1) * kSpPos * kSpTile;
+      double* Lp = Lp0 + (s & 1) * kSpPos * kSpTile;
       LLD_CHOL_STAMP(8 + 6 * s);
-      __syncthreads();                                               // (c) done: Lp holds L of step s's columns
-      LLD_CHOL_STAMP(10 + 6 * s);
       const int Jn = P->cols[s + 1][ch];
+      double* Dg = Dall + (Jn != kSpNone ? Jn : 0) * kSpTile;
       if (Jn != kSpNone) {
-        // lookahead: diagonal tile Jn (published with the updates of the steps before s) takes step s's update(s) here, then is factored
-        double* Dg = Dall + Jn * kSpTile;
+        // The next column's diagonal tile (published with the updates of the steps before s) takes step s's update(s) HERE, from L_(Jn)J tiles this
+        // wavefront forms itself (raw tile x L_JJ^-T, both in LDS since the last barrier) - its chain does not wait for the tile wavefronts' (c).
+        // L goes back in place: it is the tile wavefronts' operand in (d), and the slot's owner fetches it from there.
+        int off_cd = lrow * kCholMStride + lcol, off_ab = lcol * kCholMStride + lrow;
+        asm volatile("" : "+v"(off_cd), "+v"(off_ab));
         v4d c;
 #pragma unroll
-        for (int g = 0; g < 4; g++) c[g] = Dg[(lrow + 4 * g) * kCholMStride + lcol];
-        double dotv = 0.0;
+        for (int g = 0; g < 4; g++) c[g] = Dg[4 * g * kCholMStride + off_cd];
 #pragma unroll
         for (int c2 = 0; c2 < 2; c2++) {
           const int J = P->cols[s][c2];
           if (J == kSpNone) continue;
           const int p = P->pos[J][Jn];
           if (p == kSpNone) continue;
-          const double* Lt = Lp + p * kSpTile;
-          if (lane < 16) {                                           // y_Jn -= L_(Jn)J y_J
-            const double* pr = Lt + lane * kCholMStride;
+          double* Lt = Lp + p * kSpTile;
+          const double* pa = Lt + off_ab;
+          const double* pb = Dall + J * kSpTile + off_ab;
+          v4d l = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int cc = 0; cc < 16; cc++) dotv += pr[cc] * y[16 * J + cc];
-          }
-          const double* pa = Lt + lcol * kCholMStride + lrow;
+          for (int kk = 0; kk < 4; kk++) l = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[4 * kk], pb[4 * kk], l, 0, 0, 0);
+#pragma unroll
+          for (int g = 0; g < 4; g++) Lt[4 * g * kCholMStride + off_cd] = l[g];
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int kk = 0; kk < 4; kk++) c = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[4 * kk], pa[4 * kk], c, 0, 0, 0);
         }
-        if (lane < 16) y[16 * Jn + lane] -= dotv;
 #pragma unroll
-        for (int g = 0; g < 4; g++) Dg[(lrow + 4 * g) * kCholMStride + lcol] = c[g];
-        LLD_CHOL_STAMP(11 + 6 * s);
-        if (!chol_tile_factor_inplace(Dg, y + 16 * Jn, lane) && lane == 0) *okf = 0.0;
+        for (int g = 0; g < 4; g++) Dg[4 * g * kCholMStride + off_cd] = c[g];
       }
+      LLD_CHOL_STAMP(9 + 6 * s);
+      __syncthreads();                                               // (c) done: Lp holds L of step s's columns
+      LLD_CHOL_STAMP(10 + 6 * s);
+      if (Jn != kSpNone && !chol_tile_factor_inplace(Dg, lane) && lane == 0) *okf = 0.0;
       LLD_CHOL_STAMP(12 + 6 * s);
       __syncthreads();                                               // (d) + lookahead done
       LLD_CHOL_STAMP(13 + 6 * s);
@@ -186,10 +186,10 @@ __global__ __launch_bounds__(kSpThreads) void ba_chol_sparse_kernel(BAArrays A, 
       myI = P->slotI[w][lane]; myK = P->slotK[w][lane];
       if (myI != kSpNone) selfpos = myI == myK ? (0x80 | myI) : P->pos[myK][myI];
     }
-    // right-hand side in permuted order (the rows of step 0's columns are the panel wavefronts' own)
+    // right-hand side in permuted order
     {
       const int t = tid - 128;
-      if (t < N && (t >> 4) != P->cols[0][0] && (t >> 4) != P->cols[0][1]) { const int R = P->rowmap[t]; y[t] = R >= 0 ? A.bschur[W.x_off + R] : 0.0; }
+      if (t < N) { const int R = P->rowmap[t]; y[t] = R >= 0 ? A.bschur[W.x_off + R] : 0.0; }
     }
     // S -> registers through the row map; every load goes out before the first value is touched
     v4d acc[kSpSlots];
@@ -257,8 +257,9 @@ __global__ __launch_bounds__(kSpThreads) void ba_chol_sparse_kernel(BAArrays A, 
       double* Lnext = Lp0 + ((s + 1) & 1) * kSpPos * kSpTile;
       const int JA = P->cols[s][0], JB = P->cols[s][1];
       // (c) L_IJ = A_IJ L_JJ^-T on the matrix cores; keep it (back substitution) and leave it in the panel buffer (operand of d)
+      const unsigned mOwn = __builtin_amdgcn_readfirstlane(P->own[w][s]);           // the next column's panel wavefront forms these
       {
-        const unsigned mA = __builtin_amdgcn_readfirstlane(P->cA[w][s]), mB = __builtin_amdgcn_readfirstlane(P->cB[w][s]);
+        const unsigned mA = __builtin_amdgcn_readfirstlane(P->cA[w][s]) & ~mOwn, mB = __builtin_amdgcn_readfirstlane(P->cB[w][s]) & ~mOwn;
 #pragma unroll
         for (int sl = 0; sl < kSpSlots; sl++) {
           if ((mA | mB) & (1u << sl)) {
@@ -276,9 +277,31 @@ __global__ __launch_bounds__(kSpThreads) void ba_chol_sparse_kernel(BAArrays A, 
           __builtin_amdgcn_sched_barrier(0);
         }
       }
+      // forward solution of this step's column(s): y_J = L_JJ^-1 y_J (every earlier column's term is in; the factor is in Dall since the last barrier)
+#pragma unroll
+      for (int c2 = 0; c2 < 2; c2++) {
+        const int J = c2 == 0 ? JA : JB;
+        if (J != kSpNone && J % kSpTileWaves == w) {
+          const double* Li = Dall + J * kSpTile + lcol * kCholMStride + 4 * lrow;     // lane = row of the tile + 16 x quarter of the columns
+          const double* yj = y + 16 * J + 4 * lrow;
+          double dotv = Li[0] * yj[0] + Li[1] * yj[1] + Li[2] * yj[2] + Li[3] * yj[3];
+          dotv += __shfl_xor(dotv, 16); dotv += __shfl_xor(dotv, 32);
+          if (lane < 16) y[16 * J + lane] = dotv;
+        }
+      }
       LLD_CHOL_STAMP(9 + 6 * s);
       __syncthreads();                                               // (c) done
       LLD_CHOL_STAMP(10 + 6 * s);
+      // the tiles the panel wavefronts formed: L into this wavefront's registers (the back substitution reads it there)
+#pragma unroll
+      for (int sl = 0; sl < kSpSlots; sl++) {
+        if (mOwn & (1u << sl)) {
+          const int sp = __builtin_amdgcn_readlane(selfpos, sl);
+          const double* src = Lp + sp * kSpTile + off_cd;
+#pragma unroll
+          for (int g = 0; g < 4; g++) acc[sl][g] = src[4 * g * kCholMStride];
+        }
+      }
       // (d) trailing updates of this step's column(s), then the publishes
       {
         const unsigned mA = __builtin_amdgcn_readfirstlane(P->dA[w][s]), mB = __builtin_amdgcn_readfirstlane(P->dB[w][s]);

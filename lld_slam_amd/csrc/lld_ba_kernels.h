@@ -124,7 +124,7 @@ struct BAArrays {
   long long NC, NP, NL;        // totals (stride of the double-buffered state arrays)
   // state, double buffered: [2][N]
   double* cam_qt;              // [2][NC*7]
-  double *ptx, *pty, *ptz;     // [2][NP]
+  double *pt4;                 // [2][NP][4] x, y, z, pad (see load_pt)
   double *lqx, *lqy, *lqz, *lqw, *lal;   // [2][NL]
   // inputs
   const double* cam_qt0;       // [NC*7]
@@ -167,7 +167,8 @@ struct BAArrays {
   // per-edge mutable
   uint8_t *pe_flags, *le_flags;
   double *pe_chi2, *le_chi2;
-  double *pe_ws;               // [NPE] rho' * invSigma2 of the edge at the linearisation point (0 for level-1 edges): the 6x3 Hpl
+  double *pe_ws;               // [NPE] rho' * invSigma2 of the edge at the linearisation point (0 for level-1 edges), NEGATED for a stereo edge (the weight is >= 0: its sign
+                               //       bit carries the one flag the Schur staging needs, which spares it a gather of the flag byte - round 5): the 6x3 Hpl
                                //       block of a point edge is recomputed from it (point_hpl) instead of being stored
   double *lo_W;                // [NLO*24]  Hpl block 6x4 per (line, KF) observation: left + right edge summed
   // per-landmark mutable
@@ -365,13 +366,22 @@ __device__ __forceinline__ void chol_solve(const double* U, double lambda, const
 __device__ __forceinline__ Pose load_cam(const BAArrays& A, int buf, int cam_global) {
   return pose_load(A.cam_qt + ((size_t)buf * A.NC + cam_global) * 7);
 }
+// Point positions: [2][NP] records of four doubles (x, y, z, pad), 32 B.  The Schur staging gathers a point by its chunk position: one
+// 32-byte record is one sector where three SoA arrays were three (round 5); the landmark lanes of the point kernels read consecutive records.
 __device__ __forceinline__ Vec3 load_pt(const BAArrays& A, int buf, int g) {
-  const size_t o = (size_t)buf * A.NP + g;
-  return vec3(A.ptx[o], A.pty[o], A.ptz[o]);
+  const double* p = A.pt4 + ((size_t)buf * A.NP + g) * 4;
+  const double2 xy = *reinterpret_cast<const double2*>(p);
+  return vec3(xy.x, xy.y, p[2]);
 }
 __device__ __forceinline__ void store_pt(const BAArrays& A, int buf, int g, const Vec3& X) {
-  const size_t o = (size_t)buf * A.NP + g;
-  A.ptx[o] = X.x; A.pty[o] = X.y; A.ptz[o] = X.z;
+  double* p = A.pt4 + ((size_t)buf * A.NP + g) * 4;
+  *reinterpret_cast<double2*>(p) = make_double2(X.x, X.y); p[2] = X.z;
+}
+// A point's "has an active edge" flag: the byte array the landmark lanes read, and a copy in the fourth double of BOTH position records - the
+// Schur staging, which gathers by chunk position, finds it in the sector it fetches for the position anyway (round 5).
+__device__ __forceinline__ void set_pt_active(const BAArrays& A, int g, bool on) {
+  A.pt_active[g] = on;
+  A.pt4[(size_t)g * 4 + 3] = on ? 1.0 : 0.0; A.pt4[((size_t)A.NP + g) * 4 + 3] = on ? 1.0 : 0.0;
 }
 __device__ __forceinline__ LineQ load_ln(const BAArrays& A, int buf, int g) {
   const size_t o = (size_t)buf * A.NL + g;
@@ -454,7 +464,7 @@ __global__ __launch_bounds__(kLmThreads) void ba_init_kernel(BAArrays A, const B
     const int g = W.pt_off + p;
     const Vec3 X = vec3(A.pt0[(size_t)g * 3], A.pt0[(size_t)g * 3 + 1], A.pt0[(size_t)g * 3 + 2]);
     store_pt(A, 0, g, X); store_pt(A, 1, g, X);
-    A.pt_active[g] = A.pt_obs_start[g + 1] > A.pt_obs_start[g];
+    set_pt_active(A, g, A.pt_obs_start[g + 1] > A.pt_obs_start[g]);
   }
   for (int l = gid; l < W.n_ln; l += stride) {
     const int g = W.ln_off + l;
@@ -563,7 +573,7 @@ __device__ __forceinline__ void point_edge_linearize(const BAArrays& A, const BA
   L.rho0 = c2;
   if (fl & EF_ROBUST) L.rho0 = huber(c2, L.stereo ? W.th_stereo : W.th_mono, &w);
   L.ws = w * s;
-  A.pe_ws[e] = L.ws;
+  A.pe_ws[e] = L.stereo ? -L.ws : L.ws;                   // (sign bit = stereo edge, see BAArrays::pe_ws)
   point_jac_point(W.cam, Xc, quat_rotation(T.q), L.stereo, L.Jp);
   point_jac_pose(W.cam, Xc, L.stereo, L.Jc);
 }
@@ -717,7 +727,7 @@ __device__ __forceinline__ void ba_linearize_pt_body(const BAArrays& A, const BA
       if (lm_act && !(fl & EF_LEVEL1)) {
         double hp[27], ws_e, rho0_e;
         A.pe_chi2[e] = point_edge_blocks_closed(W, pose_load(cams + c * 7), X, ob, fl, ws_e, rho0_e, hb, hp);
-        A.pe_ws[e] = ws_e;
+        A.pe_ws[e] = (fl & EF_STEREO) ? -ws_e : ws_e;
         chi += rho0_e;
         if (c < W.n_free) {
           double* ac = acc + c * 27;
@@ -786,7 +796,7 @@ __global__ __launch_bounds__(kLinThreads, 4) void ba_linearize_pt_big_kernel(BAA
 
 // W_e^T x_c = ws * Jp^T (Jc x_c) of one point edge with the Jacobians of the linearisation point
 __device__ __forceinline__ void point_edge_wtx(const BAArrays& A, const BAWin& W, int cur, int e, uint8_t fl, int c, const Vec3& X, const double* xp, double* t) {
-  const double ws = A.pe_ws[e];
+  const double ws = fabs(A.pe_ws[e]);
   const bool stereo = (fl & EF_STEREO) != 0;
   const Pose T = load_cam(A, cur, W.cam_off + c);
   const Vec3 Xc = pose_map(T, X);
@@ -879,7 +889,7 @@ __device__ __forceinline__ void ba_backsub_pt_body(const BAArrays& A, const BAWi
       pt_cam_lm_of<kPk>(A, e, T.l0, c, l_raw);
       const int l = has ? l_raw : -1 - lane;
       const uint8_t fl = A.pe_flags[e];
-      const double ws = A.pe_ws[e];
+      const double ws = fabs(A.pe_ws[e]);
       const PtObs ob = pt_obs_of<kPk>(A, e);
       const bool lmk = lane < T.nl;
       const int g2 = W.pt_off + T.l0 + (lmk ? lane : 0);
@@ -1479,7 +1489,7 @@ __device__ __forceinline__ void schur_chunk_wide(const BAArrays& A, const BAWin&
       double w[WN];
       if constexpr (D == 3) {
         const Pose Ts = load_cam(A, cur, W.cam_off + A.sg_cams[C.cams_off + sl]);
-        point_hpl_closed(W.cam, Ts, quat_rotation(Ts.q), load_pt(A, cur, g), (A.pe_flags[id] & EF_STEREO) != 0, A.pe_ws[id], w);
+        point_hpl_closed(W.cam, Ts, quat_rotation(Ts.q), load_pt(A, cur, g), signbit(A.pe_ws[id]), fabs(A.pe_ws[id]), w);
       } else {
 #pragma unroll
         for (int i = 0; i < WN; i++) w[i] = A.lo_W[(size_t)id * WN + i];
@@ -1551,7 +1561,7 @@ __device__ __forceinline__ void schur_chunk_wave(const BAArrays& A, const BAWin&
     // them into flags where they are fetched would wait for the loads right there.
     Pose T; Mat3 Rt;
     if constexpr (D == 3) { if (stager) { T = load_cam(A, cur, W.cam_off + A.sg_cams[C.cams_off + esl]); Rt = quat_rotation(T.q); } }
-    int g_n = 0, id_n = 0, g_nn = 0, id_nn = 0, a_n = 0, fl_n = 0;
+    int g_n = 0, id_n = 0, g_nn = 0, id_nn = 0, a_n = 0;
     double v_n[VN];
     double ws_n = 0.0; Vec3 X_n = vec3(0, 0, 1);
     // Every lane issues every load, with the landmark index clamped into the chunk (a lane past the end or outside the staging range
@@ -1563,11 +1573,15 @@ __device__ __forceinline__ void schur_chunk_wave(const BAArrays& A, const BAWin&
       g = lm[tj]; id = tab[(size_t)tj * k + esl];
     };
     auto fetch_data = [&](int t0, int g, int id) {
-      a_n = act[g];
       const double* V = Vbase + (size_t)g * VN;
 #pragma unroll
       for (int i = 0; i < VN; i++) v_n[i] = V[i];
-      if constexpr (D == 3) { ws_n = A.pe_ws[id]; fl_n = A.pe_flags[id]; X_n = load_pt(A, cur, g); }
+      if constexpr (D == 3) {
+        ws_n = A.pe_ws[id];
+        const double* pr = A.pt4 + ((size_t)cur * A.NP + g) * 4;          // position + active flag: one 32-byte record (set_pt_active)
+        const double2 xy = *reinterpret_cast<const double2*>(pr), za = *reinterpret_cast<const double2*>(pr + 2);
+        X_n = vec3(xy.x, xy.y, za.x); a_n = za.y != 0.0;
+      } else a_n = act[g];      // (the stereo flag rides in the weight's sign: no gather of the edge's flag byte)
     };
     fetch_idx(0, g_n, id_n);
     fetch_idx(NB, g_nn, id_nn);
@@ -1578,7 +1592,7 @@ __device__ __forceinline__ void schur_chunk_wave(const BAArrays& A, const BAWin&
       double w[WN], v[VN];
 #pragma unroll
       for (int i = 0; i < VN; i++) v[i] = v_n[i];
-      const double ws = ws_n; const Vec3 X = X_n; const int a_raw = a_n, fl_raw = fl_n;
+      const double ws = ws_n; const Vec3 X = X_n; const int a_raw = a_n;
       const int id_cur = id_n;
       g_n = g_nn; id_n = id_nn;
       fetch_data(t0 + NB, g_n, id_n);
@@ -1593,7 +1607,7 @@ __device__ __forceinline__ void schur_chunk_wave(const BAArrays& A, const BAWin&
       __syncthreads();                                      // the previous sub-batch has been consumed
       if (stager && ej < nb) {
         // point edge: the Hpl block is a function of the linearisation-point pose, point and one weight
-        if constexpr (D == 3) { const Vec3 Xc = mat_mul(Rt, X) + T.t; point_hpl_closed_iz(W.cam, Xc, rcp_nr(Xc.z), Rt, (fl_raw & EF_STEREO) != 0, ws, w); }
+        if constexpr (D == 3) { const Vec3 Xc = mat_mul(Rt, X) + T.t; point_hpl_closed_iz(W.cam, Xc, rcp_nr(Xc.z), Rt, signbit(ws), fabs(ws), w); }
         schur_stage_one<D>(a_raw != 0, v, lambda, w, Zl + lane * WS, tl + ej * D, esl == 0);
       }
       __syncthreads();
@@ -2568,9 +2582,6 @@ __global__ __launch_bounds__(kCholMThreads) void ba_chol_mfma_kernel(BAArrays A,
 
 #include "lld_ba_chol_sparse.h"   // round 5: the same factorisation along the structure of S, two panel wavefronts where the plan has two chains
 
-#ifdef LLD_EXPERIMENTS
-#include "lld_ba_chol_exp.h"      // round 4's restructured factorisation (measured slower than the kernel above: experiments build only)
-#endif
 
 // ================================================================== LM control
 // One wavefront per window: lane 0 takes the accept / reject decision of the trial that just ran
@@ -2756,7 +2767,7 @@ __global__ __launch_bounds__(kLmThreads) void ba_classify_kernel(BAArrays A, con
       const int g = W.pt_off + p;
       int act = 0;
       for (int e = A.pt_obs_start[g]; e < A.pt_obs_start[g + 1]; e++) act += !(A.pe_flags[e] & EF_LEVEL1);
-      A.pt_active[g] = act > 0;
+      set_pt_active(A, g, act > 0);
       n_active += act;
     }
   } else {

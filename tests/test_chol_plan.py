@@ -17,7 +17,7 @@ MAXT, STRIDE, WAVES, SLOTS, POS, NONE = 22, 24, 6, 24, 20, 255
 PLAN = np.dtype([("mode", "u1"), ("NT", "u1"), ("T", "u1"), ("chains", "u1"), ("cols", "u1", (STRIDE, 2)),
                  ("slotI", "u1", (WAVES, SLOTS)), ("slotK", "u1", (WAVES, SLOTS)), ("pos", "u1", (MAXT, STRIDE)),
                  ("cA", "<u4", (WAVES, STRIDE)), ("cB", "<u4", (WAVES, STRIDE)), ("dA", "<u4", (WAVES, STRIDE)), ("dB", "<u4", (WAVES, STRIDE)),
-                 ("pub", "<u4", (WAVES, STRIDE)), ("pub0", "<u4", (WAVES,)), ("padmask", "<u4", (WAVES,)), ("yrows", "<u4", (STRIDE, 2)),
+                 ("pub", "<u4", (WAVES, STRIDE)), ("own", "<u4", (WAVES, STRIDE)), ("pub0", "<u4", (WAVES,)), ("padmask", "<u4", (WAVES,)), ("yrows", "<u4", (STRIDE, 2)),
                  ("rowmap", "<i2", (MAXT * 16,)), ("n_tiles", "<i4"), ("n_updates", "<i4"), ("n_cams", "<i4"), ("est_ns", "<i4"), ("pad_", "<i4", (3,))])
 
 
@@ -71,9 +71,7 @@ def run_plan(P, S, b):
     def factor(J):
         D = Dall[J]
         L = np.linalg.cholesky(np.tril(D) + np.tril(D, -1).T)
-        Li = np.linalg.inv(L)
-        Dall[J] = Li
-        y[16 * J:16 * J + 16] = Li @ y[16 * J:16 * J + 16]
+        Dall[J] = np.linalg.inv(L)
 
     def publish(masks, parity, forbidden_diag):
         Lp[parity] = {}
@@ -97,32 +95,9 @@ def run_plan(P, S, b):
     publish(P["pub0"], 0, set(c for c in cols[0] if c != NONE))
     for s in range(T):
         par, (JA, JB) = s & 1, cols[s]
-        for w in range(WAVES):                                      # (c)
-            for masks, J in ((P["cA"], JA), (P["cB"], JB)):
-                for sl in bits(masks[w, s]):
-                    I, K = int(P["slotI"][w, sl]), int(P["slotK"][w, sl])
-                    assert K == J and I > K
-                    L = Lp[par][pos[K][I]] @ Dall[J].T
-                    acc[(w, sl)] = L; Lp[par][pos[K][I]] = L
-        for w in range(WAVES):                                      # (d) trailing updates
-            for sl in sorted(set(bits(P["dA"][w, s])) | set(bits(P["dB"][w, s]))):
-                assert (w, sl) not in frozen, "a tile is updated after it was published"
-                I, K = int(P["slotI"][w, sl]), int(P["slotK"][w, sl])
-                for masks, J in ((P["dA"], JA), (P["dB"], JB)):
-                    if (int(masks[w, s]) >> sl) & 1:
-                        acc[(w, sl)] = acc[(w, sl)] - Lp[par][pos[J][I]] @ Lp[par][pos[J][K]].T
         nxt = set(c for c in cols[s + 1] if c != NONE)
-        old = Lp[(s + 1) & 1]
-        publish(P["pub"][:, s], (s + 1) & 1, nxt)
-        Lp_read = Lp[par]
-        # forward substitution by the tile wavefronts (rows other than the panel wavefronts')
-        ynew = y.copy()
-        for I in range(NT):
-            for ch, J in ((0, JA), (1, JB)):
-                if (int(P["yrows"][s, ch]) >> I) & 1:
-                    assert I not in nxt
-                    ynew[16 * I:16 * I + 16] -= Lp_read[pos[J][I]] @ y[16 * J:16 * J + 16]
-        # lookahead of the panel wavefronts
+        # panel wavefronts, before the barrier: their own L_(Jn)J (in place) and the update of the next diagonal tile
+        panel_tiles = set()
         for ch in range(2):
             Jn = cols[s + 1][ch]
             if Jn == NONE:
@@ -130,13 +105,49 @@ def run_plan(P, S, b):
             D = Dall[Jn]
             for J in (JA, JB):
                 if J != NONE and pos[J][Jn] != NONE:
-                    Lt = Lp_read[pos[J][Jn]]
-                    ynew[16 * Jn:16 * Jn + 16] -= Lt @ y[16 * J:16 * J + 16]
-                    D = D - Lt @ Lt.T
+                    L = Lp[par][pos[J][Jn]] @ Dall[J].T
+                    Lp[par][pos[J][Jn]] = L; panel_tiles.add((Jn, J))
+                    D = D - L @ L.T
             Dall[Jn] = D
-            y[:] = ynew; factor(Jn); ynew = y.copy()
+        own_tiles = set()
+        for w in range(WAVES):                                      # (c) on the tile wavefronts: everything but the panel's tiles
+            own = int(P["own"][w, s])
+            assert own & ~(int(P["cA"][w, s]) | int(P["cB"][w, s])) == 0
+            for sl in bits(own):
+                own_tiles.add((int(P["slotI"][w, sl]), int(P["slotK"][w, sl])))
+            for masks, J in ((P["cA"], JA), (P["cB"], JB)):
+                for sl in bits(int(masks[w, s]) & ~own):
+                    I, K = int(P["slotI"][w, sl]), int(P["slotK"][w, sl])
+                    assert K == J and I > K and (I, K) not in panel_tiles
+                    L = Lp[par][pos[K][I]] @ Dall[J].T
+                    acc[(w, sl)] = L; Lp[par][pos[K][I]] = L
+        assert own_tiles == panel_tiles, (own_tiles, panel_tiles)
+        for J in (JA, JB):                                          # forward solution of the step's columns
+            if J != NONE:
+                y[16 * J:16 * J + 16] = Dall[J] @ y[16 * J:16 * J + 16]
+        # ---- barrier
+        for w in range(WAVES):
+            for sl in bits(P["own"][w, s]):
+                I, K = int(P["slotI"][w, sl]), int(P["slotK"][w, sl])
+                acc[(w, sl)] = Lp[par][pos[K][I]].copy()
+        for w in range(WAVES):                                      # (d) trailing updates
+            for sl in sorted(set(bits(P["dA"][w, s])) | set(bits(P["dB"][w, s]))):
+                assert (w, sl) not in frozen, "a tile is updated after it was published"
+                I, K = int(P["slotI"][w, sl]), int(P["slotK"][w, sl])
+                for masks, J in ((P["dA"], JA), (P["dB"], JB)):
+                    if (int(masks[w, s]) >> sl) & 1:
+                        acc[(w, sl)] = acc[(w, sl)] - Lp[par][pos[J][I]] @ Lp[par][pos[J][K]].T
+        Lp_read = Lp[par]
+        publish(P["pub"][:, s], (s + 1) & 1, nxt)
+        ynew = y.copy()                                              # forward substitution of every row below, on the tile wavefronts
+        for I in range(NT):
+            for ch, J in ((0, JA), (1, JB)):
+                if (int(P["yrows"][s, ch]) >> I) & 1:
+                    ynew[16 * I:16 * I + 16] -= Lp_read[pos[J][I]] @ y[16 * J:16 * J + 16]
         y[:] = ynew
-        del old
+        for ch in range(2):                                          # panel wavefronts, after the barrier: the serial factor
+            if cols[s + 1][ch] != NONE:
+                factor(cols[s + 1][ch])
     x = np.zeros(N)
     for s in range(T - 1, -1, -1):
         for ch, masks in ((0, P["cA"]), (1, P["cB"])):

@@ -16,6 +16,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.environ["LLD_BA_CHOL_STAMPS"] = "1"
+os.environ.setdefault("LLD_BA_CHOL_FORCE", "3")          # the dense kernel (round 5: windows with a plan go to ba_chol_sparse_kernel by default)
 
 import numpy as np
 
@@ -49,7 +50,7 @@ def main():
     print(f"  all tile columns (panel stamp 3 -> 4): {(P[4] - P[3]) / 1e3:.2f} us")
     print(f"  back substitution (panel 4 -> 5): {(P[5] - P[4]) / 1e3:.2f} us      epilogue (5 -> 6): {(np.nanmax(s[:, 6]) - P[5]) / 1e3:.2f} us")
     print()
-    which = "experimental ba_chol_mfma2_kernel" if os.environ.get("LLD_BA_CHOL_V2") else "ba_chol_mfma_kernel"
+    which = "ba_chol_mfma_kernel"
     print(f"{which}.  per tile column J (ns):  panel wave: own L_(J+1)J + diag J+1 update | wait(c) | y_(J+1) update | factor J+1 | rest of y + wait(d)      tile waves (slowest): L_IJ | wait | trailing update | wait      column total")
     tot = np.zeros(9)
     for J in range(NT):

@@ -5,7 +5,7 @@ trial, queued or not.  Prints, for one LBA-B window and for a batch of 8 LBA-A w
 thread, at a random moment of the solve) to the return of the call, over 40 repeats.
     python tools/exp_abort_latency.py >> profiles/r04_abort_latency.txt"""
 import ctypes, os, sys, threading, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 from lld_slam_amd import BABatch, Context, synth

@@ -2,7 +2,7 @@
    python tools/exp_e2e_lanes.py [windows=256] [batches_per_lane=4] [lanes=1,2,3,4]"""
 import ctypes as C, os, sys, threading, time
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from lld_slam_amd import Context, synth, host, abi
 

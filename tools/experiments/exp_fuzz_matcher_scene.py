@@ -1,7 +1,7 @@
 """One scene of a tools/fuzz_matchers.py campaign again, with the details of a mismatch (local_points and line_stereo so far):
    [FUZZ_BIG=1] python tools/exp_fuzz_matcher_scene.py local_points|line_stereo <seed> <it> <sid>"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import numpy as np
 import fuzz_matchers as FZ

@@ -1,7 +1,7 @@
 """One fuzz window many times: how often does the device differ from the oracle, in what, and do the oracle's rounding twins differ the same way?
    python tools/exp_fuzz_window.py ["<window kwargs dict>" "<parameter dict>"]   (both as printed by tools/fuzz_ba.py; default: the PCG window of round 3)"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
 import numpy as np
 from lld_slam_amd import Context, Optimizer, synth, host
 import oracle_py as O

@@ -1,4 +1,4 @@
-# 256 windows against the number of stream groups and hardware queues (experiments build):  bash tools/exp_groups256.sh
+# 256 windows against the number of stream groups and hardware queues (experiments build):  bash tools/experiments/exp_groups256.sh
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 export LLD_AMD_LIB=$R/lld_slam_amd/csrc/liblld_amd_exp.so
 for hq in 16 24 32; do for g in 4 6 8; do

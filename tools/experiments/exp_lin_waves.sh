@@ -1,6 +1,6 @@
 #!/bin/bash
 # wavefronts per point / line linearise workgroup (experiments build, LLD_BA_LIN_WAVES="pt,ln"; bit-reproducible mode: = accumulator copies):
-# resident rate of 256 LBA-B windows and the linearise phase of one stream.   bash tools/exp_lin_waves.sh [extra bench flags]
+# resident rate of 256 LBA-B windows and the linearise phase of one stream.   bash tools/experiments/exp_lin_waves.sh [extra bench flags]
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 export LLD_AMD_LIB=$R/lld_slam_amd/csrc/liblld_amd_exp.so
 for lw in default 4,4 8,4 6,4 8,8 4,2 6,2 8,2; do

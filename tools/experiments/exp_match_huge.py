@@ -1,7 +1,7 @@
 """Brute-force matchers far beyond a frame's size (20 000 x 20 000 ORB descriptors, 1 x 100 000, 100 000 x 1, 5000 x 5000 LBD): device vs oracle,
 every output bit for bit.   python tools/exp_match_huge.py"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np
 from lld_slam_amd import Context, ORBmatcher, TwoFrameLineMatcher

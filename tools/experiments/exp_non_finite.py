@@ -1,6 +1,6 @@
 """What non-finite input does: device vs oracle statistics for a small window with one NaN / Inf planted.   python tools/exp_non_finite.py"""
 import copy, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
 import numpy as np
 from lld_slam_amd import Context, Optimizer, synth
 import oracle_py as O

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Times the guided ORB search routines call by call (kernel time comes from a rocprofv3 kernel trace of this script)."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 from lld_slam_amd import Context, ORBmatcher, synth

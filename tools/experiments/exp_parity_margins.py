@@ -3,7 +3,7 @@
 check_ba's landmark bar ("tighten check_ba to what the deterministic path actually achieves").
     python tools/exp_parity_margins.py > profiles/r04_parity_margins.txt"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np
 import oracle_py as O

@@ -2,7 +2,7 @@
 200 stereo lines a frame's LDS image is 106 KB (one workgroup per CU), at 700 + 140 it is 74 KB (two).   python tools/exp_pose_occupancy.py"""
 import json, os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch  # noqa: F401
 from lld_slam_amd import Context, PoseBatch, synth
 

@@ -2,7 +2,7 @@
 solve, the largest relative difference of chi2_final, how many windows exceed 1e-5 / 1e-4, and how many windows change an outlier set -
 the quantities tests/test_gpu_ba.py::test_batch_config_256_lba_b_windows bounds.   python tools/exp_restart_noise.py [repeats=20]"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from lld_slam_amd import Context, BABatch, synth
 

@@ -1,6 +1,6 @@
 #!/bin/bash
 # windows/s of resident batches of 32 / 64 / 128 / 256 LBA-B windows on ONE GPU: the 32-window figure over the 256-window one predicts
-# the strong-scaling efficiency of 256 windows on 8 GPUs.   bash tools/exp_small_batches.sh [groups-override]
+# the strong-scaling efficiency of 256 windows on 8 GPUs.   bash tools/experiments/exp_small_batches.sh [groups-override]
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 for n in 32 64 128 256; do
   python3 $R/bench.py --windows-per-gpu $n --steps 12 --warmup 3 --no-secondary --no-e2e --no-cpu-baseline 2>/dev/null | python3 -c "

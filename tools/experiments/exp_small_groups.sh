@@ -1,6 +1,6 @@
 #!/bin/bash
 # resident windows/s of small batches against the number of stream groups (LLD_BA_GROUPS): does a 32-window batch - the per-GPU share of the
-# strong-scaling form - gain from more dependent chains in flight?   bash tools/exp_small_groups.sh
+# strong-scaling form - gain from more dependent chains in flight?   bash tools/experiments/exp_small_groups.sh
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 for n in 16 32 64 128; do
   for g in 1 2 3 4 6 8; do

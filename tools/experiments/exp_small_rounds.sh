@@ -1,6 +1,6 @@
 #!/bin/bash
 # resident windows/s of small batches against the tasks-per-wavefront of the landmark kernels (LLD_BA_ROUNDS, experiments build) and the
-# number of stream groups: where do the wide kernels of a 16- / 32-window batch lose their efficiency?   bash tools/exp_small_rounds.sh
+# number of stream groups: where do the wide kernels of a 16- / 32-window batch lose their efficiency?   bash tools/experiments/exp_small_rounds.sh
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 export LLD_AMD_LIB=$R/lld_slam_amd/csrc/liblld_amd_exp.so
 for n in ${NS:-16 32}; do

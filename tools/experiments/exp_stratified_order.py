@@ -3,7 +3,7 @@ atomics; a wavefront holds the edges of ~10 consecutive landmarks.  `stratified`
 different cameras (sorted by first camera, then read column-wise from a G-row table), `sorted` puts equal camera sets next to each other.
    python tools/exp_stratified_order.py [n_windows=128]"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from lld_slam_amd import Context, BABatch, synth
 
