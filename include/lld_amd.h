@@ -141,7 +141,9 @@ typedef struct {
                                LDL^T does after computeSymbolicDecomposition (linear_solver_eigen.h:147-232), wherever the
                                symbolic factor fits the kernel (lld_ba_chol_plan), dense otherwise,
                                1 = block-Jacobi PCG, 2 = exact 6x6-block Cholesky on the vector ALUs,
-                               3 = the matrix-core Cholesky over all tiles in the caller's camera order (round 4's default) */
+                               3 = the matrix-core Cholesky over all tiles in the caller's camera order (round 4's default);
+                               diagnostic: 4 = structure-following in the caller's camera order as ONE chain of tile columns,
+                               5 = structure-following with the two-chain (separator) plan only, dense where none exists */
   int32_t protocol;         /* 0 = Optimizer::LocalBundleAdjustment: optimize(its_round1), outlier protocol, optimize(its_round2).
                                1 = Optimizer::BundleAdjustment / GlobalBundleAdjustment (src/Optimizer.cc:312-559) on the same
                                    kernels: ONE optimize(its_round1) call and nothing else - no classification, no line removal, all

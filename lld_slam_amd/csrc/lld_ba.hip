@@ -564,7 +564,7 @@ static int ba_batch_create_impl(lld_ctx* ctx, int n_windows, const lld_ba_window
   if (params) B->params = *params; else lld_ba_params_default(&B->params);
   const lld_ba_params& P = B->params;
   // (optimize(0) would evaluate no error at all: the classification that follows would read g2o's uninitialised _error vectors)
-  if (P.its_round1 < 1 || (P.protocol == 0 && P.its_round2 < 1) || P.its_round2 < 0 || P.max_trials <= 0 || !(P.pcg_rel_tol > 0) || P.reduced_solver < 0 || P.reduced_solver > 3 || P.protocol < 0 || P.protocol > 1 || P.abort_after_trials < 0) { delete B; return LLD_ERR_INVALID; }
+  if (P.its_round1 < 1 || (P.protocol == 0 && P.its_round2 < 1) || P.its_round2 < 0 || P.max_trials <= 0 || !(P.pcg_rel_tol > 0) || P.reduced_solver < 0 || P.reduced_solver > 5 || P.protocol < 0 || P.protocol > 1 || P.abort_after_trials < 0) { delete B; return LLD_ERR_INVALID; }
 
   // ---- layout + host staging: the windows are flattened by a few host threads straight into their final positions
   //      (every offset that depends only on the window sizes is known up front), the variable-length Schur structures are
@@ -718,7 +718,7 @@ static int ba_batch_create_impl(lld_ctx* ctx, int n_windows, const lld_ba_window
     stage_csr(wins[wi].n_free_cams, S);
     {
       static const int plan_force = exp_int("LLD_BA_CHOL_FORCE", 0);          // experiments: 1 natural order / one chain, 2 two chains only, 3 dense kernel
-      stage_chol_plan(wins[wi].n_free_cams, P.reduced_solver == 0 ? plan_force : 3, S);
+      stage_chol_plan(wins[wi].n_free_cams, P.reduced_solver == 0 ? plan_force : (P.reduced_solver == 4 ? 1 : (P.reduced_solver == 5 ? 2 : 3)), S);
     }
     lap1("chunks built");
   });
@@ -788,7 +788,7 @@ static int ba_batch_create_impl(lld_ctx* ctx, int n_windows, const lld_ba_window
     B->d_state = sl.take<BAState>(n_windows);
     A.NC = NC; A.NP = NP; A.NL = NL;
     A.cam_qt = sl.take<double>(2 * NC * 7 + 1);
-    A.pt4 = sl.take<double>(8 * NP + 4);
+    A.ptx = sl.take<double>(2 * NP + 1); A.pty = sl.take<double>(2 * NP + 1); A.ptz = sl.take<double>(2 * NP + 1);
     A.lqx = sl.take<double>(2 * NL + 1); A.lqy = sl.take<double>(2 * NL + 1); A.lqz = sl.take<double>(2 * NL + 1); A.lqw = sl.take<double>(2 * NL + 1); A.lal = sl.take<double>(2 * NL + 1);
     A.pe_flags = sl.take<uint8_t>(NPE + 1); A.le_flags = sl.take<uint8_t>(NLE + 1);
     A.pe_chi2 = sl.take<double>(NPE + 1); A.le_chi2 = sl.take<double>(NLE + 1);
@@ -1031,7 +1031,7 @@ static int ba_batch_solve_impl(lld_ba_batch* B, StopFlag abort_flag) {
       hipLaunchKernelGGL(ba_pcgm_final_kernel, dim3(nw), dim3(kPcgThreads), 0, st, A, dw, ds);
     } else if (B->params.reduced_solver == 1)
       hipLaunchKernelGGL(ba_pcg_kernel, dim3(nw), dim3(kPcgThreads), pcg_lds, st, A, dw, ds, B->params.pcg_rel_tol, B->params.pcg_max_iter);
-    else if ((B->params.reduced_solver == 0 || B->params.reduced_solver == 3) && B->max_free * 6 <= kCholMN) {    // register-resident tiles on the fp64 matrix cores
+    else if ((B->params.reduced_solver == 0 || B->params.reduced_solver >= 3) && B->max_free * 6 <= kCholMN) {    // register-resident tiles on the fp64 matrix cores
       // windows with a plan (lld_ba_chol_plan.h) factor along the structure of S; a group that holds both kinds launches both kernels and each
       // leaves the other's windows alone
       if (G.any_sparse) hipLaunchKernelGGL(ba_chol_sparse_kernel, dim3(nw), dim3(kSpThreads), kSpLdsBytes, st, A, dw, ds);

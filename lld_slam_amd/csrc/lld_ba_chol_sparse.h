@@ -24,7 +24,26 @@
 constexpr int kSpTile = 16 * kCholMStride;                          // doubles of one padded LDS tile
 constexpr int kSpN = kSpMaxT * 16;
 constexpr int kSpLdsDoubles = 2 * kSpPos * kSpTile + kSpMaxT * kSpTile + 2 * kSpTileWaves * 16 + 3 * kSpN + 32;
+// (experiments build: s_memtime stamps are parked in LDS and leave for HBM when the kernel is done - a global store per stamp put a
+// store round trip under the next s_waitcnt vmcnt(0) of every phase it was meant to time, round 5)
+constexpr int kSpStampSlots = 160;
+#ifdef LLD_EXPERIMENTS
+constexpr size_t kSpLdsBytes = kSpLdsDoubles * sizeof(double) + sizeof(CholPlan) + 8 * kSpStampSlots * sizeof(long long);
+#define LLD_SP_STAMP(k) do { if (stamp_lds && lane == 0) stamp_lds[(k)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
 constexpr size_t kSpLdsBytes = kSpLdsDoubles * sizeof(double) + sizeof(CholPlan);
+#define LLD_SP_STAMP(k) do { } while (0)
+#endif
+
+// Sum over the four lanes of a quad through the VALU (DPP quad_perm), not through the LDS pipe: the right-hand-side products below map a tile
+// row to a quad (lane = 4 x row + quarter of the columns), so their reductions are two DPP adds where a lane = row + 16 x quarter layout needs
+// two ds_bpermute round trips per add (a chain of eight dependent LDS round trips per tile row was 1 us of every step's tile-wavefront time).
+__device__ __forceinline__ double quad_sum(double v) {
+  double o = __hiloint2double(__builtin_amdgcn_mov_dpp(__double2hiint(v), 0xB1, 0xf, 0xf, true), __builtin_amdgcn_mov_dpp(__double2loint(v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+  v += o;
+  o = __hiloint2double(__builtin_amdgcn_mov_dpp(__double2hiint(v), 0x4E, 0xf, 0xf, true), __builtin_amdgcn_mov_dpp(__double2loint(v), 0x4E, 0xf, 0xf, true));          // quad_perm [2,3,0,1]
+  return v + o;
+}
 
 // Panel wavefront: factor the 16x16 tile in Dg (lower triangle used) in place into L^-1 - all the column's L_IJ = A_IJ L_JJ^-T, the forward
 // substitution y_J = L_JJ^-1 (...) and the back substitution need.  Same recurrence as chol_tile_factor (one lane per row, the identity as
@@ -82,9 +101,10 @@ __global__ __launch_bounds__(kSpThreads) void ba_chol_sparse_kernel(BAArrays A, 
   }
   if (tid == 0) *okf = 1.0;
 #ifdef LLD_EXPERIMENTS
-  long long* stamp_base = A.chol_stamps ? A.chol_stamps + ((size_t)W.win_index * 8 + wave) * kCholStampSlots : nullptr;
+  long long* stamp_lds = A.chol_stamps ? reinterpret_cast<long long*>(reinterpret_cast<char*>(P) + sizeof(CholPlan)) + wave * kSpStampSlots : nullptr;
+  if (stamp_lds) for (int i = lane; i < kSpStampSlots; i += 64) stamp_lds[i] = 0;
 #endif
-  LLD_CHOL_STAMP(0);
+  LLD_SP_STAMP(0);
   __syncthreads();                                                   // B0: the plan is in LDS
   const int NT = P->NT, T = P->T, N = NT << 4;
 
@@ -105,14 +125,14 @@ __global__ __launch_bounds__(kSpThreads) void ba_chol_sparse_kernel(BAArrays A, 
       }
       if (!chol_tile_factor_inplace(Dg, lane) && lane == 0) *okf = 0.0;
     }
-    LLD_CHOL_STAMP(1);
+    LLD_SP_STAMP(1);
     __syncthreads();                                                 // B1: tiles loaded, y staged
-    LLD_CHOL_STAMP(2);
+    LLD_SP_STAMP(2);
     __syncthreads();                                                 // B2: prologue publish done
-    LLD_CHOL_STAMP(3);
+    LLD_SP_STAMP(3);
     for (int s = 0; s < T; s++) {
       double* Lp = Lp0 + (s & 1) * kSpPos * kSpTile;
-      LLD_CHOL_STAMP(8 + 6 * s);
+      LLD_SP_STAMP(8 + 6 * s);
       const int Jn = P->cols[s + 1][ch];
       double* Dg = Dall + (Jn != kSpNone ? Jn : 0) * kSpTile;
       if (Jn != kSpNone) {
@@ -145,15 +165,15 @@ __global__ __launch_bounds__(kSpThreads) void ba_chol_sparse_kernel(BAArrays A, 
 #pragma unroll
         for (int g = 0; g < 4; g++) Dg[4 * g * kCholMStride + off_cd] = c[g];
       }
-      LLD_CHOL_STAMP(9 + 6 * s);
+      LLD_SP_STAMP(9 + 6 * s);
       __syncthreads();                                               // (c) done: Lp holds L of step s's columns
-      LLD_CHOL_STAMP(10 + 6 * s);
+      LLD_SP_STAMP(10 + 6 * s);
       if (Jn != kSpNone && !chol_tile_factor_inplace(Dg, lane) && lane == 0) *okf = 0.0;
-      LLD_CHOL_STAMP(12 + 6 * s);
+      LLD_SP_STAMP(12 + 6 * s);
       __syncthreads();                                               // (d) + lookahead done
-      LLD_CHOL_STAMP(13 + 6 * s);
+      LLD_SP_STAMP(13 + 6 * s);
     }
-    LLD_CHOL_STAMP(4);
+    LLD_SP_STAMP(4);
     // back substitution L^T x = y in reverse step order: x_J = L_JJ^-T (y_J - s_J), s_J = the tile wavefronts' column sums of L_IJ^T x_I
     for (int s = T - 1; s >= 0; s--) {
       __syncthreads();                                               // column sums of step s complete
@@ -176,7 +196,7 @@ __global__ __launch_bounds__(kSpThreads) void ba_chol_sparse_kernel(BAArrays A, 
       }
       __syncthreads();                                               // x of step s ready
     }
-    LLD_CHOL_STAMP(5);
+    LLD_SP_STAMP(5);
   } else {
     // ================================================================ tile wavefronts
     const int w = wave - 2;
@@ -228,7 +248,7 @@ __global__ __launch_bounds__(kSpThreads) void ba_chol_sparse_kernel(BAArrays A, 
       }
     }
     __builtin_amdgcn_sched_barrier(0);
-    LLD_CHOL_STAMP(1);
+    LLD_SP_STAMP(1);
     __syncthreads();                                                 // B1
     int off_cd0 = lrow * kCholMStride + lcol;
     asm volatile("" : "+v"(off_cd0));
@@ -246,11 +266,11 @@ __global__ __launch_bounds__(kSpThreads) void ba_chol_sparse_kernel(BAArrays A, 
       }                                                                                                              \
     } while (0)
     LLD_SP_PUBLISH(__builtin_amdgcn_readfirstlane(P->pub0[w]), Lp0, off_cd0);
-    LLD_CHOL_STAMP(2);
+    LLD_SP_STAMP(2);
     __syncthreads();                                                 // B2: prologue publish done
-    LLD_CHOL_STAMP(3);
+    LLD_SP_STAMP(3);
     for (int s = 0; s < T; s++) {
-      LLD_CHOL_STAMP(8 + 6 * s);
+      LLD_SP_STAMP(8 + 6 * s);
       int off_cd = lrow * kCholMStride + lcol, off_ab = lcol * kCholMStride + lrow;
       asm volatile("" : "+v"(off_cd), "+v"(off_ab));
       double* Lp = Lp0 + (s & 1) * kSpPos * kSpTile;
@@ -282,16 +302,15 @@ __global__ __launch_bounds__(kSpThreads) void ba_chol_sparse_kernel(BAArrays A, 
       for (int c2 = 0; c2 < 2; c2++) {
         const int J = c2 == 0 ? JA : JB;
         if (J != kSpNone && J % kSpTileWaves == w) {
-          const double* Li = Dall + J * kSpTile + lcol * kCholMStride + 4 * lrow;     // lane = row of the tile + 16 x quarter of the columns
-          const double* yj = y + 16 * J + 4 * lrow;
-          double dotv = Li[0] * yj[0] + Li[1] * yj[1] + Li[2] * yj[2] + Li[3] * yj[3];
-          dotv += __shfl_xor(dotv, 16); dotv += __shfl_xor(dotv, 32);
-          if (lane < 16) y[16 * J + lane] = dotv;
+          const double* Li = Dall + J * kSpTile + (lane >> 2) * kCholMStride + 4 * (lane & 3);     // lane = 4 x row of the tile + quarter of the columns
+          const double* yj = y + 16 * J + 4 * (lane & 3);
+          const double dotv = quad_sum(Li[0] * yj[0] + Li[1] * yj[1] + Li[2] * yj[2] + Li[3] * yj[3]);
+          if ((lane & 3) == 0) y[16 * J + (lane >> 2)] = dotv;
         }
       }
-      LLD_CHOL_STAMP(9 + 6 * s);
+      LLD_SP_STAMP(9 + 6 * s);
       __syncthreads();                                               // (c) done
-      LLD_CHOL_STAMP(10 + 6 * s);
+      LLD_SP_STAMP(10 + 6 * s);
       // the tiles the panel wavefronts formed: L into this wavefront's registers (the back substitution reads it there)
 #pragma unroll
       for (int sl = 0; sl < kSpSlots; sl++) {
@@ -332,6 +351,7 @@ __global__ __launch_bounds__(kSpThreads) void ba_chol_sparse_kernel(BAArrays A, 
           }
           if (sl & 1) __builtin_amdgcn_sched_barrier(0);
         }
+        LLD_SP_STAMP(11 + 6 * s);
         LLD_SP_PUBLISH(__builtin_amdgcn_readfirstlane(P->pub[w][s]), Lnext, off_cd);
       }
       // forward substitution of the right-hand side below the panel wavefronts' rows: y_I -= L_IJ y_J, tile rows I = w, w + 6, ...
@@ -339,26 +359,26 @@ __global__ __launch_bounds__(kSpThreads) void ba_chol_sparse_kernel(BAArrays A, 
         const unsigned yA = __builtin_amdgcn_readfirstlane(P->yrows[s][0]), yB = __builtin_amdgcn_readfirstlane(P->yrows[s][1]);
         for (int I = w; I < NT; I += kSpTileWaves) {
           if (!(((yA | yB) >> I) & 1)) continue;
-          double dotv = 0.0;
+          double dotv = 0.0;                                 // lane = 4 x row of the tile + quarter of the columns
           if ((yA >> I) & 1) {
-            const double* pr = Lp + P->pos[JA][I] * kSpTile + lcol * kCholMStride + 4 * lrow;
-            const double* yj = y + 16 * JA + 4 * lrow;
+            const double* pr = Lp + P->pos[JA][I] * kSpTile + (lane >> 2) * kCholMStride + 4 * (lane & 3);
+            const double* yj = y + 16 * JA + 4 * (lane & 3);
             dotv += pr[0] * yj[0] + pr[1] * yj[1] + pr[2] * yj[2] + pr[3] * yj[3];
           }
           if ((yB >> I) & 1) {
-            const double* pr = Lp + P->pos[JB][I] * kSpTile + lcol * kCholMStride + 4 * lrow;
-            const double* yj = y + 16 * JB + 4 * lrow;
+            const double* pr = Lp + P->pos[JB][I] * kSpTile + (lane >> 2) * kCholMStride + 4 * (lane & 3);
+            const double* yj = y + 16 * JB + 4 * (lane & 3);
             dotv += pr[0] * yj[0] + pr[1] * yj[1] + pr[2] * yj[2] + pr[3] * yj[3];
           }
-          dotv += __shfl_xor(dotv, 16); dotv += __shfl_xor(dotv, 32);
-          if (lane < 16) y[16 * I + lane] -= dotv;
+          dotv = quad_sum(dotv);
+          if ((lane & 3) == 0) y[16 * I + (lane >> 2)] -= dotv;
         }
       }
-      LLD_CHOL_STAMP(12 + 6 * s);
+      LLD_SP_STAMP(12 + 6 * s);
       __syncthreads();                                               // (d) + lookahead done
-      LLD_CHOL_STAMP(13 + 6 * s);
+      LLD_SP_STAMP(13 + 6 * s);
     }
-    LLD_CHOL_STAMP(4);
+    LLD_SP_STAMP(4);
     // back substitution: L lives in the register tiles, s_c = sum over the column's tiles of L[i][c] x_i
     for (int s = T - 1; s >= 0; s--) {
       const unsigned mA = __builtin_amdgcn_readfirstlane(P->cA[w][s]), mB = __builtin_amdgcn_readfirstlane(P->cB[w][s]);
@@ -379,15 +399,22 @@ __global__ __launch_bounds__(kSpThreads) void ba_chol_sparse_kernel(BAArrays A, 
       __syncthreads();                                               // column sums of step s complete
       __syncthreads();                                               // x of step s ready
     }
-    LLD_CHOL_STAMP(5);
+    LLD_SP_STAMP(5);
   }
   // back to S's row order, then the common epilogue
   if (tid < N) { const int R = P->rowmap[tid]; if (R >= 0) xo[R] = x[tid]; }
   __syncthreads();
   const bool ok = *okf != 0.0;
   solve_epilogue(A, W, S, xo, scratch, ok, 0);
-  LLD_CHOL_STAMP(6);
+  LLD_SP_STAMP(6);
+#ifdef LLD_EXPERIMENTS
+  if (stamp_lds) {
+    long long* dst = A.chol_stamps + ((size_t)W.win_index * 8 + wave) * kCholStampSlots;
+    for (int i = lane; i < kSpStampSlots; i += 64) dst[i] = stamp_lds[i];
+  }
+#endif
 }
+#undef LLD_SP_STAMP
 #undef LLD_SP_PUBLISH
 
 #endif

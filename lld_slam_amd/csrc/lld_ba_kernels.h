@@ -124,7 +124,7 @@ struct BAArrays {
   long long NC, NP, NL;        // totals (stride of the double-buffered state arrays)
   // state, double buffered: [2][N]
   double* cam_qt;              // [2][NC*7]
-  double *pt4;                 // [2][NP][4] x, y, z, pad (see load_pt)
+  double *ptx, *pty, *ptz;     // [2][NP]
   double *lqx, *lqy, *lqz, *lqw, *lal;   // [2][NL]
   // inputs
   const double* cam_qt0;       // [NC*7]
@@ -366,22 +366,17 @@ __device__ __forceinline__ void chol_solve(const double* U, double lambda, const
 __device__ __forceinline__ Pose load_cam(const BAArrays& A, int buf, int cam_global) {
   return pose_load(A.cam_qt + ((size_t)buf * A.NC + cam_global) * 7);
 }
-// Point positions: [2][NP] records of four doubles (x, y, z, pad), 32 B.  The Schur staging gathers a point by its chunk position: one
-// 32-byte record is one sector where three SoA arrays were three (round 5); the landmark lanes of the point kernels read consecutive records.
+// Point positions: SoA x, y, z [2][NP].  (Round 5 measured 32-byte records x, y, z, active - one sector for the Schur staging's gather where
+// the three arrays are three: ba_schur 16.65 -> 16.43 ms per step, but the landmark lanes of the point kernels then read 24 of every 32
+// bytes: linearise 13.74 -> 14.14, back-substitution 9.45 -> 9.75, value - 1.1 % on the same box.  Dropped; the stereo flag in the sign of
+// pe_ws, which spares the Schur staging a gather and costs nobody, stayed.)
 __device__ __forceinline__ Vec3 load_pt(const BAArrays& A, int buf, int g) {
-  const double* p = A.pt4 + ((size_t)buf * A.NP + g) * 4;
-  const double2 xy = *reinterpret_cast<const double2*>(p);
-  return vec3(xy.x, xy.y, p[2]);
+  const size_t o = (size_t)buf * A.NP + g;
+  return vec3(A.ptx[o], A.pty[o], A.ptz[o]);
 }
 __device__ __forceinline__ void store_pt(const BAArrays& A, int buf, int g, const Vec3& X) {
-  double* p = A.pt4 + ((size_t)buf * A.NP + g) * 4;
-  *reinterpret_cast<double2*>(p) = make_double2(X.x, X.y); p[2] = X.z;
-}
-// A point's "has an active edge" flag: the byte array the landmark lanes read, and a copy in the fourth double of BOTH position records - the
-// Schur staging, which gathers by chunk position, finds it in the sector it fetches for the position anyway (round 5).
-__device__ __forceinline__ void set_pt_active(const BAArrays& A, int g, bool on) {
-  A.pt_active[g] = on;
-  A.pt4[(size_t)g * 4 + 3] = on ? 1.0 : 0.0; A.pt4[((size_t)A.NP + g) * 4 + 3] = on ? 1.0 : 0.0;
+  const size_t o = (size_t)buf * A.NP + g;
+  A.ptx[o] = X.x; A.pty[o] = X.y; A.ptz[o] = X.z;
 }
 __device__ __forceinline__ LineQ load_ln(const BAArrays& A, int buf, int g) {
   const size_t o = (size_t)buf * A.NL + g;
@@ -464,7 +459,7 @@ __global__ __launch_bounds__(kLmThreads) void ba_init_kernel(BAArrays A, const B
     const int g = W.pt_off + p;
     const Vec3 X = vec3(A.pt0[(size_t)g * 3], A.pt0[(size_t)g * 3 + 1], A.pt0[(size_t)g * 3 + 2]);
     store_pt(A, 0, g, X); store_pt(A, 1, g, X);
-    set_pt_active(A, g, A.pt_obs_start[g + 1] > A.pt_obs_start[g]);
+    A.pt_active[g] = A.pt_obs_start[g + 1] > A.pt_obs_start[g];
   }
   for (int l = gid; l < W.n_ln; l += stride) {
     const int g = W.ln_off + l;
@@ -1573,15 +1568,11 @@ __device__ __forceinline__ void schur_chunk_wave(const BAArrays& A, const BAWin&
       g = lm[tj]; id = tab[(size_t)tj * k + esl];
     };
     auto fetch_data = [&](int t0, int g, int id) {
+      a_n = act[g];
       const double* V = Vbase + (size_t)g * VN;
 #pragma unroll
       for (int i = 0; i < VN; i++) v_n[i] = V[i];
-      if constexpr (D == 3) {
-        ws_n = A.pe_ws[id];
-        const double* pr = A.pt4 + ((size_t)cur * A.NP + g) * 4;          // position + active flag: one 32-byte record (set_pt_active)
-        const double2 xy = *reinterpret_cast<const double2*>(pr), za = *reinterpret_cast<const double2*>(pr + 2);
-        X_n = vec3(xy.x, xy.y, za.x); a_n = za.y != 0.0;
-      } else a_n = act[g];      // (the stereo flag rides in the weight's sign: no gather of the edge's flag byte)
+      if constexpr (D == 3) { ws_n = A.pe_ws[id]; X_n = load_pt(A, cur, g); }      // (the stereo flag rides in the weight's sign: no gather of the edge's flag byte)      // (the stereo flag rides in the weight's sign: no gather of the edge's flag byte)
     };
     fetch_idx(0, g_n, id_n);
     fetch_idx(NB, g_nn, id_nn);
@@ -2767,7 +2758,7 @@ __global__ __launch_bounds__(kLmThreads) void ba_classify_kernel(BAArrays A, con
       const int g = W.pt_off + p;
       int act = 0;
       for (int e = A.pt_obs_start[g]; e < A.pt_obs_start[g + 1]; e++) act += !(A.pe_flags[e] & EF_LEVEL1);
-      set_pt_active(A, g, act > 0);
+      A.pt_active[g] = act > 0;
       n_active += act;
     }
   } else {

@@ -140,10 +140,11 @@ def test_small_windows_match_oracle(gpu_ctx, oracle, wid, kw):
     check_ba(Optimizer(gpu_ctx).LocalBundleAdjustment(w), oracle.local_ba(w), w)
 
 
-@pytest.mark.parametrize("solver", [0, 1, 2])
+@pytest.mark.parametrize("solver", [0, 1, 2, 3, 4, 5])
 def test_all_reduced_solvers(gpu_ctx, oracle, solver):
-    """reduced_solver 0 = exact Cholesky on the fp64 matrix cores (default), 1 = block-Jacobi PCG (rel. tol 1e-12),
-    2 = exact 6x6-block Cholesky on the vector ALUs."""
+    """reduced_solver 0 = exact Cholesky on the fp64 matrix cores along the structure of S (default), 1 = block-Jacobi PCG (rel. tol 1e-12),
+    2 = exact 6x6-block Cholesky on the vector ALUs, 3 = the dense matrix-core Cholesky, 4 / 5 = the structure-following kernel with a
+    one-chain plan in the caller's order / the two-chain plan only."""
     w = synth.make_lba_small(9, n_free=12, n_fixed=3, n_points=500, n_lines=80)
     tail = "pcg" if solver == 1 else None
     check_ba(Optimizer(gpu_ctx).LocalBundleAdjustment(w, reduced_solver=solver), oracle.local_ba(w), w, tail=tail)
@@ -156,7 +157,9 @@ def test_matrix_core_cholesky_at_every_tile_padding(gpu_ctx, oracle, n_free):
     """6*n_free runs through every residue modulo the 16-wide tiles (6, 12, 18, 30, 48, 66, 96, 162, 300): padding rows,
     partial last tiles and the 1- and 19-tile extremes of the register-resident factorisation."""
     w = synth.make_lba_small(40 + n_free, n_free=n_free, n_fixed=max(2, 7 - n_free), n_points=60 * n_free + 80, n_lines=8 * n_free + 10)
-    check_ba(Optimizer(gpu_ctx).LocalBundleAdjustment(w), oracle.local_ba(w), w)
+    o = oracle.local_ba(w)
+    for solver in (0, 3, 4):
+        check_ba(Optimizer(gpu_ctx).LocalBundleAdjustment(w, reduced_solver=solver), o, w)
 
 
 @pytest.mark.parametrize("wid,kw", [
@@ -165,12 +168,13 @@ def test_matrix_core_cholesky_at_every_tile_padding(gpu_ctx, oracle, n_free):
     (2, dict(obs_per_point=25, obs_per_line=12)),                    # every camera pair shares a landmark: dense S, nothing to skip
     (3, dict(obs_per_point=2, obs_per_line=1, n_lines=40)),          # single-observation lines add diagonal blocks only
 ])
-def test_reduced_systems_from_block_tridiagonal_to_dense(gpu_ctx, oracle, wid, kw):
+@pytest.mark.parametrize("solver", [0, 3, 4, 5])
+def test_reduced_systems_from_block_tridiagonal_to_dense(gpu_ctx, oracle, wid, kw, solver):
     """The covisibility structure of the reduced camera system at its extremes (LBA-B windows are about a quarter dense at block level):
     exact zero tiles through all 19 tile columns of the matrix-core Cholesky, partly filled last tiles, a fully dense S."""
     args = dict(n_free=50, n_fixed=4, n_points=1500, n_lines=200); args.update(kw)
     w = synth.make_ba_window(seed=0x5A120000 + wid, **args)
-    check_ba(Optimizer(gpu_ctx).LocalBundleAdjustment(w), oracle.local_ba(w), w)
+    check_ba(Optimizer(gpu_ctx).LocalBundleAdjustment(w, reduced_solver=solver), oracle.local_ba(w), w)
 
 
 def test_window_of_two_unconnected_camera_groups(gpu_ctx, oracle):
@@ -192,8 +196,9 @@ def test_window_of_two_unconnected_camera_groups(gpu_ctx, oracle):
         ln_obs_cam=np.concatenate([remap(a.ln_obs_cam, 25, 0, 50), remap(b.ln_obs_cam, 25, 25, 52)]),
         ln_obs_left=np.concatenate([a.ln_obs_left, b.ln_obs_left]), ln_obs_right=np.concatenate([a.ln_obs_right, b.ln_obs_right]),
         ln_obs_octave=np.concatenate([a.ln_obs_octave, b.ln_obs_octave]))
-    g, o = Optimizer(gpu_ctx).LocalBundleAdjustment(w), oracle.local_ba(w)
-    check_ba(g, o, w, twins=oracle_twins(oracle, w))
+    o = oracle.local_ba(w)
+    for solver in (0, 3, 4, 5):                                  # two chains without a separator; dense; one chain; two chains only
+        check_ba(Optimizer(gpu_ctx).LocalBundleAdjustment(w, reduced_solver=solver), o, w, twins=oracle_twins(oracle, w))
 
 
 def test_windows_above_the_matrix_core_limit_use_the_vector_cholesky(gpu_ctx, oracle):

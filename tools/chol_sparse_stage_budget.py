@@ -49,15 +49,15 @@ def main():
     print(f"  plan -> LDS + S -> registers (tile waves, slowest, stamp 1): {np.nanmax(TW[:, 1]) / 1e3:.2f} us   panel A's own first factor done at {PA[1] / 1e3:.2f} us   prologue publish done at {np.nanmax(TW[:, 2]) / 1e3:.2f} us")
     print(f"  all steps (panel A stamp 3 -> 4): {(PA[4] - PA[3]) / 1e3:.2f} us    back substitution (4 -> 5): {(PA[5] - PA[4]) / 1e3:.2f} us    epilogue (5 -> 6): {(np.nanmax(s[:, 6]) - PA[5]) / 1e3:.2f} us")
     print()
-    print("per step (ns):  columns | panel A: own L_(Jn)J + diag update | wait(c) | factor | wait(d)   panel B: same   tile waves (slowest): L_IJ + y_J | wait | fetch + update + publish + y | wait    step total")
+    print("per step (ns):  columns | panel A: own L_(Jn)J + diag update | wait(c) | factor | wait(d)   panel B: same   tile waves (slowest): L_IJ + y_J | wait | fetch + updates | publish + y | wait    step total")
     for k in range(T):
         b0 = 8 + 6 * k
         def pan(P):
             return [P[b0 + 1] - P[b0], P[b0 + 2] - P[b0 + 1], P[b0 + 4] - P[b0 + 2], P[b0 + 5] - P[b0 + 4]]
         a, bq = pan(PA), pan(PB)
-        tw = [np.nanmax(TW[:, b0 + 1] - TW[:, b0]), np.nanmin(TW[:, b0 + 2] - TW[:, b0 + 1]), np.nanmax(TW[:, b0 + 4] - TW[:, b0 + 2]), np.nanmin(TW[:, b0 + 5] - TW[:, b0 + 4])]
+        tw = [np.nanmax(TW[:, b0 + 1] - TW[:, b0]), np.nanmin(TW[:, b0 + 2] - TW[:, b0 + 1]), np.nanmax(TW[:, b0 + 3] - TW[:, b0 + 2]), np.nanmax(TW[:, b0 + 4] - TW[:, b0 + 3]), np.nanmin(TW[:, b0 + 5] - TW[:, b0 + 4])]
         cols = tuple(int(c) for c in plan["cols"][k])
-        print(f"  s={k:2d} {str(cols):10s} A {a[0]:6.0f} {a[1]:6.0f} {a[2]:6.0f} {a[3]:6.0f}   B {bq[0]:6.0f} {bq[1]:6.0f} {bq[2]:6.0f} {bq[3]:6.0f}   tiles {tw[0]:6.0f} {tw[1]:6.0f} {tw[2]:6.0f} {tw[3]:6.0f}   step {PA[b0 + 5] - PA[b0]:6.0f}")
+        print(f"  s={k:2d} {str(cols):10s} A {a[0]:6.0f} {a[1]:6.0f} {a[2]:6.0f} {a[3]:6.0f}   B {bq[0]:6.0f} {bq[1]:6.0f} {bq[2]:6.0f} {bq[3]:6.0f}   tiles {tw[0]:6.0f} {tw[1]:6.0f} {tw[2]:6.0f} {tw[3]:6.0f} {tw[4]:6.0f}   step {PA[b0 + 5] - PA[b0]:6.0f}")
     print()
     print("phase_ms of the last solve:", np.round(ph, 3).tolist())
 
