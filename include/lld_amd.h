@@ -731,6 +731,21 @@ typedef struct {
 } lld_last_frame_points;
 int lld_orb_search_last_frame(lld_ctx* ctx, const lld_orb_search* frame, const lld_frame_view* view, const lld_last_frame_points* last,
                               int direction, float th, int check_orientation, float* proj_uvr_or_null, lld_orb_search_result* out);
+/* A frame RESIDENT on the device for the time the Tracking thread works on it (round 5).  The reference runs, on one Frame, the matcher of
+ * TrackWithMotionModel (src/Tracking.cc:904), PoseOptimization (:937), SearchLocalPoints (:1133), PoseOptimization (:1152); the two
+ * matchers above re-send the frame's 2000 keypoints (descriptors, positions, octaves, right coordinates, angles: 106 KB through pinned
+ * memory) on every call.  lld_frame_create uploads the keypoint side of `keypoints` (nt, t_desc, t_xy, t_octave, t_uright, t_angle, the grid
+ * constants and level tables; the query side is ignored) ONCE; lld_frame_search_last_frame / lld_frame_search_local_points are
+ * lld_orb_search_last_frame / lld_orb_search_local_points on that frame - same arguments, same results bit for bit - and move only their
+ * queries and the per-call occupancy bytes (t_occupied[nt] or NULL: Frame::mvpMapPoints[k] != NULL at the time of the call).  The handle
+ * belongs to the context (and host thread) it was created on; destroy it before the context. */
+typedef struct lld_frame lld_frame;
+int  lld_frame_create(lld_ctx* ctx, const lld_orb_search* keypoints, lld_frame** out);
+int  lld_frame_search_last_frame(lld_frame* frame, const uint8_t* t_occupied, const lld_frame_view* view, const lld_last_frame_points* last,
+                                 int direction, float th, int check_orientation, float* proj_uvr_or_null, lld_orb_search_result* out);
+int  lld_frame_search_local_points(lld_frame* frame, const uint8_t* t_occupied, const lld_frame_view* view, const lld_map_points* points,
+                                   float viewing_cos_limit, float th, float nnratio, lld_frustum_result* frustum_or_null, lld_orb_search_result* out);
+void lld_frame_destroy(lld_frame* frame);
 /* ORBmatcher::Fuse(KeyFrame*, vpMapPoints, th) (src/ORBmatcher.cc:825-958; the loop of LocalMapping::SearchInNeighbors) with the
  * projection loop (:841-890) on the device: cv::gemm transform, z >= 0, invz = 1/z, u = fx*(x*invz)+cx, KeyFrame::IsInImage
  * (upper bounds strict, src/KeyFrame.cc:633-636), ur = u - bf*invz, scale-invariance band, PO.dot(Pn) >= 0.5*dist3D, PredictScale;

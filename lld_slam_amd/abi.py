@@ -189,6 +189,7 @@ PRODUCT_SYMBOLS = [
     "lld_line_track_match", "lld_line_hough_cells", "lld_line_match_last_frame",
     "lld_orb_search_run", "lld_orb_search_batch", "lld_orb_search_local_points", "lld_orb_search_last_frame", "lld_orb_fuse_search", "lld_orb_search_projected", "lld_orb_search_by_sim3",
     "lld_compute_stereo_matches",
+    "lld_frame_create", "lld_frame_search_last_frame", "lld_frame_search_local_points", "lld_frame_destroy",
     "lld_sim3_params_default", "lld_optimize_sim3", "lld_optimize_sim3_batch",
     "lld_pose_graph_params_default", "lld_optimize_essential_graph",
 ]

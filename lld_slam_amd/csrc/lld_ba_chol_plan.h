@@ -131,6 +131,12 @@ inline bool build_from_segments(int nf, const uint64_t* adj, const std::vector<i
   // every earlier column J with L(I, J), L(K, J) != 0, one publish.  The tile wavefronts run a step in lock-step (two barriers), so the step
   // is as slow as its most loaded wavefront: tiles go, busiest first, to the wavefront whose load in THEIR steps is smallest (ties: fewest
   // tiles).  The diagonal tiles of step 0's columns belong to the panel wavefronts alone.
+  // The load that binds is the fp64 matrix pipe of the wavefront's SIMD (64 cycles per v_mfma_f64_16x16x4, one pipe per SIMD): the workgroup's
+  // eight wavefronts sit two per SIMD (wavefront w on SIMD w mod 4: checked by the stage-budget tool through HW_ID), so tile wavefronts 2 and 3
+  // (hardware wavefronts 4, 5) share their SIMD with a PANEL wavefront, which hardly uses the pipe, while 0 / 4 and 1 / 5 share a pipe between
+  // them: a tile costs the latter twice what it costs the former (profiles/r05_chol_sparse_stage_budget_*: the tile wavefronts' update phase
+  // was the longest stage of a step before).
+  static const int kSlow[kSpTileWaves] = {2, 2, 1, 1, 2, 2};
   auto in_step = [&](int K, int s) { return s >= 0 && s < T && (P.cols[s][0] == K || P.cols[s][1] == K); };
   struct TileJob { int I, K, n_ev; uint8_t ev_step[kSpMaxT + 2], ev_cost[kSpMaxT + 2]; };
   std::vector<TileJob> jobs;
@@ -163,12 +169,12 @@ inline bool build_from_segments(int nf, const uint64_t* adj, const std::vector<i
     for (int w = 0; w < kSpTileWaves; w++) {
       if (used[w] >= kSpSlots) continue;
       long c = 0;
-      for (int q = 0; q < j.n_ev; q++) { const long l = load[w][j.ev_step[q]] + j.ev_cost[q]; c += l * l; }
+      for (int q = 0; q < j.n_ev; q++) { const long l = load[w][j.ev_step[q]] + j.ev_cost[q] * kSlow[w]; c += l * l; }
       c = c * 64 + used[w];
       if (best < 0 || c < best_cost) { best = w; best_cost = c; }
     }
     if (best < 0) return false;
-    for (int q = 0; q < j.n_ev; q++) load[best][j.ev_step[q]] += j.ev_cost[q];
+    for (int q = 0; q < j.n_ev; q++) load[best][j.ev_step[q]] += j.ev_cost[q] * kSlow[best];
     P.slotI[best][used[best]] = (uint8_t)j.I; P.slotK[best][used[best]] = (uint8_t)j.K;
     wave_of[j.I][j.K] = (int8_t)best; slot_of[j.I][j.K] = (int8_t)used[best];
     used[best]++;

@@ -105,6 +105,9 @@ __global__ __launch_bounds__(kSpThreads) void ba_chol_sparse_kernel(BAArrays A, 
   if (stamp_lds) for (int i = lane; i < kSpStampSlots; i += 64) stamp_lds[i] = 0;
 #endif
   LLD_SP_STAMP(0);
+#ifdef LLD_EXPERIMENTS
+  if (stamp_lds && lane == 0) stamp_lds[7] = (long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID: SIMD_ID in bits 5:4
+#endif
   __syncthreads();                                                   // B0: the plan is in LDS
   const int NT = P->NT, T = P->T, N = NT << 4;
 

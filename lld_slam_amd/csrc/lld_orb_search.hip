@@ -976,10 +976,28 @@ extern "C" int lld_orb_search_run(lld_ctx* ctx, const lld_orb_search* s, lld_orb
 
 namespace {
 
+}  // namespace
+
+// A frame whose keypoint side lives on the device for as long as the Tracking thread works on it (round 5, lld_frame_*): descriptors,
+// undistorted positions, octaves, right coordinates and angles are uploaded ONCE; the per-frame routines that search this frame
+// (lld_frame_search_last_frame: Tracking.cc:904, lld_frame_search_local_points: :1133) then move only their queries and the occupancy bytes.
+struct lld_frame {
+  lld_ctx* ctx = nullptr;
+  int nt = 0; bool has_uright = false, has_angle = false;
+  char* d = nullptr;                       // one device allocation: desc | xy | octave | uright | angle
+  size_t o_td = 0, o_txy = 0, o_toct = 0, o_tur = 0, o_tang = 0;
+  lld_orb_search consts;                   // grid constants, n_levels; the level tables are copied below
+  float scale[LLD_ORB_MAX_LEVELS], sigma2[LLD_ORB_MAX_LEVELS], inv_sigma2[LLD_ORB_MAX_LEVELS];
+  std::vector<int32_t> octave;             // host copy (validation of queries needs none of the rest)
+};
+
+namespace {
+
 // Shared plumbing of the "project on the device, then search" entry points: one packed input region
 // [Problem | QRec[nq] (written by the projection kernel) | q_desc | frame keypoints | caller inputs] and one output region.
 struct ProjSearch {
   lld_ctx* ctx; const lld_orb_search* frame; int nt, nq; bool need_angle;
+  const lld_frame* resident = nullptr;     // the keypoint side is already on the device (lld_frame_*): only t_occupied travels
   size_t in = 0, out = 0;
   size_t o_q = 0, o_qd = 0, o_td = 0, o_txy = 0, o_toct = 0, o_tur = 0, o_tang = 0, o_tocc = 0;
   size_t r_match = 0, r_bd = 0, r_sd = 0, r_owner = 0, r_sum = 0, r_rem = 0;
@@ -991,17 +1009,20 @@ struct ProjSearch {
     if (nt < 0 || nq < 0) return LLD_ERR_INVALID;
     if (nt > LLD_ORB_MAX_KEYPOINTS) return LLD_ERR_UNSUPPORTED;
     if (!res->match || !res->best_dist || !res->second_dist || !res->removed) return LLD_ERR_INVALID;
-    if (nt > 0 && (!frame->t_desc || !frame->t_xy || !frame->t_octave || (need_angle && !frame->t_angle))) return LLD_ERR_INVALID;
+    if (resident) { if (need_angle && nt > 0 && !resident->has_angle) return LLD_ERR_INVALID; }
+    else if (nt > 0 && (!frame->t_desc || !frame->t_xy || !frame->t_octave || (need_angle && !frame->t_angle))) return LLD_ERR_INVALID;
     if (!frame->level_scale || frame->n_levels <= 0 || frame->n_levels > LLD_ORB_MAX_LEVELS) return LLD_ERR_INVALID;
     if (frame->grid_cols <= 0 || frame->grid_rows <= 0 || frame->grid_cols * frame->grid_rows > 8191) return LLD_ERR_INVALID;
-    for (int k = 0; k < nt; k++) if (frame->t_octave[k] < 0 || frame->t_octave[k] >= LLD_ORB_MAX_LEVELS) return LLD_ERR_INVALID;
+    if (!resident) for (int k = 0; k < nt; k++) if (frame->t_octave[k] < 0 || frame->t_octave[k] >= LLD_ORB_MAX_LEVELS) return LLD_ERR_INVALID;
     return LLD_OK;
   }
   void layout() {
     in = al(sizeof(Problem));
     o_q = add_in((size_t)nq * sizeof(QRec)); o_qd = add_in((size_t)nq * 32);
-    o_td = add_in((size_t)nt * 32); o_txy = add_in((size_t)nt * 8); o_toct = add_in((size_t)nt * 4);
-    o_tur = frame->t_uright ? add_in((size_t)nt * 4) : 0; o_tang = need_angle ? add_in((size_t)nt * 4) : 0;
+    if (!resident) {
+      o_td = add_in((size_t)nt * 32); o_txy = add_in((size_t)nt * 8); o_toct = add_in((size_t)nt * 4);
+      o_tur = frame->t_uright ? add_in((size_t)nt * 4) : 0; o_tang = need_angle ? add_in((size_t)nt * 4) : 0;
+    }
     o_tocc = frame->t_occupied ? add_in((size_t)nt) : 0;
     r_match = add_out((size_t)nq * 4); r_bd = add_out((size_t)nq * 4); r_sd = add_out((size_t)nq * 4); r_owner = add_out((size_t)nt * 4);
     r_sum = add_out(16); r_rem = add_out((size_t)nq);
@@ -1015,19 +1036,26 @@ struct ProjSearch {
   // frame keypoints + query descriptors into the staging buffer, Problem with everything but the matching rules
   Problem& pack(const uint32_t* q_desc, bool want_owner) {
     if (nq) std::memcpy(h + o_qd, q_desc, (size_t)nq * 32);
-    if (nt) {
+    if (nt && !resident) {
       std::memcpy(h + o_td, frame->t_desc, (size_t)nt * 32); std::memcpy(h + o_txy, frame->t_xy, (size_t)nt * 8);
       std::memcpy(h + o_toct, frame->t_octave, (size_t)nt * 4);
       if (frame->t_uright) std::memcpy(h + o_tur, frame->t_uright, (size_t)nt * 4);
       if (need_angle) std::memcpy(h + o_tang, frame->t_angle, (size_t)nt * 4);
-      if (frame->t_occupied) std::memcpy(h + o_tocc, frame->t_occupied, (size_t)nt);
     }
+    if (nt && frame->t_occupied) std::memcpy(h + o_tocc, frame->t_occupied, (size_t)nt);
     Problem& P = *reinterpret_cast<Problem*>(h); std::memset(&P, 0, sizeof(P));
     P.nt = nt; P.nq = nq;
-    P.t_desc = reinterpret_cast<const uint32_t*>(d + o_td); P.t_xy = reinterpret_cast<const float*>(d + o_txy);
-    P.t_octave = reinterpret_cast<const int32_t*>(d + o_toct);
-    P.t_uright = frame->t_uright ? reinterpret_cast<const float*>(d + o_tur) : nullptr;
-    P.t_angle = need_angle ? reinterpret_cast<const float*>(d + o_tang) : nullptr;
+    if (resident) {
+      P.t_desc = reinterpret_cast<const uint32_t*>(resident->d + resident->o_td); P.t_xy = reinterpret_cast<const float*>(resident->d + resident->o_txy);
+      P.t_octave = reinterpret_cast<const int32_t*>(resident->d + resident->o_toct);
+      P.t_uright = resident->has_uright ? reinterpret_cast<const float*>(resident->d + resident->o_tur) : nullptr;
+      P.t_angle = (need_angle && resident->has_angle) ? reinterpret_cast<const float*>(resident->d + resident->o_tang) : nullptr;
+    } else {
+      P.t_desc = reinterpret_cast<const uint32_t*>(d + o_td); P.t_xy = reinterpret_cast<const float*>(d + o_txy);
+      P.t_octave = reinterpret_cast<const int32_t*>(d + o_toct);
+      P.t_uright = frame->t_uright ? reinterpret_cast<const float*>(d + o_tur) : nullptr;
+      P.t_angle = need_angle ? reinterpret_cast<const float*>(d + o_tang) : nullptr;
+    }
     P.t_occupied = frame->t_occupied ? reinterpret_cast<const uint8_t*>(d + o_tocc) : nullptr;
     P.q_desc = reinterpret_cast<const uint32_t*>(d + o_qd); P.q = reinterpret_cast<const QRec*>(d + o_q);
     P.min_x = frame->grid_min_x; P.min_y = frame->grid_min_y; P.winv = frame->grid_width_inv; P.hinv = frame->grid_height_inv;
@@ -1064,10 +1092,10 @@ struct ProjSearch {
 
 }  // namespace
 
-extern "C" int lld_orb_search_local_points(lld_ctx* ctx, const lld_orb_search* frame, const lld_frame_view* view, const lld_map_points* mp,
-                                           float viewing_cos_limit, float th, float nnratio, lld_frustum_result* fr, lld_orb_search_result* out) {
+static int local_points_impl(lld_ctx* ctx, const lld_orb_search* frame, const lld_frame* resident, const lld_frame_view* view, const lld_map_points* mp,
+                             float viewing_cos_limit, float th, float nnratio, lld_frustum_result* fr, lld_orb_search_result* out) {
   if (!ctx || !frame || !view || !mp || !out) return LLD_ERR_INVALID;
-  ProjSearch S{ctx, frame, frame->nt, mp->n, false};
+  ProjSearch S{ctx, frame, frame->nt, mp->n, false, resident};
   int st = S.check(out); if (st) return st;
   const int nq = S.nq;
   if (nq > 0 && (!mp->world_pos || !mp->normal || !mp->max_distance || !mp->min_distance || !mp->desc)) return LLD_ERR_INVALID;
@@ -1114,10 +1142,15 @@ extern "C" int lld_orb_search_local_points(lld_ctx* ctx, const lld_orb_search* f
   return LLD_OK;
 }
 
-extern "C" int lld_orb_search_last_frame(lld_ctx* ctx, const lld_orb_search* frame, const lld_frame_view* view, const lld_last_frame_points* last,
-                                         int direction, float th, int check_orientation, float* proj_uvr, lld_orb_search_result* out) {
+extern "C" int lld_orb_search_local_points(lld_ctx* ctx, const lld_orb_search* frame, const lld_frame_view* view, const lld_map_points* mp,
+                                           float viewing_cos_limit, float th, float nnratio, lld_frustum_result* fr, lld_orb_search_result* out) {
+  return local_points_impl(ctx, frame, nullptr, view, mp, viewing_cos_limit, th, nnratio, fr, out);
+}
+
+static int last_frame_impl(lld_ctx* ctx, const lld_orb_search* frame, const lld_frame* resident, const lld_frame_view* view, const lld_last_frame_points* last,
+                           int direction, float th, int check_orientation, float* proj_uvr, lld_orb_search_result* out) {
   if (!ctx || !frame || !view || !last || !out) return LLD_ERR_INVALID;
-  ProjSearch S{ctx, frame, frame->nt, last->n, check_orientation != 0};
+  ProjSearch S{ctx, frame, frame->nt, last->n, check_orientation != 0, resident};
   int st = S.check(out); if (st) return st;
   const int nq = S.nq;
   if (nq > 0 && (!last->world_pos || !last->valid || !last->octave || !last->desc || (check_orientation && !last->angle))) return LLD_ERR_INVALID;
@@ -1155,6 +1188,76 @@ extern "C" int lld_orb_search_last_frame(lld_ctx* ctx, const lld_orb_search* fra
   st = S.search_and_fetch(out); if (st) return st;
   if (nq && proj_uvr) std::memcpy(proj_uvr, S.h_out + r_uvr, (size_t)nq * 12);
   return LLD_OK;
+}
+
+extern "C" int lld_orb_search_last_frame(lld_ctx* ctx, const lld_orb_search* frame, const lld_frame_view* view, const lld_last_frame_points* last,
+                                         int direction, float th, int check_orientation, float* proj_uvr, lld_orb_search_result* out) {
+  return last_frame_impl(ctx, frame, nullptr, view, last, direction, th, check_orientation, proj_uvr, out);
+}
+
+// ---- the resident frame (lld_frame_*)
+extern "C" int lld_frame_create(lld_ctx* ctx, const lld_orb_search* kp, lld_frame** out) {
+  if (!ctx || !kp || !out) return LLD_ERR_INVALID;
+  *out = nullptr;
+  const int nt = kp->nt;
+  if (nt < 0) return LLD_ERR_INVALID;
+  if (nt > LLD_ORB_MAX_KEYPOINTS) return LLD_ERR_UNSUPPORTED;
+  if (nt > 0 && (!kp->t_desc || !kp->t_xy || !kp->t_octave)) return LLD_ERR_INVALID;
+  if (!kp->level_scale || kp->n_levels <= 0 || kp->n_levels > LLD_ORB_MAX_LEVELS) return LLD_ERR_INVALID;
+  if (kp->grid_cols <= 0 || kp->grid_rows <= 0 || kp->grid_cols * kp->grid_rows > 8191) return LLD_ERR_INVALID;
+  for (int k = 0; k < nt; k++) if (kp->t_octave[k] < 0 || kp->t_octave[k] >= LLD_ORB_MAX_LEVELS) return LLD_ERR_INVALID;
+  LLD_HIP_TRY(hipSetDevice(ctx->device));
+  lld_frame* f = new lld_frame();
+  f->ctx = ctx; f->nt = nt; f->has_uright = kp->t_uright != nullptr; f->has_angle = kp->t_angle != nullptr;
+  f->consts = *kp;
+  f->consts.t_desc = nullptr; f->consts.t_xy = nullptr; f->consts.t_octave = nullptr; f->consts.t_uright = nullptr; f->consts.t_angle = nullptr; f->consts.t_occupied = nullptr;
+  f->consts.nq = 0; f->consts.q_desc = nullptr;
+  for (int l = 0; l < LLD_ORB_MAX_LEVELS; l++) {
+    f->scale[l] = l < kp->n_levels ? kp->level_scale[l] : 1.f;
+    f->sigma2[l] = (l < kp->n_levels && kp->level_sigma2) ? kp->level_sigma2[l] : 1.f;
+    f->inv_sigma2[l] = (l < kp->n_levels && kp->level_inv_sigma2) ? kp->level_inv_sigma2[l] : 1.f;
+  }
+  f->consts.level_scale = f->scale; f->consts.level_sigma2 = f->sigma2; f->consts.level_inv_sigma2 = f->inv_sigma2;
+  size_t bytes = 0;
+  auto add = [&](size_t b) { const size_t o = bytes; bytes += al(b); return o; };
+  f->o_td = add((size_t)nt * 32); f->o_txy = add((size_t)nt * 8); f->o_toct = add((size_t)nt * 4);
+  f->o_tur = f->has_uright ? add((size_t)nt * 4) : 0; f->o_tang = f->has_angle ? add((size_t)nt * 4) : 0;
+  if (hipMalloc(reinterpret_cast<void**>(&f->d), bytes + 256) != hipSuccess) { delete f; return LLD_ERR_ALLOC; }
+  void* hb = nullptr;
+  int st = lld_ctx_pinned(ctx, bytes + 256, &hb);
+  if (st) { (void)hipFree(f->d); delete f; return st; }
+  char* h = static_cast<char*>(hb);
+  if (nt) {
+    std::memcpy(h + f->o_td, kp->t_desc, (size_t)nt * 32); std::memcpy(h + f->o_txy, kp->t_xy, (size_t)nt * 8); std::memcpy(h + f->o_toct, kp->t_octave, (size_t)nt * 4);
+    if (f->has_uright) std::memcpy(h + f->o_tur, kp->t_uright, (size_t)nt * 4);
+    if (f->has_angle) std::memcpy(h + f->o_tang, kp->t_angle, (size_t)nt * 4);
+  }
+  // (the context's pinned staging is reused by the next call on this context: the copy must have left it before this one returns)
+  if (hipMemcpyAsync(f->d, h, bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) { (void)hipFree(f->d); delete f; return LLD_ERR_HIP; }
+  *out = f;
+  return LLD_OK;
+}
+
+extern "C" void lld_frame_destroy(lld_frame* f) {
+  if (!f) return;
+  (void)hipSetDevice(f->ctx->device);
+  (void)hipStreamSynchronize(f->ctx->stream);
+  if (f->d) (void)hipFree(f->d);
+  delete f;
+}
+
+extern "C" int lld_frame_search_last_frame(lld_frame* f, const uint8_t* t_occupied, const lld_frame_view* view, const lld_last_frame_points* last,
+                                           int direction, float th, int check_orientation, float* proj_uvr, lld_orb_search_result* out) {
+  if (!f) return LLD_ERR_INVALID;
+  lld_orb_search fs = f->consts; fs.nt = f->nt; fs.t_occupied = t_occupied;
+  return last_frame_impl(f->ctx, &fs, f, view, last, direction, th, check_orientation, proj_uvr, out);
+}
+
+extern "C" int lld_frame_search_local_points(lld_frame* f, const uint8_t* t_occupied, const lld_frame_view* view, const lld_map_points* mp,
+                                             float viewing_cos_limit, float th, float nnratio, lld_frustum_result* fr, lld_orb_search_result* out) {
+  if (!f) return LLD_ERR_INVALID;
+  lld_orb_search fs = f->consts; fs.nt = f->nt; fs.t_occupied = t_occupied;
+  return local_points_impl(f->ctx, &fs, f, view, mp, viewing_cos_limit, th, nnratio, fr, out);
 }
 
 extern "C" int lld_orb_fuse_search(lld_ctx* ctx, const lld_orb_search* keyframe, const lld_frame_view* view, const lld_map_points* mp, float th,

@@ -550,6 +550,70 @@ def search_last_frame(lib, ctx, Cur: Frame, view: FrameView, last: dict, cur_occ
     return out, uvr
 
 
+class ResidentFrame:
+    """lld_frame_*: the keypoint side of a Frame uploaded once; search_last_frame / search_local_points as the module-level functions of
+    the same names, on the resident copy (only the queries and the occupancy bytes travel per call)."""
+
+    def __init__(self, lib, ctx, F: Frame):
+        self.lib, self.ctx, self.F = lib, ctx, F
+        p = prepare(F, np.zeros((0, 8), np.uint32), candidates=CAND_GRID, accept_max=TH_HIGH)
+        h = C.c_void_p()
+        fn = lib.fn("frame_create"); fn.argtypes = [C.c_void_p, C.POINTER(OrbSearch), C.POINTER(C.c_void_p)]; fn.restype = C.c_int
+        st = fn(ctx, C.byref(p.s), C.byref(h))
+        if st != abi.LLD_OK:
+            raise RuntimeError(f"lld_frame_create failed: {lib.fn('status_string')(st).decode()}")
+        self.handle = h
+
+    def close(self):
+        if self.handle:
+            fn = self.lib.fn("frame_destroy"); fn.argtypes = [C.c_void_p]; fn.restype = None
+            fn(self.handle); self.handle = None
+
+    def __enter__(self): return self
+    def __exit__(self, *a): self.close()
+
+    def _result(self, n):
+        nt = self.F.n
+        out = SearchOutput(np.empty(n, np.int32), np.empty(n, np.int32), np.empty(n, np.int32), np.empty(n, np.uint8), np.empty(nt, np.int32), 0, 0)
+        r = OrbSearchResult()
+        r.match = _p(out.match, c_int32_p); r.best_dist = _p(out.best_dist, c_int32_p); r.second_dist = _p(out.second_dist, c_int32_p)
+        r.removed = _p(out.removed, c_uint8_p); r.owner = _p(out.owner, c_int32_p)
+        return out, r
+
+    def search_last_frame(self, view: FrameView, last: dict, cur_occupied=None, direction=0, th=7.0, check_orientation=True):
+        m, keep = last_frame_struct(last)
+        out, r = self._result(m.n)
+        uvr = np.zeros((m.n, 3), np.float32)
+        occ = _u8(cur_occupied)
+        fn = self.lib.fn("frame_search_last_frame")
+        fn.argtypes = [C.c_void_p, c_uint8_p, C.POINTER(FrameView), C.POINTER(LastFramePoints), C.c_int, C.c_float, C.c_int, c_float_p, C.POINTER(OrbSearchResult)]
+        fn.restype = C.c_int
+        st = fn(self.handle, _p(occ, c_uint8_p), C.byref(view), C.byref(m), int(direction), float(np.float32(th)), int(check_orientation), _p(uvr, c_float_p), C.byref(r))
+        if st != abi.LLD_OK:
+            raise RuntimeError(f"lld_frame_search_last_frame failed: {self.lib.fn('status_string')(st).decode()}")
+        out.n_matches, out.rounds = r.n_matches, r.rounds
+        return out, uvr
+
+    def search_local_points(self, view: FrameView, mp: dict, f_occupied=None, th=1.0, nnratio=0.8, viewing_cos_limit=0.5):
+        m, keep = map_points_struct(mp)
+        n = m.n
+        out, r = self._result(n)
+        fr = dict(in_view=np.zeros(n, np.uint8), proj_uvr=np.zeros((n, 3), np.float32), level=np.zeros(n, np.int32), view_cos=np.zeros(n, np.float32))
+        fs = FrustumResult()
+        fs.in_view = _p(fr["in_view"], c_uint8_p); fs.proj_uvr = _p(fr["proj_uvr"], c_float_p); fs.level = _p(fr["level"], c_int32_p)
+        fs.view_cos = _p(fr["view_cos"], c_float_p)
+        occ = _u8(f_occupied)
+        fn = self.lib.fn("frame_search_local_points")
+        fn.argtypes = [C.c_void_p, c_uint8_p, C.POINTER(FrameView), C.POINTER(MapPoints), C.c_float, C.c_float, C.c_float, C.POINTER(FrustumResult), C.POINTER(OrbSearchResult)]
+        fn.restype = C.c_int
+        st = fn(self.handle, _p(occ, c_uint8_p), C.byref(view), C.byref(m), float(np.float32(viewing_cos_limit)), float(np.float32(th)), float(np.float32(nnratio)),
+                C.byref(fs), C.byref(r))
+        if st != abi.LLD_OK:
+            raise RuntimeError(f"lld_frame_search_local_points failed: {self.lib.fn('status_string')(st).decode()}")
+        out.n_matches, out.rounds = r.n_matches, r.rounds
+        return out, fr
+
+
 def fuse_search_points(lib, ctx, KF: Frame, view: FrameView, mp: dict, th=3.0):
     """ORBmatcher::Fuse(KeyFrame*, vpMapPoints, th) (src/ORBmatcher.cc:825-958) with the projection loop on the device too.
     Returns (SearchOutput, proj_uvr [n,3]); match[i] = bestIdx or -1, n_matches = nFused."""

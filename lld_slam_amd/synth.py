@@ -837,3 +837,24 @@ def make_local_map(F, scene_id=0, n=2000, related_frac=0.8, flip_p=0.06):
     return T, dict(world_pos=Xw.astype(np.float32), normal=normal.astype(np.float32), max_distance=maxd.astype(np.float32),
                    min_distance=mind.astype(np.float32), desc=desc, has_obs=(rng.random(n) < 0.9).astype(np.uint8),
                    skip=(rng.random(n) < 0.1).astype(np.uint8), occupied=(rng.random(F.n) < 0.05).astype(np.uint8), src=src.astype(np.int32))
+
+
+def make_tracking_scene(scene_id=0, n_kp=2000, n_map=2500, n_last=1200, rot_deg=0.25, trans=0.04):
+    """One consistent little world for the Tracking thread's per-frame sequence (lld_slam_amd/tracking.py): a frame with `n_kp` keypoints,
+    its true pose, `n_map` local MapPoints most of which are back-projections of the keypoints (make_local_map), the first `n_last` of them
+    also being the last frame's tracked points (with that frame's octaves / angles), and the motion model's prediction of the pose - the
+    true pose moved by `rot_deg` degrees and `trans` metres.  Returns a dict."""
+    rng = np.random.default_rng(SEED_SEARCH + 0x7000 + scene_id)
+    F = make_orb_frame(200 + scene_id, n_kp)
+    T, mp = make_local_map(F, 200 + scene_id, n_map)
+    mp = dict(mp, skip=np.zeros(n_map, np.uint8), occupied=np.zeros(F.n, np.uint8))      # a fresh frame: nothing held, nothing seen yet
+    src = mp["src"][:n_last]
+    ang = np.mod(F.angle[src] + rng.normal(0, 4.0, n_last), 360.0).astype(np.float32)
+    last = dict(world_pos=mp["world_pos"][:n_last], valid=(rng.random(n_last) < 0.95).astype(np.uint8), octave=F.octave[src].astype(np.int32),
+                angle=ang, desc=mp["desc"][:n_last], has_obs=mp["has_obs"][:n_last])
+    w = rng.normal(size=3); w *= np.deg2rad(rot_deg) / np.linalg.norm(w)
+    dt = rng.normal(size=3); dt *= trans / np.linalg.norm(dt)
+    dT = np.eye(4); dT[:3, :3] = _rodrigues(w); dT[:3, 3] = dt
+    Tg = (dT @ T.astype(np.float64)).astype(np.float32)
+    return dict(frame=F, cam=KITTI_CAM, Tcw_true=T, pose_true=_tcw_to_qt(T.astype(np.float64)), pose_guess=_tcw_to_qt(Tg.astype(np.float64)),
+                last=last, last_ids=np.arange(n_last), map_points=mp, map_ids=np.arange(n_map))

@@ -48,6 +48,7 @@ def main():
     print(f"kernel (stamp 0 -> 6, slowest wavefront): {np.nanmax(s[:, 6]) / 1e3:.1f} us")
     print(f"  plan -> LDS + S -> registers (tile waves, slowest, stamp 1): {np.nanmax(TW[:, 1]) / 1e3:.2f} us   panel A's own first factor done at {PA[1] / 1e3:.2f} us   prologue publish done at {np.nanmax(TW[:, 2]) / 1e3:.2f} us")
     print(f"  all steps (panel A stamp 3 -> 4): {(PA[4] - PA[3]) / 1e3:.2f} us    back substitution (4 -> 5): {(PA[5] - PA[4]) / 1e3:.2f} us    epilogue (5 -> 6): {(np.nanmax(s[:, 6]) - PA[5]) / 1e3:.2f} us")
+    print("  SIMD of the wavefronts 0..7 (HW_ID bits 5:4):", [int(st[0][w, 7]) >> 4 & 3 for w in range(8)], "  slots used per tile wavefront:", [int((plan["slotI"][w] != 255).sum()) for w in range(6)])
     print()
     print("per step (ns):  columns | panel A: own L_(Jn)J + diag update | wait(c) | factor | wait(d)   panel B: same   tile waves (slowest): L_IJ + y_J | wait | fetch + updates | publish + y | wait    step total")
     for k in range(T):
