@@ -252,6 +252,64 @@ def deterministic_block(ctx, windows, repeats=3):
     return out
 
 
+def tracking_frame_block(ctx, repeats=7):
+    """The Tracking thread's per-frame sequence on ONE synthetic frame (2000 keypoints, 1200 points tracked in the last frame, 2500 local
+    MapPoints): SearchByProjection(Current, Last) -> PoseOptimization -> outlier discard -> SearchLocalPoints -> PoseOptimization
+    (src/Tracking.cc:904,937,1133,1152), through the C ABI with the frame resident on the device (lld_frame_*) and with the per-call upload,
+    next to the same chain through the CPU oracle, every stage checked against the oracle on the inputs the device chain handed it."""
+    import numpy as np
+    import oracle_py as O
+    import oracle_orbsearch as OS
+    from lld_slam_amd import synth
+    from lld_slam_amd.tracking import TrackedFrame
+    sc = synth.make_tracking_scene(0)
+    F = sc["frame"]
+
+    def chain(resident):
+        with TrackedFrame(ctx, F, sc["cam"], resident=resident) as tf:
+            t0 = time.perf_counter()
+            p1 = tf.track_with_motion_model(sc["pose_guess"], sc["last"], sc["last_ids"], th=7.0)
+            t1 = time.perf_counter()
+            p2 = tf.track_local_map(p1, sc["map_points"], sc["map_ids"], th=1.0)
+            t2 = time.perf_counter()
+            return (t1 - t0) * 1e3, (t2 - t1) * 1e3, tf.stages, p2, int(tf.kp_has.sum())
+    chain(True); chain(False)
+    res = {}
+    for name, resident in (("resident_frame", True), ("per_call_upload", False)):
+        runs = [chain(resident) for _ in range(repeats)]
+        res[name] = {"ms_per_frame": _spread([a + b for a, b, *_ in runs]), "motion_model_ms": _spread([r[0] for r in runs]), "local_map_ms": _spread([r[1] for r in runs])}
+    _, _, st, p2, n_held = chain(True)
+    # the oracle's chain on the same inputs, stage by stage (each stage gets what the device chain handed it)
+    s1, s3 = st["search_last_frame"], st["search_local_points"]
+    tc = time.perf_counter()
+    valid, uv, ur = OS.project_last_frame(s1["view"], sc["last"])
+    n1, slot1 = OS.search_by_projection_frame(F, sc["last"]["desc"], valid, uv, ur, sc["last"]["octave"], sc["last"]["angle"], sc["last"]["has_obs"], s1["occupied"], 0, 7.0, True)
+    o2 = O.pose_opt(st["pose_after_motion_model"]["problem"], 0.5)
+    k, inv, uvr, lvl, vc = OS.is_in_frustum(s3["view"], s3["points"])
+    n3, slot3 = OS.search_by_projection_map(F, s3["points"]["desc"], inv, uvr[:, :2], uvr[:, 2], lvl, vc, s3["points"]["has_obs"], s3["occupied"], 1.0, 0.8)
+    o4 = O.pose_opt(st["pose_after_local_map"]["problem"], 0.5)
+    cpu_ms = (time.perf_counter() - tc) * 1e3
+
+    def slots(out, occupied):
+        sl = np.where(np.asarray(occupied) != 0, 1 << 20, -1).astype(np.int32)
+        sl = np.where(out.owner >= 0, out.owner, sl)
+        return np.where(out.owner == -2, -1, sl).astype(np.int32)
+    g2, g4 = st["pose_after_motion_model"]["out"], st["pose_after_local_map"]["out"]
+    parity = {"search_last_frame_bit_exact": bool(s1["out"].n_matches == n1 and np.array_equal(slots(s1["out"], s1["occupied"]), slot1)),
+              "search_local_points_bit_exact": bool(s3["out"].n_matches == n3 and np.array_equal(slots(s3["out"], s3["occupied"]), slot3) and np.array_equal(s3["frustum"]["in_view"], inv)),
+              "pose_max_rel": float(max(np.max(np.abs(g.pose_qt - o.pose_qt) / np.maximum(np.abs(o.pose_qt), 1e-3)) for g, o in ((g2, o2), (g4, o4)))),
+              "pose_outlier_flags_equal": bool(np.array_equal(g2.pt_outlier, o2.pt_outlier) and np.array_equal(g4.pt_outlier, o4.pt_outlier))}
+    err0 = float(np.linalg.norm(np.asarray(sc["pose_guess"])[4:] - np.asarray(sc["pose_true"])[4:]))
+    err2 = float(np.linalg.norm(np.asarray(p2)[4:] - np.asarray(sc["pose_true"])[4:]))
+    return {"workload": "one frame: 2000 keypoints, 1200 last-frame points, 2500 local MapPoints; SearchByProjection(Current, Last) + PoseOptimization + discard + "
+                        "SearchLocalPoints + PoseOptimization (points; the line half and ComputeStereoMatches have their own entries above and in the README)",
+            "unit": "ms per frame (host wall clock through the Python mirror: ctypes marshalling and the host-side bookkeeping of Frame::mvpMapPoints included)",
+            **res, "matches": {"after_motion_model": int(n1), "local_map_added": int(n3), "map_points_held_at_the_end": n_held},
+            "translation_error_m": {"predicted_pose": round(err0, 4), "after_the_sequence": round(err2, 5)},
+            "cpu_baseline": {"value": round(cpu_ms, 2), "unit": "ms per frame", "cores": 1, "kind": "port", "sample": "the same four stages through oracle/ (one frame)"},
+            "parity": parity}
+
+
 def secondary_block(ctx, dev, repeats=5):
     """PO / MATCH / LBA-A / single call.  Every figure: `repeats` timed runs (min / median / max - the spread is what round 2's
     unexplained -22 % / -8 % between two single-shot runs lacked), HIP-event time of the kernel on the library's stream, its ruler, the
@@ -722,6 +780,7 @@ def main():
         if not args.no_secondary:
             try:
                 result["secondary"] = secondary_block(ctx, dev)
+                result["secondary"]["tracking_frame"] = tracking_frame_block(ctx)
                 result["secondary"]["small_batch"] = small_batch_block(ctx, windows)
                 result["secondary"]["deterministic"] = deterministic_block(ctx, windows)
             except Exception as ex:

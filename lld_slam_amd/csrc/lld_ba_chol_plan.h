@@ -136,7 +136,10 @@ inline bool build_from_segments(int nf, const uint64_t* adj, const std::vector<i
   // (hardware wavefronts 4, 5) share their SIMD with a PANEL wavefront, which hardly uses the pipe, while 0 / 4 and 1 / 5 share a pipe between
   // them: a tile costs the latter twice what it costs the former (profiles/r05_chol_sparse_stage_budget_*: the tile wavefronts' update phase
   // was the longest stage of a step before).
-  static const int kSlow[kSpTileWaves] = {2, 2, 1, 1, 2, 2};
+  // MEASURED, round 5: weighting by pipe sharing ({2, 2, 1, 1, 2, 2}: 22 tiles on the two wavefronts next to the panels, 11 on the others) is
+  // SLOWER - one launch 58 -> 62 - 69 us: what a tile wavefront's time is made of is its own serial chain of LDS read -> four dependent
+  // matrix-core instructions per update, not the pipe's throughput, so equal counts win.  The weights stay as the knob they are.
+  static const int kSlow[kSpTileWaves] = {1, 1, 1, 1, 1, 1};
   auto in_step = [&](int K, int s) { return s >= 0 && s < T && (P.cols[s][0] == K || P.cols[s][1] == K); };
   struct TileJob { int I, K, n_ev; uint8_t ev_step[kSpMaxT + 2], ev_cost[kSpMaxT + 2]; };
   std::vector<TileJob> jobs;

@@ -804,7 +804,7 @@ def make_two_frame_lines(scene_id=0, n_lines=260, dim=72, shared_frac=0.7, pixel
     return params, cur, last, truth
 
 
-def make_local_map(F, scene_id=0, n=2000, related_frac=0.8, flip_p=0.06):
+def make_local_map(F, scene_id=0, n=2000, related_frac=0.8, flip_p=0.06, pos_noise=0.01):
     """A frame pose and local MapPoints for Tracking::SearchLocalPoints: most points are back-projections of F's keypoints (depth
     from the stereo disparity or drawn, position perturbed a little), with their observation normals, scale-invariance distances
     consistent with the keypoint octave, and noisy copies of the descriptors; the rest lie anywhere around the camera (behind it,
@@ -817,7 +817,7 @@ def make_local_map(F, scene_id=0, n=2000, related_frac=0.8, flip_p=0.06):
     R = T[:3, :3].astype(np.float64); tt = T[:3, 3].astype(np.float64); Ow = -R.T @ tt
     src = rng.integers(0, F.n, n)
     z = np.where(F.uright[src] > 0, bf / np.maximum(F.xy[src, 0] - F.uright[src], 0.5), rng.uniform(4, 60, n))
-    Xc = np.stack([(F.xy[src, 0] - cx) * z / fx, (F.xy[src, 1] - cy) * z / fy, z], 1) + rng.normal(0, 0.01, (n, 3)) * z[:, None]
+    Xc = np.stack([(F.xy[src, 0] - cx) * z / fx, (F.xy[src, 1] - cy) * z / fy, z], 1) + rng.normal(0, pos_noise, (n, 3)) * z[:, None]
     related = rng.random(n) < related_frac
     far = ~related
     Xc[far] = np.stack([rng.uniform(-40, 40, int(far.sum())), rng.uniform(-15, 15, int(far.sum())), rng.uniform(-20, 90, int(far.sum()))], 1)
@@ -846,7 +846,7 @@ def make_tracking_scene(scene_id=0, n_kp=2000, n_map=2500, n_last=1200, rot_deg=
     true pose moved by `rot_deg` degrees and `trans` metres.  Returns a dict."""
     rng = np.random.default_rng(SEED_SEARCH + 0x7000 + scene_id)
     F = make_orb_frame(200 + scene_id, n_kp)
-    T, mp = make_local_map(F, 200 + scene_id, n_map)
+    T, mp = make_local_map(F, 200 + scene_id, n_map, pos_noise=0.0004)          # MapPoints that re-project within a pixel: PoseOptimization keeps them
     mp = dict(mp, skip=np.zeros(n_map, np.uint8), occupied=np.zeros(F.n, np.uint8))      # a fresh frame: nothing held, nothing seen yet
     src = mp["src"][:n_last]
     ang = np.mod(F.angle[src] + rng.normal(0, 4.0, n_last), 360.0).astype(np.float32)
