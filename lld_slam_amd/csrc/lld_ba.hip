@@ -804,7 +804,7 @@ static int ba_batch_create_impl(lld_ctx* ctx, int n_windows, const lld_ba_window
     A.sp_part = sl.take<double>(n_part * 36 + 2); A.sp_cpart = sl.take<double>(n_cpart * 6 + 2);
     A.records = sl.take<unsigned char>(rec_total + 256);
 #ifdef LLD_EXPERIMENTS
-    A.chol_stamps = exp_flag("LLD_BA_CHOL_STAMPS") ? sl.take<long long>((size_t)n_windows * 8 * kCholStampSlots) : nullptr;
+    A.chol_stamps = exp_flag("LLD_BA_CHOL_STAMPS") ? sl.take<long long>((size_t)n_windows * kCholStampWaves * kCholStampSlots) : nullptr;
 #endif
     B->d_counters = sl.take<int>(4 * 8);
     B->d_slot_map = sl.take<int>(2 * ((size_t)n_windows + 1)); B->d_active_pub = sl.take<int>((size_t)n_windows + 1);
@@ -832,7 +832,7 @@ static int ba_batch_create_impl(lld_ctx* ctx, int n_windows, const lld_ba_window
   lld_slab sl; sl.base = (char*)B->slab; sl.size = bytes;
   carve(sl);
 #ifdef LLD_EXPERIMENTS
-  if (A.chol_stamps && hipMemsetAsync(A.chol_stamps, 0, sizeof(long long) * (size_t)n_windows * 8 * kCholStampSlots, st) != hipSuccess) return fail(LLD_ERR_HIP);
+  if (A.chol_stamps && hipMemsetAsync(A.chol_stamps, 0, sizeof(long long) * (size_t)n_windows * kCholStampWaves * kCholStampSlots, st) != hipSuccess) return fail(LLD_ERR_HIP);
 #endif
   // section A leaves now and travels while the host places section B
   uploads_queued = true;
@@ -1270,11 +1270,11 @@ int lld_ba_batch_set_groups(lld_ba_batch* B, int n_groups) {
 
 #ifdef LLD_EXPERIMENTS
 // experiments build only (LLD_BA_CHOL_STAMPS=1 at create): the s_memtime stamps the LAST ba_chol_mfma_kernel launch of each window left,
-// [n_windows][8][kCholStampSlots] (tools/chol_stage_budget.py)
+// [n_windows][kCholStampWaves][kCholStampSlots] (tools/chol_stage_budget.py)
 __attribute__((visibility("default"))) int lld_exp_chol_stamps(lld_ba_batch* B, long long* out) {
   if (!B || !out || !B->A.chol_stamps) return LLD_ERR_INVALID;
   LLD_HIP_TRY(hipSetDevice(B->ctx->device));
-  LLD_HIP_TRY(hipMemcpy(out, B->A.chol_stamps, sizeof(long long) * (size_t)B->n_windows * 8 * kCholStampSlots, hipMemcpyDeviceToHost));
+  LLD_HIP_TRY(hipMemcpy(out, B->A.chol_stamps, sizeof(long long) * (size_t)B->n_windows * kCholStampWaves * kCholStampSlots, hipMemcpyDeviceToHost));
   return LLD_OK;
 }
 // experiments build only, no device needed: host time of every staging stage of ONE window, as lld_ba_batch_create runs them for a batch of

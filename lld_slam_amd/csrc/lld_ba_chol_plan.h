@@ -28,13 +28,13 @@ namespace lldba {
 
 constexpr int kSpMaxT = 22;          // tile rows of a plan (two padded chains + separator of 50 cameras: at most 22)
 constexpr int kSpStride = 24;        // row length of the per-step tables
-constexpr int kSpTileWaves = 6;      // wavefronts 2..7 hold tiles, wavefronts 0 and 1 are the panel wavefronts of the two chains
-constexpr int kSpSlots = 24;         // register tiles per tile wavefront (24 x 4 doubles per lane)
+constexpr int kSpTileWaves = 10;     // wavefronts 2..11 hold tiles, wavefronts 0 and 1 are the panel wavefronts of the two chains
+constexpr int kSpSlots = 14;         // register tiles per tile wavefront (14 x 4 doubles per lane; 153 VGPRs: three wavefronts per SIMD)
 constexpr int kSpPos = 20;           // tiles per LDS panel buffer (all off-diagonal tiles of the columns of one step)
-constexpr int kSpThreads = 512;
+constexpr int kSpThreads = 768;
 constexpr int kSpNone = 255;
 
-struct CholPlan {
+struct alignas(16) CholPlan {          // (16-byte multiple: the kernel copies the plan into LDS sixteen bytes at a time)
   uint8_t mode;                                   // 0: dense kernel, 1: structure-following kernel
   uint8_t NT, T, chains;                          // tile rows, steps, 1 or 2
   uint8_t cols[kSpStride][2];                     // [step][chain] tile column eliminated in that step (kSpNone: none); steps >= T: none
@@ -53,7 +53,6 @@ struct CholPlan {
   uint32_t yrows[kSpStride][2];                   // per step and chain: tile rows I with L(I, J) != 0: y_I -= L_IJ y_J on the tile wavefronts (the right-hand side is not on the panel's chain)
   int16_t rowmap[kSpMaxT * 16];                   // permuted scalar row -> row of S (-1: padding)
   int32_t n_tiles, n_updates, n_cams, est_ns;     // non-zero tiles incl. fill, tile updates, cameras, estimated time (diagnostics)
-  int32_t pad_[3];
 };
 static_assert(sizeof(CholPlan) % 16 == 0, "the kernel copies the plan into LDS sixteen bytes at a time");
 
@@ -139,7 +138,7 @@ inline bool build_from_segments(int nf, const uint64_t* adj, const std::vector<i
   // MEASURED, round 5: weighting by pipe sharing ({2, 2, 1, 1, 2, 2}: 22 tiles on the two wavefronts next to the panels, 11 on the others) is
   // SLOWER - one launch 58 -> 62 - 69 us: what a tile wavefront's time is made of is its own serial chain of LDS read -> four dependent
   // matrix-core instructions per update, not the pipe's throughput, so equal counts win.  The weights stay as the knob they are.
-  static const int kSlow[kSpTileWaves] = {1, 1, 1, 1, 1, 1};
+  static const int kSlow[16] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
   auto in_step = [&](int K, int s) { return s >= 0 && s < T && (P.cols[s][0] == K || P.cols[s][1] == K); };
   struct TileJob { int I, K, n_ev; uint8_t ev_step[kSpMaxT + 2], ev_cost[kSpMaxT + 2]; };
   std::vector<TileJob> jobs;

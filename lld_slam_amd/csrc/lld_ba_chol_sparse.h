@@ -26,10 +26,10 @@ constexpr int kSpN = kSpMaxT * 16;
 constexpr int kSpLdsDoubles = 2 * kSpPos * kSpTile + kSpMaxT * kSpTile + 2 * kSpTileWaves * 16 + 3 * kSpN + 32;
 // (experiments build: s_memtime stamps are parked in LDS and leave for HBM when the kernel is done - a global store per stamp put a
 // store round trip under the next s_waitcnt vmcnt(0) of every phase it was meant to time, round 5)
-constexpr int kSpStampSlots = 160;
+constexpr int kSpStampSlots = 144;      // 13 + 6 x 21 = 139 is the last one a plan of 22 steps leaves; 32-bit (a launch is 1e5 ticks)
 #ifdef LLD_EXPERIMENTS
-constexpr size_t kSpLdsBytes = kSpLdsDoubles * sizeof(double) + sizeof(CholPlan) + 8 * kSpStampSlots * sizeof(long long);
-#define LLD_SP_STAMP(k) do { if (stamp_lds && lane == 0) stamp_lds[(k)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+constexpr size_t kSpLdsBytes = kSpLdsDoubles * sizeof(double) + sizeof(CholPlan) + (kSpThreads / 64) * kSpStampSlots * sizeof(unsigned);
+#define LLD_SP_STAMP(k) do { if (stamp_lds && lane == 0) stamp_lds[(k)] = (unsigned)__builtin_amdgcn_s_memtime(); } while (0)
 #else
 constexpr size_t kSpLdsBytes = kSpLdsDoubles * sizeof(double) + sizeof(CholPlan);
 #define LLD_SP_STAMP(k) do { } while (0)
@@ -101,12 +101,12 @@ __global__ __launch_bounds__(kSpThreads) void ba_chol_sparse_kernel(BAArrays A, 
   }
   if (tid == 0) *okf = 1.0;
 #ifdef LLD_EXPERIMENTS
-  long long* stamp_lds = A.chol_stamps ? reinterpret_cast<long long*>(reinterpret_cast<char*>(P) + sizeof(CholPlan)) + wave * kSpStampSlots : nullptr;
+  unsigned* stamp_lds = A.chol_stamps ? reinterpret_cast<unsigned*>(reinterpret_cast<char*>(P) + sizeof(CholPlan)) + wave * kSpStampSlots : nullptr;
   if (stamp_lds) for (int i = lane; i < kSpStampSlots; i += 64) stamp_lds[i] = 0;
 #endif
   LLD_SP_STAMP(0);
 #ifdef LLD_EXPERIMENTS
-  if (stamp_lds && lane == 0) stamp_lds[7] = (long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID: SIMD_ID in bits 5:4
+  if (stamp_lds && lane == 0) stamp_lds[7] = (unsigned)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID: SIMD_ID in bits 5:4
 #endif
   __syncthreads();                                                   // B0: the plan is in LDS
   const int NT = P->NT, T = P->T, N = NT << 4;
@@ -412,8 +412,8 @@ __global__ __launch_bounds__(kSpThreads) void ba_chol_sparse_kernel(BAArrays A, 
   LLD_SP_STAMP(6);
 #ifdef LLD_EXPERIMENTS
   if (stamp_lds) {
-    long long* dst = A.chol_stamps + ((size_t)W.win_index * 8 + wave) * kCholStampSlots;
-    for (int i = lane; i < kSpStampSlots; i += 64) dst[i] = stamp_lds[i];
+    long long* dst = A.chol_stamps + ((size_t)W.win_index * kCholStampWaves + wave) * kCholStampSlots;
+    for (int i = lane; i < kSpStampSlots; i += 64) dst[i] = (long long)stamp_lds[i];
   }
 #endif
 }

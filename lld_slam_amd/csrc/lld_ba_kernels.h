@@ -195,10 +195,11 @@ struct BAArrays {
   // results
   unsigned char* records;
 #ifdef LLD_EXPERIMENTS
-  long long* chol_stamps;      // experiments build: [window][8 wavefronts][kCholStampSlots] s_memtime stamps of ba_chol_mfma_kernel's stages
+  long long* chol_stamps;      // experiments build: [window][kCholStampWaves][kCholStampSlots] s_memtime stamps of ba_chol_mfma_kernel's stages
 #endif
 };
 constexpr int kCholStampSlots = 256;
+constexpr int kCholStampWaves = 16;      // wavefront rows per window in BAArrays::chol_stamps (the dense kernel has 8 wavefronts, the structure-following one 12)
 #ifdef LLD_EXPERIMENTS
 #define LLD_CHOL_STAMP(k) do { if (stamp_base && lane == 0) stamp_base[(k)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
 #else
@@ -2309,7 +2310,7 @@ __global__ __launch_bounds__(kCholMThreads) void ba_chol_mfma_kernel(BAArrays A,
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lrow = lane >> 4, lcol = lane & 15;
 #ifdef LLD_EXPERIMENTS
-  long long* stamp_base = A.chol_stamps ? A.chol_stamps + ((size_t)W.win_index * 8 + wave) * kCholStampSlots : nullptr;
+  long long* stamp_base = A.chol_stamps ? A.chol_stamps + ((size_t)W.win_index * kCholStampWaves + wave) * kCholStampSlots : nullptr;
 #endif
   LLD_CHOL_STAMP(0);
   if (tid < N) y[tid] = (tid < n) ? A.bschur[W.x_off + tid] : 0.0;

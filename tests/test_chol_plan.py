@@ -13,12 +13,14 @@ import pytest
 
 from lld_slam_amd import abi, synth
 
-MAXT, STRIDE, WAVES, SLOTS, POS, NONE = 22, 24, 6, 24, 20, 255
-PLAN = np.dtype([("mode", "u1"), ("NT", "u1"), ("T", "u1"), ("chains", "u1"), ("cols", "u1", (STRIDE, 2)),
-                 ("slotI", "u1", (WAVES, SLOTS)), ("slotK", "u1", (WAVES, SLOTS)), ("pos", "u1", (MAXT, STRIDE)),
-                 ("cA", "<u4", (WAVES, STRIDE)), ("cB", "<u4", (WAVES, STRIDE)), ("dA", "<u4", (WAVES, STRIDE)), ("dB", "<u4", (WAVES, STRIDE)),
-                 ("pub", "<u4", (WAVES, STRIDE)), ("own", "<u4", (WAVES, STRIDE)), ("pub0", "<u4", (WAVES,)), ("padmask", "<u4", (WAVES,)), ("yrows", "<u4", (STRIDE, 2)),
-                 ("rowmap", "<i2", (MAXT * 16,)), ("n_tiles", "<i4"), ("n_updates", "<i4"), ("n_cams", "<i4"), ("est_ns", "<i4"), ("pad_", "<i4", (3,))])
+MAXT, STRIDE, WAVES, SLOTS, POS, NONE = 22, 24, 10, 14, 20, 255          # kSpMaxT, kSpStride, kSpTileWaves, kSpSlots, kSpPos, kSpNone of lld_ba_chol_plan.h
+_FIELDS = [("mode", "u1"), ("NT", "u1"), ("T", "u1"), ("chains", "u1"), ("cols", "u1", (STRIDE, 2)),
+           ("slotI", "u1", (WAVES, SLOTS)), ("slotK", "u1", (WAVES, SLOTS)), ("pos", "u1", (MAXT, STRIDE)),
+           ("cA", "<u4", (WAVES, STRIDE)), ("cB", "<u4", (WAVES, STRIDE)), ("dA", "<u4", (WAVES, STRIDE)), ("dB", "<u4", (WAVES, STRIDE)),
+           ("pub", "<u4", (WAVES, STRIDE)), ("own", "<u4", (WAVES, STRIDE)), ("pub0", "<u4", (WAVES,)), ("padmask", "<u4", (WAVES,)), ("yrows", "<u4", (STRIDE, 2)),
+           ("rowmap", "<i2", (MAXT * 16,)), ("n_tiles", "<i4"), ("n_updates", "<i4"), ("n_cams", "<i4"), ("est_ns", "<i4")]
+_raw = np.dtype(_FIELDS, align=True)
+PLAN = np.dtype(_FIELDS + [("tail_pad", "u1", ((-_raw.itemsize) % 16,))] if _raw.itemsize % 16 else _FIELDS, align=True)      # struct alignas(16)
 
 
 def get_plan(nz, force=0):
@@ -231,7 +233,7 @@ def test_the_metric_window_gets_two_chains():
 
 
 def test_dense_systems_go_to_the_dense_kernel_when_they_do_not_fit():
-    assert int(check(np.ones((50, 50), bool), expect_mode=0)["mode"]) == 0        # 190 tiles: more than the 144 register slots
+    assert int(check(np.ones((50, 50), bool), expect_mode=0)["mode"]) == 0        # 190 tiles: more than the 140 register slots
     P = check(np.ones((40, 40), bool), seed=3, expect_mode=1)                        # 120 tiles: fits, one chain
     assert int(P["chains"]) == 1 and int(P["NT"]) == 15
 

@@ -31,12 +31,13 @@ def main():
     plan = TP.get_plan(TP.window_pattern(ws[0]), int(os.environ.get("LLD_BA_CHOL_FORCE", "0")))
     with Context(0, lib=lib) as ctx, BABatch(ctx, ws) as b:
         b.solve(); b.solve()
-        st = np.zeros((nw, 8, SLOTS), dtype=np.int64)
+        st = np.zeros((nw, 16, SLOTS), dtype=np.int64)
         fn = lib.dll.lld_exp_chol_stamps
         fn.argtypes = [C.c_void_p, C.c_void_p]; fn.restype = C.c_int
         assert fn(b.handle, st.ctypes.data) == 0
         ph = b.phase_ms(); n_solve, ms_solve = b.kernel_stats(2)
     tick_ns = float(os.environ.get("LLD_TICK_NS", str(1 / 2.4)))
+    st = st[:, :12]                                             # 2 panel + 10 tile wavefronts; stamps are the low 32 bits of s_memtime
     s = st[0].astype(np.float64) * tick_ns
     t0 = s[:, 0][st[0][:, 0] != 0].min()
     s = np.where(st[0] != 0, s - t0, np.nan)
@@ -48,7 +49,7 @@ def main():
     print(f"kernel (stamp 0 -> 6, slowest wavefront): {np.nanmax(s[:, 6]) / 1e3:.1f} us")
     print(f"  plan -> LDS + S -> registers (tile waves, slowest, stamp 1): {np.nanmax(TW[:, 1]) / 1e3:.2f} us   panel A's own first factor done at {PA[1] / 1e3:.2f} us   prologue publish done at {np.nanmax(TW[:, 2]) / 1e3:.2f} us")
     print(f"  all steps (panel A stamp 3 -> 4): {(PA[4] - PA[3]) / 1e3:.2f} us    back substitution (4 -> 5): {(PA[5] - PA[4]) / 1e3:.2f} us    epilogue (5 -> 6): {(np.nanmax(s[:, 6]) - PA[5]) / 1e3:.2f} us")
-    print("  SIMD of the wavefronts 0..7 (HW_ID bits 5:4):", [int(st[0][w, 7]) >> 4 & 3 for w in range(8)], "  slots used per tile wavefront:", [int((plan["slotI"][w] != 255).sum()) for w in range(6)])
+    print("  SIMD of the wavefronts 0..11 (HW_ID bits 5:4):", [int(st[0][w, 7]) >> 4 & 3 for w in range(12)], "  slots used per tile wavefront:", [int((plan["slotI"][w] != 255).sum()) for w in range(10)])
     print()
     print("per step (ns):  columns | panel A: own L_(Jn)J + diag update | wait(c) | factor | wait(d)   panel B: same   tile waves (slowest): L_IJ + y_J | wait | fetch + updates | publish + y | wait    step total")
     for k in range(T):

@@ -31,12 +31,13 @@ def main():
     ws = [synth.make_lba_b(i) for i in range(nw)]
     with Context(0, lib=lib) as ctx, BABatch(ctx, ws) as b:
         b.solve(); b.solve()
-        st = np.zeros((nw, 8, SLOTS), dtype=np.int64)
+        st = np.zeros((nw, 16, SLOTS), dtype=np.int64)
         fn = lib.dll.lld_exp_chol_stamps
         fn.argtypes = [C.c_void_p, C.c_void_p]; fn.restype = C.c_int
         assert fn(b.handle, st.ctypes.data) == 0
         ph = b.phase_ms(); n_solve, ms_solve = b.kernel_stats(2)
     tick_ns = float(os.environ.get("LLD_TICK_NS", str(1 / 2.4)))       # s_memtime tick = shader cycle
+    st = st[:, :8]
     s = st[0].astype(np.float64) * tick_ns
     t0 = s[:, 0].min()
     s = np.where(st[0] != 0, s - t0, np.nan)

@@ -73,7 +73,7 @@ for it in range(n):
     if w.n_edges() == 0 and rng.random() < 0.8: continue
     try:
         o = O.local_ba(w, **par)
-        solver = int(rng.choice([0, 0, 1, 2])) if n_free <= 50 else 0
+        solver = int(rng.choice([0, 0, 0, 1, 2, 3, 4, 5])) if n_free <= 50 else 0      # round 5: 0 = structure-following (auto plan), 3 dense, 4 one chain, 5 two chains only
         g = Optimizer(ctx).LocalBundleAdjustment(w, reduced_solver=solver, **par)
         check_ba(g, o, w, tail="pcg" if (solver == 1 or n_free > 50) else None)      # the strict bar (every landmark to 1e-5, no twins: what exceeds it is classified below) unless the reduced solve is iterative
         done += 1
