@@ -267,15 +267,12 @@ inline bool build(int nf, const uint64_t* adj, int force, CholPlan& best, CholPl
   for (int i = 0; i < nf; i++) nat[i] = i;
   std::vector<std::vector<int>> orders;
   orders.push_back(nat);
-  if (force != 1) { std::vector<int> rc = rcm_order(nf, adj); if (rc != nat) orders.push_back(rc); }
   struct Cand { int T, NT, order, m, side; };
   std::vector<Cand> cands;
-  for (size_t oi = 0; oi < orders.size(); oi++) {
-    const std::vector<int>& pi = orders[oi];
-    if (force != 2) consider(std::vector<int>(), std::vector<int>(), pi, (int)oi, 0, 0);
-    if (force == 1) break;
-    // two chains: cut the order at m; the separator is the side of the cut that touches the other one.  Every cut is priced by its
-    // chain length first (bit operations), the few shortest are built
+  // two chains: cut the order at m; the separator is the side of the cut that touches the other one.  Every cut is priced by its chain
+  // length first (bit operations), the shortest are built
+  auto price_cuts = [&](int oi) {
+    const std::vector<int>& pi = orders[(size_t)oi];
     uint64_t left = 0, right = 0;
     for (int i = 0; i < nf; i++) right |= 1ull << pi[i];
     for (int m = 1; m < nf; m++) {
@@ -291,15 +288,22 @@ inline bool build(int nf, const uint64_t* adj, int force, CholPlan& best, CholPl
         if (na < 1 || nb < 1) continue;
         const int Tc = std::max(tiles_of(na), tiles_of(nb)) + tiles_of(nsep), NTc = tiles_of(na) + tiles_of(nb) + tiles_of(nsep);
         if (Tc >= tiles_of(nf) || NTc > kSpMaxT) continue;     // worth it only if the chain gets shorter than one chain over everything
-        cands.push_back(Cand{Tc, NTc, (int)oi, m, side});
+        cands.push_back(Cand{Tc, NTc, oi, m, side});
       }
     }
+  };
+  if (force != 1) {
+    price_cuts(0);
+    int best_T = 1 << 30;
+    for (const Cand& c : cands) best_T = std::min(best_T, c.T);
+    // the caller's order already splits well (a trajectory: keyframes in time order): no need to look for a hidden band
+    if (best_T * 4 > tiles_of(nf) * 3) { std::vector<int> rc = rcm_order(nf, adj); if (rc != nat) { orders.push_back(rc); price_cuts(1); } }
   }
   std::stable_sort(cands.begin(), cands.end(), [](const Cand& a, const Cand& b) { return a.T != b.T ? a.T < b.T : a.NT < b.NT; });
   int built = 0;
   for (const Cand& c : cands) {
-    if (built >= 3) break;
-    const std::vector<int>& pi = orders[c.order];
+    if (built >= 1) break;                               // (the price is the chain length: the first one that fits the kernel is the plan)
+    const std::vector<int>& pi = orders[(size_t)c.order];
     uint64_t left = 0, right = 0;
     for (int i = 0; i < nf; i++) (i < c.m ? left : right) |= 1ull << pi[i];
     std::vector<int> a, b, s;
@@ -310,11 +314,11 @@ inline bool build(int nf, const uint64_t* adj, int force, CholPlan& best, CholPl
       if (touches && (in_left ? c.side == 0 : c.side == 1)) s.push_back(v);
       else (in_left ? a : b).push_back(v);
     }
-    const bool had = have; const int before = have ? best.est_ns : 0;
     consider(a, b, s, c.order, c.m, c.side);
     if (P.mode == 1) built++;
-    (void)had; (void)before;
   }
+  if (!have && force != 2)                               // one chain: the caller's order, or the band an RCM order finds, whichever is estimated faster
+    for (size_t oi = 0; oi < orders.size(); oi++) consider(std::vector<int>(), std::vector<int>(), orders[oi], (int)oi, 0, 0);
   return have;
 }
 
