@@ -1463,6 +1463,51 @@ __device__ __forceinline__ void schur_stage_one(bool a, const double* v, double 
   }
 }
 
+// The same for a POINT edge, from the structure of its block (round 5).  W = ws Jc^T Jp = [ [Xc]x G ; G ] with G = ws (A^T A) R
+// (point_hpl_closed_iz), hence Z = W L^-T = [ [Xc]x H ; H ] with H = G L^-T: the triangular solve runs on three rows instead of six and the
+// three cross products act on H instead of on G - 18 multiply-adds less per (landmark, slot) of the ~200 a staging lane spends.
+// `G`: rows g0, g1, g2 of G (G[r * 3 + j]); Xc: the point in the camera frame.
+__device__ __forceinline__ void schur_stage_point(bool a, const double* v, double lambda, const double* G, const Vec3& Xc, double* zl, double* tl, bool write_t) {
+  double L[6], idg[3];
+  if (!a) {
+#pragma unroll
+    for (int i = 0; i < 18; i += 2) *reinterpret_cast<double2*>(zl + i) = make_double2(0.0, 0.0);
+    if (write_t) { tl[0] = 0.0; tl[1] = 0.0; tl[2] = 0.0; }
+    return;
+  }
+  chol_packed<3>(v, lambda, L, idg);
+  double z[18];
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      double sacc = G[r * 3 + c];
+#pragma unroll
+      for (int m = 0; m < c; m++) sacc -= z[(3 + r) * 3 + m] * L[c * (c + 1) / 2 + m];
+      z[(3 + r) * 3 + c] = sacc * idg[c];
+    }
+#pragma unroll
+  for (int c = 0; c < 3; c++) {                              // Xc x (column c of H)
+    const double h0 = z[9 + c], h1 = z[12 + c], h2 = z[15 + c];
+    z[c] = Xc.y * h2 - Xc.z * h1;
+    z[3 + c] = Xc.z * h0 - Xc.x * h2;
+    z[6 + c] = Xc.x * h1 - Xc.y * h0;
+  }
+#pragma unroll
+  for (int i = 0; i < 18; i += 2) *reinterpret_cast<double2*>(zl + i) = make_double2(z[i], z[i + 1]);
+  if (write_t) {
+    double t[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      double sacc = v[6 + c];
+#pragma unroll
+      for (int m = 0; m < c; m++) sacc -= t[m] * L[c * (c + 1) / 2 + m];
+      t[c] = sacc * idg[c];
+    }
+    tl[0] = t[0]; tl[1] = t[1]; tl[2] = t[2];
+  }
+}
+
 // A landmark with more than kSchurWideK free observations (global BA of a long track): no pipelining and no register accumulators -
 // the whole workgroup stages the landmark's k blocks, then thread t adds the products of the pairs t, t + 256, ... into the chunk's
 // partials in HBM (one writer per pair, landmarks in order: deterministic).  Such chunks hold a handful of landmarks.
@@ -1537,6 +1582,13 @@ __device__ __forceinline__ void schur_chunk_wave(const BAArrays& A, const BAWin&
   // stage lane <-> (landmark ej, slot esl) of a sub-batch
   const int ej = lane / k, esl = lane - ej * k;
   const bool stager = lane < NB * k;
+  // the lanes of the per-slot vector pass: slot cslot, interleave ci of cq
+  const int cq = (64 / k) < NB ? (64 / k) : NB;
+  const int ci = lane / k, cslot = lane - ci * k;
+  const bool con = ci < cq;
+  double cacc[6];
+#pragma unroll
+  for (int i = 0; i < 6; i++) cacc[i] = 0.0;
   for (int pass0 = 0; pass0 < np; pass0 += 64) {
     const int units = (np - pass0) < 64 ? (np - pass0) : 64;        // slot pairs of this pass
     const int q = 64 / units;                                       // landmarks worked on at a time
@@ -1546,11 +1598,9 @@ __device__ __forceinline__ void schur_chunk_wave(const BAArrays& A, const BAWin&
     while (rem >= k - sa) { rem -= k - sa; sa++; }
     const int sb = sa + rem;
     const bool diag = sa == sb;
-    double acc[36], cacc[6];
+    double acc[36];
 #pragma unroll
     for (int i = 0; i < 36; i++) acc[i] = 0.0;
-#pragma unroll
-    for (int i = 0; i < 6; i++) cacc[i] = 0.0;
     // The staging runs one sub-batch AHEAD of its loads' latency: the camera pose of a lane's slot is loop-invariant, the landmark /
     // edge indices are fetched two sub-batches ahead and the landmark data one ahead, so the two dependent HBM/L2 round trips
     // (index -> data) of a sub-batch overlap the block products of the previous one.  Bytes stay as loaded (a_n, fl_n): turning
@@ -1599,8 +1649,12 @@ __device__ __forceinline__ void schur_chunk_wave(const BAArrays& A, const BAWin&
       __syncthreads();                                      // the previous sub-batch has been consumed
       if (stager && ej < nb) {
         // point edge: the Hpl block is a function of the linearisation-point pose, point and one weight
-        if constexpr (D == 3) { const Vec3 Xc = mat_mul(Rt, X) + T.t; point_hpl_closed_iz(W.cam, Xc, rcp_nr(Xc.z), Rt, signbit(ws), fabs(ws), w); }
-        schur_stage_one<D>(a_raw != 0, v, lambda, w, Zl + lane * WS, tl + ej * D, esl == 0);
+        if constexpr (D == 3) {
+          const Vec3 Xc = mat_mul(Rt, X) + T.t;
+          double G[9];
+          point_g_closed_iz(W.cam, Xc, rcp_nr(Xc.z), Rt, signbit(ws), fabs(ws), G);
+          schur_stage_point(a_raw != 0, v, lambda, G, Xc, Zl + lane * WS, tl + ej * D, esl == 0);
+        } else schur_stage_one<D>(a_raw != 0, v, lambda, w, Zl + lane * WS, tl + ej * D, esl == 0);
       }
       __syncthreads();
       if (on) {
@@ -1610,9 +1664,6 @@ __device__ __forceinline__ void schur_chunk_wave(const BAArrays& A, const BAWin&
           double b[WN];
 #pragma unroll
           for (int i = 0; i < WN; i += 2) { const double2 t2 = *reinterpret_cast<const double2*>(zb + i); b[i] = t2.x; b[i + 1] = t2.y; }
-          double tv[D];
-#pragma unroll
-          for (int m = 0; m < D; m++) tv[m] = diag ? tl[j * D + m] : 0.0;
 #pragma unroll
           for (int rp = 0; rp < 3; rp++) {                   // two rows of Z_a at a time: 16-byte LDS reads
             double a2[2 * D];
@@ -1628,11 +1679,26 @@ __device__ __forceinline__ void schur_chunk_wave(const BAArrays& A, const BAWin&
                 for (int m = 0; m < D; m++) s0 = fma(a2[rr * D + m], b[cc * D + m], s0);
                 acc[r * 6 + cc] = s0;
               }
-              double s1 = cacc[r];
-#pragma unroll
-              for (int m = 0; m < D; m++) s1 = fma(a2[rr * D + m], tv[m], s1);
-              cacc[r] = s1;
             }
+          }
+        }
+      }
+      // Y_a b_l = Z_a (L^-1 b_l), one 6-vector per slot: lane <-> (slot, interleave) in a pass of its own (round 5).  Inside the product loop
+      // every lane carried these 6 x D multiply-adds per landmark although only the k diagonal pairs of the k (k + 1) / 2 keep them.
+      if (pass0 == 0 && con) {
+        for (int j = ci; j < nb; j += cq) {
+          const double* za = Zl + (j * k + cslot) * WS;
+          double a[WN], tv[D];
+#pragma unroll
+          for (int i = 0; i < WN; i += 2) { const double2 t2 = *reinterpret_cast<const double2*>(za + i); a[i] = t2.x; a[i + 1] = t2.y; }
+#pragma unroll
+          for (int m = 0; m < D; m++) tv[m] = tl[j * D + m];
+#pragma unroll
+          for (int r = 0; r < 6; r++) {
+            double s1 = cacc[r];
+#pragma unroll
+            for (int m = 0; m < D; m++) s1 = fma(a[r * D + m], tv[m], s1);
+            cacc[r] = s1;
           }
         }
       }
@@ -1642,20 +1708,24 @@ __device__ __forceinline__ void schur_chunk_wave(const BAArrays& A, const BAWin&
       const bool take = (qq % (2 * sft)) == 0 && qq + sft < q;
 #pragma unroll
       for (int i = 0; i < 36; i++) { const double o = __shfl_down(acc[i], sft * units); if (take) acc[i] += o; }
-#pragma unroll
-      for (int i = 0; i < 6; i++) { const double o = __shfl_down(cacc[i], sft * units); if (take) cacc[i] += o; }
     }
     if (on && qq == 0) {
       // plain stores of the chunk's partial products; ba_schur_reduce sums them into S in a fixed order (no atomics)
       double* dst = A.sp_part + (size_t)(C.part_off + pass0 + pl) * 36;
 #pragma unroll
       for (int i = 0; i < 36; i += 2) *reinterpret_cast<double2*>(dst + i) = make_double2(acc[i], acc[i + 1]);
-      if (diag) {
-        double* cd = A.sp_cpart + (size_t)(C.cpart_off + sa) * 6;
-#pragma unroll
-        for (int i = 0; i < 6; i += 2) *reinterpret_cast<double2*>(cd + i) = make_double2(cacc[i], cacc[i + 1]);
-      }
     }
+  }
+  // the slot vectors: sum over the interleave (lanes cslot + k * ci), a fixed shuffle tree, result in the lanes ci == 0
+  for (int sft = 1; sft < cq; sft <<= 1) {
+    const bool take = (ci % (2 * sft)) == 0 && ci + sft < cq;
+#pragma unroll
+    for (int i = 0; i < 6; i++) { const double o = __shfl_down(cacc[i], sft * k); if (take) cacc[i] += o; }
+  }
+  if (ci == 0) {                                            // (lanes 0 .. k - 1)
+    double* cd = A.sp_cpart + (size_t)(C.cpart_off + cslot) * 6;
+#pragma unroll
+    for (int i = 0; i < 6; i += 2) *reinterpret_cast<double2*>(cd + i) = make_double2(cacc[i], cacc[i + 1]);
   }
 }
 

@@ -273,6 +273,24 @@ LLD_HD void point_hpl_closed_iz(const CamK& k, const Vec3& Xc, double iz, const 
   }
 }
 
+// G = ws (A^T A) R of the block above alone (rows g0, g1, g2: G[r * 3 + j]); W = [ [Xc]x G ; G ].  The Schur staging applies L^-T to G first
+// and the cross products afterwards (lld_ba_kernels.h schur_stage_point).
+LLD_HD void point_g_closed_iz(const CamK& k, const Vec3& Xc, double iz, const Mat3& R, bool stereo, double ws, double* G) {
+  const double iz2 = iz * iz;
+  const double a = k.fx * iz, b = k.fy * iz;
+  const double c0 = -k.fx * Xc.x * iz2, c1 = -k.fy * Xc.y * iz2, c2 = c0 + k.bf * iz2;
+  const double m00 = ws * (stereo ? 2.0 * a * a : a * a);
+  const double m02 = ws * (stereo ? a * (c0 + c2) : a * c0);
+  const double m11 = ws * (b * b), m12 = ws * (b * c1);
+  const double m22 = ws * (stereo ? c0 * c0 + c1 * c1 + c2 * c2 : c0 * c0 + c1 * c1);
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    G[j] = m00 * R.m[0][j] + m02 * R.m[2][j];
+    G[3 + j] = m11 * R.m[1][j] + m12 * R.m[2][j];
+    G[6 + j] = m02 * R.m[0][j] + m12 * R.m[1][j] + m22 * R.m[2][j];
+  }
+}
+
 // ---------------------------------------------------------------- line edges
 // Residual of EdgeSE3ProjectLine / OnlyPose (types_six_dof_expmap.h:344-375, :403-418) plus, optionally, the adjoint
 // vectors a1,a2 with  d r_k = a1[k] . dX1m + a2[k] . dX2m  (X1m, X2m = endpoints in the camera frame, without b).
