@@ -139,73 +139,106 @@ def sharded_secondary(ctx, dev, world, rank, repeats=5):
     """N > 1: the PO frames and the ORB / LBD frame pairs of the `secondary` block split over the ranks (north_star: "independent local-BA
     windows and frame-pair match batches shard embarrassingly across the 8 GPUs ... RCCL only for the final gather").  Every rank solves
     its contiguous share (dist.shard, strong form: the totals are the config's), the rate is total items / the slowest rank's median
-    launch, and the result rows travel to rank 0 through dist.gather_rows.  No CPU legs here (N = 1 carries them)."""
+    launch, and the result rows travel to rank 0 through dist.gather_rows.  No CPU legs here (N = 1 carries them).
+    Every leg is `local work -> all ranks agree that it went well -> collectives`: a rank that fails locally (allocation, an assert) tells
+    the others through ONE all-reduce that every rank always reaches, and all of them skip the leg's collectives together - a rank alone in
+    a collective would hang the job until RCCL's timeout."""
     import numpy as np
     import torch
     from lld_slam_amd import PoseBatch, dist as D, synth
     timer = StreamTimer(ctx)
     out = {}
+
+    def leg(name, local, collect):
+        err = None; data = None
+        try:
+            data = local()
+        except Exception as ex:
+            err = repr(ex)[:300]
+        if not D.all_ranks_ok(err is None, dev, True):
+            out[name] = {"error": err or "another rank failed in this leg; its collectives were skipped on every rank"}
+            return
+        out[name] = collect(data)
+
     def agg(n_total, med_ms, counts, unit, workload, extra=None):
         worst = D.max_over_ranks(med_ms, dev, True)
         r = {"workload": workload, "value": round(n_total / (worst * 1e-3), 1), "unit": unit, "n_gpus": world, "items_per_rank": counts,
              "slowest_rank_median_launch_ms": round(worst, 4), "this_rank_median_launch_ms": round(med_ms, 4)}
         if extra: r.update(extra)
         return r
+
     # ---- PoseOptimization
     nf = 4096
-    f0, fc = D.shard(nf, world, rank, True)
-    distinct = [synth.make_pose_frame(i) for i in range(64)]
-    frames = [distinct[(f0 + i) % 64] for i in range(fc)]
-    with PoseBatch(ctx, frames, gamma=0.5) as b:
-        b.solve(); ctx.synchronize()
-        ms = [timer.time_ms(b.solve) for _ in range(repeats)]
-        res = [b.download(i) for i in range(fc)]
-    rows = torch.from_numpy(np.array([list(r.pose_qt) + [float(r.n_inliers)] for r in res], np.float64).reshape(fc, 8)).to(dev)
-    counts = D.gather_counts(fc, dev, True, world)
-    got = D.gather_rows(rows, counts, world, rank)
-    ok = None
-    if rank == 0:
-        allr = torch.cat(got).cpu().numpy()
-        # frame i of the whole set is distinct[i % 64]: equal inputs must have given equal rows on whatever rank they ran
-        ok = bool(allr.shape == (nf, 8) and np.isfinite(allr).all() and all(np.allclose(allr[i, :7], allr[i % 64, :7], rtol=0, atol=1e-12) for i in range(0, nf, 97)))
-    out["pose_opt"] = agg(nf, float(np.median(ms)), counts, "frames/s", f"{nf} PO frames split over {world} GPUs, 1000 stereo point + 400 line edges each, 4 x 10 LM iterations",
-                          {"gathered_rows_ok": ok})
+    def po_local():
+        f0, fc = D.shard(nf, world, rank, True)
+        distinct = [synth.make_pose_frame(i) for i in range(64)]
+        frames = [distinct[(f0 + i) % 64] for i in range(fc)]
+        with PoseBatch(ctx, frames, gamma=0.5) as b:
+            b.solve(); ctx.synchronize()
+            ms = [timer.time_ms(b.solve) for _ in range(repeats)]
+            res = [b.download(i) for i in range(fc)]
+        rows = torch.from_numpy(np.array([list(r.pose_qt) + [float(r.n_inliers)] for r in res], np.float64).reshape(fc, 8)).to(dev)
+        return fc, ms, rows
+    def po_collect(d):
+        fc, ms, rows = d
+        counts = D.gather_counts(fc, dev, True, world)
+        got = D.gather_rows(rows, counts, world, rank)
+        ok = None
+        if rank == 0:
+            allr = torch.cat(got).cpu().numpy()
+            # frame i of the whole set is distinct[i % 64]: equal inputs must have given equal rows on whatever rank they ran
+            ok = bool(allr.shape == (nf, 8) and np.isfinite(allr).all() and all(np.allclose(allr[i, :7], allr[i % 64, :7], rtol=0, atol=1e-12) for i in range(0, nf, 97)))
+        return agg(nf, float(np.median(ms)), counts, "frames/s", f"{nf} PO frames split over {world} GPUs, 1000 stereo point + 400 line edges each, 4 x 10 LM iterations",
+                   {"gathered_rows_ok": ok})
+    leg("pose_opt", po_local, po_collect)
+
     # ---- ORB / LBD
     B = 1024
     p0, pc = D.shard(B, world, rank, True)
     nq = nt = 2000
-    qs, ts = zip(*[synth.make_match_orb(i, nq, nt) for i in range(8)])
-    q = torch.from_numpy(np.stack([qs[(p0 + i) % 8] for i in range(pc)]).view(np.int32)).to(dev); tt = torch.from_numpy(np.stack([ts[(p0 + i) % 8] for i in range(pc)]).view(np.int32)).to(dev)
-    outs = [torch.empty((pc, nq), dtype=torch.int32, device=dev) for _ in range(4)]
-    fn = ctx.lib.fn("match_hamming256_batch_dev")
-    def run_orb():
-        assert fn(ctx.handle, pc, q.data_ptr(), nq, tt.data_ptr(), nt, *[o.data_ptr() for o in outs]) == 0
-    torch.cuda.synchronize(); run_orb(); ctx.synchronize()
-    ms = [timer.time_ms(run_orb) for _ in range(repeats)]
-    counts = D.gather_counts(pc, dev, True, world)
-    got = D.gather_rows(torch.stack(outs, 2), counts, world, rank)            # [pairs, queries, 4] int32
-    ok = None
-    if rank == 0:
-        allm = torch.cat(got)
-        ok = bool(tuple(allm.shape) == (B, nq, 4) and all(bool(torch.equal(allm[i], allm[i % 8])) for i in range(0, B, 61)))
-    out["orb_hamming256"] = agg(B, float(np.median(ms)), counts, "frame pairs/s", f"{B} frame pairs split over {world} GPUs, {nq} x {nt} 256-bit ORB descriptors", {"gathered_rows_ok": ok})
-    del q, tt, outs
+    def orb_local():
+        qs, ts = zip(*[synth.make_match_orb(i, nq, nt) for i in range(8)])
+        q = torch.from_numpy(np.stack([qs[(p0 + i) % 8] for i in range(pc)]).view(np.int32)).to(dev); tt = torch.from_numpy(np.stack([ts[(p0 + i) % 8] for i in range(pc)]).view(np.int32)).to(dev)
+        outs = [torch.empty((pc, nq), dtype=torch.int32, device=dev) for _ in range(4)]
+        fn = ctx.lib.fn("match_hamming256_batch_dev")
+        def run_orb():
+            assert fn(ctx.handle, pc, q.data_ptr(), nq, tt.data_ptr(), nt, *[o.data_ptr() for o in outs]) == 0
+        torch.cuda.synchronize(); run_orb(); ctx.synchronize()
+        ms = [timer.time_ms(run_orb) for _ in range(repeats)]
+        return ms, torch.stack(outs, 2)
+    def orb_collect(d):
+        ms, rows = d
+        counts = D.gather_counts(pc, dev, True, world)
+        got = D.gather_rows(rows, counts, world, rank)            # [pairs, queries, 4] int32
+        ok = None
+        if rank == 0:
+            allm = torch.cat(got)
+            ok = bool(tuple(allm.shape) == (B, nq, 4) and all(bool(torch.equal(allm[i], allm[i % 8])) for i in range(0, B, 61)))
+        return agg(B, float(np.median(ms)), counts, "frame pairs/s", f"{B} frame pairs split over {world} GPUs, {nq} x {nt} 256-bit ORB descriptors", {"gathered_rows_ok": ok})
+    leg("orb_hamming256", orb_local, orb_collect)
+
     n1 = n2 = 300; Dd = 72
-    ql, tl = zip(*[synth.make_match_lbd(i, n1, n2, Dd) for i in range(8)])
-    q2 = torch.from_numpy(np.stack([ql[(p0 + i) % 8] for i in range(pc)])).to(dev); t2 = torch.from_numpy(np.stack([tl[(p0 + i) % 8] for i in range(pc)])).to(dev)
-    bi = torch.empty((pc, n1), dtype=torch.int32, device=dev); si = torch.empty_like(bi)
-    bd = torch.empty((pc, n1), dtype=torch.float64, device=dev); sd = torch.empty_like(bd)
-    fn2 = ctx.lib.fn("match_l2f32_batch_dev")
-    def run_lbd():
-        assert fn2(ctx.handle, pc, q2.data_ptr(), n1, t2.data_ptr(), n2, Dd, bi.data_ptr(), bd.data_ptr(), si.data_ptr(), sd.data_ptr()) == 0
-    torch.cuda.synchronize(); run_lbd(); ctx.synchronize()
-    ms = [timer.time_ms(run_lbd) for _ in range(repeats)]
-    got = D.gather_rows(torch.stack([bi, si], 2), counts, world, rank)
-    ok = None
-    if rank == 0:
-        allm = torch.cat(got)
-        ok = bool(tuple(allm.shape) == (B, n1, 2) and all(bool(torch.equal(allm[i], allm[i % 8])) for i in range(0, B, 61)))
-    out["lbd_l2f32"] = agg(B, float(np.median(ms)), counts, "frame pairs/s", f"{B} frame pairs split over {world} GPUs, {n1} x {n2} LBD descriptors of {Dd} floats", {"gathered_rows_ok": ok})
+    def lbd_local():
+        ql, tl = zip(*[synth.make_match_lbd(i, n1, n2, Dd) for i in range(8)])
+        q2 = torch.from_numpy(np.stack([ql[(p0 + i) % 8] for i in range(pc)])).to(dev); t2 = torch.from_numpy(np.stack([tl[(p0 + i) % 8] for i in range(pc)])).to(dev)
+        bi = torch.empty((pc, n1), dtype=torch.int32, device=dev); si = torch.empty_like(bi)
+        bd = torch.empty((pc, n1), dtype=torch.float64, device=dev); sd = torch.empty_like(bd)
+        fn2 = ctx.lib.fn("match_l2f32_batch_dev")
+        def run_lbd():
+            assert fn2(ctx.handle, pc, q2.data_ptr(), n1, t2.data_ptr(), n2, Dd, bi.data_ptr(), bd.data_ptr(), si.data_ptr(), sd.data_ptr()) == 0
+        torch.cuda.synchronize(); run_lbd(); ctx.synchronize()
+        ms = [timer.time_ms(run_lbd) for _ in range(repeats)]
+        return ms, torch.stack([bi, si], 2)
+    def lbd_collect(d):
+        ms, rows = d
+        counts = D.gather_counts(pc, dev, True, world)
+        got = D.gather_rows(rows, counts, world, rank)
+        ok = None
+        if rank == 0:
+            allm = torch.cat(got)
+            ok = bool(tuple(allm.shape) == (B, n1, 2) and all(bool(torch.equal(allm[i], allm[i % 8])) for i in range(0, B, 61)))
+        return agg(B, float(np.median(ms)), counts, "frame pairs/s", f"{B} frame pairs split over {world} GPUs, {n1} x {n2} LBD descriptors of {Dd} floats", {"gathered_rows_ok": ok})
+    leg("lbd_l2f32", lbd_local, lbd_collect)
     return out
 
 

@@ -173,6 +173,8 @@ typedef struct {
                                until round 4. */
 } lld_ba_params;
 
+/* ALWAYS start from lld_ba_params_default(): a zero-initialised struct is NOT the default (deterministic = 0 selects the shared-accumulator
+ * mode, its_* = 0 is refused), and fields added by later versions get their defaults here. */
 void lld_ba_params_default(lld_ba_params* p);
 
 typedef struct {

@@ -674,6 +674,8 @@ static int ba_batch_create_impl(lld_ctx* ctx, int n_windows, const lld_ba_window
     n_threads = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
     if (g_big_solves_running[ctx->device & 63].load(std::memory_order_relaxed) > 0) n_threads = std::min(n_threads, kStagingThreadsUnderSolve);
     if (const char* e = std::getenv("LLD_HOST_THREADS")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) n_threads = v; }
+    // (the cap that protects a solve in flight holds under the override too: bench.py sets LLD_HOST_THREADS for every rank of an N > 1 run)
+    if (g_big_solves_running[ctx->device & 63].load(std::memory_order_relaxed) > 0) n_threads = std::min(n_threads, std::max(kStagingThreadsUnderSolve, 1));
     n_threads = std::min(n_threads, n_windows);
   }
   std::atomic<int> first_error{LLD_OK};

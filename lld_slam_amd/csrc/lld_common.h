@@ -37,6 +37,7 @@ struct lld_ctx {
   void* poll = nullptr;
   // kernel attributes are per device: remembered per context, not in a process-wide static (a process may hold contexts on several GPUs)
   bool orb_lds_raised = false;
+  unsigned pose_lds_raised = 0;            // one bit per pose_opt_kernel instantiation (lld_pose.hip pose_launch_as)
   // Resources of the batched local BA that outlive a batch.  A pipelined caller creates one batch after another on the same
   // context (one context per host thread): allocating a multi-gigabyte slab per batch and, worse, freeing it (hipFree synchronises
   // the device, stalling every other context's solve) was most of the host-buffer rate, and so were pageable uploads.  At most one

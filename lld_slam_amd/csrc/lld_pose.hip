@@ -672,8 +672,13 @@ static PoseArrays pose_arrays(char* d, const PoseLayout& Y) {
 }
 
 template <bool kLds, typename OT, int kThreads>
-static int pose_launch_as(hipStream_t st, int n_frames, size_t lds_bytes, const PoseFrameDev* fr, const PoseArrays& A, PoseOut* po, const lld_pose_params& prm) {
-  if (kLds) LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&pose_opt_kernel<kLds, OT, kThreads>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPoseLdsBudget));
+static int pose_launch_as(lld_ctx* ctx, hipStream_t st, int n_frames, size_t lds_bytes, const PoseFrameDev* fr, const PoseArrays& A, PoseOut* po, const lld_pose_params& prm) {
+  // the dynamic-LDS ceiling of an instantiation is raised ONCE per context (a driver call on the Tracking thread's latency path otherwise: every lld_pose_opt)
+  constexpr unsigned kBit = 1u << ((sizeof(OT) == sizeof(float) ? 1 : 0) | (kThreads == 256 ? 2 : 0));
+  if (kLds && !(ctx->pose_lds_raised & kBit)) {
+    LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&pose_opt_kernel<kLds, OT, kThreads>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPoseLdsBudget));
+    ctx->pose_lds_raised |= kBit;
+  }
   hipLaunchKernelGGL((pose_opt_kernel<kLds, OT, kThreads>), dim3(n_frames), dim3(kThreads), lds_bytes, st, fr, A, po, prm.n_rounds, prm.its_per_round, prm.max_trials);
   LLD_HIP_TRY(hipGetLastError());
   return LLD_OK;
@@ -683,11 +688,11 @@ static int pose_launch(lld_ctx* ctx, int n_frames, char* d_img, const PoseLayout
   const PoseFrameDev* fr = reinterpret_cast<const PoseFrameDev*>(d_img + Y.frames);
   PoseOut* po = reinterpret_cast<PoseOut*>(d_img + Y.out);
   const PoseArrays A = pose_arrays(d_img, Y);
-  if (!M.use_lds) return pose_launch_as<false, double, kPoseThreadsMax>(st, n_frames, 0, fr, A, po, prm);
-  if (M.f32) return M.threads == 256 ? pose_launch_as<true, float, 256>(st, n_frames, M.lds_bytes, fr, A, po, prm)
-                                     : pose_launch_as<true, float, kPoseThreadsMax>(st, n_frames, M.lds_bytes, fr, A, po, prm);
-  return M.threads == 256 ? pose_launch_as<true, double, 256>(st, n_frames, M.lds_bytes, fr, A, po, prm)
-                          : pose_launch_as<true, double, kPoseThreadsMax>(st, n_frames, M.lds_bytes, fr, A, po, prm);
+  if (!M.use_lds) return pose_launch_as<false, double, kPoseThreadsMax>(ctx, st, n_frames, 0, fr, A, po, prm);
+  if (M.f32) return M.threads == 256 ? pose_launch_as<true, float, 256>(ctx, st, n_frames, M.lds_bytes, fr, A, po, prm)
+                                     : pose_launch_as<true, float, kPoseThreadsMax>(ctx, st, n_frames, M.lds_bytes, fr, A, po, prm);
+  return M.threads == 256 ? pose_launch_as<true, double, 256>(ctx, st, n_frames, M.lds_bytes, fr, A, po, prm)
+                          : pose_launch_as<true, double, kPoseThreadsMax>(ctx, st, n_frames, M.lds_bytes, fr, A, po, prm);
 }
 
 static void pose_fill_result(const PoseLayout& Y, const char* h_out /* start of the output region */, const PoseFrameDev& F, int frame, lld_pose_result* out) {

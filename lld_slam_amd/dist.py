@@ -232,6 +232,18 @@ def max_over_ranks(value: float, device, use_dist: bool) -> float:
     return float(t.item())
 
 
+def all_ranks_ok(ok: bool, device, use_dist: bool) -> bool:
+    """True iff EVERY rank passes ok = True.  The one collective a rank reaches whether or not its local work succeeded: the ranks use it to
+    agree on skipping the collectives that follow (a rank alone in a gather hangs the job until the backend's timeout)."""
+    if not use_dist:
+        return bool(ok)
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(int(t.item()) == 1)
+
+
 def gather_counts(count: int, device, use_dist: bool, world: int) -> list[int]:
     """Windows solved per rank (strong scaling shards unevenly when world does not divide the batch)."""
     if not use_dist:

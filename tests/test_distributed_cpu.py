@@ -41,6 +41,9 @@ WORKER = textwrap.dedent('''
     g.drain()
     D.barrier(True, False)
     assert D.max_over_ranks(0.5 + rank, torch.device("cpu"), True) == 0.5 + (world - 1)
+    # the agreement every leg of bench.sharded_secondary starts with: one rank's failure is every rank's "skip the collectives"
+    assert D.all_ranks_ok(True, torch.device("cpu"), True) is True
+    assert D.all_ranks_ok(rank != 1, torch.device("cpu"), True) is False
     # ---- the other two shardable legs of the bench line: PoseOptimization frames and frame-pair match batches (fixed-stride rows)
     nfr = 7; f0, fc = D.shard(nfr, world, rank, True)
     frames = [synth.make_pose_frame(100 + i, n_points=60, n_lines=12) for i in range(nfr)]
