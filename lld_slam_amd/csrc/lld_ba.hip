@@ -160,6 +160,8 @@ struct WinStage {
   std::vector<uint8_t> pt_slot, ln_slot;                   // per landmark: its position in its task (landmark - PTask::l0; 0 for a task of one)
   ChunkStage cs[2];                                        // points, lines
   std::vector<int> blk_start, blk_src, cam_start, cam_src; // window-local CSRs over both kinds (stage_csr)
+  std::vector<int> blk_perm;                               // the blocks of S in the order ba_schur_reduce visits them: longest partial list first
+  int n_blk_nz = 0;                                        // ... of which the first n_blk_nz are structurally non-zero (the others stay the zeros the batch starts with)
   CholPlan plan;                                           // schedule of the structure-following reduced solve (stage_chol_plan; mode 0: dense kernel)
 };
 
@@ -191,9 +193,9 @@ void carve_a(lld_slab& sl, bool packed, long long NC, long long NP, long long NL
   a.le_s = sl.take<double>(NLE + 1);
 }
 struct SecBSizes { size_t blk_start, blk_src, cam_start, cam_src, lm, tab, cams, chunk, ptask, ltask; int n_windows; };
-struct SecB { int *blk_start, *blk_src, *cam_start, *cam_src, *sg_lm, *sg_tab, *sg_cams; SChunk* chunks; PTask *ptasks, *ltasks; BAWin* wins; CholPlan* plans; };
+struct SecB { int *blk_start, *blk_src, *cam_start, *cam_src, *blk_perm, *sg_lm, *sg_tab, *sg_cams; SChunk* chunks; PTask *ptasks, *ltasks; BAWin* wins; CholPlan* plans; };
 void carve_b(lld_slab& sl, const SecBSizes& z, SecB& b) {
-  b.blk_start = sl.take<int>(z.blk_start + 2); b.blk_src = sl.take<int>(z.blk_src + 1); b.cam_start = sl.take<int>(z.cam_start + 2); b.cam_src = sl.take<int>(z.cam_src + 1);
+  b.blk_start = sl.take<int>(z.blk_start + 2); b.blk_perm = sl.take<int>(z.blk_start + 2); b.blk_src = sl.take<int>(z.blk_src + 1); b.cam_start = sl.take<int>(z.cam_start + 2); b.cam_src = sl.take<int>(z.cam_src + 1);
   b.sg_lm = sl.take<int>(z.lm + 1); b.sg_tab = sl.take<int>(z.tab + 1); b.sg_cams = sl.take<int>(z.cams + 1);
   b.chunks = sl.take<SChunk>(z.chunk + 1); b.ptasks = sl.take<PTask>(z.ptask + 1); b.ltasks = sl.take<PTask>(z.ltask + 1);
   b.wins = sl.take<BAWin>((size_t)z.n_windows);
@@ -461,6 +463,27 @@ void stage_csr(int n_free, WinStage& S) {
     for (int d = 0; d < 2; d++) { std::vector<int>().swap(S.cs[d].*key); std::vector<int>().swap(S.cs[d].*val); }
   };
   csr(nblk, &ChunkStage::blk_key, &ChunkStage::blk_val, part3 * 4, S.blk_start, S.blk_src);
+  // ba_schur_reduce gives a lane one row of one block and walks that block's partial list: a diagonal block has ~50 entries, most
+  // off-diagonal ones none.  In block-index order every wavefront (ten blocks) holds about one diagonal block and waits for its list with a
+  // tenth of its lanes (round 5); sorted by list length - a counting sort, stable - the long lists share wavefronts and the empty ones too.
+  {
+    std::vector<int> len((size_t)nblk);
+    int max_len = 0;
+    // (a diagonal block is never empty: it carries Hpp + lambda I even when no landmark adds to it)
+    for (int b = 0, k = 0; b < n_free; b++)
+      for (int a = 0; a <= b; a++, k++) {
+        len[k] = (k + 1 < nblk ? S.blk_start[k + 1] : (int)S.blk_src.size()) - S.blk_start[k];
+        if (a == b) len[k] = std::max(len[k], 1);
+        max_len = std::max(max_len, len[k]);
+      }
+    S.n_blk_nz = 0;
+    for (int k = 0; k < nblk; k++) S.n_blk_nz += len[k] > 0;
+    std::vector<int> at((size_t)max_len + 2, 0);
+    for (int k = 0; k < nblk; k++) at[(size_t)(max_len - len[k]) + 1]++;
+    for (int l = 0; l <= max_len; l++) at[(size_t)l + 1] += at[l];
+    S.blk_perm.resize((size_t)nblk);
+    for (int k = 0; k < nblk; k++) S.blk_perm[(size_t)at[max_len - len[k]]++] = k;
+  }
   csr(n_free, &ChunkStage::cam_key, &ChunkStage::cam_val, cpart3, S.cam_start, S.cam_src);
 }
 
@@ -536,7 +559,7 @@ static int ba_make_groups(lld_ba_batch* B, int n_groups) {
       Gr.max_nt_pt = std::max(Gr.max_nt_pt, W.nt_pt); Gr.max_nb_ln = std::max(Gr.max_nb_ln, W.nt_ln);
       Gr.max_nl_pt = std::max(Gr.max_nl_pt, W.nl_pt); Gr.max_nl_ln = std::max(Gr.max_nl_ln, W.nl_ln);
       Gr.max_items_pt = std::max(Gr.max_items_pt, W.n_items_pt); Gr.max_items_ln = std::max(Gr.max_items_ln, W.n_items - W.n_items_pt);
-      Gr.max_blk = std::max(Gr.max_blk, W.n_free * (W.n_free + 1) / 2);
+      Gr.max_blk = std::max(Gr.max_blk, B->A.s_skip_empty ? W.n_blk_nz : W.n_free * (W.n_free + 1) / 2);
       const bool sp = (size_t)wi < B->plan_mode.size() && B->plan_mode[wi] == 1;
       Gr.any_sparse = Gr.any_sparse || sp; Gr.any_dense = Gr.any_dense || !sp;
     }
@@ -718,6 +741,7 @@ static int ba_batch_create_impl(lld_ctx* ctx, int n_windows, const lld_ba_window
       stage_chunks(wins[wi], 4, bases[wi], B->chunk_landmarks, S.cs[1]);
     }
     stage_csr(wins[wi].n_free_cams, S);
+    W.n_blk_nz = S.n_blk_nz;
     {
       static const int plan_force = exp_int("LLD_BA_CHOL_FORCE", 0);          // experiments: 1 natural order / one chain, 2 two chains only, 3 dense kernel
       stage_chol_plan(wins[wi].n_free_cams, P.reduced_solver == 0 ? plan_force : (P.reduced_solver == 4 ? 1 : (P.reduced_solver == 5 ? 2 : 3)), S);
@@ -761,6 +785,10 @@ static int ba_batch_create_impl(lld_ctx* ctx, int n_windows, const lld_ba_window
   const size_t n_part = tot.part, n_cpart = tot.cpart;
   // few windows whose reduced system is beyond the matrix-core Cholesky: the PCG runs across the whole GPU (see ba_pcgm_*)
   B->pcg_multi = n_windows <= 8 && B->max_free * 6 > kCholMN && P.reduced_solver != 2;
+  // The matrix-core solvers only READ S: its structurally empty blocks can stay the zeros the batch starts with (one memset per batch) instead of
+  // being rewritten by every ba_schur_reduce launch - three quarters of an LBA-B window's 1275 blocks (round 5).  The vector-ALU Cholesky factors in
+  // place and the PCG paths mirror the triangle: they keep the full rewrite.
+  const bool s_skip_empty = (P.reduced_solver == 0 || P.reduced_solver >= 3) && B->max_free * 6 <= kCholMN && !B->pcg_multi;
   if (B->max_free > kMaxFreeCamsOneWg && !B->pcg_multi) return fail(LLD_ERR_UNSUPPORTED);   // batches of huge windows: not in this build
   if (B->max_cams > kPcgThreads && !B->pcg_multi) return fail(LLD_ERR_UNSUPPORTED);           // (the one-workgroup solvers move one camera per lane)
   for (int wi = 0; wi < n_windows; wi++) { B->h_wins[wi].acc_copies[0] = B->acc_copies[0]; B->h_wins[wi].acc_copies[1] = B->acc_copies[1]; B->h_wins[wi].win_index = wi; B->h_wins[wi].big = B->big ? 1 : 0; }
@@ -784,7 +812,7 @@ static int ba_batch_create_impl(lld_ctx* ctx, int n_windows, const lld_ba_window
     A.pe_obs = dA.pe_obs; A.pe_cs = dA.pe_cs; A.lo_seg = dA.lo_seg; A.lo_cs = dA.lo_cs; A.lo_ln = dA.lo_ln; A.lo_oct = dA.lo_oct;
     A.pe_cam = dA.pe_cam; A.pe_u = dA.pe_u; A.pe_v = dA.pe_v; A.pe_ur = dA.pe_ur; A.pe_s = dA.pe_s;
     A.le_cam = dA.le_cam; A.le_ln = dA.le_ln; A.le_xs = dA.le_xs; A.le_ys = dA.le_ys; A.le_xe = dA.le_xe; A.le_ye = dA.le_ye; A.le_s = dA.le_s;
-    A.blk_start = dB.blk_start; A.blk_src = dB.blk_src; A.cam_start = dB.cam_start; A.cam_src = dB.cam_src;
+    A.blk_start = dB.blk_start; A.blk_perm = dB.blk_perm; A.blk_src = dB.blk_src; A.cam_start = dB.cam_start; A.cam_src = dB.cam_src;
     A.sg_lm = dB.sg_lm; A.sg_tab = dB.sg_tab; A.sg_cams = dB.sg_cams; A.sg_chunks = dB.chunks; A.ptasks = dB.ptasks; A.ltasks = dB.ltasks;
     B->d_wins = dB.wins; A.chol_plan = dB.plans;
     B->d_state = sl.take<BAState>(n_windows);
@@ -800,7 +828,7 @@ static int ba_batch_create_impl(lld_ctx* ctx, int n_windows, const lld_ba_window
     A.hpp_part = sl.take<double>(n_hpart + 2);
     A.Hpp = sl.take<double>((size_t)NF * 21 + 1); A.bp = sl.take<double>((size_t)NF * 6 + 1);
     A.S = sl.take<double>(S_total + 1); A.bschur = sl.take<double>(x_total + 1); A.xp = sl.take<double>(x_total + 1);
-    A.x_total = (long long)x_total;
+    A.x_total = (long long)x_total; A.s_skip_empty = s_skip_empty ? 1 : 0;
     if (B->pcg_multi) { A.pcg_vec = sl.take<double>(4 * x_total + 4); A.pcg_mi = sl.take<double>((size_t)NF * 36 + 1); A.pcg_sc = sl.take<double>(8 * (size_t)n_windows + 8); }
     A.chi_part = sl.take<double>(NPART + 1); A.chi_part2 = sl.take<double>(NPART + 1); A.scale_part = sl.take<double>(NPART + 1);
     A.sp_part = sl.take<double>(n_part * 36 + 2); A.sp_cpart = sl.take<double>(n_cpart * 6 + 2);
@@ -836,6 +864,7 @@ static int ba_batch_create_impl(lld_ctx* ctx, int n_windows, const lld_ba_window
 #ifdef LLD_EXPERIMENTS
   if (A.chol_stamps && hipMemsetAsync(A.chol_stamps, 0, sizeof(long long) * (size_t)n_windows * kCholStampWaves * kCholStampSlots, st) != hipSuccess) return fail(LLD_ERR_HIP);
 #endif
+  if (s_skip_empty && S_total > 0 && hipMemsetAsync(A.S, 0, S_total * sizeof(double), st) != hipSuccess) return fail(LLD_ERR_HIP);
   // section A leaves now and travels while the host places section B
   uploads_queued = true;
   if (hipMemcpyAsync((char*)B->slab + offA, arenaA, bytesA, hipMemcpyHostToDevice, st) != hipSuccess) return fail(LLD_ERR_HIP);
@@ -866,6 +895,7 @@ static int ba_batch_create_impl(lld_ctx* ctx, int n_windows, const lld_ba_window
     // the window-local CSRs number their partials from the window's first one
     const int part4 = (int)(q.part * 4), cpart0 = (int)q.cpart, bsrc0 = (int)q.blk_src, csrc0 = (int)q.cam_src;
     for (size_t i = 0; i < S.blk_start.size(); i++) hB.blk_start[q.blk_start + i] = S.blk_start[i] + bsrc0;
+    for (size_t i = 0; i < S.blk_perm.size(); i++) hB.blk_perm[q.blk_start + i] = S.blk_perm[i];
     for (size_t i = 0; i < S.blk_src.size(); i++) hB.blk_src[q.blk_src + i] = S.blk_src[i] + part4;
     for (size_t i = 0; i < S.cam_start.size(); i++) hB.cam_start[q.cam_start + i] = S.cam_start[i] + csrc0;
     for (size_t i = 0; i < S.cam_src.size(); i++) hB.cam_src[q.cam_src + i] = S.cam_src[i] + cpart0;
@@ -1011,7 +1041,7 @@ static int ba_batch_solve_impl(lld_ba_batch* B, StopFlag abort_flag) {
       hipLaunchKernelGGL(ba_schur_items_both_kernel, dim3(G.max_items_pt + G.max_items_ln, nw), dim3(kSchurThreads), std::max(B->schur_lds[0], B->schur_lds[1]), st, A, dw, ds, G.max_items_pt);
     }
     if (B->schur_wide_lds > 0) hipLaunchKernelGGL(ba_schur_wide_kernel, dim3(G.max_items_pt + G.max_items_ln, nw), dim3(kSchurWideThreads), B->schur_wide_lds, st, A, dw, ds);
-    hipLaunchKernelGGL(ba_schur_reduce_kernel, dim3((std::max(1, G.max_blk) * 6 + 255) / 256 + 1, nw), dim3(256), 0, st, A, dw, ds);
+    hipLaunchKernelGGL(ba_schur_reduce_kernel, dim3((std::max(1, G.max_blk) * 6 + 255) / 256 + 2, nw), dim3(256), 0, st, A, dw, ds);
     if (B->params.reduced_solver == 1 || B->pcg_multi) hipLaunchKernelGGL(ba_symmetrize_kernel, dim3(B->pcg_multi ? 256 : 16, nw), dim3(256), 0, st, A, dw, ds);
     LLD_HIP_TRY(hipEventRecord(ev[2], st));
     if (B->pcg_multi) {

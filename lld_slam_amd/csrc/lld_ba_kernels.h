@@ -80,6 +80,7 @@ struct BAWin {                 // immutable per-window header
   int item_off, n_items, n_items_pt;   // Schur chunks of this window (range in sg_chunks): n_items_pt point chunks, then line chunks
   int lo_off, n_lo;            // line observations (= le_off / 2)
   int blk_csr_off, cam_csr_off; // CSR (per lower S block / per free camera) of the chunk partials that add into it
+  int n_blk_nz;                // the first n_blk_nz blocks of blk_perm are structurally non-zero (diagonal, or some chunk adds to them)
   int nb_pt, nb_ln;            // landmark blocks (kLmThreads landmarks each)
   int ptask_off, n_ptasks, nt_pt;   // point tasks (4 * rounds[2] per back-substitution workgroup -> nt_pt workgroups)
   int ltask_off, n_ltasks, nt_ln;   // line tasks; partial-sum slots of a window: nt_pt + nt_ln
@@ -190,6 +191,8 @@ struct BAArrays {
   const PTask* ptasks; const PTask* ltasks;
   double *sp_part, *sp_cpart;  // per (chunk, slot pair) 6x6 partial products / per (chunk, slot) 6-vectors
   const int *blk_start, *blk_src, *cam_start, *cam_src;
+  int s_skip_empty;            // the batch's solvers only read S: ba_schur_reduce leaves the structurally empty blocks at the zeros of the batch's memset
+  const int *blk_perm;         // per window (at blk_csr_off): the lower blocks of S ordered by the length of their partial lists (ba_schur_reduce)
   const int *sg_lm, *sg_tab, *sg_cams;
   const CholPlan* chol_plan;   // [windows of the batch] schedule of the structure-following reduced solve (mode 0: the dense kernel's window); null: none
   // results
@@ -1781,7 +1784,7 @@ __global__ __launch_bounds__(kSchurWideThreads) void ba_schur_wide_kernel(BAArra
   else schur_chunk_wide<4>(A, W, C, S.lambda, S.cur, lds);
 }
 
-// grid (ceil(nblk_max * 6 / 256), nW): lane <-> one row of one lower 6x6 block of S.  S_ij = [i == j](Hpp_i + lambda I)
+// grid (ceil(nblk_max * 6 / 256) + 2, nW): lane <-> one row of one lower 6x6 block of S.  S_ij = [i == j](Hpp_i + lambda I)
 // - sum of the chunk partials listed for the block (fixed order -> deterministic), written once with a plain store.
 // blk_src = part_index * 4 + mode; mode 0: partial is Y_a W_b^T for cameras a < b -> transposed into block (b, a);
 // mode 1: same observation on the diagonal; mode 2: two observations by one camera -> P + P^T.
@@ -1792,12 +1795,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
   const BAState& S = st[wrow];
   if (S.phase != PH_RUN) return;
   const int nf = W.n_free, n = 6 * nf, nblk = nf * (nf + 1) / 2;
-  // the LAST workgroup of a window does the right-hand side, the others the blocks: for a single window both are chains of
-  // dependent cross-XCD loads and must not queue behind one another
-  const bool rhs_block = blockIdx.x == gridDim.x - 1;
-  const int idx = blockIdx.x * 256 + threadIdx.x;       // lane <-> one row of one lower 6x6 block
-  if (!rhs_block && idx < nblk * 6) {
-    const int blk = idx / 6, rr = idx - blk * 6;
+  // the LAST TWO workgroups of a window do the right-hand side (half of the rows each), the others the blocks: for a single window both are
+  // chains of dependent cross-XCD loads and must not queue behind one another
+  const int rhs_part = (int)gridDim.x - 1 - (int)blockIdx.x;   // 0 / 1: a right-hand-side workgroup
+  const bool rhs_block = rhs_part < 2;
+  // lane <-> one row of one lower 6x6 block, blocks in blk_perm order (longest partial lists first: the lanes of one wavefront walk lists of
+  // one length).  The wavefronts of that order are dealt round-robin to the window's workgroups, so that the few long-list wavefronts of a
+  // window pull their partials through different CUs (a single window: all of them in one workgroup cost 5 us per launch).
+  const int nslot6 = (A.s_skip_empty ? W.n_blk_nz : nblk) * 6, nwg = ((nslot6 + 63) / 64 + 3) / 4;
+  const int idx = (((int)threadIdx.x >> 6) * nwg + (int)blockIdx.x) * 64 + ((int)threadIdx.x & 63);
+  if (!rhs_block && (int)blockIdx.x < nwg && idx < nslot6) {
+    const int slot = idx / 6, rr = idx - slot * 6;
+    const int blk = A.blk_perm[W.blk_csr_off + slot];
     int i = (int)((sqrt(8.0 * blk + 1.0) - 1.0) * 0.5);
     while ((i + 1) * (i + 2) / 2 <= blk) i++;
     while (i * (i + 1) / 2 > blk) i--;
@@ -1860,7 +1869,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
   }
   if (rhs_block) {
     const int* cst = A.cam_start + W.cam_csr_off;
-    for (int t = threadIdx.x; t < n; t += 256) {
+    const int half = (n + 1) / 2, t_end = rhs_part == 0 ? half : n;
+    for (int t = (rhs_part == 0 ? 0 : half) + (int)threadIdx.x; t < t_end; t += 256) {
       const int c = t / 6, r = t - c * 6;
       double v = A.bp[(size_t)W.hpp_off * 6 + t];
       // a camera appears in ~50 chunks and every list entry is two dependent loads (index -> partial): sixteen entries are kept in
