@@ -436,7 +436,7 @@ def secondary_block(ctx, dev, repeats=5):
         for _ in range(repeats):
             t0 = time.perf_counter(); b.solve(); wall.append((time.perf_counter() - t0) * 1e3)
         st = b.stats(); ga = b.download(0)
-        b.set_groups(1); b.solve(); ph = b.phase_ms(); b.set_groups(0)
+        b.set_groups(1); b.set_phase_timing(True); b.solve(); ph = b.phase_ms(); b.set_phase_timing(False); b.set_groups(0)
     tc = time.perf_counter(); oa = [O.local_ba(w) for w in wa[:2]]; cpu_s = time.perf_counter() - tc
     med = float(np.median(wall)) * 1e-3
     per = {k: 0 for k in PHASES}
@@ -619,11 +619,13 @@ def main():
     elapsed = time.perf_counter() - t0
     # Roofline pass (untimed): the timed steps keep several window groups in flight on separate streams, so their HIP-event
     # brackets overlap; one more step with a single group gives disjoint per-kernel-family event times on that stream.
-    batch.set_groups(1)
+    # Per-phase events are off in the timed steps, as in the product's default (lld_ba_batch_set_phase_timing: six event records per
+    # super-step cost 1.6 % of a 256-window solve and 10 - 15 % of a small batch's); this pass turns them on.
+    batch.set_groups(1); batch.set_phase_timing(True)
     batch.solve()
     phase = batch.phase_ms()
     launches = np.array([batch.kernel_stats(k)[0] for k in range(5)], dtype=np.float64)
-    batch.set_groups(args.groups)
+    batch.set_phase_timing(False); batch.set_groups(args.groups)
     # Measured stream ceiling of this GPU (SURVEY.md §8d asks for it next to the nominal 8 TB/s): a device-to-device copy of 2 GiB,
     # bytes read + bytes written over the HIP-event time, best of 5.
     stream_gbs = None

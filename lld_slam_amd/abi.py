@@ -178,7 +178,7 @@ PRODUCT_SYMBOLS = [
     "lld_se3_from_tcw_f32", "lld_se3_to_tcw_f32", "lld_orb_inv_level_sigma2",
     "lld_ba_params_default", "lld_local_ba",
     "lld_local_ba_stopflag", "lld_ba_batch_create", "lld_ba_batch_solve", "lld_ba_batch_download", "lld_ba_batch_download_range", "lld_ba_batch_stats",
-    "lld_ba_batch_result_records", "lld_ba_batch_phase_ms", "lld_ba_batch_kernel_stats", "lld_ba_batch_set_groups",
+    "lld_ba_batch_result_records", "lld_ba_batch_set_phase_timing", "lld_ba_batch_phase_ms", "lld_ba_batch_kernel_stats", "lld_ba_batch_set_groups",
     "lld_ba_batch_destroy", "lld_ba_chol_plan",
     "lld_device_count", "lld_ba_multi_shard", "lld_ba_multi_create", "lld_ba_multi_solve", "lld_ba_multi_result_records", "lld_ba_multi_verify_gathered",
     "lld_ba_multi_download", "lld_ba_multi_times_ms", "lld_ba_multi_destroy",
@@ -282,6 +282,7 @@ class Lib:
             f("ba_batch_result_records").argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_uint64)]
             f("ba_batch_result_records").restype = C.c_int
             f("ba_batch_phase_ms").argtypes = [vp, c_double_p]; f("ba_batch_phase_ms").restype = C.c_int
+            f("ba_batch_set_phase_timing").argtypes = [vp, C.c_int]; f("ba_batch_set_phase_timing").restype = C.c_int
             f("ba_batch_kernel_stats").argtypes = [vp, C.c_int, C.POINTER(C.c_int64), c_double_p]
             f("ba_batch_kernel_stats").restype = C.c_int
             f("ba_batch_set_groups").argtypes = [vp, C.c_int]; f("ba_batch_set_groups").restype = C.c_int

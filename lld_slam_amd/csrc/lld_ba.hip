@@ -85,6 +85,9 @@ struct lld_ba_batch {
   size_t rec_stride = 0;
   unsigned char* h_records = nullptr; bool records_pinned_own = false; std::vector<unsigned char> h_records_pageable; bool records_valid = false;
   double phase_ms[LLD_BA_N_PHASES] = {};
+  bool phase_events = false;               // lld_ba_batch_set_phase_timing: HIP events at the phase boundaries of every super-step.  Off by default - an event record is a
+                                           // barrier packet of ~4 us between two dependent kernels: six per super-step were 15 % of a single window's solve, 10 % at 32
+                                           // windows, 1.6 % at 256 (tools/experiments/exp_phase_events.sh)
   int64_t launches[kNumPhases] = {};
   int super_steps = 0;
   std::vector<uint8_t> plan_mode;                         // per window: CholPlan::mode (1: ba_chol_sparse_kernel, 0: ba_chol_mfma_kernel)
@@ -1019,7 +1022,8 @@ static int ba_batch_solve_impl(lld_ba_batch* B, StopFlag abort_flag) {
     const int nw = use_slots ? std::max(1, std::min(G.rows, G.nw)) : G.nw; hipStream_t st = G.st;
     const int abort_now = abort_flag.up() ? 1 : 0;
     hipEvent_t* ev = G.ev[q];
-    LLD_HIP_TRY(hipEventRecord(ev[0], st));
+    const bool tev = B->phase_events;                                  // per-phase HIP events (lld_ba_batch_phase_ms); ev[5], the end of the super-step, is always recorded
+    if (tev) LLD_HIP_TRY(hipEventRecord(ev[0], st));
     static const int fuse_below = exp_int("LLD_BA_FUSE_BELOW", kFusePairsBelowWindows);
     const bool packed = A.packed != 0;                                 // the layout of the observations picks the kernel variant (lld_ba_kernels.h: kPk)
     const bool fuse_pairs = nw < fuse_below && !B->big && packed;      // see ba_linearize_both_kernel
@@ -1032,7 +1036,7 @@ static int ba_batch_solve_impl(lld_ba_batch* B, StopFlag abort_flag) {
       if (G.max_nl_ln > 0) hipLaunchKernelGGL(packed ? ba_linearize_ln_kernel : ba_linearize_ln_f64_kernel, dim3(G.max_nl_ln, nw), dim3(64 * B->lin_waves[1]), lin_lds_ln, st, A, dw, ds);
     }
     hipLaunchKernelGGL(ba_hpp_reduce_kernel, dim3(std::max(1, (B->max_free * 27 + 255) / 256), nw), dim3(256), 0, st, A, dw, ds);
-    LLD_HIP_TRY(hipEventRecord(ev[1], st));
+    if (tev) LLD_HIP_TRY(hipEventRecord(ev[1], st));
     static const bool split_schur = exp_flag("LLD_BA_SPLIT_SCHUR");             // experiments: the two launches of before
     if (split_schur) {
       if (G.max_items_pt > 0) hipLaunchKernelGGL(ba_schur_items_kernel<3>, dim3(G.max_items_pt, nw), dim3(kSchurThreads), B->schur_lds[0], st, A, dw, ds);
@@ -1043,7 +1047,7 @@ static int ba_batch_solve_impl(lld_ba_batch* B, StopFlag abort_flag) {
     if (B->schur_wide_lds > 0) hipLaunchKernelGGL(ba_schur_wide_kernel, dim3(G.max_items_pt + G.max_items_ln, nw), dim3(kSchurWideThreads), B->schur_wide_lds, st, A, dw, ds);
     hipLaunchKernelGGL(ba_schur_reduce_kernel, dim3((std::max(1, G.max_blk) * 6 + 255) / 256 + 2, nw), dim3(256), 0, st, A, dw, ds);
     if (B->params.reduced_solver == 1 || B->pcg_multi) hipLaunchKernelGGL(ba_symmetrize_kernel, dim3(B->pcg_multi ? 256 : 16, nw), dim3(256), 0, st, A, dw, ds);
-    LLD_HIP_TRY(hipEventRecord(ev[2], st));
+    if (tev) LLD_HIP_TRY(hipEventRecord(ev[2], st));
     if (B->pcg_multi) {
       // block-Jacobi PCG with the matrix-vector product spread over the GPU; the host looks at the `done` scalars every 16 iterations
       hipLaunchKernelGGL(ba_pcgm_init_kernel, dim3(nw), dim3(kPcgThreads), 0, st, A, dw, ds, B->params.pcg_rel_tol);
@@ -1071,7 +1075,7 @@ static int ba_batch_solve_impl(lld_ba_batch* B, StopFlag abort_flag) {
     }
     else
       hipLaunchKernelGGL(ba_chol_kernel, dim3(nw), dim3(kPcgThreads), chol_lds, st, A, dw, ds, (int)(chol_tri / sizeof(double)));
-    LLD_HIP_TRY(hipEventRecord(ev[3], st));
+    if (tev) LLD_HIP_TRY(hipEventRecord(ev[3], st));
     bool control_fused = false;
     if (B->big) {
       if (G.max_nt_pt > 0) hipLaunchKernelGGL(ba_backsub_pt_big_kernel, dim3(G.max_nt_pt, nw), dim3(kLmThreads), bs_lds, st, A, dw, ds);
@@ -1086,14 +1090,14 @@ static int ba_batch_solve_impl(lld_ba_batch* B, StopFlag abort_flag) {
       if (G.max_nt_pt > 0) hipLaunchKernelGGL(packed ? ba_backsub_pt_kernel : ba_backsub_pt_f64_kernel, dim3(G.max_nt_pt, nw), dim3(kLmThreads), bs_lds, st, A, dw, ds);
       if (G.max_nb_ln > 0) hipLaunchKernelGGL(packed ? ba_backsub_ln_kernel : ba_backsub_ln_f64_kernel, dim3(G.max_nb_ln, nw), dim3(kLmThreads), bs_lds, st, A, dw, ds);
     }
-    LLD_HIP_TRY(hipEventRecord(ev[4], st));
+    if (tev) LLD_HIP_TRY(hipEventRecord(ev[4], st));
     if (!control_fused)
       hipLaunchKernelGGL(ba_control_kernel, dim3(nw), dim3(kCtlThreads), 0, st, A, dw, ds, abort_now, G.nw, G.d_counters, G.h_counters, (live_flag && G.chunk > 1) ? B->h_abort : nullptr);   // totals land in pinned host memory
     if (G.chunk > 1) {                                    // the round transition rides along (windows in PH_TRANSITION only)
       hipLaunchKernelGGL(ba_classify_kernel, dim3(std::max(1, G.max_lblocks), nw), dim3(kLmThreads), 0, st, A, dw, ds);      // (its last workgroup per window starts round 2)
     }
     LLD_HIP_TRY(hipGetLastError());
-    LLD_HIP_TRY(hipEventRecord(ev[5], st));
+    if (tev || q == G.chunk - 1) LLD_HIP_TRY(hipEventRecord(ev[5], st));
     G.map_parity ^= 1;                                   // the next launch reads the map this one's control wrote
     return LLD_OK;
   };
@@ -1143,7 +1147,7 @@ static int ba_batch_solve_impl(lld_ba_batch* B, StopFlag abort_flag) {
       for (int q = 0; q < G.chunk; q++)
         for (int k = 0; k < kNumPhases; k++) {
           float ms = 0.f;
-          if (hipEventElapsedTime(&ms, G.ev[q][k], G.ev[q][k + 1]) == hipSuccess) B->phase_ms[k] += ms;
+          if (B->phase_events && hipEventElapsedTime(&ms, G.ev[q][k], G.ev[q][k + 1]) == hipSuccess) B->phase_ms[k] += ms;
           B->launches[k]++;
         }
       G.steps += G.chunk; B->super_steps += G.chunk;
@@ -1290,6 +1294,12 @@ int lld_ba_batch_phase_ms(lld_ba_batch* B, double* ms6) {
 int lld_ba_batch_kernel_stats(lld_ba_batch* B, int kernel, int64_t* launches, double* total_ms) {
   if (!B || kernel < 0 || kernel >= kNumPhases || !launches || !total_ms) return LLD_ERR_INVALID;
   *launches = B->launches[kernel]; *total_ms = B->phase_ms[kernel];
+  return LLD_OK;
+}
+
+int lld_ba_batch_set_phase_timing(lld_ba_batch* B, int on) {
+  if (!B) return LLD_ERR_INVALID;
+  B->phase_events = on != 0;
   return LLD_OK;
 }
 

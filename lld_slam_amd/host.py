@@ -602,6 +602,11 @@ class BABatch:
         check(self.lib.fn("ba_batch_stats")(self.handle, arr), "ba_batch_stats")
         return [stats_dict(s) for s in arr]
 
+    def set_phase_timing(self, on: bool = True):
+        """HIP events at the phase boundaries of every super-step of the following solves (phase_ms()[0:5], kernel_stats()[1]); off by default:
+        an event between two dependent kernels costs ~4 us of device time."""
+        check(self.lib.fn("ba_batch_set_phase_timing")(self.handle, 1 if on else 0), "ba_batch_set_phase_timing")
+
     def phase_ms(self) -> np.ndarray:
         ms = np.zeros(6)
         check(self.lib.fn("ba_batch_phase_ms")(self.handle, _p(ms, C.c_double)), "ba_batch_phase_ms")

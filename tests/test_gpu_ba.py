@@ -288,10 +288,17 @@ def test_batch_of_ragged_windows_advances_independently(gpu_ctx, oracle):
                 check_ba(b.download(i), oracle.local_ba(w), w)
         st = b.stats()
         assert len(st) == 7 and all(s["lm_trials"][0] >= 1 for s in st)
+        # per-phase events are opt-in (six event records per super-step are 10 - 15 % of a small batch's solve); launches are always counted
+        ms = b.phase_ms(); n, t = b.kernel_stats(1)
+        assert ms[5] > 0 and ms[:5].sum() == 0 and n >= 2 and t == 0
+        b.set_phase_timing(True); b.solve()
         ms = b.phase_ms()
-        assert ms[5] > 0 and ms[:5].sum() <= ms[5] * 1.05
+        assert ms[5] > 0 and (ms[:5] > 0).all() and ms[:5].sum() <= ms[5] * 1.05
         n, t = b.kernel_stats(1)
         assert n >= 2 and t > 0
+        for i, w in enumerate(ws):                          # the same bits with and without the events
+            check_ba(b.download(i), oracle.local_ba(w), w)
+        b.set_phase_timing(False)
         ptr, stride = b.result_records()
         assert ptr != 0 and stride % 256 == 0
 

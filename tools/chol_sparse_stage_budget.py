@@ -30,7 +30,7 @@ def main():
     import test_chol_plan as TP
     plan = TP.get_plan(TP.window_pattern(ws[0]), int(os.environ.get("LLD_BA_CHOL_FORCE", "0")))
     with Context(0, lib=lib) as ctx, BABatch(ctx, ws) as b:
-        b.solve(); b.solve()
+        b.set_phase_timing(True); b.solve(); b.solve()
         st = np.zeros((nw, 16, SLOTS), dtype=np.int64)
         fn = lib.dll.lld_exp_chol_stamps
         fn.argtypes = [C.c_void_p, C.c_void_p]; fn.restype = C.c_int

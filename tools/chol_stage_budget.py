@@ -30,7 +30,7 @@ def main():
     lib = abi.Lib(os.path.join(ROOT, "lld_slam_amd", "csrc", "liblld_amd_exp.so"), "lld_")
     ws = [synth.make_lba_b(i) for i in range(nw)]
     with Context(0, lib=lib) as ctx, BABatch(ctx, ws) as b:
-        b.solve(); b.solve()
+        b.set_phase_timing(True); b.solve(); b.solve()
         st = np.zeros((nw, 16, SLOTS), dtype=np.int64)
         fn = lib.dll.lld_exp_chol_stamps
         fn.argtypes = [C.c_void_p, C.c_void_p]; fn.restype = C.c_int

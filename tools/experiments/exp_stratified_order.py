@@ -42,7 +42,7 @@ for mode in ("caller", "stratified", "sorted"):
     with BABatch(ctx, ws) as b:
         b.solve()
         t = time.perf_counter(); b.solve(); dt = time.perf_counter() - t
-        b.set_groups(1); b.solve()
+        b.set_groups(1); b.set_phase_timing(True); b.solve()
         ph = b.phase_ms(); la = [b.kernel_stats(k)[0] for k in range(5)]
         st = b.stats()
     print(mode, "windows/s %.0f" % (n / dt), "chi2[0] %.9g" % st[0]["chi2_final"],

@@ -10,7 +10,7 @@ ws = [synth.make_lba_b(i) for i in range(n)]
 with BABatch(ctx, ws) as b:
     b.solve()
     t = time.perf_counter(); b.solve(); dt = time.perf_counter() - t
-    b.set_groups(1); b.solve()
+    b.set_groups(1); b.set_phase_timing(True); b.solve()
     ph = b.phase_ms(); la = [b.kernel_stats(k)[0] for k in range(5)]
     st = b.stats()
 names = ["linearize", "schur", "solve", "backsub", "control"]
