@@ -526,12 +526,12 @@ static int ba_make_groups(lld_ba_batch* B, int n_groups) {
   const int n_windows = B->n_windows;
   int G = n_groups;
   if (G <= 0) {
-    // >= 128 windows: groups of at least 64 (with groups of >= kChunkFromWindows windows the count hardly matters: 128 - 224 windows run within
-    // 1 % of each other with 2, 3 or 4 groups).  Smaller batches: the chains of small groups, as measured by tools/exp_small_groups.sh.
-    // (Round 4 swept the count again with {4, 2, 4, 1} tasks per wavefront below 32 windows, tools/exp_small_rounds.sh: 16 - 64 windows run within
-    // the box-to-box spread of each other - 32 windows 2730 - 2870 windows/s - with two, three or four groups; five and more fall off a cliff,
-    // 1700 windows/s.)
-    G = n_windows >= 128 ? std::min(4, n_windows / 64) : (n_windows >= 48 ? 3 : (n_windows >= 8 ? 2 : 1));
+    // Four groups from 16 windows on, three from 8: swept again in round 5 once the per-phase events had left the solve (they had made every
+    // additional chain pay six barrier packets per super-step), tools/experiments/exp_small_sweep2.sh, windows/s with 2 / 3 / 4 groups:
+    // 16 windows 2590 / 2680 / 2700, 24: 3330 / 3550 / 3600, 32: 3820 / 3960 / 3890 - 4020, 48: 4370 / 4460 / 4460, 64: 4790 / 4730 / 4760,
+    // 96: 5430 / 5530 / 5540, 128: 5730 / 5770 / 5830, 192: 6350 / 6390 / 6410; 8 windows 1510 / 1550 / 1580 (one group: 1450).
+    // Five and more fall off a cliff at every size (128 windows: 5820 -> 5020, 256: 6530 -> 5940): the streams then share hardware queues.
+    G = n_windows >= 16 ? 4 : (n_windows >= 8 ? 3 : 1);
     static const int groups_exp = exp_int("LLD_BA_GROUPS", 0);
     if (groups_exp >= 1 && groups_exp <= 8) G = groups_exp;
   }
