@@ -473,11 +473,14 @@ def secondary_block(ctx, dev, repeats=5):
 
 
 # ================================================================================================== host buffers in -> results out
-def e2e_block(windows, device, lanes=3, batches_per_lane=8):
+def e2e_block(windows, device, lanes=3, batches_per_lane=16):
     """Steady-state rate at the C ABI with HOST buffers on both sides: `lanes` host threads, each with its own context, loop
     lld_ba_batch_create -> lld_ba_batch_solve -> lld_ba_batch_download_range -> lld_ba_batch_destroy on the same 256 host windows.
     Flattening + upload of one lane's next batch and the download of its previous one overlap the other lane's solve (solves of large
-    batches take turns on a device, lld_ba.hip).  One untimed warm-up batch per lane (first touch of the pinned arenas, slab growth)."""
+    batches take turns on a device, lld_ba.hip; a batch created while another one solves gets two stream groups instead of four, which leaves
+    the other lanes' copies room next to the solve).  One untimed warm-up batch per lane (first touch of the pinned arenas, slab growth).
+    `e2e_windows_per_s` is from a STANDING start (all lanes begin with a create, the device idles for the first ~60 ms) to the last download;
+    `steady_state_windows_per_s` starts once every lane has one batch behind it."""
     import ctypes as C
     import threading
     import numpy as np

@@ -58,6 +58,7 @@ std::atomic<int> g_big_solves_running[64];   // per HIP device: solves of >= kSe
 // 48; tools/exp_e2e_lanes.py, LLD_HOST_THREADS sweep: 3 lanes at 4 / 8 / 16 threads = 5050 / 4690 / 4560 windows/s in steady state).  Four
 // threads flatten 256 LBA-B windows in 45 ms - still inside the 48 ms the solve in flight takes - and leave it alone.
 constexpr int kStagingThreadsUnderSolve = 4;
+static int staging_cap() { static const int c = std::max(1, exp_int("LLD_BA_STAGING_CAP", kStagingThreadsUnderSolve)); return c; }
 }
 
 struct lld_ba_batch {
@@ -78,6 +79,7 @@ struct lld_ba_batch {
   int* h_abort = nullptr;                                             // pinned, host-written / device-read: the live stop flag as the control kernel sees it
   int max_lblocks = 0, max_items_pt = 0, max_items_ln = 0, max_free = 0, max_cams = 0, max_blk = 0, acc_copies[2] = {4, 4}, lin_waves[2] = {kLinThreads / 64, kLinThreads / 64};   // [point, line] linearise kernel
   bool pcg_multi = false;
+  bool pipelined = false;                                 // created while another batch's large solve ran on this device (ba_make_groups)
   bool big = false;                                       // a map beyond kMaxFreeCamsLds cameras: accumulators and poses of the linearise / back-substitution kernels in HBM
   size_t schur_lds[2] = {0, 0}; size_t schur_wide_lds = 0;
   int chunk_landmarks = 32;
@@ -532,6 +534,13 @@ static int ba_make_groups(lld_ba_batch* B, int n_groups) {
     // 96: 5430 / 5530 / 5540, 128: 5730 / 5770 / 5830, 192: 6350 / 6390 / 6410; 8 windows 1510 / 1550 / 1580 (one group: 1450).
     // Five and more fall off a cliff at every size (128 windows: 5820 -> 5020, 256: 6530 -> 5940): the streams then share hardware queues.
     G = n_windows >= 16 ? 4 : (n_windows >= 8 ? 3 : 1);
+    // A pipelined caller - several contexts, each looping create -> solve -> download on the same device - has the other contexts' uploads and
+    // downloads in flight during this batch's solve.  The part runs four streams side by side and time-slices the rest: with four groups the
+    // copies compete with the solve's own chains, with two they have room.  Three lanes x 8 batches of 256 windows, host buffers in and results
+    // out (tools/experiments/exp_e2e_lanes.py, same box): 4800 - 4940 windows/s with four groups, 5120 - 5400 with three, 5450 - 5560 with two,
+    // 5440 with one; a resident batch alone keeps four (6530 against 6350 with two).  The sign of such a caller: the batch was created while
+    // another batch's solve ran on the device.
+    if (B->pipelined) G = std::min(G, 2);
     static const int groups_exp = exp_int("LLD_BA_GROUPS", 0);
     if (groups_exp >= 1 && groups_exp <= 8) G = groups_exp;
   }
@@ -696,12 +705,13 @@ static int ba_batch_create_impl(lld_ctx* ctx, int n_windows, const lld_ba_window
   }
   std::vector<WinStage> stages(n_windows);
   int n_threads = 1;
+  const bool staged_under_solve = g_big_solves_running[ctx->device & 63].load(std::memory_order_relaxed) > 0;
   if (n_windows >= 4) {
     n_threads = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
-    if (g_big_solves_running[ctx->device & 63].load(std::memory_order_relaxed) > 0) n_threads = std::min(n_threads, kStagingThreadsUnderSolve);
+    if (g_big_solves_running[ctx->device & 63].load(std::memory_order_relaxed) > 0) n_threads = std::min(n_threads, staging_cap());
     if (const char* e = std::getenv("LLD_HOST_THREADS")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) n_threads = v; }
     // (the cap that protects a solve in flight holds under the override too: bench.py sets LLD_HOST_THREADS for every rank of an N > 1 run)
-    if (g_big_solves_running[ctx->device & 63].load(std::memory_order_relaxed) > 0) n_threads = std::min(n_threads, std::max(kStagingThreadsUnderSolve, 1));
+    if (g_big_solves_running[ctx->device & 63].load(std::memory_order_relaxed) > 0) n_threads = std::min(n_threads, staging_cap());
     n_threads = std::min(n_threads, n_windows);
   }
   std::atomic<int> first_error{LLD_OK};
@@ -929,6 +939,8 @@ static int ba_batch_create_impl(lld_ctx* ctx, int n_windows, const lld_ba_window
   } else if (hipHostMalloc((void**)&B->h_counters, 256, hipHostMallocDefault) != hipSuccess) return fail(LLD_ERR_HIP);
   B->h_abort = B->h_counters + 48;                            // (the pinned block is 256 bytes: 4 ints per group x 8 groups, then the live stop word)
   lap("pinned counters");
+  // a batch that was staged under another batch's solve belongs to a pipelined caller (see ba_make_groups)
+  B->pipelined = n_windows >= kSerialiseSolvesFromWindows && (staged_under_solve || g_big_solves_running[ctx->device & 63].load(std::memory_order_relaxed) > 0);
   { int gs = ba_make_groups(B, 0); if (gs) return fail(gs); }
   lap("groups made");
   if (cached) {
@@ -1240,7 +1252,7 @@ int lld_ba_batch_download_range(lld_ba_batch* B, int first, int count, lld_ba_re
   LLD_HIP_TRY(hipSetDevice(B->ctx->device));
   int st = ba_fetch_records(B); if (st) return st;
   int n_threads = count >= 8 ? (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u) : 1;
-  if (g_big_solves_running[B->ctx->device & 63].load(std::memory_order_relaxed) > 0) n_threads = std::min(n_threads, kStagingThreadsUnderSolve);   // see there
+  if (g_big_solves_running[B->ctx->device & 63].load(std::memory_order_relaxed) > 0) n_threads = std::min(n_threads, staging_cap());   // see there
   if (const char* e = std::getenv("LLD_HOST_THREADS")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) n_threads = std::min(n_threads, v); }
   n_threads = std::max(1, std::min(n_threads, count / 4));
   std::atomic<int> next{0};
