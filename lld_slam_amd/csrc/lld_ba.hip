@@ -53,11 +53,12 @@ constexpr int kSerialiseSolvesFromWindows = 64;
 std::mutex g_big_solve[64];               // per HIP device
 std::atomic<int> g_big_solves_running[64];   // per HIP device: solves of >= kSerialiseSolvesFromWindows windows in flight
 // Host threads that flatten a batch while such a solve runs on the same device (a pipelined caller: the next batch is staged while this one
-// solves).  The solve's launch loop is one host thread that has to answer every super-step within microseconds; sixteen staging threads
-// hammering the memory system next to it made every latency-bound kernel of the solve 10 - 100 % slower (a lane's turn 54 ms instead of
-// 48; tools/exp_e2e_lanes.py, LLD_HOST_THREADS sweep: 3 lanes at 4 / 8 / 16 threads = 5050 / 4690 / 4560 windows/s in steady state).  Four
-// threads flatten 256 LBA-B windows in 45 ms - still inside the 48 ms the solve in flight takes - and leave it alone.
-constexpr int kStagingThreadsUnderSolve = 4;
+// solves).  Rounds 4 - 5 capped them at four: next to a solve on four stream groups with six event records per super-step, sixteen staging
+// threads made every latency-bound kernel 10 - 100 % slower (3 lanes at 4 / 8 / 16 threads = 5050 / 4690 / 4560 windows/s in steady state).
+// With the events gone and two groups for a pipelined batch (ba_make_groups) the solve no longer notices them, and the cap was what held a
+// two-lane caller back - tools/experiments/exp_e2e_lanes.py, same box, end to end / steady state: 2 lanes 4020 / 4390 windows/s at 4 threads,
+// 4940 / 5700 at 8, 5590 / 6600 at 16; 3 lanes 5810 / 6440, 5960 / 6560, 5950 / 6620.  The constant stays as the experiments build's knob.
+constexpr int kStagingThreadsUnderSolve = 16;
 static int staging_cap() { static const int c = std::max(1, exp_int("LLD_BA_STAGING_CAP", kStagingThreadsUnderSolve)); return c; }
 }
 
