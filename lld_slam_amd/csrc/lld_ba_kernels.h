@@ -303,21 +303,7 @@ __device__ __forceinline__ bool spd_inverse(const double* A, double* Ainv) {
   return ok;
 }
 
-// 1 / sqrt(d): v_rsq_f64 seed + two Newton steps (the library sqrt and divide are ~45 dependent instructions; the result is within an
-// ulp or two and L L^T = Hll + lambda I to rounding either way)
-// 1 / z: v_rcp_f64 seed + two Newton steps (Jacobians only; residuals keep the reference's divisions)
-__device__ __forceinline__ double rcp_nr(double z) {
-  double r = __builtin_amdgcn_rcp(z);
-  r = r * (2.0 - z * r);
-  r = r * (2.0 - z * r);
-  return r;
-}
-__device__ __forceinline__ double rsqrt_nr(double d) {
-  double y = __builtin_amdgcn_rsq(d);
-  y = y * (1.5 - (0.5 * d) * (y * y));
-  y = y * (1.5 - (0.5 * d) * (y * y));
-  return y;
-}
+// (rcp_nr / rsqrt_nr: lld_device_math.h)
 // lower Cholesky factor of (packed upper U) + lambda I, D x D: L packed row-major lower (L[i][j] at i(i+1)/2 + j, diagonal entries
 // unused), idiag[i] = 1 / L[i][i]
 template <int D>
@@ -564,13 +550,13 @@ __device__ __forceinline__ void point_edge_linearize(const BAArrays& A, const BA
   const Vec3 Xc = pose_map(T, X);
   const PtObs ob = pt_obs_of<kPk>(A, e);
   L.stereo = !(ob.ur < 0);
-  point_residual(W.cam, Xc, ob.u, ob.v, ob.ur, L.stereo, true, L.r);
+  point_residual_iz(W.cam, Xc, rcp_nr(Xc.z), ob.u, ob.v, ob.ur, L.stereo, true, L.r);
   const double s = ob.s;
   const double c2 = chi2_of(L.r, L.stereo ? 3 : 2, s);
   A.pe_chi2[e] = c2;
   double w = 1.0;
   L.rho0 = c2;
-  if (fl & EF_ROBUST) L.rho0 = huber(c2, L.stereo ? W.th_stereo : W.th_mono, &w);
+  if (fl & EF_ROBUST) L.rho0 = huber_nr(c2, L.stereo ? W.th_stereo : W.th_mono, &w);
   L.ws = w * s;
   A.pe_ws[e] = L.stereo ? -L.ws : L.ws;                   // (sign bit = stereo edge, see BAArrays::pe_ws)
   point_jac_point(W.cam, Xc, quat_rotation(T.q), L.stereo, L.Jp);
@@ -608,14 +594,14 @@ __device__ __forceinline__ double point_edge_blocks_closed(const BAWin& W, const
   const Vec3 Xc = pose_map(T, X);
   const bool stereo = !(ob.ur < 0);
   double r[3];
-  point_residual(k, Xc, ob.u, ob.v, ob.ur, stereo, true, r);
+  const double iz = rcp_nr(Xc.z), iz2 = iz * iz;             // one reciprocal for the residual and the Jacobian entries
+  point_residual_iz(k, Xc, iz, ob.u, ob.v, ob.ur, stereo, true, r);
   const double c2e = chi2_of(r, stereo ? 3 : 2, ob.s);
   double w = 1.0, rho0 = c2e;
-  if (fl & EF_ROBUST) rho0 = huber(c2e, stereo ? W.th_stereo : W.th_mono, &w);
+  if (fl & EF_ROBUST) rho0 = huber_nr(c2e, stereo ? W.th_stereo : W.th_mono, &w);
   const double ws = w * ob.s;
   ws_out = ws; rho0_out = rho0;
   const Mat3 R = quat_rotation(T.q);
-  const double iz = rcp_nr(Xc.z), iz2 = iz * iz;
   const double a = k.fx * iz, b = k.fy * iz;
   const double c0 = -k.fx * Xc.x * iz2, c1 = -k.fy * Xc.y * iz2, c2 = c0 + k.bf * iz2;
   const double m00 = ws * (stereo ? 2.0 * a * a : a * a);
@@ -821,11 +807,11 @@ __device__ __forceinline__ double point_edge_trial(const BAArrays& A, const BAWi
   const PtObs ob = pt_obs_of<kPk>(A, e);
   const bool stereo = !(ob.ur < 0);
   double r[3];
-  point_residual(W.cam, Xc, ob.u, ob.v, ob.ur, stereo, true, r);
+  point_residual_iz(W.cam, Xc, rcp_nr(Xc.z), ob.u, ob.v, ob.ur, stereo, true, r);
   const double c2 = chi2_of(r, stereo ? 3 : 2, ob.s);
   A.pe_chi2[e] = c2;
   double w, rho0 = c2;
-  if (fl & EF_ROBUST) rho0 = huber(c2, stereo ? W.th_stereo : W.th_mono, &w);
+  if (fl & EF_ROBUST) rho0 = huber_nr(c2, stereo ? W.th_stereo : W.th_mono, &w);
   return rho0;
 }
 // x_l = (Hll + lambda I)^-1 (b_l - sum W^T x_c), oplus; returns the landmark's part of computeScale
@@ -935,11 +921,11 @@ __device__ __forceinline__ void ba_backsub_pt_body(const BAArrays& A, const BAWi
         const Vec3 Xc = pose_map(pose_load(camB + c * 7), Xn);
         const bool stereo = !(ob.ur < 0);
         double r[3];
-        point_residual(W.cam, Xc, ob.u, ob.v, ob.ur, stereo, true, r);
+        point_residual_iz(W.cam, Xc, rcp_nr(Xc.z), ob.u, ob.v, ob.ur, stereo, true, r);
         const double c2 = chi2_of(r, stereo ? 3 : 2, ob.s);
         A.pe_chi2[e] = c2;
         double w, rho0 = c2;
-        if (fl & EF_ROBUST) rho0 = huber(c2, stereo ? W.th_stereo : W.th_mono, &w);
+        if (fl & EF_ROBUST) rho0 = huber_nr(c2, stereo ? W.th_stereo : W.th_mono, &w);
         chi += rho0;
       }
     } else {
@@ -983,7 +969,7 @@ __global__ __launch_bounds__(kLmThreads) void ba_backsub_pt_big_kernel(BAArrays 
 // edge of its observation and keeps their summed Hpl block; Hll/b_l (14 values) are combined over the line's lanes.
 struct LineGeom { Vec3 c0, c1, X1, X2; double alpha; };
 __device__ __forceinline__ LineGeom line_geom(const LineQ& L) {
-  const Mat3 Rl = line_rotation(L);
+  const Mat3 Rl = line_rotation_t<true>(L);
   LineGeom G; G.c0 = mat_col(Rl, 0); G.c1 = mat_col(Rl, 1); G.alpha = L.alpha; G.X1 = L.alpha * G.c1; G.X2 = G.X1 + G.c0;
   return G;
 }
@@ -1021,12 +1007,12 @@ __device__ __forceinline__ double line_obs_linearize(const BAArrays& A, const BA
     const uint8_t fl = I.fl[side];
     if (!(fl & EF_VALID) || (fl & EF_LEVEL1)) continue;
     double r[2]; LineAdj adj;
-    line_residual(W.cam, side == 1 ? W.cam.bx_right : 0.0, X1m, X2m, I.xs[side], I.ys[side], I.xe[side], I.ye[side], r, &adj);
+    line_residual_t<true>(W.cam, side == 1 ? W.cam.bx_right : 0.0, X1m, X2m, I.xs[side], I.ys[side], I.xe[side], I.ye[side], r, &adj);
     const double s = I.s[side];
     const double c2 = chi2_of(r, 2, s);
     A.le_chi2[e] = c2;
     double w = 1.0, rho0 = c2;
-    if (fl & EF_ROBUST) rho0 = huber(c2, (fl & EF_PAIRSTEREO) ? W.th_ln_stereo : W.th_ln_mono, &w);
+    if (fl & EF_ROBUST) rho0 = huber_nr(c2, (fl & EF_PAIRSTEREO) ? W.th_ln_stereo : W.th_ln_mono, &w);
     chi += rho0;
     const double ws = w * s;
     double Jc[12], Jl[8];
@@ -1196,11 +1182,11 @@ __device__ __forceinline__ double line_obs_trial(const BAArrays& A, const BAWin&
     const uint8_t fl = I.fl[side];
     if (!(fl & EF_VALID) || (fl & EF_LEVEL1)) continue;
     double r[2];
-    line_residual(W.cam, side == 1 ? W.cam.bx_right : 0.0, X1m, X2m, I.xs[side], I.ys[side], I.xe[side], I.ye[side], r, nullptr);
+    line_residual_t<true>(W.cam, side == 1 ? W.cam.bx_right : 0.0, X1m, X2m, I.xs[side], I.ys[side], I.xe[side], I.ye[side], r, nullptr);
     const double c2 = chi2_of(r, 2, I.s[side]);
     A.le_chi2[e] = c2;
     double w, rho0 = c2;
-    if (fl & EF_ROBUST) rho0 = huber(c2, (fl & EF_PAIRSTEREO) ? W.th_ln_stereo : W.th_ln_mono, &w);
+    if (fl & EF_ROBUST) rho0 = huber_nr(c2, (fl & EF_PAIRSTEREO) ? W.th_ln_stereo : W.th_ln_mono, &w);
     chi += rho0;
   }
   return chi;

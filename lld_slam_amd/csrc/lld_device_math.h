@@ -99,6 +99,39 @@ LLD_HD Quat quat_mul(const Quat& a, const Quat& b) {
   return r;
 }
 
+// 1 / z and 1 / sqrt(d) for the kernels' inner loops.  On the device: v_rcp_f64 / v_rsq_f64 seed + two Newton steps - within an ulp or two of
+// the correctly rounded quotient, ~8 instructions where the IEEE division and square root the compiler emits for `1.0 / z` and `sqrt(d)` are
+// ~15 and ~20 dependent ones.  On the host (the few host-side uses of this header): the plain expressions.
+LLD_HD double rcp_nr(double z) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double r = __builtin_amdgcn_rcp(z);
+  r = r * (2.0 - z * r);
+  r = r * (2.0 - z * r);
+  return r;
+#else
+  return 1.0 / z;
+#endif
+}
+LLD_HD double rsqrt_nr(double d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double y = __builtin_amdgcn_rsq(d);
+  y = y * (1.5 - (0.5 * d) * (y * y));
+  y = y * (1.5 - (0.5 * d) * (y * y));
+  return y;
+#else
+  return 1.0 / sqrt(d);
+#endif
+}
+
+// kFast (the batched BA kernels): one reciprocal square root and four products instead of a square root and four divisions
+template <bool kFast>
+LLD_HD Quat quat_unit_t(const Quat& q) {
+  const double n2 = q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w;
+  Quat r;
+  if (kFast) { const double in = rsqrt_nr(n2); r.x = q.x * in; r.y = q.y * in; r.z = q.z * in; r.w = q.w * in; }
+  else { const double n = sqrt(n2); r.x = q.x / n; r.y = q.y / n; r.z = q.z / n; r.w = q.w / n; }
+  return r;
+}
 LLD_HD Quat quat_unit(const Quat& q) {
   const double n = sqrt(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
   Quat r; r.x = q.x / n; r.y = q.y / n; r.z = q.z / n; r.w = q.w / n;
@@ -171,6 +204,7 @@ LLD_HD LineQ line_from_x0_dir(const Vec3& X0, const Vec3& d) {
 }
 // LineParams::GetR — every read normalises q (types/types_sba.cpp:77-79,89-92)
 LLD_HD Mat3 line_rotation(const LineQ& l) { return quat_rotation(quat_unit(l.q)); }
+template <bool kFast> LLD_HD Mat3 line_rotation_t(const LineQ& l) { return quat_rotation(quat_unit_t<kFast>(l.q)); }
 // VertexSBALine::oplusImpl (types/types_sba.h:93-104)
 LLD_HD LineQ line_oplus(const LineQ& l, const double* u) {
   Quat qr; qr.x = u[0]; qr.y = u[1]; qr.z = u[2];
@@ -190,6 +224,22 @@ LLD_HD CamK make_camk(const lld_camera& c) {
 // ---------------------------------------------------------------- point edges
 // Residuals.  EdgeStereoSE3ProjectXYZ::cam_project keeps `invz` (and, in the binary edge, `bf`) in float
 // (types_six_dof_expmap.cpp:152-159, :305-312); `binary` selects float bf*invz (LBA) vs double (pose-only).
+// The same with 1 / Xc.z supplied by the caller (the batched BA kernels need it for the Jacobians anyway and pass rcp_nr(Xc.z): the
+// float `invz` of a stereo edge then differs from the reference's only where the double quotient sits within an ulp of a float rounding
+// boundary, the mono projection by an ulp of its double product).
+LLD_HD void point_residual_iz(const CamK& k, const Vec3& Xc, double iz, double u, double v, double ur, bool stereo, bool binary, double* e) {
+  if (stereo) {
+    const float invz = (float)iz;
+    const double r0 = Xc.x * (double)invz * k.fx + k.cx;
+    const double r1 = Xc.y * (double)invz * k.fy + k.cy;
+    const double shift = binary ? (double)(k.bf_f * invz) : k.bf * (double)invz;
+    e[0] = u - r0; e[1] = v - r1; e[2] = ur - (r0 - shift);
+  } else {
+    e[0] = u - (Xc.x * iz * k.fx + k.cx);
+    e[1] = v - (Xc.y * iz * k.fy + k.cy);
+    e[2] = 0.0;
+  }
+}
 LLD_HD void point_residual(const CamK& k, const Vec3& Xc, double u, double v, double ur, bool stereo, bool binary, double* e) {
   if (stereo) {
     const float invz = (float)(1.0 / Xc.z);
@@ -296,18 +346,21 @@ LLD_HD void point_g_closed_iz(const CamK& k, const Vec3& Xc, double iz, const Ma
 // vectors a1,a2 with  d r_k = a1[k] . dX1m + a2[k] . dX2m  (X1m, X2m = endpoints in the camera frame, without b).
 // K1 = [[f,0,cx],[0,f,cy],[0,0,1]] with the single focal f = fx.
 struct LineAdj { Vec3 a1[2], a2[2]; };
-LLD_HD void line_residual(const CamK& k, double bx, const Vec3& X1m, const Vec3& X2m, double xs, double ys, double xe, double ye,
-                          double* e, LineAdj* adj) {
+template <bool kFast>
+LLD_HD void line_residual_t(const CamK& k, double bx, const Vec3& X1m, const Vec3& X2m, double xs, double ys, double xe, double ye,
+                            double* e, LineAdj* adj) {
   const double f = k.fx;
   const Vec3 P1 = vec3(f * (X1m.x + bx) + k.cx * X1m.z, f * X1m.y + k.cy * X1m.z, X1m.z);
   const Vec3 P2 = vec3(f * (X2m.x + bx) + k.cx * X2m.z, f * X2m.y + k.cy * X2m.z, X2m.z);
   const Vec3 lt = cross(P1, P2);
   const double n2 = lt.x * lt.x + lt.y * lt.y;
-  const double n = sqrt(n2), in = 1.0 / n;
+  // kFast (the batched BA kernels): 1 / n by rsqrt_nr and 1 / n^3 as its cube instead of a square root and two divisions
+  double in;
+  if (kFast) in = rsqrt_nr(n2); else { const double n = sqrt(n2); in = 1.0 / n; }
   const double d1 = xs * lt.x + ys * lt.y + lt.z, d2 = xe * lt.x + ye * lt.y + lt.z;   // x_k . l~
   e[0] = d1 * in; e[1] = d2 * in;
   if (adj) {
-    const double in3 = in / n2;
+    const double in3 = kFast ? in * in * in : in / n2;
     const double px[2] = {xs, xe}, py[2] = {ys, ye}, dd[2] = {d1, d2};
     for (int q = 0; q < 2; q++) {
       // g = D^T x_k = x_k/n - (x_k . l~)/n^3 * (l~x, l~y, 0)
@@ -318,6 +371,8 @@ LLD_HD void line_residual(const CamK& k, double bx, const Vec3& X1m, const Vec3&
     }
   }
 }
+LLD_HD void line_residual(const CamK& k, double bx, const Vec3& X1m, const Vec3& X2m, double xs, double ys, double xe, double ye,
+                          double* e, LineAdj* adj) { line_residual_t<false>(k, bx, X1m, X2m, xs, ys, xe, ye, e, adj); }
 // Pose Jacobian (2x6) from the adjoints: d r / d omega = X1m x a1 + X2m x a2, d r / d upsilon = a1 + a2
 // (FormJacobianLineWRTCam, types_six_dof_expmap.cpp:472-497, A_i = [-K skew(X_im) | K]).
 LLD_HD void line_jac_pose(const LineAdj& adj, const Vec3& X1m, const Vec3& X2m, double* Jc) {
@@ -364,6 +419,15 @@ LLD_HD bool line_depth_positive(const CamK& k, double bx, const Pose& T, const V
 }
 
 // RobustKernelHuber::robustify (core/robust_kernel_impl.cpp:78-91): returns rho0, writes rho1
+// The same without a branch and without the square root / division pair (the batched BA kernels): nearly every wavefront holds an outlier edge,
+// so all of them took the branch; sqrt(e) = e / sqrt(e).
+LLD_HD double huber_nr(double e, double delta, double* rho1) {
+  const double dsqr = delta * delta;
+  const bool in = e <= dsqr;
+  const double is = rsqrt_nr(in ? 1.0 : e);
+  *rho1 = in ? 1.0 : delta * is;
+  return in ? e : 2 * (e * is) * delta - dsqr;
+}
 LLD_HD double huber(double e, double delta, double* rho1) {
   const double dsqr = delta * delta;
   if (e <= dsqr) { *rho1 = 1.0; return e; }
