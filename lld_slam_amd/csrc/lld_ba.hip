@@ -73,7 +73,7 @@ struct lld_ba_batch {
   // window groups solved concurrently, each on its own stream (hides the latency-bound reduced solve, the per-super-step
   // host poll and kernel tails behind the other groups' work)
   struct Group { int w0 = 0, nw = 0; hipStream_t st = nullptr; bool own_stream = false; int* d_counters = nullptr; int* h_counters = nullptr;
-                 hipEvent_t ev[kChunkSmall][kNumPhases + 1] = {}; int chunk = 1, chunk0 = 1, chunk_from = 0; int steps = 0; bool active = false; int rows = 0; int map_parity = 0; int max_nt_pt = 0, max_nb_ln = 0, max_nl_pt = 0, max_nl_ln = 0, max_lblocks = 0, max_items_pt = 0, max_items_ln = 0, max_blk = 0; bool any_sparse = false, any_dense = false; };
+                 hipEvent_t ev[kChunkSmall][kNumPhases + 1] = {}; int chunk = 1, chunk0 = 1, chunk_from = 0; hipGraph_t graph = nullptr; hipGraphExec_t gexec = nullptr; int steps = 0; bool active = false; int rows = 0; int map_parity = 0; int max_nt_pt = 0, max_nb_ln = 0, max_nl_pt = 0, max_nl_ln = 0, max_lblocks = 0, max_items_pt = 0, max_items_ln = 0, max_blk = 0; bool any_sparse = false, any_dense = false; };
   std::vector<Group> groups;
   int* d_counters = nullptr; int* h_counters = nullptr;               // device / pinned, 4 ints per group
   int* d_slot_map = nullptr; int* d_active_pub = nullptr;            // per window: grid row -> window map of its group, published "still at work" bits (BAArrays::slot_map)
@@ -516,6 +516,8 @@ void stage_chol_plan(int n_free, int force, WinStage& S) {
 static void ba_drop_groups(lld_ba_batch* B) {
   for (auto& G : B->groups) {
     if (G.own_stream && G.st) (void)hipStreamSynchronize(G.st);
+    if (G.gexec) { (void)hipGraphExecDestroy(G.gexec); G.gexec = nullptr; }      // (experiments build: LLD_BA_GRAPH)
+    if (G.graph) { (void)hipGraphDestroy(G.graph); G.graph = nullptr; }
     if (B->borrowed) continue;                         // streams and events belong to the context's cache
     for (auto& row : G.ev) for (auto& e : row) if (e) (void)hipEventDestroy(e);
     if (G.own_stream && G.st) (void)hipStreamDestroy(G.st);
@@ -1029,13 +1031,17 @@ static int ba_batch_solve_impl(lld_ba_batch* B, StopFlag abort_flag) {
                                             int* wr = B->d_slot_map + (size_t)(G.map_parity ^ 1) * ((size_t)B->n_windows + 1) + G.w0;
                                             Ag.slot_map = use_slots ? wr : nullptr; Ag.active_pub = use_slots ? B->d_active_pub + G.w0 : nullptr;
                                             Ag.slot_rd = (use_slots && G.rows < G.nw) ? rd : nullptr; return Ag; };
+  // Experiments build, LLD_BA_GRAPH=1: the queued super-steps of a small group (28 launches) are captured once per batch and group into a
+  // hipGraph and replayed per poll (all rows every time: the grid must not change).  Measured, not the default: profiles/NOTES_r05.md.
+  static const bool use_graph = exp_flag("LLD_BA_GRAPH");
+  bool capturing = false;
   auto launch_superstep = [&](Group& G, int q) -> int {
     const BAWin* dw = B->d_wins + G.w0; BAState* ds = B->d_state + G.w0;
     const BAArrays A = group_arrays(G);                                // (shadows the batch's arrays: every launch below is per group)
     const int nw = use_slots ? std::max(1, std::min(G.rows, G.nw)) : G.nw; hipStream_t st = G.st;
     const int abort_now = abort_flag.up() ? 1 : 0;
     hipEvent_t* ev = G.ev[q];
-    const bool tev = B->phase_events;                                  // per-phase HIP events (lld_ba_batch_phase_ms); ev[5], the end of the super-step, is always recorded
+    const bool tev = B->phase_events && !capturing;                    // per-phase HIP events (lld_ba_batch_phase_ms); ev[5], the end of the super-step, is always recorded
     if (tev) LLD_HIP_TRY(hipEventRecord(ev[0], st));
     static const int fuse_below = exp_int("LLD_BA_FUSE_BELOW", kFusePairsBelowWindows);
     const bool packed = A.packed != 0;                                 // the layout of the observations picks the kernel variant (lld_ba_kernels.h: kPk)
@@ -1110,11 +1116,27 @@ static int ba_batch_solve_impl(lld_ba_batch* B, StopFlag abort_flag) {
       hipLaunchKernelGGL(ba_classify_kernel, dim3(std::max(1, G.max_lblocks), nw), dim3(kLmThreads), 0, st, A, dw, ds);      // (its last workgroup per window starts round 2)
     }
     LLD_HIP_TRY(hipGetLastError());
-    if (tev || q == G.chunk - 1) LLD_HIP_TRY(hipEventRecord(ev[5], st));
+    if (!capturing && (tev || q == G.chunk - 1)) LLD_HIP_TRY(hipEventRecord(ev[5], st));
     G.map_parity ^= 1;                                   // the next launch reads the map this one's control wrote
     return LLD_OK;
   };
   auto launch_chunk = [&](Group& G) -> int {
+    if (use_graph && G.chunk > 1 && (G.chunk & 1) == 0) {
+      if (!G.gexec) {
+        G.rows = G.nw;
+        LLD_HIP_TRY(hipStreamBeginCapture(G.st, hipStreamCaptureModeThreadLocal));
+        capturing = true;
+        int s_ = LLD_OK;
+        for (int q = 0; q < G.chunk && s_ == LLD_OK; q++) s_ = launch_superstep(G, q);
+        capturing = false;
+        LLD_HIP_TRY(hipStreamEndCapture(G.st, &G.graph));
+        if (s_) return s_;
+        LLD_HIP_TRY(hipGraphInstantiate(&G.gexec, G.graph, nullptr, nullptr, 0));
+      }
+      LLD_HIP_TRY(hipGraphLaunch(G.gexec, G.st));
+      LLD_HIP_TRY(hipEventRecord(G.ev[G.chunk - 1][5], G.st));
+      return LLD_OK;
+    }
     for (int q = 0; q < G.chunk; q++) { const int s_ = launch_superstep(G, q); if (s_) return s_; }
     return LLD_OK;
   };
@@ -1166,7 +1188,7 @@ static int ba_batch_solve_impl(lld_ba_batch* B, StopFlag abort_flag) {
       G.steps += G.chunk; B->super_steps += G.chunk;
       const int n_run = G.h_counters[0], n_trans = G.h_counters[1], n_fin = G.h_counters[2];
       const BAWin* dw = B->d_wins + G.w0; BAState* ds = B->d_state + G.w0;
-      if (use_slots) G.rows = n_run + n_trans;      // the control kernel left exactly these windows in the group's row map
+      if (use_slots && !(use_graph && G.gexec)) G.rows = n_run + n_trans;      // the control kernel left exactly these windows in the group's row map
       // The tail of a large solve - the few windows with rejected trials, a tenth of the solve's time at a tenth of the chip - no longer
       // holds the device's turn: the next lane's solve starts under it (host-buffer pipeline: lld_ba_batch_solve calls from other contexts).
       if (turn.owns_lock() && use_slots) {

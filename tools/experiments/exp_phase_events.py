@@ -20,5 +20,5 @@ with Context(0, lib=lib) as ctx, BABatch(ctx, ws) as b:
         t0 = time.perf_counter(); b.solve(); t.append((time.perf_counter() - t0) * 1e3)
     ph = b.phase_ms()
     st = b.stats()
-print("%-8s phase events  %3d windows  solve wall ms: min %.3f median %.3f   device total %.3f ms   trials of window 0: %d" %
-      ("with" if ON else "without", nw, min(t), float(np.median(t)), ph[5], sum(st[0]["lm_trials"])))
+print("%-8s phase events  %3d windows  solve wall ms: min %.3f median %.3f   device total %.3f ms   trials of window 0: %d  chi2 %.12g%s" %
+      ("with" if ON else "without", nw, min(t), float(np.median(t)), ph[5], sum(st[0]["lm_trials"]), st[0]["chi2_final"], "  [hipGraph]" if os.environ.get("LLD_BA_GRAPH") else ""))
