@@ -1046,6 +1046,8 @@ static int ba_batch_solve_impl(lld_ba_batch* B, StopFlag abort_flag) {
     static const int fuse_below = exp_int("LLD_BA_FUSE_BELOW", kFusePairsBelowWindows);
     const bool packed = A.packed != 0;                                 // the layout of the observations picks the kernel variant (lld_ba_kernels.h: kPk)
     const bool fuse_pairs = nw < fuse_below && !B->big && packed;      // see ba_linearize_both_kernel
+    static const int fuse_bs_below = exp_int("LLD_BA_FUSE_BS_BELOW", -1);   // experiments: the back-substitution pair (+ control) fused up to another group size than the linearisation pair
+    const bool fuse_bs = fuse_bs_below >= 0 ? (nw < fuse_bs_below && !B->big && packed) : fuse_pairs;
     if (B->big) {
       if (G.max_nl_pt > 0) hipLaunchKernelGGL(ba_linearize_pt_big_kernel, dim3(G.max_nl_pt, nw), dim3(64 * B->lin_waves[0]), lin_lds_pt, st, A, dw, ds);
       if (G.max_nl_ln > 0) hipLaunchKernelGGL(ba_linearize_ln_big_kernel, dim3(G.max_nl_ln, nw), dim3(64 * B->lin_waves[1]), lin_lds_ln, st, A, dw, ds);
@@ -1099,7 +1101,7 @@ static int ba_batch_solve_impl(lld_ba_batch* B, StopFlag abort_flag) {
     if (B->big) {
       if (G.max_nt_pt > 0) hipLaunchKernelGGL(ba_backsub_pt_big_kernel, dim3(G.max_nt_pt, nw), dim3(kLmThreads), bs_lds, st, A, dw, ds);
       if (G.max_nb_ln > 0) hipLaunchKernelGGL(ba_backsub_ln_big_kernel, dim3(G.max_nb_ln, nw), dim3(kLmThreads), bs_lds, st, A, dw, ds);
-    } else if (fuse_pairs && G.max_nt_pt > 0 && G.max_nb_ln > 0) {
+    } else if (fuse_bs && G.max_nt_pt > 0 && G.max_nb_ln > 0) {
       // small groups: both landmark kinds AND the LM control (run by each window's last workgroup) in one launch
       hipLaunchKernelGGL(ba_backsub_ctl_kernel, dim3(G.max_nt_pt + G.max_nb_ln, nw), dim3(kLmThreads), bs_lds, st, A, dw, ds, G.max_nt_pt, abort_now, G.nw, G.d_counters, G.h_counters,
                          (live_flag && G.chunk > 1) ? B->h_abort : nullptr);
