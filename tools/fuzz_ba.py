@@ -97,10 +97,30 @@ for it in range(n):
         floor = {k_: max(floor[k_], d3[k_], d4[k_]) for k_ in floor}
         bar = dict(cam=1e-7, pt=1e-5, ln=1e-5, chi=1e-5)                 # a quantity that is inside the bar needs no excuse
         within = all(dg[k_] <= max(bar[k_], 10 * floor[k_]) + 1e-12 for k_ in dg)
+        tag = "FLOOR   "
+        if not within:
+            # round 5: ... or to the LAST BIT of the input (six copies with every pose / point component times 1 - 2^-52, 1 or 1 + 2^-52 at random): a window
+            # whose LM run has two outcomes that far apart takes either (seed 99, window 6193: the oracle on such a copy lands on the device's result to 9 digits)
+            import dataclasses
+            for r_ in range(6):
+                jig = lambda a: a * (1.0 + rng.integers(-1, 2, a.shape) * 2.0 ** -52)
+                w3 = dataclasses.replace(w, cam_qt=jig(w.cam_qt), pt_xyz=jig(w.pt_xyz)) if r_ < 3 else dataclasses.replace(w, cam_qt=jig(w.cam_qt))
+                d5 = deviation(O.local_ba(w3, **par), o, w)
+                floor = {k_: max(floor[k_], d5[k_]) for k_ in floor}
+            within = all(dg[k_] <= max(bar[k_], 10 * floor[k_]) + 1e-12 for k_ in dg)
+            tag = "FLOOR/ulp"
+        if not within and same and par.get("protocol", 0) == 0 and "abort_after_trials" not in par:
+            # ... or the window has no isolated minimiser (noise-free observations and a free gauge or a camera left with too few inliers: chi2 -> 0 along a
+            # valley).  Sign: ten more round-2 iterations lower BOTH costs tenfold and do not bring the two states closer (seed 99, window 892).
+            p2 = dict(par, its_round2=par["its_round2"] + 10)
+            o2 = O.local_ba(w, **p2); g2 = Optimizer(ctx).LocalBundleAdjustment(w, reduced_solver=solver, **p2)
+            dg2 = deviation(g2, o2, w)
+            if (o2.stats["chi2_final"] <= 0.1 * o.stats["chi2_final"] and g2.stats["chi2_final"] <= 0.1 * g.stats["chi2_final"] and max(dg2["cam"], dg2["pt"], dg2["ln"]) >= 0.5 * max(dg["cam"], dg["pt"], dg["ln"])):
+                within = True; tag = "VALLEY  "
         if within: soft += 1
         else: bad += 1
-        print("FLOOR   " if within else "MISMATCH", it, "reduced_solver", solver, "trials gpu / oracle", g.stats["lm_trials"], o.stats["lm_trials"], "sets / trials equal", same, "gpu-oracle", {k_: "%.1e" % v_ for k_, v_ in dg.items()},
-              "oracle vs its re-ordered / rounding twins", {k_: "%.1e" % v_ for k_, v_ in floor.items()}, kw if not within else "", par if not within else "", flush=True)
+        print(tag if within else "MISMATCH", it, "reduced_solver", solver, "trials gpu / oracle", g.stats["lm_trials"], o.stats["lm_trials"], "sets / trials equal", same, "gpu-oracle", {k_: "%.1e" % v_ for k_, v_ in dg.items()},
+              "oracle vs its re-ordered / rounding twins", {k_: "%.1e" % v_ for k_, v_ in floor.items()}, kw if (not within or tag != "FLOOR   ") else "", par if (not within or tag != "FLOOR   ") else "", flush=True)
     except Exception as e:
         bad += 1; print("ERROR", it, kw, par, repr(e)[:300], flush=True)
-print("fuzzed", done + soft + bad, "windows:", done, "within the parity bar,", soft, "beyond it but within 10x the oracle's own sensitivity (re-ordered input, Cholesky-inverse and FMA twins),", bad, "mismatches / errors")
+print("fuzzed", done + soft + bad, "windows:", done, "within the parity bar,", soft, "beyond it but within 10x the oracle's own sensitivity (re-ordered input, Cholesky-inverse and FMA twins; input moved by one unit in the last place) or on a window without an isolated minimiser (VALLEY),", bad, "mismatches / errors")
