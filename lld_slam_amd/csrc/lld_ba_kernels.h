@@ -1734,21 +1734,21 @@ __global__ __launch_bounds__(kSchurThreads) void ba_schur_items_kernel(BAArrays 
   if (C.k <= kSchurWideK) schur_chunk_wave<D>(A, W, C, S.lambda, S.cur, lds);   // (wider chunks: ba_schur_wide_kernel)
 }
 
-// Point and line chunks in ONE launch: grid (n_pt_blocks + max line chunks, nW).  The line chunks fill the tail of the point
+// Point and line chunks in ONE launch: grid (nW, n_pt_blocks + max line chunks) - the windows run fastest, chunks are stored heaviest first (stage_chunks).  The line chunks fill the tail of the point
 // chunks instead of waiting for it - for a single window the two kernels were two dependent 17 us launches on an otherwise idle GPU.
 __global__ __launch_bounds__(kSchurThreads) void ba_schur_items_both_kernel(BAArrays A, const BAWin* __restrict__ wins, const BAState* __restrict__ st, int n_pt_blocks) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  const int wrow = LLD_ROW_WINDOW(A, st, blockIdx.y);
+  const int wrow = LLD_ROW_WINDOW(A, st, blockIdx.x);
   if (wrow < 0) return;
   const BAWin W = wins[wrow];
   const BAState& S = st[wrow];
   if (S.phase != PH_RUN) return;
-  if ((int)blockIdx.x < n_pt_blocks) {
-    if ((int)blockIdx.x >= W.n_items_pt) return;
-    const SChunk C = A.sg_chunks[W.item_off + blockIdx.x];
+  if ((int)blockIdx.y < n_pt_blocks) {
+    if ((int)blockIdx.y >= W.n_items_pt) return;
+    const SChunk C = A.sg_chunks[W.item_off + blockIdx.y];
     if (C.k <= kSchurWideK) schur_chunk_wave<3>(A, W, C, S.lambda, S.cur, lds);
   } else {
-    const int i = (int)blockIdx.x - n_pt_blocks;
+    const int i = (int)blockIdx.y - n_pt_blocks;
     if (i >= W.n_items - W.n_items_pt) return;
     const SChunk C = A.sg_chunks[W.item_off + W.n_items_pt + i];
     if (C.k <= kSchurWideK) schur_chunk_wave<4>(A, W, C, S.lambda, S.cur, lds);
