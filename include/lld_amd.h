@@ -241,9 +241,12 @@ int  lld_ba_batch_set_phase_timing(lld_ba_batch* batch, int on);
 int  lld_ba_batch_phase_ms(lld_ba_batch* batch, double* ms6);
 /* Launch count (always) and summed HIP-event time (phase timing on) of one kernel family in the last solve; `kernel` uses the phase ids 0..4. */
 int  lld_ba_batch_kernel_stats(lld_ba_batch* batch, int kernel, int64_t* launches, double* total_ms);
-/* Tuning: number of window groups solved concurrently on separate HIP streams (1..8; 0 restores the default chosen from the
- * batch size).  One group makes the HIP-event times of lld_ba_batch_phase_ms disjoint, which is what a roofline measurement
- * wants; several groups hide the latency-bound reduced solve and the per-super-step host poll. */
+/* Tuning: number of window groups solved concurrently on separate HIP streams (1..8; 0 restores the default: one group below 8 windows,
+ * three from 8, four from 16 - the device runs four streams side by side and time-slices a fifth -, and two for a batch of >= 64 windows
+ * that was CREATED WHILE ANOTHER BATCH'S SOLVE RAN on the device: such a batch belongs to a pipelined caller whose other contexts' uploads
+ * and downloads need streams of their own during its solve).  One group makes the HIP-event times of lld_ba_batch_phase_ms disjoint,
+ * which is what a roofline measurement wants; several groups hide the latency-bound reduced solve and the per-super-step host poll.
+ * Results do not depend on the grouping (bit-identical in the default deterministic mode). */
 int  lld_ba_batch_set_groups(lld_ba_batch* batch, int n_groups);
 void lld_ba_batch_destroy(lld_ba_batch* batch);
 
