@@ -737,6 +737,48 @@ static int ba_batch_create_impl(lld_ctx* ctx, int n_windows, const lld_ba_window
     worker();
     for (auto& t : pool) t.join();
   };
+  // ---- Section A travels WHILE it is written (round 5).  Its place in the slab - the start - and its size follow from the window sizes alone, and a
+  // context that has solved a batch before already owns a slab: the windows are cut into up to eight ranges, and the staging thread that finishes
+  // the last window of a range queues that range's slices of every section-A array on the context's stream.  For 256 LBA-B windows the 590 MB
+  // upload (12 ms at link speed) used to start when the last window was staged; now it ends about when staging does (one synchronous lane, host
+  // buffers in and results out: 3.8 k -> see profiles/NOTES_r05.md).  If the slab turns out too small for the rest of the batch it is re-grown
+  // and the whole section goes again, as before.
+  void* const early_slab = (cached && n_windows >= 32 && cache.slab && cache.slab_bytes >= bytesA + 4096 && !exp_flag("LLD_BA_POISON") && !exp_flag("LLD_BA_NO_EARLY_UPLOAD")) ? cache.slab : nullptr;
+  const int n_ranges = early_slab ? std::min(8, n_windows / 16) : 0;
+  std::unique_ptr<std::atomic<int>[]> range_left(n_ranges ? new std::atomic<int>[(size_t)n_ranges] : nullptr);
+  auto range_lo = [&](int r) { return (int)((long long)n_windows * r / std::max(1, n_ranges)); };
+  for (int r = 0; r < n_ranges; r++) range_left[(size_t)r].store(range_lo(r + 1) - range_lo(r));
+  auto copy_rows = [&](const void* hbase, size_t elt, long long lo, long long hi) -> bool {
+    if (!hbase || hi <= lo) return true;
+    const char* h = static_cast<const char*>(hbase) + elt * (size_t)lo;
+    char* d = static_cast<char*>(early_slab) + (h - static_cast<const char*>(arenaA));
+    return hipMemcpyAsync(d, h, elt * (size_t)(hi - lo), hipMemcpyHostToDevice, ctx->stream) == hipSuccess;
+  };
+  auto early_copy = [&](int r) {
+    if (hipSetDevice(ctx->device) != hipSuccess) { int ok = LLD_OK; first_error.compare_exchange_strong(ok, LLD_ERR_HIP); return; }
+    const WinBases& a = bases[(size_t)range_lo(r)]; const WinBases& b = bases[(size_t)range_lo(r + 1)];
+    bool ok = copy_rows(hA.cam_qt0, 7 * sizeof(double), a.NC, b.NC) && copy_rows(hA.pt0, 3 * sizeof(double), a.NP, b.NP) &&
+              copy_rows(hA.ln_x0, 3 * sizeof(double), a.NL, b.NL) && copy_rows(hA.ln_dir, 3 * sizeof(double), a.NL, b.NL) &&
+              copy_rows(hA.pt_obs_start, sizeof(int), a.NP, b.NP) && copy_rows(hA.ln_obs_start, sizeof(int), a.NL, b.NL) && copy_rows(hA.pe_pt, sizeof(int), a.NPE, b.NPE);
+    if (packed)
+      ok = ok && copy_rows(hA.pe_obs, sizeof(float4), a.NPE, b.NPE) && copy_rows(hA.pe_cs, sizeof(int), a.NPE, b.NPE) && copy_rows(hA.lo_seg, sizeof(float4), 2 * a.NLO, 2 * b.NLO) &&
+           copy_rows(hA.lo_cs, sizeof(int), a.NLO, b.NLO) && copy_rows(hA.lo_ln, sizeof(int), a.NLO, b.NLO) && copy_rows(hA.lo_oct, sizeof(unsigned short), a.NLO, b.NLO);
+    else
+      ok = ok && copy_rows(hA.pe_cam, sizeof(int), a.NPE, b.NPE) && copy_rows(hA.pe_u, sizeof(double), a.NPE, b.NPE) && copy_rows(hA.pe_v, sizeof(double), a.NPE, b.NPE) &&
+           copy_rows(hA.pe_ur, sizeof(double), a.NPE, b.NPE) && copy_rows(hA.pe_s, sizeof(double), a.NPE, b.NPE) &&
+           copy_rows(hA.le_cam, sizeof(int), 2 * a.NLO, 2 * b.NLO) && copy_rows(hA.le_ln, sizeof(int), 2 * a.NLO, 2 * b.NLO) &&
+           copy_rows(hA.le_xs, sizeof(double), 2 * a.NLO, 2 * b.NLO) && copy_rows(hA.le_ys, sizeof(double), 2 * a.NLO, 2 * b.NLO) && copy_rows(hA.le_xe, sizeof(double), 2 * a.NLO, 2 * b.NLO) &&
+           copy_rows(hA.le_ye, sizeof(double), 2 * a.NLO, 2 * b.NLO) && copy_rows(hA.le_s, sizeof(double), 2 * a.NLO, 2 * b.NLO);
+    if (!ok) { int e_ = LLD_OK; first_error.compare_exchange_strong(e_, LLD_ERR_HIP); }
+  };
+  auto window_staged = [&](int wi) {            // (every write into section A of window wi has been made)
+    if (!n_ranges) return;
+    int r = (int)(((long long)wi * n_ranges) / n_windows);
+    while (r + 1 < n_ranges && wi >= range_lo(r + 1)) r++;
+    while (r > 0 && wi < range_lo(r)) r--;
+    if (range_left[(size_t)r].fetch_sub(1) == 1) early_copy(r);
+  };
+  if (n_ranges) uploads_queued = true;
   const auto lap1 = [&](const char* what) { if (n_windows == 1) lap(what); };
   for_windows([&](int wi) {
     const int st = validate_window(wins[wi]);
@@ -757,6 +799,7 @@ static int ba_batch_create_impl(lld_ctx* ctx, int n_windows, const lld_ba_window
     } else {
       if (!stage_edges(wins[wi], P, bases[wi], W, S, H)) { int ok = LLD_OK; first_error.compare_exchange_strong(ok, kNotPacked); return; }
       lap1("edges flattened");
+      window_staged(wi);
       stage_chunks(wins[wi], 3, bases[wi], B->chunk_landmarks, S.cs[0]);
       stage_chunks(wins[wi], 4, bases[wi], B->chunk_landmarks, S.cs[1]);
     }
@@ -885,9 +928,13 @@ static int ba_batch_create_impl(lld_ctx* ctx, int n_windows, const lld_ba_window
   if (A.chol_stamps && hipMemsetAsync(A.chol_stamps, 0, sizeof(long long) * (size_t)n_windows * kCholStampWaves * kCholStampSlots, st) != hipSuccess) return fail(LLD_ERR_HIP);
 #endif
   if (s_skip_empty && S_total > 0 && hipMemsetAsync(A.S, 0, S_total * sizeof(double), st) != hipSuccess) return fail(LLD_ERR_HIP);
-  // section A leaves now and travels while the host places section B
+  // section A leaves now and travels while the host places section B - unless its ranges left while they were staged (above): then only what no
+  // window owns is still to go (the level table of the line information, the closing entries of the two observation CSRs)
   uploads_queued = true;
-  if (hipMemcpyAsync((char*)B->slab + offA, arenaA, bytesA, hipMemcpyHostToDevice, st) != hipSuccess) return fail(LLD_ERR_HIP);
+  if (n_ranges && B->slab == early_slab && offA == 0) {
+    bool ok = copy_rows(hA.ln_info, sizeof(double), 0, 256) && copy_rows(hA.pt_obs_start, sizeof(int), NP, NP + 1) && copy_rows(hA.ln_obs_start, sizeof(int), NL, NL + 1);
+    if (!ok) return fail(LLD_ERR_HIP);
+  } else if (hipMemcpyAsync((char*)B->slab + offA, arenaA, bytesA, hipMemcpyHostToDevice, st) != hipSuccess) return fail(LLD_ERR_HIP);
   lap("inputs queued");
   // ---- section B in its pinned arena: every window writes its pieces straight into their final places
   void* arenaB = nullptr;
