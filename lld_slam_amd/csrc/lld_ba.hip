@@ -32,6 +32,7 @@ constexpr int kMaxSuperSteps = 512;      // hard stop: 2 rounds x 15 iterations 
 // windows keep one poll per super-step: their polls hide behind the other groups' kernels, and two more launches per super-step
 // over that many windows cost more than they save (same sweep as kFusePairsBelowWindows).
 constexpr int kChunkSmall = 4, kChunkFromWindows = 24;
+constexpr int kSchurWindowTile = 8;      // ba_schur_items_both: windows per dispatch tile = XCDs of the device (see the kernel)
 // Experiment / debug knobs read from the environment exist only in the experiments build (make exp: -DLLD_EXPERIMENTS ->
 // liblld_amd_exp.so, loaded by tools/ and by the two tests that need LLD_BA_FORCE_BIG / LLD_BA_TIMING through LLD_AMD_LIB or abi.Lib).
 // The product library reads ONE variable, LLD_HOST_THREADS (host staging threads), documented in include/lld_amd.h.
@@ -1109,12 +1110,13 @@ static int ba_batch_solve_impl(lld_ba_batch* B, StopFlag abort_flag) {
     }
     hipLaunchKernelGGL(ba_hpp_reduce_kernel, dim3(std::max(1, (B->max_free * 27 + 255) / 256), nw), dim3(256), 0, st, A, dw, ds);
     if (tev) LLD_HIP_TRY(hipEventRecord(ev[1], st));
+    static const int schur_tile = std::max(1, exp_int("LLD_BA_SCHUR_TILE", kSchurWindowTile));
     static const bool split_schur = exp_flag("LLD_BA_SPLIT_SCHUR");             // experiments: the two launches of before
     if (split_schur) {
       if (G.max_items_pt > 0) hipLaunchKernelGGL(ba_schur_items_kernel<3>, dim3(G.max_items_pt, nw), dim3(kSchurThreads), B->schur_lds[0], st, A, dw, ds);
       if (G.max_items_ln > 0) hipLaunchKernelGGL(ba_schur_items_kernel<4>, dim3(G.max_items_ln, nw), dim3(kSchurThreads), B->schur_lds[1], st, A, dw, ds);
     } else if (G.max_items_pt + G.max_items_ln > 0) {
-      hipLaunchKernelGGL(ba_schur_items_both_kernel, dim3(nw, G.max_items_pt + G.max_items_ln), dim3(kSchurThreads), std::max(B->schur_lds[0], B->schur_lds[1]), st, A, dw, ds, G.max_items_pt);
+      hipLaunchKernelGGL(ba_schur_items_both_kernel, dim3(nw, G.max_items_pt + G.max_items_ln), dim3(kSchurThreads), std::max(B->schur_lds[0], B->schur_lds[1]), st, A, dw, ds, G.max_items_pt, schur_tile);
     }
     if (B->schur_wide_lds > 0) hipLaunchKernelGGL(ba_schur_wide_kernel, dim3(G.max_items_pt + G.max_items_ln, nw), dim3(kSchurWideThreads), B->schur_wide_lds, st, A, dw, ds);
     hipLaunchKernelGGL(ba_schur_reduce_kernel, dim3((std::max(1, G.max_blk) * 6 + 255) / 256 + 2, nw), dim3(256), 0, st, A, dw, ds);
