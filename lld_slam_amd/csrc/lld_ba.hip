@@ -450,7 +450,8 @@ void stage_chunks(const lld_ba_window& w, int D, const WinBases& b, int chunk_la
   }
   // Longest first: ba_schur_items takes one wavefront per chunk and its grid runs over the windows fastest, so every window's heaviest chunks are
   // dispatched first and the launch drains on the light ones (a chunk is self-contained - its offsets travel with it - so the order is free).
-  std::stable_sort(out.chunks.begin(), out.chunks.end(), [](const SChunk& a, const SChunk& b) {
+  // (a map of thousands of keyframes has ~1e5 chunks of one or two landmarks each: nothing to order there)
+  if (out.chunks.size() <= 4096) std::stable_sort(out.chunks.begin(), out.chunks.end(), [](const SChunk& a, const SChunk& b) {
     return (long long)a.n_lm * a.k * (a.k + 1) > (long long)b.n_lm * b.k * (b.k + 1); });
 }
 
@@ -1116,7 +1117,7 @@ static int ba_batch_solve_impl(lld_ba_batch* B, StopFlag abort_flag) {
       if (G.max_items_pt > 0) hipLaunchKernelGGL(ba_schur_items_kernel<3>, dim3(G.max_items_pt, nw), dim3(kSchurThreads), B->schur_lds[0], st, A, dw, ds);
       if (G.max_items_ln > 0) hipLaunchKernelGGL(ba_schur_items_kernel<4>, dim3(G.max_items_ln, nw), dim3(kSchurThreads), B->schur_lds[1], st, A, dw, ds);
     } else if (G.max_items_pt + G.max_items_ln > 0) {
-      hipLaunchKernelGGL(ba_schur_items_both_kernel, dim3(nw, G.max_items_pt + G.max_items_ln), dim3(kSchurThreads), std::max(B->schur_lds[0], B->schur_lds[1]), st, A, dw, ds, G.max_items_pt, schur_tile);
+      hipLaunchKernelGGL(ba_schur_items_both_kernel, dim3((unsigned)((long long)nw * (G.max_items_pt + G.max_items_ln))), dim3(kSchurThreads), std::max(B->schur_lds[0], B->schur_lds[1]), st, A, dw, ds, G.max_items_pt, schur_tile, nw, G.max_items_pt + G.max_items_ln);
     }
     if (B->schur_wide_lds > 0) hipLaunchKernelGGL(ba_schur_wide_kernel, dim3(G.max_items_pt + G.max_items_ln, nw), dim3(kSchurWideThreads), B->schur_wide_lds, st, A, dw, ds);
     hipLaunchKernelGGL(ba_schur_reduce_kernel, dim3((std::max(1, G.max_blk) * 6 + 255) / 256 + 2, nw), dim3(256), 0, st, A, dw, ds);

@@ -1734,9 +1734,9 @@ __global__ __launch_bounds__(kSchurThreads) void ba_schur_items_kernel(BAArrays 
   if (C.k <= kSchurWideK) schur_chunk_wave<D>(A, W, C, S.lambda, S.cur, lds);   // (wider chunks: ba_schur_wide_kernel)
 }
 
-// Point and line chunks in ONE launch: grid (nW, n_pt_blocks + max line chunks) - the windows run fastest, chunks are stored heaviest first (stage_chunks).  The line chunks fill the tail of the point
+// Point and line chunks in ONE launch: grid (nW * (n_pt_blocks + max line chunks)), see the dispatch order below; chunks are stored heaviest first (stage_chunks).  The line chunks fill the tail of the point
 // chunks instead of waiting for it - for a single window the two kernels were two dependent 17 us launches on an otherwise idle GPU.
-__global__ __launch_bounds__(kSchurThreads) void ba_schur_items_both_kernel(BAArrays A, const BAWin* __restrict__ wins, const BAState* __restrict__ st, int n_pt_blocks, int win_tile) {
+__global__ __launch_bounds__(kSchurThreads) void ba_schur_items_both_kernel(BAArrays A, const BAWin* __restrict__ wins, const BAState* __restrict__ st, int n_pt_blocks, int win_tile, int nrow, int nch) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   // dispatch order (x fastest) -> (window row, chunk): tiles of win_tile windows, inside a tile the chunk index runs slowest.  Workgroups go to
   // the eight XCDs round-robin, so with a tile of 8 (any multiple of 8) ALL chunks of a window run on ONE XCD, close together in time: the sectors
@@ -1744,8 +1744,7 @@ __global__ __launch_bounds__(kSchurThreads) void ba_schur_items_both_kernel(BAAr
   // into one L2 once instead of into up to eight.  FETCH_SIZE of this kernel per launch of 256 windows, tools/experiments/exp_schur_tile.sh:
   // windows one after the other 671 k KiB, tile 8: 360 k, 16: 373 k, 32: 389 k, 64: 504 k, all 256: 766 k; the time is within noise from 8 to 32
   // and 3 - 4 % better than either extreme.  A window's chunks are stored heaviest first, so every tile drains on its light chunks.
-  const int nrow = (int)gridDim.x, nch = (int)gridDim.y;
-  const int lin = (int)blockIdx.y * nrow + (int)blockIdx.x;
+  const int lin = (int)blockIdx.x;                             // one-dimensional grid of nrow x nch workgroups (a map of thousands of keyframes has more chunks than gridDim.y may be)
   const int tile = lin / (win_tile * nch), row0 = tile * win_tile, tsz = min(win_tile, nrow - row0), rem = lin - tile * win_tile * nch;
   const int ci = rem / tsz, row = row0 + rem - ci * tsz;
   const int wrow = LLD_ROW_WINDOW(A, st, row);
