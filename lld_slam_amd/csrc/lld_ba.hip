@@ -1117,6 +1117,7 @@ static int ba_batch_solve_impl(lld_ba_batch* B, StopFlag abort_flag) {
       if (G.max_items_pt > 0) hipLaunchKernelGGL(ba_schur_items_kernel<3>, dim3(G.max_items_pt, nw), dim3(kSchurThreads), B->schur_lds[0], st, A, dw, ds);
       if (G.max_items_ln > 0) hipLaunchKernelGGL(ba_schur_items_kernel<4>, dim3(G.max_items_ln, nw), dim3(kSchurThreads), B->schur_lds[1], st, A, dw, ds);
     } else if (G.max_items_pt + G.max_items_ln > 0) {
+      if ((long long)nw * (G.max_items_pt + G.max_items_ln) > 0x7fffffffll) return LLD_ERR_UNSUPPORTED;      // (one workgroup per window and chunk)
       hipLaunchKernelGGL(ba_schur_items_both_kernel, dim3((unsigned)((long long)nw * (G.max_items_pt + G.max_items_ln))), dim3(kSchurThreads), std::max(B->schur_lds[0], B->schur_lds[1]), st, A, dw, ds, G.max_items_pt, schur_tile, nw, G.max_items_pt + G.max_items_ln);
     }
     if (B->schur_wide_lds > 0) hipLaunchKernelGGL(ba_schur_wide_kernel, dim3(G.max_items_pt + G.max_items_ln, nw), dim3(kSchurWideThreads), B->schur_wide_lds, st, A, dw, ds);
