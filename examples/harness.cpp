@@ -10,8 +10,11 @@
 //   harness lines <in> <out>    Tracking::AddLinesFrom + Tracking::MatchLinesLastKF
 //   harness init <in> <out>     ORBmatcher::SearchForInitialization
 //   harness loop <in> <out>     the relocalisation / Scw / SearchBySim3 matchers with their projection loops
+//   harness track <in> <out>    the Tracking thread's per-frame chain on one device-resident Frame (TrackWithMotionModel + TrackLocalMap,
+//                               lines included), repeated header[9] times with the host wall clock around every repeat
 //
 // File layout: int32 header (counts), then the arrays in the order they appear in the structs, native endianness.
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -221,8 +224,79 @@ int run_sim3(const char* in, const char* out) {
 
 }  // namespace
 
+// The frame-rate path, driven the way a patched Tracking thread would drive it: the Frame's keypoints and lines are uploaded once
+// (Frame constructor), then TrackWithMotionModel and TrackLocalMap are two calls that only queue work, and one download ends the frame.
+// header[10] != 0: the host also fetches stage 1's record between the two calls (what the reference's UpdateLocalMap needs).
+int run_track(const char* in, const char* out) {
+  Reader r(in);
+  int32_t h[16]; r.get(h, 16);      // nt n_levels n_last n_mp nl nr dim n_last_lines n_local_lines repeats download_between
+  const int nt = h[0], n_levels = h[1], n_last = h[2], n_mp = h[3], nl = h[4], nr = h[5], dim = h[6], n_ll = h[7], n_ml = h[8], repeats = h[9];
+  float fc[6]; r.get(fc, 6);        // min_x min_y max_x max_y grid_width_inv grid_height_inv
+  std::vector<float> scale, inv_sigma2; r.get(scale, n_levels); r.get(inv_sigma2, n_levels);
+  double dc[8]; r.get(dc, 8);       // fx fy cx cy bf gamma line_thr_base md_thr
+  std::vector<uint32_t> t_desc; std::vector<float> t_xy, t_ur, t_ang; std::vector<int32_t> t_oct;
+  r.get(t_desc, 8 * (size_t)nt); r.get(t_xy, 2 * (size_t)nt); r.get(t_oct, nt); r.get(t_ur, nt); r.get(t_ang, nt);
+  lld_frame_view view; r.get(&view, 1);
+  float Tcw[16]; r.get(Tcw, 16);
+  std::vector<float> l_pos, l_ang; std::vector<uint8_t> l_valid, l_obs; std::vector<int32_t> l_oct, l_id; std::vector<uint32_t> l_desc;
+  r.get(l_pos, 3 * (size_t)n_last); r.get(l_valid, n_last); r.get(l_oct, n_last); r.get(l_ang, n_last); r.get(l_desc, 8 * (size_t)n_last); r.get(l_obs, n_last); r.get(l_id, n_last);
+  std::vector<float> m_pos, m_nrm, m_maxd, m_mind; std::vector<uint32_t> m_desc; std::vector<uint8_t> m_obs, m_skip; std::vector<int32_t> m_id;
+  r.get(m_pos, 3 * (size_t)n_mp); r.get(m_nrm, 3 * (size_t)n_mp); r.get(m_maxd, n_mp); r.get(m_mind, n_mp); r.get(m_desc, 8 * (size_t)n_mp); r.get(m_obs, n_mp); r.get(m_skip, n_mp);
+  r.get(m_id, n_mp);
+  std::vector<float> ln_left, ln_right, ln_desc; std::vector<int32_t> ln_lo, ln_ro, ln_lm;
+  r.get(ln_left, 4 * (size_t)nl); r.get(ln_lo, nl); r.get(ln_right, 4 * (size_t)nr); r.get(ln_ro, nr); r.get(ln_lm, nl); r.get(ln_desc, (size_t)nl * dim);
+  struct LineSet { std::vector<double> x0, dir, x1, x2; std::vector<uint8_t> skip; std::vector<float> desc; std::vector<int32_t> id; lld_map_lines c; };
+  auto read_lines = [&](LineSet& L, int n) {
+    r.get(L.x0, 3 * (size_t)n); r.get(L.dir, 3 * (size_t)n); r.get(L.x1, 3 * (size_t)n); r.get(L.x2, 3 * (size_t)n); r.get(L.skip, n); r.get(L.desc, (size_t)n * dim); r.get(L.id, n);
+    L.c = lld_map_lines{n, L.x0.data(), L.dir.data(), L.x1.data(), L.x2.data(), L.skip.data(), L.desc.data(), L.id.data()};
+  };
+  LineSet last_lines, local_lines; read_lines(last_lines, n_ll); read_lines(local_lines, n_ml);
+
+  lld_orb_search kp{};
+  kp.nt = nt; kp.t_desc = t_desc.data(); kp.t_xy = t_xy.data(); kp.t_octave = t_oct.data(); kp.t_uright = t_ur.data(); kp.t_angle = t_ang.data();
+  kp.grid_min_x = fc[0]; kp.grid_min_y = fc[1]; kp.grid_width_inv = fc[4]; kp.grid_height_inv = fc[5]; kp.grid_cols = 64; kp.grid_rows = 48;
+  kp.n_levels = n_levels; kp.level_scale = scale.data(); kp.level_inv_sigma2 = inv_sigma2.data();
+  lld_frame_lines fl{};
+  fl.n_left = nl; fl.left = ln_left.data(); fl.left_octave = ln_lo.data(); fl.n_right = nr; fl.right = ln_right.data(); fl.right_octave = ln_ro.data();
+  fl.line_matches = ln_lm.data(); fl.desc = ln_desc.data(); fl.dim = dim; fl.sx = 1.0 / fc[2]; fl.sy = 1.0 / fc[3];
+  lld_last_frame_points last{n_last, l_pos.data(), l_valid.data(), l_oct.data(), l_ang.data(), l_desc.data(), l_obs.data()};
+  lld_map_points mp{n_mp, m_pos.data(), m_nrm.data(), m_maxd.data(), m_mind.data(), m_desc.data(), m_obs.data(), m_skip.data()};
+
+  lld_amd::Context ctx(0);
+  lld_amd::TrackedFrame frame(ctx, kp, nl > 0 ? &fl : nullptr);
+  frame.params.cam = lld_camera{dc[0], dc[1], dc[2], dc[3], dc[4]};
+  frame.params.pose.gamma = dc[5]; frame.params.line_thr_reproj_base = dc[6]; frame.params.line_md_thr = dc[7];
+  lld_amd::TrackRecord r1, r2, r1_between;
+  std::vector<double> ms_total(repeats), ms_queue1(repeats), ms_queue2(repeats);
+  typedef std::chrono::steady_clock clk;
+  for (int it = 0; it < repeats; it++) {
+    const clk::time_point t0 = clk::now();
+    frame.TrackWithMotionModel(view, Tcw, last, l_id.data(), n_ll > 0 ? &last_lines.c : nullptr);
+    const clk::time_point t1 = clk::now();
+    if (h[10]) frame.Download(&r1_between, nullptr);
+    const clk::time_point t1b = clk::now();
+    frame.TrackLocalMap(mp, m_id.data(), n_ml > 0 ? &local_lines.c : nullptr);
+    const clk::time_point t2 = clk::now();
+    frame.Download(&r1, &r2);
+    const clk::time_point t3 = clk::now();
+    ms_total[it] = std::chrono::duration<double, std::milli>(t3 - t0).count();
+    ms_queue1[it] = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    ms_queue2[it] = std::chrono::duration<double, std::milli>(t2 - t1b).count();
+  }
+  Writer w(out);
+  for (const lld_amd::TrackRecord* rec : {&r1, &r2}) {
+    w.put(rec->r.pose_qt, 7); w.put(&rec->r.chi2, 1);
+    const int32_t c[12] = {rec->r.n_inliers, rec->r.lm_iterations, rec->r.lm_trials, rec->r.n_edges, rec->r.n_search_first, rec->r.n_search, rec->r.used_wide,
+                           rec->r.n_points, rec->r.n_points_map, rec->r.n_lines_matched, rec->r.n_lines, rec->r.n_discarded};
+    w.put(c, 12);
+    w.put(rec->kp_point_id); w.put(rec->kp_outlier); w.put(rec->ln_line_id); w.put(rec->ln_outlier);
+  }
+  w.put(ms_total); w.put(ms_queue1); w.put(ms_queue2);
+  return 0;
+}
+
 int main(int argc, char** argv) {
-  if (argc != 4) { std::fprintf(stderr, "usage: harness ba|gba|pose|orb|sim3|lines|init|loop <in> <out>\n"); return 2; }
+  if (argc != 4) { std::fprintf(stderr, "usage: harness ba|gba|pose|orb|sim3|lines|init|loop|track <in> <out>\n"); return 2; }
   try {
     if (!std::strcmp(argv[1], "ba")) return run_ba(argv[2], argv[3], false);
     if (!std::strcmp(argv[1], "gba")) return run_ba(argv[2], argv[3], true);
@@ -232,6 +306,7 @@ int main(int argc, char** argv) {
     if (!std::strcmp(argv[1], "lines")) return run_lines(argv[2], argv[3]);
     if (!std::strcmp(argv[1], "init")) return run_init(argv[2], argv[3]);
     if (!std::strcmp(argv[1], "loop")) return run_loop(argv[2], argv[3]);
+    if (!std::strcmp(argv[1], "track")) return run_track(argv[2], argv[3]);
     std::fprintf(stderr, "unknown mode %s\n", argv[1]);
     return 2;
   } catch (const std::exception& e) {

@@ -221,6 +221,10 @@ int lld_local_ba_stopflag(lld_ctx* ctx, const lld_ba_window* in, const lld_ba_pa
 typedef struct lld_ba_batch lld_ba_batch;
 int  lld_ba_batch_create(lld_ctx* ctx, int n_windows, const lld_ba_window* windows,
                          const lld_ba_params* params, lld_ba_batch** out);
+/* Error contract of a solve: when lld_ba_batch_solve returns anything but LLD_OK (a HIP call failed, a launch the build cannot express),
+ * every stream the solve used has been drained before the call returns, and the batch is FAILED: its device state is somewhere inside an
+ * LM trial, so solve / download / download_range / stats / result_records / phase_ms return LLD_ERR_INVALID from then on.  Destroy it and
+ * create it again; the context stays usable. */
 int  lld_ba_batch_solve(lld_ba_batch* batch, volatile const int* abort_flag); /* async on ctx stream until the final sync */
 int  lld_ba_batch_download(lld_ba_batch* batch, int window, lld_ba_result* out);
 /* Windows [first, first + count) into out[0..count): the same as `count` calls of lld_ba_batch_download, unpacked by several host
@@ -256,8 +260,8 @@ void lld_ba_batch_destroy(lld_ba_batch* batch);
  * and one context per shard, created and driven by the library.  devices[] lists the HIP device of every shard; a device may appear
  * more than once (two shards share it).  Shard d owns the windows lld_ba_multi_shard(n_windows, n_devices, d) - the block partition of
  * lld_slam_amd/dist.py's shard(strong=True).  lld_ba_multi_solve runs every shard's lld_ba_batch_solve concurrently and, as each shard
- * finishes, copies its records into one buffer on devices[0] (hipMemcpyPeerAsync: peer-to-peer over xGMI, what an RCCL send / recv pair
- * of that size does; the torchrun path of bench.py uses RCCL itself): record k of the whole batch at k * stride.
+ * finishes, copies its records into one buffer on devices[0] with hipMemcpyPeerAsync (a peer-to-peer copy over xGMI; a DEVIATION from north_star's
+ * "RCCL for the final gather", chosen so that a torch process does not host a second RCCL instance - the torchrun path of bench.py uses RCCL itself): record k of the whole batch at k * stride.
  * lld_ba_multi_verify_gathered is the receiver's check that every record IS the window the partition put there (win_index and edge count
  * in the header) with a finished protocol.  Results per window are those of lld_ba_batch_* on that shard's batch, bit for bit. */
 int  lld_device_count(void);                                          /* visible HIP devices; 0 without a GPU */
@@ -754,6 +758,98 @@ int  lld_frame_search_last_frame(lld_frame* frame, const uint8_t* t_occupied, co
 int  lld_frame_search_local_points(lld_frame* frame, const uint8_t* t_occupied, const lld_frame_view* view, const lld_map_points* points,
                                    float viewing_cos_limit, float th, float nnratio, lld_frustum_result* frustum_or_null, lld_orb_search_result* out);
 void lld_frame_destroy(lld_frame* frame);
+/* ------------------------------------------------------------------ the Tracking thread's per-frame chain, device resident (round 6)
+ * On one stereo Frame the reference runs
+ *   TrackWithMotionModel (src/Tracking.cc:885-994): SearchByProjection(Current, Last, th) - again with 2*th when it finds fewer than 20
+ *     (:904-911) -> AddLinesFrom(mLastFrame.mvpMapLines) (:924) -> Optimizer::PoseOptimization (:937) -> outlier discard (:940-975);
+ *   TrackLocalMap (:1126-1220): SearchLocalPoints (:1133, :1613-1664) -> AddLinesFrom(local_lines) (:1140) -> PoseOptimization (:1152)
+ *     -> statistics / discard (:1155-1187),
+ * and between those calls the Frame carries mvpMapPoints, mvbOutlier, mvpMapLines, mvbOutlierLines and mTcw.  lld_frame_track_* keeps
+ * exactly that state in HBM next to the resident keypoints: every stage reads what the stage before it left on the device, the edges of
+ * PoseOptimization are gathered from the match tables by a kernel (what Optimizer.cc:683-804 does from mvpMapPoints / mvpMapLines), and
+ * NOTHING travels to the host between the stages.  Both calls only upload their map-side inputs (one copy), queue their kernels on the
+ * context's stream and return; lld_frame_track_download fetches both stages' records in one copy and is the only synchronisation.
+ * (The reference's host needs the MapPoints of stage 1 for UpdateLocalMap before it can name the local map of stage 2: such a caller
+ * downloads between the two calls - 10 KB - and still has no search -> PoseOptimization hand-over through the host.)
+ *
+ * MapPoints / MapLines are named by caller-chosen ids >= 0 (MapPoint::mnId / MapLine ids, or indices into the caller's own tables):
+ *   - "pMP->mnLastFrameSeen == mCurrentFrame.mnId" (:1640), which makes SearchLocalPoints skip the points the frame already holds (:1629)
+ *     AND those the outlier discard of stage 1 marked (:949), is an id look-up against the frame's held + discarded ids;
+ *   - "pML->tracked_last_id == mCurrentFrame.mnId" (:1023) likewise against the lines stage 1 assigned (kept even when PoseOptimization
+ *     then threw the line out, as in the reference, which never resets tracked_last_id).
+ * Stale state the reference keeps is kept: mvbOutlierLines is not cleared when an outlier line leaves the frame (:962-975), so a line
+ * edge that never reaches a classification (fewer than 10 edges, Optimizer.cc:878) reads the old flag.
+ * Deviations (both inside the "OpenCV restated" caveat of the searches above): the camera-to-world matrix AddLinesFrom receives is the
+ * frame's own Rwc = Rcw^T, Ow (Frame::UpdatePoseMatrices) widened to double, where the reference inverts mTcw with cv::Mat::inv() (a float
+ * LU, equal up to float rounding); stage 2's float view is formed on the device from the optimised SE3Quat exactly as
+ * lld_se3_to_tcw_f32 + UpdatePoseMatrices form it on the host.
+ * `params` of the two calls of one frame must agree.  The handle belongs to one context / host thread like every lld_frame call. */
+typedef struct {
+  int32_t n_left;  const float* left;  const int32_t* left_octave;    /* mvLinesLeft: [n][4] startPointX, startPointY, endPointX, endPointY; octave */
+  int32_t n_right; const float* right; const int32_t* right_octave;   /* mvLinesRight                                                              */
+  const int32_t* line_matches;                                         /* [n_left] Frame::line_matches: right line of left line i, or -1            */
+  const float* desc; int32_t dim;                                      /* mDescriptorsLines [n_left][dim], dim <= 128                                */
+  int32_t reserved;
+  double sx, sy;                                                       /* 1 / mnMaxX, 1 / mnMaxY (the Hough grid of lld_line_track_match)            */
+} lld_frame_lines;
+/* Uploads the frame's lines ONCE (and fills the 50 x 50 Hough grid cells on the device); NULL or n_left = 0: a frame without lines.  Resets the
+ * tracking state of the frame.  Call it after lld_frame_create and before lld_frame_track_motion_model; synchronous. */
+int  lld_frame_set_lines(lld_frame* frame, const lld_frame_lines* lines);
+typedef struct {
+  int32_t n;
+  const double* x0; const double* dir;                                 /* [n][3] MapLine::GetMinimalPos                                              */
+  const double* x1; const double* x2;                                  /* [n][3] GetMainPoints3D                                                     */
+  const uint8_t* skip;                                                 /* [n] or NULL: NULL entry / isBad (src/Tracking.cc:1018-1034)                */
+  const float* desc;                                                   /* [n][dim] descs[i] / mLastFrame.mDescriptorsLines.row(i)                    */
+  const int32_t* id;                                                   /* [n] >= 0                                                                   */
+} lld_map_lines;
+typedef struct {
+  lld_camera cam;                   /* PoseOptimization's intrinsics (fx, fy, cx, cy, bf as doubles of the Frame's floats)                           */
+  lld_pose_params pose;             /* gamma, 4 x 10 iterations                                                                                      */
+  float   th_motion;                /* 7 (stereo) / 15 (src/Tracking.cc:899-903)                                                                     */
+  float   th_local;                 /* 1; 3 RGBD; 5 after a relocalisation (:1652-1658)                                                              */
+  float   nnratio_local;            /* 0.8 (:1651)                                                                                                   */
+  float   viewing_cos_limit;        /* 0.5 (:1646)                                                                                                   */
+  int32_t direction;                /* lld_orb_search_last_frame's: +1 bForward, -1 bBackward, 0 neither                                             */
+  int32_t check_orientation;        /* 1: ORBmatcher(0.9, true) (:888)                                                                               */
+  int32_t wide_retry;               /* 1: search again with 2 * th_motion when the first search finds < 20 (:907-911), decided on the device          */
+  int32_t monocular;                /* 0 (the chain is the stereo system's)                                                                          */
+  double  line_thr_reproj_base;     /* 2 (:924, :1140)                                                                                               */
+  double  line_md_thr;              /* mdThr                                                                                                         */
+  int32_t line_use_grid;            /* as lld_line_track_params.use_grid                                                                             */
+  int32_t reserved;
+} lld_track_params;
+void lld_track_params_default(lld_track_params* p);
+typedef struct {
+  double  pose_qt[7];               /* mTcw after the stage's PoseOptimization (pFrame->SetPose, Optimizer.cc:918)                                   */
+  double  chi2;
+  int32_t n_inliers;                /* PoseOptimization's return value                                                                               */
+  int32_t lm_iterations, lm_trials, n_edges;
+  int32_t n_search_first;           /* nmatches of the (first) search                                                                                */
+  int32_t n_search;                 /* nmatches of the search whose matches the frame took (stage 1: the wide one if used_wide)                      */
+  int32_t used_wide;
+  int32_t n_points;                 /* MapPoints the frame holds after the stage's discard (stage 1: `nmatches`, :952)                               */
+  int32_t n_points_map;             /* ... of which Observations() > 0 (stage 1: nmatchesMap, :955; stage 2: mnMatchesInliers, :1164)                */
+  int32_t n_lines_matched;          /* MapLines the frame held when PoseOptimization started (lcnt_init / lcnt, :926-932, :1142-1149)                */
+  int32_t n_lines;                  /* ... and after the outlier lines left (:962-975, :1176-1187)                                                   */
+  int32_t n_discarded;
+  /* caller-allocated, any may be NULL.  Ids / flags as the stage's PoseOptimization saw them, BEFORE its discard:                                   */
+  int32_t* kp_point_id;             /* [nt] id of mvpMapPoints[k] or -1                                                                              */
+  uint8_t* kp_outlier;              /* [nt] mvbOutlier[k] of those (the discard removes exactly the flagged ones)                                    */
+  int32_t* ln_line_id;              /* [n_left] id of mvpMapLines[i] or -1                                                                           */
+  uint8_t* ln_outlier;              /* [n_left] mvbOutlierLines[i] of those                                                                          */
+} lld_track_result;
+/* Stage 1.  `view`: Frame::UpdatePoseMatrices of the predicted pose mVelocity * mLastFrame.mTcw (as for lld_frame_search_last_frame);
+ * `pose_qt`: Converter::toSE3Quat of the same matrix (lld_se3_from_tcw_f32).  last / last_point_id: LastFrame.mvpMapPoints as for
+ * lld_frame_search_last_frame plus the id of every entry; last_lines: mLastFrame.mvpMapLines (NULL: none). */
+int  lld_frame_track_motion_model(lld_frame* frame, const lld_track_params* params, const lld_frame_view* view, const double* pose_qt,
+                                  const lld_last_frame_points* last, const int32_t* last_point_id, const lld_map_lines* last_lines);
+/* Stage 2, on the pose and the MapPoints / MapLines stage 1 left in the frame.  local_points->skip: isBad only - what the frame holds or
+ * discarded is skipped by id on the device.  local_lines: Tracking::local_lines with their descriptors (NULL: none). */
+int  lld_frame_track_local_map(lld_frame* frame, const lld_track_params* params, const lld_map_points* local_points, const int32_t* local_point_id,
+                               const lld_map_lines* local_lines);
+/* Waits for the queued stages and fetches their records (either may be NULL; stage2 is meaningful only after lld_frame_track_local_map). */
+int  lld_frame_track_download(lld_frame* frame, lld_track_result* stage1, lld_track_result* stage2);
 /* ORBmatcher::Fuse(KeyFrame*, vpMapPoints, th) (src/ORBmatcher.cc:825-958; the loop of LocalMapping::SearchInNeighbors) with the
  * projection loop (:841-890) on the device: cv::gemm transform, z >= 0, invz = 1/z, u = fx*(x*invz)+cx, KeyFrame::IsInImage
  * (upper bounds strict, src/KeyFrame.cc:633-636), ur = u - bf*invz, scale-invariance band, PO.dot(Pn) >= 0.5*dist3D, PredictScale;

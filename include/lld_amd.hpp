@@ -371,5 +371,49 @@ class Tracking {
   double K_[9]; double b_, sx_, sy_, mdThr_; bool mono_;
 };
 
+// The Tracking thread's per-frame chain on ONE device-resident Frame (lld_frame_track_*, include/lld_amd.h): what Tracking::TrackWithMotionModel
+// (src/Tracking.cc:885-994) and Tracking::TrackLocalMap (:1126-1220) do to mCurrentFrame, with mvpMapPoints / mvbOutlier / mvpMapLines /
+// mvbOutlierLines / mTcw living in HBM between the calls.  Both Track* calls only queue work; Download() is the one synchronisation.
+struct TrackRecord {
+  lld_track_result r{};
+  std::vector<int32_t> kp_point_id, ln_line_id;
+  std::vector<uint8_t> kp_outlier, ln_outlier;
+  void bind(int nt, int nl) {
+    kp_point_id.assign(nt, -1); kp_outlier.assign(nt, 0); ln_line_id.assign(nl, -1); ln_outlier.assign(nl, 0);
+    r.kp_point_id = kp_point_id.data(); r.kp_outlier = kp_outlier.data(); r.ln_line_id = ln_line_id.data(); r.ln_outlier = ln_outlier.data();
+  }
+};
+class TrackedFrame {
+ public:
+  // keypoints: the keypoint side of an lld_orb_search (as for lld_frame_create); lines: NULL for a frame without lines
+  TrackedFrame(Context& ctx, const lld_orb_search& keypoints, const lld_frame_lines* lines) : nt_(keypoints.nt), nl_(lines ? lines->n_left : 0) {
+    check(lld_frame_create(ctx.get(), &keypoints, &f_), "lld_frame_create");
+    const int st = lld_frame_set_lines(f_, lines);
+    if (st != LLD_OK) { lld_frame_destroy(f_); f_ = nullptr; check(st, "lld_frame_set_lines"); }
+    lld_track_params_default(&params);
+  }
+  ~TrackedFrame() { if (f_) lld_frame_destroy(f_); }
+  TrackedFrame(const TrackedFrame&) = delete;
+  TrackedFrame& operator=(const TrackedFrame&) = delete;
+  lld_track_params params;
+  // Tcw: the predicted pose mVelocity * mLastFrame.mTcw as the float matrix the Frame holds; `view`: its UpdatePoseMatrices
+  void TrackWithMotionModel(const lld_frame_view& view, const float Tcw[16], const lld_last_frame_points& last, const int32_t* last_ids, const lld_map_lines* last_lines) {
+    double qt[7];
+    lld_se3_from_tcw_f32(Tcw, qt);                       // Converter::toSE3Quat(pFrame->mTcw)
+    check(lld_frame_track_motion_model(f_, &params, &view, qt, &last, last_ids, last_lines), "lld_frame_track_motion_model");
+  }
+  void TrackLocalMap(const lld_map_points& local_points, const int32_t* ids, const lld_map_lines* local_lines) {
+    check(lld_frame_track_local_map(f_, &params, &local_points, ids, local_lines), "lld_frame_track_local_map");
+  }
+  void Download(TrackRecord* stage1, TrackRecord* stage2) {
+    if (stage1) stage1->bind(nt_, nl_);
+    if (stage2) stage2->bind(nt_, nl_);
+    check(lld_frame_track_download(f_, stage1 ? &stage1->r : nullptr, stage2 ? &stage2->r : nullptr), "lld_frame_track_download");
+  }
+ private:
+  lld_frame* f_ = nullptr;
+  int nt_, nl_;
+};
+
 }  // namespace lld_amd
 #endif

@@ -82,6 +82,7 @@ struct lld_ba_batch {
   int max_lblocks = 0, max_items_pt = 0, max_items_ln = 0, max_free = 0, max_cams = 0, max_blk = 0, acc_copies[2] = {4, 4}, lin_waves[2] = {kLinThreads / 64, kLinThreads / 64};   // [point, line] linearise kernel
   bool pcg_multi = false;
   bool pipelined = false;                                 // created while another batch's large solve ran on this device (ba_make_groups)
+  bool failed = false;                                    // a solve returned an error: the device state is mid-trial, every entry point but destroy refuses the batch
   bool big = false;                                       // a map beyond kMaxFreeCamsLds cameras: accumulators and poses of the linearise / back-substitution kernels in HBM
   size_t schur_lds[2] = {0, 0}; size_t schur_wide_lds = 0;
   int chunk_landmarks = 32;
@@ -908,8 +909,11 @@ static int ba_batch_create_impl(lld_ctx* ctx, int n_windows, const lld_ba_window
   lld_slab dry; dry.base = reinterpret_cast<char*>(256);
   carve(dry);
   const size_t bytes = dry.used + 4096;
+  bool slab_regrown = false;                          // the early ranges went into an allocation that no longer exists (never inferred from
+                                                      // pointer equality: hipMalloc may hand the base just freed back)
   if (cached) {
     if (bytes > cache.slab_bytes) {                   // grow-only (hipFree synchronises the device: it happens only while a context warms up)
+      slab_regrown = true;
       void* old_slab = cache.slab;
       cache.slab = nullptr; cache.slab_bytes = 0;          // (before the free: a failure must not leave a dangling pointer in the cache)
       if (old_slab && hipFree(old_slab) != hipSuccess) return fail(LLD_ERR_HIP);
@@ -933,7 +937,7 @@ static int ba_batch_create_impl(lld_ctx* ctx, int n_windows, const lld_ba_window
   // section A leaves now and travels while the host places section B - unless its ranges left while they were staged (above): then only what no
   // window owns is still to go (the level table of the line information, the closing entries of the two observation CSRs)
   uploads_queued = true;
-  if (n_ranges && B->slab == early_slab && offA == 0) {
+  if (n_ranges && !slab_regrown && B->slab == early_slab && offA == 0) {
     bool ok = copy_rows(hA.ln_info, sizeof(double), 0, 256) && copy_rows(hA.pt_obs_start, sizeof(int), NP, NP + 1) && copy_rows(hA.ln_obs_start, sizeof(int), NL, NL + 1);
     if (!ok) return fail(LLD_ERR_HIP);
   } else if (hipMemcpyAsync((char*)B->slab + offA, arenaA, bytesA, hipMemcpyHostToDevice, st) != hipSuccess) return fail(LLD_ERR_HIP);
@@ -1033,10 +1037,9 @@ struct StopFlag {
   bool up() const { return (i32 && *i32) || (u8 && *u8); }
 };
 
-static int ba_batch_solve_impl(lld_ba_batch* B, StopFlag abort_flag) {
-  if (!B) return LLD_ERR_INVALID;
+// The solve proper.  t_begin / t_end belong to the caller (ba_batch_solve_impl), which also owns what happens when this returns an error.
+static int ba_batch_solve_body(lld_ba_batch* B, StopFlag abort_flag, hipEvent_t t_begin, hipEvent_t t_end) {
   lld_ctx* ctx = B->ctx;
-  LLD_HIP_TRY(hipSetDevice(ctx->device));
   std::unique_lock<std::mutex> turn(g_big_solve[ctx->device & 63], std::defer_lock);
   struct RunningGuard { std::atomic<int>* c; ~RunningGuard() { if (c) c->fetch_sub(1, std::memory_order_relaxed); } } running{nullptr};
   if (B->n_windows >= kSerialiseSolvesFromWindows) {
@@ -1048,8 +1051,6 @@ static int ba_batch_solve_impl(lld_ba_batch* B, StopFlag abort_flag) {
   for (auto& m : B->phase_ms) m = 0.0;
   for (auto& l : B->launches) l = 0;
   B->super_steps = 0;
-  hipEvent_t t_begin, t_end;
-  LLD_HIP_TRY(hipEventCreate(&t_begin)); LLD_HIP_TRY(hipEventCreate(&t_end));
   LLD_HIP_TRY(hipEventRecord(t_begin, ctx->stream));
   const size_t lin_lds_pt = B->big ? 64 : ((size_t)B->max_free * 27 * B->acc_copies[0] + 8 + (size_t)B->max_cams * 7) * sizeof(double);
   const size_t lin_lds_ln = B->big ? 64 : ((size_t)B->max_free * 27 * B->acc_copies[1] + 8 + (size_t)B->max_cams * 7) * sizeof(double);
@@ -1088,8 +1089,13 @@ static int ba_batch_solve_impl(lld_ba_batch* B, StopFlag abort_flag) {
   // hipGraph and replayed per poll (all rows every time: the grid must not change).  Measured, not the default: profiles/NOTES_r05.md.
   static const bool use_graph = exp_flag("LLD_BA_GRAPH");
   bool capturing = false;
+  int n_superstep_launches = 0;
+  const int fail_at = exp_int("LLD_BA_FAIL_AT_SUPERSTEP", -1);      // (read per solve, so that one test process can set and clear it)
   auto launch_superstep = [&](Group& G, int q) -> int {
     const BAWin* dw = B->d_wins + G.w0; BAState* ds = B->d_state + G.w0;
+    // experiments build: LLD_BA_FAIL_AT_SUPERSTEP=n makes the n-th super-step launch of a solve fail the way an inexpressible grid does,
+    // with the other groups' kernels in flight (tests/test_gpu_ba.py: the error contract of a solve)
+    if (fail_at >= 0 && n_superstep_launches++ == fail_at) return LLD_ERR_UNSUPPORTED;
     const BAArrays A = group_arrays(G);                                // (shadows the batch's arrays: every launch below is per group)
     const int nw = use_slots ? std::max(1, std::min(G.rows, G.nw)) : G.nw; hipStream_t st = G.st;
     const int abort_now = abort_flag.up() ? 1 : 0;
@@ -1117,7 +1123,7 @@ static int ba_batch_solve_impl(lld_ba_batch* B, StopFlag abort_flag) {
       if (G.max_items_pt > 0) hipLaunchKernelGGL(ba_schur_items_kernel<3>, dim3(G.max_items_pt, nw), dim3(kSchurThreads), B->schur_lds[0], st, A, dw, ds);
       if (G.max_items_ln > 0) hipLaunchKernelGGL(ba_schur_items_kernel<4>, dim3(G.max_items_ln, nw), dim3(kSchurThreads), B->schur_lds[1], st, A, dw, ds);
     } else if (G.max_items_pt + G.max_items_ln > 0) {
-      if ((long long)nw * (G.max_items_pt + G.max_items_ln) > 0x7fffffffll) return LLD_ERR_UNSUPPORTED;      // (one workgroup per window and chunk)
+      if ((long long)nw * (G.max_items_pt + G.max_items_ln) * kSchurThreads > 0xffffffffll) return LLD_ERR_UNSUPPORTED;      // (one workgroup per window and chunk; an AQL packet carries the grid as a 32-bit count of work-ITEMS: 2^26 workgroups of 64)
       hipLaunchKernelGGL(ba_schur_items_both_kernel, dim3((unsigned)((long long)nw * (G.max_items_pt + G.max_items_ln))), dim3(kSchurThreads), std::max(B->schur_lds[0], B->schur_lds[1]), st, A, dw, ds, G.max_items_pt, schur_tile, nw, G.max_items_pt + G.max_items_ln);
     }
     if (B->schur_wide_lds > 0) hipLaunchKernelGGL(ba_schur_wide_kernel, dim3(G.max_items_pt + G.max_items_ln, nw), dim3(kSchurWideThreads), B->schur_wide_lds, st, A, dw, ds);
@@ -1276,8 +1282,30 @@ static int ba_batch_solve_impl(lld_ba_batch* B, StopFlag abort_flag) {
   float tot = 0.f;
   (void)hipEventElapsedTime(&tot, t_begin, t_end);
   B->phase_ms[kNumPhases] = tot;
-  (void)hipEventDestroy(t_begin); (void)hipEventDestroy(t_end);
   return LLD_OK;
+}
+
+// Error contract of a solve (include/lld_amd.h): when anything inside fails - a HIP call, a launch the build cannot express - the other
+// groups' streams may still hold kernels of this batch.  They are drained before the status goes back to the caller, and the batch is marked
+// failed: its device state is somewhere inside an LM trial, so lld_ba_batch_solve / _download / _phase_ms refuse it (LLD_ERR_INVALID) until it
+// is destroyed and created again.  The two events are owned here so that no return path leaks them.
+static int ba_batch_solve_impl(lld_ba_batch* B, StopFlag abort_flag) {
+  if (!B || B->failed) return LLD_ERR_INVALID;
+  lld_ctx* ctx = B->ctx;
+  LLD_HIP_TRY(hipSetDevice(ctx->device));
+  struct Events {
+    hipEvent_t a = nullptr, b = nullptr;
+    ~Events() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+  } ev;
+  LLD_HIP_TRY(hipEventCreate(&ev.a)); LLD_HIP_TRY(hipEventCreate(&ev.b));
+  const int st = ba_batch_solve_body(B, abort_flag, ev.a, ev.b);
+  if (st != LLD_OK) {
+    for (auto& G : B->groups) if (G.st) (void)hipStreamSynchronize(G.st);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipGetLastError();                              // (a sticky launch error was reported through `st`)
+    B->failed = true; B->records_valid = false;
+  }
+  return st;
 }
 
 int lld_ba_batch_solve(lld_ba_batch* B, volatile const int* abort_flag) { return ba_batch_solve_impl(B, StopFlag{abort_flag, nullptr}); }
@@ -1320,7 +1348,7 @@ static void fill_stats(const lld_ba_batch* B, int wi, lld_ba_stats* s) {
 static void ba_unpack_record(const lld_ba_batch* B, int wi, lld_ba_result* out);
 
 int lld_ba_batch_download(lld_ba_batch* B, int wi, lld_ba_result* out) {
-  if (!B || !out || wi < 0 || wi >= B->n_windows) return LLD_ERR_INVALID;
+  if (!B || B->failed || !out || wi < 0 || wi >= B->n_windows) return LLD_ERR_INVALID;
   LLD_HIP_TRY(hipSetDevice(B->ctx->device));
   int st = ba_fetch_records(B); if (st) return st;
   ba_unpack_record(B, wi, out);
@@ -1328,7 +1356,7 @@ int lld_ba_batch_download(lld_ba_batch* B, int wi, lld_ba_result* out) {
 }
 
 int lld_ba_batch_download_range(lld_ba_batch* B, int first, int count, lld_ba_result* out) {
-  if (!B || !out || first < 0 || count < 0 || first + count > B->n_windows) return LLD_ERR_INVALID;
+  if (!B || B->failed || !out || first < 0 || count < 0 || first + count > B->n_windows) return LLD_ERR_INVALID;
   LLD_HIP_TRY(hipSetDevice(B->ctx->device));
   int st = ba_fetch_records(B); if (st) return st;
   int n_threads = count >= 8 ? (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u) : 1;
@@ -1364,7 +1392,7 @@ static void ba_unpack_record(const lld_ba_batch* B, int wi, lld_ba_result* out) 
 }
 
 int lld_ba_batch_stats(lld_ba_batch* B, lld_ba_stats* stats) {
-  if (!B || !stats) return LLD_ERR_INVALID;
+  if (!B || B->failed || !stats) return LLD_ERR_INVALID;
   LLD_HIP_TRY(hipSetDevice(B->ctx->device));
   int st = ba_fetch_records(B); if (st) return st;
   for (int w = 0; w < B->n_windows; w++) fill_stats(B, w, stats + w);
@@ -1372,13 +1400,13 @@ int lld_ba_batch_stats(lld_ba_batch* B, lld_ba_stats* stats) {
 }
 
 int lld_ba_batch_result_records(lld_ba_batch* B, void** dev_ptr, uint64_t* stride_bytes) {
-  if (!B || !dev_ptr || !stride_bytes) return LLD_ERR_INVALID;
+  if (!B || B->failed || !dev_ptr || !stride_bytes) return LLD_ERR_INVALID;
   *dev_ptr = B->A.records; *stride_bytes = B->rec_stride;
   return LLD_OK;
 }
 
 int lld_ba_batch_phase_ms(lld_ba_batch* B, double* ms6) {
-  if (!B || !ms6) return LLD_ERR_INVALID;
+  if (!B || B->failed || !ms6) return LLD_ERR_INVALID;
   for (int i = 0; i < LLD_BA_N_PHASES; i++) ms6[i] = B->phase_ms[i];
   return LLD_OK;
 }

@@ -13,6 +13,7 @@
 #include <cmath>
 
 #include "lld_common.h"
+#include "lld_track_internal.h"
 
 namespace {
 
@@ -518,8 +519,10 @@ __global__ __launch_bounds__(64) void line_track_gate_kernel(LineTrackParams P, 
                                                             const double* __restrict__ x1, const double* __restrict__ x2, const uint8_t* __restrict__ skip,
                                                             int n_cur, const float* __restrict__ left, const int* __restrict__ loct,
                                                             const float* __restrict__ right, const int* __restrict__ lmatch,
-                                                            const uint8_t* __restrict__ occupied, const int* __restrict__ cell, uint8_t* __restrict__ gate) {
+                                                            const uint8_t* __restrict__ occupied, const int* __restrict__ cell, uint8_t* __restrict__ gate,
+                                                            const LineTrackParams* __restrict__ P_dev) {
   const int i = blockIdx.x, lane = threadIdx.x;
+  if (P_dev) P = *P_dev;                                                      // the pose came out of a kernel (lld_frame_track_*): camera in device memory
   uint8_t* grow = gate + (size_t)i * n_cur;
   bool row_ok = !(skip && skip[i]);
   double X1c[3], X2c[3];
@@ -1016,7 +1019,7 @@ int lld_line_track_match(lld_ctx* ctx, const lld_line_track_params* prm, int n_m
   hipLaunchKernelGGL(line_track_gate_kernel, dim3(n_map), dim3(64), 0, sm, P, reinterpret_cast<const double*>(d + o_x0), reinterpret_cast<const double*>(d + o_dr),
                      reinterpret_cast<const double*>(d + o_x1), reinterpret_cast<const double*>(d + o_x2), reinterpret_cast<const uint8_t*>(d + o_sk), n_cur,
                      reinterpret_cast<const float*>(d + o_ll), reinterpret_cast<const int*>(d + o_lo), reinterpret_cast<const float*>(d + o_rl),
-                     reinterpret_cast<const int*>(d + o_lm), reinterpret_cast<const uint8_t*>(d + o_oc), dcell, dgate);
+                     reinterpret_cast<const int*>(d + o_lm), reinterpret_cast<const uint8_t*>(d + o_oc), dcell, dgate, nullptr);
   // `md > mdThr` rejects (Tracking.cc:1099): distances up to and including md_thr pass, where the stereo matcher's tau is strict
   const double tau = std::nextafter(prm->md_thr, 1.7976931348623157e308);
   const size_t lds = (size_t)n_cur * 8 + (size_t)dim * 4 + 16;
@@ -1100,3 +1103,44 @@ int lld_line_match_last_frame(lld_ctx* ctx, const lld_line_lastkf_params* prm, i
 }
 
 }  // extern "C"
+
+// ================================================================ Tracking::AddLinesFrom on device arrays (lld_track_internal.h): the kernels of
+// lld_line_track_match with every operand already in HBM and the camera read from device memory; nothing is copied, nothing waits.
+namespace lld_track {
+static_assert(sizeof(LineTrackDevParams) == sizeof(LineTrackParams), "lld_track_internal.h restates LineTrackParams");
+static inline size_t lt_pad(size_t b) { return (b + 255) & ~size_t(255); }
+size_t line_track_work_bytes(int n_map, int n_cur) {
+  const size_t pairs = (size_t)n_map * (size_t)n_cur;
+  return lt_pad(pairs) + lt_pad(pairs * 8) + lt_pad((size_t)n_map * sizeof(LineCand)) + 256;
+}
+int line_cells_dev(hipStream_t st, const float* d_left, int n, double sx, double sy, int32_t* d_cell) {
+  if (n > 0) hipLaunchKernelGGL(line_cells_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_left, n, sx, sy, d_cell);
+  LLD_HIP_TRY(hipGetLastError());
+  return LLD_OK;
+}
+int line_track_launch_dev(lld_ctx* ctx, hipStream_t st, const LineTrackDevParams* params_d, const LineMapDev& map, const LineFrameDev& cur, double md_thr,
+                          void* d_work, int32_t* matches_d) {
+  (void)ctx;
+  const int n_map = map.n, n_cur = cur.n_cur, dim = cur.dim;
+  if (n_map <= 0 || n_cur <= 0) return LLD_OK;                               // (the caller pre-fills matches_d with -1)
+  if (dim > 128 || (size_t)n_cur * 8 + (size_t)dim * 4 > 150 * 1024) return LLD_ERR_UNSUPPORTED;
+  const size_t pairs = (size_t)n_map * (size_t)n_cur;
+  char* w = static_cast<char*>(d_work);
+  uint8_t* dgate = reinterpret_cast<uint8_t*>(w);
+  double* dmat = reinterpret_cast<double*>(w + lt_pad(pairs));
+  LineCand* dc = reinterpret_cast<LineCand*>(w + lt_pad(pairs) + lt_pad(pairs * 8));
+  LineTrackParams P0; std::memset(&P0, 0, sizeof P0);
+  hipLaunchKernelGGL(line_track_gate_kernel, dim3(n_map), dim3(64), 0, st, P0, map.x0, map.dir, map.x1, map.x2, map.skip, n_cur, cur.left, cur.loct, cur.right,
+                     cur.lmatch, cur.occupied, cur.cell, dgate, reinterpret_cast<const LineTrackParams*>(params_d));
+  const double tau = std::nextafter(md_thr, 1.7976931348623157e308);         // `md > mdThr` rejects (Tracking.cc:1099)
+  const size_t lds = (size_t)n_cur * 8 + (size_t)dim * 4 + 16;
+  if (lds > 48 * 1024) LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&line_candidates_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  if ((size_t)n_cur + 16 > 48 * 1024) LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&line_resolve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)n_cur + 16));
+  LineGateParams G0; std::memset(&G0, 0, sizeof G0);
+  hipLaunchKernelGGL(line_candidates_kernel<false>, dim3(n_map), dim3(64), lds, st, G0, nullptr, nullptr, nullptr, nullptr, map.desc, cur.desc, dim, n_cur, dgate, tau,
+                     nullptr, dmat, dc);
+  hipLaunchKernelGGL(line_resolve_kernel, dim3(1), dim3(64), (size_t)n_cur + 16, st, dc, dmat, dgate, n_map, n_cur, tau, matches_d, nullptr);
+  LLD_HIP_TRY(hipGetLastError());
+  return LLD_OK;
+}
+}  // namespace lld_track

@@ -14,6 +14,7 @@
 //     the latest, in practice 2-4 rounds);
 //   * float gates use explicit round-to-nearest intrinsics so no FMA contraction can change a comparison.
 #include "lld_common.h"
+#include "lld_track_internal.h"
 
 namespace {
 
@@ -50,6 +51,8 @@ struct Problem {
   int32_t* match; int32_t* best_dist; int32_t* second_dist; uint8_t* removed; int32_t* owner; int32_t* summary;   // summary: n_matches, rounds
   int desc_in_lds, want_owner;
   unsigned long long* cache;   // [nq][kTopK] device scratch of sequential problems: the smallest candidate keys of round 1
+  // device-resident chains (lld_frame_track_*): the whole search is skipped unless (*run_if < run_if_below) == (run_if_want != 0)
+  const int32_t* run_if; int run_if_below, run_if_want;
 };
 
 template <class Ptr>
@@ -124,6 +127,7 @@ __device__ __forceinline__ bool gates_pass(const Problem& P, const QRec& Q, cons
 __global__ __launch_bounds__(kThreads) void orb_search_kernel(const Problem* __restrict__ problems) {
   extern __shared__ __align__(16) unsigned char lds_raw[];
   const Problem& P = problems[blockIdx.x];
+  if (P.run_if && ((*P.run_if < P.run_if_below) != (P.run_if_want != 0))) return;
   const int nt = P.nt, nq = P.nq, tid = threadIdx.x;
   const int n_cells = P.cols * P.rows;
   const bool grid = P.candidates == LLD_ORB_CAND_GRID, rows = P.candidates == LLD_ORB_CAND_ROWS;
@@ -602,11 +606,13 @@ struct FrustumArgs {
   float scale[LLD_ORB_MAX_LEVELS];
   float cos_limit, th;
   QRec* q; uint8_t* in_view; float* uvr; int32_t* level; float* view_cos;
+  const lld_frame_view* view_d;          // non-null: the view lives in device memory (the pose was optimised on the device)
 };
 
 __global__ __launch_bounds__(256) void frustum_kernel(FrustumArgs F) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= F.n) return;
+  if (F.view_d) F.V = *F.view_d;
   QRec Q; memset(&Q, 0, sizeof(Q));
   Q.level_min = -1; Q.level_max = -1;
   Q.flags = (!F.has_obs || F.has_obs[i]) ? 2 : 0;
@@ -657,11 +663,15 @@ struct LastFrameArgs {
   float scale[LLD_ORB_MAX_LEVELS];
   float th;
   QRec* q; float* uvr;
+  const lld_frame_view* view_d;
+  const int32_t* run_if; int run_if_below, run_if_want;
 };
 
 __global__ __launch_bounds__(256) void project_last_frame_kernel(LastFrameArgs F) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= F.n) return;
+  if (F.run_if && ((*F.run_if < F.run_if_below) != (F.run_if_want != 0))) return;
+  if (F.view_d) F.V = *F.view_d;
   QRec Q; memset(&Q, 0, sizeof(Q));
   Q.level_min = -1; Q.level_max = -1;
   Q.flags = (!F.has_obs || F.has_obs[i]) ? 2 : 0;
@@ -978,18 +988,7 @@ namespace {
 
 }  // namespace
 
-// A frame whose keypoint side lives on the device for as long as the Tracking thread works on it (round 5, lld_frame_*): descriptors,
-// undistorted positions, octaves, right coordinates and angles are uploaded ONCE; the per-frame routines that search this frame
-// (lld_frame_search_last_frame: Tracking.cc:904, lld_frame_search_local_points: :1133) then move only their queries and the occupancy bytes.
-struct lld_frame {
-  lld_ctx* ctx = nullptr;
-  int nt = 0; bool has_uright = false, has_angle = false;
-  char* d = nullptr;                       // one device allocation: desc | xy | octave | uright | angle
-  size_t o_td = 0, o_txy = 0, o_toct = 0, o_tur = 0, o_tang = 0;
-  lld_orb_search consts;                   // grid constants, n_levels; the level tables are copied below
-  float scale[LLD_ORB_MAX_LEVELS], sigma2[LLD_ORB_MAX_LEVELS], inv_sigma2[LLD_ORB_MAX_LEVELS];
-  std::vector<int32_t> octave;             // host copy (validation of queries needs none of the rest)
-};
+// (struct lld_frame: lld_track_internal.h)
 
 namespace {
 
@@ -1242,6 +1241,7 @@ extern "C" void lld_frame_destroy(lld_frame* f) {
   if (!f) return;
   (void)hipSetDevice(f->ctx->device);
   (void)hipStreamSynchronize(f->ctx->stream);
+  lld_track::state_free(f);
   if (f->d) (void)hipFree(f->d);
   delete f;
 }
@@ -1394,3 +1394,77 @@ extern "C" int lld_orb_search_by_sim3(lld_ctx* ctx, const lld_orb_search* kf1, c
   *n_found = found;
   return LLD_OK;
 }
+
+// ================================================================ launchers for the device-resident Tracking chain (lld_track_internal.h)
+namespace lld_track {
+
+size_t orbs_problem_bytes() { return al(sizeof(Problem)); }
+size_t orbs_qrec_bytes(int nq) { return al((size_t)nq * sizeof(QRec)); }
+size_t orbs_cache_bytes(int nq) { return al((size_t)nq * 8 * kTopK); }
+
+void orbs_fill_problem(const lld_frame* f, int mode, int nq, const uint8_t* d_occupied, const void* d_qrec, const uint32_t* d_qdesc, const SearchOut& out,
+                       void* d_cache, float nnratio, int check_orientation, RunIf run_if, void* problem_h) {
+  Problem& P = *static_cast<Problem*>(problem_h); std::memset(&P, 0, sizeof(P));
+  const lld_orb_search& c = f->consts;
+  P.nt = f->nt; P.nq = nq;
+  P.t_desc = reinterpret_cast<const uint32_t*>(f->d + f->o_td); P.t_xy = reinterpret_cast<const float*>(f->d + f->o_txy);
+  P.t_octave = reinterpret_cast<const int32_t*>(f->d + f->o_toct);
+  P.t_uright = f->has_uright ? reinterpret_cast<const float*>(f->d + f->o_tur) : nullptr;
+  P.t_angle = (check_orientation && f->has_angle) ? reinterpret_cast<const float*>(f->d + f->o_tang) : nullptr;
+  P.t_occupied = d_occupied;
+  P.q_desc = d_qdesc; P.q = static_cast<const QRec*>(d_qrec);
+  P.min_x = c.grid_min_x; P.min_y = c.grid_min_y; P.winv = c.grid_width_inv; P.hinv = c.grid_height_inv;
+  P.cols = c.grid_cols; P.rows = c.grid_rows; P.n_levels = c.n_levels;
+  for (int l = 0; l < LLD_ORB_MAX_LEVELS; l++) { P.scale[l] = l < c.n_levels ? f->scale[l] : 1.f; P.sigma2[l] = 1.f; P.inv_sigma2[l] = 1.f; }
+  P.candidates = LLD_ORB_CAND_GRID;
+  P.gates = LLD_ORB_GATE_LEVEL | LLD_ORB_GATE_STEREO; P.accept_max = 100;       // TH_HIGH (src/ORBmatcher.cc:117, :1418)
+  if (mode == 0) { P.ratio_mode = 0; P.check_orientation = check_orientation != 0; }
+  else { P.ratio_mode = 2; P.nnratio = nnratio; }
+  P.sequential = 1;
+  P.match = out.match; P.best_dist = out.best_dist; P.second_dist = out.second_dist; P.removed = out.removed; P.owner = out.owner; P.summary = out.summary;
+  P.want_owner = 1;
+  P.cache = static_cast<unsigned long long*>(d_cache);
+  P.desc_in_lds = lds_bytes(P.nt, P.cols * P.rows, true, true) <= kLdsLimit;
+  P.run_if = run_if.flag; P.run_if_below = run_if.below; P.run_if_want = run_if.want;
+}
+
+static int orbs_launch_search(lld_ctx* ctx, hipStream_t st, const lld_frame* f, const void* problem_d) {
+  const lld_orb_search& c = f->consts;
+  const bool desc_in_lds = lds_bytes(f->nt, c.grid_cols * c.grid_rows, true, true) <= kLdsLimit;
+  const size_t lds = lds_bytes(f->nt, c.grid_cols * c.grid_rows, true, desc_in_lds);
+  if (!ctx->orb_lds_raised) { LLD_HIP_TRY(hipFuncSetAttribute((const void*)orb_search_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit)); ctx->orb_lds_raised = true; }
+  hipLaunchKernelGGL(orb_search_kernel, dim3(1), dim3(kThreads), lds, st, static_cast<const Problem*>(problem_d));
+  LLD_HIP_TRY(hipGetLastError());
+  return LLD_OK;
+}
+
+int orbs_launch_last_frame(lld_ctx* ctx, hipStream_t st, const lld_frame* f, const lld_frame_view* view_h, const lld_frame_view* view_d, const LastFrameDev& last,
+                           int direction, float th, void* d_qrec, const void* problem_d, RunIf run_if) {
+  if (last.n > 0) {
+    LastFrameArgs F; std::memset(&F, 0, sizeof(F));
+    if (view_h) F.V = *view_h;
+    F.view_d = view_d; F.n = last.n; F.direction = direction;
+    F.pos = last.pos; F.valid = last.valid; F.octave = last.octave; F.angle = last.angle; F.has_obs = last.has_obs;
+    for (int l = 0; l < LLD_ORB_MAX_LEVELS; l++) F.scale[l] = l < f->consts.n_levels ? f->scale[l] : 1.f;
+    F.th = th; F.q = static_cast<QRec*>(d_qrec); F.uvr = nullptr;
+    F.run_if = run_if.flag; F.run_if_below = run_if.below; F.run_if_want = run_if.want;
+    hipLaunchKernelGGL(project_last_frame_kernel, dim3((last.n + 255) / 256), dim3(256), 0, st, F);
+  }
+  return orbs_launch_search(ctx, st, f, problem_d);
+}
+
+int orbs_launch_local_points(lld_ctx* ctx, hipStream_t st, const lld_frame* f, const lld_frame_view* view_h, const lld_frame_view* view_d, const MapPointsDev& mp,
+                             float cos_limit, float th, void* d_qrec, const void* problem_d) {
+  if (mp.n > 0) {
+    FrustumArgs F; std::memset(&F, 0, sizeof(F));
+    if (view_h) F.V = *view_h;
+    F.view_d = view_d; F.n = mp.n;
+    F.pos = mp.pos; F.nrm = mp.normal; F.maxd = mp.maxd; F.mind = mp.mind; F.has_obs = mp.has_obs; F.skip = mp.skip;
+    for (int l = 0; l < LLD_ORB_MAX_LEVELS; l++) F.scale[l] = l < f->consts.n_levels ? f->scale[l] : 1.f;
+    F.cos_limit = cos_limit; F.th = th; F.q = static_cast<QRec*>(d_qrec);
+    hipLaunchKernelGGL(frustum_kernel, dim3((mp.n + 255) / 256), dim3(256), 0, st, F);
+  }
+  return orbs_launch_search(ctx, st, f, problem_d);
+}
+
+}  // namespace lld_track

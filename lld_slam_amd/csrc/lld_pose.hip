@@ -15,6 +15,7 @@
 // (only outliers are re-evaluated before classification).  Frames too large for LDS run the same code on HBM-resident working arrays.
 #include "lld_common.h"
 #include "lld_device_math.h"
+#include "lld_track_internal.h"
 
 namespace {
 
@@ -26,6 +27,17 @@ constexpr size_t kPoseLdsBudget = 150 * 1024;              // dynamic LDS availa
 constexpr size_t kPoseLdsBudgetPair = 78 * 1024;           // ... to each of two co-resident frames (the kernel's static LDS is 2.2 KB per workgroup)
 constexpr uint8_t PF_LEVEL = 1, PF_ROBUST = 2, PF_OUTLIER = 4;             // point working flags
 constexpr uint8_t LF_LEVEL = 1, LF_ROBUST = 2, LF_LAST = 4, LF_STEREO = 8, LF_THR_STEREO = 16; // line-edge flags (LAST / STEREO / THR_STEREO are inputs)
+
+#ifdef LLD_EXPERIMENTS
+#define LLD_PO_T0() long long po_t_ = (long long)__builtin_amdgcn_s_memtime()
+#define LLD_PO_LAP(k) do { const long long n_ = (long long)__builtin_amdgcn_s_memtime(); po_acc[(k)] += n_ - po_t_; po_t_ = n_; } while (0)
+#define LLD_PO_COUNT(k) do { po_acc[(k)] += 1; } while (0)
+#else
+#define LLD_PO_T0() do {} while (0)
+#define LLD_PO_LAP(k) do {} while (0)
+#define LLD_PO_COUNT(k) do {} while (0)
+#endif
+enum { PO_STAGE = 0, PO_BUILD, PO_REDUCE, PO_SOLVE, PO_TRIAL_SWEEP, PO_TRIAL_SUM, PO_CLASSIFY, PO_ROUND_HEAD, PO_N_ITS, PO_N_TRIALS, PO_N_SOLVES, PO_TOTAL, PO_N_STAMPS };
 
 struct PoseFrameDev {            // per-frame header in HBM
   CamK cam;
@@ -48,6 +60,12 @@ struct PoseArrays {
   double *pt_chi2, *le_chi2; uint8_t *pt_fl, *le_fl;
   // results
   uint8_t *pt_outlier, *ln_outlier;
+  // device-resident frames (lld_frame_track_*): edge e belongs to keypoint pt_kp[e], line l of the problem to frame line ln_fi[l]; the flags go
+  // straight into Frame::mvbOutlier / mvbOutlierLines (kp_outlier / fl_outlier), the result also to track_out.  All null otherwise.
+  const int* pt_kp = nullptr; const int* ln_fi = nullptr;
+  uint8_t* kp_outlier = nullptr; uint8_t* fl_outlier = nullptr;
+  double* track_out = nullptr;
+  long long* stamps = nullptr;      // experiments build: per-stage s_memtime sums of frame 0's wavefront 0 (tools/pose_stage_budget.py)
 };
 
 struct PoseOut { double qt[7]; double chi2; int n_inliers, lm_iterations, lm_trials, pad; };
@@ -249,6 +267,12 @@ __global__ __launch_bounds__(kThreads, 2) void pose_opt_kernel(const PoseFrameDe
   __shared__ double sol[kCand * 10];            // per candidate: trial pose (7), scale, solver ok, lambda
   __shared__ double red1[2 * kWaves];
   int flip = 0;
+#ifdef LLD_EXPERIMENTS
+  long long po_acc[PO_N_STAMPS];
+  for (int i = 0; i < PO_N_STAMPS; i++) po_acc[i] = 0;
+  const long long po_begin = (long long)__builtin_amdgcn_s_memtime();
+#endif
+  LLD_PO_T0();
   const PoseFrameDev& F = frames[blockIdx.x];
   const CamK cam = F.cam;
   const int tid = threadIdx.x;
@@ -305,8 +329,9 @@ __global__ __launch_bounds__(kThreads, 2) void pose_opt_kernel(const PoseFrameDe
   // every solve starts from: level 0, Huber kernels on, nothing flagged
   for (int i = tid; i < n_pt; i += kThreads) { pfl[i] = PF_ROBUST; if constexpr (kLds) pchi_f[i] = 0.f; else pchi_d[i] = 0.0; }
   for (int i = tid; i < n_le; i += kThreads) lfl[i] = a.le_fl0[lo + i] | LF_ROBUST;
-  for (int i = tid; i < n_ln; i += kThreads) a.ln_outlier[no + i] = 0;
+  for (int i = tid; i < n_ln; i += kThreads) a.ln_outlier[no + i] = 0;       // (Frame::mvbOutlierLines itself is NOT reset by the reference: a.fl_outlier keeps what it holds)
   __syncthreads();
+  LLD_PO_LAP(PO_STAGE);
 
   int lm_iterations = 0, lm_trials = 0;
   double last_chi = 0.0;
@@ -403,6 +428,7 @@ __global__ __launch_bounds__(kThreads, 2) void pose_opt_kernel(const PoseFrameDe
       for (int i = tid; i < n_pt; i += kThreads) cnt += (pfl[i] & PF_LEVEL) ? 0.0 : 1.0;
       for (int i = tid; i < n_le; i += kThreads) cnt += (lfl[i] & LF_LEVEL) ? 0.0 : 1.0;
       cnt = block_sum1<kWaves>(cnt, red1, flip);
+      LLD_PO_LAP(PO_ROUND_HEAD);
       if (cnt > 0.5) {
         bool ok = true;
         for (int it = 0; it < its_per_round && ok; it++) {
@@ -410,6 +436,7 @@ __global__ __launch_bounds__(kThreads, 2) void pose_opt_kernel(const PoseFrameDe
           {
             double acc[28];
             sweep_build(T, acc);
+            LLD_PO_LAP(PO_BUILD);
             wave_sum28(acc, red + (tid >> 6) * 28);               // red / tot were last read before the previous trial's barrier
             __syncthreads();
             if (tid < 28) {
@@ -423,6 +450,7 @@ __global__ __launch_bounds__(kThreads, 2) void pose_opt_kernel(const PoseFrameDe
           // other wavefronts read tot[27] only after the barrier that follows the first solve
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
           __builtin_amdgcn_wave_barrier();
+          LLD_PO_LAP(PO_REDUCE);
           bool first_trial = true;
           double currentChi = 0.0, iniChi = 0.0;
           double rho = 0.0; int q = 0;
@@ -456,6 +484,7 @@ __global__ __launch_bounds__(kThreads, 2) void pose_opt_kernel(const PoseFrameDe
                 so[7] = scale; so[8] = ok2 ? 1.0 : 0.0; so[9] = lam;
               }
               __syncthreads();
+              LLD_PO_LAP(PO_SOLVE); LLD_PO_COUNT(PO_N_SOLVES);
             }
             const double* so = sol + (q - q_base) * 10;
             const Pose Tn = pose_load(so);
@@ -466,7 +495,10 @@ __global__ __launch_bounds__(kThreads, 2) void pose_opt_kernel(const PoseFrameDe
               if (it == 0) { lambda = so[9]; ni = 2.0; nBadLM = 0; }
               first_trial = false;
             }
-            const double tmp = block_sum1<kWaves>(sweep_chi(Tn), red1, flip);   // its barrier also fences `sol` and `tot` against the next trial
+            const double my_chi = sweep_chi(Tn);
+            LLD_PO_LAP(PO_TRIAL_SWEEP);
+            const double tmp = block_sum1<kWaves>(my_chi, red1, flip);   // its barrier also fences `sol` and `tot` against the next trial
+            LLD_PO_LAP(PO_TRIAL_SUM); LLD_PO_COUNT(PO_N_TRIALS);
             const double tempChi = ok2 ? tmp : 1.7976931348623157e308;
             rho = (currentChi - tempChi) / scale;
             if (rho > 0 && isfinite(tempChi)) {
@@ -479,7 +511,7 @@ __global__ __launch_bounds__(kThreads, 2) void pose_opt_kernel(const PoseFrameDe
             if (q - q_base == kCand) q_base = q;                       // (more than kCand rejections in a row: the next block of candidates)
           } while (rho < 0 && q < max_trials);
           last_chi = currentChi;
-          lm_iterations++;
+          lm_iterations++; LLD_PO_COUNT(PO_N_ITS);
           if (q == max_trials || rho == 0) ok = false;
           else {
             if ((iniChi - currentChi) * 1e3 < iniChi) nBadLM++; else nBadLM = 0;
@@ -489,6 +521,7 @@ __global__ __launch_bounds__(kThreads, 2) void pose_opt_kernel(const PoseFrameDe
       }
       // ---- classification (Optimizer.cc:827-913)
       __syncthreads();
+      LLD_PO_LAP(PO_ROUND_HEAD);
       const PoseRt Trt = pose_rt(T);
       double nb = 0.0;
       for (int i = tid; i < n_pt; i += kThreads) {
@@ -524,18 +557,35 @@ __global__ __launch_bounds__(kThreads, 2) void pose_opt_kernel(const PoseFrameDe
         const double thr = st ? F.thr_ln_stereo : F.thr_ln_mono;
         const bool bad = (double)chif > thr;
         fl = (uint8_t)((fl & ~LF_LEVEL) | (bad ? LF_LEVEL : 0));
-        if (fl & LF_LAST) a.ln_outlier[no + idx] = bad;              // the right-image edge overwrites the left one
+        if (fl & LF_LAST) { a.ln_outlier[no + idx] = bad; if (a.ln_fi) a.fl_outlier[a.ln_fi[idx]] = bad; }   // the right-image edge overwrites the left one
         if (round == 2) fl &= (uint8_t)~LF_ROBUST;
         lfl[i] = fl;
       }
       __syncthreads();
+      LLD_PO_LAP(PO_CLASSIFY);
     }
   }
-  for (int i = tid; i < n_pt; i += kThreads) a.pt_outlier[po + i] = (pfl[i] & PF_OUTLIER) ? 1 : 0;
+  for (int i = tid; i < n_pt; i += kThreads) {
+    const uint8_t bad = (pfl[i] & PF_OUTLIER) ? 1 : 0;
+    a.pt_outlier[po + i] = bad;
+    if (a.pt_kp) a.kp_outlier[a.pt_kp[i]] = bad;
+  }
   if (tid == 0) {
     PoseOut& o = out[blockIdx.x];
+    // PoseOptimization returns before it touches the frame when it has fewer than three points (Optimizer.cc:809-810): the pose stays
     pose_store(T, o.qt);
     o.chi2 = last_chi; o.n_inliers = enough ? n_pt - nBad_pts : 0; o.lm_iterations = lm_iterations; o.lm_trials = lm_trials; o.pad = 0;
+#ifdef LLD_EXPERIMENTS
+    if (a.stamps && blockIdx.x == 0) {
+      po_acc[PO_TOTAL] = (long long)__builtin_amdgcn_s_memtime() - po_begin;
+      for (int i = 0; i < PO_N_STAMPS; i++) a.stamps[i] = po_acc[i];
+    }
+#endif
+    if (a.track_out) {
+      pose_store(T, a.track_out); a.track_out[7] = last_chi;
+      int* ti = reinterpret_cast<int*>(a.track_out + 8);
+      ti[0] = o.n_inliers; ti[1] = lm_iterations; ti[2] = lm_trials; ti[3] = n_pt + n_le; ti[4] = n_pt; ti[5] = n_le;
+    }
   }
 }
 
@@ -703,6 +753,132 @@ static void pose_fill_result(const PoseLayout& Y, const char* h_out /* start of 
   if (out->ln_outlier && F.n_ln) std::memcpy(out->ln_outlier, h_out + (Y.ln_outlier - Y.in_bytes) + F.ln_off, F.n_ln);
 }
 
+// ================================================================ the resident frame's PoseOptimization (lld_frame_track_*, lld_track_internal.h)
+// The edges are gathered ON THE DEVICE from what the frame holds, in the order Optimizer::PoseOptimization adds them: one point edge per
+// keypoint with a MapPoint in keypoint order (stereo iff mvuRight[i] >= 0, src/Optimizer.cc:739-792), then AddLineMinOnlyPose for every
+// frame line with a MapLine in line order (:796-804).  One workgroup: an exclusive scan numbers the edges, every lane writes its keypoints'
+// / lines' rows of the image pose_opt_kernel reads.  pt_kp / ln_fi map the edges back to the frame for the outlier flags.
+namespace {
+constexpr int kAsmThreads = 1024;
+struct PoseAsmConsts { double delta_mono, delta_stereo, delta_ln_stereo, delta_ln_mono, thr_ln_stereo, thr_ln_mono; };
+
+__device__ __forceinline__ int block_excl_scan(int v, int* lds /*[kAsmThreads/64 + 1]*/, int& total) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int incl = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off); if (lane >= off) incl += t; }
+  __syncthreads();                                             // (lds may still be read by the previous scan)
+  if (lane == 63) lds[wave] = incl;
+  __syncthreads();
+  int base = 0, tot = 0;
+  for (int w = 0; w < kAsmThreads / 64; w++) { const int t = lds[w]; if (w < wave) base += t; tot += t; }
+  total = tot;
+  return base + incl - v;
+}
+
+__global__ __launch_bounds__(kAsmThreads) void pose_assemble_kernel(lld_track::PoseTrackDev in, PoseAsmConsts dc, char* img, PoseLayout Y, int* pt_kp, int* ln_fi) {
+  __shared__ int scan_lds[kAsmThreads / 64 + 1];
+  extern __shared__ unsigned char edge_stereo[];               // vnStereoLines: one entry per line EDGE, in the order they are added
+  const int tid = threadIdx.x;
+  const CamK cam = lld::make_camk(in.cam);
+  double* pt = reinterpret_cast<double*>(img + Y.pt);
+  double* le = reinterpret_cast<double*>(img + Y.le);
+  int* le_line = reinterpret_cast<int*>(img + Y.le_line);
+  uint8_t* le_fl0 = reinterpret_cast<uint8_t*>(img + Y.le_fl0);
+  // ---- points
+  const int per = (in.nt + kAsmThreads - 1) / kAsmThreads, k0 = min(tid * per, in.nt), k1 = min(k0 + per, in.nt);
+  int cnt = 0;
+  for (int k = k0; k < k1; k++) cnt += in.kp_has[k] ? 1 : 0;
+  int n_pt;
+  int e = block_excl_scan(cnt, scan_lds, n_pt);
+  for (int k = k0; k < k1; k++) {
+    if (!in.kp_has[k]) continue;
+    const float ur = in.t_uright ? in.t_uright[k] : -1.f;
+    pt[0 * Y.NP + e] = (double)in.kp_world[3 * k]; pt[1 * Y.NP + e] = (double)in.kp_world[3 * k + 1]; pt[2 * Y.NP + e] = (double)in.kp_world[3 * k + 2];
+    pt[3 * Y.NP + e] = (double)in.t_xy[2 * k]; pt[4 * Y.NP + e] = (double)in.t_xy[2 * k + 1];
+    pt[5 * Y.NP + e] = ur < 0.f ? -1.0 : (double)ur;
+    pt[6 * Y.NP + e] = (double)in.inv_sigma2[in.t_octave[k]];
+    pt_kp[e] = k;
+    e++;
+  }
+  // ---- lines: rank of the line among those with a MapLine, and the index of its first edge
+  const int lper = (in.nl + kAsmThreads - 1) / kAsmThreads, l0 = min(tid * lper, in.nl), l1 = min(l0 + lper, in.nl);
+  int lc = 0, ec = 0;
+  for (int i = l0; i < l1; i++) if (in.ln_has[i]) { lc++; ec += in.ln_match[i] >= 0 ? 2 : 1; }
+  int n_ln, n_le;
+  int l = block_excl_scan(lc, scan_lds, n_ln);
+  int ie = block_excl_scan(ec, scan_lds, n_le);
+  {
+    int ie2 = ie;
+    for (int i = l0; i < l1; i++) if (in.ln_has[i]) { const bool hr = in.ln_match[i] >= 0; edge_stereo[ie2++] = hr; if (hr) edge_stereo[ie2++] = 1; }
+  }
+  __syncthreads();
+  for (int i = l0; i < l1; i++) {
+    if (!in.ln_has[i]) continue;
+    const int ri = in.ln_match[i];
+    const bool hr = ri >= 0;
+    // vnStereoLines is filled per EDGE and read with the LINE's index in the frame (Optimizer.cc:643-648 vs :898); beyond the edge count: stereo
+    const bool thr_stereo = i < n_le ? edge_stereo[i] != 0 : true;
+    const double x0[3] = {in.ln_x0[3 * i], in.ln_x0[3 * i + 1], in.ln_x0[3 * i + 2]}, dr[3] = {in.ln_dir[3 * i], in.ln_dir[3 * i + 1], in.ln_dir[3 * i + 2]};
+    for (int si = 0; si < 2; si++) {
+      if (si == 1 && !hr) continue;
+      const float* kl = si == 0 ? in.ln_left + 4 * i : in.ln_right + 4 * ri;
+      const int oct = si == 0 ? in.ln_loct[i] : in.ln_roct[ri];
+      le[0 * Y.NE + ie] = x0[0]; le[1 * Y.NE + ie] = x0[1]; le[2 * Y.NE + ie] = x0[2];
+      le[3 * Y.NE + ie] = x0[0] + dr[0]; le[4 * Y.NE + ie] = x0[1] + dr[1]; le[5 * Y.NE + ie] = x0[2] + dr[2];
+      le[6 * Y.NE + ie] = (double)kl[0]; le[7 * Y.NE + ie] = (double)kl[1]; le[8 * Y.NE + ie] = (double)kl[2]; le[9 * Y.NE + ie] = (double)kl[3];
+      le[10 * Y.NE + ie] = lld::line_info(in.gamma, oct);
+      le[11 * Y.NE + ie] = si == 1 ? cam.bx_right : 0.0;
+      le_line[ie] = l;
+      le_fl0[ie] = (uint8_t)(((si == 1 || !hr) ? LF_LAST : 0) | (hr ? LF_STEREO : 0) | (thr_stereo ? LF_THR_STEREO : 0));
+      ie++;
+    }
+    ln_fi[l] = i;
+    l++;
+  }
+  if (tid == 0) {
+    PoseFrameDev F;
+    F.cam = cam;
+    for (int k = 0; k < 7; k++) F.T0[k] = in.pose_qt[k];
+    F.pt_off = 0; F.n_pt = n_pt; F.le_off = 0; F.n_le = n_le; F.ln_off = 0; F.n_ln = n_ln;
+    F.delta_mono = dc.delta_mono; F.delta_stereo = dc.delta_stereo; F.delta_ln_stereo = dc.delta_ln_stereo; F.delta_ln_mono = dc.delta_ln_mono;
+    F.thr_ln_stereo = dc.thr_ln_stereo; F.thr_ln_mono = dc.thr_ln_mono;
+    *reinterpret_cast<PoseFrameDev*>(img + Y.frames) = F;
+  }
+}
+}  // namespace
+
+namespace lld_track {
+static PoseLayout track_layout(int nt, int nl) { return pose_layout(1, (size_t)nt, 2 * (size_t)nl, (size_t)nl, true); }
+size_t pose_track_work_bytes(int nt, int nl) {
+  const PoseLayout Y = track_layout(nt, nl);
+  return Y.total + lld_slab::pad(4 * ((size_t)nt + 1)) + lld_slab::pad(4 * ((size_t)nl + 1)) + 256;
+}
+int pose_track_launch(lld_ctx* ctx, hipStream_t st, const PoseTrackDev& in, const lld_pose_params& prm, void* d_work) {
+  if (in.nl > 16 * 1024) return LLD_ERR_UNSUPPORTED;           // (the edge flags of the line scan live in LDS)
+  char* d_img = static_cast<char*>(d_work);
+  const PoseLayout Y = track_layout(in.nt, in.nl);
+  int* pt_kp = reinterpret_cast<int*>(d_img + Y.total);
+  int* ln_fi = reinterpret_cast<int*>(d_img + Y.total + lld_slab::pad(4 * ((size_t)in.nt + 1)));
+  const float dMono = (float)std::sqrt(5.991), dStereo = (float)std::sqrt(7.815);
+  float dLnS = dStereo, dLnM = dMono;
+  dLnS *= prm.gamma; dLnM *= prm.gamma;                        // float *= double (Optimizer.cc:706-707)
+  PoseAsmConsts dc{(double)dMono, (double)dStereo, (double)dLnS, (double)dLnM, (double)(dLnS * dLnS), (double)(dLnM * dLnM)};
+  PoseTrackDev inq = in; inq.gamma = prm.gamma;
+  hipLaunchKernelGGL(pose_assemble_kernel, dim3(1), dim3(kAsmThreads), (size_t)2 * in.nl + 16, st, inq, dc, d_img, Y, pt_kp, ln_fi);
+  PoseArrays A = pose_arrays(d_img, Y);
+  A.pt_kp = pt_kp; A.ln_fi = ln_fi; A.kp_outlier = in.kp_outlier; A.fl_outlier = in.ln_outlier; A.track_out = in.pose_out;
+  // the edge counts are the device's: the launch reserves the LDS of the largest frame this handle can hold (frame data are floats)
+  const size_t lds = pose_lds_bytes(in.nt, in.nl, 2 * in.nl, true);
+  const PoseFrameDev* fr = reinterpret_cast<const PoseFrameDev*>(d_img + Y.frames);
+  PoseOut* po = reinterpret_cast<PoseOut*>(d_img + Y.out);
+  int s;
+  if (lds <= kPoseLdsBudget) s = pose_launch_as<true, float, kPoseThreadsMax>(ctx, st, 1, lds, fr, A, po, prm);
+  else s = pose_launch_as<false, double, kPoseThreadsMax>(ctx, st, 1, 0, fr, A, po, prm);
+  return s;
+}
+}  // namespace lld_track
+
 struct lld_pose_batch {
   lld_ctx* ctx = nullptr;
   int n_frames = 0;
@@ -790,3 +966,34 @@ int lld_pose_opt(lld_ctx* ctx, const lld_pose_problem* in, const lld_pose_params
 }
 
 }  // extern "C"
+
+#ifdef LLD_EXPERIMENTS
+// experiments build only: one lld_pose_opt with the per-stage s_memtime sums of the frame's first wavefront (tools/pose_stage_budget.py)
+extern "C" __attribute__((visibility("default"))) int lld_exp_pose_stamps(lld_ctx* ctx, const lld_pose_problem* in, const lld_pose_params* params, lld_pose_result* out, long long* stamps16) {
+  if (!ctx || !in || !out || !stamps16) return LLD_ERR_INVALID;
+  LLD_HIP_TRY(hipSetDevice(ctx->device));
+  lld_pose_params prm;
+  if (params) prm = *params; else lld_pose_params_default(&prm);
+  PoseCounts C;
+  int st = pose_count(1, in, &C); if (st) return st;
+  const PoseMode M = pose_mode(ctx, 1, C);
+  if (!M.use_lds || !M.f32) return LLD_ERR_UNSUPPORTED;
+  const PoseLayout Y = pose_layout(1, C.np, C.ne, C.nl, false);
+  void* hb; st = lld_ctx_pinned(ctx, Y.in_bytes + Y.out_bytes, &hb); if (st) return st;
+  void* db; st = lld_ctx_scratch(ctx, Y.total + 512, &db); if (st) return st;
+  char* h_img = static_cast<char*>(hb); char* d_img = static_cast<char*>(db);
+  PoseFrameDev F;
+  pose_pack(1, in, prm.gamma, Y, h_img, &F);
+  hipStream_t s = ctx->stream;
+  LLD_HIP_TRY(hipMemcpyAsync(d_img, h_img, Y.in_bytes, hipMemcpyHostToDevice, s));
+  PoseArrays A = pose_arrays(d_img, Y);
+  A.stamps = reinterpret_cast<long long*>(d_img + lld_slab::pad(Y.total));
+  st = pose_launch_as<true, float, kPoseThreadsMax>(ctx, s, 1, M.lds_bytes, reinterpret_cast<const PoseFrameDev*>(d_img + Y.frames), A, reinterpret_cast<PoseOut*>(d_img + Y.out), prm);
+  if (st) return st;
+  LLD_HIP_TRY(hipMemcpyAsync(h_img + Y.in_bytes, d_img + Y.in_bytes, Y.out_bytes, hipMemcpyDeviceToHost, s));
+  LLD_HIP_TRY(hipStreamSynchronize(s));
+  pose_fill_result(Y, h_img + Y.in_bytes, F, 0, out);
+  LLD_HIP_TRY(hipMemcpy(stamps16, A.stamps, sizeof(long long) * PO_N_STAMPS, hipMemcpyDeviceToHost));
+  return LLD_OK;
+}
+#endif

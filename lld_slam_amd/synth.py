@@ -839,7 +839,7 @@ def make_local_map(F, scene_id=0, n=2000, related_frac=0.8, flip_p=0.06, pos_noi
                    skip=(rng.random(n) < 0.1).astype(np.uint8), occupied=(rng.random(F.n) < 0.05).astype(np.uint8), src=src.astype(np.int32))
 
 
-def make_tracking_scene(scene_id=0, n_kp=2000, n_map=2500, n_last=1200, rot_deg=0.25, trans=0.04):
+def make_tracking_scene(scene_id=0, n_kp=2000, n_map=2500, n_last=1200, rot_deg=0.25, trans=0.04, n_lines=300, n_map_lines=260, n_last_lines=140):
     """One consistent little world for the Tracking thread's per-frame sequence (lld_slam_amd/tracking.py): a frame with `n_kp` keypoints,
     its true pose, `n_map` local MapPoints most of which are back-projections of the keypoints (make_local_map), the first `n_last` of them
     also being the last frame's tracked points (with that frame's octaves / angles), and the motion model's prediction of the pose - the
@@ -856,5 +856,74 @@ def make_tracking_scene(scene_id=0, n_kp=2000, n_map=2500, n_last=1200, rot_deg=
     dt = rng.normal(size=3); dt *= trans / np.linalg.norm(dt)
     dT = np.eye(4); dT[:3, :3] = _rodrigues(w); dT[:3, 3] = dt
     Tg = (dT @ T.astype(np.float64)).astype(np.float32)
-    return dict(frame=F, cam=KITTI_CAM, Tcw_true=T, pose_true=_tcw_to_qt(T.astype(np.float64)), pose_guess=_tcw_to_qt(Tg.astype(np.float64)),
-                last=last, last_ids=np.arange(n_last), map_points=mp, map_ids=np.arange(n_map))
+    sc = dict(frame=F, cam=KITTI_CAM, Tcw_true=T, Tcw_guess=Tg, pose_true=_tcw_to_qt(T.astype(np.float64)), pose_guess=_tcw_to_qt(Tg.astype(np.float64)),
+              last=last, last_ids=np.arange(n_last), map_points=mp, map_ids=np.arange(n_map))
+    if n_lines > 0:
+        sc.update(make_tracking_lines(scene_id, T.astype(np.float64), n_map_lines, n_lines, n_last_lines, Tcw_guess=Tg.astype(np.float64)))
+    return sc
+
+
+def make_tracking_lines(scene_id, Tcw, n_map=260, n_cur=300, n_last=140, dim=72, related_frac=0.75, pixel_noise=0.4, desc_noise=0.05, no_partner_frac=0.1,
+                        outlier_frac=0.12, Tcw_guess=None, trap_frac=0.12):
+    """The line half of make_tracking_scene: `n_cur` stereo lines of the frame at the true pose Tcw (world -> camera), `n_map` MapLines of which
+    the first `related_frac * min(n_map, n_cur)` project onto frame lines (a few with a pose-inconsistent 3D position that passes the 2-pixel
+    association gate of the predicted pose only sometimes, and PoseOptimization must then throw out), the rest elsewhere or behind the camera.
+    The first `n_last` MapLines are the last frame's (mLastFrame.mvpMapLines), all of them the local map's - with the same ids, so that
+    TrackLocalMap meets the lines TrackWithMotionModel already tracked.  Returns dict(lines=..., last_lines=..., local_lines=...)."""
+    rng = np.random.default_rng(SEED_SEARCH + 0x9000 + scene_id)
+    fx, fy, cx, cy, bf = [float(np.float32(c)) for c in KITTI_CAM]
+    b = float(np.float32(np.float32(bf) / np.float32(fx)))
+    Rcw = Tcw[:3, :3]; tcw = Tcw[:3, 3]
+    z = rng.uniform(3.0, 40.0, n_map)
+    c = np.stack([(rng.uniform(60, 1180, n_map) - cx) * z / fx, (rng.uniform(30, 340, n_map) - cy) * z / fy, z], 1)
+    behind = rng.random(n_map) < 0.04
+    c[behind, 2] = -rng.uniform(1.0, 10.0, int(behind.sum()))
+    d = rng.normal(size=(n_map, 3)); d[:, 2] *= 0.3; d /= np.linalg.norm(d, axis=1, keepdims=True)
+    half = rng.uniform(0.3, 2.5, n_map)[:, None] * 0.5
+    A, B = c - half * d, c + half * d                                        # camera frame of the TRUE pose
+
+    def proj(X, shift):
+        Xc = X - np.array([shift, 0, 0]); zz = np.maximum(Xc[:, 2], 0.3)
+        return np.stack([fx * Xc[:, 0] / zz + cx, fy * Xc[:, 1] / zz + cy], 1)
+    m = int(related_frac * min(n_map, n_cur))
+    to_w = lambda X: (Rcw.T @ (X - tcw).T).T
+    Aw, Bw = to_w(A), to_w(B)
+    if Tcw_guess is not None:
+        # traps: lines observed where the PREDICTED pose projects them - they pass AddLinesFrom's gate in TrackWithMotionModel and are
+        # outliers of the PoseOptimization that follows (the discard of src/Tracking.cc:962-975 needs something to discard)
+        trap = np.nonzero(rng.random(m) < trap_frac)[0]
+        Rg = Tcw_guess[:3, :3]; tg = Tcw_guess[:3, 3]
+        A = A.copy(); B = B.copy()
+        A[trap] = (Rg @ Aw[trap].T).T + tg; B[trap] = (Rg @ Bw[trap].T).T + tg
+    left = np.concatenate([proj(A[:m], 0.0), proj(B[:m], 0.0)], 1) + rng.normal(0, pixel_noise, (m, 4))
+    sft = rng.uniform(-0.2, 0.2, (m, 2))
+    Ar, Br = A[:m] + sft[:, :1] * (B[:m] - A[:m]), B[:m] + sft[:, 1:] * (B[:m] - A[:m])
+    right = np.concatenate([proj(Ar, b), proj(Br, b)], 1) + rng.normal(0, pixel_noise, (m, 4))
+    off = rng.random(m) < outlier_frac                                       # observed a little off: inside the association gate now and then, outside PoseOptimization's
+    left[off] += rng.normal(0, 1.2, (int(off.sum()), 4)); right[off] += rng.normal(0, 1.2, (int(off.sum()), 4))
+
+    def unrelated(n):
+        p = np.stack([rng.uniform(0, 1241, n), rng.uniform(0, 376, n)], 1)
+        return np.concatenate([p, p + rng.normal(0, 40, (n, 2))], 1)
+    left = np.concatenate([left, unrelated(n_cur - m)]); right = np.concatenate([right, unrelated(n_cur - m)])
+    lo = rng.integers(0, 3, n_cur); ro = lo.copy(); flip = rng.random(n_cur) < 0.1; ro[flip] = rng.integers(0, 3, int(flip.sum()))
+    dirw = (Bw - Aw) / np.linalg.norm(Bw - Aw, axis=1, keepdims=True)
+    X0 = Aw - np.sum(Aw * dirw, axis=1, keepdims=True) * dirw
+    dm = rng.normal(size=(n_map, dim)); dm /= np.linalg.norm(dm, axis=1, keepdims=True)
+    dup = rng.integers(0, m, max(1, n_map // 12)); tgt = rng.integers(0, m, dup.size)
+    dm[dup] = dm[tgt] + rng.normal(0, 0.01, (dup.size, dim))               # rivals for the same frame line
+    dc = rng.normal(size=(n_cur, dim)); dc /= np.linalg.norm(dc, axis=1, keepdims=True)
+    dc[:m] = dm[:m] + rng.normal(0, desc_noise, (m, dim))
+    perm = rng.permutation(n_cur); rperm = rng.permutation(n_cur)
+    inv_r = np.empty(n_cur, np.int64); inv_r[rperm] = np.arange(n_cur)
+    line_matches = inv_r[perm].astype(np.int32)
+    line_matches[rng.random(n_cur) < no_partner_frac] = -1
+    lines = dict(left_lines=left[perm].astype(np.float32), left_octave=lo[perm].astype(np.int32), right_lines=right[rperm].astype(np.float32),
+                 right_octave=ro[rperm].astype(np.int32), line_matches=line_matches, desc=dc[perm].astype(np.float32))
+    order = rng.permutation(n_map)                                           # the map's own order: not the frame's
+    ids = (1000 + np.arange(n_map)).astype(np.int32)
+
+    def pick(sel, skip_frac):
+        return dict(X0=X0[sel], dir=dirw[sel], X1=Aw[sel], X2=Bw[sel], desc=dm[sel].astype(np.float32), id=ids[sel],
+                    skip=(rng.random(len(sel)) < skip_frac).astype(np.uint8))
+    return dict(lines=lines, last_lines=pick(order[:n_last], 0.05), local_lines=pick(rng.permutation(n_map), 0.03))

@@ -43,6 +43,7 @@ class TrackedFrame:
         self.kp_has = np.zeros(F.n, bool)                        # mvpMapPoints[i] != NULL
         self.kp_world = np.zeros((F.n, 3), np.float32)           # its GetWorldPos()
         self.kp_point = np.full(F.n, -1, np.int64)               # an id of the MapPoint (caller's numbering)
+        self.discarded = np.zeros(0, np.int64)                   # MapPoints dropped as outliers in this frame: mnLastFrameSeen = mnId (src/Tracking.cc:949)
         self.stages = {}                                         # what every stage returned, for the checker
 
     def close(self):
@@ -61,6 +62,7 @@ class TrackedFrame:
         self.stages[tag] = dict(problem=prob, edge_keypoint=idx, out=out)
         # the discard of src/Tracking.cc:940-958 / :1160-1178: an outlier edge's MapPoint leaves the frame
         bad = idx[out.pt_outlier != 0]
+        self.discarded = np.concatenate([self.discarded, self.kp_point[bad]])
         self.kp_has[bad] = False; self.kp_point[bad] = -1
         return out.pose_qt
 
@@ -84,7 +86,9 @@ class TrackedFrame:
     def track_local_map(self, pose_qt, mp: dict, mp_ids, th=1.0, nnratio=0.8):
         """SearchLocalPoints (points the frame already holds are skipped, src/Tracking.cc:1620-1632) + PoseOptimization."""
         view = self._view(pose_qt)
-        held = np.isin(mp_ids, self.kp_point[self.kp_has])
+        # mnLastFrameSeen == mCurrentFrame.mnId (:1640): the points the frame holds (:1629) AND those the discard after the first
+        # PoseOptimization marked (:949) - the latter must not be projected and matched again in this frame
+        held = np.isin(mp_ids, self.kp_point[self.kp_has]) | np.isin(mp_ids, self.discarded)
         skip = (np.asarray(mp["skip"]) != 0) | held
         mp2 = dict(mp, skip=skip.astype(np.uint8))
         occ = self.kp_has.astype(np.uint8)
@@ -98,3 +102,193 @@ class TrackedFrame:
             if out.owner[k] == q:
                 self.kp_has[k] = True; self.kp_world[k] = mp["world_pos"][q]; self.kp_point[k] = mp_ids[q]
         return self._optimise(pose_qt, "pose_after_local_map")
+
+
+# ------------------------------------------------------------------------------------------------ the device-resident chain (round 6)
+import ctypes as C
+
+from . import abi
+from .abi import c_double_p, c_float_p, c_int32_p, c_uint8_p
+
+
+class FrameLines(C.Structure):
+    _fields_ = [("n_left", C.c_int32), ("left", c_float_p), ("left_octave", c_int32_p), ("n_right", C.c_int32), ("right", c_float_p),
+                ("right_octave", c_int32_p), ("line_matches", c_int32_p), ("desc", c_float_p), ("dim", C.c_int32), ("reserved", C.c_int32),
+                ("sx", C.c_double), ("sy", C.c_double)]
+
+
+class MapLines(C.Structure):
+    _fields_ = [("n", C.c_int32), ("x0", c_double_p), ("dir", c_double_p), ("x1", c_double_p), ("x2", c_double_p), ("skip", c_uint8_p),
+                ("desc", c_float_p), ("id", c_int32_p)]
+
+
+class TrackParams(C.Structure):
+    _fields_ = [("cam", abi.Camera), ("pose", abi.PoseParams), ("th_motion", C.c_float), ("th_local", C.c_float), ("nnratio_local", C.c_float),
+                ("viewing_cos_limit", C.c_float), ("direction", C.c_int32), ("check_orientation", C.c_int32), ("wide_retry", C.c_int32),
+                ("monocular", C.c_int32), ("line_thr_reproj_base", C.c_double), ("line_md_thr", C.c_double), ("line_use_grid", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
+class TrackResult(C.Structure):
+    _fields_ = [("pose_qt", C.c_double * 7), ("chi2", C.c_double), ("n_inliers", C.c_int32), ("lm_iterations", C.c_int32), ("lm_trials", C.c_int32),
+                ("n_edges", C.c_int32), ("n_search_first", C.c_int32), ("n_search", C.c_int32), ("used_wide", C.c_int32), ("n_points", C.c_int32),
+                ("n_points_map", C.c_int32), ("n_lines_matched", C.c_int32), ("n_lines", C.c_int32), ("n_discarded", C.c_int32),
+                ("kp_point_id", c_int32_p), ("kp_outlier", c_uint8_p), ("ln_line_id", c_int32_p), ("ln_outlier", c_uint8_p)]
+
+
+_COUNTERS = ("n_inliers", "lm_iterations", "lm_trials", "n_edges", "n_search_first", "n_search", "used_wide", "n_points", "n_points_map",
+             "n_lines_matched", "n_lines", "n_discarded")
+
+
+def map_lines_struct(ml: dict | None):
+    """lld_map_lines from a dict with X0, dir, X1, X2 [n,3], desc [n,dim], id [n] and optionally skip [n]; returns (struct, arrays kept alive)."""
+    m = MapLines()
+    if ml is None:
+        return m, {}
+    keep = dict(x0=np.ascontiguousarray(ml["X0"], np.float64).reshape(-1, 3), dir=np.ascontiguousarray(ml["dir"], np.float64).reshape(-1, 3),
+                x1=np.ascontiguousarray(ml["X1"], np.float64).reshape(-1, 3), x2=np.ascontiguousarray(ml["X2"], np.float64).reshape(-1, 3),
+                desc=np.ascontiguousarray(ml["desc"], np.float32), id=np.ascontiguousarray(ml["id"], np.int32),
+                skip=None if ml.get("skip") is None else np.ascontiguousarray(ml["skip"], np.uint8))
+    m.n = keep["x0"].shape[0]
+    m.x0 = keep["x0"].ctypes.data_as(c_double_p); m.dir = keep["dir"].ctypes.data_as(c_double_p)
+    m.x1 = keep["x1"].ctypes.data_as(c_double_p); m.x2 = keep["x2"].ctypes.data_as(c_double_p)
+    m.skip = None if keep["skip"] is None else keep["skip"].ctypes.data_as(c_uint8_p)
+    m.desc = keep["desc"].ctypes.data_as(c_float_p); m.id = keep["id"].ctypes.data_as(c_int32_p)
+    return m, keep
+
+
+class DeviceTrackedFrame:
+    """lld_frame_track_*: the whole per-frame sequence on the device (include/lld_amd.h).  `lines`: dict with left_lines [n,4], left_octave,
+    right_lines, right_octave, line_matches, desc (the frame's mvLinesLeft / mvLinesRight / line_matches / mDescriptorsLines) or None."""
+
+    def __init__(self, ctx, F: orb_search.Frame, cam, lines: dict | None = None, gamma=0.5, **params):
+        self.ctx, self.lib, self.F, self.cam = ctx, ctx.lib, F, cam
+        self.res = orb_search.ResidentFrame(ctx.lib, ctx.handle, F)
+        lib = self.lib
+        lib.fn("frame_set_lines").argtypes = [C.c_void_p, C.POINTER(FrameLines)]; lib.fn("frame_set_lines").restype = C.c_int
+        lib.fn("track_params_default").argtypes = [C.POINTER(TrackParams)]; lib.fn("track_params_default").restype = None
+        lib.fn("frame_track_motion_model").argtypes = [C.c_void_p, C.POINTER(TrackParams), C.POINTER(orb_search.FrameView), c_double_p,
+                                                       C.POINTER(orb_search.LastFramePoints), c_int32_p, C.POINTER(MapLines)]
+        lib.fn("frame_track_motion_model").restype = C.c_int
+        lib.fn("frame_track_local_map").argtypes = [C.c_void_p, C.POINTER(TrackParams), C.POINTER(orb_search.MapPoints), c_int32_p, C.POINTER(MapLines)]
+        lib.fn("frame_track_local_map").restype = C.c_int
+        lib.fn("frame_track_download").argtypes = [C.c_void_p, C.POINTER(TrackResult), C.POINTER(TrackResult)]; lib.fn("frame_track_download").restype = C.c_int
+        self.n_lines = 0
+        if lines is not None:
+            k = dict(left=np.ascontiguousarray(lines["left_lines"], np.float32).reshape(-1, 4), lo=np.ascontiguousarray(lines["left_octave"], np.int32),
+                     right=np.ascontiguousarray(lines["right_lines"], np.float32).reshape(-1, 4), ro=np.ascontiguousarray(lines["right_octave"], np.int32),
+                     lm=np.ascontiguousarray(lines["line_matches"], np.int32), desc=np.ascontiguousarray(lines["desc"], np.float32))
+            L = FrameLines()
+            L.n_left = k["left"].shape[0]; L.left = k["left"].ctypes.data_as(c_float_p); L.left_octave = k["lo"].ctypes.data_as(c_int32_p)
+            L.n_right = k["right"].shape[0]; L.right = k["right"].ctypes.data_as(c_float_p); L.right_octave = k["ro"].ctypes.data_as(c_int32_p)
+            L.line_matches = k["lm"].ctypes.data_as(c_int32_p); L.desc = k["desc"].ctypes.data_as(c_float_p); L.dim = k["desc"].shape[1]
+            L.sx = 1.0 / float(F.max_x); L.sy = 1.0 / float(F.max_y)
+            self._check(lib.fn("frame_set_lines")(self.res.handle, C.byref(L)), "lld_frame_set_lines")
+            self.n_lines = int(L.n_left)
+        self.params = TrackParams()
+        lib.fn("track_params_default")(C.byref(self.params))
+        self.params.cam = abi.Camera(*[float(np.float32(c)) for c in cam])
+        self.params.pose.gamma = gamma
+        for k_, v in params.items():
+            setattr(self.params, k_, v)
+
+    def _check(self, st, what):
+        if st != abi.LLD_OK:
+            raise RuntimeError(f"{what} failed: {self.lib.fn('status_string')(st).decode()}")
+
+    def close(self):
+        if self.res is not None:
+            self.res.close(); self.res = None
+
+    def __enter__(self): return self
+    def __exit__(self, *a): self.close()
+
+    def track_with_motion_model(self, Tcw_f32, last: dict, last_ids, last_lines: dict | None = None):
+        """Queues stage 1 from the predicted float pose matrix (mVelocity * mLastFrame.mTcw); returns nothing (see download())."""
+        from .host import se3_from_tcw_f32
+        T = np.ascontiguousarray(Tcw_f32, np.float32).reshape(4, 4)
+        view = orb_search.frame_view(T, self.cam, self.F)
+        qt = np.ascontiguousarray(se3_from_tcw_f32(self.lib, T), np.float64)
+        m, keep = orb_search.last_frame_struct(last)
+        ids = np.ascontiguousarray(last_ids, np.int32)
+        ml, keep2 = map_lines_struct(last_lines)
+        self._check(self.lib.fn("frame_track_motion_model")(self.res.handle, C.byref(self.params), C.byref(view), qt.ctypes.data_as(c_double_p), C.byref(m),
+                                                             ids.ctypes.data_as(c_int32_p), C.byref(ml) if last_lines is not None else None), "lld_frame_track_motion_model")
+        return view, qt
+
+    def track_local_map(self, mp: dict, mp_ids, local_lines: dict | None = None):
+        m, keep = orb_search.map_points_struct(mp)
+        ids = np.ascontiguousarray(mp_ids, np.int32)
+        ml, keep2 = map_lines_struct(local_lines)
+        self._check(self.lib.fn("frame_track_local_map")(self.res.handle, C.byref(self.params), C.byref(m), ids.ctypes.data_as(c_int32_p),
+                                                          C.byref(ml) if local_lines is not None else None), "lld_frame_track_local_map")
+
+    def download(self, stage2=True):
+        """One copy, one synchronisation: the records of stage 1 and (if queued) stage 2 as dicts."""
+        nt, nl = self.F.n, self.n_lines
+        outs = []
+        for _ in range(2):
+            r = TrackResult()
+            a = dict(kp_point_id=np.empty(nt, np.int32), kp_outlier=np.empty(nt, np.uint8), ln_line_id=np.empty(nl, np.int32), ln_outlier=np.empty(nl, np.uint8))
+            r.kp_point_id = a["kp_point_id"].ctypes.data_as(c_int32_p); r.kp_outlier = a["kp_outlier"].ctypes.data_as(c_uint8_p)
+            r.ln_line_id = a["ln_line_id"].ctypes.data_as(c_int32_p); r.ln_outlier = a["ln_outlier"].ctypes.data_as(c_uint8_p)
+            outs.append((r, a))
+        self._check(self.lib.fn("frame_track_download")(self.res.handle, C.byref(outs[0][0]), C.byref(outs[1][0]) if stage2 else None), "lld_frame_track_download")
+        res = []
+        for r, a in outs[:2 if stage2 else 1]:
+            d = dict(a, pose_qt=np.array(list(r.pose_qt)), chi2=float(r.chi2))
+            for c in _COUNTERS: d[c] = int(getattr(r, c))
+            res.append(d)
+        return res
+
+
+# ------------------------------------------------------------------------------------------------ flat files of examples/harness.cpp `track`
+def write_harness_scene(path, sc: dict, repeats=1, download_between=False, gamma=0.5, thr_base=2.0, md_thr=0.9):
+    """A make_tracking_scene dict as the flat binary `examples/harness track` reads (layout: run_track in examples/harness.cpp)."""
+    F = sc["frame"]; lines = sc.get("lines")
+    T = np.ascontiguousarray(sc["Tcw_guess"], np.float32).reshape(4, 4)
+    view = orb_search.frame_view(T, sc["cam"], F)
+    last, mp = sc["last"], sc["map_points"]
+    n_last, n_mp = len(sc["last_ids"]), len(sc["map_ids"])
+    nl = 0 if lines is None else np.asarray(lines["left_lines"]).reshape(-1, 4).shape[0]
+    nr = 0 if lines is None else np.asarray(lines["right_lines"]).reshape(-1, 4).shape[0]
+    dim = 1 if lines is None else np.asarray(lines["desc"]).shape[1]
+    ll, ml = (sc.get("last_lines"), sc.get("local_lines")) if lines is not None else (None, None)
+    n_ll = 0 if ll is None else len(ll["id"]); n_ml = 0 if ml is None else len(ml["id"])
+    f32 = lambda a: np.ascontiguousarray(a, np.float32); i32 = lambda a: np.ascontiguousarray(a, np.int32); u8 = lambda a: np.ascontiguousarray(a, np.uint8)
+    with open(path, "wb") as f:
+        i32([F.n, F.scale.shape[0], n_last, n_mp, nl, nr, dim, n_ll, n_ml, repeats, int(download_between), 0, 0, 0, 0, 0]).tofile(f)
+        f32([F.min_x, F.min_y, F.max_x, F.max_y, F.width_inv, F.height_inv]).tofile(f)
+        f32(F.scale).tofile(f); f32(F.inv_sigma2).tofile(f)
+        np.array([float(np.float32(c)) for c in sc["cam"]] + [gamma, thr_base, md_thr], np.float64).tofile(f)
+        np.ascontiguousarray(F.desc, np.uint32).tofile(f); f32(F.xy).tofile(f); i32(F.octave).tofile(f); f32(F.uright).tofile(f); f32(F.angle).tofile(f)
+        f.write(bytes(view)); f32(T).tofile(f)
+        obs = last.get("has_obs") if last.get("has_obs") is not None else np.ones(n_last, np.uint8)
+        f32(last["world_pos"]).tofile(f); u8(last["valid"]).tofile(f); i32(last["octave"]).tofile(f); f32(last["angle"]).tofile(f)
+        np.ascontiguousarray(last["desc"], np.uint32).tofile(f); u8(obs).tofile(f); i32(sc["last_ids"]).tofile(f)
+        mobs = mp.get("has_obs") if mp.get("has_obs") is not None else np.ones(n_mp, np.uint8)
+        f32(mp["world_pos"]).tofile(f); f32(mp["normal"]).tofile(f); f32(mp["max_distance"]).tofile(f); f32(mp["min_distance"]).tofile(f)
+        np.ascontiguousarray(mp["desc"], np.uint32).tofile(f); u8(mobs).tofile(f); u8(mp["skip"]).tofile(f); i32(sc["map_ids"]).tofile(f)
+        if lines is not None:
+            f32(lines["left_lines"]).tofile(f); i32(lines["left_octave"]).tofile(f); f32(lines["right_lines"]).tofile(f); i32(lines["right_octave"]).tofile(f)
+            i32(lines["line_matches"]).tofile(f); f32(lines["desc"]).tofile(f)
+        for L in (ll, ml):
+            if L is None or len(L["id"]) == 0: continue
+            for k in ("X0", "dir", "X1", "X2"): np.ascontiguousarray(L[k], np.float64).tofile(f)
+            u8(L["skip"] if L.get("skip") is not None else np.zeros(len(L["id"]), np.uint8)).tofile(f); f32(L["desc"]).tofile(f); i32(L["id"]).tofile(f)
+    return nl
+
+
+def read_harness_result(path, nt, nl, repeats):
+    """(record of stage 1, record of stage 2, dict of per-repeat host milliseconds) written by `examples/harness track`."""
+    recs = []
+    with open(path, "rb") as f:
+        for _ in range(2):
+            d = dict(pose_qt=np.fromfile(f, np.float64, 7), chi2=float(np.fromfile(f, np.float64, 1)[0]))
+            c = np.fromfile(f, np.int32, 12)
+            for k, v in zip(_COUNTERS, c): d[k] = int(v)
+            d["kp_point_id"] = np.fromfile(f, np.int32, nt); d["kp_outlier"] = np.fromfile(f, np.uint8, nt)
+            d["ln_line_id"] = np.fromfile(f, np.int32, nl); d["ln_outlier"] = np.fromfile(f, np.uint8, nl)
+            recs.append(d)
+        ms = dict(total=np.fromfile(f, np.float64, repeats), queue_motion_model=np.fromfile(f, np.float64, repeats), queue_local_map=np.fromfile(f, np.float64, repeats))
+    return recs[0], recs[1], ms

@@ -5,7 +5,7 @@ import re
 
 import pytest
 
-from lld_slam_amd import abi, orb_search
+from lld_slam_amd import abi, orb_search, tracking
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -39,18 +39,24 @@ def test_struct_layouts_match_the_header(tmp_path):
              ("lld_last_frame_points", orb_search.LastFramePoints), ("lld_keypoints", orb_search.Keypoints),
              ("lld_stereo_pyramids", orb_search.StereoPyramids), ("lld_stereo_result", orb_search.StereoResult),
              ("lld_sim3_problem", abi.Sim3Problem), ("lld_sim3_params", abi.Sim3Params), ("lld_sim3_result", abi.Sim3Result),
-             ("lld_pose_graph", abi.PoseGraph), ("lld_pose_graph_params", abi.PoseGraphParams), ("lld_pose_graph_result", abi.PoseGraphResult)]
+             ("lld_pose_graph", abi.PoseGraph), ("lld_pose_graph_params", abi.PoseGraphParams), ("lld_pose_graph_result", abi.PoseGraphResult),
+             ("lld_frame_lines", tracking.FrameLines), ("lld_map_lines", tracking.MapLines), ("lld_track_params", tracking.TrackParams),
+             ("lld_track_result", tracking.TrackResult)]
     src = tmp_path / "sz.c"
     body = "".join(f'printf("%zu\\n", sizeof({n}));' for n, _ in names)
     # field offsets of the widest struct too: equal sizes alone would not catch two swapped members
     probes = ["t_occupied", "q_valid", "q_epiline", "cand_range", "n_cand", "grid_min_x", "n_levels", "disp_min", "only_stereo",
               "candidates", "nnratio", "check_orientation"]
     body += "".join(f'printf("%zu\\n", offsetof(lld_orb_search, {f}));' for f in probes)
+    tprobes = [("lld_track_params", tracking.TrackParams, f) for f in ("pose", "th_motion", "direction", "line_thr_reproj_base", "line_use_grid")] + \
+              [("lld_track_result", tracking.TrackResult, f) for f in ("chi2", "n_search_first", "n_discarded", "kp_point_id", "ln_outlier")] + \
+              [("lld_frame_lines", tracking.FrameLines, f) for f in ("right_octave", "line_matches", "dim", "sx")]
+    body += "".join(f'printf("%zu\\n", offsetof({n}, {f}));' for n, _, f in tprobes)
     src.write_text(f'#include <stdio.h>\n#include <stddef.h>\n#include "{ROOT}/include/lld_amd.h"\nint main(void){{{body}return 0;}}\n')
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", str(src), "-o", str(exe)])   # the header is plain C
     sizes = [int(x) for x in subprocess.check_output([str(exe)]).split()]
-    assert sizes == [ctypes.sizeof(c) for _, c in names] + [getattr(orb_search.OrbSearch, f).offset for f in probes]
+    assert sizes == [ctypes.sizeof(c) for _, c in names] + [getattr(orb_search.OrbSearch, f).offset for f in probes] + [getattr(c, f).offset for _, c, f in tprobes]
 
 
 def test_host_helpers_agree_with_oracle_without_a_gpu(oracle):

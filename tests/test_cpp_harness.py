@@ -290,3 +290,27 @@ def test_harness_relocalisation_and_loop_closing_matchers(harness, tmp_path):
     np.testing.assert_array_equal(m12, exp)
     assert counts[3] == int((exp >= 0).sum())
 
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("between", [False, True])
+def test_harness_tracking_chain(harness, tmp_path, oracle, between):
+    """`harness track`: the Tracking thread's per-frame chain (TrackWithMotionModel + TrackLocalMap, lines included) driven from compiled
+    C++ through lld_amd::TrackedFrame, several repeats on one handle - against the oracle's own run of the sequence; with and without the
+    host fetching stage 1's record between the two calls."""
+    import oracle_tracking as OT
+    from lld_slam_amd import synth, tracking
+    sc = synth.make_tracking_scene(8)
+    repeats = 3
+    nl = tracking.write_harness_scene(tmp_path / "in.bin", sc, repeats=repeats, download_between=between)
+    p = run(harness, "track", tmp_path)
+    assert p.returncode == 0, p.stderr
+    g1, g2, ms = tracking.read_harness_result(tmp_path / "out.bin", sc["frame"].n, nl, repeats)
+    e1, e2 = OT.track_frame(sc)
+    for g, e in ((g1, e1), (g2, e2)):
+        for k in ("kp_point_id", "kp_outlier", "ln_line_id", "ln_outlier"):
+            np.testing.assert_array_equal(g[k], e[k], err_msg=k)
+        for k in ("n_inliers", "n_edges", "n_search_first", "n_search", "used_wide", "n_points", "n_points_map", "n_lines_matched", "n_lines", "n_discarded"):
+            assert g[k] == e[k], k
+        np.testing.assert_allclose(g["pose_qt"], e["pose_qt"], rtol=1e-5, atol=1e-8)
+    assert ms["total"].shape == (repeats,) and np.all(ms["total"] > 0)

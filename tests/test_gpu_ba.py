@@ -547,6 +547,26 @@ def test_product_build_reads_no_experiment_knob(gpu_ctx, monkeypatch):
     Optimizer(gpu_ctx).LocalBundleAdjustment(w, deterministic=1)
 
 
+def test_solve_error_contract(exp_ctx, oracle, monkeypatch):
+    """A failure INSIDE lld_ba_batch_solve (LLD_BA_FAIL_AT_SUPERSTEP, a knob of the experiments build, makes the n-th super-step launch
+    return LLD_ERR_UNSUPPORTED the way an inexpressible grid does - with the other stream groups' kernels in flight): the status comes back
+    only after every group stream has drained, the batch refuses solve / download / stats from then on (its device state is mid-trial), it
+    can be destroyed, and the SAME context solves a fresh batch of the same windows to the usual bar."""
+    ws = [synth.make_lba_small(200 + i, n_free=4 + i % 5, n_fixed=1 + i % 2, n_points=150 + 20 * i, n_lines=20 + 3 * i) for i in range(40)]
+    for fail_at in (0, 3, 9):                                       # first launch; another group's first; well inside the solve
+        with BABatch(exp_ctx, ws) as b:
+            monkeypatch.setenv("LLD_BA_FAIL_AT_SUPERSTEP", str(fail_at))
+            try:
+                with pytest.raises(RuntimeError, match="UNSUPPORTED|unsupported|-5"): b.solve()
+            finally: monkeypatch.delenv("LLD_BA_FAIL_AT_SUPERSTEP")
+            with pytest.raises(RuntimeError): b.solve()            # no knob now: the batch itself is refused
+            with pytest.raises(RuntimeError): b.download(0)
+            with pytest.raises(RuntimeError): b.download_all()
+    with BABatch(exp_ctx, ws) as b:
+        b.solve()
+        for i in (0, 17, 39): check_ba(b.download(i), oracle.local_ba(ws[i]), ws[i], twins=oracle_twins(oracle, ws[i]))
+
+
 # ---------------------------------------------------------------------------------------------------------------- deterministic mode
 def _same_bits(a, b):
     for f in ("cam_qt", "pt_xyz", "line_x0", "line_dir", "pt_obs_outlier", "ln_edge_outlier", "line_removed"):

@@ -1,0 +1,156 @@
+"""lld_frame_track_*: the Tracking thread's per-frame chain as one device-resident sequence, lines included (src/Tracking.cc:885-994 and
+:1126-1220), against the oracle's OWN run of the whole sequence (oracle/oracle_tracking.py: nothing of the device chain's intermediate
+state is handed to the checker).  Per stage: the MapPoint / MapLine id of every keypoint / line and every outlier flag bit-exact, every
+counter equal, pose and chi2 to 1e-5 relative (north_star's bar), LM iteration / trial counts equal."""
+import numpy as np
+import pytest
+
+import oracle_tracking as OT
+from lld_slam_amd import synth
+from lld_slam_amd.tracking import DeviceTrackedFrame, TrackedFrame
+
+pytestmark = pytest.mark.gpu
+
+COUNTERS = ("n_inliers", "n_edges", "n_search_first", "n_search", "used_wide", "n_points", "n_points_map", "n_lines_matched", "n_lines", "n_discarded")
+POSE_RTOL = 1e-5            # north_star: final pose within 1e-5 relative
+LM_IT_SLACK, LM_TRIAL_SLACK = 1, 3      # LM iterations / trials of a stage against the oracle's (a trial whose gain ratio is zero to rounding flips); the differences
+LM_LOG = []                             # actually seen go to gpurun_out/track_chain_lm_counts.txt (profiles/r06_parity_margins.txt)
+
+
+def run_device(gpu_ctx, sc, download_between=False, **params):
+    with DeviceTrackedFrame(gpu_ctx, sc["frame"], sc["cam"], sc.get("lines"), **params) as tf:
+        tf.track_with_motion_model(sc["Tcw_guess"], sc["last"], sc["last_ids"], sc.get("last_lines"))
+        first = tf.download(stage2=False)[0] if download_between else None
+        tf.track_local_map(sc["map_points"], sc["map_ids"], sc.get("local_lines"))
+        r1, r2 = tf.download()
+        if first is not None:
+            same_record(first, r1, exact_pose=True)
+        return r1, r2
+
+
+def same_record(g, e, exact_pose=False):
+    for k in ("kp_point_id", "kp_outlier", "ln_line_id", "ln_outlier"):
+        np.testing.assert_array_equal(g[k], e[k], err_msg=k)
+    for k in COUNTERS:
+        assert g[k] == e[k], (k, g[k], e[k])
+    if exact_pose:
+        np.testing.assert_array_equal(g["pose_qt"], e["pose_qt"]); assert g["chi2"] == e["chi2"]
+    else:
+        np.testing.assert_allclose(g["pose_qt"], e["pose_qt"], rtol=POSE_RTOL, atol=1e-8)
+        assert abs(g["chi2"] - e["chi2"]) <= POSE_RTOL * max(abs(e["chi2"]), 1e-12)
+    if exact_pose:
+        assert g["lm_iterations"] == e["lm_iterations"] and g["lm_trials"] == e["lm_trials"]
+        return
+    LM_LOG.append((g["lm_iterations"] - e["lm_iterations"], g["lm_trials"] - e["lm_trials"]))
+    assert abs(g["lm_iterations"] - e["lm_iterations"]) <= LM_IT_SLACK and abs(g["lm_trials"] - e["lm_trials"]) <= LM_TRIAL_SLACK, \
+        (g["lm_iterations"], e["lm_iterations"], g["lm_trials"], e["lm_trials"])
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _lm_count_log():
+    yield
+    import os
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/track_chain_lm_counts.txt", "w") as f:
+        f.write("# tests/test_gpu_track_chain.py: device minus oracle, per compared stage record: LM iterations, LM trials\n")
+        for a, b in LM_LOG: f.write(f"{a:+d} {b:+d}\n")
+        if LM_LOG:
+            f.write(f"# records {len(LM_LOG)}, max |iterations| {max(abs(a) for a, _ in LM_LOG)}, max |trials| {max(abs(b) for _, b in LM_LOG)}, "
+                    f"records with any difference {sum(1 for a, b in LM_LOG if a or b)}\n")
+
+
+@pytest.mark.parametrize("scene", [0, 1, 2, 3])
+def test_chain_against_the_oracles_own_sequence(gpu_ctx, oracle, scene):
+    sc = synth.make_tracking_scene(scene)
+    g1, g2 = run_device(gpu_ctx, sc, download_between=(scene == 1))
+    e1, e2 = OT.track_frame(sc)
+    same_record(g1, e1); same_record(g2, e2)
+    # the scene exercises what it is meant to: matches in both stages, lines in both stages, a discard the local map must not undo
+    assert e1["n_search"] > 300 and e2["n_search"] > 100 and e1["n_lines_matched"] > 10 and e2["n_lines_matched"] > e1["n_lines"]
+    assert e1["n_discarded"] >= 1
+    discarded = e1["kp_point_id"][e1["kp_outlier"] != 0]
+    assert np.all(np.isin(discarded, sc["map_ids"]))                    # ... and those MapPoints ARE among the local map's (mnLastFrameSeen, :949 / :1640)
+    assert not np.any(np.isin(discarded, g2["kp_point_id"]))
+    err0 = np.linalg.norm(np.asarray(sc["pose_guess"])[4:] - np.asarray(sc["pose_true"])[4:])
+    assert np.linalg.norm(g2["pose_qt"][4:] - np.asarray(sc["pose_true"])[4:]) < 0.1 * err0
+
+
+def test_outlier_lines_leave_the_frame(gpu_ctx, oracle):
+    """Scenes whose trap lines (observed where the PREDICTED pose projects them) are matched by AddLinesFrom and thrown out by PoseOptimization."""
+    seen = 0
+    for scene in (2, 3, 5, 7):
+        sc = synth.make_tracking_scene(scene)
+        g1, g2 = run_device(gpu_ctx, sc)
+        e1, e2 = OT.track_frame(sc)
+        same_record(g1, e1); same_record(g2, e2)
+        seen += int(e1["ln_outlier"].sum())
+        gone = e1["ln_line_id"][e1["ln_outlier"] != 0]
+        assert not np.any(np.isin(gone, g2["ln_line_id"]))              # tracked_last_id keeps them out of TrackLocalMap's AddLinesFrom (:1023)
+    assert seen >= 3
+
+
+def test_wide_retry_is_decided_on_the_device(gpu_ctx, oracle):
+    """A prediction so far off that SearchByProjection(th) finds fewer than 20 matches: the 2*th search runs (src/Tracking.cc:907-911)."""
+    hit = 0
+    for scene, rot, trans in ((10, 2.0, 1.0), (12, 3.0, 1.5), (14, 2.2, 0.6)):
+        sc = synth.make_tracking_scene(scene, rot_deg=rot, trans=trans)
+        g1, g2 = run_device(gpu_ctx, sc)
+        e1, e2 = OT.track_frame(sc)
+        same_record(g1, e1); same_record(g2, e2)
+        hit += e1["used_wide"]
+        n1, n2 = run_device(gpu_ctx, sc, wide_retry=0)
+        f1, f2 = OT.track_frame(sc, wide_retry=False)
+        same_record(n1, f1); same_record(n2, f2)
+        assert n1["used_wide"] == 0
+    assert hit >= 2
+
+
+@pytest.mark.parametrize("case", ["no_lines", "no_last_points", "few_points", "no_map", "mono"])
+def test_chain_edge_cases(gpu_ctx, oracle, case):
+    sc = synth.make_tracking_scene(20, n_kp=600, n_map=700, n_last=300)
+    if case == "no_lines":
+        sc = synth.make_tracking_scene(21, n_lines=0)
+        assert "lines" not in sc
+    elif case == "no_last_points":                                       # PoseOptimization returns before optimising: the predicted pose stays (Optimizer.cc:809)
+        sc["last"] = {k: v[:0] for k, v in sc["last"].items()}; sc["last_ids"] = sc["last_ids"][:0]
+    elif case == "few_points":                                           # fewer than 10 edges: the line classification is never reached (:878)
+        sc["last"] = {k: v[:4] for k, v in sc["last"].items()}; sc["last_ids"] = sc["last_ids"][:4]
+        sc["last_lines"] = {k: v[:2] for k, v in sc["last_lines"].items()}
+    elif case == "no_map":
+        sc["map_points"] = {k: (v[:0] if k != "occupied" else v) for k, v in sc["map_points"].items()}; sc["map_ids"] = sc["map_ids"][:0]
+        sc["local_lines"] = {k: v[:0] for k, v in sc["local_lines"].items()}
+    elif case == "mono":                                                 # a frame without stereo partners: monocular point edges, left-only line edges
+        F = sc["frame"]; F.uright = np.full_like(F.uright, -1.0)
+        sc["lines"]["line_matches"] = np.full_like(sc["lines"]["line_matches"], -1)
+    g1, g2 = run_device(gpu_ctx, sc)
+    e1, e2 = OT.track_frame(sc)
+    same_record(g1, e1); same_record(g2, e2)
+
+
+def test_chain_equals_the_call_by_call_mirror_on_points(gpu_ctx):
+    """Without lines the chain must hold the MapPoints the four separate calls of round 5 (lld_slam_amd/tracking.py TrackedFrame, matches
+    through the host between the stages) end up with - same ids on the same keypoints, poses equal to rounding."""
+    sc = synth.make_tracking_scene(4, n_lines=0)
+    g1, g2 = run_device(gpu_ctx, sc)
+    with TrackedFrame(gpu_ctx, sc["frame"], sc["cam"], resident=True) as tf:
+        p1 = tf.track_with_motion_model(sc["pose_guess"], sc["last"], sc["last_ids"], th=7.0)
+        after1 = tf.kp_point.copy()
+        p2 = tf.track_local_map(p1, sc["map_points"], sc["map_ids"], th=1.0)
+        after2 = tf.kp_point.copy()
+    kept1 = np.where(g1["kp_outlier"] != 0, -1, g1["kp_point_id"]); kept2 = np.where(g2["kp_outlier"] != 0, -1, g2["kp_point_id"])
+    np.testing.assert_array_equal(kept1, after1); np.testing.assert_array_equal(kept2, after2)
+    np.testing.assert_allclose(g1["pose_qt"], p1, rtol=1e-9, atol=1e-12); np.testing.assert_allclose(g2["pose_qt"], p2, rtol=1e-7, atol=1e-10)
+
+
+def test_handle_is_reusable_and_repeatable(gpu_ctx):
+    """The same handle tracks the same inputs twice (bit-identical records), and a second scene after it."""
+    sc = synth.make_tracking_scene(6)
+    with DeviceTrackedFrame(gpu_ctx, sc["frame"], sc["cam"], sc["lines"]) as tf:
+        recs = []
+        for _ in range(2):
+            tf.track_with_motion_model(sc["Tcw_guess"], sc["last"], sc["last_ids"], sc["last_lines"])
+            tf.track_local_map(sc["map_points"], sc["map_ids"], sc["local_lines"])
+            recs.append(tf.download())
+        for a, b in zip(recs[0], recs[1]):
+            same_record(a, b, exact_pose=True)
+            assert a["lm_trials"] == b["lm_trials"]
