@@ -135,69 +135,100 @@ __global__ __launch_bounds__(1024) void track_after_pose_kernel(TrackDev D, View
   const int tid = threadIdx.x;
   if (tid < 8) cnt[tid] = 0;
   __syncthreads();
-  int n_pts = 0, n_map = 0, n_disc = 0, n_lm = 0, n_ln = 0;
-  for (int k = tid; k < D.nt; k += blockDim.x) {
-    const bool has = D.kp_has[k] != 0;
-    const uint8_t bad = has ? D.kp_outlier[k] : 0;
-    D.rec_kp_id[stage][k] = has ? D.kp_id[k] : -1;
-    D.rec_kp_out[stage][k] = bad;
-    if (!has) continue;
-    if (bad) {
-      if (stage == 0) { const int at = atomicAdd(D.n_discard, 1); D.discard[at] = D.kp_id[k]; D.kp_outlier[k] = 0; }
-      D.kp_has[k] = 0; D.kp_id[k] = -1;
-      n_disc++;
-    } else { n_pts++; if (D.kp_obs[k]) n_map++; }
-  }
-  for (int i = tid; i < D.nl; i += blockDim.x) {
-    const bool has = D.ln_has[i] != 0;
-    D.rec_ln_id[stage][i] = has ? D.ln_id[i] : -1;
-    D.rec_ln_out[stage][i] = has ? D.ln_outlier[i] : 0;
-    if (!has) continue;
-    n_lm++;
-    if (D.ln_outlier[i]) { D.ln_has[i] = 0; D.ln_id[i] = -1; } else n_ln++;
-  }
-  atomicAdd(&cnt[0], n_pts); atomicAdd(&cnt[1], n_map); atomicAdd(&cnt[2], n_disc); atomicAdd(&cnt[3], n_lm); atomicAdd(&cnt[4], n_ln);
-  __syncthreads();
-  if (tid == 0) {
+  // the last wavefront's first lane turns the optimised pose into the frame's float view while the other fifteen walk the keypoints and lines
+  // (a chain of ~500 dependent fp64 instructions behind one global load: it would otherwise follow the walk's own chain of loads)
+  constexpr int kWalk = 960;
+  if (tid == kWalk) {
+    const int* pi = reinterpret_cast<const int*>(D.pose_out + 8);
     RecHeader& H = *D.rec_h[stage];
     for (int c = 0; c < 7; c++) H.pose_qt[c] = D.pose_out[c];
     H.chi2 = D.pose_out[7];
-    const int* pi = reinterpret_cast<const int*>(D.pose_out + 8);
     H.i[RI_INL] = pi[0]; H.i[RI_ITS] = pi[1]; H.i[RI_TRIALS] = pi[2]; H.i[RI_EDGES] = pi[3];
-    H.i[RI_POINTS] = cnt[0]; H.i[RI_POINTS_MAP] = cnt[1]; H.i[RI_DISCARDED] = cnt[2]; H.i[RI_LINES_MATCHED] = cnt[3]; H.i[RI_LINES] = cnt[4];
     // pFrame->SetPose(pose) - unless PoseOptimization returned before it optimised (fewer than three points, Optimizer.cc:809-810)
     if (pi[4] >= 3) view_from_pose(D.pose_out, C, D.view, D.line_params, D.pose_qt);
+  }
+  int n_pts = 0, n_map = 0, n_disc = 0, n_lm = 0, n_ln = 0;
+  for (int k0 = 0; k0 < D.nt && tid < kWalk; k0 += 2 * kWalk) {
+    // two keypoints per lane, every load issued before the first use
+    const int ka = k0 + tid, kb = ka + kWalk;
+    const bool ina = ka < D.nt, inb = kb < D.nt;
+    const int kca = ina ? ka : 0, kcb = inb ? kb : 0;
+    const uint8_t ha = D.kp_has[kca], hb = D.kp_has[kcb], oa = D.kp_outlier[kca], ob = D.kp_outlier[kcb], va = D.kp_obs[kca], vb = D.kp_obs[kcb];
+    const int32_t ia = D.kp_id[kca], ib = D.kp_id[kcb];
+    auto one = [&](int k, bool in, uint8_t has_, uint8_t out_, uint8_t obs_, int32_t id_) {
+      if (!in) return;
+      const bool has = has_ != 0;
+      const uint8_t bad = has ? out_ : 0;
+      D.rec_kp_id[stage][k] = has ? id_ : -1;
+      D.rec_kp_out[stage][k] = bad;
+      if (!has) return;
+      if (bad) {
+        if (stage == 0) { const int at = atomicAdd(D.n_discard, 1); D.discard[at] = id_; D.kp_outlier[k] = 0; }
+        D.kp_has[k] = 0; D.kp_id[k] = -1;
+        n_disc++;
+      } else { n_pts++; if (obs_) n_map++; }
+    };
+    one(ka, ina, ha, oa, va, ia); one(kb, inb, hb, ob, vb, ib);
+  }
+  for (int i = tid; i < D.nl && tid < kWalk; i += kWalk) {
+    const uint8_t has_ = D.ln_has[i], out_ = D.ln_outlier[i]; const int32_t id_ = D.ln_id[i];
+    const bool has = has_ != 0;
+    D.rec_ln_id[stage][i] = has ? id_ : -1;
+    D.rec_ln_out[stage][i] = has ? out_ : 0;
+    if (!has) continue;
+    n_lm++;
+    if (out_) { D.ln_has[i] = 0; D.ln_id[i] = -1; } else n_ln++;
+  }
+  // wavefront sums first: five LDS atomics per wavefront instead of per lane
+  for (int off = 32; off > 0; off >>= 1) {
+    n_pts += __shfl_xor(n_pts, off); n_map += __shfl_xor(n_map, off); n_disc += __shfl_xor(n_disc, off); n_lm += __shfl_xor(n_lm, off); n_ln += __shfl_xor(n_ln, off);
+  }
+  if ((tid & 63) == 0) { atomicAdd(&cnt[0], n_pts); atomicAdd(&cnt[1], n_map); atomicAdd(&cnt[2], n_disc); atomicAdd(&cnt[3], n_lm); atomicAdd(&cnt[4], n_ln); }
+  __syncthreads();
+  if (tid == 0) {
+    RecHeader& H = *D.rec_h[stage];
+    H.i[RI_POINTS] = cnt[0]; H.i[RI_POINTS_MAP] = cnt[1]; H.i[RI_DISCARDED] = cnt[2]; H.i[RI_LINES_MATCHED] = cnt[3]; H.i[RI_LINES] = cnt[4];
   }
 }
 
 // SearchLocalPoints' "already seen in this frame" (src/Tracking.cc:1616-1643): pMP->mnLastFrameSeen == mCurrentFrame.mnId holds for the
-// MapPoints the frame holds (:1629) and for those the outlier discard marked (:949).  Ids are the caller's; the set is staged in LDS and
-// every local MapPoint looks its id up.  Lines: tracked_last_id == mnId (:1023) against the list of lines assigned so far.
-__global__ __launch_bounds__(256) void track_mark_seen_kernel(TrackDev D, int n_mp, const int32_t* mp_id, const uint8_t* mp_skip, uint8_t* mp_skip_out,
-                                                             int n_ml, const int32_t* ml_id, const uint8_t* ml_skip, uint8_t* ml_skip_out) {
-  extern __shared__ int32_t ids[];                   // [nt + n_discard] point ids, then [n_tracked] line ids
-  const int tid = threadIdx.x;
-  const int nd = *D.n_discard, ntr = min(*D.n_tracked, D.tracked_cap);
-  for (int k = tid; k < D.nt; k += blockDim.x) ids[k] = D.kp_has[k] ? D.kp_id[k] : -1;
-  for (int k = tid; k < nd; k += blockDim.x) ids[D.nt + k] = D.discard[k];
-  int32_t* lids = ids + D.nt + D.nt;
-  for (int k = tid; k < ntr; k += blockDim.x) lids[k] = D.tracked[k];
-  __syncthreads();
-  const int n_pid = D.nt + nd;
-  for (int q = blockIdx.x * blockDim.x + tid; q < n_mp + n_ml; q += gridDim.x * blockDim.x) {
-    if (q < n_mp) {
-      const int32_t id = mp_id[q];
-      bool seen = mp_skip && mp_skip[q];
-      if (!seen) for (int k = 0; k < n_pid; k++) seen |= ids[k] == id;
-      mp_skip_out[q] = seen ? 1 : 0;
-    } else {
-      const int j = q - n_mp;
-      const int32_t id = ml_id[j];
-      bool seen = ml_skip && ml_skip[j];
-      if (!seen) for (int k = 0; k < ntr; k++) seen |= lids[k] == id;
-      ml_skip_out[j] = seen ? 1 : 0;
-    }
+// MapPoints the frame holds (:1629) and for those the outlier discard marked (:949).  Ids are the caller's (>= 0).  Lines: tracked_last_id ==
+// mnId (:1023) against the list of lines assigned so far.
+constexpr int kSeenThreads = 1024;
+__device__ __forceinline__ unsigned seen_hash(int32_t id, unsigned mask) { return ((unsigned)id * 2654435761u >> 7) & mask; }
+__device__ __forceinline__ void seen_insert(int32_t* tab, unsigned mask, int32_t id) {
+  unsigned h = seen_hash(id, mask);
+  for (;;) {
+    const int32_t old = atomicCAS(&tab[h], -1, id);
+    if (old == -1 || old == id) return;
+    h = (h + 1) & mask;
   }
+}
+__device__ __forceinline__ bool seen_lookup(const int32_t* tab, unsigned mask, int32_t id) {
+  unsigned h = seen_hash(id, mask);
+  for (;;) {
+    const int32_t v = tab[h];
+    if (v == id) return true;
+    if (v == -1) return false;
+    h = (h + 1) & mask;
+  }
+}
+// One workgroup: the ids the frame holds or discarded (and the lines it tracked) go into two open-addressing hash sets in LDS (at most half
+// full: ids >= 0, -1 = empty), then every local MapPoint / MapLine probes its id.
+__global__ __launch_bounds__(kSeenThreads) void track_mark_seen_kernel(TrackDev D, int n_mp, const int32_t* mp_id, const uint8_t* mp_skip, uint8_t* mp_skip_out,
+                                                                      int n_ml, const int32_t* ml_id, const uint8_t* ml_skip, uint8_t* ml_skip_out, unsigned pmask, unsigned lmask) {
+  extern __shared__ int32_t seen_tab[];              // [pmask + 1] point ids, then [lmask + 1] line ids
+  int32_t* ptab = seen_tab; int32_t* ltab = seen_tab + pmask + 1;
+  const int tid = threadIdx.x;
+  for (unsigned k = tid; k < pmask + 1 + lmask + 1; k += kSeenThreads) seen_tab[k] = -1;
+  const int nd = *D.n_discard, ntr = min(*D.n_tracked, D.tracked_cap);
+  __syncthreads();
+  for (int k = tid; k < D.nt; k += kSeenThreads) if (D.kp_has[k]) seen_insert(ptab, pmask, D.kp_id[k]);
+  for (int k = tid; k < nd; k += kSeenThreads) seen_insert(ptab, pmask, D.discard[k]);
+  for (int k = tid; k < ntr; k += kSeenThreads) seen_insert(ltab, lmask, D.tracked[k]);
+  __syncthreads();
+  for (int q = tid; q < n_mp; q += kSeenThreads) mp_skip_out[q] = ((mp_skip && mp_skip[q]) || seen_lookup(ptab, pmask, mp_id[q])) ? 1 : 0;
+  for (int j = tid; j < n_ml; j += kSeenThreads) ml_skip_out[j] = ((ml_skip && ml_skip[j]) || seen_lookup(ltab, lmask, ml_id[j])) ? 1 : 0;
 }
 
 __global__ void track_fill_i32_kernel(int32_t* p, int n, int32_t v) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = v; }
@@ -536,14 +567,15 @@ int lld_frame_track_local_map(lld_frame* f, const lld_track_params* P, const lld
   LLD_HIP_TRY(hipEventRecord(S->uploaded[1], st)); S->upload_pending[1] = true;
   // ---- kernels
   {
-    const int total = nq + n_map;
-    const size_t lds = ((size_t)2 * nt + (size_t)S->D.tracked_cap) * 4 + 16;
+    auto pow2 = [](unsigned n) { unsigned p = 64; while (p < n) p <<= 1; return p; };
+    const unsigned psize = pow2(4u * (unsigned)std::max(nt, 1)), lsize = pow2(2u * (unsigned)S->D.tracked_cap);     // held + discarded <= 2 nt ids: at most half full
+    const size_t lds = ((size_t)psize + lsize) * 4;
     if (lds > 150 * 1024) return LLD_ERR_UNSUPPORTED;
     if (lds > 48 * 1024) LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&track_mark_seen_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    if (total > 0)
-      hipLaunchKernelGGL(track_mark_seen_kernel, dim3(std::min(64, (total + 255) / 256)), dim3(256), lds, st, S->D, nq, reinterpret_cast<const int32_t*>(d + o_id),
+    if (nq + n_map > 0)
+      hipLaunchKernelGGL(track_mark_seen_kernel, dim3(1), dim3(kSeenThreads), lds, st, S->D, nq, reinterpret_cast<const int32_t*>(d + o_id),
                          reinterpret_cast<const uint8_t*>(d + o_skip), reinterpret_cast<uint8_t*>(d + o_skip2), n_map, reinterpret_cast<const int32_t*>(d + U.id),
-                         reinterpret_cast<const uint8_t*>(d + U.skip), reinterpret_cast<uint8_t*>(d + o_lskip2));
+                         reinterpret_cast<const uint8_t*>(d + U.skip), reinterpret_cast<uint8_t*>(d + o_lskip2), psize - 1, lsize - 1);
   }
   const MapPointsDev MP{nq, reinterpret_cast<const float*>(d + o_pos), reinterpret_cast<const float*>(d + o_nrm), reinterpret_cast<const float*>(d + o_maxd),
                         reinterpret_cast<const float*>(d + o_mind), reinterpret_cast<const uint8_t*>(d + o_obs), reinterpret_cast<const uint8_t*>(d + o_skip2)};

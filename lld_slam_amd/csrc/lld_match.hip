@@ -247,8 +247,7 @@ __global__ __launch_bounds__(64) void l2f32_best2_row_kernel(const float* __rest
 // (strict '<' while scanning in index order = lexicographic (distance, index) minimum).  Only `taken` is order dependent, so:
 //   line_candidates_kernel  one wavefront per LEFT line: gates + float-L2 distances of its row, then the row's kLineTopK smallest
 //                           (distance, index) candidates by repeated wavefront argmin - all left lines in parallel;
-//   line_resolve_kernel     one wavefront walks the left lines in order and takes the first untaken entry of each short list
-//                           (LDS only); a list that is full and completely taken falls back to a scan of the stored row.
+//   line_resolve_kernel     the order-dependent assignment by fixed-point rounds over all left lines at once (see there).
 constexpr int kLineTopK = 8;
 struct LineCand { double d[kLineTopK]; int idx[kLineTopK]; int n, pad; };
 constexpr double kInfD = 1.7976931348623157e308;
@@ -400,56 +399,64 @@ __global__ __launch_bounds__(64) void line_candidates_kernel(LineGateParams P, c
   if (lane == 0) { cand[j].n = n; cand[j].pad = 0; }
 }
 
-// one wavefront; LDS: taken[nt] bytes (dynamic) + a chunk of candidate lists (static)
-constexpr int kResolveChunk = 256;
-__global__ __launch_bounds__(64) void line_resolve_kernel(const LineCand* __restrict__ cand, const double* __restrict__ dmat, const uint8_t* __restrict__ gate,
-                                                         int nq, int nt, double tau, int* __restrict__ matches, double* __restrict__ match_dist) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char taken[];
-  __shared__ LineCand chunk[kResolveChunk];
-  const int lane = threadIdx.x;
-  for (int i = lane; i < nt; i += 64) taken[i] = 0;
-  for (int j0 = 0; j0 < nq; j0 += kResolveChunk) {
-    const int nj = min(kResolveChunk, nq - j0);
-    __syncthreads();
-    {
-      const int words = nj * (int)(sizeof(LineCand) / 4);
-      const int* src = reinterpret_cast<const int*>(cand + j0); int* dst = reinterpret_cast<int*>(chunk);
-      for (int i = lane; i < words; i += 64) dst[i] = src[i];
-    }
-    __syncthreads();
-    for (int jj = 0; jj < nj; jj++) {
-      const int j = j0 + jj;
-      const LineCand& C = chunk[jj];
-      const int my_i = lane < kLineTopK ? C.idx[lane] : -1;
-      const bool free_ = lane < C.n && !taken[my_i];
-      const unsigned long long mask = __ballot(free_);
-      int bi = -1; double bd = kInfD;
-      if (mask) {
-        const int w = __ffsll((long long)mask) - 1;
-        bi = C.idx[w]; bd = C.d[w];
-      } else if (C.n == kLineTopK) {
-        // every listed candidate is taken and the list was cut: scan the stored row like the reference does
-        double sd = kInfD; int si = 0x7fffffff;
-        for (int oi = lane; oi < nt; oi += 64) {
-          if (taken[oi]) continue;
+// The greedy, order-dependent assignment ("left line j takes its best right line that no EARLIER left line took") by fixed-point rounds, as
+// the guided ORB search resolves its occupancy (lld_orb_search.hip): a round lets every line pick, in parallel, the first entry of its short
+// list that no line with a smaller index picked in the round before; blk[c] = the smallest index that picks c.  Line 0 is final after one
+// round, line j after j + 1 at the latest, and a round that changes nothing has reached the sequential answer - in practice 3 to 6 rounds of
+// a few hundred cycles, where the one-wavefront walk of rounds 2 - 5 paid ~400 cycles per LINE (45 us for 260 map lines).  A list that is
+// full and completely taken falls back to a scan of the stored row like the reference does.  One workgroup; LDS: blk[nt] + pick[nq] ints.
+constexpr int kResolveThreads = 256;
+inline size_t line_resolve_lds(int nq, int nt) { return ((size_t)nq + (size_t)nt) * 4 + 16; }
+static int line_resolve_prepare(int nq, int nt);      // raises the kernel's dynamic-LDS ceiling when blk + pick need more than the default (defined after the kernel)
+__global__ __launch_bounds__(kResolveThreads) void line_resolve_kernel(const LineCand* __restrict__ cand, const double* __restrict__ dmat, const uint8_t* __restrict__ gate,
+                                                                      int nq, int nt, double tau, int* __restrict__ matches, double* __restrict__ match_dist) {
+  extern __shared__ __attribute__((aligned(16))) int res_lds[];
+  __shared__ int changed;
+  int* blk = res_lds; int* pick = res_lds + nt;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < nt; i += kResolveThreads) blk[i] = 0x7fffffff;
+  for (int j = tid; j < nq; j += kResolveThreads) pick[j] = -1;
+  if (tid == 0) changed = 0;
+  __syncthreads();
+  for (;;) {
+    for (int j = tid; j < nq; j += kResolveThreads) {
+      const LineCand& C = cand[j];
+      const int n = C.n;
+      int bi = -1;
+      for (int k = 0; k < n; k++) { const int c = C.idx[k]; if (blk[c] >= j) { bi = c; break; } }
+      if (bi < 0 && n == kLineTopK) {
+        // every listed candidate is taken and the list was cut: the row as the reference scans it (strict '<' in index order)
+        double sd = kInfD;
+        for (int oi = 0; oi < nt; oi++) {
+          if (blk[oi] < j) continue;
           if (gate && !gate[(size_t)j * nt + oi]) continue;
           const double d = dmat[(size_t)j * nt + oi];
-          if (d < tau && d < sd) { sd = d; si = oi; }
+          if (d < tau && d < sd) { sd = d; bi = oi; }
         }
-        for (int off = 32; off > 0; off >>= 1) {
-          const double od = __shfl_xor(sd, off); const int oidx = __shfl_xor(si, off);
-          if (od < sd || (od == sd && oidx < si)) { sd = od; si = oidx; }
-        }
-        if (si != 0x7fffffff) { bi = si; bd = sd; }
       }
-      if (lane == 0) {
-        matches[j] = bi;
-        if (match_dist) match_dist[j] = bi >= 0 ? bd : kInfD;
-        if (bi >= 0) taken[bi] = 1;
-      }
-      __syncthreads();                                               // one wavefront: orders the LDS write before the next reads
+      if (bi != pick[j]) { pick[j] = bi; changed = 1; }
     }
+    __syncthreads();
+    const int any = changed;
+    if (!any) break;
+    for (int i = tid; i < nt; i += kResolveThreads) blk[i] = 0x7fffffff;
+    __syncthreads();
+    for (int j = tid; j < nq; j += kResolveThreads) { const int c = pick[j]; if (c >= 0) atomicMin(&blk[c], j); }
+    if (tid == 0) changed = 0;
+    __syncthreads();
   }
+  for (int j = tid; j < nq; j += kResolveThreads) {
+    const int bi = pick[j];
+    matches[j] = bi;
+    if (match_dist) match_dist[j] = bi >= 0 ? dmat[(size_t)j * nt + bi] : kInfD;
+  }
+}
+
+static int line_resolve_prepare(int nq, int nt) {
+  const size_t lds = line_resolve_lds(nq, nt);
+  if (lds > 150 * 1024) return LLD_ERR_UNSUPPORTED;                          // (about 38 000 lines on both sides together)
+  if (lds > 48 * 1024) LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&line_resolve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  return LLD_OK;
 }
 
 // ------------------------------------------------------------------ Tracking::AddLinesFrom (src/Tracking.cc:996-1124)
@@ -912,7 +919,7 @@ static int line_match_core(lld_ctx* ctx, const lld_line_stereo_params* geom, con
     LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&line_candidates_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&line_candidates_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
-  if ((size_t)nt + 16 > 48 * 1024) LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&line_resolve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)nt + 16));
+  
   if (geom)
     hipLaunchKernelGGL(line_candidates_kernel<true>, dim3(nq), dim3(64), lds, sm, P, reinterpret_cast<const float*>(d + o_ll), reinterpret_cast<const int*>(d + o_lo),
                        reinterpret_cast<const float*>(d + o_rl), reinterpret_cast<const int*>(d + o_ro), reinterpret_cast<const float*>(d + o_q),
@@ -920,7 +927,8 @@ static int line_match_core(lld_ctx* ctx, const lld_line_stereo_params* geom, con
   else
     hipLaunchKernelGGL(line_candidates_kernel<false>, dim3(nq), dim3(64), lds, sm, P, nullptr, nullptr, nullptr, nullptr, reinterpret_cast<const float*>(d + o_q),
                        reinterpret_cast<const float*>(d + o_t), dim, nt, dgate_in, tau, nullptr, dmat, dc);
-  hipLaunchKernelGGL(line_resolve_kernel, dim3(1), dim3(64), (size_t)nt + 16, sm, dc, dmat, geom ? dgate : dgate_in, nq, nt, tau,
+  { const int rs = line_resolve_prepare(nq, nt); if (rs) return rs; }
+  hipLaunchKernelGGL(line_resolve_kernel, dim3(1), dim3(kResolveThreads), line_resolve_lds(nq, nt), sm, dc, dmat, geom ? dgate : dgate_in, nq, nt, tau,
                      reinterpret_cast<int*>(d_out + r_m), reinterpret_cast<double*>(d_out + r_d));
   LLD_HIP_TRY(hipGetLastError());
   LLD_HIP_TRY(hipMemcpyAsync(h_out, d_out, out, hipMemcpyDeviceToHost, sm));
@@ -1024,11 +1032,12 @@ int lld_line_track_match(lld_ctx* ctx, const lld_line_track_params* prm, int n_m
   const double tau = std::nextafter(prm->md_thr, 1.7976931348623157e308);
   const size_t lds = (size_t)n_cur * 8 + (size_t)dim * 4 + 16;
   if (lds > 48 * 1024) LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&line_candidates_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  if ((size_t)n_cur + 16 > 48 * 1024) LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&line_resolve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)n_cur + 16));
+  
   LineGateParams G0; std::memset(&G0, 0, sizeof G0);
   hipLaunchKernelGGL(line_candidates_kernel<false>, dim3(n_map), dim3(64), lds, sm, G0, nullptr, nullptr, nullptr, nullptr, reinterpret_cast<const float*>(d + o_q),
                      reinterpret_cast<const float*>(d + o_t), dim, n_cur, dgate, tau, nullptr, dmat, dc);
-  hipLaunchKernelGGL(line_resolve_kernel, dim3(1), dim3(64), (size_t)n_cur + 16, sm, dc, dmat, dgate, n_map, n_cur, tau,
+  { const int rs = line_resolve_prepare(n_map, n_cur); if (rs) return rs; }
+  hipLaunchKernelGGL(line_resolve_kernel, dim3(1), dim3(kResolveThreads), line_resolve_lds(n_map, n_cur), sm, dc, dmat, dgate, n_map, n_cur, tau,
                      reinterpret_cast<int*>(d_out + r_m), reinterpret_cast<double*>(d_out + r_d));
   LLD_HIP_TRY(hipGetLastError());
   LLD_HIP_TRY(hipMemcpyAsync(h_out, d_out, gate_out ? out : r_g, hipMemcpyDeviceToHost, sm));
@@ -1135,11 +1144,12 @@ int line_track_launch_dev(lld_ctx* ctx, hipStream_t st, const LineTrackDevParams
   const double tau = std::nextafter(md_thr, 1.7976931348623157e308);         // `md > mdThr` rejects (Tracking.cc:1099)
   const size_t lds = (size_t)n_cur * 8 + (size_t)dim * 4 + 16;
   if (lds > 48 * 1024) LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&line_candidates_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  if ((size_t)n_cur + 16 > 48 * 1024) LLD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&line_resolve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)n_cur + 16));
+  
   LineGateParams G0; std::memset(&G0, 0, sizeof G0);
   hipLaunchKernelGGL(line_candidates_kernel<false>, dim3(n_map), dim3(64), lds, st, G0, nullptr, nullptr, nullptr, nullptr, map.desc, cur.desc, dim, n_cur, dgate, tau,
                      nullptr, dmat, dc);
-  hipLaunchKernelGGL(line_resolve_kernel, dim3(1), dim3(64), (size_t)n_cur + 16, st, dc, dmat, dgate, n_map, n_cur, tau, matches_d, nullptr);
+  { const int rs = line_resolve_prepare(n_map, n_cur); if (rs) return rs; }
+  hipLaunchKernelGGL(line_resolve_kernel, dim3(1), dim3(kResolveThreads), line_resolve_lds(n_map, n_cur), st, dc, dmat, dgate, n_map, n_cur, tau, matches_d, nullptr);
   LLD_HIP_TRY(hipGetLastError());
   return LLD_OK;
 }

@@ -160,6 +160,10 @@ __device__ __forceinline__ Pose pose_oplus_rcp(const Pose& T, const double* u) {
   return r;
 }
 
+// (Round 6 tried exp(omega) as a quaternion directly, with series for sin / cos below 1/4 rad - 10 us off a frame's kernel.  Not kept: the
+// series are MORE accurate than the reference's closed forms (1 - cos t) / t^2, (t - sin t) / t^3, whose cancellation noise decides whether
+// a trial at convergence "improves" chi2: a monocular frame that the oracle walks in 20 iterations / 52 trials took 20 / 20 with the accurate
+// map and 17 / 44 with this one.  Same pose to 5e-13 either way; the reference's arithmetic stays.  profiles/NOTES_r06.md.)
 // Dense LDL^T of the 6x6 system (LinearSolverDense, solvers/linear_solver_dense.h:65-113): fails unless all pivots > 0.
 __device__ __forceinline__ bool solve6(const double* Hu /*21 upper, row-major packed*/, double lambda, const double* b, double* x) {
   double A[6][6];
@@ -181,7 +185,7 @@ __device__ __forceinline__ bool solve6(const double* Hu /*21 upper, row-major pa
 #pragma unroll
     for (int p = 0; p < j; p++) d -= A[j][p] * A[j][p] * A[p][p];
     if (!(d > 0.0) || !isfinite(d)) ok = false;
-    inv[j] = 1.0 / d;
+    inv[j] = rcp_nr(d);                                              // (v_rcp_f64 + two Newton steps: this chain runs on one wavefront while the workgroup waits)
 #pragma unroll
     for (int i = j + 1; i < 6; i++) {
       double s = A[i][j];
@@ -473,7 +477,10 @@ __global__ __launch_bounds__(kThreads, 2) void pose_opt_kernel(const PoseFrameDe
                   for (int r = 0; r < 6; r++) { md = fmax(fabs(Hb[k]), md); k += 6 - r; }
                   lam = 1e-5 * md; nij = 2.0;
                 }
-                for (int j = 0; j < tid; j++) { lam *= nij; nij *= 2; }
+                // lambda after `tid` rejections: lam * prod_{k < tid} (nij 2^k).  nij is 2 whenever candidates are formed (an accepted trial and
+                // computeLambdaInit both reset it; a round that ran out of trials ends), so the products are exact powers of two - in any order
+                if (nij == 2.0) lam = ldexp(lam, tid * (tid + 1) / 2);
+                else for (int j = 0; j < tid; j++) { lam *= nij; nij *= 2; }
                 const bool ok2 = solve6(Hb, lam, Hb + 21, x);
                 const Pose Tn = pose_oplus_rcp(T, x);
                 double scale = 0.0;

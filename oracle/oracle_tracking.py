@@ -37,7 +37,7 @@ class Frame:
         self.ln_out = np.zeros(nl, np.uint8)
         self.seen_points: set[int] = set()          # MapPoints with mnLastFrameSeen == this frame's id
         self.tracked_lines: set[int] = set()        # MapLines with tracked_last_id == this frame's id
-        self.view = None; self.pose_qt = None
+        self.view = None; self.pose_qt = None; self.problems = []
 
     def set_pose_matrix(self, Tcw_f32):
         """Frame::SetPose + UpdatePoseMatrices."""
@@ -86,6 +86,7 @@ class Frame:
                               pt_inv_sigma2=F.inv_sigma2[F.octave[idx]].astype(np.float64), ln_x0=self.ln_x0[li].reshape(-1, 3), ln_dir=self.ln_dir[li].reshape(-1, 3),
                               ln_left=left, ln_right=right, ln_octave=octs, ln_frame_index=li.astype(np.int32)).normalise()
         out = O.pose_opt(prob, gamma)
+        self.problems.append(prob)                                        # (for tools/experiments: the edges as PoseOptimization saw them)
         n_le = int(len(li) + np.count_nonzero(np.asarray(L["line_matches"])[li] >= 0)) if len(li) else 0
         self.kp_out[idx] = out.pt_outlier
         if len(idx) >= 3 and len(idx) + n_le >= 10:                       # the line classification is reached (Optimizer.cc:809, :878)
@@ -160,4 +161,5 @@ def track_frame(sc: dict, gamma=0.5, th_motion=7.0, th_local=1.0, nnratio=0.8, w
     lbad = fr.ln_has & (fr.ln_out != 0)
     fr.ln_has[lbad] = False; fr.ln_id[lbad] = -1
     rec2["n_lines"] = int(fr.ln_has.sum())
+    track_frame.last_problems = fr.problems
     return rec1, rec2
