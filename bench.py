@@ -285,62 +285,47 @@ def deterministic_block(ctx, windows, repeats=3):
     return out
 
 
-def tracking_frame_block(ctx, repeats=7):
-    """The Tracking thread's per-frame sequence on ONE synthetic frame (2000 keypoints, 1200 points tracked in the last frame, 2500 local
-    MapPoints): SearchByProjection(Current, Last) -> PoseOptimization -> outlier discard -> SearchLocalPoints -> PoseOptimization
-    (src/Tracking.cc:904,937,1133,1152), through the C ABI with the frame resident on the device (lld_frame_*) and with the per-call upload,
-    next to the same chain through the CPU oracle, every stage checked against the oracle on the inputs the device chain handed it."""
+def tracking_frame_block(ctx, repeats=200):
+    """The Tracking thread's per-frame chain on ONE synthetic stereo frame (2000 keypoints + 300 stereo lines; 1200 points and 140 lines tracked in
+    the last frame; 2500 local MapPoints, 260 local MapLines): TrackWithMotionModel = SearchByProjection(Current, Last) -> AddLinesFrom ->
+    PoseOptimization -> outlier discard, TrackLocalMap = SearchLocalPoints -> AddLinesFrom -> PoseOptimization (src/Tracking.cc:885-994,
+    :1126-1220) as ONE device-resident sequence behind the C ABI (lld_frame_track_*), driven from COMPILED C++ (examples/harness track, a child
+    process: `repeats` frames on one handle, host wall clock per frame), next to the CPU oracle's own run of the whole sequence
+    (oracle/oracle_tracking.py) whose per-stage records are compared with the device's."""
     import numpy as np
-    import oracle_py as O
-    import oracle_orbsearch as OS
-    from lld_slam_amd import synth
-    from lld_slam_amd.tracking import TrackedFrame
-    sc = synth.make_tracking_scene(0)
-    F = sc["frame"]
+    import oracle_tracking as OT
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+    import time_track_chain as TT
+    res, sc, (g1, g2) = TT.run(repeats, 0, False)
+    res_between = TT.run(repeats, 0, True)[0]
+    res_points = TT.run(repeats, 0, False, n_lines=0)[0]
+    OT.track_frame(sc)                                            # (first call loads the oracle library)
+    cpu = []
+    for _ in range(5):
+        tc = time.perf_counter(); e1, e2 = OT.track_frame(sc); cpu.append((time.perf_counter() - tc) * 1e3)
 
-    def chain(resident):
-        with TrackedFrame(ctx, F, sc["cam"], resident=resident) as tf:
-            t0 = time.perf_counter()
-            p1 = tf.track_with_motion_model(sc["pose_guess"], sc["last"], sc["last_ids"], th=7.0)
-            t1 = time.perf_counter()
-            p2 = tf.track_local_map(p1, sc["map_points"], sc["map_ids"], th=1.0)
-            t2 = time.perf_counter()
-            return (t1 - t0) * 1e3, (t2 - t1) * 1e3, tf.stages, p2, int(tf.kp_has.sum())
-    chain(True); chain(False)
-    res = {}
-    for name, resident in (("resident_frame", True), ("per_call_upload", False)):
-        runs = [chain(resident) for _ in range(repeats)]
-        res[name] = {"ms_per_frame": _spread([a + b for a, b, *_ in runs]), "motion_model_ms": _spread([r[0] for r in runs]), "local_map_ms": _spread([r[1] for r in runs])}
-    _, _, st, p2, n_held = chain(True)
-    # the oracle's chain on the same inputs, stage by stage (each stage gets what the device chain handed it)
-    s1, s3 = st["search_last_frame"], st["search_local_points"]
-    tc = time.perf_counter()
-    valid, uv, ur = OS.project_last_frame(s1["view"], sc["last"])
-    n1, slot1 = OS.search_by_projection_frame(F, sc["last"]["desc"], valid, uv, ur, sc["last"]["octave"], sc["last"]["angle"], sc["last"]["has_obs"], s1["occupied"], 0, 7.0, True)
-    o2 = O.pose_opt(st["pose_after_motion_model"]["problem"], 0.5)
-    k, inv, uvr, lvl, vc = OS.is_in_frustum(s3["view"], s3["points"])
-    n3, slot3 = OS.search_by_projection_map(F, s3["points"]["desc"], inv, uvr[:, :2], uvr[:, 2], lvl, vc, s3["points"]["has_obs"], s3["occupied"], 1.0, 0.8)
-    o4 = O.pose_opt(st["pose_after_local_map"]["problem"], 0.5)
-    cpu_ms = (time.perf_counter() - tc) * 1e3
-
-    def slots(out, occupied):
-        sl = np.where(np.asarray(occupied) != 0, 1 << 20, -1).astype(np.int32)
-        sl = np.where(out.owner >= 0, out.owner, sl)
-        return np.where(out.owner == -2, -1, sl).astype(np.int32)
-    g2, g4 = st["pose_after_motion_model"]["out"], st["pose_after_local_map"]["out"]
-    parity = {"search_last_frame_bit_exact": bool(s1["out"].n_matches == n1 and np.array_equal(slots(s1["out"], s1["occupied"]), slot1)),
-              "search_local_points_bit_exact": bool(s3["out"].n_matches == n3 and np.array_equal(slots(s3["out"], s3["occupied"]), slot3) and np.array_equal(s3["frustum"]["in_view"], inv)),
-              "pose_max_rel": float(max(np.max(np.abs(g.pose_qt - o.pose_qt) / np.maximum(np.abs(o.pose_qt), 1e-3)) for g, o in ((g2, o2), (g4, o4)))),
-              "pose_outlier_flags_equal": bool(np.array_equal(g2.pt_outlier, o2.pt_outlier) and np.array_equal(g4.pt_outlier, o4.pt_outlier))}
+    def same(g, e):
+        ids = all(np.array_equal(g[k], e[k]) for k in ("kp_point_id", "kp_outlier", "ln_line_id", "ln_outlier"))
+        cnt = all(g[k] == e[k] for k in ("n_inliers", "n_edges", "n_search", "n_points", "n_points_map", "n_lines_matched", "n_lines", "n_discarded"))
+        dq = float(np.max(np.abs(g["pose_qt"][:4] - e["pose_qt"][:4]))); dt = float(np.linalg.norm(g["pose_qt"][4:] - e["pose_qt"][4:]) / max(1.0, np.linalg.norm(e["pose_qt"][4:])))
+        return ids, cnt, max(dq, dt), abs(g["chi2"] - e["chi2"]) / max(abs(e["chi2"]), 1e-12)
+    a, b = same(g1, e1), same(g2, e2)
     err0 = float(np.linalg.norm(np.asarray(sc["pose_guess"])[4:] - np.asarray(sc["pose_true"])[4:]))
-    err2 = float(np.linalg.norm(np.asarray(p2)[4:] - np.asarray(sc["pose_true"])[4:]))
-    return {"workload": "one frame: 2000 keypoints, 1200 last-frame points, 2500 local MapPoints; SearchByProjection(Current, Last) + PoseOptimization + discard + "
-                        "SearchLocalPoints + PoseOptimization (points; the line half and ComputeStereoMatches have their own entries above and in the README)",
-            "unit": "ms per frame (host wall clock through the Python mirror: ctypes marshalling and the host-side bookkeeping of Frame::mvpMapPoints included)",
-            **res, "matches": {"after_motion_model": int(n1), "local_map_added": int(n3), "map_points_held_at_the_end": n_held},
+    err2 = float(np.linalg.norm(g2["pose_qt"][4:] - np.asarray(sc["pose_true"])[4:]))
+    return {"workload": "one stereo frame: 2000 keypoints + 300 lines; last frame 1200 points + 140 lines; local map 2500 MapPoints + 260 MapLines; both stages of the "
+                        "Tracking thread (search -> AddLinesFrom -> PoseOptimization -> discard, twice) with the Frame's state resident in HBM",
+            "unit": "ms per frame (host wall clock around TrackWithMotionModel + TrackLocalMap + download in examples/harness.cpp; uploads of the stage inputs included, "
+                    "the Frame's own keypoints / lines are uploaded once per frame handle, outside)",
+            "driven_from": "compiled C++ (examples/harness track), child process",
+            "one_download_at_the_end": res, "download_between_the_stages": res_between, "points_only_no_lines": res_points,
             "translation_error_m": {"predicted_pose": round(err0, 4), "after_the_sequence": round(err2, 5)},
-            "cpu_baseline": {"value": round(cpu_ms, 2), "unit": "ms per frame", "cores": 1, "kind": "port", "sample": "the same four stages through oracle/ (one frame)"},
-            "parity": parity}
+            "cpu_baseline": {"value": round(float(np.median(cpu)), 2), "unit": "ms per frame", "cores": 1, "kind": "port",
+                             "sample": "the same two stages, lines included, through oracle/oracle_tracking.py (median of 5)"},
+            "parity": {"against": "the oracle's own run of the sequence (no device state handed over)",
+                       "stage1_ids_and_outlier_flags_bit_exact": bool(a[0]), "stage2_ids_and_outlier_flags_bit_exact": bool(b[0]),
+                       "counters_equal": bool(a[1] and b[1]), "pose_max_rel": max(a[2], b[2]), "chi2_max_rel": max(a[3], b[3]),
+                       "lm_iterations_trials_device": [g1["lm_iterations"], g1["lm_trials"], g2["lm_iterations"], g2["lm_trials"]],
+                       "lm_iterations_trials_oracle": [e1["lm_iterations"], e1["lm_trials"], e2["lm_iterations"], e2["lm_trials"]]}}
 
 
 def secondary_block(ctx, dev, repeats=5):
@@ -652,6 +637,8 @@ def main():
     # same RecordGather the N > 1 line times, the same check of the gathered records - so that the driver's N = 1 line says whether the
     # collective path works on this box (`gathered_records_ok`), not null.  Failing to bring RCCL up must not cost the headline line.
     late_gather = None
+    pg_inited = use_dist                                          # a process group we must destroy, whatever happens after its creation
+    rccl_overhead = None
     if world == 1 and not use_dist and not args.no_rccl_check:
         try:
             sys.stdout.flush(); saved_stdout = os.dup(1); os.dup2(2, 1)          # (RCCL's banner goes to stderr)
@@ -659,12 +646,22 @@ def main():
             for k_, v_ in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29577")):
                 os.environ.setdefault(k_, v_)
             dist.init_process_group("nccl", device_id=dev)
+            pg_inited = True
             late_counts = D.gather_counts(wpg, dev, True, 1)
             late_stride = D.max_count_stride(rec_stride, dev, True)
             late = D.RecordGather(records, 1, 0, n_bytes=max(late_counts) * late_stride, enabled=True, local_stride=rec_stride, common_stride=late_stride)
             batch.set_groups(args.groups); batch.solve(); late.step(); late.drain()
             D.barrier(True, True)
             late_gather = (late, late_counts, late_stride)
+            # ... and the proxy of what N > 1 ranks pay for the collective: the SAME K timed steps once more with the gather of
+            # every step started behind its solve (asynchronous, overlapping the next solve's stream groups - exactly the N > 1 step), against
+            # the plain K steps timed above on this box.  rccl_overhead = rate with the gather / rate without.
+            t0g = time.perf_counter()
+            for _ in range(args.steps):
+                batch.solve(); late.step()
+            late.drain(); D.barrier(True, True)
+            rccl_overhead = {"value": round(elapsed / (time.perf_counter() - t0g), 4), "what": "windows/s of K steps with the asynchronous one-rank RCCL gather of every "
+                             "step's records inside the timed region / windows/s of the plain K steps (same box, same batch)", "steps": args.steps}
         except Exception as ex:
             print(f"[bench] one-rank RCCL check skipped: {ex!r}", file=sys.stderr)
             late_gather = None
@@ -796,6 +793,9 @@ def main():
                    "mean_pcg_iterations_per_trial": float(np.sum([s["pcg_iterations"] for s in stats]) / max(1, np.sum([sum(s["lm_trials"]) for s in stats])))},
             # what this line was measured on: N > 1 figures exist only when a multi-GPU node ran this script (the builder's box has one GPU)
             "n_gpus_measured": world,
+            # one rank, measured: what the asynchronous RCCL gather of every step costs the solve it overlaps (null under a launcher: there the
+            # gather IS inside `value`); DESIGN.md 5 states the policy that follows from it
+            "rccl_overhead": rccl_overhead,
         }
     batch.close()
     if world > 1 and not args.no_secondary:
@@ -824,9 +824,11 @@ def main():
             except Exception as ex:
                 result["secondary"] = dict(result.get("secondary") or {}, error=repr(ex)[:300])
     ctx.close()
-    if use_dist or late_gather is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if pg_inited:
+        try:
+            dist.barrier()
+        finally:
+            dist.destroy_process_group()
     if saved_stdout is not None:
         sys.stdout.flush()
         try:                                  # what native libraries (RCCL: "Librccl path : ...") left in the C stdio buffer goes where fd 1 points NOW

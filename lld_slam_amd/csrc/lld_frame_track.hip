@@ -94,38 +94,6 @@ __global__ void track_reset_kernel(TrackDev D, const double* pose_guess, const l
   }
 }
 
-// CurrentFrame.mvpMapPoints[bestIdx2] = pMP (src/ORBmatcher.cc:1427, :124): keypoint k belongs to the query the search left in owner[k]
-// (the orientation filter's removals are already out: owner < 0).  `alt`: the wide second search, used when the first found fewer than
-// `below` matches (Tracking.cc:907-911: fill(NULL) + SearchByProjection(2*th)).
-struct ApplySrc { const int32_t* owner; const int32_t* summary; };
-__global__ void track_apply_points_kernel(TrackDev D, ApplySrc first, ApplySrc alt, int below, const float* q_pos, const int32_t* q_id, const uint8_t* q_obs, int stage) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool wide = alt.owner && first.summary[0] < below;
-  const ApplySrc S = wide ? alt : first;
-  if (k == 0) {
-    int32_t* h = D.rec_h[stage]->i;
-    h[RI_SEARCH1] = first.summary[0]; h[RI_SEARCH] = S.summary[0]; h[RI_WIDE] = wide ? 1 : 0;
-  }
-  if (k >= D.nt) return;
-  const int q = S.owner[k];
-  if (q < 0) return;
-  D.kp_has[k] = 1; D.kp_id[k] = q_id[q]; D.kp_obs[k] = q_obs ? q_obs[q] : 1;
-  D.kp_world[3 * k] = q_pos[3 * q]; D.kp_world[3 * k + 1] = q_pos[3 * q + 1]; D.kp_world[3 * k + 2] = q_pos[3 * q + 2];
-}
-
-// mCurrentFrame.mvpMapLines[mi] = pML; pML->tracked_last_id = mnId (src/Tracking.cc:1116-1117).  The resolve kernel gave every frame line
-// to at most one map line, so the writes do not collide.
-__global__ void track_apply_lines_kernel(TrackDev D, int n_map, const int32_t* matches, const double* x0, const double* dir, const int32_t* id, int stage) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_map) return;
-  const int mi = matches[i];
-  if (mi < 0) return;
-  D.ln_has[mi] = 1; D.ln_id[mi] = id[i];
-  for (int c = 0; c < 3; c++) { D.ln_x0[3 * mi + c] = x0[3 * i + c]; D.ln_dir[3 * mi + c] = dir[3 * i + c]; }
-  const int at = atomicAdd(D.n_tracked, 1);
-  if (at < D.tracked_cap) D.tracked[at] = id[i];
-}
-
 // What follows PoseOptimization.  stage 0 = TrackWithMotionModel (src/Tracking.cc:940-975): an outlier point leaves the frame, its flag is
 // cleared, its MapPoint is marked seen (-> the discard list); an outlier line leaves, its flag STAYS (the reference does not clear
 // mvbOutlierLines).  stage 1 = TrackLocalMap (:1155-1187): outlier points leave (STEREO) with their flag kept, outlier lines leave.
@@ -230,8 +198,6 @@ __global__ __launch_bounds__(kSeenThreads) void track_mark_seen_kernel(TrackDev 
   for (int q = tid; q < n_mp; q += kSeenThreads) mp_skip_out[q] = ((mp_skip && mp_skip[q]) || seen_lookup(ptab, pmask, mp_id[q])) ? 1 : 0;
   for (int j = tid; j < n_ml; j += kSeenThreads) ml_skip_out[j] = ((ml_skip && ml_skip[j]) || seen_lookup(ltab, lmask, ml_id[j])) ? 1 : 0;
 }
-
-__global__ void track_fill_i32_kernel(int32_t* p, int n, int32_t v) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = v; }
 
 inline size_t al(size_t b) { return (b + 255) & ~size_t(255); }
 
@@ -376,13 +342,12 @@ int run_lines(lld_frame* f, hipStream_t st, const lld_track_params* P, const lld
   const int n_map = ML ? ML->n : 0;
   if (n_map <= 0 || S->nl <= 0) return LLD_OK;
   int32_t* d_matches = reinterpret_cast<int32_t*>(d_in + U.matches);
-  hipLaunchKernelGGL(track_fill_i32_kernel, dim3((n_map + 255) / 256), dim3(256), 0, st, d_matches, n_map, -1);
   LineMapDev M{n_map, reinterpret_cast<const double*>(d_in + U.x0), reinterpret_cast<const double*>(d_in + U.dir), reinterpret_cast<const double*>(d_in + U.x1),
                reinterpret_cast<const double*>(d_in + U.x2), d_skip, reinterpret_cast<const float*>(d_in + U.desc)};
   LineFrameDev Cur{S->nl, S->ln_left, S->ln_loct, S->ln_right, S->ln_match, S->D.ln_has, S->ln_cell, S->ln_desc, S->dim};
-  int s = line_track_launch_dev(f->ctx, st, S->D.line_params, M, Cur, P->line_md_thr, d_line_work, d_matches); if (s) return s;
-  hipLaunchKernelGGL(track_apply_lines_kernel, dim3((n_map + 255) / 256), dim3(256), 0, st, S->D, n_map, d_matches, M.x0, M.dir, reinterpret_cast<const int32_t*>(d_in + U.id), stage);
-  return LLD_OK;
+  const LineApplyDev ap{S->D.ln_has, S->D.ln_x0, S->D.ln_dir, S->D.ln_id, S->D.tracked, S->D.n_tracked, S->D.tracked_cap, reinterpret_cast<const int32_t*>(d_in + U.id)};
+  (void)stage;
+  return line_track_launch_dev(f->ctx, st, S->D.line_params, M, Cur, P->line_md_thr, d_line_work, d_matches, ap);
 }
 
 int run_pose(lld_frame* f, hipStream_t st, const lld_track_params* P, char* d_pose_work, int stage) {
@@ -501,8 +466,13 @@ int lld_frame_track_motion_model(lld_frame* f, const lld_track_params* P, const 
                       reinterpret_cast<uint8_t*>(d + o_so[k][3]), reinterpret_cast<int32_t*>(d + o_so[k][4]), reinterpret_cast<int32_t*>(d + o_so[k][5])};
   const bool wide = P->wide_retry != 0;
   const RunIf gate{so[0].summary, 20, 1};                                     // if(nmatches<20) (src/Tracking.cc:907)
-  orbs_fill_problem(f, 0, nq, S->D.kp_has, d + o_qrec, reinterpret_cast<const uint32_t*>(d + o_desc), so[0], d + o_cache, 0.f, P->check_orientation, RunIf{}, h + o_prob1);
-  orbs_fill_problem(f, 0, nq, S->D.kp_has, d + o_qrec, reinterpret_cast<const uint32_t*>(d + o_desc), so[1], d + o_cache, 0.f, P->check_orientation, gate, h + o_prob2);
+  const LastFrameDev LF{nq, reinterpret_cast<const float*>(d + o_pos), reinterpret_cast<const uint8_t*>(d + o_val), reinterpret_cast<const int32_t*>(d + o_oct),
+                        reinterpret_cast<const float*>(d + o_ang), reinterpret_cast<const uint8_t*>(d + o_obs)};
+  int32_t* counts = S->D.rec_h[0]->i + RI_SEARCH1;                            // RI_SEARCH1, RI_SEARCH, RI_WIDE are consecutive
+  ApplyDev ap{S->D.kp_has, S->D.kp_world, S->D.kp_id, S->D.kp_obs, LF.pos, reinterpret_cast<const int32_t*>(d + o_id), LF.has_obs, counts, wide ? 20 : 0, 0};
+  orbs_fill_problem(f, 0, nq, S->D.kp_has, d + o_qrec, reinterpret_cast<const uint32_t*>(d + o_desc), so[0], d + o_cache, 0.f, P->check_orientation, RunIf{}, ap, h + o_prob1);
+  ap.min_matches = 0; ap.is_retry = 1;
+  orbs_fill_problem(f, 0, nq, S->D.kp_has, d + o_qrec, reinterpret_cast<const uint32_t*>(d + o_desc), so[1], d + o_cache, 0.f, P->check_orientation, gate, ap, h + o_prob2);
   hipStream_t st = ctx->stream;
   LLD_HIP_TRY(hipMemcpyAsync(d, h, up_bytes, hipMemcpyHostToDevice, st));
   LLD_HIP_TRY(hipEventRecord(S->uploaded[0], st)); S->upload_pending[0] = true;
@@ -510,12 +480,12 @@ int lld_frame_track_motion_model(lld_frame* f, const lld_track_params* P, const 
   const int nmax = std::max(std::max(nt, S->nl), 64);
   hipLaunchKernelGGL(track_reset_kernel, dim3((nmax + 255) / 256), dim3(256), 0, st, S->D, reinterpret_cast<const double*>(d + o_pose),
                      reinterpret_cast<const lld_frame_view*>(d + o_view), reinterpret_cast<const LineTrackDevParams*>(d + o_lp));
-  const LastFrameDev LF{nq, reinterpret_cast<const float*>(d + o_pos), reinterpret_cast<const uint8_t*>(d + o_val), reinterpret_cast<const int32_t*>(d + o_oct),
-                        reinterpret_cast<const float*>(d + o_ang), reinterpret_cast<const uint8_t*>(d + o_obs)};
-  s = orbs_launch_last_frame(ctx, st, f, view, nullptr, LF, P->direction, P->th_motion, d + o_qrec, d + o_prob1, RunIf{}); if (s) return s;
-  if (wide) { s = orbs_launch_last_frame(ctx, st, f, view, nullptr, LF, P->direction, 2.f * P->th_motion, d + o_qrec, d + o_prob2, gate); if (s) return s; }
-  hipLaunchKernelGGL(track_apply_points_kernel, dim3((std::max(nt, 1) + 255) / 256), dim3(256), 0, st, S->D, ApplySrc{so[0].owner, so[0].summary},
-                     wide ? ApplySrc{so[1].owner, so[1].summary} : ApplySrc{nullptr, nullptr}, 20, LF.pos, reinterpret_cast<const int32_t*>(d + o_id), LF.has_obs, 0);
+  s = orbs_project_last_frame(st, f, view, nullptr, LF, P->direction, P->th_motion, d + o_qrec, RunIf{}); if (s) return s;
+  s = orbs_launch(ctx, st, f, d + o_prob1); if (s) return s;
+  if (wide) {
+    s = orbs_project_last_frame(st, f, view, nullptr, LF, P->direction, 2.f * P->th_motion, d + o_qrec, gate); if (s) return s;
+    s = orbs_launch(ctx, st, f, d + o_prob2); if (s) return s;
+  }
   s = run_lines(f, st, P, n_map ? last_lines : nullptr, d, U, reinterpret_cast<const uint8_t*>(d + U.skip), d + o_lwork, 0); if (s) return s;
   s = run_pose(f, st, P, d + o_pwork, 0); if (s) return s;
   S->stage1_queued = true;
@@ -561,7 +531,10 @@ int lld_frame_track_local_map(lld_frame* f, const lld_track_params* P, const lld
   if (n_map) pack_lines(h, U, local_lines, S->dim);
   const SearchOut so{reinterpret_cast<int32_t*>(d + o_so[0]), reinterpret_cast<int32_t*>(d + o_so[1]), reinterpret_cast<int32_t*>(d + o_so[2]),
                      reinterpret_cast<uint8_t*>(d + o_so[3]), reinterpret_cast<int32_t*>(d + o_so[4]), reinterpret_cast<int32_t*>(d + o_so[5])};
-  orbs_fill_problem(f, 1, nq, S->D.kp_has, d + o_qrec, reinterpret_cast<const uint32_t*>(d + o_desc), so, d + o_cache, P->nnratio_local, 0, RunIf{}, h + o_prob);
+  const MapPointsDev MP{nq, reinterpret_cast<const float*>(d + o_pos), reinterpret_cast<const float*>(d + o_nrm), reinterpret_cast<const float*>(d + o_maxd),
+                        reinterpret_cast<const float*>(d + o_mind), reinterpret_cast<const uint8_t*>(d + o_obs), reinterpret_cast<const uint8_t*>(d + o_skip2)};
+  const ApplyDev ap{S->D.kp_has, S->D.kp_world, S->D.kp_id, S->D.kp_obs, MP.pos, reinterpret_cast<const int32_t*>(d + o_id), MP.has_obs, S->D.rec_h[1]->i + RI_SEARCH1, 0, 0};
+  orbs_fill_problem(f, 1, nq, S->D.kp_has, d + o_qrec, reinterpret_cast<const uint32_t*>(d + o_desc), so, d + o_cache, P->nnratio_local, 0, RunIf{}, ap, h + o_prob);
   hipStream_t st = ctx->stream;
   LLD_HIP_TRY(hipMemcpyAsync(d, h, up_bytes, hipMemcpyHostToDevice, st));
   LLD_HIP_TRY(hipEventRecord(S->uploaded[1], st)); S->upload_pending[1] = true;
@@ -577,11 +550,8 @@ int lld_frame_track_local_map(lld_frame* f, const lld_track_params* P, const lld
                          reinterpret_cast<const uint8_t*>(d + o_skip), reinterpret_cast<uint8_t*>(d + o_skip2), n_map, reinterpret_cast<const int32_t*>(d + U.id),
                          reinterpret_cast<const uint8_t*>(d + U.skip), reinterpret_cast<uint8_t*>(d + o_lskip2), psize - 1, lsize - 1);
   }
-  const MapPointsDev MP{nq, reinterpret_cast<const float*>(d + o_pos), reinterpret_cast<const float*>(d + o_nrm), reinterpret_cast<const float*>(d + o_maxd),
-                        reinterpret_cast<const float*>(d + o_mind), reinterpret_cast<const uint8_t*>(d + o_obs), reinterpret_cast<const uint8_t*>(d + o_skip2)};
-  s = orbs_launch_local_points(ctx, st, f, nullptr, S->D.view, MP, P->viewing_cos_limit, P->th_local, d + o_qrec, d + o_prob); if (s) return s;
-  hipLaunchKernelGGL(track_apply_points_kernel, dim3((std::max(nt, 1) + 255) / 256), dim3(256), 0, st, S->D, ApplySrc{so.owner, so.summary}, ApplySrc{nullptr, nullptr}, 0,
-                     MP.pos, reinterpret_cast<const int32_t*>(d + o_id), MP.has_obs, 1);
+  s = orbs_project_local_points(st, f, nullptr, S->D.view, MP, P->viewing_cos_limit, P->th_local, d + o_qrec); if (s) return s;
+  s = orbs_launch(ctx, st, f, d + o_prob); if (s) return s;
   s = run_lines(f, st, P, n_map ? local_lines : nullptr, d, U, reinterpret_cast<const uint8_t*>(d + o_lskip2), d + o_lwork, 1); if (s) return s;
   s = run_pose(f, st, P, d + o_pwork, 1); if (s) return s;
   return LLD_OK;

@@ -409,7 +409,8 @@ constexpr int kResolveThreads = 256;
 inline size_t line_resolve_lds(int nq, int nt) { return ((size_t)nq + (size_t)nt) * 4 + 16; }
 static int line_resolve_prepare(int nq, int nt);      // raises the kernel's dynamic-LDS ceiling when blk + pick need more than the default (defined after the kernel)
 __global__ __launch_bounds__(kResolveThreads) void line_resolve_kernel(const LineCand* __restrict__ cand, const double* __restrict__ dmat, const uint8_t* __restrict__ gate,
-                                                                      int nq, int nt, double tau, int* __restrict__ matches, double* __restrict__ match_dist) {
+                                                                      int nq, int nt, double tau, int* __restrict__ matches, double* __restrict__ match_dist,
+                                                                      lld_track::LineApplyDev ap, const double* __restrict__ map_x0, const double* __restrict__ map_dir) {
   extern __shared__ __attribute__((aligned(16))) int res_lds[];
   __shared__ int changed;
   int* blk = res_lds; int* pick = res_lds + nt;
@@ -449,6 +450,13 @@ __global__ __launch_bounds__(kResolveThreads) void line_resolve_kernel(const Lin
     const int bi = pick[j];
     matches[j] = bi;
     if (match_dist) match_dist[j] = bi >= 0 ? dmat[(size_t)j * nt + bi] : kInfD;
+    // the device-resident chain (lld_frame_track_*): the frame line takes the map line here (every frame line has at most one taker)
+    if (ap.ln_has && bi >= 0) {
+      ap.ln_has[bi] = 1; ap.ln_id[bi] = ap.map_id[j];
+      for (int c = 0; c < 3; c++) { ap.ln_x0[3 * bi + c] = map_x0[3 * j + c]; ap.ln_dir[3 * bi + c] = map_dir[3 * j + c]; }
+      const int at = atomicAdd(ap.n_tracked, 1);
+      if (at < ap.tracked_cap) ap.tracked[at] = ap.map_id[j];
+    }
   }
 }
 
@@ -929,7 +937,7 @@ static int line_match_core(lld_ctx* ctx, const lld_line_stereo_params* geom, con
                        reinterpret_cast<const float*>(d + o_t), dim, nt, dgate_in, tau, nullptr, dmat, dc);
   { const int rs = line_resolve_prepare(nq, nt); if (rs) return rs; }
   hipLaunchKernelGGL(line_resolve_kernel, dim3(1), dim3(kResolveThreads), line_resolve_lds(nq, nt), sm, dc, dmat, geom ? dgate : dgate_in, nq, nt, tau,
-                     reinterpret_cast<int*>(d_out + r_m), reinterpret_cast<double*>(d_out + r_d));
+                     reinterpret_cast<int*>(d_out + r_m), reinterpret_cast<double*>(d_out + r_d), lld_track::LineApplyDev{}, nullptr, nullptr);
   LLD_HIP_TRY(hipGetLastError());
   LLD_HIP_TRY(hipMemcpyAsync(h_out, d_out, out, hipMemcpyDeviceToHost, sm));
   LLD_HIP_TRY(hipStreamSynchronize(sm));
@@ -1038,7 +1046,7 @@ int lld_line_track_match(lld_ctx* ctx, const lld_line_track_params* prm, int n_m
                      reinterpret_cast<const float*>(d + o_t), dim, n_cur, dgate, tau, nullptr, dmat, dc);
   { const int rs = line_resolve_prepare(n_map, n_cur); if (rs) return rs; }
   hipLaunchKernelGGL(line_resolve_kernel, dim3(1), dim3(kResolveThreads), line_resolve_lds(n_map, n_cur), sm, dc, dmat, dgate, n_map, n_cur, tau,
-                     reinterpret_cast<int*>(d_out + r_m), reinterpret_cast<double*>(d_out + r_d));
+                     reinterpret_cast<int*>(d_out + r_m), reinterpret_cast<double*>(d_out + r_d), lld_track::LineApplyDev{}, nullptr, nullptr);
   LLD_HIP_TRY(hipGetLastError());
   LLD_HIP_TRY(hipMemcpyAsync(h_out, d_out, gate_out ? out : r_g, hipMemcpyDeviceToHost, sm));
   LLD_HIP_TRY(hipStreamSynchronize(sm));
@@ -1128,10 +1136,10 @@ int line_cells_dev(hipStream_t st, const float* d_left, int n, double sx, double
   return LLD_OK;
 }
 int line_track_launch_dev(lld_ctx* ctx, hipStream_t st, const LineTrackDevParams* params_d, const LineMapDev& map, const LineFrameDev& cur, double md_thr,
-                          void* d_work, int32_t* matches_d) {
+                          void* d_work, int32_t* matches_d, const LineApplyDev& apply) {
   (void)ctx;
   const int n_map = map.n, n_cur = cur.n_cur, dim = cur.dim;
-  if (n_map <= 0 || n_cur <= 0) return LLD_OK;                               // (the caller pre-fills matches_d with -1)
+  if (n_map <= 0 || n_cur <= 0) return LLD_OK;                               // (nothing to associate: the caller does not read matches_d then)
   if (dim > 128 || (size_t)n_cur * 8 + (size_t)dim * 4 > 150 * 1024) return LLD_ERR_UNSUPPORTED;
   const size_t pairs = (size_t)n_map * (size_t)n_cur;
   char* w = static_cast<char*>(d_work);
@@ -1149,7 +1157,7 @@ int line_track_launch_dev(lld_ctx* ctx, hipStream_t st, const LineTrackDevParams
   hipLaunchKernelGGL(line_candidates_kernel<false>, dim3(n_map), dim3(64), lds, st, G0, nullptr, nullptr, nullptr, nullptr, map.desc, cur.desc, dim, n_cur, dgate, tau,
                      nullptr, dmat, dc);
   { const int rs = line_resolve_prepare(n_map, n_cur); if (rs) return rs; }
-  hipLaunchKernelGGL(line_resolve_kernel, dim3(1), dim3(kResolveThreads), line_resolve_lds(n_map, n_cur), st, dc, dmat, dgate, n_map, n_cur, tau, matches_d, nullptr);
+  hipLaunchKernelGGL(line_resolve_kernel, dim3(1), dim3(kResolveThreads), line_resolve_lds(n_map, n_cur), st, dc, dmat, dgate, n_map, n_cur, tau, matches_d, nullptr, apply, map.x0, map.dir);
   LLD_HIP_TRY(hipGetLastError());
   return LLD_OK;
 }

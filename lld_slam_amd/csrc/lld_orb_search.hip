@@ -53,6 +53,11 @@ struct Problem {
   unsigned long long* cache;   // [nq][kTopK] device scratch of sequential problems: the smallest candidate keys of round 1
   // device-resident chains (lld_frame_track_*): the whole search is skipped unless (*run_if < run_if_below) == (run_if_want != 0)
   const int32_t* run_if; int run_if_below, run_if_want;
+  // ... and hands the frame what it matched: CurrentFrame.mvpMapPoints[bestIdx] = pMP (src/ORBmatcher.cc:124, :1427) for every keypoint the search
+  // leaves with an owner, if it accepted at least ap_min_matches (Tracking.cc:907: a first search below 20 is thrown away and repeated wider)
+  uint8_t* ap_has; float* ap_world; int32_t* ap_id; uint8_t* ap_obs;
+  const float* ap_q_pos; const int32_t* ap_q_id; const uint8_t* ap_q_obs;
+  int32_t* ap_counts; int ap_min_matches, ap_is_retry;      // ap_counts: [0] n of the first search, [1] n of the search whose matches were taken, [2] retry used
 };
 
 template <class Ptr>
@@ -122,6 +127,172 @@ __device__ __forceinline__ bool gates_pass(const Problem& P, const QRec& Q, cons
     if (!((double)dsqr < 3.84 * (double)lvl[16 + oct])) return false;
   }
   return true;
+}
+
+// ---- the reference's OpenCV calls on float data, as this build restates them (see include/lld_amd.h) --------------------------
+// `R*P + t` is ONE cv::gemm: double accumulation in k order, one rounding to float
+__device__ __forceinline__ void cv_transform(const lld_frame_view& V, const float* P, float* Pc) {
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+    Pc[r] = (float)__dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn((double)V.Rcw[3 * r], (double)P[0]), __dmul_rn((double)V.Rcw[3 * r + 1], (double)P[1])),
+                                       __dmul_rn((double)V.Rcw[3 * r + 2], (double)P[2])), (double)V.tcw[r]);
+}
+// cv::norm(a) and a.dot(b) of CV_32F vectors accumulate in double
+__device__ __forceinline__ double cv_dot3(const float* a, const float* b) {
+  return __dadd_rn(__dadd_rn(__dmul_rn((double)a[0], (double)b[0]), __dmul_rn((double)a[1], (double)b[1])), __dmul_rn((double)a[2], (double)b[2]));
+}
+__device__ __forceinline__ float cv_norm3(const float* a) { return (float)__dsqrt_rn(cv_dot3(a, a)); }
+// log(float) as the reference's libm computes it.  MapPoint::PredictScale takes ceil(log(ratio) / mfLogScaleFactor): where the quotient
+// lands on an integer, a logarithm that is one unit in the last place off moves the predicted level by one, and the device library's
+// logf and glibc's are both "within an ulp" without being the same function (found by tools/fuzz_matchers.py with FUZZ_BIG=1: one
+// level in 6128 in-view points of one scene in 100 000).  This is glibc's algorithm (sysdeps/ieee754/flt-32/e_logf.c and
+// logf_data.c, glibc >= 2.27, taken from ARM's optimized routines; constants checked against the libm.so.6 of this image, glibc 2.35):
+// x = 2^k z with z in [0x1.66p-1, 0x1.66p0), sixteen sub-intervals with 1/c and log(c) tabulated, log1p(z/c - 1) by a cubic, all in
+// double, rounded to float once.  tests/test_oracle_kat.py holds the same restatement (oracle/) against std::log(float) on this host;
+// contraction of its multiply-adds does not change the float result (0 differences in 2e8 random arguments either way).
+__device__ __forceinline__ float glibc_logf(float x) {
+  const double T[16][2] = {
+      {0x1.661ec79f8f3bep+0, -0x1.57bf7808caadep-2}, {0x1.571ed4aaf883dp+0, -0x1.2bef0a7c06ddbp-2}, {0x1.49539f0f010bp+0, -0x1.01eae7f513a67p-2},
+      {0x1.3c995b0b80385p+0, -0x1.b31d8a68224e9p-3}, {0x1.30d190c8864a5p+0, -0x1.6574f0ac07758p-3}, {0x1.25e227b0b8eap+0, -0x1.1aa2bc79c81p-3},
+      {0x1.1bb4a4a1a343fp+0, -0x1.a4e76ce8c0e5ep-4}, {0x1.12358f08ae5bap+0, -0x1.1973c5a611cccp-4}, {0x1.0953f419900a7p+0, -0x1.252f438e10c1ep-5},
+      {0x1p+0, 0x0p+0},                              {0x1.e608cfd9a47acp-1, 0x1.aa5aa5df25984p-5},  {0x1.ca4b31f026aap-1, 0x1.c5e53aa362eb4p-4},
+      {0x1.b2036576afce6p-1, 0x1.526e57720db08p-3},  {0x1.9c2d163a1aa2dp-1, 0x1.bc2860d22477p-3},   {0x1.886e6037841edp-1, 0x1.1058bc8a07ee1p-2},
+      {0x1.767dcf5534862p-1, 0x1.4043057b6ee09p-2}};
+  const double Ln2 = 0x1.62e42fefa39efp-1, A0 = -0x1.00ea348b88334p-2, A1 = 0x1.5575b0be00b6ap-2, A2 = -0x1.ffffef20a4123p-2;
+  const uint32_t ix = __float_as_uint(x);
+  if (ix == 0x3f800000u) return 0.0f;
+  if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u) return logf(x);            // zero, subnormal, negative, inf, nan: not a distance ratio
+  const uint32_t tmp = ix - 0x3f330000u;
+  const int i = (int)((tmp >> 19) & 15u), k = (int)tmp >> 23;                   // arithmetic shift
+  const double z = (double)__uint_as_float(ix - (tmp & 0xff800000u));
+  const double r = __dsub_rn(__dmul_rn(z, T[i][0]), 1.0), y0 = __dadd_rn(T[i][1], __dmul_rn((double)k, Ln2)), r2 = __dmul_rn(r, r);
+  double y = __dadd_rn(__dmul_rn(A1, r), A2);
+  y = __dadd_rn(__dmul_rn(A0, r2), y);
+  y = __dadd_rn(__dmul_rn(y, r2), __dadd_rn(y0, r));
+  return (float)y;
+}
+
+// MapPoint::PredictScale (src/MapPoint.cc:402-417): float log, float division, ceil, clamp
+__device__ __forceinline__ int predict_scale(float max_distance, float dist, const lld_frame_view& V) {
+  const float ratio = __fdiv_rn(max_distance, dist);
+  int n = (int)ceilf(__fdiv_rn(glibc_logf(ratio), V.log_scale_factor));
+  if (n < 0) n = 0; else if (n >= V.n_levels) n = V.n_levels - 1;
+  return n;
+}
+
+// Frame::isInFrustum (src/Frame.cc:333-389) for one MapPoint per lane, written straight into the query record of the search
+// kernel.  Float / double mixture as the reference's OpenCV calls (see include/lld_amd.h); every float operation is an explicit
+// round-to-nearest intrinsic, so nothing is contracted into an FMA.
+struct FrustumArgs {
+  lld_frame_view V;
+  int n;
+  const float* pos; const float* nrm; const float* maxd; const float* mind; const uint8_t* has_obs; const uint8_t* skip;
+  float scale[LLD_ORB_MAX_LEVELS];
+  float cos_limit, th;
+  QRec* q; uint8_t* in_view; float* uvr; int32_t* level; float* view_cos;
+  const lld_frame_view* view_d;          // non-null: the view lives in device memory (the pose was optimised on the device)
+};
+
+__device__ __forceinline__ void frustum_one(const FrustumArgs& F, int i) {
+  QRec Q; memset(&Q, 0, sizeof(Q));
+  Q.level_min = -1; Q.level_max = -1;
+  Q.flags = (!F.has_obs || F.has_obs[i]) ? 2 : 0;
+  bool ok = !(F.skip && F.skip[i]);
+  float u = 0.f, v = 0.f, ur = 0.f, vc = 0.f; int lvl = 0;
+  do {
+    if (!ok) break;
+    const float P[3] = {F.pos[3 * i], F.pos[3 * i + 1], F.pos[3 * i + 2]};
+    float Pc[3]; cv_transform(F.V, P, Pc);
+    ok = false;
+    if (Pc[2] < 0.0f) break;
+    const float invz = __fdiv_rn(1.0f, Pc[2]);
+    u = __fadd_rn(__fmul_rn(__fmul_rn(F.V.fx, Pc[0]), invz), F.V.cx);
+    v = __fadd_rn(__fmul_rn(__fmul_rn(F.V.fy, Pc[1]), invz), F.V.cy);
+    if (u < F.V.min_x || u > F.V.max_x) break;
+    if (v < F.V.min_y || v > F.V.max_y) break;
+    const float maxDistance = __fmul_rn(1.2f, F.maxd[i]), minDistance = __fmul_rn(0.8f, F.mind[i]);
+    const float PO[3] = {__fsub_rn(P[0], F.V.Ow[0]), __fsub_rn(P[1], F.V.Ow[1]), __fsub_rn(P[2], F.V.Ow[2])};
+    const float dist = cv_norm3(PO);
+    if (dist < minDistance || dist > maxDistance) break;
+    vc = (float)__ddiv_rn(cv_dot3(PO, F.nrm + 3 * i), (double)dist);             // PO.dot(Pn)/dist
+    if (vc < F.cos_limit) break;
+    lvl = predict_scale(F.maxd[i], dist, F.V);
+    ur = __fsub_rn(u, __fmul_rn(F.V.bf, invz));
+    ok = true;
+  } while (false);
+  if (ok) {
+    float r = ((double)vc > 0.998) ? 2.5f : 4.0f;                                // RadiusByViewingCos, src/ORBmatcher.cc:131-137
+    if (F.th != 1.0f) r = __fmul_rn(r, F.th);
+    const float radius = __fmul_rn(r, F.scale[lvl]);
+    Q.u = u; Q.v = v; Q.radius = radius; Q.ur = ur; Q.stereo_radius = radius;
+    Q.level_min = lvl - 1; Q.level_max = lvl;
+    Q.flags |= 1;
+  }
+  F.q[i] = Q;
+  if (F.in_view) F.in_view[i] = ok ? 1 : 0;
+  if (F.uvr) { F.uvr[3 * i] = u; F.uvr[3 * i + 1] = v; F.uvr[3 * i + 2] = ur; }
+  if (F.level) F.level[i] = lvl;
+  if (F.view_cos) F.view_cos[i] = vc;
+}
+__global__ __launch_bounds__(256) void frustum_kernel(FrustumArgs F) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= F.n) return;
+  if (F.view_d) F.V = *F.view_d;
+  frustum_one(F, i);
+}
+
+// Projection loop of ORBmatcher::SearchByProjection(Current, Last, th, bMono) (src/ORBmatcher.cc:1352-1386), one lane per keypoint of
+// the last frame, written straight into the query record of the search kernel.
+struct LastFrameArgs {
+  lld_frame_view V;
+  int n, direction;
+  const float* pos; const uint8_t* valid; const int32_t* octave; const float* angle; const uint8_t* has_obs;
+  float scale[LLD_ORB_MAX_LEVELS];
+  float th;
+  QRec* q; float* uvr;
+  const lld_frame_view* view_d;
+  const int32_t* run_if; int run_if_below, run_if_want;
+  // ... and hands the frame what it matched: CurrentFrame.mvpMapPoints[bestIdx] = pMP (src/ORBmatcher.cc:124, :1427) for every keypoint the search
+  // leaves with an owner, if it accepted at least ap_min_matches (Tracking.cc:907: a first search below 20 is thrown away and repeated wider)
+  uint8_t* ap_has; float* ap_world; int32_t* ap_id; uint8_t* ap_obs;
+  const float* ap_q_pos; const int32_t* ap_q_id; const uint8_t* ap_q_obs;
+  int32_t* ap_counts; int ap_min_matches, ap_is_retry;      // ap_counts: [0] n of the first search, [1] n of the search whose matches were taken, [2] retry used
+};
+
+__device__ __forceinline__ void project_last_one(const LastFrameArgs& F, int i) {
+  QRec Q; memset(&Q, 0, sizeof(Q));
+  Q.level_min = -1; Q.level_max = -1;
+  Q.flags = (!F.has_obs || F.has_obs[i]) ? 2 : 0;
+  Q.angle = F.angle ? F.angle[i] : 0.f;
+  float u = 0.f, v = 0.f, ur = 0.f;
+  if (F.valid[i]) {
+    const float P[3] = {F.pos[3 * i], F.pos[3 * i + 1], F.pos[3 * i + 2]};
+    float Pc[3]; cv_transform(F.V, P, Pc);                                       // x3Dc = Rcw*x3Dw+tcw
+    const float invzc = (float)__ddiv_rn(1.0, (double)Pc[2]);                   // const float invzc = 1.0/x3Dc.at<float>(2);
+    if (!(invzc < 0.f)) {
+      u = __fadd_rn(__fmul_rn(__fmul_rn(F.V.fx, Pc[0]), invzc), F.V.cx);
+      v = __fadd_rn(__fmul_rn(__fmul_rn(F.V.fy, Pc[1]), invzc), F.V.cy);
+      if (!(u < F.V.min_x || u > F.V.max_x) && !(v < F.V.min_y || v > F.V.max_y)) {
+        const int oct = F.octave[i];
+        const float radius = __fmul_rn(F.th, F.scale[oct]);
+        ur = __fsub_rn(u, __fmul_rn(F.V.bf, invzc));                             // :1402
+        Q.u = u; Q.v = v; Q.radius = radius; Q.ur = ur; Q.stereo_radius = radius;
+        if (F.direction > 0) { Q.level_min = oct; Q.level_max = -1; }            // GetFeaturesInArea(u,v,radius,nLastOctave)
+        else if (F.direction < 0) { Q.level_min = 0; Q.level_max = oct; }        // (u,v,radius,0,nLastOctave)
+        else { Q.level_min = oct - 1; Q.level_max = oct + 1; }
+        Q.flags |= 1;
+      }
+    }
+  }
+  F.q[i] = Q;
+  if (F.uvr) { F.uvr[3 * i] = u; F.uvr[3 * i + 1] = v; F.uvr[3 * i + 2] = ur; }
+}
+__global__ __launch_bounds__(256) void project_last_frame_kernel(LastFrameArgs F) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= F.n) return;
+  if (F.run_if && ((*F.run_if < F.run_if_below) != (F.run_if_want != 0))) return;
+  if (F.view_d) F.V = *F.view_d;
+  project_last_one(F, i);
 }
 
 __global__ __launch_bounds__(kThreads) void orb_search_kernel(const Problem* __restrict__ problems) {
@@ -543,161 +714,22 @@ __global__ __launch_bounds__(kThreads) void orb_search_kernel(const Problem* __r
   __syncthreads();
   if (P.want_owner) for (int k = tid; k < nt; k += kThreads) P.owner[k] = owner[k];
   if (tid == 0) { P.summary[0] = ctl[1] - ctl[2]; P.summary[1] = rounds; }
-}
-
-// ---- the reference's OpenCV calls on float data, as this build restates them (see include/lld_amd.h) --------------------------
-// `R*P + t` is ONE cv::gemm: double accumulation in k order, one rounding to float
-__device__ __forceinline__ void cv_transform(const lld_frame_view& V, const float* P, float* Pc) {
-#pragma unroll
-  for (int r = 0; r < 3; r++)
-    Pc[r] = (float)__dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn((double)V.Rcw[3 * r], (double)P[0]), __dmul_rn((double)V.Rcw[3 * r + 1], (double)P[1])),
-                                       __dmul_rn((double)V.Rcw[3 * r + 2], (double)P[2])), (double)V.tcw[r]);
-}
-// cv::norm(a) and a.dot(b) of CV_32F vectors accumulate in double
-__device__ __forceinline__ double cv_dot3(const float* a, const float* b) {
-  return __dadd_rn(__dadd_rn(__dmul_rn((double)a[0], (double)b[0]), __dmul_rn((double)a[1], (double)b[1])), __dmul_rn((double)a[2], (double)b[2]));
-}
-__device__ __forceinline__ float cv_norm3(const float* a) { return (float)__dsqrt_rn(cv_dot3(a, a)); }
-// log(float) as the reference's libm computes it.  MapPoint::PredictScale takes ceil(log(ratio) / mfLogScaleFactor): where the quotient
-// lands on an integer, a logarithm that is one unit in the last place off moves the predicted level by one, and the device library's
-// logf and glibc's are both "within an ulp" without being the same function (found by tools/fuzz_matchers.py with FUZZ_BIG=1: one
-// level in 6128 in-view points of one scene in 100 000).  This is glibc's algorithm (sysdeps/ieee754/flt-32/e_logf.c and
-// logf_data.c, glibc >= 2.27, taken from ARM's optimized routines; constants checked against the libm.so.6 of this image, glibc 2.35):
-// x = 2^k z with z in [0x1.66p-1, 0x1.66p0), sixteen sub-intervals with 1/c and log(c) tabulated, log1p(z/c - 1) by a cubic, all in
-// double, rounded to float once.  tests/test_oracle_kat.py holds the same restatement (oracle/) against std::log(float) on this host;
-// contraction of its multiply-adds does not change the float result (0 differences in 2e8 random arguments either way).
-__device__ __forceinline__ float glibc_logf(float x) {
-  const double T[16][2] = {
-      {0x1.661ec79f8f3bep+0, -0x1.57bf7808caadep-2}, {0x1.571ed4aaf883dp+0, -0x1.2bef0a7c06ddbp-2}, {0x1.49539f0f010bp+0, -0x1.01eae7f513a67p-2},
-      {0x1.3c995b0b80385p+0, -0x1.b31d8a68224e9p-3}, {0x1.30d190c8864a5p+0, -0x1.6574f0ac07758p-3}, {0x1.25e227b0b8eap+0, -0x1.1aa2bc79c81p-3},
-      {0x1.1bb4a4a1a343fp+0, -0x1.a4e76ce8c0e5ep-4}, {0x1.12358f08ae5bap+0, -0x1.1973c5a611cccp-4}, {0x1.0953f419900a7p+0, -0x1.252f438e10c1ep-5},
-      {0x1p+0, 0x0p+0},                              {0x1.e608cfd9a47acp-1, 0x1.aa5aa5df25984p-5},  {0x1.ca4b31f026aap-1, 0x1.c5e53aa362eb4p-4},
-      {0x1.b2036576afce6p-1, 0x1.526e57720db08p-3},  {0x1.9c2d163a1aa2dp-1, 0x1.bc2860d22477p-3},   {0x1.886e6037841edp-1, 0x1.1058bc8a07ee1p-2},
-      {0x1.767dcf5534862p-1, 0x1.4043057b6ee09p-2}};
-  const double Ln2 = 0x1.62e42fefa39efp-1, A0 = -0x1.00ea348b88334p-2, A1 = 0x1.5575b0be00b6ap-2, A2 = -0x1.ffffef20a4123p-2;
-  const uint32_t ix = __float_as_uint(x);
-  if (ix == 0x3f800000u) return 0.0f;
-  if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u) return logf(x);            // zero, subnormal, negative, inf, nan: not a distance ratio
-  const uint32_t tmp = ix - 0x3f330000u;
-  const int i = (int)((tmp >> 19) & 15u), k = (int)tmp >> 23;                   // arithmetic shift
-  const double z = (double)__uint_as_float(ix - (tmp & 0xff800000u));
-  const double r = __dsub_rn(__dmul_rn(z, T[i][0]), 1.0), y0 = __dadd_rn(T[i][1], __dmul_rn((double)k, Ln2)), r2 = __dmul_rn(r, r);
-  double y = __dadd_rn(__dmul_rn(A1, r), A2);
-  y = __dadd_rn(__dmul_rn(A0, r2), y);
-  y = __dadd_rn(__dmul_rn(y, r2), __dadd_rn(y0, r));
-  return (float)y;
-}
-
-// MapPoint::PredictScale (src/MapPoint.cc:402-417): float log, float division, ceil, clamp
-__device__ __forceinline__ int predict_scale(float max_distance, float dist, const lld_frame_view& V) {
-  const float ratio = __fdiv_rn(max_distance, dist);
-  int n = (int)ceilf(__fdiv_rn(glibc_logf(ratio), V.log_scale_factor));
-  if (n < 0) n = 0; else if (n >= V.n_levels) n = V.n_levels - 1;
-  return n;
-}
-
-// Frame::isInFrustum (src/Frame.cc:333-389) for one MapPoint per lane, written straight into the query record of the search
-// kernel.  Float / double mixture as the reference's OpenCV calls (see include/lld_amd.h); every float operation is an explicit
-// round-to-nearest intrinsic, so nothing is contracted into an FMA.
-struct FrustumArgs {
-  lld_frame_view V;
-  int n;
-  const float* pos; const float* nrm; const float* maxd; const float* mind; const uint8_t* has_obs; const uint8_t* skip;
-  float scale[LLD_ORB_MAX_LEVELS];
-  float cos_limit, th;
-  QRec* q; uint8_t* in_view; float* uvr; int32_t* level; float* view_cos;
-  const lld_frame_view* view_d;          // non-null: the view lives in device memory (the pose was optimised on the device)
-};
-
-__global__ __launch_bounds__(256) void frustum_kernel(FrustumArgs F) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= F.n) return;
-  if (F.view_d) F.V = *F.view_d;
-  QRec Q; memset(&Q, 0, sizeof(Q));
-  Q.level_min = -1; Q.level_max = -1;
-  Q.flags = (!F.has_obs || F.has_obs[i]) ? 2 : 0;
-  bool ok = !(F.skip && F.skip[i]);
-  float u = 0.f, v = 0.f, ur = 0.f, vc = 0.f; int lvl = 0;
-  do {
-    if (!ok) break;
-    const float P[3] = {F.pos[3 * i], F.pos[3 * i + 1], F.pos[3 * i + 2]};
-    float Pc[3]; cv_transform(F.V, P, Pc);
-    ok = false;
-    if (Pc[2] < 0.0f) break;
-    const float invz = __fdiv_rn(1.0f, Pc[2]);
-    u = __fadd_rn(__fmul_rn(__fmul_rn(F.V.fx, Pc[0]), invz), F.V.cx);
-    v = __fadd_rn(__fmul_rn(__fmul_rn(F.V.fy, Pc[1]), invz), F.V.cy);
-    if (u < F.V.min_x || u > F.V.max_x) break;
-    if (v < F.V.min_y || v > F.V.max_y) break;
-    const float maxDistance = __fmul_rn(1.2f, F.maxd[i]), minDistance = __fmul_rn(0.8f, F.mind[i]);
-    const float PO[3] = {__fsub_rn(P[0], F.V.Ow[0]), __fsub_rn(P[1], F.V.Ow[1]), __fsub_rn(P[2], F.V.Ow[2])};
-    const float dist = cv_norm3(PO);
-    if (dist < minDistance || dist > maxDistance) break;
-    vc = (float)__ddiv_rn(cv_dot3(PO, F.nrm + 3 * i), (double)dist);             // PO.dot(Pn)/dist
-    if (vc < F.cos_limit) break;
-    lvl = predict_scale(F.maxd[i], dist, F.V);
-    ur = __fsub_rn(u, __fmul_rn(F.V.bf, invz));
-    ok = true;
-  } while (false);
-  if (ok) {
-    float r = ((double)vc > 0.998) ? 2.5f : 4.0f;                                // RadiusByViewingCos, src/ORBmatcher.cc:131-137
-    if (F.th != 1.0f) r = __fmul_rn(r, F.th);
-    const float radius = __fmul_rn(r, F.scale[lvl]);
-    Q.u = u; Q.v = v; Q.radius = radius; Q.ur = ur; Q.stereo_radius = radius;
-    Q.level_min = lvl - 1; Q.level_max = lvl;
-    Q.flags |= 1;
-  }
-  F.q[i] = Q;
-  if (F.in_view) F.in_view[i] = ok ? 1 : 0;
-  if (F.uvr) { F.uvr[3 * i] = u; F.uvr[3 * i + 1] = v; F.uvr[3 * i + 2] = ur; }
-  if (F.level) F.level[i] = lvl;
-  if (F.view_cos) F.view_cos[i] = vc;
-}
-
-// Projection loop of ORBmatcher::SearchByProjection(Current, Last, th, bMono) (src/ORBmatcher.cc:1352-1386), one lane per keypoint of
-// the last frame, written straight into the query record of the search kernel.
-struct LastFrameArgs {
-  lld_frame_view V;
-  int n, direction;
-  const float* pos; const uint8_t* valid; const int32_t* octave; const float* angle; const uint8_t* has_obs;
-  float scale[LLD_ORB_MAX_LEVELS];
-  float th;
-  QRec* q; float* uvr;
-  const lld_frame_view* view_d;
-  const int32_t* run_if; int run_if_below, run_if_want;
-};
-
-__global__ __launch_bounds__(256) void project_last_frame_kernel(LastFrameArgs F) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= F.n) return;
-  if (F.run_if && ((*F.run_if < F.run_if_below) != (F.run_if_want != 0))) return;
-  if (F.view_d) F.V = *F.view_d;
-  QRec Q; memset(&Q, 0, sizeof(Q));
-  Q.level_min = -1; Q.level_max = -1;
-  Q.flags = (!F.has_obs || F.has_obs[i]) ? 2 : 0;
-  Q.angle = F.angle ? F.angle[i] : 0.f;
-  float u = 0.f, v = 0.f, ur = 0.f;
-  if (F.valid[i]) {
-    const float P[3] = {F.pos[3 * i], F.pos[3 * i + 1], F.pos[3 * i + 2]};
-    float Pc[3]; cv_transform(F.V, P, Pc);                                       // x3Dc = Rcw*x3Dw+tcw
-    const float invzc = (float)__ddiv_rn(1.0, (double)Pc[2]);                   // const float invzc = 1.0/x3Dc.at<float>(2);
-    if (!(invzc < 0.f)) {
-      u = __fadd_rn(__fmul_rn(__fmul_rn(F.V.fx, Pc[0]), invzc), F.V.cx);
-      v = __fadd_rn(__fmul_rn(__fmul_rn(F.V.fy, Pc[1]), invzc), F.V.cy);
-      if (!(u < F.V.min_x || u > F.V.max_x) && !(v < F.V.min_y || v > F.V.max_y)) {
-        const int oct = F.octave[i];
-        const float radius = __fmul_rn(F.th, F.scale[oct]);
-        ur = __fsub_rn(u, __fmul_rn(F.V.bf, invzc));                             // :1402
-        Q.u = u; Q.v = v; Q.radius = radius; Q.ur = ur; Q.stereo_radius = radius;
-        if (F.direction > 0) { Q.level_min = oct; Q.level_max = -1; }            // GetFeaturesInArea(u,v,radius,nLastOctave)
-        else if (F.direction < 0) { Q.level_min = 0; Q.level_max = oct; }        // (u,v,radius,0,nLastOctave)
-        else { Q.level_min = oct - 1; Q.level_max = oct + 1; }
-        Q.flags |= 1;
+  if (P.ap_has) {
+    const int n_matches = ctl[1] - ctl[2];
+    const bool take = n_matches >= P.ap_min_matches;
+    if (tid == 0) {
+      if (!P.ap_is_retry) { P.ap_counts[0] = n_matches; if (take) { P.ap_counts[1] = n_matches; P.ap_counts[2] = 0; } }
+      else { P.ap_counts[1] = n_matches; P.ap_counts[2] = 1; }
+    }
+    if (take) {
+      for (int k = tid; k < nt; k += kThreads) {
+        const int q = owner[k];
+        if (q < 0) continue;
+        P.ap_has[k] = 1; P.ap_id[k] = P.ap_q_id[q]; P.ap_obs[k] = P.ap_q_obs ? P.ap_q_obs[q] : 1;
+        P.ap_world[3 * k] = P.ap_q_pos[3 * q]; P.ap_world[3 * k + 1] = P.ap_q_pos[3 * q + 1]; P.ap_world[3 * k + 2] = P.ap_q_pos[3 * q + 2];
       }
     }
   }
-  F.q[i] = Q;
-  if (F.uvr) { F.uvr[3 * i] = u; F.uvr[3 * i + 1] = v; F.uvr[3 * i + 2] = ur; }
 }
 
 // Projection loop of ORBmatcher::Fuse(KeyFrame*, vpMapPoints, th) (src/ORBmatcher.cc:841-890), one lane per MapPoint.
@@ -1401,9 +1433,8 @@ namespace lld_track {
 size_t orbs_problem_bytes() { return al(sizeof(Problem)); }
 size_t orbs_qrec_bytes(int nq) { return al((size_t)nq * sizeof(QRec)); }
 size_t orbs_cache_bytes(int nq) { return al((size_t)nq * 8 * kTopK); }
-
 void orbs_fill_problem(const lld_frame* f, int mode, int nq, const uint8_t* d_occupied, const void* d_qrec, const uint32_t* d_qdesc, const SearchOut& out,
-                       void* d_cache, float nnratio, int check_orientation, RunIf run_if, void* problem_h) {
+                       void* d_cache, float nnratio, int check_orientation, RunIf run_if, const ApplyDev& ap, void* problem_h) {
   Problem& P = *static_cast<Problem*>(problem_h); std::memset(&P, 0, sizeof(P));
   const lld_orb_search& c = f->consts;
   P.nt = f->nt; P.nq = nq;
@@ -1426,9 +1457,42 @@ void orbs_fill_problem(const lld_frame* f, int mode, int nq, const uint8_t* d_oc
   P.cache = static_cast<unsigned long long*>(d_cache);
   P.desc_in_lds = lds_bytes(P.nt, P.cols * P.rows, true, true) <= kLdsLimit;
   P.run_if = run_if.flag; P.run_if_below = run_if.below; P.run_if_want = run_if.want;
+  P.ap_has = ap.kp_has; P.ap_world = ap.kp_world; P.ap_id = ap.kp_id; P.ap_obs = ap.kp_obs; P.ap_q_pos = ap.q_pos; P.ap_q_id = ap.q_id; P.ap_q_obs = ap.q_obs;
+  P.ap_counts = ap.counts; P.ap_min_matches = ap.min_matches; P.ap_is_retry = ap.is_retry;
 }
 
-static int orbs_launch_search(lld_ctx* ctx, hipStream_t st, const lld_frame* f, const void* problem_d) {
+// (Round 6 also tried the projection loops as a prologue of the search kernel: one launch less, but 2500 frustum tests on ONE compute unit take
+// 38 us where ten workgroups of frustum_kernel take 11 - the chain got 30 us slower.  The projections keep their own launches.)
+int orbs_project_last_frame(hipStream_t st, const lld_frame* f, const lld_frame_view* view_h, const lld_frame_view* view_d, const LastFrameDev& last, int direction, float th,
+                            void* d_qrec, RunIf run_if) {
+  if (last.n <= 0) return LLD_OK;
+  LastFrameArgs F; std::memset(&F, 0, sizeof(F));
+  if (view_h) F.V = *view_h;
+  F.view_d = view_d; F.n = last.n; F.direction = direction;
+  F.pos = last.pos; F.valid = last.valid; F.octave = last.octave; F.angle = last.angle; F.has_obs = last.has_obs;
+  for (int l = 0; l < LLD_ORB_MAX_LEVELS; l++) F.scale[l] = l < f->consts.n_levels ? f->scale[l] : 1.f;
+  F.th = th; F.q = static_cast<QRec*>(d_qrec); F.uvr = nullptr;
+  F.run_if = run_if.flag; F.run_if_below = run_if.below; F.run_if_want = run_if.want;
+  hipLaunchKernelGGL(project_last_frame_kernel, dim3((last.n + 255) / 256), dim3(256), 0, st, F);
+  LLD_HIP_TRY(hipGetLastError());
+  return LLD_OK;
+}
+
+int orbs_project_local_points(hipStream_t st, const lld_frame* f, const lld_frame_view* view_h, const lld_frame_view* view_d, const MapPointsDev& mp, float cos_limit, float th,
+                              void* d_qrec) {
+  if (mp.n <= 0) return LLD_OK;
+  FrustumArgs F; std::memset(&F, 0, sizeof(F));
+  if (view_h) F.V = *view_h;
+  F.view_d = view_d; F.n = mp.n;
+  F.pos = mp.pos; F.nrm = mp.normal; F.maxd = mp.maxd; F.mind = mp.mind; F.has_obs = mp.has_obs; F.skip = mp.skip;
+  for (int l = 0; l < LLD_ORB_MAX_LEVELS; l++) F.scale[l] = l < f->consts.n_levels ? f->scale[l] : 1.f;
+  F.cos_limit = cos_limit; F.th = th; F.q = static_cast<QRec*>(d_qrec);
+  hipLaunchKernelGGL(frustum_kernel, dim3((mp.n + 255) / 256), dim3(256), 0, st, F);
+  LLD_HIP_TRY(hipGetLastError());
+  return LLD_OK;
+}
+
+int orbs_launch(lld_ctx* ctx, hipStream_t st, const lld_frame* f, const void* problem_d) {
   const lld_orb_search& c = f->consts;
   const bool desc_in_lds = lds_bytes(f->nt, c.grid_cols * c.grid_rows, true, true) <= kLdsLimit;
   const size_t lds = lds_bytes(f->nt, c.grid_cols * c.grid_rows, true, desc_in_lds);
@@ -1436,35 +1500,6 @@ static int orbs_launch_search(lld_ctx* ctx, hipStream_t st, const lld_frame* f, 
   hipLaunchKernelGGL(orb_search_kernel, dim3(1), dim3(kThreads), lds, st, static_cast<const Problem*>(problem_d));
   LLD_HIP_TRY(hipGetLastError());
   return LLD_OK;
-}
-
-int orbs_launch_last_frame(lld_ctx* ctx, hipStream_t st, const lld_frame* f, const lld_frame_view* view_h, const lld_frame_view* view_d, const LastFrameDev& last,
-                           int direction, float th, void* d_qrec, const void* problem_d, RunIf run_if) {
-  if (last.n > 0) {
-    LastFrameArgs F; std::memset(&F, 0, sizeof(F));
-    if (view_h) F.V = *view_h;
-    F.view_d = view_d; F.n = last.n; F.direction = direction;
-    F.pos = last.pos; F.valid = last.valid; F.octave = last.octave; F.angle = last.angle; F.has_obs = last.has_obs;
-    for (int l = 0; l < LLD_ORB_MAX_LEVELS; l++) F.scale[l] = l < f->consts.n_levels ? f->scale[l] : 1.f;
-    F.th = th; F.q = static_cast<QRec*>(d_qrec); F.uvr = nullptr;
-    F.run_if = run_if.flag; F.run_if_below = run_if.below; F.run_if_want = run_if.want;
-    hipLaunchKernelGGL(project_last_frame_kernel, dim3((last.n + 255) / 256), dim3(256), 0, st, F);
-  }
-  return orbs_launch_search(ctx, st, f, problem_d);
-}
-
-int orbs_launch_local_points(lld_ctx* ctx, hipStream_t st, const lld_frame* f, const lld_frame_view* view_h, const lld_frame_view* view_d, const MapPointsDev& mp,
-                             float cos_limit, float th, void* d_qrec, const void* problem_d) {
-  if (mp.n > 0) {
-    FrustumArgs F; std::memset(&F, 0, sizeof(F));
-    if (view_h) F.V = *view_h;
-    F.view_d = view_d; F.n = mp.n;
-    F.pos = mp.pos; F.nrm = mp.normal; F.maxd = mp.maxd; F.mind = mp.mind; F.has_obs = mp.has_obs; F.skip = mp.skip;
-    for (int l = 0; l < LLD_ORB_MAX_LEVELS; l++) F.scale[l] = l < f->consts.n_levels ? f->scale[l] : 1.f;
-    F.cos_limit = cos_limit; F.th = th; F.q = static_cast<QRec*>(d_qrec);
-    hipLaunchKernelGGL(frustum_kernel, dim3((mp.n + 255) / 256), dim3(256), 0, st, F);
-  }
-  return orbs_launch_search(ctx, st, f, problem_d);
 }
 
 }  // namespace lld_track
