@@ -589,3 +589,4 @@ int lld_frame_track_download(lld_frame* f, lld_track_result* r1, lld_track_resul
 }
 
 }  // extern "C"
+

@@ -53,6 +53,7 @@ struct Problem {
   unsigned long long* cache;   // [nq][kTopK] device scratch of sequential problems: the smallest candidate keys of round 1
   // device-resident chains (lld_frame_track_*): the whole search is skipped unless (*run_if < run_if_below) == (run_if_want != 0)
   const int32_t* run_if; int run_if_below, run_if_want;
+  const uint8_t* t_occ_obs;    // non-null: a keypoint is occupied only if t_occupied[k] AND t_occ_obs[k] (its MapPoint has observations, ORBmatcher.cc:98-100, :1409-1411)
   // ... and hands the frame what it matched: CurrentFrame.mvpMapPoints[bestIdx] = pMP (src/ORBmatcher.cc:124, :1427) for every keypoint the search
   // leaves with an owner, if it accepted at least ap_min_matches (Tracking.cc:907: a first search below 20 is thrown away and repeated wider)
   uint8_t* ap_has; float* ap_world; int32_t* ap_id; uint8_t* ap_obs;
@@ -324,7 +325,7 @@ __global__ __launch_bounds__(kThreads) void orb_search_kernel(const Problem* __r
     } else if (rows) {                                                          // bucket = (octave, image row) of the keypoint (search aid only)
       cell = min(P.t_octave[k], P.cols - 1) * P.rows + min(max((int)floorf(T.y), 0), P.rows - 1);
     }
-    T.meta = (P.t_octave[k] & 15) | (k << 4) | ((cell + 1) << 16) | ((P.t_occupied && P.t_occupied[k]) ? (1 << 29) : 0);
+    T.meta = (P.t_octave[k] & 15) | (k << 4) | ((cell + 1) << 16) | ((P.t_occupied && P.t_occupied[k] && (!P.t_occ_obs || P.t_occ_obs[k])) ? (1 << 29) : 0);
     return T;
   };
   auto place = [&](int pos, int k, const TKey& T) {
@@ -1457,6 +1458,7 @@ void orbs_fill_problem(const lld_frame* f, int mode, int nq, const uint8_t* d_oc
   P.cache = static_cast<unsigned long long*>(d_cache);
   P.desc_in_lds = lds_bytes(P.nt, P.cols * P.rows, true, true) <= kLdsLimit;
   P.run_if = run_if.flag; P.run_if_below = run_if.below; P.run_if_want = run_if.want;
+  P.t_occ_obs = ap.kp_obs;                                                      // (the frame's own flags: only a MapPoint with observations blocks its keypoint)
   P.ap_has = ap.kp_has; P.ap_world = ap.kp_world; P.ap_id = ap.kp_id; P.ap_obs = ap.kp_obs; P.ap_q_pos = ap.q_pos; P.ap_q_id = ap.q_id; P.ap_q_obs = ap.q_obs;
   P.ap_counts = ap.counts; P.ap_min_matches = ap.min_matches; P.ap_is_retry = ap.is_retry;
 }

@@ -918,6 +918,9 @@ def make_tracking_lines(scene_id, Tcw, n_map=260, n_cur=300, n_last=140, dim=72,
     inv_r = np.empty(n_cur, np.int64); inv_r[rperm] = np.arange(n_cur)
     line_matches = inv_r[perm].astype(np.int32)
     line_matches[rng.random(n_cur) < no_partner_frac] = -1
+    # a detected KeyLine lies inside its image: no negative coordinates (lld_pose_problem marks "no right line" by a negative xs, as the
+    # adapters of the reference's Frame do)
+    left = np.maximum(left, 0.5); right = np.maximum(right, 0.5)
     lines = dict(left_lines=left[perm].astype(np.float32), left_octave=lo[perm].astype(np.int32), right_lines=right[rperm].astype(np.float32),
                  right_octave=ro[rperm].astype(np.int32), line_matches=line_matches, desc=dc[perm].astype(np.float32))
     order = rng.permutation(n_map)                                           # the map's own order: not the frame's

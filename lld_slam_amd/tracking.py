@@ -43,6 +43,7 @@ class TrackedFrame:
         self.kp_has = np.zeros(F.n, bool)                        # mvpMapPoints[i] != NULL
         self.kp_world = np.zeros((F.n, 3), np.float32)           # its GetWorldPos()
         self.kp_point = np.full(F.n, -1, np.int64)               # an id of the MapPoint (caller's numbering)
+        self.kp_obs = np.zeros(F.n, bool)                        # its Observations() > 0: only such a MapPoint blocks its keypoint (src/ORBmatcher.cc:98-100)
         self.discarded = np.zeros(0, np.int64)                   # MapPoints dropped as outliers in this frame: mnLastFrameSeen = mnId (src/Tracking.cc:949)
         self.stages = {}                                         # what every stage returned, for the checker
 
@@ -69,7 +70,7 @@ class TrackedFrame:
     def track_with_motion_model(self, pose_qt_guess, last: dict, last_ids, th=7.0, direction=0):
         """SearchByProjection(Current, Last) from the predicted pose, PoseOptimization on the matches, outlier discard."""
         view = self._view(pose_qt_guess)
-        occ = self.kp_has.astype(np.uint8)
+        occ = (self.kp_has & self.kp_obs).astype(np.uint8)
         if self.res is not None:
             out, uvr = self.res.search_last_frame(view, last, occ, direction, th, True)
         else:
@@ -81,6 +82,7 @@ class TrackedFrame:
             k = int(out.match[q])
             if out.owner[k] == q:
                 self.kp_has[k] = True; self.kp_world[k] = last["world_pos"][q]; self.kp_point[k] = last_ids[q]
+                self.kp_obs[k] = True if last.get("has_obs") is None else bool(last["has_obs"][q])
         return self._optimise(pose_qt_guess, "pose_after_motion_model")
 
     def track_local_map(self, pose_qt, mp: dict, mp_ids, th=1.0, nnratio=0.8):
@@ -91,7 +93,7 @@ class TrackedFrame:
         held = np.isin(mp_ids, self.kp_point[self.kp_has]) | np.isin(mp_ids, self.discarded)
         skip = (np.asarray(mp["skip"]) != 0) | held
         mp2 = dict(mp, skip=skip.astype(np.uint8))
-        occ = self.kp_has.astype(np.uint8)
+        occ = (self.kp_has & self.kp_obs).astype(np.uint8)
         if self.res is not None:
             out, fr = self.res.search_local_points(view, mp2, occ, th, nnratio)
         else:
@@ -101,6 +103,7 @@ class TrackedFrame:
             k = int(out.match[q])
             if out.owner[k] == q:
                 self.kp_has[k] = True; self.kp_world[k] = mp["world_pos"][q]; self.kp_point[k] = mp_ids[q]
+                self.kp_obs[k] = True if mp.get("has_obs") is None else bool(mp["has_obs"][q])
         return self._optimise(pose_qt, "pose_after_local_map")
 
 

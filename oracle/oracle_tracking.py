@@ -146,10 +146,10 @@ def track_frame(sc: dict, gamma=0.5, th_motion=7.0, th_local=1.0, nnratio=0.8, w
     skip = (np.asarray(mp["skip"]) != 0) | np.isin(mp_ids, list(fr.seen_points))
     mp2 = dict(mp, skip=skip.astype(np.uint8))
     k, inv, uvr, lvl, vc = OS.is_in_frustum(fr.view, mp2)
-    occ = fr.kp_has.astype(np.uint8)
+    occ = (fr.kp_has & (fr.kp_obs != 0)).astype(np.uint8)                # if(F.mvpMapPoints[idx]) if(F.mvpMapPoints[idx]->Observations()>0) continue;  (ORBmatcher.cc:98-100)
     mp_obs = mp2.get("has_obs") if mp2.get("has_obs") is not None else np.ones(len(mp_ids), np.uint8)
     n2, slot = OS.search_by_projection_map(F, mp2["desc"], inv, uvr[:, :2], uvr[:, 2], lvl, vc, mp_obs, occ, th_local, nnratio)
-    for kk in np.nonzero((slot >= 0) & (slot < (1 << 20)))[0]:
+    for kk in np.nonzero((slot >= 0) & (slot < (1 << 20)))[0]:          # (a keypoint whose MapPoint has no observations may be taken over: the last writer stays)
         q = int(slot[kk])
         fr.kp_has[kk] = True; fr.kp_world[kk] = np.asarray(mp["world_pos"], np.float32)[q]; fr.kp_id[kk] = int(mp_ids[q]); fr.kp_obs[kk] = int(mp_obs[q])
     fr.add_lines_from(sc.get("local_lines"), thr_base, md_thr, use_grid)

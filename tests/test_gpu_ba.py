@@ -17,7 +17,12 @@ RTOL = 1e-5
 # spread).  Round 4 allowed max(4, 5 %) of the population; round 5 logs the count of every call (profiles/r05_parity_margins.txt, written
 # through gpurun_out/ by the fixture below) and holds it to the largest count observed + 1.
 MAX_EXCUSED_LANDMARKS = 6
+# LM iterations (both rounds together) of the device against the oracle's: a trial whose gain is zero to rounding ends a round one iteration
+# earlier or later.  Logged per check_ba call; held to the largest difference seen (exact solvers) / seen with a `tail` (iterative solver,
+# unordered accumulators).
+MAX_LM_IT_DIFF, MAX_LM_IT_DIFF_NOISY = 1, 2
 _MARGIN_LOG = []
+_LM_LOG = []
 
 
 def _log_margin(kind, n_beyond, n, worst):
@@ -35,6 +40,13 @@ def _write_margin_log():
         with open(os.path.join(d, "parity_margins_test_gpu_ba.txt"), "w") as f:
             f.write("# per check_ba call of tests/test_gpu_ba.py: landmarks beyond 1e-5 relative of the oracle (each within 10x the oracle's twin spread, or the test fails)\n")
             f.write("\n".join(_MARGIN_LOG) + "\n")
+    if _LM_LOG and os.path.isdir(d):
+        with open(os.path.join(d, "lm_counts_test_gpu_ba.txt"), "w") as f:
+            f.write("# per check_ba call of tests/test_gpu_ba.py: device minus oracle, LM iterations and LM trials (both rounds summed), tail\n")
+            for a, b, t in _LM_LOG: f.write(f"{a:+d} {b:+d} {t}\n")
+            ex = [(a, b) for a, b, t in _LM_LOG if t == "-"]; nz = [(a, b) for a, b, t in _LM_LOG if t != "-"]
+            f.write(f"# exact solvers: {len(ex)} calls, max |iterations| {max([abs(a) for a, _ in ex] or [0])}, max |trials| {max([abs(b) for _, b in ex] or [0])}, calls with any difference {sum(1 for a, b in ex if a or b)}\n")
+            f.write(f"# with a tail (pcg / shared accumulators): {len(nz)} calls, max |iterations| {max([abs(a) for a, _ in nz] or [0])}, max |trials| {max([abs(b) for _, b in nz] or [0])}\n")
 
 
 def landmark_rel(a, b):
@@ -107,8 +119,11 @@ def check_ba(g, o, w, rtol=RTOL, pt_floor=None, tail=None, twins=None):
             assert np.all(dn <= np.maximum(rtol, 10 * floor)) and (dn > rtol).sum() <= MAX_EXCUSED_LANDMARKS, (float(dn.max()), int(np.argmax(dn)), float(floor[int(np.argmax(dn))]))
         else:
             assert dn.max() <= (10 * rtol if noisy else rtol)
-    # same LM trajectory up to decisions taken on rounding-level chi2 differences at convergence
-    assert abs(sum(g.stats["lm_iterations"]) - sum(o.stats["lm_iterations"])) <= 2
+    # same LM trajectory up to decisions taken on rounding-level chi2 differences at convergence: the differences actually seen are logged
+    # (round 6, profiles/r06_parity_margins.txt) and held to their maximum, MAX_LM_IT_DIFF
+    d_it = sum(g.stats["lm_iterations"]) - sum(o.stats["lm_iterations"]); d_tr = sum(g.stats["lm_trials"]) - sum(o.stats["lm_trials"])
+    _LM_LOG.append((d_it, d_tr, tail or "-"))
+    assert abs(d_it) <= (MAX_LM_IT_DIFF_NOISY if noisy else MAX_LM_IT_DIFF), (d_it, d_tr)
     np.testing.assert_array_equal(g.cam_qt[w.n_free_cams:], w.cam_qt[w.n_free_cams:])      # fixed cameras untouched
 
 

@@ -18,8 +18,26 @@ def _check(g, o, n_points):
     np.testing.assert_allclose(g.pose_qt, o.pose_qt, rtol=RTOL, atol=1e-7)
     assert g.chi2 == pytest.approx(o.chi2, rel=RTOL)
     # LM accept/reject decisions at convergence hinge on chi2 differences at rounding level (rho ~ 0/0), so the trial
-    # count may differ by a few while the result does not
-    assert abs(g.lm_iterations - o.lm_iterations) <= 2 and abs(g.lm_trials - o.lm_trials) <= 10
+    # count may differ by a few while the result does not: the differences actually seen are logged (gpurun_out/lm_counts_test_gpu_pose.txt
+    # -> profiles/r06_parity_margins.txt) and held to their maximum
+    _LM_LOG.append((g.lm_iterations - o.lm_iterations, g.lm_trials - o.lm_trials))
+    assert abs(g.lm_iterations - o.lm_iterations) <= MAX_IT_DIFF and abs(g.lm_trials - o.lm_trials) <= MAX_TRIAL_DIFF, _LM_LOG[-1]
+
+
+MAX_IT_DIFF, MAX_TRIAL_DIFF = 2, 10
+_LM_LOG = []
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _write_lm_log():
+    yield
+    import os
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if _LM_LOG and os.path.isdir(d):
+        with open(os.path.join(d, "lm_counts_test_gpu_pose.txt"), "w") as f:
+            f.write("# per _check call of tests/test_gpu_pose.py: device minus oracle, LM iterations and trials\n")
+            for a, b in _LM_LOG: f.write(f"{a:+d} {b:+d}\n")
+            f.write(f"# {len(_LM_LOG)} calls, max |iterations| {max(abs(a) for a, _ in _LM_LOG)}, max |trials| {max(abs(b) for _, b in _LM_LOG)}, calls with any difference {sum(1 for a, b in _LM_LOG if a or b)}\n")
 
 
 @pytest.mark.parametrize("fid,kw", [

@@ -1,7 +1,7 @@
 """lld_frame_track_*: the Tracking thread's per-frame chain as one device-resident sequence, lines included (src/Tracking.cc:885-994 and
 :1126-1220), against the oracle's OWN run of the whole sequence (oracle/oracle_tracking.py: nothing of the device chain's intermediate
 state is handed to the checker).  Per stage: the MapPoint / MapLine id of every keypoint / line and every outlier flag bit-exact, every
-counter equal, pose and chi2 to 1e-5 relative (north_star's bar), LM iteration / trial counts within the logged rounding slack."""
+counter equal, pose to 1e-7 and chi2 to 1e-9 relative (north_star's bar: 1e-5), LM iteration / trial counts within the logged rounding slack."""
 import numpy as np
 import pytest
 
@@ -12,14 +12,17 @@ from lld_slam_amd.tracking import DeviceTrackedFrame, TrackedFrame
 pytestmark = pytest.mark.gpu
 
 COUNTERS = ("n_inliers", "n_edges", "n_search_first", "n_search", "used_wide", "n_points", "n_points_map", "n_lines_matched", "n_lines", "n_discarded")
-POSE_RTOL = 1e-5            # north_star: final pose within 1e-5 relative
+# north_star's bar is 1e-5 relative on pose and chi2.  Held here to what the chain actually reaches against the oracle's own run, with two
+# orders of margin: 38 records of this file max |dq| 7e-15, |dt| / max(1, |t|) 1e-13, chi2 5e-13; tools/fuzz_track_chain.py, 800 records
+# (profiles/r06_fuzz_track_chain_*.txt): 7e-11, 4e-9, 8e-13 - also where the LM counts below differ.
+POSE_TOL, CHI2_TOL = 1e-7, 1e-9
 # LM iterations / trials of a stage against the oracle's.  Once a round has converged, whether a trial "improves" chi2 is decided by the last
 # bits of two sums that the device adds in another order than the oracle: a round then ends one way (ten rejected trials, levenberg.cpp:149-160)
 # or the other (three iterations below 1e-3 relative gain, the nBadLM rule of this fork), and a stuck iteration spends between one and ten
-# trials - same pose to 1e-6 of its norm, other counts (tools/experiments/exp_chain_pose_trials.py walks one such frame round by round).
+# trials - same pose to 1e-13 here, other counts (tools/experiments/exp_chain_pose_trials.py walks one such frame round by round).
 # Held to the maximum seen over the 38 records of this file, 28 of which are equal (gpurun_out/track_chain_lm_counts.txt ->
 # profiles/r06_parity_margins.txt).
-LM_IT_SLACK, LM_TRIAL_SLACK = 3, 18
+LM_IT_SLACK, LM_TRIAL_SLACK = 3, 8
 LM_LOG = []
 POSE_LOG = []
 
@@ -43,18 +46,13 @@ def same_record(g, e, exact_pose=False):
     if exact_pose:
         np.testing.assert_array_equal(g["pose_qt"], e["pose_qt"]); assert g["chi2"] == e["chi2"]
     else:
-        # north_star's bar: 1e-5 relative - of the unit quaternion per component, of the translation against its norm (a component that happens
-        # to be small is not held to five digits of ITSELF), of chi2
+        # the unit quaternion per component, the translation against its norm, chi2 relative
         dq = float(np.max(np.abs(g["pose_qt"][:4] - e["pose_qt"][:4])))
         dt = float(np.linalg.norm(g["pose_qt"][4:] - e["pose_qt"][4:]) / max(1.0, np.linalg.norm(e["pose_qt"][4:])))
         dc = abs(g["chi2"] - e["chi2"]) / max(abs(e["chi2"]), 1e-12)
-        # chi2 is the LM cost where the LAST round stopped.  When the round stops at another iteration on the two sides (see LM_IT_SLACK below:
-        # a stuck iteration - every damped step rejected because the robustified cost and the rho'-weighted model disagree - is accepted or
-        # given up on the last bits of two sums) the two costs are costs of different iterates of a sequence that still moves in its fourth
-        # digit: the pose bar stays, the cost bar is that of one LM iteration's gain (the nBadLM stop rule: 1e-3).
         same_path = g["lm_iterations"] == e["lm_iterations"] and g["lm_trials"] == e["lm_trials"]
         POSE_LOG.append((dq, dt, dc, same_path))
-        assert dq <= POSE_RTOL and dt <= POSE_RTOL and dc <= (POSE_RTOL if same_path else 1e-3), (dq, dt, dc, same_path)
+        assert dq <= POSE_TOL and dt <= POSE_TOL and dc <= CHI2_TOL, (dq, dt, dc, same_path)
     if exact_pose:
         assert g["lm_iterations"] == e["lm_iterations"] and g["lm_trials"] == e["lm_trials"]
         return
