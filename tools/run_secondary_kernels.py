@@ -12,3 +12,15 @@ if __name__ == "__main__":
     torch.cuda.set_device(0)
     with Context(0) as ctx:
         print(json.dumps(bench.secondary_block(ctx, torch.device("cuda", 0), repeats=3)))
+        # round 6: the frame-rate path as well - 20 single-frame PoseOptimization calls (config PO) and 20 frames of the device-resident
+        # Tracking chain (lld_frame_track_*: orb_search_kernel, line kernels, pose_assemble / pose_opt_kernel<512>, track_* kernels)
+        from lld_slam_amd import Optimizer, synth
+        from lld_slam_amd.tracking import DeviceTrackedFrame
+        f = synth.make_pose_frame(0)
+        for _ in range(20): Optimizer(ctx).PoseOptimization(f, gamma=0.5)
+        sc = synth.make_tracking_scene(0)
+        with DeviceTrackedFrame(ctx, sc["frame"], sc["cam"], sc["lines"]) as tf:
+            for _ in range(20):
+                tf.track_with_motion_model(sc["Tcw_guess"], sc["last"], sc["last_ids"], sc["last_lines"])
+                tf.track_local_map(sc["map_points"], sc["map_ids"], sc["local_lines"])
+                tf.download()
