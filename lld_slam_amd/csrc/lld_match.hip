@@ -399,53 +399,106 @@ __global__ __launch_bounds__(64) void line_candidates_kernel(LineGateParams P, c
   if (lane == 0) { cand[j].n = n; cand[j].pad = 0; }
 }
 
-// The greedy, order-dependent assignment ("left line j takes its best right line that no EARLIER left line took") by fixed-point rounds, as
-// the guided ORB search resolves its occupancy (lld_orb_search.hip): a round lets every line pick, in parallel, the first entry of its short
-// list that no line with a smaller index picked in the round before; blk[c] = the smallest index that picks c.  Line 0 is final after one
-// round, line j after j + 1 at the latest, and a round that changes nothing has reached the sequential answer - in practice 3 to 6 rounds of
-// a few hundred cycles, where the one-wavefront walk of rounds 2 - 5 paid ~400 cycles per LINE (45 us for 260 map lines).  A list that is
-// full and completely taken falls back to a scan of the stored row like the reference does.  One workgroup; LDS: blk[nt] + pick[nq] ints.
+// The greedy, order-dependent assignment ("left line j takes its best right line that no EARLIER left line took").  Two regimes:
+//   * fixed-point rounds, as the guided ORB search resolves its occupancy (lld_orb_search.hip): a round lets every line pick, in parallel, the
+//     first entry of its short list that no line with a smaller index picked in the round before; blk[c] = the smallest index that picks c.
+//     Line 0 is final after one round, line j after j + 1 at the latest, and a round that changes nothing has reached the sequential answer.
+//     AddLinesFrom's sparse candidate sets converge in 3 - 6 rounds of a few hundred cycles (the one-wavefront walk of rounds 2 - 5 paid
+//     ~400 cycles per LINE: 45 us for 260 map lines, now 5);
+//   * where the rounds do NOT converge quickly - the stereo matcher with its wide tau: unrelated lines take over partners of later lines and
+//     the corrections ripple down one line per round (300 x 300: ~300 rounds, 340 us) - the kernel stops after kResolveRounds rounds and ONE
+//     wavefront walks the rest in order: every line below the smallest index that changed in the last round is final (its inputs, the picks of
+//     the lines before it, did not change, nor did its own), so the walk starts there with their picks as the taken set.
+// A list that is full and completely taken falls back to a scan of the stored row like the reference does.  One workgroup; LDS: blk[nt] + pick[nq].
 constexpr int kResolveThreads = 256;
+constexpr int kResolveRounds = 8;
 inline size_t line_resolve_lds(int nq, int nt) { return ((size_t)nq + (size_t)nt) * 4 + 16; }
 static int line_resolve_prepare(int nq, int nt);      // raises the kernel's dynamic-LDS ceiling when blk + pick need more than the default (defined after the kernel)
 __global__ __launch_bounds__(kResolveThreads) void line_resolve_kernel(const LineCand* __restrict__ cand, const double* __restrict__ dmat, const uint8_t* __restrict__ gate,
                                                                       int nq, int nt, double tau, int* __restrict__ matches, double* __restrict__ match_dist,
                                                                       lld_track::LineApplyDev ap, const double* __restrict__ map_x0, const double* __restrict__ map_dir) {
   extern __shared__ __attribute__((aligned(16))) int res_lds[];
-  __shared__ int changed;
+  __shared__ int changed_min, scan_min;
+  __shared__ int clist[kResolveThreads][kLineTopK + 1];  // the ordered walk's candidate lists, a chunk of lines at a time
   int* blk = res_lds; int* pick = res_lds + nt;
   const int tid = threadIdx.x;
-  for (int i = tid; i < nt; i += kResolveThreads) blk[i] = 0x7fffffff;
+  constexpr int kFree = 0x7fffffff;
+  for (int i = tid; i < nt; i += kResolveThreads) blk[i] = kFree;
   for (int j = tid; j < nq; j += kResolveThreads) pick[j] = -1;
-  if (tid == 0) changed = 0;
+  if (tid == 0) { changed_min = kFree; scan_min = kFree; }
   __syncthreads();
-  for (;;) {
+  int walk_from = kFree;                                  // < kFree: lines from this index on are walked in order
+  for (int round = 0;; round++) {
     for (int j = tid; j < nq; j += kResolveThreads) {
       const LineCand& C = cand[j];
       const int n = C.n;
       int bi = -1;
       for (int k = 0; k < n; k++) { const int c = C.idx[k]; if (blk[c] >= j) { bi = c; break; } }
-      if (bi < 0 && n == kLineTopK) {
-        // every listed candidate is taken and the list was cut: the row as the reference scans it (strict '<' in index order)
-        double sd = kInfD;
-        for (int oi = 0; oi < nt; oi++) {
-          if (blk[oi] < j) continue;
-          if (gate && !gate[(size_t)j * nt + oi]) continue;
-          const double d = dmat[(size_t)j * nt + oi];
-          if (d < tau && d < sd) { sd = d; bi = oi; }
-        }
-      }
-      if (bi != pick[j]) { pick[j] = bi; changed = 1; }
+      // every listed candidate taken and the list was cut: this line needs a scan of its stored row, which only the ordered walk does
+      // (with the wavefront's 64 lanes and the FINAL taken set); the line and everything after it is left to the walk
+      if (bi < 0 && n == kLineTopK) atomicMin(&scan_min, j);
+      if (bi != pick[j]) { pick[j] = bi; atomicMin(&changed_min, j); }
     }
     __syncthreads();
-    const int any = changed;
-    if (!any) break;
-    for (int i = tid; i < nt; i += kResolveThreads) blk[i] = 0x7fffffff;
+    const int first_changed = changed_min, first_scan = scan_min;
+    if (first_changed == kFree || first_changed >= first_scan) { walk_from = first_scan; break; }     // converged (below the first line that needs a row scan)
+    if (round + 1 >= kResolveRounds) walk_from = min(first_changed, first_scan);
+    __syncthreads();
+    for (int i = tid; i < nt; i += kResolveThreads) blk[i] = kFree;
+    if (tid == 0) { changed_min = kFree; scan_min = kFree; }
     __syncthreads();
     for (int j = tid; j < nq; j += kResolveThreads) { const int c = pick[j]; if (c >= 0) atomicMin(&blk[c], j); }
-    if (tid == 0) changed = 0;
     __syncthreads();
+    if (walk_from != kFree) break;
   }
+  if (walk_from != kFree) {
+    // the taken set of the walk: the (final) picks of the lines below walk_from
+    __syncthreads();
+    for (int i = tid; i < nt; i += kResolveThreads) blk[i] = kFree;
+    __syncthreads();
+    for (int j = tid; j < min(walk_from, nq); j += kResolveThreads) { const int c = pick[j]; if (c >= 0) blk[c] = j; }
+    for (int j0 = walk_from; j0 < nq; j0 += kResolveThreads) {
+      const int nj = min(kResolveThreads, nq - j0);
+      __syncthreads();
+      if (tid < nj) {
+        const LineCand& C = cand[j0 + tid];
+#pragma unroll
+        for (int k = 0; k < kLineTopK; k++) clist[tid][k] = C.idx[k];
+        clist[tid][kLineTopK] = C.n;
+      }
+      __syncthreads();
+      if (tid < 64) {
+        const int lane = tid;
+        for (int jj = 0; jj < nj; jj++) {
+          const int j = j0 + jj;
+          const int n = clist[jj][kLineTopK];
+          const int my_i = lane < n ? clist[jj][lane] : 0;
+          const bool free_ = lane < n && blk[my_i] == kFree;
+          const unsigned long long mask = __ballot(free_);
+          int bi = -1;
+          if (mask) bi = __builtin_amdgcn_readlane(my_i, __ffsll((long long)mask) - 1);
+          else if (n == kLineTopK) {
+            double sd = kInfD; int si = kFree;
+            for (int oi = lane; oi < nt; oi += 64) {
+              if (blk[oi] != kFree) continue;
+              if (gate && !gate[(size_t)j * nt + oi]) continue;
+              const double d = dmat[(size_t)j * nt + oi];
+              if (d < tau && d < sd) { sd = d; si = oi; }
+            }
+            for (int off = 32; off > 0; off >>= 1) {
+              const double od = __shfl_xor(sd, off); const int oidx = __shfl_xor(si, off);
+              if (od < sd || (od == sd && oidx < si)) { sd = od; si = oidx; }
+            }
+            if (si != kFree) bi = si;
+          }
+          if (lane == 0) { pick[j] = bi; if (bi >= 0) blk[bi] = j; }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // (one wavefront: its LDS operations retire in order; this keeps the compiler from moving the next reads up)
+          __builtin_amdgcn_wave_barrier();
+        }
+      }
+    }
+  }
+  __syncthreads();
   for (int j = tid; j < nq; j += kResolveThreads) {
     const int bi = pick[j];
     matches[j] = bi;

@@ -24,7 +24,7 @@ def _check(g, o, n_points):
     assert abs(g.lm_iterations - o.lm_iterations) <= MAX_IT_DIFF and abs(g.lm_trials - o.lm_trials) <= MAX_TRIAL_DIFF, _LM_LOG[-1]
 
 
-MAX_IT_DIFF, MAX_TRIAL_DIFF = 2, 10
+MAX_IT_DIFF, MAX_TRIAL_DIFF = 0, 2                  # seen on HEAD over the 66 calls of this file: iterations equal everywhere, trials differ by <= 2 in 4 calls
 _LM_LOG = []
 
 
