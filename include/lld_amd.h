@@ -833,11 +833,15 @@ typedef struct {
   int32_t n_lines_matched;          /* MapLines the frame held when PoseOptimization started (lcnt_init / lcnt, :926-932, :1142-1149)                */
   int32_t n_lines;                  /* ... and after the outlier lines left (:962-975, :1176-1187)                                                   */
   int32_t n_discarded;
+  int32_t n_point_edges;            /* nInitialCorrespondences of the stage's PoseOptimization (below 3 it returned without touching the pose, Optimizer.cc:809) */
+  int32_t n_in_view;                /* stage 2: nToMatch of SearchLocalPoints (local MapPoints inside the frustum, src/Tracking.cc:1645-1649)              */
   /* caller-allocated, any may be NULL.  Ids / flags as the stage's PoseOptimization saw them, BEFORE its discard:                                   */
   int32_t* kp_point_id;             /* [nt] id of mvpMapPoints[k] or -1                                                                              */
   uint8_t* kp_outlier;              /* [nt] mvbOutlier[k] of those (the discard removes exactly the flagged ones)                                    */
   int32_t* ln_line_id;              /* [n_left] id of mvpMapLines[i] or -1                                                                           */
   uint8_t* ln_outlier;              /* [n_left] mvbOutlierLines[i] of those                                                                          */
+  uint8_t* mp_in_view;              /* stage 2 only, [local_points->n] or NULL: Frame::isInFrustum of every local MapPoint that was not skipped (what the
+                                       reference leaves in pMP->mbTrackInView and counts with IncreaseVisible, src/Tracking.cc:1645-1649)            */
 } lld_track_result;
 /* Stage 1.  `view`: Frame::UpdatePoseMatrices of the predicted pose mVelocity * mLastFrame.mTcw (as for lld_frame_search_last_frame);
  * `pose_qt`: Converter::toSE3Quat of the same matrix (lld_se3_from_tcw_f32).  last / last_point_id: LastFrame.mvpMapPoints as for

@@ -28,8 +28,8 @@ using namespace lld_track;
 constexpr int kRecInts = 16;
 struct RecHeader { double pose_qt[7]; double chi2; int32_t i[kRecInts]; };
 // i[]: 0 n_inliers, 1 lm_iterations, 2 lm_trials, 3 n_edges, 4 n_search_first, 5 n_search, 6 used_wide, 7 n_points, 8 n_points_map,
-//      9 n_lines_matched, 10 n_lines, 11 n_discarded
-enum { RI_INL = 0, RI_ITS, RI_TRIALS, RI_EDGES, RI_SEARCH1, RI_SEARCH, RI_WIDE, RI_POINTS, RI_POINTS_MAP, RI_LINES_MATCHED, RI_LINES, RI_DISCARDED };
+//      9 n_lines_matched, 10 n_lines, 11 n_discarded, 12 n_point_edges, 13 n_in_view
+enum { RI_INL = 0, RI_ITS, RI_TRIALS, RI_EDGES, RI_SEARCH1, RI_SEARCH, RI_WIDE, RI_POINTS, RI_POINTS_MAP, RI_LINES_MATCHED, RI_LINES, RI_DISCARDED, RI_POINT_EDGES, RI_IN_VIEW };
 
 struct TrackDev {                 // device pointers of the frame's tracking state (all inside lld_frame_track_state::d_state)
   int nt, nl, nr, dim;
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(1024) void track_after_pose_kernel(TrackDev D, View
     RecHeader& H = *D.rec_h[stage];
     for (int c = 0; c < 7; c++) H.pose_qt[c] = D.pose_out[c];
     H.chi2 = D.pose_out[7];
-    H.i[RI_INL] = pi[0]; H.i[RI_ITS] = pi[1]; H.i[RI_TRIALS] = pi[2]; H.i[RI_EDGES] = pi[3];
+    H.i[RI_INL] = pi[0]; H.i[RI_ITS] = pi[1]; H.i[RI_TRIALS] = pi[2]; H.i[RI_EDGES] = pi[3]; H.i[RI_POINT_EDGES] = pi[4];
     // pFrame->SetPose(pose) - unless PoseOptimization returned before it optimised (fewer than three points, Optimizer.cc:809-810)
     if (pi[4] >= 3) view_from_pose(D.pose_out, C, D.view, D.line_params, D.pose_qt);
   }
@@ -218,6 +218,7 @@ struct lld_frame_track_state {
   char* h_rec = nullptr; size_t h_rec_bytes = 0;
   ViewConsts consts{};
   bool stage1_queued = false;
+  size_t in_view_off = 0; int n_in_view = 0;   // Frame::isInFrustum flags of stage 2's local MapPoints, inside d_work
 };
 
 namespace lld_track {
@@ -488,7 +489,7 @@ int lld_frame_track_motion_model(lld_frame* f, const lld_track_params* P, const 
   }
   s = run_lines(f, st, P, n_map ? last_lines : nullptr, d, U, reinterpret_cast<const uint8_t*>(d + U.skip), d + o_lwork, 0); if (s) return s;
   s = run_pose(f, st, P, d + o_pwork, 0); if (s) return s;
-  S->stage1_queued = true;
+  S->stage1_queued = true; S->n_in_view = 0;
   return LLD_OK;
 }
 
@@ -512,7 +513,7 @@ int lld_frame_track_local_map(lld_frame* f, const lld_track_params* P, const lld
   LinesUp U{}; lay_lines(o, n_map, S->dim, &U, nullptr);
   const size_t up_bytes = o;
   U.matches = take((size_t)std::max(n_map, 1) * 4);
-  const size_t o_skip2 = take(nq), o_lskip2 = take(std::max(n_map, 1));
+  const size_t o_skip2 = take(nq), o_lskip2 = take(std::max(n_map, 1)), o_inview = take(std::max(nq, 1));
   size_t o_so[6];
   o_so[0] = take((size_t)nq * 4); o_so[1] = take((size_t)nq * 4); o_so[2] = take((size_t)nq * 4); o_so[3] = take(nq); o_so[4] = take((size_t)nt * 4); o_so[5] = take(16);
   const size_t o_qrec = take(orbs_qrec_bytes(nq)), o_cache = take(orbs_cache_bytes(nq));
@@ -550,7 +551,9 @@ int lld_frame_track_local_map(lld_frame* f, const lld_track_params* P, const lld
                          reinterpret_cast<const uint8_t*>(d + o_skip), reinterpret_cast<uint8_t*>(d + o_skip2), n_map, reinterpret_cast<const int32_t*>(d + U.id),
                          reinterpret_cast<const uint8_t*>(d + U.skip), reinterpret_cast<uint8_t*>(d + o_lskip2), psize - 1, lsize - 1);
   }
-  s = orbs_project_local_points(st, f, nullptr, S->D.view, MP, P->viewing_cos_limit, P->th_local, d + o_qrec); if (s) return s;
+  S->in_view_off = o_inview; S->n_in_view = nq;
+  s = orbs_project_local_points(st, f, nullptr, S->D.view, MP, P->viewing_cos_limit, P->th_local, d + o_qrec, reinterpret_cast<uint8_t*>(d + o_inview),
+                                S->D.rec_h[1]->i + RI_IN_VIEW); if (s) return s;
   s = orbs_launch(ctx, st, f, d + o_prob); if (s) return s;
   s = run_lines(f, st, P, n_map ? local_lines : nullptr, d, U, reinterpret_cast<const uint8_t*>(d + o_lskip2), d + o_lwork, 1); if (s) return s;
   s = run_pose(f, st, P, d + o_pwork, 1); if (s) return s;
@@ -561,14 +564,18 @@ int lld_frame_track_download(lld_frame* f, lld_track_result* r1, lld_track_resul
   if (!f || !f->track || !f->track->stage1_queued) return LLD_ERR_INVALID;
   lld_frame_track_state* S = f->track; lld_ctx* ctx = f->ctx;
   LLD_HIP_TRY(hipSetDevice(ctx->device));
-  if (S->rec_bytes > S->h_rec_bytes) {
+  const bool want_view = r2 && r2->mp_in_view && S->n_in_view > 0;
+  const size_t need = S->rec_bytes + (want_view ? (size_t)S->n_in_view : 0);
+  if (need > S->h_rec_bytes) {
     if (S->h_rec) LLD_HIP_TRY(hipHostFree(S->h_rec));
     S->h_rec = nullptr; S->h_rec_bytes = 0;
-    LLD_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&S->h_rec), S->rec_bytes + 4096, hipHostMallocDefault));
-    S->h_rec_bytes = S->rec_bytes + 4096;
+    LLD_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&S->h_rec), need + 4096, hipHostMallocDefault));
+    S->h_rec_bytes = need + 4096;
   }
   LLD_HIP_TRY(hipMemcpyAsync(S->h_rec, S->d_state + S->rec_off, S->rec_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  if (want_view) LLD_HIP_TRY(hipMemcpyAsync(S->h_rec + S->rec_bytes, S->d_work + S->in_view_off, (size_t)S->n_in_view, hipMemcpyDeviceToHost, ctx->stream));
   LLD_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (want_view) std::memcpy(r2->mp_in_view, S->h_rec + S->rec_bytes, (size_t)S->n_in_view);
   const TrackDev& D = S->D;
   lld_track_result* rr[2] = {r1, r2};
   for (int s = 0; s < 2; s++) {
@@ -580,6 +587,7 @@ int lld_frame_track_download(lld_frame* f, lld_track_result* r1, lld_track_resul
     r->n_inliers = H->i[RI_INL]; r->lm_iterations = H->i[RI_ITS]; r->lm_trials = H->i[RI_TRIALS]; r->n_edges = H->i[RI_EDGES];
     r->n_search_first = H->i[RI_SEARCH1]; r->n_search = H->i[RI_SEARCH]; r->used_wide = H->i[RI_WIDE]; r->n_points = H->i[RI_POINTS];
     r->n_points_map = H->i[RI_POINTS_MAP]; r->n_lines_matched = H->i[RI_LINES_MATCHED]; r->n_lines = H->i[RI_LINES]; r->n_discarded = H->i[RI_DISCARDED];
+    r->n_point_edges = H->i[RI_POINT_EDGES]; r->n_in_view = H->i[RI_IN_VIEW];
     if (r->kp_point_id && D.nt) std::memcpy(r->kp_point_id, at(D.rec_kp_id[s]), (size_t)D.nt * 4);
     if (r->kp_outlier && D.nt) std::memcpy(r->kp_outlier, at(D.rec_kp_out[s]), D.nt);
     if (r->ln_line_id && D.nl) std::memcpy(r->ln_line_id, at(D.rec_ln_id[s]), (size_t)D.nl * 4);

@@ -192,9 +192,10 @@ struct FrustumArgs {
   float cos_limit, th;
   QRec* q; uint8_t* in_view; float* uvr; int32_t* level; float* view_cos;
   const lld_frame_view* view_d;          // non-null: the view lives in device memory (the pose was optimised on the device)
+  int32_t* n_in_view;                    // non-null: += the number of points inside the frustum
 };
 
-__device__ __forceinline__ void frustum_one(const FrustumArgs& F, int i) {
+__device__ __forceinline__ bool frustum_one(const FrustumArgs& F, int i) {
   QRec Q; memset(&Q, 0, sizeof(Q));
   Q.level_min = -1; Q.level_max = -1;
   Q.flags = (!F.has_obs || F.has_obs[i]) ? 2 : 0;
@@ -234,12 +235,19 @@ __device__ __forceinline__ void frustum_one(const FrustumArgs& F, int i) {
   if (F.uvr) { F.uvr[3 * i] = u; F.uvr[3 * i + 1] = v; F.uvr[3 * i + 2] = ur; }
   if (F.level) F.level[i] = lvl;
   if (F.view_cos) F.view_cos[i] = vc;
+  return ok;
 }
 __global__ __launch_bounds__(256) void frustum_kernel(FrustumArgs F) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= F.n) return;
-  if (F.view_d) F.V = *F.view_d;
-  frustum_one(F, i);
+  bool ok = false;
+  if (i < F.n) {
+    if (F.view_d) F.V = *F.view_d;
+    ok = frustum_one(F, i);
+  }
+  if (F.n_in_view) {                                                            // nToMatch (src/Tracking.cc:1647), one atomic per wavefront
+    const unsigned long long m = __ballot(ok);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(F.n_in_view, __popcll(m));
+  }
 }
 
 // Projection loop of ORBmatcher::SearchByProjection(Current, Last, th, bMono) (src/ORBmatcher.cc:1352-1386), one lane per keypoint of
@@ -1481,14 +1489,14 @@ int orbs_project_last_frame(hipStream_t st, const lld_frame* f, const lld_frame_
 }
 
 int orbs_project_local_points(hipStream_t st, const lld_frame* f, const lld_frame_view* view_h, const lld_frame_view* view_d, const MapPointsDev& mp, float cos_limit, float th,
-                              void* d_qrec) {
+                              void* d_qrec, uint8_t* d_in_view, int32_t* d_n_in_view) {
   if (mp.n <= 0) return LLD_OK;
   FrustumArgs F; std::memset(&F, 0, sizeof(F));
   if (view_h) F.V = *view_h;
   F.view_d = view_d; F.n = mp.n;
   F.pos = mp.pos; F.nrm = mp.normal; F.maxd = mp.maxd; F.mind = mp.mind; F.has_obs = mp.has_obs; F.skip = mp.skip;
   for (int l = 0; l < LLD_ORB_MAX_LEVELS; l++) F.scale[l] = l < f->consts.n_levels ? f->scale[l] : 1.f;
-  F.cos_limit = cos_limit; F.th = th; F.q = static_cast<QRec*>(d_qrec);
+  F.cos_limit = cos_limit; F.th = th; F.q = static_cast<QRec*>(d_qrec); F.in_view = d_in_view; F.n_in_view = d_n_in_view;
   hipLaunchKernelGGL(frustum_kernel, dim3((mp.n + 255) / 256), dim3(256), 0, st, F);
   LLD_HIP_TRY(hipGetLastError());
   return LLD_OK;

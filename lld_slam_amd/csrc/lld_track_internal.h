@@ -49,7 +49,7 @@ void orbs_fill_problem(const lld_frame* f, int mode, int nq, const uint8_t* d_oc
 int orbs_project_last_frame(hipStream_t st, const lld_frame* f, const lld_frame_view* view_h, const lld_frame_view* view_d, const LastFrameDev& last, int direction, float th,
                             void* d_qrec, RunIf run_if);
 int orbs_project_local_points(hipStream_t st, const lld_frame* f, const lld_frame_view* view_h, const lld_frame_view* view_d, const MapPointsDev& mp, float cos_limit, float th,
-                              void* d_qrec);
+                              void* d_qrec, uint8_t* d_in_view, int32_t* d_n_in_view);
 int orbs_launch(lld_ctx* ctx, hipStream_t st, const lld_frame* f, const void* problem_d);
 
 // ---------------------------------------------------------------- Tracking::AddLinesFrom on device arrays (lld_match.hip)

@@ -136,11 +136,12 @@ class TrackResult(C.Structure):
     _fields_ = [("pose_qt", C.c_double * 7), ("chi2", C.c_double), ("n_inliers", C.c_int32), ("lm_iterations", C.c_int32), ("lm_trials", C.c_int32),
                 ("n_edges", C.c_int32), ("n_search_first", C.c_int32), ("n_search", C.c_int32), ("used_wide", C.c_int32), ("n_points", C.c_int32),
                 ("n_points_map", C.c_int32), ("n_lines_matched", C.c_int32), ("n_lines", C.c_int32), ("n_discarded", C.c_int32),
-                ("kp_point_id", c_int32_p), ("kp_outlier", c_uint8_p), ("ln_line_id", c_int32_p), ("ln_outlier", c_uint8_p)]
+                ("n_point_edges", C.c_int32), ("n_in_view", C.c_int32),
+                ("kp_point_id", c_int32_p), ("kp_outlier", c_uint8_p), ("ln_line_id", c_int32_p), ("ln_outlier", c_uint8_p), ("mp_in_view", c_uint8_p)]
 
 
 _COUNTERS = ("n_inliers", "lm_iterations", "lm_trials", "n_edges", "n_search_first", "n_search", "used_wide", "n_points", "n_points_map",
-             "n_lines_matched", "n_lines", "n_discarded")
+             "n_lines_matched", "n_lines", "n_discarded", "n_point_edges", "n_in_view")
 
 
 def map_lines_struct(ml: dict | None):
@@ -176,7 +177,7 @@ class DeviceTrackedFrame:
         lib.fn("frame_track_local_map").argtypes = [C.c_void_p, C.POINTER(TrackParams), C.POINTER(orb_search.MapPoints), c_int32_p, C.POINTER(MapLines)]
         lib.fn("frame_track_local_map").restype = C.c_int
         lib.fn("frame_track_download").argtypes = [C.c_void_p, C.POINTER(TrackResult), C.POINTER(TrackResult)]; lib.fn("frame_track_download").restype = C.c_int
-        self.n_lines = 0
+        self.n_lines = 0; self.n_local_points = 0
         if lines is not None:
             k = dict(left=np.ascontiguousarray(lines["left_lines"], np.float32).reshape(-1, 4), lo=np.ascontiguousarray(lines["left_octave"], np.int32),
                      right=np.ascontiguousarray(lines["right_lines"], np.float32).reshape(-1, 4), ro=np.ascontiguousarray(lines["right_octave"], np.int32),
@@ -222,6 +223,7 @@ class DeviceTrackedFrame:
     def track_local_map(self, mp: dict, mp_ids, local_lines: dict | None = None):
         m, keep = orb_search.map_points_struct(mp)
         ids = np.ascontiguousarray(mp_ids, np.int32)
+        self.n_local_points = int(m.n)
         ml, keep2 = map_lines_struct(local_lines)
         self._check(self.lib.fn("frame_track_local_map")(self.res.handle, C.byref(self.params), C.byref(m), ids.ctypes.data_as(c_int32_p),
                                                           C.byref(ml) if local_lines is not None else None), "lld_frame_track_local_map")
@@ -230,11 +232,13 @@ class DeviceTrackedFrame:
         """One copy, one synchronisation: the records of stage 1 and (if queued) stage 2 as dicts."""
         nt, nl = self.F.n, self.n_lines
         outs = []
-        for _ in range(2):
+        for st_ in range(2):
             r = TrackResult()
             a = dict(kp_point_id=np.empty(nt, np.int32), kp_outlier=np.empty(nt, np.uint8), ln_line_id=np.empty(nl, np.int32), ln_outlier=np.empty(nl, np.uint8))
             r.kp_point_id = a["kp_point_id"].ctypes.data_as(c_int32_p); r.kp_outlier = a["kp_outlier"].ctypes.data_as(c_uint8_p)
             r.ln_line_id = a["ln_line_id"].ctypes.data_as(c_int32_p); r.ln_outlier = a["ln_outlier"].ctypes.data_as(c_uint8_p)
+            if st_ == 1 and stage2:
+                a["mp_in_view"] = np.zeros(self.n_local_points, np.uint8); r.mp_in_view = a["mp_in_view"].ctypes.data_as(c_uint8_p)
             outs.append((r, a))
         self._check(self.lib.fn("frame_track_download")(self.res.handle, C.byref(outs[0][0]), C.byref(outs[1][0]) if stage2 else None), "lld_frame_track_download")
         res = []
@@ -289,7 +293,7 @@ def read_harness_result(path, nt, nl, repeats):
         for _ in range(2):
             d = dict(pose_qt=np.fromfile(f, np.float64, 7), chi2=float(np.fromfile(f, np.float64, 1)[0]))
             c = np.fromfile(f, np.int32, 12)
-            for k, v in zip(_COUNTERS, c): d[k] = int(v)
+            for k, v in zip(_COUNTERS[:12], c): d[k] = int(v)
             d["kp_point_id"] = np.fromfile(f, np.int32, nt); d["kp_outlier"] = np.fromfile(f, np.uint8, nt)
             d["ln_line_id"] = np.fromfile(f, np.int32, nl); d["ln_outlier"] = np.fromfile(f, np.uint8, nl)
             recs.append(d)

@@ -131,7 +131,7 @@ def track_frame(sc: dict, gamma=0.5, th_motion=7.0, th_local=1.0, nnratio=0.8, w
         fr.kp_has[k] = True; fr.kp_world[k] = np.asarray(last["world_pos"], np.float32)[q]; fr.kp_id[k] = int(last_ids[q]); fr.kp_obs[k] = int(has_obs[q])
     fr.add_lines_from(sc.get("last_lines"), thr_base, md_thr, use_grid)
     out, n_edges = fr.pose_optimization(gamma)
-    rec1 = fr.record(out, n_edges, dict(n_search_first=int(n1), n_search=int(n_used), used_wide=used_wide))
+    rec1 = fr.record(out, n_edges, dict(n_search_first=int(n1), n_search=int(n_used), used_wide=used_wide, n_point_edges=int(fr.problems[-1].n_points), n_in_view=0))
     # discard (:940-975)
     bad = fr.kp_has & (fr.kp_out != 0)
     fr.seen_points.update(int(i) for i in fr.kp_id[bad])
@@ -154,7 +154,8 @@ def track_frame(sc: dict, gamma=0.5, th_motion=7.0, th_local=1.0, nnratio=0.8, w
         fr.kp_has[kk] = True; fr.kp_world[kk] = np.asarray(mp["world_pos"], np.float32)[q]; fr.kp_id[kk] = int(mp_ids[q]); fr.kp_obs[kk] = int(mp_obs[q])
     fr.add_lines_from(sc.get("local_lines"), thr_base, md_thr, use_grid)
     out, n_edges = fr.pose_optimization(gamma)
-    rec2 = fr.record(out, n_edges, dict(n_search_first=int(n2), n_search=int(n2), used_wide=0))
+    rec2 = fr.record(out, n_edges, dict(n_search_first=int(n2), n_search=int(n2), used_wide=0, n_point_edges=int(fr.problems[-1].n_points), n_in_view=int(np.count_nonzero(inv)),
+                                        mp_in_view=np.asarray(inv, np.uint8).copy()))
     bad = fr.kp_has & (fr.kp_out != 0)
     fr.kp_has[bad] = False; fr.kp_id[bad] = -1                            # STEREO: mvpMapPoints[i] = NULL, mvbOutlier stays (:1170-1171)
     rec2.update(n_points=int(fr.kp_has.sum()), n_points_map=int((fr.kp_has & (fr.kp_obs != 0)).sum()), n_discarded=int(bad.sum()))

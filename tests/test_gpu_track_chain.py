@@ -11,7 +11,7 @@ from lld_slam_amd.tracking import DeviceTrackedFrame, TrackedFrame
 
 pytestmark = pytest.mark.gpu
 
-COUNTERS = ("n_inliers", "n_edges", "n_search_first", "n_search", "used_wide", "n_points", "n_points_map", "n_lines_matched", "n_lines", "n_discarded")
+COUNTERS = ("n_inliers", "n_edges", "n_search_first", "n_search", "used_wide", "n_points", "n_points_map", "n_lines_matched", "n_lines", "n_discarded", "n_point_edges", "n_in_view")
 # north_star's bar is 1e-5 relative on pose and chi2.  Held here to what the chain actually reaches against the oracle's own run, with two
 # orders of margin: 38 records of this file max |dq| 7e-15, |dt| / max(1, |t|) 1e-13, chi2 5e-13; tools/fuzz_track_chain.py, 800 records
 # (profiles/r06_fuzz_track_chain_*.txt): 7e-11, 4e-9, 8e-13 - also where the LM counts below differ.
@@ -41,6 +41,8 @@ def run_device(gpu_ctx, sc, download_between=False, **params):
 def same_record(g, e, exact_pose=False):
     for k in ("kp_point_id", "kp_outlier", "ln_line_id", "ln_outlier"):
         np.testing.assert_array_equal(g[k], e[k], err_msg=k)
+    if "mp_in_view" in g and "mp_in_view" in e:                         # stage 2: Frame::isInFrustum of the local MapPoints that were not skipped
+        np.testing.assert_array_equal(g["mp_in_view"], e["mp_in_view"], err_msg="mp_in_view")
     for k in COUNTERS:
         assert g[k] == e[k], (k, g[k], e[k])
     if exact_pose:

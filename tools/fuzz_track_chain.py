@@ -14,11 +14,11 @@ from lld_slam_amd import Context, synth
 from lld_slam_amd.tracking import DeviceTrackedFrame
 
 KEYS = ("kp_point_id", "kp_outlier", "ln_line_id", "ln_outlier")
-CNT = ("n_inliers", "n_edges", "n_search_first", "n_search", "used_wide", "n_points", "n_points_map", "n_lines_matched", "n_lines", "n_discarded")
+CNT = ("n_inliers", "n_edges", "n_search_first", "n_search", "used_wide", "n_points", "n_points_map", "n_lines_matched", "n_lines", "n_discarded", "n_point_edges", "n_in_view")
 
 
 def compare(g, e):
-    if not all(np.array_equal(g[k], e[k]) for k in KEYS): return "MISMATCH ids/flags", 0, 0, 0
+    if not all(np.array_equal(g[k], e[k]) for k in KEYS + (("mp_in_view",) if "mp_in_view" in g and "mp_in_view" in e else ())): return "MISMATCH ids/flags", 0, 0, 0
     if not all(g[k] == e[k] for k in CNT): return "MISMATCH counters", 0, 0, 0
     dq = float(np.max(np.abs(g["pose_qt"][:4] - e["pose_qt"][:4])))
     dt = float(np.linalg.norm(g["pose_qt"][4:] - e["pose_qt"][4:]) / max(1.0, np.linalg.norm(e["pose_qt"][4:])))
