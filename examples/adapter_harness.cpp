@@ -24,6 +24,7 @@
 #include "../adapters/lld_optimizer_adapter.h"
 #include "../adapters/lld_matcher_adapter.h"
 #include "../adapters/lld_line_adapter.h"
+#include "../adapters/lld_tracking_adapter.h"
 
 std::mutex lld_slam::MapPoint::mGlobalMutex;        // the doubles' static member (the real class defines its own, MapPoint.cc:30)
 
@@ -691,8 +692,136 @@ int run_lastkf(const char* in, const char* out) {
   return 0;
 }
 
+// Tracking::TrackWithMotionModel + Tracking::TrackLocalMap through adapters/lld_tracking_adapter.cc on a live object graph: the scene file of
+// `harness track` (lld_slam_amd/tracking.py write_harness_scene) plus a tail {Tlast[16] f32, mb f32, mbOnlyTracking i32, half_outliers i32,
+// via_set_state i32, 0}.  via_set_state: TrackLocalMap runs on a SECOND device frame that was handed the object graph's state (FrameOnDevice::SetFrameState),
+// the way it follows TrackReferenceKeyFrame in the running system.
+// One MapPoint / MapLine object per id, shared by the last frame and the local map as in the running system.
+int run_track(const char* in, const char* out) {
+  Reader r(in);
+  int32_t h[16]; r.get(h, 16);      // nt n_levels n_last n_mp nl nr dim n_last_lines n_local_lines repeats download_between
+  const int nt = h[0], n_levels = h[1], n_last = h[2], n_mp = h[3], nl = h[4], nr = h[5], dim = h[6], n_ll = h[7], n_ml = h[8];
+  float fc[6]; r.get(fc, 6);        // min_x min_y max_x max_y grid_width_inv grid_height_inv
+  std::vector<float> scale, inv_sigma2; r.get(scale, n_levels); r.get(inv_sigma2, n_levels);
+  double dc[8]; r.get(dc, 8);       // fx fy cx cy bf gamma line_thr_base md_thr
+  std::vector<uint32_t> t_desc; std::vector<float> t_xy, t_ur, t_ang; std::vector<int32_t> t_oct;
+  r.get(t_desc, 8 * (size_t)nt); r.get(t_xy, 2 * (size_t)nt); r.get(t_oct, nt); r.get(t_ur, nt); r.get(t_ang, nt);
+  lld_frame_view view; r.get(&view, 1);
+  float Tcw[16]; r.get(Tcw, 16);
+  std::vector<float> l_pos, l_ang; std::vector<uint8_t> l_valid, l_obs; std::vector<int32_t> l_oct, l_id; std::vector<uint32_t> l_desc;
+  r.get(l_pos, 3 * (size_t)n_last); r.get(l_valid, n_last); r.get(l_oct, n_last); r.get(l_ang, n_last); r.get(l_desc, 8 * (size_t)n_last); r.get(l_obs, n_last); r.get(l_id, n_last);
+  std::vector<float> m_pos, m_nrm, m_maxd, m_mind; std::vector<uint32_t> m_desc; std::vector<uint8_t> m_obs, m_skip; std::vector<int32_t> m_id;
+  r.get(m_pos, 3 * (size_t)n_mp); r.get(m_nrm, 3 * (size_t)n_mp); r.get(m_maxd, n_mp); r.get(m_mind, n_mp); r.get(m_desc, 8 * (size_t)n_mp); r.get(m_obs, n_mp); r.get(m_skip, n_mp);
+  r.get(m_id, n_mp);
+  std::vector<float> ln_left, ln_right, ln_desc; std::vector<int32_t> ln_lo, ln_ro, ln_lm;
+  r.get(ln_left, 4 * (size_t)nl); r.get(ln_lo, nl); r.get(ln_right, 4 * (size_t)nr); r.get(ln_ro, nr); r.get(ln_lm, nl); r.get(ln_desc, (size_t)nl * dim);
+  struct LineSet { std::vector<double> x0, dir, x1, x2; std::vector<uint8_t> skip; std::vector<float> desc; std::vector<int32_t> id; };
+  auto read_lines = [&](LineSet& L, int n) {
+    r.get(L.x0, 3 * (size_t)n); r.get(L.dir, 3 * (size_t)n); r.get(L.x1, 3 * (size_t)n); r.get(L.x2, 3 * (size_t)n); r.get(L.skip, n); r.get(L.desc, (size_t)n * dim); r.get(L.id, n);
+  };
+  LineSet last_lines, local_lines; read_lines(last_lines, n_ll); read_lines(local_lines, n_ml);
+  float Tlast[16], mb; int32_t tail[4]; r.get(Tlast, 16); r.get(&mb, 1); r.get(tail, 4);     // ..., mbOnlyTracking, half_outliers, via_set_state, 0
+
+  // ---- the current frame as Frame::Frame leaves it
+  Frame Cur;
+  Cur.N = nt; Cur.mnId = 42; Cur.fx = (float)dc[0]; Cur.fy = (float)dc[1]; Cur.cx = (float)dc[2]; Cur.cy = (float)dc[3]; Cur.mbf = (float)dc[4]; Cur.mb = mb;
+  Cur.mvKeysUn.resize(nt);
+  for (int k = 0; k < nt; k++) { Cur.mvKeysUn[k].pt.x = t_xy[2 * k]; Cur.mvKeysUn[k].pt.y = t_xy[2 * k + 1]; Cur.mvKeysUn[k].octave = t_oct[k]; Cur.mvKeysUn[k].angle = t_ang[k]; }
+  Cur.mvKeys = Cur.mvKeysUn; Cur.mvuRight = t_ur;
+  Cur.mDescriptors = MatU8(nt, 32); std::memcpy(Cur.mDescriptors.ptr<unsigned char>(), t_desc.data(), 32 * (size_t)nt);
+  Cur.mnMinX = fc[0]; Cur.mnMinY = fc[1]; Cur.mnMaxX = fc[2]; Cur.mnMaxY = fc[3]; Cur.mfGridElementWidthInv = fc[4]; Cur.mfGridElementHeightInv = fc[5];
+  Cur.mnScaleLevels = n_levels; Cur.mfScaleFactor = scale[1]; Cur.mfLogScaleFactor = view.log_scale_factor; Cur.mvScaleFactors = scale; Cur.mvInvLevelSigma2 = inv_sigma2;
+  Cur.mvLevelSigma2.resize(n_levels); for (int l = 0; l < n_levels; l++) Cur.mvLevelSigma2[l] = scale[l] * scale[l];
+  Cur.mvpMapPoints.assign(nt, nullptr); Cur.mvbOutlier.assign(nt, false);
+  for (int i = 0; i < nl; i++) { KeyLine q; q.startPointX = ln_left[4 * i]; q.startPointY = ln_left[4 * i + 1]; q.endPointX = ln_left[4 * i + 2]; q.endPointY = ln_left[4 * i + 3]; q.octave = ln_lo[i]; Cur.mvLinesLeft.push_back(q); }
+  for (int i = 0; i < nr; i++) { KeyLine q; q.startPointX = ln_right[4 * i]; q.startPointY = ln_right[4 * i + 1]; q.endPointX = ln_right[4 * i + 2]; q.endPointY = ln_right[4 * i + 3]; q.octave = ln_ro[i]; Cur.mvLinesRight.push_back(q); }
+  Cur.line_matches.assign(ln_lm.begin(), ln_lm.end());
+  if (nl > 0) Cur.mDescriptorsLines = Mat(nl, dim, ln_desc.data());
+  Cur.mvpMapLines.assign(nl, nullptr); Cur.mvbOutlierLines.assign(nl, false);
+  Cur.SetPose(Mat(4, 4, Tcw));                 // mCurrentFrame.SetPose(mVelocity*mLastFrame.mTcw)
+
+  // ---- the map: one object per id
+  std::map<int32_t, std::unique_ptr<MapPoint> > points;
+  std::vector<MapPoint*> mvpLocalMapPoints;
+  for (int i = 0; i < n_mp; i++) {
+    std::unique_ptr<MapPoint>& p = points[m_id[i]];
+    p.reset(new MapPoint());
+    p->mnId = (unsigned long)m_id[i]; p->mWorldPos = Mat(3, 1, &m_pos[3 * i]); p->mNormalVector = Mat(3, 1, &m_nrm[3 * i]); p->mfMaxDistance = m_maxd[i]; p->mfMinDistance = m_mind[i];
+    p->mDescriptor = MatU8(1, 32); std::memcpy(p->mDescriptor.ptr<unsigned char>(), &m_desc[8 * (size_t)i], 32);
+    p->nObs = m_obs[i] ? 3 : 0; p->mbBad = m_skip[i] != 0;
+    mvpLocalMapPoints.push_back(p.get());
+  }
+  Frame Last;
+  Last.N = n_last; Last.mnId = 41; Last.mvKeys.resize(n_last); Last.mvKeysUn.resize(n_last); Last.mvpMapPoints.assign(n_last, nullptr); Last.mvbOutlier.assign(n_last, false);
+  Last.SetPose(Mat(4, 4, Tlast));
+  for (int i = 0; i < n_last; i++) {
+    Last.mvKeys[i].octave = l_oct[i]; Last.mvKeysUn[i].angle = l_ang[i];
+    std::unique_ptr<MapPoint>& p = points[l_id[i]];
+    if (!p) {                                   // a point of the last frame outside the local map (UpdateLastFrame's temporal points are such)
+      p.reset(new MapPoint());
+      p->mnId = (unsigned long)l_id[i]; p->mWorldPos = Mat(3, 1, &l_pos[3 * i]); p->mDescriptor = MatU8(1, 32); std::memcpy(p->mDescriptor.ptr<unsigned char>(), &l_desc[8 * (size_t)i], 32);
+      p->nObs = l_obs[i] ? 3 : 0;
+    }
+    if (l_valid[i]) Last.mvpMapPoints[i] = p.get();
+    else if (tail[1] && (i & 1)) { Last.mvpMapPoints[i] = p.get(); Last.mvbOutlier[i] = true; }          // the two ways the reference skips an entry (:1356-1358)
+  }
+  std::map<int32_t, std::unique_ptr<MapLine> > lines;
+  auto line_obj = [&](const LineSet& L, int i) {
+    std::unique_ptr<MapLine>& q = lines[L.id[i]];
+    if (!q) {
+      q.reset(new MapLine()); q->mnId = (unsigned long)L.id[i];
+      for (int c = 0; c < 3; c++) { q->mX0(c) = L.x0[3 * i + c]; q->mDir(c) = L.dir[3 * i + c]; q->mX1(c) = L.x1[3 * i + c]; q->mX2(c) = L.x2[3 * i + c]; }
+    }
+    if (L.skip[i]) q->mbBad = true;
+    return q.get();
+  };
+  Last.mvpMapLines.assign(n_ll, nullptr);
+  for (int i = 0; i < n_ll; i++) Last.mvpMapLines[i] = line_obj(last_lines, i);
+  if (n_ll > 0) Last.mDescriptorsLines = Mat(n_ll, dim, last_lines.desc.data());
+  std::vector<MapLine*> tracking_local_lines; std::vector<Mat> local_line_descs;
+  for (int i = 0; i < n_ml; i++) { tracking_local_lines.push_back(line_obj(local_lines, i)); local_line_descs.push_back(Mat(1, dim, &local_lines.desc[(size_t)i * dim])); }
+
+  lld_amd::Context ctx(0);
+  lld_adapter::TrackingMembers tm; tm.gamma = dc[5]; tm.mdThr = dc[7]; tm.mbOnlyTracking = tail[0] != 0;
+  lld_adapter::FrameOnDevice dev(ctx.get(), Cur);
+  lld_adapter::TrackTrace t1, t2;
+  Writer w(out);
+  auto put_trace = [&](const lld_adapter::TrackTrace& t) {
+    w.put(t.r.pose_qt, 7); w.put(&t.r.chi2, 1);
+    const int32_t c[12] = {t.r.n_inliers, t.r.lm_iterations, t.r.lm_trials, t.r.n_edges, t.r.n_search_first, t.r.n_search, t.r.used_wide,
+                           t.r.n_points, t.r.n_points_map, t.r.n_lines_matched, t.r.n_lines, t.r.n_discarded};
+    w.put(c, 12); w.put(t.kp_point_id); w.put(t.kp_outlier); w.put(t.ln_line_id); w.put(t.ln_outlier);
+  };
+  auto put_objects = [&]() {                    // what a reader of the object graph sees now
+    std::vector<int32_t> kp(nt), ln(nl), pt; std::vector<uint8_t> ko(nt), lo(nl);
+    for (int k = 0; k < nt; k++) { kp[k] = Cur.mvpMapPoints[k] ? (int32_t)Cur.mvpMapPoints[k]->mnId : -1; ko[k] = Cur.mvbOutlier[k]; }
+    for (int i = 0; i < nl; i++) { ln[i] = Cur.mvpMapLines[i] ? (int32_t)Cur.mvpMapLines[i]->mnId : -1; lo[i] = Cur.mvbOutlierLines[i]; }
+    w.put(kp); w.put(ko); w.put(ln); w.put(lo); w.put(Cur.mTcw.ptr<float>(), 16);
+    const int32_t n[2] = {(int32_t)points.size(), (int32_t)lines.size()};
+    w.put(n, 2);
+    for (const auto& e : points) { const int32_t v[5] = {e.first, e.second->mnVisible, e.second->mnFound, (int32_t)e.second->mbTrackInView, (int32_t)e.second->mnLastFrameSeen}; w.put(v, 5); }
+    for (const auto& e : lines) { const int32_t v[2] = {e.first, (int32_t)e.second->tracked_last_id}; w.put(v, 2); }
+  };
+  bool mbVO = false; int mnMatchesInliers = -1;
+  const bool ok = dev.TrackWithMotionModel(tm, Cur, Last, &mbVO, &t1);
+  put_trace(t1); put_objects();
+  if (tail[2]) {
+    lld_adapter::FrameOnDevice dev2(ctx.get(), Cur);
+    dev2.SetFrameState(tm, Cur);
+    dev2.TrackLocalMap(tm, Cur, mvpLocalMapPoints, tracking_local_lines, local_line_descs, &mnMatchesInliers, &t2);
+  } else {
+    dev.TrackLocalMap(tm, Cur, mvpLocalMapPoints, tracking_local_lines, local_line_descs, &mnMatchesInliers, &t2);
+  }
+  put_trace(t2); put_objects();
+  w.put(t2.mp_in_view);
+  const int32_t fin[4] = {(int32_t)ok, (int32_t)mbVO, mnMatchesInliers, Cur.n_set_pose};
+  w.put(fin, 4);
+  std::printf("adapter-track: TrackWithMotionModel %s (%d points, %d lines), TrackLocalMap %d inliers (%d lines)\n", ok ? "ok" : "lost", t1.r.n_points, t1.r.n_lines, mnMatchesInliers, t2.r.n_lines);
+  return 0;
+}
+
 int main(int argc, char** argv) {
-  if (argc < 4) { std::fprintf(stderr, "usage: adapter_harness ba|pose|match|loopmatch|bow|lines <in> <out> [seed]\n"); return 2; }
+  if (argc < 4) { std::fprintf(stderr, "usage: adapter_harness ba|pose|match|loopmatch|bow|lines|init|lastkf|track <in> <out> [seed]\n"); return 2; }
   const unsigned seed = argc > 4 ? (unsigned)std::atoi(argv[4]) : 1u;
   try {
     const std::string mode = argv[1];
@@ -704,6 +833,7 @@ int main(int argc, char** argv) {
     if (mode == "lines") return run_lines(argv[2], argv[3]);
     if (mode == "init") return run_init(argv[2], argv[3]);
     if (mode == "lastkf") return run_lastkf(argv[2], argv[3]);
+    if (mode == "track") return run_track(argv[2], argv[3]);
     std::fprintf(stderr, "unknown mode %s\n", argv[1]);
     return 2;
   } catch (const std::exception& e) {

@@ -848,6 +848,26 @@ typedef struct {
  * lld_frame_search_last_frame plus the id of every entry; last_lines: mLastFrame.mvpMapLines (NULL: none). */
 int  lld_frame_track_motion_model(lld_frame* frame, const lld_track_params* params, const lld_frame_view* view, const double* pose_qt,
                                   const lld_last_frame_points* last, const int32_t* last_point_id, const lld_map_lines* last_lines);
+/* Stage 1 ran elsewhere: Tracking::TrackReferenceKeyFrame (src/Tracking.cc:770-816) or Tracking::Relocalization end with the same
+ * PoseOptimization + outlier discard but find their matches by bag of words / PnP.  This call hands the device what such a routine left in
+ * the frame, so that lld_frame_track_local_map can follow on the same handle (Tracking::Track runs TrackLocalMap after whichever routine
+ * produced the pose, :401-407).  The record of stage 1 reads as empty afterwards. */
+typedef struct {
+  const int32_t* kp_point_id;       /* [nt] id of mvpMapPoints[k] or -1                                                                              */
+  const float*   kp_world_pos;      /* [nt][3] GetWorldPos() of those (ignored where the id is -1)                                                   */
+  const uint8_t* kp_has_obs;        /* [nt] Observations() > 0, or NULL: all                                                                         */
+  const uint8_t* kp_outlier;        /* [nt] mvbOutlier, or NULL: none                                                                                */
+  int32_t        n_seen;            /* MapPoints with mnLastFrameSeen == mCurrentFrame.mnId the frame does not hold (the discard's, :805-808); <= nt */
+  const int32_t* seen_point_id;
+  const int32_t* ln_line_id;        /* [n_left] id of mvpMapLines[i] or -1; NULL: the frame holds no lines (TrackReferenceKeyFrame adds none)        */
+  const double*  ln_x0;             /* [n_left][3] GetMinimalPos of those                                                                            */
+  const double*  ln_dir;
+  const uint8_t* ln_outlier;        /* [n_left] mvbOutlierLines, or NULL: none                                                                       */
+  int32_t        n_tracked;         /* further MapLines with tracked_last_id == mCurrentFrame.mnId (<= n_left + 16 together with the held ones)      */
+  const int32_t* tracked_line_id;
+} lld_frame_held;
+/* view / pose_qt: Frame::UpdatePoseMatrices and Converter::toSE3Quat of the frame's mTcw, as for lld_frame_track_motion_model. */
+int  lld_frame_track_set_state(lld_frame* frame, const lld_track_params* params, const lld_frame_view* view, const double* pose_qt, const lld_frame_held* held);
 /* Stage 2, on the pose and the MapPoints / MapLines stage 1 left in the frame.  local_points->skip: isBad only - what the frame holds or
  * discarded is skipped by id on the device.  local_lines: Tracking::local_lines with their descriptors (NULL: none). */
 int  lld_frame_track_local_map(lld_frame* frame, const lld_track_params* params, const lld_map_points* local_points, const int32_t* local_point_id,

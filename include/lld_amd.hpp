@@ -402,6 +402,12 @@ class TrackedFrame {
     lld_se3_from_tcw_f32(Tcw, qt);                       // Converter::toSE3Quat(pFrame->mTcw)
     check(lld_frame_track_motion_model(f_, &params, &view, qt, &last, last_ids, last_lines), "lld_frame_track_motion_model");
   }
+  // stage 1 ran elsewhere (TrackReferenceKeyFrame / Relocalization): the frame's pose and what it holds, then TrackLocalMap as usual
+  void SetState(const lld_frame_view& view, const float Tcw[16], const lld_frame_held& held) {
+    double qt[7];
+    lld_se3_from_tcw_f32(Tcw, qt);
+    check(lld_frame_track_set_state(f_, &params, &view, qt, &held), "lld_frame_track_set_state");
+  }
   void TrackLocalMap(const lld_map_points& local_points, const int32_t* ids, const lld_map_lines* local_lines) {
     check(lld_frame_track_local_map(f_, &params, &local_points, ids, local_lines), "lld_frame_track_local_map");
   }

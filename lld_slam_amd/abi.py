@@ -190,7 +190,7 @@ PRODUCT_SYMBOLS = [
     "lld_orb_search_run", "lld_orb_search_batch", "lld_orb_search_local_points", "lld_orb_search_last_frame", "lld_orb_fuse_search", "lld_orb_search_projected", "lld_orb_search_by_sim3",
     "lld_compute_stereo_matches",
     "lld_frame_create", "lld_frame_search_last_frame", "lld_frame_search_local_points", "lld_frame_destroy",
-    "lld_frame_set_lines", "lld_track_params_default", "lld_frame_track_motion_model", "lld_frame_track_local_map", "lld_frame_track_download",
+    "lld_frame_set_lines", "lld_track_params_default", "lld_frame_track_motion_model", "lld_frame_track_local_map", "lld_frame_track_download", "lld_frame_track_set_state",
     "lld_sim3_params_default", "lld_optimize_sim3", "lld_optimize_sim3_batch",
     "lld_pose_graph_params_default", "lld_optimize_essential_graph",
 ]

@@ -94,6 +94,36 @@ __global__ void track_reset_kernel(TrackDev D, const double* pose_guess, const l
   }
 }
 
+// The frame enters TrackLocalMap from a stage 1 that ran elsewhere (lld_frame_track_set_state): what that routine left in the frame.
+struct HeldUp { const int32_t* kp_id; const float* kp_world; const uint8_t* kp_obs; const uint8_t* kp_out; const int32_t* seen; int n_seen;
+                const int32_t* ln_id; const double* ln_x0; const double* ln_dir; const uint8_t* ln_out; const int32_t* tracked; int n_tracked; };
+__global__ void track_load_kernel(TrackDev D, HeldUp U, const double* pose_qt, const lld_frame_view* view_up, const LineTrackDevParams* lp_up) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) { *D.view = *view_up; *D.line_params = *lp_up; *D.n_discard = U.n_seen; }
+  if (i < D.nt) {
+    const int32_t id = U.kp_id[i];
+    const bool has = id >= 0;
+    D.kp_has[i] = has; D.kp_id[i] = has ? id : -1; D.kp_obs[i] = has ? U.kp_obs[i] : 0; D.kp_outlier[i] = U.kp_out[i];
+    for (int c = 0; c < 3; c++) D.kp_world[3 * i + c] = has ? U.kp_world[3 * i + c] : 0.f;
+  }
+  if (i < U.n_seen) D.discard[i] = U.seen[i];
+  if (i < D.nl) {
+    const int32_t id = U.ln_id[i];
+    const bool has = id >= 0;
+    D.ln_has[i] = has; D.ln_id[i] = has ? id : -1; D.ln_outlier[i] = U.ln_out[i];
+    for (int c = 0; c < 3; c++) { D.ln_x0[3 * i + c] = has ? U.ln_x0[3 * i + c] : 0.0; D.ln_dir[3 * i + c] = has ? U.ln_dir[3 * i + c] : 0.0; }
+  }
+  if (i < U.n_tracked) D.tracked[i] = U.tracked[i];
+  if (i == 0) *D.n_tracked = U.n_tracked;
+  if (i < 7) D.pose_qt[i] = pose_qt[i];
+  if (i < 2 * (int)(sizeof(RecHeader) / 4)) {
+    int32_t* h = reinterpret_cast<int32_t*>(i < (int)(sizeof(RecHeader) / 4) ? D.rec_h[0] : D.rec_h[1]);
+    h[i % (int)(sizeof(RecHeader) / 4)] = 0;
+  }
+  if (i < D.nt) { D.rec_kp_id[0][i] = -1; D.rec_kp_out[0][i] = 0; }
+  if (i < D.nl) { D.rec_ln_id[0][i] = -1; D.rec_ln_out[0][i] = 0; }
+}
+
 // What follows PoseOptimization.  stage 0 = TrackWithMotionModel (src/Tracking.cc:940-975): an outlier point leaves the frame, its flag is
 // cleared, its MapPoint is marked seen (-> the discard list); an outlier line leaves, its flag STAYS (the reference does not clear
 // mvbOutlierLines).  stage 1 = TrackLocalMap (:1155-1187): outlier points leave (STEREO) with their flag kept, outlier lines leave.
@@ -489,6 +519,67 @@ int lld_frame_track_motion_model(lld_frame* f, const lld_track_params* P, const 
   }
   s = run_lines(f, st, P, n_map ? last_lines : nullptr, d, U, reinterpret_cast<const uint8_t*>(d + U.skip), d + o_lwork, 0); if (s) return s;
   s = run_pose(f, st, P, d + o_pwork, 0); if (s) return s;
+  S->stage1_queued = true; S->n_in_view = 0;
+  return LLD_OK;
+}
+
+int lld_frame_track_set_state(lld_frame* f, const lld_track_params* P, const lld_frame_view* view, const double* pose_qt, const lld_frame_held* held) {
+  if (!f || !P || !view || !pose_qt || !held) return LLD_ERR_INVALID;
+  const int nt = f->nt;
+  if (view->n_levels != f->consts.n_levels) return LLD_ERR_INVALID;
+  if (nt > 0 && (!held->kp_point_id || !held->kp_world_pos)) return LLD_ERR_INVALID;
+  if (held->n_seen < 0 || held->n_seen > nt || (held->n_seen > 0 && !held->seen_point_id)) return LLD_ERR_INVALID;   // the outlier discard marks at most one MapPoint per keypoint
+  lld_ctx* ctx = f->ctx;
+  LLD_HIP_TRY(hipSetDevice(ctx->device));
+  int s = ensure_state(f); if (s) return s;
+  lld_frame_track_state* S = f->track;
+  const int nl = S->nl;
+  if (nl > 0 && held->ln_line_id && (!held->ln_x0 || !held->ln_dir)) return LLD_ERR_INVALID;
+  int n_held_lines = 0;
+  if (nl > 0 && held->ln_line_id) for (int i = 0; i < nl; i++) n_held_lines += held->ln_line_id[i] >= 0;
+  if (held->n_tracked < 0 || (held->n_tracked > 0 && !held->tracked_line_id) || n_held_lines + held->n_tracked > S->D.tracked_cap - nl) return LLD_ERR_INVALID;
+  for (int k = 0; k < held->n_seen; k++) if (held->seen_point_id[k] < 0) return LLD_ERR_INVALID;
+  for (int k = 0; k < held->n_tracked; k++) if (held->tracked_line_id[k] < 0) return LLD_ERR_INVALID;
+  fill_consts(S, f, P, view);
+  size_t o = 0;
+  auto take = [&](size_t bytes) { const size_t at = o; o += al(bytes); return at; };
+  const int n_trk = n_held_lines + held->n_tracked;
+  const size_t o_pose = take(7 * 8), o_lp = take(sizeof(LineTrackDevParams)), o_view = take(sizeof(lld_frame_view));
+  const size_t o_id = take((size_t)nt * 4), o_w = take((size_t)nt * 12), o_obs = take(nt), o_out = take(nt), o_seen = take((size_t)std::max(held->n_seen, 1) * 4);
+  const size_t o_lid = take((size_t)nl * 4), o_lx0 = take((size_t)nl * 24), o_ldir = take((size_t)nl * 24), o_lout = take(nl), o_trk = take((size_t)std::max(n_trk, 1) * 4);
+  s = ensure_work(S, ctx, o); if (s) return s;
+  s = ensure_stage(S, 0, o); if (s) return s;
+  char* h = S->h_stage[0]; char* d = S->d_work;
+  std::memcpy(h + o_pose, pose_qt, 7 * 8);
+  line_params_from_view(S->consts, *view, reinterpret_cast<LineTrackDevParams*>(h + o_lp));
+  std::memcpy(h + o_view, view, sizeof(lld_frame_view));
+  if (nt) {
+    std::memcpy(h + o_id, held->kp_point_id, (size_t)nt * 4); std::memcpy(h + o_w, held->kp_world_pos, (size_t)nt * 12);
+    if (held->kp_has_obs) std::memcpy(h + o_obs, held->kp_has_obs, nt); else std::memset(h + o_obs, 1, nt);
+    if (held->kp_outlier) std::memcpy(h + o_out, held->kp_outlier, nt); else std::memset(h + o_out, 0, nt);
+  }
+  if (held->n_seen) std::memcpy(h + o_seen, held->seen_point_id, (size_t)held->n_seen * 4);
+  if (nl) {
+    int32_t* trk = reinterpret_cast<int32_t*>(h + o_trk); int at = 0;
+    if (held->ln_line_id) {
+      std::memcpy(h + o_lid, held->ln_line_id, (size_t)nl * 4); std::memcpy(h + o_lx0, held->ln_x0, (size_t)nl * 24); std::memcpy(h + o_ldir, held->ln_dir, (size_t)nl * 24);
+      for (int i = 0; i < nl; i++) if (held->ln_line_id[i] >= 0) trk[at++] = held->ln_line_id[i];      // a line the frame holds was tracked by it (tracked_last_id, :1117)
+    } else {
+      std::memset(h + o_lid, 0xff, (size_t)nl * 4); std::memset(h + o_lx0, 0, (size_t)nl * 24); std::memset(h + o_ldir, 0, (size_t)nl * 24);
+    }
+    if (held->ln_outlier) std::memcpy(h + o_lout, held->ln_outlier, nl); else std::memset(h + o_lout, 0, nl);
+    for (int k = 0; k < held->n_tracked; k++) trk[at++] = held->tracked_line_id[k];
+  }
+  hipStream_t st = ctx->stream;
+  LLD_HIP_TRY(hipMemcpyAsync(d, h, o, hipMemcpyHostToDevice, st));
+  LLD_HIP_TRY(hipEventRecord(S->uploaded[0], st)); S->upload_pending[0] = true;
+  const HeldUp U{reinterpret_cast<const int32_t*>(d + o_id), reinterpret_cast<const float*>(d + o_w), reinterpret_cast<const uint8_t*>(d + o_obs), reinterpret_cast<const uint8_t*>(d + o_out),
+                 reinterpret_cast<const int32_t*>(d + o_seen), held->n_seen, reinterpret_cast<const int32_t*>(d + o_lid), reinterpret_cast<const double*>(d + o_lx0),
+                 reinterpret_cast<const double*>(d + o_ldir), reinterpret_cast<const uint8_t*>(d + o_lout), reinterpret_cast<const int32_t*>(d + o_trk), nl ? n_trk : 0};
+  const int nmax = std::max(std::max(std::max(nt, nl), n_trk), 64);
+  hipLaunchKernelGGL(track_load_kernel, dim3((nmax + 255) / 256), dim3(256), 0, st, S->D, U, reinterpret_cast<const double*>(d + o_pose),
+                     reinterpret_cast<const lld_frame_view*>(d + o_view), reinterpret_cast<const LineTrackDevParams*>(d + o_lp));
+  LLD_HIP_TRY(hipGetLastError());
   S->stage1_queued = true; S->n_in_view = 0;
   return LLD_OK;
 }

@@ -140,6 +140,13 @@ class TrackResult(C.Structure):
                 ("kp_point_id", c_int32_p), ("kp_outlier", c_uint8_p), ("ln_line_id", c_int32_p), ("ln_outlier", c_uint8_p), ("mp_in_view", c_uint8_p)]
 
 
+class FrameHeld(C.Structure):
+    """lld_frame_held (include/lld_amd.h): what a stage 1 that ran elsewhere left in the frame."""
+    _fields_ = [("kp_point_id", c_int32_p), ("kp_world_pos", c_float_p), ("kp_has_obs", c_uint8_p), ("kp_outlier", c_uint8_p), ("n_seen", C.c_int32),
+                ("seen_point_id", c_int32_p), ("ln_line_id", c_int32_p), ("ln_x0", c_double_p), ("ln_dir", c_double_p), ("ln_outlier", c_uint8_p),
+                ("n_tracked", C.c_int32), ("tracked_line_id", c_int32_p)]
+
+
 _COUNTERS = ("n_inliers", "lm_iterations", "lm_trials", "n_edges", "n_search_first", "n_search", "used_wide", "n_points", "n_points_map",
              "n_lines_matched", "n_lines", "n_discarded", "n_point_edges", "n_in_view")
 
@@ -218,6 +225,30 @@ class DeviceTrackedFrame:
         ml, keep2 = map_lines_struct(last_lines)
         self._check(self.lib.fn("frame_track_motion_model")(self.res.handle, C.byref(self.params), C.byref(view), qt.ctypes.data_as(c_double_p), C.byref(m),
                                                              ids.ctypes.data_as(c_int32_p), C.byref(ml) if last_lines is not None else None), "lld_frame_track_motion_model")
+        return view, qt
+
+    def set_state(self, Tcw_f32, kp_point_id, kp_world_pos, kp_has_obs=None, kp_outlier=None, seen_point_id=(), ln_line_id=None, ln_x0=None, ln_dir=None,
+                  ln_outlier=None, tracked_line_id=()):
+        """lld_frame_track_set_state: stage 1 ran elsewhere (TrackReferenceKeyFrame / Relocalization); the frame's float pose and what it holds."""
+        from .host import se3_from_tcw_f32
+        fn = self.lib.fn("frame_track_set_state")
+        fn.argtypes = [C.c_void_p, C.POINTER(TrackParams), C.POINTER(orb_search.FrameView), c_double_p, C.POINTER(FrameHeld)]; fn.restype = C.c_int
+        T = np.ascontiguousarray(Tcw_f32, np.float32).reshape(4, 4)
+        view = orb_search.frame_view(T, self.cam, self.F)
+        qt = np.ascontiguousarray(se3_from_tcw_f32(self.lib, T), np.float64)
+        H = FrameHeld(); keep = []
+
+        def arr(a, dt, ptr):
+            if a is None: return None
+            a = np.ascontiguousarray(a, dt); keep.append(a)
+            return a.ctypes.data_as(ptr)
+        H.kp_point_id = arr(kp_point_id, np.int32, c_int32_p); H.kp_world_pos = arr(kp_world_pos, np.float32, c_float_p)
+        H.kp_has_obs = arr(kp_has_obs, np.uint8, c_uint8_p); H.kp_outlier = arr(kp_outlier, np.uint8, c_uint8_p)
+        H.n_seen = len(seen_point_id); H.seen_point_id = arr(seen_point_id if len(seen_point_id) else None, np.int32, c_int32_p)
+        H.ln_line_id = arr(ln_line_id, np.int32, c_int32_p); H.ln_x0 = arr(ln_x0, np.float64, c_double_p); H.ln_dir = arr(ln_dir, np.float64, c_double_p)
+        H.ln_outlier = arr(ln_outlier, np.uint8, c_uint8_p)
+        H.n_tracked = len(tracked_line_id); H.tracked_line_id = arr(tracked_line_id if len(tracked_line_id) else None, np.int32, c_int32_p)
+        self._check(fn(self.res.handle, C.byref(self.params), C.byref(view), qt.ctypes.data_as(c_double_p), C.byref(H)), "lld_frame_track_set_state")
         return view, qt
 
     def track_local_map(self, mp: dict, mp_ids, local_lines: dict | None = None):

@@ -41,7 +41,7 @@ def test_struct_layouts_match_the_header(tmp_path):
              ("lld_sim3_problem", abi.Sim3Problem), ("lld_sim3_params", abi.Sim3Params), ("lld_sim3_result", abi.Sim3Result),
              ("lld_pose_graph", abi.PoseGraph), ("lld_pose_graph_params", abi.PoseGraphParams), ("lld_pose_graph_result", abi.PoseGraphResult),
              ("lld_frame_lines", tracking.FrameLines), ("lld_map_lines", tracking.MapLines), ("lld_track_params", tracking.TrackParams),
-             ("lld_track_result", tracking.TrackResult)]
+             ("lld_track_result", tracking.TrackResult), ("lld_frame_held", tracking.FrameHeld)]
     src = tmp_path / "sz.c"
     body = "".join(f'printf("%zu\\n", sizeof({n}));' for n, _ in names)
     # field offsets of the widest struct too: equal sizes alone would not catch two swapped members
@@ -50,7 +50,8 @@ def test_struct_layouts_match_the_header(tmp_path):
     body += "".join(f'printf("%zu\\n", offsetof(lld_orb_search, {f}));' for f in probes)
     tprobes = [("lld_track_params", tracking.TrackParams, f) for f in ("pose", "th_motion", "direction", "line_thr_reproj_base", "line_use_grid")] + \
               [("lld_track_result", tracking.TrackResult, f) for f in ("chi2", "n_search_first", "n_discarded", "kp_point_id", "ln_outlier")] + \
-              [("lld_frame_lines", tracking.FrameLines, f) for f in ("right_octave", "line_matches", "dim", "sx")]
+              [("lld_frame_lines", tracking.FrameLines, f) for f in ("right_octave", "line_matches", "dim", "sx")] + \
+              [("lld_frame_held", tracking.FrameHeld, f) for f in ("kp_outlier", "seen_point_id", "ln_dir", "n_tracked", "tracked_line_id")]
     body += "".join(f'printf("%zu\\n", offsetof({n}, {f}));' for n, _, f in tprobes)
     src.write_text(f'#include <stdio.h>\n#include <stddef.h>\n#include "{ROOT}/include/lld_amd.h"\nint main(void){{{body}return 0;}}\n')
     exe = tmp_path / "sz"

@@ -659,3 +659,106 @@ def test_match_lines_last_kf_adapter_on_frames(harness, oracle, tmp_path, scene)
     assert ok.sum() > 20 and c[1] == ok.sum() and c[0] == ok.sum() + int(cur["occupied"].astype(bool).sum())      # mapline_cnt + cnt0 (:1610)
     assert wired.all()                                                          # every object-side statement of :1598-1605, and untouched slots untouched
     np.testing.assert_allclose(dr[ok], od[ok], atol=1e-7); np.testing.assert_allclose(x0[ok], ox[ok], rtol=1e-6, atol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------------- the Tracking thread's per-frame chain
+def _read_track_dump(path, nt, nl, n_mp):
+    """What `adapter_harness track` wrote: per stage the record the adapter got and the object graph as a reader sees it afterwards."""
+    from lld_slam_amd import tracking
+    stages = []
+    with open(path, "rb") as f:
+        for _ in range(2):
+            d = dict(pose_qt=np.fromfile(f, np.float64, 7), chi2=float(np.fromfile(f, np.float64, 1)[0]))
+            for k, v in zip(tracking._COUNTERS[:12], np.fromfile(f, np.int32, 12)): d[k] = int(v)
+            d["kp_point_id"] = np.fromfile(f, np.int32, nt); d["kp_outlier"] = np.fromfile(f, np.uint8, nt)
+            d["ln_line_id"] = np.fromfile(f, np.int32, nl); d["ln_outlier"] = np.fromfile(f, np.uint8, nl)
+            o = dict(mvpMapPoints=np.fromfile(f, np.int32, nt), mvbOutlier=np.fromfile(f, np.uint8, nt), mvpMapLines=np.fromfile(f, np.int32, nl),
+                     mvbOutlierLines=np.fromfile(f, np.uint8, nl), mTcw=np.fromfile(f, np.float32, 16).reshape(4, 4))
+            n = np.fromfile(f, np.int32, 2)
+            o["points"] = np.fromfile(f, np.int32, 5 * n[0]).reshape(-1, 5)      # id, mnVisible, mnFound, mbTrackInView, mnLastFrameSeen (sorted by id)
+            o["lines"] = np.fromfile(f, np.int32, 2 * n[1]).reshape(-1, 2)       # id, tracked_last_id
+            stages.append((d, o))
+        in_view = np.fromfile(f, np.uint8, n_mp)
+        fin = np.fromfile(f, np.int32, 4)
+    return stages[0], stages[1], in_view, fin
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene,direction,only_tracking,via_set_state", [(8, 0, 0, 0), (9, 1, 0, 0), (10, -1, 1, 0), (8, 0, 0, 1), (11, 0, 1, 1)])
+def test_tracking_chain_adapter_on_live_objects(harness, oracle, tmp_path, scene, direction, only_tracking, via_set_state):
+    """adapters/lld_tracking_adapter.cc: Tracking::TrackWithMotionModel and Tracking::TrackLocalMap on a Frame / MapPoint / MapLine object graph
+    (one object per id, shared by the last frame and the local map).  The records equal the oracle's run of the chain, and the objects end up as
+    the reference's loops leave them (via_set_state: TrackLocalMap on a second device frame that was handed the objects' state through
+    lld_frame_track_set_state - how it follows TrackReferenceKeyFrame or Relocalization): mvpMapPoints / mvbOutlier / mvpMapLines / mvbOutlierLines / mTcw of the frame after each routine,
+    mnLastFrameSeen / mbTrackInView / mnVisible / mnFound of every MapPoint, tracked_last_id of every MapLine, the routines' return values."""
+    import oracle_tracking as OT
+    from lld_slam_amd import tracking
+    sc = synth.make_tracking_scene(scene)
+    mp = sc["map_points"]
+    mp["skip"] = mp["skip"].copy(); mp["skip"][5::97] = 1                        # a few bad MapPoints in the local map
+    # a few MapPoints of the last frame sit five pixels off their keypoint: matched by the search, thrown out by PoseOptimization (the discard of :940-956)
+    T = np.asarray(sc["Tcw_true"], np.float64); wp = np.array(mp["world_pos"], np.float32)
+    for i in range(3, len(sc["last_ids"]), 61):
+        z = float(T[2, :3] @ wp[i] + T[2, 3])
+        wp[i] += (T[:3, :3].T @ np.array([5.0 * z / sc["cam"][0], 0.0, 0.0])).astype(np.float32)
+    mp["world_pos"] = wp; sc["last"]["world_pos"] = wp[:len(sc["last_ids"])]
+    # one MapLine object per id: a line that is bad in one list is bad in the other
+    bad = set()
+    for L in (sc["last_lines"], sc["local_lines"]): bad |= set(int(i) for i in np.asarray(L["id"])[np.asarray(L["skip"]) != 0])
+    for L in (sc["last_lines"], sc["local_lines"]): L["skip"] = np.isin(L["id"], list(bad)).astype(np.uint8)
+    F = sc["frame"]; nt = F.n; n_mp = len(sc["map_ids"]); cur_id = 42
+    nl = tracking.write_harness_scene(tmp_path / "in.bin", sc)
+    Tlast = np.array(sc["Tcw_guess"], np.float32).reshape(4, 4).copy()
+    mb = np.float32(sc["cam"][4]) / np.float32(sc["cam"][0])
+    Tlast[2, 3] += np.float32(2.0 * direction)                                  # tlc = (0, 0, dz): forward / backward / neither against mb (ORBmatcher.cc:1338-1350)
+    with open(tmp_path / "in.bin", "ab") as f:
+        Tlast.tofile(f); np.array([mb], np.float32).tofile(f); np.array([only_tracking, 1, via_set_state, 0], np.int32).tofile(f)
+    p = subprocess.run([harness, "track", str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    (g1, o1), (g2, o2), in_view, fin = _read_track_dump(tmp_path / "out.bin", nt, nl, n_mp)
+    e1, e2 = OT.track_frame(sc, direction=direction)
+    for g, e in ((g1, e1), (g2, e2)):
+        for k in ("kp_point_id", "kp_outlier", "ln_line_id", "ln_outlier"):
+            np.testing.assert_array_equal(g[k], e[k], err_msg=k)
+        for k in ("n_inliers", "n_edges", "n_search_first", "n_search", "used_wide", "n_points", "n_points_map", "n_lines_matched", "n_lines", "n_discarded"):
+            assert g[k] == e[k], k
+        np.testing.assert_allclose(g["pose_qt"], e["pose_qt"], rtol=1e-6, atol=1e-8)
+    np.testing.assert_array_equal(in_view, e2["mp_in_view"])
+    lib = oracle.lib()
+    # ---- the frame after each routine
+    held = []
+    flags_pt, flags_ln = np.zeros(nt, np.uint8), np.zeros(nl, np.uint8)
+    for st, (e, o) in enumerate(((e1, o1), (e2, o2))):
+        keep = (e["kp_point_id"] >= 0) & (e["kp_outlier"] == 0)
+        np.testing.assert_array_equal(o["mvpMapPoints"], np.where(keep, e["kp_point_id"], -1))
+        if st == 1: flags_pt = np.where(e["kp_point_id"] >= 0, e["kp_outlier"], flags_pt)        # stage 1 clears the flag of what it throws out (:947), stage 2 does not (:1170)
+        np.testing.assert_array_equal(o["mvbOutlier"], flags_pt)
+        lkeep = (e["ln_line_id"] >= 0) & (e["ln_outlier"] == 0)
+        np.testing.assert_array_equal(o["mvpMapLines"], np.where(lkeep, e["ln_line_id"], -1))
+        flags_ln = np.where(e["ln_line_id"] >= 0, e["ln_outlier"], flags_ln)                     # mvbOutlierLines is never cleared
+        np.testing.assert_array_equal(o["mvbOutlierLines"], flags_ln)
+        np.testing.assert_allclose(o["mTcw"], host.se3_to_tcw_f32(lib, e["pose_qt"]), rtol=0, atol=2e-6)
+        held.append(set(int(i) for i in e["kp_point_id"][keep]))
+    # ---- the MapPoints
+    thrown1 = set(int(i) for i in e1["kp_point_id"][(e1["kp_point_id"] >= 0) & (e1["kp_outlier"] != 0)])
+    ids = np.asarray(sc["map_ids"]); order = np.argsort(ids)
+    assert np.array_equal(o1["points"][:, 0], ids[order]) and np.array_equal(o2["points"][:, 0], ids[order])
+    seen1 = np.array([cur_id if int(i) in thrown1 else 0 for i in ids[order]])
+    np.testing.assert_array_equal(o1["points"][:, 4], seen1)
+    assert np.all(o1["points"][:, 1] == 1) and np.all(o1["points"][:, 2] == 1) and np.all(o1["points"][:, 3] == 0)
+    vis = 1 + np.array([int(i) in held[0] for i in ids]) + e2["mp_in_view"].astype(int)
+    found = 1 + np.array([int(i) in held[1] for i in ids])
+    seen2 = np.array([cur_id if (int(i) in thrown1 or int(i) in held[0]) else 0 for i in ids])
+    np.testing.assert_array_equal(o2["points"][:, 1], vis[order]); np.testing.assert_array_equal(o2["points"][:, 2], found[order])
+    np.testing.assert_array_equal(o2["points"][:, 3], e2["mp_in_view"][order]); np.testing.assert_array_equal(o2["points"][:, 4], seen2[order])
+    assert vis.max() == 2 and e2["mp_in_view"].sum() > 100 and len(thrown1) > 0
+    # ---- the MapLines
+    took = set()
+    for e, o in ((e1, o1), (e2, o2)):
+        took |= set(int(i) for i in e["ln_line_id"][e["ln_line_id"] >= 0])
+        np.testing.assert_array_equal(o["lines"][:, 1], [cur_id if int(i) in took else -1 for i in o["lines"][:, 0]])
+    assert len(took) > 20
+    # ---- return values (src/Tracking.cc:985-993, :1164-1167) and the three SetPose calls (the prediction + one per PoseOptimization)
+    ok = e1["n_search"] >= 10 and ((e1["n_points"] > 20) if only_tracking else (e1["n_points_map"] >= 7))
+    assert fin[0] == int(ok) and fin[1] == int(bool(only_tracking) and e1["n_points_map"] < 10)
+    assert fin[2] == (e2["n_points"] if only_tracking else e2["n_points_map"]) and fin[3] == 3

@@ -175,3 +175,60 @@ def test_handle_is_reusable_and_repeatable(gpu_ctx):
         for a, b in zip(recs[0], recs[1]):
             same_record(a, b, exact_pose=True)
             assert a["lm_trials"] == b["lm_trials"]
+
+
+@pytest.mark.parametrize("scene", [4, 5])
+def test_local_map_follows_a_state_handed_in_by_the_host(gpu_ctx, scene):
+    """lld_frame_track_set_state: TrackLocalMap after a stage 1 that ran elsewhere (TrackReferenceKeyFrame, Relocalization).  A fresh handle is
+    given what stage 1 of the chain left in the frame - float pose, held MapPoints / MapLines, flags, the ids it marked without holding - and its
+    TrackLocalMap record equals the chained one."""
+    from lld_slam_amd import host
+    sc = synth.make_tracking_scene(scene)
+    r1, r2 = run_device(gpu_ctx, sc)
+    nt = sc["frame"].n
+    keep = (r1["kp_point_id"] >= 0) & (r1["kp_outlier"] == 0)
+    ids = np.where(keep, r1["kp_point_id"], -1).astype(np.int32)
+    pos_of = np.asarray(sc["last"]["world_pos"], np.float32); obs_of = np.asarray(sc["last"]["has_obs"], np.uint8)   # last_ids = arange
+    world = np.where(keep[:, None], pos_of[np.maximum(ids, 0)], 0).astype(np.float32)
+    obs = np.where(keep, obs_of[np.maximum(ids, 0)], 0).astype(np.uint8)
+    seen = r1["kp_point_id"][(r1["kp_point_id"] >= 0) & (r1["kp_outlier"] != 0)]
+    LL = sc["last_lines"]; row_of = {int(i): k for k, i in enumerate(LL["id"])}
+    lkeep = (r1["ln_line_id"] >= 0) & (r1["ln_outlier"] == 0)
+    lid = np.where(lkeep, r1["ln_line_id"], -1).astype(np.int32)
+    x0 = np.zeros((len(lid), 3)); dr = np.zeros((len(lid), 3))
+    for i in np.nonzero(lkeep)[0]:
+        x0[i] = LL["X0"][row_of[int(lid[i])]]; dr[i] = LL["dir"][row_of[int(lid[i])]]
+    thrown = r1["ln_line_id"][(r1["ln_line_id"] >= 0) & (r1["ln_outlier"] != 0)]
+    assert (len(seen) > 0 or scene != 4) and lkeep.sum() > 10
+    T = host.se3_to_tcw_f32(gpu_ctx.lib, r1["pose_qt"])
+    with DeviceTrackedFrame(gpu_ctx, sc["frame"], sc["cam"], sc["lines"]) as tf:
+        tf.set_state(T, ids, world, obs, np.zeros(nt, np.uint8), seen, lid, x0, dr, r1["ln_outlier"], thrown)
+        tf.track_local_map(sc["map_points"], sc["map_ids"], sc["local_lines"])
+        e1, g2 = tf.download()
+        # (the host's toSE3Quat of the float matrix and the device's differ in the last bit of one component: ids, flags and counters equal, pose to 1e-12)
+        for k in ("kp_point_id", "kp_outlier", "ln_line_id", "ln_outlier", "mp_in_view"):
+            np.testing.assert_array_equal(g2[k], r2[k], err_msg=k)
+        for k in COUNTERS:
+            assert g2[k] == r2[k], (k, g2[k], r2[k])
+        np.testing.assert_allclose(g2["pose_qt"], r2["pose_qt"], rtol=1e-12, atol=1e-13); assert abs(g2["chi2"] - r2["chi2"]) <= 1e-10 * r2["chi2"]
+        assert np.all(e1["kp_point_id"] == -1) and e1["n_points"] == 0          # stage 1's record reads as empty
+        # a frame that holds nothing: TrackLocalMap alone finds its points from the predicted pose
+        tf.set_state(sc["Tcw_guess"], np.full(nt, -1, np.int32), np.zeros((nt, 3), np.float32))
+        tf.track_local_map(sc["map_points"], sc["map_ids"], sc["local_lines"])
+        _, g3 = tf.download()
+        assert g3["n_points"] > 100 and g3["n_discarded"] >= 0
+
+
+def test_set_state_refuses_what_it_cannot_hold(gpu_ctx):
+    sc = synth.make_tracking_scene(4)
+    nt = sc["frame"].n
+    with DeviceTrackedFrame(gpu_ctx, sc["frame"], sc["cam"], sc["lines"]) as tf:
+        none = np.full(nt, -1, np.int32); w = np.zeros((nt, 3), np.float32)
+        with pytest.raises(RuntimeError):
+            tf.set_state(sc["Tcw_guess"], none, w, seen_point_id=np.arange(nt + 1))            # more marked MapPoints than keypoints
+        with pytest.raises(RuntimeError):
+            tf.set_state(sc["Tcw_guess"], none, w, seen_point_id=[-3])
+        with pytest.raises(RuntimeError):
+            tf.set_state(sc["Tcw_guess"], none, w, tracked_line_id=np.arange(tf.n_lines + 17))  # the tracked list keeps room for TrackLocalMap's own lines
+        with pytest.raises(RuntimeError):
+            tf.set_state(sc["Tcw_guess"], none, w, ln_line_id=np.full(tf.n_lines, -1, np.int32))  # ids without positions
