@@ -1497,6 +1497,47 @@ __device__ __forceinline__ void schur_stage_point(bool a, const double* v, doubl
   }
 }
 
+// H form of a staged point block (round 6): only H (3 x 3, row major) and Xc go to LDS - 12 doubles instead of the 18 of Z = [ [Xc]x H ; H ];
+// the product loop rebuilds the four 3 x 3 blocks of Z_a Z_b^T from M = H_a H_b^T (schur_chunk_wave).  kSchurHS: LDS stride in doubles.
+#ifndef LLD_SCHUR_ZFORM
+#define LLD_SCHUR_HFORM 1
+#endif
+constexpr int kSchurHS = 14;
+__device__ __forceinline__ void schur_stage_point_h(bool a, const double* v, double lambda, const double* G, const Vec3& Xc, double* zl, double* tl, bool write_t) {
+  double L[6], idg[3];
+  if (!a) {
+#pragma unroll
+    for (int i = 0; i < 12; i += 2) *reinterpret_cast<double2*>(zl + i) = make_double2(0.0, 0.0);
+    if (write_t) { tl[0] = 0.0; tl[1] = 0.0; tl[2] = 0.0; }
+    return;
+  }
+  chol_packed<3>(v, lambda, L, idg);
+  double h[12];
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      double sacc = G[r * 3 + c];
+#pragma unroll
+      for (int m = 0; m < c; m++) sacc -= h[r * 3 + m] * L[c * (c + 1) / 2 + m];
+      h[r * 3 + c] = sacc * idg[c];
+    }
+  h[9] = Xc.x; h[10] = Xc.y; h[11] = Xc.z;
+#pragma unroll
+  for (int i = 0; i < 12; i += 2) *reinterpret_cast<double2*>(zl + i) = make_double2(h[i], h[i + 1]);
+  if (write_t) {
+    double t[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      double sacc = v[6 + c];
+#pragma unroll
+      for (int m = 0; m < c; m++) sacc -= t[m] * L[c * (c + 1) / 2 + m];
+      t[c] = sacc * idg[c];
+    }
+    tl[0] = t[0]; tl[1] = t[1]; tl[2] = t[2];
+  }
+}
+
 // A landmark with more than kSchurWideK free observations (global BA of a long track): no pipelining and no register accumulators -
 // the whole workgroup stages the landmark's k blocks, then thread t adds the products of the pairs t, t + 256, ... into the chunk's
 // partials in HBM (one writer per pair, landmarks in order: deterministic).  Such chunks hold a handful of landmarks.
@@ -1558,7 +1599,13 @@ __device__ __forceinline__ void schur_chunk_wave(const BAArrays& A, const BAWin&
   constexpr int VN = (D == 3) ? 9 : 14, WN = 6 * D;
   // LDS stride of a staged 6xD block: 144 B for points (conflict-free as is); 192 B would put slots 0 and 4 of a line on the
   // same banks, so line blocks are padded to 208 B (still 16-B aligned)
+#ifdef LLD_SCHUR_HFORM
+  constexpr bool kH = (D == 3);
+  constexpr int WS = (D == 3) ? kSchurHS : 26;
+#else
+  constexpr bool kH = false;
   constexpr int WS = (D == 3) ? 18 : 26;
+#endif
   const double* __restrict__ Vbase = (D == 3) ? A.pt_V : A.ln_V;
   const uint8_t* __restrict__ act = (D == 3) ? A.pt_active : A.ln_active;
   const int lane = threadIdx.x;
@@ -1642,7 +1689,8 @@ __device__ __forceinline__ void schur_chunk_wave(const BAArrays& A, const BAWin&
           const Vec3 Xc = mat_mul(Rt, X) + T.t;
           double G[9];
           point_g_closed_iz(W.cam, Xc, rcp_nr(Xc.z), Rt, signbit(ws), fabs(ws), G);
-          schur_stage_point(a_raw != 0, v, lambda, G, Xc, Zl + lane * WS, tl + ej * D, esl == 0);
+          if constexpr (kH) schur_stage_point_h(a_raw != 0, v, lambda, G, Xc, Zl + lane * WS, tl + ej * D, esl == 0);
+          else schur_stage_point(a_raw != 0, v, lambda, G, Xc, Zl + lane * WS, tl + ej * D, esl == 0);
         } else schur_stage_one<D>(a_raw != 0, v, lambda, w, Zl + lane * WS, tl + ej * D, esl == 0);
       }
       __syncthreads();
@@ -1650,6 +1698,40 @@ __device__ __forceinline__ void schur_chunk_wave(const BAArrays& A, const BAWin&
         for (int j = qq; j < nb; j += q) {
           const double* za = Zl + (j * k + sa) * WS;
           const double* zb = Zl + (j * k + sb) * WS;
+          if constexpr (kH) {
+            // Z_a Z_b^T = [ a M b^T, a M ; M b^T, M ] with M = H_a H_b^T, a = [Xa]x, b = [Xb]x: 27 + 9 + 18 + 9 + 18 + 18 = 99 operations against the
+            // 108 FMAs of the full 6x3 . 3x6 product, and 24 LDS doubles per (pair, landmark) instead of 36.  (Reading the next landmark's operands
+            // ahead of this one's products by hand measured 1 % slower: tools/experiments/r06_schur_hform_prefetch.patch.)
+            double ha[12], hb[12];
+#pragma unroll
+            for (int i = 0; i < 12; i += 2) { const double2 t2 = *reinterpret_cast<const double2*>(zb + i); hb[i] = t2.x; hb[i + 1] = t2.y; }
+#pragma unroll
+            for (int i = 0; i < 12; i += 2) { const double2 t2 = *reinterpret_cast<const double2*>(za + i); ha[i] = t2.x; ha[i + 1] = t2.y; }
+            double M[9], P[9];
+#pragma unroll
+            for (int r = 0; r < 3; r++)
+#pragma unroll
+              for (int c = 0; c < 3; c++) M[r * 3 + c] = fma(ha[r * 3 + 2], hb[c * 3 + 2], fma(ha[r * 3 + 1], hb[c * 3 + 1], ha[r * 3] * hb[c * 3]));
+            const double xa = ha[9], ya = ha[10], za_ = ha[11], xb = hb[9], yb = hb[10], zb_ = hb[11];
+#pragma unroll
+            for (int r = 0; r < 3; r++) {                          // P = M b^T
+              const double m0 = M[r * 3], m1 = M[r * 3 + 1], m2 = M[r * 3 + 2];
+              P[r * 3] = fma(yb, m2, -(zb_ * m1)); P[r * 3 + 1] = fma(zb_, m0, -(xb * m2)); P[r * 3 + 2] = fma(xb, m1, -(yb * m0));
+            }
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+              acc[18 + 3 + c] += M[c]; acc[24 + 3 + c] += M[3 + c]; acc[30 + 3 + c] += M[6 + c];        // lower right: M
+              acc[18 + c] += P[c]; acc[24 + c] += P[3 + c]; acc[30 + c] += P[6 + c];                    // lower left: M b^T
+              // upper right: a M, upper left: a P   (row 0 = ya * row 2 - za * row 1, row 1 = za * row 0 - xa * row 2, row 2 = xa * row 1 - ya * row 0)
+              acc[3 + c] = fma(ya, M[6 + c], fma(-za_, M[3 + c], acc[3 + c]));
+              acc[6 + 3 + c] = fma(za_, M[c], fma(-xa, M[6 + c], acc[6 + 3 + c]));
+              acc[12 + 3 + c] = fma(xa, M[3 + c], fma(-ya, M[c], acc[12 + 3 + c]));
+              acc[c] = fma(ya, P[6 + c], fma(-za_, P[3 + c], acc[c]));
+              acc[6 + c] = fma(za_, P[c], fma(-xa, P[6 + c], acc[6 + c]));
+              acc[12 + c] = fma(xa, P[3 + c], fma(-ya, P[c], acc[12 + c]));
+            }
+            continue;
+          }
           double b[WN];
 #pragma unroll
           for (int i = 0; i < WN; i += 2) { const double2 t2 = *reinterpret_cast<const double2*>(zb + i); b[i] = t2.x; b[i + 1] = t2.y; }
@@ -1677,6 +1759,18 @@ __device__ __forceinline__ void schur_chunk_wave(const BAArrays& A, const BAWin&
       if (pass0 == 0 && con) {
         for (int j = ci; j < nb; j += cq) {
           const double* za = Zl + (j * k + cslot) * WS;
+          if constexpr (kH) {                                      // Z t = [ Xc x (H t) ; H t ]
+            double ha[12];
+#pragma unroll
+            for (int i = 0; i < 12; i += 2) { const double2 t2 = *reinterpret_cast<const double2*>(za + i); ha[i] = t2.x; ha[i + 1] = t2.y; }
+            const double t0_ = tl[j * 3], t1_ = tl[j * 3 + 1], t2_ = tl[j * 3 + 2];
+            const double h0 = fma(ha[2], t2_, fma(ha[1], t1_, ha[0] * t0_)), h1 = fma(ha[5], t2_, fma(ha[4], t1_, ha[3] * t0_)), h2 = fma(ha[8], t2_, fma(ha[7], t1_, ha[6] * t0_));
+            cacc[3] += h0; cacc[4] += h1; cacc[5] += h2;
+            cacc[0] = fma(ha[10], h2, fma(-ha[11], h1, cacc[0]));
+            cacc[1] = fma(ha[11], h0, fma(-ha[9], h2, cacc[1]));
+            cacc[2] = fma(ha[9], h1, fma(-ha[10], h0, cacc[2]));
+            continue;
+          }
           double a[WN], tv[D];
 #pragma unroll
           for (int i = 0; i < WN; i += 2) { const double2 t2 = *reinterpret_cast<const double2*>(za + i); a[i] = t2.x; a[i + 1] = t2.y; }

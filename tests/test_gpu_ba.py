@@ -175,7 +175,9 @@ def test_matrix_core_cholesky_at_every_tile_padding(gpu_ctx, oracle, n_free):
     w = synth.make_lba_small(40 + n_free, n_free=n_free, n_fixed=max(2, 7 - n_free), n_points=60 * n_free + 80, n_lines=8 * n_free + 10)
     o = oracle.local_ba(w)
     for solver in (0, 3, 4):
-        check_ba(Optimizer(gpu_ctx).LocalBundleAdjustment(w, reduced_solver=solver), o, w)
+        # (n_free = 8: one weak line's direction sits at 1.08e-5 since the H-form Schur products of round 6 changed the summation order of S;
+        # the oracle's own rounding twins carry the excuse, per landmark, as everywhere else in this file)
+        check_ba(Optimizer(gpu_ctx).LocalBundleAdjustment(w, reduced_solver=solver), o, w, twins=oracle_twins(oracle, w))
 
 
 @pytest.mark.parametrize("wid,kw", [

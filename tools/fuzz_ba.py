@@ -52,7 +52,7 @@ def deviation_permuted(b, po, lo, o, w):
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-bad = 0; done = 0; soft = 0
+bad = 0; done = 0; soft = 0; by_tag = {}
 batch = []
 for it in range(n):
     n_free = int(rng.integers(0, 40)); n_fixed = int(rng.integers(1 if n_free == 0 else 0, 6))
@@ -117,10 +117,17 @@ for it in range(n):
             dg2 = deviation(g2, o2, w)
             if (o2.stats["chi2_final"] <= 0.1 * o.stats["chi2_final"] and g2.stats["chi2_final"] <= 0.1 * g.stats["chi2_final"] and max(dg2["cam"], dg2["pt"], dg2["ln"]) >= 0.5 * max(dg["cam"], dg["pt"], dg["ln"])):
                 within = True; tag = "VALLEY  "
-        if within: soft += 1
+        if within: soft += 1; by_tag[tag.strip()] = by_tag.get(tag.strip(), 0) + 1
         else: bad += 1
         print(tag if within else "MISMATCH", it, "reduced_solver", solver, "trials gpu / oracle", g.stats["lm_trials"], o.stats["lm_trials"], "sets / trials equal", same, "gpu-oracle", {k_: "%.1e" % v_ for k_, v_ in dg.items()},
               "oracle vs its re-ordered / rounding twins", {k_: "%.1e" % v_ for k_, v_ in floor.items()}, kw if (not within or tag != "FLOOR   ") else "", par if (not within or tag != "FLOOR   ") else "", flush=True)
     except Exception as e:
         bad += 1; print("ERROR", it, kw, par, repr(e)[:300], flush=True)
+# The excuses are counted one by one and bounded (a solver regression on ill-conditioned windows must not hide in them).  Bounds = about twice
+# the rates of the runs on record (profiles/r0*_fuzz_ba_*.txt: FLOOR 2.3 - 2.7 %, FLOOR/ulp and VALLEY a handful per 20 000).
+total = done + soft + bad
+limits = {"FLOOR": 0.05, "FLOOR/ulp": 0.002, "VALLEY": 0.002}
+over = {k_: v_ for k_, v_ in by_tag.items() if v_ > max(2, int(limits.get(k_, 0.0) * total))}
+print("excused by kind:", {k_: by_tag.get(k_, 0) for k_ in limits}, "bounds", {k_: max(2, int(v_ * total)) for k_, v_ in limits.items()}, "exceeded:" if over else "none exceeded", over if over else "")
 print("fuzzed", done + soft + bad, "windows:", done, "within the parity bar,", soft, "beyond it but within 10x the oracle's own sensitivity (re-ordered input, Cholesky-inverse and FMA twins; input moved by one unit in the last place) or on a window without an isolated minimiser (VALLEY),", bad, "mismatches / errors")
+sys.exit(1 if (bad or over) else 0)
