@@ -299,7 +299,9 @@ bool stage_edges(const lld_ba_window& w, const lld_ba_params& P, const WinBases&
         for (int o = w.pt_obs_start[p]; o < w.pt_obs_start[p + 1]; o++) {
           pt[o] = p; cs[o] = w.pt_obs_cam[o] | slot;
           float4 q;
-          ok &= narrow(w.pt_obs_uvr[3 * (size_t)o], q.x) & narrow(w.pt_obs_uvr[3 * (size_t)o + 1], q.y) & narrow(w.pt_obs_uvr[3 * (size_t)o + 2], q.z) & narrow(w.pt_obs_inv_sigma2[o], q.w);
+          const bool n0 = narrow(w.pt_obs_uvr[3 * (size_t)o], q.x), n1 = narrow(w.pt_obs_uvr[3 * (size_t)o + 1], q.y), n2 = narrow(w.pt_obs_uvr[3 * (size_t)o + 2], q.z);
+          const bool n3 = narrow(w.pt_obs_inv_sigma2[o], q.w);      // (all four are narrowed whatever the others say: q is stored either way)
+          ok &= n0 && n1 && n2 && n3;
           ob[o] = q;
         }
       }
@@ -328,7 +330,11 @@ bool stage_edges(const lld_ba_window& w, const lld_ba_params& P, const WinBases&
           const double* Lf = w.ln_obs_left + 4 * (size_t)o; const double* Rt = w.ln_obs_right + 4 * (size_t)o;
           const bool has_right = !(Rt[0] < 0);                                        // startPointX >= 0 (LineOptimizer.cc:60)
           float4 a, c;
-          ok &= narrow(Lf[0], a.x) & narrow(Lf[1], a.y) & narrow(Lf[2], a.z) & narrow(Lf[3], a.w) & narrow(Rt[0], c.x) & narrow(Rt[1], c.y) & narrow(Rt[2], c.z) & narrow(Rt[3], c.w);
+          bool all = true;                                                           // (every component is narrowed whatever the others say: a and c are stored either way)
+          const double in8[8] = {Lf[0], Lf[1], Lf[2], Lf[3], Rt[0], Rt[1], Rt[2], Rt[3]};
+          float* out8[8] = {&a.x, &a.y, &a.z, &a.w, &c.x, &c.y, &c.z, &c.w};
+          for (int q = 0; q < 8; q++) { const bool nq = narrow(in8[q], *out8[q]); all = all && nq; }
+          ok &= all;
           seg[2 * (size_t)o] = a; seg[2 * (size_t)o + 1] = c;
           cs[o] = w.ln_obs_cam[o] | slot; ln[o] = l;
           const int ol = w.ln_obs_octave[2 * (size_t)o], orr = w.ln_obs_octave[2 * (size_t)o + 1];

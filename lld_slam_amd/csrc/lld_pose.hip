@@ -22,7 +22,6 @@ namespace {
 using namespace lld;
 
 constexpr int kPoseThreadsMax = 512;
-constexpr int kPoseWavesMax = kPoseThreadsMax / 64;
 constexpr size_t kPoseLdsBudget = 150 * 1024;              // dynamic LDS available to the staged frame (160 KB per CU)
 constexpr size_t kPoseLdsBudgetPair = 78 * 1024;           // ... to each of two co-resident frames (the kernel's static LDS is 2.2 KB per workgroup)
 constexpr uint8_t PF_LEVEL = 1, PF_ROBUST = 2, PF_OUTLIER = 4;             // point working flags
