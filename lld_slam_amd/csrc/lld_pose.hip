@@ -69,15 +69,55 @@ struct PoseArrays {
 
 struct PoseOut { double qt[7]; double chi2; int n_inliers, lm_iterations, lm_trials, pad; };
 
+// ---- cross-lane sums without the LDS (round 6).  __shfl_xor compiles to ds_bpermute_b32 - two LDS instructions and a round trip of the CU's
+// one LDS pipe per double and step; a frame's kernel does 28-value sums twenty times and one-value sums forty-five times with eight wavefronts
+// queueing for that pipe.  gfx950 can pair lanes in the vector ALU instead: v_permlane32_swap / v_permlane16_swap exchange the halves / the odd and
+// even rows of two registers, DPP moves pair lanes inside a row of sixteen.  The six pairings used - xor 32, xor 16, xor 8 (row_ror:8), xor 7
+// (row_half_mirror), xor 2 and xor 1 (quad_perm) - generate all 64 lanes, so after the six steps every lane has met every other one exactly once.
+typedef unsigned int lld_u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned dlo(double x) { return (unsigned)__double2loint(x); }
+__device__ __forceinline__ unsigned dhi(double x) { return (unsigned)__double2hiint(x); }
+__device__ __forceinline__ double dmk(unsigned lo, unsigned hi) { return __hiloint2double((int)hi, (int)lo); }
+// x + (x of lane ^ 32) in the lanes below 32 and y + (y of lane ^ 32) in the lanes from 32 up: v_permlane32_swap exchanges lanes [32, 64) of its
+// first operand with lanes [0, 32) of its second, after which both registers hold one own and one partner value of the kind the lane keeps.
+__device__ __forceinline__ double pair32_sum(double x, double y) {
+  const lld_u2 l = __builtin_amdgcn_permlane32_swap(dlo(x), dlo(y), false, false), h = __builtin_amdgcn_permlane32_swap(dhi(x), dhi(y), false, false);
+  return dmk(l[0], h[0]) + dmk(l[1], h[1]);
+}
+// the same with lane ^ 16 (v_permlane16_swap: the odd rows of the first operand against the even rows of the second): x in the even rows, y in the odd ones
+__device__ __forceinline__ double pair16_sum(double x, double y) {
+  const lld_u2 l = __builtin_amdgcn_permlane16_swap(dlo(x), dlo(y), false, false), h = __builtin_amdgcn_permlane16_swap(dhi(x), dhi(y), false, false);
+  return dmk(l[0], h[0]) + dmk(l[1], h[1]);
+}
+constexpr int kDppRor8 = 0x128, kDppHalfMirror = 0x141, kDppQuadXor2 = 0x4E, kDppQuadXor1 = 0xB1;
+// the value of the partner lane under one DPP pairing (all lanes)
+template <int kCtrl>
+__device__ __forceinline__ double dpp_partner(double x) {
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)dlo(x), kCtrl, 0xf, 0xf, false), hi = __builtin_amdgcn_update_dpp(0, (int)dhi(x), kCtrl, 0xf, 0xf, false);
+  return dmk((unsigned)lo, (unsigned)hi);
+}
+// lanes whose selector bit is clear receive the partner's x, the others the partner's y; the selector is a whole bank of four lanes (bit 8: banks 2, 3;
+// bit 4: banks 1, 3), so the two DPP moves write complementary banks of one register - no select
+template <int kCtrl, int kBanksClear>
+__device__ __forceinline__ double dpp_partner_xy(double x, double y) {
+  int lo = __builtin_amdgcn_update_dpp(0, (int)dlo(x), kCtrl, 0xf, kBanksClear, false), hi = __builtin_amdgcn_update_dpp(0, (int)dhi(x), kCtrl, 0xf, kBanksClear, false);
+  lo = __builtin_amdgcn_update_dpp(lo, (int)dlo(y), kCtrl, 0xf, 0xf ^ kBanksClear, false); hi = __builtin_amdgcn_update_dpp(hi, (int)dhi(y), kCtrl, 0xf, 0xf ^ kBanksClear, false);
+  return dmk((unsigned)lo, (unsigned)hi);
+}
+// every lane returns the wavefront's total (fixed tree)
+__device__ __forceinline__ double wave_sum_all1(double x) {
+  x = pair32_sum(x, x);
+  x = pair16_sum(x, x);
+  x += dpp_partner<kDppRor8>(x);
+  x += dpp_partner<kDppHalfMirror>(x);
+  x += dpp_partner<kDppQuadXor2>(x);
+  x += dpp_partner<kDppQuadXor1>(x);
+  return x;
+}
 template <int N>
 __device__ __forceinline__ void wave_sum_all(double* v) {
 #pragma unroll
-  for (int i = 0; i < N; i++) {
-    double x = v[i];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
-    v[i] = x;
-  }
+  for (int i = 0; i < N; i++) v[i] = wave_sum_all1(v[i]);
 }
 // Fixed-tree block sum of one double per lane; every lane returns the total.  Consecutive calls alternate between two LDS
 // buffers (`flip`), so ONE barrier per call is enough: a buffer is rewritten only after every lane has passed the barrier of the
@@ -85,7 +125,7 @@ __device__ __forceinline__ void wave_sum_all(double* v) {
 template <int kWaves>
 __device__ __forceinline__ double block_sum1(double x, double* lds /* [2][kWaves] */, int& flip) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  wave_sum_all<1>(&x);
+  x = wave_sum_all1(x);
   double* buf = lds + flip * kWaves;
   flip ^= 1;
   if (lane == 0) buf[wave] = x;
@@ -96,25 +136,24 @@ __device__ __forceinline__ double block_sum1(double x, double* lds /* [2][kWaves
   return s;
 }
 
-// Sum of 28 values per lane over the wavefront with a halving butterfly: at every step a lane keeps one half of its values and
-// sends the other half to its partner, so 14 + 7 + 4 + 2 + 1 + 1 = 29 shuffles do the work of 28 x 6.  The totals land in
-// dst[0..27] (LDS).  Fixed tree, hence deterministic.
+// Sum of 28 values per lane over the wavefront with a halving butterfly: at every step a lane keeps one half of its values and hands the other half to
+// its partner, so 14 + 7 + 4 + 2 + 1 + 1 = 29 exchanges do the work of 28 x 6.  The totals land in dst[0..27] (LDS).  Fixed tree, hence deterministic.
+// Which lane ends with which total: index = 14 [lane & 32] + 7 [lane & 16] + 4 [lane & 8] + 2 [lane & 4] + [lane & 2], the even lanes store.
 __device__ __forceinline__ void wave_sum28(const double* v, double* dst) {
   const int lane = threadIdx.x & 63;
   const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8, b2 = lane & 4, b1 = lane & 2;
   double s[14], t[8], u[4], w[2];
 #pragma unroll
-  for (int i = 0; i < 14; i++) { const double keep = b5 ? v[i + 14] : v[i], send = b5 ? v[i] : v[i + 14]; s[i] = keep + __shfl_xor(send, 32); }
+  for (int i = 0; i < 14; i++) s[i] = pair32_sum(v[i], v[i + 14]);
 #pragma unroll
-  for (int i = 0; i < 7; i++) { const double keep = b4 ? s[i + 7] : s[i], send = b4 ? s[i] : s[i + 7]; t[i] = keep + __shfl_xor(send, 16); }
+  for (int i = 0; i < 7; i++) t[i] = pair16_sum(s[i], s[i + 7]);
   t[7] = 0.0;
 #pragma unroll
-  for (int i = 0; i < 4; i++) { const double keep = b3 ? t[i + 4] : t[i], send = b3 ? t[i] : t[i + 4]; u[i] = keep + __shfl_xor(send, 8); }
+  for (int i = 0; i < 4; i++) u[i] = (b3 ? t[i + 4] : t[i]) + dpp_partner_xy<kDppRor8, 0x3>(t[i], t[i + 4]);
 #pragma unroll
-  for (int i = 0; i < 2; i++) { const double keep = b2 ? u[i + 2] : u[i], send = b2 ? u[i] : u[i + 2]; w[i] = keep + __shfl_xor(send, 4); }
-  const double keep = b1 ? w[1] : w[0], send = b1 ? w[0] : w[1];
-  double r = keep + __shfl_xor(send, 2);
-  r += __shfl_xor(r, 1);
+  for (int i = 0; i < 2; i++) w[i] = (b2 ? u[i + 2] : u[i]) + dpp_partner_xy<kDppHalfMirror, 0x5>(u[i], u[i + 2]);
+  double r = (b1 ? w[1] : w[0]) + dpp_partner<kDppQuadXor2>(b1 ? w[0] : w[1]);
+  r += dpp_partner<kDppQuadXor1>(r);
   const int sub = (b3 ? 4 : 0) + (b2 ? 2 : 0) + (b1 ? 1 : 0);
   if (!(lane & 1) && sub < 7) dst[(b5 ? 14 : 0) + (b4 ? 7 : 0) + sub] = r;
 }
@@ -1000,6 +1039,36 @@ extern "C" __attribute__((visibility("default"))) int lld_exp_pose_stamps(lld_ct
   LLD_HIP_TRY(hipStreamSynchronize(s));
   pose_fill_result(Y, h_img + Y.in_bytes, F, 0, out);
   LLD_HIP_TRY(hipMemcpy(stamps16, A.stamps, sizeof(long long) * PO_N_STAMPS, hipMemcpyDeviceToHost));
+  return LLD_OK;
+}
+#endif
+
+#ifdef LLD_EXPERIMENTS
+// experiments build only: the cross-lane sums of pose_opt_kernel on their own (tests/test_gpu_pose.py): `in` holds [64][28] doubles (lane-major);
+// out28[28] = wave_sum28 of them, out1[64] = wave_sum_all1 of every lane's first value as each lane sees it.
+namespace {
+__global__ void pose_wave_sums_kernel(const double* in, double* out28, double* out1) {
+  __shared__ double dst[28];
+  double v[28];
+  for (int i = 0; i < 28; i++) v[i] = in[threadIdx.x * 28 + i];
+  wave_sum28(v, dst);
+  out1[threadIdx.x] = wave_sum_all1(v[0]);
+  __syncthreads();
+  if (threadIdx.x < 28) out28[threadIdx.x] = dst[threadIdx.x];
+}
+}  // namespace
+extern "C" __attribute__((visibility("default"))) int lld_exp_pose_wave_sums(lld_ctx* ctx, const double* in, double* out28, double* out1) {
+  if (!ctx || !in || !out28 || !out1) return LLD_ERR_INVALID;
+  LLD_HIP_TRY(hipSetDevice(ctx->device));
+  void* db; int st = lld_ctx_scratch(ctx, (64 * 28 + 28 + 64) * sizeof(double), &db); if (st) return st;
+  double* d = static_cast<double*>(db);
+  hipStream_t s = ctx->stream;
+  LLD_HIP_TRY(hipMemcpyAsync(d, in, 64 * 28 * sizeof(double), hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(pose_wave_sums_kernel, dim3(1), dim3(64), 0, s, d, d + 64 * 28, d + 64 * 28 + 28);
+  LLD_HIP_TRY(hipGetLastError());
+  LLD_HIP_TRY(hipMemcpyAsync(out28, d + 64 * 28, 28 * sizeof(double), hipMemcpyDeviceToHost, s));
+  LLD_HIP_TRY(hipMemcpyAsync(out1, d + 64 * 28 + 28, 64 * sizeof(double), hipMemcpyDeviceToHost, s));
+  LLD_HIP_TRY(hipStreamSynchronize(s));
   return LLD_OK;
 }
 #endif

@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 RTOL = 1e-5
 
 
-def _check(g, o, n_points):
+def _check(g, o, n_points, weak=False):
     assert g.n_inliers == o.n_inliers
     np.testing.assert_array_equal(g.pt_outlier, o.pt_outlier)
     np.testing.assert_array_equal(g.ln_outlier, o.ln_outlier)
@@ -21,10 +21,14 @@ def _check(g, o, n_points):
     # count may differ by a few while the result does not: the differences actually seen are logged (gpurun_out/lm_counts_test_gpu_pose.txt
     # -> profiles/r06_parity_margins.txt) and held to their maximum
     _LM_LOG.append((g.lm_iterations - o.lm_iterations, g.lm_trials - o.lm_trials))
-    assert abs(g.lm_iterations - o.lm_iterations) <= MAX_IT_DIFF and abs(g.lm_trials - o.lm_trials) <= MAX_TRIAL_DIFF, _LM_LOG[-1]
+    assert abs(g.lm_iterations - o.lm_iterations) <= MAX_IT_DIFF and abs(g.lm_trials - o.lm_trials) <= (MAX_TRIAL_DIFF_WEAK if weak else MAX_TRIAL_DIFF), _LM_LOG[-1]
 
 
-MAX_IT_DIFF, MAX_TRIAL_DIFF = 0, 2                  # seen on HEAD over the 66 calls of this file: iterations equal everywhere, trials differ by <= 2 in 4 calls
+# Seen on HEAD over the 66 calls of this file (round 6, after the wavefront sums left the LDS - another summation tree, so other last bits than before):
+# 62 calls equal, iterations differ by 1 in one call, trials by <= 2 in three.  The one frame with monocular observations only is weakly constrained along
+# the viewing direction: its converged rounds spend their ten rejected trials or not on the last bits of two sums (device 20 iterations / 70 trials, oracle
+# 20 / 52, same pose to 1e-11; profiles/NOTES_r06.md walks such a frame round by round) - it gets its own bound instead of loosening everyone's.
+MAX_IT_DIFF, MAX_TRIAL_DIFF, MAX_TRIAL_DIFF_WEAK = 1, 2, 20
 _LM_LOG = []
 
 
@@ -57,7 +61,7 @@ def test_pose_optimization_matches_oracle(gpu_ctx, oracle, fid, kw):
     f = synth.make_pose_frame(fid, **kw)
     g = Optimizer(gpu_ctx).PoseOptimization(f, gamma=0.5)
     o = oracle.pose_opt(f, gamma=0.5)
-    _check(g, o, f.n_points)
+    _check(g, o, f.n_points, weak=kw.get("mono_frac", 0.0) == 1.0)
     if f.n_points >= 50 and kw.get("mono_frac", 0.0) < 1.0 and kw.get("outlier_frac", 0.0) < 0.5:
         gt = f.meta["gt_qt"]
         assert np.linalg.norm(g.pose_qt[4:] - gt[4:]) < 0.05
@@ -173,3 +177,33 @@ def test_non_finite_frame_terminates_and_leaves_the_context_clean(gpu_ctx, oracl
         _check(b.download(0), ref, clean.n_points); _check(b.download(2), ref, clean.n_points)
     _check(Optimizer(gpu_ctx).PoseOptimization(clean, gamma=0.5), ref, clean.n_points)
 
+
+
+def test_cross_lane_sums_of_the_pose_kernel():
+    """pose_opt_kernel's wavefront sums without the LDS (round 6: v_permlane32_swap / v_permlane16_swap / DPP pairings instead of ds_bpermute): every
+    one of the 28 totals and the one-value sum as every lane sees it, against numpy on random and on adversarial inputs (one lane carries everything;
+    a different value in every lane and slot) - and identical from run to run."""
+    import ctypes as C, os
+    from lld_slam_amd import Context, abi
+    lib = abi.Lib(os.path.join(os.path.dirname(abi.product_library_path()), "liblld_amd_exp.so"), "lld_")
+    ctx = Context(0, lib=lib)
+    try:
+        fn = lib.fn("exp_pose_wave_sums")
+        dp = C.POINTER(C.c_double)
+        fn.argtypes = [C.c_void_p, dp, dp, dp]; fn.restype = C.c_int
+        rng = np.random.default_rng(5)
+        cases = [rng.normal(size=(64, 28)), np.arange(64 * 28, dtype=np.float64).reshape(64, 28) + 1.0, np.zeros((64, 28))]
+        cases[2][37] = rng.normal(size=28) * 1e6
+        for v in cases:
+            v = np.ascontiguousarray(v)
+            outs = []
+            for _ in range(2):
+                o28 = np.zeros(28); o1 = np.zeros(64)
+                assert fn(ctx.handle, v.ctypes.data_as(dp), o28.ctypes.data_as(dp), o1.ctypes.data_as(dp)) == 0
+                outs.append((o28, o1))
+            np.testing.assert_array_equal(outs[0][0], outs[1][0]); np.testing.assert_array_equal(outs[0][1], outs[1][1])
+            scale = np.abs(v).sum(0) + 1e-300
+            assert np.all(np.abs(outs[0][0] - v.sum(0)) <= 1e-14 * scale), (outs[0][0], v.sum(0))
+            assert np.all(outs[0][1] == outs[0][1][0]) and abs(outs[0][1][0] - v[:, 0].sum()) <= 1e-14 * scale[0]
+    finally:
+        ctx.close()
