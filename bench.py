@@ -550,9 +550,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--ramp-seconds", type=float, default=1.5, help="untimed solves before the warm-up steps until this much wall clock has passed (clock ramp of a fresh process; 0 = none)")
+    ap.add_argument("--ramp-steps-max", type=int, default=60)
     ap.add_argument("--windows-per-gpu", type=int, default=256, help="windows per GPU (weak scaling); with --strong: windows in total")
     ap.add_argument("--strong", action="store_true", help="strong scaling: the same --windows-per-gpu windows split over the ranks (SURVEY §8d: 256 windows, 32 per GPU at 8)")
-    ap.add_argument("--cpu-sample", type=int, default=10, help="LBA-B windows timed on the CPU oracle (rank 0, N=1 only)")
+    ap.add_argument("--cpu-sample", type=int, default=40, help="LBA-B windows timed on the CPU oracle (rank 0, N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the PO / MATCH / LBA-A / single-call block (N=1 only anyway)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the host-buffers-in / results-out pipeline (N=1 only anyway)")
@@ -623,6 +625,13 @@ def main():
         batch.solve()                     # synchronous on the library's stream (it polls the LM state every super-step)
         gather.step()                     # the final gather over xGMI, the only collective: asynchronous, overlaps the next solve
 
+    # Clock ramp (untimed, before the W warm-up steps): a fresh process on an idle GPU runs its first second of solves 8 - 10 % slower (the window
+    # generation above leaves the GPU idle for seconds; power management, cold TLBs and the first touch of the batch's work slab) - measured on fresh
+    # boxes: 6.2 k windows/s for W = 1 straight after start-up against 6.8 k - 6.9 k a second later on the same box.  Reported in config.ramp.
+    ramp_steps, ramp_t0 = 0, time.perf_counter()
+    while ramp_steps < args.ramp_steps_max and time.perf_counter() - ramp_t0 < args.ramp_seconds:
+        step(); ramp_steps += 1
+    ramp_s = time.perf_counter() - ramp_t0
     for _ in range(args.warmup):
         step()
     gather.drain()
@@ -684,12 +693,23 @@ def main():
             # ... and the proxy of what N > 1 ranks pay for the collective: the SAME K timed steps once more with the gather of
             # every step started behind its solve (asynchronous, overlapping the next solve's stream groups - exactly the N > 1 step), against
             # the plain K steps timed above on this box.  rccl_overhead = rate with the gather / rate without.
-            t0g = time.perf_counter()
-            for _ in range(args.steps):
-                batch.solve(); late.step()
-            late.drain(); D.barrier(True, True)
-            rccl_overhead = {"value": round(elapsed / (time.perf_counter() - t0g), 4), "what": "windows/s of K steps with the asynchronous one-rank RCCL gather of every "
-                             "step's records inside the timed region / windows/s of the plain K steps (same box, same batch)", "steps": args.steps}
+            # Three alternating pairs right here (K steps with the gather, K plain), medians: a single pair against the timed region above moved between
+            # 0.90 and 1.09 from run to run (the headline's K steps are a second old by now).
+            with_g, plain = [], []
+            for _ in range(3):
+                t0g = time.perf_counter()
+                for _ in range(args.steps):
+                    batch.solve(); late.step()
+                late.drain(); D.barrier(True, True)
+                with_g.append(time.perf_counter() - t0g)
+                t0p = time.perf_counter()
+                for _ in range(args.steps):
+                    batch.solve()
+                D.barrier(True, True)
+                plain.append(time.perf_counter() - t0p)
+            rccl_overhead = {"value": round(float(np.median(plain) / np.median(with_g)), 4), "what": "windows/s of K steps with the asynchronous one-rank RCCL gather of every "
+                             "step's records inside the timed region / windows/s of K plain steps (same box, same batch; medians of three alternating pairs)", "steps": args.steps,
+                             "seconds_with_gather": [round(x, 4) for x in with_g], "seconds_plain": [round(x, 4) for x in plain]}
         except Exception as ex:
             print(f"[bench] one-rank RCCL check skipped: {ex!r}", file=sys.stderr)
             late_gather = None
@@ -826,7 +846,7 @@ def main():
                                    f"windows resident in HBM, every step restarts from the uploaded state",
                        "bit_reproducible": not args.shared_accumulators, "windows_per_gpu": counts if args.strong else wpg, "edges_per_window": int(windows[0].n_edges()),
                        "parallelism": f"{world} x independent window batches, RCCL gather of result records", "resident": True,
-                       "result_record_bytes": int(rec_stride), "generate_s": round(gen_s, 1), "host_threads_per_rank": budget, "gathered_records_ok": gathered_ok,
+                       "result_record_bytes": int(rec_stride), "generate_s": round(gen_s, 1), "ramp": {"untimed_solves_before_the_warmup_steps": ramp_steps, "seconds": round(ramp_s, 2)}, "host_threads_per_rank": budget, "gathered_records_ok": gathered_ok,
                        "gathered_records_how": ("RCCL gather inside every timed step" if use_dist else ("one untimed step through a one-rank RCCL group after the timed region" if late_gather is not None else None))},
             "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
             "lm": {"mean_trials_per_window": float(np.mean([sum(s["lm_trials"]) for s in stats])),

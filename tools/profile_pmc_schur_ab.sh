@@ -12,7 +12,7 @@ for spec in "$@"; do
   if [ "$P" = default ]; then unset LLD_AMD_LIB; else export LLD_AMD_LIB=$R/$P; fi
   for pass in "sq_b SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_SALU"; do
     set -- $pass; name=$1; shift
-    rocprofv3 --kernel-trace --pmc "$@" -d $OUT/${L}_$name -o $name -- python3 $R/bench.py --steps 1 --warmup 1 --windows-per-gpu 256 --no-cpu-baseline --no-secondary --no-e2e --no-rccl-check --gen-workers 1 --groups 1 > $OUT/${L}_$name.log 2>&1
+    rocprofv3 --kernel-trace --pmc "$@" -d $OUT/${L}_$name -o $name -- python3 $R/bench.py --steps 1 --warmup 1 --windows-per-gpu 256 --no-cpu-baseline --no-secondary --no-e2e --no-rccl-check --ramp-seconds 0 --gen-workers 1 --groups 1 > $OUT/${L}_$name.log 2>&1
     python3 $R/tools/rocpd_summary.py $(find $OUT/${L}_$name -name "*_results.db" | head -1) > $OUT/${L}_$name.txt 2>&1
   done
 done

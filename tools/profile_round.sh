@@ -8,7 +8,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 bash $R/tools/profile_kt.sh ${TAG}_256 256 1 > /dev/null 2>&1
 bash $R/tools/profile_pmc_sq.sh $TAG 256 > /dev/null 2>&1
 ( OUT=$R/gpurun_out/pmc_$TAG; cd /tmp && export TMPDIR=/tmp
-  CMD="python3 $R/bench.py --steps 1 --warmup 1 --windows-per-gpu 256 --no-cpu-baseline --no-secondary --no-e2e --no-rccl-check --gen-workers 1 --groups 1"
+  CMD="python3 $R/bench.py --steps 1 --warmup 1 --windows-per-gpu 256 --no-cpu-baseline --no-secondary --no-e2e --no-rccl-check --ramp-seconds 0 --gen-workers 1 --groups 1"
   for pass in "tcc_fetch FETCH_SIZE" "tcc_write WRITE_SIZE"; do set -- $pass; name=$1; shift
     rocprofv3 --kernel-trace --pmc "$@" -d $OUT/$name -o $name -- $CMD > $OUT/$name.log 2>&1
     python3 $R/tools/rocpd_summary.py $(find $OUT/$name -name "*_results.db" | head -1) > $OUT/$name.txt 2>&1
