@@ -630,8 +630,9 @@ def main():
     # boxes: 6.2 k windows/s for W = 1 straight after start-up against 6.8 k - 6.9 k a second later on the same box.  Reported in config.ramp.
     ramp_steps, ramp_t0 = 0, time.perf_counter()
     while ramp_steps < args.ramp_steps_max and time.perf_counter() - ramp_t0 < args.ramp_seconds:
-        step(); ramp_steps += 1
+        batch.solve(); ramp_steps += 1       # the solve alone: the number of ramp steps is decided by each rank's own clock, so no collective may sit in this loop
     ramp_s = time.perf_counter() - ramp_t0
+    D.barrier(use_dist, True)
     for _ in range(args.warmup):
         step()
     gather.drain()
